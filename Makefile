@@ -1,0 +1,39 @@
+# Top-level build: product libraries (handbrake_amd/) + checkers (oracle/).
+#   make            everything
+#   make product    libhbrt.so, libhbhip.so (HIP kernels + C-ABI), libhbhip_filters.so
+#   make oracle     liboracle.so and, when /root/reference exists, oracle/_ref/libhbref.so
+HIPCC   ?= /opt/rocm/bin/hipcc
+CC      ?= gcc
+ARCH    ?= gfx950
+PKG     := handbrake_amd
+CFLAGS  := -std=gnu99 -O2 -g -fPIC -Wall -Wno-unused-function -Iinclude -I$(PKG)/libhb
+HIPFLAGS:= --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Iinclude -I$(PKG)/csrc -Wall -Wno-unused-function
+
+HIP_SRC := $(wildcard $(PKG)/csrc/*.hip)
+HIP_OBJ := $(HIP_SRC:%.hip=%.o)
+HIP_HDR := $(wildcard $(PKG)/csrc/*.h) $(wildcard include/*.h)
+FLT_SRC := $(wildcard $(PKG)/libhb/*_hip.c) $(PKG)/libhb/hbhip_registry.c
+
+all: product oracle
+product: $(PKG)/libhbrt.so $(PKG)/libhbhip.so $(PKG)/libhbhip_filters.so
+
+$(PKG)/libhbrt.so: $(PKG)/libhb/hb_runtime.c $(PKG)/libhb/hb_harness.c $(PKG)/libhb/hb_harness.h include/hbhip_libhb.h
+	$(CC) $(CFLAGS) -shared -o $@ $(PKG)/libhb/hb_runtime.c $(PKG)/libhb/hb_harness.c -lm -lpthread
+
+$(PKG)/csrc/%.o: $(PKG)/csrc/%.hip $(HIP_HDR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(PKG)/libhbhip.so: $(HIP_OBJ)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(HIP_OBJ)
+
+$(PKG)/libhbhip_filters.so: $(FLT_SRC) $(PKG)/libhbrt.so $(PKG)/libhbhip.so include/hbhip.h include/hbhip_libhb.h
+	$(CC) $(CFLAGS) -shared -o $@ $(FLT_SRC) -L$(PKG) -lhbhip -lhbrt -lm -Wl,-rpath,'$$ORIGIN' -Wl,--no-undefined
+
+oracle: $(PKG)/libhbrt.so
+	$(MAKE) -C oracle all
+
+clean:
+	rm -f $(PKG)/*.so $(PKG)/csrc/*.o
+	$(MAKE) -C oracle clean
+
+.PHONY: all product oracle clean

@@ -1,0 +1,183 @@
+"""ctypes binding of the filter-chain driver (libhb/hb_harness.c in libhbrt.so).
+
+The driver plays work.c's role for a list of ``hb_filter_object_t`` - it does
+not care whether they are the HIP drop-ins (``libhbhip_filters.so``) or the
+reference's own objects (``oracle/_ref/libhbref.so``, tests only).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+AV_PIX_FMT_YUV420P = 0
+AV_PIX_FMT_YUV420P10 = 62
+
+HB_COMB_NONE, HB_COMB_LIGHT, HB_COMB_HEAVY = 0, 1, 2
+
+
+class FrameInfo(C.Structure):
+    _fields_ = [("is_eof", C.c_int), ("start", C.c_int64), ("stop", C.c_int64),
+                ("flags", C.c_int), ("combed", C.c_int), ("width", C.c_int),
+                ("height", C.c_int), ("fmt", C.c_int), ("nplanes", C.c_int),
+                ("plane_width", C.c_int * 4), ("plane_height", C.c_int * 4),
+                ("plane_stride", C.c_int * 4)]
+
+
+_rt = None
+
+
+def runtime() -> C.CDLL:
+    """libhbrt.so, loaded RTLD_GLOBAL so filter libraries resolve against it."""
+    global _rt
+    if _rt is None:
+        path = os.path.join(_HERE, "libhbrt.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing - run `make` (or __graft_entry__.build())")
+        lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        lib.hbh_chain_open.restype = C.c_void_p
+        lib.hbh_chain_open.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_char_p),
+                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        lib.hbh_chain_push.restype = C.c_int
+        lib.hbh_chain_push.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int),
+                                       C.c_int64, C.c_int64, C.c_int, C.c_int]
+        lib.hbh_chain_push_eof.restype = C.c_int
+        lib.hbh_chain_push_eof.argtypes = [C.c_void_p]
+        lib.hbh_chain_pending.restype = C.c_int
+        lib.hbh_chain_pending.argtypes = [C.c_void_p]
+        lib.hbh_chain_peek.restype = C.c_int
+        lib.hbh_chain_peek.argtypes = [C.c_void_p, C.POINTER(FrameInfo)]
+        lib.hbh_chain_pop.restype = C.c_int
+        lib.hbh_chain_pop.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+        lib.hbh_chain_output_geometry.restype = None
+        lib.hbh_chain_output_geometry.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 4
+        lib.hbh_chain_close.restype = None
+        lib.hbh_chain_close.argtypes = [C.c_void_p]
+        lib.hbhip_set_log_level.argtypes = [C.c_int]
+        lib.hbhip_set_cpu_count.argtypes = [C.c_int]
+        _rt = lib
+    return _rt
+
+
+@dataclass
+class OutFrame:
+    planes: tuple          # (Y, Cb, Cr) uint8 arrays, cropped to plane width
+    start: int
+    stop: int
+    flags: int
+    combed: int
+    width: int
+    height: int
+
+
+class Chain:
+    """A filter chain: ``Chain(lib, [("hb_filter_nlmeans", "y-strength=6")], w, h)``."""
+
+    def __init__(self, lib: C.CDLL, stages, width: int, height: int,
+                 pix_fmt: int = AV_PIX_FMT_YUV420P, vrate=(30000, 1001)):
+        self._rt = runtime()
+        n = len(stages)
+        protos = (C.c_void_p * n)()
+        settings = (C.c_char_p * n)()
+        for i, (sym, st) in enumerate(stages):
+            protos[i] = C.addressof(C.c_char.in_dll(lib, sym))
+            settings[i] = (st or "").encode()
+        self._keep = (lib, protos, settings)
+        self.width, self.height = width, height
+        self._h = self._rt.hbh_chain_open(n, protos, settings, pix_fmt, width, height,
+                                          vrate[0], vrate[1])
+        if not self._h:
+            raise RuntimeError(f"filter chain init failed: {stages}")
+        self.eof = False
+
+    def push(self, planes, start: int = 0, stop: int = 3003, flags: int = 0x10, combed: int = 0):
+        ptrs = (C.c_void_p * 3)()
+        strides = (C.c_int * 3)()
+        keep = []
+        for i, p in enumerate(planes):
+            a = np.ascontiguousarray(p)
+            keep.append(a)
+            ptrs[i] = a.ctypes.data
+            strides[i] = a.strides[0]
+        rc = self._rt.hbh_chain_push(self._h, ptrs, strides, start, stop, flags, combed)
+        if rc != 0:
+            raise RuntimeError(f"hbh_chain_push failed ({rc})")
+
+    def push_eof(self):
+        rc = self._rt.hbh_chain_push_eof(self._h)
+        if rc != 0:
+            raise RuntimeError(f"hbh_chain_push_eof failed ({rc})")
+
+    def pending(self) -> int:
+        return self._rt.hbh_chain_pending(self._h)
+
+    def pop(self):
+        """Next output frame, or None for the EOF marker / empty queue."""
+        info = FrameInfo()
+        if self._rt.hbh_chain_peek(self._h, C.byref(info)) != 0:
+            return None
+        if info.is_eof or info.nplanes == 0:
+            self._rt.hbh_chain_pop(self._h, None, None)
+            self.eof = True
+            return None
+        ptrs = (C.c_void_p * 3)()
+        strides = (C.c_int * 3)()
+        arrs = []
+        for p in range(3):
+            a = np.empty((info.plane_height[p], info.plane_stride[p]), dtype=np.uint8)
+            arrs.append(a)
+            ptrs[p] = a.ctypes.data
+            strides[p] = a.strides[0]
+        self._rt.hbh_chain_pop(self._h, ptrs, strides)
+        bps = 2 if info.fmt in (62, 123) else 1
+        planes = tuple(a[:, : info.plane_width[p] * bps] for p, a in enumerate(arrs))
+        return OutFrame(planes, info.start, info.stop, info.flags, info.combed,
+                        info.width, info.height)
+
+    def drain(self):
+        out = []
+        while self.pending():
+            f = self.pop()
+            if f is not None:
+                out.append(f)
+        return out
+
+    def output_geometry(self):
+        v = [C.c_int() for _ in range(4)]
+        self._rt.hbh_chain_output_geometry(self._h, *[C.byref(x) for x in v])
+        return tuple(x.value for x in v)
+
+    def close(self):
+        if self._h:
+            self._rt.hbh_chain_close(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def run_stream(lib, stages, frames, flags: int = 0x10, pix_fmt: int = AV_PIX_FMT_YUV420P,
+               duration: int = 3003):
+    """Push every frame then EOF; return all OutFrames in output order."""
+    h, w = frames[0][0].shape
+    out = []
+    with Chain(lib, stages, w, h, pix_fmt) as ch:
+        for i, fr in enumerate(frames):
+            ch.push(fr, start=i * duration, stop=(i + 1) * duration, flags=flags)
+            out += ch.drain()
+        ch.push_eof()
+        out += ch.drain()
+    return out

@@ -1,0 +1,222 @@
+/* hb_harness.c — a single-threaded stand-in for the part of work.c that owns a
+ * video filter chain: it instantiates filter objects the way do_job() does
+ * (copy the registered object, attach settings, call init() with the running
+ * hb_filter_init_t, work.c:1840-1870), then plays filter_loop() (work.c:2527-2600)
+ * for every stage in order: work(&in, &out), close `in` unless the filter took
+ * it, push the `->next` chain of `out` to the next stage, stop a stage at
+ * HB_FILTER_DONE.
+ *
+ * It is deliberately agnostic of WHICH filter objects it drives: the parity
+ * tests run the reference's own objects (oracle/_ref/libhbref.so) and the HIP
+ * drop-ins (libhbhip_filters.so) through exactly the same calls.
+ */
+#include "hbhip_libhb.h"
+#include "hb_harness.h"
+
+#define HBH_MAX_STAGES 8
+
+struct hbh_chain_s
+{
+    int                 nstages;
+    hb_filter_object_t *stage[HBH_MAX_STAGES];
+    int                 done[HBH_MAX_STAGES];
+    hb_filter_init_t    init;        /* state after the last stage's init()   */
+    hb_filter_init_t    init_in;     /* what the first stage was given        */
+    hb_buffer_list_t    out;         /* frames that left the last stage       */
+    int                 eof_seen;
+    int                 failed;
+};
+
+static hb_filter_object_t *clone_filter(const hb_filter_object_t *proto, const char *settings)
+{
+    /* hb_filter_copy (common.c:5247-5258): shallow copy + own settings dict */
+    hb_filter_object_t *f = malloc(sizeof(*f));
+    if (f == NULL) return NULL;
+    memcpy(f, proto, sizeof(*f));
+    f->settings = hbhip_dict_from_string(settings ? settings : "");
+    f->private_data = NULL;
+    f->sub_filter = NULL;
+    return f;
+}
+
+hbh_chain_t *hbh_chain_open(int nstages, void *const *protos, const char *const *settings,
+                            int pix_fmt, int width, int height,
+                            int vrate_num, int vrate_den)
+{
+    if (nstages < 1 || nstages > HBH_MAX_STAGES) return NULL;
+    hbh_chain_t *c = calloc(1, sizeof(*c));
+    if (c == NULL) return NULL;
+
+    hb_filter_init_t init;
+    memset(&init, 0, sizeof(init));
+    init.pix_fmt = pix_fmt;
+    init.hw_pix_fmt = AV_PIX_FMT_NONE;
+    init.geometry.width = width;
+    init.geometry.height = height;
+    init.geometry.par.num = 1;
+    init.geometry.par.den = 1;
+    init.vrate.num = vrate_num;
+    init.vrate.den = vrate_den;
+    init.time_base.num = 1;
+    init.time_base.den = 90000;
+    init.color_prim = 1;
+    init.color_transfer = 1;
+    init.color_matrix = 1;
+    init.color_range = 1;
+    init.chroma_location = 1;
+    c->init_in = init;
+
+    for (int i = 0; i < nstages; i++)
+    {
+        hb_filter_object_t *f = clone_filter((const hb_filter_object_t *)protos[i], settings ? settings[i] : NULL);
+        if (f == NULL || f->init == NULL || f->init(f, &init) != 0)
+        {
+            /* work.c:1861-1868 would drop the filter and continue; a test
+             * harness wants to know instead. */
+            hb_error("hbh_chain_open: init of stage %d (%s) failed", i, f ? f->name : "?");
+            if (f) { hb_dict_free(&f->settings); free(f); }
+            hbh_chain_close(c);
+            return NULL;
+        }
+        c->stage[c->nstages++] = f;
+    }
+    c->init = init;
+    return c;
+}
+
+/* Run `in` (one buffer, not a chain) through stage s and everything after it. */
+static void run_from(hbh_chain_t *c, int s, hb_buffer_t *in)
+{
+    if (s >= c->nstages)
+    {
+        hb_buffer_list_append(&c->out, in);
+        return;
+    }
+    hb_filter_object_t *f = c->stage[s];
+    if (c->done[s])
+    {
+        /* stage already finished (saw EOF): filter_loop has exited, drop */
+        hb_buffer_close(&in);
+        return;
+    }
+    hb_buffer_t *out = NULL;
+    int status = f->work(f, &in, &out);
+    if (in != NULL)
+        hb_buffer_close(&in);
+    if (status == HB_FILTER_FAILED)
+        c->failed = 1;
+    if (status == HB_FILTER_DONE)
+        c->done[s] = 1;
+    while (out != NULL)
+    {
+        hb_buffer_t *next = out->next;
+        out->next = NULL;
+        run_from(c, s + 1, out);
+        out = next;
+    }
+}
+
+int hbh_chain_push(hbh_chain_t *c, const uint8_t *const plane[3], const int stride[3],
+                   int64_t start, int64_t stop, int flags, int combed)
+{
+    if (c == NULL || c->eof_seen) return -1;
+    hb_buffer_t *b = hb_frame_buffer_init(c->init_in.pix_fmt, c->init_in.geometry.width,
+                                          c->init_in.geometry.height);
+    if (b == NULL) return -1;
+    for (int p = 0; p <= b->f.max_plane; p++)
+    {
+        const int row = MIN(stride[p], b->plane[p].stride);
+        for (int y = 0; y < b->plane[p].height; y++)
+            memcpy(b->plane[p].data + (size_t)y * b->plane[p].stride,
+                   plane[p] + (size_t)y * stride[p], row);
+    }
+    b->s.start = start;
+    b->s.stop = stop;
+    b->s.duration = (double)(stop - start);
+    b->s.flags = (uint16_t)flags;
+    b->s.combed = (uint8_t)combed;
+    b->f.color_prim = c->init_in.color_prim;
+    b->f.color_transfer = c->init_in.color_transfer;
+    b->f.color_matrix = c->init_in.color_matrix;
+    b->f.color_range = c->init_in.color_range;
+    b->f.chroma_location = c->init_in.chroma_location;
+    run_from(c, 0, b);
+    return c->failed ? -2 : 0;
+}
+
+int hbh_chain_push_eof(hbh_chain_t *c)
+{
+    if (c == NULL || c->eof_seen) return -1;
+    c->eof_seen = 1;
+    run_from(c, 0, hb_buffer_eof_init());
+    return c->failed ? -2 : 0;
+}
+
+int hbh_chain_pending(hbh_chain_t *c)
+{
+    return c ? hb_buffer_list_count(&c->out) : 0;
+}
+
+int hbh_chain_peek(hbh_chain_t *c, hbh_frame_info_t *info)
+{
+    hb_buffer_t *b = c ? hb_buffer_list_head(&c->out) : NULL;
+    if (b == NULL) return -1;
+    memset(info, 0, sizeof(*info));
+    info->is_eof = !!(b->s.flags & HB_BUF_FLAG_EOF);
+    info->start = b->s.start;
+    info->stop = b->s.stop;
+    info->flags = b->s.flags;
+    info->combed = b->s.combed;
+    info->width = b->f.width;
+    info->height = b->f.height;
+    info->fmt = b->f.fmt;
+    info->nplanes = b->size ? b->f.max_plane + 1 : 0;
+    for (int p = 0; p < info->nplanes; p++)
+    {
+        info->plane_width[p] = b->plane[p].width;
+        info->plane_height[p] = b->plane[p].height;
+        info->plane_stride[p] = b->plane[p].stride;
+    }
+    return 0;
+}
+
+int hbh_chain_pop(hbh_chain_t *c, uint8_t *const plane[3], const int stride[3])
+{
+    hb_buffer_t *b = c ? hb_buffer_list_rem_head(&c->out) : NULL;
+    if (b == NULL) return -1;
+    if (b->size && plane != NULL)
+    {
+        for (int p = 0; p <= b->f.max_plane; p++)
+        {
+            if (plane[p] == NULL) continue;
+            const int row = MIN(stride[p], b->plane[p].stride);
+            for (int y = 0; y < b->plane[p].height; y++)
+                memcpy(plane[p] + (size_t)y * stride[p],
+                       b->plane[p].data + (size_t)y * b->plane[p].stride, row);
+        }
+    }
+    hb_buffer_close(&b);
+    return 0;
+}
+
+void hbh_chain_output_geometry(hbh_chain_t *c, int *width, int *height, int *vrate_num, int *vrate_den)
+{
+    if (width)     *width = c->init.geometry.width;
+    if (height)    *height = c->init.geometry.height;
+    if (vrate_num) *vrate_num = c->init.vrate.num;
+    if (vrate_den) *vrate_den = c->init.vrate.den;
+}
+
+void hbh_chain_close(hbh_chain_t *c)
+{
+    if (c == NULL) return;
+    for (int i = 0; i < c->nstages; i++)
+    {
+        hb_filter_object_t *f = c->stage[i];
+        if (f->close) f->close(f);
+        hb_dict_free(&f->settings);
+        free(f);
+    }
+    hb_buffer_list_close(&c->out);
+    free(c);
+}

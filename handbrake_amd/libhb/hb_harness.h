@@ -1,0 +1,49 @@
+/* hb_harness.h — C interface of the filter-chain test/bench driver
+ * (hb_harness.c).  Plain C types only so Python can bind it with ctypes. */
+#ifndef HBHIP_HARNESS_H
+#define HBHIP_HARNESS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hbh_chain_s hbh_chain_t;
+
+typedef struct hbh_frame_info_s
+{
+    int     is_eof;
+    int64_t start;
+    int64_t stop;
+    int     flags;
+    int     combed;
+    int     width;
+    int     height;
+    int     fmt;
+    int     nplanes;
+    int     plane_width[4];
+    int     plane_height[4];
+    int     plane_stride[4];
+} hbh_frame_info_t;
+
+/* protos[i] = address of a registered hb_filter_object_t (e.g. &hb_filter_nlmeans);
+ * settings[i] = "key=value:key=value" or NULL. */
+hbh_chain_t *hbh_chain_open(int nstages, void *const *protos, const char *const *settings,
+                            int pix_fmt, int width, int height,
+                            int vrate_num, int vrate_den);
+int  hbh_chain_push(hbh_chain_t *c, const uint8_t *const plane[3], const int stride[3],
+                    int64_t start, int64_t stop, int flags, int combed);
+int  hbh_chain_push_eof(hbh_chain_t *c);
+int  hbh_chain_pending(hbh_chain_t *c);
+int  hbh_chain_peek(hbh_chain_t *c, hbh_frame_info_t *info);
+int  hbh_chain_pop(hbh_chain_t *c, uint8_t *const plane[3], const int stride[3]);
+void hbh_chain_output_geometry(hbh_chain_t *c, int *width, int *height, int *vrate_num, int *vrate_den);
+void hbh_chain_close(hbh_chain_t *c);
+
+void hbhip_set_log_level(int level);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

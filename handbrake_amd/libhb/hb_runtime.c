@@ -1,0 +1,590 @@
+/* hb_runtime.c — standalone stand-in for the libhb L1 services a video filter
+ * uses (buffers, buffer lists, settings dictionary, locks/conds/threads,
+ * logging, pixel-format descriptors).
+ *
+ * This file exists only so that filter objects — ours AND the reference's own,
+ * compiled in place by oracle/Makefile — can be driven OUTSIDE of libhb by the
+ * test harness.  Inside libhb the real fifo.c / ports.c / hb_dict.c provide
+ * these symbols.  Semantics follow, re-implemented:
+ *   fifo.c:358-457   hb_buffer_init (64 B tail padding, NOPTS timestamps)
+ *   fifo.c:618-622   hb_buffer_copy_props
+ *   fifo.c:820-881   hb_buffer_init_planes / hb_frame_buffer_init
+ *   fifo.c:883-958   blank_stride / mirror_stride (incl. the 8-bit dispatch quirk)
+ *   common.c:4002-4235 hb_buffer_list_*
+ * One deliberate difference: frame buffers are always zero-filled (the
+ * reference recycles pool buffers with stale content; SURVEY §6b hazard 10) so
+ * that the oracle is deterministic.
+ */
+#include "hbhip_libhb.h"
+
+#include <pthread.h>
+#include <stdarg.h>
+#include <unistd.h>
+
+/* ------------------------------------------------------------------ logging */
+static int g_log_level = 0;
+
+void hbhip_set_log_level(int level) { g_log_level = level; }
+
+void hb_log(const char *fmt, ...)
+{
+    if (g_log_level < 1) return;
+    va_list ap;
+    va_start(ap, fmt);
+    vfprintf(stderr, fmt, ap);
+    fputc('\n', stderr);
+    va_end(ap);
+}
+
+void hb_deep_log(int level, const char *fmt, ...)
+{
+    if (g_log_level < level + 1) return;
+    va_list ap;
+    va_start(ap, fmt);
+    vfprintf(stderr, fmt, ap);
+    fputc('\n', stderr);
+    va_end(ap);
+}
+
+void hb_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    fputs("ERROR: ", stderr);
+    vfprintf(stderr, fmt, ap);
+    fputc('\n', stderr);
+    va_end(ap);
+}
+
+/* ------------------------------------------------------- pixel descriptors */
+static const AVPixFmtDescriptor k_desc_yuv420p = {
+    "yuv420p", 3, 1, 1, 0,
+    { {0, 1, 0, 0, 8}, {1, 1, 0, 0, 8}, {2, 1, 0, 0, 8}, {0, 0, 0, 0, 0} } };
+static const AVPixFmtDescriptor k_desc_yuv422p = {
+    "yuv422p", 3, 1, 0, 0,
+    { {0, 1, 0, 0, 8}, {1, 1, 0, 0, 8}, {2, 1, 0, 0, 8}, {0, 0, 0, 0, 0} } };
+static const AVPixFmtDescriptor k_desc_yuv444p = {
+    "yuv444p", 3, 0, 0, 0,
+    { {0, 1, 0, 0, 8}, {1, 1, 0, 0, 8}, {2, 1, 0, 0, 8}, {0, 0, 0, 0, 0} } };
+static const AVPixFmtDescriptor k_desc_gray8 = {
+    "gray", 1, 0, 0, 0,
+    { {0, 1, 0, 0, 8}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0} } };
+static const AVPixFmtDescriptor k_desc_yuv420p10 = {
+    "yuv420p10le", 3, 1, 1, 0,
+    { {0, 2, 0, 0, 10}, {1, 2, 0, 0, 10}, {2, 2, 0, 0, 10}, {0, 0, 0, 0, 0} } };
+static const AVPixFmtDescriptor k_desc_yuv420p12 = {
+    "yuv420p12le", 3, 1, 1, 0,
+    { {0, 2, 0, 0, 12}, {1, 2, 0, 0, 12}, {2, 2, 0, 0, 12}, {0, 0, 0, 0, 0} } };
+
+const AVPixFmtDescriptor *av_pix_fmt_desc_get(int pix_fmt)
+{
+    switch (pix_fmt)
+    {
+        case AV_PIX_FMT_YUV420P:     return &k_desc_yuv420p;
+        case AV_PIX_FMT_YUV422P:     return &k_desc_yuv422p;
+        case AV_PIX_FMT_YUV444P:     return &k_desc_yuv444p;
+        case AV_PIX_FMT_GRAY8:       return &k_desc_gray8;
+        case AV_PIX_FMT_YUV420P10LE: return &k_desc_yuv420p10;
+        case AV_PIX_FMT_YUV420P12LE: return &k_desc_yuv420p12;
+        default:                     return NULL;
+    }
+}
+
+int av_image_get_linesize(int pix_fmt, int width, int plane)
+{
+    const AVPixFmtDescriptor *d = av_pix_fmt_desc_get(pix_fmt);
+    if (d == NULL) return -1;
+    int w = width;
+    if (plane == 1 || plane == 2)
+        w = -((-width) >> d->log2_chroma_w);
+    return w * d->comp[plane].step;
+}
+
+void *av_malloc(size_t size)
+{
+    void *p = NULL;
+    if (posix_memalign(&p, 64, size ? size : 1) != 0) return NULL;
+    return p;
+}
+
+void av_freep(void *arg)
+{
+    void **pp = (void **)arg;
+    free(*pp);
+    *pp = NULL;
+}
+
+int av_get_cpu_flags(void)
+{
+#if defined(__x86_64__)
+    return AV_CPU_FLAG_SSE2;
+#else
+    return 0;
+#endif
+}
+
+/* ----------------------------------------------------------------- threads */
+struct hb_lock_s   { pthread_mutex_t m; };
+struct hb_cond_s   { pthread_cond_t c; };
+struct hb_thread_s { pthread_t t; thread_func_t *fn; void *arg; };
+
+static int g_cpu_override = 0;
+void hbhip_set_cpu_count(int n) { g_cpu_override = n; }
+
+int hb_get_cpu_count(void)
+{
+    if (g_cpu_override > 0) return g_cpu_override;
+    long n = sysconf(_SC_NPROCESSORS_ONLN);
+    if (n < 1) n = 1;
+    if (n > 128) n = 128;
+    return (int)n;
+}
+
+hb_lock_t *hb_lock_init(void)
+{
+    hb_lock_t *l = calloc(1, sizeof(*l));
+    if (l) pthread_mutex_init(&l->m, NULL);
+    return l;
+}
+void hb_lock_close(hb_lock_t **l)
+{
+    if (l == NULL || *l == NULL) return;
+    pthread_mutex_destroy(&(*l)->m);
+    free(*l);
+    *l = NULL;
+}
+void hb_lock(hb_lock_t *l)   { pthread_mutex_lock(&l->m); }
+void hb_unlock(hb_lock_t *l) { pthread_mutex_unlock(&l->m); }
+
+hb_cond_t *hb_cond_init(void)
+{
+    hb_cond_t *c = calloc(1, sizeof(*c));
+    if (c) pthread_cond_init(&c->c, NULL);
+    return c;
+}
+void hb_cond_wait(hb_cond_t *c, hb_lock_t *l) { pthread_cond_wait(&c->c, &l->m); }
+void hb_cond_signal(hb_cond_t *c)    { pthread_cond_signal(&c->c); }
+void hb_cond_broadcast(hb_cond_t *c) { pthread_cond_broadcast(&c->c); }
+void hb_cond_close(hb_cond_t **c)
+{
+    if (c == NULL || *c == NULL) return;
+    pthread_cond_destroy(&(*c)->c);
+    free(*c);
+    *c = NULL;
+}
+
+static void *thread_trampoline(void *p)
+{
+    hb_thread_t *t = p;
+    t->fn(t->arg);
+    return NULL;
+}
+
+hb_thread_t *hb_thread_init(const char *name, thread_func_t *function, void *arg, int priority)
+{
+    (void)name; (void)priority;
+    hb_thread_t *t = calloc(1, sizeof(*t));
+    if (t == NULL) return NULL;
+    t->fn = function;
+    t->arg = arg;
+    if (pthread_create(&t->t, NULL, thread_trampoline, t) != 0)
+    {
+        free(t);
+        return NULL;
+    }
+    return t;
+}
+
+void hb_thread_close(hb_thread_t **t)
+{
+    if (t == NULL || *t == NULL) return;
+    pthread_join((*t)->t, NULL);
+    free(*t);
+    *t = NULL;
+}
+
+/* -------------------------------------------------------------- dictionary */
+typedef struct kv_s { char *k; char *v; struct kv_s *next; } kv_t;
+struct hbhip_dict_s { kv_t *head; kv_t *tail; };
+
+hb_dict_t *hb_dict_init(void) { return calloc(1, sizeof(hb_dict_t)); }
+
+void hb_dict_free(hb_dict_t **pd)
+{
+    if (pd == NULL || *pd == NULL) return;
+    kv_t *e = (*pd)->head;
+    while (e)
+    {
+        kv_t *n = e->next;
+        free(e->k); free(e->v); free(e);
+        e = n;
+    }
+    free(*pd);
+    *pd = NULL;
+}
+
+static kv_t *dict_find(const hb_dict_t *d, const char *key)
+{
+    if (d == NULL) return NULL;
+    for (kv_t *e = d->head; e; e = e->next)
+        if (!strcmp(e->k, key)) return e;
+    return NULL;
+}
+
+void hbhip_dict_set(hb_dict_t *d, const char *key, const char *value)
+{
+    kv_t *e = dict_find(d, key);
+    if (e)
+    {
+        free(e->v);
+        e->v = strdup(value);
+        return;
+    }
+    e = calloc(1, sizeof(*e));
+    e->k = strdup(key);
+    e->v = strdup(value);
+    if (d->tail) d->tail->next = e; else d->head = e;
+    d->tail = e;
+}
+
+hb_dict_t *hbhip_dict_from_string(const char *settings)
+{
+    hb_dict_t *d = hb_dict_init();
+    if (settings == NULL || d == NULL) return d;
+    char *copy = strdup(settings), *save = NULL;
+    for (char *tok = strtok_r(copy, ":", &save); tok; tok = strtok_r(NULL, ":", &save))
+    {
+        char *eq = strchr(tok, '=');
+        if (eq == NULL) continue;
+        *eq = 0;
+        hbhip_dict_set(d, tok, eq + 1);
+    }
+    free(copy);
+    return d;
+}
+
+int hb_dict_extract_int(int *dst, const hb_dict_t *dict, const char *key)
+{
+    kv_t *e = dict_find(dict, key);
+    if (e == NULL || dst == NULL) return 0;
+    char *end = NULL;
+    double v = strtod(e->v, &end);
+    if (end == e->v)
+    {
+        if (!strcasecmp(e->v, "true") || !strcasecmp(e->v, "yes")) { *dst = 1; return 1; }
+        if (!strcasecmp(e->v, "false") || !strcasecmp(e->v, "no")) { *dst = 0; return 1; }
+        return 0;
+    }
+    *dst = (int)v;
+    return 1;
+}
+
+int hb_dict_extract_double(double *dst, const hb_dict_t *dict, const char *key)
+{
+    kv_t *e = dict_find(dict, key);
+    if (e == NULL || dst == NULL) return 0;
+    char *end = NULL;
+    double v = strtod(e->v, &end);
+    if (end == e->v) return 0;
+    *dst = v;
+    return 1;
+}
+
+int hb_dict_extract_bool(int *dst, const hb_dict_t *dict, const char *key)
+{
+    int v;
+    if (!hb_dict_extract_int(&v, dict, key)) return 0;
+    *dst = !!v;
+    return 1;
+}
+
+int hb_dict_extract_string(char **dst, const hb_dict_t *dict, const char *key)
+{
+    kv_t *e = dict_find(dict, key);
+    if (e == NULL || dst == NULL) return 0;
+    *dst = strdup(e->v);
+    return 1;
+}
+
+/* ----------------------------------------------------------------- buffers */
+#define HBHIP_BUF_PADDING 64
+
+hb_buffer_t *hb_buffer_init(int size)
+{
+    hb_buffer_t *b = calloc(1, sizeof(*b));
+    if (b == NULL) return NULL;
+    b->size = size;
+    b->alloc = size ? size + HBHIP_BUF_PADDING : 0;
+    if (size)
+    {
+        b->data = av_malloc(b->alloc);
+        if (b->data == NULL) { free(b); return NULL; }
+        memset(b->data, 0, b->alloc);
+    }
+    b->s.start = AV_NOPTS_VALUE;
+    b->s.stop = AV_NOPTS_VALUE;
+    b->s.renderOffset = AV_NOPTS_VALUE;
+    b->s.scr_sequence = -1;
+    return b;
+}
+
+hb_buffer_t *hb_buffer_eof_init(void)
+{
+    hb_buffer_t *b = hb_buffer_init(0);
+    if (b) b->s.flags = HB_BUF_FLAG_EOF;
+    return b;
+}
+
+void hb_buffer_init_planes(hb_buffer_t *b)
+{
+    uint8_t *p = b->data;
+    for (int pp = 0; pp <= b->f.max_plane; pp++)
+    {
+        b->plane[pp].data   = p;
+        b->plane[pp].stride = hb_image_stride(b->f.fmt, b->f.width, pp);
+        b->plane[pp].width  = hb_image_width(b->f.fmt, b->f.width, pp);
+        b->plane[pp].height = hb_image_height(b->f.fmt, b->f.height, pp);
+        b->plane[pp].size   = b->plane[pp].stride * b->plane[pp].height;
+        p += b->plane[pp].size;
+    }
+}
+
+hb_buffer_t *hb_frame_buffer_init(int pix_fmt, int width, int height)
+{
+    const AVPixFmtDescriptor *desc = av_pix_fmt_desc_get(pix_fmt);
+    if (desc == NULL) return NULL;
+
+    int max_plane = 0, size = 0;
+    uint8_t seen[4] = {0, 0, 0, 0};
+    for (int i = 0; i < desc->nb_components; i++)
+    {
+        int pp = desc->comp[i].plane;
+        if (pp > max_plane) max_plane = pp;
+        if (!seen[pp])
+        {
+            seen[pp] = 1;
+            size += hb_image_stride(pix_fmt, width, pp) * hb_image_height(pix_fmt, height, pp);
+        }
+    }
+    hb_buffer_t *b = hb_buffer_init(size);
+    if (b == NULL) return NULL;
+    b->f.max_plane = max_plane;
+    b->s.type = FRAME_BUF;
+    b->f.width = width;
+    b->f.height = height;
+    b->f.fmt = pix_fmt;
+    hb_buffer_init_planes(b);
+    return b;
+}
+
+void hb_frame_buffer_blank_stride(hb_buffer_t *buf)
+{
+    for (int pp = 0; pp <= buf->f.max_plane; pp++)
+    {
+        uint8_t *d = buf->plane[pp].data;
+        if (d == NULL) continue;
+        for (int y = 0; y < buf->plane[pp].height; y++)
+            memset(d + (size_t)y * buf->plane[pp].stride + buf->plane[pp].width, 0x80,
+                   buf->plane[pp].stride - buf->plane[pp].width);
+    }
+}
+
+/* fifo.c:906-958.  The reference computes depth = (bits > 8 ? 2 : 1) and then
+ * switches on `case 8`, so every format goes down the 16-bit branch; keep that. */
+static void mirror_stride_u16(uint8_t *data, int width, int height, int stride)
+{
+    uint16_t *px = (uint16_t *)data;
+    stride /= 2;
+    const int margin = stride - width;
+    const int front = margin / 2;
+    const int back = margin - front;
+    for (int y = 0; y < height; y++)
+    {
+        int pos = y * stride + width;
+        for (int i = 0; i < back; i++)
+            px[pos + i] = px[pos - i - 1];
+        pos = (y + 1) * stride - 1;
+        for (int i = 0; i < front; i++)
+            px[pos - i] = px[pos + i + 1];
+    }
+}
+
+void hb_frame_buffer_mirror_stride(hb_buffer_t *buf)
+{
+    for (int pp = 0; pp <= buf->f.max_plane; pp++)
+    {
+        if (buf->plane[pp].data == NULL) continue;
+        mirror_stride_u16(buf->plane[pp].data, buf->plane[pp].width,
+                          buf->plane[pp].height, buf->plane[pp].stride);
+    }
+}
+
+void hb_buffer_close(hb_buffer_t **pb)
+{
+    if (pb == NULL) return;
+    hb_buffer_t *b = *pb;
+    while (b)
+    {
+        hb_buffer_t *next = b->next;
+        if (b->data && b->storage_type == STANDARD)
+            free(b->data);
+        free(b);
+        b = next;
+    }
+    *pb = NULL;
+}
+
+void hb_buffer_copy_props(hb_buffer_t *dst, const hb_buffer_t *src)
+{
+    dst->s = src->s;
+}
+
+int hb_buffer_copy(hb_buffer_t *dst, const hb_buffer_t *src)
+{
+    if (src == NULL || dst == NULL || dst->size < src->size) return -1;
+    memcpy(dst->data, src->data, src->size);
+    dst->f = src->f;
+    hb_buffer_copy_props(dst, src);
+    if (dst->s.type == FRAME_BUF)
+        hb_buffer_init_planes(dst);
+    return 0;
+}
+
+hb_buffer_t *hb_buffer_dup(const hb_buffer_t *src)
+{
+    if (src == NULL) return NULL;
+    hb_buffer_t *b = hb_buffer_init(src->size);
+    if (b == NULL) return NULL;
+    if (src->size) memcpy(b->data, src->data, src->size);
+    b->s = src->s;
+    b->f = src->f;
+    if (b->s.type == FRAME_BUF)
+        hb_buffer_init_planes(b);
+    return b;
+}
+
+hb_buffer_t *hb_buffer_shallow_dup(const hb_buffer_t *src)
+{
+    return hb_buffer_dup(src);
+}
+
+/* ------------------------------------------------------------ buffer lists */
+static hb_buffer_t *chain_end(hb_buffer_t *b, int *count, int *size)
+{
+    *count = 1;
+    *size = b->size;
+    while (b->next)
+    {
+        b = b->next;
+        (*count)++;
+        *size += b->size;
+    }
+    return b;
+}
+
+void hb_buffer_list_append(hb_buffer_list_t *l, hb_buffer_t *buf)
+{
+    if (buf == NULL) return;
+    int n, sz;
+    hb_buffer_t *end = chain_end(buf, &n, &sz);
+    if (l->tail == NULL) l->head = buf; else l->tail->next = buf;
+    l->tail = end;
+    l->count += n;
+    l->size += sz;
+}
+
+void hb_buffer_list_prepend(hb_buffer_list_t *l, hb_buffer_t *buf)
+{
+    if (buf == NULL) return;
+    int n, sz;
+    hb_buffer_t *end = chain_end(buf, &n, &sz);
+    if (l->tail == NULL) l->tail = end; else end->next = l->head;
+    l->head = buf;
+    l->count += n;
+    l->size += sz;
+}
+
+hb_buffer_t *hb_buffer_list_head(hb_buffer_list_t *l) { return l ? l->head : NULL; }
+hb_buffer_t *hb_buffer_list_tail(hb_buffer_list_t *l) { return l ? l->tail : NULL; }
+
+hb_buffer_t *hb_buffer_list_rem_head(hb_buffer_list_t *l)
+{
+    if (l == NULL || l->head == NULL) return NULL;
+    hb_buffer_t *h = l->head;
+    if (l->head == l->tail) l->tail = NULL;
+    l->head = h->next;
+    l->count--;
+    l->size -= h->size;
+    h->next = NULL;
+    return h;
+}
+
+hb_buffer_t *hb_buffer_list_rem_tail(hb_buffer_list_t *l)
+{
+    if (l == NULL || l->tail == NULL) return NULL;
+    hb_buffer_t *t = l->tail;
+    if (l->head == t)
+    {
+        l->head = l->tail = NULL;
+        l->count = 0;
+        l->size = 0;
+    }
+    else
+    {
+        hb_buffer_t *p = l->head;
+        while (p->next != t) p = p->next;
+        p->next = NULL;
+        l->tail = p;
+        l->count--;
+        l->size -= t->size;
+    }
+    t->next = NULL;
+    return t;
+}
+
+hb_buffer_t *hb_buffer_list_rem(hb_buffer_list_t *l, hb_buffer_t *b)
+{
+    if (l == NULL) return NULL;
+    if (b == l->head) return hb_buffer_list_rem_head(l);
+    hb_buffer_t *a = l->head;
+    while (a && a->next != b) a = a->next;
+    if (a == NULL) return NULL;
+    a->next = b->next;
+    if (l->tail == b) l->tail = a;
+    l->count--;
+    l->size -= b->size;
+    b->next = NULL;
+    return b;
+}
+
+hb_buffer_t *hb_buffer_list_clear(hb_buffer_list_t *l)
+{
+    if (l == NULL) return NULL;
+    hb_buffer_t *h = l->head;
+    l->head = l->tail = NULL;
+    l->count = 0;
+    l->size = 0;
+    return h;
+}
+
+hb_buffer_t *hb_buffer_list_set(hb_buffer_list_t *l, hb_buffer_t *buf)
+{
+    if (l == NULL) return NULL;
+    hb_buffer_t *old = l->head;
+    l->head = buf;
+    l->tail = NULL;
+    l->count = 0;
+    l->size = 0;
+    if (buf)
+        l->tail = chain_end(buf, &l->count, &l->size);
+    return old;
+}
+
+void hb_buffer_list_close(hb_buffer_list_t *l)
+{
+    hb_buffer_t *b = hb_buffer_list_clear(l);
+    hb_buffer_close(&b);
+}
+
+int hb_buffer_list_count(hb_buffer_list_t *l) { return l ? l->count : 0; }
+int hb_buffer_list_size(hb_buffer_list_t *l)  { return l ? l->size : 0; }

@@ -1,0 +1,428 @@
+/* hbhip_libhb.h — the slice of libhb's L1/L3 interface that a video filter
+ * plugin touches, written from scratch so the HIP-backed filter objects (and
+ * the test oracle) can be built OUTSIDE of libhb.
+ *
+ * When these filters are compiled inside libhb this header is
+ * not used at all: define HBHIP_IN_LIBHB and "handbrake/handbrake.h" supplies
+ * the real declarations.  Every declaration below names the reference
+ * declaration it stands in for (path relative to /root/reference/libhb):
+ *
+ *   hb_filter_object_t, hb_filter_init_t, HB_FILTER_*   handbrake/common.h:1628-1780
+ *   hb_buffer_t, hb_buffer_settings_t, hb_image_format_t handbrake/internal.h:65-165
+ *   hb_image_stride/width/height, hb_image_copy_plane   handbrake/internal.h:220-275
+ *   hb_buffer_list_t                                    handbrake/common.h:115-134
+ *   hb_lock/hb_cond/hb_thread                           handbrake/ports.h:162-210
+ *   hb_dict_extract_*                                   handbrake/hb_dict.h:54-69
+ *   HB_*_REG                                            handbrake/common.h:1887-1893
+ *
+ * Only fields a filter reads or writes are present; the struct layouts are our
+ * own (both the oracle wrapper TUs and our filters compile against THIS file,
+ * so they agree with each other by construction).
+ */
+#ifndef HBHIP_LIBHB_H
+#define HBHIP_LIBHB_H
+
+#ifdef HBHIP_IN_LIBHB
+#include "handbrake/handbrake.h"
+#else
+
+#include <stdint.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <strings.h>
+#include <math.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __LIBHB__
+#define __LIBHB__ 1
+#endif
+
+#if defined(__x86_64__) && !defined(ARCH_X86)
+#define ARCH_X86 1
+#define ARCH_X86_64 1
+#endif
+
+/* ---- small macros (common.h:59-80) ------------------------------------ */
+#ifndef MIN
+#define MIN(a, b) (((a) < (b)) ? (a) : (b))
+#endif
+#ifndef MAX
+#define MAX(a, b) (((a) > (b)) ? (a) : (b))
+#endif
+#ifndef ABS
+#define ABS(a) ((a) > 0 ? (a) : (-(a)))
+#endif
+#define MULTIPLE_MOD_UP(a, b) (((b) * (int)(((a) + ((b) - 1)) / (b))))
+#define HB_ALIGN(x, a) (((x) + (a) - 1) & ~((a) - 1))
+
+#define HB_FLOAT_REG    "(([0-9]+([.,][0-9]+)?)|([.,][0-9]+))"
+#define HB_INT_REG      "([0-9]+)"
+#define HB_RATIONAL_REG "([0-9]+/[0-9]+)"
+#define HB_BOOL_REG     "(yes|no|true|false|[01])"
+#define HB_ALL_REG      "(.*)"
+
+/* ---- libavutil stand-ins ------------------------------------------------ */
+#define AV_NOPTS_VALUE ((int64_t)UINT64_C(0x8000000000000000))
+#define FFMIN(a, b) ((a) > (b) ? (b) : (a))
+#define FFMAX(a, b) ((a) > (b) ? (a) : (b))
+#define AV_CEIL_RSHIFT(a, b) (-((-(a)) >> (b)))
+
+enum hbhip_pix_fmt
+{
+    AV_PIX_FMT_NONE        = -1,
+    AV_PIX_FMT_YUV420P     = 0,
+    AV_PIX_FMT_YUV422P     = 4,
+    AV_PIX_FMT_YUV444P     = 5,
+    AV_PIX_FMT_GRAY8       = 8,
+    AV_PIX_FMT_YUV420P10LE = 62,
+    AV_PIX_FMT_YUV420P10   = 62,
+    AV_PIX_FMT_YUV420P12LE = 123,
+    AV_PIX_FMT_YUV420P12   = 123
+};
+
+typedef struct AVComponentDescriptor
+{
+    int plane;
+    int step;
+    int offset;
+    int shift;
+    int depth;
+} AVComponentDescriptor;
+
+typedef struct AVPixFmtDescriptor
+{
+    const char *name;
+    uint8_t     nb_components;
+    uint8_t     log2_chroma_w;
+    uint8_t     log2_chroma_h;
+    uint64_t    flags;
+    AVComponentDescriptor comp[4];
+} AVPixFmtDescriptor;
+
+const AVPixFmtDescriptor *av_pix_fmt_desc_get(int pix_fmt);
+int  av_image_get_linesize(int pix_fmt, int width, int plane);
+void *av_malloc(size_t size);
+void  av_freep(void *ptr);
+#define AV_CPU_FLAG_SSE2 0x0010
+int  av_get_cpu_flags(void);
+
+typedef struct AVChannelLayout { int nb_channels; } AVChannelLayout;
+
+/* ---- opaque handles ------------------------------------------------------ */
+typedef struct hb_job_s            hb_job_t;
+typedef struct hb_fifo_s           hb_fifo_t;
+typedef struct hb_subtitle_s       hb_subtitle_t;
+typedef struct hb_lock_s           hb_lock_t;
+typedef struct hb_cond_s           hb_cond_t;
+typedef struct hb_thread_s         hb_thread_t;
+typedef struct hb_filter_private_s hb_filter_private_t;
+typedef struct hb_filter_object_s  hb_filter_object_t;
+typedef struct hb_buffer_s         hb_buffer_t;
+typedef struct hb_buffer_list_s    hb_buffer_list_t;
+typedef struct hbhip_dict_s        hb_dict_t;
+typedef struct hbhip_dict_s        hb_value_t;
+
+typedef struct hb_rational_s { int num; int den; } hb_rational_t;
+typedef struct hb_geometry_s { int width; int height; hb_rational_t par; } hb_geometry_t;
+
+/* ---- logging (handbrake/internal.h:23-32) ------------------------------- */
+void hb_log(const char *fmt, ...);
+void hb_deep_log(int level, const char *fmt, ...);
+void hb_error(const char *fmt, ...);
+
+/* ---- ports.h:162-210 ------------------------------------------------------ */
+#define HB_LOW_PRIORITY    0
+#define HB_NORMAL_PRIORITY 0
+typedef void (thread_func_t)(void *);
+hb_thread_t *hb_thread_init(const char *name, thread_func_t *function, void *arg, int priority);
+void         hb_thread_close(hb_thread_t **);
+hb_lock_t   *hb_lock_init(void);
+void         hb_lock_close(hb_lock_t **);
+void         hb_lock(hb_lock_t *);
+void         hb_unlock(hb_lock_t *);
+hb_cond_t   *hb_cond_init(void);
+void         hb_cond_wait(hb_cond_t *, hb_lock_t *);
+void         hb_cond_signal(hb_cond_t *);
+void         hb_cond_broadcast(hb_cond_t *);
+void         hb_cond_close(hb_cond_t **);
+int          hb_get_cpu_count(void);
+/* test/bench hook (ours): override what hb_get_cpu_count() reports; 0 = real. */
+void         hbhip_set_cpu_count(int n);
+
+/* ---- settings dictionary (hb_dict.h:54-69) -------------------------------
+ * Stand-in: an ordered list of key/value strings.  hb_dict_extract_* return 1
+ * when the key exists (and was convertible), 0 otherwise, like the reference. */
+hb_dict_t *hb_dict_init(void);
+void       hb_dict_free(hb_dict_t **);
+void       hbhip_dict_set(hb_dict_t *, const char *key, const char *value);
+/* "key=value:key=value" (the CLI / settings_template form). */
+hb_dict_t *hbhip_dict_from_string(const char *settings);
+int hb_dict_extract_int(int *dst, const hb_dict_t *dict, const char *key);
+int hb_dict_extract_double(double *dst, const hb_dict_t *dict, const char *key);
+int hb_dict_extract_bool(int *dst, const hb_dict_t *dict, const char *key);
+int hb_dict_extract_string(char **dst, const hb_dict_t *dict, const char *key);
+
+/* ---- buffers (internal.h:65-165) ------------------------------------------ */
+#define PIC_FLAG_TOP_FIELD_FIRST    0x0008
+#define PIC_FLAG_PROGRESSIVE_FRAME  0x0010
+#define PIC_FLAG_REPEAT_FIRST_FIELD 0x0100
+#define PIC_FLAG_REPEAT_FRAME       0x0200
+#define HB_BUF_FLAG_EOF             0x0400
+#define HB_BUF_FLAG_EOS             0x0800
+
+#define HB_COMB_NONE  0
+#define HB_COMB_LIGHT 1
+#define HB_COMB_HEAVY 2
+
+typedef struct hb_buffer_settings_s
+{
+    enum { OTHER_BUF, AUDIO_BUF, VIDEO_BUF, SUBTITLE_BUF, FRAME_BUF } type;
+    int      id;
+    int64_t  start;
+    double   duration;
+    int64_t  stop;
+    int64_t  renderOffset;
+    int64_t  pcr;
+    int      scr_sequence;
+    int      split;
+    uint8_t  discontinuity;
+    int      new_chap;
+    uint8_t  frametype;
+    uint16_t flags;
+    uint8_t  combed;
+} hb_buffer_settings_t;
+
+typedef struct hb_image_format_s
+{
+    int x, y;
+    int width, height;
+    int fmt;
+    int color_prim, color_transfer, color_matrix, color_range;
+    int chroma_location;
+    int max_plane;
+    int window_width, window_height;
+} hb_image_format_t;
+
+struct hb_buffer_s
+{
+    int      size;
+    int      alloc;
+    uint8_t *data;
+    int      offset;
+
+    hb_buffer_settings_t s;
+    hb_image_format_t    f;
+
+    struct buffer_plane
+    {
+        uint8_t *data;
+        int      stride;
+        int      width;
+        int      height;
+        int      size;
+    } plane[4];
+
+    void *storage;
+    enum { STANDARD, AVFRAME, COREMEDIA, HBHIP_DEVICE } storage_type;
+
+    hb_buffer_t *palette;
+    void       **side_data;
+    int          nb_side_data;
+
+    hb_buffer_t *next;
+};
+
+struct hb_buffer_list_s
+{
+    hb_buffer_t *head;
+    hb_buffer_t *tail;
+    int count;
+    int size;
+};
+
+hb_buffer_t *hb_buffer_init(int size);
+hb_buffer_t *hb_buffer_eof_init(void);
+hb_buffer_t *hb_frame_buffer_init(int pix_fmt, int w, int h);
+void         hb_frame_buffer_blank_stride(hb_buffer_t *buf);
+void         hb_frame_buffer_mirror_stride(hb_buffer_t *buf);
+void         hb_buffer_init_planes(hb_buffer_t *b);
+void         hb_buffer_close(hb_buffer_t **);
+hb_buffer_t *hb_buffer_dup(const hb_buffer_t *src);
+hb_buffer_t *hb_buffer_shallow_dup(const hb_buffer_t *src);
+int          hb_buffer_copy(hb_buffer_t *dst, const hb_buffer_t *src);
+void         hb_buffer_copy_props(hb_buffer_t *dst, const hb_buffer_t *src);
+
+void         hb_buffer_list_append(hb_buffer_list_t *list, hb_buffer_t *buf);
+void         hb_buffer_list_prepend(hb_buffer_list_t *list, hb_buffer_t *buf);
+hb_buffer_t *hb_buffer_list_head(hb_buffer_list_t *list);
+hb_buffer_t *hb_buffer_list_rem_head(hb_buffer_list_t *list);
+hb_buffer_t *hb_buffer_list_tail(hb_buffer_list_t *list);
+hb_buffer_t *hb_buffer_list_rem_tail(hb_buffer_list_t *list);
+hb_buffer_t *hb_buffer_list_rem(hb_buffer_list_t *list, hb_buffer_t *b);
+hb_buffer_t *hb_buffer_list_clear(hb_buffer_list_t *list);
+hb_buffer_t *hb_buffer_list_set(hb_buffer_list_t *list, hb_buffer_t *buf);
+void         hb_buffer_list_close(hb_buffer_list_t *list);
+int          hb_buffer_list_count(hb_buffer_list_t *list);
+int          hb_buffer_list_size(hb_buffer_list_t *list);
+
+/* internal.h:220-275 */
+static inline int hb_image_stride(int pix_fmt, int width, int plane)
+{
+    int linesize = av_image_get_linesize(pix_fmt, width, plane);
+    return MULTIPLE_MOD_UP(linesize, 64);
+}
+
+static inline int hb_image_width(int pix_fmt, int width, int plane)
+{
+    const AVPixFmtDescriptor *desc = av_pix_fmt_desc_get(pix_fmt);
+    if (desc != NULL && (plane == 1 || plane == 2))
+        width = -((-width) >> desc->log2_chroma_w);
+    return width;
+}
+
+static inline int hb_image_height(int pix_fmt, int height, int plane)
+{
+    const AVPixFmtDescriptor *desc = av_pix_fmt_desc_get(pix_fmt);
+    if (desc != NULL && (plane == 1 || plane == 2))
+        height = -((-height) >> desc->log2_chroma_h);
+    return height;
+}
+
+static inline void hb_image_copy_plane(uint8_t *dst, const uint8_t *src,
+                                       const int stride_dst, const int stride_src,
+                                       const int height)
+{
+    if (src == dst)
+        return;
+    if (stride_src == stride_dst)
+    {
+        memcpy(dst, src, (size_t)stride_dst * height);
+        return;
+    }
+    const int n = stride_src < stride_dst ? ABS(stride_src) : stride_dst;
+    for (int y = 0; y < height; y++)
+        memcpy(dst + (size_t)y * stride_dst, src + (ptrdiff_t)y * stride_src, n);
+}
+
+/* ---- filter plugin surface (common.h:1628-1780) ---------------------------- */
+#define HB_FILTER_OK     0
+#define HB_FILTER_DELAY  1
+#define HB_FILTER_FAILED 2
+#define HB_FILTER_DROP   3
+#define HB_FILTER_DONE   4
+
+typedef struct hb_filter_init_s
+{
+    hb_job_t     *job;
+    int           pix_fmt;
+    int           hw_pix_fmt;
+    void         *hw_frames_ctx;
+    int           color_prim;
+    int           color_transfer;
+    int           color_matrix;
+    int           color_range;
+    int           chroma_location;
+    hb_geometry_t geometry;
+    int           crop[4];
+    int           grayscale;
+    hb_rational_t vrate;
+    int           cfr;
+    hb_rational_t time_base;
+    int           samplerate;
+    int           sample_fmt;
+    AVChannelLayout ch_layout;
+} hb_filter_init_t;
+
+typedef struct hb_filter_info_s
+{
+    char            *human_readable_desc;
+    hb_filter_init_t output;
+} hb_filter_info_t;
+
+struct hb_filter_object_s
+{
+    int         id;
+    int         enforce_order;
+    int         skip;
+    int         aliased;
+    char       *name;
+    char       *short_name;
+    hb_dict_t  *settings;
+
+    int  (*init)(hb_filter_object_t *, hb_filter_init_t *);
+    int  (*init_thread)(hb_filter_object_t *, int);
+    int  (*post_init)(hb_filter_object_t *, hb_job_t *);
+    int  (*work)(hb_filter_object_t *, hb_buffer_t **, hb_buffer_t **);
+    int  (*work_thread)(hb_filter_object_t *, hb_buffer_t **, hb_buffer_t **, int);
+    void (*close)(hb_filter_object_t *);
+    hb_filter_info_t *(*info)(hb_filter_object_t *);
+
+    const char *settings_template;
+
+    hb_fifo_t *fifo_in;
+    hb_fifo_t *fifo_out;
+    hb_subtitle_t *subtitle;
+    hb_filter_private_t *private_data;
+    hb_thread_t *thread;
+    volatile int *done;
+    int status;
+    int chapter_val;
+    int64_t chapter_time;
+    hb_filter_object_t *sub_filter;
+};
+
+/* Numeric ids are the reference's (common.h:1729-1778). */
+enum
+{
+    HB_FILTER_INVALID = 0,
+    HB_FILTER_FIRST = 1,
+    HB_FILTER_ADAPTER_VT,
+    HB_FILTER_DETELECINE,
+    HB_FILTER_COMB_DETECT,
+    HB_FILTER_COMB_DETECT_VT,
+    HB_FILTER_DECOMB,
+    HB_FILTER_YADIF,
+    HB_FILTER_YADIF_VT,
+    HB_FILTER_BWDIF,
+    HB_FILTER_BWDIF_VT,
+    HB_FILTER_VFR,
+    HB_FILTER_DEBLOCK,
+    HB_FILTER_DEBAND,
+    HB_FILTER_DENOISE,
+    HB_FILTER_HQDN3D = HB_FILTER_DENOISE,
+    HB_FILTER_BM3D,
+    HB_FILTER_NLMEANS,
+    HB_FILTER_CHROMA_SMOOTH,
+    HB_FILTER_CHROMA_SMOOTH_VT,
+    HB_FILTER_ROTATE,
+    HB_FILTER_ROTATE_VT,
+    HB_FILTER_RENDER_SUB,
+    HB_FILTER_CROP_SCALE,
+    HB_FILTER_CROP_SCALE_VT,
+    HB_FILTER_LAPSHARP,
+    HB_FILTER_LAPSHARP_VT,
+    HB_FILTER_UNSHARP,
+    HB_FILTER_UNSHARP_VT,
+    HB_FILTER_GRAYSCALE,
+    HB_FILTER_GRAYSCALE_VT,
+    HB_FILTER_PAD,
+    HB_FILTER_PAD_VT,
+    HB_FILTER_COLORSPACE,
+    HB_FILTER_FORMAT,
+    HB_FILTER_RPU,
+    HB_FILTER_AVFILTER,
+    HB_FILTER_LAST,
+    HB_FILTER_MT_FRAME
+};
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* HBHIP_IN_LIBHB */
+#endif /* HBHIP_LIBHB_H */

@@ -1,0 +1,67 @@
+/* oracle.h — CPU restatement of libhb's per-pixel video filters.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * liboracle.so or oracle/_ref/libhbref.so, and only as the checker.  The
+ * product path (handbrake_amd/) never links or calls anything here.
+ *
+ * Every function is a plain-C, single-threaded restatement of one reference
+ * routine, written in our own structure, and names the reference lines it
+ * follows (paths relative to /root/reference/libhb).  Parity of THIS file with
+ * the reference is pinned by tests/test_oracle_vs_ref.py, which runs the
+ * reference's own C (compiled in place into oracle/_ref/libhbref.so by
+ * oracle/Makefile) on the same seeded inputs, and by the golden fixtures under
+ * tests/golden/ that were generated from the reference (tests/golden/make_golden.py).
+ */
+#ifndef HB_ORACLE_H
+#define HB_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- NLMeans (nlmeans.c, templates/nlmeans_template.c) ---------------------- */
+
+typedef struct
+{
+    double strength;     /* already clamped, y-strength etc. (nlmeans.c:329)    */
+    double origin_tune;  /* 0.01..1 (nlmeans.c:330-331)                          */
+    int    patch_size;   /* odd (nlmeans.c:332-333)                              */
+    int    range;        /* odd (nlmeans.c:334-335)                              */
+    int    nframes;      /* temporal depth actually available for this call      */
+    int    prefilter;    /* NLMEANS_PREFILTER_MODE_* bits (nlmeans.c:71-82)      */
+} orc_nlmeans_params_t;
+
+/* Table construction of nlmeans.c:345-358: exptable[128], weight_fact_table, diff_max. */
+void orc_nlmeans_tables(double strength, int patch_size,
+                        float exptable[128], float *weight_fact_table, int *diff_max);
+
+/* Border width used for a plane, nlmeans.c:529. */
+int orc_nlmeans_border(int patch_size);
+
+/* nlmeans_alloc_8 + nlmeans_border_8 (nlmeans_template.c:20-101): copy w x h
+ * (pitch src_stride) into a (w+2b) x (h+2b) plane with mirrored edges. */
+void orc_nlmeans_make_bordered(const uint8_t *src, int w, int h, int src_stride,
+                               int border, uint8_t *dst);
+
+/* nlmeans_prefilter_8 (nlmeans_template.c:103-543) on a bordered plane.
+ * `bordered` is the output of orc_nlmeans_make_bordered; `pre` receives the
+ * prefiltered bordered plane (same size).  Returns 1 when a prefilter ran,
+ * 0 when `filter_type` selects none (then `pre` is a plain copy). */
+int orc_nlmeans_prefilter(const uint8_t *bordered, int w, int h, int border,
+                          int filter_type, uint8_t *pre);
+
+/* nlmeans_plane_8 (nlmeans_template.c:593-717).  frames[f] = bordered planes
+ * (frame 0 = the frame being filtered, f>0 = the following frames);
+ * frames_pre[f] = their prefiltered versions (== frames[f] when prefilter=0). */
+void orc_nlmeans_plane(const uint8_t *const *frames, const uint8_t *const *frames_pre,
+                       int nframes, int w, int h, int border,
+                       const orc_nlmeans_params_t *p,
+                       uint8_t *dst, int dst_stride);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

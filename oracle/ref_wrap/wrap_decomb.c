@@ -1,0 +1,4 @@
+/* Compiles the reference's libhb/decomb.c in place (found through -I$(REF)/libhb),
+ * unmodified, against include/hbhip_libhb.h.  See wrap_common.h. */
+#include "wrap_common.h"
+#include "decomb.c"

@@ -1,0 +1,88 @@
+"""Loaders for the two CHECKERS (tests / smoke / bench cpu_baseline only).
+
+* ``oracle()``  - oracle/liboracle.so, our plain-C restatement.
+* ``ref()``     - oracle/_ref/libhbref.so, the reference's own C compiled in
+  place (present when it was built in a container that has /root/reference;
+  the prebuilt .so travels to the GPU box).  Returns None when absent.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from handbrake_amd import hbrt
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_oracle = None
+_ref = None
+
+
+class NLMeansParams(C.Structure):
+    _fields_ = [("strength", C.c_double), ("origin_tune", C.c_double),
+                ("patch_size", C.c_int), ("range", C.c_int),
+                ("nframes", C.c_int), ("prefilter", C.c_int)]
+
+
+def oracle() -> C.CDLL:
+    global _oracle
+    if _oracle is None:
+        path = os.path.join(ROOT, "oracle", "liboracle.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing - run `make oracle`")
+        _oracle = C.CDLL(path)
+    return _oracle
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        path = os.path.join(ROOT, "oracle", "_ref", "libhbref.so")
+        if not os.path.exists(path):
+            return None
+        hbrt.runtime()
+        _ref = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    return _ref
+
+
+def u8p(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+# ---------------------------------------------------------------- NLMeans
+def orc_nlmeans_plane(planes, strength=6.0, origin_tune=1.0, patch=7, rng=3, prefilter=0):
+    """planes: list of 2-D uint8 arrays (frame 0 = filtered frame, then look-ahead)."""
+    lib = oracle()
+    h, w = planes[0].shape
+    border = lib.orc_nlmeans_border(patch)
+    bw, bh = w + 2 * border, h + 2 * border
+    bordered, pre = [], []
+    for p in planes:
+        p = np.ascontiguousarray(p)
+        b = np.zeros((bh, bw), np.uint8)
+        lib.orc_nlmeans_make_bordered(u8p(p), w, h, p.strides[0], border, u8p(b))
+        q = np.zeros_like(b)
+        lib.orc_nlmeans_prefilter(u8p(b), w, h, border, prefilter, u8p(q))
+        bordered.append(b)
+        pre.append(q)
+    n = len(planes)
+    fr = (C.POINTER(C.c_uint8) * n)(*[u8p(b) for b in bordered])
+    fp = (C.POINTER(C.c_uint8) * n)(*[u8p(b) for b in pre])
+    par = NLMeansParams(strength, origin_tune, patch, rng, n, prefilter)
+    dst = np.zeros((h, w), np.uint8)
+    lib.orc_nlmeans_plane(fr, fp, n, w, h, border, C.byref(par), u8p(dst), w)
+    return dst
+
+
+def ref_nlmeans_plane(settings: str, c: int, planes, force_scalar=False):
+    lib = ref()
+    h, w = planes[0].shape
+    keep = [np.ascontiguousarray(p) for p in planes]
+    ptrs = (C.POINTER(C.c_uint8) * len(keep))(*[u8p(p) for p in keep])
+    dst = np.zeros((h, w), np.uint8)
+    rc = lib.hbref_nlmeans_plane_8(settings.encode(), c, ptrs, len(keep), w, h,
+                                   keep[0].strides[0], u8p(dst), w, int(force_scalar))
+    assert rc == 0
+    return dst
