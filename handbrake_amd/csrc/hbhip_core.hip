@@ -1,0 +1,461 @@
+// hbhip_core.hip — context, stream, event-based per-kernel timing, device
+// picture pool and the generic push/pull half of the C ABI (include/hbhip.h).
+#include "hbhip_internal.h"
+
+#include <new>
+
+// ---------------------------------------------------------------- ctx helpers
+int hbhip_ctx::fail(hipError_t e, const char *what)
+{
+    last_error = std::string(what) + ": " + hipGetErrorString(e);
+    (void)hipGetLastError();
+    if (e == hipErrorOutOfMemory) return HBHIP_ERR_NOMEM;
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice) return HBHIP_ERR_NODEVICE;
+    return HBHIP_ERR_HIP;
+}
+
+hipEvent_t hbhip_ctx::ev_get()
+{
+    if (!ev_pool.empty())
+    {
+        hipEvent_t e = ev_pool.back();
+        ev_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+int hbhip_ctx::prof_name(const char *name)
+{
+    for (size_t i = 0; i < prof_stats.size(); i++)
+        if (prof_stats[i].name == name) return (int)i;
+    hbhip_prof_stat s;
+    s.name = name;
+    prof_stats.push_back(s);
+    return (int)prof_stats.size() - 1;
+}
+
+void hbhip_ctx::prof_begin(const char *name)
+{
+    if (prof_pending.size() >= 8192) prof_resolve();
+    hbhip_prof_pending p;
+    p.name_idx = prof_name(name);
+    p.ev0 = ev_get();
+    p.ev1 = ev_get();
+    if (p.ev0) (void)hipEventRecord(p.ev0, stream);
+    prof_pending.push_back(p);
+}
+
+void hbhip_ctx::prof_end()
+{
+    if (prof_pending.empty()) return;
+    hbhip_prof_pending &p = prof_pending.back();
+    if (p.ev1) (void)hipEventRecord(p.ev1, stream);
+}
+
+void hbhip_ctx::prof_resolve()
+{
+    if (prof_pending.empty()) return;
+    (void)hipStreamSynchronize(stream);
+    for (auto &p : prof_pending)
+    {
+        float ms = 0.f;
+        if (p.ev0 && p.ev1 && hipEventElapsedTime(&ms, p.ev0, p.ev1) == hipSuccess)
+        {
+            prof_stats[p.name_idx].launches++;
+            prof_stats[p.name_idx].total_ms += ms;
+        }
+        if (p.ev0) ev_pool.push_back(p.ev0);
+        if (p.ev1) ev_pool.push_back(p.ev1);
+    }
+    prof_pending.clear();
+}
+
+// ---------------------------------------------------------------- pool
+PicturePool::~PicturePool()
+{
+    for (DevPicture *p : all_)
+    {
+        if (p->base) (void)hipFree(p->base);
+        delete p;
+    }
+}
+
+void PicturePool::configure(hbhip_ctx *ctx, const PicGeometry &g, int pitch_align, int pad_rows)
+{
+    ctx_ = ctx;
+    geo_ = g;
+    pitch_align_ = pitch_align;
+    pad_rows_ = pad_rows;
+}
+
+DevPicture *PicturePool::acquire()
+{
+    if (!free_.empty())
+    {
+        DevPicture *p = free_.back();
+        free_.pop_back();
+        return p;
+    }
+    DevPicture *p = new (std::nothrow) DevPicture();
+    if (!p) return nullptr;
+    size_t off[3], total = 0;
+    for (int c = 0; c < 3; c++)
+    {
+        p->width[c] = geo_.pw[c];
+        p->height[c] = geo_.ph[c];
+        p->pitch[c] = hbhip_align_up(geo_.pw[c] * geo_.bps, pitch_align_);
+        off[c] = total;
+        total += (size_t)p->pitch[c] * (geo_.ph[c] + pad_rows_);
+        total = (total + 255) & ~(size_t)255;
+    }
+    p->bps = geo_.bps;
+    p->bytes = total;
+    if (hipMalloc((void **)&p->base, total) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        delete p;
+        return nullptr;
+    }
+    (void)hipMemsetAsync(p->base, 0, total, ctx_->stream);
+    for (int c = 0; c < 3; c++) p->plane[c] = p->base + off[c];
+    all_.push_back(p);
+    return p;
+}
+
+void PicturePool::release(DevPicture *p)
+{
+    if (p) free_.push_back(p);
+}
+
+// ---------------------------------------------------------------- copies
+int hbhip_copy_h2d(hbhip_ctx *ctx, DevPicture *dst, const hbhip_host_frame *src)
+{
+    for (int c = 0; c < 3; c++)
+    {
+        const size_t row = (size_t)dst->width[c] * dst->bps;
+        if (src->plane[c] == nullptr || src->stride[c] < (int)row) return HBHIP_ERR_ARG;
+        HBHIP_CHECK(ctx, hipMemcpy2DAsync(dst->plane[c], dst->pitch[c], src->plane[c], src->stride[c],
+                                          row, dst->height[c], hipMemcpyHostToDevice, ctx->stream));
+    }
+    return HBHIP_OK;
+}
+
+int hbhip_copy_d2h(hbhip_ctx *ctx, const hbhip_host_frame *dst, const DevPicture *src)
+{
+    for (int c = 0; c < 3; c++)
+    {
+        const size_t row = (size_t)src->width[c] * src->bps;
+        if (dst->plane[c] == nullptr || dst->stride[c] < (int)row) return HBHIP_ERR_ARG;
+        HBHIP_CHECK(ctx, hipMemcpy2DAsync(dst->plane[c], dst->stride[c], src->plane[c], src->pitch[c],
+                                          row, src->height[c], hipMemcpyDeviceToHost, ctx->stream));
+    }
+    return HBHIP_OK;
+}
+
+int hbhip_copy_d2d_in(hbhip_ctx *ctx, DevPicture *dst, const hbhip_dev_frame *src)
+{
+    for (int c = 0; c < 3; c++)
+    {
+        const size_t row = (size_t)dst->width[c] * dst->bps;
+        if (src->plane[c] == nullptr || src->stride[c] < (int)row) return HBHIP_ERR_ARG;
+        HBHIP_CHECK(ctx, hipMemcpy2DAsync(dst->plane[c], dst->pitch[c], src->plane[c], src->stride[c],
+                                          row, dst->height[c], hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    return HBHIP_OK;
+}
+
+int hbhip_copy_d2d_out(hbhip_ctx *ctx, const hbhip_dev_frame *dst, const DevPicture *src)
+{
+    for (int c = 0; c < 3; c++)
+    {
+        const size_t row = (size_t)src->width[c] * src->bps;
+        if (dst->plane[c] == nullptr || dst->stride[c] < (int)row) return HBHIP_ERR_ARG;
+        HBHIP_CHECK(ctx, hipMemcpy2DAsync(dst->plane[c], dst->stride[c], src->plane[c], src->pitch[c],
+                                          row, src->height[c], hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    return HBHIP_OK;
+}
+
+// ---------------------------------------------------------------- C ABI
+extern "C" {
+
+int hbhip_abi_version(void) { return HBHIP_ABI_VERSION; }
+
+int hbhip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+const char *hbhip_strerror(int code)
+{
+    switch (code)
+    {
+        case HBHIP_OK:              return "ok";
+        case HBHIP_AGAIN:           return "no frame ready yet";
+        case HBHIP_ERR_NODEVICE:    return "no usable HIP device";
+        case HBHIP_ERR_HIP:         return "HIP runtime error (see hbhip_ctx_last_error)";
+        case HBHIP_ERR_ARG:         return "invalid argument";
+        case HBHIP_ERR_NOMEM:       return "out of (device) memory";
+        case HBHIP_ERR_UNSUPPORTED: return "settings not supported by the HIP path";
+        case HBHIP_ERR_STATE:       return "call not valid in this state";
+        default:                    return "unknown hbhip error";
+    }
+}
+
+static int ctx_create_common(int device, void *stream, bool adopt, hbhip_ctx **out)
+{
+    if (out == nullptr) return HBHIP_ERR_ARG;
+    *out = nullptr;
+    int n = hbhip_device_count();
+    if (n <= 0 || device < 0 || device >= n) return HBHIP_ERR_NODEVICE;
+    if (hipSetDevice(device) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        return HBHIP_ERR_NODEVICE;
+    }
+    hbhip_ctx *ctx = new (std::nothrow) hbhip_ctx();
+    if (!ctx) return HBHIP_ERR_NOMEM;
+    ctx->device = device;
+    if (adopt)
+    {
+        ctx->stream = (hipStream_t)stream;
+        ctx->own_stream = false;
+    }
+    else if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        delete ctx;
+        return HBHIP_ERR_HIP;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess)
+        snprintf(ctx->dev_name, sizeof(ctx->dev_name), "%s (%s, %d CUs)", prop.name,
+                 prop.gcnArchName, prop.multiProcessorCount);
+    *out = ctx;
+    return HBHIP_OK;
+}
+
+int hbhip_ctx_create(int device, hbhip_ctx **out)
+{
+    return ctx_create_common(device, nullptr, false, out);
+}
+
+int hbhip_ctx_create_on_stream(int device, void *hip_stream, hbhip_ctx **out)
+{
+    return ctx_create_common(device, hip_stream, true, out);
+}
+
+void hbhip_ctx_destroy(hbhip_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &p : ctx->prof_pending)
+    {
+        if (p.ev0) (void)hipEventDestroy(p.ev0);
+        if (p.ev1) (void)hipEventDestroy(p.ev1);
+    }
+    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    for (int i = 0; i < HBHIP_MAX_MARKS; i++)
+        if (ctx->marks[i]) (void)hipEventDestroy(ctx->marks[i]);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int hbhip_ctx_sync(hbhip_ctx *ctx)
+{
+    if (!ctx) return HBHIP_ERR_ARG;
+    HBHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return HBHIP_OK;
+}
+
+const char *hbhip_ctx_last_error(hbhip_ctx *ctx)
+{
+    return ctx ? ctx->last_error.c_str() : "";
+}
+
+int hbhip_ctx_device_name(hbhip_ctx *ctx, char *buf, int len)
+{
+    if (!ctx || !buf || len <= 0) return HBHIP_ERR_ARG;
+    snprintf(buf, len, "%s", ctx->dev_name);
+    return HBHIP_OK;
+}
+
+int hbhip_ctx_profile_enable(hbhip_ctx *ctx, int on)
+{
+    if (!ctx) return HBHIP_ERR_ARG;
+    if (!on) ctx->prof_resolve();
+    ctx->profile = on != 0;
+    return HBHIP_OK;
+}
+
+int hbhip_ctx_profile_reset(hbhip_ctx *ctx)
+{
+    if (!ctx) return HBHIP_ERR_ARG;
+    ctx->prof_resolve();
+    ctx->prof_stats.clear();
+    return HBHIP_OK;
+}
+
+int hbhip_ctx_profile_count(hbhip_ctx *ctx)
+{
+    if (!ctx) return HBHIP_ERR_ARG;
+    ctx->prof_resolve();
+    return (int)ctx->prof_stats.size();
+}
+
+int hbhip_ctx_profile_get(hbhip_ctx *ctx, int idx, char *name, int name_len,
+                          int64_t *launches, double *total_ms)
+{
+    if (!ctx || idx < 0 || idx >= (int)ctx->prof_stats.size()) return HBHIP_ERR_ARG;
+    const hbhip_prof_stat &s = ctx->prof_stats[idx];
+    if (name && name_len > 0) snprintf(name, name_len, "%s", s.name.c_str());
+    if (launches) *launches = s.launches;
+    if (total_ms) *total_ms = s.total_ms;
+    return HBHIP_OK;
+}
+
+int hbhip_ctx_mark(hbhip_ctx *ctx, int slot)
+{
+    if (!ctx || slot < 0 || slot >= HBHIP_MAX_MARKS) return HBHIP_ERR_ARG;
+    if (!ctx->marks[slot]) HBHIP_CHECK(ctx, hipEventCreate(&ctx->marks[slot]));
+    HBHIP_CHECK(ctx, hipEventRecord(ctx->marks[slot], ctx->stream));
+    return HBHIP_OK;
+}
+
+int hbhip_ctx_elapsed_ms(hbhip_ctx *ctx, int a, int b, double *ms)
+{
+    if (!ctx || !ms || a < 0 || b < 0 || a >= HBHIP_MAX_MARKS || b >= HBHIP_MAX_MARKS ||
+        !ctx->marks[a] || !ctx->marks[b])
+        return HBHIP_ERR_ARG;
+    HBHIP_CHECK(ctx, hipEventSynchronize(ctx->marks[b]));
+    float f = 0.f;
+    HBHIP_CHECK(ctx, hipEventElapsedTime(&f, ctx->marks[a], ctx->marks[b]));
+    *ms = f;
+    return HBHIP_OK;
+}
+
+int hbhip_dev_alloc(hbhip_ctx *ctx, size_t bytes, void **out)
+{
+    if (!ctx || !out) return HBHIP_ERR_ARG;
+    HBHIP_CHECK(ctx, hipSetDevice(ctx->device));
+    HBHIP_CHECK(ctx, hipMalloc(out, bytes));
+    return HBHIP_OK;
+}
+
+int hbhip_dev_free(hbhip_ctx *ctx, void *p)
+{
+    if (!ctx) return HBHIP_ERR_ARG;
+    HBHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    HBHIP_CHECK(ctx, hipFree(p));
+    return HBHIP_OK;
+}
+
+int hbhip_dev_upload(hbhip_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (!ctx) return HBHIP_ERR_ARG;
+    HBHIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HBHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return HBHIP_OK;
+}
+
+int hbhip_dev_download(hbhip_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (!ctx) return HBHIP_ERR_ARG;
+    HBHIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HBHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return HBHIP_OK;
+}
+
+// ---- generic filter surface -------------------------------------------------
+int hbhip_filter_push(hbhip_filter *f, const hbhip_host_frame *in, int64_t tag)
+{
+    if (!f || !in) return HBHIP_ERR_ARG;
+    (void)hipSetDevice(f->ctx->device);
+    DevPicture *pic = f->acquire_input();
+    if (!pic) return HBHIP_ERR_NOMEM;
+    pic->tag = tag;
+    int rc = hbhip_copy_h2d(f->ctx, pic, in);
+    if (rc != HBHIP_OK) return rc;
+    // The caller may free or reuse its (pageable) planes as soon as we return
+    // (filter_loop closes buf_in, work.c:2566-2569), so the upload must have
+    // consumed them.
+    if (hipStreamSynchronize(f->ctx->stream) != hipSuccess)
+        return f->ctx->fail(hipGetLastError(), "hipStreamSynchronize(push)");
+    return f->submit(pic);
+}
+
+int hbhip_filter_push_dev(hbhip_filter *f, const hbhip_dev_frame *in, int64_t tag)
+{
+    if (!f || !in) return HBHIP_ERR_ARG;
+    (void)hipSetDevice(f->ctx->device);
+    DevPicture *pic = f->acquire_input();
+    if (!pic) return HBHIP_ERR_NOMEM;
+    pic->tag = tag;
+    int rc = hbhip_copy_d2d_in(f->ctx, pic, in);
+    if (rc != HBHIP_OK) return rc;
+    return f->submit(pic);
+}
+
+int hbhip_filter_pull(hbhip_filter *f, const hbhip_host_frame *out, int64_t *tag)
+{
+    if (!f || !out) return HBHIP_ERR_ARG;
+    DevPicture *pic = f->pop_output();
+    if (!pic) return HBHIP_AGAIN;
+    if (tag) *tag = pic->tag;
+    int rc = hbhip_copy_d2h(f->ctx, out, pic);
+    if (rc == HBHIP_OK && hipStreamSynchronize(f->ctx->stream) != hipSuccess)
+        rc = f->ctx->fail(hipGetLastError(), "hipStreamSynchronize(pull)");
+    f->recycle_output(pic);
+    return rc;
+}
+
+int hbhip_filter_pull_dev(hbhip_filter *f, const hbhip_dev_frame *out, int64_t *tag)
+{
+    if (!f || !out) return HBHIP_ERR_ARG;
+    DevPicture *pic = f->pop_output();
+    if (!pic) return HBHIP_AGAIN;
+    if (tag) *tag = pic->tag;
+    int rc = hbhip_copy_d2d_out(f->ctx, out, pic);
+    f->recycle_output(pic);
+    return rc;
+}
+
+int hbhip_filter_flush(hbhip_filter *f)
+{
+    if (!f) return HBHIP_ERR_ARG;
+    (void)hipSetDevice(f->ctx->device);
+    return f->flush();
+}
+
+int hbhip_filter_pending(hbhip_filter *f)
+{
+    return f ? f->pending() : 0;
+}
+
+void hbhip_filter_destroy(hbhip_filter *f)
+{
+    if (!f) return;
+    (void)hipSetDevice(f->ctx->device);
+    (void)hipStreamSynchronize(f->ctx->stream);
+    delete f;
+}
+
+int hbhip_filter_out_geometry(hbhip_filter *f, int *width, int *height)
+{
+    if (!f) return HBHIP_ERR_ARG;
+    if (width) *width = f->out_geo.width;
+    if (height) *height = f->out_geo.height;
+    return HBHIP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,142 @@
+// hbhip_internal.h — shared plumbing of libhbhip.so (context, stream, launch
+// bookkeeping, device frame pool, filter base class).  Not part of the ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "hbhip.h"
+
+#define HBHIP_MAX_MARKS 8
+
+struct hbhip_prof_pending
+{
+    int        name_idx;
+    hipEvent_t ev0, ev1;
+};
+
+struct hbhip_prof_stat
+{
+    std::string name;
+    int64_t     launches = 0;
+    double      total_ms = 0.0;
+};
+
+struct hbhip_ctx
+{
+    int         device = 0;
+    hipStream_t stream = nullptr;
+    bool        own_stream = true;
+    std::string last_error;
+    char        dev_name[256] = {0};
+
+    bool                            profile = false;
+    std::vector<hbhip_prof_stat>    prof_stats;
+    std::vector<hbhip_prof_pending> prof_pending;
+    std::vector<hipEvent_t>         ev_pool;
+    hipEvent_t                      marks[HBHIP_MAX_MARKS] = {};
+
+    int  fail(hipError_t e, const char *what);
+    int  prof_name(const char *name);
+    void prof_begin(const char *name);
+    void prof_end();
+    void prof_resolve();
+    hipEvent_t ev_get();
+};
+
+#define HBHIP_CHECK(ctx, expr)                                                  \
+    do {                                                                        \
+        hipError_t _e = (expr);                                                 \
+        if (_e != hipSuccess) return (ctx)->fail(_e, #expr);                    \
+    } while (0)
+
+// Launch a kernel on the context's stream; when profiling is on the launch is
+// bracketed by two events whose delta is accumulated under `name`.
+#define HBHIP_LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                \
+    do {                                                                        \
+        if ((ctx)->profile) (ctx)->prof_begin(name);                            \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__); \
+        if ((ctx)->profile) (ctx)->prof_end();                                  \
+    } while (0)
+
+static inline int hbhip_align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+// One planar picture in HBM (a single allocation, planes 256-byte aligned).
+struct DevPicture
+{
+    uint8_t *base = nullptr;
+    uint8_t *plane[3] = {nullptr, nullptr, nullptr};
+    int      pitch[3] = {0, 0, 0};
+    int      width[3] = {0, 0, 0};   // in pixels
+    int      height[3] = {0, 0, 0};
+    int      bps = 1;
+    int64_t  tag = 0;
+    size_t   bytes = 0;
+};
+
+// Geometry of a planar YUV picture.
+struct PicGeometry
+{
+    int width = 0, height = 0, depth = 8, bps = 1;
+    int log2_cw = 1, log2_ch = 1;
+    int pw[3], ph[3];
+    void set(int w, int h, int d, int lcw, int lch)
+    {
+        width = w; height = h; depth = d; bps = d > 8 ? 2 : 1;
+        log2_cw = lcw; log2_ch = lch;
+        pw[0] = w; ph[0] = h;
+        pw[1] = pw[2] = -((-w) >> lcw);
+        ph[1] = ph[2] = -((-h) >> lch);
+    }
+};
+
+// Pool of equally-shaped device pictures; reuse is stream-ordered by design
+// (every producer/consumer of a picture runs on the context's single stream).
+class PicturePool
+{
+public:
+    PicturePool() = default;
+    ~PicturePool();
+    void configure(hbhip_ctx *ctx, const PicGeometry &g, int pitch_align = 256, int pad_rows = 0);
+    DevPicture *acquire();            // nullptr on allocation failure
+    void        release(DevPicture *p);
+    const PicGeometry &geometry() const { return geo_; }
+private:
+    hbhip_ctx *ctx_ = nullptr;
+    PicGeometry geo_;
+    int pitch_align_ = 256;
+    int pad_rows_ = 0;
+    std::vector<DevPicture *> all_;
+    std::vector<DevPicture *> free_;
+};
+
+// Copy helpers (2-D, any pitch on either side), all on ctx->stream.
+int hbhip_copy_h2d(hbhip_ctx *ctx, DevPicture *dst, const hbhip_host_frame *src);
+int hbhip_copy_d2h(hbhip_ctx *ctx, const hbhip_host_frame *dst, const DevPicture *src);
+int hbhip_copy_d2d_in(hbhip_ctx *ctx, DevPicture *dst, const hbhip_dev_frame *src);
+int hbhip_copy_d2d_out(hbhip_ctx *ctx, const hbhip_dev_frame *dst, const DevPicture *src);
+
+// Base class of every filter instance behind the C ABI.
+struct hbhip_filter
+{
+    hbhip_ctx  *ctx = nullptr;
+    PicGeometry in_geo, out_geo;
+    explicit hbhip_filter(hbhip_ctx *c) : ctx(c) {}
+    virtual ~hbhip_filter() {}
+
+    // Input side: the subclass gets a device picture already filled.
+    virtual DevPicture *acquire_input() = 0;
+    virtual int submit(DevPicture *pic) = 0;       // takes ownership
+    virtual int flush() = 0;
+    // Output side.
+    virtual int pending() = 0;
+    virtual DevPicture *pop_output() = 0;          // nullptr when none
+    virtual void recycle_output(DevPicture *pic) = 0;
+};

@@ -1,0 +1,527 @@
+// nlmeans.hip — Non-local-means denoise for gfx950.
+//
+// Replaces the CPU hot loop of libhb/templates/nlmeans_template.c:545-717
+// (build_integral_* + nlmeans_plane_8) and the bordered-copy of :20-101.
+//
+// Algorithm per output pixel (identical integers / identical float sequence to
+// the reference, SURVEY §6b hazards 1-8):
+//   for f in frames (f=0 is the frame itself, f>0 the FOLLOWING frames)
+//     for dy, dx in [-r/2, r/2]^2                      (nlmeans_template.c:629-640)
+//       origin (f=0,0,0): sums += origin_tune (in double)           (:644-655)
+//       diff  = sum over the n x n patch of (src - cmp(+dx,+dy))^2   (:573-574,:682)
+//       if diff < diff_max: w = exptable[(int)(diff * wft)]          (:685-690)
+//            weight_sum += w ; pixel_sum += w * cmp(+dx,+dy)         (:692-693)
+//   out = (u8)(pixel_sum / weight_sum), 0 -> source pixel            (:710-711)
+//
+// GPU mapping (no integral image): one workgroup owns a 128 x 64 tile.  The
+// source tile (+patch halo) and, per temporal frame, the compare tile (+patch
+// +search halo) are staged in LDS with the reference's mirrored borders applied
+// by index reflection (nlmeans_template.c:29-41), so no bordered copy of the
+// frame is ever materialised in HBM.  Each thread owns 4 adjacent columns x 8
+// rows: per displacement it walks 8+n-1 rows, forms the squared differences of
+// its 4+n-1 byte window, reduces them to 4 horizontal n-sums, and keeps a
+// vertical sliding n-row sum in registers; weight/pixel accumulators for its 32
+// pixels live in registers across all displacements and frames.  HBM traffic is
+// therefore ~(nframes + 1) bytes per pixel; the kernel is VALU-bound.
+#include "hbhip_internal.h"
+
+#include <algorithm>
+
+namespace {
+
+constexpr int PX = 4;            // pixels per thread along x (one dword)
+constexpr int RY = 8;            // rows per thread
+constexpr int TXN = 32;          // threads along x
+constexpr int TYN = 8;           // threads along y
+constexpr int TW = TXN * PX;     // 128
+constexpr int TH = TYN * RY;     // 64
+constexpr int NLM_BORDER = 16;   // nlmeans.c:529 for every patch size <= 29
+
+struct NlmJob
+{
+    const uint8_t *frame[HBHIP_NLMEANS_FRAMES_MAX];
+    uint8_t       *dst;
+    const float   *exptable;
+    double         origin_tune;
+    float          wft;
+    int            diff_max;
+    int            w, h, pitch, dst_pitch;
+    int            nframes, r_half;
+    int            tiles_x, tile_start;
+};
+
+struct __attribute__((packed, aligned(1))) u32_unaligned { uint32_t v; };
+
+// mirrored coordinate (edge pixel repeated), then clamped so far-out halo
+// reads of tiny planes stay inside the allocation.
+__device__ __forceinline__ int reflect(int x, int n)
+{
+    x = x < 0 ? -1 - x : x;
+    x = x >= n ? 2 * n - 1 - x : x;
+    return min(max(x, 0), n - 1);
+}
+
+// Stage a (rows x dwords*4) byte window of `plane`, whose top-left pixel is
+// (x0, y0), into LDS as packed dwords.
+__device__ __forceinline__ void load_tile(uint32_t *lds, int dwords, int rows,
+                                          const uint8_t *__restrict__ plane, int pitch,
+                                          int w, int h, int x0, int y0)
+{
+    const int total = dwords * rows;
+    for (int i = threadIdx.x; i < total; i += TXN * TYN)
+    {
+        const int r = i / dwords;
+        const int c = i - r * dwords;
+        const int y = reflect(y0 + r, h);
+        const int x = x0 + 4 * c;
+        const uint8_t *row = plane + (size_t)y * pitch;
+        uint32_t v;
+        if (x >= 0 && x + 3 < w)
+        {
+            v = reinterpret_cast<const u32_unaligned *>(row + x)->v;
+        }
+        else
+        {
+            v = (uint32_t)row[reflect(x, w)] | ((uint32_t)row[reflect(x + 1, w)] << 8) |
+                ((uint32_t)row[reflect(x + 2, w)] << 16) | ((uint32_t)row[reflect(x + 3, w)] << 24);
+        }
+        lds[i] = v;
+    }
+}
+
+__device__ __forceinline__ uint32_t byte_of(uint32_t v, int k) { return (v >> (8 * k)) & 0xffu; }
+
+template <int N>
+__global__ __launch_bounds__(TXN * TYN) void nlmeans_plane_kernel(const NlmJob *__restrict__ jobs, int njobs,
+                                                                  int cmp_dwords, int cmp_rows)
+{
+    constexpr int NH = N / 2;
+    constexpr int W = PX + 2 * NH;          // bytes of a thread's row window
+    constexpr int ND = (W + 3) / 4;         // dwords covering it when aligned
+    constexpr int SPD = TXN + ND;           // src tile pitch (dwords)
+    constexpr int SROWS = TH + 2 * NH;
+    constexpr int ROWS = RY + N - 1;        // rows a thread walks per displacement
+
+    extern __shared__ uint32_t smem[];
+    uint32_t *s_src = smem;
+    uint32_t *s_cmp = smem + SPD * SROWS;
+    float *s_exp = reinterpret_cast<float *>(s_cmp + cmp_dwords * cmp_rows);
+
+    // which (frame, plane) job does this tile belong to?
+    int j = 0;
+    while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].tile_start) j++;
+    const NlmJob &job = jobs[j];
+    const int tile = blockIdx.x - job.tile_start;
+    const int tile_y = tile / job.tiles_x;
+    const int tile_x = tile - tile_y * job.tiles_x;
+    const int tx0 = tile_x * TW, ty0 = tile_y * TH;
+    const int w = job.w, h = job.h, pitch = job.pitch;
+    const int RH = job.r_half;
+    const int HALO = NH + RH;
+    const int CPD = cmp_dwords;
+
+    const int tx = threadIdx.x & (TXN - 1);
+    const int ty = threadIdx.x / TXN;
+
+    if (threadIdx.x < 128) s_exp[threadIdx.x] = job.exptable[threadIdx.x];
+    load_tile(s_src, SPD, SROWS, job.frame[0], pitch, w, h, tx0 - NH, ty0 - NH);
+
+    float aw[RY][PX], ap[RY][PX];
+    uint32_t srcpix[RY];
+#pragma unroll
+    for (int o = 0; o < RY; o++)
+    {
+        srcpix[o] = 0;
+#pragma unroll
+        for (int p = 0; p < PX; p++) { aw[o][p] = 0.f; ap[o][p] = 0.f; }
+    }
+
+    const float wft = job.wft;
+    const int diff_max = job.diff_max;
+    const double origin_tune = job.origin_tune;
+
+    for (int f = 0; f < job.nframes; f++)
+    {
+        __syncthreads();   // everyone is done with the previous compare tile
+        load_tile(s_cmp, CPD, cmp_rows, job.frame[f], pitch, w, h, tx0 - HALO, ty0 - HALO);
+        __syncthreads();
+
+        if (f == 0)
+        {
+            // centre pixels of the frame being filtered (origin term + zero fallback)
+            const int s = RH + NH;
+#pragma unroll
+            for (int o = 0; o < RY; o++)
+            {
+                const uint32_t *c = s_cmp + (ty * RY + o + HALO) * CPD + tx + (s >> 2);
+                srcpix[o] = __builtin_amdgcn_alignbyte(c[1], c[0], s & 3);
+            }
+        }
+
+        for (int dy = -RH; dy <= RH; dy++)
+        {
+            for (int dx = -RH; dx <= RH; dx++)
+            {
+                if (f == 0 && dx == 0 && dy == 0)
+                {
+#pragma unroll
+                    for (int o = 0; o < RY; o++)
+#pragma unroll
+                        for (int p = 0; p < PX; p++)
+                        {
+                            aw[o][p] = (float)((double)aw[o][p] + origin_tune);
+                            ap[o][p] = (float)((double)ap[o][p] + origin_tune * (double)(int)byte_of(srcpix[o], p));
+                        }
+                    continue;
+                }
+
+                const int s = dx + RH;                       // 0 .. 2RH, uniform
+                const int sh = s & 3;
+                const uint32_t *srow = s_src + (ty * RY) * SPD + tx;
+                const uint32_t *crow = s_cmp + (ty * RY + dy + RH) * CPD + tx + (s >> 2);
+                const int sp = s + NH;                       // byte offset of the centre pixels
+                const uint32_t *prow = s_cmp + (ty * RY + dy + RH + NH) * CPD + tx + (sp >> 2);
+                const int psh = sp & 3;
+
+                uint32_t ring[N][PX];
+                uint32_t v[PX];
+#pragma unroll
+                for (int p = 0; p < PX; p++) v[p] = 0;
+
+#pragma unroll
+                for (int i = 0; i < ROWS; i++)
+                {
+                    // squared differences over this row's window
+                    uint32_t a[ND], b[ND + 1];
+#pragma unroll
+                    for (int k = 0; k < ND; k++) a[k] = srow[i * SPD + k];
+#pragma unroll
+                    for (int k = 0; k <= ND; k++) b[k] = crow[i * CPD + k];
+                    uint32_t D[W];
+#pragma unroll
+                    for (int q = 0; q < W; q++)
+                    {
+                        const uint32_t bw = __builtin_amdgcn_alignbyte(b[q / 4 + 1], b[q / 4], sh);
+                        const int d = (int)byte_of(a[q / 4], q & 3) - (int)byte_of(bw, q & 3);
+                        D[q] = (uint32_t)(d * d);
+                    }
+                    // horizontal n-sums for the 4 pixels
+                    uint32_t hs[PX];
+                    if (N >= PX)
+                    {
+                        uint32_t core = 0;
+#pragma unroll
+                        for (int q = PX - 1; q < N; q++) core += D[q];
+#pragma unroll
+                        for (int p = 0; p < PX; p++)
+                        {
+                            uint32_t t = core;
+#pragma unroll
+                            for (int q = p; q < PX - 1; q++) t += D[q];
+#pragma unroll
+                            for (int q = N; q < N + p; q++) t += D[q];
+                            hs[p] = t;
+                        }
+                    }
+                    else
+                    {
+#pragma unroll
+                        for (int p = 0; p < PX; p++)
+                        {
+                            uint32_t t = 0;
+#pragma unroll
+                            for (int q = p; q < p + N; q++) t += D[q];
+                            hs[p] = t;
+                        }
+                    }
+                    // vertical sliding window
+#pragma unroll
+                    for (int p = 0; p < PX; p++)
+                    {
+                        v[p] += hs[p];
+                        if (i >= N) v[p] -= ring[i % N][p];
+                        ring[i % N][p] = hs[p];
+                    }
+                    if (i >= N - 1)
+                    {
+                        const int o = i - (N - 1);
+                        const uint32_t pix = __builtin_amdgcn_alignbyte(prow[o * CPD + 1], prow[o * CPD], psh);
+#pragma unroll
+                        for (int p = 0; p < PX; p++)
+                        {
+                            const int diff = (int)v[p];
+                            int idx = (int)((float)diff * wft);
+                            idx = diff < diff_max ? idx : 127;
+                            idx = min(idx, 127);
+                            const float wgt = s_exp[idx];
+                            const float pv = (float)(int)byte_of(pix, p);
+                            aw[o][p] += wgt;
+                            ap[o][p] += wgt * pv;
+                        }
+                    }
+                    // keep the scheduler from hoisting every row's LDS reads to the
+                    // top of the unrolled walk (that costs ~250 VGPRs + spills)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+
+    // normalise + store
+    const int x = tx0 + tx * PX;
+    if (x >= w) return;
+#pragma unroll
+    for (int o = 0; o < RY; o++)
+    {
+        const int y = ty0 + ty * RY + o;
+        if (y >= h) break;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int p = 0; p < PX; p++)
+        {
+            const float q = ap[o][p] / aw[o][p];
+            uint32_t r = (uint32_t)(int)q & 0xffu;
+            if (r == 0) r = byte_of(srcpix[o], p);
+            packed |= r << (8 * p);
+        }
+        uint8_t *out = job.dst + (size_t)y * job.dst_pitch + x;
+        if (x + 3 < w)
+        {
+            *reinterpret_cast<uint32_t *>(out) = packed;
+        }
+        else
+        {
+            for (int p = 0; p < PX && x + p < w; p++) out[p] = (uint8_t)(packed >> (8 * p));
+        }
+    }
+}
+
+__global__ void copy_plane_kernel(uint8_t *dst, int dst_pitch, const uint8_t *src, int src_pitch,
+                                  int row_bytes, int rows)
+{
+    const int x = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int y = blockIdx.y;
+    if (y >= rows || x >= row_bytes) return;
+    const uint8_t *s = src + (size_t)y * src_pitch + x;
+    uint8_t *d = dst + (size_t)y * dst_pitch + x;
+    if (x + 3 < row_bytes)
+        *reinterpret_cast<uint32_t *>(d) = *reinterpret_cast<const uint32_t *>(s);
+    else
+        for (int i = 0; x + i < row_bytes; i++) d[i] = s[i];
+}
+
+// ------------------------------------------------------------------- host side
+class NlmFilter : public hbhip_filter
+{
+public:
+    NlmFilter(hbhip_ctx *c, const hbhip_nlmeans_params &p) : hbhip_filter(c), par(p) {}
+    ~NlmFilter() override
+    {
+        if (d_exp) (void)hipFree(d_exp);
+        if (d_jobs) (void)hipFree(d_jobs);
+        if (h_jobs) (void)hipHostFree(h_jobs);
+        for (int i = 0; i < NTABLES; i++)
+            if (table_ev[i]) (void)hipEventDestroy(table_ev[i]);
+    }
+
+    int setup(int width, int height, int depth, int lcw, int lch)
+    {
+        in_geo.set(width, height, depth, lcw, lch);
+        out_geo = in_geo;
+        pool.configure(ctx, in_geo);
+        max_frames = 1;
+        for (int c = 0; c < 3; c++)
+        {
+            max_frames = std::max(max_frames, par.nframes[c]);
+            if (par.strength[c] == 0) continue;
+            const int n = par.patch_size[c];
+            if (n != 3 && n != 5 && n != 7 && n != 9) return HBHIP_ERR_UNSUPPORTED;
+            if (n / 2 + par.range[c] / 2 > NLM_BORDER) return HBHIP_ERR_UNSUPPORTED;
+            if (par.prefilter[c] != 0) return HBHIP_ERR_UNSUPPORTED;
+            if (par.nframes[c] < 1 || par.nframes[c] > HBHIP_NLMEANS_FRAMES_MAX) return HBHIP_ERR_ARG;
+            if (in_geo.pw[c] < NLM_BORDER || in_geo.ph[c] < NLM_BORDER) return HBHIP_ERR_UNSUPPORTED;
+        }
+        HBHIP_CHECK(ctx, hipMalloc((void **)&d_exp, sizeof(float) * 3 * 128));
+        HBHIP_CHECK(ctx, hipMemcpyAsync(d_exp, par.exptable, sizeof(float) * 3 * 128,
+                                        hipMemcpyHostToDevice, ctx->stream));
+        HBHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        return HBHIP_OK;
+    }
+
+    DevPicture *acquire_input() override { return pool.acquire(); }
+
+    int submit(DevPicture *pic) override
+    {
+        in.push_back(pic);
+        return schedule(false);
+    }
+
+    int flush() override { return schedule(true); }
+    int pending() override { return (int)out.size(); }
+
+    DevPicture *pop_output() override
+    {
+        if (out.empty()) return nullptr;
+        DevPicture *p = out.front();
+        out.pop_front();
+        return p;
+    }
+    void recycle_output(DevPicture *p) override { pool.release(p); }
+
+    int batch = 1;
+
+private:
+    int ensure_jobs(int n)
+    {
+        if (n <= jobs_cap) return HBHIP_OK;
+        if (d_jobs) (void)hipFree(d_jobs);
+        if (h_jobs) (void)hipHostFree(h_jobs);
+        d_jobs = nullptr; h_jobs = nullptr; jobs_cap = 0;
+        HBHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        // a ring of job tables; a slot is rewritten only after the upload that
+        // last read it has completed (event per slot)
+        HBHIP_CHECK(ctx, hipMalloc((void **)&d_jobs, sizeof(NlmJob) * n * NTABLES));
+        HBHIP_CHECK(ctx, hipHostMalloc((void **)&h_jobs, sizeof(NlmJob) * n * NTABLES, hipHostMallocDefault));
+        for (int i = 0; i < NTABLES; i++)
+        {
+            if (!table_ev[i]) HBHIP_CHECK(ctx, hipEventCreateWithFlags(&table_ev[i], hipEventDisableTiming));
+            table_used[i] = false;
+        }
+        jobs_cap = n;
+        return HBHIP_OK;
+    }
+
+    // Filter as many queued frames as are ready (all of them when draining).
+    int schedule(bool draining)
+    {
+        int ready = draining ? (int)in.size() : (int)in.size() - (max_frames - 1);
+        if (ready <= 0) return HBHIP_OK;
+        if (!draining && ready < batch) return HBHIP_OK;
+
+        std::vector<DevPicture *> outs(ready, nullptr);
+        for (int t = 0; t < ready; t++)
+        {
+            outs[t] = pool.acquire();
+            if (!outs[t]) return HBHIP_ERR_NOMEM;
+            outs[t]->tag = in[t]->tag;
+        }
+
+        int rc = ensure_jobs(ready * 3);
+        if (rc != HBHIP_OK) return rc;
+
+        // group jobs by patch size (one launch per distinct n)
+        for (int n : {3, 5, 7, 9})
+        {
+            bool any = false;
+            for (int c = 0; c < 3; c++) any |= (par.strength[c] != 0 && par.patch_size[c] == n);
+            if (!any) continue;
+            table = (table + 1) % NTABLES;
+            if (table_used[table]) HBHIP_CHECK(ctx, hipEventSynchronize(table_ev[table]));
+            NlmJob *hj = h_jobs + (size_t)table * jobs_cap;
+            NlmJob *dj = d_jobs + (size_t)table * jobs_cap;
+            int nj = 0, tiles = 0, max_rh = 0;
+            for (int t = 0; t < ready; t++)
+                for (int c = 0; c < 3; c++)
+                {
+                    if (par.strength[c] == 0 || par.patch_size[c] != n) continue;
+                    NlmJob &jb = hj[nj++];
+                    int avail = (int)in.size() - t;
+                    jb.nframes = std::min(par.nframes[c], avail);
+                    for (int f = 0; f < jb.nframes; f++) jb.frame[f] = in[t + f]->plane[c];
+                    jb.dst = outs[t]->plane[c];
+                    jb.exptable = d_exp + 128 * c;
+                    jb.origin_tune = par.origin_tune[c];
+                    jb.wft = par.weight_fact_table[c];
+                    jb.diff_max = par.diff_max[c];
+                    jb.w = in_geo.pw[c];
+                    jb.h = in_geo.ph[c];
+                    jb.pitch = in[t]->pitch[c];
+                    jb.dst_pitch = outs[t]->pitch[c];
+                    jb.r_half = (par.range[c] - 1) / 2;
+                    jb.tiles_x = (jb.w + TW - 1) / TW;
+                    jb.tile_start = tiles;
+                    tiles += jb.tiles_x * ((jb.h + TH - 1) / TH);
+                    max_rh = std::max(max_rh, jb.r_half);
+                }
+            if (nj == 0) continue;
+            HBHIP_CHECK(ctx, hipMemcpyAsync(dj, hj, sizeof(NlmJob) * nj, hipMemcpyHostToDevice, ctx->stream));
+            HBHIP_CHECK(ctx, hipEventRecord(table_ev[table], ctx->stream));
+            table_used[table] = true;
+            const int nh = n / 2, W = PX + 2 * nh, ND = (W + 3) / 4;
+            const int cmp_dwords = TXN + ND + (2 * max_rh) / 4 + 2;
+            const int cmp_rows = TH + 2 * (nh + max_rh);
+            const size_t shmem = sizeof(uint32_t) * ((TXN + ND) * (TH + 2 * nh) + cmp_dwords * cmp_rows) + 512;
+            dim3 grid(tiles), block(TXN * TYN);
+            switch (n)
+            {
+                case 3: HBHIP_LAUNCH(ctx, "nlmeans_plane_n3", nlmeans_plane_kernel<3>, grid, block, shmem, dj, nj, cmp_dwords, cmp_rows); break;
+                case 5: HBHIP_LAUNCH(ctx, "nlmeans_plane_n5", nlmeans_plane_kernel<5>, grid, block, shmem, dj, nj, cmp_dwords, cmp_rows); break;
+                case 7: HBHIP_LAUNCH(ctx, "nlmeans_plane_n7", nlmeans_plane_kernel<7>, grid, block, shmem, dj, nj, cmp_dwords, cmp_rows); break;
+                case 9: HBHIP_LAUNCH(ctx, "nlmeans_plane_n9", nlmeans_plane_kernel<9>, grid, block, shmem, dj, nj, cmp_dwords, cmp_rows); break;
+            }
+            HBHIP_CHECK(ctx, hipGetLastError());
+        }
+
+        // strength == 0 planes are passed through (nlmeans.c:493-499)
+        for (int t = 0; t < ready; t++)
+            for (int c = 0; c < 3; c++)
+                if (par.strength[c] == 0)
+                {
+                    const int row = in_geo.pw[c] * in_geo.bps;
+                    dim3 grid((row / 4 + 255) / 256 + 1, in_geo.ph[c]);
+                    HBHIP_LAUNCH(ctx, "nlmeans_copy_plane", copy_plane_kernel, grid, dim3(256), 0,
+                                 outs[t]->plane[c], outs[t]->pitch[c], (const uint8_t *)in[t]->plane[c],
+                                 in[t]->pitch[c], row, in_geo.ph[c]);
+                }
+
+        for (int t = 0; t < ready; t++)
+        {
+            out.push_back(outs[t]);
+            pool.release(in.front());   // stream-ordered reuse
+            in.pop_front();
+        }
+        return HBHIP_OK;
+    }
+
+    hbhip_nlmeans_params par;
+    PicturePool pool;
+    std::deque<DevPicture *> in, out;
+    int max_frames = 1;
+    float *d_exp = nullptr;
+    NlmJob *d_jobs = nullptr, *h_jobs = nullptr;
+    int jobs_cap = 0, table = 0;
+    static constexpr int NTABLES = 8;
+    hipEvent_t table_ev[NTABLES] = {};
+    bool table_used[NTABLES] = {};
+};
+
+} // namespace
+
+extern "C" int hbhip_nlmeans_create(hbhip_ctx *ctx, const hbhip_nlmeans_params *p,
+                                    int width, int height, int depth,
+                                    int log2_chroma_w, int log2_chroma_h, hbhip_filter **out)
+{
+    if (!ctx || !p || !out) return HBHIP_ERR_ARG;
+    *out = nullptr;
+    if (depth != 8) return HBHIP_ERR_UNSUPPORTED;
+    if (width < 1 || height < 1) return HBHIP_ERR_ARG;
+    (void)hipSetDevice(ctx->device);
+    NlmFilter *f = new (std::nothrow) NlmFilter(ctx, *p);
+    if (!f) return HBHIP_ERR_NOMEM;
+    int rc = f->setup(width, height, depth, log2_chroma_w, log2_chroma_h);
+    if (rc != HBHIP_OK)
+    {
+        delete f;
+        return rc;
+    }
+    *out = f;
+    return HBHIP_OK;
+}
+
+extern "C" int hbhip_nlmeans_set_batch(hbhip_filter *f, int frames)
+{
+    NlmFilter *n = dynamic_cast<NlmFilter *>(f);
+    if (!n || frames < 1) return HBHIP_ERR_ARG;
+    n->batch = frames;
+    return HBHIP_OK;
+}

@@ -1,0 +1,225 @@
+"""ctypes binding of the product C ABI (include/hbhip.h -> libhbhip.so) and of
+the HIP filter objects (libhbhip_filters.so).  Fails loudly when the native
+libraries are missing - there is no Python/CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import hbrt
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+HBHIP_OK, HBHIP_AGAIN = 0, 1
+
+#: every entry point include/hbhip.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "hbhip_abi_version", "hbhip_device_count", "hbhip_strerror", "hbhip_ctx_create",
+    "hbhip_ctx_create_on_stream", "hbhip_ctx_destroy", "hbhip_ctx_sync", "hbhip_ctx_last_error",
+    "hbhip_ctx_device_name", "hbhip_ctx_profile_enable", "hbhip_ctx_profile_reset",
+    "hbhip_ctx_profile_count", "hbhip_ctx_profile_get", "hbhip_ctx_mark", "hbhip_ctx_elapsed_ms",
+    "hbhip_dev_alloc", "hbhip_dev_free", "hbhip_dev_upload", "hbhip_dev_download",
+    "hbhip_filter_push", "hbhip_filter_push_dev", "hbhip_filter_pull", "hbhip_filter_pull_dev",
+    "hbhip_filter_flush", "hbhip_filter_pending", "hbhip_filter_destroy",
+    "hbhip_filter_out_geometry", "hbhip_nlmeans_create", "hbhip_nlmeans_set_batch",
+]
+
+
+class HostFrame(C.Structure):
+    _fields_ = [("plane", C.c_void_p * 3), ("stride", C.c_int * 3)]
+
+
+class DevFrame(C.Structure):
+    _fields_ = [("plane", C.c_void_p * 3), ("stride", C.c_int * 3)]
+
+
+class NLMeansParams(C.Structure):
+    _fields_ = [("strength", C.c_double * 3), ("origin_tune", C.c_double * 3),
+                ("patch_size", C.c_int * 3), ("range", C.c_int * 3),
+                ("nframes", C.c_int * 3), ("prefilter", C.c_int * 3),
+                ("exptable", (C.c_float * 128) * 3), ("weight_fact_table", C.c_float * 3),
+                ("diff_max", C.c_int * 3)]
+
+
+_lib = None
+_flt = None
+
+
+def lib() -> C.CDLL:
+    """libhbhip.so (HIP kernels + C ABI)."""
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "libhbhip.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: the HIP extension is not built "
+                               "(run __graft_entry__.build() / make)")
+        L = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        L.hbhip_strerror.restype = C.c_char_p
+        L.hbhip_strerror.argtypes = [C.c_int]
+        L.hbhip_ctx_last_error.restype = C.c_char_p
+        L.hbhip_ctx_last_error.argtypes = [C.c_void_p]
+        L.hbhip_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.hbhip_ctx_create_on_stream.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.hbhip_ctx_destroy.argtypes = [C.c_void_p]
+        L.hbhip_ctx_destroy.restype = None
+        L.hbhip_ctx_sync.argtypes = [C.c_void_p]
+        L.hbhip_ctx_device_name.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        L.hbhip_ctx_profile_enable.argtypes = [C.c_void_p, C.c_int]
+        L.hbhip_ctx_profile_reset.argtypes = [C.c_void_p]
+        L.hbhip_ctx_profile_count.argtypes = [C.c_void_p]
+        L.hbhip_ctx_profile_get.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int,
+                                            C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+        L.hbhip_ctx_mark.argtypes = [C.c_void_p, C.c_int]
+        L.hbhip_ctx_elapsed_ms.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        L.hbhip_dev_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.hbhip_dev_free.argtypes = [C.c_void_p, C.c_void_p]
+        L.hbhip_dev_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.hbhip_dev_download.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.hbhip_filter_push.argtypes = [C.c_void_p, C.POINTER(HostFrame), C.c_int64]
+        L.hbhip_filter_push_dev.argtypes = [C.c_void_p, C.POINTER(DevFrame), C.c_int64]
+        L.hbhip_filter_pull.argtypes = [C.c_void_p, C.POINTER(HostFrame), C.POINTER(C.c_int64)]
+        L.hbhip_filter_pull_dev.argtypes = [C.c_void_p, C.POINTER(DevFrame), C.POINTER(C.c_int64)]
+        L.hbhip_filter_flush.argtypes = [C.c_void_p]
+        L.hbhip_filter_pending.argtypes = [C.c_void_p]
+        L.hbhip_filter_destroy.argtypes = [C.c_void_p]
+        L.hbhip_filter_destroy.restype = None
+        L.hbhip_filter_out_geometry.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.hbhip_nlmeans_create.argtypes = [C.c_void_p, C.POINTER(NLMeansParams), C.c_int, C.c_int,
+                                           C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.hbhip_nlmeans_set_batch.argtypes = [C.c_void_p, C.c_int]
+        _lib = L
+    return _lib
+
+
+def filters() -> C.CDLL:
+    """libhbhip_filters.so: the hb_filter_object_t drop-ins (hb_filter_*_hip)."""
+    global _flt
+    if _flt is None:
+        hbrt.runtime()
+        lib()
+        path = os.path.join(_HERE, "libhbhip_filters.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: run __graft_entry__.build() / make")
+        F = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        F.hbhip_host_ctx_ptr.restype = C.c_void_p
+        F.hbhip_filter_get.restype = C.c_void_p
+        F.hbhip_filter_get.argtypes = [C.c_int]
+        F.hbhip_nlmeans_params_from_settings.restype = None
+        F.hbhip_nlmeans_params_from_settings.argtypes = [C.c_char_p, C.c_int, C.POINTER(NLMeansParams)]
+        _flt = F
+    return _flt
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def check(rc: int, ctx=None, what: str = ""):
+    if rc < 0:
+        msg = lib().hbhip_strerror(rc).decode()
+        if ctx:
+            msg += " | " + lib().hbhip_ctx_last_error(ctx).decode()
+        raise HipError(f"{what}: {msg}")
+    return rc
+
+
+class Ctx:
+    """A device context (one GPU, one stream)."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        L = lib()
+        h = C.c_void_p()
+        if stream is None:
+            check(L.hbhip_ctx_create(device, C.byref(h)), what="hbhip_ctx_create")
+        else:
+            check(L.hbhip_ctx_create_on_stream(device, C.c_void_p(stream), C.byref(h)),
+                  what="hbhip_ctx_create_on_stream")
+        self.h = h
+
+    def sync(self):
+        check(lib().hbhip_ctx_sync(self.h), self.h, "sync")
+
+    def name(self) -> str:
+        buf = C.create_string_buffer(256)
+        lib().hbhip_ctx_device_name(self.h, buf, 256)
+        return buf.value.decode()
+
+    def profile(self, on: bool):
+        check(lib().hbhip_ctx_profile_enable(self.h, int(on)), self.h)
+
+    def profile_reset(self):
+        check(lib().hbhip_ctx_profile_reset(self.h), self.h)
+
+    def profile_stats(self) -> dict:
+        L = lib()
+        out = {}
+        for i in range(L.hbhip_ctx_profile_count(self.h)):
+            name = C.create_string_buffer(128)
+            n = C.c_int64()
+            ms = C.c_double()
+            L.hbhip_ctx_profile_get(self.h, i, name, 128, C.byref(n), C.byref(ms))
+            out[name.value.decode()] = (n.value, ms.value)
+        return out
+
+    def mark(self, slot: int):
+        check(lib().hbhip_ctx_mark(self.h, slot), self.h, "mark")
+
+    def elapsed_ms(self, a: int, b: int) -> float:
+        ms = C.c_double()
+        check(lib().hbhip_ctx_elapsed_ms(self.h, a, b, C.byref(ms)), self.h, "elapsed")
+        return ms.value
+
+    def close(self):
+        if self.h:
+            lib().hbhip_ctx_destroy(self.h)
+            self.h = None
+
+
+def dev_frame(tensors) -> DevFrame:
+    """DevFrame over three 2-D uint8 torch CUDA tensors (kept alive by the caller)."""
+    f = DevFrame()
+    for i, t in enumerate(tensors):
+        f.plane[i] = t.data_ptr()
+        f.stride[i] = t.stride(0) * t.element_size()
+    return f
+
+
+class DeviceFilter:
+    """Thin wrapper of an hbhip_filter* for device-resident frames (bench / tests)."""
+
+    def __init__(self, ctx: Ctx, handle):
+        self.ctx, self.h = ctx, handle
+
+    def push_dev(self, frame: DevFrame, tag: int = 0):
+        check(lib().hbhip_filter_push_dev(self.h, C.byref(frame), tag), self.ctx.h, "push_dev")
+
+    def pull_dev(self, frame: DevFrame):
+        tag = C.c_int64()
+        rc = check(lib().hbhip_filter_pull_dev(self.h, C.byref(frame), C.byref(tag)), self.ctx.h, "pull_dev")
+        return None if rc == HBHIP_AGAIN else tag.value
+
+    def flush(self):
+        check(lib().hbhip_filter_flush(self.h), self.ctx.h, "flush")
+
+    def pending(self) -> int:
+        return lib().hbhip_filter_pending(self.h)
+
+    def close(self):
+        if self.h:
+            lib().hbhip_filter_destroy(self.h)
+            self.h = None
+
+
+NLMEANS_MEDIUM = ("y-strength=6:y-origin-tune=1:y-patch-size=7:y-range=3:y-frame-count=2:y-prefilter=0:"
+                  "cb-strength=6:cb-origin-tune=1:cb-patch-size=7:cb-range=3:cb-frame-count=2:cb-prefilter=0")
+
+
+def nlmeans_device_filter(ctx: Ctx, settings: str, width: int, height: int, batch: int = 1) -> DeviceFilter:
+    """An NLMeans instance driven through the C ABI with device-resident frames."""
+    par = NLMeansParams()
+    filters().hbhip_nlmeans_params_from_settings(settings.encode(), 8, C.byref(par))
+    h = C.c_void_p()
+    check(lib().hbhip_nlmeans_create(ctx.h, C.byref(par), width, height, 8, 1, 1, C.byref(h)),
+          ctx.h, "hbhip_nlmeans_create")
+    check(lib().hbhip_nlmeans_set_batch(h, batch), ctx.h, "set_batch")
+    return DeviceFilter(ctx, h)

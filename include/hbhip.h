@@ -1,0 +1,137 @@
+/* hbhip.h — C ABI of libhbhip.so: libhb's per-pixel video-filter hot path as
+ * hand-written HIP kernels for AMD Instinct MI355X (gfx950 / CDNA4).
+ *
+ * This is the drop-in boundary.  libhb stays C: each HIP-backed
+ * hb_filter_object_t (handbrake_amd/libhb/<filter>_hip.c) keeps the reference's
+ * init/work/close surface (libhb/handbrake/common.h:1670-1711) and only
+ * translates hb_buffer_t <-> plane pointers before calling the functions below.
+ * Plain pointers and sizes only; no C++ or torch types cross this boundary; no
+ * exception crosses it either.  Every entry point names the reference
+ * interface it replaces (paths relative to /root/reference/libhb).
+ *
+ * Conventions
+ *   - return 0 (HBHIP_OK) on success, HBHIP_AGAIN (1) when a pull has no frame
+ *     ready yet, negative HBHIP_ERR_* on failure (hbhip_strerror()).
+ *   - the caller owns host memory; the library owns device memory and, unless
+ *     one is adopted (hbhip_ctx_create_on_stream), one hipStream_t per context.
+ *   - one caller thread per filter instance (that is what filter_loop gives,
+ *     work.c:2527-2600); distinct instances / contexts are independent.
+ *   - a missing GPU is an error (HBHIP_ERR_NODEVICE): there is NO CPU fallback
+ *     inside this library.  libhb falls back by re-inserting its CPU filter
+ *     when a HIP filter's init() fails (work.c:1861-1868 semantics).
+ */
+#ifndef HBHIP_H
+#define HBHIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HBHIP_OK               0
+#define HBHIP_AGAIN            1
+#define HBHIP_ERR_NODEVICE    (-1)
+#define HBHIP_ERR_HIP         (-2)
+#define HBHIP_ERR_ARG         (-3)
+#define HBHIP_ERR_NOMEM       (-4)
+#define HBHIP_ERR_UNSUPPORTED (-5)
+#define HBHIP_ERR_STATE       (-6)
+
+#define HBHIP_ABI_VERSION 1
+
+typedef struct hbhip_ctx    hbhip_ctx;
+typedef struct hbhip_filter hbhip_filter;
+
+/* A planar picture living in HOST memory: what hb_buffer_t.plane[] describes
+ * (handbrake/internal.h:137-144).  stride in bytes. */
+typedef struct hbhip_host_frame
+{
+    uint8_t *plane[3];
+    int      stride[3];
+} hbhip_host_frame;
+
+/* A planar picture living in DEVICE memory (HBM).  Used by the device-resident
+ * hand-off between adjacent HIP filters (the reference's
+ * precedent is hb_buffer_t.storage_type = COREMEDIA, internal.h:152-153) and
+ * by bench.py, whose inputs are resident in HBM before the timed region. */
+typedef struct hbhip_dev_frame
+{
+    void *plane[3];
+    int   stride[3];
+} hbhip_dev_frame;
+
+/* ---- library / context ------------------------------------------------------ */
+int         hbhip_abi_version(void);
+int         hbhip_device_count(void);                 /* hb_get_cpu_count() analogue, ports.c:292 */
+const char *hbhip_strerror(int code);
+int         hbhip_ctx_create(int device, hbhip_ctx **out);
+/* Adopt an existing hipStream_t (passed as void*) instead of creating one. */
+int         hbhip_ctx_create_on_stream(int device, void *hip_stream, hbhip_ctx **out);
+void        hbhip_ctx_destroy(hbhip_ctx *ctx);
+int         hbhip_ctx_sync(hbhip_ctx *ctx);           /* hipStreamSynchronize */
+const char *hbhip_ctx_last_error(hbhip_ctx *ctx);     /* text of the last HIP failure */
+int         hbhip_ctx_device_name(hbhip_ctx *ctx, char *buf, int len);
+
+/* Per-kernel timing with HIP events on the context's stream (off by default).
+ * When enabled every kernel launch is bracketed by two events; stats are read
+ * back per kernel name.  bench.py derives roofline.achieved from these. */
+int  hbhip_ctx_profile_enable(hbhip_ctx *ctx, int on);
+int  hbhip_ctx_profile_reset(hbhip_ctx *ctx);
+int  hbhip_ctx_profile_count(hbhip_ctx *ctx);         /* distinct kernel names seen (syncs) */
+int  hbhip_ctx_profile_get(hbhip_ctx *ctx, int idx, char *name, int name_len,
+                           int64_t *launches, double *total_ms);
+/* Two user events on the stream, for whole-region timing. */
+int  hbhip_ctx_mark(hbhip_ctx *ctx, int slot);        /* slot 0..7: record event */
+int  hbhip_ctx_elapsed_ms(hbhip_ctx *ctx, int slot_a, int slot_b, double *ms); /* syncs slot_b */
+
+/* Device memory helpers (thin hipMalloc/hipFree/hipMemcpy wrappers so a C host
+ * never needs the HIP headers). */
+int  hbhip_dev_alloc(hbhip_ctx *ctx, size_t bytes, void **out);
+int  hbhip_dev_free(hbhip_ctx *ctx, void *p);
+int  hbhip_dev_upload(hbhip_ctx *ctx, void *dst, const void *src, size_t bytes);
+int  hbhip_dev_download(hbhip_ctx *ctx, void *dst, const void *src, size_t bytes);
+
+/* ---- generic streaming surface of a filter instance ---------------------------
+ * Mirrors hb_filter_object_t.work (common.h:1682-1685): push one input frame,
+ * pull zero or more output frames, flush at EOF, destroy in close().
+ * `tag` travels with the frame (the host filter keeps hb_buffer_t props by tag). */
+int  hbhip_filter_push(hbhip_filter *f, const hbhip_host_frame *in, int64_t tag);
+int  hbhip_filter_push_dev(hbhip_filter *f, const hbhip_dev_frame *in, int64_t tag);
+int  hbhip_filter_pull(hbhip_filter *f, const hbhip_host_frame *out, int64_t *tag);
+int  hbhip_filter_pull_dev(hbhip_filter *f, const hbhip_dev_frame *out, int64_t *tag);
+int  hbhip_filter_flush(hbhip_filter *f);             /* input ended (HB_BUF_FLAG_EOF) */
+int  hbhip_filter_pending(hbhip_filter *f);           /* frames a pull would return now */
+void hbhip_filter_destroy(hbhip_filter *f);
+/* Output geometry (cropscale / rotate change it; init->geometry, cropscale.c:170-178). */
+int  hbhip_filter_out_geometry(hbhip_filter *f, int *width, int *height);
+
+/* ---- NLMeans  (replaces nlmeans.c:223-419 init tables + nlmeans_template.c:545-717) */
+#define HBHIP_NLMEANS_FRAMES_MAX 32                   /* NLMEANS_FRAMES_MAX, nlmeans.c:87 */
+typedef struct hbhip_nlmeans_params
+{
+    /* per plane Y,Cb,Cr, already cascaded/sanitised exactly as nlmeans.c:306-343 */
+    double strength[3];
+    double origin_tune[3];
+    int    patch_size[3];
+    int    range[3];
+    int    nframes[3];
+    int    prefilter[3];
+    /* tables built on the host with libm, as nlmeans.c:345-358 does */
+    float  exptable[3][128];
+    float  weight_fact_table[3];
+    int    diff_max[3];
+} hbhip_nlmeans_params;
+
+int hbhip_nlmeans_create(hbhip_ctx *ctx, const hbhip_nlmeans_params *p,
+                         int width, int height, int depth,
+                         int log2_chroma_w, int log2_chroma_h,
+                         hbhip_filter **out);
+/* Max frames processed per kernel launch when several are queued (default 8). */
+int hbhip_nlmeans_set_batch(hbhip_filter *f, int frames);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HBHIP_H */

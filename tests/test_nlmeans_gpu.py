@@ -1,0 +1,128 @@
+"""GPU parity: HIP NLMeans (through the hb_filter_object_t drop-in and through
+the raw C ABI) against the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+from handbrake_amd import hbrt, hip, synth
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+MEDIUM = hip.NLMEANS_MEDIUM
+
+
+def oracle_stream(frames, settings_per_plane):
+    """Per-plane oracle over a whole stream with the EOF shrinking window."""
+    out = []
+    n = len(frames)
+    for t in range(n):
+        planes = []
+        for c in range(3):
+            st = settings_per_plane[c]
+            if st["strength"] == 0:
+                planes.append(frames[t][c].copy())
+                continue
+            nf = min(st["nframes"], n - t)
+            planes.append(ol.orc_nlmeans_plane([frames[t + f][c] for f in range(nf)],
+                                               st["strength"], st["origin_tune"], st["patch"],
+                                               st["range"], 0))
+        out.append(planes)
+    return out
+
+
+def run_hip(frames, settings):
+    return hbrt.run_stream(hip.filters(), [("hb_filter_nlmeans_hip", settings)], frames)
+
+
+def par(strength=6, origin_tune=1.0, patch=7, rng=3, nframes=2):
+    return dict(strength=strength, origin_tune=origin_tune, patch=patch, range=rng, nframes=nframes)
+
+
+@pytest.mark.parametrize("w,h", [(64, 48), (638, 362), (320, 180)])
+def test_medium_bit_exact_small(built, w, h):
+    frames = synth.stream("progressive", w, h, 5)
+    got = run_hip(frames, MEDIUM)
+    want = oracle_stream(frames, [par(), par(), par()])
+    assert len(got) == len(frames)
+    for t in range(len(frames)):
+        for c in range(3):
+            np.testing.assert_array_equal(got[t].planes[c], want[t][c], err_msg=f"frame {t} plane {c}")
+        assert got[t].start == t * 3003
+
+
+def test_random_noise_input(built):
+    frames = synth.stream("random", 200, 120, 3)
+    got = run_hip(frames, MEDIUM)
+    want = oracle_stream(frames, [par(), par(), par()])
+    for t in range(3):
+        for c in range(3):
+            np.testing.assert_array_equal(got[t].planes[c], want[t][c])
+
+
+@pytest.mark.parametrize("settings,pp", [
+    ("y-strength=3:y-origin-tune=0.8:y-patch-size=3:y-range=5:y-frame-count=2:"
+     "cb-strength=6:cb-origin-tune=0.8:cb-patch-size=5:cb-range=5:cb-frame-count=2",
+     [par(3, 0.8, 3, 5, 2), par(6, 0.8, 5, 5, 2), par(6, 0.8, 5, 5, 2)]),          # tune=tape
+    ("y-strength=5:y-origin-tune=0.15:y-patch-size=5:y-range=7:y-frame-count=4:"
+     "cb-strength=4:cb-origin-tune=0.15:cb-patch-size=5:cb-range=7:cb-frame-count=4",
+     [par(5, 0.15, 5, 7, 4), par(4, 0.15, 5, 7, 4), par(4, 0.15, 5, 7, 4)]),       # tune=animation
+    ("y-strength=0:cb-strength=6:cb-origin-tune=0.8:cb-patch-size=7:cb-range=3:cb-frame-count=2",
+     [par(0), par(6, 0.8, 7, 3, 2), par(6, 0.8, 7, 3, 2)]),                         # tune=grain
+    ("y-strength=6:y-origin-tune=0.8:y-patch-size=7:y-range=3:y-frame-count=2:"
+     "cb-strength=6:cb-origin-tune=0.7:cb-patch-size=7:cb-range=5:cb-frame-count=1",
+     [par(6, 0.8, 7, 3, 2), par(6, 0.7, 7, 5, 1), par(6, 0.7, 7, 5, 1)]),          # tune=highmotion
+])
+def test_tunes_bit_exact(built, settings, pp):
+    frames = synth.stream("progressive", 192, 108, 6)
+    got = run_hip(frames, settings)
+    want = oracle_stream(frames, pp)
+    assert len(got) == len(frames)
+    for t in range(len(frames)):
+        for c in range(3):
+            np.testing.assert_array_equal(got[t].planes[c], want[t][c], err_msg=f"frame {t} plane {c}")
+
+
+def test_1080p_against_reference_if_present(built):
+    """Full BASELINE size, one frame pair, against the reference's own C when
+    oracle/_ref travelled with the snapshot, else against the restatement."""
+    frames = synth.stream("progressive", 1920, 1080, 3)
+    got = run_hip(frames, MEDIUM)
+    assert len(got) == 3
+    ref = ol.ref()
+    for c in range(3):
+        if ref is not None:
+            want = ol.ref_nlmeans_plane(MEDIUM, c, [frames[0][c], frames[1][c]])
+        else:
+            want = ol.orc_nlmeans_plane([frames[0][c], frames[1][c]])
+        np.testing.assert_array_equal(got[0].planes[c], want)
+
+
+def test_device_resident_batched_equals_streamed(built):
+    """The bench path (push_dev / pull_dev, batched launches) gives the same
+    bytes as the host-buffer path."""
+    import torch
+    w, h, n = 320, 180, 9
+    frames = synth.stream("progressive", w, h, n)
+    want = run_hip(frames, MEDIUM)
+    ctx = hip.Ctx(0)
+    flt = hip.nlmeans_device_filter(ctx, MEDIUM, w, h, batch=4)
+    dev_in = [[torch.from_numpy(p.copy()).cuda() for p in fr] for fr in frames]
+    dev_out = [[torch.zeros_like(p) for p in fr] for fr in dev_in]
+    torch.cuda.synchronize()
+    got = 0
+    for t in range(n):
+        flt.push_dev(hip.dev_frame(dev_in[t]), t)
+        while flt.pending():
+            assert flt.pull_dev(hip.dev_frame(dev_out[got])) == got
+            got += 1
+    flt.flush()
+    while flt.pending():
+        assert flt.pull_dev(hip.dev_frame(dev_out[got])) == got
+        got += 1
+    ctx.sync()
+    assert got == n
+    for t in range(n):
+        for c in range(3):
+            np.testing.assert_array_equal(dev_out[t][c].cpu().numpy(), want[t].planes[c])
+    flt.close()
+    ctx.close()
