@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py — filtered frames/sec of the libhb video-filter hot path on MI355X.
+
+Workload (BASELINE.json configs[1], the configuration `metric` is quoted on):
+NLMeans "medium" (strength 6, origin-tune 1, patch 7, range 3, 2 frames, no
+prefilter; libhb/param.c:410-415) on 1920x1080 YUV420P 8-bit synthetic frames.
+
+A "step" = one pass of the hot path over one batch of BATCH consecutive frames
+of a stream that is already resident in HBM: the frames are pushed through the
+product C ABI (hbhip_filter_process_dev -> nlmeans_plane kernel) and the BATCH
+filtered frames are written to device output buffers.  Nothing of the oracle or
+of any CPU path runs inside the timed region.
+
+Multi-GPU (--gpus N, launched by torch.distributed.run): every rank filters its
+own independent stream on its own GPU (frames shard by stream); no
+data-path collective.  RCCL is used only to reduce {frames, seconds}: value =
+total frames of all ranks / max-over-ranks time.  scaling = weak.
+
+Also reported on the same JSON line:
+  roofline      - dominant kernel, algorithmic bytes/launch over its mean launch
+                  time measured with HIP events on the stream it runs on.
+  cpu_baseline  - the reference's own C NLMeans (oracle/_ref, taskset-threaded as
+                  libhb does) - or the single-thread port if the prebuilt _ref is
+                  absent - timed on this box's host cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+W, H = 1920, 1080
+BATCH = 16
+# read 2 frames + write 1 = 3 x 3,110,400 B per 1080p 4:2:0 frame
+ALGO_BYTES_PER_FRAME = 3 * (W * H * 3 // 2)
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def cpu_baseline(frames_np):
+    """Reference NLMeans on the host cores (rank 0, N=1 only). ~10-30 s of CPU work."""
+    from handbrake_amd import hbrt, hip
+    import oracle_lib as ol
+    settings = hip.NLMEANS_MEDIUM
+    ref = ol.ref()
+    if ref is not None:
+        ncpu = min(os.cpu_count() or 1, 128)
+        threads = ncpu // 2 if ncpu >= 32 else (ncpu // 4) * 3 if ncpu >= 16 else ncpu  # nlmeans.c:361-373
+        n = max(2 * threads + 2, 24)
+        seq = [frames_np[i % len(frames_np)] for i in range(n)]
+        t0 = time.perf_counter()
+        out = hbrt.run_stream(ref, [("hb_filter_nlmeans", settings)], seq)
+        dt = time.perf_counter() - t0
+        if dt < 8.0:   # too short to be meaningful: repeat with a longer sample
+            k = int(min(10.0 / max(dt, 1e-3), 8)) + 1
+            seq = seq * k
+            t0 = time.perf_counter()
+            out = hbrt.run_stream(ref, [("hb_filter_nlmeans", settings)], seq)
+            dt = time.perf_counter() - t0
+        return {"value": round(len(out) / dt, 3), "unit": "frames/s", "cores": threads,
+                "kind": "reference",
+                "sample": f"{len(out)} frames 1920x1080 YUV420P through the reference hb_filter_nlmeans "
+                          f"init/work/close (libhb/nlmeans.c compiled in place, taskset threads={threads}, "
+                          f"SSE2 integral), {dt:.1f}s wall"}
+    # port: single-thread restatement, a few frames
+    n = 3
+    t0 = time.perf_counter()
+    for t in range(n):
+        for c in range(3):
+            ol.orc_nlmeans_plane([frames_np[t][c], frames_np[t + 1][c]])
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{n} frames 1920x1080 YUV420P, oracle/nlmeans_oracle.c single thread, {dt:.1f}s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from handbrake_amd import hip, shard, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    B = args.batch
+    # one independent synthetic stream per rank (cfg = 2 + rank*16 keeps rank 0 == configs[1])
+    frames_np = synth.stream("progressive", W, H, B + 1, cfg=2 + 16 * rank)
+    dev_in = [[torch.from_numpy(p).cuda() for p in fr] for fr in frames_np]
+    dev_out = [[torch.empty_like(p) for p in dev_in[0]] for _ in range(B)]
+    torch.cuda.synchronize()
+
+    ctx = hip.Ctx(local_rank)
+    flt = hip.nlmeans_device_filter(ctx, hip.NLMEANS_MEDIUM, W, H, batch=B)
+    in_arr = (hip.DevFrame * B)(*[hip.dev_frame(dev_in[1 + i]) for i in range(B)])
+    out_arr = (hip.DevFrame * B)(*[hip.dev_frame(f) for f in dev_out])
+    flt.push_dev(hip.dev_frame(dev_in[0]), 0)       # prime the 1-frame look-ahead
+
+    def step(i):
+        n = flt.process_dev(in_arr, 1 + i * B, out_arr)
+        assert n == B, f"step produced {n} frames, expected {B}"
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    ctx.profile(True)
+    ctx.profile_reset()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    ctx.sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+    stats = ctx.profile_stats()
+    ctx.profile(False)
+
+    frames_local = float(args.steps * B)
+    frames_total, dt_max = shard.reduce_throughput(frames_local, dt, device="cuda")
+
+    if rank == 0:
+        # dominant kernel = most total time
+        kname, (launches, total_ms) = max(stats.items(), key=lambda kv: kv[1][1])
+        avg_s = total_ms / launches / 1e3
+        frames_per_launch = frames_local / launches
+        algo_bytes = ALGO_BYTES_PER_FRAME * frames_per_launch
+        achieved = algo_bytes / avg_s / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc)).get(kname, {}).get(str(B))
+                if rec:
+                    traffic = rec["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "filtered frames/sec, 1080p YUV420p NLMeans (medium) hot path",
+            "value": round(frames_total / dt_max, 2),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt_max / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8 (f32 weights)",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: nlmeans medium (patch 7, range 3, 2 frames) "
+                                   "1920x1080 YUV420P 8-bit, inputs resident in HBM",
+                       "frames_per_step": B, "width": W, "height": H,
+                       "parallelism": f"{world} independent stream(s), one per GPU",
+                       "device": ctx.name()},
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": traffic,
+                         "launch_us": round(avg_s * 1e6, 2), "launches": launches,
+                         "algorithmic_bytes_per_launch": int(algo_bytes),
+                         "note": "NLMeans is VALU-bound (about 430 integer/float lane-ops per byte-pixel); "
+                                 "see DESIGN.md for the VALU roofline of this kernel"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(frames_np)
+        print(json.dumps(out), flush=True)
+
+    flt.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

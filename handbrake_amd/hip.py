@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "hbhip_ctx_profile_count", "hbhip_ctx_profile_get", "hbhip_ctx_mark", "hbhip_ctx_elapsed_ms",
     "hbhip_dev_alloc", "hbhip_dev_free", "hbhip_dev_upload", "hbhip_dev_download",
     "hbhip_filter_push", "hbhip_filter_push_dev", "hbhip_filter_pull", "hbhip_filter_pull_dev",
-    "hbhip_filter_flush", "hbhip_filter_pending", "hbhip_filter_destroy",
+    "hbhip_filter_process_dev", "hbhip_filter_flush", "hbhip_filter_pending", "hbhip_filter_destroy",
     "hbhip_filter_out_geometry", "hbhip_nlmeans_create", "hbhip_nlmeans_set_batch",
 ]
 
@@ -80,6 +80,8 @@ def lib() -> C.CDLL:
         L.hbhip_filter_pull.argtypes = [C.c_void_p, C.POINTER(HostFrame), C.POINTER(C.c_int64)]
         L.hbhip_filter_pull_dev.argtypes = [C.c_void_p, C.POINTER(DevFrame), C.POINTER(C.c_int64)]
         L.hbhip_filter_flush.argtypes = [C.c_void_p]
+        L.hbhip_filter_process_dev.argtypes = [C.c_void_p, C.POINTER(DevFrame), C.c_int, C.c_int64,
+                                               C.POINTER(DevFrame), C.c_int, C.POINTER(C.c_int)]
         L.hbhip_filter_pending.argtypes = [C.c_void_p]
         L.hbhip_filter_destroy.argtypes = [C.c_void_p]
         L.hbhip_filter_destroy.restype = None
@@ -197,6 +199,14 @@ class DeviceFilter:
         tag = C.c_int64()
         rc = check(lib().hbhip_filter_pull_dev(self.h, C.byref(frame), C.byref(tag)), self.ctx.h, "pull_dev")
         return None if rc == HBHIP_AGAIN else tag.value
+
+    def process_dev(self, frames_in, tag0: int, frames_out) -> int:
+        """frames_in / frames_out: ctypes arrays of DevFrame.  Returns frames written."""
+        n = C.c_int()
+        check(lib().hbhip_filter_process_dev(self.h, frames_in, len(frames_in), tag0,
+                                             frames_out, len(frames_out), C.byref(n)),
+              self.ctx.h, "process_dev")
+        return n.value
 
     def flush(self):
         check(lib().hbhip_filter_flush(self.h), self.ctx.h, "flush")

@@ -101,6 +101,11 @@ int  hbhip_filter_push(hbhip_filter *f, const hbhip_host_frame *in, int64_t tag)
 int  hbhip_filter_push_dev(hbhip_filter *f, const hbhip_dev_frame *in, int64_t tag);
 int  hbhip_filter_pull(hbhip_filter *f, const hbhip_host_frame *out, int64_t *tag);
 int  hbhip_filter_pull_dev(hbhip_filter *f, const hbhip_dev_frame *out, int64_t *tag);
+/* Batch form of push_dev/pull_dev: push n_in frames (tags tag0, tag0+1, ...) and
+ * pull every frame that becomes ready into out[0..out_cap); *n_out = frames
+ * written.  One ABI crossing per batch instead of two per frame. */
+int  hbhip_filter_process_dev(hbhip_filter *f, const hbhip_dev_frame *in, int n_in, int64_t tag0,
+                              const hbhip_dev_frame *out, int out_cap, int *n_out);
 int  hbhip_filter_flush(hbhip_filter *f);             /* input ended (HB_BUF_FLAG_EOF) */
 int  hbhip_filter_pending(hbhip_filter *f);           /* frames a pull would return now */
 void hbhip_filter_destroy(hbhip_filter *f);

@@ -308,6 +308,7 @@ static void patch_ssd(const uint8_t *a_img, const uint8_t *b_img, int bw,
 }
 
 void orc_nlmeans_plane(const uint8_t *const *frames, const uint8_t *const *frames_pre,
+                       const uint8_t *src_pre_plane,
                        int nframes, int w, int h, int border,
                        const orc_nlmeans_params_t *p,
                        uint8_t *dst, int dst_stride)
@@ -328,7 +329,7 @@ void orc_nlmeans_plane(const uint8_t *const *frames, const uint8_t *const *frame
     uint32_t *colsum = malloc(sizeof(uint32_t) * (w + n));
 
     const uint8_t *src = frames[0] + origin;
-    const uint8_t *src_pre = frames_pre[0] + origin;
+    const uint8_t *src_pre = (src_pre_plane ? src_pre_plane : frames_pre[0]) + origin;
 
     for (int f = 0; f < nframes; f++)
     {

@@ -55,8 +55,15 @@ int orc_nlmeans_prefilter(const uint8_t *bordered, int w, int h, int border,
 
 /* nlmeans_plane_8 (nlmeans_template.c:593-717).  frames[f] = bordered planes
  * (frame 0 = the frame being filtered, f>0 = the following frames);
- * frames_pre[f] = their prefiltered versions (== frames[f] when prefilter=0). */
+ * frames_pre[f] = their prefiltered versions (== frames[f] when prefilter=0).
+ * src_pre_plane: the plane the patch differences take the SOURCE pixels from.
+ * The reference latches `src_pre` (:615) BEFORE it prefilters frame 0 (:631), so
+ * a frame that was never a look-ahead frame of an earlier call (the first frame
+ * of a stream, or any frame when nframes == 1) is compared in its RAW form
+ * against prefiltered neighbours; pass frames[0] for that case, NULL (or
+ * frames_pre[0]) when frame 0 had already been prefiltered. */
 void orc_nlmeans_plane(const uint8_t *const *frames, const uint8_t *const *frames_pre,
+                       const uint8_t *src_pre_plane,
                        int nframes, int w, int h, int border,
                        const orc_nlmeans_params_t *p,
                        uint8_t *dst, int dst_stride);

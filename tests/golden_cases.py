@@ -1,0 +1,32 @@
+"""The golden-vector cases: (synthetic stream, reference filter chain).
+make_golden.py runs them through the reference; tests replay them through the
+oracle restatement (CPU) and the HIP drop-ins (GPU)."""
+
+NLM_MEDIUM = ("y-strength=6:y-origin-tune=1:y-patch-size=7:y-range=3:y-frame-count=2:y-prefilter=0:"
+              "cb-strength=6:cb-origin-tune=1:cb-patch-size=7:cb-range=3:cb-frame-count=2:cb-prefilter=0")
+NLM_TAPE = ("y-strength=3:y-origin-tune=0.8:y-patch-size=3:y-range=5:y-frame-count=2:y-prefilter=0:"
+            "cb-strength=6:cb-origin-tune=0.8:cb-patch-size=5:cb-range=5:cb-frame-count=2:cb-prefilter=0")
+NLM_ANIM_LIGHT = ("y-strength=3:y-origin-tune=0.15:y-patch-size=5:y-range=7:y-frame-count=3:y-prefilter=0:"
+                  "cb-strength=2.25:cb-origin-tune=0.15:cb-patch-size=5:cb-range=7:cb-frame-count=3:cb-prefilter=0")
+
+def nlm(strength=6, origin_tune=1.0, patch=7, rng=3, nframes=2, prefilter=0):
+    return dict(strength=strength, origin_tune=origin_tune, patch=patch, range=rng,
+                nframes=nframes, prefilter=prefilter)
+
+
+# name -> case.  `chain` = [(reference filter object symbol, settings)], `hip` = the drop-in symbols.
+CASES = {
+    "nlmeans_medium_96x64": dict(model="progressive", w=96, h=64, n=4,
+                                 chain=[("hb_filter_nlmeans", NLM_MEDIUM + ":threads=2")],
+                                 hip=[("hb_filter_nlmeans_hip", NLM_MEDIUM)],
+                                 orc=[("nlmeans", [nlm(), nlm(), nlm()])]),
+    "nlmeans_tape_70x50": dict(model="progressive", w=70, h=50, n=4,
+                               chain=[("hb_filter_nlmeans", NLM_TAPE + ":threads=1")],
+                               hip=[("hb_filter_nlmeans_hip", NLM_TAPE)],
+                               orc=[("nlmeans", [nlm(3, 0.8, 3, 5, 2), nlm(6, 0.8, 5, 5, 2), nlm(6, 0.8, 5, 5, 2)])]),
+    "nlmeans_animation_light_80x48": dict(model="random", w=80, h=48, n=5,
+                                          chain=[("hb_filter_nlmeans", NLM_ANIM_LIGHT + ":threads=3")],
+                                          hip=[("hb_filter_nlmeans_hip", NLM_ANIM_LIGHT)],
+                                          orc=[("nlmeans", [nlm(3, 0.15, 5, 7, 3), nlm(2.25, 0.15, 5, 7, 3),
+                                                            nlm(2.25, 0.15, 5, 7, 3)])]),
+}

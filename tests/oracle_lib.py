@@ -52,7 +52,8 @@ def u8p(a: np.ndarray):
 
 
 # ---------------------------------------------------------------- NLMeans
-def orc_nlmeans_plane(planes, strength=6.0, origin_tune=1.0, patch=7, rng=3, prefilter=0):
+def orc_nlmeans_plane(planes, strength=6.0, origin_tune=1.0, patch=7, rng=3, prefilter=0,
+                      src_already_prefiltered=False):
     """planes: list of 2-D uint8 arrays (frame 0 = filtered frame, then look-ahead)."""
     lib = oracle()
     h, w = planes[0].shape
@@ -72,7 +73,8 @@ def orc_nlmeans_plane(planes, strength=6.0, origin_tune=1.0, patch=7, rng=3, pre
     fp = (C.POINTER(C.c_uint8) * n)(*[u8p(b) for b in pre])
     par = NLMeansParams(strength, origin_tune, patch, rng, n, prefilter)
     dst = np.zeros((h, w), np.uint8)
-    lib.orc_nlmeans_plane(fr, fp, n, w, h, border, C.byref(par), u8p(dst), w)
+    src_pre = None if src_already_prefiltered else u8p(bordered[0])
+    lib.orc_nlmeans_plane(fr, fp, src_pre, n, w, h, border, C.byref(par), u8p(dst), w)
     return dst
 
 

@@ -1,0 +1,54 @@
+"""World-size-2 CPU test (gloo) of the multi-GPU path's only communication: the
+throughput reduction, plus the stream->rank sharding."""
+import os
+import socket
+import sys
+
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from handbrake_amd import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    frames, secs = shard.reduce_throughput(100.0 * (rank + 1), 1.0 + rank)
+    streams = shard.stream_for_rank(rank, world, 5)
+    q.put((rank, frames, secs, streams))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reduce_throughput_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, frames, secs, streams in res:
+        assert frames == 300.0          # SUM over ranks
+        assert secs == 2.0              # MAX over ranks
+    assert res[0][3] == [0, 2, 4] and res[1][3] == [1, 3]
+
+
+def test_single_process_identity():
+    sys.path.insert(0, ROOT)
+    from handbrake_amd import shard
+    assert shard.reduce_throughput(10, 2.5) == (10.0, 2.5)

@@ -1,0 +1,77 @@
+"""CPU: pin the oracle restatement to the reference's own C (oracle/_ref) on
+seeded inputs.  Skipped where the prebuilt _ref library is absent."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from handbrake_amd import synth
+import oracle_lib as ol
+
+needs_ref = pytest.mark.skipif(ol.ref() is None, reason="oracle/_ref/libhbref.so not built (no /root/reference)")
+
+
+def nlm_settings(s, o, n, r, f, pf=0):
+    return (f"y-strength={s}:y-origin-tune={o}:y-patch-size={n}:y-range={r}:"
+            f"y-frame-count={f}:y-prefilter={pf}")
+
+
+@needs_ref
+@pytest.mark.parametrize("s,o,n,r,f", [(6, 1, 7, 3, 2), (1.5, 0.9, 7, 3, 2), (10, 1, 7, 3, 2), (3, 0.8, 3, 5, 2),
+                                       (5, 0.15, 5, 7, 4), (4, 0.5, 5, 9, 1), (8, 0.6, 9, 3, 3)])
+def test_nlmeans_plane_matches_reference(built, s, o, n, r, f):
+    frames = synth.stream("progressive", 150, 90, f)
+    planes = [fr[0] for fr in frames]
+    want = ol.ref_nlmeans_plane(nlm_settings(s, o, n, r, f), 0, planes)
+    got = ol.orc_nlmeans_plane(planes, s, o, n, r, 0)
+    np.testing.assert_array_equal(got, want)
+
+
+@needs_ref
+def test_nlmeans_sse2_equals_scalar(built):
+    frames = synth.stream("random", 131, 67, 2)
+    planes = [fr[0] for fr in frames]
+    st = nlm_settings(6, 1, 7, 3, 2)
+    np.testing.assert_array_equal(ol.ref_nlmeans_plane(st, 0, planes, force_scalar=True),
+                                  ol.ref_nlmeans_plane(st, 0, planes, force_scalar=False))
+
+
+@needs_ref
+def test_nlmeans_tables_match_reference(built):
+    for s, n in [(6, 7), (1.5, 7), (3, 3), (2.25, 5), (10, 9)]:
+        exp_r = (C.c_float * 128)()
+        wft_r, dm_r = C.c_float(), C.c_int()
+        assert ol.ref().hbref_nlmeans_tables(nlm_settings(s, 1, n, 3, 2).encode(), 0, exp_r,
+                                             C.byref(wft_r), C.byref(dm_r)) == 0
+        exp_o = (C.c_float * 128)()
+        wft_o, dm_o = C.c_float(), C.c_int()
+        fn = ol.oracle().orc_nlmeans_tables
+        fn.argtypes = [C.c_double, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]
+        fn(s, n, exp_o, C.byref(wft_o), C.byref(dm_o))
+        assert list(exp_r) == list(exp_o) and wft_r.value == wft_o.value and dm_r.value == dm_o.value
+
+
+@needs_ref
+@pytest.mark.parametrize("pf", [1, 2, 4, 8, 16, 32, 257, 514, 769, 1025, 1026, 1281, 1040, 1060])
+def test_nlmeans_prefilter_matches_reference(built, pf):
+    fr = synth.progressive_frame(97, 61, 3)[0]
+    lib = ol.ref()
+    want = np.zeros_like(fr)
+    assert lib.hbref_nlmeans_prefilter_8(ol.u8p(np.ascontiguousarray(fr)), 97, 61, fr.strides[0], pf, 16,
+                                         ol.u8p(want), 97) == 0
+    o = ol.oracle()
+    b = np.zeros((61 + 32, 97 + 32), np.uint8)
+    o.orc_nlmeans_make_bordered(ol.u8p(np.ascontiguousarray(fr)), 97, 61, fr.strides[0], 16, ol.u8p(b))
+    pre = np.zeros_like(b)
+    o.orc_nlmeans_prefilter(ol.u8p(b), 97, 61, 16, pf, ol.u8p(pre))
+    np.testing.assert_array_equal(pre[16:16 + 61, 16:16 + 97], want)
+
+
+@needs_ref
+def test_nlmeans_with_prefilter_matches_reference(built):
+    frames = synth.stream("progressive", 120, 70, 2)
+    planes = [fr[0] for fr in frames]
+    for pf in (1, 1026, 2 + 512):
+        want = ol.ref_nlmeans_plane(nlm_settings(6, 1, 7, 3, 2, pf), 0, planes)
+        got = ol.orc_nlmeans_plane(planes, 6, 1.0, 7, 3, pf)
+        np.testing.assert_array_equal(got, want)
