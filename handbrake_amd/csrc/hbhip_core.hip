@@ -2,6 +2,7 @@
 // picture pool and the generic push/pull half of the C ABI (include/hbhip.h).
 #include "hbhip_internal.h"
 
+#include <algorithm>
 #include <new>
 
 // ---------------------------------------------------------------- ctx helpers
@@ -131,12 +132,15 @@ void PicturePool::release(DevPicture *p)
 }
 
 // ---------------------------------------------------------------- copies
+// Uploads carry the caller's row padding too (up to our pitch): a few reference
+// filters read into it (lapsharp.c:145-157 when stride > width).
 int hbhip_copy_h2d(hbhip_ctx *ctx, DevPicture *dst, const hbhip_host_frame *src)
 {
     for (int c = 0; c < 3; c++)
     {
-        const size_t row = (size_t)dst->width[c] * dst->bps;
-        if (src->plane[c] == nullptr || src->stride[c] < (int)row) return HBHIP_ERR_ARG;
+        const size_t vis = (size_t)dst->width[c] * dst->bps;
+        if (src->plane[c] == nullptr || src->stride[c] < (int)vis) return HBHIP_ERR_ARG;
+        const size_t row = (size_t)std::min(src->stride[c], dst->pitch[c]);
         HBHIP_CHECK(ctx, hipMemcpy2DAsync(dst->plane[c], dst->pitch[c], src->plane[c], src->stride[c],
                                           row, dst->height[c], hipMemcpyHostToDevice, ctx->stream));
     }
@@ -159,8 +163,9 @@ int hbhip_copy_d2d_in(hbhip_ctx *ctx, DevPicture *dst, const hbhip_dev_frame *sr
 {
     for (int c = 0; c < 3; c++)
     {
-        const size_t row = (size_t)dst->width[c] * dst->bps;
-        if (src->plane[c] == nullptr || src->stride[c] < (int)row) return HBHIP_ERR_ARG;
+        const size_t vis = (size_t)dst->width[c] * dst->bps;
+        if (src->plane[c] == nullptr || src->stride[c] < (int)vis) return HBHIP_ERR_ARG;
+        const size_t row = (size_t)std::min(src->stride[c], dst->pitch[c]);
         HBHIP_CHECK(ctx, hipMemcpy2DAsync(dst->plane[c], dst->pitch[c], src->plane[c], src->stride[c],
                                           row, dst->height[c], hipMemcpyDeviceToDevice, ctx->stream));
     }
@@ -384,6 +389,7 @@ int hbhip_filter_push(hbhip_filter *f, const hbhip_host_frame *in, int64_t tag)
     DevPicture *pic = f->acquire_input();
     if (!pic) return HBHIP_ERR_NOMEM;
     pic->tag = tag;
+    for (int c = 0; c < 3; c++) f->in_stride[c] = in->stride[c];
     int rc = hbhip_copy_h2d(f->ctx, pic, in);
     if (rc != HBHIP_OK) return rc;
     // The caller may free or reuse its (pageable) planes as soon as we return
@@ -401,6 +407,7 @@ int hbhip_filter_push_dev(hbhip_filter *f, const hbhip_dev_frame *in, int64_t ta
     DevPicture *pic = f->acquire_input();
     if (!pic) return HBHIP_ERR_NOMEM;
     pic->tag = tag;
+    for (int c = 0; c < 3; c++) f->in_stride[c] = in->stride[c];
     int rc = hbhip_copy_d2d_in(f->ctx, pic, in);
     if (rc != HBHIP_OK) return rc;
     return f->submit(pic);

@@ -128,6 +128,9 @@ struct hbhip_filter
 {
     hbhip_ctx  *ctx = nullptr;
     PicGeometry in_geo, out_geo;
+    // byte stride the CALLER's planes had at the last push (some reference
+    // filters derive an edge rule from it, e.g. lapsharp.c:145)
+    int         in_stride[3] = {0, 0, 0};
     explicit hbhip_filter(hbhip_ctx *c) : ctx(c) {}
     virtual ~hbhip_filter() {}
 
@@ -139,4 +142,48 @@ struct hbhip_filter
     virtual int pending() = 0;
     virtual DevPicture *pop_output() = 0;          // nullptr when none
     virtual void recycle_output(DevPicture *pic) = 0;
+};
+
+// A stateless one-frame-in / one-frame-out filter: subclasses implement process().
+struct SimpleFilter : hbhip_filter
+{
+    PicturePool in_pool, out_pool;
+    std::deque<DevPicture *> outq;
+    explicit SimpleFilter(hbhip_ctx *c) : hbhip_filter(c) {}
+
+    void configure(const PicGeometry &gin, const PicGeometry &gout)
+    {
+        in_geo = gin;
+        out_geo = gout;
+        in_pool.configure(ctx, gin);
+        out_pool.configure(ctx, gout);
+    }
+    virtual int process(DevPicture *in, DevPicture *out) = 0;
+
+    DevPicture *acquire_input() override { return in_pool.acquire(); }
+    int submit(DevPicture *pic) override
+    {
+        DevPicture *o = out_pool.acquire();
+        if (!o) return HBHIP_ERR_NOMEM;
+        o->tag = pic->tag;
+        int rc = process(pic, o);
+        in_pool.release(pic);              // stream-ordered reuse
+        if (rc != HBHIP_OK)
+        {
+            out_pool.release(o);
+            return rc;
+        }
+        outq.push_back(o);
+        return HBHIP_OK;
+    }
+    int flush() override { return HBHIP_OK; }
+    int pending() override { return (int)outq.size(); }
+    DevPicture *pop_output() override
+    {
+        if (outq.empty()) return nullptr;
+        DevPicture *p = outq.front();
+        outq.pop_front();
+        return p;
+    }
+    void recycle_output(DevPicture *p) override { out_pool.release(p); }
 };

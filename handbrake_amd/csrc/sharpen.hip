@@ -1,0 +1,312 @@
+// sharpen.hip — lapsharp, unsharp and chroma-smooth for gfx950 (8-bit).
+//
+//   lapsharp_kernel<S>   replaces lapsharp_8        libhb/lapsharp.c:125-182
+//   blur_mix_kernel      replaces unsharp_8         libhb/unsharp.c:89-173
+//                        and      chroma_smooth_8   libhb/chroma_smooth.c:87-172
+//
+// All three are one read + one write per pixel (HBM-bound, 2 B/pixel
+// algorithmic); the neighbourhood reuse is served by LDS (blur) or L1/L2
+// (3x3 / 5x5 Laplacian rows read as aligned dwords).  Results are bit-exact:
+// lapsharp replays the reference's int16 accumulate and double mix; the
+// binomial blur is exact in uint32 modular arithmetic (the reference's running
+// pair sums are the same sums, unsharp.c:128-156).
+#include "hbhip_internal.h"
+
+namespace {
+
+// ------------------------------------------------------------------ lapsharp
+struct LapKernel { int tap[25]; int size; double coef; };
+
+constexpr LapKernel LAP_TABLE[4] = {
+    { { 0, -1, 0, -1, 5, -1, 0, -1, 0 }, 3, 1.0 },                                      // lap     lapsharp.c:37-42
+    { { -1, -4, -1, -4, 25, -4, -1, -4, -1 }, 3, 1.0 / 5 },                             // isolap  :47-52
+    { { 0, 0, -1, 0, 0, 0, -1, -2, -1, 0, -1, -2, 21, -2, -1, 0, -1, -2, -1, 0, 0, 0, -1, 0, 0 }, 5, 1.0 / 5 },   // log :58-65
+    { { 0, -1, -1, -1, 0, -1, -3, -4, -3, -1, -1, -4, 55, -4, -1, -1, -3, -4, -3, -1, 0, -1, -1, -1, 0 }, 5, 1.0 / 15 } }; // isolog :71-78
+
+struct LapArgs
+{
+    const uint8_t *src;
+    uint8_t       *dst;
+    int            width, height, src_pitch, dst_pitch;
+    int            stride_border;     // (caller stride - width) / 2, lapsharp.c:145
+    int            tap[25];
+    double         coef, strength;
+};
+
+__device__ __forceinline__ uint32_t byte_at(const uint32_t (&v)[3], int k)   // k in [-4, 7]
+{
+    const int kk = k + 4;
+    return (v[kk >> 2] >> (8 * (kk & 3))) & 0xffu;
+}
+
+// one thread = 4 horizontally adjacent pixels (one aligned dword of output)
+template <int S>
+__global__ __launch_bounds__(256) void lapsharp_kernel(LapArgs a)
+{
+    constexpr int LO = -((S - 1) / 2), HI = (S + 1) / 2;
+    const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int y = blockIdx.y;
+    if (x0 >= a.width) return;
+
+    const int pitch_dw = a.src_pitch >> 2;
+    const int xd = x0 >> 2;
+    uint32_t rows[S][3];
+#pragma unroll
+    for (int j = 0; j < S; j++)
+    {
+        int yy = y + LO + j;
+        yy = min(max(yy, 0), a.height - 1);                  // only read for pixels that end up copied
+        const uint32_t *r = reinterpret_cast<const uint32_t *>(a.src + (size_t)yy * a.src_pitch);
+        rows[j][0] = r[max(xd - 1, 0)];
+        rows[j][1] = r[xd];
+        rows[j][2] = r[min(xd + 1, pitch_dw - 1)];
+    }
+
+    uint32_t packed = 0;
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+    {
+        const int x = x0 + p;
+        const int centre = (int)byte_at(rows[-LO], p);
+        int out = centre;
+        const bool copy = (y < HI) || (y > a.height - HI) || (x < a.stride_border + HI) ||
+                          (x > a.width + a.stride_border - HI);
+        if (!copy)
+        {
+            int acc = 0;                                     // fits int16 for every table (lapsharp.c:148)
+#pragma unroll
+            for (int k = 0; k < S; k++)
+#pragma unroll
+                for (int j = 0; j < S; j++)
+                    acc += a.tap[j * S + k] * (int)byte_at(rows[j], p + LO + k);
+            const double mixed = (((double)acc * a.coef) - (double)centre) * a.strength;   // :174-175
+            out = (int)(short)(int)mixed + centre;
+            out = out < 0 ? 0 : out;
+            out = out > 255 ? 255 : out;
+        }
+        packed |= (uint32_t)out << (8 * p);
+    }
+    uint8_t *d = a.dst + (size_t)y * a.dst_pitch + x0;
+    if (x0 + 3 < a.width)
+        *reinterpret_cast<uint32_t *>(d) = packed;
+    else
+        for (int p = 0; x0 + p < a.width; p++) d[p] = (uint8_t)(packed >> (8 * p));
+}
+
+// ------------------------------------------------------------------ binomial blur + mix
+constexpr int BT_W = 64, BT_H = 16, MAX_STEPS = 7;
+
+struct BlurArgs
+{
+    const uint8_t *src;
+    uint8_t       *dst;
+    int            width, height, src_pitch, dst_pitch;
+    int            steps, scalebits, halfscale, amount;
+    int            sign, vmin, vmax;
+    uint32_t       coef[2 * MAX_STEPS + 1];
+};
+
+__global__ __launch_bounds__(256) void blur_mix_kernel(BlurArgs a)
+{
+    __shared__ uint8_t  s_src[(BT_H + 2 * MAX_STEPS) * (BT_W + 2 * MAX_STEPS)];
+    __shared__ uint32_t s_h[(BT_H + 2 * MAX_STEPS) * BT_W];
+
+    const int s = a.steps;
+    const int tw = BT_W + 2 * s, th = BT_H + 2 * s;
+    const int x0 = blockIdx.x * BT_W, y0 = blockIdx.y * BT_H;
+
+    // edge-clamped tile (unsharp.c:126 clamps x, :117-120 / :166-170 clamp y)
+    for (int i = threadIdx.x; i < tw * th; i += 256)
+    {
+        const int r = i / tw, c = i - r * tw;
+        const int y = min(max(y0 - s + r, 0), a.height - 1);
+        const int x = min(max(x0 - s + c, 0), a.width - 1);
+        s_src[i] = a.src[(size_t)y * a.src_pitch + x];
+    }
+    __syncthreads();
+
+    // horizontal binomial sums for every tile row
+    for (int i = threadIdx.x; i < th * BT_W; i += 256)
+    {
+        const int r = i / BT_W, c = i - r * BT_W;
+        uint32_t sum = 0;
+        for (int k = 0; k <= 2 * s; k++)
+            sum += a.coef[k] * (uint32_t)s_src[r * tw + c + k];
+        s_h[i] = sum;
+    }
+    __syncthreads();
+
+    // vertical sums + mix; thread -> 4 rows of one column (coalesced rows)
+    const int c = threadIdx.x & (BT_W - 1);
+    const int rg = threadIdx.x / BT_W;                       // 0..3
+    const int x = x0 + c;
+    if (x >= a.width) return;
+#pragma unroll
+    for (int q = 0; q < BT_H / 4; q++)
+    {
+        const int r = rg * (BT_H / 4) + q;
+        const int y = y0 + r;
+        if (y >= a.height) break;
+        uint32_t t = 0;
+        for (int k = 0; k <= 2 * s; k++)
+            t += a.coef[k] * s_h[(r + k) * BT_W + c];
+        const int p = (int)s_src[(r + s) * tw + c + s];
+        const int blur = (int)((t + (uint32_t)a.halfscale) >> a.scalebits);
+        const int d = ((p - blur) * a.amount) >> 16;         // arithmetic shift, as gcc does
+        int res = a.sign > 0 ? p + d : p - d;
+        res = res > a.vmax ? a.vmax : res < a.vmin ? a.vmin : res;
+        a.dst[(size_t)y * a.dst_pitch + x] = (uint8_t)res;
+    }
+}
+
+__global__ void plane_copy_kernel(uint8_t *dst, int dst_pitch, const uint8_t *src, int src_pitch,
+                                  int row_bytes, int rows)
+{
+    const int x = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int y = blockIdx.y;
+    if (y >= rows || x >= row_bytes) return;
+    const uint8_t *s = src + (size_t)y * src_pitch + x;
+    uint8_t *d = dst + (size_t)y * dst_pitch + x;
+    if (x + 3 < row_bytes)
+        *reinterpret_cast<uint32_t *>(d) = *reinterpret_cast<const uint32_t *>(s);
+    else
+        for (int i = 0; x + i < row_bytes; i++) d[i] = s[i];
+}
+
+int launch_copy(hbhip_ctx *ctx, const char *name, DevPicture *in, DevPicture *out, int c)
+{
+    const int row = in->width[c] * in->bps;
+    dim3 grid((row / 4 + 255) / 256 + 1, in->height[c]);
+    HBHIP_LAUNCH(ctx, name, plane_copy_kernel, grid, dim3(256), 0, out->plane[c], out->pitch[c],
+                 (const uint8_t *)in->plane[c], in->pitch[c], row, in->height[c]);
+    HBHIP_CHECK(ctx, hipGetLastError());
+    return HBHIP_OK;
+}
+
+// ------------------------------------------------------------------ filter classes
+class LapsharpFilter : public SimpleFilter
+{
+public:
+    LapsharpFilter(hbhip_ctx *c, const hbhip_lapsharp_params &p) : SimpleFilter(c), par(p) {}
+    int process(DevPicture *in, DevPicture *out) override
+    {
+        for (int c = 0; c < 3; c++)
+        {
+            const LapKernel &k = LAP_TABLE[par.kernel[c]];
+            LapArgs a;
+            a.src = in->plane[c]; a.dst = out->plane[c];
+            a.width = in->width[c]; a.height = in->height[c];
+            a.src_pitch = in->pitch[c]; a.dst_pitch = out->pitch[c];
+            a.stride_border = (in_stride[c] - in->width[c]) / 2;
+            for (int i = 0; i < 25; i++) a.tap[i] = k.tap[i];
+            a.coef = k.coef; a.strength = par.strength[c];
+            dim3 grid(((a.width + 3) / 4 + 255) / 256, a.height), block(256);
+            if (k.size == 3)
+                HBHIP_LAUNCH(ctx, "lapsharp_3x3", lapsharp_kernel<3>, grid, block, 0, a);
+            else
+                HBHIP_LAUNCH(ctx, "lapsharp_5x5", lapsharp_kernel<5>, grid, block, 0, a);
+            HBHIP_CHECK(ctx, hipGetLastError());
+        }
+        return HBHIP_OK;
+    }
+    hbhip_lapsharp_params par;
+};
+
+class BlurMixFilter : public SimpleFilter
+{
+public:
+    BlurMixFilter(hbhip_ctx *c, const hbhip_blur_params &p, int sign_, int vmin_, int vmax_, const char *nm)
+        : SimpleFilter(c), par(p), sign(sign_), vmin(vmin_), vmax(vmax_), name(nm) {}
+    int process(DevPicture *in, DevPicture *out) override
+    {
+        for (int c = 0; c < 3; c++)
+        {
+            const int amount = par.amount[c];
+            if (!amount)
+            {
+                int rc = launch_copy(ctx, "plane_copy", in, out, c);    // unsharp.c:111-115
+                if (rc != HBHIP_OK) return rc;
+                continue;
+            }
+            BlurArgs a;
+            a.src = in->plane[c]; a.dst = out->plane[c];
+            a.width = in->width[c]; a.height = in->height[c];
+            a.src_pitch = in->pitch[c]; a.dst_pitch = out->pitch[c];
+            a.steps = par.size[c] / 2;
+            a.scalebits = a.steps * 4;
+            a.halfscale = 1 << (a.scalebits - 1);
+            a.amount = amount;
+            a.sign = sign; a.vmin = vmin; a.vmax = vmax;
+            // binomial row of order 2*steps
+            uint32_t row[2 * MAX_STEPS + 1] = {1};
+            for (int n = 1; n <= 2 * a.steps; n++)
+            {
+                row[n] = 1;
+                for (int k = n - 1; k >= 1; k--) row[k] += row[k - 1];
+            }
+            for (int i = 0; i <= 2 * MAX_STEPS; i++) a.coef[i] = i <= 2 * a.steps ? row[i] : 0;
+            dim3 grid((a.width + BT_W - 1) / BT_W, (a.height + BT_H - 1) / BT_H), block(256);
+            HBHIP_LAUNCH(ctx, name, blur_mix_kernel, grid, block, 0, a);
+            HBHIP_CHECK(ctx, hipGetLastError());
+        }
+        return HBHIP_OK;
+    }
+    hbhip_blur_params par;
+    int sign, vmin, vmax;
+    const char *name;
+};
+
+template <class F, class... A>
+int create_simple(hbhip_ctx *ctx, int width, int height, int depth, int lcw, int lch, hbhip_filter **out, A &&...args)
+{
+    if (!ctx || !out) return HBHIP_ERR_ARG;
+    *out = nullptr;
+    if (depth != 8) return HBHIP_ERR_UNSUPPORTED;
+    if (width < 1 || height < 1) return HBHIP_ERR_ARG;
+    (void)hipSetDevice(ctx->device);
+    F *f = new (std::nothrow) F(ctx, std::forward<A>(args)...);
+    if (!f) return HBHIP_ERR_NOMEM;
+    PicGeometry g;
+    g.set(width, height, depth, lcw, lch);
+    f->configure(g, g);
+    *out = f;
+    return HBHIP_OK;
+}
+
+} // namespace
+
+extern "C" int hbhip_lapsharp_create(hbhip_ctx *ctx, const hbhip_lapsharp_params *p, int width, int height,
+                                     int depth, int log2_chroma_w, int log2_chroma_h, hbhip_filter **out)
+{
+    if (!p) return HBHIP_ERR_ARG;
+    for (int c = 0; c < 3; c++)
+        if (p->kernel[c] < 0 || p->kernel[c] > 3) return HBHIP_ERR_ARG;
+    return create_simple<LapsharpFilter>(ctx, width, height, depth, log2_chroma_w, log2_chroma_h, out, *p);
+}
+
+static int check_blur(const hbhip_blur_params *p)
+{
+    if (!p) return HBHIP_ERR_ARG;
+    for (int c = 0; c < 3; c++)
+        if (p->amount[c] != 0 && (p->size[c] < 3 || p->size[c] > 15 || !(p->size[c] & 1))) return HBHIP_ERR_ARG;
+    return HBHIP_OK;
+}
+
+extern "C" int hbhip_unsharp_create(hbhip_ctx *ctx, const hbhip_blur_params *p, int width, int height,
+                                    int depth, int log2_chroma_w, int log2_chroma_h, hbhip_filter **out)
+{
+    int rc = check_blur(p);
+    if (rc != HBHIP_OK) return rc;
+    return create_simple<BlurMixFilter>(ctx, width, height, depth, log2_chroma_w, log2_chroma_h, out,
+                                        *p, +1, 0, 255, "unsharp_blur_mix");
+}
+
+extern "C" int hbhip_chroma_smooth_create(hbhip_ctx *ctx, const hbhip_blur_params *p, int width, int height,
+                                          int depth, int log2_chroma_w, int log2_chroma_h, hbhip_filter **out)
+{
+    int rc = check_blur(p);
+    if (rc != HBHIP_OK) return rc;
+    // clamp range max/16 .. max - max/16 for 8-bit (chroma_smooth.c:233-235)
+    return create_simple<BlurMixFilter>(ctx, width, height, depth, log2_chroma_w, log2_chroma_h, out,
+                                        *p, -1, 16, 240, "chroma_smooth_blur_mix");
+}

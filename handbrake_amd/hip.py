@@ -22,6 +22,7 @@ ABI_SYMBOLS = [
     "hbhip_filter_push", "hbhip_filter_push_dev", "hbhip_filter_pull", "hbhip_filter_pull_dev",
     "hbhip_filter_process_dev", "hbhip_filter_flush", "hbhip_filter_pending", "hbhip_filter_destroy",
     "hbhip_filter_out_geometry", "hbhip_nlmeans_create", "hbhip_nlmeans_set_batch",
+    "hbhip_lapsharp_create", "hbhip_unsharp_create", "hbhip_chroma_smooth_create",
 ]
 
 

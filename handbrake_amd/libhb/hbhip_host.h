@@ -39,9 +39,19 @@ static inline hb_buffer_t *hbhip_host_alloc_out(const hb_filter_init_t *o, int w
     return out;
 }
 
+/* Shared body of the stateless (one in, one out) HIP filters: EOF is forwarded
+ * (e.g. lapsharp.c:326-331), otherwise the frame goes through the device filter
+ * and comes back in a fresh hb_frame_buffer_init() buffer carrying the input's
+ * properties (lapsharp.c:334-353). */
+int hbhip_host_simple_work(hbhip_filter *dev, const hb_filter_init_t *output, const char *who,
+                           hb_buffer_t **buf_in, hb_buffer_t **buf_out);
+
 /* The HIP drop-ins registered by this library (ids = the CPU filters' ids,
  * SURVEY Appendix D). */
 extern hb_filter_object_t hb_filter_nlmeans_hip;
+extern hb_filter_object_t hb_filter_lapsharp_hip;
+extern hb_filter_object_t hb_filter_unsharp_hip;
+extern hb_filter_object_t hb_filter_chroma_smooth_hip;
 
 void hbhip_nlmeans_params_from_settings(const char *settings, int depth, hbhip_nlmeans_params *p);
 

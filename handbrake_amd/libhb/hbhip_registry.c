@@ -59,7 +59,10 @@ hb_filter_object_t *hbhip_filter_get(int filter_id)
 {
     switch (filter_id)
     {
-        case HB_FILTER_NLMEANS: return &hb_filter_nlmeans_hip;
+        case HB_FILTER_NLMEANS:       return &hb_filter_nlmeans_hip;
+        case HB_FILTER_LAPSHARP:      return &hb_filter_lapsharp_hip;
+        case HB_FILTER_UNSHARP:       return &hb_filter_unsharp_hip;
+        case HB_FILTER_CHROMA_SMOOTH: return &hb_filter_chroma_smooth_hip;
         default:                return NULL;
     }
 }
@@ -68,4 +71,38 @@ hb_filter_object_t *hbhip_filter_get(int filter_id)
 void *hbhip_host_ctx_ptr(void)
 {
     return hbhip_host_ctx();
+}
+
+int hbhip_host_simple_work(hbhip_filter *dev, const hb_filter_init_t *output, const char *who,
+                           hb_buffer_t **buf_in, hb_buffer_t **buf_out)
+{
+    hb_buffer_t *in = *buf_in;
+    if (in->s.flags & HB_BUF_FLAG_EOF)
+    {
+        *buf_out = in;
+        *buf_in = NULL;
+        return HB_FILTER_DONE;
+    }
+    int ow = in->f.width, oh = in->f.height;
+    hbhip_filter_out_geometry(dev, &ow, &oh);
+    hb_buffer_t *out = hbhip_host_alloc_out(output, ow, oh);
+    if (out == NULL)
+        return HB_FILTER_FAILED;
+
+    hbhip_host_frame fin, fout;
+    hbhip_host_frame_from_buf(&fin, in);
+    hbhip_host_frame_from_buf(&fout, out);
+    int64_t tag;
+    int rc = hbhip_filter_push(dev, &fin, 0);
+    if (rc == HBHIP_OK)
+        rc = hbhip_filter_pull(dev, &fout, &tag);
+    if (rc != HBHIP_OK)
+    {
+        hb_error("%s(hip): %s", who, hbhip_strerror(rc));
+        hb_buffer_close(&out);
+        return HB_FILTER_FAILED;
+    }
+    hb_buffer_copy_props(out, in);
+    *buf_out = out;
+    return HB_FILTER_OK;
 }

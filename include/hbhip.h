@@ -136,6 +136,27 @@ int hbhip_nlmeans_create(hbhip_ctx *ctx, const hbhip_nlmeans_params *p,
 /* Max frames processed per kernel launch when several are queued (default 8). */
 int hbhip_nlmeans_set_batch(hbhip_filter *f, int frames);
 
+/* ---- Lapsharp  (replaces lapsharp_8, lapsharp.c:125-182) ------------------------ */
+typedef struct hbhip_lapsharp_params
+{
+    double strength[3];   /* sanitised 0..1.5 (lapsharp.c:304-305)                         */
+    int    kernel[3];     /* 0 lap, 1 isolap, 2 log, 3 isolog (lapsharp.c:80-86)           */
+} hbhip_lapsharp_params;
+int hbhip_lapsharp_create(hbhip_ctx *ctx, const hbhip_lapsharp_params *p, int width, int height,
+                          int depth, int log2_chroma_w, int log2_chroma_h, hbhip_filter **out);
+
+/* ---- Unsharp / chroma smooth (replace unsharp_8 unsharp.c:89-173 and
+ *      chroma_smooth_8 chroma_smooth.c:87-172) ------------------------------------- */
+typedef struct hbhip_blur_params
+{
+    int amount[3];        /* (int)(strength * 65536.0); 0 = plane is copied (unsharp.c:258) */
+    int size[3];          /* odd 3..15 (unsharp.c:251-254)                                 */
+} hbhip_blur_params;
+int hbhip_unsharp_create(hbhip_ctx *ctx, const hbhip_blur_params *p, int width, int height,
+                         int depth, int log2_chroma_w, int log2_chroma_h, hbhip_filter **out);
+int hbhip_chroma_smooth_create(hbhip_ctx *ctx, const hbhip_blur_params *p, int width, int height,
+                               int depth, int log2_chroma_w, int log2_chroma_h, hbhip_filter **out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -68,6 +68,26 @@ void orc_nlmeans_plane(const uint8_t *const *frames, const uint8_t *const *frame
                        const orc_nlmeans_params_t *p,
                        uint8_t *dst, int dst_stride);
 
+/* ---- Lapsharp (lapsharp.c) ---------------------------------------------------- */
+
+/* lapsharp_8 (lapsharp.c:125-182): one plane.  kernel: 0 lap, 1 isolap, 2 log,
+ * 3 isolog (tables at lapsharp.c:37-86).  src_stride participates in the edge
+ * rule through stride_border = (stride - width) / 2 (:145). */
+void orc_lapsharp_plane(const uint8_t *src, uint8_t *dst, int width, int height,
+                        int src_stride, int dst_stride, double strength, int kernel);
+
+/* ---- Unsharp / chroma smooth (unsharp.c, chroma_smooth.c) ---------------------- */
+
+/* unsharp_8 (unsharp.c:89-173).  size is the (odd, 3..15) blur width, strength
+ * the user strength; amount/steps/scalebits/halfscale derive as unsharp.c:256-261. */
+void orc_unsharp_plane(const uint8_t *src, uint8_t *dst, int width, int height,
+                       int src_stride, int dst_stride, double strength, int size);
+
+/* chroma_smooth_8 (chroma_smooth.c:87-172) for a CHROMA plane (luma is a plain
+ * copy, chroma_smooth.c:262-269); clamps to [16,240] (:233-235). */
+void orc_chroma_smooth_plane(const uint8_t *src, uint8_t *dst, int width, int height,
+                             int src_stride, int dst_stride, double strength, int size);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,14 @@ def nlm(strength=6, origin_tune=1.0, patch=7, rng=3, nframes=2, prefilter=0):
                 nframes=nframes, prefilter=prefilter)
 
 
+def lap(strength=0.2, kernel="isolap"):
+    return dict(strength=strength, kernel=kernel)
+
+
+def blur(strength=0.25, size=7):
+    return dict(strength=strength, size=size)
+
+
 # name -> case.  `chain` = [(reference filter object symbol, settings)], `hip` = the drop-in symbols.
 CASES = {
     "nlmeans_medium_96x64": dict(model="progressive", w=96, h=64, n=4,
@@ -29,4 +37,24 @@ CASES = {
                                           hip=[("hb_filter_nlmeans_hip", NLM_ANIM_LIGHT)],
                                           orc=[("nlmeans", [nlm(3, 0.15, 5, 7, 3), nlm(2.25, 0.15, 5, 7, 3),
                                                             nlm(2.25, 0.15, 5, 7, 3)])]),
+    "lapsharp_medium_134x70": dict(model="progressive", w=134, h=70, n=2,
+                                   chain=[("hb_filter_lapsharp", "y-strength=0.2:y-kernel=isolap:cb-strength=0.2:cb-kernel=isolap")],
+                                   hip=[("hb_filter_lapsharp_hip", "y-strength=0.2:y-kernel=isolap:cb-strength=0.2:cb-kernel=isolap")],
+                                   orc=[("lapsharp", [lap(), lap(), lap()])]),
+    "lapsharp_isolog_strong_128x64": dict(model="random", w=128, h=64, n=2,
+                                          chain=[("hb_filter_lapsharp", "y-strength=1.3:y-kernel=isolog:cb-strength=0.6:cb-kernel=log")],
+                                          hip=[("hb_filter_lapsharp_hip", "y-strength=1.3:y-kernel=isolog:cb-strength=0.6:cb-kernel=log")],
+                                          orc=[("lapsharp", [lap(1.3, "isolog"), lap(0.6, "log"), lap(0.6, "log")])]),
+    "unsharp_medium_134x70": dict(model="progressive", w=134, h=70, n=2,
+                                  chain=[("hb_filter_unsharp", "y-strength=0.25:y-size=7:cb-strength=0.25:cb-size=7")],
+                                  hip=[("hb_filter_unsharp_hip", "y-strength=0.25:y-size=7:cb-strength=0.25:cb-size=7")],
+                                  orc=[("unsharp", [blur(), blur(), blur()])]),
+    "unsharp_size15_96x64": dict(model="random", w=96, h=64, n=1,
+                                 chain=[("hb_filter_unsharp", "y-strength=1.5:y-size=15:cb-strength=0.8:cb-size=3")],
+                                 hip=[("hb_filter_unsharp_hip", "y-strength=1.5:y-size=15:cb-strength=0.8:cb-size=3")],
+                                 orc=[("unsharp", [blur(1.5, 15), blur(0.8, 3), blur(0.8, 3)])]),
+    "chroma_smooth_medium_134x70": dict(model="random", w=134, h=70, n=2,
+                                        chain=[("hb_filter_chroma_smooth", "cb-strength=0.6:cb-size=7")],
+                                        hip=[("hb_filter_chroma_smooth_hip", "cb-strength=0.6:cb-size=7")],
+                                        orc=[("chroma_smooth", [blur(0.6, 7), blur(0.6, 7)])]),
 }

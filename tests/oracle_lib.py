@@ -88,3 +88,51 @@ def ref_nlmeans_plane(settings: str, c: int, planes, force_scalar=False):
                                    keep[0].strides[0], u8p(dst), w, int(force_scalar))
     assert rc == 0
     return dst
+
+
+# ---------------------------------------------------------------- sharpen family
+def hb_stride(width: int) -> int:
+    """hb_image_stride for 8-bit planes (handbrake/internal.h:220-228)."""
+    return (width + 63) // 64 * 64
+
+
+def padded(plane: np.ndarray) -> np.ndarray:
+    """Plane as libhb stores it: rows at a 64-byte-multiple stride, zero padding
+    (what the harness's calloc'd hb_frame_buffer_init gives the reference)."""
+    h, w = plane.shape
+    buf = np.zeros((h, hb_stride(w)), np.uint8)
+    buf[:, :w] = plane
+    return buf
+
+
+LAPSHARP_KERNELS = {"lap": 0, "isolap": 1, "log": 2, "isolog": 3}
+
+
+def orc_lapsharp_plane(plane, strength=0.2, kernel="isolap"):
+    h, w = plane.shape
+    src = padded(plane)
+    dst = np.zeros_like(src)
+    fn = oracle().orc_lapsharp_plane
+    fn.argtypes = [C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_int,
+                   C.c_double, C.c_int]
+    fn(u8p(src), u8p(dst), w, h, src.strides[0], dst.strides[0], strength, LAPSHARP_KERNELS[kernel])
+    return dst[:, :w].copy()
+
+
+def _blur(fn_name, plane, strength, size):
+    h, w = plane.shape
+    src = padded(plane)
+    dst = np.zeros_like(src)
+    fn = getattr(oracle(), fn_name)
+    fn.argtypes = [C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_int,
+                   C.c_double, C.c_int]
+    fn(u8p(src), u8p(dst), w, h, src.strides[0], dst.strides[0], strength, size)
+    return dst[:, :w].copy()
+
+
+def orc_unsharp_plane(plane, strength=0.25, size=7):
+    return _blur("orc_unsharp_plane", plane, strength, size)
+
+
+def orc_chroma_smooth_plane(plane, strength=0.25, size=7):
+    return _blur("orc_chroma_smooth_plane", plane, strength, size)

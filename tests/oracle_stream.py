@@ -43,3 +43,25 @@ def load_golden(path):
     frames = [tuple(z[f"f{t}_p{c}"] for c in range(3)) for t in range(n)]
     meta = [z[f"f{t}_meta"] for t in range(n)]
     return frames, meta
+
+
+def lapsharp_stream(frames, par):
+    """par: 3 dicts {strength, kernel}."""
+    return [tuple(ol.orc_lapsharp_plane(fr[c], par[c]["strength"], par[c]["kernel"]) for c in range(3))
+            for fr in frames]
+
+
+def unsharp_stream(frames, par):
+    """par: 3 dicts {strength, size}."""
+    return [tuple(ol.orc_unsharp_plane(fr[c], par[c]["strength"], par[c]["size"]) for c in range(3))
+            for fr in frames]
+
+
+def chroma_smooth_stream(frames, par):
+    """par: dict {strength, size} for cb and cr (list of 2)."""
+    return [(fr[0].copy(),) + tuple(ol.orc_chroma_smooth_plane(fr[c], par[c - 1]["strength"], par[c - 1]["size"])
+                                    for c in (1, 2)) for fr in frames]
+
+
+STREAMS.update({"lapsharp": lapsharp_stream, "unsharp": unsharp_stream,
+                "chroma_smooth": chroma_smooth_stream})

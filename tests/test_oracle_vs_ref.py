@@ -75,3 +75,38 @@ def test_nlmeans_with_prefilter_matches_reference(built):
         want = ol.ref_nlmeans_plane(nlm_settings(6, 1, 7, 3, 2, pf), 0, planes)
         got = ol.orc_nlmeans_plane(planes, 6, 1.0, 7, 3, pf)
         np.testing.assert_array_equal(got, want)
+
+
+# ---------------------------------------------------------------- sharpen family
+from handbrake_amd import hbrt  # noqa: E402
+import oracle_stream as os_  # noqa: E402
+
+
+def _eq_stream(got, want):
+    assert len(got) == len(want)
+    for t in range(len(want)):
+        for c in range(3):
+            np.testing.assert_array_equal(got[t].planes[c], want[t][c], err_msg=f"frame {t} plane {c}")
+
+
+@needs_ref
+@pytest.mark.parametrize("w,h", [(128, 72), (638, 362), (70, 50)])
+@pytest.mark.parametrize("kern", ["lap", "isolap", "log", "isolog"])
+def test_lapsharp_matches_reference(built, w, h, kern):
+    frames = synth.stream("progressive", w, h, 2)
+    got = hbrt.run_stream(ol.ref(), [("hb_filter_lapsharp", f"y-strength=0.2:y-kernel={kern}:cb-strength=0.7:cb-kernel={kern}")], frames)
+    want = os_.lapsharp_stream(frames, [dict(strength=0.2, kernel=kern)] + [dict(strength=0.7, kernel=kern)] * 2)
+    _eq_stream(got, want)
+
+
+@needs_ref
+@pytest.mark.parametrize("w,h", [(128, 72), (638, 362)])
+@pytest.mark.parametrize("size", [3, 7, 13, 15])
+def test_unsharp_and_chroma_smooth_match_reference(built, w, h, size):
+    frames = synth.stream("random", w, h, 2)
+    got = hbrt.run_stream(ol.ref(), [("hb_filter_unsharp", f"y-strength=0.25:y-size={size}:cb-strength=1.2:cb-size={size}")], frames)
+    want = os_.unsharp_stream(frames, [dict(strength=0.25, size=size)] + [dict(strength=1.2, size=size)] * 2)
+    _eq_stream(got, want)
+    got = hbrt.run_stream(ol.ref(), [("hb_filter_chroma_smooth", f"cb-strength=1.2:cb-size={size}")], frames)
+    want = os_.chroma_smooth_stream(frames, [dict(strength=1.2, size=size)] * 2)
+    _eq_stream(got, want)
