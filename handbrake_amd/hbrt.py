@@ -170,13 +170,15 @@ class Chain:
 
 
 def run_stream(lib, stages, frames, flags: int = 0x10, pix_fmt: int = AV_PIX_FMT_YUV420P,
-               duration: int = 3003):
-    """Push every frame then EOF; return all OutFrames in output order."""
+               duration: int = 3003, combed=None):
+    """Push every frame then EOF; return all OutFrames in output order.
+    combed: optional per-frame HB_COMB_* values stamped on the input buffers."""
     h, w = frames[0][0].shape
     out = []
     with Chain(lib, stages, w, h, pix_fmt) as ch:
         for i, fr in enumerate(frames):
-            ch.push(fr, start=i * duration, stop=(i + 1) * duration, flags=flags)
+            ch.push(fr, start=i * duration, stop=(i + 1) * duration, flags=flags,
+                    combed=0 if combed is None else combed[i])
             out += ch.drain()
         ch.push_eof()
         out += ch.drain()

@@ -1,0 +1,221 @@
+/* comb_detect_oracle.c — CPU restatement of libhb's comb detection (8-bit luma).
+ * TEST INFRASTRUCTURE ONLY (see oracle.h).
+ *
+ * Follows /root/reference/libhb/comb_detect.c and templates/comb_detect_template.c:
+ *   template :288-402  gamma detect      template :789-933  integer detect
+ *   comb_detect.c :901-966 mask filter   :726-792 erode   :556-622 dilate
+ *   :221-276 / :384-454 block scoring    :1029-1049 classification
+ *   :1051-1072 pass order                :1074-1081 gamma LUT, :1151-1161 thresholds
+ * The reference splits every pass into row segments per CPU; none of the results
+ * depends on the split (each pass reads a finished buffer, block rows start at
+ * multiples of block_height in every segment), so whole planes are walked.
+ *
+ * Quirk kept on purpose: the three 3x3 mask passes take their row pointers at
+ * column 1 and then index columns 1..width-2 from there (comb_detect.c:939-947),
+ * i.e. they produce columns 2..width-1 and read column `width`, which is the
+ * stride padding or — when stride == width — the first pixel of the next row.
+ */
+#include "oracle.h"
+
+#include <math.h>
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
+
+struct orc_comb
+{
+    orc_comb_params_t p;
+    int width, height, stride;
+    uint8_t *mask, *mask_filtered, *mask_temp;
+    float lut[256];
+    float g_mthresh, g_athresh, g_athresh6;
+    int athresh_sq, athresh6, c32_min, c32_max;
+};
+
+orc_comb_t *orc_comb_new(int width, int height, const orc_comb_params_t *p)
+{
+    orc_comb_t *c = calloc(1, sizeof(*c));
+    c->p = *p;
+    if (c->p.block_width > width)   c->p.block_width = width;       /* :1139-1146 */
+    if (c->p.block_height > height) c->p.block_height = height;
+    c->width = width;
+    c->height = height;
+    c->stride = (width + 63) / 64 * 64;
+    /* +64: the reference's buffers carry AV_INPUT_BUFFER_PADDING_SIZE after the plane */
+    c->mask          = calloc((size_t)c->stride * height + 64, 1);
+    c->mask_filtered = calloc((size_t)c->stride * height + 64, 1);
+    c->mask_temp     = calloc((size_t)c->stride * height + 64, 1);
+    for (int i = 0; i < 256; i++)
+        c->lut[i] = pow(((float)i / (float)255), 2.2f);            /* :1074-1081 */
+    c->g_mthresh  = (float)c->p.motion_threshold / (float)255;     /* :1153-1155 */
+    c->g_athresh  = (float)c->p.spatial_threshold / (float)255;
+    c->g_athresh6 = 6 * c->g_athresh;
+    c->athresh_sq = c->p.spatial_threshold * c->p.spatial_threshold;
+    c->athresh6   = 6 * c->p.spatial_threshold;
+    c->c32_min = 10;
+    c->c32_max = 15;
+    return c;
+}
+
+void orc_comb_free(orc_comb_t *c)
+{
+    if (!c) return;
+    free(c->mask); free(c->mask_filtered); free(c->mask_temp);
+    free(c);
+}
+
+const uint8_t *orc_comb_mask(orc_comb_t *c, int which, int *stride)
+{
+    if (stride) *stride = c->stride;
+    return which == 0 ? c->mask : which == 1 ? c->mask_filtered : c->mask_temp;
+}
+
+/* template :288-402 (gamma) and :789-933 (integer) */
+static void detect(orc_comb_t *c, const uint8_t *prev, const uint8_t *cur, const uint8_t *next,
+                   int stride, int force)
+{
+    const int gamma = c->p.mode & 1;
+    for (int y = 2; y < c->height - 2; y++)
+    {
+        const uint8_t *pr = prev + (size_t)y * stride, *cu = cur + (size_t)y * stride, *nx = next + (size_t)y * stride;
+        uint8_t *m = c->mask + (size_t)y * c->stride;
+        memset(m, 0, c->stride);
+        for (int x = 0; x < c->width; x++)
+        {
+            const int v = cu[x], u1 = cu[x - stride], d1 = cu[x + stride];
+            const int u2 = cu[x - 2 * stride], d2 = cu[x + 2 * stride];
+            if (gamma)
+            {
+                const float *L = c->lut;
+                const float up = L[v] - L[u1], dn = L[v] - L[d1];
+                if (!((up > c->g_athresh && dn > c->g_athresh) || (up < -c->g_athresh && dn < -c->g_athresh)))
+                    continue;
+                int motion = 0;
+                if (c->g_mthresh > 0)
+                {
+                    if (fabs(L[pr[x]] - L[v]) > c->g_mthresh &&
+                        fabs(L[u1] - L[nx[x - stride]]) > c->g_mthresh &&
+                        fabs(L[d1] - L[nx[x + stride]]) > c->g_mthresh)
+                        motion++;
+                    if (fabs(L[nx[x]] - L[v]) > c->g_mthresh &&
+                        fabs(L[pr[x - stride]] - L[u1]) > c->g_mthresh &&
+                        fabs(L[pr[x + stride]] - L[d1]) > c->g_mthresh)
+                        motion++;
+                }
+                else
+                    motion = 1;
+                if (motion || force)
+                {
+                    const float combing = fabs(L[u2] + (4 * L[v]) + L[d2] - (3 * (L[u1] + L[d1])));
+                    if (combing > c->g_athresh6)
+                        m[x] = 1;
+                }
+            }
+            else
+            {
+                const int at = c->p.spatial_threshold, mt = c->p.motion_threshold;
+                const int up = v - u1, dn = v - d1;
+                if (!((up > at && dn > at) || (up < -at && dn < -at)))
+                    continue;
+                int motion = 0;
+                if (mt > 0)
+                {
+                    if (abs(pr[x] - v) > mt && abs(u1 - nx[x - stride]) > mt && abs(d1 - nx[x + stride]) > mt)
+                        motion++;
+                    if (abs(nx[x] - v) > mt && abs(pr[x - stride] - u1) > mt && abs(pr[x + stride] - d1) > mt)
+                        motion++;
+                }
+                else
+                    motion = 1;
+                if (!(motion || force))
+                    continue;
+                if (c->p.spatial_metric == 0)
+                {
+                    if (abs(v - d2) < c->c32_min && abs(v - d1) > c->c32_max) m[x] = 1;
+                }
+                else if (c->p.spatial_metric == 1)
+                {
+                    if ((u1 - v) * (d1 - v) > c->athresh_sq) m[x] = 1;
+                }
+                else if (c->p.spatial_metric == 2)
+                {
+                    if (abs(u2 + 4 * v + d2 - 3 * (u1 + d1)) > c->athresh6) m[x] = 1;
+                }
+            }
+        }
+    }
+}
+
+/* The shared frame of the three 3x3 passes: rows 1..height-2, source/destination
+ * pointers offset by one column (see the file comment). op: 0 filter, 1 erode, 2 dilate */
+static void mask_pass(const orc_comb_t *c, const uint8_t *src, uint8_t *dst, int op)
+{
+    const int st = c->stride;
+    for (int y = 1; y < c->height - 1; y++)
+    {
+        const uint8_t *p = src + (size_t)(y - 1) * st + 1, *q = src + (size_t)y * st + 1,
+                      *n = src + (size_t)(y + 1) * st + 1;
+        uint8_t *o = dst + (size_t)y * st + 1;
+        for (int x = 1; x < c->width - 1; x++)
+        {
+            if (op == 0)
+            {
+                const int hc = q[x - 1] & q[x] & q[x + 1];
+                const int vc = p[x] & q[x] & n[x];
+                o[x] = c->p.filter_mode == 1 ? hc : (hc & vc);
+                continue;
+            }
+            const int count = p[x - 1] + p[x] + p[x + 1] + q[x - 1] + q[x + 1] + n[x - 1] + n[x] + n[x + 1];
+            if (op == 1) o[x] = q[x] == 0 ? 0 : count >= 2;      /* erosion threshold 2, :734 */
+            else         o[x] = q[x] ? 1 : count >= 4;           /* dilation threshold 4, :564 */
+        }
+    }
+}
+
+/* :221-276 and :384-454 folded with :1029-1049 */
+static int score_blocks(const orc_comb_t *c, int filtered)
+{
+    const int bw = c->p.block_width, bh = c->p.block_height, thr = c->p.block_threshold;
+    const uint8_t *m = filtered ? c->mask_filtered : c->mask;
+    int light = 0;
+    for (int y = 0; y + bh <= c->height; y += bh)
+        for (int x = 0; x < c->width - bw; x += bw)
+        {
+            int score = 0;
+            for (int by = 0; by < bh; by++)
+            {
+                const uint8_t *r = m + (size_t)(y + by) * c->stride + x;
+                for (int bx = 0; bx < bw; bx++)
+                {
+                    if (filtered)                         score += r[bx];
+                    else if (x + bx == 0)                 score += r[bx] & r[bx + 1];
+                    else if (x + bx == c->width - 1)      score += r[bx - 1] & r[bx];
+                    else                                  score += r[bx - 1] & r[bx] & r[bx + 1];
+                }
+            }
+            if (score > thr)       return 2;
+            if (score >= thr / 2)  light = 1;
+        }
+    return light;
+}
+
+int orc_comb_classify(orc_comb_t *c, const uint8_t *prev, const uint8_t *cur, const uint8_t *next,
+                      int stride, int force_exhaustive)
+{
+    detect(c, prev, cur, next, stride, force_exhaustive);
+    const int filt = (c->p.mode & 2) != 0;
+    if (filt)
+    {
+        if (c->p.filter_mode == 1)
+            mask_pass(c, c->mask, c->mask_filtered, 0);
+        else
+            mask_pass(c, c->mask, c->mask_temp, 0);
+        if (c->p.filter_mode == 2)
+        {
+            mask_pass(c, c->mask_temp, c->mask_filtered, 1);
+            mask_pass(c, c->mask_filtered, c->mask_temp, 2);
+            mask_pass(c, c->mask_temp, c->mask_filtered, 1);
+        }
+    }
+    return score_blocks(c, filt);
+}

@@ -88,6 +88,53 @@ void orc_unsharp_plane(const uint8_t *src, uint8_t *dst, int width, int height,
 void orc_chroma_smooth_plane(const uint8_t *src, uint8_t *dst, int width, int height,
                              int src_stride, int dst_stride, double strength, int size);
 
+/* ---- Decomb: yadif / blend / cubic (decomb.c, templates/decomb_template.c) ------- */
+
+#define ORC_DECOMB_YADIF      1
+#define ORC_DECOMB_BLEND      2
+#define ORC_DECOMB_CUBIC      4
+#define ORC_DECOMB_EEDI2      8
+#define ORC_DECOMB_BOB       16
+#define ORC_DECOMB_SELECTIVE 32
+
+/* One plane of filter_8 + yadif_decomb_filter_work_8 (decomb_template.c:714-898)
+ * for an already resolved per-frame `mode` (the value filter_8 computes at
+ * :820-833: 0, BLEND, or pv->mode & ~SELECTIVE).  prev/cur/next are the ref[0..2]
+ * planes (common `stride`), `guess` the EEDI2 full-plane prediction (may be NULL
+ * unless mode has EEDI2), parity/tff as passed to pv->filter (decomb.c:539-552).
+ * Rows of the filtered parity are interpolated, the others copied from cur. */
+void orc_decomb_plane(const uint8_t *prev, const uint8_t *cur, const uint8_t *next, int stride,
+                      const uint8_t *guess, int guess_stride,
+                      uint8_t *dst, int dst_stride, int width, int height,
+                      int mode, int parity, int tff);
+
+/* ---- Comb detect (comb_detect.c, templates/comb_detect_template.c) -------------- */
+
+typedef struct
+{
+    int mode;               /* 1 gamma | 2 filter (4 mask / 8 composite overlays not restated) */
+    int spatial_metric;     /* 0,1,2 (non-gamma path only)                                     */
+    int motion_threshold;
+    int spatial_threshold;
+    int filter_mode;        /* 0, 1 classic, 2 erode/dilate                                    */
+    int block_threshold;
+    int block_width;
+    int block_height;
+} orc_comb_params_t;
+
+typedef struct orc_comb orc_comb_t;
+
+/* comb_detect_init's state that survives frames: three zero-initialised masks at
+ * hb_image_stride(GRAY8,width), gamma LUT, derived thresholds (comb_detect.c:1083-1190). */
+orc_comb_t *orc_comb_new(int width, int height, const orc_comb_params_t *p);
+void        orc_comb_free(orc_comb_t *c);
+/* comb_segmenter (comb_detect.c:1051-1072) on luma planes prev/cur/next (common
+ * stride): returns HB_COMB_NONE/LIGHT/HEAVY (0/1/2). */
+int         orc_comb_classify(orc_comb_t *c, const uint8_t *prev, const uint8_t *cur,
+                              const uint8_t *next, int stride, int force_exhaustive);
+/* which: 0 mask, 1 mask_filtered, 2 mask_temp; returns the plane, *stride set. */
+const uint8_t *orc_comb_mask(orc_comb_t *c, int which, int *stride);
+
 #ifdef __cplusplus
 }
 #endif

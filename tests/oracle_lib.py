@@ -136,3 +136,50 @@ def orc_unsharp_plane(plane, strength=0.25, size=7):
 
 def orc_chroma_smooth_plane(plane, strength=0.25, size=7):
     return _blur("orc_chroma_smooth_plane", plane, strength, size)
+
+
+# ---------------------------------------------------------------- decomb
+def orc_decomb_plane(prev, cur, nxt, mode, parity, tff, guess=None):
+    h, w = cur.shape
+    P, Cu, N = padded(prev), padded(cur), padded(nxt)
+    G = padded(guess) if guess is not None else None
+    dst = np.zeros_like(Cu)
+    fn = oracle().orc_decomb_plane
+    fn.argtypes = [C.POINTER(C.c_uint8)] * 3 + [C.c_int, C.POINTER(C.c_uint8), C.c_int,
+                                                C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int,
+                                                C.c_int, C.c_int, C.c_int]
+    fn(u8p(P), u8p(Cu), u8p(N), Cu.strides[0], u8p(G) if G is not None else None,
+       G.strides[0] if G is not None else 0, u8p(dst), dst.strides[0], w, h, mode, parity, tff)
+    return dst[:, :w].copy()
+
+
+# ---------------------------------------------------------------- comb detect
+class CombParams(C.Structure):
+    _fields_ = [("mode", C.c_int), ("spatial_metric", C.c_int), ("motion_threshold", C.c_int),
+                ("spatial_threshold", C.c_int), ("filter_mode", C.c_int), ("block_threshold", C.c_int),
+                ("block_width", C.c_int), ("block_height", C.c_int)]
+
+
+class OrcComb:
+    """orc_comb_t wrapper. Defaults = comb_detect.c:1118-1125."""
+
+    def __init__(self, width, height, mode=3, spatial_metric=2, motion_thresh=3, spatial_thresh=3,
+                 filter_mode=2, block_thresh=40, block_width=16, block_height=16):
+        lib = oracle()
+        lib.orc_comb_new.restype = C.c_void_p
+        lib.orc_comb_new.argtypes = [C.c_int, C.c_int, C.POINTER(CombParams)]
+        lib.orc_comb_classify.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint8)] * 3 + [C.c_int, C.c_int]
+        lib.orc_comb_free.argtypes = [C.c_void_p]
+        p = CombParams(mode, spatial_metric, motion_thresh, spatial_thresh, filter_mode,
+                       block_thresh, block_width, block_height)
+        self.h = lib.orc_comb_new(width, height, C.byref(p))
+        self.lib = lib
+
+    def classify(self, prev, cur, nxt, force):
+        P, Cu, N = padded(prev), padded(cur), padded(nxt)
+        return self.lib.orc_comb_classify(self.h, u8p(P), u8p(Cu), u8p(N), Cu.strides[0], int(force))
+
+    def close(self):
+        if self.h:
+            self.lib.orc_comb_free(self.h)
+            self.h = None

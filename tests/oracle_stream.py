@@ -65,3 +65,80 @@ def chroma_smooth_stream(frames, par):
 
 STREAMS.update({"lapsharp": lapsharp_stream, "unsharp": unsharp_stream,
                 "chroma_smooth": chroma_smooth_stream})
+
+
+# ---------------------------------------------------------------- decomb
+DECOMB_YADIF, DECOMB_BLEND, DECOMB_CUBIC, DECOMB_EEDI2, DECOMB_BOB, DECOMB_SELECTIVE = 1, 2, 4, 8, 16, 32
+PIC_FLAG_TOP_FIELD_FIRST, PIC_FLAG_PROGRESSIVE_FRAME = 0x0008, 0x0010
+
+
+def decomb_stream(frames, par, flags=PIC_FLAG_TOP_FIELD_FIRST, combed=None, duration=3003, eedi2=None):
+    """Whole-stream replay of hb_decomb_work / process_frame (decomb.c:495-612).
+
+    frames: list of (Y,Cb,Cr); par: dict(mode=..., parity=-1).  combed: per-frame
+    HB_COMB_* (only looked at in selective mode).  eedi2: callable
+    (cur_planes, tff_for_eedi2) -> 3 guess planes, required when mode has EEDI2.
+    Returns list of dict(planes, start, stop)."""
+    mode = par.get("mode", 7)
+    parity_opt = par.get("parity", -1)
+    n = len(frames)
+    out = []
+    if n == 0:
+        return out
+
+    def meta(i):
+        return dict(start=i * duration, stop=(i + 1) * duration,
+                    combed=0 if combed is None else combed[i])
+
+    def emit(i_prev, i_cur, i_next):
+        m = meta(i_cur)
+        if (mode & DECOMB_SELECTIVE) and m["combed"] == 0:
+            out.append(dict(planes=tuple(p.copy() for p in frames[i_cur]), **m))   # shallow dup
+            return
+        if parity_opt < 0:
+            tff = (1 if (flags & PIC_FLAG_TOP_FIELD_FIRST) else 0) if not (flags & PIC_FLAG_PROGRESSIVE_FRAME) else 1
+        else:
+            tff = (parity_opt & 1) ^ 1
+        is_combed = m["combed"] if (mode & DECOMB_SELECTIVE) else 2
+        if (mode & DECOMB_BLEND) and is_combed == 1:
+            fmode = DECOMB_BLEND
+        elif is_combed != 0:
+            fmode = mode & ~DECOMB_SELECTIVE
+        else:
+            fmode = 0
+        made = []
+        for frame in range(2 if (mode & DECOMB_BOB) else 1):
+            parity = frame ^ tff ^ 1
+            guess = [None, None, None]
+            if fmode & DECOMB_EEDI2:
+                guess = eedi2(frames[i_cur], 1 - parity)          # pv->tff = !parity (decomb.c:542)
+            planes = tuple(ol.orc_decomb_plane(frames[i_prev][c], frames[i_cur][c], frames[i_next][c],
+                                               fmode, parity, tff, guess[c]) for c in range(3))
+            made.append(dict(planes=planes, **m))
+        if mode & DECOMB_BOB:
+            first, second = made[0], made[-1]
+            first["stop"] -= (first["stop"] - first["start"]) // 2
+            second["start"] = first["stop"]
+        out.extend(made)
+
+    # first frame is stored twice and delays (decomb.c:597-605); EOF repeats the last (:584-589)
+    for t in range(1, n):
+        emit(max(t - 2, 0), t - 1, t)
+    emit(max(n - 2, 0), n - 1, n - 1)
+    return out
+
+
+# ---------------------------------------------------------------- comb detect
+def comb_detect_stream(frames, par):
+    """Per-frame HB_COMB_* as comb_detect_work assigns them (comb_detect.c:1499-1583):
+    frame t is classified from luma (t-1, t, t+1); the first and the last frame use
+    themselves as missing neighbour and force the exhaustive check."""
+    h, w = frames[0][0].shape
+    oc = ol.OrcComb(w, h, **par)
+    n = len(frames)
+    out = []
+    for t in range(n):
+        force = (t == 0) or (t == n - 1)
+        out.append(oc.classify(frames[max(t - 1, 0)][0], frames[t][0], frames[min(t + 1, n - 1)][0], force))
+    oc.close()
+    return out
