@@ -1,0 +1,328 @@
+// comb_detect.hip — comb detection for gfx950 (8-bit luma).
+//
+//   comb_detect_kernel     replaces detect_gamma_combed_segment_8 / detect_combed_segment_8
+//                          (libhb/templates/comb_detect_template.c:288-402, 789-933)
+//   comb_mask_pass_kernel  replaces mask_filter_work / mask_erode_work / mask_dilate_work
+//                          (libhb/comb_detect.c:901-966, 726-792, 556-622)
+//   comb_score_kernel      replaces check_filtered_combing_mask / check_combing_mask +
+//                          check_combing_results (comb_detect.c:221-276, 384-454, 1029-1049)
+//
+// The masks are kept in HBM exactly as the reference keeps them: one byte per
+// pixel at hb_image_stride(GRAY8, width) (= width rounded up to 64), rows
+// contiguous, because the 3x3 mask passes index from column 1 and therefore read
+// column `width` (comb_detect.c:939-947) — the stride padding, or the first byte of
+// the next row when stride == width.  All passes are HBM-bound byte streams; the
+// classification is reduced on the device to one int (atomicMax) and read back.
+#include "hbhip_internal.h"
+
+namespace {
+
+struct CombConst
+{
+    int   mode, spatial_metric, motion_threshold, spatial_threshold, filter_mode;
+    int   block_threshold, block_width, block_height;
+    float g_mthresh, g_athresh, g_athresh6;
+    int   athresh_sq, athresh6;
+};
+
+__global__ __launch_bounds__(256) void comb_detect_kernel(const uint8_t *__restrict__ prev,
+                                                          const uint8_t *__restrict__ cur,
+                                                          const uint8_t *__restrict__ next, int pitch,
+                                                          uint8_t *__restrict__ mask, int mask_stride,
+                                                          int width, int height, CombConst k,
+                                                          const float *__restrict__ lut_g, int force)
+{
+    __shared__ float L[256];
+    L[threadIdx.y * blockDim.x + threadIdx.x] = lut_g[threadIdx.y * blockDim.x + threadIdx.x];
+    __syncthreads();
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = 2 + blockIdx.y * blockDim.y + threadIdx.y;        // rows 2 .. height-3 (:312-319)
+    if (y >= height - 2 || x >= mask_stride) return;
+    uint8_t out = 0;                                                  // memset(mask, 0, mask_stride) (:342)
+    if (x < width)
+    {
+        const uint8_t *c = cur + (size_t)y * pitch + x;
+        const uint8_t *p = prev + (size_t)y * pitch + x;
+        const uint8_t *n = next + (size_t)y * pitch + x;
+        const int v = c[0], u1 = c[-pitch], d1 = c[pitch], u2 = c[-2 * pitch], d2 = c[2 * pitch];
+        if (k.mode & 1)
+        {
+            const float up = L[v] - L[u1], dn = L[v] - L[d1];
+            if ((up > k.g_athresh && dn > k.g_athresh) || (up < -k.g_athresh && dn < -k.g_athresh))
+            {
+                int motion = 0;
+                if (k.g_mthresh > 0)
+                {
+                    if (fabsf(L[p[0]] - L[v]) > k.g_mthresh && fabsf(L[u1] - L[n[-pitch]]) > k.g_mthresh &&
+                        fabsf(L[d1] - L[n[pitch]]) > k.g_mthresh)
+                        motion++;
+                    if (fabsf(L[n[0]] - L[v]) > k.g_mthresh && fabsf(L[p[-pitch]] - L[u1]) > k.g_mthresh &&
+                        fabsf(L[p[pitch]] - L[d1]) > k.g_mthresh)
+                        motion++;
+                }
+                else
+                    motion = 1;
+                if (motion || force)
+                {
+                    // (:382-386) same association as the reference, no contraction
+                    const float combing = fabsf(L[u2] + (4 * L[v]) + L[d2] - (3 * (L[u1] + L[d1])));
+                    if (combing > k.g_athresh6) out = 1;
+                }
+            }
+        }
+        else
+        {
+            const int at = k.spatial_threshold, mt = k.motion_threshold;
+            const int up = v - u1, dn = v - d1;
+            if ((up > at && dn > at) || (up < -at && dn < -at))
+            {
+                int motion = 0;
+                if (mt > 0)
+                {
+                    if (abs((int)p[0] - v) > mt && abs(u1 - (int)n[-pitch]) > mt && abs(d1 - (int)n[pitch]) > mt) motion++;
+                    if (abs((int)n[0] - v) > mt && abs((int)p[-pitch] - u1) > mt && abs((int)p[pitch] - d1) > mt) motion++;
+                }
+                else
+                    motion = 1;
+                if (motion || force)
+                {
+                    if (k.spatial_metric == 0)      { if (abs(v - d2) < 10 && abs(v - d1) > 15) out = 1; }
+                    else if (k.spatial_metric == 1) { if ((u1 - v) * (d1 - v) > k.athresh_sq) out = 1; }
+                    else if (k.spatial_metric == 2) { if (abs(u2 + 4 * v + d2 - 3 * (u1 + d1)) > k.athresh6) out = 1; }
+                }
+            }
+        }
+    }
+    mask[(size_t)y * mask_stride + x] = out;
+}
+
+// op 0: filter (classic -> h, else h&v), 1: erode (thr 2), 2: dilate (thr 4).
+// Row pointers start at column 1 and columns 1..width-2 are indexed from there.
+__global__ __launch_bounds__(256) void comb_mask_pass_kernel(const uint8_t *__restrict__ src,
+                                                             uint8_t *__restrict__ dst, int stride,
+                                                             int width, int height, int op, int classic)
+{
+    const int xx = 1 + blockIdx.x * blockDim.x + threadIdx.x;        // 1 .. width-2
+    const int y = 1 + blockIdx.y * blockDim.y + threadIdx.y;         // 1 .. height-2
+    if (xx >= width - 1 || y >= height - 1) return;
+    const uint8_t *q = src + (size_t)y * stride + 1 + xx;
+    const uint8_t *p = q - stride, *n = q + stride;
+    int r;
+    if (op == 0)
+    {
+        const int hc = q[-1] & q[0] & q[1];
+        const int vc = p[0] & q[0] & n[0];
+        r = classic ? hc : (hc & vc);
+    }
+    else
+    {
+        const int count = p[-1] + p[0] + p[1] + q[-1] + q[1] + n[-1] + n[0] + n[1];
+        r = op == 1 ? (q[0] == 0 ? 0 : count >= 2) : (q[0] ? 1 : count >= 4);
+    }
+    dst[(size_t)y * stride + 1 + xx] = (uint8_t)r;
+}
+
+// one wave per block_width x block_height block; result = max category seen
+__global__ __launch_bounds__(64) void comb_score_kernel(const uint8_t *__restrict__ mask, int stride,
+                                                        int width, int height, int bw, int bh, int thr,
+                                                        int filtered, int blocks_x, int *result)
+{
+    const int bx = blockIdx.x % blocks_x, by = blockIdx.x / blocks_x;
+    const int x0 = bx * bw, y0 = by * bh;
+    int score = 0;
+    for (int i = threadIdx.x; i < bw * bh; i += 64)
+    {
+        const int iy = i / bw, ix = i - iy * bw;
+        const uint8_t *r = mask + (size_t)(y0 + iy) * stride + x0 + ix;
+        const int xa = x0 + ix;
+        if (filtered)             score += r[0];
+        else if (xa == 0)         score += r[0] & r[1];
+        else if (xa == width - 1) score += r[-1] & r[0];
+        else                      score += r[-1] & r[0] & r[1];
+    }
+    for (int off = 32; off > 0; off >>= 1) score += __shfl_down(score, off, 64);
+    if (threadIdx.x == 0)
+    {
+        const int cat = score > thr ? 2 : (score >= thr / 2 ? 1 : 0);
+        if (cat) atomicMax(result, cat);
+    }
+}
+
+class CombDetectFilter : public hbhip_filter
+{
+public:
+    CombDetectFilter(hbhip_ctx *c, const hbhip_comb_detect_params &p) : hbhip_filter(c), par(p) {}
+    ~CombDetectFilter() override
+    {
+        for (int i = 0; i < 3; i++) if (luma_alloc[i]) (void)hipFree(luma_alloc[i]);
+        if (masks) (void)hipFree(masks);
+        if (d_lut) (void)hipFree(d_lut);
+        if (d_result) (void)hipFree(d_result);
+        if (h_result) (void)hipHostFree(h_result);
+    }
+
+    int setup(int w, int h)
+    {
+        width = w; height = h;
+        in_geo.set(w, h, 8, 1, 1);
+        out_geo = in_geo;
+        if (par.block_width > w) par.block_width = w;               // comb_detect.c:1139-1146
+        if (par.block_height > h) par.block_height = h;
+        if (par.block_width < 1 || par.block_height < 1) return HBHIP_ERR_ARG;
+        if (par.mode & ~3) return HBHIP_ERR_UNSUPPORTED;            // mask / composite overlays
+        if (h < 5 || w < 4) return HBHIP_ERR_UNSUPPORTED;
+        pitch = hbhip_align_up(w, 256);
+        mstride = hbhip_align_up(w, 64);                            // hb_image_stride(GRAY8, w)
+        for (int i = 0; i < 3; i++)
+        {
+            HBHIP_CHECK(ctx, hipMalloc((void **)&luma_alloc[i], (size_t)pitch * h));
+            slot[i] = -1;
+        }
+        const size_t msz = (size_t)mstride * h + 256;               // tail guard for the column-`width` reads
+        HBHIP_CHECK(ctx, hipMalloc((void **)&masks, 3 * msz));
+        HBHIP_CHECK(ctx, hipMemsetAsync(masks, 0, 3 * msz, ctx->stream));
+        mask = masks; mask_filtered = masks + msz; mask_temp = masks + 2 * msz;
+        HBHIP_CHECK(ctx, hipMalloc((void **)&d_lut, sizeof(float) * 256));
+        HBHIP_CHECK(ctx, hipMemcpyAsync(d_lut, par.gamma_lut, sizeof(float) * 256, hipMemcpyHostToDevice, ctx->stream));
+        HBHIP_CHECK(ctx, hipMalloc((void **)&d_result, sizeof(int)));
+        HBHIP_CHECK(ctx, hipHostMalloc((void **)&h_result, sizeof(int), hipHostMallocDefault));
+        HBHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        k.mode = par.mode; k.spatial_metric = par.spatial_metric;
+        k.motion_threshold = par.motion_threshold; k.spatial_threshold = par.spatial_threshold;
+        k.filter_mode = par.filter_mode; k.block_threshold = par.block_threshold;
+        k.block_width = par.block_width; k.block_height = par.block_height;
+        k.g_mthresh = (float)par.motion_threshold / (float)255;     // comb_detect.c:1153-1158
+        k.g_athresh = (float)par.spatial_threshold / (float)255;
+        k.g_athresh6 = 6 * k.g_athresh;
+        k.athresh_sq = par.spatial_threshold * par.spatial_threshold;
+        k.athresh6 = 6 * par.spatial_threshold;
+        return HBHIP_OK;
+    }
+
+    // ring of device luma planes: ref[i] -> which allocation
+    int store(const void *luma, int stride, bool device)
+    {
+        // rotate: the allocation that held ref[0] is reused unless ref[1]/ref[2] still point at it
+        int freed = ref[0];
+        ref[0] = ref[1]; ref[1] = ref[2];
+        if (luma == nullptr)
+        {
+            if (ref[2] < 0) return HBHIP_ERR_STATE;
+            return HBHIP_OK;                                          // ref[2] repeated
+        }
+        int use = -1;
+        for (int i = 0; i < 3 && use < 0; i++)
+            if (i != ref[0] && i != ref[1]) use = i;
+        (void)freed;
+        if (stride < width) return HBHIP_ERR_ARG;
+        HBHIP_CHECK(ctx, hipMemcpy2DAsync(luma_alloc[use], pitch, luma, stride, width, height,
+                                          device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+        if (!device) HBHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        ref[2] = use;
+        return HBHIP_OK;
+    }
+
+    int classify(int force, int *combed)
+    {
+        if (ref[0] < 0 || ref[1] < 0 || ref[2] < 0) return HBHIP_ERR_STATE;
+        dim3 b(64, 4);
+        dim3 g((mstride + 63) / 64, (height - 4 + 3) / 4);
+        HBHIP_LAUNCH(ctx, "comb_detect", comb_detect_kernel, g, b, 0, (const uint8_t *)luma_alloc[ref[0]],
+                     (const uint8_t *)luma_alloc[ref[1]], (const uint8_t *)luma_alloc[ref[2]], pitch, mask, mstride,
+                     width, height, k, (const float *)d_lut, force);
+        const bool filt = (par.mode & 2) != 0;
+        dim3 gm((width - 2 + 63) / 64, (height - 2 + 3) / 4);
+        if (filt)
+        {
+            if (par.filter_mode == 1)
+                HBHIP_LAUNCH(ctx, "comb_mask_filter", comb_mask_pass_kernel, gm, b, 0, (const uint8_t *)mask, mask_filtered, mstride, width, height, 0, 1);
+            else
+                HBHIP_LAUNCH(ctx, "comb_mask_filter", comb_mask_pass_kernel, gm, b, 0, (const uint8_t *)mask, mask_temp, mstride, width, height, 0, 0);
+            if (par.filter_mode == 2)
+            {
+                HBHIP_LAUNCH(ctx, "comb_mask_erode", comb_mask_pass_kernel, gm, b, 0, (const uint8_t *)mask_temp, mask_filtered, mstride, width, height, 1, 0);
+                HBHIP_LAUNCH(ctx, "comb_mask_dilate", comb_mask_pass_kernel, gm, b, 0, (const uint8_t *)mask_filtered, mask_temp, mstride, width, height, 2, 0);
+                HBHIP_LAUNCH(ctx, "comb_mask_erode", comb_mask_pass_kernel, gm, b, 0, (const uint8_t *)mask_temp, mask_filtered, mstride, width, height, 1, 0);
+            }
+        }
+        HBHIP_CHECK(ctx, hipMemsetAsync(d_result, 0, sizeof(int), ctx->stream));
+        const int bw = par.block_width, bh = par.block_height;
+        const int blocks_x = (width - bw + bw - 1) / bw;             // x = 0, bw, ... while x < width - bw
+        const int blocks_y = height / bh;                            // y + bh <= height
+        if (blocks_x > 0 && blocks_y > 0)
+        {
+            HBHIP_LAUNCH(ctx, "comb_block_score", comb_score_kernel, dim3(blocks_x * blocks_y), dim3(64), 0,
+                         (const uint8_t *)(filt ? mask_filtered : mask), mstride, width, height, bw, bh,
+                         par.block_threshold, filt ? 1 : 0, blocks_x, d_result);
+        }
+        HBHIP_CHECK(ctx, hipGetLastError());
+        HBHIP_CHECK(ctx, hipMemcpyAsync(h_result, d_result, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HBHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        *combed = *h_result;
+        return HBHIP_OK;
+    }
+
+    // generic surface: comb detect does not transform pictures
+    DevPicture *acquire_input() override { return nullptr; }
+    int submit(DevPicture *) override { return HBHIP_ERR_STATE; }
+    int flush() override { return HBHIP_OK; }
+    int pending() override { return 0; }
+    DevPicture *pop_output() override { return nullptr; }
+    void recycle_output(DevPicture *) override {}
+
+private:
+    hbhip_comb_detect_params par;
+    CombConst k;
+    int width = 0, height = 0, pitch = 0, mstride = 0;
+    uint8_t *luma_alloc[3] = {nullptr, nullptr, nullptr};
+    int slot[3];
+    int ref[3] = {-1, -1, -1};
+    uint8_t *masks = nullptr, *mask = nullptr, *mask_filtered = nullptr, *mask_temp = nullptr;
+    float *d_lut = nullptr;
+    int *d_result = nullptr, *h_result = nullptr;
+};
+
+} // namespace
+
+extern "C" int hbhip_comb_detect_create(hbhip_ctx *ctx, const hbhip_comb_detect_params *p, int width, int height,
+                                        int depth, hbhip_filter **out)
+{
+    if (!ctx || !p || !out) return HBHIP_ERR_ARG;
+    *out = nullptr;
+    if (depth != 8) return HBHIP_ERR_UNSUPPORTED;
+    (void)hipSetDevice(ctx->device);
+    CombDetectFilter *f = new (std::nothrow) CombDetectFilter(ctx, *p);
+    if (!f) return HBHIP_ERR_NOMEM;
+    int rc = f->setup(width, height);
+    if (rc != HBHIP_OK)
+    {
+        delete f;
+        return rc;
+    }
+    *out = f;
+    return HBHIP_OK;
+}
+
+extern "C" int hbhip_comb_detect_store(hbhip_filter *f, const uint8_t *luma, int stride)
+{
+    CombDetectFilter *c = dynamic_cast<CombDetectFilter *>(f);
+    if (!c) return HBHIP_ERR_ARG;
+    (void)hipSetDevice(f->ctx->device);
+    return c->store(luma, stride, false);
+}
+
+extern "C" int hbhip_comb_detect_store_dev(hbhip_filter *f, const void *luma, int stride)
+{
+    CombDetectFilter *c = dynamic_cast<CombDetectFilter *>(f);
+    if (!c) return HBHIP_ERR_ARG;
+    (void)hipSetDevice(f->ctx->device);
+    return c->store(luma, stride, true);
+}
+
+extern "C" int hbhip_comb_detect_classify(hbhip_filter *f, int force_exhaustive, int *combed)
+{
+    CombDetectFilter *c = dynamic_cast<CombDetectFilter *>(f);
+    if (!c || !combed) return HBHIP_ERR_ARG;
+    (void)hipSetDevice(f->ctx->device);
+    return c->classify(force_exhaustive, combed);
+}

@@ -1,0 +1,374 @@
+// decomb.hip — decomb (yadif / blend / cubic / EEDI2-guided) for gfx950, 8-bit.
+//
+//   decomb_plane_kernel   replaces yadif_decomb_filter_work_8 + yadif_filter_line_8,
+//                         cubic_interpolate_line_8, blend_filter_line_8 and the row
+//                         copies of filter_8   (libhb/templates/decomb_template.c:43-107,
+//                         279-361, 579-898)
+//   DecombFilter          replaces store_ref / process_frame / hb_decomb_work frame
+//                         logic               (libhb/decomb.c:195-200, 495-612)
+//
+// One thread per output pixel, three planes per launch.  Rows of the parity being
+// rebuilt are interpolated, the others are copied from the current frame; every
+// decision (vertical-edge rows, the x margin of the spatial search, first/last
+// row stride mirroring, C-style truncating /40) follows the reference so the
+// output is bit-exact.  HBM-bound: reads prev/cur/next (+EEDI2 guess), writes one
+// frame = 4 (5) bytes per pixel algorithmic; vertical neighbours come from L2.
+#include "hbhip_internal.h"
+#include "eedi2_engine.h"
+
+namespace {
+
+enum { M_YADIF = 1, M_BLEND = 2, M_CUBIC = 4, M_EEDI2 = 8, M_BOB = 16, M_SELECTIVE = 32 };
+enum { PIC_TFF = 0x0008, PIC_PROGRESSIVE = 0x0010 };
+
+struct DecombPlane
+{
+    const uint8_t *prev, *cur, *next, *guess;
+    uint8_t       *dst;
+    int            pitch, guess_pitch, dst_pitch, w, h;
+};
+
+struct DecombArgs
+{
+    DecombPlane pl[3];
+    int mode;            // resolved per-frame mode (decomb_template.c:820-833)
+    int parity;          // rows with (y & 1) == (parity ? 0 : 1) are rebuilt
+    int field_parity;    // parity ^ tff, the `parity` argument of yadif_filter_line
+};
+
+__device__ __forceinline__ int crop8(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }
+__device__ __forceinline__ int cubic4(int y0, int y1, int y2, int y3)
+{
+    return crop8((y0 * -3 + y1 * 23 + y2 * 23 + y3 * -3) / 40);      // :43-48, C division
+}
+__device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
+__device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
+
+__device__ __forceinline__ bool yadif_check(const uint8_t *c, int sp, int sn, int st, int j, bool cubic_ok,
+                                            int &best, int &pred)
+{
+    const int score = abs((int)c[sp - 1 + j] - (int)c[sn - 1 - j]) + abs((int)c[sp + j] - (int)c[sn - j]) +
+                      abs((int)c[sp + 1 + j] - (int)c[sn + 1 - j]);
+    if (score >= best) return false;
+    best = score;
+    if (cubic_ok)
+    {
+        // :541-570
+        if (j == -1)      pred = cubic4(c[-3 * st - 3], c[-st - 1], c[st + 1], c[3 * st + 3]);
+        else if (j == -2) pred = cubic4((c[-3 * st - 4] + c[-st - 4]) / 2, c[-st - 2], c[st + 2], (c[3 * st + 4] + c[st + 4]) / 2);
+        else if (j == 1)  pred = cubic4(c[-3 * st + 3], c[-st + 1], c[st - 1], c[3 * st - 3]);
+        else              pred = cubic4((c[-3 * st + 4] + c[-st + 4]) / 2, c[-st + 2], c[st - 2], (c[3 * st - 4] + c[st - 4]) / 2);
+    }
+    else
+    {
+        pred = ((int)c[sp + j] + (int)c[sn - j]) >> 1;
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(256) void decomb_plane_kernel(DecombArgs a)
+{
+    const DecombPlane &P = a.pl[blockIdx.z];
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= P.w || y >= P.h) return;
+    const int st = P.pitch;
+    const uint8_t *c = P.cur + (size_t)y * st + x;
+    uint8_t *o = P.dst + (size_t)y * P.dst_pitch + x;
+    const int mode = a.mode;
+
+    if (mode == 0)                                         // pass-through (:892-897)
+    {
+        *o = *c;
+        return;
+    }
+    if ((mode & M_EEDI2) && !(mode & M_YADIF))             // EEDI2 only (:855-875)
+    {
+        *o = P.guess[(size_t)y * P.guess_pitch + x];
+        return;
+    }
+    if ((y & 1) != (a.parity ? 0 : 1))                     // kept field (:795-807)
+    {
+        *o = *c;
+        return;
+    }
+    const int h = P.h;
+    if (mode == M_BLEND)                                   // :300-361
+    {
+        int u1, u2, d1, d2;
+        if (y > 1 && y < h - 2) { u1 = -st; u2 = -2 * st; d1 = st; d2 = 2 * st; }
+        else if (y == 0)        { u1 = u2 = 0; d1 = st; d2 = 2 * st; }
+        else if (y == 1)        { u1 = u2 = -st; d1 = st; d2 = 2 * st; }
+        else if (y == h - 2)    { u1 = -st; u2 = -2 * st; d1 = d2 = st; }
+        else                    { u1 = -st; u2 = -2 * st; d1 = d2 = 0; }
+        const int v = (-(int)c[u2] + 2 * (int)c[u1] + 6 * (int)c[0] + 2 * (int)c[d1] - (int)c[d2]) >> 3;
+        *o = (uint8_t)crop8(v);
+        return;
+    }
+    if (mode == M_CUBIC)                                   // :50-107
+    {
+        int p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+        if (y >= 3)                { p0 = c[-3 * st]; p1 = c[-st]; }
+        else if (y == 2 || y == 1) { p0 = p1 = c[-st]; }
+        else if (y == 0)           { p0 = p1 = c[st]; }
+        if (y <= h - 4)                      { p2 = c[st]; p3 = c[3 * st]; }
+        else if (y == h - 3 || y == h - 2)   { p2 = p3 = c[st]; }
+        else if (y == h - 1)                 { p2 = p3 = c[-st]; }
+        *o = (uint8_t)cubic4(p0, p1, p2, p3);
+        return;
+    }
+    if (!(mode & M_YADIF))
+        return;                                            // untouched, as the reference leaves it
+
+    // ---- yadif_filter_line (:579-712)
+    const uint8_t *pp = P.prev + (size_t)y * st + x;
+    const uint8_t *pn = P.next + (size_t)y * st + x;
+    const uint8_t *p2 = a.field_parity ? pp : c;
+    const uint8_t *n2 = a.field_parity ? c : pn;
+    const int sp = y ? -st : st;
+    const int sn = y + 1 < h ? st : -st;
+    const bool vertical_edge = (y < 3) || (y > h - 4);
+    const bool use_cubic = (mode & M_CUBIC) && !vertical_edge;
+    const int margin = (mode & M_CUBIC) ? 3 : 2;
+
+    const int cc = c[sp];
+    const int d = ((int)p2[0] + (int)n2[0]) >> 1;
+    const int e = c[sn];
+    const int td0 = abs((int)p2[0] - (int)n2[0]);
+    const int td1 = (abs((int)pp[sp] - cc) + abs((int)pp[sn] - e)) >> 1;
+    const int td2 = (abs((int)pn[sp] - cc) + abs((int)pn[sn] - e)) >> 1;
+    int diff = max3i(td0 >> 1, td1, td2);
+    int pred;
+    if (mode & M_EEDI2)
+    {
+        pred = P.guess[(size_t)y * P.guess_pitch + x];
+    }
+    else
+    {
+        pred = use_cubic ? cubic4(c[-3 * st], c[-st], c[st], c[3 * st]) : (cc + e) >> 1;
+        if (x > margin && x < P.w - (margin + 1))
+        {
+            int best = abs((int)c[sp - 1] - (int)c[sn - 1]) + abs(cc - e) + abs((int)c[sp + 1] - (int)c[sn + 1]) - 1;
+            if (yadif_check(c, sp, sn, st, -1, use_cubic, best, pred))
+                yadif_check(c, sp, sn, st, -2, use_cubic, best, pred);
+            if (yadif_check(c, sp, sn, st, 1, use_cubic, best, pred))
+                yadif_check(c, sp, sn, st, 2, use_cubic, best, pred);
+        }
+    }
+    if (!vertical_edge)
+    {
+        const int b = ((int)p2[-2 * st] + (int)n2[-2 * st]) >> 1;
+        const int f = ((int)p2[2 * st] + (int)n2[2 * st]) >> 1;
+        const int mx = max3i(d - e, d - cc, min(b - cc, f - e));
+        const int mn = min3i(d - e, d - cc, max(b - cc, f - e));
+        diff = max3i(diff, mn, -mx);
+    }
+    if (pred > d + diff)      pred = d + diff;
+    else if (pred < d - diff) pred = d - diff;
+    *o = (uint8_t)pred;
+}
+
+// ------------------------------------------------------------------- host side
+class DecombFilter : public hbhip_filter
+{
+public:
+    DecombFilter(hbhip_ctx *c, const hbhip_decomb_params &p) : hbhip_filter(c), par(p) {}
+    ~DecombFilter() override { delete eedi; }
+
+    int setup(int width, int height, int depth, int lcw, int lch)
+    {
+        in_geo.set(width, height, depth, lcw, lch);
+        out_geo = in_geo;
+        pool.configure(ctx, in_geo);
+        // the mode a HEAVY frame is filtered with (decomb_template.c:828-831); reject the
+        // combinations for which the reference leaves the rebuilt rows unwritten (:741-789)
+        const int hm = par.mode & ~M_SELECTIVE;
+        if (!(hm == 0 || hm == M_BLEND || hm == M_CUBIC || (hm & M_YADIF) || (hm & M_EEDI2)))
+            return HBHIP_ERR_UNSUPPORTED;
+        if (par.mode & M_EEDI2)
+        {
+            if (par.post_processing != 0 && par.post_processing != 1) return HBHIP_ERR_UNSUPPORTED;
+            Eedi2Params ep = { par.magnitude_threshold, par.variance_threshold, par.laplacian_threshold,
+                               par.dilation_threshold, par.erosion_threshold, par.noise_threshold,
+                               par.maximum_search_distance, par.post_processing };
+            eedi = new (std::nothrow) Eedi2Engine(ctx, in_geo, ep);
+            if (!eedi) return HBHIP_ERR_NOMEM;
+            int rc = eedi->init();
+            if (rc != HBHIP_OK) return rc;
+        }
+        return HBHIP_OK;
+    }
+
+    DevPicture *acquire_input() override
+    {
+        DevPicture *p = pool.acquire();
+        if (p) { p->refs = 0; p->flags = next_flags; p->combed = next_combed; }
+        return p;
+    }
+
+    int submit(DevPicture *pic) override
+    {
+        // hb_decomb_work (decomb.c:573-612)
+        if (!ready)
+        {
+            store_ref(pic);
+            store_ref(pic);
+            ready = true;
+            return HBHIP_OK;                   // HB_FILTER_DELAY
+        }
+        store_ref(pic);
+        return process_frame();
+    }
+
+    int flush() override
+    {
+        if (ref[2] != nullptr && !flushed)
+        {
+            store_ref(ref[2]);                 // duplicate the last frame (decomb.c:584-589)
+            flushed = true;
+            return process_frame();
+        }
+        return HBHIP_OK;
+    }
+
+    int pending() override { return (int)outq.size(); }
+    DevPicture *pop_output() override
+    {
+        if (outq.empty()) return nullptr;
+        DevPicture *p = outq.front();
+        outq.pop_front();
+        return p;
+    }
+    void recycle_output(DevPicture *p) override { pool.release(p); }
+
+    int next_flags = 0, next_combed = 0;
+
+private:
+    void unref(DevPicture *p)
+    {
+        if (p && --p->refs == 0) pool.release(p);
+    }
+    void store_ref(DevPicture *p)              // decomb.c:195-200
+    {
+        unref(ref[0]);
+        ref[0] = ref[1];
+        ref[1] = ref[2];
+        ref[2] = p;
+        p->refs++;
+    }
+
+    int launch(DevPicture *dst, int mode, int parity, int tff)
+    {
+        DecombArgs a;
+        for (int c = 0; c < 3; c++)
+        {
+            DecombPlane &P = a.pl[c];
+            P.prev = ref[0]->plane[c]; P.cur = ref[1]->plane[c]; P.next = ref[2]->plane[c];
+            P.guess = nullptr; P.guess_pitch = 0;
+            if ((mode & M_EEDI2) && eedi)
+            {
+                P.guess = eedi->result().plane[c];
+                P.guess_pitch = eedi->result().stride[c];
+            }
+            P.dst = dst->plane[c];
+            P.pitch = ref[1]->pitch[c]; P.dst_pitch = dst->pitch[c];
+            P.w = in_geo.pw[c]; P.h = in_geo.ph[c];
+        }
+        a.mode = mode; a.parity = parity; a.field_parity = parity ^ tff;
+        dim3 block(64, 4), grid((in_geo.pw[0] + 63) / 64, (in_geo.ph[0] + 3) / 4, 3);
+        HBHIP_LAUNCH(ctx, "decomb_plane", decomb_plane_kernel, grid, block, 0, a);
+        HBHIP_CHECK(ctx, hipGetLastError());
+        return HBHIP_OK;
+    }
+
+    int process_frame()                        // decomb.c:495-571 + filter_8 mode choice
+    {
+        DevPicture *cur = ref[1];
+        const bool selective = par.mode & M_SELECTIVE;
+        if (selective && cur->combed == 0)
+        {
+            DevPicture *o = pool.acquire();
+            if (!o) return HBHIP_ERR_NOMEM;
+            o->tag = cur->tag << 1; o->aux = 0;
+            int rc = launch(o, 0, 0, 0);       // plain copy of ref[1]
+            if (rc != HBHIP_OK) return rc;
+            outq.push_back(o);
+            return HBHIP_OK;
+        }
+        int tff;
+        if (par.parity < 0)
+            tff = ((cur->flags & PIC_PROGRESSIVE) == 0) ? !!(cur->flags & PIC_TFF) : 1;
+        else
+            tff = (par.parity & 1) ^ 1;
+
+        const int is_combed = selective ? cur->combed : 2;
+        int mode = 0;
+        if ((par.mode & M_BLEND) && is_combed == 1) mode = M_BLEND;
+        else if (is_combed != 0)                    mode = par.mode & ~M_SELECTIVE;
+
+        const int nframes = (par.mode & M_BOB) ? 2 : 1;
+        for (int frame = 0; frame < nframes; frame++)
+        {
+            const int parity = frame ^ tff ^ 1;
+            if ((mode & M_EEDI2) && eedi)
+            {
+                int rc = eedi->run(cur, !parity);            // pv->tff = !parity (decomb.c:542)
+                if (rc != HBHIP_OK) return rc;
+            }
+            DevPicture *o = pool.acquire();
+            if (!o) return HBHIP_ERR_NOMEM;
+            o->tag = (cur->tag << 1) | frame; o->aux = frame;
+            int rc = launch(o, mode, parity, tff);
+            if (rc != HBHIP_OK) return rc;
+            outq.push_back(o);
+        }
+        return HBHIP_OK;
+    }
+
+    hbhip_decomb_params par;
+    PicturePool pool;
+    DevPicture *ref[3] = {nullptr, nullptr, nullptr};
+    std::deque<DevPicture *> outq;
+    Eedi2Engine *eedi = nullptr;
+    bool ready = false, flushed = false;
+};
+
+} // namespace
+
+extern "C" int hbhip_decomb_create(hbhip_ctx *ctx, const hbhip_decomb_params *p, int width, int height,
+                                   int depth, int log2_chroma_w, int log2_chroma_h, hbhip_filter **out)
+{
+    if (!ctx || !p || !out) return HBHIP_ERR_ARG;
+    *out = nullptr;
+    if (depth != 8) return HBHIP_ERR_UNSUPPORTED;
+    if (width < 8 || height < 8) return HBHIP_ERR_UNSUPPORTED;
+    (void)hipSetDevice(ctx->device);
+    DecombFilter *f = new (std::nothrow) DecombFilter(ctx, *p);
+    if (!f) return HBHIP_ERR_NOMEM;
+    int rc = f->setup(width, height, depth, log2_chroma_w, log2_chroma_h);
+    if (rc != HBHIP_OK)
+    {
+        delete f;
+        return rc;
+    }
+    *out = f;
+    return HBHIP_OK;
+}
+
+extern "C" int hbhip_decomb_push(hbhip_filter *f, const hbhip_host_frame *in, int64_t tag, int pic_flags, int combed)
+{
+    DecombFilter *d = dynamic_cast<DecombFilter *>(f);
+    if (!d) return HBHIP_ERR_ARG;
+    d->next_flags = pic_flags;
+    d->next_combed = combed;
+    return hbhip_filter_push(f, in, tag);
+}
+
+extern "C" int hbhip_decomb_push_dev(hbhip_filter *f, const hbhip_dev_frame *in, int64_t tag, int pic_flags, int combed)
+{
+    DecombFilter *d = dynamic_cast<DecombFilter *>(f);
+    if (!d) return HBHIP_ERR_ARG;
+    d->next_flags = pic_flags;
+    d->next_combed = combed;
+    return hbhip_filter_push_dev(f, in, tag);
+}

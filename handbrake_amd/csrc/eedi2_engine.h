@@ -1,0 +1,52 @@
+// eedi2_engine.h — internal interface between the decomb filter (decomb.hip) and
+// the EEDI2 pass pipeline (eedi2.hip).  Not part of the ABI.
+#pragma once
+
+#include "hbhip_internal.h"
+
+struct Eedi2Params
+{
+    int magnitude_threshold, variance_threshold, laplacian_threshold;
+    int dilation_threshold, erosion_threshold, noise_threshold;
+    int maximum_search_distance, post_processing;
+};
+
+// A 3-plane frame laid out byte-for-byte like hb_frame_buffer_init() lays it out
+// (libhb/fifo.c:820-881): plane p at base + sum of stride*height of the planes
+// before it, stride = width rounded up to 64.  EEDI2 reads a few bytes outside
+// rows / planes (eedi2_template.c:395-447, 1194-1195), so the layout — not just
+// the pixels — is part of its behaviour; `guard` zero bytes surround the frame.
+struct EediFrame
+{
+    uint8_t *alloc = nullptr;
+    uint8_t *base = nullptr;
+    uint8_t *plane[3] = {nullptr, nullptr, nullptr};
+    int      stride[3] = {0, 0, 0};
+    int      width[3] = {0, 0, 0};
+    int      height[3] = {0, 0, 0};
+    size_t   bytes = 0;
+};
+
+class Eedi2Engine
+{
+public:
+    Eedi2Engine(hbhip_ctx *ctx, const PicGeometry &geo, const Eedi2Params &p);
+    ~Eedi2Engine();
+    int  init();                                   // allocate the 9 scratch frames (zeroed once)
+    // eedi2_planer (decomb_template.c:455-473): field extraction + the pass
+    // sequence of eedi2_interpolate_plane for the 3 planes; `tff` is pv->tff.
+    int  run(const DevPicture *cur, int tff);
+    const EediFrame &result() const { return full_[0]; }   // eedi_full[DST2PF]
+    const EediFrame &half(int i) const { return half_[i]; }
+    const EediFrame &full(int i) const { return full_[i]; }
+
+private:
+    int alloc_frame(EediFrame &f, int width, int height);
+    hbhip_ctx  *ctx_;
+    PicGeometry geo_;
+    Eedi2Params par_;
+    EediFrame   half_[4];    // SRCPF, MSKPF, TMPPF, DSTPF          (decomb.c:64-68)
+    EediFrame   full_[5];    // DST2PF, TMP2PF2, MSK2PF, TMP2PF, DST2MPF (decomb.c:69-74)
+    uint32_t   *lattice_tmp_ = nullptr;
+    uint8_t    *d_limlut_ = nullptr;
+};

@@ -79,6 +79,10 @@ struct DevPicture
     int      bps = 1;
     int64_t  tag = 0;
     size_t   bytes = 0;
+    int      refs = 0;       // used by filters that keep a picture in several ring slots
+    int      flags = 0;      // PIC_FLAG_* of the source buffer (decomb / comb detect)
+    int      combed = 0;     // HB_COMB_* of the source buffer
+    int      aux = 0;        // filter specific (decomb: which field of a bob pair)
 };
 
 // Geometry of a planar YUV picture.

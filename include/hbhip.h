@@ -157,6 +157,43 @@ int hbhip_unsharp_create(hbhip_ctx *ctx, const hbhip_blur_params *p, int width, 
 int hbhip_chroma_smooth_create(hbhip_ctx *ctx, const hbhip_blur_params *p, int width, int height,
                                int depth, int log2_chroma_w, int log2_chroma_h, hbhip_filter **out);
 
+/* ---- Decomb (replaces decomb.c:495-612 frame logic + decomb_template.c:579-898
+ *      line filters + eedi2_template.c passes) -------------------------------------- */
+typedef struct hbhip_decomb_params
+{
+    int mode;                       /* MODE_DECOMB_* bits, decomb.h:13-18                  */
+    int parity;                     /* -1 = from picture flags (decomb.c:519-528)          */
+    /* EEDI2 (decomb.c:234-243) */
+    int magnitude_threshold, variance_threshold, laplacian_threshold;
+    int dilation_threshold, erosion_threshold, noise_threshold;
+    int maximum_search_distance, post_processing;
+} hbhip_decomb_params;
+int hbhip_decomb_create(hbhip_ctx *ctx, const hbhip_decomb_params *p, int width, int height,
+                        int depth, int log2_chroma_w, int log2_chroma_h, hbhip_filter **out);
+/* push with the per-buffer state decomb looks at: s.flags (PIC_FLAG_*) and
+ * s.combed (HB_COMB_*, set upstream by comb detect).  Pulled tags are
+ * (input tag << 1) | field_index, field_index = 1 for the second frame of a bob pair. */
+int hbhip_decomb_push(hbhip_filter *f, const hbhip_host_frame *in, int64_t tag, int pic_flags, int combed);
+int hbhip_decomb_push_dev(hbhip_filter *f, const hbhip_dev_frame *in, int64_t tag, int pic_flags, int combed);
+
+/* ---- Comb detect (replaces comb_detect.c:1051-1072 comb_segmenter and the passes it
+ *      runs: comb_detect_template.c:288-402/789-933, comb_detect.c:221-276, 384-454,
+ *      556-622, 726-792, 901-966, 1029-1049) ------------------------------------------ */
+typedef struct hbhip_comb_detect_params
+{
+    int mode, spatial_metric, motion_threshold, spatial_threshold;
+    int filter_mode, block_threshold, block_width, block_height;
+    float gamma_lut[256];           /* built on the host as comb_detect.c:1074-1081 does   */
+} hbhip_comb_detect_params;
+int hbhip_comb_detect_create(hbhip_ctx *ctx, const hbhip_comb_detect_params *p, int width, int height,
+                             int depth, hbhip_filter **out);
+/* store_ref (comb_detect.c:1007-1018): the luma plane becomes the newest of the
+ * prev/cur/next ring.  luma == NULL repeats the newest plane (first frame / EOF). */
+int hbhip_comb_detect_store(hbhip_filter *f, const uint8_t *luma, int stride);
+int hbhip_comb_detect_store_dev(hbhip_filter *f, const void *luma, int stride);
+/* comb_segmenter on the ring: *combed = HB_COMB_NONE/LIGHT/HEAVY for the middle plane. */
+int hbhip_comb_detect_classify(hbhip_filter *f, int force_exhaustive, int *combed);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,6 +22,11 @@ def blur(strength=0.25, size=7):
     return dict(strength=strength, size=size)
 
 
+COMB_DEFAULT = ("mode=3:spatial-metric=2:motion-thresh=1:spatial-thresh=1:filter-mode=2:"
+                "block-thresh=40:block-width=16:block-height=16")          # param.c:204-207
+COMB_DEFAULT_PAR = dict(mode=3, spatial_metric=2, motion_thresh=1, spatial_thresh=1, filter_mode=2,
+                        block_thresh=40, block_width=16, block_height=16)
+
 # name -> case.  `chain` = [(reference filter object symbol, settings)], `hip` = the drop-in symbols.
 CASES = {
     "nlmeans_medium_96x64": dict(model="progressive", w=96, h=64, n=4,
@@ -57,4 +62,16 @@ CASES = {
                                         chain=[("hb_filter_chroma_smooth", "cb-strength=0.6:cb-size=7")],
                                         hip=[("hb_filter_chroma_smooth_hip", "cb-strength=0.6:cb-size=7")],
                                         orc=[("chroma_smooth", [blur(0.6, 7), blur(0.6, 7)])]),
+    "decomb_default_134x70": dict(model="interlaced", w=134, h=70, n=4,
+                                  chain=[("hb_filter_decomb", "mode=7")],
+                                  hip=[("hb_filter_decomb_hip", "mode=7")],
+                                  orc=[("decomb", dict(mode=7))]),
+    "decomb_bob_128x64": dict(model="interlaced", w=128, h=64, n=4,
+                              chain=[("hb_filter_decomb", "mode=23")],
+                              hip=[("hb_filter_decomb_hip", "mode=23")],
+                              orc=[("decomb", dict(mode=23))]),
+    "combdetect_decomb_selective_192x96": dict(model="interlaced", w=192, h=96, n=5,
+                                               chain=[("hb_filter_comb_detect", COMB_DEFAULT), ("hb_filter_decomb", "mode=39")],
+                                               hip=[("hb_filter_comb_detect_hip", COMB_DEFAULT), ("hb_filter_decomb_hip", "mode=39")],
+                                               orc=[("comb_detect", COMB_DEFAULT_PAR), ("decomb", dict(mode=39))]),
 }

@@ -30,11 +30,28 @@ def nlmeans_stream(frames, planes_par):
 STREAMS = {"nlmeans": nlmeans_stream}
 
 
-def run_chain(frames, orc_chain):
-    cur = frames
+def run_chain(frames, orc_chain, flags=0x10):
+    """Replay a chain.  Stages exchange (planes list, per-frame combed list);
+    returns list of plane tuples (metadata of the last stage in run_chain.last_meta)."""
+    cur = [tuple(f) for f in frames]
+    combed = None
+    meta = None
     for kind, par in orc_chain:
-        cur = STREAMS[kind](cur, par)
+        if kind == "comb_detect":
+            combed = comb_detect_stream(cur, par)
+            meta = [dict(combed=c) for c in combed]
+        elif kind == "decomb":
+            res = decomb_stream(cur, par, flags=flags, combed=combed)
+            cur = [r["planes"] for r in res]
+            meta = [dict(start=r["start"], stop=r["stop"], combed=r["combed"]) for r in res]
+            combed = [r["combed"] for r in res]
+        else:
+            cur = STREAMS[kind](cur, par)
+    run_chain.last_meta = meta
     return cur
+
+
+run_chain.last_meta = None
 
 
 def load_golden(path):

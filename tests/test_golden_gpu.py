@@ -29,4 +29,5 @@ def test_hip_matches_golden(built, name):
                 d = np.abs(got[t].planes[c].astype(int) - want[t][c].astype(int)).max()
                 assert d <= tol, f"{name} frame {t} plane {c}: max |delta| {d} > {tol}"
         assert got[t].start == int(meta[t][0])
+        assert got[t].stop == int(meta[t][1])
         assert got[t].combed == int(meta[t][3])
