@@ -1,0 +1,718 @@
+/* eedi2_oracle.c — CPU restatement of EEDI2 as decomb drives it (8-bit,
+ * post-processing 0/1).  TEST INFRASTRUCTURE ONLY (see oracle.h).
+ *
+ * Follows /root/reference/libhb/templates/eedi2_template.c pass by pass and the
+ * pass order of eedi2_interpolate_plane (templates/decomb_template.c:366-441).
+ * Things that look like mistakes but are the reference's behaviour, kept here:
+ *   - build_edge_mask is CALLED with (magnitude, variance, laplacian) but DECLARED
+ *     (mthresh, lthresh, vthresh) (decomb_template.c:391-393 vs eedi2_template.c:122):
+ *     the variance test uses the laplacian setting and vice versa;
+ *   - it clears only the upper half of the mask (eedi2_template.c:132): the lower
+ *     half keeps whatever the previous run left there (the mask is stateful);
+ *   - mark_directions_2x compares dmskp[x+1] with dmskpn[x-1] (:835);
+ *   - every pass indexes a flat buffer, so "x-1-u" style offsets run into the
+ *     neighbouring row / plane / padding (e.g. :395-447, :1194-1195, :1296-1310).
+ *     The nine scratch frames are therefore laid out byte-for-byte as
+ *     hb_frame_buffer_init lays them out (fifo.c:820-881) inside zeroed guards.
+ */
+#include "oracle.h"
+
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define PEAK    255
+#define NEUTRAL 128
+#define GUARD   4096
+
+static const uint8_t LIMLUT[33] = { 6, 6, 7, 7, 8, 8, 9, 9, 9, 10, 10, 11, 11, 12, 12, 12, 12, 12, 12, 12,
+                                    12, 12, 12, 12, 12, 12, 12, 12, 12, 12, 12, 255, 255 };   /* eedi2.c:21-25 as u8 */
+
+typedef struct
+{
+    uint8_t *alloc;
+    uint8_t *plane[3];
+    int stride[3], width[3], height[3];
+} frame_t;
+
+struct orc_eedi2
+{
+    orc_eedi2_params_t p;
+    int width, height;
+    frame_t half[4];   /* SRCPF MSKPF TMPPF DSTPF */
+    frame_t full[5];   /* DST2PF TMP2PF2 MSK2PF TMP2PF DST2MPF */
+};
+
+static inline int iabs(int v) { return v < 0 ? -v : v; }
+static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int imax(int a, int b) { return a > b ? a : b; }
+
+static void frame_alloc(frame_t *f, int width, int height)
+{
+    size_t total = 0, off[3];
+    for (int c = 0; c < 3; c++)
+    {
+        f->width[c]  = c ? (width + 1) / 2 : width;
+        f->height[c] = c ? (height + 1) / 2 : height;
+        f->stride[c] = (f->width[c] + 63) / 64 * 64;
+        off[c] = total;
+        total += (size_t)f->stride[c] * f->height[c];
+    }
+    f->alloc = calloc(total + 2 * GUARD, 1);
+    for (int c = 0; c < 3; c++)
+        f->plane[c] = f->alloc + GUARD + off[c];
+}
+
+orc_eedi2_t *orc_eedi2_new(int width, int height, const orc_eedi2_params_t *p)
+{
+    orc_eedi2_t *e = calloc(1, sizeof(*e));
+    e->p = *p;
+    e->width = width;
+    e->height = height;
+    for (int i = 0; i < 4; i++) frame_alloc(&e->half[i], width, height / 2);   /* decomb.c:291-296 */
+    for (int i = 0; i < 5; i++) frame_alloc(&e->full[i], width, height);       /* :299-303 */
+    return e;
+}
+
+void orc_eedi2_free(orc_eedi2_t *e)
+{
+    if (!e) return;
+    for (int i = 0; i < 4; i++) free(e->half[i].alloc);
+    for (int i = 0; i < 5; i++) free(e->full[i].alloc);
+    free(e);
+}
+
+const uint8_t *orc_eedi2_plane(orc_eedi2_t *e, int buffer, int plane, int *stride, int *height)
+{
+    frame_t *f = buffer < 4 ? &e->half[buffer] : &e->full[buffer - 4];
+    if (stride) *stride = f->stride[plane];
+    if (height) *height = f->height[plane];
+    return f->plane[plane];
+}
+
+/* eedi2_bit_blit (:46-68) for equal pitches */
+static void blit(uint8_t *dst, const uint8_t *src, int pitch, int width, int height)
+{
+    for (int y = 0; y < height; y++)
+        memcpy(dst + (size_t)y * pitch, src + (size_t)y * pitch, width);
+}
+
+/* insertion sort of <= 9 values + the reference's midpoint rule (eedi2.c:65-80, e.g. :500-502) */
+static int sorted_mid(int *v, int n)
+{
+    for (int i = 1; i < n; i++)
+    {
+        const int t = v[i];
+        int j = i;
+        while (j > 0 && v[j - 1] > t) { v[j] = v[j - 1]; j--; }
+        v[j] = t;
+    }
+    return (n & 1) ? v[n >> 1] : (v[(n - 1) >> 1] + v[n >> 1] + 1) >> 1;
+}
+
+/* mean of the values within `lim` of mid, mixed with mid and rounded (:701 etc.);
+ * returns the count of values used through *count. */
+static int vote(const int *v, int n, int mid, int lim, int *count)
+{
+    int sum = 0, cnt = 0;
+    for (int i = 0; i < n; i++)
+        if (iabs(v[i] - mid) <= lim) { cnt++; sum += v[i]; }
+    *count = cnt;
+    return (int)(((float)(sum + mid) / (float)(cnt + 1)) + 0.5f);
+}
+
+/* ---- half-height passes ------------------------------------------------------------ */
+
+/* :122-195 */
+static void build_edge_mask(uint8_t *dst, const uint8_t *src, int pitch, int width, int height,
+                            int magnitude, int variance, int laplacian)
+{
+    const int mth = magnitude * 10;
+    const int vth = laplacian * 81;       /* sic: the value passed third lands in `vthresh` */
+    const int lth = variance;             /* and the second in `lthresh`                    */
+    memset(dst, 0, (size_t)(height / 2) * pitch);
+    for (int y = 1; y < height - 1; y++)
+    {
+        const uint8_t *p = src + (size_t)(y - 1) * pitch, *c = p + pitch, *n = c + pitch;
+        uint8_t *o = dst + (size_t)y * pitch;
+        for (int x = 1; x < width - 1; x++)
+        {
+#define FLATCOL(i) (iabs(p[i] - c[i]) < 10 && iabs(c[i] - n[i]) < 10 && iabs(p[i] - n[i]) < 10)
+            if (FLATCOL(x) || (FLATCOL(x - 1) && FLATCOL(x + 1)))
+                continue;
+#undef FLATCOL
+            int sum = 0, sumsq = 0;
+            for (int i = -1; i <= 1; i++)
+            {
+                sum   += p[x + i] + c[x + i] + n[x + i];
+                sumsq += p[x + i] * p[x + i] + c[x + i] * c[x + i] + n[x + i] * n[x + i];
+            }
+            if (9 * sumsq - sum * sum < vth)
+                continue;
+            const int ix = c[x + 1] - c[x - 1];
+            const int iy = imax(imax(iabs(p[x] - n[x]), iabs(p[x] - c[x])), iabs(c[x] - n[x]));
+            if (ix * ix + iy * iy >= mth)
+            {
+                o[x] = PEAK;
+                continue;
+            }
+            const int ixx = c[x - 1] - 2 * c[x] + c[x + 1];
+            const int iyy = p[x] - 2 * c[x] + n[x];
+            if (iabs(ixx) + iabs(iyy) >= lth)
+                o[x] = PEAK;
+        }
+    }
+}
+
+static int peaks_around(const uint8_t *p, const uint8_t *c, const uint8_t *n, int x)
+{
+    return (p[x - 1] == PEAK) + (p[x] == PEAK) + (p[x + 1] == PEAK) + (c[x - 1] == PEAK) +
+           (c[x + 1] == PEAK) + (n[x - 1] == PEAK) + (n[x] == PEAK) + (n[x + 1] == PEAK);
+}
+
+/* grow != 0: dilate (:207-247), else erode (:259-293) */
+static void morph_edge_mask(const uint8_t *msk, uint8_t *dst, int pitch, int width, int height, int thr, int grow)
+{
+    blit(dst, msk, pitch, width, height);
+    for (int y = 1; y < height - 1; y++)
+    {
+        const uint8_t *p = msk + (size_t)(y - 1) * pitch, *c = p + pitch, *n = c + pitch;
+        uint8_t *o = dst + (size_t)y * pitch;
+        for (int x = 1; x < width - 1; x++)
+        {
+            if (grow)
+            {
+                if (c[x] != 0) continue;
+                if (peaks_around(p, c, n, x) >= thr) o[x] = PEAK;
+            }
+            else
+            {
+                if (c[x] != PEAK) continue;
+                if (peaks_around(p, c, n, x) < thr) o[x] = 0;
+            }
+        }
+    }
+}
+
+/* :308-342 */
+static void remove_small_gaps(const uint8_t *msk, uint8_t *dst, int pitch, int width, int height)
+{
+    blit(dst, msk, pitch, width, height);
+    for (int y = 1; y < height - 1; y++)
+    {
+        const uint8_t *m = msk + (size_t)y * pitch;
+        uint8_t *o = dst + (size_t)y * pitch;
+        for (int x = 3; x < width - 3; x++)
+        {
+            if (m[x])
+            {
+                if (m[x - 3] || m[x - 2] || m[x - 1] || m[x + 1] || m[x + 2] || m[x + 3]) continue;
+                o[x] = 0;
+            }
+            else if ((m[x + 1] && (m[x - 1] || m[x - 2] || m[x - 3])) ||
+                     (m[x + 2] && (m[x - 1] || m[x - 2])) || (m[x + 3] && m[x - 1]))
+                o[x] = PEAK;
+        }
+    }
+}
+
+static inline int sad3(const uint8_t *a, int ai, const uint8_t *b, int bi)
+{
+    return iabs(a[ai - 1] - b[bi - 1]) + iabs(a[ai] - b[bi]) + iabs(a[ai + 1] - b[bi + 1]);
+}
+
+/* :358-525 */
+static void calc_directions(int plane, const uint8_t *msk, const uint8_t *src, uint8_t *dst, int pitch,
+                            int width, int height, int maxd, int nt)
+{
+    const int nt13 = (uint8_t)(nt * 13), nt19 = (uint8_t)(nt * 19);   /* declared `pixel` (:364-365) */
+    const int maxdt = plane == 0 ? maxd : (maxd >> 1);
+    memset(dst, 255, (size_t)pitch * height);
+    for (int y = 1; y < height - 1; y++)
+    {
+        const uint8_t *mp = msk + (size_t)(y - 1) * pitch, *mc = mp + pitch, *mn = mc + pitch;
+        const uint8_t *s2p = src + (ptrdiff_t)(y - 2) * pitch, *sp = s2p + pitch, *sc = sp + pitch,
+                      *sn = sc + pitch, *s2n = sn + pitch;
+        uint8_t *o = dst + (size_t)y * pitch;
+        for (int x = 1; x < width - 1; x++)
+        {
+            if (mc[x] != PEAK || (mc[x - 1] != PEAK && mc[x + 1] != PEAK))
+                continue;
+            const int startu = imax(-x + 1, -maxdt), stopu = imin(width - 2 - x, maxdt);
+            const int vert = iabs(sc[x] - sn[x]) + iabs(sc[x] - sp[x]);
+            int minb = imin(nt13, vert * 6), mina = imin(nt19, vert * 9);
+            int minc = mina, mind = minb, mine = minb;
+            int dira = -5000, dirb = -5000, dirc = -5000, dird = -5000, dire = -5000;
+            for (int u = startu; u <= stopu; u++)
+            {
+                if (!(y == 1 || mp[x - 1 + u] == PEAK || mp[x + u] == PEAK || mp[x + 1 + u] == PEAK))
+                    continue;
+                if (!(y == height - 2 || mn[x - 1 - u] == PEAK || mn[x - u] == PEAK || mn[x + 1 - u] == PEAK))
+                    continue;
+                const int diffsn = sad3(sc, x, sn, x - u);
+                const int diffsp = sad3(sc, x, sp, x + u);
+                const int diffps = sad3(sp, x, sc, x - u);
+                const int diffns = sad3(sn, x, sc, x + u);
+                const int diff = diffsn + diffsp + diffps + diffns;
+                int diffd = diffsp + diffns, diffe = diffsn + diffps;
+                if (diff < minb) { dirb = u; minb = diff; }
+                if (y > 1)
+                {
+                    const int diff2pp = sad3(s2p, x, sp, x - u);
+                    const int diffp2p = sad3(sp, x, s2p, x + u);
+                    const int diffa = diff + diff2pp + diffp2p;
+                    diffd += diffp2p;
+                    diffe += diff2pp;
+                    if (diffa < mina) { dira = u; mina = diffa; }
+                }
+                if (y < height - 2)
+                {
+                    const int diff2nn = sad3(s2n, x, sn, x + u);
+                    const int diffn2n = sad3(sn, x, s2n, x - u);
+                    const int diffc = diff + diff2nn + diffn2n;
+                    diffd += diff2nn;
+                    diffe += diffn2n;
+                    if (diffc < minc) { dirc = u; minc = diffc; }
+                }
+                if (diffd < mind) { dird = u; mind = diffd; }
+                if (diffe < mine) { dire = u; mine = diffe; }
+            }
+            int order[5], k = 0;
+            if (dira != -5000) order[k++] = dira;
+            if (dirb != -5000) order[k++] = dirb;
+            if (dirc != -5000) order[k++] = dirc;
+            if (dird != -5000) order[k++] = dird;
+            if (dire != -5000) order[k++] = dire;
+            if (k <= 1)
+            {
+                o[x] = NEUTRAL;
+                continue;
+            }
+            const int mid = sorted_mid(order, k);
+            const int tlim = imax(LIMLUT[iabs(mid)] >> 2, 2);
+            int sum = 0, count = 0;
+            for (int i = 0; i < k; i++)
+                if (iabs(order[i] - mid) <= tlim) { count++; sum += order[i]; }
+            if (count > 1)
+                o[x] = (uint8_t)(NEUTRAL + ((int)((float)sum / (float)count) * 4));
+            else
+                o[x] = NEUTRAL;
+        }
+    }
+}
+
+static int collect3(int *v, int k, const uint8_t *row, int x, int skip_centre)
+{
+    if (row[x - 1] != PEAK) v[k++] = row[x - 1];
+    if (!skip_centre && row[x] != PEAK) v[k++] = row[x];
+    if (row[x + 1] != PEAK) v[k++] = row[x + 1];
+    return k;
+}
+
+/* filter_dir_map (:649-709) when expand == 0, expand_dir_map (:722-773) when expand != 0 */
+static void dir_map_pass(const uint8_t *msk, const uint8_t *dmsk, uint8_t *dst, int pitch,
+                         int width, int height, int expand)
+{
+    blit(dst, dmsk, pitch, width, height);
+    for (int y = 1; y < height - 1; y++)
+    {
+        const uint8_t *dp = dmsk + (size_t)(y - 1) * pitch, *dc = dp + pitch, *dn = dc + pitch;
+        const uint8_t *m = msk + (size_t)y * pitch;
+        uint8_t *o = dst + (size_t)y * pitch;
+        for (int x = 1; x < width - 1; x++)
+        {
+            if (m[x] != PEAK) continue;
+            if (expand && dc[x] != PEAK) continue;
+            int order[9], u = 0;
+            u = collect3(order, u, dp, x, 0);
+            u = collect3(order, u, dc, x, expand);
+            u = collect3(order, u, dn, x, 0);
+            if (u < (expand ? 5 : 4))
+            {
+                if (!expand) o[x] = PEAK;
+                continue;
+            }
+            const int mid = sorted_mid(order, u);
+            int count;
+            const int val = vote(order, u, mid, LIMLUT[iabs(mid - NEUTRAL) >> 2], &count);
+            if (expand)
+            {
+                if (count < 5) continue;
+            }
+            else if (count < 4 || (count < 5 && dc[x] == PEAK))
+            {
+                o[x] = PEAK;
+                continue;
+            }
+            o[x] = (uint8_t)val;
+        }
+    }
+}
+
+/* does the walk j = from..to along `row`/`other` trip one of the three tests (:565-575)? */
+static int trips(const uint8_t *side, const uint8_t *dc, int x, int from, int to, int lim, int side_is_next)
+{
+    for (int j = from; j <= to; j++)
+    {
+        const int s = side[x + j], c = dc[x + j], ref = dc[x];
+        if ((iabs(s - ref) > lim && s != PEAK) ||
+            (side_is_next ? (s == PEAK && c == PEAK) : (c == PEAK && s == PEAK)) ||
+            (iabs(c - ref) > lim && c != PEAK))
+            return 1;
+    }
+    return 0;
+}
+
+/* :538-635 */
+static void filter_map(const uint8_t *msk, const uint8_t *dmsk, uint8_t *dst, int pitch, int width, int height)
+{
+    blit(dst, dmsk, pitch, width, height);
+    for (int y = 1; y < height - 1; y++)
+    {
+        const uint8_t *dp = dmsk + (size_t)(y - 1) * pitch, *dc = dp + pitch, *dn = dc + pitch;
+        const uint8_t *m = msk + (size_t)y * pitch;
+        uint8_t *o = dst + (size_t)y * pitch;
+        for (int x = 1; x < width - 1; x++)
+        {
+            if (dc[x] == PEAK || m[x] != PEAK) continue;
+            int dir = (dc[x] - NEUTRAL) >> 2;
+            const int lim = imax(iabs(dir) * 2, 12 << 2);
+            dir >>= 2;
+            int ict, icb = 0;
+            if (dir < 0) ict = trips(dp, dc, x, imax(-x, dir), 0, lim, 0);
+            else         ict = trips(dp, dc, x, 0, imin(width - x - 1, dir), lim, 0);
+            if (!ict) continue;
+            if (dir < 0) icb = trips(dn, dc, x, 0, imin(width - x - 1, iabs(dir)), lim, 1);
+            else         icb = trips(dn, dc, x, imax(-x, -dir), 0, lim, 1);
+            if (icb) o[x] = PEAK;
+        }
+    }
+}
+
+/* :98-108 */
+static void upscale_by_2(const uint8_t *src, uint8_t *dst, int height, int pitch)
+{
+    for (int y = 0; y < height; y++)
+    {
+        memcpy(dst + (size_t)(2 * y) * pitch, src + (size_t)y * pitch, pitch);
+        memcpy(dst + (size_t)(2 * y + 1) * pitch, src + (size_t)y * pitch, pitch);
+    }
+}
+
+/* ---- full-height passes ------------------------------------------------------------ */
+
+/* :787-858 */
+static void mark_directions_2x(const uint8_t *msk, const uint8_t *dmsk, uint8_t *dst, int pitch,
+                               int tff, int width, int height)
+{
+    memset(dst, 255, (size_t)pitch * height);
+    for (int y = 2 - tff; y < height - 1; y += 2)
+    {
+        const uint8_t *d0 = dmsk + (size_t)(y - 1) * pitch, *d1 = d0 + 2 * (size_t)pitch;
+        const uint8_t *m0 = msk + (size_t)(y - 1) * pitch, *m1 = m0 + 2 * (size_t)pitch;
+        uint8_t *o = dst + (size_t)y * pitch;
+        for (int x = 1; x < width - 1; x++)
+        {
+            if (m0[x] != PEAK && m1[x] != PEAK) continue;
+            int order[6], v = 0;
+            v = collect3(order, v, d0, x, 0);
+            v = collect3(order, v, d1, x, 0);
+            if (v < 3) continue;
+            const int mid = sorted_mid(order, v);
+            const int lim = LIMLUT[iabs(mid - NEUTRAL) >> 2];
+            int u = 0;
+            if (iabs(d0[x - 1] - d1[x - 1]) <= lim || d0[x - 1] == PEAK || d1[x - 1] == PEAK) u++;
+            if (iabs(d0[x] - d1[x]) <= lim || d0[x] == PEAK || d1[x] == PEAK) u++;
+            if (iabs(d0[x + 1] - d1[x - 1]) <= lim || d0[x + 1] == PEAK || d1[x + 1] == PEAK) u++;   /* sic */
+            if (u < 2) continue;
+            int count;
+            const int val = vote(order, v, mid, lim, &count);
+            if (count < v - 2 || count < 2) continue;
+            o[x] = (uint8_t)val;
+        }
+    }
+}
+
+/* filter_dir_map_2x (:872-939) / expand_dir_map_2x (:953-1011) */
+static void dir_map_pass_2x(const uint8_t *msk, const uint8_t *dmsk, uint8_t *dst, int pitch,
+                            int field, int width, int height, int expand)
+{
+    blit(dst, dmsk, pitch, width, height);
+    for (int y = 2 - field; y < height - 1; y += 2)
+    {
+        const uint8_t *dc = dmsk + (size_t)y * pitch;
+        const uint8_t *dp = dc - 2 * (ptrdiff_t)pitch, *dn = dc + 2 * (ptrdiff_t)pitch;
+        const uint8_t *m0 = msk + (size_t)(y - 1) * pitch, *m1 = m0 + 2 * (size_t)pitch;
+        uint8_t *o = dst + (size_t)y * pitch;
+        for (int x = 1; x < width - 1; x++)
+        {
+            if (m0[x] != PEAK && m1[x] != PEAK) continue;
+            if (expand && dc[x] != PEAK) continue;
+            int order[9], u = 0;
+            if (y > 1) u = collect3(order, u, dp, x, 0);
+            u = collect3(order, u, dc, x, expand);
+            if (y < height - 2) u = collect3(order, u, dn, x, 0);
+            if (u < (expand ? 5 : 4))
+            {
+                if (!expand) o[x] = PEAK;
+                continue;
+            }
+            const int mid = sorted_mid(order, u);
+            int count;
+            const int val = vote(order, u, mid, LIMLUT[iabs(mid - NEUTRAL) >> 2], &count);
+            if (expand)
+            {
+                if (count < 5) continue;
+            }
+            else if (count < 4 || (count < 5 && dc[x] == PEAK))
+            {
+                o[x] = PEAK;
+                continue;
+            }
+            o[x] = (uint8_t)val;
+        }
+    }
+}
+
+/* :1025-1132 */
+static void fill_gaps_2x(const uint8_t *msk, const uint8_t *dmsk, uint8_t *dst, int pitch,
+                         int field, int width, int height)
+{
+    blit(dst, dmsk, pitch, width, height);
+    for (int y = 2 - field; y < height - 1; y += 2)
+    {
+        const uint8_t *dc = dmsk + (size_t)y * pitch;
+        const uint8_t *dp = dc - 2 * (ptrdiff_t)pitch, *dn = dc + 2 * (ptrdiff_t)pitch;
+        const uint8_t *mc = msk + (size_t)(y - 1) * pitch;
+        const uint8_t *mp = mc - 2 * (ptrdiff_t)pitch, *mn = mc + 2 * (ptrdiff_t)pitch, *mnn = mn + 2 * (ptrdiff_t)pitch;
+        uint8_t *o = dst + (size_t)y * pitch;
+        for (int x = 1; x < width - 1; x++)
+        {
+            if (dc[x] != PEAK || (mc[x] != PEAK && mn[x] != PEAK)) continue;
+            int u = x - 1, back = 500, forward = -500;
+            while (u)
+            {
+                if (dc[u] != PEAK) { back = dc[u]; break; }
+                if (mc[u] != PEAK && mn[u] != PEAK) break;
+                u--;
+            }
+            int v = x + 1;
+            while (v < width)
+            {
+                if (dc[v] != PEAK) { forward = dc[v]; break; }
+                if (mc[v] != PEAK && mn[v] != PEAK) break;
+                v++;
+            }
+            int tc = 1, bc = 1, mint = 500, maxt = -20, minb = 500, maxb = -20;
+            for (int j = u; j <= v; j++)
+            {
+                if (tc)
+                {
+                    if (y <= 2 || dp[j] == PEAK || (mp[j] != PEAK && mc[j] != PEAK)) { tc = 0; mint = maxt = 20; }
+                    else { if (dp[j] < mint) mint = dp[j]; if (dp[j] > maxt) maxt = dp[j]; }
+                }
+                if (bc)
+                {
+                    if (y >= height - 3 || dn[j] == PEAK || (mn[j] != PEAK && mnn[j] != PEAK)) { bc = 0; minb = maxb = 20; }
+                    else { if (dn[j] < minb) minb = dn[j]; if (dn[j] > maxb) maxb = dn[j]; }
+                }
+            }
+            if (maxt == -20) maxt = mint = 20;
+            if (maxb == -20) maxb = minb = 20;
+            const int far = imax(iabs(forward - NEUTRAL), iabs(back - NEUTRAL));
+            const int thresh = imax(imax(far >> 2, 8), imax(iabs(mint - maxt), iabs(minb - maxb)));
+            const int flim = imin(far >> 2, 6);
+            if (iabs(forward - back) <= thresh && (v - u - 1 <= flim || tc || bc))
+            {
+                const double step = (double)(forward - back) / (double)(v - u);
+                for (int j = 0; j < v - u - 1; j++)
+                    o[u + j + 1] = (uint8_t)(back + (int)(j * step + 0.5));
+            }
+        }
+    }
+}
+
+/* :1148-1335 — in place: dmsk row y and dst row y are rewritten left to right and the
+ * test at x looks at the already rewritten dmsk[x-1]. */
+static void interpolate_lattice(int plane, uint8_t *dmsk, uint8_t *dst, const uint8_t *omsk, int pitch,
+                                int field, int nt, int width, int height)
+{
+    const int nt4 = (uint8_t)(nt * 4), nt7 = (uint8_t)(nt * 7), nt8 = (uint8_t)(nt * 8);   /* `pixel` typed (:1159-1161) */
+    if (field == 1) memcpy(dst + (size_t)(height - 1) * pitch, dst + (size_t)(height - 2) * pitch, width);
+    else            memcpy(dst, dst + pitch, width);
+    for (int y = 2 - field; y < height - 1; y += 2)
+    {
+        uint8_t *top = dst + (size_t)(y - 1) * pitch, *mid = top + pitch, *bot = mid + pitch;
+        const uint8_t *ot = omsk + (size_t)(y - 1) * pitch, *ob = ot + 2 * (size_t)pitch;
+        uint8_t *dm = dmsk + (size_t)y * pitch;
+        for (int x = 0; x < width; x++)
+        {
+            int dir = dm[x];
+            const int lim = LIMLUT[iabs(dir - NEUTRAL) >> 2];
+            const int avg = (top[x] + bot[x] + 1) >> 1;
+            if (dir == PEAK || (iabs(dm[x] - dm[x - 1]) > lim && iabs(dm[x] - dm[x + 1]) > lim))
+            {
+                mid[x] = (uint8_t)avg;
+                if (dir != PEAK) dm[x] = NEUTRAL;
+                continue;
+            }
+            if (lim < 9)
+            {
+                const int sum = top[x - 1] + top[x] + top[x + 1] + bot[x - 1] + bot[x] + bot[x + 1];
+                const int sumsq = top[x - 1] * top[x - 1] + top[x] * top[x] + top[x + 1] * top[x + 1] +
+                                  bot[x - 1] * bot[x - 1] + bot[x] * bot[x] + bot[x + 1] * bot[x + 1];
+                if (6 * sumsq - sum * sum < 576)
+                {
+                    mid[x] = (uint8_t)avg;
+                    dm[x] = PEAK;
+                    continue;
+                }
+            }
+            if (x > 1 && x < width - 2 &&
+                ((top[x] < imax(top[x - 2], top[x - 1]) - 3 && top[x] < imax(top[x + 2], top[x + 1]) - 3 &&
+                  bot[x] < imax(bot[x - 2], bot[x - 1]) - 3 && bot[x] < imax(bot[x + 2], bot[x + 1]) - 3) ||
+                 (top[x] > imin(top[x - 2], top[x - 1]) + 3 && top[x] > imin(top[x + 2], top[x + 1]) + 3 &&
+                  bot[x] > imin(bot[x - 2], bot[x - 1]) + 3 && bot[x] > imin(bot[x + 2], bot[x + 1]) + 3)))
+            {
+                mid[x] = (uint8_t)avg;
+                dm[x] = NEUTRAL;
+                continue;
+            }
+            dir = (dir - NEUTRAL + 2) >> 2;
+            int val = avg;
+            const int startu = (dir - 2 < 0) ? imax(-x + 1, imax(dir - 2, -width + 2 + x))
+                                             : imin(x - 1, imin(dir - 2, width - 2 - x));
+            const int stopu = (dir + 2 < 0) ? imax(-x + 1, imax(dir + 2, -width + 2 + x))
+                                            : imin(x - 1, imin(dir + 2, width - 2 - x));
+            int min = nt8;
+            const int here = dm[x];
+#define NEAR(row, i) ((row)[i] != PEAK && iabs((row)[i] - here) <= lim)
+            for (int u = startu; u <= stopu; u++)
+            {
+                const int diff = sad3(top, x, bot, x - u) + sad3(bot, x, top, x + u);
+                if (!(diff < min && (NEAR(ot, x - 1 + u) || NEAR(ot, x + u) || NEAR(ot, x + 1 + u)) &&
+                      (NEAR(ob, x - 1 - u) || NEAR(ob, x - u) || NEAR(ob, x + 1 - u))))
+                    continue;
+                const int h0 = u >> 1, h1 = (u + 1) >> 1;
+                const int diff2 = sad3(top, x + h0, bot, x - h0);
+                if (!(diff2 < nt4 &&
+                      (((iabs(ot[x + h0] - ob[x - h0]) <= lim || iabs(ot[x + h0] - ob[x - h1]) <= lim) && ot[x + h0] != PEAK) ||
+                       ((iabs(ot[x + h1] - ob[x - h0]) <= lim || iabs(ot[x + h1] - ob[x - h1]) <= lim) && ot[x + h1] != PEAK))))
+                    continue;
+                if ((iabs(here - ot[x + h0]) <= lim || iabs(here - ot[x + h1]) <= lim) &&
+                    (iabs(here - ob[x - h0]) <= lim || iabs(here - ob[x - h1]) <= lim))
+                {
+                    val = (top[x + h0] + top[x + h1] + bot[x - h0] + bot[x - h1] + 2) >> 2;
+                    min = diff;
+                    dir = u;
+                }
+            }
+#undef NEAR
+            if (min != nt8)
+            {
+                mid[x] = (uint8_t)val;
+                dm[x] = (uint8_t)(NEUTRAL + dir * 4);
+                continue;
+            }
+            const int lo = imin(top[x], bot[x]), hi = imax(top[x], bot[x]);
+            const int d = plane == 0 ? 4 : 2;
+            const int su = imax(-x + 1, -d), eu = imin(width - 2 - x, d);
+            min = nt7;
+            for (int u = su; u <= eu; u++)
+            {
+                const int h0 = u >> 1, h1 = (u + 1) >> 1;
+                const int p1 = top[x + h0] + top[x + h1];
+                const int p2 = bot[x - h0] + bot[x - h1];
+                const int diff = sad3(top, x, bot, x - u) + sad3(bot, x, top, x + u) + iabs(p1 - p2);
+                if (diff < min)
+                {
+                    const int valt = (p1 + p2 + 2) >> 2;
+                    if (valt >= lo && valt <= hi) { val = valt; min = diff; dir = u; }
+                }
+            }
+            mid[x] = (uint8_t)val;
+            dm[x] = (min == 7 * nt) ? NEUTRAL : (uint8_t)(NEUTRAL + dir * 4);   /* compares with the UNtruncated 7*nt (:1324) */
+        }
+    }
+}
+
+/* :1349-1378 */
+static void post_process(const uint8_t *nmsk, const uint8_t *omsk, uint8_t *dst, int pitch,
+                         int field, int width, int height)
+{
+    for (int y = 2 - field; y < height - 1; y += 2)
+    {
+        const uint8_t *nm = nmsk + (size_t)y * pitch, *om = omsk + (size_t)y * pitch;
+        uint8_t *d = dst + (size_t)y * pitch;
+        for (int x = 0; x < width; x++)
+        {
+            const int lim = LIMLUT[iabs(nm[x] - NEUTRAL) >> 2];
+            if (iabs(nm[x] - om[x]) > lim && om[x] != PEAK && om[x] != NEUTRAL)
+                d[x] = (uint8_t)((d[x - pitch] + d[x + pitch] + 1) >> 1);
+        }
+    }
+}
+
+/* ---- sequencing (decomb_template.c:366-473) ------------------------------------------ */
+static void run_plane(orc_eedi2_t *e, int c, int tff, int npasses)
+{
+    uint8_t *srcp = e->half[0].plane[c], *mskp = e->half[1].plane[c], *tmpp = e->half[2].plane[c], *dstp = e->half[3].plane[c];
+    uint8_t *dst2p = e->full[0].plane[c], *tmp2p2 = e->full[1].plane[c], *msk2p = e->full[2].plane[c],
+            *tmp2p = e->full[3].plane[c], *dst2mp = e->full[4].plane[c];
+    const int pitch = e->full[0].stride[c], height = e->full[0].height[c], width = e->full[0].width[c];
+    const int hh = e->half[0].height[c];
+    const orc_eedi2_params_t *p = &e->p;
+    int n = 0;
+#define STEP(call) do { if (n++ >= npasses) return; call; } while (0)
+    STEP(build_edge_mask(mskp, srcp, pitch, width, hh, p->magnitude_threshold, p->variance_threshold, p->laplacian_threshold));
+    STEP(morph_edge_mask(mskp, tmpp, pitch, width, hh, p->erosion_threshold, 0));
+    STEP(morph_edge_mask(tmpp, mskp, pitch, width, hh, p->dilation_threshold, 1));
+    STEP(morph_edge_mask(mskp, tmpp, pitch, width, hh, p->erosion_threshold, 0));
+    STEP(remove_small_gaps(tmpp, mskp, pitch, width, hh));
+    STEP(calc_directions(c, mskp, srcp, tmpp, pitch, width, hh, p->maximum_search_distance, p->noise_threshold));
+    STEP(dir_map_pass(mskp, tmpp, dstp, pitch, width, hh, 0));
+    STEP(dir_map_pass(mskp, dstp, tmpp, pitch, width, hh, 1));
+    STEP(filter_map(mskp, tmpp, dstp, pitch, width, hh));
+    STEP(upscale_by_2(srcp, dst2p, hh, pitch));
+    STEP(upscale_by_2(dstp, tmp2p2, hh, pitch));
+    STEP(upscale_by_2(mskp, msk2p, hh, pitch));
+    STEP(mark_directions_2x(msk2p, tmp2p2, tmp2p, pitch, tff, width, height));
+    STEP(dir_map_pass_2x(msk2p, tmp2p, dst2mp, pitch, tff, width, height, 0));
+    STEP(dir_map_pass_2x(msk2p, dst2mp, tmp2p, pitch, tff, width, height, 1));
+    STEP(fill_gaps_2x(msk2p, tmp2p, dst2mp, pitch, tff, width, height));
+    STEP(fill_gaps_2x(msk2p, dst2mp, tmp2p, pitch, tff, width, height));
+    STEP(interpolate_lattice(c, tmp2p, dst2p, tmp2p2, pitch, tff, p->noise_threshold, width, height));
+    if (p->post_processing == 1 || p->post_processing == 3)
+    {
+        STEP(blit(tmp2p2, tmp2p, pitch, width, height));
+        STEP(dir_map_pass_2x(msk2p, tmp2p, dst2mp, pitch, tff, width, height, 0));
+        STEP(dir_map_pass_2x(msk2p, dst2mp, tmp2p, pitch, tff, width, height, 1));
+        STEP(post_process(tmp2p, tmp2p2, dst2p, pitch, tff, width, height));
+    }
+#undef STEP
+}
+
+void orc_eedi2_run_partial(orc_eedi2_t *e, const uint8_t *const cur[3], const int stride[3], int tff, int npasses)
+{
+    /* eedi2_fill_half_height_buffer_plane (:77-89): kept-field rows, min(pitch) bytes each */
+    for (int c = 0; c < 3; c++)
+    {
+        const int dst_pitch = e->half[0].stride[c];
+        const int n = imin(stride[c], dst_pitch);
+        const uint8_t *s = cur[c] + (size_t)stride[c] * (!tff);
+        uint8_t *d = e->half[0].plane[c];
+        for (int y = e->full[0].height[c]; y > 0; y -= 2)
+        {
+            memcpy(d, s, n);
+            d += dst_pitch;
+            s += 2 * (size_t)stride[c];
+        }
+    }
+    for (int c = 0; c < 3; c++)
+        run_plane(e, c, tff, npasses);
+}
+
+void orc_eedi2_run(orc_eedi2_t *e, const uint8_t *const cur[3], const int stride[3], int tff)
+{
+    orc_eedi2_run_partial(e, cur, stride, tff, 1000);
+}

@@ -135,6 +135,32 @@ int         orc_comb_classify(orc_comb_t *c, const uint8_t *prev, const uint8_t 
 /* which: 0 mask, 1 mask_filtered, 2 mask_temp; returns the plane, *stride set. */
 const uint8_t *orc_comb_mask(orc_comb_t *c, int which, int *stride);
 
+/* ---- EEDI2 (eedi2.c, templates/eedi2_template.c, decomb_template.c:366-473) ------- */
+
+typedef struct
+{
+    int magnitude_threshold, variance_threshold, laplacian_threshold;   /* decomb.c:234-236 */
+    int dilation_threshold, erosion_threshold, noise_threshold;         /* :237-239         */
+    int maximum_search_distance, post_processing;                       /* :240-241         */
+} orc_eedi2_params_t;
+
+typedef struct orc_eedi2 orc_eedi2_t;
+
+/* The nine 3-plane scratch frames of decomb (eedi_half[4] of height/2, eedi_full[5]),
+ * laid out like hb_frame_buffer_init lays them out and zero-initialised ONCE: the
+ * edge mask deliberately keeps state across calls (eedi2_template.c:132). */
+orc_eedi2_t *orc_eedi2_new(int width, int height, const orc_eedi2_params_t *p);
+void         orc_eedi2_free(orc_eedi2_t *e);
+/* eedi2_planer_8 (decomb_template.c:455-473): extract the kept field of `cur`
+ * (3 planes, strides) and run eedi2_interpolate_plane_8 on each plane; tff = pv->tff. */
+void         orc_eedi2_run(orc_eedi2_t *e, const uint8_t *const cur[3], const int stride[3], int tff);
+/* buffer: 0..3 = eedi_half[SRCPF,MSKPF,TMPPF,DSTPF], 4..8 = eedi_full[DST2PF,TMP2PF2,
+ * MSK2PF,TMP2PF,DST2MPF] (decomb.c:64-74).  The result of a run is buffer 4. */
+const uint8_t *orc_eedi2_plane(orc_eedi2_t *e, int buffer, int plane, int *stride, int *height);
+/* Run only the first `npasses` steps of the pass list (debugging / per-pass pinning). */
+void         orc_eedi2_run_partial(orc_eedi2_t *e, const uint8_t *const cur[3], const int stride[3],
+                                   int tff, int npasses);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,4 +74,12 @@ CASES = {
                                                chain=[("hb_filter_comb_detect", COMB_DEFAULT), ("hb_filter_decomb", "mode=39")],
                                                hip=[("hb_filter_comb_detect_hip", COMB_DEFAULT), ("hb_filter_decomb_hip", "mode=39")],
                                                orc=[("comb_detect", COMB_DEFAULT_PAR), ("decomb", dict(mode=39))]),
+    "decomb_eedi2_bob_128x64": dict(model="interlaced", w=128, h=64, n=3,
+                                    chain=[("hb_filter_decomb", "mode=31")],
+                                    hip=[("hb_filter_decomb_hip", "mode=31")],
+                                    orc=[("decomb", dict(mode=31))]),
+    "decomb_eedi2_only_190x96": dict(model="interlaced", w=190, h=96, n=3,
+                                     chain=[("hb_filter_decomb", "mode=8")],
+                                     hip=[("hb_filter_decomb_hip", "mode=8")],
+                                     orc=[("decomb", dict(mode=8))]),
 }

@@ -183,3 +183,93 @@ class OrcComb:
         if self.h:
             self.lib.orc_comb_free(self.h)
             self.h = None
+
+
+# ---------------------------------------------------------------- EEDI2
+class Eedi2Params(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("magnitude_threshold", "variance_threshold", "laplacian_threshold",
+                                       "dilation_threshold", "erosion_threshold", "noise_threshold",
+                                       "maximum_search_distance", "post_processing")]
+
+
+EEDI2_BUFFERS = ["srcp", "mskp", "tmpp", "dstp", "dst2p", "tmp2p2", "msk2p", "tmp2p", "dst2mp"]
+
+
+def _planes3(frame):
+    keep = [padded(p) for p in frame]
+    ptrs = (C.POINTER(C.c_uint8) * 3)(*[u8p(p) for p in keep])
+    strides = (C.c_int * 3)(*[p.strides[0] for p in keep])
+    return keep, ptrs, strides
+
+
+class OrcEedi2:
+    """Stateful oracle EEDI2 (the edge mask carries over between runs)."""
+
+    def __init__(self, width, height, magnitude=10, variance=20, laplacian=20, dilation=4, erosion=2,
+                 noise=50, search=24, postproc=1):
+        lib = oracle()
+        lib.orc_eedi2_new.restype = C.c_void_p
+        lib.orc_eedi2_new.argtypes = [C.c_int, C.c_int, C.POINTER(Eedi2Params)]
+        lib.orc_eedi2_run.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_int), C.c_int]
+        lib.orc_eedi2_run_partial.argtypes = lib.orc_eedi2_run.argtypes + [C.c_int]
+        lib.orc_eedi2_plane.restype = C.POINTER(C.c_uint8)
+        lib.orc_eedi2_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        lib.orc_eedi2_free.argtypes = [C.c_void_p]
+        p = Eedi2Params(magnitude, variance, laplacian, dilation, erosion, noise, search, postproc)
+        self.lib, self.w, self.h = lib, width, height
+        self.e = lib.orc_eedi2_new(width, height, C.byref(p))
+
+    def run(self, frame, tff, npasses=None):
+        keep, ptrs, strides = _planes3(frame)
+        if npasses is None:
+            self.lib.orc_eedi2_run(self.e, ptrs, strides, int(tff))
+        else:
+            self.lib.orc_eedi2_run_partial(self.e, ptrs, strides, int(tff), npasses)
+
+    def plane(self, buffer, plane):
+        st, ht = C.c_int(), C.c_int()
+        ptr = self.lib.orc_eedi2_plane(self.e, buffer, plane, C.byref(st), C.byref(ht))
+        return np.ctypeslib.as_array(ptr, shape=(ht.value, st.value)).copy()
+
+    def guess(self):
+        """The 3 predicted planes (eedi_full[DST2PF]) cropped to width."""
+        out = []
+        for c in range(3):
+            a = self.plane(4, c)
+            out.append(a[:, : (self.w if c == 0 else (self.w + 1) // 2)].copy())
+        return out
+
+    def close(self):
+        if self.e:
+            self.lib.orc_eedi2_free(self.e)
+            self.e = None
+
+
+class RefEedi2:
+    """The reference's own eedi2_planer_8 driven through oracle/ref_wrap/wrap_decomb.c."""
+
+    def __init__(self, width, height, settings="mode=8"):
+        lib = ref()
+        lib.hbref_eedi2_new.restype = C.c_void_p
+        lib.hbref_eedi2_new.argtypes = [C.c_int, C.c_int, C.c_char_p]
+        lib.hbref_eedi2_run.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_int), C.c_int]
+        lib.hbref_eedi2_plane.restype = C.POINTER(C.c_uint8)
+        lib.hbref_eedi2_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        lib.hbref_eedi2_free.argtypes = [C.c_void_p]
+        self.lib = lib
+        self.h = lib.hbref_eedi2_new(width, height, settings.encode())
+        assert self.h
+
+    def run(self, frame, tff):
+        keep, ptrs, strides = _planes3(frame)
+        self.lib.hbref_eedi2_run(self.h, ptrs, strides, int(tff))
+
+    def plane(self, buffer, plane):
+        st, ht = C.c_int(), C.c_int()
+        ptr = self.lib.hbref_eedi2_plane(self.h, buffer, plane, C.byref(st), C.byref(ht))
+        return np.ctypeslib.as_array(ptr, shape=(ht.value, st.value)).copy()
+
+    def close(self):
+        if self.h:
+            self.lib.hbref_eedi2_free(self.h)
+            self.h = None

@@ -41,7 +41,8 @@ def run_chain(frames, orc_chain, flags=0x10):
             combed = comb_detect_stream(cur, par)
             meta = [dict(combed=c) for c in combed]
         elif kind == "decomb":
-            res = decomb_stream(cur, par, flags=flags, combed=combed)
+            fn = decomb_eedi2_stream if (par.get("mode", 7) & DECOMB_EEDI2) else decomb_stream
+            res = fn(cur, par, flags=flags, combed=combed)
             cur = [r["planes"] for r in res]
             meta = [dict(start=r["start"], stop=r["stop"], combed=r["combed"]) for r in res]
             combed = [r["combed"] for r in res]
@@ -159,3 +160,21 @@ def comb_detect_stream(frames, par):
         out.append(oc.classify(frames[max(t - 1, 0)][0], frames[t][0], frames[min(t + 1, n - 1)][0], force))
     oc.close()
     return out
+
+
+def decomb_eedi2_stream(frames, par, flags=PIC_FLAG_TOP_FIELD_FIRST, combed=None, duration=3003):
+    """decomb_stream with the (stateful) EEDI2 oracle supplying the spatial guess."""
+    h, w = frames[0][0].shape
+    keys = dict(magnitude="magnitude", variance="variance", laplacian="laplacian", dilation="dilation",
+                erosion="erosion", noise="noise", search="search", postproc="postproc")
+    kw = {k: par[k] for k in keys if k in par}
+    oe = ol.OrcEedi2(w, h, **kw)
+
+    def guess(cur, tff):
+        oe.run(cur, tff)
+        return oe.guess()
+
+    try:
+        return decomb_stream(frames, par, flags=flags, combed=combed, duration=duration, eedi2=guess)
+    finally:
+        oe.close()

@@ -110,3 +110,85 @@ def test_unsharp_and_chroma_smooth_match_reference(built, w, h, size):
     got = hbrt.run_stream(ol.ref(), [("hb_filter_chroma_smooth", f"cb-strength=1.2:cb-size={size}")], frames)
     want = os_.chroma_smooth_stream(frames, [dict(strength=1.2, size=size)] * 2)
     _eq_stream(got, want)
+
+
+# ---------------------------------------------------------------- decomb / comb detect / EEDI2
+TFF = 0x0008
+
+
+def _eq_dstream(got, want):
+    assert len(got) == len(want)
+    for t in range(len(want)):
+        for c in range(3):
+            np.testing.assert_array_equal(got[t].planes[c], want[t]["planes"][c], err_msg=f"frame {t} plane {c}")
+        assert (got[t].start, got[t].stop) == (want[t]["start"], want[t]["stop"])
+
+
+@needs_ref
+@pytest.mark.parametrize("w,h", [(128, 72), (638, 362)])
+@pytest.mark.parametrize("mode", [1, 2, 4, 5, 7, 3, 23, 21, 39, 55])
+def test_decomb_matches_reference(built, w, h, mode):
+    frames = synth.stream("interlaced", w, h, 5)
+    combed = [2, 1, 0, 2, 1]
+    got = hbrt.run_stream(ol.ref(), [("hb_filter_decomb", f"mode={mode}")], frames, flags=TFF, combed=combed)
+    _eq_dstream(got, os_.decomb_stream(frames, dict(mode=mode), flags=TFF, combed=combed))
+
+
+COMB_CASES = [
+    ("", {}),
+    ("mode=3:spatial-metric=2:motion-thresh=1:spatial-thresh=1:filter-mode=2:block-thresh=40:block-width=16:block-height=16",
+     dict(mode=3, spatial_metric=2, motion_thresh=1, spatial_thresh=1, filter_mode=2, block_thresh=40)),
+    ("mode=0:spatial-metric=2:motion-thresh=6:spatial-thresh=9:filter-mode=1:block-thresh=80",
+     dict(mode=0, spatial_metric=2, motion_thresh=6, spatial_thresh=9, filter_mode=1, block_thresh=80)),
+    ("mode=2:spatial-metric=1:motion-thresh=2:spatial-thresh=3:filter-mode=1:block-thresh=40",
+     dict(mode=2, spatial_metric=1, motion_thresh=2, spatial_thresh=3, filter_mode=1, block_thresh=40)),
+    ("mode=2:spatial-metric=0:motion-thresh=0:spatial-thresh=3:filter-mode=2:block-thresh=20",
+     dict(mode=2, spatial_metric=0, motion_thresh=0, spatial_thresh=3, filter_mode=2, block_thresh=20)),
+    ("mode=1:block-thresh=300", dict(mode=1, block_thresh=300)),
+]
+
+
+@needs_ref
+@pytest.mark.parametrize("model", ["interlaced", "progressive", "random"])
+@pytest.mark.parametrize("w,h", [(128, 72), (638, 362), (320, 200)])
+def test_comb_detect_matches_reference(built, model, w, h):
+    frames = synth.stream(model, w, h, 6)
+    for st, par in COMB_CASES:
+        got = hbrt.run_stream(ol.ref(), [("hb_filter_comb_detect", st)], frames, flags=TFF)
+        assert [g.combed for g in got] == os_.comb_detect_stream(frames, par), (st,)
+
+
+@needs_ref
+@pytest.mark.parametrize("w,h", [(128, 72), (638, 360), (960, 540)])
+def test_eedi2_every_scratch_buffer_matches_reference(built, w, h):
+    """All nine EEDI2 scratch frames, three planes each, over consecutive stateful
+    runs (the edge mask keeps state, eedi2_template.c:132)."""
+    if h % 4:
+        pytest.skip("the reference overruns its buffers when the chroma height is odd")
+    frames = synth.stream("interlaced", w, h, 2)
+    r, o = ol.RefEedi2(w, h), ol.OrcEedi2(w, h)
+    try:
+        for fr in frames:
+            for tff in (1, 0):
+                r.run(fr, tff)
+                o.run(fr, tff)
+                for b in range(9):
+                    for c in range(3):
+                        np.testing.assert_array_equal(o.plane(b, c), r.plane(b, c),
+                                                      err_msg=f"{ol.EEDI2_BUFFERS[b]} plane {c} tff {tff}")
+    finally:
+        r.close()
+        o.close()
+
+
+@needs_ref
+@pytest.mark.parametrize("mode,extra,par", [
+    (8, "", {}), (15, "", {}), (31, "", {}), (63, "", {}),
+    (9, ":postproc=0:noise-thresh=30:search-distance=12", dict(postproc=0, noise=30, search=12)),
+    (27, ":magnitude-thresh=5:variance-thresh=10:laplacian-thresh=30:dilation-thresh=3:erosion-thresh=3",
+     dict(magnitude=5, variance=10, laplacian=30, dilation=3, erosion=3))])
+def test_decomb_eedi2_matches_reference(built, mode, extra, par):
+    frames = synth.stream("interlaced", 638, 360, 4)
+    combed = [2, 1, 0, 2]
+    got = hbrt.run_stream(ol.ref(), [("hb_filter_decomb", f"mode={mode}{extra}")], frames, flags=TFF, combed=combed)
+    _eq_dstream(got, os_.decomb_eedi2_stream(frames, dict(mode=mode, **par), flags=TFF, combed=combed))
