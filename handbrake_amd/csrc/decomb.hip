@@ -242,6 +242,7 @@ public:
     void recycle_output(DevPicture *p) override { pool.release(p); }
 
     int next_flags = 0, next_combed = 0;
+    Eedi2Engine *engine() { return eedi; }
 
 private:
     void unref(DevPicture *p)
@@ -371,4 +372,23 @@ extern "C" int hbhip_decomb_push_dev(hbhip_filter *f, const hbhip_dev_frame *in,
     d->next_flags = pic_flags;
     d->next_combed = combed;
     return hbhip_filter_push_dev(f, in, tag);
+}
+
+// Test hook: download one plane of one EEDI2 scratch frame (0..3 = eedi_half[],
+// 4..8 = eedi_full[], decomb.c:64-74) so every pass can be pinned against the oracle.
+extern "C" int hbhip_decomb_debug_eedi_plane(hbhip_filter *f, int buffer, int plane, uint8_t *dst, int dst_stride,
+                                             int *stride, int *height)
+{
+    DecombFilter *d = dynamic_cast<DecombFilter *>(f);
+    if (!d || !d->engine() || buffer < 0 || buffer > 8 || plane < 0 || plane > 2) return HBHIP_ERR_ARG;
+    const EediFrame &fr = buffer < 4 ? d->engine()->half(buffer) : d->engine()->full(buffer - 4);
+    if (stride) *stride = fr.stride[plane];
+    if (height) *height = fr.height[plane];
+    if (dst == nullptr) return HBHIP_OK;
+    if (dst_stride < fr.stride[plane]) return HBHIP_ERR_ARG;
+    hbhip_ctx *ctx = f->ctx;
+    HBHIP_CHECK(ctx, hipMemcpy2DAsync(dst, dst_stride, fr.plane[plane], fr.stride[plane], fr.stride[plane],
+                                      fr.height[plane], hipMemcpyDeviceToHost, ctx->stream));
+    HBHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return HBHIP_OK;
 }

@@ -1,9 +1,769 @@
-// eedi2.hip — EEDI2 pass pipeline (placeholder until the passes land).
+// eedi2.hip — EEDI2 (edge-directed interpolation of one field) for gfx950, 8-bit.
+//
+// One kernel per reference pass (libhb/templates/eedi2_template.c), sequenced as
+// eedi2_interpolate_plane does (libhb/templates/decomb_template.c:366-441), each
+// launch covering the three planes (blockIdx.z).  The nine scratch frames live in
+// HBM with the byte layout hb_frame_buffer_init gives them (fifo.c:820-881) inside
+// zeroed guards, because the reference's passes index a flat buffer and read a few
+// bytes outside rows and planes (e.g. eedi2_template.c:395-447, 1194-1195); with the
+// same layout the same bytes are read and the result is bit-identical.  The edge
+// mask keeps state between runs exactly as the reference's does (:132).
+//
+//   k_fill_half        eedi2_fill_half_height_buffer_plane   :77-89
+//   k_edge_mask        eedi2_build_edge_mask                 :122-195
+//   k_morph            eedi2_erode/dilate_edge_mask          :207-293
+//   k_small_gaps       eedi2_remove_small_gaps               :308-342
+//   k_calc_directions  eedi2_calc_directions                 :358-525   (the time sink)
+//   k_dir_map          eedi2_filter_dir_map / expand_dir_map :649-773 and the _2x forms :872-1011
+//   k_filter_map       eedi2_filter_map                      :538-635
+//   k_upscale3         eedi2_upscale_by_2 (x3)               :98-108
+//   k_mark_2x          eedi2_mark_directions_2x              :787-858
+//   k_fill_gaps        eedi2_fill_gaps_2x                    :1025-1132
+//   k_lattice          eedi2_interpolate_lattice             :1148-1335
+//   k_blit / k_post    eedi2_bit_blit :46-68 / eedi2_post_process :1349-1378
+//
+// interpolate_lattice rewrites its direction row in place and tests the value it
+// just wrote at x-1 (:1194), a left-to-right dependency.  Each row is given to one
+// wavefront: lanes evaluate both possible outcomes of their pixel in parallel and
+// the chain is resolved with a 64-lane prefix composition of 2-state maps, the
+// carry running from chunk to chunk.
 #include "eedi2_engine.h"
 
+namespace {
+
+constexpr int PEAK = 255, NEUTRAL = 128;
+constexpr size_t GUARD = 4096;
+
+__constant__ uint8_t c_limlut[33] = { 6, 6, 7, 7, 8, 8, 9, 9, 9, 10, 10, 11, 11, 12, 12, 12, 12, 12, 12, 12,
+                                      12, 12, 12, 12, 12, 12, 12, 12, 12, 12, 12, 255, 255 };   // eedi2.c:21-25 stored as u8
+
+struct P3
+{
+    uint8_t *a[3];       // pass specific roles, see each kernel
+    uint8_t *b[3];
+    uint8_t *c[3];
+    uint8_t *d[3];
+    uint8_t *e[3];
+    uint8_t *f[3];
+    int pitch[3], width[3], height[3];   // height = rows of the buffers this pass walks
+};
+
+__device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
+
+__device__ __forceinline__ int sad3(const uint8_t *a, int ai, const uint8_t *b, int bi)
+{
+    return iabs((int)a[ai - 1] - (int)b[bi - 1]) + iabs((int)a[ai] - (int)b[bi]) + iabs((int)a[ai + 1] - (int)b[bi + 1]);
+}
+
+// insertion sort + midpoint rule (eedi2.c:65-80)
+__device__ __forceinline__ int sorted_mid(int *v, int n)
+{
+    for (int i = 1; i < n; i++)
+    {
+        const int t = v[i];
+        int j = i;
+        while (j > 0 && v[j - 1] > t) { v[j] = v[j - 1]; j--; }
+        v[j] = t;
+    }
+    return (n & 1) ? v[n >> 1] : (v[(n - 1) >> 1] + v[n >> 1] + 1) >> 1;
+}
+
+__device__ __forceinline__ int vote(const int *v, int n, int mid, int lim, int &count)
+{
+    int sum = 0, cnt = 0;
+    for (int i = 0; i < n; i++)
+        if (iabs(v[i] - mid) <= lim) { cnt++; sum += v[i]; }
+    count = cnt;
+    return (int)(((float)(sum + mid) / (float)(cnt + 1)) + 0.5f);
+}
+
+__device__ __forceinline__ int collect3(int *v, int k, const uint8_t *row, int x, bool skip_centre)
+{
+    if (row[x - 1] != PEAK) v[k++] = row[x - 1];
+    if (!skip_centre && row[x] != PEAK) v[k++] = row[x];
+    if (row[x + 1] != PEAK) v[k++] = row[x + 1];
+    return k;
+}
+
+#define XY_PLANE(P)                                                         \
+    const int pl = blockIdx.z;                                              \
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;                    \
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;                    \
+    const int pitch = (P).pitch[pl], width = (P).width[pl], height = (P).height[pl]; \
+    (void)width; (void)height; (void)pitch
+
+// a = source plane (device pitch in `spitch`), b = srcp
+__global__ void k_fill_half(P3 P, int spitch0, int spitch1, int spitch2, int start_line, int rows0, int rows1, int rows2)
+{
+    XY_PLANE(P);
+    const int spitch = pl == 0 ? spitch0 : pl == 1 ? spitch1 : spitch2;
+    const int rows = pl == 0 ? rows0 : pl == 1 ? rows1 : rows2;
+    if (x >= pitch || y >= rows) return;
+    P.b[pl][(size_t)y * pitch + x] = P.a[pl][(size_t)(start_line + 2 * y) * spitch + x];
+}
+
+// a = srcp, b = mskp (in place: upper half cleared, lower half keeps its old content)
+__global__ void k_edge_mask(P3 P, int mth, int vth, int lth)
+{
+    XY_PLANE(P);
+    if (x >= pitch || y >= height) return;
+    uint8_t *o = P.b[pl] + (size_t)y * pitch + x;
+    int out = (y < height / 2) ? 0 : -1;                      // -1 = leave as is
+    if (x >= 1 && x < width - 1 && y >= 1 && y < height - 1)
+    {
+        const uint8_t *c = P.a[pl] + (size_t)y * pitch + x;
+        const uint8_t *p = c - pitch, *n = c + pitch;
+#define FLATCOL(i) (iabs((int)p[i] - (int)c[i]) < 10 && iabs((int)c[i] - (int)n[i]) < 10 && iabs((int)p[i] - (int)n[i]) < 10)
+        if (!(FLATCOL(0) || (FLATCOL(-1) && FLATCOL(1))))
+        {
+            int sum = 0, sumsq = 0;
+#pragma unroll
+            for (int i = -1; i <= 1; i++)
+            {
+                const int a0 = p[i], a1 = c[i], a2 = n[i];
+                sum += a0 + a1 + a2;
+                sumsq += a0 * a0 + a1 * a1 + a2 * a2;
+            }
+            if (9 * sumsq - sum * sum >= vth)
+            {
+                const int ix = (int)c[1] - (int)c[-1];
+                const int iy = max(max(iabs((int)p[0] - (int)n[0]), iabs((int)p[0] - (int)c[0])), iabs((int)c[0] - (int)n[0]));
+                if (ix * ix + iy * iy >= mth)
+                    out = PEAK;
+                else
+                {
+                    const int ixx = (int)c[-1] - 2 * (int)c[0] + (int)c[1];
+                    const int iyy = (int)p[0] - 2 * (int)c[0] + (int)n[0];
+                    if (iabs(ixx) + iabs(iyy) >= lth) out = PEAK;
+                }
+            }
+        }
+#undef FLATCOL
+    }
+    if (out >= 0) *o = (uint8_t)out;
+}
+
+// a = mask in, b = mask out
+__global__ void k_morph(P3 P, int thr, int grow)
+{
+    XY_PLANE(P);
+    if (x >= width || y >= height) return;
+    const uint8_t *c = P.a[pl] + (size_t)y * pitch + x;
+    int out = c[0];
+    if (x >= 1 && x < width - 1 && y >= 1 && y < height - 1)
+    {
+        const uint8_t *p = c - pitch, *n = c + pitch;
+        if (grow ? (c[0] == 0) : (c[0] == PEAK))
+        {
+            const int count = (p[-1] == PEAK) + (p[0] == PEAK) + (p[1] == PEAK) + (c[-1] == PEAK) + (c[1] == PEAK) +
+                              (n[-1] == PEAK) + (n[0] == PEAK) + (n[1] == PEAK);
+            if (grow) { if (count >= thr) out = PEAK; }
+            else      { if (count < thr) out = 0; }
+        }
+    }
+    P.b[pl][(size_t)y * pitch + x] = (uint8_t)out;
+}
+
+__global__ void k_small_gaps(P3 P)
+{
+    XY_PLANE(P);
+    if (x >= width || y >= height) return;
+    const uint8_t *m = P.a[pl] + (size_t)y * pitch + x;
+    int out = m[0];
+    if (x >= 3 && x < width - 3 && y >= 1 && y < height - 1)
+    {
+        if (m[0])
+        {
+            if (!(m[-3] || m[-2] || m[-1] || m[1] || m[2] || m[3])) out = 0;
+        }
+        else if ((m[1] && (m[-1] || m[-2] || m[-3])) || (m[2] && (m[-1] || m[-2])) || (m[3] && m[-1]))
+            out = PEAK;
+    }
+    P.b[pl][(size_t)y * pitch + x] = (uint8_t)out;
+}
+
+// a = mskp, b = srcp, c = out (tmpp)
+__global__ void k_calc_directions(P3 P, int maxd, int nt13, int nt19)
+{
+    XY_PLANE(P);
+    if (x >= pitch || y >= height) return;
+    uint8_t *o = P.c[pl] + (size_t)y * pitch + x;
+    int out = 255;                                            // memset(dstp, 255, pitch*height)
+    if (x >= 1 && x < width - 1 && y >= 1 && y < height - 1)
+    {
+        const uint8_t *mc = P.a[pl] + (size_t)y * pitch;
+        if (mc[x] == PEAK && (mc[x - 1] == PEAK || mc[x + 1] == PEAK))
+        {
+            const uint8_t *mp = mc - pitch, *mn = mc + pitch;
+            const uint8_t *sc = P.b[pl] + (size_t)y * pitch;
+            const uint8_t *sp = sc - pitch, *sn = sc + pitch, *s2p = sp - pitch, *s2n = sn + pitch;
+            const int maxdt = pl == 0 ? maxd : (maxd >> 1);
+            const int startu = max(-x + 1, -maxdt), stopu = min(width - 2 - x, maxdt);
+            const int vert = iabs((int)sc[x] - (int)sn[x]) + iabs((int)sc[x] - (int)sp[x]);
+            int minb = min(nt13, vert * 6), mina = min(nt19, vert * 9);
+            int minc = mina, mind = minb, mine = minb;
+            int dira = -5000, dirb = -5000, dirc = -5000, dird = -5000, dire = -5000;
+            for (int u = startu; u <= stopu; u++)
+            {
+                if (!(y == 1 || mp[x - 1 + u] == PEAK || mp[x + u] == PEAK || mp[x + 1 + u] == PEAK)) continue;
+                if (!(y == height - 2 || mn[x - 1 - u] == PEAK || mn[x - u] == PEAK || mn[x + 1 - u] == PEAK)) continue;
+                const int diffsn = sad3(sc, x, sn, x - u);
+                const int diffsp = sad3(sc, x, sp, x + u);
+                const int diffps = sad3(sp, x, sc, x - u);
+                const int diffns = sad3(sn, x, sc, x + u);
+                const int diff = diffsn + diffsp + diffps + diffns;
+                int diffd = diffsp + diffns, diffe = diffsn + diffps;
+                if (diff < minb) { dirb = u; minb = diff; }
+                if (y > 1)
+                {
+                    const int diff2pp = sad3(s2p, x, sp, x - u);
+                    const int diffp2p = sad3(sp, x, s2p, x + u);
+                    const int diffa = diff + diff2pp + diffp2p;
+                    diffd += diffp2p;
+                    diffe += diff2pp;
+                    if (diffa < mina) { dira = u; mina = diffa; }
+                }
+                if (y < height - 2)
+                {
+                    const int diff2nn = sad3(s2n, x, sn, x + u);
+                    const int diffn2n = sad3(sn, x, s2n, x - u);
+                    const int diffc = diff + diff2nn + diffn2n;
+                    diffd += diff2nn;
+                    diffe += diffn2n;
+                    if (diffc < minc) { dirc = u; minc = diffc; }
+                }
+                if (diffd < mind) { dird = u; mind = diffd; }
+                if (diffe < mine) { dire = u; mine = diffe; }
+            }
+            int order[5], k = 0;
+            if (dira != -5000) order[k++] = dira;
+            if (dirb != -5000) order[k++] = dirb;
+            if (dirc != -5000) order[k++] = dirc;
+            if (dird != -5000) order[k++] = dird;
+            if (dire != -5000) order[k++] = dire;
+            out = NEUTRAL;
+            if (k > 1)
+            {
+                const int mid = sorted_mid(order, k);
+                const int tlim = max((int)c_limlut[iabs(mid)] >> 2, 2);
+                int sum = 0, count = 0;
+                for (int i = 0; i < k; i++)
+                    if (iabs(order[i] - mid) <= tlim) { count++; sum += order[i]; }
+                if (count > 1) out = (NEUTRAL + ((int)((float)sum / (float)count) * 4)) & 0xff;
+            }
+        }
+    }
+    *o = (uint8_t)out;
+}
+
+// filter_dir_map / expand_dir_map and their _2x forms.
+// a = edge mask, b = direction map in, c = out.  step = 1 (half height) or 2.
+// step 1: rows 1..height-2, neighbours y+-1, mask row y.
+// step 2: rows y0, y0+2, ... < height-1, neighbours y+-2 (guarded by y>1 / y<height-2), mask rows y-1 and y+1.
+__global__ void k_dir_map(P3 P, int step, int y0, int expand)
+{
+    XY_PLANE(P);
+    if (x >= width || y >= height) return;
+    const uint8_t *dc = P.b[pl] + (size_t)y * pitch;
+    int out = dc[x];                                           // bit_blit
+    const bool row_ok = step == 1 ? (y >= 1 && y < height - 1) : (y >= y0 && y < height - 1 && ((y - y0) & 1) == 0);
+    if (row_ok && x >= 1 && x < width - 1)
+    {
+        bool masked;
+        if (step == 1) masked = P.a[pl][(size_t)y * pitch + x] == PEAK;
+        else           masked = P.a[pl][(size_t)(y - 1) * pitch + x] == PEAK || P.a[pl][(size_t)(y + 1) * pitch + x] == PEAK;
+        if (masked && !(expand && dc[x] != PEAK))
+        {
+            int order[9], u = 0;
+            if (step == 1 || y > 1) u = collect3(order, u, dc - step * pitch, x, false);
+            u = collect3(order, u, dc, x, expand);
+            if (step == 1 || y < height - 2) u = collect3(order, u, dc + step * pitch, x, false);
+            if (u < (expand ? 5 : 4))
+            {
+                if (!expand) out = PEAK;
+            }
+            else
+            {
+                const int mid = sorted_mid(order, u);
+                int count;
+                const int val = vote(order, u, mid, c_limlut[iabs(mid - NEUTRAL) >> 2], count);
+                if (expand)
+                {
+                    if (count >= 5) out = val & 0xff;
+                }
+                else if (count < 4 || (count < 5 && dc[x] == PEAK))
+                    out = PEAK;
+                else
+                    out = val & 0xff;
+            }
+        }
+    }
+    P.c[pl][(size_t)y * pitch + x] = (uint8_t)out;
+}
+
+__device__ __forceinline__ bool trips(const uint8_t *side, const uint8_t *dc, int x, int from, int to, int lim)
+{
+    const int ref = dc[x];
+    for (int j = from; j <= to; j++)
+    {
+        const int s = side[x + j], c = dc[x + j];
+        if ((iabs(s - ref) > lim && s != PEAK) || (c == PEAK && s == PEAK) || (iabs(c - ref) > lim && c != PEAK))
+            return true;
+    }
+    return false;
+}
+
+// a = mskp, b = dmsk in, c = out
+__global__ void k_filter_map(P3 P)
+{
+    XY_PLANE(P);
+    if (x >= width || y >= height) return;
+    const uint8_t *dc = P.b[pl] + (size_t)y * pitch;
+    int out = dc[x];
+    if (x >= 1 && x < width - 1 && y >= 1 && y < height - 1 && dc[x] != PEAK && P.a[pl][(size_t)y * pitch + x] == PEAK)
+    {
+        const uint8_t *dp = dc - pitch, *dn = dc + pitch;
+        int dir = ((int)dc[x] - NEUTRAL) >> 2;
+        const int lim = max(iabs(dir) * 2, 12 << 2);
+        dir >>= 2;
+        bool ict;
+        if (dir < 0) ict = trips(dp, dc, x, max(-x, dir), 0, lim);
+        else         ict = trips(dp, dc, x, 0, min(width - x - 1, dir), lim);
+        if (ict)
+        {
+            bool icb;
+            if (dir < 0) icb = trips(dn, dc, x, 0, min(width - x - 1, iabs(dir)), lim);
+            else         icb = trips(dn, dc, x, max(-x, -dir), 0, lim);
+            if (icb) out = PEAK;
+        }
+    }
+    P.c[pl][(size_t)y * pitch + x] = (uint8_t)out;
+}
+
+// line doubling of three half-height planes: a->d, b->e, c->f ; height = half height
+__global__ void k_upscale3(P3 P)
+{
+    XY_PLANE(P);
+    if (x >= pitch || y >= height) return;
+    const size_t s = (size_t)y * pitch + x, d0 = (size_t)(2 * y) * pitch + x, d1 = d0 + pitch;
+    const uint8_t va = P.a[pl][s], vb = P.b[pl][s], vc = P.c[pl][s];
+    P.d[pl][d0] = va; P.d[pl][d1] = va;
+    P.e[pl][d0] = vb; P.e[pl][d1] = vb;
+    P.f[pl][d0] = vc; P.f[pl][d1] = vc;
+}
+
+// a = msk2p, b = dmsk (tmp2p2), c = out (tmp2p)
+__global__ void k_mark_2x(P3 P, int y0)
+{
+    XY_PLANE(P);
+    if (x >= pitch || y >= height) return;
+    int out = 255;                                            // memset(dstp, 255, pitch*height)
+    if (y >= y0 && y < height - 1 && ((y - y0) & 1) == 0 && x >= 1 && x < width - 1)
+    {
+        const uint8_t *d0 = P.b[pl] + (size_t)(y - 1) * pitch, *d1 = d0 + 2 * (size_t)pitch;
+        const uint8_t *m0 = P.a[pl] + (size_t)(y - 1) * pitch, *m1 = m0 + 2 * (size_t)pitch;
+        if (m0[x] == PEAK || m1[x] == PEAK)
+        {
+            int order[6], v = 0;
+            v = collect3(order, v, d0, x, false);
+            v = collect3(order, v, d1, x, false);
+            if (v >= 3)
+            {
+                const int mid = sorted_mid(order, v);
+                const int lim = c_limlut[iabs(mid - NEUTRAL) >> 2];
+                int u = 0;
+                if (iabs((int)d0[x - 1] - (int)d1[x - 1]) <= lim || d0[x - 1] == PEAK || d1[x - 1] == PEAK) u++;
+                if (iabs((int)d0[x] - (int)d1[x]) <= lim || d0[x] == PEAK || d1[x] == PEAK) u++;
+                if (iabs((int)d0[x + 1] - (int)d1[x - 1]) <= lim || d0[x + 1] == PEAK || d1[x + 1] == PEAK) u++;   // sic (:835)
+                if (u >= 2)
+                {
+                    int count;
+                    const int val = vote(order, v, mid, lim, count);
+                    if (!(count < v - 2 || count < 2)) out = val & 0xff;
+                }
+            }
+        }
+    }
+    P.c[pl][(size_t)y * pitch + x] = (uint8_t)out;
+}
+
+// a = msk2p, b = dmsk in, c = out.  Every pixel of a fillable gap computes the same
+// (u, v, back, forward, verdict) as its neighbours in the gap (:1053-1120), so each
+// thread only writes its own pixel.
+__global__ void k_fill_gaps(P3 P, int y0)
+{
+    XY_PLANE(P);
+    if (x >= width || y >= height) return;
+    const uint8_t *dc = P.b[pl] + (size_t)y * pitch;
+    int out = dc[x];
+    if (y >= y0 && y < height - 1 && ((y - y0) & 1) == 0 && x >= 1 && x < width - 1)
+    {
+        const uint8_t *mc = P.a[pl] + (size_t)(y - 1) * pitch;
+        const uint8_t *mn = mc + 2 * (size_t)pitch;
+        if (dc[x] == PEAK && (mc[x] == PEAK || mn[x] == PEAK))
+        {
+            const uint8_t *dp = dc - 2 * (ptrdiff_t)pitch, *dn = dc + 2 * (ptrdiff_t)pitch;
+            const uint8_t *mp = mc - 2 * (ptrdiff_t)pitch, *mnn = mn + 2 * (ptrdiff_t)pitch;
+            int u = x - 1, back = 500, forward = -500;
+            while (u)
+            {
+                if (dc[u] != PEAK) { back = dc[u]; break; }
+                if (mc[u] != PEAK && mn[u] != PEAK) break;
+                u--;
+            }
+            int v = x + 1;
+            while (v < width)
+            {
+                if (dc[v] != PEAK) { forward = dc[v]; break; }
+                if (mc[v] != PEAK && mn[v] != PEAK) break;
+                v++;
+            }
+            int tc = 1, bc = 1, mint = 500, maxt = -20, minb = 500, maxb = -20;
+            for (int j = u; j <= v; j++)
+            {
+                if (tc)
+                {
+                    if (y <= 2 || dp[j] == PEAK || (mp[j] != PEAK && mc[j] != PEAK)) { tc = 0; mint = maxt = 20; }
+                    else { mint = min(mint, (int)dp[j]); maxt = max(maxt, (int)dp[j]); }
+                }
+                if (bc)
+                {
+                    if (y >= height - 3 || dn[j] == PEAK || (mn[j] != PEAK && mnn[j] != PEAK)) { bc = 0; minb = maxb = 20; }
+                    else { minb = min(minb, (int)dn[j]); maxb = max(maxb, (int)dn[j]); }
+                }
+            }
+            if (maxt == -20) maxt = mint = 20;
+            if (maxb == -20) maxb = minb = 20;
+            const int far = max(iabs(forward - NEUTRAL), iabs(back - NEUTRAL));
+            const int thresh = max(max(far >> 2, 8), max(iabs(mint - maxt), iabs(minb - maxb)));
+            const int flim = min(far >> 2, 6);
+            if (iabs(forward - back) <= thresh && (v - u - 1 <= flim || tc || bc))
+            {
+                const double stepd = (double)(forward - back) / (double)(v - u);
+                const int j = x - u - 1;
+                out = (back + (int)(j * stepd + 0.5)) & 0xff;
+            }
+        }
+    }
+    P.c[pl][(size_t)y * pitch + x] = (uint8_t)out;
+}
+
+// a = dmsk (tmp2p, in/out), b = dst (dst2p, in/out), c = omsk (tmp2p2).
+// grid.y = processed rows (+1 for the border-row copy), block = one wavefront.
+__global__ __launch_bounds__(64) void k_lattice(P3 P, int field, int nt4, int nt7, int nt8, int nt)
+{
+    const int pl = blockIdx.z;
+    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
+    const int lane = threadIdx.x;
+    const int nrows = (height - 1 - (2 - field) + 1) / 2;      // rows y0, y0+2, ... < height-1
+    uint8_t *dst = P.b[pl];
+    if ((int)blockIdx.y >= nrows)
+    {
+        if ((int)blockIdx.y == nrows)                          // the one-row blit (:1162-1179)
+            for (int xx = lane; xx < width; xx += 64)
+            {
+                if (field == 1) dst[(size_t)(height - 1) * pitch + xx] = dst[(size_t)(height - 2) * pitch + xx];
+                else            dst[xx] = dst[pitch + xx];
+            }
+        return;
+    }
+    const int y = (2 - field) + 2 * blockIdx.y;
+    const uint8_t *top = dst + (size_t)(y - 1) * pitch, *bot = top + 2 * (size_t)pitch;
+    uint8_t *mid = dst + (size_t)y * pitch;
+    const uint8_t *ot = P.c[pl] + (size_t)(y - 1) * pitch, *ob = ot + 2 * (size_t)pitch;
+    uint8_t *dm = P.a[pl] + (size_t)y * pitch;
+
+    // value standing at dm[x-1] for x == 0: memory just before the row, never written by this pass
+    int carry_val = dm[-1];
+    for (int x0 = 0; x0 < width; x0 += 64)
+    {
+        const int x = x0 + lane;
+        const bool live = x < width;
+        // ---- both outcomes of this pixel
+        int d = 0, lim = 0, valA = 0, newA = 0, valB = 0, newB = 0;
+        bool always_a = false, right = false;
+        if (live)
+        {
+            d = dm[x];
+            lim = c_limlut[iabs(d - NEUTRAL) >> 2];
+            const int avg = ((int)top[x] + (int)bot[x] + 1) >> 1;
+            valA = avg;
+            newA = d == PEAK ? PEAK : NEUTRAL;
+            always_a = d == PEAK;
+            right = iabs(d - (int)dm[x + 1]) > lim;
+            if (!always_a)
+            {
+                bool done = false;
+                if (lim < 9)
+                {
+                    const int t0 = top[x - 1], t1 = top[x], t2 = top[x + 1], b0 = bot[x - 1], b1 = bot[x], b2 = bot[x + 1];
+                    const int sum = t0 + t1 + t2 + b0 + b1 + b2;
+                    const int sumsq = t0 * t0 + t1 * t1 + t2 * t2 + b0 * b0 + b1 * b1 + b2 * b2;
+                    if (6 * sumsq - sum * sum < 576) { valB = avg; newB = PEAK; done = true; }
+                }
+                if (!done && x > 1 && x < width - 2)
+                {
+                    const int t = top[x], b = bot[x];
+                    const int tl = max((int)top[x - 2], (int)top[x - 1]), tr = max((int)top[x + 2], (int)top[x + 1]);
+                    const int bl = max((int)bot[x - 2], (int)bot[x - 1]), br = max((int)bot[x + 2], (int)bot[x + 1]);
+                    const int tl2 = min((int)top[x - 2], (int)top[x - 1]), tr2 = min((int)top[x + 2], (int)top[x + 1]);
+                    const int bl2 = min((int)bot[x - 2], (int)bot[x - 1]), br2 = min((int)bot[x + 2], (int)bot[x + 1]);
+                    if ((t < tl - 3 && t < tr - 3 && b < bl - 3 && b < br - 3) ||
+                        (t > tl2 + 3 && t > tr2 + 3 && b > bl2 + 3 && b > br2 + 3))
+                    { valB = avg; newB = NEUTRAL; done = true; }
+                }
+                if (!done)
+                {
+                    int dir = (d - NEUTRAL + 2) >> 2;
+                    int val = avg;
+                    const int startu = (dir - 2 < 0) ? max(-x + 1, max(dir - 2, -width + 2 + x)) : min(x - 1, min(dir - 2, width - 2 - x));
+                    const int stopu = (dir + 2 < 0) ? max(-x + 1, max(dir + 2, -width + 2 + x)) : min(x - 1, min(dir + 2, width - 2 - x));
+                    int mn = nt8;
+#define NEAR(row, i) ((row)[i] != PEAK && iabs((int)(row)[i] - d) <= lim)
+                    for (int u = startu; u <= stopu; u++)
+                    {
+                        const int diff = sad3(top, x, bot, x - u) + sad3(bot, x, top, x + u);
+                        if (!(diff < mn && (NEAR(ot, x - 1 + u) || NEAR(ot, x + u) || NEAR(ot, x + 1 + u)) &&
+                              (NEAR(ob, x - 1 - u) || NEAR(ob, x - u) || NEAR(ob, x + 1 - u))))
+                            continue;
+                        const int h0 = u >> 1, h1 = (u + 1) >> 1;
+                        const int diff2 = sad3(top, x + h0, bot, x - h0);
+                        const int o0 = ot[x + h0], o1 = ot[x + h1], q0 = ob[x - h0], q1 = ob[x - h1];
+                        if (!(diff2 < nt4 && (((iabs(o0 - q0) <= lim || iabs(o0 - q1) <= lim) && o0 != PEAK) ||
+                                              ((iabs(o1 - q0) <= lim || iabs(o1 - q1) <= lim) && o1 != PEAK))))
+                            continue;
+                        if ((iabs(d - o0) <= lim || iabs(d - o1) <= lim) && (iabs(d - q0) <= lim || iabs(d - q1) <= lim))
+                        {
+                            val = ((int)top[x + h0] + (int)top[x + h1] + (int)bot[x - h0] + (int)bot[x - h1] + 2) >> 2;
+                            mn = diff;
+                            dir = u;
+                        }
+                    }
+#undef NEAR
+                    if (mn != nt8)
+                    {
+                        valB = val;
+                        newB = (NEUTRAL + dir * 4) & 0xff;
+                    }
+                    else
+                    {
+                        const int lo = min((int)top[x], (int)bot[x]), hi = max((int)top[x], (int)bot[x]);
+                        const int dd = pl == 0 ? 4 : 2;
+                        const int su = max(-x + 1, -dd), eu = min(width - 2 - x, dd);
+                        mn = nt7;
+                        for (int u = su; u <= eu; u++)
+                        {
+                            const int h0 = u >> 1, h1 = (u + 1) >> 1;
+                            const int p1 = (int)top[x + h0] + (int)top[x + h1];
+                            const int p2 = (int)bot[x - h0] + (int)bot[x - h1];
+                            const int diff = sad3(top, x, bot, x - u) + sad3(bot, x, top, x + u) + iabs(p1 - p2);
+                            if (diff < mn)
+                            {
+                                const int valt = (p1 + p2 + 2) >> 2;
+                                if (valt >= lo && valt <= hi) { val = valt; mn = diff; dir = u; }
+                            }
+                        }
+                        valB = val;
+                        newB = (mn == 7 * nt) ? NEUTRAL : ((NEUTRAL + dir * 4) & 0xff);
+                    }
+                }
+            }
+        }
+        // ---- resolve the left-to-right chain inside the chunk
+        // outcome 0 = A, 1 = B.  What this pixel does depends on the value left standing at x-1.
+        const int prevA = __shfl_up(newA, 1, 64), prevB = __shfl_up(newB, 1, 64);
+        unsigned m;                                            // bit s = outcome when the left pixel took outcome s
+        if (!live || always_a) m = 0u;
+        else
+        {
+            const int pa = lane == 0 ? carry_val : prevA;
+            const int pb = lane == 0 ? carry_val : prevB;
+            const unsigned oa = (right && iabs(d - pa) > lim) ? 0u : 1u;
+            const unsigned ob2 = (right && iabs(d - pb) > lim) ? 0u : 1u;
+            m = oa | (ob2 << 1);
+        }
+        // inclusive prefix composition: m[x] := m[x] o m[x-1] o ... (apply the earlier map first)
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1)
+        {
+            const unsigned e = __shfl_up(m, off, 64);
+            if (lane >= off)
+                m = ((m >> (e & 1u)) & 1u) | (((m >> ((e >> 1) & 1u)) & 1u) << 1);
+        }
+        // lane 0's map ignores its input (it was built from carry_val), so every composed map is constant
+        const unsigned outcome = m & 1u;
+        if (live)
+        {
+            mid[x] = (uint8_t)(outcome ? valB : valA);
+            const int nd = outcome ? newB : newA;
+            if (nd != d) dm[x] = (uint8_t)nd;
+            carry_val = nd;
+        }
+        // value standing at the last pixel of this chunk
+        const int last = min(63, width - 1 - x0);
+        carry_val = __shfl(carry_val, last, 64);
+    }
+}
+
+// a = src, b = dst : copies `width` bytes of every row (eedi2_bit_blit)
+__global__ void k_blit(P3 P)
+{
+    XY_PLANE(P);
+    if (x >= width || y >= height) return;
+    P.b[pl][(size_t)y * pitch + x] = P.a[pl][(size_t)y * pitch + x];
+}
+
+// a = nmsk, b = omsk, c = dst (in place, row y from rows y+-1)
+__global__ void k_post(P3 P, int y0)
+{
+    XY_PLANE(P);
+    if (x >= width || y >= height - 1 || y < y0 || ((y - y0) & 1)) return;
+    const int nm = P.a[pl][(size_t)y * pitch + x], om = P.b[pl][(size_t)y * pitch + x];
+    const int lim = c_limlut[iabs(nm - NEUTRAL) >> 2];
+    if (iabs(nm - om) > lim && om != PEAK && om != NEUTRAL)
+    {
+        uint8_t *d = P.c[pl] + (size_t)y * pitch + x;
+        *d = (uint8_t)(((int)d[-pitch] + (int)d[pitch] + 1) >> 1);
+    }
+}
+
+} // namespace
+
+// ------------------------------------------------------------------- engine
 Eedi2Engine::Eedi2Engine(hbhip_ctx *ctx, const PicGeometry &geo, const Eedi2Params &p)
     : ctx_(ctx), geo_(geo), par_(p) {}
-Eedi2Engine::~Eedi2Engine() {}
-int Eedi2Engine::init() { return HBHIP_ERR_UNSUPPORTED; }
-int Eedi2Engine::run(const DevPicture *, int) { return HBHIP_ERR_UNSUPPORTED; }
-int Eedi2Engine::alloc_frame(EediFrame &, int, int) { return HBHIP_ERR_UNSUPPORTED; }
+
+Eedi2Engine::~Eedi2Engine()
+{
+    for (auto &f : half_) if (f.alloc) (void)hipFree(f.alloc);
+    for (auto &f : full_) if (f.alloc) (void)hipFree(f.alloc);
+}
+
+int Eedi2Engine::alloc_frame(EediFrame &f, int width, int height)
+{
+    size_t off[3], total = 0;
+    for (int c = 0; c < 3; c++)
+    {
+        f.width[c] = c ? -((-width) >> geo_.log2_cw) : width;
+        f.height[c] = c ? -((-height) >> geo_.log2_ch) : height;
+        f.stride[c] = hbhip_align_up(f.width[c], 64);          // hb_image_stride
+        off[c] = total;
+        total += (size_t)f.stride[c] * f.height[c];
+    }
+    f.bytes = total + 2 * GUARD;
+    HBHIP_CHECK(ctx_, hipMalloc((void **)&f.alloc, f.bytes));
+    HBHIP_CHECK(ctx_, hipMemsetAsync(f.alloc, 0, f.bytes, ctx_->stream));
+    f.base = f.alloc + GUARD;
+    for (int c = 0; c < 3; c++) f.plane[c] = f.base + off[c];
+    return HBHIP_OK;
+}
+
+int Eedi2Engine::init()
+{
+    // the reference overruns its scratch planes when a chroma plane has an odd number
+    // of rows (upscale_by_2 writes 2*ceil(h/2) rows); refuse instead of guessing
+    if (geo_.height % (2 << geo_.log2_ch) != 0 || geo_.height < 16 || geo_.width < 16)
+        return HBHIP_ERR_UNSUPPORTED;
+    if (par_.post_processing != 0 && par_.post_processing != 1) return HBHIP_ERR_UNSUPPORTED;
+    for (auto &f : half_)
+    {
+        int rc = alloc_frame(f, geo_.width, geo_.height / 2);      // decomb.c:291-296
+        if (rc != HBHIP_OK) return rc;
+    }
+    for (auto &f : full_)
+    {
+        int rc = alloc_frame(f, geo_.width, geo_.height);          // decomb.c:299-303
+        if (rc != HBHIP_OK) return rc;
+    }
+    HBHIP_CHECK(ctx_, hipStreamSynchronize(ctx_->stream));
+    return HBHIP_OK;
+}
+
+int Eedi2Engine::run(const DevPicture *cur, int tff)
+{
+    EediFrame &srcp = half_[0], &mskp = half_[1], &tmpp = half_[2], &dstp = half_[3];
+    EediFrame &dst2p = full_[0], &tmp2p2 = full_[1], &msk2p = full_[2], &tmp2p = full_[3], &dst2mp = full_[4];
+    const dim3 blk(64, 4);
+    auto grid_for = [&](const EediFrame &f, bool whole_pitch) {
+        const int w = whole_pitch ? f.stride[0] : f.width[0];
+        return dim3((w + 63) / 64, (f.height[0] + 3) / 4, 3);
+    };
+    auto geom = [&](P3 &P, const EediFrame &f) {
+        for (int c = 0; c < 3; c++) { P.pitch[c] = f.stride[c]; P.width[c] = f.width[c]; P.height[c] = f.height[c]; }
+    };
+    auto bind = [&](uint8_t *(&slot)[3], const EediFrame &f) { for (int c = 0; c < 3; c++) slot[c] = f.plane[c]; };
+
+    P3 P;
+    memset(&P, 0, sizeof(P));
+
+    // field extraction (decomb_template.c:455-473)
+    geom(P, srcp);
+    for (int c = 0; c < 3; c++) P.a[c] = cur->plane[c];
+    bind(P.b, srcp);
+    {
+        int rows[3];
+        for (int c = 0; c < 3; c++) rows[c] = (dst2p.height[c] + 1) / 2;
+        HBHIP_LAUNCH(ctx_, "eedi2_fill_half", k_fill_half, grid_for(srcp, true), blk, 0, P,
+                     cur->pitch[0], cur->pitch[1], cur->pitch[2], !tff, rows[0], rows[1], rows[2]);
+    }
+    // half-height passes
+    geom(P, srcp);
+    bind(P.a, srcp); bind(P.b, mskp);
+    HBHIP_LAUNCH(ctx_, "eedi2_edge_mask", k_edge_mask, grid_for(srcp, true), blk, 0, P,
+                 par_.magnitude_threshold * 10, par_.laplacian_threshold * 81, par_.variance_threshold);
+    bind(P.a, mskp); bind(P.b, tmpp);
+    HBHIP_LAUNCH(ctx_, "eedi2_erode", k_morph, grid_for(srcp, false), blk, 0, P, par_.erosion_threshold, 0);
+    bind(P.a, tmpp); bind(P.b, mskp);
+    HBHIP_LAUNCH(ctx_, "eedi2_dilate", k_morph, grid_for(srcp, false), blk, 0, P, par_.dilation_threshold, 1);
+    bind(P.a, mskp); bind(P.b, tmpp);
+    HBHIP_LAUNCH(ctx_, "eedi2_erode", k_morph, grid_for(srcp, false), blk, 0, P, par_.erosion_threshold, 0);
+    bind(P.a, tmpp); bind(P.b, mskp);
+    HBHIP_LAUNCH(ctx_, "eedi2_small_gaps", k_small_gaps, grid_for(srcp, false), blk, 0, P);
+    bind(P.a, mskp); bind(P.b, srcp); bind(P.c, tmpp);
+    HBHIP_LAUNCH(ctx_, "eedi2_calc_directions", k_calc_directions, grid_for(srcp, true), blk, 0, P,
+                 par_.maximum_search_distance, (par_.noise_threshold * 13) & 0xff, (par_.noise_threshold * 19) & 0xff);
+    bind(P.a, mskp); bind(P.b, tmpp); bind(P.c, dstp);
+    HBHIP_LAUNCH(ctx_, "eedi2_filter_dir_map", k_dir_map, grid_for(srcp, false), blk, 0, P, 1, 1, 0);
+    bind(P.a, mskp); bind(P.b, dstp); bind(P.c, tmpp);
+    HBHIP_LAUNCH(ctx_, "eedi2_expand_dir_map", k_dir_map, grid_for(srcp, false), blk, 0, P, 1, 1, 1);
+    bind(P.a, mskp); bind(P.b, tmpp); bind(P.c, dstp);
+    HBHIP_LAUNCH(ctx_, "eedi2_filter_map", k_filter_map, grid_for(srcp, false), blk, 0, P);
+    // line doubling
+    bind(P.a, srcp); bind(P.b, dstp); bind(P.c, mskp);
+    bind(P.d, dst2p); bind(P.e, tmp2p2); bind(P.f, msk2p);
+    HBHIP_LAUNCH(ctx_, "eedi2_upscale_by_2", k_upscale3, grid_for(srcp, true), blk, 0, P);
+    // full-height passes
+    geom(P, dst2p);
+    const int y0 = 2 - tff;
+    bind(P.a, msk2p); bind(P.b, tmp2p2); bind(P.c, tmp2p);
+    HBHIP_LAUNCH(ctx_, "eedi2_mark_directions_2x", k_mark_2x, grid_for(dst2p, true), blk, 0, P, y0);
+    bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
+    HBHIP_LAUNCH(ctx_, "eedi2_filter_dir_map_2x", k_dir_map, grid_for(dst2p, false), blk, 0, P, 2, y0, 0);
+    bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
+    HBHIP_LAUNCH(ctx_, "eedi2_expand_dir_map_2x", k_dir_map, grid_for(dst2p, false), blk, 0, P, 2, y0, 1);
+    bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
+    HBHIP_LAUNCH(ctx_, "eedi2_fill_gaps_2x", k_fill_gaps, grid_for(dst2p, false), blk, 0, P, y0);
+    bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
+    HBHIP_LAUNCH(ctx_, "eedi2_fill_gaps_2x", k_fill_gaps, grid_for(dst2p, false), blk, 0, P, y0);
+    // lattice
+    bind(P.a, tmp2p); bind(P.b, dst2p); bind(P.c, tmp2p2);
+    {
+        const int nrows = (dst2p.height[0] - 1 - y0 + 1) / 2;
+        const int nt = par_.noise_threshold;
+        HBHIP_LAUNCH(ctx_, "eedi2_interpolate_lattice", k_lattice, dim3(1, nrows + 1, 3), dim3(64), 0, P, tff,
+                     (nt * 4) & 0xff, (nt * 7) & 0xff, (nt * 8) & 0xff, nt);
+    }
+    if (par_.post_processing == 1 || par_.post_processing == 3)
+    {
+        bind(P.a, tmp2p); bind(P.b, tmp2p2);
+        HBHIP_LAUNCH(ctx_, "eedi2_bit_blit", k_blit, grid_for(dst2p, false), blk, 0, P);
+        bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
+        HBHIP_LAUNCH(ctx_, "eedi2_filter_dir_map_2x", k_dir_map, grid_for(dst2p, false), blk, 0, P, 2, y0, 0);
+        bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
+        HBHIP_LAUNCH(ctx_, "eedi2_expand_dir_map_2x", k_dir_map, grid_for(dst2p, false), blk, 0, P, 2, y0, 1);
+        bind(P.a, tmp2p); bind(P.b, tmp2p2); bind(P.c, dst2p);
+        HBHIP_LAUNCH(ctx_, "eedi2_post_process", k_post, grid_for(dst2p, false), blk, 0, P, y0);
+    }
+    HBHIP_CHECK(ctx_, hipGetLastError());
+    return HBHIP_OK;
+}

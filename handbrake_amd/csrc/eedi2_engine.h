@@ -47,6 +47,4 @@ private:
     Eedi2Params par_;
     EediFrame   half_[4];    // SRCPF, MSKPF, TMPPF, DSTPF          (decomb.c:64-68)
     EediFrame   full_[5];    // DST2PF, TMP2PF2, MSK2PF, TMP2PF, DST2MPF (decomb.c:69-74)
-    uint32_t   *lattice_tmp_ = nullptr;
-    uint8_t    *d_limlut_ = nullptr;
 };

@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "hbhip_filter_process_dev", "hbhip_filter_flush", "hbhip_filter_pending", "hbhip_filter_destroy",
     "hbhip_filter_out_geometry", "hbhip_nlmeans_create", "hbhip_nlmeans_set_batch",
     "hbhip_lapsharp_create", "hbhip_unsharp_create", "hbhip_chroma_smooth_create",
-    "hbhip_decomb_create", "hbhip_decomb_push", "hbhip_decomb_push_dev",
+    "hbhip_decomb_create", "hbhip_decomb_push", "hbhip_decomb_push_dev", "hbhip_decomb_debug_eedi_plane",
     "hbhip_comb_detect_create", "hbhip_comb_detect_store", "hbhip_comb_detect_store_dev",
     "hbhip_comb_detect_classify",
 ]
@@ -237,3 +237,71 @@ def nlmeans_device_filter(ctx: Ctx, settings: str, width: int, height: int, batc
           ctx.h, "hbhip_nlmeans_create")
     check(lib().hbhip_nlmeans_set_batch(h, batch), ctx.h, "set_batch")
     return DeviceFilter(ctx, h)
+
+
+class DecombParams(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("mode", "parity", "magnitude_threshold", "variance_threshold",
+                                       "laplacian_threshold", "dilation_threshold", "erosion_threshold",
+                                       "noise_threshold", "maximum_search_distance", "post_processing")]
+
+
+def host_frame(planes) -> HostFrame:
+    """HostFrame over three 2-D uint8 numpy arrays (kept alive by the caller)."""
+    f = HostFrame()
+    for i, a in enumerate(planes):
+        f.plane[i] = a.ctypes.data
+        f.stride[i] = a.strides[0]
+    return f
+
+
+class DecombDevice:
+    """A decomb instance driven through the raw C ABI with host frames (tests of the
+    EEDI2 scratch buffers; the hb_filter_object_t path is hb_filter_decomb_hip)."""
+
+    def __init__(self, ctx: Ctx, width, height, mode=8, parity=-1, magnitude=10, variance=20, laplacian=20,
+                 dilation=4, erosion=2, noise=50, search=24, postproc=1):
+        L = lib()
+        L.hbhip_decomb_create.argtypes = [C.c_void_p, C.POINTER(DecombParams)] + [C.c_int] * 5 + [C.POINTER(C.c_void_p)]
+        L.hbhip_decomb_push.argtypes = [C.c_void_p, C.POINTER(HostFrame), C.c_int64, C.c_int, C.c_int]
+        L.hbhip_decomb_debug_eedi_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                                    C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        par = DecombParams(mode, parity, magnitude, variance, laplacian, dilation, erosion, noise, search, postproc)
+        h = C.c_void_p()
+        check(L.hbhip_decomb_create(ctx.h, C.byref(par), width, height, 8, 1, 1, C.byref(h)), ctx.h, "decomb_create")
+        self.ctx, self.h, self.w, self.hgt = ctx, h, width, height
+        self.tag = 0
+
+    def push(self, planes, flags=0x0008, combed=2):
+        import numpy as np
+        keep = [np.ascontiguousarray(p) for p in planes]
+        fr = host_frame(keep)
+        check(lib().hbhip_decomb_push(self.h, C.byref(fr), self.tag, flags, combed), self.ctx.h, "decomb_push")
+        self.tag += 1
+
+    def pull(self):
+        import numpy as np
+        if lib().hbhip_filter_pending(self.h) <= 0:
+            return None
+        cw, ch = (self.w + 1) // 2, (self.hgt + 1) // 2
+        out = [np.zeros((self.hgt, self.w), np.uint8), np.zeros((ch, cw), np.uint8), np.zeros((ch, cw), np.uint8)]
+        fr = host_frame(out)
+        tag = C.c_int64()
+        check(lib().hbhip_filter_pull(self.h, C.byref(fr), C.byref(tag)), self.ctx.h, "pull")
+        return tag.value, out
+
+    def flush(self):
+        check(lib().hbhip_filter_flush(self.h), self.ctx.h, "flush")
+
+    def eedi_plane(self, buffer, plane):
+        import numpy as np
+        st, ht = C.c_int(), C.c_int()
+        check(lib().hbhip_decomb_debug_eedi_plane(self.h, buffer, plane, None, 0, C.byref(st), C.byref(ht)), self.ctx.h)
+        a = np.zeros((ht.value, st.value), np.uint8)
+        check(lib().hbhip_decomb_debug_eedi_plane(self.h, buffer, plane, a.ctypes.data, st.value, C.byref(st), C.byref(ht)),
+              self.ctx.h, "debug_eedi_plane")
+        return a
+
+    def close(self):
+        if self.h:
+            lib().hbhip_filter_destroy(self.h)
+            self.h = None

@@ -175,6 +175,10 @@ int hbhip_decomb_create(hbhip_ctx *ctx, const hbhip_decomb_params *p, int width,
  * (input tag << 1) | field_index, field_index = 1 for the second frame of a bob pair. */
 int hbhip_decomb_push(hbhip_filter *f, const hbhip_host_frame *in, int64_t tag, int pic_flags, int combed);
 int hbhip_decomb_push_dev(hbhip_filter *f, const hbhip_dev_frame *in, int64_t tag, int pic_flags, int combed);
+/* Test hook: copy one plane of an EEDI2 scratch frame to the host (buffer 0..3 = eedi_half[],
+ * 4..8 = eedi_full[], decomb.c:64-74); dst == NULL only queries stride/height. */
+int hbhip_decomb_debug_eedi_plane(hbhip_filter *f, int buffer, int plane, uint8_t *dst, int dst_stride,
+                                  int *stride, int *height);
 
 /* ---- Comb detect (replaces comb_detect.c:1051-1072 comb_segmenter and the passes it
  *      runs: comb_detect_template.c:288-402/789-933, comb_detect.c:221-276, 384-454,

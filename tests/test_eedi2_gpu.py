@@ -1,0 +1,73 @@
+"""GPU parity: EEDI2 on the device, every scratch frame of every pass against the
+oracle (which is itself pinned buffer-by-buffer to the reference), then the whole
+decomb+EEDI2 filter through the hb_filter_object_t surface."""
+import numpy as np
+import pytest
+
+from handbrake_amd import hbrt, hip, synth
+import oracle_lib as ol
+import oracle_stream as os_
+
+pytestmark = pytest.mark.gpu
+TFF = 0x0008
+
+
+@pytest.mark.parametrize("w,h", [(128, 72), (638, 360), (1920, 1080)])
+def test_every_scratch_buffer(built, w, h):
+    """mode 24 = EEDI2 + bob, TFF: each pushed frame runs EEDI2 twice (tff=1, then tff=0).
+    After each push the device scratch frames must equal the oracle's after the same runs."""
+    frames = synth.stream("interlaced", w, h, 3)
+    ctx = hip.Ctx(0)
+    dev = hip.DecombDevice(ctx, w, h, mode=24)
+    oe = ol.OrcEedi2(w, h)
+    try:
+        dev.push(frames[0])                      # first frame only primes the ring
+        for t in range(1, 3):
+            dev.push(frames[t])                  # processes frame t-1: fields tff=1 then tff=0
+            for tff in (1, 0):
+                oe.run(frames[t - 1], tff)
+            while dev.pull() is not None:
+                pass
+            for b in range(9):
+                for c in range(3):
+                    np.testing.assert_array_equal(dev.eedi_plane(b, c), oe.plane(b, c),
+                                                  err_msg=f"{ol.EEDI2_BUFFERS[b]} plane {c} after frame {t - 1}")
+    finally:
+        oe.close()
+        dev.close()
+        ctx.close()
+
+
+@pytest.mark.parametrize("w,h", [(128, 72), (638, 360)])
+@pytest.mark.parametrize("mode,extra,par", [
+    (8, "", {}), (15, "", {}), (31, "", {}), (63, "", {}),
+    (9, ":postproc=0:noise-thresh=30:search-distance=12", dict(postproc=0, noise=30, search=12)),
+    (27, ":magnitude-thresh=5:variance-thresh=10:laplacian-thresh=30:dilation-thresh=3:erosion-thresh=3",
+     dict(magnitude=5, variance=10, laplacian=30, dilation=3, erosion=3))])
+def test_decomb_eedi2_filter(built, w, h, mode, extra, par):
+    frames = synth.stream("interlaced", w, h, 4)
+    combed = [2, 1, 0, 2]
+    got = hbrt.run_stream(hip.filters(), [("hb_filter_decomb_hip", f"mode={mode}{extra}")], frames, flags=TFF, combed=combed)
+    want = os_.decomb_eedi2_stream(frames, dict(mode=mode, **par), flags=TFF, combed=combed)
+    assert len(got) == len(want)
+    for t in range(len(want)):
+        for c in range(3):
+            np.testing.assert_array_equal(got[t].planes[c], want[t]["planes"][c], err_msg=f"frame {t} plane {c}")
+        assert (got[t].start, got[t].stop) == (want[t]["start"], want[t]["stop"])
+
+
+def test_decomb_eedi2_bob_1080i(built):
+    """BASELINE configs[2]: decomb EEDI2 bob on 1920x1080 interlaced."""
+    frames = synth.stream("interlaced", 1920, 1080, 3)
+    got = hbrt.run_stream(hip.filters(), [("hb_filter_decomb_hip", "mode=31")], frames, flags=TFF)
+    want = os_.decomb_eedi2_stream(frames, dict(mode=31), flags=TFF)
+    assert len(got) == len(want) == 6
+    for t in range(6):
+        for c in range(3):
+            np.testing.assert_array_equal(got[t].planes[c], want[t]["planes"][c], err_msg=f"frame {t} plane {c}")
+
+
+def test_odd_chroma_height_is_refused(built):
+    """The reference overruns its buffers there; the HIP filter must decline (init fails)."""
+    with pytest.raises(RuntimeError):
+        hbrt.Chain(hip.filters(), [("hb_filter_decomb_hip", "mode=31")], 638, 362)
