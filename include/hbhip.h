@@ -157,6 +157,16 @@ int hbhip_unsharp_create(hbhip_ctx *ctx, const hbhip_blur_params *p, int width, 
 int hbhip_chroma_smooth_create(hbhip_ctx *ctx, const hbhip_blur_params *p, int width, int height,
                                int depth, int log2_chroma_w, int log2_chroma_h, hbhip_filter **out);
 
+/* ---- hqdn3d (replaces hqdn3d_denoise_spatial/temporal/depth, denoise.c:102-201) --- */
+typedef struct hbhip_hqdn3d_params
+{
+    /* coef[2*c] spatial, coef[2*c+1] temporal table of plane c, each built on the host
+     * exactly as hqdn3d_precalc_coef builds it (denoise.c:78-94; entry 0 = strength != 0) */
+    int16_t coef[6][8192];
+} hbhip_hqdn3d_params;
+int hbhip_hqdn3d_create(hbhip_ctx *ctx, const hbhip_hqdn3d_params *p, int width, int height,
+                        int depth, int log2_chroma_w, int log2_chroma_h, hbhip_filter **out);
+
 /* ---- Decomb (replaces decomb.c:495-612 frame logic + decomb_template.c:579-898
  *      line filters + eedi2_template.c passes) -------------------------------------- */
 typedef struct hbhip_decomb_params

@@ -88,6 +88,19 @@ void orc_unsharp_plane(const uint8_t *src, uint8_t *dst, int width, int height,
 void orc_chroma_smooth_plane(const uint8_t *src, uint8_t *dst, int width, int height,
                              int src_stride, int dst_stride, double strength, int size);
 
+/* ---- hqdn3d (denoise.c) --------------------------------------------------------- */
+
+/* hqdn3d_precalc_coef (denoise.c:78-94), 8-bit: ct[8192]; ct[0] doubles as the
+ * "strength is non-zero" flag. */
+void orc_hqdn3d_coef(int16_t ct[8192], double dist25);
+
+/* hqdn3d_denoise_depth (denoise.c:167-201) for one 8-bit plane.  frame_ant is the
+ * persistent w*h uint16 state (previous output, 16-bit fixed point); pass
+ * *state_valid = 0 on the first frame (it is then seeded from the input, :175-188). */
+void orc_hqdn3d_plane(const uint8_t *src, uint8_t *dst, int w, int h, int sstride, int dstride,
+                      uint16_t *frame_ant, int *state_valid,
+                      const int16_t spatial[8192], const int16_t temporal[8192]);
+
 /* ---- Decomb: yadif / blend / cubic (decomb.c, templates/decomb_template.c) ------- */
 
 #define ORC_DECOMB_YADIF      1

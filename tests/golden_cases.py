@@ -82,4 +82,8 @@ CASES = {
                                      chain=[("hb_filter_decomb", "mode=8")],
                                      hip=[("hb_filter_decomb_hip", "mode=8")],
                                      orc=[("decomb", dict(mode=8))]),
+    "hqdn3d_medium_134x70": dict(model="progressive", w=134, h=70, n=4,
+                                 chain=[("hb_filter_denoise", "y-spatial=3:cb-spatial=2:cr-spatial=2:y-temporal=2:cb-temporal=3:cr-temporal=3")],
+                                 hip=[("hb_filter_denoise_hip", "y-spatial=3:cb-spatial=2:cr-spatial=2:y-temporal=2:cb-temporal=3:cr-temporal=3")],
+                                 orc=[("hqdn3d", dict(y_spatial=3, cb_spatial=2, cr_spatial=2, y_temporal=2, cb_temporal=3, cr_temporal=3))]),
 }

@@ -273,3 +273,43 @@ class RefEedi2:
         if self.h:
             self.lib.hbref_eedi2_free(self.h)
             self.h = None
+
+
+# ---------------------------------------------------------------- hqdn3d
+class OrcHqdn3d:
+    """Stateful hqdn3d oracle.  Strengths follow hb_denoise_init's defaulting (denoise.c:228-256)."""
+
+    def __init__(self, width, height, y_spatial=None, cb_spatial=None, cr_spatial=None,
+                 y_temporal=None, cb_temporal=None, cr_temporal=None):
+        ys = 4.0 if y_spatial is None else y_spatial
+        cbs = 3.0 * ys / 4.0 if cb_spatial is None else cb_spatial
+        crs = cbs if cr_spatial is None else cr_spatial
+        yt = 6.0 * ys / 4.0 if y_temporal is None else y_temporal
+        cbt = yt * cbs / ys if cb_temporal is None else cb_temporal
+        crt = cbt if cr_temporal is None else cr_temporal
+        lib = oracle()
+        lib.orc_hqdn3d_coef.argtypes = [C.POINTER(C.c_int16), C.c_double]
+        lib.orc_hqdn3d_plane.argtypes = [C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.POINTER(C.c_uint16), C.POINTER(C.c_int), C.POINTER(C.c_int16), C.POINTER(C.c_int16)]
+        self.lib = lib
+        self.coef = []
+        for v in (ys, yt, cbs, cbt, crs, crt):
+            t = (C.c_int16 * 8192)()
+            lib.orc_hqdn3d_coef(t, v)
+            self.coef.append(t)
+        self.state = [None, None, None]
+        self.valid = [C.c_int(0), C.c_int(0), C.c_int(0)]
+
+    def frame(self, planes):
+        out = []
+        for c, p in enumerate(planes):
+            h, w = p.shape
+            src = padded(p)
+            dst = np.zeros_like(src)
+            if self.state[c] is None:
+                self.state[c] = np.zeros((h, w), np.uint16)
+            self.lib.orc_hqdn3d_plane(u8p(src), u8p(dst), w, h, src.strides[0], dst.strides[0],
+                                      self.state[c].ctypes.data_as(C.POINTER(C.c_uint16)), C.byref(self.valid[c]),
+                                      self.coef[2 * c], self.coef[2 * c + 1])
+            out.append(dst[:, :w].copy())
+        return tuple(out)

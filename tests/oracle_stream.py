@@ -178,3 +178,12 @@ def decomb_eedi2_stream(frames, par, flags=PIC_FLAG_TOP_FIELD_FIRST, combed=None
         return decomb_stream(frames, par, flags=flags, combed=combed, duration=duration, eedi2=guess)
     finally:
         oe.close()
+
+
+def hqdn3d_stream(frames, par):
+    h, w = frames[0][0].shape
+    o = ol.OrcHqdn3d(w, h, **par)
+    return [o.frame(fr) for fr in frames]
+
+
+STREAMS["hqdn3d"] = hqdn3d_stream

@@ -192,3 +192,22 @@ def test_decomb_eedi2_matches_reference(built, mode, extra, par):
     combed = [2, 1, 0, 2]
     got = hbrt.run_stream(ol.ref(), [("hb_filter_decomb", f"mode={mode}{extra}")], frames, flags=TFF, combed=combed)
     _eq_dstream(got, os_.decomb_eedi2_stream(frames, dict(mode=mode, **par), flags=TFF, combed=combed))
+
+
+HQ_CASES = [
+    ("", {}),
+    ("y-spatial=2:cb-spatial=1.5:cr-spatial=1.5:y-temporal=3:cb-temporal=2.25:cr-temporal=2.25",
+     dict(y_spatial=2, cb_spatial=1.5, cr_spatial=1.5, y_temporal=3, cb_temporal=2.25, cr_temporal=2.25)),
+    ("y-spatial=0:y-temporal=6:cb-spatial=0:cb-temporal=4", dict(y_spatial=0, y_temporal=6, cb_spatial=0, cb_temporal=4)),
+    ("y-spatial=8:cb-spatial=6:y-temporal=0", dict(y_spatial=8, cb_spatial=6, y_temporal=0)),
+]
+
+
+@needs_ref
+@pytest.mark.parametrize("model", ["progressive", "random"])
+@pytest.mark.parametrize("w,h", [(128, 72), (638, 362)])
+def test_hqdn3d_matches_reference(built, model, w, h):
+    frames = synth.stream(model, w, h, 4)
+    for st, par in HQ_CASES:
+        got = hbrt.run_stream(ol.ref(), [("hb_filter_denoise", st)], frames)
+        _eq_stream(got, os_.hqdn3d_stream(frames, par))
