@@ -1,0 +1,421 @@
+// alias.hip — the libavfilter/zimg-backed "alias" filters as real GPU filters (8-bit):
+//
+//   rotate_kernel       transpose / hflip / vflip as rotate_init composes them
+//                       (libhb/rotate.c:169-256 -> FFmpeg transpose,hflip,vflip)
+//   monochrome_kernel   FFmpeg monochrome as grayscale_init configures it
+//                       (libhb/grayscale.c:32-68; same math as the reference's Metal
+//                       shader platform/macosx/shaders/grayscale_vt.metal:68-136)
+//   cropscale_kernel    crop + zscale(filter=lanczos) as crop_scale_init configures them
+//                       (libhb/cropscale.c:52-185)
+//
+// PARITY UNPINNED: the arithmetic of these filters is in FFmpeg / zimg, which are not in
+// the reference tree.  These kernels are bit-exact against OUR restatement
+// (oracle/alias_oracle.c): pure permutations for rotate; host-built exp() table + plain
+// IEEE float ops for monochrome; host-built Lanczos tap tables (double, libm sin) and
+// double accumulation in the oracle's order for the scaler.
+// All three are HBM-bound (1 read + 1 write per pixel; the scaler reads each source
+// pixel ~taps^2/scale^2 times from L2).
+#include "hbhip_internal.h"
+
+#include <cmath>
+#include <vector>
+
+namespace {
+
+// ------------------------------------------------------------------ rotate
+enum { T_NONE = 0, T_CCLOCK_FLIP, T_CLOCK, T_CCLOCK, T_CLOCK_FLIP };
+
+struct RotArgs
+{
+    const uint8_t *src;
+    uint8_t       *dst;
+    int sw, sh, spitch, dw, dh, dpitch;
+    int trans, hflip, vflip;
+};
+
+__device__ __forceinline__ void rot_map(const RotArgs &a, int x, int y, int &sx, int &sy)
+{
+    switch (a.trans)
+    {
+        case T_CCLOCK_FLIP: sx = y;            sy = x;            break;
+        case T_CLOCK:       sx = y;            sy = a.sh - 1 - x; break;
+        case T_CCLOCK:      sx = a.sw - 1 - y; sy = x;            break;
+        case T_CLOCK_FLIP:  sx = a.sw - 1 - y; sy = a.sh - 1 - x; break;
+        default:            sx = a.hflip ? a.sw - 1 - x : x; sy = a.vflip ? a.sh - 1 - y : y; break;
+    }
+}
+
+// 64x64 output tile per block of 64x4 threads.  Transposing modes go through LDS so
+// that both the gather from the source rows and the store to the output rows coalesce.
+__global__ __launch_bounds__(256) void rotate_kernel(RotArgs a)
+{
+    __shared__ uint8_t tile[64][65];
+    const int ox = blockIdx.x * 64, oy = blockIdx.y * 64;
+    if (a.trans == T_NONE)
+    {
+        for (int r = threadIdx.y; r < 64; r += 4)
+        {
+            const int x = ox + threadIdx.x, y = oy + r;
+            if (x < a.dw && y < a.dh)
+            {
+                int sx, sy;
+                rot_map(a, x, y, sx, sy);
+                a.dst[(size_t)y * a.dpitch + x] = a.src[(size_t)sy * a.spitch + sx];
+            }
+        }
+        return;
+    }
+    // gather: consecutive lanes walk consecutive output ROWS (= consecutive source columns)
+    for (int r = threadIdx.y; r < 64; r += 4)
+    {
+        const int x = ox + r, y = oy + threadIdx.x;
+        if (x < a.dw && y < a.dh)
+        {
+            int sx, sy;
+            rot_map(a, x, y, sx, sy);
+            tile[r][threadIdx.x] = a.src[(size_t)sy * a.spitch + sx];
+        }
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 64; r += 4)
+    {
+        const int x = ox + threadIdx.x, y = oy + r;
+        if (x < a.dw && y < a.dh)
+            a.dst[(size_t)y * a.dpitch + x] = tile[threadIdx.x][r];
+    }
+}
+
+class RotateFilter : public SimpleFilter
+{
+public:
+    RotateFilter(hbhip_ctx *c, int angle, int flip) : SimpleFilter(c)
+    {
+        switch (angle)                                     // rotate.c:190-215
+        {
+            case 0:   hflip = flip; break;
+            case 90:  trans = flip ? T_CLOCK_FLIP : T_CLOCK; break;
+            case 180: vflip = 1; hflip = !flip; break;
+            case 270: trans = flip ? T_CCLOCK_FLIP : T_CCLOCK; break;
+        }
+    }
+    bool transposes() const { return trans != T_NONE; }
+    int process(DevPicture *in, DevPicture *out) override
+    {
+        for (int c = 0; c < 3; c++)
+        {
+            RotArgs a;
+            a.src = in->plane[c]; a.dst = out->plane[c];
+            a.sw = in->width[c]; a.sh = in->height[c]; a.spitch = in->pitch[c];
+            a.dw = out->width[c]; a.dh = out->height[c]; a.dpitch = out->pitch[c];
+            a.trans = trans; a.hflip = hflip; a.vflip = vflip;
+            HBHIP_LAUNCH(ctx, "rotate", rotate_kernel, dim3((a.dw + 63) / 64, (a.dh + 63) / 64), dim3(64, 4), 0, a);
+        }
+        HBHIP_CHECK(ctx, hipGetLastError());
+        return HBHIP_OK;
+    }
+    int trans = T_NONE, hflip = 0, vflip = 0;
+};
+
+// ------------------------------------------------------------------ monochrome
+__device__ __forceinline__ float envelope(const float x)
+{
+    const float beta = 0.6f;
+    if (x < beta)
+    {
+        const float tmp = fabsf(x / beta - 1.f);
+        return 1.f - tmp * tmp;
+    }
+    const float tmp = (1.f - x) / (1.f - beta);
+    return tmp * tmp * (3.f - 2.f * tmp);
+}
+
+__global__ __launch_bounds__(256) void monochrome_kernel(const uint8_t *__restrict__ yp, int ypitch,
+                                                         const uint8_t *__restrict__ up,
+                                                         const uint8_t *__restrict__ vp, int cpitch,
+                                                         uint8_t *__restrict__ dst, int dpitch, int w, int h,
+                                                         int subw, int subh, const float *__restrict__ wlut,
+                                                         float ihigh)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const float imax = 1.f / 255;
+    const int cx = x >> subw, cy = y >> subh;
+    const float fy = yp[(size_t)y * ypitch + x] * imax;
+    const int u = up[(size_t)cy * cpitch + cx], v = vp[(size_t)cy * cpitch + cx];
+    float ny = wlut[u * 256 + v];                          // exp(-clip(dist/size)) built on the host
+    const float tt = envelope(fy);
+    const float t = tt + (1.f - tt) * ihigh;
+    ny = (1.f - t) * fy + t * ny * fy;
+    int q = __float2int_rn(ny * 255);
+    q = q < 0 ? 0 : q > 255 ? 255 : q;
+    dst[(size_t)y * dpitch + x] = (uint8_t)q;
+}
+
+__global__ void fill_plane_kernel(uint8_t *dst, int pitch, int w, int h, int value)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x < w && y < h) dst[(size_t)y * pitch + x] = (uint8_t)value;
+}
+
+class MonochromeFilter : public SimpleFilter
+{
+public:
+    MonochromeFilter(hbhip_ctx *c, double cb_, double cr_, double size_, double high_)
+        : SimpleFilter(c), cb(cb_), cr(cr_), size(size_), high(high_) {}
+    ~MonochromeFilter() override { if (d_lut) (void)hipFree(d_lut); }
+    int setup()
+    {
+        std::vector<float> lut(256 * 256);
+        const float imax = 1.f / 255;
+        const float isize = 1.f / (float)size;
+        const float b = (float)cb * .5f, r = (float)cr * .5f;
+        for (int u = 0; u < 256; u++)
+            for (int v = 0; v < 256; v++)
+            {
+                const float fu = u * imax - .5f, fv = v * imax - .5f;
+                float d = ((b - fu) * (b - fu) + (r - fv) * (r - fv)) * isize;
+                d = d < 0.f ? 0.f : d > 1.f ? 1.f : d;
+                lut[u * 256 + v] = expf(-d);
+            }
+        HBHIP_CHECK(ctx, hipMalloc((void **)&d_lut, sizeof(float) * lut.size()));
+        HBHIP_CHECK(ctx, hipMemcpyAsync(d_lut, lut.data(), sizeof(float) * lut.size(), hipMemcpyHostToDevice, ctx->stream));
+        HBHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        return HBHIP_OK;
+    }
+    int process(DevPicture *in, DevPicture *out) override
+    {
+        const int w = in->width[0], h = in->height[0];
+        HBHIP_LAUNCH(ctx, "monochrome", monochrome_kernel, dim3((w + 63) / 64, (h + 3) / 4), dim3(64, 4), 0,
+                     (const uint8_t *)in->plane[0], in->pitch[0], (const uint8_t *)in->plane[1],
+                     (const uint8_t *)in->plane[2], in->pitch[1], out->plane[0], out->pitch[0], w, h,
+                     in_geo.log2_cw, in_geo.log2_ch, (const float *)d_lut, 1.f - (float)high);
+        for (int c = 1; c < 3; c++)
+            HBHIP_LAUNCH(ctx, "monochrome_fill", fill_plane_kernel, dim3((out->width[c] + 255) / 256, out->height[c]),
+                         dim3(256), 0, out->plane[c], out->pitch[c], out->width[c], out->height[c], 128);
+        HBHIP_CHECK(ctx, hipGetLastError());
+        return HBHIP_OK;
+    }
+    double cb, cr, size, high;
+    float *d_lut = nullptr;
+};
+
+// ------------------------------------------------------------------ crop + lanczos scale
+struct ScaleArgs
+{
+    const uint8_t *src;      // already offset to the crop window
+    uint8_t       *dst;
+    int spitch, dpitch, dw, dh, tx, ty;
+    const int    *ix, *iy;
+    const double *cx, *cy;
+};
+
+__global__ __launch_bounds__(256) void cropscale_kernel(ScaleArgs a)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= a.dw || y >= a.dh) return;
+    const int *ix = a.ix + (size_t)x * a.tx;
+    const double *cx = a.cx + (size_t)x * a.tx;
+    double acc = 0.0;
+    for (int j = 0; j < a.ty; j++)
+    {
+        const uint8_t *row = a.src + (size_t)a.iy[(size_t)y * a.ty + j] * a.spitch;
+        double h = 0.0;
+        for (int i = 0; i < a.tx; i++)
+            h += cx[i] * (double)row[ix[i]];
+        acc += a.cy[(size_t)y * a.ty + j] * h;
+    }
+    acc = acc < 0.0 ? 0.0 : acc > 255.0 ? 255.0 : acc;
+    a.dst[(size_t)y * a.dpitch + x] = (uint8_t)(int)(acc + 0.5);
+}
+
+__global__ void crop_copy_kernel(const uint8_t *src, int spitch, uint8_t *dst, int dpitch, int w, int h)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x < w && y < h) dst[(size_t)y * dpitch + x] = src[(size_t)y * spitch + x];
+}
+
+double lanczos3(double x)
+{
+    const double pi = 3.14159265358979323846;
+    x = std::fabs(x);
+    if (x >= 3.0) return 0.0;
+    if (x == 0.0) return 1.0;
+    const double a = x * pi;
+    return (std::sin(a) / a) * (std::sin(a / 3.0) / (a / 3.0));
+}
+
+// zimg-style tap table of one dimension (see oracle/alias_oracle.c for the conventions)
+int lanczos_table(int src_dim, int dst_dim, double shift, std::vector<int> &idx, std::vector<double> &coef)
+{
+    const double scale = (double)dst_dim / (double)src_dim;
+    const double step = scale < 1.0 ? scale : 1.0;
+    const double support = 3.0 / step;
+    int taps = (int)std::ceil(support) * 2;
+    if (taps < 1) taps = 1;
+    if (taps > 64) taps = 64;
+    idx.assign((size_t)dst_dim * taps, 0);
+    coef.assign((size_t)dst_dim * taps, 0.0);
+    for (int i = 0; i < dst_dim; i++)
+    {
+        const double pos = (i + 0.5) / scale + shift;
+        const double begin = std::floor(pos - taps / 2.0 + 0.5);
+        double w[64], total = 0.0;
+        for (int k = 0; k < taps; k++)
+        {
+            w[k] = lanczos3((begin + k + 0.5 - pos) * step);
+            total += w[k];
+        }
+        for (int k = 0; k < taps; k++)
+        {
+            long j = (long)begin + k;
+            if (j < 0) j = -j - 1;
+            if (j >= src_dim) j = 2L * src_dim - 1 - j;
+            if (j < 0) j = 0;
+            if (j >= src_dim) j = src_dim - 1;
+            idx[(size_t)i * taps + k] = (int)j;
+            coef[(size_t)i * taps + k] = w[k] / total;
+        }
+    }
+    return taps;
+}
+
+class CropScaleFilter : public SimpleFilter
+{
+public:
+    CropScaleFilter(hbhip_ctx *c, const hbhip_cropscale_params &p) : SimpleFilter(c), par(p) {}
+    ~CropScaleFilter() override
+    {
+        for (int c = 0; c < 3; c++)
+        {
+            if (d_ix[c]) (void)hipFree(d_ix[c]);
+            if (d_iy[c]) (void)hipFree(d_iy[c]);
+            if (d_cx[c]) (void)hipFree(d_cx[c]);
+            if (d_cy[c]) (void)hipFree(d_cy[c]);
+        }
+    }
+    int setup()
+    {
+        const int cw = in_geo.width - par.crop_left - par.crop_right;
+        const int ch = in_geo.height - par.crop_top - par.crop_bottom;
+        if (cw < 1 || ch < 1) return HBHIP_ERR_ARG;
+        for (int c = 0; c < 3; c++)
+        {
+            const int lw = c ? in_geo.log2_cw : 0, lh = c ? in_geo.log2_ch : 0;
+            crop_x[c] = par.crop_left >> lw;
+            crop_y[c] = par.crop_top >> lh;
+            crop_w[c] = c ? -((-cw) >> lw) : cw;
+            crop_h[c] = c ? -((-ch) >> lh) : ch;
+            const int dw = out_geo.pw[c], dh = out_geo.ph[c];
+            // left-sited chroma: 0.25 * (1 - src/dst) of a chroma sample, horizontally only
+            const double sx = (c && lw) ? 0.25 * (1.0 - (double)cw / (double)out_geo.width) : 0.0;
+            identity[c] = (dw == crop_w[c] && dh == crop_h[c] && sx == 0.0);
+            if (identity[c]) continue;
+            std::vector<int> ix, iy;
+            std::vector<double> cx, cy;
+            tx[c] = lanczos_table(crop_w[c], dw, sx, ix, cx);
+            ty[c] = lanczos_table(crop_h[c], dh, 0.0, iy, cy);
+            HBHIP_CHECK(ctx, hipMalloc((void **)&d_ix[c], sizeof(int) * ix.size()));
+            HBHIP_CHECK(ctx, hipMalloc((void **)&d_iy[c], sizeof(int) * iy.size()));
+            HBHIP_CHECK(ctx, hipMalloc((void **)&d_cx[c], sizeof(double) * cx.size()));
+            HBHIP_CHECK(ctx, hipMalloc((void **)&d_cy[c], sizeof(double) * cy.size()));
+            HBHIP_CHECK(ctx, hipMemcpy(d_ix[c], ix.data(), sizeof(int) * ix.size(), hipMemcpyHostToDevice));
+            HBHIP_CHECK(ctx, hipMemcpy(d_iy[c], iy.data(), sizeof(int) * iy.size(), hipMemcpyHostToDevice));
+            HBHIP_CHECK(ctx, hipMemcpy(d_cx[c], cx.data(), sizeof(double) * cx.size(), hipMemcpyHostToDevice));
+            HBHIP_CHECK(ctx, hipMemcpy(d_cy[c], cy.data(), sizeof(double) * cy.size(), hipMemcpyHostToDevice));
+        }
+        return HBHIP_OK;
+    }
+    int process(DevPicture *in, DevPicture *out) override
+    {
+        for (int c = 0; c < 3; c++)
+        {
+            const uint8_t *win = in->plane[c] + (size_t)crop_y[c] * in->pitch[c] + crop_x[c];
+            const int dw = out->width[c], dh = out->height[c];
+            if (identity[c])
+            {
+                HBHIP_LAUNCH(ctx, "crop_copy", crop_copy_kernel, dim3((dw + 255) / 256, dh), dim3(256), 0,
+                             win, in->pitch[c], out->plane[c], out->pitch[c], dw, dh);
+                continue;
+            }
+            ScaleArgs a;
+            a.src = win; a.dst = out->plane[c];
+            a.spitch = in->pitch[c]; a.dpitch = out->pitch[c];
+            a.dw = dw; a.dh = dh; a.tx = tx[c]; a.ty = ty[c];
+            a.ix = d_ix[c]; a.iy = d_iy[c]; a.cx = d_cx[c]; a.cy = d_cy[c];
+            HBHIP_LAUNCH(ctx, "cropscale_lanczos", cropscale_kernel, dim3((dw + 63) / 64, (dh + 3) / 4), dim3(64, 4), 0, a);
+        }
+        HBHIP_CHECK(ctx, hipGetLastError());
+        return HBHIP_OK;
+    }
+    hbhip_cropscale_params par;
+    int crop_x[3], crop_y[3], crop_w[3], crop_h[3], tx[3] = {0, 0, 0}, ty[3] = {0, 0, 0};
+    bool identity[3] = {false, false, false};
+    int *d_ix[3] = {nullptr, nullptr, nullptr}, *d_iy[3] = {nullptr, nullptr, nullptr};
+    double *d_cx[3] = {nullptr, nullptr, nullptr}, *d_cy[3] = {nullptr, nullptr, nullptr};
+};
+
+} // namespace
+
+extern "C" int hbhip_rotate_create(hbhip_ctx *ctx, int angle, int hflip, int width, int height, int depth,
+                                   int log2_chroma_w, int log2_chroma_h, hbhip_filter **out)
+{
+    if (!ctx || !out) return HBHIP_ERR_ARG;
+    *out = nullptr;
+    if (depth != 8) return HBHIP_ERR_UNSUPPORTED;
+    if (angle != 0 && angle != 90 && angle != 180 && angle != 270) return HBHIP_ERR_ARG;
+    if ((angle == 90 || angle == 270) && log2_chroma_w != log2_chroma_h) return HBHIP_ERR_UNSUPPORTED;
+    (void)hipSetDevice(ctx->device);
+    RotateFilter *f = new (std::nothrow) RotateFilter(ctx, angle, hflip);
+    if (!f) return HBHIP_ERR_NOMEM;
+    PicGeometry gi, go;
+    gi.set(width, height, depth, log2_chroma_w, log2_chroma_h);
+    if (f->transposes()) go.set(height, width, depth, log2_chroma_w, log2_chroma_h);
+    else                 go = gi;
+    f->configure(gi, go);
+    *out = f;
+    return HBHIP_OK;
+}
+
+extern "C" int hbhip_grayscale_create(hbhip_ctx *ctx, double cb, double cr, double size, double high,
+                                      int width, int height, int depth, int log2_chroma_w, int log2_chroma_h,
+                                      hbhip_filter **out)
+{
+    if (!ctx || !out) return HBHIP_ERR_ARG;
+    *out = nullptr;
+    if (depth != 8) return HBHIP_ERR_UNSUPPORTED;
+    if (!(size > 0)) return HBHIP_ERR_ARG;
+    (void)hipSetDevice(ctx->device);
+    MonochromeFilter *f = new (std::nothrow) MonochromeFilter(ctx, cb, cr, size, high);
+    if (!f) return HBHIP_ERR_NOMEM;
+    PicGeometry g;
+    g.set(width, height, depth, log2_chroma_w, log2_chroma_h);
+    f->configure(g, g);
+    int rc = f->setup();
+    if (rc != HBHIP_OK) { delete f; return rc; }
+    *out = f;
+    return HBHIP_OK;
+}
+
+extern "C" int hbhip_cropscale_create(hbhip_ctx *ctx, const hbhip_cropscale_params *p, int width, int height,
+                                      int depth, int log2_chroma_w, int log2_chroma_h, hbhip_filter **out)
+{
+    if (!ctx || !p || !out) return HBHIP_ERR_ARG;
+    *out = nullptr;
+    if (depth != 8) return HBHIP_ERR_UNSUPPORTED;
+    if (p->width < 1 || p->height < 1) return HBHIP_ERR_ARG;
+    (void)hipSetDevice(ctx->device);
+    CropScaleFilter *f = new (std::nothrow) CropScaleFilter(ctx, *p);
+    if (!f) return HBHIP_ERR_NOMEM;
+    PicGeometry gi, go;
+    gi.set(width, height, depth, log2_chroma_w, log2_chroma_h);
+    go.set(p->width, p->height, depth, log2_chroma_w, log2_chroma_h);
+    f->configure(gi, go);
+    int rc = f->setup();
+    if (rc != HBHIP_OK) { delete f; return rc; }
+    *out = f;
+    return HBHIP_OK;
+}

@@ -26,6 +26,7 @@ ABI_SYMBOLS = [
     "hbhip_hqdn3d_create", "hbhip_decomb_create", "hbhip_decomb_push", "hbhip_decomb_push_dev", "hbhip_decomb_debug_eedi_plane",
     "hbhip_comb_detect_create", "hbhip_comb_detect_store", "hbhip_comb_detect_store_dev",
     "hbhip_comb_detect_classify",
+    "hbhip_rotate_create", "hbhip_grayscale_create", "hbhip_cropscale_create",
 ]
 
 

@@ -1,0 +1,218 @@
+/* alias_hip.c — HIP-backed drop-ins for the reference's libavfilter "alias" filters:
+ *   hb_filter_crop_scale_hip  (libhb/cropscale.c:21-185)
+ *   hb_filter_grayscale_hip   (libhb/grayscale.c:13-68)
+ *   hb_filter_rotate_hip      (libhb/rotate.c:15-270)
+ *
+ * In the reference these objects have .skip = 1 and no work(): their init() only
+ * builds settings for FFmpeg's crop/zscale, monochrome and transpose/hflip/vflip,
+ * which hb_avfilter_combine later merges into one HB_FILTER_AVFILTER graph
+ * (hbavfilter.c:510-622).  Here they are real filters (skip = 0, own work), exactly
+ * as the reference's own HB_FILTER_*_VT GPU variants are; they must therefore be
+ * left out of hb_avfilter_combine's switch.  Same settings keys,
+ * same mutation of init->geometry / PAR / crop for the filters downstream.
+ * The pixel arithmetic is FFmpeg's / zimg's in the reference and is NOT in its tree:
+ * parity is pinned to oracle/alias_oracle.c only ("parity unpinned").
+ */
+#include "hbhip_host.h"
+
+struct hb_filter_private_s
+{
+    hbhip_filter    *dev;
+    hb_filter_init_t input;
+    hb_filter_init_t output;
+};
+
+static void alias_hip_close(hb_filter_object_t *filter)
+{
+    hb_filter_private_t *pv = filter->private_data;
+    if (pv == NULL) return;
+    hbhip_filter_destroy(pv->dev);
+    free(pv);
+    filter->private_data = NULL;
+}
+
+static int alias_hip_work(hb_filter_object_t *filter, hb_buffer_t **buf_in, hb_buffer_t **buf_out)
+{
+    hb_filter_private_t *pv = filter->private_data;
+    return hbhip_host_simple_work(pv->dev, &pv->output, filter->short_name, buf_in, buf_out);
+}
+
+static hb_filter_private_t *alias_begin(hb_filter_object_t *filter, hb_filter_init_t *init,
+                                        const AVPixFmtDescriptor **desc)
+{
+    hb_filter_private_t *pv = calloc(1, sizeof(*pv));
+    filter->private_data = pv;
+    if (pv == NULL) return NULL;
+    pv->input = *init;
+    *desc = av_pix_fmt_desc_get(init->pix_fmt);
+    if (*desc == NULL)
+    {
+        free(pv);
+        filter->private_data = NULL;
+        return NULL;
+    }
+    return pv;
+}
+
+static int alias_fail(hb_filter_object_t *filter, int rc)
+{
+    hb_error("%s(hip): %s", filter->short_name, hbhip_strerror(rc));
+    free(filter->private_data);
+    filter->private_data = NULL;
+    return 1;
+}
+
+/* ---- crop + scale ------------------------------------------------------------------ */
+static int crop_scale_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init);
+
+static const char crop_scale_hip_template[] =
+    "width=^"HB_INT_REG"$:height=^"HB_INT_REG"$:"
+    "crop-top=^"HB_INT_REG"$:crop-bottom=^"HB_INT_REG"$:"
+    "crop-left=^"HB_INT_REG"$:crop-right=^"HB_INT_REG"$";
+
+hb_filter_object_t hb_filter_crop_scale_hip =
+{
+    .id                = HB_FILTER_CROP_SCALE,
+    .enforce_order     = 1,
+    .name              = "Crop and Scale (HIP)",
+    .short_name        = "cropscale",
+    .settings          = NULL,
+    .init              = crop_scale_hip_init,
+    .work              = alias_hip_work,
+    .close             = alias_hip_close,
+    .settings_template = crop_scale_hip_template,
+};
+
+static int64_t gcd64(int64_t a, int64_t b) { while (b) { int64_t t = a % b; a = b; b = t; } return a < 0 ? -a : a; }
+
+/* hb_limit_rational (common.c) stand-in: reduce, then halve until both terms fit */
+static void limit_rational(int *num, int *den, int64_t n, int64_t d, int64_t limit)
+{
+    int64_t g = gcd64(n, d);
+    if (g > 1) { n /= g; d /= g; }
+    while (n > limit || d > limit) { n >>= 1; d >>= 1; }
+    if (n < 1) n = 1;
+    if (d < 1) d = 1;
+    *num = (int)n;
+    *den = (int)d;
+}
+
+static int crop_scale_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init)
+{
+    const AVPixFmtDescriptor *desc;
+    hb_filter_private_t *pv = alias_begin(filter, init, &desc);
+    if (pv == NULL) return 1;
+
+    hbhip_cropscale_params p;
+    memset(&p, 0, sizeof(p));
+    hb_dict_extract_int(&p.crop_top, filter->settings, "crop-top");          /* cropscale.c:68-71 */
+    hb_dict_extract_int(&p.crop_bottom, filter->settings, "crop-bottom");
+    hb_dict_extract_int(&p.crop_left, filter->settings, "crop-left");
+    hb_dict_extract_int(&p.crop_right, filter->settings, "crop-right");
+    const int cropped_width  = init->geometry.width - p.crop_left - p.crop_right;
+    const int cropped_height = init->geometry.height - p.crop_top - p.crop_bottom;
+    p.width = cropped_width;
+    p.height = cropped_height;
+    hb_dict_extract_int(&p.width, filter->settings, "width");                /* :93-94 */
+    hb_dict_extract_int(&p.height, filter->settings, "height");
+
+    hbhip_ctx *ctx = hbhip_host_ctx();
+    if (ctx == NULL) return alias_fail(filter, HBHIP_ERR_NODEVICE);
+    int rc = hbhip_cropscale_create(ctx, &p, init->geometry.width, init->geometry.height, desc->comp[0].depth,
+                                    desc->log2_chroma_w, desc->log2_chroma_h, &pv->dev);
+    if (rc != HBHIP_OK) return alias_fail(filter, rc);
+
+    init->crop[0] = p.crop_top;                                              /* :168-178 */
+    init->crop[1] = p.crop_bottom;
+    init->crop[2] = p.crop_left;
+    init->crop[3] = p.crop_right;
+    limit_rational(&init->geometry.par.num, &init->geometry.par.den,
+                   (int64_t)init->geometry.par.num * p.height * cropped_width,
+                   (int64_t)init->geometry.par.den * p.width * cropped_height, 65535);
+    init->geometry.width = p.width;
+    init->geometry.height = p.height;
+    pv->output = *init;
+    return 0;
+}
+
+/* ---- grayscale ----------------------------------------------------------------------- */
+static int grayscale_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init);
+
+static const char grayscale_hip_template[] =
+    "cb=^"HB_FLOAT_REG"$:cr=^"HB_FLOAT_REG"$:size=^"HB_FLOAT_REG"$:high=^"HB_FLOAT_REG"$";
+
+hb_filter_object_t hb_filter_grayscale_hip =
+{
+    .id                = HB_FILTER_GRAYSCALE,
+    .enforce_order     = 1,
+    .name              = "Grayscale (HIP)",
+    .short_name        = "grayscale",
+    .settings          = NULL,
+    .init              = grayscale_hip_init,
+    .work              = alias_hip_work,
+    .close             = alias_hip_close,
+    .settings_template = grayscale_hip_template,
+};
+
+static int grayscale_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init)
+{
+    const AVPixFmtDescriptor *desc;
+    hb_filter_private_t *pv = alias_begin(filter, init, &desc);
+    if (pv == NULL) return 1;
+    double cb = 0, cr = 0, size = 1, high = 0;                               /* grayscale.c:43-48 */
+    hb_dict_extract_double(&cb, filter->settings, "cb");
+    hb_dict_extract_double(&cr, filter->settings, "cr");
+    hb_dict_extract_double(&size, filter->settings, "size");
+    hb_dict_extract_double(&high, filter->settings, "high");
+    hbhip_ctx *ctx = hbhip_host_ctx();
+    if (ctx == NULL) return alias_fail(filter, HBHIP_ERR_NODEVICE);
+    int rc = hbhip_grayscale_create(ctx, cb, cr, size, high, init->geometry.width, init->geometry.height,
+                                    desc->comp[0].depth, desc->log2_chroma_w, desc->log2_chroma_h, &pv->dev);
+    if (rc != HBHIP_OK) return alias_fail(filter, rc);
+    pv->output = *init;
+    return 0;
+}
+
+/* ---- rotate -------------------------------------------------------------------------- */
+static int rotate_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init);
+
+static const char rotate_hip_template[] =
+    "angle=^(0|90|180|270)$:hflip=^"HB_BOOL_REG"$:disable=^"HB_BOOL_REG"$";
+
+hb_filter_object_t hb_filter_rotate_hip =
+{
+    .id                = HB_FILTER_ROTATE,
+    .enforce_order     = 1,
+    .name              = "Rotate (HIP)",
+    .short_name        = "rotate",
+    .settings          = NULL,
+    .init              = rotate_hip_init,
+    .work              = alias_hip_work,
+    .close             = alias_hip_close,
+    .settings_template = rotate_hip_template,
+};
+
+static int rotate_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init)
+{
+    const AVPixFmtDescriptor *desc;
+    hb_filter_private_t *pv = alias_begin(filter, init, &desc);
+    if (pv == NULL) return 1;
+    int angle = 0, flip = 0;
+    hb_dict_extract_int(&angle, filter->settings, "angle");                  /* rotate.c:166-167 */
+    hb_dict_extract_bool(&flip, filter->settings, "hflip");
+    hbhip_ctx *ctx = hbhip_host_ctx();
+    if (ctx == NULL) return alias_fail(filter, HBHIP_ERR_NODEVICE);
+    int rc = hbhip_rotate_create(ctx, angle, flip, init->geometry.width, init->geometry.height,
+                                 desc->comp[0].depth, desc->log2_chroma_w, desc->log2_chroma_h, &pv->dev);
+    if (rc != HBHIP_OK) return alias_fail(filter, rc);
+    if (angle == 90 || angle == 270)                                         /* rotate.c:195-214, 261-263 */
+    {
+        const int w = init->geometry.width, n = init->geometry.par.num;
+        init->geometry.width = init->geometry.height;
+        init->geometry.height = w;
+        init->geometry.par.num = init->geometry.par.den;
+        init->geometry.par.den = n;
+    }
+    pv->output = *init;
+    return 0;
+}

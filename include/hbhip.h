@@ -208,6 +208,24 @@ int hbhip_comb_detect_store_dev(hbhip_filter *f, const void *luma, int stride);
 /* comb_segmenter on the ring: *combed = HB_COMB_NONE/LIGHT/HEAVY for the middle plane. */
 int hbhip_comb_detect_classify(hbhip_filter *f, int force_exhaustive, int *combed);
 
+/* ---- Alias family (libavfilter/zimg-backed in the reference; arithmetic external,
+ *      parity pinned to oracle/alias_oracle.c only — see DESIGN.md) ------------------- */
+/* rotate_init's transpose/hflip/vflip composition (rotate.c:169-256). angle 0/90/180/270. */
+int hbhip_rotate_create(hbhip_ctx *ctx, int angle, int hflip, int width, int height, int depth,
+                        int log2_chroma_w, int log2_chroma_h, hbhip_filter **out);
+/* FFmpeg `monochrome=cb:cr:size:high` as grayscale_init sets it up (grayscale.c:43-61). */
+int hbhip_grayscale_create(hbhip_ctx *ctx, double cb, double cr, double size, double high,
+                           int width, int height, int depth, int log2_chroma_w, int log2_chroma_h,
+                           hbhip_filter **out);
+/* `crop` + `zscale=filter=lanczos` as crop_scale_init sets them up (cropscale.c:63-165). */
+typedef struct hbhip_cropscale_params
+{
+    int width, height;                                   /* output size                   */
+    int crop_top, crop_bottom, crop_left, crop_right;    /* cropscale.c:68-73             */
+} hbhip_cropscale_params;
+int hbhip_cropscale_create(hbhip_ctx *ctx, const hbhip_cropscale_params *p, int width, int height,
+                           int depth, int log2_chroma_w, int log2_chroma_h, hbhip_filter **out);
+
 #ifdef __cplusplus
 }
 #endif

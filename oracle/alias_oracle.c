@@ -1,0 +1,192 @@
+/* alias_oracle.c — CPU restatement of the libavfilter/zimg-backed alias filters:
+ * rotate (transpose/hflip/vflip), grayscale (monochrome), crop+scale (crop, zscale
+ * lanczos).  TEST INFRASTRUCTURE ONLY (see oracle.h).
+ *
+ *                    ***  PARITY UNPINNED  ***
+ * The arithmetic of these filters lives in FFmpeg 9.0.1 / zimg snapshot-20250624,
+ * which are NOT part of /root/reference (contrib/{ffmpeg,zimg}/module.defs fetch
+ * tarballs at build time) and the reference has no test or golden vector for them.
+ * This file restates their published algorithms from memory:
+ *   - transpose dir: cclock_flip out(x,y)=in(y,x); clock out(x,y)=in(y,h-1-x);
+ *     cclock out(x,y)=in(w-1-y,x); clock_flip out(x,y)=in(w-1-y,h-1-x)
+ *     [in(col,row)]; hflip / vflip mirror columns / rows.  Pure index permutations.
+ *   - monochrome (vf_monochrome.c): per luma sample, with chroma (u,v) centred on 0:
+ *       ny = exp(-clip(((b-u)^2 + (r-v)^2) / size, 0, 1)),  b = cb/2, r = cr/2
+ *       tt = envelope(y)  (beta 0.6 smoothstep pair), t = tt + (1-tt)*(1-high)
+ *       y' = (1-t)*y + t*ny*y ; output lrintf(y'*255) clipped; chroma := 128.
+ *     The same formulas appear in the reference's own Metal shader
+ *     (libhb/platform/macosx/shaders/grayscale_vt.metal:68-112).
+ *   - zscale lanczos (zimg resize): separable 3-lobe Lanczos, support stretched by
+ *     1/scale when shrinking, windows centred with round-half-up, taps that fall
+ *     outside the picture reflected back in (edge sample repeated), weights
+ *     normalised per output sample; left-sited 4:2:0 chroma gets the horizontal
+ *     shift 0.25*(1 - src/dst).  zimg itself filters in 16-bit fixed point; this
+ *     restatement uses double and rounds half up once at the end, so it can differ
+ *     from real zimg by 1 LSB.
+ * The HIP path is tested bit-for-bit against THIS file (tables are built by the
+ * same formulas with host libm), never against FFmpeg/zimg.
+ */
+#include "oracle.h"
+
+#include <math.h>
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- rotate -------------------------------------------------------------------- */
+enum { T_NONE, T_CCLOCK_FLIP, T_CLOCK, T_CCLOCK, T_CLOCK_FLIP };
+
+void orc_rotate_plane(const uint8_t *src, int sw, int sh, int sstride,
+                      uint8_t *dst, int dstride, int angle, int flip)
+{
+    /* rotate.c:190-215: 0 -> hflip if asked; 90 -> clock[_flip]; 180 -> vflip (+hflip
+     * unless asked); 270 -> cclock[_flip] */
+    int trans = T_NONE, hflip = 0, vflip = 0;
+    switch (angle)
+    {
+        case 0:   hflip = flip; break;
+        case 90:  trans = flip ? T_CLOCK_FLIP : T_CLOCK; break;
+        case 180: vflip = 1; hflip = !flip; break;
+        case 270: trans = flip ? T_CCLOCK_FLIP : T_CCLOCK; break;
+    }
+    if (trans != T_NONE)
+    {
+        const int dw = sh, dh = sw;
+        for (int y = 0; y < dh; y++)
+            for (int x = 0; x < dw; x++)
+            {
+                int sx, sy;                     /* source column, row */
+                switch (trans)
+                {
+                    case T_CCLOCK_FLIP: sx = y;          sy = x;          break;
+                    case T_CLOCK:       sx = y;          sy = sh - 1 - x; break;
+                    case T_CCLOCK:      sx = sw - 1 - y; sy = x;          break;
+                    default:            sx = sw - 1 - y; sy = sh - 1 - x; break;
+                }
+                dst[(size_t)y * dstride + x] = src[(size_t)sy * sstride + sx];
+            }
+        return;
+    }
+    for (int y = 0; y < sh; y++)
+        for (int x = 0; x < sw; x++)
+            dst[(size_t)y * dstride + x] = src[(size_t)(vflip ? sh - 1 - y : y) * sstride + (hflip ? sw - 1 - x : x)];
+}
+
+/* ---- monochrome ------------------------------------------------------------------ */
+static float envelope(const float x)
+{
+    const float beta = 0.6f;
+    if (x < beta)
+    {
+        const float tmp = fabsf(x / beta - 1.f);
+        return 1.f - tmp * tmp;
+    }
+    const float tmp = (1.f - x) / (1.f - beta);
+    return tmp * tmp * (3.f - 2.f * tmp);
+}
+
+static float chroma_weight(float b, float r, float u, float v, float size)
+{
+    float d = ((b - u) * (b - u) + (r - v) * (r - v)) * size;
+    d = d < 0.f ? 0.f : d > 1.f ? 1.f : d;
+    return expf(-d);
+}
+
+void orc_monochrome_luma(const uint8_t *yp, int ystride, const uint8_t *up, const uint8_t *vp, int cstride,
+                         uint8_t *dst, int dstride, int w, int h, int subw, int subh,
+                         double cb, double cr, double size, double high)
+{
+    const float imax = 1.f / 255;
+    const float ihigh = 1.f - (float)high;
+    const float isize = 1.f / (float)size;
+    const float b = (float)cb * .5f, r = (float)cr * .5f;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+        {
+            const int cx = x >> subw, cy = y >> subh;
+            const float fy = yp[(size_t)y * ystride + x] * imax;
+            const float fu = up[(size_t)cy * cstride + cx] * imax - .5f;
+            const float fv = vp[(size_t)cy * cstride + cx] * imax - .5f;
+            float ny = chroma_weight(b, r, fu, fv, isize);
+            const float tt = envelope(fy);
+            const float t = tt + (1.f - tt) * ihigh;
+            ny = (1.f - t) * fy + t * ny * fy;
+            long q = lrintf(ny * 255);
+            dst[(size_t)y * dstride + x] = q < 0 ? 0 : q > 255 ? 255 : (uint8_t)q;
+        }
+}
+
+/* ---- lanczos resize ---------------------------------------------------------------- */
+static double lanczos3(double x)
+{
+    const double pi = 3.14159265358979323846;
+    x = fabs(x);
+    if (x >= 3.0) return 0.0;
+    if (x == 0.0) return 1.0;
+    const double a = x * pi;
+    return (sin(a) / a) * (sin(a / 3.0) / (a / 3.0));
+}
+
+int orc_lanczos_table(int src_dim, int dst_dim, double shift, int *idx, double *coef)
+{
+    const double scale = (double)dst_dim / (double)src_dim;
+    const double step = scale < 1.0 ? scale : 1.0;
+    const double support = 3.0 / step;
+    int taps = (int)ceil(support) * 2;
+    if (taps < 1) taps = 1;
+    if (taps > 64) taps = 64;
+    for (int i = 0; i < dst_dim; i++)
+    {
+        const double pos = (i + 0.5) / scale + shift;              /* in source sample-edge coordinates */
+        const double begin = floor(pos - taps / 2.0 + 0.5);        /* round half up */
+        double w[64], total = 0.0;
+        for (int k = 0; k < taps; k++)
+        {
+            w[k] = lanczos3((begin + k + 0.5 - pos) * step);
+            total += w[k];
+        }
+        for (int k = 0; k < taps; k++)
+        {
+            long j = (long)begin + k;
+            if (j < 0) j = -j - 1;                                  /* reflect, edge sample repeated */
+            if (j >= src_dim) j = 2L * src_dim - 1 - j;
+            if (j < 0) j = 0;
+            if (j >= src_dim) j = src_dim - 1;
+            idx[(size_t)i * taps + k] = (int)j;
+            coef[(size_t)i * taps + k] = w[k] / total;
+        }
+    }
+    return taps;
+}
+
+void orc_cropscale_plane(const uint8_t *src, int sstride, int crop_x, int crop_y, int crop_w, int crop_h,
+                         uint8_t *dst, int dstride, int dw, int dh, double shift_x, double shift_y)
+{
+    const uint8_t *win = src + (size_t)crop_y * sstride + crop_x;
+    if (dw == crop_w && dh == crop_h && shift_x == 0.0 && shift_y == 0.0)
+    {
+        for (int y = 0; y < dh; y++)
+            memcpy(dst + (size_t)y * dstride, win + (size_t)y * sstride, dw);
+        return;
+    }
+    int *ix = malloc(sizeof(int) * (size_t)dw * 64), *iy = malloc(sizeof(int) * (size_t)dh * 64);
+    double *cx = malloc(sizeof(double) * (size_t)dw * 64), *cy = malloc(sizeof(double) * (size_t)dh * 64);
+    const int tx = orc_lanczos_table(crop_w, dw, shift_x, ix, cx);
+    const int ty = orc_lanczos_table(crop_h, dh, shift_y, iy, cy);
+    for (int y = 0; y < dh; y++)
+        for (int x = 0; x < dw; x++)
+        {
+            double acc = 0.0;
+            for (int j = 0; j < ty; j++)
+            {
+                const uint8_t *row = win + (size_t)iy[(size_t)y * ty + j] * sstride;
+                double h = 0.0;
+                for (int i = 0; i < tx; i++)
+                    h += cx[(size_t)x * tx + i] * row[ix[(size_t)x * tx + i]];
+                acc += cy[(size_t)y * ty + j] * h;
+            }
+            acc = acc < 0.0 ? 0.0 : acc > 255.0 ? 255.0 : acc;
+            dst[(size_t)y * dstride + x] = (uint8_t)(int)(acc + 0.5);
+        }
+    free(ix); free(iy); free(cx); free(cy);
+}

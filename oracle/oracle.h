@@ -174,6 +174,35 @@ const uint8_t *orc_eedi2_plane(orc_eedi2_t *e, int buffer, int plane, int *strid
 void         orc_eedi2_run_partial(orc_eedi2_t *e, const uint8_t *const cur[3], const int stride[3],
                                    int tff, int npasses);
 
+/* ---- Alias family: crop/scale, grayscale, rotate — PARITY UNPINNED -------------------
+ * In the reference these four filters are settings shims (cropscale.c:52-185,
+ * grayscale.c:32-68, rotate.c:148-270, colorspace.c:31-207) around libavfilter /
+ * zimg filters whose sources are NOT in /root/reference (FFmpeg 9.0.1 and zimg
+ * snapshot-20250624 are fetched at build time, contrib/ffmpeg/module.defs:15-17,
+ * contrib/zimg/module.defs:4-7) and no reference test pins their output.  What
+ * follows restates their PUBLISHED behaviour from memory; it pins the HIP path to
+ * this restatement, not to FFmpeg/zimg bits.  alias_oracle.c carries the details. */
+
+/* transpose / hflip / vflip as rotate_init composes them (rotate.c:169-256).
+ * Output is sw x sh for 0/180, sh x sw for 90/270. */
+void orc_rotate_plane(const uint8_t *src, int sw, int sh, int sstride,
+                      uint8_t *dst, int dstride, int angle, int hflip);
+
+/* vf_monochrome on 8-bit 4:2:0 (grayscale.c:43-61 passes cb, cr, size, high through):
+ * luma is re-weighted by the chroma distance, chroma planes become 128. */
+void orc_monochrome_luma(const uint8_t *y, int ystride, const uint8_t *u, const uint8_t *v, int cstride,
+                         uint8_t *dst, int dstride, int w, int h, int subw, int subh,
+                         double cb, double cr, double size, double high);
+
+/* crop (pointer offset) + zscale(filter=lanczos) of ONE plane.  The plane handed in
+ * is the full uncropped plane; crop_x/crop_y/crop_w/crop_h select the window in plane
+ * pixels; shift_x is the sub-sample shift zimg applies to left-sited chroma. */
+void orc_cropscale_plane(const uint8_t *src, int sstride, int crop_x, int crop_y, int crop_w, int crop_h,
+                         uint8_t *dst, int dstride, int dw, int dh, double shift_x, double shift_y);
+/* The tap table of one dimension (exposed so tests can look at it): for each of the
+ * `dst_dim` outputs `taps` (index, weight) pairs; returns taps. idx/coef sized dst_dim*64. */
+int orc_lanczos_table(int src_dim, int dst_dim, double shift, int *idx, double *coef);
+
 #ifdef __cplusplus
 }
 #endif

@@ -187,3 +187,18 @@ def hqdn3d_stream(frames, par):
 
 
 STREAMS["hqdn3d"] = hqdn3d_stream
+
+
+def rotate_stream(frames, par):
+    return [ol.orc_rotate_frame(fr, par.get("angle", 0), par.get("hflip", 0)) for fr in frames]
+
+
+def grayscale_stream(frames, par):
+    return [ol.orc_grayscale_frame(fr, **par) for fr in frames]
+
+
+def cropscale_stream(frames, par):
+    return [ol.orc_cropscale_frame(fr, **par) for fr in frames]
+
+
+STREAMS.update({"rotate": rotate_stream, "grayscale": grayscale_stream, "cropscale": cropscale_stream})

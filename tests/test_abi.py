@@ -39,7 +39,8 @@ def test_filter_objects_registered(built):
     F = hip.filters()
     for sym, fid in [("hb_filter_nlmeans_hip", 16), ("hb_filter_lapsharp_hip", 24),
                      ("hb_filter_unsharp_hip", 26), ("hb_filter_chroma_smooth_hip", 17),
-                     ("hb_filter_decomb_hip", 6), ("hb_filter_denoise_hip", 14), ("hb_filter_comb_detect_hip", 4)]:
+                     ("hb_filter_decomb_hip", 6), ("hb_filter_denoise_hip", 14),
+                     ("hb_filter_crop_scale_hip", 22), ("hb_filter_grayscale_hip", 28), ("hb_filter_rotate_hip", 19), ("hb_filter_comb_detect_hip", 4)]:
         addr = C.addressof(C.c_char.in_dll(F, sym))
         assert F.hbhip_filter_get(fid) == addr
         assert C.c_int.in_dll(F, sym).value == fid          # .id is the first field

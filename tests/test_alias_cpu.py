@@ -1,0 +1,69 @@
+"""CPU: the alias-family restatement (rotate / grayscale / crop+scale).  Its parity with
+FFmpeg / zimg is UNPINNED (their sources are not in the reference tree), so these tests
+check the properties the published algorithms guarantee, on BASELINE configs[0]'s
+640x360 frames (CPU plumbing config) and on odd sizes."""
+import numpy as np
+import pytest
+
+from handbrake_amd import synth
+import oracle_lib as ol
+
+
+@pytest.mark.parametrize("w,h", [(640, 360), (638, 362)])
+def test_rotate_is_a_permutation_and_composes(built, w, h):
+    fr = synth.progressive_frame(w, h, 1)
+    for angle in (0, 90, 180, 270):
+        for flip in (0, 1):
+            out = ol.orc_rotate_frame(fr, angle, flip)
+            for c in range(3):
+                assert out[c].shape == (fr[c].shape[::-1] if angle in (90, 270) else fr[c].shape)
+                assert np.array_equal(np.sort(out[c], axis=None), np.sort(fr[c], axis=None))
+    r90 = ol.orc_rotate_frame(fr, 90, 0)
+    for c in range(3):
+        np.testing.assert_array_equal(r90[c], np.rot90(fr[c], -1))                       # clockwise
+        np.testing.assert_array_equal(ol.orc_rotate_frame(fr, 270, 0)[c], np.rot90(fr[c], 1))
+        np.testing.assert_array_equal(ol.orc_rotate_frame(fr, 180, 0)[c], fr[c][::-1, ::-1])
+        np.testing.assert_array_equal(ol.orc_rotate_frame(fr, 0, 1)[c], fr[c][:, ::-1])
+        np.testing.assert_array_equal(ol.orc_rotate_frame(fr, 180, 1)[c], fr[c][::-1, :])
+        np.testing.assert_array_equal(ol.orc_rotate_frame(r90, 270, 0)[c], fr[c])          # round trip
+
+
+def test_grayscale_neutralises_chroma_and_keeps_range(built):
+    fr = synth.progressive_frame(640, 360, 2)
+    y, u, v = ol.orc_grayscale_frame(fr)
+    assert (u == 128).all() and (v == 128).all()
+    assert y.shape == fr[0].shape
+    # with the preset (cb=cr=0,size=1,high=0) luma can only be attenuated, never amplified
+    assert (y.astype(int) <= fr[0].astype(int) + 1).all()
+    # idempotent on the chroma planes, deterministic
+    y2, _, _ = ol.orc_grayscale_frame(fr)
+    np.testing.assert_array_equal(y, y2)
+
+
+def test_scale_identity_constant_and_partition_of_unity(built):
+    fr = synth.progressive_frame(320, 180, 0)
+    same = ol.orc_cropscale_frame(fr, 320, 180)
+    np.testing.assert_array_equal(same[0], fr[0])                     # luma identity (chroma has no shift at 1:1 either)
+    np.testing.assert_array_equal(same[1], fr[1])
+    flat = tuple(np.full_like(p, 77) for p in fr)
+    up = ol.orc_cropscale_frame(flat, 640, 360)
+    for c in range(3):
+        assert (up[c] == 77).all()                                    # weights sum to 1
+    import ctypes as C
+    idx = (C.c_int * (640 * 64))()
+    coef = (C.c_double * (640 * 64))()
+    fn = ol.oracle().orc_lanczos_table
+    fn.argtypes = [C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    taps = fn(320, 640, 0.0, idx, coef)
+    assert taps == 6
+    sums = np.array(coef[: 640 * taps]).reshape(640, taps).sum(axis=1)
+    assert np.allclose(sums, 1.0, atol=1e-12)
+    taps = fn(640, 320, 0.0, idx, coef)
+    assert taps == 12                                                 # support stretches when shrinking
+
+
+def test_crop_is_a_window(built):
+    fr = synth.progressive_frame(320, 180, 3)
+    out = ol.orc_cropscale_frame(fr, 300, 160, top=8, bottom=12, left=4, right=16)
+    np.testing.assert_array_equal(out[0], fr[0][8:168, 4:304])
+    np.testing.assert_array_equal(out[1], fr[1][4:84, 2:152])

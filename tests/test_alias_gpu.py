@@ -1,0 +1,60 @@
+"""GPU: rotate / grayscale / crop+scale HIP drop-ins vs the oracle restatement (bit-exact
+against OUR restatement; parity with FFmpeg/zimg itself is unpinned, see oracle.h)."""
+import numpy as np
+import pytest
+
+from handbrake_amd import hbrt, hip, synth
+import oracle_stream as os_
+
+pytestmark = pytest.mark.gpu
+
+
+def run(stage, frames):
+    return hbrt.run_stream(hip.filters(), [stage], frames)
+
+
+def check(got, want):
+    assert len(got) == len(want)
+    for t in range(len(want)):
+        for c in range(3):
+            assert got[t].planes[c].shape == want[t][c].shape, f"frame {t} plane {c} shape"
+            np.testing.assert_array_equal(got[t].planes[c], want[t][c], err_msg=f"frame {t} plane {c}")
+
+
+@pytest.mark.parametrize("w,h", [(640, 360), (638, 362), (1920, 1080)])
+@pytest.mark.parametrize("angle,flip", [(0, 1), (90, 0), (90, 1), (180, 0), (180, 1), (270, 0), (270, 1)])
+def test_rotate(built, w, h, angle, flip):
+    frames = synth.stream("progressive", w, h, 2)
+    got = run(("hb_filter_rotate_hip", f"angle={angle}:hflip={flip}"), frames)
+    check(got, os_.rotate_stream(frames, dict(angle=angle, hflip=flip)))
+    if angle in (90, 270):
+        assert (got[0].width, got[0].height) == (h, w)
+
+
+@pytest.mark.parametrize("w,h", [(640, 360), (638, 362), (1920, 1080)])
+@pytest.mark.parametrize("st,par", [("cb=0:cr=0:size=1:high=0", {}),
+                                    ("cb=0.3:cr=-0.2:size=0.5:high=0.4", dict(cb=0.3, cr=-0.2, size=0.5, high=0.4))])
+def test_grayscale(built, w, h, st, par):
+    frames = synth.stream("progressive", w, h, 2) + synth.stream("random", w, h, 1)
+    check(run(("hb_filter_grayscale_hip", st), frames), os_.grayscale_stream(frames, par))
+
+
+@pytest.mark.parametrize("w,h,ow,oh,crop", [(320, 180, 640, 360, (0, 0, 0, 0)), (640, 360, 320, 180, (0, 0, 0, 0)),
+                                            (638, 362, 850, 480, (2, 4, 6, 8)), (320, 180, 300, 160, (8, 12, 4, 16)),
+                                            (1920, 1080, 3840, 2160, (0, 0, 0, 0))])
+def test_cropscale(built, w, h, ow, oh, crop):
+    frames = synth.stream("progressive", w, h, 2 if w < 1000 else 1)
+    t, b, l, r = crop
+    st = f"width={ow}:height={oh}:crop-top={t}:crop-bottom={b}:crop-left={l}:crop-right={r}"
+    got = run(("hb_filter_crop_scale_hip", st), frames)
+    check(got, os_.cropscale_stream(frames, dict(width=ow, height=oh, top=t, bottom=b, left=l, right=r)))
+    assert (got[0].width, got[0].height) == (ow, oh)
+
+
+def test_config1_grayscale_then_rotate(built):
+    """BASELINE configs[0] on the GPU: grayscale + rotate, 640x360."""
+    frames = synth.stream("progressive", 640, 360, 4)
+    chain = [("hb_filter_rotate_hip", "angle=90:hflip=0"), ("hb_filter_grayscale_hip", "cb=0:cr=0:size=1:high=0")]
+    got = hbrt.run_stream(hip.filters(), chain, frames)
+    want = os_.grayscale_stream(os_.rotate_stream(frames, dict(angle=90)), {})
+    check(got, want)
