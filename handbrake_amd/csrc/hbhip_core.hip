@@ -184,6 +184,25 @@ int hbhip_copy_d2d_out(hbhip_ctx *ctx, const hbhip_dev_frame *dst, const DevPict
     return HBHIP_OK;
 }
 
+int hbhip_filter::process_dev_batch(const hbhip_dev_frame *in, int n_in, int64_t tag0,
+                                    const hbhip_dev_frame *out, int out_cap, int *n_out)
+{
+    int produced = 0;
+    for (int i = 0; i < n_in; i++)
+    {
+        int rc = hbhip_filter_push_dev(this, &in[i], tag0 + i);
+        if (rc != HBHIP_OK) return rc;
+        while (produced < out_cap && pending() > 0)
+        {
+            rc = hbhip_filter_pull_dev(this, &out[produced], nullptr);
+            if (rc != HBHIP_OK) return rc;
+            produced++;
+        }
+    }
+    *n_out = produced;
+    return HBHIP_OK;
+}
+
 // ---------------------------------------------------------------- C ABI
 extern "C" {
 
@@ -441,20 +460,8 @@ int hbhip_filter_process_dev(hbhip_filter *f, const hbhip_dev_frame *in, int n_i
                              const hbhip_dev_frame *out, int out_cap, int *n_out)
 {
     if (!f || (n_in > 0 && !in) || !n_out) return HBHIP_ERR_ARG;
-    int produced = 0;
-    for (int i = 0; i < n_in; i++)
-    {
-        int rc = hbhip_filter_push_dev(f, &in[i], tag0 + i);
-        if (rc != HBHIP_OK) return rc;
-        while (produced < out_cap && f->pending() > 0)
-        {
-            rc = hbhip_filter_pull_dev(f, &out[produced], nullptr);
-            if (rc != HBHIP_OK) return rc;
-            produced++;
-        }
-    }
-    *n_out = produced;
-    return HBHIP_OK;
+    (void)hipSetDevice(f->ctx->device);
+    return f->process_dev_batch(in, n_in, tag0, out, out_cap, n_out);
 }
 
 int hbhip_filter_flush(hbhip_filter *f)

@@ -146,6 +146,10 @@ struct hbhip_filter
     virtual int pending() = 0;
     virtual DevPicture *pop_output() = 0;          // nullptr when none
     virtual void recycle_output(DevPicture *pic) = 0;
+    // Device-resident batch: default = push_dev/pull_dev per frame; filters may override
+    // with a zero-copy path that reads the caller's frames and writes its outputs in place.
+    virtual int process_dev_batch(const hbhip_dev_frame *in, int n_in, int64_t tag0,
+                                  const hbhip_dev_frame *out, int out_cap, int *n_out);
 };
 
 // A stateless one-frame-in / one-frame-out filter: subclasses implement process().

@@ -40,12 +40,13 @@ constexpr int NLM_BORDER = 16;   // nlmeans.c:529 for every patch size <= 29
 struct NlmJob
 {
     const uint8_t *frame[HBHIP_NLMEANS_FRAMES_MAX];
+    int            fpitch[HBHIP_NLMEANS_FRAMES_MAX];   // row pitch of each temporal frame
     uint8_t       *dst;
     const float   *exptable;
     double         origin_tune;
     float          wft;
     int            diff_max;
-    int            w, h, pitch, dst_pitch;
+    int            w, h, dst_pitch;
     int            nframes, r_half;
     int            tiles_x, tile_start;
 };
@@ -68,7 +69,13 @@ __device__ __forceinline__ void load_tile(uint32_t *lds, int dwords, int rows,
                                           int w, int h, int x0, int y0)
 {
     const int total = dwords * rows;
-    for (int i = threadIdx.x; i < total; i += TXN * TYN)
+    // The index math below depends only on the thread id; hide that from LICM, which
+    // otherwise precomputes it for every iteration and parks ~120 VGPRs across the
+    // whole displacement loop (occupancy 2 -> 3+).
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+#pragma nounroll
+    for (int i = tid; i < total; i += TXN * TYN)
     {
         const int r = i / dwords;
         const int c = i - r * dwords;
@@ -91,8 +98,9 @@ __device__ __forceinline__ void load_tile(uint32_t *lds, int dwords, int rows,
 
 __device__ __forceinline__ uint32_t byte_of(uint32_t v, int k) { return (v >> (8 * k)) & 0xffu; }
 
-template <int N>
-__global__ __launch_bounds__(TXN * TYN) void nlmeans_plane_kernel(const NlmJob *__restrict__ jobs, int njobs,
+// VAR bit 0: software-prefetch the next row's LDS words; bit 1: ask for 3 waves/SIMD.
+template <int N, int VAR>
+__global__ __launch_bounds__(TXN * TYN, (VAR & 2) ? 3 : 1) void nlmeans_plane_kernel(const NlmJob *__restrict__ jobs, int njobs,
                                                                   int cmp_dwords, int cmp_rows)
 {
     constexpr int NH = N / 2;
@@ -115,7 +123,7 @@ __global__ __launch_bounds__(TXN * TYN) void nlmeans_plane_kernel(const NlmJob *
     const int tile_y = tile / job.tiles_x;
     const int tile_x = tile - tile_y * job.tiles_x;
     const int tx0 = tile_x * TW, ty0 = tile_y * TH;
-    const int w = job.w, h = job.h, pitch = job.pitch;
+    const int w = job.w, h = job.h;
     const int RH = job.r_half;
     const int HALO = NH + RH;
     const int CPD = cmp_dwords;
@@ -124,7 +132,7 @@ __global__ __launch_bounds__(TXN * TYN) void nlmeans_plane_kernel(const NlmJob *
     const int ty = threadIdx.x / TXN;
 
     if (threadIdx.x < 128) s_exp[threadIdx.x] = job.exptable[threadIdx.x];
-    load_tile(s_src, SPD, SROWS, job.frame[0], pitch, w, h, tx0 - NH, ty0 - NH);
+    load_tile(s_src, SPD, SROWS, job.frame[0], job.fpitch[0], w, h, tx0 - NH, ty0 - NH);
 
     float aw[RY][PX], ap[RY][PX];
     uint32_t srcpix[RY];
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(TXN * TYN) void nlmeans_plane_kernel(const NlmJob *
     for (int f = 0; f < job.nframes; f++)
     {
         __syncthreads();   // everyone is done with the previous compare tile
-        load_tile(s_cmp, CPD, cmp_rows, job.frame[f], pitch, w, h, tx0 - HALO, ty0 - HALO);
+        load_tile(s_cmp, CPD, cmp_rows, job.frame[f], job.fpitch[f], w, h, tx0 - HALO, ty0 - HALO);
         __syncthreads();
 
         if (f == 0)
@@ -166,12 +174,17 @@ __global__ __launch_bounds__(TXN * TYN) void nlmeans_plane_kernel(const NlmJob *
                 {
 #pragma unroll
                     for (int o = 0; o < RY; o++)
+                    {
 #pragma unroll
                         for (int p = 0; p < PX; p++)
                         {
                             aw[o][p] = (float)((double)aw[o][p] + origin_tune);
                             ap[o][p] = (float)((double)ap[o][p] + origin_tune * (double)(int)byte_of(srcpix[o], p));
                         }
+                        // executed once per tile: keep the f64 temporaries of one row at a time,
+                        // or this block alone sets the kernel's VGPR count (236 -> occupancy 2)
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     continue;
                 }
 
@@ -188,15 +201,40 @@ __global__ __launch_bounds__(TXN * TYN) void nlmeans_plane_kernel(const NlmJob *
 #pragma unroll
                 for (int p = 0; p < PX; p++) v[p] = 0;
 
+                uint32_t a_n[ND], b_n[ND + 1];
+                if (VAR & 1)
+                {
+#pragma unroll
+                    for (int k = 0; k < ND; k++) a_n[k] = srow[k];
+#pragma unroll
+                    for (int k = 0; k <= ND; k++) b_n[k] = crow[k];
+                }
 #pragma unroll
                 for (int i = 0; i < ROWS; i++)
                 {
                     // squared differences over this row's window
                     uint32_t a[ND], b[ND + 1];
+                    if (VAR & 1)
+                    {
 #pragma unroll
-                    for (int k = 0; k < ND; k++) a[k] = srow[i * SPD + k];
+                        for (int k = 0; k < ND; k++) a[k] = a_n[k];
 #pragma unroll
-                    for (int k = 0; k <= ND; k++) b[k] = crow[i * CPD + k];
+                        for (int k = 0; k <= ND; k++) b[k] = b_n[k];
+                        if (i + 1 < ROWS)
+                        {
+#pragma unroll
+                            for (int k = 0; k < ND; k++) a_n[k] = srow[(i + 1) * SPD + k];
+#pragma unroll
+                            for (int k = 0; k <= ND; k++) b_n[k] = crow[(i + 1) * CPD + k];
+                        }
+                    }
+                    else
+                    {
+#pragma unroll
+                        for (int k = 0; k < ND; k++) a[k] = srow[i * SPD + k];
+#pragma unroll
+                        for (int k = 0; k <= ND; k++) b[k] = crow[i * CPD + k];
+                    }
                     uint32_t D[W];
 #pragma unroll
                     for (int q = 0; q < W; q++)
@@ -341,6 +379,7 @@ public:
             if (par.nframes[c] < 1 || par.nframes[c] > HBHIP_NLMEANS_FRAMES_MAX) return HBHIP_ERR_ARG;
             if (in_geo.pw[c] < NLM_BORDER || in_geo.ph[c] < NLM_BORDER) return HBHIP_ERR_UNSUPPORTED;
         }
+        if (const char *e = getenv("HBHIP_NLM_VARIANT")) variant = atoi(e);
         HBHIP_CHECK(ctx, hipMalloc((void **)&d_exp, sizeof(float) * 3 * 128));
         HBHIP_CHECK(ctx, hipMemcpyAsync(d_exp, par.exptable, sizeof(float) * 3 * 128,
                                         hipMemcpyHostToDevice, ctx->stream));
@@ -369,6 +408,7 @@ public:
     void recycle_output(DevPicture *p) override { pool.release(p); }
 
     int batch = 1;
+    int variant = 3;
 
 private:
     int ensure_jobs(int n)
@@ -391,23 +431,27 @@ private:
         return HBHIP_OK;
     }
 
-    // Filter as many queued frames as are ready (all of them when draining).
-    int schedule(bool draining)
+    struct View { uint8_t *plane[3]; int pitch[3]; };
+
+    static View view_of(const DevPicture *p)
     {
-        int ready = draining ? (int)in.size() : (int)in.size() - (max_frames - 1);
-        if (ready <= 0) return HBHIP_OK;
-        if (!draining && ready < batch) return HBHIP_OK;
+        View v;
+        for (int c = 0; c < 3; c++) { v.plane[c] = p->plane[c]; v.pitch[c] = p->pitch[c]; }
+        return v;
+    }
+    static View view_of(const hbhip_dev_frame &f)
+    {
+        View v;
+        for (int c = 0; c < 3; c++) { v.plane[c] = (uint8_t *)f.plane[c]; v.pitch[c] = f.stride[c]; }
+        return v;
+    }
 
-        std::vector<DevPicture *> outs(ready, nullptr);
-        for (int t = 0; t < ready; t++)
-        {
-            outs[t] = pool.acquire();
-            if (!outs[t]) return HBHIP_ERR_NOMEM;
-            outs[t]->tag = in[t]->tag;
-        }
-
+    // Filter frames ins[0..ready) (ins beyond `ready` are look-ahead only) into outs[0..ready).
+    int launch_views(const std::vector<View> &ins, int ready, const std::vector<View> &outs)
+    {
         int rc = ensure_jobs(ready * 3);
         if (rc != HBHIP_OK) return rc;
+        const int total = (int)ins.size();
 
         // group jobs by patch size (one launch per distinct n)
         for (int n : {3, 5, 7, 9})
@@ -425,18 +469,20 @@ private:
                 {
                     if (par.strength[c] == 0 || par.patch_size[c] != n) continue;
                     NlmJob &jb = hj[nj++];
-                    int avail = (int)in.size() - t;
-                    jb.nframes = std::min(par.nframes[c], avail);
-                    for (int f = 0; f < jb.nframes; f++) jb.frame[f] = in[t + f]->plane[c];
-                    jb.dst = outs[t]->plane[c];
+                    jb.nframes = std::min(par.nframes[c], total - t);
+                    for (int f = 0; f < jb.nframes; f++)
+                    {
+                        jb.frame[f] = ins[t + f].plane[c];
+                        jb.fpitch[f] = ins[t + f].pitch[c];
+                    }
+                    jb.dst = outs[t].plane[c];
                     jb.exptable = d_exp + 128 * c;
                     jb.origin_tune = par.origin_tune[c];
                     jb.wft = par.weight_fact_table[c];
                     jb.diff_max = par.diff_max[c];
                     jb.w = in_geo.pw[c];
                     jb.h = in_geo.ph[c];
-                    jb.pitch = in[t]->pitch[c];
-                    jb.dst_pitch = outs[t]->pitch[c];
+                    jb.dst_pitch = outs[t].pitch[c];
                     jb.r_half = (par.range[c] - 1) / 2;
                     jb.tiles_x = (jb.w + TW - 1) / TW;
                     jb.tile_start = tiles;
@@ -452,13 +498,18 @@ private:
             const int cmp_rows = TH + 2 * (nh + max_rh);
             const size_t shmem = sizeof(uint32_t) * ((TXN + ND) * (TH + 2 * nh) + cmp_dwords * cmp_rows) + 512;
             dim3 grid(tiles), block(TXN * TYN);
+#define NLM_GO(NN, VV) HBHIP_LAUNCH(ctx, "nlmeans_plane_n" #NN, (nlmeans_plane_kernel<NN, VV>), grid, block, shmem, dj, nj, cmp_dwords, cmp_rows)
+#define NLM_VAR(NN) do { switch (variant) { case 0: NLM_GO(NN, 0); break; case 1: NLM_GO(NN, 1); break; \
+                                            case 2: NLM_GO(NN, 2); break; default: NLM_GO(NN, 3); break; } } while (0)
             switch (n)
             {
-                case 3: HBHIP_LAUNCH(ctx, "nlmeans_plane_n3", nlmeans_plane_kernel<3>, grid, block, shmem, dj, nj, cmp_dwords, cmp_rows); break;
-                case 5: HBHIP_LAUNCH(ctx, "nlmeans_plane_n5", nlmeans_plane_kernel<5>, grid, block, shmem, dj, nj, cmp_dwords, cmp_rows); break;
-                case 7: HBHIP_LAUNCH(ctx, "nlmeans_plane_n7", nlmeans_plane_kernel<7>, grid, block, shmem, dj, nj, cmp_dwords, cmp_rows); break;
-                case 9: HBHIP_LAUNCH(ctx, "nlmeans_plane_n9", nlmeans_plane_kernel<9>, grid, block, shmem, dj, nj, cmp_dwords, cmp_rows); break;
+                case 3: NLM_VAR(3); break;
+                case 5: NLM_VAR(5); break;
+                case 7: NLM_VAR(7); break;
+                case 9: NLM_VAR(9); break;
             }
+#undef NLM_VAR
+#undef NLM_GO
             HBHIP_CHECK(ctx, hipGetLastError());
         }
 
@@ -470,10 +521,31 @@ private:
                     const int row = in_geo.pw[c] * in_geo.bps;
                     dim3 grid((row / 4 + 255) / 256 + 1, in_geo.ph[c]);
                     HBHIP_LAUNCH(ctx, "nlmeans_copy_plane", copy_plane_kernel, grid, dim3(256), 0,
-                                 outs[t]->plane[c], outs[t]->pitch[c], (const uint8_t *)in[t]->plane[c],
-                                 in[t]->pitch[c], row, in_geo.ph[c]);
+                                 outs[t].plane[c], outs[t].pitch[c], (const uint8_t *)ins[t].plane[c],
+                                 ins[t].pitch[c], row, in_geo.ph[c]);
                 }
+        return HBHIP_OK;
+    }
 
+    // Filter as many queued frames as are ready (all of them when draining).
+    int schedule(bool draining)
+    {
+        int ready = draining ? (int)in.size() : (int)in.size() - (max_frames - 1);
+        if (ready <= 0) return HBHIP_OK;
+        if (!draining && ready < batch) return HBHIP_OK;
+
+        std::vector<DevPicture *> outs(ready, nullptr);
+        std::vector<View> vin, vout;
+        for (DevPicture *p : in) vin.push_back(view_of(p));
+        for (int t = 0; t < ready; t++)
+        {
+            outs[t] = pool.acquire();
+            if (!outs[t]) return HBHIP_ERR_NOMEM;
+            outs[t]->tag = in[t]->tag;
+            vout.push_back(view_of(outs[t]));
+        }
+        int rc = launch_views(vin, ready, vout);
+        if (rc != HBHIP_OK) return rc;
         for (int t = 0; t < ready; t++)
         {
             out.push_back(outs[t]);
@@ -483,6 +555,50 @@ private:
         return HBHIP_OK;
     }
 
+public:
+    // Zero-copy batch: the kernel reads the caller's frames and writes the caller's output
+    // frames; only the max_frames-1 look-ahead frames are copied into the ring for the next call.
+    int process_dev_batch(const hbhip_dev_frame *fin, int n_in, int64_t tag0,
+                          const hbhip_dev_frame *fout, int out_cap, int *n_out) override
+    {
+        const int keep = max_frames - 1;
+        const int total = (int)in.size() + n_in;
+        const int ready = total - keep;
+        bool direct = out.empty() && n_in >= keep && ready > 0 && ready <= out_cap && (int)in.size() <= ready;
+        for (int i = 0; direct && i < n_in; i++)
+            for (int c = 0; c < 3; c++)
+                if ((fin[i].stride[c] & 3) || ((uintptr_t)fin[i].plane[c] & 3)) direct = false;
+        for (int i = 0; direct && i < ready; i++)
+            for (int c = 0; c < 3; c++)
+                if ((fout[i].stride[c] & 3) || ((uintptr_t)fout[i].plane[c] & 3)) direct = false;
+        if (!direct)
+            return hbhip_filter::process_dev_batch(fin, n_in, tag0, fout, out_cap, n_out);
+
+        std::vector<View> vin, vout;
+        for (DevPicture *p : in) vin.push_back(view_of(p));
+        for (int i = 0; i < n_in; i++) vin.push_back(view_of(fin[i]));
+        for (int t = 0; t < ready; t++) vout.push_back(view_of(fout[t]));
+        int rc = launch_views(vin, ready, vout);
+        if (rc != HBHIP_OK) return rc;
+        while (!in.empty())
+        {
+            pool.release(in.front());
+            in.pop_front();
+        }
+        for (int i = n_in - keep; i < n_in; i++)
+        {
+            DevPicture *p = pool.acquire();
+            if (!p) return HBHIP_ERR_NOMEM;
+            p->tag = tag0 + i;
+            rc = hbhip_copy_d2d_in(ctx, p, &fin[i]);
+            if (rc != HBHIP_OK) return rc;
+            in.push_back(p);
+        }
+        *n_out = ready;
+        return HBHIP_OK;
+    }
+
+private:
     hbhip_nlmeans_params par;
     PicturePool pool;
     std::deque<DevPicture *> in, out;

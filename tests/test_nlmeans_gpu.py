@@ -126,3 +126,36 @@ def test_device_resident_batched_equals_streamed(built):
             np.testing.assert_array_equal(dev_out[t][c].cpu().numpy(), want[t].planes[c])
     flt.close()
     ctx.close()
+
+
+def test_zero_copy_process_dev_equals_streamed(built):
+    """bench.py's entry point (hbhip_filter_process_dev, zero-copy batches) gives the same
+    bytes as the frame-at-a-time host path, across consecutive batches."""
+    import torch
+    w, h, B, nb = 320, 180, 4, 3
+    frames = synth.stream("progressive", w, h, 1 + B * nb)
+    want = run_hip(frames, MEDIUM)
+    ctx = hip.Ctx(0)
+    flt = hip.nlmeans_device_filter(ctx, MEDIUM, w, h, batch=B)
+    dev_in = [[torch.from_numpy(p.copy()).cuda() for p in fr] for fr in frames]
+    dev_out = [[torch.zeros_like(p) for p in fr] for fr in dev_in]
+    torch.cuda.synchronize()
+    flt.push_dev(hip.dev_frame(dev_in[0]), 0)
+    done = 0
+    for b in range(nb):
+        ins = (hip.DevFrame * B)(*[hip.dev_frame(dev_in[1 + b * B + i]) for i in range(B)])
+        outs = (hip.DevFrame * B)(*[hip.dev_frame(dev_out[done + i]) for i in range(B)])
+        n = flt.process_dev(ins, 1 + b * B, outs)
+        assert n == B
+        done += n
+    flt.flush()
+    while flt.pending():
+        flt.pull_dev(hip.dev_frame(dev_out[done]))
+        done += 1
+    ctx.sync()
+    assert done == len(frames)
+    for t in range(len(frames)):
+        for c in range(3):
+            np.testing.assert_array_equal(dev_out[t][c].cpu().numpy(), want[t].planes[c], err_msg=f"frame {t} plane {c}")
+    flt.close()
+    ctx.close()
