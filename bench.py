@@ -79,6 +79,97 @@ def cpu_baseline(frames_np):
             "sample": f"{n} frames 1920x1080 YUV420P, oracle/nlmeans_oracle.c single thread, {dt:.1f}s wall"}
 
 
+def secondary(args):
+    """configs[2] / configs[3] measured the same way (device-resident, one stream per GPU).
+    Not the default bench line; used for DESIGN.md / profiles."""
+    import torch
+    from handbrake_amd import hip, shard, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    ctx = hip.Ctx(local_rank)
+    nsrc = 8
+    frames_np = synth.stream("interlaced", W, H, nsrc, cfg=3 + 16 * rank)
+    dev_in = [[torch.from_numpy(p).cuda() for p in fr] for fr in frames_np]
+    fin = [hip.dev_frame(f) for f in dev_in]
+    torch.cuda.synchronize()
+
+    def planes(w, h):
+        return [torch.empty((h, w), dtype=torch.uint8, device="cuda"),
+                torch.empty((h // 2, w // 2), dtype=torch.uint8, device="cuda"),
+                torch.empty((h // 2, w // 2), dtype=torch.uint8, device="cuda")]
+
+    decomb = hip.DecombDevice(ctx, W, H, mode=31)
+    decomb_f = hip.DeviceFilter(ctx, decomb.h)
+    t1080, t1080b, t2160, t2160b = planes(W, H), planes(W, H), planes(2 * W, 2 * H), planes(2 * W, 2 * H)
+    f1080, f1080b, f2160, f2160b = map(hip.dev_frame, (t1080, t1080b, t2160, t2160b))
+    chain = args.workload == "chain4"
+    if chain:
+        nlm = hip.nlmeans_device_filter(ctx, hip.NLMEANS_MEDIUM, W, H, batch=1)
+        scale = hip.cropscale_device_filter(ctx, W, H, 2 * W, 2 * H)
+        sharp = hip.lapsharp_device_filter(ctx, 2 * W, 2 * H)
+
+    produced = 0
+
+    def feed(i):
+        nonlocal produced
+        hip.decomb_push_dev(decomb_f, fin[i % nsrc], i)
+        while decomb_f.pending():
+            decomb_f.pull_dev(f1080)
+            if not chain:
+                produced += 1
+                continue
+            nlm.push_dev(f1080, 0)
+            while nlm.pending():
+                nlm.pull_dev(f1080b)
+                scale.push_dev(f1080b, 0)
+                scale.pull_dev(f2160)
+                sharp.push_dev(f2160, 0)
+                sharp.pull_dev(f2160b)
+                produced += 1
+
+    for i in range(args.warmup):
+        feed(i)
+    ctx.sync()
+    torch.cuda.synchronize()
+    ctx.profile(True)
+    ctx.profile_reset()
+    start = produced
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        feed(args.warmup + i)
+    ctx.sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    stats = ctx.profile_stats()
+    ctx.profile(False)
+    out_frames = produced - start
+    frames_total, dt_max = shard.reduce_throughput(float(out_frames), dt, device="cuda")
+    if rank == 0:
+        top = sorted(stats.items(), key=lambda kv: -kv[1][1])[:6]
+        kname, (launches, total_ms) = top[0]
+        per_out = {"decomb_eedi2": 4 * (W * H * 3 // 2), "chain4": 62_200_000}[args.workload]   # SURVEY §8d
+        print(json.dumps({
+            "metric": "filtered output frames/sec (" + args.workload + ")",
+            "value": round(frames_total / dt_max, 2), "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt_max / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": {"decomb_eedi2": "BASELINE configs[2]: decomb EEDI2 bob (mode 31) 1920x1080 interlaced",
+                                    "chain4": "BASELINE configs[3]: decomb(31)->nlmeans medium->cropscale lanczos "
+                                              "1080p->2160p->lapsharp, per-frame launches"}[args.workload],
+                       "input_frames_per_step": 1, "output_frames_per_step": 2, "device": ctx.name()},
+            "chain_hbm_GBps_algorithmic": round(per_out * frames_total / dt_max / 1e9, 2),
+            "top_kernels": [{"kernel": k, "launches": n, "avg_us": round(ms / n * 1e3, 1)} for k, (n, ms) in top],
+            "roofline": None, "cpu_baseline": None}), flush=True)
+    ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,7 +177,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="nlmeans", choices=["nlmeans", "decomb_eedi2", "chain4"],
+                    help="nlmeans = BASELINE configs[1] (default, the bench line the driver records); "
+                         "decomb_eedi2 = configs[2]; chain4 = configs[3] (decomb->nlmeans->cropscale->lapsharp)")
     args = ap.parse_args()
+    if args.workload != "nlmeans":
+        return secondary(args)
 
     import torch
     import torch.distributed as dist

@@ -17,6 +17,7 @@
 // pixel ~taps^2/scale^2 times from L2).
 #include "hbhip_internal.h"
 
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -211,22 +212,32 @@ struct ScaleArgs
     const double *cx, *cy;
 };
 
-__global__ __launch_bounds__(256) void cropscale_kernel(ScaleArgs a)
+// Pass 1: H[r][x] = sum_i cx[x][i] * src[r][ix[x][i]] for every source row r of the crop window.
+// Pass 2: out[y][x] = round(clamp(sum_j cy[y][j] * H[iy[y][j]][x])).
+// Same products, same order of additions as the one-loop form in oracle/alias_oracle.c, so the
+// split changes nothing numerically; it turns taps^2 gathers per pixel into 2*taps.
+__global__ __launch_bounds__(256) void cropscale_h_kernel(ScaleArgs a, double *__restrict__ hbuf, int src_rows)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= a.dw || r >= src_rows) return;
+    const int *ix = a.ix + (size_t)x * a.tx;
+    const double *cx = a.cx + (size_t)x * a.tx;
+    const uint8_t *row = a.src + (size_t)r * a.spitch;
+    double h = 0.0;
+    for (int i = 0; i < a.tx; i++)
+        h += cx[i] * (double)row[ix[i]];
+    hbuf[(size_t)r * a.dw + x] = h;
+}
+
+__global__ __launch_bounds__(256) void cropscale_v_kernel(ScaleArgs a, const double *__restrict__ hbuf)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= a.dw || y >= a.dh) return;
-    const int *ix = a.ix + (size_t)x * a.tx;
-    const double *cx = a.cx + (size_t)x * a.tx;
     double acc = 0.0;
     for (int j = 0; j < a.ty; j++)
-    {
-        const uint8_t *row = a.src + (size_t)a.iy[(size_t)y * a.ty + j] * a.spitch;
-        double h = 0.0;
-        for (int i = 0; i < a.tx; i++)
-            h += cx[i] * (double)row[ix[i]];
-        acc += a.cy[(size_t)y * a.ty + j] * h;
-    }
+        acc += a.cy[(size_t)y * a.ty + j] * hbuf[(size_t)a.iy[(size_t)y * a.ty + j] * a.dw + x];
     acc = acc < 0.0 ? 0.0 : acc > 255.0 ? 255.0 : acc;
     a.dst[(size_t)y * a.dpitch + x] = (uint8_t)(int)(acc + 0.5);
 }
@@ -296,6 +307,7 @@ public:
             if (d_cx[c]) (void)hipFree(d_cx[c]);
             if (d_cy[c]) (void)hipFree(d_cy[c]);
         }
+        if (hbuf) (void)hipFree(hbuf);
     }
     int setup()
     {
@@ -327,6 +339,10 @@ public:
             HBHIP_CHECK(ctx, hipMemcpy(d_cx[c], cx.data(), sizeof(double) * cx.size(), hipMemcpyHostToDevice));
             HBHIP_CHECK(ctx, hipMemcpy(d_cy[c], cy.data(), sizeof(double) * cy.size(), hipMemcpyHostToDevice));
         }
+        size_t need = 0;
+        for (int c = 0; c < 3; c++)
+            if (!identity[c]) need = std::max(need, (size_t)out_geo.pw[c] * crop_h[c]);
+        if (need) HBHIP_CHECK(ctx, hipMalloc((void **)&hbuf, sizeof(double) * need));
         return HBHIP_OK;
     }
     int process(DevPicture *in, DevPicture *out) override
@@ -346,7 +362,10 @@ public:
             a.spitch = in->pitch[c]; a.dpitch = out->pitch[c];
             a.dw = dw; a.dh = dh; a.tx = tx[c]; a.ty = ty[c];
             a.ix = d_ix[c]; a.iy = d_iy[c]; a.cx = d_cx[c]; a.cy = d_cy[c];
-            HBHIP_LAUNCH(ctx, "cropscale_lanczos", cropscale_kernel, dim3((dw + 63) / 64, (dh + 3) / 4), dim3(64, 4), 0, a);
+            HBHIP_LAUNCH(ctx, "cropscale_lanczos_h", cropscale_h_kernel, dim3((dw + 63) / 64, (crop_h[c] + 3) / 4),
+                         dim3(64, 4), 0, a, hbuf, crop_h[c]);
+            HBHIP_LAUNCH(ctx, "cropscale_lanczos_v", cropscale_v_kernel, dim3((dw + 63) / 64, (dh + 3) / 4),
+                         dim3(64, 4), 0, a, (const double *)hbuf);
         }
         HBHIP_CHECK(ctx, hipGetLastError());
         return HBHIP_OK;
@@ -356,6 +375,7 @@ public:
     bool identity[3] = {false, false, false};
     int *d_ix[3] = {nullptr, nullptr, nullptr}, *d_iy[3] = {nullptr, nullptr, nullptr};
     double *d_cx[3] = {nullptr, nullptr, nullptr}, *d_cy[3] = {nullptr, nullptr, nullptr};
+    double *hbuf = nullptr;     // horizontally filtered rows of one plane (dst_w x crop_h doubles)
 };
 
 } // namespace

@@ -32,7 +32,7 @@
 namespace {
 
 constexpr int PEAK = 255, NEUTRAL = 128;
-constexpr size_t GUARD = 4096;
+constexpr size_t GUARD = 32768;   // >= 2 rows + halo of the widest plane the LDS staging may touch
 
 __constant__ uint8_t c_limlut[33] = { 6, 6, 7, 7, 8, 8, 9, 9, 9, 10, 10, 11, 11, 12, 12, 12, 12, 12, 12, 12,
                                       12, 12, 12, 12, 12, 12, 12, 12, 12, 12, 12, 255, 255 };   // eedi2.c:21-25 stored as u8
@@ -182,78 +182,200 @@ __global__ void k_small_gaps(P3 P)
     P.b[pl][(size_t)y * pitch + x] = (uint8_t)out;
 }
 
-// a = mskp, b = srcp, c = out (tmpp)
-__global__ void k_calc_directions(P3 P, int maxd, int nt13, int nt19)
+// calc_directions in two launches so that no lane idles while its neighbour walks the
+// +-maxd search: k_calc_dir_mark fills the plane with 255 (the reference's memset) and
+// appends every pixel that passes the edge test (:392-393) to a work list; k_calc_dir_work
+// gives each listed pixel its own lane.  a = mskp, b = srcp, c = out (tmpp).
+__global__ void k_calc_dir_mark(P3 P, uint32_t *__restrict__ list, int *__restrict__ count)
 {
     XY_PLANE(P);
     if (x >= pitch || y >= height) return;
-    uint8_t *o = P.c[pl] + (size_t)y * pitch + x;
-    int out = 255;                                            // memset(dstp, 255, pitch*height)
+    P.c[pl][(size_t)y * pitch + x] = 255;                      // memset(dstp, 255, pitch*height)
     if (x >= 1 && x < width - 1 && y >= 1 && y < height - 1)
     {
         const uint8_t *mc = P.a[pl] + (size_t)y * pitch;
         if (mc[x] == PEAK && (mc[x - 1] == PEAK || mc[x + 1] == PEAK))
+            list[atomicAdd(count, 1)] = (uint32_t)x | ((uint32_t)y << 14) | ((uint32_t)pl << 28);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_calc_dir_work(P3 P, const uint32_t *__restrict__ list,
+                                                       const int *__restrict__ count, int maxd, int nt13, int nt19)
+{
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= *count) return;
+    const uint32_t e = list[gid];
+    const int x = e & 0x3fff, y = (e >> 14) & 0x3fff, pl = e >> 28;
+    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
+    const uint8_t *mc = P.a[pl] + (size_t)y * pitch;
+    const uint8_t *mp = mc - pitch, *mn = mc + pitch;
+    const uint8_t *sc = P.b[pl] + (size_t)y * pitch;
+    const uint8_t *sp = sc - pitch, *sn = sc + pitch, *s2p = sp - pitch, *s2n = sn + pitch;
+    const int maxdt = pl == 0 ? maxd : (maxd >> 1);
+    const int startu = max(-x + 1, -maxdt), stopu = min(width - 2 - x, maxdt);
+    const int vert = iabs((int)sc[x] - (int)sn[x]) + iabs((int)sc[x] - (int)sp[x]);
+    int minb = min(nt13, vert * 6), mina = min(nt19, vert * 9);
+    int minc = mina, mind = minb, mine = minb;
+    int dira = -5000, dirb = -5000, dirc = -5000, dird = -5000, dire = -5000;
+    for (int u = startu; u <= stopu; u++)
+    {
+        if (!(y == 1 || mp[x - 1 + u] == PEAK || mp[x + u] == PEAK || mp[x + 1 + u] == PEAK)) continue;
+        if (!(y == height - 2 || mn[x - 1 - u] == PEAK || mn[x - u] == PEAK || mn[x + 1 - u] == PEAK)) continue;
+        const int diffsn = sad3(sc, x, sn, x - u);
+        const int diffsp = sad3(sc, x, sp, x + u);
+        const int diffps = sad3(sp, x, sc, x - u);
+        const int diffns = sad3(sn, x, sc, x + u);
+        const int diff = diffsn + diffsp + diffps + diffns;
+        int diffd = diffsp + diffns, diffe = diffsn + diffps;
+        if (diff < minb) { dirb = u; minb = diff; }
+        if (y > 1)
         {
-            const uint8_t *mp = mc - pitch, *mn = mc + pitch;
-            const uint8_t *sc = P.b[pl] + (size_t)y * pitch;
-            const uint8_t *sp = sc - pitch, *sn = sc + pitch, *s2p = sp - pitch, *s2n = sn + pitch;
-            const int maxdt = pl == 0 ? maxd : (maxd >> 1);
-            const int startu = max(-x + 1, -maxdt), stopu = min(width - 2 - x, maxdt);
-            const int vert = iabs((int)sc[x] - (int)sn[x]) + iabs((int)sc[x] - (int)sp[x]);
-            int minb = min(nt13, vert * 6), mina = min(nt19, vert * 9);
-            int minc = mina, mind = minb, mine = minb;
-            int dira = -5000, dirb = -5000, dirc = -5000, dird = -5000, dire = -5000;
-            for (int u = startu; u <= stopu; u++)
-            {
-                if (!(y == 1 || mp[x - 1 + u] == PEAK || mp[x + u] == PEAK || mp[x + 1 + u] == PEAK)) continue;
-                if (!(y == height - 2 || mn[x - 1 - u] == PEAK || mn[x - u] == PEAK || mn[x + 1 - u] == PEAK)) continue;
-                const int diffsn = sad3(sc, x, sn, x - u);
-                const int diffsp = sad3(sc, x, sp, x + u);
-                const int diffps = sad3(sp, x, sc, x - u);
-                const int diffns = sad3(sn, x, sc, x + u);
-                const int diff = diffsn + diffsp + diffps + diffns;
-                int diffd = diffsp + diffns, diffe = diffsn + diffps;
-                if (diff < minb) { dirb = u; minb = diff; }
-                if (y > 1)
-                {
-                    const int diff2pp = sad3(s2p, x, sp, x - u);
-                    const int diffp2p = sad3(sp, x, s2p, x + u);
-                    const int diffa = diff + diff2pp + diffp2p;
-                    diffd += diffp2p;
-                    diffe += diff2pp;
-                    if (diffa < mina) { dira = u; mina = diffa; }
-                }
-                if (y < height - 2)
-                {
-                    const int diff2nn = sad3(s2n, x, sn, x + u);
-                    const int diffn2n = sad3(sn, x, s2n, x - u);
-                    const int diffc = diff + diff2nn + diffn2n;
-                    diffd += diff2nn;
-                    diffe += diffn2n;
-                    if (diffc < minc) { dirc = u; minc = diffc; }
-                }
-                if (diffd < mind) { dird = u; mind = diffd; }
-                if (diffe < mine) { dire = u; mine = diffe; }
-            }
-            int order[5], k = 0;
-            if (dira != -5000) order[k++] = dira;
-            if (dirb != -5000) order[k++] = dirb;
-            if (dirc != -5000) order[k++] = dirc;
-            if (dird != -5000) order[k++] = dird;
-            if (dire != -5000) order[k++] = dire;
-            out = NEUTRAL;
-            if (k > 1)
-            {
-                const int mid = sorted_mid(order, k);
-                const int tlim = max((int)c_limlut[iabs(mid)] >> 2, 2);
-                int sum = 0, count = 0;
-                for (int i = 0; i < k; i++)
-                    if (iabs(order[i] - mid) <= tlim) { count++; sum += order[i]; }
-                if (count > 1) out = (NEUTRAL + ((int)((float)sum / (float)count) * 4)) & 0xff;
-            }
+            const int diff2pp = sad3(s2p, x, sp, x - u);
+            const int diffp2p = sad3(sp, x, s2p, x + u);
+            const int diffa = diff + diff2pp + diffp2p;
+            diffd += diffp2p;
+            diffe += diff2pp;
+            if (diffa < mina) { dira = u; mina = diffa; }
+        }
+        if (y < height - 2)
+        {
+            const int diff2nn = sad3(s2n, x, sn, x + u);
+            const int diffn2n = sad3(sn, x, s2n, x - u);
+            const int diffc = diff + diff2nn + diffn2n;
+            diffd += diff2nn;
+            diffe += diffn2n;
+            if (diffc < minc) { dirc = u; minc = diffc; }
+        }
+        if (diffd < mind) { dird = u; mind = diffd; }
+        if (diffe < mine) { dire = u; mine = diffe; }
+    }
+    int order[5], k = 0;
+    if (dira != -5000) order[k++] = dira;
+    if (dirb != -5000) order[k++] = dirb;
+    if (dirc != -5000) order[k++] = dirc;
+    if (dird != -5000) order[k++] = dird;
+    if (dire != -5000) order[k++] = dire;
+    int out = NEUTRAL;
+    if (k > 1)
+    {
+        const int mid = sorted_mid(order, k);
+        const int tlim = max((int)c_limlut[iabs(mid)] >> 2, 2);
+        int sum = 0, cnt = 0;
+        for (int i = 0; i < k; i++)
+            if (iabs(order[i] - mid) <= tlim) { cnt++; sum += order[i]; }
+        if (cnt > 1) out = (NEUTRAL + ((int)((float)sum / (float)cnt) * 4)) & 0xff;
+    }
+    P.c[pl][(size_t)y * pitch + x] = (uint8_t)out;
+}
+
+// calc_directions, fast path (search distance <= 30): one block = 256 consecutive pixels of one
+// row.  The 5 source rows and 3 mask rows the search touches are staged in LDS (with the same
+// flat addressing, so out-of-row offsets pick up the same bytes), the pixels that pass the edge
+// test are compacted inside the block so that busy lanes are contiguous, and each listed pixel
+// walks its +-maxd window out of LDS.
+constexpr int CD_W = 256, CD_HALO = 32, CD_LW = CD_W + 2 * CD_HALO;
+
+__device__ __forceinline__ int sad3l(const uint8_t *a, int ai, const uint8_t *b, int bi)
+{
+    return (int)__usad(a[ai + 1], b[bi + 1], __usad(a[ai], b[bi], __usad(a[ai - 1], b[bi - 1], 0u)));
+}
+
+__global__ __launch_bounds__(CD_W) void k_calc_dir_tile(P3 P, int maxd, int nt13, int nt19)
+{
+    __shared__ uint8_t s_src[5][CD_LW];
+    __shared__ uint8_t s_msk[3][CD_LW];
+    __shared__ uint16_t s_list[CD_W];
+    __shared__ int s_count;
+    const int pl = blockIdx.z;
+    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
+    const int x0 = blockIdx.x * CD_W, y = blockIdx.y;
+    if (y >= height || x0 >= pitch) return;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_count = 0;
+    {
+        const uint8_t *sb = P.b[pl] + (ptrdiff_t)(y - 2) * pitch + x0 - CD_HALO;
+        const uint8_t *mb = P.a[pl] + (ptrdiff_t)(y - 1) * pitch + x0 - CD_HALO;
+        for (int i = tid; i < CD_LW; i += CD_W)
+        {
+#pragma unroll
+            for (int r = 0; r < 5; r++) s_src[r][i] = sb[(ptrdiff_t)r * pitch + i];
+#pragma unroll
+            for (int r = 0; r < 3; r++) s_msk[r][i] = mb[(ptrdiff_t)r * pitch + i];
         }
     }
-    *o = (uint8_t)out;
+    __syncthreads();
+    const int x = x0 + tid, c = tid + CD_HALO;
+    bool active = false;
+    if (x < pitch)
+    {
+        if (x >= 1 && x < width - 1 && y >= 1 && y < height - 1)
+            active = s_msk[1][c] == PEAK && (s_msk[1][c - 1] == PEAK || s_msk[1][c + 1] == PEAK);
+        if (!active) P.c[pl][(size_t)y * pitch + x] = 255;        // memset(dstp, 255, pitch*height)
+    }
+    if (active) s_list[atomicAdd(&s_count, 1)] = (uint16_t)tid;
+    __syncthreads();
+    if (tid >= s_count) return;
+
+    const int lx = s_list[tid];
+    const int px = x0 + lx, cc = lx + CD_HALO;
+    const uint8_t *s2p = s_src[0], *sp = s_src[1], *sc = s_src[2], *sn = s_src[3], *s2n = s_src[4];
+    const uint8_t *mp = s_msk[0], *mn = s_msk[2];
+    const int maxdt = pl == 0 ? maxd : (maxd >> 1);
+    const int startu = max(-px + 1, -maxdt), stopu = min(width - 2 - px, maxdt);
+    const int vert = iabs((int)sc[cc] - (int)sn[cc]) + iabs((int)sc[cc] - (int)sp[cc]);
+    int minb = min(nt13, vert * 6), mina = min(nt19, vert * 9);
+    int minc = mina, mind = minb, mine = minb;
+    int dira = -5000, dirb = -5000, dirc = -5000, dird = -5000, dire = -5000;
+    const bool first = y == 1, last = y == height - 2;
+    for (int u = startu; u <= stopu; u++)
+    {
+        if (!(first || mp[cc - 1 + u] == PEAK || mp[cc + u] == PEAK || mp[cc + 1 + u] == PEAK)) continue;
+        if (!(last || mn[cc - 1 - u] == PEAK || mn[cc - u] == PEAK || mn[cc + 1 - u] == PEAK)) continue;
+        const int diffsn = sad3l(sc, cc, sn, cc - u);
+        const int diffsp = sad3l(sc, cc, sp, cc + u);
+        const int diffps = sad3l(sp, cc, sc, cc - u);
+        const int diffns = sad3l(sn, cc, sc, cc + u);
+        const int diff = diffsn + diffsp + diffps + diffns;
+        int diffd = diffsp + diffns, diffe = diffsn + diffps;
+        if (diff < minb) { dirb = u; minb = diff; }
+        if (!first)
+        {
+            const int diff2pp = sad3l(s2p, cc, sp, cc - u);
+            const int diffp2p = sad3l(sp, cc, s2p, cc + u);
+            const int diffa = diff + diff2pp + diffp2p;
+            diffd += diffp2p;
+            diffe += diff2pp;
+            if (diffa < mina) { dira = u; mina = diffa; }
+        }
+        if (!last)
+        {
+            const int diff2nn = sad3l(s2n, cc, sn, cc + u);
+            const int diffn2n = sad3l(sn, cc, s2n, cc - u);
+            const int diffc = diff + diff2nn + diffn2n;
+            diffd += diff2nn;
+            diffe += diffn2n;
+            if (diffc < minc) { dirc = u; minc = diffc; }
+        }
+        if (diffd < mind) { dird = u; mind = diffd; }
+        if (diffe < mine) { dire = u; mine = diffe; }
+    }
+    int order[5], k = 0;
+    if (dira != -5000) order[k++] = dira;
+    if (dirb != -5000) order[k++] = dirb;
+    if (dirc != -5000) order[k++] = dirc;
+    if (dird != -5000) order[k++] = dird;
+    if (dire != -5000) order[k++] = dire;
+    int out = NEUTRAL;
+    if (k > 1)
+    {
+        const int mid = sorted_mid(order, k);
+        const int tlim = max((int)c_limlut[iabs(mid)] >> 2, 2);
+        int sum = 0, cnt = 0;
+        for (int i = 0; i < k; i++)
+            if (iabs(order[i] - mid) <= tlim) { cnt++; sum += order[i]; }
+        if (cnt > 1) out = (NEUTRAL + ((int)((float)sum / (float)cnt) * 4)) & 0xff;
+    }
+    P.c[pl][(size_t)y * pitch + px] = (uint8_t)out;
 }
 
 // filter_dir_map / expand_dir_map and their _2x forms.
@@ -448,18 +570,130 @@ __global__ void k_fill_gaps(P3 P, int y0)
     P.c[pl][(size_t)y * pitch + x] = (uint8_t)out;
 }
 
+// interpolate_lattice in two launches.
+// k_lattice_cand (one thread per pixel of the rows being rebuilt): everything about a pixel
+// that does not depend on its left neighbour's NEW direction value, packed into 32 bits:
+//   [7:0] valA  = vertical average (outcome A)      [15:8]  valB = outcome-B pixel value
+//   [23:16] newB = outcome-B direction value        bit 24 = "always A" (dir == peak)
+//   bit 25 = right-hand test |d[x]-d[x+1]| > lim    (newA is NEUTRAL, or PEAK when always A)
+// k_lattice_resolve (one wavefront per row): resolves which outcome each pixel takes —
+// that depends on the value just written at x-1 (:1194) — with a 64-lane prefix composition
+// of 2-state maps, carrying the last written value from chunk to chunk, then writes the row.
 // a = dmsk (tmp2p, in/out), b = dst (dst2p, in/out), c = omsk (tmp2p2).
+__global__ __launch_bounds__(256) void k_lattice_cand(P3 P, uint32_t *__restrict__ cand, int cand_pitch,
+                                                       int cand_plane_stride, int field, int nt4, int nt7, int nt8, int nt)
+{
+    const int pl = blockIdx.z;
+    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ri = blockIdx.y * blockDim.y + threadIdx.y;
+    const int nrows = (height - (2 - field)) / 2;
+    if (x >= width || ri >= nrows) return;
+    const int y = (2 - field) + 2 * ri;
+    const uint8_t *dst = P.b[pl];
+    const uint8_t *top = dst + (size_t)(y - 1) * pitch, *bot = top + 2 * (size_t)pitch;
+    const uint8_t *ot = P.c[pl] + (size_t)(y - 1) * pitch, *ob = ot + 2 * (size_t)pitch;
+    const uint8_t *dm = P.a[pl] + (size_t)y * pitch;
+
+    const int d = dm[x];
+    const int lim = c_limlut[iabs(d - NEUTRAL) >> 2];
+    const int avg = ((int)top[x] + (int)bot[x] + 1) >> 1;
+    const bool always_a = d == PEAK;
+    const bool right = iabs(d - (int)dm[x + 1]) > lim;
+    int valB = avg, newB = NEUTRAL;
+    if (!always_a)
+    {
+        bool done = false;
+        if (lim < 9)
+        {
+            const int t0 = top[x - 1], t1 = top[x], t2 = top[x + 1], b0 = bot[x - 1], b1 = bot[x], b2 = bot[x + 1];
+            const int sum = t0 + t1 + t2 + b0 + b1 + b2;
+            const int sumsq = t0 * t0 + t1 * t1 + t2 * t2 + b0 * b0 + b1 * b1 + b2 * b2;
+            if (6 * sumsq - sum * sum < 576) { valB = avg; newB = PEAK; done = true; }
+        }
+        if (!done && x > 1 && x < width - 2)
+        {
+            const int t = top[x], b = bot[x];
+            const int tl = max((int)top[x - 2], (int)top[x - 1]), tr = max((int)top[x + 2], (int)top[x + 1]);
+            const int bl = max((int)bot[x - 2], (int)bot[x - 1]), br = max((int)bot[x + 2], (int)bot[x + 1]);
+            const int tl2 = min((int)top[x - 2], (int)top[x - 1]), tr2 = min((int)top[x + 2], (int)top[x + 1]);
+            const int bl2 = min((int)bot[x - 2], (int)bot[x - 1]), br2 = min((int)bot[x + 2], (int)bot[x + 1]);
+            if ((t < tl - 3 && t < tr - 3 && b < bl - 3 && b < br - 3) ||
+                (t > tl2 + 3 && t > tr2 + 3 && b > bl2 + 3 && b > br2 + 3))
+            { valB = avg; newB = NEUTRAL; done = true; }
+        }
+        if (!done)
+        {
+            int dir = (d - NEUTRAL + 2) >> 2;
+            int val = avg;
+            const int startu = (dir - 2 < 0) ? max(-x + 1, max(dir - 2, -width + 2 + x)) : min(x - 1, min(dir - 2, width - 2 - x));
+            const int stopu = (dir + 2 < 0) ? max(-x + 1, max(dir + 2, -width + 2 + x)) : min(x - 1, min(dir + 2, width - 2 - x));
+            int mn = nt8;
+#define NEAR(row, i) ((row)[i] != PEAK && iabs((int)(row)[i] - d) <= lim)
+            for (int u = startu; u <= stopu; u++)
+            {
+                const int diff = sad3(top, x, bot, x - u) + sad3(bot, x, top, x + u);
+                if (!(diff < mn && (NEAR(ot, x - 1 + u) || NEAR(ot, x + u) || NEAR(ot, x + 1 + u)) &&
+                      (NEAR(ob, x - 1 - u) || NEAR(ob, x - u) || NEAR(ob, x + 1 - u))))
+                    continue;
+                const int h0 = u >> 1, h1 = (u + 1) >> 1;
+                const int diff2 = sad3(top, x + h0, bot, x - h0);
+                const int o0 = ot[x + h0], o1 = ot[x + h1], q0 = ob[x - h0], q1 = ob[x - h1];
+                if (!(diff2 < nt4 && (((iabs(o0 - q0) <= lim || iabs(o0 - q1) <= lim) && o0 != PEAK) ||
+                                      ((iabs(o1 - q0) <= lim || iabs(o1 - q1) <= lim) && o1 != PEAK))))
+                    continue;
+                if ((iabs(d - o0) <= lim || iabs(d - o1) <= lim) && (iabs(d - q0) <= lim || iabs(d - q1) <= lim))
+                {
+                    val = ((int)top[x + h0] + (int)top[x + h1] + (int)bot[x - h0] + (int)bot[x - h1] + 2) >> 2;
+                    mn = diff;
+                    dir = u;
+                }
+            }
+#undef NEAR
+            if (mn != nt8)
+            {
+                valB = val;
+                newB = (NEUTRAL + dir * 4) & 0xff;
+            }
+            else
+            {
+                const int lo = min((int)top[x], (int)bot[x]), hi = max((int)top[x], (int)bot[x]);
+                const int dd = pl == 0 ? 4 : 2;
+                const int su = max(-x + 1, -dd), eu = min(width - 2 - x, dd);
+                mn = nt7;
+                for (int u = su; u <= eu; u++)
+                {
+                    const int h0 = u >> 1, h1 = (u + 1) >> 1;
+                    const int p1 = (int)top[x + h0] + (int)top[x + h1];
+                    const int p2 = (int)bot[x - h0] + (int)bot[x - h1];
+                    const int diff = sad3(top, x, bot, x - u) + sad3(bot, x, top, x + u) + iabs(p1 - p2);
+                    if (diff < mn)
+                    {
+                        const int valt = (p1 + p2 + 2) >> 2;
+                        if (valt >= lo && valt <= hi) { val = valt; mn = diff; dir = u; }
+                    }
+                }
+                valB = val;
+                newB = (mn == 7 * nt) ? NEUTRAL : ((NEUTRAL + dir * 4) & 0xff);
+            }
+        }
+    }
+    cand[(size_t)pl * cand_plane_stride + (size_t)ri * cand_pitch + x] =
+        (uint32_t)avg | ((uint32_t)valB << 8) | ((uint32_t)newB << 16) | ((uint32_t)always_a << 24) | ((uint32_t)right << 25);
+}
+
 // grid.y = processed rows (+1 for the border-row copy), block = one wavefront.
-__global__ __launch_bounds__(64) void k_lattice(P3 P, int field, int nt4, int nt7, int nt8, int nt)
+__global__ __launch_bounds__(64) void k_lattice_resolve(P3 P, const uint32_t *__restrict__ cand, int cand_pitch,
+                                                        int cand_plane_stride, int field)
 {
     const int pl = blockIdx.z;
     const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
     const int lane = threadIdx.x;
-    const int nrows = (height - 1 - (2 - field) + 1) / 2;      // rows y0, y0+2, ... < height-1
+    const int nrows = (height - (2 - field)) / 2;                // rows y0, y0+2, ... < height-1
     uint8_t *dst = P.b[pl];
     if ((int)blockIdx.y >= nrows)
     {
-        if ((int)blockIdx.y == nrows)                          // the one-row blit (:1162-1179)
+        if ((int)blockIdx.y == nrows)                              // the one-row blit (:1162-1179)
             for (int xx = lane; xx < width; xx += 64)
             {
                 if (field == 1) dst[(size_t)(height - 1) * pitch + xx] = dst[(size_t)(height - 2) * pitch + xx];
@@ -468,10 +702,9 @@ __global__ __launch_bounds__(64) void k_lattice(P3 P, int field, int nt4, int nt
         return;
     }
     const int y = (2 - field) + 2 * blockIdx.y;
-    const uint8_t *top = dst + (size_t)(y - 1) * pitch, *bot = top + 2 * (size_t)pitch;
     uint8_t *mid = dst + (size_t)y * pitch;
-    const uint8_t *ot = P.c[pl] + (size_t)(y - 1) * pitch, *ob = ot + 2 * (size_t)pitch;
     uint8_t *dm = P.a[pl] + (size_t)y * pitch;
+    const uint32_t *cr = cand + (size_t)pl * cand_plane_stride + (size_t)blockIdx.y * cand_pitch;
 
     // value standing at dm[x-1] for x == 0: memory just before the row, never written by this pass
     int carry_val = dm[-1];
@@ -479,97 +712,17 @@ __global__ __launch_bounds__(64) void k_lattice(P3 P, int field, int nt4, int nt
     {
         const int x = x0 + lane;
         const bool live = x < width;
-        // ---- both outcomes of this pixel
         int d = 0, lim = 0, valA = 0, newA = 0, valB = 0, newB = 0;
         bool always_a = false, right = false;
         if (live)
         {
+            const uint32_t c = cr[x];
             d = dm[x];
             lim = c_limlut[iabs(d - NEUTRAL) >> 2];
-            const int avg = ((int)top[x] + (int)bot[x] + 1) >> 1;
-            valA = avg;
-            newA = d == PEAK ? PEAK : NEUTRAL;
-            always_a = d == PEAK;
-            right = iabs(d - (int)dm[x + 1]) > lim;
-            if (!always_a)
-            {
-                bool done = false;
-                if (lim < 9)
-                {
-                    const int t0 = top[x - 1], t1 = top[x], t2 = top[x + 1], b0 = bot[x - 1], b1 = bot[x], b2 = bot[x + 1];
-                    const int sum = t0 + t1 + t2 + b0 + b1 + b2;
-                    const int sumsq = t0 * t0 + t1 * t1 + t2 * t2 + b0 * b0 + b1 * b1 + b2 * b2;
-                    if (6 * sumsq - sum * sum < 576) { valB = avg; newB = PEAK; done = true; }
-                }
-                if (!done && x > 1 && x < width - 2)
-                {
-                    const int t = top[x], b = bot[x];
-                    const int tl = max((int)top[x - 2], (int)top[x - 1]), tr = max((int)top[x + 2], (int)top[x + 1]);
-                    const int bl = max((int)bot[x - 2], (int)bot[x - 1]), br = max((int)bot[x + 2], (int)bot[x + 1]);
-                    const int tl2 = min((int)top[x - 2], (int)top[x - 1]), tr2 = min((int)top[x + 2], (int)top[x + 1]);
-                    const int bl2 = min((int)bot[x - 2], (int)bot[x - 1]), br2 = min((int)bot[x + 2], (int)bot[x + 1]);
-                    if ((t < tl - 3 && t < tr - 3 && b < bl - 3 && b < br - 3) ||
-                        (t > tl2 + 3 && t > tr2 + 3 && b > bl2 + 3 && b > br2 + 3))
-                    { valB = avg; newB = NEUTRAL; done = true; }
-                }
-                if (!done)
-                {
-                    int dir = (d - NEUTRAL + 2) >> 2;
-                    int val = avg;
-                    const int startu = (dir - 2 < 0) ? max(-x + 1, max(dir - 2, -width + 2 + x)) : min(x - 1, min(dir - 2, width - 2 - x));
-                    const int stopu = (dir + 2 < 0) ? max(-x + 1, max(dir + 2, -width + 2 + x)) : min(x - 1, min(dir + 2, width - 2 - x));
-                    int mn = nt8;
-#define NEAR(row, i) ((row)[i] != PEAK && iabs((int)(row)[i] - d) <= lim)
-                    for (int u = startu; u <= stopu; u++)
-                    {
-                        const int diff = sad3(top, x, bot, x - u) + sad3(bot, x, top, x + u);
-                        if (!(diff < mn && (NEAR(ot, x - 1 + u) || NEAR(ot, x + u) || NEAR(ot, x + 1 + u)) &&
-                              (NEAR(ob, x - 1 - u) || NEAR(ob, x - u) || NEAR(ob, x + 1 - u))))
-                            continue;
-                        const int h0 = u >> 1, h1 = (u + 1) >> 1;
-                        const int diff2 = sad3(top, x + h0, bot, x - h0);
-                        const int o0 = ot[x + h0], o1 = ot[x + h1], q0 = ob[x - h0], q1 = ob[x - h1];
-                        if (!(diff2 < nt4 && (((iabs(o0 - q0) <= lim || iabs(o0 - q1) <= lim) && o0 != PEAK) ||
-                                              ((iabs(o1 - q0) <= lim || iabs(o1 - q1) <= lim) && o1 != PEAK))))
-                            continue;
-                        if ((iabs(d - o0) <= lim || iabs(d - o1) <= lim) && (iabs(d - q0) <= lim || iabs(d - q1) <= lim))
-                        {
-                            val = ((int)top[x + h0] + (int)top[x + h1] + (int)bot[x - h0] + (int)bot[x - h1] + 2) >> 2;
-                            mn = diff;
-                            dir = u;
-                        }
-                    }
-#undef NEAR
-                    if (mn != nt8)
-                    {
-                        valB = val;
-                        newB = (NEUTRAL + dir * 4) & 0xff;
-                    }
-                    else
-                    {
-                        const int lo = min((int)top[x], (int)bot[x]), hi = max((int)top[x], (int)bot[x]);
-                        const int dd = pl == 0 ? 4 : 2;
-                        const int su = max(-x + 1, -dd), eu = min(width - 2 - x, dd);
-                        mn = nt7;
-                        for (int u = su; u <= eu; u++)
-                        {
-                            const int h0 = u >> 1, h1 = (u + 1) >> 1;
-                            const int p1 = (int)top[x + h0] + (int)top[x + h1];
-                            const int p2 = (int)bot[x - h0] + (int)bot[x - h1];
-                            const int diff = sad3(top, x, bot, x - u) + sad3(bot, x, top, x + u) + iabs(p1 - p2);
-                            if (diff < mn)
-                            {
-                                const int valt = (p1 + p2 + 2) >> 2;
-                                if (valt >= lo && valt <= hi) { val = valt; mn = diff; dir = u; }
-                            }
-                        }
-                        valB = val;
-                        newB = (mn == 7 * nt) ? NEUTRAL : ((NEUTRAL + dir * 4) & 0xff);
-                    }
-                }
-            }
+            valA = c & 0xff; valB = (c >> 8) & 0xff; newB = (c >> 16) & 0xff;
+            always_a = (c >> 24) & 1; right = (c >> 25) & 1;
+            newA = always_a ? PEAK : NEUTRAL;
         }
-        // ---- resolve the left-to-right chain inside the chunk
         // outcome 0 = A, 1 = B.  What this pixel does depends on the value left standing at x-1.
         const int prevA = __shfl_up(newA, 1, 64), prevB = __shfl_up(newB, 1, 64);
         unsigned m;                                            // bit s = outcome when the left pixel took outcome s
@@ -599,7 +752,6 @@ __global__ __launch_bounds__(64) void k_lattice(P3 P, int field, int nt4, int nt
             if (nd != d) dm[x] = (uint8_t)nd;
             carry_val = nd;
         }
-        // value standing at the last pixel of this chunk
         const int last = min(63, width - 1 - x0);
         carry_val = __shfl(carry_val, last, 64);
     }
@@ -637,6 +789,9 @@ Eedi2Engine::~Eedi2Engine()
 {
     for (auto &f : half_) if (f.alloc) (void)hipFree(f.alloc);
     for (auto &f : full_) if (f.alloc) (void)hipFree(f.alloc);
+    if (work_list_) (void)hipFree(work_list_);
+    if (work_count_) (void)hipFree(work_count_);
+    if (cand_) (void)hipFree(cand_);
 }
 
 int Eedi2Engine::alloc_frame(EediFrame &f, int width, int height)
@@ -675,6 +830,15 @@ int Eedi2Engine::init()
         int rc = alloc_frame(f, geo_.width, geo_.height);          // decomb.c:299-303
         if (rc != HBHIP_OK) return rc;
     }
+    // work list of calc_directions (every half-height pixel could qualify) + lattice candidates
+    size_t half_px = 0;
+    for (int c = 0; c < 3; c++) half_px += (size_t)half_[0].stride[c] * half_[0].height[c];
+    HBHIP_CHECK(ctx_, hipMalloc((void **)&work_list_, sizeof(uint32_t) * half_px));
+    HBHIP_CHECK(ctx_, hipMalloc((void **)&work_count_, sizeof(int)));
+    cand_pitch_ = full_[0].stride[0];
+    cand_plane_stride_ = cand_pitch_ * ((full_[0].height[0] + 1) / 2);
+    HBHIP_CHECK(ctx_, hipMalloc((void **)&cand_, sizeof(uint32_t) * (size_t)cand_plane_stride_ * 3));
+    if (geo_.width >= (1 << 14) || geo_.height >= (1 << 14)) return HBHIP_ERR_UNSUPPORTED;
     HBHIP_CHECK(ctx_, hipStreamSynchronize(ctx_->stream));
     return HBHIP_OK;
 }
@@ -720,8 +884,22 @@ int Eedi2Engine::run(const DevPicture *cur, int tff)
     bind(P.a, tmpp); bind(P.b, mskp);
     HBHIP_LAUNCH(ctx_, "eedi2_small_gaps", k_small_gaps, grid_for(srcp, false), blk, 0, P);
     bind(P.a, mskp); bind(P.b, srcp); bind(P.c, tmpp);
-    HBHIP_LAUNCH(ctx_, "eedi2_calc_directions", k_calc_directions, grid_for(srcp, true), blk, 0, P,
-                 par_.maximum_search_distance, (par_.noise_threshold * 13) & 0xff, (par_.noise_threshold * 19) & 0xff);
+    if (par_.maximum_search_distance <= CD_HALO - 2)
+    {
+        HBHIP_LAUNCH(ctx_, "eedi2_calc_directions", k_calc_dir_tile,
+                     dim3((srcp.stride[0] + CD_W - 1) / CD_W, srcp.height[0], 3), dim3(CD_W), 0, P,
+                     par_.maximum_search_distance, (par_.noise_threshold * 13) & 0xff, (par_.noise_threshold * 19) & 0xff);
+    }
+    else
+    {
+        HBHIP_CHECK(ctx_, hipMemsetAsync(work_count_, 0, sizeof(int), ctx_->stream));
+        HBHIP_LAUNCH(ctx_, "eedi2_calc_directions_mark", k_calc_dir_mark, grid_for(srcp, true), blk, 0, P, work_list_, work_count_);
+        size_t half_px = 0;
+        for (int c = 0; c < 3; c++) half_px += (size_t)srcp.width[c] * srcp.height[c];
+        HBHIP_LAUNCH(ctx_, "eedi2_calc_directions_work", k_calc_dir_work, dim3((unsigned)((half_px + 255) / 256)), dim3(256), 0, P,
+                     (const uint32_t *)work_list_, (const int *)work_count_, par_.maximum_search_distance,
+                     (par_.noise_threshold * 13) & 0xff, (par_.noise_threshold * 19) & 0xff);
+    }
     bind(P.a, mskp); bind(P.b, tmpp); bind(P.c, dstp);
     HBHIP_LAUNCH(ctx_, "eedi2_filter_dir_map", k_dir_map, grid_for(srcp, false), blk, 0, P, 1, 1, 0);
     bind(P.a, mskp); bind(P.b, dstp); bind(P.c, tmpp);
@@ -748,10 +926,12 @@ int Eedi2Engine::run(const DevPicture *cur, int tff)
     // lattice
     bind(P.a, tmp2p); bind(P.b, dst2p); bind(P.c, tmp2p2);
     {
-        const int nrows = (dst2p.height[0] - 1 - y0 + 1) / 2;
+        const int nrows = (dst2p.height[0] - y0) / 2;
         const int nt = par_.noise_threshold;
-        HBHIP_LAUNCH(ctx_, "eedi2_interpolate_lattice", k_lattice, dim3(1, nrows + 1, 3), dim3(64), 0, P, tff,
-                     (nt * 4) & 0xff, (nt * 7) & 0xff, (nt * 8) & 0xff, nt);
+        HBHIP_LAUNCH(ctx_, "eedi2_lattice_candidates", k_lattice_cand, dim3((dst2p.width[0] + 63) / 64, (nrows + 3) / 4, 3),
+                     blk, 0, P, cand_, cand_pitch_, cand_plane_stride_, tff, (nt * 4) & 0xff, (nt * 7) & 0xff, (nt * 8) & 0xff, nt);
+        HBHIP_LAUNCH(ctx_, "eedi2_lattice_resolve", k_lattice_resolve, dim3(1, nrows + 1, 3), dim3(64), 0, P,
+                     (const uint32_t *)cand_, cand_pitch_, cand_plane_stride_, tff);
     }
     if (par_.post_processing == 1 || par_.post_processing == 3)
     {

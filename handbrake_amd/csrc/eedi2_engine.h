@@ -47,4 +47,8 @@ private:
     Eedi2Params par_;
     EediFrame   half_[4];    // SRCPF, MSKPF, TMPPF, DSTPF          (decomb.c:64-68)
     EediFrame   full_[5];    // DST2PF, TMP2PF2, MSK2PF, TMP2PF, DST2MPF (decomb.c:69-74)
+    uint32_t   *work_list_ = nullptr;   // calc_directions: compacted edge pixels
+    int        *work_count_ = nullptr;
+    uint32_t   *cand_ = nullptr;        // interpolate_lattice: per-pixel candidate outcomes
+    int         cand_pitch_ = 0, cand_plane_stride_ = 0;
 };

@@ -46,6 +46,7 @@ struct NlmJob
     double         origin_tune;
     float          wft;
     int            diff_max;
+    int            diff_cap;       // FAST gate: smallest diff whose table index is 127 (weight 0)
     int            w, h, dst_pitch;
     int            nframes, r_half;
     int            tiles_x, tile_start;
@@ -99,7 +100,10 @@ __device__ __forceinline__ void load_tile(uint32_t *lds, int dwords, int rows,
 __device__ __forceinline__ uint32_t byte_of(uint32_t v, int k) { return (v >> (8 * k)) & 0xffu; }
 
 // VAR bit 0: software-prefetch the next row's LDS words; bit 1: ask for 3 waves/SIMD.
-template <int N, int VAR>
+// FAST: the gate `diff < diff_max` (nlmeans_template.c:685) is folded into a clamp of diff to
+// diff_cap, the smallest diff whose table index is 127 (= weight 0, nlmeans.c:358); the host
+// only selects it when that is exactly equivalent (diff_cap <= diff_max and index(diff_cap) == 127).
+template <int N, int VAR, bool FAST>
 __global__ __launch_bounds__(TXN * TYN, (VAR & 2) ? 3 : 1) void nlmeans_plane_kernel(const NlmJob *__restrict__ jobs, int njobs,
                                                                   int cmp_dwords, int cmp_rows)
 {
@@ -146,6 +150,7 @@ __global__ __launch_bounds__(TXN * TYN, (VAR & 2) ? 3 : 1) void nlmeans_plane_ke
 
     const float wft = job.wft;
     const int diff_max = job.diff_max;
+    const int diff_cap = job.diff_cap;
     const double origin_tune = job.origin_tune;
 
     for (int f = 0; f < job.nframes; f++)
@@ -287,10 +292,18 @@ __global__ __launch_bounds__(TXN * TYN, (VAR & 2) ? 3 : 1) void nlmeans_plane_ke
 #pragma unroll
                         for (int p = 0; p < PX; p++)
                         {
-                            const int diff = (int)v[p];
-                            int idx = (int)((float)diff * wft);
-                            idx = diff < diff_max ? idx : 127;
-                            idx = min(idx, 127);
+                            int idx;
+                            if (FAST)
+                            {
+                                idx = (int)((float)(int)min(v[p], (uint32_t)diff_cap) * wft);
+                            }
+                            else
+                            {
+                                const int diff = (int)v[p];
+                                idx = (int)((float)diff * wft);
+                                idx = diff < diff_max ? idx : 127;
+                                idx = min(idx, 127);
+                            }
                             const float wgt = s_exp[idx];
                             const float pv = (float)(int)byte_of(pix, p);
                             aw[o][p] += wgt;
@@ -380,6 +393,21 @@ public:
             if (in_geo.pw[c] < NLM_BORDER || in_geo.ph[c] < NLM_BORDER) return HBHIP_ERR_UNSUPPORTED;
         }
         if (const char *e = getenv("HBHIP_NLM_VARIANT")) variant = atoi(e);
+        for (int c = 0; c < 3; c++)
+        {
+            // smallest diff whose index reaches 127; usable only if that index is exactly 127,
+            // it does not exceed diff_max, and the table really ends in 0
+            diff_cap[c] = -1;
+            const float wft = par.weight_fact_table[c];
+            if (par.strength[c] == 0 || par.exptable[c][127] != 0.f || !(wft > 0.f)) continue;
+            for (int d = 0; d <= par.diff_max[c]; d++)
+                if ((int)((float)d * wft) >= 127)
+                {
+                    if ((int)((float)d * wft) == 127) diff_cap[c] = d;
+                    break;
+                }
+            if (getenv("HBHIP_NLM_NOFAST")) diff_cap[c] = -1;
+        }
         HBHIP_CHECK(ctx, hipMalloc((void **)&d_exp, sizeof(float) * 3 * 128));
         HBHIP_CHECK(ctx, hipMemcpyAsync(d_exp, par.exptable, sizeof(float) * 3 * 128,
                                         hipMemcpyHostToDevice, ctx->stream));
@@ -409,6 +437,7 @@ public:
 
     int batch = 1;
     int variant = 3;
+    int diff_cap[3] = {-1, -1, -1};
 
 private:
     int ensure_jobs(int n)
@@ -464,6 +493,7 @@ private:
             NlmJob *hj = h_jobs + (size_t)table * jobs_cap;
             NlmJob *dj = d_jobs + (size_t)table * jobs_cap;
             int nj = 0, tiles = 0, max_rh = 0;
+            bool fast = true;
             for (int t = 0; t < ready; t++)
                 for (int c = 0; c < 3; c++)
                 {
@@ -480,6 +510,8 @@ private:
                     jb.origin_tune = par.origin_tune[c];
                     jb.wft = par.weight_fact_table[c];
                     jb.diff_max = par.diff_max[c];
+                    jb.diff_cap = diff_cap[c];
+                    fast &= diff_cap[c] >= 0;
                     jb.w = in_geo.pw[c];
                     jb.h = in_geo.ph[c];
                     jb.dst_pitch = outs[t].pitch[c];
@@ -498,9 +530,9 @@ private:
             const int cmp_rows = TH + 2 * (nh + max_rh);
             const size_t shmem = sizeof(uint32_t) * ((TXN + ND) * (TH + 2 * nh) + cmp_dwords * cmp_rows) + 512;
             dim3 grid(tiles), block(TXN * TYN);
-#define NLM_GO(NN, VV) HBHIP_LAUNCH(ctx, "nlmeans_plane_n" #NN, (nlmeans_plane_kernel<NN, VV>), grid, block, shmem, dj, nj, cmp_dwords, cmp_rows)
-#define NLM_VAR(NN) do { switch (variant) { case 0: NLM_GO(NN, 0); break; case 1: NLM_GO(NN, 1); break; \
-                                            case 2: NLM_GO(NN, 2); break; default: NLM_GO(NN, 3); break; } } while (0)
+#define NLM_GO(NN, VV, FF) HBHIP_LAUNCH(ctx, "nlmeans_plane_n" #NN, (nlmeans_plane_kernel<NN, VV, FF>), grid, block, shmem, dj, nj, cmp_dwords, cmp_rows)
+#define NLM_VAR(NN) do { if (variant == 0) { if (fast) NLM_GO(NN, 0, true); else NLM_GO(NN, 0, false); } \
+                         else { if (fast) NLM_GO(NN, 3, true); else NLM_GO(NN, 3, false); } } while (0)
             switch (n)
             {
                 case 3: NLM_VAR(3); break;

@@ -306,3 +306,41 @@ class DecombDevice:
         if self.h:
             lib().hbhip_filter_destroy(self.h)
             self.h = None
+
+
+class LapsharpParams(C.Structure):
+    _fields_ = [("strength", C.c_double * 3), ("kernel", C.c_int * 3)]
+
+
+class CropScaleParams(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("width", "height", "crop_top", "crop_bottom", "crop_left", "crop_right")]
+
+
+def _create(fn_name, ctx, argtypes, *args):
+    L = lib()
+    fn = getattr(L, fn_name)
+    fn.argtypes = argtypes
+    h = C.c_void_p()
+    check(fn(*args, C.byref(h)), ctx.h, fn_name)
+    return DeviceFilter(ctx, h)
+
+
+def lapsharp_device_filter(ctx, width, height, strength=0.2, kernel=1):
+    """lapsharp 'medium' = strength 0.2, isolap (param.c:932-935)."""
+    p = LapsharpParams((C.c_double * 3)(strength, strength, strength), (C.c_int * 3)(kernel, kernel, kernel))
+    return _create("hbhip_lapsharp_create", ctx,
+                   [C.c_void_p, C.POINTER(LapsharpParams)] + [C.c_int] * 5 + [C.POINTER(C.c_void_p)],
+                   ctx.h, C.byref(p), width, height, 8, 1, 1)
+
+
+def cropscale_device_filter(ctx, width, height, out_w, out_h, crop=(0, 0, 0, 0)):
+    p = CropScaleParams(out_w, out_h, *crop)
+    return _create("hbhip_cropscale_create", ctx,
+                   [C.c_void_p, C.POINTER(CropScaleParams)] + [C.c_int] * 5 + [C.POINTER(C.c_void_p)],
+                   ctx.h, C.byref(p), width, height, 8, 1, 1)
+
+
+def decomb_push_dev(flt, frame: DevFrame, tag: int, flags: int = 0x0008, combed: int = 2):
+    L = lib()
+    L.hbhip_decomb_push_dev.argtypes = [C.c_void_p, C.POINTER(DevFrame), C.c_int64, C.c_int, C.c_int]
+    check(L.hbhip_decomb_push_dev(flt.h, C.byref(frame), tag, flags, combed), flt.ctx.h, "decomb_push_dev")
