@@ -93,13 +93,16 @@ __device__ __forceinline__ int collect3(int *v, int k, const uint8_t *row, int x
     (void)width; (void)height; (void)pitch
 
 // a = source plane (device pitch in `spitch`), b = srcp
+// The reference copies min(src_pitch, dst_pitch) bytes per row, i.e. it drags the source
+// buffer's row padding along (undefined bytes in libhb, zeros in the calloc'ing test runtime).
+// Device-resident frames have no such padding, so bytes at x >= width are written as 0.
 __global__ void k_fill_half(P3 P, int spitch0, int spitch1, int spitch2, int start_line, int rows0, int rows1, int rows2)
 {
     XY_PLANE(P);
     const int spitch = pl == 0 ? spitch0 : pl == 1 ? spitch1 : spitch2;
     const int rows = pl == 0 ? rows0 : pl == 1 ? rows1 : rows2;
     if (x >= pitch || y >= rows) return;
-    P.b[pl][(size_t)y * pitch + x] = P.a[pl][(size_t)(start_line + 2 * y) * spitch + x];
+    P.b[pl][(size_t)y * pitch + x] = x < width ? P.a[pl][(size_t)(start_line + 2 * y) * spitch + x] : 0;
 }
 
 // a = srcp, b = mskp (in place: upper half cleared, lower half keeps its old content)

@@ -288,6 +288,11 @@ void hbhip_ctx_destroy(hbhip_ctx *ctx)
         if (p.ev0) (void)hipEventDestroy(p.ev0);
         if (p.ev1) (void)hipEventDestroy(p.ev1);
     }
+    for (hbhip_frame *fr : ctx->frame_pool)
+    {
+        if (fr->pic.base) (void)hipFree(fr->pic.base);
+        delete fr;
+    }
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     for (int i = 0; i < HBHIP_MAX_MARKS; i++)
         if (ctx->marks[i]) (void)hipEventDestroy(ctx->marks[i]);
@@ -400,6 +405,104 @@ int hbhip_dev_download(hbhip_ctx *ctx, void *dst, const void *src, size_t bytes)
     return HBHIP_OK;
 }
 
+// ---- device-resident frames -----------------------------------------------------
+int hbhip_frame_alloc(hbhip_ctx *ctx, int width, int height, int depth, int lcw, int lch, hbhip_frame **out)
+{
+    if (!ctx || !out || width < 1 || height < 1) return HBHIP_ERR_ARG;
+    *out = nullptr;
+    (void)hipSetDevice(ctx->device);
+    std::unique_lock<std::mutex> lk(ctx->frame_lock);
+    for (size_t i = 0; i < ctx->frame_pool.size(); i++)
+    {
+        hbhip_frame *fr = ctx->frame_pool[i];
+        if (fr->width == width && fr->height == height && fr->depth == depth && fr->lcw == lcw && fr->lch == lch)
+        {
+            ctx->frame_pool.erase(ctx->frame_pool.begin() + i);
+            fr->refs = 1;
+            *out = fr;
+            return HBHIP_OK;
+        }
+    }
+    lk.unlock();
+    hbhip_frame *fr = new (std::nothrow) hbhip_frame();
+    if (!fr) return HBHIP_ERR_NOMEM;
+    fr->ctx = ctx; fr->width = width; fr->height = height; fr->depth = depth; fr->lcw = lcw; fr->lch = lch;
+    PicGeometry g;
+    g.set(width, height, depth, lcw, lch);
+    size_t off[3], total = 0;
+    for (int c = 0; c < 3; c++)
+    {
+        fr->pic.width[c] = g.pw[c];
+        fr->pic.height[c] = g.ph[c];
+        fr->pic.pitch[c] = hbhip_align_up(g.pw[c] * g.bps, 256);
+        off[c] = total;
+        total += (size_t)fr->pic.pitch[c] * g.ph[c];
+        total = (total + 255) & ~(size_t)255;
+    }
+    fr->pic.bps = g.bps;
+    fr->pic.bytes = total;
+    if (hipMalloc((void **)&fr->pic.base, total) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        delete fr;
+        return HBHIP_ERR_NOMEM;
+    }
+    (void)hipMemsetAsync(fr->pic.base, 0, total, ctx->stream);
+    for (int c = 0; c < 3; c++) fr->pic.plane[c] = fr->pic.base + off[c];
+    *out = fr;
+    return HBHIP_OK;
+}
+
+void hbhip_frame_retain(hbhip_frame *fr)
+{
+    if (!fr) return;
+    std::lock_guard<std::mutex> lk(fr->ctx->frame_lock);
+    fr->refs++;
+}
+
+void hbhip_frame_release(hbhip_frame *fr)
+{
+    if (!fr) return;
+    std::lock_guard<std::mutex> lk(fr->ctx->frame_lock);
+    if (--fr->refs > 0) return;
+    fr->ctx->frame_pool.push_back(fr);        // reuse is stream-ordered (one stream per context)
+}
+
+int hbhip_frame_describe(hbhip_frame *fr, hbhip_dev_frame *out, int *width, int *height)
+{
+    if (!fr || !out) return HBHIP_ERR_ARG;
+    for (int c = 0; c < 3; c++)
+    {
+        out->plane[c] = fr->pic.plane[c];
+        out->stride[c] = fr->pic.pitch[c];
+    }
+    if (width) *width = fr->width;
+    if (height) *height = fr->height;
+    return HBHIP_OK;
+}
+
+int hbhip_frame_upload(hbhip_frame *fr, const hbhip_host_frame *src)
+{
+    if (!fr || !src) return HBHIP_ERR_ARG;
+    (void)hipSetDevice(fr->ctx->device);
+    int rc = hbhip_copy_h2d(fr->ctx, &fr->pic, src);
+    if (rc != HBHIP_OK) return rc;
+    if (hipStreamSynchronize(fr->ctx->stream) != hipSuccess)
+        return fr->ctx->fail(hipGetLastError(), "hipStreamSynchronize(frame_upload)");
+    return HBHIP_OK;
+}
+
+int hbhip_frame_download(hbhip_frame *fr, const hbhip_host_frame *dst)
+{
+    if (!fr || !dst) return HBHIP_ERR_ARG;
+    (void)hipSetDevice(fr->ctx->device);
+    int rc = hbhip_copy_d2h(fr->ctx, dst, &fr->pic);
+    if (rc != HBHIP_OK) return rc;
+    if (hipStreamSynchronize(fr->ctx->stream) != hipSuccess)
+        return fr->ctx->fail(hipGetLastError(), "hipStreamSynchronize(frame_download)");
+    return HBHIP_OK;
+}
+
 // ---- generic filter surface -------------------------------------------------
 int hbhip_filter_push(hbhip_filter *f, const hbhip_host_frame *in, int64_t tag)
 {
@@ -409,6 +512,7 @@ int hbhip_filter_push(hbhip_filter *f, const hbhip_host_frame *in, int64_t tag)
     if (!pic) return HBHIP_ERR_NOMEM;
     pic->tag = tag;
     for (int c = 0; c < 3; c++) f->in_stride[c] = in->stride[c];
+    f->in_is_dev = false;
     int rc = hbhip_copy_h2d(f->ctx, pic, in);
     if (rc != HBHIP_OK) return rc;
     // The caller may free or reuse its (pageable) planes as soon as we return
@@ -427,6 +531,7 @@ int hbhip_filter_push_dev(hbhip_filter *f, const hbhip_dev_frame *in, int64_t ta
     if (!pic) return HBHIP_ERR_NOMEM;
     pic->tag = tag;
     for (int c = 0; c < 3; c++) f->in_stride[c] = in->stride[c];
+    f->in_is_dev = true;
     int rc = hbhip_copy_d2d_in(f->ctx, pic, in);
     if (rc != HBHIP_OK) return rc;
     return f->submit(pic);

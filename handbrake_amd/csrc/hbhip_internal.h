@@ -9,6 +9,7 @@
 #include <cstring>
 #include <deque>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -42,6 +43,10 @@ struct hbhip_ctx
     std::vector<hbhip_prof_pending> prof_pending;
     std::vector<hipEvent_t>         ev_pool;
     hipEvent_t                      marks[HBHIP_MAX_MARKS] = {};
+
+    // pool of device-resident frames handed between filters (hbhip_frame_*)
+    std::vector<struct hbhip_frame *> frame_pool;
+    std::mutex frame_lock;          // filters of one job run on different host threads
 
     int  fail(hipError_t e, const char *what);
     int  prof_name(const char *name);
@@ -83,6 +88,15 @@ struct DevPicture
     int      flags = 0;      // PIC_FLAG_* of the source buffer (decomb / comb detect)
     int      combed = 0;     // HB_COMB_* of the source buffer
     int      aux = 0;        // filter specific (decomb: which field of a bob pair)
+};
+
+// A reference-counted device picture that travels between filters inside an hb_buffer_t.
+struct hbhip_frame
+{
+    hbhip_ctx  *ctx = nullptr;
+    DevPicture  pic;
+    int         width = 0, height = 0, depth = 8, lcw = 1, lch = 1;
+    int         refs = 1;
 };
 
 // Geometry of a planar YUV picture.
@@ -135,6 +149,7 @@ struct hbhip_filter
     // byte stride the CALLER's planes had at the last push (some reference
     // filters derive an edge rule from it, e.g. lapsharp.c:145)
     int         in_stride[3] = {0, 0, 0};
+    bool        in_is_dev = false;      // last push came from a device-resident frame
     explicit hbhip_filter(hbhip_ctx *c) : ctx(c) {}
     virtual ~hbhip_filter() {}
 

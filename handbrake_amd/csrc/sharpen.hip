@@ -29,6 +29,7 @@ struct LapArgs
     uint8_t       *dst;
     int            width, height, src_pitch, dst_pitch;
     int            stride_border;     // (caller stride - width) / 2, lapsharp.c:145
+    int            valid_w;           // bytes at x >= valid_w read as 0 (device-resident input has no row padding)
     int            tap[25];
     double         coef, strength;
 };
@@ -60,6 +61,18 @@ __global__ __launch_bounds__(256) void lapsharp_kernel(LapArgs a)
         rows[j][0] = r[max(xd - 1, 0)];
         rows[j][1] = r[xd];
         rows[j][2] = r[min(xd + 1, pitch_dw - 1)];
+        if (x0 + 8 > a.valid_w)
+        {
+            // keep bytes [x0-4, x0+8) that lie below valid_w
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+            {
+                const int base = x0 - 4 + 4 * k;
+                const int keep = a.valid_w - base;            // number of valid low bytes in this dword
+                if (keep <= 0) rows[j][k] = 0;
+                else if (keep < 4) rows[j][k] &= (1u << (8 * keep)) - 1u;
+            }
+        }
     }
 
     uint32_t packed = 0;
@@ -197,7 +210,11 @@ public:
             a.src = in->plane[c]; a.dst = out->plane[c];
             a.width = in->width[c]; a.height = in->height[c];
             a.src_pitch = in->pitch[c]; a.dst_pitch = out->pitch[c];
-            a.stride_border = (in_stride[c] - in->width[c]) / 2;
+            // host buffers: the caller's stride decides (lapsharp.c:145); device-resident frames have no
+            // hb_buffer stride, so use what hb_image_stride would be and read the padding as zeros
+            const int hb_stride = in_is_dev ? hbhip_align_up(in->width[c], 64) : in_stride[c];
+            a.stride_border = (hb_stride - in->width[c]) / 2;
+            a.valid_w = in_is_dev ? in->width[c] : (1 << 30);
             for (int i = 0; i < 25; i++) a.tap[i] = k.tap[i];
             a.coef = k.coef; a.strength = par.strength[c];
             dim3 grid(((a.width + 3) / 4 + 255) / 256, a.height), block(256);

@@ -20,6 +20,7 @@ struct hb_filter_private_s
     hbhip_filter    *dev;
     hb_filter_init_t input;
     hb_filter_init_t output;
+    int              dev_io;
 };
 
 static void alias_hip_close(hb_filter_object_t *filter)
@@ -34,7 +35,7 @@ static void alias_hip_close(hb_filter_object_t *filter)
 static int alias_hip_work(hb_filter_object_t *filter, hb_buffer_t **buf_in, hb_buffer_t **buf_out)
 {
     hb_filter_private_t *pv = filter->private_data;
-    return hbhip_host_simple_work(pv->dev, &pv->output, filter->short_name, buf_in, buf_out);
+    return hbhip_host_simple_work(pv->dev, &pv->output, filter->short_name, pv->dev_io, buf_in, buf_out);
 }
 
 static hb_filter_private_t *alias_begin(hb_filter_object_t *filter, hb_filter_init_t *init,
@@ -44,6 +45,7 @@ static hb_filter_private_t *alias_begin(hb_filter_object_t *filter, hb_filter_in
     filter->private_data = pv;
     if (pv == NULL) return NULL;
     pv->input = *init;
+    pv->dev_io = hbhip_host_dev_io(init);
     *desc = av_pix_fmt_desc_get(init->pix_fmt);
     if (*desc == NULL)
     {

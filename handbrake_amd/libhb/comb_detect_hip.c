@@ -124,8 +124,18 @@ static int store_ref(hb_filter_private_t *pv, hb_buffer_t *b, int repeat)
     memmove(&pv->ref_used[0], &pv->ref_used[1], sizeof(pv->ref_used[0]) * 2);
     pv->ref[2] = b;
     pv->ref_used[2] = 0;
-    int rc = repeat ? hbhip_comb_detect_store(pv->dev, NULL, 0)
-                    : hbhip_comb_detect_store(pv->dev, b->plane[0].data, b->plane[0].stride);
+    int rc;
+    hbhip_frame *fr = hbhip_host_frame_of(b);
+    if (repeat)
+        rc = hbhip_comb_detect_store(pv->dev, NULL, 0);
+    else if (fr != NULL)
+    {
+        hbhip_dev_frame d;
+        hbhip_frame_describe(fr, &d, NULL, NULL);
+        rc = hbhip_comb_detect_store_dev(pv->dev, d.plane[0], d.stride[0]);
+    }
+    else
+        rc = hbhip_comb_detect_store(pv->dev, b->plane[0].data, b->plane[0].stride);
     if (rc != HBHIP_OK)
         hb_error("comb_detect(hip): store: %s", hbhip_strerror(rc));
     return rc;

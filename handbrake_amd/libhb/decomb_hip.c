@@ -17,6 +17,7 @@ struct hb_filter_private_s
     hb_buffer_list_t    props;       /* per queued input frame: its `s` */
     int64_t             next_tag;
     int                 ready;
+    int                 dev_io;
     hb_filter_init_t    input;
     hb_filter_init_t    output;
 };
@@ -54,6 +55,7 @@ static int decomb_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init)
     if (pv == NULL) return -1;
     filter->private_data = pv;
     pv->input = *init;
+    pv->dev_io = hbhip_host_dev_io(init);
     hb_buffer_list_clear(&pv->props);
 
     const AVPixFmtDescriptor *desc = av_pix_fmt_desc_get(init->pix_fmt);
@@ -124,17 +126,12 @@ static int decomb_hip_collect(hb_filter_private_t *pv, hb_buffer_list_t *list)
     hb_buffer_t *props = hb_buffer_list_rem_head(&pv->props);
     while (hbhip_filter_pending(pv->dev) > 0)
     {
-        hb_buffer_t *out = hbhip_host_alloc_out(&pv->output, pv->input.geometry.width,
-                                                pv->input.geometry.height);
-        if (out == NULL) { hb_buffer_close(&props); return -1; }
-        hbhip_host_frame hf;
-        hbhip_host_frame_from_buf(&hf, out);
-        int64_t tag;
-        int rc = hbhip_filter_pull(pv->dev, &hf, &tag);
-        if (rc != HBHIP_OK)
+        int64_t tag = 0;
+        hb_buffer_t *out = hbhip_host_pull(pv->dev, &pv->output, pv->input.geometry.width,
+                                           pv->input.geometry.height, pv->dev_io, &tag);
+        if (out == NULL)
         {
-            hb_error("decomb(hip): pull: %s", hbhip_strerror(rc));
-            hb_buffer_close(&out);
+            hb_error("decomb(hip): pull failed");
             hb_buffer_close(&props);
             return -1;
         }
@@ -174,9 +171,20 @@ static int decomb_hip_work(hb_filter_object_t *filter, hb_buffer_t **buf_in, hb_
         return HB_FILTER_DONE;
     }
 
-    hbhip_host_frame hf;
-    hbhip_host_frame_from_buf(&hf, in);
-    int rc = hbhip_decomb_push(pv->dev, &hf, pv->next_tag++, in->s.flags, in->s.combed);
+    int rc;
+    hbhip_frame *fr = hbhip_host_frame_of(in);
+    if (fr != NULL)
+    {
+        hbhip_dev_frame d;
+        hbhip_frame_describe(fr, &d, NULL, NULL);
+        rc = hbhip_decomb_push_dev(pv->dev, &d, pv->next_tag++, in->s.flags, in->s.combed);
+    }
+    else
+    {
+        hbhip_host_frame hf;
+        hbhip_host_frame_from_buf(&hf, in);
+        rc = hbhip_decomb_push(pv->dev, &hf, pv->next_tag++, in->s.flags, in->s.combed);
+    }
     if (rc != HBHIP_OK)
     {
         hb_error("decomb(hip): push: %s", hbhip_strerror(rc));

@@ -13,6 +13,7 @@ struct hb_filter_private_s
     hbhip_filter       *dev;
     hb_filter_init_t    input;
     hb_filter_init_t    output;
+    int                 dev_io;
 };
 
 static int  denoise_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init);
@@ -57,6 +58,7 @@ static int denoise_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init)
     if (pv == NULL) return -1;
     filter->private_data = pv;
     pv->input = *init;
+    pv->dev_io = hbhip_host_dev_io(init);
 
     const AVPixFmtDescriptor *desc = av_pix_fmt_desc_get(init->pix_fmt);
     if (desc == NULL || desc->comp[0].depth != 8) goto fail;
@@ -104,5 +106,5 @@ static void denoise_hip_close(hb_filter_object_t *filter)
 static int denoise_hip_work(hb_filter_object_t *filter, hb_buffer_t **buf_in, hb_buffer_t **buf_out)
 {
     hb_filter_private_t *pv = filter->private_data;
-    return hbhip_host_simple_work(pv->dev, &pv->output, "hqdn3d", buf_in, buf_out);
+    return hbhip_host_simple_work(pv->dev, &pv->output, "hqdn3d", pv->dev_io, buf_in, buf_out);
 }

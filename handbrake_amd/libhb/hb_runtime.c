@@ -419,6 +419,18 @@ void hb_frame_buffer_mirror_stride(hb_buffer_t *buf)
     }
 }
 
+/* Device-resident buffers (storage_type HBHIP_DEVICE): the runtime does not know the
+ * device library; it is told how to drop / share a storage handle.  Inside libhb this is
+ * one more case in fifo.c's free_buffer_resources / hb_buffer_shallow_dup, next to COREMEDIA. */
+static void (*g_storage_release)(void *) = NULL;
+static void (*g_storage_retain)(void *) = NULL;
+
+void hbhip_rt_set_storage_hooks(void (*retain)(void *), void (*release)(void *))
+{
+    g_storage_retain = retain;
+    g_storage_release = release;
+}
+
 void hb_buffer_close(hb_buffer_t **pb)
 {
     if (pb == NULL) return;
@@ -426,6 +438,8 @@ void hb_buffer_close(hb_buffer_t **pb)
     while (b)
     {
         hb_buffer_t *next = b->next;
+        if (b->storage_type == HBHIP_DEVICE && b->storage && g_storage_release)
+            g_storage_release(b->storage);
         if (b->data && b->storage_type == STANDARD)
             free(b->data);
         free(b);
@@ -453,6 +467,19 @@ int hb_buffer_copy(hb_buffer_t *dst, const hb_buffer_t *src)
 hb_buffer_t *hb_buffer_dup(const hb_buffer_t *src)
 {
     if (src == NULL) return NULL;
+    if (src->storage_type == HBHIP_DEVICE)
+    {
+        /* share the device picture, like av_frame_ref in the reference's AVFRAME case (fifo.c:668-714) */
+        hb_buffer_t *b = hb_buffer_init(0);
+        if (b == NULL) return NULL;
+        b->s = src->s;
+        b->f = src->f;
+        memcpy(b->plane, src->plane, sizeof(b->plane));
+        b->storage = src->storage;
+        b->storage_type = HBHIP_DEVICE;
+        if (g_storage_retain) g_storage_retain(b->storage);
+        return b;
+    }
     hb_buffer_t *b = hb_buffer_init(src->size);
     if (b == NULL) return NULL;
     if (src->size) memcpy(b->data, src->data, src->size);

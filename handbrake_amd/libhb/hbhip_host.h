@@ -39,12 +39,36 @@ static inline hb_buffer_t *hbhip_host_alloc_out(const hb_filter_init_t *o, int w
     return out;
 }
 
+/* ---- device-resident hand-off -------------------------------------
+ * Between hb_filter_hip_upload and hb_filter_hip_download the chain's frames stay in HBM:
+ * init->hw_pix_fmt is set to AV_PIX_FMT_HBHIP by the upload adapter (as the reference's
+ * VideoToolbox path sets hw_pix_fmt for its Metal filters), every HIP filter that sees it
+ * takes and produces hb_buffer_t whose storage_type is HBHIP_DEVICE and whose `storage` is
+ * an hbhip_frame*, and the download adapter restores host buffers. */
+#define AV_PIX_FMT_HBHIP 0x48495001
+static inline int hbhip_host_dev_io(const hb_filter_init_t *init) { return init->hw_pix_fmt == AV_PIX_FMT_HBHIP; }
+static inline hbhip_frame *hbhip_host_frame_of(const hb_buffer_t *b)
+{
+    return b->storage_type == HBHIP_DEVICE ? (hbhip_frame *)b->storage : NULL;
+}
+/* hb_buffer_t shell around a device frame (takes over the caller's reference). */
+hb_buffer_t *hbhip_host_wrap_frame(hbhip_frame *fr, const hb_filter_init_t *o, int width, int height);
+/* Feed `in` (host planes or device frame) to a device filter. */
+int hbhip_host_push(hbhip_filter *dev, const hb_buffer_t *in, int64_t tag);
+/* Next finished frame of a device filter as a fresh buffer: device-resident when dev_io,
+ * else hb_frame_buffer_init() + download.  NULL on error. */
+hb_buffer_t *hbhip_host_pull(hbhip_filter *dev, const hb_filter_init_t *o, int width, int height,
+                             int dev_io, int64_t *tag);
+
+extern hb_filter_object_t hb_filter_hip_upload;
+extern hb_filter_object_t hb_filter_hip_download;
+
 /* Shared body of the stateless (one in, one out) HIP filters: EOF is forwarded
  * (e.g. lapsharp.c:326-331), otherwise the frame goes through the device filter
  * and comes back in a fresh hb_frame_buffer_init() buffer carrying the input's
  * properties (lapsharp.c:334-353). */
 int hbhip_host_simple_work(hbhip_filter *dev, const hb_filter_init_t *output, const char *who,
-                           hb_buffer_t **buf_in, hb_buffer_t **buf_out);
+                           int dev_io, hb_buffer_t **buf_in, hb_buffer_t **buf_out);
 
 /* The HIP drop-ins registered by this library (ids = the CPU filters' ids,
  * SURVEY Appendix D). */

@@ -69,7 +69,9 @@ hb_filter_object_t *hbhip_filter_get(int filter_id)
         case HB_FILTER_ROTATE:        return &hb_filter_rotate_hip;
         case HB_FILTER_DECOMB:        return &hb_filter_decomb_hip;
         case HB_FILTER_COMB_DETECT:   return &hb_filter_comb_detect_hip;
-        default:                return NULL;
+        case HB_FILTER_HIP_UPLOAD:    return &hb_filter_hip_upload;
+        case HB_FILTER_HIP_DOWNLOAD:  return &hb_filter_hip_download;
+        default:                      return NULL;
     }
 }
 
@@ -79,8 +81,104 @@ void *hbhip_host_ctx_ptr(void)
     return hbhip_host_ctx();
 }
 
+/* ---- device-resident buffers ----------------------------------------------------------- */
+static void storage_retain(void *p)  { hbhip_frame_retain((hbhip_frame *)p); }
+static void storage_release(void *p) { hbhip_frame_release((hbhip_frame *)p); }
+
+__attribute__((constructor)) static void hbhip_host_register_hooks(void)
+{
+#ifndef HBHIP_IN_LIBHB
+    hbhip_rt_set_storage_hooks(storage_retain, storage_release);
+#endif
+}
+
+hb_buffer_t *hbhip_host_wrap_frame(hbhip_frame *fr, const hb_filter_init_t *o, int width, int height)
+{
+    hb_buffer_t *b = hb_buffer_init(0);
+    if (b == NULL)
+    {
+        hbhip_frame_release(fr);
+        return NULL;
+    }
+    const AVPixFmtDescriptor *desc = av_pix_fmt_desc_get(o->pix_fmt);
+    b->s.type = FRAME_BUF;
+    b->f.fmt = o->pix_fmt;
+    b->f.width = width;
+    b->f.height = height;
+    b->f.max_plane = 2;
+    b->f.color_prim = o->color_prim;
+    b->f.color_transfer = o->color_transfer;
+    b->f.color_matrix = o->color_matrix;
+    b->f.color_range = o->color_range;
+    b->f.chroma_location = o->chroma_location;
+    hbhip_dev_frame d;
+    hbhip_frame_describe(fr, &d, NULL, NULL);
+    for (int p = 0; p < 3; p++)
+    {
+        b->plane[p].data = NULL;                       /* not host-addressable */
+        b->plane[p].stride = d.stride[p];
+        b->plane[p].width = hb_image_width(o->pix_fmt, width, p);
+        b->plane[p].height = hb_image_height(o->pix_fmt, height, p);
+        b->plane[p].size = 0;
+    }
+    (void)desc;
+    b->storage = fr;
+    b->storage_type = HBHIP_DEVICE;
+    return b;
+}
+
+int hbhip_host_push(hbhip_filter *dev, const hb_buffer_t *in, int64_t tag)
+{
+    hbhip_frame *fr = hbhip_host_frame_of(in);
+    if (fr != NULL)
+    {
+        hbhip_dev_frame d;
+        hbhip_frame_describe(fr, &d, NULL, NULL);
+        return hbhip_filter_push_dev(dev, &d, tag);
+    }
+    hbhip_host_frame hf;
+    hbhip_host_frame_from_buf(&hf, in);
+    return hbhip_filter_push(dev, &hf, tag);
+}
+
+hb_buffer_t *hbhip_host_pull(hbhip_filter *dev, const hb_filter_init_t *o, int width, int height,
+                             int dev_io, int64_t *tag)
+{
+    int64_t t = 0;
+    if (dev_io)
+    {
+        const AVPixFmtDescriptor *desc = av_pix_fmt_desc_get(o->pix_fmt);
+        hbhip_frame *fr = NULL;
+        if (desc == NULL ||
+            hbhip_frame_alloc(hbhip_host_ctx(), width, height, desc->comp[0].depth,
+                              desc->log2_chroma_w, desc->log2_chroma_h, &fr) != HBHIP_OK)
+            return NULL;
+        hbhip_host_ctx_release();
+        hbhip_dev_frame d;
+        hbhip_frame_describe(fr, &d, NULL, NULL);
+        if (hbhip_filter_pull_dev(dev, &d, &t) != HBHIP_OK)
+        {
+            hbhip_frame_release(fr);
+            return NULL;
+        }
+        if (tag) *tag = t;
+        return hbhip_host_wrap_frame(fr, o, width, height);
+    }
+    hb_buffer_t *out = hbhip_host_alloc_out(o, width, height);
+    if (out == NULL) return NULL;
+    hbhip_host_frame hf;
+    hbhip_host_frame_from_buf(&hf, out);
+    if (hbhip_filter_pull(dev, &hf, &t) != HBHIP_OK)
+    {
+        hb_buffer_close(&out);
+        return NULL;
+    }
+    if (tag) *tag = t;
+    return out;
+}
+
 int hbhip_host_simple_work(hbhip_filter *dev, const hb_filter_init_t *output, const char *who,
-                           hb_buffer_t **buf_in, hb_buffer_t **buf_out)
+                           int dev_io, hb_buffer_t **buf_in, hb_buffer_t **buf_out)
 {
     hb_buffer_t *in = *buf_in;
     if (in->s.flags & HB_BUF_FLAG_EOF)
@@ -91,20 +189,101 @@ int hbhip_host_simple_work(hbhip_filter *dev, const hb_filter_init_t *output, co
     }
     int ow = in->f.width, oh = in->f.height;
     hbhip_filter_out_geometry(dev, &ow, &oh);
-    hb_buffer_t *out = hbhip_host_alloc_out(output, ow, oh);
+    int rc = hbhip_host_push(dev, in, 0);
+    hb_buffer_t *out = rc == HBHIP_OK ? hbhip_host_pull(dev, output, ow, oh, dev_io, NULL) : NULL;
     if (out == NULL)
-        return HB_FILTER_FAILED;
-
-    hbhip_host_frame fin, fout;
-    hbhip_host_frame_from_buf(&fin, in);
-    hbhip_host_frame_from_buf(&fout, out);
-    int64_t tag;
-    int rc = hbhip_filter_push(dev, &fin, 0);
-    if (rc == HBHIP_OK)
-        rc = hbhip_filter_pull(dev, &fout, &tag);
-    if (rc != HBHIP_OK)
     {
-        hb_error("%s(hip): %s", who, hbhip_strerror(rc));
+        hb_error("%s(hip): push/pull failed (%s)", who, hbhip_strerror(rc));
+        return HB_FILTER_FAILED;
+    }
+    hb_buffer_copy_props(out, in);
+    *buf_out = out;
+    return HB_FILTER_OK;
+}
+
+/* ---- adapters: host <-> device at the ends of a run of HIP filters ----------------------
+ * (the reference's analogue is HB_FILTER_ADAPTER_VT, platform/macosx/adapter_vt.c) */
+struct hb_filter_private_s
+{
+    hb_filter_init_t input;
+    hb_filter_init_t output;
+    int              depth, lcw, lch;
+};
+
+static int adapter_init(hb_filter_object_t *filter, hb_filter_init_t *init, int to_device)
+{
+    hb_filter_private_t *pv = calloc(1, sizeof(*pv));
+    if (pv == NULL) return 1;
+    const AVPixFmtDescriptor *desc = av_pix_fmt_desc_get(init->pix_fmt);
+    if (desc == NULL || desc->comp[0].depth != 8 || hbhip_host_ctx() == NULL)
+    {
+        free(pv);
+        return 1;
+    }
+    pv->depth = desc->comp[0].depth;
+    pv->lcw = desc->log2_chroma_w;
+    pv->lch = desc->log2_chroma_h;
+    pv->input = *init;
+    init->hw_pix_fmt = to_device ? AV_PIX_FMT_HBHIP : AV_PIX_FMT_NONE;
+    pv->output = *init;
+    filter->private_data = pv;
+    return 0;
+}
+
+static int upload_init(hb_filter_object_t *f, hb_filter_init_t *init)   { return adapter_init(f, init, 1); }
+static int download_init(hb_filter_object_t *f, hb_filter_init_t *init) { return adapter_init(f, init, 0); }
+
+static void adapter_close(hb_filter_object_t *filter)
+{
+    free(filter->private_data);
+    filter->private_data = NULL;
+}
+
+static int upload_work(hb_filter_object_t *filter, hb_buffer_t **buf_in, hb_buffer_t **buf_out)
+{
+    hb_filter_private_t *pv = filter->private_data;
+    hb_buffer_t *in = *buf_in;
+    if ((in->s.flags & HB_BUF_FLAG_EOF) || hbhip_host_frame_of(in) != NULL)
+    {
+        *buf_out = in;
+        *buf_in = NULL;
+        return (in->s.flags & HB_BUF_FLAG_EOF) ? HB_FILTER_DONE : HB_FILTER_OK;
+    }
+    hbhip_frame *fr = NULL;
+    hbhip_host_frame hf;
+    hbhip_host_frame_from_buf(&hf, in);
+    if (hbhip_frame_alloc(hbhip_host_ctx(), in->f.width, in->f.height, pv->depth, pv->lcw, pv->lch, &fr) != HBHIP_OK)
+        return HB_FILTER_FAILED;
+    hbhip_host_ctx_release();
+    if (hbhip_frame_upload(fr, &hf) != HBHIP_OK)
+    {
+        hbhip_frame_release(fr);
+        return HB_FILTER_FAILED;
+    }
+    hb_buffer_t *out = hbhip_host_wrap_frame(fr, &pv->output, in->f.width, in->f.height);
+    if (out == NULL) return HB_FILTER_FAILED;
+    hb_buffer_copy_props(out, in);
+    *buf_out = out;
+    return HB_FILTER_OK;
+}
+
+static int download_work(hb_filter_object_t *filter, hb_buffer_t **buf_in, hb_buffer_t **buf_out)
+{
+    hb_filter_private_t *pv = filter->private_data;
+    hb_buffer_t *in = *buf_in;
+    hbhip_frame *fr = hbhip_host_frame_of(in);
+    if ((in->s.flags & HB_BUF_FLAG_EOF) || fr == NULL)
+    {
+        *buf_out = in;
+        *buf_in = NULL;
+        return (in->s.flags & HB_BUF_FLAG_EOF) ? HB_FILTER_DONE : HB_FILTER_OK;
+    }
+    hb_buffer_t *out = hbhip_host_alloc_out(&pv->output, in->f.width, in->f.height);
+    if (out == NULL) return HB_FILTER_FAILED;
+    hbhip_host_frame hf;
+    hbhip_host_frame_from_buf(&hf, out);
+    if (hbhip_frame_download(fr, &hf) != HBHIP_OK)
+    {
         hb_buffer_close(&out);
         return HB_FILTER_FAILED;
     }
@@ -112,3 +291,25 @@ int hbhip_host_simple_work(hbhip_filter *dev, const hb_filter_init_t *output, co
     *buf_out = out;
     return HB_FILTER_OK;
 }
+
+hb_filter_object_t hb_filter_hip_upload =
+{
+    .id            = HB_FILTER_HIP_UPLOAD,
+    .enforce_order = 0,
+    .name          = "HIP upload adapter",
+    .short_name    = "hipupload",
+    .init          = upload_init,
+    .work          = upload_work,
+    .close         = adapter_close,
+};
+
+hb_filter_object_t hb_filter_hip_download =
+{
+    .id            = HB_FILTER_HIP_DOWNLOAD,
+    .enforce_order = 0,
+    .name          = "HIP download adapter",
+    .short_name    = "hipdownload",
+    .init          = download_init,
+    .work          = download_work,
+    .close         = adapter_close,
+};

@@ -10,6 +10,7 @@ struct hb_filter_private_s
     hbhip_filter         *dev;
     hb_filter_init_t      input;
     hb_filter_init_t      output;
+    int                   dev_io;
 };
 
 static int  lapsharp_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init);
@@ -49,6 +50,7 @@ static int lapsharp_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init)
     if (pv == NULL) return -1;
     filter->private_data = pv;
     pv->input = *init;
+    pv->dev_io = hbhip_host_dev_io(init);
 
     const AVPixFmtDescriptor *desc = av_pix_fmt_desc_get(init->pix_fmt);
     if (desc == NULL) goto fail;
@@ -113,7 +115,7 @@ static void lapsharp_hip_close(hb_filter_object_t *filter)
 static int lapsharp_hip_work(hb_filter_object_t *filter, hb_buffer_t **buf_in, hb_buffer_t **buf_out)
 {
     hb_filter_private_t *pv = filter->private_data;
-    if (!((*buf_in)->s.flags & HB_BUF_FLAG_EOF))
+    if (!((*buf_in)->s.flags & HB_BUF_FLAG_EOF) && hbhip_host_frame_of(*buf_in) == NULL)
         hb_frame_buffer_mirror_stride(*buf_in);                             /* lapsharp.c:333 */
-    return hbhip_host_simple_work(pv->dev, &pv->output, "lapsharp", buf_in, buf_out);
+    return hbhip_host_simple_work(pv->dev, &pv->output, "lapsharp", pv->dev_io, buf_in, buf_out);
 }

@@ -28,6 +28,7 @@ struct hb_filter_private_s
     hbhip_filter        *dev;
     hb_buffer_list_t     props;      /* one zero-size buffer per queued frame, holds `s` */
     int64_t              next_tag;
+    int                  dev_io;
     hb_filter_init_t     input;
     hb_filter_init_t     output;
 };
@@ -147,6 +148,7 @@ static int nlmeans_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init)
     }
     filter->private_data = pv;
     pv->input = *init;
+    pv->dev_io = hbhip_host_dev_io(init);
 
     const AVPixFmtDescriptor *desc = av_pix_fmt_desc_get(init->pix_fmt);
     if (desc == NULL)
@@ -198,18 +200,11 @@ static int nlmeans_hip_collect(hb_filter_private_t *pv, hb_buffer_list_t *list)
 {
     while (hbhip_filter_pending(pv->dev) > 0)
     {
-        hb_buffer_t *out = hbhip_host_alloc_out(&pv->output, pv->input.geometry.width,
-                                                pv->input.geometry.height);
+        hb_buffer_t *out = hbhip_host_pull(pv->dev, &pv->output, pv->input.geometry.width,
+                                           pv->input.geometry.height, pv->dev_io, NULL);
         if (out == NULL)
-            return -1;
-        hbhip_host_frame hf;
-        hbhip_host_frame_from_buf(&hf, out);
-        int64_t tag;
-        int rc = hbhip_filter_pull(pv->dev, &hf, &tag);
-        if (rc != HBHIP_OK)
         {
-            hb_error("nlmeans(hip): pull: %s", hbhip_strerror(rc));
-            hb_buffer_close(&out);
+            hb_error("nlmeans(hip): pull failed");
             return -1;
         }
         hb_buffer_t *props = hb_buffer_list_rem_head(&pv->props);
@@ -246,9 +241,7 @@ static int nlmeans_hip_work(hb_filter_object_t *filter, hb_buffer_t **buf_in, hb
         return HB_FILTER_DONE;
     }
 
-    hbhip_host_frame hf;
-    hbhip_host_frame_from_buf(&hf, in);
-    int rc = hbhip_filter_push(pv->dev, &hf, pv->next_tag++);
+    int rc = hbhip_host_push(pv->dev, in, pv->next_tag++);
     if (rc != HBHIP_OK)
     {
         hb_error("nlmeans(hip): push: %s", hbhip_strerror(rc));

@@ -12,6 +12,7 @@ struct hb_filter_private_s
     hbhip_filter     *dev;
     hb_filter_init_t  input;
     hb_filter_init_t  output;
+    int               dev_io;
 };
 
 static int  unsharp_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init);
@@ -61,6 +62,7 @@ static int blur_hip_init_common(hb_filter_object_t *filter, hb_filter_init_t *in
     if (pv == NULL) return -1;
     filter->private_data = pv;
     pv->input = *init;
+    pv->dev_io = hbhip_host_dev_io(init);
 
     const AVPixFmtDescriptor *desc = av_pix_fmt_desc_get(init->pix_fmt);
     if (desc == NULL) goto fail;
@@ -140,5 +142,5 @@ static void blur_hip_close(hb_filter_object_t *filter)
 static int blur_hip_work(hb_filter_object_t *filter, hb_buffer_t **buf_in, hb_buffer_t **buf_out)
 {
     hb_filter_private_t *pv = filter->private_data;
-    return hbhip_host_simple_work(pv->dev, &pv->output, filter->short_name, buf_in, buf_out);
+    return hbhip_host_simple_work(pv->dev, &pv->output, filter->short_name, pv->dev_io, buf_in, buf_out);
 }

@@ -93,6 +93,21 @@ int  hbhip_dev_free(hbhip_ctx *ctx, void *p);
 int  hbhip_dev_upload(hbhip_ctx *ctx, void *dst, const void *src, size_t bytes);
 int  hbhip_dev_download(hbhip_ctx *ctx, void *dst, const void *src, size_t bytes);
 
+/* ---- device-resident frames (hand-off between adjacent HIP filters) -----------------
+ * The reference's GPU precedent keeps frames on the device between its Metal filters
+ * by giving hb_buffer_t a storage_type (COREMEDIA, internal.h:152-153) and bracketing the
+ * run of GPU filters with an adapter (HB_FILTER_ADAPTER_VT, platform/macosx/adapter_vt.c).
+ * hbhip_frame is the HIP equivalent of the CVPixelBuffer behind such a buffer: a
+ * reference-counted picture in HBM, recycled through a per-context pool. */
+typedef struct hbhip_frame hbhip_frame;
+int  hbhip_frame_alloc(hbhip_ctx *ctx, int width, int height, int depth,
+                       int log2_chroma_w, int log2_chroma_h, hbhip_frame **out);
+void hbhip_frame_retain(hbhip_frame *fr);
+void hbhip_frame_release(hbhip_frame *fr);            /* back to the pool at refcount 0 */
+int  hbhip_frame_describe(hbhip_frame *fr, hbhip_dev_frame *out, int *width, int *height);
+int  hbhip_frame_upload(hbhip_frame *fr, const hbhip_host_frame *src);      /* H2D, returns when src is consumed */
+int  hbhip_frame_download(hbhip_frame *fr, const hbhip_host_frame *dst);    /* D2H, synchronous */
+
 /* ---- generic streaming surface of a filter instance ---------------------------
  * Mirrors hb_filter_object_t.work (common.h:1682-1685): push one input frame,
  * pull zero or more output frames, flush at EOF, destroy in close().

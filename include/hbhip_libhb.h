@@ -256,6 +256,8 @@ hb_buffer_t *hb_buffer_dup(const hb_buffer_t *src);
 hb_buffer_t *hb_buffer_shallow_dup(const hb_buffer_t *src);
 int          hb_buffer_copy(hb_buffer_t *dst, const hb_buffer_t *src);
 void         hb_buffer_copy_props(hb_buffer_t *dst, const hb_buffer_t *src);
+/* stand-in runtime only: how to share / drop an HBHIP_DEVICE storage handle */
+void         hbhip_rt_set_storage_hooks(void (*retain)(void *), void (*release)(void *));
 
 void         hb_buffer_list_append(hb_buffer_list_t *list, hb_buffer_t *buf);
 void         hb_buffer_list_prepend(hb_buffer_list_t *list, hb_buffer_t *buf);
@@ -417,7 +419,10 @@ enum
     HB_FILTER_RPU,
     HB_FILTER_AVFILTER,
     HB_FILTER_LAST,
-    HB_FILTER_MT_FRAME
+    HB_FILTER_MT_FRAME,
+    /* appended, never inserted (saved job JSON and the C# interop carry the numbers above) */
+    HB_FILTER_HIP_UPLOAD,
+    HB_FILTER_HIP_DOWNLOAD
 };
 
 #ifdef __cplusplus

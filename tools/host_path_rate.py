@@ -17,6 +17,8 @@ CASES = [
       ("hb_filter_lapsharp_hip", "y-strength=0.2:y-kernel=isolap:cb-strength=0.2:cb-kernel=isolap")], 8),
     ("lapsharp 1080p", "progressive", [("hb_filter_lapsharp_hip", "y-strength=0.2:y-kernel=isolap")], 0x10),
 ]
+UP, DOWN = ("hb_filter_hip_upload", ""), ("hb_filter_hip_download", "")
+CASES = CASES + [(nm + "  [device hand-off]", m, [UP] + ch + [DOWN], fl) for nm, m, ch, fl in CASES if len(ch) > 1]
 for name, model, chain, flags in CASES:
     frames = synth.stream(model, 1920, 1080, 8)
     seq = [frames[i % 8] for i in range(n)]
@@ -24,4 +26,4 @@ for name, model, chain, flags in CASES:
     t0 = time.perf_counter()
     out = hbrt.run_stream(hip.filters(), chain, seq, flags=flags)
     dt = time.perf_counter() - t0
-    print(f"{name:55s} in {n/dt:8.1f} fps   out {len(out)/dt:8.1f} fps   ({dt*1e3/n:.2f} ms per input frame)")
+    print(f"{name:72s} in {n/dt:8.1f} fps   out {len(out)/dt:8.1f} fps   ({dt*1e3/n:.2f} ms per input frame)")
