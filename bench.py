@@ -79,6 +79,27 @@ def cpu_baseline(frames_np):
             "sample": f"{n} frames 1920x1080 YUV420P, oracle/nlmeans_oracle.c single thread, {dt:.1f}s wall"}
 
 
+def cpu_baseline_chain(workload, frames_np):
+    """The reference's own filter objects (oracle/_ref) for configs[2]/[3] on the host cores.
+    EEDI2 runs on 3 plane threads whatever the core count (decomb.c:386-394), ~0.5 s per field."""
+    from handbrake_amd import hbrt, hip
+    import oracle_lib as ol
+    ref = ol.ref()
+    if ref is None:
+        return None
+    chain = [("hb_filter_decomb", "mode=31")]
+    note = "reference hb_filter_decomb mode=31 (EEDI2 bob)"
+    if workload == "chain4":
+        chain += [("hb_filter_nlmeans", hip.NLMEANS_MEDIUM), ("hb_filter_lapsharp", "y-strength=0.2:y-kernel=isolap")]
+        note += " -> hb_filter_nlmeans medium -> hb_filter_lapsharp @1080p (the reference's cropscale is zimg, not buildable here)"
+    seq = [frames_np[i % len(frames_np)] for i in range(10)]
+    t0 = time.perf_counter()
+    out = hbrt.run_stream(ref, chain, seq, flags=8)
+    dt = time.perf_counter() - t0
+    return {"value": round(len(out) / dt, 3), "unit": "output frames/s", "cores": os.cpu_count(), "kind": "reference",
+            "sample": f"{len(seq)} input / {len(out)} output frames 1920x1080, {note}, {dt:.1f}s wall"}
+
+
 def secondary(args):
     """configs[2] / configs[3] measured the same way (device-resident, one stream per GPU).
     Not the default bench line; used for DESIGN.md / profiles."""
@@ -166,7 +187,9 @@ def secondary(args):
                        "input_frames_per_step": 1, "output_frames_per_step": 2, "device": ctx.name()},
             "chain_hbm_GBps_algorithmic": round(per_out * frames_total / dt_max / 1e9, 2),
             "top_kernels": [{"kernel": k, "launches": n, "avg_us": round(ms / n * 1e3, 1)} for k, (n, ms) in top],
-            "roofline": None, "cpu_baseline": None}), flush=True)
+            "roofline": None,
+            "cpu_baseline": None if (world > 1 or args.no_cpu_baseline) else cpu_baseline_chain(args.workload, frames_np)}),
+            flush=True)
     ctx.close()
 
 

@@ -139,14 +139,18 @@ __global__ __launch_bounds__(TXN * TYN, (VAR & 2) ? 3 : 1) void nlmeans_plane_ke
     load_tile(s_src, SPD, SROWS, job.frame[0], job.fpitch[0], w, h, tx0 - NH, ty0 - NH);
 
     float aw[RY][PX], ap[RY][PX];
-    uint32_t srcpix[RY];
 #pragma unroll
     for (int o = 0; o < RY; o++)
-    {
-        srcpix[o] = 0;
 #pragma unroll
         for (int p = 0; p < PX; p++) { aw[o][p] = 0.f; ap[o][p] = 0.f; }
-    }
+
+    // The 4 centre pixels of output row o of the frame being filtered (origin term, zero
+    // fallback).  They stay in the source tile for the whole kernel, so they are re-read
+    // from LDS in the two cold places that need them instead of occupying 8 VGPRs.
+    auto centre4 = [&](int o) -> uint32_t {
+        const uint32_t *c = s_src + (ty * RY + o + NH) * SPD + tx;
+        return __builtin_amdgcn_alignbyte(c[(NH >> 2) + 1], c[NH >> 2], NH & 3);
+    };
 
     const float wft = job.wft;
     const int diff_max = job.diff_max;
@@ -159,18 +163,6 @@ __global__ __launch_bounds__(TXN * TYN, (VAR & 2) ? 3 : 1) void nlmeans_plane_ke
         load_tile(s_cmp, CPD, cmp_rows, job.frame[f], job.fpitch[f], w, h, tx0 - HALO, ty0 - HALO);
         __syncthreads();
 
-        if (f == 0)
-        {
-            // centre pixels of the frame being filtered (origin term + zero fallback)
-            const int s = RH + NH;
-#pragma unroll
-            for (int o = 0; o < RY; o++)
-            {
-                const uint32_t *c = s_cmp + (ty * RY + o + HALO) * CPD + tx + (s >> 2);
-                srcpix[o] = __builtin_amdgcn_alignbyte(c[1], c[0], s & 3);
-            }
-        }
-
         for (int dy = -RH; dy <= RH; dy++)
         {
             for (int dx = -RH; dx <= RH; dx++)
@@ -180,15 +172,16 @@ __global__ __launch_bounds__(TXN * TYN, (VAR & 2) ? 3 : 1) void nlmeans_plane_ke
 #pragma unroll
                     for (int o = 0; o < RY; o++)
                     {
+                        const uint32_t cpx = centre4(o);
 #pragma unroll
                         for (int p = 0; p < PX; p++)
                         {
                             aw[o][p] = (float)((double)aw[o][p] + origin_tune);
-                            ap[o][p] = (float)((double)ap[o][p] + origin_tune * (double)(int)byte_of(srcpix[o], p));
+                            ap[o][p] = (float)((double)ap[o][p] + origin_tune * (double)(int)byte_of(cpx, p));
+                            // executed once per tile: one pixel's f64 temporaries at a time, so that this
+                            // cold block does not push the kernel over the 168-VGPR (3 waves/SIMD) line
+                            __builtin_amdgcn_sched_barrier(0);
                         }
-                        // executed once per tile: keep the f64 temporaries of one row at a time,
-                        // or this block alone sets the kernel's VGPR count (236 -> occupancy 2)
-                        __builtin_amdgcn_sched_barrier(0);
                     }
                     continue;
                 }
@@ -327,13 +320,15 @@ __global__ __launch_bounds__(TXN * TYN, (VAR & 2) ? 3 : 1) void nlmeans_plane_ke
         const int y = ty0 + ty * RY + o;
         if (y >= h) break;
         uint32_t packed = 0;
+        const uint32_t cpx = centre4(o);
 #pragma unroll
         for (int p = 0; p < PX; p++)
         {
             const float q = ap[o][p] / aw[o][p];
             uint32_t r = (uint32_t)(int)q & 0xffu;
-            if (r == 0) r = byte_of(srcpix[o], p);
+            if (r == 0) r = byte_of(cpx, p);
             packed |= r << (8 * p);
+            __builtin_amdgcn_sched_barrier(0);       // one IEEE division sequence at a time (register pressure)
         }
         uint8_t *out = job.dst + (size_t)y * job.dst_pitch + x;
         if (x + 3 < w)

@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""Per-kernel achieved GB/s against the HBM roofline, measured with HIP events on the stream
+(ctx profile) while each filter runs device-resident on synthetic 1080p (2160p where the
+chain runs it there).  Algorithmic bytes per launch follow SURVEY §8d.  Output: JSON on stdout."""
+import ctypes as C
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from handbrake_amd import hip, synth
+
+W, H = 1920, 1080
+PEAK = 8000.0
+FRAME = W * H * 3 // 2
+N = 24
+
+
+def planes(w, h):
+    return [torch.empty((h, w), dtype=torch.uint8, device="cuda"),
+            torch.empty((h // 2, w // 2), dtype=torch.uint8, device="cuda"),
+            torch.empty((h // 2, w // 2), dtype=torch.uint8, device="cuda")]
+
+
+def simple(ctx, make, w, h, ow, oh, model="progressive", feeds=N):
+    frames = synth.stream(model, w, h, 4)
+    dev_in = [[torch.from_numpy(p).cuda() for p in fr] for fr in frames]
+    out = planes(ow, oh)
+    torch.cuda.synchronize()
+    flt = make()
+    fin = [hip.dev_frame(f) for f in dev_in]
+    fo = hip.dev_frame(out)
+    for i in range(3):
+        flt.push_dev(fin[i % 4], i)
+        while flt.pending():
+            flt.pull_dev(fo)
+    ctx.sync()
+    ctx.profile(True)
+    ctx.profile_reset()
+    for i in range(feeds):
+        flt.push_dev(fin[i % 4], i)
+        while flt.pending():
+            flt.pull_dev(fo)
+    ctx.sync()
+    st = ctx.profile_stats()
+    ctx.profile(False)
+    flt.close()
+    return st
+
+
+def main():
+    ctx = hip.Ctx(0)
+    L = hip.lib()
+    res = {}
+
+    def add(stats, table):
+        for k, (n, ms) in stats.items():
+            if k not in table:
+                continue
+            b = table[k]
+            us = ms / n * 1e3
+            res[k] = {"launches": n, "avg_us": round(us, 2), "algorithmic_bytes_per_launch": b,
+                      "achieved_GBps": round(b / (us * 1e-6) / 1e9, 1), "frac_of_8TBps": round(b / (us * 1e-6) / 1e9 / PEAK, 4)}
+
+    Y, Cc = W * H, W * H // 4
+    # lapsharp at 2160p (where config 4 runs it): one launch per plane, 2 B/pixel
+    st = simple(ctx, lambda: hip.lapsharp_device_filter(ctx, 2 * W, 2 * H), 2 * W, 2 * H, 2 * W, 2 * H)
+    add(st, {"lapsharp_3x3": 2 * (4 * FRAME) // 3})           # mean over Y (4Y) + 2 chroma launches
+    # unsharp / chroma smooth 1080p
+    def mk_blur(fn):
+        class BP(C.Structure):
+            _fields_ = [("amount", C.c_int * 3), ("size", C.c_int * 3)]
+        p = BP((C.c_int * 3)(16384, 16384, 16384), (C.c_int * 3)(7, 7, 7))
+        return hip._create(fn, ctx, [C.c_void_p, C.POINTER(BP)] + [C.c_int] * 5 + [C.POINTER(C.c_void_p)],
+                           ctx.h, C.byref(p), W, H, 8, 1, 1)
+    add(simple(ctx, lambda: mk_blur("hbhip_unsharp_create"), W, H, W, H), {"unsharp_blur_mix": 2 * FRAME // 3})
+    add(simple(ctx, lambda: mk_blur("hbhip_chroma_smooth_create"), W, H, W, H), {"chroma_smooth_blur_mix": 2 * Cc})
+    # cropscale 1080p -> 2160p
+    st = simple(ctx, lambda: hip.cropscale_device_filter(ctx, W, H, 2 * W, 2 * H), W, H, 2 * W, 2 * H)
+    add(st, {"cropscale_lanczos_h": (FRAME + 8 * 2 * FRAME) // 3, "cropscale_lanczos_v": (8 * 2 * FRAME + 4 * FRAME) // 3})
+    # rotate / grayscale 1080p
+    rot = lambda: hip._create("hbhip_rotate_create", ctx, [C.c_void_p] + [C.c_int] * 7 + [C.POINTER(C.c_void_p)],
+                              ctx.h, 90, 0, W, H, 8, 1, 1)
+    add(simple(ctx, rot, W, H, H, W), {"rotate": 2 * FRAME // 3})
+    gray = lambda: hip._create("hbhip_grayscale_create", ctx, [C.c_void_p] + [C.c_double] * 4 + [C.c_int] * 5 + [C.POINTER(C.c_void_p)],
+                               ctx.h, 0.0, 0.0, 1.0, 0.0, W, H, 8, 1, 1)
+    add(simple(ctx, gray, W, H, W, H), {"monochrome": Y + 2 * Cc + Y})
+    # decomb default (mode 7) and EEDI2 bob: via DecombDevice + push_dev
+    L.hbhip_decomb_push_dev.argtypes = [C.c_void_p, C.POINTER(hip.DevFrame), C.c_int64, C.c_int, C.c_int]
+    for mode in (7, 31):
+        frames = synth.stream("interlaced", W, H, 4)
+        dev_in = [[torch.from_numpy(p).cuda() for p in fr] for fr in frames]
+        out = planes(W, H)
+        torch.cuda.synchronize()
+        dd = hip.DecombDevice(ctx, W, H, mode=mode)
+        fo = hip.dev_frame(out)
+        fin = [hip.dev_frame(f) for f in dev_in]
+
+        def feed(i):
+            hip.check(L.hbhip_decomb_push_dev(dd.h, C.byref(fin[i % 4]), i, 8, 2), ctx.h)
+            while L.hbhip_filter_pending(dd.h) > 0:
+                hip.check(L.hbhip_filter_pull_dev(dd.h, C.byref(fo), None), ctx.h)
+        for i in range(3):
+            feed(i)
+        ctx.sync(); ctx.profile(True); ctx.profile_reset()
+        for i in range(N):
+            feed(3 + i)
+        ctx.sync()
+        st = ctx.profile_stats(); ctx.profile(False)
+        if mode == 7:
+            add(st, {"decomb_plane": 4 * FRAME})
+        else:
+            half = FRAME // 2
+            add(st, {"eedi2_calc_directions": 3 * half, "eedi2_lattice_candidates": 3 * FRAME // 2 + FRAME // 2 * 4,
+                     "eedi2_lattice_resolve": FRAME // 2 * 4 + FRAME, "eedi2_filter_dir_map_2x": 3 * FRAME,
+                     "eedi2_expand_dir_map_2x": 3 * FRAME, "eedi2_fill_gaps_2x": 3 * FRAME,
+                     "eedi2_mark_directions_2x": 3 * FRAME, "eedi2_filter_dir_map": 3 * half,
+                     "eedi2_expand_dir_map": 3 * half, "eedi2_filter_map": 3 * half, "eedi2_erode": 2 * half,
+                     "eedi2_dilate": 2 * half, "eedi2_edge_mask": 2 * half, "eedi2_small_gaps": 2 * half,
+                     "eedi2_upscale_by_2": 3 * half + 3 * FRAME, "eedi2_bit_blit": 2 * FRAME, "eedi2_post_process": 3 * FRAME,
+                     "eedi2_fill_half": 2 * half})
+        dd.close()
+    # hqdn3d 1080p
+    frames = synth.stream("progressive", W, H, 4)
+    class HQ(C.Structure):
+        _fields_ = [("coef", (C.c_int16 * 8192) * 6)]
+    F = hip.filters()
+    # host-built tables through the drop-in's own code: run the filter object once is simpler -> use oracle-free path
+    print(json.dumps(res, indent=1))
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
