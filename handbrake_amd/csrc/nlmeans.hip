@@ -342,6 +342,256 @@ __global__ __launch_bounds__(TXN * TYN, (VAR & 2) ? 3 : 1) void nlmeans_plane_ke
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Lane-sharing variant (the default).  In the kernel above every thread squares the differences of
+// its whole 4+n-1 byte window, i.e. (4+n-1)/4 of the work is redone by its neighbours.  Here a lane
+// squares only its own 4 bytes per row, forms the prefix / suffix sums of those 4 squares, and the
+// horizontal n-sums are completed with DPP wave shifts: pixel p of lane l needs the last
+// (n/2 - p) squares of lane l-1 and the first (p + n/2 - 3) squares of lane l+1.  The two outer
+// lanes of each 32-lane tile row only feed their neighbours (they own no output), so a tile is
+// (32-2)*4 = 120 pixels wide; n <= 9 keeps every window inside the adjacent lanes.
+constexpr int LTXA = TXN - 2;            // lanes of a tile row that own output pixels
+constexpr int LTW = LTXA * PX;           // 120
+constexpr int LSPD = 36;                 // LDS pitch in dwords: the two tile rows of a wave are
+                                         // 8 rows apart = 288 dwords = 32 banks apart (no conflicts)
+
+__device__ __forceinline__ void load_tile_p(uint32_t *lds, int pitch, int dwords, int rows,
+                                            const uint8_t *__restrict__ plane, int src_pitch,
+                                            int w, int h, int x0, int y0)
+{
+    const int total = dwords * rows;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+#pragma nounroll
+    for (int i = tid; i < total; i += TXN * TYN)
+    {
+        const int r = i / dwords;
+        const int c = i - r * dwords;
+        const int y = reflect(y0 + r, h);
+        const int x = x0 + 4 * c;
+        const uint8_t *row = plane + (size_t)y * src_pitch;
+        uint32_t v;
+        if (x >= 0 && x + 3 < w)
+        {
+            v = reinterpret_cast<const u32_unaligned *>(row + x)->v;
+        }
+        else
+        {
+            v = (uint32_t)row[reflect(x, w)] | ((uint32_t)row[reflect(x + 1, w)] << 8) |
+                ((uint32_t)row[reflect(x + 2, w)] << 16) | ((uint32_t)row[reflect(x + 3, w)] << 24);
+        }
+        lds[r * pitch + c] = v;
+    }
+}
+
+// DPP wave shifts (all 64 lanes are active wherever these are used).
+__device__ __forceinline__ uint32_t from_lane_below(uint32_t x)   // lane l <- lane l-1
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t from_lane_above(uint32_t x)   // lane l <- lane l+1
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+}
+
+template <int N, bool FAST>
+__global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJob *__restrict__ jobs, int njobs,
+                                                                     int cpd, int cmp_rows, int rq)
+{
+    constexpr int NH = N / 2;
+    constexpr int SROWS = TH + 2 * NH;
+    constexpr int ROWS = RY + N - 1;
+    static_assert(NH <= PX, "patch must not reach past the adjacent lane");
+
+    extern __shared__ uint32_t smem[];
+    uint32_t *s_src = smem;
+    uint32_t *s_cmp = smem + LSPD * SROWS;
+    float *s_exp = reinterpret_cast<float *>(s_cmp + cpd * cmp_rows + 4);
+
+    int j = 0;
+    while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].tile_start) j++;
+    const NlmJob &job = jobs[j];
+    const int tile = blockIdx.x - job.tile_start;
+    const int tile_y = tile / job.tiles_x;
+    const int tile_x = tile - tile_y * job.tiles_x;
+    const int tx0 = tile_x * LTW, ty0 = tile_y * TH;
+    const int w = job.w, h = job.h;
+    const int RH = job.r_half;
+
+    const int tx = threadIdx.x & (TXN - 1);
+    const int ty = threadIdx.x / TXN;
+
+    if (threadIdx.x < 128) s_exp[threadIdx.x] = job.exptable[threadIdx.x];
+    // lane tx holds the source pixels tx0 + 4*(tx-1) .. +3: the tile starts one lane left of tx0
+    load_tile_p(s_src, LSPD, TXN, SROWS, job.frame[0], job.fpitch[0], w, h, tx0 - PX, ty0 - NH);
+
+    float aw[RY][PX], ap[RY][PX];
+#pragma unroll
+    for (int o = 0; o < RY; o++)
+#pragma unroll
+        for (int p = 0; p < PX; p++) { aw[o][p] = 0.f; ap[o][p] = 0.f; }
+
+    const float wft = job.wft;
+    const int diff_max = job.diff_max;
+    const int diff_cap = job.diff_cap;
+    const double origin_tune = job.origin_tune;
+    // a wave (two tile rows of lanes) whose 16 output rows all lie below the plane has nothing to do
+    const bool wave_live = ty0 + (ty & ~1) * RY < h;
+
+    for (int f = 0; f < job.nframes; f++)
+    {
+        __syncthreads();
+        load_tile_p(s_cmp, cpd, cpd, cmp_rows, job.frame[f], job.fpitch[f], w, h,
+                    tx0 - PX - 4 * rq, ty0 - NH - RH);
+        __syncthreads();
+        if (!wave_live) continue;
+
+        for (int dy = -RH; dy <= RH; dy++)
+        {
+            for (int dx = -RH; dx <= RH; dx++)
+            {
+                if (f == 0 && dx == 0 && dy == 0)
+                {
+#pragma unroll
+                    for (int o = 0; o < RY; o++)
+                    {
+                        const uint32_t cpx = s_src[(ty * RY + o + NH) * LSPD + tx];
+#pragma unroll
+                        for (int p = 0; p < PX; p++)
+                        {
+                            aw[o][p] = (float)((double)aw[o][p] + origin_tune);
+                            ap[o][p] = (float)((double)ap[o][p] + origin_tune * (double)(int)byte_of(cpx, p));
+                            __builtin_amdgcn_sched_barrier(0);   // cold block: keep its f64 temporaries few
+                        }
+                    }
+                    continue;
+                }
+
+                const int s = dx + 4 * rq;                   // >= 0, wave-uniform
+                const int sh = s & 3;
+                const uint32_t *srow = s_src + (ty * RY) * LSPD + tx;
+                const uint32_t *crow = s_cmp + (ty * RY + dy + RH) * cpd + tx + (s >> 2);
+
+                uint32_t ring[N][PX];
+                uint32_t v[PX];
+                uint32_t centre[NH + 1];                     // compare-frame dwords of the last NH+1 rows
+#pragma unroll
+                for (int p = 0; p < PX; p++) v[p] = 0;
+
+                uint32_t a_n = srow[0], b_n0 = crow[0], b_n1 = crow[1];
+#pragma unroll
+                for (int i = 0; i < ROWS; i++)
+                {
+                    const uint32_t a = a_n;
+                    const uint32_t bw = __builtin_amdgcn_alignbyte(b_n1, b_n0, sh);
+                    if (i + 1 < ROWS)
+                    {
+                        a_n = srow[(i + 1) * LSPD];
+                        b_n0 = crow[(i + 1) * cpd];
+                        b_n1 = crow[(i + 1) * cpd + 1];
+                    }
+                    centre[i % (NH + 1)] = bw;
+
+                    // squares of this lane's own 4 differences; prefix and suffix sums
+                    uint32_t sq[PX], pre[PX + 1], suf[PX + 1];
+#pragma unroll
+                    for (int q = 0; q < PX; q++)
+                    {
+                        const int d = (int)byte_of(a, q) - (int)byte_of(bw, q);
+                        sq[q] = (uint32_t)(d * d);
+                    }
+                    pre[0] = 0; suf[0] = 0;
+#pragma unroll
+                    for (int q = 0; q < PX; q++)
+                    {
+                        pre[q + 1] = pre[q] + sq[q];
+                        suf[q + 1] = suf[q] + sq[PX - 1 - q];
+                    }
+                    uint32_t hs[PX];
+#pragma unroll
+                    for (int p = 0; p < PX; p++)
+                    {
+                        const int lo = p - NH, hi = p + NH;
+                        uint32_t t;
+                        if (lo <= 0 && hi >= PX - 1) t = pre[PX];
+                        else if (lo <= 0) t = pre[hi + 1];
+                        else if (hi >= PX - 1) t = suf[PX - lo];
+                        else t = pre[hi + 1] - pre[lo];
+                        // one VOP2 add per neighbour so that each folds its DPP move (an add3 cannot)
+                        if (lo < 0) { t += from_lane_below(suf[-lo]); asm volatile("" : "+v"(t)); }
+                        if (hi > PX - 1) { t += from_lane_above(pre[hi - (PX - 1)]); asm volatile("" : "+v"(t)); }
+                        hs[p] = t;
+                    }
+                    // vertical sliding window
+#pragma unroll
+                    for (int p = 0; p < PX; p++)
+                    {
+                        v[p] += hs[p];
+                        if (i >= N) v[p] -= ring[i % N][p];
+                        ring[i % N][p] = hs[p];
+                    }
+                    if (i >= N - 1)
+                    {
+                        const int o = i - (N - 1);
+                        const uint32_t pix = centre[(i - NH) % (NH + 1)];
+#pragma unroll
+                        for (int p = 0; p < PX; p++)
+                        {
+                            int idx;
+                            if (FAST)
+                            {
+                                idx = (int)((float)(int)min(v[p], (uint32_t)diff_cap) * wft);
+                            }
+                            else
+                            {
+                                const int diff = (int)v[p];
+                                idx = (int)((float)diff * wft);
+                                idx = diff < diff_max ? idx : 127;
+                                idx = min(idx, 127);
+                            }
+                            const float wgt = s_exp[idx];
+                            const float pv = (float)(int)byte_of(pix, p);
+                            aw[o][p] += wgt;
+                            ap[o][p] += wgt * pv;
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+
+    // normalise + store (the outer lanes own no pixels)
+    const int x = tx0 + (tx - 1) * PX;
+    if (tx == 0 || tx == TXN - 1 || x >= w) return;
+#pragma unroll
+    for (int o = 0; o < RY; o++)
+    {
+        const int y = ty0 + ty * RY + o;
+        if (y >= h) break;
+        uint32_t packed = 0;
+        const uint32_t cpx = s_src[(ty * RY + o + NH) * LSPD + tx];
+#pragma unroll
+        for (int p = 0; p < PX; p++)
+        {
+            const float q = ap[o][p] / aw[o][p];
+            uint32_t r = (uint32_t)(int)q & 0xffu;
+            if (r == 0) r = byte_of(cpx, p);
+            packed |= r << (8 * p);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        uint8_t *out = job.dst + (size_t)y * job.dst_pitch + x;
+        if (x + 3 < w)
+        {
+            *reinterpret_cast<uint32_t *>(out) = packed;
+        }
+        else
+        {
+            for (int p = 0; p < PX && x + p < w; p++) out[p] = (uint8_t)(packed >> (8 * p));
+        }
+    }
+}
+
 __global__ void copy_plane_kernel(uint8_t *dst, int dst_pitch, const uint8_t *src, int src_pitch,
                                   int row_bytes, int rows)
 {
@@ -431,7 +681,7 @@ public:
     void recycle_output(DevPicture *p) override { pool.release(p); }
 
     int batch = 1;
-    int variant = 3;
+    int variant = 4;      // 4: lane-sharing kernel; 0/3: per-thread-window kernel (HBHIP_NLM_VARIANT)
     int diff_cap[3] = {-1, -1, -1};
 
 private:
@@ -489,6 +739,7 @@ private:
             NlmJob *dj = d_jobs + (size_t)table * jobs_cap;
             int nj = 0, tiles = 0, max_rh = 0;
             bool fast = true;
+            const int tile_w = variant >= 4 ? LTW : TW;
             for (int t = 0; t < ready; t++)
                 for (int c = 0; c < 3; c++)
                 {
@@ -511,7 +762,7 @@ private:
                     jb.h = in_geo.ph[c];
                     jb.dst_pitch = outs[t].pitch[c];
                     jb.r_half = (par.range[c] - 1) / 2;
-                    jb.tiles_x = (jb.w + TW - 1) / TW;
+                    jb.tiles_x = (jb.w + tile_w - 1) / tile_w;
                     jb.tile_start = tiles;
                     tiles += jb.tiles_x * ((jb.h + TH - 1) / TH);
                     max_rh = std::max(max_rh, jb.r_half);
@@ -520,23 +771,45 @@ private:
             HBHIP_CHECK(ctx, hipMemcpyAsync(dj, hj, sizeof(NlmJob) * nj, hipMemcpyHostToDevice, ctx->stream));
             HBHIP_CHECK(ctx, hipEventRecord(table_ev[table], ctx->stream));
             table_used[table] = true;
-            const int nh = n / 2, W = PX + 2 * nh, ND = (W + 3) / 4;
-            const int cmp_dwords = TXN + ND + (2 * max_rh) / 4 + 2;
+            const int nh = n / 2;
             const int cmp_rows = TH + 2 * (nh + max_rh);
-            const size_t shmem = sizeof(uint32_t) * ((TXN + ND) * (TH + 2 * nh) + cmp_dwords * cmp_rows) + 512;
             dim3 grid(tiles), block(TXN * TYN);
+            if (variant >= 4)
+            {
+                // compare tile: 32 lanes + rq dwords of search halo either side, pitch = 4 (mod 8)
+                const int rq = (max_rh + 3) / 4;
+                const int cpd = (32 + 2 * rq + 1 + 3) / 8 * 8 + 4;
+                const size_t shmem = sizeof(uint32_t) * (LSPD * (TH + 2 * nh) + cpd * cmp_rows + 4) + 512;
+#define NLM_GO(NN, FF) HBHIP_LAUNCH(ctx, "nlmeans_plane_n" #NN, (nlmeans_lanes_kernel<NN, FF>), grid, block, shmem, dj, nj, cpd, cmp_rows, rq)
+#define NLM_VAR(NN) do { if (fast) NLM_GO(NN, true); else NLM_GO(NN, false); } while (0)
+                switch (n)
+                {
+                    case 3: NLM_VAR(3); break;
+                    case 5: NLM_VAR(5); break;
+                    case 7: NLM_VAR(7); break;
+                    case 9: NLM_VAR(9); break;
+                }
+#undef NLM_VAR
+#undef NLM_GO
+            }
+            else
+            {
+                const int W = PX + 2 * nh, ND = (W + 3) / 4;
+                const int cmp_dwords = TXN + ND + (2 * max_rh) / 4 + 2;
+                const size_t shmem = sizeof(uint32_t) * ((TXN + ND) * (TH + 2 * nh) + cmp_dwords * cmp_rows) + 512;
 #define NLM_GO(NN, VV, FF) HBHIP_LAUNCH(ctx, "nlmeans_plane_n" #NN, (nlmeans_plane_kernel<NN, VV, FF>), grid, block, shmem, dj, nj, cmp_dwords, cmp_rows)
 #define NLM_VAR(NN) do { if (variant == 0) { if (fast) NLM_GO(NN, 0, true); else NLM_GO(NN, 0, false); } \
                          else { if (fast) NLM_GO(NN, 3, true); else NLM_GO(NN, 3, false); } } while (0)
-            switch (n)
-            {
-                case 3: NLM_VAR(3); break;
-                case 5: NLM_VAR(5); break;
-                case 7: NLM_VAR(7); break;
-                case 9: NLM_VAR(9); break;
-            }
+                switch (n)
+                {
+                    case 3: NLM_VAR(3); break;
+                    case 5: NLM_VAR(5); break;
+                    case 7: NLM_VAR(7); break;
+                    case 9: NLM_VAR(9); break;
+                }
 #undef NLM_VAR
 #undef NLM_GO
+            }
             HBHIP_CHECK(ctx, hipGetLastError());
         }
 
