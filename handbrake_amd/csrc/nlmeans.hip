@@ -53,6 +53,7 @@ struct NlmJob
 };
 
 struct __attribute__((packed, aligned(1))) u32_unaligned { uint32_t v; };
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 // mirrored coordinate (edge pixel repeated), then clamped so far-out halo
 // reads of tiny planes stay inside the allocation.
@@ -355,32 +356,34 @@ constexpr int LTW = LTXA * PX;           // 120
 constexpr int LSPD = 36;                 // LDS pitch in dwords: the two tile rows of a wave are
                                          // 8 rows apart = 288 dwords = 32 banks apart (no conflicts)
 
+// Stage a (rows x dwords*4)-byte window of `plane` whose top-left pixel is (x0, y0) into LDS
+// (row pitch `pitch` dwords) with the reference's mirrored borders (nlmeans_template.c:29-41).
+// A thread keeps one column for the whole tile, so the column reflection and the index split
+// are computed once; the per-row work is a row reflection, one address and one load.
 __device__ __forceinline__ void load_tile_p(uint32_t *lds, int pitch, int dwords, int rows,
                                             const uint8_t *__restrict__ plane, int src_pitch,
                                             int w, int h, int x0, int y0)
 {
-    const int total = dwords * rows;
     int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));
+    asm volatile("" : "+v"(tid));                      // keep this cold code out of LICM's reach
+    const int rpp = (TXN * TYN) / dwords;              // rows per pass
+    const int r0 = (int)(((float)tid + 0.5f) * (1.0f / (float)dwords));   // tid / dwords (tid < 2^10)
+    const int c = tid - r0 * dwords;
+    if (r0 >= rpp) return;
+    const int x = x0 + 4 * c;
+    const bool whole = x >= 0 && x + 3 < w;
+    const int o0 = reflect(x, w), o1 = reflect(x + 1, w), o2 = reflect(x + 2, w), o3 = reflect(x + 3, w);
+    uint32_t *out = lds + r0 * pitch + c;
 #pragma nounroll
-    for (int i = tid; i < total; i += TXN * TYN)
+    for (int r = r0; r < rows; r += rpp, out += rpp * pitch)
     {
-        const int r = i / dwords;
-        const int c = i - r * dwords;
-        const int y = reflect(y0 + r, h);
-        const int x = x0 + 4 * c;
-        const uint8_t *row = plane + (size_t)y * src_pitch;
+        const uint8_t *row = plane + (size_t)reflect(y0 + r, h) * src_pitch;
         uint32_t v;
-        if (x >= 0 && x + 3 < w)
-        {
+        if (whole)
             v = reinterpret_cast<const u32_unaligned *>(row + x)->v;
-        }
         else
-        {
-            v = (uint32_t)row[reflect(x, w)] | ((uint32_t)row[reflect(x + 1, w)] << 8) |
-                ((uint32_t)row[reflect(x + 2, w)] << 16) | ((uint32_t)row[reflect(x + 3, w)] << 24);
-        }
-        lds[r * pitch + c] = v;
+            v = (uint32_t)row[o0] | ((uint32_t)row[o1] << 8) | ((uint32_t)row[o2] << 16) | ((uint32_t)row[o3] << 24);
+        *out = v;
     }
 }
 
@@ -425,11 +428,14 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
     // lane tx holds the source pixels tx0 + 4*(tx-1) .. +3: the tile starts one lane left of tx0
     load_tile_p(s_src, LSPD, TXN, SROWS, job.frame[0], job.fpitch[0], w, h, tx0 - PX, ty0 - NH);
 
-    float aw[RY][PX], ap[RY][PX];
+    // weight / weighted-pixel accumulators as float pairs: the adds and the w*pixel product
+    // below are packed (v_pk_add_f32 / v_pk_mul_f32, each lane of a pair rounded like the scalar op)
+    f2 aw[RY][PX / 2], ap[RY][PX / 2];
 #pragma unroll
     for (int o = 0; o < RY; o++)
 #pragma unroll
-        for (int p = 0; p < PX; p++) { aw[o][p] = 0.f; ap[o][p] = 0.f; }
+        for (int p = 0; p < PX / 2; p++) { aw[o][p] = f2{0.f, 0.f}; ap[o][p] = f2{0.f, 0.f}; }
+    const f2 wft2 = {job.wft, job.wft};
 
     const float wft = job.wft;
     const int diff_max = job.diff_max;
@@ -459,8 +465,8 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
 #pragma unroll
                         for (int p = 0; p < PX; p++)
                         {
-                            aw[o][p] = (float)((double)aw[o][p] + origin_tune);
-                            ap[o][p] = (float)((double)ap[o][p] + origin_tune * (double)(int)byte_of(cpx, p));
+                            aw[o][p / 2][p & 1] = (float)((double)aw[o][p / 2][p & 1] + origin_tune);
+                            ap[o][p / 2][p & 1] = (float)((double)ap[o][p / 2][p & 1] + origin_tune * (double)(int)byte_of(cpx, p));
                             __builtin_amdgcn_sched_barrier(0);   // cold block: keep its f64 temporaries few
                         }
                     }
@@ -535,24 +541,32 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
                         const int o = i - (N - 1);
                         const uint32_t pix = centre[(i - NH) % (NH + 1)];
 #pragma unroll
-                        for (int p = 0; p < PX; p++)
+                        for (int pp = 0; pp < PX / 2; pp++)
                         {
-                            int idx;
+                            int idx[2];
                             if (FAST)
                             {
-                                idx = (int)((float)(int)min(v[p], (uint32_t)diff_cap) * wft);
+                                const f2 fd = {(float)(int)min(v[2 * pp], (uint32_t)diff_cap),
+                                               (float)(int)min(v[2 * pp + 1], (uint32_t)diff_cap)};
+                                const f2 fi = fd * wft2;
+                                idx[0] = (int)fi.x;
+                                idx[1] = (int)fi.y;
                             }
                             else
                             {
-                                const int diff = (int)v[p];
-                                idx = (int)((float)diff * wft);
-                                idx = diff < diff_max ? idx : 127;
-                                idx = min(idx, 127);
+#pragma unroll
+                                for (int e = 0; e < 2; e++)
+                                {
+                                    const int diff = (int)v[2 * pp + e];
+                                    int ix = (int)((float)diff * wft);
+                                    ix = diff < diff_max ? ix : 127;
+                                    idx[e] = min(ix, 127);
+                                }
                             }
-                            const float wgt = s_exp[idx];
-                            const float pv = (float)(int)byte_of(pix, p);
-                            aw[o][p] += wgt;
-                            ap[o][p] += wgt * pv;
+                            const f2 wgt = {s_exp[idx[0]], s_exp[idx[1]]};
+                            const f2 pv = {(float)(int)byte_of(pix, 2 * pp), (float)(int)byte_of(pix, 2 * pp + 1)};
+                            aw[o][pp] += wgt;
+                            ap[o][pp] += wgt * pv;
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -574,7 +588,7 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
 #pragma unroll
         for (int p = 0; p < PX; p++)
         {
-            const float q = ap[o][p] / aw[o][p];
+            const float q = ap[o][p / 2][p & 1] / aw[o][p / 2][p & 1];
             uint32_t r = (uint32_t)(int)q & 0xffu;
             if (r == 0) r = byte_of(cpx, p);
             packed |= r << (8 * p);
