@@ -478,11 +478,15 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
                 const uint32_t *srow = s_src + (ty * RY) * LSPD + tx;
                 const uint32_t *crow = s_cmp + (ty * RY + dy + RH) * cpd + tx + (s >> 2);
 
-                uint32_t ring[N][PX];
-                uint32_t v[PX];
-                uint32_t centre[NH + 1];                     // compare-frame dwords of the last NH+1 rows
+                // Column sums first: C[q] is the running (prefix) sum down this lane's 4 columns of the
+                // squared differences, hist[] keeps the first RY-1 of them, so the n-row window sum of
+                // output row o is C(after row o+n-1) - C(after row o-1).  Only output rows then pay
+                // for the horizontal n-sum across lanes.
+                uint32_t C[PX], hist[RY - 1][PX], v[PX];
+                uint32_t centre[NH + 2];                     // compare-frame dwords of the last NH+2 rows
+                f2 wq[PX / 2];                               // table weights in flight for the previous output row
 #pragma unroll
-                for (int p = 0; p < PX; p++) v[p] = 0;
+                for (int q = 0; q < PX; q++) C[q] = 0;
 
                 uint32_t a_n = srow[0], b_n0 = crow[0], b_n1 = crow[1];
 #pragma unroll
@@ -496,50 +500,58 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
                         b_n0 = crow[(i + 1) * cpd];
                         b_n1 = crow[(i + 1) * cpd + 1];
                     }
-                    centre[i % (NH + 1)] = bw;
-
-                    // squares of this lane's own 4 differences; prefix and suffix sums
-                    uint32_t sq[PX], pre[PX + 1], suf[PX + 1];
+                    centre[i % (NH + 2)] = bw;
 #pragma unroll
                     for (int q = 0; q < PX; q++)
                     {
                         const int d = (int)byte_of(a, q) - (int)byte_of(bw, q);
-                        sq[q] = (uint32_t)(d * d);
-                    }
-                    pre[0] = 0; suf[0] = 0;
-#pragma unroll
-                    for (int q = 0; q < PX; q++)
-                    {
-                        pre[q + 1] = pre[q] + sq[q];
-                        suf[q + 1] = suf[q] + sq[PX - 1 - q];
-                    }
-                    uint32_t hs[PX];
-#pragma unroll
-                    for (int p = 0; p < PX; p++)
-                    {
-                        const int lo = p - NH, hi = p + NH;
-                        uint32_t t;
-                        if (lo <= 0 && hi >= PX - 1) t = pre[PX];
-                        else if (lo <= 0) t = pre[hi + 1];
-                        else if (hi >= PX - 1) t = suf[PX - lo];
-                        else t = pre[hi + 1] - pre[lo];
-                        // one VOP2 add per neighbour so that each folds its DPP move (an add3 cannot)
-                        if (lo < 0) { t += from_lane_below(suf[-lo]); asm volatile("" : "+v"(t)); }
-                        if (hi > PX - 1) { t += from_lane_above(pre[hi - (PX - 1)]); asm volatile("" : "+v"(t)); }
-                        hs[p] = t;
-                    }
-                    // vertical sliding window
-#pragma unroll
-                    for (int p = 0; p < PX; p++)
-                    {
-                        v[p] += hs[p];
-                        if (i >= N) v[p] -= ring[i % N][p];
-                        ring[i % N][p] = hs[p];
+                        C[q] += (uint32_t)(d * d);
+                        if (i < RY - 1) hist[i][q] = C[q];
                     }
                     if (i >= N - 1)
                     {
                         const int o = i - (N - 1);
-                        const uint32_t pix = centre[(i - NH) % (NH + 1)];
+                        uint32_t V[PX], pre[PX + 1], suf[PX + 1];
+#pragma unroll
+                        for (int q = 0; q < PX; q++) V[q] = o > 0 ? C[q] - hist[o > 0 ? o - 1 : 0][q] : C[q];
+                        pre[0] = 0; suf[0] = 0;
+#pragma unroll
+                        for (int q = 0; q < PX; q++)
+                        {
+                            pre[q + 1] = pre[q] + V[q];
+                            suf[q + 1] = suf[q] + V[PX - 1 - q];
+                        }
+#pragma unroll
+                        for (int p = 0; p < PX; p++)
+                        {
+                            const int lo = p - NH, hi = p + NH;
+                            uint32_t t;
+                            if (lo <= 0 && hi >= PX - 1) t = pre[PX];
+                            else if (lo <= 0) t = pre[hi + 1];
+                            else if (hi >= PX - 1) t = suf[PX - lo];
+                            else t = pre[hi + 1] - pre[lo];
+                            // one VOP2 add per neighbour so that each folds its DPP move (an add3 cannot)
+                            if (lo < 0) { t += from_lane_below(suf[-lo]); asm volatile("" : "+v"(t)); }
+                            if (hi > PX - 1) { t += from_lane_above(pre[hi - (PX - 1)]); asm volatile("" : "+v"(t)); }
+                            v[p] = t;
+                        }
+                    }
+                    // The table reads issued for the previous output row have had this row's integer
+                    // work to complete: fold them in now, then issue this row's.
+                    if (i >= N)
+                    {
+                        const int o = i - N;
+                        const uint32_t pix = centre[(i - 1 - NH) % (NH + 2)];
+#pragma unroll
+                        for (int pp = 0; pp < PX / 2; pp++)
+                        {
+                            const f2 pv = {(float)(int)byte_of(pix, 2 * pp), (float)(int)byte_of(pix, 2 * pp + 1)};
+                            aw[o][pp] += wq[pp];
+                            ap[o][pp] += wq[pp] * pv;
+                        }
+                    }
+                    if (i >= N - 1)
+                    {
 #pragma unroll
                         for (int pp = 0; pp < PX / 2; pp++)
                         {
@@ -563,13 +575,21 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
                                     idx[e] = min(ix, 127);
                                 }
                             }
-                            const f2 wgt = {s_exp[idx[0]], s_exp[idx[1]]};
-                            const f2 pv = {(float)(int)byte_of(pix, 2 * pp), (float)(int)byte_of(pix, 2 * pp + 1)};
-                            aw[o][pp] += wgt;
-                            ap[o][pp] += wgt * pv;
+                            wq[pp] = f2{s_exp[idx[0]], s_exp[idx[1]]};
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                }
+                {
+                    // last output row of this displacement
+                    const uint32_t pix = centre[(ROWS - 1 - NH) % (NH + 2)];
+#pragma unroll
+                    for (int pp = 0; pp < PX / 2; pp++)
+                    {
+                        const f2 pv = {(float)(int)byte_of(pix, 2 * pp), (float)(int)byte_of(pix, 2 * pp + 1)};
+                        aw[RY - 1][pp] += wq[pp];
+                        ap[RY - 1][pp] += wq[pp] * pv;
+                    }
                 }
             }
         }
