@@ -353,8 +353,6 @@ __global__ __launch_bounds__(TXN * TYN, (VAR & 2) ? 3 : 1) void nlmeans_plane_ke
 // (32-2)*4 = 120 pixels wide; n <= 9 keeps every window inside the adjacent lanes.
 constexpr int LTXA = TXN - 2;            // lanes of a tile row that own output pixels
 constexpr int LTW = LTXA * PX;           // 120
-constexpr int LSPD = 36;                 // LDS pitch in dwords: the two tile rows of a wave are
-                                         // 8 rows apart = 288 dwords = 32 banks apart (no conflicts)
 
 // Stage a (rows x dwords*4)-byte window of `plane` whose top-left pixel is (x0, y0) into LDS
 // (row pitch `pitch` dwords) with the reference's mirrored borders (nlmeans_template.c:29-41).
@@ -374,6 +372,16 @@ __device__ __forceinline__ void load_tile_p(uint32_t *lds, int pitch, int dwords
     const bool whole = x >= 0 && x + 3 < w;
     const int o0 = reflect(x, w), o1 = reflect(x + 1, w), o2 = reflect(x + 2, w), o3 = reflect(x + 3, w);
     uint32_t *out = lds + r0 * pitch + c;
+    if (y0 >= 0 && y0 + rows <= h && x0 >= 0 && x0 + 4 * dwords <= w)
+    {
+        // tile and halo wholly inside the plane (most tiles): no reflection, one pointer bump per row
+        const uint8_t *ptr = plane + (size_t)(y0 + r0) * src_pitch + x;
+        const size_t step = (size_t)rpp * src_pitch;
+#pragma nounroll
+        for (int r = r0; r < rows; r += rpp, out += rpp * pitch, ptr += step)
+            *out = reinterpret_cast<const u32_unaligned *>(ptr)->v;
+        return;
+    }
 #pragma nounroll
     for (int r = r0; r < rows; r += rpp, out += rpp * pitch)
     {
@@ -397,19 +405,23 @@ __device__ __forceinline__ uint32_t from_lane_above(uint32_t x)   // lane l <- l
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
 }
 
-template <int N, bool FAST>
+template <int N, bool FAST, int CPD>
 __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJob *__restrict__ jobs, int njobs,
-                                                                     int cpd, int cmp_rows, int rq)
+                                                                     int cmp_rows, int rq)
 {
     constexpr int NH = N / 2;
-    constexpr int SROWS = TH + 2 * NH;
     constexpr int ROWS = RY + N - 1;
     static_assert(NH <= PX, "patch must not reach past the adjacent lane");
+    static_assert(CPD % 8 == 4, "the two tile rows of a wave must sit 32 banks apart");
 
+    // Two tiles of CPD x cmp_rows dwords: s_t0 holds frame 0 with the patch + search halo for the
+    // whole kernel (it is both the source patch tile and the compare tile of f = 0), s_tc the
+    // following frames in turn.  CPD is a template constant so every LDS read in the row walk
+    // uses an immediate offset.
     extern __shared__ uint32_t smem[];
-    uint32_t *s_src = smem;
-    uint32_t *s_cmp = smem + LSPD * SROWS;
-    float *s_exp = reinterpret_cast<float *>(s_cmp + cpd * cmp_rows + 4);
+    uint32_t *s_t0 = smem;
+    uint32_t *s_tc = smem + CPD * cmp_rows + 4;
+    float *s_exp = reinterpret_cast<float *>(s_tc + CPD * cmp_rows + 4);
 
     int j = 0;
     while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].tile_start) j++;
@@ -425,8 +437,11 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
     const int ty = threadIdx.x / TXN;
 
     if (threadIdx.x < 128) s_exp[threadIdx.x] = job.exptable[threadIdx.x];
-    // lane tx holds the source pixels tx0 + 4*(tx-1) .. +3: the tile starts one lane left of tx0
-    load_tile_p(s_src, LSPD, TXN, SROWS, job.frame[0], job.fpitch[0], w, h, tx0 - PX, ty0 - NH);
+    // lane tx holds the source pixels tx0 + 4*(tx-1) .. +3: the tiles start one lane (and rq
+    // dwords of search halo) left of tx0
+    load_tile_p(s_t0, CPD, CPD, cmp_rows, job.frame[0], job.fpitch[0], w, h,
+                tx0 - PX - 4 * rq, ty0 - NH - RH);
+    const uint32_t *own = s_t0 + (ty * RY + RH) * CPD + tx + rq;   // this lane's source dwords, row 0 of its walk
 
     // weight / weighted-pixel accumulators as float pairs: the adds and the w*pixel product
     // below are packed (v_pk_add_f32 / v_pk_mul_f32, each lane of a pair rounded like the scalar op)
@@ -446,11 +461,15 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
 
     for (int f = 0; f < job.nframes; f++)
     {
-        __syncthreads();
-        load_tile_p(s_cmp, cpd, cpd, cmp_rows, job.frame[f], job.fpitch[f], w, h,
-                    tx0 - PX - 4 * rq, ty0 - NH - RH);
+        if (f > 0)
+        {
+            __syncthreads();   // everyone is done with the previous compare tile
+            load_tile_p(s_tc, CPD, CPD, cmp_rows, job.frame[f], job.fpitch[f], w, h,
+                        tx0 - PX - 4 * rq, ty0 - NH - RH);
+        }
         __syncthreads();
         if (!wave_live) continue;
+        const uint32_t *cmp_tile = f > 0 ? s_tc : s_t0;
 
         for (int dy = -RH; dy <= RH; dy++)
         {
@@ -461,7 +480,7 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
 #pragma unroll
                     for (int o = 0; o < RY; o++)
                     {
-                        const uint32_t cpx = s_src[(ty * RY + o + NH) * LSPD + tx];
+                        const uint32_t cpx = own[(o + NH) * CPD];
 #pragma unroll
                         for (int p = 0; p < PX; p++)
                         {
@@ -475,8 +494,8 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
 
                 const int s = dx + 4 * rq;                   // >= 0, wave-uniform
                 const int sh = s & 3;
-                const uint32_t *srow = s_src + (ty * RY) * LSPD + tx;
-                const uint32_t *crow = s_cmp + (ty * RY + dy + RH) * cpd + tx + (s >> 2);
+                const uint32_t *srow = own;
+                const uint32_t *crow = cmp_tile + (ty * RY + dy + RH) * CPD + tx + (s >> 2);
 
                 // Column sums first: C[q] is the running (prefix) sum down this lane's 4 columns of the
                 // squared differences, hist[] keeps the first RY-1 of them, so the n-row window sum of
@@ -496,9 +515,9 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
                     const uint32_t bw = __builtin_amdgcn_alignbyte(b_n1, b_n0, sh);
                     if (i + 1 < ROWS)
                     {
-                        a_n = srow[(i + 1) * LSPD];
-                        b_n0 = crow[(i + 1) * cpd];
-                        b_n1 = crow[(i + 1) * cpd + 1];
+                        a_n = srow[(i + 1) * CPD];
+                        b_n0 = crow[(i + 1) * CPD];
+                        b_n1 = crow[(i + 1) * CPD + 1];
                     }
                     centre[i % (NH + 2)] = bw;
 #pragma unroll
@@ -604,7 +623,7 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
         const int y = ty0 + ty * RY + o;
         if (y >= h) break;
         uint32_t packed = 0;
-        const uint32_t cpx = s_src[(ty * RY + o + NH) * LSPD + tx];
+        const uint32_t cpx = own[(o + NH) * CPD];
 #pragma unroll
         for (int p = 0; p < PX; p++)
         {
@@ -810,12 +829,14 @@ private:
             dim3 grid(tiles), block(TXN * TYN);
             if (variant >= 4)
             {
-                // compare tile: 32 lanes + rq dwords of search halo either side, pitch = 4 (mod 8)
+                // tiles: 32 lanes + rq dwords of search halo either side (+1 for the alignbyte high
+                // word), pitch = 4 (mod 8) dwords
                 const int rq = (max_rh + 3) / 4;
-                const int cpd = (32 + 2 * rq + 1 + 3) / 8 * 8 + 4;
-                const size_t shmem = sizeof(uint32_t) * (LSPD * (TH + 2 * nh) + cpd * cmp_rows + 4) + 512;
-#define NLM_GO(NN, FF) HBHIP_LAUNCH(ctx, "nlmeans_plane_n" #NN, (nlmeans_lanes_kernel<NN, FF>), grid, block, shmem, dj, nj, cpd, cmp_rows, rq)
-#define NLM_VAR(NN) do { if (fast) NLM_GO(NN, true); else NLM_GO(NN, false); } while (0)
+                const int cpd = rq <= 1 ? 36 : 44;
+                const size_t shmem = sizeof(uint32_t) * 2 * (cpd * cmp_rows + 4) + 512;
+#define NLM_GO(NN, FF, CC) HBHIP_LAUNCH(ctx, "nlmeans_plane_n" #NN, (nlmeans_lanes_kernel<NN, FF, CC>), grid, block, shmem, dj, nj, cmp_rows, rq)
+#define NLM_VAR(NN) do { if (cpd == 36) { if (fast) NLM_GO(NN, true, 36); else NLM_GO(NN, false, 36); } \
+                         else { if (fast) NLM_GO(NN, true, 44); else NLM_GO(NN, false, 44); } } while (0)
                 switch (n)
                 {
                     case 3: NLM_VAR(3); break;

@@ -71,6 +71,10 @@ def test_random_noise_input(built):
     ("y-strength=6:y-origin-tune=0.8:y-patch-size=7:y-range=3:y-frame-count=2:"
      "cb-strength=6:cb-origin-tune=0.7:cb-patch-size=7:cb-range=5:cb-frame-count=1",
      [par(6, 0.8, 7, 3, 2), par(6, 0.7, 7, 5, 1), par(6, 0.7, 7, 5, 1)]),          # tune=highmotion
+    # widest patch the kernel takes and a search range that needs the wide (44-dword) LDS tiles
+    ("y-strength=8:y-origin-tune=0.5:y-patch-size=9:y-range=11:y-frame-count=3:"
+     "cb-strength=2:cb-origin-tune=1:cb-patch-size=3:cb-range=9:cb-frame-count=1",
+     [par(8, 0.5, 9, 11, 3), par(2, 1.0, 3, 9, 1), par(2, 1.0, 3, 9, 1)]),
 ])
 def test_tunes_bit_exact(built, settings, pp):
     frames = synth.stream("progressive", 192, 108, 6)
