@@ -273,12 +273,14 @@ def main():
         algo_bytes = ALGO_BYTES_PER_FRAME * frames_per_launch
         achieved = algo_bytes / avg_s / 1e9
         traffic = None
+        valu_insts = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc)).get(kname, {}).get(str(B))
                 if rec:
                     traffic = rec["hbm_bytes_per_launch"]
+                    valu_insts = rec.get("valu_insts_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -304,9 +306,17 @@ def main():
                          "traffic": traffic,
                          "launch_us": round(avg_s * 1e6, 2), "launches": launches,
                          "algorithmic_bytes_per_launch": int(algo_bytes),
-                         "note": "NLMeans is VALU-bound (about 430 integer/float lane-ops per byte-pixel); "
-                                 "see DESIGN.md for the VALU roofline of this kernel"},
+                         "note": "NLMeans is VALU-bound (about 320 integer/float lane-ops per pixel); "
+                                 "'valu' prices the same launch against the vector-ALU issue rate"},
         }
+        if valu_insts:
+            # wave64 VALU instructions (SQ_INSTS_VALU of the committed PMC pass) against the issue
+            # peak: 256 CUs x 4 SIMDs, one wave64 instruction per 4 cycles, 2.4 GHz
+            peak = 256 * 4 * 2.4e9 / 4
+            out["roofline"]["valu"] = {"insts_per_launch": int(valu_insts),
+                                       "achieved_ginst_s": round(valu_insts / avg_s / 1e9, 1),
+                                       "peak_ginst_s": round(peak / 1e9, 1),
+                                       "frac": round(valu_insts / avg_s / peak, 4)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames_np)
         print(json.dumps(out), flush=True)

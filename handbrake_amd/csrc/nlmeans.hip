@@ -13,16 +13,17 @@
 //            weight_sum += w ; pixel_sum += w * cmp(+dx,+dy)         (:692-693)
 //   out = (u8)(pixel_sum / weight_sum), 0 -> source pixel            (:710-711)
 //
-// GPU mapping (no integral image): one workgroup owns a 128 x 64 tile.  The
-// source tile (+patch halo) and, per temporal frame, the compare tile (+patch
-// +search halo) are staged in LDS with the reference's mirrored borders applied
-// by index reflection (nlmeans_template.c:29-41), so no bordered copy of the
-// frame is ever materialised in HBM.  Each thread owns 4 adjacent columns x 8
-// rows: per displacement it walks 8+n-1 rows, forms the squared differences of
-// its 4+n-1 byte window, reduces them to 4 horizontal n-sums, and keeps a
-// vertical sliding n-row sum in registers; weight/pixel accumulators for its 32
-// pixels live in registers across all displacements and frames.  HBM traffic is
-// therefore ~(nframes + 1) bytes per pixel; the kernel is VALU-bound.
+// GPU mapping (no integral image): one workgroup (32 x 8 lanes) owns a 120 x 64 tile.  Frame 0's
+// tile with the patch + search halo stays in LDS for the whole kernel (it is the source patch tile
+// and the compare tile of f = 0); each following frame's tile is staged in turn; the reference's
+// mirrored borders (nlmeans_template.c:29-41) are applied by index reflection while staging, so no
+// bordered copy of a frame is ever materialised in HBM.  A lane owns 4 adjacent columns x 8 rows.
+// Per displacement it walks 8+n-1 rows keeping prefix sums of the squared differences down its own
+// 4 columns; on each of its 8 output rows the n-row column sums are combined into the 4 horizontal
+// n-sums with DPP wave shifts (the needed prefix / suffix sums of the neighbouring lanes), so no
+// square is computed twice along x.  Weight / pixel accumulators of the 32 pixels live in registers
+// across all displacements and frames.  HBM traffic is ~(nframes + 1) bytes per pixel; the kernel
+// is VALU-bound (see DESIGN.md for the instruction budget).
 #include "hbhip_internal.h"
 
 #include <algorithm>
@@ -33,7 +34,6 @@ constexpr int PX = 4;            // pixels per thread along x (one dword)
 constexpr int RY = 8;            // rows per thread
 constexpr int TXN = 32;          // threads along x
 constexpr int TYN = 8;           // threads along y
-constexpr int TW = TXN * PX;     // 128
 constexpr int TH = TYN * RY;     // 64
 constexpr int NLM_BORDER = 16;   // nlmeans.c:529 for every patch size <= 29
 
@@ -64,289 +64,11 @@ __device__ __forceinline__ int reflect(int x, int n)
     return min(max(x, 0), n - 1);
 }
 
-// Stage a (rows x dwords*4) byte window of `plane`, whose top-left pixel is
-// (x0, y0), into LDS as packed dwords.
-__device__ __forceinline__ void load_tile(uint32_t *lds, int dwords, int rows,
-                                          const uint8_t *__restrict__ plane, int pitch,
-                                          int w, int h, int x0, int y0)
-{
-    const int total = dwords * rows;
-    // The index math below depends only on the thread id; hide that from LICM, which
-    // otherwise precomputes it for every iteration and parks ~120 VGPRs across the
-    // whole displacement loop (occupancy 2 -> 3+).
-    int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));
-#pragma nounroll
-    for (int i = tid; i < total; i += TXN * TYN)
-    {
-        const int r = i / dwords;
-        const int c = i - r * dwords;
-        const int y = reflect(y0 + r, h);
-        const int x = x0 + 4 * c;
-        const uint8_t *row = plane + (size_t)y * pitch;
-        uint32_t v;
-        if (x >= 0 && x + 3 < w)
-        {
-            v = reinterpret_cast<const u32_unaligned *>(row + x)->v;
-        }
-        else
-        {
-            v = (uint32_t)row[reflect(x, w)] | ((uint32_t)row[reflect(x + 1, w)] << 8) |
-                ((uint32_t)row[reflect(x + 2, w)] << 16) | ((uint32_t)row[reflect(x + 3, w)] << 24);
-        }
-        lds[i] = v;
-    }
-}
-
 __device__ __forceinline__ uint32_t byte_of(uint32_t v, int k) { return (v >> (8 * k)) & 0xffu; }
 
-// VAR bit 0: software-prefetch the next row's LDS words; bit 1: ask for 3 waves/SIMD.
-// FAST: the gate `diff < diff_max` (nlmeans_template.c:685) is folded into a clamp of diff to
-// diff_cap, the smallest diff whose table index is 127 (= weight 0, nlmeans.c:358); the host
-// only selects it when that is exactly equivalent (diff_cap <= diff_max and index(diff_cap) == 127).
-template <int N, int VAR, bool FAST>
-__global__ __launch_bounds__(TXN * TYN, (VAR & 2) ? 3 : 1) void nlmeans_plane_kernel(const NlmJob *__restrict__ jobs, int njobs,
-                                                                  int cmp_dwords, int cmp_rows)
-{
-    constexpr int NH = N / 2;
-    constexpr int W = PX + 2 * NH;          // bytes of a thread's row window
-    constexpr int ND = (W + 3) / 4;         // dwords covering it when aligned
-    constexpr int SPD = TXN + ND;           // src tile pitch (dwords)
-    constexpr int SROWS = TH + 2 * NH;
-    constexpr int ROWS = RY + N - 1;        // rows a thread walks per displacement
-
-    extern __shared__ uint32_t smem[];
-    uint32_t *s_src = smem;
-    uint32_t *s_cmp = smem + SPD * SROWS;
-    float *s_exp = reinterpret_cast<float *>(s_cmp + cmp_dwords * cmp_rows);
-
-    // which (frame, plane) job does this tile belong to?
-    int j = 0;
-    while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].tile_start) j++;
-    const NlmJob &job = jobs[j];
-    const int tile = blockIdx.x - job.tile_start;
-    const int tile_y = tile / job.tiles_x;
-    const int tile_x = tile - tile_y * job.tiles_x;
-    const int tx0 = tile_x * TW, ty0 = tile_y * TH;
-    const int w = job.w, h = job.h;
-    const int RH = job.r_half;
-    const int HALO = NH + RH;
-    const int CPD = cmp_dwords;
-
-    const int tx = threadIdx.x & (TXN - 1);
-    const int ty = threadIdx.x / TXN;
-
-    if (threadIdx.x < 128) s_exp[threadIdx.x] = job.exptable[threadIdx.x];
-    load_tile(s_src, SPD, SROWS, job.frame[0], job.fpitch[0], w, h, tx0 - NH, ty0 - NH);
-
-    float aw[RY][PX], ap[RY][PX];
-#pragma unroll
-    for (int o = 0; o < RY; o++)
-#pragma unroll
-        for (int p = 0; p < PX; p++) { aw[o][p] = 0.f; ap[o][p] = 0.f; }
-
-    // The 4 centre pixels of output row o of the frame being filtered (origin term, zero
-    // fallback).  They stay in the source tile for the whole kernel, so they are re-read
-    // from LDS in the two cold places that need them instead of occupying 8 VGPRs.
-    auto centre4 = [&](int o) -> uint32_t {
-        const uint32_t *c = s_src + (ty * RY + o + NH) * SPD + tx;
-        return __builtin_amdgcn_alignbyte(c[(NH >> 2) + 1], c[NH >> 2], NH & 3);
-    };
-
-    const float wft = job.wft;
-    const int diff_max = job.diff_max;
-    const int diff_cap = job.diff_cap;
-    const double origin_tune = job.origin_tune;
-
-    for (int f = 0; f < job.nframes; f++)
-    {
-        __syncthreads();   // everyone is done with the previous compare tile
-        load_tile(s_cmp, CPD, cmp_rows, job.frame[f], job.fpitch[f], w, h, tx0 - HALO, ty0 - HALO);
-        __syncthreads();
-
-        for (int dy = -RH; dy <= RH; dy++)
-        {
-            for (int dx = -RH; dx <= RH; dx++)
-            {
-                if (f == 0 && dx == 0 && dy == 0)
-                {
-#pragma unroll
-                    for (int o = 0; o < RY; o++)
-                    {
-                        const uint32_t cpx = centre4(o);
-#pragma unroll
-                        for (int p = 0; p < PX; p++)
-                        {
-                            aw[o][p] = (float)((double)aw[o][p] + origin_tune);
-                            ap[o][p] = (float)((double)ap[o][p] + origin_tune * (double)(int)byte_of(cpx, p));
-                            // executed once per tile: one pixel's f64 temporaries at a time, so that this
-                            // cold block does not push the kernel over the 168-VGPR (3 waves/SIMD) line
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    }
-                    continue;
-                }
-
-                const int s = dx + RH;                       // 0 .. 2RH, uniform
-                const int sh = s & 3;
-                const uint32_t *srow = s_src + (ty * RY) * SPD + tx;
-                const uint32_t *crow = s_cmp + (ty * RY + dy + RH) * CPD + tx + (s >> 2);
-                const int sp = s + NH;                       // byte offset of the centre pixels
-                const uint32_t *prow = s_cmp + (ty * RY + dy + RH + NH) * CPD + tx + (sp >> 2);
-                const int psh = sp & 3;
-
-                uint32_t ring[N][PX];
-                uint32_t v[PX];
-#pragma unroll
-                for (int p = 0; p < PX; p++) v[p] = 0;
-
-                uint32_t a_n[ND], b_n[ND + 1];
-                if (VAR & 1)
-                {
-#pragma unroll
-                    for (int k = 0; k < ND; k++) a_n[k] = srow[k];
-#pragma unroll
-                    for (int k = 0; k <= ND; k++) b_n[k] = crow[k];
-                }
-#pragma unroll
-                for (int i = 0; i < ROWS; i++)
-                {
-                    // squared differences over this row's window
-                    uint32_t a[ND], b[ND + 1];
-                    if (VAR & 1)
-                    {
-#pragma unroll
-                        for (int k = 0; k < ND; k++) a[k] = a_n[k];
-#pragma unroll
-                        for (int k = 0; k <= ND; k++) b[k] = b_n[k];
-                        if (i + 1 < ROWS)
-                        {
-#pragma unroll
-                            for (int k = 0; k < ND; k++) a_n[k] = srow[(i + 1) * SPD + k];
-#pragma unroll
-                            for (int k = 0; k <= ND; k++) b_n[k] = crow[(i + 1) * CPD + k];
-                        }
-                    }
-                    else
-                    {
-#pragma unroll
-                        for (int k = 0; k < ND; k++) a[k] = srow[i * SPD + k];
-#pragma unroll
-                        for (int k = 0; k <= ND; k++) b[k] = crow[i * CPD + k];
-                    }
-                    uint32_t D[W];
-#pragma unroll
-                    for (int q = 0; q < W; q++)
-                    {
-                        const uint32_t bw = __builtin_amdgcn_alignbyte(b[q / 4 + 1], b[q / 4], sh);
-                        const int d = (int)byte_of(a[q / 4], q & 3) - (int)byte_of(bw, q & 3);
-                        D[q] = (uint32_t)(d * d);
-                    }
-                    // horizontal n-sums for the 4 pixels
-                    uint32_t hs[PX];
-                    if (N >= PX)
-                    {
-                        uint32_t core = 0;
-#pragma unroll
-                        for (int q = PX - 1; q < N; q++) core += D[q];
-#pragma unroll
-                        for (int p = 0; p < PX; p++)
-                        {
-                            uint32_t t = core;
-#pragma unroll
-                            for (int q = p; q < PX - 1; q++) t += D[q];
-#pragma unroll
-                            for (int q = N; q < N + p; q++) t += D[q];
-                            hs[p] = t;
-                        }
-                    }
-                    else
-                    {
-#pragma unroll
-                        for (int p = 0; p < PX; p++)
-                        {
-                            uint32_t t = 0;
-#pragma unroll
-                            for (int q = p; q < p + N; q++) t += D[q];
-                            hs[p] = t;
-                        }
-                    }
-                    // vertical sliding window
-#pragma unroll
-                    for (int p = 0; p < PX; p++)
-                    {
-                        v[p] += hs[p];
-                        if (i >= N) v[p] -= ring[i % N][p];
-                        ring[i % N][p] = hs[p];
-                    }
-                    if (i >= N - 1)
-                    {
-                        const int o = i - (N - 1);
-                        const uint32_t pix = __builtin_amdgcn_alignbyte(prow[o * CPD + 1], prow[o * CPD], psh);
-#pragma unroll
-                        for (int p = 0; p < PX; p++)
-                        {
-                            int idx;
-                            if (FAST)
-                            {
-                                idx = (int)((float)(int)min(v[p], (uint32_t)diff_cap) * wft);
-                            }
-                            else
-                            {
-                                const int diff = (int)v[p];
-                                idx = (int)((float)diff * wft);
-                                idx = diff < diff_max ? idx : 127;
-                                idx = min(idx, 127);
-                            }
-                            const float wgt = s_exp[idx];
-                            const float pv = (float)(int)byte_of(pix, p);
-                            aw[o][p] += wgt;
-                            ap[o][p] += wgt * pv;
-                        }
-                    }
-                    // keep the scheduler from hoisting every row's LDS reads to the
-                    // top of the unrolled walk (that costs ~250 VGPRs + spills)
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-    }
-
-    // normalise + store
-    const int x = tx0 + tx * PX;
-    if (x >= w) return;
-#pragma unroll
-    for (int o = 0; o < RY; o++)
-    {
-        const int y = ty0 + ty * RY + o;
-        if (y >= h) break;
-        uint32_t packed = 0;
-        const uint32_t cpx = centre4(o);
-#pragma unroll
-        for (int p = 0; p < PX; p++)
-        {
-            const float q = ap[o][p] / aw[o][p];
-            uint32_t r = (uint32_t)(int)q & 0xffu;
-            if (r == 0) r = byte_of(cpx, p);
-            packed |= r << (8 * p);
-            __builtin_amdgcn_sched_barrier(0);       // one IEEE division sequence at a time (register pressure)
-        }
-        uint8_t *out = job.dst + (size_t)y * job.dst_pitch + x;
-        if (x + 3 < w)
-        {
-            *reinterpret_cast<uint32_t *>(out) = packed;
-        }
-        else
-        {
-            for (int p = 0; p < PX && x + p < w; p++) out[p] = (uint8_t)(packed >> (8 * p));
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
-// Lane-sharing variant (the default).  In the kernel above every thread squares the differences of
-// its whole 4+n-1 byte window, i.e. (4+n-1)/4 of the work is redone by its neighbours.  Here a lane
-// squares only its own 4 bytes per row, forms the prefix / suffix sums of those 4 squares, and the
+// Lane sharing.  A thread that squared the differences of its whole 4+n-1 byte window would redo
+// (n-1)/4 of its neighbours' work.  Here a lane squares only its own 4 bytes per row, and the
 // horizontal n-sums are completed with DPP wave shifts: pixel p of lane l needs the last
 // (n/2 - p) squares of lane l-1 and the first (p + n/2 - 3) squares of lane l+1.  The two outer
 // lanes of each 32-lane tile row only feed their neighbours (they own no output), so a tile is
@@ -690,7 +412,6 @@ public:
             if (par.nframes[c] < 1 || par.nframes[c] > HBHIP_NLMEANS_FRAMES_MAX) return HBHIP_ERR_ARG;
             if (in_geo.pw[c] < NLM_BORDER || in_geo.ph[c] < NLM_BORDER) return HBHIP_ERR_UNSUPPORTED;
         }
-        if (const char *e = getenv("HBHIP_NLM_VARIANT")) variant = atoi(e);
         for (int c = 0; c < 3; c++)
         {
             // smallest diff whose index reaches 127; usable only if that index is exactly 127,
@@ -734,7 +455,6 @@ public:
     void recycle_output(DevPicture *p) override { pool.release(p); }
 
     int batch = 1;
-    int variant = 4;      // 4: lane-sharing kernel; 0/3: per-thread-window kernel (HBHIP_NLM_VARIANT)
     int diff_cap[3] = {-1, -1, -1};
 
 private:
@@ -792,7 +512,6 @@ private:
             NlmJob *dj = d_jobs + (size_t)table * jobs_cap;
             int nj = 0, tiles = 0, max_rh = 0;
             bool fast = true;
-            const int tile_w = variant >= 4 ? LTW : TW;
             for (int t = 0; t < ready; t++)
                 for (int c = 0; c < 3; c++)
                 {
@@ -815,7 +534,7 @@ private:
                     jb.h = in_geo.ph[c];
                     jb.dst_pitch = outs[t].pitch[c];
                     jb.r_half = (par.range[c] - 1) / 2;
-                    jb.tiles_x = (jb.w + tile_w - 1) / tile_w;
+                    jb.tiles_x = (jb.w + LTW - 1) / LTW;
                     jb.tile_start = tiles;
                     tiles += jb.tiles_x * ((jb.h + TH - 1) / TH);
                     max_rh = std::max(max_rh, jb.r_half);
@@ -827,44 +546,29 @@ private:
             const int nh = n / 2;
             const int cmp_rows = TH + 2 * (nh + max_rh);
             dim3 grid(tiles), block(TXN * TYN);
-            if (variant >= 4)
-            {
-                // tiles: 32 lanes + rq dwords of search halo either side (+1 for the alignbyte high
-                // word), pitch = 4 (mod 8) dwords
-                const int rq = (max_rh + 3) / 4;
-                const int cpd = rq <= 1 ? 36 : 44;
-                const size_t shmem = sizeof(uint32_t) * 2 * (cpd * cmp_rows + 4) + 512;
-#define NLM_GO(NN, FF, CC) HBHIP_LAUNCH(ctx, "nlmeans_plane_n" #NN, (nlmeans_lanes_kernel<NN, FF, CC>), grid, block, shmem, dj, nj, cmp_rows, rq)
+            // tiles: 32 lanes + rq dwords of search halo either side (+1 for the alignbyte high
+            // word), pitch = 4 (mod 8) dwords
+            const int rq = (max_rh + 3) / 4;
+            const int cpd = rq <= 1 ? 36 : 44;
+            const size_t shmem = sizeof(uint32_t) * 2 * (cpd * cmp_rows + 4) + 512;
+            // the widest search ranges need more than the default 64 KB of dynamic LDS
+#define NLM_GO(NN, FF, CC) do { \
+                if (shmem > 65536) \
+                    HBHIP_CHECK(ctx, hipFuncSetAttribute((const void *)nlmeans_lanes_kernel<NN, FF, CC>, \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
+                HBHIP_LAUNCH(ctx, "nlmeans_plane_n" #NN, (nlmeans_lanes_kernel<NN, FF, CC>), grid, block, shmem, dj, nj, cmp_rows, rq); \
+            } while (0)
 #define NLM_VAR(NN) do { if (cpd == 36) { if (fast) NLM_GO(NN, true, 36); else NLM_GO(NN, false, 36); } \
-                         else { if (fast) NLM_GO(NN, true, 44); else NLM_GO(NN, false, 44); } } while (0)
-                switch (n)
-                {
-                    case 3: NLM_VAR(3); break;
-                    case 5: NLM_VAR(5); break;
-                    case 7: NLM_VAR(7); break;
-                    case 9: NLM_VAR(9); break;
-                }
-#undef NLM_VAR
-#undef NLM_GO
-            }
-            else
+                     else { if (fast) NLM_GO(NN, true, 44); else NLM_GO(NN, false, 44); } } while (0)
+            switch (n)
             {
-                const int W = PX + 2 * nh, ND = (W + 3) / 4;
-                const int cmp_dwords = TXN + ND + (2 * max_rh) / 4 + 2;
-                const size_t shmem = sizeof(uint32_t) * ((TXN + ND) * (TH + 2 * nh) + cmp_dwords * cmp_rows) + 512;
-#define NLM_GO(NN, VV, FF) HBHIP_LAUNCH(ctx, "nlmeans_plane_n" #NN, (nlmeans_plane_kernel<NN, VV, FF>), grid, block, shmem, dj, nj, cmp_dwords, cmp_rows)
-#define NLM_VAR(NN) do { if (variant == 0) { if (fast) NLM_GO(NN, 0, true); else NLM_GO(NN, 0, false); } \
-                         else { if (fast) NLM_GO(NN, 3, true); else NLM_GO(NN, 3, false); } } while (0)
-                switch (n)
-                {
-                    case 3: NLM_VAR(3); break;
-                    case 5: NLM_VAR(5); break;
-                    case 7: NLM_VAR(7); break;
-                    case 9: NLM_VAR(9); break;
-                }
+                case 3: NLM_VAR(3); break;
+                case 5: NLM_VAR(5); break;
+                case 7: NLM_VAR(7); break;
+                case 9: NLM_VAR(9); break;
+            }
 #undef NLM_VAR
 #undef NLM_GO
-            }
             HBHIP_CHECK(ctx, hipGetLastError());
         }
 

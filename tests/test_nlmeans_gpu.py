@@ -75,6 +75,9 @@ def test_random_noise_input(built):
     ("y-strength=8:y-origin-tune=0.5:y-patch-size=9:y-range=11:y-frame-count=3:"
      "cb-strength=2:cb-origin-tune=1:cb-patch-size=3:cb-range=9:cb-frame-count=1",
      [par(8, 0.5, 9, 11, 3), par(2, 1.0, 3, 9, 1), par(2, 1.0, 3, 9, 1)]),
+    # the largest search range the reference's 16-pixel border admits with patch 3 (> 64 KB of LDS)
+    ("y-strength=4:y-origin-tune=1:y-patch-size=3:y-range=29:y-frame-count=2:cb-strength=0",
+     [par(4, 1.0, 3, 29, 2), par(0), par(0)]),
 ])
 def test_tunes_bit_exact(built, settings, pp):
     frames = synth.stream("progressive", 192, 108, 6)
