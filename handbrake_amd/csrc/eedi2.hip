@@ -786,10 +786,14 @@ __global__ void k_post(P3 P, int y0)
 
 // ------------------------------------------------------------------- engine
 Eedi2Engine::Eedi2Engine(hbhip_ctx *ctx, const PicGeometry &geo, const Eedi2Params &p)
-    : ctx_(ctx), geo_(geo), par_(p) {}
+    : ctx_(ctx), geo_(geo), par_(p)
+{
+    use_graph_ = getenv("HBHIP_NO_GRAPH") == nullptr;
+}
 
 Eedi2Engine::~Eedi2Engine()
 {
+    for (auto &g : graph_) if (g) (void)hipGraphExecDestroy(g);
     for (auto &f : half_) if (f.alloc) (void)hipFree(f.alloc);
     for (auto &f : full_) if (f.alloc) (void)hipFree(f.alloc);
     if (work_list_) (void)hipFree(work_list_);
@@ -848,6 +852,63 @@ int Eedi2Engine::init()
 
 int Eedi2Engine::run(const DevPicture *cur, int tff)
 {
+    EediFrame &srcp = half_[0], &dst2p = full_[0];
+    P3 P;
+    memset(&P, 0, sizeof(P));
+
+    // field extraction (decomb_template.c:455-473)
+    for (int c = 0; c < 3; c++)
+    {
+        P.pitch[c] = srcp.stride[c]; P.width[c] = srcp.width[c]; P.height[c] = srcp.height[c];
+        P.a[c] = cur->plane[c];
+        P.b[c] = srcp.plane[c];
+    }
+    {
+        int rows[3];
+        for (int c = 0; c < 3; c++) rows[c] = (dst2p.height[c] + 1) / 2;
+        HBHIP_LAUNCH(ctx_, "eedi2_fill_half", k_fill_half,
+                     dim3((srcp.stride[0] + 63) / 64, (srcp.height[0] + 3) / 4, 3), dim3(64, 4), 0, P,
+                     cur->pitch[0], cur->pitch[1], cur->pitch[2], !tff, rows[0], rows[1], rows[2]);
+    }
+    HBHIP_CHECK(ctx_, hipGetLastError());
+
+    // Everything after the field extraction only touches this engine's own scratch frames, so
+    // the ~22 launches of a field are identical from frame to frame (per field parity): they are
+    // captured once into a hipGraph and replayed, which removes the per-launch submission gaps.
+    // The per-kernel profiler needs individual launches, so it bypasses the graph.
+    if (ctx_->profile || !use_graph_) return enqueue_passes(tff);
+    hipGraphExec_t &exec = graph_[tff ? 1 : 0];
+    if (!exec)
+    {
+        hipGraph_t g = nullptr;
+        HBHIP_CHECK(ctx_, hipStreamBeginCapture(ctx_->stream, hipStreamCaptureModeThreadLocal));
+        const int rc = enqueue_passes(tff);
+        const hipError_t e = hipStreamEndCapture(ctx_->stream, &g);
+        if (rc != HBHIP_OK || e != hipSuccess || !g)
+        {
+            if (g) (void)hipGraphDestroy(g);
+            use_graph_ = false;                      // fall back to plain launches for good
+            (void)hipGetLastError();
+            return enqueue_passes(tff);
+        }
+        const hipError_t ie = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (ie != hipSuccess)
+        {
+            exec = nullptr;
+            use_graph_ = false;
+            (void)hipGetLastError();
+            return enqueue_passes(tff);
+        }
+    }
+    HBHIP_CHECK(ctx_, hipGraphLaunch(exec, ctx_->stream));
+    return HBHIP_OK;
+}
+
+// The pass sequence of eedi2_interpolate_plane (decomb_template.c:366-441) for the 3 planes, from
+// the edge mask to the post-processing, on the engine's scratch frames.
+int Eedi2Engine::enqueue_passes(int tff)
+{
     EediFrame &srcp = half_[0], &mskp = half_[1], &tmpp = half_[2], &dstp = half_[3];
     EediFrame &dst2p = full_[0], &tmp2p2 = full_[1], &msk2p = full_[2], &tmp2p = full_[3], &dst2mp = full_[4];
     const dim3 blk(64, 4);
@@ -863,16 +924,6 @@ int Eedi2Engine::run(const DevPicture *cur, int tff)
     P3 P;
     memset(&P, 0, sizeof(P));
 
-    // field extraction (decomb_template.c:455-473)
-    geom(P, srcp);
-    for (int c = 0; c < 3; c++) P.a[c] = cur->plane[c];
-    bind(P.b, srcp);
-    {
-        int rows[3];
-        for (int c = 0; c < 3; c++) rows[c] = (dst2p.height[c] + 1) / 2;
-        HBHIP_LAUNCH(ctx_, "eedi2_fill_half", k_fill_half, grid_for(srcp, true), blk, 0, P,
-                     cur->pitch[0], cur->pitch[1], cur->pitch[2], !tff, rows[0], rows[1], rows[2]);
-    }
     // half-height passes
     geom(P, srcp);
     bind(P.a, srcp); bind(P.b, mskp);

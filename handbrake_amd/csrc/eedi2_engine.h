@@ -42,6 +42,9 @@ public:
 
 private:
     int alloc_frame(EediFrame &f, int width, int height);
+    int enqueue_passes(int tff);                   // everything after the field extraction
+    hipGraphExec_t graph_[2] = {nullptr, nullptr}; // captured pass sequence per field parity
+    bool        use_graph_ = true;
     hbhip_ctx  *ctx_;
     PicGeometry geo_;
     Eedi2Params par_;

@@ -27,6 +27,7 @@
 #include "hbhip_internal.h"
 
 #include <algorithm>
+#include <unordered_map>
 
 namespace {
 
@@ -41,6 +42,13 @@ struct NlmJob
 {
     const uint8_t *frame[HBHIP_NLMEANS_FRAMES_MAX];
     int            fpitch[HBHIP_NLMEANS_FRAMES_MAX];   // row pitch of each temporal frame
+    // prefilter != 0 only (nlmeans_template.c:428-543): the prefiltered twin of every frame, which
+    // the patch distances are taken on, and the plane frame 0's patches are read from (src_pre,
+    // latched at :615 -- the raw frame until the frame has been prefiltered by an earlier call)
+    const uint8_t *frame_pre[HBHIP_NLMEANS_FRAMES_MAX];
+    int            ppitch[HBHIP_NLMEANS_FRAMES_MAX];
+    const uint8_t *src_pre;
+    int            src_pre_pitch;
     uint8_t       *dst;
     const float   *exptable;
     double         origin_tune;
@@ -127,7 +135,7 @@ __device__ __forceinline__ uint32_t from_lane_above(uint32_t x)   // lane l <- l
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
 }
 
-template <int N, bool FAST, int CPD>
+template <int N, bool FAST, int CPD, bool PRE>
 __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJob *__restrict__ jobs, int njobs,
                                                                      int cmp_rows, int rq)
 {
@@ -136,17 +144,28 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
     static_assert(NH <= PX, "patch must not reach past the adjacent lane");
     static_assert(CPD % 8 == 4, "the two tile rows of a wave must sit 32 banks apart");
 
-    // Two tiles of CPD x cmp_rows dwords: s_t0 holds frame 0 with the patch + search halo for the
-    // whole kernel (it is both the source patch tile and the compare tile of f = 0), s_tc the
-    // following frames in turn.  CPD is a template constant so every LDS read in the row walk
-    // uses an immediate offset.
+    // Tiles of CPD x cmp_rows dwords.  Without a prefilter: s_t0 holds frame 0 with the patch +
+    // search halo for the whole kernel (it is both the source patch tile and the compare tile of
+    // f = 0), s_tc the following frames in turn.  With a prefilter (PRE) the patch distances are
+    // taken between src_pre (s_t0) and the prefiltered frame f (s_tc), while the pixel values
+    // that are averaged come from the raw frames: s_r0 (frame 0, also the origin term and the
+    // zero fallback) and s_rc (frame f > 0).  CPD is a template constant so every LDS read in
+    // the row walk uses an immediate offset.
     extern __shared__ uint32_t smem[];
+    const int tile_dwords = CPD * cmp_rows + 4;
     uint32_t *s_t0 = smem;
-    uint32_t *s_tc = smem + CPD * cmp_rows + 4;
-    float *s_exp = reinterpret_cast<float *>(s_tc + CPD * cmp_rows + 4);
+    uint32_t *s_tc = s_t0 + tile_dwords;
+    uint32_t *s_r0 = PRE ? s_tc + tile_dwords : s_t0;
+    uint32_t *s_rc = PRE ? s_r0 + tile_dwords : s_tc;
+    float *s_exp = reinterpret_cast<float *>((PRE ? s_rc : s_tc) + tile_dwords);
 
+    // which (frame, plane) job owns this tile: binary search over the jobs' first tile indices
     int j = 0;
-    while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].tile_start) j++;
+    for (int hi = njobs - 1; j < hi;)
+    {
+        const int mid = (j + hi + 1) >> 1;
+        if ((int)blockIdx.x >= jobs[mid].tile_start) j = mid; else hi = mid - 1;
+    }
     const NlmJob &job = jobs[j];
     const int tile = blockIdx.x - job.tile_start;
     const int tile_y = tile / job.tiles_x;
@@ -161,9 +180,21 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
     if (threadIdx.x < 128) s_exp[threadIdx.x] = job.exptable[threadIdx.x];
     // lane tx holds the source pixels tx0 + 4*(tx-1) .. +3: the tiles start one lane (and rq
     // dwords of search halo) left of tx0
-    load_tile_p(s_t0, CPD, CPD, cmp_rows, job.frame[0], job.fpitch[0], w, h,
-                tx0 - PX - 4 * rq, ty0 - NH - RH);
-    const uint32_t *own = s_t0 + (ty * RY + RH) * CPD + tx + rq;   // this lane's source dwords, row 0 of its walk
+    if (PRE)
+    {
+        load_tile_p(s_t0, CPD, CPD, cmp_rows, job.src_pre, job.src_pre_pitch, w, h,
+                    tx0 - PX - 4 * rq, ty0 - NH - RH);
+        load_tile_p(s_r0, CPD, CPD, cmp_rows, job.frame[0], job.fpitch[0], w, h,
+                    tx0 - PX - 4 * rq, ty0 - NH - RH);
+    }
+    else
+    {
+        load_tile_p(s_t0, CPD, CPD, cmp_rows, job.frame[0], job.fpitch[0], w, h,
+                    tx0 - PX - 4 * rq, ty0 - NH - RH);
+    }
+    const int own_off = (ty * RY + RH) * CPD + tx + rq;
+    const uint32_t *own = s_t0 + own_off;       // this lane's source-patch dwords, row 0 of its walk
+    const uint32_t *own_raw = s_r0 + own_off;   // the same pixels of the raw frame being filtered
 
     // weight / weighted-pixel accumulators as float pairs: the adds and the w*pixel product
     // below are packed (v_pk_add_f32 / v_pk_mul_f32, each lane of a pair rounded like the scalar op)
@@ -183,15 +214,27 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
 
     for (int f = 0; f < job.nframes; f++)
     {
-        if (f > 0)
+        if (PRE || f > 0)
         {
             __syncthreads();   // everyone is done with the previous compare tile
-            load_tile_p(s_tc, CPD, CPD, cmp_rows, job.frame[f], job.fpitch[f], w, h,
-                        tx0 - PX - 4 * rq, ty0 - NH - RH);
+            if (PRE)
+            {
+                load_tile_p(s_tc, CPD, CPD, cmp_rows, job.frame_pre[f], job.ppitch[f], w, h,
+                            tx0 - PX - 4 * rq, ty0 - NH - RH);
+                if (f > 0)
+                    load_tile_p(s_rc, CPD, CPD, cmp_rows, job.frame[f], job.fpitch[f], w, h,
+                                tx0 - PX - 4 * rq, ty0 - NH - RH);
+            }
+            else
+            {
+                load_tile_p(s_tc, CPD, CPD, cmp_rows, job.frame[f], job.fpitch[f], w, h,
+                            tx0 - PX - 4 * rq, ty0 - NH - RH);
+            }
         }
         __syncthreads();
         if (!wave_live) continue;
-        const uint32_t *cmp_tile = f > 0 ? s_tc : s_t0;
+        const uint32_t *cmp_tile = (PRE || f > 0) ? s_tc : s_t0;     // what the patch distances are taken against
+        const uint32_t *pix_tile = f > 0 ? s_rc : s_r0;              // what is averaged (== cmp_tile without a prefilter)
 
         for (int dy = -RH; dy <= RH; dy++)
         {
@@ -202,7 +245,7 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
 #pragma unroll
                     for (int o = 0; o < RY; o++)
                     {
-                        const uint32_t cpx = own[(o + NH) * CPD];
+                        const uint32_t cpx = own_raw[(o + NH) * CPD];
 #pragma unroll
                         for (int p = 0; p < PX; p++)
                         {
@@ -224,8 +267,10 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
                 // output row o is C(after row o+n-1) - C(after row o-1).  Only output rows then pay
                 // for the horizontal n-sum across lanes.
                 uint32_t C[PX], hist[RY - 1][PX], v[PX];
-                uint32_t centre[NH + 2];                     // compare-frame dwords of the last NH+2 rows
-                f2 wq[PX / 2];                               // table weights in flight for the previous output row
+                uint32_t centre[NH + 1];                     // compare-frame dwords of the last NH+1 rows
+                uint32_t pixq = 0;                           // pixels and ...
+                f2 wq[PX / 2];                               // ... table weights in flight for the previous output row
+                const uint32_t *prow = pix_tile + (ty * RY + dy + RH + NH) * CPD + tx + (s >> 2);   // PRE only
 #pragma unroll
                 for (int q = 0; q < PX; q++) C[q] = 0;
 
@@ -241,7 +286,7 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
                         b_n0 = crow[(i + 1) * CPD];
                         b_n1 = crow[(i + 1) * CPD + 1];
                     }
-                    centre[i % (NH + 2)] = bw;
+                    if (!PRE) centre[i % (NH + 1)] = bw;
 #pragma unroll
                     for (int q = 0; q < PX; q++)
                     {
@@ -282,7 +327,7 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
                     if (i >= N)
                     {
                         const int o = i - N;
-                        const uint32_t pix = centre[(i - 1 - NH) % (NH + 2)];
+                        const uint32_t pix = pixq;
 #pragma unroll
                         for (int pp = 0; pp < PX / 2; pp++)
                         {
@@ -293,6 +338,14 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
                     }
                     if (i >= N - 1)
                     {
+                        // the pixels that go with these weights: the compare frame's row i - NH
+                        if (PRE)
+                        {
+                            const int o = i - (N - 1);
+                            pixq = __builtin_amdgcn_alignbyte(prow[o * CPD + 1], prow[o * CPD], sh);
+                        }
+                        else
+                            pixq = centre[(i - NH) % (NH + 1)];
 #pragma unroll
                         for (int pp = 0; pp < PX / 2; pp++)
                         {
@@ -323,7 +376,7 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
                 }
                 {
                     // last output row of this displacement
-                    const uint32_t pix = centre[(ROWS - 1 - NH) % (NH + 2)];
+                    const uint32_t pix = pixq;
 #pragma unroll
                     for (int pp = 0; pp < PX / 2; pp++)
                     {
@@ -345,7 +398,7 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
         const int y = ty0 + ty * RY + o;
         if (y >= h) break;
         uint32_t packed = 0;
-        const uint32_t cpx = own[(o + NH) * CPD];
+        const uint32_t cpx = own_raw[(o + NH) * CPD];
 #pragma unroll
         for (int p = 0; p < PX; p++)
         {
@@ -365,6 +418,202 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
             for (int p = 0; p < PX && x + p < w; p++) out[p] = (uint8_t)(packed >> (8 * p));
         }
     }
+}
+
+// ------------------------------------------------------------------------------- prefilters
+// nlmeans_prefilter (nlmeans_template.c:428-543) on one plane.  The reference filters the bordered
+// image and re-mirrors the result, so a prefiltered plane is fully described by its w x h interior;
+// reads outside the plane mirror (the 16-pixel border is wider than any window here).
+constexpr int PF_MEAN3 = 1, PF_MEAN5 = 2, PF_MEDIAN3 = 4, PF_MEDIAN5 = 8, PF_CSM3 = 16, PF_CSM5 = 32,
+              PF_REDUCE25 = 256, PF_REDUCE50 = 512, PF_EDGEBOOST = 1024, PF_PASSTHRU = 2048,
+              PF_BASE = PF_MEAN3 | PF_MEAN5 | PF_MEDIAN3 | PF_MEDIAN5 | PF_CSM3 | PF_CSM5;
+
+__device__ __forceinline__ int pf_mix(int pre, int src, int wet, int dry)
+{
+    return dry > 0 ? ((wet * pre + dry * src) / (wet + dry)) & 0xff : pre;     // :498-525
+}
+
+// base filter (+ the wet/dry blend when no edge boost comes in between)
+__global__ __launch_bounds__(256) void nlm_prefilter_kernel(const uint8_t *__restrict__ src, int spitch,
+                                                            uint8_t *__restrict__ dst, int dpitch,
+                                                            int w, int h, int type, int wet, int dry)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    auto at = [&](int xx, int yy) -> int { return src[(size_t)reflect(yy, h) * spitch + reflect(xx, w)]; };
+    const int centre = at(x, y);
+    int out = centre;
+    // one base filter, picked in the reference's order of precedence (:459-496)
+    const int kind = (type & PF_CSM5) ? PF_CSM5 : (type & PF_CSM3) ? PF_CSM3 : (type & PF_MEDIAN5) ? PF_MEDIAN5
+                   : (type & PF_MEDIAN3) ? PF_MEDIAN3 : (type & PF_MEAN5) ? PF_MEAN5 : PF_MEAN3;
+    const int size = (kind & (PF_CSM5 | PF_MEDIAN5 | PF_MEAN5)) ? 5 : 3;
+    const int lo = -((size - 1) / 2), hi = (size + 1) / 2;
+    if (kind & (PF_CSM5 | PF_CSM3))
+    {
+        // nlmeans_filter_csm (:232-323): the reference leaves its row loop with `goto end` at the
+        // first neighbour and at the origin, so the first column contributes only its top pixel
+        // and the centre column only the pixels above the origin.
+        int vmin = 0, vmax = 0;
+        for (int dx = lo; dx < hi; dx++)
+            for (int dy = lo; dy < hi; dy++)
+            {
+                if (dx == 0 && dy == 0) break;
+                const int v = at(x + dx, y + dy);
+                if (dx == lo && dy == lo) { vmin = vmax = v; break; }
+                vmin = min(vmin, v);
+                vmax = max(vmax, v);
+            }
+        const int mid = (vmin + vmax) / 2;
+        const int min2 = (vmin + mid) / 2, max2 = (vmax + mid) / 2;
+        const int min3 = (min2 + mid) / 2, max3 = (max2 + mid) / 2;
+        if      (centre < vmin) out = vmin;
+        else if (centre > vmax) out = vmax;
+        else if (centre < min2) out = min2;
+        else if (centre > max2) out = max2;
+        else if (centre < min3) out = min3;
+        else if (centre > max3) out = max3;
+    }
+    else if (kind & (PF_MEDIAN5 | PF_MEDIAN3))
+    {
+        // nlmeans_filter_median (:135-230): the networks return the true median = the element of
+        // rank n/2; found here by counting, for every candidate, the elements that sort before it.
+        const int n = size * size;
+        for (int i = 0; i < n; i++)
+        {
+            const int vi = at(x + lo + i / size, y + lo + i % size);
+            int rank = 0;
+            for (int j = 0; j < n; j++)
+            {
+                const int vj = at(x + lo + j / size, y + lo + j % size);
+                rank += (vj < vi) || (vj == vi && j < i);
+            }
+            if (rank == n / 2) out = vi;
+        }
+    }
+    else
+    {
+        // nlmeans_filter_mean (:103-133): uint16 window sum scaled by a double, truncated
+        int sum = 0;
+        for (int dx = lo; dx < hi; dx++)
+            for (int dy = lo; dy < hi; dy++) sum += at(x + dx, y + dy);
+        out = (int)(uint8_t)((double)(sum & 0xffff) * (1.0 / (double)(size * size)));
+    }
+    if (!(type & PF_EDGEBOOST)) out = pf_mix(out, centre, wet, dry);
+    dst[(size_t)y * dpitch + x] = (uint8_t)out;
+}
+
+// nlmeans_filter_edgeboost, first pass (:335-377): Sobel-like gradients in uint16 (negative sums
+// wrap, as in the reference), classified into {16, 128, 235}.
+__global__ __launch_bounds__(256) void nlm_edge_mask_kernel(const uint8_t *__restrict__ src, int spitch,
+                                                            uint8_t *__restrict__ mask, int mpitch, int w, int h)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    auto at = [&](int xx, int yy) -> int { return src[(size_t)reflect(yy, h) * spitch + reflect(xx, w)]; };
+    const int kern[3][3] = { {-31, 0, 31}, {-44, 0, 44}, {-31, 0, 31} };
+    int g1 = 0, g2 = 0;
+#pragma unroll
+    for (int dx = -1; dx <= 1; dx++)
+#pragma unroll
+        for (int dy = -1; dy <= 1; dy++)
+        {
+            const int v = at(x + dx, y + dy);
+            g1 += kern[dy + 1][dx + 1] * v;
+            g2 += kern[dx + 1][dy + 1] * v;
+        }
+    const double coef = 1.0 / 126.42;
+    const uint32_t a = (uint32_t)(uint16_t)(int)(((double)(g1 & 0xffff) * coef) + 128);
+    const uint32_t b = (uint32_t)(uint16_t)(int)(((double)(g2 & 0xffff) * coef) + 128);
+    const uint32_t m = (a + b) & 0xff;
+    mask[(size_t)y * mpitch + x] = m > 160 ? 235 : m > 16 ? 128 : 16;
+}
+
+// nlmeans_filter_edgeboost, second pass (:379-424) + the wet/dry blend.  The reference edits the
+// mask in place in raster order, so whether a pixel counts as "edge" for its right and lower
+// neighbours depends on whether it was itself demoted just before: a chain through the whole
+// plane.  One workgroup walks the rows in order; within a row the only unknown of a pixel is
+// whether its left neighbour survived, so each pixel is a map {left dead, left alive} -> {dead,
+// alive}, and the row is resolved with a prefix composition of those maps (threads compose their
+// own run of pixels, then a block scan joins the runs).
+constexpr int EB_THREADS = 256;
+__global__ __launch_bounds__(EB_THREADS) void nlm_edge_apply_kernel(const uint8_t *__restrict__ src, int spitch,
+                                                                     uint8_t *__restrict__ mask, int mpitch,
+                                                                     uint8_t *__restrict__ pre, int ppitch,
+                                                                     int w, int h)
+{
+    __shared__ uint8_t s_map[EB_THREADS];      // bit0 = outcome if the run's left neighbour is dead, bit1 = if alive
+    __shared__ uint8_t s_in[EB_THREADS];       // resolved state entering each thread's run
+    const int t = threadIdx.x;
+    const int per = (w + EB_THREADS - 1) / EB_THREADS;
+    const int x0 = t * per, x1 = min(w, x0 + per);
+    for (int y = 0; y < h; y++)
+    {
+        uint8_t *mrow = mask + (size_t)y * mpitch;
+        const uint8_t *mup = mrow - mpitch, *mdn = mrow + mpitch;
+        // everything but the left neighbour: the row above is final, this row's right neighbour
+        // and the row below still hold their first-pass values; outside the plane counts as 0
+        // the pixel right of this thread's run belongs to the next thread, which may demote it
+        // while this thread still needs its first-pass value
+        const int right_of_run = x1 < w ? mrow[x1] : 0;
+        auto others = [&](int x) -> int {
+            int c = 1;                                                      // the pixel itself (> 16, else no test)
+            if (x + 1 < w) c += (x + 1 == x1 ? right_of_run : (int)mrow[x + 1]) > 16;
+            if (y > 0)     c += (x > 0 && mup[x - 1] > 16) + (mup[x] > 16) + (x + 1 < w && mup[x + 1] > 16);
+            if (y + 1 < h) c += (x > 0 && mdn[x - 1] > 16) + (mdn[x] > 16) + (x + 1 < w && mdn[x + 1] > 16);
+            return c;
+        };
+        // compose this thread's run: state s = "pixel x-1 is an edge after its own test"
+        int f0 = 0, f1 = 1;                                                 // identity map
+        for (int x = x0; x < x1; x++)
+        {
+            int g0, g1;
+            if (mrow[x] <= 16) { g0 = 0; g1 = 0; }
+            else { const int c = others(x); g0 = c >= 3; g1 = c + 1 >= 3; }
+            f0 = f0 ? g1 : g0;
+            f1 = f1 ? g1 : g0;
+        }
+        s_map[t] = (uint8_t)(f0 | (f1 << 1));
+        __syncthreads();
+        if (t == 0)
+        {
+            int state = 0;                                                  // nothing left of column 0
+            for (int i = 0; i < EB_THREADS; i++)
+            {
+                s_in[i] = (uint8_t)state;
+                state = (s_map[i] >> state) & 1;
+            }
+        }
+        __syncthreads();
+        int state = s_in[t];
+        for (int x = x0; x < x1; x++)
+        {
+            const int m = mrow[x];
+            if (m <= 16) { state = 0; continue; }
+            const int c = others(x) + state;
+            if (c < 3)
+            {
+                mrow[x] = 16;
+                state = 0;
+                continue;
+            }
+            state = 1;
+            const int sv = src[(size_t)y * spitch + x];
+            uint8_t *o = pre + (size_t)y * ppitch + x;
+            *o = (uint8_t)(m == 235 ? (3 * sv + *o) / 4 : (2 * sv + 3 * *o) / 5);
+        }
+        __threadfence_block();
+        __syncthreads();                                                    // row y is final before row y+1 reads it
+    }
+}
+
+// the wet/dry blend (:498-525) when the edge boost had to run between it and the base filter
+__global__ __launch_bounds__(256) void nlm_mix_kernel(const uint8_t *__restrict__ src, int spitch,
+                                                      uint8_t *__restrict__ pre, int ppitch, int w, int h, int wet, int dry)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    uint8_t *o = pre + (size_t)y * ppitch + x;
+    *o = (uint8_t)pf_mix(*o, src[(size_t)y * spitch + x], wet, dry);
 }
 
 __global__ void copy_plane_kernel(uint8_t *dst, int dst_pitch, const uint8_t *src, int src_pitch,
@@ -403,12 +652,16 @@ public:
         max_frames = 1;
         for (int c = 0; c < 3; c++)
         {
+            // a prefilter only exists if one of the base filters is selected (:438-443)
+            pf_type[c] = (par.prefilter[c] & PF_BASE) ? par.prefilter[c] : 0;
+            passthru[c] = (par.prefilter[c] & PF_PASSTHRU) != 0;
+            any_pre |= pf_type[c] != 0;
+            if (passthru[c]) continue;                 // the plane is not denoised at all (nlmeans.c:485-492)
             max_frames = std::max(max_frames, par.nframes[c]);
             if (par.strength[c] == 0) continue;
             const int n = par.patch_size[c];
             if (n != 3 && n != 5 && n != 7 && n != 9) return HBHIP_ERR_UNSUPPORTED;
             if (n / 2 + par.range[c] / 2 > NLM_BORDER) return HBHIP_ERR_UNSUPPORTED;
-            if (par.prefilter[c] != 0) return HBHIP_ERR_UNSUPPORTED;
             if (par.nframes[c] < 1 || par.nframes[c] > HBHIP_NLMEANS_FRAMES_MAX) return HBHIP_ERR_ARG;
             if (in_geo.pw[c] < NLM_BORDER || in_geo.ph[c] < NLM_BORDER) return HBHIP_ERR_UNSUPPORTED;
         }
@@ -427,6 +680,15 @@ public:
                 }
             if (getenv("HBHIP_NLM_NOFAST")) diff_cap[c] = -1;
         }
+        if (any_pre)
+        {
+            pre_pool.configure(ctx, in_geo);
+            if (par.prefilter[0] & PF_EDGEBOOST || par.prefilter[1] & PF_EDGEBOOST || par.prefilter[2] & PF_EDGEBOOST)
+            {
+                mask_pic = pre_pool.acquire();
+                if (!mask_pic) return HBHIP_ERR_NOMEM;
+            }
+        }
         HBHIP_CHECK(ctx, hipMalloc((void **)&d_exp, sizeof(float) * 3 * 128));
         HBHIP_CHECK(ctx, hipMemcpyAsync(d_exp, par.exptable, sizeof(float) * 3 * 128,
                                         hipMemcpyHostToDevice, ctx->stream));
@@ -438,6 +700,11 @@ public:
 
     int submit(DevPicture *pic) override
     {
+        if (any_pre)
+        {
+            int rc = prefilter_frame(pic);
+            if (rc != HBHIP_OK) return rc;
+        }
         in.push_back(pic);
         return schedule(false);
     }
@@ -456,6 +723,9 @@ public:
 
     int batch = 1;
     int diff_cap[3] = {-1, -1, -1};
+    int pf_type[3] = {0, 0, 0};          // effective prefilter bits per plane (0 = none)
+    bool passthru[3] = {false, false, false};
+    bool any_pre = false;
 
 private:
     int ensure_jobs(int n)
@@ -478,19 +748,88 @@ private:
         return HBHIP_OK;
     }
 
-    struct View { uint8_t *plane[3]; int pitch[3]; };
+    // pre*: the prefiltered twin of the frame (== the raw plane where a plane has no prefilter);
+    // first: this is the first frame of the stream (its src_pre is latched raw, see NlmJob)
+    struct View { uint8_t *plane[3]; int pitch[3]; uint8_t *pre[3]; int ppitch[3]; bool first; };
 
-    static View view_of(const DevPicture *p)
+    View view_of(const DevPicture *p)
     {
         View v;
-        for (int c = 0; c < 3; c++) { v.plane[c] = p->plane[c]; v.pitch[c] = p->pitch[c]; }
+        const DevPicture *q = nullptr;
+        if (any_pre)
+        {
+            auto it = pre_of.find(p);
+            if (it != pre_of.end()) q = it->second;
+        }
+        for (int c = 0; c < 3; c++)
+        {
+            v.plane[c] = p->plane[c]; v.pitch[c] = p->pitch[c];
+            const bool has = q && pf_type[c];
+            v.pre[c] = has ? q->plane[c] : p->plane[c];
+            v.ppitch[c] = has ? q->pitch[c] : p->pitch[c];
+        }
+        v.first = p->aux == 1;
         return v;
     }
     static View view_of(const hbhip_dev_frame &f)
     {
         View v;
-        for (int c = 0; c < 3; c++) { v.plane[c] = (uint8_t *)f.plane[c]; v.pitch[c] = f.stride[c]; }
+        for (int c = 0; c < 3; c++)
+        {
+            v.plane[c] = (uint8_t *)f.plane[c]; v.pitch[c] = f.stride[c];
+            v.pre[c] = v.plane[c]; v.ppitch[c] = v.pitch[c];
+        }
+        v.first = false;
         return v;
+    }
+
+    void release_input(DevPicture *p)
+    {
+        if (any_pre)
+        {
+            auto it = pre_of.find(p);
+            if (it != pre_of.end())
+            {
+                pre_pool.release(it->second);
+                pre_of.erase(it);
+            }
+        }
+        pool.release(p);
+    }
+
+    // nlmeans_prefilter (nlmeans_template.c:428-543) of every plane that has one, into the frame's twin
+    int prefilter_frame(DevPicture *pic)
+    {
+        DevPicture *q = pre_pool.acquire();
+        if (!q) return HBHIP_ERR_NOMEM;
+        pre_of[pic] = q;
+        pic->aux = frames_seen++ == 0 ? 1 : 0;
+        for (int c = 0; c < 3; c++)
+        {
+            const int type = pf_type[c];
+            if (!type) continue;
+            const int w = in_geo.pw[c], h = in_geo.ph[c];
+            int wet = 1, dry = 0;
+            if ((type & PF_REDUCE50) && (type & PF_REDUCE25)) { wet = 1; dry = 3; }
+            else if (type & PF_REDUCE50)                      { wet = 1; dry = 1; }
+            else if (type & PF_REDUCE25)                      { wet = 3; dry = 1; }
+            const dim3 grid((w + 63) / 64, (h + 3) / 4), block(256);
+            HBHIP_LAUNCH(ctx, "nlmeans_prefilter", nlm_prefilter_kernel, grid, block, 0,
+                         (const uint8_t *)pic->plane[c], pic->pitch[c], q->plane[c], q->pitch[c], w, h, type, wet, dry);
+            if (type & PF_EDGEBOOST)
+            {
+                HBHIP_LAUNCH(ctx, "nlmeans_edge_mask", nlm_edge_mask_kernel, grid, block, 0,
+                             (const uint8_t *)pic->plane[c], pic->pitch[c], mask_pic->plane[c], mask_pic->pitch[c], w, h);
+                HBHIP_LAUNCH(ctx, "nlmeans_edge_apply", nlm_edge_apply_kernel, dim3(1), dim3(EB_THREADS), 0,
+                             (const uint8_t *)pic->plane[c], pic->pitch[c], mask_pic->plane[c], mask_pic->pitch[c],
+                             q->plane[c], q->pitch[c], w, h);
+                if (dry > 0)
+                    HBHIP_LAUNCH(ctx, "nlmeans_prefilter_mix", nlm_mix_kernel, grid, block, 0,
+                                 (const uint8_t *)pic->plane[c], pic->pitch[c], q->plane[c], q->pitch[c], w, h, wet, dry);
+            }
+        }
+        HBHIP_CHECK(ctx, hipGetLastError());
+        return HBHIP_OK;
     }
 
     // Filter frames ins[0..ready) (ins beyond `ready` are look-ahead only) into outs[0..ready).
@@ -503,8 +842,13 @@ private:
         // group jobs by patch size (one launch per distinct n)
         for (int n : {3, 5, 7, 9})
         {
-            bool any = false;
-            for (int c = 0; c < 3; c++) any |= (par.strength[c] != 0 && par.patch_size[c] == n);
+            bool any = false, pre = false;
+            for (int c = 0; c < 3; c++)
+                if (!passthru[c] && par.strength[c] != 0 && par.patch_size[c] == n)
+                {
+                    any = true;
+                    pre |= pf_type[c] != 0;
+                }
             if (!any) continue;
             table = (table + 1) % NTABLES;
             if (table_used[table]) HBHIP_CHECK(ctx, hipEventSynchronize(table_ev[table]));
@@ -515,14 +859,24 @@ private:
             for (int t = 0; t < ready; t++)
                 for (int c = 0; c < 3; c++)
                 {
-                    if (par.strength[c] == 0 || par.patch_size[c] != n) continue;
+                    if (passthru[c] || par.strength[c] == 0 || par.patch_size[c] != n) continue;
                     NlmJob &jb = hj[nj++];
                     jb.nframes = std::min(par.nframes[c], total - t);
                     for (int f = 0; f < jb.nframes; f++)
                     {
                         jb.frame[f] = ins[t + f].plane[c];
                         jb.fpitch[f] = ins[t + f].pitch[c];
+                        jb.frame_pre[f] = ins[t + f].pre[c];
+                        jb.ppitch[f] = ins[t + f].ppitch[c];
                     }
+                    // src_pre is latched before the frame's own prefilter call (nlmeans_template.c:615
+                    // vs :631): it is the prefiltered plane only if an earlier frame already used this
+                    // one as a compare frame, i.e. not for the first frame of the stream and never
+                    // with a single-frame window.  (With threads > 1 the reference races here; this
+                    // is its single-threaded order.)
+                    const bool latched_raw = ins[t].first || par.nframes[c] < 2;
+                    jb.src_pre = latched_raw ? ins[t].plane[c] : ins[t].pre[c];
+                    jb.src_pre_pitch = latched_raw ? ins[t].pitch[c] : ins[t].ppitch[c];
                     jb.dst = outs[t].plane[c];
                     jb.exptable = d_exp + 128 * c;
                     jb.origin_tune = par.origin_tune[c];
@@ -550,16 +904,17 @@ private:
             // word), pitch = 4 (mod 8) dwords
             const int rq = (max_rh + 3) / 4;
             const int cpd = rq <= 1 ? 36 : 44;
-            const size_t shmem = sizeof(uint32_t) * 2 * (cpd * cmp_rows + 4) + 512;
+            const size_t shmem = sizeof(uint32_t) * (pre ? 4 : 2) * (cpd * cmp_rows + 4) + 512;
             // the widest search ranges need more than the default 64 KB of dynamic LDS
-#define NLM_GO(NN, FF, CC) do { \
+#define NLM_GO(NN, FF, CC, PP) do { \
                 if (shmem > 65536) \
-                    HBHIP_CHECK(ctx, hipFuncSetAttribute((const void *)nlmeans_lanes_kernel<NN, FF, CC>, \
+                    HBHIP_CHECK(ctx, hipFuncSetAttribute((const void *)nlmeans_lanes_kernel<NN, FF, CC, PP>, \
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
-                HBHIP_LAUNCH(ctx, "nlmeans_plane_n" #NN, (nlmeans_lanes_kernel<NN, FF, CC>), grid, block, shmem, dj, nj, cmp_rows, rq); \
+                HBHIP_LAUNCH(ctx, "nlmeans_plane_n" #NN, (nlmeans_lanes_kernel<NN, FF, CC, PP>), grid, block, shmem, dj, nj, cmp_rows, rq); \
             } while (0)
-#define NLM_VAR(NN) do { if (cpd == 36) { if (fast) NLM_GO(NN, true, 36); else NLM_GO(NN, false, 36); } \
-                     else { if (fast) NLM_GO(NN, true, 44); else NLM_GO(NN, false, 44); } } while (0)
+#define NLM_PRE(NN, FF, CC) do { if (pre) NLM_GO(NN, FF, CC, true); else NLM_GO(NN, FF, CC, false); } while (0)
+#define NLM_VAR(NN) do { if (cpd == 36) { if (fast) NLM_PRE(NN, true, 36); else NLM_PRE(NN, false, 36); } \
+                     else { if (fast) NLM_PRE(NN, true, 44); else NLM_PRE(NN, false, 44); } } while (0)
             switch (n)
             {
                 case 3: NLM_VAR(3); break;
@@ -568,20 +923,23 @@ private:
                 case 9: NLM_VAR(9); break;
             }
 #undef NLM_VAR
+#undef NLM_PRE
 #undef NLM_GO
             HBHIP_CHECK(ctx, hipGetLastError());
         }
 
-        // strength == 0 planes are passed through (nlmeans.c:493-499)
+        // prefilter "passthru" planes output their prefiltered twin (nlmeans.c:485-492, with
+        // nlmeans_template.c:533-537), strength == 0 planes the frame itself (nlmeans.c:493-499)
         for (int t = 0; t < ready; t++)
             for (int c = 0; c < 3; c++)
-                if (par.strength[c] == 0)
+                if (passthru[c] || par.strength[c] == 0)
                 {
                     const int row = in_geo.pw[c] * in_geo.bps;
                     dim3 grid((row / 4 + 255) / 256 + 1, in_geo.ph[c]);
                     HBHIP_LAUNCH(ctx, "nlmeans_copy_plane", copy_plane_kernel, grid, dim3(256), 0,
-                                 outs[t].plane[c], outs[t].pitch[c], (const uint8_t *)ins[t].plane[c],
-                                 ins[t].pitch[c], row, in_geo.ph[c]);
+                                 outs[t].plane[c], outs[t].pitch[c],
+                                 (const uint8_t *)(passthru[c] ? ins[t].pre[c] : ins[t].plane[c]),
+                                 passthru[c] ? ins[t].ppitch[c] : ins[t].pitch[c], row, in_geo.ph[c]);
                 }
         return HBHIP_OK;
     }
@@ -608,7 +966,7 @@ private:
         for (int t = 0; t < ready; t++)
         {
             out.push_back(outs[t]);
-            pool.release(in.front());   // stream-ordered reuse
+            release_input(in.front());   // stream-ordered reuse
             in.pop_front();
         }
         return HBHIP_OK;
@@ -623,7 +981,7 @@ public:
         const int keep = max_frames - 1;
         const int total = (int)in.size() + n_in;
         const int ready = total - keep;
-        bool direct = out.empty() && n_in >= keep && ready > 0 && ready <= out_cap && (int)in.size() <= ready;
+        bool direct = !any_pre && out.empty() && n_in >= keep && ready > 0 && ready <= out_cap && (int)in.size() <= ready;
         for (int i = 0; direct && i < n_in; i++)
             for (int c = 0; c < 3; c++)
                 if ((fin[i].stride[c] & 3) || ((uintptr_t)fin[i].plane[c] & 3)) direct = false;
@@ -641,7 +999,7 @@ public:
         if (rc != HBHIP_OK) return rc;
         while (!in.empty())
         {
-            pool.release(in.front());
+            release_input(in.front());
             in.pop_front();
         }
         for (int i = n_in - keep; i < n_in; i++)
@@ -660,6 +1018,10 @@ public:
 private:
     hbhip_nlmeans_params par;
     PicturePool pool;
+    PicturePool pre_pool;                                    // prefiltered twins (+ the edge-boost mask)
+    std::unordered_map<const DevPicture *, DevPicture *> pre_of;
+    DevPicture *mask_pic = nullptr;
+    long frames_seen = 0;
     std::deque<DevPicture *> in, out;
     int max_frames = 1;
     float *d_exp = nullptr;

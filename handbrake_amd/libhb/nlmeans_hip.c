@@ -13,8 +13,8 @@
  *     (SURVEY §6b hazard 8).
  *   - at EOF the remaining frames are filtered with the same shrinking
  *     temporal window as nlmeans_filter_flush (nlmeans.c:599-664).
- * If the device path cannot take the settings (prefilter != 0, >8-bit, patch
- * size outside 3/5/7/9) init() returns non-zero so libhb keeps its CPU filter
+ * If the device path cannot take the settings (>8-bit, patch size outside
+ * 3/5/7/9) init() returns non-zero so libhb keeps its CPU filter
  * (work.c:1861-1868); there is no CPU code in here.
  */
 #include "hbhip_host.h"

@@ -9,6 +9,15 @@ NLM_TAPE = ("y-strength=3:y-origin-tune=0.8:y-patch-size=3:y-range=5:y-frame-cou
 NLM_ANIM_LIGHT = ("y-strength=3:y-origin-tune=0.15:y-patch-size=5:y-range=7:y-frame-count=3:y-prefilter=0:"
                   "cb-strength=2.25:cb-origin-tune=0.15:cb-patch-size=5:cb-range=7:cb-frame-count=3:cb-prefilter=0")
 
+NLM_PRE_A = ("y-strength=6:y-origin-tune=1:y-patch-size=7:y-range=3:y-frame-count=2:y-prefilter=272:"
+             "cb-strength=6:cb-origin-tune=1:cb-patch-size=5:cb-range=3:cb-frame-count=2:cb-prefilter=8")
+NLM_PRE_B = ("y-strength=5:y-origin-tune=0.5:y-patch-size=5:y-range=5:y-frame-count=3:y-prefilter=1537:"
+             "cb-strength=4:cb-origin-tune=1:cb-patch-size=3:cb-range=3:cb-frame-count=1:cb-prefilter=2")
+NLM_PRE_C = ("y-strength=6:y-origin-tune=1:y-patch-size=7:y-range=3:y-frame-count=2:y-prefilter=2049:"
+             "cb-strength=6:cb-origin-tune=0.8:cb-patch-size=7:cb-range=3:cb-frame-count=2:cb-prefilter=1028:"
+             "cr-strength=6:cr-origin-tune=0.8:cr-patch-size=7:cr-range=3:cr-frame-count=2:cr-prefilter=800")
+
+
 def nlm(strength=6, origin_tune=1.0, patch=7, rng=3, nframes=2, prefilter=0):
     return dict(strength=strength, origin_tune=origin_tune, patch=patch, range=rng,
                 nframes=nframes, prefilter=prefilter)
@@ -42,6 +51,23 @@ CASES = {
                                           hip=[("hb_filter_nlmeans_hip", NLM_ANIM_LIGHT)],
                                           orc=[("nlmeans", [nlm(3, 0.15, 5, 7, 3), nlm(2.25, 0.15, 5, 7, 3),
                                                             nlm(2.25, 0.15, 5, 7, 3)])]),
+    # NLMeans prefilters (nlmeans_template.c:103-543).  threads=1: with more threads the reference
+    # races on which frames are already prefiltered when src_pre is latched.
+    "nlmeans_pre_csm3_median5_96x64": dict(model="progressive", w=96, h=64, n=4,
+                                           chain=[("hb_filter_nlmeans", NLM_PRE_A + ":threads=1")],
+                                           hip=[("hb_filter_nlmeans_hip", NLM_PRE_A)],
+                                           orc=[("nlmeans", [nlm(6, 1.0, 7, 3, 2, 16 + 256), nlm(6, 1.0, 5, 3, 2, 8),
+                                                             nlm(6, 1.0, 5, 3, 2, 8)])]),
+    "nlmeans_pre_edgeboost_80x48": dict(model="random", w=80, h=48, n=4,
+                                        chain=[("hb_filter_nlmeans", NLM_PRE_B + ":threads=1")],
+                                        hip=[("hb_filter_nlmeans_hip", NLM_PRE_B)],
+                                        orc=[("nlmeans", [nlm(5, 0.5, 5, 5, 3, 1 + 1024 + 512), nlm(4, 1.0, 3, 3, 1, 2),
+                                                          nlm(4, 1.0, 3, 3, 1, 2)])]),
+    "nlmeans_pre_passthru_70x50": dict(model="progressive", w=70, h=50, n=3,
+                                       chain=[("hb_filter_nlmeans", NLM_PRE_C + ":threads=1")],
+                                       hip=[("hb_filter_nlmeans_hip", NLM_PRE_C)],
+                                       orc=[("nlmeans", [nlm(6, 1.0, 7, 3, 2, 2049), nlm(6, 0.8, 7, 3, 2, 4 + 1024),
+                                                         nlm(6, 0.8, 7, 3, 2, 32 + 256 + 512)])]),
     "lapsharp_medium_134x70": dict(model="progressive", w=134, h=70, n=2,
                                    chain=[("hb_filter_lapsharp", "y-strength=0.2:y-kernel=isolap:cb-strength=0.2:cb-kernel=isolap")],
                                    hip=[("hb_filter_lapsharp_hip", "y-strength=0.2:y-kernel=isolap:cb-strength=0.2:cb-kernel=isolap")],

@@ -78,6 +78,19 @@ def orc_nlmeans_plane(planes, strength=6.0, origin_tune=1.0, patch=7, rng=3, pre
     return dst
 
 
+def orc_nlmeans_prefiltered(plane, prefilter, patch=7):
+    """The w x h interior of nlmeans_prefilter's output for one plane."""
+    lib = oracle()
+    p = np.ascontiguousarray(plane)
+    h, w = p.shape
+    border = lib.orc_nlmeans_border(patch)
+    b = np.zeros((h + 2 * border, w + 2 * border), np.uint8)
+    lib.orc_nlmeans_make_bordered(u8p(p), w, h, p.strides[0], border, u8p(b))
+    q = np.zeros_like(b)
+    lib.orc_nlmeans_prefilter(u8p(b), w, h, border, prefilter, u8p(q))
+    return np.ascontiguousarray(q[border:border + h, border:border + w])
+
+
 def ref_nlmeans_plane(settings: str, c: int, planes, force_scalar=False):
     lib = ref()
     h, w = planes[0].shape

@@ -16,13 +16,20 @@ def nlmeans_stream(frames, planes_par):
         planes = []
         for c in range(3):
             p = planes_par[c]
+            pf = p.get("prefilter", 0)
+            if pf & 2048:                                   # passthru: the prefiltered plane is the output
+                planes.append(ol.orc_nlmeans_prefiltered(frames[t][c], pf, p["patch"]))
+                continue
             if p["strength"] == 0:
                 planes.append(frames[t][c].copy())
                 continue
             nf = min(p["nframes"], n - t)
+            # src_pre is latched before frame t's own prefilter call (nlmeans_template.c:615 vs :631):
+            # it is prefiltered only if an earlier frame used frame t as a compare frame
             planes.append(ol.orc_nlmeans_plane([frames[t + f][c] for f in range(nf)],
                                                p["strength"], p["origin_tune"], p["patch"],
-                                               p["range"], p.get("prefilter", 0)))
+                                               p["range"], pf,
+                                               src_already_prefiltered=(t >= 1 and p["nframes"] >= 2)))
         out.append(tuple(planes))
     return out
 

@@ -166,3 +166,34 @@ def test_zero_copy_process_dev_equals_streamed(built):
             np.testing.assert_array_equal(dev_out[t][c].cpu().numpy(), want[t].planes[c], err_msg=f"frame {t} plane {c}")
     flt.close()
     ctx.close()
+
+
+def ppar(strength, origin_tune, patch, rng, nframes, prefilter):
+    d = par(strength, origin_tune, patch, rng, nframes)
+    d["prefilter"] = prefilter
+    return d
+
+
+@pytest.mark.parametrize("w,h,settings,pp", [
+    # every base prefilter, edge boost on a plane wider than one workgroup pass, both blends
+    (638, 362,
+     "y-strength=6:y-origin-tune=1:y-patch-size=7:y-range=3:y-frame-count=2:y-prefilter=1025:"
+     "cb-strength=6:cb-origin-tune=1:cb-patch-size=7:cb-range=3:cb-frame-count=2:cb-prefilter=2:"
+     "cr-strength=6:cr-origin-tune=1:cr-patch-size=7:cr-range=3:cr-frame-count=2:cr-prefilter=772",
+     [ppar(6, 1.0, 7, 3, 2, 1025), ppar(6, 1.0, 7, 3, 2, 2), ppar(6, 1.0, 7, 3, 2, 772)]),
+    (200, 120,
+     "y-strength=4:y-origin-tune=0.7:y-patch-size=5:y-range=5:y-frame-count=1:y-prefilter=32:"
+     "cb-strength=5:cb-origin-tune=1:cb-patch-size=3:cb-range=5:cb-frame-count=3:cb-prefilter=1304:"
+     "cr-strength=5:cr-origin-tune=1:cr-patch-size=3:cr-range=5:cr-frame-count=3:cr-prefilter=2064",
+     [ppar(4, 0.7, 5, 5, 1, 32), ppar(5, 1.0, 3, 5, 3, 1304), ppar(5, 1.0, 3, 5, 3, 2064)]),
+])
+def test_prefilters_bit_exact(built, w, h, settings, pp):
+    """nlmeans_prefilter modes (nlmeans_template.c:103-543) incl. the src_pre latch of :615."""
+    import oracle_stream as ostream
+    frames = synth.stream("progressive" if w > 300 else "random", w, h, 4)
+    got = run_hip(frames, settings)
+    want = ostream.nlmeans_stream(frames, pp)
+    assert len(got) == len(frames)
+    for t in range(len(frames)):
+        for c in range(3):
+            np.testing.assert_array_equal(got[t].planes[c], want[t][c], err_msg=f"frame {t} plane {c}")
