@@ -77,6 +77,56 @@ __device__ __forceinline__ int vote(const int *v, int n, int mid, int lim, int &
     return (int)(((float)(sum + mid) / (float)(cnt + 1)) + 0.5f);
 }
 
+
+// Register-only variant of the two helpers above for the dir-map kernels: the candidates sit in
+// fixed slots (an absent one holds ABSENT, larger than any value and farther from any midpoint
+// than any vote limit), a sorting network orders them, and the n present values are then the
+// first n -- no data-dependent loop, no indexed register file.
+constexpr int ABSENT = 1000;
+
+__device__ __forceinline__ void cswap(int &a, int &b)
+{
+    const int lo = min(a, b), hi = max(a, b);
+    a = lo; b = hi;
+}
+
+// midpoint of the n present values among 9 slots (n >= 4); the slots end up sorted
+__device__ __forceinline__ int mid9(int &v0, int &v1, int &v2, int &v3, int &v4, int &v5, int &v6, int &v7, int &v8, int n)
+{
+    cswap(v0, v3); cswap(v1, v7); cswap(v2, v5); cswap(v4, v8);
+    cswap(v0, v7); cswap(v2, v4); cswap(v3, v8); cswap(v5, v6);
+    cswap(v0, v2); cswap(v1, v3); cswap(v4, v5); cswap(v7, v8);
+    cswap(v1, v4); cswap(v3, v6); cswap(v5, v7);
+    cswap(v0, v1); cswap(v2, v4); cswap(v3, v5); cswap(v6, v8);
+    cswap(v2, v3); cswap(v4, v5); cswap(v6, v7);
+    cswap(v1, v2); cswap(v3, v4); cswap(v5, v6);
+    // n = 4..9: lower middle index (n-1)>>1 = 1,2,2,3,3,4 ; upper n>>1 = 2,2,3,3,4,4
+    const int lo = n <= 4 ? v1 : (n <= 6 ? v2 : (n <= 8 ? v3 : v4));
+    const int hi = n <= 5 ? v2 : (n <= 7 ? v3 : v4);
+    return (n & 1) ? hi : (lo + hi + 1) >> 1;
+}
+
+// midpoint of the n present values among 6 slots (n >= 3)
+__device__ __forceinline__ int mid6(int &v0, int &v1, int &v2, int &v3, int &v4, int &v5, int n)
+{
+    cswap(v0, v5); cswap(v1, v3); cswap(v2, v4);
+    cswap(v1, v2); cswap(v3, v4);
+    cswap(v0, v3); cswap(v2, v5);
+    cswap(v0, v1); cswap(v2, v3); cswap(v4, v5);
+    cswap(v1, v2); cswap(v3, v4);
+    // n = 3..6: lower middle index 1,1,2,2 ; upper 1,2,2,3
+    const int lo = n <= 4 ? v1 : v2;
+    const int hi = n <= 3 ? v1 : (n <= 5 ? v2 : v3);
+    return (n & 1) ? hi : (lo + hi + 1) >> 1;
+}
+
+__device__ __forceinline__ void vote1(int v, int mid, int lim, int &sum, int &cnt)
+{
+    const bool in = iabs(v - mid) <= lim;        // never true for ABSENT (lim <= 255)
+    cnt += in;
+    sum += in ? v : 0;
+}
+
 __device__ __forceinline__ int collect3(int *v, int k, const uint8_t *row, int x, bool skip_centre)
 {
     if (row[x - 1] != PEAK) v[k++] = row[x - 1];
@@ -105,84 +155,144 @@ __global__ void k_fill_half(P3 P, int spitch0, int spitch1, int spitch2, int sta
     P.b[pl][(size_t)y * pitch + x] = x < width ? P.a[pl][(size_t)(start_line + 2 * y) * spitch + x] : 0;
 }
 
-// a = srcp, b = mskp (in place: upper half cleared, lower half keeps its old content)
-__global__ void k_edge_mask(P3 P, int mth, int vth, int lth)
+// ------------------------------------------------------------------------------------------
+// Four pixels per thread.  One byte per thread makes these passes latency bound: a wave lives
+// for one memory round trip whatever it computes, so the time is (#waves / resident waves) x
+// latency.  The *4 kernels below give a thread one aligned dword of its row and the dwords either
+// side of it (bytes x-4 .. x+7) from each row it needs: 4x fewer waves, same bytes, same flat
+// addressing (reads left of column 0 / right of the pitch land in the neighbouring row exactly
+// as the reference's pointer arithmetic does).
+struct Win12 { uint32_t w0, w1, w2; };
+
+__device__ __forceinline__ Win12 ldwin(const uint8_t *row_at_x)
 {
-    XY_PLANE(P);
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(row_at_x);
+    return Win12{p[-1], p[0], p[1]};
+}
+
+// byte at column x+i, i in [-4, 7] (compile-time after unrolling)
+__device__ __forceinline__ int wb(const Win12 &w, int i)
+{
+    const int k = i + 4;
+    const uint32_t d = k < 4 ? w.w0 : (k < 8 ? w.w1 : w.w2);
+    return (int)((d >> (8 * (k & 3))) & 0xffu);
+}
+
+// store the 4 result bytes of columns x..x+3, of which only those < limit exist in the reference's loop
+__device__ __forceinline__ void st4(uint8_t *dst_at_x, const int (&out)[4], int x, int limit)
+{
+    if (x + 3 < limit)
+        *reinterpret_cast<uint32_t *>(dst_at_x) = (uint32_t)out[0] | ((uint32_t)out[1] << 8) | ((uint32_t)out[2] << 16) | ((uint32_t)out[3] << 24);
+    else
+        for (int k = 0; k < 4 && x + k < limit; k++) dst_at_x[k] = (uint8_t)out[k];
+}
+
+#define XY4_PLANE(P)                                                        \
+    const int pl = blockIdx.z;                                              \
+    const int x = 4 * (blockIdx.x * blockDim.x + threadIdx.x);              \
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;                    \
+    const int pitch = (P).pitch[pl], width = (P).width[pl], height = (P).height[pl]; \
+    (void)width; (void)height; (void)pitch
+
+// k_edge_mask, 4 pixels per thread.  a = srcp, b = mskp (upper half rewritten, lower half only gains PEAKs)
+__global__ void k_edge_mask4(P3 P, int mth, int vth, int lth)
+{
+    XY4_PLANE(P);
     if (x >= pitch || y >= height) return;
+    const uint8_t *c = P.a[pl] + (size_t)y * pitch + x;
+    const Win12 wp = ldwin(c - pitch), wc = ldwin(c), wn = ldwin(c + pitch);
     uint8_t *o = P.b[pl] + (size_t)y * pitch + x;
-    int out = (y < height / 2) ? 0 : -1;                      // -1 = leave as is
-    if (x >= 1 && x < width - 1 && y >= 1 && y < height - 1)
-    {
-        const uint8_t *c = P.a[pl] + (size_t)y * pitch + x;
-        const uint8_t *p = c - pitch, *n = c + pitch;
-#define FLATCOL(i) (iabs((int)p[i] - (int)c[i]) < 10 && iabs((int)c[i] - (int)n[i]) < 10 && iabs((int)p[i] - (int)n[i]) < 10)
-        if (!(FLATCOL(0) || (FLATCOL(-1) && FLATCOL(1))))
-        {
-            int sum = 0, sumsq = 0;
+    const uint32_t old = *reinterpret_cast<const uint32_t *>(o);
+    int out[4];
 #pragma unroll
-            for (int i = -1; i <= 1; i++)
+    for (int k = 0; k < 4; k++)
+    {
+        int r = (y < height / 2) ? 0 : (int)((old >> (8 * k)) & 0xffu);
+        const int xx = x + k;
+        if (xx >= 1 && xx < width - 1 && y >= 1 && y < height - 1)
+        {
+            const int P0 = wb(wp, k - 1), P1 = wb(wp, k), P2 = wb(wp, k + 1);
+            const int C0 = wb(wc, k - 1), C1 = wb(wc, k), C2 = wb(wc, k + 1);
+            const int N0 = wb(wn, k - 1), N1 = wb(wn, k), N2 = wb(wn, k + 1);
+#define FLATCOL(a, b, d) (iabs((a) - (b)) < 10 && iabs((b) - (d)) < 10 && iabs((a) - (d)) < 10)
+            if (!(FLATCOL(P1, C1, N1) || (FLATCOL(P0, C0, N0) && FLATCOL(P2, C2, N2))))
             {
-                const int a0 = p[i], a1 = c[i], a2 = n[i];
-                sum += a0 + a1 + a2;
-                sumsq += a0 * a0 + a1 * a1 + a2 * a2;
-            }
-            if (9 * sumsq - sum * sum >= vth)
-            {
-                const int ix = (int)c[1] - (int)c[-1];
-                const int iy = max(max(iabs((int)p[0] - (int)n[0]), iabs((int)p[0] - (int)c[0])), iabs((int)c[0] - (int)n[0]));
-                if (ix * ix + iy * iy >= mth)
-                    out = PEAK;
-                else
+                const int sum = P0 + P1 + P2 + C0 + C1 + C2 + N0 + N1 + N2;
+                const int sumsq = P0 * P0 + P1 * P1 + P2 * P2 + C0 * C0 + C1 * C1 + C2 * C2 + N0 * N0 + N1 * N1 + N2 * N2;
+                if (9 * sumsq - sum * sum >= vth)
                 {
-                    const int ixx = (int)c[-1] - 2 * (int)c[0] + (int)c[1];
-                    const int iyy = (int)p[0] - 2 * (int)c[0] + (int)n[0];
-                    if (iabs(ixx) + iabs(iyy) >= lth) out = PEAK;
+                    const int ix = C2 - C0;
+                    const int iy = max(max(iabs(P1 - N1), iabs(P1 - C1)), iabs(C1 - N1));
+                    if (ix * ix + iy * iy >= mth)
+                        r = PEAK;
+                    else
+                    {
+                        const int ixx = C0 - 2 * C1 + C2;
+                        const int iyy = P1 - 2 * C1 + N1;
+                        if (iabs(ixx) + iabs(iyy) >= lth) r = PEAK;
+                    }
                 }
             }
-        }
 #undef FLATCOL
+        }
+        out[k] = r;
     }
-    if (out >= 0) *o = (uint8_t)out;
+    st4(o, out, x, pitch);
 }
 
-// a = mask in, b = mask out
-__global__ void k_morph(P3 P, int thr, int grow)
+// k_morph, 4 pixels per thread
+__global__ void k_morph4(P3 P, int thr, int grow)
 {
-    XY_PLANE(P);
+    XY4_PLANE(P);
     if (x >= width || y >= height) return;
     const uint8_t *c = P.a[pl] + (size_t)y * pitch + x;
-    int out = c[0];
-    if (x >= 1 && x < width - 1 && y >= 1 && y < height - 1)
+    const Win12 wp = ldwin(c - pitch), wc = ldwin(c), wn = ldwin(c + pitch);
+    int out[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
     {
-        const uint8_t *p = c - pitch, *n = c + pitch;
-        if (grow ? (c[0] == 0) : (c[0] == PEAK))
+        const int c1 = wb(wc, k);
+        int r = c1;
+        const int xx = x + k;
+        if (xx >= 1 && xx < width - 1 && y >= 1 && y < height - 1 && (grow ? (c1 == 0) : (c1 == PEAK)))
         {
-            const int count = (p[-1] == PEAK) + (p[0] == PEAK) + (p[1] == PEAK) + (c[-1] == PEAK) + (c[1] == PEAK) +
-                              (n[-1] == PEAK) + (n[0] == PEAK) + (n[1] == PEAK);
-            if (grow) { if (count >= thr) out = PEAK; }
-            else      { if (count < thr) out = 0; }
+            const int count = (wb(wp, k - 1) == PEAK) + (wb(wp, k) == PEAK) + (wb(wp, k + 1) == PEAK) +
+                              (wb(wc, k - 1) == PEAK) + (wb(wc, k + 1) == PEAK) +
+                              (wb(wn, k - 1) == PEAK) + (wb(wn, k) == PEAK) + (wb(wn, k + 1) == PEAK);
+            if (grow) { if (count >= thr) r = PEAK; }
+            else      { if (count < thr) r = 0; }
         }
+        out[k] = r;
     }
-    P.b[pl][(size_t)y * pitch + x] = (uint8_t)out;
+    st4(P.b[pl] + (size_t)y * pitch + x, out, x, width);
 }
 
-__global__ void k_small_gaps(P3 P)
+// k_small_gaps, 4 pixels per thread
+__global__ void k_small_gaps4(P3 P)
 {
-    XY_PLANE(P);
+    XY4_PLANE(P);
     if (x >= width || y >= height) return;
-    const uint8_t *m = P.a[pl] + (size_t)y * pitch + x;
-    int out = m[0];
-    if (x >= 3 && x < width - 3 && y >= 1 && y < height - 1)
+    const Win12 w = ldwin(P.a[pl] + (size_t)y * pitch + x);
+    int out[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
     {
-        if (m[0])
+        const int a3 = wb(w, k - 3), a2 = wb(w, k - 2), a1 = wb(w, k - 1), c = wb(w, k);
+        const int b1 = wb(w, k + 1), b2 = wb(w, k + 2), b3 = wb(w, k + 3);
+        int r = c;
+        const int xx = x + k;
+        if (xx >= 3 && xx < width - 3 && y >= 1 && y < height - 1)
         {
-            if (!(m[-3] || m[-2] || m[-1] || m[1] || m[2] || m[3])) out = 0;
+            if (c)
+            {
+                if (!(a3 || a2 || a1 || b1 || b2 || b3)) r = 0;
+            }
+            else if ((b1 && (a1 || a2 || a3)) || (b2 && (a1 || a2)) || (b3 && a1))
+                r = PEAK;
         }
-        else if ((m[1] && (m[-1] || m[-2] || m[-3])) || (m[2] && (m[-1] || m[-2])) || (m[3] && m[-1]))
-            out = PEAK;
+        out[k] = r;
     }
-    P.b[pl][(size_t)y * pitch + x] = (uint8_t)out;
+    st4(P.b[pl] + (size_t)y * pitch + x, out, x, width);
 }
 
 // calc_directions in two launches so that no lane idles while its neighbour walks the
@@ -389,34 +499,51 @@ __global__ void k_dir_map(P3 P, int step, int y0, int expand)
 {
     XY_PLANE(P);
     if (x >= width || y >= height) return;
-    const uint8_t *dc = P.b[pl] + (size_t)y * pitch;
-    int out = dc[x];                                           // bit_blit
+    // Every byte this pixel may look at is loaded before the first decision (the rows exist: the
+    // scratch frames sit inside zeroed guard bands), so the kernel pays one memory round trip
+    // instead of three dependent ones.
+    const uint8_t *dc = P.b[pl] + (size_t)y * pitch + x;
+    const uint8_t *du = dc - (ptrdiff_t)step * pitch, *dd = dc + (ptrdiff_t)step * pitch;
+    const uint8_t *mk = P.a[pl] + (size_t)y * pitch + x;
+    const int c0 = dc[-1], c1 = dc[0], c2 = dc[1];
+    const int u0 = du[-1], u1 = du[0], u2 = du[1];
+    const int n0 = dd[-1], n1 = dd[0], n2 = dd[1];
+    const int m0 = step == 1 ? mk[0] : mk[-(ptrdiff_t)pitch], m1 = step == 1 ? 0 : mk[pitch];
+    int out = c1;                                              // bit_blit
     const bool row_ok = step == 1 ? (y >= 1 && y < height - 1) : (y >= y0 && y < height - 1 && ((y - y0) & 1) == 0);
     if (row_ok && x >= 1 && x < width - 1)
     {
-        bool masked;
-        if (step == 1) masked = P.a[pl][(size_t)y * pitch + x] == PEAK;
-        else           masked = P.a[pl][(size_t)(y - 1) * pitch + x] == PEAK || P.a[pl][(size_t)(y + 1) * pitch + x] == PEAK;
-        if (masked && !(expand && dc[x] != PEAK))
+        const bool masked = m0 == PEAK || (step != 1 && m1 == PEAK);
+        if (masked && !(expand && c1 != PEAK))
         {
-            int order[9], u = 0;
-            if (step == 1 || y > 1) u = collect3(order, u, dc - step * pitch, x, false);
-            u = collect3(order, u, dc, x, expand);
-            if (step == 1 || y < height - 2) u = collect3(order, u, dc + step * pitch, x, false);
+            // keep this a real branch: flattened, every wave would pay for the sort below
+            asm volatile("" ::: "memory");
+            const bool up_ok = step == 1 || y > 1, dn_ok = step == 1 || y < height - 2;
+            const bool h0 = up_ok && u0 != PEAK, h1 = up_ok && u1 != PEAK, h2 = up_ok && u2 != PEAK;
+            const bool h3 = c0 != PEAK, h4 = !expand && c1 != PEAK, h5 = c2 != PEAK;
+            const bool h6 = dn_ok && n0 != PEAK, h7 = dn_ok && n1 != PEAK, h8 = dn_ok && n2 != PEAK;
+            const int u = h0 + h1 + h2 + h3 + h4 + h5 + h6 + h7 + h8;
             if (u < (expand ? 5 : 4))
             {
                 if (!expand) out = PEAK;
             }
             else
             {
-                const int mid = sorted_mid(order, u);
-                int count;
-                const int val = vote(order, u, mid, c_limlut[iabs(mid - NEUTRAL) >> 2], count);
+                int v0 = h0 ? u0 : ABSENT, v1 = h1 ? u1 : ABSENT, v2 = h2 ? u2 : ABSENT;
+                int v3 = h3 ? c0 : ABSENT, v4 = h4 ? c1 : ABSENT, v5 = h5 ? c2 : ABSENT;
+                int v6 = h6 ? n0 : ABSENT, v7 = h7 ? n1 : ABSENT, v8 = h8 ? n2 : ABSENT;
+                const int mid = mid9(v0, v1, v2, v3, v4, v5, v6, v7, v8, u);
+                const int lim = c_limlut[iabs(mid - NEUTRAL) >> 2];
+                int sum = 0, count = 0;
+                vote1(v0, mid, lim, sum, count); vote1(v1, mid, lim, sum, count); vote1(v2, mid, lim, sum, count);
+                vote1(v3, mid, lim, sum, count); vote1(v4, mid, lim, sum, count); vote1(v5, mid, lim, sum, count);
+                vote1(v6, mid, lim, sum, count); vote1(v7, mid, lim, sum, count); vote1(v8, mid, lim, sum, count);
+                const int val = (int)(((float)(sum + mid) / (float)(count + 1)) + 0.5f);
                 if (expand)
                 {
                     if (count >= 5) out = val & 0xff;
                 }
-                else if (count < 4 || (count < 5 && dc[x] == PEAK))
+                else if (count < 4 || (count < 5 && c1 == PEAK))
                     out = PEAK;
                 else
                     out = val & 0xff;
@@ -465,16 +592,22 @@ __global__ void k_filter_map(P3 P)
     P.c[pl][(size_t)y * pitch + x] = (uint8_t)out;
 }
 
-// line doubling of three half-height planes: a->d, b->e, c->f ; height = half height
+// line doubling of three half-height planes: a->d, b->e, c->f ; height = half height.
+// 16 bytes per thread (the pitch is a multiple of 64).
 __global__ void k_upscale3(P3 P)
 {
-    XY_PLANE(P);
+    const int pl = blockIdx.z;
+    const int x = 16 * (blockIdx.x * blockDim.x + threadIdx.x);
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    const int pitch = P.pitch[pl], height = P.height[pl];
     if (x >= pitch || y >= height) return;
     const size_t s = (size_t)y * pitch + x, d0 = (size_t)(2 * y) * pitch + x, d1 = d0 + pitch;
-    const uint8_t va = P.a[pl][s], vb = P.b[pl][s], vc = P.c[pl][s];
-    P.d[pl][d0] = va; P.d[pl][d1] = va;
-    P.e[pl][d0] = vb; P.e[pl][d1] = vb;
-    P.f[pl][d0] = vc; P.f[pl][d1] = vc;
+    const uint4 va = *reinterpret_cast<const uint4 *>(P.a[pl] + s);
+    const uint4 vb = *reinterpret_cast<const uint4 *>(P.b[pl] + s);
+    const uint4 vc = *reinterpret_cast<const uint4 *>(P.c[pl] + s);
+    *reinterpret_cast<uint4 *>(P.d[pl] + d0) = va; *reinterpret_cast<uint4 *>(P.d[pl] + d1) = va;
+    *reinterpret_cast<uint4 *>(P.e[pl] + d0) = vb; *reinterpret_cast<uint4 *>(P.e[pl] + d1) = vb;
+    *reinterpret_cast<uint4 *>(P.f[pl] + d0) = vc; *reinterpret_cast<uint4 *>(P.f[pl] + d1) = vc;
 }
 
 // a = msk2p, b = dmsk (tmp2p2), c = out (tmp2p)
@@ -483,27 +616,33 @@ __global__ void k_mark_2x(P3 P, int y0)
     XY_PLANE(P);
     if (x >= pitch || y >= height) return;
     int out = 255;                                            // memset(dstp, 255, pitch*height)
+    // all loads up front (one memory round trip); rows y-1 / y+1 exist inside the guard bands
+    const uint8_t *d0 = P.b[pl] + (ptrdiff_t)(y - 1) * pitch + x, *d1 = d0 + 2 * (size_t)pitch;
+    const uint8_t *m0 = P.a[pl] + (ptrdiff_t)(y - 1) * pitch + x, *m1 = m0 + 2 * (size_t)pitch;
+    const int a0 = d0[-1], a1 = d0[0], a2 = d0[1], b0 = d1[-1], b1 = d1[0], b2 = d1[1];
+    const int k0 = m0[0], k1 = m1[0];
     if (y >= y0 && y < height - 1 && ((y - y0) & 1) == 0 && x >= 1 && x < width - 1)
     {
-        const uint8_t *d0 = P.b[pl] + (size_t)(y - 1) * pitch, *d1 = d0 + 2 * (size_t)pitch;
-        const uint8_t *m0 = P.a[pl] + (size_t)(y - 1) * pitch, *m1 = m0 + 2 * (size_t)pitch;
-        if (m0[x] == PEAK || m1[x] == PEAK)
+        if (k0 == PEAK || k1 == PEAK)
         {
-            int order[6], v = 0;
-            v = collect3(order, v, d0, x, false);
-            v = collect3(order, v, d1, x, false);
+            asm volatile("" ::: "memory");                    // keep the branch (see k_dir_map)
+            const int v = (a0 != PEAK) + (a1 != PEAK) + (a2 != PEAK) + (b0 != PEAK) + (b1 != PEAK) + (b2 != PEAK);
             if (v >= 3)
             {
-                const int mid = sorted_mid(order, v);
+                int s0 = a0 != PEAK ? a0 : ABSENT, s1 = a1 != PEAK ? a1 : ABSENT, s2 = a2 != PEAK ? a2 : ABSENT;
+                int s3 = b0 != PEAK ? b0 : ABSENT, s4 = b1 != PEAK ? b1 : ABSENT, s5 = b2 != PEAK ? b2 : ABSENT;
+                const int mid = mid6(s0, s1, s2, s3, s4, s5, v);
                 const int lim = c_limlut[iabs(mid - NEUTRAL) >> 2];
                 int u = 0;
-                if (iabs((int)d0[x - 1] - (int)d1[x - 1]) <= lim || d0[x - 1] == PEAK || d1[x - 1] == PEAK) u++;
-                if (iabs((int)d0[x] - (int)d1[x]) <= lim || d0[x] == PEAK || d1[x] == PEAK) u++;
-                if (iabs((int)d0[x + 1] - (int)d1[x - 1]) <= lim || d0[x + 1] == PEAK || d1[x + 1] == PEAK) u++;   // sic (:835)
+                if (iabs(a0 - b0) <= lim || a0 == PEAK || b0 == PEAK) u++;
+                if (iabs(a1 - b1) <= lim || a1 == PEAK || b1 == PEAK) u++;
+                if (iabs(a2 - b0) <= lim || a2 == PEAK || b2 == PEAK) u++;   // sic (:835): d0[x+1] against d1[x-1]
                 if (u >= 2)
                 {
-                    int count;
-                    const int val = vote(order, v, mid, lim, count);
+                    int sum = 0, count = 0;
+                    vote1(s0, mid, lim, sum, count); vote1(s1, mid, lim, sum, count); vote1(s2, mid, lim, sum, count);
+                    vote1(s3, mid, lim, sum, count); vote1(s4, mid, lim, sum, count); vote1(s5, mid, lim, sum, count);
+                    const int val = (int)(((float)(sum + mid) / (float)(count + 1)) + 0.5f);
                     if (!(count < v - 2 || count < 2)) out = val & 0xff;
                 }
             }
@@ -598,29 +737,32 @@ __global__ __launch_bounds__(256) void k_lattice_cand(P3 P, uint32_t *__restrict
     const uint8_t *ot = P.c[pl] + (size_t)(y - 1) * pitch, *ob = ot + 2 * (size_t)pitch;
     const uint8_t *dm = P.a[pl] + (size_t)y * pitch;
 
-    const int d = dm[x];
+    // the fixed-offset bytes every path below needs, loaded together
+    const int d = dm[x], dr = dm[x + 1];
+    const int T0 = top[x - 2], T1 = top[x - 1], T2 = top[x], T3 = top[x + 1], T4 = top[x + 2];
+    const int B0 = bot[x - 2], B1 = bot[x - 1], B2 = bot[x], B3 = bot[x + 1], B4 = bot[x + 2];
     const int lim = c_limlut[iabs(d - NEUTRAL) >> 2];
-    const int avg = ((int)top[x] + (int)bot[x] + 1) >> 1;
+    const int avg = (T2 + B2 + 1) >> 1;
     const bool always_a = d == PEAK;
-    const bool right = iabs(d - (int)dm[x + 1]) > lim;
+    const bool right = iabs(d - dr) > lim;
     int valB = avg, newB = NEUTRAL;
     if (!always_a)
     {
         bool done = false;
         if (lim < 9)
         {
-            const int t0 = top[x - 1], t1 = top[x], t2 = top[x + 1], b0 = bot[x - 1], b1 = bot[x], b2 = bot[x + 1];
+            const int t0 = T1, t1 = T2, t2 = T3, b0 = B1, b1 = B2, b2 = B3;
             const int sum = t0 + t1 + t2 + b0 + b1 + b2;
             const int sumsq = t0 * t0 + t1 * t1 + t2 * t2 + b0 * b0 + b1 * b1 + b2 * b2;
             if (6 * sumsq - sum * sum < 576) { valB = avg; newB = PEAK; done = true; }
         }
         if (!done && x > 1 && x < width - 2)
         {
-            const int t = top[x], b = bot[x];
-            const int tl = max((int)top[x - 2], (int)top[x - 1]), tr = max((int)top[x + 2], (int)top[x + 1]);
-            const int bl = max((int)bot[x - 2], (int)bot[x - 1]), br = max((int)bot[x + 2], (int)bot[x + 1]);
-            const int tl2 = min((int)top[x - 2], (int)top[x - 1]), tr2 = min((int)top[x + 2], (int)top[x + 1]);
-            const int bl2 = min((int)bot[x - 2], (int)bot[x - 1]), br2 = min((int)bot[x + 2], (int)bot[x + 1]);
+            const int t = T2, b = B2;
+            const int tl = max(T0, T1), tr = max(T4, T3);
+            const int bl = max(B0, B1), br = max(B4, B3);
+            const int tl2 = min(T0, T1), tr2 = min(T4, T3);
+            const int bl2 = min(B0, B1), br2 = min(B4, B3);
             if ((t < tl - 3 && t < tr - 3 && b < bl - 3 && b < br - 3) ||
                 (t > tl2 + 3 && t > tr2 + 3 && b > bl2 + 3 && b > br2 + 3))
             { valB = avg; newB = NEUTRAL; done = true; }
@@ -760,26 +902,38 @@ __global__ __launch_bounds__(64) void k_lattice_resolve(P3 P, const uint32_t *__
     }
 }
 
-// a = src, b = dst : copies `width` bytes of every row (eedi2_bit_blit)
+// a = src, b = dst : copies `width` bytes of every row (eedi2_bit_blit), 4 per thread
 __global__ void k_blit(P3 P)
 {
-    XY_PLANE(P);
+    XY4_PLANE(P);
     if (x >= width || y >= height) return;
-    P.b[pl][(size_t)y * pitch + x] = P.a[pl][(size_t)y * pitch + x];
+    const uint32_t v = *reinterpret_cast<const uint32_t *>(P.a[pl] + (size_t)y * pitch + x);
+    const int out[4] = { (int)(v & 0xffu), (int)((v >> 8) & 0xffu), (int)((v >> 16) & 0xffu), (int)(v >> 24) };
+    st4(P.b[pl] + (size_t)y * pitch + x, out, x, width);
 }
 
-// a = nmsk, b = omsk, c = dst (in place, row y from rows y+-1)
+// a = nmsk, b = omsk, c = dst (in place, row y from rows y+-1), 4 pixels per thread
 __global__ void k_post(P3 P, int y0)
 {
-    XY_PLANE(P);
+    XY4_PLANE(P);
     if (x >= width || y >= height - 1 || y < y0 || ((y - y0) & 1)) return;
-    const int nm = P.a[pl][(size_t)y * pitch + x], om = P.b[pl][(size_t)y * pitch + x];
-    const int lim = c_limlut[iabs(nm - NEUTRAL) >> 2];
-    if (iabs(nm - om) > lim && om != PEAK && om != NEUTRAL)
+    const size_t at = (size_t)y * pitch + x;
+    const uint32_t nm4 = *reinterpret_cast<const uint32_t *>(P.a[pl] + at), om4 = *reinterpret_cast<const uint32_t *>(P.b[pl] + at);
+    uint8_t *d = P.c[pl] + at;
+    const uint32_t up4 = *reinterpret_cast<const uint32_t *>(d - pitch), dn4 = *reinterpret_cast<const uint32_t *>(d + pitch);
+    const uint32_t cur4 = *reinterpret_cast<const uint32_t *>(d);
+    int out[4];
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
     {
-        uint8_t *d = P.c[pl] + (size_t)y * pitch + x;
-        *d = (uint8_t)(((int)d[-pitch] + (int)d[pitch] + 1) >> 1);
+        const int nm = (nm4 >> (8 * k)) & 0xffu, om = (om4 >> (8 * k)) & 0xffu;
+        const int lim = c_limlut[iabs(nm - NEUTRAL) >> 2];
+        const bool fix = iabs(nm - om) > lim && om != PEAK && om != NEUTRAL;
+        out[k] = fix ? (int)((((up4 >> (8 * k)) & 0xffu) + ((dn4 >> (8 * k)) & 0xffu) + 1) >> 1) : (int)((cur4 >> (8 * k)) & 0xffu);
+        any |= fix;
     }
+    if (any) st4(d, out, x, width);
 }
 
 } // namespace
@@ -916,6 +1070,10 @@ int Eedi2Engine::enqueue_passes(int tff)
         const int w = whole_pitch ? f.stride[0] : f.width[0];
         return dim3((w + 63) / 64, (f.height[0] + 3) / 4, 3);
     };
+    auto grid4_for = [&](const EediFrame &f, bool whole_pitch) {        // kernels with 4 pixels per thread
+        const int w = whole_pitch ? f.stride[0] : f.width[0];
+        return dim3((w + 255) / 256, (f.height[0] + 3) / 4, 3);
+    };
     auto geom = [&](P3 &P, const EediFrame &f) {
         for (int c = 0; c < 3; c++) { P.pitch[c] = f.stride[c]; P.width[c] = f.width[c]; P.height[c] = f.height[c]; }
     };
@@ -927,16 +1085,16 @@ int Eedi2Engine::enqueue_passes(int tff)
     // half-height passes
     geom(P, srcp);
     bind(P.a, srcp); bind(P.b, mskp);
-    HBHIP_LAUNCH(ctx_, "eedi2_edge_mask", k_edge_mask, grid_for(srcp, true), blk, 0, P,
+    HBHIP_LAUNCH(ctx_, "eedi2_edge_mask", k_edge_mask4, grid4_for(srcp, true), blk, 0, P,
                  par_.magnitude_threshold * 10, par_.laplacian_threshold * 81, par_.variance_threshold);
     bind(P.a, mskp); bind(P.b, tmpp);
-    HBHIP_LAUNCH(ctx_, "eedi2_erode", k_morph, grid_for(srcp, false), blk, 0, P, par_.erosion_threshold, 0);
+    HBHIP_LAUNCH(ctx_, "eedi2_erode", k_morph4, grid4_for(srcp, false), blk, 0, P, par_.erosion_threshold, 0);
     bind(P.a, tmpp); bind(P.b, mskp);
-    HBHIP_LAUNCH(ctx_, "eedi2_dilate", k_morph, grid_for(srcp, false), blk, 0, P, par_.dilation_threshold, 1);
+    HBHIP_LAUNCH(ctx_, "eedi2_dilate", k_morph4, grid4_for(srcp, false), blk, 0, P, par_.dilation_threshold, 1);
     bind(P.a, mskp); bind(P.b, tmpp);
-    HBHIP_LAUNCH(ctx_, "eedi2_erode", k_morph, grid_for(srcp, false), blk, 0, P, par_.erosion_threshold, 0);
+    HBHIP_LAUNCH(ctx_, "eedi2_erode", k_morph4, grid4_for(srcp, false), blk, 0, P, par_.erosion_threshold, 0);
     bind(P.a, tmpp); bind(P.b, mskp);
-    HBHIP_LAUNCH(ctx_, "eedi2_small_gaps", k_small_gaps, grid_for(srcp, false), blk, 0, P);
+    HBHIP_LAUNCH(ctx_, "eedi2_small_gaps", k_small_gaps4, grid4_for(srcp, false), blk, 0, P);
     bind(P.a, mskp); bind(P.b, srcp); bind(P.c, tmpp);
     if (par_.maximum_search_distance <= CD_HALO - 2)
     {
@@ -963,7 +1121,7 @@ int Eedi2Engine::enqueue_passes(int tff)
     // line doubling
     bind(P.a, srcp); bind(P.b, dstp); bind(P.c, mskp);
     bind(P.d, dst2p); bind(P.e, tmp2p2); bind(P.f, msk2p);
-    HBHIP_LAUNCH(ctx_, "eedi2_upscale_by_2", k_upscale3, grid_for(srcp, true), blk, 0, P);
+    HBHIP_LAUNCH(ctx_, "eedi2_upscale_by_2", k_upscale3, dim3((srcp.stride[0] / 16 + 63) / 64, (srcp.height[0] + 3) / 4, 3), blk, 0, P);
     // full-height passes
     geom(P, dst2p);
     const int y0 = 2 - tff;
@@ -990,13 +1148,13 @@ int Eedi2Engine::enqueue_passes(int tff)
     if (par_.post_processing == 1 || par_.post_processing == 3)
     {
         bind(P.a, tmp2p); bind(P.b, tmp2p2);
-        HBHIP_LAUNCH(ctx_, "eedi2_bit_blit", k_blit, grid_for(dst2p, false), blk, 0, P);
+        HBHIP_LAUNCH(ctx_, "eedi2_bit_blit", k_blit, grid4_for(dst2p, false), blk, 0, P);
         bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
         HBHIP_LAUNCH(ctx_, "eedi2_filter_dir_map_2x", k_dir_map, grid_for(dst2p, false), blk, 0, P, 2, y0, 0);
         bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
         HBHIP_LAUNCH(ctx_, "eedi2_expand_dir_map_2x", k_dir_map, grid_for(dst2p, false), blk, 0, P, 2, y0, 1);
         bind(P.a, tmp2p); bind(P.b, tmp2p2); bind(P.c, dst2p);
-        HBHIP_LAUNCH(ctx_, "eedi2_post_process", k_post, grid_for(dst2p, false), blk, 0, P, y0);
+        HBHIP_LAUNCH(ctx_, "eedi2_post_process", k_post, grid4_for(dst2p, false), blk, 0, P, y0);
     }
     HBHIP_CHECK(ctx_, hipGetLastError());
     return HBHIP_OK;
