@@ -388,15 +388,22 @@ __global__ __launch_bounds__(256) void k_calc_dir_work(P3 P, const uint32_t *__r
 // walks its +-maxd window out of LDS.
 constexpr int CD_W = 256, CD_HALO = 32, CD_LW = CD_W + 2 * CD_HALO;
 
-__device__ __forceinline__ int sad3l(const uint8_t *a, int ai, const uint8_t *b, int bi)
+// does any of the three low bytes equal 255?
+__device__ __forceinline__ bool any_peak3(uint32_t v)
 {
-    return (int)__usad(a[ai + 1], b[bi + 1], __usad(a[ai], b[bi], __usad(a[ai - 1], b[bi - 1], 0u)));
+    const uint32_t t = v & 0x00ffffffu;
+    return ((((t & 0x007f7f7fu) + 0x00010101u) & t) & 0x00808080u) != 0u;
+}
+
+// sum of absolute differences of the three low bytes (+ acc)
+__device__ __forceinline__ uint32_t sad3p(uint32_t a24, uint32_t b, uint32_t acc)
+{
+    return __builtin_amdgcn_sad_u8(a24, b & 0x00ffffffu, acc);
 }
 
 __global__ __launch_bounds__(CD_W) void k_calc_dir_tile(P3 P, int maxd, int nt13, int nt19)
 {
-    __shared__ uint8_t s_src[5][CD_LW];
-    __shared__ uint8_t s_msk[3][CD_LW];
+    __shared__ __attribute__((aligned(16))) uint8_t s_band[8][CD_LW];   // rows 0..4 source y-2..y+2, 5..7 mask y-1..y+1
     __shared__ uint16_t s_list[CD_W];
     __shared__ int s_count;
     const int pl = blockIdx.z;
@@ -406,14 +413,14 @@ __global__ __launch_bounds__(CD_W) void k_calc_dir_tile(P3 P, int maxd, int nt13
     const int tid = threadIdx.x;
     if (tid == 0) s_count = 0;
     {
+        // staged as dwords (x0, CD_HALO and the pitch are multiples of 4)
         const uint8_t *sb = P.b[pl] + (ptrdiff_t)(y - 2) * pitch + x0 - CD_HALO;
         const uint8_t *mb = P.a[pl] + (ptrdiff_t)(y - 1) * pitch + x0 - CD_HALO;
-        for (int i = tid; i < CD_LW; i += CD_W)
+        for (int i = tid; i < 8 * (CD_LW / 4); i += CD_W)
         {
-#pragma unroll
-            for (int r = 0; r < 5; r++) s_src[r][i] = sb[(ptrdiff_t)r * pitch + i];
-#pragma unroll
-            for (int r = 0; r < 3; r++) s_msk[r][i] = mb[(ptrdiff_t)r * pitch + i];
+            const int r = i / (CD_LW / 4), c4 = i - r * (CD_LW / 4);
+            const uint8_t *src = r < 5 ? sb + (ptrdiff_t)r * pitch : mb + (ptrdiff_t)(r - 5) * pitch;
+            reinterpret_cast<uint32_t *>(s_band[r])[c4] = reinterpret_cast<const uint32_t *>(src)[c4];
         }
     }
     __syncthreads();
@@ -422,7 +429,7 @@ __global__ __launch_bounds__(CD_W) void k_calc_dir_tile(P3 P, int maxd, int nt13
     if (x < pitch)
     {
         if (x >= 1 && x < width - 1 && y >= 1 && y < height - 1)
-            active = s_msk[1][c] == PEAK && (s_msk[1][c - 1] == PEAK || s_msk[1][c + 1] == PEAK);
+            active = s_band[6][c] == PEAK && (s_band[6][c - 1] == PEAK || s_band[6][c + 1] == PEAK);
         if (!active) P.c[pl][(size_t)y * pitch + x] = 255;        // memset(dstp, 255, pitch*height)
     }
     if (active) s_list[atomicAdd(&s_count, 1)] = (uint16_t)tid;
@@ -431,30 +438,46 @@ __global__ __launch_bounds__(CD_W) void k_calc_dir_tile(P3 P, int maxd, int nt13
 
     const int lx = s_list[tid];
     const int px = x0 + lx, cc = lx + CD_HALO;
-    const uint8_t *s2p = s_src[0], *sp = s_src[1], *sc = s_src[2], *sn = s_src[3], *s2n = s_src[4];
-    const uint8_t *mp = s_msk[0], *mn = s_msk[2];
     const int maxdt = pl == 0 ? maxd : (maxd >> 1);
     const int startu = max(-px + 1, -maxdt), stopu = min(width - 2 - px, maxdt);
-    const int vert = iabs((int)sc[cc] - (int)sn[cc]) + iabs((int)sc[cc] - (int)sp[cc]);
+    // the centre triples (columns cc-1..cc+1) of the five source rows, packed in 24 bits
+    auto triple = [&](int r) -> uint32_t {
+        return (uint32_t)s_band[r][cc - 1] | ((uint32_t)s_band[r][cc] << 8) | ((uint32_t)s_band[r][cc + 1] << 16);
+    };
+    const uint32_t F2p = triple(0), Fp = triple(1), Fc = triple(2), Fn = triple(3), F2n = triple(4);
+    const int vert = iabs((int)s_band[2][cc] - (int)s_band[3][cc]) + iabs((int)s_band[2][cc] - (int)s_band[1][cc]);
     int minb = min(nt13, vert * 6), mina = min(nt19, vert * 9);
     int minc = mina, mind = minb, mine = minb;
     int dira = -5000, dirb = -5000, dirc = -5000, dird = -5000, dire = -5000;
     const bool first = y == 1, last = y == height - 2;
+    // Per step u the triples at column (cc-1+u) of four rows and at (cc-1-u) of five rows are
+    // needed: each is two aligned LDS dwords realigned with v_alignbyte (an unaligned LDS dword
+    // read exists on gfx950 but is several times slower), then one v_sad_u8 against a centre triple.
+    const uint32_t *band = reinterpret_cast<const uint32_t *>(&s_band[0][0]);
+    constexpr int RW = CD_LW / 4;                                   // dwords per staged row
+    struct { uint32_t sn_m, sp_p, sc_m, sc_p, sp_m, s2p_p, sn_p, s2n_m, mp_p, mn_m; } g;
     for (int u = startu; u <= stopu; u++)
     {
-        if (!(first || mp[cc - 1 + u] == PEAK || mp[cc + u] == PEAK || mp[cc + 1 + u] == PEAK)) continue;
-        if (!(last || mn[cc - 1 - u] == PEAK || mn[cc - u] == PEAK || mn[cc + 1 - u] == PEAK)) continue;
-        const int diffsn = sad3l(sc, cc, sn, cc - u);
-        const int diffsp = sad3l(sc, cc, sp, cc + u);
-        const int diffps = sad3l(sp, cc, sc, cc - u);
-        const int diffns = sad3l(sn, cc, sc, cc + u);
-        const int diff = diffsn + diffsp + diffps + diffns;
-        int diffd = diffsp + diffns, diffe = diffsn + diffps;
+        const int ca = cc - 1 + u, cm = cc - 1 - u;
+        const uint32_t *qa = band + (ca >> 2), *qm = band + (cm >> 2);
+        const uint32_t sa = (uint32_t)(ca & 3), sm = (uint32_t)(cm & 3);
+#define TRI(q, row, sh) __builtin_amdgcn_alignbyte((q)[(row) * RW + 1], (q)[(row) * RW], (sh))
+        g.mp_p = TRI(qa, 5, sa);
+        g.mn_m = TRI(qm, 7, sm);
+        if (!(first || any_peak3(g.mp_p))) continue;              // (:395-399)
+        if (!(last || any_peak3(g.mn_m))) continue;
+        g.sn_m = TRI(qm, 3, sm); g.sc_m = TRI(qm, 2, sm); g.sp_m = TRI(qm, 1, sm); g.s2n_m = TRI(qm, 4, sm);
+        g.sp_p = TRI(qa, 1, sa); g.sc_p = TRI(qa, 2, sa); g.s2p_p = TRI(qa, 0, sa); g.sn_p = TRI(qa, 3, sa);
+#undef TRI
+        const int e1 = (int)sad3p(Fp, g.sc_m, sad3p(Fc, g.sn_m, 0));   // diffsn + diffps
+        const int d1 = (int)sad3p(Fn, g.sc_p, sad3p(Fc, g.sp_p, 0));   // diffsp + diffns
+        const int diff = e1 + d1;
+        int diffd = d1, diffe = e1;
         if (diff < minb) { dirb = u; minb = diff; }
         if (!first)
         {
-            const int diff2pp = sad3l(s2p, cc, sp, cc - u);
-            const int diffp2p = sad3l(sp, cc, s2p, cc + u);
+            const int diff2pp = (int)sad3p(F2p, g.sp_m, 0);
+            const int diffp2p = (int)sad3p(Fp, g.s2p_p, 0);
             const int diffa = diff + diff2pp + diffp2p;
             diffd += diffp2p;
             diffe += diff2pp;
@@ -462,8 +485,8 @@ __global__ __launch_bounds__(CD_W) void k_calc_dir_tile(P3 P, int maxd, int nt13
         }
         if (!last)
         {
-            const int diff2nn = sad3l(s2n, cc, sn, cc + u);
-            const int diffn2n = sad3l(sn, cc, s2n, cc - u);
+            const int diff2nn = (int)sad3p(F2n, g.sn_p, 0);
+            const int diffn2n = (int)sad3p(Fn, g.s2n_m, 0);
             const int diffc = diff + diff2nn + diffn2n;
             diffd += diff2nn;
             diffe += diffn2n;
