@@ -745,20 +745,40 @@ __global__ void k_fill_gaps(P3 P, int y0)
 // that depends on the value just written at x-1 (:1194) — with a 64-lane prefix composition
 // of 2-state maps, carrying the last written value from chunk to chunk, then writes the row.
 // a = dmsk (tmp2p, in/out), b = dst (dst2p, in/out), c = omsk (tmp2p2).
-__global__ __launch_bounds__(256) void k_lattice_cand(P3 P, uint32_t *__restrict__ cand, int cand_pitch,
-                                                       int cand_plane_stride, int field, int nt4, int nt7, int nt8, int nt)
+constexpr int LC_W = 256, LC_HALO = 40, LC_LW = LC_W + 2 * LC_HALO;   // |u| <= 34, +-1 for the triples, rounded to dwords
+
+__global__ __launch_bounds__(LC_W) void k_lattice_cand(P3 P, uint32_t *__restrict__ cand, int cand_pitch,
+                                                        int cand_plane_stride, int field, int nt4, int nt7, int nt8, int nt)
 {
+    // One workgroup = 256 consecutive pixels of one rebuilt row.  The five rows the search reads
+    // (dst y-1 / y+1, old direction map y-1 / y+1, new direction map y) are staged in LDS with the
+    // same flat addressing, so every data-dependent byte read below is an LDS read.
+    __shared__ __attribute__((aligned(16))) uint8_t s_rows[5][LC_LW];
     const int pl = blockIdx.z;
     const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int ri = blockIdx.y * blockDim.y + threadIdx.y;
+    const int x0 = blockIdx.x * LC_W;
+    const int x = x0 + threadIdx.x;
+    const int ri = blockIdx.y;
     const int nrows = (height - (2 - field)) / 2;
-    if (x >= width || ri >= nrows) return;
+    if (x0 >= width || ri >= nrows) return;
     const int y = (2 - field) + 2 * ri;
-    const uint8_t *dst = P.b[pl];
-    const uint8_t *top = dst + (size_t)(y - 1) * pitch, *bot = top + 2 * (size_t)pitch;
-    const uint8_t *ot = P.c[pl] + (size_t)(y - 1) * pitch, *ob = ot + 2 * (size_t)pitch;
-    const uint8_t *dm = P.a[pl] + (size_t)y * pitch;
+    {
+        const uint8_t *g[5] = { P.b[pl] + (size_t)(y - 1) * pitch, P.b[pl] + (size_t)(y + 1) * pitch,
+                                P.c[pl] + (size_t)(y - 1) * pitch, P.c[pl] + (size_t)(y + 1) * pitch,
+                                P.a[pl] + (size_t)y * pitch };
+        for (int i = threadIdx.x; i < 5 * (LC_LW / 4); i += LC_W)
+        {
+            const int r = i / (LC_LW / 4), c4 = i - r * (LC_LW / 4);
+            reinterpret_cast<uint32_t *>(s_rows[r])[c4] =
+                reinterpret_cast<const uint32_t *>(g[r] + x0 - LC_HALO)[c4];
+        }
+    }
+    __syncthreads();
+    if (x >= width) return;
+    // row pointers indexed by the absolute column, as in the reference
+    const uint8_t *top = s_rows[0] + LC_HALO - x0, *bot = s_rows[1] + LC_HALO - x0;
+    const uint8_t *ot = s_rows[2] + LC_HALO - x0, *ob = s_rows[3] + LC_HALO - x0;
+    const uint8_t *dm = s_rows[4] + LC_HALO - x0;
 
     // the fixed-offset bytes every path below needs, loaded together
     const int d = dm[x], dr = dm[x + 1];
@@ -1163,8 +1183,8 @@ int Eedi2Engine::enqueue_passes(int tff)
     {
         const int nrows = (dst2p.height[0] - y0) / 2;
         const int nt = par_.noise_threshold;
-        HBHIP_LAUNCH(ctx_, "eedi2_lattice_candidates", k_lattice_cand, dim3((dst2p.width[0] + 63) / 64, (nrows + 3) / 4, 3),
-                     blk, 0, P, cand_, cand_pitch_, cand_plane_stride_, tff, (nt * 4) & 0xff, (nt * 7) & 0xff, (nt * 8) & 0xff, nt);
+        HBHIP_LAUNCH(ctx_, "eedi2_lattice_candidates", k_lattice_cand, dim3((dst2p.width[0] + LC_W - 1) / LC_W, nrows, 3),
+                     dim3(LC_W), 0, P, cand_, cand_pitch_, cand_plane_stride_, tff, (nt * 4) & 0xff, (nt * 7) & 0xff, (nt * 8) & 0xff, nt);
         HBHIP_LAUNCH(ctx_, "eedi2_lattice_resolve", k_lattice_resolve, dim3(1, nrows + 1, 3), dim3(64), 0, P,
                      (const uint32_t *)cand_, cand_pitch_, cand_plane_stride_, tff);
     }
