@@ -242,6 +242,95 @@ __global__ __launch_bounds__(256) void cropscale_v_kernel(ScaleArgs a, const dou
     a.dst[(size_t)y * a.dpitch + x] = (uint8_t)(int)(acc + 0.5);
 }
 
+// Both passes in one kernel: a workgroup owns a FS_TW x FS_TH tile of the output.  It first forms
+// the horizontally filtered values H[r][x] of the few source rows its output rows tap (those sit in
+// LDS as doubles instead of making a round trip through HBM), then the vertical sums.  Each H value
+// and each output is the same sequence of double operations as in the two-pass kernels above.
+constexpr int FS_TW = 64, FS_TH = 32, FS_MAXR = 40;
+struct ScaleArgs3 { ScaleArgs p[3]; int active[3]; };
+
+// TX / TY > 0: the tap counts are compile-time (6 x 6 for any upscale), so the taps of a thread's
+// column live in registers and the loops unroll; 0 = read the counts from the arguments.
+template <int TX, int TY>
+__global__ __launch_bounds__(256) void cropscale_fused_kernel(ScaleArgs3 all)
+{
+    __shared__ double s_h[FS_MAXR][FS_TW];
+    __shared__ int s_rmin, s_rmax;
+    const int pl = blockIdx.z;
+    if (!all.active[pl]) return;
+    const ScaleArgs &a = all.p[pl];
+    const int x0 = blockIdx.x * FS_TW, y0 = blockIdx.y * FS_TH;
+    if (x0 >= a.dw || y0 >= a.dh) return;
+    const int t = threadIdx.x;
+    const int tx = TX > 0 ? TX : a.tx, ty = TY > 0 ? TY : a.ty;
+    const int rows = min(FS_TH, a.dh - y0);
+    if (t == 0) { s_rmin = 0x7fffffff; s_rmax = -1; }
+    __syncthreads();
+    {
+        int lo = 0x7fffffff, hi = -1;
+        for (int i = t; i < rows * ty; i += 256)
+        {
+            const int r = a.iy[(size_t)y0 * ty + i];
+            lo = min(lo, r); hi = max(hi, r);
+        }
+        if (hi >= 0) { atomicMin(&s_rmin, lo); atomicMax(&s_rmax, hi); }
+    }
+    __syncthreads();
+    const int rmin = s_rmin, nr = s_rmax - rmin + 1;            // nr <= FS_MAXR (checked by the host)
+    const int xl = t & (FS_TW - 1), x = x0 + xl;
+    const int wave_row = __builtin_amdgcn_readfirstlane(t / FS_TW);   // a wave = one tile row: uniform
+    if (x < a.dw)
+    {
+        const int *ix = a.ix + (size_t)x * tx;
+        const double *cx = a.cx + (size_t)x * tx;
+        if (TX > 0)
+        {
+            int ixr[TX > 0 ? TX : 1];
+            double cxr[TX > 0 ? TX : 1];
+#pragma unroll
+            for (int i = 0; i < TX; i++) { ixr[i] = ix[i]; cxr[i] = cx[i]; }
+            for (int rr = wave_row; rr < nr; rr += 256 / FS_TW)
+            {
+                const uint8_t *row = a.src + (size_t)(rmin + rr) * a.spitch;
+                double h = 0.0;
+#pragma unroll
+                for (int i = 0; i < TX; i++) h += cxr[i] * (double)row[ixr[i]];
+                s_h[rr][xl] = h;
+            }
+        }
+        else
+        {
+            for (int rr = wave_row; rr < nr; rr += 256 / FS_TW)
+            {
+                const uint8_t *row = a.src + (size_t)(rmin + rr) * a.spitch;
+                double h = 0.0;
+                for (int i = 0; i < tx; i++) h += cx[i] * (double)row[ix[i]];
+                s_h[rr][xl] = h;
+            }
+        }
+    }
+    __syncthreads();
+    if (x >= a.dw) return;
+    for (int yy = wave_row; yy < rows; yy += 256 / FS_TW)
+    {
+        const int y = y0 + yy;                                   // uniform: the taps come through scalar loads
+        const double *cy = a.cy + (size_t)y * ty;
+        const int *iy = a.iy + (size_t)y * ty;
+        double acc = 0.0;
+        if (TY > 0)
+        {
+#pragma unroll
+            for (int j = 0; j < TY; j++) acc += cy[j] * s_h[iy[j] - rmin][xl];
+        }
+        else
+        {
+            for (int j = 0; j < ty; j++) acc += cy[j] * s_h[iy[j] - rmin][xl];
+        }
+        acc = acc < 0.0 ? 0.0 : acc > 255.0 ? 255.0 : acc;
+        a.dst[(size_t)y * a.dpitch + x] = (uint8_t)(int)(acc + 0.5);
+    }
+}
+
 __global__ void crop_copy_kernel(const uint8_t *src, int spitch, uint8_t *dst, int dpitch, int w, int h)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -330,6 +419,17 @@ public:
             std::vector<double> cx, cy;
             tx[c] = lanczos_table(crop_w[c], dw, sx, ix, cx);
             ty[c] = lanczos_table(crop_h[c], dh, 0.0, iy, cy);
+            // the fused kernel keeps the tapped source rows of a 32-row output tile in LDS
+            for (int y0 = 0; y0 < dh && fused; y0 += FS_TH)
+            {
+                int lo = 0x7fffffff, hi = -1;
+                for (int i = 0; i < std::min(FS_TH, dh - y0) * ty[c]; i++)
+                {
+                    lo = std::min(lo, iy[(size_t)y0 * ty[c] + i]);
+                    hi = std::max(hi, iy[(size_t)y0 * ty[c] + i]);
+                }
+                if (hi - lo + 1 > FS_MAXR) fused = false;
+            }
             HBHIP_CHECK(ctx, hipMalloc((void **)&d_ix[c], sizeof(int) * ix.size()));
             HBHIP_CHECK(ctx, hipMalloc((void **)&d_iy[c], sizeof(int) * iy.size()));
             HBHIP_CHECK(ctx, hipMalloc((void **)&d_cx[c], sizeof(double) * cx.size()));
@@ -339,14 +439,17 @@ public:
             HBHIP_CHECK(ctx, hipMemcpy(d_cx[c], cx.data(), sizeof(double) * cx.size(), hipMemcpyHostToDevice));
             HBHIP_CHECK(ctx, hipMemcpy(d_cy[c], cy.data(), sizeof(double) * cy.size(), hipMemcpyHostToDevice));
         }
+        if (getenv("HBHIP_SCALE_TWO_PASS")) fused = false;
         size_t need = 0;
         for (int c = 0; c < 3; c++)
             if (!identity[c]) need = std::max(need, (size_t)out_geo.pw[c] * crop_h[c]);
-        if (need) HBHIP_CHECK(ctx, hipMalloc((void **)&hbuf, sizeof(double) * need));
+        if (need && !fused) HBHIP_CHECK(ctx, hipMalloc((void **)&hbuf, sizeof(double) * need));
         return HBHIP_OK;
     }
     int process(DevPicture *in, DevPicture *out) override
     {
+        ScaleArgs3 all;
+        memset(&all, 0, sizeof(all));
         for (int c = 0; c < 3; c++)
         {
             const uint8_t *win = in->plane[c] + (size_t)crop_y[c] * in->pitch[c] + crop_x[c];
@@ -355,6 +458,16 @@ public:
             {
                 HBHIP_LAUNCH(ctx, "crop_copy", crop_copy_kernel, dim3((dw + 255) / 256, dh), dim3(256), 0,
                              win, in->pitch[c], out->plane[c], out->pitch[c], dw, dh);
+                continue;
+            }
+            if (fused)
+            {
+                ScaleArgs &f = all.p[c];
+                f.src = win; f.dst = out->plane[c];
+                f.spitch = in->pitch[c]; f.dpitch = out->pitch[c];
+                f.dw = dw; f.dh = dh; f.tx = tx[c]; f.ty = ty[c];
+                f.ix = d_ix[c]; f.iy = d_iy[c]; f.cx = d_cx[c]; f.cy = d_cy[c];
+                all.active[c] = 1;
                 continue;
             }
             ScaleArgs a;
@@ -367,9 +480,18 @@ public:
             HBHIP_LAUNCH(ctx, "cropscale_lanczos_v", cropscale_v_kernel, dim3((dw + 63) / 64, (dh + 3) / 4),
                          dim3(64, 4), 0, a, (const double *)hbuf);
         }
+        if (all.active[0] || all.active[1] || all.active[2])
+        {
+            const dim3 grid((out->width[0] + FS_TW - 1) / FS_TW, (out->height[0] + FS_TH - 1) / FS_TH, 3);
+            bool six = true;
+            for (int c = 0; c < 3; c++) six &= !all.active[c] || (tx[c] == 6 && ty[c] == 6);
+            if (six) HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", (cropscale_fused_kernel<6, 6>), grid, dim3(256), 0, all);
+            else     HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", (cropscale_fused_kernel<0, 0>), grid, dim3(256), 0, all);
+        }
         HBHIP_CHECK(ctx, hipGetLastError());
         return HBHIP_OK;
     }
+    bool fused = true;          // all scaled planes fit the fused kernel's LDS budget
     hbhip_cropscale_params par;
     int crop_x[3], crop_y[3], crop_w[3], crop_h[3], tx[3] = {0, 0, 0}, ty[3] = {0, 0, 0};
     bool identity[3] = {false, false, false};

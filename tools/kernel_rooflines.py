@@ -78,7 +78,8 @@ def main():
     add(simple(ctx, lambda: mk_blur("hbhip_chroma_smooth_create"), W, H, W, H), {"chroma_smooth_blur_mix": 2 * Cc})
     # cropscale 1080p -> 2160p
     st = simple(ctx, lambda: hip.cropscale_device_filter(ctx, W, H, 2 * W, 2 * H), W, H, 2 * W, 2 * H)
-    add(st, {"cropscale_lanczos_h": (FRAME + 8 * 2 * FRAME) // 3, "cropscale_lanczos_v": (8 * 2 * FRAME + 4 * FRAME) // 3})
+    add(st, {"cropscale_lanczos_h": (FRAME + 8 * 2 * FRAME) // 3, "cropscale_lanczos_v": (8 * 2 * FRAME + 4 * FRAME) // 3,
+             "cropscale_lanczos_fused": FRAME + 4 * FRAME})            # one launch for the 3 planes: read 1080p, write 2160p
     # rotate / grayscale 1080p
     rot = lambda: hip._create("hbhip_rotate_create", ctx, [C.c_void_p] + [C.c_int] * 7 + [C.POINTER(C.c_void_p)],
                               ctx.h, 90, 0, W, H, 8, 1, 1)
