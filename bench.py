@@ -114,67 +114,78 @@ def secondary(args):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    ctx = hip.Ctx(local_rank)
     nsrc = 8
     frames_np = synth.stream("interlaced", W, H, nsrc, cfg=3 + 16 * rank)
     dev_in = [[torch.from_numpy(p).cuda() for p in fr] for fr in frames_np]
     fin = [hip.dev_frame(f) for f in dev_in]
     torch.cuda.synchronize()
+    chain = args.workload == "chain4"
 
     def planes(w, h):
         return [torch.empty((h, w), dtype=torch.uint8, device="cuda"),
                 torch.empty((h // 2, w // 2), dtype=torch.uint8, device="cuda"),
                 torch.empty((h // 2, w // 2), dtype=torch.uint8, device="cuda")]
 
-    decomb = hip.DecombDevice(ctx, W, H, mode=31)
-    decomb_f = hip.DeviceFilter(ctx, decomb.h)
-    t1080, t1080b, t2160, t2160b = planes(W, H), planes(W, H), planes(2 * W, 2 * H), planes(2 * W, 2 * H)
-    f1080, f1080b, f2160, f2160b = map(hip.dev_frame, (t1080, t1080b, t2160, t2160b))
-    chain = args.workload == "chain4"
-    if chain:
-        nlm = hip.nlmeans_device_filter(ctx, hip.NLMEANS_MEDIUM, W, H, batch=1)
-        scale = hip.cropscale_device_filter(ctx, W, H, 2 * W, 2 * H)
-        sharp = hip.lapsharp_device_filter(ctx, 2 * W, 2 * H)
+    class Lane:
+        """One independent stream: its own context (HIP stream), filter instances and frames."""
+        def __init__(self):
+            self.ctx = hip.Ctx(local_rank)
+            self.decomb = hip.DecombDevice(self.ctx, W, H, mode=31)
+            self.decomb_f = hip.DeviceFilter(self.ctx, self.decomb.h)
+            self.t = [planes(W, H), planes(W, H), planes(2 * W, 2 * H), planes(2 * W, 2 * H)]
+            self.f1080, self.f1080b, self.f2160, self.f2160b = map(hip.dev_frame, self.t)
+            if chain:
+                self.nlm = hip.nlmeans_device_filter(self.ctx, hip.NLMEANS_MEDIUM, W, H, batch=1)
+                self.scale = hip.cropscale_device_filter(self.ctx, W, H, 2 * W, 2 * H)
+                self.sharp = hip.lapsharp_device_filter(self.ctx, 2 * W, 2 * H)
+            self.produced = 0
 
-    produced = 0
+        def feed(self, i):
+            hip.decomb_push_dev(self.decomb_f, fin[i % nsrc], i)
+            while self.decomb_f.pending():
+                self.decomb_f.pull_dev(self.f1080)
+                if not chain:
+                    self.produced += 1
+                    continue
+                self.nlm.push_dev(self.f1080, 0)
+                while self.nlm.pending():
+                    self.nlm.pull_dev(self.f1080b)
+                    self.scale.push_dev(self.f1080b, 0)
+                    self.scale.pull_dev(self.f2160)
+                    self.sharp.push_dev(self.f2160, 0)
+                    self.sharp.pull_dev(self.f2160b)
+                    self.produced += 1
+
+    lanes = [Lane() for _ in range(max(1, args.streams))]
+    ctx = lanes[0].ctx
 
     def feed(i):
-        nonlocal produced
-        hip.decomb_push_dev(decomb_f, fin[i % nsrc], i)
-        while decomb_f.pending():
-            decomb_f.pull_dev(f1080)
-            if not chain:
-                produced += 1
-                continue
-            nlm.push_dev(f1080, 0)
-            while nlm.pending():
-                nlm.pull_dev(f1080b)
-                scale.push_dev(f1080b, 0)
-                scale.pull_dev(f2160)
-                sharp.push_dev(f2160, 0)
-                sharp.pull_dev(f2160b)
-                produced += 1
+        for ln in lanes:
+            ln.feed(i)
+
+    def sync_all():
+        for ln in lanes:
+            ln.ctx.sync()
+        torch.cuda.synchronize()
 
     for i in range(args.warmup):
         feed(i)
-    ctx.sync()
-    torch.cuda.synchronize()
-    ctx.profile(True)
-    ctx.profile_reset()
-    start = produced
+    sync_all()
+    if len(lanes) == 1:          # the per-kernel timer serialises a context: only in single-stream runs
+        ctx.profile(True)
+        ctx.profile_reset()
+    start = sum(ln.produced for ln in lanes)
     t0 = time.perf_counter()
     for i in range(args.steps):
         feed(args.warmup + i)
-    ctx.sync()
-    torch.cuda.synchronize()
+    sync_all()
     dt = time.perf_counter() - t0
-    stats = ctx.profile_stats()
+    stats = ctx.profile_stats() if len(lanes) == 1 else {}
     ctx.profile(False)
-    out_frames = produced - start
+    out_frames = sum(ln.produced for ln in lanes) - start
     frames_total, dt_max = shard.reduce_throughput(float(out_frames), dt, device="cuda")
     if rank == 0:
         top = sorted(stats.items(), key=lambda kv: -kv[1][1])[:6]
-        kname, (launches, total_ms) = top[0]
         per_out = {"decomb_eedi2": 4 * (W * H * 3 // 2), "chain4": 62_200_000}[args.workload]   # SURVEY §8d
         print(json.dumps({
             "metric": "filtered output frames/sec (" + args.workload + ")",
@@ -184,13 +195,15 @@ def secondary(args):
             "config": {"workload": {"decomb_eedi2": "BASELINE configs[2]: decomb EEDI2 bob (mode 31) 1920x1080 interlaced",
                                     "chain4": "BASELINE configs[3]: decomb(31)->nlmeans medium->cropscale lanczos "
                                               "1080p->2160p->lapsharp, per-frame launches"}[args.workload],
-                       "input_frames_per_step": 1, "output_frames_per_step": 2, "device": ctx.name()},
+                       "input_frames_per_step": len(lanes), "output_frames_per_step": 2 * len(lanes),
+                       "streams_per_gpu": len(lanes), "device": ctx.name()},
             "chain_hbm_GBps_algorithmic": round(per_out * frames_total / dt_max / 1e9, 2),
             "top_kernels": [{"kernel": k, "launches": n, "avg_us": round(ms / n * 1e3, 1)} for k, (n, ms) in top],
             "roofline": None,
             "cpu_baseline": None if (world > 1 or args.no_cpu_baseline) else cpu_baseline_chain(args.workload, frames_np)}),
             flush=True)
-    ctx.close()
+    for ln in lanes:
+        ln.ctx.close()
 
 
 def main():
@@ -200,6 +213,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="secondary workloads only: independent streams (filter instances on their own "
+                         "HIP streams) fed round-robin on each GPU")
     ap.add_argument("--workload", default="nlmeans", choices=["nlmeans", "decomb_eedi2", "chain4"],
                     help="nlmeans = BASELINE configs[1] (default, the bench line the driver records); "
                          "decomb_eedi2 = configs[2]; chain4 = configs[3] (decomb->nlmeans->cropscale->lapsharp)")
