@@ -130,7 +130,9 @@ def secondary(args):
         """One independent stream: its own context (HIP stream), filter instances and frames."""
         def __init__(self):
             self.ctx = hip.Ctx(local_rank)
-            self.decomb = hip.DecombDevice(self.ctx, W, H, mode=31)
+            self.decomb = hip.DecombDevice(self.ctx, W, H, mode=63 if args.comb_detect else 31)
+            self.comb = hip.CombDetectDevice(self.ctx, W, H) if args.comb_detect else None
+            self.held = None            # frame waiting for its successor before it can be classified
             self.decomb_f = hip.DeviceFilter(self.ctx, self.decomb.h)
             self.t = [planes(W, H), planes(W, H), planes(2 * W, 2 * H), planes(2 * W, 2 * H)]
             self.f1080, self.f1080b, self.f2160, self.f2160b = map(hip.dev_frame, self.t)
@@ -141,7 +143,19 @@ def secondary(args):
             self.produced = 0
 
         def feed(self, i):
-            hip.decomb_push_dev(self.decomb_f, fin[i % nsrc], i)
+            if self.comb is None:
+                hip.decomb_push_dev(self.decomb_f, fin[i % nsrc], i)
+            else:
+                # comb_detect_work (comb_detect.c:1537-1583): frame i-1 is classified from the luma of
+                # i-2, i-1, i and handed to the selective decomb (mode 63) with its s.combed
+                luma = dev_in[i % nsrc][0]
+                if self.held is None:
+                    self.comb.store_dev(luma.data_ptr(), luma.stride(0))
+                self.comb.store_dev(luma.data_ptr(), luma.stride(0))
+                if self.held is not None:
+                    combed = self.comb.classify(force=(self.held == 0))
+                    hip.decomb_push_dev(self.decomb_f, fin[self.held % nsrc], self.held, combed=combed)
+                self.held = i
             while self.decomb_f.pending():
                 self.decomb_f.pull_dev(self.f1080)
                 if not chain:
@@ -213,6 +227,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--comb-detect", action="store_true",
+                    help="secondary workloads only: run comb detection in front of the (then selective) decomb, "
+                         "as BASELINE configs[2] words it")
     ap.add_argument("--streams", type=int, default=1,
                     help="secondary workloads only: independent streams (filter instances on their own "
                          "HIP streams) fed round-robin on each GPU")

@@ -127,6 +127,9 @@ __global__ __launch_bounds__(64) void comb_score_kernel(const uint8_t *__restric
                                                         int width, int height, int bw, int bh, int thr,
                                                         int filtered, int blocks_x, int *result)
 {
+    // HEAVY already found by another block: nothing can change the maximum any more (the
+    // reference stops scanning in the same situation, comb_detect.c:211-214)
+    if (__hip_atomic_load(result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 2) return;
     const int bx = blockIdx.x % blocks_x, by = blockIdx.x / blocks_x;
     const int x0 = bx * bw, y0 = by * bh;
     int score = 0;
@@ -144,7 +147,9 @@ __global__ __launch_bounds__(64) void comb_score_kernel(const uint8_t *__restric
     if (threadIdx.x == 0)
     {
         const int cat = score > thr ? 2 : (score >= thr / 2 ? 1 : 0);
-        if (cat) atomicMax(result, cat);
+        // thousands of blocks agree on combed material: only the ones that would raise the
+        // maximum touch the atomic, the rest would just queue up behind each other at L2
+        if (cat > __hip_atomic_load(result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(result, cat);
     }
 }
 

@@ -257,6 +257,48 @@ def host_frame(planes) -> HostFrame:
     return f
 
 
+class CombDetectParams(C.Structure):
+    _fields_ = [("mode", C.c_int), ("spatial_metric", C.c_int), ("motion_threshold", C.c_int),
+                ("spatial_threshold", C.c_int), ("filter_mode", C.c_int), ("block_threshold", C.c_int),
+                ("block_width", C.c_int), ("block_height", C.c_int), ("gamma_lut", C.c_float * 256)]
+
+
+class CombDetectDevice:
+    """Comb detection through the raw C ABI on device-resident luma planes (bench.py; the
+    hb_filter_object_t path is hb_filter_comb_detect_hip).  Defaults = param.c:204-207."""
+
+    def __init__(self, ctx: Ctx, width, height, mode=3, spatial_metric=2, motion_thresh=1, spatial_thresh=1,
+                 filter_mode=2, block_thresh=40, block_width=16, block_height=16):
+        import numpy as np
+        L = lib()
+        L.hbhip_comb_detect_create.argtypes = [C.c_void_p, C.POINTER(CombDetectParams)] + [C.c_int] * 3 + [C.POINTER(C.c_void_p)]
+        L.hbhip_comb_detect_store_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.hbhip_comb_detect_classify.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        par = CombDetectParams(mode, spatial_metric, motion_thresh, spatial_thresh, filter_mode, block_thresh,
+                               block_width, block_height)
+        # comb_detect.c:1074-1081: pow((float)i / (float)max, 2.2f), evaluated in double, stored as float
+        lut = np.power((np.arange(256, dtype=np.float32) / np.float32(255)).astype(np.float64),
+                       np.float64(np.float32(2.2))).astype(np.float32)
+        for i in range(256):
+            par.gamma_lut[i] = float(lut[i])
+        h = C.c_void_p()
+        check(L.hbhip_comb_detect_create(ctx.h, C.byref(par), width, height, 8, C.byref(h)), ctx.h, "comb_detect_create")
+        self.ctx, self.h = ctx, h
+
+    def store_dev(self, luma_ptr, stride):
+        check(lib().hbhip_comb_detect_store_dev(self.h, C.c_void_p(luma_ptr), stride), self.ctx.h, "comb_detect_store_dev")
+
+    def classify(self, force=False):
+        out = C.c_int()
+        check(lib().hbhip_comb_detect_classify(self.h, int(force), C.byref(out)), self.ctx.h, "comb_detect_classify")
+        return out.value
+
+    def close(self):
+        if self.h:
+            lib().hbhip_filter_destroy(self.h)
+            self.h = None
+
+
 class DecombDevice:
     """A decomb instance driven through the raw C ABI with host frames (tests of the
     EEDI2 scratch buffers; the hb_filter_object_t path is hb_filter_decomb_hip)."""
