@@ -16,6 +16,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 AV_PIX_FMT_YUV420P = 0
 AV_PIX_FMT_YUV420P10 = 62
+AV_PIX_FMT_YUV420P12 = 123
+PIX_FMT_FOR_DEPTH = {8: AV_PIX_FMT_YUV420P, 10: AV_PIX_FMT_YUV420P10, 12: AV_PIX_FMT_YUV420P12}
 
 HB_COMB_NONE, HB_COMB_LIGHT, HB_COMB_HEAVY = 0, 1, 2
 
@@ -135,6 +137,8 @@ class Chain:
         self._rt.hbh_chain_pop(self._h, ptrs, strides)
         bps = 2 if info.fmt in (62, 123) else 1
         planes = tuple(a[:, : info.plane_width[p] * bps] for p, a in enumerate(arrs))
+        if bps == 2:                      # 10 / 12-bit samples in 16-bit containers
+            planes = tuple(np.ascontiguousarray(p).view(np.uint16) for p in planes)
         return OutFrame(planes, info.start, info.stop, info.flags, info.combed,
                         info.width, info.height)
 

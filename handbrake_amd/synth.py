@@ -124,12 +124,27 @@ def random_frame(w: int, h: int, t: int, cfg: int = 9):
     return yp, cb, cr
 
 
-def stream(model: str, w: int, h: int, nframes: int, cfg: int | None = None):
-    """List of (Y, Cb, Cr) tuples."""
+def stream(model: str, w: int, h: int, nframes: int, cfg: int | None = None, depth: int = 8):
+    """List of (Y, Cb, Cr) tuples.  depth 10 / 12: uint16 planes - the 8-bit model in the high
+    bits, the low depth-8 bits drawn from the same LCG (so wider samples carry real detail)."""
     gen = {"progressive": progressive_frame, "interlaced": interlaced_frame,
            "random": random_frame}[model]
     kw = {} if cfg is None else {"cfg": cfg}
-    return [gen(w, h, t, **kw) for t in range(nframes)]
+    frames = [gen(w, h, t, **kw) for t in range(nframes)]
+    if depth == 8:
+        return frames
+    extra = depth - 8
+    out = []
+    for t, fr in enumerate(frames):
+        seed = frame_seed(0x51 if cfg is None else cfg, t) ^ 0x5bd1e995
+        lows = lcg_stream(seed, sum(p.size for p in fr))
+        planes, at = [], 0
+        for p in fr:
+            lo = ((lows[at:at + p.size] >> 9) & ((1 << extra) - 1)).astype(np.uint16).reshape(p.shape)
+            at += p.size
+            planes.append((p.astype(np.uint16) << extra) | lo)
+        out.append(tuple(planes))
+    return out
 
 
 def flags_for(model: str) -> int:

@@ -381,3 +381,146 @@ void orc_nlmeans_plane(const uint8_t *const *frames, const uint8_t *const *frame
     free(ssd);
     free(acc);
 }
+
+
+/* ---- 16-bit samples (nlmeans_plane_16 etc.: the same template instantiated with
+ * pixel = uint16_t, nlmeans.c:253-262; depths 10 and 12 in 16-bit containers) ----------
+ * prefilter = 0 only.  The strength is scaled by (depth-8)^2 before the tables are built
+ * (nlmeans.c:343); everything else is the 8-bit algorithm on wider samples. */
+static void mirror_borders16(uint16_t *mem, int w, int h, int border)
+{
+    const int bw = w + 2 * border;
+    uint16_t *img = mem + border + (size_t)bw * border;
+    for (int y = 0; y < h; y++)
+    {
+        uint16_t *row = img + (size_t)y * bw;
+        for (int i = 0; i < border; i++)
+        {
+            row[-1 - i] = row[i];
+            row[w + i]  = row[w - 1 - i];
+        }
+    }
+    for (int i = 0; i < border; i++)
+    {
+        memcpy(img - border - (size_t)(i + 1) * bw, img - border + (size_t)i * bw, sizeof(uint16_t) * bw);
+        memcpy(img - border + (size_t)(h + i) * bw, img - border + (size_t)(h - 1 - i) * bw, sizeof(uint16_t) * bw);
+    }
+}
+
+static void patch_ssd16(const uint16_t *a_img, const uint16_t *b_img, int bw,
+                        int w, int h, int n, int dx, int dy,
+                        uint32_t *colsum, uint32_t *ssd)
+{
+    const int nh = (n - 1) / 2;
+    const int ew = w + n - 1;
+    memset(colsum, 0, sizeof(uint32_t) * ew);
+    for (int yy = -nh; yy < h + nh; yy++)
+    {
+        const uint16_t *pa = a_img + (ptrdiff_t)yy * bw - nh;
+        const uint16_t *pb = b_img + (ptrdiff_t)(yy + dy) * bw - nh + dx;
+        for (int i = 0; i < ew; i++)
+        {
+            const int dn = pa[i] - pb[i];
+            colsum[i] += (uint32_t)dn * (uint32_t)dn;
+        }
+        if (yy - n >= -nh)
+        {
+            const uint16_t *qa = a_img + (ptrdiff_t)(yy - n) * bw - nh;
+            const uint16_t *qb = b_img + (ptrdiff_t)(yy - n + dy) * bw - nh + dx;
+            for (int i = 0; i < ew; i++)
+            {
+                const int dold = qa[i] - qb[i];
+                colsum[i] -= (uint32_t)dold * (uint32_t)dold;
+            }
+        }
+        const int y = yy - nh;
+        if (y < 0)
+            continue;
+        uint32_t run = 0;
+        for (int i = 0; i < n; i++)
+            run += colsum[i];
+        uint32_t *out = ssd + (size_t)y * w;
+        out[0] = run;
+        for (int x = 1; x < w; x++)
+        {
+            run += colsum[x + n - 1] - colsum[x - 1];
+            out[x] = run;
+        }
+    }
+}
+
+void orc_nlmeans_plane16(const uint16_t *const *planes, int plane_stride, int nframes, int w, int h,
+                         int depth, const orc_nlmeans_params_t *p, uint16_t *dst, int dst_stride)
+{
+    float exptable[EXPSIZE];
+    float wft;
+    int diff_max;
+    const double scaled = p->strength * (depth > 8 ? (depth - 8) * (depth - 8) : 1);   /* nlmeans.c:343 */
+    orc_nlmeans_tables(scaled, p->patch_size, exptable, &wft, &diff_max);
+
+    const int n = p->patch_size;
+    const int r_half = (p->range - 1) / 2;
+    const int border = orc_nlmeans_border(n);
+    const int bw = w + 2 * border, bh = h + 2 * border;
+    const size_t origin = border + (size_t)bw * border;
+    const double origin_tune = p->origin_tune;
+
+    uint16_t **fr = malloc(sizeof(uint16_t *) * nframes);
+    for (int f = 0; f < nframes; f++)
+    {
+        fr[f] = calloc((size_t)bw * bh, sizeof(uint16_t));
+        for (int y = 0; y < h; y++)
+            memcpy(fr[f] + origin + (size_t)y * bw, planes[f] + (size_t)y * plane_stride, sizeof(uint16_t) * w);
+        mirror_borders16(fr[f], w, h, border);
+    }
+    acc_t *acc = calloc((size_t)w * h, sizeof(acc_t));
+    uint32_t *ssd = malloc(sizeof(uint32_t) * (size_t)w * h);
+    uint32_t *colsum = malloc(sizeof(uint32_t) * (w + n));
+    const uint16_t *src = fr[0] + origin;
+
+    for (int f = 0; f < nframes; f++)
+    {
+        const uint16_t *cmp = fr[f] + origin;
+        for (int dy = -r_half; dy <= r_half; dy++)
+            for (int dx = -r_half; dx <= r_half; dx++)
+            {
+                if (f == 0 && dx == 0 && dy == 0)
+                {
+                    for (int y = 0; y < h; y++)
+                        for (int x = 0; x < w; x++)
+                        {
+                            acc_t *a = &acc[(size_t)y * w + x];
+                            a->weight_sum += origin_tune;
+                            a->pixel_sum  += origin_tune * src[(size_t)y * bw + x];
+                        }
+                    continue;
+                }
+                patch_ssd16(src, cmp, bw, w, h, n, dx, dy, colsum, ssd);
+                for (int y = 0; y < h; y++)
+                    for (int x = 0; x < w; x++)
+                    {
+                        const int diff = (int)ssd[(size_t)y * w + x];
+                        if (diff < diff_max)
+                        {
+                            const int idx = diff * wft;
+                            const float weight = exptable[idx];
+                            acc_t *a = &acc[(size_t)y * w + x];
+                            a->weight_sum += weight;
+                            a->pixel_sum  += weight * cmp[(ptrdiff_t)(y + dy) * bw + x + dx];
+                        }
+                    }
+            }
+    }
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+        {
+            const acc_t *a = &acc[(size_t)y * w + x];
+            const uint16_t v = (uint16_t)(a->pixel_sum / a->weight_sum);
+            dst[(size_t)y * dst_stride + x] = v ? v : src[(size_t)y * bw + x];
+        }
+    free(colsum);
+    free(ssd);
+    free(acc);
+    for (int f = 0; f < nframes; f++) free(fr[f]);
+    free(fr);
+}

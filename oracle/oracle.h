@@ -68,6 +68,12 @@ void orc_nlmeans_plane(const uint8_t *const *frames, const uint8_t *const *frame
                        const orc_nlmeans_params_t *p,
                        uint8_t *dst, int dst_stride);
 
+/* nlmeans_plane_16 (the same template with 16-bit samples, depth 10 / 12), prefilter = 0.
+ * planes[f] = unbordered w x h planes, `plane_stride` in samples; p->strength is the
+ * setting's value, the (depth-8)^2 scaling of nlmeans.c:343 is applied inside. */
+void orc_nlmeans_plane16(const uint16_t *const *planes, int plane_stride, int nframes, int w, int h,
+                         int depth, const orc_nlmeans_params_t *p, uint16_t *dst, int dst_stride);
+
 /* ---- Lapsharp (lapsharp.c) ---------------------------------------------------- */
 
 /* lapsharp_8 (lapsharp.c:125-182): one plane.  kernel: 0 lap, 1 isolap, 2 log,

@@ -29,8 +29,9 @@ def main():
     if ref is None:
         raise SystemExit("oracle/_ref/libhbref.so missing: run `make oracle` where /root/reference exists")
     for name, case in gc.CASES.items():
-        frames = synth.stream(case["model"], case["w"], case["h"], case["n"])
-        out = hbrt.run_stream(ref, case["chain"], frames, flags=synth.flags_for(case["model"]))
+        frames = synth.stream(case["model"], case["w"], case["h"], case["n"], depth=case.get("depth", 8))
+        out = hbrt.run_stream(ref, case["chain"], frames, flags=synth.flags_for(case["model"]),
+                              pix_fmt=hbrt.PIX_FMT_FOR_DEPTH[case.get("depth", 8)])
         arrs = {}
         for t, fr in enumerate(out):
             for c in range(3):

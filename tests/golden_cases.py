@@ -18,9 +18,9 @@ NLM_PRE_C = ("y-strength=6:y-origin-tune=1:y-patch-size=7:y-range=3:y-frame-coun
              "cr-strength=6:cr-origin-tune=0.8:cr-patch-size=7:cr-range=3:cr-frame-count=2:cr-prefilter=800")
 
 
-def nlm(strength=6, origin_tune=1.0, patch=7, rng=3, nframes=2, prefilter=0):
+def nlm(strength=6, origin_tune=1.0, patch=7, rng=3, nframes=2, prefilter=0, depth=8):
     return dict(strength=strength, origin_tune=origin_tune, patch=patch, range=rng,
-                nframes=nframes, prefilter=prefilter)
+                nframes=nframes, prefilter=prefilter, depth=depth)
 
 
 def lap(strength=0.2, kernel="isolap"):
@@ -68,6 +68,16 @@ CASES = {
                                        hip=[("hb_filter_nlmeans_hip", NLM_PRE_C)],
                                        orc=[("nlmeans", [nlm(6, 1.0, 7, 3, 2, 2049), nlm(6, 0.8, 7, 3, 2, 4 + 1024),
                                                          nlm(6, 0.8, 7, 3, 2, 32 + 256 + 512)])]),
+    # 16-bit samples (the _16 template instantiations, nlmeans.c:253-262): YUV420P10 / P12
+    "nlmeans_medium_10bit_96x64": dict(model="progressive", w=96, h=64, n=4, depth=10,
+                                       chain=[("hb_filter_nlmeans", NLM_MEDIUM + ":threads=2")],
+                                       hip=[("hb_filter_nlmeans_hip", NLM_MEDIUM)],
+                                       orc=[("nlmeans", [nlm(depth=10), nlm(depth=10), nlm(depth=10)])]),
+    "nlmeans_tape_12bit_70x50": dict(model="random", w=70, h=50, n=3, depth=12,
+                                     chain=[("hb_filter_nlmeans", NLM_TAPE + ":threads=1")],
+                                     hip=[("hb_filter_nlmeans_hip", NLM_TAPE)],
+                                     orc=[("nlmeans", [nlm(3, 0.8, 3, 5, 2, depth=12), nlm(6, 0.8, 5, 5, 2, depth=12),
+                                                       nlm(6, 0.8, 5, 5, 2, depth=12)])]),
     "lapsharp_medium_134x70": dict(model="progressive", w=134, h=70, n=2,
                                    chain=[("hb_filter_lapsharp", "y-strength=0.2:y-kernel=isolap:cb-strength=0.2:cb-kernel=isolap")],
                                    hip=[("hb_filter_lapsharp_hip", "y-strength=0.2:y-kernel=isolap:cb-strength=0.2:cb-kernel=isolap")],

@@ -78,6 +78,22 @@ def orc_nlmeans_plane(planes, strength=6.0, origin_tune=1.0, patch=7, rng=3, pre
     return dst
 
 
+def orc_nlmeans_plane16(planes, depth, strength=6.0, origin_tune=1.0, patch=7, rng=3):
+    """planes: list of 2-D uint16 arrays (frame 0 = filtered frame, then look-ahead); prefilter 0."""
+    lib = oracle()
+    h, w = planes[0].shape
+    keep = [np.ascontiguousarray(p, dtype=np.uint16) for p in planes]
+    u16p = C.POINTER(C.c_uint16)
+    ptrs = (u16p * len(keep))(*[k.ctypes.data_as(u16p) for k in keep])
+    par = NLMeansParams(strength, origin_tune, patch, rng, len(keep), 0)
+    dst = np.zeros((h, w), np.uint16)
+    lib.orc_nlmeans_plane16.argtypes = [C.POINTER(u16p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.POINTER(NLMeansParams), u16p, C.c_int]
+    lib.orc_nlmeans_plane16.restype = None
+    lib.orc_nlmeans_plane16(ptrs, w, len(keep), w, h, depth, C.byref(par), dst.ctypes.data_as(u16p), w)
+    return dst
+
+
 def orc_nlmeans_prefiltered(plane, prefilter, patch=7):
     """The w x h interior of nlmeans_prefilter's output for one plane."""
     lib = oracle()

@@ -17,6 +17,14 @@ def nlmeans_stream(frames, planes_par):
         for c in range(3):
             p = planes_par[c]
             pf = p.get("prefilter", 0)
+            if frames[t][c].dtype == np.uint16:             # 10 / 12-bit samples (depth in the parameters)
+                if p["strength"] == 0:
+                    planes.append(frames[t][c].copy())
+                    continue
+                nf = min(p["nframes"], n - t)
+                planes.append(ol.orc_nlmeans_plane16([frames[t + f][c] for f in range(nf)], p["depth"],
+                                                     p["strength"], p["origin_tune"], p["patch"], p["range"]))
+                continue
             if pf & 2048:                                   # passthru: the prefiltered plane is the output
                 planes.append(ol.orc_nlmeans_prefiltered(frames[t][c], pf, p["patch"]))
                 continue

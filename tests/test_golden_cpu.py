@@ -16,7 +16,7 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def test_oracle_matches_golden(built, name):
     case = gc.CASES[name]
     want, _ = os_.load_golden(os.path.join(GOLD, name + ".npz"))
-    frames = synth.stream(case["model"], case["w"], case["h"], case["n"])
+    frames = synth.stream(case["model"], case["w"], case["h"], case["n"], depth=case.get("depth", 8))
     got = os_.run_chain(frames, case["orc"], flags=synth.flags_for(case["model"]))
     assert len(got) == len(want)
     for t in range(len(want)):

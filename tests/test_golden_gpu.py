@@ -17,8 +17,9 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def test_hip_matches_golden(built, name):
     case = gc.CASES[name]
     want, meta = os_.load_golden(os.path.join(GOLD, name + ".npz"))
-    frames = synth.stream(case["model"], case["w"], case["h"], case["n"])
-    got = hbrt.run_stream(hip.filters(), case["hip"], frames, flags=synth.flags_for(case["model"]))
+    frames = synth.stream(case["model"], case["w"], case["h"], case["n"], depth=case.get("depth", 8))
+    got = hbrt.run_stream(hip.filters(), case["hip"], frames, flags=synth.flags_for(case["model"]),
+                              pix_fmt=hbrt.PIX_FMT_FOR_DEPTH[case.get("depth", 8)])
     assert len(got) == len(want)
     tol = case.get("tol", 0)
     for t in range(len(want)):
