@@ -227,6 +227,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--depth", type=int, default=8, choices=[8, 10, 12],
+                    help="nlmeans workload only: sample depth (10 / 12 = 16-bit containers); the recorded "
+                         "bench line is the 8-bit one BASELINE.json names")
     ap.add_argument("--comb-detect", action="store_true",
                     help="secondary workloads only: run comb detection in front of the (then selective) decomb, "
                          "as BASELINE configs[2] words it")
@@ -258,13 +261,13 @@ def main():
 
     B = args.batch
     # one independent synthetic stream per rank (cfg = 2 + rank*16 keeps rank 0 == configs[1])
-    frames_np = synth.stream("progressive", W, H, B + 1, cfg=2 + 16 * rank)
+    frames_np = synth.stream("progressive", W, H, B + 1, cfg=2 + 16 * rank, depth=args.depth)
     dev_in = [[torch.from_numpy(p).cuda() for p in fr] for fr in frames_np]
     dev_out = [[torch.empty_like(p) for p in dev_in[0]] for _ in range(B)]
     torch.cuda.synchronize()
 
     ctx = hip.Ctx(local_rank)
-    flt = hip.nlmeans_device_filter(ctx, hip.NLMEANS_MEDIUM, W, H, batch=B)
+    flt = hip.nlmeans_device_filter(ctx, hip.NLMEANS_MEDIUM, W, H, batch=B, depth=args.depth)
     in_arr = (hip.DevFrame * B)(*[hip.dev_frame(dev_in[1 + i]) for i in range(B)])
     out_arr = (hip.DevFrame * B)(*[hip.dev_frame(f) for f in dev_out])
     flt.push_dev(hip.dev_frame(dev_in[0]), 0)       # prime the 1-frame look-ahead
@@ -303,7 +306,7 @@ def main():
         kname, (launches, total_ms) = max(stats.items(), key=lambda kv: kv[1][1])
         avg_s = total_ms / launches / 1e3
         frames_per_launch = frames_local / launches
-        algo_bytes = ALGO_BYTES_PER_FRAME * frames_per_launch
+        algo_bytes = ALGO_BYTES_PER_FRAME * frames_per_launch * (2 if args.depth > 8 else 1)
         achieved = algo_bytes / avg_s / 1e9
         traffic = None
         valu_insts = None
@@ -327,7 +330,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u8 (f32 weights)",
+            "dtype": "u8 (f32 weights)" if args.depth == 8 else f"u16, {args.depth}-bit samples (f32 weights)",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: nlmeans medium (patch 7, range 3, 2 frames) "
                                    "1920x1080 YUV420P 8-bit, inputs resident in HBM",
@@ -350,7 +353,7 @@ def main():
                                        "achieved_ginst_s": round(valu_insts / avg_s / 1e9, 1),
                                        "peak_ginst_s": round(peak / 1e9, 1),
                                        "frac": round(valu_insts / avg_s / peak, 4)}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.depth == 8:
             out["cpu_baseline"] = cpu_baseline(frames_np)
         print(json.dumps(out), flush=True)
 

@@ -420,6 +420,270 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
     }
 }
 
+// ------------------------------------------------------------------------------- 16-bit samples
+// The same kernel for pixel = uint16_t (nlmeans_plane_16 etc., nlmeans.c:253-262; depth 10 or 12
+// in 16-bit containers; prefilter = 0).  A lane still owns 4 pixels x 8 rows, now 2 dwords per
+// row; tiles hold 2 pixels per dword.  Squared differences stay below 2^24 and the patch sums
+// below 2^31 for depths <= 12, so the integer path is unchanged.
+__device__ __forceinline__ void load_tile16(uint32_t *lds, int pitch, int dwords, int rows,
+                                            const uint8_t *__restrict__ plane, int src_pitch_bytes,
+                                            int w, int h, int x0, int y0)
+{
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int rpp = (TXN * TYN) / dwords;
+    const int r0 = (int)(((float)tid + 0.5f) * (1.0f / (float)dwords));
+    const int c = tid - r0 * dwords;
+    if (r0 >= rpp) return;
+    const int x = x0 + 2 * c;                                  // first of the dword's two pixels
+    const bool whole = x >= 0 && x + 1 < w;
+    const int o0 = reflect(x, w), o1 = reflect(x + 1, w);
+    uint32_t *out = lds + r0 * pitch + c;
+#pragma nounroll
+    for (int r = r0; r < rows; r += rpp, out += rpp * pitch)
+    {
+        const uint16_t *row = reinterpret_cast<const uint16_t *>(plane + (size_t)reflect(y0 + r, h) * src_pitch_bytes);
+        uint32_t v;
+        if (whole)
+            v = reinterpret_cast<const u32_unaligned *>(row + x)->v;
+        else
+            v = (uint32_t)row[o0] | ((uint32_t)row[o1] << 16);
+        *out = v;
+    }
+}
+
+__device__ __forceinline__ uint32_t half_of(uint32_t v, int k) { return (v >> (16 * k)) & 0xffffu; }
+
+template <int N, bool FAST, int CPD>
+__global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes16_kernel(const NlmJob *__restrict__ jobs, int njobs,
+                                                                       int cmp_rows, int rq)
+{
+    constexpr int NH = N / 2;
+    constexpr int ROWS = RY + N - 1;
+    static_assert(NH <= PX, "patch must not reach past the adjacent lane");
+    static_assert(CPD % 8 == 4, "the two tile rows of a wave must sit 32 banks apart");
+
+    extern __shared__ uint32_t smem[];
+    const int tile_dwords = CPD * cmp_rows + 4;
+    uint32_t *s_t0 = smem;                                       // frame 0: source patches and compare tile of f = 0
+    uint32_t *s_tc = s_t0 + tile_dwords;                         // frame f > 0
+    float *s_exp = reinterpret_cast<float *>(s_tc + tile_dwords);
+
+    int j = 0;
+    for (int hi = njobs - 1; j < hi;)
+    {
+        const int mid = (j + hi + 1) >> 1;
+        if ((int)blockIdx.x >= jobs[mid].tile_start) j = mid; else hi = mid - 1;
+    }
+    const NlmJob &job = jobs[j];
+    const int tile = blockIdx.x - job.tile_start;
+    const int tile_y = tile / job.tiles_x;
+    const int tile_x = tile - tile_y * job.tiles_x;
+    const int tx0 = tile_x * LTW, ty0 = tile_y * TH;
+    const int w = job.w, h = job.h;
+    const int RH = job.r_half;
+
+    const int tx = threadIdx.x & (TXN - 1);
+    const int ty = threadIdx.x / TXN;
+
+    if (threadIdx.x < 128) s_exp[threadIdx.x] = job.exptable[threadIdx.x];
+    load_tile16(s_t0, CPD, CPD, cmp_rows, job.frame[0], job.fpitch[0], w, h, tx0 - PX - 4 * rq, ty0 - NH - RH);
+    // lane tx's own 4 pixels = dwords 2*tx + 2*rq, +1 of a tile row
+    const uint32_t *own = s_t0 + (ty * RY + RH) * CPD + 2 * tx + 2 * rq;
+
+    f2 aw[RY][PX / 2], ap[RY][PX / 2];
+#pragma unroll
+    for (int o = 0; o < RY; o++)
+#pragma unroll
+        for (int p = 0; p < PX / 2; p++) { aw[o][p] = f2{0.f, 0.f}; ap[o][p] = f2{0.f, 0.f}; }
+    const f2 wft2 = {job.wft, job.wft};
+    const float wft = job.wft;
+    const int diff_max = job.diff_max;
+    const int diff_cap = job.diff_cap;
+    const double origin_tune = job.origin_tune;
+    const bool wave_live = ty0 + (ty & ~1) * RY < h;
+
+    for (int f = 0; f < job.nframes; f++)
+    {
+        if (f > 0)
+        {
+            __syncthreads();
+            load_tile16(s_tc, CPD, CPD, cmp_rows, job.frame[f], job.fpitch[f], w, h,
+                        tx0 - PX - 4 * rq, ty0 - NH - RH);
+        }
+        __syncthreads();
+        if (!wave_live) continue;
+        const uint32_t *cmp_tile = f > 0 ? s_tc : s_t0;
+
+        for (int dy = -RH; dy <= RH; dy++)
+        {
+            for (int dx = -RH; dx <= RH; dx++)
+            {
+                if (f == 0 && dx == 0 && dy == 0)
+                {
+#pragma unroll
+                    for (int o = 0; o < RY; o++)
+                    {
+                        const uint32_t c0 = own[(o + NH) * CPD], c1 = own[(o + NH) * CPD + 1];
+#pragma unroll
+                        for (int p = 0; p < PX; p++)
+                        {
+                            const int sv = (int)half_of(p < 2 ? c0 : c1, p & 1);
+                            aw[o][p / 2][p & 1] = (float)((double)aw[o][p / 2][p & 1] + origin_tune);
+                            ap[o][p / 2][p & 1] = (float)((double)ap[o][p / 2][p & 1] + origin_tune * (double)sv);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    continue;
+                }
+
+                const int s = dx + 4 * rq;                   // pixel offset of the compare window, >= 0, uniform
+                const int sh = 2 * (s & 1);                  // byte shift inside the dword pair
+                const uint32_t *srow = own;
+                const uint32_t *crow = cmp_tile + (ty * RY + dy + RH) * CPD + 2 * tx + (s >> 1);
+                const uint32_t *prow = crow + NH * CPD;      // the row whose pixels are averaged
+
+                uint32_t C[PX], hist[RY - 1][PX], v[PX];
+                uint32_t pixq0 = 0, pixq1 = 0;
+                f2 wq[PX / 2];
+#pragma unroll
+                for (int q = 0; q < PX; q++) C[q] = 0;
+
+                uint32_t a_n0 = srow[0], a_n1 = srow[1], b_n0 = crow[0], b_n1 = crow[1], b_n2 = crow[2];
+#pragma unroll
+                for (int i = 0; i < ROWS; i++)
+                {
+                    const uint32_t a0 = a_n0, a1 = a_n1;
+                    const uint32_t bw0 = __builtin_amdgcn_alignbyte(b_n1, b_n0, sh);
+                    const uint32_t bw1 = __builtin_amdgcn_alignbyte(b_n2, b_n1, sh);
+                    if (i + 1 < ROWS)
+                    {
+                        a_n0 = srow[(i + 1) * CPD]; a_n1 = srow[(i + 1) * CPD + 1];
+                        b_n0 = crow[(i + 1) * CPD]; b_n1 = crow[(i + 1) * CPD + 1]; b_n2 = crow[(i + 1) * CPD + 2];
+                    }
+#pragma unroll
+                    for (int q = 0; q < PX; q++)
+                    {
+                        const int d = (int)half_of(q < 2 ? a0 : a1, q & 1) - (int)half_of(q < 2 ? bw0 : bw1, q & 1);
+                        C[q] += (uint32_t)(d * d);
+                        if (i < RY - 1) hist[i][q] = C[q];
+                    }
+                    if (i >= N - 1)
+                    {
+                        const int o = i - (N - 1);
+                        uint32_t V[PX], pre[PX + 1], suf[PX + 1];
+#pragma unroll
+                        for (int q = 0; q < PX; q++) V[q] = o > 0 ? C[q] - hist[o > 0 ? o - 1 : 0][q] : C[q];
+                        pre[0] = 0; suf[0] = 0;
+#pragma unroll
+                        for (int q = 0; q < PX; q++)
+                        {
+                            pre[q + 1] = pre[q] + V[q];
+                            suf[q + 1] = suf[q] + V[PX - 1 - q];
+                        }
+#pragma unroll
+                        for (int p = 0; p < PX; p++)
+                        {
+                            const int lo = p - NH, hi = p + NH;
+                            uint32_t t;
+                            if (lo <= 0 && hi >= PX - 1) t = pre[PX];
+                            else if (lo <= 0) t = pre[hi + 1];
+                            else if (hi >= PX - 1) t = suf[PX - lo];
+                            else t = pre[hi + 1] - pre[lo];
+                            if (lo < 0) { t += from_lane_below(suf[-lo]); asm volatile("" : "+v"(t)); }
+                            if (hi > PX - 1) { t += from_lane_above(pre[hi - (PX - 1)]); asm volatile("" : "+v"(t)); }
+                            v[p] = t;
+                        }
+                    }
+                    if (i >= N)
+                    {
+                        const int o = i - N;
+#pragma unroll
+                        for (int pp = 0; pp < PX / 2; pp++)
+                        {
+                            const uint32_t pix = pp ? pixq1 : pixq0;
+                            const f2 pv = {(float)(int)half_of(pix, 0), (float)(int)half_of(pix, 1)};
+                            aw[o][pp] += wq[pp];
+                            ap[o][pp] += wq[pp] * pv;
+                        }
+                    }
+                    if (i >= N - 1)
+                    {
+                        const int o = i - (N - 1);
+                        const uint32_t p0 = prow[o * CPD], p1 = prow[o * CPD + 1], p2 = prow[o * CPD + 2];
+                        pixq0 = __builtin_amdgcn_alignbyte(p1, p0, sh);
+                        pixq1 = __builtin_amdgcn_alignbyte(p2, p1, sh);
+#pragma unroll
+                        for (int pp = 0; pp < PX / 2; pp++)
+                        {
+                            int idx[2];
+                            if (FAST)
+                            {
+                                const f2 fd = {(float)(int)min(v[2 * pp], (uint32_t)diff_cap),
+                                               (float)(int)min(v[2 * pp + 1], (uint32_t)diff_cap)};
+                                const f2 fi = fd * wft2;
+                                idx[0] = (int)fi.x;
+                                idx[1] = (int)fi.y;
+                            }
+                            else
+                            {
+#pragma unroll
+                                for (int e = 0; e < 2; e++)
+                                {
+                                    const int diff = (int)v[2 * pp + e];
+                                    int ix = (int)((float)diff * wft);
+                                    ix = diff < diff_max ? ix : 127;
+                                    idx[e] = min(ix, 127);
+                                }
+                            }
+                            wq[pp] = f2{s_exp[idx[0]], s_exp[idx[1]]};
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int pp = 0; pp < PX / 2; pp++)
+                {
+                    const uint32_t pix = pp ? pixq1 : pixq0;
+                    const f2 pv = {(float)(int)half_of(pix, 0), (float)(int)half_of(pix, 1)};
+                    aw[RY - 1][pp] += wq[pp];
+                    ap[RY - 1][pp] += wq[pp] * pv;
+                }
+            }
+        }
+    }
+
+    const int x = tx0 + (tx - 1) * PX;
+    if (tx == 0 || tx == TXN - 1 || x >= w) return;
+#pragma unroll
+    for (int o = 0; o < RY; o++)
+    {
+        const int y = ty0 + ty * RY + o;
+        if (y >= h) break;
+        const uint32_t c0 = own[(o + NH) * CPD], c1 = own[(o + NH) * CPD + 1];
+        uint32_t r[PX];
+#pragma unroll
+        for (int p = 0; p < PX; p++)
+        {
+            const float q = ap[o][p / 2][p & 1] / aw[o][p / 2][p & 1];
+            uint32_t rv = (uint32_t)(int)q & 0xffffu;
+            if (rv == 0) rv = half_of(p < 2 ? c0 : c1, p & 1);
+            r[p] = rv;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        uint16_t *out = reinterpret_cast<uint16_t *>(job.dst + (size_t)y * job.dst_pitch) + x;
+        if (x + 3 < w)
+        {
+            reinterpret_cast<uint32_t *>(out)[0] = r[0] | (r[1] << 16);
+            reinterpret_cast<uint32_t *>(out)[1] = r[2] | (r[3] << 16);
+        }
+        else
+        {
+            for (int p = 0; p < PX && x + p < w; p++) out[p] = (uint16_t)r[p];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------- prefilters
 // nlmeans_prefilter (nlmeans_template.c:428-543) on one plane.  The reference filters the bordered
 // image and re-mirrors the result, so a prefiltered plane is fully described by its w x h interior;
@@ -655,6 +919,7 @@ public:
             // a prefilter only exists if one of the base filters is selected (:438-443)
             pf_type[c] = (par.prefilter[c] & PF_BASE) ? par.prefilter[c] : 0;
             passthru[c] = (par.prefilter[c] & PF_PASSTHRU) != 0;
+            if (in_geo.bps == 2 && (pf_type[c] || passthru[c])) return HBHIP_ERR_UNSUPPORTED;   // prefilters: 8-bit only
             any_pre |= pf_type[c] != 0;
             if (passthru[c]) continue;                 // the plane is not denoised at all (nlmeans.c:485-492)
             max_frames = std::max(max_frames, par.nframes[c]);
@@ -903,17 +1168,22 @@ private:
             // tiles: 32 lanes + rq dwords of search halo either side (+1 for the alignbyte high
             // word), pitch = 4 (mod 8) dwords
             const int rq = (max_rh + 3) / 4;
-            const int cpd = rq <= 1 ? 36 : 44;
+            const bool wide = in_geo.bps == 2;                 // 16-bit samples: 2 pixels per tile dword
+            const int cpd = wide ? (rq <= 2 ? 76 : 84) : (rq <= 1 ? 36 : 44);
             const size_t shmem = sizeof(uint32_t) * (pre ? 4 : 2) * (cpd * cmp_rows + 4) + 512;
             // the widest search ranges need more than the default 64 KB of dynamic LDS
-#define NLM_GO(NN, FF, CC, PP) do { \
+#define NLM_LAUNCH(KERNEL) do { \
                 if (shmem > 65536) \
-                    HBHIP_CHECK(ctx, hipFuncSetAttribute((const void *)nlmeans_lanes_kernel<NN, FF, CC, PP>, \
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
-                HBHIP_LAUNCH(ctx, "nlmeans_plane_n" #NN, (nlmeans_lanes_kernel<NN, FF, CC, PP>), grid, block, shmem, dj, nj, cmp_rows, rq); \
+                    HBHIP_CHECK(ctx, hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
+                HBHIP_LAUNCH(ctx, kname, (KERNEL), grid, block, shmem, dj, nj, cmp_rows, rq); \
             } while (0)
+#define NLM_GO(NN, FF, CC, PP) NLM_LAUNCH((nlmeans_lanes_kernel<NN, FF, CC, PP>))
 #define NLM_PRE(NN, FF, CC) do { if (pre) NLM_GO(NN, FF, CC, true); else NLM_GO(NN, FF, CC, false); } while (0)
-#define NLM_VAR(NN) do { if (cpd == 36) { if (fast) NLM_PRE(NN, true, 36); else NLM_PRE(NN, false, 36); } \
+#define NLM_16(NN, FF) do { if (cpd == 76) NLM_LAUNCH((nlmeans_lanes16_kernel<NN, FF, 76>)); \
+                            else NLM_LAUNCH((nlmeans_lanes16_kernel<NN, FF, 84>)); } while (0)
+#define NLM_VAR(NN) do { const char *kname = "nlmeans_plane_n" #NN; \
+                     if (wide) { if (fast) NLM_16(NN, true); else NLM_16(NN, false); } \
+                     else if (cpd == 36) { if (fast) NLM_PRE(NN, true, 36); else NLM_PRE(NN, false, 36); } \
                      else { if (fast) NLM_PRE(NN, true, 44); else NLM_PRE(NN, false, 44); } } while (0)
             switch (n)
             {
@@ -923,8 +1193,10 @@ private:
                 case 9: NLM_VAR(9); break;
             }
 #undef NLM_VAR
+#undef NLM_16
 #undef NLM_PRE
 #undef NLM_GO
+#undef NLM_LAUNCH
             HBHIP_CHECK(ctx, hipGetLastError());
         }
 
@@ -1040,7 +1312,7 @@ extern "C" int hbhip_nlmeans_create(hbhip_ctx *ctx, const hbhip_nlmeans_params *
 {
     if (!ctx || !p || !out) return HBHIP_ERR_ARG;
     *out = nullptr;
-    if (depth != 8) return HBHIP_ERR_UNSUPPORTED;
+    if (depth != 8 && depth != 10 && depth != 12) return HBHIP_ERR_UNSUPPORTED;
     if (width < 1 || height < 1) return HBHIP_ERR_ARG;
     (void)hipSetDevice(ctx->device);
     NlmFilter *f = new (std::nothrow) NlmFilter(ctx, *p);

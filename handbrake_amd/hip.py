@@ -231,12 +231,14 @@ NLMEANS_MEDIUM = ("y-strength=6:y-origin-tune=1:y-patch-size=7:y-range=3:y-frame
                   "cb-strength=6:cb-origin-tune=1:cb-patch-size=7:cb-range=3:cb-frame-count=2:cb-prefilter=0")
 
 
-def nlmeans_device_filter(ctx: Ctx, settings: str, width: int, height: int, batch: int = 1) -> DeviceFilter:
-    """An NLMeans instance driven through the C ABI with device-resident frames."""
+def nlmeans_device_filter(ctx: Ctx, settings: str, width: int, height: int, batch: int = 1,
+                          depth: int = 8) -> DeviceFilter:
+    """An NLMeans instance driven through the C ABI with device-resident frames
+    (depth 10 / 12: uint16 planes)."""
     par = NLMeansParams()
-    filters().hbhip_nlmeans_params_from_settings(settings.encode(), 8, C.byref(par))
+    filters().hbhip_nlmeans_params_from_settings(settings.encode(), depth, C.byref(par))
     h = C.c_void_p()
-    check(lib().hbhip_nlmeans_create(ctx.h, C.byref(par), width, height, 8, 1, 1, C.byref(h)),
+    check(lib().hbhip_nlmeans_create(ctx.h, C.byref(par), width, height, depth, 1, 1, C.byref(h)),
           ctx.h, "hbhip_nlmeans_create")
     check(lib().hbhip_nlmeans_set_batch(h, batch), ctx.h, "set_batch")
     return DeviceFilter(ctx, h)

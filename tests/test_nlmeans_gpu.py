@@ -197,3 +197,19 @@ def test_prefilters_bit_exact(built, w, h, settings, pp):
     for t in range(len(frames)):
         for c in range(3):
             np.testing.assert_array_equal(got[t].planes[c], want[t][c], err_msg=f"frame {t} plane {c}")
+
+
+@pytest.mark.parametrize("depth,w,h", [(10, 638, 362), (12, 200, 120)])
+def test_16bit_samples_bit_exact(built, depth, w, h):
+    """YUV420P10 / P12 (the _16 template instantiations, nlmeans.c:253-262) through the drop-in."""
+    import oracle_stream as ostream
+    frames = synth.stream("progressive", w, h, 3, depth=depth)
+    got = hbrt.run_stream(hip.filters(), [("hb_filter_nlmeans_hip", MEDIUM)], frames,
+                          pix_fmt=hbrt.PIX_FMT_FOR_DEPTH[depth])
+    pp = [dict(par(), depth=depth) for _ in range(3)]
+    want = ostream.nlmeans_stream(frames, pp)
+    assert len(got) == len(frames)
+    for t in range(len(frames)):
+        for c in range(3):
+            assert got[t].planes[c].dtype == np.uint16
+            np.testing.assert_array_equal(got[t].planes[c], want[t][c], err_msg=f"frame {t} plane {c}")
