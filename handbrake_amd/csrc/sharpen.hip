@@ -106,6 +106,82 @@ __global__ __launch_bounds__(256) void lapsharp_kernel(LapArgs a)
         for (int p = 0; x0 + p < a.width; p++) d[p] = (uint8_t)(packed >> (8 * p));
 }
 
+// lapsharp_16 (DEF_LAPSHARP_FUNC(lapsharp, 16, 32), lapsharp.c:184): 16-bit samples, int32
+// accumulator, clamp to (1 << depth) - 1.  One thread = 2 adjacent pixels (one dword);
+// width / stride_border are in samples, pitches in bytes.
+template <int S>
+__global__ __launch_bounds__(256) void lapsharp16_kernel(LapArgs a, int max_value)
+{
+    constexpr int LO = -((S - 1) / 2), HI = (S + 1) / 2;
+    const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    const int y = blockIdx.y;
+    if (x0 >= a.width) return;
+    const int pitch_dw = a.src_pitch >> 2;
+    const int xd = x0 >> 1;
+    uint32_t rows[S][3];                                     // samples x0-2 .. x0+3 of each row
+#pragma unroll
+    for (int j = 0; j < S; j++)
+    {
+        int yy = y + LO + j;
+        yy = min(max(yy, 0), a.height - 1);
+        const uint32_t *r = reinterpret_cast<const uint32_t *>(a.src + (size_t)yy * a.src_pitch);
+        rows[j][0] = r[max(xd - 1, 0)];
+        rows[j][1] = r[xd];
+        rows[j][2] = r[min(xd + 1, pitch_dw - 1)];
+        if (x0 + 4 > a.width)
+        {
+            // Right of the plane the reference reads its stride padding, which lapsharp has just
+            // filled with hb_frame_buffer_mirror_stride (lapsharp.c:333 -> fifo.c:906-932; the 16-bit
+            // variant is the one that really mirrors): sample w + i = sample w - 1 - i.
+            const uint16_t *r16 = reinterpret_cast<const uint16_t *>(r);
+#pragma unroll
+            for (int k = 0; k < 6; k++)
+            {
+                const int xx = x0 - 2 + k;
+                if (xx >= a.width)
+                {
+                    const uint32_t m = r16[max(2 * a.width - 1 - xx, 0)];
+                    uint32_t &d = rows[j][k >> 1];
+                    d = (k & 1) ? ((d & 0x0000ffffu) | (m << 16)) : ((d & 0xffff0000u) | m);
+                }
+            }
+        }
+    }
+    auto at = [&](int j, int k) -> int {                    // sample x0 + k of row j, k in [-2, 3]
+        const int kk = k + 2;
+        return (int)((rows[j][kk >> 1] >> (16 * (kk & 1))) & 0xffffu);
+    };
+    uint32_t res[2];
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+    {
+        const int x = x0 + p;
+        const int centre = at(-LO, p);
+        int out = centre;
+        const bool copy = (y < HI) || (y > a.height - HI) || (x < a.stride_border + HI) ||
+                          (x > a.width + a.stride_border - HI);
+        if (!copy)
+        {
+            int acc = 0;
+#pragma unroll
+            for (int k = 0; k < S; k++)
+#pragma unroll
+                for (int j = 0; j < S; j++)
+                    acc += a.tap[j * S + k] * at(j, p + LO + k);
+            const double mixed = (((double)acc * a.coef) - (double)centre) * a.strength;
+            out = (int)mixed + centre;
+            out = out < 0 ? 0 : out;
+            out = out > max_value ? max_value : out;
+        }
+        res[p] = (uint32_t)out;
+    }
+    uint16_t *d = reinterpret_cast<uint16_t *>(a.dst + (size_t)y * a.dst_pitch) + x0;
+    if (x0 + 1 < a.width)
+        *reinterpret_cast<uint32_t *>(d) = res[0] | (res[1] << 16);
+    else
+        d[0] = (uint16_t)res[0];
+}
+
 // ------------------------------------------------------------------ binomial blur + mix
 constexpr int BT_W = 64, BT_H = 16, MAX_STEPS = 7;
 
@@ -119,9 +195,12 @@ struct BlurArgs
     uint32_t       coef[2 * MAX_STEPS + 1];
 };
 
+// PIX = uint8_t, or uint16_t for the _16 instantiations (unsharp.c:171, chroma_smooth.c:170);
+// pitches stay in bytes
+template <typename PIX>
 __global__ __launch_bounds__(256) void blur_mix_kernel(BlurArgs a)
 {
-    __shared__ uint8_t  s_src[(BT_H + 2 * MAX_STEPS) * (BT_W + 2 * MAX_STEPS)];
+    __shared__ PIX      s_src[(BT_H + 2 * MAX_STEPS) * (BT_W + 2 * MAX_STEPS)];
     __shared__ uint32_t s_h[(BT_H + 2 * MAX_STEPS) * BT_W];
 
     const int s = a.steps;
@@ -134,7 +213,7 @@ __global__ __launch_bounds__(256) void blur_mix_kernel(BlurArgs a)
         const int r = i / tw, c = i - r * tw;
         const int y = min(max(y0 - s + r, 0), a.height - 1);
         const int x = min(max(x0 - s + c, 0), a.width - 1);
-        s_src[i] = a.src[(size_t)y * a.src_pitch + x];
+        s_src[i] = reinterpret_cast<const PIX *>(a.src + (size_t)y * a.src_pitch)[x];
     }
     __syncthreads();
 
@@ -168,7 +247,7 @@ __global__ __launch_bounds__(256) void blur_mix_kernel(BlurArgs a)
         const int d = ((p - blur) * a.amount) >> 16;         // arithmetic shift, as gcc does
         int res = a.sign > 0 ? p + d : p - d;
         res = res > a.vmax ? a.vmax : res < a.vmin ? a.vmin : res;
-        a.dst[(size_t)y * a.dst_pitch + x] = (uint8_t)res;
+        reinterpret_cast<PIX *>(a.dst + (size_t)y * a.dst_pitch)[x] = (PIX)res;
     }
 }
 
@@ -212,11 +291,23 @@ public:
             a.src_pitch = in->pitch[c]; a.dst_pitch = out->pitch[c];
             // host buffers: the caller's stride decides (lapsharp.c:145); device-resident frames have no
             // hb_buffer stride, so use what hb_image_stride would be and read the padding as zeros
-            const int hb_stride = in_is_dev ? hbhip_align_up(in->width[c], 64) : in_stride[c];
+            // (in samples: the reference divides the strides by bps first, lapsharp.c:137-138)
+            const int hb_stride = in_is_dev ? hbhip_align_up(in->width[c] * in->bps, 64) / in->bps : in_stride[c] / in->bps;
             a.stride_border = (hb_stride - in->width[c]) / 2;
             a.valid_w = in_is_dev ? in->width[c] : (1 << 30);
             for (int i = 0; i < 25; i++) a.tap[i] = k.tap[i];
             a.coef = k.coef; a.strength = par.strength[c];
+            if (in->bps == 2)
+            {
+                dim3 grid16(((a.width + 1) / 2 + 255) / 256, a.height);
+                const int max_value = (1 << in_geo.depth) - 1;
+                if (k.size == 3)
+                    HBHIP_LAUNCH(ctx, "lapsharp_3x3", lapsharp16_kernel<3>, grid16, dim3(256), 0, a, max_value);
+                else
+                    HBHIP_LAUNCH(ctx, "lapsharp_5x5", lapsharp16_kernel<5>, grid16, dim3(256), 0, a, max_value);
+                HBHIP_CHECK(ctx, hipGetLastError());
+                continue;
+            }
             dim3 grid(((a.width + 3) / 4 + 255) / 256, a.height), block(256);
             if (k.size == 3)
                 HBHIP_LAUNCH(ctx, "lapsharp_3x3", lapsharp_kernel<3>, grid, block, 0, a);
@@ -263,7 +354,8 @@ public:
             }
             for (int i = 0; i <= 2 * MAX_STEPS; i++) a.coef[i] = i <= 2 * a.steps ? row[i] : 0;
             dim3 grid((a.width + BT_W - 1) / BT_W, (a.height + BT_H - 1) / BT_H), block(256);
-            HBHIP_LAUNCH(ctx, name, blur_mix_kernel, grid, block, 0, a);
+            if (in->bps == 2) HBHIP_LAUNCH(ctx, name, blur_mix_kernel<uint16_t>, grid, block, 0, a);
+            else              HBHIP_LAUNCH(ctx, name, blur_mix_kernel<uint8_t>, grid, block, 0, a);
             HBHIP_CHECK(ctx, hipGetLastError());
         }
         return HBHIP_OK;
@@ -278,7 +370,7 @@ int create_simple(hbhip_ctx *ctx, int width, int height, int depth, int lcw, int
 {
     if (!ctx || !out) return HBHIP_ERR_ARG;
     *out = nullptr;
-    if (depth != 8) return HBHIP_ERR_UNSUPPORTED;
+    if (depth != 8 && depth != 10 && depth != 12) return HBHIP_ERR_UNSUPPORTED;
     if (width < 1 || height < 1) return HBHIP_ERR_ARG;
     (void)hipSetDevice(ctx->device);
     F *f = new (std::nothrow) F(ctx, std::forward<A>(args)...);
@@ -315,7 +407,7 @@ extern "C" int hbhip_unsharp_create(hbhip_ctx *ctx, const hbhip_blur_params *p, 
     int rc = check_blur(p);
     if (rc != HBHIP_OK) return rc;
     return create_simple<BlurMixFilter>(ctx, width, height, depth, log2_chroma_w, log2_chroma_h, out,
-                                        *p, +1, 0, 255, "unsharp_blur_mix");
+                                        *p, +1, 0, (1 << depth) - 1, "unsharp_blur_mix");
 }
 
 extern "C" int hbhip_chroma_smooth_create(hbhip_ctx *ctx, const hbhip_blur_params *p, int width, int height,
@@ -323,7 +415,8 @@ extern "C" int hbhip_chroma_smooth_create(hbhip_ctx *ctx, const hbhip_blur_param
 {
     int rc = check_blur(p);
     if (rc != HBHIP_OK) return rc;
-    // clamp range max/16 .. max - max/16 for 8-bit (chroma_smooth.c:233-235)
+    // clamp range max/16 .. max - max/16 (chroma_smooth.c:233-235)
+    const int max = 1 << depth;
     return create_simple<BlurMixFilter>(ctx, width, height, depth, log2_chroma_w, log2_chroma_h, out,
-                                        *p, -1, 16, 240, "chroma_smooth_blur_mix");
+                                        *p, -1, max / 16, max - max / 16, "chroma_smooth_blur_mix");
 }

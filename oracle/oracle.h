@@ -94,6 +94,14 @@ void orc_unsharp_plane(const uint8_t *src, uint8_t *dst, int width, int height,
 void orc_chroma_smooth_plane(const uint8_t *src, uint8_t *dst, int width, int height,
                              int src_stride, int dst_stride, double strength, int size);
 
+/* The _16 instantiations of the three filters above (depth 10 / 12; strides in samples). */
+void orc_lapsharp_plane16(const uint16_t *src, uint16_t *dst, int width, int height,
+                          int src_stride, int dst_stride, double strength, int kernel, int depth);
+void orc_unsharp_plane16(const uint16_t *src, uint16_t *dst, int width, int height,
+                         int src_stride, int dst_stride, double strength, int size, int depth);
+void orc_chroma_smooth_plane16(const uint16_t *src, uint16_t *dst, int width, int height,
+                               int src_stride, int dst_stride, double strength, int size, int depth);
+
 /* ---- hqdn3d (denoise.c) --------------------------------------------------------- */
 
 /* hqdn3d_precalc_coef (denoise.c:78-94), 8-bit: ct[8192]; ct[0] doubles as the

@@ -23,12 +23,12 @@ def nlm(strength=6, origin_tune=1.0, patch=7, rng=3, nframes=2, prefilter=0, dep
                 nframes=nframes, prefilter=prefilter, depth=depth)
 
 
-def lap(strength=0.2, kernel="isolap"):
-    return dict(strength=strength, kernel=kernel)
+def lap(strength=0.2, kernel="isolap", depth=8):
+    return dict(strength=strength, kernel=kernel, depth=depth)
 
 
-def blur(strength=0.25, size=7):
-    return dict(strength=strength, size=size)
+def blur(strength=0.25, size=7, depth=8):
+    return dict(strength=strength, size=size, depth=depth)
 
 
 COMB_DEFAULT = ("mode=3:spatial-metric=2:motion-thresh=1:spatial-thresh=1:filter-mode=2:"
@@ -78,6 +78,18 @@ CASES = {
                                      hip=[("hb_filter_nlmeans_hip", NLM_TAPE)],
                                      orc=[("nlmeans", [nlm(3, 0.8, 3, 5, 2, depth=12), nlm(6, 0.8, 5, 5, 2, depth=12),
                                                        nlm(6, 0.8, 5, 5, 2, depth=12)])]),
+    "lapsharp_isolog_10bit_134x70": dict(model="progressive", w=134, h=70, n=2, depth=10,
+                                         chain=[("hb_filter_lapsharp", "y-strength=1.1:y-kernel=isolog:cb-strength=0.4:cb-kernel=lap")],
+                                         hip=[("hb_filter_lapsharp_hip", "y-strength=1.1:y-kernel=isolog:cb-strength=0.4:cb-kernel=lap")],
+                                         orc=[("lapsharp", [lap(1.1, "isolog", 10), lap(0.4, "lap", 10), lap(0.4, "lap", 10)])]),
+    "unsharp_12bit_96x64": dict(model="random", w=96, h=64, n=2, depth=12,
+                                chain=[("hb_filter_unsharp", "y-strength=0.9:y-size=15:cb-strength=0.5:cb-size=5")],
+                                hip=[("hb_filter_unsharp_hip", "y-strength=0.9:y-size=15:cb-strength=0.5:cb-size=5")],
+                                orc=[("unsharp", [blur(0.9, 15, 12), blur(0.5, 5, 12), blur(0.5, 5, 12)])]),
+    "chroma_smooth_10bit_134x70": dict(model="random", w=134, h=70, n=2, depth=10,
+                                       chain=[("hb_filter_chroma_smooth", "cb-strength=0.8:cb-size=9")],
+                                       hip=[("hb_filter_chroma_smooth_hip", "cb-strength=0.8:cb-size=9")],
+                                       orc=[("chroma_smooth", [blur(0.8, 9, 10), blur(0.8, 9, 10)])]),
     "lapsharp_medium_134x70": dict(model="progressive", w=134, h=70, n=2,
                                    chain=[("hb_filter_lapsharp", "y-strength=0.2:y-kernel=isolap:cb-strength=0.2:cb-kernel=isolap")],
                                    hip=[("hb_filter_lapsharp_hip", "y-strength=0.2:y-kernel=isolap:cb-strength=0.2:cb-kernel=isolap")],

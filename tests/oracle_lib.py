@@ -137,7 +137,44 @@ def padded(plane: np.ndarray) -> np.ndarray:
 LAPSHARP_KERNELS = {"lap": 0, "isolap": 1, "log": 2, "isolog": 3}
 
 
-def orc_lapsharp_plane(plane, strength=0.2, kernel="isolap"):
+def padded16(plane: np.ndarray) -> np.ndarray:
+    """16-bit plane as libhb stores it: row stride = width*2 bytes rounded up to 64."""
+    h, w = plane.shape
+    buf = np.zeros((h, hb_stride(2 * w) // 2), np.uint16)
+    buf[:, :w] = plane
+    return buf
+
+
+def mirrored16(plane: np.ndarray) -> np.ndarray:
+    """padded16 + hb_frame_buffer_mirror_stride (fifo.c:906-932), which lapsharp applies to its
+    input: the first half of each row's padding mirrors the row's end, the second half the start
+    of the next row (the last row's second half is left as it is)."""
+    buf = padded16(plane)
+    h, w = plane.shape
+    margin = buf.shape[1] - w
+    front, back = margin // 2, margin - margin // 2
+    for i in range(back):
+        buf[:, w + i] = buf[:, w - 1 - i]
+    for i in range(front):
+        buf[:-1, buf.shape[1] - 1 - i] = buf[1:, i]
+    return buf
+
+
+def _call16(fn_name, plane, *tail, mirror=False):
+    h, w = plane.shape
+    src = mirrored16(plane) if mirror else padded16(plane)
+    dst = np.zeros_like(src)
+    u16p = C.POINTER(C.c_uint16)
+    fn = getattr(oracle(), fn_name)
+    fn.restype = None
+    fn.argtypes = [u16p, u16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int]
+    fn(src.ctypes.data_as(u16p), dst.ctypes.data_as(u16p), w, h, src.shape[1], dst.shape[1], *tail)
+    return dst[:, :w].copy()
+
+
+def orc_lapsharp_plane(plane, strength=0.2, kernel="isolap", depth=8):
+    if plane.dtype == np.uint16:
+        return _call16("orc_lapsharp_plane16", plane, strength, LAPSHARP_KERNELS[kernel], depth, mirror=True)
     h, w = plane.shape
     src = padded(plane)
     dst = np.zeros_like(src)
@@ -159,11 +196,15 @@ def _blur(fn_name, plane, strength, size):
     return dst[:, :w].copy()
 
 
-def orc_unsharp_plane(plane, strength=0.25, size=7):
+def orc_unsharp_plane(plane, strength=0.25, size=7, depth=8):
+    if plane.dtype == np.uint16:
+        return _call16("orc_unsharp_plane16", plane, strength, size, depth)
     return _blur("orc_unsharp_plane", plane, strength, size)
 
 
-def orc_chroma_smooth_plane(plane, strength=0.25, size=7):
+def orc_chroma_smooth_plane(plane, strength=0.25, size=7, depth=8):
+    if plane.dtype == np.uint16:
+        return _call16("orc_chroma_smooth_plane16", plane, strength, size, depth)
     return _blur("orc_chroma_smooth_plane", plane, strength, size)
 
 

@@ -80,19 +80,20 @@ def load_golden(path):
 
 def lapsharp_stream(frames, par):
     """par: 3 dicts {strength, kernel}."""
-    return [tuple(ol.orc_lapsharp_plane(fr[c], par[c]["strength"], par[c]["kernel"]) for c in range(3))
-            for fr in frames]
+    return [tuple(ol.orc_lapsharp_plane(fr[c], par[c]["strength"], par[c]["kernel"], par[c].get("depth", 8))
+                  for c in range(3)) for fr in frames]
 
 
 def unsharp_stream(frames, par):
     """par: 3 dicts {strength, size}."""
-    return [tuple(ol.orc_unsharp_plane(fr[c], par[c]["strength"], par[c]["size"]) for c in range(3))
-            for fr in frames]
+    return [tuple(ol.orc_unsharp_plane(fr[c], par[c]["strength"], par[c]["size"], par[c].get("depth", 8))
+                  for c in range(3)) for fr in frames]
 
 
 def chroma_smooth_stream(frames, par):
     """par: dict {strength, size} for cb and cr (list of 2)."""
-    return [(fr[0].copy(),) + tuple(ol.orc_chroma_smooth_plane(fr[c], par[c - 1]["strength"], par[c - 1]["size"])
+    return [(fr[0].copy(),) + tuple(ol.orc_chroma_smooth_plane(fr[c], par[c - 1]["strength"], par[c - 1]["size"],
+                                                               par[c - 1].get("depth", 8))
                                     for c in (1, 2)) for fr in frames]
 
 
