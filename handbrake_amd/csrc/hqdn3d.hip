@@ -18,6 +18,9 @@ namespace {
 constexpr int LUT_N = 8192, CENTRE = 4096;
 
 __device__ __forceinline__ uint32_t load8(uint32_t px) { return (px << 8) + 127u; }      // denoise.c:32-33
+// LOAD / STORE for depth 8 + SH... i.e. SH = 16 - depth (denoise.c:32-35): 8 for bytes, 6 / 4 for
+// 10 / 12-bit samples in 16-bit containers; the fixed-point state and the LUTs do not depend on it
+template <int SH> __device__ __forceinline__ uint32_t load_sh(uint32_t px) { return (px << SH) + (((1u << SH) - 1u) >> 1); }
 __device__ __forceinline__ uint32_t lowpass(int prev, int cur, const int16_t *coef)       // :96-100
 {
     return (uint32_t)(cur + coef[CENTRE + ((prev - cur) >> 4)]);
@@ -116,6 +119,74 @@ __global__ __launch_bounds__(256) void hqdn3d_t_kernel(const uint8_t *__restrict
     dst[(size_t)y * dpitch + x] = (uint8_t)(t >> 8);
 }
 
+// ---- depth 10 / 12 (16-bit containers): the same three kernels with 16-bit samples ----------
+template <int SH>
+__global__ __launch_bounds__(64) void hqdn3d_h16_kernel(const uint8_t *__restrict__ src, int spitch,
+                                                        uint16_t *__restrict__ hbuf, int w, int h,
+                                                        const int16_t *__restrict__ spatial_g)
+{
+    __shared__ int16_t lut[LUT_N];
+    stage_lut(lut, spatial_g, 64);
+    __syncthreads();
+    const int y = blockIdx.x * 64 + threadIdx.x;
+    if (y >= h) return;
+    const uint16_t *s = reinterpret_cast<const uint16_t *>(src + (size_t)y * spitch);
+    uint16_t *o = hbuf + (size_t)y * w;
+    uint32_t run = load_sh<SH>(s[0]);
+    if (y == 0) run = lowpass((int)run, (int)load_sh<SH>(s[0]), lut);      // row 0 quirk (:140-146)
+    o[0] = (uint16_t)run;
+    for (int x = 1; x < w; x++)
+    {
+        run = lowpass((int)run, (int)load_sh<SH>(s[x]), lut);
+        o[x] = (uint16_t)run;
+    }
+}
+
+template <int SH>
+__global__ __launch_bounds__(64) void hqdn3d_vt16_kernel(const uint8_t *__restrict__ src, int spitch,
+                                                         const uint16_t *__restrict__ hbuf,
+                                                         uint16_t *__restrict__ ant, uint8_t *__restrict__ dst,
+                                                         int dpitch, int w, int h, int seeded,
+                                                         const int16_t *__restrict__ spatial_g,
+                                                         const int16_t *__restrict__ temporal_g)
+{
+    __shared__ int16_t lut_s[LUT_N];
+    __shared__ int16_t lut_t[LUT_N];
+    stage_lut(lut_s, spatial_g, 64);
+    stage_lut(lut_t, temporal_g, 64);
+    __syncthreads();
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    if (x >= w) return;
+    uint32_t line = 0;
+    for (int y = 0; y < h; y++)
+    {
+        const uint32_t hv = hbuf[(size_t)y * w + x];
+        const uint32_t v = y == 0 ? hv : lowpass((int)(uint16_t)line, (int)hv, lut_s);
+        line = v;
+        const uint32_t cur = reinterpret_cast<const uint16_t *>(src + (size_t)y * spitch)[x];
+        const uint32_t prev = seeded ? ant[(size_t)y * w + x] : (uint16_t)load_sh<SH>(cur);
+        const uint32_t t = lowpass((int)prev, (int)v, lut_t);
+        ant[(size_t)y * w + x] = (uint16_t)t;
+        reinterpret_cast<uint16_t *>(dst + (size_t)y * dpitch)[x] = (uint16_t)(t >> SH);
+    }
+}
+
+template <int SH>
+__global__ __launch_bounds__(256) void hqdn3d_t16_kernel(const uint8_t *__restrict__ src, int spitch,
+                                                         uint16_t *__restrict__ ant, uint8_t *__restrict__ dst,
+                                                         int dpitch, int w, int h, int seeded,
+                                                         const int16_t *__restrict__ temporal_g)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    const uint32_t cur = load_sh<SH>(reinterpret_cast<const uint16_t *>(src + (size_t)y * spitch)[x]);
+    const uint32_t prev = seeded ? ant[(size_t)y * w + x] : (uint16_t)cur;
+    const uint32_t t = (uint32_t)((int)cur + temporal_g[CENTRE + (((int)prev - (int)cur) >> 4)]);
+    ant[(size_t)y * w + x] = (uint16_t)t;
+    reinterpret_cast<uint16_t *>(dst + (size_t)y * dpitch)[x] = (uint16_t)(t >> SH);
+}
+
 class Hqdn3dFilter : public SimpleFilter
 {
 public:
@@ -142,20 +213,28 @@ public:
         {
             const int w = in->width[c], h = in->height[c];
             const int16_t *sp = d_coef + (size_t)(2 * c) * LUT_N, *tp = sp + LUT_N;
-            if (par.coef[2 * c][0])                                  // spatial strength != 0 (denoise.c:191)
+            const bool spatial = par.coef[2 * c][0] != 0;             // spatial strength != 0 (denoise.c:191)
+            const uint8_t *src = in->plane[c];
+#define HQ_SPATIAL(HK, VK) do { \
+                HBHIP_LAUNCH(ctx, "hqdn3d_h", HK, dim3((h + 63) / 64), dim3(64), 0, src, in->pitch[c], hbuf, w, h, sp); \
+                HBHIP_LAUNCH(ctx, "hqdn3d_vt", VK, dim3((w + 63) / 64), dim3(64), 0, src, in->pitch[c], \
+                             (const uint16_t *)hbuf, ant[c], out->plane[c], out->pitch[c], w, h, seeded[c], sp, tp); } while (0)
+#define HQ_TEMPORAL(TK) HBHIP_LAUNCH(ctx, "hqdn3d_t", TK, dim3((w + 255) / 256, h), dim3(256), 0, src, in->pitch[c], \
+                                     ant[c], out->plane[c], out->pitch[c], w, h, seeded[c], tp)
+            if (in_geo.depth == 8)
             {
-                HBHIP_LAUNCH(ctx, "hqdn3d_h", hqdn3d_h_kernel, dim3((h + 63) / 64), dim3(64), 0,
-                             (const uint8_t *)in->plane[c], in->pitch[c], hbuf, w, h, sp);
-                HBHIP_LAUNCH(ctx, "hqdn3d_vt", hqdn3d_vt_kernel, dim3((w + 63) / 64), dim3(64), 0,
-                             (const uint8_t *)in->plane[c], in->pitch[c], (const uint16_t *)hbuf, ant[c],
-                             out->plane[c], out->pitch[c], w, h, seeded[c], sp, tp);
+                if (spatial) HQ_SPATIAL(hqdn3d_h_kernel, hqdn3d_vt_kernel); else HQ_TEMPORAL(hqdn3d_t_kernel);
+            }
+            else if (in_geo.depth == 10)
+            {
+                if (spatial) HQ_SPATIAL(hqdn3d_h16_kernel<6>, hqdn3d_vt16_kernel<6>); else HQ_TEMPORAL(hqdn3d_t16_kernel<6>);
             }
             else
             {
-                HBHIP_LAUNCH(ctx, "hqdn3d_t", hqdn3d_t_kernel, dim3((w + 255) / 256, h), dim3(256), 0,
-                             (const uint8_t *)in->plane[c], in->pitch[c], ant[c], out->plane[c], out->pitch[c],
-                             w, h, seeded[c], tp);
+                if (spatial) HQ_SPATIAL(hqdn3d_h16_kernel<4>, hqdn3d_vt16_kernel<4>); else HQ_TEMPORAL(hqdn3d_t16_kernel<4>);
             }
+#undef HQ_SPATIAL
+#undef HQ_TEMPORAL
             seeded[c] = 1;
         }
         HBHIP_CHECK(ctx, hipGetLastError());
@@ -175,7 +254,7 @@ extern "C" int hbhip_hqdn3d_create(hbhip_ctx *ctx, const hbhip_hqdn3d_params *p,
 {
     if (!ctx || !p || !out) return HBHIP_ERR_ARG;
     *out = nullptr;
-    if (depth != 8) return HBHIP_ERR_UNSUPPORTED;
+    if (depth != 8 && depth != 10 && depth != 12) return HBHIP_ERR_UNSUPPORTED;
     if (width < 1 || height < 1) return HBHIP_ERR_ARG;
     (void)hipSetDevice(ctx->device);
     Hqdn3dFilter *f = new (std::nothrow) Hqdn3dFilter(ctx, *p);

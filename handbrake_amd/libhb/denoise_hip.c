@@ -39,7 +39,8 @@ hb_filter_object_t hb_filter_denoise_hip =
     .settings_template = denoise_hip_template,
 };
 
-/* denoise.c:78-94 for 8-bit */
+/* denoise.c:78-94; LUT_BITS is 4 for every depth below 16 (denoise.c:31), so the table is the
+ * same for 8, 10 and 12-bit samples */
 static void precalc_coef(int16_t *ct, double dist25)
 {
     const double gamma = log(0.25) / log(1.0 - FFMIN(dist25, 252.0) / 255.0 - 0.00001);
@@ -61,7 +62,7 @@ static int denoise_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init)
     pv->dev_io = hbhip_host_dev_io(init);
 
     const AVPixFmtDescriptor *desc = av_pix_fmt_desc_get(init->pix_fmt);
-    if (desc == NULL || desc->comp[0].depth != 8) goto fail;
+    if (desc == NULL || (desc->comp[0].depth != 8 && desc->comp[0].depth != 10 && desc->comp[0].depth != 12)) goto fail;
 
     double sy, scb, scr, ty, tcb, tcr;                      /* denoise.c:228-256 */
     if (!hb_dict_extract_double(&sy, filter->settings, "y-spatial"))    sy = 4.0;

@@ -30,8 +30,18 @@ void orc_hqdn3d_coef(int16_t ct[8192], double dist25)
     ct[0] = !!dist25;
 }
 
-/* 8-bit sample -> 16-bit fixed point (denoise.c:32-33) and back (:34-35) */
-static inline uint32_t load8(const uint8_t *row, int x) { return ((uint32_t)row[x] << 8) + 127; }
+/* sample -> 16-bit fixed point (LOAD, denoise.c:32-33) and back (STORE, :34-35); rows are byte
+ * pointers, 16-bit containers for depth > 8.  LUT_BITS is 4 for every depth below 16 (:31). */
+static inline uint32_t load_d(const uint8_t *row, int x, int depth)
+{
+    const uint32_t v = depth == 8 ? row[x] : ((const uint16_t *)row)[x];
+    return (v << (16 - depth)) + (((1u << (16 - depth)) - 1) >> 1);
+}
+static inline void store_d(uint8_t *row, int x, uint32_t val, int depth)
+{
+    if (depth == 8) row[x] = val >> 8;
+    else ((uint16_t *)row)[x] = val >> (16 - depth);
+}
 
 /* :96-100 ; `coef` points at the table centre */
 static inline uint32_t lowpass(int prev, int cur, const int16_t *coef)
@@ -40,9 +50,9 @@ static inline uint32_t lowpass(int prev, int cur, const int16_t *coef)
     return cur + coef[d];
 }
 
-void orc_hqdn3d_plane(const uint8_t *src, uint8_t *dst, int w, int h, int sstride, int dstride,
-                      uint16_t *frame_ant, int *state_valid,
-                      const int16_t spatial_t[8192], const int16_t temporal_t[8192])
+void orc_hqdn3d_plane_d(const uint8_t *src, uint8_t *dst, int w, int h, int sstride, int dstride,
+                        uint16_t *frame_ant, int *state_valid,
+                        const int16_t spatial_t[8192], const int16_t temporal_t[8192], int depth)
 {
     const int16_t *spatial = spatial_t + CENTRE, *temporal = temporal_t + CENTRE;
 
@@ -50,7 +60,7 @@ void orc_hqdn3d_plane(const uint8_t *src, uint8_t *dst, int w, int h, int sstrid
     {
         for (int y = 0; y < h; y++)
             for (int x = 0; x < w; x++)
-                frame_ant[(size_t)y * w + x] = load8(src + (size_t)y * sstride, x);
+                frame_ant[(size_t)y * w + x] = load_d(src + (size_t)y * sstride, x, depth);
         *state_valid = 1;
     }
 
@@ -61,9 +71,9 @@ void orc_hqdn3d_plane(const uint8_t *src, uint8_t *dst, int w, int h, int sstrid
             for (int x = 0; x < w; x++)
             {
                 uint16_t *a = &frame_ant[(size_t)y * w + x];
-                const uint32_t t = lowpass(*a, load8(src + (size_t)y * sstride, x), temporal);
+                const uint32_t t = lowpass(*a, load_d(src + (size_t)y * sstride, x, depth), temporal);
                 *a = t;
-                dst[(size_t)y * dstride + x] = t >> 8;
+                store_d(dst + (size_t)y * dstride, x, t, depth);
             }
         return;
     }
@@ -75,13 +85,13 @@ void orc_hqdn3d_plane(const uint8_t *src, uint8_t *dst, int w, int h, int sstrid
         const uint8_t *s = src + (size_t)y * sstride;
         /* horizontal recurrence.  Row 0 starts from lowpass(LOAD(0), LOAD(0)) (:140-146),
          * every other row from LOAD(0) itself (:153-160). */
-        uint32_t run = load8(s, 0);
+        uint32_t run = load_d(s, 0, depth);
         if (y == 0)
-            run = lowpass(run, load8(s, 0), spatial);
+            run = lowpass(run, load_d(s, 0, depth), spatial);
         hrow[0] = run;
         for (int x = 1; x < w; x++)
         {
-            run = lowpass(run, load8(s, x), spatial);
+            run = lowpass(run, load_d(s, x, depth), spatial);
             hrow[x] = run;
         }
         for (int x = 0; x < w; x++)
@@ -93,9 +103,16 @@ void orc_hqdn3d_plane(const uint8_t *src, uint8_t *dst, int w, int h, int sstrid
             uint16_t *a = &frame_ant[(size_t)y * w + x];
             const uint32_t t = lowpass(*a, v, temporal);
             *a = t;
-            dst[(size_t)y * dstride + x] = t >> 8;
+            store_d(dst + (size_t)y * dstride, x, t, depth);
         }
     }
     free(line_ant);
     free(hrow);
+}
+
+void orc_hqdn3d_plane(const uint8_t *src, uint8_t *dst, int w, int h, int sstride, int dstride,
+                      uint16_t *frame_ant, int *state_valid,
+                      const int16_t spatial_t[8192], const int16_t temporal_t[8192])
+{
+    orc_hqdn3d_plane_d(src, dst, w, h, sstride, dstride, frame_ant, state_valid, spatial_t, temporal_t, 8);
 }

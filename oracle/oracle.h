@@ -114,6 +114,11 @@ void orc_hqdn3d_coef(int16_t ct[8192], double dist25);
 void orc_hqdn3d_plane(const uint8_t *src, uint8_t *dst, int w, int h, int sstride, int dstride,
                       uint16_t *frame_ant, int *state_valid,
                       const int16_t spatial[8192], const int16_t temporal[8192]);
+/* The same for any depth the reference dispatches (denoise.c:205-213; 10 / 12 here): rows are byte
+ * pointers to 16-bit containers, strides in bytes. */
+void orc_hqdn3d_plane_d(const uint8_t *src, uint8_t *dst, int w, int h, int sstride, int dstride,
+                        uint16_t *frame_ant, int *state_valid,
+                        const int16_t spatial_t[8192], const int16_t temporal_t[8192], int depth);
 
 /* ---- Decomb: yadif / blend / cubic (decomb.c, templates/decomb_template.c) ------- */
 

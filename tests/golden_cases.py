@@ -130,6 +130,14 @@ CASES = {
                                      chain=[("hb_filter_decomb", "mode=8")],
                                      hip=[("hb_filter_decomb_hip", "mode=8")],
                                      orc=[("decomb", dict(mode=8))]),
+    "hqdn3d_10bit_134x70": dict(model="progressive", w=134, h=70, n=4, depth=10,
+                                chain=[("hb_filter_denoise", "y-spatial=3:cb-spatial=2:cr-spatial=0:y-temporal=2:cb-temporal=3:cr-temporal=4")],
+                                hip=[("hb_filter_denoise_hip", "y-spatial=3:cb-spatial=2:cr-spatial=0:y-temporal=2:cb-temporal=3:cr-temporal=4")],
+                                orc=[("hqdn3d", dict(y_spatial=3, cb_spatial=2, cr_spatial=0, y_temporal=2, cb_temporal=3, cr_temporal=4, depth=10))]),
+    "hqdn3d_12bit_96x64": dict(model="random", w=96, h=64, n=3, depth=12,
+                               chain=[("hb_filter_denoise", "y-spatial=4")],
+                               hip=[("hb_filter_denoise_hip", "y-spatial=4")],
+                               orc=[("hqdn3d", dict(y_spatial=4, depth=12))]),
     "hqdn3d_medium_134x70": dict(model="progressive", w=134, h=70, n=4,
                                  chain=[("hb_filter_denoise", "y-spatial=3:cb-spatial=2:cr-spatial=2:y-temporal=2:cb-temporal=3:cr-temporal=3")],
                                  hip=[("hb_filter_denoise_hip", "y-spatial=3:cb-spatial=2:cr-spatial=2:y-temporal=2:cb-temporal=3:cr-temporal=3")],

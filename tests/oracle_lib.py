@@ -350,7 +350,8 @@ class OrcHqdn3d:
     """Stateful hqdn3d oracle.  Strengths follow hb_denoise_init's defaulting (denoise.c:228-256)."""
 
     def __init__(self, width, height, y_spatial=None, cb_spatial=None, cr_spatial=None,
-                 y_temporal=None, cb_temporal=None, cr_temporal=None):
+                 y_temporal=None, cb_temporal=None, cr_temporal=None, depth=8):
+        self.depth = depth
         ys = 4.0 if y_spatial is None else y_spatial
         cbs = 3.0 * ys / 4.0 if cb_spatial is None else cb_spatial
         crs = cbs if cr_spatial is None else cr_spatial
@@ -359,8 +360,10 @@ class OrcHqdn3d:
         crt = cbt if cr_temporal is None else cr_temporal
         lib = oracle()
         lib.orc_hqdn3d_coef.argtypes = [C.POINTER(C.c_int16), C.c_double]
-        lib.orc_hqdn3d_plane.argtypes = [C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_int,
-                                         C.POINTER(C.c_uint16), C.POINTER(C.c_int), C.POINTER(C.c_int16), C.POINTER(C.c_int16)]
+        lib.orc_hqdn3d_plane_d.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.POINTER(C.c_uint16), C.POINTER(C.c_int), C.POINTER(C.c_int16),
+                                           C.POINTER(C.c_int16), C.c_int]
+        lib.orc_hqdn3d_plane_d.restype = None
         self.lib = lib
         self.coef = []
         for v in (ys, yt, cbs, cbt, crs, crt):
@@ -374,13 +377,13 @@ class OrcHqdn3d:
         out = []
         for c, p in enumerate(planes):
             h, w = p.shape
-            src = padded(p)
+            src = padded16(p) if p.dtype == np.uint16 else padded(p)
             dst = np.zeros_like(src)
             if self.state[c] is None:
                 self.state[c] = np.zeros((h, w), np.uint16)
-            self.lib.orc_hqdn3d_plane(u8p(src), u8p(dst), w, h, src.strides[0], dst.strides[0],
-                                      self.state[c].ctypes.data_as(C.POINTER(C.c_uint16)), C.byref(self.valid[c]),
-                                      self.coef[2 * c], self.coef[2 * c + 1])
+            self.lib.orc_hqdn3d_plane_d(src.ctypes.data, dst.ctypes.data, w, h, src.strides[0], dst.strides[0],
+                                        self.state[c].ctypes.data_as(C.POINTER(C.c_uint16)), C.byref(self.valid[c]),
+                                        self.coef[2 * c], self.coef[2 * c + 1], self.depth)
             out.append(dst[:, :w].copy())
         return tuple(out)
 
