@@ -36,15 +36,17 @@ struct DecombArgs
     int field_parity;    // parity ^ tff, the `parity` argument of yadif_filter_line
 };
 
-__device__ __forceinline__ int crop8(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }
-__device__ __forceinline__ int cubic4(int y0, int y1, int y2, int y3)
+// the reference's crop table (init_crop_table, :23-41): clamp to [0, max_value]
+__device__ __forceinline__ int cropv(int v, int maxv) { return v < 0 ? 0 : v > maxv ? maxv : v; }
+__device__ __forceinline__ int cubic4(int y0, int y1, int y2, int y3, int maxv)
 {
-    return crop8((y0 * -3 + y1 * 23 + y2 * 23 + y3 * -3) / 40);      // :43-48, C division
+    return cropv((y0 * -3 + y1 * 23 + y2 * 23 + y3 * -3) / 40, maxv);      // :43-48, C division
 }
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
 
-__device__ __forceinline__ bool yadif_check(const uint8_t *c, int sp, int sn, int st, int j, bool cubic_ok,
+template <typename PIX>
+__device__ __forceinline__ bool yadif_check(const PIX *c, int sp, int sn, int st, int j, bool cubic_ok, int maxv,
                                             int &best, int &pred)
 {
     const int score = abs((int)c[sp - 1 + j] - (int)c[sn - 1 - j]) + abs((int)c[sp + j] - (int)c[sn - j]) +
@@ -54,10 +56,10 @@ __device__ __forceinline__ bool yadif_check(const uint8_t *c, int sp, int sn, in
     if (cubic_ok)
     {
         // :541-570
-        if (j == -1)      pred = cubic4(c[-3 * st - 3], c[-st - 1], c[st + 1], c[3 * st + 3]);
-        else if (j == -2) pred = cubic4((c[-3 * st - 4] + c[-st - 4]) / 2, c[-st - 2], c[st + 2], (c[3 * st + 4] + c[st + 4]) / 2);
-        else if (j == 1)  pred = cubic4(c[-3 * st + 3], c[-st + 1], c[st - 1], c[3 * st - 3]);
-        else              pred = cubic4((c[-3 * st + 4] + c[-st + 4]) / 2, c[-st + 2], c[st - 2], (c[3 * st - 4] + c[st - 4]) / 2);
+        if (j == -1)      pred = cubic4(c[-3 * st - 3], c[-st - 1], c[st + 1], c[3 * st + 3], maxv);
+        else if (j == -2) pred = cubic4((c[-3 * st - 4] + c[-st - 4]) / 2, c[-st - 2], c[st + 2], (c[3 * st + 4] + c[st + 4]) / 2, maxv);
+        else if (j == 1)  pred = cubic4(c[-3 * st + 3], c[-st + 1], c[st - 1], c[3 * st - 3], maxv);
+        else              pred = cubic4((c[-3 * st + 4] + c[-st + 4]) / 2, c[-st + 2], c[st - 2], (c[3 * st - 4] + c[st - 4]) / 2, maxv);
     }
     else
     {
@@ -66,15 +68,19 @@ __device__ __forceinline__ bool yadif_check(const uint8_t *c, int sp, int sn, in
     return true;
 }
 
-__global__ __launch_bounds__(256) void decomb_plane_kernel(DecombArgs a)
+// PIX = uint8_t, or uint16_t for the _16 instantiation (decomb.c:324-331); pitches arrive in bytes,
+// maxv = (1 << depth) - 1
+template <typename PIX>
+__global__ __launch_bounds__(256) void decomb_plane_kernel(DecombArgs a, int maxv)
 {
     const DecombPlane &P = a.pl[blockIdx.z];
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= P.w || y >= P.h) return;
-    const int st = P.pitch;
-    const uint8_t *c = P.cur + (size_t)y * st + x;
-    uint8_t *o = P.dst + (size_t)y * P.dst_pitch + x;
+    const int st = P.pitch / (int)sizeof(PIX);
+    const PIX *c = reinterpret_cast<const PIX *>(P.cur) + (size_t)y * st + x;
+    PIX *o = reinterpret_cast<PIX *>(P.dst + (size_t)y * P.dst_pitch) + x;
+    const PIX *guess = reinterpret_cast<const PIX *>(P.guess + (size_t)y * P.guess_pitch) + x;
     const int mode = a.mode;
 
     if (mode == 0)                                         // pass-through (:892-897)
@@ -84,7 +90,7 @@ __global__ __launch_bounds__(256) void decomb_plane_kernel(DecombArgs a)
     }
     if ((mode & M_EEDI2) && !(mode & M_YADIF))             // EEDI2 only (:855-875)
     {
-        *o = P.guess[(size_t)y * P.guess_pitch + x];
+        *o = *guess;
         return;
     }
     if ((y & 1) != (a.parity ? 0 : 1))                     // kept field (:795-807)
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(256) void decomb_plane_kernel(DecombArgs a)
         else if (y == h - 2)    { u1 = -st; u2 = -2 * st; d1 = d2 = st; }
         else                    { u1 = -st; u2 = -2 * st; d1 = d2 = 0; }
         const int v = (-(int)c[u2] + 2 * (int)c[u1] + 6 * (int)c[0] + 2 * (int)c[d1] - (int)c[d2]) >> 3;
-        *o = (uint8_t)crop8(v);
+        *o = (PIX)cropv(v, maxv);
         return;
     }
     if (mode == M_CUBIC)                                   // :50-107
@@ -114,17 +120,17 @@ __global__ __launch_bounds__(256) void decomb_plane_kernel(DecombArgs a)
         if (y <= h - 4)                      { p2 = c[st]; p3 = c[3 * st]; }
         else if (y == h - 3 || y == h - 2)   { p2 = p3 = c[st]; }
         else if (y == h - 1)                 { p2 = p3 = c[-st]; }
-        *o = (uint8_t)cubic4(p0, p1, p2, p3);
+        *o = (PIX)cubic4(p0, p1, p2, p3, maxv);
         return;
     }
     if (!(mode & M_YADIF))
         return;                                            // untouched, as the reference leaves it
 
     // ---- yadif_filter_line (:579-712)
-    const uint8_t *pp = P.prev + (size_t)y * st + x;
-    const uint8_t *pn = P.next + (size_t)y * st + x;
-    const uint8_t *p2 = a.field_parity ? pp : c;
-    const uint8_t *n2 = a.field_parity ? c : pn;
+    const PIX *pp = reinterpret_cast<const PIX *>(P.prev) + (size_t)y * st + x;
+    const PIX *pn = reinterpret_cast<const PIX *>(P.next) + (size_t)y * st + x;
+    const PIX *p2 = a.field_parity ? pp : c;
+    const PIX *n2 = a.field_parity ? c : pn;
     const int sp = y ? -st : st;
     const int sn = y + 1 < h ? st : -st;
     const bool vertical_edge = (y < 3) || (y > h - 4);
@@ -141,18 +147,18 @@ __global__ __launch_bounds__(256) void decomb_plane_kernel(DecombArgs a)
     int pred;
     if (mode & M_EEDI2)
     {
-        pred = P.guess[(size_t)y * P.guess_pitch + x];
+        pred = *guess;
     }
     else
     {
-        pred = use_cubic ? cubic4(c[-3 * st], c[-st], c[st], c[3 * st]) : (cc + e) >> 1;
+        pred = use_cubic ? cubic4(c[-3 * st], c[-st], c[st], c[3 * st], maxv) : (cc + e) >> 1;
         if (x > margin && x < P.w - (margin + 1))
         {
             int best = abs((int)c[sp - 1] - (int)c[sn - 1]) + abs(cc - e) + abs((int)c[sp + 1] - (int)c[sn + 1]) - 1;
-            if (yadif_check(c, sp, sn, st, -1, use_cubic, best, pred))
-                yadif_check(c, sp, sn, st, -2, use_cubic, best, pred);
-            if (yadif_check(c, sp, sn, st, 1, use_cubic, best, pred))
-                yadif_check(c, sp, sn, st, 2, use_cubic, best, pred);
+            if (yadif_check(c, sp, sn, st, -1, use_cubic, maxv, best, pred))
+                yadif_check(c, sp, sn, st, -2, use_cubic, maxv, best, pred);
+            if (yadif_check(c, sp, sn, st, 1, use_cubic, maxv, best, pred))
+                yadif_check(c, sp, sn, st, 2, use_cubic, maxv, best, pred);
         }
     }
     if (!vertical_edge)
@@ -165,7 +171,7 @@ __global__ __launch_bounds__(256) void decomb_plane_kernel(DecombArgs a)
     }
     if (pred > d + diff)      pred = d + diff;
     else if (pred < d - diff) pred = d - diff;
-    *o = (uint8_t)pred;
+    *o = (PIX)pred;
 }
 
 // ------------------------------------------------------------------- host side
@@ -187,6 +193,7 @@ public:
             return HBHIP_ERR_UNSUPPORTED;
         if (par.mode & M_EEDI2)
         {
+            if (in_geo.bps != 1) return HBHIP_ERR_UNSUPPORTED;     // the EEDI2 passes are built for 8-bit samples only
             if (par.post_processing != 0 && par.post_processing != 1) return HBHIP_ERR_UNSUPPORTED;
             Eedi2Params ep = { par.magnitude_threshold, par.variance_threshold, par.laplacian_threshold,
                                par.dilation_threshold, par.erosion_threshold, par.noise_threshold,
@@ -277,7 +284,9 @@ private:
         }
         a.mode = mode; a.parity = parity; a.field_parity = parity ^ tff;
         dim3 block(64, 4), grid((in_geo.pw[0] + 63) / 64, (in_geo.ph[0] + 3) / 4, 3);
-        HBHIP_LAUNCH(ctx, "decomb_plane", decomb_plane_kernel, grid, block, 0, a);
+        const int maxv = (1 << in_geo.depth) - 1;
+        if (in_geo.bps == 2) HBHIP_LAUNCH(ctx, "decomb_plane", decomb_plane_kernel<uint16_t>, grid, block, 0, a, maxv);
+        else                 HBHIP_LAUNCH(ctx, "decomb_plane", decomb_plane_kernel<uint8_t>, grid, block, 0, a, maxv);
         HBHIP_CHECK(ctx, hipGetLastError());
         return HBHIP_OK;
     }
@@ -341,7 +350,7 @@ extern "C" int hbhip_decomb_create(hbhip_ctx *ctx, const hbhip_decomb_params *p,
 {
     if (!ctx || !p || !out) return HBHIP_ERR_ARG;
     *out = nullptr;
-    if (depth != 8) return HBHIP_ERR_UNSUPPORTED;
+    if (depth != 8 && depth != 10 && depth != 12) return HBHIP_ERR_UNSUPPORTED;
     if (width < 8 || height < 8) return HBHIP_ERR_UNSUPPORTED;
     (void)hipSetDevice(ctx->device);
     DecombFilter *f = new (std::nothrow) DecombFilter(ctx, *p);

@@ -139,6 +139,11 @@ void orc_decomb_plane(const uint8_t *prev, const uint8_t *cur, const uint8_t *ne
                       const uint8_t *guess, int guess_stride,
                       uint8_t *dst, int dst_stride, int width, int height,
                       int mode, int parity, int tff);
+/* the _16 instantiation (decomb.c:324-331): 16-bit samples, strides in samples, depth 10 / 12 */
+void orc_decomb_plane16(const uint16_t *prev, const uint16_t *cur, const uint16_t *next, int stride,
+                        const uint16_t *guess, int guess_stride,
+                        uint16_t *dst, int dst_stride, int width, int height,
+                        int mode, int parity, int tff, int depth);
 
 /* ---- Comb detect (comb_detect.c, templates/comb_detect_template.c) -------------- */
 

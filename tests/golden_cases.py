@@ -130,6 +130,18 @@ CASES = {
                                      chain=[("hb_filter_decomb", "mode=8")],
                                      hip=[("hb_filter_decomb_hip", "mode=8")],
                                      orc=[("decomb", dict(mode=8))]),
+    "decomb_default_10bit_134x70": dict(model="interlaced", w=134, h=70, n=4, depth=10,
+                                        chain=[("hb_filter_decomb", "mode=7")],
+                                        hip=[("hb_filter_decomb_hip", "mode=7")],
+                                        orc=[("decomb", dict(mode=7, depth=10))]),
+    "decomb_bob_12bit_128x64": dict(model="interlaced", w=128, h=64, n=4, depth=12,
+                                    chain=[("hb_filter_decomb", "mode=23")],
+                                    hip=[("hb_filter_decomb_hip", "mode=23")],
+                                    orc=[("decomb", dict(mode=23, depth=12))]),
+    "decomb_cubic_10bit_96x64": dict(model="interlaced", w=96, h=64, n=3, depth=10,
+                                     chain=[("hb_filter_decomb", "mode=4")],
+                                     hip=[("hb_filter_decomb_hip", "mode=4")],
+                                     orc=[("decomb", dict(mode=4, depth=10))]),
     "hqdn3d_10bit_134x70": dict(model="progressive", w=134, h=70, n=4, depth=10,
                                 chain=[("hb_filter_denoise", "y-spatial=3:cb-spatial=2:cr-spatial=0:y-temporal=2:cb-temporal=3:cr-temporal=4")],
                                 hip=[("hb_filter_denoise_hip", "y-spatial=3:cb-spatial=2:cr-spatial=0:y-temporal=2:cb-temporal=3:cr-temporal=4")],

@@ -209,8 +209,18 @@ def orc_chroma_smooth_plane(plane, strength=0.25, size=7, depth=8):
 
 
 # ---------------------------------------------------------------- decomb
-def orc_decomb_plane(prev, cur, nxt, mode, parity, tff, guess=None):
+def orc_decomb_plane(prev, cur, nxt, mode, parity, tff, guess=None, depth=8):
     h, w = cur.shape
+    if cur.dtype == np.uint16:                      # the _16 instantiation; no EEDI2 guess at this depth
+        P, Cu, N = padded16(prev), padded16(cur), padded16(nxt)
+        dst = np.zeros_like(Cu)
+        u16p = C.POINTER(C.c_uint16)
+        fn = oracle().orc_decomb_plane16
+        fn.restype = None
+        fn.argtypes = [u16p] * 3 + [C.c_int, u16p, C.c_int, u16p] + [C.c_int] * 7
+        fn(P.ctypes.data_as(u16p), Cu.ctypes.data_as(u16p), N.ctypes.data_as(u16p), Cu.shape[1], None, 0,
+           dst.ctypes.data_as(u16p), dst.shape[1], w, h, mode, parity, tff, depth)
+        return dst[:, :w].copy()
     P, Cu, N = padded(prev), padded(cur), padded(nxt)
     G = padded(guess) if guess is not None else None
     dst = np.zeros_like(Cu)

@@ -147,7 +147,7 @@ def decomb_stream(frames, par, flags=PIC_FLAG_TOP_FIELD_FIRST, combed=None, dura
             if fmode & DECOMB_EEDI2:
                 guess = eedi2(frames[i_cur], 1 - parity)          # pv->tff = !parity (decomb.c:542)
             planes = tuple(ol.orc_decomb_plane(frames[i_prev][c], frames[i_cur][c], frames[i_next][c],
-                                               fmode, parity, tff, guess[c]) for c in range(3))
+                                               fmode, parity, tff, guess[c], par.get("depth", 8)) for c in range(3))
             made.append(dict(planes=planes, **m))
         if mode & DECOMB_BOB:
             first, second = made[0], made[-1]
