@@ -23,27 +23,35 @@ struct CombConst
     int   block_threshold, block_width, block_height;
     float g_mthresh, g_athresh, g_athresh6;
     int   athresh_sq, athresh6;
+    int   c32_min, c32_max;          // 10 / 15 scaled to the sample depth (comb_detect.c:1161-1162)
+    int   lut_len;                   // 1 << depth
 };
 
-__global__ __launch_bounds__(256) void comb_detect_kernel(const uint8_t *__restrict__ prev,
-                                                          const uint8_t *__restrict__ cur,
-                                                          const uint8_t *__restrict__ next, int pitch,
+// PIX = uint8_t or uint16_t (detect_*_combed_segment_16): `pitch` is in samples; the gamma
+// table (1 << depth floats, built by the host) is staged in dynamic LDS.
+template <typename PIX>
+__global__ __launch_bounds__(256) void comb_detect_kernel(const PIX *__restrict__ prev,
+                                                          const PIX *__restrict__ cur,
+                                                          const PIX *__restrict__ next, int pitch,
                                                           uint8_t *__restrict__ mask, int mask_stride,
                                                           int width, int height, CombConst k,
                                                           const float *__restrict__ lut_g, int force)
 {
-    __shared__ float L[256];
-    L[threadIdx.y * blockDim.x + threadIdx.x] = lut_g[threadIdx.y * blockDim.x + threadIdx.x];
-    __syncthreads();
+    extern __shared__ float L[];
+    if (k.mode & 1)
+    {
+        for (int i = threadIdx.y * blockDim.x + threadIdx.x; i < k.lut_len; i += 256) L[i] = lut_g[i];
+        __syncthreads();
+    }
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = 2 + blockIdx.y * blockDim.y + threadIdx.y;        // rows 2 .. height-3 (:312-319)
     if (y >= height - 2 || x >= mask_stride) return;
     uint8_t out = 0;                                                  // memset(mask, 0, mask_stride) (:342)
     if (x < width)
     {
-        const uint8_t *c = cur + (size_t)y * pitch + x;
-        const uint8_t *p = prev + (size_t)y * pitch + x;
-        const uint8_t *n = next + (size_t)y * pitch + x;
+        const PIX *c = cur + (size_t)y * pitch + x;
+        const PIX *p = prev + (size_t)y * pitch + x;
+        const PIX *n = next + (size_t)y * pitch + x;
         const int v = c[0], u1 = c[-pitch], d1 = c[pitch], u2 = c[-2 * pitch], d2 = c[2 * pitch];
         if (k.mode & 1)
         {
@@ -86,7 +94,7 @@ __global__ __launch_bounds__(256) void comb_detect_kernel(const uint8_t *__restr
                     motion = 1;
                 if (motion || force)
                 {
-                    if (k.spatial_metric == 0)      { if (abs(v - d2) < 10 && abs(v - d1) > 15) out = 1; }
+                    if (k.spatial_metric == 0)      { if (abs(v - d2) < k.c32_min && abs(v - d1) > k.c32_max) out = 1; }
                     else if (k.spatial_metric == 1) { if ((u1 - v) * (d1 - v) > k.athresh_sq) out = 1; }
                     else if (k.spatial_metric == 2) { if (abs(u2 + 4 * v + d2 - 3 * (u1 + d1)) > k.athresh6) out = 1; }
                 }
@@ -166,17 +174,22 @@ public:
         if (h_result) (void)hipHostFree(h_result);
     }
 
-    int setup(int w, int h)
+    int setup(int w, int h, int depth)
     {
         width = w; height = h;
-        in_geo.set(w, h, 8, 1, 1);
+        in_geo.set(w, h, depth, 1, 1);
+        bps = in_geo.bps;
+        const int up = depth - 8;                                   // thresholds scale with the depth (:1151-1153)
+        const int max_value = (1 << depth) - 1;
+        par.motion_threshold <<= up;
+        par.spatial_threshold <<= up;
         out_geo = in_geo;
         if (par.block_width > w) par.block_width = w;               // comb_detect.c:1139-1146
         if (par.block_height > h) par.block_height = h;
         if (par.block_width < 1 || par.block_height < 1) return HBHIP_ERR_ARG;
         if (par.mode & ~3) return HBHIP_ERR_UNSUPPORTED;            // mask / composite overlays
         if (h < 5 || w < 4) return HBHIP_ERR_UNSUPPORTED;
-        pitch = hbhip_align_up(w, 256);
+        pitch = hbhip_align_up(w * bps, 256);                      // bytes
         mstride = hbhip_align_up(w, 64);                            // hb_image_stride(GRAY8, w)
         for (int i = 0; i < 3; i++)
         {
@@ -187,8 +200,12 @@ public:
         HBHIP_CHECK(ctx, hipMalloc((void **)&masks, 3 * msz));
         HBHIP_CHECK(ctx, hipMemsetAsync(masks, 0, 3 * msz, ctx->stream));
         mask = masks; mask_filtered = masks + msz; mask_temp = masks + 2 * msz;
-        HBHIP_CHECK(ctx, hipMalloc((void **)&d_lut, sizeof(float) * 256));
-        HBHIP_CHECK(ctx, hipMemcpyAsync(d_lut, par.gamma_lut, sizeof(float) * 256, hipMemcpyHostToDevice, ctx->stream));
+        HBHIP_CHECK(ctx, hipMalloc((void **)&d_lut, sizeof(float) * (max_value + 1)));
+        if (depth == 8)
+        {
+            HBHIP_CHECK(ctx, hipMemcpyAsync(d_lut, par.gamma_lut, sizeof(float) * 256, hipMemcpyHostToDevice, ctx->stream));
+            lut_ready = true;
+        }
         HBHIP_CHECK(ctx, hipMalloc((void **)&d_result, sizeof(int)));
         HBHIP_CHECK(ctx, hipHostMalloc((void **)&h_result, sizeof(int), hipHostMallocDefault));
         HBHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -196,11 +213,23 @@ public:
         k.motion_threshold = par.motion_threshold; k.spatial_threshold = par.spatial_threshold;
         k.filter_mode = par.filter_mode; k.block_threshold = par.block_threshold;
         k.block_width = par.block_width; k.block_height = par.block_height;
-        k.g_mthresh = (float)par.motion_threshold / (float)255;     // comb_detect.c:1153-1158
-        k.g_athresh = (float)par.spatial_threshold / (float)255;
+        k.g_mthresh = (float)par.motion_threshold / (float)max_value;     // comb_detect.c:1153-1158
+        k.g_athresh = (float)par.spatial_threshold / (float)max_value;
         k.g_athresh6 = 6 * k.g_athresh;
         k.athresh_sq = par.spatial_threshold * par.spatial_threshold;
         k.athresh6 = 6 * par.spatial_threshold;
+        k.c32_min = 10 << up; k.c32_max = 15 << up;
+        k.lut_len = max_value + 1;
+        return HBHIP_OK;
+    }
+
+    // depth > 8: the (1 << depth)-entry gamma table arrives separately (the params struct holds 256)
+    int set_gamma_lut(const float *lut, int entries)
+    {
+        if (!lut || entries != k.lut_len) return HBHIP_ERR_ARG;
+        HBHIP_CHECK(ctx, hipMemcpyAsync(d_lut, lut, sizeof(float) * entries, hipMemcpyHostToDevice, ctx->stream));
+        HBHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        lut_ready = true;
         return HBHIP_OK;
     }
 
@@ -219,8 +248,8 @@ public:
         for (int i = 0; i < 3 && use < 0; i++)
             if (i != ref[0] && i != ref[1]) use = i;
         (void)freed;
-        if (stride < width) return HBHIP_ERR_ARG;
-        HBHIP_CHECK(ctx, hipMemcpy2DAsync(luma_alloc[use], pitch, luma, stride, width, height,
+        if (stride < width * bps) return HBHIP_ERR_ARG;
+        HBHIP_CHECK(ctx, hipMemcpy2DAsync(luma_alloc[use], pitch, luma, stride, (size_t)width * bps, height,
                                           device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
         if (!device) HBHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         ref[2] = use;
@@ -230,11 +259,18 @@ public:
     int classify(int force, int *combed)
     {
         if (ref[0] < 0 || ref[1] < 0 || ref[2] < 0) return HBHIP_ERR_STATE;
+        if ((par.mode & 1) && !lut_ready) return HBHIP_ERR_STATE;
         dim3 b(64, 4);
         dim3 g((mstride + 63) / 64, (height - 4 + 3) / 4);
-        HBHIP_LAUNCH(ctx, "comb_detect", comb_detect_kernel, g, b, 0, (const uint8_t *)luma_alloc[ref[0]],
-                     (const uint8_t *)luma_alloc[ref[1]], (const uint8_t *)luma_alloc[ref[2]], pitch, mask, mstride,
-                     width, height, k, (const float *)d_lut, force);
+        const size_t lds = (par.mode & 1) ? sizeof(float) * k.lut_len : 0;
+        if (bps == 2)
+            HBHIP_LAUNCH(ctx, "comb_detect", comb_detect_kernel<uint16_t>, g, b, lds, (const uint16_t *)luma_alloc[ref[0]],
+                         (const uint16_t *)luma_alloc[ref[1]], (const uint16_t *)luma_alloc[ref[2]], pitch / 2, mask, mstride,
+                         width, height, k, (const float *)d_lut, force);
+        else
+            HBHIP_LAUNCH(ctx, "comb_detect", comb_detect_kernel<uint8_t>, g, b, lds, (const uint8_t *)luma_alloc[ref[0]],
+                         (const uint8_t *)luma_alloc[ref[1]], (const uint8_t *)luma_alloc[ref[2]], pitch, mask, mstride,
+                         width, height, k, (const float *)d_lut, force);
         const bool filt = (par.mode & 2) != 0;
         dim3 gm((width - 2 + 63) / 64, (height - 2 + 3) / 4);
         if (filt)
@@ -278,7 +314,8 @@ public:
 private:
     hbhip_comb_detect_params par;
     CombConst k;
-    int width = 0, height = 0, pitch = 0, mstride = 0;
+    int width = 0, height = 0, pitch = 0, mstride = 0, bps = 1;
+    bool lut_ready = false;
     uint8_t *luma_alloc[3] = {nullptr, nullptr, nullptr};
     int slot[3];
     int ref[3] = {-1, -1, -1};
@@ -294,11 +331,11 @@ extern "C" int hbhip_comb_detect_create(hbhip_ctx *ctx, const hbhip_comb_detect_
 {
     if (!ctx || !p || !out) return HBHIP_ERR_ARG;
     *out = nullptr;
-    if (depth != 8) return HBHIP_ERR_UNSUPPORTED;
+    if (depth != 8 && depth != 10 && depth != 12) return HBHIP_ERR_UNSUPPORTED;
     (void)hipSetDevice(ctx->device);
     CombDetectFilter *f = new (std::nothrow) CombDetectFilter(ctx, *p);
     if (!f) return HBHIP_ERR_NOMEM;
-    int rc = f->setup(width, height);
+    int rc = f->setup(width, height, depth);
     if (rc != HBHIP_OK)
     {
         delete f;
@@ -322,6 +359,14 @@ extern "C" int hbhip_comb_detect_store_dev(hbhip_filter *f, const void *luma, in
     if (!c) return HBHIP_ERR_ARG;
     (void)hipSetDevice(f->ctx->device);
     return c->store(luma, stride, true);
+}
+
+extern "C" int hbhip_comb_detect_set_gamma_lut(hbhip_filter *f, const float *lut, int entries)
+{
+    CombDetectFilter *c = dynamic_cast<CombDetectFilter *>(f);
+    if (!c) return HBHIP_ERR_ARG;
+    (void)hipSetDevice(f->ctx->device);
+    return c->set_gamma_lut(lut, entries);
 }
 
 extern "C" int hbhip_comb_detect_classify(hbhip_filter *f, int force_exhaustive, int *combed)

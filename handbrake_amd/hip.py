@@ -26,7 +26,8 @@ ABI_SYMBOLS = [
     "hbhip_filter_out_geometry", "hbhip_nlmeans_create", "hbhip_nlmeans_set_batch",
     "hbhip_lapsharp_create", "hbhip_unsharp_create", "hbhip_chroma_smooth_create",
     "hbhip_hqdn3d_create", "hbhip_decomb_create", "hbhip_decomb_push", "hbhip_decomb_push_dev", "hbhip_decomb_debug_eedi_plane",
-    "hbhip_comb_detect_create", "hbhip_comb_detect_store", "hbhip_comb_detect_store_dev",
+    "hbhip_comb_detect_create", "hbhip_comb_detect_set_gamma_lut", "hbhip_comb_detect_store",
+    "hbhip_comb_detect_store_dev",
     "hbhip_comb_detect_classify",
     "hbhip_rotate_create", "hbhip_grayscale_create", "hbhip_cropscale_create",
 ]

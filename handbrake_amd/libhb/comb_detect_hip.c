@@ -80,14 +80,27 @@ static int comb_detect_hip_init(hb_filter_object_t *filter, hb_filter_init_t *in
         hb_dict_extract_int(&p->block_width, d, "block-width");
         hb_dict_extract_int(&p->block_height, d, "block-height");
     }
+    float *wide_lut = NULL;                /* comb_detect.c:1074-1081, host libm; 1 << depth entries */
     if (depth == 8)
-        for (int i = 0; i < 256; i++)      /* comb_detect.c:1074-1081, host libm */
+    {
+        for (int i = 0; i < 256; i++)
             p->gamma_lut[i] = pow(((float)i / (float)max_value), 2.2f);
+    }
+    else
+    {
+        wide_lut = malloc(sizeof(float) * (max_value + 1));
+        if (wide_lut == NULL) goto fail;
+        for (int i = 0; i <= max_value; i++)
+            wide_lut[i] = pow(((float)i / (float)max_value), 2.2f);
+    }
 
     pv->force_exhaustive = 1;              /* :1111 */
     hbhip_ctx *ctx = hbhip_host_ctx();
-    if (ctx == NULL) goto fail;
+    if (ctx == NULL) { free(wide_lut); goto fail; }
     int rc = hbhip_comb_detect_create(ctx, p, init->geometry.width, init->geometry.height, depth, &pv->dev);
+    if (rc == HBHIP_OK && wide_lut != NULL)
+        rc = hbhip_comb_detect_set_gamma_lut(pv->dev, wide_lut, max_value + 1);
+    free(wide_lut);
     if (rc != HBHIP_OK)
     {
         hb_error("comb_detect(hip): %s", hbhip_strerror(rc));

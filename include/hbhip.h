@@ -218,6 +218,9 @@ int hbhip_comb_detect_create(hbhip_ctx *ctx, const hbhip_comb_detect_params *p, 
                              int depth, hbhip_filter **out);
 /* store_ref (comb_detect.c:1007-1018): the luma plane becomes the newest of the
  * prev/cur/next ring.  luma == NULL repeats the newest plane (first frame / EOF). */
+/* depth > 8: the gamma table has 1 << depth entries (comb_detect.c:1102, 1074-1081), more than
+ * the params struct holds; hand it over before the first classify.  (depth 8 uses p->gamma_lut.) */
+int hbhip_comb_detect_set_gamma_lut(hbhip_filter *f, const float *lut, int entries);
 int hbhip_comb_detect_store(hbhip_filter *f, const uint8_t *luma, int stride);
 int hbhip_comb_detect_store_dev(hbhip_filter *f, const void *luma, int stride);
 /* comb_segmenter on the ring: *combed = HB_COMB_NONE/LIGHT/HEAVY for the middle plane. */

@@ -27,15 +27,26 @@ struct orc_comb
     orc_comb_params_t p;
     int width, height, stride;
     uint8_t *mask, *mask_filtered, *mask_temp;
-    float lut[256];
+    int depth;
+    float *lut;                      /* 1 << depth entries (:1102) */
     float g_mthresh, g_athresh, g_athresh6;
     int athresh_sq, athresh6, c32_min, c32_max;
 };
 
 orc_comb_t *orc_comb_new(int width, int height, const orc_comb_params_t *p)
 {
+    return orc_comb_new_depth(width, height, p, 8);
+}
+
+/* depth 10 / 12: 16-bit luma samples, thresholds scaled as comb_detect.c:1151-1162 */
+orc_comb_t *orc_comb_new_depth(int width, int height, const orc_comb_params_t *p, int depth)
+{
     orc_comb_t *c = calloc(1, sizeof(*c));
     c->p = *p;
+    c->depth = depth;
+    const int max_value = (1 << depth) - 1;
+    c->p.motion_threshold  <<= (depth - 8);
+    c->p.spatial_threshold <<= (depth - 8);
     if (c->p.block_width > width)   c->p.block_width = width;       /* :1139-1146 */
     if (c->p.block_height > height) c->p.block_height = height;
     c->width = width;
@@ -45,22 +56,23 @@ orc_comb_t *orc_comb_new(int width, int height, const orc_comb_params_t *p)
     c->mask          = calloc((size_t)c->stride * height + 64, 1);
     c->mask_filtered = calloc((size_t)c->stride * height + 64, 1);
     c->mask_temp     = calloc((size_t)c->stride * height + 64, 1);
-    for (int i = 0; i < 256; i++)
-        c->lut[i] = pow(((float)i / (float)255), 2.2f);            /* :1074-1081 */
-    c->g_mthresh  = (float)c->p.motion_threshold / (float)255;     /* :1153-1155 */
-    c->g_athresh  = (float)c->p.spatial_threshold / (float)255;
+    c->lut = malloc(sizeof(float) * (max_value + 1));
+    for (int i = 0; i <= max_value; i++)
+        c->lut[i] = pow(((float)i / (float)max_value), 2.2f);      /* :1074-1081 */
+    c->g_mthresh  = (float)c->p.motion_threshold / (float)max_value;     /* :1153-1155 */
+    c->g_athresh  = (float)c->p.spatial_threshold / (float)max_value;
     c->g_athresh6 = 6 * c->g_athresh;
     c->athresh_sq = c->p.spatial_threshold * c->p.spatial_threshold;
     c->athresh6   = 6 * c->p.spatial_threshold;
-    c->c32_min = 10;
-    c->c32_max = 15;
+    c->c32_min = 10 << (depth - 8);                                /* :1161-1162 */
+    c->c32_max = 15 << (depth - 8);
     return c;
 }
 
 void orc_comb_free(orc_comb_t *c)
 {
     if (!c) return;
-    free(c->mask); free(c->mask_filtered); free(c->mask_temp);
+    free(c->mask); free(c->mask_filtered); free(c->mask_temp); free(c->lut);
     free(c);
 }
 
@@ -71,19 +83,21 @@ const uint8_t *orc_comb_mask(orc_comb_t *c, int which, int *stride)
 }
 
 /* template :288-402 (gamma) and :789-933 (integer) */
-static void detect(orc_comb_t *c, const uint8_t *prev, const uint8_t *cur, const uint8_t *next,
+/* luma planes: uint8_t, or uint16_t when depth > 8; `stride` in samples */
+#define SMP(p, i) (c->depth > 8 ? (int)((const uint16_t *)(p))[i] : (int)((const uint8_t *)(p))[i])
+static void detect(orc_comb_t *c, const void *prev, const void *cur, const void *next,
                    int stride, int force)
 {
     const int gamma = c->p.mode & 1;
     for (int y = 2; y < c->height - 2; y++)
     {
-        const uint8_t *pr = prev + (size_t)y * stride, *cu = cur + (size_t)y * stride, *nx = next + (size_t)y * stride;
+        const ptrdiff_t row = (ptrdiff_t)y * stride;
         uint8_t *m = c->mask + (size_t)y * c->stride;
         memset(m, 0, c->stride);
         for (int x = 0; x < c->width; x++)
         {
-            const int v = cu[x], u1 = cu[x - stride], d1 = cu[x + stride];
-            const int u2 = cu[x - 2 * stride], d2 = cu[x + 2 * stride];
+            const int v = SMP(cur, row + x), u1 = SMP(cur, row + x - stride), d1 = SMP(cur, row + x + stride);
+            const int u2 = SMP(cur, row + x - 2 * stride), d2 = SMP(cur, row + x + 2 * stride);
             if (gamma)
             {
                 const float *L = c->lut;
@@ -93,13 +107,13 @@ static void detect(orc_comb_t *c, const uint8_t *prev, const uint8_t *cur, const
                 int motion = 0;
                 if (c->g_mthresh > 0)
                 {
-                    if (fabs(L[pr[x]] - L[v]) > c->g_mthresh &&
-                        fabs(L[u1] - L[nx[x - stride]]) > c->g_mthresh &&
-                        fabs(L[d1] - L[nx[x + stride]]) > c->g_mthresh)
+                    if (fabs(L[SMP(prev, row + x)] - L[v]) > c->g_mthresh &&
+                        fabs(L[u1] - L[SMP(next, row + x - stride)]) > c->g_mthresh &&
+                        fabs(L[d1] - L[SMP(next, row + x + stride)]) > c->g_mthresh)
                         motion++;
-                    if (fabs(L[nx[x]] - L[v]) > c->g_mthresh &&
-                        fabs(L[pr[x - stride]] - L[u1]) > c->g_mthresh &&
-                        fabs(L[pr[x + stride]] - L[d1]) > c->g_mthresh)
+                    if (fabs(L[SMP(next, row + x)] - L[v]) > c->g_mthresh &&
+                        fabs(L[SMP(prev, row + x - stride)] - L[u1]) > c->g_mthresh &&
+                        fabs(L[SMP(prev, row + x + stride)] - L[d1]) > c->g_mthresh)
                         motion++;
                 }
                 else
@@ -120,9 +134,9 @@ static void detect(orc_comb_t *c, const uint8_t *prev, const uint8_t *cur, const
                 int motion = 0;
                 if (mt > 0)
                 {
-                    if (abs(pr[x] - v) > mt && abs(u1 - nx[x - stride]) > mt && abs(d1 - nx[x + stride]) > mt)
+                    if (abs(SMP(prev, row + x) - v) > mt && abs(u1 - SMP(next, row + x - stride)) > mt && abs(d1 - SMP(next, row + x + stride)) > mt)
                         motion++;
-                    if (abs(nx[x] - v) > mt && abs(pr[x - stride] - u1) > mt && abs(pr[x + stride] - d1) > mt)
+                    if (abs(SMP(next, row + x) - v) > mt && abs(SMP(prev, row + x - stride) - u1) > mt && abs(SMP(prev, row + x + stride) - d1) > mt)
                         motion++;
                 }
                 else
@@ -145,6 +159,7 @@ static void detect(orc_comb_t *c, const uint8_t *prev, const uint8_t *cur, const
         }
     }
 }
+#undef SMP
 
 /* The shared frame of the three 3x3 passes: rows 1..height-2, source/destination
  * pointers offset by one column (see the file comment). op: 0 filter, 1 erode, 2 dilate */
@@ -202,6 +217,7 @@ static int score_blocks(const orc_comb_t *c, int filtered)
 int orc_comb_classify(orc_comb_t *c, const uint8_t *prev, const uint8_t *cur, const uint8_t *next,
                       int stride, int force_exhaustive)
 {
+    /* depth > 8: the pointers address uint16_t samples, `stride` counts samples */
     detect(c, prev, cur, next, stride, force_exhaustive);
     const int filt = (c->p.mode & 2) != 0;
     if (filt)

@@ -164,6 +164,8 @@ typedef struct orc_comb orc_comb_t;
 /* comb_detect_init's state that survives frames: three zero-initialised masks at
  * hb_image_stride(GRAY8,width), gamma LUT, derived thresholds (comb_detect.c:1083-1190). */
 orc_comb_t *orc_comb_new(int width, int height, const orc_comb_params_t *p);
+/* 16-bit luma (depth 10 / 12): classify then takes uint16_t planes, stride in samples */
+orc_comb_t *orc_comb_new_depth(int width, int height, const orc_comb_params_t *p, int depth);
 void        orc_comb_free(orc_comb_t *c);
 /* comb_segmenter (comb_detect.c:1051-1072) on luma planes prev/cur/next (common
  * stride): returns HB_COMB_NONE/LIGHT/HEAVY (0/1/2). */

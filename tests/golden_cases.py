@@ -130,6 +130,18 @@ CASES = {
                                      chain=[("hb_filter_decomb", "mode=8")],
                                      hip=[("hb_filter_decomb_hip", "mode=8")],
                                      orc=[("decomb", dict(mode=8))]),
+    "combdetect_decomb_selective_10bit_192x96": dict(model="interlaced", w=192, h=96, n=5, depth=10,
+                                                     chain=[("hb_filter_comb_detect", COMB_DEFAULT), ("hb_filter_decomb", "mode=39")],
+                                                     hip=[("hb_filter_comb_detect_hip", COMB_DEFAULT), ("hb_filter_decomb_hip", "mode=39")],
+                                                     orc=[("comb_detect", dict(COMB_DEFAULT_PAR, depth=10)), ("decomb", dict(mode=39, depth=10))]),
+    "combdetect_nogamma_12bit_128x64": dict(model="progressive", w=128, h=64, n=4, depth=12,
+                                            chain=[("hb_filter_comb_detect", "mode=2:spatial-metric=0:motion-thresh=2:spatial-thresh=2:filter-mode=1:block-thresh=20:block-width=16:block-height=16"),
+                                                   ("hb_filter_decomb", "mode=39")],
+                                            hip=[("hb_filter_comb_detect_hip", "mode=2:spatial-metric=0:motion-thresh=2:spatial-thresh=2:filter-mode=1:block-thresh=20:block-width=16:block-height=16"),
+                                                 ("hb_filter_decomb_hip", "mode=39")],
+                                            orc=[("comb_detect", dict(mode=2, spatial_metric=0, motion_thresh=2, spatial_thresh=2, filter_mode=1,
+                                                                      block_thresh=20, block_width=16, block_height=16, depth=12)),
+                                                 ("decomb", dict(mode=39, depth=12))]),
     "decomb_default_10bit_134x70": dict(model="interlaced", w=134, h=70, n=4, depth=10,
                                         chain=[("hb_filter_decomb", "mode=7")],
                                         hip=[("hb_filter_decomb_hip", "mode=7")],

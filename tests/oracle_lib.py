@@ -244,20 +244,23 @@ class OrcComb:
     """orc_comb_t wrapper. Defaults = comb_detect.c:1118-1125."""
 
     def __init__(self, width, height, mode=3, spatial_metric=2, motion_thresh=3, spatial_thresh=3,
-                 filter_mode=2, block_thresh=40, block_width=16, block_height=16):
+                 filter_mode=2, block_thresh=40, block_width=16, block_height=16, depth=8):
         lib = oracle()
-        lib.orc_comb_new.restype = C.c_void_p
-        lib.orc_comb_new.argtypes = [C.c_int, C.c_int, C.POINTER(CombParams)]
-        lib.orc_comb_classify.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint8)] * 3 + [C.c_int, C.c_int]
+        lib.orc_comb_new_depth.restype = C.c_void_p
+        lib.orc_comb_new_depth.argtypes = [C.c_int, C.c_int, C.POINTER(CombParams), C.c_int]
+        lib.orc_comb_classify.argtypes = [C.c_void_p] + [C.c_void_p] * 3 + [C.c_int, C.c_int]
         lib.orc_comb_free.argtypes = [C.c_void_p]
         p = CombParams(mode, spatial_metric, motion_thresh, spatial_thresh, filter_mode,
                        block_thresh, block_width, block_height)
-        self.h = lib.orc_comb_new(width, height, C.byref(p))
+        self.h = lib.orc_comb_new_depth(width, height, C.byref(p), depth)
         self.lib = lib
 
     def classify(self, prev, cur, nxt, force):
+        if cur.dtype == np.uint16:
+            P, Cu, N = padded16(prev), padded16(cur), padded16(nxt)
+            return self.lib.orc_comb_classify(self.h, P.ctypes.data, Cu.ctypes.data, N.ctypes.data, Cu.shape[1], int(force))
         P, Cu, N = padded(prev), padded(cur), padded(nxt)
-        return self.lib.orc_comb_classify(self.h, u8p(P), u8p(Cu), u8p(N), Cu.strides[0], int(force))
+        return self.lib.orc_comb_classify(self.h, P.ctypes.data, Cu.ctypes.data, N.ctypes.data, Cu.strides[0], int(force))
 
     def close(self):
         if self.h:
