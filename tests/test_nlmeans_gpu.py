@@ -213,3 +213,28 @@ def test_16bit_samples_bit_exact(built, depth, w, h):
         for c in range(3):
             assert got[t].planes[c].dtype == np.uint16
             np.testing.assert_array_equal(got[t].planes[c], want[t][c], err_msg=f"frame {t} plane {c}")
+
+
+@pytest.mark.parametrize("pix_fmt,sx,sy", [(4, 2, 1), (5, 1, 1)])      # YUV422P, YUV444P
+def test_other_chroma_subsamplings(built, pix_fmt, sx, sy):
+    """The drop-ins take their plane geometry from the pixel format descriptor (log2_chroma_w/h),
+    like the reference (nlmeans.c:523-530): 4:2:2 and 4:4:4 streams, NLMeans then lapsharp."""
+    import oracle_stream as ostream
+    w, h = 200, 120
+    base = synth.stream("progressive", 2 * w, 2 * h, 3)                 # 4:2:0 at twice the size
+    frames = []
+    for y, cb, cr in base:
+        yy = np.ascontiguousarray(y[:h, :w])
+        cw, ch = w // sx, h // sy
+        frames.append((yy, np.ascontiguousarray(cb[:ch, :cw]), np.ascontiguousarray(cr[:ch, :cw])))
+    lap = "y-strength=0.4:y-kernel=isolap:cb-strength=0.3:cb-kernel=log"
+    got = hbrt.run_stream(hip.filters(), [("hb_filter_nlmeans_hip", MEDIUM), ("hb_filter_lapsharp_hip", lap)],
+                          frames, pix_fmt=pix_fmt)
+    want = ostream.run_chain(frames, [("nlmeans", [par(), par(), par()]),
+                                      ("lapsharp", [dict(strength=0.4, kernel="isolap"), dict(strength=0.3, kernel="log"),
+                                                    dict(strength=0.3, kernel="log")])])
+    assert len(got) == len(frames)
+    for t in range(len(frames)):
+        for c in range(3):
+            assert got[t].planes[c].shape == frames[t][c].shape
+            np.testing.assert_array_equal(got[t].planes[c], want[t][c], err_msg=f"frame {t} plane {c}")
