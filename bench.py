@@ -51,23 +51,43 @@ def cpu_baseline(frames_np):
     ref = ol.ref()
     if ref is not None:
         ncpu = min(os.cpu_count() or 1, 128)
-        threads = ncpu // 2 if ncpu >= 32 else (ncpu // 4) * 3 if ncpu >= 16 else ncpu  # nlmeans.c:361-373
-        n = max(2 * threads + 2, 24)
-        seq = [frames_np[i % len(frames_np)] for i in range(n)]
-        t0 = time.perf_counter()
-        out = hbrt.run_stream(ref, [("hb_filter_nlmeans", settings)], seq)
-        dt = time.perf_counter() - t0
-        if dt < 8.0:   # too short to be meaningful: repeat with a longer sample
-            k = int(min(10.0 / max(dt, 1e-3), 8)) + 1
-            seq = seq * k
+        rule = lambda c: c // 2 if c >= 32 else (c // 4) * 3 if c >= 16 else max(c, 1)   # nlmeans.c:361-373
+        candidates = [rule(ncpu)]
+        # a container CPU quota (cgroup cpu.max) below the visible core count throttles an
+        # over-subscribed run: also time the thread count the quota supports and keep the better
+        quota = None
+        try:
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+            if q != "max":
+                quota = max(1, int(int(q) / int(per)))
+        except Exception:
+            quota = None
+        if quota and quota < ncpu and quota not in candidates:
+            candidates.append(quota)
+        best = None
+        for threads in candidates:
+            st = settings + f":threads={threads}"
+            n = max(2 * threads + 2, 24)
+            seq = [frames_np[i % len(frames_np)] for i in range(n)]
             t0 = time.perf_counter()
-            out = hbrt.run_stream(ref, [("hb_filter_nlmeans", settings)], seq)
+            out = hbrt.run_stream(ref, [("hb_filter_nlmeans", st)], seq)
             dt = time.perf_counter() - t0
-        return {"value": round(len(out) / dt, 3), "unit": "frames/s", "cores": threads,
+            if dt < 5.0:   # too short to be meaningful: repeat with a sample of about 8 s
+                k = int(min(8.0 / max(dt, 1e-3), 64)) + 1
+                seq = seq * k
+                t0 = time.perf_counter()
+                out = hbrt.run_stream(ref, [("hb_filter_nlmeans", st)], seq)
+                dt = time.perf_counter() - t0
+            rec = (len(out) / dt, threads, len(out), dt)
+            if best is None or rec[0] > best[0]:
+                best = rec
+        fps, threads, nout, dt = best
+        return {"value": round(fps, 3), "unit": "frames/s", "cores": threads,
                 "kind": "reference",
-                "sample": f"{len(out)} frames 1920x1080 YUV420P through the reference hb_filter_nlmeans "
-                          f"init/work/close (libhb/nlmeans.c compiled in place, taskset threads={threads}, "
-                          f"SSE2 integral), {dt:.1f}s wall"}
+                "sample": f"{nout} frames 1920x1080 YUV420P through the reference hb_filter_nlmeans "
+                          f"init/work/close (libhb/nlmeans.c compiled in place, taskset threads={threads}"
+                          f"{' = best of ' + str(candidates) if len(candidates) > 1 else ''}, "
+                          f"{'cpu quota ' + str(quota) + ' CPUs, ' if quota else ''}SSE2 integral), {dt:.1f}s wall"}
     # port: single-thread restatement, a few frames
     n = 3
     t0 = time.perf_counter()
