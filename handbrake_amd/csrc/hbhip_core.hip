@@ -208,6 +208,24 @@ extern "C" {
 
 int hbhip_abi_version(void) { return HBHIP_ABI_VERSION; }
 
+int hbhip_host_alloc(size_t bytes, void **out)
+{
+    if (!out) return HBHIP_ERR_ARG;
+    *out = nullptr;
+    if (hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        *out = nullptr;
+        return HBHIP_ERR_NOMEM;
+    }
+    return HBHIP_OK;
+}
+
+void hbhip_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
 int hbhip_device_count(void)
 {
     int n = 0;

@@ -14,6 +14,7 @@ HBHIP_OK, HBHIP_AGAIN = 0, 1
 
 #: every entry point include/hbhip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
+    "hbhip_host_alloc", "hbhip_host_free",
     "hbhip_abi_version", "hbhip_device_count", "hbhip_strerror", "hbhip_ctx_create",
     "hbhip_ctx_create_on_stream", "hbhip_ctx_destroy", "hbhip_ctx_sync", "hbhip_ctx_last_error",
     "hbhip_ctx_device_name", "hbhip_ctx_profile_enable", "hbhip_ctx_profile_reset",

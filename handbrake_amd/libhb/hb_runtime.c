@@ -309,6 +309,18 @@ int hb_dict_extract_string(char **dst, const hb_dict_t *dict, const char *key)
 /* ----------------------------------------------------------------- buffers */
 #define HBHIP_BUF_PADDING 64
 
+/* Frame-sized buffers can come from an allocator supplied by the device library (page-locked
+ * memory, recycled): what a HIP build of libhb would do in fifo.c's buffer pools. */
+static void *(*g_big_alloc)(size_t) = NULL;
+static void (*g_big_free)(void *, size_t) = NULL;
+#define HBHIP_BIG_BUFFER (64 * 1024)
+
+void hbhip_rt_set_alloc_hooks(void *(*alloc)(size_t), void (*release)(void *, size_t))
+{
+    g_big_alloc = alloc;
+    g_big_free = release;
+}
+
 hb_buffer_t *hb_buffer_init(int size)
 {
     hb_buffer_t *b = calloc(1, sizeof(*b));
@@ -317,7 +329,12 @@ hb_buffer_t *hb_buffer_init(int size)
     b->alloc = size ? size + HBHIP_BUF_PADDING : 0;
     if (size)
     {
-        b->data = av_malloc(b->alloc);
+        if (g_big_alloc != NULL && b->alloc >= HBHIP_BIG_BUFFER)
+        {
+            b->data = g_big_alloc(b->alloc);
+            if (b->data != NULL) b->hooked_alloc = 1;
+        }
+        if (b->data == NULL) b->data = av_malloc(b->alloc);
         if (b->data == NULL) { free(b); return NULL; }
         memset(b->data, 0, b->alloc);
     }
@@ -441,7 +458,10 @@ void hb_buffer_close(hb_buffer_t **pb)
         if (b->storage_type == HBHIP_DEVICE && b->storage && g_storage_release)
             g_storage_release(b->storage);
         if (b->data && b->storage_type == STANDARD)
-            free(b->data);
+        {
+            if (b->hooked_alloc && g_big_free) g_big_free(b->data, b->alloc);
+            else free(b->data);
+        }
         free(b);
         b = next;
     }

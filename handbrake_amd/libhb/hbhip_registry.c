@@ -85,10 +85,55 @@ void *hbhip_host_ctx_ptr(void)
 static void storage_retain(void *p)  { hbhip_frame_retain((hbhip_frame *)p); }
 static void storage_release(void *p) { hbhip_frame_release((hbhip_frame *)p); }
 
+/* ---- page-locked frame buffers ------------------------------------------------------------
+ * hb_buffer payloads of frame size come from a recycling pool of hipHostMalloc'd blocks, so the
+ * uploads / downloads of the filters are DMA transfers.  (hipHostMalloc itself is far too slow to
+ * call per frame.)  Blocks are kept per exact size; at most PIN_KEEP idle blocks are retained.
+ * HBHIP_PINNED=0 turns the pool off. */
+#define PIN_KEEP 64
+static pthread_mutex_t g_pin_lock = PTHREAD_MUTEX_INITIALIZER;
+static struct { void *p; size_t size; } g_pin_idle[PIN_KEEP];
+static int g_pin_count = 0;
+
+static void *pinned_alloc(size_t size)
+{
+    void *p = NULL;
+    pthread_mutex_lock(&g_pin_lock);
+    for (int i = 0; i < g_pin_count; i++)
+        if (g_pin_idle[i].size == size)
+        {
+            p = g_pin_idle[i].p;
+            g_pin_idle[i] = g_pin_idle[--g_pin_count];
+            break;
+        }
+    pthread_mutex_unlock(&g_pin_lock);
+    if (p != NULL) return p;
+    if (hbhip_device_count() <= 0) return NULL;               /* no GPU: plain malloc in the caller */
+    if (hbhip_host_alloc(size, &p) != HBHIP_OK) return NULL;
+    return p;
+}
+
+static void pinned_release(void *p, size_t size)
+{
+    pthread_mutex_lock(&g_pin_lock);
+    if (g_pin_count < PIN_KEEP)
+    {
+        g_pin_idle[g_pin_count].p = p;
+        g_pin_idle[g_pin_count].size = size;
+        g_pin_count++;
+        p = NULL;
+    }
+    pthread_mutex_unlock(&g_pin_lock);
+    if (p != NULL) hbhip_host_free(p);
+}
+
 __attribute__((constructor)) static void hbhip_host_register_hooks(void)
 {
 #ifndef HBHIP_IN_LIBHB
     hbhip_rt_set_storage_hooks(storage_retain, storage_release);
+    const char *e = getenv("HBHIP_PINNED");
+    if (e == NULL || atoi(e) != 0)
+        hbhip_rt_set_alloc_hooks(pinned_alloc, pinned_release);
 #endif
 }
 

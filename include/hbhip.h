@@ -88,6 +88,11 @@ int  hbhip_ctx_elapsed_ms(hbhip_ctx *ctx, int slot_a, int slot_b, double *ms); /
 
 /* Device memory helpers (thin hipMalloc/hipFree/hipMemcpy wrappers so a C host
  * never needs the HIP headers). */
+/* Page-locked host memory (hipHostMalloc): frame buffers allocated from it make the H2D / D2H
+ * copies of hbhip_filter_push / pull true DMA transfers instead of staged pageable copies.
+ * What fifo.c's buffer pools would allocate from in a HIP build (hb_buffer_init, fifo.c:358-457). */
+int  hbhip_host_alloc(size_t bytes, void **out);
+void hbhip_host_free(void *p);
 int  hbhip_dev_alloc(hbhip_ctx *ctx, size_t bytes, void **out);
 int  hbhip_dev_free(hbhip_ctx *ctx, void *p);
 int  hbhip_dev_upload(hbhip_ctx *ctx, void *dst, const void *src, size_t bytes);

@@ -235,6 +235,9 @@ struct hb_buffer_s
     int          nb_side_data;
 
     hb_buffer_t *next;
+#ifndef HBHIP_IN_LIBHB
+    int          hooked_alloc;   /* stand-in runtime only: `data` came from hbhip_rt_set_alloc_hooks' allocator */
+#endif
 };
 
 struct hb_buffer_list_s
@@ -258,6 +261,8 @@ int          hb_buffer_copy(hb_buffer_t *dst, const hb_buffer_t *src);
 void         hb_buffer_copy_props(hb_buffer_t *dst, const hb_buffer_t *src);
 /* stand-in runtime only: how to share / drop an HBHIP_DEVICE storage handle */
 void         hbhip_rt_set_storage_hooks(void (*retain)(void *), void (*release)(void *));
+/* stand-in runtime only: allocator for frame-sized buffer payloads (page-locked pool) */
+void         hbhip_rt_set_alloc_hooks(void *(*alloc)(size_t), void (*release)(void *, size_t));
 
 void         hb_buffer_list_append(hb_buffer_list_t *list, hb_buffer_t *buf);
 void         hb_buffer_list_prepend(hb_buffer_list_t *list, hb_buffer_t *buf);
