@@ -89,10 +89,12 @@ def test_tunes_bit_exact(built, settings, pp):
             np.testing.assert_array_equal(got[t].planes[c], want[t][c], err_msg=f"frame {t} plane {c}")
 
 
-def test_1080p_against_reference_if_present(built):
-    """Full BASELINE size, one frame pair, against the reference's own C when
-    oracle/_ref travelled with the snapshot, else against the restatement."""
-    frames = synth.stream("progressive", 1920, 1080, 3)
+@pytest.mark.parametrize("w,h", [(1920, 1080), (1918, 1078)])
+def test_1080p_against_reference_if_present(built, w, h):
+    """Full BASELINE size (and its non-64-multiple-stride neighbour), one frame pair,
+    against the reference's own C when oracle/_ref travelled with the snapshot, else against
+    the restatement."""
+    frames = synth.stream("progressive", w, h, 3)
     got = run_hip(frames, MEDIUM)
     assert len(got) == 3
     ref = ol.ref()
