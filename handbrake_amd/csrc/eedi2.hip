@@ -194,28 +194,89 @@ __device__ __forceinline__ void st4(uint8_t *dst_at_x, const int (&out)[4], int 
     const int pitch = (P).pitch[pl], width = (P).width[pl], height = (P).height[pl]; \
     (void)width; (void)height; (void)pitch
 
-// k_edge_mask, 4 pixels per thread.  a = srcp, b = mskp (upper half rewritten, lower half only gains PEAKs)
-__global__ void k_edge_mask4(P3 P, int mth, int vth, int lth)
+// ------------------------------------------------------------------------------------------
+// The five mask passes in one launch: build_edge_mask -> erode -> dilate -> erode ->
+// remove_small_gaps (decomb_template.c:390-397) each only look one pixel (three along x for the
+// last) around themselves, so a workgroup can carry a 128 x 16 tile of the final mask through all
+// of them in LDS with a shrinking halo.  a = srcp, b = the PREVIOUS field's final mask (the rows of
+// the lower half that build_edge_mask does not touch keep it, :146-150), c = the new mask.  The old
+// and the new mask are different buffers (the engine alternates them) because neighbouring tiles
+// read each other's halos.  Pixels a pass does not process keep their input, as in the reference.
+constexpr int MF_W = 128, MF_H = 16, MF_OX = 8, MF_OY = 4;      // tile and the LDS frame's origin offset
+constexpr int MF_LP = MF_W + 2 * MF_OX, MF_LR = MF_H + 2 * MF_OY; // 144 x 24
+
+struct MfTile { int x0, y0, width, height, fx, fy, t; };
+
+// a region = the tile grown by (hx, hy), clipped to the plane, walked by all 256 threads;
+// body(x, y, lx, ly) gets plane and LDS coordinates
+template <typename F>
+__device__ __forceinline__ void mf_region(const MfTile &T, int hx, int hy, F body)
 {
-    XY4_PLANE(P);
-    if (x >= pitch || y >= height) return;
-    const uint8_t *c = P.a[pl] + (size_t)y * pitch + x;
-    const Win12 wp = ldwin(c - pitch), wc = ldwin(c), wn = ldwin(c + pitch);
-    uint8_t *o = P.b[pl] + (size_t)y * pitch + x;
-    const uint32_t old = *reinterpret_cast<const uint32_t *>(o);
-    int out[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-    {
-        int r = (y < height / 2) ? 0 : (int)((old >> (8 * k)) & 0xffu);
-        const int xx = x + k;
-        if (xx >= 1 && xx < width - 1 && y >= 1 && y < height - 1)
+    const int rx0 = max(T.x0 - hx, 0), rx1 = min(T.x0 + MF_W + hx, T.width);
+    const int ry0 = max(T.y0 - hy, 0), ry1 = min(T.y0 + MF_H + hy, T.height);
+    // 4 rows of 64 lanes at a time (no index division in these hot loops)
+    for (int y = ry0 + (T.t >> 6); y < ry1; y += 4)
+        for (int x = rx0 + (T.t & 63); x < rx1; x += 64)
+            body(x, y, x - T.fx, y - T.fy);
+}
+
+// erode (grow = 0, :259-293) / dilate (grow = 1, :207-247) of one region
+template <typename A>
+__device__ __forceinline__ void mf_morph(const MfTile &T, A &src, A &dst, int hx, int hy, int thr, int grow)
+{
+    mf_region(T, hx, hy, [&](int x, int y, int lx, int ly) {
+        const int c1 = src[ly][lx];
+        int r = c1;
+        if (x >= 1 && x < T.width - 1 && y >= 1 && y < T.height - 1 && (grow ? (c1 == 0) : (c1 == PEAK)))
         {
-            const int P0 = wb(wp, k - 1), P1 = wb(wp, k), P2 = wb(wp, k + 1);
-            const int C0 = wb(wc, k - 1), C1 = wb(wc, k), C2 = wb(wc, k + 1);
-            const int N0 = wb(wn, k - 1), N1 = wb(wn, k), N2 = wb(wn, k + 1);
-#define FLATCOL(a, b, d) (iabs((a) - (b)) < 10 && iabs((b) - (d)) < 10 && iabs((a) - (d)) < 10)
-            if (!(FLATCOL(P1, C1, N1) || (FLATCOL(P0, C0, N0) && FLATCOL(P2, C2, N2))))
+            const int count = (src[ly - 1][lx - 1] == PEAK) + (src[ly - 1][lx] == PEAK) + (src[ly - 1][lx + 1] == PEAK) +
+                              (src[ly][lx - 1] == PEAK) + (src[ly][lx + 1] == PEAK) +
+                              (src[ly + 1][lx - 1] == PEAK) + (src[ly + 1][lx] == PEAK) + (src[ly + 1][lx + 1] == PEAK);
+            if (grow) { if (count >= thr) r = PEAK; }
+            else      { if (count < thr) r = 0; }
+        }
+        dst[ly][lx] = (uint8_t)r;
+    });
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_mask_fused(P3 P, int mth, int vth, int lth, int erode_thr, int dilate_thr)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_src[MF_LR][MF_LP];
+    __shared__ __attribute__((aligned(16))) uint8_t s_a[MF_LR][MF_LP];
+    __shared__ __attribute__((aligned(16))) uint8_t s_b[MF_LR][MF_LP];
+    const int pl = blockIdx.z;
+    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
+    const int x0 = blockIdx.x * MF_W, y0 = blockIdx.y * MF_H;
+    if (x0 >= width || y0 >= height) return;
+    const MfTile T = { x0, y0, width, height, x0 - MF_OX, y0 - MF_OY, (int)threadIdx.x };
+
+    // stage source and old mask (dwords; columns outside [0, pitch) and rows outside the plane are not needed)
+    for (int i = T.t; i < MF_LR * (MF_LP / 4); i += 256)
+    {
+        const int r = i / (MF_LP / 4), c4 = i - r * (MF_LP / 4);
+        const int y = T.fy + r, x = T.fx + 4 * c4;
+        uint32_t sv = 0, mv = 0;
+        if (y >= 0 && y < height && x >= 0 && x < pitch)
+        {
+            sv = *reinterpret_cast<const uint32_t *>(P.a[pl] + (size_t)y * pitch + x);
+            mv = *reinterpret_cast<const uint32_t *>(P.b[pl] + (size_t)y * pitch + x);
+        }
+        reinterpret_cast<uint32_t *>(s_src[r])[c4] = sv;
+        reinterpret_cast<uint32_t *>(s_a[r])[c4] = mv;
+    }
+    __syncthreads();
+
+    // build_edge_mask (:122-195), in place on the old mask
+    mf_region(T, 6, 3, [&](int x, int y, int lx, int ly) {
+        int r = (y < height / 2) ? 0 : (int)s_a[ly][lx];
+        if (x >= 1 && x < width - 1 && y >= 1 && y < height - 1)
+        {
+            const int P0 = s_src[ly - 1][lx - 1], P1 = s_src[ly - 1][lx], P2 = s_src[ly - 1][lx + 1];
+            const int C0 = s_src[ly][lx - 1], C1 = s_src[ly][lx], C2 = s_src[ly][lx + 1];
+            const int N0 = s_src[ly + 1][lx - 1], N1 = s_src[ly + 1][lx], N2 = s_src[ly + 1][lx + 1];
+            auto flat = [](int a, int b, int d) { return iabs(a - b) < 10 && iabs(b - d) < 10 && iabs(a - d) < 10; };
+            if (!(flat(P1, C1, N1) || (flat(P0, C0, N0) && flat(P2, C2, N2))))
             {
                 const int sum = P0 + P1 + P2 + C0 + C1 + C2 + N0 + N1 + N2;
                 const int sumsq = P0 * P0 + P1 * P1 + P2 * P2 + C0 * C0 + C1 * C1 + C2 * C2 + N0 * N0 + N1 * N1 + N2 * N2;
@@ -233,56 +294,23 @@ __global__ void k_edge_mask4(P3 P, int mth, int vth, int lth)
                     }
                 }
             }
-#undef FLATCOL
         }
-        out[k] = r;
-    }
-    st4(o, out, x, pitch);
-}
+        s_a[ly][lx] = (uint8_t)r;
+    });
+    __syncthreads();
 
-// k_morph, 4 pixels per thread
-__global__ void k_morph4(P3 P, int thr, int grow)
-{
-    XY4_PLANE(P);
-    if (x >= width || y >= height) return;
-    const uint8_t *c = P.a[pl] + (size_t)y * pitch + x;
-    const Win12 wp = ldwin(c - pitch), wc = ldwin(c), wn = ldwin(c + pitch);
-    int out[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-    {
-        const int c1 = wb(wc, k);
-        int r = c1;
-        const int xx = x + k;
-        if (xx >= 1 && xx < width - 1 && y >= 1 && y < height - 1 && (grow ? (c1 == 0) : (c1 == PEAK)))
-        {
-            const int count = (wb(wp, k - 1) == PEAK) + (wb(wp, k) == PEAK) + (wb(wp, k + 1) == PEAK) +
-                              (wb(wc, k - 1) == PEAK) + (wb(wc, k + 1) == PEAK) +
-                              (wb(wn, k - 1) == PEAK) + (wb(wn, k) == PEAK) + (wb(wn, k + 1) == PEAK);
-            if (grow) { if (count >= thr) r = PEAK; }
-            else      { if (count < thr) r = 0; }
-        }
-        out[k] = r;
-    }
-    st4(P.b[pl] + (size_t)y * pitch + x, out, x, width);
-}
+    mf_morph(T, s_a, s_b, 5, 2, erode_thr, 0);
+    mf_morph(T, s_b, s_a, 4, 1, dilate_thr, 1);
+    mf_morph(T, s_a, s_b, 3, 0, erode_thr, 0);
 
-// k_small_gaps, 4 pixels per thread
-__global__ void k_small_gaps4(P3 P)
-{
-    XY4_PLANE(P);
-    if (x >= width || y >= height) return;
-    const Win12 w = ldwin(P.a[pl] + (size_t)y * pitch + x);
-    int out[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-    {
-        const int a3 = wb(w, k - 3), a2 = wb(w, k - 2), a1 = wb(w, k - 1), c = wb(w, k);
-        const int b1 = wb(w, k + 1), b2 = wb(w, k + 2), b3 = wb(w, k + 3);
+    // remove_small_gaps (:308-342) on the tile, straight to the new mask
+    mf_region(T, 0, 0, [&](int x, int y, int lx, int ly) {
+        const int c = s_b[ly][lx];
         int r = c;
-        const int xx = x + k;
-        if (xx >= 3 && xx < width - 3 && y >= 1 && y < height - 1)
+        if (x >= 3 && x < width - 3 && y >= 1 && y < height - 1)
         {
+            const int a3 = s_b[ly][lx - 3], a2 = s_b[ly][lx - 2], a1 = s_b[ly][lx - 1];
+            const int b1 = s_b[ly][lx + 1], b2 = s_b[ly][lx + 2], b3 = s_b[ly][lx + 3];
             if (c)
             {
                 if (!(a3 || a2 || a1 || b1 || b2 || b3)) r = 0;
@@ -290,9 +318,8 @@ __global__ void k_small_gaps4(P3 P)
             else if ((b1 && (a1 || a2 || a3)) || (b2 && (a1 || a2)) || (b3 && a1))
                 r = PEAK;
         }
-        out[k] = r;
-    }
-    st4(P.b[pl] + (size_t)y * pitch + x, out, x, width);
+        P.c[pl][(size_t)y * pitch + x] = (uint8_t)r;
+    });
 }
 
 // calc_directions in two launches so that no lane idles while its neighbour walks the
@@ -990,7 +1017,8 @@ Eedi2Engine::Eedi2Engine(hbhip_ctx *ctx, const PicGeometry &geo, const Eedi2Para
 
 Eedi2Engine::~Eedi2Engine()
 {
-    for (auto &g : graph_) if (g) (void)hipGraphExecDestroy(g);
+    for (auto &gg : graph_) for (auto &g : gg) if (g) (void)hipGraphExecDestroy(g);
+    if (mask_[1].alloc) (void)hipFree(mask_[1].alloc);
     for (auto &f : half_) if (f.alloc) (void)hipFree(f.alloc);
     for (auto &f : full_) if (f.alloc) (void)hipFree(f.alloc);
     if (work_list_) (void)hipFree(work_list_);
@@ -1034,6 +1062,12 @@ int Eedi2Engine::init()
         int rc = alloc_frame(f, geo_.width, geo_.height);          // decomb.c:299-303
         if (rc != HBHIP_OK) return rc;
     }
+    mask_[0] = half_[1];                                           // same memory as MSKPF (not owned twice)
+    {
+        int rc = alloc_frame(mask_[1], geo_.width, geo_.height / 2);
+        if (rc != HBHIP_OK) return rc;
+    }
+    mask_sel_ = 0;
     // work list of calc_directions (every half-height pixel could qualify) + lattice candidates
     size_t half_px = 0;
     for (int c = 0; c < 3; c++) half_px += (size_t)half_[0].stride[c] * half_[0].height[c];
@@ -1073,20 +1107,22 @@ int Eedi2Engine::run(const DevPicture *cur, int tff)
     // the ~22 launches of a field are identical from frame to frame (per field parity): they are
     // captured once into a hipGraph and replayed, which removes the per-launch submission gaps.
     // The per-kernel profiler needs individual launches, so it bypasses the graph.
-    if (ctx_->profile || !use_graph_) return enqueue_passes(tff);
-    hipGraphExec_t &exec = graph_[tff ? 1 : 0];
+    const int sel = mask_sel_ ^ 1;                 // the new mask goes to the other buffer
+    mask_sel_ = sel;
+    if (ctx_->profile || !use_graph_) return enqueue_passes(tff, sel);
+    hipGraphExec_t &exec = graph_[tff ? 1 : 0][sel];
     if (!exec)
     {
         hipGraph_t g = nullptr;
         HBHIP_CHECK(ctx_, hipStreamBeginCapture(ctx_->stream, hipStreamCaptureModeThreadLocal));
-        const int rc = enqueue_passes(tff);
+        const int rc = enqueue_passes(tff, sel);
         const hipError_t e = hipStreamEndCapture(ctx_->stream, &g);
         if (rc != HBHIP_OK || e != hipSuccess || !g)
         {
             if (g) (void)hipGraphDestroy(g);
             use_graph_ = false;                      // fall back to plain launches for good
             (void)hipGetLastError();
-            return enqueue_passes(tff);
+            return enqueue_passes(tff, sel);
         }
         const hipError_t ie = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
         (void)hipGraphDestroy(g);
@@ -1095,7 +1131,7 @@ int Eedi2Engine::run(const DevPicture *cur, int tff)
             exec = nullptr;
             use_graph_ = false;
             (void)hipGetLastError();
-            return enqueue_passes(tff);
+            return enqueue_passes(tff, sel);
         }
     }
     HBHIP_CHECK(ctx_, hipGraphLaunch(exec, ctx_->stream));
@@ -1104,9 +1140,9 @@ int Eedi2Engine::run(const DevPicture *cur, int tff)
 
 // The pass sequence of eedi2_interpolate_plane (decomb_template.c:366-441) for the 3 planes, from
 // the edge mask to the post-processing, on the engine's scratch frames.
-int Eedi2Engine::enqueue_passes(int tff)
+int Eedi2Engine::enqueue_passes(int tff, int sel)
 {
-    EediFrame &srcp = half_[0], &mskp = half_[1], &tmpp = half_[2], &dstp = half_[3];
+    EediFrame &srcp = half_[0], &mskp = mask_[sel], &mskp_old = mask_[sel ^ 1], &tmpp = half_[2], &dstp = half_[3];
     EediFrame &dst2p = full_[0], &tmp2p2 = full_[1], &msk2p = full_[2], &tmp2p = full_[3], &dst2mp = full_[4];
     const dim3 blk(64, 4);
     auto grid_for = [&](const EediFrame &f, bool whole_pitch) {
@@ -1127,17 +1163,12 @@ int Eedi2Engine::enqueue_passes(int tff)
 
     // half-height passes
     geom(P, srcp);
-    bind(P.a, srcp); bind(P.b, mskp);
-    HBHIP_LAUNCH(ctx_, "eedi2_edge_mask", k_edge_mask4, grid4_for(srcp, true), blk, 0, P,
-                 par_.magnitude_threshold * 10, par_.laplacian_threshold * 81, par_.variance_threshold);
-    bind(P.a, mskp); bind(P.b, tmpp);
-    HBHIP_LAUNCH(ctx_, "eedi2_erode", k_morph4, grid4_for(srcp, false), blk, 0, P, par_.erosion_threshold, 0);
-    bind(P.a, tmpp); bind(P.b, mskp);
-    HBHIP_LAUNCH(ctx_, "eedi2_dilate", k_morph4, grid4_for(srcp, false), blk, 0, P, par_.dilation_threshold, 1);
-    bind(P.a, mskp); bind(P.b, tmpp);
-    HBHIP_LAUNCH(ctx_, "eedi2_erode", k_morph4, grid4_for(srcp, false), blk, 0, P, par_.erosion_threshold, 0);
-    bind(P.a, tmpp); bind(P.b, mskp);
-    HBHIP_LAUNCH(ctx_, "eedi2_small_gaps", k_small_gaps4, grid4_for(srcp, false), blk, 0, P);
+    // edge mask, erode, dilate, erode, remove_small_gaps in one launch (old mask -> new mask)
+    bind(P.a, srcp); bind(P.b, mskp_old); bind(P.c, mskp);
+    HBHIP_LAUNCH(ctx_, "eedi2_mask_passes", k_mask_fused,
+                 dim3((srcp.width[0] + MF_W - 1) / MF_W, (srcp.height[0] + MF_H - 1) / MF_H, 3), dim3(256), 0, P,
+                 par_.magnitude_threshold * 10, par_.laplacian_threshold * 81, par_.variance_threshold,
+                 par_.erosion_threshold, par_.dilation_threshold);
     bind(P.a, mskp); bind(P.b, srcp); bind(P.c, tmpp);
     if (par_.maximum_search_distance <= CD_HALO - 2)
     {

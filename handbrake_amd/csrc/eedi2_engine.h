@@ -37,13 +37,17 @@ public:
     // sequence of eedi2_interpolate_plane for the 3 planes; `tff` is pv->tff.
     int  run(const DevPicture *cur, int tff);
     const EediFrame &result() const { return full_[0]; }   // eedi_full[DST2PF]
-    const EediFrame &half(int i) const { return half_[i]; }
+    // MSKPF alternates between two buffers (the fused mask kernel reads the previous field's mask
+    // while it writes the new one): index 1 always names the current one
+    const EediFrame &half(int i) const { return i == 1 ? mask_[mask_sel_] : half_[i]; }
     const EediFrame &full(int i) const { return full_[i]; }
 
 private:
     int alloc_frame(EediFrame &f, int width, int height);
-    int enqueue_passes(int tff);                   // everything after the field extraction
-    hipGraphExec_t graph_[2] = {nullptr, nullptr}; // captured pass sequence per field parity
+    int enqueue_passes(int tff, int sel);          // everything after the field extraction; sel = mask buffer to write
+    hipGraphExec_t graph_[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // captured pass sequence per (field parity, mask buffer)
+    EediFrame   mask_[2];                          // the two MSKPF buffers (mask_[0] is half_[1])
+    int         mask_sel_ = 0;                     // which one holds the current mask
     bool        use_graph_ = true;
     hbhip_ctx  *ctx_;
     PicGeometry geo_;
