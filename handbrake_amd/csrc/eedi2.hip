@@ -1,8 +1,8 @@
 // eedi2.hip — EEDI2 (edge-directed interpolation of one field) for gfx950, 8-bit.
 //
-// One kernel per reference pass (libhb/templates/eedi2_template.c), sequenced as
+// The reference's passes (libhb/templates/eedi2_template.c), sequenced as
 // eedi2_interpolate_plane does (libhb/templates/decomb_template.c:366-441), each
-// launch covering the three planes (blockIdx.z).  The nine scratch frames live in
+// launch covering the three planes (blockIdx.z).  The scratch frames live in
 // HBM with the byte layout hb_frame_buffer_init gives them (fifo.c:820-881) inside
 // zeroed guards, because the reference's passes index a flat buffer and read a few
 // bytes outside rows and planes (e.g. eedi2_template.c:395-447, 1194-1195); with the
@@ -10,16 +10,16 @@
 // mask keeps state between runs exactly as the reference's does (:132).
 //
 //   k_fill_half        eedi2_fill_half_height_buffer_plane   :77-89
-//   k_edge_mask        eedi2_build_edge_mask                 :122-195
-//   k_morph            eedi2_erode/dilate_edge_mask          :207-293
-//   k_small_gaps       eedi2_remove_small_gaps               :308-342
-//   k_calc_directions  eedi2_calc_directions                 :358-525   (the time sink)
+//   k_mask_fused       eedi2_build_edge_mask :122-195, erode/dilate_edge_mask :207-293,
+//                      remove_small_gaps :308-342 — five passes, one LDS-tiled launch
+//   k_calc_dir_tile    eedi2_calc_directions                 :358-525   (the time sink; k_calc_dir_mark/work
+//                      is the fallback for search distances beyond the LDS halo)
 //   k_dir_map          eedi2_filter_dir_map / expand_dir_map :649-773 and the _2x forms :872-1011
 //   k_filter_map       eedi2_filter_map                      :538-635
 //   k_upscale3         eedi2_upscale_by_2 (x3)               :98-108
 //   k_mark_2x          eedi2_mark_directions_2x              :787-858
 //   k_fill_gaps        eedi2_fill_gaps_2x                    :1025-1132
-//   k_lattice          eedi2_interpolate_lattice             :1148-1335
+//   k_lattice_cand / k_lattice_resolve   eedi2_interpolate_lattice   :1148-1335
 //   k_blit / k_post    eedi2_bit_blit :46-68 / eedi2_post_process :1349-1378
 //
 // interpolate_lattice rewrites its direction row in place and tests the value it
