@@ -897,19 +897,28 @@ __global__ __launch_bounds__(LC_W) void k_lattice_cand(P3 P, uint32_t *__restric
         (uint32_t)avg | ((uint32_t)valB << 8) | ((uint32_t)newB << 16) | ((uint32_t)always_a << 24) | ((uint32_t)right << 25);
 }
 
-// grid.y = processed rows (+1 for the border-row copy), block = one wavefront.
-__global__ __launch_bounds__(64) void k_lattice_resolve(P3 P, const uint32_t *__restrict__ cand, int cand_pitch,
-                                                        int cand_plane_stride, int field)
+// grid.y = processed rows (+1 for the border-row copy); one workgroup of LR_T threads per row, one
+// pixel per thread and pass over the row.  Which outcome a pixel takes depends only on which outcome
+// its left neighbour took (that decides the value left standing at x-1, :1194), so every pixel is a
+// 2-state map; the maps are composed by a prefix scan inside each wave, the 16 wave maps are chained
+// by one thread, and the incoming state of the next LR_T pixels is the outcome of the last one.
+constexpr int LR_T = 1024;
+
+__global__ __launch_bounds__(LR_T) void k_lattice_resolve(P3 P, const uint32_t *__restrict__ cand, int cand_pitch,
+                                                          int cand_plane_stride, int field)
 {
+    __shared__ uint8_t s_wmap[LR_T / 64];        // composed map of each wave
+    __shared__ uint8_t s_win[LR_T / 64];         // resolved state entering each wave
+    __shared__ int s_carry;                      // outcome of the last pixel of the previous pass
     const int pl = blockIdx.z;
     const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
-    const int lane = threadIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int nrows = (height - (2 - field)) / 2;                // rows y0, y0+2, ... < height-1
     uint8_t *dst = P.b[pl];
     if ((int)blockIdx.y >= nrows)
     {
         if ((int)blockIdx.y == nrows)                              // the one-row blit (:1162-1179)
-            for (int xx = lane; xx < width; xx += 64)
+            for (int xx = t; xx < width; xx += LR_T)
             {
                 if (field == 1) dst[(size_t)(height - 1) * pitch + xx] = dst[(size_t)(height - 2) * pitch + xx];
                 else            dst[xx] = dst[pitch + xx];
@@ -920,12 +929,14 @@ __global__ __launch_bounds__(64) void k_lattice_resolve(P3 P, const uint32_t *__
     uint8_t *mid = dst + (size_t)y * pitch;
     uint8_t *dm = P.a[pl] + (size_t)y * pitch;
     const uint32_t *cr = cand + (size_t)pl * cand_plane_stride + (size_t)blockIdx.y * cand_pitch;
-
     // value standing at dm[x-1] for x == 0: memory just before the row, never written by this pass
-    int carry_val = dm[-1];
-    for (int x0 = 0; x0 < width; x0 += 64)
+    const int before_row = dm[-1];
+    if (t == 0) s_carry = 0;
+    __syncthreads();
+
+    for (int x0 = 0; x0 < width; x0 += LR_T)
     {
-        const int x = x0 + lane;
+        const int x = x0 + t;
         const bool live = x < width;
         int d = 0, lim = 0, valA = 0, newA = 0, valB = 0, newB = 0;
         bool always_a = false, right = false;
@@ -938,19 +949,28 @@ __global__ __launch_bounds__(64) void k_lattice_resolve(P3 P, const uint32_t *__
             always_a = (c >> 24) & 1; right = (c >> 25) & 1;
             newA = always_a ? PEAK : NEUTRAL;
         }
-        // outcome 0 = A, 1 = B.  What this pixel does depends on the value left standing at x-1.
-        const int prevA = __shfl_up(newA, 1, 64), prevB = __shfl_up(newB, 1, 64);
+        // the two values pixel x-1 can leave behind: from the neighbouring lane, or (first lane of a
+        // wave) from that pixel's candidate word; nothing has been written to this row yet
+        int pa = __shfl_up(newA, 1, 64), pb = __shfl_up(newB, 1, 64);
+        if (lane == 0 && live)
+        {
+            if (x == 0) { pa = before_row; pb = before_row; }
+            else
+            {
+                const uint32_t cl = cr[x - 1];
+                pa = ((cl >> 24) & 1) ? PEAK : NEUTRAL;
+                pb = (cl >> 16) & 0xff;
+            }
+        }
         unsigned m;                                            // bit s = outcome when the left pixel took outcome s
         if (!live || always_a) m = 0u;
         else
         {
-            const int pa = lane == 0 ? carry_val : prevA;
-            const int pb = lane == 0 ? carry_val : prevB;
             const unsigned oa = (right && iabs(d - pa) > lim) ? 0u : 1u;
             const unsigned ob2 = (right && iabs(d - pb) > lim) ? 0u : 1u;
             m = oa | (ob2 << 1);
         }
-        // inclusive prefix composition: m[x] := m[x] o m[x-1] o ... (apply the earlier map first)
+        // inclusive prefix composition inside the wave: m[x] := m[x] o m[x-1] o ... (earlier map first)
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1)
         {
@@ -958,17 +978,27 @@ __global__ __launch_bounds__(64) void k_lattice_resolve(P3 P, const uint32_t *__
             if (lane >= off)
                 m = ((m >> (e & 1u)) & 1u) | (((m >> ((e >> 1) & 1u)) & 1u) << 1);
         }
-        // lane 0's map ignores its input (it was built from carry_val), so every composed map is constant
-        const unsigned outcome = m & 1u;
+        if (lane == 63) s_wmap[wave] = (uint8_t)m;
+        __syncthreads();
+        if (t == 0)
+        {
+            unsigned state = (unsigned)s_carry;                  // outcome of pixel x0 - 1 (irrelevant for x0 == 0)
+            for (int w = 0; w < LR_T / 64; w++)
+            {
+                s_win[w] = (uint8_t)state;
+                state = (s_wmap[w] >> state) & 1u;
+            }
+        }
+        __syncthreads();
+        const unsigned outcome = (m >> s_win[wave]) & 1u;
         if (live)
         {
             mid[x] = (uint8_t)(outcome ? valB : valA);
             const int nd = outcome ? newB : newA;
             if (nd != d) dm[x] = (uint8_t)nd;
-            carry_val = nd;
         }
-        const int last = min(63, width - 1 - x0);
-        carry_val = __shfl(carry_val, last, 64);
+        if (x == min(x0 + LR_T, width) - 1) s_carry = (int)outcome;
+        __syncthreads();
     }
 }
 
@@ -1216,7 +1246,7 @@ int Eedi2Engine::enqueue_passes(int tff, int sel)
         const int nt = par_.noise_threshold;
         HBHIP_LAUNCH(ctx_, "eedi2_lattice_candidates", k_lattice_cand, dim3((dst2p.width[0] + LC_W - 1) / LC_W, nrows, 3),
                      dim3(LC_W), 0, P, cand_, cand_pitch_, cand_plane_stride_, tff, (nt * 4) & 0xff, (nt * 7) & 0xff, (nt * 8) & 0xff, nt);
-        HBHIP_LAUNCH(ctx_, "eedi2_lattice_resolve", k_lattice_resolve, dim3(1, nrows + 1, 3), dim3(64), 0, P,
+        HBHIP_LAUNCH(ctx_, "eedi2_lattice_resolve", k_lattice_resolve, dim3(1, nrows + 1, 3), dim3(LR_T), 0, P,
                      (const uint32_t *)cand_, cand_pitch_, cand_plane_stride_, tff);
     }
     if (par_.post_processing == 1 || par_.post_processing == 3)
