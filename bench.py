@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 W, H = 1920, 1080
-BATCH = 16
+BATCH = 32          # frames per launch: 13 312 tiles = 17.3 rounds of the 768 resident workgroups
 # read 2 frames + write 1 = 3 x 3,110,400 B per 1080p 4:2:0 frame
 ALGO_BYTES_PER_FRAME = 3 * (W * H * 3 // 2)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s
