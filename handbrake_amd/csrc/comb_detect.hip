@@ -131,34 +131,52 @@ __global__ __launch_bounds__(256) void comb_mask_pass_kernel(const uint8_t *__re
 }
 
 // one wave per block_width x block_height block; result = max category seen
-__global__ __launch_bounds__(64) void comb_score_kernel(const uint8_t *__restrict__ mask, int stride,
-                                                        int width, int height, int bw, int bh, int thr,
-                                                        int filtered, int blocks_x, int *result)
+// One workgroup (4 waves) per row of blocks: each wave sums one block at a time, the categories are
+// maximised inside the workgroup and one atomic per workgroup reaches the result word (a global
+// atomic - or even an uncached read - per block would queue 8100 requests on one L2 channel).
+__global__ __launch_bounds__(256) void comb_score_kernel(const uint8_t *__restrict__ mask, int stride,
+                                                         int width, int height, int bw, int bh, int thr,
+                                                         int filtered, int blocks_x, int *result)
 {
-    // HEAVY already found by another block: nothing can change the maximum any more (the
-    // reference stops scanning in the same situation, comb_detect.c:211-214)
-    if (__hip_atomic_load(result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 2) return;
-    const int bx = blockIdx.x % blocks_x, by = blockIdx.x / blocks_x;
-    const int x0 = bx * bw, y0 = by * bh;
-    int score = 0;
-    for (int i = threadIdx.x; i < bw * bh; i += 64)
+    __shared__ int s_cat;
+    if (threadIdx.x == 0) s_cat = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int by = blockIdx.x, y0 = by * bh;
+    int best = 0;
+    for (int bx = wave; bx < blocks_x; bx += 4)
     {
-        const int iy = i / bw, ix = i - iy * bw;
-        const uint8_t *r = mask + (size_t)(y0 + iy) * stride + x0 + ix;
-        const int xa = x0 + ix;
-        if (filtered)             score += r[0];
-        else if (xa == 0)         score += r[0] & r[1];
-        else if (xa == width - 1) score += r[-1] & r[0];
-        else                      score += r[-1] & r[0] & r[1];
-    }
-    for (int off = 32; off > 0; off >>= 1) score += __shfl_down(score, off, 64);
-    if (threadIdx.x == 0)
-    {
+        const int x0 = bx * bw;
+        int score = 0;
+        if (filtered && bw == 16 && bh == 16 && !(stride & 3))
+        {
+            // the default 16 x 16 block of a filtered mask: one aligned dword of 0/1 bytes per lane
+            const int iy = lane >> 2, ix = (lane & 3) * 4;
+            const uint32_t v = *reinterpret_cast<const uint32_t *>(mask + (size_t)(y0 + iy) * stride + x0 + ix);
+            score = (int)((v * 0x01010101u) >> 24);
+        }
+        else
+        {
+            for (int i = lane; i < bw * bh; i += 64)
+            {
+                const int iy = i / bw, ix = i - iy * bw;
+                const uint8_t *r = mask + (size_t)(y0 + iy) * stride + x0 + ix;
+                const int xa = x0 + ix;
+                if (filtered)             score += r[0];
+                else if (xa == 0)         score += r[0] & r[1];
+                else if (xa == width - 1) score += r[-1] & r[0];
+                else                      score += r[-1] & r[0] & r[1];
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) score += __shfl_down(score, off, 64);
+        score = __shfl(score, 0, 64);
         const int cat = score > thr ? 2 : (score >= thr / 2 ? 1 : 0);
-        // thousands of blocks agree on combed material: only the ones that would raise the
-        // maximum touch the atomic, the rest would just queue up behind each other at L2
-        if (cat > __hip_atomic_load(result, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(result, cat);
+        best = max(best, cat);
+        if (best == 2) break;                                   // HEAVY: nothing can raise it (comb_detect.c:211-214)
     }
+    if (lane == 0 && best) atomicMax(&s_cat, best);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cat) atomicMax(result, s_cat);
 }
 
 class CombDetectFilter : public hbhip_filter
@@ -292,7 +310,7 @@ public:
         const int blocks_y = height / bh;                            // y + bh <= height
         if (blocks_x > 0 && blocks_y > 0)
         {
-            HBHIP_LAUNCH(ctx, "comb_block_score", comb_score_kernel, dim3(blocks_x * blocks_y), dim3(64), 0,
+            HBHIP_LAUNCH(ctx, "comb_block_score", comb_score_kernel, dim3(blocks_y), dim3(256), 0,
                          (const uint8_t *)(filt ? mask_filtered : mask), mstride, width, height, bw, bh,
                          par.block_threshold, filt ? 1 : 0, blocks_x, d_result);
         }

@@ -91,15 +91,30 @@ __global__ __launch_bounds__(64) void hqdn3d_vt_kernel(const uint8_t *__restrict
     const int x = blockIdx.x * 64 + threadIdx.x;
     if (x >= w) return;
     uint32_t line = 0;
-    for (int y = 0; y < h; y++)
+    // the loads of a row do not depend on the recurrence: fetch 4 rows ahead of the dependent
+    // LUT chain, which is what bounds this kernel
+    constexpr int U = 4;
+    for (int y0 = 0; y0 < h; y0 += U)
     {
-        const uint32_t hv = hbuf[(size_t)y * w + x];
-        const uint32_t v = y == 0 ? hv : lowpass((int)(uint16_t)line, (int)hv, lut_s);
-        line = v;
-        const uint32_t prev = seeded ? ant[(size_t)y * w + x] : (uint16_t)load8(src[(size_t)y * spitch + x]);
-        const uint32_t t = lowpass((int)prev, (int)v, lut_t);
-        ant[(size_t)y * w + x] = (uint16_t)t;
-        dst[(size_t)y * dpitch + x] = (uint8_t)(t >> 8);
+        uint32_t hv[U], pv[U];
+#pragma unroll
+        for (int k = 0; k < U; k++)
+        {
+            const int y = min(y0 + k, h - 1);
+            hv[k] = hbuf[(size_t)y * w + x];
+            pv[k] = seeded ? ant[(size_t)y * w + x] : (uint16_t)load8(src[(size_t)y * spitch + x]);
+        }
+#pragma unroll
+        for (int k = 0; k < U; k++)
+        {
+            const int y = y0 + k;
+            if (y >= h) break;
+            const uint32_t v = y == 0 ? hv[k] : lowpass((int)(uint16_t)line, (int)hv[k], lut_s);
+            line = v;
+            const uint32_t t = lowpass((int)pv[k], (int)v, lut_t);
+            ant[(size_t)y * w + x] = (uint16_t)t;
+            dst[(size_t)y * dpitch + x] = (uint8_t)(t >> 8);
+        }
     }
 }
 
@@ -158,16 +173,29 @@ __global__ __launch_bounds__(64) void hqdn3d_vt16_kernel(const uint8_t *__restri
     const int x = blockIdx.x * 64 + threadIdx.x;
     if (x >= w) return;
     uint32_t line = 0;
-    for (int y = 0; y < h; y++)
+    constexpr int U = 4;                                   // rows fetched ahead of the LUT chain
+    for (int y0 = 0; y0 < h; y0 += U)
     {
-        const uint32_t hv = hbuf[(size_t)y * w + x];
-        const uint32_t v = y == 0 ? hv : lowpass((int)(uint16_t)line, (int)hv, lut_s);
-        line = v;
-        const uint32_t cur = reinterpret_cast<const uint16_t *>(src + (size_t)y * spitch)[x];
-        const uint32_t prev = seeded ? ant[(size_t)y * w + x] : (uint16_t)load_sh<SH>(cur);
-        const uint32_t t = lowpass((int)prev, (int)v, lut_t);
-        ant[(size_t)y * w + x] = (uint16_t)t;
-        reinterpret_cast<uint16_t *>(dst + (size_t)y * dpitch)[x] = (uint16_t)(t >> SH);
+        uint32_t hv[U], pv[U];
+#pragma unroll
+        for (int k = 0; k < U; k++)
+        {
+            const int y = min(y0 + k, h - 1);
+            hv[k] = hbuf[(size_t)y * w + x];
+            pv[k] = seeded ? ant[(size_t)y * w + x]
+                           : (uint16_t)load_sh<SH>(reinterpret_cast<const uint16_t *>(src + (size_t)y * spitch)[x]);
+        }
+#pragma unroll
+        for (int k = 0; k < U; k++)
+        {
+            const int y = y0 + k;
+            if (y >= h) break;
+            const uint32_t v = y == 0 ? hv[k] : lowpass((int)(uint16_t)line, (int)hv[k], lut_s);
+            line = v;
+            const uint32_t t = lowpass((int)pv[k], (int)v, lut_t);
+            ant[(size_t)y * w + x] = (uint16_t)t;
+            reinterpret_cast<uint16_t *>(dst + (size_t)y * dpitch)[x] = (uint16_t)(t >> SH);
+        }
     }
 }
 

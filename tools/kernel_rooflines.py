@@ -119,15 +119,46 @@ def main():
                      "eedi2_mark_directions_2x": 3 * FRAME, "eedi2_filter_dir_map": 3 * half,
                      "eedi2_expand_dir_map": 3 * half, "eedi2_filter_map": 3 * half, "eedi2_erode": 2 * half,
                      "eedi2_dilate": 2 * half, "eedi2_edge_mask": 2 * half, "eedi2_small_gaps": 2 * half,
+                     "eedi2_mask_passes": 3 * half,
                      "eedi2_upscale_by_2": 3 * half + 3 * FRAME, "eedi2_bit_blit": 2 * FRAME, "eedi2_post_process": 3 * FRAME,
                      "eedi2_fill_half": 2 * half})
         dd.close()
-    # hqdn3d 1080p
-    frames = synth.stream("progressive", W, H, 4)
+    # hqdn3d 1080p (tables as denoise.c:78-94 builds them; only the timing matters here)
+    import numpy as np
+
+    def coef(dist25):
+        i = np.arange(-4096, 4096, dtype=np.float64)
+        f = (i * 32 + 15) / 512.0
+        gamma = np.log(0.25) / np.log(1.0 - min(dist25, 252.0) / 255.0 - 0.00001)
+        ct = np.rint(np.power(np.maximum(0.0, 1.0 - np.abs(f) / 255.0), gamma) * 256.0 * f).astype(np.int16)
+        ct[0] = 1 if dist25 else 0
+        return ct
+
     class HQ(C.Structure):
         _fields_ = [("coef", (C.c_int16 * 8192) * 6)]
-    F = hip.filters()
-    # host-built tables through the drop-in's own code: run the filter object once is simpler -> use oracle-free path
+    hq = HQ()
+    for k, v in enumerate((4.0, 6.0, 3.0, 4.5, 3.0, 4.5)):
+        C.memmove(hq.coef[k], coef(v).ctypes.data, 8192 * 2)
+    mk = lambda: hip._create("hbhip_hqdn3d_create", ctx, [C.c_void_p, C.POINTER(HQ)] + [C.c_int] * 5 + [C.POINTER(C.c_void_p)],
+                             ctx.h, C.byref(hq), W, H, 8, 1, 1)
+    add(simple(ctx, mk, W, H, W, H), {"hqdn3d_h": (Y + 2 * Y) , "hqdn3d_vt": (Y + 2 * Y + 2 * Y + 2 * Y + Y)})
+    # comb detect 1080p: 3 luma planes -> mask -> 4 mask passes -> block scores
+    frames = synth.stream("interlaced", W, H, 4)
+    dev_in = [[torch.from_numpy(p).cuda() for p in fr] for fr in frames]
+    torch.cuda.synchronize()
+    cd = hip.CombDetectDevice(ctx, W, H)
+    for i in range(3):
+        cd.store_dev(dev_in[i % 4][0].data_ptr(), dev_in[i % 4][0].stride(0))
+    cd.classify()
+    ctx.sync(); ctx.profile(True); ctx.profile_reset()
+    for i in range(N):
+        cd.store_dev(dev_in[i % 4][0].data_ptr(), dev_in[i % 4][0].stride(0))
+        cd.classify()
+    ctx.sync()
+    st = ctx.profile_stats(); ctx.profile(False)
+    add(st, {"comb_detect": 3 * Y + Y, "comb_mask_filter": 2 * Y, "comb_mask_erode": 2 * Y, "comb_mask_dilate": 2 * Y,
+             "comb_block_score": Y})
+    cd.close()
     print(json.dumps(res, indent=1))
     ctx.close()
 
