@@ -17,7 +17,6 @@ namespace {
 
 constexpr int LUT_N = 8192, CENTRE = 4096;
 
-__device__ __forceinline__ uint32_t load8(uint32_t px) { return (px << 8) + 127u; }      // denoise.c:32-33
 // LOAD / STORE for depth 8 + SH... i.e. SH = 16 - depth (denoise.c:32-35): 8 for bytes, 6 / 4 for
 // 10 / 12-bit samples in 16-bit containers; the fixed-point state and the LUTs do not depend on it
 template <int SH> __device__ __forceinline__ uint32_t load_sh(uint32_t px) { return (px << SH) + (((1u << SH) - 1u) >> 1); }
@@ -32,63 +31,86 @@ __device__ __forceinline__ void stage_lut(int16_t *dst, const int16_t *src, int 
         reinterpret_cast<uint32_t *>(dst)[i] = reinterpret_cast<const uint32_t *>(src)[i];
 }
 
-// one thread per row; 16 pixels per global load
-__global__ __launch_bounds__(64) void hqdn3d_h_kernel(const uint8_t *__restrict__ src, int spitch,
-                                                      uint16_t *__restrict__ hbuf, int w, int h,
-                                                      const int16_t *__restrict__ spatial_g)
+// The three planes of a frame are independent, and each of these kernels is latency bound with
+// few threads (one per row / per column), so one launch covers all planes: blockIdx.y (h, vt) or
+// blockIdx.z (t) selects the plane.
+struct HqPlane
 {
+    const uint8_t *src;
+    uint8_t       *dst;
+    uint16_t      *hbuf, *ant;
+    const int16_t *spatial, *temporal;
+    int spitch, dpitch, w, h, seeded, spatial_on;
+};
+struct HqArgs { HqPlane pl[3]; };
+
+// PIX = uint8_t (SH = 8) or uint16_t (SH = 16 - depth): LOAD / STORE of denoise.c:32-35
+template <typename PIX, int SH> __device__ __forceinline__ uint32_t hq_load(const uint8_t *row, int x)
+{
+    return load_sh<SH>(reinterpret_cast<const PIX *>(row)[x]);
+}
+
+// horizontal recurrence: one thread per row
+template <typename PIX, int SH>
+__global__ __launch_bounds__(64) void hqdn3d_h_kernel(HqArgs a)
+{
+    const HqPlane &P = a.pl[blockIdx.y];
+    if (!P.spatial_on) return;
     __shared__ int16_t lut[LUT_N];
-    stage_lut(lut, spatial_g, 64);
+    stage_lut(lut, P.spatial, 64);
     __syncthreads();
     const int y = blockIdx.x * 64 + threadIdx.x;
-    if (y >= h) return;
-    const uint8_t *s = src + (size_t)y * spitch;
-    uint16_t *o = hbuf + (size_t)y * w;
-    uint32_t run = load8(s[0]);
-    if (y == 0) run = lowpass((int)run, (int)load8(s[0]), lut);      // row 0 quirk (:140-146)
+    if (y >= P.h) return;
+    const int w = P.w;
+    const uint8_t *s = P.src + (size_t)y * P.spitch;
+    uint16_t *o = P.hbuf + (size_t)y * w;
+    uint32_t run = hq_load<PIX, SH>(s, 0);
+    if (y == 0) run = lowpass((int)run, (int)hq_load<PIX, SH>(s, 0), lut);      // row 0 quirk (:140-146)
     o[0] = (uint16_t)run;
     int x = 1;
-    // head up to a 16-byte boundary, then 16 pixels per load
-    for (; x < w && (x & 15); x++)
+    if (sizeof(PIX) == 1)
     {
-        run = lowpass((int)run, (int)load8(s[x]), lut);
-        o[x] = (uint16_t)run;
-    }
-    for (; x + 16 <= w; x += 16)
-    {
-        const uint4 v = *reinterpret_cast<const uint4 *>(s + x);
-        const uint32_t wds[4] = { v.x, v.y, v.z, v.w };
-        uint16_t r[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++)
+        // bytes: head up to a 16-byte boundary, then 16 pixels per load
+        for (; x < w && (x & 15); x++)
         {
-            run = lowpass((int)run, (int)load8((wds[k >> 2] >> (8 * (k & 3))) & 0xffu), lut);
-            r[k] = (uint16_t)run;
+            run = lowpass((int)run, (int)hq_load<PIX, SH>(s, x), lut);
+            o[x] = (uint16_t)run;
         }
+        for (; x + 16 <= w; x += 16)
+        {
+            const uint4 v = *reinterpret_cast<const uint4 *>(s + x);
+            const uint32_t wds[4] = { v.x, v.y, v.z, v.w };
+            uint16_t r[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) o[x + k] = r[k];
+            for (int k = 0; k < 16; k++)
+            {
+                run = lowpass((int)run, (int)load_sh<SH>((wds[k >> 2] >> (8 * (k & 3))) & 0xffu), lut);
+                r[k] = (uint16_t)run;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) o[x + k] = r[k];
+        }
     }
     for (; x < w; x++)
     {
-        run = lowpass((int)run, (int)load8(s[x]), lut);
+        run = lowpass((int)run, (int)hq_load<PIX, SH>(s, x), lut);
         o[x] = (uint16_t)run;
     }
 }
 
-// one thread per column
-__global__ __launch_bounds__(64) void hqdn3d_vt_kernel(const uint8_t *__restrict__ src, int spitch,
-                                                       const uint16_t *__restrict__ hbuf,
-                                                       uint16_t *__restrict__ ant, uint8_t *__restrict__ dst,
-                                                       int dpitch, int w, int h, int seeded,
-                                                       const int16_t *__restrict__ spatial_g,
-                                                       const int16_t *__restrict__ temporal_g)
+// vertical recurrence + temporal step: one thread per column
+template <typename PIX, int SH>
+__global__ __launch_bounds__(64) void hqdn3d_vt_kernel(HqArgs a)
 {
+    const HqPlane &P = a.pl[blockIdx.y];
+    if (!P.spatial_on) return;
     __shared__ int16_t lut_s[LUT_N];
     __shared__ int16_t lut_t[LUT_N];
-    stage_lut(lut_s, spatial_g, 64);
-    stage_lut(lut_t, temporal_g, 64);
+    stage_lut(lut_s, P.spatial, 64);
+    stage_lut(lut_t, P.temporal, 64);
     __syncthreads();
     const int x = blockIdx.x * 64 + threadIdx.x;
+    const int w = P.w, h = P.h;
     if (x >= w) return;
     uint32_t line = 0;
     // the loads of a row do not depend on the recurrence: fetch 4 rows ahead of the dependent
@@ -101,8 +123,8 @@ __global__ __launch_bounds__(64) void hqdn3d_vt_kernel(const uint8_t *__restrict
         for (int k = 0; k < U; k++)
         {
             const int y = min(y0 + k, h - 1);
-            hv[k] = hbuf[(size_t)y * w + x];
-            pv[k] = seeded ? ant[(size_t)y * w + x] : (uint16_t)load8(src[(size_t)y * spitch + x]);
+            hv[k] = P.hbuf[(size_t)y * w + x];
+            pv[k] = P.seeded ? P.ant[(size_t)y * w + x] : (uint16_t)hq_load<PIX, SH>(P.src + (size_t)y * P.spitch, x);
         }
 #pragma unroll
         for (int k = 0; k < U; k++)
@@ -112,107 +134,26 @@ __global__ __launch_bounds__(64) void hqdn3d_vt_kernel(const uint8_t *__restrict
             const uint32_t v = y == 0 ? hv[k] : lowpass((int)(uint16_t)line, (int)hv[k], lut_s);
             line = v;
             const uint32_t t = lowpass((int)pv[k], (int)v, lut_t);
-            ant[(size_t)y * w + x] = (uint16_t)t;
-            dst[(size_t)y * dpitch + x] = (uint8_t)(t >> 8);
+            P.ant[(size_t)y * w + x] = (uint16_t)t;
+            reinterpret_cast<PIX *>(P.dst + (size_t)y * P.dpitch)[x] = (PIX)(t >> SH);
         }
     }
 }
 
-// temporal only: fully parallel
-__global__ __launch_bounds__(256) void hqdn3d_t_kernel(const uint8_t *__restrict__ src, int spitch,
-                                                       uint16_t *__restrict__ ant, uint8_t *__restrict__ dst,
-                                                       int dpitch, int w, int h, int seeded,
-                                                       const int16_t *__restrict__ temporal_g)
+// temporal only (spatial strength 0): fully parallel
+template <typename PIX, int SH>
+__global__ __launch_bounds__(256) void hqdn3d_t_kernel(HqArgs a)
 {
+    const HqPlane &P = a.pl[blockIdx.z];
+    if (P.spatial_on) return;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
-    if (x >= w || y >= h) return;
-    const uint32_t cur = load8(src[(size_t)y * spitch + x]);
-    const uint32_t prev = seeded ? ant[(size_t)y * w + x] : (uint16_t)cur;
-    const uint32_t t = (uint32_t)((int)cur + temporal_g[CENTRE + (((int)prev - (int)cur) >> 4)]);
-    ant[(size_t)y * w + x] = (uint16_t)t;
-    dst[(size_t)y * dpitch + x] = (uint8_t)(t >> 8);
-}
-
-// ---- depth 10 / 12 (16-bit containers): the same three kernels with 16-bit samples ----------
-template <int SH>
-__global__ __launch_bounds__(64) void hqdn3d_h16_kernel(const uint8_t *__restrict__ src, int spitch,
-                                                        uint16_t *__restrict__ hbuf, int w, int h,
-                                                        const int16_t *__restrict__ spatial_g)
-{
-    __shared__ int16_t lut[LUT_N];
-    stage_lut(lut, spatial_g, 64);
-    __syncthreads();
-    const int y = blockIdx.x * 64 + threadIdx.x;
-    if (y >= h) return;
-    const uint16_t *s = reinterpret_cast<const uint16_t *>(src + (size_t)y * spitch);
-    uint16_t *o = hbuf + (size_t)y * w;
-    uint32_t run = load_sh<SH>(s[0]);
-    if (y == 0) run = lowpass((int)run, (int)load_sh<SH>(s[0]), lut);      // row 0 quirk (:140-146)
-    o[0] = (uint16_t)run;
-    for (int x = 1; x < w; x++)
-    {
-        run = lowpass((int)run, (int)load_sh<SH>(s[x]), lut);
-        o[x] = (uint16_t)run;
-    }
-}
-
-template <int SH>
-__global__ __launch_bounds__(64) void hqdn3d_vt16_kernel(const uint8_t *__restrict__ src, int spitch,
-                                                         const uint16_t *__restrict__ hbuf,
-                                                         uint16_t *__restrict__ ant, uint8_t *__restrict__ dst,
-                                                         int dpitch, int w, int h, int seeded,
-                                                         const int16_t *__restrict__ spatial_g,
-                                                         const int16_t *__restrict__ temporal_g)
-{
-    __shared__ int16_t lut_s[LUT_N];
-    __shared__ int16_t lut_t[LUT_N];
-    stage_lut(lut_s, spatial_g, 64);
-    stage_lut(lut_t, temporal_g, 64);
-    __syncthreads();
-    const int x = blockIdx.x * 64 + threadIdx.x;
-    if (x >= w) return;
-    uint32_t line = 0;
-    constexpr int U = 4;                                   // rows fetched ahead of the LUT chain
-    for (int y0 = 0; y0 < h; y0 += U)
-    {
-        uint32_t hv[U], pv[U];
-#pragma unroll
-        for (int k = 0; k < U; k++)
-        {
-            const int y = min(y0 + k, h - 1);
-            hv[k] = hbuf[(size_t)y * w + x];
-            pv[k] = seeded ? ant[(size_t)y * w + x]
-                           : (uint16_t)load_sh<SH>(reinterpret_cast<const uint16_t *>(src + (size_t)y * spitch)[x]);
-        }
-#pragma unroll
-        for (int k = 0; k < U; k++)
-        {
-            const int y = y0 + k;
-            if (y >= h) break;
-            const uint32_t v = y == 0 ? hv[k] : lowpass((int)(uint16_t)line, (int)hv[k], lut_s);
-            line = v;
-            const uint32_t t = lowpass((int)pv[k], (int)v, lut_t);
-            ant[(size_t)y * w + x] = (uint16_t)t;
-            reinterpret_cast<uint16_t *>(dst + (size_t)y * dpitch)[x] = (uint16_t)(t >> SH);
-        }
-    }
-}
-
-template <int SH>
-__global__ __launch_bounds__(256) void hqdn3d_t16_kernel(const uint8_t *__restrict__ src, int spitch,
-                                                         uint16_t *__restrict__ ant, uint8_t *__restrict__ dst,
-                                                         int dpitch, int w, int h, int seeded,
-                                                         const int16_t *__restrict__ temporal_g)
-{
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    if (x >= w || y >= h) return;
-    const uint32_t cur = load_sh<SH>(reinterpret_cast<const uint16_t *>(src + (size_t)y * spitch)[x]);
-    const uint32_t prev = seeded ? ant[(size_t)y * w + x] : (uint16_t)cur;
-    const uint32_t t = (uint32_t)((int)cur + temporal_g[CENTRE + (((int)prev - (int)cur) >> 4)]);
-    ant[(size_t)y * w + x] = (uint16_t)t;
-    reinterpret_cast<uint16_t *>(dst + (size_t)y * dpitch)[x] = (uint16_t)(t >> SH);
+    if (x >= P.w || y >= P.h) return;
+    const uint32_t cur = hq_load<PIX, SH>(P.src + (size_t)y * P.spitch, x);
+    const uint32_t prev = P.seeded ? P.ant[(size_t)y * P.w + x] : (uint16_t)cur;
+    const uint32_t t = (uint32_t)((int)cur + P.temporal[CENTRE + (((int)prev - (int)cur) >> 4)]);
+    P.ant[(size_t)y * P.w + x] = (uint16_t)t;
+    reinterpret_cast<PIX *>(P.dst + (size_t)y * P.dpitch)[x] = (PIX)(t >> SH);
 }
 
 class Hqdn3dFilter : public SimpleFilter
@@ -223,7 +164,7 @@ public:
     {
         if (d_coef) (void)hipFree(d_coef);
         for (int c = 0; c < 3; c++) if (ant[c]) (void)hipFree(ant[c]);
-        if (hbuf) (void)hipFree(hbuf);
+        for (int c = 0; c < 3; c++) if (hbuf[c]) (void)hipFree(hbuf[c]);
     }
     int setup()
     {
@@ -231,47 +172,50 @@ public:
         HBHIP_CHECK(ctx, hipMemcpyAsync(d_coef, par.coef, sizeof(int16_t) * 6 * LUT_N, hipMemcpyHostToDevice, ctx->stream));
         for (int c = 0; c < 3; c++)
             HBHIP_CHECK(ctx, hipMalloc((void **)&ant[c], sizeof(uint16_t) * (size_t)in_geo.pw[c] * in_geo.ph[c]));
-        HBHIP_CHECK(ctx, hipMalloc((void **)&hbuf, sizeof(uint16_t) * (size_t)in_geo.pw[0] * in_geo.ph[0]));
+        for (int c = 0; c < 3; c++)
+            HBHIP_CHECK(ctx, hipMalloc((void **)&hbuf[c], sizeof(uint16_t) * (size_t)in_geo.pw[c] * in_geo.ph[c]));
         HBHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         return HBHIP_OK;
     }
     int process(DevPicture *in, DevPicture *out) override
     {
+        HqArgs a;
+        bool any_spatial = false, any_temporal = false;
+        int max_w = 0, max_h = 0;
         for (int c = 0; c < 3; c++)
         {
-            const int w = in->width[c], h = in->height[c];
-            const int16_t *sp = d_coef + (size_t)(2 * c) * LUT_N, *tp = sp + LUT_N;
-            const bool spatial = par.coef[2 * c][0] != 0;             // spatial strength != 0 (denoise.c:191)
-            const uint8_t *src = in->plane[c];
-#define HQ_SPATIAL(HK, VK) do { \
-                HBHIP_LAUNCH(ctx, "hqdn3d_h", HK, dim3((h + 63) / 64), dim3(64), 0, src, in->pitch[c], hbuf, w, h, sp); \
-                HBHIP_LAUNCH(ctx, "hqdn3d_vt", VK, dim3((w + 63) / 64), dim3(64), 0, src, in->pitch[c], \
-                             (const uint16_t *)hbuf, ant[c], out->plane[c], out->pitch[c], w, h, seeded[c], sp, tp); } while (0)
-#define HQ_TEMPORAL(TK) HBHIP_LAUNCH(ctx, "hqdn3d_t", TK, dim3((w + 255) / 256, h), dim3(256), 0, src, in->pitch[c], \
-                                     ant[c], out->plane[c], out->pitch[c], w, h, seeded[c], tp)
-            if (in_geo.depth == 8)
-            {
-                if (spatial) HQ_SPATIAL(hqdn3d_h_kernel, hqdn3d_vt_kernel); else HQ_TEMPORAL(hqdn3d_t_kernel);
-            }
-            else if (in_geo.depth == 10)
-            {
-                if (spatial) HQ_SPATIAL(hqdn3d_h16_kernel<6>, hqdn3d_vt16_kernel<6>); else HQ_TEMPORAL(hqdn3d_t16_kernel<6>);
-            }
-            else
-            {
-                if (spatial) HQ_SPATIAL(hqdn3d_h16_kernel<4>, hqdn3d_vt16_kernel<4>); else HQ_TEMPORAL(hqdn3d_t16_kernel<4>);
-            }
-#undef HQ_SPATIAL
-#undef HQ_TEMPORAL
+            HqPlane &P = a.pl[c];
+            P.src = in->plane[c]; P.dst = out->plane[c];
+            P.spitch = in->pitch[c]; P.dpitch = out->pitch[c];
+            P.w = in->width[c]; P.h = in->height[c];
+            P.hbuf = hbuf[c]; P.ant = ant[c];
+            P.spatial = d_coef + (size_t)(2 * c) * LUT_N; P.temporal = P.spatial + LUT_N;
+            P.seeded = seeded[c];
+            P.spatial_on = par.coef[2 * c][0] != 0;                  // spatial strength != 0 (denoise.c:191)
+            (P.spatial_on ? any_spatial : any_temporal) = true;
+            max_w = std::max(max_w, P.w); max_h = std::max(max_h, P.h);
             seeded[c] = 1;
         }
+#define HQ_GO(PIX, SH) do { \
+            if (any_spatial) \
+            { \
+                HBHIP_LAUNCH(ctx, "hqdn3d_h", (hqdn3d_h_kernel<PIX, SH>), dim3((max_h + 63) / 64, 3), dim3(64), 0, a); \
+                HBHIP_LAUNCH(ctx, "hqdn3d_vt", (hqdn3d_vt_kernel<PIX, SH>), dim3((max_w + 63) / 64, 3), dim3(64), 0, a); \
+            } \
+            if (any_temporal) \
+                HBHIP_LAUNCH(ctx, "hqdn3d_t", (hqdn3d_t_kernel<PIX, SH>), dim3((max_w + 255) / 256, max_h, 3), dim3(256), 0, a); \
+        } while (0)
+        if (in_geo.depth == 8)       HQ_GO(uint8_t, 8);
+        else if (in_geo.depth == 10) HQ_GO(uint16_t, 6);
+        else                         HQ_GO(uint16_t, 4);
+#undef HQ_GO
         HBHIP_CHECK(ctx, hipGetLastError());
         return HBHIP_OK;
     }
     hbhip_hqdn3d_params par;
     int16_t *d_coef = nullptr;
     uint16_t *ant[3] = {nullptr, nullptr, nullptr};
-    uint16_t *hbuf = nullptr;
+    uint16_t *hbuf[3] = {nullptr, nullptr, nullptr};   // h-filtered rows, one buffer per plane
     int seeded[3] = {0, 0, 0};
 };
 

@@ -141,7 +141,7 @@ def main():
         C.memmove(hq.coef[k], coef(v).ctypes.data, 8192 * 2)
     mk = lambda: hip._create("hbhip_hqdn3d_create", ctx, [C.c_void_p, C.POINTER(HQ)] + [C.c_int] * 5 + [C.POINTER(C.c_void_p)],
                              ctx.h, C.byref(hq), W, H, 8, 1, 1)
-    add(simple(ctx, mk, W, H, W, H), {"hqdn3d_h": (Y + 2 * Y) , "hqdn3d_vt": (Y + 2 * Y + 2 * Y + 2 * Y + Y)})
+    add(simple(ctx, mk, W, H, W, H), {"hqdn3d_h": 3 * FRAME, "hqdn3d_vt": 8 * FRAME})    # one launch = 3 planes: px in + u16 out; u16 in, px in, u16 state in/out, px out
     # comb detect 1080p: 3 luma planes -> mask -> 4 mask passes -> block scores
     frames = synth.stream("interlaced", W, H, 4)
     dev_in = [[torch.from_numpy(p).cuda() for p in fr] for fr in frames]
