@@ -34,6 +34,9 @@ struct LapArgs
     double         coef, strength;
 };
 
+// the planes of a frame that share a kernel size go in one launch (blockIdx.z)
+struct LapArgs3 { LapArgs p[3]; };
+
 __device__ __forceinline__ uint32_t byte_at(const uint32_t (&v)[3], int k)   // k in [-4, 7]
 {
     const int kk = k + 4;
@@ -42,12 +45,13 @@ __device__ __forceinline__ uint32_t byte_at(const uint32_t (&v)[3], int k)   // 
 
 // one thread = 4 horizontally adjacent pixels (one aligned dword of output)
 template <int S>
-__global__ __launch_bounds__(256) void lapsharp_kernel(LapArgs a)
+__global__ __launch_bounds__(256) void lapsharp_kernel(LapArgs3 all)
 {
+    const LapArgs &a = all.p[blockIdx.z];
     constexpr int LO = -((S - 1) / 2), HI = (S + 1) / 2;
     const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const int y = blockIdx.y;
-    if (x0 >= a.width) return;
+    if (x0 >= a.width || y >= a.height) return;
 
     const int pitch_dw = a.src_pitch >> 2;
     const int xd = x0 >> 2;
@@ -110,12 +114,13 @@ __global__ __launch_bounds__(256) void lapsharp_kernel(LapArgs a)
 // accumulator, clamp to (1 << depth) - 1.  One thread = 2 adjacent pixels (one dword);
 // width / stride_border are in samples, pitches in bytes.
 template <int S>
-__global__ __launch_bounds__(256) void lapsharp16_kernel(LapArgs a, int max_value)
+__global__ __launch_bounds__(256) void lapsharp16_kernel(LapArgs3 all, int max_value)
 {
+    const LapArgs &a = all.p[blockIdx.z];
     constexpr int LO = -((S - 1) / 2), HI = (S + 1) / 2;
     const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 2;
     const int y = blockIdx.y;
-    if (x0 >= a.width) return;
+    if (x0 >= a.width || y >= a.height) return;
     const int pitch_dw = a.src_pitch >> 2;
     const int xd = x0 >> 1;
     uint32_t rows[S][3];                                     // samples x0-2 .. x0+3 of each row
@@ -197,15 +202,19 @@ struct BlurArgs
 
 // PIX = uint8_t, or uint16_t for the _16 instantiations (unsharp.c:171, chroma_smooth.c:170);
 // pitches stay in bytes
+struct BlurArgs3 { BlurArgs p[3]; };
+
 template <typename PIX>
-__global__ __launch_bounds__(256) void blur_mix_kernel(BlurArgs a)
+__global__ __launch_bounds__(256) void blur_mix_kernel(BlurArgs3 all)
 {
+    const BlurArgs &a = all.p[blockIdx.z];
     __shared__ PIX      s_src[(BT_H + 2 * MAX_STEPS) * (BT_W + 2 * MAX_STEPS)];
     __shared__ uint32_t s_h[(BT_H + 2 * MAX_STEPS) * BT_W];
 
     const int s = a.steps;
     const int tw = BT_W + 2 * s, th = BT_H + 2 * s;
     const int x0 = blockIdx.x * BT_W, y0 = blockIdx.y * BT_H;
+    if (x0 >= a.width || y0 >= a.height) return;          // the grid is sized for the largest plane of the launch
 
     // edge-clamped tile (unsharp.c:126 clamps x, :117-120 / :166-170 clamp y)
     for (int i = threadIdx.x; i < tw * th; i += 256)
@@ -282,37 +291,44 @@ public:
     LapsharpFilter(hbhip_ctx *c, const hbhip_lapsharp_params &p) : SimpleFilter(c), par(p) {}
     int process(DevPicture *in, DevPicture *out) override
     {
-        for (int c = 0; c < 3; c++)
+        // one launch per kernel size present (3x3: lap / isolap, 5x5: log / isolog), covering the planes that use it
+        for (int size : {3, 5})
         {
-            const LapKernel &k = LAP_TABLE[par.kernel[c]];
-            LapArgs a;
-            a.src = in->plane[c]; a.dst = out->plane[c];
-            a.width = in->width[c]; a.height = in->height[c];
-            a.src_pitch = in->pitch[c]; a.dst_pitch = out->pitch[c];
-            // host buffers: the caller's stride decides (lapsharp.c:145); device-resident frames have no
-            // hb_buffer stride, so use what hb_image_stride would be and read the padding as zeros
-            // (in samples: the reference divides the strides by bps first, lapsharp.c:137-138)
-            const int hb_stride = in_is_dev ? hbhip_align_up(in->width[c] * in->bps, 64) / in->bps : in_stride[c] / in->bps;
-            a.stride_border = (hb_stride - in->width[c]) / 2;
-            a.valid_w = in_is_dev ? in->width[c] : (1 << 30);
-            for (int i = 0; i < 25; i++) a.tap[i] = k.tap[i];
-            a.coef = k.coef; a.strength = par.strength[c];
+            LapArgs3 all;
+            int n = 0, max_w = 0, max_h = 0;
+            for (int c = 0; c < 3; c++)
+            {
+                const LapKernel &k = LAP_TABLE[par.kernel[c]];
+                if (k.size != size) continue;
+                LapArgs &a = all.p[n++];
+                a.src = in->plane[c]; a.dst = out->plane[c];
+                a.width = in->width[c]; a.height = in->height[c];
+                a.src_pitch = in->pitch[c]; a.dst_pitch = out->pitch[c];
+                // host buffers: the caller's stride decides (lapsharp.c:145); device-resident frames have no
+                // hb_buffer stride, so use what hb_image_stride would be and read the padding as zeros
+                // (in samples: the reference divides the strides by bps first, lapsharp.c:137-138)
+                const int hb_stride = in_is_dev ? hbhip_align_up(in->width[c] * in->bps, 64) / in->bps : in_stride[c] / in->bps;
+                a.stride_border = (hb_stride - in->width[c]) / 2;
+                a.valid_w = in_is_dev ? in->width[c] : (1 << 30);
+                for (int i = 0; i < 25; i++) a.tap[i] = k.tap[i];
+                a.coef = k.coef; a.strength = par.strength[c];
+                max_w = std::max(max_w, a.width); max_h = std::max(max_h, a.height);
+            }
+            if (n == 0) continue;
+            const char *name = size == 3 ? "lapsharp_3x3" : "lapsharp_5x5";
             if (in->bps == 2)
             {
-                dim3 grid16(((a.width + 1) / 2 + 255) / 256, a.height);
+                const dim3 grid(((max_w + 1) / 2 + 255) / 256, max_h, n);
                 const int max_value = (1 << in_geo.depth) - 1;
-                if (k.size == 3)
-                    HBHIP_LAUNCH(ctx, "lapsharp_3x3", lapsharp16_kernel<3>, grid16, dim3(256), 0, a, max_value);
-                else
-                    HBHIP_LAUNCH(ctx, "lapsharp_5x5", lapsharp16_kernel<5>, grid16, dim3(256), 0, a, max_value);
-                HBHIP_CHECK(ctx, hipGetLastError());
-                continue;
+                if (size == 3) HBHIP_LAUNCH(ctx, name, lapsharp16_kernel<3>, grid, dim3(256), 0, all, max_value);
+                else           HBHIP_LAUNCH(ctx, name, lapsharp16_kernel<5>, grid, dim3(256), 0, all, max_value);
             }
-            dim3 grid(((a.width + 3) / 4 + 255) / 256, a.height), block(256);
-            if (k.size == 3)
-                HBHIP_LAUNCH(ctx, "lapsharp_3x3", lapsharp_kernel<3>, grid, block, 0, a);
             else
-                HBHIP_LAUNCH(ctx, "lapsharp_5x5", lapsharp_kernel<5>, grid, block, 0, a);
+            {
+                const dim3 grid(((max_w + 3) / 4 + 255) / 256, max_h, n);
+                if (size == 3) HBHIP_LAUNCH(ctx, name, lapsharp_kernel<3>, grid, dim3(256), 0, all);
+                else           HBHIP_LAUNCH(ctx, name, lapsharp_kernel<5>, grid, dim3(256), 0, all);
+            }
             HBHIP_CHECK(ctx, hipGetLastError());
         }
         return HBHIP_OK;
@@ -327,6 +343,8 @@ public:
         : SimpleFilter(c), par(p), sign(sign_), vmin(vmin_), vmax(vmax_), name(nm) {}
     int process(DevPicture *in, DevPicture *out) override
     {
+        BlurArgs3 all;
+        int n = 0, max_w = 0, max_h = 0;
         for (int c = 0; c < 3; c++)
         {
             const int amount = par.amount[c];
@@ -336,7 +354,7 @@ public:
                 if (rc != HBHIP_OK) return rc;
                 continue;
             }
-            BlurArgs a;
+            BlurArgs &a = all.p[n++];
             a.src = in->plane[c]; a.dst = out->plane[c];
             a.width = in->width[c]; a.height = in->height[c];
             a.src_pitch = in->pitch[c]; a.dst_pitch = out->pitch[c];
@@ -347,15 +365,20 @@ public:
             a.sign = sign; a.vmin = vmin; a.vmax = vmax;
             // binomial row of order 2*steps
             uint32_t row[2 * MAX_STEPS + 1] = {1};
-            for (int n = 1; n <= 2 * a.steps; n++)
+            for (int k = 1; k <= 2 * a.steps; k++)
             {
-                row[n] = 1;
-                for (int k = n - 1; k >= 1; k--) row[k] += row[k - 1];
+                row[k] = 1;
+                for (int i = k - 1; i >= 1; i--) row[i] += row[i - 1];
             }
             for (int i = 0; i <= 2 * MAX_STEPS; i++) a.coef[i] = i <= 2 * a.steps ? row[i] : 0;
-            dim3 grid((a.width + BT_W - 1) / BT_W, (a.height + BT_H - 1) / BT_H), block(256);
-            if (in->bps == 2) HBHIP_LAUNCH(ctx, name, blur_mix_kernel<uint16_t>, grid, block, 0, a);
-            else              HBHIP_LAUNCH(ctx, name, blur_mix_kernel<uint8_t>, grid, block, 0, a);
+            max_w = std::max(max_w, a.width); max_h = std::max(max_h, a.height);
+        }
+        if (n > 0)
+        {
+            // the filtered planes of the frame in one launch (blockIdx.z)
+            dim3 grid((max_w + BT_W - 1) / BT_W, (max_h + BT_H - 1) / BT_H, n), block(256);
+            if (in->bps == 2) HBHIP_LAUNCH(ctx, name, blur_mix_kernel<uint16_t>, grid, block, 0, all);
+            else              HBHIP_LAUNCH(ctx, name, blur_mix_kernel<uint8_t>, grid, block, 0, all);
             HBHIP_CHECK(ctx, hipGetLastError());
         }
         return HBHIP_OK;

@@ -64,9 +64,9 @@ def main():
                       "achieved_GBps": round(b / (us * 1e-6) / 1e9, 1), "frac_of_8TBps": round(b / (us * 1e-6) / 1e9 / PEAK, 4)}
 
     Y, Cc = W * H, W * H // 4
-    # lapsharp at 2160p (where config 4 runs it): one launch per plane, 2 B/pixel
+    # lapsharp at 2160p (where config 4 runs it): one launch for the 3 planes, 2 B/pixel
     st = simple(ctx, lambda: hip.lapsharp_device_filter(ctx, 2 * W, 2 * H), 2 * W, 2 * H, 2 * W, 2 * H)
-    add(st, {"lapsharp_3x3": 2 * (4 * FRAME) // 3})           # mean over Y (4Y) + 2 chroma launches
+    add(st, {"lapsharp_3x3": 2 * (4 * FRAME)})
     # unsharp / chroma smooth 1080p
     def mk_blur(fn):
         class BP(C.Structure):
@@ -74,8 +74,8 @@ def main():
         p = BP((C.c_int * 3)(16384, 16384, 16384), (C.c_int * 3)(7, 7, 7))
         return hip._create(fn, ctx, [C.c_void_p, C.POINTER(BP)] + [C.c_int] * 5 + [C.POINTER(C.c_void_p)],
                            ctx.h, C.byref(p), W, H, 8, 1, 1)
-    add(simple(ctx, lambda: mk_blur("hbhip_unsharp_create"), W, H, W, H), {"unsharp_blur_mix": 2 * FRAME // 3})
-    add(simple(ctx, lambda: mk_blur("hbhip_chroma_smooth_create"), W, H, W, H), {"chroma_smooth_blur_mix": 2 * Cc})
+    add(simple(ctx, lambda: mk_blur("hbhip_unsharp_create"), W, H, W, H), {"unsharp_blur_mix": 2 * FRAME})
+    add(simple(ctx, lambda: mk_blur("hbhip_chroma_smooth_create"), W, H, W, H), {"chroma_smooth_blur_mix": 2 * 2 * Cc})
     # cropscale 1080p -> 2160p
     st = simple(ctx, lambda: hip.cropscale_device_filter(ctx, W, H, 2 * W, 2 * H), W, H, 2 * W, 2 * H)
     add(st, {"cropscale_lanczos_h": (FRAME + 8 * 2 * FRAME) // 3, "cropscale_lanczos_v": (8 * 2 * FRAME + 4 * FRAME) // 3,
