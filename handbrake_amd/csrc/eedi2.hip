@@ -16,11 +16,11 @@
 //                      is the fallback for search distances beyond the LDS halo)
 //   k_dir_map          eedi2_filter_dir_map / expand_dir_map :649-773 and the _2x forms :872-1011
 //   k_filter_map       eedi2_filter_map                      :538-635
-//   k_upscale3         eedi2_upscale_by_2 (x3)               :98-108
-//   k_mark_2x          eedi2_mark_directions_2x              :787-858
+//   k_mark_2x          eedi2_upscale_by_2 (x3) :98-108 + eedi2_mark_directions_2x :787-858
 //   k_fill_gaps        eedi2_fill_gaps_2x                    :1025-1132
 //   k_lattice_cand / k_lattice_resolve   eedi2_interpolate_lattice   :1148-1335
-//   k_blit / k_post    eedi2_bit_blit :46-68 / eedi2_post_process :1349-1378
+//   k_post             eedi2_post_process :1349-1378 (the eedi2_bit_blit before it, :46-68, is folded into
+//                      the dir-map filter that follows it)
 //
 // interpolate_lattice rewrites its direction row in place and tests the value it
 // just wrote at x-1 (:1194), a left-to-right dependency.  Each row is given to one
@@ -45,6 +45,7 @@ struct P3
     uint8_t *d[3];
     uint8_t *e[3];
     uint8_t *f[3];
+    uint8_t *g[3];
     int pitch[3], width[3], height[3];   // height = rows of the buffers this pass walks
 };
 
@@ -560,6 +561,7 @@ __global__ void k_dir_map(P3 P, int step, int y0, int expand)
     const int n0 = dd[-1], n1 = dd[0], n2 = dd[1];
     const int m0 = step == 1 ? mk[0] : mk[-(ptrdiff_t)pitch], m1 = step == 1 ? 0 : mk[pitch];
     int out = c1;                                              // bit_blit
+    if (P.d[pl]) P.d[pl][(size_t)y * pitch + x] = (uint8_t)c1;  // optional copy of the input (the eedi2_bit_blit before post-processing)
     const bool row_ok = step == 1 ? (y >= 1 && y < height - 1) : (y >= y0 && y < height - 1 && ((y - y0) & 1) == 0);
     if (row_ok && x >= 1 && x < width - 1)
     {
@@ -642,33 +644,26 @@ __global__ void k_filter_map(P3 P)
     P.c[pl][(size_t)y * pitch + x] = (uint8_t)out;
 }
 
-// line doubling of three half-height planes: a->d, b->e, c->f ; height = half height.
-// 16 bytes per thread (the pitch is a multiple of 64).
-__global__ void k_upscale3(P3 P)
-{
-    const int pl = blockIdx.z;
-    const int x = 16 * (blockIdx.x * blockDim.x + threadIdx.x);
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    const int pitch = P.pitch[pl], height = P.height[pl];
-    if (x >= pitch || y >= height) return;
-    const size_t s = (size_t)y * pitch + x, d0 = (size_t)(2 * y) * pitch + x, d1 = d0 + pitch;
-    const uint4 va = *reinterpret_cast<const uint4 *>(P.a[pl] + s);
-    const uint4 vb = *reinterpret_cast<const uint4 *>(P.b[pl] + s);
-    const uint4 vc = *reinterpret_cast<const uint4 *>(P.c[pl] + s);
-    *reinterpret_cast<uint4 *>(P.d[pl] + d0) = va; *reinterpret_cast<uint4 *>(P.d[pl] + d1) = va;
-    *reinterpret_cast<uint4 *>(P.e[pl] + d0) = vb; *reinterpret_cast<uint4 *>(P.e[pl] + d1) = vb;
-    *reinterpret_cast<uint4 *>(P.f[pl] + d0) = vc; *reinterpret_cast<uint4 *>(P.f[pl] + d1) = vc;
-}
-
 // a = msk2p, b = dmsk (tmp2p2), c = out (tmp2p)
+// Also performs the three eedi2_upscale_by_2 line doublings (:98-108, decomb_template.c:408-410):
+// g (srcp) -> d (dst2p), b (dstp, the half-height direction map) -> e (tmp2p2), a (mskp) -> f (msk2p).
+// The rows y-1 / y+1 of the doubled maps that mark_directions reads are rows (y-1)>>1 / (y+1)>>1 of
+// the half-height ones, so it reads those directly and no separate upscale launch is needed.
+// a = mskp, b = dstp, c = out (tmp2p), g = srcp; `height` = full height.
 __global__ void k_mark_2x(P3 P, int y0)
 {
     XY_PLANE(P);
     if (x >= pitch || y >= height) return;
     int out = 255;                                            // memset(dstp, 255, pitch*height)
-    // all loads up front (one memory round trip); rows y-1 / y+1 exist inside the guard bands
-    const uint8_t *d0 = P.b[pl] + (ptrdiff_t)(y - 1) * pitch + x, *d1 = d0 + 2 * (size_t)pitch;
-    const uint8_t *m0 = P.a[pl] + (ptrdiff_t)(y - 1) * pitch + x, *m1 = m0 + 2 * (size_t)pitch;
+    {
+        const size_t hs = (size_t)(y >> 1) * pitch + x, fs = (size_t)y * pitch + x;
+        P.d[pl][fs] = P.g[pl][hs];
+        P.e[pl][fs] = P.b[pl][hs];
+        P.f[pl][fs] = P.a[pl][hs];
+    }
+    // all loads up front (one memory round trip); row -1 exists inside the guard band
+    const uint8_t *d0 = P.b[pl] + (ptrdiff_t)((y - 1) >> 1) * pitch + x, *d1 = P.b[pl] + (ptrdiff_t)((y + 1) >> 1) * pitch + x;
+    const uint8_t *m0 = P.a[pl] + (ptrdiff_t)((y - 1) >> 1) * pitch + x, *m1 = P.a[pl] + (ptrdiff_t)((y + 1) >> 1) * pitch + x;
     const int a0 = d0[-1], a1 = d0[0], a2 = d0[1], b0 = d1[-1], b1 = d1[0], b2 = d1[1];
     const int k0 = m0[0], k1 = m1[0];
     if (y >= y0 && y < height - 1 && ((y - y0) & 1) == 0 && x >= 1 && x < width - 1)
@@ -1002,16 +997,6 @@ __global__ __launch_bounds__(LR_T) void k_lattice_resolve(P3 P, const uint32_t *
     }
 }
 
-// a = src, b = dst : copies `width` bytes of every row (eedi2_bit_blit), 4 per thread
-__global__ void k_blit(P3 P)
-{
-    XY4_PLANE(P);
-    if (x >= width || y >= height) return;
-    const uint32_t v = *reinterpret_cast<const uint32_t *>(P.a[pl] + (size_t)y * pitch + x);
-    const int out[4] = { (int)(v & 0xffu), (int)((v >> 8) & 0xffu), (int)((v >> 16) & 0xffu), (int)(v >> 24) };
-    st4(P.b[pl] + (size_t)y * pitch + x, out, x, width);
-}
-
 // a = nmsk, b = omsk, c = dst (in place, row y from rows y+-1), 4 pixels per thread
 __global__ void k_post(P3 P, int y0)
 {
@@ -1222,15 +1207,13 @@ int Eedi2Engine::enqueue_passes(int tff, int sel)
     HBHIP_LAUNCH(ctx_, "eedi2_expand_dir_map", k_dir_map, grid_for(srcp, false), blk, 0, P, 1, 1, 1);
     bind(P.a, mskp); bind(P.b, tmpp); bind(P.c, dstp);
     HBHIP_LAUNCH(ctx_, "eedi2_filter_map", k_filter_map, grid_for(srcp, false), blk, 0, P);
-    // line doubling
-    bind(P.a, srcp); bind(P.b, dstp); bind(P.c, mskp);
-    bind(P.d, dst2p); bind(P.e, tmp2p2); bind(P.f, msk2p);
-    HBHIP_LAUNCH(ctx_, "eedi2_upscale_by_2", k_upscale3, dim3((srcp.stride[0] / 16 + 63) / 64, (srcp.height[0] + 3) / 4, 3), blk, 0, P);
-    // full-height passes
+    // line doubling of srcp / dstp / mskp + mark_directions_2x in one launch (full-height geometry)
     geom(P, dst2p);
     const int y0 = 2 - tff;
-    bind(P.a, msk2p); bind(P.b, tmp2p2); bind(P.c, tmp2p);
+    bind(P.g, srcp); bind(P.b, dstp); bind(P.a, mskp);
+    bind(P.d, dst2p); bind(P.e, tmp2p2); bind(P.f, msk2p); bind(P.c, tmp2p);
     HBHIP_LAUNCH(ctx_, "eedi2_mark_directions_2x", k_mark_2x, grid_for(dst2p, true), blk, 0, P, y0);
+    for (int c = 0; c < 3; c++) P.d[c] = P.e[c] = P.f[c] = P.g[c] = nullptr;    // slot d doubles as k_dir_map's optional copy target
     bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
     HBHIP_LAUNCH(ctx_, "eedi2_filter_dir_map_2x", k_dir_map, grid_for(dst2p, false), blk, 0, P, 2, y0, 0);
     bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
@@ -1251,10 +1234,12 @@ int Eedi2Engine::enqueue_passes(int tff, int sel)
     }
     if (par_.post_processing == 1 || par_.post_processing == 3)
     {
-        bind(P.a, tmp2p); bind(P.b, tmp2p2);
-        HBHIP_LAUNCH(ctx_, "eedi2_bit_blit", k_blit, grid4_for(dst2p, false), blk, 0, P);
-        bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
+        // eedi2_bit_blit(tmp2p -> tmp2p2) keeps the pre-filter direction map for post_process
+        // (decomb_template.c:426); the filter that follows reads every byte of tmp2p the blit copies,
+        // so it writes that copy itself (slot d) and the separate launch is saved
+        bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp); bind(P.d, tmp2p2);
         HBHIP_LAUNCH(ctx_, "eedi2_filter_dir_map_2x", k_dir_map, grid_for(dst2p, false), blk, 0, P, 2, y0, 0);
+        for (int c = 0; c < 3; c++) P.d[c] = nullptr;
         bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
         HBHIP_LAUNCH(ctx_, "eedi2_expand_dir_map_2x", k_dir_map, grid_for(dst2p, false), blk, 0, P, 2, y0, 1);
         bind(P.a, tmp2p); bind(P.b, tmp2p2); bind(P.c, dst2p);
