@@ -156,6 +156,7 @@ def secondary(args):
             self.decomb_f = hip.DeviceFilter(self.ctx, self.decomb.h)
             self.t = [planes(W, H), planes(W, H), planes(2 * W, 2 * H), planes(2 * W, 2 * H)]
             self.f1080, self.f1080b, self.f2160, self.f2160b = map(hip.dev_frame, self.t)
+            self.a1080b, self.a2160, self.a2160b = [(hip.DevFrame * 1)(f) for f in (self.f1080b, self.f2160, self.f2160b)]
             if chain:
                 self.nlm = hip.nlmeans_device_filter(self.ctx, hip.NLMEANS_MEDIUM, W, H, batch=1)
                 self.scale = hip.cropscale_device_filter(self.ctx, W, H, 2 * W, 2 * H)
@@ -184,10 +185,9 @@ def secondary(args):
                 self.nlm.push_dev(self.f1080, 0)
                 while self.nlm.pending():
                     self.nlm.pull_dev(self.f1080b)
-                    self.scale.push_dev(self.f1080b, 0)
-                    self.scale.pull_dev(self.f2160)
-                    self.sharp.push_dev(self.f2160, 0)
-                    self.sharp.pull_dev(self.f2160b)
+                    # stateless filters read / write the frames in place (hbhip_filter_process_dev)
+                    self.scale.process_dev(self.a1080b, 0, self.a2160)
+                    self.sharp.process_dev(self.a2160, 0, self.a2160b)
                     self.produced += 1
 
     lanes = [Lane() for _ in range(max(1, args.streams))]

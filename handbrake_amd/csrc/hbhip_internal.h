@@ -209,4 +209,38 @@ struct SimpleFilter : hbhip_filter
         return p;
     }
     void recycle_output(DevPicture *p) override { out_pool.release(p); }
+
+    // Zero-copy: a stateless filter can read the caller's device frame and write the caller's
+    // output frame directly (no pool pictures, no device-to-device copies).  Falls back to the
+    // copying path when a plane is not 16-byte aligned (some kernels use vector loads).
+    int process_dev_batch(const hbhip_dev_frame *in, int n_in, int64_t tag0,
+                          const hbhip_dev_frame *out, int out_cap, int *n_out) override
+    {
+        bool direct = outq.empty() && n_in <= out_cap;
+        for (int i = 0; direct && i < n_in; i++)
+            for (int c = 0; c < 3; c++)
+                if ((in[i].stride[c] & 15) || ((uintptr_t)in[i].plane[c] & 15) ||
+                    (out[i].stride[c] & 15) || ((uintptr_t)out[i].plane[c] & 15))
+                    direct = false;
+        if (!direct) return hbhip_filter::process_dev_batch(in, n_in, tag0, out, out_cap, n_out);
+        for (int i = 0; i < n_in; i++)
+        {
+            DevPicture vi, vo;
+            for (int c = 0; c < 3; c++)
+            {
+                vi.plane[c] = (uint8_t *)in[i].plane[c];  vi.pitch[c] = in[i].stride[c];
+                vi.width[c] = in_geo.pw[c];               vi.height[c] = in_geo.ph[c];
+                vo.plane[c] = (uint8_t *)out[i].plane[c]; vo.pitch[c] = out[i].stride[c];
+                vo.width[c] = out_geo.pw[c];              vo.height[c] = out_geo.ph[c];
+                in_stride[c] = in[i].stride[c];
+            }
+            vi.bps = in_geo.bps; vo.bps = out_geo.bps;
+            vi.tag = vo.tag = tag0 + i;
+            in_is_dev = true;
+            int rc = process(&vi, &vo);
+            if (rc != HBHIP_OK) return rc;
+        }
+        *n_out = n_in;
+        return HBHIP_OK;
+    }
 };

@@ -234,8 +234,36 @@ int hbhip_host_simple_work(hbhip_filter *dev, const hb_filter_init_t *output, co
     }
     int ow = in->f.width, oh = in->f.height;
     hbhip_filter_out_geometry(dev, &ow, &oh);
-    int rc = hbhip_host_push(dev, in, 0);
-    hb_buffer_t *out = rc == HBHIP_OK ? hbhip_host_pull(dev, output, ow, oh, dev_io, NULL) : NULL;
+    int rc;
+    hb_buffer_t *out = NULL;
+    hbhip_frame *src = hbhip_host_frame_of(in);
+    if (src != NULL && dev_io)
+    {
+        /* device frame in, device frame out: the filter reads and writes the two frames in place */
+        const AVPixFmtDescriptor *desc = av_pix_fmt_desc_get(output->pix_fmt);
+        hbhip_frame *dst = NULL;
+        rc = desc == NULL ? HBHIP_ERR_ARG
+                          : hbhip_frame_alloc(hbhip_host_ctx(), ow, oh, desc->comp[0].depth,
+                                              desc->log2_chroma_w, desc->log2_chroma_h, &dst);
+        if (desc != NULL) hbhip_host_ctx_release();
+        if (rc == HBHIP_OK)
+        {
+            hbhip_dev_frame di, dd;
+            int n = 0;
+            hbhip_frame_describe(src, &di, NULL, NULL);
+            hbhip_frame_describe(dst, &dd, NULL, NULL);
+            rc = hbhip_filter_process_dev(dev, &di, 1, 0, &dd, 1, &n);
+            if (rc == HBHIP_OK && n == 1)
+                out = hbhip_host_wrap_frame(dst, output, ow, oh);      /* takes the reference */
+            else
+                hbhip_frame_release(dst);
+        }
+    }
+    else
+    {
+        rc = hbhip_host_push(dev, in, 0);
+        out = rc == HBHIP_OK ? hbhip_host_pull(dev, output, ow, oh, dev_io, NULL) : NULL;
+    }
     if (out == NULL)
     {
         hb_error("%s(hip): push/pull failed (%s)", who, hbhip_strerror(rc));
