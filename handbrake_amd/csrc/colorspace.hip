@@ -1,0 +1,525 @@
+// colorspace.hip — the reference's colorspace filter (libhb/colorspace.c:20-207) for gfx950.
+//
+// In the reference colorspace_init only builds an FFmpeg graph
+//     zscale=transfer=linear:npl -> format=gbrpf32le -> tonemap      (PQ / HLG sources only, :126-162)
+//     -> zscale=primaries:transfer:matrix:range -> format=<pix_fmt>  (:170-193)
+// which hb_avfilter_combine merges into HB_FILTER_AVFILTER; the arithmetic is zimg's and
+// vf_tonemap.c's (not in the reference tree: "parity unpinned", pinned to oracle/colorspace_oracle.c,
+// whose header lists what is restated and what is simplified).
+//
+// MI355X shape: the CPU graph makes five passes over float planes (to float, chroma to 4:4:4,
+// colour conversion, chroma back to 4:2:0, to integer).  Here one launch does all of it: a
+// workgroup owns a 64 x 16 luma tile, converts the tile plus the one-column / three-row apron the
+// chroma decimation needs, keeps the converted Cb'/Cr' of that region in LDS (10 KB), writes luma
+// straight out and then decimates chroma from LDS.  HBM traffic is the input frame once and the
+// output frame once; the transfer-function tables (2 x 64 KB) stay in L2.
+#include "hbhip_internal.h"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+constexpr int LUT_N = 16384;
+constexpr int CS_TW = 64, CS_TH = 16, CS_RW = CS_TW + 2, CS_RH = CS_TH + 3;
+
+struct CsPlan
+{
+    int   need_linear, gamut, tonemap, vmax;
+    float yoff_in, ymul_in, coff_in, cmul_in;
+    float ymul_out, yoff_out, cmul_out, coff_out;
+    float m_in[3][3], m_out[3][3], m_gamut[3][3], m_direct[3][3];
+    float tm_param, tm_peak, tm_a, tm_b, tm_c;
+    const float *lut_in, *lut_out;
+};
+
+struct CsArgs
+{
+    const uint8_t *src[3];
+    uint8_t       *dst[3];
+    int spitch[3], dpitch[3];
+    int w, h, cw, ch, subw, subh;
+};
+
+// ---- per-sample pipeline: every operation in float, correctly rounded, in the oracle's order ----
+__device__ __forceinline__ float lut_lerp(const float *__restrict__ lut, float t)
+{
+    int i = (int)t;
+    if (i > LUT_N - 1) i = LUT_N - 1;
+    const float f = t - (float)i;
+    const float a = lut[i], b = lut[i + 1];
+    return a + (b - a) * f;
+}
+
+__device__ __forceinline__ float clip01(float v) { return v < 0.f ? 0.f : v > 1.f ? 1.f : v; }
+
+__device__ __forceinline__ float hable_dev(float in)
+{
+    const float a = 0.15f, b = 0.50f, c = 0.10f, d = 0.20f, e = 0.02f, f = 0.30f;
+    return __fdiv_rn(in * (in * a + b * c) + d * e, in * (in * a + b) + d * f) - __fdiv_rn(e, f);
+}
+
+// vf_tonemap.c's operators on the brightest component
+__device__ __forceinline__ float tonemap_sig(const CsPlan &p, float sig)
+{
+    switch (p.tonemap)
+    {
+        case 1: return __fdiv_rn(sig * p.tm_param, p.tm_peak);
+        case 3: { const float v = sig * p.tm_param; return v < 0.f ? 0.f : v > 1.f ? 1.f : v; }
+        case 4: return __fdiv_rn(__fdiv_rn(sig, sig + p.tm_param) * (p.tm_peak + p.tm_param), p.tm_peak);
+        case 5: return __fdiv_rn(hable_dev(sig), p.tm_a);
+        case 6:
+            if (sig <= p.tm_param) return sig;
+            return __fdiv_rn(p.tm_c * (sig + p.tm_a), sig + p.tm_b);
+    }
+    return sig;
+}
+
+__device__ __forceinline__ void convert_px(const CsPlan &p, float y, float u, float v, float out[3])
+{
+    if (!p.need_linear)
+    {
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            out[i] = p.m_direct[i][0] * y + p.m_direct[i][1] * u + p.m_direct[i][2] * v;
+        return;
+    }
+    float c[3], g[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+    {
+        const float e = p.m_in[i][0] * y + p.m_in[i][1] * u + p.m_in[i][2] * v;
+        c[i] = lut_lerp(p.lut_in, clip01(e) * (float)LUT_N);
+    }
+    if (p.tonemap >= 0)
+    {
+        float sig = c[0] > c[1] ? c[0] : c[1];
+        sig = sig > c[2] ? sig : c[2];
+        sig = sig > 1e-6f ? sig : 1e-6f;
+        const float k = __fdiv_rn(tonemap_sig(p, sig), sig);
+#pragma unroll
+        for (int i = 0; i < 3; i++) c[i] *= k;
+    }
+    if (p.gamut)
+    {
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            g[i] = p.m_gamut[i][0] * c[0] + p.m_gamut[i][1] * c[1] + p.m_gamut[i][2] * c[2];
+    }
+    else
+    {
+#pragma unroll
+        for (int i = 0; i < 3; i++) g[i] = c[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+        g[i] = lut_lerp(p.lut_out, __fsqrt_rn(clip01(g[i])) * (float)LUT_N);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+        out[i] = p.m_out[i][0] * g[0] + p.m_out[i][1] * g[1] + p.m_out[i][2] * g[2];
+}
+
+__device__ __forceinline__ int quant(float v, float mul, float off, int vmax)
+{
+    const int q = __float2int_rn(v * mul + off);
+    return q < 0 ? 0 : q > vmax ? vmax : q;
+}
+
+template <typename PIX>
+__device__ __forceinline__ float sample(const uint8_t *plane, int pitch, int x, int y)
+{
+    return (float)reinterpret_cast<const PIX *>(plane + (size_t)y * pitch)[x];
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
+
+template <typename PIX>
+__global__ __launch_bounds__(256) void colorspace_kernel(CsArgs a, CsPlan p)
+{
+    __shared__ float s_u[CS_RH][CS_RW], s_v[CS_RH][CS_RW];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * CS_TW, y0 = blockIdx.y * CS_TH;
+    const int hx = a.subw ? 1 : 0, hy = a.subh ? 1 : 0;
+    const int rw = CS_TW + hx, rh = CS_TH + (a.subh ? 3 : 0);
+
+    // phase 1: convert the tile and its apron at luma resolution
+    for (int i = tid; i < rw * rh; i += 256)
+    {
+        const int ry = i / rw, rx = i - ry * rw;
+        const int ux = x0 - hx + rx, uy = y0 - hy + ry;              // unclamped luma position
+        const int x = clampi(ux, 0, a.w - 1), y = clampi(uy, 0, a.h - 1);
+        int r0 = y, r1 = y, c0 = x, c1 = x;
+        float wy0 = 1.f, wy1 = 0.f, wx0 = 1.f, wx1 = 0.f;
+        if (a.subh)
+        {
+            const int k = y >> 1;
+            if (y & 1) { r0 = k; r1 = clampi(k + 1, 0, a.ch - 1); wy0 = 0.75f; wy1 = 0.25f; }
+            else       { r0 = clampi(k - 1, 0, a.ch - 1); r1 = k; wy0 = 0.25f; wy1 = 0.75f; }
+        }
+        if (a.subw)
+        {
+            c0 = x >> 1; c1 = c0;
+            if (x & 1) { c1 = clampi(c0 + 1, 0, a.cw - 1); wx0 = 0.5f; wx1 = 0.5f; }
+        }
+        float uv[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+        {
+            const uint8_t *pl = a.src[1 + k];
+            const int pt = a.spitch[1 + k];
+            const float s00 = (sample<PIX>(pl, pt, c0, r0) - p.coff_in) * p.cmul_in;
+            const float s10 = (sample<PIX>(pl, pt, c0, r1) - p.coff_in) * p.cmul_in;
+            const float s01 = (sample<PIX>(pl, pt, c1, r0) - p.coff_in) * p.cmul_in;
+            const float s11 = (sample<PIX>(pl, pt, c1, r1) - p.coff_in) * p.cmul_in;
+            const float va = wy0 * s00 + wy1 * s10;
+            const float vb = wy0 * s01 + wy1 * s11;
+            uv[k] = wx0 * va + wx1 * vb;
+        }
+        const float yf = (sample<PIX>(a.src[0], a.spitch[0], x, y) - p.yoff_in) * p.ymul_in;
+        float o[3];
+        convert_px(p, yf, uv[0], uv[1], o);
+        s_u[ry][rx] = o[1];
+        s_v[ry][rx] = o[2];
+        if (ux >= x0 && ux < x0 + CS_TW && ux < a.w && uy >= y0 && uy < y0 + CS_TH && uy < a.h)
+            reinterpret_cast<PIX *>(a.dst[0] + (size_t)uy * a.dpitch[0])[ux] = (PIX)quant(o[0], p.ymul_out, p.yoff_out, p.vmax);
+    }
+    __syncthreads();
+
+    // phase 2: chroma of the tile, decimated from LDS (rows first, then columns)
+    const int ncx = CS_TW >> a.subw, ncy = CS_TH >> a.subh;
+    for (int i = tid; i < ncx * ncy; i += 256)
+    {
+        const int oy = i / ncx, ox = i - oy * ncx;
+        const int cx = (x0 >> a.subw) + ox, cy = (y0 >> a.subh) + oy;
+        if (cx >= a.cw || cy >= a.ch) continue;
+        const int rx = (ox << a.subw) + hx, ry = (oy << a.subh) + hy;
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+        {
+            float (*s)[CS_RW] = k ? s_v : s_u;
+            float col[3];
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+            {
+                const int xx = a.subw ? rx - 1 + j : rx;
+                col[j] = a.subh ? 0.125f * s[ry - 1][xx] + 0.375f * s[ry][xx] + 0.375f * s[ry + 1][xx] + 0.125f * s[ry + 2][xx]
+                                : s[ry][xx];
+            }
+            const float v = a.subw ? 0.25f * col[0] + 0.5f * col[1] + 0.25f * col[2] : col[1];
+            reinterpret_cast<PIX *>(a.dst[1 + k] + (size_t)cy * a.dpitch[1 + k])[cx] = (PIX)quant(v, p.cmul_out, p.coff_out, p.vmax);
+        }
+    }
+}
+
+// ---- plan construction on the host (double, host libm; the oracle builds the same tables) --------
+void mul3(double r[3][3], const double a[3][3], const double b[3][3])
+{
+    double t[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            t[i][j] = a[i][0] * b[0][j] + a[i][1] * b[1][j] + a[i][2] * b[2][j];
+    memcpy(r, t, sizeof(t));
+}
+
+void inv3(double r[3][3], const double m[3][3])
+{
+    const double c00 = m[1][1] * m[2][2] - m[1][2] * m[2][1];
+    const double c01 = m[1][2] * m[2][0] - m[1][0] * m[2][2];
+    const double c02 = m[1][0] * m[2][1] - m[1][1] * m[2][0];
+    const double det = m[0][0] * c00 + m[0][1] * c01 + m[0][2] * c02;
+    double t[3][3];
+    t[0][0] = c00 / det;
+    t[1][0] = c01 / det;
+    t[2][0] = c02 / det;
+    t[0][1] = (m[0][2] * m[2][1] - m[0][1] * m[2][2]) / det;
+    t[1][1] = (m[0][0] * m[2][2] - m[0][2] * m[2][0]) / det;
+    t[2][1] = (m[0][1] * m[2][0] - m[0][0] * m[2][1]) / det;
+    t[0][2] = (m[0][1] * m[1][2] - m[0][2] * m[1][1]) / det;
+    t[1][2] = (m[0][2] * m[1][0] - m[0][0] * m[1][2]) / det;
+    t[2][2] = (m[0][0] * m[1][1] - m[0][1] * m[1][0]) / det;
+    memcpy(r, t, sizeof(t));
+}
+
+// (Kr, Kb) of an AVCOL_SPC_* / HB_COLR_MAT_* id
+bool luma_coefficients(int id, double &kr, double &kb)
+{
+    switch (id)
+    {
+        case 1: kr = 0.2126; kb = 0.0722; return true;
+        case 4: kr = 0.30;   kb = 0.11;   return true;
+        case 5: case 6: kr = 0.299; kb = 0.114; return true;
+        case 7: kr = 0.212;  kb = 0.087;  return true;
+        case 9: kr = 0.2627; kb = 0.0593; return true;
+    }
+    return false;
+}
+
+// chromaticities (xr yr xg yg xb yb xw yw) of an AVCOL_PRI_* / HB_COLR_PRI_* id
+bool chromaticities(int id, double xy[8])
+{
+    struct Row { int id; double v[8]; };
+    static const Row rows[] = {
+        { 1,  { 0.640, 0.330, 0.300, 0.600, 0.150, 0.060, 0.3127, 0.3290 } },
+        { 4,  { 0.670, 0.330, 0.210, 0.710, 0.140, 0.080, 0.310,  0.316  } },
+        { 5,  { 0.640, 0.330, 0.290, 0.600, 0.150, 0.060, 0.3127, 0.3290 } },
+        { 6,  { 0.630, 0.340, 0.310, 0.595, 0.155, 0.070, 0.3127, 0.3290 } },
+        { 8,  { 0.681, 0.319, 0.243, 0.692, 0.145, 0.049, 0.310,  0.316  } },
+        { 9,  { 0.708, 0.292, 0.170, 0.797, 0.131, 0.046, 0.3127, 0.3290 } },
+        { 11, { 0.680, 0.320, 0.265, 0.690, 0.150, 0.060, 0.314,  0.351  } },
+        { 12, { 0.680, 0.320, 0.265, 0.690, 0.150, 0.060, 0.3127, 0.3290 } },
+        { 22, { 0.630, 0.340, 0.295, 0.605, 0.155, 0.077, 0.3127, 0.3290 } },
+    };
+    for (const Row &r : rows)
+        if (r.id == id) { memcpy(xy, r.v, sizeof(r.v)); return true; }
+    return false;
+}
+
+int primaries_class(int id) { return id == 7 ? 6 : id; }                            // smpte240m = smpte170m (SMPTE C)
+int transfer_class(int id) { return (id == 6 || id == 14 || id == 15) ? 1 : id; }   // 601 / 2020 share 709's curve
+
+void rgb_to_xyz(double m[3][3], const double xy[8])
+{
+    double p[3][3], pi[3][3];
+    for (int i = 0; i < 3; i++)
+    {
+        p[0][i] = xy[2 * i] / xy[2 * i + 1];
+        p[1][i] = 1.0;
+        p[2][i] = (1.0 - xy[2 * i] - xy[2 * i + 1]) / xy[2 * i + 1];
+    }
+    const double w[3] = { xy[6] / xy[7], 1.0, (1.0 - xy[6] - xy[7]) / xy[7] };
+    inv3(pi, p);
+    for (int i = 0; i < 3; i++)
+    {
+        const double s = pi[i][0] * w[0] + pi[i][1] * w[1] + pi[i][2] * w[2];
+        for (int r = 0; r < 3; r++)
+            m[r][i] = p[r][i] * s;
+    }
+}
+
+void gamut_matrix(double g[3][3], const double in_xy[8], const double out_xy[8])
+{
+    double a[3][3], b[3][3], bi[3][3];
+    rgb_to_xyz(a, in_xy);
+    rgb_to_xyz(b, out_xy);
+    inv3(bi, b);
+    if (in_xy[6] != out_xy[6] || in_xy[7] != out_xy[7])
+    {
+        // Bradford adaptation between the white points
+        static const double br[3][3] = { { 0.8951, 0.2664, -0.1614 }, { -0.7502, 1.7135, 0.0367 }, { 0.0389, -0.0685, 1.0296 } };
+        double bri[3][3], d[3][3] = { { 0 } }, t[3][3];
+        const double wi[3] = { in_xy[6] / in_xy[7], 1.0, (1.0 - in_xy[6] - in_xy[7]) / in_xy[7] };
+        const double wo[3] = { out_xy[6] / out_xy[7], 1.0, (1.0 - out_xy[6] - out_xy[7]) / out_xy[7] };
+        inv3(bri, br);
+        for (int i = 0; i < 3; i++)
+        {
+            const double ci = br[i][0] * wi[0] + br[i][1] * wi[1] + br[i][2] * wi[2];
+            const double co = br[i][0] * wo[0] + br[i][1] * wo[1] + br[i][2] * wo[2];
+            d[i][i] = co / ci;
+        }
+        mul3(t, d, br);
+        mul3(t, bri, t);
+        mul3(a, t, a);
+    }
+    mul3(g, bi, a);
+}
+
+// display-referred transfer functions (zimg's set); PQ / HLG only towards linear light
+bool to_linear(int cls, double v, double npl, double &out)
+{
+    switch (cls)
+    {
+        case 1:  out = pow(v, 2.4); return true;
+        case 4:  out = pow(v, 2.2); return true;
+        case 5:  out = pow(v, 2.8); return true;
+        case 7:  out = v < 0.0913 ? v / 4.0 : pow((v + 0.1115) / 1.1115, 1.0 / 0.45); return true;
+        case 8:  out = v; return true;
+        case 13: out = v <= 0.04045 ? v / 12.92 : pow((v + 0.055) / 1.055, 2.4); return true;
+        case 16:
+        {
+            const double m1 = 0.1593017578125, m2 = 78.84375, c1 = 0.8359375, c2 = 18.8515625, c3 = 18.6875;
+            const double p = pow(v, 1.0 / m2);
+            double num = p - c1;
+            if (num < 0.0) num = 0.0;
+            out = pow(num / (c2 - c3 * p), 1.0 / m1) * (10000.0 / npl);
+            return true;
+        }
+        case 18:
+        {
+            const double a = 0.17883277, b = 0.28466892, c = 0.55991073;
+            const double s = v <= 0.5 ? v * v / 3.0 : (exp((v - c) / a) + b) / 12.0;
+            out = pow(s, 1.2) * (1000.0 / npl);
+            return true;
+        }
+    }
+    return false;
+}
+
+bool to_gamma(int cls, double x, double &out)
+{
+    switch (cls)
+    {
+        case 1:  out = pow(x, 1.0 / 2.4); return true;
+        case 4:  out = pow(x, 1.0 / 2.2); return true;
+        case 5:  out = pow(x, 1.0 / 2.8); return true;
+        case 7:  out = x < 0.0228 ? 4.0 * x : 1.1115 * pow(x, 0.45) - 0.1115; return true;
+        case 8:  out = x; return true;
+        case 13: out = x <= 0.0031308 ? 12.92 * x : 1.055 * pow(x, 1.0 / 2.4) - 0.055; return true;
+    }
+    return false;
+}
+
+float hable_host(float in)
+{
+    const float a = 0.15f, b = 0.50f, c = 0.10f, d = 0.20f, e = 0.02f, f = 0.30f;
+    return (in * (in * a + b * c) + d * e) / (in * (in * a + b) + d * f) - e / f;
+}
+
+class ColorspaceFilter : public SimpleFilter
+{
+public:
+    ColorspaceFilter(hbhip_ctx *c, const hbhip_colorspace_params &p) : SimpleFilter(c), par(p) {}
+    ~ColorspaceFilter() override
+    {
+        if (d_lut_in) (void)hipFree(d_lut_in);
+        if (d_lut_out) (void)hipFree(d_lut_out);
+    }
+    int setup(int depth)
+    {
+        memset(&plan, 0, sizeof(plan));
+        const int s = depth - 8;
+        plan.vmax = (1 << depth) - 1;
+        double kr_i, kb_i, kr_o, kb_o;
+        if (!luma_coefficients(par.in_matrix, kr_i, kb_i) || !luma_coefficients(par.out_matrix, kr_o, kb_o)) return HBHIP_ERR_UNSUPPORTED;
+        if (par.in_range < 1 || par.in_range > 2 || par.out_range < 1 || par.out_range > 2) return HBHIP_ERR_UNSUPPORTED;
+        const bool lim_i = par.in_range == 1, lim_o = par.out_range == 1;
+        plan.yoff_in = lim_i ? (float)(16 << s) : 0.f;
+        plan.ymul_in = (float)(1.0 / (lim_i ? (double)(219 << s) : (double)plan.vmax));
+        plan.coff_in = (float)(1 << (depth - 1));
+        plan.cmul_in = (float)(1.0 / (lim_i ? (double)(224 << s) : (double)plan.vmax));
+        plan.yoff_out = lim_o ? (float)(16 << s) : 0.f;
+        plan.ymul_out = lim_o ? (float)(219 << s) : (float)plan.vmax;
+        plan.coff_out = (float)(1 << (depth - 1));
+        plan.cmul_out = lim_o ? (float)(224 << s) : (float)plan.vmax;
+
+        const double kg_i = 1.0 - kr_i - kb_i, kg_o = 1.0 - kr_o - kb_o;
+        const double mi[3][3] = { { 1.0, 0.0, 2.0 * (1.0 - kr_i) },
+                                  { 1.0, -2.0 * kb_i * (1.0 - kb_i) / kg_i, -2.0 * kr_i * (1.0 - kr_i) / kg_i },
+                                  { 1.0, 2.0 * (1.0 - kb_i), 0.0 } };
+        const double mo[3][3] = { { kr_o, kg_o, kb_o },
+                                  { -kr_o / (2.0 * (1.0 - kb_o)), -kg_o / (2.0 * (1.0 - kb_o)), 0.5 },
+                                  { 0.5, -kg_o / (2.0 * (1.0 - kr_o)), -kb_o / (2.0 * (1.0 - kr_o)) } };
+        const int tc_i = transfer_class(par.in_transfer), tc_o = transfer_class(par.out_transfer);
+        const int pc_i = primaries_class(par.in_prim), pc_o = primaries_class(par.out_prim);
+        plan.need_linear = tc_i != tc_o || pc_i != pc_o;
+        plan.tonemap = -1;
+        double md[3][3];
+        mul3(md, mo, mi);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++)
+            {
+                plan.m_in[i][j] = (float)mi[i][j];
+                plan.m_out[i][j] = (float)mo[i][j];
+                plan.m_direct[i][j] = (float)md[i][j];
+            }
+        if (!plan.need_linear) return HBHIP_OK;
+
+        plan.gamut = pc_i != pc_o;
+        if (plan.gamut)
+        {
+            double xi[8], xo[8], g[3][3];
+            if (!chromaticities(pc_i, xi) || !chromaticities(pc_o, xo)) return HBHIP_ERR_UNSUPPORTED;
+            gamut_matrix(g, xi, xo);
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++)
+                    plan.m_gamut[i][j] = (float)g[i][j];
+        }
+        std::vector<float> lin(LUT_N + 1), gam(LUT_N + 1);
+        for (int i = 0; i <= LUT_N; i++)
+        {
+            double a, b;
+            const double u = (double)i / LUT_N;
+            if (!to_linear(tc_i, u, par.npl, a) || !to_gamma(tc_o, u * u, b)) return HBHIP_ERR_UNSUPPORTED;
+            lin[i] = (float)a;
+            gam[i] = (float)b;
+        }
+        // tone mapping only on the PQ / HLG -> other-transfer path (colorspace.c:126-127)
+        if ((par.in_transfer == 16 || par.in_transfer == 18) && tc_i != tc_o)
+        {
+            plan.tonemap = par.tonemap;
+            float param = (float)par.param;              // NAN = vf_tonemap's default for the operator
+            const double peak = par.peak;
+            if (!(peak > 0)) return HBHIP_ERR_ARG;
+            switch (par.tonemap)
+            {
+                case HBHIP_TONEMAP_NONE: break;
+                case HBHIP_TONEMAP_LINEAR: case HBHIP_TONEMAP_CLIP: if (std::isnan(param)) param = 1.0f; break;
+                case HBHIP_TONEMAP_REINHARD: param = std::isnan(param) ? 1.0f : (1.0f - param) / param; break;
+                case HBHIP_TONEMAP_HABLE: plan.tm_a = hable_host((float)peak); break;
+                case HBHIP_TONEMAP_MOBIUS:
+                {
+                    if (std::isnan(param)) param = 0.3f;
+                    const float j = param;
+                    const float a = -j * j * (peak - 1.0f) / (j * j - 2.0f * j + peak);
+                    const float b = (j * j - 2.0f * j * peak + peak) / (peak - 1.0f > 1e-6 ? peak - 1.0f : 1e-6);
+                    plan.tm_a = a;
+                    plan.tm_b = b;
+                    plan.tm_c = (b * b + 2.0f * b * j + j * j) / (b - a);
+                    break;
+                }
+                default: return HBHIP_ERR_UNSUPPORTED;     // gamma: a powf per pixel, not built
+            }
+            plan.tm_param = param;
+            plan.tm_peak = (float)peak;
+        }
+        HBHIP_CHECK(ctx, hipMalloc((void **)&d_lut_in, sizeof(float) * lin.size()));
+        HBHIP_CHECK(ctx, hipMalloc((void **)&d_lut_out, sizeof(float) * gam.size()));
+        HBHIP_CHECK(ctx, hipMemcpyAsync(d_lut_in, lin.data(), sizeof(float) * lin.size(), hipMemcpyHostToDevice, ctx->stream));
+        HBHIP_CHECK(ctx, hipMemcpyAsync(d_lut_out, gam.data(), sizeof(float) * gam.size(), hipMemcpyHostToDevice, ctx->stream));
+        HBHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        plan.lut_in = d_lut_in;
+        plan.lut_out = d_lut_out;
+        return HBHIP_OK;
+    }
+    int process(DevPicture *in, DevPicture *out) override
+    {
+        CsArgs a;
+        for (int c = 0; c < 3; c++)
+        {
+            a.src[c] = in->plane[c]; a.dst[c] = out->plane[c];
+            a.spitch[c] = in->pitch[c]; a.dpitch[c] = out->pitch[c];
+        }
+        a.w = in->width[0]; a.h = in->height[0]; a.cw = in->width[1]; a.ch = in->height[1];
+        a.subw = in_geo.log2_cw; a.subh = in_geo.log2_ch;
+        const dim3 grid((a.w + CS_TW - 1) / CS_TW, (a.h + CS_TH - 1) / CS_TH);
+        if (in_geo.bps == 1) HBHIP_LAUNCH(ctx, "colorspace", colorspace_kernel<uint8_t>, grid, dim3(256), 0, a, plan);
+        else                 HBHIP_LAUNCH(ctx, "colorspace", colorspace_kernel<uint16_t>, grid, dim3(256), 0, a, plan);
+        HBHIP_CHECK(ctx, hipGetLastError());
+        return HBHIP_OK;
+    }
+    hbhip_colorspace_params par;
+    CsPlan plan;
+    float *d_lut_in = nullptr, *d_lut_out = nullptr;
+};
+
+} // namespace
+
+extern "C" int hbhip_colorspace_create(hbhip_ctx *ctx, const hbhip_colorspace_params *p, int width, int height,
+                                       int depth, int log2_chroma_w, int log2_chroma_h, hbhip_filter **out)
+{
+    if (!ctx || !p || !out) return HBHIP_ERR_ARG;
+    *out = nullptr;
+    if (depth != 8 && depth != 10 && depth != 12) return HBHIP_ERR_UNSUPPORTED;
+    if (log2_chroma_w < 0 || log2_chroma_w > 1 || log2_chroma_h < 0 || log2_chroma_h > 1) return HBHIP_ERR_UNSUPPORTED;
+    if (width < 2 || height < 2 || !(p->npl > 0)) return HBHIP_ERR_ARG;
+    (void)hipSetDevice(ctx->device);
+    ColorspaceFilter *f = new (std::nothrow) ColorspaceFilter(ctx, *p);
+    if (!f) return HBHIP_ERR_NOMEM;
+    PicGeometry g;
+    g.set(width, height, depth, log2_chroma_w, log2_chroma_h);
+    f->configure(g, g);
+    int rc = f->setup(depth);
+    if (rc != HBHIP_OK) { delete f; return rc; }
+    *out = f;
+    return HBHIP_OK;
+}

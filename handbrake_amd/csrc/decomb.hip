@@ -194,7 +194,7 @@ public:
         if (par.mode & M_EEDI2)
         {
             if (in_geo.bps != 1) return HBHIP_ERR_UNSUPPORTED;     // the EEDI2 passes are built for 8-bit samples only
-            if (par.post_processing != 0 && par.post_processing != 1) return HBHIP_ERR_UNSUPPORTED;
+            if (par.post_processing < 0 || par.post_processing > 3) return HBHIP_ERR_UNSUPPORTED;
             Eedi2Params ep = { par.magnitude_threshold, par.variance_threshold, par.laplacian_threshold,
                                par.dilation_threshold, par.erosion_threshold, par.noise_threshold,
                                par.maximum_search_distance, par.post_processing };

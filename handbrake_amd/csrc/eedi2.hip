@@ -21,6 +21,9 @@
 //   k_lattice_cand / k_lattice_resolve   eedi2_interpolate_lattice   :1148-1335
 //   k_post             eedi2_post_process :1349-1378 (the eedi2_bit_blit before it, :46-68, is folded into
 //                      the dir-map filter that follows it)
+//   k_blur1 / k_derivatives / k_blur_sqrt2 / k_post_corner   post-processing 2/3: eedi2_gaussian_blur1
+//                      :1391-1527, eedi2_calc_derivatives :1760-1848, eedi2_gaussian_blur_sqrt2 :1539-1748,
+//                      eedi2_post_process_corner :1864-1904
 //
 // interpolate_lattice rewrites its direction row in place and tests the value it
 // just wrote at x-1 (:1194), a left-to-right dependency.  Each row is given to one
@@ -1021,6 +1024,118 @@ __global__ void k_post(P3 P, int y0)
     if (any) st4(d, out, x, width);
 }
 
+// ------------------------------------------------------------------------------------------
+// Post-processing 2/3: junctions and corners (eedi2_template.c:1391-1904; decomb_template.c:432-441).
+// The reference's three plane threads share ONE set of derivative arrays (decomb.c:398-403), so
+// its own result is a data race; what is reproduced here is the defined order "Y, Cb, Cr one
+// after the other" on the same flat arrays (oracle/ref_wrap/wrap_decomb.c:hbref_eedi2_run_serial).
+// The flat layout matters: the horizontal pass of gaussian_blur_sqrt2 reads src[x+3] instead of
+// src[x-3] at x == width-2 (:1589) — the next row, the row padding, or whatever another plane
+// left there — so the planes run one after the other and index the arrays exactly as it does.
+// Both blurs are symmetric FIRs whose out-of-range taps are mirrored about the centre (written
+// in the reference as doubled coefficients on the surviving side).
+struct CornerArgs
+{
+    uint8_t *src, *tmp;          // srcp (blurred in place) and tmpp of one plane
+    int     *c[3];               // cx2, cy2, cxy (shared by the planes)
+    int     *t[3];               // tmpc, one per array (the reference reuses one; nothing of it outlives a blur)
+    int      pitch, width, height;   // half-height geometry of the plane
+};
+
+__device__ __forceinline__ int fold_tap(int centre, int d, int n, int &hi)
+{
+    int lo = centre - d;
+    hi = centre + d;
+    if (lo < 0) lo = hi;
+    if (hi >= n) hi = lo;
+    return lo;
+}
+
+// eedi2_gaussian_blur1 (:1391-1527), one axis per launch: VERT = false src -> tmp, true tmp -> src
+template <bool VERT>
+__global__ void k_blur1(CornerArgs A)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= A.width || y >= A.height) return;
+    const uint8_t *in = VERT ? A.tmp : A.src;
+    uint8_t *out = VERT ? A.src : A.tmp;
+    const int W[4] = { 26152, 15862, 3539, 291 };
+    int acc = in[(size_t)y * A.pitch + x] * W[0] + 32768;
+#pragma unroll
+    for (int d = 1; d <= 3; d++)
+    {
+        int hi;
+        const int lo = fold_tap(VERT ? y : x, d, VERT ? A.height : A.width, hi);
+        const size_t il = VERT ? (size_t)lo * A.pitch + x : (size_t)y * A.pitch + lo;
+        const size_t ih = VERT ? (size_t)hi * A.pitch + x : (size_t)y * A.pitch + hi;
+        acc += ((int)in[il] + (int)in[ih]) * W[d];
+    }
+    out[(size_t)y * A.pitch + x] = (uint8_t)(acc >> 16);
+}
+
+// eedi2_calc_derivatives (:1760-1848): differences against clamped neighbours
+__global__ void k_derivatives(CornerArgs A)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= A.width || y >= A.height) return;
+    const uint8_t *s = A.src + (size_t)y * A.pitch;
+    const uint8_t *up = A.src + (size_t)max(y - 1, 0) * A.pitch, *dn = A.src + (size_t)min(y + 1, A.height - 1) * A.pitch;
+    const int ix = (int)s[min(x + 1, A.width - 1)] - (int)s[max(x - 1, 0)];
+    const int iy = (int)up[x] - (int)dn[x];
+    const size_t at = (size_t)y * A.pitch + x;
+    A.c[0][at] = (ix * ix) >> 1;
+    A.c[1][at] = (iy * iy) >> 1;
+    A.c[2][at] = (ix * iy) >> 1;
+}
+
+// eedi2_gaussian_blur_sqrt2 (:1539-1748), one axis per launch, the three arrays in blockIdx.z:
+// VERT = false c -> t (>> 16, with the x+3 read of :1589), true t -> c (>> 18)
+template <bool VERT>
+__global__ void k_blur_sqrt2(CornerArgs A)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= A.width || y >= A.height) return;
+    const int *in = VERT ? A.t[blockIdx.z] : A.c[blockIdx.z];
+    int *out = VERT ? A.c[blockIdx.z] : A.t[blockIdx.z];
+    const int W[5] = { 18508, 14415, 6809, 1951, 339 };
+    int acc = in[(size_t)y * A.pitch + x] * W[0] + 32768;
+#pragma unroll
+    for (int d = 1; d <= 4; d++)
+    {
+        int hi;
+        int lo = fold_tap(VERT ? y : x, d, VERT ? A.height : A.width, hi);
+        if (!VERT && d == 3 && x == A.width - 2) lo = hi = x + 3;
+        const size_t il = VERT ? (size_t)lo * A.pitch + x : (size_t)y * A.pitch + lo;
+        const size_t ih = VERT ? (size_t)hi * A.pitch + x : (size_t)y * A.pitch + hi;
+        acc += (in[il] + in[ih]) * W[d];
+    }
+    out[(size_t)y * A.pitch + x] = acc >> (VERT ? 18 : 16);
+}
+
+// eedi2_post_process_corner (:1864-1904): msk = tmp2p2, dst = dst2p (row y from rows y+-1, which
+// belong to the kept field and are never written here).  The response is evaluated in double, in
+// the reference's operation order (int products, 0.09 * s * s, one subtraction, truncation).
+__global__ void k_post_corner(CornerArgs A, const uint8_t *msk, uint8_t *dst, int field, int height)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y * blockDim.y + threadIdx.y;
+    const int y = 8 - field + 2 * r;
+    if (x < 4 || x >= A.width - 4 || y >= height - 7) return;
+    const size_t at = (size_t)y * A.pitch + x;
+    const int m = msk[at];
+    if (m == PEAK || m == NEUTRAL) return;
+    bool hit = false;
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+    {
+        const size_t i = (size_t)(3 + r + k) * A.pitch + x;
+        const int a = A.c[0][i], b = A.c[1][i], c = A.c[2][i];
+        const double s = (double)(a + b);
+        const double resp = (double)(a * b - c * c) - 0.09 * s * s;
+        hit |= (int)resp > 775;
+    }
+    if (hit) dst[at] = (uint8_t)(((int)dst[at - A.pitch] + (int)dst[at + A.pitch] + 1) >> 1);
+}
+
 } // namespace
 
 // ------------------------------------------------------------------- engine
@@ -1039,6 +1154,11 @@ Eedi2Engine::~Eedi2Engine()
     if (work_list_) (void)hipFree(work_list_);
     if (work_count_) (void)hipFree(work_count_);
     if (cand_) (void)hipFree(cand_);
+    for (int i = 0; i < 3; i++)
+    {
+        if (deriv_[i]) (void)hipFree(deriv_[i]);
+        if (deriv_tmp_[i]) (void)hipFree(deriv_tmp_[i]);
+    }
 }
 
 int Eedi2Engine::alloc_frame(EediFrame &f, int width, int height)
@@ -1066,7 +1186,7 @@ int Eedi2Engine::init()
     // of rows (upscale_by_2 writes 2*ceil(h/2) rows); refuse instead of guessing
     if (geo_.height % (2 << geo_.log2_ch) != 0 || geo_.height < 16 || geo_.width < 16)
         return HBHIP_ERR_UNSUPPORTED;
-    if (par_.post_processing != 0 && par_.post_processing != 1) return HBHIP_ERR_UNSUPPORTED;
+    if (par_.post_processing < 0 || par_.post_processing > 3) return HBHIP_ERR_UNSUPPORTED;
     for (auto &f : half_)
     {
         int rc = alloc_frame(f, geo_.width, geo_.height / 2);      // decomb.c:291-296
@@ -1092,6 +1212,20 @@ int Eedi2Engine::init()
     cand_plane_stride_ = cand_pitch_ * ((full_[0].height[0] + 1) / 2);
     HBHIP_CHECK(ctx_, hipMalloc((void **)&cand_, sizeof(uint32_t) * (size_t)cand_plane_stride_ * 3));
     if (geo_.width >= (1 << 14) || geo_.height >= (1 << 14)) return HBHIP_ERR_UNSUPPORTED;
+    if (par_.post_processing > 1)
+    {
+        // cx2, cy2, cxy: height * stride(luma) ints each, shared by the planes (decomb.c:398-403);
+        // zeroed once — the reference mallocs them, and one element per row is read before anything
+        // wrote it (eedi2_template.c:1589)
+        const size_t n = sizeof(int) * (size_t)geo_.height * full_[0].stride[0];
+        for (int i = 0; i < 3; i++)
+        {
+            HBHIP_CHECK(ctx_, hipMalloc((void **)&deriv_[i], n));
+            HBHIP_CHECK(ctx_, hipMemsetAsync(deriv_[i], 0, n, ctx_->stream));
+            HBHIP_CHECK(ctx_, hipMalloc((void **)&deriv_tmp_[i], n));
+            HBHIP_CHECK(ctx_, hipMemsetAsync(deriv_tmp_[i], 0, n, ctx_->stream));
+        }
+    }
     HBHIP_CHECK(ctx_, hipStreamSynchronize(ctx_->stream));
     return HBHIP_OK;
 }
@@ -1244,6 +1378,27 @@ int Eedi2Engine::enqueue_passes(int tff, int sel)
         HBHIP_LAUNCH(ctx_, "eedi2_expand_dir_map_2x", k_dir_map, grid_for(dst2p, false), blk, 0, P, 2, y0, 1);
         bind(P.a, tmp2p); bind(P.b, tmp2p2); bind(P.c, dst2p);
         HBHIP_LAUNCH(ctx_, "eedi2_post_process", k_post, grid4_for(dst2p, false), blk, 0, P, y0);
+    }
+    if (par_.post_processing == 2 || par_.post_processing == 3)
+    {
+        // junctions and corners, plane after plane (see CornerArgs)
+        for (int c = 0; c < 3; c++)
+        {
+            CornerArgs A;
+            A.src = srcp.plane[c]; A.tmp = tmpp.plane[c];
+            for (int i = 0; i < 3; i++) { A.c[i] = deriv_[i]; A.t[i] = deriv_tmp_[i]; }
+            A.pitch = srcp.stride[c]; A.width = srcp.width[c]; A.height = srcp.height[c];
+            const dim3 g1((A.width + 63) / 64, (A.height + 3) / 4, 1), g3(g1.x, g1.y, 3);
+            HBHIP_LAUNCH(ctx_, "eedi2_gaussian_blur1_h", k_blur1<false>, g1, blk, 0, A);
+            HBHIP_LAUNCH(ctx_, "eedi2_gaussian_blur1_v", k_blur1<true>, g1, blk, 0, A);
+            HBHIP_LAUNCH(ctx_, "eedi2_calc_derivatives", k_derivatives, g1, blk, 0, A);
+            HBHIP_LAUNCH(ctx_, "eedi2_gaussian_blur_sqrt2_h", k_blur_sqrt2<false>, g3, blk, 0, A);
+            HBHIP_LAUNCH(ctx_, "eedi2_gaussian_blur_sqrt2_v", k_blur_sqrt2<true>, g3, blk, 0, A);
+            const int rows = (dst2p.height[c] - 7 - (8 - tff) + 1) / 2;      // y = 8-field, 10-field, ... < height-7
+            if (rows > 0)
+                HBHIP_LAUNCH(ctx_, "eedi2_post_process_corner", k_post_corner, dim3((A.width + 63) / 64, (rows + 3) / 4, 1), blk, 0, A,
+                             (const uint8_t *)tmp2p2.plane[c], dst2p.plane[c], tff, dst2p.height[c]);
+        }
     }
     HBHIP_CHECK(ctx_, hipGetLastError());
     return HBHIP_OK;

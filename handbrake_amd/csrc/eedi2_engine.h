@@ -58,4 +58,6 @@ private:
     int        *work_count_ = nullptr;
     uint32_t   *cand_ = nullptr;        // interpolate_lattice: per-pixel candidate outcomes
     int         cand_pitch_ = 0, cand_plane_stride_ = 0;
+    int        *deriv_[3] = {nullptr, nullptr, nullptr};       // post-processing 2/3: cx2, cy2, cxy (decomb.c:398-403)
+    int        *deriv_tmp_[3] = {nullptr, nullptr, nullptr};   //                      tmpc, one per array
 };

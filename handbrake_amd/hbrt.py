@@ -173,6 +173,14 @@ class Chain:
             pass
 
 
+def set_source_color(prim: int = 1, transfer: int = 1, matrix: int = 1, color_range: int = 1):
+    """Colour description (init->color_*) of the source of chains opened from now on."""
+    rt = runtime()
+    rt.hbh_set_source_color.argtypes = [C.c_int] * 4
+    rt.hbh_set_source_color.restype = None
+    rt.hbh_set_source_color(prim, transfer, matrix, color_range)
+
+
 def run_stream(lib, stages, frames, flags: int = 0x10, pix_fmt: int = AV_PIX_FMT_YUV420P,
                duration: int = 3003, combed=None):
     """Push every frame then EOF; return all OutFrames in output order.

@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "hbhip_comb_detect_create", "hbhip_comb_detect_set_gamma_lut", "hbhip_comb_detect_store",
     "hbhip_comb_detect_store_dev",
     "hbhip_comb_detect_classify",
-    "hbhip_rotate_create", "hbhip_grayscale_create", "hbhip_cropscale_create",
+    "hbhip_rotate_create", "hbhip_grayscale_create", "hbhip_cropscale_create", "hbhip_colorspace_create",
 ]
 
 
@@ -386,6 +386,24 @@ def cropscale_device_filter(ctx, width, height, out_w, out_h, crop=(0, 0, 0, 0))
     return _create("hbhip_cropscale_create", ctx,
                    [C.c_void_p, C.POINTER(CropScaleParams)] + [C.c_int] * 5 + [C.POINTER(C.c_void_p)],
                    ctx.h, C.byref(p), width, height, 8, 1, 1)
+
+
+class ColorspaceParams(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("in_prim", "in_transfer", "in_matrix", "in_range",
+                                       "out_prim", "out_transfer", "out_matrix", "out_range", "tonemap")] + \
+               [(n, C.c_double) for n in ("param", "desat", "npl", "peak")]
+
+
+TONEMAPS = {"none": 0, "linear": 1, "gamma": 2, "clip": 3, "reinhard": 4, "hable": 5, "mobius": 6}
+
+
+def colorspace_device_filter(ctx, width, height, src, dst, tonemap="hable", param=float("nan"), desat=0.0,
+                             npl=100.0, peak=10.0, depth=8, log2_cw=1, log2_ch=1):
+    """src / dst = (primaries, transfer, matrix, range) in AVCOL_* numbers, range 1 = tv, 2 = pc."""
+    p = ColorspaceParams(*src, *dst, TONEMAPS[tonemap], param, desat, npl, peak)
+    return _create("hbhip_colorspace_create", ctx,
+                   [C.c_void_p, C.POINTER(ColorspaceParams)] + [C.c_int] * 5 + [C.POINTER(C.c_void_p)],
+                   ctx.h, C.byref(p), width, height, depth, log2_cw, log2_ch)
 
 
 def decomb_push_dev(flt, frame: DevFrame, tag: int, flags: int = 0x0008, combed: int = 2):

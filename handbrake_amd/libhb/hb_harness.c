@@ -39,6 +39,13 @@ static hb_filter_object_t *clone_filter(const hb_filter_object_t *proto, const c
     return f;
 }
 
+static int g_src_color[4] = { 1, 1, 1, 1 };
+
+void hbh_set_source_color(int prim, int transfer, int matrix, int range)
+{
+    g_src_color[0] = prim; g_src_color[1] = transfer; g_src_color[2] = matrix; g_src_color[3] = range;
+}
+
 hbh_chain_t *hbh_chain_open(int nstages, void *const *protos, const char *const *settings,
                             int pix_fmt, int width, int height,
                             int vrate_num, int vrate_den)
@@ -59,10 +66,10 @@ hbh_chain_t *hbh_chain_open(int nstages, void *const *protos, const char *const 
     init.vrate.den = vrate_den;
     init.time_base.num = 1;
     init.time_base.den = 90000;
-    init.color_prim = 1;
-    init.color_transfer = 1;
-    init.color_matrix = 1;
-    init.color_range = 1;
+    init.color_prim = g_src_color[0];
+    init.color_transfer = g_src_color[1];
+    init.color_matrix = g_src_color[2];
+    init.color_range = g_src_color[3];
     init.chroma_location = 1;
     c->init_in = init;
 

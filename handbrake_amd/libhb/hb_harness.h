@@ -32,6 +32,9 @@ typedef struct hbh_frame_info_s
 hbh_chain_t *hbh_chain_open(int nstages, void *const *protos, const char *const *settings,
                             int pix_fmt, int width, int height,
                             int vrate_num, int vrate_den);
+/* Colour description of the source for chains opened from now on (init->color_*; AVCOL_* numbers,
+ * range 1 = tv, 2 = pc).  Default bt709 / tv. */
+void hbh_set_source_color(int prim, int transfer, int matrix, int range);
 int  hbh_chain_push(hbh_chain_t *c, const uint8_t *const plane[3], const int stride[3],
                     int64_t start, int64_t stop, int flags, int combed);
 int  hbh_chain_push_eof(hbh_chain_t *c);

@@ -80,6 +80,7 @@ extern hb_filter_object_t hb_filter_denoise_hip;
 extern hb_filter_object_t hb_filter_crop_scale_hip;
 extern hb_filter_object_t hb_filter_grayscale_hip;
 extern hb_filter_object_t hb_filter_rotate_hip;
+extern hb_filter_object_t hb_filter_colorspace_hip;
 extern hb_filter_object_t hb_filter_decomb_hip;
 extern hb_filter_object_t hb_filter_comb_detect_hip;
 

@@ -124,11 +124,31 @@ def random_frame(w: int, h: int, t: int, cfg: int = 9):
     return yp, cb, cr
 
 
+def corners_frame(w: int, h: int, t: int, cfg: int = 11):
+    """Moving diamonds (luma) and discs (chroma) with field-shifted motion: plenty of junctions and
+    corners on edge pixels, which is what EEDI2's post-processing 2/3 reacts to."""
+    cw, ch = _chroma_dims(w, h)
+    ny, ncb, ncr = _noise(frame_seed(cfg, t), [(h, w), (ch, cw), (ch, cw)], 3)
+    x = np.arange(w, dtype=np.int64)[None, :]
+    y = np.arange(h, dtype=np.int64)[:, None]
+    ft = 2 * t + (y & 1)
+    xs = x + 4 * ft
+    luma = np.where((((xs + y) // 16) + ((xs - y) // 16)) & 1, 210, 50) + ny
+    cx = np.arange(cw, dtype=np.int64)[None, :]
+    cy = np.arange(ch, dtype=np.int64)[:, None]
+    cxs = cx + 2 * (2 * t + (cy & 1))
+    disc = ((cxs % 40 - 20) ** 2 + (cy % 40 - 20) ** 2) < 150
+    cb = np.where(disc, 220, 30) + ncb
+    cr = np.where(disc, 40, 200) + ncr
+    clip = lambda a: np.clip(a, 0, 255).astype(np.uint8)
+    return clip(luma), clip(cb), clip(cr)
+
+
 def stream(model: str, w: int, h: int, nframes: int, cfg: int | None = None, depth: int = 8):
     """List of (Y, Cb, Cr) tuples.  depth 10 / 12: uint16 planes - the 8-bit model in the high
     bits, the low depth-8 bits drawn from the same LCG (so wider samples carry real detail)."""
     gen = {"progressive": progressive_frame, "interlaced": interlaced_frame,
-           "random": random_frame}[model]
+           "random": random_frame, "corners": corners_frame}[model]
     kw = {} if cfg is None else {"cfg": cfg}
     frames = [gen(w, h, t, **kw) for t in range(nframes)]
     if depth == 8:
@@ -148,4 +168,4 @@ def stream(model: str, w: int, h: int, nframes: int, cfg: int | None = None, dep
 
 
 def flags_for(model: str) -> int:
-    return PIC_FLAG_TOP_FIELD_FIRST if model == "interlaced" else PIC_FLAG_PROGRESSIVE_FRAME
+    return PIC_FLAG_TOP_FIELD_FIRST if model in ("interlaced", "corners") else PIC_FLAG_PROGRESSIVE_FRAME

@@ -248,6 +248,26 @@ typedef struct hbhip_cropscale_params
 } hbhip_cropscale_params;
 int hbhip_cropscale_create(hbhip_ctx *ctx, const hbhip_cropscale_params *p, int width, int height,
                            int depth, int log2_chroma_w, int log2_chroma_h, hbhip_filter **out);
+/* The zscale [-> format=gbrpf32le -> tonemap] -> zscale -> format graph colorspace_init builds
+ * (colorspace.c:126-193): matrix / range / transfer / primaries conversion, with tone mapping
+ * when the source transfer is SMPTE 2084 or ARIB STD-B67 and the transfer changes.  Colour ids
+ * are the AVCOL_* = HB_COLR_* numbers (common.h), range 1 = tv, 2 = pc; tonemap ids are
+ * vf_tonemap's.  Arithmetic pinned to oracle/colorspace_oracle.c only (parity unpinned).
+ * 8/10/12-bit, 4:2:0 / 4:2:2 / 4:4:4.  HBHIP_ERR_UNSUPPORTED for conversions outside its tables. */
+enum { HBHIP_TONEMAP_NONE = 0, HBHIP_TONEMAP_LINEAR = 1, HBHIP_TONEMAP_GAMMA = 2, HBHIP_TONEMAP_CLIP = 3,
+       HBHIP_TONEMAP_REINHARD = 4, HBHIP_TONEMAP_HABLE = 5, HBHIP_TONEMAP_MOBIUS = 6 };
+typedef struct hbhip_colorspace_params
+{
+    int in_prim, in_transfer, in_matrix, in_range;       /* init->color_* (colorspace.c:96-99)      */
+    int out_prim, out_transfer, out_matrix, out_range;   /* after the settings are applied (:101-120) */
+    int tonemap;                                         /* HBHIP_TONEMAP_*; "hable" by default (:151) */
+    double param;                                        /* NAN = the operator's default (:154-157)  */
+    double desat;                                        /* carried; FFmpeg disables it on GBR frames */
+    double npl;                                          /* nominal peak luminance, 100 (:74)        */
+    double peak;                                         /* determine_signal_peak (:37-49)           */
+} hbhip_colorspace_params;
+int hbhip_colorspace_create(hbhip_ctx *ctx, const hbhip_colorspace_params *p, int width, int height,
+                            int depth, int log2_chroma_w, int log2_chroma_h, hbhip_filter **out);
 
 #ifdef __cplusplus
 }

@@ -1,5 +1,5 @@
 /* eedi2_oracle.c — CPU restatement of EEDI2 as decomb drives it (8-bit,
- * post-processing 0/1).  TEST INFRASTRUCTURE ONLY (see oracle.h).
+ * post-processing 0..3).  TEST INFRASTRUCTURE ONLY (see oracle.h).
  *
  * Follows /root/reference/libhb/templates/eedi2_template.c pass by pass and the
  * pass order of eedi2_interpolate_plane (templates/decomb_template.c:366-441).
@@ -14,6 +14,14 @@
  *     neighbouring row / plane / padding (e.g. :395-447, :1194-1195, :1296-1310).
  *     The nine scratch frames are therefore laid out byte-for-byte as
  *     hb_frame_buffer_init lays them out (fifo.c:820-881) inside zeroed guards.
+ *   - post-processing 2/3: the three plane threads of the reference share ONE set of
+ *     derivative arrays (decomb.c:398-403, decomb_template.c:380-383), so its own
+ *     output is a data race; the semantics pinned here (and by hbref_eedi2_run_serial
+ *     in ref_wrap/wrap_decomb.c) are "planes one after the other, Y Cb Cr", arrays
+ *     zeroed once at start (the reference mallocs them: fresh pages read as 0);
+ *   - gaussian_blur_sqrt2's horizontal pass reads src[x+3] instead of src[x-3] at
+ *     x == width-2 (:1589): an element of the next row / of the padding / of whatever
+ *     another plane left in the shared array.  Kept, on the same flat arrays.
  */
 #include "oracle.h"
 
@@ -41,6 +49,7 @@ struct orc_eedi2
     int width, height;
     frame_t half[4];   /* SRCPF MSKPF TMPPF DSTPF */
     frame_t full[5];   /* DST2PF TMP2PF2 MSK2PF TMP2PF DST2MPF */
+    int *cx2, *cy2, *cxy, *tmpc;   /* decomb.c:398-403: height * stride(luma) ints each, shared by the planes */
 };
 
 static inline int iabs(int v) { return v < 0 ? -v : v; }
@@ -71,6 +80,14 @@ orc_eedi2_t *orc_eedi2_new(int width, int height, const orc_eedi2_params_t *p)
     e->height = height;
     for (int i = 0; i < 4; i++) frame_alloc(&e->half[i], width, height / 2);   /* decomb.c:291-296 */
     for (int i = 0; i < 5; i++) frame_alloc(&e->full[i], width, height);       /* :299-303 */
+    if (p->post_processing > 1)
+    {
+        const size_t n = (size_t)height * e->full[0].stride[0];
+        e->cx2 = calloc(n, sizeof(int));
+        e->cy2 = calloc(n, sizeof(int));
+        e->cxy = calloc(n, sizeof(int));
+        e->tmpc = calloc(n, sizeof(int));
+    }
     return e;
 }
 
@@ -79,6 +96,7 @@ void orc_eedi2_free(orc_eedi2_t *e)
     if (!e) return;
     for (int i = 0; i < 4; i++) free(e->half[i].alloc);
     for (int i = 0; i < 5; i++) free(e->full[i].alloc);
+    free(e->cx2); free(e->cy2); free(e->cxy); free(e->tmpc);
     free(e);
 }
 
@@ -653,6 +671,134 @@ static void post_process(const uint8_t *nmsk, const uint8_t *omsk, uint8_t *dst,
     }
 }
 
+/* ---- post-processing 2/3: junctions and corners (eedi2_template.c:1391-1904) ------------ */
+
+/* Both blurs are symmetric FIR filters whose taps, where they would fall outside the row /
+ * column, are replaced by their mirror image about the centre (the reference writes this as
+ * doubled coefficients on the surviving side: 582 = 2*291 ... :1399-1424, :1549-1594). */
+static inline int fold(int centre, int d, int n, int *partner)
+{
+    int lo = centre - d, hi = centre + d;
+    if (lo < 0) lo = hi;
+    if (hi >= n) hi = lo;
+    *partner = hi;
+    return lo;
+}
+
+/* eedi2_gaussian_blur1 (:1391-1527): 7 taps, src -> tmp horizontally, tmp -> dst vertically */
+static void gaussian_blur1(const uint8_t *src, uint8_t *tmp, uint8_t *dst, int pitch, int width, int height)
+{
+    static const int W[4] = { 26152, 15862, 3539, 291 };
+    for (int y = 0; y < height; y++)
+    {
+        const uint8_t *s = src + (size_t)y * pitch;
+        uint8_t *t = tmp + (size_t)y * pitch;
+        for (int x = 0; x < width; x++)
+        {
+            int acc = s[x] * W[0] + 32768;
+            for (int d = 1; d <= 3; d++)
+            {
+                int hi, lo = fold(x, d, width, &hi);
+                acc += (s[lo] + s[hi]) * W[d];
+            }
+            t[x] = (uint8_t)(acc >> 16);
+        }
+    }
+    for (int y = 0; y < height; y++)
+    {
+        uint8_t *o = dst + (size_t)y * pitch;
+        for (int x = 0; x < width; x++)
+        {
+            int acc = tmp[(size_t)y * pitch + x] * W[0] + 32768;
+            for (int d = 1; d <= 3; d++)
+            {
+                int hi, lo = fold(y, d, height, &hi);
+                acc += (tmp[(size_t)lo * pitch + x] + tmp[(size_t)hi * pitch + x]) * W[d];
+            }
+            o[x] = (uint8_t)(acc >> 16);
+        }
+    }
+}
+
+/* eedi2_calc_derivatives (:1760-1848): central differences with clamped neighbours
+ * (left/right difference one-sided at the row ends, up/down one-sided at the first/last row) */
+static void calc_derivatives(const uint8_t *src, int pitch, int width, int height, int *x2, int *y2, int *xy)
+{
+    for (int y = 0; y < height; y++)
+    {
+        const uint8_t *s = src + (size_t)y * pitch;
+        const uint8_t *up = src + (size_t)imax(y - 1, 0) * pitch;
+        const uint8_t *dn = src + (size_t)imin(y + 1, height - 1) * pitch;
+        for (int x = 0; x < width; x++)
+        {
+            const int ix = s[imin(x + 1, width - 1)] - s[imax(x - 1, 0)];
+            const int iy = up[x] - dn[x];
+            x2[(size_t)y * pitch + x] = (ix * ix) >> 1;
+            y2[(size_t)y * pitch + x] = (iy * iy) >> 1;
+            xy[(size_t)y * pitch + x] = (ix * iy) >> 1;
+        }
+    }
+}
+
+/* eedi2_gaussian_blur_sqrt2 (:1539-1748): 9 taps on an int array, >>16 then >>18 */
+static void gaussian_blur_sqrt2(const int *src, int *tmp, int *dst, int pitch, int width, int height)
+{
+    static const int W[5] = { 18508, 14415, 6809, 1951, 339 };
+    for (int y = 0; y < height; y++)
+    {
+        const int *s = src + (size_t)y * pitch;
+        int *t = tmp + (size_t)y * pitch;
+        for (int x = 0; x < width; x++)
+        {
+            int acc = s[x] * W[0] + 32768;
+            for (int d = 1; d <= 4; d++)
+            {
+                int hi, lo = fold(x, d, width, &hi);
+                if (d == 3 && x == width - 2) lo = hi = x + 3;       /* :1589 reads x+3, past the row */
+                acc += (s[lo] + s[hi]) * W[d];
+            }
+            t[x] = acc >> 16;
+        }
+    }
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++)
+        {
+            int acc = tmp[(size_t)y * pitch + x] * W[0] + 32768;
+            for (int d = 1; d <= 4; d++)
+            {
+                int hi, lo = fold(y, d, height, &hi);
+                acc += (tmp[(size_t)lo * pitch + x] + tmp[(size_t)hi * pitch + x]) * W[d];
+            }
+            dst[(size_t)y * pitch + x] = acc >> 18;
+        }
+}
+
+/* eedi2_post_process_corner (:1864-1904): Harris-style response on the blurred derivative
+ * products of the two field rows around an interpolated row; > 775 -> vertical average */
+static void post_process_corner(const int *x2, const int *y2, const int *xy, int pitch, const uint8_t *msk,
+                                uint8_t *dst, int field, int width, int height)
+{
+    int drow = 3;
+    for (int y = 8 - field; y < height - 7; y += 2, drow++)
+    {
+        const uint8_t *m = msk + (size_t)y * pitch;
+        uint8_t *d = dst + (size_t)y * pitch;
+        for (int x = 4; x < width - 4; x++)
+        {
+            if (m[x] == PEAK || m[x] == NEUTRAL) continue;
+            int hit = 0;
+            for (int k = 0; k < 2; k++)
+            {
+                const size_t i = (size_t)(drow + k) * pitch + x;
+                const int a = x2[i], b = y2[i], c = xy[i];
+                const int r = (int)(a * b - c * c - 0.09 * (a + b) * (a + b));
+                hit |= r > 775;
+            }
+            if (hit) d[x] = (uint8_t)((d[x - pitch] + d[x + pitch] + 1) >> 1);
+        }
+    }
+}
+
 /* ---- sequencing (decomb_template.c:366-473) ------------------------------------------ */
 static void run_plane(orc_eedi2_t *e, int c, int tff, int npasses)
 {
@@ -688,6 +834,15 @@ static void run_plane(orc_eedi2_t *e, int c, int tff, int npasses)
         STEP(dir_map_pass_2x(msk2p, tmp2p, dst2mp, pitch, tff, width, height, 0));
         STEP(dir_map_pass_2x(msk2p, dst2mp, tmp2p, pitch, tff, width, height, 1));
         STEP(post_process(tmp2p, tmp2p2, dst2p, pitch, tff, width, height));
+    }
+    if (p->post_processing == 2 || p->post_processing == 3)
+    {
+        STEP(gaussian_blur1(srcp, tmpp, srcp, pitch, width, hh));
+        STEP(calc_derivatives(srcp, pitch, width, hh, e->cx2, e->cy2, e->cxy));
+        STEP(gaussian_blur_sqrt2(e->cx2, e->tmpc, e->cx2, pitch, width, hh));
+        STEP(gaussian_blur_sqrt2(e->cy2, e->tmpc, e->cy2, pitch, width, hh));
+        STEP(gaussian_blur_sqrt2(e->cxy, e->tmpc, e->cxy, pitch, width, hh));
+        STEP(post_process_corner(e->cx2, e->cy2, e->cxy, pitch, tmp2p2, dst2p, tff, width, height));
     }
 #undef STEP
 }

@@ -229,6 +229,19 @@ void orc_cropscale_plane(const uint8_t *src, int sstride, int crop_x, int crop_y
  * `dst_dim` outputs `taps` (index, weight) pairs; returns taps. idx/coef sized dst_dim*64. */
 int orc_lanczos_table(int src_dim, int dst_dim, double shift, int *idx, double *coef);
 
+/* ---- colorspace (colorspace.c:20-207 -> zscale / tonemap; PARITY UNPINNED, colorspace_oracle.c) -- */
+typedef struct
+{
+    int in_prim, in_transfer, in_matrix, in_range;       /* AVCOL_* = HB_COLR_* numbers; range 1 = tv, 2 = pc */
+    int out_prim, out_transfer, out_matrix, out_range;
+    int tonemap;                                         /* vf_tonemap: 0 none 1 linear 2 gamma 3 clip 4 reinhard 5 hable 6 mobius */
+    double param, desat, npl, peak;                      /* param NAN = the operator's default; desat ignored (see .c) */
+} orc_colorspace_params_t;
+/* One 3-plane frame, 8..16-bit samples (uint16 above 8), chroma subsampled by subw/subh (0 or 1).
+ * Returns 0, or -1 for a conversion the restatement does not cover. */
+int orc_colorspace_frame(const orc_colorspace_params_t *cs, const void *const src[3], const int sstride[3],
+                         void *const dst[3], const int dstride[3], int w, int h, int depth, int subw, int subh);
+
 #ifdef __cplusplus
 }
 #endif

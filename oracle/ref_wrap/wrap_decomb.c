@@ -19,6 +19,15 @@ HBREF_EXPORT void *hbref_eedi2_new(int width, int height, const char *settings)
         free(f);
         return NULL;
     }
+    /* post-processing 2/3: the derivative arrays come from malloc (decomb.c:400-403) and the
+     * blur reads one element per row that nothing has written yet (eedi2_template.c:1589);
+     * start from zeros, as fresh pages would */
+    hb_filter_private_t *pv = f->private_data;
+    if (pv->cx2 != NULL)
+    {
+        const size_t n = (size_t)height * hb_image_stride(init.pix_fmt, width, 0) * sizeof(int);
+        memset(pv->cx2, 0, n); memset(pv->cy2, 0, n); memset(pv->cxy, 0, n); memset(pv->tmpc, 0, n);
+    }
     return f;
 }
 
@@ -35,6 +44,31 @@ HBREF_EXPORT void hbref_eedi2_run(void *h, const uint8_t *const plane[3], const 
     pv->ref[1] = b;
     pv->tff = tff;
     eedi2_planer_8(pv);
+}
+
+/* The same, but the three planes one after the other on the caller's thread instead of on the
+ * three taskset threads: with post-processing 2/3 the plane threads share cx2/cy2/cxy/tmpc
+ * (decomb_template.c:380-383), so only a fixed order gives a defined result to pin. */
+HBREF_EXPORT void hbref_eedi2_run_serial(void *h, const uint8_t *const plane[3], const int stride[3], int tff)
+{
+    hb_filter_object_t *f = h;
+    hb_filter_private_t *pv = f->private_data;
+    hb_buffer_t *b = hb_frame_buffer_init(pv->input.pix_fmt, pv->input.geometry.width, pv->input.geometry.height);
+    for (int p = 0; p < 3; p++)
+        for (int y = 0; y < b->plane[p].height; y++)
+            memcpy(b->plane[p].data + (size_t)y * b->plane[p].stride, plane[p] + (size_t)y * stride[p],
+                   MIN(stride[p], b->plane[p].stride));
+    hb_buffer_close(&pv->ref[1]);
+    pv->ref[1] = b;
+    pv->tff = tff;
+    for (int p = 0; p < 3; p++)
+    {
+        const int src_pitch = b->plane[p].stride, dst_pitch = pv->eedi_half[SRCPF]->plane[p].stride;
+        eedi2_fill_half_height_buffer_plane_8(b->plane[p].data + src_pitch * !tff, pv->eedi_half[SRCPF]->plane[p].data,
+                                              src_pitch, dst_pitch, b->plane[p].height);
+    }
+    for (int p = 0; p < 3; p++)
+        eedi2_interpolate_plane_8(pv, p);
 }
 
 HBREF_EXPORT const uint8_t *hbref_eedi2_plane(void *h, int buffer, int plane, int *stride, int *height)

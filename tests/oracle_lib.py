@@ -336,6 +336,7 @@ class RefEedi2:
         lib.hbref_eedi2_new.restype = C.c_void_p
         lib.hbref_eedi2_new.argtypes = [C.c_int, C.c_int, C.c_char_p]
         lib.hbref_eedi2_run.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_int), C.c_int]
+        lib.hbref_eedi2_run_serial.argtypes = lib.hbref_eedi2_run.argtypes
         lib.hbref_eedi2_plane.restype = C.POINTER(C.c_uint8)
         lib.hbref_eedi2_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         lib.hbref_eedi2_free.argtypes = [C.c_void_p]
@@ -343,9 +344,11 @@ class RefEedi2:
         self.h = lib.hbref_eedi2_new(width, height, settings.encode())
         assert self.h
 
-    def run(self, frame, tff):
+    def run(self, frame, tff, serial=False):
+        """serial: the three planes in order on this thread (needed for postproc 2/3, where the
+        reference's plane threads share the derivative arrays)."""
         keep, ptrs, strides = _planes3(frame)
-        self.lib.hbref_eedi2_run(self.h, ptrs, strides, int(tff))
+        (self.lib.hbref_eedi2_run_serial if serial else self.lib.hbref_eedi2_run)(self.h, ptrs, strides, int(tff))
 
     def plane(self, buffer, plane):
         st, ht = C.c_int(), C.c_int()
@@ -446,3 +449,35 @@ def orc_cropscale_frame(frame, width, height, top=0, bottom=0, left=0, right=0):
         fn(u8p(p), p.strides[0], cx, cy, pw, ph, u8p(dst), dst.strides[0], dw, dh, sx, 0.0)
         out.append(dst)
     return tuple(out)
+
+
+class ColorspaceParams(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("in_prim", "in_transfer", "in_matrix", "in_range",
+                                       "out_prim", "out_transfer", "out_matrix", "out_range", "tonemap")] + \
+               [(n, C.c_double) for n in ("param", "desat", "npl", "peak")]
+
+
+TONEMAPS = {"none": 0, "linear": 1, "gamma": 2, "clip": 3, "reinhard": 4, "hable": 5, "mobius": 6}
+
+
+def colorspace_params(src, dst, tonemap="hable", param=float("nan"), desat=0.0, npl=100.0, peak=10.0):
+    """src / dst: (primaries, transfer, matrix, range) in AVCOL_* numbers (range 1 = tv, 2 = pc)."""
+    return ColorspaceParams(*src, *dst, TONEMAPS[tonemap], param, desat, npl, peak)
+
+
+def orc_colorspace_frame(frame, params, depth=8, subw=1, subh=1):
+    fn = oracle().orc_colorspace_frame
+    fn.restype = C.c_int
+    fn.argtypes = [C.POINTER(ColorspaceParams), C.POINTER(C.c_void_p), C.POINTER(C.c_int),
+                   C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    src = [np.ascontiguousarray(p) for p in frame]
+    dst = [np.zeros_like(p) for p in src]
+    h, w = src[0].shape
+    sp = (C.c_void_p * 3)(*[p.ctypes.data for p in src])
+    dp = (C.c_void_p * 3)(*[p.ctypes.data for p in dst])
+    ss = (C.c_int * 3)(*[p.strides[0] for p in src])
+    ds = (C.c_int * 3)(*[p.strides[0] for p in dst])
+    rc = fn(C.byref(params), sp, ss, dp, ds, w, h, depth, subw, subh)
+    if rc != 0:
+        raise ValueError("conversion not covered by the oracle")
+    return tuple(dst)

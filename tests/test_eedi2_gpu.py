@@ -38,10 +38,43 @@ def test_every_scratch_buffer(built, w, h):
         ctx.close()
 
 
+@pytest.mark.parametrize("postproc", [2, 3])
+@pytest.mark.parametrize("w,h", [(128, 72), (322, 184), (638, 360), (1920, 1080)])
+def test_corner_postprocessing_every_scratch_buffer(built, w, h, postproc):
+    """post-processing 2/3 (gaussian blurs, derivative products, corner test; eedi2_template.c:1391-1904),
+    on input with real corners, against the oracle (pinned to the reference's plane-serial run)."""
+    frames = synth.stream("corners", w, h, 3)
+    ctx = hip.Ctx(0)
+    dev = hip.DecombDevice(ctx, w, h, mode=24, postproc=postproc)
+    oe, plain = ol.OrcEedi2(w, h, postproc=postproc), ol.OrcEedi2(w, h, postproc=postproc & 1)
+    changed = 0
+    try:
+        dev.push(frames[0])
+        for t in range(1, 3):
+            dev.push(frames[t])
+            for tff in (1, 0):
+                oe.run(frames[t - 1], tff)
+                plain.run(frames[t - 1], tff)
+                changed += sum(int((a != b).sum()) for a, b in zip(oe.guess(), plain.guess()))
+            while dev.pull() is not None:
+                pass
+            for b in range(9):
+                for c in range(3):
+                    np.testing.assert_array_equal(dev.eedi_plane(b, c), oe.plane(b, c),
+                                                  err_msg=f"{ol.EEDI2_BUFFERS[b]} plane {c} after frame {t - 1}")
+        assert changed > 0
+    finally:
+        oe.close()
+        plain.close()
+        dev.close()
+        ctx.close()
+
+
 @pytest.mark.parametrize("w,h", [(128, 72), (638, 360)])
 @pytest.mark.parametrize("mode,extra,par", [
     (8, "", {}), (15, "", {}), (31, "", {}), (63, "", {}),
     (9, ":postproc=0:noise-thresh=30:search-distance=12", dict(postproc=0, noise=30, search=12)),
+    (31, ":postproc=3", dict(postproc=3)), (15, ":postproc=2", dict(postproc=2)),
     (27, ":magnitude-thresh=5:variance-thresh=10:laplacian-thresh=30:dilation-thresh=3:erosion-thresh=3",
      dict(magnitude=5, variance=10, laplacian=30, dilation=3, erosion=3))])
 def test_decomb_eedi2_filter(built, w, h, mode, extra, par):

@@ -182,6 +182,37 @@ def test_eedi2_every_scratch_buffer_matches_reference(built, w, h):
 
 
 @needs_ref
+@pytest.mark.parametrize("postproc", [2, 3])
+@pytest.mark.parametrize("w,h", [(64, 48), (128, 72), (638, 360), (322, 184)])
+def test_eedi2_corner_postprocessing_matches_reference(built, w, h, postproc):
+    """post-processing 2/3 (gaussian blurs, derivatives, corner test; eedi2_template.c:1391-1904)
+    against the reference's eedi2_interpolate_plane_8 run plane after plane: its three plane
+    threads share the derivative arrays, so only the serial order is defined."""
+    if h % 4:
+        pytest.skip("the reference overruns its buffers when the chroma height is odd")
+    frames = synth.stream("corners", w, h, 3)
+    r, o = ol.RefEedi2(w, h, f"mode=8:postproc={postproc}"), ol.OrcEedi2(w, h, postproc=postproc)
+    plain = ol.OrcEedi2(w, h, postproc=postproc & 1)
+    changed = 0
+    try:
+        for fr in frames:
+            for tff in (1, 0):
+                r.run(fr, tff, serial=True)
+                o.run(fr, tff)
+                plain.run(fr, tff)
+                changed += sum(int((a != b).sum()) for a, b in zip(o.guess(), plain.guess()))
+                for b in range(9):
+                    for c in range(3):
+                        np.testing.assert_array_equal(o.plane(b, c), r.plane(b, c),
+                                                      err_msg=f"{ol.EEDI2_BUFFERS[b]} plane {c} tff {tff}")
+        assert changed > 0 or w < 128, "the corner test never fired: the case would be vacuous"
+    finally:
+        r.close()
+        o.close()
+        plain.close()
+
+
+@needs_ref
 @pytest.mark.parametrize("mode,extra,par", [
     (8, "", {}), (15, "", {}), (31, "", {}), (63, "", {}),
     (9, ":postproc=0:noise-thresh=30:search-distance=12", dict(postproc=0, noise=30, search=12)),
