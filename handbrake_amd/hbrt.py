@@ -195,3 +195,47 @@ def run_stream(lib, stages, frames, flags: int = 0x10, pix_fmt: int = AV_PIX_FMT
         ch.push_eof()
         out += ch.drain()
     return out
+
+
+# ---- compositor objects (hb_blend_object_t) -------------------------------------------------
+AV_PIX_FMT_YUVA420P, AV_PIX_FMT_YUVA422P, AV_PIX_FMT_YUVA444P = 33, 78, 79
+
+
+class Overlay(C.Structure):
+    """One rendered subtitle bitmap (Y, Cb, Cr, alpha planes, 8-bit) placed at (x, y)."""
+    _fields_ = [("plane", C.c_void_p * 4), ("stride", C.c_int * 4),
+                ("x", C.c_int), ("y", C.c_int), ("width", C.c_int), ("height", C.c_int)]
+
+
+def overlay_array(overlays):
+    """overlays: list of (x, y, (Y, Cb, Cr, A) uint8 arrays).  Returns (ctypes array, keep-alive list)."""
+    arr = (Overlay * max(len(overlays), 1))()
+    keep = []
+    for i, (x, y, planes) in enumerate(overlays):
+        planes = [np.ascontiguousarray(p) for p in planes]
+        keep.append(planes)
+        for k, p in enumerate(planes):
+            arr[i].plane[k] = p.ctypes.data
+            arr[i].stride[k] = p.strides[0]
+        arr[i].x, arr[i].y = x, y
+        arr[i].height, arr[i].width = planes[0].shape
+    return arr, keep
+
+
+def blend_run(lib, symbol, frame, overlays, pix_fmt=AV_PIX_FMT_YUV420P, overlay_fmt=AV_PIX_FMT_YUVA444P,
+              chroma_location=1, passes=1):
+    """Run the compositor object `symbol` of `lib` (e.g. "hb_blend_hip") on a copy of `frame`."""
+    rt = runtime()
+    rt.hbh_blend_run.restype = C.c_int
+    rt.hbh_blend_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.POINTER(Overlay), C.c_int]
+    out = [np.ascontiguousarray(p).copy() for p in frame]
+    h, w = out[0].shape
+    ptrs = (C.c_void_p * 3)(*[p.ctypes.data for p in out])
+    strides = (C.c_int * 3)(*[p.strides[0] for p in out])
+    arr, keep = overlay_array(overlays)
+    proto = C.addressof(C.c_char.in_dll(lib, symbol))
+    rc = rt.hbh_blend_run(proto, pix_fmt, w, h, chroma_location, overlay_fmt, ptrs, strides, len(overlays), arr, passes)
+    if rc != 0:
+        raise RuntimeError(f"hbh_blend_run({symbol}) failed ({rc})")
+    return tuple(out)

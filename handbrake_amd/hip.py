@@ -31,6 +31,7 @@ ABI_SYMBOLS = [
     "hbhip_comb_detect_store_dev",
     "hbhip_comb_detect_classify",
     "hbhip_rotate_create", "hbhip_grayscale_create", "hbhip_cropscale_create", "hbhip_colorspace_create",
+    "hbhip_blend_create", "hbhip_blend_set_overlays", "hbhip_blend_apply", "hbhip_blend_apply_dev", "hbhip_blend_destroy",
 ]
 
 
@@ -410,3 +411,34 @@ def decomb_push_dev(flt, frame: DevFrame, tag: int, flags: int = 0x0008, combed:
     L = lib()
     L.hbhip_decomb_push_dev.argtypes = [C.c_void_p, C.POINTER(DevFrame), C.c_int64, C.c_int, C.c_int]
     check(L.hbhip_decomb_push_dev(flt.h, C.byref(frame), tag, flags, combed), flt.ctx.h, "decomb_push_dev")
+
+
+class BlendDevice:
+    """hbhip_blend*: the subtitle compositor on device frames (tests / bench)."""
+
+    def __init__(self, ctx: Ctx, width, height, depth=8, log2_cw=1, log2_ch=1, chroma_location=1,
+                 overlay_log2_cw=0, overlay_log2_ch=0):
+        L = lib()
+        L.hbhip_blend_create.argtypes = [C.c_void_p] + [C.c_int] * 8 + [C.POINTER(C.c_void_p)]
+        L.hbhip_blend_set_overlays.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.hbhip_blend_apply_dev.argtypes = [C.c_void_p, C.POINTER(DevFrame)]
+        L.hbhip_blend_destroy.argtypes = [C.c_void_p]
+        L.hbhip_blend_destroy.restype = None
+        h = C.c_void_p()
+        check(L.hbhip_blend_create(ctx.h, width, height, depth, log2_cw, log2_ch, chroma_location,
+                                   overlay_log2_cw, overlay_log2_ch, C.byref(h)), ctx.h, "hbhip_blend_create")
+        self.ctx, self.h = ctx, h
+
+    def set_overlays(self, overlays):
+        """overlays: list of (x, y, (Y, Cb, Cr, A) uint8 arrays)."""
+        from . import hbrt
+        arr, keep = hbrt.overlay_array(overlays)       # same layout as hbhip_overlay
+        check(lib().hbhip_blend_set_overlays(self.h, C.cast(arr, C.c_void_p), len(overlays)), self.ctx.h, "set_overlays")
+
+    def apply_dev(self, frame: DevFrame):
+        check(lib().hbhip_blend_apply_dev(self.h, C.byref(frame)), self.ctx.h, "blend_apply_dev")
+
+    def close(self):
+        if self.h:
+            lib().hbhip_blend_destroy(self.h)
+            self.h = None

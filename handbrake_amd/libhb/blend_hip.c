@@ -1,0 +1,128 @@
+/* blend_hip.c — HIP-backed drop-in for the reference's subtitle compositor object `hb_blend`
+ * (libhb/blend.c:40-46; type hb_blend_object_t, handbrake/common.h:1813-1828).
+ *
+ * rendersub.c picks the compositor in its own hb_blend_init (:1129-1161: `hb_blend_vt` for
+ * VideoToolbox frames, `hb_blend` otherwise), copies the object, calls init once and then
+ * work(frame, overlay list, changed) for every frame (:467, :888, :1011, :1122).  `hb_blend_hip` is a
+ * third choice with the same three entry points; INTEGRATION.md shows the two-line change.
+ * Same contract as hb_blend_work (:848-873): no overlays => the frame is returned untouched; a
+ * frame that is not writable is duplicated first; overlays are composited in list order.
+ * The bitmaps are uploaded only when `changed` says the list is new.  Frames already in HBM
+ * (storage_type HBHIP_DEVICE) are composited in place without leaving the device.
+ */
+#include "hbhip_host.h"
+
+struct hb_blend_private_s
+{
+    hbhip_blend *dev;
+    int          have_overlays;      /* the device holds the current list */
+};
+
+static int blend_hip_init(hb_blend_object_t *object, int in_width, int in_height, int in_pix_fmt,
+                          int in_chroma_location, int in_color_range, int overlay_pix_fmt)
+{
+    (void)in_color_range;
+    hb_blend_private_t *pv = calloc(1, sizeof(*pv));
+    object->private_data = pv;
+    if (pv == NULL)
+    {
+        hb_error("blend(hip): calloc failed");
+        return -1;
+    }
+    const AVPixFmtDescriptor *in_desc = av_pix_fmt_desc_get(in_pix_fmt);
+    const AVPixFmtDescriptor *ov_desc = av_pix_fmt_desc_get(overlay_pix_fmt);
+    hbhip_ctx *ctx = in_desc != NULL && ov_desc != NULL ? hbhip_host_ctx() : NULL;
+    int rc = ctx == NULL ? HBHIP_ERR_NODEVICE : HBHIP_OK;
+    if (rc == HBHIP_OK && av_pix_fmt_count_planes(in_pix_fmt) != 3)
+        rc = HBHIP_ERR_UNSUPPORTED;                     /* NV12 / P010: blend8onbi*, not built */
+    if (rc == HBHIP_OK)
+        rc = hbhip_blend_create(ctx, in_width, in_height, in_desc->comp[0].depth, in_desc->log2_chroma_w,
+                                in_desc->log2_chroma_h, in_chroma_location, ov_desc->log2_chroma_w,
+                                ov_desc->log2_chroma_h, &pv->dev);
+    if (rc != HBHIP_OK)
+    {
+        hb_error("blend(hip): %s", hbhip_strerror(rc));
+        free(pv);
+        object->private_data = NULL;
+        return -1;
+    }
+    return 0;
+}
+
+static hb_buffer_t *blend_hip_work(hb_blend_object_t *object, hb_buffer_t *in, hb_buffer_list_t *overlays, int changed)
+{
+    hb_blend_private_t *pv = object->private_data;
+    hb_buffer_t *out = in;
+    const int n = hb_buffer_list_count(overlays);
+    if (n == 0)
+        return out;                                                                /* blend.c:856-859 */
+
+    int rc = HBHIP_OK;
+    if (changed || !pv->have_overlays)
+    {
+        hbhip_overlay *ov = calloc((size_t)n, sizeof(*ov));
+        if (ov == NULL) return NULL;
+        int i = 0;
+        for (hb_buffer_t *o = hb_buffer_list_head(overlays); o != NULL && i < n; o = o->next, i++)
+        {
+            for (int p = 0; p < 4; p++)
+            {
+                ov[i].plane[p] = o->plane[p].data;
+                ov[i].stride[p] = o->plane[p].stride;
+            }
+            ov[i].x = o->f.x;
+            ov[i].y = o->f.y;
+            ov[i].width = o->f.width;
+            ov[i].height = o->f.height;
+        }
+        rc = hbhip_blend_set_overlays(pv->dev, ov, i);
+        free(ov);
+        pv->have_overlays = rc == HBHIP_OK;
+    }
+    if (rc == HBHIP_OK)
+    {
+        hbhip_frame *dev_frame = hbhip_host_frame_of(in);
+        if (dev_frame != NULL)
+        {
+            hbhip_dev_frame d;
+            hbhip_frame_describe(dev_frame, &d, NULL, NULL);
+            rc = hbhip_blend_apply_dev(pv->dev, &d);
+        }
+        else
+        {
+            if (hb_buffer_is_writable(in) == 0)                                    /* :861-865 */
+            {
+                out = hb_buffer_dup(in);
+                hb_buffer_close(&in);
+                if (out == NULL) return NULL;
+            }
+            hbhip_host_frame f;
+            hbhip_host_frame_from_buf(&f, out);
+            rc = hbhip_blend_apply(pv->dev, &f);
+        }
+    }
+    if (rc != HBHIP_OK)
+    {
+        hb_error("blend(hip): %s", hbhip_strerror(rc));
+        hb_buffer_close(&out);
+        return NULL;
+    }
+    return out;
+}
+
+static void blend_hip_close(hb_blend_object_t *object)
+{
+    hb_blend_private_t *pv = object->private_data;
+    if (pv == NULL) return;
+    hbhip_blend_destroy(pv->dev);
+    free(pv);
+    object->private_data = NULL;
+}
+
+hb_blend_object_t hb_blend_hip =
+{
+    .name  = "Blend (HIP)",
+    .init  = blend_hip_init,
+    .work  = blend_hip_work,
+    .close = blend_hip_close,
+};

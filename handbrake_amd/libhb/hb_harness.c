@@ -227,3 +227,50 @@ void hbh_chain_close(hbh_chain_t *c)
     hb_buffer_list_close(&c->out);
     free(c);
 }
+
+/* ---- compositor objects (hb_blend_object_t, handbrake/common.h:1813-1828) ------------------
+ * Plays rendersub.c's part (:1129-1161, :467): copy the prototype, init, hand `work` the frame and
+ * the list of rendered overlays.  `passes` > 1 repeats work() on a fresh copy of the frame with
+ * changed = 0 (the overlays of the previous call are still valid), as rendersub does between
+ * subtitle changes; the frame written back is the last pass's. */
+int hbh_blend_run(const void *proto, int pix_fmt, int width, int height, int chroma_location, int overlay_fmt,
+                  uint8_t *const plane[3], const int stride[3], int n_overlays, const hbh_overlay_t *ov, int passes)
+{
+    hb_blend_object_t blend = *(const hb_blend_object_t *)proto;
+    if (blend.init(&blend, width, height, pix_fmt, chroma_location, 1, overlay_fmt) != 0) return -1;
+    hb_buffer_list_t list;
+    memset(&list, 0, sizeof(list));
+    for (int i = 0; i < n_overlays; i++)
+    {
+        hb_buffer_t *o = hb_frame_buffer_init(overlay_fmt, ov[i].width, ov[i].height);
+        if (o == NULL) return -1;
+        for (int p = 0; p <= o->f.max_plane; p++)
+            for (int y = 0; y < o->plane[p].height; y++)
+                memcpy(o->plane[p].data + (size_t)y * o->plane[p].stride, ov[i].plane[p] + (size_t)y * ov[i].stride[p],
+                       o->plane[p].width);
+        o->f.x = ov[i].x;
+        o->f.y = ov[i].y;
+        hb_buffer_list_append(&list, o);
+    }
+    int rc = 0;
+    for (int pass = 0; pass < passes && rc == 0; pass++)
+    {
+        hb_buffer_t *b = hb_frame_buffer_init(pix_fmt, width, height);
+        if (b == NULL) { rc = -1; break; }
+        for (int p = 0; p <= b->f.max_plane; p++)
+            for (int y = 0; y < b->plane[p].height; y++)
+                memcpy(b->plane[p].data + (size_t)y * b->plane[p].stride, plane[p] + (size_t)y * stride[p],
+                       MIN(stride[p], b->plane[p].stride));
+        hb_buffer_t *out = blend.work(&blend, b, &list, pass == 0);
+        if (out == NULL) { rc = -2; break; }
+        if (pass == passes - 1)
+            for (int p = 0; p <= out->f.max_plane; p++)
+                for (int y = 0; y < out->plane[p].height; y++)
+                    memcpy(plane[p] + (size_t)y * stride[p], out->plane[p].data + (size_t)y * out->plane[p].stride,
+                           MIN(stride[p], out->plane[p].stride));
+        hb_buffer_close(&out);
+    }
+    hb_buffer_list_close(&list);
+    blend.close(&blend);
+    return rc;
+}

@@ -44,6 +44,17 @@ int  hbh_chain_pop(hbh_chain_t *c, uint8_t *const plane[3], const int stride[3])
 void hbh_chain_output_geometry(hbh_chain_t *c, int *width, int *height, int *vrate_num, int *vrate_den);
 void hbh_chain_close(hbh_chain_t *c);
 
+/* One rendered subtitle bitmap: 4 planes (Y, Cb, Cr, alpha; 8-bit), placed at (x, y) of the frame. */
+typedef struct
+{
+    const uint8_t *plane[4];
+    int            stride[4];
+    int            x, y, width, height;
+} hbh_overlay_t;
+/* Run a compositor object (address of an hb_blend_object_t) on one frame, in place. */
+int hbh_blend_run(const void *proto, int pix_fmt, int width, int height, int chroma_location, int overlay_fmt,
+                  uint8_t *const plane[3], const int stride[3], int n_overlays, const hbh_overlay_t *ov, int passes);
+
 void hbhip_set_log_level(int level);
 
 #ifdef __cplusplus

@@ -69,6 +69,15 @@ static const AVPixFmtDescriptor k_desc_yuv444p = {
 static const AVPixFmtDescriptor k_desc_gray8 = {
     "gray", 1, 0, 0, 0,
     { {0, 1, 0, 0, 8}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0} } };
+static const AVPixFmtDescriptor k_desc_yuva420p = {
+    "yuva420p", 4, 1, 1, 0,
+    { {0, 1, 0, 0, 8}, {1, 1, 0, 0, 8}, {2, 1, 0, 0, 8}, {3, 1, 0, 0, 8} } };
+static const AVPixFmtDescriptor k_desc_yuva422p = {
+    "yuva422p", 4, 1, 0, 0,
+    { {0, 1, 0, 0, 8}, {1, 1, 0, 0, 8}, {2, 1, 0, 0, 8}, {3, 1, 0, 0, 8} } };
+static const AVPixFmtDescriptor k_desc_yuva444p = {
+    "yuva444p", 4, 0, 0, 0,
+    { {0, 1, 0, 0, 8}, {1, 1, 0, 0, 8}, {2, 1, 0, 0, 8}, {3, 1, 0, 0, 8} } };
 static const AVPixFmtDescriptor k_desc_yuv420p10 = {
     "yuv420p10le", 3, 1, 1, 0,
     { {0, 2, 0, 0, 10}, {1, 2, 0, 0, 10}, {2, 2, 0, 0, 10}, {0, 0, 0, 0, 0} } };
@@ -84,10 +93,23 @@ const AVPixFmtDescriptor *av_pix_fmt_desc_get(int pix_fmt)
         case AV_PIX_FMT_YUV422P:     return &k_desc_yuv422p;
         case AV_PIX_FMT_YUV444P:     return &k_desc_yuv444p;
         case AV_PIX_FMT_GRAY8:       return &k_desc_gray8;
+        case AV_PIX_FMT_YUVA420P:    return &k_desc_yuva420p;
+        case AV_PIX_FMT_YUVA422P:    return &k_desc_yuva422p;
+        case AV_PIX_FMT_YUVA444P:    return &k_desc_yuva444p;
         case AV_PIX_FMT_YUV420P10LE: return &k_desc_yuv420p10;
         case AV_PIX_FMT_YUV420P12LE: return &k_desc_yuv420p12;
         default:                     return NULL;
     }
+}
+
+int av_pix_fmt_count_planes(int pix_fmt)
+{
+    const AVPixFmtDescriptor *d = av_pix_fmt_desc_get(pix_fmt);
+    if (d == NULL) return -1;
+    int n = 0;
+    for (int i = 0; i < d->nb_components; i++)
+        if (d->comp[i].plane + 1 > n) n = d->comp[i].plane + 1;
+    return n;
 }
 
 int av_image_get_linesize(int pix_fmt, int width, int plane)
@@ -392,6 +414,33 @@ hb_buffer_t *hb_frame_buffer_init(int pix_fmt, int width, int height)
     b->f.fmt = pix_fmt;
     hb_buffer_init_planes(b);
     return b;
+}
+
+/* fifo.c:624-639 (the stand-in runtime only has STANDARD and device buffers) */
+int hb_buffer_is_writable(const hb_buffer_t *buf)
+{
+    return buf->storage_type == STANDARD;
+}
+
+/* common.c:7054-7091.  The position of the chroma sample inside its 2x2 / 2x1 luma block picks a
+ * window into the kernel 1 3 9 27 9 3 1; an even offset averages two neighbouring taps. */
+void hb_compute_chroma_smoothing_coefficient(uint32_t chroma_coeffs[2][4], int pix_fmt, int chroma_location)
+{
+    const AVPixFmtDescriptor *desc = av_pix_fmt_desc_get(pix_fmt);
+    int wx = 4 - (1 << desc->log2_chroma_w), wy = 4 - (1 << desc->log2_chroma_h);
+    const int left = chroma_location == AVCHROMA_LOC_TOPLEFT || chroma_location == AVCHROMA_LOC_LEFT ||
+                     chroma_location == AVCHROMA_LOC_BOTTOMLEFT;
+    /* the reference's switch falls through TOPLEFT -> TOP and BOTTOMLEFT -> BOTTOM -> CENTER */
+    const int vertical = chroma_location == AVCHROMA_LOC_TOPLEFT || chroma_location == AVCHROMA_LOC_TOP ||
+                         chroma_location == AVCHROMA_LOC_BOTTOMLEFT || chroma_location == AVCHROMA_LOC_BOTTOM;
+    if (left) wx += (1 << desc->log2_chroma_w) - 1;
+    if (vertical) wy += (1 << desc->log2_chroma_h) - 1;
+    static const uint32_t base[] = { 1, 3, 9, 27, 9, 3, 1 };
+    for (int i = 0; i < 4; i++)
+    {
+        chroma_coeffs[0][i] = (base[i + wx] + base[i + wx + !(wx & 1)]) >> 1;
+        chroma_coeffs[1][i] = (base[i + wy] + base[i + wy + !(wy & 1)]) >> 1;
+    }
 }
 
 void hb_frame_buffer_blank_stride(hb_buffer_t *buf)

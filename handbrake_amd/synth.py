@@ -169,3 +169,35 @@ def stream(model: str, w: int, h: int, nframes: int, cfg: int | None = None, dep
 
 def flags_for(model: str) -> int:
     return PIC_FLAG_TOP_FIELD_FIRST if model in ("interlaced", "corners") else PIC_FLAG_PROGRESSIVE_FRAME
+
+
+def overlays(w: int, h: int, count: int, seed: int = 1, subsampled: bool = False, inside: bool = False):
+    """`count` synthetic subtitle bitmaps for a w x h frame: (x, y, (Y, Cb, Cr, A)) with uint8 planes.
+    Alpha mixes fully transparent, opaque and soft-edged areas; positions include odd offsets and,
+    unless `inside`, bitmaps hanging over the left / top frame edge.  subsampled: 4:2:0 chroma planes
+    (an overlay already in the frame's format) instead of 4:4:4."""
+    out = []
+    for i in range(count):
+        r = lcg_stream(frame_seed(0x77, seed * 131 + i), 8)
+        bw = 16 + int(r[0] >> 16) % max(8, w // 2)
+        bh = 8 + int(r[1] >> 16) % max(8, h // 3)
+        bw, bh = min(bw, w), min(bh, h)
+        x = int(r[2] >> 16) % max(1, w - bw + 1)
+        y = int(r[3] >> 16) % max(1, h - bh + 1)
+        if not inside and i % 3 == 1:
+            x, y = -(int(r[4] >> 16) % (bw // 2)), -(int(r[5] >> 16) % (bh // 2))
+        n = bw * bh
+        v = (lcg_stream(frame_seed(0x78, seed * 977 + i), 4 * n) >> np.uint32(24)).astype(np.uint8)
+        yy = v[:n].reshape(bh, bw)
+        cb, cr, a = v[n:2 * n].reshape(bh, bw), v[2 * n:3 * n].reshape(bh, bw), v[3 * n:].reshape(bh, bw).copy()
+        gx = np.arange(bw)[None, :]
+        gy = np.arange(bh)[:, None]
+        a[(gx // 5 + gy // 3) % 4 == 0] = 0
+        a[(gx // 7 + gy // 4) % 5 == 1] = 255
+        if subsampled:
+            # even offsets only: for an odd overhang over the left / top edge the reference's
+            # same-subsampling path writes one chroma sample outside the row / plane (blend.c:485-505)
+            x, y = x & ~1, y & ~1
+            cb, cr = cb[::2, ::2], cr[::2, ::2]
+        out.append((x, y, (yy.copy(), np.ascontiguousarray(cb), np.ascontiguousarray(cr), a)))
+    return out

@@ -269,6 +269,29 @@ typedef struct hbhip_colorspace_params
 int hbhip_colorspace_create(hbhip_ctx *ctx, const hbhip_colorspace_params *p, int width, int height,
                             int depth, int log2_chroma_w, int log2_chroma_h, hbhip_filter **out);
 
+/* ---- Subtitle compositor (replaces hb_blend, blend.c: the object rendersub.c hands every frame
+ *      and the list of rendered overlays, rendersub.c:467, 1129-1161) -------------------------
+ * Planar 8/10/12-bit frames; overlays are 8-bit Y/Cb/Cr/alpha bitmaps either in the frame's chroma
+ * subsampling (blend8on8 / blend8on1x, blend.c:425-604) or 4:4:4 on a subsampled frame
+ * (blend_subsample_8on8 / _8on1x, :48-328, weights from the chroma location, common.c:7054-7091). */
+typedef struct hbhip_blend hbhip_blend;
+typedef struct hbhip_overlay
+{
+    const uint8_t *plane[4];          /* Y, Cb, Cr, alpha (host memory) */
+    int            stride[4];
+    int            x, y, width, height;   /* hb_buffer_t.f.x / .y / .width / .height of the overlay */
+} hbhip_overlay;
+/* hb_blend_init (:788-846); chroma_location is the AVCHROMA_LOC_* number */
+int  hbhip_blend_create(hbhip_ctx *ctx, int width, int height, int depth, int log2_chroma_w, int log2_chroma_h,
+                        int chroma_location, int overlay_log2_chroma_w, int overlay_log2_chroma_h, hbhip_blend **out);
+/* Upload the current overlay list (call again only when it changes: rendersub's `changed`).
+ * The bitmaps are consumed when this returns. */
+int  hbhip_blend_set_overlays(hbhip_blend *b, const hbhip_overlay *ov, int n);
+/* hb_blend_work (:848-873): composite the overlays, in order, onto the frame in place. */
+int  hbhip_blend_apply(hbhip_blend *b, const hbhip_host_frame *frame);       /* H2D, blend, D2H; synchronous */
+int  hbhip_blend_apply_dev(hbhip_blend *b, const hbhip_dev_frame *frame);    /* frame already in HBM */
+void hbhip_blend_destroy(hbhip_blend *b);                                    /* hb_blend_close (:875-885) */
+
 #ifdef __cplusplus
 }
 #endif

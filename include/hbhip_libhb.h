@@ -79,6 +79,9 @@ enum hbhip_pix_fmt
     AV_PIX_FMT_YUV422P     = 4,
     AV_PIX_FMT_YUV444P     = 5,
     AV_PIX_FMT_GRAY8       = 8,
+    AV_PIX_FMT_YUVA420P    = 33,   /* subtitle overlays (rendersub.c: pix_fmt_alpha) */
+    AV_PIX_FMT_YUVA422P    = 78,
+    AV_PIX_FMT_YUVA444P    = 79,
     AV_PIX_FMT_YUV420P10LE = 62,
     AV_PIX_FMT_YUV420P10   = 62,
     AV_PIX_FMT_YUV420P12LE = 123,
@@ -105,6 +108,9 @@ typedef struct AVPixFmtDescriptor
 } AVPixFmtDescriptor;
 
 const AVPixFmtDescriptor *av_pix_fmt_desc_get(int pix_fmt);
+int  av_pix_fmt_count_planes(int pix_fmt);
+enum { AVCHROMA_LOC_UNSPECIFIED = 0, AVCHROMA_LOC_LEFT, AVCHROMA_LOC_CENTER, AVCHROMA_LOC_TOPLEFT,
+       AVCHROMA_LOC_TOP, AVCHROMA_LOC_BOTTOMLEFT, AVCHROMA_LOC_BOTTOM };
 int  av_image_get_linesize(int pix_fmt, int width, int plane);
 void *av_malloc(size_t size);
 void  av_freep(void *ptr);
@@ -122,6 +128,8 @@ typedef struct hb_cond_s           hb_cond_t;
 typedef struct hb_thread_s         hb_thread_t;
 typedef struct hb_filter_private_s hb_filter_private_t;
 typedef struct hb_filter_object_s  hb_filter_object_t;
+typedef struct hb_blend_private_s  hb_blend_private_t;
+typedef struct hb_blend_object_s   hb_blend_object_t;
 typedef struct hb_buffer_s         hb_buffer_t;
 typedef struct hb_buffer_list_s    hb_buffer_list_t;
 typedef struct hbhip_dict_s        hb_dict_t;
@@ -259,6 +267,9 @@ hb_buffer_t *hb_buffer_dup(const hb_buffer_t *src);
 hb_buffer_t *hb_buffer_shallow_dup(const hb_buffer_t *src);
 int          hb_buffer_copy(hb_buffer_t *dst, const hb_buffer_t *src);
 void         hb_buffer_copy_props(hb_buffer_t *dst, const hb_buffer_t *src);
+int          hb_buffer_is_writable(const hb_buffer_t *buf);       /* fifo.c:624-639 */
+/* common.c:7054-7091: weights of the up-to-4 overlay samples under one chroma sample, per axis */
+void         hb_compute_chroma_smoothing_coefficient(uint32_t chroma_coeffs[2][4], int pix_fmt, int chroma_location);
 /* stand-in runtime only: how to share / drop an HBHIP_DEVICE storage handle */
 void         hbhip_rt_set_storage_hooks(void (*retain)(void *), void (*release)(void *));
 /* stand-in runtime only: allocator for frame-sized buffer payloads (page-locked pool) */
@@ -428,6 +439,17 @@ enum
     /* appended, never inserted (saved job JSON and the C# interop carry the numbers above) */
     HB_FILTER_HIP_UPLOAD,
     HB_FILTER_HIP_DOWNLOAD
+};
+
+/* ---- the subtitle compositor plugin type (handbrake/common.h:1813-1828) ---------------- */
+struct hb_blend_object_s
+{
+    char *name;
+    int          (*init)(hb_blend_object_t *, int in_width, int in_height, int in_pix_fmt,
+                         int in_chroma_location, int in_color_range, int overlay_pix_fmt);
+    hb_buffer_t *(*work)(hb_blend_object_t *, hb_buffer_t *, hb_buffer_list_t *, int changed);
+    void         (*close)(hb_blend_object_t *);
+    hb_blend_private_t *private_data;
 };
 
 #ifdef __cplusplus

@@ -242,6 +242,18 @@ typedef struct
 int orc_colorspace_frame(const orc_colorspace_params_t *cs, const void *const src[3], const int sstride[3],
                          void *const dst[3], const int dstride[3], int w, int h, int depth, int subw, int subh);
 
+/* ---- subtitle compositor (blend.c; planar frames) ------------------------------------------- */
+typedef struct
+{
+    const uint8_t *plane[4];          /* Y, Cb, Cr, alpha - 8-bit */
+    int            stride[4];
+    int            x, y, width, height;
+} orc_overlay_t;
+/* hb_blend_work (:848-873) on one frame, in place: the overlays in order.  depth 8 -> uint8 planes,
+ * above -> uint16.  Returns -1 for a combination the reference's planar functions do not cover. */
+int orc_blend_frame(void *const plane[3], const int stride[3], int width, int height, int depth, int wshift, int hshift,
+                    int chroma_location, int overlay_wshift, int overlay_hshift, const orc_overlay_t *ov, int n);
+
 #ifdef __cplusplus
 }
 #endif

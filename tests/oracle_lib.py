@@ -481,3 +481,19 @@ def orc_colorspace_frame(frame, params, depth=8, subw=1, subh=1):
     if rc != 0:
         raise ValueError("conversion not covered by the oracle")
     return tuple(dst)
+
+
+def orc_blend_frame(frame, overlays, depth=8, wshift=1, hshift=1, chroma_location=1, overlay_wshift=0, overlay_hshift=0):
+    """overlays: list of (x, y, (Y, Cb, Cr, A)).  Returns the composited copy of `frame`."""
+    from handbrake_amd import hbrt
+    fn = oracle().orc_blend_frame
+    fn.restype = C.c_int
+    fn.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int)] + [C.c_int] * 8 + [C.POINTER(hbrt.Overlay), C.c_int]
+    out = [np.ascontiguousarray(p).copy() for p in frame]
+    h, w = out[0].shape
+    ptrs = (C.c_void_p * 3)(*[p.ctypes.data for p in out])
+    strides = (C.c_int * 3)(*[p.strides[0] for p in out])
+    arr, keep = hbrt.overlay_array(overlays)
+    if fn(ptrs, strides, w, h, depth, wshift, hshift, chroma_location, overlay_wshift, overlay_hshift, arr, len(overlays)) != 0:
+        raise ValueError("overlay / frame combination not covered")
+    return tuple(out)
