@@ -239,3 +239,19 @@ def blend_run(lib, symbol, frame, overlays, pix_fmt=AV_PIX_FMT_YUV420P, overlay_
     if rc != 0:
         raise RuntimeError(f"hbh_blend_run({symbol}) failed ({rc})")
     return tuple(out)
+
+
+def motion_metric_run(lib, symbol, luma_a, luma_b, pix_fmt=AV_PIX_FMT_YUV420P) -> float:
+    """Run the metric object `symbol` of `lib` (e.g. "hb_motion_metric_hip") on two luma planes."""
+    rt = runtime()
+    rt.hbh_motion_metric_run.restype = C.c_int
+    rt.hbh_motion_metric_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                         C.c_void_p, C.c_int, C.POINTER(C.c_float)]
+    a, b = np.ascontiguousarray(luma_a), np.ascontiguousarray(luma_b)
+    h, w = a.shape
+    out = C.c_float()
+    proto = C.addressof(C.c_char.in_dll(lib, symbol))
+    rc = rt.hbh_motion_metric_run(proto, pix_fmt, w, h, a.ctypes.data, a.strides[0], b.ctypes.data, b.strides[0], C.byref(out))
+    if rc != 0:
+        raise RuntimeError(f"hbh_motion_metric_run({symbol}) failed ({rc})")
+    return out.value

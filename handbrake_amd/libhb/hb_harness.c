@@ -274,3 +274,31 @@ int hbh_blend_run(const void *proto, int pix_fmt, int width, int height, int chr
     blend.close(&blend);
     return rc;
 }
+
+/* ---- frame-difference metric objects (hb_motion_metric_object_t) ---------------------------
+ * vfr.c's part (:76-108, :380): copy the prototype, init with the stream's hb_filter_init_t, then
+ * work(previous frame, current frame).  Only luma is looked at. */
+int hbh_motion_metric_run(const void *proto, int pix_fmt, int width, int height,
+                          const uint8_t *luma_a, int stride_a, const uint8_t *luma_b, int stride_b, float *out)
+{
+    hb_motion_metric_object_t metric = *(const hb_motion_metric_object_t *)proto;
+    hb_filter_init_t init;
+    memset(&init, 0, sizeof(init));
+    init.pix_fmt = pix_fmt;
+    init.hw_pix_fmt = AV_PIX_FMT_NONE;
+    init.geometry.width = width;
+    init.geometry.height = height;
+    if (metric.init(&metric, &init) != 0) return -1;
+    hb_buffer_t *a = hb_frame_buffer_init(pix_fmt, width, height), *b = hb_frame_buffer_init(pix_fmt, width, height);
+    if (a == NULL || b == NULL) return -1;
+    for (int y = 0; y < height; y++)
+    {
+        memcpy(a->plane[0].data + (size_t)y * a->plane[0].stride, luma_a + (size_t)y * stride_a, MIN(stride_a, a->plane[0].stride));
+        memcpy(b->plane[0].data + (size_t)y * b->plane[0].stride, luma_b + (size_t)y * stride_b, MIN(stride_b, b->plane[0].stride));
+    }
+    *out = metric.work(&metric, a, b);
+    hb_buffer_close(&a);
+    hb_buffer_close(&b);
+    metric.close(&metric);
+    return 0;
+}

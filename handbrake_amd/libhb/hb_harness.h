@@ -44,6 +44,10 @@ int  hbh_chain_pop(hbh_chain_t *c, uint8_t *const plane[3], const int stride[3])
 void hbh_chain_output_geometry(hbh_chain_t *c, int *width, int *height, int *vrate_num, int *vrate_den);
 void hbh_chain_close(hbh_chain_t *c);
 
+/* Run a frame-difference metric object (address of an hb_motion_metric_object_t) on two lumas. */
+int hbh_motion_metric_run(const void *proto, int pix_fmt, int width, int height,
+                          const uint8_t *luma_a, int stride_a, const uint8_t *luma_b, int stride_b, float *out);
+
 /* One rendered subtitle bitmap: 4 planes (Y, Cb, Cr, alpha; 8-bit), placed at (x, y) of the frame. */
 typedef struct
 {

@@ -269,6 +269,19 @@ typedef struct hbhip_colorspace_params
 int hbhip_colorspace_create(hbhip_ctx *ctx, const hbhip_colorspace_params *p, int width, int height,
                             int depth, int log2_chroma_w, int log2_chroma_h, hbhip_filter **out);
 
+/* ---- Frame-difference metric (replaces hb_motion_metric, motion_metric.c: the object vfr.c
+ *      calls on consecutive frames to choose the one to drop, vfr.c:76-108, 380) ---------------
+ * gamma_lut: the 1 << depth entries build_gamma_lut produces (:36-42), built by the caller. */
+typedef struct hbhip_motion_metric hbhip_motion_metric;
+int  hbhip_motion_metric_create(hbhip_ctx *ctx, int width, int height, int depth,
+                                const unsigned *gamma_lut, int entries, hbhip_motion_metric **out);
+/* hb_motion_metric_work (:268-279): luma planes of two frames -> the metric.  Synchronous. */
+int  hbhip_motion_metric_run(hbhip_motion_metric *m, const uint8_t *luma_a, int stride_a,
+                             const uint8_t *luma_b, int stride_b, float *out);             /* host planes */
+int  hbhip_motion_metric_run_dev(hbhip_motion_metric *m, const void *luma_a, int stride_a,
+                                 const void *luma_b, int stride_b, float *out);            /* planes in HBM */
+void hbhip_motion_metric_destroy(hbhip_motion_metric *m);
+
 /* ---- Subtitle compositor (replaces hb_blend, blend.c: the object rendersub.c hands every frame
  *      and the list of rendered overlays, rendersub.c:467, 1129-1161) -------------------------
  * Planar 8/10/12-bit frames; overlays are 8-bit Y/Cb/Cr/alpha bitmaps either in the frame's chroma

@@ -129,6 +129,8 @@ typedef struct hb_thread_s         hb_thread_t;
 typedef struct hb_filter_private_s hb_filter_private_t;
 typedef struct hb_filter_object_s  hb_filter_object_t;
 typedef struct hb_blend_private_s  hb_blend_private_t;
+typedef struct hb_motion_metric_private_s hb_motion_metric_private_t;
+typedef struct hb_motion_metric_object_s  hb_motion_metric_object_t;
 typedef struct hb_blend_object_s   hb_blend_object_t;
 typedef struct hb_buffer_s         hb_buffer_t;
 typedef struct hb_buffer_list_s    hb_buffer_list_t;
@@ -439,6 +441,16 @@ enum
     /* appended, never inserted (saved job JSON and the C# interop carry the numbers above) */
     HB_FILTER_HIP_UPLOAD,
     HB_FILTER_HIP_DOWNLOAD
+};
+
+/* ---- the frame-difference metric plugin type vfr.c uses (handbrake/common.h:1799-1811) -- */
+struct hb_motion_metric_object_s
+{
+    char *name;
+    int   (*init)(hb_motion_metric_object_t *, hb_filter_init_t *);
+    float (*work)(hb_motion_metric_object_t *, hb_buffer_t *, hb_buffer_t *);
+    void  (*close)(hb_motion_metric_object_t *);
+    hb_motion_metric_private_t *private_data;
 };
 
 /* ---- the subtitle compositor plugin type (handbrake/common.h:1813-1828) ---------------- */

@@ -242,6 +242,12 @@ typedef struct
 int orc_colorspace_frame(const orc_colorspace_params_t *cs, const void *const src[3], const int sstride[3],
                          void *const dst[3], const int dstride[3], int w, int h, int depth, int subw, int subh);
 
+/* ---- frame-difference metric of vfr (motion_metric.c) -------------------------------------- */
+/* The scaled 2.2-gamma table (1 << depth entries), :36-42. */
+void  orc_motion_gamma_lut(unsigned *lut, int depth);
+/* hb_motion_metric_work (:268-279) on two luma planes (uint16 samples above 8 bits, strides in bytes). */
+float orc_motion_metric(const void *a, int stride_a, const void *b, int stride_b, int width, int height, int depth);
+
 /* ---- subtitle compositor (blend.c; planar frames) ------------------------------------------- */
 typedef struct
 {

@@ -497,3 +497,12 @@ def orc_blend_frame(frame, overlays, depth=8, wshift=1, hshift=1, chroma_locatio
     if fn(ptrs, strides, w, h, depth, wshift, hshift, chroma_location, overlay_wshift, overlay_hshift, arr, len(overlays)) != 0:
         raise ValueError("overlay / frame combination not covered")
     return tuple(out)
+
+
+def orc_motion_metric(luma_a, luma_b, depth=8) -> float:
+    fn = oracle().orc_motion_metric
+    fn.restype = C.c_float
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    a, b = np.ascontiguousarray(luma_a), np.ascontiguousarray(luma_b)
+    h, w = a.shape
+    return fn(a.ctypes.data, a.strides[0], b.ctypes.data, b.strides[0], w, h, depth)
