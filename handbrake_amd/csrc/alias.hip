@@ -48,9 +48,10 @@ __device__ __forceinline__ void rot_map(const RotArgs &a, int x, int y, int &sx,
 
 // 64x64 output tile per block of 64x4 threads.  Transposing modes go through LDS so
 // that both the gather from the source rows and the store to the output rows coalesce.
+template <typename PIX>
 __global__ __launch_bounds__(256) void rotate_kernel(RotArgs a)
 {
-    __shared__ uint8_t tile[64][65];
+    __shared__ PIX tile[64][65];
     const int ox = blockIdx.x * 64, oy = blockIdx.y * 64;
     if (a.trans == T_NONE)
     {
@@ -61,7 +62,8 @@ __global__ __launch_bounds__(256) void rotate_kernel(RotArgs a)
             {
                 int sx, sy;
                 rot_map(a, x, y, sx, sy);
-                a.dst[(size_t)y * a.dpitch + x] = a.src[(size_t)sy * a.spitch + sx];
+                reinterpret_cast<PIX *>(a.dst + (size_t)y * a.dpitch)[x] =
+                    reinterpret_cast<const PIX *>(a.src + (size_t)sy * a.spitch)[sx];
             }
         }
         return;
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(256) void rotate_kernel(RotArgs a)
         {
             int sx, sy;
             rot_map(a, x, y, sx, sy);
-            tile[r][threadIdx.x] = a.src[(size_t)sy * a.spitch + sx];
+            tile[r][threadIdx.x] = reinterpret_cast<const PIX *>(a.src + (size_t)sy * a.spitch)[sx];
         }
     }
     __syncthreads();
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(256) void rotate_kernel(RotArgs a)
     {
         const int x = ox + threadIdx.x, y = oy + r;
         if (x < a.dw && y < a.dh)
-            a.dst[(size_t)y * a.dpitch + x] = tile[threadIdx.x][r];
+            reinterpret_cast<PIX *>(a.dst + (size_t)y * a.dpitch)[x] = tile[threadIdx.x][r];
     }
 }
 
@@ -109,7 +111,8 @@ public:
             a.sw = in->width[c]; a.sh = in->height[c]; a.spitch = in->pitch[c];
             a.dw = out->width[c]; a.dh = out->height[c]; a.dpitch = out->pitch[c];
             a.trans = trans; a.hflip = hflip; a.vflip = vflip;
-            HBHIP_LAUNCH(ctx, "rotate", rotate_kernel, dim3((a.dw + 63) / 64, (a.dh + 63) / 64), dim3(64, 4), 0, a);
+            if (in_geo.bps == 1) HBHIP_LAUNCH(ctx, "rotate", rotate_kernel<uint8_t>, dim3((a.dw + 63) / 64, (a.dh + 63) / 64), dim3(64, 4), 0, a);
+            else                 HBHIP_LAUNCH(ctx, "rotate", rotate_kernel<uint16_t>, dim3((a.dw + 63) / 64, (a.dh + 63) / 64), dim3(64, 4), 0, a);
         }
         HBHIP_CHECK(ctx, hipGetLastError());
         return HBHIP_OK;
@@ -130,34 +133,37 @@ __device__ __forceinline__ float envelope(const float x)
     return tmp * tmp * (3.f - 2.f * tmp);
 }
 
+template <typename PIX>
 __global__ __launch_bounds__(256) void monochrome_kernel(const uint8_t *__restrict__ yp, int ypitch,
                                                          const uint8_t *__restrict__ up,
                                                          const uint8_t *__restrict__ vp, int cpitch,
                                                          uint8_t *__restrict__ dst, int dpitch, int w, int h,
                                                          int subw, int subh, const float *__restrict__ wlut,
-                                                         float ihigh)
+                                                         float ihigh, int max)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= w || y >= h) return;
-    const float imax = 1.f / 255;
+    const float imax = 1.f / max;
     const int cx = x >> subw, cy = y >> subh;
-    const float fy = yp[(size_t)y * ypitch + x] * imax;
-    const int u = up[(size_t)cy * cpitch + cx], v = vp[(size_t)cy * cpitch + cx];
-    float ny = wlut[u * 256 + v];                          // exp(-clip(dist/size)) built on the host
+    const float fy = reinterpret_cast<const PIX *>(yp + (size_t)y * ypitch)[x] * imax;
+    const int u = reinterpret_cast<const PIX *>(up + (size_t)cy * cpitch)[cx];
+    const int v = reinterpret_cast<const PIX *>(vp + (size_t)cy * cpitch)[cx];
+    float ny = wlut[(size_t)u * (max + 1) + v];            // exp(-clip(dist/size)) built on the host
     const float tt = envelope(fy);
     const float t = tt + (1.f - tt) * ihigh;
     ny = (1.f - t) * fy + t * ny * fy;
-    int q = __float2int_rn(ny * 255);
-    q = q < 0 ? 0 : q > 255 ? 255 : q;
-    dst[(size_t)y * dpitch + x] = (uint8_t)q;
+    int q = __float2int_rn(ny * max);
+    q = q < 0 ? 0 : q > max ? max : q;
+    reinterpret_cast<PIX *>(dst + (size_t)y * dpitch)[x] = (PIX)q;
 }
 
+template <typename PIX>
 __global__ void fill_plane_kernel(uint8_t *dst, int pitch, int w, int h, int value)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
-    if (x < w && y < h) dst[(size_t)y * pitch + x] = (uint8_t)value;
+    if (x < w && y < h) reinterpret_cast<PIX *>(dst + (size_t)y * pitch)[x] = (PIX)value;
 }
 
 class MonochromeFilter : public SimpleFilter
@@ -168,17 +174,19 @@ public:
     ~MonochromeFilter() override { if (d_lut) (void)hipFree(d_lut); }
     int setup()
     {
-        std::vector<float> lut(256 * 256);
-        const float imax = 1.f / 255;
+        // one entry per (Cb, Cr) pair: 256 KB at 8 bits, 4 MB at 10, 64 MB at 12
+        const int n = 1 << in_geo.depth;
+        std::vector<float> lut((size_t)n * n);
+        const float imax = 1.f / (n - 1);
         const float isize = 1.f / (float)size;
         const float b = (float)cb * .5f, r = (float)cr * .5f;
-        for (int u = 0; u < 256; u++)
-            for (int v = 0; v < 256; v++)
+        for (int u = 0; u < n; u++)
+            for (int v = 0; v < n; v++)
             {
                 const float fu = u * imax - .5f, fv = v * imax - .5f;
                 float d = ((b - fu) * (b - fu) + (r - fv) * (r - fv)) * isize;
                 d = d < 0.f ? 0.f : d > 1.f ? 1.f : d;
-                lut[u * 256 + v] = expf(-d);
+                lut[(size_t)u * n + v] = expf(-d);
             }
         HBHIP_CHECK(ctx, hipMalloc((void **)&d_lut, sizeof(float) * lut.size()));
         HBHIP_CHECK(ctx, hipMemcpyAsync(d_lut, lut.data(), sizeof(float) * lut.size(), hipMemcpyHostToDevice, ctx->stream));
@@ -188,13 +196,25 @@ public:
     int process(DevPicture *in, DevPicture *out) override
     {
         const int w = in->width[0], h = in->height[0];
-        HBHIP_LAUNCH(ctx, "monochrome", monochrome_kernel, dim3((w + 63) / 64, (h + 3) / 4), dim3(64, 4), 0,
-                     (const uint8_t *)in->plane[0], in->pitch[0], (const uint8_t *)in->plane[1],
-                     (const uint8_t *)in->plane[2], in->pitch[1], out->plane[0], out->pitch[0], w, h,
-                     in_geo.log2_cw, in_geo.log2_ch, (const float *)d_lut, 1.f - (float)high);
+        const int max = (1 << in_geo.depth) - 1, mid = 1 << (in_geo.depth - 1);
+        if (in_geo.bps == 1)
+            HBHIP_LAUNCH(ctx, "monochrome", monochrome_kernel<uint8_t>, dim3((w + 63) / 64, (h + 3) / 4), dim3(64, 4), 0,
+                         (const uint8_t *)in->plane[0], in->pitch[0], (const uint8_t *)in->plane[1],
+                         (const uint8_t *)in->plane[2], in->pitch[1], out->plane[0], out->pitch[0], w, h,
+                         in_geo.log2_cw, in_geo.log2_ch, (const float *)d_lut, 1.f - (float)high, max);
+        else
+            HBHIP_LAUNCH(ctx, "monochrome", monochrome_kernel<uint16_t>, dim3((w + 63) / 64, (h + 3) / 4), dim3(64, 4), 0,
+                         (const uint8_t *)in->plane[0], in->pitch[0], (const uint8_t *)in->plane[1],
+                         (const uint8_t *)in->plane[2], in->pitch[1], out->plane[0], out->pitch[0], w, h,
+                         in_geo.log2_cw, in_geo.log2_ch, (const float *)d_lut, 1.f - (float)high, max);
         for (int c = 1; c < 3; c++)
-            HBHIP_LAUNCH(ctx, "monochrome_fill", fill_plane_kernel, dim3((out->width[c] + 255) / 256, out->height[c]),
-                         dim3(256), 0, out->plane[c], out->pitch[c], out->width[c], out->height[c], 128);
+        {
+            const dim3 grid((out->width[c] + 255) / 256, out->height[c]);
+            if (in_geo.bps == 1) HBHIP_LAUNCH(ctx, "monochrome_fill", fill_plane_kernel<uint8_t>, grid, dim3(256), 0,
+                                              out->plane[c], out->pitch[c], out->width[c], out->height[c], mid);
+            else                 HBHIP_LAUNCH(ctx, "monochrome_fill", fill_plane_kernel<uint16_t>, grid, dim3(256), 0,
+                                              out->plane[c], out->pitch[c], out->width[c], out->height[c], mid);
+        }
         HBHIP_CHECK(ctx, hipGetLastError());
         return HBHIP_OK;
     }
@@ -210,12 +230,14 @@ struct ScaleArgs
     int spitch, dpitch, dw, dh, tx, ty;
     const int    *ix, *iy;
     const double *cx, *cy;
+    double vmax;             // (1 << depth) - 1
 };
 
 // Pass 1: H[r][x] = sum_i cx[x][i] * src[r][ix[x][i]] for every source row r of the crop window.
 // Pass 2: out[y][x] = round(clamp(sum_j cy[y][j] * H[iy[y][j]][x])).
 // Same products, same order of additions as the one-loop form in oracle/alias_oracle.c, so the
 // split changes nothing numerically; it turns taps^2 gathers per pixel into 2*taps.
+template <typename PIX>
 __global__ __launch_bounds__(256) void cropscale_h_kernel(ScaleArgs a, double *__restrict__ hbuf, int src_rows)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -223,13 +245,14 @@ __global__ __launch_bounds__(256) void cropscale_h_kernel(ScaleArgs a, double *_
     if (x >= a.dw || r >= src_rows) return;
     const int *ix = a.ix + (size_t)x * a.tx;
     const double *cx = a.cx + (size_t)x * a.tx;
-    const uint8_t *row = a.src + (size_t)r * a.spitch;
+    const PIX *row = reinterpret_cast<const PIX *>(a.src + (size_t)r * a.spitch);
     double h = 0.0;
     for (int i = 0; i < a.tx; i++)
         h += cx[i] * (double)row[ix[i]];
     hbuf[(size_t)r * a.dw + x] = h;
 }
 
+template <typename PIX>
 __global__ __launch_bounds__(256) void cropscale_v_kernel(ScaleArgs a, const double *__restrict__ hbuf)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -238,8 +261,8 @@ __global__ __launch_bounds__(256) void cropscale_v_kernel(ScaleArgs a, const dou
     double acc = 0.0;
     for (int j = 0; j < a.ty; j++)
         acc += a.cy[(size_t)y * a.ty + j] * hbuf[(size_t)a.iy[(size_t)y * a.ty + j] * a.dw + x];
-    acc = acc < 0.0 ? 0.0 : acc > 255.0 ? 255.0 : acc;
-    a.dst[(size_t)y * a.dpitch + x] = (uint8_t)(int)(acc + 0.5);
+    acc = acc < 0.0 ? 0.0 : acc > a.vmax ? a.vmax : acc;
+    reinterpret_cast<PIX *>(a.dst + (size_t)y * a.dpitch)[x] = (PIX)(int)(acc + 0.5);
 }
 
 // Both passes in one kernel: a workgroup owns a FS_TW x FS_TH tile of the output.  It first forms
@@ -251,7 +274,7 @@ struct ScaleArgs3 { ScaleArgs p[3]; int active[3]; };
 
 // TX / TY > 0: the tap counts are compile-time (6 x 6 for any upscale), so the taps of a thread's
 // column live in registers and the loops unroll; 0 = read the counts from the arguments.
-template <int TX, int TY>
+template <int TX, int TY, typename PIX>
 __global__ __launch_bounds__(256) void cropscale_fused_kernel(ScaleArgs3 all)
 {
     __shared__ double s_h[FS_MAXR][FS_TW];
@@ -291,7 +314,7 @@ __global__ __launch_bounds__(256) void cropscale_fused_kernel(ScaleArgs3 all)
             for (int i = 0; i < TX; i++) { ixr[i] = ix[i]; cxr[i] = cx[i]; }
             for (int rr = wave_row; rr < nr; rr += 256 / FS_TW)
             {
-                const uint8_t *row = a.src + (size_t)(rmin + rr) * a.spitch;
+                const PIX *row = reinterpret_cast<const PIX *>(a.src + (size_t)(rmin + rr) * a.spitch);
                 double h = 0.0;
 #pragma unroll
                 for (int i = 0; i < TX; i++) h += cxr[i] * (double)row[ixr[i]];
@@ -302,7 +325,7 @@ __global__ __launch_bounds__(256) void cropscale_fused_kernel(ScaleArgs3 all)
         {
             for (int rr = wave_row; rr < nr; rr += 256 / FS_TW)
             {
-                const uint8_t *row = a.src + (size_t)(rmin + rr) * a.spitch;
+                const PIX *row = reinterpret_cast<const PIX *>(a.src + (size_t)(rmin + rr) * a.spitch);
                 double h = 0.0;
                 for (int i = 0; i < tx; i++) h += cx[i] * (double)row[ix[i]];
                 s_h[rr][xl] = h;
@@ -326,8 +349,8 @@ __global__ __launch_bounds__(256) void cropscale_fused_kernel(ScaleArgs3 all)
         {
             for (int j = 0; j < ty; j++) acc += cy[j] * s_h[iy[j] - rmin][xl];
         }
-        acc = acc < 0.0 ? 0.0 : acc > 255.0 ? 255.0 : acc;
-        a.dst[(size_t)y * a.dpitch + x] = (uint8_t)(int)(acc + 0.5);
+        acc = acc < 0.0 ? 0.0 : acc > a.vmax ? a.vmax : acc;
+        reinterpret_cast<PIX *>(a.dst + (size_t)y * a.dpitch)[x] = (PIX)(int)(acc + 0.5);
     }
 }
 
@@ -452,12 +475,13 @@ public:
         memset(&all, 0, sizeof(all));
         for (int c = 0; c < 3; c++)
         {
-            const uint8_t *win = in->plane[c] + (size_t)crop_y[c] * in->pitch[c] + crop_x[c];
+            const uint8_t *win = in->plane[c] + (size_t)crop_y[c] * in->pitch[c] + (size_t)crop_x[c] * in_geo.bps;
             const int dw = out->width[c], dh = out->height[c];
+            const double vmax = (double)((1 << in_geo.depth) - 1);
             if (identity[c])
             {
-                HBHIP_LAUNCH(ctx, "crop_copy", crop_copy_kernel, dim3((dw + 255) / 256, dh), dim3(256), 0,
-                             win, in->pitch[c], out->plane[c], out->pitch[c], dw, dh);
+                HBHIP_LAUNCH(ctx, "crop_copy", crop_copy_kernel, dim3((dw * in_geo.bps + 255) / 256, dh), dim3(256), 0,
+                             win, in->pitch[c], out->plane[c], out->pitch[c], dw * in_geo.bps, dh);
                 continue;
             }
             if (fused)
@@ -466,7 +490,7 @@ public:
                 f.src = win; f.dst = out->plane[c];
                 f.spitch = in->pitch[c]; f.dpitch = out->pitch[c];
                 f.dw = dw; f.dh = dh; f.tx = tx[c]; f.ty = ty[c];
-                f.ix = d_ix[c]; f.iy = d_iy[c]; f.cx = d_cx[c]; f.cy = d_cy[c];
+                f.ix = d_ix[c]; f.iy = d_iy[c]; f.cx = d_cx[c]; f.cy = d_cy[c]; f.vmax = vmax;
                 all.active[c] = 1;
                 continue;
             }
@@ -474,19 +498,34 @@ public:
             a.src = win; a.dst = out->plane[c];
             a.spitch = in->pitch[c]; a.dpitch = out->pitch[c];
             a.dw = dw; a.dh = dh; a.tx = tx[c]; a.ty = ty[c];
-            a.ix = d_ix[c]; a.iy = d_iy[c]; a.cx = d_cx[c]; a.cy = d_cy[c];
-            HBHIP_LAUNCH(ctx, "cropscale_lanczos_h", cropscale_h_kernel, dim3((dw + 63) / 64, (crop_h[c] + 3) / 4),
-                         dim3(64, 4), 0, a, hbuf, crop_h[c]);
-            HBHIP_LAUNCH(ctx, "cropscale_lanczos_v", cropscale_v_kernel, dim3((dw + 63) / 64, (dh + 3) / 4),
-                         dim3(64, 4), 0, a, (const double *)hbuf);
+            a.ix = d_ix[c]; a.iy = d_iy[c]; a.cx = d_cx[c]; a.cy = d_cy[c]; a.vmax = vmax;
+            const dim3 gh((dw + 63) / 64, (crop_h[c] + 3) / 4), gv((dw + 63) / 64, (dh + 3) / 4);
+            if (in_geo.bps == 1)
+            {
+                HBHIP_LAUNCH(ctx, "cropscale_lanczos_h", cropscale_h_kernel<uint8_t>, gh, dim3(64, 4), 0, a, hbuf, crop_h[c]);
+                HBHIP_LAUNCH(ctx, "cropscale_lanczos_v", cropscale_v_kernel<uint8_t>, gv, dim3(64, 4), 0, a, (const double *)hbuf);
+            }
+            else
+            {
+                HBHIP_LAUNCH(ctx, "cropscale_lanczos_h", cropscale_h_kernel<uint16_t>, gh, dim3(64, 4), 0, a, hbuf, crop_h[c]);
+                HBHIP_LAUNCH(ctx, "cropscale_lanczos_v", cropscale_v_kernel<uint16_t>, gv, dim3(64, 4), 0, a, (const double *)hbuf);
+            }
         }
         if (all.active[0] || all.active[1] || all.active[2])
         {
             const dim3 grid((out->width[0] + FS_TW - 1) / FS_TW, (out->height[0] + FS_TH - 1) / FS_TH, 3);
             bool six = true;
             for (int c = 0; c < 3; c++) six &= !all.active[c] || (tx[c] == 6 && ty[c] == 6);
-            if (six) HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", (cropscale_fused_kernel<6, 6>), grid, dim3(256), 0, all);
-            else     HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", (cropscale_fused_kernel<0, 0>), grid, dim3(256), 0, all);
+            if (in_geo.bps == 1)
+            {
+                if (six) HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", (cropscale_fused_kernel<6, 6, uint8_t>), grid, dim3(256), 0, all);
+                else     HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", (cropscale_fused_kernel<0, 0, uint8_t>), grid, dim3(256), 0, all);
+            }
+            else
+            {
+                if (six) HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", (cropscale_fused_kernel<6, 6, uint16_t>), grid, dim3(256), 0, all);
+                else     HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", (cropscale_fused_kernel<0, 0, uint16_t>), grid, dim3(256), 0, all);
+            }
         }
         HBHIP_CHECK(ctx, hipGetLastError());
         return HBHIP_OK;
@@ -507,7 +546,7 @@ extern "C" int hbhip_rotate_create(hbhip_ctx *ctx, int angle, int hflip, int wid
 {
     if (!ctx || !out) return HBHIP_ERR_ARG;
     *out = nullptr;
-    if (depth != 8) return HBHIP_ERR_UNSUPPORTED;
+    if (depth != 8 && depth != 10 && depth != 12) return HBHIP_ERR_UNSUPPORTED;
     if (angle != 0 && angle != 90 && angle != 180 && angle != 270) return HBHIP_ERR_ARG;
     if ((angle == 90 || angle == 270) && log2_chroma_w != log2_chroma_h) return HBHIP_ERR_UNSUPPORTED;
     (void)hipSetDevice(ctx->device);
@@ -528,7 +567,7 @@ extern "C" int hbhip_grayscale_create(hbhip_ctx *ctx, double cb, double cr, doub
 {
     if (!ctx || !out) return HBHIP_ERR_ARG;
     *out = nullptr;
-    if (depth != 8) return HBHIP_ERR_UNSUPPORTED;
+    if (depth != 8 && depth != 10 && depth != 12) return HBHIP_ERR_UNSUPPORTED;
     if (!(size > 0)) return HBHIP_ERR_ARG;
     (void)hipSetDevice(ctx->device);
     MonochromeFilter *f = new (std::nothrow) MonochromeFilter(ctx, cb, cr, size, high);
@@ -547,7 +586,7 @@ extern "C" int hbhip_cropscale_create(hbhip_ctx *ctx, const hbhip_cropscale_para
 {
     if (!ctx || !p || !out) return HBHIP_ERR_ARG;
     *out = nullptr;
-    if (depth != 8) return HBHIP_ERR_UNSUPPORTED;
+    if (depth != 8 && depth != 10 && depth != 12) return HBHIP_ERR_UNSUPPORTED;
     if (p->width < 1 || p->height < 1) return HBHIP_ERR_ARG;
     (void)hipSetDevice(ctx->device);
     CropScaleFilter *f = new (std::nothrow) CropScaleFilter(ctx, *p);

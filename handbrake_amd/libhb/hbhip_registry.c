@@ -289,7 +289,8 @@ static int adapter_init(hb_filter_object_t *filter, hb_filter_init_t *init, int 
     hb_filter_private_t *pv = calloc(1, sizeof(*pv));
     if (pv == NULL) return 1;
     const AVPixFmtDescriptor *desc = av_pix_fmt_desc_get(init->pix_fmt);
-    if (desc == NULL || desc->comp[0].depth != 8 || hbhip_host_ctx() == NULL)
+    if (desc == NULL || (desc->comp[0].depth != 8 && desc->comp[0].depth != 10 && desc->comp[0].depth != 12) ||
+        hbhip_host_ctx() == NULL)
     {
         free(pv);
         return 1;

@@ -36,8 +36,26 @@
 /* ---- rotate -------------------------------------------------------------------- */
 enum { T_NONE, T_CCLOCK_FLIP, T_CLOCK, T_CCLOCK, T_CLOCK_FLIP };
 
+static inline unsigned getpx(const void *plane, int stride, int x, int y, int bps)
+{
+    const uint8_t *row = (const uint8_t *)plane + (size_t)y * stride;
+    return bps == 1 ? row[x] : ((const uint16_t *)row)[x];
+}
+static inline void setpx(void *plane, int stride, int x, int y, int bps, unsigned v)
+{
+    uint8_t *row = (uint8_t *)plane + (size_t)y * stride;
+    if (bps == 1) row[x] = (uint8_t)v; else ((uint16_t *)row)[x] = (uint16_t)v;
+}
+
 void orc_rotate_plane(const uint8_t *src, int sw, int sh, int sstride,
                       uint8_t *dst, int dstride, int angle, int flip)
+{
+    orc_rotate_plane_d(src, sw, sh, sstride, dst, dstride, angle, flip, 1);
+}
+
+/* bps = bytes per sample (1, or 2 for 10 / 12-bit); strides in bytes */
+void orc_rotate_plane_d(const void *src, int sw, int sh, int sstride,
+                        void *dst, int dstride, int angle, int flip, int bps)
 {
     /* rotate.c:190-215: 0 -> hflip if asked; 90 -> clock[_flip]; 180 -> vflip (+hflip
      * unless asked); 270 -> cclock[_flip] */
@@ -63,13 +81,13 @@ void orc_rotate_plane(const uint8_t *src, int sw, int sh, int sstride,
                     case T_CCLOCK:      sx = sw - 1 - y; sy = x;          break;
                     default:            sx = sw - 1 - y; sy = sh - 1 - x; break;
                 }
-                dst[(size_t)y * dstride + x] = src[(size_t)sy * sstride + sx];
+                setpx(dst, dstride, x, y, bps, getpx(src, sstride, sx, sy, bps));
             }
         return;
     }
     for (int y = 0; y < sh; y++)
         for (int x = 0; x < sw; x++)
-            dst[(size_t)y * dstride + x] = src[(size_t)(vflip ? sh - 1 - y : y) * sstride + (hflip ? sw - 1 - x : x)];
+            setpx(dst, dstride, x, y, bps, getpx(src, sstride, hflip ? sw - 1 - x : x, vflip ? sh - 1 - y : y, bps));
 }
 
 /* ---- monochrome ------------------------------------------------------------------ */
@@ -96,7 +114,16 @@ void orc_monochrome_luma(const uint8_t *yp, int ystride, const uint8_t *up, cons
                          uint8_t *dst, int dstride, int w, int h, int subw, int subh,
                          double cb, double cr, double size, double high)
 {
-    const float imax = 1.f / 255;
+    orc_monochrome_luma_d(yp, ystride, up, vp, cstride, dst, dstride, w, h, subw, subh, cb, cr, size, high, 8);
+}
+
+/* vf_monochrome.c's 16-bit slice functions are the 8-bit ones with 255 replaced by (1 << depth) - 1 */
+void orc_monochrome_luma_d(const void *yp, int ystride, const void *up, const void *vp, int cstride,
+                           void *dst, int dstride, int w, int h, int subw, int subh,
+                           double cb, double cr, double size, double high, int depth)
+{
+    const int bps = depth > 8 ? 2 : 1, max = (1 << depth) - 1;
+    const float imax = 1.f / max;
     const float ihigh = 1.f - (float)high;
     const float isize = 1.f / (float)size;
     const float b = (float)cb * .5f, r = (float)cr * .5f;
@@ -104,15 +131,15 @@ void orc_monochrome_luma(const uint8_t *yp, int ystride, const uint8_t *up, cons
         for (int x = 0; x < w; x++)
         {
             const int cx = x >> subw, cy = y >> subh;
-            const float fy = yp[(size_t)y * ystride + x] * imax;
-            const float fu = up[(size_t)cy * cstride + cx] * imax - .5f;
-            const float fv = vp[(size_t)cy * cstride + cx] * imax - .5f;
+            const float fy = getpx(yp, ystride, x, y, bps) * imax;
+            const float fu = getpx(up, cstride, cx, cy, bps) * imax - .5f;
+            const float fv = getpx(vp, cstride, cx, cy, bps) * imax - .5f;
             float ny = chroma_weight(b, r, fu, fv, isize);
             const float tt = envelope(fy);
             const float t = tt + (1.f - tt) * ihigh;
             ny = (1.f - t) * fy + t * ny * fy;
-            long q = lrintf(ny * 255);
-            dst[(size_t)y * dstride + x] = q < 0 ? 0 : q > 255 ? 255 : (uint8_t)q;
+            long q = lrintf(ny * max);
+            setpx(dst, dstride, x, y, bps, q < 0 ? 0 : q > max ? max : (unsigned)q);
         }
 }
 
@@ -162,11 +189,20 @@ int orc_lanczos_table(int src_dim, int dst_dim, double shift, int *idx, double *
 void orc_cropscale_plane(const uint8_t *src, int sstride, int crop_x, int crop_y, int crop_w, int crop_h,
                          uint8_t *dst, int dstride, int dw, int dh, double shift_x, double shift_y)
 {
-    const uint8_t *win = src + (size_t)crop_y * sstride + crop_x;
+    orc_cropscale_plane_d(src, sstride, crop_x, crop_y, crop_w, crop_h, dst, dstride, dw, dh, shift_x, shift_y, 8);
+}
+
+/* the same for `depth`-bit samples (uint16 above 8): only the clip limit changes */
+void orc_cropscale_plane_d(const void *src, int sstride, int crop_x, int crop_y, int crop_w, int crop_h,
+                           void *dst, int dstride, int dw, int dh, double shift_x, double shift_y, int depth)
+{
+    const int bps = depth > 8 ? 2 : 1;
+    const double vmax = (double)((1 << depth) - 1);
+    const uint8_t *win = (const uint8_t *)src + (size_t)crop_y * sstride + (size_t)crop_x * bps;
     if (dw == crop_w && dh == crop_h && shift_x == 0.0 && shift_y == 0.0)
     {
         for (int y = 0; y < dh; y++)
-            memcpy(dst + (size_t)y * dstride, win + (size_t)y * sstride, dw);
+            memcpy((uint8_t *)dst + (size_t)y * dstride, win + (size_t)y * sstride, (size_t)dw * bps);
         return;
     }
     int *ix = malloc(sizeof(int) * (size_t)dw * 64), *iy = malloc(sizeof(int) * (size_t)dh * 64);
@@ -179,14 +215,14 @@ void orc_cropscale_plane(const uint8_t *src, int sstride, int crop_x, int crop_y
             double acc = 0.0;
             for (int j = 0; j < ty; j++)
             {
-                const uint8_t *row = win + (size_t)iy[(size_t)y * ty + j] * sstride;
+                const int r = iy[(size_t)y * ty + j];
                 double h = 0.0;
                 for (int i = 0; i < tx; i++)
-                    h += cx[(size_t)x * tx + i] * row[ix[(size_t)x * tx + i]];
+                    h += cx[(size_t)x * tx + i] * (double)getpx(win, sstride, ix[(size_t)x * tx + i], r, bps);
                 acc += cy[(size_t)y * ty + j] * h;
             }
-            acc = acc < 0.0 ? 0.0 : acc > 255.0 ? 255.0 : acc;
-            dst[(size_t)y * dstride + x] = (uint8_t)(int)(acc + 0.5);
+            acc = acc < 0.0 ? 0.0 : acc > vmax ? vmax : acc;
+            setpx(dst, dstride, x, y, bps, (unsigned)(int)(acc + 0.5));
         }
     free(ix); free(iy); free(cx); free(cy);
 }

@@ -225,6 +225,14 @@ void orc_monochrome_luma(const uint8_t *y, int ystride, const uint8_t *u, const 
  * pixels; shift_x is the sub-sample shift zimg applies to left-sited chroma. */
 void orc_cropscale_plane(const uint8_t *src, int sstride, int crop_x, int crop_y, int crop_w, int crop_h,
                          uint8_t *dst, int dstride, int dw, int dh, double shift_x, double shift_y);
+/* The same three for `depth`-bit samples (uint16 planes above 8 bits; strides in bytes). */
+void orc_rotate_plane_d(const void *src, int sw, int sh, int sstride,
+                        void *dst, int dstride, int angle, int flip, int bps);
+void orc_monochrome_luma_d(const void *yp, int ystride, const void *up, const void *vp, int cstride,
+                           void *dst, int dstride, int w, int h, int subw, int subh,
+                           double cb, double cr, double size, double high, int depth);
+void orc_cropscale_plane_d(const void *src, int sstride, int crop_x, int crop_y, int crop_w, int crop_h,
+                           void *dst, int dstride, int dw, int dh, double shift_x, double shift_y, int depth);
 /* The tap table of one dimension (exposed so tests can look at it): for each of the
  * `dst_dim` outputs `taps` (index, weight) pairs; returns taps. idx/coef sized dst_dim*64. */
 int orc_lanczos_table(int src_dim, int dst_dim, double shift, int *idx, double *coef);

@@ -405,35 +405,40 @@ class OrcHqdn3d:
 
 
 # ---------------------------------------------------------------- alias family (parity unpinned)
+def _depth_of(frame):
+    return 8 if frame[0].dtype == np.uint8 else None
+
+
 def orc_rotate_frame(frame, angle, hflip):
-    fn = oracle().orc_rotate_plane
-    fn.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int]
+    fn = oracle().orc_rotate_plane_d
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
     out = []
     for p in frame:
         p = np.ascontiguousarray(p)
         h, w = p.shape
-        dst = np.zeros((w, h) if angle in (90, 270) else (h, w), np.uint8)
-        fn(u8p(p), w, h, p.strides[0], u8p(dst), dst.strides[0], angle, int(hflip))
+        dst = np.zeros((w, h) if angle in (90, 270) else (h, w), p.dtype)
+        fn(p.ctypes.data, w, h, p.strides[0], dst.ctypes.data, dst.strides[0], angle, int(hflip), p.itemsize)
         out.append(dst)
     return tuple(out)
 
 
-def orc_grayscale_frame(frame, cb=0.0, cr=0.0, size=1.0, high=0.0):
-    fn = oracle().orc_monochrome_luma
-    fn.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int,
-                   C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                   C.c_double, C.c_double, C.c_double, C.c_double]
+def orc_grayscale_frame(frame, cb=0.0, cr=0.0, size=1.0, high=0.0, depth=8):
+    fn = oracle().orc_monochrome_luma_d
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                   C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                   C.c_double, C.c_double, C.c_double, C.c_double, C.c_int]
     y, u, v = [np.ascontiguousarray(p) for p in frame]
     h, w = y.shape
     dst = np.zeros_like(y)
-    fn(u8p(y), y.strides[0], u8p(u), u8p(v), u.strides[0], u8p(dst), dst.strides[0], w, h, 1, 1, cb, cr, size, high)
-    return dst, np.full_like(u, 128), np.full_like(v, 128)
+    fn(y.ctypes.data, y.strides[0], u.ctypes.data, v.ctypes.data, u.strides[0], dst.ctypes.data, dst.strides[0],
+       w, h, 1, 1, cb, cr, size, high, depth)
+    return dst, np.full_like(u, 1 << (depth - 1)), np.full_like(v, 1 << (depth - 1))
 
 
-def orc_cropscale_frame(frame, width, height, top=0, bottom=0, left=0, right=0):
-    fn = oracle().orc_cropscale_plane
-    fn.argtypes = [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint8), C.c_int,
-                   C.c_int, C.c_int, C.c_double, C.c_double]
+def orc_cropscale_frame(frame, width, height, top=0, bottom=0, left=0, right=0, depth=8):
+    fn = oracle().orc_cropscale_plane_d
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                   C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]
     h0, w0 = frame[0].shape
     cw, ch = w0 - left - right, h0 - top - bottom
     out = []
@@ -445,8 +450,8 @@ def orc_cropscale_frame(frame, width, height, top=0, bottom=0, left=0, right=0):
             cx, cy, pw, ph = left >> 1, top >> 1, (cw + 1) // 2, (ch + 1) // 2
             dw, dh = (width + 1) // 2, (height + 1) // 2
             sx = 0.25 * (1.0 - cw / width)
-        dst = np.zeros((dh, dw), np.uint8)
-        fn(u8p(p), p.strides[0], cx, cy, pw, ph, u8p(dst), dst.strides[0], dw, dh, sx, 0.0)
+        dst = np.zeros((dh, dw), p.dtype)
+        fn(p.ctypes.data, p.strides[0], cx, cy, pw, ph, dst.ctypes.data, dst.strides[0], dw, dh, sx, 0.0, depth)
         out.append(dst)
     return tuple(out)
 

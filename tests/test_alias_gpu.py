@@ -58,3 +58,55 @@ def test_config1_grayscale_then_rotate(built):
     got = hbrt.run_stream(hip.filters(), chain, frames)
     want = os_.grayscale_stream(os_.rotate_stream(frames, dict(angle=90)), {})
     check(got, want)
+
+
+# ---- 10 / 12-bit samples: the same kernels instantiated for uint16 ----------
+def run16(stage, frames, depth):
+    return hbrt.run_stream(hip.filters(), [stage], frames, pix_fmt=hbrt.PIX_FMT_FOR_DEPTH[depth])
+
+
+@pytest.mark.parametrize("depth", [10, 12])
+@pytest.mark.parametrize("angle,flip", [(0, 1), (90, 0), (180, 1), (270, 1)])
+def test_rotate_16bit(built, depth, angle, flip):
+    frames = synth.stream("progressive", 638, 362, 2, depth=depth)
+    got = run16(("hb_filter_rotate_hip", f"angle={angle}:hflip={flip}"), frames, depth)
+    check(got, os_.rotate_stream(frames, dict(angle=angle, hflip=flip)))
+    assert got[0].planes[0].dtype == np.uint16
+
+
+@pytest.mark.parametrize("depth", [10, 12])
+@pytest.mark.parametrize("st,par", [("cb=0:cr=0:size=1:high=0", {}),
+                                    ("cb=0.3:cr=-0.2:size=0.5:high=0.4", dict(cb=0.3, cr=-0.2, size=0.5, high=0.4))])
+def test_grayscale_16bit(built, depth, st, par):
+    frames = synth.stream("progressive", 638, 362, 1, depth=depth) + synth.stream("random", 638, 362, 1, depth=depth)
+    check(run16(("hb_filter_grayscale_hip", st), frames, depth), os_.grayscale_stream(frames, dict(par, depth=depth)))
+
+
+@pytest.mark.parametrize("depth", [10, 12])
+@pytest.mark.parametrize("w,h,ow,oh,crop", [(320, 180, 640, 360, (0, 0, 0, 0)), (640, 360, 320, 180, (0, 0, 0, 0)),
+                                            (638, 362, 850, 480, (2, 4, 6, 8)), (1920, 1080, 3840, 2160, (0, 0, 0, 0))])
+def test_cropscale_16bit(built, depth, w, h, ow, oh, crop):
+    frames = synth.stream("progressive", w, h, 1, depth=depth) + ([] if w > 1000 else synth.stream("random", w, h, 1, depth=depth))
+    t, b, l, r = crop
+    st = f"width={ow}:height={oh}:crop-top={t}:crop-bottom={b}:crop-left={l}:crop-right={r}"
+    got = run16(("hb_filter_crop_scale_hip", st), frames, depth)
+    check(got, os_.cropscale_stream(frames, dict(width=ow, height=oh, top=t, bottom=b, left=l, right=r, depth=depth)))
+
+
+def test_10bit_device_resident_chain(built):
+    """HDR-style chain that never leaves HBM: colorspace (PQ -> 709) -> crop-scale -> lapsharp, 10-bit."""
+    frames = synth.stream("progressive", 640, 360, 3, depth=10)
+    chain = [("hb_filter_colorspace_hip", "primaries=bt709:transfer=bt709:matrix=bt709"),
+             ("hb_filter_crop_scale_hip", "width=960:height=540"),
+             ("hb_filter_lapsharp_hip", "y-strength=0.2:y-kernel=isolap:cb-strength=0.2:cb-kernel=isolap")]
+    hbrt.set_source_color(9, 16, 9, 1)
+    try:
+        host = hbrt.run_stream(hip.filters(), chain, frames, pix_fmt=hbrt.PIX_FMT_FOR_DEPTH[10])
+        dev = hbrt.run_stream(hip.filters(), [("hb_filter_hip_upload", "")] + chain + [("hb_filter_hip_download", "")],
+                              frames, pix_fmt=hbrt.PIX_FMT_FOR_DEPTH[10])
+    finally:
+        hbrt.set_source_color()
+    assert len(dev) == len(host) == 3
+    for t in range(3):
+        for c in range(3):
+            np.testing.assert_array_equal(dev[t].planes[c], host[t].planes[c], err_msg=f"frame {t} plane {c}")
