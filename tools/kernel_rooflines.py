@@ -8,6 +8,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
 import torch
 from handbrake_amd import hip, synth
 
@@ -17,16 +18,16 @@ FRAME = W * H * 3 // 2
 N = 24
 
 
-def planes(w, h):
-    return [torch.empty((h, w), dtype=torch.uint8, device="cuda"),
-            torch.empty((h // 2, w // 2), dtype=torch.uint8, device="cuda"),
-            torch.empty((h // 2, w // 2), dtype=torch.uint8, device="cuda")]
+def planes(w, h, dtype=torch.uint8):
+    return [torch.empty((h, w), dtype=dtype, device="cuda"),
+            torch.empty((h // 2, w // 2), dtype=dtype, device="cuda"),
+            torch.empty((h // 2, w // 2), dtype=dtype, device="cuda")]
 
 
-def simple(ctx, make, w, h, ow, oh, model="progressive", feeds=N):
-    frames = synth.stream(model, w, h, 4)
-    dev_in = [[torch.from_numpy(p).cuda() for p in fr] for fr in frames]
-    out = planes(ow, oh)
+def simple(ctx, make, w, h, ow, oh, model="progressive", feeds=N, depth=8):
+    frames = synth.stream(model, w, h, 4, depth=depth)
+    dev_in = [[torch.from_numpy(p.view(np.int16) if depth > 8 else p).cuda() for p in fr] for fr in frames]
+    out = planes(ow, oh, torch.int16 if depth > 8 else torch.uint8)
     torch.cuda.synchronize()
     flt = make()
     fin = [hip.dev_frame(f) for f in dev_in]
@@ -159,6 +160,49 @@ def main():
     add(st, {"comb_detect": 3 * Y + Y, "comb_mask_filter": 2 * Y, "comb_mask_erode": 2 * Y, "comb_mask_dilate": 2 * Y,
              "comb_block_score": Y})
     cd.close()
+    # colorspace: BT.601 -> BT.709 8-bit (linearised, primaries change) and HDR10 -> BT.709 10-bit (hable)
+    add(simple(ctx, lambda: hip.colorspace_device_filter(ctx, W, H, (6, 6, 6, 1), (1, 1, 1, 1)), W, H, W, H),
+        {"colorspace": 2 * FRAME})
+    res["colorspace (8-bit SDR 601->709)"] = res.pop("colorspace")
+    add(simple(ctx, lambda: hip.colorspace_device_filter(ctx, W, H, (9, 16, 9, 1), (1, 1, 1, 1), peak=100.0, depth=10),
+               W, H, W, H, depth=10), {"colorspace": 2 * 2 * FRAME})
+    res["colorspace (10-bit HDR10->709 hable)"] = res.pop("colorspace")
+    add(simple(ctx, lambda: hip.colorspace_device_filter(ctx, W, H, (1, 1, 1, 1), (1, 1, 6, 2)), W, H, W, H),
+        {"colorspace": 2 * FRAME})
+    res["colorspace (8-bit matrix+range only)"] = res.pop("colorspace")
+    # subtitle compositor: 8 overlays (about 20 % of the picture) on a device-resident 1080p frame
+    frame = [torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in synth.stream("progressive", W, H, 1)[0]]
+    ovs = synth.overlays(W, H, 8, seed=5, inside=True)
+    touched = sum(int(o[2][0].size * 2 * 1.5 + o[2][0].size * 4) for o in ovs)     # frame samples read+written, bitmaps read
+    b = hip.BlendDevice(ctx, W, H)
+    b.set_overlays(ovs)
+    fd = hip.dev_frame(frame)
+    b.apply_dev(fd)
+    ctx.sync(); ctx.profile(True); ctx.profile_reset()
+    for i in range(N):
+        b.apply_dev(fd)
+    ctx.sync()
+    st = ctx.profile_stats(); ctx.profile(False)
+    add(st, {"blend_subsample": touched // len(ovs)})
+    b.close()
+    # vfr's motion metric: two 1080p lumas read once
+    L.hbhip_motion_metric_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    L.hbhip_motion_metric_run_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_float)]
+    L.hbhip_motion_metric_destroy.argtypes = [C.c_void_p]
+    lut = (C.c_uint * 256)(*[int(4095 * (np.float32(i) / np.float32(254)) ** 2.2) for i in range(256)])
+    m = C.c_void_p()
+    hip.check(L.hbhip_motion_metric_create(ctx.h, W, H, 8, lut, 256, C.byref(m)), ctx.h)
+    fr2 = [torch.from_numpy(np.ascontiguousarray(f[0])).cuda() for f in synth.stream("progressive", W, H, 2)]
+    torch.cuda.synchronize()
+    val = C.c_float()
+    L.hbhip_motion_metric_run_dev(m, fr2[0].data_ptr(), W, fr2[1].data_ptr(), W, C.byref(val))
+    ctx.sync(); ctx.profile(True); ctx.profile_reset()
+    for i in range(N):
+        L.hbhip_motion_metric_run_dev(m, fr2[0].data_ptr(), W, fr2[1].data_ptr(), W, C.byref(val))
+    ctx.sync()
+    st = ctx.profile_stats(); ctx.profile(False)
+    add(st, {"motion_metric": 2 * Y})
+    L.hbhip_motion_metric_destroy(m)
     print(json.dumps(res, indent=1))
     ctx.close()
 
