@@ -539,7 +539,75 @@ public:
     double *hbuf = nullptr;     // horizontally filtered rows of one plane (dst_w x crop_h doubles)
 };
 
+// ------------------------------------------------------------------ pad
+// FFmpeg vf_pad as pad_init configures it (libhb/pad.c:40-148): the picture at (x, y) of a larger
+// one, the rest one colour.  One launch for the three planes; HBM-bound (read in, write out).
+struct PadArgs
+{
+    const uint8_t *src[3];
+    uint8_t       *dst[3];
+    int spitch[3], dpitch[3], sw[3], sh[3], dw[3], dh[3], x[3], y[3], fill[3];
+};
+
+template <typename PIX>
+__global__ __launch_bounds__(256) void pad_kernel(PadArgs a)
+{
+    const int c = blockIdx.z;
+    const int xx = blockIdx.x * blockDim.x + threadIdx.x, yy = blockIdx.y * blockDim.y + threadIdx.y;
+    if (xx >= a.dw[c] || yy >= a.dh[c]) return;
+    const int sx = xx - a.x[c], sy = yy - a.y[c];
+    const bool inside = sx >= 0 && sx < a.sw[c] && sy >= 0 && sy < a.sh[c];
+    const PIX v = inside ? reinterpret_cast<const PIX *>(a.src[c] + (size_t)sy * a.spitch[c])[sx] : (PIX)a.fill[c];
+    reinterpret_cast<PIX *>(a.dst[c] + (size_t)yy * a.dpitch[c])[xx] = v;
+}
+
+class PadFilter : public SimpleFilter
+{
+public:
+    PadFilter(hbhip_ctx *c, const hbhip_pad_params &p) : SimpleFilter(c), par(p) {}
+    int process(DevPicture *in, DevPicture *out) override
+    {
+        PadArgs a;
+        for (int c = 0; c < 3; c++)
+        {
+            a.src[c] = in->plane[c]; a.dst[c] = out->plane[c];
+            a.spitch[c] = in->pitch[c]; a.dpitch[c] = out->pitch[c];
+            a.sw[c] = in->width[c]; a.sh[c] = in->height[c]; a.dw[c] = out->width[c]; a.dh[c] = out->height[c];
+            a.x[c] = c ? par.x >> in_geo.log2_cw : par.x;
+            a.y[c] = c ? par.y >> in_geo.log2_ch : par.y;
+            a.fill[c] = par.fill[c];
+        }
+        const dim3 grid((a.dw[0] + 63) / 64, (a.dh[0] + 3) / 4, 3);
+        if (in_geo.bps == 1) HBHIP_LAUNCH(ctx, "pad", pad_kernel<uint8_t>, grid, dim3(64, 4), 0, a);
+        else                 HBHIP_LAUNCH(ctx, "pad", pad_kernel<uint16_t>, grid, dim3(64, 4), 0, a);
+        HBHIP_CHECK(ctx, hipGetLastError());
+        return HBHIP_OK;
+    }
+    hbhip_pad_params par;
+};
+
 } // namespace
+
+extern "C" int hbhip_pad_create(hbhip_ctx *ctx, const hbhip_pad_params *p, int width, int height, int depth,
+                                int log2_chroma_w, int log2_chroma_h, hbhip_filter **out)
+{
+    if (!ctx || !p || !out) return HBHIP_ERR_ARG;
+    *out = nullptr;
+    if (depth != 8 && depth != 10 && depth != 12) return HBHIP_ERR_UNSUPPORTED;
+    if (p->width < width || p->height < height || p->x < 0 || p->y < 0 ||
+        p->x + width > p->width || p->y + height > p->height) return HBHIP_ERR_ARG;
+    // vf_pad rounds the offsets down to the chroma subsampling; the caller has done so
+    if ((p->x & ((1 << log2_chroma_w) - 1)) || (p->y & ((1 << log2_chroma_h) - 1))) return HBHIP_ERR_ARG;
+    (void)hipSetDevice(ctx->device);
+    PadFilter *f = new (std::nothrow) PadFilter(ctx, *p);
+    if (!f) return HBHIP_ERR_NOMEM;
+    PicGeometry gi, go;
+    gi.set(width, height, depth, log2_chroma_w, log2_chroma_h);
+    go.set(p->width, p->height, depth, log2_chroma_w, log2_chroma_h);
+    f->configure(gi, go);
+    *out = f;
+    return HBHIP_OK;
+}
 
 extern "C" int hbhip_rotate_create(hbhip_ctx *ctx, int angle, int hflip, int width, int height, int depth,
                                    int log2_chroma_w, int log2_chroma_h, hbhip_filter **out)

@@ -248,6 +248,16 @@ typedef struct hbhip_cropscale_params
 } hbhip_cropscale_params;
 int hbhip_cropscale_create(hbhip_ctx *ctx, const hbhip_cropscale_params *p, int width, int height,
                            int depth, int log2_chroma_w, int log2_chroma_h, hbhip_filter **out);
+/* FFmpeg `pad=width:height:x:y:color` as pad_init sets it up (pad.c:40-148): the picture at (x, y)
+ * of a width x height one, the rest filled with fill[] (Y, Cb, Cr sample values, already converted
+ * from the RGB colour the way drawutils.c:ff_draw_color does).  x, y multiples of the chroma subsampling. */
+typedef struct hbhip_pad_params
+{
+    int width, height, x, y;
+    int fill[3];
+} hbhip_pad_params;
+int hbhip_pad_create(hbhip_ctx *ctx, const hbhip_pad_params *p, int width, int height, int depth,
+                     int log2_chroma_w, int log2_chroma_h, hbhip_filter **out);
 /* The zscale [-> format=gbrpf32le -> tonemap] -> zscale -> format graph colorspace_init builds
  * (colorspace.c:126-193): matrix / range / transfer / primaries conversion, with tone mapping
  * when the source transfer is SMPTE 2084 or ARIB STD-B67 and the transfer changes.  Colour ids

@@ -226,3 +226,51 @@ void orc_cropscale_plane_d(const void *src, int sstride, int crop_x, int crop_y,
         }
     free(ix); free(iy); free(cx); free(cy);
 }
+
+/* ---- pad (libhb/pad.c:40-148 -> FFmpeg vf_pad.c + drawutils.c; parity unpinned) ----------------
+ * vf_pad copies the input picture into a larger one at (x, y) - both rounded down to the chroma
+ * subsampling - and fills the rest with one colour.  The colour is given as RGB and converted the
+ * way drawutils.c:ff_draw_color does: Y'CbCr through the (Kr, Kb) of the frame's matrix (BT.601 when
+ * unspecified), scaled to the frame's range (limited when unspecified), component = (unsigned)(v *
+ * ((1 << depth) - 1) + 0.5) with v in [0, 1]. */
+void orc_pad_color(int rgb, int matrix, int full_range, int depth, int out[3])
+{
+    double kr = 0.299, kb = 0.114;                              /* smpte170m, also the fallback */
+    switch (matrix)
+    {
+        case 1: kr = 0.2126; kb = 0.0722; break;
+        case 4: kr = 0.30;   kb = 0.11;   break;
+        case 7: kr = 0.212;  kb = 0.087;  break;
+        case 9: case 10: kr = 0.2627; kb = 0.0593; break;
+    }
+    const double kg = 1.0 - kr - kb;
+    const double r = ((rgb >> 16) & 0xff) / 255., g = ((rgb >> 8) & 0xff) / 255., b = (rgb & 0xff) / 255.;
+    double v[3];
+    v[0] = kr * r + kg * g + kb * b;
+    v[1] = (-kr * r - kg * g + (1.0 - kb) * b) / (2.0 * (1.0 - kb));
+    v[2] = ((1.0 - kr) * r - kg * g - kb * b) / (2.0 * (1.0 - kr));
+    for (int i = 0; i < 3; i++)
+    {
+        const int chroma = i > 0;
+        if (!full_range)
+        {
+            v[i] *= (chroma ? 224. : 219.) / 255.;
+            v[i] += (chroma ? 128. : 16.) / 255.;
+        }
+        else if (chroma)
+            v[i] += 0.5;
+        out[i] = (int)(unsigned)(v[i] * ((1 << depth) - 1) + 0.5);
+    }
+}
+
+/* one plane: (x, y) and the fill value are the plane's own (already shifted for chroma) */
+void orc_pad_plane(const void *src, int sw, int sh, int sstride, void *dst, int dw, int dh, int dstride,
+                   int x, int y, int fill, int bps)
+{
+    for (int yy = 0; yy < dh; yy++)
+        for (int xx = 0; xx < dw; xx++)
+        {
+            const int inside = xx >= x && xx < x + sw && yy >= y && yy < y + sh;
+            setpx(dst, dstride, xx, yy, bps, inside ? getpx(src, sstride, xx - x, yy - y, bps) : (unsigned)fill);
+        }
+}

@@ -233,6 +233,10 @@ void orc_monochrome_luma_d(const void *yp, int ystride, const void *up, const vo
                            double cb, double cr, double size, double high, int depth);
 void orc_cropscale_plane_d(const void *src, int sstride, int crop_x, int crop_y, int crop_w, int crop_h,
                            void *dst, int dstride, int dw, int dh, double shift_x, double shift_y, int depth);
+/* pad (pad.c -> vf_pad): the fill colour of drawutils.c:ff_draw_color for an 0xRRGGBB value, and one plane. */
+void orc_pad_color(int rgb, int matrix, int full_range, int depth, int out[3]);
+void orc_pad_plane(const void *src, int sw, int sh, int sstride, void *dst, int dw, int dh, int dstride,
+                   int x, int y, int fill, int bps);
 /* The tap table of one dimension (exposed so tests can look at it): for each of the
  * `dst_dim` outputs `taps` (index, weight) pairs; returns taps. idx/coef sized dst_dim*64. */
 int orc_lanczos_table(int src_dim, int dst_dim, double shift, int *idx, double *coef);

@@ -511,3 +511,25 @@ def orc_motion_metric(luma_a, luma_b, depth=8) -> float:
     a, b = np.ascontiguousarray(luma_a), np.ascontiguousarray(luma_b)
     h, w = a.shape
     return fn(a.ctypes.data, a.strides[0], b.ctypes.data, b.strides[0], w, h, depth)
+
+
+def orc_pad_frame(frame, width, height, x, y, rgb=0, matrix=1, full_range=False, depth=8):
+    """vf_pad as pad.c configures it: x, y already resolved (>= 0); rounds them to the 4:2:0 grid."""
+    L = oracle()
+    L.orc_pad_color.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.orc_pad_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                C.c_int, C.c_int, C.c_int, C.c_int]
+    fill = (C.c_int * 3)()
+    L.orc_pad_color(rgb, matrix, int(full_range), depth, fill)
+    x &= ~1
+    y &= ~1
+    out = []
+    for c, p in enumerate(frame):
+        p = np.ascontiguousarray(p)
+        sh, sw = p.shape
+        dw, dh = (width, height) if c == 0 else ((width + 1) // 2, (height + 1) // 2)
+        dst = np.zeros((dh, dw), p.dtype)
+        L.orc_pad_plane(p.ctypes.data, sw, sh, p.strides[0], dst.ctypes.data, dw, dh, dst.strides[0],
+                        x if c == 0 else x >> 1, y if c == 0 else y >> 1, fill[c], p.itemsize)
+        out.append(dst)
+    return tuple(out)

@@ -67,3 +67,23 @@ def test_crop_is_a_window(built):
     out = ol.orc_cropscale_frame(fr, 300, 160, top=8, bottom=12, left=4, right=16)
     np.testing.assert_array_equal(out[0], fr[0][8:168, 4:304])
     np.testing.assert_array_equal(out[1], fr[1][4:84, 2:152])
+
+
+def test_pad_fill_colours(built):
+    """drawutils.c:ff_draw_color for the colours anyone pads with."""
+    import ctypes as C
+    L = ol.oracle()
+    L.orc_pad_color.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+
+    def col(rgb, matrix=1, full=0, depth=8):
+        out = (C.c_int * 3)()
+        L.orc_pad_color(rgb, matrix, full, depth, out)
+        return tuple(out)
+    assert col(0x000000) == (16, 128, 128)
+    assert col(0xFFFFFF) == (235, 128, 128)
+    assert col(0x000000, full=1) == (0, 128, 128) and col(0xFFFFFF, full=1) == (255, 128, 128)
+    assert col(0xFF0000) == (63, 102, 240)                     # BT.709 red
+    assert col(0xFF0000, matrix=6) == (81, 90, 240)            # BT.601 red
+    # above 8 bits ff_draw_color scales the 8-bit-anchored values by (2^depth - 1) / 255, so 10-bit
+    # black is (64, 514, 514) rather than (64, 512, 512)
+    assert col(0x000000, depth=10) == (64, 514, 514) and col(0xFFFFFF, depth=10) == (943, 514, 514)

@@ -5,6 +5,7 @@ import pytest
 
 from handbrake_amd import hbrt, hip, synth
 import oracle_stream as os_
+import oracle_lib as ol
 
 pytestmark = pytest.mark.gpu
 
@@ -110,3 +111,17 @@ def test_10bit_device_resident_chain(built):
     for t in range(3):
         for c in range(3):
             np.testing.assert_array_equal(dev[t].planes[c], host[t].planes[c], err_msg=f"frame {t} plane {c}")
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("st,geo,rgb", [
+    ("width=720:height=404", (720, 404, 40, 22), 0),                                   # centred (x, y unset)
+    ("top=10:bottom=30:left=6:right=18:color=0x336699", (664, 400, 6, 10), 0x336699),   # from the four margins
+    ("width=700:height=400:x=17:y=9:color=white", (700, 400, 16, 8), 0xFFFFFF),         # odd offsets round down
+    ("width=100:height=100", (640, 360, 0, 0), 0)])                                     # never smaller than the input
+def test_pad(built, depth, st, geo, rgb):
+    frames = synth.stream("progressive", 640, 360, 2, depth=depth)
+    got = hbrt.run_stream(hip.filters(), [("hb_filter_pad_hip", st)], frames, pix_fmt=hbrt.PIX_FMT_FOR_DEPTH[depth])
+    w, h, x, y = geo
+    check(got, [ol.orc_pad_frame(fr, w, h, x, y, rgb=rgb, depth=depth) for fr in frames])
+    assert (got[0].width, got[0].height) == (w, h)
