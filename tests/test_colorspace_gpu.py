@@ -42,7 +42,7 @@ def check(got, frames, params, depth=8, **kw):
             np.testing.assert_array_equal(got[t].planes[c], want[c], err_msg=f"frame {t} plane {c}")
 
 
-@pytest.mark.parametrize("w,h", [(640, 360), (638, 362), (130, 66)])
+@pytest.mark.parametrize("w,h", [(640, 360), (638, 362), (130, 66), (641, 361), (67, 35)])
 @pytest.mark.parametrize("src,settings,dst,kw", SDR_CASES)
 def test_sdr_conversions(built, w, h, src, settings, dst, kw):
     frames = synth.stream("progressive", w, h, 1) + synth.stream("random", w, h, 1)
