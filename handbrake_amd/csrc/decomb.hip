@@ -175,6 +175,75 @@ __global__ __launch_bounds__(256) void decomb_plane_kernel(DecombArgs a, int max
 }
 
 // ------------------------------------------------------------------- host side
+// ------------------------------------------------------------------------------------------
+// FFmpeg's yadif, which is what the reference's "Deinterlace" filter is (libhb/deinterlace.c:43-143
+// only builds `yadif=mode=send_frame|send_field[_nospatial]:deint=...:parity=...` for libavfilter;
+// the arithmetic is vf_yadif.c's - not in the reference tree, parity unpinned, restated in
+// oracle/decomb_oracle.c:orc_yadif_ff_plane).  Same frame ring as decomb (first frame filtered
+// against itself as `prev`, last one against itself as `next`), same field order.  Per rebuilt
+// sample: temporal prediction d = (prev2 + next2) / 2, bounded to +-diff around it, where diff is
+// the largest of the three temporal differences and - unless `nospatial` or next to the top /
+// bottom edge - is widened by the vertical-neighbour check over rows y +- 2; the spatial
+// prediction is the average of the rows above / below, replaced by a diagonal average when one of
+// the +-1 (then +-2) diagonals matches better - only for 3 <= x < w - 3 (vf_yadif.c: filter_edges).
+template <typename PIX>
+__global__ __launch_bounds__(256) void yadif_ff_kernel(DecombArgs a, int nospatial)
+{
+    const DecombPlane &P = a.pl[blockIdx.z];
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= P.w || y >= P.h) return;
+    const int st = P.pitch / (int)sizeof(PIX);
+    const size_t at = (size_t)y * st + x;
+    const PIX *cur = reinterpret_cast<const PIX *>(P.cur) + at;
+    PIX *o = reinterpret_cast<PIX *>(P.dst + (size_t)y * P.dst_pitch) + x;
+    if (a.mode == 0 || !((y ^ a.parity) & 1))              // pass-through frame, or a row of the kept field
+    {
+        *o = *cur;
+        return;
+    }
+    const PIX *prev = reinterpret_cast<const PIX *>(P.prev) + at;
+    const PIX *next = reinterpret_cast<const PIX *>(P.next) + at;
+    const int h = P.h, w = P.w;
+    const int prefs = y + 1 < h ? st : -st, mrefs = y ? -st : st;
+    const bool skip_vertical = nospatial || y == 1 || y + 2 == h;       // `mode = 2` of filter_slice
+    const PIX *prev2 = a.field_parity ? prev : cur;
+    const PIX *next2 = a.field_parity ? cur : next;
+
+    const int c = cur[mrefs], e = cur[prefs];
+    const int d = ((int)prev2[0] + (int)next2[0]) >> 1;
+    const int td0 = abs((int)prev2[0] - (int)next2[0]);
+    const int td1 = (abs((int)prev[mrefs] - c) + abs((int)prev[prefs] - e)) >> 1;
+    const int td2 = (abs((int)next[mrefs] - c) + abs((int)next[prefs] - e)) >> 1;
+    int diff = max(max(td0 >> 1, td1), td2);
+    int pred = (c + e) >> 1;
+    if (x >= 3 && x < w - 3)
+    {
+        int score = abs((int)cur[mrefs - 1] - (int)cur[prefs - 1]) + abs(c - e) + abs((int)cur[mrefs + 1] - (int)cur[prefs + 1]) - 1;
+        auto check = [&](int j) -> bool {
+            const int s = abs((int)cur[mrefs - 1 + j] - (int)cur[prefs - 1 - j]) + abs((int)cur[mrefs + j] - (int)cur[prefs - j]) +
+                          abs((int)cur[mrefs + 1 + j] - (int)cur[prefs + 1 - j]);
+            if (s >= score) return false;
+            score = s;
+            pred = ((int)cur[mrefs + j] + (int)cur[prefs - j]) >> 1;
+            return true;
+        };
+        if (check(-1)) check(-2);
+        if (check(1)) check(2);
+    }
+    if (!skip_vertical)
+    {
+        const int b = ((int)prev2[2 * mrefs] + (int)next2[2 * mrefs]) >> 1;
+        const int f = ((int)prev2[2 * prefs] + (int)next2[2 * prefs]) >> 1;
+        const int mx = max(max(d - e, d - c), min(b - c, f - e));
+        const int mn = min(min(d - e, d - c), max(b - c, f - e));
+        diff = max(max(diff, mn), -mx);
+    }
+    if (pred > d + diff) pred = d + diff;
+    else if (pred < d - diff) pred = d - diff;
+    *o = (PIX)pred;
+}
+
 class DecombFilter : public hbhip_filter
 {
 public:
@@ -186,6 +255,7 @@ public:
         in_geo.set(width, height, depth, lcw, lch);
         out_geo = in_geo;
         pool.configure(ctx, in_geo);
+        if (ff_yadif) return HBHIP_OK;
         // the mode a HEAVY frame is filtered with (decomb_template.c:828-831); reject the
         // combinations for which the reference leaves the rebuilt rows unwritten (:741-789)
         const int hm = par.mode & ~M_SELECTIVE;
@@ -285,6 +355,13 @@ private:
         a.mode = mode; a.parity = parity; a.field_parity = parity ^ tff;
         dim3 block(64, 4), grid((in_geo.pw[0] + 63) / 64, (in_geo.ph[0] + 3) / 4, 3);
         const int maxv = (1 << in_geo.depth) - 1;
+        if (ff_yadif)
+        {
+            if (in_geo.bps == 2) HBHIP_LAUNCH(ctx, "yadif", yadif_ff_kernel<uint16_t>, grid, block, 0, a, ff_nospatial);
+            else                 HBHIP_LAUNCH(ctx, "yadif", yadif_ff_kernel<uint8_t>, grid, block, 0, a, ff_nospatial);
+            HBHIP_CHECK(ctx, hipGetLastError());
+            return HBHIP_OK;
+        }
         if (in_geo.bps == 2) HBHIP_LAUNCH(ctx, "decomb_plane", decomb_plane_kernel<uint16_t>, grid, block, 0, a, maxv);
         else                 HBHIP_LAUNCH(ctx, "decomb_plane", decomb_plane_kernel<uint8_t>, grid, block, 0, a, maxv);
         HBHIP_CHECK(ctx, hipGetLastError());
@@ -307,7 +384,10 @@ private:
         }
         int tff;
         if (par.parity < 0)
-            tff = ((cur->flags & PIC_PROGRESSIVE) == 0) ? !!(cur->flags & PIC_TFF) : 1;
+            // yadif_common.c:return_frame looks at the frame's interlaced flag, which HandBrake sets
+            // from s.combed (hbffmpeg.c:107-114); decomb looks at PIC_FLAG_PROGRESSIVE_FRAME (decomb.c:519-528)
+            tff = ff_yadif ? (cur->combed ? !!(cur->flags & PIC_TFF) : 1)
+                           : (((cur->flags & PIC_PROGRESSIVE) == 0) ? !!(cur->flags & PIC_TFF) : 1);
         else
             tff = (par.parity & 1) ^ 1;
 
@@ -335,6 +415,10 @@ private:
         return HBHIP_OK;
     }
 
+public:
+    bool ff_yadif = false;      // FFmpeg's yadif instead of decomb's line filters (hbhip_yadif_create)
+    int  ff_nospatial = 0;      // send_frame_nospatial / send_field_nospatial
+private:
     hbhip_decomb_params par;
     PicturePool pool;
     DevPicture *ref[3] = {nullptr, nullptr, nullptr};
@@ -355,6 +439,35 @@ extern "C" int hbhip_decomb_create(hbhip_ctx *ctx, const hbhip_decomb_params *p,
     (void)hipSetDevice(ctx->device);
     DecombFilter *f = new (std::nothrow) DecombFilter(ctx, *p);
     if (!f) return HBHIP_ERR_NOMEM;
+    int rc = f->setup(width, height, depth, log2_chroma_w, log2_chroma_h);
+    if (rc != HBHIP_OK)
+    {
+        delete f;
+        return rc;
+    }
+    *out = f;
+    return HBHIP_OK;
+}
+
+extern "C" int hbhip_yadif_create(hbhip_ctx *ctx, int spatial_check, int bob, int selective, int parity,
+                                  int width, int height, int depth, int log2_chroma_w, int log2_chroma_h,
+                                  hbhip_filter **out)
+{
+    if (!ctx || !out) return HBHIP_ERR_ARG;
+    *out = nullptr;
+    if (depth != 8 && depth != 10 && depth != 12) return HBHIP_ERR_UNSUPPORTED;
+    if (width < 8 || height < 8) return HBHIP_ERR_UNSUPPORTED;
+    (void)hipSetDevice(ctx->device);
+    hbhip_decomb_params p;
+    memset(&p, 0, sizeof(p));
+    // the frame ring, field order, bob pairing and combed-only selection are decomb's (M_YADIF keeps
+    // process_frame on its deinterlacing branch; the kernel is vf_yadif's)
+    p.mode = M_YADIF | (bob ? M_BOB : 0) | (selective ? M_SELECTIVE : 0);
+    p.parity = parity;
+    DecombFilter *f = new (std::nothrow) DecombFilter(ctx, p);
+    if (!f) return HBHIP_ERR_NOMEM;
+    f->ff_yadif = true;
+    f->ff_nospatial = !spatial_check;
     int rc = f->setup(width, height, depth, log2_chroma_w, log2_chroma_h);
     if (rc != HBHIP_OK)
     {

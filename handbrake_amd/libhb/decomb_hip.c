@@ -18,6 +18,8 @@ struct hb_filter_private_s
     int64_t             next_tag;
     int                 ready;
     int                 dev_io;
+    int                 selective;   /* yadif: deint=interlaced */
+    int                 ff_yadif;    /* the Deinterlace (FFmpeg yadif) object below: outputs are progressive */
     hb_filter_init_t    input;
     hb_filter_init_t    output;
 };
@@ -113,7 +115,7 @@ static void decomb_hip_close(hb_filter_object_t *filter)
 {
     hb_filter_private_t *pv = filter->private_data;
     if (pv == NULL) return;
-    hbhip_filter_destroy(pv->dev);
+    if (pv->dev != NULL) hbhip_filter_destroy(pv->dev);
     hb_buffer_list_close(&pv->props);
     free(pv);
     filter->private_data = NULL;
@@ -137,6 +139,13 @@ static int decomb_hip_collect(hb_filter_private_t *pv, hb_buffer_list_t *list)
         }
         if (props != NULL)
             hb_buffer_copy_props(out, props);                  /* decomb.c:555 */
+        if (pv->ff_yadif && (props == NULL || pv->selective == 0 || props->s.combed != 0))
+        {
+            /* yadif clears the interlaced flag of what it deinterlaced (yadif_common.c), which comes
+             * back as PIC_FLAG_PROGRESSIVE_FRAME and no combed mark (hbffmpeg.c:151-162) */
+            out->s.flags |= PIC_FLAG_PROGRESSIVE_FRAME;
+            out->s.combed = HB_COMB_NONE;
+        }
         if (tag & 1) second = out; else first = out;
         hb_buffer_list_append(list, out);
     }
@@ -157,6 +166,13 @@ static int decomb_hip_work(hb_filter_object_t *filter, hb_buffer_t **buf_in, hb_
     hb_buffer_list_t list;
     hb_buffer_list_clear(&list);
 
+    if (pv->dev == NULL)
+    {
+        /* Deinterlace with the enable bit off: the reference adds no avfilter at all (deinterlace.c:88-91) */
+        *buf_out = in;
+        *buf_in = NULL;
+        return (in->s.flags & HB_BUF_FLAG_EOF) ? HB_FILTER_DONE : HB_FILTER_OK;
+    }
     if (in->s.flags & HB_BUF_FLAG_EOF)
     {
         /* the last frame is processed against a copy of itself (decomb.c:584-589) */
@@ -206,4 +222,76 @@ static int decomb_hip_work(hb_filter_object_t *filter, hb_buffer_t **buf_in, hb_
     }
     *buf_out = hb_buffer_list_clear(&list);
     return HB_FILTER_OK;
+}
+
+
+/* ---- Deinterlace = FFmpeg yadif (libhb/deinterlace.c:43-143) ---------------------------------
+ * In the reference hb_filter_yadif has .skip = 1: deinterlace_init only writes
+ * `yadif=mode=send_frame|send_field[_nospatial][:deint=interlaced][:parity=tff|bff]` for
+ * libavfilter and doubles vrate for bob.  Here it is a real filter on the decomb frame ring (same
+ * first / last frame handling as yadif_common.c: the first frame's `prev` and the last frame's
+ * `next` are the frame itself), with vf_yadif.c's line filter (csrc/decomb.hip:yadif_ff_kernel,
+ * parity unpinned).  A bob pair splits the frame's time span, which for contiguous timestamps is
+ * what yadif's pts arithmetic (cur * 2, cur + next) comes to. */
+static int yadif_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init);
+
+static const char yadif_hip_template[] = "mode=^"HB_INT_REG"$:parity=^([01])$";
+
+hb_filter_object_t hb_filter_yadif_hip =
+{
+    .id                = HB_FILTER_YADIF,
+    .enforce_order     = 1,
+    .name              = "Deinterlace (HIP)",
+    .short_name        = "deinterlace",
+    .settings          = NULL,
+    .init              = yadif_hip_init,
+    .work              = decomb_hip_work,
+    .close             = decomb_hip_close,
+    .settings_template = yadif_hip_template,
+};
+
+#define YADIF_ENABLE    1      /* deinterlace.c:59-69 */
+#define YADIF_SPATIAL   2
+#define YADIF_BOB       4
+#define YADIF_SELECTIVE 8
+
+static int yadif_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init)
+{
+    hb_filter_private_t *pv = calloc(1, sizeof(*pv));
+    if (pv == NULL) return -1;
+    filter->private_data = pv;
+    pv->input = *init;
+    pv->dev_io = hbhip_host_dev_io(init);
+    pv->ff_yadif = 1;
+    hb_buffer_list_clear(&pv->props);
+
+    int mode = 3, parity = -1;                                   /* :82-86 */
+    if (filter->settings != NULL)
+    {
+        hb_dict_extract_int(&mode, filter->settings, "mode");
+        hb_dict_extract_int(&parity, filter->settings, "parity");
+    }
+    if (!(mode & YADIF_ENABLE))                                  /* :88-91: nothing to do */
+    {
+        pv->output = *init;
+        return 0;
+    }
+    pv->selective = !!(mode & YADIF_SELECTIVE);
+    const AVPixFmtDescriptor *desc = av_pix_fmt_desc_get(init->pix_fmt);
+    hbhip_ctx *ctx = desc != NULL ? hbhip_host_ctx() : NULL;
+    int rc = ctx == NULL ? HBHIP_ERR_NODEVICE
+                         : hbhip_yadif_create(ctx, !!(mode & YADIF_SPATIAL), !!(mode & YADIF_BOB), pv->selective, parity,
+                                              init->geometry.width, init->geometry.height, desc->comp[0].depth,
+                                              desc->log2_chroma_w, desc->log2_chroma_h, &pv->dev);
+    if (rc != HBHIP_OK)
+    {
+        hb_error("deinterlace(hip): %s", hbhip_strerror(rc));
+        free(pv);
+        filter->private_data = NULL;
+        return -1;
+    }
+    if (mode & YADIF_BOB)
+        init->vrate.num *= 2;                                    /* :107 */
+    pv->output = *init;
+    return 0;
 }

@@ -205,6 +205,14 @@ int hbhip_decomb_create(hbhip_ctx *ctx, const hbhip_decomb_params *p, int width,
  * (input tag << 1) | field_index, field_index = 1 for the second frame of a bob pair. */
 int hbhip_decomb_push(hbhip_filter *f, const hbhip_host_frame *in, int64_t tag, int pic_flags, int combed);
 int hbhip_decomb_push_dev(hbhip_filter *f, const hbhip_dev_frame *in, int64_t tag, int pic_flags, int combed);
+/* The reference's "Deinterlace" filter = FFmpeg yadif as deinterlace_init configures it
+ * (deinterlace.c:72-143): spatial_check 0 = send_*_nospatial, bob = send_field (two frames per
+ * input), selective = deint=interlaced (only frames whose s.combed is set), parity -1 / 0 (tff) /
+ * 1 (bff).  Frames go in with hbhip_decomb_push[_dev] (flags + combed) and come out like decomb's.
+ * Arithmetic of vf_yadif.c, parity unpinned (oracle/decomb_oracle.c:orc_yadif_ff_plane). */
+int hbhip_yadif_create(hbhip_ctx *ctx, int spatial_check, int bob, int selective, int parity,
+                       int width, int height, int depth, int log2_chroma_w, int log2_chroma_h,
+                       hbhip_filter **out);
 /* Test hook: copy one plane of an EEDI2 scratch frame to the host (buffer 0..3 = eedi_half[],
  * 4..8 = eedi_full[], decomb.c:64-74); dst == NULL only queries stride/height. */
 int hbhip_decomb_debug_eedi_plane(hbhip_filter *f, int buffer, int plane, uint8_t *dst, int dst_stride,

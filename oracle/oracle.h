@@ -254,6 +254,10 @@ typedef struct
 int orc_colorspace_frame(const orc_colorspace_params_t *cs, const void *const src[3], const int sstride[3],
                          void *const dst[3], const int dstride[3], int w, int h, int depth, int subw, int subh);
 
+/* ---- FFmpeg yadif, the reference's "Deinterlace" filter (deinterlace.c -> vf_yadif.c; PARITY UNPINNED) -- */
+void orc_yadif_ff_plane(const void *prev, const void *cur, const void *next, int stride, int w, int h,
+                        void *dst, int dst_stride, int parity, int tff, int nospatial, int bps);
+
 /* ---- frame-difference metric of vfr (motion_metric.c) -------------------------------------- */
 /* The scaled 2.2-gamma table (1 << depth entries), :36-42. */
 void  orc_motion_gamma_lut(unsigned *lut, int depth);

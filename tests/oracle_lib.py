@@ -533,3 +533,15 @@ def orc_pad_frame(frame, width, height, x, y, rgb=0, matrix=1, full_range=False,
                         x if c == 0 else x >> 1, y if c == 0 else y >> 1, fill[c], p.itemsize)
         out.append(dst)
     return tuple(out)
+
+
+def orc_yadif_ff_plane(prev, cur, nxt, parity, tff, nospatial):
+    fn = oracle().orc_yadif_ff_plane
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                   C.c_int, C.c_int, C.c_int, C.c_int]
+    p, c, n = [np.ascontiguousarray(a) for a in (prev, cur, nxt)]
+    h, w = c.shape
+    dst = np.zeros_like(c)
+    fn(p.ctypes.data, c.ctypes.data, n.ctypes.data, c.strides[0], w, h, dst.ctypes.data, dst.strides[0],
+       int(parity), int(tff), int(nospatial), c.itemsize)
+    return dst

@@ -218,3 +218,36 @@ def cropscale_stream(frames, par):
 
 
 STREAMS.update({"rotate": rotate_stream, "grayscale": grayscale_stream, "cropscale": cropscale_stream})
+
+
+def yadif_stream(frames, mode=3, parity_opt=-1, flags=PIC_FLAG_TOP_FIELD_FIRST, combed=None, duration=3003):
+    """The reference's Deinterlace filter = FFmpeg yadif as deinterlace.c:72-143 configures it.
+    mode bits: 1 enable, 2 spatial check, 4 bob (send_field), 8 selective (deint=interlaced: only
+    frames with s.combed set).  Frame sequencing of yadif_common.c: frame t is filtered from
+    (t-1, t, t+1), the first with itself as prev, the last with itself as next.
+    Returns list of dict(planes, start, stop)."""
+    n = len(frames)
+    out = []
+    if not (mode & 1):
+        return [dict(planes=fr, start=i * duration, stop=(i + 1) * duration) for i, fr in enumerate(frames)]
+    for t in range(n):
+        prev, cur, nxt = frames[max(t - 1, 0)], frames[t], frames[min(t + 1, n - 1)]
+        cmb = 2 if combed is None else combed[t]
+        start, stop = t * duration, (t + 1) * duration
+        if (mode & 8) and cmb == 0:
+            out.append(dict(planes=tuple(p.copy() for p in cur), start=start, stop=stop))
+            continue
+        if parity_opt < 0:
+            tff = (1 if (flags & PIC_FLAG_TOP_FIELD_FIRST) else 0) if cmb else 1      # interlaced flag = s.combed
+        else:
+            tff = (parity_opt & 1) ^ 1
+        made = []
+        for field in range(2 if (mode & 4) else 1):
+            parity = field ^ tff ^ 1
+            made.append(dict(planes=tuple(ol.orc_yadif_ff_plane(prev[c], cur[c], nxt[c], parity, tff, not (mode & 2))
+                                          for c in range(3)), start=start, stop=stop))
+        if mode & 4:
+            made[0]["stop"] -= (made[0]["stop"] - made[0]["start"]) // 2
+            made[1]["start"] = made[0]["stop"]
+        out.extend(made)
+    return out
