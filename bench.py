@@ -205,8 +205,9 @@ def secondary(args):
     for i in range(args.warmup):
         feed(i)
     sync_all()
-    if len(lanes) == 1:          # the per-kernel timer serialises a context: only in single-stream runs
-        ctx.profile(True)
+    timer = len(lanes) == 1 and not args.no_kernel_timer
+    if timer:                    # the per-kernel timer serialises a context (individual launches, no graphs,
+        ctx.profile(True)        # no second EEDI2 stream): only in single-stream runs, and optional
         ctx.profile_reset()
     start = sum(ln.produced for ln in lanes)
     t0 = time.perf_counter()
@@ -214,7 +215,7 @@ def secondary(args):
         feed(args.warmup + i)
     sync_all()
     dt = time.perf_counter() - t0
-    stats = ctx.profile_stats() if len(lanes) == 1 else {}
+    stats = ctx.profile_stats() if timer else {}
     ctx.profile(False)
     out_frames = sum(ln.produced for ln in lanes) - start
     frames_total, dt_max = shard.reduce_throughput(float(out_frames), dt, device="cuda")
@@ -253,6 +254,9 @@ def main():
     ap.add_argument("--comb-detect", action="store_true",
                     help="secondary workloads only: run comb detection in front of the (then selective) decomb, "
                          "as BASELINE configs[2] words it")
+    ap.add_argument("--no-kernel-timer", action="store_true",
+                    help="secondary workloads only: leave the per-kernel HIP-event timer off, so the filters run "
+                         "as they do in production (captured graphs, both fields of an EEDI2 bob pair in flight)")
     ap.add_argument("--streams", type=int, default=1,
                     help="secondary workloads only: independent streams (filter instances on their own "
                          "HIP streams) fed round-robin on each GPU")

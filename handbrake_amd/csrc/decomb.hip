@@ -248,7 +248,13 @@ class DecombFilter : public hbhip_filter
 {
 public:
     DecombFilter(hbhip_ctx *c, const hbhip_decomb_params &p) : hbhip_filter(c), par(p) {}
-    ~DecombFilter() override { delete eedi; }
+    ~DecombFilter() override
+    {
+        delete eedi_side;
+        delete eedi;
+        if (ev_frame) (void)hipEventDestroy(ev_frame);
+        if (side_ctx) hbhip_ctx_destroy(side_ctx);
+    }
 
     int setup(int width, int height, int depth, int lcw, int lch)
     {
@@ -272,6 +278,22 @@ public:
             if (!eedi) return HBHIP_ERR_NOMEM;
             int rc = eedi->init();
             if (rc != HBHIP_OK) return rc;
+            // The two fields of a bob pair are two EEDI2 runs that only depend on each other through
+            // the edge mask (the first of ~22 kernels).  Each run is a chain of small dependent
+            // launches that leaves most of the GPU idle, so the second field runs on an engine of its
+            // own (own scratch frames, own HIP stream) next to the first.  Not with post-processing
+            // 2/3, whose derivative arrays carry values from run to run (eedi2.hip, CornerArgs).
+            if ((par.mode & M_BOB) && par.post_processing < 2 && getenv("HBHIP_EEDI2_SERIAL") == nullptr)
+            {
+                if (hbhip_ctx_create(ctx->device, &side_ctx) != HBHIP_OK) { side_ctx = nullptr; return HBHIP_OK; }
+                eedi_side = new (std::nothrow) Eedi2Engine(side_ctx, in_geo, ep, ctx, eedi->share());
+                if (!eedi_side || eedi_side->init() != HBHIP_OK ||
+                    hipEventCreateWithFlags(&ev_frame, hipEventDisableTiming) != hipSuccess)
+                {
+                    delete eedi_side;
+                    eedi_side = nullptr;
+                }
+            }
         }
         return HBHIP_OK;
     }
@@ -319,7 +341,7 @@ public:
     void recycle_output(DevPicture *p) override { pool.release(p); }
 
     int next_flags = 0, next_combed = 0;
-    Eedi2Engine *engine() { return eedi; }
+    Eedi2Engine *engine() { return last_engine ? last_engine : eedi; }    // the one holding the latest run's scratch
 
 private:
     void unref(DevPicture *p)
@@ -335,18 +357,19 @@ private:
         p->refs++;
     }
 
-    int launch(DevPicture *dst, int mode, int parity, int tff)
+    int launch(DevPicture *dst, int mode, int parity, int tff, Eedi2Engine *guess_from = nullptr)
     {
+        if (!guess_from) guess_from = eedi;
         DecombArgs a;
         for (int c = 0; c < 3; c++)
         {
             DecombPlane &P = a.pl[c];
             P.prev = ref[0]->plane[c]; P.cur = ref[1]->plane[c]; P.next = ref[2]->plane[c];
             P.guess = nullptr; P.guess_pitch = 0;
-            if ((mode & M_EEDI2) && eedi)
+            if ((mode & M_EEDI2) && guess_from)
             {
-                P.guess = eedi->result().plane[c];
-                P.guess_pitch = eedi->result().stride[c];
+                P.guess = guess_from->result().plane[c];
+                P.guess_pitch = guess_from->result().stride[c];
             }
             P.dst = dst->plane[c];
             P.pitch = ref[1]->pitch[c]; P.dst_pitch = dst->pitch[c];
@@ -397,18 +420,34 @@ private:
         else if (is_combed != 0)                    mode = par.mode & ~M_SELECTIVE;
 
         const int nframes = (par.mode & M_BOB) ? 2 : 1;
+        // two engines: both EEDI2 runs are enqueued first (the second one on its own stream, behind an
+        // event that marks `cur` complete and the previous frame's outputs launched), then the outputs
+        const bool paired = (mode & M_EEDI2) && eedi && eedi_side && nframes == 2 && !ctx->profile;
+        if (paired)
+        {
+            HBHIP_CHECK(ctx, hipEventRecord(ev_frame, ctx->stream));
+            for (int frame = 0; frame < 2; frame++)
+            {
+                const int parity = frame ^ tff ^ 1;
+                Eedi2Engine *e = frame ? eedi_side : eedi;
+                int rc = e->run(cur, !parity, frame ? ev_frame : nullptr);       // pv->tff = !parity (decomb.c:542)
+                if (rc != HBHIP_OK) return rc;
+            }
+        }
         for (int frame = 0; frame < nframes; frame++)
         {
             const int parity = frame ^ tff ^ 1;
+            Eedi2Engine *e = (paired && frame) ? eedi_side : eedi;
             if ((mode & M_EEDI2) && eedi)
             {
-                int rc = eedi->run(cur, !parity);            // pv->tff = !parity (decomb.c:542)
+                int rc = paired ? e->join() : e->run(cur, !parity);
                 if (rc != HBHIP_OK) return rc;
+                last_engine = e;
             }
             DevPicture *o = pool.acquire();
             if (!o) return HBHIP_ERR_NOMEM;
             o->tag = (cur->tag << 1) | frame; o->aux = frame;
-            int rc = launch(o, mode, parity, tff);
+            int rc = launch(o, mode, parity, tff, e);
             if (rc != HBHIP_OK) return rc;
             outq.push_back(o);
         }
@@ -424,6 +463,10 @@ private:
     DevPicture *ref[3] = {nullptr, nullptr, nullptr};
     std::deque<DevPicture *> outq;
     Eedi2Engine *eedi = nullptr;
+    Eedi2Engine *eedi_side = nullptr;      // second field of a bob pair, on side_ctx's stream
+    Eedi2Engine *last_engine = nullptr;
+    hbhip_ctx   *side_ctx = nullptr;
+    hipEvent_t   ev_frame = nullptr;
     bool ready = false, flushed = false;
 };
 

@@ -1139,16 +1139,20 @@ __global__ void k_post_corner(CornerArgs A, const uint8_t *msk, uint8_t *dst, in
 } // namespace
 
 // ------------------------------------------------------------------- engine
-Eedi2Engine::Eedi2Engine(hbhip_ctx *ctx, const PicGeometry &geo, const Eedi2Params &p)
+Eedi2Engine::Eedi2Engine(hbhip_ctx *ctx, const PicGeometry &geo, const Eedi2Params &p, hbhip_ctx *main, EediMaskShare *share)
     : ctx_(ctx), geo_(geo), par_(p)
 {
     use_graph_ = getenv("HBHIP_NO_GRAPH") == nullptr;
+    main_ = main ? main : ctx;
+    share_ = share ? share : &own_share_;
 }
 
 Eedi2Engine::~Eedi2Engine()
 {
     for (auto &gg : graph_) for (auto &g : gg) if (g) (void)hipGraphExecDestroy(g);
-    if (mask_[1].alloc) (void)hipFree(mask_[1].alloc);
+    if (own_share_.mask[1].alloc) (void)hipFree(own_share_.mask[1].alloc);
+    if (own_share_.ev_mask) (void)hipEventDestroy(own_share_.ev_mask);
+    if (ev_done_) (void)hipEventDestroy(ev_done_);
     for (auto &f : half_) if (f.alloc) (void)hipFree(f.alloc);
     for (auto &f : full_) if (f.alloc) (void)hipFree(f.alloc);
     if (work_list_) (void)hipFree(work_list_);
@@ -1197,12 +1201,15 @@ int Eedi2Engine::init()
         int rc = alloc_frame(f, geo_.width, geo_.height);          // decomb.c:299-303
         if (rc != HBHIP_OK) return rc;
     }
-    mask_[0] = half_[1];                                           // same memory as MSKPF (not owned twice)
+    if (share_ == &own_share_)
     {
-        int rc = alloc_frame(mask_[1], geo_.width, geo_.height / 2);
+        own_share_.mask[0] = half_[1];                             // same memory as MSKPF (not owned twice)
+        int rc = alloc_frame(own_share_.mask[1], geo_.width, geo_.height / 2);
         if (rc != HBHIP_OK) return rc;
+        own_share_.sel = 0;
+        HBHIP_CHECK(ctx_, hipEventCreateWithFlags(&own_share_.ev_mask, hipEventDisableTiming));
     }
-    mask_sel_ = 0;
+    if (main_ != ctx_) HBHIP_CHECK(ctx_, hipEventCreateWithFlags(&ev_done_, hipEventDisableTiming));
     // work list of calc_directions (every half-height pixel could qualify) + lattice candidates
     size_t half_px = 0;
     for (int c = 0; c < 3; c++) half_px += (size_t)half_[0].stride[c] * half_[0].height[c];
@@ -1230,11 +1237,12 @@ int Eedi2Engine::init()
     return HBHIP_OK;
 }
 
-int Eedi2Engine::run(const DevPicture *cur, int tff)
+int Eedi2Engine::run(const DevPicture *cur, int tff, hipEvent_t wait_for)
 {
     EediFrame &srcp = half_[0], &dst2p = full_[0];
     P3 P;
     memset(&P, 0, sizeof(P));
+    if (wait_for) HBHIP_CHECK(ctx_, hipStreamWaitEvent(ctx_->stream, wait_for, 0));
 
     // field extraction (decomb_template.c:455-473)
     for (int c = 0; c < 3; c++)
@@ -1252,46 +1260,82 @@ int Eedi2Engine::run(const DevPicture *cur, int tff)
     }
     HBHIP_CHECK(ctx_, hipGetLastError());
 
-    // Everything after the field extraction only touches this engine's own scratch frames, so
-    // the ~22 launches of a field are identical from frame to frame (per field parity): they are
+    // The mask passes read the previous run's mask (possibly made on the other engine's stream) and
+    // write the other buffer; an event behind them lets the next run's mask passes start while the
+    // rest of this run is still going.
+    const int sel = share_->sel ^ 1;               // the new mask goes to the other buffer
+    share_->sel = sel;
+    if (share_->ev_valid) HBHIP_CHECK(ctx_, hipStreamWaitEvent(ctx_->stream, share_->ev_mask, 0));
+    {
+        const int rc = enqueue_mask(sel);
+        if (rc != HBHIP_OK) return rc;
+    }
+    HBHIP_CHECK(ctx_, hipEventRecord(share_->ev_mask, ctx_->stream));
+    share_->ev_valid = true;
+
+    // Everything after the mask only touches this engine's own scratch frames, so the ~20 launches
+    // of a field are identical from frame to frame (per field parity and mask buffer): they are
     // captured once into a hipGraph and replayed, which removes the per-launch submission gaps.
     // The per-kernel profiler needs individual launches, so it bypasses the graph.
-    const int sel = mask_sel_ ^ 1;                 // the new mask goes to the other buffer
-    mask_sel_ = sel;
-    if (ctx_->profile || !use_graph_) return enqueue_passes(tff, sel);
-    hipGraphExec_t &exec = graph_[tff ? 1 : 0][sel];
-    if (!exec)
+    int rc = HBHIP_OK;
+    if (ctx_->profile || !use_graph_) rc = enqueue_passes(tff, sel);
+    else
     {
-        hipGraph_t g = nullptr;
-        HBHIP_CHECK(ctx_, hipStreamBeginCapture(ctx_->stream, hipStreamCaptureModeThreadLocal));
-        const int rc = enqueue_passes(tff, sel);
-        const hipError_t e = hipStreamEndCapture(ctx_->stream, &g);
-        if (rc != HBHIP_OK || e != hipSuccess || !g)
+        hipGraphExec_t &exec = graph_[tff ? 1 : 0][sel];
+        if (!exec)
         {
+            hipGraph_t g = nullptr;
+            HBHIP_CHECK(ctx_, hipStreamBeginCapture(ctx_->stream, hipStreamCaptureModeThreadLocal));
+            const int crc = enqueue_passes(tff, sel);
+            const hipError_t e = hipStreamEndCapture(ctx_->stream, &g);
+            hipError_t ie = hipErrorUnknown;
+            if (crc == HBHIP_OK && e == hipSuccess && g) ie = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
             if (g) (void)hipGraphDestroy(g);
-            use_graph_ = false;                      // fall back to plain launches for good
-            (void)hipGetLastError();
-            return enqueue_passes(tff, sel);
+            if (ie != hipSuccess)
+            {
+                exec = nullptr;
+                use_graph_ = false;                  // fall back to plain launches for good
+                (void)hipGetLastError();
+            }
         }
-        const hipError_t ie = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(g);
-        if (ie != hipSuccess)
-        {
-            exec = nullptr;
-            use_graph_ = false;
-            (void)hipGetLastError();
-            return enqueue_passes(tff, sel);
-        }
+        if (exec) HBHIP_CHECK(ctx_, hipGraphLaunch(exec, ctx_->stream));
+        else      rc = enqueue_passes(tff, sel);
     }
-    HBHIP_CHECK(ctx_, hipGraphLaunch(exec, ctx_->stream));
+    if (rc != HBHIP_OK) return rc;
+    if (ev_done_) HBHIP_CHECK(ctx_, hipEventRecord(ev_done_, ctx_->stream));
+    return HBHIP_OK;
+}
+
+int Eedi2Engine::join()
+{
+    if (ev_done_) HBHIP_CHECK(main_, hipStreamWaitEvent(main_->stream, ev_done_, 0));
     return HBHIP_OK;
 }
 
 // The pass sequence of eedi2_interpolate_plane (decomb_template.c:366-441) for the 3 planes, from
 // the edge mask to the post-processing, on the engine's scratch frames.
+int Eedi2Engine::enqueue_mask(int sel)
+{
+    EediFrame &srcp = half_[0], &mskp = share_->mask[sel], &mskp_old = share_->mask[sel ^ 1];
+    P3 P;
+    memset(&P, 0, sizeof(P));
+    for (int c = 0; c < 3; c++)
+    {
+        P.pitch[c] = srcp.stride[c]; P.width[c] = srcp.width[c]; P.height[c] = srcp.height[c];
+        P.a[c] = srcp.plane[c]; P.b[c] = mskp_old.plane[c]; P.c[c] = mskp.plane[c];
+    }
+    // edge mask, erode, dilate, erode, remove_small_gaps in one launch (old mask -> new mask)
+    HBHIP_LAUNCH(ctx_, "eedi2_mask_passes", k_mask_fused,
+                 dim3((srcp.width[0] + MF_W - 1) / MF_W, (srcp.height[0] + MF_H - 1) / MF_H, 3), dim3(256), 0, P,
+                 par_.magnitude_threshold * 10, par_.laplacian_threshold * 81, par_.variance_threshold,
+                 par_.erosion_threshold, par_.dilation_threshold);
+    HBHIP_CHECK(ctx_, hipGetLastError());
+    return HBHIP_OK;
+}
+
 int Eedi2Engine::enqueue_passes(int tff, int sel)
 {
-    EediFrame &srcp = half_[0], &mskp = mask_[sel], &mskp_old = mask_[sel ^ 1], &tmpp = half_[2], &dstp = half_[3];
+    EediFrame &srcp = half_[0], &mskp = share_->mask[sel], &tmpp = half_[2], &dstp = half_[3];
     EediFrame &dst2p = full_[0], &tmp2p2 = full_[1], &msk2p = full_[2], &tmp2p = full_[3], &dst2mp = full_[4];
     const dim3 blk(64, 4);
     auto grid_for = [&](const EediFrame &f, bool whole_pitch) {
@@ -1312,12 +1356,6 @@ int Eedi2Engine::enqueue_passes(int tff, int sel)
 
     // half-height passes
     geom(P, srcp);
-    // edge mask, erode, dilate, erode, remove_small_gaps in one launch (old mask -> new mask)
-    bind(P.a, srcp); bind(P.b, mskp_old); bind(P.c, mskp);
-    HBHIP_LAUNCH(ctx_, "eedi2_mask_passes", k_mask_fused,
-                 dim3((srcp.width[0] + MF_W - 1) / MF_W, (srcp.height[0] + MF_H - 1) / MF_H, 3), dim3(256), 0, P,
-                 par_.magnitude_threshold * 10, par_.laplacian_threshold * 81, par_.variance_threshold,
-                 par_.erosion_threshold, par_.dilation_threshold);
     bind(P.a, mskp); bind(P.b, srcp); bind(P.c, tmpp);
     if (par_.maximum_search_distance <= CD_HALO - 2)
     {

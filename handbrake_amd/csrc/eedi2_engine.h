@@ -27,27 +27,48 @@ struct EediFrame
     size_t   bytes = 0;
 };
 
+// The edge mask is the one piece of EEDI2 state that runs depend on (the lower half of MSKPF keeps
+// the previous run's mask, eedi2_template.c:132).  When the two fields of a bob pair run on two
+// engines (two HIP streams), both work on the same pair of mask buffers, in run order.
+struct EediMaskShare
+{
+    EediFrame  mask[2];
+    int        sel = 0;               // which one holds the current mask
+    hipEvent_t ev_mask = nullptr;     // recorded behind every mask kernel: the next run's mask kernel waits for it
+    bool       ev_valid = false;
+};
+
 class Eedi2Engine
 {
 public:
-    Eedi2Engine(hbhip_ctx *ctx, const PicGeometry &geo, const Eedi2Params &p);
+    // main: the filter's context when this engine executes on a context (stream) of its own;
+    // share: the first engine's mask state when this is the second engine of a pair
+    Eedi2Engine(hbhip_ctx *ctx, const PicGeometry &geo, const Eedi2Params &p,
+                hbhip_ctx *main = nullptr, EediMaskShare *share = nullptr);
     ~Eedi2Engine();
     int  init();                                   // allocate the 9 scratch frames (zeroed once)
     // eedi2_planer (decomb_template.c:455-473): field extraction + the pass
     // sequence of eedi2_interpolate_plane for the 3 planes; `tff` is pv->tff.
-    int  run(const DevPicture *cur, int tff);
+    // wait_for: an event of the main stream behind which `cur` is complete and this engine's previous
+    // result has been consumed (side engines only; the main-stream engine is ordered by its stream)
+    int  run(const DevPicture *cur, int tff, hipEvent_t wait_for = nullptr);
+    int  join();                                   // side engine: make the main stream wait for the last run
+    EediMaskShare *share() { return share_; }
     const EediFrame &result() const { return full_[0]; }   // eedi_full[DST2PF]
     // MSKPF alternates between two buffers (the fused mask kernel reads the previous field's mask
     // while it writes the new one): index 1 always names the current one
-    const EediFrame &half(int i) const { return i == 1 ? mask_[mask_sel_] : half_[i]; }
+    const EediFrame &half(int i) const { return i == 1 ? share_->mask[share_->sel] : half_[i]; }
     const EediFrame &full(int i) const { return full_[i]; }
 
 private:
     int alloc_frame(EediFrame &f, int width, int height);
-    int enqueue_passes(int tff, int sel);          // everything after the field extraction; sel = mask buffer to write
+    int enqueue_mask(int sel);                     // the five mask passes; sel = mask buffer to write
+    int enqueue_passes(int tff, int sel);          // everything after them
     hipGraphExec_t graph_[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // captured pass sequence per (field parity, mask buffer)
-    EediFrame   mask_[2];                          // the two MSKPF buffers (mask_[0] is half_[1])
-    int         mask_sel_ = 0;                     // which one holds the current mask
+    EediMaskShare  own_share_;                     // the two MSKPF buffers (mask[0] is half_[1]) when not shared
+    EediMaskShare *share_ = nullptr;
+    hbhip_ctx  *main_ = nullptr;                   // != ctx_ for a side engine
+    hipEvent_t  ev_done_ = nullptr;
     bool        use_graph_ = true;
     hbhip_ctx  *ctx_;
     PicGeometry geo_;
