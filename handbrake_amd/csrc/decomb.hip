@@ -250,6 +250,7 @@ public:
     DecombFilter(hbhip_ctx *c, const hbhip_decomb_params &p) : hbhip_filter(c), par(p) {}
     ~DecombFilter() override
     {
+        if (side_ctx) (void)hipStreamSynchronize(side_ctx->stream);
         delete eedi_side;
         delete eedi;
         if (ev_frame) (void)hipEventDestroy(ev_frame);
