@@ -130,6 +130,69 @@ __global__ __launch_bounds__(256) void comb_mask_pass_kernel(const uint8_t *__re
     dst[(size_t)y * stride + 1 + xx] = (uint8_t)r;
 }
 
+// The four mask passes of filter mode 2 (mask_filter_work h&v -> mask_erode_work -> mask_dilate_work ->
+// mask_erode_work, comb_detect.c:556-966) in one launch: each pass looks one cell around itself, so a
+// workgroup carries a 64 x 16 tile of the final mask through all four in LDS with a shrinking apron
+// instead of four round trips through HBM.  Every pass writes only rows 1..height-2, columns
+// 2..width-1 (the reference's row pointers start at column 1); everything else in the intermediate
+// buffers is the zero they were allocated with, which is what `live` restores here.  The first pass
+// reads column `width` of the detector's mask through the same flat addressing as the reference
+// (the next row's column 0 when the stride equals the width).
+constexpr int CF_W = 64, CF_H = 16, CF_A = 4, CF_LW = CF_W + 2 * CF_A, CF_LH = CF_H + 2 * CF_A;
+
+__global__ __launch_bounds__(256) void comb_mask_fused_kernel(const uint8_t *__restrict__ mask, uint8_t *__restrict__ dst,
+                                                              int stride, int width, int height)
+{
+    __shared__ uint8_t s_a[CF_LH][CF_LW], s_b[CF_LH][CF_LW];
+    const int c0 = 2 + blockIdx.x * CF_W - CF_A, r0 = 1 + blockIdx.y * CF_H - CF_A;     // global position of LDS cell (0, 0)
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+    auto live = [&](int r, int c) { return r >= 1 && r <= height - 2 && c >= 2 && c <= width - 1; };
+
+    for (int i = tid; i < CF_LH * CF_LW; i += 256)
+    {
+        const int lr = i / CF_LW, lc = i - lr * CF_LW;
+        const int r = r0 + lr, c = c0 + lc;
+        uint8_t v = 0;
+        if (r >= 0 && r < height && c >= 0 && c <= width && !(c == width && r == height - 1 && stride == width))
+            v = mask[(size_t)r * stride + c];
+        s_a[lr][lc] = v;
+    }
+    __syncthreads();
+    // pass 1: horizontal & vertical triple test, apron 3
+    for (int i = tid; i < (CF_LH - 2) * (CF_LW - 2); i += 256)
+    {
+        const int lr = 1 + i / (CF_LW - 2), lc = 1 + i % (CF_LW - 2);
+        int v = 0;
+        if (live(r0 + lr, c0 + lc))
+            v = s_a[lr][lc - 1] & s_a[lr][lc] & s_a[lr][lc + 1] & s_a[lr - 1][lc] & s_a[lr + 1][lc];
+        s_b[lr][lc] = (uint8_t)v;
+    }
+    __syncthreads();
+    // passes 2-4: erode (>= 2 neighbours), dilate (>= 4), erode; ping-pong s_b -> s_a -> s_b -> out
+    for (int pass = 0; pass < 3; pass++)
+    {
+        uint8_t (*in)[CF_LW] = (pass & 1) ? s_a : s_b;
+        uint8_t (*out)[CF_LW] = (pass & 1) ? s_b : s_a;
+        const int ap = 2 + pass;                                   // cells dropped on each side
+        const int nw = CF_LW - 2 * ap, nh = CF_LH - 2 * ap;
+        for (int i = tid; i < nw * nh; i += 256)
+        {
+            const int lr = ap + i / nw, lc = ap + i % nw;
+            const int r = r0 + lr, c = c0 + lc;
+            int v = 0;
+            if (live(r, c))
+            {
+                const int count = in[lr - 1][lc - 1] + in[lr - 1][lc] + in[lr - 1][lc + 1] + in[lr][lc - 1] + in[lr][lc + 1] +
+                                  in[lr + 1][lc - 1] + in[lr + 1][lc] + in[lr + 1][lc + 1];
+                v = pass == 1 ? (in[lr][lc] ? 1 : count >= 4) : (in[lr][lc] == 0 ? 0 : count >= 2);
+                if (pass == 2) dst[(size_t)r * stride + c] = (uint8_t)v;
+            }
+            if (pass < 2) out[lr][lc] = (uint8_t)v;
+        }
+        __syncthreads();
+    }
+}
+
 // one wave per block_width x block_height block; result = max category seen
 // One workgroup (4 waves) per row of blocks: each wave sums one block at a time, the categories are
 // maximised inside the workgroup and one atomic per workgroup reaches the result word (a global
@@ -293,11 +356,16 @@ public:
         dim3 gm((width - 2 + 63) / 64, (height - 2 + 3) / 4);
         if (filt)
         {
-            if (par.filter_mode == 1)
+            const bool fused = par.filter_mode == 2 && getenv("HBHIP_COMB_UNFUSED") == nullptr;
+            if (fused)
+                HBHIP_LAUNCH(ctx, "comb_mask_passes", comb_mask_fused_kernel,
+                             dim3((width - 2 + CF_W - 1) / CF_W, (height - 2 + CF_H - 1) / CF_H), b, 0,
+                             (const uint8_t *)mask, mask_filtered, mstride, width, height);
+            else if (par.filter_mode == 1)
                 HBHIP_LAUNCH(ctx, "comb_mask_filter", comb_mask_pass_kernel, gm, b, 0, (const uint8_t *)mask, mask_filtered, mstride, width, height, 0, 1);
             else
                 HBHIP_LAUNCH(ctx, "comb_mask_filter", comb_mask_pass_kernel, gm, b, 0, (const uint8_t *)mask, mask_temp, mstride, width, height, 0, 0);
-            if (par.filter_mode == 2)
+            if (par.filter_mode == 2 && !fused)
             {
                 HBHIP_LAUNCH(ctx, "comb_mask_erode", comb_mask_pass_kernel, gm, b, 0, (const uint8_t *)mask_temp, mask_filtered, mstride, width, height, 1, 0);
                 HBHIP_LAUNCH(ctx, "comb_mask_dilate", comb_mask_pass_kernel, gm, b, 0, (const uint8_t *)mask_filtered, mask_temp, mstride, width, height, 2, 0);

@@ -157,7 +157,7 @@ def main():
         cd.classify()
     ctx.sync()
     st = ctx.profile_stats(); ctx.profile(False)
-    add(st, {"comb_detect": 3 * Y + Y, "comb_mask_filter": 2 * Y, "comb_mask_erode": 2 * Y, "comb_mask_dilate": 2 * Y,
+    add(st, {"comb_detect": 3 * Y + Y, "comb_mask_passes": 2 * Y, "comb_mask_filter": 2 * Y, "comb_mask_erode": 2 * Y, "comb_mask_dilate": 2 * Y,
              "comb_block_score": Y})
     cd.close()
     # colorspace: BT.601 -> BT.709 8-bit (linearised, primaries change) and HDR10 -> BT.709 10-bit (hable)
