@@ -407,6 +407,8 @@ static void mirror_borders16(uint16_t *mem, int w, int h, int border)
     }
 }
 
+#include "nlmeans_prefilter16.h"
+
 static void patch_ssd16(const uint16_t *a_img, const uint16_t *b_img, int bw,
                         int w, int h, int n, int dx, int dy,
                         uint32_t *colsum, uint32_t *ssd)

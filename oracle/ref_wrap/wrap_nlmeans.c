@@ -82,6 +82,26 @@ HBREF_EXPORT int hbref_nlmeans_tables(const char *settings, int c, float *exptab
 }
 
 /* prefilter only: returns the prefiltered (de-bordered) plane */
+/* The same for the 16-bit template instantiation (nlmeans_prefilter_16, nlmeans.c:253-262);
+ * `stride` and `dst_stride` in bytes, samples uint16. */
+HBREF_EXPORT int hbref_nlmeans_prefilter_16(const uint8_t *plane, int w, int h, int stride,
+                                            int filter_type, int border, uint8_t *dst, int dst_stride)
+{
+    BorderedPlane bp;
+    memset(&bp, 0, sizeof(bp));
+    nlmeans_alloc_16(plane, w, stride / 2, h, &bp, border);      /* src_s is in samples */
+    bp.mutex = hb_lock_init();
+    nlmeans_prefilter_16(&bp, filter_type);
+    const uint16_t *img = (const uint16_t *)bp.image_pre;
+    const int bw = w + 2 * border;
+    for (int y = 0; y < h; y++)
+        memcpy(dst + (size_t)y * dst_stride, img + (size_t)y * bw, sizeof(uint16_t) * w);
+    if (bp.mem_pre != bp.mem) free(bp.mem_pre);
+    free(bp.mem);
+    hb_lock_close(&bp.mutex);
+    return 0;
+}
+
 HBREF_EXPORT int hbref_nlmeans_prefilter_8(const uint8_t *plane, int w, int h, int stride,
                                            int filter_type, int border, uint8_t *dst, int dst_stride)
 {

@@ -68,6 +68,29 @@ def test_nlmeans_prefilter_matches_reference(built, pf):
 
 
 @needs_ref
+@pytest.mark.parametrize("depth", [10, 12])
+@pytest.mark.parametrize("model", ["progressive", "random"])
+@pytest.mark.parametrize("pf", [1, 2, 4, 8, 16, 32, 257, 514, 769, 1025, 1026, 1281, 1040, 1060])
+def test_nlmeans_prefilter_16bit_matches_reference(built, pf, model, depth):
+    """nlmeans_prefilter_16 (wider accumulators, unscaled edge-boost thresholds): groundwork for the
+    HIP path, which still refuses prefilters above 8 bits."""
+    import ctypes as C
+    fr = np.ascontiguousarray(synth.stream(model, 97, 61, 1, depth=depth)[0][0])
+    lib, o = ol.ref(), ol.oracle()
+    want = np.zeros_like(fr)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib.hbref_nlmeans_prefilter_16.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    assert lib.hbref_nlmeans_prefilter_16(vp(fr), 97, 61, fr.strides[0], pf, 16, vp(want), want.strides[0]) == 0
+    b = np.zeros((61 + 32, 97 + 32), np.uint16)
+    o.orc_nlmeans_make_bordered16.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    o.orc_nlmeans_prefilter16.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    o.orc_nlmeans_make_bordered16(vp(fr), 97, 61, fr.strides[0] // 2, 16, vp(b))
+    pre = np.zeros_like(b)
+    o.orc_nlmeans_prefilter16(vp(b), 97, 61, 16, pf, vp(pre))
+    np.testing.assert_array_equal(pre[16:16 + 61, 16:16 + 97], want)
+
+
+@needs_ref
 def test_nlmeans_with_prefilter_matches_reference(built):
     frames = synth.stream("progressive", 120, 70, 2)
     planes = [fr[0] for fr in frames]
