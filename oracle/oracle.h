@@ -258,6 +258,16 @@ typedef struct
 int orc_colorspace_frame(const orc_colorspace_params_t *cs, const void *const src[3], const int sstride[3],
                          void *const dst[3], const int dstride[3], int w, int h, int depth, int subw, int subh);
 
+/* ---- EEDI2 on 10 / 12-bit samples (eedi2_template.c instantiated with pixel = uint16_t) -----------
+ * Groundwork: the HIP EEDI2 passes are 8-bit only so far.  Same scratch frames and run semantics as
+ * the 8-bit object above; planes are uint16, strides / pitches in SAMPLES. */
+typedef struct orc_eedi2_16 orc_eedi2_16_t;
+orc_eedi2_16_t *orc_eedi2_16_new(int width, int height, int depth, const orc_eedi2_params_t *p);
+void            orc_eedi2_16_free(orc_eedi2_16_t *e);
+void            orc_eedi2_16_run(orc_eedi2_16_t *e, const uint16_t *const cur[3], const int stride[3], int tff);
+void            orc_eedi2_16_run_partial(orc_eedi2_16_t *e, const uint16_t *const cur[3], const int stride[3], int tff, int npasses);
+const uint16_t *orc_eedi2_16_plane(orc_eedi2_16_t *e, int buffer, int plane, int *stride, int *height);
+
 /* ---- FFmpeg yadif, the reference's "Deinterlace" filter (deinterlace.c -> vf_yadif.c; PARITY UNPINNED) -- */
 void orc_yadif_ff_plane(const void *prev, const void *cur, const void *next, int stride, int w, int h,
                         void *dst, int dst_stride, int parity, int tff, int nospatial, int bps);

@@ -31,6 +31,59 @@ HBREF_EXPORT void *hbref_eedi2_new(int width, int height, const char *settings)
     return f;
 }
 
+/* The same object for a 10 / 12-bit pixel format (the reference then runs its _16 template functions) */
+HBREF_EXPORT void *hbref_eedi2_new_fmt(int width, int height, const char *settings, int pix_fmt)
+{
+    hb_filter_object_t *f = calloc(1, sizeof(*f));
+    *f = hb_filter_decomb;
+    hb_filter_init_t init;
+    memset(&init, 0, sizeof(init));
+    init.pix_fmt = pix_fmt;
+    init.geometry.width = width;
+    init.geometry.height = height;
+    f->settings = hbhip_dict_from_string(settings);
+    if (f->init(f, &init) != 0)
+    {
+        free(f);
+        return NULL;
+    }
+    hb_filter_private_t *pv = f->private_data;
+    if (pv->cx2 != NULL)
+    {
+        const size_t n = (size_t)height * hb_image_stride(init.pix_fmt, width, 0) * sizeof(int);
+        memset(pv->cx2, 0, n); memset(pv->cy2, 0, n); memset(pv->cxy, 0, n); memset(pv->tmpc, 0, n);
+    }
+    return f;
+}
+
+/* eedi2_planer_16 / plane-serial eedi2_interpolate_plane_16 on a frame of uint16 samples (strides in bytes) */
+HBREF_EXPORT void hbref_eedi2_run16(void *h, const uint8_t *const plane[3], const int stride[3], int tff, int serial)
+{
+    hb_filter_object_t *f = h;
+    hb_filter_private_t *pv = f->private_data;
+    hb_buffer_t *b = hb_frame_buffer_init(pv->input.pix_fmt, pv->input.geometry.width, pv->input.geometry.height);
+    for (int p = 0; p < 3; p++)
+        for (int y = 0; y < b->plane[p].height; y++)
+            memcpy(b->plane[p].data + (size_t)y * b->plane[p].stride, plane[p] + (size_t)y * stride[p],
+                   MIN(stride[p], b->plane[p].stride));
+    hb_buffer_close(&pv->ref[1]);
+    pv->ref[1] = b;
+    pv->tff = tff;
+    if (!serial)
+    {
+        eedi2_planer_16(pv);
+        return;
+    }
+    for (int p = 0; p < 3; p++)
+    {
+        const int src_pitch = b->plane[p].stride / 2, dst_pitch = pv->eedi_half[SRCPF]->plane[p].stride / 2;
+        eedi2_fill_half_height_buffer_plane_16((uint16_t *)b->plane[p].data + src_pitch * !tff,
+                                               (uint16_t *)pv->eedi_half[SRCPF]->plane[p].data, src_pitch, dst_pitch, b->plane[p].height);
+    }
+    for (int p = 0; p < 3; p++)
+        eedi2_interpolate_plane_16(pv, p);
+}
+
 HBREF_EXPORT void hbref_eedi2_run(void *h, const uint8_t *const plane[3], const int stride[3], int tff)
 {
     hb_filter_object_t *f = h;

@@ -7,7 +7,7 @@ handbrake_amd/synth.py and stores the output planes.  Only runs where
 /root/reference exists; the resulting .npz files are committed so that the
 oracle restatement and the HIP path can be pinned anywhere (GPU box included).
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [case names ...]
 """
 import os
 import sys
@@ -28,7 +28,10 @@ def main():
     ref = ol.ref()
     if ref is None:
         raise SystemExit("oracle/_ref/libhbref.so missing: run `make oracle` where /root/reference exists")
+    only = set(sys.argv[1:])            # optional: regenerate just the named cases
     for name, case in gc.CASES.items():
+        if only and name not in only:
+            continue
         frames = synth.stream(case["model"], case["w"], case["h"], case["n"], depth=case.get("depth", 8))
         out = hbrt.run_stream(ref, case["chain"], frames, flags=synth.flags_for(case["model"]),
                               pix_fmt=hbrt.PIX_FMT_FOR_DEPTH[case.get("depth", 8)])

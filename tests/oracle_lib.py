@@ -211,14 +211,16 @@ def orc_chroma_smooth_plane(plane, strength=0.25, size=7, depth=8):
 # ---------------------------------------------------------------- decomb
 def orc_decomb_plane(prev, cur, nxt, mode, parity, tff, guess=None, depth=8):
     h, w = cur.shape
-    if cur.dtype == np.uint16:                      # the _16 instantiation; no EEDI2 guess at this depth
+    if cur.dtype == np.uint16:                      # the _16 instantiation; pitches in samples
         P, Cu, N = padded16(prev), padded16(cur), padded16(nxt)
+        G = padded16(guess) if guess is not None else None
         dst = np.zeros_like(Cu)
         u16p = C.POINTER(C.c_uint16)
         fn = oracle().orc_decomb_plane16
         fn.restype = None
         fn.argtypes = [u16p] * 3 + [C.c_int, u16p, C.c_int, u16p] + [C.c_int] * 7
-        fn(P.ctypes.data_as(u16p), Cu.ctypes.data_as(u16p), N.ctypes.data_as(u16p), Cu.shape[1], None, 0,
+        fn(P.ctypes.data_as(u16p), Cu.ctypes.data_as(u16p), N.ctypes.data_as(u16p), Cu.shape[1],
+           G.ctypes.data_as(u16p) if G is not None else None, G.shape[1] if G is not None else 0,
            dst.ctypes.data_as(u16p), dst.shape[1], w, h, mode, parity, tff, depth)
         return dst[:, :w].copy()
     P, Cu, N = padded(prev), padded(cur), padded(nxt)
@@ -545,3 +547,69 @@ def orc_yadif_ff_plane(prev, cur, nxt, parity, tff, nospatial):
     fn(p.ctypes.data, c.ctypes.data, n.ctypes.data, c.strides[0], w, h, dst.ctypes.data, dst.strides[0],
        int(parity), int(tff), int(nospatial), c.itemsize)
     return dst
+
+
+class OrcEedi2_16:
+    """The 16-bit EEDI2 restatement (oracle/eedi2_16_oracle.c); planes are uint16, depth 10 / 12."""
+
+    def __init__(self, width, height, depth, magnitude=10, variance=20, laplacian=20, dilation=4, erosion=2,
+                 noise=50, search=24, postproc=1):
+        lib = oracle()
+        lib.orc_eedi2_16_new.restype = C.c_void_p
+        lib.orc_eedi2_16_new.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(Eedi2Params)]
+        lib.orc_eedi2_16_run_partial.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int]
+        lib.orc_eedi2_16_plane.restype = C.POINTER(C.c_uint16)
+        lib.orc_eedi2_16_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        lib.orc_eedi2_16_free.argtypes = [C.c_void_p]
+        p = Eedi2Params(magnitude, variance, laplacian, dilation, erosion, noise, search, postproc)
+        self.lib, self.w, self.h = lib, width, height
+        self.e = lib.orc_eedi2_16_new(width, height, depth, C.byref(p))
+
+    def run(self, frame, tff, npasses=1000):
+        keep = [padded16(p) for p in frame]
+        ptrs = (C.c_void_p * 3)(*[k.ctypes.data for k in keep])
+        strides = (C.c_int * 3)(*[k.strides[0] // 2 for k in keep])        # samples
+        self.lib.orc_eedi2_16_run_partial(self.e, ptrs, strides, int(tff), npasses)
+
+    def plane(self, buffer, plane):
+        st, ht = C.c_int(), C.c_int()
+        ptr = self.lib.orc_eedi2_16_plane(self.e, buffer, plane, C.byref(st), C.byref(ht))
+        return np.ctypeslib.as_array(ptr, shape=(ht.value, st.value)).copy()
+
+    def close(self):
+        if self.e:
+            self.lib.orc_eedi2_16_free(self.e)
+            self.e = None
+
+
+class RefEedi2_16:
+    """The reference's eedi2_planer_16 / eedi2_interpolate_plane_16 on a 10 / 12-bit frame."""
+
+    def __init__(self, width, height, pix_fmt, settings="mode=8"):
+        lib = ref()
+        lib.hbref_eedi2_new_fmt.restype = C.c_void_p
+        lib.hbref_eedi2_new_fmt.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int]
+        lib.hbref_eedi2_run16.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int]
+        lib.hbref_eedi2_plane.restype = C.POINTER(C.c_uint8)
+        lib.hbref_eedi2_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        lib.hbref_eedi2_free.argtypes = [C.c_void_p]
+        self.lib = lib
+        self.h = lib.hbref_eedi2_new_fmt(width, height, settings.encode(), pix_fmt)
+        assert self.h
+
+    def run(self, frame, tff, serial=False):
+        keep = [padded16(p) for p in frame]
+        ptrs = (C.c_void_p * 3)(*[k.ctypes.data for k in keep])
+        strides = (C.c_int * 3)(*[k.strides[0] for k in keep])             # bytes
+        self.lib.hbref_eedi2_run16(self.h, ptrs, strides, int(tff), int(serial))
+
+    def plane(self, buffer, plane):
+        st, ht = C.c_int(), C.c_int()
+        ptr = self.lib.hbref_eedi2_plane(self.h, buffer, plane, C.byref(st), C.byref(ht))
+        raw = np.ctypeslib.as_array(ptr, shape=(ht.value, st.value)).copy()
+        return raw.view(np.uint16)                                         # (height, stride in samples)
+
+    def close(self):
+        if self.h:
+            self.lib.hbref_eedi2_free(self.h)
+            self.h = None

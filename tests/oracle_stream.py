@@ -184,11 +184,14 @@ def decomb_eedi2_stream(frames, par, flags=PIC_FLAG_TOP_FIELD_FIRST, combed=None
     keys = dict(magnitude="magnitude", variance="variance", laplacian="laplacian", dilation="dilation",
                 erosion="erosion", noise="noise", search="search", postproc="postproc")
     kw = {k: par[k] for k in keys if k in par}
-    oe = ol.OrcEedi2(w, h, **kw)
+    depth = par.get("depth", 8)
+    oe = ol.OrcEedi2(w, h, **kw) if depth == 8 else ol.OrcEedi2_16(w, h, depth, **kw)
 
     def guess(cur, tff):
         oe.run(cur, tff)
-        return oe.guess()
+        if depth == 8:
+            return oe.guess()
+        return [np.ascontiguousarray(oe.plane(4, c)[:, : (w if c == 0 else (w + 1) // 2)]) for c in range(3)]
 
     try:
         return decomb_stream(frames, par, flags=flags, combed=combed, duration=duration, eedi2=guess)

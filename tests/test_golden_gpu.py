@@ -16,6 +16,8 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 @pytest.mark.parametrize("name", sorted(gc.CASES))
 def test_hip_matches_golden(built, name):
     case = gc.CASES[name]
+    if case.get("hip") is None:
+        pytest.skip("no HIP path for this case yet (oracle-only golden)")
     want, meta = os_.load_golden(os.path.join(GOLD, name + ".npz"))
     frames = synth.stream(case["model"], case["w"], case["h"], case["n"], depth=case.get("depth", 8))
     got = hbrt.run_stream(hip.filters(), case["hip"], frames, flags=synth.flags_for(case["model"]),

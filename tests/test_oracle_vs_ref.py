@@ -236,6 +236,38 @@ def test_eedi2_corner_postprocessing_matches_reference(built, w, h, postproc):
 
 
 @needs_ref
+@pytest.mark.parametrize("depth", [10, 12])
+@pytest.mark.parametrize("w,h", [(128, 72), (638, 360), (322, 184)])
+@pytest.mark.parametrize("settings,par,model", [
+    ("mode=8", {}, "interlaced"),
+    ("mode=8:postproc=0:noise-thresh=30:search-distance=12", dict(postproc=0, noise=30, search=12), "interlaced"),
+    ("mode=8:magnitude-thresh=5:variance-thresh=10:laplacian-thresh=30:dilation-thresh=3:erosion-thresh=3",
+     dict(magnitude=5, variance=10, laplacian=30, dilation=3, erosion=3), "corners"),
+    ("mode=8:postproc=2", dict(postproc=2), "corners"),
+    ("mode=8:postproc=3", dict(postproc=3), "corners")])
+def test_eedi2_16bit_every_scratch_buffer_matches_reference(built, depth, w, h, settings, par, model):
+    """The 16-bit restatement (oracle/eedi2_16_oracle.c) against the reference's _16 template functions:
+    all nine scratch frames, three planes, consecutive stateful runs.  Groundwork - the HIP EEDI2
+    passes are 8-bit only so far.  postproc 2/3 plane-serial, as for 8 bits."""
+    from handbrake_amd import hbrt
+    serial = par.get("postproc", 1) > 1
+    frames = synth.stream(model, w, h, 3, depth=depth)
+    r, o = ol.RefEedi2_16(w, h, hbrt.PIX_FMT_FOR_DEPTH[depth], settings), ol.OrcEedi2_16(w, h, depth, **par)
+    try:
+        for fr in frames:
+            for tff in (1, 0):
+                r.run(fr, tff, serial=serial)
+                o.run(fr, tff)
+                for b in range(9):
+                    for c in range(3):
+                        np.testing.assert_array_equal(o.plane(b, c), r.plane(b, c),
+                                                      err_msg=f"{ol.EEDI2_BUFFERS[b]} plane {c} tff {tff}")
+    finally:
+        r.close()
+        o.close()
+
+
+@needs_ref
 @pytest.mark.parametrize("mode,extra,par", [
     (8, "", {}), (15, "", {}), (31, "", {}), (63, "", {}),
     (9, ":postproc=0:noise-thresh=30:search-distance=12", dict(postproc=0, noise=30, search=12)),
@@ -246,6 +278,20 @@ def test_decomb_eedi2_matches_reference(built, mode, extra, par):
     combed = [2, 1, 0, 2]
     got = hbrt.run_stream(ol.ref(), [("hb_filter_decomb", f"mode={mode}{extra}")], frames, flags=TFF, combed=combed)
     _eq_dstream(got, os_.decomb_eedi2_stream(frames, dict(mode=mode, **par), flags=TFF, combed=combed))
+
+
+@needs_ref
+@pytest.mark.parametrize("depth", [10, 12])
+@pytest.mark.parametrize("mode", [8, 15, 31, 63])
+def test_decomb_eedi2_16bit_matches_reference(built, depth, mode):
+    """The whole decomb plugin with EEDI2 on 10 / 12-bit frames (reference init / work / close) against
+    the oracle stream built on the 16-bit EEDI2 and decomb restatements."""
+    from handbrake_amd import hbrt
+    frames = synth.stream("interlaced", 638, 360, 4, depth=depth)
+    combed = [2, 1, 0, 2]
+    got = hbrt.run_stream(ol.ref(), [("hb_filter_decomb", f"mode={mode}")], frames, flags=TFF, combed=combed,
+                          pix_fmt=hbrt.PIX_FMT_FOR_DEPTH[depth])
+    _eq_dstream(got, os_.decomb_eedi2_stream(frames, dict(mode=mode, depth=depth), flags=TFF, combed=combed))
 
 
 HQ_CASES = [
