@@ -407,6 +407,9 @@ static void mirror_borders16(uint16_t *mem, int w, int h, int border)
     }
 }
 
+void orc_nlmeans_plane16_pf(const uint16_t *const *planes, int plane_stride, int nframes, int w, int h,
+                            int depth, const orc_nlmeans_params_t *p, int src_prefiltered,
+                            uint16_t *dst, int dst_stride);
 #include "nlmeans_prefilter16.h"
 
 static void patch_ssd16(const uint16_t *a_img, const uint16_t *b_img, int bw,
@@ -454,6 +457,17 @@ static void patch_ssd16(const uint16_t *a_img, const uint16_t *b_img, int bw,
 void orc_nlmeans_plane16(const uint16_t *const *planes, int plane_stride, int nframes, int w, int h,
                          int depth, const orc_nlmeans_params_t *p, uint16_t *dst, int dst_stride)
 {
+    orc_nlmeans_plane16_pf(planes, plane_stride, nframes, w, h, depth, p, 0, dst, dst_stride);
+}
+
+/* The same with the prefilters of nlmeans_prefilter_16 (p->prefilter): patches are compared on the
+ * prefiltered planes, the weighted sum runs over the raw ones (nlmeans_template.c:614-635).
+ * src_prefiltered: whether frame 0's own patches come from its prefiltered plane - the reference
+ * latches src_pre before frame 0's prefilter call (:615 vs :631), see oracle_stream.nlmeans_stream. */
+void orc_nlmeans_plane16_pf(const uint16_t *const *planes, int plane_stride, int nframes, int w, int h,
+                            int depth, const orc_nlmeans_params_t *p, int src_prefiltered,
+                            uint16_t *dst, int dst_stride)
+{
     float exptable[EXPSIZE];
     float wft;
     int diff_max;
@@ -467,14 +481,17 @@ void orc_nlmeans_plane16(const uint16_t *const *planes, int plane_stride, int nf
     const size_t origin = border + (size_t)bw * border;
     const double origin_tune = p->origin_tune;
 
-    uint16_t **fr = malloc(sizeof(uint16_t *) * nframes);
+    uint16_t **fr = malloc(sizeof(uint16_t *) * nframes), **pre = malloc(sizeof(uint16_t *) * nframes);
     for (int f = 0; f < nframes; f++)
     {
         fr[f] = calloc((size_t)bw * bh, sizeof(uint16_t));
         for (int y = 0; y < h; y++)
             memcpy(fr[f] + origin + (size_t)y * bw, planes[f] + (size_t)y * plane_stride, sizeof(uint16_t) * w);
         mirror_borders16(fr[f], w, h, border);
+        pre[f] = malloc(sizeof(uint16_t) * (size_t)bw * bh);
+        orc_nlmeans_prefilter16(fr[f], w, h, border, p->prefilter, pre[f]);
     }
+    const uint16_t *src_pre = (src_prefiltered ? pre[0] : fr[0]) + origin;
     acc_t *acc = calloc((size_t)w * h, sizeof(acc_t));
     uint32_t *ssd = malloc(sizeof(uint32_t) * (size_t)w * h);
     uint32_t *colsum = malloc(sizeof(uint32_t) * (w + n));
@@ -483,6 +500,7 @@ void orc_nlmeans_plane16(const uint16_t *const *planes, int plane_stride, int nf
     for (int f = 0; f < nframes; f++)
     {
         const uint16_t *cmp = fr[f] + origin;
+        const uint16_t *cmp_pre = pre[f] + origin;
         for (int dy = -r_half; dy <= r_half; dy++)
             for (int dx = -r_half; dx <= r_half; dx++)
             {
@@ -497,7 +515,7 @@ void orc_nlmeans_plane16(const uint16_t *const *planes, int plane_stride, int nf
                         }
                     continue;
                 }
-                patch_ssd16(src, cmp, bw, w, h, n, dx, dy, colsum, ssd);
+                patch_ssd16(src_pre, cmp_pre, bw, w, h, n, dx, dy, colsum, ssd);
                 for (int y = 0; y < h; y++)
                     for (int x = 0; x < w; x++)
                     {
@@ -523,6 +541,7 @@ void orc_nlmeans_plane16(const uint16_t *const *planes, int plane_stride, int nf
     free(colsum);
     free(ssd);
     free(acc);
-    for (int f = 0; f < nframes; f++) free(fr[f]);
+    for (int f = 0; f < nframes; f++) { free(fr[f]); free(pre[f]); }
     free(fr);
+    free(pre);
 }

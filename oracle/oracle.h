@@ -73,6 +73,9 @@ void orc_nlmeans_plane(const uint8_t *const *frames, const uint8_t *const *frame
  * setting's value, the (depth-8)^2 scaling of nlmeans.c:343 is applied inside. */
 void orc_nlmeans_plane16(const uint16_t *const *planes, int plane_stride, int nframes, int w, int h,
                          int depth, const orc_nlmeans_params_t *p, uint16_t *dst, int dst_stride);
+void orc_nlmeans_plane16_pf(const uint16_t *const *planes, int plane_stride, int nframes, int w, int h,
+                            int depth, const orc_nlmeans_params_t *p, int src_prefiltered,
+                            uint16_t *dst, int dst_stride);
 /* The 16-bit prefilters (nlmeans_prefilter_16): bordered sample arrays as in the 8-bit forms above.
  * Groundwork for the HIP path, which still refuses prefilters above 8 bits. */
 void orc_nlmeans_make_bordered16(const uint16_t *src, int w, int h, int src_stride, int border, uint16_t *dst);

@@ -126,6 +126,17 @@ CASES = {
                                     chain=[("hb_filter_decomb", "mode=31")],
                                     hip=[("hb_filter_decomb_hip", "mode=31")],
                                     orc=[("decomb", dict(mode=31))]),
+    # 10 / 12-bit NLMeans with prefilters: oracle-only for now (the HIP prefilters are 8-bit), threads=1
+    # for the same reason as the 8-bit prefilter cases
+    "nlmeans_prefilter_10bit_134x70": dict(model="progressive", w=134, h=70, n=4, depth=10,
+                                           chain=[("hb_filter_nlmeans", NLM_PRE_A + ":threads=1")], hip=None,
+                                           orc=[("nlmeans", [nlm(prefilter=272, depth=10), nlm(patch=5, prefilter=8, depth=10),
+                                                             nlm(patch=5, prefilter=8, depth=10)])]),
+    "nlmeans_prefilter_12bit_96x64": dict(model="random", w=96, h=64, n=4, depth=12,
+                                          chain=[("hb_filter_nlmeans", NLM_PRE_C + ":threads=1")], hip=None,
+                                          orc=[("nlmeans", [nlm(prefilter=2049, depth=12),
+                                                            nlm(origin_tune=0.8, prefilter=1028, depth=12),
+                                                            nlm(origin_tune=0.8, prefilter=800, depth=12)])]),
     # 10 / 12-bit EEDI2: pinned for the oracle (eedi2_16_oracle.c); the HIP EEDI2 passes are 8-bit only
     # so far (hip=None: the GPU test skips these), the vectors are here for when they are not
     "decomb_eedi2_bob_10bit_128x64": dict(model="interlaced", w=128, h=64, n=3, depth=10,

@@ -78,20 +78,37 @@ def orc_nlmeans_plane(planes, strength=6.0, origin_tune=1.0, patch=7, rng=3, pre
     return dst
 
 
-def orc_nlmeans_plane16(planes, depth, strength=6.0, origin_tune=1.0, patch=7, rng=3):
-    """planes: list of 2-D uint16 arrays (frame 0 = filtered frame, then look-ahead); prefilter 0."""
+def orc_nlmeans_plane16(planes, depth, strength=6.0, origin_tune=1.0, patch=7, rng=3, prefilter=0,
+                        src_already_prefiltered=False):
+    """planes: list of 2-D uint16 arrays (frame 0 = filtered frame, then look-ahead)."""
     lib = oracle()
     h, w = planes[0].shape
     keep = [np.ascontiguousarray(p, dtype=np.uint16) for p in planes]
     u16p = C.POINTER(C.c_uint16)
     ptrs = (u16p * len(keep))(*[k.ctypes.data_as(u16p) for k in keep])
-    par = NLMeansParams(strength, origin_tune, patch, rng, len(keep), 0)
+    par = NLMeansParams(strength, origin_tune, patch, rng, len(keep), prefilter)
     dst = np.zeros((h, w), np.uint16)
-    lib.orc_nlmeans_plane16.argtypes = [C.POINTER(u16p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                        C.POINTER(NLMeansParams), u16p, C.c_int]
-    lib.orc_nlmeans_plane16.restype = None
-    lib.orc_nlmeans_plane16(ptrs, w, len(keep), w, h, depth, C.byref(par), dst.ctypes.data_as(u16p), w)
+    lib.orc_nlmeans_plane16_pf.argtypes = [C.POINTER(u16p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.POINTER(NLMeansParams), C.c_int, u16p, C.c_int]
+    lib.orc_nlmeans_plane16_pf.restype = None
+    lib.orc_nlmeans_plane16_pf(ptrs, w, len(keep), w, h, depth, C.byref(par), int(src_already_prefiltered),
+                               dst.ctypes.data_as(u16p), w)
     return dst
+
+
+def orc_nlmeans_prefiltered16(plane, prefilter, patch=7):
+    """The w x h interior of nlmeans_prefilter_16's output for one uint16 plane."""
+    lib = oracle()
+    p = np.ascontiguousarray(plane, dtype=np.uint16)
+    h, w = p.shape
+    border = lib.orc_nlmeans_border(patch)
+    b = np.zeros((h + 2 * border, w + 2 * border), np.uint16)
+    q = np.zeros_like(b)
+    lib.orc_nlmeans_make_bordered16.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.orc_nlmeans_prefilter16.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.orc_nlmeans_make_bordered16(p.ctypes.data, w, h, p.strides[0] // 2, border, b.ctypes.data)
+    lib.orc_nlmeans_prefilter16(b.ctypes.data, w, h, border, prefilter, q.ctypes.data)
+    return np.ascontiguousarray(q[border:border + h, border:border + w])
 
 
 def orc_nlmeans_prefiltered(plane, prefilter, patch=7):

@@ -18,12 +18,16 @@ def nlmeans_stream(frames, planes_par):
             p = planes_par[c]
             pf = p.get("prefilter", 0)
             if frames[t][c].dtype == np.uint16:             # 10 / 12-bit samples (depth in the parameters)
+                if pf & 2048:
+                    planes.append(ol.orc_nlmeans_prefiltered16(frames[t][c], pf, p["patch"]))
+                    continue
                 if p["strength"] == 0:
                     planes.append(frames[t][c].copy())
                     continue
                 nf = min(p["nframes"], n - t)
                 planes.append(ol.orc_nlmeans_plane16([frames[t + f][c] for f in range(nf)], p["depth"],
-                                                     p["strength"], p["origin_tune"], p["patch"], p["range"]))
+                                                     p["strength"], p["origin_tune"], p["patch"], p["range"], pf,
+                                                     src_already_prefiltered=(t >= 1 and p["nframes"] >= 2)))
                 continue
             if pf & 2048:                                   # passthru: the prefiltered plane is the output
                 planes.append(ol.orc_nlmeans_prefiltered(frames[t][c], pf, p["patch"]))
