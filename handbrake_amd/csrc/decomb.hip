@@ -251,6 +251,7 @@ public:
     ~DecombFilter() override
     {
         if (side_ctx) (void)hipStreamSynchronize(side_ctx->stream);
+        delete eedi16;
         delete eedi_side;
         delete eedi;
         if (ev_frame) (void)hipEventDestroy(ev_frame);
@@ -268,9 +269,19 @@ public:
         const int hm = par.mode & ~M_SELECTIVE;
         if (!(hm == 0 || hm == M_BLEND || hm == M_CUBIC || (hm & M_YADIF) || (hm & M_EEDI2)))
             return HBHIP_ERR_UNSUPPORTED;
+        if ((par.mode & M_EEDI2) && in_geo.bps != 1)
+        {
+            // 10 / 12-bit EEDI2: eedi2_16.hip, first correct form (tests/test_eedi2_gpu.py::test_16bit_*)
+            if (par.post_processing < 0 || par.post_processing > 3) return HBHIP_ERR_UNSUPPORTED;
+            Eedi2Params ep = { par.magnitude_threshold, par.variance_threshold, par.laplacian_threshold,
+                               par.dilation_threshold, par.erosion_threshold, par.noise_threshold,
+                               par.maximum_search_distance, par.post_processing };
+            eedi16 = new (std::nothrow) Eedi2Engine16(ctx, in_geo, ep);
+            if (!eedi16) return HBHIP_ERR_NOMEM;
+            return eedi16->init();
+        }
         if (par.mode & M_EEDI2)
         {
-            if (in_geo.bps != 1) return HBHIP_ERR_UNSUPPORTED;     // the EEDI2 passes are built for 8-bit samples only
             if (par.post_processing < 0 || par.post_processing > 3) return HBHIP_ERR_UNSUPPORTED;
             Eedi2Params ep = { par.magnitude_threshold, par.variance_threshold, par.laplacian_threshold,
                                par.dilation_threshold, par.erosion_threshold, par.noise_threshold,
@@ -367,7 +378,12 @@ private:
             DecombPlane &P = a.pl[c];
             P.prev = ref[0]->plane[c]; P.cur = ref[1]->plane[c]; P.next = ref[2]->plane[c];
             P.guess = nullptr; P.guess_pitch = 0;
-            if ((mode & M_EEDI2) && guess_from)
+            if ((mode & M_EEDI2) && eedi16)
+            {
+                P.guess = eedi16->result().plane[c];
+                P.guess_pitch = eedi16->result().stride[c];
+            }
+            else if ((mode & M_EEDI2) && guess_from)
             {
                 P.guess = guess_from->result().plane[c];
                 P.guess_pitch = guess_from->result().stride[c];
@@ -439,7 +455,12 @@ private:
         {
             const int parity = frame ^ tff ^ 1;
             Eedi2Engine *e = (paired && frame) ? eedi_side : eedi;
-            if ((mode & M_EEDI2) && eedi)
+            if ((mode & M_EEDI2) && eedi16)
+            {
+                int rc = eedi16->run(cur, !parity);                              // pv->tff = !parity (decomb.c:542)
+                if (rc != HBHIP_OK) return rc;
+            }
+            else if ((mode & M_EEDI2) && eedi)
             {
                 int rc = paired ? e->join() : e->run(cur, !parity);
                 if (rc != HBHIP_OK) return rc;
@@ -465,6 +486,9 @@ private:
     std::deque<DevPicture *> outq;
     Eedi2Engine *eedi = nullptr;
     Eedi2Engine *eedi_side = nullptr;      // second field of a bob pair, on side_ctx's stream
+public:
+    Eedi2Engine16 *eedi16 = nullptr;       // 10 / 12-bit samples
+private:
     Eedi2Engine *last_engine = nullptr;
     hbhip_ctx   *side_ctx = nullptr;
     hipEvent_t   ev_frame = nullptr;
@@ -546,8 +570,9 @@ extern "C" int hbhip_decomb_debug_eedi_plane(hbhip_filter *f, int buffer, int pl
                                              int *stride, int *height)
 {
     DecombFilter *d = dynamic_cast<DecombFilter *>(f);
-    if (!d || !d->engine() || buffer < 0 || buffer > 8 || plane < 0 || plane > 2) return HBHIP_ERR_ARG;
-    const EediFrame &fr = buffer < 4 ? d->engine()->half(buffer) : d->engine()->full(buffer - 4);
+    if (!d || (!d->engine() && !d->eedi16) || buffer < 0 || buffer > 8 || plane < 0 || plane > 2) return HBHIP_ERR_ARG;
+    const EediFrame &fr = d->eedi16 ? (buffer < 4 ? d->eedi16->half(buffer) : d->eedi16->full(buffer - 4))
+                                    : (buffer < 4 ? d->engine()->half(buffer) : d->engine()->full(buffer - 4));
     if (stride) *stride = fr.stride[plane];
     if (height) *height = fr.height[plane];
     if (dst == nullptr) return HBHIP_OK;

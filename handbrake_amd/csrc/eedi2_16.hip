@@ -1,0 +1,826 @@
+// eedi2_16.hip — EEDI2 for 10 / 12-bit samples (eedi2_template.c instantiated with pixel = uint16_t,
+// decomb.c:324-331), first correct form: one thread per sample and pass, no LDS tiling, the
+// in-place lattice pass walked serially per row.  The tuned 8-bit kernels of eedi2.hip lean on byte
+// packing (packed SAD, 4 samples per dword) and do not carry over; this file follows the pinned
+// restatement oracle/eedi2_16_oracle.c pass by pass instead.
+//
+// What the reference does differently above 8 bits (all marked "16:" in the oracle): thresholds shifted
+// by depth-8 or typed `pixel` = uint16 so that they wrap at 16 bits, limlut << (depth-8), PEAK / NEUTRAL
+// from the depth, sums and squares taken on samples >> (depth-8).  Scratch frames keep the sample
+// layout hb_frame_buffer_init gives a 16-bit frame (stride = 2*width rounded up to 64 bytes), inside
+// zeroed guards, because the passes index flat buffers and read outside rows / planes.
+// All pitches inside the kernels are in SAMPLES.
+#include "eedi2_engine.h"
+
+namespace {
+
+constexpr size_t GUARD16 = 32768;          // samples
+
+struct K16
+{
+    int peak, neutral, shift;
+    int limlut[33];                        // eedi2_init_limlut (:23-33): (pixel)eedi2_limlut[i] << shift, stored as pixel
+};
+
+struct Q3
+{
+    uint16_t *a[3], *b[3], *c[3];          // pass specific roles, see each kernel
+    int pitch[3], width[3], height[3];
+};
+
+#define XY16(P)                                                              \
+    const int pl = blockIdx.z;                                               \
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;                     \
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;                     \
+    const int pitch = (P).pitch[pl], width = (P).width[pl], height = (P).height[pl]; \
+    (void)width; (void)height; (void)pitch
+
+__device__ __forceinline__ int iabs16(int v) { return v < 0 ? -v : v; }
+
+__device__ __forceinline__ int sad3w(const uint16_t *a, int ai, const uint16_t *b, int bi)
+{
+    return iabs16((int)a[ai - 1] - (int)b[bi - 1]) + iabs16((int)a[ai] - (int)b[bi]) + iabs16((int)a[ai + 1] - (int)b[bi + 1]);
+}
+
+// insertion sort + midpoint rule (eedi2.c:65-80)
+__device__ __forceinline__ int sorted_mid16(int *v, int n)
+{
+    for (int i = 1; i < n; i++)
+    {
+        const int t = v[i];
+        int j = i;
+        while (j > 0 && v[j - 1] > t) { v[j] = v[j - 1]; j--; }
+        v[j] = t;
+    }
+    return (n & 1) ? v[n >> 1] : (v[(n - 1) >> 1] + v[n >> 1] + 1) >> 1;
+}
+
+__device__ __forceinline__ int vote16(const int *v, int n, int mid, int lim, int &count)
+{
+    int sum = 0, cnt = 0;
+    for (int i = 0; i < n; i++)
+        if (iabs16(v[i] - mid) <= lim) { cnt++; sum += v[i]; }
+    count = cnt;
+    return (int)(((float)(sum + mid) / (float)(cnt + 1)) + 0.5f);
+}
+
+__device__ __forceinline__ int collect16(int *v, int k, const uint16_t *row, int x, bool skip_centre, int peak)
+{
+    if (row[x - 1] != peak) v[k++] = row[x - 1];
+    if (!skip_centre && row[x] != peak) v[k++] = row[x];
+    if (row[x + 1] != peak) v[k++] = row[x + 1];
+    return k;
+}
+
+// a = source plane (pitch in samples in `sp*`), b = srcp.  Device frames have no row padding:
+// samples at x >= width are written as 0 (see the 8-bit k_fill_half).
+__global__ void q_fill_half(Q3 P, int sp0, int sp1, int sp2, int start_line, int rows0, int rows1, int rows2)
+{
+    XY16(P);
+    const int sp = pl == 0 ? sp0 : pl == 1 ? sp1 : sp2;
+    const int rows = pl == 0 ? rows0 : pl == 1 ? rows1 : rows2;
+    if (x >= pitch || y >= rows) return;
+    P.b[pl][(size_t)y * pitch + x] = x < width ? P.a[pl][(size_t)(start_line + 2 * y) * sp + x] : (uint16_t)0;
+}
+
+// eedi2_build_edge_mask (:122-195), in place: a = srcp, c = mskp.  Rows of the upper half are cleared
+// first (whole pitch), the lower half keeps the previous run's mask where nothing is set (:132).
+__global__ void q_edge_mask(Q3 P, K16 k, int mth, int vth, int lth)
+{
+    XY16(P);
+    if (x >= pitch || y >= height) return;
+    bool set = false;
+    if (x >= 1 && x < width - 1 && y >= 1 && y < height - 1)
+    {
+        const uint16_t *c = P.a[pl] + (size_t)y * pitch, *p = c - pitch, *n = c + pitch;
+        const int ten = (uint16_t)(10 << k.shift), sh = k.shift;
+        auto flat = [&](int i) {
+            return iabs16((int)p[i] - (int)c[i]) < ten && iabs16((int)c[i] - (int)n[i]) < ten && iabs16((int)p[i] - (int)n[i]) < ten;
+        };
+        if (!(flat(x) || (flat(x - 1) && flat(x + 1))))
+        {
+            int sum = 0, sumsq = 0;
+            for (int i = -1; i <= 1; i++)
+            {
+                sum += (int)p[x + i] + (int)c[x + i] + (int)n[x + i];
+                sumsq += (p[x + i] >> sh) * (p[x + i] >> sh) + (c[x + i] >> sh) * (c[x + i] >> sh) + (n[x + i] >> sh) * (n[x + i] >> sh);
+            }
+            sum >>= sh;
+            if (!(9 * sumsq - sum * sum < vth))
+            {
+                const int ix = ((int)c[x + 1] - (int)c[x - 1]) >> sh;
+                const int iy = max(max(iabs16((int)p[x] - (int)n[x]), iabs16((int)p[x] - (int)c[x])), iabs16((int)c[x] - (int)n[x])) >> sh;
+                if (ix * ix + iy * iy >= mth) set = true;
+                else
+                {
+                    const int ixx = ((int)c[x - 1] - 2 * (int)c[x] + (int)c[x + 1]) >> sh;
+                    const int iyy = ((int)p[x] - 2 * (int)c[x] + (int)n[x]) >> sh;
+                    set = iabs16(ixx) + iabs16(iyy) >= lth;
+                }
+            }
+        }
+    }
+    uint16_t *o = P.c[pl] + (size_t)y * pitch + x;
+    if (set) *o = (uint16_t)k.peak;
+    else if (y < height / 2) *o = 0;
+}
+
+__device__ __forceinline__ int peaks_around16(const uint16_t *p, const uint16_t *c, const uint16_t *n, int x, int peak)
+{
+    return (p[x - 1] == peak) + (p[x] == peak) + (p[x + 1] == peak) + (c[x - 1] == peak) +
+           (c[x + 1] == peak) + (n[x - 1] == peak) + (n[x] == peak) + (n[x + 1] == peak);
+}
+
+// dilate (:207-247) when grow, erode (:259-293) otherwise: a = mask in, c = out
+__global__ void q_morph(Q3 P, K16 k, int thr, int grow)
+{
+    XY16(P);
+    if (x >= width || y >= height) return;
+    const uint16_t *c = P.a[pl] + (size_t)y * pitch, *p = c - pitch, *n = c + pitch;
+    int v = c[x];
+    if (x >= 1 && x < width - 1 && y >= 1 && y < height - 1)
+    {
+        if (grow) { if (v == 0 && peaks_around16(p, c, n, x, k.peak) >= thr) v = k.peak; }
+        else      { if (v == k.peak && peaks_around16(p, c, n, x, k.peak) < thr) v = 0; }
+    }
+    P.c[pl][(size_t)y * pitch + x] = (uint16_t)v;
+}
+
+// eedi2_remove_small_gaps (:308-342): a = mask in, c = out
+__global__ void q_small_gaps(Q3 P, K16 k)
+{
+    XY16(P);
+    if (x >= width || y >= height) return;
+    const uint16_t *m = P.a[pl] + (size_t)y * pitch;
+    int v = m[x];
+    if (x >= 3 && x < width - 3 && y >= 1 && y < height - 1)
+    {
+        if (m[x])
+        {
+            if (!(m[x - 3] || m[x - 2] || m[x - 1] || m[x + 1] || m[x + 2] || m[x + 3])) v = 0;
+        }
+        else if ((m[x + 1] && (m[x - 1] || m[x - 2] || m[x - 3])) || (m[x + 2] && (m[x - 1] || m[x - 2])) || (m[x + 3] && m[x - 1]))
+            v = k.peak;
+    }
+    P.c[pl][(size_t)y * pitch + x] = (uint16_t)v;
+}
+
+// eedi2_calc_directions (:358-525): a = mskp, b = srcp, c = out (whole pitch pre-filled with PEAK)
+__global__ void q_calc_dir(Q3 P, K16 k, int maxd, int nt)
+{
+    XY16(P);
+    if (x >= pitch || y >= height) return;
+    const int peak = k.peak;
+    int out = peak;
+    const uint16_t *mc = P.a[pl] + (size_t)y * pitch, *mp = mc - pitch, *mn = mc + pitch;
+    if (x >= 1 && x < width - 1 && y >= 1 && y < height - 1 && mc[x] == peak && (mc[x - 1] == peak || mc[x + 1] == peak))
+    {
+        const uint16_t *sc = P.b[pl] + (size_t)y * pitch, *sp = sc - pitch, *s2p = sp - pitch, *sn = sc + pitch, *s2n = sn + pitch;
+        const int nt13 = (uint16_t)((nt << k.shift) * 13), nt19 = (uint16_t)((nt << k.shift) * 19);
+        const int maxdt = pl == 0 ? maxd : (maxd >> 1);
+        const int startu = max(-x + 1, -maxdt), stopu = min(width - 2 - x, maxdt);
+        const int vert = iabs16((int)sc[x] - (int)sn[x]) + iabs16((int)sc[x] - (int)sp[x]);
+        int minb = min(nt13, vert * 6), mina = min(nt19, vert * 9);
+        int minc = mina, mind = minb, mine = minb;
+        int dira = -5000, dirb = -5000, dirc = -5000, dird = -5000, dire = -5000;
+        for (int u = startu; u <= stopu; u++)
+        {
+            if (!(y == 1 || mp[x - 1 + u] == peak || mp[x + u] == peak || mp[x + 1 + u] == peak)) continue;
+            if (!(y == height - 2 || mn[x - 1 - u] == peak || mn[x - u] == peak || mn[x + 1 - u] == peak)) continue;
+            const int diffsn = sad3w(sc, x, sn, x - u);
+            const int diffsp = sad3w(sc, x, sp, x + u);
+            const int diffps = sad3w(sp, x, sc, x - u);
+            const int diffns = sad3w(sn, x, sc, x + u);
+            const int diff = diffsn + diffsp + diffps + diffns;
+            int diffd = diffsp + diffns, diffe = diffsn + diffps;
+            if (diff < minb) { dirb = u; minb = diff; }
+            if (y > 1)
+            {
+                const int diff2pp = sad3w(s2p, x, sp, x - u);
+                const int diffp2p = sad3w(sp, x, s2p, x + u);
+                const int diffa = diff + diff2pp + diffp2p;
+                diffd += diffp2p;
+                diffe += diff2pp;
+                if (diffa < mina) { dira = u; mina = diffa; }
+            }
+            if (y < height - 2)
+            {
+                const int diff2nn = sad3w(s2n, x, sn, x + u);
+                const int diffn2n = sad3w(sn, x, s2n, x - u);
+                const int diffc = diff + diff2nn + diffn2n;
+                diffd += diff2nn;
+                diffe += diffn2n;
+                if (diffc < minc) { dirc = u; minc = diffc; }
+            }
+            if (diffd < mind) { dird = u; mind = diffd; }
+            if (diffe < mine) { dire = u; mine = diffe; }
+        }
+        int order[5], n = 0;
+        if (dira != -5000) order[n++] = dira;
+        if (dirb != -5000) order[n++] = dirb;
+        if (dirc != -5000) order[n++] = dirc;
+        if (dird != -5000) order[n++] = dird;
+        if (dire != -5000) order[n++] = dire;
+        out = k.neutral;
+        if (n > 1)
+        {
+            const int mid = sorted_mid16(order, n);
+            const int tlim = max(k.limlut[iabs16(mid)] >> 2, 2);
+            int sum = 0, count = 0;
+            for (int i = 0; i < n; i++)
+                if (iabs16(order[i] - mid) <= tlim) { count++; sum += order[i]; }
+            if (count > 1) out = (uint16_t)(k.neutral + ((int)((float)sum / (float)count) << (2 + k.shift)));
+        }
+    }
+    P.c[pl][(size_t)y * pitch + x] = (uint16_t)out;
+}
+
+// filter_dir_map (:649-709) / expand_dir_map (:722-773) and, with step 2, the _2x forms (:872-1011).
+// a = mask, b = direction map in, c = out.  step 1: rows 1..height-2 looking at rows y+-1 and mask row y;
+// step 2: rows y0, y0+2, ... looking at rows y+-2 and mask rows y-1 / y+1.
+__global__ void q_dir_map(Q3 P, K16 k, int step, int y0, int expand)
+{
+    XY16(P);
+    if (x >= width || y >= height) return;
+    const int peak = k.peak;
+    const uint16_t *dc = P.b[pl] + (size_t)y * pitch;
+    int v = dc[x];
+    const bool row_on = step == 1 ? (y >= 1 && y < height - 1) : (y >= y0 && y < height - 1 && ((y - y0) & 1) == 0);
+    if (row_on && x >= 1 && x < width - 1)
+    {
+        bool masked;
+        if (step == 1) masked = P.a[pl][(size_t)y * pitch + x] == peak;
+        else           masked = P.a[pl][(size_t)(y - 1) * pitch + x] == peak || P.a[pl][(size_t)(y + 1) * pitch + x] == peak;
+        if (masked && !(expand && dc[x] != peak))
+        {
+            const uint16_t *dp = dc - (ptrdiff_t)step * pitch, *dn = dc + (ptrdiff_t)step * pitch;
+            int order[9], u = 0;
+            if (step == 1 || y > 1) u = collect16(order, u, dp, x, false, peak);
+            u = collect16(order, u, dc, x, expand != 0, peak);
+            if (step == 1 || y < height - 2) u = collect16(order, u, dn, x, false, peak);
+            if (u < (expand ? 5 : 4))
+            {
+                if (!expand) v = peak;
+            }
+            else
+            {
+                const int mid = sorted_mid16(order, u);
+                int count;
+                const int val = vote16(order, u, mid, k.limlut[iabs16(mid - k.neutral) >> (2 + k.shift)], count);
+                if (expand) { if (count >= 5) v = val; }
+                else if (count < 4 || (count < 5 && dc[x] == peak)) v = peak;
+                else v = val;
+            }
+        }
+    }
+    P.c[pl][(size_t)y * pitch + x] = (uint16_t)v;
+}
+
+__device__ __forceinline__ bool trips16(const uint16_t *side, const uint16_t *dc, int x, int from, int to, int lim, int peak)
+{
+    for (int j = from; j <= to; j++)
+    {
+        const int s = side[x + j], c = dc[x + j], ref = dc[x];
+        if ((iabs16(s - ref) > lim && s != peak) || (s == peak && c == peak) || (iabs16(c - ref) > lim && c != peak)) return true;
+    }
+    return false;
+}
+
+// eedi2_filter_map (:538-635): a = mask, b = direction map in, c = out
+__global__ void q_filter_map(Q3 P, K16 k)
+{
+    XY16(P);
+    if (x >= width || y >= height) return;
+    const int peak = k.peak;
+    const uint16_t *dc = P.b[pl] + (size_t)y * pitch;
+    int v = dc[x];
+    if (x >= 1 && x < width - 1 && y >= 1 && y < height - 1 && dc[x] != peak && P.a[pl][(size_t)y * pitch + x] == peak)
+    {
+        const uint16_t *dp = dc - pitch, *dn = dc + pitch;
+        int dir = ((int)dc[x] - k.neutral) >> 2;
+        const int lim = max(iabs16(dir) * 2, 12 << (2 + k.shift));
+        dir >>= 2 + k.shift;
+        bool ict;
+        if (dir < 0) ict = trips16(dp, dc, x, max(-x, dir), 0, lim, peak);
+        else         ict = trips16(dp, dc, x, 0, min(width - x - 1, dir), lim, peak);
+        if (ict)
+        {
+            bool icb;
+            if (dir < 0) icb = trips16(dn, dc, x, 0, min(width - x - 1, iabs16(dir)), lim, peak);
+            else         icb = trips16(dn, dc, x, max(-x, -dir), 0, lim, peak);
+            if (icb) v = peak;
+        }
+    }
+    P.c[pl][(size_t)y * pitch + x] = (uint16_t)v;
+}
+
+// eedi2_upscale_by_2 (:98-108): whole pitch; a = half-height in, c = full-height out (height = half height)
+__global__ void q_upscale(Q3 P)
+{
+    XY16(P);
+    if (x >= pitch || y >= height) return;
+    const uint16_t v = P.a[pl][(size_t)y * pitch + x];
+    P.c[pl][(size_t)(2 * y) * pitch + x] = v;
+    P.c[pl][(size_t)(2 * y + 1) * pitch + x] = v;
+}
+
+// eedi2_mark_directions_2x (:787-858): a = msk2p, b = tmp2p2 (direction map), c = out (pre-filled PEAK, whole pitch)
+__global__ void q_mark_2x(Q3 P, K16 k, int y0)
+{
+    XY16(P);
+    if (x >= pitch || y >= height) return;
+    const int peak = k.peak;
+    int v = peak;
+    if (x >= 1 && x < width - 1 && y >= y0 && y < height - 1 && ((y - y0) & 1) == 0)
+    {
+        const uint16_t *d0 = P.b[pl] + (size_t)(y - 1) * pitch, *d1 = d0 + 2 * (size_t)pitch;
+        const uint16_t *m0 = P.a[pl] + (size_t)(y - 1) * pitch, *m1 = m0 + 2 * (size_t)pitch;
+        if (m0[x] == peak || m1[x] == peak)
+        {
+            int order[6], n = 0;
+            n = collect16(order, n, d0, x, false, peak);
+            n = collect16(order, n, d1, x, false, peak);
+            if (n >= 3)
+            {
+                const int mid = sorted_mid16(order, n);
+                const int lim = k.limlut[iabs16(mid - k.neutral) >> (2 + k.shift)];
+                int u = 0;
+                if (iabs16((int)d0[x - 1] - (int)d1[x - 1]) <= lim || d0[x - 1] == peak || d1[x - 1] == peak) u++;
+                if (iabs16((int)d0[x] - (int)d1[x]) <= lim || d0[x] == peak || d1[x] == peak) u++;
+                if (iabs16((int)d0[x + 1] - (int)d1[x - 1]) <= lim || d0[x + 1] == peak || d1[x + 1] == peak) u++;   // sic (:835)
+                if (u >= 2)
+                {
+                    int count;
+                    const int val = vote16(order, n, mid, lim, count);
+                    if (!(count < n - 2 || count < 2)) v = val;
+                }
+            }
+        }
+    }
+    P.c[pl][(size_t)y * pitch + x] = (uint16_t)v;
+}
+
+// eedi2_fill_gaps_2x (:1025-1132): a = msk2p, b = direction map in, c = out.  Launched after a copy
+// of b into c; a thread whose sample opens a fillable gap writes the whole span (every thread of the
+// same gap computes and writes the same values).
+__global__ void q_fill_gaps(Q3 P, K16 k, int y0)
+{
+    XY16(P);
+    if (x < 1 || x >= width - 1 || y < y0 || y >= height - 1 || ((y - y0) & 1)) return;
+    const int peak = k.peak;
+    const uint16_t *dc = P.b[pl] + (size_t)y * pitch;
+    const uint16_t *dp = dc - 2 * (ptrdiff_t)pitch, *dn = dc + 2 * (ptrdiff_t)pitch;
+    const uint16_t *mc = P.a[pl] + (size_t)(y - 1) * pitch;
+    const uint16_t *mp = mc - 2 * (ptrdiff_t)pitch, *mn = mc + 2 * (ptrdiff_t)pitch, *mnn = mn + 2 * (ptrdiff_t)pitch;
+    if (dc[x] != peak || (mc[x] != peak && mn[x] != peak)) return;
+    const int eight = 8 << k.shift, twenty = 20 << k.shift, five_hundred = 500 << k.shift;
+    int u = x - 1, back = five_hundred, forward = -five_hundred;
+    while (u)
+    {
+        if (dc[u] != peak) { back = dc[u]; break; }
+        if (mc[u] != peak && mn[u] != peak) break;
+        u--;
+    }
+    int v = x + 1;
+    while (v < width)
+    {
+        if (dc[v] != peak) { forward = dc[v]; break; }
+        if (mc[v] != peak && mn[v] != peak) break;
+        v++;
+    }
+    int tc = 1, bc = 1, mint = five_hundred, maxt = -twenty, minb = five_hundred, maxb = -twenty;
+    for (int j = u; j <= v; j++)
+    {
+        if (tc)
+        {
+            if (y <= 2 || dp[j] == peak || (mp[j] != peak && mc[j] != peak)) { tc = 0; mint = maxt = twenty; }
+            else { if (dp[j] < mint) mint = dp[j]; if (dp[j] > maxt) maxt = dp[j]; }
+        }
+        if (bc)
+        {
+            if (y >= height - 3 || dn[j] == peak || (mn[j] != peak && mnn[j] != peak)) { bc = 0; minb = maxb = twenty; }
+            else { if (dn[j] < minb) minb = dn[j]; if (dn[j] > maxb) maxb = dn[j]; }
+        }
+    }
+    if (maxt == -twenty) maxt = mint = twenty;
+    if (maxb == -twenty) maxb = minb = twenty;
+    const int far = max(iabs16(forward - k.neutral), iabs16(back - k.neutral));
+    const int thresh = max(max(far >> 2, eight), max(iabs16(mint - maxt), iabs16(minb - maxb)));
+    const int flim = min(far >> (2 + k.shift), 6);
+    if (iabs16(forward - back) <= thresh && (v - u - 1 <= flim || tc || bc))
+    {
+        const double step = (double)(forward - back) / (double)(v - u);
+        uint16_t *o = P.c[pl] + (size_t)y * pitch;
+        for (int j = 0; j < v - u - 1; j++)
+            o[u + j + 1] = (uint16_t)(back + (int)(j * step + 0.5));
+    }
+}
+
+// plain copy of the visible width (eedi2_bit_blit :46-68): a = in, c = out
+__global__ void q_blit(Q3 P)
+{
+    XY16(P);
+    if (x >= width || y >= height) return;
+    P.c[pl][(size_t)y * pitch + x] = P.a[pl][(size_t)y * pitch + x];
+}
+
+// eedi2_interpolate_lattice (:1148-1335), in place: a = tmp2p (direction map, rewritten), b = dst2p
+// (rewritten on the interpolated rows), c = tmp2p2.  The test at x looks at the direction just
+// written at x-1, so a row is walked left to right by one thread; rows are independent.
+__global__ void q_lattice(Q3 P, K16 k, int field, int nt)
+{
+    const int pl = blockIdx.z;
+    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nrows = (height - 1 - (2 - field) + 1) / 2;                 // rows 2-field, 4-field, ... < height-1
+    uint16_t *dstp = P.b[pl];
+    if (r == nrows)                                                       // the one-row blit (:1162-1179)
+    {
+        for (int xx = 0; xx < width; xx++)
+        {
+            if (field == 1) dstp[(size_t)(height - 1) * pitch + xx] = dstp[(size_t)(height - 2) * pitch + xx];
+            else            dstp[xx] = dstp[pitch + xx];
+        }
+        return;
+    }
+    if (r > nrows) return;
+    const int y = (2 - field) + 2 * r;
+    if (y >= height - 1) return;
+    const int peak = k.peak, neutral = k.neutral, sh = k.shift, sh2 = 2 + k.shift;
+    const int nt4 = (uint16_t)((nt << sh) * 4), nt7 = (uint16_t)((nt << sh) * 7), nt8 = (uint16_t)((nt << sh) * 8);
+    const int three = 3 << sh, nine = 9 << sh;
+    uint16_t *top = dstp + (size_t)(y - 1) * pitch, *mid = top + pitch, *bot = mid + pitch;
+    const uint16_t *ot = P.c[pl] + (size_t)(y - 1) * pitch, *ob = ot + 2 * (size_t)pitch;
+    uint16_t *dm = P.a[pl] + (size_t)y * pitch;
+    for (int x = 0; x < width; x++)
+    {
+        int dir = dm[x];
+        const int lim = k.limlut[iabs16(dir - neutral) >> sh2];
+        const int avg = ((int)top[x] + (int)bot[x] + 1) >> 1;
+        if (dir == peak || (iabs16((int)dm[x] - (int)dm[x - 1]) > lim && iabs16((int)dm[x] - (int)dm[x + 1]) > lim))
+        {
+            mid[x] = (uint16_t)avg;
+            if (dir != peak) dm[x] = (uint16_t)neutral;
+            continue;
+        }
+        if (lim < nine)
+        {
+            const int sum = ((int)top[x - 1] + (int)top[x] + (int)top[x + 1] + (int)bot[x - 1] + (int)bot[x] + (int)bot[x + 1]) >> sh;
+            auto sq = [&](int v) { return (v >> sh) * (v >> sh); };
+            const int sumsq = sq(top[x - 1]) + sq(top[x]) + sq(top[x + 1]) + sq(bot[x - 1]) + sq(bot[x]) + sq(bot[x + 1]);
+            if (6 * sumsq - sum * sum < 576)
+            {
+                mid[x] = (uint16_t)avg;
+                dm[x] = (uint16_t)peak;
+                continue;
+            }
+        }
+        if (x > 1 && x < width - 2 &&
+            (((int)top[x] < max((int)top[x - 2], (int)top[x - 1]) - three && (int)top[x] < max((int)top[x + 2], (int)top[x + 1]) - three &&
+              (int)bot[x] < max((int)bot[x - 2], (int)bot[x - 1]) - three && (int)bot[x] < max((int)bot[x + 2], (int)bot[x + 1]) - three) ||
+             ((int)top[x] > min((int)top[x - 2], (int)top[x - 1]) + three && (int)top[x] > min((int)top[x + 2], (int)top[x + 1]) + three &&
+              (int)bot[x] > min((int)bot[x - 2], (int)bot[x - 1]) + three && (int)bot[x] > min((int)bot[x + 2], (int)bot[x + 1]) + three)))
+        {
+            mid[x] = (uint16_t)avg;
+            dm[x] = (uint16_t)neutral;
+            continue;
+        }
+        dir = (dir - neutral + (1 << (sh2 - 1))) >> sh2;
+        int val = avg;
+        const int startu = (dir - 2 < 0) ? max(-x + 1, max(dir - 2, -width + 2 + x)) : min(x - 1, min(dir - 2, width - 2 - x));
+        const int stopu = (dir + 2 < 0) ? max(-x + 1, max(dir + 2, -width + 2 + x)) : min(x - 1, min(dir + 2, width - 2 - x));
+        int mn = nt8;
+        const int here = dm[x];
+        auto near = [&](const uint16_t *row, int i) { return row[i] != peak && iabs16((int)row[i] - here) <= lim; };
+        for (int u = startu; u <= stopu; u++)
+        {
+            const int diff = sad3w(top, x, bot, x - u) + sad3w(bot, x, top, x + u);
+            if (!(diff < mn && (near(ot, x - 1 + u) || near(ot, x + u) || near(ot, x + 1 + u)) &&
+                  (near(ob, x - 1 - u) || near(ob, x - u) || near(ob, x + 1 - u))))
+                continue;
+            const int h0 = u >> 1, h1 = (u + 1) >> 1;
+            const int diff2 = sad3w(top, x + h0, bot, x - h0);
+            if (!(diff2 < nt4 &&
+                  (((iabs16((int)ot[x + h0] - (int)ob[x - h0]) <= lim || iabs16((int)ot[x + h0] - (int)ob[x - h1]) <= lim) && ot[x + h0] != peak) ||
+                   ((iabs16((int)ot[x + h1] - (int)ob[x - h0]) <= lim || iabs16((int)ot[x + h1] - (int)ob[x - h1]) <= lim) && ot[x + h1] != peak))))
+                continue;
+            if ((iabs16(here - (int)ot[x + h0]) <= lim || iabs16(here - (int)ot[x + h1]) <= lim) &&
+                (iabs16(here - (int)ob[x - h0]) <= lim || iabs16(here - (int)ob[x - h1]) <= lim))
+            {
+                val = ((int)top[x + h0] + (int)top[x + h1] + (int)bot[x - h0] + (int)bot[x - h1] + 2) >> 2;
+                mn = diff;
+                dir = u;
+            }
+        }
+        if (mn != nt8)
+        {
+            mid[x] = (uint16_t)val;
+            dm[x] = (uint16_t)(neutral + (dir << sh2));
+            continue;
+        }
+        const int lo = min((int)top[x], (int)bot[x]), hi = max((int)top[x], (int)bot[x]);
+        const int d = pl == 0 ? 4 : 2;
+        const int su = max(-x + 1, -d), eu = min(width - 2 - x, d);
+        mn = nt7;
+        for (int u = su; u <= eu; u++)
+        {
+            const int h0 = u >> 1, h1 = (u + 1) >> 1;
+            const int p1 = (int)top[x + h0] + (int)top[x + h1];
+            const int p2 = (int)bot[x - h0] + (int)bot[x - h1];
+            const int diff = sad3w(top, x, bot, x - u) + sad3w(bot, x, top, x + u) + iabs16(p1 - p2);
+            if (diff < mn)
+            {
+                const int valt = (p1 + p2 + 2) >> 2;
+                if (valt >= lo && valt <= hi) { val = valt; mn = diff; dir = u; }
+            }
+        }
+        mid[x] = (uint16_t)val;
+        dm[x] = (mn == 7 * nt) ? (uint16_t)neutral : (uint16_t)(neutral + (dir << sh2));      // unshifted 7*nt (:1324)
+    }
+}
+
+// eedi2_post_process (:1349-1378): a = new direction map, b = old one, c = dst2p (in place, rows y from y+-1)
+__global__ void q_post(Q3 P, K16 k, int y0)
+{
+    XY16(P);
+    if (x >= width || y < y0 || y >= height - 1 || ((y - y0) & 1)) return;
+    const size_t at = (size_t)y * pitch + x;
+    const int nm = P.a[pl][at], om = P.b[pl][at];
+    const int lim = k.limlut[iabs16(nm - k.neutral) >> (2 + k.shift)];
+    if (iabs16(nm - om) > lim && om != k.peak && om != k.neutral)
+    {
+        uint16_t *d = P.c[pl] + at;
+        *d = (uint16_t)(((int)d[-pitch] + (int)d[pitch] + 1) >> 1);
+    }
+}
+
+// ---- post-processing 2/3 (:1391-1904), as in eedi2.hip but on uint16 samples -----------------------
+struct Corner16
+{
+    uint16_t *src, *tmp;
+    int      *c[3], *t[3];
+    int       pitch, width, height;
+};
+
+__device__ __forceinline__ int fold16(int centre, int d, int n, int &hi)
+{
+    int lo = centre - d;
+    hi = centre + d;
+    if (lo < 0) lo = hi;
+    if (hi >= n) hi = lo;
+    return lo;
+}
+
+template <bool VERT>
+__global__ void q_blur1(Corner16 A)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= A.width || y >= A.height) return;
+    const uint16_t *in = VERT ? A.tmp : A.src;
+    uint16_t *out = VERT ? A.src : A.tmp;
+    const int W[4] = { 26152, 15862, 3539, 291 };
+    int acc = (int)in[(size_t)y * A.pitch + x] * W[0] + 32768;
+#pragma unroll
+    for (int d = 1; d <= 3; d++)
+    {
+        int hi;
+        const int lo = fold16(VERT ? y : x, d, VERT ? A.height : A.width, hi);
+        const size_t il = VERT ? (size_t)lo * A.pitch + x : (size_t)y * A.pitch + lo;
+        const size_t ih = VERT ? (size_t)hi * A.pitch + x : (size_t)y * A.pitch + hi;
+        acc += ((int)in[il] + (int)in[ih]) * W[d];
+    }
+    out[(size_t)y * A.pitch + x] = (uint16_t)(acc >> 16);
+}
+
+__global__ void q_derivatives(Corner16 A, int shift)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= A.width || y >= A.height) return;
+    const uint16_t *s = A.src + (size_t)y * A.pitch;
+    const uint16_t *up = A.src + (size_t)max(y - 1, 0) * A.pitch, *dn = A.src + (size_t)min(y + 1, A.height - 1) * A.pitch;
+    const int ix = ((int)s[min(x + 1, A.width - 1)] - (int)s[max(x - 1, 0)]) >> shift;
+    const int iy = ((int)up[x] - (int)dn[x]) >> shift;
+    const size_t at = (size_t)y * A.pitch + x;
+    A.c[0][at] = (ix * ix) >> 1;
+    A.c[1][at] = (iy * iy) >> 1;
+    A.c[2][at] = (ix * iy) >> 1;
+}
+
+template <bool VERT>
+__global__ void q_blur_sqrt2(Corner16 A)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= A.width || y >= A.height) return;
+    const int *in = VERT ? A.t[blockIdx.z] : A.c[blockIdx.z];
+    int *out = VERT ? A.c[blockIdx.z] : A.t[blockIdx.z];
+    const int W[5] = { 18508, 14415, 6809, 1951, 339 };
+    int acc = in[(size_t)y * A.pitch + x] * W[0] + 32768;
+#pragma unroll
+    for (int d = 1; d <= 4; d++)
+    {
+        int hi;
+        int lo = fold16(VERT ? y : x, d, VERT ? A.height : A.width, hi);
+        if (!VERT && d == 3 && x == A.width - 2) lo = hi = x + 3;                  // :1589
+        const size_t il = VERT ? (size_t)lo * A.pitch + x : (size_t)y * A.pitch + lo;
+        const size_t ih = VERT ? (size_t)hi * A.pitch + x : (size_t)y * A.pitch + hi;
+        acc += (in[il] + in[ih]) * W[d];
+    }
+    out[(size_t)y * A.pitch + x] = acc >> (VERT ? 18 : 16);
+}
+
+__global__ void q_post_corner(Corner16 A, const uint16_t *msk, uint16_t *dst, int field, int height, int peak, int neutral)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y * blockDim.y + threadIdx.y;
+    const int y = 8 - field + 2 * r;
+    if (x < 4 || x >= A.width - 4 || y >= height - 7) return;
+    const size_t at = (size_t)y * A.pitch + x;
+    const int m = msk[at];
+    if (m == peak || m == neutral) return;
+    bool hit = false;
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+    {
+        const size_t i = (size_t)(3 + r + q) * A.pitch + x;
+        const int a = A.c[0][i], b = A.c[1][i], c = A.c[2][i];
+        const double s = (double)(a + b);
+        const double resp = (double)(a * b - c * c) - 0.09 * s * s;
+        hit |= (int)resp > 775;
+    }
+    if (hit) dst[at] = (uint16_t)(((int)dst[at - A.pitch] + (int)dst[at + A.pitch] + 1) >> 1);
+}
+
+} // namespace
+
+// ------------------------------------------------------------------- engine
+Eedi2Engine16::Eedi2Engine16(hbhip_ctx *ctx, const PicGeometry &geo, const Eedi2Params &p) : ctx_(ctx), geo_(geo), par_(p) {}
+
+Eedi2Engine16::~Eedi2Engine16()
+{
+    for (auto &f : half_) if (f.alloc) (void)hipFree(f.alloc);
+    for (auto &f : full_) if (f.alloc) (void)hipFree(f.alloc);
+    for (int i = 0; i < 3; i++)
+    {
+        if (deriv_[i]) (void)hipFree(deriv_[i]);
+        if (deriv_tmp_[i]) (void)hipFree(deriv_tmp_[i]);
+    }
+}
+
+int Eedi2Engine16::alloc_frame(EediFrame &f, int width, int height)
+{
+    size_t off[3], total = 0;                                       // in samples
+    for (int c = 0; c < 3; c++)
+    {
+        f.width[c] = c ? -((-width) >> geo_.log2_cw) : width;
+        f.height[c] = c ? -((-height) >> geo_.log2_ch) : height;
+        f.stride[c] = hbhip_align_up(f.width[c] * 2, 64);           // hb_image_stride of a 16-bit plane, bytes
+        off[c] = total;
+        total += (size_t)(f.stride[c] / 2) * f.height[c];
+    }
+    f.bytes = 2 * (total + 2 * GUARD16);
+    HBHIP_CHECK(ctx_, hipMalloc((void **)&f.alloc, f.bytes));
+    HBHIP_CHECK(ctx_, hipMemsetAsync(f.alloc, 0, f.bytes, ctx_->stream));
+    f.base = f.alloc + 2 * GUARD16;
+    for (int c = 0; c < 3; c++) f.plane[c] = f.base + 2 * off[c];
+    return HBHIP_OK;
+}
+
+int Eedi2Engine16::init()
+{
+    if (geo_.bps != 2 || geo_.depth < 9 || geo_.depth > 16) return HBHIP_ERR_UNSUPPORTED;
+    if (geo_.height % (2 << geo_.log2_ch) != 0 || geo_.height < 16 || geo_.width < 16) return HBHIP_ERR_UNSUPPORTED;
+    if (par_.post_processing < 0 || par_.post_processing > 3) return HBHIP_ERR_UNSUPPORTED;
+    for (auto &f : half_) { int rc = alloc_frame(f, geo_.width, geo_.height / 2); if (rc != HBHIP_OK) return rc; }
+    for (auto &f : full_) { int rc = alloc_frame(f, geo_.width, geo_.height); if (rc != HBHIP_OK) return rc; }
+    if (par_.post_processing > 1)
+    {
+        const size_t n = sizeof(int) * (size_t)geo_.height * full_[0].stride[0];     // decomb.c:398-403 sizes them by the byte stride
+        for (int i = 0; i < 3; i++)
+        {
+            HBHIP_CHECK(ctx_, hipMalloc((void **)&deriv_[i], n));
+            HBHIP_CHECK(ctx_, hipMemsetAsync(deriv_[i], 0, n, ctx_->stream));
+            HBHIP_CHECK(ctx_, hipMalloc((void **)&deriv_tmp_[i], n));
+            HBHIP_CHECK(ctx_, hipMemsetAsync(deriv_tmp_[i], 0, n, ctx_->stream));
+        }
+    }
+    HBHIP_CHECK(ctx_, hipStreamSynchronize(ctx_->stream));
+    return HBHIP_OK;
+}
+
+int Eedi2Engine16::run(const DevPicture *cur, int tff)
+{
+    EediFrame &srcp = half_[0], &mskp = half_[1], &tmpp = half_[2], &dstp = half_[3];
+    EediFrame &dst2p = full_[0], &tmp2p2 = full_[1], &msk2p = full_[2], &tmp2p = full_[3], &dst2mp = full_[4];
+    K16 k;
+    k.shift = geo_.depth - 8;
+    k.peak = (1 << geo_.depth) - 1;
+    k.neutral = 1 << (geo_.depth - 1);
+    static const int base[33] = { 6, 6, 7, 7, 8, 8, 9, 9, 9, 10, 10, 11, 11, 12, 12, 12, 12, 12, 12, 12,
+                                  12, 12, 12, 12, 12, 12, 12, 12, 12, 12, 12, -1, -1 };        // eedi2.c:21-25
+    for (int i = 0; i < 33; i++) k.limlut[i] = (uint16_t)((uint16_t)base[i] << k.shift);
+
+    const dim3 blk(64, 4);
+    auto geom = [&](Q3 &P, const EediFrame &f) {
+        for (int c = 0; c < 3; c++) { P.pitch[c] = f.stride[c] / 2; P.width[c] = f.width[c]; P.height[c] = f.height[c]; }
+    };
+    auto bind = [&](uint16_t *(&slot)[3], const EediFrame &f) { for (int c = 0; c < 3; c++) slot[c] = (uint16_t *)f.plane[c]; };
+    auto grid = [&](const EediFrame &f, bool whole_pitch) {
+        const int w = whole_pitch ? f.stride[0] / 2 : f.width[0];
+        return dim3((w + 63) / 64, (f.height[0] + 3) / 4, 3);
+    };
+    Q3 P;
+    memset(&P, 0, sizeof(P));
+
+    // field extraction (decomb_template.c:455-473)
+    geom(P, srcp);
+    for (int c = 0; c < 3; c++) P.a[c] = (uint16_t *)cur->plane[c];
+    bind(P.b, srcp);
+    {
+        int rows[3];
+        for (int c = 0; c < 3; c++) rows[c] = (dst2p.height[c] + 1) / 2;
+        HBHIP_LAUNCH(ctx_, "eedi2_16_fill_half", q_fill_half, grid(srcp, true), blk, 0, P,
+                     cur->pitch[0] / 2, cur->pitch[1] / 2, cur->pitch[2] / 2, !tff, rows[0], rows[1], rows[2]);
+    }
+    // half-height passes (decomb_template.c:390-404)
+    bind(P.a, srcp); bind(P.c, mskp);
+    HBHIP_LAUNCH(ctx_, "eedi2_16_edge_mask", q_edge_mask, grid(srcp, true), blk, 0, P, k,
+                 par_.magnitude_threshold * 10, par_.laplacian_threshold * 81, par_.variance_threshold);
+    bind(P.a, mskp); bind(P.c, tmpp);
+    HBHIP_LAUNCH(ctx_, "eedi2_16_erode", q_morph, grid(srcp, false), blk, 0, P, k, par_.erosion_threshold, 0);
+    bind(P.a, tmpp); bind(P.c, mskp);
+    HBHIP_LAUNCH(ctx_, "eedi2_16_dilate", q_morph, grid(srcp, false), blk, 0, P, k, par_.dilation_threshold, 1);
+    bind(P.a, mskp); bind(P.c, tmpp);
+    HBHIP_LAUNCH(ctx_, "eedi2_16_erode", q_morph, grid(srcp, false), blk, 0, P, k, par_.erosion_threshold, 0);
+    bind(P.a, tmpp); bind(P.c, mskp);
+    HBHIP_LAUNCH(ctx_, "eedi2_16_small_gaps", q_small_gaps, grid(srcp, false), blk, 0, P, k);
+    bind(P.a, mskp); bind(P.b, srcp); bind(P.c, tmpp);
+    HBHIP_LAUNCH(ctx_, "eedi2_16_calc_directions", q_calc_dir, grid(srcp, true), blk, 0, P, k, par_.maximum_search_distance, par_.noise_threshold);
+    bind(P.a, mskp); bind(P.b, tmpp); bind(P.c, dstp);
+    HBHIP_LAUNCH(ctx_, "eedi2_16_filter_dir_map", q_dir_map, grid(srcp, false), blk, 0, P, k, 1, 1, 0);
+    bind(P.a, mskp); bind(P.b, dstp); bind(P.c, tmpp);
+    HBHIP_LAUNCH(ctx_, "eedi2_16_expand_dir_map", q_dir_map, grid(srcp, false), blk, 0, P, k, 1, 1, 1);
+    bind(P.a, mskp); bind(P.b, tmpp); bind(P.c, dstp);
+    HBHIP_LAUNCH(ctx_, "eedi2_16_filter_map", q_filter_map, grid(srcp, false), blk, 0, P, k);
+    // line doubling
+    bind(P.a, srcp); bind(P.c, dst2p);
+    HBHIP_LAUNCH(ctx_, "eedi2_16_upscale", q_upscale, grid(srcp, true), blk, 0, P);
+    bind(P.a, dstp); bind(P.c, tmp2p2);
+    HBHIP_LAUNCH(ctx_, "eedi2_16_upscale", q_upscale, grid(srcp, true), blk, 0, P);
+    bind(P.a, mskp); bind(P.c, msk2p);
+    HBHIP_LAUNCH(ctx_, "eedi2_16_upscale", q_upscale, grid(srcp, true), blk, 0, P);
+    // full-height passes
+    geom(P, dst2p);
+    const int y0 = 2 - tff;
+    bind(P.a, msk2p); bind(P.b, tmp2p2); bind(P.c, tmp2p);
+    HBHIP_LAUNCH(ctx_, "eedi2_16_mark_directions_2x", q_mark_2x, grid(dst2p, true), blk, 0, P, k, y0);
+    bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
+    HBHIP_LAUNCH(ctx_, "eedi2_16_filter_dir_map_2x", q_dir_map, grid(dst2p, false), blk, 0, P, k, 2, y0, 0);
+    bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
+    HBHIP_LAUNCH(ctx_, "eedi2_16_expand_dir_map_2x", q_dir_map, grid(dst2p, false), blk, 0, P, k, 2, y0, 1);
+    for (int pass = 0; pass < 2; pass++)
+    {
+        const EediFrame &in = pass ? dst2mp : tmp2p, &out = pass ? tmp2p : dst2mp;
+        bind(P.a, in); bind(P.c, out);
+        HBHIP_LAUNCH(ctx_, "eedi2_16_blit", q_blit, grid(dst2p, false), blk, 0, P);
+        bind(P.a, msk2p); bind(P.b, in); bind(P.c, out);
+        HBHIP_LAUNCH(ctx_, "eedi2_16_fill_gaps_2x", q_fill_gaps, grid(dst2p, false), blk, 0, P, k, y0);
+    }
+    bind(P.a, tmp2p); bind(P.b, dst2p); bind(P.c, tmp2p2);
+    {
+        const int nrows = (dst2p.height[0] - 1 - y0 + 1) / 2;
+        HBHIP_LAUNCH(ctx_, "eedi2_16_interpolate_lattice", q_lattice, dim3((nrows + 1 + 63) / 64, 1, 3), dim3(64), 0, P, k, tff,
+                     par_.noise_threshold);
+    }
+    if (par_.post_processing == 1 || par_.post_processing == 3)
+    {
+        bind(P.a, tmp2p); bind(P.c, tmp2p2);
+        HBHIP_LAUNCH(ctx_, "eedi2_16_blit", q_blit, grid(dst2p, false), blk, 0, P);                 // eedi2_bit_blit(tmp2p -> tmp2p2)
+        bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
+        HBHIP_LAUNCH(ctx_, "eedi2_16_filter_dir_map_2x", q_dir_map, grid(dst2p, false), blk, 0, P, k, 2, y0, 0);
+        bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
+        HBHIP_LAUNCH(ctx_, "eedi2_16_expand_dir_map_2x", q_dir_map, grid(dst2p, false), blk, 0, P, k, 2, y0, 1);
+        bind(P.a, tmp2p); bind(P.b, tmp2p2); bind(P.c, dst2p);
+        HBHIP_LAUNCH(ctx_, "eedi2_16_post_process", q_post, grid(dst2p, false), blk, 0, P, k, y0);
+    }
+    if (par_.post_processing == 2 || par_.post_processing == 3)
+    {
+        for (int c = 0; c < 3; c++)                                  // plane after plane, see eedi2.hip (CornerArgs)
+        {
+            Corner16 A;
+            A.src = (uint16_t *)srcp.plane[c]; A.tmp = (uint16_t *)tmpp.plane[c];
+            for (int i = 0; i < 3; i++) { A.c[i] = deriv_[i]; A.t[i] = deriv_tmp_[i]; }
+            A.pitch = srcp.stride[c] / 2; A.width = srcp.width[c]; A.height = srcp.height[c];
+            const dim3 g1((A.width + 63) / 64, (A.height + 3) / 4, 1), g3(g1.x, g1.y, 3);
+            HBHIP_LAUNCH(ctx_, "eedi2_16_gaussian_blur1_h", q_blur1<false>, g1, blk, 0, A);
+            HBHIP_LAUNCH(ctx_, "eedi2_16_gaussian_blur1_v", q_blur1<true>, g1, blk, 0, A);
+            HBHIP_LAUNCH(ctx_, "eedi2_16_calc_derivatives", q_derivatives, g1, blk, 0, A, k.shift);
+            HBHIP_LAUNCH(ctx_, "eedi2_16_gaussian_blur_sqrt2_h", q_blur_sqrt2<false>, g3, blk, 0, A);
+            HBHIP_LAUNCH(ctx_, "eedi2_16_gaussian_blur_sqrt2_v", q_blur_sqrt2<true>, g3, blk, 0, A);
+            const int rows = (dst2p.height[c] - 7 - (8 - tff) + 1) / 2;
+            if (rows > 0)
+                HBHIP_LAUNCH(ctx_, "eedi2_16_post_process_corner", q_post_corner, dim3((A.width + 63) / 64, (rows + 3) / 4, 1), blk, 0, A,
+                             (const uint16_t *)tmp2p2.plane[c], (uint16_t *)dst2p.plane[c], tff, dst2p.height[c], k.peak, k.neutral);
+        }
+    }
+    HBHIP_CHECK(ctx_, hipGetLastError());
+    return HBHIP_OK;
+}

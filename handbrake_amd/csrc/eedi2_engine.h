@@ -82,3 +82,28 @@ private:
     int        *deriv_[3] = {nullptr, nullptr, nullptr};       // post-processing 2/3: cx2, cy2, cxy (decomb.c:398-403)
     int        *deriv_tmp_[3] = {nullptr, nullptr, nullptr};   //                      tmpc, one per array
 };
+
+// EEDI2 on 10 / 12-bit samples (eedi2_16.hip): same role as Eedi2Engine, first correct form (one thread
+// per sample and pass, serial lattice rows, no graphs / pairing).  EediFrame strides are in BYTES, the
+// planes hold uint16 samples in the layout hb_frame_buffer_init gives a 16-bit frame.
+class Eedi2Engine16
+{
+public:
+    Eedi2Engine16(hbhip_ctx *ctx, const PicGeometry &geo, const Eedi2Params &p);
+    ~Eedi2Engine16();
+    int  init();
+    int  run(const DevPicture *cur, int tff);
+    const EediFrame &result() const { return full_[0]; }
+    const EediFrame &half(int i) const { return half_[i]; }
+    const EediFrame &full(int i) const { return full_[i]; }
+
+private:
+    int alloc_frame(EediFrame &f, int width, int height);
+    hbhip_ctx  *ctx_;
+    PicGeometry geo_;
+    Eedi2Params par_;
+    EediFrame   half_[4];    // SRCPF, MSKPF, TMPPF, DSTPF
+    EediFrame   full_[5];    // DST2PF, TMP2PF2, MSK2PF, TMP2PF, DST2MPF
+    int        *deriv_[3] = {nullptr, nullptr, nullptr};
+    int        *deriv_tmp_[3] = {nullptr, nullptr, nullptr};
+};

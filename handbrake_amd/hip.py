@@ -310,7 +310,7 @@ class DecombDevice:
     EEDI2 scratch buffers; the hb_filter_object_t path is hb_filter_decomb_hip)."""
 
     def __init__(self, ctx: Ctx, width, height, mode=8, parity=-1, magnitude=10, variance=20, laplacian=20,
-                 dilation=4, erosion=2, noise=50, search=24, postproc=1):
+                 dilation=4, erosion=2, noise=50, search=24, postproc=1, depth=8):
         L = lib()
         L.hbhip_decomb_create.argtypes = [C.c_void_p, C.POINTER(DecombParams)] + [C.c_int] * 5 + [C.POINTER(C.c_void_p)]
         L.hbhip_decomb_push.argtypes = [C.c_void_p, C.POINTER(HostFrame), C.c_int64, C.c_int, C.c_int]
@@ -318,8 +318,8 @@ class DecombDevice:
                                                     C.POINTER(C.c_int), C.POINTER(C.c_int)]
         par = DecombParams(mode, parity, magnitude, variance, laplacian, dilation, erosion, noise, search, postproc)
         h = C.c_void_p()
-        check(L.hbhip_decomb_create(ctx.h, C.byref(par), width, height, 8, 1, 1, C.byref(h)), ctx.h, "decomb_create")
-        self.ctx, self.h, self.w, self.hgt = ctx, h, width, height
+        check(L.hbhip_decomb_create(ctx.h, C.byref(par), width, height, depth, 1, 1, C.byref(h)), ctx.h, "decomb_create")
+        self.ctx, self.h, self.w, self.hgt, self.depth = ctx, h, width, height, depth
         self.tag = 0
 
     def push(self, planes, flags=0x0008, combed=2):
@@ -334,7 +334,8 @@ class DecombDevice:
         if lib().hbhip_filter_pending(self.h) <= 0:
             return None
         cw, ch = (self.w + 1) // 2, (self.hgt + 1) // 2
-        out = [np.zeros((self.hgt, self.w), np.uint8), np.zeros((ch, cw), np.uint8), np.zeros((ch, cw), np.uint8)]
+        dt = np.uint8 if self.depth == 8 else np.uint16
+        out = [np.zeros((self.hgt, self.w), dt), np.zeros((ch, cw), dt), np.zeros((ch, cw), dt)]
         fr = host_frame(out)
         tag = C.c_int64()
         check(lib().hbhip_filter_pull(self.h, C.byref(fr), C.byref(tag)), self.ctx.h, "pull")
@@ -350,7 +351,7 @@ class DecombDevice:
         a = np.zeros((ht.value, st.value), np.uint8)
         check(lib().hbhip_decomb_debug_eedi_plane(self.h, buffer, plane, a.ctypes.data, st.value, C.byref(st), C.byref(ht)),
               self.ctx.h, "debug_eedi_plane")
-        return a
+        return a if self.depth == 8 else a.view(np.uint16)          # (height, stride in samples)
 
     def close(self):
         if self.h:

@@ -137,13 +137,14 @@ CASES = {
                                           orc=[("nlmeans", [nlm(prefilter=2049, depth=12),
                                                             nlm(origin_tune=0.8, prefilter=1028, depth=12),
                                                             nlm(origin_tune=0.8, prefilter=800, depth=12)])]),
-    # 10 / 12-bit EEDI2: pinned for the oracle (eedi2_16_oracle.c); the HIP EEDI2 passes are 8-bit only
-    # so far (hip=None: the GPU test skips these), the vectors are here for when they are not
+    # 10 / 12-bit EEDI2 (oracle eedi2_16_oracle.c, kernels csrc/eedi2_16.hip)
     "decomb_eedi2_bob_10bit_128x64": dict(model="interlaced", w=128, h=64, n=3, depth=10,
-                                          chain=[("hb_filter_decomb", "mode=31")], hip=None,
+                                          chain=[("hb_filter_decomb", "mode=31")],
+                                          hip=[("hb_filter_decomb_hip", "mode=31")],
                                           orc=[("decomb", dict(mode=31, depth=10))]),
     "decomb_eedi2_cubic_12bit_190x96": dict(model="interlaced", w=190, h=96, n=3, depth=12,
-                                            chain=[("hb_filter_decomb", "mode=15:noise-thresh=30")], hip=None,
+                                            chain=[("hb_filter_decomb", "mode=15:noise-thresh=30")],
+                                            hip=[("hb_filter_decomb_hip", "mode=15:noise-thresh=30")],
                                             orc=[("decomb", dict(mode=15, noise=30, depth=12))]),
     "decomb_eedi2_only_190x96": dict(model="interlaced", w=190, h=96, n=3,
                                      chain=[("hb_filter_decomb", "mode=8")],

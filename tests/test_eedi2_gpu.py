@@ -104,3 +104,46 @@ def test_odd_chroma_height_is_refused(built):
     """The reference overruns its buffers there; the HIP filter must decline (init fails)."""
     with pytest.raises(RuntimeError):
         hbrt.Chain(hip.filters(), [("hb_filter_decomb_hip", "mode=31")], 638, 362)
+
+
+# ---- 10 / 12-bit EEDI2 (csrc/eedi2_16.hip) ----------------------------------------------------------
+@pytest.mark.parametrize("depth", [10, 12])
+@pytest.mark.parametrize("w,h,postproc", [(128, 72, 1), (638, 360, 1), (322, 184, 3), (322, 184, 0), (322, 184, 2)])
+def test_16bit_every_scratch_buffer(built, depth, w, h, postproc):
+    frames = synth.stream("corners" if postproc > 1 else "interlaced", w, h, 3, depth=depth)
+    ctx = hip.Ctx(0)
+    dev = hip.DecombDevice(ctx, w, h, mode=24, postproc=postproc, depth=depth)
+    oe = ol.OrcEedi2_16(w, h, depth, postproc=postproc)
+    try:
+        dev.push(frames[0])
+        for t in range(1, 3):
+            dev.push(frames[t])
+            for tff in (1, 0):
+                oe.run(frames[t - 1], tff)
+            while dev.pull() is not None:
+                pass
+            for b in range(9):
+                for c in range(3):
+                    np.testing.assert_array_equal(dev.eedi_plane(b, c), oe.plane(b, c),
+                                                  err_msg=f"{ol.EEDI2_BUFFERS[b]} plane {c} after frame {t - 1}")
+    finally:
+        oe.close()
+        dev.close()
+        ctx.close()
+
+
+@pytest.mark.parametrize("name", ["decomb_eedi2_bob_10bit_128x64", "decomb_eedi2_cubic_12bit_190x96"])
+def test_16bit_decomb_eedi2_golden(built, name):
+    """The reference-generated 10 / 12-bit vectors through the hb_filter_object_t surface."""
+    import os
+    import golden_cases as gc
+    case = gc.CASES[name]
+    want, meta = os_.load_golden(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    frames = synth.stream(case["model"], case["w"], case["h"], case["n"], depth=case["depth"])
+    got = hbrt.run_stream(hip.filters(), [("hb_filter_decomb_hip", case["chain"][0][1])], frames,
+                          flags=synth.flags_for(case["model"]), pix_fmt=hbrt.PIX_FMT_FOR_DEPTH[case["depth"]])
+    assert len(got) == len(want)
+    for t in range(len(want)):
+        for c in range(3):
+            np.testing.assert_array_equal(got[t].planes[c], want[t][c], err_msg=f"{name} frame {t} plane {c}")
+        assert (got[t].start, got[t].stop) == (int(meta[t][0]), int(meta[t][1]))
