@@ -44,3 +44,41 @@ def test_filter_objects_registered(built):
         addr = C.addressof(C.c_char.in_dll(F, sym))
         assert F.hbhip_filter_get(fid) == addr
         assert C.c_int.in_dll(F, sym).value == fid          # .id is the first field
+
+
+NEW_FILTERS = ["hb_filter_colorspace_hip", "hb_filter_pad_hip", "hb_filter_yadif_hip"]
+
+
+def test_later_filter_objects_registered(built):
+    """The drop-ins added after the first set are reachable through hbhip_filter_get by their own ids."""
+    F = hip.filters()
+    F.hbhip_filter_get.restype = C.c_void_p
+    for sym in NEW_FILTERS:
+        addr = C.addressof(C.c_char.in_dll(F, sym))
+        fid = C.c_int.in_dll(F, sym).value
+        assert fid > 0 and F.hbhip_filter_get(fid) == addr, sym
+    for sym in ("hb_blend_hip", "hb_motion_metric_hip"):          # helper objects: exported, not in the id switch
+        assert C.addressof(C.c_char.in_dll(F, sym))
+
+
+def test_without_a_gpu_every_drop_in_refuses_to_start(built):
+    """No CPU fallback anywhere: on a machine without a device every filter's init() fails (libhb then
+    keeps its own CPU filter, work.c:1861-1868); only the do-nothing configurations start."""
+    import pytest
+    from handbrake_amd import hbrt
+    if hip.lib().hbhip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    F = hip.filters()
+    stages = [("hb_filter_nlmeans_hip", hip.NLMEANS_MEDIUM), ("hb_filter_decomb_hip", "mode=7"),
+              ("hb_filter_comb_detect_hip", ""), ("hb_filter_lapsharp_hip", "y-strength=0.2:y-kernel=isolap"),
+              ("hb_filter_unsharp_hip", "y-strength=0.25:y-size=7"), ("hb_filter_chroma_smooth_hip", "cb-strength=0.25:cb-size=7"),
+              ("hb_filter_denoise_hip", ""), ("hb_filter_crop_scale_hip", "width=320:height=180"),
+              ("hb_filter_grayscale_hip", "cb=0:cr=0:size=1:high=0"), ("hb_filter_rotate_hip", "angle=90:hflip=0"),
+              ("hb_filter_colorspace_hip", "matrix=smpte170m"), ("hb_filter_pad_hip", "width=700:height=400"),
+              ("hb_filter_yadif_hip", "mode=3"), ("hb_filter_hip_upload", "")]
+    for stage in stages:
+        with pytest.raises(RuntimeError):
+            hbrt.Chain(F, [stage], 640, 360)
+    for stage in [("hb_filter_colorspace_hip", ""), ("hb_filter_colorspace_hip", "matrix=bt709:range=tv"),
+                  ("hb_filter_yadif_hip", "mode=0")]:
+        hbrt.Chain(F, [stage], 640, 360).close()                 # nothing to do => no device needed
