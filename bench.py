@@ -1,27 +1,39 @@
 #!/usr/bin/env python3
 """bench.py — filtered frames/sec of the libhb video-filter hot path on MI355X.
 
-Workload (BASELINE.json configs[1], the configuration `metric` is quoted on):
-NLMeans "medium" (strength 6, origin-tune 1, patch 7, range 3, 2 frames, no
-prefilter; libhb/param.c:410-415) on 1920x1080 YUV420P 8-bit synthetic frames.
+Default workload = the chain BASELINE.json's `metric` names ("1080p YUV420p NLMeans+decomb
+chain"), in the form BASELINE configs[3] spells out:
 
-A "step" = one pass of the hot path over one batch of BATCH consecutive frames
-of a stream that is already resident in HBM: the frames are pushed through the
-product C ABI (hbhip_filter_process_dev -> nlmeans_plane kernel) and the BATCH
-filtered frames are written to device output buffers.  Nothing of the oracle or
-of any CPU path runs inside the timed region.
+    decomb (mode 31: yadif+blend+cubic+EEDI2, bob) -> NLMeans medium -> crop/scale Lanczos
+    1920x1080 -> 3840x2160 -> lapsharp (medium: 0.2, isolap)
 
-Multi-GPU (--gpus N, launched by torch.distributed.run): every rank filters its
-own independent stream on its own GPU (frames shard by stream); no
-data-path collective.  RCCL is used only to reduce {frames, seconds}: value =
-total frames of all ranks / max-over-ranks time.  scaling = weak.
+on 1920x1080 YUV420P 8-bit interlaced synthetic frames.  A "step" = one pass of the chain over
+one batch of BATCH consecutive input frames of a stream that is already resident in HBM; every
+input frame leaves as two 3840x2160 output frames (bob).  The frames go through the product C ABI
+(hbhip_chain_process_dev: the run of HIP filters fused the way hb_avfilter_combine fuses a run of
+libavfilter filters) exactly as they would in production: captured EEDI2 graphs, both fields of
+a bob pair in flight, pictures handed from stage to stage by pointer.  `value` counts OUTPUT
+frames.  Nothing of the oracle or of any CPU path runs inside the timed region.
 
-Also reported on the same JSON line:
-  roofline      - dominant kernel, algorithmic bytes/launch over its mean launch
-                  time measured with HIP events on the stream it runs on.
-  cpu_baseline  - the reference's own C NLMeans (oracle/_ref, taskset-threaded as
-                  libhb does) - or the single-thread port if the prebuilt _ref is
-                  absent - timed on this box's host cores on a bounded sample.
+Other workloads (--workload): nlmeans = configs[1], decomb_eedi2 = configs[2] (add
+--comb-detect for the comb-detect + selective-decomb pair), chain2160 = the per-GPU stream of
+configs[4] (3840x2160 interlaced in, same chain without the then-identity scaler, work.c:1467-1473).
+
+Multi-GPU (--gpus N under torch.distributed.run): every rank filters its own independent stream
+on its own GPU (frames shard by stream); no data-path collective; RCCL only reduces
+{frames, seconds}: value = total output frames of all ranks / max-over-ranks time.  scaling = weak.
+
+Also on the JSON line:
+  roofline       dominant kernel of the workload (largest share of GPU time): algorithmic bytes per
+                 launch / its mean launch time.  Launch times come from a pass right after the timed
+                 region in which the same launches are bracketed by HIP events on the stream they run
+                 on (the bracketing serialises the two EEDI2 engines and bypasses the graphs, which is
+                 why it is not done inside the timed region); `kernels` lists the rest.
+  cpu_baseline   the reference's own C filters (oracle/_ref, threaded by its own taskset.c as libhb
+                 does) on this box's host cores, bounded sample; the scaler leg is our restatement
+                 (zimg is not buildable here) and is labelled as such.
+  pcie_inclusive the same chain through the hb_filter_object_t surface with host hb_buffer_t in and
+                 out (upload adapter ... download adapter) — PCIe included.  Never `value`.
 """
 from __future__ import annotations
 
@@ -36,14 +48,67 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-W, H = 1920, 1080
-BATCH = 32          # frames per launch: 13 312 tiles = 17.3 rounds of the 768 resident workgroups
-# read 2 frames + write 1 = 3 x 3,110,400 B per 1080p 4:2:0 frame
-ALGO_BYTES_PER_FRAME = 3 * (W * H * 3 // 2)
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s
+LAPSHARP = "y-strength=0.2:y-kernel=isolap:cb-strength=0.2:cb-kernel=isolap"     # param.c:932-935
+
+WORKLOADS = {
+    "chain": dict(w=1920, h=1080, model="interlaced", batch=16, scale=(3840, 2160), cfg=3,
+                  text="BASELINE configs[3]: decomb(31, EEDI2 bob) -> nlmeans medium -> cropscale lanczos "
+                       "1920x1080 -> 3840x2160 -> lapsharp, 1080i YUV420P 8-bit in, inputs resident in HBM"),
+    "chain2160": dict(w=3840, h=2160, model="interlaced", batch=4, scale=None, cfg=4,
+                      text="BASELINE configs[4], one stream per GPU: decomb(31, EEDI2 bob) -> nlmeans medium -> "
+                           "lapsharp on 3840x2160 interlaced YUV420P 8-bit (identity crop/scale dropped, "
+                           "work.c:1467-1473), inputs resident in HBM"),
+    "decomb_eedi2": dict(w=1920, h=1080, model="interlaced", batch=16, scale=None, cfg=3,
+                         text="BASELINE configs[2]: decomb EEDI2 bob (mode 31) 1920x1080 interlaced"),
+    "nlmeans": dict(w=1920, h=1080, model="progressive", batch=32, scale=None, cfg=2,
+                    text="BASELINE configs[1]: nlmeans medium (patch 7, range 3, 2 frames) 1920x1080 YUV420P "
+                         "8-bit, inputs resident in HBM"),
+}
 
 
-def cpu_baseline(frames_np):
+def frame_bytes(w, h):
+    return w * h * 3 // 2
+
+
+def algorithmic_bytes(kernel, w, h, out_w, out_h, frames_per_launch=1):
+    """ALGORITHMIC bytes one launch of `kernel` moves: planes it must read +
+    planes it must write once each, 8-bit 4:2:0.  half = one field-sized 3-plane picture."""
+    full, half, out = frame_bytes(w, h), frame_bytes(w, h) // 2, frame_bytes(out_w, out_h)
+    t = {
+        "nlmeans_plane_n7": 3 * full * frames_per_launch,            # read 2 frames + write 1
+        "nlmeans_plane_n5": 3 * full * frames_per_launch, "nlmeans_plane_n3": 3 * full * frames_per_launch,
+        "nlmeans_plane_n9": 3 * full * frames_per_launch,
+        "decomb_plane": 5 * full,                                     # prev, cur, next, EEDI2 guess -> out
+        "cropscale_lanczos_fused": full + out,
+        "lapsharp_3x3": 2 * out, "lapsharp_5x5": 2 * out,
+        "copy_planes": 2 * full,
+        "eedi2_fill_half": half + half,                               # reads one field, writes srcp
+        "eedi2_mask_passes": 3 * half,                                # srcp + old mask -> new mask
+        "eedi2_calc_directions": 3 * half,                            # mskp + srcp -> tmpp
+        "eedi2_filter_dir_map": 3 * half, "eedi2_expand_dir_map": 3 * half, "eedi2_filter_map": 3 * half,
+        "eedi2_mark_directions_2x": 3 * half + 4 * full,              # 3 line doublings + tmp2p
+        "eedi2_filter_dir_map_2x": 3 * full, "eedi2_expand_dir_map_2x": 3 * full,
+        "eedi2_fill_gaps_2x": 3 * full,
+        "eedi2_lattice_candidates": 3 * full + 4 * full,              # tmp2p, dst2p, tmp2p2 -> u32 candidates
+        "eedi2_lattice_resolve": 4 * full + 2 * full,
+        "eedi2_post_process": 4 * full,
+        "comb_detect": 3 * w * h + w * h, "comb_mask_passes": 2 * w * h, "comb_block_score": w * h,
+    }
+    return t.get(kernel)
+
+
+def cpu_quota():
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            return max(1, int(int(q) / int(per)))
+    except Exception:
+        pass
+    return None
+
+
+def cpu_baseline_nlmeans(frames_np):
     """Reference NLMeans on the host cores (rank 0, N=1 only). ~10-30 s of CPU work."""
     from handbrake_amd import hbrt, hip
     import oracle_lib as ol
@@ -55,13 +120,7 @@ def cpu_baseline(frames_np):
         candidates = [rule(ncpu)]
         # a container CPU quota (cgroup cpu.max) below the visible core count throttles an
         # over-subscribed run: also time the thread count the quota supports and keep the better
-        quota = None
-        try:
-            q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-            if q != "max":
-                quota = max(1, int(int(q) / int(per)))
-        except Exception:
-            quota = None
+        quota = cpu_quota()
         if quota and quota < ncpu and quota not in candidates:
             candidates.append(quota)
         best = None
@@ -99,192 +158,76 @@ def cpu_baseline(frames_np):
             "sample": f"{n} frames 1920x1080 YUV420P, oracle/nlmeans_oracle.c single thread, {dt:.1f}s wall"}
 
 
-def cpu_baseline_chain(workload, frames_np):
-    """The reference's own filter objects (oracle/_ref) for configs[2]/[3] on the host cores.
-    EEDI2 runs on 3 plane threads whatever the core count (decomb.c:386-394), ~0.5 s per field."""
+def cpu_baseline_chain(workload, frames_np, scale):
+    """The reference's own filter objects (oracle/_ref) for the chain workloads on the host cores.
+    EEDI2 runs on 3 plane threads whatever the core count (decomb.c:386-394), ~0.5 s per 1080p field."""
     from handbrake_amd import hbrt, hip
     import oracle_lib as ol
+    import oracle_stream as os_
     ref = ol.ref()
     if ref is None:
         return None
+    quota = cpu_quota()
+    threads = min(os.cpu_count() or 1, quota or 1 << 30)
+    nlm = hip.NLMEANS_MEDIUM + f":threads={threads}"
+    n_in = 6 if frames_np[0][0].shape[1] <= 1920 else 2
+    seq = [frames_np[i % len(frames_np)] for i in range(n_in)]
     chain = [("hb_filter_decomb", "mode=31")]
-    note = "reference hb_filter_decomb mode=31 (EEDI2 bob)"
-    if workload == "chain4":
-        chain += [("hb_filter_nlmeans", hip.NLMEANS_MEDIUM), ("hb_filter_lapsharp", "y-strength=0.2:y-kernel=isolap")]
-        note += " -> hb_filter_nlmeans medium -> hb_filter_lapsharp @1080p (the reference's cropscale is zimg, not buildable here)"
-    seq = [frames_np[i % len(frames_np)] for i in range(10)]
+    note = "reference hb_filter_decomb mode=31 (EEDI2 bob, 3 plane threads)"
+    if workload != "decomb_eedi2":
+        chain.append(("hb_filter_nlmeans", nlm))
+        note += f" -> hb_filter_nlmeans medium (taskset threads={threads})"
     t0 = time.perf_counter()
     out = hbrt.run_stream(ref, chain, seq, flags=8)
     dt = time.perf_counter() - t0
-    return {"value": round(len(out) / dt, 3), "unit": "output frames/s", "cores": os.cpu_count(), "kind": "reference",
-            "sample": f"{len(seq)} input / {len(out)} output frames 1920x1080, {note}, {dt:.1f}s wall"}
+    frames = [o.planes for o in out]
+    if workload != "decomb_eedi2":
+        if scale:
+            t1 = time.perf_counter()
+            frames = os_.cropscale_stream(frames, dict(width=scale[0], height=scale[1]))
+            dt += time.perf_counter() - t1
+            note += f" -> crop/scale Lanczos to {scale[0]}x{scale[1]} (OUR restatement oracle/alias_oracle.c: the " \
+                    f"reference's scaler is zimg, not buildable here)"
+        t1 = time.perf_counter()
+        out2 = hbrt.run_stream(ref, [("hb_filter_lapsharp", LAPSHARP)], frames)
+        dt += time.perf_counter() - t1
+        note += " -> reference hb_filter_lapsharp (mt_frame_filter threaded)"
+        assert len(out2) == len(out)
+    return {"value": round(len(out) / dt, 3), "unit": "output frames/s", "cores": threads, "kind": "reference",
+            "sample": f"{len(seq)} input / {len(out)} output frames, {note}; stages timed one after the other, "
+                      f"{dt:.1f}s wall"}
 
 
-def secondary(args):
-    """configs[2] / configs[3] measured the same way (device-resident, one stream per GPU).
-    Not the default bench line; used for DESIGN.md / profiles."""
-    import torch
-    from handbrake_amd import hip, shard, synth
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    nsrc = 8
-    frames_np = synth.stream("interlaced", W, H, nsrc, cfg=3 + 16 * rank)
-    dev_in = [[torch.from_numpy(p).cuda() for p in fr] for fr in frames_np]
-    fin = [hip.dev_frame(f) for f in dev_in]
-    torch.cuda.synchronize()
-    chain = args.workload == "chain4"
-
-    def planes(w, h):
-        return [torch.empty((h, w), dtype=torch.uint8, device="cuda"),
-                torch.empty((h // 2, w // 2), dtype=torch.uint8, device="cuda"),
-                torch.empty((h // 2, w // 2), dtype=torch.uint8, device="cuda")]
-
-    class Lane:
-        """One independent stream: its own context (HIP stream), filter instances and frames."""
-        def __init__(self):
-            self.ctx = hip.Ctx(local_rank)
-            self.decomb = hip.DecombDevice(self.ctx, W, H, mode=63 if args.comb_detect else 31)
-            self.comb = hip.CombDetectDevice(self.ctx, W, H) if args.comb_detect else None
-            self.held = None            # frame waiting for its successor before it can be classified
-            self.decomb_f = hip.DeviceFilter(self.ctx, self.decomb.h)
-            self.t = [planes(W, H), planes(W, H), planes(2 * W, 2 * H), planes(2 * W, 2 * H)]
-            self.f1080, self.f1080b, self.f2160, self.f2160b = map(hip.dev_frame, self.t)
-            self.a1080b, self.a2160, self.a2160b = [(hip.DevFrame * 1)(f) for f in (self.f1080b, self.f2160, self.f2160b)]
-            if chain:
-                self.nlm = hip.nlmeans_device_filter(self.ctx, hip.NLMEANS_MEDIUM, W, H, batch=1)
-                self.scale = hip.cropscale_device_filter(self.ctx, W, H, 2 * W, 2 * H)
-                self.sharp = hip.lapsharp_device_filter(self.ctx, 2 * W, 2 * H)
-            self.produced = 0
-
-        def feed(self, i):
-            if self.comb is None:
-                hip.decomb_push_dev(self.decomb_f, fin[i % nsrc], i)
-            else:
-                # comb_detect_work (comb_detect.c:1537-1583): frame i-1 is classified from the luma of
-                # i-2, i-1, i and handed to the selective decomb (mode 63) with its s.combed
-                luma = dev_in[i % nsrc][0]
-                if self.held is None:
-                    self.comb.store_dev(luma.data_ptr(), luma.stride(0))
-                self.comb.store_dev(luma.data_ptr(), luma.stride(0))
-                if self.held is not None:
-                    combed = self.comb.classify(force=(self.held == 0))
-                    hip.decomb_push_dev(self.decomb_f, fin[self.held % nsrc], self.held, combed=combed)
-                self.held = i
-            while self.decomb_f.pending():
-                self.decomb_f.pull_dev(self.f1080)
-                if not chain:
-                    self.produced += 1
-                    continue
-                self.nlm.push_dev(self.f1080, 0)
-                while self.nlm.pending():
-                    self.nlm.pull_dev(self.f1080b)
-                    # stateless filters read / write the frames in place (hbhip_filter_process_dev)
-                    self.scale.process_dev(self.a1080b, 0, self.a2160)
-                    self.sharp.process_dev(self.a2160, 0, self.a2160b)
-                    self.produced += 1
-
-    lanes = [Lane() for _ in range(max(1, args.streams))]
-    ctx = lanes[0].ctx
-
-    def feed(i):
-        for ln in lanes:
-            ln.feed(i)
-
-    def sync_all():
-        for ln in lanes:
-            ln.ctx.sync()
-        torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        feed(i)
-    sync_all()
-    timer = len(lanes) == 1 and not args.no_kernel_timer
-    if timer:                    # the per-kernel timer serialises a context (individual launches, no graphs,
-        ctx.profile(True)        # no second EEDI2 stream): only in single-stream runs, and optional
-        ctx.profile_reset()
-    start = sum(ln.produced for ln in lanes)
+def pcie_inclusive(workload, frames_np, scale, n_in=24):
+    """The chain through the hb_filter_object_t surface, host hb_buffer_t in and out (H2D + D2H on the path)."""
+    from handbrake_amd import hbrt, hip
+    chain = [("hb_filter_hip_upload", ""), ("hb_filter_decomb_hip", "mode=31")]
+    if workload != "decomb_eedi2":
+        chain.append(("hb_filter_nlmeans_hip", hip.NLMEANS_MEDIUM))
+        if scale:
+            chain.append(("hb_filter_crop_scale_hip", "width=%d:height=%d" % scale))
+        chain.append(("hb_filter_lapsharp_hip", LAPSHARP))
+    chain.append(("hb_filter_hip_download", ""))
+    seq = [frames_np[i % len(frames_np)] for i in range(n_in)]
+    hbrt.run_stream(hip.filters(), chain, seq[:3], flags=8)          # warm-up: allocations, code objects, graphs
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        feed(args.warmup + i)
-    sync_all()
+    out = hbrt.run_stream(hip.filters(), chain, seq, flags=8)
     dt = time.perf_counter() - t0
-    stats = ctx.profile_stats() if timer else {}
-    ctx.profile(False)
-    out_frames = sum(ln.produced for ln in lanes) - start
-    frames_total, dt_max = shard.reduce_throughput(float(out_frames), dt, device="cuda")
-    if rank == 0:
-        top = sorted(stats.items(), key=lambda kv: -kv[1][1])[:6]
-        per_out = {"decomb_eedi2": 4 * (W * H * 3 // 2), "chain4": 62_200_000}[args.workload]   # SURVEY §8d
-        print(json.dumps({
-            "metric": "filtered output frames/sec (" + args.workload + ")",
-            "value": round(frames_total / dt_max, 2), "unit": "frames/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt_max / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": {"decomb_eedi2": "BASELINE configs[2]: decomb EEDI2 bob (mode 31) 1920x1080 interlaced",
-                                    "chain4": "BASELINE configs[3]: decomb(31)->nlmeans medium->cropscale lanczos "
-                                              "1080p->2160p->lapsharp, per-frame launches"}[args.workload],
-                       "input_frames_per_step": len(lanes), "output_frames_per_step": 2 * len(lanes),
-                       "streams_per_gpu": len(lanes), "device": ctx.name()},
-            "chain_hbm_GBps_algorithmic": round(per_out * frames_total / dt_max / 1e9, 2),
-            "top_kernels": [{"kernel": k, "launches": n, "avg_us": round(ms / n * 1e3, 1)} for k, (n, ms) in top],
-            "roofline": None,
-            "cpu_baseline": None if (world > 1 or args.no_cpu_baseline) else cpu_baseline_chain(args.workload, frames_np)}),
-            flush=True)
-    for ln in lanes:
-        ln.ctx.close()
+    return {"value": round(len(out) / dt, 2), "unit": "output frames/s", "input_fps": round(n_in / dt, 2),
+            "path": "hb_filter_object_t chain (hip_upload -> ... -> hip_download) driven by the libhb stand-in "
+                    "harness, pinned host hb_buffer_t in and out, one work() per frame",
+            "sample": f"{n_in} input / {len(out)} output frames, {dt:.2f}s wall"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=BATCH)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--depth", type=int, default=8, choices=[8, 10, 12],
-                    help="nlmeans workload only: sample depth (10 / 12 = 16-bit containers); the recorded "
-                         "bench line is the 8-bit one BASELINE.json names")
-    ap.add_argument("--comb-detect", action="store_true",
-                    help="secondary workloads only: run comb detection in front of the (then selective) decomb, "
-                         "as BASELINE configs[2] words it")
-    ap.add_argument("--no-kernel-timer", action="store_true",
-                    help="secondary workloads only: leave the per-kernel HIP-event timer off, so the filters run "
-                         "as they do in production (captured graphs, both fields of an EEDI2 bob pair in flight)")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="secondary workloads only: independent streams (filter instances on their own "
-                         "HIP streams) fed round-robin on each GPU")
-    ap.add_argument("--workload", default="nlmeans", choices=["nlmeans", "decomb_eedi2", "chain4"],
-                    help="nlmeans = BASELINE configs[1] (default, the bench line the driver records); "
-                         "decomb_eedi2 = configs[2]; chain4 = configs[3] (decomb->nlmeans->cropscale->lapsharp)")
-    args = ap.parse_args()
-    if args.workload != "nlmeans":
-        return secondary(args)
-
+def run_nlmeans(args, world, rank, local_rank):
+    """configs[1]: NLMeans medium alone, BATCH frames per launch through hbhip_filter_process_dev."""
     import torch
     import torch.distributed as dist
     from handbrake_amd import hip, shard, synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    B = args.batch
-    # one independent synthetic stream per rank (cfg = 2 + rank*16 keeps rank 0 == configs[1])
+    wl = WORKLOADS["nlmeans"]
+    W, H = wl["w"], wl["h"]
+    B = args.batch or wl["batch"]
     frames_np = synth.stream("progressive", W, H, B + 1, cfg=2 + 16 * rank, depth=args.depth)
     dev_in = [[torch.from_numpy(p).cuda() for p in fr] for fr in frames_np]
     dev_out = [[torch.empty_like(p) for p in dev_in[0]] for _ in range(B)]
@@ -324,66 +267,273 @@ def main():
 
     frames_local = float(args.steps * B)
     frames_total, dt_max = shard.reduce_throughput(frames_local, dt, device="cuda")
-
     if rank == 0:
-        # dominant kernel = most total time
         kname, (launches, total_ms) = max(stats.items(), key=lambda kv: kv[1][1])
         avg_s = total_ms / launches / 1e3
         frames_per_launch = frames_local / launches
-        algo_bytes = ALGO_BYTES_PER_FRAME * frames_per_launch * (2 if args.depth > 8 else 1)
+        algo_bytes = 3 * frame_bytes(W, H) * frames_per_launch * (2 if args.depth > 8 else 1)
         achieved = algo_bytes / avg_s / 1e9
-        traffic = None
-        valu_insts = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                rec = json.load(open(pmc)).get(kname, {}).get(str(B))
-                if rec:
-                    traffic = rec["hbm_bytes_per_launch"]
-                    valu_insts = rec.get("valu_insts_per_launch")
-            except Exception:
-                traffic = None
+        traffic, valu_insts = pmc_record(kname, B)
         out = {
-            "metric": "filtered frames/sec, 1080p YUV420p NLMeans (medium) hot path",
-            "value": round(frames_total / dt_max, 2),
-            "unit": "frames/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(dt_max / args.steps * 1e3, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
+            "metric": "filtered frames/sec, 1080p YUV420p NLMeans (medium) alone [the NLMeans+decomb chain is the default workload]",
+            "value": round(frames_total / dt_max, 2), "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt_max / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 (f32 weights)" if args.depth == 8 else f"u16, {args.depth}-bit samples (f32 weights)",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: nlmeans medium (patch 7, range 3, 2 frames) "
-                                   "1920x1080 YUV420P 8-bit, inputs resident in HBM",
-                       "frames_per_step": B, "width": W, "height": H,
-                       "parallelism": f"{world} independent stream(s), one per GPU",
-                       "device": ctx.name()},
+            "config": {"workload": wl["text"], "frames_per_step": B, "width": W, "height": H,
+                       "parallelism": f"{world} independent stream(s), one per GPU", "device": ctx.name()},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": traffic,
-                         "launch_us": round(avg_s * 1e6, 2), "launches": launches,
+                         "traffic": traffic, "launch_us": round(avg_s * 1e6, 2), "launches": launches,
                          "algorithmic_bytes_per_launch": int(algo_bytes),
                          "note": "NLMeans is VALU-bound (about 320 integer/float lane-ops per pixel); "
-                                 "'valu' prices the same launch against the vector-ALU issue rate"},
+                                 "'valu' prices the same launch against the measured vector-ALU issue rate"},
         }
         if valu_insts:
-            # wave64 VALU instructions (SQ_INSTS_VALU of the committed PMC pass) against the issue
-            # peak: 256 CUs x 4 SIMDs, one wave64 instruction per 4 cycles, 2.4 GHz
-            peak = 256 * 4 * 2.4e9 / 4
-            out["roofline"]["valu"] = {"insts_per_launch": int(valu_insts),
-                                       "achieved_ginst_s": round(valu_insts / avg_s / 1e9, 1),
-                                       "peak_ginst_s": round(peak / 1e9, 1),
-                                       "frac": round(valu_insts / avg_s / peak, 4)}
+            out["roofline"]["valu"] = valu_roofline(valu_insts, avg_s)
         if world == 1 and not args.no_cpu_baseline and args.depth == 8:
-            out["cpu_baseline"] = cpu_baseline(frames_np)
+            out["cpu_baseline"] = cpu_baseline_nlmeans(frames_np)
         print(json.dumps(out), flush=True)
-
     flt.close()
     ctx.close()
+
+
+def pmc_record(kname, frames_per_launch):
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            rec = json.load(open(pmc)).get(kname, {}).get(str(frames_per_launch))
+            if rec:
+                return rec.get("hbm_bytes_per_launch"), rec.get("valu_insts_per_launch")
+        except Exception:
+            pass
+    return None, None
+
+
+def valu_roofline(valu_insts, avg_s):
+    """wave64 VALU instructions (SQ_INSTS_VALU of the committed PMC pass) against the issue peak the
+    micro-benchmark tools/valu_rate.hip measured on this GPU type (profiles/r02_valu_rate.json): cycles a
+    SIMD needs per wave64 instruction for the NLMeans kernel's instruction mix."""
+    cyc, src = 4.0, "assumed 4 cycles per wave64 instruction (no micro-benchmark result committed)"
+    p = os.path.join(ROOT, "profiles", "r02_valu_rate.json")
+    if os.path.exists(p):
+        try:
+            rec = json.load(open(p))
+            cyc = float(rec["nlmeans_mix"]["cyc_per_inst"])
+            src = rec["nlmeans_mix"]["note"]
+        except Exception:
+            pass
+    peak = 256 * 4 * 2.4e9 / cyc
+    return {"insts_per_launch": int(valu_insts), "achieved_ginst_s": round(valu_insts / avg_s / 1e9, 1),
+            "peak_ginst_s": round(peak / 1e9, 1), "frac": round(valu_insts / avg_s / peak, 4),
+            "cycles_per_wave_inst": cyc, "peak_source": src}
+
+
+def run_chain(args, world, rank, local_rank):
+    """The chain workloads through hbhip_chain (device-resident, one or more independent streams per GPU)."""
+    import torch
+    from handbrake_amd import hip, shard, synth
+
+    wl = WORKLOADS[args.workload]
+    W, H, scale = wl["w"], wl["h"], wl["scale"]
+    OW, OH = scale if scale else (W, H)
+    B = args.batch or wl["batch"]
+    nsrc = min(B, 8)
+    frames_np = synth.stream("interlaced", W, H, nsrc, cfg=wl["cfg"] + 16 * rank)
+    dev_in = [[torch.from_numpy(p).cuda() for p in fr] for fr in frames_np]
+    in_arr = (hip.DevFrame * B)(*[hip.dev_frame(dev_in[i % nsrc]) for i in range(B)])
+    flags = [synth.PIC_FLAG_TOP_FIELD_FIRST] * B
+    torch.cuda.synchronize()
+    only_decomb = args.workload == "decomb_eedi2"
+
+    def planes(w, h):
+        return [torch.empty((h, w), dtype=torch.uint8, device="cuda"),
+                torch.empty((h // 2, w // 2), dtype=torch.uint8, device="cuda"),
+                torch.empty((h // 2, w // 2), dtype=torch.uint8, device="cuda")]
+
+    class Lane:
+        """One independent stream: its own context (HIP stream), filter instances, chain and output frames."""
+        def __init__(self):
+            self.ctx = hip.Ctx(local_rank)
+            self.decomb = hip.DecombDevice(self.ctx, W, H, mode=63 if args.comb_detect else 31)
+            self.comb = hip.CombDetectDevice(self.ctx, W, H) if args.comb_detect else None
+            stages = [hip.DeviceFilter(self.ctx, self.decomb.h)]
+            if not only_decomb:
+                stages.append(hip.nlmeans_device_filter(self.ctx, hip.NLMEANS_MEDIUM, W, H, batch=1))
+                if scale:
+                    stages.append(hip.cropscale_device_filter(self.ctx, W, H, OW, OH))
+                stages.append(hip.lapsharp_device_filter(self.ctx, OW, OH))
+            self.decomb.h = None                              # owned by the chain from here on
+            self.chain = hip.Chain(self.ctx, stages)
+            self.cap = 2 * B + 4
+            self.out_t = [planes(OW, OH) for _ in range(self.cap)]
+            self.out_arr = (hip.DevFrame * self.cap)(*[hip.dev_frame(t) for t in self.out_t])
+            self.produced = 0
+            self.fed = 0
+
+        def combed_for(self, i0, n):
+            """comb_detect_work (comb_detect.c:1537-1583): frame i is classified from the luma of i-1, i, i+1."""
+            res = []
+            for i in range(i0, i0 + n):
+                for j in ((i - 1, i, i + 1) if i == 0 else (i + 1,)):
+                    luma = dev_in[max(j, 0) % nsrc][0]
+                    self.comb.store_dev(luma.data_ptr(), luma.stride(0))
+                res.append(self.comb.classify(force=(i == 0)))
+            return res
+
+        def step(self):
+            combed = self.combed_for(self.fed, B) if self.comb else [2] * B
+            self.produced += self.chain.process_dev(in_arr, self.out_arr, tag0=self.fed, flags=flags, combed=combed)
+            self.fed += B
+
+        def close(self):
+            self.chain.close()
+            if self.comb:
+                self.comb.close()
+            self.ctx.close()
+
+    lanes = [Lane() for _ in range(max(1, args.streams))]
+    ctx = lanes[0].ctx
+
+    def sync_all():
+        for ln in lanes:
+            ln.ctx.sync()
+        torch.cuda.synchronize()
+
+    def fence():
+        sync_all()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        for ln in lanes:
+            ln.step()
+    fence()
+    start = sum(ln.produced for ln in lanes)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        for ln in lanes:
+            ln.step()
+    sync_all()
+    dt = time.perf_counter() - t0
     if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    out_frames = sum(ln.produced for ln in lanes) - start
+    frames_total, dt_max = shard.reduce_throughput(float(out_frames), dt, device="cuda")
+
+    # per-kernel launch times: same launches, bracketed by HIP events on their stream, right after the timed region
+    stats = {}
+    if not args.no_kernel_timer:
+        ctx.profile(True)
+        ctx.profile_reset()
+        for _ in range(2):
+            lanes[0].step()
+        ctx.sync()
+        stats = ctx.profile_stats()
+        ctx.profile(False)
+
+    if rank == 0:
+        top = sorted(stats.items(), key=lambda kv: -kv[1][1])
+        total_ms = sum(ms for _, (_, ms) in top) or 1.0
+        kernels = []
+        for k, (n, ms) in top[:12]:
+            # the profiled pass ran 2 steps = 4 B frames through NLMeans, in n launches
+            ab = algorithmic_bytes(k, W, H, OW, OH, frames_per_launch=4 * B / n if k.startswith("nlmeans_plane") else 1)
+            ab = int(ab) if ab else ab
+            avg = ms / n / 1e3
+            kernels.append({"kernel": k, "launches": n, "avg_us": round(avg * 1e6, 2), "share": round(ms / total_ms, 4),
+                            "algorithmic_bytes_per_launch": ab,
+                            "frac_of_hbm_peak": None if ab is None else round(ab / avg / 1e9 / HBM_PEAK_GBS, 5)})
+        roof = None
+        if kernels:
+            d = kernels[0]
+            ab = d["algorithmic_bytes_per_launch"]
+            if ab:
+                achieved = ab / (d["avg_us"] * 1e-6) / 1e9
+                traffic, _ = pmc_record(d["kernel"], 1)
+                roof = {"bound": "hbm", "kernel": d["kernel"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                        "launch_us": d["avg_us"], "launches": d["launches"], "share_of_gpu_time": d["share"],
+                        "algorithmic_bytes_per_launch": ab,
+                        "note": "dominant kernel of the chain = largest share of summed kernel time in the event-"
+                                "bracketed pass that follows the timed region"}
+        per_out = {"chain": 62_208_000, "chain2160": 4 * frame_bytes(W, H) + 3 * frame_bytes(W, H) + 2 * frame_bytes(W, H),
+                   "decomb_eedi2": 4 * frame_bytes(W, H)}[args.workload]      # SURVEY §8d, per output frame
+        line = {
+            "metric": "filtered frames/sec, 1080p YUV420p NLMeans+decomb chain" if args.workload == "chain"
+                      else "filtered frames/sec (" + args.workload + ")",
+            "value": round(frames_total / dt_max, 2), "unit": "output frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt_max / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 (f32 NLMeans weights, "
+            "f64 scaler / sharpen mix as the reference)", "data": "synthetic",
+            "config": {"workload": wl["text"] + (" + comb detect in front (selective decomb, mode 63)" if args.comb_detect else ""),
+                       "input_frames_per_step": B * len(lanes), "output_frames_per_step": 2 * B * len(lanes),
+                       "input": f"{W}x{H}", "output": f"{OW}x{OH}", "streams_per_gpu": len(lanes),
+                       "parallelism": f"{world} GPU(s) x {len(lanes)} independent stream(s)", "device": ctx.name()},
+            "input_fps": round(frames_total / dt_max / 2, 2),
+            "chain_hbm_GBps_algorithmic": round(per_out * frames_total / dt_max / 1e9, 2),
+            "chain_frac_of_hbm_peak": round(per_out * frames_total / dt_max / 1e9 / HBM_PEAK_GBS, 5),
+            "roofline": roof, "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_chain(args.workload, frames_np, scale)
+        else:
+            line["cpu_baseline"] = None
+        if world == 1 and not args.no_pcie:
+            try:
+                line["pcie_inclusive"] = pcie_inclusive(args.workload, frames_np, scale)
+            except Exception as e:                                           # never lose the bench line over it
+                line["pcie_inclusive"] = {"error": repr(e)}
+        print(json.dumps(line), flush=True)
+    for ln in lanes:
+        ln.close()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=0,
+                    help="input frames per step (default: per workload - chain 16, chain2160 4, nlmeans 32)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive pass of the chain workloads")
+    ap.add_argument("--depth", type=int, default=8, choices=[8, 10, 12],
+                    help="nlmeans workload only: sample depth (10 / 12 = 16-bit containers)")
+    ap.add_argument("--comb-detect", action="store_true",
+                    help="chain workloads: run comb detection in front of the (then selective) decomb, "
+                         "as BASELINE configs[2] words it")
+    ap.add_argument("--no-kernel-timer", action="store_true",
+                    help="chain workloads: skip the event-bracketed pass after the timed region (roofline = null)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="chain workloads: independent streams (own HIP stream and filter instances) per GPU")
+    ap.add_argument("--workload", default="chain", choices=sorted(WORKLOADS),
+                    help="chain = BASELINE's metric, configs[3] (default, the line the driver records); nlmeans = "
+                         "configs[1]; decomb_eedi2 = configs[2]; chain2160 = one stream of configs[4]")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.workload == "nlmeans":
+        run_nlmeans(args, world, rank, local_rank)
+    else:
+        run_chain(args, world, rank, local_rank)
+    if world > 1:
+        import torch.distributed as dist
         dist.destroy_process_group()
 
 

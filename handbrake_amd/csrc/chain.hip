@@ -1,0 +1,247 @@
+// chain.hip — a run of adjacent HIP filters fused into one object (hbhip_chain).
+//
+// libhb gives every filter its own thread and fifo (work.c:2527-2600) — except for runs of
+// libavfilter-backed filters, which hb_avfilter_combine (hbavfilter.c:510-622) merges into ONE
+// filter object whose work() pushes a frame through the whole graph.  hbhip_chain is that idea
+// for a run of HIP filters: one caller, one stream, and pictures handed from one stage to the
+// next by pointer (hbhip_pic_release returns each to the pool of the stage that produced it),
+// so a frame that enters the chain is read from HBM once per stage and never copied between
+// stages.  A batch of input frames is walked stage by stage: stage k sees all the frames of the
+// batch before stage k+1 starts, which lets batching stages (NLMeans) cover them in one launch.
+//
+// The last stage writes straight into the caller's output frames when it can (stateless filters);
+// the first stage gets the caller's frames through one 3-plane copy launch (stateful filters keep
+// input pictures beyond the call, the caller's frames are only borrowed for its duration).
+#include "hbhip_internal.h"
+
+#include <deque>
+#include <new>
+#include <vector>
+
+namespace {
+
+struct CopyArgs
+{
+    const uint8_t *src[3];
+    uint8_t       *dst[3];
+    int spitch[3], dpitch[3], row_bytes[3], rows[3];
+};
+
+// 16 bytes per thread where both rows allow it; the three planes in one launch
+__global__ void __launch_bounds__(256) copy3_kernel(CopyArgs a)
+{
+    const int pl = blockIdx.z;
+    const int y = blockIdx.y;
+    if (y >= a.rows[pl]) return;
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 16;
+    const int rb = a.row_bytes[pl];
+    if (x >= rb) return;
+    const uint8_t *s = a.src[pl] + (size_t)y * a.spitch[pl] + x;
+    uint8_t *d = a.dst[pl] + (size_t)y * a.dpitch[pl] + x;
+    if (x + 16 <= rb && (((uintptr_t)s | (uintptr_t)d) & 15) == 0)
+        *reinterpret_cast<uint4 *>(d) = *reinterpret_cast<const uint4 *>(s);
+    else
+        for (int i = 0; i < 16 && x + i < rb; i++) d[i] = s[i];
+}
+
+int copy3(hbhip_ctx *ctx, const CopyArgs &a)
+{
+    int maxrow = 0, maxrows = 0;
+    for (int c = 0; c < 3; c++) { maxrow = std::max(maxrow, a.row_bytes[c]); maxrows = std::max(maxrows, a.rows[c]); }
+    dim3 grid((maxrow + 4095) / 4096, maxrows, 3);
+    HBHIP_LAUNCH(ctx, "copy_planes", copy3_kernel, grid, dim3(256), 0, a);
+    HBHIP_CHECK(ctx, hipGetLastError());
+    return HBHIP_OK;
+}
+
+} // namespace
+
+struct hbhip_chain
+{
+    hbhip_ctx *ctx = nullptr;
+    std::vector<hbhip_filter *> st;
+    std::deque<DevPicture *> held;          // finished pictures the caller had no room for yet
+
+    int copy_in(DevPicture *dst, const hbhip_dev_frame *src)
+    {
+        CopyArgs a;
+        for (int c = 0; c < 3; c++)
+        {
+            const int vis = dst->width[c] * dst->bps;
+            if (src->plane[c] == nullptr || src->stride[c] < vis) return HBHIP_ERR_ARG;
+            a.src[c] = (const uint8_t *)src->plane[c]; a.spitch[c] = src->stride[c];
+            a.dst[c] = dst->plane[c];                  a.dpitch[c] = dst->pitch[c];
+            a.row_bytes[c] = vis; a.rows[c] = dst->height[c];
+        }
+        return copy3(ctx, a);
+    }
+    int copy_out(const hbhip_dev_frame *dst, const DevPicture *src)
+    {
+        CopyArgs a;
+        for (int c = 0; c < 3; c++)
+        {
+            const int vis = src->width[c] * src->bps;
+            if (dst->plane[c] == nullptr || dst->stride[c] < vis) return HBHIP_ERR_ARG;
+            a.src[c] = src->plane[c];            a.spitch[c] = src->pitch[c];
+            a.dst[c] = (uint8_t *)dst->plane[c]; a.dpitch[c] = dst->stride[c];
+            a.row_bytes[c] = vis; a.rows[c] = src->height[c];
+        }
+        return copy3(ctx, a);
+    }
+
+    // Deliver held / freshly finished pictures into the caller's frames.
+    int deliver(const hbhip_dev_frame *out, int64_t *tags, int cap, int &produced)
+    {
+        hbhip_filter *last = st.back();
+        while (!held.empty() && produced < cap)
+        {
+            DevPicture *p = held.front();
+            held.pop_front();
+            int rc = copy_out(&out[produced], p);
+            if (tags) tags[produced] = p->tag;
+            last->recycle_output(p);
+            if (rc != HBHIP_OK) return rc;
+            produced++;
+        }
+        return HBHIP_OK;
+    }
+
+    int run(const hbhip_dev_frame *in, const int *flags, const int *combed, int n_in, int64_t tag0, bool flush,
+            const hbhip_dev_frame *out, int64_t *tags, int cap, int *n_out)
+    {
+        int produced = 0;
+        int rc = deliver(out, tags, cap, produced);
+        if (rc != HBHIP_OK) return rc;
+
+        std::vector<DevPicture *> cur, next;
+        hbhip_filter *first = st.front();
+        for (int i = 0; i < n_in; i++)
+        {
+            DevPicture *p = first->acquire_input();
+            if (!p) return HBHIP_ERR_NOMEM;
+            p->tag = tag0 + i;
+            p->refs = 0;
+            if (flags) p->flags = flags[i];
+            if (combed) p->combed = combed[i];
+            for (int c = 0; c < 3; c++) first->in_stride[c] = in[i].stride[c];
+            first->in_is_dev = true;
+            rc = copy_in(p, &in[i]);
+            if (rc != HBHIP_OK) return rc;
+            cur.push_back(p);
+        }
+        for (size_t s = 0; s < st.size(); s++)
+        {
+            hbhip_filter *f = st[s];
+            const bool is_last = s + 1 == st.size();
+            // the last stage writes the caller's frames itself when every frame it is about to
+            // make has a slot and nothing older is waiting
+            bool direct = is_last && held.empty() && f->can_submit_to() && produced + (int)cur.size() <= cap;
+            for (DevPicture *p : cur)
+            {
+                if (s > 0)
+                {
+                    for (int c = 0; c < 3; c++) f->in_stride[c] = p->pitch[c];
+                    f->in_is_dev = true;
+                }
+                if (direct)
+                {
+                    DevPicture vo;
+                    for (int c = 0; c < 3; c++)
+                    {
+                        vo.plane[c] = (uint8_t *)out[produced].plane[c]; vo.pitch[c] = out[produced].stride[c];
+                        vo.width[c] = f->out_geo.pw[c]; vo.height[c] = f->out_geo.ph[c];
+                        if (vo.plane[c] == nullptr || vo.pitch[c] < vo.width[c] * f->out_geo.bps ||
+                            (vo.pitch[c] & 15) || ((uintptr_t)vo.plane[c] & 15))
+                            direct = false;
+                    }
+                    vo.bps = f->out_geo.bps;
+                    if (direct)
+                    {
+                        if (tags) tags[produced] = p->tag;
+                        rc = f->submit_to(p, &vo);
+                        if (rc != HBHIP_OK) return rc;
+                        produced++;
+                        continue;
+                    }
+                }
+                rc = f->submit(p);
+                if (rc != HBHIP_OK) return rc;
+            }
+            rc = flush ? f->flush() : f->kick();
+            if (rc != HBHIP_OK) return rc;
+            next.clear();
+            while (f->pending() > 0)
+            {
+                DevPicture *o = f->pop_output();
+                if (!o) break;
+                o->refs = 0;
+                next.push_back(o);
+            }
+            cur.swap(next);
+        }
+        for (DevPicture *p : cur) held.push_back(p);
+        rc = deliver(out, tags, cap, produced);
+        if (rc != HBHIP_OK) return rc;
+        *n_out = produced;
+        return HBHIP_OK;
+    }
+};
+
+extern "C" {
+
+int hbhip_chain_create(hbhip_ctx *ctx, hbhip_filter *const *stages, int n_stages, hbhip_chain **out)
+{
+    if (!ctx || !stages || n_stages < 1 || !out) return HBHIP_ERR_ARG;
+    *out = nullptr;
+    for (int i = 0; i < n_stages; i++)
+    {
+        if (!stages[i] || stages[i]->ctx != ctx) return HBHIP_ERR_ARG;
+        if (i > 0)
+        {
+            const PicGeometry &a = stages[i - 1]->out_geo, &b = stages[i]->in_geo;
+            if (a.width != b.width || a.height != b.height || a.depth != b.depth ||
+                a.log2_cw != b.log2_cw || a.log2_ch != b.log2_ch)
+                return HBHIP_ERR_ARG;
+        }
+    }
+    hbhip_chain *c = new (std::nothrow) hbhip_chain();
+    if (!c) return HBHIP_ERR_NOMEM;
+    c->ctx = ctx;
+    c->st.assign(stages, stages + n_stages);
+    for (hbhip_filter *f : c->st) f->defer_launches(true);
+    *out = c;
+    return HBHIP_OK;
+}
+
+int hbhip_chain_process_dev(hbhip_chain *c, const hbhip_dev_frame *in, const int *pic_flags, const int *combed,
+                            int n_in, int64_t tag0, const hbhip_dev_frame *out, int64_t *out_tags, int out_cap,
+                            int *n_out)
+{
+    if (!c || (n_in > 0 && !in) || (out_cap > 0 && !out) || !n_out || n_in < 0 || out_cap < 0) return HBHIP_ERR_ARG;
+    (void)hipSetDevice(c->ctx->device);
+    return c->run(in, pic_flags, combed, n_in, tag0, false, out, out_tags, out_cap, n_out);
+}
+
+int hbhip_chain_flush_dev(hbhip_chain *c, const hbhip_dev_frame *out, int64_t *out_tags, int out_cap, int *n_out)
+{
+    if (!c || (out_cap > 0 && !out) || !n_out || out_cap < 0) return HBHIP_ERR_ARG;
+    (void)hipSetDevice(c->ctx->device);
+    return c->run(nullptr, nullptr, nullptr, 0, 0, true, out, out_tags, out_cap, n_out);
+}
+
+int hbhip_chain_pending(hbhip_chain *c)
+{
+    return c ? (int)c->held.size() : 0;
+}
+
+void hbhip_chain_destroy(hbhip_chain *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->ctx->device);
+    (void)hipStreamSynchronize(c->ctx->stream);
+    for (DevPicture *p : c->held) c->st.back()->recycle_output(p);
+    for (hbhip_filter *f : c->st) f->defer_launches(false);
+    delete c;
+}
+
+} // extern "C"

@@ -358,7 +358,7 @@ public:
 private:
     void unref(DevPicture *p)
     {
-        if (p && --p->refs == 0) pool.release(p);
+        if (p && --p->refs == 0) hbhip_pic_release(p);     // possibly another filter's picture (fused chain)
     }
     void store_ref(DevPicture *p)              // decomb.c:195-200
     {

@@ -122,6 +122,7 @@ DevPicture *PicturePool::acquire()
     }
     (void)hipMemsetAsync(p->base, 0, total, ctx_->stream);
     for (int c = 0; c < 3; c++) p->plane[c] = p->base + off[c];
+    p->owner = this;
     all_.push_back(p);
     return p;
 }

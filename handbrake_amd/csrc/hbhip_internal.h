@@ -88,6 +88,7 @@ struct DevPicture
     int      flags = 0;      // PIC_FLAG_* of the source buffer (decomb / comb detect)
     int      combed = 0;     // HB_COMB_* of the source buffer
     int      aux = 0;        // filter specific (decomb: which field of a bob pair)
+    class PicturePool *owner = nullptr;   // the pool the picture goes back to (hbhip_pic_release)
 };
 
 // A reference-counted device picture that travels between filters inside an hb_buffer_t.
@@ -135,6 +136,14 @@ private:
     std::vector<DevPicture *> free_;
 };
 
+// Give a picture back to the pool it came from.  Filters release their INPUT pictures through this,
+// so that a picture one filter produced can be handed to the next filter of a fused chain
+// (hbhip_chain, chain.hip) without a copy: whoever finishes with it returns it to its producer's pool.
+inline void hbhip_pic_release(DevPicture *p)
+{
+    if (p && p->owner) p->owner->release(p);
+}
+
 // Copy helpers (2-D, any pitch on either side), all on ctx->stream.
 int hbhip_copy_h2d(hbhip_ctx *ctx, DevPicture *dst, const hbhip_host_frame *src);
 int hbhip_copy_d2h(hbhip_ctx *ctx, const hbhip_host_frame *dst, const DevPicture *src);
@@ -165,6 +174,15 @@ struct hbhip_filter
     // with a zero-copy path that reads the caller's frames and writes its outputs in place.
     virtual int process_dev_batch(const hbhip_dev_frame *in, int n_in, int64_t tag0,
                                   const hbhip_dev_frame *out, int out_cap, int *n_out);
+    // ---- fused chains (hbhip_chain) ----
+    // Launch whatever is ready now (filters that wait for a batch to fill up).
+    virtual int kick() { return HBHIP_OK; }
+    // true: the filter gathers frames until kick() instead of launching on its own batch threshold
+    virtual void defer_launches(bool) {}
+    // One frame in, written straight into the caller's picture `out` (a view, not pool-owned);
+    // takes ownership of `in`.  HBHIP_ERR_UNSUPPORTED when the filter has no such path.
+    virtual int submit_to(DevPicture *, const DevPicture *) { return HBHIP_ERR_UNSUPPORTED; }
+    virtual bool can_submit_to() const { return false; }
 };
 
 // A stateless one-frame-in / one-frame-out filter: subclasses implement process().
@@ -190,7 +208,7 @@ struct SimpleFilter : hbhip_filter
         if (!o) return HBHIP_ERR_NOMEM;
         o->tag = pic->tag;
         int rc = process(pic, o);
-        in_pool.release(pic);              // stream-ordered reuse
+        hbhip_pic_release(pic);            // stream-ordered reuse (back to whichever pool made it)
         if (rc != HBHIP_OK)
         {
             out_pool.release(o);
@@ -209,6 +227,15 @@ struct SimpleFilter : hbhip_filter
         return p;
     }
     void recycle_output(DevPicture *p) override { out_pool.release(p); }
+    bool can_submit_to() const override { return outq.empty(); }
+    int submit_to(DevPicture *pic, const DevPicture *out) override
+    {
+        DevPicture vo = *out;
+        vo.tag = pic->tag;
+        int rc = process(pic, &vo);
+        hbhip_pic_release(pic);
+        return rc;
+    }
 
     // Zero-copy: a stateless filter can read the caller's device frame and write the caller's
     // output frame directly (no pool pictures, no device-to-device copies).  Falls back to the

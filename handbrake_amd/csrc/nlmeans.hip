@@ -976,6 +976,9 @@ public:
 
     int flush() override { return schedule(true); }
     int pending() override { return (int)out.size(); }
+    // fused chain: gather the frames of a chain batch, launch once for all that are ready
+    void defer_launches(bool on) override { deferred = on; }
+    int kick() override { return schedule(false, true); }
 
     DevPicture *pop_output() override
     {
@@ -987,6 +990,7 @@ public:
     void recycle_output(DevPicture *p) override { pool.release(p); }
 
     int batch = 1;
+    bool deferred = false;
     int diff_cap[3] = {-1, -1, -1};
     int pf_type[3] = {0, 0, 0};          // effective prefilter bits per plane (0 = none)
     bool passthru[3] = {false, false, false};
@@ -1059,7 +1063,7 @@ private:
                 pre_of.erase(it);
             }
         }
-        pool.release(p);
+        hbhip_pic_release(p);          // possibly another filter's picture (fused chain)
     }
 
     // nlmeans_prefilter (nlmeans_template.c:428-543) of every plane that has one, into the frame's twin
@@ -1217,11 +1221,11 @@ private:
     }
 
     // Filter as many queued frames as are ready (all of them when draining).
-    int schedule(bool draining)
+    int schedule(bool draining, bool kicked = false)
     {
         int ready = draining ? (int)in.size() : (int)in.size() - (max_frames - 1);
         if (ready <= 0) return HBHIP_OK;
-        if (!draining && ready < batch) return HBHIP_OK;
+        if (!draining && !kicked && (deferred || ready < batch)) return HBHIP_OK;
 
         std::vector<DevPicture *> outs(ready, nullptr);
         std::vector<View> vin, vout;

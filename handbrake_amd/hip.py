@@ -24,7 +24,9 @@ ABI_SYMBOLS = [
     "hbhip_frame_upload", "hbhip_frame_download",
     "hbhip_filter_push", "hbhip_filter_push_dev", "hbhip_filter_pull", "hbhip_filter_pull_dev",
     "hbhip_filter_process_dev", "hbhip_filter_flush", "hbhip_filter_pending", "hbhip_filter_destroy",
-    "hbhip_filter_out_geometry", "hbhip_nlmeans_create", "hbhip_nlmeans_set_batch",
+    "hbhip_filter_out_geometry",
+    "hbhip_chain_create", "hbhip_chain_process_dev", "hbhip_chain_flush_dev", "hbhip_chain_pending", "hbhip_chain_destroy",
+    "hbhip_nlmeans_create", "hbhip_nlmeans_set_batch",
     "hbhip_lapsharp_create", "hbhip_unsharp_create", "hbhip_chroma_smooth_create",
     "hbhip_hqdn3d_create", "hbhip_decomb_create", "hbhip_decomb_push", "hbhip_decomb_push_dev", "hbhip_decomb_debug_eedi_plane",
     "hbhip_comb_detect_create", "hbhip_comb_detect_set_gamma_lut", "hbhip_comb_detect_store",
@@ -100,6 +102,14 @@ def lib() -> C.CDLL:
         L.hbhip_nlmeans_create.argtypes = [C.c_void_p, C.POINTER(NLMeansParams), C.c_int, C.c_int,
                                            C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.hbhip_nlmeans_set_batch.argtypes = [C.c_void_p, C.c_int]
+        L.hbhip_chain_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)]
+        L.hbhip_chain_process_dev.argtypes = [C.c_void_p, C.POINTER(DevFrame), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                              C.c_int, C.c_int64, C.POINTER(DevFrame), C.POINTER(C.c_int64), C.c_int,
+                                              C.POINTER(C.c_int)]
+        L.hbhip_chain_flush_dev.argtypes = [C.c_void_p, C.POINTER(DevFrame), C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int)]
+        L.hbhip_chain_pending.argtypes = [C.c_void_p]
+        L.hbhip_chain_destroy.argtypes = [C.c_void_p]
+        L.hbhip_chain_destroy.restype = None
         _lib = L
     return _lib
 
@@ -229,6 +239,40 @@ class DeviceFilter:
         if self.h:
             lib().hbhip_filter_destroy(self.h)
             self.h = None
+
+
+class Chain:
+    """hbhip_chain: a run of device filters fused into one object (frames stay in HBM between the
+    stages, handed over by pointer).  `stages` = DeviceFilter objects sharing `ctx`; the chain closes
+    them itself, last stage first."""
+
+    def __init__(self, ctx: Ctx, stages):
+        self.ctx, self.stages = ctx, list(stages)
+        arr = (C.c_void_p * len(self.stages))(*[s.h for s in self.stages])
+        h = C.c_void_p()
+        check(lib().hbhip_chain_create(ctx.h, arr, len(self.stages), C.byref(h)), ctx.h, "hbhip_chain_create")
+        self.h = h
+
+    def process_dev(self, frames_in, frames_out, tag0: int = 0, flags=None, combed=None, tags=None) -> int:
+        n = C.c_int()
+        nin = len(frames_in)
+        fl = (C.c_int * nin)(*flags) if flags is not None else None
+        cb = (C.c_int * nin)(*combed) if combed is not None else None
+        check(lib().hbhip_chain_process_dev(self.h, frames_in, fl, cb, nin, tag0, frames_out, tags, len(frames_out),
+                                            C.byref(n)), self.ctx.h, "chain_process_dev")
+        return n.value
+
+    def flush_dev(self, frames_out, tags=None) -> int:
+        n = C.c_int()
+        check(lib().hbhip_chain_flush_dev(self.h, frames_out, tags, len(frames_out), C.byref(n)), self.ctx.h, "chain_flush_dev")
+        return n.value
+
+    def close(self):
+        if self.h:
+            lib().hbhip_chain_destroy(self.h)
+            self.h = None
+            for s in reversed(self.stages):
+                s.close()
 
 
 NLMEANS_MEDIUM = ("y-strength=6:y-origin-tune=1:y-patch-size=7:y-range=3:y-frame-count=2:y-prefilter=0:"

@@ -132,6 +132,25 @@ void hbhip_filter_destroy(hbhip_filter *f);
 /* Output geometry (cropscale / rotate change it; init->geometry, cropscale.c:170-178). */
 int  hbhip_filter_out_geometry(hbhip_filter *f, int *width, int *height);
 
+/* ---- a run of adjacent HIP filters fused into one object ------------------------------------
+ * The reference merges runs of libavfilter-backed filters into one filter object whose work()
+ * pushes a frame through the whole graph (hb_avfilter_combine, hbavfilter.c:510-622); this is the
+ * same for a run of HIP filters: one caller thread, pictures handed from stage to stage in HBM by
+ * pointer (no copies between stages), a batch of frames walked stage by stage so that batching
+ * stages (NLMeans) cover the batch in one launch.  The chain BORROWS the filters: they must share
+ * `ctx`, consecutive geometries must match, and after hbhip_chain_destroy the caller destroys them
+ * LAST STAGE FIRST (a stage may still hold pictures of the stage before it).
+ * pic_flags / combed: per input frame, what hbhip_decomb_push carries (NULL = 0); out_tags: the
+ * tag of each output frame (decomb stages shift tags as documented at hbhip_decomb_push). */
+typedef struct hbhip_chain hbhip_chain;
+int  hbhip_chain_create(hbhip_ctx *ctx, hbhip_filter *const *stages, int n_stages, hbhip_chain **out);
+int  hbhip_chain_process_dev(hbhip_chain *c, const hbhip_dev_frame *in, const int *pic_flags, const int *combed,
+                             int n_in, int64_t tag0, const hbhip_dev_frame *out, int64_t *out_tags, int out_cap,
+                             int *n_out);
+int  hbhip_chain_flush_dev(hbhip_chain *c, const hbhip_dev_frame *out, int64_t *out_tags, int out_cap, int *n_out);
+int  hbhip_chain_pending(hbhip_chain *c);             /* finished frames waiting for room in `out` */
+void hbhip_chain_destroy(hbhip_chain *c);
+
 /* ---- NLMeans  (replaces nlmeans.c:223-419 init tables + nlmeans_template.c:545-717) */
 #define HBHIP_NLMEANS_FRAMES_MAX 32                   /* NLMEANS_FRAMES_MAX, nlmeans.c:87 */
 typedef struct hbhip_nlmeans_params
