@@ -316,15 +316,16 @@ def valu_roofline(valu_insts, avg_s):
     micro-benchmark tools/valu_rate.hip measured on this GPU type (profiles/r02_valu_rate.json): cycles a
     SIMD needs per wave64 instruction for the NLMeans kernel's instruction mix."""
     cyc, src = 4.0, "assumed 4 cycles per wave64 instruction (no micro-benchmark result committed)"
+    peak = 256 * 4 * 2.4e9 / cyc
     p = os.path.join(ROOT, "profiles", "r02_valu_rate.json")
     if os.path.exists(p):
         try:
             rec = json.load(open(p))
             cyc = float(rec["nlmeans_mix"]["cyc_per_inst"])
+            peak = float(rec["nlmeans_mix"]["peak_ginst_s"]) * 1e9
             src = rec["nlmeans_mix"]["note"]
         except Exception:
             pass
-    peak = 256 * 4 * 2.4e9 / cyc
     return {"insts_per_launch": int(valu_insts), "achieved_ginst_s": round(valu_insts / avg_s / 1e9, 1),
             "peak_ginst_s": round(peak / 1e9, 1), "frac": round(valu_insts / avg_s / peak, 4),
             "cycles_per_wave_inst": cyc, "peak_source": src}

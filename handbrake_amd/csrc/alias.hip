@@ -586,7 +586,99 @@ public:
     hbhip_pad_params par;
 };
 
+// ------------------------------------------------------------------ format (depth conversion)
+// `format=pix_fmts=...` (libhb/format.c:13-111): libavfilter inserts a same-size `scale`, i.e. libswscale's
+// unscaled planar copy (swscale_unscaled.c:planarCopyWrapper; parity unpinned, restated in
+// oracle/alias_oracle.c:orc_format_plane).  Up: shift (limited range, chroma) or top-bit replication
+// (full-range luma); down: ordered dither then the overflow clamp tmp - (tmp >> depth).  One launch for the
+// three planes, four samples per thread, HBM-bound (read in + write out).
+struct FormatArgs
+{
+    const uint8_t *src[3];
+    uint8_t       *dst[3];
+    int spitch[3], dpitch[3], w[3], h[3];
+    int sdepth, ddepth, full_range;
+};
+
+template <typename SRC, typename DST>
+__global__ __launch_bounds__(256) void format_kernel(FormatArgs a)
+{
+    const int c = blockIdx.z;
+    const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x0 >= a.w[c] || y >= a.h[c]) return;
+    const SRC *s = reinterpret_cast<const SRC *>(a.src[c] + (size_t)y * a.spitch[c]);
+    DST *d = reinterpret_cast<DST *>(a.dst[c] + (size_t)y * a.dpitch[c]);
+    const bool shiftonly = c != 0 || !a.full_range;
+    const int up = a.ddepth - a.sdepth;
+    for (int i = 0; i < 4 && x0 + i < a.w[c]; i++)
+    {
+        const int x = x0 + i;
+        const unsigned v = s[x];
+        unsigned o;
+        if (up == 0) o = v;
+        else if (up > 0) o = shiftonly ? v << up : (v << up) | (v >> (2 * a.sdepth - a.ddepth));
+        else
+        {
+            const int shift = -up;
+            // dithers[shift - 1][y & 7][x & 7] of swscale_unscaled.c for shift 2 / 4 (2x2 / 4x4 ordered matrices)
+            // one nibble per cell: {1,2;3,0} and {4,8,7,11; 12,0,15,3; 6,10,5,9; 14,2,13,1}
+            constexpr uint64_t D4 = 0xB784ull | (0x3F0Cull << 16) | (0x95A6ull << 32) | (0x1D2Eull << 48);
+            const unsigned dm = shift == 2 ? ((0x0321u >> (4 * ((y & 1) * 2 + (x & 1)))) & 15u)
+                                           : (unsigned)((D4 >> (16 * (y & 3) + 4 * (x & 3))) & 15u);
+            const unsigned tmp = (v + dm) >> shift;
+            o = tmp - (tmp >> a.ddepth);
+        }
+        d[x] = (DST)o;
+    }
+}
+
+class FormatFilter : public SimpleFilter
+{
+public:
+    FormatFilter(hbhip_ctx *c, int full) : SimpleFilter(c), full_range(full) {}
+    int process(DevPicture *in, DevPicture *out) override
+    {
+        FormatArgs a;
+        for (int c = 0; c < 3; c++)
+        {
+            a.src[c] = in->plane[c]; a.dst[c] = out->plane[c];
+            a.spitch[c] = in->pitch[c]; a.dpitch[c] = out->pitch[c];
+            a.w[c] = in_geo.pw[c]; a.h[c] = in_geo.ph[c];
+        }
+        a.sdepth = in_geo.depth; a.ddepth = out_geo.depth; a.full_range = full_range;
+        const dim3 grid((a.w[0] + 255) / 256, (a.h[0] + 3) / 4, 3);
+        if (in_geo.bps == 1 && out_geo.bps == 1)      HBHIP_LAUNCH(ctx, "format", (format_kernel<uint8_t, uint8_t>), grid, dim3(64, 4), 0, a);
+        else if (in_geo.bps == 1)                     HBHIP_LAUNCH(ctx, "format", (format_kernel<uint8_t, uint16_t>), grid, dim3(64, 4), 0, a);
+        else if (out_geo.bps == 1)                    HBHIP_LAUNCH(ctx, "format", (format_kernel<uint16_t, uint8_t>), grid, dim3(64, 4), 0, a);
+        else                                          HBHIP_LAUNCH(ctx, "format", (format_kernel<uint16_t, uint16_t>), grid, dim3(64, 4), 0, a);
+        HBHIP_CHECK(ctx, hipGetLastError());
+        return HBHIP_OK;
+    }
+    int full_range;
+};
+
 } // namespace
+
+extern "C" int hbhip_format_create(hbhip_ctx *ctx, int width, int height, int src_depth, int dst_depth,
+                                   int log2_chroma_w, int log2_chroma_h, int full_range, hbhip_filter **out)
+{
+    if (!ctx || !out) return HBHIP_ERR_ARG;
+    *out = nullptr;
+    for (int d : {src_depth, dst_depth})
+        if (d != 8 && d != 10 && d != 12) return HBHIP_ERR_UNSUPPORTED;
+    // the range-stretching dither of full-range luma on the way down is not restated
+    if (dst_depth < src_depth && full_range) return HBHIP_ERR_UNSUPPORTED;
+    if (width < 1 || height < 1) return HBHIP_ERR_ARG;
+    (void)hipSetDevice(ctx->device);
+    FormatFilter *f = new (std::nothrow) FormatFilter(ctx, full_range);
+    if (!f) return HBHIP_ERR_NOMEM;
+    PicGeometry gi, go;
+    gi.set(width, height, src_depth, log2_chroma_w, log2_chroma_h);
+    go.set(width, height, dst_depth, log2_chroma_w, log2_chroma_h);
+    f->configure(gi, go);
+    *out = f;
+    return HBHIP_OK;
+}
 
 extern "C" int hbhip_pad_create(hbhip_ctx *ctx, const hbhip_pad_params *p, int width, int height, int depth,
                                 int log2_chroma_w, int log2_chroma_h, hbhip_filter **out)

@@ -244,6 +244,84 @@ __global__ __launch_bounds__(256) void yadif_ff_kernel(DecombArgs a, int nospati
     *o = (PIX)pred;
 }
 
+// FFmpeg's bwdif as the reference's "Bwdif" filter configures it (deinterlace.c:46 -> vf_bwdif.c; parity
+// unpinned, restated in oracle/decomb_oracle.c:orc_bwdif_plane, which lists where it follows the in-tree
+// Metal port platform/macosx/shaders/bwdif_vt.metal and where the C filter differs from that port).
+// One thread per sample.  field_end = yadif->current_field == YADIF_FIELD_END: the intra (spatial only)
+// filter of the first field of a stream and of the last field of a bob stream.  df = bytes per sample:
+// vf_bwdif.c's mirror tests at the top / bottom rows compare against it, (y + df) < h, y > df - 1, ...
+template <typename PIX>
+__global__ __launch_bounds__(256) void bwdif_kernel(DecombArgs a, int field_end, int clip_max)
+{
+    const DecombPlane &P = a.pl[blockIdx.z];
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= P.w || y >= P.h) return;
+    const int st = P.pitch / (int)sizeof(PIX), df = (int)sizeof(PIX), h = P.h;
+    const size_t at = (size_t)y * st + x;
+    const PIX *cur = reinterpret_cast<const PIX *>(P.cur) + at;
+    PIX *o = reinterpret_cast<PIX *>(P.dst + (size_t)y * P.dst_pitch) + x;
+    if (a.mode == 0 || !((y ^ a.parity) & 1))              // pass-through frame, or a row of the kept field
+    {
+        *o = *cur;
+        return;
+    }
+    constexpr int lf0 = 4309, lf1 = 213, hf0 = 5570, hf1 = 3801, hf2 = 1016, sp0 = 5077, sp1 = 981;
+    if (field_end)
+    {
+        const int prefs = (y + df) < h ? st : -st, mrefs = y > (df - 1) ? -st : st;
+        const int prefs3 = (y + 3 * df) < h ? 3 * st : -st, mrefs3 = y > (3 * df - 1) ? -3 * st : st;
+        const int v = (sp0 * ((int)cur[mrefs] + (int)cur[prefs]) - sp1 * ((int)cur[mrefs3] + (int)cur[prefs3])) >> 13;
+        *o = (PIX)min(max(v, 0), clip_max);
+        return;
+    }
+    const PIX *prev = reinterpret_cast<const PIX *>(P.prev) + at;
+    const PIX *next = reinterpret_cast<const PIX *>(P.next) + at;
+    const PIX *prev2 = a.field_parity ? prev : cur;
+    const PIX *next2 = a.field_parity ? cur : next;
+    const bool edge = (y < 4) || ((y + 5) > h);
+    const int prefs = edge ? ((y + df) < h ? st : -st) : st, mrefs = edge ? (y > (df - 1) ? -st : st) : -st;
+    const int c = cur[mrefs], e = cur[prefs];
+    const int p0 = prev2[0], n0 = next2[0];
+    const int d = (p0 + n0) >> 1;
+    const int td0 = abs(p0 - n0);
+    const int td1 = (abs((int)prev[mrefs] - c) + abs((int)prev[prefs] - e)) >> 1;
+    const int td2 = (abs((int)next[mrefs] - c) + abs((int)next[prefs] - e)) >> 1;
+    int diff = max(max(td0 >> 1, td1), td2);
+    if (!diff)
+    {
+        *o = (PIX)d;
+        return;
+    }
+    const bool spat = edge ? !((y < 2) || ((y + 3) > h)) : true;
+    if (spat)
+    {
+        const int b = (((int)prev2[-2 * st] + (int)next2[-2 * st]) >> 1) - c;
+        const int f = (((int)prev2[2 * st] + (int)next2[2 * st]) >> 1) - e;
+        const int dc = d - c, de = d - e;
+        const int mx = max(max(de, dc), min(b, f));
+        const int mn = min(min(de, dc), max(b, f));
+        diff = max(max(diff, mn), -mx);
+    }
+    int interpol;
+    if (edge)
+        interpol = (c + e) >> 1;
+    else
+    {
+        const int c3 = (int)cur[-3 * st] + (int)cur[3 * st];
+        if (abs(c - e) > td0)
+            interpol = (((hf0 * (p0 + n0)
+                          - hf1 * ((int)prev2[-2 * st] + (int)next2[-2 * st] + (int)prev2[2 * st] + (int)next2[2 * st])
+                          + hf2 * ((int)prev2[-4 * st] + (int)next2[-4 * st] + (int)prev2[4 * st] + (int)next2[4 * st])) >> 2)
+                        + lf0 * (c + e) - lf1 * c3) >> 13;
+        else
+            interpol = (sp0 * (c + e) - sp1 * c3) >> 13;
+    }
+    if (interpol > d + diff) interpol = d + diff;
+    else if (interpol < d - diff) interpol = d - diff;
+    *o = (PIX)min(max(interpol, 0), clip_max);
+}
+
 class DecombFilter : public hbhip_filter
 {
 public:
@@ -337,6 +415,7 @@ public:
         {
             store_ref(ref[2]);                 // duplicate the last frame (decomb.c:584-589)
             flushed = true;
+            if (ff_bwdif) bw_field = BW_BACK_END;          // ff_yadif_request_frame at EOF
             return process_frame();
         }
         return HBHIP_OK;
@@ -395,6 +474,18 @@ private:
         a.mode = mode; a.parity = parity; a.field_parity = parity ^ tff;
         dim3 block(64, 4), grid((in_geo.pw[0] + 63) / 64, (in_geo.ph[0] + 3) / 4, 3);
         const int maxv = (1 << in_geo.depth) - 1;
+        if (ff_bwdif)
+        {
+            // yadif->current_field (yadif_common.c, vf_bwdif.c:filter): BACK_END becomes END at the second
+            // field; END selects the intra filter and is consumed by the first field that is filtered
+            if (bw_second && bw_field == BW_BACK_END) bw_field = BW_END;
+            const int field_end = mode != 0 && bw_field == BW_END;
+            if (in_geo.bps == 2) HBHIP_LAUNCH(ctx, "bwdif", bwdif_kernel<uint16_t>, grid, block, 0, a, field_end, maxv);
+            else                 HBHIP_LAUNCH(ctx, "bwdif", bwdif_kernel<uint8_t>, grid, block, 0, a, field_end, maxv);
+            if (mode != 0 && bw_field == BW_END) bw_field = BW_NORMAL;
+            HBHIP_CHECK(ctx, hipGetLastError());
+            return HBHIP_OK;
+        }
         if (ff_yadif)
         {
             if (in_geo.bps == 2) HBHIP_LAUNCH(ctx, "yadif", yadif_ff_kernel<uint16_t>, grid, block, 0, a, ff_nospatial);
@@ -417,6 +508,7 @@ private:
             DevPicture *o = pool.acquire();
             if (!o) return HBHIP_ERR_NOMEM;
             o->tag = cur->tag << 1; o->aux = 0;
+            bw_second = false;
             int rc = launch(o, 0, 0, 0);       // plain copy of ref[1]
             if (rc != HBHIP_OK) return rc;
             outq.push_back(o);
@@ -469,6 +561,7 @@ private:
             DevPicture *o = pool.acquire();
             if (!o) return HBHIP_ERR_NOMEM;
             o->tag = (cur->tag << 1) | frame; o->aux = frame;
+            bw_second = frame == 1;
             int rc = launch(o, mode, parity, tff, e);
             if (rc != HBHIP_OK) return rc;
             outq.push_back(o);
@@ -478,6 +571,10 @@ private:
 
 public:
     bool ff_yadif = false;      // FFmpeg's yadif instead of decomb's line filters (hbhip_yadif_create)
+    bool ff_bwdif = false;      // FFmpeg's bwdif (hbhip_bwdif_create); implies ff_yadif's frame / flag handling
+    enum { BW_NORMAL = 0, BW_END = 1, BW_BACK_END = 2 };
+    int  bw_field = BW_END;     // yadif->current_field: END from the first frame on until a field is filtered
+    bool bw_second = false;
     int  ff_nospatial = 0;      // send_frame_nospatial / send_field_nospatial
 private:
     hbhip_decomb_params par;
@@ -543,6 +640,18 @@ extern "C" int hbhip_yadif_create(hbhip_ctx *ctx, int spatial_check, int bob, in
         return rc;
     }
     *out = f;
+    return HBHIP_OK;
+}
+
+extern "C" int hbhip_bwdif_create(hbhip_ctx *ctx, int bob, int selective, int parity,
+                                  int width, int height, int depth, int log2_chroma_w, int log2_chroma_h,
+                                  hbhip_filter **out)
+{
+    // same frame ring / parity / selection as the yadif object; only the line filter and its
+    // current_field state differ
+    int rc = hbhip_yadif_create(ctx, 1, bob, selective, parity, width, height, depth, log2_chroma_w, log2_chroma_h, out);
+    if (rc != HBHIP_OK) return rc;
+    static_cast<DecombFilter *>(*out)->ff_bwdif = true;
     return HBHIP_OK;
 }
 

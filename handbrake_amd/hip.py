@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "hbhip_comb_detect_create", "hbhip_comb_detect_set_gamma_lut", "hbhip_comb_detect_store",
     "hbhip_comb_detect_store_dev",
     "hbhip_comb_detect_classify",
-    "hbhip_rotate_create", "hbhip_grayscale_create", "hbhip_cropscale_create", "hbhip_colorspace_create", "hbhip_pad_create", "hbhip_yadif_create",
+    "hbhip_rotate_create", "hbhip_grayscale_create", "hbhip_cropscale_create", "hbhip_colorspace_create", "hbhip_pad_create", "hbhip_yadif_create", "hbhip_bwdif_create", "hbhip_format_create",
     "hbhip_blend_create", "hbhip_blend_set_overlays", "hbhip_blend_apply", "hbhip_blend_apply_dev", "hbhip_blend_destroy",
     "hbhip_motion_metric_create", "hbhip_motion_metric_run", "hbhip_motion_metric_run_dev", "hbhip_motion_metric_destroy",
 ]

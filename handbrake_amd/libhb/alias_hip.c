@@ -218,3 +218,70 @@ static int rotate_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init)
     pv->output = *init;
     return 0;
 }
+
+/* ---- format (libhb/format.c:13-111) -------------------------------------------------------------
+ * In the reference this object has .skip = 1: format_init only writes `format=pix_fmts=<name>` for
+ * libavfilter (:97-100) and sets init->pix_fmt (:107); the conversion itself is the `scale` filter
+ * libavfilter auto-inserts, i.e. libswscale.  work.c adds it when the encoder wants another pixel format
+ * than the pipeline's (work.c:1530-1549), typically 8 <-> 10 bits.  Here it is a real filter for what that
+ * use needs - planar YUV depth changes with the subsampling unchanged (csrc/alias.hip:format_kernel,
+ * parity unpinned); any other target (different subsampling, semi-planar, RGB) makes init() fail, which
+ * keeps the CPU filter (work.c:1861-1868). */
+static int format_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init);
+static int format_hip_work(hb_filter_object_t *filter, hb_buffer_t **buf_in, hb_buffer_t **buf_out);
+
+static const char format_hip_template[] = "format=^"HB_ALL_REG"$";
+
+hb_filter_object_t hb_filter_format_hip =
+{
+    .id                = HB_FILTER_FORMAT,
+    .enforce_order     = 1,
+    .name              = "Format (HIP)",
+    .short_name        = "format",
+    .settings          = NULL,
+    .init              = format_hip_init,
+    .work              = format_hip_work,
+    .close             = alias_hip_close,
+    .settings_template = format_hip_template,
+};
+
+static int format_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init)
+{
+    const AVPixFmtDescriptor *desc;
+    hb_filter_private_t *pv = alias_begin(filter, init, &desc);
+    if (pv == NULL) return 1;
+    char *format = NULL;
+    hb_dict_extract_string(&format, filter->settings, "format");              /* format.c:46-52 */
+    if (format == NULL)
+    {
+        pv->output = *init;                                                   /* nothing to do: frames pass through */
+        return 0;
+    }
+    const int dst_fmt = av_get_pix_fmt(format);                               /* :107 */
+    free(format);
+    const AVPixFmtDescriptor *dd = av_pix_fmt_desc_get(dst_fmt);
+    if (dd == NULL || dd->nb_components != desc->nb_components || desc->nb_components < 3 ||
+        dd->log2_chroma_w != desc->log2_chroma_w || dd->log2_chroma_h != desc->log2_chroma_h)
+        return alias_fail(filter, HBHIP_ERR_UNSUPPORTED);
+    hbhip_ctx *ctx = hbhip_host_ctx();
+    if (ctx == NULL) return alias_fail(filter, HBHIP_ERR_NODEVICE);
+    int rc = hbhip_format_create(ctx, init->geometry.width, init->geometry.height, desc->comp[0].depth,
+                                 dd->comp[0].depth, desc->log2_chroma_w, desc->log2_chroma_h,
+                                 init->color_range == 2 /* AVCOL_RANGE_JPEG */, &pv->dev);
+    if (rc != HBHIP_OK) return alias_fail(filter, rc);
+    init->pix_fmt = dst_fmt;
+    pv->output = *init;
+    return 0;
+}
+
+static int format_hip_work(hb_filter_object_t *filter, hb_buffer_t **buf_in, hb_buffer_t **buf_out)
+{
+    hb_filter_private_t *pv = filter->private_data;
+    if (pv->dev == NULL)
+    {
+        *buf_out = *buf_in;
+        *buf_in = NULL;
+        return ((*buf_out)->s.flags & HB_BUF_FLAG_EOF) ? HB_FILTER_DONE : HB_FILTER_OK;
+    }
+    return hbhip_host_simple_work(pv->dev, &pv->output, filter->short_name, pv->dev_io, buf_in, buf_out);
+}

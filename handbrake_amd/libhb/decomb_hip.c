@@ -255,7 +255,29 @@ hb_filter_object_t hb_filter_yadif_hip =
 #define YADIF_BOB       4
 #define YADIF_SELECTIVE 8
 
-static int yadif_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init)
+static int deint_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init, int is_yadif);
+static int yadif_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init) { return deint_hip_init(filter, init, 1); }
+static int bwdif_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init) { return deint_hip_init(filter, init, 0); }
+
+/* ---- Bwdif = FFmpeg bwdif (libhb/deinterlace.c:46: the same macro instantiates hb_filter_bwdif, and
+ * deinterlace_init :72-143 configures it like yadif except that the spatial bit only exists for yadif,
+ * :98-122).  Real filter on the decomb frame ring like the yadif object above; line filters of vf_bwdif.c
+ * (csrc/decomb.hip:bwdif_kernel, parity unpinned), including yadif_common.c's current_field bookkeeping:
+ * the first field of the stream and - in bob mode - the last one are filtered spatially only. */
+hb_filter_object_t hb_filter_bwdif_hip =
+{
+    .id                = HB_FILTER_BWDIF,
+    .enforce_order     = 1,
+    .name              = "Bwdif (HIP)",
+    .short_name        = "bwdif",
+    .settings          = NULL,
+    .init              = bwdif_hip_init,
+    .work              = decomb_hip_work,
+    .close             = decomb_hip_close,
+    .settings_template = yadif_hip_template,
+};
+
+static int deint_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init, int is_yadif)
 {
     hb_filter_private_t *pv = calloc(1, sizeof(*pv));
     if (pv == NULL) return -1;
@@ -280,12 +302,15 @@ static int yadif_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init)
     const AVPixFmtDescriptor *desc = av_pix_fmt_desc_get(init->pix_fmt);
     hbhip_ctx *ctx = desc != NULL ? hbhip_host_ctx() : NULL;
     int rc = ctx == NULL ? HBHIP_ERR_NODEVICE
-                         : hbhip_yadif_create(ctx, !!(mode & YADIF_SPATIAL), !!(mode & YADIF_BOB), pv->selective, parity,
+           : is_yadif    ? hbhip_yadif_create(ctx, !!(mode & YADIF_SPATIAL), !!(mode & YADIF_BOB), pv->selective, parity,
+                                              init->geometry.width, init->geometry.height, desc->comp[0].depth,
+                                              desc->log2_chroma_w, desc->log2_chroma_h, &pv->dev)
+                         : hbhip_bwdif_create(ctx, !!(mode & YADIF_BOB), pv->selective, parity,
                                               init->geometry.width, init->geometry.height, desc->comp[0].depth,
                                               desc->log2_chroma_w, desc->log2_chroma_h, &pv->dev);
     if (rc != HBHIP_OK)
     {
-        hb_error("deinterlace(hip): %s", hbhip_strerror(rc));
+        hb_error("%s(hip): %s", is_yadif ? "deinterlace" : "bwdif", hbhip_strerror(rc));
         free(pv);
         filter->private_data = NULL;
         return -1;

@@ -102,6 +102,23 @@ const AVPixFmtDescriptor *av_pix_fmt_desc_get(int pix_fmt)
     }
 }
 
+int av_get_pix_fmt(const char *name)
+{
+    static const int known[] = { AV_PIX_FMT_YUV420P, AV_PIX_FMT_YUV422P, AV_PIX_FMT_YUV444P, AV_PIX_FMT_GRAY8,
+                                 AV_PIX_FMT_YUVA420P, AV_PIX_FMT_YUVA422P, AV_PIX_FMT_YUVA444P,
+                                 AV_PIX_FMT_YUV420P10LE, AV_PIX_FMT_YUV420P12LE };
+    if (name == NULL) return AV_PIX_FMT_NONE;
+    for (size_t i = 0; i < sizeof(known) / sizeof(known[0]); i++)
+    {
+        const AVPixFmtDescriptor *d = av_pix_fmt_desc_get(known[i]);
+        if (strcmp(d->name, name) == 0) return known[i];
+        /* native-endian aliases: "yuv420p10" == "yuv420p10le" here */
+        const size_t n = strlen(name);
+        if (strlen(d->name) == n + 2 && strncmp(d->name, name, n) == 0 && strcmp(d->name + n, "le") == 0) return known[i];
+    }
+    return AV_PIX_FMT_NONE;
+}
+
 int av_pix_fmt_count_planes(int pix_fmt)
 {
     const AVPixFmtDescriptor *d = av_pix_fmt_desc_get(pix_fmt);

@@ -83,6 +83,8 @@ extern hb_filter_object_t hb_filter_rotate_hip;
 extern hb_filter_object_t hb_filter_colorspace_hip;
 extern hb_filter_object_t hb_filter_pad_hip;
 extern hb_filter_object_t hb_filter_yadif_hip;
+extern hb_filter_object_t hb_filter_bwdif_hip;
+extern hb_filter_object_t hb_filter_format_hip;
 /* the subtitle compositor object rendersub.c can use in place of hb_blend (blend.c:40-46) */
 extern hb_blend_object_t  hb_blend_hip;
 /* the frame-difference metric object vfr.c can use in place of hb_motion_metric (motion_metric.c:306-312) */

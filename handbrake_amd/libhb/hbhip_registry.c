@@ -70,6 +70,8 @@ hb_filter_object_t *hbhip_filter_get(int filter_id)
         case HB_FILTER_COLORSPACE:    return &hb_filter_colorspace_hip;
         case HB_FILTER_PAD:           return &hb_filter_pad_hip;
         case HB_FILTER_YADIF:         return &hb_filter_yadif_hip;
+        case HB_FILTER_BWDIF:         return &hb_filter_bwdif_hip;
+        case HB_FILTER_FORMAT:        return &hb_filter_format_hip;
         case HB_FILTER_DECOMB:        return &hb_filter_decomb_hip;
         case HB_FILTER_COMB_DETECT:   return &hb_filter_comb_detect_hip;
         case HB_FILTER_HIP_UPLOAD:    return &hb_filter_hip_upload;

@@ -232,6 +232,13 @@ int hbhip_decomb_push_dev(hbhip_filter *f, const hbhip_dev_frame *in, int64_t ta
 int hbhip_yadif_create(hbhip_ctx *ctx, int spatial_check, int bob, int selective, int parity,
                        int width, int height, int depth, int log2_chroma_w, int log2_chroma_h,
                        hbhip_filter **out);
+/* The reference's "Bwdif" filter = FFmpeg bwdif as deinterlace_init configures it (deinterlace.c:46, 72-143; the
+ * spatial bit is yadif-only, :98-122): bob = send_field, selective = deint=interlaced, parity as above.  Same
+ * push / pull surface as hbhip_yadif_create.  Arithmetic of vf_bwdif.c, parity unpinned
+ * (oracle/decomb_oracle.c:orc_bwdif_plane, which follows platform/macosx/shaders/bwdif_vt.metal where the two agree). */
+int hbhip_bwdif_create(hbhip_ctx *ctx, int bob, int selective, int parity,
+                       int width, int height, int depth, int log2_chroma_w, int log2_chroma_h,
+                       hbhip_filter **out);
 /* Test hook: copy one plane of an EEDI2 scratch frame to the host (buffer 0..3 = eedi_half[],
  * 4..8 = eedi_full[], decomb.c:64-74); dst == NULL only queries stride/height. */
 int hbhip_decomb_debug_eedi_plane(hbhip_filter *f, int buffer, int plane, uint8_t *dst, int dst_stride,
@@ -285,6 +292,13 @@ typedef struct hbhip_pad_params
 } hbhip_pad_params;
 int hbhip_pad_create(hbhip_ctx *ctx, const hbhip_pad_params *p, int width, int height, int depth,
                      int log2_chroma_w, int log2_chroma_h, hbhip_filter **out);
+/* `format=pix_fmts=<fmt>` as format_init sets it up (format.c:13-111): libavfilter then converts with a same-size
+ * `scale`, i.e. libswscale's unscaled planar copy.  Built: planar YUV depth changes 8 / 10 / 12 -> 8 / 10 / 12 with the
+ * chroma subsampling unchanged (up: shift, full-range luma replicates the top bits; down: ordered dither, limited
+ * range only - full-range down conversion returns HBHIP_ERR_UNSUPPORTED).  Arithmetic pinned to
+ * oracle/alias_oracle.c:orc_format_plane only (parity unpinned). */
+int hbhip_format_create(hbhip_ctx *ctx, int width, int height, int src_depth, int dst_depth,
+                        int log2_chroma_w, int log2_chroma_h, int full_range, hbhip_filter **out);
 /* The zscale [-> format=gbrpf32le -> tonemap] -> zscale -> format graph colorspace_init builds
  * (colorspace.c:126-193): matrix / range / transfer / primaries conversion, with tone mapping
  * when the source transfer is SMPTE 2084 or ARIB STD-B67 and the transfer changes.  Colour ids

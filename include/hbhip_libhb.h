@@ -108,6 +108,7 @@ typedef struct AVPixFmtDescriptor
 } AVPixFmtDescriptor;
 
 const AVPixFmtDescriptor *av_pix_fmt_desc_get(int pix_fmt);
+int av_get_pix_fmt(const char *name);                 /* libavutil/pixdesc.h; AV_PIX_FMT_NONE when unknown */
 int  av_pix_fmt_count_planes(int pix_fmt);
 enum { AVCHROMA_LOC_UNSPECIFIED = 0, AVCHROMA_LOC_LEFT, AVCHROMA_LOC_CENTER, AVCHROMA_LOC_TOPLEFT,
        AVCHROMA_LOC_TOP, AVCHROMA_LOC_BOTTOMLEFT, AVCHROMA_LOC_BOTTOM };

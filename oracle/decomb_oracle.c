@@ -126,3 +126,103 @@ void orc_yadif_ff_plane(const void *prev, const void *cur, const void *next, int
             else          ((uint16_t *)dst)[(long)y * dstp + x] = (uint16_t)out;
         }
 }
+
+/* ---- FFmpeg bwdif, the reference's "Bwdif" filter (deinterlace.c:46 -> libavfilter vf_bwdif.c; PARITY UNPINNED) --
+ * libavfilter is not in the reference tree (FFmpeg 9.0.1, contrib/ffmpeg/module.defs:15-17).  This restates
+ * vf_bwdif.c's C line filters (filter_intra / filter_line / filter_edge and the row dispatch of filter_slice)
+ * from the published algorithm, in integers as the CPU filter computes.  The reference tree holds a second
+ * restatement, platform/macosx/shaders/bwdif_vt.metal (a port of vf_bwdif_cuda), which this follows
+ * operation for operation where the two agree:
+ *   coefficients                         metal :67-69   = coef_lf / coef_hf / coef_sp
+ *   intra (field-end) filter             metal :71-78   = FILTER_INTRA
+ *   temporal differences, d, `!diff`     metal :89-99   = FILTER1
+ *   vertical-neighbour widening          metal :101-107 = SPAT_CHECK
+ *   high-frequency / spatial interpol    metal :110-117 = FILTER_LINE
+ *   clamp to d +- diff, clip             metal :119-124 = FILTER2
+ *   prev2/prev1/next1/next2 choice       metal :152-156 = `prev2 = parity ? prev : cur; next2 = parity ? cur : next`
+ * and departs from it where the Metal port departs from the C filter: (i) integer >> instead of float
+ * division; (ii) the last high-frequency tap is next2[prefs4] (the shader repeats next2_mrefs4, :113);
+ * (iii) the C filter has explicit edge rows: y < 4 or y + 5 > h use filter_edge ((c + e) >> 1, with the
+ * vertical check only where rows y +- 2 exist), and rows whose +-1 / +-3 neighbours fall outside are
+ * mirrored with vf_bwdif.c's own tests, which compare against the sample SIZE df:
+ * (y + df) < h, y > df - 1, (y + 3 df) < h, y > 3 df - 1.
+ * field_end = yadif->current_field == YADIF_FIELD_END (first field of a stream, last field of a bob stream). */
+void orc_bwdif_plane(const void *prev, const void *cur, const void *next, int stride, int w, int h,
+                     void *dst, int dst_stride, int parity, int tff, int field_end, int bps, int depth)
+{
+    static const int coef_lf[2] = { 4309, 213 }, coef_hf[3] = { 5570, 3801, 1016 }, coef_sp[2] = { 5077, 981 };
+    const int st = stride / bps, dstp = dst_stride / bps, df = bps;
+    const int clip_max = (1 << depth) - 1;
+    const int fp = parity ^ tff;
+    const void *prev2 = fp ? prev : cur, *next2 = fp ? cur : next;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+        {
+            const long at = (long)y * st + x;
+            int out;
+            if (!((y ^ parity) & 1))
+                out = yd_px(cur, at, bps);
+            else if (field_end)
+            {
+                const int prefs = (y + df) < h ? st : -st, mrefs = y > (df - 1) ? -st : st;
+                const int prefs3 = (y + 3 * df) < h ? 3 * st : -st, mrefs3 = y > (3 * df - 1) ? -3 * st : st;
+                int interpol = (coef_sp[0] * (yd_px(cur, at + mrefs, bps) + yd_px(cur, at + prefs, bps)) -
+                                coef_sp[1] * (yd_px(cur, at + mrefs3, bps) + yd_px(cur, at + prefs3, bps))) >> 13;
+                out = interpol < 0 ? 0 : interpol > clip_max ? clip_max : interpol;
+            }
+            else
+            {
+                const int edge = (y < 4) || ((y + 5) > h);
+                const int prefs = edge ? ((y + df) < h ? st : -st) : st, mrefs = edge ? (y > (df - 1) ? -st : st) : -st;
+                const int prefs2 = 2 * st, mrefs2 = -2 * st;
+                const int c = yd_px(cur, at + mrefs, bps), e = yd_px(cur, at + prefs, bps);
+                const int p0 = yd_px(prev2, at, bps), n0 = yd_px(next2, at, bps);
+                const int d = (p0 + n0) >> 1;
+                const int td0 = abs(p0 - n0);
+                const int td1 = (abs(yd_px(prev, at + mrefs, bps) - c) + abs(yd_px(prev, at + prefs, bps) - e)) >> 1;
+                const int td2 = (abs(yd_px(next, at + mrefs, bps) - c) + abs(yd_px(next, at + prefs, bps) - e)) >> 1;
+                int diff = td0 >> 1;
+                if (td1 > diff) diff = td1;
+                if (td2 > diff) diff = td2;
+                if (!diff)
+                    out = d;
+                else
+                {
+                    const int spat = edge ? !((y < 2) || ((y + 3) > h)) : 1;
+                    if (spat)
+                    {
+                        const int b = ((yd_px(prev2, at + mrefs2, bps) + yd_px(next2, at + mrefs2, bps)) >> 1) - c;
+                        const int f = ((yd_px(prev2, at + prefs2, bps) + yd_px(next2, at + prefs2, bps)) >> 1) - e;
+                        const int dc = d - c, de = d - e;
+                        int mx = de > dc ? de : dc, mn = de < dc ? de : dc;
+                        const int lo = b < f ? b : f, hi = b > f ? b : f;
+                        if (lo > mx) mx = lo;
+                        if (hi < mn) mn = hi;
+                        if (mn > diff) diff = mn;
+                        if (-mx > diff) diff = -mx;
+                    }
+                    int interpol;
+                    if (edge)
+                        interpol = (c + e) >> 1;
+                    else
+                    {
+                        const int c3 = yd_px(cur, at - 3 * st, bps) + yd_px(cur, at + 3 * st, bps);
+                        if (abs(c - e) > td0)
+                            interpol = (((coef_hf[0] * (p0 + n0)
+                                          - coef_hf[1] * (yd_px(prev2, at + mrefs2, bps) + yd_px(next2, at + mrefs2, bps) +
+                                                          yd_px(prev2, at + prefs2, bps) + yd_px(next2, at + prefs2, bps))
+                                          + coef_hf[2] * (yd_px(prev2, at - 4 * st, bps) + yd_px(next2, at - 4 * st, bps) +
+                                                          yd_px(prev2, at + 4 * st, bps) + yd_px(next2, at + 4 * st, bps))) >> 2)
+                                        + coef_lf[0] * (c + e) - coef_lf[1] * c3) >> 13;
+                        else
+                            interpol = (coef_sp[0] * (c + e) - coef_sp[1] * c3) >> 13;
+                    }
+                    if (interpol > d + diff) interpol = d + diff;
+                    else if (interpol < d - diff) interpol = d - diff;
+                    out = interpol < 0 ? 0 : interpol > clip_max ? clip_max : interpol;
+                }
+            }
+            if (bps == 1) ((uint8_t *)dst)[(long)y * dstp + x] = (uint8_t)out;
+            else          ((uint16_t *)dst)[(long)y * dstp + x] = (uint16_t)out;
+        }
+}

@@ -275,6 +275,15 @@ const uint16_t *orc_eedi2_16_plane(orc_eedi2_16_t *e, int buffer, int plane, int
 void orc_yadif_ff_plane(const void *prev, const void *cur, const void *next, int stride, int w, int h,
                         void *dst, int dst_stride, int parity, int tff, int nospatial, int bps);
 
+/* ---- format=pix_fmts (format.c:13-111 -> libswscale unscaled planar copy; PARITY UNPINNED) ------------ */
+int orc_format_plane(const void *src, int sstride, int sdepth, void *dst, int dstride, int ddepth,
+                     int w, int h, int plane, int full_range);
+
+/* ---- FFmpeg bwdif, the reference's "Bwdif" filter (deinterlace.c:46 -> vf_bwdif.c; PARITY UNPINNED; follows
+ *      platform/macosx/shaders/bwdif_vt.metal where that port agrees with the C filter) ------------------- */
+void orc_bwdif_plane(const void *prev, const void *cur, const void *next, int stride, int w, int h,
+                     void *dst, int dst_stride, int parity, int tff, int field_end, int bps, int depth);
+
 /* ---- frame-difference metric of vfr (motion_metric.c) -------------------------------------- */
 /* The scaled 2.2-gamma table (1 << depth entries), :36-42. */
 void  orc_motion_gamma_lut(unsigned *lut, int depth);

@@ -566,6 +566,32 @@ def orc_yadif_ff_plane(prev, cur, nxt, parity, tff, nospatial):
     return dst
 
 
+def orc_format_frame(frame, sdepth, ddepth, full_range=False):
+    fn = oracle().orc_format_plane
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    out = []
+    for c, p in enumerate(frame):
+        p = np.ascontiguousarray(p)
+        h, w = p.shape
+        dst = np.zeros((h, w), np.uint8 if ddepth == 8 else np.uint16)
+        rc = fn(p.ctypes.data, p.strides[0], sdepth, dst.ctypes.data, dst.strides[0], ddepth, w, h, c, int(full_range))
+        assert rc == 0, "conversion not restated"
+        out.append(dst)
+    return tuple(out)
+
+
+def orc_bwdif_plane(prev, cur, nxt, parity, tff, field_end, depth=8):
+    fn = oracle().orc_bwdif_plane
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    p, c, n = [np.ascontiguousarray(a) for a in (prev, cur, nxt)]
+    h, w = c.shape
+    dst = np.zeros_like(c)
+    fn(p.ctypes.data, c.ctypes.data, n.ctypes.data, c.strides[0], w, h, dst.ctypes.data, dst.strides[0],
+       int(parity), int(tff), int(field_end), c.itemsize, depth)
+    return dst
+
+
 class OrcEedi2_16:
     """The 16-bit EEDI2 restatement (oracle/eedi2_16_oracle.c); planes are uint16, depth 10 / 12."""
 

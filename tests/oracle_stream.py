@@ -227,7 +227,8 @@ def cropscale_stream(frames, par):
 STREAMS.update({"rotate": rotate_stream, "grayscale": grayscale_stream, "cropscale": cropscale_stream})
 
 
-def yadif_stream(frames, mode=3, parity_opt=-1, flags=PIC_FLAG_TOP_FIELD_FIRST, combed=None, duration=3003):
+def yadif_stream(frames, mode=3, parity_opt=-1, flags=PIC_FLAG_TOP_FIELD_FIRST, combed=None, duration=3003,
+                 bwdif=False, depth=8):
     """The reference's Deinterlace filter = FFmpeg yadif as deinterlace.c:72-143 configures it.
     mode bits: 1 enable, 2 spatial check, 4 bob (send_field), 8 selective (deint=interlaced: only
     frames with s.combed set).  Frame sequencing of yadif_common.c: frame t is filtered from
@@ -237,6 +238,11 @@ def yadif_stream(frames, mode=3, parity_opt=-1, flags=PIC_FLAG_TOP_FIELD_FIRST, 
     out = []
     if not (mode & 1):
         return [dict(planes=fr, start=i * duration, stop=(i + 1) * duration) for i, fr in enumerate(frames)]
+    # bwdif: yadif->current_field (yadif_common.c / vf_bwdif.c).  FIELD_END from the first frame on until the
+    # first field that is really filtered (intra filter); the flushed last frame arrives with BACK_END, which
+    # its SECOND field turns into FIELD_END (bob only) - the last field of a bob stream is intra filtered too.
+    END, BACK_END, NORMAL = 1, 2, 0
+    field_state = END
     for t in range(n):
         prev, cur, nxt = frames[max(t - 1, 0)], frames[t], frames[min(t + 1, n - 1)]
         cmb = 2 if combed is None else combed[t]
@@ -249,10 +255,20 @@ def yadif_stream(frames, mode=3, parity_opt=-1, flags=PIC_FLAG_TOP_FIELD_FIRST, 
         else:
             tff = (parity_opt & 1) ^ 1
         made = []
+        if t == n - 1:
+            field_state = BACK_END
         for field in range(2 if (mode & 4) else 1):
             parity = field ^ tff ^ 1
-            made.append(dict(planes=tuple(ol.orc_yadif_ff_plane(prev[c], cur[c], nxt[c], parity, tff, not (mode & 2))
-                                          for c in range(3)), start=start, stop=stop))
+            if bwdif:
+                if field == 1 and field_state == BACK_END:
+                    field_state = END
+                planes = tuple(ol.orc_bwdif_plane(prev[c], cur[c], nxt[c], parity, tff, field_state == END, depth)
+                               for c in range(3))
+                if field_state == END:
+                    field_state = NORMAL
+            else:
+                planes = tuple(ol.orc_yadif_ff_plane(prev[c], cur[c], nxt[c], parity, tff, not (mode & 2)) for c in range(3))
+            made.append(dict(planes=planes, start=start, stop=stop))
         if mode & 4:
             made[0]["stop"] -= (made[0]["stop"] - made[0]["start"]) // 2
             made[1]["start"] = made[0]["stop"]

@@ -46,7 +46,7 @@ def test_filter_objects_registered(built):
         assert C.c_int.in_dll(F, sym).value == fid          # .id is the first field
 
 
-NEW_FILTERS = ["hb_filter_colorspace_hip", "hb_filter_pad_hip", "hb_filter_yadif_hip"]
+NEW_FILTERS = ["hb_filter_colorspace_hip", "hb_filter_pad_hip", "hb_filter_yadif_hip", "hb_filter_bwdif_hip"]
 
 
 def test_later_filter_objects_registered(built):

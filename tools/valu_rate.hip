@@ -52,6 +52,42 @@
 #define OP_RCPF(r)    "v_rcp_f32 " r ", " r "\n"
 #define OP_CNDMASK(r) "v_cndmask_b32 " r ", " r ", %8, vcc\n"
 #define OP_CMP(r)     "v_cmp_lt_u32 vcc, " r ", %8\n"
+#define OP_MINF(r)    "v_min_f32 " r ", " r ", %8\n"
+#define OP_MAXF(r)    "v_max_f32 " r ", " r ", %8\n"
+#define OP_SUBF(r)    "v_sub_f32 " r ", " r ", %8\n"
+#define OP_MAC(r)     "v_fmac_f32 " r ", " r ", %8\n"
+#define OP_MED3(r)    "v_med3_i32 " r ", " r ", %8, %8\n"
+#define OP_MAXU(r)    "v_max_u32 " r ", " r ", %8\n"
+#define OP_MINI(r)    "v_min_i32 " r ", " r ", %8\n"
+#define OP_OR(r)      "v_or_b32 " r ", " r ", %8\n"
+#define OP_XOR(r)     "v_xor_b32 " r ", " r ", %8\n"
+#define OP_MOV(r)     "v_mov_b32 " r ", %8\n"
+#define OP_MOVDPP(r)  "v_mov_b32_dpp " r ", %8 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+#define OP_LSHR(r)    "v_lshrrev_b32 " r ", 1, " r "\n"
+#define OP_ASHR(r)    "v_ashrrev_i32 " r ", 1, " r "\n"
+#define OP_ADDCO(r)   "v_add_co_u32 " r ", vcc, " r ", %8\n"
+#define OP_SUBREV(r)  "v_subrev_u32 " r ", " r ", %8\n"
+#define OP_LSHLADD(r) "v_lshl_add_u32 " r ", " r ", 1, %8\n"
+#define OP_ADDLSHL(r) "v_add_lshl_u32 " r ", " r ", %8, 1\n"
+#define OP_ANDOR(r)   "v_and_or_b32 " r ", " r ", %8, %8\n"
+#define OP_BFI(r)     "v_bfi_b32 " r ", " r ", %8, %8\n"
+#define OP_MULI24(r)  "v_mul_i32_i24 " r ", " r ", %8\n"
+#define OP_MADI16(r)  "v_mad_i32_i16 " r ", " r ", %8, " r "\n"
+#define OP_MADU16(r)  "v_mad_u32_u16 " r ", " r ", %8, " r "\n"
+#define OP_DOT2(r)    "v_dot2_u32_u16 " r ", " r ", %8, " r "\n"
+#define OP_DOT4I(r)   "v_dot4_i32_i8 " r ", " r ", %8, " r "\n"
+#define OP_PKADD16(r) "v_pk_add_u16 " r ", " r ", %8\n"
+#define OP_PKSUB16(r) "v_pk_sub_i16 " r ", " r ", %8\n"
+#define OP_PKMUL16(r) "v_pk_mul_lo_u16 " r ", " r ", %8\n"
+#define OP_PKMAD16(r) "v_pk_mad_u16 " r ", " r ", %8, " r "\n"
+#define OP_PKMIN16(r) "v_pk_min_u16 " r ", " r ", %8\n"
+#define OP_CVTUB2(r)  "v_cvt_f32_ubyte2 " r ", " r "\n"
+#define OP_CVTPKU8(r) "v_cvt_pk_u8_f32 " r ", " r ", 1, %8\n"
+#define OP_CVTI32(r)  "v_cvt_i32_f32 " r ", " r "\n"
+#define OP_SADU16(r)  "v_sad_u16 " r ", " r ", %8, " r "\n"
+#define OP_MSAD(r)    "v_msad_u8 " r ", " r ", %8, " r "\n"
+#define OP_SDWAADD(r) "v_add_u32_sdwa " r ", " r ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
+#define OP_SDWAMUL(r) "v_mul_u32_u24_sdwa " r ", " r ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0\n"
 // 64-bit register classes
 #define OP_PKMUL(r)   "v_pk_mul_f32 " r ", " r ", %8\n"
 #define OP_PKADD(r)   "v_pk_add_f32 " r ", " r ", %8\n"
@@ -127,6 +163,42 @@ DEFINE_KERNEL(k_fma_f32, uint32_t, OP_FMAF)
 DEFINE_KERNEL(k_rcp_f32, uint32_t, OP_RCPF)
 DEFINE_KERNEL(k_cndmask, uint32_t, OP_CNDMASK)
 DEFINE_KERNEL(k_cmp, uint32_t, OP_CMP)
+DEFINE_KERNEL(k_min_f32, uint32_t, OP_MINF)
+DEFINE_KERNEL(k_max_f32, uint32_t, OP_MAXF)
+DEFINE_KERNEL(k_sub_f32, uint32_t, OP_SUBF)
+DEFINE_KERNEL(k_fmac_f32, uint32_t, OP_MAC)
+DEFINE_KERNEL(k_med3, uint32_t, OP_MED3)
+DEFINE_KERNEL(k_max_u32, uint32_t, OP_MAXU)
+DEFINE_KERNEL(k_min_i32, uint32_t, OP_MINI)
+DEFINE_KERNEL(k_or, uint32_t, OP_OR)
+DEFINE_KERNEL(k_xor, uint32_t, OP_XOR)
+DEFINE_KERNEL(k_mov, uint32_t, OP_MOV)
+DEFINE_KERNEL(k_mov_dpp, uint32_t, OP_MOVDPP)
+DEFINE_KERNEL(k_lshr, uint32_t, OP_LSHR)
+DEFINE_KERNEL(k_ashr, uint32_t, OP_ASHR)
+DEFINE_KERNEL(k_add_co, uint32_t, OP_ADDCO)
+DEFINE_KERNEL(k_subrev, uint32_t, OP_SUBREV)
+DEFINE_KERNEL(k_lshl_add, uint32_t, OP_LSHLADD)
+DEFINE_KERNEL(k_add_lshl, uint32_t, OP_ADDLSHL)
+DEFINE_KERNEL(k_and_or, uint32_t, OP_ANDOR)
+DEFINE_KERNEL(k_bfi, uint32_t, OP_BFI)
+DEFINE_KERNEL(k_mul_i24, uint32_t, OP_MULI24)
+DEFINE_KERNEL(k_mad_i16, uint32_t, OP_MADI16)
+DEFINE_KERNEL(k_mad_u16, uint32_t, OP_MADU16)
+DEFINE_KERNEL(k_dot2, uint32_t, OP_DOT2)
+DEFINE_KERNEL(k_dot4i, uint32_t, OP_DOT4I)
+DEFINE_KERNEL(k_pk_add16, uint32_t, OP_PKADD16)
+DEFINE_KERNEL(k_pk_sub16, uint32_t, OP_PKSUB16)
+DEFINE_KERNEL(k_pk_mul16, uint32_t, OP_PKMUL16)
+DEFINE_KERNEL(k_pk_mad16, uint32_t, OP_PKMAD16)
+DEFINE_KERNEL(k_pk_min16, uint32_t, OP_PKMIN16)
+DEFINE_KERNEL(k_cvt_ub2, uint32_t, OP_CVTUB2)
+DEFINE_KERNEL(k_cvt_pk_u8, uint32_t, OP_CVTPKU8)
+DEFINE_KERNEL(k_cvt_i32, uint32_t, OP_CVTI32)
+DEFINE_KERNEL(k_sad_u16, uint32_t, OP_SADU16)
+DEFINE_KERNEL(k_msad, uint32_t, OP_MSAD)
+DEFINE_KERNEL(k_sdwa_add_word, uint32_t, OP_SDWAADD)
+DEFINE_KERNEL(k_sdwa_mul_byte, uint32_t, OP_SDWAMUL)
 DEFINE_KERNEL(k_pk_mul_f32, float2v, OP_PKMUL)
 DEFINE_KERNEL(k_pk_add_f32, float2v, OP_PKADD)
 DEFINE_KERNEL(k_pk_fma_f32, float2v, OP_PKFMA)
@@ -149,6 +221,16 @@ int main(int argc, char **argv)
         {"v_cvt_f32_ubyte0", k_cvt_f32_ubyte}, {"v_cvt_f32_u32", k_cvt_f32_u32}, {"v_cvt_u32_f32", k_cvt_u32_f32},
         {"v_mul_f32", k_mul_f32}, {"v_add_f32", k_add_f32}, {"v_fma_f32", k_fma_f32}, {"v_rcp_f32", k_rcp_f32},
         {"v_cndmask_b32", k_cndmask}, {"v_cmp_lt_u32", k_cmp},
+        {"v_min_f32", k_min_f32}, {"v_max_f32", k_max_f32}, {"v_sub_f32", k_sub_f32}, {"v_fmac_f32", k_fmac_f32},
+        {"v_med3_i32", k_med3}, {"v_max_u32", k_max_u32}, {"v_min_i32", k_min_i32}, {"v_or_b32", k_or}, {"v_xor_b32", k_xor},
+        {"v_mov_b32", k_mov}, {"v_mov_b32_dpp row_shr", k_mov_dpp}, {"v_lshrrev_b32", k_lshr}, {"v_ashrrev_i32", k_ashr},
+        {"v_add_co_u32", k_add_co}, {"v_subrev_u32", k_subrev}, {"v_lshl_add_u32", k_lshl_add}, {"v_add_lshl_u32", k_add_lshl},
+        {"v_and_or_b32", k_and_or}, {"v_bfi_b32", k_bfi}, {"v_mul_i32_i24", k_mul_i24}, {"v_mad_i32_i16", k_mad_i16},
+        {"v_mad_u32_u16", k_mad_u16}, {"v_dot2_u32_u16", k_dot2}, {"v_dot4_i32_i8", k_dot4i},
+        {"v_pk_add_u16", k_pk_add16}, {"v_pk_sub_i16", k_pk_sub16}, {"v_pk_mul_lo_u16", k_pk_mul16},
+        {"v_pk_mad_u16", k_pk_mad16}, {"v_pk_min_u16", k_pk_min16}, {"v_cvt_f32_ubyte2", k_cvt_ub2},
+        {"v_cvt_pk_u8_f32", k_cvt_pk_u8}, {"v_cvt_i32_f32", k_cvt_i32}, {"v_sad_u16", k_sad_u16}, {"v_msad_u8", k_msad},
+        {"v_add_u32_sdwa word", k_sdwa_add_word}, {"v_mul_u32_u24_sdwa byte", k_sdwa_mul_byte},
         {"v_pk_mul_f32", k_pk_mul_f32}, {"v_pk_add_f32", k_pk_add_f32}, {"v_pk_fma_f32", k_pk_fma_f32},
         {"v_add_f64", k_add_f64}, {"v_lshl_add_u64", k_lshl_add_u64},
     };
@@ -191,8 +273,8 @@ int main(int argc, char **argv)
             const double cyc_per_inst = mean_cyc / (k * n_wave);
             const double ginst = (double)blocks * 4 * n_wave / (ms * 1e-3) / 1e9;
             char buf[256];
-            snprintf(buf, sizeof(buf), "%s\"k%d\": {\"cyc_per_inst\": %.3f, \"ginst_s_chip\": %.1f, \"wall_ms\": %.3f}",
-                     k == 1 ? "" : ", ", k, cyc_per_inst, ginst, ms);
+            snprintf(buf, sizeof(buf), "%s\"k%d\": {\"cyc_per_inst\": %.3f, \"ginst_s_chip\": %.1f, \"wall_ms\": %.3f, \"counter_mhz\": %.0f}",
+                     k == 1 ? "" : ", ", k, cyc_per_inst, ginst, ms, mean_cyc / (ms * 1e3));
             json += buf;
             printf("%-26s k=%d  %.3f cyc/inst/SIMD  %.1f Ginst/s chip  (%.3f ms)\n", classes[c].name, k, cyc_per_inst, ginst, ms);
         }
