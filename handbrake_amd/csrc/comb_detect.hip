@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void comb_mask_fused_kernel(const uint8_t *__r
 // atomic - or even an uncached read - per block would queue 8100 requests on one L2 channel).
 __global__ __launch_bounds__(256) void comb_score_kernel(const uint8_t *__restrict__ mask, int stride,
                                                          int width, int height, int bw, int bh, int thr,
-                                                         int filtered, int blocks_x, int *result)
+                                                         int filtered, int blocks_x, int *result, int overlay)
 {
     __shared__ int s_cat;
     if (threadIdx.x == 0) s_cat = 0;
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void comb_score_kernel(const uint8_t *__restri
     {
         const int x0 = bx * bw;
         int score = 0;
-        if (filtered && bw == 16 && bh == 16 && !(stride & 3))
+        if (filtered && bw == 16 && bh == 16 && !(stride & 3) && !overlay)     // overlay modes: cells may hold 128
         {
             // the default 16 x 16 block of a filtered mask: one aligned dword of 0/1 bytes per lane
             const int iy = lane >> 2, ix = (lane & 3) * 4;
@@ -234,12 +234,66 @@ __global__ __launch_bounds__(256) void comb_score_kernel(const uint8_t *__restri
         for (int off = 32; off > 0; off >>= 1) score += __shfl_down(score, off, 64);
         score = __shfl(score, 0, 64);
         const int cat = score > thr ? 2 : (score >= thr / 2 ? 1 : 0);
+        if (overlay && cat && lane == 0)
+        {
+            // mask_box_x / _y as ONE check thread leaves them (comb_detect.c:205-214): the first block in raster
+            // order above the threshold, else the last one at or above half of it
+            const int idx = by * blocks_x + bx;
+            if (cat == 2) atomicMax(result + 1, 0x7fffffff - idx);
+            atomicMax(result + 2, idx + 1);
+        }
         best = max(best, cat);
         if (best == 2) break;                                   // HEAVY: nothing can raise it (comb_detect.c:211-214)
     }
     if (lane == 0 && best) atomicMax(&s_cat, best);
     __syncthreads();
     if (threadIdx.x == 0 && s_cat) atomicMax(result, s_cat);
+}
+
+// draw_mask_box (comb_detect_template.c:21-53): the outline of the recorded block, value 128, into the mask itself
+// (it stays there: later frames' passes and block sums see whatever cell no pass rewrites).  The bottom line of a
+// box in the last block row lands on row `height` when the height is a multiple of the block height - one row
+// past the plane, where the reference scribbles into its allocation padding; skipped here.
+__global__ void comb_draw_box_kernel(uint8_t *mask, int stride, int height, int x, int y, int bw, int bh)
+{
+    for (int i = threadIdx.x; i < bw; i += blockDim.x)
+    {
+        mask[(size_t)y * stride + x + i] = 128;
+        if (y + bh < height) mask[(size_t)(y + bh) * stride + x + i] = 128;
+    }
+    for (int i = threadIdx.x; i < bh; i += blockDim.x)
+    {
+        mask[(size_t)(y + i) * stride + x] = 128;
+        mask[(size_t)(y + i) * stride + x + bw] = 128;
+    }
+}
+
+struct OverlayArgs
+{
+    uint8_t *plane[3];
+    int pitch[3], w[3], h[3];
+    const uint8_t *mask;
+    int mstride, composite, maxv, half;
+};
+
+// apply_mask (comb_detect_template.c:72-136): mask-only mode blanks the picture (luma 0, chroma half); luma then takes
+// the maximum where the mask is 1 and half where it is 128 (the box).
+template <typename PIX>
+__global__ __launch_bounds__(256) void comb_overlay_kernel(OverlayArgs a)
+{
+    const int c = blockIdx.z;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= a.w[c] || y >= a.h[c]) return;
+    PIX *p = reinterpret_cast<PIX *>(a.plane[c] + (size_t)y * a.pitch[c]) + x;
+    if (c != 0)
+    {
+        if (!a.composite) *p = (PIX)a.half;
+        return;
+    }
+    const int m = a.mask[(size_t)y * a.mstride + x];
+    if (m == 1)        *p = (PIX)a.maxv;
+    else if (m == 128) *p = (PIX)a.half;
+    else if (!a.composite) *p = 0;
 }
 
 class CombDetectFilter : public hbhip_filter
@@ -253,6 +307,7 @@ public:
         if (d_lut) (void)hipFree(d_lut);
         if (d_result) (void)hipFree(d_result);
         if (h_result) (void)hipHostFree(h_result);
+        if (stage) (void)hipFree(stage);
     }
 
     int setup(int w, int h, int depth)
@@ -268,7 +323,8 @@ public:
         if (par.block_width > w) par.block_width = w;               // comb_detect.c:1139-1146
         if (par.block_height > h) par.block_height = h;
         if (par.block_width < 1 || par.block_height < 1) return HBHIP_ERR_ARG;
-        if (par.mode & ~3) return HBHIP_ERR_UNSUPPORTED;            // mask / composite overlays
+        if (par.mode & ~15) return HBHIP_ERR_UNSUPPORTED;
+        overlay = (par.mode & 12) != 0;                             // MODE_MASK / MODE_COMPOSITE (comb_detect.c:25-26)
         if (h < 5 || w < 4) return HBHIP_ERR_UNSUPPORTED;
         pitch = hbhip_align_up(w * bps, 256);                      // bytes
         mstride = hbhip_align_up(w, 64);                            // hb_image_stride(GRAY8, w)
@@ -287,8 +343,8 @@ public:
             HBHIP_CHECK(ctx, hipMemcpyAsync(d_lut, par.gamma_lut, sizeof(float) * 256, hipMemcpyHostToDevice, ctx->stream));
             lut_ready = true;
         }
-        HBHIP_CHECK(ctx, hipMalloc((void **)&d_result, sizeof(int)));
-        HBHIP_CHECK(ctx, hipHostMalloc((void **)&h_result, sizeof(int), hipHostMallocDefault));
+        HBHIP_CHECK(ctx, hipMalloc((void **)&d_result, sizeof(int) * 4));
+        HBHIP_CHECK(ctx, hipHostMalloc((void **)&h_result, sizeof(int) * 4, hipHostMallocDefault));
         HBHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         k.mode = par.mode; k.spatial_metric = par.spatial_metric;
         k.motion_threshold = par.motion_threshold; k.spatial_threshold = par.spatial_threshold;
@@ -356,7 +412,10 @@ public:
         dim3 gm((width - 2 + 63) / 64, (height - 2 + 3) / 4);
         if (filt)
         {
-            const bool fused = par.filter_mode == 2 && getenv("HBHIP_COMB_UNFUSED") == nullptr;
+            // overlay modes: the box outline written into the filtered mask persists in the cells no pass rewrites
+            // and the passes read it, so they run one by one on the real buffers (the fused kernel carries its
+            // intermediate masks in LDS and assumes those cells are zero)
+            const bool fused = par.filter_mode == 2 && !overlay && getenv("HBHIP_COMB_UNFUSED") == nullptr;
             if (fused)
                 HBHIP_LAUNCH(ctx, "comb_mask_passes", comb_mask_fused_kernel,
                              dim3((width - 2 + CF_W - 1) / CF_W, (height - 2 + CF_H - 1) / CF_H), b, 0,
@@ -372,7 +431,7 @@ public:
                 HBHIP_LAUNCH(ctx, "comb_mask_erode", comb_mask_pass_kernel, gm, b, 0, (const uint8_t *)mask_temp, mask_filtered, mstride, width, height, 1, 0);
             }
         }
-        HBHIP_CHECK(ctx, hipMemsetAsync(d_result, 0, sizeof(int), ctx->stream));
+        HBHIP_CHECK(ctx, hipMemsetAsync(d_result, 0, sizeof(int) * 4, ctx->stream));
         const int bw = par.block_width, bh = par.block_height;
         const int blocks_x = (width - bw + bw - 1) / bw;             // x = 0, bw, ... while x < width - bw
         const int blocks_y = height / bh;                            // y + bh <= height
@@ -380,12 +439,77 @@ public:
         {
             HBHIP_LAUNCH(ctx, "comb_block_score", comb_score_kernel, dim3(blocks_y), dim3(256), 0,
                          (const uint8_t *)(filt ? mask_filtered : mask), mstride, width, height, bw, bh,
-                         par.block_threshold, filt ? 1 : 0, blocks_x, d_result);
+                         par.block_threshold, filt ? 1 : 0, blocks_x, d_result, overlay ? 1 : 0);
         }
         HBHIP_CHECK(ctx, hipGetLastError());
-        HBHIP_CHECK(ctx, hipMemcpyAsync(h_result, d_result, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HBHIP_CHECK(ctx, hipMemcpyAsync(h_result, d_result, sizeof(int) * 4, hipMemcpyDeviceToHost, ctx->stream));
         HBHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        *combed = *h_result;
+        *combed = h_result[0];
+        if (overlay && h_result[2] > 0 && blocks_x > 0)
+        {
+            const int idx = h_result[1] > 0 ? 0x7fffffff - h_result[1] : h_result[2] - 1;
+            box_x = (idx % blocks_x) * bw;
+            box_y = (idx / blocks_x) * bh;
+        }
+        return HBHIP_OK;
+    }
+
+    // draw_mask_box + apply_mask (comb_detect_template.c:21-136) on a picture holding a copy of the frame that was
+    // just classified: planes in HBM, pitches in bytes.
+    int overlay_dev(const hbhip_dev_frame *fr, const int plane_w[3], const int plane_h[3])
+    {
+        if (!overlay) return HBHIP_ERR_STATE;
+        uint8_t *m = (par.mode & 2) ? mask_filtered : mask;
+        HBHIP_LAUNCH(ctx, "comb_draw_box", comb_draw_box_kernel, dim3(1), dim3(256), 0, m, mstride, height, box_x, box_y,
+                     par.block_width, par.block_height);
+        const int maxv = (1 << in_geo.depth) - 1, half = 1 << (in_geo.depth - 1);
+        OverlayArgs a;
+        for (int c = 0; c < 3; c++)
+        {
+            a.plane[c] = (uint8_t *)fr->plane[c]; a.pitch[c] = fr->stride[c];
+            a.w[c] = plane_w[c]; a.h[c] = plane_h[c];
+        }
+        a.mask = m; a.mstride = mstride; a.composite = (par.mode & 8) != 0; a.maxv = maxv; a.half = half;
+        const dim3 grid((plane_w[0] + 63) / 64, (plane_h[0] + 3) / 4, 3);
+        if (bps == 2) HBHIP_LAUNCH(ctx, "comb_overlay", comb_overlay_kernel<uint16_t>, grid, dim3(64, 4), 0, a);
+        else          HBHIP_LAUNCH(ctx, "comb_overlay", comb_overlay_kernel<uint8_t>, grid, dim3(64, 4), 0, a);
+        HBHIP_CHECK(ctx, hipGetLastError());
+        return HBHIP_OK;
+    }
+
+    // the same for a frame in host memory: staged through a device picture
+    int overlay_host(const hbhip_host_frame *fr, const int plane_w[3], const int plane_h[3])
+    {
+        if (!overlay) return HBHIP_ERR_STATE;
+        size_t off[3], total = 0;
+        int pitchv[3];
+        for (int c = 0; c < 3; c++)
+        {
+            pitchv[c] = hbhip_align_up(plane_w[c] * bps, 256);
+            off[c] = total;
+            total += (size_t)pitchv[c] * plane_h[c];
+        }
+        if (total > stage_bytes)
+        {
+            if (stage) (void)hipFree(stage);
+            stage = nullptr; stage_bytes = 0;
+            HBHIP_CHECK(ctx, hipMalloc((void **)&stage, total));
+            stage_bytes = total;
+        }
+        hbhip_dev_frame d;
+        for (int c = 0; c < 3; c++)
+        {
+            d.plane[c] = stage + off[c]; d.stride[c] = pitchv[c];
+            if (fr->plane[c] == nullptr || fr->stride[c] < plane_w[c] * bps) return HBHIP_ERR_ARG;
+            HBHIP_CHECK(ctx, hipMemcpy2DAsync(d.plane[c], pitchv[c], fr->plane[c], fr->stride[c], (size_t)plane_w[c] * bps,
+                                              plane_h[c], hipMemcpyHostToDevice, ctx->stream));
+        }
+        int rc = overlay_dev(&d, plane_w, plane_h);
+        if (rc != HBHIP_OK) return rc;
+        for (int c = 0; c < 3; c++)
+            HBHIP_CHECK(ctx, hipMemcpy2DAsync(fr->plane[c], fr->stride[c], d.plane[c], pitchv[c], (size_t)plane_w[c] * bps,
+                                              plane_h[c], hipMemcpyDeviceToHost, ctx->stream));
+        HBHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         return HBHIP_OK;
     }
 
@@ -408,6 +532,10 @@ private:
     uint8_t *masks = nullptr, *mask = nullptr, *mask_filtered = nullptr, *mask_temp = nullptr;
     float *d_lut = nullptr;
     int *d_result = nullptr, *h_result = nullptr;
+    bool overlay = false;
+    int box_x = 0, box_y = 0;                        // pv->mask_box_x / _y
+    uint8_t *stage = nullptr;
+    size_t stage_bytes = 0;
 };
 
 } // namespace
@@ -453,6 +581,22 @@ extern "C" int hbhip_comb_detect_set_gamma_lut(hbhip_filter *f, const float *lut
     if (!c) return HBHIP_ERR_ARG;
     (void)hipSetDevice(f->ctx->device);
     return c->set_gamma_lut(lut, entries);
+}
+
+extern "C" int hbhip_comb_detect_overlay(hbhip_filter *f, const hbhip_host_frame *frame, const int plane_w[3], const int plane_h[3])
+{
+    CombDetectFilter *c = dynamic_cast<CombDetectFilter *>(f);
+    if (!c || !frame || !plane_w || !plane_h) return HBHIP_ERR_ARG;
+    (void)hipSetDevice(f->ctx->device);
+    return c->overlay_host(frame, plane_w, plane_h);
+}
+
+extern "C" int hbhip_comb_detect_overlay_dev(hbhip_filter *f, const hbhip_dev_frame *frame, const int plane_w[3], const int plane_h[3])
+{
+    CombDetectFilter *c = dynamic_cast<CombDetectFilter *>(f);
+    if (!c || !frame || !plane_w || !plane_h) return HBHIP_ERR_ARG;
+    (void)hipSetDevice(f->ctx->device);
+    return c->overlay_dev(frame, plane_w, plane_h);
 }
 
 extern "C" int hbhip_comb_detect_classify(hbhip_filter *f, int force_exhaustive, int *combed)

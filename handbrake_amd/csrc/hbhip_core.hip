@@ -500,6 +500,18 @@ int hbhip_frame_describe(hbhip_frame *fr, hbhip_dev_frame *out, int *width, int 
     return HBHIP_OK;
 }
 
+int hbhip_frame_copy(hbhip_frame *dst, hbhip_frame *src)
+{
+    if (!dst || !src || dst->ctx != src->ctx) return HBHIP_ERR_ARG;
+    if (dst->width != src->width || dst->height != src->height || dst->depth != src->depth ||
+        dst->lcw != src->lcw || dst->lch != src->lch)
+        return HBHIP_ERR_ARG;
+    (void)hipSetDevice(dst->ctx->device);
+    hbhip_dev_frame d;
+    for (int c = 0; c < 3; c++) { d.plane[c] = src->pic.plane[c]; d.stride[c] = src->pic.pitch[c]; }
+    return hbhip_copy_d2d_in(dst->ctx, &dst->pic, &d);
+}
+
 int hbhip_frame_upload(hbhip_frame *fr, const hbhip_host_frame *src)
 {
     if (!fr || !src) return HBHIP_ERR_ARG;

@@ -454,7 +454,7 @@ __device__ __forceinline__ void load_tile16(uint32_t *lds, int pitch, int dwords
 
 __device__ __forceinline__ uint32_t half_of(uint32_t v, int k) { return (v >> (16 * k)) & 0xffffu; }
 
-template <int N, bool FAST, int CPD>
+template <int N, bool FAST, int CPD, bool PRE>
 __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes16_kernel(const NlmJob *__restrict__ jobs, int njobs,
                                                                        int cmp_rows, int rq)
 {
@@ -467,7 +467,12 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes16_kernel(const Nlm
     const int tile_dwords = CPD * cmp_rows + 4;
     uint32_t *s_t0 = smem;                                       // frame 0: source patches and compare tile of f = 0
     uint32_t *s_tc = s_t0 + tile_dwords;                         // frame f > 0
-    float *s_exp = reinterpret_cast<float *>(s_tc + tile_dwords);
+    // PRE (a prefilter is on, nlmeans.c:253-262 `_16` instantiation of nlmeans_template.c:428-543): distances between
+    // src_pre (s_t0) and the prefiltered frame f (s_tc); the samples that are averaged come from the raw frames,
+    // s_r0 (frame 0: also the origin term and the zero fallback) and s_rc (frame f > 0) - as in the 8-bit kernel
+    uint32_t *s_r0 = PRE ? s_tc + tile_dwords : s_t0;
+    uint32_t *s_rc = PRE ? s_r0 + tile_dwords : s_tc;
+    float *s_exp = reinterpret_cast<float *>((PRE ? s_rc : s_tc) + tile_dwords);
 
     int j = 0;
     for (int hi = njobs - 1; j < hi;)
@@ -487,9 +492,17 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes16_kernel(const Nlm
     const int ty = threadIdx.x / TXN;
 
     if (threadIdx.x < 128) s_exp[threadIdx.x] = job.exptable[threadIdx.x];
-    load_tile16(s_t0, CPD, CPD, cmp_rows, job.frame[0], job.fpitch[0], w, h, tx0 - PX - 4 * rq, ty0 - NH - RH);
+    if (PRE)
+    {
+        load_tile16(s_t0, CPD, CPD, cmp_rows, job.src_pre, job.src_pre_pitch, w, h, tx0 - PX - 4 * rq, ty0 - NH - RH);
+        load_tile16(s_r0, CPD, CPD, cmp_rows, job.frame[0], job.fpitch[0], w, h, tx0 - PX - 4 * rq, ty0 - NH - RH);
+    }
+    else
+        load_tile16(s_t0, CPD, CPD, cmp_rows, job.frame[0], job.fpitch[0], w, h, tx0 - PX - 4 * rq, ty0 - NH - RH);
     // lane tx's own 4 pixels = dwords 2*tx + 2*rq, +1 of a tile row
-    const uint32_t *own = s_t0 + (ty * RY + RH) * CPD + 2 * tx + 2 * rq;
+    const int own_off = (ty * RY + RH) * CPD + 2 * tx + 2 * rq;
+    const uint32_t *own = s_t0 + own_off;
+    const uint32_t *own_raw = s_r0 + own_off;                    // the same samples of the raw frame being filtered
 
     f2 aw[RY][PX / 2], ap[RY][PX / 2];
 #pragma unroll
@@ -505,15 +518,25 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes16_kernel(const Nlm
 
     for (int f = 0; f < job.nframes; f++)
     {
-        if (f > 0)
+        if (PRE || f > 0)
         {
             __syncthreads();
-            load_tile16(s_tc, CPD, CPD, cmp_rows, job.frame[f], job.fpitch[f], w, h,
-                        tx0 - PX - 4 * rq, ty0 - NH - RH);
+            if (PRE)
+            {
+                load_tile16(s_tc, CPD, CPD, cmp_rows, job.frame_pre[f], job.ppitch[f], w, h,
+                            tx0 - PX - 4 * rq, ty0 - NH - RH);
+                if (f > 0)
+                    load_tile16(s_rc, CPD, CPD, cmp_rows, job.frame[f], job.fpitch[f], w, h,
+                                tx0 - PX - 4 * rq, ty0 - NH - RH);
+            }
+            else
+                load_tile16(s_tc, CPD, CPD, cmp_rows, job.frame[f], job.fpitch[f], w, h,
+                            tx0 - PX - 4 * rq, ty0 - NH - RH);
         }
         __syncthreads();
         if (!wave_live) continue;
-        const uint32_t *cmp_tile = f > 0 ? s_tc : s_t0;
+        const uint32_t *cmp_tile = (PRE || f > 0) ? s_tc : s_t0;
+        const uint32_t *pix_tile = f > 0 ? s_rc : s_r0;          // what is averaged (== cmp_tile without a prefilter)
 
         for (int dy = -RH; dy <= RH; dy++)
         {
@@ -524,7 +547,7 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes16_kernel(const Nlm
 #pragma unroll
                     for (int o = 0; o < RY; o++)
                     {
-                        const uint32_t c0 = own[(o + NH) * CPD], c1 = own[(o + NH) * CPD + 1];
+                        const uint32_t c0 = own_raw[(o + NH) * CPD], c1 = own_raw[(o + NH) * CPD + 1];
 #pragma unroll
                         for (int p = 0; p < PX; p++)
                         {
@@ -541,7 +564,7 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes16_kernel(const Nlm
                 const int sh = 2 * (s & 1);                  // byte shift inside the dword pair
                 const uint32_t *srow = own;
                 const uint32_t *crow = cmp_tile + (ty * RY + dy + RH) * CPD + 2 * tx + (s >> 1);
-                const uint32_t *prow = crow + NH * CPD;      // the row whose pixels are averaged
+                const uint32_t *prow = pix_tile + (ty * RY + dy + RH + NH) * CPD + 2 * tx + (s >> 1);   // the row whose pixels are averaged
 
                 uint32_t C[PX], hist[RY - 1][PX], v[PX];
                 uint32_t pixq0 = 0, pixq1 = 0;
@@ -660,7 +683,7 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes16_kernel(const Nlm
     {
         const int y = ty0 + ty * RY + o;
         if (y >= h) break;
-        const uint32_t c0 = own[(o + NH) * CPD], c1 = own[(o + NH) * CPD + 1];
+        const uint32_t c0 = own_raw[(o + NH) * CPD], c1 = own_raw[(o + NH) * CPD + 1];
         uint32_t r[PX];
 #pragma unroll
         for (int p = 0; p < PX; p++)
@@ -692,19 +715,29 @@ constexpr int PF_MEAN3 = 1, PF_MEAN5 = 2, PF_MEDIAN3 = 4, PF_MEDIAN5 = 8, PF_CSM
               PF_REDUCE25 = 256, PF_REDUCE50 = 512, PF_EDGEBOOST = 1024, PF_PASSTHRU = 2048,
               PF_BASE = PF_MEAN3 | PF_MEAN5 | PF_MEDIAN3 | PF_MEDIAN5 | PF_CSM3 | PF_CSM5;
 
+// PIX = uint8_t, or uint16_t for the `_16` instantiation (nlmeans.c:253-262: pixel = uint16_t, pixel_2 = uint32_t);
+// pitches are in BYTES.  What the wider types change is noted where it matters (oracle/nlmeans_prefilter16.h).
+template <typename PIX>
 __device__ __forceinline__ int pf_mix(int pre, int src, int wet, int dry)
 {
-    return dry > 0 ? ((wet * pre + dry * src) / (wet + dry)) & 0xff : pre;     // :498-525
+    return dry > 0 ? (int)(PIX)((wet * pre + dry * src) / (wet + dry)) : pre;     // :498-525
+}
+
+template <typename PIX>
+__device__ __forceinline__ const PIX *pf_row(const uint8_t *base, int pitch, int y)
+{
+    return reinterpret_cast<const PIX *>(base + (size_t)y * pitch);
 }
 
 // base filter (+ the wet/dry blend when no edge boost comes in between)
+template <typename PIX>
 __global__ __launch_bounds__(256) void nlm_prefilter_kernel(const uint8_t *__restrict__ src, int spitch,
                                                             uint8_t *__restrict__ dst, int dpitch,
                                                             int w, int h, int type, int wet, int dry)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
-    auto at = [&](int xx, int yy) -> int { return src[(size_t)reflect(yy, h) * spitch + reflect(xx, w)]; };
+    auto at = [&](int xx, int yy) -> int { return pf_row<PIX>(src, spitch, reflect(yy, h))[reflect(xx, w)]; };
     const int centre = at(x, y);
     int out = centre;
     // one base filter, picked in the reference's order of precedence (:459-496)
@@ -756,24 +789,27 @@ __global__ __launch_bounds__(256) void nlm_prefilter_kernel(const uint8_t *__res
     }
     else
     {
-        // nlmeans_filter_mean (:103-133): uint16 window sum scaled by a double, truncated
+        // nlmeans_filter_mean (:103-133): window sum in pixel_2 (uint16 / uint32) scaled by a double, truncated
         int sum = 0;
         for (int dx = lo; dx < hi; dx++)
             for (int dy = lo; dy < hi; dy++) sum += at(x + dx, y + dy);
-        out = (int)(uint8_t)((double)(sum & 0xffff) * (1.0 / (double)(size * size)));
+        if (sizeof(PIX) == 1) out = (int)(uint8_t)((double)(sum & 0xffff) * (1.0 / (double)(size * size)));
+        else                  out = (int)(uint16_t)((double)(uint32_t)sum * (1.0 / (double)(size * size)));
     }
-    if (!(type & PF_EDGEBOOST)) out = pf_mix(out, centre, wet, dry);
-    dst[(size_t)y * dpitch + x] = (uint8_t)out;
+    if (!(type & PF_EDGEBOOST)) out = pf_mix<PIX>(out, centre, wet, dry);
+    reinterpret_cast<PIX *>(dst + (size_t)y * dpitch)[x] = (PIX)out;
 }
 
-// nlmeans_filter_edgeboost, first pass (:335-377): Sobel-like gradients in uint16 (negative sums
-// wrap, as in the reference), classified into {16, 128, 235}.
+// nlmeans_filter_edgeboost, first pass (:335-377): Sobel-like gradients in pixel_2 = uint16 / uint32 (negative
+// sums wrap, as in the reference), classified into {16, 128, 235} - thresholds NOT scaled with the depth
+// (:367-378), so on 10 / 12-bit data nearly every sample classifies as a strong edge.  The mask is a byte plane.
+template <typename PIX>
 __global__ __launch_bounds__(256) void nlm_edge_mask_kernel(const uint8_t *__restrict__ src, int spitch,
                                                             uint8_t *__restrict__ mask, int mpitch, int w, int h)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
-    auto at = [&](int xx, int yy) -> int { return src[(size_t)reflect(yy, h) * spitch + reflect(xx, w)]; };
+    auto at = [&](int xx, int yy) -> int { return pf_row<PIX>(src, spitch, reflect(yy, h))[reflect(xx, w)]; };
     const int kern[3][3] = { {-31, 0, 31}, {-44, 0, 44}, {-31, 0, 31} };
     int g1 = 0, g2 = 0;
 #pragma unroll
@@ -786,9 +822,19 @@ __global__ __launch_bounds__(256) void nlm_edge_mask_kernel(const uint8_t *__res
             g2 += kern[dx + 1][dy + 1] * v;
         }
     const double coef = 1.0 / 126.42;
-    const uint32_t a = (uint32_t)(uint16_t)(int)(((double)(g1 & 0xffff) * coef) + 128);
-    const uint32_t b = (uint32_t)(uint16_t)(int)(((double)(g2 & 0xffff) * coef) + 128);
-    const uint32_t m = (a + b) & 0xff;
+    uint32_t m;
+    if (sizeof(PIX) == 1)
+    {
+        const uint32_t a = (uint32_t)(uint16_t)(int)(((double)(g1 & 0xffff) * coef) + 128);
+        const uint32_t b = (uint32_t)(uint16_t)(int)(((double)(g2 & 0xffff) * coef) + 128);
+        m = (a + b) & 0xff;
+    }
+    else
+    {
+        const uint32_t a = (uint32_t)(((double)(uint32_t)g1 * coef) + 128);
+        const uint32_t b = (uint32_t)(((double)(uint32_t)g2 * coef) + 128);
+        m = (a + b) & 0xffff;
+    }
     mask[(size_t)y * mpitch + x] = m > 160 ? 235 : m > 16 ? 128 : 16;
 }
 
@@ -800,6 +846,7 @@ __global__ __launch_bounds__(256) void nlm_edge_mask_kernel(const uint8_t *__res
 // alive}, and the row is resolved with a prefix composition of those maps (threads compose their
 // own run of pixels, then a block scan joins the runs).
 constexpr int EB_THREADS = 256;
+template <typename PIX>
 __global__ __launch_bounds__(EB_THREADS) void nlm_edge_apply_kernel(const uint8_t *__restrict__ src, int spitch,
                                                                      uint8_t *__restrict__ mask, int mpitch,
                                                                      uint8_t *__restrict__ pre, int ppitch,
@@ -861,9 +908,9 @@ __global__ __launch_bounds__(EB_THREADS) void nlm_edge_apply_kernel(const uint8_
                 continue;
             }
             state = 1;
-            const int sv = src[(size_t)y * spitch + x];
-            uint8_t *o = pre + (size_t)y * ppitch + x;
-            *o = (uint8_t)(m == 235 ? (3 * sv + *o) / 4 : (2 * sv + 3 * *o) / 5);
+            const int sv = pf_row<PIX>(src, spitch, y)[x];
+            PIX *o = reinterpret_cast<PIX *>(pre + (size_t)y * ppitch) + x;
+            *o = (PIX)(m == 235 ? (3 * sv + (int)*o) / 4 : (2 * sv + 3 * (int)*o) / 5);
         }
         __threadfence_block();
         __syncthreads();                                                    // row y is final before row y+1 reads it
@@ -871,13 +918,14 @@ __global__ __launch_bounds__(EB_THREADS) void nlm_edge_apply_kernel(const uint8_
 }
 
 // the wet/dry blend (:498-525) when the edge boost had to run between it and the base filter
+template <typename PIX>
 __global__ __launch_bounds__(256) void nlm_mix_kernel(const uint8_t *__restrict__ src, int spitch,
                                                       uint8_t *__restrict__ pre, int ppitch, int w, int h, int wet, int dry)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
-    uint8_t *o = pre + (size_t)y * ppitch + x;
-    *o = (uint8_t)pf_mix(*o, src[(size_t)y * spitch + x], wet, dry);
+    PIX *o = reinterpret_cast<PIX *>(pre + (size_t)y * ppitch) + x;
+    *o = (PIX)pf_mix<PIX>(*o, pf_row<PIX>(src, spitch, y)[x], wet, dry);
 }
 
 __global__ void copy_plane_kernel(uint8_t *dst, int dst_pitch, const uint8_t *src, int src_pitch,
@@ -919,7 +967,6 @@ public:
             // a prefilter only exists if one of the base filters is selected (:438-443)
             pf_type[c] = (par.prefilter[c] & PF_BASE) ? par.prefilter[c] : 0;
             passthru[c] = (par.prefilter[c] & PF_PASSTHRU) != 0;
-            if (in_geo.bps == 2 && (pf_type[c] || passthru[c])) return HBHIP_ERR_UNSUPPORTED;   // prefilters: 8-bit only
             any_pre |= pf_type[c] != 0;
             if (passthru[c]) continue;                 // the plane is not denoised at all (nlmeans.c:485-492)
             max_frames = std::max(max_frames, par.nframes[c]);
@@ -1083,19 +1130,23 @@ private:
             else if (type & PF_REDUCE50)                      { wet = 1; dry = 1; }
             else if (type & PF_REDUCE25)                      { wet = 3; dry = 1; }
             const dim3 grid((w + 63) / 64, (h + 3) / 4), block(256);
-            HBHIP_LAUNCH(ctx, "nlmeans_prefilter", nlm_prefilter_kernel, grid, block, 0,
-                         (const uint8_t *)pic->plane[c], pic->pitch[c], q->plane[c], q->pitch[c], w, h, type, wet, dry);
+#define PF_LAUNCH(NAME, KERNEL, GRID, BLOCK, ...) do { \
+                if (in_geo.bps == 2) HBHIP_LAUNCH(ctx, NAME, KERNEL<uint16_t>, GRID, BLOCK, 0, __VA_ARGS__); \
+                else                 HBHIP_LAUNCH(ctx, NAME, KERNEL<uint8_t>, GRID, BLOCK, 0, __VA_ARGS__); } while (0)
+            PF_LAUNCH("nlmeans_prefilter", nlm_prefilter_kernel, grid, block,
+                      (const uint8_t *)pic->plane[c], pic->pitch[c], q->plane[c], q->pitch[c], w, h, type, wet, dry);
             if (type & PF_EDGEBOOST)
             {
-                HBHIP_LAUNCH(ctx, "nlmeans_edge_mask", nlm_edge_mask_kernel, grid, block, 0,
-                             (const uint8_t *)pic->plane[c], pic->pitch[c], mask_pic->plane[c], mask_pic->pitch[c], w, h);
-                HBHIP_LAUNCH(ctx, "nlmeans_edge_apply", nlm_edge_apply_kernel, dim3(1), dim3(EB_THREADS), 0,
-                             (const uint8_t *)pic->plane[c], pic->pitch[c], mask_pic->plane[c], mask_pic->pitch[c],
-                             q->plane[c], q->pitch[c], w, h);
+                PF_LAUNCH("nlmeans_edge_mask", nlm_edge_mask_kernel, grid, block,
+                          (const uint8_t *)pic->plane[c], pic->pitch[c], mask_pic->plane[c], mask_pic->pitch[c], w, h);
+                PF_LAUNCH("nlmeans_edge_apply", nlm_edge_apply_kernel, dim3(1), dim3(EB_THREADS),
+                          (const uint8_t *)pic->plane[c], pic->pitch[c], mask_pic->plane[c], mask_pic->pitch[c],
+                          q->plane[c], q->pitch[c], w, h);
                 if (dry > 0)
-                    HBHIP_LAUNCH(ctx, "nlmeans_prefilter_mix", nlm_mix_kernel, grid, block, 0,
-                                 (const uint8_t *)pic->plane[c], pic->pitch[c], q->plane[c], q->pitch[c], w, h, wet, dry);
+                    PF_LAUNCH("nlmeans_prefilter_mix", nlm_mix_kernel, grid, block,
+                              (const uint8_t *)pic->plane[c], pic->pitch[c], q->plane[c], q->pitch[c], w, h, wet, dry);
             }
+#undef PF_LAUNCH
         }
         HBHIP_CHECK(ctx, hipGetLastError());
         return HBHIP_OK;
@@ -1183,8 +1234,9 @@ private:
             } while (0)
 #define NLM_GO(NN, FF, CC, PP) NLM_LAUNCH((nlmeans_lanes_kernel<NN, FF, CC, PP>))
 #define NLM_PRE(NN, FF, CC) do { if (pre) NLM_GO(NN, FF, CC, true); else NLM_GO(NN, FF, CC, false); } while (0)
-#define NLM_16(NN, FF) do { if (cpd == 76) NLM_LAUNCH((nlmeans_lanes16_kernel<NN, FF, 76>)); \
-                            else NLM_LAUNCH((nlmeans_lanes16_kernel<NN, FF, 84>)); } while (0)
+#define NLM_16P(NN, FF, PP) do { if (cpd == 76) NLM_LAUNCH((nlmeans_lanes16_kernel<NN, FF, 76, PP>)); \
+                                else NLM_LAUNCH((nlmeans_lanes16_kernel<NN, FF, 84, PP>)); } while (0)
+#define NLM_16(NN, FF) do { if (pre) NLM_16P(NN, FF, true); else NLM_16P(NN, FF, false); } while (0)
 #define NLM_VAR(NN) do { const char *kname = "nlmeans_plane_n" #NN; \
                      if (wide) { if (fast) NLM_16(NN, true); else NLM_16(NN, false); } \
                      else if (cpd == 36) { if (fast) NLM_PRE(NN, true, 36); else NLM_PRE(NN, false, 36); } \
@@ -1198,6 +1250,7 @@ private:
             }
 #undef NLM_VAR
 #undef NLM_16
+#undef NLM_16P
 #undef NLM_PRE
 #undef NLM_GO
 #undef NLM_LAUNCH

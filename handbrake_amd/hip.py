@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "hbhip_ctx_device_name", "hbhip_ctx_profile_enable", "hbhip_ctx_profile_reset",
     "hbhip_ctx_profile_count", "hbhip_ctx_profile_get", "hbhip_ctx_mark", "hbhip_ctx_elapsed_ms",
     "hbhip_dev_alloc", "hbhip_dev_free", "hbhip_dev_upload", "hbhip_dev_download",
-    "hbhip_frame_alloc", "hbhip_frame_retain", "hbhip_frame_release", "hbhip_frame_describe",
+    "hbhip_frame_alloc", "hbhip_frame_retain", "hbhip_frame_release", "hbhip_frame_describe", "hbhip_frame_copy",
     "hbhip_frame_upload", "hbhip_frame_download",
     "hbhip_filter_push", "hbhip_filter_push_dev", "hbhip_filter_pull", "hbhip_filter_pull_dev",
     "hbhip_filter_process_dev", "hbhip_filter_flush", "hbhip_filter_pending", "hbhip_filter_destroy",
@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "hbhip_hqdn3d_create", "hbhip_decomb_create", "hbhip_decomb_push", "hbhip_decomb_push_dev", "hbhip_decomb_debug_eedi_plane",
     "hbhip_comb_detect_create", "hbhip_comb_detect_set_gamma_lut", "hbhip_comb_detect_store",
     "hbhip_comb_detect_store_dev",
-    "hbhip_comb_detect_classify",
+    "hbhip_comb_detect_classify", "hbhip_comb_detect_overlay", "hbhip_comb_detect_overlay_dev",
     "hbhip_rotate_create", "hbhip_grayscale_create", "hbhip_cropscale_create", "hbhip_colorspace_create", "hbhip_pad_create", "hbhip_yadif_create", "hbhip_bwdif_create", "hbhip_format_create",
     "hbhip_blend_create", "hbhip_blend_set_overlays", "hbhip_blend_apply", "hbhip_blend_apply_dev", "hbhip_blend_destroy",
     "hbhip_motion_metric_create", "hbhip_motion_metric_run", "hbhip_motion_metric_run_dev", "hbhip_motion_metric_destroy",

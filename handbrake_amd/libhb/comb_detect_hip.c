@@ -6,8 +6,14 @@
  * The filter does not change pixels: it stamps s.combed on the frame in the
  * middle of a prev/cur/next window and forwards the very same hb_buffer_t
  * (comb_detect.c:1529-1531), holding output back until more than three buffers
- * are queued (:1579-1582).  Only the luma plane goes to the GPU.  The mask
- * overlay modes (4 / 8) are not offered: init() fails and libhb keeps its CPU filter.
+ * are queued (:1579-1582).  Only the luma plane goes to the GPU.
+ *
+ * The debugging modes 4 (MODE_MASK) and 8 (MODE_COMPOSITE) do change pixels: a combed frame leaves as a
+ * copy with the combing mask drawn on it (process_frame :1519-1526, comb_detect_template.c:21-136).  The
+ * reference lets its check threads race on the box position (:205-208); here it is the one a single check
+ * thread leaves.  The reference copies with hb_buffer_shallow_dup, which for decoder-backed (AVFRAME) buffers
+ * shares the pixels it then draws on; the copy here is always a private one (what the reference does for
+ * STANDARD buffers).
  */
 #include "hbhip_host.h"
 
@@ -21,6 +27,7 @@ struct hb_filter_private_s
     int                      force_exhaustive;
     int                      heavy, light, none, frames;
     hb_buffer_list_t         out_list;
+    hb_filter_init_t         input;
 };
 
 static int  comb_detect_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init);
@@ -53,6 +60,7 @@ static int comb_detect_hip_init(hb_filter_object_t *filter, hb_filter_init_t *in
     if (pv == NULL) return -1;
     filter->private_data = pv;
     hb_buffer_list_clear(&pv->out_list);
+    pv->input = *init;
 
     const AVPixFmtDescriptor *desc = av_pix_fmt_desc_get(init->pix_fmt);
     if (desc == NULL) goto fail;
@@ -154,6 +162,48 @@ static int store_ref(hb_filter_private_t *pv, hb_buffer_t *b, int repeat)
     return rc;
 }
 
+/* a private copy of `src` with the mask drawn on it (apply_mask, comb_detect_template.c:72-136) */
+static hb_buffer_t *overlay_copy(hb_filter_private_t *pv, hb_buffer_t *src)
+{
+    int pw[3], ph[3];
+    for (int p = 0; p < 3; p++)
+    {
+        pw[p] = hb_image_width(pv->input.pix_fmt, src->f.width, p);
+        ph[p] = hb_image_height(pv->input.pix_fmt, src->f.height, p);
+    }
+    hbhip_frame *fr = hbhip_host_frame_of(src);
+    if (fr != NULL)
+    {
+        const AVPixFmtDescriptor *desc = av_pix_fmt_desc_get(pv->input.pix_fmt);
+        hbhip_frame *dst = NULL;
+        if (desc == NULL ||
+            hbhip_frame_alloc(hbhip_host_ctx(), src->f.width, src->f.height, desc->comp[0].depth,
+                              desc->log2_chroma_w, desc->log2_chroma_h, &dst) != HBHIP_OK)
+            return NULL;
+        hbhip_host_ctx_release();
+        hbhip_dev_frame d;
+        hbhip_frame_describe(dst, &d, NULL, NULL);
+        if (hbhip_frame_copy(dst, fr) != HBHIP_OK || hbhip_comb_detect_overlay_dev(pv->dev, &d, pw, ph) != HBHIP_OK)
+        {
+            hbhip_frame_release(dst);
+            return NULL;
+        }
+        hb_buffer_t *out = hbhip_host_wrap_frame(dst, &pv->input, src->f.width, src->f.height);
+        if (out != NULL) hb_buffer_copy_props(out, src);
+        return out;
+    }
+    hb_buffer_t *out = hb_buffer_dup(src);
+    if (out == NULL) return NULL;
+    hbhip_host_frame hf;
+    hbhip_host_frame_from_buf(&hf, out);
+    if (hbhip_comb_detect_overlay(pv->dev, &hf, pw, ph) != HBHIP_OK)
+    {
+        hb_buffer_close(&out);
+        return NULL;
+    }
+    return out;
+}
+
 static int process_frame(hb_filter_private_t *pv)      /* comb_detect.c:1499-1535 */
 {
     int combed = HB_COMB_NONE;
@@ -167,9 +217,23 @@ static int process_frame(hb_filter_private_t *pv)      /* comb_detect.c:1499-153
     else if (combed == HB_COMB_LIGHT) pv->light++;
     else pv->none++;
     pv->frames++;
-    pv->ref_used[1] = 1;
-    pv->ref[1]->s.combed = combed;
-    hb_buffer_list_append(&pv->out_list, pv->ref[1]);
+    if ((pv->par.mode & (4 | 8)) && combed)             /* MODE_MASK / MODE_COMPOSITE, :1519-1526 */
+    {
+        hb_buffer_t *out = overlay_copy(pv, pv->ref[1]);
+        if (out == NULL)
+        {
+            hb_error("comb_detect(hip): mask overlay failed");
+            return -1;
+        }
+        out->s.combed = combed;
+        hb_buffer_list_append(&pv->out_list, out);
+    }
+    else
+    {
+        pv->ref_used[1] = 1;
+        pv->ref[1]->s.combed = combed;
+        hb_buffer_list_append(&pv->out_list, pv->ref[1]);
+    }
     pv->force_exhaustive = 0;
     return 0;
 }
@@ -186,12 +250,18 @@ static int comb_detect_hip_work(hb_filter_object_t *filter, hb_buffer_t **buf_in
         if (pv->ref[2] != NULL)
         {
             if (store_ref(pv, hb_buffer_shallow_dup(pv->ref[2]), 1) != HBHIP_OK)
+            {
+                hb_buffer_close(&in);                   /* consumed above: nobody else will */
                 return HB_FILTER_FAILED;
+            }
             if (pv->ref[0] != NULL)
             {
                 pv->force_exhaustive = 1;
                 if (process_frame(pv) != 0)
+                {
+                    hb_buffer_close(&in);
                     return HB_FILTER_FAILED;
+                }
             }
         }
         hb_buffer_list_append(&pv->out_list, in);

@@ -110,6 +110,7 @@ int  hbhip_frame_alloc(hbhip_ctx *ctx, int width, int height, int depth,
 void hbhip_frame_retain(hbhip_frame *fr);
 void hbhip_frame_release(hbhip_frame *fr);            /* back to the pool at refcount 0 */
 int  hbhip_frame_describe(hbhip_frame *fr, hbhip_dev_frame *out, int *width, int *height);
+int  hbhip_frame_copy(hbhip_frame *dst, hbhip_frame *src);                  /* same geometry; stream-ordered D2D */
 int  hbhip_frame_upload(hbhip_frame *fr, const hbhip_host_frame *src);      /* H2D, returns when src is consumed */
 int  hbhip_frame_download(hbhip_frame *fr, const hbhip_host_frame *dst);    /* D2H, synchronous */
 
@@ -264,6 +265,14 @@ int hbhip_comb_detect_store(hbhip_filter *f, const uint8_t *luma, int stride);
 int hbhip_comb_detect_store_dev(hbhip_filter *f, const void *luma, int stride);
 /* comb_segmenter on the ring: *combed = HB_COMB_NONE/LIGHT/HEAVY for the middle plane. */
 int hbhip_comb_detect_classify(hbhip_filter *f, int force_exhaustive, int *combed);
+
+/* Mask overlay, modes 4 (MODE_MASK) / 8 (MODE_COMPOSITE): draw_mask_box + apply_mask (comb_detect_template.c:21-136)
+ * on `frame`, which holds a COPY of the frame the last classify judged combed (process_frame, comb_detect.c:1519-1526).
+ * plane_w / plane_h: samples per row and rows of each plane.  The box position is the one a single check thread
+ * leaves (the reference's segment threads race on it, comb_detect.c:205-208); its outline stays in the mask, as in
+ * the reference. */
+int hbhip_comb_detect_overlay(hbhip_filter *f, const hbhip_host_frame *frame, const int plane_w[3], const int plane_h[3]);
+int hbhip_comb_detect_overlay_dev(hbhip_filter *f, const hbhip_dev_frame *frame, const int plane_w[3], const int plane_h[3]);
 
 /* ---- Alias family (libavfilter/zimg-backed in the reference; arithmetic external,
  *      parity pinned to oracle/alias_oracle.c only — see DESIGN.md) ------------------- */

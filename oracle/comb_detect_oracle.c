@@ -31,6 +31,7 @@ struct orc_comb
     float *lut;                      /* 1 << depth entries (:1102) */
     float g_mthresh, g_athresh, g_athresh6;
     int athresh_sq, athresh6, c32_min, c32_max;
+    int box_x, box_y;                /* pv->mask_box_x / _y: the last block the check recorded (:205-208, 262-265) */
 };
 
 orc_comb_t *orc_comb_new(int width, int height, const orc_comb_params_t *p)
@@ -187,8 +188,11 @@ static void mask_pass(const orc_comb_t *c, const uint8_t *src, uint8_t *dst, int
     }
 }
 
-/* :221-276 and :384-454 folded with :1029-1049 */
-static int score_blocks(const orc_comb_t *c, int filtered)
+/* :221-276 and :384-454 folded with :1029-1049.  Also keeps mask_box_x / _y the way ONE check thread leaves
+ * them (the reference's segment threads race on it, :205-208 - the overlay modes are pinned with cpu_count = 1):
+ * every block with score >= threshold / 2 overwrites the position, the scan stops at the first block whose score
+ * exceeds the threshold. */
+static int score_blocks(orc_comb_t *c, int filtered)
 {
     const int bw = c->p.block_width, bh = c->p.block_height, thr = c->p.block_threshold;
     const uint8_t *m = filtered ? c->mask_filtered : c->mask;
@@ -208,6 +212,7 @@ static int score_blocks(const orc_comb_t *c, int filtered)
                     else                                  score += r[bx - 1] & r[bx] & r[bx + 1];
                 }
             }
+            if (score >= thr / 2)  { c->box_x = x; c->box_y = y; }
             if (score > thr)       return 2;
             if (score >= thr / 2)  light = 1;
         }
@@ -234,4 +239,55 @@ int orc_comb_classify(orc_comb_t *c, const uint8_t *prev, const uint8_t *cur, co
         }
     }
     return score_blocks(c, filt);
+}
+
+
+/* ---- mask overlay, modes 4 (MODE_MASK) and 8 (MODE_COMPOSITE): comb_detect_template.c:21-136 ----------------
+ * process_frame (comb_detect.c:1519-1526) calls this on a COPY of the classified frame when it is combed.
+ * draw_mask_box (:21-53) first writes 128 along the outline of the last recorded block INTO THE MASK BUFFER
+ * (the filtered one in filter mode) - and nothing clears it: cells no pass rewrites (columns 0-1, rows 0 and
+ * height-1 of the filtered mask; rows 0, 1, height-2, height-1 of the detector's mask) keep the 128 for the
+ * rest of the stream, where block scoring and the 3x3 passes read it.  Kept as is; the only departure: the
+ * bottom line of a box in the last block row of a picture whose height is a multiple of the block height falls
+ * on row `height`, one row past the buffer - the reference scribbles into its allocation padding there, here
+ * that line is skipped.
+ * apply_mask (:72-136): mask-only mode blanks the picture (luma 0, chroma half, whole plane), then luma takes
+ * max where the mask is 1 and half where it is 128. */
+void orc_comb_overlay(orc_comb_t *c, void *const plane[3], const int stride[3], const int pheight[3])
+{
+    const int filt = (c->p.mode & 2) != 0;
+    uint8_t *m = filt ? c->mask_filtered : c->mask;
+    const int st = c->stride, x = c->box_x, y = c->box_y, bw = c->p.block_width, bh = c->p.block_height;
+    for (int bx = 0; bx < bw; bx++)
+    {
+        m[(size_t)y * st + x + bx] = 128;
+        if (y + bh < c->height) m[(size_t)(y + bh) * st + x + bx] = 128;
+    }
+    for (int by = 0; by < bh; by++)
+    {
+        m[(size_t)(y + by) * st + x] = 128;
+        m[(size_t)(y + by) * st + x + bw] = 128;
+    }
+    const int max = (1 << c->depth) - 1, half = 1 << (c->depth - 1);   /* comb_detect.c:1104-1105 */
+    const int bps = c->depth > 8 ? 2 : 1;
+    for (int pp = 0; pp < 3; pp++)
+    {
+        if (!(c->p.mode & 8))
+            for (int yy = 0; yy < pheight[pp]; yy++)
+                for (int xx = 0; xx < stride[pp] / bps; xx++)
+                {
+                    if (bps == 1) ((uint8_t *)plane[pp])[(size_t)yy * stride[pp] + xx] = pp ? (uint8_t)half : 0;
+                    else ((uint16_t *)((uint8_t *)plane[pp] + (size_t)yy * stride[pp]))[xx] = pp ? (uint16_t)half : 0;
+                }
+        if (pp != 0) continue;
+        for (int yy = 0; yy < c->height; yy++)
+            for (int xx = 0; xx < c->width; xx++)
+            {
+                const int mv = m[(size_t)yy * st + xx];
+                if (mv != 1 && mv != 128) continue;
+                const int v = mv == 1 ? max : half;
+                if (bps == 1) ((uint8_t *)plane[0])[(size_t)yy * stride[0] + xx] = (uint8_t)v;
+                else ((uint16_t *)((uint8_t *)plane[0] + (size_t)yy * stride[0]))[xx] = (uint16_t)v;
+            }
+    }
 }

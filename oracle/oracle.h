@@ -178,6 +178,9 @@ void        orc_comb_free(orc_comb_t *c);
  * stride): returns HB_COMB_NONE/LIGHT/HEAVY (0/1/2). */
 int         orc_comb_classify(orc_comb_t *c, const uint8_t *prev, const uint8_t *cur,
                               const uint8_t *next, int stride, int force_exhaustive);
+/* modes 4 / 8: draw_mask_box + apply_mask (comb_detect_template.c:21-136) on a copy of the classified frame;
+ * plane strides in bytes, pheight = rows of each plane.  Call right after a classify that returned != 0. */
+void orc_comb_overlay(orc_comb_t *c, void *const plane[3], const int stride[3], const int pheight[3]);
 /* which: 0 mask, 1 mask_filtered, 2 mask_temp; returns the plane, *stride set. */
 const uint8_t *orc_comb_mask(orc_comb_t *c, int which, int *stride);
 

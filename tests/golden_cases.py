@@ -126,14 +126,15 @@ CASES = {
                                     chain=[("hb_filter_decomb", "mode=31")],
                                     hip=[("hb_filter_decomb_hip", "mode=31")],
                                     orc=[("decomb", dict(mode=31))]),
-    # 10 / 12-bit NLMeans with prefilters: oracle-only for now (the HIP prefilters are 8-bit), threads=1
-    # for the same reason as the 8-bit prefilter cases
+    # 10 / 12-bit NLMeans with prefilters; threads=1 for the same reason as the 8-bit prefilter cases
     "nlmeans_prefilter_10bit_134x70": dict(model="progressive", w=134, h=70, n=4, depth=10,
-                                           chain=[("hb_filter_nlmeans", NLM_PRE_A + ":threads=1")], hip=None,
+                                           chain=[("hb_filter_nlmeans", NLM_PRE_A + ":threads=1")],
+                                           hip=[("hb_filter_nlmeans_hip", NLM_PRE_A)],
                                            orc=[("nlmeans", [nlm(prefilter=272, depth=10), nlm(patch=5, prefilter=8, depth=10),
                                                              nlm(patch=5, prefilter=8, depth=10)])]),
     "nlmeans_prefilter_12bit_96x64": dict(model="random", w=96, h=64, n=4, depth=12,
-                                          chain=[("hb_filter_nlmeans", NLM_PRE_C + ":threads=1")], hip=None,
+                                          chain=[("hb_filter_nlmeans", NLM_PRE_C + ":threads=1")],
+                                          hip=[("hb_filter_nlmeans_hip", NLM_PRE_C)],
                                           orc=[("nlmeans", [nlm(prefilter=2049, depth=12),
                                                             nlm(origin_tune=0.8, prefilter=1028, depth=12),
                                                             nlm(origin_tune=0.8, prefilter=800, depth=12)])]),

@@ -281,6 +281,16 @@ class OrcComb:
         P, Cu, N = padded(prev), padded(cur), padded(nxt)
         return self.lib.orc_comb_classify(self.h, P.ctypes.data, Cu.ctypes.data, N.ctypes.data, Cu.strides[0], int(force))
 
+    def overlay(self, frame):
+        """draw_mask_box + apply_mask on a copy of `frame` (3 planes); call after a classify that returned != 0."""
+        self.lib.orc_comb_overlay.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        out = [np.ascontiguousarray(p).copy() for p in frame]
+        ptrs = (C.c_void_p * 3)(*[p.ctypes.data for p in out])
+        strides = (C.c_int * 3)(*[p.strides[0] for p in out])
+        heights = (C.c_int * 3)(*[p.shape[0] for p in out])
+        self.lib.orc_comb_overlay(self.h, ptrs, strides, heights)
+        return tuple(out)
+
     def close(self):
         if self.h:
             self.lib.orc_comb_free(self.h)

@@ -182,6 +182,22 @@ def comb_detect_stream(frames, par):
     return out
 
 
+def comb_detect_overlay_stream(frames, par):
+    """comb detect with a mask overlay mode (4 = mask only, 8 = composite; comb_detect.c:1519-1526): per frame
+    (combed, planes) - combed frames leave as a copy with the mask drawn on it, the others untouched.  The mask
+    buffers (and the box outlines drawn into them) live as long as the stream."""
+    h, w = frames[0][0].shape
+    oc = ol.OrcComb(w, h, **par)
+    n = len(frames)
+    out = []
+    for t in range(n):
+        force = (t == 0) or (t == n - 1)
+        c = oc.classify(frames[max(t - 1, 0)][0], frames[t][0], frames[min(t + 1, n - 1)][0], force)
+        out.append((c, oc.overlay(frames[t]) if c else tuple(frames[t])))
+    oc.close()
+    return out
+
+
 def decomb_eedi2_stream(frames, par, flags=PIC_FLAG_TOP_FIELD_FIRST, combed=None, duration=3003):
     """decomb_stream with the (stateful) EEDI2 oracle supplying the spatial guess."""
     h, w = frames[0][0].shape

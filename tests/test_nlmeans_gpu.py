@@ -201,6 +201,38 @@ def test_prefilters_bit_exact(built, w, h, settings, pp):
             np.testing.assert_array_equal(got[t].planes[c], want[t][c], err_msg=f"frame {t} plane {c}")
 
 
+PRE16 = [
+    ("y-strength=6:y-origin-tune=1:y-patch-size=7:y-range=3:y-frame-count=2:y-prefilter=1025:"
+     "cb-strength=6:cb-origin-tune=1:cb-patch-size=7:cb-range=3:cb-frame-count=2:cb-prefilter=2:"
+     "cr-strength=6:cr-origin-tune=1:cr-patch-size=7:cr-range=3:cr-frame-count=2:cr-prefilter=772",
+     [(6, 1.0, 7, 3, 2, 1025), (6, 1.0, 7, 3, 2, 2), (6, 1.0, 7, 3, 2, 772)]),
+    ("y-strength=4:y-origin-tune=0.7:y-patch-size=5:y-range=5:y-frame-count=1:y-prefilter=32:"
+     "cb-strength=5:cb-origin-tune=1:cb-patch-size=3:cb-range=5:cb-frame-count=3:cb-prefilter=1304:"
+     "cr-strength=5:cr-origin-tune=1:cr-patch-size=3:cr-range=5:cr-frame-count=3:cr-prefilter=2064",
+     [(4, 0.7, 5, 5, 1, 32), (5, 1.0, 3, 5, 3, 1304), (5, 1.0, 3, 5, 3, 2064)]),
+    ("y-strength=6:y-origin-tune=1:y-patch-size=7:y-range=3:y-frame-count=2:y-prefilter=272:"
+     "cb-strength=6:cb-origin-tune=1:cb-patch-size=5:cb-range=3:cb-frame-count=2:cb-prefilter=8",
+     [(6, 1.0, 7, 3, 2, 272), (6, 1.0, 5, 3, 2, 8), (6, 1.0, 5, 3, 2, 8)]),
+]
+
+
+@pytest.mark.parametrize("depth,w,h", [(10, 638, 362), (12, 200, 120), (10, 96, 64)])
+@pytest.mark.parametrize("case", range(len(PRE16)))
+def test_prefilters_16bit_bit_exact(built, depth, w, h, case):
+    """The prefilters of the `_16` instantiation (nlmeans.c:253-262, nlmeans_template.c:103-543 with pixel = uint16_t,
+    pixel_2 = uint32_t) on the GPU: uint32 window sums, edge-boost thresholds NOT scaled with the depth."""
+    import oracle_stream as ostream
+    settings, pars = PRE16[case]
+    frames = synth.stream("progressive" if w > 300 else "random", w, h, 4, depth=depth)
+    got = hbrt.run_stream(hip.filters(), [("hb_filter_nlmeans_hip", settings)], frames, pix_fmt=hbrt.PIX_FMT_FOR_DEPTH[depth])
+    pp = [dict(ppar(*a), depth=depth) for a in pars]
+    want = ostream.nlmeans_stream(frames, pp)
+    assert len(got) == len(frames)
+    for t in range(len(frames)):
+        for c in range(3):
+            np.testing.assert_array_equal(got[t].planes[c], want[t][c], err_msg=f"frame {t} plane {c}")
+
+
 @pytest.mark.parametrize("depth,w,h", [(10, 638, 362), (12, 200, 120)])
 def test_16bit_samples_bit_exact(built, depth, w, h):
     """YUV420P10 / P12 (the _16 template instantiations, nlmeans.c:253-262) through the drop-in."""
