@@ -12,7 +12,7 @@ HIPFLAGS:= --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fa
 HIP_SRC := $(wildcard $(PKG)/csrc/*.hip)
 HIP_OBJ := $(HIP_SRC:%.hip=%.o)
 HIP_HDR := $(wildcard $(PKG)/csrc/*.h) $(wildcard include/*.h)
-FLT_SRC := $(wildcard $(PKG)/libhb/*_hip.c) $(PKG)/libhb/hbhip_registry.c
+FLT_SRC := $(wildcard $(PKG)/libhb/*_hip.c) $(PKG)/libhb/hbhip_registry.c $(PKG)/libhb/hip_common.c
 
 all: product oracle
 product: $(PKG)/libhbrt.so $(PKG)/libhbhip.so $(PKG)/libhbhip_filters.so
@@ -26,7 +26,7 @@ $(PKG)/csrc/%.o: $(PKG)/csrc/%.hip $(HIP_HDR)
 $(PKG)/libhbhip.so: $(HIP_OBJ)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(HIP_OBJ)
 
-$(PKG)/libhbhip_filters.so: $(FLT_SRC) $(PKG)/libhbrt.so $(PKG)/libhbhip.so include/hbhip.h include/hbhip_libhb.h
+$(PKG)/libhbhip_filters.so: $(FLT_SRC) $(PKG)/libhbrt.so $(PKG)/libhbhip.so include/hbhip.h include/hbhip_libhb.h $(wildcard $(PKG)/libhb/*.h)
 	$(CC) $(CFLAGS) -shared -o $@ $(FLT_SRC) -L$(PKG) -lhbhip -lhbrt -lm -Wl,-rpath,'$$ORIGIN' -Wl,--no-undefined
 
 oracle: $(PKG)/libhbrt.so

@@ -59,6 +59,12 @@ def runtime() -> C.CDLL:
         lib.hbh_chain_output_geometry.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 4
         lib.hbh_chain_close.restype = None
         lib.hbh_chain_close.argtypes = [C.c_void_p]
+        lib.hbh_job_open.restype = C.c_void_p
+        lib.hbh_job_open.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_char_p)] + [C.c_int] * 6
+        lib.hbh_chain_describe.restype = C.c_int
+        lib.hbh_chain_describe.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        lib.hbhip_rt_register_filter.restype = None
+        lib.hbhip_rt_register_filter.argtypes = [C.c_int, C.c_void_p]
         lib.hbhip_set_log_level.argtypes = [C.c_int]
         lib.hbhip_set_cpu_count.argtypes = [C.c_int]
         _rt = lib
@@ -171,6 +177,59 @@ class Chain:
             self.close()
         except Exception:
             pass
+
+
+# hb_filter_object_t ids (handbrake/common.h:1729-1778; include/hbhip_libhb.h)
+FILTER_ID = {"comb_detect": 4, "decomb": 6, "yadif": 7, "bwdif": 9, "denoise": 14, "nlmeans": 16, "chroma_smooth": 17,
+             "rotate": 19, "crop_scale": 22, "lapsharp": 24, "unsharp": 26, "grayscale": 28, "pad": 30,
+             "colorspace": 32, "format": 33}
+
+
+def register_filters(lib: C.CDLL, symbols: dict):
+    """What hb_filter_get's switch holds inside libhb: {filter id: symbol of the registered object in `lib`}."""
+    rt = runtime()
+    for fid, sym in symbols.items():
+        rt.hbhip_rt_register_filter(fid, None if sym is None else C.addressof(C.c_char.in_dll(lib, sym)))
+    return lib
+
+
+class Job(Chain):
+    """A chain built the way do_job() builds it (hbh_job_open): filters by id from the registered objects, the HIP
+    swap + adapters (hb_hip_setup_hw_filters) when use_hip, CPU fallback when a drop-in's init declines."""
+
+    def __init__(self, filters, width: int, height: int, pix_fmt: int = AV_PIX_FMT_YUV420P, vrate=(30000, 1001),
+                 use_hip: bool = True):
+        self._rt = runtime()
+        n = len(filters)
+        ids = (C.c_int * n)(*[f[0] for f in filters])
+        settings = (C.c_char_p * n)(*[(f[1] or "").encode() for f in filters])
+        self._keep = (ids, settings)
+        self.width, self.height = width, height
+        self._h = self._rt.hbh_job_open(n, ids, settings, pix_fmt, width, height, vrate[0], vrate[1], int(use_hip))
+        if not self._h:
+            raise RuntimeError(f"job init failed: {filters}")
+        self.eof = False
+
+    def stages(self):
+        buf = C.create_string_buffer(2048)
+        self._rt.hbh_chain_describe(self._h, buf, 2048)
+        return [s for s in buf.value.decode().split("|") if s]
+
+
+def run_job(filters, frames, flags: int = 0x10, pix_fmt: int = AV_PIX_FMT_YUV420P, duration: int = 3003, combed=None,
+            use_hip: bool = True):
+    """run_stream for a Job; returns (stage names, OutFrames)."""
+    h, w = frames[0][0].shape
+    out = []
+    with Job(filters, w, h, pix_fmt, use_hip=use_hip) as ch:
+        names = ch.stages()
+        for i, fr in enumerate(frames):
+            ch.push(fr, start=i * duration, stop=(i + 1) * duration, flags=flags,
+                    combed=0 if combed is None else combed[i])
+            out += ch.drain()
+        ch.push_eof()
+        out += ch.drain()
+    return names, out
 
 
 def set_source_color(prim: int = 1, transfer: int = 1, matrix: int = 1, color_range: int = 1):

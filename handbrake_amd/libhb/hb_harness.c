@@ -13,7 +13,7 @@
 #include "hbhip_libhb.h"
 #include "hb_harness.h"
 
-#define HBH_MAX_STAGES 8
+#define HBH_MAX_STAGES 32
 
 struct hbh_chain_s
 {
@@ -41,9 +41,90 @@ static hb_filter_object_t *clone_filter(const hb_filter_object_t *proto, const c
 
 static int g_src_color[4] = { 1, 1, 1, 1 };
 
+/* what work.c calls directly inside libhb (hip_common.h); here the filter library registers them when it loads */
+static void (*g_hip_setup)(hb_job_t *) = NULL;
+static int  (*g_hip_init_failed)(hb_job_t *, int, hb_filter_init_t *) = NULL;
+
+void hbhip_rt_set_job_hooks(void (*setup)(hb_job_t *), int (*init_failed)(hb_job_t *, int, hb_filter_init_t *))
+{
+    g_hip_setup = setup;
+    g_hip_init_failed = init_failed;
+}
+
 void hbh_set_source_color(int prim, int transfer, int matrix, int range)
 {
     g_src_color[0] = prim; g_src_color[1] = transfer; g_src_color[2] = matrix; g_src_color[3] = range;
+}
+
+static void source_init(hb_filter_init_t *init, int pix_fmt, int width, int height, int vrate_num, int vrate_den);
+
+/* A job the way do_job() prepares its video filters (work.c:1820-1870): the filter list is built from the
+ * REGISTERED (CPU) objects by id - hb_filter_init + hb_add_filter_dict, which orders by id (hb.c:1701-1713) -, then
+ * sanitize_filter_list_post's hook swaps in the HIP drop-ins (hb_hip_setup_hw_filters), then every filter is
+ * initialised with the running hb_filter_init_t; a filter whose init fails is dropped (:1861-1868) unless the hook
+ * puts its CPU filter back (hb_hip_filter_init_failed).  use_hip = 0 leaves the list as registered. */
+hbh_chain_t *hbh_job_open(int nfilters, const int *ids, const char *const *settings, int pix_fmt, int width, int height,
+                          int vrate_num, int vrate_den, int use_hip)
+{
+    hbh_chain_t *c = calloc(1, sizeof(*c));
+    if (c == NULL) return NULL;
+    hb_job_t job;
+    memset(&job, 0, sizeof(job));
+    job.hw_pix_fmt = AV_PIX_FMT_NONE;
+    job.input_pix_fmt = pix_fmt;
+    job.list_filter = hb_list_init();
+    for (int i = 0; i < nfilters; i++)
+    {
+        hb_filter_object_t *f = hb_filter_init(ids[i]);
+        if (f == NULL)
+        {
+            hb_error("hbh_job_open: no filter registered for id %d", ids[i]);
+            continue;
+        }
+        hb_dict_t *d = hbhip_dict_from_string(settings && settings[i] ? settings[i] : "");
+        hb_add_filter_dict(job.list_filter, f, d);
+        hb_dict_free(&d);
+    }
+    if (use_hip && g_hip_setup != NULL) g_hip_setup(&job);
+
+    hb_filter_init_t init;
+    source_init(&init, pix_fmt, width, height, vrate_num, vrate_den);
+    c->init_in = init;
+    for (int i = 0; i < hb_list_count(job.list_filter);)
+    {
+        hb_filter_object_t *f = hb_list_item(job.list_filter, i);
+        f->private_data = NULL;
+        if (f->init != NULL && f->init(f, &init))
+        {
+            const int back = (use_hip && g_hip_init_failed != NULL) ? g_hip_init_failed(&job, i, &init) : 0;
+            if (back > 0)
+            {
+                i -= back - 1;
+                continue;
+            }
+            hb_log("Failure to initialise filter '%s', disabling", f->name);
+            hb_list_rem(job.list_filter, f);
+            hb_filter_close(&f);
+            continue;
+        }
+        i++;
+    }
+    for (int i = 0; i < hb_list_count(job.list_filter) && c->nstages < HBH_MAX_STAGES; i++)
+        c->stage[c->nstages++] = hb_list_item(job.list_filter, i);
+    hb_list_close(&job.list_filter);
+    c->init = init;
+    return c;
+}
+
+/* "name|name|..." of the stages, for tests that check what the swap / fallback left in the list */
+int hbh_chain_describe(hbh_chain_t *c, char *buf, int len)
+{
+    if (c == NULL || buf == NULL || len < 1) return -1;
+    int n = 0;
+    buf[0] = 0;
+    for (int i = 0; i < c->nstages; i++)
+        n += snprintf(buf + n, n < len ? len - n : 0, "%s%s", i ? "|" : "", c->stage[i]->name);
+    return c->nstages;
 }
 
 hbh_chain_t *hbh_chain_open(int nstages, void *const *protos, const char *const *settings,
@@ -55,7 +136,9 @@ hbh_chain_t *hbh_chain_open(int nstages, void *const *protos, const char *const 
     if (c == NULL) return NULL;
 
     hb_filter_init_t init;
-    memset(&init, 0, sizeof(init));
+    source_init(&init, pix_fmt, width, height, vrate_num, vrate_den);
+    c->init_in = init;
+
     init.pix_fmt = pix_fmt;
     init.hw_pix_fmt = AV_PIX_FMT_NONE;
     init.geometry.width = width;
@@ -89,6 +172,28 @@ hbh_chain_t *hbh_chain_open(int nstages, void *const *protos, const char *const 
     }
     c->init = init;
     return c;
+}
+
+static void source_init(hb_filter_init_t *pinit, int pix_fmt, int width, int height, int vrate_num, int vrate_den)
+{
+    hb_filter_init_t init;
+    memset(&init, 0, sizeof(init));
+    init.pix_fmt = pix_fmt;
+    init.hw_pix_fmt = AV_PIX_FMT_NONE;
+    init.geometry.width = width;
+    init.geometry.height = height;
+    init.geometry.par.num = 1;
+    init.geometry.par.den = 1;
+    init.vrate.num = vrate_num;
+    init.vrate.den = vrate_den;
+    init.time_base.num = 1;
+    init.time_base.den = 90000;
+    init.color_prim = g_src_color[0];
+    init.color_transfer = g_src_color[1];
+    init.color_matrix = g_src_color[2];
+    init.color_range = g_src_color[3];
+    init.chroma_location = 1;
+    *pinit = init;
 }
 
 /* Run `in` (one buffer, not a chain) through stage s and everything after it. */

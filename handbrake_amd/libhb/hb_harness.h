@@ -32,6 +32,12 @@ typedef struct hbh_frame_info_s
 hbh_chain_t *hbh_chain_open(int nstages, void *const *protos, const char *const *settings,
                             int pix_fmt, int width, int height,
                             int vrate_num, int vrate_den);
+/* The same chain built the way do_job() builds it: filters by ID from the registered (CPU) objects, the HIP swap
+ * (hb_hip_setup_hw_filters) when use_hip, init with drop / CPU-fallback on failure (work.c:1820-1870). */
+hbh_chain_t *hbh_job_open(int nfilters, const int *ids, const char *const *settings, int pix_fmt, int width, int height,
+                          int vrate_num, int vrate_den, int use_hip);
+/* "|"-separated names of the stages as initialised; returns their count */
+int hbh_chain_describe(hbh_chain_t *c, char *buf, int len);
 /* Colour description of the source for chains opened from now on (init->color_*; AVCOL_* numbers,
  * range 1 = tv, 2 = pc).  Default bt709 / tv. */
 void hbh_set_source_color(int prim, int transfer, int matrix, int range);

@@ -701,3 +701,120 @@ void hb_buffer_list_close(hb_buffer_list_t *l)
 
 int hb_buffer_list_count(hb_buffer_list_t *l) { return l ? l->count : 0; }
 int hb_buffer_list_size(hb_buffer_list_t *l)  { return l ? l->size : 0; }
+
+
+/* ---------------------------------------------------------------- lists, filter registry, filter lists
+ * (common.c:2489-2700, :5247-5540; hb.c:1676-1723) */
+struct hb_list_s { void **items; int count, cap; };
+
+hb_list_t *hb_list_init(void) { return calloc(1, sizeof(hb_list_t)); }
+int hb_list_count(const hb_list_t *l) { return l ? l->count : 0; }
+void *hb_list_item(const hb_list_t *l, int i) { return (l == NULL || i < 0 || i >= l->count) ? NULL : l->items[i]; }
+
+void hb_list_insert(hb_list_t *l, int pos, void *p)
+{
+    if (l == NULL || p == NULL) return;
+    if (l->count == l->cap)
+    {
+        l->cap = l->cap ? 2 * l->cap : 8;
+        l->items = realloc(l->items, sizeof(void *) * l->cap);
+    }
+    if (pos < 0) pos = 0;
+    if (pos > l->count) pos = l->count;
+    memmove(&l->items[pos + 1], &l->items[pos], sizeof(void *) * (l->count - pos));
+    l->items[pos] = p;
+    l->count++;
+}
+
+void hb_list_add(hb_list_t *l, void *p) { hb_list_insert(l, hb_list_count(l), p); }
+
+void hb_list_rem(hb_list_t *l, void *p)
+{
+    if (l == NULL) return;
+    for (int i = 0; i < l->count; i++)
+        if (l->items[i] == p)
+        {
+            memmove(&l->items[i], &l->items[i + 1], sizeof(void *) * (l->count - i - 1));
+            l->count--;
+            return;
+        }
+}
+
+void hb_list_close(hb_list_t **pl)
+{
+    if (pl == NULL || *pl == NULL) return;
+    free((*pl)->items);
+    free(*pl);
+    *pl = NULL;
+}
+
+hb_dict_t *hb_value_dup(const hb_dict_t *d)
+{
+    hb_dict_t *c = hb_dict_init();
+    if (d != NULL && c != NULL)
+        for (kv_t *e = d->head; e; e = e->next) hbhip_dict_set(c, e->k, e->v);
+    return c;
+}
+
+#define RT_MAX_FILTER_ID 64
+static hb_filter_object_t *g_registry[RT_MAX_FILTER_ID];
+
+void hbhip_rt_register_filter(int filter_id, hb_filter_object_t *proto)
+{
+    if (filter_id >= 0 && filter_id < RT_MAX_FILTER_ID) g_registry[filter_id] = proto;
+}
+
+hb_filter_object_t *hb_filter_get(int filter_id)
+{
+    return (filter_id >= 0 && filter_id < RT_MAX_FILTER_ID) ? g_registry[filter_id] : NULL;
+}
+
+hb_filter_object_t *hb_filter_copy(hb_filter_object_t *filter)            /* common.c:5247-5258 */
+{
+    if (filter == NULL) return NULL;
+    hb_filter_object_t *c = malloc(sizeof(*c));
+    if (c == NULL) return NULL;
+    memcpy(c, filter, sizeof(*c));
+    if (filter->settings) c->settings = hb_value_dup(filter->settings);
+    c->sub_filter = hb_filter_copy(filter->sub_filter);
+    return c;
+}
+
+hb_filter_object_t *hb_filter_init(int filter_id)                         /* common.c:5497-5522, without the mt_frame wrap */
+{
+    return hb_filter_copy(hb_filter_get(filter_id));
+}
+
+void hb_filter_close(hb_filter_object_t **pf)                             /* common.c:5524-5537 */
+{
+    if (pf == NULL || *pf == NULL) return;
+    hb_filter_close(&(*pf)->sub_filter);
+    hb_dict_free(&(*pf)->settings);
+    free(*pf);
+    *pf = NULL;
+}
+
+hb_filter_object_t *hb_filter_find(const hb_list_t *list, int filter_id)  /* common.c:5305-5323 */
+{
+    for (int i = 0; i < hb_list_count(list); i++)
+    {
+        hb_filter_object_t *f = hb_list_item(list, i);
+        if (f->id == filter_id) return f;
+    }
+    return NULL;
+}
+
+void hb_add_filter_dict(hb_list_t *list, hb_filter_object_t *filter, const hb_dict_t *settings_in)   /* hb.c:1676-1723 */
+{
+    if (filter == NULL) return;
+    hb_dict_free(&filter->settings);
+    filter->settings = settings_in ? hb_value_dup(settings_in) : hb_dict_init();
+    if (filter->enforce_order)
+        for (int i = 0; i < hb_list_count(list); i++)
+        {
+            hb_filter_object_t *f = hb_list_item(list, i);
+            if (f->id > filter->id) { hb_list_insert(list, i, filter); return; }
+            if (f->id == filter->id) { hb_filter_close(&filter); return; }         /* no filter twice */
+        }
+    hb_list_add(list, filter);
+}

@@ -9,6 +9,7 @@
  * the equivalent hb_hip_setup_hw_filters().
  */
 #include "hbhip_host.h"
+#include "hip_common.h"
 
 #include <pthread.h>
 
@@ -136,6 +137,7 @@ __attribute__((constructor)) static void hbhip_host_register_hooks(void)
 {
 #ifndef HBHIP_IN_LIBHB
     hbhip_rt_set_storage_hooks(storage_retain, storage_release);
+    hbhip_rt_set_job_hooks(hb_hip_setup_hw_filters, hb_hip_filter_init_failed);   /* inside libhb work.c calls them itself */
     const char *e = getenv("HBHIP_PINNED");
     if (e == NULL || atoi(e) != 0)
         hbhip_rt_set_alloc_hooks(pinned_alloc, pinned_release);

@@ -1,0 +1,16 @@
+/* hip_common.h — the two calls libhb's work.c makes to put the HIP drop-ins into a job (hip_common.c).
+ * Counterpart of handbrake/platform/macosx/vt_common.h:hb_vt_setup_hw_filters. */
+#ifndef HBHIP_HIP_COMMON_H
+#define HBHIP_HIP_COMMON_H
+
+/* sanitize_filter_list_post (work.c:1515-1523): swap CPU filters for HIP drop-ins in place, bracket runs of
+ * drop-ins with the upload / download adapters. */
+void hb_hip_setup_hw_filters(hb_job_t *job);
+/* the filter init loop (work.c:1855-1868), when init() of job->list_filter[index] failed: if that filter is a HIP
+ * drop-in, put the CPU filter of the same id and settings back in its place (fixing the adapters around it) and
+ * return > 0 - the loop then CONTINUES AT index - (return value - 1) instead of dropping the filter; 0 = not ours. */
+int  hb_hip_filter_init_failed(hb_job_t *job, int index, hb_filter_init_t *init);
+/* hb_avfilter_combine (hbavfilter.c:520-541): an aliased id whose object is a drop-in is a real filter */
+int  hb_hip_filter_is_hip(const hb_filter_object_t *filter);
+
+#endif

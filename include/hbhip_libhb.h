@@ -444,6 +444,37 @@ enum
     HB_FILTER_HIP_DOWNLOAD
 };
 
+/* ---- the job's filter list: hb_list (common.c:2489-2700), hb_filter_get / _init / _copy / _close / _find
+ *      (common.c:5247-5540), hb_add_filter_dict (hb.c:1676-1723).  Stand-in: only what the swap of CPU filters
+ *      for HIP ones touches (handbrake_amd/libhb/hip_common.c; the reference's precedent is
+ *      platform/macosx/vt_common.c:486-540, called from work.c:1515-1523). -------------------------------- */
+typedef struct hb_list_s hb_list_t;
+hb_list_t *hb_list_init(void);
+int        hb_list_count(const hb_list_t *);
+void      *hb_list_item(const hb_list_t *, int);
+void       hb_list_add(hb_list_t *, void *);
+void       hb_list_insert(hb_list_t *, int pos, void *);
+void       hb_list_rem(hb_list_t *, void *);
+void       hb_list_close(hb_list_t **);
+hb_dict_t *hb_value_dup(const hb_dict_t *);                         /* hb_dict.h: deep copy of a settings dict */
+struct hb_job_s                                                     /* the fields of hb_job_t the swap reads */
+{
+    hb_list_t   *list_filter;
+    int          hw_pix_fmt;                                        /* AV_PIX_FMT_NONE unless a hw decoder set it */
+    int          input_pix_fmt;
+    volatile int done;
+};
+hb_filter_object_t *hb_filter_get(int filter_id);                   /* the registered CPU prototype, or NULL */
+hb_filter_object_t *hb_filter_init(int filter_id);                  /* a copy of it, ready for settings */
+hb_filter_object_t *hb_filter_copy(hb_filter_object_t *);
+void                hb_filter_close(hb_filter_object_t **);
+hb_filter_object_t *hb_filter_find(const hb_list_t *, int filter_id);
+void                hb_add_filter_dict(hb_list_t *, hb_filter_object_t *, const hb_dict_t *settings);
+/* stand-in only: what hb_filter_get's switch holds inside libhb (tests register the reference's own objects) */
+void                hbhip_rt_register_filter(int filter_id, hb_filter_object_t *proto);
+/* stand-in only: the harness's do_job() calls hip_common.c through these (inside libhb work.c calls it directly) */
+void                hbhip_rt_set_job_hooks(void (*setup)(hb_job_t *), int (*init_failed)(hb_job_t *, int, hb_filter_init_t *));
+
 /* ---- the frame-difference metric plugin type vfr.c uses (handbrake/common.h:1799-1811) -- */
 struct hb_motion_metric_object_s
 {
