@@ -53,6 +53,7 @@ struct P3
 };
 
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
+__device__ __forceinline__ int hbhip_align_up_dev(int v, int a) { return (v + a - 1) / a * a; }
 
 __device__ __forceinline__ int sad3(const uint8_t *a, int ai, const uint8_t *b, int bi)
 {
@@ -157,6 +158,26 @@ __global__ void k_fill_half(P3 P, int spitch0, int spitch1, int spitch2, int sta
     const int rows = pl == 0 ? rows0 : pl == 1 ? rows1 : rows2;
     if (x >= pitch || y >= rows) return;
     P.b[pl][(size_t)y * pitch + x] = x < width ? P.a[pl][(size_t)(start_line + 2 * y) * spitch + x] : 0;
+}
+
+// the same with one dword per thread (pitches and plane offsets are multiples of 4)
+__global__ __launch_bounds__(256) void k_fill_half4(P3 P, int spitch0, int spitch1, int spitch2, int start_line, int rows0, int rows1, int rows2)
+{
+    const int pl = blockIdx.z;
+    const int x = 4 * (blockIdx.x * blockDim.x + threadIdx.x), y = blockIdx.y * blockDim.y + threadIdx.y;
+    const int pitch = P.pitch[pl], width = P.width[pl];
+    const int spitch = pl == 0 ? spitch0 : pl == 1 ? spitch1 : spitch2;
+    const int rows = pl == 0 ? rows0 : pl == 1 ? rows1 : rows2;
+    if (x >= pitch || y >= rows) return;
+    uint32_t v = 0;
+    if (x < width)
+    {
+        const uint8_t *sp = P.a[pl] + (size_t)(start_line + 2 * y) * spitch + x;
+        if (((spitch | (uintptr_t)P.a[pl]) & 3) == 0) v = *reinterpret_cast<const uint32_t *>(sp);
+        else v = (uint32_t)sp[0] | ((uint32_t)sp[1] << 8) | ((uint32_t)sp[2] << 16) | ((uint32_t)sp[3] << 24);
+        if (x + 3 >= width) v &= 0xffffffffu >> (8 * (x + 4 - width));     // bytes at x >= width are written as 0
+    }
+    *reinterpret_cast<uint32_t *>(P.b[pl] + (size_t)y * pitch + x) = v;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -545,6 +566,139 @@ __global__ __launch_bounds__(CD_W) void k_calc_dir_tile(P3 P, int maxd, int nt13
     P.c[pl][(size_t)y * pitch + px] = (uint8_t)out;
 }
 
+// calc_directions, second form of the fast path.  Same block shape as k_calc_dir_tile (256 consecutive pixels of one row,
+// active pixels compacted), but the search loop is stripped to what has to happen per step:
+//  * the 3-byte groups every step needs ("triples": bytes i..i+2 of a staged row, i = cc-1+-u) are formed ONCE per block
+//    into LDS tables, one dword per column and source row - a step reads eight dwords at per-lane columns instead of
+//    twenty and realigns nothing;
+//  * the two edge-mask look-ups of a step (:395-399: is there a mask peak among the three pixels above at +u / below at
+//    -u) are two flag bits carried in the spare top byte of the centre row's table;
+//  * each running minimum and its offset are ONE integer, (sum << 6) | (u + 32): `if (sum < min) { min = sum; dir = u; }`
+//    with u ascending is exactly min() on that key (ties keep the earlier = smaller u, the initial threshold is
+//    (thr << 6) | 0 so only strictly smaller sums get in, and low bits 0 mean "never set" = the reference's -5000);
+//  * the loop runs -maxd .. +maxd for every lane with the per-lane range test folded into the step's predicate, so the
+//    trip count is wave-uniform and the step body is one predicated region.
+// Values are the reference's (:358-525): same sums, same order of comparisons.
+__global__ __launch_bounds__(CD_W) void k_calc_dir_tile2(P3 P, int maxd, int nt13, int nt19)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_band[8][CD_LW];   // rows 0..4 source y-2..y+2, 5..7 mask y-1..y+1
+    __shared__ uint32_t s_tri[5][CD_LW];                                  // [r][i] = bytes i..i+2 of source row r (+ flags in row 2)
+    __shared__ uint16_t s_list[CD_W];
+    __shared__ int s_count;
+    const int pl = blockIdx.z;
+    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
+    const int x0 = blockIdx.x * CD_W, y = blockIdx.y;
+    if (y >= height || x0 >= pitch) return;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_count = 0;
+    {
+        const uint8_t *sb = P.b[pl] + (ptrdiff_t)(y - 2) * pitch + x0 - CD_HALO;
+        const uint8_t *mb = P.a[pl] + (ptrdiff_t)(y - 1) * pitch + x0 - CD_HALO;
+        for (int i = tid; i < 8 * (CD_LW / 4); i += CD_W)
+        {
+            const int r = i / (CD_LW / 4), c4 = i - r * (CD_LW / 4);
+            const uint8_t *src = r < 5 ? sb + (ptrdiff_t)r * pitch : mb + (ptrdiff_t)(r - 5) * pitch;
+            reinterpret_cast<uint32_t *>(s_band[r])[c4] = reinterpret_cast<const uint32_t *>(src)[c4];
+        }
+    }
+    __syncthreads();
+    const int x = x0 + tid, c = tid + CD_HALO;
+    bool active = false;
+    if (x < pitch)
+    {
+        if (x >= 1 && x < width - 1 && y >= 1 && y < height - 1)
+            active = s_band[6][c] == PEAK && (s_band[6][c - 1] == PEAK || s_band[6][c + 1] == PEAK);
+        if (!active) P.c[pl][(size_t)y * pitch + x] = 255;        // memset(dstp, 255, pitch*height)
+    }
+    if (active) s_list[atomicAdd(&s_count, 1)] = (uint16_t)tid;
+    __syncthreads();
+    const int count = s_count;
+    if (count == 0) return;
+    {
+        // the tables: column i of row r <- dwords i/4 and i/4 + 1 of the staged row, realigned once
+        const uint32_t *band = reinterpret_cast<const uint32_t *>(&s_band[0][0]);
+        constexpr int RW = CD_LW / 4;
+        for (int i = tid; i < CD_LW - 3; i += CD_W)      // columns 1 .. CD_LW-4 are looked at (cc-1+-u, |u| <= CD_HALO-2)
+        {
+            const int q = i >> 2, sh = i & 3;
+#define TRI(row) (__builtin_amdgcn_alignbyte(band[(row) * RW + q + 1], band[(row) * RW + q], sh) & 0x00ffffffu)
+            const uint32_t mp = TRI(5), mn = TRI(7);
+            s_tri[0][i] = TRI(0);
+            s_tri[1][i] = TRI(1);
+            s_tri[2][i] = TRI(2) | (any_peak3(mp) ? 1u << 24 : 0u) | (any_peak3(mn) ? 1u << 25 : 0u);
+            s_tri[3][i] = TRI(3);
+            s_tri[4][i] = TRI(4);
+#undef TRI
+        }
+    }
+    __syncthreads();
+    if (tid >= count) return;
+
+    const int lx = s_list[tid];
+    const int px = x0 + lx, cc = lx + CD_HALO;
+    const int maxdt = pl == 0 ? maxd : (maxd >> 1);
+    const int startu = max(-px + 1, -maxdt), stopu = min(width - 2 - px, maxdt);
+    const uint32_t F2p = s_tri[0][cc - 1], Fp = s_tri[1][cc - 1], Fc = s_tri[2][cc - 1] & 0x00ffffffu,
+                   Fn = s_tri[3][cc - 1], F2n = s_tri[4][cc - 1];
+    const int ctr = (int)((Fc >> 8) & 0xff);
+    const int vert = iabs(ctr - (int)((Fn >> 8) & 0xff)) + iabs(ctr - (int)((Fp >> 8) & 0xff));
+    const bool first = y == 1, last = y == height - 2;
+    // keys: (running minimum << 6) | (u + 32), low six bits 0 = unset
+    uint32_t kb = (uint32_t)min(nt13, vert * 6) << 6, ka = (uint32_t)min(nt19, vert * 9) << 6;
+    uint32_t kc = ka, kd = kb, ke = kb;
+    const uint32_t need_p = first ? 0u : 1u << 24, need_m = last ? 0u : 1u << 25;
+    const uint32_t span = (uint32_t)(stopu - startu);
+    const uint32_t *tp = &s_tri[0][cc - 1 - maxdt], *tm = &s_tri[0][cc - 1 + maxdt];   // columns cc-1+u / cc-1-u at u = -maxdt
+    for (int u = -maxdt; u <= maxdt; u++, tp++, tm--)
+    {
+        const uint32_t c_p = tp[2 * CD_LW], c_m = tm[2 * CD_LW];
+        // in range, and - unless on the first / last row - a mask peak above at +u and below at -u (:395-399)
+        if ((uint32_t)(u - startu) > span || ((c_p & need_p) != need_p) || ((c_m & need_m) != need_m)) continue;
+        const uint32_t ub = (uint32_t)(u + 32);
+        const uint32_t sn_m = tm[3 * CD_LW], sp_p = tp[1 * CD_LW];
+        const int e1 = (int)__builtin_amdgcn_sad_u8(Fp, c_m & 0x00ffffffu, __builtin_amdgcn_sad_u8(Fc, sn_m, 0u));   // diffsn + diffps
+        const int d1 = (int)__builtin_amdgcn_sad_u8(Fn, c_p & 0x00ffffffu, __builtin_amdgcn_sad_u8(Fc, sp_p, 0u));   // diffsp + diffns
+        const int diff = e1 + d1;
+        int diffd = d1, diffe = e1;
+        kb = min(kb, ((uint32_t)diff << 6) | ub);
+        if (!first)
+        {
+            const int diff2pp = (int)__builtin_amdgcn_sad_u8(F2p, tm[1 * CD_LW], 0u);
+            const int diffp2p = (int)__builtin_amdgcn_sad_u8(Fp, tp[0 * CD_LW], 0u);
+            diffd += diffp2p;
+            diffe += diff2pp;
+            ka = min(ka, ((uint32_t)(diff + diff2pp + diffp2p) << 6) | ub);
+        }
+        if (!last)
+        {
+            const int diff2nn = (int)__builtin_amdgcn_sad_u8(F2n, tp[3 * CD_LW], 0u);
+            const int diffn2n = (int)__builtin_amdgcn_sad_u8(Fn, tm[4 * CD_LW], 0u);
+            diffd += diff2nn;
+            diffe += diffn2n;
+            kc = min(kc, ((uint32_t)(diff + diff2nn + diffn2n) << 6) | ub);
+        }
+        kd = min(kd, ((uint32_t)diffd << 6) | ub);
+        ke = min(ke, ((uint32_t)diffe << 6) | ub);
+    }
+    int order[5], k = 0;
+    if (ka & 63) order[k++] = (int)(ka & 63) - 32;
+    if (kb & 63) order[k++] = (int)(kb & 63) - 32;
+    if (kc & 63) order[k++] = (int)(kc & 63) - 32;
+    if (kd & 63) order[k++] = (int)(kd & 63) - 32;
+    if (ke & 63) order[k++] = (int)(ke & 63) - 32;
+    int out = NEUTRAL;
+    if (k > 1)
+    {
+        const int mid = sorted_mid(order, k);
+        const int tlim = max((int)c_limlut[iabs(mid)] >> 2, 2);
+        int sum = 0, cnt = 0;
+        for (int i = 0; i < k; i++)
+            if (iabs(order[i] - mid) <= tlim) { cnt++; sum += order[i]; }
+        if (cnt > 1) out = (NEUTRAL + ((int)((float)sum / (float)cnt) * 4)) & 0xff;
+    }
+    P.c[pl][(size_t)y * pitch + px] = (uint8_t)out;
+}
+
 // filter_dir_map / expand_dir_map and their _2x forms.
 // a = edge mask, b = direction map in, c = out.  step = 1 (half height) or 2.
 // step 1: rows 1..height-2, neighbours y+-1, mask row y.
@@ -606,6 +760,79 @@ __global__ void k_dir_map(P3 P, int step, int y0, int expand)
         }
     }
     P.c[pl][(size_t)y * pitch + x] = (uint8_t)out;
+}
+
+// k_dir_map with four pixels per thread (the form that runs; k_dir_map above is the one-pixel reference form kept for
+// HBHIP_EEDI2_1PX).  One byte per thread makes these passes latency bound: a wave lives for two dependent memory round
+// trips whatever it computes, so the time is (#waves / resident waves) x that.  Here a thread owns one aligned dword of
+// its row: three 12-byte windows (rows y-step, y, y+step of the direction map) + one or two mask dwords, a quarter of
+// the waves and of the load instructions, one dword store.  In the _2x forms (step 2) every other row is only copied:
+// that is decided per row (a wave = one row), before anything but the row's own dword is loaded.
+__device__ __forceinline__ int dir_map_px(int u0, int u1, int u2, int c0, int c1, int c2, int n0, int n1, int n2,
+                                          bool up_ok, bool dn_ok, int expand)
+{
+    const bool h0 = up_ok && u0 != PEAK, h1 = up_ok && u1 != PEAK, h2 = up_ok && u2 != PEAK;
+    const bool h3 = c0 != PEAK, h4 = !expand && c1 != PEAK, h5 = c2 != PEAK;
+    const bool h6 = dn_ok && n0 != PEAK, h7 = dn_ok && n1 != PEAK, h8 = dn_ok && n2 != PEAK;
+    const int u = h0 + h1 + h2 + h3 + h4 + h5 + h6 + h7 + h8;
+    if (u < (expand ? 5 : 4)) return expand ? c1 : PEAK;
+    int v0 = h0 ? u0 : ABSENT, v1 = h1 ? u1 : ABSENT, v2 = h2 ? u2 : ABSENT;
+    int v3 = h3 ? c0 : ABSENT, v4 = h4 ? c1 : ABSENT, v5 = h5 ? c2 : ABSENT;
+    int v6 = h6 ? n0 : ABSENT, v7 = h7 ? n1 : ABSENT, v8 = h8 ? n2 : ABSENT;
+    const int mid = mid9(v0, v1, v2, v3, v4, v5, v6, v7, v8, u);
+    const int lim = c_limlut[iabs(mid - NEUTRAL) >> 2];
+    int sum = 0, count = 0;
+    vote1(v0, mid, lim, sum, count); vote1(v1, mid, lim, sum, count); vote1(v2, mid, lim, sum, count);
+    vote1(v3, mid, lim, sum, count); vote1(v4, mid, lim, sum, count); vote1(v5, mid, lim, sum, count);
+    vote1(v6, mid, lim, sum, count); vote1(v7, mid, lim, sum, count); vote1(v8, mid, lim, sum, count);
+    const int val = (int)(((float)(sum + mid) / (float)(count + 1)) + 0.5f);
+    if (expand) return count >= 5 ? (val & 0xff) : c1;
+    if (count < 4 || (count < 5 && c1 == PEAK)) return PEAK;
+    return val & 0xff;
+}
+
+__global__ __launch_bounds__(256) void k_dir_map4(P3 P, int step, int y0, int expand)
+{
+    XY4_PLANE(P);
+    if (x >= width || y >= height) return;
+    const uint8_t *dc = P.b[pl] + (size_t)y * pitch + x;
+    uint8_t *o = P.c[pl] + (size_t)y * pitch + x;
+    const bool row_ok = step == 1 ? (y >= 1 && y < height - 1) : (y >= y0 && y < height - 1 && ((y - y0) & 1) == 0);
+    if (!row_ok)
+    {
+        // bit_blit only (and the optional copy of the input, the eedi2_bit_blit before post-processing)
+        const uint32_t v = *reinterpret_cast<const uint32_t *>(dc);
+        int out[4] = { (int)(v & 0xff), (int)((v >> 8) & 0xff), (int)((v >> 16) & 0xff), (int)(v >> 24) };
+        st4(o, out, x, width);
+        if (P.d[pl]) st4(P.d[pl] + (size_t)y * pitch + x, out, x, width);
+        return;
+    }
+    const Win12 wc = ldwin(dc), wu = ldwin(dc - (ptrdiff_t)step * pitch), wd = ldwin(dc + (ptrdiff_t)step * pitch);
+    const uint8_t *mk = P.a[pl] + (size_t)y * pitch + x;
+    const uint32_t m0 = *reinterpret_cast<const uint32_t *>(step == 1 ? mk : mk - (ptrdiff_t)pitch);
+    const uint32_t m1 = step == 1 ? 0u : *reinterpret_cast<const uint32_t *>(mk + pitch);
+    const bool up_ok = step == 1 || y > 1, dn_ok = step == 1 || y < height - 2;
+    int out[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+        const int c1 = wb(wc, k);
+        out[k] = c1;
+        const int xx = x + k;
+        const bool masked = ((m0 >> (8 * k)) & 0xff) == PEAK || (step != 1 && ((m1 >> (8 * k)) & 0xff) == PEAK);
+        if (xx >= 1 && xx < width - 1 && masked && !(expand && c1 != PEAK))
+        {
+            asm volatile("" ::: "memory");                     // a real branch: waves without a masked pixel skip the sort
+            out[k] = dir_map_px(wb(wu, k - 1), wb(wu, k), wb(wu, k + 1), wb(wc, k - 1), c1, wb(wc, k + 1),
+                                wb(wd, k - 1), wb(wd, k), wb(wd, k + 1), up_ok, dn_ok, expand);
+        }
+    }
+    st4(o, out, x, width);
+    if (P.d[pl])
+    {
+        int in[4] = { wb(wc, 0), wb(wc, 1), wb(wc, 2), wb(wc, 3) };
+        st4(P.d[pl] + (size_t)y * pitch + x, in, x, width);
+    }
 }
 
 __device__ __forceinline__ bool trips(const uint8_t *side, const uint8_t *dc, int x, int from, int to, int lim)
@@ -699,6 +926,62 @@ __global__ void k_mark_2x(P3 P, int y0)
     P.c[pl][(size_t)y * pitch + x] = (uint8_t)out;
 }
 
+// k_mark_2x with four pixels per thread (see k_dir_map4): the three line doublings are dword copies, and only the
+// rows mark_directions_2x rebuilds (every other one) load the two neighbouring half-height rows.
+__global__ __launch_bounds__(256) void k_mark_2x4(P3 P, int y0)
+{
+    XY4_PLANE(P);
+    if (x >= pitch || y >= height) return;
+    {
+        const size_t hs = (size_t)(y >> 1) * pitch + x, fs = (size_t)y * pitch + x;
+        *reinterpret_cast<uint32_t *>(P.d[pl] + fs) = *reinterpret_cast<const uint32_t *>(P.g[pl] + hs);
+        *reinterpret_cast<uint32_t *>(P.e[pl] + fs) = *reinterpret_cast<const uint32_t *>(P.b[pl] + hs);
+        *reinterpret_cast<uint32_t *>(P.f[pl] + fs) = *reinterpret_cast<const uint32_t *>(P.a[pl] + hs);
+    }
+    uint32_t *o = reinterpret_cast<uint32_t *>(P.c[pl] + (size_t)y * pitch + x);
+    if (!(y >= y0 && y < height - 1 && ((y - y0) & 1) == 0))
+    {
+        *o = 0xffffffffu;                                         // memset(dstp, 255, pitch*height)
+        return;
+    }
+    const Win12 wa = ldwin(P.b[pl] + (ptrdiff_t)((y - 1) >> 1) * pitch + x), wbn = ldwin(P.b[pl] + (ptrdiff_t)((y + 1) >> 1) * pitch + x);
+    const uint32_t k0w = *reinterpret_cast<const uint32_t *>(P.a[pl] + (ptrdiff_t)((y - 1) >> 1) * pitch + x);
+    const uint32_t k1w = *reinterpret_cast<const uint32_t *>(P.a[pl] + (ptrdiff_t)((y + 1) >> 1) * pitch + x);
+    uint32_t packed = 0xffffffffu;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+        const int xx = x + k;
+        const int k0 = (k0w >> (8 * k)) & 0xff, k1 = (k1w >> (8 * k)) & 0xff;
+        if (xx >= 1 && xx < width - 1 && (k0 == PEAK || k1 == PEAK))
+        {
+            asm volatile("" ::: "memory");                        // keep the branch (see k_dir_map)
+            const int a0 = wb(wa, k - 1), a1 = wb(wa, k), a2 = wb(wa, k + 1), b0 = wb(wbn, k - 1), b1 = wb(wbn, k), b2 = wb(wbn, k + 1);
+            const int v = (a0 != PEAK) + (a1 != PEAK) + (a2 != PEAK) + (b0 != PEAK) + (b1 != PEAK) + (b2 != PEAK);
+            if (v >= 3)
+            {
+                int s0 = a0 != PEAK ? a0 : ABSENT, s1 = a1 != PEAK ? a1 : ABSENT, s2 = a2 != PEAK ? a2 : ABSENT;
+                int s3 = b0 != PEAK ? b0 : ABSENT, s4 = b1 != PEAK ? b1 : ABSENT, s5 = b2 != PEAK ? b2 : ABSENT;
+                const int mid = mid6(s0, s1, s2, s3, s4, s5, v);
+                const int lim = c_limlut[iabs(mid - NEUTRAL) >> 2];
+                int u = 0;
+                if (iabs(a0 - b0) <= lim || a0 == PEAK || b0 == PEAK) u++;
+                if (iabs(a1 - b1) <= lim || a1 == PEAK || b1 == PEAK) u++;
+                if (iabs(a2 - b0) <= lim || a2 == PEAK || b2 == PEAK) u++;   // sic (:835): d0[x+1] against d1[x-1]
+                if (u >= 2)
+                {
+                    int sum = 0, count = 0;
+                    vote1(s0, mid, lim, sum, count); vote1(s1, mid, lim, sum, count); vote1(s2, mid, lim, sum, count);
+                    vote1(s3, mid, lim, sum, count); vote1(s4, mid, lim, sum, count); vote1(s5, mid, lim, sum, count);
+                    const int val = (int)(((float)(sum + mid) / (float)(count + 1)) + 0.5f);
+                    if (!(count < v - 2 || count < 2)) packed = (packed & ~(0xffu << (8 * k))) | ((uint32_t)(val & 0xff) << (8 * k));
+                }
+            }
+        }
+    }
+    *o = packed;
+}
+
 // a = msk2p, b = dmsk in, c = out.  Every pixel of a fillable gap computes the same
 // (u, v, back, forward, verdict) as its neighbours in the gap (:1053-1120), so each
 // thread only writes its own pixel.
@@ -758,6 +1041,134 @@ __global__ void k_fill_gaps(P3 P, int y0)
         }
     }
     P.c[pl][(size_t)y * pitch + x] = (uint8_t)out;
+}
+
+// fill_gaps_2x, the form that runs (k_fill_gaps above is the one-pixel form kept for HBHIP_EEDI2_1PX).
+// Two things cost time in the one-pixel form: most waves exist only to copy 64 bytes, and the few pixels that really
+// are gaps (direction unknown inside the mask) walk left and right on dependent byte loads (:1053-1073) while the
+// rest of their wave idles.  Here a workgroup owns FG_W consecutive pixels of one rebuilt row:
+//   1. the seven rows involved (dc = y, mask y-1 / y+1 / y-3 / y+3, direction y-2 / y+2) are staged in LDS with
+//      FG_HALO pixels either side (dwords, same flat addressing);
+//   2. every thread takes four pixels of the span: copies them to the output row (in LDS) and appends the gap pixels
+//      among them to a list - the gap pixels of the span end up in consecutive lanes;
+//   3. the list is worked off one gap pixel per thread; a walk reads LDS while it stays inside the staged span and
+//      falls back to memory beyond it (rare);
+//   4. the output row leaves as dwords.
+// Rows the pass does not rebuild are only copied (the reference's bit_blit), decided per workgroup.
+// (Tried and dropped: four pixels per thread without compaction - nearly every wave then pays four serial walks, 45 us
+// against 29; the walk on LDS without compaction, 38 us.)
+constexpr int FG_W = 1024, FG_HALO = 64, FG_LW = FG_W + 2 * FG_HALO;
+
+__global__ __launch_bounds__(256) void k_fill_gaps_c(P3 P, int y0)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_r[7][FG_LW];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[FG_W];
+    __shared__ uint16_t s_list[FG_W];
+    __shared__ int s_count;
+    const int pl = blockIdx.z, y = blockIdx.y;
+    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
+    const int x0 = blockIdx.x * FG_W, tid = threadIdx.x;
+    if (y >= height || x0 >= width) return;
+    const uint8_t *dcg = P.b[pl] + (size_t)y * pitch;
+    uint8_t *og = P.c[pl] + (size_t)y * pitch;
+    const int x = x0 + 4 * tid;
+    if (!(y >= y0 && y < height - 1 && ((y - y0) & 1) == 0))
+    {
+        if (x < width)
+        {
+            const uint32_t v = *reinterpret_cast<const uint32_t *>(dcg + x);
+            if (x + 3 < width) *reinterpret_cast<uint32_t *>(og + x) = v;
+            else for (int k = 0; k < 4 && x + k < width; k++) og[x + k] = (uint8_t)(v >> (8 * k));
+        }
+        return;
+    }
+    if (tid == 0) s_count = 0;
+    const uint8_t *g[7] = { dcg, P.a[pl] + (ptrdiff_t)(y - 1) * pitch, P.a[pl] + (ptrdiff_t)(y + 1) * pitch,
+                            dcg - 2 * (ptrdiff_t)pitch, dcg + 2 * (ptrdiff_t)pitch,
+                            P.a[pl] + (ptrdiff_t)(y - 3) * pitch, P.a[pl] + (ptrdiff_t)(y + 3) * pitch };
+    const int lo = x0 - FG_HALO;                                   // column of staged byte 0 (a multiple of 4)
+    const int ndw = (min(FG_W, hbhip_align_up_dev(width - x0, 4)) + 2 * FG_HALO) / 4;
+    for (int r = 0; r < 7; r++)
+        for (int i = tid; i < ndw; i += 256)
+            reinterpret_cast<uint32_t *>(s_r[r])[i] = reinterpret_cast<const uint32_t *>(g[r] + lo)[i];
+    __syncthreads();
+    enum { DC = 0, MC = 1, MN = 2, DP = 3, DN = 4, MP = 5, MNN = 6 };
+    if (x < width)
+    {
+        const int c = 4 * tid + FG_HALO;
+        const uint32_t cw = *reinterpret_cast<const uint32_t *>(&s_r[DC][c]);
+        const uint32_t mcw = *reinterpret_cast<const uint32_t *>(&s_r[MC][c]), mnw = *reinterpret_cast<const uint32_t *>(&s_r[MN][c]);
+        *reinterpret_cast<uint32_t *>(&s_out[4 * tid]) = cw;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            const int xx = x + k;
+            if (xx >= 1 && xx < width - 1 && ((cw >> (8 * k)) & 0xff) == PEAK &&
+                (((mcw >> (8 * k)) & 0xff) == PEAK || ((mnw >> (8 * k)) & 0xff) == PEAK))
+                s_list[atomicAdd(&s_count, 1)] = (uint16_t)(4 * tid + k);
+        }
+    }
+    __syncthreads();
+    const int count = s_count;
+    const unsigned staged = 4u * (unsigned)ndw;
+    auto rd = [&](int r, int col) -> int {
+        const unsigned k = (unsigned)(col - lo);
+        return k < staged ? (int)s_r[r][k] : (int)g[r][col];
+    };
+    for (int i = tid; i < count; i += 256)
+    {
+        const int lx = s_list[i], px = x0 + lx;
+        int u = px - 1, back = 500, forward = -500;
+        while (u)
+        {
+            const int d = rd(DC, u);
+            if (d != PEAK) { back = d; break; }
+            if (rd(MC, u) != PEAK && rd(MN, u) != PEAK) break;
+            u--;
+        }
+        int v = px + 1;
+        while (v < width)
+        {
+            const int d = rd(DC, v);
+            if (d != PEAK) { forward = d; break; }
+            if (rd(MC, v) != PEAK && rd(MN, v) != PEAK) break;
+            v++;
+        }
+        int tc = 1, bc = 1, mint = 500, maxt = -20, minb = 500, maxb = -20;
+        for (int j = u; j <= v; j++)
+        {
+            if (tc)
+            {
+                int t;
+                if (y <= 2 || (t = rd(DP, j)) == PEAK || (rd(MP, j) != PEAK && rd(MC, j) != PEAK)) { tc = 0; mint = maxt = 20; }
+                else { mint = min(mint, t); maxt = max(maxt, t); }
+            }
+            if (bc)
+            {
+                int t;
+                if (y >= height - 3 || (t = rd(DN, j)) == PEAK || (rd(MN, j) != PEAK && rd(MNN, j) != PEAK)) { bc = 0; minb = maxb = 20; }
+                else { minb = min(minb, t); maxb = max(maxb, t); }
+            }
+        }
+        if (maxt == -20) maxt = mint = 20;
+        if (maxb == -20) maxb = minb = 20;
+        const int far = max(iabs(forward - NEUTRAL), iabs(back - NEUTRAL));
+        const int thresh = max(max(far >> 2, 8), max(iabs(mint - maxt), iabs(minb - maxb)));
+        const int flim = min(far >> 2, 6);
+        if (iabs(forward - back) <= thresh && (v - u - 1 <= flim || tc || bc))
+        {
+            const double stepd = (double)(forward - back) / (double)(v - u);
+            const int j = px - u - 1;
+            s_out[lx] = (uint8_t)((back + (int)(j * stepd + 0.5)) & 0xff);
+        }
+    }
+    __syncthreads();
+    if (x < width)
+    {
+        const uint32_t v = *reinterpret_cast<const uint32_t *>(&s_out[4 * tid]);
+        if (x + 3 < width) *reinterpret_cast<uint32_t *>(og + x) = v;
+        else for (int k = 0; k < 4 && x + k < width; k++) og[x + k] = (uint8_t)(v >> (8 * k));
+    }
 }
 
 // interpolate_lattice in two launches.
@@ -1254,8 +1665,8 @@ int Eedi2Engine::run(const DevPicture *cur, int tff, hipEvent_t wait_for)
     {
         int rows[3];
         for (int c = 0; c < 3; c++) rows[c] = (dst2p.height[c] + 1) / 2;
-        HBHIP_LAUNCH(ctx_, "eedi2_fill_half", k_fill_half,
-                     dim3((srcp.stride[0] + 63) / 64, (srcp.height[0] + 3) / 4, 3), dim3(64, 4), 0, P,
+        HBHIP_LAUNCH(ctx_, "eedi2_fill_half", k_fill_half4,
+                     dim3((srcp.stride[0] + 255) / 256, (srcp.height[0] + 3) / 4, 3), dim3(64, 4), 0, P,
                      cur->pitch[0], cur->pitch[1], cur->pitch[2], !tff, rows[0], rows[1], rows[2]);
     }
     HBHIP_CHECK(ctx_, hipGetLastError());
@@ -1346,6 +1757,11 @@ int Eedi2Engine::enqueue_passes(int tff, int sel)
         const int w = whole_pitch ? f.stride[0] : f.width[0];
         return dim3((w + 255) / 256, (f.height[0] + 3) / 4, 3);
     };
+    static const bool one_px = getenv("HBHIP_EEDI2_1PX") != nullptr;                   // A/B switch: the one-pixel-per-thread forms
+    auto dir_map = [&](const char *name, const EediFrame &f, const P3 &Pv, int step, int y0v, int expand) {
+        if (one_px) HBHIP_LAUNCH(ctx_, name, k_dir_map, grid_for(f, false), blk, 0, Pv, step, y0v, expand);
+        else        HBHIP_LAUNCH(ctx_, name, k_dir_map4, grid4_for(f, false), blk, 0, Pv, step, y0v, expand);
+    };
     auto geom = [&](P3 &P, const EediFrame &f) {
         for (int c = 0; c < 3; c++) { P.pitch[c] = f.stride[c]; P.width[c] = f.width[c]; P.height[c] = f.height[c]; }
     };
@@ -1359,9 +1775,15 @@ int Eedi2Engine::enqueue_passes(int tff, int sel)
     bind(P.a, mskp); bind(P.b, srcp); bind(P.c, tmpp);
     if (par_.maximum_search_distance <= CD_HALO - 2)
     {
-        HBHIP_LAUNCH(ctx_, "eedi2_calc_directions", k_calc_dir_tile,
-                     dim3((srcp.stride[0] + CD_W - 1) / CD_W, srcp.height[0], 3), dim3(CD_W), 0, P,
-                     par_.maximum_search_distance, (par_.noise_threshold * 13) & 0xff, (par_.noise_threshold * 19) & 0xff);
+        static const bool old_form = getenv("HBHIP_EEDI2_OLD_CALCDIR") != nullptr;     // A/B switch for profiling
+        if (old_form)
+            HBHIP_LAUNCH(ctx_, "eedi2_calc_directions", k_calc_dir_tile,
+                         dim3((srcp.stride[0] + CD_W - 1) / CD_W, srcp.height[0], 3), dim3(CD_W), 0, P,
+                         par_.maximum_search_distance, (par_.noise_threshold * 13) & 0xff, (par_.noise_threshold * 19) & 0xff);
+        else
+            HBHIP_LAUNCH(ctx_, "eedi2_calc_directions", k_calc_dir_tile2,
+                         dim3((srcp.stride[0] + CD_W - 1) / CD_W, srcp.height[0], 3), dim3(CD_W), 0, P,
+                         par_.maximum_search_distance, (par_.noise_threshold * 13) & 0xff, (par_.noise_threshold * 19) & 0xff);
     }
     else
     {
@@ -1374,9 +1796,9 @@ int Eedi2Engine::enqueue_passes(int tff, int sel)
                      (par_.noise_threshold * 13) & 0xff, (par_.noise_threshold * 19) & 0xff);
     }
     bind(P.a, mskp); bind(P.b, tmpp); bind(P.c, dstp);
-    HBHIP_LAUNCH(ctx_, "eedi2_filter_dir_map", k_dir_map, grid_for(srcp, false), blk, 0, P, 1, 1, 0);
+    dir_map("eedi2_filter_dir_map", srcp, P, 1, 1, 0);
     bind(P.a, mskp); bind(P.b, dstp); bind(P.c, tmpp);
-    HBHIP_LAUNCH(ctx_, "eedi2_expand_dir_map", k_dir_map, grid_for(srcp, false), blk, 0, P, 1, 1, 1);
+    dir_map("eedi2_expand_dir_map", srcp, P, 1, 1, 1);
     bind(P.a, mskp); bind(P.b, tmpp); bind(P.c, dstp);
     HBHIP_LAUNCH(ctx_, "eedi2_filter_map", k_filter_map, grid_for(srcp, false), blk, 0, P);
     // line doubling of srcp / dstp / mskp + mark_directions_2x in one launch (full-height geometry)
@@ -1384,16 +1806,22 @@ int Eedi2Engine::enqueue_passes(int tff, int sel)
     const int y0 = 2 - tff;
     bind(P.g, srcp); bind(P.b, dstp); bind(P.a, mskp);
     bind(P.d, dst2p); bind(P.e, tmp2p2); bind(P.f, msk2p); bind(P.c, tmp2p);
-    HBHIP_LAUNCH(ctx_, "eedi2_mark_directions_2x", k_mark_2x, grid_for(dst2p, true), blk, 0, P, y0);
+    if (one_px) HBHIP_LAUNCH(ctx_, "eedi2_mark_directions_2x", k_mark_2x, grid_for(dst2p, true), blk, 0, P, y0);
+    else        HBHIP_LAUNCH(ctx_, "eedi2_mark_directions_2x", k_mark_2x4, grid4_for(dst2p, true), blk, 0, P, y0);
     for (int c = 0; c < 3; c++) P.d[c] = P.e[c] = P.f[c] = P.g[c] = nullptr;    // slot d doubles as k_dir_map's optional copy target
     bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
-    HBHIP_LAUNCH(ctx_, "eedi2_filter_dir_map_2x", k_dir_map, grid_for(dst2p, false), blk, 0, P, 2, y0, 0);
+    dir_map("eedi2_filter_dir_map_2x", dst2p, P, 2, y0, 0);
     bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
-    HBHIP_LAUNCH(ctx_, "eedi2_expand_dir_map_2x", k_dir_map, grid_for(dst2p, false), blk, 0, P, 2, y0, 1);
+    dir_map("eedi2_expand_dir_map_2x", dst2p, P, 2, y0, 1);
+    auto fill_gaps = [&](const P3 &Pv) {
+        if (one_px) HBHIP_LAUNCH(ctx_, "eedi2_fill_gaps_2x", k_fill_gaps, grid_for(dst2p, false), blk, 0, Pv, y0);
+        else        HBHIP_LAUNCH(ctx_, "eedi2_fill_gaps_2x", k_fill_gaps_c, dim3((dst2p.width[0] + FG_W - 1) / FG_W, dst2p.height[0], 3),
+                                 dim3(256), 0, Pv, y0);
+    };
     bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
-    HBHIP_LAUNCH(ctx_, "eedi2_fill_gaps_2x", k_fill_gaps, grid_for(dst2p, false), blk, 0, P, y0);
+    fill_gaps(P);
     bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
-    HBHIP_LAUNCH(ctx_, "eedi2_fill_gaps_2x", k_fill_gaps, grid_for(dst2p, false), blk, 0, P, y0);
+    fill_gaps(P);
     // lattice
     bind(P.a, tmp2p); bind(P.b, dst2p); bind(P.c, tmp2p2);
     {
@@ -1410,10 +1838,10 @@ int Eedi2Engine::enqueue_passes(int tff, int sel)
         // (decomb_template.c:426); the filter that follows reads every byte of tmp2p the blit copies,
         // so it writes that copy itself (slot d) and the separate launch is saved
         bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp); bind(P.d, tmp2p2);
-        HBHIP_LAUNCH(ctx_, "eedi2_filter_dir_map_2x", k_dir_map, grid_for(dst2p, false), blk, 0, P, 2, y0, 0);
+        dir_map("eedi2_filter_dir_map_2x", dst2p, P, 2, y0, 0);
         for (int c = 0; c < 3; c++) P.d[c] = nullptr;
         bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
-        HBHIP_LAUNCH(ctx_, "eedi2_expand_dir_map_2x", k_dir_map, grid_for(dst2p, false), blk, 0, P, 2, y0, 1);
+        dir_map("eedi2_expand_dir_map_2x", dst2p, P, 2, y0, 1);
         bind(P.a, tmp2p); bind(P.b, tmp2p2); bind(P.c, dst2p);
         HBHIP_LAUNCH(ctx_, "eedi2_post_process", k_post, grid4_for(dst2p, false), blk, 0, P, y0);
     }

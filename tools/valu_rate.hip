@@ -52,6 +52,10 @@
 #define OP_RCPF(r)    "v_rcp_f32 " r ", " r "\n"
 #define OP_CNDMASK(r) "v_cndmask_b32 " r ", " r ", %8, vcc\n"
 #define OP_CMP(r)     "v_cmp_lt_u32 vcc, " r ", %8\n"
+#define OP_CNDS(r)    "v_cndmask_b32_e64 " r ", " r ", %8, s[10:11]\n"
+#define OP_CMPS(r)    "v_cmp_lt_u32_e64 s[10:11], " r ", %8\n"
+#define OP_CMPCND(r)  "v_cmp_lt_u32 vcc, " r ", %8\nv_cndmask_b32 " r ", " r ", %8, vcc\n"
+#define OP_MINMAX(r)  "v_min_u32 " r ", " r ", %8\nv_max_u32 " r ", " r ", %8\n"
 #define OP_MINF(r)    "v_min_f32 " r ", " r ", %8\n"
 #define OP_MAXF(r)    "v_max_f32 " r ", " r ", %8\n"
 #define OP_SUBF(r)    "v_sub_f32 " r ", " r ", %8\n"
@@ -120,7 +124,7 @@ struct Init<uint64_t> { static __device__ uint64_t make(uint32_t s) { return (ui
             asm volatile(R64(OP)                                                                            \
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) \
                          : "v"(b)                                                                           \
-                         : "vcc");                                                                          \
+                         : "vcc", "s10", "s11");                                                                          \
         uint64_t t1 = __builtin_readcyclecounter();                                                         \
         TYPE r = a0;                                                                                        \
         uint32_t acc = 0;                                                                                   \
@@ -163,6 +167,10 @@ DEFINE_KERNEL(k_fma_f32, uint32_t, OP_FMAF)
 DEFINE_KERNEL(k_rcp_f32, uint32_t, OP_RCPF)
 DEFINE_KERNEL(k_cndmask, uint32_t, OP_CNDMASK)
 DEFINE_KERNEL(k_cmp, uint32_t, OP_CMP)
+DEFINE_KERNEL(k_cnd_sgpr, uint32_t, OP_CNDS)
+DEFINE_KERNEL(k_cmp_sgpr, uint32_t, OP_CMPS)
+DEFINE_KERNEL(k_cmp_cnd_pair, uint32_t, OP_CMPCND)
+DEFINE_KERNEL(k_min_max_pair, uint32_t, OP_MINMAX)
 DEFINE_KERNEL(k_min_f32, uint32_t, OP_MINF)
 DEFINE_KERNEL(k_max_f32, uint32_t, OP_MAXF)
 DEFINE_KERNEL(k_sub_f32, uint32_t, OP_SUBF)
@@ -221,6 +229,8 @@ int main(int argc, char **argv)
         {"v_cvt_f32_ubyte0", k_cvt_f32_ubyte}, {"v_cvt_f32_u32", k_cvt_f32_u32}, {"v_cvt_u32_f32", k_cvt_u32_f32},
         {"v_mul_f32", k_mul_f32}, {"v_add_f32", k_add_f32}, {"v_fma_f32", k_fma_f32}, {"v_rcp_f32", k_rcp_f32},
         {"v_cndmask_b32", k_cndmask}, {"v_cmp_lt_u32", k_cmp},
+        {"v_cndmask_b32_e64 sgpr mask", k_cnd_sgpr}, {"v_cmp_lt_u32_e64 sgpr dst", k_cmp_sgpr},
+        {"v_cmp+v_cndmask pair (2 insts)", k_cmp_cnd_pair}, {"v_min+v_max pair (2 insts)", k_min_max_pair},
         {"v_min_f32", k_min_f32}, {"v_max_f32", k_max_f32}, {"v_sub_f32", k_sub_f32}, {"v_fmac_f32", k_fmac_f32},
         {"v_med3_i32", k_med3}, {"v_max_u32", k_max_u32}, {"v_min_i32", k_min_i32}, {"v_or_b32", k_or}, {"v_xor_b32", k_xor},
         {"v_mov_b32", k_mov}, {"v_mov_b32_dpp row_shr", k_mov_dpp}, {"v_lshrrev_b32", k_lshr}, {"v_ashrrev_i32", k_ashr},
