@@ -126,7 +126,12 @@ struct hbhip_chain
             for (int c = 0; c < 3; c++) first->in_stride[c] = in[i].stride[c];
             first->in_is_dev = true;
             rc = copy_in(p, &in[i]);
-            if (rc != HBHIP_OK) return rc;
+            if (rc != HBHIP_OK)
+            {
+                first->abandon_input(p);
+                for (DevPicture *q : cur) first->abandon_input(q);
+                return rc;
+            }
             cur.push_back(p);
         }
         for (size_t s = 0; s < st.size(); s++)

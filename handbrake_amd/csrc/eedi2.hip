@@ -1561,6 +1561,7 @@ Eedi2Engine::Eedi2Engine(hbhip_ctx *ctx, const PicGeometry &geo, const Eedi2Para
 Eedi2Engine::~Eedi2Engine()
 {
     for (auto &gg : graph_) for (auto &g : gg) if (g) (void)hipGraphExecDestroy(g);
+    if (cap_ctx_) hbhip_ctx_destroy(cap_ctx_);
     if (own_share_.mask[1].alloc) (void)hipFree(own_share_.mask[1].alloc);
     if (own_share_.ev_mask) (void)hipEventDestroy(own_share_.ev_mask);
     if (ev_done_) (void)hipEventDestroy(ev_done_);
@@ -1689,16 +1690,18 @@ int Eedi2Engine::run(const DevPicture *cur, int tff, hipEvent_t wait_for)
     // captured once into a hipGraph and replayed, which removes the per-launch submission gaps.
     // The per-kernel profiler needs individual launches, so it bypasses the graph.
     int rc = HBHIP_OK;
-    if (ctx_->profile || !use_graph_) rc = enqueue_passes(tff, sel);
+    if (ctx_->profile || !use_graph_) rc = enqueue_passes(tff, sel, ctx_);
     else
     {
         hipGraphExec_t &exec = graph_[tff ? 1 : 0][sel];
         if (!exec)
         {
             hipGraph_t g = nullptr;
-            HBHIP_CHECK(ctx_, hipStreamBeginCapture(ctx_->stream, hipStreamCaptureModeThreadLocal));
-            const int crc = enqueue_passes(tff, sel);
-            const hipError_t e = hipStreamEndCapture(ctx_->stream, &g);
+            if (!cap_ctx_ && hbhip_ctx_create(ctx_->device, &cap_ctx_) != HBHIP_OK) cap_ctx_ = nullptr;
+            if (!cap_ctx_) { use_graph_ = false; return enqueue_passes(tff, sel, ctx_); }
+            HBHIP_CHECK(ctx_, hipStreamBeginCapture(cap_ctx_->stream, hipStreamCaptureModeThreadLocal));
+            const int crc = enqueue_passes(tff, sel, cap_ctx_);
+            const hipError_t e = hipStreamEndCapture(cap_ctx_->stream, &g);
             hipError_t ie = hipErrorUnknown;
             if (crc == HBHIP_OK && e == hipSuccess && g) ie = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
             if (g) (void)hipGraphDestroy(g);
@@ -1710,7 +1713,7 @@ int Eedi2Engine::run(const DevPicture *cur, int tff, hipEvent_t wait_for)
             }
         }
         if (exec) HBHIP_CHECK(ctx_, hipGraphLaunch(exec, ctx_->stream));
-        else      rc = enqueue_passes(tff, sel);
+        else      rc = enqueue_passes(tff, sel, ctx_);
     }
     if (rc != HBHIP_OK) return rc;
     if (ev_done_) HBHIP_CHECK(ctx_, hipEventRecord(ev_done_, ctx_->stream));
@@ -1744,8 +1747,11 @@ int Eedi2Engine::enqueue_mask(int sel)
     return HBHIP_OK;
 }
 
-int Eedi2Engine::enqueue_passes(int tff, int sel)
+int Eedi2Engine::enqueue_passes(int tff, int sel, hbhip_ctx *lc)
 {
+    // lc = the context whose stream the launches go to: the engine's own, or - while the sequence is being captured
+    // into a graph - a private one (another filter's thread may be launching into the shared stream at that moment,
+    // and whatever enters a capturing stream becomes part of the capture)
     EediFrame &srcp = half_[0], &mskp = share_->mask[sel], &tmpp = half_[2], &dstp = half_[3];
     EediFrame &dst2p = full_[0], &tmp2p2 = full_[1], &msk2p = full_[2], &tmp2p = full_[3], &dst2mp = full_[4];
     const dim3 blk(64, 4);
@@ -1759,8 +1765,8 @@ int Eedi2Engine::enqueue_passes(int tff, int sel)
     };
     static const bool one_px = getenv("HBHIP_EEDI2_1PX") != nullptr;                   // A/B switch: the one-pixel-per-thread forms
     auto dir_map = [&](const char *name, const EediFrame &f, const P3 &Pv, int step, int y0v, int expand) {
-        if (one_px) HBHIP_LAUNCH(ctx_, name, k_dir_map, grid_for(f, false), blk, 0, Pv, step, y0v, expand);
-        else        HBHIP_LAUNCH(ctx_, name, k_dir_map4, grid4_for(f, false), blk, 0, Pv, step, y0v, expand);
+        if (one_px) HBHIP_LAUNCH(lc, name, k_dir_map, grid_for(f, false), blk, 0, Pv, step, y0v, expand);
+        else        HBHIP_LAUNCH(lc, name, k_dir_map4, grid4_for(f, false), blk, 0, Pv, step, y0v, expand);
     };
     auto geom = [&](P3 &P, const EediFrame &f) {
         for (int c = 0; c < 3; c++) { P.pitch[c] = f.stride[c]; P.width[c] = f.width[c]; P.height[c] = f.height[c]; }
@@ -1777,21 +1783,21 @@ int Eedi2Engine::enqueue_passes(int tff, int sel)
     {
         static const bool old_form = getenv("HBHIP_EEDI2_OLD_CALCDIR") != nullptr;     // A/B switch for profiling
         if (old_form)
-            HBHIP_LAUNCH(ctx_, "eedi2_calc_directions", k_calc_dir_tile,
+            HBHIP_LAUNCH(lc, "eedi2_calc_directions", k_calc_dir_tile,
                          dim3((srcp.stride[0] + CD_W - 1) / CD_W, srcp.height[0], 3), dim3(CD_W), 0, P,
                          par_.maximum_search_distance, (par_.noise_threshold * 13) & 0xff, (par_.noise_threshold * 19) & 0xff);
         else
-            HBHIP_LAUNCH(ctx_, "eedi2_calc_directions", k_calc_dir_tile2,
+            HBHIP_LAUNCH(lc, "eedi2_calc_directions", k_calc_dir_tile2,
                          dim3((srcp.stride[0] + CD_W - 1) / CD_W, srcp.height[0], 3), dim3(CD_W), 0, P,
                          par_.maximum_search_distance, (par_.noise_threshold * 13) & 0xff, (par_.noise_threshold * 19) & 0xff);
     }
     else
     {
-        HBHIP_CHECK(ctx_, hipMemsetAsync(work_count_, 0, sizeof(int), ctx_->stream));
-        HBHIP_LAUNCH(ctx_, "eedi2_calc_directions_mark", k_calc_dir_mark, grid_for(srcp, true), blk, 0, P, work_list_, work_count_);
+        HBHIP_CHECK(lc, hipMemsetAsync(work_count_, 0, sizeof(int), lc->stream));
+        HBHIP_LAUNCH(lc, "eedi2_calc_directions_mark", k_calc_dir_mark, grid_for(srcp, true), blk, 0, P, work_list_, work_count_);
         size_t half_px = 0;
         for (int c = 0; c < 3; c++) half_px += (size_t)srcp.width[c] * srcp.height[c];
-        HBHIP_LAUNCH(ctx_, "eedi2_calc_directions_work", k_calc_dir_work, dim3((unsigned)((half_px + 255) / 256)), dim3(256), 0, P,
+        HBHIP_LAUNCH(lc, "eedi2_calc_directions_work", k_calc_dir_work, dim3((unsigned)((half_px + 255) / 256)), dim3(256), 0, P,
                      (const uint32_t *)work_list_, (const int *)work_count_, par_.maximum_search_distance,
                      (par_.noise_threshold * 13) & 0xff, (par_.noise_threshold * 19) & 0xff);
     }
@@ -1800,22 +1806,22 @@ int Eedi2Engine::enqueue_passes(int tff, int sel)
     bind(P.a, mskp); bind(P.b, dstp); bind(P.c, tmpp);
     dir_map("eedi2_expand_dir_map", srcp, P, 1, 1, 1);
     bind(P.a, mskp); bind(P.b, tmpp); bind(P.c, dstp);
-    HBHIP_LAUNCH(ctx_, "eedi2_filter_map", k_filter_map, grid_for(srcp, false), blk, 0, P);
+    HBHIP_LAUNCH(lc, "eedi2_filter_map", k_filter_map, grid_for(srcp, false), blk, 0, P);
     // line doubling of srcp / dstp / mskp + mark_directions_2x in one launch (full-height geometry)
     geom(P, dst2p);
     const int y0 = 2 - tff;
     bind(P.g, srcp); bind(P.b, dstp); bind(P.a, mskp);
     bind(P.d, dst2p); bind(P.e, tmp2p2); bind(P.f, msk2p); bind(P.c, tmp2p);
-    if (one_px) HBHIP_LAUNCH(ctx_, "eedi2_mark_directions_2x", k_mark_2x, grid_for(dst2p, true), blk, 0, P, y0);
-    else        HBHIP_LAUNCH(ctx_, "eedi2_mark_directions_2x", k_mark_2x4, grid4_for(dst2p, true), blk, 0, P, y0);
+    if (one_px) HBHIP_LAUNCH(lc, "eedi2_mark_directions_2x", k_mark_2x, grid_for(dst2p, true), blk, 0, P, y0);
+    else        HBHIP_LAUNCH(lc, "eedi2_mark_directions_2x", k_mark_2x4, grid4_for(dst2p, true), blk, 0, P, y0);
     for (int c = 0; c < 3; c++) P.d[c] = P.e[c] = P.f[c] = P.g[c] = nullptr;    // slot d doubles as k_dir_map's optional copy target
     bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
     dir_map("eedi2_filter_dir_map_2x", dst2p, P, 2, y0, 0);
     bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
     dir_map("eedi2_expand_dir_map_2x", dst2p, P, 2, y0, 1);
     auto fill_gaps = [&](const P3 &Pv) {
-        if (one_px) HBHIP_LAUNCH(ctx_, "eedi2_fill_gaps_2x", k_fill_gaps, grid_for(dst2p, false), blk, 0, Pv, y0);
-        else        HBHIP_LAUNCH(ctx_, "eedi2_fill_gaps_2x", k_fill_gaps_c, dim3((dst2p.width[0] + FG_W - 1) / FG_W, dst2p.height[0], 3),
+        if (one_px) HBHIP_LAUNCH(lc, "eedi2_fill_gaps_2x", k_fill_gaps, grid_for(dst2p, false), blk, 0, Pv, y0);
+        else        HBHIP_LAUNCH(lc, "eedi2_fill_gaps_2x", k_fill_gaps_c, dim3((dst2p.width[0] + FG_W - 1) / FG_W, dst2p.height[0], 3),
                                  dim3(256), 0, Pv, y0);
     };
     bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
@@ -1827,9 +1833,9 @@ int Eedi2Engine::enqueue_passes(int tff, int sel)
     {
         const int nrows = (dst2p.height[0] - y0) / 2;
         const int nt = par_.noise_threshold;
-        HBHIP_LAUNCH(ctx_, "eedi2_lattice_candidates", k_lattice_cand, dim3((dst2p.width[0] + LC_W - 1) / LC_W, nrows, 3),
+        HBHIP_LAUNCH(lc, "eedi2_lattice_candidates", k_lattice_cand, dim3((dst2p.width[0] + LC_W - 1) / LC_W, nrows, 3),
                      dim3(LC_W), 0, P, cand_, cand_pitch_, cand_plane_stride_, tff, (nt * 4) & 0xff, (nt * 7) & 0xff, (nt * 8) & 0xff, nt);
-        HBHIP_LAUNCH(ctx_, "eedi2_lattice_resolve", k_lattice_resolve, dim3(1, nrows + 1, 3), dim3(LR_T), 0, P,
+        HBHIP_LAUNCH(lc, "eedi2_lattice_resolve", k_lattice_resolve, dim3(1, nrows + 1, 3), dim3(LR_T), 0, P,
                      (const uint32_t *)cand_, cand_pitch_, cand_plane_stride_, tff);
     }
     if (par_.post_processing == 1 || par_.post_processing == 3)
@@ -1843,7 +1849,7 @@ int Eedi2Engine::enqueue_passes(int tff, int sel)
         bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
         dir_map("eedi2_expand_dir_map_2x", dst2p, P, 2, y0, 1);
         bind(P.a, tmp2p); bind(P.b, tmp2p2); bind(P.c, dst2p);
-        HBHIP_LAUNCH(ctx_, "eedi2_post_process", k_post, grid4_for(dst2p, false), blk, 0, P, y0);
+        HBHIP_LAUNCH(lc, "eedi2_post_process", k_post, grid4_for(dst2p, false), blk, 0, P, y0);
     }
     if (par_.post_processing == 2 || par_.post_processing == 3)
     {
@@ -1855,17 +1861,17 @@ int Eedi2Engine::enqueue_passes(int tff, int sel)
             for (int i = 0; i < 3; i++) { A.c[i] = deriv_[i]; A.t[i] = deriv_tmp_[i]; }
             A.pitch = srcp.stride[c]; A.width = srcp.width[c]; A.height = srcp.height[c];
             const dim3 g1((A.width + 63) / 64, (A.height + 3) / 4, 1), g3(g1.x, g1.y, 3);
-            HBHIP_LAUNCH(ctx_, "eedi2_gaussian_blur1_h", k_blur1<false>, g1, blk, 0, A);
-            HBHIP_LAUNCH(ctx_, "eedi2_gaussian_blur1_v", k_blur1<true>, g1, blk, 0, A);
-            HBHIP_LAUNCH(ctx_, "eedi2_calc_derivatives", k_derivatives, g1, blk, 0, A);
-            HBHIP_LAUNCH(ctx_, "eedi2_gaussian_blur_sqrt2_h", k_blur_sqrt2<false>, g3, blk, 0, A);
-            HBHIP_LAUNCH(ctx_, "eedi2_gaussian_blur_sqrt2_v", k_blur_sqrt2<true>, g3, blk, 0, A);
+            HBHIP_LAUNCH(lc, "eedi2_gaussian_blur1_h", k_blur1<false>, g1, blk, 0, A);
+            HBHIP_LAUNCH(lc, "eedi2_gaussian_blur1_v", k_blur1<true>, g1, blk, 0, A);
+            HBHIP_LAUNCH(lc, "eedi2_calc_derivatives", k_derivatives, g1, blk, 0, A);
+            HBHIP_LAUNCH(lc, "eedi2_gaussian_blur_sqrt2_h", k_blur_sqrt2<false>, g3, blk, 0, A);
+            HBHIP_LAUNCH(lc, "eedi2_gaussian_blur_sqrt2_v", k_blur_sqrt2<true>, g3, blk, 0, A);
             const int rows = (dst2p.height[c] - 7 - (8 - tff) + 1) / 2;      // y = 8-field, 10-field, ... < height-7
             if (rows > 0)
-                HBHIP_LAUNCH(ctx_, "eedi2_post_process_corner", k_post_corner, dim3((A.width + 63) / 64, (rows + 3) / 4, 1), blk, 0, A,
+                HBHIP_LAUNCH(lc, "eedi2_post_process_corner", k_post_corner, dim3((A.width + 63) / 64, (rows + 3) / 4, 1), blk, 0, A,
                              (const uint8_t *)tmp2p2.plane[c], dst2p.plane[c], tff, dst2p.height[c]);
         }
     }
-    HBHIP_CHECK(ctx_, hipGetLastError());
+    HBHIP_CHECK(lc, hipGetLastError());
     return HBHIP_OK;
 }

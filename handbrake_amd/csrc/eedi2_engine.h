@@ -63,11 +63,12 @@ public:
 private:
     int alloc_frame(EediFrame &f, int width, int height);
     int enqueue_mask(int sel);                     // the five mask passes; sel = mask buffer to write
-    int enqueue_passes(int tff, int sel);          // everything after them
+    int enqueue_passes(int tff, int sel, hbhip_ctx *lc);   // everything after them, launched on lc's stream
     hipGraphExec_t graph_[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // captured pass sequence per (field parity, mask buffer)
     EediMaskShare  own_share_;                     // the two MSKPF buffers (mask[0] is half_[1]) when not shared
     EediMaskShare *share_ = nullptr;
     hbhip_ctx  *main_ = nullptr;                   // != ctx_ for a side engine
+    hbhip_ctx  *cap_ctx_ = nullptr;                // private stream the pass sequence is captured on
     hipEvent_t  ev_done_ = nullptr;
     bool        use_graph_ = true;
     hbhip_ctx  *ctx_;

@@ -8,6 +8,7 @@
 // ---------------------------------------------------------------- ctx helpers
 int hbhip_ctx::fail(hipError_t e, const char *what)
 {
+    std::lock_guard<std::recursive_mutex> lk(state_lock);
     last_error = std::string(what) + ": " + hipGetErrorString(e);
     (void)hipGetLastError();
     if (e == hipErrorOutOfMemory) return HBHIP_ERR_NOMEM;
@@ -40,6 +41,7 @@ int hbhip_ctx::prof_name(const char *name)
 
 void hbhip_ctx::prof_begin(const char *name)
 {
+    std::lock_guard<std::recursive_mutex> lk(state_lock);
     if (prof_pending.size() >= 8192) prof_resolve();
     hbhip_prof_pending p;
     p.name_idx = prof_name(name);
@@ -51,6 +53,7 @@ void hbhip_ctx::prof_begin(const char *name)
 
 void hbhip_ctx::prof_end()
 {
+    std::lock_guard<std::recursive_mutex> lk(state_lock);
     if (prof_pending.empty()) return;
     hbhip_prof_pending &p = prof_pending.back();
     if (p.ev1) (void)hipEventRecord(p.ev1, stream);
@@ -58,6 +61,7 @@ void hbhip_ctx::prof_end()
 
 void hbhip_ctx::prof_resolve()
 {
+    std::lock_guard<std::recursive_mutex> lk(state_lock);
     if (prof_pending.empty()) return;
     (void)hipStreamSynchronize(stream);
     for (auto &p : prof_pending)
@@ -328,7 +332,12 @@ int hbhip_ctx_sync(hbhip_ctx *ctx)
 
 const char *hbhip_ctx_last_error(hbhip_ctx *ctx)
 {
-    return ctx ? ctx->last_error.c_str() : "";
+    if (!ctx) return "";
+    // a copy per calling thread: the string itself may be rewritten by another filter's thread
+    static thread_local std::string copy;
+    std::lock_guard<std::recursive_mutex> lk(ctx->state_lock);
+    copy = ctx->last_error;
+    return copy.c_str();
 }
 
 int hbhip_ctx_device_name(hbhip_ctx *ctx, char *buf, int len)
@@ -341,6 +350,7 @@ int hbhip_ctx_device_name(hbhip_ctx *ctx, char *buf, int len)
 int hbhip_ctx_profile_enable(hbhip_ctx *ctx, int on)
 {
     if (!ctx) return HBHIP_ERR_ARG;
+    std::lock_guard<std::recursive_mutex> lk(ctx->state_lock);
     if (!on) ctx->prof_resolve();
     ctx->profile = on != 0;
     return HBHIP_OK;
@@ -545,12 +555,16 @@ int hbhip_filter_push(hbhip_filter *f, const hbhip_host_frame *in, int64_t tag)
     for (int c = 0; c < 3; c++) f->in_stride[c] = in->stride[c];
     f->in_is_dev = false;
     int rc = hbhip_copy_h2d(f->ctx, pic, in);
-    if (rc != HBHIP_OK) return rc;
     // The caller may free or reuse its (pageable) planes as soon as we return
     // (filter_loop closes buf_in, work.c:2566-2569), so the upload must have
     // consumed them.
-    if (hipStreamSynchronize(f->ctx->stream) != hipSuccess)
-        return f->ctx->fail(hipGetLastError(), "hipStreamSynchronize(push)");
+    if (rc == HBHIP_OK && hipStreamSynchronize(f->ctx->stream) != hipSuccess)
+        rc = f->ctx->fail(hipGetLastError(), "hipStreamSynchronize(push)");
+    if (rc != HBHIP_OK)
+    {
+        f->abandon_input(pic);             // not submitted: back to its pool
+        return rc;
+    }
     return f->submit(pic);
 }
 
@@ -564,7 +578,11 @@ int hbhip_filter_push_dev(hbhip_filter *f, const hbhip_dev_frame *in, int64_t ta
     for (int c = 0; c < 3; c++) f->in_stride[c] = in->stride[c];
     f->in_is_dev = true;
     int rc = hbhip_copy_d2d_in(f->ctx, pic, in);
-    if (rc != HBHIP_OK) return rc;
+    if (rc != HBHIP_OK)
+    {
+        f->abandon_input(pic);
+        return rc;
+    }
     return f->submit(pic);
 }
 

@@ -47,6 +47,9 @@ struct hbhip_ctx
     // pool of device-resident frames handed between filters (hbhip_frame_*)
     std::vector<struct hbhip_frame *> frame_pool;
     std::mutex frame_lock;          // filters of one job run on different host threads
+    // last_error and the profiler's bookkeeping are written from whichever filter thread fails / launches:
+    // libhb runs every filter of a job on its own thread (work.c:2527-2600) and they share this context
+    std::recursive_mutex state_lock;
 
     int  fail(hipError_t e, const char *what);
     int  prof_name(const char *name);
@@ -66,9 +69,16 @@ struct hbhip_ctx
 // bracketed by two events whose delta is accumulated under `name`.
 #define HBHIP_LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                \
     do {                                                                        \
-        if ((ctx)->profile) (ctx)->prof_begin(name);                            \
-        hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__); \
-        if ((ctx)->profile) (ctx)->prof_end();                                  \
+        if ((ctx)->profile)                                                     \
+        {                                                                       \
+            /* launch and its two events as one unit: other filter threads share the stream */ \
+            std::lock_guard<std::recursive_mutex> _plk((ctx)->state_lock);      \
+            (ctx)->prof_begin(name);                                            \
+            hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__); \
+            (ctx)->prof_end();                                                  \
+        }                                                                       \
+        else                                                                    \
+            hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__); \
     } while (0)
 
 static inline int hbhip_align_up(int v, int a) { return (v + a - 1) / a * a; }
@@ -165,6 +175,8 @@ struct hbhip_filter
     // Input side: the subclass gets a device picture already filled.
     virtual DevPicture *acquire_input() = 0;
     virtual int submit(DevPicture *pic) = 0;       // takes ownership
+    // give back a picture from acquire_input() that was never submitted (a failed upload)
+    virtual void abandon_input(DevPicture *pic) { hbhip_pic_release(pic); }
     virtual int flush() = 0;
     // Output side.
     virtual int pending() = 0;

@@ -1286,12 +1286,20 @@ private:
         for (int t = 0; t < ready; t++)
         {
             outs[t] = pool.acquire();
-            if (!outs[t]) return HBHIP_ERR_NOMEM;
+            if (!outs[t])
+            {
+                for (int k = 0; k < t; k++) pool.release(outs[k]);      // nothing was launched into them
+                return HBHIP_ERR_NOMEM;
+            }
             outs[t]->tag = in[t]->tag;
             vout.push_back(view_of(outs[t]));
         }
         int rc = launch_views(vin, ready, vout);
-        if (rc != HBHIP_OK) return rc;
+        if (rc != HBHIP_OK)
+        {
+            for (DevPicture *o : outs) pool.release(o);
+            return rc;
+        }
         for (int t = 0; t < ready; t++)
         {
             out.push_back(outs[t]);

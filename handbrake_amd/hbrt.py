@@ -232,6 +232,14 @@ def run_job(filters, frames, flags: int = 0x10, pix_fmt: int = AV_PIX_FMT_YUV420
     return names, out
 
 
+def set_threaded(on: bool):
+    """Chains / jobs opened from now on run one thread per filter, as libhb's filter_loop does."""
+    rt = runtime()
+    rt.hbh_set_threaded.argtypes = [C.c_int]
+    rt.hbh_set_threaded.restype = None
+    rt.hbh_set_threaded(int(on))
+
+
 def set_source_color(prim: int = 1, transfer: int = 1, matrix: int = 1, color_range: int = 1):
     """Colour description (init->color_*) of the source of chains opened from now on."""
     rt = runtime()

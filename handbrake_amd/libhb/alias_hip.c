@@ -85,19 +85,38 @@ hb_filter_object_t hb_filter_crop_scale_hip =
     .settings_template = crop_scale_hip_template,
 };
 
-static int64_t gcd64(int64_t a, int64_t b) { while (b) { int64_t t = a % b; a = b; b = t; } return a < 0 ? -a : a; }
-
-/* hb_limit_rational (common.c) stand-in: reduce, then halve until both terms fit */
-static void limit_rational(int *num, int *den, int64_t n, int64_t d, int64_t limit)
+#ifdef HBHIP_IN_LIBHB
+#define limit_rational hb_limit_rational
+#else
+/* hb_limit_rational (common.c:3912-3938), the same arithmetic: reduce by the gcd (hb_reduce64, :3947-3968); if a term
+ * still reaches the limit, the larger one becomes the limit and the other is scaled by a double and truncated */
+static void limit_rational(int *x, int *y, int64_t num, int64_t den, int limit)
 {
-    int64_t g = gcd64(n, d);
-    if (g > 1) { n /= g; d /= g; }
-    while (n > limit || d > limit) { n >>= 1; d >>= 1; }
-    if (n < 1) n = 1;
-    if (d < 1) d = 1;
-    *num = (int)n;
-    *den = (int)d;
+    int64_t n = num, d = den;
+    while (d) { int64_t t = d; d = n % d; n = t; }
+    if (n) { num /= n; den /= n; }
+    if (num < limit && den < limit)
+    {
+        *x = (int)num;
+        *y = (int)den;
+        return;
+    }
+    if (num > den)
+    {
+        double div = (double)limit / num;
+        num = limit;
+        den *= div;
+    }
+    else
+    {
+        double div = (double)limit / den;
+        den = limit;
+        num *= div;
+    }
+    *x = (int)num;
+    *y = (int)den;
 }
+#endif
 
 static int crop_scale_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init)
 {
@@ -117,6 +136,16 @@ static int crop_scale_hip_init(hb_filter_object_t *filter, hb_filter_init_t *ini
     p.height = cropped_height;
     hb_dict_extract_int(&p.width, filter->settings, "width");                /* :93-94 */
     hb_dict_extract_int(&p.height, filter->settings, "height");
+    /* The restated scaler is zimg's (zscale=filter=lanczos).  The reference only takes that path when
+     * hb_av_can_use_zscale() agrees (cropscale.c:97-118; hbffmpeg.c:870-915: every dimension even, a planar YUV
+     * format) and otherwise scales with swscale "lanczos+accurate_rnd", which computes something else: decline,
+     * so that the CPU filter stays (work.c:1861-1868), rather than replace it with different arithmetic. */
+    if ((cropped_width & 1) || (cropped_height & 1) || (p.width & 1) || (p.height & 1))
+    {
+        hb_log("cropscale(hip): odd dimension %dx%d -> %dx%d is the reference's swscale case, not built",
+               cropped_width, cropped_height, p.width, p.height);
+        return alias_fail(filter, HBHIP_ERR_UNSUPPORTED);
+    }
 
     hbhip_ctx *ctx = hbhip_host_ctx();
     if (ctx == NULL) return alias_fail(filter, HBHIP_ERR_NODEVICE);

@@ -13,10 +13,25 @@
 #include "hbhip_libhb.h"
 #include "hb_harness.h"
 
+#include <pthread.h>
+
 #define HBH_MAX_STAGES 32
+
+/* threaded mode: a fifo in front of every stage, one thread per stage (filter_loop, work.c:2527-2600) */
+typedef struct
+{
+    pthread_mutex_t lock;
+    pthread_cond_t  cond;
+    hb_buffer_t    *head, *tail;
+} hbh_fifo_t;
 
 struct hbh_chain_s
 {
+    int                 threaded;
+    hbh_fifo_t          fifo[HBH_MAX_STAGES];
+    pthread_t           thread[HBH_MAX_STAGES];
+    int                 thread_live[HBH_MAX_STAGES];
+    pthread_mutex_t     out_lock;
     int                 nstages;
     hb_filter_object_t *stage[HBH_MAX_STAGES];
     int                 done[HBH_MAX_STAGES];
@@ -40,6 +55,100 @@ static hb_filter_object_t *clone_filter(const hb_filter_object_t *proto, const c
 }
 
 static int g_src_color[4] = { 1, 1, 1, 1 };
+static int g_threaded = 0;
+
+/* Chains opened from now on run every stage on a thread of its own, as libhb does (work.c:2527-2600): distinct
+ * filters then call into the shared device context concurrently.  Frames pushed are queued; hbh_chain_push_eof()
+ * returns when every stage has finished, so output is complete once it returns. */
+void hbh_set_threaded(int on) { g_threaded = on; }
+
+static void fifo_put(hbh_fifo_t *q, hb_buffer_t *b)
+{
+    pthread_mutex_lock(&q->lock);
+    b->next = NULL;
+    if (q->tail) q->tail->next = b; else q->head = b;
+    q->tail = b;
+    pthread_cond_signal(&q->cond);
+    pthread_mutex_unlock(&q->lock);
+}
+
+static hb_buffer_t *fifo_get(hbh_fifo_t *q)
+{
+    pthread_mutex_lock(&q->lock);
+    while (q->head == NULL) pthread_cond_wait(&q->cond, &q->lock);
+    hb_buffer_t *b = q->head;
+    q->head = b->next;
+    if (q->head == NULL) q->tail = NULL;
+    b->next = NULL;
+    pthread_mutex_unlock(&q->lock);
+    return b;
+}
+
+typedef struct { hbh_chain_t *c; int s; } stage_arg_t;
+
+static void *stage_loop(void *pv)                 /* filter_loop (work.c:2527-2600) */
+{
+    stage_arg_t *a = pv;
+    hbh_chain_t *c = a->c;
+    const int s = a->s;
+    free(a);
+    hb_filter_object_t *f = c->stage[s];
+    for (;;)
+    {
+        hb_buffer_t *in = fifo_get(&c->fifo[s]), *out = NULL;
+        const int eof_in = (in->s.flags & HB_BUF_FLAG_EOF) != 0;
+        int status = f->work(f, &in, &out);
+        if (in != NULL) hb_buffer_close(&in);
+        if (status == HB_FILTER_FAILED)
+        {
+            c->failed = 1;
+            if (out == NULL) out = hb_buffer_eof_init();      /* let the stages behind finish */
+        }
+        while (out != NULL)
+        {
+            hb_buffer_t *next = out->next;
+            out->next = NULL;
+            if (s + 1 < c->nstages) fifo_put(&c->fifo[s + 1], out);
+            else
+            {
+                pthread_mutex_lock(&c->out_lock);
+                hb_buffer_list_append(&c->out, out);
+                pthread_mutex_unlock(&c->out_lock);
+            }
+            out = next;
+        }
+        if (status == HB_FILTER_DONE || status == HB_FILTER_FAILED || (eof_in && status != HB_FILTER_DELAY)) break;
+    }
+    return NULL;
+}
+
+static void start_threads(hbh_chain_t *c)
+{
+    if (!g_threaded) return;
+    c->threaded = 1;
+    pthread_mutex_init(&c->out_lock, NULL);
+    for (int s = 0; s < c->nstages; s++)
+    {
+        pthread_mutex_init(&c->fifo[s].lock, NULL);
+        pthread_cond_init(&c->fifo[s].cond, NULL);
+    }
+    for (int s = 0; s < c->nstages; s++)
+    {
+        stage_arg_t *a = malloc(sizeof(*a));
+        a->c = c; a->s = s;
+        c->thread_live[s] = pthread_create(&c->thread[s], NULL, stage_loop, a) == 0;
+    }
+}
+
+static void join_threads(hbh_chain_t *c)
+{
+    for (int s = 0; s < c->nstages; s++)
+        if (c->thread_live[s])
+        {
+            pthread_join(c->thread[s], NULL);
+            c->thread_live[s] = 0;
+        }
+}
 
 /* what work.c calls directly inside libhb (hip_common.h); here the filter library registers them when it loads */
 static void (*g_hip_setup)(hb_job_t *) = NULL;
@@ -113,6 +222,7 @@ hbh_chain_t *hbh_job_open(int nfilters, const int *ids, const char *const *setti
         c->stage[c->nstages++] = hb_list_item(job.list_filter, i);
     hb_list_close(&job.list_filter);
     c->init = init;
+    start_threads(c);
     return c;
 }
 
@@ -171,6 +281,7 @@ hbh_chain_t *hbh_chain_open(int nstages, void *const *protos, const char *const 
         c->stage[c->nstages++] = f;
     }
     c->init = init;
+    start_threads(c);
     return c;
 }
 
@@ -252,7 +363,8 @@ int hbh_chain_push(hbh_chain_t *c, const uint8_t *const plane[3], const int stri
     b->f.color_matrix = c->init_in.color_matrix;
     b->f.color_range = c->init_in.color_range;
     b->f.chroma_location = c->init_in.chroma_location;
-    run_from(c, 0, b);
+    if (c->threaded) fifo_put(&c->fifo[0], b);
+    else             run_from(c, 0, b);
     return c->failed ? -2 : 0;
 }
 
@@ -260,13 +372,21 @@ int hbh_chain_push_eof(hbh_chain_t *c)
 {
     if (c == NULL || c->eof_seen) return -1;
     c->eof_seen = 1;
-    run_from(c, 0, hb_buffer_eof_init());
+    if (c->threaded)
+    {
+        fifo_put(&c->fifo[0], hb_buffer_eof_init());
+        join_threads(c);                         /* every stage has seen EOF and returned: the output is complete */
+    }
+    else
+        run_from(c, 0, hb_buffer_eof_init());
     return c->failed ? -2 : 0;
 }
 
 int hbh_chain_pending(hbh_chain_t *c)
 {
-    return c ? hb_buffer_list_count(&c->out) : 0;
+    if (c == NULL) return 0;
+    if (c->threaded && !c->eof_seen) return 0;      /* stages are still running: collect after hbh_chain_push_eof() */
+    return hb_buffer_list_count(&c->out);
 }
 
 int hbh_chain_peek(hbh_chain_t *c, hbh_frame_info_t *info)
@@ -322,6 +442,11 @@ void hbh_chain_output_geometry(hbh_chain_t *c, int *width, int *height, int *vra
 void hbh_chain_close(hbh_chain_t *c)
 {
     if (c == NULL) return;
+    if (c->threaded && !c->eof_seen)
+    {
+        fifo_put(&c->fifo[0], hb_buffer_eof_init());
+        join_threads(c);
+    }
     for (int i = 0; i < c->nstages; i++)
     {
         hb_filter_object_t *f = c->stage[i];

@@ -38,6 +38,9 @@ hbh_chain_t *hbh_job_open(int nfilters, const int *ids, const char *const *setti
                           int vrate_num, int vrate_den, int use_hip);
 /* "|"-separated names of the stages as initialised; returns their count */
 int hbh_chain_describe(hbh_chain_t *c, char *buf, int len);
+/* Chains opened from now on run every stage on its own thread with a fifo in front (filter_loop, work.c:2527-2600);
+ * output is collected after hbh_chain_push_eof(), which joins the stages. */
+void hbh_set_threaded(int on);
 /* Colour description of the source for chains opened from now on (init->color_*; AVCOL_* numbers,
  * range 1 = tv, 2 = pc).  Default bt709 / tv. */
 void hbh_set_source_color(int prim, int transfer, int matrix, int range);

@@ -92,7 +92,9 @@ extern hb_motion_metric_object_t hb_motion_metric_hip;
 extern hb_filter_object_t hb_filter_decomb_hip;
 extern hb_filter_object_t hb_filter_comb_detect_hip;
 
-void hbhip_nlmeans_params_from_settings(const char *settings, int depth, hbhip_nlmeans_params *p);
+#ifndef HBHIP_IN_LIBHB
+void hbhip_nlmeans_params_from_settings(const char *settings, int depth, hbhip_nlmeans_params *p);   /* bench / tests only */
+#endif
 
 /* hb_filter_get() analogue (common.c:5331-5495) for the HIP drop-ins. */
 hb_filter_object_t *hbhip_filter_get(int filter_id);

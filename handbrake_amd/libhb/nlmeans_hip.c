@@ -129,14 +129,17 @@ static void nlmeans_hip_params(hb_dict_t *dict, int depth, hbhip_nlmeans_params 
     }
 }
 
-/* Same parameter/table derivation from a "key=value:..." string, for callers
- * that drive the C ABI directly (bench.py, device-resident tests). */
+#ifndef HBHIP_IN_LIBHB
+/* Same parameter/table derivation from a "key=value:..." string, for callers that drive the C ABI directly
+ * (bench.py, device-resident tests).  Uses the stand-in runtime's string parser, so it does not exist in a build
+ * inside libhb (where nothing needs it). */
 void hbhip_nlmeans_params_from_settings(const char *settings, int depth, hbhip_nlmeans_params *p)
 {
     hb_dict_t *d = hbhip_dict_from_string(settings);
     nlmeans_hip_params(d, depth, p);
     hb_dict_free(&d);
 }
+#endif
 
 static int nlmeans_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init)
 {
