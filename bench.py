@@ -199,7 +199,8 @@ def cpu_baseline_chain(workload, frames_np, scale):
 
 
 def pcie_inclusive(workload, frames_np, scale, n_in=24):
-    """The chain through the hb_filter_object_t surface, host hb_buffer_t in and out (H2D + D2H on the path)."""
+    """The chain through the hb_filter_object_t surface, host hb_buffer_t in and out (H2D + D2H on the path), driven
+    the way libhb drives it: one thread per filter with a fifo in front (filter_loop, work.c:2527-2600)."""
     from handbrake_amd import hbrt, hip
     chain = [("hb_filter_hip_upload", ""), ("hb_filter_decomb_hip", "mode=31")]
     if workload != "decomb_eedi2":
@@ -209,14 +210,32 @@ def pcie_inclusive(workload, frames_np, scale, n_in=24):
         chain.append(("hb_filter_lapsharp_hip", LAPSHARP))
     chain.append(("hb_filter_hip_download", ""))
     seq = [frames_np[i % len(frames_np)] for i in range(n_in)]
-    hbrt.run_stream(hip.filters(), chain, seq[:3], flags=8)          # warm-up: allocations, code objects, graphs
-    t0 = time.perf_counter()
-    out = hbrt.run_stream(hip.filters(), chain, seq, flags=8)
-    dt = time.perf_counter() - t0
-    return {"value": round(len(out) / dt, 2), "unit": "output frames/s", "input_fps": round(n_in / dt, 2),
-            "path": "hb_filter_object_t chain (hip_upload -> ... -> hip_download) driven by the libhb stand-in "
-                    "harness, pinned host hb_buffer_t in and out, one work() per frame",
-            "sample": f"{n_in} input / {len(out)} output frames, {dt:.2f}s wall"}
+    h, w = seq[0][0].shape
+
+    def run(threaded):
+        hbrt.set_threaded(threaded)
+        try:
+            with hbrt.Chain(hip.filters(), chain, w, h) as ch:
+                t0 = time.perf_counter()
+                for i, fr in enumerate(seq):
+                    ch.push(fr, start=i * 3003, stop=(i + 1) * 3003, flags=8)
+                    if not threaded:
+                        ch.drain()
+                ch.push_eof()                     # threaded: returns when every stage has finished
+                dt = time.perf_counter() - t0
+                n_out = 0 if not threaded else sum(1 for f in ch.drain())
+            return dt, n_out
+        finally:
+            hbrt.set_threaded(False)
+
+    run(True)                                     # warm-up: allocations, pinned pool, code objects, graphs
+    dt, n_out = run(True)
+    return {"value": round(n_out / dt, 2), "unit": "output frames/s", "input_fps": round(n_in / dt, 2),
+            "path": "hb_filter_object_t chain (hip_upload -> ... -> hip_download) in the libhb stand-in harness, one thread "
+                    "per filter as filter_loop runs them, pinned host hb_buffer_t in and out; H2D / D2H on the "
+                    "context's copy streams",
+            "pcie_GBps": round((n_in * frame_bytes(w, h) + n_out * frame_bytes(*(scale or (w, h)))) / dt / 1e9, 2),
+            "sample": f"{n_in} input / {n_out} output frames, {dt:.3f}s wall"}
 
 
 def run_nlmeans(args, world, rank, local_rank):

@@ -386,9 +386,23 @@ public:
             if (i != ref[0] && i != ref[1]) use = i;
         (void)freed;
         if (stride < width * bps) return HBHIP_ERR_ARG;
-        HBHIP_CHECK(ctx, hipMemcpy2DAsync(luma_alloc[use], pitch, luma, stride, (size_t)width * bps, height,
-                                          device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
-        if (!device) HBHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (device)
+            HBHIP_CHECK(ctx, hipMemcpy2DAsync(luma_alloc[use], pitch, luma, stride, (size_t)width * bps, height,
+                                              hipMemcpyDeviceToDevice, ctx->stream));
+        else
+        {
+            // on the context's upload stream: wait for this copy only, not for what the job's other filters have
+            // queued on the compute stream.  The slot being overwritten was last read by a classify() two frames ago,
+            // and classify() waits for its kernels, so nothing can still be reading it.
+            hipEvent_t done = ctx->sync_ev_get();
+            if (!done) return ctx->fail(hipErrorOutOfMemory, "hipEventCreate(store)");
+            HBHIP_CHECK(ctx, hipMemcpy2DAsync(luma_alloc[use], pitch, luma, stride, (size_t)width * bps, height,
+                                              hipMemcpyHostToDevice, ctx->up_stream));
+            HBHIP_CHECK(ctx, hipEventRecord(done, ctx->up_stream));
+            const hipError_t e = hipEventSynchronize(done);
+            ctx->sync_ev_put(done);
+            if (e != hipSuccess) return ctx->fail(e, "hipEventSynchronize(store)");
+        }
         ref[2] = use;
         return HBHIP_OK;
     }
@@ -443,7 +457,16 @@ public:
         }
         HBHIP_CHECK(ctx, hipGetLastError());
         HBHIP_CHECK(ctx, hipMemcpyAsync(h_result, d_result, sizeof(int) * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HBHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        {
+            // wait for the verdict - an event behind the read-back rather than the whole stream, which other filter
+            // threads keep filling
+            hipEvent_t done = ctx->sync_ev_get();
+            if (!done) return ctx->fail(hipErrorOutOfMemory, "hipEventCreate(classify)");
+            HBHIP_CHECK(ctx, hipEventRecord(done, ctx->stream));
+            const hipError_t e = hipEventSynchronize(done);
+            ctx->sync_ev_put(done);
+            if (e != hipSuccess) return ctx->fail(e, "hipEventSynchronize(classify)");
+        }
         *combed = h_result[0];
         if (overlay && h_result[2] > 0 && blocks_x > 0)
         {

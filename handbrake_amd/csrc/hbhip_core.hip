@@ -29,6 +29,36 @@ hipEvent_t hbhip_ctx::ev_get()
     return e;
 }
 
+hipEvent_t hbhip_ctx::sync_ev_get()
+{
+    {
+        std::lock_guard<std::recursive_mutex> lk(state_lock);
+        if (!sync_ev_pool.empty())
+        {
+            hipEvent_t e = sync_ev_pool.back();
+            sync_ev_pool.pop_back();
+            return e;
+        }
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    return e;
+}
+
+void hbhip_ctx::sync_ev_put(hipEvent_t e)
+{
+    if (!e) return;
+    std::lock_guard<std::recursive_mutex> lk(state_lock);
+    sync_ev_pool.push_back(e);
+}
+
+void hbhip_pic_mark_idle(hbhip_ctx *ctx, DevPicture *p)
+{
+    if (!ctx || !p) return;
+    if (!p->idle && hipEventCreateWithFlags(&p->idle, hipEventDisableTiming) != hipSuccess) { p->idle = nullptr; return; }
+    p->idle_valid = hipEventRecord(p->idle, ctx->stream) == hipSuccess;
+}
+
 int hbhip_ctx::prof_name(const char *name)
 {
     for (size_t i = 0; i < prof_stats.size(); i++)
@@ -83,6 +113,7 @@ PicturePool::~PicturePool()
 {
     for (DevPicture *p : all_)
     {
+        if (p->idle) (void)hipEventDestroy(p->idle);
         if (p->base) (void)hipFree(p->base);
         delete p;
     }
@@ -125,6 +156,7 @@ DevPicture *PicturePool::acquire()
         return nullptr;
     }
     (void)hipMemsetAsync(p->base, 0, total, ctx_->stream);
+    hbhip_pic_mark_idle(ctx_, p);          // an upload (on the copy stream) must not overtake the clearing
     for (int c = 0; c < 3; c++) p->plane[c] = p->base + off[c];
     p->owner = this;
     all_.push_back(p);
@@ -133,7 +165,9 @@ DevPicture *PicturePool::acquire()
 
 void PicturePool::release(DevPicture *p)
 {
-    if (p) free_.push_back(p);
+    if (!p) return;
+    hbhip_pic_mark_idle(ctx_, p);          // an upload into the recycled picture waits for this (hbhip_copy_h2d)
+    free_.push_back(p);
 }
 
 // ---------------------------------------------------------------- copies
@@ -142,25 +176,46 @@ void PicturePool::release(DevPicture *p)
 int hbhip_copy_h2d(hbhip_ctx *ctx, DevPicture *dst, const hbhip_host_frame *src)
 {
     for (int c = 0; c < 3; c++)
+        if (src->plane[c] == nullptr || src->stride[c] < dst->width[c] * dst->bps) return HBHIP_ERR_ARG;
+    hipEvent_t done = ctx->sync_ev_get();
+    if (!done) return ctx->fail(hipErrorOutOfMemory, "hipEventCreate(upload)");
+    // whatever still reads the picture's previous contents was queued on ctx->stream before it was recycled
+    if (dst->idle_valid) HBHIP_CHECK(ctx, hipStreamWaitEvent(ctx->up_stream, dst->idle, 0));
+    for (int c = 0; c < 3; c++)
     {
-        const size_t vis = (size_t)dst->width[c] * dst->bps;
-        if (src->plane[c] == nullptr || src->stride[c] < (int)vis) return HBHIP_ERR_ARG;
         const size_t row = (size_t)std::min(src->stride[c], dst->pitch[c]);
         HBHIP_CHECK(ctx, hipMemcpy2DAsync(dst->plane[c], dst->pitch[c], src->plane[c], src->stride[c],
-                                          row, dst->height[c], hipMemcpyHostToDevice, ctx->stream));
+                                          row, dst->height[c], hipMemcpyHostToDevice, ctx->up_stream));
     }
+    // The caller may free or reuse its planes as soon as we return (filter_loop closes buf_in, work.c:2566-2569):
+    // wait for THIS copy - not for the kernels other filters have queued.  Once it has completed, work launched
+    // on any stream afterwards sees the data.
+    HBHIP_CHECK(ctx, hipEventRecord(done, ctx->up_stream));
+    const hipError_t e = hipEventSynchronize(done);
+    ctx->sync_ev_put(done);
+    if (e != hipSuccess) return ctx->fail(e, "hipEventSynchronize(upload)");
     return HBHIP_OK;
 }
 
 int hbhip_copy_d2h(hbhip_ctx *ctx, const hbhip_host_frame *dst, const DevPicture *src)
 {
     for (int c = 0; c < 3; c++)
+        if (dst->plane[c] == nullptr || dst->stride[c] < src->width[c] * src->bps) return HBHIP_ERR_ARG;
+    hipEvent_t ev = ctx->sync_ev_get();
+    if (!ev) return ctx->fail(hipErrorOutOfMemory, "hipEventCreate(download)");
+    // the picture's producers are on ctx->stream, all queued by now
+    HBHIP_CHECK(ctx, hipEventRecord(ev, ctx->stream));
+    HBHIP_CHECK(ctx, hipStreamWaitEvent(ctx->down_stream, ev, 0));
+    for (int c = 0; c < 3; c++)
     {
         const size_t row = (size_t)src->width[c] * src->bps;
-        if (dst->plane[c] == nullptr || dst->stride[c] < (int)row) return HBHIP_ERR_ARG;
         HBHIP_CHECK(ctx, hipMemcpy2DAsync(dst->plane[c], dst->stride[c], src->plane[c], src->pitch[c],
-                                          row, src->height[c], hipMemcpyDeviceToHost, ctx->stream));
+                                          row, src->height[c], hipMemcpyDeviceToHost, ctx->down_stream));
     }
+    HBHIP_CHECK(ctx, hipEventRecord(ev, ctx->down_stream));
+    const hipError_t e = hipEventSynchronize(ev);
+    ctx->sync_ev_put(ev);
+    if (e != hipSuccess) return ctx->fail(e, "hipEventSynchronize(download)");
     return HBHIP_OK;
 }
 
@@ -283,6 +338,15 @@ static int ctx_create_common(int device, void *stream, bool adopt, hbhip_ctx **o
         delete ctx;
         return HBHIP_ERR_HIP;
     }
+    if (hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->down_stream, hipStreamNonBlocking) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        if (ctx->up_stream) (void)hipStreamDestroy(ctx->up_stream);
+        if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return HBHIP_ERR_HIP;
+    }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess)
         snprintf(ctx->dev_name, sizeof(ctx->dev_name), "%s (%s, %d CUs)", prop.name,
@@ -306,6 +370,9 @@ void hbhip_ctx_destroy(hbhip_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->up_stream) { (void)hipStreamSynchronize(ctx->up_stream); (void)hipStreamDestroy(ctx->up_stream); }
+    if (ctx->down_stream) { (void)hipStreamSynchronize(ctx->down_stream); (void)hipStreamDestroy(ctx->down_stream); }
+    for (hipEvent_t e : ctx->sync_ev_pool) (void)hipEventDestroy(e);
     for (auto &p : ctx->prof_pending)
     {
         if (p.ev0) (void)hipEventDestroy(p.ev0);
@@ -313,6 +380,7 @@ void hbhip_ctx_destroy(hbhip_ctx *ctx)
     }
     for (hbhip_frame *fr : ctx->frame_pool)
     {
+        if (fr->pic.idle) (void)hipEventDestroy(fr->pic.idle);
         if (fr->pic.base) (void)hipFree(fr->pic.base);
         delete fr;
     }
@@ -477,6 +545,7 @@ int hbhip_frame_alloc(hbhip_ctx *ctx, int width, int height, int depth, int lcw,
         return HBHIP_ERR_NOMEM;
     }
     (void)hipMemsetAsync(fr->pic.base, 0, total, ctx->stream);
+    hbhip_pic_mark_idle(ctx, &fr->pic);    // an upload (on the copy stream) must not overtake the clearing
     for (int c = 0; c < 3; c++) fr->pic.plane[c] = fr->pic.base + off[c];
     *out = fr;
     return HBHIP_OK;
@@ -494,7 +563,9 @@ void hbhip_frame_release(hbhip_frame *fr)
     if (!fr) return;
     std::lock_guard<std::mutex> lk(fr->ctx->frame_lock);
     if (--fr->refs > 0) return;
-    fr->ctx->frame_pool.push_back(fr);        // reuse is stream-ordered (one stream per context)
+    (void)hipSetDevice(fr->ctx->device);
+    hbhip_pic_mark_idle(fr->ctx, &fr->pic);   // its users are all queued on the context's stream by now
+    fr->ctx->frame_pool.push_back(fr);        // reuse is ordered by that event (uploads) or by the stream itself
 }
 
 int hbhip_frame_describe(hbhip_frame *fr, hbhip_dev_frame *out, int *width, int *height)
@@ -526,22 +597,14 @@ int hbhip_frame_upload(hbhip_frame *fr, const hbhip_host_frame *src)
 {
     if (!fr || !src) return HBHIP_ERR_ARG;
     (void)hipSetDevice(fr->ctx->device);
-    int rc = hbhip_copy_h2d(fr->ctx, &fr->pic, src);
-    if (rc != HBHIP_OK) return rc;
-    if (hipStreamSynchronize(fr->ctx->stream) != hipSuccess)
-        return fr->ctx->fail(hipGetLastError(), "hipStreamSynchronize(frame_upload)");
-    return HBHIP_OK;
+    return hbhip_copy_h2d(fr->ctx, &fr->pic, src);
 }
 
 int hbhip_frame_download(hbhip_frame *fr, const hbhip_host_frame *dst)
 {
     if (!fr || !dst) return HBHIP_ERR_ARG;
     (void)hipSetDevice(fr->ctx->device);
-    int rc = hbhip_copy_d2h(fr->ctx, dst, &fr->pic);
-    if (rc != HBHIP_OK) return rc;
-    if (hipStreamSynchronize(fr->ctx->stream) != hipSuccess)
-        return fr->ctx->fail(hipGetLastError(), "hipStreamSynchronize(frame_download)");
-    return HBHIP_OK;
+    return hbhip_copy_d2h(fr->ctx, dst, &fr->pic);
 }
 
 // ---- generic filter surface -------------------------------------------------
@@ -554,12 +617,7 @@ int hbhip_filter_push(hbhip_filter *f, const hbhip_host_frame *in, int64_t tag)
     pic->tag = tag;
     for (int c = 0; c < 3; c++) f->in_stride[c] = in->stride[c];
     f->in_is_dev = false;
-    int rc = hbhip_copy_h2d(f->ctx, pic, in);
-    // The caller may free or reuse its (pageable) planes as soon as we return
-    // (filter_loop closes buf_in, work.c:2566-2569), so the upload must have
-    // consumed them.
-    if (rc == HBHIP_OK && hipStreamSynchronize(f->ctx->stream) != hipSuccess)
-        rc = f->ctx->fail(hipGetLastError(), "hipStreamSynchronize(push)");
+    int rc = hbhip_copy_h2d(f->ctx, pic, in);          // returns when `in` has been consumed
     if (rc != HBHIP_OK)
     {
         f->abandon_input(pic);             // not submitted: back to its pool
@@ -592,9 +650,7 @@ int hbhip_filter_pull(hbhip_filter *f, const hbhip_host_frame *out, int64_t *tag
     DevPicture *pic = f->pop_output();
     if (!pic) return HBHIP_AGAIN;
     if (tag) *tag = pic->tag;
-    int rc = hbhip_copy_d2h(f->ctx, out, pic);
-    if (rc == HBHIP_OK && hipStreamSynchronize(f->ctx->stream) != hipSuccess)
-        rc = f->ctx->fail(hipGetLastError(), "hipStreamSynchronize(pull)");
+    int rc = hbhip_copy_d2h(f->ctx, out, pic);         // returns when `out` is filled
     f->recycle_output(pic);
     return rc;
 }

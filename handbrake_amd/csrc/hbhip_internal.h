@@ -35,6 +35,15 @@ struct hbhip_ctx
     int         device = 0;
     hipStream_t stream = nullptr;
     bool        own_stream = true;
+    // Transfers of host frames run on two streams of their own, so that a filter thread moving a frame waits for
+    // ITS copy and not for every kernel the job's other filters have queued on `stream` (libhb runs each filter on
+    // its own thread, work.c:2527-2600), and so that copies overlap the kernels.  Ordering against `stream` is by
+    // events: a picture's `idle` event (recorded when it goes back to its pool) gates the next upload into it, an
+    // event recorded on `stream` at download time gates the copy out.
+    hipStream_t up_stream = nullptr, down_stream = nullptr;
+    std::vector<hipEvent_t> sync_ev_pool;           // hipEventDisableTiming events (state_lock)
+    hipEvent_t sync_ev_get();
+    void       sync_ev_put(hipEvent_t e);
     std::string last_error;
     char        dev_name[256] = {0};
 
@@ -98,6 +107,8 @@ struct DevPicture
     int      flags = 0;      // PIC_FLAG_* of the source buffer (decomb / comb detect)
     int      combed = 0;     // HB_COMB_* of the source buffer
     int      aux = 0;        // filter specific (decomb: which field of a bob pair)
+    hipEvent_t idle = nullptr;   // recorded on the context's stream when the picture goes back to its pool:
+    bool     idle_valid = false; // everything that used it has been queued before that point
     class PicturePool *owner = nullptr;   // the pool the picture goes back to (hbhip_pic_release)
 };
 
@@ -154,9 +165,13 @@ inline void hbhip_pic_release(DevPicture *p)
     if (p && p->owner) p->owner->release(p);
 }
 
-// Copy helpers (2-D, any pitch on either side), all on ctx->stream.
+// Host <-> device: on the context's copy streams, synchronous for the CALLER only (see hbhip_ctx::up_stream):
+// upload returns when `src` has been consumed, download when `dst` is filled.
 int hbhip_copy_h2d(hbhip_ctx *ctx, DevPicture *dst, const hbhip_host_frame *src);
 int hbhip_copy_d2h(hbhip_ctx *ctx, const hbhip_host_frame *dst, const DevPicture *src);
+// record `p->idle` on the context's stream (the picture is being recycled)
+void hbhip_pic_mark_idle(hbhip_ctx *ctx, DevPicture *p);
+// Device <-> device copies (2-D, any pitch on either side) on ctx->stream.
 int hbhip_copy_d2d_in(hbhip_ctx *ctx, DevPicture *dst, const hbhip_dev_frame *src);
 int hbhip_copy_d2d_out(hbhip_ctx *ctx, const hbhip_dev_frame *dst, const DevPicture *src);
 
