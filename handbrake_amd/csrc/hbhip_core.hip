@@ -674,6 +674,84 @@ int hbhip_filter_process_dev(hbhip_filter *f, const hbhip_dev_frame *in, int n_i
     return f->process_dev_batch(in, n_in, tag0, out, out_cap, n_out);
 }
 
+// ---- pipelined host path ---------------------------------------------------------------
+// push + pull of a one-in / one-out filter as ONE asynchronous submission: upload on the context's upload stream,
+// the filter's kernels on the compute stream behind an event, the download on the download stream behind another.
+// Nothing waits on the host; hbhip_filter_wait() later blocks on the oldest submission's last event only.  With two
+// submissions in flight the H2D of frame n, the kernels of frame n-1 and the D2H of frame n-2 overlap - what the
+// reference gets from keeping `threads` frames in flight (nlmeans.c:464-597, mt_frame_filter.c:45-237).
+int hbhip_filter_submit_async(hbhip_filter *f, const hbhip_host_frame *in, const hbhip_host_frame *out, int64_t tag)
+{
+    if (!f || !in || !out) return HBHIP_ERR_ARG;
+    hbhip_ctx *ctx = f->ctx;
+    (void)hipSetDevice(ctx->device);
+    DevPicture *pic = f->acquire_input();
+    if (!pic) return HBHIP_ERR_NOMEM;
+    DevPicture *o = f->acquire_output();
+    if (!o)
+    {
+        f->abandon_input(pic);
+        return HBHIP_ERR_UNSUPPORTED;              // not a one-in / one-out filter: use push / pull
+    }
+    hipEvent_t ev = ctx->sync_ev_get(), done = ctx->sync_ev_get();
+    int rc = (ev && done) ? HBHIP_OK : HBHIP_ERR_NOMEM;
+    for (int c = 0; rc == HBHIP_OK && c < 3; c++)
+        if (!in->plane[c] || in->stride[c] < pic->width[c] * pic->bps || !out->plane[c] ||
+            out->stride[c] < o->width[c] * o->bps)
+            rc = HBHIP_ERR_ARG;
+    auto fail = [&](int code) {
+        f->abandon_input(pic);
+        f->recycle_output(o);
+        ctx->sync_ev_put(ev);
+        ctx->sync_ev_put(done);
+        return code;
+    };
+    if (rc != HBHIP_OK) return fail(rc);
+#define ASYNC_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(ctx->fail(e_, #expr)); } while (0)
+    pic->tag = tag;
+    for (int c = 0; c < 3; c++) f->in_stride[c] = in->stride[c];
+    f->in_is_dev = false;
+    if (pic->idle_valid) ASYNC_CHECK(hipStreamWaitEvent(ctx->up_stream, pic->idle, 0));
+    for (int c = 0; c < 3; c++)
+        ASYNC_CHECK(hipMemcpy2DAsync(pic->plane[c], pic->pitch[c], in->plane[c], in->stride[c],
+                                     (size_t)std::min(in->stride[c], pic->pitch[c]), pic->height[c],
+                                     hipMemcpyHostToDevice, ctx->up_stream));
+    ASYNC_CHECK(hipEventRecord(ev, ctx->up_stream));
+    ASYNC_CHECK(hipStreamWaitEvent(ctx->stream, ev, 0));
+    rc = f->process_pair(pic, o);
+    if (rc != HBHIP_OK) return fail(rc);
+    hbhip_pic_release(pic);                        // idle event behind the kernels that read it
+    ASYNC_CHECK(hipEventRecord(ev, ctx->stream));
+    ASYNC_CHECK(hipStreamWaitEvent(ctx->down_stream, ev, 0));
+    for (int c = 0; c < 3; c++)
+        ASYNC_CHECK(hipMemcpy2DAsync(out->plane[c], out->stride[c], o->plane[c], o->pitch[c], (size_t)o->width[c] * o->bps,
+                                     o->height[c], hipMemcpyDeviceToHost, ctx->down_stream));
+    ASYNC_CHECK(hipEventRecord(done, ctx->down_stream));
+#undef ASYNC_CHECK
+    ctx->sync_ev_put(ev);
+    f->async_q.push_back({o, done, tag});
+    return HBHIP_OK;
+}
+
+int hbhip_filter_wait(hbhip_filter *f, int64_t *tag)
+{
+    if (!f) return HBHIP_ERR_ARG;
+    if (f->async_q.empty()) return HBHIP_AGAIN;
+    (void)hipSetDevice(f->ctx->device);
+    hbhip_filter::AsyncSlot s = f->async_q.front();
+    f->async_q.pop_front();
+    const hipError_t e = hipEventSynchronize(s.done);
+    f->ctx->sync_ev_put(s.done);
+    f->recycle_output(s.out);
+    if (tag) *tag = s.tag;
+    return e == hipSuccess ? HBHIP_OK : f->ctx->fail(e, "hipEventSynchronize(wait)");
+}
+
+int hbhip_filter_inflight(hbhip_filter *f)
+{
+    return f ? (int)f->async_q.size() : 0;
+}
+
 int hbhip_filter_flush(hbhip_filter *f)
 {
     if (!f) return HBHIP_ERR_ARG;
@@ -690,6 +768,7 @@ void hbhip_filter_destroy(hbhip_filter *f)
 {
     if (!f) return;
     (void)hipSetDevice(f->ctx->device);
+    while (!f->async_q.empty()) (void)hbhip_filter_wait(f, nullptr);
     (void)hipStreamSynchronize(f->ctx->stream);
     delete f;
 }

@@ -210,6 +210,11 @@ struct hbhip_filter
     // takes ownership of `in`.  HBHIP_ERR_UNSUPPORTED when the filter has no such path.
     virtual int submit_to(DevPicture *, const DevPicture *) { return HBHIP_ERR_UNSUPPORTED; }
     virtual bool can_submit_to() const { return false; }
+    // ---- pipelined host path (hbhip_filter_submit_async): one-in / one-out filters ----
+    virtual DevPicture *acquire_output() { return nullptr; }
+    virtual int process_pair(DevPicture *, DevPicture *) { return HBHIP_ERR_UNSUPPORTED; }   // in -> out on ctx->stream
+    struct AsyncSlot { DevPicture *out; hipEvent_t done; int64_t tag; };
+    std::deque<AsyncSlot> async_q;
 };
 
 // A stateless one-frame-in / one-frame-out filter: subclasses implement process().
@@ -254,6 +259,8 @@ struct SimpleFilter : hbhip_filter
         return p;
     }
     void recycle_output(DevPicture *p) override { out_pool.release(p); }
+    DevPicture *acquire_output() override { return out_pool.acquire(); }
+    int process_pair(DevPicture *in, DevPicture *out) override { out->tag = in->tag; return process(in, out); }
     bool can_submit_to() const override { return outq.empty(); }
     int submit_to(DevPicture *pic, const DevPicture *out) override
     {

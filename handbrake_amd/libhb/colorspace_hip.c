@@ -201,7 +201,7 @@ static void colorspace_hip_close(hb_filter_object_t *filter)
 {
     hb_filter_private_t *pv = filter->private_data;
     if (pv == NULL) return;
-    if (pv->dev != NULL) hbhip_filter_destroy(pv->dev);
+    if (pv->dev != NULL) hbhip_host_simple_destroy(pv->dev);
     free(pv);
     filter->private_data = NULL;
 }

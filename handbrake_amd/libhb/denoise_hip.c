@@ -99,7 +99,7 @@ static void denoise_hip_close(hb_filter_object_t *filter)
 {
     hb_filter_private_t *pv = filter->private_data;
     if (pv == NULL) return;
-    hbhip_filter_destroy(pv->dev);
+    hbhip_host_simple_destroy(pv->dev);
     free(pv);
     filter->private_data = NULL;
 }

@@ -60,6 +60,9 @@ int hbhip_host_push(hbhip_filter *dev, const hb_buffer_t *in, int64_t tag);
 hb_buffer_t *hbhip_host_pull(hbhip_filter *dev, const hb_filter_init_t *o, int width, int height,
                              int dev_io, int64_t *tag);
 
+/* destroy a device filter driven by hbhip_host_simple_work (drops what is still in its pipe) */
+void hbhip_host_simple_destroy(hbhip_filter *dev);
+
 extern hb_filter_object_t hb_filter_hip_upload;
 extern hb_filter_object_t hb_filter_hip_download;
 

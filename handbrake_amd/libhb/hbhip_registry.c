@@ -229,13 +229,53 @@ hb_buffer_t *hbhip_host_pull(hbhip_filter *dev, const hb_filter_init_t *o, int w
     return out;
 }
 
+/* host frames: two submissions kept in flight (hbhip_filter_submit_async), so that the upload of this frame, the
+ * kernels of the previous one and the download of the one before overlap.  The price is the reference's own: the
+ * filter answers HB_FILTER_DELAY until the pipe is full (nlmeans.c:548 does the same for `threads` frames). */
+#define HBHIP_PIPE_DEPTH 2
+typedef struct { hb_buffer_t *in, *out; } pipe_pair_t;
+
+static hb_buffer_t *pipe_collect(hbhip_filter *dev)
+{
+    int64_t tag = 0;
+    if (hbhip_filter_wait(dev, &tag) != HBHIP_OK) return NULL;
+    pipe_pair_t *pp = (pipe_pair_t *)(intptr_t)tag;
+    hb_buffer_t *out = pp->out;
+    hb_buffer_copy_props(out, pp->in);
+    hb_buffer_close(&pp->in);
+    free(pp);
+    return out;
+}
+
+/* close(): frames still in the pipe (a cancelled job) are dropped with their buffers */
+void hbhip_host_simple_destroy(hbhip_filter *dev)
+{
+    if (dev == NULL) return;
+    while (hbhip_filter_inflight(dev) > 0)
+    {
+        hb_buffer_t *o = pipe_collect(dev);
+        if (o == NULL) break;
+        hb_buffer_close(&o);
+    }
+    hbhip_filter_destroy(dev);
+}
+
 int hbhip_host_simple_work(hbhip_filter *dev, const hb_filter_init_t *output, const char *who,
                            int dev_io, hb_buffer_t **buf_in, hb_buffer_t **buf_out)
 {
     hb_buffer_t *in = *buf_in;
     if (in->s.flags & HB_BUF_FLAG_EOF)
     {
-        *buf_out = in;
+        hb_buffer_list_t list;
+        hb_buffer_list_clear(&list);
+        while (hbhip_filter_inflight(dev) > 0)                 /* drain the pipe in order */
+        {
+            hb_buffer_t *o = pipe_collect(dev);
+            if (o == NULL) { hb_buffer_list_close(&list); return HB_FILTER_FAILED; }
+            hb_buffer_list_append(&list, o);
+        }
+        hb_buffer_list_append(&list, in);
+        *buf_out = hb_buffer_list_clear(&list);
         *buf_in = NULL;
         return HB_FILTER_DONE;
     }
@@ -265,6 +305,43 @@ int hbhip_host_simple_work(hbhip_filter *dev, const hb_filter_init_t *output, co
             else
                 hbhip_frame_release(dst);
         }
+    }
+    else if (src == NULL && !dev_io)
+    {
+        /* host frame in, host frame out: pipelined */
+        out = hbhip_host_alloc_out(output, ow, oh);
+        pipe_pair_t *pp = out != NULL ? malloc(sizeof(*pp)) : NULL;
+        if (pp == NULL)
+        {
+            hb_buffer_close(&out);
+            hb_error("%s(hip): out of memory", who);
+            return HB_FILTER_FAILED;
+        }
+        pp->in = in;
+        pp->out = out;
+        hbhip_host_frame hi, ho;
+        hbhip_host_frame_from_buf(&hi, in);
+        hbhip_host_frame_from_buf(&ho, out);
+        rc = hbhip_filter_submit_async(dev, &hi, &ho, (int64_t)(intptr_t)pp);
+        if (rc == HBHIP_OK)
+        {
+            *buf_in = NULL;                                         /* ours until its submission has finished */
+            if (hbhip_filter_inflight(dev) <= HBHIP_PIPE_DEPTH)
+                return HB_FILTER_DELAY;
+            out = pipe_collect(dev);
+            if (out == NULL) { hb_error("%s(hip): wait failed", who); return HB_FILTER_FAILED; }
+            *buf_out = out;
+            return HB_FILTER_OK;
+        }
+        free(pp);
+        hb_buffer_close(&out);
+        if (rc != HBHIP_ERR_UNSUPPORTED)
+        {
+            hb_error("%s(hip): submit failed (%s)", who, hbhip_strerror(rc));
+            return HB_FILTER_FAILED;
+        }
+        rc = hbhip_host_push(dev, in, 0);                           /* not a one-in / one-out device filter */
+        out = rc == HBHIP_OK ? hbhip_host_pull(dev, output, ow, oh, dev_io, NULL) : NULL;
     }
     else
     {

@@ -127,6 +127,14 @@ int  hbhip_filter_pull_dev(hbhip_filter *f, const hbhip_dev_frame *out, int64_t 
  * written.  One ABI crossing per batch instead of two per frame. */
 int  hbhip_filter_process_dev(hbhip_filter *f, const hbhip_dev_frame *in, int n_in, int64_t tag0,
                               const hbhip_dev_frame *out, int out_cap, int *n_out);
+/* Pipelined form of push + pull for filters that make one frame from one frame: queue the upload of `in`, the
+ * filter, and the download into `out`, and return at once.  `in` and `out` must stay valid until hbhip_filter_wait()
+ * has returned this submission (they finish in submission order; `tag` comes back with it).  Two or three submissions
+ * in flight overlap H2D, kernels and D2H - the role `threads` frames in flight play in the reference
+ * (nlmeans.c:464-597, mt_frame_filter.c:45-237).  HBHIP_ERR_UNSUPPORTED: not such a filter, use push / pull. */
+int  hbhip_filter_submit_async(hbhip_filter *f, const hbhip_host_frame *in, const hbhip_host_frame *out, int64_t tag);
+int  hbhip_filter_wait(hbhip_filter *f, int64_t *tag);      /* oldest submission done; HBHIP_AGAIN when none is in flight */
+int  hbhip_filter_inflight(hbhip_filter *f);
 int  hbhip_filter_flush(hbhip_filter *f);             /* input ended (HB_BUF_FLAG_EOF) */
 int  hbhip_filter_pending(hbhip_filter *f);           /* frames a pull would return now */
 void hbhip_filter_destroy(hbhip_filter *f);
