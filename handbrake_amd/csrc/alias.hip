@@ -272,8 +272,7 @@ __global__ __launch_bounds__(256) void cropscale_v_kernel(ScaleArgs a, const dou
 constexpr int FS_TW = 64, FS_TH = 32, FS_MAXR = 40;
 struct ScaleArgs3 { ScaleArgs p[3]; int active[3]; };
 
-// TX / TY > 0: the tap counts are compile-time (6 x 6 for any upscale), so the taps of a thread's
-// column live in registers and the loops unroll; 0 = read the counts from the arguments.
+// Any tap counts (read from the arguments); the 6 x 6 case has its own kernel below.
 template <int TX, int TY, typename PIX>
 __global__ __launch_bounds__(256) void cropscale_fused_kernel(ScaleArgs3 all)
 {
@@ -306,30 +305,12 @@ __global__ __launch_bounds__(256) void cropscale_fused_kernel(ScaleArgs3 all)
     {
         const int *ix = a.ix + (size_t)x * tx;
         const double *cx = a.cx + (size_t)x * tx;
-        if (TX > 0)
+        for (int rr = wave_row; rr < nr; rr += 256 / FS_TW)
         {
-            int ixr[TX > 0 ? TX : 1];
-            double cxr[TX > 0 ? TX : 1];
-#pragma unroll
-            for (int i = 0; i < TX; i++) { ixr[i] = ix[i]; cxr[i] = cx[i]; }
-            for (int rr = wave_row; rr < nr; rr += 256 / FS_TW)
-            {
-                const PIX *row = reinterpret_cast<const PIX *>(a.src + (size_t)(rmin + rr) * a.spitch);
-                double h = 0.0;
-#pragma unroll
-                for (int i = 0; i < TX; i++) h += cxr[i] * (double)row[ixr[i]];
-                s_h[rr][xl] = h;
-            }
-        }
-        else
-        {
-            for (int rr = wave_row; rr < nr; rr += 256 / FS_TW)
-            {
-                const PIX *row = reinterpret_cast<const PIX *>(a.src + (size_t)(rmin + rr) * a.spitch);
-                double h = 0.0;
-                for (int i = 0; i < tx; i++) h += cx[i] * (double)row[ix[i]];
-                s_h[rr][xl] = h;
-            }
+            const PIX *row = reinterpret_cast<const PIX *>(a.src + (size_t)(rmin + rr) * a.spitch);
+            double h = 0.0;
+            for (int i = 0; i < tx; i++) h += cx[i] * (double)row[ix[i]];
+            s_h[rr][xl] = h;
         }
     }
     __syncthreads();
@@ -340,17 +321,95 @@ __global__ __launch_bounds__(256) void cropscale_fused_kernel(ScaleArgs3 all)
         const double *cy = a.cy + (size_t)y * ty;
         const int *iy = a.iy + (size_t)y * ty;
         double acc = 0.0;
-        if (TY > 0)
-        {
-#pragma unroll
-            for (int j = 0; j < TY; j++) acc += cy[j] * s_h[iy[j] - rmin][xl];
-        }
-        else
-        {
-            for (int j = 0; j < ty; j++) acc += cy[j] * s_h[iy[j] - rmin][xl];
-        }
+        for (int j = 0; j < ty; j++) acc += cy[j] * s_h[iy[j] - rmin][xl];
         acc = acc < 0.0 ? 0.0 : acc > a.vmax ? a.vmax : acc;
         reinterpret_cast<PIX *>(a.dst + (size_t)y * a.dpitch)[x] = (PIX)(int)(acc + 0.5);
+    }
+}
+
+// The 6 x 6-tap case (every upscale, e.g. 1080p -> 2160p), the form that runs for it.  What bounded the generic kernel
+// above was not arithmetic but a chain of dependent latencies per workgroup at low occupancy: tap rows from memory, a
+// barrier, per-thread tap tables from memory, byte gathers from memory for every horizontal tap, a barrier, then scalar
+// loads of the vertical taps for every output row - with 20 KB of LDS allowing five workgroups per CU.  Here
+//   * the host precomputes, per tile row and tile column, which source rows / columns the tile taps (tile_y, tile_x);
+//   * ONE round of loads fetches everything a workgroup needs: the tapped source samples (dwords -> LDS), the vertical
+//     taps of its 32 output rows (-> LDS) and each thread's own six horizontal taps (-> registers);
+//   * the horizontal pass gathers from LDS, the vertical pass reads its taps from LDS (broadcast);
+//   * LDS is sized to what the tile really taps (dynamic): 22 rows for a 2x upscale instead of 40.
+// Each H value and each output is the same sequence of double operations as in the kernels above.
+struct Tile6 { const int *tile_y[3]; const int *tile_x[3]; int nr_max, span_max; };
+
+template <typename PIX>
+__global__ __launch_bounds__(256) void cropscale_fused6_kernel(ScaleArgs3 all, Tile6 T)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem6[];
+    const int pl = blockIdx.z;
+    if (!all.active[pl]) return;
+    const ScaleArgs &a = all.p[pl];
+    const int x0 = blockIdx.x * FS_TW, y0 = blockIdx.y * FS_TH;
+    if (x0 >= a.dw || y0 >= a.dh) return;
+    const int t = threadIdx.x;
+    const int rows = min(FS_TH, a.dh - y0);
+    const int rmin = T.tile_y[pl][2 * blockIdx.y], nr = T.tile_y[pl][2 * blockIdx.y + 1];
+    const int c0 = T.tile_x[pl][2 * blockIdx.x], span = T.tile_x[pl][2 * blockIdx.x + 1];
+    double *s_h = smem6;                                             // [nr_max][FS_TW]
+    double *s_cy = s_h + (size_t)T.nr_max * FS_TW;                   // [FS_TH][6]
+    int *s_iy = reinterpret_cast<int *>(s_cy + FS_TH * 6);           // [FS_TH][6]
+    const int sp = (T.span_max + 4 + 3) & ~3;                        // samples per staged row
+    PIX *s_src = reinterpret_cast<PIX *>(s_iy + FS_TH * 6);          // [nr_max][sp]
+    const int xl = t & (FS_TW - 1), x = x0 + xl;
+    const int wave_row = __builtin_amdgcn_readfirstlane(t / FS_TW);
+
+    // one round of loads
+    int ixr[6];
+    double cxr[6];
+    if (x < a.dw)
+    {
+#pragma unroll
+        for (int i = 0; i < 6; i++) { ixr[i] = a.ix[(size_t)x * 6 + i] - c0; cxr[i] = a.cx[(size_t)x * 6 + i]; }
+    }
+    if (t < rows * 6)
+    {
+        s_cy[t] = a.cy[(size_t)y0 * 6 + t];
+        s_iy[t] = a.iy[(size_t)y0 * 6 + t] - rmin;
+    }
+    {
+        const int ndw = (span * (int)sizeof(PIX) + 3) / 4;
+        const int avail = a.spitch - c0 * (int)sizeof(PIX);          // bytes from c0 to the end of the row's pitch
+        const bool aligned = ((a.spitch | (int)((uintptr_t)a.src & 3)) & 3) == 0;
+        for (int i = t; i < nr * ndw; i += 256)
+        {
+            const int rr = i / ndw, d = i - rr * ndw;
+            const uint8_t *g = a.src + (size_t)(rmin + rr) * a.spitch + (size_t)c0 * sizeof(PIX) + 4 * d;
+            uint32_t v;
+            if (aligned && 4 * d + 4 <= avail) v = *reinterpret_cast<const uint32_t *>(g);
+            else
+            {
+                v = 0;
+                for (int k = 0; k < 4 && 4 * d + k < avail; k++) v |= (uint32_t)g[k] << (8 * k);
+            }
+            reinterpret_cast<uint32_t *>(s_src + (size_t)rr * sp)[d] = v;
+        }
+    }
+    __syncthreads();
+    if (x < a.dw)
+        for (int rr = wave_row; rr < nr; rr += 256 / FS_TW)
+        {
+            const PIX *row = s_src + (size_t)rr * sp;
+            double h = 0.0;
+#pragma unroll
+            for (int i = 0; i < 6; i++) h += cxr[i] * (double)row[ixr[i]];
+            s_h[rr * FS_TW + xl] = h;
+        }
+    __syncthreads();
+    if (x >= a.dw) return;
+    for (int yy = wave_row; yy < rows; yy += 256 / FS_TW)
+    {
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; j++) acc += s_cy[yy * 6 + j] * s_h[s_iy[yy * 6 + j] * FS_TW + xl];
+        acc = acc < 0.0 ? 0.0 : acc > a.vmax ? a.vmax : acc;
+        reinterpret_cast<PIX *>(a.dst + (size_t)(y0 + yy) * a.dpitch)[x] = (PIX)(int)(acc + 0.5);
     }
 }
 
@@ -418,6 +477,8 @@ public:
             if (d_iy[c]) (void)hipFree(d_iy[c]);
             if (d_cx[c]) (void)hipFree(d_cx[c]);
             if (d_cy[c]) (void)hipFree(d_cy[c]);
+            if (d_tile_y[c]) (void)hipFree(d_tile_y[c]);
+            if (d_tile_x[c]) (void)hipFree(d_tile_x[c]);
         }
         if (hbuf) (void)hipFree(hbuf);
     }
@@ -452,6 +513,32 @@ public:
                     hi = std::max(hi, iy[(size_t)y0 * ty[c] + i]);
                 }
                 if (hi - lo + 1 > FS_MAXR) fused = false;
+            }
+            if (tx[c] == 6 && ty[c] == 6)
+            {
+                // which source rows / columns each output tile taps (cropscale_fused6_kernel); the column origin is
+                // rounded down to a dword of samples
+                std::vector<int> tyv, txv;
+                const int al = 4 / in_geo.bps;
+                for (int y0 = 0; y0 < dh; y0 += FS_TH)
+                {
+                    int lo = 0x7fffffff, hi = -1;
+                    for (int i = 0; i < std::min(FS_TH, dh - y0) * 6; i++) { lo = std::min(lo, iy[(size_t)y0 * 6 + i]); hi = std::max(hi, iy[(size_t)y0 * 6 + i]); }
+                    tyv.push_back(lo); tyv.push_back(hi - lo + 1);
+                    nr_max = std::max(nr_max, hi - lo + 1);
+                }
+                for (int x0 = 0; x0 < dw; x0 += FS_TW)
+                {
+                    int lo = 0x7fffffff, hi = -1;
+                    for (int i = 0; i < std::min(FS_TW, dw - x0) * 6; i++) { lo = std::min(lo, ix[(size_t)x0 * 6 + i]); hi = std::max(hi, ix[(size_t)x0 * 6 + i]); }
+                    lo = lo / al * al;
+                    txv.push_back(lo); txv.push_back(hi - lo + 1);
+                    span_max = std::max(span_max, hi - lo + 1);
+                }
+                HBHIP_CHECK(ctx, hipMalloc((void **)&d_tile_y[c], sizeof(int) * tyv.size()));
+                HBHIP_CHECK(ctx, hipMalloc((void **)&d_tile_x[c], sizeof(int) * txv.size()));
+                HBHIP_CHECK(ctx, hipMemcpy(d_tile_y[c], tyv.data(), sizeof(int) * tyv.size(), hipMemcpyHostToDevice));
+                HBHIP_CHECK(ctx, hipMemcpy(d_tile_x[c], txv.data(), sizeof(int) * txv.size(), hipMemcpyHostToDevice));
             }
             HBHIP_CHECK(ctx, hipMalloc((void **)&d_ix[c], sizeof(int) * ix.size()));
             HBHIP_CHECK(ctx, hipMalloc((void **)&d_iy[c], sizeof(int) * iy.size()));
@@ -516,16 +603,21 @@ public:
             const dim3 grid((out->width[0] + FS_TW - 1) / FS_TW, (out->height[0] + FS_TH - 1) / FS_TH, 3);
             bool six = true;
             for (int c = 0; c < 3; c++) six &= !all.active[c] || (tx[c] == 6 && ty[c] == 6);
-            if (in_geo.bps == 1)
+            const int sp = (span_max + 4 + 3) & ~3;
+            const size_t lds6 = sizeof(double) * ((size_t)nr_max * FS_TW + FS_TH * 6) + sizeof(int) * FS_TH * 6 +
+                                (size_t)nr_max * sp * in_geo.bps + 16;
+            if (six && lds6 <= 64 * 1024 && getenv("HBHIP_SCALE_GENERIC") == nullptr)
             {
-                if (six) HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", (cropscale_fused_kernel<6, 6, uint8_t>), grid, dim3(256), 0, all);
-                else     HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", (cropscale_fused_kernel<0, 0, uint8_t>), grid, dim3(256), 0, all);
+                Tile6 T;
+                for (int c = 0; c < 3; c++) { T.tile_y[c] = d_tile_y[c]; T.tile_x[c] = d_tile_x[c]; }
+                T.nr_max = nr_max; T.span_max = span_max;
+                if (in_geo.bps == 1) HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", cropscale_fused6_kernel<uint8_t>, grid, dim3(256), lds6, all, T);
+                else                 HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", cropscale_fused6_kernel<uint16_t>, grid, dim3(256), lds6, all, T);
             }
+            else if (in_geo.bps == 1)
+                HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", (cropscale_fused_kernel<0, 0, uint8_t>), grid, dim3(256), 0, all);
             else
-            {
-                if (six) HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", (cropscale_fused_kernel<6, 6, uint16_t>), grid, dim3(256), 0, all);
-                else     HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", (cropscale_fused_kernel<0, 0, uint16_t>), grid, dim3(256), 0, all);
-            }
+                HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", (cropscale_fused_kernel<0, 0, uint16_t>), grid, dim3(256), 0, all);
         }
         HBHIP_CHECK(ctx, hipGetLastError());
         return HBHIP_OK;
@@ -537,6 +629,8 @@ public:
     int *d_ix[3] = {nullptr, nullptr, nullptr}, *d_iy[3] = {nullptr, nullptr, nullptr};
     double *d_cx[3] = {nullptr, nullptr, nullptr}, *d_cy[3] = {nullptr, nullptr, nullptr};
     double *hbuf = nullptr;     // horizontally filtered rows of one plane (dst_w x crop_h doubles)
+    int *d_tile_y[3] = {nullptr, nullptr, nullptr}, *d_tile_x[3] = {nullptr, nullptr, nullptr};
+    int nr_max = 0, span_max = 0;
 };
 
 // ------------------------------------------------------------------ pad
