@@ -141,36 +141,35 @@ struct hbhip_chain
             // the last stage writes the caller's frames itself when every frame it is about to
             // make has a slot and nothing older is waiting
             bool direct = is_last && held.empty() && f->can_submit_to() && produced + (int)cur.size() <= cap;
-            for (DevPicture *p : cur)
+            std::vector<DevPicture> views;
+            if (direct)
             {
-                if (s > 0)
+                views.resize(cur.size());
+                for (size_t i = 0; i < cur.size() && direct; i++)
                 {
-                    for (int c = 0; c < 3; c++) f->in_stride[c] = p->pitch[c];
-                    f->in_is_dev = true;
-                }
-                if (direct)
-                {
-                    DevPicture vo;
+                    DevPicture &vo = views[i];
                     for (int c = 0; c < 3; c++)
                     {
-                        vo.plane[c] = (uint8_t *)out[produced].plane[c]; vo.pitch[c] = out[produced].stride[c];
+                        vo.plane[c] = (uint8_t *)out[produced + i].plane[c]; vo.pitch[c] = out[produced + i].stride[c];
                         vo.width[c] = f->out_geo.pw[c]; vo.height[c] = f->out_geo.ph[c];
                         if (vo.plane[c] == nullptr || vo.pitch[c] < vo.width[c] * f->out_geo.bps ||
                             (vo.pitch[c] & 15) || ((uintptr_t)vo.plane[c] & 15))
                             direct = false;
                     }
                     vo.bps = f->out_geo.bps;
-                    if (direct)
-                    {
-                        if (tags) tags[produced] = p->tag;
-                        rc = f->submit_to(p, &vo);
-                        if (rc != HBHIP_OK) return rc;
-                        produced++;
-                        continue;
-                    }
                 }
-                rc = f->submit(p);
+            }
+            if (!cur.empty())
+            {
+                if (s > 0)
+                {
+                    for (int c = 0; c < 3; c++) f->in_stride[c] = cur[0]->pitch[c];
+                    f->in_is_dev = true;
+                }
+                if (direct && tags) for (size_t i = 0; i < cur.size(); i++) tags[produced + i] = cur[i]->tag;
+                rc = f->submit_many(cur.data(), (int)cur.size(), direct ? views.data() : nullptr);
                 if (rc != HBHIP_OK) return rc;
+                if (direct) produced += (int)cur.size();
             }
             rc = flush ? f->flush() : f->kick();
             if (rc != HBHIP_OK) return rc;

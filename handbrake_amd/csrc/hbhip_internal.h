@@ -210,6 +210,17 @@ struct hbhip_filter
     // takes ownership of `in`.  HBHIP_ERR_UNSUPPORTED when the filter has no such path.
     virtual int submit_to(DevPicture *, const DevPicture *) { return HBHIP_ERR_UNSUPPORTED; }
     virtual bool can_submit_to() const { return false; }
+    // Several pictures at once (a chain batch).  out_views != nullptr: write into those pictures (only when
+    // can_submit_to()); default = one by one.
+    virtual int submit_many(DevPicture *const *pics, int n, const DevPicture *out_views)
+    {
+        for (int i = 0; i < n; i++)
+        {
+            int rc = out_views ? submit_to(pics[i], &out_views[i]) : submit(pics[i]);
+            if (rc != HBHIP_OK) return rc;
+        }
+        return HBHIP_OK;
+    }
     // ---- pipelined host path (hbhip_filter_submit_async): one-in / one-out filters ----
     virtual DevPicture *acquire_output() { return nullptr; }
     virtual int process_pair(DevPicture *, DevPicture *) { return HBHIP_ERR_UNSUPPORTED; }   // in -> out on ctx->stream
@@ -232,6 +243,49 @@ struct SimpleFilter : hbhip_filter
         out_pool.configure(ctx, gout);
     }
     virtual int process(DevPicture *in, DevPicture *out) = 0;
+    // n frames at once: filters whose kernels take several frames per launch override this (single planes are
+    // too small to fill the GPU or to hide a launch)
+    virtual int process_many(DevPicture *const *ins, DevPicture *const *outs, int n)
+    {
+        for (int i = 0; i < n; i++)
+        {
+            int rc = process(ins[i], outs[i]);
+            if (rc != HBHIP_OK) return rc;
+        }
+        return HBHIP_OK;
+    }
+    // fused chains: the pictures of a batch in one go; outs == nullptr -> own output pictures (queued), else the
+    // caller's pictures (views).  Takes ownership of the inputs.
+    int submit_many(DevPicture *const *pics, int n, const DevPicture *out_views) override
+    {
+        std::vector<DevPicture *> outs(n, nullptr);
+        std::vector<DevPicture> views;
+        if (out_views)
+        {
+            views.assign(out_views, out_views + n);
+            for (int i = 0; i < n; i++) { views[i].tag = pics[i]->tag; outs[i] = &views[i]; }
+        }
+        else
+            for (int i = 0; i < n; i++)
+            {
+                outs[i] = out_pool.acquire();
+                if (!outs[i])
+                {
+                    for (int k = 0; k < i; k++) out_pool.release(outs[k]);
+                    return HBHIP_ERR_NOMEM;
+                }
+                outs[i]->tag = pics[i]->tag;
+            }
+        int rc = process_many(pics, outs.data(), n);
+        for (int i = 0; i < n; i++) hbhip_pic_release(pics[i]);
+        if (rc != HBHIP_OK)
+        {
+            if (!out_views) for (DevPicture *o : outs) out_pool.release(o);
+            return rc;
+        }
+        if (!out_views) for (DevPicture *o : outs) outq.push_back(o);
+        return HBHIP_OK;
+    }
 
     DevPicture *acquire_input() override { return in_pool.acquire(); }
     int submit(DevPicture *pic) override
@@ -284,23 +338,25 @@ struct SimpleFilter : hbhip_filter
                     (out[i].stride[c] & 15) || ((uintptr_t)out[i].plane[c] & 15))
                     direct = false;
         if (!direct) return hbhip_filter::process_dev_batch(in, n_in, tag0, out, out_cap, n_out);
+        std::vector<DevPicture> vi(n_in), vo(n_in);
+        std::vector<DevPicture *> pi(n_in), po(n_in);
         for (int i = 0; i < n_in; i++)
         {
-            DevPicture vi, vo;
             for (int c = 0; c < 3; c++)
             {
-                vi.plane[c] = (uint8_t *)in[i].plane[c];  vi.pitch[c] = in[i].stride[c];
-                vi.width[c] = in_geo.pw[c];               vi.height[c] = in_geo.ph[c];
-                vo.plane[c] = (uint8_t *)out[i].plane[c]; vo.pitch[c] = out[i].stride[c];
-                vo.width[c] = out_geo.pw[c];              vo.height[c] = out_geo.ph[c];
+                vi[i].plane[c] = (uint8_t *)in[i].plane[c];  vi[i].pitch[c] = in[i].stride[c];
+                vi[i].width[c] = in_geo.pw[c];               vi[i].height[c] = in_geo.ph[c];
+                vo[i].plane[c] = (uint8_t *)out[i].plane[c]; vo[i].pitch[c] = out[i].stride[c];
+                vo[i].width[c] = out_geo.pw[c];              vo[i].height[c] = out_geo.ph[c];
                 in_stride[c] = in[i].stride[c];
             }
-            vi.bps = in_geo.bps; vo.bps = out_geo.bps;
-            vi.tag = vo.tag = tag0 + i;
-            in_is_dev = true;
-            int rc = process(&vi, &vo);
-            if (rc != HBHIP_OK) return rc;
+            vi[i].bps = in_geo.bps; vo[i].bps = out_geo.bps;
+            vi[i].tag = vo[i].tag = tag0 + i;
+            pi[i] = &vi[i]; po[i] = &vo[i];
         }
+        in_is_dev = true;
+        int rc = process_many(pi.data(), po.data(), n_in);
+        if (rc != HBHIP_OK) return rc;
         *n_out = n_in;
         return HBHIP_OK;
     }
