@@ -459,7 +459,7 @@ def run_chain(args, world, rank, local_rank):
         top = sorted(stats.items(), key=lambda kv: -kv[1][1])
         total_ms = sum(ms for _, (_, ms) in top) or 1.0
         kernels = []
-        for k, (n, ms) in top[:12]:
+        for k, (n, ms) in top[:24]:
             # the profiled pass ran 2 steps = 4 B frames through NLMeans, in n launches
             ab = algorithmic_bytes(k, W, H, OW, OH, frames_per_launch=4 * B / n if k.startswith("nlmeans_plane") else 1)
             ab = int(ab) if ab else ab

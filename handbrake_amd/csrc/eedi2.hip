@@ -347,6 +347,173 @@ __global__ __launch_bounds__(256) void k_mask_fused(P3 P, int mth, int vth, int 
     });
 }
 
+// The same five passes on dwords.  Every value of the mask is 0 or 255, so inside the kernel a mask
+// pixel is one byte holding 0 / 1 and four of them are handled by one 32-bit operation: the 8-neighbour
+// count of erode / dilate is a sum of byte-shifted dwords (at most 8 per byte, no carries), the
+// threshold test one add (bit 7 of count + 0x80 - thr), remove_small_gaps a handful of ANDs / ORs of
+// shifted dwords.  A thread owns one dword column of the LDS frame and a strip of 4 rows; it loads the
+// 6 rows x 3 dwords around the strip once and keeps the per-row partial sums in registers.  Each pass
+// computes the whole frame minus one more row top and bottom; the cells next to the frame's left / right
+// edge come out wrong by design (they read the unwritten pad column), one byte further in per pass,
+// which the 8-byte column halo absorbs (the tile needs x0-3 .. x0+130 from the last erode).
+constexpr int MF_DW = MF_LP / 4;                 // 36 dwords per LDS row
+constexpr int MF_DP = MF_DW + 2;                 // + one pad dword either side
+constexpr int MF_SR = 4;                         // rows per thread and pass
+
+// 0xff in byte k when lo <= X + k < hi
+__device__ __forceinline__ uint32_t mf_bytes_in(int X, int lo, int hi)
+{
+    uint32_t m = 0xffffffffu;
+    const int a = lo - X, b = hi - X;
+    if (a > 0) m = a >= 4 ? 0u : (m << (8 * a));
+    if (b < 4) m = b <= 0 ? 0u : (m & (0xffffffffu >> (8 * (4 - b))));
+    return m;
+}
+
+// erode (GROW = false) / dilate (GROW = true) of LDS rows ra .. rb
+template <bool GROW>
+__device__ __forceinline__ void mf_morph4(const uint32_t (*src)[MF_DP], uint32_t (*dst)[MF_DP], int c4, int strip,
+                                          int ra, int rb, int thr, uint32_t px1, int fy, int height)
+{
+    const int r0 = ra + strip * MF_SR;
+    if (r0 <= rb)
+    {
+        const uint32_t K = (uint32_t)(0x80 - min(max(thr, 0), 9)) * 0x01010101u;
+        uint32_t S2[MF_SR + 2], S3[MF_SR + 2], C[MF_SR + 2];
+#pragma unroll
+        for (int i = 0; i < MF_SR + 2; i++)
+        {
+            const int r = min(r0 - 1 + i, MF_LR - 1);
+            const uint32_t l = src[r][c4], c = src[r][c4 + 1], rr = src[r][c4 + 2];
+            const uint32_t lb = __builtin_amdgcn_alignbyte(c, l, 3), rbv = __builtin_amdgcn_alignbyte(rr, c, 1);
+            C[i] = c;
+            S2[i] = lb + rbv;
+            S3[i] = S2[i] + c;
+        }
+#pragma unroll
+        for (int i = 0; i < MF_SR; i++)
+        {
+            const int r = r0 + i;
+            if (r > rb) break;
+            const int y = fy + r;
+            const uint32_t count = S3[i] + S2[i + 1] + S3[i + 2];
+            const uint32_t ge = ((count + K) >> 7) & 0x01010101u;          // count >= thr, per byte
+            const uint32_t pm = (y >= 1 && y < height - 1) ? px1 : 0u;
+            const uint32_t c = C[i + 1];
+            dst[r][c4 + 1] = GROW ? (c | (ge & pm)) : (c & ~((ge ^ 0x01010101u) & pm));
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_mask_fused4(P3 P, int mth, int vth, int lth, int erode_thr, int dilate_thr)
+{
+    __shared__ uint32_t s_src[MF_LR][MF_DP];
+    __shared__ uint32_t s_a[MF_LR][MF_DP];
+    __shared__ uint32_t s_b[MF_LR][MF_DP];
+    const int pl = blockIdx.z;
+    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
+    const int x0 = blockIdx.x * MF_W, y0 = blockIdx.y * MF_H;
+    if (x0 >= width || y0 >= height) return;
+    const int t = threadIdx.x, fx = x0 - MF_OX, fy = y0 - MF_OY;
+
+    for (int i = t; i < MF_LR * MF_DW; i += 256)
+    {
+        const int r = i / MF_DW, c4 = i - r * MF_DW;
+        const int y = fy + r, x = fx + 4 * c4;
+        uint32_t sv = 0, mv = 0;
+        if (y >= 0 && y < height && x >= 0 && x < pitch)
+        {
+            sv = *reinterpret_cast<const uint32_t *>(P.a[pl] + (size_t)y * pitch + x);
+            mv = *reinterpret_cast<const uint32_t *>(P.b[pl] + (size_t)y * pitch + x);
+        }
+        s_src[r][c4 + 1] = sv;
+        s_a[r][c4 + 1] = mv & 0x01010101u;
+    }
+    __syncthreads();
+
+    const int c4 = t % MF_DW, strip = t / MF_DW;               // strip 7 (t >= 252) has no rows in any pass
+    const int X = fx + 4 * c4;
+    const uint32_t px1 = mf_bytes_in(X, 1, width - 1) & 0x01010101u;
+
+    // build_edge_mask (:122-195), in place on the old mask; LDS rows 1 .. 22
+    {
+        const int r0 = 1 + strip * MF_SR;
+        if (r0 <= MF_LR - 2)
+        {
+            int b[MF_SR + 2][6], q[MF_SR + 2][6];
+#pragma unroll
+            for (int i = 0; i < MF_SR + 2; i++)
+            {
+                const int r = min(r0 - 1 + i, MF_LR - 1);
+                const uint32_t l = s_src[r][c4], c = s_src[r][c4 + 1], rr = s_src[r][c4 + 2];
+                b[i][0] = (int)(l >> 24);
+                b[i][1] = (int)(c & 0xffu); b[i][2] = (int)((c >> 8) & 0xffu); b[i][3] = (int)((c >> 16) & 0xffu); b[i][4] = (int)(c >> 24);
+                b[i][5] = (int)(rr & 0xffu);
+#pragma unroll
+                for (int j = 0; j < 6; j++) q[i][j] = b[i][j] * b[i][j];
+            }
+#pragma unroll
+            for (int i = 0; i < MF_SR; i++)
+            {
+                const int r = r0 + i;
+                if (r > MF_LR - 2) break;
+                const int y = fy + r;
+                const int (&Pr)[6] = b[i], (&Cr)[6] = b[i + 1], (&Nr)[6] = b[i + 2];
+                int cs[6], cq[6];
+                bool fl[6];
+#pragma unroll
+                for (int j = 0; j < 6; j++)
+                {
+                    cs[j] = Pr[j] + Cr[j] + Nr[j];
+                    cq[j] = q[i][j] + q[i + 1][j] + q[i + 2][j];
+                    fl[j] = iabs(Pr[j] - Cr[j]) < 10 && iabs(Cr[j] - Nr[j]) < 10 && iabs(Pr[j] - Nr[j]) < 10;
+                }
+                uint32_t edge = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                {
+                    const int sum = cs[k] + cs[k + 1] + cs[k + 2], sumsq = cq[k] + cq[k + 1] + cq[k + 2];
+                    const int C0 = Cr[k], C1 = Cr[k + 1], C2 = Cr[k + 2], P1 = Pr[k + 1], N1 = Nr[k + 1];
+                    const int ix = C2 - C0;
+                    const int iy = max(max(iabs(P1 - N1), iabs(P1 - C1)), iabs(C1 - N1));
+                    const int ixx = C0 - 2 * C1 + C2, iyy = P1 - 2 * C1 + N1;
+                    const bool e = !(fl[k + 1] || (fl[k] && fl[k + 2])) && 9 * sumsq - sum * sum >= vth &&
+                                   (ix * ix + iy * iy >= mth || iabs(ixx) + iabs(iyy) >= lth);
+                    edge |= (e ? 1u : 0u) << (8 * k);
+                }
+                const uint32_t keep = (y < height / 2) ? 0u : s_a[r][c4 + 1];
+                const uint32_t pm = (y >= 1 && y < height - 1) ? px1 : 0u;
+                s_a[r][c4 + 1] = keep | (edge & pm);
+            }
+        }
+    }
+    __syncthreads();
+
+    mf_morph4<false>(s_a, s_b, c4, strip, 2, MF_LR - 3, erode_thr, px1, fy, height);
+    mf_morph4<true>(s_b, s_a, c4, strip, 3, MF_LR - 4, dilate_thr, px1, fy, height);
+    mf_morph4<false>(s_a, s_b, c4, strip, 4, MF_LR - 5, erode_thr, px1, fy, height);
+
+    // remove_small_gaps (:308-342) on the tile's 16 rows x 32 dwords, straight to the new mask
+    for (int i = t; i < MF_H * (MF_W / 4); i += 256)
+    {
+        const int r = MF_OY + i / (MF_W / 4), g4 = MF_OX / 4 + (i & (MF_W / 4 - 1));
+        const int y = fy + r, x = fx + 4 * g4;
+        if (y >= height || x >= width) continue;
+        const uint32_t l = s_b[r][g4], c = s_b[r][g4 + 1], rr = s_b[r][g4 + 2];
+        const uint32_t a1 = __builtin_amdgcn_alignbyte(c, l, 3), a2 = __builtin_amdgcn_alignbyte(c, l, 2), a3 = __builtin_amdgcn_alignbyte(c, l, 1);
+        const uint32_t b1 = __builtin_amdgcn_alignbyte(rr, c, 1), b2 = __builtin_amdgcn_alignbyte(rr, c, 2), b3 = __builtin_amdgcn_alignbyte(rr, c, 3);
+        const uint32_t a12 = a1 | a2, a123 = a12 | a3;
+        const uint32_t set = c & (a123 | b1 | b2 | b3);                               // a set pixel survives with any neighbour set
+        const uint32_t fill = ((b1 & a123) | (b2 & a12) | (b3 & a1)) & (c ^ 0x01010101u);
+        const uint32_t pm = (y >= 1 && y < height - 1) ? (mf_bytes_in(x, 3, width - 3) & 0x01010101u) : 0u;
+        const uint32_t res = (((set | fill) & pm) | (c & ~pm)) * 255u;
+        uint8_t *d = P.c[pl] + (size_t)y * pitch + x;
+        if (x + 3 < width) *reinterpret_cast<uint32_t *>(d) = res;
+        else for (int k = 0; k < 4 && x + k < width; k++) d[k] = (uint8_t)(res >> (8 * k));
+    }
+}
+
 // calc_directions in two launches so that no lane idles while its neighbour walks the
 // +-maxd search: k_calc_dir_mark fills the plane with 255 (the reference's memset) and
 // appends every pixel that passes the edge test (:392-393) to a work list; k_calc_dir_work
@@ -1739,10 +1906,16 @@ int Eedi2Engine::enqueue_mask(int sel)
         P.a[c] = srcp.plane[c]; P.b[c] = mskp_old.plane[c]; P.c[c] = mskp.plane[c];
     }
     // edge mask, erode, dilate, erode, remove_small_gaps in one launch (old mask -> new mask)
-    HBHIP_LAUNCH(ctx_, "eedi2_mask_passes", k_mask_fused,
-                 dim3((srcp.width[0] + MF_W - 1) / MF_W, (srcp.height[0] + MF_H - 1) / MF_H, 3), dim3(256), 0, P,
-                 par_.magnitude_threshold * 10, par_.laplacian_threshold * 81, par_.variance_threshold,
-                 par_.erosion_threshold, par_.dilation_threshold);
+    static const bool one_px = getenv("HBHIP_EEDI2_1PX") != nullptr;                   // A/B switch: the byte-per-thread form
+    const dim3 grid((srcp.width[0] + MF_W - 1) / MF_W, (srcp.height[0] + MF_H - 1) / MF_H, 3);
+    if (one_px)
+        HBHIP_LAUNCH(ctx_, "eedi2_mask_passes", k_mask_fused, grid, dim3(256), 0, P,
+                     par_.magnitude_threshold * 10, par_.laplacian_threshold * 81, par_.variance_threshold,
+                     par_.erosion_threshold, par_.dilation_threshold);
+    else
+        HBHIP_LAUNCH(ctx_, "eedi2_mask_passes", k_mask_fused4, grid, dim3(256), 0, P,
+                     par_.magnitude_threshold * 10, par_.laplacian_threshold * 81, par_.variance_threshold,
+                     par_.erosion_threshold, par_.dilation_threshold);
     HBHIP_CHECK(ctx_, hipGetLastError());
     return HBHIP_OK;
 }
