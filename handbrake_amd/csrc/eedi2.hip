@@ -1002,6 +1002,99 @@ __global__ __launch_bounds__(256) void k_dir_map4(P3 P, int step, int y0, int ex
     }
 }
 
+// k_dir_map4 in two phases.  Which pixels reach the sort is decided by byte arithmetic on whole dwords
+// (phase 1: peak tests, the 3x3 count of usable neighbours and the thresholds on it, four pixels per
+// 32-bit operation); on real pictures that is a small minority, spread so that nearly every wave
+// holds a few - and a wave pays for the sort if one lane needs it.  So phase 1 only queues them (LDS
+// list, per workgroup of 4 rows x 256 pixels) and phase 2 gives each queued pixel a lane of its own:
+// the sort runs on full waves, on as few of them as the queue fills.
+__device__ __forceinline__ uint32_t ff_bytes(uint32_t v)          // 0x80 in every byte that is 0xff
+{
+    return (((v & 0x7f7f7f7fu) + 0x01010101u) & v) & 0x80808080u;
+}
+__device__ __forceinline__ uint32_t live3(const Win12 &w, uint32_t &centre)   // per byte: usable (non-peak) values among x-1, x, x+1
+{
+    const uint32_t n0 = (~ff_bytes(w.w0) >> 7) & 0x01010101u, n1 = (~ff_bytes(w.w1) >> 7) & 0x01010101u, n2 = (~ff_bytes(w.w2) >> 7) & 0x01010101u;
+    centre = n1;
+    return __builtin_amdgcn_alignbyte(n1, n0, 3) + n1 + __builtin_amdgcn_alignbyte(n2, n1, 1);
+}
+
+__global__ __launch_bounds__(256) void k_dir_map_c(P3 P, int step, int y0, int expand)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[4][256];
+    __shared__ uint16_t s_list[4 * 256];
+    __shared__ int s_count;
+    const int pl = blockIdx.z;
+    const int bx0 = 4 * (blockIdx.x * 64), x = bx0 + 4 * threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
+    if (bx0 >= width || (int)blockIdx.y * 4 >= height) return;                       // whole workgroup outside
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+    const bool inside = x < width && y < height;
+    const bool row_ok = step == 1 ? (y >= 1 && y < height - 1) : (y >= y0 && y < height - 1 && ((y - y0) & 1) == 0);
+    const uint8_t *dc = P.b[pl] + (size_t)y * pitch + x;
+    if (inside)
+    {
+        uint32_t out;
+        if (!row_ok) out = *reinterpret_cast<const uint32_t *>(dc);                   // bit_blit only
+        else
+        {
+            const Win12 wc = ldwin(dc), wu = ldwin(dc - (ptrdiff_t)step * pitch), wd = ldwin(dc + (ptrdiff_t)step * pitch);
+            const uint8_t *mk = P.a[pl] + (size_t)y * pitch + x;
+            const uint32_t m0 = *reinterpret_cast<const uint32_t *>(step == 1 ? mk : mk - (ptrdiff_t)pitch);
+            const uint32_t m1 = step == 1 ? 0u : *reinterpret_cast<const uint32_t *>(mk + pitch);
+            const bool up_ok = step == 1 || y > 1, dn_ok = step == 1 || y < height - 2;
+            uint32_t nc, nu, nd;
+            const uint32_t s3c = live3(wc, nc), s3u = live3(wu, nu), s3d = live3(wd, nd);
+            uint32_t u = expand ? s3c - nc : s3c;                                      // expand leaves the centre out (:671)
+            if (up_ok) u += s3u;
+            if (dn_ok) u += s3d;
+            const uint32_t enough = ((u + (uint32_t)(0x80 - (expand ? 5 : 4)) * 0x01010101u) >> 7) & 0x01010101u;
+            uint32_t cand = ((ff_bytes(m0) | ff_bytes(m1)) >> 7) & mf_bytes_in(x, 1, width - 1);
+            if (expand) cand &= ~nc;                                                   // expand only fills peak pixels
+            out = wc.w1;
+            if (!expand) out |= (cand & ~enough) * 255u;                               // too few neighbours: peak
+            uint32_t sortpx = cand & enough;
+            if (sortpx)
+            {
+                const int n = __popc(sortpx);
+                int at = atomicAdd(&s_count, n);
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if ((sortpx >> (8 * k)) & 1u) s_list[at++] = (uint16_t)((threadIdx.y << 8) | (4 * threadIdx.x + k));
+            }
+            (void)nu; (void)nd;
+        }
+        *reinterpret_cast<uint32_t *>(&s_out[threadIdx.y][4 * threadIdx.x]) = out;
+        if (P.d[pl])                                                                    // optional copy of the input (the eedi2_bit_blit before post-processing)
+        {
+            const uint32_t v = *reinterpret_cast<const uint32_t *>(dc);
+            int in[4] = { (int)(v & 0xff), (int)((v >> 8) & 0xff), (int)((v >> 16) & 0xff), (int)(v >> 24) };
+            st4(P.d[pl] + (size_t)y * pitch + x, in, x, width);
+        }
+    }
+    __syncthreads();
+    const int count = s_count;
+    for (int i = tid; i < count; i += 256)
+    {
+        const int e = s_list[i], ly = e >> 8, lx = e & 255;
+        const int yy = blockIdx.y * 4 + ly;
+        const uint8_t *c = P.b[pl] + (size_t)yy * pitch + bx0 + lx;
+        const uint8_t *up = c - (ptrdiff_t)step * pitch, *dn = c + (ptrdiff_t)step * pitch;
+        const bool up_ok = step == 1 || yy > 1, dn_ok = step == 1 || yy < height - 2;
+        s_out[ly][lx] = (uint8_t)dir_map_px(up[-1], up[0], up[1], c[-1], c[0], c[1], dn[-1], dn[0], dn[1], up_ok, dn_ok, expand);
+    }
+    __syncthreads();
+    if (inside)
+    {
+        const uint32_t v = *reinterpret_cast<const uint32_t *>(&s_out[threadIdx.y][4 * threadIdx.x]);
+        uint8_t *o = P.c[pl] + (size_t)y * pitch + x;
+        if (x + 3 < width) *reinterpret_cast<uint32_t *>(o) = v;
+        else for (int k = 0; k < 4 && x + k < width; k++) o[k] = (uint8_t)(v >> (8 * k));
+    }
+}
+
 __device__ __forceinline__ bool trips(const uint8_t *side, const uint8_t *dc, int x, int from, int to, int lim)
 {
     const int ref = dc[x];
@@ -1338,51 +1431,10 @@ __global__ __launch_bounds__(256) void k_fill_gaps_c(P3 P, int y0)
     }
 }
 
-// interpolate_lattice in two launches.
-// k_lattice_cand (one thread per pixel of the rows being rebuilt): everything about a pixel
-// that does not depend on its left neighbour's NEW direction value, packed into 32 bits:
-//   [7:0] valA  = vertical average (outcome A)      [15:8]  valB = outcome-B pixel value
-//   [23:16] newB = outcome-B direction value        bit 24 = "always A" (dir == peak)
-//   bit 25 = right-hand test |d[x]-d[x+1]| > lim    (newA is NEUTRAL, or PEAK when always A)
-// k_lattice_resolve (one wavefront per row): resolves which outcome each pixel takes —
-// that depends on the value just written at x-1 (:1194) — with a 64-lane prefix composition
-// of 2-state maps, carrying the last written value from chunk to chunk, then writes the row.
-// a = dmsk (tmp2p, in/out), b = dst (dst2p, in/out), c = omsk (tmp2p2).
-constexpr int LC_W = 256, LC_HALO = 40, LC_LW = LC_W + 2 * LC_HALO;   // |u| <= 34, +-1 for the triples, rounded to dwords
-
-__global__ __launch_bounds__(LC_W) void k_lattice_cand(P3 P, uint32_t *__restrict__ cand, int cand_pitch,
-                                                        int cand_plane_stride, int field, int nt4, int nt7, int nt8, int nt)
+// Everything k_lattice_cand packs for one pixel; the row pointers are indexed by the absolute column.
+__device__ __forceinline__ uint32_t lattice_px(const uint8_t *top, const uint8_t *bot, const uint8_t *ot, const uint8_t *ob,
+                                               const uint8_t *dm, int x, int width, int pl, int nt4, int nt7, int nt8, int nt)
 {
-    // One workgroup = 256 consecutive pixels of one rebuilt row.  The five rows the search reads
-    // (dst y-1 / y+1, old direction map y-1 / y+1, new direction map y) are staged in LDS with the
-    // same flat addressing, so every data-dependent byte read below is an LDS read.
-    __shared__ __attribute__((aligned(16))) uint8_t s_rows[5][LC_LW];
-    const int pl = blockIdx.z;
-    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
-    const int x0 = blockIdx.x * LC_W;
-    const int x = x0 + threadIdx.x;
-    const int ri = blockIdx.y;
-    const int nrows = (height - (2 - field)) / 2;
-    if (x0 >= width || ri >= nrows) return;
-    const int y = (2 - field) + 2 * ri;
-    {
-        const uint8_t *g[5] = { P.b[pl] + (size_t)(y - 1) * pitch, P.b[pl] + (size_t)(y + 1) * pitch,
-                                P.c[pl] + (size_t)(y - 1) * pitch, P.c[pl] + (size_t)(y + 1) * pitch,
-                                P.a[pl] + (size_t)y * pitch };
-        for (int i = threadIdx.x; i < 5 * (LC_LW / 4); i += LC_W)
-        {
-            const int r = i / (LC_LW / 4), c4 = i - r * (LC_LW / 4);
-            reinterpret_cast<uint32_t *>(s_rows[r])[c4] =
-                reinterpret_cast<const uint32_t *>(g[r] + x0 - LC_HALO)[c4];
-        }
-    }
-    __syncthreads();
-    if (x >= width) return;
-    // row pointers indexed by the absolute column, as in the reference
-    const uint8_t *top = s_rows[0] + LC_HALO - x0, *bot = s_rows[1] + LC_HALO - x0;
-    const uint8_t *ot = s_rows[2] + LC_HALO - x0, *ob = s_rows[3] + LC_HALO - x0;
-    const uint8_t *dm = s_rows[4] + LC_HALO - x0;
-
     // the fixed-offset bytes every path below needs, loaded together
     const int d = dm[x], dr = dm[x + 1];
     const int T0 = top[x - 2], T1 = top[x - 1], T2 = top[x], T3 = top[x + 1], T4 = top[x + 2];
@@ -1469,8 +1521,247 @@ __global__ __launch_bounds__(LC_W) void k_lattice_cand(P3 P, uint32_t *__restric
             }
         }
     }
-    cand[(size_t)pl * cand_plane_stride + (size_t)ri * cand_pitch + x] =
-        (uint32_t)avg | ((uint32_t)valB << 8) | ((uint32_t)newB << 16) | ((uint32_t)always_a << 24) | ((uint32_t)right << 25);
+    return (uint32_t)avg | ((uint32_t)valB << 8) | ((uint32_t)newB << 16) | ((uint32_t)always_a << 24) | ((uint32_t)right << 25);
+}
+
+// lattice_px cut at its two decision points, for k_lattice_cand_q: each stage either finishes the word or hands
+// the pixel to the next one.  `base` carries the bits every outcome shares (valA and the right-hand test).
+constexpr uint32_t LAT_MORE = 0x80000000u;
+
+// the variance and the edge test on the fixed 2 x 5 neighbourhood (:1213-1240)
+__device__ __forceinline__ uint32_t lattice_stage_a(const uint8_t *top, const uint8_t *bot, const uint8_t *dm, int x, int width, uint32_t base)
+{
+    const int d = dm[x];
+    const int T0 = top[x - 2], T1 = top[x - 1], T2 = top[x], T3 = top[x + 1], T4 = top[x + 2];
+    const int B0 = bot[x - 2], B1 = bot[x - 1], B2 = bot[x], B3 = bot[x + 1], B4 = bot[x + 2];
+    const int lim = c_limlut[iabs(d - NEUTRAL) >> 2];
+    const uint32_t avg = base & 0xffu;
+    if (lim < 9)
+    {
+        const int sum = T1 + T2 + T3 + B1 + B2 + B3;
+        const int sumsq = T1 * T1 + T2 * T2 + T3 * T3 + B1 * B1 + B2 * B2 + B3 * B3;
+        if (6 * sumsq - sum * sum < 576) return base | (avg << 8) | ((uint32_t)PEAK << 16);
+    }
+    if (x > 1 && x < width - 2)
+    {
+        const int t = T2, b = B2;
+        const int tl = max(T0, T1), tr = max(T4, T3);
+        const int bl = max(B0, B1), br = max(B4, B3);
+        const int tl2 = min(T0, T1), tr2 = min(T4, T3);
+        const int bl2 = min(B0, B1), br2 = min(B4, B3);
+        if ((t < tl - 3 && t < tr - 3 && b < bl - 3 && b < br - 3) ||
+            (t > tl2 + 3 && t > tr2 + 3 && b > bl2 + 3 && b > br2 + 3))
+            return base | (avg << 8) | ((uint32_t)NEUTRAL << 16);
+    }
+    return base | LAT_MORE;
+}
+
+// the search around the pixel's direction (:1242-1290)
+__device__ __forceinline__ uint32_t lattice_stage_b(const uint8_t *top, const uint8_t *bot, const uint8_t *ot, const uint8_t *ob,
+                                                    const uint8_t *dm, int x, int width, int nt4, int nt8, uint32_t base)
+{
+    const int d = dm[x];
+    const int lim = c_limlut[iabs(d - NEUTRAL) >> 2];
+    int dir = (d - NEUTRAL + 2) >> 2;
+    int val = (int)(base & 0xffu);
+    const int startu = (dir - 2 < 0) ? max(-x + 1, max(dir - 2, -width + 2 + x)) : min(x - 1, min(dir - 2, width - 2 - x));
+    const int stopu = (dir + 2 < 0) ? max(-x + 1, max(dir + 2, -width + 2 + x)) : min(x - 1, min(dir + 2, width - 2 - x));
+    int mn = nt8;
+#define NEAR(row, i) ((row)[i] != PEAK && iabs((int)(row)[i] - d) <= lim)
+    for (int u = startu; u <= stopu; u++)
+    {
+        const int diff = sad3(top, x, bot, x - u) + sad3(bot, x, top, x + u);
+        if (!(diff < mn && (NEAR(ot, x - 1 + u) || NEAR(ot, x + u) || NEAR(ot, x + 1 + u)) &&
+              (NEAR(ob, x - 1 - u) || NEAR(ob, x - u) || NEAR(ob, x + 1 - u))))
+            continue;
+        const int h0 = u >> 1, h1 = (u + 1) >> 1;
+        const int diff2 = sad3(top, x + h0, bot, x - h0);
+        const int o0 = ot[x + h0], o1 = ot[x + h1], q0 = ob[x - h0], q1 = ob[x - h1];
+        if (!(diff2 < nt4 && (((iabs(o0 - q0) <= lim || iabs(o0 - q1) <= lim) && o0 != PEAK) ||
+                              ((iabs(o1 - q0) <= lim || iabs(o1 - q1) <= lim) && o1 != PEAK))))
+            continue;
+        if ((iabs(d - o0) <= lim || iabs(d - o1) <= lim) && (iabs(d - q0) <= lim || iabs(d - q1) <= lim))
+        {
+            val = ((int)top[x + h0] + (int)top[x + h1] + (int)bot[x - h0] + (int)bot[x - h1] + 2) >> 2;
+            mn = diff;
+            dir = u;
+        }
+    }
+#undef NEAR
+    if (mn != nt8) return base | ((uint32_t)val << 8) | ((uint32_t)((NEUTRAL + dir * 4) & 0xff) << 16);
+    return base | LAT_MORE;
+}
+
+// the short search for pixels the first one left without a match (:1292-1318)
+__device__ __forceinline__ uint32_t lattice_stage_c(const uint8_t *top, const uint8_t *bot, const uint8_t *dm, int x, int width, int pl,
+                                                    int nt7, int nt, uint32_t base)
+{
+    int dir = ((int)dm[x] - NEUTRAL + 2) >> 2;
+    int val = (int)(base & 0xffu);
+    const int lo = min((int)top[x], (int)bot[x]), hi = max((int)top[x], (int)bot[x]);
+    const int dd = pl == 0 ? 4 : 2;
+    const int su = max(-x + 1, -dd), eu = min(width - 2 - x, dd);
+    int mn = nt7;
+    for (int u = su; u <= eu; u++)
+    {
+        const int h0 = u >> 1, h1 = (u + 1) >> 1;
+        const int p1 = (int)top[x + h0] + (int)top[x + h1];
+        const int p2 = (int)bot[x - h0] + (int)bot[x - h1];
+        const int diff = sad3(top, x, bot, x - u) + sad3(bot, x, top, x + u) + iabs(p1 - p2);
+        if (diff < mn)
+        {
+            const int valt = (p1 + p2 + 2) >> 2;
+            if (valt >= lo && valt <= hi) { val = valt; mn = diff; dir = u; }
+        }
+    }
+    const int newB = (mn == 7 * nt) ? NEUTRAL : ((NEUTRAL + dir * 4) & 0xff);
+    return base | ((uint32_t)val << 8) | ((uint32_t)newB << 16);
+}
+
+// interpolate_lattice in two launches.
+// k_lattice_cand (one thread per pixel of the rows being rebuilt): everything about a pixel
+// that does not depend on its left neighbour's NEW direction value, packed into 32 bits:
+//   [7:0] valA  = vertical average (outcome A)      [15:8]  valB = outcome-B pixel value
+//   [23:16] newB = outcome-B direction value        bit 24 = "always A" (dir == peak)
+//   bit 25 = right-hand test |d[x]-d[x+1]| > lim    (newA is NEUTRAL, or PEAK when always A)
+// k_lattice_resolve (one wavefront per row): resolves which outcome each pixel takes —
+// that depends on the value just written at x-1 (:1194) — with a 64-lane prefix composition
+// of 2-state maps, carrying the last written value from chunk to chunk, then writes the row.
+// a = dmsk (tmp2p, in/out), b = dst (dst2p, in/out), c = omsk (tmp2p2).
+constexpr int LC_W = 256, LC_HALO = 40, LC_LW = LC_W + 2 * LC_HALO;   // |u| <= 34, +-1 for the triples, rounded to dwords
+
+__global__ __launch_bounds__(LC_W) void k_lattice_cand(P3 P, uint32_t *__restrict__ cand, int cand_pitch,
+                                                        int cand_plane_stride, int field, int nt4, int nt7, int nt8, int nt)
+{
+    // One workgroup = 256 consecutive pixels of one rebuilt row.  The five rows the search reads
+    // (dst y-1 / y+1, old direction map y-1 / y+1, new direction map y) are staged in LDS with the
+    // same flat addressing, so every data-dependent byte read below is an LDS read.
+    __shared__ __attribute__((aligned(16))) uint8_t s_rows[5][LC_LW];
+    const int pl = blockIdx.z;
+    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
+    const int x0 = blockIdx.x * LC_W;
+    const int x = x0 + threadIdx.x;
+    const int ri = blockIdx.y;
+    const int nrows = (height - (2 - field)) / 2;
+    if (x0 >= width || ri >= nrows) return;
+    const int y = (2 - field) + 2 * ri;
+    {
+        const uint8_t *g[5] = { P.b[pl] + (size_t)(y - 1) * pitch, P.b[pl] + (size_t)(y + 1) * pitch,
+                                P.c[pl] + (size_t)(y - 1) * pitch, P.c[pl] + (size_t)(y + 1) * pitch,
+                                P.a[pl] + (size_t)y * pitch };
+        for (int i = threadIdx.x; i < 5 * (LC_LW / 4); i += LC_W)
+        {
+            const int r = i / (LC_LW / 4), c4 = i - r * (LC_LW / 4);
+            reinterpret_cast<uint32_t *>(s_rows[r])[c4] =
+                reinterpret_cast<const uint32_t *>(g[r] + x0 - LC_HALO)[c4];
+        }
+    }
+    __syncthreads();
+    if (x >= width) return;
+    // row pointers indexed by the absolute column, as in the reference
+    const uint8_t *top = s_rows[0] + LC_HALO - x0, *bot = s_rows[1] + LC_HALO - x0;
+    const uint8_t *ot = s_rows[2] + LC_HALO - x0, *ob = s_rows[3] + LC_HALO - x0;
+    const uint8_t *dm = s_rows[4] + LC_HALO - x0;
+
+    cand[(size_t)pl * cand_plane_stride + (size_t)ri * cand_pitch + x] = lattice_px(top, bot, ot, ob, dm, x, width, pl, nt4, nt7, nt8, nt);
+}
+
+// k_lattice_cand with the searching pixels queued.  Only pixels that carry a direction (d != peak) go
+// through the variance / edge tests and the two searches - on real pictures roughly one in ten, but
+// nearly every wave holds some, and pays for all of it.  A workgroup takes 1024 pixels of a row:
+// every thread packs the word of its four pixels as if they were "always A" (vertical average, the
+// right-hand test) and queues those that are not; the queue then gets one lane per pixel.
+constexpr int LQ_W = 1024, LQ_LW = LQ_W + 2 * LC_HALO;
+
+__global__ __launch_bounds__(256) void k_lattice_cand_q(P3 P, uint32_t *__restrict__ cand, int cand_pitch,
+                                                        int cand_plane_stride, int field, int nt4, int nt7, int nt8, int nt)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_rows[5][LQ_LW];
+    __shared__ __attribute__((aligned(16))) uint32_t s_cand[LQ_W];
+    __shared__ uint16_t s_list[3][LQ_W];                          // one queue per stage
+    __shared__ int s_count[3];
+    const int pl = blockIdx.z;
+    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
+    const int x0 = blockIdx.x * LQ_W, t = threadIdx.x;
+    const int ri = blockIdx.y;
+    const int nrows = (height - (2 - field)) / 2;
+    if (x0 >= width || ri >= nrows) return;
+    const int y = (2 - field) + 2 * ri;
+    if (t < 3) s_count[t] = 0;
+    {
+        const uint8_t *g[5] = { P.b[pl] + (size_t)(y - 1) * pitch, P.b[pl] + (size_t)(y + 1) * pitch,
+                                P.c[pl] + (size_t)(y - 1) * pitch, P.c[pl] + (size_t)(y + 1) * pitch,
+                                P.a[pl] + (size_t)y * pitch };
+        // only as far right as the row's pixels (+ halo) reach
+        const int need4 = (min(LQ_W, hbhip_align_up_dev(width - x0, 4)) + 2 * LC_HALO) / 4;
+        for (int r = 0; r < 5; r++)
+            for (int c4 = t; c4 < need4; c4 += 256)
+                reinterpret_cast<uint32_t *>(s_rows[r])[c4] = reinterpret_cast<const uint32_t *>(g[r] + x0 - LC_HALO)[c4];
+    }
+    __syncthreads();
+    const uint8_t *top = s_rows[0] + LC_HALO - x0, *bot = s_rows[1] + LC_HALO - x0;
+    const uint8_t *ot = s_rows[2] + LC_HALO - x0, *ob = s_rows[3] + LC_HALO - x0;
+    const uint8_t *dm = s_rows[4] + LC_HALO - x0;
+    {
+        const int x = x0 + 4 * t;
+        if (x < width)
+        {
+            const uint32_t d4 = *reinterpret_cast<const uint32_t *>(dm + x), dn = dm[x + 4];
+            const uint32_t t4 = *reinterpret_cast<const uint32_t *>(top + x), b4 = *reinterpret_cast<const uint32_t *>(bot + x);
+            uint32_t w[4];
+            uint32_t queue = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                const int d = (d4 >> (8 * k)) & 0xff, dr = k < 3 ? (int)((d4 >> (8 * k + 8)) & 0xff) : (int)dn;
+                const int avg = (int)(((t4 >> (8 * k)) & 0xff) + ((b4 >> (8 * k)) & 0xff) + 1) >> 1;
+                const int lim = c_limlut[iabs(d - NEUTRAL) >> 2];
+                const bool right = iabs(d - dr) > lim;
+                const bool searching = d != PEAK && x + k < width;
+                w[k] = searching ? ((uint32_t)avg | ((uint32_t)right << 25))
+                                 : ((uint32_t)avg | ((uint32_t)avg << 8) | ((uint32_t)NEUTRAL << 16) | (1u << 24) | ((uint32_t)right << 25));
+                if (searching) queue |= 1u << k;
+            }
+            *reinterpret_cast<uint4 *>(&s_cand[4 * t]) = make_uint4(w[0], w[1], w[2], w[3]);
+            if (queue)
+            {
+                int at = atomicAdd(&s_count[0], __popc(queue));
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if ((queue >> k) & 1u) s_list[0][at++] = (uint16_t)(4 * t + k);
+            }
+        }
+    }
+    __syncthreads();
+    // a stage's lanes all run the same code: the tests, then the 5-step search, then the short search
+    for (int i = t, n = s_count[0]; i < n; i += 256)
+    {
+        const int lx = s_list[0][i];
+        const uint32_t w = lattice_stage_a(top, bot, dm, x0 + lx, width, s_cand[lx]);
+        if (w & LAT_MORE) s_list[1][atomicAdd(&s_count[1], 1)] = (uint16_t)lx;
+        else s_cand[lx] = w;
+    }
+    __syncthreads();
+    for (int i = t, n = s_count[1]; i < n; i += 256)
+    {
+        const int lx = s_list[1][i];
+        const uint32_t w = lattice_stage_b(top, bot, ot, ob, dm, x0 + lx, width, nt4, nt8, s_cand[lx]);
+        if (w & LAT_MORE) s_list[2][atomicAdd(&s_count[2], 1)] = (uint16_t)lx;
+        else s_cand[lx] = w;
+    }
+    __syncthreads();
+    for (int i = t, n = s_count[2]; i < n; i += 256)
+    {
+        const int lx = s_list[2][i];
+        s_cand[lx] = lattice_stage_c(top, bot, dm, x0 + lx, width, pl, nt7, nt, s_cand[lx]);
+    }
+    __syncthreads();
+    {
+        const int x = x0 + 4 * t;
+        uint32_t *o = cand + (size_t)pl * cand_plane_stride + (size_t)ri * cand_pitch + x;
+        if (x + 3 < width && (cand_pitch & 3) == 0) *reinterpret_cast<uint4 *>(o) = *reinterpret_cast<const uint4 *>(&s_cand[4 * t]);
+        else for (int k = 0; k < 4 && x + k < width; k++) o[k] = s_cand[4 * t + k];
+    }
 }
 
 // grid.y = processed rows (+1 for the border-row copy); one workgroup of LR_T threads per row, one
@@ -1938,8 +2229,12 @@ int Eedi2Engine::enqueue_passes(int tff, int sel, hbhip_ctx *lc)
     };
     static const bool one_px = getenv("HBHIP_EEDI2_1PX") != nullptr;                   // A/B switch: the one-pixel-per-thread forms
     auto dir_map = [&](const char *name, const EediFrame &f, const P3 &Pv, int step, int y0v, int expand) {
-        if (one_px) HBHIP_LAUNCH(lc, name, k_dir_map, grid_for(f, false), blk, 0, Pv, step, y0v, expand);
-        else        HBHIP_LAUNCH(lc, name, k_dir_map4, grid4_for(f, false), blk, 0, Pv, step, y0v, expand);
+        static const bool four_px = getenv("HBHIP_EEDI2_4PX") != nullptr;              // A/B switch: four pixels per thread, sort in place
+        if (one_px)       HBHIP_LAUNCH(lc, name, k_dir_map, grid_for(f, false), blk, 0, Pv, step, y0v, expand);
+        // the queueing form pays where few pixels reach the sort (expand: only peak pixels with >= 5 usable neighbours);
+        // filter_dir_map sorts at most masked pixels, there the in-place form is ahead
+        else if (four_px || !expand) HBHIP_LAUNCH(lc, name, k_dir_map4, grid4_for(f, false), blk, 0, Pv, step, y0v, expand);
+        else              HBHIP_LAUNCH(lc, name, k_dir_map_c, grid4_for(f, false), blk, 0, Pv, step, y0v, expand);
     };
     auto geom = [&](P3 &P, const EediFrame &f) {
         for (int c = 0; c < 3; c++) { P.pitch[c] = f.stride[c]; P.width[c] = f.width[c]; P.height[c] = f.height[c]; }
@@ -2006,8 +2301,12 @@ int Eedi2Engine::enqueue_passes(int tff, int sel, hbhip_ctx *lc)
     {
         const int nrows = (dst2p.height[0] - y0) / 2;
         const int nt = par_.noise_threshold;
-        HBHIP_LAUNCH(lc, "eedi2_lattice_candidates", k_lattice_cand, dim3((dst2p.width[0] + LC_W - 1) / LC_W, nrows, 3),
-                     dim3(LC_W), 0, P, cand_, cand_pitch_, cand_plane_stride_, tff, (nt * 4) & 0xff, (nt * 7) & 0xff, (nt * 8) & 0xff, nt);
+        if (one_px)
+            HBHIP_LAUNCH(lc, "eedi2_lattice_candidates", k_lattice_cand, dim3((dst2p.width[0] + LC_W - 1) / LC_W, nrows, 3),
+                         dim3(LC_W), 0, P, cand_, cand_pitch_, cand_plane_stride_, tff, (nt * 4) & 0xff, (nt * 7) & 0xff, (nt * 8) & 0xff, nt);
+        else
+            HBHIP_LAUNCH(lc, "eedi2_lattice_candidates", k_lattice_cand_q, dim3((dst2p.width[0] + LQ_W - 1) / LQ_W, nrows, 3),
+                         dim3(256), 0, P, cand_, cand_pitch_, cand_plane_stride_, tff, (nt * 4) & 0xff, (nt * 7) & 0xff, (nt * 8) & 0xff, nt);
         HBHIP_LAUNCH(lc, "eedi2_lattice_resolve", k_lattice_resolve, dim3(1, nrows + 1, 3), dim3(LR_T), 0, P,
                      (const uint32_t *)cand_, cand_pitch_, cand_plane_stride_, tff);
     }

@@ -1,0 +1,15 @@
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r02o; O=$GRAFT_REPO_ROOT/gpurun_out/r02o; R=$GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+cd /tmp
+PROF="python $R/bench.py --workload decomb_eedi2 --steps 4 --warmup 2 --no-cpu-baseline --no-pcie --no-kernel-timer"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- $PROF > $O/kt.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_SQ -o pmc -- $PROF > $O/pmc_SQ.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_SMEM --output-format csv -d $O/pmc_SQ2 -o pmc -- $PROF > $O/pmc_SQ2.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LEVEL_WAVES SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_SQ3 -o pmc -- $PROF > $O/pmc_SQ3.log 2>&1
+cd $R
+python tools/summarize_pmc.py $O $O/pmc_summary.json > /dev/null 2>&1
+find $O -name '*kernel_trace.csv' -size +3M -delete
+find $O -name '*counter_collection.csv' -size +3M -delete
+find $O -name '*.db' -delete
+tail -3 $O/pmc_SQ3.log
+du -sh $O
