@@ -15,6 +15,8 @@
 // frame = 4 (5) bytes per pixel algorithmic; vertical neighbours come from L2.
 #include "hbhip_internal.h"
 #include "eedi2_engine.h"
+#include <algorithm>
+#include <vector>
 
 namespace {
 
@@ -328,12 +330,16 @@ public:
     DecombFilter(hbhip_ctx *c, const hbhip_decomb_params &p) : hbhip_filter(c), par(p) {}
     ~DecombFilter() override
     {
-        if (side_ctx) (void)hipStreamSynchronize(side_ctx->stream);
+        for (hbhip_ctx *c : ring_ctx) (void)hipStreamSynchronize(c->stream);
+        ring_busy.clear();
+        for (DevPicture *p : late_unref) hbhip_pic_release(p);
+        late_unref.clear();
         delete eedi16;
-        delete eedi_side;
+        for (Eedi2Engine *e : ring) delete e;
         delete eedi;
+        if (ring_share.ev_mask) (void)hipEventDestroy(ring_share.ev_mask);
         if (ev_frame) (void)hipEventDestroy(ev_frame);
-        if (side_ctx) hbhip_ctx_destroy(side_ctx);
+        for (hbhip_ctx *c : ring_ctx) hbhip_ctx_destroy(c);
     }
 
     int setup(int width, int height, int depth, int lcw, int lch)
@@ -368,20 +374,38 @@ public:
             if (!eedi) return HBHIP_ERR_NOMEM;
             int rc = eedi->init();
             if (rc != HBHIP_OK) return rc;
-            // The two fields of a bob pair are two EEDI2 runs that only depend on each other through
-            // the edge mask (the first of ~22 kernels).  Each run is a chain of small dependent
-            // launches that leaves most of the GPU idle, so the second field runs on an engine of its
-            // own (own scratch frames, own HIP stream) next to the first.  Not with post-processing
+            // EEDI2 runs only depend on each other through the edge mask (the first of ~17 kernels).  Each run is a
+            // chain of dependent launches, most of them too short to fill the GPU and each followed by a drain, so
+            // consecutive runs (the two fields of a bob pair, then the next frame's) go round a ring of engines, each
+            // with scratch frames and a HIP stream of its own, and overlap.  The blend that consumes a run's result
+            // is launched on the same stream; the filter's stream joins the ring when the batch is complete (kick /
+            // flush), or at the end of each call when it is driven one frame at a time.  Not with post-processing
             // 2/3, whose derivative arrays carry values from run to run (eedi2.hip, CornerArgs).
-            if ((par.mode & M_BOB) && par.post_processing < 2 && getenv("HBHIP_EEDI2_SERIAL") == nullptr)
+            int n_ring = 4;
+            if (const char *e = getenv("HBHIP_EEDI2_ENGINES")) n_ring = atoi(e);
+            if (getenv("HBHIP_EEDI2_SERIAL")) n_ring = 0;
+            n_ring = std::min(n_ring, EEDI_MAX_RING);
+            if (n_ring >= 2 && par.post_processing < 2)
             {
-                if (hbhip_ctx_create(ctx->device, &side_ctx) != HBHIP_OK) { side_ctx = nullptr; return HBHIP_OK; }
-                eedi_side = new (std::nothrow) Eedi2Engine(side_ctx, in_geo, ep, ctx, eedi->share());
-                if (!eedi_side || eedi_side->init() != HBHIP_OK ||
-                    hipEventCreateWithFlags(&ev_frame, hipEventDisableTiming) != hipSuccess)
+                bool ok = hipEventCreateWithFlags(&ev_frame, hipEventDisableTiming) == hipSuccess &&
+                          hipEventCreateWithFlags(&ring_share.ev_mask, hipEventDisableTiming) == hipSuccess;
+                for (int i = 0; ok && i < n_ring; i++)
                 {
-                    delete eedi_side;
-                    eedi_side = nullptr;
+                    hbhip_ctx *sc = nullptr;
+                    if (hbhip_ctx_create(ctx->device, &sc) != HBHIP_OK) { ok = false; break; }
+                    ring_ctx.push_back(sc);
+                    Eedi2Engine *e = new (std::nothrow) Eedi2Engine(sc, in_geo, ep, ctx, &ring_share, i);
+                    if (!e) { ok = false; break; }
+                    ring.push_back(e);
+                    ok = e->init() == HBHIP_OK;
+                }
+                // the first run reads "the previous mask" from the last engine's buffer: zeros, like the reference's
+                ring_share.sel = n_ring - 1;
+                if (!ok)
+                {
+                    for (Eedi2Engine *e : ring) delete e;
+                    ring.clear();
+                    (void)hipGetLastError();
                 }
             }
         }
@@ -406,20 +430,28 @@ public:
             return HBHIP_OK;                   // HB_FILTER_DELAY
         }
         store_ref(pic);
-        return process_frame();
+        const int rc = process_frame();
+        if (rc != HBHIP_OK || !deferred) join_ring();
+        return rc;
     }
 
     int flush() override
     {
+        int rc = HBHIP_OK;
         if (ref[2] != nullptr && !flushed)
         {
             store_ref(ref[2]);                 // duplicate the last frame (decomb.c:584-589)
             flushed = true;
             if (ff_bwdif) bw_field = BW_BACK_END;          // ff_yadif_request_frame at EOF
-            return process_frame();
+            rc = process_frame();
         }
-        return HBHIP_OK;
+        join_ring();
+        return rc;
     }
+
+    // fused chain: the whole batch is submitted before anything downstream looks at the outputs
+    void defer_launches(bool on) override { deferred = on; if (!on) join_ring(); }
+    int  kick() override { join_ring(); return HBHIP_OK; }
 
     int pending() override { return (int)outq.size(); }
     DevPicture *pop_output() override
@@ -437,7 +469,18 @@ public:
 private:
     void unref(DevPicture *p)
     {
-        if (p && --p->refs == 0) hbhip_pic_release(p);     // possibly another filter's picture (fused chain)
+        if (!p || --p->refs != 0) return;
+        // a blend on a ring engine's stream may still be reading it: hand it back when the ring has been joined
+        if (!ring_busy.empty()) late_unref.push_back(p);
+        else hbhip_pic_release(p);                         // possibly another filter's picture (fused chain)
+    }
+    // make the filter's stream wait for everything the ring engines have been given
+    void join_ring()
+    {
+        for (Eedi2Engine *e : ring_busy) (void)e->join();
+        ring_busy.clear();
+        for (DevPicture *p : late_unref) hbhip_pic_release(p);
+        late_unref.clear();
     }
     void store_ref(DevPicture *p)              // decomb.c:195-200
     {
@@ -448,9 +491,10 @@ private:
         p->refs++;
     }
 
-    int launch(DevPicture *dst, int mode, int parity, int tff, Eedi2Engine *guess_from = nullptr)
+    int launch(DevPicture *dst, int mode, int parity, int tff, Eedi2Engine *guess_from = nullptr, hbhip_ctx *lc = nullptr)
     {
         if (!guess_from) guess_from = eedi;
+        if (!lc) lc = ctx;                 // the stream the blend goes to: the filter's, or the ring engine's that made the guess
         DecombArgs a;
         for (int c = 0; c < 3; c++)
         {
@@ -493,9 +537,9 @@ private:
             HBHIP_CHECK(ctx, hipGetLastError());
             return HBHIP_OK;
         }
-        if (in_geo.bps == 2) HBHIP_LAUNCH(ctx, "decomb_plane", decomb_plane_kernel<uint16_t>, grid, block, 0, a, maxv);
-        else                 HBHIP_LAUNCH(ctx, "decomb_plane", decomb_plane_kernel<uint8_t>, grid, block, 0, a, maxv);
-        HBHIP_CHECK(ctx, hipGetLastError());
+        if (in_geo.bps == 2) HBHIP_LAUNCH(lc, "decomb_plane", decomb_plane_kernel<uint16_t>, grid, block, 0, a, maxv);
+        else                 HBHIP_LAUNCH(lc, "decomb_plane", decomb_plane_kernel<uint8_t>, grid, block, 0, a, maxv);
+        HBHIP_CHECK(lc, hipGetLastError());
         return HBHIP_OK;
     }
 
@@ -529,32 +573,33 @@ private:
         else if (is_combed != 0)                    mode = par.mode & ~M_SELECTIVE;
 
         const int nframes = (par.mode & M_BOB) ? 2 : 1;
-        // two engines: both EEDI2 runs are enqueued first (the second one on its own stream, behind an
-        // event that marks `cur` complete and the previous frame's outputs launched), then the outputs
-        const bool paired = (mode & M_EEDI2) && eedi && eedi_side && nframes == 2 && !ctx->profile;
-        if (paired)
-        {
-            HBHIP_CHECK(ctx, hipEventRecord(ev_frame, ctx->stream));
-            for (int frame = 0; frame < 2; frame++)
-            {
-                const int parity = frame ^ tff ^ 1;
-                Eedi2Engine *e = frame ? eedi_side : eedi;
-                int rc = e->run(cur, !parity, frame ? ev_frame : nullptr);       // pv->tff = !parity (decomb.c:542)
-                if (rc != HBHIP_OK) return rc;
-            }
-        }
+        // ring of engines: each field's run and the blend that consumes it go to the next engine's stream, behind an
+        // event that marks `cur` (and everything else launched so far) complete on the filter's stream
+        const bool ringed = (mode & M_EEDI2) && eedi && !ring.empty() && !ctx->profile;
+        if (ringed) HBHIP_CHECK(ctx, hipEventRecord(ev_frame, ctx->stream));
         for (int frame = 0; frame < nframes; frame++)
         {
             const int parity = frame ^ tff ^ 1;
-            Eedi2Engine *e = (paired && frame) ? eedi_side : eedi;
+            Eedi2Engine *e = eedi;
+            hbhip_ctx *lc = ctx;
             if ((mode & M_EEDI2) && eedi16)
             {
                 int rc = eedi16->run(cur, !parity);                              // pv->tff = !parity (decomb.c:542)
                 if (rc != HBHIP_OK) return rc;
             }
+            else if (ringed)
+            {
+                e = ring[ring_next];
+                ring_next = (ring_next + 1) % ring.size();
+                lc = e->stream_ctx();
+                if (std::find(ring_busy.begin(), ring_busy.end(), e) == ring_busy.end()) ring_busy.push_back(e);
+                int rc = e->run(cur, !parity, ev_frame);
+                if (rc != HBHIP_OK) return rc;
+                last_engine = e;
+            }
             else if ((mode & M_EEDI2) && eedi)
             {
-                int rc = paired ? e->join() : e->run(cur, !parity);
+                int rc = e->run(cur, !parity);
                 if (rc != HBHIP_OK) return rc;
                 last_engine = e;
             }
@@ -562,8 +607,11 @@ private:
             if (!o) return HBHIP_ERR_NOMEM;
             o->tag = (cur->tag << 1) | frame; o->aux = frame;
             bw_second = frame == 1;
-            int rc = launch(o, mode, parity, tff, e);
+            // a recycled picture may still be read by whoever had it last
+            if (lc != ctx && o->idle_valid) HBHIP_CHECK(lc, hipStreamWaitEvent(lc->stream, o->idle, 0));
+            int rc = launch(o, mode, parity, tff, e, lc);
             if (rc != HBHIP_OK) return rc;
+            if (lc != ctx) { rc = e->mark_done(); if (rc != HBHIP_OK) return rc; }
             outq.push_back(o);
         }
         return HBHIP_OK;
@@ -581,13 +629,18 @@ private:
     PicturePool pool;
     DevPicture *ref[3] = {nullptr, nullptr, nullptr};
     std::deque<DevPicture *> outq;
-    Eedi2Engine *eedi = nullptr;
-    Eedi2Engine *eedi_side = nullptr;      // second field of a bob pair, on side_ctx's stream
+    Eedi2Engine *eedi = nullptr;           // runs on the filter's stream (serial use, per-kernel profiling)
+    std::vector<Eedi2Engine *> ring;       // engines with streams of their own, used in turn
+    std::vector<hbhip_ctx *> ring_ctx;
+    std::vector<Eedi2Engine *> ring_busy;  // engines given work since the last join
+    std::vector<DevPicture *> late_unref;  // input pictures whose last reference went while the ring was busy
+    EediMaskShare ring_share;
+    size_t ring_next = 0;
+    bool deferred = false;
 public:
     Eedi2Engine16 *eedi16 = nullptr;       // 10 / 12-bit samples
 private:
     Eedi2Engine *last_engine = nullptr;
-    hbhip_ctx   *side_ctx = nullptr;
     hipEvent_t   ev_frame = nullptr;
     bool ready = false, flushed = false;
 };

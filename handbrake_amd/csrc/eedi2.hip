@@ -2008,12 +2008,14 @@ __global__ void k_post_corner(CornerArgs A, const uint8_t *msk, uint8_t *dst, in
 } // namespace
 
 // ------------------------------------------------------------------- engine
-Eedi2Engine::Eedi2Engine(hbhip_ctx *ctx, const PicGeometry &geo, const Eedi2Params &p, hbhip_ctx *main, EediMaskShare *share)
+Eedi2Engine::Eedi2Engine(hbhip_ctx *ctx, const PicGeometry &geo, const Eedi2Params &p, hbhip_ctx *main, EediMaskShare *share,
+                         int ring_index)
     : ctx_(ctx), geo_(geo), par_(p)
 {
     use_graph_ = getenv("HBHIP_NO_GRAPH") == nullptr;
     main_ = main ? main : ctx;
     share_ = share ? share : &own_share_;
+    ring_index_ = share ? ring_index : -1;
 }
 
 Eedi2Engine::~Eedi2Engine()
@@ -2079,6 +2081,7 @@ int Eedi2Engine::init()
         own_share_.sel = 0;
         HBHIP_CHECK(ctx_, hipEventCreateWithFlags(&own_share_.ev_mask, hipEventDisableTiming));
     }
+    if (ring_index_ >= 0) share_->mask[ring_index_] = half_[1];   // this engine's MSKPF is its buffer of the ring
     if (main_ != ctx_) HBHIP_CHECK(ctx_, hipEventCreateWithFlags(&ev_done_, hipEventDisableTiming));
     // work list of calc_directions (every half-height pixel could qualify) + lattice candidates
     size_t half_px = 0;
@@ -2133,11 +2136,12 @@ int Eedi2Engine::run(const DevPicture *cur, int tff, hipEvent_t wait_for)
     // The mask passes read the previous run's mask (possibly made on the other engine's stream) and
     // write the other buffer; an event behind them lets the next run's mask passes start while the
     // rest of this run is still going.
-    const int sel = share_->sel ^ 1;               // the new mask goes to the other buffer
+    const int old = share_->sel;
+    const int sel = ring_index_ >= 0 ? ring_index_ : (old ^ 1);     // the new mask goes to another buffer
     share_->sel = sel;
     if (share_->ev_valid) HBHIP_CHECK(ctx_, hipStreamWaitEvent(ctx_->stream, share_->ev_mask, 0));
     {
-        const int rc = enqueue_mask(sel);
+        const int rc = enqueue_mask(sel, old);
         if (rc != HBHIP_OK) return rc;
     }
     HBHIP_CHECK(ctx_, hipEventRecord(share_->ev_mask, ctx_->stream));
@@ -2151,7 +2155,7 @@ int Eedi2Engine::run(const DevPicture *cur, int tff, hipEvent_t wait_for)
     if (ctx_->profile || !use_graph_) rc = enqueue_passes(tff, sel, ctx_);
     else
     {
-        hipGraphExec_t &exec = graph_[tff ? 1 : 0][sel];
+        hipGraphExec_t &exec = graph_[tff ? 1 : 0][ring_index_ >= 0 ? 0 : sel];
         if (!exec)
         {
             hipGraph_t g = nullptr;
@@ -2178,6 +2182,12 @@ int Eedi2Engine::run(const DevPicture *cur, int tff, hipEvent_t wait_for)
     return HBHIP_OK;
 }
 
+int Eedi2Engine::mark_done()
+{
+    if (ev_done_) HBHIP_CHECK(ctx_, hipEventRecord(ev_done_, ctx_->stream));
+    return HBHIP_OK;
+}
+
 int Eedi2Engine::join()
 {
     if (ev_done_) HBHIP_CHECK(main_, hipStreamWaitEvent(main_->stream, ev_done_, 0));
@@ -2186,9 +2196,9 @@ int Eedi2Engine::join()
 
 // The pass sequence of eedi2_interpolate_plane (decomb_template.c:366-441) for the 3 planes, from
 // the edge mask to the post-processing, on the engine's scratch frames.
-int Eedi2Engine::enqueue_mask(int sel)
+int Eedi2Engine::enqueue_mask(int sel, int old)
 {
-    EediFrame &srcp = half_[0], &mskp = share_->mask[sel], &mskp_old = share_->mask[sel ^ 1];
+    EediFrame &srcp = half_[0], &mskp = share_->mask[sel], &mskp_old = share_->mask[old];
     P3 P;
     memset(&P, 0, sizeof(P));
     for (int c = 0; c < 3; c++)

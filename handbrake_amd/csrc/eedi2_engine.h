@@ -28,11 +28,14 @@ struct EediFrame
 };
 
 // The edge mask is the one piece of EEDI2 state that runs depend on (the lower half of MSKPF keeps
-// the previous run's mask, eedi2_template.c:132).  When the two fields of a bob pair run on two
-// engines (two HIP streams), both work on the same pair of mask buffers, in run order.
+// the previous run's mask, eedi2_template.c:132).  When consecutive runs go to different engines
+// (different HIP streams), they all work on one set of mask buffers, in run order: a lone engine
+// alternates between two, an engine of a ring always writes its own (mask[i] = its MSKPF frame) and
+// reads the one the previous run wrote.
+constexpr int EEDI_MAX_RING = 8;
 struct EediMaskShare
 {
-    EediFrame  mask[2];
+    EediFrame  mask[EEDI_MAX_RING];
     int        sel = 0;               // which one holds the current mask
     hipEvent_t ev_mask = nullptr;     // recorded behind every mask kernel: the next run's mask kernel waits for it
     bool       ev_valid = false;
@@ -42,9 +45,9 @@ class Eedi2Engine
 {
 public:
     // main: the filter's context when this engine executes on a context (stream) of its own;
-    // share: the first engine's mask state when this is the second engine of a pair
+    // share + ring_index: the ring's mask state and this engine's place in it (see EediMaskShare)
     Eedi2Engine(hbhip_ctx *ctx, const PicGeometry &geo, const Eedi2Params &p,
-                hbhip_ctx *main = nullptr, EediMaskShare *share = nullptr);
+                hbhip_ctx *main = nullptr, EediMaskShare *share = nullptr, int ring_index = -1);
     ~Eedi2Engine();
     int  init();                                   // allocate the 9 scratch frames (zeroed once)
     // eedi2_planer (decomb_template.c:455-473): field extraction + the pass
@@ -52,7 +55,9 @@ public:
     // wait_for: an event of the main stream behind which `cur` is complete and this engine's previous
     // result has been consumed (side engines only; the main-stream engine is ordered by its stream)
     int  run(const DevPicture *cur, int tff, hipEvent_t wait_for = nullptr);
+    int  mark_done();                              // side engine: whatever was launched on its stream so far belongs to the run
     int  join();                                   // side engine: make the main stream wait for the last run
+    hbhip_ctx *stream_ctx() { return ctx_; }       // the context (stream) the engine launches on
     EediMaskShare *share() { return share_; }
     const EediFrame &result() const { return full_[0]; }   // eedi_full[DST2PF]
     // MSKPF alternates between two buffers (the fused mask kernel reads the previous field's mask
@@ -62,11 +67,12 @@ public:
 
 private:
     int alloc_frame(EediFrame &f, int width, int height);
-    int enqueue_mask(int sel);                     // the five mask passes; sel = mask buffer to write
+    int enqueue_mask(int sel, int old);            // the five mask passes; sel = mask buffer to write, old = the previous run's
     int enqueue_passes(int tff, int sel, hbhip_ctx *lc);   // everything after them, launched on lc's stream
     hipGraphExec_t graph_[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // captured pass sequence per (field parity, mask buffer)
     EediMaskShare  own_share_;                     // the two MSKPF buffers (mask[0] is half_[1]) when not shared
     EediMaskShare *share_ = nullptr;
+    int         ring_index_ = -1;                  // >= 0: engine of a ring, writes share_->mask[ring_index_]
     hbhip_ctx  *main_ = nullptr;                   // != ctx_ for a side engine
     hbhip_ctx  *cap_ctx_ = nullptr;                // private stream the pass sequence is captured on
     hipEvent_t  ev_done_ = nullptr;
