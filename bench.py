@@ -373,17 +373,28 @@ def run_chain(args, world, rank, local_rank):
                 torch.empty((h // 2, w // 2), dtype=torch.uint8, device="cuda")]
 
     class Lane:
-        """One independent stream: its own context (HIP stream), filter instances, chain and output frames."""
-        def __init__(self):
+        """One independent stream of frames: its own contexts, filter instances, chain and output frames.
+        split: every stage on a context (HIP stream) of its own - one stream per filter, as libhb runs one
+        thread per filter - so the chain overlaps the stages of consecutive batches."""
+        def __init__(self, split):
             self.ctx = hip.Ctx(local_rank)
-            self.decomb = hip.DecombDevice(self.ctx, W, H, mode=63 if args.comb_detect else 31)
+            self.ctxs = [self.ctx]
+
+            def stage_ctx():
+                if not split:
+                    return self.ctx
+                self.ctxs.append(hip.Ctx(local_rank))
+                return self.ctxs[-1]
+
+            c = stage_ctx()
+            self.decomb = hip.DecombDevice(c, W, H, mode=63 if args.comb_detect else 31)
             self.comb = hip.CombDetectDevice(self.ctx, W, H) if args.comb_detect else None
-            stages = [hip.DeviceFilter(self.ctx, self.decomb.h)]
+            stages = [hip.DeviceFilter(c, self.decomb.h)]
             if not only_decomb:
-                stages.append(hip.nlmeans_device_filter(self.ctx, hip.NLMEANS_MEDIUM, W, H, batch=1))
+                stages.append(hip.nlmeans_device_filter(stage_ctx(), hip.NLMEANS_MEDIUM, W, H, batch=1))
                 if scale:
-                    stages.append(hip.cropscale_device_filter(self.ctx, W, H, OW, OH))
-                stages.append(hip.lapsharp_device_filter(self.ctx, OW, OH))
+                    stages.append(hip.cropscale_device_filter(stage_ctx(), W, H, OW, OH))
+                stages.append(hip.lapsharp_device_filter(stage_ctx(), OW, OH))
             self.decomb.h = None                              # owned by the chain from here on
             self.chain = hip.Chain(self.ctx, stages)
             self.cap = 2 * B + 4
@@ -407,18 +418,22 @@ def run_chain(args, world, rank, local_rank):
             self.produced += self.chain.process_dev(in_arr, self.out_arr, tag0=self.fed, flags=flags, combed=combed)
             self.fed += B
 
+        def sync(self):
+            self.chain.sync()
+
         def close(self):
             self.chain.close()
             if self.comb:
                 self.comb.close()
-            self.ctx.close()
+            for c in reversed(self.ctxs):
+                c.close()
 
-    lanes = [Lane() for _ in range(max(1, args.streams))]
+    lanes = [Lane(args.stage_streams) for _ in range(max(1, args.streams))]
     ctx = lanes[0].ctx
 
     def sync_all():
         for ln in lanes:
-            ln.ctx.sync()
+            ln.sync()
         torch.cuda.synchronize()
 
     def fence():
@@ -436,6 +451,7 @@ def run_chain(args, world, rank, local_rank):
     for _ in range(args.steps):
         for ln in lanes:
             ln.step()
+    t_enq = time.perf_counter() - t0                     # host time to enqueue the timed steps (nothing waited for yet)
     sync_all()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -447,13 +463,19 @@ def run_chain(args, world, rank, local_rank):
     # per-kernel launch times: same launches, bracketed by HIP events on their stream, right after the timed region
     stats = {}
     if not args.no_kernel_timer:
-        ctx.profile(True)
-        ctx.profile_reset()
+        # on one stream (a lane of its own, all stages on one context) so that every launch is timed alone
+        pl = Lane(False)
         for _ in range(2):
-            lanes[0].step()
-        ctx.sync()
-        stats = ctx.profile_stats()
-        ctx.profile(False)
+            pl.step()
+        pl.sync()
+        pl.ctx.profile(True)
+        pl.ctx.profile_reset()
+        for _ in range(2):
+            pl.step()
+        pl.ctx.sync()
+        stats = pl.ctx.profile_stats()
+        pl.ctx.profile(False)
+        pl.close()
 
     if rank == 0:
         top = sorted(stats.items(), key=lambda kv: -kv[1][1])
@@ -492,8 +514,10 @@ def run_chain(args, world, rank, local_rank):
             "config": {"workload": wl["text"] + (" + comb detect in front (selective decomb, mode 63)" if args.comb_detect else ""),
                        "input_frames_per_step": B * len(lanes), "output_frames_per_step": 2 * B * len(lanes),
                        "input": f"{W}x{H}", "output": f"{OW}x{OH}", "streams_per_gpu": len(lanes),
+                       "stage_streams": bool(args.stage_streams),
                        "parallelism": f"{world} GPU(s) x {len(lanes)} independent stream(s)", "device": ctx.name()},
             "input_fps": round(frames_total / dt_max / 2, 2),
+            "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4),
             "chain_hbm_GBps_algorithmic": round(per_out * frames_total / dt_max / 1e9, 2),
             "chain_frac_of_hbm_peak": round(per_out * frames_total / dt_max / 1e9 / HBM_PEAK_GBS, 5),
             "roofline": roof, "kernels": kernels,
@@ -528,6 +552,10 @@ def main():
                          "as BASELINE configs[2] words it")
     ap.add_argument("--no-kernel-timer", action="store_true",
                     help="chain workloads: skip the event-bracketed pass after the timed region (roofline = null)")
+    ap.add_argument("--stage-streams", type=int, default=0,
+                    help="chain workloads: 1 = every filter of the chain on a HIP stream of its own (libhb: one thread per "
+                         "filter), 0 = the whole chain on one stream (default; measured equal - the EEDI2 engine ring "
+                         "already keeps the GPU full)")
     ap.add_argument("--streams", type=int, default=1,
                     help="chain workloads: independent streams (own HIP stream and filter instances) per GPU")
     ap.add_argument("--workload", default="chain", choices=sorted(WORKLOADS),

@@ -12,8 +12,18 @@
 // The last stage writes straight into the caller's output frames when it can (stateless filters);
 // the first stage gets the caller's frames through one 3-plane copy launch (stateful filters keep
 // input pictures beyond the call, the caller's frames are only borrowed for its duration).
+//
+// Stages may live on contexts (HIP streams) of their own - the counterpart of libhb's one thread per
+// filter: the chain then orders stage k+1 behind stage k with an event per hand-over, nothing else,
+// so while the last stages work on one batch the first ones already run the next.  Pictures find
+// their way back across streams through their `idle` event (PicturePool).  The caller's input frames
+// must be complete in the chain context's stream order; the output frames are complete once
+// hbhip_chain_sync() returns (or the last stage's context has been synchronized).
 #include "hbhip_internal.h"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <deque>
 #include <new>
 #include <vector>
@@ -61,6 +71,19 @@ struct hbhip_chain
     hbhip_ctx *ctx = nullptr;
     std::vector<hbhip_filter *> st;
     std::deque<DevPicture *> held;          // finished pictures the caller had no room for yet
+    std::vector<hipEvent_t> ev;             // ev[s]: stage s has been given everything of the current batch; ev[n]: the caller's inputs
+    bool split = false;                     // stages on more than one context
+    std::vector<double> host_ms;            // HBHIP_CHAIN_TIMING: host time spent per stage (+ copy-in at the end)
+    bool timing = getenv("HBHIP_CHAIN_TIMING") != nullptr;
+
+    // make `to`'s stream wait for what `from`'s stream holds right now
+    int order(hbhip_ctx *from, hbhip_ctx *to, hipEvent_t e)
+    {
+        if (from == to) return HBHIP_OK;
+        HBHIP_CHECK(ctx, hipEventRecord(e, from->stream));
+        HBHIP_CHECK(ctx, hipStreamWaitEvent(to->stream, e, 0));
+        return HBHIP_OK;
+    }
 
     int copy_in(DevPicture *dst, const hbhip_dev_frame *src)
     {
@@ -73,7 +96,7 @@ struct hbhip_chain
             a.dst[c] = dst->plane[c];                  a.dpitch[c] = dst->pitch[c];
             a.row_bytes[c] = vis; a.rows[c] = dst->height[c];
         }
-        return copy3(ctx, a);
+        return copy3(st.front()->ctx, a);
     }
     int copy_out(const hbhip_dev_frame *dst, const DevPicture *src)
     {
@@ -86,7 +109,7 @@ struct hbhip_chain
             a.dst[c] = (uint8_t *)dst->plane[c]; a.dpitch[c] = dst->stride[c];
             a.row_bytes[c] = vis; a.rows[c] = src->height[c];
         }
-        return copy3(ctx, a);
+        return copy3(st.back()->ctx, a);
     }
 
     // Deliver held / freshly finished pictures into the caller's frames.
@@ -115,6 +138,10 @@ struct hbhip_chain
 
         std::vector<DevPicture *> cur, next;
         hbhip_filter *first = st.front();
+        auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        if (timing && host_ms.empty()) host_ms.assign(st.size() + 1, 0.0);
+        double t_mark = timing ? now() : 0.0;
+        if (n_in > 0) { rc = order(ctx, first->ctx, ev[st.size()]); if (rc != HBHIP_OK) return rc; }
         for (int i = 0; i < n_in; i++)
         {
             DevPicture *p = first->acquire_input();
@@ -134,6 +161,7 @@ struct hbhip_chain
             }
             cur.push_back(p);
         }
+        if (timing) { const double t = now(); host_ms[st.size()] += t - t_mark; t_mark = t; }
         for (size_t s = 0; s < st.size(); s++)
         {
             hbhip_filter *f = st[s];
@@ -165,6 +193,8 @@ struct hbhip_chain
                 {
                     for (int c = 0; c < 3; c++) f->in_stride[c] = cur[0]->pitch[c];
                     f->in_is_dev = true;
+                    rc = order(st[s - 1]->ctx, f->ctx, ev[s - 1]);        // the pictures of `cur` are complete on the previous stage's stream
+                    if (rc != HBHIP_OK) return rc;
                 }
                 if (direct && tags) for (size_t i = 0; i < cur.size(); i++) tags[produced + i] = cur[i]->tag;
                 rc = f->submit_many(cur.data(), (int)cur.size(), direct ? views.data() : nullptr);
@@ -182,6 +212,7 @@ struct hbhip_chain
                 next.push_back(o);
             }
             cur.swap(next);
+            if (timing) { const double t = now(); host_ms[s] += t - t_mark; t_mark = t; }
         }
         for (DevPicture *p : cur) held.push_back(p);
         rc = deliver(out, tags, cap, produced);
@@ -199,7 +230,7 @@ int hbhip_chain_create(hbhip_ctx *ctx, hbhip_filter *const *stages, int n_stages
     *out = nullptr;
     for (int i = 0; i < n_stages; i++)
     {
-        if (!stages[i] || stages[i]->ctx != ctx) return HBHIP_ERR_ARG;
+        if (!stages[i] || !stages[i]->ctx || stages[i]->ctx->device != ctx->device) return HBHIP_ERR_ARG;
         if (i > 0)
         {
             const PicGeometry &a = stages[i - 1]->out_geo, &b = stages[i]->in_geo;
@@ -212,7 +243,19 @@ int hbhip_chain_create(hbhip_ctx *ctx, hbhip_filter *const *stages, int n_stages
     if (!c) return HBHIP_ERR_NOMEM;
     c->ctx = ctx;
     c->st.assign(stages, stages + n_stages);
-    for (hbhip_filter *f : c->st) f->defer_launches(true);
+    (void)hipSetDevice(ctx->device);
+    for (int i = 0; i <= n_stages; i++)
+    {
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess)
+        {
+            for (hipEvent_t x : c->ev) (void)hipEventDestroy(x);
+            delete c;
+            return HBHIP_ERR_NOMEM;
+        }
+        c->ev.push_back(e);
+    }
+    for (hbhip_filter *f : c->st) { f->defer_launches(true); c->split |= f->ctx != ctx; }
     *out = c;
     return HBHIP_OK;
 }
@@ -238,13 +281,30 @@ int hbhip_chain_pending(hbhip_chain *c)
     return c ? (int)c->held.size() : 0;
 }
 
+int hbhip_chain_sync(hbhip_chain *c)
+{
+    if (!c) return HBHIP_ERR_ARG;
+    (void)hipSetDevice(c->ctx->device);
+    HBHIP_CHECK(c->ctx, hipStreamSynchronize(c->ctx->stream));
+    for (hbhip_filter *f : c->st)
+        if (f->ctx != c->ctx) HBHIP_CHECK(c->ctx, hipStreamSynchronize(f->ctx->stream));
+    return HBHIP_OK;
+}
+
 void hbhip_chain_destroy(hbhip_chain *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->ctx->device);
-    (void)hipStreamSynchronize(c->ctx->stream);
+    (void)hbhip_chain_sync(c);
     for (DevPicture *p : c->held) c->st.back()->recycle_output(p);
     for (hbhip_filter *f : c->st) f->defer_launches(false);
+    for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    if (c->timing && !c->host_ms.empty())
+    {
+        fprintf(stderr, "hbhip_chain host ms: copy-in %.2f", c->host_ms.back());
+        for (size_t i = 0; i + 1 < c->host_ms.size(); i++) fprintf(stderr, ", stage %zu %.2f", i, c->host_ms[i]);
+        fprintf(stderr, "\n");
+    }
     delete c;
 }
 

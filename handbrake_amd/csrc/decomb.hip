@@ -332,7 +332,7 @@ public:
     {
         for (hbhip_ctx *c : ring_ctx) (void)hipStreamSynchronize(c->stream);
         ring_busy.clear();
-        for (DevPicture *p : late_unref) hbhip_pic_release(p);
+        for (DevPicture *p : late_unref) hbhip_pic_release(p, ctx);
         late_unref.clear();
         delete eedi16;
         for (Eedi2Engine *e : ring) delete e;
@@ -472,14 +472,14 @@ private:
         if (!p || --p->refs != 0) return;
         // a blend on a ring engine's stream may still be reading it: hand it back when the ring has been joined
         if (!ring_busy.empty()) late_unref.push_back(p);
-        else hbhip_pic_release(p);                         // possibly another filter's picture (fused chain)
+        else hbhip_pic_release(p, ctx);                    // possibly another filter's picture (fused chain)
     }
     // make the filter's stream wait for everything the ring engines have been given
     void join_ring()
     {
         for (Eedi2Engine *e : ring_busy) (void)e->join();
         ring_busy.clear();
-        for (DevPicture *p : late_unref) hbhip_pic_release(p);
+        for (DevPicture *p : late_unref) hbhip_pic_release(p, ctx);
         late_unref.clear();
     }
     void store_ref(DevPicture *p)              // decomb.c:195-200

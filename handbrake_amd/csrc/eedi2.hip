@@ -866,6 +866,154 @@ __global__ __launch_bounds__(CD_W) void k_calc_dir_tile2(P3 P, int maxd, int nt1
     P.c[pl][(size_t)y * pitch + px] = (uint8_t)out;
 }
 
+// calc_directions, third form: k_calc_dir_tile2 with the search loop walking only the steps that pass the mask test
+// (see the bit sets below).  maxd <= 31 (the set is one 64-bit word).
+__global__ __launch_bounds__(CD_W) void k_calc_dir_tile3(P3 P, int maxd, int nt13, int nt19)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_band[8][CD_LW];   // rows 0..4 source y-2..y+2, 5..7 mask y-1..y+1
+    __shared__ uint32_t s_tri[5][CD_LW];                                  // [r][i] = bytes i..i+2 of source row r (+ flags in row 2)
+    __shared__ uint16_t s_list[CD_W];
+    __shared__ uint64_t s_bp[8], s_bm[8];                                 // bit i: a mask peak among columns i..i+2 of the row above / below
+    __shared__ int s_count;
+    const int pl = blockIdx.z;
+    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
+    const int x0 = blockIdx.x * CD_W, y = blockIdx.y;
+    if (y >= height || x0 >= pitch) return;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_count = 0;
+    {
+        const uint8_t *sb = P.b[pl] + (ptrdiff_t)(y - 2) * pitch + x0 - CD_HALO;
+        const uint8_t *mb = P.a[pl] + (ptrdiff_t)(y - 1) * pitch + x0 - CD_HALO;
+        for (int i = tid; i < 8 * (CD_LW / 4); i += CD_W)
+        {
+            const int r = i / (CD_LW / 4), c4 = i - r * (CD_LW / 4);
+            const uint8_t *src = r < 5 ? sb + (ptrdiff_t)r * pitch : mb + (ptrdiff_t)(r - 5) * pitch;
+            reinterpret_cast<uint32_t *>(s_band[r])[c4] = reinterpret_cast<const uint32_t *>(src)[c4];
+        }
+    }
+    __syncthreads();
+    const int x = x0 + tid, c = tid + CD_HALO;
+    bool active = false;
+    if (x < pitch)
+    {
+        if (x >= 1 && x < width - 1 && y >= 1 && y < height - 1)
+            active = s_band[6][c] == PEAK && (s_band[6][c - 1] == PEAK || s_band[6][c + 1] == PEAK);
+        if (!active) P.c[pl][(size_t)y * pitch + x] = 255;        // memset(dstp, 255, pitch*height)
+    }
+    if (active) s_list[atomicAdd(&s_count, 1)] = (uint16_t)tid;
+    __syncthreads();
+    const int count = s_count;
+    if (count == 0) return;
+    {
+        // the tables: column i of row r <- dwords i/4 and i/4 + 1 of the staged row, realigned once
+        const uint32_t *band = reinterpret_cast<const uint32_t *>(&s_band[0][0]);
+        constexpr int RW = CD_LW / 4;
+        for (int k = 0; k < 2; k++)                      // columns 1 .. CD_LW-4 are looked at (cc-1+-u, |u| <= CD_HALO-2)
+        {
+            const int i = tid + k * CD_W;
+            bool fp = false, fm = false;
+            if (i < CD_LW - 3)
+            {
+                const int q = i >> 2, sh = i & 3;
+#define TRI(row) (__builtin_amdgcn_alignbyte(band[(row) * RW + q + 1], band[(row) * RW + q], sh) & 0x00ffffffu)
+                fp = any_peak3(TRI(5));
+                fm = any_peak3(TRI(7));
+                s_tri[0][i] = TRI(0);
+                s_tri[1][i] = TRI(1);
+                s_tri[2][i] = TRI(2);
+                s_tri[3][i] = TRI(3);
+                s_tri[4][i] = TRI(4);
+#undef TRI
+            }
+            const uint64_t wp = __ballot(fp), wm = __ballot(fm);      // the wave's 64 consecutive columns = one word
+            if ((tid & 63) == 0) { s_bp[i >> 6] = wp; s_bm[i >> 6] = wm; }
+        }
+    }
+    __syncthreads();
+    if (tid >= count) return;
+
+    const int lx = s_list[tid];
+    const int px = x0 + lx, cc = lx + CD_HALO;
+    const int maxdt = pl == 0 ? maxd : (maxd >> 1);
+    const int startu = max(-px + 1, -maxdt), stopu = min(width - 2 - px, maxdt);
+    const int b = cc - 1;
+    const uint32_t F2p = s_tri[0][b], Fp = s_tri[1][b], Fc = s_tri[2][b], Fn = s_tri[3][b], F2n = s_tri[4][b];
+    const int ctr = (int)((Fc >> 8) & 0xff);
+    const int vert = iabs(ctr - (int)((Fn >> 8) & 0xff)) + iabs(ctr - (int)((Fp >> 8) & 0xff));
+    const bool first = y == 1, last = y == height - 2;
+    // keys: (running minimum << 6) | (u + 32), low six bits 0 = unset
+    uint32_t kb = (uint32_t)min(nt13, vert * 6) << 6, ka = (uint32_t)min(nt19, vert * 9) << 6;
+    uint32_t kc = ka, kd = kb, ke = kb;
+    // The steps this pixel takes, as a bit set (bit j: u = j - maxdt): inside its range, and - unless on the first /
+    // last row - with a mask peak above at +u and below at -u (:395-399).  Above: bits b-maxdt .. b+maxdt of s_bp in
+    // that order; below: the same bits of s_bm in reverse.  Only about a quarter of the steps pass, so walking the set
+    // bits (ascending u, as the key minimum needs nothing else) more than halves the trips of a wave.
+    const int len = 2 * maxdt + 1;
+    auto window = [&](const uint64_t *bits) {
+        const int start = b - maxdt, wq = start >> 6, sh = start & 63;
+        const uint64_t lo = bits[wq], hi = bits[wq + 1];
+        return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+    };
+    uint64_t pass = 0;
+    if (stopu >= startu)
+    {
+        const int nb = stopu - startu + 1;
+        pass = (nb >= 64 ? ~0ull : ((1ull << nb) - 1ull)) << (startu + maxdt);
+        if (!first) pass &= window(s_bp);
+        if (!last)  pass &= __brevll(window(s_bm)) >> (64 - len);
+    }
+    while (pass)
+    {
+        const int j = __ffsll((unsigned long long)pass) - 1;
+        pass &= pass - 1ull;
+        const int u = j - maxdt;
+        const uint32_t ub = (uint32_t)(u + 32);
+        const uint32_t *tp = &s_tri[0][b + u], *tm = &s_tri[0][b - u];
+        const uint32_t c_p = tp[2 * CD_LW], c_m = tm[2 * CD_LW];
+        const uint32_t sn_m = tm[3 * CD_LW], sp_p = tp[1 * CD_LW];
+        const int e1 = (int)__builtin_amdgcn_sad_u8(Fp, c_m, __builtin_amdgcn_sad_u8(Fc, sn_m, 0u));   // diffsn + diffps
+        const int d1 = (int)__builtin_amdgcn_sad_u8(Fn, c_p, __builtin_amdgcn_sad_u8(Fc, sp_p, 0u));   // diffsp + diffns
+        const int diff = e1 + d1;
+        int diffd = d1, diffe = e1;
+        kb = min(kb, ((uint32_t)diff << 6) | ub);
+        if (!first)
+        {
+            const int diff2pp = (int)__builtin_amdgcn_sad_u8(F2p, tm[1 * CD_LW], 0u);
+            const int diffp2p = (int)__builtin_amdgcn_sad_u8(Fp, tp[0 * CD_LW], 0u);
+            diffd += diffp2p;
+            diffe += diff2pp;
+            ka = min(ka, ((uint32_t)(diff + diff2pp + diffp2p) << 6) | ub);
+        }
+        if (!last)
+        {
+            const int diff2nn = (int)__builtin_amdgcn_sad_u8(F2n, tp[3 * CD_LW], 0u);
+            const int diffn2n = (int)__builtin_amdgcn_sad_u8(Fn, tm[4 * CD_LW], 0u);
+            diffd += diff2nn;
+            diffe += diffn2n;
+            kc = min(kc, ((uint32_t)(diff + diff2nn + diffn2n) << 6) | ub);
+        }
+        kd = min(kd, ((uint32_t)diffd << 6) | ub);
+        ke = min(ke, ((uint32_t)diffe << 6) | ub);
+    }
+    int order[5], k = 0;
+    if (ka & 63) order[k++] = (int)(ka & 63) - 32;
+    if (kb & 63) order[k++] = (int)(kb & 63) - 32;
+    if (kc & 63) order[k++] = (int)(kc & 63) - 32;
+    if (kd & 63) order[k++] = (int)(kd & 63) - 32;
+    if (ke & 63) order[k++] = (int)(ke & 63) - 32;
+    int out = NEUTRAL;
+    if (k > 1)
+    {
+        const int mid = sorted_mid(order, k);
+        const int tlim = max((int)c_limlut[iabs(mid)] >> 2, 2);
+        int sum = 0, cnt = 0;
+        for (int i = 0; i < k; i++)
+            if (iabs(order[i] - mid) <= tlim) { cnt++; sum += order[i]; }
+        if (cnt > 1) out = (NEUTRAL + ((int)((float)sum / (float)cnt) * 4)) & 0xff;
+    }
+    P.c[pl][(size_t)y * pitch + px] = (uint8_t)out;
+}
+
 // filter_dir_map / expand_dir_map and their _2x forms.
 // a = edge mask, b = direction map in, c = out.  step = 1 (half height) or 2.
 // step 1: rows 1..height-2, neighbours y+-1, mask row y.
@@ -2264,8 +2412,12 @@ int Eedi2Engine::enqueue_passes(int tff, int sel, hbhip_ctx *lc)
             HBHIP_LAUNCH(lc, "eedi2_calc_directions", k_calc_dir_tile,
                          dim3((srcp.stride[0] + CD_W - 1) / CD_W, srcp.height[0], 3), dim3(CD_W), 0, P,
                          par_.maximum_search_distance, (par_.noise_threshold * 13) & 0xff, (par_.noise_threshold * 19) & 0xff);
-        else
+        else if (one_px || par_.maximum_search_distance > 31)
             HBHIP_LAUNCH(lc, "eedi2_calc_directions", k_calc_dir_tile2,
+                         dim3((srcp.stride[0] + CD_W - 1) / CD_W, srcp.height[0], 3), dim3(CD_W), 0, P,
+                         par_.maximum_search_distance, (par_.noise_threshold * 13) & 0xff, (par_.noise_threshold * 19) & 0xff);
+        else
+            HBHIP_LAUNCH(lc, "eedi2_calc_directions", k_calc_dir_tile3,
                          dim3((srcp.stride[0] + CD_W - 1) / CD_W, srcp.height[0], 3), dim3(CD_W), 0, P,
                          par_.maximum_search_distance, (par_.noise_threshold * 13) & 0xff, (par_.noise_threshold * 19) & 0xff);
     }

@@ -57,6 +57,7 @@ void hbhip_pic_mark_idle(hbhip_ctx *ctx, DevPicture *p)
     if (!ctx || !p) return;
     if (!p->idle && hipEventCreateWithFlags(&p->idle, hipEventDisableTiming) != hipSuccess) { p->idle = nullptr; return; }
     p->idle_valid = hipEventRecord(p->idle, ctx->stream) == hipSuccess;
+    p->idle_on = ctx->stream;
 }
 
 int hbhip_ctx::prof_name(const char *name)
@@ -131,9 +132,25 @@ DevPicture *PicturePool::acquire()
 {
     if (!free_.empty())
     {
-        DevPicture *p = free_.back();
-        free_.pop_back();
-        return p;
+        // Most recently released first (warm in L2) when its last user ran on this pool's stream.  One last used on
+        // ANOTHER stream (a later stage of a chain with a stream per stage) is only taken once that user is done:
+        // waiting for it here would chain this stage's next batch behind the later stage's current one.  While there
+        // is no such picture the pool grows (to a bound), after that the longest-released one is waited for.
+        for (size_t i = free_.size(); i-- > 0;)
+        {
+            DevPicture *p = free_[i];
+            if (p->idle_valid && p->idle_on != ctx_->stream && hipEventQuery(p->idle) != hipSuccess) continue;
+            free_.erase(free_.begin() + (ptrdiff_t)i);
+            return p;
+        }
+        (void)hipGetLastError();                       // hipEventQuery's hipErrorNotReady
+        if (all_.size() >= max_pictures_)
+        {
+            DevPicture *p = free_.front();
+            free_.erase(free_.begin());
+            (void)hipStreamWaitEvent(ctx_->stream, p->idle, 0);
+            return p;
+        }
     }
     DevPicture *p = new (std::nothrow) DevPicture();
     if (!p) return nullptr;
@@ -163,10 +180,10 @@ DevPicture *PicturePool::acquire()
     return p;
 }
 
-void PicturePool::release(DevPicture *p)
+void PicturePool::release(DevPicture *p, hbhip_ctx *last_user)
 {
     if (!p) return;
-    hbhip_pic_mark_idle(ctx_, p);          // an upload into the recycled picture waits for this (hbhip_copy_h2d)
+    hbhip_pic_mark_idle(last_user ? last_user : ctx_, p);   // an upload into the recycled picture waits for this (hbhip_copy_h2d)
     free_.push_back(p);
 }
 
@@ -720,7 +737,7 @@ int hbhip_filter_submit_async(hbhip_filter *f, const hbhip_host_frame *in, const
     ASYNC_CHECK(hipStreamWaitEvent(ctx->stream, ev, 0));
     rc = f->process_pair(pic, o);
     if (rc != HBHIP_OK) return fail(rc);
-    hbhip_pic_release(pic);                        // idle event behind the kernels that read it
+    hbhip_pic_release(pic, f->ctx);                // idle event behind the kernels that read it
     ASYNC_CHECK(hipEventRecord(ev, ctx->stream));
     ASYNC_CHECK(hipStreamWaitEvent(ctx->down_stream, ev, 0));
     for (int c = 0; c < 3; c++)

@@ -107,8 +107,9 @@ struct DevPicture
     int      flags = 0;      // PIC_FLAG_* of the source buffer (decomb / comb detect)
     int      combed = 0;     // HB_COMB_* of the source buffer
     int      aux = 0;        // filter specific (decomb: which field of a bob pair)
-    hipEvent_t idle = nullptr;   // recorded on the context's stream when the picture goes back to its pool:
+    hipEvent_t idle = nullptr;   // recorded on the stream of its last user when the picture goes back to its pool:
     bool     idle_valid = false; // everything that used it has been queued before that point
+    hipStream_t idle_on = nullptr;   // the stream `idle` was recorded on
     class PicturePool *owner = nullptr;   // the pool the picture goes back to (hbhip_pic_release)
 };
 
@@ -137,8 +138,9 @@ struct PicGeometry
     }
 };
 
-// Pool of equally-shaped device pictures; reuse is stream-ordered by design
-// (every producer/consumer of a picture runs on the context's single stream).
+// Pool of equally-shaped device pictures.  Reuse is stream-ordered: a picture handed back by a user on the pool's
+// own stream needs nothing; one handed back from another context's stream (a fused chain whose stages run on
+// streams of their own) makes the pool's stream wait for that user's `idle` event when it is taken out again.
 class PicturePool
 {
 public:
@@ -146,7 +148,7 @@ public:
     ~PicturePool();
     void configure(hbhip_ctx *ctx, const PicGeometry &g, int pitch_align = 256, int pad_rows = 0);
     DevPicture *acquire();            // nullptr on allocation failure
-    void        release(DevPicture *p);
+    void        release(DevPicture *p, hbhip_ctx *last_user = nullptr);   // last_user: the context that read it (default: the pool's)
     const PicGeometry &geometry() const { return geo_; }
 private:
     hbhip_ctx *ctx_ = nullptr;
@@ -155,14 +157,15 @@ private:
     int pad_rows_ = 0;
     std::vector<DevPicture *> all_;
     std::vector<DevPicture *> free_;
+    size_t max_pictures_ = 192;           // growth bound of the cross-stream case (acquire)
 };
 
 // Give a picture back to the pool it came from.  Filters release their INPUT pictures through this,
 // so that a picture one filter produced can be handed to the next filter of a fused chain
 // (hbhip_chain, chain.hip) without a copy: whoever finishes with it returns it to its producer's pool.
-inline void hbhip_pic_release(DevPicture *p)
+inline void hbhip_pic_release(DevPicture *p, hbhip_ctx *last_user = nullptr)
 {
-    if (p && p->owner) p->owner->release(p);
+    if (p && p->owner) p->owner->release(p, last_user);
 }
 
 // Host <-> device: on the context's copy streams, synchronous for the CALLER only (see hbhip_ctx::up_stream):
@@ -191,7 +194,7 @@ struct hbhip_filter
     virtual DevPicture *acquire_input() = 0;
     virtual int submit(DevPicture *pic) = 0;       // takes ownership
     // give back a picture from acquire_input() that was never submitted (a failed upload)
-    virtual void abandon_input(DevPicture *pic) { hbhip_pic_release(pic); }
+    virtual void abandon_input(DevPicture *pic) { hbhip_pic_release(pic, ctx); }
     virtual int flush() = 0;
     // Output side.
     virtual int pending() = 0;
@@ -277,7 +280,7 @@ struct SimpleFilter : hbhip_filter
                 outs[i]->tag = pics[i]->tag;
             }
         int rc = process_many(pics, outs.data(), n);
-        for (int i = 0; i < n; i++) hbhip_pic_release(pics[i]);
+        for (int i = 0; i < n; i++) hbhip_pic_release(pics[i], ctx);
         if (rc != HBHIP_OK)
         {
             if (!out_views) for (DevPicture *o : outs) out_pool.release(o);
@@ -294,7 +297,7 @@ struct SimpleFilter : hbhip_filter
         if (!o) return HBHIP_ERR_NOMEM;
         o->tag = pic->tag;
         int rc = process(pic, o);
-        hbhip_pic_release(pic);            // stream-ordered reuse (back to whichever pool made it)
+        hbhip_pic_release(pic, ctx);       // stream-ordered reuse (back to whichever pool made it)
         if (rc != HBHIP_OK)
         {
             out_pool.release(o);
@@ -321,7 +324,7 @@ struct SimpleFilter : hbhip_filter
         DevPicture vo = *out;
         vo.tag = pic->tag;
         int rc = process(pic, &vo);
-        hbhip_pic_release(pic);
+        hbhip_pic_release(pic, ctx);
         return rc;
     }
 

@@ -38,7 +38,7 @@ constexpr int TYN = 8;           // threads along y
 constexpr int TH = TYN * RY;     // 64
 constexpr int NLM_BORDER = 16;   // nlmeans.c:529 for every patch size <= 29
 
-struct NlmJob
+struct alignas(16) NlmJob
 {
     const uint8_t *frame[HBHIP_NLMEANS_FRAMES_MAX];
     int            fpitch[HBHIP_NLMEANS_FRAMES_MAX];   // row pitch of each temporal frame
@@ -59,6 +59,13 @@ struct NlmJob
     int            nframes, r_half;
     int            tiles_x, tile_start;
 };
+
+// the job table's way to the device (see launch_views): src = the pinned host buffer, read over the bus
+__global__ void job_table_kernel(uint4 *__restrict__ dst, const uint4 *__restrict__ src, int n16)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+}
 
 struct __attribute__((packed, aligned(1))) u32_unaligned { uint32_t v; };
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -1055,6 +1062,7 @@ private:
         // last read it has completed (event per slot)
         HBHIP_CHECK(ctx, hipMalloc((void **)&d_jobs, sizeof(NlmJob) * n * NTABLES));
         HBHIP_CHECK(ctx, hipHostMalloc((void **)&h_jobs, sizeof(NlmJob) * n * NTABLES, hipHostMallocDefault));
+        HBHIP_CHECK(ctx, hipHostGetDevicePointer((void **)&h_jobs_dev, h_jobs, 0));
         for (int i = 0; i < NTABLES; i++)
         {
             if (!table_ev[i]) HBHIP_CHECK(ctx, hipEventCreateWithFlags(&table_ev[i], hipEventDisableTiming));
@@ -1110,7 +1118,7 @@ private:
                 pre_of.erase(it);
             }
         }
-        hbhip_pic_release(p);          // possibly another filter's picture (fused chain)
+        hbhip_pic_release(p, ctx);     // possibly another filter's picture (fused chain)
     }
 
     // nlmeans_prefilter (nlmeans_template.c:428-543) of every plane that has one, into the frame's twin
@@ -1214,7 +1222,14 @@ private:
                     max_rh = std::max(max_rh, jb.r_half);
                 }
             if (nj == 0) continue;
-            HBHIP_CHECK(ctx, hipMemcpyAsync(dj, hj, sizeof(NlmJob) * nj, hipMemcpyHostToDevice, ctx->stream));
+            // the table travels by a copy kernel reading the pinned host buffer: hipMemcpyAsync of this size holds the
+            // calling thread until the stream gets to it (measured 1.4 ms per call in a busy chain)
+            {
+                static_assert(sizeof(NlmJob) % 16 == 0, "NlmJob is copied in 16-byte units");
+                const int n16 = (int)(sizeof(NlmJob) * nj / 16);
+                HBHIP_LAUNCH(ctx, "nlmeans_job_table", job_table_kernel, dim3((n16 + 255) / 256), dim3(256), 0,
+                             reinterpret_cast<uint4 *>(dj), reinterpret_cast<const uint4 *>(h_jobs_dev + (size_t)table * jobs_cap), n16);
+            }
             HBHIP_CHECK(ctx, hipEventRecord(table_ev[table], ctx->stream));
             table_used[table] = true;
             const int nh = n / 2;
@@ -1362,7 +1377,7 @@ private:
     std::deque<DevPicture *> in, out;
     int max_frames = 1;
     float *d_exp = nullptr;
-    NlmJob *d_jobs = nullptr, *h_jobs = nullptr;
+    NlmJob *d_jobs = nullptr, *h_jobs = nullptr, *h_jobs_dev = nullptr;   // h_jobs_dev: the device's address of h_jobs
     int jobs_cap = 0, table = 0;
     static constexpr int NTABLES = 8;
     hipEvent_t table_ev[NTABLES] = {};

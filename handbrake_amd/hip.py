@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "hbhip_filter_push", "hbhip_filter_push_dev", "hbhip_filter_pull", "hbhip_filter_pull_dev",
     "hbhip_filter_process_dev", "hbhip_filter_submit_async", "hbhip_filter_wait", "hbhip_filter_inflight", "hbhip_filter_flush", "hbhip_filter_pending", "hbhip_filter_destroy",
     "hbhip_filter_out_geometry",
-    "hbhip_chain_create", "hbhip_chain_process_dev", "hbhip_chain_flush_dev", "hbhip_chain_pending", "hbhip_chain_destroy",
+    "hbhip_chain_create", "hbhip_chain_process_dev", "hbhip_chain_flush_dev", "hbhip_chain_pending", "hbhip_chain_sync", "hbhip_chain_destroy",
     "hbhip_nlmeans_create", "hbhip_nlmeans_set_batch",
     "hbhip_lapsharp_create", "hbhip_unsharp_create", "hbhip_chroma_smooth_create",
     "hbhip_hqdn3d_create", "hbhip_decomb_create", "hbhip_decomb_push", "hbhip_decomb_push_dev", "hbhip_decomb_debug_eedi_plane",
@@ -108,6 +108,7 @@ def lib() -> C.CDLL:
                                               C.POINTER(C.c_int)]
         L.hbhip_chain_flush_dev.argtypes = [C.c_void_p, C.POINTER(DevFrame), C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int)]
         L.hbhip_chain_pending.argtypes = [C.c_void_p]
+        L.hbhip_chain_sync.argtypes = [C.c_void_p]
         L.hbhip_chain_destroy.argtypes = [C.c_void_p]
         L.hbhip_chain_destroy.restype = None
         _lib = L
@@ -243,8 +244,9 @@ class DeviceFilter:
 
 class Chain:
     """hbhip_chain: a run of device filters fused into one object (frames stay in HBM between the
-    stages, handed over by pointer).  `stages` = DeviceFilter objects sharing `ctx`; the chain closes
-    them itself, last stage first."""
+    stages, handed over by pointer).  `stages` = DeviceFilter objects on `ctx`, or each on a context of
+    its own (then every stage runs on its own HIP stream and batches overlap; outputs are complete after
+    sync()); the chain closes them itself, last stage first."""
 
     def __init__(self, ctx: Ctx, stages):
         self.ctx, self.stages = ctx, list(stages)
@@ -266,6 +268,9 @@ class Chain:
         n = C.c_int()
         check(lib().hbhip_chain_flush_dev(self.h, frames_out, tags, len(frames_out), C.byref(n)), self.ctx.h, "chain_flush_dev")
         return n.value
+
+    def sync(self):
+        check(lib().hbhip_chain_sync(self.h), self.ctx.h, "chain_sync")
 
     def close(self):
         if self.h:

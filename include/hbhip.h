@@ -146,9 +146,14 @@ int  hbhip_filter_out_geometry(hbhip_filter *f, int *width, int *height);
  * pushes a frame through the whole graph (hb_avfilter_combine, hbavfilter.c:510-622); this is the
  * same for a run of HIP filters: one caller thread, pictures handed from stage to stage in HBM by
  * pointer (no copies between stages), a batch of frames walked stage by stage so that batching
- * stages (NLMeans) cover the batch in one launch.  The chain BORROWS the filters: they must share
- * `ctx`, consecutive geometries must match, and after hbhip_chain_destroy the caller destroys them
- * LAST STAGE FIRST (a stage may still hold pictures of the stage before it).
+ * stages (NLMeans) cover the batch in one launch.  The chain BORROWS the filters: consecutive
+ * geometries must match, and after hbhip_chain_destroy the caller destroys them LAST STAGE FIRST
+ * (a stage may still hold pictures of the stage before it).
+ * Stages created on `ctx` all run on its stream.  Stages created on contexts of their own (same
+ * device) run on THEIR streams - libhb's one thread per filter (work.c:2527-2600) as one stream per
+ * filter: the chain orders each hand-over with an event, so the first stages start on the next batch
+ * while the last ones finish this one.  Input frames must be complete in `ctx`'s stream order when
+ * hbhip_chain_process_dev is called; output frames are complete after hbhip_chain_sync().
  * pic_flags / combed: per input frame, what hbhip_decomb_push carries (NULL = 0); out_tags: the
  * tag of each output frame (decomb stages shift tags as documented at hbhip_decomb_push). */
 typedef struct hbhip_chain hbhip_chain;
@@ -158,6 +163,7 @@ int  hbhip_chain_process_dev(hbhip_chain *c, const hbhip_dev_frame *in, const in
                              int *n_out);
 int  hbhip_chain_flush_dev(hbhip_chain *c, const hbhip_dev_frame *out, int64_t *out_tags, int out_cap, int *n_out);
 int  hbhip_chain_pending(hbhip_chain *c);             /* finished frames waiting for room in `out` */
+int  hbhip_chain_sync(hbhip_chain *c);                /* wait for every stage's stream */
 void hbhip_chain_destroy(hbhip_chain *c);
 
 /* ---- NLMeans  (replaces nlmeans.c:223-419 init tables + nlmeans_template.c:545-717) */

@@ -94,45 +94,65 @@ def _dev(planes, torch):
     return [torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in planes]
 
 
+@pytest.mark.parametrize("split", [False, True], ids=["one_stream", "stream_per_stage"])
 @pytest.mark.parametrize("w,h,scale_to,batches", [(640, 360, (1280, 720), (3, 1, 2)), (1920, 1080, (3840, 2160), (4,)),
                                                   (638, 360, None, (1, 1, 4))])
-def test_fused_chain_object_vs_chained_oracle(built, w, h, scale_to, batches):
+def test_fused_chain_object_vs_chained_oracle(built, w, h, scale_to, batches, split):
+    """split: every stage on a context (HIP stream) of its own; the batches are then submitted back to back, each into
+    output frames of its own, and only synchronized at the end - consecutive batches overlap inside the chain."""
     import torch
     n = sum(batches)
     frames = synth.stream("interlaced", w, h, n, cfg=3)
     want = os_.run_chain(frames, chain_oracle(scale_to), flags=TFF)
     ow, oh = scale_to if scale_to else (w, h)
     ctx = hip.Ctx(0)
-    dec = hip.DecombDevice(ctx, w, h, mode=31)
-    stages = [hip.DeviceFilter(ctx, dec.h), hip.nlmeans_device_filter(ctx, hip.NLMEANS_MEDIUM, w, h, batch=1)]
+    ctxs = [ctx]
+
+    def sctx():
+        if split:
+            ctxs.append(hip.Ctx(0))
+        return ctxs[-1]
+
+    c0 = sctx()
+    dec = hip.DecombDevice(c0, w, h, mode=31)
+    stages = [hip.DeviceFilter(c0, dec.h), hip.nlmeans_device_filter(sctx(), hip.NLMEANS_MEDIUM, w, h, batch=1)]
     dec.h = None
     if scale_to:
-        stages.append(hip.cropscale_device_filter(ctx, w, h, ow, oh))
-    stages.append(hip.lapsharp_device_filter(ctx, ow, oh))
+        stages.append(hip.cropscale_device_filter(sctx(), w, h, ow, oh))
+    stages.append(hip.lapsharp_device_filter(sctx(), ow, oh))
     chain = hip.Chain(ctx, stages)
     try:
         dev_in = [_dev(f, torch) for f in frames]
         torch.cuda.synchronize()
         cap = 2 * n + 2
-        outs = [[torch.zeros((oh, ow), dtype=torch.uint8, device="cuda"),
-                 torch.zeros(((oh + 1) // 2, (ow + 1) // 2), dtype=torch.uint8, device="cuda"),
-                 torch.zeros(((oh + 1) // 2, (ow + 1) // 2), dtype=torch.uint8, device="cuda")] for _ in range(cap)]
-        got, t = [], 0
+
+        def out_frames():
+            return [[torch.zeros((oh, ow), dtype=torch.uint8, device="cuda"),
+                     torch.zeros(((oh + 1) // 2, (ow + 1) // 2), dtype=torch.uint8, device="cuda"),
+                     torch.zeros(((oh + 1) // 2, (ow + 1) // 2), dtype=torch.uint8, device="cuda")] for _ in range(cap)]
+
+        calls, t = [], 0                                   # (output frames, how many were produced) per call
         for b in batches:
+            outs = out_frames()
+            torch.cuda.synchronize()                       # the zero fill runs on torch's stream
             arr_in = (hip.DevFrame * b)(*[hip.dev_frame(dev_in[t + i]) for i in range(b)])
             arr_out = (hip.DevFrame * cap)(*[hip.dev_frame(o) for o in outs])
             k = chain.process_dev(arr_in, arr_out, tag0=t, flags=[TFF] * b, combed=[2] * b)
-            ctx.sync()
-            got += [[p.cpu().numpy().copy() for p in outs[i]] for i in range(k)]
+            if not split:
+                chain.sync()
+            calls.append((outs, k))
             t += b
+        outs = out_frames()
+        torch.cuda.synchronize()
         arr_out = (hip.DevFrame * cap)(*[hip.dev_frame(o) for o in outs])
-        k = chain.flush_dev(arr_out)
-        ctx.sync()
-        got += [[p.cpu().numpy().copy() for p in outs[i]] for i in range(k)]
+        calls.append((outs, chain.flush_dev(arr_out)))
+        chain.sync()
+        got = [[p.cpu().numpy().copy() for p in o[i]] for o, k in calls for i in range(k)]
         assert len(got) == len(want) == 2 * n
         for i in range(len(want)):
             for c in range(3):
                 np.testing.assert_array_equal(got[i][c], want[i][c], err_msg=f"fused chain frame {i} plane {c}")
     finally:
         chain.close()
-        ctx.close()
+        for c in reversed(ctxs):
+            c.close()

@@ -1,4 +1,4 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r02q; O=$GRAFT_REPO_ROOT/gpurun_out/r02q; R=$GRAFT_REPO_ROOT
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r03b; O=$GRAFT_REPO_ROOT/gpurun_out/r03b; R=$GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 cd /tmp
 PROF="python $R/bench.py --workload decomb_eedi2 --steps 4 --warmup 2 --no-cpu-baseline --no-pcie --no-kernel-timer"
