@@ -176,6 +176,187 @@ __global__ __launch_bounds__(256) void decomb_plane_kernel(DecombArgs a, int max
     *o = (PIX)pred;
 }
 
+// ---- decomb_plane_kernel for 8-bit samples, four pixels per thread and several frames per launch --------------
+// One plane of one 1080p frame is ~2 MB: a launch per frame is mostly dispatch latency, and a thread per byte spends
+// its time on load instructions.  Here a thread owns one aligned dword of its row (the rows it needs come in as
+// dwords or 12-byte windows x-4 .. x+7, the arithmetic is the scalar kernel's, per byte), and grid.z runs over the
+// planes of up to DB_FRAMES frames that share the geometry (the frames of a chain batch).
+constexpr int DB_FRAMES = 16;
+
+struct DecombFrame
+{
+    const uint8_t *prev[3], *cur[3], *next[3], *guess[3];
+    uint8_t       *dst[3];
+    int mode, parity, field_parity, pad;
+};
+
+struct DecombBatch
+{
+    DecombFrame f[DB_FRAMES];
+    int pitch[3], guess_pitch[3], dst_pitch[3], w[3], h[3];
+    int n = 0;
+};
+
+struct W12 { uint32_t w0, w1, w2; };       // bytes x-4 .. x+7 of a row
+
+__device__ __forceinline__ int w12b(const W12 &w, int i)          // byte at column x+i, i in [-4, 7] (constant after unrolling)
+{
+    const int k = i + 4;
+    const uint32_t d = k < 4 ? w.w0 : (k < 8 ? w.w1 : w.w2);
+    return (int)((d >> (8 * (k & 3))) & 0xffu);
+}
+__device__ __forceinline__ int dwb(uint32_t d, int k) { return (int)((d >> (8 * k)) & 0xffu); }
+
+// the dwords either side are only read where they exist inside the row
+__device__ __forceinline__ W12 ldw12(const uint8_t *row, int x, int pitch)
+{
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(row + x);
+    return W12{ x >= 4 ? p[-1] : 0u, p[0], x + 4 < pitch ? p[1] : 0u };
+}
+
+__global__ __launch_bounds__(256) void decomb_plane4_kernel(DecombBatch B)
+{
+    const int pl = blockIdx.z % 3;
+    const DecombFrame &F = B.f[blockIdx.z / 3];
+    const int w = B.w[pl], h = B.h[pl], st = B.pitch[pl];
+    const int x = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const uint8_t *cb = F.cur[pl];
+    const uint8_t *crow = cb + (size_t)y * st;
+    uint8_t *orow = F.dst[pl] + (size_t)y * B.dst_pitch[pl];
+    const int mode = F.mode;
+    auto store = [&](uint32_t v) {
+        if (x + 3 < w) *reinterpret_cast<uint32_t *>(orow + x) = v;
+        else for (int k = 0; k < 4 && x + k < w; k++) orow[x + k] = (uint8_t)(v >> (8 * k));
+    };
+    auto dw = [&](const uint8_t *row) { return *reinterpret_cast<const uint32_t *>(row + x); };
+
+    if (mode == 0) { store(dw(crow)); return; }                                    // pass-through (:892-897)
+    if ((mode & M_EEDI2) && !(mode & M_YADIF))                                    // EEDI2 only (:855-875)
+    {
+        store(dw(F.guess[pl] + (size_t)y * B.guess_pitch[pl]));
+        return;
+    }
+    if ((y & 1) != (F.parity ? 0 : 1)) { store(dw(crow)); return; }               // kept field (:795-807)
+
+    uint32_t out = 0;
+    if (mode == M_BLEND)                                                           // :300-361
+    {
+        int u1, u2, d1, d2;
+        if (y > 1 && y < h - 2) { u1 = -st; u2 = -2 * st; d1 = st; d2 = 2 * st; }
+        else if (y == 0)        { u1 = u2 = 0; d1 = st; d2 = 2 * st; }
+        else if (y == 1)        { u1 = u2 = -st; d1 = st; d2 = 2 * st; }
+        else if (y == h - 2)    { u1 = -st; u2 = -2 * st; d1 = d2 = st; }
+        else                    { u1 = -st; u2 = -2 * st; d1 = d2 = 0; }
+        const uint32_t a2 = dw(crow + u2), a1 = dw(crow + u1), c0 = dw(crow), b1 = dw(crow + d1), b2 = dw(crow + d2);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            out |= (uint32_t)cropv((-dwb(a2, k) + 2 * dwb(a1, k) + 6 * dwb(c0, k) + 2 * dwb(b1, k) - dwb(b2, k)) >> 3, 255) << (8 * k);
+        store(out);
+        return;
+    }
+    if (mode == M_CUBIC)                                                           // :50-107
+    {
+        // which rows stand in for p0..p3 depends on y only
+        int o0, o1, o2, o3;
+        if (y >= 3)                { o0 = -3 * st; o1 = -st; }
+        else if (y == 2 || y == 1) { o0 = o1 = -st; }
+        else                       { o0 = o1 = st; }
+        if (y <= h - 4)                    { o2 = st; o3 = 3 * st; }
+        else if (y == h - 3 || y == h - 2) { o2 = o3 = st; }
+        else                               { o2 = o3 = -st; }
+        const uint32_t p0 = dw(crow + o0), p1 = dw(crow + o1), p2 = dw(crow + o2), p3 = dw(crow + o3);
+#pragma unroll
+        for (int k = 0; k < 4; k++) out |= (uint32_t)cubic4(dwb(p0, k), dwb(p1, k), dwb(p2, k), dwb(p3, k), 255) << (8 * k);
+        store(out);
+        return;
+    }
+    if (!(mode & M_YADIF)) return;                                                 // untouched, as the reference leaves it
+
+    // ---- yadif_filter_line (:579-712)
+    const uint8_t *prow = F.prev[pl] + (size_t)y * st, *nrow = F.next[pl] + (size_t)y * st;
+    const uint8_t *p2row = F.field_parity ? prow : crow, *n2row = F.field_parity ? crow : nrow;
+    const int sp = y ? -st : st;
+    const int sn = y + 1 < h ? st : -st;
+    const bool vertical_edge = (y < 3) || (y > h - 4);
+    const bool use_cubic = (mode & M_CUBIC) && !vertical_edge;
+    const int margin = (mode & M_CUBIC) ? 3 : 2;
+    const bool spatial = !(mode & M_EEDI2);
+
+    const uint32_t p20 = dw(p2row), n20 = dw(n2row);
+    const uint32_t ppu = dw(prow + sp), ppd = dw(prow + sn), pnu = dw(nrow + sp), pnd = dw(nrow + sn);
+    uint32_t p2a = 0, p2b = 0, n2a = 0, n2b = 0;                                   // rows y-2 / y+2
+    if (!vertical_edge) { p2a = dw(p2row - 2 * st); p2b = dw(p2row + 2 * st); n2a = dw(n2row - 2 * st); n2b = dw(n2row + 2 * st); }
+    uint32_t g = 0;
+    if (!spatial) g = dw(F.guess[pl] + (size_t)y * B.guess_pitch[pl]);
+    W12 cu, cd, cu3 = {0, 0, 0}, cd3 = {0, 0, 0};                                  // rows y+sp, y+sn, y-3, y+3 of cur
+    if (spatial)
+    {
+        cu = ldw12(crow + sp, x, st); cd = ldw12(crow + sn, x, st);
+        if (use_cubic) { cu3 = ldw12(crow - 3 * st, x, st); cd3 = ldw12(crow + 3 * st, x, st); }
+    }
+    else
+    {
+        cu = W12{0u, dw(crow + sp), 0u}; cd = W12{0u, dw(crow + sn), 0u};
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+        const int cc = w12b(cu, k), e = w12b(cd, k);
+        const int P2 = dwb(p20, k), N2 = dwb(n20, k);
+        const int d = (P2 + N2) >> 1;
+        const int td0 = abs(P2 - N2);
+        const int td1 = (abs(dwb(ppu, k) - cc) + abs(dwb(ppd, k) - e)) >> 1;
+        const int td2 = (abs(dwb(pnu, k) - cc) + abs(dwb(pnd, k) - e)) >> 1;
+        int diff = max3i(td0 >> 1, td1, td2);
+        int pred;
+        if (!spatial) pred = dwb(g, k);
+        else
+        {
+            // c[sp + i] = cu(k + i), c[sn + i] = cd(k + i); with the cubic predictor sp = -st, sn = st (no vertical edge)
+            pred = use_cubic ? cubic4(w12b(cu3, k), cc, e, w12b(cd3, k), 255) : (cc + e) >> 1;
+            const int xx = x + k;
+            if (xx > margin && xx < w - (margin + 1))
+            {
+                int best = abs(w12b(cu, k - 1) - w12b(cd, k - 1)) + abs(cc - e) + abs(w12b(cu, k + 1) - w12b(cd, k + 1)) - 1;
+                auto check = [&](int j) -> bool {
+                    const int score = abs(w12b(cu, k - 1 + j) - w12b(cd, k - 1 - j)) + abs(w12b(cu, k + j) - w12b(cd, k - j)) +
+                                      abs(w12b(cu, k + 1 + j) - w12b(cd, k + 1 - j));
+                    if (score >= best) return false;
+                    best = score;
+                    if (use_cubic)
+                    {
+                        // :541-570
+                        if (j == -1)      pred = cubic4(w12b(cu3, k - 3), w12b(cu, k - 1), w12b(cd, k + 1), w12b(cd3, k + 3), 255);
+                        else if (j == -2) pred = cubic4((w12b(cu3, k - 4) + w12b(cu, k - 4)) / 2, w12b(cu, k - 2), w12b(cd, k + 2),
+                                                        (w12b(cd3, k + 4) + w12b(cd, k + 4)) / 2, 255);
+                        else if (j == 1)  pred = cubic4(w12b(cu3, k + 3), w12b(cu, k + 1), w12b(cd, k - 1), w12b(cd3, k - 3), 255);
+                        else              pred = cubic4((w12b(cu3, k + 4) + w12b(cu, k + 4)) / 2, w12b(cu, k + 2), w12b(cd, k - 2),
+                                                        (w12b(cd3, k - 4) + w12b(cd, k - 4)) / 2, 255);
+                    }
+                    else pred = (w12b(cu, k + j) + w12b(cd, k - j)) >> 1;
+                    return true;
+                };
+                if (check(-1)) check(-2);
+                if (check(1)) check(2);
+            }
+        }
+        if (!vertical_edge)
+        {
+            const int b = (dwb(p2a, k) + dwb(n2a, k)) >> 1;
+            const int f = (dwb(p2b, k) + dwb(n2b, k)) >> 1;
+            const int mx = max3i(d - e, d - cc, min(b - cc, f - e));
+            const int mn = min3i(d - e, d - cc, max(b - cc, f - e));
+            diff = max3i(diff, mn, -mx);
+        }
+        if (pred > d + diff)      pred = d + diff;
+        else if (pred < d - diff) pred = d - diff;
+        out |= (uint32_t)(pred & 0xff) << (8 * k);
+    }
+    store(out);
+}
+
 // ------------------------------------------------------------------- host side
 // ------------------------------------------------------------------------------------------
 // FFmpeg's yadif, which is what the reference's "Deinterlace" filter is (libhb/deinterlace.c:43-143
@@ -470,13 +651,15 @@ private:
     void unref(DevPicture *p)
     {
         if (!p || --p->refs != 0) return;
-        // a blend on a ring engine's stream may still be reading it: hand it back when the ring has been joined
-        if (!ring_busy.empty()) late_unref.push_back(p);
+        // a blend on a ring engine's stream, or one gathered for the batch launch, may still read it: hand it back
+        // when the ring has been joined / the batch is out
+        if (!ring_busy.empty() || batch.n > 0) late_unref.push_back(p);
         else hbhip_pic_release(p, ctx);                    // possibly another filter's picture (fused chain)
     }
     // make the filter's stream wait for everything the ring engines have been given
     void join_ring()
     {
+        (void)launch_batch(batch, ctx);
         for (Eedi2Engine *e : ring_busy) (void)e->join();
         ring_busy.clear();
         for (DevPicture *p : late_unref) hbhip_pic_release(p, ctx);
@@ -537,8 +720,42 @@ private:
             HBHIP_CHECK(ctx, hipGetLastError());
             return HBHIP_OK;
         }
-        if (in_geo.bps == 2) HBHIP_LAUNCH(lc, "decomb_plane", decomb_plane_kernel<uint16_t>, grid, block, 0, a, maxv);
-        else                 HBHIP_LAUNCH(lc, "decomb_plane", decomb_plane_kernel<uint8_t>, grid, block, 0, a, maxv);
+        if (in_geo.bps == 2)
+        {
+            HBHIP_LAUNCH(lc, "decomb_plane", decomb_plane_kernel<uint16_t>, grid, block, 0, a, maxv);
+            HBHIP_CHECK(lc, hipGetLastError());
+            return HBHIP_OK;
+        }
+        // 8-bit: four pixels per thread; on the filter's own stream inside a chain batch the frames are gathered and
+        // go out DB_FRAMES per launch (launch_batch), anywhere else at once
+        static const bool one_px = getenv("HBHIP_DECOMB_1PX") != nullptr;             // A/B switch: the byte-per-thread kernel
+        if (one_px)
+        {
+            HBHIP_LAUNCH(lc, "decomb_plane", decomb_plane_kernel<uint8_t>, grid, block, 0, a, maxv);
+            HBHIP_CHECK(lc, hipGetLastError());
+            return HBHIP_OK;
+        }
+        const bool gather = deferred && lc == ctx;
+        DecombBatch &B = gather ? batch : single;
+        if (!gather) B.n = 0;
+        DecombFrame &F = B.f[B.n++];
+        for (int c = 0; c < 3; c++)
+        {
+            const DecombPlane &P = a.pl[c];
+            F.prev[c] = P.prev; F.cur[c] = P.cur; F.next[c] = P.next; F.guess[c] = P.guess; F.dst[c] = P.dst;
+            B.pitch[c] = P.pitch; B.guess_pitch[c] = P.guess_pitch; B.dst_pitch[c] = P.dst_pitch; B.w[c] = P.w; B.h[c] = P.h;
+        }
+        F.mode = a.mode; F.parity = a.parity; F.field_parity = a.field_parity; F.pad = 0;
+        if (!gather || B.n == DB_FRAMES) return launch_batch(B, lc);
+        return HBHIP_OK;
+    }
+
+    int launch_batch(DecombBatch &B, hbhip_ctx *lc)
+    {
+        if (B.n == 0) return HBHIP_OK;
+        const dim3 block(64, 4), grid((B.w[0] + 255) / 256, (B.h[0] + 3) / 4, 3 * B.n);
+        B.n = 0;
+        HBHIP_LAUNCH(lc, "decomb_plane", decomb_plane4_kernel, grid, block, 0, B);
         HBHIP_CHECK(lc, hipGetLastError());
         return HBHIP_OK;
     }
@@ -637,6 +854,7 @@ private:
     EediMaskShare ring_share;
     size_t ring_next = 0;
     bool deferred = false;
+    DecombBatch batch, single;             // blends gathered for one launch (chain batch) / the one being launched now
 public:
     Eedi2Engine16 *eedi16 = nullptr;       // 10 / 12-bit samples
 private:

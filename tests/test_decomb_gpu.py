@@ -83,3 +83,46 @@ def test_comb_detect_feeds_decomb(built):
         for c in range(3):
             np.testing.assert_array_equal(got[t].planes[c], want_planes[t][c], err_msg=f"frame {t} plane {c}")
         assert (got[t].start, got[t].stop, got[t].combed) == (meta[t]["start"], meta[t]["stop"], meta[t]["combed"])
+
+
+@pytest.mark.parametrize("mode,combed", [(7, None), (39, [2, 1, 0, 2, 0, 1, 2, 2, 0]), (23, None), (2, None), (4, None)])
+@pytest.mark.parametrize("w,h", [(322, 182), (1920, 1080)])
+def test_decomb_in_a_chain_batch(built, w, h, mode, combed):
+    """Inside a fused chain the blends of a batch are gathered into one launch (several frames per launch,
+    decomb.hip:decomb_plane4_kernel) and the input pictures are handed back only after it: same frames as the oracle."""
+    import torch
+    n = 9 if w < 1000 else 5
+    frames = synth.stream("interlaced", w, h, n)
+    cmb = combed[:n] if combed else None
+    want = os_.decomb_stream(frames, dict(mode=mode), flags=TFF, combed=cmb)
+    ctx = hip.Ctx(0)
+    dec = hip.DecombDevice(ctx, w, h, mode=mode)
+    stage = hip.DeviceFilter(ctx, dec.h)
+    dec.h = None
+    chain = hip.Chain(ctx, [stage])
+    try:
+        dev_in = [[torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in f] for f in frames]
+        cap = 2 * n + 2
+        outs = [[torch.zeros((h, w), dtype=torch.uint8, device="cuda"),
+                 torch.zeros(((h + 1) // 2, (w + 1) // 2), dtype=torch.uint8, device="cuda"),
+                 torch.zeros(((h + 1) // 2, (w + 1) // 2), dtype=torch.uint8, device="cuda")] for _ in range(cap)]
+        torch.cuda.synchronize()
+        got, t = [], 0
+        for b in (n - 2, 2):
+            arr_in = (hip.DevFrame * b)(*[hip.dev_frame(dev_in[t + i]) for i in range(b)])
+            arr_out = (hip.DevFrame * cap)(*[hip.dev_frame(o) for o in outs])
+            k = chain.process_dev(arr_in, arr_out, tag0=t, flags=[TFF] * b, combed=(cmb[t:t + b] if cmb else [2] * b))
+            chain.sync()
+            got += [[p.cpu().numpy().copy() for p in outs[i]] for i in range(k)]
+            t += b
+        arr_out = (hip.DevFrame * cap)(*[hip.dev_frame(o) for o in outs])
+        k = chain.flush_dev(arr_out)
+        chain.sync()
+        got += [[p.cpu().numpy().copy() for p in outs[i]] for i in range(k)]
+        assert len(got) == len(want)
+        for i in range(len(want)):
+            for c in range(3):
+                np.testing.assert_array_equal(got[i][c], want[i]["planes"][c], err_msg=f"frame {i} plane {c}")
+    finally:
+        chain.close()
+        ctx.close()
