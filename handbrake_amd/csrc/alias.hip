@@ -88,6 +88,75 @@ __global__ __launch_bounds__(256) void rotate_kernel(RotArgs a)
     }
 }
 
+// rotate_kernel for 8-bit planes, all three planes of up to RB_FRAMES frames per launch, dwords to and from HBM.
+// A workgroup makes one 64 x 64 output tile: the source rectangle it maps to goes into LDS as it lies (16 dwords per
+// row), every thread then assembles output dwords from four LDS bytes (rot_map per byte) - the same for the
+// transposing and the mirroring modes.  A 1080p plane is ~2 MB, a launch per plane mostly dispatch latency.
+constexpr int RB_FRAMES = 16;
+
+struct RotBatch
+{
+    int sw[3], sh[3], spitch[3], dw[3], dh[3], dpitch[3];
+    int trans, hflip, vflip, n;
+    const uint8_t *src[RB_FRAMES][3];
+    uint8_t       *dst[RB_FRAMES][3];
+};
+
+__global__ __launch_bounds__(256) void rotate8_batch_kernel(RotBatch B)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t tile[64][68];
+    const int job = blockIdx.z, f = job / 3, c = job - 3 * f;
+    RotArgs a;
+    a.src = B.src[f][c]; a.dst = B.dst[f][c];
+    a.sw = B.sw[c]; a.sh = B.sh[c]; a.spitch = B.spitch[c]; a.dw = B.dw[c]; a.dh = B.dh[c]; a.dpitch = B.dpitch[c];
+    a.trans = B.trans; a.hflip = B.hflip; a.vflip = B.vflip;
+    const int ox = blockIdx.x * 64, oy = blockIdx.y * 64;
+    if (ox >= a.dw || oy >= a.dh) return;
+    const int tw = min(64, a.dw - ox), th = min(64, a.dh - oy);
+    // the source rectangle: the maps are monotonic per axis, so two opposite corners bound it
+    int ax, ay, bx, by;
+    rot_map(a, ox, oy, ax, ay);
+    rot_map(a, ox + tw - 1, oy + th - 1, bx, by);
+    const int sx0 = min(ax, bx), sy0 = min(ay, by), sx1 = max(ax, bx), sy1 = max(ay, by);
+    const int t = threadIdx.y * 64 + threadIdx.x;
+    const int cols = sx1 - sx0 + 1, rows = sy1 - sy0 + 1;
+    if ((sx0 & 3) == 0 && cols == 64)
+    {
+        for (int i = t; i < rows * 16; i += 256)
+        {
+            const int r = i >> 4, q = i & 15;
+            *reinterpret_cast<uint32_t *>(&tile[r][4 * q]) =
+                *reinterpret_cast<const uint32_t *>(a.src + (size_t)(sy0 + r) * a.spitch + sx0 + 4 * q);
+        }
+    }
+    else
+    {
+        for (int i = t; i < rows * 64; i += 256)
+        {
+            const int r = i >> 6, q = i & 63;
+            if (q < cols) tile[r][q] = a.src[(size_t)(sy0 + r) * a.spitch + sx0 + q];
+        }
+    }
+    __syncthreads();
+    for (int i = t; i < th * 16; i += 256)
+    {
+        const int r = i >> 4, q = i & 15;
+        const int x = ox + 4 * q, y = oy + r;
+        if (x >= a.dw) continue;
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            int sx, sy;
+            rot_map(a, min(x + k, a.dw - 1), y, sx, sy);
+            v |= (uint32_t)tile[sy - sy0][sx - sx0] << (8 * k);
+        }
+        uint8_t *d = a.dst + (size_t)y * a.dpitch + x;
+        if (x + 3 < a.dw) *reinterpret_cast<uint32_t *>(d) = v;
+        else for (int k = 0; k < 4 && x + k < a.dw; k++) d[k] = (uint8_t)(v >> (8 * k));
+    }
+}
+
 class RotateFilter : public SimpleFilter
 {
 public:
@@ -102,8 +171,41 @@ public:
         }
     }
     bool transposes() const { return trans != T_NONE; }
+    int process_many(DevPicture *const *ins, DevPicture *const *outs, int n) override
+    {
+        if (in_geo.bps != 1 || getenv("HBHIP_ROTATE_OLD")) return SimpleFilter::process_many(ins, outs, n);
+        for (int at = 0; at < n; at += RB_FRAMES)
+        {
+            const int nf = std::min(RB_FRAMES, n - at);
+            RotBatch B;
+            int max_w = 0, max_h = 0;
+            for (int c = 0; c < 3; c++)
+            {
+                B.sw[c] = ins[at]->width[c]; B.sh[c] = ins[at]->height[c]; B.spitch[c] = ins[at]->pitch[c];
+                B.dw[c] = outs[at]->width[c]; B.dh[c] = outs[at]->height[c]; B.dpitch[c] = outs[at]->pitch[c];
+                max_w = std::max(max_w, B.dw[c]); max_h = std::max(max_h, B.dh[c]);
+                for (int f = 0; f < nf; f++)
+                {
+                    if (ins[at + f]->pitch[c] != B.spitch[c] || outs[at + f]->pitch[c] != B.dpitch[c] || (B.spitch[c] & 3) ||
+                        ((uintptr_t)ins[at + f]->plane[c] & 3) || ((uintptr_t)outs[at + f]->plane[c] & 3) || (B.dpitch[c] & 3))
+                        return SimpleFilter::process_many(ins, outs, n);
+                    B.src[f][c] = ins[at + f]->plane[c];
+                    B.dst[f][c] = outs[at + f]->plane[c];
+                }
+            }
+            B.trans = trans; B.hflip = hflip; B.vflip = vflip; B.n = nf;
+            HBHIP_LAUNCH(ctx, "rotate", rotate8_batch_kernel, dim3((max_w + 63) / 64, (max_h + 63) / 64, 3 * nf), dim3(64, 4), 0, B);
+            HBHIP_CHECK(ctx, hipGetLastError());
+        }
+        return HBHIP_OK;
+    }
     int process(DevPicture *in, DevPicture *out) override
     {
+        if (in_geo.bps == 1 && !getenv("HBHIP_ROTATE_OLD"))
+        {
+            DevPicture *i1[1] = { in }, *o1[1] = { out };
+            return process_many(i1, o1, 1);
+        }
         for (int c = 0; c < 3; c++)
         {
             RotArgs a;
@@ -166,6 +268,71 @@ __global__ void fill_plane_kernel(uint8_t *dst, int pitch, int w, int h, int val
     if (x < w && y < h) reinterpret_cast<PIX *>(dst + (size_t)y * pitch)[x] = (PIX)value;
 }
 
+// monochrome_kernel for 8-bit 4:2:0, up to MB_FRAMES frames per launch.  grid.z = 2 jobs per frame: the luma job
+// gives a thread 4 pixels of two rows (one dword each) and the two (Cb, Cr) pairs above them - so the weight table is
+// looked up once per chroma sample, not once per pixel - the other job fills both chroma planes, 16 bytes per store.
+constexpr int MB_FRAMES = 16;
+
+struct MonoBatch
+{
+    const uint8_t *y[MB_FRAMES], *u[MB_FRAMES], *v[MB_FRAMES];
+    uint8_t       *dy[MB_FRAMES], *du[MB_FRAMES], *dv[MB_FRAMES];
+    int ypitch, cpitch, dpitch, dcpitch, w, h, cw, ch;
+    const float *wlut;
+    float ihigh;
+};
+
+__global__ __launch_bounds__(256) void monochrome8_batch_kernel(MonoBatch B)
+{
+    const int f = blockIdx.z >> 1;
+    if (blockIdx.z & 1)
+    {
+        // chroma fill: rows of cw bytes, both planes
+        const int x = 16 * (blockIdx.x * 64 + threadIdx.x);
+        const int row = blockIdx.y * 4 + threadIdx.y;
+        if (x >= B.cw || row >= 2 * B.ch) return;
+        uint8_t *d = (row < B.ch ? B.du[f] + (size_t)row * B.dcpitch : B.dv[f] + (size_t)(row - B.ch) * B.dcpitch) + x;
+        if (x + 15 < B.cw && (((uintptr_t)d) & 15) == 0) *reinterpret_cast<uint4 *>(d) = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+        else for (int k = 0; k < 16 && x + k < B.cw; k++) d[k] = 128;
+        return;
+    }
+    const int x = 4 * (blockIdx.x * 64 + threadIdx.x);
+    const int y = 2 * (blockIdx.y * 4 + threadIdx.y);
+    if (x >= B.w || y >= B.h) return;
+    const float imax = 1.f / 255;
+    const uint8_t *crow_u = B.u[f] + (size_t)(y >> 1) * B.cpitch + (x >> 1), *crow_v = B.v[f] + (size_t)(y >> 1) * B.cpitch + (x >> 1);
+    float wgt[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+    {
+        const int cx = min((x >> 1) + k, B.cw - 1) - (x >> 1);
+        wgt[k] = B.wlut[(size_t)crow_u[cx] * 256 + crow_v[cx]];          // exp(-clip(dist/size)) built on the host
+    }
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+    {
+        if (y + r >= B.h) break;
+        const uint8_t *yr = B.y[f] + (size_t)(y + r) * B.ypitch + x;
+        const uint32_t in = *reinterpret_cast<const uint32_t *>(yr);
+        uint32_t out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            const float fy = (float)((in >> (8 * k)) & 0xffu) * imax;
+            float ny = wgt[k >> 1];
+            const float tt = envelope(fy);
+            const float t = tt + (1.f - tt) * B.ihigh;
+            ny = (1.f - t) * fy + t * ny * fy;
+            int q = __float2int_rn(ny * 255);
+            q = q < 0 ? 0 : q > 255 ? 255 : q;
+            out |= (uint32_t)q << (8 * k);
+        }
+        uint8_t *d = B.dy[f] + (size_t)(y + r) * B.dpitch + x;
+        if (x + 3 < B.w) *reinterpret_cast<uint32_t *>(d) = out;
+        else for (int k = 0; k < 4 && x + k < B.w; k++) d[k] = (uint8_t)(out >> (8 * k));
+    }
+}
+
 class MonochromeFilter : public SimpleFilter
 {
 public:
@@ -193,8 +360,41 @@ public:
         HBHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         return HBHIP_OK;
     }
+    int process_many(DevPicture *const *ins, DevPicture *const *outs, int n) override
+    {
+        bool ok = in_geo.bps == 1 && in_geo.log2_cw == 1 && in_geo.log2_ch == 1 && !getenv("HBHIP_MONOCHROME_OLD");
+        for (int i = 0; ok && i < n; i++)
+            for (int c = 0; c < 3; c++)
+                ok &= ins[i]->pitch[c] == ins[0]->pitch[c] && outs[i]->pitch[c] == outs[0]->pitch[c] && (ins[i]->pitch[0] & 3) == 0 &&
+                      (outs[i]->pitch[0] & 3) == 0 && ((uintptr_t)ins[i]->plane[0] & 3) == 0 && ((uintptr_t)outs[i]->plane[0] & 3) == 0;
+        if (!ok) return SimpleFilter::process_many(ins, outs, n);
+        for (int at = 0; at < n; at += MB_FRAMES)
+        {
+            const int nf = std::min(MB_FRAMES, n - at);
+            MonoBatch B;
+            for (int f = 0; f < nf; f++)
+            {
+                B.y[f] = ins[at + f]->plane[0]; B.u[f] = ins[at + f]->plane[1]; B.v[f] = ins[at + f]->plane[2];
+                B.dy[f] = outs[at + f]->plane[0]; B.du[f] = outs[at + f]->plane[1]; B.dv[f] = outs[at + f]->plane[2];
+            }
+            B.ypitch = ins[at]->pitch[0]; B.cpitch = ins[at]->pitch[1]; B.dpitch = outs[at]->pitch[0]; B.dcpitch = outs[at]->pitch[1];
+            B.w = ins[at]->width[0]; B.h = ins[at]->height[0]; B.cw = outs[at]->width[1]; B.ch = outs[at]->height[1];
+            B.wlut = d_lut; B.ihigh = 1.f - (float)high;
+            // luma job: 4 x 2 pixels per thread; fill job: 16 bytes per thread over 2 * ch rows - one grid covers both
+            const int gx = std::max(((B.w + 3) / 4 + 63) / 64, ((B.cw + 15) / 16 + 63) / 64);
+            const int gy = std::max(((B.h + 1) / 2 + 3) / 4, (2 * B.ch + 3) / 4);
+            HBHIP_LAUNCH(ctx, "monochrome", monochrome8_batch_kernel, dim3(gx, gy, 2 * nf), dim3(64, 4), 0, B);
+            HBHIP_CHECK(ctx, hipGetLastError());
+        }
+        return HBHIP_OK;
+    }
     int process(DevPicture *in, DevPicture *out) override
     {
+        if (in_geo.bps == 1 && in_geo.log2_cw == 1 && in_geo.log2_ch == 1 && !getenv("HBHIP_MONOCHROME_OLD"))
+        {
+            DevPicture *i1[1] = { in }, *o1[1] = { out };
+            return process_many(i1, o1, 1);
+        }
         const int w = in->width[0], h = in->height[0];
         const int max = (1 << in_geo.depth) - 1, mid = 1 << (in_geo.depth - 1);
         if (in_geo.bps == 1)

@@ -125,3 +125,54 @@ def test_pad(built, depth, st, geo, rgb):
     w, h, x, y = geo
     check(got, [ol.orc_pad_frame(fr, w, h, x, y, rgb=rgb, depth=depth) for fr in frames])
     assert (got[0].width, got[0].height) == (w, h)
+
+
+# ---- several device-resident frames per launch (hbhip_filter_process_dev -> process_many) ------------------------------
+def _batch_through(make, frames, ow, oh):
+    import ctypes as C
+    import torch
+    ctx = hip.Ctx(0)
+    flt = make(ctx)
+    try:
+        dev_in = [[torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in f] for f in frames]
+        outs = [[torch.zeros((oh, ow), dtype=torch.uint8, device="cuda"),
+                 torch.zeros(((oh + 1) // 2, (ow + 1) // 2), dtype=torch.uint8, device="cuda"),
+                 torch.zeros(((oh + 1) // 2, (ow + 1) // 2), dtype=torch.uint8, device="cuda")] for _ in frames]
+        torch.cuda.synchronize()
+        n = len(frames)
+        arr_in = (hip.DevFrame * n)(*[hip.dev_frame(f) for f in dev_in])
+        arr_out = (hip.DevFrame * n)(*[hip.dev_frame(o) for o in outs])
+        assert flt.process_dev(arr_in, 0, arr_out) == n
+        ctx.sync()
+        return [[p.cpu().numpy() for p in o] for o in outs]
+    finally:
+        flt.close()
+        ctx.close()
+
+
+@pytest.mark.parametrize("w,h", [(640, 360), (636, 358), (1920, 1080)])
+@pytest.mark.parametrize("angle,flip", [(0, 1), (90, 0), (90, 1), (180, 0), (270, 0), (270, 1)])
+def test_rotate_many_frames_per_launch(built, w, h, angle, flip):
+    import ctypes as C
+    frames = synth.stream("progressive", w, h, 5)
+    ow, oh = (h, w) if angle in (90, 270) else (w, h)
+    make = lambda ctx: hip._create("hbhip_rotate_create", ctx, [C.c_void_p] + [C.c_int] * 7 + [C.POINTER(C.c_void_p)],
+                                   ctx.h, angle, flip, w, h, 8, 1, 1)
+    got = _batch_through(make, frames, ow, oh)
+    want = os_.rotate_stream(frames, dict(angle=angle, hflip=flip))
+    for t in range(len(want)):
+        for c in range(3):
+            np.testing.assert_array_equal(got[t][c], want[t][c], err_msg=f"frame {t} plane {c}")
+
+
+@pytest.mark.parametrize("w,h", [(640, 360), (638, 362), (1920, 1080)])
+def test_grayscale_many_frames_per_launch(built, w, h):
+    import ctypes as C
+    frames = synth.stream("progressive", w, h, 5)
+    make = lambda ctx: hip._create("hbhip_grayscale_create", ctx, [C.c_void_p] + [C.c_double] * 4 + [C.c_int] * 5 + [C.POINTER(C.c_void_p)],
+                                   ctx.h, 0.1, -0.2, 0.8, 0.3, w, h, 8, 1, 1)
+    got = _batch_through(make, frames, w, h)
+    want = os_.grayscale_stream(frames, dict(cb=0.1, cr=-0.2, size=0.8, high=0.3))
+    for t in range(len(want)):
+        for c in range(3):
+            np.testing.assert_array_equal(got[t][c], want[t][c], err_msg=f"frame {t} plane {c}")
