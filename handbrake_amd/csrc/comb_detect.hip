@@ -104,6 +104,120 @@ __global__ __launch_bounds__(256) void comb_detect_kernel(const PIX *__restrict_
     mask[(size_t)y * mask_stride + x] = out;
 }
 
+// ---- 8-bit, four pixels per thread, several frames per launch -------------------------------------------------------
+// A 1080p luma is 2 MB: one frame per launch is dispatch latency, one byte per thread is load instructions.  Here
+// grid.z runs over up to CB_FRAMES frames (frame f is classified from lumas f, f+1, f+2 of the batch - consecutive
+// frames share two of their three planes, which then come from L2), a thread owns an aligned dword of its row, and
+// only threads with a pixel that passes the first (vertical) test load the other two frames' rows.
+constexpr int CB_FRAMES = 16;
+
+struct CombBatch
+{
+    const uint8_t *luma[CB_FRAMES + 2];
+    uint32_t force;                  // bit f: frame f is checked exhaustively (no motion test)
+    int n;
+};
+
+__device__ __forceinline__ int cb_b(uint32_t d, int k) { return (int)((d >> (8 * k)) & 0xffu); }
+
+template <bool GAMMA>
+__global__ __launch_bounds__(256) void comb_detect4_kernel(CombBatch B, int pitch, uint8_t *__restrict__ mask_base, size_t mask_fs,
+                                                           int mask_stride, int width, int height, CombConst k,
+                                                           const float *__restrict__ lut_g)
+{
+    __shared__ float L[256];
+    if (GAMMA)
+    {
+        L[threadIdx.y * 64 + threadIdx.x] = lut_g[threadIdx.y * 64 + threadIdx.x];
+        __syncthreads();
+    }
+    const int f = blockIdx.z;
+    const int x = 4 * (blockIdx.x * 64 + threadIdx.x);
+    const int y = 2 + blockIdx.y * 4 + threadIdx.y;                   // rows 2 .. height-3 (:312-319)
+    if (y >= height - 2 || x >= mask_stride) return;
+    const int force = (B.force >> f) & 1;
+    uint32_t out = 0;                                                  // memset(mask, 0, mask_stride) (:342)
+    if (x < width)
+    {
+        const size_t at = (size_t)y * pitch + x;
+        const uint8_t *c = B.luma[f + 1] + at;
+        auto ld = [](const uint8_t *q) { return *reinterpret_cast<const uint32_t *>(q); };
+        const uint32_t cv = ld(c), cu1 = ld(c - pitch), cd1 = ld(c + pitch);
+        uint32_t cand = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+        {
+            const int v = cb_b(cv, j), u1 = cb_b(cu1, j), d1 = cb_b(cd1, j);
+            bool pass;
+            if (GAMMA)
+            {
+                const float up = L[v] - L[u1], dn = L[v] - L[d1];
+                pass = (up > k.g_athresh && dn > k.g_athresh) || (up < -k.g_athresh && dn < -k.g_athresh);
+            }
+            else
+            {
+                const int at_ = k.spatial_threshold, up = v - u1, dn = v - d1;
+                pass = (up > at_ && dn > at_) || (up < -at_ && dn < -at_);
+            }
+            if (pass && x + j < width) cand |= 1u << j;
+        }
+        if (cand)
+        {
+            const uint8_t *p = B.luma[f] + at, *n = B.luma[f + 2] + at;
+            const uint32_t cu2 = ld(c - 2 * pitch), cd2 = ld(c + 2 * pitch);
+            const uint32_t pv = ld(p), pu1 = ld(p - pitch), pd1 = ld(p + pitch);
+            const uint32_t nv = ld(n), nu1 = ld(n - pitch), nd1 = ld(n + pitch);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+            {
+                if (!((cand >> j) & 1u)) continue;
+                const int v = cb_b(cv, j), u1 = cb_b(cu1, j), d1 = cb_b(cd1, j), u2 = cb_b(cu2, j), d2 = cb_b(cd2, j);
+                int motion = 0;
+                bool comb = false;
+                if (GAMMA)
+                {
+                    if (k.g_mthresh > 0)
+                    {
+                        if (fabsf(L[cb_b(pv, j)] - L[v]) > k.g_mthresh && fabsf(L[u1] - L[cb_b(nu1, j)]) > k.g_mthresh &&
+                            fabsf(L[d1] - L[cb_b(nd1, j)]) > k.g_mthresh)
+                            motion++;
+                        if (fabsf(L[cb_b(nv, j)] - L[v]) > k.g_mthresh && fabsf(L[cb_b(pu1, j)] - L[u1]) > k.g_mthresh &&
+                            fabsf(L[cb_b(pd1, j)] - L[d1]) > k.g_mthresh)
+                            motion++;
+                    }
+                    else
+                        motion = 1;
+                    if (motion || force)
+                    {
+                        // (:382-386) same association as the reference, no contraction
+                        const float combing = fabsf(L[u2] + (4 * L[v]) + L[d2] - (3 * (L[u1] + L[d1])));
+                        comb = combing > k.g_athresh6;
+                    }
+                }
+                else
+                {
+                    const int mt = k.motion_threshold;
+                    if (mt > 0)
+                    {
+                        if (abs(cb_b(pv, j) - v) > mt && abs(u1 - cb_b(nu1, j)) > mt && abs(d1 - cb_b(nd1, j)) > mt) motion++;
+                        if (abs(cb_b(nv, j) - v) > mt && abs(cb_b(pu1, j) - u1) > mt && abs(cb_b(pd1, j) - d1) > mt) motion++;
+                    }
+                    else
+                        motion = 1;
+                    if (motion || force)
+                    {
+                        if (k.spatial_metric == 0)      comb = abs(v - d2) < k.c32_min && abs(v - d1) > k.c32_max;
+                        else if (k.spatial_metric == 1) comb = (u1 - v) * (d1 - v) > k.athresh_sq;
+                        else if (k.spatial_metric == 2) comb = abs(u2 + 4 * v + d2 - 3 * (u1 + d1)) > k.athresh6;
+                    }
+                }
+                if (comb) out |= 1u << (8 * j);
+            }
+        }
+    }
+    *reinterpret_cast<uint32_t *>(mask_base + (size_t)f * mask_fs + (size_t)y * mask_stride + x) = out;
+}
+
 // op 0: filter (classic -> h, else h&v), 1: erode (thr 2), 2: dilate (thr 4).
 // Row pointers start at column 1 and columns 1..width-2 are indexed from there.
 __global__ __launch_bounds__(256) void comb_mask_pass_kernel(const uint8_t *__restrict__ src,
@@ -193,15 +307,118 @@ __global__ __launch_bounds__(256) void comb_mask_fused_kernel(const uint8_t *__r
     }
 }
 
+// comb_mask_fused_kernel on dwords, several frames per launch (grid.z).  The cells are 0 / 1 bytes, so four of them go
+// through each pass in one 32-bit operation: the triple tests of pass 1 are ANDs of byte-shifted dwords, the
+// 8-neighbour counts of the erode / dilate passes sums of them (at most 8 per byte) and the thresholds one add each
+// (bit 7 of count + 0x80 - thr).  A thread owns a dword column of the LDS frame and two rows per pass.  The tile is
+// 64 x 16 cells at a dword-aligned column (the `live` test keeps columns 0, 1 and the border rows at zero).
+constexpr int CQ_DW = (64 + 8) / 4, CQ_DP = CQ_DW + 2, CQ_ROWS = 16 + 8;      // 18 dwords (+1 pad either side) x 24 rows
+
+__device__ __forceinline__ uint32_t cq_bytes_in(int X, int lo, int hi)            // 0x01 in byte k when lo <= X + k <= hi
+{
+    uint32_t m = 0x01010101u;
+    const int a = lo - X, b = hi + 1 - X;
+    if (a > 0) m = a >= 4 ? 0u : (m << (8 * a));
+    if (b < 4) m = b <= 0 ? 0u : (m & (0x01010101u >> (8 * (4 - b))));
+    return m;
+}
+
+__global__ __launch_bounds__(256) void comb_mask_fused4_kernel(const uint8_t *__restrict__ mask_base, uint8_t *__restrict__ dst_base,
+                                                               size_t fs, int stride, int width, int height)
+{
+    __shared__ uint32_t s_a[CQ_ROWS][CQ_DP], s_b[CQ_ROWS][CQ_DP];
+    const uint8_t *mask = mask_base + (size_t)blockIdx.z * fs;
+    uint8_t *dst = dst_base + (size_t)blockIdx.z * fs;
+    const int fc = blockIdx.x * 64 - 4, fr = blockIdx.y * 16 - 4;             // plane position of frame cell (0, 0)
+    const int t = threadIdx.y * 64 + threadIdx.x;
+    for (int i = t; i < CQ_ROWS * CQ_DW; i += 256)
+    {
+        const int lr = i / CQ_DW, q = i - lr * CQ_DW;
+        const int r = fr + lr, c = fc + 4 * q;
+        uint32_t v = 0;
+        if (r >= 0 && r < height && c >= 0 && c <= width)
+        {
+            v = *reinterpret_cast<const uint32_t *>(mask + (size_t)r * stride + c);
+            // column `width` of the last row lies past the plane when the rows are packed (elsewhere the reference reads
+            // the next row's column 0 there, and so does the flat dword)
+            if (r == height - 1 && stride == width && c + 3 >= width) v = c >= width ? 0u : (v & (0xffffffffu >> (8 * (c + 4 - width))));
+        }
+        s_a[lr][q + 1] = v;
+    }
+    __syncthreads();
+    const int q = t % CQ_DW, strip = t / CQ_DW;                                   // 14 strips of 2 rows
+    const uint32_t lcol = cq_bytes_in(fc + 4 * q, 2, width - 1);                  // live columns of this dword
+    auto live_row = [&](int lr) { const int r = fr + lr; return r >= 1 && r <= height - 2; };
+    // pass 1: horizontal & vertical triple test, frame rows 1 .. 22
+    {
+        const int r0 = 1 + 2 * strip;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+        {
+            const int lr = r0 + i;
+            if (lr > CQ_ROWS - 2 || strip >= 14) break;
+            const uint32_t l = s_a[lr][q], c = s_a[lr][q + 1], r = s_a[lr][q + 2];
+            const uint32_t v = __builtin_amdgcn_alignbyte(c, l, 3) & c & __builtin_amdgcn_alignbyte(r, c, 1) & s_a[lr - 1][q + 1] & s_a[lr + 1][q + 1];
+            s_b[lr][q + 1] = live_row(lr) ? (v & lcol) : 0u;
+        }
+    }
+    __syncthreads();
+    // passes 2-4: erode (>= 2 neighbours), dilate (>= 4), erode; s_b -> s_a -> s_b -> out
+#pragma unroll
+    for (int pass = 0; pass < 3; pass++)
+    {
+        uint32_t (*in)[CQ_DP] = (pass & 1) ? s_a : s_b;
+        uint32_t (*out)[CQ_DP] = (pass & 1) ? s_b : s_a;
+        const int ap = 2 + pass;                                               // frame rows ap .. 23 - ap
+        const int r0 = ap + 2 * strip;
+        if (strip < 14 && r0 <= CQ_ROWS - 1 - ap)
+        {
+            const uint32_t K = (uint32_t)(0x80 - (pass == 1 ? 4 : 2)) * 0x01010101u;
+            uint32_t S2[4], S3[4], C[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+            {
+                const int lr = min(r0 - 1 + i, CQ_ROWS - 1);
+                const uint32_t l = in[lr][q], c = in[lr][q + 1], r = in[lr][q + 2];
+                C[i] = c;
+                S2[i] = __builtin_amdgcn_alignbyte(c, l, 3) + __builtin_amdgcn_alignbyte(r, c, 1);
+                S3[i] = S2[i] + c;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+            {
+                const int lr = r0 + i;
+                if (lr > CQ_ROWS - 1 - ap) break;
+                const uint32_t count = S3[i] + S2[i + 1] + S3[i + 2];
+                const uint32_t ge = ((count + K) >> 7) & 0x01010101u;
+                const uint32_t c = C[i + 1];
+                uint32_t v = pass == 1 ? (c | ge) : (c & ge);
+                v = live_row(lr) ? (v & lcol) : 0u;
+                if (pass < 2) out[lr][q + 1] = v;
+                else
+                {
+                    // the tile: frame rows 4 .. 19, dword columns 1 .. 16
+                    const int r = fr + lr, cc = fc + 4 * q;
+                    if (q >= 1 && q <= 16 && r >= 0 && r < height && cc < stride)
+                        *reinterpret_cast<uint32_t *>(dst + (size_t)r * stride + cc) = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // one wave per block_width x block_height block; result = max category seen
 // One workgroup (4 waves) per row of blocks: each wave sums one block at a time, the categories are
 // maximised inside the workgroup and one atomic per workgroup reaches the result word (a global
 // atomic - or even an uncached read - per block would queue 8100 requests on one L2 channel).
 __global__ __launch_bounds__(256) void comb_score_kernel(const uint8_t *__restrict__ mask, int stride,
                                                          int width, int height, int bw, int bh, int thr,
-                                                         int filtered, int blocks_x, int *result, int overlay)
+                                                         int filtered, int blocks_x, int *result, int overlay, size_t fs)
 {
     __shared__ int s_cat;
+    mask += (size_t)blockIdx.y * fs;                           // grid.y = frames of a batch, 4 result words each
+    result += 4 * blockIdx.y;
     if (threadIdx.x == 0) s_cat = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -308,6 +525,9 @@ public:
         if (d_result) (void)hipFree(d_result);
         if (h_result) (void)hipHostFree(h_result);
         if (stage) (void)hipFree(stage);
+        if (bmasks) (void)hipFree(bmasks);
+        if (d_bresult) (void)hipFree(d_bresult);
+        if (h_bresult) (void)hipHostFree(h_bresult);
     }
 
     int setup(int w, int h, int depth)
@@ -414,7 +634,18 @@ public:
         dim3 b(64, 4);
         dim3 g((mstride + 63) / 64, (height - 4 + 3) / 4);
         const size_t lds = (par.mode & 1) ? sizeof(float) * k.lut_len : 0;
-        if (bps == 2)
+        static const bool one_px = getenv("HBHIP_COMB_1PX") != nullptr;                // A/B switch: the byte-per-thread kernels
+        const bool quad = bps == 1 && !overlay && !one_px;
+        if (quad)
+        {
+            CombBatch B;
+            for (int i = 0; i < 3; i++) B.luma[i] = luma_alloc[ref[i]];
+            B.force = force ? 1u : 0u; B.n = 1;
+            const dim3 g4((mstride / 4 + 63) / 64, (height - 4 + 3) / 4, 1);
+            if (par.mode & 1) HBHIP_LAUNCH(ctx, "comb_detect", comb_detect4_kernel<true>, g4, b, 0, B, pitch, mask, (size_t)0, mstride, width, height, k, (const float *)d_lut);
+            else              HBHIP_LAUNCH(ctx, "comb_detect", comb_detect4_kernel<false>, g4, b, 0, B, pitch, mask, (size_t)0, mstride, width, height, k, (const float *)d_lut);
+        }
+        else if (bps == 2)
             HBHIP_LAUNCH(ctx, "comb_detect", comb_detect_kernel<uint16_t>, g, b, lds, (const uint16_t *)luma_alloc[ref[0]],
                          (const uint16_t *)luma_alloc[ref[1]], (const uint16_t *)luma_alloc[ref[2]], pitch / 2, mask, mstride,
                          width, height, k, (const float *)d_lut, force);
@@ -430,7 +661,10 @@ public:
             // and the passes read it, so they run one by one on the real buffers (the fused kernel carries its
             // intermediate masks in LDS and assumes those cells are zero)
             const bool fused = par.filter_mode == 2 && !overlay && getenv("HBHIP_COMB_UNFUSED") == nullptr;
-            if (fused)
+            if (fused && quad)
+                HBHIP_LAUNCH(ctx, "comb_mask_passes", comb_mask_fused4_kernel, dim3((width + 63) / 64, (height + 15) / 16, 1), b, 0,
+                             (const uint8_t *)mask, mask_filtered, (size_t)0, mstride, width, height);
+            else if (fused)
                 HBHIP_LAUNCH(ctx, "comb_mask_passes", comb_mask_fused_kernel,
                              dim3((width - 2 + CF_W - 1) / CF_W, (height - 2 + CF_H - 1) / CF_H), b, 0,
                              (const uint8_t *)mask, mask_filtered, mstride, width, height);
@@ -453,7 +687,7 @@ public:
         {
             HBHIP_LAUNCH(ctx, "comb_block_score", comb_score_kernel, dim3(blocks_y), dim3(256), 0,
                          (const uint8_t *)(filt ? mask_filtered : mask), mstride, width, height, bw, bh,
-                         par.block_threshold, filt ? 1 : 0, blocks_x, d_result, overlay ? 1 : 0);
+                         par.block_threshold, filt ? 1 : 0, blocks_x, d_result, overlay ? 1 : 0, (size_t)0);
         }
         HBHIP_CHECK(ctx, hipGetLastError());
         HBHIP_CHECK(ctx, hipMemcpyAsync(h_result, d_result, sizeof(int) * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -474,6 +708,55 @@ public:
             box_x = (idx % blocks_x) * bw;
             box_y = (idx / blocks_x) * bh;
         }
+        return HBHIP_OK;
+    }
+
+    // n frames at once: frame i is classified from lumas[i], lumas[i + 1], lumas[i + 2] (device pointers, `stride` bytes a
+    // row), in three launches and one read-back for all of them.  Independent of the ring store() / classify() work on.
+    int classify_many(const void *const *lumas, int stride, int n, uint32_t force_bits, int *combed)
+    {
+        if (n < 1 || n > CB_FRAMES || bps != 1 || overlay) return HBHIP_ERR_UNSUPPORTED;
+        const bool filt = (par.mode & 2) != 0;
+        if (filt && par.filter_mode != 2) return HBHIP_ERR_UNSUPPORTED;
+        if ((par.mode & 1) && !lut_ready) return HBHIP_ERR_STATE;
+        if (stride < width || (stride & 3)) return HBHIP_ERR_ARG;
+        CombBatch B;
+        for (int i = 0; i < n + 2; i++)
+        {
+            if (!lumas[i] || ((uintptr_t)lumas[i] & 3)) return HBHIP_ERR_ARG;
+            B.luma[i] = (const uint8_t *)lumas[i];
+        }
+        B.force = force_bits; B.n = n;
+        const size_t msz = (size_t)mstride * height + 256, fs = 2 * msz;
+        if (!bmasks)
+        {
+            HBHIP_CHECK(ctx, hipMalloc((void **)&bmasks, fs * CB_FRAMES));
+            HBHIP_CHECK(ctx, hipMemsetAsync(bmasks, 0, fs * CB_FRAMES, ctx->stream));
+            HBHIP_CHECK(ctx, hipMalloc((void **)&d_bresult, sizeof(int) * 4 * CB_FRAMES));
+            HBHIP_CHECK(ctx, hipHostMalloc((void **)&h_bresult, sizeof(int) * 4 * CB_FRAMES, hipHostMallocDefault));
+        }
+        const dim3 b(64, 4), g4((mstride / 4 + 63) / 64, (height - 4 + 3) / 4, n);
+        if (par.mode & 1) HBHIP_LAUNCH(ctx, "comb_detect", comb_detect4_kernel<true>, g4, b, 0, B, stride, bmasks, fs, mstride, width, height, k, (const float *)d_lut);
+        else              HBHIP_LAUNCH(ctx, "comb_detect", comb_detect4_kernel<false>, g4, b, 0, B, stride, bmasks, fs, mstride, width, height, k, (const float *)d_lut);
+        if (filt)
+            HBHIP_LAUNCH(ctx, "comb_mask_passes", comb_mask_fused4_kernel, dim3((width + 63) / 64, (height + 15) / 16, n), b, 0,
+                         (const uint8_t *)bmasks, bmasks + msz, fs, mstride, width, height);
+        HBHIP_CHECK(ctx, hipMemsetAsync(d_bresult, 0, sizeof(int) * 4 * n, ctx->stream));
+        const int bw = par.block_width, bh = par.block_height;
+        const int blocks_x = (width - bw + bw - 1) / bw, blocks_y = height / bh;
+        if (blocks_x > 0 && blocks_y > 0)
+            HBHIP_LAUNCH(ctx, "comb_block_score", comb_score_kernel, dim3(blocks_y, n), dim3(256), 0,
+                         (const uint8_t *)(filt ? bmasks + msz : bmasks), mstride, width, height, bw, bh,
+                         par.block_threshold, filt ? 1 : 0, blocks_x, d_bresult, 0, fs);
+        HBHIP_CHECK(ctx, hipGetLastError());
+        HBHIP_CHECK(ctx, hipMemcpyAsync(h_bresult, d_bresult, sizeof(int) * 4 * n, hipMemcpyDeviceToHost, ctx->stream));
+        hipEvent_t done = ctx->sync_ev_get();
+        if (!done) return ctx->fail(hipErrorOutOfMemory, "hipEventCreate(classify_many)");
+        HBHIP_CHECK(ctx, hipEventRecord(done, ctx->stream));
+        const hipError_t e = hipEventSynchronize(done);
+        ctx->sync_ev_put(done);
+        if (e != hipSuccess) return ctx->fail(e, "hipEventSynchronize(classify_many)");
+        for (int i = 0; i < n; i++) combed[i] = h_bresult[4 * i];
         return HBHIP_OK;
     }
 
@@ -559,6 +842,8 @@ private:
     int box_x = 0, box_y = 0;                        // pv->mask_box_x / _y
     uint8_t *stage = nullptr;
     size_t stage_bytes = 0;
+    uint8_t *bmasks = nullptr;                       // classify_many: CB_FRAMES x (mask, filtered mask)
+    int *d_bresult = nullptr, *h_bresult = nullptr;
 };
 
 } // namespace
@@ -620,6 +905,15 @@ extern "C" int hbhip_comb_detect_overlay_dev(hbhip_filter *f, const hbhip_dev_fr
     if (!c || !frame || !plane_w || !plane_h) return HBHIP_ERR_ARG;
     (void)hipSetDevice(f->ctx->device);
     return c->overlay_dev(frame, plane_w, plane_h);
+}
+
+extern "C" int hbhip_comb_detect_classify_many_dev(hbhip_filter *f, const void *const *lumas, int stride, int n_frames,
+                                                   unsigned force_bits, int *combed)
+{
+    CombDetectFilter *c = dynamic_cast<CombDetectFilter *>(f);
+    if (!c || !lumas || !combed) return HBHIP_ERR_ARG;
+    (void)hipSetDevice(f->ctx->device);
+    return c->classify_many(lumas, stride, n_frames, force_bits, combed);
 }
 
 extern "C" int hbhip_comb_detect_classify(hbhip_filter *f, int force_exhaustive, int *combed)

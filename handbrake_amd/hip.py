@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "hbhip_hqdn3d_create", "hbhip_decomb_create", "hbhip_decomb_push", "hbhip_decomb_push_dev", "hbhip_decomb_debug_eedi_plane",
     "hbhip_comb_detect_create", "hbhip_comb_detect_set_gamma_lut", "hbhip_comb_detect_store",
     "hbhip_comb_detect_store_dev",
-    "hbhip_comb_detect_classify", "hbhip_comb_detect_overlay", "hbhip_comb_detect_overlay_dev",
+    "hbhip_comb_detect_classify", "hbhip_comb_detect_classify_many_dev", "hbhip_comb_detect_overlay", "hbhip_comb_detect_overlay_dev",
     "hbhip_rotate_create", "hbhip_grayscale_create", "hbhip_cropscale_create", "hbhip_colorspace_create", "hbhip_pad_create", "hbhip_yadif_create", "hbhip_bwdif_create", "hbhip_format_create",
     "hbhip_blend_create", "hbhip_blend_set_overlays", "hbhip_blend_apply", "hbhip_blend_apply_dev", "hbhip_blend_destroy",
     "hbhip_motion_metric_create", "hbhip_motion_metric_run", "hbhip_motion_metric_run_dev", "hbhip_motion_metric_destroy",
@@ -347,6 +347,17 @@ class CombDetectDevice:
         out = C.c_int()
         check(lib().hbhip_comb_detect_classify(self.h, int(force), C.byref(out)), self.ctx.h, "comb_detect_classify")
         return out.value
+
+    def classify_many(self, luma_ptrs, stride, force_bits=0):
+        """len(luma_ptrs) - 2 verdicts in one go: frame i from lumas i, i+1, i+2 (device pointers)."""
+        n = len(luma_ptrs) - 2
+        L = lib()
+        L.hbhip_comb_detect_classify_many_dev.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_uint,
+                                                          C.POINTER(C.c_int)]
+        arr = (C.c_void_p * len(luma_ptrs))(*luma_ptrs)
+        out = (C.c_int * n)()
+        check(L.hbhip_comb_detect_classify_many_dev(self.h, arr, stride, n, force_bits, out), self.ctx.h, "comb_detect_classify_many")
+        return list(out)
 
     def close(self):
         if self.h:

@@ -279,6 +279,12 @@ int hbhip_comb_detect_store(hbhip_filter *f, const uint8_t *luma, int stride);
 int hbhip_comb_detect_store_dev(hbhip_filter *f, const void *luma, int stride);
 /* comb_segmenter on the ring: *combed = HB_COMB_NONE/LIGHT/HEAVY for the middle plane. */
 int hbhip_comb_detect_classify(hbhip_filter *f, int force_exhaustive, int *combed);
+/* The same verdicts for n_frames (<= 16) frames at once, for callers that hold the lumas in HBM: frame i is judged
+ * from lumas[i], lumas[i + 1], lumas[i + 2] (prev / cur / next as the ring would hold them - n_frames + 2 device
+ * pointers, `stride` bytes a row, 4-byte aligned), bit i of force_bits = force_exhaustive for frame i.  Three
+ * launches and one read-back whatever n_frames is; does not touch the ring.  8-bit, modes 0-3, filter-mode 0 or 2. */
+int hbhip_comb_detect_classify_many_dev(hbhip_filter *f, const void *const *lumas, int stride, int n_frames,
+                                        unsigned force_bits, int *combed);
 
 /* Mask overlay, modes 4 (MODE_MASK) / 8 (MODE_COMPOSITE): draw_mask_box + apply_mask (comb_detect_template.c:21-136)
  * on `frame`, which holds a COPY of the frame the last classify judged combed (process_frame, comb_detect.c:1519-1526).

@@ -126,3 +126,28 @@ def test_decomb_in_a_chain_batch(built, w, h, mode, combed):
     finally:
         chain.close()
         ctx.close()
+
+
+@pytest.mark.parametrize("model", ["interlaced", "progressive", "random"])
+@pytest.mark.parametrize("w,h", [(128, 72), (636, 362), (1920, 1080)])
+@pytest.mark.parametrize("par", [gc.COMB_DEFAULT_PAR, dict(mode=2, spatial_metric=0, motion_thresh=0, spatial_thresh=3, filter_mode=2, block_thresh=20),
+                                 dict(mode=0, spatial_metric=1, motion_thresh=2, spatial_thresh=3, block_thresh=40),
+                                 dict(mode=1, block_thresh=300)], ids=["default", "int_filter", "int_plain", "gamma_plain"])
+def test_comb_detect_many_frames_per_launch(built, model, w, h, par):
+    """hbhip_comb_detect_classify_many_dev: the verdicts of a run of frames from three launches (frames along grid.z)
+    are the oracle's frame-by-frame ones."""
+    import torch
+    n = 6
+    frames = synth.stream(model, w, h, n)
+    want = os_.comb_detect_stream(frames, par)
+    ctx = hip.Ctx(0)
+    cd = hip.CombDetectDevice(ctx, w, h, **{k: v for k, v in par.items()})
+    try:
+        lumas = [torch.from_numpy(np.ascontiguousarray(f[0])).cuda() for f in frames]
+        torch.cuda.synchronize()
+        order = [0] + list(range(n)) + [n - 1]                       # the first / last frame stand in for their missing neighbour
+        got = cd.classify_many([lumas[i].data_ptr() for i in order], lumas[0].stride(0), force_bits=1 | (1 << (n - 1)))
+        assert got == want
+    finally:
+        cd.close()
+        ctx.close()
