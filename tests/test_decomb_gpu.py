@@ -143,7 +143,11 @@ def test_comb_detect_many_frames_per_launch(built, model, w, h, par):
     ctx = hip.Ctx(0)
     cd = hip.CombDetectDevice(ctx, w, h, **{k: v for k, v in par.items()})
     try:
-        lumas = [torch.from_numpy(np.ascontiguousarray(f[0])).cuda() for f in frames]
+        lumas = []
+        for f in frames:                                             # rows padded to 64 bytes, as hb_frame_buffer_init pads them
+            t = torch.zeros((h, (w + 63) // 64 * 64), dtype=torch.uint8, device="cuda")[:, :w]
+            t.copy_(torch.from_numpy(np.ascontiguousarray(f[0])))
+            lumas.append(t)
         torch.cuda.synchronize()
         order = [0] + list(range(n)) + [n - 1]                       # the first / last frame stand in for their missing neighbour
         got = cd.classify_many([lumas[i].data_ptr() for i in order], lumas[0].stride(0), force_bits=1 | (1 << (n - 1)))

@@ -19,9 +19,10 @@ N = 24
 
 
 def planes(w, h, dtype=torch.uint8):
-    return [torch.empty((h, w), dtype=dtype, device="cuda"),
-            torch.empty((h // 2, w // 2), dtype=dtype, device="cuda"),
-            torch.empty((h // 2, w // 2), dtype=dtype, device="cuda")]
+    """rows padded to 64 samples, as hb_frame_buffer_init lays them out (and as the batch paths want them: 16-byte rows)"""
+    def plane(pw, ph):
+        return torch.empty((ph, (pw + 63) // 64 * 64), dtype=dtype, device="cuda")[:, :pw]
+    return [plane(w, h), plane(w // 2, h // 2), plane(w // 2, h // 2)]
 
 
 def simple(ctx, make, w, h, ow, oh, model="progressive", feeds=N, depth=8):
@@ -203,6 +204,93 @@ def main():
     st = ctx.profile_stats(); ctx.profile(False)
     add(st, {"motion_metric": 2 * Y})
     L.hbhip_motion_metric_destroy(m)
+    # ---- the stateless / per-frame kernels with the frames of a batch in one launch --------------
+    NB = 16
+
+    def add_batched(stats, table, label, frames_per_launch):
+        for k, (n, ms) in stats.items():
+            if k not in table:
+                continue
+            b = table[k] * frames_per_launch
+            us = ms / n * 1e3
+            res[label] = {"kernel": k, "frames_per_launch": frames_per_launch, "launches": n, "avg_us": round(us, 2),
+                          "us_per_frame": round(us / frames_per_launch, 3), "algorithmic_bytes_per_launch": b,
+                          "achieved_GBps": round(b / (us * 1e-6) / 1e9, 1), "frac_of_8TBps": round(b / (us * 1e-6) / 1e9 / PEAK, 4)}
+
+    def batched(make, w, h, ow, oh, model="progressive", reps=8):
+        frames = synth.stream(model, w, h, 4)
+        dev_in = [[torch.from_numpy(p).cuda() for p in fr] for fr in frames]
+        outs = [planes(ow, oh) for _ in range(NB)]
+        torch.cuda.synchronize()
+        flt = make()
+        arr_in = (hip.DevFrame * NB)(*[hip.dev_frame(dev_in[i % 4]) for i in range(NB)])
+        arr_out = (hip.DevFrame * NB)(*[hip.dev_frame(o) for o in outs])
+        for _ in range(2):
+            flt.process_dev(arr_in, 0, arr_out)
+        ctx.sync(); ctx.profile(True); ctx.profile_reset()
+        for _ in range(reps):
+            flt.process_dev(arr_in, 0, arr_out)
+        ctx.sync()
+        st = ctx.profile_stats(); ctx.profile(False)
+        flt.close()
+        return st
+
+    add_batched(batched(lambda: hip.lapsharp_device_filter(ctx, 2 * W, 2 * H), 2 * W, 2 * H, 2 * W, 2 * H),
+                {"lapsharp_3x3": 2 * (4 * FRAME)}, "lapsharp_3x3 @2160p x16", NB)
+    add_batched(batched(rot, W, H, H, W), {"rotate": 2 * FRAME}, "rotate 90 x16", NB)       # one launch = the 3 planes of 16 frames
+    add_batched(batched(gray, W, H, W, H), {"monochrome": 2 * FRAME}, "grayscale x16", NB)
+    # decomb blend (default mode 7: yadif + cubic), the frames of a chain batch in one launch
+    frames = synth.stream("interlaced", W, H, 4)
+    dev_in = [[torch.from_numpy(p).cuda() for p in fr] for fr in frames]
+    outs = [planes(W, H) for _ in range(NB + 2)]
+    torch.cuda.synchronize()
+    dd = hip.DecombDevice(ctx, W, H, mode=7)
+    stage = hip.DeviceFilter(ctx, dd.h)
+    dd.h = None
+    chain = hip.Chain(ctx, [stage])
+    arr_in = (hip.DevFrame * NB)(*[hip.dev_frame(dev_in[i % 4]) for i in range(NB)])
+    arr_out = (hip.DevFrame * (NB + 2))(*[hip.dev_frame(o) for o in outs])
+    for _ in range(2):
+        chain.process_dev(arr_in, arr_out, flags=[8] * NB, combed=[2] * NB)
+    ctx.sync(); ctx.profile(True); ctx.profile_reset()
+    for _ in range(8):
+        chain.process_dev(arr_in, arr_out, flags=[8] * NB, combed=[2] * NB)
+    ctx.sync()
+    st = ctx.profile_stats(); ctx.profile(False)
+    chain.close()
+    add_batched(st, {"decomb_plane": 4 * FRAME}, "decomb_plane (mode 7) x16", NB)
+    # comb detect: 16 frames from 18 lumas in three launches
+    lumas = [torch.from_numpy(np.ascontiguousarray(frames[i % 4][0])).cuda() for i in range(NB + 2)]       # 1920-byte rows: 16-byte aligned
+    torch.cuda.synchronize()
+    cd = hip.CombDetectDevice(ctx, W, H)
+    ptrs = [t.data_ptr() for t in lumas]
+    for _ in range(2):
+        cd.classify_many(ptrs, W)
+    ctx.sync(); ctx.profile(True); ctx.profile_reset()
+    for _ in range(8):
+        cd.classify_many(ptrs, W)
+    ctx.sync()
+    st = ctx.profile_stats(); ctx.profile(False)
+    cd.close()
+    add_batched(st, {"comb_detect": 3 * Y + Y}, "comb_detect x16", NB)
+    add_batched(st, {"comb_mask_passes": 2 * Y}, "comb_mask_passes x16", NB)
+    add_batched(st, {"comb_block_score": Y}, "comb_block_score x16", NB)
+    # what a plain device-to-device copy of the same size reaches (torch's copy kernel; 16 frames = 100 MB read + written)
+    a = torch.empty(NB * FRAME, dtype=torch.uint8, device="cuda")
+    b2 = torch.empty_like(a)
+    for _ in range(3):
+        b2.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(10):
+        b2.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / 10
+    res["(reference) device copy of 16 frames"] = {"avg_us": round(us, 2), "algorithmic_bytes_per_launch": 2 * NB * FRAME,
+                                                   "achieved_GBps": round(2 * NB * FRAME / (us * 1e-6) / 1e9, 1),
+                                                   "frac_of_8TBps": round(2 * NB * FRAME / (us * 1e-6) / 1e9 / PEAK, 4)}
     print(json.dumps(res, indent=1))
     ctx.close()
 
