@@ -352,6 +352,7 @@ def valu_roofline(valu_insts, avg_s):
 
 def run_chain(args, world, rank, local_rank):
     """The chain workloads through hbhip_chain (device-resident, one or more independent streams per GPU)."""
+    import numpy as np
     import torch
     from handbrake_amd import hip, shard, synth
 
@@ -360,17 +361,19 @@ def run_chain(args, world, rank, local_rank):
     OW, OH = scale if scale else (W, H)
     B = args.batch or wl["batch"]
     nsrc = min(B, 8)
-    frames_np = synth.stream("interlaced", W, H, nsrc, cfg=wl["cfg"] + 16 * rank)
-    dev_in = [[torch.from_numpy(p).cuda() for p in fr] for fr in frames_np]
+    depth = args.depth if args.workload == "decomb_eedi2" else 8      # 10 / 12 bits: the decomb workload only (eedi2_16.hip)
+    frames_np = synth.stream("interlaced", W, H, nsrc, cfg=wl["cfg"] + 16 * rank, depth=depth)
+    dev_in = [[torch.from_numpy(p.view(np.int16) if depth > 8 else p).cuda() for p in fr] for fr in frames_np]
     in_arr = (hip.DevFrame * B)(*[hip.dev_frame(dev_in[i % nsrc]) for i in range(B)])
     flags = [synth.PIC_FLAG_TOP_FIELD_FIRST] * B
     torch.cuda.synchronize()
     only_decomb = args.workload == "decomb_eedi2"
 
     def planes(w, h):
-        return [torch.empty((h, w), dtype=torch.uint8, device="cuda"),
-                torch.empty((h // 2, w // 2), dtype=torch.uint8, device="cuda"),
-                torch.empty((h // 2, w // 2), dtype=torch.uint8, device="cuda")]
+        dt = torch.uint8 if depth == 8 else torch.int16
+        return [torch.empty((h, w), dtype=dt, device="cuda"),
+                torch.empty((h // 2, w // 2), dtype=dt, device="cuda"),
+                torch.empty((h // 2, w // 2), dtype=dt, device="cuda")]
 
     class Lane:
         """One independent stream of frames: its own contexts, filter instances, chain and output frames.
@@ -387,7 +390,7 @@ def run_chain(args, world, rank, local_rank):
                 return self.ctxs[-1]
 
             c = stage_ctx()
-            self.decomb = hip.DecombDevice(c, W, H, mode=63 if args.comb_detect else 31)
+            self.decomb = hip.DecombDevice(c, W, H, mode=63 if args.comb_detect else 31, depth=depth)
             self.comb = hip.CombDetectDevice(self.ctx, W, H) if args.comb_detect else None
             stages = [hip.DeviceFilter(c, self.decomb.h)]
             if not only_decomb:
@@ -509,8 +512,9 @@ def run_chain(args, world, rank, local_rank):
                       else "filtered frames/sec (" + args.workload + ")",
             "value": round(frames_total / dt_max, 2), "unit": "output frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt_max / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8 (f32 NLMeans weights, "
-            "f64 scaler / sharpen mix as the reference)", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": ("u8" if depth == 8 else f"u16, {depth}-bit samples") + " (f32 NLMeans weights, f64 scaler / sharpen mix as the reference)",
+            "data": "synthetic",
             "config": {"workload": wl["text"] + (" + comb detect in front (selective decomb, mode 63)" if args.comb_detect else ""),
                        "input_frames_per_step": B * len(lanes), "output_frames_per_step": 2 * B * len(lanes),
                        "input": f"{W}x{H}", "output": f"{OW}x{OH}", "streams_per_gpu": len(lanes),
@@ -546,7 +550,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive pass of the chain workloads")
     ap.add_argument("--depth", type=int, default=8, choices=[8, 10, 12],
-                    help="nlmeans workload only: sample depth (10 / 12 = 16-bit containers)")
+                    help="nlmeans and decomb_eedi2 workloads: sample depth (10 / 12 = 16-bit containers)")
     ap.add_argument("--comb-detect", action="store_true",
                     help="chain workloads: run comb detection in front of the (then selective) decomb, "
                          "as BASELINE configs[2] words it")

@@ -539,6 +539,209 @@ __global__ void q_lattice(Q3 P, K16 k, int field, int nt)
     }
 }
 
+// interpolate_lattice in two launches, as for 8-bit samples (eedi2.hip: k_lattice_cand / k_lattice_resolve).  Of all a
+// pixel's tests only one looks at the direction value just written at x-1 (the left-hand half of :1194); everything else
+// - including the whole "outcome B" the pixel takes when that test fails - reads values no pixel of the pass changes.
+// q_lattice_cand (one thread per pixel of the rebuilt rows) packs into 64 bits:
+//   [15:0] valA = vertical average (outcome A)   [31:16] valB   [47:32] newB = outcome-B direction value
+//   bit 48 = "always A" (direction == peak)      bit 49 = right-hand test |d[x] - d[x+1]| > lim
+// q_lattice_resolve16 (one workgroup per row) resolves which outcome each pixel takes: every pixel is a 2-state map of
+// its left neighbour's outcome, composed by a prefix scan, and writes the row.
+__global__ __launch_bounds__(256) void q_lattice_cand(Q3 P, K16 k, int field, int nt, unsigned long long *__restrict__ cand,
+                                                      int cand_pitch, int cand_plane_stride)
+{
+    const int pl = blockIdx.z;
+    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    const int nrows = (height - 1 - (2 - field) + 1) / 2;
+    if (x >= width || r >= nrows) return;
+    const int y = (2 - field) + 2 * r;
+    const int peak = k.peak, neutral = k.neutral, sh = k.shift, sh2 = 2 + k.shift;
+    const int nt4 = (uint16_t)((nt << sh) * 4), nt7 = (uint16_t)((nt << sh) * 7), nt8 = (uint16_t)((nt << sh) * 8);
+    const int three = 3 << sh, nine = 9 << sh;
+    const uint16_t *top = P.b[pl] + (size_t)(y - 1) * pitch, *bot = top + 2 * (size_t)pitch;
+    const uint16_t *ot = P.c[pl] + (size_t)(y - 1) * pitch, *ob = ot + 2 * (size_t)pitch;
+    const uint16_t *dm = P.a[pl] + (size_t)y * pitch;
+    int dir = dm[x];
+    const int here = dir;
+    const int lim = k.limlut[iabs16(dir - neutral) >> sh2];
+    const int avg = ((int)top[x] + (int)bot[x] + 1) >> 1;
+    const bool always_a = dir == peak;
+    const bool right = iabs16(here - (int)dm[x + 1]) > lim;
+    int valB = avg, newB = neutral;
+    if (!always_a)
+    {
+        bool done = false;
+        if (lim < nine)
+        {
+            const int sum = ((int)top[x - 1] + (int)top[x] + (int)top[x + 1] + (int)bot[x - 1] + (int)bot[x] + (int)bot[x + 1]) >> sh;
+            auto sq = [&](int v) { return (v >> sh) * (v >> sh); };
+            const int sumsq = sq(top[x - 1]) + sq(top[x]) + sq(top[x + 1]) + sq(bot[x - 1]) + sq(bot[x]) + sq(bot[x + 1]);
+            if (6 * sumsq - sum * sum < 576) { valB = avg; newB = peak; done = true; }
+        }
+        if (!done && x > 1 && x < width - 2 &&
+            (((int)top[x] < max((int)top[x - 2], (int)top[x - 1]) - three && (int)top[x] < max((int)top[x + 2], (int)top[x + 1]) - three &&
+              (int)bot[x] < max((int)bot[x - 2], (int)bot[x - 1]) - three && (int)bot[x] < max((int)bot[x + 2], (int)bot[x + 1]) - three) ||
+             ((int)top[x] > min((int)top[x - 2], (int)top[x - 1]) + three && (int)top[x] > min((int)top[x + 2], (int)top[x + 1]) + three &&
+              (int)bot[x] > min((int)bot[x - 2], (int)bot[x - 1]) + three && (int)bot[x] > min((int)bot[x + 2], (int)bot[x + 1]) + three)))
+        { valB = avg; newB = neutral; done = true; }
+        if (!done)
+        {
+            dir = (dir - neutral + (1 << (sh2 - 1))) >> sh2;
+            int val = avg;
+            const int startu = (dir - 2 < 0) ? max(-x + 1, max(dir - 2, -width + 2 + x)) : min(x - 1, min(dir - 2, width - 2 - x));
+            const int stopu = (dir + 2 < 0) ? max(-x + 1, max(dir + 2, -width + 2 + x)) : min(x - 1, min(dir + 2, width - 2 - x));
+            int mn = nt8;
+            auto near = [&](const uint16_t *row, int i) { return row[i] != peak && iabs16((int)row[i] - here) <= lim; };
+            for (int u = startu; u <= stopu; u++)
+            {
+                const int diff = sad3w(top, x, bot, x - u) + sad3w(bot, x, top, x + u);
+                if (!(diff < mn && (near(ot, x - 1 + u) || near(ot, x + u) || near(ot, x + 1 + u)) &&
+                      (near(ob, x - 1 - u) || near(ob, x - u) || near(ob, x + 1 - u))))
+                    continue;
+                const int h0 = u >> 1, h1 = (u + 1) >> 1;
+                const int diff2 = sad3w(top, x + h0, bot, x - h0);
+                if (!(diff2 < nt4 &&
+                      (((iabs16((int)ot[x + h0] - (int)ob[x - h0]) <= lim || iabs16((int)ot[x + h0] - (int)ob[x - h1]) <= lim) && ot[x + h0] != peak) ||
+                       ((iabs16((int)ot[x + h1] - (int)ob[x - h0]) <= lim || iabs16((int)ot[x + h1] - (int)ob[x - h1]) <= lim) && ot[x + h1] != peak))))
+                    continue;
+                if ((iabs16(here - (int)ot[x + h0]) <= lim || iabs16(here - (int)ot[x + h1]) <= lim) &&
+                    (iabs16(here - (int)ob[x - h0]) <= lim || iabs16(here - (int)ob[x - h1]) <= lim))
+                {
+                    val = ((int)top[x + h0] + (int)top[x + h1] + (int)bot[x - h0] + (int)bot[x - h1] + 2) >> 2;
+                    mn = diff;
+                    dir = u;
+                }
+            }
+            if (mn != nt8)
+            {
+                valB = val;
+                newB = (uint16_t)(neutral + (dir << sh2));
+            }
+            else
+            {
+                const int lo = min((int)top[x], (int)bot[x]), hi = max((int)top[x], (int)bot[x]);
+                const int d = pl == 0 ? 4 : 2;
+                const int su = max(-x + 1, -d), eu = min(width - 2 - x, d);
+                mn = nt7;
+                for (int u = su; u <= eu; u++)
+                {
+                    const int h0 = u >> 1, h1 = (u + 1) >> 1;
+                    const int p1 = (int)top[x + h0] + (int)top[x + h1];
+                    const int p2 = (int)bot[x - h0] + (int)bot[x - h1];
+                    const int diff = sad3w(top, x, bot, x - u) + sad3w(bot, x, top, x + u) + iabs16(p1 - p2);
+                    if (diff < mn)
+                    {
+                        const int valt = (p1 + p2 + 2) >> 2;
+                        if (valt >= lo && valt <= hi) { val = valt; mn = diff; dir = u; }
+                    }
+                }
+                valB = val;
+                newB = (mn == 7 * nt) ? neutral : (int)(uint16_t)(neutral + (dir << sh2));      // unshifted 7*nt (:1324)
+            }
+        }
+    }
+    cand[(size_t)pl * cand_plane_stride + (size_t)r * cand_pitch + x] =
+        (unsigned long long)(uint16_t)avg | ((unsigned long long)(uint16_t)valB << 16) | ((unsigned long long)(uint16_t)newB << 32) |
+        ((unsigned long long)always_a << 48) | ((unsigned long long)right << 49);
+}
+
+constexpr int LR16_T = 1024;
+
+__global__ __launch_bounds__(LR16_T) void q_lattice_resolve16(Q3 P, K16 k, int field, const unsigned long long *__restrict__ cand,
+                                                              int cand_pitch, int cand_plane_stride)
+{
+    __shared__ uint8_t s_wmap[LR16_T / 64];        // composed map of each wave
+    __shared__ uint8_t s_win[LR16_T / 64];         // resolved state entering each wave
+    __shared__ int s_carry;                        // outcome of the last pixel of the previous pass
+    const int pl = blockIdx.z;
+    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int nrows = (height - 1 - (2 - field) + 1) / 2;
+    uint16_t *dst = P.b[pl];
+    if ((int)blockIdx.y >= nrows)
+    {
+        if ((int)blockIdx.y == nrows)                              // the one-row blit (:1162-1179)
+            for (int xx = t; xx < width; xx += LR16_T)
+            {
+                if (field == 1) dst[(size_t)(height - 1) * pitch + xx] = dst[(size_t)(height - 2) * pitch + xx];
+                else            dst[xx] = dst[pitch + xx];
+            }
+        return;
+    }
+    const int y = (2 - field) + 2 * blockIdx.y;
+    uint16_t *mid = dst + (size_t)y * pitch;
+    uint16_t *dm = P.a[pl] + (size_t)y * pitch;
+    const unsigned long long *cr = cand + (size_t)pl * cand_plane_stride + (size_t)blockIdx.y * cand_pitch;
+    const int sh2 = 2 + k.shift;
+    const int before_row = dm[-1];                                 // stands at dm[x-1] for x == 0; never written by this pass
+    if (t == 0) s_carry = 0;
+    __syncthreads();
+    for (int x0 = 0; x0 < width; x0 += LR16_T)
+    {
+        const int x = x0 + t;
+        const bool live = x < width;
+        int d = 0, lim = 0, valA = 0, newA = 0, valB = 0, newB = 0;
+        bool always_a = false, right = false;
+        if (live)
+        {
+            const unsigned long long c = cr[x];
+            d = dm[x];
+            lim = k.limlut[iabs16(d - k.neutral) >> sh2];
+            valA = (int)(c & 0xffff); valB = (int)((c >> 16) & 0xffff); newB = (int)((c >> 32) & 0xffff);
+            always_a = (c >> 48) & 1; right = (c >> 49) & 1;
+            newA = always_a ? k.peak : k.neutral;
+        }
+        int pa = __shfl_up(newA, 1, 64), pb = __shfl_up(newB, 1, 64);
+        if (lane == 0 && live)
+        {
+            if (x == 0) { pa = before_row; pb = before_row; }
+            else
+            {
+                const unsigned long long cl = cr[x - 1];
+                pa = ((cl >> 48) & 1) ? k.peak : k.neutral;
+                pb = (int)((cl >> 32) & 0xffff);
+            }
+        }
+        unsigned m;                                            // bit s = outcome when the left pixel took outcome s
+        if (!live || always_a) m = 0u;
+        else
+        {
+            const unsigned oa = (right && iabs16(d - pa) > lim) ? 0u : 1u;
+            const unsigned ob2 = (right && iabs16(d - pb) > lim) ? 0u : 1u;
+            m = oa | (ob2 << 1);
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1)
+        {
+            const unsigned e = __shfl_up(m, off, 64);
+            if (lane >= off)
+                m = ((m >> (e & 1u)) & 1u) | (((m >> ((e >> 1) & 1u)) & 1u) << 1);
+        }
+        if (lane == 63) s_wmap[wave] = (uint8_t)m;
+        __syncthreads();
+        if (t == 0)
+        {
+            unsigned state = (unsigned)s_carry;                  // outcome of pixel x0 - 1 (irrelevant for x0 == 0)
+            for (int w = 0; w < LR16_T / 64; w++)
+            {
+                s_win[w] = (uint8_t)state;
+                state = (s_wmap[w] >> state) & 1u;
+            }
+        }
+        __syncthreads();
+        const unsigned outcome = (m >> s_win[wave]) & 1u;
+        if (live)
+        {
+            mid[x] = (uint16_t)(outcome ? valB : valA);
+            const int nd = outcome ? newB : newA;
+            if (nd != d) dm[x] = (uint16_t)nd;
+        }
+        if (x == min(x0 + LR16_T, width) - 1) s_carry = (int)outcome;
+        __syncthreads();
+    }
+}
+
 // eedi2_post_process (:1349-1378): a = new direction map, b = old one, c = dst2p (in place, rows y from y+-1)
 __global__ void q_post(Q3 P, K16 k, int y0)
 {
@@ -656,6 +859,7 @@ Eedi2Engine16::Eedi2Engine16(hbhip_ctx *ctx, const PicGeometry &geo, const Eedi2
 
 Eedi2Engine16::~Eedi2Engine16()
 {
+    if (cand_) (void)hipFree(cand_);
     for (auto &f : half_) if (f.alloc) (void)hipFree(f.alloc);
     for (auto &f : full_) if (f.alloc) (void)hipFree(f.alloc);
     for (int i = 0; i < 3; i++)
@@ -702,6 +906,10 @@ int Eedi2Engine16::init()
             HBHIP_CHECK(ctx_, hipMemsetAsync(deriv_tmp_[i], 0, n, ctx_->stream));
         }
     }
+    // interpolate_lattice: per-pixel candidate outcomes of the rebuilt rows (every other row of the full-height frame)
+    cand_pitch_ = full_[0].stride[0] / 2;
+    cand_plane_stride_ = cand_pitch_ * ((full_[0].height[0] + 1) / 2);
+    HBHIP_CHECK(ctx_, hipMalloc((void **)&cand_, sizeof(unsigned long long) * 3 * (size_t)cand_plane_stride_));
     HBHIP_CHECK(ctx_, hipStreamSynchronize(ctx_->stream));
     return HBHIP_OK;
 }
@@ -787,8 +995,17 @@ int Eedi2Engine16::run(const DevPicture *cur, int tff)
     bind(P.a, tmp2p); bind(P.b, dst2p); bind(P.c, tmp2p2);
     {
         const int nrows = (dst2p.height[0] - 1 - y0 + 1) / 2;
-        HBHIP_LAUNCH(ctx_, "eedi2_16_interpolate_lattice", q_lattice, dim3((nrows + 1 + 63) / 64, 1, 3), dim3(64), 0, P, k, tff,
-                     par_.noise_threshold);
+        static const bool serial = getenv("HBHIP_EEDI2_16_SERIAL_LATTICE") != nullptr;     // A/B switch: one thread per row
+        if (serial || !cand_)
+            HBHIP_LAUNCH(ctx_, "eedi2_16_interpolate_lattice", q_lattice, dim3((nrows + 1 + 63) / 64, 1, 3), dim3(64), 0, P, k, tff,
+                         par_.noise_threshold);
+        else
+        {
+            HBHIP_LAUNCH(ctx_, "eedi2_16_lattice_candidates", q_lattice_cand, dim3((dst2p.width[0] + 255) / 256, nrows, 3), dim3(256), 0, P, k,
+                         tff, par_.noise_threshold, cand_, cand_pitch_, cand_plane_stride_);
+            HBHIP_LAUNCH(ctx_, "eedi2_16_lattice_resolve", q_lattice_resolve16, dim3(1, nrows + 1, 3), dim3(LR16_T), 0, P, k, tff,
+                         (const unsigned long long *)cand_, cand_pitch_, cand_plane_stride_);
+        }
     }
     if (par_.post_processing == 1 || par_.post_processing == 3)
     {

@@ -111,6 +111,8 @@ private:
     Eedi2Params par_;
     EediFrame   half_[4];    // SRCPF, MSKPF, TMPPF, DSTPF
     EediFrame   full_[5];    // DST2PF, TMP2PF2, MSK2PF, TMP2PF, DST2MPF
+    unsigned long long *cand_ = nullptr;   // interpolate_lattice: per-pixel candidate outcomes
+    int         cand_pitch_ = 0, cand_plane_stride_ = 0;
     int        *deriv_[3] = {nullptr, nullptr, nullptr};
     int        *deriv_tmp_[3] = {nullptr, nullptr, nullptr};
 };

@@ -3,7 +3,7 @@
 # trace + PMC passes of the default bench workload.  Everything lands under gpurun_out/<tag>/.
 # Usage: tools/gpu_round.sh <tag> [tests|notests] [extra pytest args...]
 set -u
-TAG=${1:-r02a}; MODE=${2:-tests}; shift 2 || true
+TAG=${1:-r02z}; MODE=${2:-tests}; shift 2 || true
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -15,11 +15,18 @@ if [ "$MODE" = "tests" ]; then
   tail -5 $OUT/pytest.log
 fi
 [ -x tools/valu_rate ] && timeout 300 tools/valu_rate $OUT/valu_rate.json > $OUT/valu_rate.log 2>&1
-for WL in chain nlmeans decomb_eedi2 chain2160; do
-  timeout 600 python bench.py --workload $WL --steps 20 --warmup 3 > $OUT/bench_$WL.json 2> $OUT/bench_$WL.err
-  head -c 1500 $OUT/bench_$WL.json; echo
+# the driver's command line first (defaults), then the other workloads
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err
+head -c 1200 $OUT/bench_default.json; echo
+for WL in chain2160 decomb_eedi2 nlmeans; do
+  timeout 600 python bench.py --workload $WL --steps 20 --warmup 3 --no-pcie > $OUT/bench_$WL.json 2> $OUT/bench_$WL.err
+  head -c 600 $OUT/bench_$WL.json; echo
 done
-timeout 300 python bench.py --workload chain --streams 2 --no-cpu-baseline --no-pcie --no-kernel-timer > $OUT/bench_chain_2streams.json 2>> $OUT/bench_chain.err
+timeout 300 python bench.py --workload decomb_eedi2 --depth 10 --no-cpu-baseline --no-pcie > $OUT/bench_decomb_eedi2_10bit.json 2> $OUT/bench_decomb_eedi2_10bit.err
+timeout 300 python bench.py --workload chain --stage-streams 1 --no-cpu-baseline --no-pcie --no-kernel-timer > $OUT/bench_chain_stage_streams.json 2>> $OUT/bench_default.err
+timeout 300 python bench.py --workload chain --streams 2 --no-cpu-baseline --no-pcie --no-kernel-timer > $OUT/bench_chain_2streams.json 2>> $OUT/bench_default.err
+timeout 300 python bench.py --workload chain --comb-detect --no-cpu-baseline --no-pcie --no-kernel-timer > $OUT/bench_chain_combdetect.json 2>> $OUT/bench_default.err
+timeout 600 python tools/kernel_rooflines.py > $OUT/kernel_rooflines.json 2> $OUT/kernel_rooflines.err
 cd /tmp
 PROF="python $R/bench.py --workload chain --steps 6 --warmup 2 --no-cpu-baseline --no-pcie --no-kernel-timer"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $PROF > $OUT/kt.log 2>&1
@@ -32,6 +39,6 @@ cd $R
 python tools/summarize_pmc.py $OUT $OUT/pmc_summary.json > /dev/null 2>&1
 # keep only small files
 find $OUT -name '*kernel_trace.csv' -size +3M -delete
-find $OUT -name '*counter_collection.csv' -size +3M -delete
+find $OUT -name '*counter_collection.csv' -delete
 find $OUT -name '*.db' -delete
 du -sh $OUT
