@@ -485,11 +485,13 @@ def run_chain(args, world, rank, local_rank):
         total_ms = sum(ms for _, (_, ms) in top) or 1.0
         kernels = []
         for k, (n, ms) in top[:24]:
-            # the profiled pass ran 2 steps = 4 B frames through NLMeans, in n launches
-            ab = algorithmic_bytes(k, W, H, OW, OH, frames_per_launch=4 * B / n if k.startswith("nlmeans_plane") else 1)
-            ab = int(ab) if ab else ab
+            # the profiled pass ran 2 steps = 4 B output frames; NLMeans, the blend and lapsharp take the frames of a
+            # batch in one launch, everything else runs once per field / frame
+            fpl = 4 * B / n if (k.startswith("nlmeans_plane") or k in ("decomb_plane", "lapsharp_3x3", "lapsharp_5x5")) else 1
+            ab = algorithmic_bytes(k, W, H, OW, OH, frames_per_launch=fpl if k.startswith("nlmeans_plane") else 1)
+            ab = int(ab * (1 if k.startswith("nlmeans_plane") else fpl)) if ab else ab
             avg = ms / n / 1e3
-            kernels.append({"kernel": k, "launches": n, "avg_us": round(avg * 1e6, 2), "share": round(ms / total_ms, 4),
+            kernels.append({"kernel": k, "launches": n, "frames_per_launch": round(fpl, 2), "avg_us": round(avg * 1e6, 2), "share": round(ms / total_ms, 4),
                             "algorithmic_bytes_per_launch": ab,
                             "frac_of_hbm_peak": None if ab is None else round(ab / avg / 1e9 / HBM_PEAK_GBS, 5)})
         roof = None
@@ -498,13 +500,16 @@ def run_chain(args, world, rank, local_rank):
             ab = d["algorithmic_bytes_per_launch"]
             if ab:
                 achieved = ab / (d["avg_us"] * 1e-6) / 1e9
-                traffic, _ = pmc_record(d["kernel"], 1)
+                traffic, valu = pmc_record(d["kernel"], int(round(d["frames_per_launch"])))
                 roof = {"bound": "hbm", "kernel": d["kernel"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                         "launch_us": d["avg_us"], "launches": d["launches"], "share_of_gpu_time": d["share"],
                         "algorithmic_bytes_per_launch": ab,
                         "note": "dominant kernel of the chain = largest share of summed kernel time in the event-"
-                                "bracketed pass that follows the timed region"}
+                                "bracketed pass that follows the timed region; its bytes are small against its "
+                                "arithmetic (a +-24 step search per edge pixel), see `valu`"}
+                if valu:
+                    roof["valu"] = valu_roofline(valu, d["avg_us"] * 1e-6)
         per_out = {"chain": 62_208_000, "chain2160": 4 * frame_bytes(W, H) + 3 * frame_bytes(W, H) + 2 * frame_bytes(W, H),
                    "decomb_eedi2": 4 * frame_bytes(W, H)}[args.workload]      # SURVEY §8d, per output frame
         line = {
