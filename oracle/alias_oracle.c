@@ -232,7 +232,13 @@ void orc_cropscale_plane_d(const void *src, int sstride, int crop_x, int crop_y,
  * subsampling - and fills the rest with one colour.  The colour is given as RGB and converted the
  * way drawutils.c:ff_draw_color does: Y'CbCr through the (Kr, Kb) of the frame's matrix (BT.601 when
  * unspecified), scaled to the frame's range (limited when unspecified), component = (unsigned)(v *
- * ((1 << depth) - 1) + 0.5) with v in [0, 1]. */
+ * ((1 << depth) - 1) + 0.5) with v in [0, 1].
+ * The reference's own restatement of the copy-or-fill step, platform/macosx/shaders/pad_vt.metal (a port of
+ * FFmpeg's pad.cl): a destination sample at `pos` is the fill colour when pos.x < offset.x, pos.y < offset.y,
+ * pos.x >= src_width + offset.x or pos.y >= src_height + offset.y, else the source sample at pos - offset
+ * (:54-58, :72-73) - the test orc_pad_plane applies per plane with the offsets shifted by the plane's
+ * subsampling; the shader receives the colour already converted (color_y / color_u / color_v, :19-27), which
+ * is what orc_pad_color computes. */
 void orc_pad_color(int rgb, int matrix, int full_range, int depth, int out[3])
 {
     double kr = 0.299, kb = 0.114;                              /* smpte170m, also the fallback */

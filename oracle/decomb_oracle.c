@@ -59,7 +59,23 @@ void orc_decomb_plane16(const uint16_t *prev, const uint16_t *cur, const uint16_
  * filter_slice), which is not part of /root/reference; restated from its published source.
  * One plane: rows with ((y ^ parity) & 1) are rebuilt, the others copied from `cur`.
  * field_parity = parity ^ tff picks the same-parity neighbours (prev2 / next2); nospatial = the
- * send_*_nospatial modes (no vertical-neighbour widening of the temporal bound). */
+ * send_*_nospatial modes (no vertical-neighbour widening of the temporal bound).
+ *
+ * The reference tree does hold one restatement of this filter: platform/macosx/shaders/yadif_vt.metal (a
+ * port of FFmpeg's vf_yadif_cuda, used by the VideoToolbox build).  Line by line against it:
+ *   kept field copied                          metal :264-269  `pos.y % 2 == params.parity`  = rows with !((y ^ parity) & 1)
+ *   prev2 / next2 choice                       metal :241-245  is_second_field ? (prev, cur | next, next) : (prev, prev | cur, next)
+ *                                                               = prev2 = field_parity ? prev : cur, next2 = field_parity ? cur : next
+ *   c, d, e and the three temporal differences  metal :121-131  p1 = F, p2 = (D + I) / 2, p3 = G, tdiff0..2, diff = max3
+ *                                                               (here td0 is halved before the max, as filter_line_c does: `temporal_diff0 >> 1`;
+ *                                                               the shader's `tdiff0 = abs(D - I)` is not - a difference of the CUDA port)
+ *   vertical-neighbour widening                 metal :133-137  maxi / mini over p0..p4  = b, f, max / min below
+ *   spatial prediction and the +-1, +-2 checks  metal :87-114   (d + k) / 2 then the two nested score tests each side = CHECK(-1) CHECK(-2), CHECK(1) CHECK(2)
+ *   clamp to d +- diff                          metal :139
+ * Where the two differ this file follows vf_yadif.c, which is what libhb's own (non-Apple) Deinterlace filter
+ * runs through libavfilter: integer arithmetic with `>> 1` where the shader divides floats by 2, the first
+ * spatial score reduced by 1 (`- 1` in filter_line_c, absent in the shader), and no diagonal checks within 3
+ * columns of the left / right edge (filter_edges) where the shader's sampler clamps coordinates instead. */
 static inline int yd_px(const void *p, long at, int bps)
 {
     return bps == 1 ? ((const uint8_t *)p)[at] : ((const uint16_t *)p)[at];
