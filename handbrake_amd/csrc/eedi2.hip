@@ -1579,6 +1579,206 @@ __global__ __launch_bounds__(256) void k_fill_gaps_c(P3 P, int y0)
     }
 }
 
+// k_fill_gaps_c with the walks done on bitmaps (the form that runs).  Every pixel of a gap walks the gap's whole length
+// on dependent byte reads in k_fill_gaps_c - 1.9 M VALU instructions in a 24.7 us kernel: its time is the longest
+// chain, and meanwhile its waves hold slots the other engines' kernels wait for.  Here the staged rows are first
+// turned into four bit rows (ballots), and a pixel finds its gap's ends, and whether the rows above / below break
+// the gap's support, with a few 64-bit operations; only the min / max over a supported gap still walks bytes
+// (independent reads).  Walks that leave the staged span take the byte path (rare).
+__global__ __launch_bounds__(256) void k_fill_gaps_b(P3 P, int y0)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_r[7][FG_LW];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[FG_W];
+    __shared__ uint16_t s_list[FG_W];
+    __shared__ int s_count;
+    __shared__ uint64_t s_stop[FG_LW / 64 + 1], s_np[FG_LW / 64 + 1], s_bt[FG_LW / 64 + 1], s_bb[FG_LW / 64 + 1];   // one bit per staged column
+    const int pl = blockIdx.z, y = blockIdx.y;
+    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
+    const int x0 = blockIdx.x * FG_W, tid = threadIdx.x;
+    if (y >= height || x0 >= width) return;
+    const uint8_t *dcg = P.b[pl] + (size_t)y * pitch;
+    uint8_t *og = P.c[pl] + (size_t)y * pitch;
+    const int x = x0 + 4 * tid;
+    if (!(y >= y0 && y < height - 1 && ((y - y0) & 1) == 0))
+    {
+        if (x < width)
+        {
+            const uint32_t v = *reinterpret_cast<const uint32_t *>(dcg + x);
+            if (x + 3 < width) *reinterpret_cast<uint32_t *>(og + x) = v;
+            else for (int k = 0; k < 4 && x + k < width; k++) og[x + k] = (uint8_t)(v >> (8 * k));
+        }
+        return;
+    }
+    if (tid == 0) s_count = 0;
+    const uint8_t *g[7] = { dcg, P.a[pl] + (ptrdiff_t)(y - 1) * pitch, P.a[pl] + (ptrdiff_t)(y + 1) * pitch,
+                            dcg - 2 * (ptrdiff_t)pitch, dcg + 2 * (ptrdiff_t)pitch,
+                            P.a[pl] + (ptrdiff_t)(y - 3) * pitch, P.a[pl] + (ptrdiff_t)(y + 3) * pitch };
+    const int lo = x0 - FG_HALO;                                   // column of staged byte 0 (a multiple of 4)
+    const int ndw = (min(FG_W, hbhip_align_up_dev(width - x0, 4)) + 2 * FG_HALO) / 4;
+    {
+        // all loads of a thread in flight before the first LDS store (ndw <= 288: two dwords per row and thread)
+        uint32_t v[7][2];
+#pragma unroll
+        for (int r = 0; r < 7; r++)
+#pragma unroll
+            for (int k = 0; k < 2; k++)
+            {
+                const int i = tid + 256 * k;
+                v[r][k] = i < ndw ? reinterpret_cast<const uint32_t *>(g[r] + lo)[i] : 0u;
+            }
+#pragma unroll
+        for (int r = 0; r < 7; r++)
+#pragma unroll
+            for (int k = 0; k < 2; k++)
+            {
+                const int i = tid + 256 * k;
+                if (i < ndw) reinterpret_cast<uint32_t *>(s_r[r])[i] = v[r][k];
+            }
+    }
+    __syncthreads();
+    enum { DC = 0, MC = 1, MN = 2, DP = 3, DN = 4, MP = 5, MNN = 6 };
+    const unsigned staged = 4u * (unsigned)ndw;
+    // Per staged column: does a walk stop here (a known direction, or outside the mask: :1055-1058), is the direction
+    // known, does the row above / below end the "top / bottom continues" state (:1078-1093).  The walks then are
+    // bit scans instead of chains of dependent byte reads.
+    for (int k = 0; k < (FG_LW + 255) / 256; k++)
+    {
+        const unsigned col = tid + 256 * k;
+        bool np = false, stop = false, bt = false, bb = false;
+        if (col < staged)
+        {
+            const bool mc = s_r[MC][col] == PEAK, mn = s_r[MN][col] == PEAK;
+            np = s_r[DC][col] != PEAK;
+            stop = np || (!mc && !mn);
+            bt = s_r[DP][col] == PEAK || (s_r[MP][col] != PEAK && !mc);
+            bb = s_r[DN][col] == PEAK || (!mn && s_r[MNN][col] != PEAK);
+        }
+        const uint64_t w0 = __ballot(stop), w1 = __ballot(np), w2 = __ballot(bt), w3 = __ballot(bb);
+        if ((tid & 63) == 0 && (col >> 6) < FG_LW / 64 + 1) { s_stop[col >> 6] = w0; s_np[col >> 6] = w1; s_bt[col >> 6] = w2; s_bb[col >> 6] = w3; }
+    }
+    if (x < width)
+    {
+        const int c = 4 * tid + FG_HALO;
+        const uint32_t cw = *reinterpret_cast<const uint32_t *>(&s_r[DC][c]);
+        const uint32_t mcw = *reinterpret_cast<const uint32_t *>(&s_r[MC][c]), mnw = *reinterpret_cast<const uint32_t *>(&s_r[MN][c]);
+        *reinterpret_cast<uint32_t *>(&s_out[4 * tid]) = cw;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            const int xx = x + k;
+            if (xx >= 1 && xx < width - 1 && ((cw >> (8 * k)) & 0xff) == PEAK &&
+                (((mcw >> (8 * k)) & 0xff) == PEAK || ((mnw >> (8 * k)) & 0xff) == PEAK))
+                s_list[atomicAdd(&s_count, 1)] = (uint16_t)(4 * tid + k);
+        }
+    }
+    __syncthreads();
+    const int count = s_count;
+    auto rd = [&](int r, int col) -> int {
+        const unsigned k = (unsigned)(col - lo);
+        return k < staged ? (int)s_r[r][k] : (int)g[r][col];
+    };
+    for (int i = tid; i < count; i += 256)
+    {
+        const int lx = s_list[i], px = x0 + lx;
+        int u = px - 1, back = 500, forward = -500;
+        int v = px + 1;
+        int tc = 1, bc = 1, mint = 500, maxt = -20, minb = 500, maxb = -20;
+        // the two walks as bit scans over the staged columns [first, last) = plane columns [max(lo, 1), min(lo + staged, width))
+        const int c = px - lo;
+        const int first = max(1 - lo, 0), last = min((int)staged, width - lo);
+        int ul = -1, vl = -1;
+        for (int wi = (c - 1) >> 6; wi >= (first >> 6) && c - 1 >= first; wi--)      // highest stop bit in [first, c - 1]
+        {
+            uint64_t w = s_stop[wi];
+            if (wi == ((c - 1) >> 6) && ((c - 1) & 63) != 63) w &= (2ull << ((c - 1) & 63)) - 1ull;
+            if (wi == (first >> 6)) w &= ~0ull << (first & 63);
+            if (w) { ul = 64 * wi + 63 - __clzll((long long)w); break; }
+        }
+        for (int wi = (c + 1) >> 6; wi <= ((last - 1) >> 6) && c + 1 < last; wi++)   // lowest stop bit in [c + 1, last - 1]
+        {
+            uint64_t w = s_stop[wi];
+            if (wi == ((c + 1) >> 6)) w &= ~0ull << ((c + 1) & 63);
+            if (wi == ((last - 1) >> 6) && ((last - 1) & 63) != 63) w &= (2ull << ((last - 1) & 63)) - 1ull;
+            if (w) { vl = 64 * wi + __ffsll((long long)w) - 1; break; }
+        }
+        // inside the staged span when each walk found its stop there or ran into the row end inside it
+        const bool fast = (ul >= 0 || lo <= 1) && (vl >= 0 || lo + (int)staged > width);     // column `width` itself must be staged too
+        if (fast)
+        {
+            if (ul >= 0) { u = lo + ul; if ((s_np[ul >> 6] >> (ul & 63)) & 1ull) back = s_r[DC][ul]; }
+            else u = 0;
+            if (vl >= 0) { v = lo + vl; if ((s_np[vl >> 6] >> (vl & 63)) & 1ull) forward = s_r[DC][vl]; }
+            else v = width;
+            // columns u .. v (v = width included, as the reference's loop includes it) are staged
+            const int a0 = u - lo, a1 = v - lo;
+            auto any_in = [&](const uint64_t *bits) {
+                for (int wi = a0 >> 6; wi <= (a1 >> 6); wi++)
+                {
+                    uint64_t w = bits[wi];
+                    if (wi == (a0 >> 6)) w &= ~0ull << (a0 & 63);
+                    if (wi == (a1 >> 6) && (a1 & 63) != 63) w &= (2ull << (a1 & 63)) - 1ull;
+                    if (w) return true;
+                }
+                return false;
+            };
+            if (y <= 2 || any_in(s_bt)) { tc = 0; mint = maxt = 20; }
+            else for (int j = a0; j <= a1; j++) { const int t = s_r[DP][j]; mint = min(mint, t); maxt = max(maxt, t); }
+            if (y >= height - 3 || any_in(s_bb)) { bc = 0; minb = maxb = 20; }
+            else for (int j = a0; j <= a1; j++) { const int t = s_r[DN][j]; minb = min(minb, t); maxb = max(maxb, t); }
+        }
+        else
+        {
+        while (u)
+        {
+            const int d = rd(DC, u);
+            if (d != PEAK) { back = d; break; }
+            if (rd(MC, u) != PEAK && rd(MN, u) != PEAK) break;
+            u--;
+        }
+        while (v < width)
+        {
+            const int d = rd(DC, v);
+            if (d != PEAK) { forward = d; break; }
+            if (rd(MC, v) != PEAK && rd(MN, v) != PEAK) break;
+            v++;
+        }
+        }
+        for (int j = u; !fast && j <= v; j++)
+        {
+            if (tc)
+            {
+                int t;
+                if (y <= 2 || (t = rd(DP, j)) == PEAK || (rd(MP, j) != PEAK && rd(MC, j) != PEAK)) { tc = 0; mint = maxt = 20; }
+                else { mint = min(mint, t); maxt = max(maxt, t); }
+            }
+            if (bc)
+            {
+                int t;
+                if (y >= height - 3 || (t = rd(DN, j)) == PEAK || (rd(MN, j) != PEAK && rd(MNN, j) != PEAK)) { bc = 0; minb = maxb = 20; }
+                else { minb = min(minb, t); maxb = max(maxb, t); }
+            }
+        }
+        if (maxt == -20) maxt = mint = 20;
+        if (maxb == -20) maxb = minb = 20;
+        const int far = max(iabs(forward - NEUTRAL), iabs(back - NEUTRAL));
+        const int thresh = max(max(far >> 2, 8), max(iabs(mint - maxt), iabs(minb - maxb)));
+        const int flim = min(far >> 2, 6);
+        if (iabs(forward - back) <= thresh && (v - u - 1 <= flim || tc || bc))
+        {
+            const double stepd = (double)(forward - back) / (double)(v - u);
+            const int j = px - u - 1;
+            s_out[lx] = (uint8_t)((back + (int)(j * stepd + 0.5)) & 0xff);
+        }
+    }
+    __syncthreads();
+    if (x < width)
+    {
+        const uint32_t v = *reinterpret_cast<const uint32_t *>(&s_out[4 * tid]);
+        if (x + 3 < width) *reinterpret_cast<uint32_t *>(og + x) = v;
+        else for (int k = 0; k < 4 && x + k < width; k++) og[x + k] = (uint8_t)(v >> (8 * k));
+    }
+}
+
 // Everything k_lattice_cand packs for one pixel; the row pointers are indexed by the absolute column.
 __device__ __forceinline__ uint32_t lattice_px(const uint8_t *top, const uint8_t *bot, const uint8_t *ot, const uint8_t *ob,
                                                const uint8_t *dm, int x, int width, int pl, int nt4, int nt7, int nt8, int nt)
@@ -2451,8 +2651,10 @@ int Eedi2Engine::enqueue_passes(int tff, int sel, hbhip_ctx *lc)
     dir_map("eedi2_expand_dir_map_2x", dst2p, P, 2, y0, 1);
     auto fill_gaps = [&](const P3 &Pv) {
         if (one_px) HBHIP_LAUNCH(lc, "eedi2_fill_gaps_2x", k_fill_gaps, grid_for(dst2p, false), blk, 0, Pv, y0);
-        else        HBHIP_LAUNCH(lc, "eedi2_fill_gaps_2x", k_fill_gaps_c, dim3((dst2p.width[0] + FG_W - 1) / FG_W, dst2p.height[0], 3),
-                                 dim3(256), 0, Pv, y0);
+        else if (getenv("HBHIP_EEDI2_FILLGAPS_WALK"))                                   // A/B switch: the byte walks
+            HBHIP_LAUNCH(lc, "eedi2_fill_gaps_2x", k_fill_gaps_c, dim3((dst2p.width[0] + FG_W - 1) / FG_W, dst2p.height[0], 3), dim3(256), 0, Pv, y0);
+        else
+            HBHIP_LAUNCH(lc, "eedi2_fill_gaps_2x", k_fill_gaps_b, dim3((dst2p.width[0] + FG_W - 1) / FG_W, dst2p.height[0], 3), dim3(256), 0, Pv, y0);
     };
     bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
     fill_gaps(P);
