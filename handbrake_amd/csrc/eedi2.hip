@@ -406,7 +406,13 @@ __device__ __forceinline__ void mf_morph4(const uint32_t (*src)[MF_DP], uint32_t
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_mask_fused4(P3 P, int mth, int vth, int lth, int erode_thr, int dilate_thr)
+// FROM_FRAME: the field extraction (eedi2_fill_half, decomb_template.c:455-473) rides along: the source rows are
+// read from the frame itself (P.d = its planes, row start_line + 2y at pitch spitch[pl]) and the tile's own part of
+// SRCPF (P.a) is written for the passes that follow; bytes at x >= width read as 0, as fill_half writes them.
+struct MaskSrc { int spitch[3], start_line; };
+
+template <bool FROM_FRAME>
+__global__ __launch_bounds__(256) void k_mask_fused4(P3 P, MaskSrc S, int mth, int vth, int lth, int erode_thr, int dilate_thr)
 {
     __shared__ uint32_t s_src[MF_LR][MF_DP];
     __shared__ uint32_t s_a[MF_LR][MF_DP];
@@ -424,7 +430,19 @@ __global__ __launch_bounds__(256) void k_mask_fused4(P3 P, int mth, int vth, int
         uint32_t sv = 0, mv = 0;
         if (y >= 0 && y < height && x >= 0 && x < pitch)
         {
-            sv = *reinterpret_cast<const uint32_t *>(P.a[pl] + (size_t)y * pitch + x);
+            if (FROM_FRAME)
+            {
+                if (x < width)
+                {
+                    sv = *reinterpret_cast<const uint32_t *>(P.d[pl] + (size_t)(S.start_line + 2 * y) * S.spitch[pl] + x);
+                    if (x + 3 >= width) sv &= 0xffffffffu >> (8 * (x + 4 - width));
+                }
+                // the tile's own cells go out as SRCPF (every cell of the plane belongs to exactly one tile)
+                if (r >= MF_OY && r < MF_OY + MF_H && c4 >= MF_OX / 4 && c4 < (MF_OX + MF_W) / 4)
+                    *reinterpret_cast<uint32_t *>(P.a[pl] + (size_t)y * pitch + x) = sv;
+            }
+            else
+                sv = *reinterpret_cast<const uint32_t *>(P.a[pl] + (size_t)y * pitch + x);
             mv = *reinterpret_cast<const uint32_t *>(P.b[pl] + (size_t)y * pitch + x);
         }
         s_src[r][c4 + 1] = sv;
@@ -1167,7 +1185,9 @@ __device__ __forceinline__ uint32_t live3(const Win12 &w, uint32_t &centre)   //
     return __builtin_amdgcn_alignbyte(n1, n0, 3) + n1 + __builtin_amdgcn_alignbyte(n2, n1, 1);
 }
 
-__global__ __launch_bounds__(256) void k_dir_map_c(P3 P, int step, int y0, int expand)
+// post != 0 (the last expand_dir_map_2x of a field): eedi2_post_process (:1349-1378, k_post) rides along - it is
+// pointwise in the map this pass has just made (e = the map before the post filters, f = dst2p, rebuilt rows only).
+__global__ __launch_bounds__(256) void k_dir_map_c(P3 P, int step, int y0, int expand, int post)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_out[4][256];
     __shared__ uint16_t s_list[4 * 256];
@@ -1240,6 +1260,26 @@ __global__ __launch_bounds__(256) void k_dir_map_c(P3 P, int step, int y0, int e
         uint8_t *o = P.c[pl] + (size_t)y * pitch + x;
         if (x + 3 < width) *reinterpret_cast<uint32_t *>(o) = v;
         else for (int k = 0; k < 4 && x + k < width; k++) o[k] = (uint8_t)(v >> (8 * k));
+        if (post && row_ok)
+        {
+            const size_t at = (size_t)y * pitch + x;
+            const uint32_t om4 = *reinterpret_cast<const uint32_t *>(P.e[pl] + at);
+            uint8_t *d = P.f[pl] + at;
+            const uint32_t up4 = *reinterpret_cast<const uint32_t *>(d - pitch), dn4 = *reinterpret_cast<const uint32_t *>(d + pitch);
+            const uint32_t cur4 = *reinterpret_cast<const uint32_t *>(d);
+            int out[4];
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                const int nm = (v >> (8 * k)) & 0xffu, om = (om4 >> (8 * k)) & 0xffu;
+                const int lim = c_limlut[iabs(nm - NEUTRAL) >> 2];
+                const bool fix = iabs(nm - om) > lim && om != PEAK && om != NEUTRAL;
+                out[k] = fix ? (int)((((up4 >> (8 * k)) & 0xffu) + ((dn4 >> (8 * k)) & 0xffu) + 1) >> 1) : (int)((cur4 >> (8 * k)) & 0xffu);
+                any |= fix;
+            }
+            if (any) st4(d, out, x, width);
+        }
     }
 }
 
@@ -2472,6 +2512,12 @@ int Eedi2Engine::run(const DevPicture *cur, int tff, hipEvent_t wait_for)
         P.a[c] = cur->plane[c];
         P.b[c] = srcp.plane[c];
     }
+    // (a launch of its own only for the byte-per-thread A/B form or a frame whose rows are not dword aligned; otherwise
+    // the mask kernel reads the field rows from the frame and writes SRCPF, see k_mask_fused4<true>)
+    static const bool one_px_fill = getenv("HBHIP_EEDI2_1PX") != nullptr;
+    bool from_frame = !one_px_fill;
+    for (int c = 0; c < 3; c++) from_frame &= (cur->pitch[c] & 3) == 0 && ((uintptr_t)cur->plane[c] & 3) == 0;
+    if (!from_frame)
     {
         int rows[3];
         for (int c = 0; c < 3; c++) rows[c] = (dst2p.height[c] + 1) / 2;
@@ -2489,7 +2535,7 @@ int Eedi2Engine::run(const DevPicture *cur, int tff, hipEvent_t wait_for)
     share_->sel = sel;
     if (share_->ev_valid) HBHIP_CHECK(ctx_, hipStreamWaitEvent(ctx_->stream, share_->ev_mask, 0));
     {
-        const int rc = enqueue_mask(sel, old);
+        const int rc = enqueue_mask(sel, old, from_frame ? cur : nullptr, !tff);
         if (rc != HBHIP_OK) return rc;
     }
     HBHIP_CHECK(ctx_, hipEventRecord(share_->ev_mask, ctx_->stream));
@@ -2544,15 +2590,18 @@ int Eedi2Engine::join()
 
 // The pass sequence of eedi2_interpolate_plane (decomb_template.c:366-441) for the 3 planes, from
 // the edge mask to the post-processing, on the engine's scratch frames.
-int Eedi2Engine::enqueue_mask(int sel, int old)
+int Eedi2Engine::enqueue_mask(int sel, int old, const DevPicture *frame, int start_line)
 {
+    // frame != nullptr: the kernel extracts the field itself (rows start_line, start_line + 2, ... of `frame`)
     EediFrame &srcp = half_[0], &mskp = share_->mask[sel], &mskp_old = share_->mask[old];
     P3 P;
     memset(&P, 0, sizeof(P));
+    MaskSrc S = {{0, 0, 0}, start_line};
     for (int c = 0; c < 3; c++)
     {
         P.pitch[c] = srcp.stride[c]; P.width[c] = srcp.width[c]; P.height[c] = srcp.height[c];
         P.a[c] = srcp.plane[c]; P.b[c] = mskp_old.plane[c]; P.c[c] = mskp.plane[c];
+        if (frame) { P.d[c] = frame->plane[c]; S.spitch[c] = frame->pitch[c]; }
     }
     // edge mask, erode, dilate, erode, remove_small_gaps in one launch (old mask -> new mask)
     static const bool one_px = getenv("HBHIP_EEDI2_1PX") != nullptr;                   // A/B switch: the byte-per-thread form
@@ -2561,8 +2610,12 @@ int Eedi2Engine::enqueue_mask(int sel, int old)
         HBHIP_LAUNCH(ctx_, "eedi2_mask_passes", k_mask_fused, grid, dim3(256), 0, P,
                      par_.magnitude_threshold * 10, par_.laplacian_threshold * 81, par_.variance_threshold,
                      par_.erosion_threshold, par_.dilation_threshold);
+    else if (frame)
+        HBHIP_LAUNCH(ctx_, "eedi2_mask_passes", k_mask_fused4<true>, grid, dim3(256), 0, P, S,
+                     par_.magnitude_threshold * 10, par_.laplacian_threshold * 81, par_.variance_threshold,
+                     par_.erosion_threshold, par_.dilation_threshold);
     else
-        HBHIP_LAUNCH(ctx_, "eedi2_mask_passes", k_mask_fused4, grid, dim3(256), 0, P,
+        HBHIP_LAUNCH(ctx_, "eedi2_mask_passes", k_mask_fused4<false>, grid, dim3(256), 0, P, S,
                      par_.magnitude_threshold * 10, par_.laplacian_threshold * 81, par_.variance_threshold,
                      par_.erosion_threshold, par_.dilation_threshold);
     HBHIP_CHECK(ctx_, hipGetLastError());
@@ -2586,13 +2639,14 @@ int Eedi2Engine::enqueue_passes(int tff, int sel, hbhip_ctx *lc)
         return dim3((w + 255) / 256, (f.height[0] + 3) / 4, 3);
     };
     static const bool one_px = getenv("HBHIP_EEDI2_1PX") != nullptr;                   // A/B switch: the one-pixel-per-thread forms
-    auto dir_map = [&](const char *name, const EediFrame &f, const P3 &Pv, int step, int y0v, int expand) {
+    bool post_folded = false;
+    auto dir_map = [&](const char *name, const EediFrame &f, const P3 &Pv, int step, int y0v, int expand, int post = 0) {
         static const bool four_px = getenv("HBHIP_EEDI2_4PX") != nullptr;              // A/B switch: four pixels per thread, sort in place
         if (one_px)       HBHIP_LAUNCH(lc, name, k_dir_map, grid_for(f, false), blk, 0, Pv, step, y0v, expand);
         // the queueing form pays where few pixels reach the sort (expand: only peak pixels with >= 5 usable neighbours);
         // filter_dir_map sorts at most masked pixels, there the in-place form is ahead
         else if (four_px || !expand) HBHIP_LAUNCH(lc, name, k_dir_map4, grid4_for(f, false), blk, 0, Pv, step, y0v, expand);
-        else              HBHIP_LAUNCH(lc, name, k_dir_map_c, grid4_for(f, false), blk, 0, Pv, step, y0v, expand);
+        else            { HBHIP_LAUNCH(lc, name, k_dir_map_c, grid4_for(f, false), blk, 0, Pv, step, y0v, expand, post); post_folded = post != 0; }
     };
     auto geom = [&](P3 &P, const EediFrame &f) {
         for (int c = 0; c < 3; c++) { P.pitch[c] = f.stride[c]; P.width[c] = f.width[c]; P.height[c] = f.height[c]; }
@@ -2682,10 +2736,11 @@ int Eedi2Engine::enqueue_passes(int tff, int sel, hbhip_ctx *lc)
         bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp); bind(P.d, tmp2p2);
         dir_map("eedi2_filter_dir_map_2x", dst2p, P, 2, y0, 0);
         for (int c = 0; c < 3; c++) P.d[c] = nullptr;
-        bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
-        dir_map("eedi2_expand_dir_map_2x", dst2p, P, 2, y0, 1);
+        bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p); bind(P.e, tmp2p2); bind(P.f, dst2p);
+        dir_map("eedi2_expand_dir_map_2x", dst2p, P, 2, y0, 1, 1);                          // + post_process where the kernel can carry it
+        for (int c = 0; c < 3; c++) P.e[c] = P.f[c] = nullptr;
         bind(P.a, tmp2p); bind(P.b, tmp2p2); bind(P.c, dst2p);
-        HBHIP_LAUNCH(lc, "eedi2_post_process", k_post, grid4_for(dst2p, false), blk, 0, P, y0);
+        if (!post_folded) HBHIP_LAUNCH(lc, "eedi2_post_process", k_post, grid4_for(dst2p, false), blk, 0, P, y0);
     }
     if (par_.post_processing == 2 || par_.post_processing == 3)
     {

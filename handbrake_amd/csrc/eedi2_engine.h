@@ -67,7 +67,8 @@ public:
 
 private:
     int alloc_frame(EediFrame &f, int width, int height);
-    int enqueue_mask(int sel, int old);            // the five mask passes; sel = mask buffer to write, old = the previous run's
+    // the five mask passes (+ the field extraction when `frame` is given); sel = mask buffer to write, old = the previous run's
+    int enqueue_mask(int sel, int old, const DevPicture *frame, int start_line);
     int enqueue_passes(int tff, int sel, hbhip_ctx *lc);   // everything after them, launched on lc's stream
     hipGraphExec_t graph_[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // captured pass sequence per (field parity, mask buffer)
     EediMaskShare  own_share_;                     // the two MSKPF buffers (mask[0] is half_[1]) when not shared
