@@ -51,6 +51,8 @@ def runtime() -> C.CDLL:
         lib.hbh_chain_push_eof.argtypes = [C.c_void_p]
         lib.hbh_chain_pending.restype = C.c_int
         lib.hbh_chain_pending.argtypes = [C.c_void_p]
+        lib.hbh_chain_produced.restype = C.c_int
+        lib.hbh_chain_produced.argtypes = [C.c_void_p]
         lib.hbh_chain_peek.restype = C.c_int
         lib.hbh_chain_peek.argtypes = [C.c_void_p, C.POINTER(FrameInfo)]
         lib.hbh_chain_pop.restype = C.c_int
@@ -122,6 +124,10 @@ class Chain:
 
     def pending(self) -> int:
         return self._rt.hbh_chain_pending(self._h)
+
+    def produced(self) -> int:
+        """Threaded mode: frames the last stage has made so far (callable while the stages run)."""
+        return self._rt.hbh_chain_produced(self._h)
 
     def pop(self):
         """Next output frame, or None for the EOF marker / empty queue."""
@@ -238,6 +244,14 @@ def set_threaded(on: bool):
     rt.hbh_set_threaded.argtypes = [C.c_int]
     rt.hbh_set_threaded.restype = None
     rt.hbh_set_threaded(int(on))
+
+
+def set_discard_output(on: bool):
+    """Threaded chains opened from now on drop (and count) the frames their last stage makes: Chain.produced()."""
+    rt = runtime()
+    rt.hbh_set_discard_output.argtypes = [C.c_int]
+    rt.hbh_set_discard_output.restype = None
+    rt.hbh_set_discard_output(int(on))
 
 
 def set_source_color(prim: int = 1, transfer: int = 1, matrix: int = 1, color_range: int = 1):

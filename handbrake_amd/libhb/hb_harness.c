@@ -32,6 +32,7 @@ struct hbh_chain_s
     pthread_t           thread[HBH_MAX_STAGES];
     int                 thread_live[HBH_MAX_STAGES];
     pthread_mutex_t     out_lock;
+    int                 discard, produced;  /* threaded mode: drop finished frames / how many the last stage has made */
     int                 nstages;
     hb_filter_object_t *stage[HBH_MAX_STAGES];
     int                 done[HBH_MAX_STAGES];
@@ -56,11 +57,13 @@ static hb_filter_object_t *clone_filter(const hb_filter_object_t *proto, const c
 
 static int g_src_color[4] = { 1, 1, 1, 1 };
 static int g_threaded = 0;
+static int g_discard = 0;            /* threaded mode: count and drop the last stage's frames (a consumer that keeps up) */
 
 /* Chains opened from now on run every stage on a thread of its own, as libhb does (work.c:2527-2600): distinct
  * filters then call into the shared device context concurrently.  Frames pushed are queued; hbh_chain_push_eof()
  * returns when every stage has finished, so output is complete once it returns. */
 void hbh_set_threaded(int on) { g_threaded = on; }
+void hbh_set_discard_output(int on) { g_discard = on; }
 
 static void fifo_put(hbh_fifo_t *q, hb_buffer_t *b)
 {
@@ -112,7 +115,9 @@ static void *stage_loop(void *pv)                 /* filter_loop (work.c:2527-26
             else
             {
                 pthread_mutex_lock(&c->out_lock);
-                hb_buffer_list_append(&c->out, out);
+                if (!(out->s.flags & HB_BUF_FLAG_EOF)) c->produced++;
+                if (c->discard && !(out->s.flags & HB_BUF_FLAG_EOF)) hb_buffer_close(&out);
+                else hb_buffer_list_append(&c->out, out);
                 pthread_mutex_unlock(&c->out_lock);
             }
             out = next;
@@ -126,6 +131,7 @@ static void start_threads(hbh_chain_t *c)
 {
     if (!g_threaded) return;
     c->threaded = 1;
+    c->discard = g_discard;
     pthread_mutex_init(&c->out_lock, NULL);
     for (int s = 0; s < c->nstages; s++)
     {
@@ -380,6 +386,15 @@ int hbh_chain_push_eof(hbh_chain_t *c)
     else
         run_from(c, 0, hb_buffer_eof_init());
     return c->failed ? -2 : 0;
+}
+
+int hbh_chain_produced(hbh_chain_t *c)
+{
+    if (c == NULL || !c->threaded) return 0;
+    pthread_mutex_lock(&c->out_lock);
+    const int n = c->produced;
+    pthread_mutex_unlock(&c->out_lock);
+    return n;
 }
 
 int hbh_chain_pending(hbh_chain_t *c)

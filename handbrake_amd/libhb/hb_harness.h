@@ -41,6 +41,10 @@ int hbh_chain_describe(hbh_chain_t *c, char *buf, int len);
 /* Chains opened from now on run every stage on its own thread with a fifo in front (filter_loop, work.c:2527-2600);
  * output is collected after hbh_chain_push_eof(), which joins the stages. */
 void hbh_set_threaded(int on);
+/* Threaded chains opened from now on drop the frames their last stage makes (a consumer that keeps up, e.g. an
+ * encoder) and only count them: hbh_chain_produced() = frames made so far, callable while the stages run. */
+void hbh_set_discard_output(int on);
+int  hbh_chain_produced(hbh_chain_t *c);
 /* Colour description of the source for chains opened from now on (init->color_*; AVCOL_* numbers,
  * range 1 = tv, 2 = pc).  Default bt709 / tv. */
 void hbh_set_source_color(int prim, int transfer, int matrix, int range);
