@@ -21,7 +21,6 @@
 
 namespace {
 
-constexpr int LUT_N = 16384;
 constexpr int CS_TW = 64, CS_TH = 16, CS_RW = CS_TW + 2, CS_RH = CS_TH + 3;
 
 struct CsPlan
@@ -31,7 +30,8 @@ struct CsPlan
     float ymul_out, yoff_out, cmul_out, coff_out;
     float m_in[3][3], m_out[3][3], m_gamut[3][3], m_direct[3][3];
     float tm_param, tm_peak, tm_a, tm_b, tm_c;
-    const float *lut_in, *lut_out;
+    int   tc_in, tc_out;                 // transfer classes
+    float lin_scale, gam_scale;          // PQ / HLG: display-light scale after the EOTF / before its inverse
 };
 
 struct CsArgs
@@ -43,16 +43,115 @@ struct CsArgs
 };
 
 // ---- per-sample pipeline: every operation in float, correctly rounded, in the oracle's order ----
-__device__ __forceinline__ float lut_lerp(const float *__restrict__ lut, float t)
+// Deterministic float math: range reduction + fixed polynomials in IEEE single +, -, *, / (no contraction, correctly
+// rounded division) - the operation sequence of oracle/colorspace_oracle.c's det_* routines, so that transfer
+// functions can be evaluated per sample (no tables, nothing clipped before the integer conversion) and still
+// come out bit for bit as the checker's.  HOST_DEV: the same code builds the per-filter tone-map constants on the host.
+#define HBHIP_HD __host__ __device__ __forceinline__
+HBHIP_HD uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+HBHIP_HD float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+HBHIP_HD float fdiv(float a, float b)
 {
-    int i = (int)t;
-    if (i > LUT_N - 1) i = LUT_N - 1;
-    const float f = t - (float)i;
-    const float a = lut[i], b = lut[i + 1];
-    return a + (b - a) * f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __fdiv_rn(a, b);
+#else
+    return a / b;
+#endif
 }
 
-__device__ __forceinline__ float clip01(float v) { return v < 0.f ? 0.f : v > 1.f ? 1.f : v; }
+HBHIP_HD float det_log2f(float x)
+{
+    const uint32_t bits = f2u(x);
+    int e = (int)(bits >> 23) - 127;
+    float m = u2f((bits & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421354f) { m = m * 0.5f; e += 1; }
+    const float t = fdiv(m - 1.0f, m + 1.0f);
+    const float t2 = t * t;
+    float p = 0.111111112f;
+    p = p * t2 + 0.142857149f;
+    p = p * t2 + 0.200000003f;
+    p = p * t2 + 0.333333343f;
+    p = p * t2 + 1.0f;
+    return (float)e + (t * p) * 2.88539004f;
+}
+
+HBHIP_HD float det_exp2f(float y)
+{
+    if (!(y >= -126.0f)) return 0.0f;                  /* also what a NaN becomes */
+    if (y > 127.0f) y = 127.0f;
+    const int i = (int)(y + (y < 0.0f ? -0.5f : 0.5f));
+    const float z = (y - (float)i) * 0.693147182f;
+    float p = 0.000198412701f;
+    p = p * z + 0.00138888892f;
+    p = p * z + 0.00833333377f;
+    p = p * z + 0.0416666679f;
+    p = p * z + 0.166666672f;
+    p = p * z + 0.5f;
+    p = p * z + 1.0f;
+    p = p * z + 1.0f;
+    return p * u2f((uint32_t)(i + 127) << 23);
+}
+
+HBHIP_HD float det_powf(float x, float y) { return x <= 0.0f ? 0.0f : det_exp2f(y * det_log2f(x)); }
+HBHIP_HD float det_expf(float x) { return det_exp2f(x * 1.44269502f); }
+HBHIP_HD float det_logf(float x) { return det_log2f(x) * 0.693147182f; }
+
+// transfer functions, display referred as zimg's set (gamma.cpp); classes as transfer_class() numbers them
+__device__ __forceinline__ float to_linear_dev(int cls, float v)
+{
+    switch (cls)
+    {
+        case 1:  return det_powf(v, 2.4f);
+        case 4:  return det_powf(v, 2.2f);
+        case 5:  return det_powf(v, 2.8f);
+        case 7:  return v < 0.0913f ? fdiv(v, 4.0f) : det_powf(fdiv(v + 0.1115f, 1.1115f), 1.0f / 0.45f);
+        case 13: return v <= 0.04045f ? fdiv(v, 12.92f) : det_powf(fdiv(v + 0.055f, 1.055f), 2.4f);
+        case 16:
+        {
+            if (v <= 0.0f) return 0.0f;
+            const float p = det_powf(v, 1.0f / 78.84375f);
+            float num = p - 0.8359375f;
+            if (num < 0.0f) num = 0.0f;
+            float den = 18.8515625f - 18.6875f * p;
+            if (den < 1e-6f) den = 1e-6f;
+            return det_powf(fdiv(num, den), 1.0f / 0.1593017578125f);
+        }
+        case 18:
+        {
+            const float x = v < 0.0f ? 0.0f : v;
+            const float s = x <= 0.5f ? fdiv(x * x, 3.0f) : fdiv(det_expf(fdiv(x - 0.55991073f, 0.17883277f)) + 0.28466892f, 12.0f);
+            return det_powf(s, 1.2f);
+        }
+    }
+    return v;
+}
+
+__device__ __forceinline__ float to_gamma_dev(int cls, float x)
+{
+    switch (cls)
+    {
+        case 1:  return det_powf(x, 1.0f / 2.4f);
+        case 4:  return det_powf(x, 1.0f / 2.2f);
+        case 5:  return det_powf(x, 1.0f / 2.8f);
+        case 7:  return x < 0.0228f ? 4.0f * x : 1.1115f * det_powf(x, 0.45f) - 0.1115f;
+        case 13: return x <= 0.0031308f ? 12.92f * x : 1.055f * det_powf(x, 1.0f / 2.4f) - 0.055f;
+        case 16:
+        {
+            if (x <= 0.0f) return 0.0f;
+            const float xp = det_powf(x, 0.1593017578125f);
+            const float num = (0.8359375f - 1.0f) + (18.8515625f - 18.6875f) * xp;
+            const float den = 1.0f + 18.6875f * xp;
+            return det_powf(1.0f + fdiv(num, den), 78.84375f);
+        }
+        case 18:
+        {
+            if (x <= 0.0f) return 0.0f;
+            const float s = det_powf(x, 1.0f / 1.2f);
+            return s <= 1.0f / 12.0f ? __fsqrt_rn(3.0f * s) : 0.17883277f * det_logf(12.0f * s - 0.28466892f) + 0.55991073f;
+        }
+    }
+    return x;
+}
 
 __device__ __forceinline__ float hable_dev(float in)
 {
@@ -66,6 +165,7 @@ __device__ __forceinline__ float tonemap_sig(const CsPlan &p, float sig)
     switch (p.tonemap)
     {
         case 1: return __fdiv_rn(sig * p.tm_param, p.tm_peak);
+        case 2: return sig > 0.05f ? det_powf(__fdiv_rn(sig, p.tm_peak), p.tm_a) : sig * p.tm_b;      // gamma: tm_a = 1 / param
         case 3: { const float v = sig * p.tm_param; return v < 0.f ? 0.f : v > 1.f ? 1.f : v; }
         case 4: return __fdiv_rn(__fdiv_rn(sig, sig + p.tm_param) * (p.tm_peak + p.tm_param), p.tm_peak);
         case 5: return __fdiv_rn(hable_dev(sig), p.tm_a);
@@ -90,7 +190,7 @@ __device__ __forceinline__ void convert_px(const CsPlan &p, float y, float u, fl
     for (int i = 0; i < 3; i++)
     {
         const float e = p.m_in[i][0] * y + p.m_in[i][1] * u + p.m_in[i][2] * v;
-        c[i] = lut_lerp(p.lut_in, clip01(e) * (float)LUT_N);
+        c[i] = to_linear_dev(p.tc_in, e) * p.lin_scale;
     }
     if (p.tonemap >= 0)
     {
@@ -114,7 +214,7 @@ __device__ __forceinline__ void convert_px(const CsPlan &p, float y, float u, fl
     }
 #pragma unroll
     for (int i = 0; i < 3; i++)
-        g[i] = lut_lerp(p.lut_out, __fsqrt_rn(clip01(g[i])) * (float)LUT_N);
+        g[i] = to_gamma_dev(p.tc_out, g[i] * p.gam_scale);
 #pragma unroll
     for (int i = 0; i < 3; i++)
         out[i] = p.m_out[i][0] * g[0] + p.m_out[i][1] * g[1] + p.m_out[i][2] * g[2];
@@ -122,7 +222,10 @@ __device__ __forceinline__ void convert_px(const CsPlan &p, float y, float u, fl
 
 __device__ __forceinline__ int quant(float v, float mul, float off, int vmax)
 {
-    const int q = __float2int_rn(v * mul + off);
+    float t = v * mul + off;                 // +-inf / NaN (out-of-gamut input beyond a transfer function's pole): to the clip limits
+    if (!(t > -1e9f)) t = -1e9f;
+    if (t > 1e9f) t = 1e9f;
+    const int q = __float2int_rn(t);
     return q < 0 ? 0 : q > vmax ? vmax : q;
 }
 
@@ -250,6 +353,7 @@ bool luma_coefficients(int id, double &kr, double &kb)
         case 4: kr = 0.30;   kb = 0.11;   return true;
         case 5: case 6: kr = 0.299; kb = 0.114; return true;
         case 7: kr = 0.212;  kb = 0.087;  return true;
+        case 8: kr = 0.25; kb = 0.25; return true;          // YCgCo: placeholders, setup() installs its fixed matrix
         case 9: kr = 0.2627; kb = 0.0593; return true;
     }
     return false;
@@ -325,48 +429,9 @@ void gamut_matrix(double g[3][3], const double in_xy[8], const double out_xy[8])
 }
 
 // display-referred transfer functions (zimg's set); PQ / HLG only towards linear light
-bool to_linear(int cls, double v, double npl, double &out)
+bool transfer_known(int cls)
 {
-    switch (cls)
-    {
-        case 1:  out = pow(v, 2.4); return true;
-        case 4:  out = pow(v, 2.2); return true;
-        case 5:  out = pow(v, 2.8); return true;
-        case 7:  out = v < 0.0913 ? v / 4.0 : pow((v + 0.1115) / 1.1115, 1.0 / 0.45); return true;
-        case 8:  out = v; return true;
-        case 13: out = v <= 0.04045 ? v / 12.92 : pow((v + 0.055) / 1.055, 2.4); return true;
-        case 16:
-        {
-            const double m1 = 0.1593017578125, m2 = 78.84375, c1 = 0.8359375, c2 = 18.8515625, c3 = 18.6875;
-            const double p = pow(v, 1.0 / m2);
-            double num = p - c1;
-            if (num < 0.0) num = 0.0;
-            out = pow(num / (c2 - c3 * p), 1.0 / m1) * (10000.0 / npl);
-            return true;
-        }
-        case 18:
-        {
-            const double a = 0.17883277, b = 0.28466892, c = 0.55991073;
-            const double s = v <= 0.5 ? v * v / 3.0 : (exp((v - c) / a) + b) / 12.0;
-            out = pow(s, 1.2) * (1000.0 / npl);
-            return true;
-        }
-    }
-    return false;
-}
-
-bool to_gamma(int cls, double x, double &out)
-{
-    switch (cls)
-    {
-        case 1:  out = pow(x, 1.0 / 2.4); return true;
-        case 4:  out = pow(x, 1.0 / 2.2); return true;
-        case 5:  out = pow(x, 1.0 / 2.8); return true;
-        case 7:  out = x < 0.0228 ? 4.0 * x : 1.1115 * pow(x, 0.45) - 0.1115; return true;
-        case 8:  out = x; return true;
-        case 13: out = x <= 0.0031308 ? 12.92 * x : 1.055 * pow(x, 1.0 / 2.4) - 0.055; return true;
-    }
-    return false;
+    return cls == 1 || cls == 4 || cls == 5 || cls == 7 || cls == 8 || cls == 13 || cls == 16 || cls == 18;
 }
 
 float hable_host(float in)
@@ -379,11 +444,6 @@ class ColorspaceFilter : public SimpleFilter
 {
 public:
     ColorspaceFilter(hbhip_ctx *c, const hbhip_colorspace_params &p) : SimpleFilter(c), par(p) {}
-    ~ColorspaceFilter() override
-    {
-        if (d_lut_in) (void)hipFree(d_lut_in);
-        if (d_lut_out) (void)hipFree(d_lut_out);
-    }
     int setup(int depth)
     {
         memset(&plan, 0, sizeof(plan));
@@ -403,12 +463,17 @@ public:
         plan.cmul_out = lim_o ? (float)(224 << s) : (float)plan.vmax;
 
         const double kg_i = 1.0 - kr_i - kb_i, kg_o = 1.0 - kr_o - kb_o;
-        const double mi[3][3] = { { 1.0, 0.0, 2.0 * (1.0 - kr_i) },
-                                  { 1.0, -2.0 * kb_i * (1.0 - kb_i) / kg_i, -2.0 * kr_i * (1.0 - kr_i) / kg_i },
-                                  { 1.0, 2.0 * (1.0 - kb_i), 0.0 } };
-        const double mo[3][3] = { { kr_o, kg_o, kb_o },
-                                  { -kr_o / (2.0 * (1.0 - kb_o)), -kg_o / (2.0 * (1.0 - kb_o)), 0.5 },
-                                  { 0.5, -kg_o / (2.0 * (1.0 - kr_o)), -kb_o / (2.0 * (1.0 - kr_o)) } };
+        double mi[3][3] = { { 1.0, 0.0, 2.0 * (1.0 - kr_i) },
+                            { 1.0, -2.0 * kb_i * (1.0 - kb_i) / kg_i, -2.0 * kr_i * (1.0 - kr_i) / kg_i },
+                            { 1.0, 2.0 * (1.0 - kb_i), 0.0 } };
+        double mo[3][3] = { { kr_o, kg_o, kb_o },
+                            { -kr_o / (2.0 * (1.0 - kb_o)), -kg_o / (2.0 * (1.0 - kb_o)), 0.5 },
+                            { 0.5, -kg_o / (2.0 * (1.0 - kr_o)), -kb_o / (2.0 * (1.0 - kr_o)) } };
+        // YCgCo (AVCOL_SPC_YCGCO = 8; planes Y, Cg, Co): Y = (R + 2G + B) / 4, Cg = (-R + 2G - B) / 4, Co = (R - B) / 2
+        static const double ycgco_i[3][3] = { { 1.0, -1.0, 1.0 }, { 1.0, 1.0, 0.0 }, { 1.0, -1.0, -1.0 } };
+        static const double ycgco_o[3][3] = { { 0.25, 0.5, 0.25 }, { -0.25, 0.5, -0.25 }, { 0.5, 0.0, -0.5 } };
+        if (par.in_matrix == 8) memcpy(mi, ycgco_i, sizeof(mi));
+        if (par.out_matrix == 8) memcpy(mo, ycgco_o, sizeof(mo));
         const int tc_i = transfer_class(par.in_transfer), tc_o = transfer_class(par.out_transfer);
         const int pc_i = primaries_class(par.in_prim), pc_o = primaries_class(par.out_prim);
         plan.need_linear = tc_i != tc_o || pc_i != pc_o;
@@ -434,15 +499,11 @@ public:
                 for (int j = 0; j < 3; j++)
                     plan.m_gamut[i][j] = (float)g[i][j];
         }
-        std::vector<float> lin(LUT_N + 1), gam(LUT_N + 1);
-        for (int i = 0; i <= LUT_N; i++)
-        {
-            double a, b;
-            const double u = (double)i / LUT_N;
-            if (!to_linear(tc_i, u, par.npl, a) || !to_gamma(tc_o, u * u, b)) return HBHIP_ERR_UNSUPPORTED;
-            lin[i] = (float)a;
-            gam[i] = (float)b;
-        }
+        if (!transfer_known(tc_i) || !transfer_known(tc_o)) return HBHIP_ERR_UNSUPPORTED;
+        plan.tc_in = tc_i;
+        plan.tc_out = tc_o;
+        plan.lin_scale = tc_i == 16 ? (float)(10000.0 / par.npl) : tc_i == 18 ? (float)(1000.0 / par.npl) : 1.0f;
+        plan.gam_scale = tc_o == 16 ? (float)(par.npl / 10000.0) : tc_o == 18 ? (float)(par.npl / 1000.0) : 1.0f;
         // tone mapping only on the PQ / HLG -> other-transfer path (colorspace.c:126-127)
         if ((par.in_transfer == 16 || par.in_transfer == 18) && tc_i != tc_o)
         {
@@ -454,6 +515,11 @@ public:
             {
                 case HBHIP_TONEMAP_NONE: break;
                 case HBHIP_TONEMAP_LINEAR: case HBHIP_TONEMAP_CLIP: if (std::isnan(param)) param = 1.0f; break;
+                case HBHIP_TONEMAP_GAMMA:                  // vf_tonemap.c: default 1.8
+                    if (std::isnan(param)) param = 1.8f;
+                    plan.tm_a = 1.0f / param;
+                    plan.tm_b = det_powf(0.05f / (float)peak, plan.tm_a) / 0.05f;
+                    break;
                 case HBHIP_TONEMAP_REINHARD: param = std::isnan(param) ? 1.0f : (1.0f - param) / param; break;
                 case HBHIP_TONEMAP_HABLE: plan.tm_a = hable_host((float)peak); break;
                 case HBHIP_TONEMAP_MOBIUS:
@@ -467,18 +533,11 @@ public:
                     plan.tm_c = (b * b + 2.0f * b * j + j * j) / (b - a);
                     break;
                 }
-                default: return HBHIP_ERR_UNSUPPORTED;     // gamma: a powf per pixel, not built
+                default: return HBHIP_ERR_UNSUPPORTED;
             }
             plan.tm_param = param;
             plan.tm_peak = (float)peak;
         }
-        HBHIP_CHECK(ctx, hipMalloc((void **)&d_lut_in, sizeof(float) * lin.size()));
-        HBHIP_CHECK(ctx, hipMalloc((void **)&d_lut_out, sizeof(float) * gam.size()));
-        HBHIP_CHECK(ctx, hipMemcpyAsync(d_lut_in, lin.data(), sizeof(float) * lin.size(), hipMemcpyHostToDevice, ctx->stream));
-        HBHIP_CHECK(ctx, hipMemcpyAsync(d_lut_out, gam.data(), sizeof(float) * gam.size(), hipMemcpyHostToDevice, ctx->stream));
-        HBHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        plan.lut_in = d_lut_in;
-        plan.lut_out = d_lut_out;
         return HBHIP_OK;
     }
     int process(DevPicture *in, DevPicture *out) override
@@ -499,7 +558,6 @@ public:
     }
     hbhip_colorspace_params par;
     CsPlan plan;
-    float *d_lut_in = nullptr, *d_lut_out = nullptr;
 };
 
 } // namespace

@@ -342,7 +342,7 @@ typedef struct hbhip_colorspace_params
     int out_prim, out_transfer, out_matrix, out_range;   /* after the settings are applied (:101-120) */
     int tonemap;                                         /* HBHIP_TONEMAP_*; "hable" by default (:151) */
     double param;                                        /* NAN = the operator's default (:154-157)  */
-    double desat;                                        /* carried; FFmpeg disables it on GBR frames */
+    double desat;                                        /* carried; without effect, as in FFmpeg on GBR frames */
     double npl;                                          /* nominal peak luminance, 100 (:74)        */
     double peak;                                         /* determine_signal_peak (:37-49)           */
 } hbhip_colorspace_params;

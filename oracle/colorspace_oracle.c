@@ -15,21 +15,24 @@
  *     up   x even: c[x/2]; x odd: (c[k] + c[k+1]) / 2;  y = 2k: 1/4 c[k-1] + 3/4 c[k],
  *          y = 2k+1: 3/4 c[k] + 1/4 c[k+1];   edges repeat;
  *     down columns 2k-1, 2k, 2k+1 with 1/4 1/2 1/4; rows 2k-1 .. 2k+2 with 1/8 3/8 3/8 1/8;
- *   - Y'CbCr <-> R'G'B' from (Kr, Kb) of the matrix; when neither transfer class nor
+ *   - Y'CbCr <-> R'G'B' from (Kr, Kb) of the matrix (YCgCo: its own fixed matrix); when neither transfer class nor
  *     primaries change, one combined 3x3 matrix and no linearisation (as zimg's
  *     operation graph does);
  *   - transfer functions as zimg's display-referred set: BT.709/601/2020 = pure 2.4 gamma
  *     (BT.1886), gamma22/28, sRGB, SMPTE 240M, linear, ST 2084 (x 10000/npl) and
- *     ARIB STD-B67 with the 1.2 OOTF (x 1000/npl) — the last two as inputs only;
+ *     ARIB STD-B67 with the 1.2 OOTF (x 1000/npl), both as inputs and as outputs;
  *   - primaries conversion through XYZ with Bradford adaptation between white points;
- *   - vf_tonemap.c's operators (none, linear, clip, reinhard, hable, mobius) on the
+ *   - vf_tonemap.c's operators (none, linear, gamma, clip, reinhard, hable, mobius) on the
  *     brightest component, with its parameter defaults; its desaturation step is skipped
  *     because the frame is GBR at that point (no luma coefficients => FFmpeg disables it);
  *   - float -> integer: round to nearest even (lrintf), clipped to [0, max].
- * Deliberate simplifications, shared with the HIP kernel and documented in DESIGN.md:
- * transfer functions are evaluated through 16385-entry tables with linear interpolation
- * (the inverse one indexed by sqrt(x)), built with host libm, and their arguments are
- * clipped to [0, 1].  So results can differ from real zimg by an LSB, and in super-whites.
+ * Transfer functions are evaluated per sample, as zimg's scalar path does (gamma.cpp), on unclipped arguments:
+ * values below black and above white go through (the pure power laws return 0 below 0 like zimg's rec_1886
+ * pair, the piecewise ones continue their linear segment), and only the final integer conversion clips.
+ * The powers / exp / log are the deterministic float routines below (range reduction + fixed polynomials in
+ * IEEE single arithmetic, no libm, about 2e-6 relative) so that the HIP kernel can reproduce them bit for bit;
+ * tests/test_colorspace_cpu.py holds them against libm.  What still separates this file from real zimg is that
+ * rounding - not modelling: no tables, no clipping of super-whites.
  * The HIP path is tested bit-for-bit against THIS file, never against FFmpeg/zimg.
  */
 #include "oracle.h"
@@ -39,8 +42,6 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define LUT_N 16384
-
 typedef struct
 {
     int   need_linear, gamut, tonemap;
@@ -48,7 +49,8 @@ typedef struct
     float ymul_out, yoff_out, cmul_out, coff_out;
     float m_in[3][3], m_out[3][3], m_gamut[3][3], m_direct[3][3];
     float tm_param, tm_peak, tm_a, tm_b, tm_c;       /* operator constants, see tonemap_sig() */
-    float *lut_in, *lut_out;
+    int   tc_in, tc_out;                            /* transfer classes */
+    float lin_scale, gam_scale;                     /* PQ / HLG: display-light scale after the EOTF / before its inverse */
     int   vmax;
 } plan_t;
 
@@ -90,6 +92,7 @@ static int matrix_coeffs(int id, double *kr, double *kb)
         case 4:  *kr = 0.30;   *kb = 0.11;   return 1;      /* fcc        */
         case 5: case 6: *kr = 0.299; *kb = 0.114; return 1; /* bt470bg, smpte170m */
         case 7:  *kr = 0.212;  *kb = 0.087;  return 1;      /* smpte240m  */
+        case 8:  *kr = 0.25;   *kb = 0.25;   return 1;      /* YCgCo: placeholders, build_plan installs its fixed matrix */
         case 9:  *kr = 0.2627; *kb = 0.0593; return 1;      /* bt2020nc   */
     }
     return 0;
@@ -165,62 +168,118 @@ static void gamut_matrix(double g[3][3], const double in_xy[8], const double out
     mul3(g, bi, a);
 }
 
-/* ---- transfer functions (double, table construction only) ------------------------------- */
-static int to_linear(int cls, double v, double npl, double *out)
+/* ---- deterministic float math (IEEE single +, -, *, / only; the HIP kernel carries the same sequence) ---- */
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+/* log2 of a positive normal float: x = m 2^e with m in [sqrt(1/2), sqrt(2)), log2 m by the atanh series in (m-1)/(m+1) */
+static inline float det_log2f(float x)
 {
-    switch (cls)
-    {
-        case 1:  *out = pow(v, 2.4); return 1;
-        case 4:  *out = pow(v, 2.2); return 1;
-        case 5:  *out = pow(v, 2.8); return 1;
-        case 7:  *out = v < 0.0913 ? v / 4.0 : pow((v + 0.1115) / 1.1115, 1.0 / 0.45); return 1;
-        case 8:  *out = v; return 1;
-        case 13: *out = v <= 0.04045 ? v / 12.92 : pow((v + 0.055) / 1.055, 2.4); return 1;
-        case 16:
-        {
-            const double m1 = 0.1593017578125, m2 = 78.84375, c1 = 0.8359375, c2 = 18.8515625, c3 = 18.6875;
-            const double p = pow(v, 1.0 / m2);
-            double num = p - c1;
-            if (num < 0.0) num = 0.0;
-            *out = pow(num / (c2 - c3 * p), 1.0 / m1) * (10000.0 / npl);
-            return 1;
-        }
-        case 18:
-        {
-            const double a = 0.17883277, b = 0.28466892, c = 0.55991073;
-            const double s = v <= 0.5 ? v * v / 3.0 : (exp((v - c) / a) + b) / 12.0;
-            *out = pow(s, 1.2) * (1000.0 / npl);
-            return 1;
-        }
-    }
-    return 0;
+    const uint32_t bits = f2u(x);
+    int e = (int)(bits >> 23) - 127;
+    float m = u2f((bits & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421354f) { m = m * 0.5f; e += 1; }
+    const float t = (m - 1.0f) / (m + 1.0f);
+    const float t2 = t * t;
+    float p = 0.111111112f;
+    p = p * t2 + 0.142857149f;
+    p = p * t2 + 0.200000003f;
+    p = p * t2 + 0.333333343f;
+    p = p * t2 + 1.0f;
+    return (float)e + (t * p) * 2.88539004f;
 }
 
-static int to_gamma(int cls, double x, double *out)
+/* 2^y: y = i + f with |f| <= 1/2, e^(f ln 2) by its Taylor polynomial of degree 7, scaled by the exponent bits */
+static inline float det_exp2f(float y)
+{
+    if (!(y >= -126.0f)) return 0.0f;                  /* also what a NaN becomes */
+    if (y > 127.0f) y = 127.0f;
+    const int i = (int)(y + (y < 0.0f ? -0.5f : 0.5f));
+    const float z = (y - (float)i) * 0.693147182f;
+    float p = 0.000198412701f;
+    p = p * z + 0.00138888892f;
+    p = p * z + 0.00833333377f;
+    p = p * z + 0.0416666679f;
+    p = p * z + 0.166666672f;
+    p = p * z + 0.5f;
+    p = p * z + 1.0f;
+    p = p * z + 1.0f;
+    return p * u2f((uint32_t)(i + 127) << 23);
+}
+
+static inline float det_powf(float x, float y) { return x <= 0.0f ? 0.0f : det_exp2f(y * det_log2f(x)); }
+static inline float det_expf(float x) { return det_exp2f(x * 1.44269502f); }
+static inline float det_logf(float x) { return det_log2f(x) * 0.693147182f; }          /* x > 0 */
+
+/* test entry points (tests/test_colorspace_cpu.py holds them against libm) */
+float orc_det_powf(float x, float y) { return det_powf(x, y); }
+float orc_det_expf(float x) { return det_expf(x); }
+float orc_det_logf(float x) { return det_logf(x); }
+
+/* ---- transfer functions, per sample, display referred as zimg's set (gamma.cpp) ------------ */
+static int transfer_known(int cls, int as_output)
+{
+    (void)as_output;
+    return cls == 1 || cls == 4 || cls == 5 || cls == 7 || cls == 8 || cls == 13 || cls == 16 || cls == 18;
+}
+
+static inline float to_linear(int cls, float v)
 {
     switch (cls)
     {
-        case 1:  *out = pow(x, 1.0 / 2.4); return 1;
-        case 4:  *out = pow(x, 1.0 / 2.2); return 1;
-        case 5:  *out = pow(x, 1.0 / 2.8); return 1;
-        case 7:  *out = x < 0.0228 ? 4.0 * x : 1.1115 * pow(x, 0.45) - 0.1115; return 1;
-        case 8:  *out = x; return 1;
-        case 13: *out = x <= 0.0031308 ? 12.92 * x : 1.055 * pow(x, 1.0 / 2.4) - 0.055; return 1;
+        case 1:  return det_powf(v, 2.4f);
+        case 4:  return det_powf(v, 2.2f);
+        case 5:  return det_powf(v, 2.8f);
+        case 7:  return v < 0.0913f ? v / 4.0f : det_powf((v + 0.1115f) / 1.1115f, 1.0f / 0.45f);
+        case 13: return v <= 0.04045f ? v / 12.92f : det_powf((v + 0.055f) / 1.055f, 2.4f);
+        case 16:                                                     /* ST 2084 EOTF, 1.0 = 10000 cd/m2 */
+        {
+            if (v <= 0.0f) return 0.0f;
+            const float p = det_powf(v, 1.0f / 78.84375f);
+            float num = p - 0.8359375f;
+            if (num < 0.0f) num = 0.0f;
+            float den = 18.8515625f - 18.6875f * p;
+            if (den < 1e-6f) den = 1e-6f;
+            return det_powf(num / den, 1.0f / 0.1593017578125f);
+        }
+        case 18:                                                     /* ARIB STD-B67 inverse OETF + 1.2 OOTF, 1.0 = 1000 cd/m2 */
+        {
+            const float x = v < 0.0f ? 0.0f : v;
+            const float s = x <= 0.5f ? x * x / 3.0f : (det_expf((x - 0.55991073f) / 0.17883277f) + 0.28466892f) / 12.0f;
+            return det_powf(s, 1.2f);
+        }
     }
-    return 0;
+    return v;                                                        /* 8: linear */
+}
+
+static inline float to_gamma(int cls, float x)
+{
+    switch (cls)
+    {
+        case 1:  return det_powf(x, 1.0f / 2.4f);
+        case 4:  return det_powf(x, 1.0f / 2.2f);
+        case 5:  return det_powf(x, 1.0f / 2.8f);
+        case 7:  return x < 0.0228f ? 4.0f * x : 1.1115f * det_powf(x, 0.45f) - 0.1115f;
+        case 13: return x <= 0.0031308f ? 12.92f * x : 1.055f * det_powf(x, 1.0f / 2.4f) - 0.055f;
+        case 16:                                                     /* ST 2084 inverse EOTF */
+        {
+            if (x <= 0.0f) return 0.0f;
+            const float xp = det_powf(x, 0.1593017578125f);
+            const float num = (0.8359375f - 1.0f) + (18.8515625f - 18.6875f) * xp;
+            const float den = 1.0f + 18.6875f * xp;
+            return det_powf(1.0f + num / den, 78.84375f);
+        }
+        case 18:                                                     /* inverse 1.2 OOTF + ARIB STD-B67 OETF */
+        {
+            if (x <= 0.0f) return 0.0f;
+            const float s = det_powf(x, 1.0f / 1.2f);
+            return s <= 1.0f / 12.0f ? sqrtf(3.0f * s) : 0.17883277f * det_logf(12.0f * s - 0.28466892f) + 0.55991073f;
+        }
+    }
+    return x;                                                        /* 8: linear */
 }
 
 /* ---- per-sample float pipeline (every operation in float, in this order) ---------------- */
-static inline float lut_lerp(const float *lut, float t)
-{
-    int i = (int)t;
-    if (i > LUT_N - 1) i = LUT_N - 1;
-    const float f = t - (float)i;
-    return lut[i] + (lut[i + 1] - lut[i]) * f;
-}
-
-static inline float clip01(float v) { return v < 0.f ? 0.f : v > 1.f ? 1.f : v; }
-
 static inline float hable(float in)
 {
     const float a = 0.15f, b = 0.50f, c = 0.10f, d = 0.20f, e = 0.02f, f = 0.30f;
@@ -233,6 +292,8 @@ static inline float tonemap_sig(const plan_t *p, float sig)
     switch (p->tonemap)
     {
         case 1: return sig * p->tm_param / p->tm_peak;                                       /* linear   */
+        case 2:                                                                              /* gamma: tm_a = 1 / param, tm_b = pow(0.05 / peak, 1 / param) / 0.05 */
+            return sig > 0.05f ? det_powf(sig / p->tm_peak, p->tm_a) : sig * p->tm_b;
         case 3: { const float v = sig * p->tm_param; return v < 0.f ? 0.f : v > 1.f ? 1.f : v; }   /* clip */
         case 4: return sig / (sig + p->tm_param) * (p->tm_peak + p->tm_param) / p->tm_peak;     /* reinhard */
         case 5: return hable(sig) / p->tm_a;                                                 /* hable: tm_a = hable(peak) */
@@ -255,7 +316,7 @@ static inline void convert_px(const plan_t *p, float y, float u, float v, float 
     for (int i = 0; i < 3; i++)
     {
         const float e = p->m_in[i][0] * y + p->m_in[i][1] * u + p->m_in[i][2] * v;
-        c[i] = lut_lerp(p->lut_in, clip01(e) * (float)LUT_N);
+        c[i] = to_linear(p->tc_in, e) * p->lin_scale;
     }
     if (p->tonemap >= 0)
     {
@@ -271,14 +332,19 @@ static inline void convert_px(const plan_t *p, float y, float u, float v, float 
     else
         for (int i = 0; i < 3; i++) g[i] = c[i];
     for (int i = 0; i < 3; i++)
-        g[i] = lut_lerp(p->lut_out, sqrtf(clip01(g[i])) * (float)LUT_N);
+        g[i] = to_gamma(p->tc_out, g[i] * p->gam_scale);
     for (int i = 0; i < 3; i++)
         out[i] = p->m_out[i][0] * g[0] + p->m_out[i][1] * g[1] + p->m_out[i][2] * g[2];
 }
 
 static inline int quant(float v, float mul, float off, int vmax)
 {
-    const long q = lrintf(v * mul + off);
+    /* out-of-gamut input can reach +-inf / NaN on the way (e.g. the PQ EOTF beyond its pole): pinned to the clip
+     * limits here rather than left to what the float -> integer conversion of the platform makes of them */
+    float t = v * mul + off;
+    if (!(t > -1e9f)) t = -1e9f;
+    if (t > 1e9f) t = 1e9f;
+    const long q = lrintf(t);
     return q < 0 ? 0 : q > vmax ? vmax : (int)q;
 }
 
@@ -302,12 +368,17 @@ static int build_plan(plan_t *p, const orc_colorspace_params_t *cs, int depth)
     p->cmul_out = lim_o ? (float)(224 << s) : (float)p->vmax;
 
     const double kg_i = 1.0 - kr_i - kb_i, kg_o = 1.0 - kr_o - kb_o;
-    const double mi[3][3] = { { 1.0, 0.0, 2.0 * (1.0 - kr_i) },
-                              { 1.0, -2.0 * kb_i * (1.0 - kb_i) / kg_i, -2.0 * kr_i * (1.0 - kr_i) / kg_i },
-                              { 1.0, 2.0 * (1.0 - kb_i), 0.0 } };
-    const double mo[3][3] = { { kr_o, kg_o, kb_o },
-                              { -kr_o / (2.0 * (1.0 - kb_o)), -kg_o / (2.0 * (1.0 - kb_o)), 0.5 },
-                              { 0.5, -kg_o / (2.0 * (1.0 - kr_o)), -kb_o / (2.0 * (1.0 - kr_o)) } };
+    double mi[3][3] = { { 1.0, 0.0, 2.0 * (1.0 - kr_i) },
+                        { 1.0, -2.0 * kb_i * (1.0 - kb_i) / kg_i, -2.0 * kr_i * (1.0 - kr_i) / kg_i },
+                        { 1.0, 2.0 * (1.0 - kb_i), 0.0 } };
+    double mo[3][3] = { { kr_o, kg_o, kb_o },
+                        { -kr_o / (2.0 * (1.0 - kb_o)), -kg_o / (2.0 * (1.0 - kb_o)), 0.5 },
+                        { 0.5, -kg_o / (2.0 * (1.0 - kr_o)), -kb_o / (2.0 * (1.0 - kr_o)) } };
+    /* YCgCo (AVCOL_SPC_YCGCO = 8; planes Y, Cg, Co): Y = (R + 2G + B) / 4, Cg = (-R + 2G - B) / 4, Co = (R - B) / 2 */
+    static const double ycgco_i[3][3] = { { 1.0, -1.0, 1.0 }, { 1.0, 1.0, 0.0 }, { 1.0, -1.0, -1.0 } };
+    static const double ycgco_o[3][3] = { { 0.25, 0.5, 0.25 }, { -0.25, 0.5, -0.25 }, { 0.5, 0.0, -0.5 } };
+    if (cs->in_matrix == 8) memcpy(mi, ycgco_i, sizeof(mi));
+    if (cs->out_matrix == 8) memcpy(mo, ycgco_o, sizeof(mo));
     const int tc_i = transfer_class(cs->in_transfer), tc_o = transfer_class(cs->out_transfer);
     const int pc_i = primaries_class(cs->in_prim), pc_o = primaries_class(cs->out_prim);
     p->need_linear = tc_i != tc_o || pc_i != pc_o;
@@ -333,16 +404,11 @@ static int build_plan(plan_t *p, const orc_colorspace_params_t *cs, int depth)
             for (int j = 0; j < 3; j++)
                 p->m_gamut[i][j] = (float)g[i][j];
     }
-    p->lut_in = malloc(sizeof(float) * (LUT_N + 1));
-    p->lut_out = malloc(sizeof(float) * (LUT_N + 1));
-    for (int i = 0; i <= LUT_N; i++)
-    {
-        double a, b;
-        const double u = (double)i / LUT_N;
-        if (!to_linear(tc_i, u, cs->npl, &a) || !to_gamma(tc_o, u * u, &b)) { free(p->lut_in); free(p->lut_out); return -1; }
-        p->lut_in[i] = (float)a;
-        p->lut_out[i] = (float)b;
-    }
+    if (!transfer_known(tc_i, 0) || !transfer_known(tc_o, 1)) return -1;
+    p->tc_in = tc_i;
+    p->tc_out = tc_o;
+    p->lin_scale = tc_i == 16 ? (float)(10000.0 / cs->npl) : tc_i == 18 ? (float)(1000.0 / cs->npl) : 1.0f;
+    p->gam_scale = tc_o == 16 ? (float)(cs->npl / 10000.0) : tc_o == 18 ? (float)(cs->npl / 1000.0) : 1.0f;
     /* tone mapping only on the PQ / HLG -> other-transfer path (colorspace.c:126-127) */
     if ((cs->in_transfer == 16 || cs->in_transfer == 18) && tc_i != tc_o)
     {
@@ -353,6 +419,11 @@ static int build_plan(plan_t *p, const orc_colorspace_params_t *cs, int depth)
         {
             case 0: break;
             case 1: case 3: if (isnan(param)) param = 1.0f; break;
+            case 2:                                                 /* gamma (vf_tonemap.c: default 1.8) */
+                if (isnan(param)) param = 1.8f;
+                p->tm_a = 1.0f / param;
+                p->tm_b = det_powf(0.05f / (float)peak, p->tm_a) / 0.05f;
+                break;
             case 4: param = isnan(param) ? 1.0f : (1.0f - param) / param; break;
             case 5: p->tm_a = hable((float)peak); break;
             case 6:
@@ -366,7 +437,7 @@ static int build_plan(plan_t *p, const orc_colorspace_params_t *cs, int depth)
                 p->tm_c = (b * b + 2.0f * b * j + j * j) / (b - a);
                 break;
             }
-            default: free(p->lut_in); free(p->lut_out); return -1;      /* gamma needs powf per pixel: not built */
+            default: return -1;
         }
         p->tm_param = param;
         p->tm_peak = (float)peak;
@@ -461,6 +532,5 @@ int orc_colorspace_frame(const orc_colorspace_params_t *cs, const void *const sr
             }
     }
     free(oy); free(ou); free(ov);
-    free(p.lut_in); free(p.lut_out);
     return 0;
 }

@@ -517,6 +517,25 @@ def orc_colorspace_frame(frame, params, depth=8, subw=1, subh=1):
     return tuple(dst)
 
 
+def _det(name, *args):
+    fn = getattr(oracle(), name)
+    fn.restype = C.c_float
+    fn.argtypes = [C.c_float] * len(args)
+    return float(fn(*args))
+
+
+def det_powf(x, y):
+    return _det("orc_det_powf", x, y)
+
+
+def det_expf(x):
+    return _det("orc_det_expf", x)
+
+
+def det_logf(x):
+    return _det("orc_det_logf", x)
+
+
 def orc_blend_frame(frame, overlays, depth=8, wshift=1, hshift=1, chroma_location=1, overlay_wshift=0, overlay_hshift=0):
     """overlays: list of (x, y, (Y, Cb, Cr, A)).  Returns the composited copy of `frame`."""
     from handbrake_amd import hbrt

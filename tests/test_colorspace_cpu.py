@@ -54,16 +54,21 @@ def test_primaries_conversion_of_smpte_c_red(built):
 
 
 @pytest.mark.parametrize("src", [HDR10, HLG])
-@pytest.mark.parametrize("tm", ["hable", "mobius", "reinhard", "clip", "linear", "none"])
+@pytest.mark.parametrize("tm", ["hable", "mobius", "reinhard", "gamma", "clip", "linear", "none"])
 def test_tone_curves_are_monotone_and_in_range(built, src, tm):
+    """Up to the signal peak the curve stays inside the SDR range; beyond it nothing is clipped before the integer
+    conversion (super-whites go through, as in zimg), so the curve only has to stay monotone."""
     prev = -1
+    peak_code = 64 + 876 * (0.7518 if src == HDR10 else 1.0)        # PQ code of 1000 cd/m2 = peak 10 at npl 100; HLG full scale
     for code in range(64, 941, 73):
         p = ol.colorspace_params(src, BT709, tonemap=tm, peak=10.0)
         y, cb, cr = px(ol.orc_colorspace_frame(flat(code, 512, 512, dt=np.uint16), p, depth=10))
-        assert 64 <= y <= 940 and abs(cb - 512) <= 2 and abs(cr - 512) <= 2
-        assert y >= prev
+        assert abs(cb - 512) <= 2 and abs(cr - 512) <= 2
+        if code <= peak_code and tm not in ("none", "linear"):
+            assert 64 <= y <= 944
+        assert 64 <= y <= 1023 and y >= prev
         prev = y
-    assert prev > 700                      # peak white ends up near the top of the SDR range
+    assert prev > 700                      # peak white ends up near the top of the SDR range (or above it)
 
 
 def test_pq_reference_white(built):
@@ -76,12 +81,40 @@ def test_pq_reference_white(built):
 
 def test_uncovered_conversions_are_refused(built):
     with pytest.raises(ValueError):
-        ol.orc_colorspace_frame(flat(100, 128, 128), ol.colorspace_params(BT709, (1, 16, 1, 1)))     # PQ as output
+        ol.orc_colorspace_frame(flat(100, 128, 128), ol.colorspace_params(BT709, (1, 1, 10, 1)))     # bt2020 constant luminance
     with pytest.raises(ValueError):
-        ol.orc_colorspace_frame(flat(100, 128, 128), ol.colorspace_params(BT709, (1, 1, 8, 1)))      # YCgCo
-    with pytest.raises(ValueError):
-        ol.orc_colorspace_frame(flat(100, 512, 512, dt=np.uint16),
-                                ol.colorspace_params(HDR10, BT709, tonemap="gamma"), depth=10)
+        ol.orc_colorspace_frame(flat(100, 128, 128), ol.colorspace_params(BT709, (1, 3, 1, 1)))      # unknown transfer
+
+
+@pytest.mark.parametrize("via", [(9, 16, 9, 1), (9, 18, 9, 1), (1, 1, 8, 1), (1, 13, 1, 2)], ids=["pq", "hlg", "ycgco", "srgb_full"])
+def test_round_trips_through_the_new_outputs(built, via):
+    """BT.709 -> X -> BT.709 at 10 bits comes back within a code or two (PQ / HLG as *output* transfers, the YCgCo
+    matrix): forward and inverse functions are consistent."""
+    for code, cb, cr in [(64, 512, 512), (300, 512, 512), (502, 400, 600), (940, 512, 512), (700, 620, 380)]:
+        src = flat(code, cb, cr, dt=np.uint16)
+        there = ol.orc_colorspace_frame(src, ol.colorspace_params(BT709, via, tonemap="none"), depth=10)
+        back = ol.orc_colorspace_frame(there, ol.colorspace_params(via, BT709, tonemap="none"), depth=10)
+        y, u, v = px(back)
+        assert abs(y - code) <= 2 and abs(u - cb) <= 3 and abs(v - cr) <= 3, (via, code, px(there), (y, u, v))
+
+
+def test_deterministic_math_against_libm(built):
+    """det_powf / det_expf / det_logf (the routines the HIP kernel reproduces bit for bit) against libm in double."""
+    import math
+    rng = np.random.default_rng(5)
+    xs = np.concatenate([rng.uniform(1e-6, 1.0, 4000), rng.uniform(1.0, 120.0, 2000)]).astype(np.float32)
+    worst = 0.0
+    for x in xs[:3000]:
+        for yexp in (2.4, 1 / 2.4, 0.45, 1 / 0.45, 2.8, 0.1593017578125, 78.84375 if x < 1.02 else 1.2, 1 / 78.84375):
+            got = ol.det_powf(float(x), float(np.float32(yexp)))
+            want = math.pow(float(x), float(np.float32(yexp)))
+            if want > 1e-30 and want < 1e30:
+                worst = max(worst, abs(got - want) / want)
+    assert worst < 2e-5, worst
+    for x in rng.uniform(-8, 8, 2000).astype(np.float32):
+        assert abs(ol.det_expf(float(x)) - math.exp(float(x))) / math.exp(float(x)) < 2e-6
+    for x in rng.uniform(1e-4, 50, 2000).astype(np.float32):
+        assert abs(ol.det_logf(float(x)) - math.log(float(x))) < 2e-6 + 2e-6 * abs(math.log(float(x)))
 
 
 def test_chroma_siting_round_trip_on_smooth_content(built):

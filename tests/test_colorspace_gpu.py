@@ -22,6 +22,11 @@ SDR_CASES = [
     (BT709, "primaries=smpte432:transfer=iec61966-2-1", (12, 13, 1, 1), {}),
     ((4, 4, 4, 1), "primaries=bt709:transfer=bt709:matrix=bt709", BT709, {}),       # NTSC 1953 (white C: Bradford)
     (BT709, "transfer=linear", (1, 8, 1, 1), {}),
+    (BT709, "matrix=ycgco", (1, 1, 8, 1), {}),                                      # the fixed YCgCo matrix, both ways
+    ((1, 1, 8, 2), "matrix=bt709:range=tv", (1, 1, 1, 1), {}),
+    (BT709, "primaries=bt2020:transfer=smpte2084:matrix=bt2020nc", (9, 16, 9, 1), {}),          # PQ / HLG as output transfers
+    (BT709, "primaries=bt2020:transfer=arib-std-b67:matrix=bt2020nc", (9, 18, 9, 1), {}),
+    ((1, 13, 1, 2), "transfer=smpte240m:range=tv", (1, 7, 1, 1), {}),              # sRGB full range (super-whites stay) -> 240M
 ]
 
 
@@ -52,7 +57,8 @@ def test_sdr_conversions(built, w, h, src, settings, dst, kw):
 @pytest.mark.parametrize("depth", [10, 12])
 @pytest.mark.parametrize("src", [HDR10, HLG])
 @pytest.mark.parametrize("tm,param", [("hable", None), ("mobius", None), ("mobius", 0.5), ("reinhard", None),
-                                      ("reinhard", 0.7), ("clip", None), ("linear", 2.0), ("none", None)])
+                                      ("reinhard", 0.7), ("clip", None), ("linear", 2.0), ("none", None),
+                                      ("gamma", None), ("gamma", 2.2)])
 def test_hdr_to_sdr_tone_mapping(built, depth, src, tm, param):
     w, h = 322, 182
     frames = synth.stream("progressive", w, h, 1, depth=depth) + synth.stream("random", w, h, 1, depth=depth)
@@ -97,6 +103,6 @@ def test_unsupported_conversion_fails_init(built):
     hbrt.set_source_color(*BT709)
     try:
         with pytest.raises(RuntimeError):
-            hbrt.Chain(hip.filters(), [("hb_filter_colorspace_hip", "transfer=smpte2084")], 320, 180)
+            hbrt.Chain(hip.filters(), [("hb_filter_colorspace_hip", "matrix=bt2020c")], 320, 180)      # constant luminance
     finally:
         hbrt.set_source_color()
