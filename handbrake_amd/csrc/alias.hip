@@ -121,13 +121,14 @@ __global__ __launch_bounds__(256) void rotate8_batch_kernel(RotBatch B)
     const int sx0 = min(ax, bx), sy0 = min(ay, by), sx1 = max(ax, bx), sy1 = max(ay, by);
     const int t = threadIdx.y * 64 + threadIdx.x;
     const int cols = sx1 - sx0 + 1, rows = sy1 - sy0 + 1;
+    // (offsets inside a plane fit 32 bits and rows / pitches 24: v_mul_u32_u24 instead of the quarter-rate 64-bit multiply)
     if ((sx0 & 3) == 0 && cols == 64)
     {
         for (int i = t; i < rows * 16; i += 256)
         {
             const int r = i >> 4, q = i & 15;
             *reinterpret_cast<uint32_t *>(&tile[r][4 * q]) =
-                *reinterpret_cast<const uint32_t *>(a.src + (size_t)(sy0 + r) * a.spitch + sx0 + 4 * q);
+                *reinterpret_cast<const uint32_t *>(a.src + ((uint32_t)__mul24(sy0 + r, a.spitch) + (uint32_t)(sx0 + 4 * q)));
         }
     }
     else
@@ -135,24 +136,31 @@ __global__ __launch_bounds__(256) void rotate8_batch_kernel(RotBatch B)
         for (int i = t; i < rows * 64; i += 256)
         {
             const int r = i >> 6, q = i & 63;
-            if (q < cols) tile[r][q] = a.src[(size_t)(sy0 + r) * a.spitch + sx0 + q];
+            if (q < cols) tile[r][q] = a.src[(uint32_t)__mul24(sy0 + r, a.spitch) + (uint32_t)(sx0 + q)];
         }
     }
     __syncthreads();
+    // rot_map is affine in (x, y), so is the position of an output pixel's source byte inside the tile: its value at the
+    // tile's origin and its steps in x and y (uniform) replace a map evaluation and a row multiply per byte
+    int i00, ix, iy;
+    {
+        int sx, sy;
+        rot_map(a, ox, oy, sx, sy);     i00 = (sy - sy0) * 68 + (sx - sx0);
+        rot_map(a, ox + 1, oy, sx, sy); ix = (sy - sy0) * 68 + (sx - sx0) - i00;
+        rot_map(a, ox, oy + 1, sx, sy); iy = (sy - sy0) * 68 + (sx - sx0) - i00;
+    }
+    const uint8_t *flat = &tile[0][0];
     for (int i = t; i < th * 16; i += 256)
     {
         const int r = i >> 4, q = i & 15;
         const int x = ox + 4 * q, y = oy + r;
         if (x >= a.dw) continue;
+        const int base = i00 + __mul24(iy, r);
         uint32_t v = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++)
-        {
-            int sx, sy;
-            rot_map(a, min(x + k, a.dw - 1), y, sx, sy);
-            v |= (uint32_t)tile[sy - sy0][sx - sx0] << (8 * k);
-        }
-        uint8_t *d = a.dst + (size_t)y * a.dpitch + x;
+            v |= (uint32_t)flat[base + __mul24(ix, min(4 * q + k, tw - 1))] << (8 * k);      // past the width: any byte of the tile
+        uint8_t *d = a.dst + ((uint32_t)__mul24(y, a.dpitch) + (uint32_t)x);
         if (x + 3 < a.dw) *reinterpret_cast<uint32_t *>(d) = v;
         else for (int k = 0; k < 4 && x + k < a.dw; k++) d[k] = (uint8_t)(v >> (8 * k));
     }

@@ -1032,6 +1032,236 @@ __global__ __launch_bounds__(CD_W) void k_calc_dir_tile3(P3 P, int maxd, int nt1
     P.c[pl][(size_t)y * pitch + px] = (uint8_t)out;
 }
 
+// calc_directions, fourth form: a block takes 256 columns x R rows.
+//  * Rows share their staging: R + 4 source and R + 2 mask rows (and the triple tables / peak bitmaps made from them)
+//    serve R rows of pixels instead of 5 + 3 for one, and the masked pixels of R rows fill the waves of the search (one row
+//    of this content leaves the last wave of a block's list three quarters empty).
+//  * The list keeps column order: lanes of a wave read neighbouring table columns, so the eight table reads of a step stay
+//    nearly free of LDS bank conflicts.  Ordering the list by the number of steps (counting sort, or a stable partition
+//    into coarse bins) evens out the trip counts of a wave but scatters its columns: SQ_LDS_BANK_CONFLICT 1.6 M -> 4.2 M
+//    cycles per launch and a slower kernel (57 / 55 against 52 us), with no fewer VALU instructions to show for it (the
+//    search is a quarter of them) - measured, not kept.
+//  * A running minimum and its offset are one integer built by v_sad_hi_u8 chains (see calc_dir_search), a step forms its
+//    two table addresses with one instruction each: 31 VALU instructions per step against 45.
+//  * The output rows are assembled in LDS and stored as dwords.
+// Values are those of k_calc_dir_tile3 (:358-525).  maxd <= 30.  Per launch (1080i field, the bench's content):
+// SQ_INSTS_VALU 26.5 M -> 16.8 M, SQ_INSTS_SALU 11.3 M -> 2.2 M, SQ_INSTS_LDS 3.2 M -> 2.1 M.
+
+template <bool EDGE>
+__device__ __forceinline__ int calc_dir_search(const uint32_t *tr, uint64_t pass, int maxdt, bool first, bool last, int nt13, int nt19)
+{
+    // tr = &s_tri[j][b]: row k of the table is k * CD_LW further (k = 0..4: rows y-2 .. y+2)
+    const uint32_t F2p = tr[0], Fp = tr[CD_LW], Fc = tr[2 * CD_LW], Fn = tr[3 * CD_LW], F2n = tr[4 * CD_LW];
+    const int ctr = (int)((Fc >> 8) & 0xff);
+    const int vert = iabs(ctr - (int)((Fn >> 8) & 0xff)) + iabs(ctr - (int)((Fp >> 8) & 0xff));
+    // Keys: (running minimum << 16) | tag, tag = u + 32 (twice that for key a), tag 0 = unset.  `if (sum < min) { min = sum;
+    // dir = u; }` with u ascending is min() on that key: the initial key is (threshold << 16) | 0, so only strictly smaller
+    // sums get in, and among equal sums the smaller tag = the earlier u stays.  v_sad_hi_u8 adds its sum already shifted
+    // by 16, so a key is a chain of them started from the tag; the tags are placed so that every key collects exactly one
+    // (d1, s2pp carry it; key a = d1 + e1 + s2pp + sp2p gets two).  Sums stay below 2^16 (at most 20 bytes).
+    uint32_t kb = (uint32_t)min(nt13, vert * 6) << 16, ka = (uint32_t)min(nt19, vert * 9) << 16;
+    uint32_t kc = ka, kd = kb, ke = kb;
+    // LDS byte addresses of columns b+u / b-u at jj = u + maxdt = 0, kept opaque so that a step forms its two addresses
+    // and its tag with one instruction each
+    typedef __attribute__((address_space(3))) const uint32_t *lds_u32;
+    uint32_t ap0 = (uint32_t)(uintptr_t)(lds_u32)(tr - maxdt), am0 = (uint32_t)(uintptr_t)(lds_u32)(tr + maxdt);
+    uint32_t tag0 = (uint32_t)(32 - maxdt);
+    asm volatile("" : "+v"(ap0), "+v"(am0), "+s"(tag0));
+#define SADH(a, b, acc) __builtin_amdgcn_sad_hi_u8((a), (b), (acc))
+    while (pass)
+    {
+        const int jj = __ffsll((unsigned long long)pass) - 1;
+        pass &= pass - 1ull;
+        const uint32_t tag = (uint32_t)jj + tag0;
+        const lds_u32 tp = (lds_u32)(uintptr_t)(ap0 + 4u * (uint32_t)jj), tm = (lds_u32)(uintptr_t)(am0 - 4u * (uint32_t)jj);
+        const uint32_t e1 = SADH(Fp, tm[2 * CD_LW], SADH(Fc, tm[3 * CD_LW], 0u));     // diffsn + diffps
+        const uint32_t d1 = SADH(Fn, tp[2 * CD_LW], SADH(Fc, tp[1 * CD_LW], tag));    // diffsp + diffns (+ tag)
+        const uint32_t diff = e1 + d1;
+        uint32_t diffd = d1, diffe = e1;
+        kb = min(kb, diff);
+        if (!EDGE || !first)
+        {
+            const uint32_t diff2pp = SADH(F2p, tm[1 * CD_LW], tag);
+            const uint32_t diffp2p = SADH(Fp, tp[0 * CD_LW], 0u);
+            diffd += diffp2p;
+            diffe += diff2pp;
+            ka = min(ka, diff + diff2pp + diffp2p);
+        }
+        else
+            diffe += tag;
+        if (!EDGE || !last)
+        {
+            const uint32_t diff2nn = SADH(F2n, tp[3 * CD_LW], 0u);
+            const uint32_t diffn2n = SADH(Fn, tm[4 * CD_LW], 0u);
+            diffd += diff2nn;
+            diffe += diffn2n;
+            kc = min(kc, diff + diff2nn + diffn2n);
+        }
+        kd = min(kd, diffd);
+        ke = min(ke, diffe);
+    }
+#undef SADH
+    // the offsets that were set, sorted (unset ones as a large sentinel at the end): 9-exchange network on 5 values
+    constexpr int BIG = 1 << 20;
+    const int ta = (int)((ka & 0xffffu) >> 1), tb = (int)(kb & 0xffffu), tc = (int)(kc & 0xffffu), td = (int)(kd & 0xffffu),
+              te = (int)(ke & 0xffffu);
+    int v0 = ta ? ta - 32 : BIG, v1 = tb ? tb - 32 : BIG, v2 = tc ? tc - 32 : BIG, v3 = td ? td - 32 : BIG, v4 = te ? te - 32 : BIG;
+    const int k = (ta != 0) + (tb != 0) + (tc != 0) + (td != 0) + (te != 0);
+#define CD_CX(a, b) { const int lo_ = min(a, b), hi_ = max(a, b); a = lo_; b = hi_; }
+    CD_CX(v0, v1) CD_CX(v3, v4) CD_CX(v2, v4) CD_CX(v2, v3) CD_CX(v0, v3) CD_CX(v0, v2) CD_CX(v1, v4) CD_CX(v1, v3) CD_CX(v1, v2)
+#undef CD_CX
+    int out = NEUTRAL;
+    if (k > 1)
+    {
+        // sorted_mid's midpoint rule (eedi2.c:65-80): odd k -> v[k/2], even k -> (v[(k-1)/2] + v[k/2] + 1) >> 1; one formula
+        // serves both ((2v + 1) >> 1 == v)
+        const int lo = k == 2 ? v0 : (k == 5 ? v2 : v1);        // v[(k-1)>>1]: 0 1 1 2 for k = 2 3 4 5
+        const int hi = k >= 4 ? v2 : v1;                         // v[k>>1]:     1 1 2 2
+        const int mid = (lo + hi + 1) >> 1;
+        const int tlim = max((int)c_limlut[iabs(mid)] >> 2, 2);
+        int sum = 0, cnt = 0;
+        if (iabs(v0 - mid) <= tlim) { cnt++; sum += v0; }        // the sentinels fail the test by themselves
+        if (iabs(v1 - mid) <= tlim) { cnt++; sum += v1; }
+        if (iabs(v2 - mid) <= tlim) { cnt++; sum += v2; }
+        if (iabs(v3 - mid) <= tlim) { cnt++; sum += v3; }
+        if (iabs(v4 - mid) <= tlim) { cnt++; sum += v4; }
+        if (cnt > 1) out = (NEUTRAL + ((int)((float)sum / (float)cnt) * 4)) & 0xff;
+    }
+    return out;
+}
+
+template <int R>
+__global__ __launch_bounds__(CD_W) void k_calc_dir_rows(P3 P, int maxd, int nt13, int nt19)
+{
+    constexpr int NS = R + 4, NM = R + 2, RW = CD_LW / 4;
+    __shared__ __attribute__((aligned(16))) uint8_t s_band[NS + NM][CD_LW];   // staged rows: 0..NS-1 source y0-2.., NS.. mask y0-1..
+    __shared__ uint32_t s_tri[NS][CD_LW];                                      // [r][i] = bytes i..i+2 of source row r
+    __shared__ uint64_t s_bits[NM][8];                                         // bit i: a mask peak among columns i..i+2 of mask row m
+    __shared__ uint16_t s_list[R * CD_W];                                      // the listed pixels, (row << 8) | column
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[R][CD_W];
+    __shared__ int s_count;
+    const int pl = blockIdx.z;
+    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
+    const int x0 = blockIdx.x * CD_W, y0 = blockIdx.y * R;
+    if (y0 >= height || x0 >= pitch) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0) s_count = 0;
+    if (tid < NM * 3) s_bits[tid / 3][5 + tid % 3] = 0;           // words past the staged columns (the window reads one of them)
+    uint32_t *band = reinterpret_cast<uint32_t *>(&s_band[0][0]);
+    {
+        // flat addressing as in the one-row forms (out-of-row columns pick up the neighbouring rows' bytes, as the
+        // reference's pointer arithmetic does); rows past height + 1 serve no pixel and are not touched
+        const uint8_t *sb = P.b[pl] + x0 - CD_HALO, *mb = P.a[pl] + x0 - CD_HALO;
+        for (int i = tid; i < (NS + NM) * RW; i += CD_W)
+        {
+            const int r = i / RW, c4 = i - r * RW;
+            const uint8_t *src = r < NS ? sb + (ptrdiff_t)min(y0 - 2 + r, height + 1) * pitch
+                                        : mb + (ptrdiff_t)min(y0 - 1 + (r - NS), height) * pitch;
+            band[i] = reinterpret_cast<const uint32_t *>(src)[c4];
+        }
+    }
+    __syncthreads();
+    // tables and peak bitmaps: column i of row r <- dwords i/4 and i/4 + 1 of the staged row, realigned once; columns
+    // 0 .. CD_LW-4 (b+-u, |u| <= CD_HALO-2): a first round for all, the 61 columns left over for the first wave
+    for (int k = 0; k < 2; k++)
+    {
+        if (k == 1 && tid >= 64) break;                          // wave-uniform
+        const int i = tid + k * CD_W;
+        uint32_t fbits = 0;
+        if (i < CD_LW - 3)
+        {
+            const int q = i >> 2;
+            const uint32_t sh = (uint32_t)(i & 3);
+#define TRI(row) (__builtin_amdgcn_alignbyte(band[(row) * RW + q + 1], band[(row) * RW + q], sh) & 0x00ffffffu)
+#pragma unroll
+            for (int r = 0; r < NS; r++) s_tri[r][i] = TRI(r);
+#pragma unroll
+            for (int m = 0; m < NM; m++) fbits |= any_peak3(TRI(NS + m)) ? 1u << m : 0u;
+#undef TRI
+        }
+#pragma unroll
+        for (int m = 0; m < NM; m++)
+        {
+            const uint64_t w = __ballot((fbits >> m) & 1u);           // the wave's 64 consecutive columns = one word
+            if (lane == 0) s_bits[m][i >> 6] = w;
+        }
+    }
+    // the pixels that pass the edge test (:392-393), four per thread from dwords of the mask row; the rest of the
+    // output is 255 (memset(dstp, 255, pitch*height))
+#pragma unroll
+    for (int jr = 0; jr < R; jr += CD_W / 64)
+    {
+        const int j = jr + (tid >> 6), y = y0 + j, xb = x0 + 4 * lane;
+        if (R % (CD_W / 64) != 0 && j >= R) break;                // wave-uniform (R smaller than the block's waves)
+        const uint32_t *mrow = band + (NS + j + 1) * RW + CD_HALO / 4 + lane;
+        const uint32_t prev = mrow[-1], cur = mrow[0], next = mrow[1];
+        auto eq255 = [](uint32_t v) { return (((v & 0x7f7f7f7fu) + 0x01010101u) & v) & 0x80808080u; };
+        uint32_t act = eq255(cur) & (eq255(__builtin_amdgcn_alignbyte(cur, prev, 3)) | eq255(__builtin_amdgcn_alignbyte(next, cur, 1)));
+        if (y < 1 || y >= height - 1) act = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (xb + k < 1 || xb + k >= width - 1) act &= ~(0x80u << (8 * k));
+        reinterpret_cast<uint32_t *>(&s_out[j][0])[lane] = 0xffffffffu;
+        // listed in column order (see above)
+        int total = 0, before = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            const uint64_t bal = __ballot((act >> (8 * k + 7)) & 1u);
+            before += (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            total += __popcll(bal);
+        }
+        int base = 0;
+        if (lane == 0 && total) base = atomicAdd(&s_count, total);
+        base = __builtin_amdgcn_readfirstlane(base) + before;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if ((act >> (8 * k + 7)) & 1u) s_list[base++] = (uint16_t)((j << 8) | (4 * lane + k));
+    }
+    __syncthreads();
+    const int count = s_count;
+    if (count)                                        // block-uniform
+    {
+        const int maxdt = pl == 0 ? maxd : (maxd >> 1);
+        const int len = 2 * maxdt + 1;
+        const bool edge = y0 <= 1 || y0 + R - 1 >= height - 2;
+        for (int p = tid; p < count; p += CD_W)
+        {
+            const uint32_t id = s_list[p];
+            const int j = (int)(id >> 8), lx = (int)(id & 255u), y = y0 + j, px = x0 + lx, b = lx + CD_HALO - 1;
+            // The steps this pixel takes, as a bit set (bit jj: u = jj - maxdt): inside its range, and - unless on the first /
+            // last row - with a mask peak above at +u and below at -u (:395-399).  Above: bits b-maxdt .. b+maxdt of the row's
+            // bitmap in that order; below: the same bits of the other row's in reverse.
+            const int startu = max(-px + 1, -maxdt), stopu = min(width - 2 - px, maxdt);
+            auto window = [&](const uint64_t *bits) {
+                const int start = b - maxdt, wq = start >> 6, sh = start & 63;
+                const uint64_t lo = bits[wq], hi = bits[wq + 1];
+                return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+            };
+            uint64_t pass = 0;
+            if (stopu >= startu)
+            {
+                const int nb = stopu - startu + 1;
+                pass = (nb >= 64 ? ~0ull : ((1ull << nb) - 1ull)) << (startu + maxdt);
+                if (y != 1)          pass &= window(s_bits[j]);
+                if (y != height - 2) pass &= __brevll(window(s_bits[j + 2])) >> (64 - len);
+            }
+            const uint32_t *tr = &s_tri[j][b];
+            const int out = edge ? calc_dir_search<true>(tr, pass, maxdt, y == 1, y == height - 2, nt13, nt19)
+                                 : calc_dir_search<false>(tr, pass, maxdt, false, false, nt13, nt19);
+            s_out[j][lx] = (uint8_t)out;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int jr = 0; jr < R; jr += CD_W / 64)
+    {
+        const int j = jr + (tid >> 6), y = y0 + j, xb = x0 + 4 * lane;
+        if (j < R && y < height && xb < pitch)
+            *reinterpret_cast<uint32_t *>(P.c[pl] + (size_t)y * pitch + xb) = reinterpret_cast<const uint32_t *>(&s_out[j][0])[lane];
+    }
+}
+
 // filter_dir_map / expand_dir_map and their _2x forms.
 // a = edge mask, b = direction map in, c = out.  step = 1 (half height) or 2.
 // step 1: rows 1..height-2, neighbours y+-1, mask row y.
@@ -2662,6 +2892,8 @@ int Eedi2Engine::enqueue_passes(int tff, int sel, hbhip_ctx *lc)
     if (par_.maximum_search_distance <= CD_HALO - 2)
     {
         static const bool old_form = getenv("HBHIP_EEDI2_OLD_CALCDIR") != nullptr;     // A/B switch for profiling
+        static const bool tile3_form = getenv("HBHIP_EEDI2_CALCDIR_TILE3") != nullptr;  // A/B switch: one row per block, unsorted
+        static const int rows_per_block = getenv("HBHIP_EEDI2_CALCDIR_ROWS") ? atoi(getenv("HBHIP_EEDI2_CALCDIR_ROWS")) : 2;   // A/B: 2, 4 or 8 rows per block
         if (old_form)
             HBHIP_LAUNCH(lc, "eedi2_calc_directions", k_calc_dir_tile,
                          dim3((srcp.stride[0] + CD_W - 1) / CD_W, srcp.height[0], 3), dim3(CD_W), 0, P,
@@ -2670,10 +2902,26 @@ int Eedi2Engine::enqueue_passes(int tff, int sel, hbhip_ctx *lc)
             HBHIP_LAUNCH(lc, "eedi2_calc_directions", k_calc_dir_tile2,
                          dim3((srcp.stride[0] + CD_W - 1) / CD_W, srcp.height[0], 3), dim3(CD_W), 0, P,
                          par_.maximum_search_distance, (par_.noise_threshold * 13) & 0xff, (par_.noise_threshold * 19) & 0xff);
-        else
+        else if (tile3_form)
             HBHIP_LAUNCH(lc, "eedi2_calc_directions", k_calc_dir_tile3,
                          dim3((srcp.stride[0] + CD_W - 1) / CD_W, srcp.height[0], 3), dim3(CD_W), 0, P,
                          par_.maximum_search_distance, (par_.noise_threshold * 13) & 0xff, (par_.noise_threshold * 19) & 0xff);
+        // rows per block, measured (kernel alone / decomb bob throughput): 2: 44 us / 5.72 k fps, 4: 53 / 5.62 k, 8: 69 / 5.82 k
+        // (the more rows, the fewer instructions - and the fewer, longer workgroups to balance over the CUs);
+        // k_calc_dir_tile3: 54 us / 5.37 k fps
+        else if (rows_per_block == 2)
+            HBHIP_LAUNCH(lc, "eedi2_calc_directions", k_calc_dir_rows<2>,
+                         dim3((srcp.stride[0] + CD_W - 1) / CD_W, (srcp.height[0] + 1) / 2, 3), dim3(CD_W), 0, P,
+                         par_.maximum_search_distance, (par_.noise_threshold * 13) & 0xff, (par_.noise_threshold * 19) & 0xff);
+        else if (rows_per_block == 8)
+            HBHIP_LAUNCH(lc, "eedi2_calc_directions", k_calc_dir_rows<8>,
+                         dim3((srcp.stride[0] + CD_W - 1) / CD_W, (srcp.height[0] + 7) / 8, 3), dim3(CD_W), 0, P,
+                         par_.maximum_search_distance, (par_.noise_threshold * 13) & 0xff, (par_.noise_threshold * 19) & 0xff);
+        else if (rows_per_block == 4)
+            HBHIP_LAUNCH(lc, "eedi2_calc_directions", k_calc_dir_rows<4>,
+                         dim3((srcp.stride[0] + CD_W - 1) / CD_W, (srcp.height[0] + 3) / 4, 3), dim3(CD_W), 0, P,
+                         par_.maximum_search_distance, (par_.noise_threshold * 13) & 0xff, (par_.noise_threshold * 19) & 0xff);
+        else return HBHIP_ERR_ARG;
     }
     else
     {

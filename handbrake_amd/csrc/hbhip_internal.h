@@ -76,8 +76,25 @@ struct hbhip_ctx
 
 // Launch a kernel on the context's stream; when profiling is on the launch is
 // bracketed by two events whose delta is accumulated under `name`.
+// What-if profiling: HBHIP_SKIP_KERNELS=<substring>[,<substring>...] drops the launches whose name matches (results are
+// wrong then, by design): how much of a workload's wall time hangs on a kernel is then a measurement, not an estimate.
+static inline bool hbhip_skip_launch(const char *name)
+{
+    static const char *list = getenv("HBHIP_SKIP_KERNELS");
+    if (!list || !*list) return false;
+    for (const char *p = list; *p; )
+    {
+        const char *q = strchr(p, ',');
+        const size_t n = q ? (size_t)(q - p) : strlen(p);
+        if (n && n < 96) { char sub[96]; memcpy(sub, p, n); sub[n] = 0; if (strstr(name, sub)) return true; }
+        p = q ? q + 1 : p + n;
+    }
+    return false;
+}
+
 #define HBHIP_LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                \
     do {                                                                        \
+        if (hbhip_skip_launch(name)) break;                                     \
         if ((ctx)->profile)                                                     \
         {                                                                       \
             /* launch and its two events as one unit: other filter threads share the stream */ \

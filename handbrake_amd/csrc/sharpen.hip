@@ -204,59 +204,101 @@ struct BlurArgs
 // pitches stay in bytes
 struct BlurArgs3 { BlurArgs p[3]; };
 
+// The blur size is a compile-time constant of the body (S = steps, size = 2 S + 1; the kernel switches on the plane's
+// steps, uniform per workgroup): the tap loops unroll, the binomial coefficients sit in SGPRs, and a multiply-add of a tap
+// is one v_mad_u32_u24 - the sums are the reference's uint32 sums modulo 2^32, and with 8-bit samples every factor stays
+// below 2^24 (coefficients <= 3432, horizontal sums <= 255 * 2^14), so the 24-bit multiply (low 32 bits of the full
+// product) is exact; the full 32-bit multiply it replaces is a quarter-rate instruction.  16-bit samples keep the full
+// multiply in the vertical pass (horizontal sums reach 2^30).  A thread's four output rows share their 4 + 2 S
+// horizontal sums in registers.
+template <typename PIX, int S>
+__device__ __forceinline__ void blur_mix_body(const BlurArgs &a, PIX *s_src, uint32_t *s_h)
+{
+    constexpr int TW = BT_W + 2 * S, TH = BT_H + 2 * S, NT = 2 * S + 1;
+    const int x0 = blockIdx.x * BT_W, y0 = blockIdx.y * BT_H;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+
+    // edge-clamped tile (unsharp.c:126 clamps x, :117-120 / :166-170 clamp y)
+    // (all of a wave's loads are issued before the first one is waited for: the staging is a chain of memory latencies
+    // otherwise, one per tile row)
+    {
+        constexpr int NR = (TH + 3) / 4;
+        PIX v0[NR], v1[NR];
+        const int xa = min(max(x0 - S + lane, 0), a.width - 1), xb = min(max(x0 - S + lane + 64, 0), a.width - 1);
+#pragma unroll
+        for (int k = 0; k < NR; k++)
+        {
+            const int y = min(max(y0 - S + wv + 4 * k, 0), a.height - 1);      // rows past the tile are loaded, not stored
+            const PIX *row = reinterpret_cast<const PIX *>(a.src + (uint32_t)__mul24(y, a.src_pitch));
+            v0[k] = row[xa];
+            v1[k] = row[xb];
+        }
+#pragma unroll
+        for (int k = 0; k < NR; k++)
+        {
+            const int r = wv + 4 * k;
+            if (r < TH)
+            {
+                s_src[r * TW + lane] = v0[k];
+                if (lane + 64 < TW) s_src[r * TW + lane + 64] = v1[k];
+            }
+        }
+    }
+    __syncthreads();
+
+    // horizontal binomial sums for every tile row
+    for (int r = wv; r < TH; r += 4)
+    {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int k = 0; k < NT; k++) sum = __umul24(a.coef[k], (uint32_t)s_src[r * TW + lane + k]) + sum;
+        s_h[r * BT_W + lane] = sum;
+    }
+    __syncthreads();
+
+    // vertical sums + mix; thread -> 4 rows of one column (coalesced rows)
+    const int c = lane, x = x0 + c;
+    if (x >= a.width) return;
+    constexpr int Q = BT_H / 4;
+    const int r0 = wv * Q;
+    uint32_t h[Q + 2 * S];
+#pragma unroll
+    for (int k = 0; k < Q + 2 * S; k++) h[k] = s_h[(r0 + k) * BT_W + c];
+#pragma unroll
+    for (int q = 0; q < Q; q++)
+    {
+        const int r = r0 + q, y = y0 + r;
+        if (y >= a.height) break;
+        uint32_t t = 0;
+#pragma unroll
+        for (int k = 0; k < NT; k++)
+            t = sizeof(PIX) == 1 ? __umul24(a.coef[k], h[q + k]) + t : a.coef[k] * h[q + k] + t;
+        const int p = (int)s_src[(r + S) * TW + c + S];
+        const int blur = (int)((t + (uint32_t)a.halfscale) >> a.scalebits);
+        const int d = ((p - blur) * a.amount) >> 16;         // arithmetic shift, as gcc does
+        int res = a.sign > 0 ? p + d : p - d;
+        res = res > a.vmax ? a.vmax : res < a.vmin ? a.vmin : res;
+        reinterpret_cast<PIX *>(a.dst + (size_t)y * a.dst_pitch)[x] = (PIX)res;
+    }
+}
+
 template <typename PIX>
 __global__ __launch_bounds__(256) void blur_mix_kernel(BlurArgs3 all)
 {
     const BlurArgs &a = all.p[blockIdx.z];
     __shared__ PIX      s_src[(BT_H + 2 * MAX_STEPS) * (BT_W + 2 * MAX_STEPS)];
     __shared__ uint32_t s_h[(BT_H + 2 * MAX_STEPS) * BT_W];
-
-    const int s = a.steps;
-    const int tw = BT_W + 2 * s, th = BT_H + 2 * s;
-    const int x0 = blockIdx.x * BT_W, y0 = blockIdx.y * BT_H;
-    if (x0 >= a.width || y0 >= a.height) return;          // the grid is sized for the largest plane of the launch
-
-    // edge-clamped tile (unsharp.c:126 clamps x, :117-120 / :166-170 clamp y)
-    for (int i = threadIdx.x; i < tw * th; i += 256)
+    if ((int)(blockIdx.x * BT_W) >= a.width || (int)(blockIdx.y * BT_H) >= a.height) return;   // the grid is sized for the largest plane of the launch
+    switch (a.steps)                                         // uniform per workgroup
     {
-        const int r = i / tw, c = i - r * tw;
-        const int y = min(max(y0 - s + r, 0), a.height - 1);
-        const int x = min(max(x0 - s + c, 0), a.width - 1);
-        s_src[i] = reinterpret_cast<const PIX *>(a.src + (size_t)y * a.src_pitch)[x];
-    }
-    __syncthreads();
-
-    // horizontal binomial sums for every tile row
-    for (int i = threadIdx.x; i < th * BT_W; i += 256)
-    {
-        const int r = i / BT_W, c = i - r * BT_W;
-        uint32_t sum = 0;
-        for (int k = 0; k <= 2 * s; k++)
-            sum += a.coef[k] * (uint32_t)s_src[r * tw + c + k];
-        s_h[i] = sum;
-    }
-    __syncthreads();
-
-    // vertical sums + mix; thread -> 4 rows of one column (coalesced rows)
-    const int c = threadIdx.x & (BT_W - 1);
-    const int rg = threadIdx.x / BT_W;                       // 0..3
-    const int x = x0 + c;
-    if (x >= a.width) return;
-#pragma unroll
-    for (int q = 0; q < BT_H / 4; q++)
-    {
-        const int r = rg * (BT_H / 4) + q;
-        const int y = y0 + r;
-        if (y >= a.height) break;
-        uint32_t t = 0;
-        for (int k = 0; k <= 2 * s; k++)
-            t += a.coef[k] * s_h[(r + k) * BT_W + c];
-        const int p = (int)s_src[(r + s) * tw + c + s];
-        const int blur = (int)((t + (uint32_t)a.halfscale) >> a.scalebits);
-        const int d = ((p - blur) * a.amount) >> 16;         // arithmetic shift, as gcc does
-        int res = a.sign > 0 ? p + d : p - d;
-        res = res > a.vmax ? a.vmax : res < a.vmin ? a.vmin : res;
-        reinterpret_cast<PIX *>(a.dst + (size_t)y * a.dst_pitch)[x] = (PIX)res;
+        case 1: blur_mix_body<PIX, 1>(a, s_src, s_h); break;
+        case 2: blur_mix_body<PIX, 2>(a, s_src, s_h); break;
+        case 3: blur_mix_body<PIX, 3>(a, s_src, s_h); break;
+        case 4: blur_mix_body<PIX, 4>(a, s_src, s_h); break;
+        case 5: blur_mix_body<PIX, 5>(a, s_src, s_h); break;
+        case 6: blur_mix_body<PIX, 6>(a, s_src, s_h); break;
+        case 7: blur_mix_body<PIX, 7>(a, s_src, s_h); break;
+        default: break;
     }
 }
 
@@ -315,10 +357,14 @@ __global__ __launch_bounds__(256) void lapsharp3_rows_kernel(LapBatch3 B)
     const bool tail = x0 + 8 > P.valid_w;
 
     int u_prev[4], u_cur[4], v_cur[4], m_cur[4];
+    // byte offsets of the three dwords of a row this thread reads (clamped into the row: only read for pixels that end up
+    // copied), as 32-bit unsigned offsets from the plane's base: a row costs one multiply and three adds of address work
+    const uint32_t o0 = 4u * (uint32_t)max(xd - 1, 0), o1 = 4u * (uint32_t)xd, o2 = 4u * (uint32_t)min(xd + 1, pitch_dw - 1);
     auto load_row = [&](int yy, int (&u)[4], int (&v)[4], int (&m)[4]) {
         yy = min(max(yy, 0), P.height - 1);                  // only read for pixels that end up copied
-        const uint32_t *r = reinterpret_cast<const uint32_t *>(src + (size_t)yy * P.src_pitch);
-        uint32_t w[3] = { r[max(xd - 1, 0)], r[xd], r[min(xd + 1, pitch_dw - 1)] };
+        const uint32_t ro = (uint32_t)__mul24(yy, P.src_pitch);      // rows and pitches stay below 2^23
+        uint32_t w[3] = { *reinterpret_cast<const uint32_t *>(src + (ro + o0)), *reinterpret_cast<const uint32_t *>(src + (ro + o1)),
+                          *reinterpret_cast<const uint32_t *>(src + (ro + o2)) };
         if (tail)
         {
 #pragma unroll
@@ -337,8 +383,9 @@ __global__ __launch_bounds__(256) void lapsharp3_rows_kernel(LapBatch3 B)
         {
             const int h = bb[k] + bb[k + 2];
             m[k] = bb[k + 1];
-            u[k] = P.a * h + P.b * m[k];
-            v[k] = P.b * h + P.c * m[k];
+            // (24-bit multiplies: |taps| <= 25, samples <= 510 - the full 32-bit multiply is a quarter-rate instruction)
+            u[k] = __mul24(P.a, h) + __mul24(P.b, m[k]);
+            v[k] = __mul24(P.b, h) + __mul24(P.c, m[k]);
         }
     };
     {
@@ -347,29 +394,49 @@ __global__ __launch_bounds__(256) void lapsharp3_rows_kernel(LapBatch3 B)
         load_row(ys, u_cur, v_cur, m_cur);
     }
     const int y_end = min(ys + LS_ROWS, P.height);
-    for (int y = ys; y < y_end; y++)
+    // which of the thread's four columns are copied whatever the row (x < stride_border + HI || x > width + stride_border
+    // - HI, lapsharp.c:167-171); interior threads (nearly all) then run the row body without any per-pixel border test
+    uint32_t copy_cols = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (x0 + k < P.stride_border + 2 || x0 + k > P.width + P.stride_border - 2) copy_cols |= 1u << k;
+    const bool full_dword = x0 + 3 < P.width;
+    // fully unrolled: the carried rows (u_prev / u_cur / v_cur / m_cur) rotate by renaming instead of sixteen moves per row
+#pragma unroll
+    for (int r = 0; r < LS_ROWS; r++)
     {
+        const int y = ys + r;
+        if (y >= y_end) break;
         int u_next[4], v_next[4], m_next[4];
         load_row(y + 1, u_next, v_next, m_next);
         const bool row_copy = (y < 2) || (y > P.height - 2);                 // y < HI || y > height - HI, HI = 2
         uint32_t packed = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++)
+        if (row_copy)                                                        // wave-uniform (a wave works on one row)
         {
-            const int x = x0 + k;
-            const int centre = m_cur[k];
-            int out = centre;
-            if (!(row_copy || x < P.stride_border + 2 || x > P.width + P.stride_border - 2))
+#pragma unroll
+            for (int k = 0; k < 4; k++) packed |= (uint32_t)m_cur[k] << (8 * k);
+        }
+        else
+        {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
             {
+                const int centre = m_cur[k];
                 const int acc = u_prev[k] + v_cur[k] + u_next[k];
                 const double mixed = (((double)acc * P.coef) - (double)centre) * P.strength;   // lapsharp.c:174-175
-                out = (int)(short)(int)mixed + centre;
+                int out = (int)(short)(int)mixed + centre;
                 out = min(max(out, 0), 255);
+                packed |= (uint32_t)out << (8 * k);
             }
-            packed |= (uint32_t)out << (8 * k);
+            if (copy_cols)                                                   // border columns keep the source sample
+            {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if ((copy_cols >> k) & 1u) packed = (packed & ~(0xffu << (8 * k))) | ((uint32_t)m_cur[k] << (8 * k));
+            }
         }
-        uint8_t *d = dst + (size_t)y * P.dst_pitch + x0;
-        if (x0 + 3 < P.width) *reinterpret_cast<uint32_t *>(d) = packed;
+        uint8_t *d = dst + ((uint32_t)__mul24(y, P.dst_pitch) + (uint32_t)x0);
+        if (full_dword) *reinterpret_cast<uint32_t *>(d) = packed;
         else for (int k = 0; x0 + k < P.width; k++) d[k] = (uint8_t)(packed >> (8 * k));
 #pragma unroll
         for (int k = 0; k < 4; k++) { u_prev[k] = u_cur[k]; u_cur[k] = u_next[k]; v_cur[k] = v_next[k]; m_cur[k] = m_next[k]; }

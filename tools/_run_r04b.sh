@@ -1,0 +1,30 @@
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r04b; O=$GRAFT_REPO_ROOT/gpurun_out/r04b
+run() { # tag, workload, env...
+  tag=$1; wl=$2; shift 2
+  env "$@" timeout 200 python bench.py --workload $wl --no-cpu-baseline --no-pcie --no-kernel-timer --steps 12 --warmup 3 > $O/$tag.json 2> $O/$tag.err
+  python - <<PY
+import json
+try:
+    b=json.load(open("$O/$tag.json")); print("$tag", b["value"], b["ms_per_step"], b.get("host_enqueue_ms_per_step"))
+except Exception as e: print("$tag", "ERR", e)
+PY
+}
+run d_base decomb_eedi2 A=1
+run d_tile3 decomb_eedi2 HBHIP_EEDI2_CALCDIR_TILE3=1
+run d_nocalc decomb_eedi2 HBHIP_SKIP_KERNELS=eedi2_calc_directions
+run d_nolat decomb_eedi2 HBHIP_SKIP_KERNELS=eedi2_lattice
+run d_nofill decomb_eedi2 HBHIP_SKIP_KERNELS=eedi2_fill_gaps
+run d_nodirmap decomb_eedi2 HBHIP_SKIP_KERNELS=dir_map
+run d_onlymask decomb_eedi2 HBHIP_SKIP_KERNELS=eedi2_calc,eedi2_filter,eedi2_expand,eedi2_mark,eedi2_fill_gaps,eedi2_lattice,eedi2_post
+run d_none decomb_eedi2 HBHIP_SKIP_KERNELS=eedi2_,decomb_
+run d_e1 decomb_eedi2 HBHIP_EEDI2_ENGINES=1
+run d_e2 decomb_eedi2 HBHIP_EEDI2_ENGINES=2
+run d_e2_nocalc decomb_eedi2 HBHIP_EEDI2_ENGINES=2 HBHIP_SKIP_KERNELS=eedi2_calc_directions
+run d_serial decomb_eedi2 HBHIP_EEDI2_SERIAL=1
+run d_serial_nocalc decomb_eedi2 HBHIP_EEDI2_SERIAL=1 HBHIP_SKIP_KERNELS=eedi2_calc_directions
+run c_base chain A=1
+run c_nocalc chain HBHIP_SKIP_KERNELS=eedi2_calc_directions
+run c_noeedi chain HBHIP_SKIP_KERNELS=eedi2_
+run c_nonlm chain HBHIP_SKIP_KERNELS=nlmeans
+run c_noscale chain HBHIP_SKIP_KERNELS=cropscale
+run c_nolap chain HBHIP_SKIP_KERNELS=lapsharp
