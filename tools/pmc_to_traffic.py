@@ -9,7 +9,7 @@ import sys
 # C++ kernel name (as summarize_pmc.py shortens it) -> name of the launch in hbhip's profiler; frames per launch of
 # the chain workload's default batch (16 input frames = 32 fields / output frames)
 NAMES = {
-    "k_calc_dir_tile3": ("eedi2_calc_directions", 1), "k_fill_gaps_c": ("eedi2_fill_gaps_2x", 1),
+    "k_calc_dir_tile3": ("eedi2_calc_directions", 1), "k_calc_dir_rows": ("eedi2_calc_directions", 1), "k_fill_gaps_c": ("eedi2_fill_gaps_2x", 1),
     "k_lattice_cand_q": ("eedi2_lattice_candidates", 1), "k_lattice_resolve": ("eedi2_lattice_resolve", 1),
     "k_mask_fused4": ("eedi2_mask_passes", 1), "k_mark_2x4": ("eedi2_mark_directions_2x", 1),
     "k_filter_map": ("eedi2_filter_map", 1), "k_post": ("eedi2_post_process", 1), "k_fill_half4": ("eedi2_fill_half", 1),
