@@ -2872,10 +2872,11 @@ int Eedi2Engine::enqueue_passes(int tff, int sel, hbhip_ctx *lc)
     bool post_folded = false;
     auto dir_map = [&](const char *name, const EediFrame &f, const P3 &Pv, int step, int y0v, int expand, int post = 0) {
         static const bool four_px = getenv("HBHIP_EEDI2_4PX") != nullptr;              // A/B switch: four pixels per thread, sort in place
+        static const bool filter_queue = getenv("HBHIP_EEDI2_FILTER_QUEUE") != nullptr;  // A/B switch: filter_dir_map through the queueing form too
         if (one_px)       HBHIP_LAUNCH(lc, name, k_dir_map, grid_for(f, false), blk, 0, Pv, step, y0v, expand);
         // the queueing form pays where few pixels reach the sort (expand: only peak pixels with >= 5 usable neighbours);
         // filter_dir_map sorts at most masked pixels, there the in-place form is ahead
-        else if (four_px || !expand) HBHIP_LAUNCH(lc, name, k_dir_map4, grid4_for(f, false), blk, 0, Pv, step, y0v, expand);
+        else if (four_px || (!expand && !filter_queue)) HBHIP_LAUNCH(lc, name, k_dir_map4, grid4_for(f, false), blk, 0, Pv, step, y0v, expand);
         else            { HBHIP_LAUNCH(lc, name, k_dir_map_c, grid4_for(f, false), blk, 0, Pv, step, y0v, expand, post); post_folded = post != 0; }
     };
     auto geom = [&](P3 &P, const EediFrame &f) {

@@ -235,6 +235,209 @@ __global__ void q_calc_dir(Q3 P, K16 k, int maxd, int nt)
     P.c[pl][(size_t)y * pitch + x] = (uint16_t)out;
 }
 
+// calc_directions for search distances <= 30, the form that runs: the structure of k_calc_dir_rows (eedi2.hip) on 16-bit
+// samples.  A block takes 256 columns x R rows: R + 4 source and R + 2 mask rows staged in LDS (flat addressing, as the
+// reference's pointers), the three samples every search step needs of a row (columns i .. i+2) formed once into a table
+// of dword pairs ({s[i] | s[i+1] << 16, s[i+2]}: a 3-sample SAD is two v_sad_u16), the mask rows reduced to peak
+// bitmaps (ballots) from which each masked pixel cuts its step set as a 64-bit word, the masked pixels listed in column
+// order, one lane each.  A running minimum and its offset are one integer, (sum << 6) | (u + 32) (sums of 18 samples
+// stay below 2^26); values and comparisons are q_calc_dir's (:358-525).
+constexpr int QW = 256, QHALO = 32, QLW = QW + 2 * QHALO;
+
+__device__ __forceinline__ uint32_t sad3q(uint2 a, uint2 b, uint32_t acc)
+{
+    return __builtin_amdgcn_sad_u16(a.x, b.x, __builtin_amdgcn_sad_u16(a.y, b.y, acc));
+}
+
+template <bool EDGE>
+__device__ __forceinline__ int calc_dir_search16(const uint2 *tr, uint64_t pass, int maxdt, bool first, bool last, int nt13, int nt19,
+                                                 const int *limlut, int neutral, int shift)
+{
+    // tr = &s_tri[j][b]: row r of the table is r * QLW further (r = 0..4: rows y-2 .. y+2)
+    const uint2 F2p = tr[0], Fp = tr[QLW], Fc = tr[2 * QLW], Fn = tr[3 * QLW], F2n = tr[4 * QLW];
+    const int ctr = (int)(Fc.x >> 16);
+    const int vert = iabs16(ctr - (int)(Fn.x >> 16)) + iabs16(ctr - (int)(Fp.x >> 16));
+    // keys: (running minimum << 6) | (u + 32), low six bits 0 = unset (the reference's -5000)
+    uint32_t kb = (uint32_t)min(nt13, vert * 6) << 6, ka = (uint32_t)min(nt19, vert * 9) << 6;
+    uint32_t kc = ka, kd = kb, ke = kb;
+    while (pass)
+    {
+        const int jj = __ffsll((unsigned long long)pass) - 1;
+        pass &= pass - 1ull;
+        const int u = jj - maxdt;
+        const uint32_t ub = (uint32_t)(u + 32);
+        const uint2 *tp = tr + u, *tm = tr - u;
+        const uint32_t e1 = sad3q(Fp, tm[2 * QLW], sad3q(Fc, tm[3 * QLW], 0u));     // diffsn + diffps
+        const uint32_t d1 = sad3q(Fn, tp[2 * QLW], sad3q(Fc, tp[1 * QLW], 0u));     // diffsp + diffns
+        const uint32_t diff = e1 + d1;
+        uint32_t diffd = d1, diffe = e1;
+        kb = min(kb, (diff << 6) | ub);
+        if (!EDGE || !first)
+        {
+            const uint32_t diff2pp = sad3q(F2p, tm[1 * QLW], 0u);
+            const uint32_t diffp2p = sad3q(Fp, tp[0 * QLW], 0u);
+            diffd += diffp2p;
+            diffe += diff2pp;
+            ka = min(ka, ((diff + diff2pp + diffp2p) << 6) | ub);
+        }
+        if (!EDGE || !last)
+        {
+            const uint32_t diff2nn = sad3q(F2n, tp[3 * QLW], 0u);
+            const uint32_t diffn2n = sad3q(Fn, tm[4 * QLW], 0u);
+            diffd += diff2nn;
+            diffe += diffn2n;
+            kc = min(kc, ((diff + diff2nn + diffn2n) << 6) | ub);
+        }
+        kd = min(kd, (diffd << 6) | ub);
+        ke = min(ke, (diffe << 6) | ub);
+    }
+    // the offsets that were set, sorted (unset ones as a large sentinel at the end): 9-exchange network on 5 values
+    constexpr int BIG = 1 << 20;
+    const int ta = (int)(ka & 63u), tb = (int)(kb & 63u), tc = (int)(kc & 63u), td = (int)(kd & 63u), te = (int)(ke & 63u);
+    int v0 = ta ? ta - 32 : BIG, v1 = tb ? tb - 32 : BIG, v2 = tc ? tc - 32 : BIG, v3 = td ? td - 32 : BIG, v4 = te ? te - 32 : BIG;
+    const int n = (ta != 0) + (tb != 0) + (tc != 0) + (td != 0) + (te != 0);
+#define Q_CX(a, b) { const int lo_ = min(a, b), hi_ = max(a, b); a = lo_; b = hi_; }
+    Q_CX(v0, v1) Q_CX(v3, v4) Q_CX(v2, v4) Q_CX(v2, v3) Q_CX(v0, v3) Q_CX(v0, v2) Q_CX(v1, v4) Q_CX(v1, v3) Q_CX(v1, v2)
+#undef Q_CX
+    int out = neutral;
+    if (n > 1)
+    {
+        // sorted_mid16's midpoint rule: odd n -> v[n/2], even n -> (v[(n-1)/2] + v[n/2] + 1) >> 1; one formula serves both
+        const int lo = n == 2 ? v0 : (n == 5 ? v2 : v1);
+        const int hi = n >= 4 ? v2 : v1;
+        const int mid = (lo + hi + 1) >> 1;
+        const int tlim = max(limlut[iabs16(mid)] >> 2, 2);
+        int sum = 0, cnt = 0;
+        if (iabs16(v0 - mid) <= tlim) { cnt++; sum += v0; }          // the sentinels fail the test by themselves
+        if (iabs16(v1 - mid) <= tlim) { cnt++; sum += v1; }
+        if (iabs16(v2 - mid) <= tlim) { cnt++; sum += v2; }
+        if (iabs16(v3 - mid) <= tlim) { cnt++; sum += v3; }
+        if (iabs16(v4 - mid) <= tlim) { cnt++; sum += v4; }
+        if (cnt > 1) out = (uint16_t)(neutral + ((int)((float)sum / (float)cnt) << (2 + shift)));
+    }
+    return out;
+}
+
+template <int R>
+__global__ __launch_bounds__(QW) void q_calc_dir_rows(Q3 P, K16 k, int maxd, int nt)
+{
+    constexpr int NS = R + 4, NM = R + 2, RWD = QLW / 2;                      // RWD: dwords per staged row
+    __shared__ __attribute__((aligned(16))) uint16_t s_band[NS + NM][QLW];    // staged rows: 0..NS-1 source y0-2.., NS.. mask y0-1..
+    __shared__ uint2    s_tri[NS][QLW];                                       // [r][i] = samples i..i+2 of source row r
+    __shared__ uint64_t s_pk[NM][8];                                          // bit i: mask row m holds the peak value at column i
+    __shared__ uint16_t s_list[R * QW];                                       // the listed pixels, (row << 8) | column
+    __shared__ __attribute__((aligned(16))) uint16_t s_out[R][QW];
+    __shared__ int s_lim[33];
+    __shared__ int s_count;
+    const int pl = blockIdx.z;
+    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
+    const int x0 = blockIdx.x * QW, y0 = blockIdx.y * R;
+    if (y0 >= height || x0 >= pitch) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int peak = k.peak;
+    if (tid == 0) s_count = 0;
+    if (tid < 33) s_lim[tid] = k.limlut[tid];
+    if (tid >= 64 && tid < 64 + NM * 3) s_pk[(tid - 64) / 3][5 + (tid - 64) % 3] = 0;   // words past the staged columns
+    uint32_t *band = reinterpret_cast<uint32_t *>(&s_band[0][0]);
+    {
+        // flat addressing (out-of-row columns pick up the neighbouring rows' samples, as the reference's pointer arithmetic
+        // does); rows past height + 1 serve no pixel and are not touched
+        const uint16_t *sb = P.b[pl] + x0 - QHALO, *mb = P.a[pl] + x0 - QHALO;
+        for (int i = tid; i < (NS + NM) * RWD; i += QW)
+        {
+            const int r = i / RWD, c2 = i - r * RWD;
+            const uint16_t *src = r < NS ? sb + (ptrdiff_t)min(y0 - 2 + r, height + 1) * pitch
+                                         : mb + (ptrdiff_t)min(y0 - 1 + (r - NS), height) * pitch;
+            band[i] = reinterpret_cast<const uint32_t *>(src)[c2];
+        }
+    }
+    __syncthreads();
+    // tables (columns 0 .. QLW-3) and peak bitmaps (columns 0 .. QLW-1): a first round for all, the rest for the first wave
+    for (int rnd = 0; rnd < 2; rnd++)
+    {
+        if (rnd == 1 && tid >= 64) break;                            // wave-uniform
+        const int i = tid + rnd * QW;
+        if (i < QLW - 2)
+        {
+            const int q = i >> 1;
+            const uint32_t sh = (uint32_t)(i & 1) * 2u;
+#pragma unroll
+            for (int r = 0; r < NS; r++)
+            {
+                const uint32_t d0 = band[r * RWD + q], d1 = band[r * RWD + q + 1];
+                s_tri[r][i] = make_uint2(__builtin_amdgcn_alignbyte(d1, d0, sh), (d1 >> (8u * sh)) & 0xffffu);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < NM; m++)
+        {
+            const uint64_t w = __ballot(i < QLW && s_band[NS + m][i < QLW ? i : 0] == peak);   // the wave's 64 consecutive columns = one word
+            if (lane == 0 && i < QLW) s_pk[m][i >> 6] = w;
+        }
+    }
+    // the pixels that pass the edge test (:392-393), a row of the block per round, listed in column order; the rest of the
+    // output is the peak value (the reference's memset)
+#pragma unroll
+    for (int j = 0; j < R; j++)
+    {
+        const int y = y0 + j, x = x0 + tid;
+        const uint16_t *m = &s_band[NS + j + 1][tid + QHALO];
+        const bool act = y >= 1 && y < height - 1 && x >= 1 && x < width - 1 && m[0] == peak && (m[-1] == peak || m[1] == peak);
+        s_out[j][tid] = (uint16_t)peak;
+        const uint64_t bal = __ballot(act);
+        int base = 0;
+        if (lane == 0 && bal) base = atomicAdd(&s_count, __popcll(bal));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (act) s_list[base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (uint16_t)((j << 8) | tid);
+    }
+    __syncthreads();
+    const int count = s_count;
+    if (count)                                        // block-uniform
+    {
+        const int nt13 = (uint16_t)((nt << k.shift) * 13), nt19 = (uint16_t)((nt << k.shift) * 19);
+        const int maxdt = pl == 0 ? maxd : (maxd >> 1);
+        const int len = 2 * maxdt + 1;
+        const uint64_t lenmask = (1ull << len) - 1ull;
+        const bool edge = y0 <= 1 || y0 + R - 1 >= height - 2;
+        for (int p = tid; p < count; p += QW)
+        {
+            const uint32_t id = s_list[p];
+            const int j = (int)(id >> 8), lx = (int)(id & 255u), y = y0 + j, px = x0 + lx, b = lx + QHALO - 1;
+            // The steps this pixel takes, as a bit set (bit jj: u = jj - maxdt): inside its range, and - unless on the first /
+            // last row - with a mask peak among the three samples above at +u and below at -u (:395-399).  any3 bit t of a
+            // row's window: a peak among columns b-maxdt+t .. +2; above it is used as it lies, below reversed.
+            const int startu = max(-px + 1, -maxdt), stopu = min(width - 2 - px, maxdt);
+            auto any3 = [&](const uint64_t *bits) {
+                const int start = b - maxdt, wq = start >> 6, sh = start & 63;
+                const uint64_t lo = bits[wq], hi = bits[wq + 1];
+                const uint64_t w = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+                return (w | (w >> 1) | (w >> 2)) & lenmask;
+            };
+            uint64_t pass = 0;
+            if (stopu >= startu)
+            {
+                const int nb = stopu - startu + 1;
+                pass = (nb >= 64 ? ~0ull : ((1ull << nb) - 1ull)) << (startu + maxdt);
+                if (y != 1)          pass &= any3(s_pk[j]);
+                if (y != height - 2) pass &= __brevll(any3(s_pk[j + 2])) >> (64 - len);
+            }
+            const uint2 *tr = &s_tri[j][b];
+            const int out = edge ? calc_dir_search16<true>(tr, pass, maxdt, y == 1, y == height - 2, nt13, nt19, s_lim, k.neutral, k.shift)
+                                 : calc_dir_search16<false>(tr, pass, maxdt, false, false, nt13, nt19, s_lim, k.neutral, k.shift);
+            s_out[j][lx] = (uint16_t)out;
+        }
+        __syncthreads();
+    }
+    // output rows as dwords (two samples); the whole pitch is written, as the one-thread form does
+#pragma unroll
+    for (int i = tid; i < R * (QW / 2); i += QW)
+    {
+        const int j = i / (QW / 2), c2 = i - j * (QW / 2), y = y0 + j, xb = x0 + 2 * c2;
+        if (y < height && xb < pitch)
+            *reinterpret_cast<uint32_t *>(P.c[pl] + (size_t)y * pitch + xb) = reinterpret_cast<const uint32_t *>(&s_out[j][0])[c2];
+    }
+}
+
 // filter_dir_map (:649-709) / expand_dir_map (:722-773) and, with step 2, the _2x forms (:872-1011).
 // a = mask, b = direction map in, c = out.  step 1: rows 1..height-2 looking at rows y+-1 and mask row y;
 // step 2: rows y0, y0+2, ... looking at rows y+-2 and mask rows y-1 / y+1.
@@ -961,7 +1164,12 @@ int Eedi2Engine16::run(const DevPicture *cur, int tff)
     bind(P.a, tmpp); bind(P.c, mskp);
     HBHIP_LAUNCH(ctx_, "eedi2_16_small_gaps", q_small_gaps, grid(srcp, false), blk, 0, P, k);
     bind(P.a, mskp); bind(P.b, srcp); bind(P.c, tmpp);
-    HBHIP_LAUNCH(ctx_, "eedi2_16_calc_directions", q_calc_dir, grid(srcp, true), blk, 0, P, k, par_.maximum_search_distance, par_.noise_threshold);
+    static const bool one_sample_calc_dir = getenv("HBHIP_EEDI2_16_OLD_CALCDIR") != nullptr;     // A/B switch
+    if (par_.maximum_search_distance <= QHALO - 2 && !one_sample_calc_dir)
+        HBHIP_LAUNCH(ctx_, "eedi2_16_calc_directions", q_calc_dir_rows<2>, dim3((srcp.stride[0] / 2 + QW - 1) / QW, (srcp.height[0] + 1) / 2, 3),
+                     dim3(QW), 0, P, k, par_.maximum_search_distance, par_.noise_threshold);
+    else
+        HBHIP_LAUNCH(ctx_, "eedi2_16_calc_directions", q_calc_dir, grid(srcp, true), blk, 0, P, k, par_.maximum_search_distance, par_.noise_threshold);
     bind(P.a, mskp); bind(P.b, tmpp); bind(P.c, dstp);
     HBHIP_LAUNCH(ctx_, "eedi2_16_filter_dir_map", q_dir_map, grid(srcp, false), blk, 0, P, k, 1, 1, 0);
     bind(P.a, mskp); bind(P.b, dstp); bind(P.c, tmpp);
