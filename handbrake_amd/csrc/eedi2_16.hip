@@ -441,6 +441,54 @@ __global__ __launch_bounds__(QW) void q_calc_dir_rows(Q3 P, K16 k, int maxd, int
 // filter_dir_map (:649-709) / expand_dir_map (:722-773) and, with step 2, the _2x forms (:872-1011).
 // a = mask, b = direction map in, c = out.  step 1: rows 1..height-2 looking at rows y+-1 and mask row y;
 // step 2: rows y0, y0+2, ... looking at rows y+-2 and mask rows y-1 / y+1.
+// (the candidates sit in nine fixed slots - an absent one holds ABSENT16, larger than any sample and farther from any
+// midpoint than any vote limit - and a sorting network orders them: no data-dependent loop, no indexed array; the
+// midpoint and the vote are sorted_mid16's / vote16's, as in the 8-bit k_dir_map)
+constexpr int ABSENT16 = 1 << 20;
+
+__device__ __forceinline__ void cswap16(int &a, int &b)
+{
+    const int lo = min(a, b), hi = max(a, b);
+    a = lo; b = hi;
+}
+
+// midpoint of the n present values among 9 slots (n >= 4)
+__device__ __forceinline__ int mid9q(int &v0, int &v1, int &v2, int &v3, int &v4, int &v5, int &v6, int &v7, int &v8, int n)
+{
+    cswap16(v0, v3); cswap16(v1, v7); cswap16(v2, v5); cswap16(v4, v8);
+    cswap16(v0, v7); cswap16(v2, v4); cswap16(v3, v8); cswap16(v5, v6);
+    cswap16(v0, v2); cswap16(v1, v3); cswap16(v4, v5); cswap16(v7, v8);
+    cswap16(v1, v4); cswap16(v3, v6); cswap16(v5, v7);
+    cswap16(v0, v1); cswap16(v2, v4); cswap16(v3, v5); cswap16(v6, v8);
+    cswap16(v2, v3); cswap16(v4, v5); cswap16(v6, v7);
+    cswap16(v1, v2); cswap16(v3, v4); cswap16(v5, v6);
+    // n = 4..9: lower middle index (n-1)>>1 = 1,2,2,3,3,4 ; upper n>>1 = 2,2,3,3,4,4
+    const int lo = n <= 4 ? v1 : (n <= 6 ? v2 : (n <= 8 ? v3 : v4));
+    const int hi = n <= 5 ? v2 : (n <= 7 ? v3 : v4);
+    return (n & 1) ? hi : (lo + hi + 1) >> 1;
+}
+
+// midpoint of the n present values among 6 slots (n >= 3)
+__device__ __forceinline__ int mid6q(int &v0, int &v1, int &v2, int &v3, int &v4, int &v5, int n)
+{
+    cswap16(v0, v5); cswap16(v1, v3); cswap16(v2, v4);
+    cswap16(v1, v2); cswap16(v3, v4);
+    cswap16(v0, v3); cswap16(v2, v5);
+    cswap16(v0, v1); cswap16(v2, v3); cswap16(v4, v5);
+    cswap16(v1, v2); cswap16(v3, v4);
+    // n = 3..6: lower middle index 1,1,2,2 ; upper 1,2,2,3
+    const int lo = n <= 4 ? v1 : v2;
+    const int hi = n <= 3 ? v1 : (n <= 5 ? v2 : v3);
+    return (n & 1) ? hi : (lo + hi + 1) >> 1;
+}
+
+__device__ __forceinline__ void vote1q(int v, int mid, int lim, int &sum, int &cnt)
+{
+    const bool in = iabs16(v - mid) <= lim;      // never true for ABSENT16
+    cnt += in;
+    sum += in ? v : 0;
+}
+
 __global__ void q_dir_map(Q3 P, K16 k, int step, int y0, int expand)
 {
     XY16(P);
@@ -454,24 +502,33 @@ __global__ void q_dir_map(Q3 P, K16 k, int step, int y0, int expand)
         bool masked;
         if (step == 1) masked = P.a[pl][(size_t)y * pitch + x] == peak;
         else           masked = P.a[pl][(size_t)(y - 1) * pitch + x] == peak || P.a[pl][(size_t)(y + 1) * pitch + x] == peak;
-        if (masked && !(expand && dc[x] != peak))
+        if (masked && !(expand && v != peak))
         {
-            const uint16_t *dp = dc - (ptrdiff_t)step * pitch, *dn = dc + (ptrdiff_t)step * pitch;
-            int order[9], u = 0;
-            if (step == 1 || y > 1) u = collect16(order, u, dp, x, false, peak);
-            u = collect16(order, u, dc, x, expand != 0, peak);
-            if (step == 1 || y < height - 2) u = collect16(order, u, dn, x, false, peak);
+            const bool up_ok = step == 1 || y > 1, dn_ok = step == 1 || y < height - 2;
+            const uint16_t *dp = up_ok ? dc - (ptrdiff_t)step * pitch : dc, *dn = dn_ok ? dc + (ptrdiff_t)step * pitch : dc;
+            const int u0 = dp[x - 1], u1 = dp[x], u2 = dp[x + 1], c0 = dc[x - 1], c2 = dc[x + 1], n0 = dn[x - 1], n1 = dn[x], n2 = dn[x + 1];
+            const bool h0 = up_ok && u0 != peak, h1 = up_ok && u1 != peak, h2 = up_ok && u2 != peak;
+            const bool h3 = c0 != peak, h4 = !expand && v != peak, h5 = c2 != peak;
+            const bool h6 = dn_ok && n0 != peak, h7 = dn_ok && n1 != peak, h8 = dn_ok && n2 != peak;
+            const int u = h0 + h1 + h2 + h3 + h4 + h5 + h6 + h7 + h8;
             if (u < (expand ? 5 : 4))
             {
                 if (!expand) v = peak;
             }
             else
             {
-                const int mid = sorted_mid16(order, u);
-                int count;
-                const int val = vote16(order, u, mid, k.limlut[iabs16(mid - k.neutral) >> (2 + k.shift)], count);
+                int v0 = h0 ? u0 : ABSENT16, v1 = h1 ? u1 : ABSENT16, v2 = h2 ? u2 : ABSENT16;
+                int v3 = h3 ? c0 : ABSENT16, v4 = h4 ? v : ABSENT16, v5 = h5 ? c2 : ABSENT16;
+                int v6 = h6 ? n0 : ABSENT16, v7 = h7 ? n1 : ABSENT16, v8 = h8 ? n2 : ABSENT16;
+                const int mid = mid9q(v0, v1, v2, v3, v4, v5, v6, v7, v8, u);
+                const int lim = k.limlut[iabs16(mid - k.neutral) >> (2 + k.shift)];
+                int sum = 0, count = 0;
+                vote1q(v0, mid, lim, sum, count); vote1q(v1, mid, lim, sum, count); vote1q(v2, mid, lim, sum, count);
+                vote1q(v3, mid, lim, sum, count); vote1q(v4, mid, lim, sum, count); vote1q(v5, mid, lim, sum, count);
+                vote1q(v6, mid, lim, sum, count); vote1q(v7, mid, lim, sum, count); vote1q(v8, mid, lim, sum, count);
+                const int val = (int)(((float)(sum + mid) / (float)(count + 1)) + 0.5f);
                 if (expand) { if (count >= 5) v = val; }
-                else if (count < 4 || (count < 5 && dc[x] == peak)) v = peak;
+                else if (count < 4 || (count < 5 && v == peak)) v = peak;
                 else v = val;
             }
         }
@@ -540,21 +597,25 @@ __global__ void q_mark_2x(Q3 P, K16 k, int y0)
         const uint16_t *m0 = P.a[pl] + (size_t)(y - 1) * pitch, *m1 = m0 + 2 * (size_t)pitch;
         if (m0[x] == peak || m1[x] == peak)
         {
-            int order[6], n = 0;
-            n = collect16(order, n, d0, x, false, peak);
-            n = collect16(order, n, d1, x, false, peak);
+            const int a0 = d0[x - 1], a1 = d0[x], a2 = d0[x + 1], b0 = d1[x - 1], b1 = d1[x], b2 = d1[x + 1];
+            const bool h0 = a0 != peak, h1 = a1 != peak, h2 = a2 != peak, h3 = b0 != peak, h4 = b1 != peak, h5 = b2 != peak;
+            const int n = h0 + h1 + h2 + h3 + h4 + h5;
             if (n >= 3)
             {
-                const int mid = sorted_mid16(order, n);
+                int v0 = h0 ? a0 : ABSENT16, v1 = h1 ? a1 : ABSENT16, v2 = h2 ? a2 : ABSENT16;
+                int v3 = h3 ? b0 : ABSENT16, v4 = h4 ? b1 : ABSENT16, v5 = h5 ? b2 : ABSENT16;
+                const int mid = mid6q(v0, v1, v2, v3, v4, v5, n);
                 const int lim = k.limlut[iabs16(mid - k.neutral) >> (2 + k.shift)];
                 int u = 0;
-                if (iabs16((int)d0[x - 1] - (int)d1[x - 1]) <= lim || d0[x - 1] == peak || d1[x - 1] == peak) u++;
-                if (iabs16((int)d0[x] - (int)d1[x]) <= lim || d0[x] == peak || d1[x] == peak) u++;
-                if (iabs16((int)d0[x + 1] - (int)d1[x - 1]) <= lim || d0[x + 1] == peak || d1[x + 1] == peak) u++;   // sic (:835)
+                if (iabs16(a0 - b0) <= lim || !h0 || !h3) u++;
+                if (iabs16(a1 - b1) <= lim || !h1 || !h4) u++;
+                if (iabs16(a2 - b0) <= lim || !h2 || !h5) u++;                                   // sic (:835)
                 if (u >= 2)
                 {
-                    int count;
-                    const int val = vote16(order, n, mid, lim, count);
+                    int sum = 0, count = 0;
+                    vote1q(v0, mid, lim, sum, count); vote1q(v1, mid, lim, sum, count); vote1q(v2, mid, lim, sum, count);
+                    vote1q(v3, mid, lim, sum, count); vote1q(v4, mid, lim, sum, count); vote1q(v5, mid, lim, sum, count);
+                    const int val = (int)(((float)(sum + mid) / (float)(count + 1)) + 0.5f);
                     if (!(count < n - 2 || count < 2)) v = val;
                 }
             }
