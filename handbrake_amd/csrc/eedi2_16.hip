@@ -1123,6 +1123,8 @@ Eedi2Engine16::Eedi2Engine16(hbhip_ctx *ctx, const PicGeometry &geo, const Eedi2
 
 Eedi2Engine16::~Eedi2Engine16()
 {
+    for (auto &g : graph_) if (g) (void)hipGraphExecDestroy(g);
+    if (cap_ctx_) hbhip_ctx_destroy(cap_ctx_);
     if (cand_) (void)hipFree(cand_);
     for (auto &f : half_) if (f.alloc) (void)hipFree(f.alloc);
     for (auto &f : full_) if (f.alloc) (void)hipFree(f.alloc);
@@ -1178,7 +1180,7 @@ int Eedi2Engine16::init()
     return HBHIP_OK;
 }
 
-int Eedi2Engine16::run(const DevPicture *cur, int tff)
+int Eedi2Engine16::enqueue(const DevPicture *cur, int tff, hbhip_ctx *lc, bool do_fill, bool do_rest)
 {
     EediFrame &srcp = half_[0], &mskp = half_[1], &tmpp = half_[2], &dstp = half_[3];
     EediFrame &dst2p = full_[0], &tmp2p2 = full_[1], &msk2p = full_[2], &tmp2p = full_[3], &dst2mp = full_[4];
@@ -1204,88 +1206,90 @@ int Eedi2Engine16::run(const DevPicture *cur, int tff)
 
     // field extraction (decomb_template.c:455-473)
     geom(P, srcp);
-    for (int c = 0; c < 3; c++) P.a[c] = (uint16_t *)cur->plane[c];
+    if (do_fill) for (int c = 0; c < 3; c++) P.a[c] = (uint16_t *)cur->plane[c];
     bind(P.b, srcp);
+    if (do_fill)
     {
         int rows[3];
         for (int c = 0; c < 3; c++) rows[c] = (dst2p.height[c] + 1) / 2;
-        HBHIP_LAUNCH(ctx_, "eedi2_16_fill_half", q_fill_half, grid(srcp, true), blk, 0, P,
+        HBHIP_LAUNCH(lc, "eedi2_16_fill_half", q_fill_half, grid(srcp, true), blk, 0, P,
                      cur->pitch[0] / 2, cur->pitch[1] / 2, cur->pitch[2] / 2, !tff, rows[0], rows[1], rows[2]);
     }
+    if (!do_rest) { HBHIP_CHECK(lc, hipGetLastError()); return HBHIP_OK; }
     // half-height passes (decomb_template.c:390-404)
     bind(P.a, srcp); bind(P.c, mskp);
-    HBHIP_LAUNCH(ctx_, "eedi2_16_edge_mask", q_edge_mask, grid(srcp, true), blk, 0, P, k,
+    HBHIP_LAUNCH(lc, "eedi2_16_edge_mask", q_edge_mask, grid(srcp, true), blk, 0, P, k,
                  par_.magnitude_threshold * 10, par_.laplacian_threshold * 81, par_.variance_threshold);
     bind(P.a, mskp); bind(P.c, tmpp);
-    HBHIP_LAUNCH(ctx_, "eedi2_16_erode", q_morph, grid(srcp, false), blk, 0, P, k, par_.erosion_threshold, 0);
+    HBHIP_LAUNCH(lc, "eedi2_16_erode", q_morph, grid(srcp, false), blk, 0, P, k, par_.erosion_threshold, 0);
     bind(P.a, tmpp); bind(P.c, mskp);
-    HBHIP_LAUNCH(ctx_, "eedi2_16_dilate", q_morph, grid(srcp, false), blk, 0, P, k, par_.dilation_threshold, 1);
+    HBHIP_LAUNCH(lc, "eedi2_16_dilate", q_morph, grid(srcp, false), blk, 0, P, k, par_.dilation_threshold, 1);
     bind(P.a, mskp); bind(P.c, tmpp);
-    HBHIP_LAUNCH(ctx_, "eedi2_16_erode", q_morph, grid(srcp, false), blk, 0, P, k, par_.erosion_threshold, 0);
+    HBHIP_LAUNCH(lc, "eedi2_16_erode", q_morph, grid(srcp, false), blk, 0, P, k, par_.erosion_threshold, 0);
     bind(P.a, tmpp); bind(P.c, mskp);
-    HBHIP_LAUNCH(ctx_, "eedi2_16_small_gaps", q_small_gaps, grid(srcp, false), blk, 0, P, k);
+    HBHIP_LAUNCH(lc, "eedi2_16_small_gaps", q_small_gaps, grid(srcp, false), blk, 0, P, k);
     bind(P.a, mskp); bind(P.b, srcp); bind(P.c, tmpp);
     static const bool one_sample_calc_dir = getenv("HBHIP_EEDI2_16_OLD_CALCDIR") != nullptr;     // A/B switch
     if (par_.maximum_search_distance <= QHALO - 2 && !one_sample_calc_dir)
-        HBHIP_LAUNCH(ctx_, "eedi2_16_calc_directions", q_calc_dir_rows<2>, dim3((srcp.stride[0] / 2 + QW - 1) / QW, (srcp.height[0] + 1) / 2, 3),
+        HBHIP_LAUNCH(lc, "eedi2_16_calc_directions", q_calc_dir_rows<2>, dim3((srcp.stride[0] / 2 + QW - 1) / QW, (srcp.height[0] + 1) / 2, 3),
                      dim3(QW), 0, P, k, par_.maximum_search_distance, par_.noise_threshold);
     else
-        HBHIP_LAUNCH(ctx_, "eedi2_16_calc_directions", q_calc_dir, grid(srcp, true), blk, 0, P, k, par_.maximum_search_distance, par_.noise_threshold);
+        HBHIP_LAUNCH(lc, "eedi2_16_calc_directions", q_calc_dir, grid(srcp, true), blk, 0, P, k, par_.maximum_search_distance, par_.noise_threshold);
     bind(P.a, mskp); bind(P.b, tmpp); bind(P.c, dstp);
-    HBHIP_LAUNCH(ctx_, "eedi2_16_filter_dir_map", q_dir_map, grid(srcp, false), blk, 0, P, k, 1, 1, 0);
+    HBHIP_LAUNCH(lc, "eedi2_16_filter_dir_map", q_dir_map, grid(srcp, false), blk, 0, P, k, 1, 1, 0);
     bind(P.a, mskp); bind(P.b, dstp); bind(P.c, tmpp);
-    HBHIP_LAUNCH(ctx_, "eedi2_16_expand_dir_map", q_dir_map, grid(srcp, false), blk, 0, P, k, 1, 1, 1);
+    HBHIP_LAUNCH(lc, "eedi2_16_expand_dir_map", q_dir_map, grid(srcp, false), blk, 0, P, k, 1, 1, 1);
     bind(P.a, mskp); bind(P.b, tmpp); bind(P.c, dstp);
-    HBHIP_LAUNCH(ctx_, "eedi2_16_filter_map", q_filter_map, grid(srcp, false), blk, 0, P, k);
+    HBHIP_LAUNCH(lc, "eedi2_16_filter_map", q_filter_map, grid(srcp, false), blk, 0, P, k);
     // line doubling
     bind(P.a, srcp); bind(P.c, dst2p);
-    HBHIP_LAUNCH(ctx_, "eedi2_16_upscale", q_upscale, grid(srcp, true), blk, 0, P);
+    HBHIP_LAUNCH(lc, "eedi2_16_upscale", q_upscale, grid(srcp, true), blk, 0, P);
     bind(P.a, dstp); bind(P.c, tmp2p2);
-    HBHIP_LAUNCH(ctx_, "eedi2_16_upscale", q_upscale, grid(srcp, true), blk, 0, P);
+    HBHIP_LAUNCH(lc, "eedi2_16_upscale", q_upscale, grid(srcp, true), blk, 0, P);
     bind(P.a, mskp); bind(P.c, msk2p);
-    HBHIP_LAUNCH(ctx_, "eedi2_16_upscale", q_upscale, grid(srcp, true), blk, 0, P);
+    HBHIP_LAUNCH(lc, "eedi2_16_upscale", q_upscale, grid(srcp, true), blk, 0, P);
     // full-height passes
     geom(P, dst2p);
     const int y0 = 2 - tff;
     bind(P.a, msk2p); bind(P.b, tmp2p2); bind(P.c, tmp2p);
-    HBHIP_LAUNCH(ctx_, "eedi2_16_mark_directions_2x", q_mark_2x, grid(dst2p, true), blk, 0, P, k, y0);
+    HBHIP_LAUNCH(lc, "eedi2_16_mark_directions_2x", q_mark_2x, grid(dst2p, true), blk, 0, P, k, y0);
     bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
-    HBHIP_LAUNCH(ctx_, "eedi2_16_filter_dir_map_2x", q_dir_map, grid(dst2p, false), blk, 0, P, k, 2, y0, 0);
+    HBHIP_LAUNCH(lc, "eedi2_16_filter_dir_map_2x", q_dir_map, grid(dst2p, false), blk, 0, P, k, 2, y0, 0);
     bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
-    HBHIP_LAUNCH(ctx_, "eedi2_16_expand_dir_map_2x", q_dir_map, grid(dst2p, false), blk, 0, P, k, 2, y0, 1);
+    HBHIP_LAUNCH(lc, "eedi2_16_expand_dir_map_2x", q_dir_map, grid(dst2p, false), blk, 0, P, k, 2, y0, 1);
     for (int pass = 0; pass < 2; pass++)
     {
         const EediFrame &in = pass ? dst2mp : tmp2p, &out = pass ? tmp2p : dst2mp;
         bind(P.a, in); bind(P.c, out);
-        HBHIP_LAUNCH(ctx_, "eedi2_16_blit", q_blit, grid(dst2p, false), blk, 0, P);
+        HBHIP_LAUNCH(lc, "eedi2_16_blit", q_blit, grid(dst2p, false), blk, 0, P);
         bind(P.a, msk2p); bind(P.b, in); bind(P.c, out);
-        HBHIP_LAUNCH(ctx_, "eedi2_16_fill_gaps_2x", q_fill_gaps, grid(dst2p, false), blk, 0, P, k, y0);
+        HBHIP_LAUNCH(lc, "eedi2_16_fill_gaps_2x", q_fill_gaps, grid(dst2p, false), blk, 0, P, k, y0);
     }
     bind(P.a, tmp2p); bind(P.b, dst2p); bind(P.c, tmp2p2);
     {
         const int nrows = (dst2p.height[0] - 1 - y0 + 1) / 2;
         static const bool serial = getenv("HBHIP_EEDI2_16_SERIAL_LATTICE") != nullptr;     // A/B switch: one thread per row
         if (serial || !cand_)
-            HBHIP_LAUNCH(ctx_, "eedi2_16_interpolate_lattice", q_lattice, dim3((nrows + 1 + 63) / 64, 1, 3), dim3(64), 0, P, k, tff,
+            HBHIP_LAUNCH(lc, "eedi2_16_interpolate_lattice", q_lattice, dim3((nrows + 1 + 63) / 64, 1, 3), dim3(64), 0, P, k, tff,
                          par_.noise_threshold);
         else
         {
-            HBHIP_LAUNCH(ctx_, "eedi2_16_lattice_candidates", q_lattice_cand, dim3((dst2p.width[0] + 255) / 256, nrows, 3), dim3(256), 0, P, k,
+            HBHIP_LAUNCH(lc, "eedi2_16_lattice_candidates", q_lattice_cand, dim3((dst2p.width[0] + 255) / 256, nrows, 3), dim3(256), 0, P, k,
                          tff, par_.noise_threshold, cand_, cand_pitch_, cand_plane_stride_);
-            HBHIP_LAUNCH(ctx_, "eedi2_16_lattice_resolve", q_lattice_resolve16, dim3(1, nrows + 1, 3), dim3(LR16_T), 0, P, k, tff,
+            HBHIP_LAUNCH(lc, "eedi2_16_lattice_resolve", q_lattice_resolve16, dim3(1, nrows + 1, 3), dim3(LR16_T), 0, P, k, tff,
                          (const unsigned long long *)cand_, cand_pitch_, cand_plane_stride_);
         }
     }
     if (par_.post_processing == 1 || par_.post_processing == 3)
     {
         bind(P.a, tmp2p); bind(P.c, tmp2p2);
-        HBHIP_LAUNCH(ctx_, "eedi2_16_blit", q_blit, grid(dst2p, false), blk, 0, P);                 // eedi2_bit_blit(tmp2p -> tmp2p2)
+        HBHIP_LAUNCH(lc, "eedi2_16_blit", q_blit, grid(dst2p, false), blk, 0, P);                 // eedi2_bit_blit(tmp2p -> tmp2p2)
         bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
-        HBHIP_LAUNCH(ctx_, "eedi2_16_filter_dir_map_2x", q_dir_map, grid(dst2p, false), blk, 0, P, k, 2, y0, 0);
+        HBHIP_LAUNCH(lc, "eedi2_16_filter_dir_map_2x", q_dir_map, grid(dst2p, false), blk, 0, P, k, 2, y0, 0);
         bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
-        HBHIP_LAUNCH(ctx_, "eedi2_16_expand_dir_map_2x", q_dir_map, grid(dst2p, false), blk, 0, P, k, 2, y0, 1);
+        HBHIP_LAUNCH(lc, "eedi2_16_expand_dir_map_2x", q_dir_map, grid(dst2p, false), blk, 0, P, k, 2, y0, 1);
         bind(P.a, tmp2p); bind(P.b, tmp2p2); bind(P.c, dst2p);
-        HBHIP_LAUNCH(ctx_, "eedi2_16_post_process", q_post, grid(dst2p, false), blk, 0, P, k, y0);
+        HBHIP_LAUNCH(lc, "eedi2_16_post_process", q_post, grid(dst2p, false), blk, 0, P, k, y0);
     }
     if (par_.post_processing == 2 || par_.post_processing == 3)
     {
@@ -1296,17 +1300,51 @@ int Eedi2Engine16::run(const DevPicture *cur, int tff)
             for (int i = 0; i < 3; i++) { A.c[i] = deriv_[i]; A.t[i] = deriv_tmp_[i]; }
             A.pitch = srcp.stride[c] / 2; A.width = srcp.width[c]; A.height = srcp.height[c];
             const dim3 g1((A.width + 63) / 64, (A.height + 3) / 4, 1), g3(g1.x, g1.y, 3);
-            HBHIP_LAUNCH(ctx_, "eedi2_16_gaussian_blur1_h", q_blur1<false>, g1, blk, 0, A);
-            HBHIP_LAUNCH(ctx_, "eedi2_16_gaussian_blur1_v", q_blur1<true>, g1, blk, 0, A);
-            HBHIP_LAUNCH(ctx_, "eedi2_16_calc_derivatives", q_derivatives, g1, blk, 0, A, k.shift);
-            HBHIP_LAUNCH(ctx_, "eedi2_16_gaussian_blur_sqrt2_h", q_blur_sqrt2<false>, g3, blk, 0, A);
-            HBHIP_LAUNCH(ctx_, "eedi2_16_gaussian_blur_sqrt2_v", q_blur_sqrt2<true>, g3, blk, 0, A);
+            HBHIP_LAUNCH(lc, "eedi2_16_gaussian_blur1_h", q_blur1<false>, g1, blk, 0, A);
+            HBHIP_LAUNCH(lc, "eedi2_16_gaussian_blur1_v", q_blur1<true>, g1, blk, 0, A);
+            HBHIP_LAUNCH(lc, "eedi2_16_calc_derivatives", q_derivatives, g1, blk, 0, A, k.shift);
+            HBHIP_LAUNCH(lc, "eedi2_16_gaussian_blur_sqrt2_h", q_blur_sqrt2<false>, g3, blk, 0, A);
+            HBHIP_LAUNCH(lc, "eedi2_16_gaussian_blur_sqrt2_v", q_blur_sqrt2<true>, g3, blk, 0, A);
             const int rows = (dst2p.height[c] - 7 - (8 - tff) + 1) / 2;
             if (rows > 0)
-                HBHIP_LAUNCH(ctx_, "eedi2_16_post_process_corner", q_post_corner, dim3((A.width + 63) / 64, (rows + 3) / 4, 1), blk, 0, A,
+                HBHIP_LAUNCH(lc, "eedi2_16_post_process_corner", q_post_corner, dim3((A.width + 63) / 64, (rows + 3) / 4, 1), blk, 0, A,
                              (const uint16_t *)tmp2p2.plane[c], (uint16_t *)dst2p.plane[c], tff, dst2p.height[c], k.peak, k.neutral);
         }
     }
-    HBHIP_CHECK(ctx_, hipGetLastError());
+    HBHIP_CHECK(lc, hipGetLastError());
     return HBHIP_OK;
+}
+
+// One field: the field extraction reads the caller's picture (a different one every time) and is launched as it is; the
+// ~28 launches after it only touch this engine's scratch frames and are the same from field to field (per field parity):
+// captured once into a hipGraph and replayed - the 16-bit path was bound by the host's launch calls (9.5 ms of enqueueing
+// for a 12 ms step of 32 fields).  The per-kernel profiler needs individual launches and bypasses the graph.
+int Eedi2Engine16::run(const DevPicture *cur, int tff)
+{
+    static const bool no_graph = getenv("HBHIP_EEDI2_16_NO_GRAPH") != nullptr;          // A/B switch
+    if (ctx_->profile || !use_graph_ || no_graph) return enqueue(cur, tff, ctx_, true, true);
+    int rc = enqueue(cur, tff, ctx_, true, false);
+    if (rc != HBHIP_OK) return rc;
+    hipGraphExec_t &exec = graph_[tff ? 1 : 0];
+    if (!exec)
+    {
+        hipGraph_t g = nullptr;
+        if (!cap_ctx_ && hbhip_ctx_create(ctx_->device, &cap_ctx_) != HBHIP_OK) cap_ctx_ = nullptr;
+        if (!cap_ctx_) { use_graph_ = false; return enqueue(cur, tff, ctx_, false, true); }
+        HBHIP_CHECK(ctx_, hipStreamBeginCapture(cap_ctx_->stream, hipStreamCaptureModeThreadLocal));
+        const int crc = enqueue(cur, tff, cap_ctx_, false, true);
+        const hipError_t e = hipStreamEndCapture(cap_ctx_->stream, &g);
+        hipError_t ie = hipErrorUnknown;
+        if (crc == HBHIP_OK && e == hipSuccess && g) ie = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+        if (g) (void)hipGraphDestroy(g);
+        if (ie != hipSuccess)
+        {
+            exec = nullptr;
+            use_graph_ = false;                      // fall back to plain launches for good
+            (void)hipGetLastError();
+        }
+    }
+    if (exec) HBHIP_CHECK(ctx_, hipGraphLaunch(exec, ctx_->stream));
+    else      rc = enqueue(cur, tff, ctx_, false, true);
+    return rc;
 }

@@ -107,6 +107,11 @@ public:
 
 private:
     int alloc_frame(EediFrame &f, int width, int height);
+    // the field extraction (do_fill) and / or the pass sequence behind it (do_rest), launched on lc's stream
+    int enqueue(const DevPicture *cur, int tff, hbhip_ctx *lc, bool do_fill, bool do_rest);
+    hipGraphExec_t graph_[2] = {nullptr, nullptr};   // captured pass sequence per field parity
+    hbhip_ctx  *cap_ctx_ = nullptr;                  // private stream the pass sequence is captured on
+    bool        use_graph_ = true;
     hbhip_ctx  *ctx_;
     PicGeometry geo_;
     Eedi2Params par_;
