@@ -121,7 +121,8 @@ __global__ __launch_bounds__(256) void rotate8_batch_kernel(RotBatch B)
     const int sx0 = min(ax, bx), sy0 = min(ay, by), sx1 = max(ax, bx), sy1 = max(ay, by);
     const int t = threadIdx.y * 64 + threadIdx.x;
     const int cols = sx1 - sx0 + 1, rows = sy1 - sy0 + 1;
-    // (offsets inside a plane fit 32 bits and rows / pitches 24: v_mul_u32_u24 instead of the quarter-rate 64-bit multiply)
+    // (offsets inside a plane fit 32 bits and rows / pitches 24: one v_mul_u32_u24 and a 32-bit offset instead of 64-bit
+    // address arithmetic per access)
     if ((sx0 & 3) == 0 && cols == 64)
     {
         for (int i = t; i < rows * 16; i += 256)

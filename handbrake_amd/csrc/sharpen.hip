@@ -205,12 +205,12 @@ struct BlurArgs
 struct BlurArgs3 { BlurArgs p[3]; };
 
 // The blur size is a compile-time constant of the body (S = steps, size = 2 S + 1; the kernel switches on the plane's
-// steps, uniform per workgroup): the tap loops unroll, the binomial coefficients sit in SGPRs, and a multiply-add of a tap
-// is one v_mad_u32_u24 - the sums are the reference's uint32 sums modulo 2^32, and with 8-bit samples every factor stays
+// steps, uniform per workgroup): the tap loops unroll, the binomial coefficients sit in SGPRs, a multiply-add of a tap is
+// one v_mad_u32_u24 - the sums are the reference's uint32 sums modulo 2^32, and with 8-bit samples every factor stays
 // below 2^24 (coefficients <= 3432, horizontal sums <= 255 * 2^14), so the 24-bit multiply (low 32 bits of the full
-// product) is exact; the full 32-bit multiply it replaces is a quarter-rate instruction.  16-bit samples keep the full
-// multiply in the vertical pass (horizontal sums reach 2^30).  A thread's four output rows share their 4 + 2 S
-// horizontal sums in registers.
+// product) is exact; 16-bit samples keep the full multiply in the vertical pass (horizontal sums reach 2^30).  A
+// thread's four output rows share their 4 + 2 S horizontal sums in registers.  (Sizes 11 - 15 and 10 / 12-bit samples
+// run here; 8-bit planes with sizes up to 9 take blur_rows8_kernel below.)
 template <typename PIX, int S>
 __device__ __forceinline__ void blur_mix_body(const BlurArgs &a, PIX *s_src, uint32_t *s_h)
 {
@@ -251,7 +251,7 @@ __device__ __forceinline__ void blur_mix_body(const BlurArgs &a, PIX *s_src, uin
     {
         uint32_t sum = 0;
 #pragma unroll
-        for (int k = 0; k < NT; k++) sum = __umul24(a.coef[k], (uint32_t)s_src[r * TW + lane + k]) + sum;
+        for (int k = 0; k < NT; k++) sum = __umul24(a.coef[k] & 0xffffu, (uint32_t)s_src[r * TW + lane + k]) + sum;
         s_h[r * BT_W + lane] = sum;
     }
     __syncthreads();
@@ -272,7 +272,7 @@ __device__ __forceinline__ void blur_mix_body(const BlurArgs &a, PIX *s_src, uin
         uint32_t t = 0;
 #pragma unroll
         for (int k = 0; k < NT; k++)
-            t = sizeof(PIX) == 1 ? __umul24(a.coef[k], h[q + k]) + t : a.coef[k] * h[q + k] + t;
+            t = sizeof(PIX) == 1 ? __umul24(a.coef[k] & 0xffffu, h[q + k] & 0xffffffu) + t : a.coef[k] * h[q + k] + t;
         const int p = (int)s_src[(r + S) * TW + c + S];
         const int blur = (int)((t + (uint32_t)a.halfscale) >> a.scalebits);
         const int d = ((p - blur) * a.amount) >> 16;         // arithmetic shift, as gcc does
@@ -299,6 +299,150 @@ __global__ __launch_bounds__(256) void blur_mix_kernel(BlurArgs3 all)
         case 6: blur_mix_body<PIX, 6>(a, s_src, s_h); break;
         case 7: blur_mix_body<PIX, 7>(a, s_src, s_h); break;
         default: break;
+    }
+}
+
+// ---- unsharp / chroma smooth, 8-bit, sizes 3..9: the form that runs ------------------------------------------------
+// The lapsharp rows kernel's shape.  A thread owns four adjacent columns (one dword of every row) and walks BR_ROWS rows
+// down.  A row comes in as three dwords (columns x0-4 .. x0+7, enough for 2 S + 1 <= 9 taps), its four horizontal binomial
+// sums stay in registers in a window of 2 S + 1 rows, and an output row is the vertical sum over the window, the
+// reference's rounding shift, and its mix with the centre sample (unsharp.c:128-170): no LDS, every sample loaded three
+// times from L1 / L2 instead of gathered bytewise, one dword stored per row.  Columns and rows outside the plane are
+// clamped (unsharp.c:117-126, 166-170): threads whose window crosses a border gather their twelve bytes one by one.
+// The sums are the reference's uint32 sums, taken exactly in float (see the kernel).  One launch covers the three planes
+// of up to BR_FRAMES frames (blockIdx.z); a plane with amount 0 is copied (unsharp.c:111-115).
+constexpr int BR_ROWS = 16, BR_FRAMES = 16, BR_MAX_STEPS = 4;
+struct BlurPlane8 { int width, height, src_pitch, dst_pitch, steps, scalebits, halfscale, amount, active; uint32_t coef[2 * BR_MAX_STEPS + 1]; };
+struct BlurBatch8
+{
+    BlurPlane8     pl[3];
+    int            sign, vmin, vmax;
+    const uint8_t *src[BR_FRAMES][3];
+    uint8_t       *dst[BR_FRAMES][3];
+};
+
+template <int S>
+__global__ __launch_bounds__(256) void blur_rows8_kernel(BlurBatch8 B)
+{
+    constexpr int NT = 2 * S + 1;
+    const int job = blockIdx.z, f = job / 3, c = job - 3 * f;
+    const BlurPlane8 &P = B.pl[c];
+    if (P.active == 0) return;
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int ys = (blockIdx.y * 4 + threadIdx.y) * BR_ROWS;
+    if (x0 >= P.width || ys >= P.height) return;
+    const uint8_t *src = B.src[f][c];
+    uint8_t *dst = B.dst[f][c];
+    const bool full_dword = x0 + 3 < P.width;
+    auto store_row = [&](int y, uint32_t v) {
+        uint8_t *d = dst + ((uint32_t)__mul24(y, P.dst_pitch) + (uint32_t)x0);
+        if (full_dword) *reinterpret_cast<uint32_t *>(d) = v;
+        else for (int k = 0; x0 + k < P.width; k++) d[k] = (uint8_t)(v >> (8 * k));
+    };
+    if (P.active == 2 || P.steps != S)                                     // a copied plane (the launch's S is another plane's)
+    {
+        if (P.active != 2) return;
+        for (int r = 0; r < BR_ROWS && ys + r < P.height; r++)
+        {
+            const uint8_t *g = src + ((uint32_t)__mul24(ys + r, P.src_pitch) + (uint32_t)x0);
+            uint32_t v = 0;
+            if (full_dword) v = *reinterpret_cast<const uint32_t *>(g);
+            else for (int k = 0; x0 + k < P.width; k++) v |= (uint32_t)g[k] << (8 * k);
+            store_row(ys + r, v);
+        }
+        return;
+    }
+    const bool interior = x0 >= 4 && x0 + 7 <= P.width - 1;
+    // The binomial sums are taken in float: every value is an integer below 2^24 (coefficients <= 70, horizontal sums <=
+    // 255 * 2^8, vertical sums <= 255 * 2^16 = 2^24 - 65536) and every partial sum is no larger than the final one, so each
+    // fused multiply-add is exact and the result is the reference's uint32 sum.  A byte becomes a float in one
+    // instruction (v_cvt_f32_ubyteN) and v_fma_f32 issues in 2 cycles per wave (the compiler pairs them into
+    // v_pk_fma_f32), where every integer multiply-add takes 4 (profiles/r02_valu_rate.json).
+    float cf[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) cf[t] = (float)P.coef[t];
+    // a row's three dwords (columns x0-4 .. x0+7, clamped into the plane)
+    struct Raw { uint32_t w0, w1, w2; };
+    auto load_raw = [&](int yy) -> Raw {
+        yy = min(max(yy, 0), P.height - 1);
+        const uint32_t ro = (uint32_t)__mul24(yy, P.src_pitch);
+        Raw w;
+        if (interior)
+        {
+            const uint32_t *g = reinterpret_cast<const uint32_t *>(src + (ro + (uint32_t)x0));
+            w.w0 = g[-1]; w.w1 = g[0]; w.w2 = g[1];
+        }
+        else
+        {
+            w.w0 = w.w1 = w.w2 = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+            {
+                w.w0 |= (uint32_t)src[ro + (uint32_t)min(max(x0 - 4 + i, 0), P.width - 1)] << (8 * i);
+                w.w1 |= (uint32_t)src[ro + (uint32_t)min(max(x0 + i, 0), P.width - 1)] << (8 * i);
+                w.w2 |= (uint32_t)src[ro + (uint32_t)min(max(x0 + 4 + i, 0), P.width - 1)] << (8 * i);
+            }
+        }
+        return w;
+    };
+    // its four horizontal sums and its own dword (the centre samples)
+    auto sums = [&](const Raw &w, float (&h)[4], uint32_t &centre) {
+        centre = w.w1;
+        float b[12];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            b[i] = (float)((w.w0 >> (8 * i)) & 0xffu); b[4 + i] = (float)((w.w1 >> (8 * i)) & 0xffu); b[8 + i] = (float)((w.w2 >> (8 * i)) & 0xffu);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; t++) sum = __fmaf_rn(cf[t], b[4 - S + k + t], sum);
+            h[k] = sum;
+        }
+    };
+    float H[NT][4];                                                        // rows y-S .. y+S of the row being made
+    uint32_t C[NT];
+    {
+        // the rows before the first output row: all their loads first, then the arithmetic
+        Raw w[NT - 1];
+#pragma unroll
+        for (int r = 0; r < NT - 1; r++) w[r] = load_raw(ys - S + r);
+#pragma unroll
+        for (int r = 0; r < NT - 1; r++) sums(w[r], H[r], C[r]);
+    }
+    // (issuing a row's loads one row ahead of their use changes nothing: 111 against 103 us per 16 frames)
+#pragma unroll
+    for (int r = 0; r < BR_ROWS; r++)
+    {
+        const int y = ys + r;
+        if (y >= P.height) break;
+        sums(load_raw(y + S), H[NT - 1], C[NT - 1]);
+        uint32_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            float tf = 0.f;
+#pragma unroll
+            for (int j = 0; j < NT; j++) tf = __fmaf_rn(cf[j], H[j][k], tf);
+            const uint32_t t = (uint32_t)tf;
+            const int p = (int)((C[S] >> (8 * k)) & 0xffu);
+            const int blur = (int)((t + (uint32_t)P.halfscale) >> P.scalebits);
+            const int d = ((p - blur) * P.amount) >> 16;                   // arithmetic shift, as gcc does
+            int res = B.sign > 0 ? p + d : p - d;
+            res = res > B.vmax ? B.vmax : res < B.vmin ? B.vmin : res;
+            packed |= (uint32_t)res << (8 * k);
+        }
+        store_row(y, packed);
+#pragma unroll
+        for (int j = 0; j < NT - 1; j++)
+        {
+            C[j] = C[j + 1];
+#pragma unroll
+            for (int k = 0; k < 4; k++) H[j][k] = H[j + 1][k];
+        }
     }
 }
 
@@ -383,7 +527,7 @@ __global__ __launch_bounds__(256) void lapsharp3_rows_kernel(LapBatch3 B)
         {
             const int h = bb[k] + bb[k + 2];
             m[k] = bb[k + 1];
-            // (24-bit multiplies: |taps| <= 25, samples <= 510 - the full 32-bit multiply is a quarter-rate instruction)
+            // (|taps| <= 25, samples <= 510: 24-bit multiply-adds, no 64-bit v_mad_u64_u32 forms)
             u[k] = __mul24(P.a, h) + __mul24(P.b, m[k]);
             v[k] = __mul24(P.b, h) + __mul24(P.c, m[k]);
         }
@@ -544,8 +688,86 @@ class BlurMixFilter : public SimpleFilter
 public:
     BlurMixFilter(hbhip_ctx *c, const hbhip_blur_params &p, int sign_, int vmin_, int vmax_, const char *nm)
         : SimpleFilter(c), par(p), sign(sign_), vmin(vmin_), vmax(vmax_), name(nm) {}
+    // the rows kernel takes 8-bit planes with sizes up to 9 whose rows are dword aligned
+    bool rows_ok(const DevPicture *in, const DevPicture *out) const
+    {
+        if (in_geo.bps != 1 || getenv("HBHIP_BLUR_OLD")) return false;
+        for (int c = 0; c < 3; c++)
+        {
+            if (par.amount[c] && par.size[c] / 2 > BR_MAX_STEPS) return false;
+            if ((in->pitch[c] & 3) || (out->pitch[c] & 3) || ((uintptr_t)in->plane[c] & 3) || ((uintptr_t)out->plane[c] & 3)) return false;
+        }
+        return true;
+    }
+    int run_rows(DevPicture *const *ins, DevPicture *const *outs, int nf)
+    {
+        BlurBatch8 B;
+        memset(&B, 0, sizeof(B));
+        B.sign = sign; B.vmin = vmin; B.vmax = vmax;
+        int max_w = 0, max_h = 0;
+        bool want[BR_MAX_STEPS + 1] = {false};
+        for (int c = 0; c < 3; c++)
+        {
+            BlurPlane8 &P = B.pl[c];
+            P.width = ins[0]->width[c]; P.height = ins[0]->height[c];
+            P.src_pitch = ins[0]->pitch[c]; P.dst_pitch = outs[0]->pitch[c];
+            P.amount = par.amount[c];
+            P.active = P.amount ? 1 : 2;
+            P.steps = P.amount ? par.size[c] / 2 : 0;
+            P.scalebits = P.steps * 4;
+            P.halfscale = P.steps ? 1 << (P.scalebits - 1) : 0;
+            uint32_t row[2 * BR_MAX_STEPS + 1] = {1};                       // binomial row of order 2*steps
+            for (int k = 1; k <= 2 * P.steps; k++)
+            {
+                row[k] = 1;
+                for (int i = k - 1; i >= 1; i--) row[i] += row[i - 1];
+            }
+            for (int i = 0; i <= 2 * BR_MAX_STEPS; i++) P.coef[i] = i <= 2 * P.steps ? row[i] : 0;
+            if (P.amount) want[P.steps] = true;
+            max_w = std::max(max_w, P.width); max_h = std::max(max_h, P.height);
+            for (int f = 0; f < nf; f++) { B.src[f][c] = ins[f]->plane[c]; B.dst[f][c] = outs[f]->plane[c]; }
+        }
+        const dim3 grid(((max_w + 3) / 4 + 63) / 64, (max_h + 4 * BR_ROWS - 1) / (4 * BR_ROWS), 3 * nf), block(64, 4);
+        bool copies_done = false;
+        for (int st = 1; st <= BR_MAX_STEPS; st++)
+        {
+            if (!want[st]) continue;
+            if (copies_done)
+                for (int c = 0; c < 3; c++) if (B.pl[c].active == 2) B.pl[c].active = 0;     // copied by the first launch
+            switch (st)
+            {
+                case 1: HBHIP_LAUNCH(ctx, name, blur_rows8_kernel<1>, grid, block, 0, B); break;
+                case 2: HBHIP_LAUNCH(ctx, name, blur_rows8_kernel<2>, grid, block, 0, B); break;
+                case 3: HBHIP_LAUNCH(ctx, name, blur_rows8_kernel<3>, grid, block, 0, B); break;
+                default: HBHIP_LAUNCH(ctx, name, blur_rows8_kernel<4>, grid, block, 0, B); break;
+            }
+            copies_done = true;
+        }
+        if (!copies_done)                                                    // nothing filtered: every plane is a copy
+            HBHIP_LAUNCH(ctx, name, blur_rows8_kernel<1>, grid, block, 0, B);
+        HBHIP_CHECK(ctx, hipGetLastError());
+        return HBHIP_OK;
+    }
+    // up to BR_FRAMES frames per launch (hbhip_filter_process_dev / a chain batch)
+    int process_many(DevPicture *const *ins, DevPicture *const *outs, int n) override
+    {
+        bool ok = n > 0;
+        for (int f = 0; f < n && ok; f++)
+        {
+            ok = rows_ok(ins[f], outs[f]);
+            for (int c = 0; c < 3 && ok; c++) ok = ins[f]->pitch[c] == ins[0]->pitch[c] && outs[f]->pitch[c] == outs[0]->pitch[c];
+        }
+        if (!ok) return SimpleFilter::process_many(ins, outs, n);
+        for (int at = 0; at < n; at += BR_FRAMES)
+        {
+            const int rc = run_rows(ins + at, outs + at, std::min(BR_FRAMES, n - at));
+            if (rc != HBHIP_OK) return rc;
+        }
+        return HBHIP_OK;
+    }
     int process(DevPicture *in, DevPicture *out) override
     {
+        if (rows_ok(in, out)) return run_rows(&in, &out, 1);
         BlurArgs3 all;
         int n = 0, max_w = 0, max_h = 0;
         for (int c = 0; c < 3; c++)

@@ -70,10 +70,10 @@ def main():
     st = simple(ctx, lambda: hip.lapsharp_device_filter(ctx, 2 * W, 2 * H), 2 * W, 2 * H, 2 * W, 2 * H)
     add(st, {"lapsharp_3x3": 2 * (4 * FRAME)})
     # unsharp / chroma smooth 1080p
-    def mk_blur(fn):
+    def mk_blur(fn, luma_amount=16384):
         class BP(C.Structure):
             _fields_ = [("amount", C.c_int * 3), ("size", C.c_int * 3)]
-        p = BP((C.c_int * 3)(16384, 16384, 16384), (C.c_int * 3)(7, 7, 7))
+        p = BP((C.c_int * 3)(luma_amount, 16384, 16384), (C.c_int * 3)(7, 7, 7))
         return hip._create(fn, ctx, [C.c_void_p, C.POINTER(BP)] + [C.c_int] * 5 + [C.POINTER(C.c_void_p)],
                            ctx.h, C.byref(p), W, H, 8, 1, 1)
     add(simple(ctx, lambda: mk_blur("hbhip_unsharp_create"), W, H, W, H), {"unsharp_blur_mix": 2 * FRAME})
@@ -239,6 +239,9 @@ def main():
                 {"lapsharp_3x3": 2 * (4 * FRAME)}, "lapsharp_3x3 @2160p x16", NB)
     add_batched(batched(rot, W, H, H, W), {"rotate": 2 * FRAME}, "rotate 90 x16", NB)       # one launch = the 3 planes of 16 frames
     add_batched(batched(gray, W, H, W, H), {"monochrome": 2 * FRAME}, "grayscale x16", NB)
+    add_batched(batched(lambda: mk_blur("hbhip_unsharp_create"), W, H, W, H), {"unsharp_blur_mix": 2 * FRAME}, "unsharp 7x7 x16", NB)
+    add_batched(batched(lambda: mk_blur("hbhip_chroma_smooth_create", 0), W, H, W, H), {"chroma_smooth_blur_mix": 2 * FRAME},
+                "chroma_smooth 7x7 x16 (luma copied)", NB)
     # decomb blend (default mode 7: yadif + cubic), the frames of a chain batch in one launch
     frames = synth.stream("interlaced", W, H, 4)
     dev_in = [[torch.from_numpy(p).cuda() for p in fr] for fr in frames]
