@@ -181,9 +181,23 @@ public:
         }
     }
     bool transposes() const { return trans != T_NONE; }
+    // the batch kernel moves dwords: 8-bit planes whose rows are dword aligned
+    bool batch_ok(const DevPicture *in, const DevPicture *out) const
+    {
+        if (in_geo.bps != 1 || getenv("HBHIP_ROTATE_OLD")) return false;
+        for (int c = 0; c < 3; c++)
+            if ((in->pitch[c] & 3) || (out->pitch[c] & 3) || ((uintptr_t)in->plane[c] & 3) || ((uintptr_t)out->plane[c] & 3)) return false;
+        return true;
+    }
     int process_many(DevPicture *const *ins, DevPicture *const *outs, int n) override
     {
-        if (in_geo.bps != 1 || getenv("HBHIP_ROTATE_OLD")) return SimpleFilter::process_many(ins, outs, n);
+        bool ok = n > 0;
+        for (int f = 0; ok && f < n; f++)
+        {
+            ok = batch_ok(ins[f], outs[f]);
+            for (int c = 0; ok && c < 3; c++) ok = ins[f]->pitch[c] == ins[0]->pitch[c] && outs[f]->pitch[c] == outs[0]->pitch[c];
+        }
+        if (!ok) return SimpleFilter::process_many(ins, outs, n);          // frame by frame (process() does not come back here then)
         for (int at = 0; at < n; at += RB_FRAMES)
         {
             const int nf = std::min(RB_FRAMES, n - at);
@@ -196,9 +210,6 @@ public:
                 max_w = std::max(max_w, B.dw[c]); max_h = std::max(max_h, B.dh[c]);
                 for (int f = 0; f < nf; f++)
                 {
-                    if (ins[at + f]->pitch[c] != B.spitch[c] || outs[at + f]->pitch[c] != B.dpitch[c] || (B.spitch[c] & 3) ||
-                        ((uintptr_t)ins[at + f]->plane[c] & 3) || ((uintptr_t)outs[at + f]->plane[c] & 3) || (B.dpitch[c] & 3))
-                        return SimpleFilter::process_many(ins, outs, n);
                     B.src[f][c] = ins[at + f]->plane[c];
                     B.dst[f][c] = outs[at + f]->plane[c];
                 }
@@ -211,7 +222,7 @@ public:
     }
     int process(DevPicture *in, DevPicture *out) override
     {
-        if (in_geo.bps == 1 && !getenv("HBHIP_ROTATE_OLD"))
+        if (batch_ok(in, out))
         {
             DevPicture *i1[1] = { in }, *o1[1] = { out };
             return process_many(i1, o1, 1);
@@ -392,15 +403,22 @@ public:
         HBHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         return HBHIP_OK;
     }
+    // the batch kernel moves 16 luma / 8 chroma bytes at a time: 8-bit 4:2:0 planes aligned accordingly
+    bool batch_ok(const DevPicture *in, const DevPicture *out) const
+    {
+        return in_geo.bps == 1 && in_geo.log2_cw == 1 && in_geo.log2_ch == 1 && !getenv("HBHIP_MONOCHROME_OLD") &&
+               (in->pitch[0] & 15) == 0 && (out->pitch[0] & 15) == 0 && ((uintptr_t)in->plane[0] & 15) == 0 && ((uintptr_t)out->plane[0] & 15) == 0 &&
+               (in->pitch[1] & 7) == 0 && ((uintptr_t)in->plane[1] & 7) == 0 && ((uintptr_t)in->plane[2] & 7) == 0;
+    }
     int process_many(DevPicture *const *ins, DevPicture *const *outs, int n) override
     {
-        bool ok = in_geo.bps == 1 && in_geo.log2_cw == 1 && in_geo.log2_ch == 1 && !getenv("HBHIP_MONOCHROME_OLD");
+        bool ok = n > 0;
         for (int i = 0; ok && i < n; i++)
-            for (int c = 0; c < 3; c++)
-                ok &= ins[i]->pitch[c] == ins[0]->pitch[c] && outs[i]->pitch[c] == outs[0]->pitch[c] && (ins[i]->pitch[0] & 15) == 0 &&
-                      (outs[i]->pitch[0] & 15) == 0 && ((uintptr_t)ins[i]->plane[0] & 15) == 0 && ((uintptr_t)outs[i]->plane[0] & 15) == 0 &&
-                      (ins[i]->pitch[1] & 7) == 0 && ((uintptr_t)ins[i]->plane[1] & 7) == 0 && ((uintptr_t)ins[i]->plane[2] & 7) == 0;
-        if (!ok) return SimpleFilter::process_many(ins, outs, n);
+        {
+            ok = batch_ok(ins[i], outs[i]);
+            for (int c = 0; ok && c < 3; c++) ok = ins[i]->pitch[c] == ins[0]->pitch[c] && outs[i]->pitch[c] == outs[0]->pitch[c];
+        }
+        if (!ok) return SimpleFilter::process_many(ins, outs, n);          // frame by frame (process() does not come back here then)
         for (int at = 0; at < n; at += MB_FRAMES)
         {
             const int nf = std::min(MB_FRAMES, n - at);
@@ -423,7 +441,7 @@ public:
     }
     int process(DevPicture *in, DevPicture *out) override
     {
-        if (in_geo.bps == 1 && in_geo.log2_cw == 1 && in_geo.log2_ch == 1 && !getenv("HBHIP_MONOCHROME_OLD"))
+        if (batch_ok(in, out))
         {
             DevPicture *i1[1] = { in }, *o1[1] = { out };
             return process_many(i1, o1, 1);
