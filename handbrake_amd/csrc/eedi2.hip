@@ -1133,10 +1133,10 @@ __device__ __forceinline__ int calc_dir_search(const uint32_t *tr, uint64_t pass
 template <int R>
 __global__ __launch_bounds__(CD_W) void k_calc_dir_rows(P3 P, int maxd, int nt13, int nt19)
 {
-    constexpr int NS = R + 4, NM = R + 2, RW = CD_LW / 4;
+    constexpr int NS = R + 4, NM = R + 2, RW = CD_LW / 4, RQ = CD_LW / 16;
     __shared__ __attribute__((aligned(16))) uint8_t s_band[NS + NM][CD_LW];   // staged rows: 0..NS-1 source y0-2.., NS.. mask y0-1..
-    __shared__ uint32_t s_tri[NS][CD_LW];                                      // [r][i] = bytes i..i+2 of source row r
-    __shared__ uint64_t s_bits[NM][8];                                         // bit i: a mask peak among columns i..i+2 of mask row m
+    __shared__ __attribute__((aligned(16))) uint32_t s_tri[NS][CD_LW];         // [r][i] = bytes i..i+2 of source row r
+    __shared__ uint64_t s_bits[NM][8];                                         // bit i: mask row m is 255 at column i
     __shared__ uint16_t s_list[R * CD_W];                                      // the listed pixels, (row << 8) | column
     __shared__ __attribute__((aligned(16))) uint8_t s_out[R][CD_W];
     __shared__ int s_count;
@@ -1150,39 +1150,36 @@ __global__ __launch_bounds__(CD_W) void k_calc_dir_rows(P3 P, int maxd, int nt13
     uint32_t *band = reinterpret_cast<uint32_t *>(&s_band[0][0]);
     {
         // flat addressing as in the one-row forms (out-of-row columns pick up the neighbouring rows' bytes, as the
-        // reference's pointer arithmetic does); rows past height + 1 serve no pixel and are not touched
+        // reference's pointer arithmetic does); rows past height + 1 serve no pixel and are not touched.  16 bytes per
+        // load (the scratch planes, their pitches and x0 - CD_HALO are multiples of 16).
         const uint8_t *sb = P.b[pl] + x0 - CD_HALO, *mb = P.a[pl] + x0 - CD_HALO;
-        for (int i = tid; i < (NS + NM) * RW; i += CD_W)
+        for (int i = tid; i < (NS + NM) * RQ; i += CD_W)
         {
-            const int r = i / RW, c4 = i - r * RW;
+            const int r = i / RQ, c16 = i - r * RQ;
             const uint8_t *src = r < NS ? sb + (ptrdiff_t)min(y0 - 2 + r, height + 1) * pitch
                                         : mb + (ptrdiff_t)min(y0 - 1 + (r - NS), height) * pitch;
-            band[i] = reinterpret_cast<const uint32_t *>(src)[c4];
+            reinterpret_cast<uint4 *>(band)[i] = reinterpret_cast<const uint4 *>(src)[c16];
         }
     }
     __syncthreads();
-    // tables and peak bitmaps: column i of row r <- dwords i/4 and i/4 + 1 of the staged row, realigned once; columns
-    // 0 .. CD_LW-4 (b+-u, |u| <= CD_HALO-2): a first round for all, the 61 columns left over for the first wave
+    // tables: the four columns of a staged dword at a time (two dwords realigned three ways, one 16-byte write); columns
+    // 0 .. CD_LW-4 are looked at (b+-u, |u| <= CD_HALO-2), the last dword's are made but never read
+    for (int i = tid; i < NS * RW; i += CD_W)
+    {
+        const uint32_t d0 = band[i], d1 = band[i + 1];
+        reinterpret_cast<uint4 *>(&s_tri[0][0])[i] =
+            make_uint4(d0 & 0x00ffffffu, __builtin_amdgcn_alignbyte(d1, d0, 1) & 0x00ffffffu,
+                       __builtin_amdgcn_alignbyte(d1, d0, 2) & 0x00ffffffu, __builtin_amdgcn_alignbyte(d1, d0, 3) & 0x00ffffffu);
+    }
+    // peak bitmaps of the mask rows: a first round for all, the 64 columns left over for the first wave
     for (int k = 0; k < 2; k++)
     {
         if (k == 1 && tid >= 64) break;                          // wave-uniform
         const int i = tid + k * CD_W;
-        uint32_t fbits = 0;
-        if (i < CD_LW - 3)
-        {
-            const int q = i >> 2;
-            const uint32_t sh = (uint32_t)(i & 3);
-#define TRI(row) (__builtin_amdgcn_alignbyte(band[(row) * RW + q + 1], band[(row) * RW + q], sh) & 0x00ffffffu)
-#pragma unroll
-            for (int r = 0; r < NS; r++) s_tri[r][i] = TRI(r);
-#pragma unroll
-            for (int m = 0; m < NM; m++) fbits |= any_peak3(TRI(NS + m)) ? 1u << m : 0u;
-#undef TRI
-        }
 #pragma unroll
         for (int m = 0; m < NM; m++)
         {
-            const uint64_t w = __ballot((fbits >> m) & 1u);           // the wave's 64 consecutive columns = one word
+            const uint64_t w = __ballot(s_band[NS + m][i] == PEAK);   // the wave's 64 consecutive columns = one word
             if (lane == 0) s_bits[m][i >> 6] = w;
         }
     }
@@ -1224,6 +1221,7 @@ __global__ __launch_bounds__(CD_W) void k_calc_dir_rows(P3 P, int maxd, int nt13
     {
         const int maxdt = pl == 0 ? maxd : (maxd >> 1);
         const int len = 2 * maxdt + 1;
+        const uint64_t lenmask = (1ull << len) - 1ull;
         const bool edge = y0 <= 1 || y0 + R - 1 >= height - 2;
         for (int p = tid; p < count; p += CD_W)
         {
@@ -1233,10 +1231,12 @@ __global__ __launch_bounds__(CD_W) void k_calc_dir_rows(P3 P, int maxd, int nt13
             // last row - with a mask peak above at +u and below at -u (:395-399).  Above: bits b-maxdt .. b+maxdt of the row's
             // bitmap in that order; below: the same bits of the other row's in reverse.
             const int startu = max(-px + 1, -maxdt), stopu = min(width - 2 - px, maxdt);
+            // bit t of a row's window: a mask peak among columns b-maxdt+t .. +2 (len + 2 <= 63 bits of the bitmap)
             auto window = [&](const uint64_t *bits) {
                 const int start = b - maxdt, wq = start >> 6, sh = start & 63;
                 const uint64_t lo = bits[wq], hi = bits[wq + 1];
-                return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+                const uint64_t w = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+                return (w | (w >> 1) | (w >> 2)) & lenmask;
             };
             uint64_t pass = 0;
             if (stopu >= startu)
