@@ -124,7 +124,7 @@ def test_lapsharp_matches_reference(built, w, h, kern):
 
 @needs_ref
 @pytest.mark.parametrize("w,h", [(128, 72), (638, 362)])
-@pytest.mark.parametrize("size", [3, 7, 13, 15])
+@pytest.mark.parametrize("size", [3, 5, 7, 9, 13, 15])
 def test_unsharp_and_chroma_smooth_match_reference(built, w, h, size):
     frames = synth.stream("random", w, h, 2)
     got = hbrt.run_stream(ol.ref(), [("hb_filter_unsharp", f"y-strength=0.25:y-size={size}:cb-strength=1.2:cb-size={size}")], frames)
@@ -133,6 +133,16 @@ def test_unsharp_and_chroma_smooth_match_reference(built, w, h, size):
     got = hbrt.run_stream(ol.ref(), [("hb_filter_chroma_smooth", f"cb-strength=1.2:cb-size={size}")], frames)
     want = os_.chroma_smooth_stream(frames, [dict(strength=1.2, size=size)] * 2)
     _eq_stream(got, want)
+
+
+@needs_ref
+def test_unsharp_mixed_sizes_match_reference(built):
+    """luma and chroma with different blur sizes (what the GPU path splits into one launch per size)"""
+    frames = synth.stream("random", 190, 96, 2)
+    for ysz, csz in ((5, 9), (3, 15), (9, 7)):
+        got = hbrt.run_stream(ol.ref(), [("hb_filter_unsharp", f"y-strength=0.75:y-size={ysz}:cb-strength=0.5:cb-size={csz}")], frames)
+        want = os_.unsharp_stream(frames, [dict(strength=0.75, size=ysz)] + [dict(strength=0.5, size=csz)] * 2)
+        _eq_stream(got, want)
 
 
 # ---------------------------------------------------------------- decomb / comb detect / EEDI2
