@@ -1,6 +1,6 @@
 # What-if profiling: the decomb / chain workloads with the launches of one kernel (family) dropped at a time
 # (HBHIP_SKIP_KERNELS, hbhip_internal.h) - how much of the wall time hangs on each.  Run on the GPU box: bash tools/whatif_skip_kernels.sh
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/whatif; O=$GRAFT_REPO_ROOT/gpurun_out/whatif
+R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; mkdir -p gpurun_out/whatif; O=$R/gpurun_out/whatif
 run() { # tag, workload, env...
   tag=$1; wl=$2; shift 2
   env "$@" timeout 200 python bench.py --workload $wl --no-cpu-baseline --no-pcie --no-kernel-timer --steps 12 --warmup 3 > $O/$tag.json 2> $O/$tag.err
