@@ -106,6 +106,10 @@ CASES = {
                                  chain=[("hb_filter_unsharp", "y-strength=1.5:y-size=15:cb-strength=0.8:cb-size=3")],
                                  hip=[("hb_filter_unsharp_hip", "y-strength=1.5:y-size=15:cb-strength=0.8:cb-size=3")],
                                  orc=[("unsharp", [blur(1.5, 15), blur(0.8, 3), blur(0.8, 3)])]),
+    "unsharp_sizes_5_9_190x96": dict(model="random", w=190, h=96, n=2,
+                                     chain=[("hb_filter_unsharp", "y-strength=0.75:y-size=5:cb-strength=0.5:cb-size=9")],
+                                     hip=[("hb_filter_unsharp_hip", "y-strength=0.75:y-size=5:cb-strength=0.5:cb-size=9")],
+                                     orc=[("unsharp", [blur(0.75, 5), blur(0.5, 9), blur(0.5, 9)])]),
     "chroma_smooth_medium_134x70": dict(model="random", w=134, h=70, n=2,
                                         chain=[("hb_filter_chroma_smooth", "cb-strength=0.6:cb-size=7")],
                                         hip=[("hb_filter_chroma_smooth_hip", "cb-strength=0.6:cb-size=7")],
