@@ -11,8 +11,8 @@ on 1920x1080 YUV420P 8-bit interlaced synthetic frames.  A "step" = one pass of 
 one batch of BATCH consecutive input frames of a stream that is already resident in HBM; every
 input frame leaves as two 3840x2160 output frames (bob).  The frames go through the product C ABI
 (hbhip_chain_process_dev: the run of HIP filters fused the way hb_avfilter_combine fuses a run of
-libavfilter filters) exactly as they would in production: captured EEDI2 graphs, both fields of
-a bob pair in flight, pictures handed from stage to stage by pointer.  `value` counts OUTPUT
+libavfilter filters) exactly as they would in production: every EEDI2 pass taking the fields of a batch
+in one launch, pictures handed from stage to stage by pointer.  `value` counts OUTPUT
 frames.  Nothing of the oracle or of any CPU path runs inside the timed region.
 
 Other workloads (--workload): nlmeans = configs[1], decomb_eedi2 = configs[2] (add
@@ -27,8 +27,7 @@ Also on the JSON line:
   roofline       dominant kernel of the workload (largest share of GPU time): algorithmic bytes per
                  launch / its mean launch time.  Launch times come from a pass right after the timed
                  region in which the same launches are bracketed by HIP events on the stream they run
-                 on (the bracketing serialises the two EEDI2 engines and bypasses the graphs, which is
-                 why it is not done inside the timed region); `kernels` lists the rest.
+                 on; `kernels` lists the rest.
   cpu_baseline   the reference's own C filters (oracle/_ref, threaded by its own taskset.c as libhb
                  does) on this box's host cores, bounded sample; the scaler leg is our restatement
                  (zimg is not buildable here) and is labelled as such.
@@ -83,8 +82,8 @@ def algorithmic_bytes(kernel, w, h, out_w, out_h, frames_per_launch=1):
         "cropscale_lanczos_fused": full + out,
         "lapsharp_3x3": 2 * out, "lapsharp_5x5": 2 * out,
         "copy_planes": 2 * full,
-        "eedi2_fill_half": half + half,                               # reads one field, writes srcp
-        "eedi2_mask_passes": 3 * half,                                # srcp + old mask -> new mask
+        "eedi2_mask_passes": 2 * half,                                # the lower half of a field: field rows + old mask -> srcp + new mask
+        "eedi2_mask_upper": 1.5 * half,                               # the upper half: field rows -> srcp + new mask
         "eedi2_calc_directions": 3 * half,                            # mskp + srcp -> tmpp
         "eedi2_filter_dir_map": 3 * half, "eedi2_expand_dir_map": 3 * half, "eedi2_filter_map": 3 * half,
         "eedi2_mark_directions_2x": 3 * half + 4 * full,              # 3 line doublings + tmp2p
@@ -490,9 +489,10 @@ def run_chain(args, world, rank, local_rank):
         total_ms = sum(ms for _, (_, ms) in top) or 1.0
         kernels = []
         for k, (n, ms) in top[:24]:
-            # the profiled pass ran 2 steps = 4 B output frames; NLMeans, the blend and lapsharp take the frames of a
-            # batch in one launch, everything else runs once per field / frame
-            fpl = 4 * B / n if (k.startswith("nlmeans_plane") or k in ("decomb_plane", "lapsharp_3x3", "lapsharp_5x5")) else 1
+            # the profiled pass ran 2 steps = 4 B output frames (= fields); the kernels take the frames / fields of a
+            # batch in one launch (EEDI2: HBHIP_EEDI2_FIELDS per launch; a pass that runs twice per field counts half)
+            per_field = {"eedi2_fill_gaps_2x": 2, "eedi2_filter_dir_map_2x": 2, "eedi2_expand_dir_map_2x": 2}.get(k, 1)
+            fpl = 4 * B * per_field / n
             ab = algorithmic_bytes(k, W, H, OW, OH, frames_per_launch=fpl if k.startswith("nlmeans_plane") else 1)
             ab = int(ab * (1 if k.startswith("nlmeans_plane") else fpl)) if ab else ab
             avg = ms / n / 1e3
@@ -512,7 +512,8 @@ def run_chain(args, world, rank, local_rank):
                         "algorithmic_bytes_per_launch": ab,
                         "note": "dominant kernel of the chain = largest share of summed kernel time in the event-"
                                 "bracketed pass that follows the timed region; its bytes are small against its "
-                                "arithmetic (a +-24 step search per edge pixel), see `valu`"}
+                                "arithmetic (a +-24 step search per edge pixel), see `valu`; a launch covers "
+                                "`frames_per_launch` fields"}
                 if valu:
                     roof["valu"] = valu_roofline(valu, d["avg_us"] * 1e-6)
         per_out = {"chain": 62_208_000, "chain2160": 4 * frame_bytes(W, H) + 3 * frame_bytes(W, H) + 2 * frame_bytes(W, H),

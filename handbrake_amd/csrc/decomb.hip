@@ -511,16 +511,10 @@ public:
     DecombFilter(hbhip_ctx *c, const hbhip_decomb_params &p) : hbhip_filter(c), par(p) {}
     ~DecombFilter() override
     {
-        for (hbhip_ctx *c : ring_ctx) (void)hipStreamSynchronize(c->stream);
-        ring_busy.clear();
         for (DevPicture *p : late_unref) hbhip_pic_release(p, ctx);
         late_unref.clear();
         delete eedi16;
-        for (Eedi2Engine *e : ring) delete e;
         delete eedi;
-        if (ring_share.ev_mask) (void)hipEventDestroy(ring_share.ev_mask);
-        if (ev_frame) (void)hipEventDestroy(ev_frame);
-        for (hbhip_ctx *c : ring_ctx) hbhip_ctx_destroy(c);
     }
 
     int setup(int width, int height, int depth, int lcw, int lch)
@@ -551,44 +545,17 @@ public:
             Eedi2Params ep = { par.magnitude_threshold, par.variance_threshold, par.laplacian_threshold,
                                par.dilation_threshold, par.erosion_threshold, par.noise_threshold,
                                par.maximum_search_distance, par.post_processing };
-            eedi = new (std::nothrow) Eedi2Engine(ctx, in_geo, ep);
+            // EEDI2 runs depend on each other only through the edge mask (the first of ~15 kernels), and every kernel
+            // of a run is too short to fill the GPU.  So the fields of a chain batch (both fields of every frame with
+            // bob) are queued and go through each pass together: one launch per pass for up to `fields` fields
+            // (Eedi2Engine), followed by the blends that consume the guesses.  Driven a frame at a time (work() of the
+            // plugin), a frame's fields still share their launches.
+            int fields = 16;
+            if (const char *e = getenv("HBHIP_EEDI2_FIELDS")) fields = atoi(e);       // tuning: fields per launch (1..32)
+            eedi = new (std::nothrow) Eedi2Engine(ctx, in_geo, ep, fields);
             if (!eedi) return HBHIP_ERR_NOMEM;
             int rc = eedi->init();
             if (rc != HBHIP_OK) return rc;
-            // EEDI2 runs only depend on each other through the edge mask (the first of ~17 kernels).  Each run is a
-            // chain of dependent launches, most of them too short to fill the GPU and each followed by a drain, so
-            // consecutive runs (the two fields of a bob pair, then the next frame's) go round a ring of engines, each
-            // with scratch frames and a HIP stream of its own, and overlap.  The blend that consumes a run's result
-            // is launched on the same stream; the filter's stream joins the ring when the batch is complete (kick /
-            // flush), or at the end of each call when it is driven one frame at a time.  Not with post-processing
-            // 2/3, whose derivative arrays carry values from run to run (eedi2.hip, CornerArgs).
-            int n_ring = 4;
-            if (const char *e = getenv("HBHIP_EEDI2_ENGINES")) n_ring = atoi(e);
-            if (getenv("HBHIP_EEDI2_SERIAL")) n_ring = 0;
-            n_ring = std::min(n_ring, EEDI_MAX_RING);
-            if (n_ring >= 2 && par.post_processing < 2)
-            {
-                bool ok = hipEventCreateWithFlags(&ev_frame, hipEventDisableTiming) == hipSuccess &&
-                          hipEventCreateWithFlags(&ring_share.ev_mask, hipEventDisableTiming) == hipSuccess;
-                for (int i = 0; ok && i < n_ring; i++)
-                {
-                    hbhip_ctx *sc = nullptr;
-                    if (hbhip_ctx_create(ctx->device, &sc) != HBHIP_OK) { ok = false; break; }
-                    ring_ctx.push_back(sc);
-                    Eedi2Engine *e = new (std::nothrow) Eedi2Engine(sc, in_geo, ep, ctx, &ring_share, i);
-                    if (!e) { ok = false; break; }
-                    ring.push_back(e);
-                    ok = e->init() == HBHIP_OK;
-                }
-                // the first run reads "the previous mask" from the last engine's buffer: zeros, like the reference's
-                ring_share.sel = n_ring - 1;
-                if (!ok)
-                {
-                    for (Eedi2Engine *e : ring) delete e;
-                    ring.clear();
-                    (void)hipGetLastError();
-                }
-            }
         }
         return HBHIP_OK;
     }
@@ -611,8 +578,8 @@ public:
             return HBHIP_OK;                   // HB_FILTER_DELAY
         }
         store_ref(pic);
-        const int rc = process_frame();
-        if (rc != HBHIP_OK || !deferred) join_ring();
+        int rc = process_frame();
+        if (rc != HBHIP_OK || !deferred) { const int rc2 = flush_batch(); if (rc == HBHIP_OK) rc = rc2; }
         return rc;
     }
 
@@ -626,13 +593,13 @@ public:
             if (ff_bwdif) bw_field = BW_BACK_END;          // ff_yadif_request_frame at EOF
             rc = process_frame();
         }
-        join_ring();
-        return rc;
+        const int rc2 = flush_batch();
+        return rc != HBHIP_OK ? rc : rc2;
     }
 
     // fused chain: the whole batch is submitted before anything downstream looks at the outputs
-    void defer_launches(bool on) override { deferred = on; if (!on) join_ring(); }
-    int  kick() override { join_ring(); return HBHIP_OK; }
+    void defer_launches(bool on) override { deferred = on; if (!on) (void)flush_batch(); }
+    int  kick() override { return flush_batch(); }
 
     int pending() override { return (int)outq.size(); }
     DevPicture *pop_output() override
@@ -645,25 +612,25 @@ public:
     void recycle_output(DevPicture *p) override { pool.release(p); }
 
     int next_flags = 0, next_combed = 0;
-    Eedi2Engine *engine() { return last_engine ? last_engine : eedi; }    // the one holding the latest run's scratch
+    Eedi2Engine *engine() { return eedi; }
 
 private:
     void unref(DevPicture *p)
     {
         if (!p || --p->refs != 0) return;
-        // a blend on a ring engine's stream, or one gathered for the batch launch, may still read it: hand it back
-        // when the ring has been joined / the batch is out
-        if (!ring_busy.empty() || batch.n > 0) late_unref.push_back(p);
+        // a queued EEDI2 field or a blend gathered for the batch launch may still read it: hand it back when the
+        // batch is out
+        if (batch.n > 0 || (eedi && eedi->queued() > 0)) late_unref.push_back(p);
         else hbhip_pic_release(p, ctx);                    // possibly another filter's picture (fused chain)
     }
-    // make the filter's stream wait for everything the ring engines have been given
-    void join_ring()
+    // launch what has been gathered: the queued EEDI2 fields, then the blends (which read their guesses)
+    int flush_batch()
     {
-        (void)launch_batch(batch, ctx);
-        for (Eedi2Engine *e : ring_busy) (void)e->join();
-        ring_busy.clear();
+        int rc = eedi ? eedi->launch(ctx) : HBHIP_OK;
+        const int rc2 = launch_batch(batch, ctx);
         for (DevPicture *p : late_unref) hbhip_pic_release(p, ctx);
         late_unref.clear();
+        return rc != HBHIP_OK ? rc : rc2;
     }
     void store_ref(DevPicture *p)              // decomb.c:195-200
     {
@@ -674,10 +641,10 @@ private:
         p->refs++;
     }
 
-    int launch(DevPicture *dst, int mode, int parity, int tff, Eedi2Engine *guess_from = nullptr, hbhip_ctx *lc = nullptr)
+    // slot: the EEDI2 slot holding this frame's guess (8-bit EEDI2 modes)
+    int launch(DevPicture *dst, int mode, int parity, int tff, int slot = -1)
     {
-        if (!guess_from) guess_from = eedi;
-        if (!lc) lc = ctx;                 // the stream the blend goes to: the filter's, or the ring engine's that made the guess
+        hbhip_ctx *lc = ctx;
         DecombArgs a;
         for (int c = 0; c < 3; c++)
         {
@@ -689,10 +656,11 @@ private:
                 P.guess = eedi16->result().plane[c];
                 P.guess_pitch = eedi16->result().stride[c];
             }
-            else if ((mode & M_EEDI2) && guess_from)
+            else if ((mode & M_EEDI2) && eedi && slot >= 0)
             {
-                P.guess = guess_from->result().plane[c];
-                P.guess_pitch = guess_from->result().stride[c];
+                const EediFrame g = eedi->result(slot);
+                P.guess = g.plane[c];
+                P.guess_pitch = g.stride[c];
             }
             P.dst = dst->plane[c];
             P.pitch = ref[1]->pitch[c]; P.dst_pitch = dst->pitch[c];
@@ -726,27 +694,25 @@ private:
             HBHIP_CHECK(lc, hipGetLastError());
             return HBHIP_OK;
         }
-        // 8-bit: four pixels per thread; on the filter's own stream inside a chain batch the frames are gathered and
-        // go out DB_FRAMES per launch (launch_batch), anywhere else at once
-        static const bool one_px = getenv("HBHIP_DECOMB_1PX") != nullptr;             // A/B switch: the byte-per-thread kernel
-        if (one_px)
+        // 8-bit: four pixels per thread.  The frames are gathered and go out together (launch_batch, at most DB_FRAMES
+        // per launch): at the end of the call, or - inside a chain batch - when the batch is complete.  A frame whose
+        // guess is still queued in the EEDI2 engine cannot be launched before the engine, so a full blend batch
+        // flushes both.
+        if (batch.n == DB_FRAMES)
         {
-            HBHIP_LAUNCH(lc, "decomb_plane", decomb_plane_kernel<uint8_t>, grid, block, 0, a, maxv);
-            HBHIP_CHECK(lc, hipGetLastError());
-            return HBHIP_OK;
+            const int rc = flush_batch();
+            if (rc != HBHIP_OK) return rc;
         }
-        const bool gather = deferred && lc == ctx;
-        DecombBatch &B = gather ? batch : single;
-        if (!gather) B.n = 0;
+        DecombBatch &B = batch;
         DecombFrame &F = B.f[B.n++];
         for (int c = 0; c < 3; c++)
         {
             const DecombPlane &P = a.pl[c];
             F.prev[c] = P.prev; F.cur[c] = P.cur; F.next[c] = P.next; F.guess[c] = P.guess; F.dst[c] = P.dst;
-            B.pitch[c] = P.pitch; B.guess_pitch[c] = P.guess_pitch; B.dst_pitch[c] = P.dst_pitch; B.w[c] = P.w; B.h[c] = P.h;
+            B.pitch[c] = P.pitch; B.dst_pitch[c] = P.dst_pitch; B.w[c] = P.w; B.h[c] = P.h;
+            if (P.guess) B.guess_pitch[c] = P.guess_pitch;          // the same for every frame that has a guess
         }
         F.mode = a.mode; F.parity = a.parity; F.field_parity = a.field_parity; F.pad = 0;
-        if (!gather || B.n == DB_FRAMES) return launch_batch(B, lc);
         return HBHIP_OK;
     }
 
@@ -790,45 +756,31 @@ private:
         else if (is_combed != 0)                    mode = par.mode & ~M_SELECTIVE;
 
         const int nframes = (par.mode & M_BOB) ? 2 : 1;
-        // ring of engines: each field's run and the blend that consumes it go to the next engine's stream, behind an
-        // event that marks `cur` (and everything else launched so far) complete on the filter's stream
-        const bool ringed = (mode & M_EEDI2) && eedi && !ring.empty() && !ctx->profile;
-        if (ringed) HBHIP_CHECK(ctx, hipEventRecord(ev_frame, ctx->stream));
         for (int frame = 0; frame < nframes; frame++)
         {
             const int parity = frame ^ tff ^ 1;
-            Eedi2Engine *e = eedi;
-            hbhip_ctx *lc = ctx;
+            int slot = -1;
             if ((mode & M_EEDI2) && eedi16)
             {
                 int rc = eedi16->run(cur, !parity);                              // pv->tff = !parity (decomb.c:542)
                 if (rc != HBHIP_OK) return rc;
             }
-            else if (ringed)
-            {
-                e = ring[ring_next];
-                ring_next = (ring_next + 1) % ring.size();
-                lc = e->stream_ctx();
-                if (std::find(ring_busy.begin(), ring_busy.end(), e) == ring_busy.end()) ring_busy.push_back(e);
-                int rc = e->run(cur, !parity, ev_frame);
-                if (rc != HBHIP_OK) return rc;
-                last_engine = e;
-            }
             else if ((mode & M_EEDI2) && eedi)
             {
-                int rc = e->run(cur, !parity);
-                if (rc != HBHIP_OK) return rc;
-                last_engine = e;
+                if (eedi->queued() == eedi->capacity())
+                {
+                    int rc = flush_batch();
+                    if (rc != HBHIP_OK) return rc;
+                }
+                slot = eedi->add_field(cur, !parity);                            // pv->tff = !parity (decomb.c:542)
+                if (slot < 0) return HBHIP_ERR_ARG;
             }
             DevPicture *o = pool.acquire();
             if (!o) return HBHIP_ERR_NOMEM;
             o->tag = (cur->tag << 1) | frame; o->aux = frame;
             bw_second = frame == 1;
-            // a recycled picture may still be read by whoever had it last
-            if (lc != ctx && o->idle_valid) HBHIP_CHECK(lc, hipStreamWaitEvent(lc->stream, o->idle, 0));
-            int rc = launch(o, mode, parity, tff, e, lc);
+            int rc = launch(o, mode, parity, tff, slot);
             if (rc != HBHIP_OK) return rc;
-            if (lc != ctx) { rc = e->mark_done(); if (rc != HBHIP_OK) return rc; }
             outq.push_back(o);
         }
         return HBHIP_OK;
@@ -846,20 +798,13 @@ private:
     PicturePool pool;
     DevPicture *ref[3] = {nullptr, nullptr, nullptr};
     std::deque<DevPicture *> outq;
-    Eedi2Engine *eedi = nullptr;           // runs on the filter's stream (serial use, per-kernel profiling)
-    std::vector<Eedi2Engine *> ring;       // engines with streams of their own, used in turn
-    std::vector<hbhip_ctx *> ring_ctx;
-    std::vector<Eedi2Engine *> ring_busy;  // engines given work since the last join
-    std::vector<DevPicture *> late_unref;  // input pictures whose last reference went while the ring was busy
-    EediMaskShare ring_share;
-    size_t ring_next = 0;
+    Eedi2Engine *eedi = nullptr;           // 8-bit EEDI2: fields queued here run together (flush_batch)
+    std::vector<DevPicture *> late_unref;  // input pictures whose last reference went while something gathered could still read them
     bool deferred = false;
-    DecombBatch batch, single;             // blends gathered for one launch (chain batch) / the one being launched now
+    DecombBatch batch;                     // blends gathered for one launch
 public:
     Eedi2Engine16 *eedi16 = nullptr;       // 10 / 12-bit samples
 private:
-    Eedi2Engine *last_engine = nullptr;
-    hipEvent_t   ev_frame = nullptr;
     bool ready = false, flushed = false;
 };
 
@@ -951,8 +896,9 @@ extern "C" int hbhip_decomb_debug_eedi_plane(hbhip_filter *f, int buffer, int pl
 {
     DecombFilter *d = dynamic_cast<DecombFilter *>(f);
     if (!d || (!d->engine() && !d->eedi16) || buffer < 0 || buffer > 8 || plane < 0 || plane > 2) return HBHIP_ERR_ARG;
-    const EediFrame &fr = d->eedi16 ? (buffer < 4 ? d->eedi16->half(buffer) : d->eedi16->full(buffer - 4))
-                                    : (buffer < 4 ? d->engine()->half(buffer) : d->engine()->full(buffer - 4));
+    const int slot = d->eedi16 ? 0 : d->engine()->last_slot();          // the latest run's scratch
+    const EediFrame fr = d->eedi16 ? (buffer < 4 ? d->eedi16->half(buffer) : d->eedi16->full(buffer - 4))
+                                   : (buffer < 4 ? d->engine()->half(buffer, slot) : d->engine()->full(buffer - 4, slot));
     if (stride) *stride = fr.stride[plane];
     if (height) *height = fr.height[plane];
     if (dst == nullptr) return HBHIP_OK;

@@ -31,10 +31,12 @@
 // the chain is resolved with a 64-lane prefix composition of 2-state maps, the
 // carry running from chunk to chunk.
 #include "eedi2_engine.h"
+#include <algorithm>
 
 namespace {
 
 constexpr int PEAK = 255, NEUTRAL = 128;
+constexpr int EEDI_MAX_FIELDS = EEDI_MAX_BATCH;   // fields per launch (P3::tffbits is one word)
 constexpr size_t GUARD = 32768;   // >= 2 rows + halo of the widest plane the LDS staging may touch
 
 __constant__ uint8_t c_limlut[33] = { 6, 6, 7, 7, 8, 8, 9, 9, 9, 10, 10, 11, 11, 12, 12, 12, 12, 12, 12, 12,
@@ -50,7 +52,32 @@ struct P3
     uint8_t *f[3];
     uint8_t *g[3];
     int pitch[3], width[3], height[3];   // height = rows of the buffers this pass walks
+    size_t   fstride;    // field batching: the scratch buffers of consecutive fields of a launch lie this many bytes apart
+    uint32_t tffbits;    // bit f: pv->tff of field f of the launch (the rebuilt rows start at y0 = 2 - tff)
 };
+
+// A launch covers the three planes of every field of a batch: blockIdx.z = 3 * field + plane.  All scratch frames of
+// a field sit in one slab (Eedi2Engine::init), so one offset moves every pointer of the pass to the block's field.
+// The block's pointers are picked once into Q (scalar loads from the kernel arguments; P itself is never written -
+// a dynamically indexed store would push the whole struct into scratch memory).
+struct PL { uint8_t *a, *b, *c, *d, *e, *f, *g; };
+__device__ __forceinline__ PL plane_ptrs(const P3 &P, int pl, size_t off)
+{
+    PL q = { P.a[pl], P.b[pl], P.c[pl], P.d[pl], P.e[pl], P.f[pl], P.g[pl] };
+    if (q.a) q.a += off;
+    if (q.b) q.b += off;
+    if (q.c) q.c += off;
+    if (q.d) q.d += off;
+    if (q.e) q.e += off;
+    if (q.f) q.f += off;
+    if (q.g) q.g += off;
+    return q;
+}
+#define FIELD_PLANE(P)                                                      \
+    const int fld = (int)blockIdx.z / 3, pl = (int)blockIdx.z - 3 * fld;    \
+    const int tff = (int)(((P).tffbits >> fld) & 1u);                       \
+    const PL Q = plane_ptrs((P), pl, (size_t)fld * (P).fstride);            \
+    (void)tff
 
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int hbhip_align_up_dev(int v, int a) { return (v + a - 1) / a * a; }
@@ -71,15 +98,6 @@ __device__ __forceinline__ int sorted_mid(int *v, int n)
         v[j] = t;
     }
     return (n & 1) ? v[n >> 1] : (v[(n - 1) >> 1] + v[n >> 1] + 1) >> 1;
-}
-
-__device__ __forceinline__ int vote(const int *v, int n, int mid, int lim, int &count)
-{
-    int sum = 0, cnt = 0;
-    for (int i = 0; i < n; i++)
-        if (iabs(v[i] - mid) <= lim) { cnt++; sum += v[i]; }
-    count = cnt;
-    return (int)(((float)(sum + mid) / (float)(cnt + 1)) + 0.5f);
 }
 
 
@@ -132,53 +150,12 @@ __device__ __forceinline__ void vote1(int v, int mid, int lim, int &sum, int &cn
     sum += in ? v : 0;
 }
 
-__device__ __forceinline__ int collect3(int *v, int k, const uint8_t *row, int x, bool skip_centre)
-{
-    if (row[x - 1] != PEAK) v[k++] = row[x - 1];
-    if (!skip_centre && row[x] != PEAK) v[k++] = row[x];
-    if (row[x + 1] != PEAK) v[k++] = row[x + 1];
-    return k;
-}
-
 #define XY_PLANE(P)                                                         \
-    const int pl = blockIdx.z;                                              \
+    FIELD_PLANE(P);                                                         \
     const int x = blockIdx.x * blockDim.x + threadIdx.x;                    \
     const int y = blockIdx.y * blockDim.y + threadIdx.y;                    \
     const int pitch = (P).pitch[pl], width = (P).width[pl], height = (P).height[pl]; \
     (void)width; (void)height; (void)pitch
-
-// a = source plane (device pitch in `spitch`), b = srcp
-// The reference copies min(src_pitch, dst_pitch) bytes per row, i.e. it drags the source
-// buffer's row padding along (undefined bytes in libhb, zeros in the calloc'ing test runtime).
-// Device-resident frames have no such padding, so bytes at x >= width are written as 0.
-__global__ void k_fill_half(P3 P, int spitch0, int spitch1, int spitch2, int start_line, int rows0, int rows1, int rows2)
-{
-    XY_PLANE(P);
-    const int spitch = pl == 0 ? spitch0 : pl == 1 ? spitch1 : spitch2;
-    const int rows = pl == 0 ? rows0 : pl == 1 ? rows1 : rows2;
-    if (x >= pitch || y >= rows) return;
-    P.b[pl][(size_t)y * pitch + x] = x < width ? P.a[pl][(size_t)(start_line + 2 * y) * spitch + x] : 0;
-}
-
-// the same with one dword per thread (pitches and plane offsets are multiples of 4)
-__global__ __launch_bounds__(256) void k_fill_half4(P3 P, int spitch0, int spitch1, int spitch2, int start_line, int rows0, int rows1, int rows2)
-{
-    const int pl = blockIdx.z;
-    const int x = 4 * (blockIdx.x * blockDim.x + threadIdx.x), y = blockIdx.y * blockDim.y + threadIdx.y;
-    const int pitch = P.pitch[pl], width = P.width[pl];
-    const int spitch = pl == 0 ? spitch0 : pl == 1 ? spitch1 : spitch2;
-    const int rows = pl == 0 ? rows0 : pl == 1 ? rows1 : rows2;
-    if (x >= pitch || y >= rows) return;
-    uint32_t v = 0;
-    if (x < width)
-    {
-        const uint8_t *sp = P.a[pl] + (size_t)(start_line + 2 * y) * spitch + x;
-        if (((spitch | (uintptr_t)P.a[pl]) & 3) == 0) v = *reinterpret_cast<const uint32_t *>(sp);
-        else v = (uint32_t)sp[0] | ((uint32_t)sp[1] << 8) | ((uint32_t)sp[2] << 16) | ((uint32_t)sp[3] << 24);
-        if (x + 3 >= width) v &= 0xffffffffu >> (8 * (x + 4 - width));     // bytes at x >= width are written as 0
-    }
-    *reinterpret_cast<uint32_t *>(P.b[pl] + (size_t)y * pitch + x) = v;
-}
 
 // ------------------------------------------------------------------------------------------
 // Four pixels per thread.  One byte per thread makes these passes latency bound: a wave lives
@@ -213,7 +190,7 @@ __device__ __forceinline__ void st4(uint8_t *dst_at_x, const int (&out)[4], int 
 }
 
 #define XY4_PLANE(P)                                                        \
-    const int pl = blockIdx.z;                                              \
+    FIELD_PLANE(P);                                                         \
     const int x = 4 * (blockIdx.x * blockDim.x + threadIdx.x);              \
     const int y = blockIdx.y * blockDim.y + threadIdx.y;                    \
     const int pitch = (P).pitch[pl], width = (P).width[pl], height = (P).height[pl]; \
@@ -230,124 +207,8 @@ __device__ __forceinline__ void st4(uint8_t *dst_at_x, const int (&out)[4], int 
 constexpr int MF_W = 128, MF_H = 16, MF_OX = 8, MF_OY = 4;      // tile and the LDS frame's origin offset
 constexpr int MF_LP = MF_W + 2 * MF_OX, MF_LR = MF_H + 2 * MF_OY; // 144 x 24
 
-struct MfTile { int x0, y0, width, height, fx, fy, t; };
 
-// a region = the tile grown by (hx, hy), clipped to the plane, walked by all 256 threads;
-// body(x, y, lx, ly) gets plane and LDS coordinates
-template <typename F>
-__device__ __forceinline__ void mf_region(const MfTile &T, int hx, int hy, F body)
-{
-    const int rx0 = max(T.x0 - hx, 0), rx1 = min(T.x0 + MF_W + hx, T.width);
-    const int ry0 = max(T.y0 - hy, 0), ry1 = min(T.y0 + MF_H + hy, T.height);
-    // 4 rows of 64 lanes at a time (no index division in these hot loops)
-    for (int y = ry0 + (T.t >> 6); y < ry1; y += 4)
-        for (int x = rx0 + (T.t & 63); x < rx1; x += 64)
-            body(x, y, x - T.fx, y - T.fy);
-}
-
-// erode (grow = 0, :259-293) / dilate (grow = 1, :207-247) of one region
-template <typename A>
-__device__ __forceinline__ void mf_morph(const MfTile &T, A &src, A &dst, int hx, int hy, int thr, int grow)
-{
-    mf_region(T, hx, hy, [&](int x, int y, int lx, int ly) {
-        const int c1 = src[ly][lx];
-        int r = c1;
-        if (x >= 1 && x < T.width - 1 && y >= 1 && y < T.height - 1 && (grow ? (c1 == 0) : (c1 == PEAK)))
-        {
-            const int count = (src[ly - 1][lx - 1] == PEAK) + (src[ly - 1][lx] == PEAK) + (src[ly - 1][lx + 1] == PEAK) +
-                              (src[ly][lx - 1] == PEAK) + (src[ly][lx + 1] == PEAK) +
-                              (src[ly + 1][lx - 1] == PEAK) + (src[ly + 1][lx] == PEAK) + (src[ly + 1][lx + 1] == PEAK);
-            if (grow) { if (count >= thr) r = PEAK; }
-            else      { if (count < thr) r = 0; }
-        }
-        dst[ly][lx] = (uint8_t)r;
-    });
-    __syncthreads();
-}
-
-__global__ __launch_bounds__(256) void k_mask_fused(P3 P, int mth, int vth, int lth, int erode_thr, int dilate_thr)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t s_src[MF_LR][MF_LP];
-    __shared__ __attribute__((aligned(16))) uint8_t s_a[MF_LR][MF_LP];
-    __shared__ __attribute__((aligned(16))) uint8_t s_b[MF_LR][MF_LP];
-    const int pl = blockIdx.z;
-    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
-    const int x0 = blockIdx.x * MF_W, y0 = blockIdx.y * MF_H;
-    if (x0 >= width || y0 >= height) return;
-    const MfTile T = { x0, y0, width, height, x0 - MF_OX, y0 - MF_OY, (int)threadIdx.x };
-
-    // stage source and old mask (dwords; columns outside [0, pitch) and rows outside the plane are not needed)
-    for (int i = T.t; i < MF_LR * (MF_LP / 4); i += 256)
-    {
-        const int r = i / (MF_LP / 4), c4 = i - r * (MF_LP / 4);
-        const int y = T.fy + r, x = T.fx + 4 * c4;
-        uint32_t sv = 0, mv = 0;
-        if (y >= 0 && y < height && x >= 0 && x < pitch)
-        {
-            sv = *reinterpret_cast<const uint32_t *>(P.a[pl] + (size_t)y * pitch + x);
-            mv = *reinterpret_cast<const uint32_t *>(P.b[pl] + (size_t)y * pitch + x);
-        }
-        reinterpret_cast<uint32_t *>(s_src[r])[c4] = sv;
-        reinterpret_cast<uint32_t *>(s_a[r])[c4] = mv;
-    }
-    __syncthreads();
-
-    // build_edge_mask (:122-195), in place on the old mask
-    mf_region(T, 6, 3, [&](int x, int y, int lx, int ly) {
-        int r = (y < height / 2) ? 0 : (int)s_a[ly][lx];
-        if (x >= 1 && x < width - 1 && y >= 1 && y < height - 1)
-        {
-            const int P0 = s_src[ly - 1][lx - 1], P1 = s_src[ly - 1][lx], P2 = s_src[ly - 1][lx + 1];
-            const int C0 = s_src[ly][lx - 1], C1 = s_src[ly][lx], C2 = s_src[ly][lx + 1];
-            const int N0 = s_src[ly + 1][lx - 1], N1 = s_src[ly + 1][lx], N2 = s_src[ly + 1][lx + 1];
-            auto flat = [](int a, int b, int d) { return iabs(a - b) < 10 && iabs(b - d) < 10 && iabs(a - d) < 10; };
-            if (!(flat(P1, C1, N1) || (flat(P0, C0, N0) && flat(P2, C2, N2))))
-            {
-                const int sum = P0 + P1 + P2 + C0 + C1 + C2 + N0 + N1 + N2;
-                const int sumsq = P0 * P0 + P1 * P1 + P2 * P2 + C0 * C0 + C1 * C1 + C2 * C2 + N0 * N0 + N1 * N1 + N2 * N2;
-                if (9 * sumsq - sum * sum >= vth)
-                {
-                    const int ix = C2 - C0;
-                    const int iy = max(max(iabs(P1 - N1), iabs(P1 - C1)), iabs(C1 - N1));
-                    if (ix * ix + iy * iy >= mth)
-                        r = PEAK;
-                    else
-                    {
-                        const int ixx = C0 - 2 * C1 + C2;
-                        const int iyy = P1 - 2 * C1 + N1;
-                        if (iabs(ixx) + iabs(iyy) >= lth) r = PEAK;
-                    }
-                }
-            }
-        }
-        s_a[ly][lx] = (uint8_t)r;
-    });
-    __syncthreads();
-
-    mf_morph(T, s_a, s_b, 5, 2, erode_thr, 0);
-    mf_morph(T, s_b, s_a, 4, 1, dilate_thr, 1);
-    mf_morph(T, s_a, s_b, 3, 0, erode_thr, 0);
-
-    // remove_small_gaps (:308-342) on the tile, straight to the new mask
-    mf_region(T, 0, 0, [&](int x, int y, int lx, int ly) {
-        const int c = s_b[ly][lx];
-        int r = c;
-        if (x >= 3 && x < width - 3 && y >= 1 && y < height - 1)
-        {
-            const int a3 = s_b[ly][lx - 3], a2 = s_b[ly][lx - 2], a1 = s_b[ly][lx - 1];
-            const int b1 = s_b[ly][lx + 1], b2 = s_b[ly][lx + 2], b3 = s_b[ly][lx + 3];
-            if (c)
-            {
-                if (!(a3 || a2 || a1 || b1 || b2 || b3)) r = 0;
-            }
-            else if ((b1 && (a1 || a2 || a3)) || (b2 && (a1 || a2)) || (b3 && a1))
-                r = PEAK;
-        }
-        P.c[pl][(size_t)y * pitch + x] = (uint8_t)r;
-    });
-}
-
-// The same five passes on dwords.  Every value of the mask is 0 or 255, so inside the kernel a mask
+// The passes work on dwords.  Every value of the mask is 0 or 255, so inside the kernel a mask
 // pixel is one byte holding 0 / 1 and four of them are handled by one 32-bit operation: the 8-neighbour
 // count of erode / dilate is a sum of byte-shifted dwords (at most 8 per byte, no carries), the
 // threshold test one add (bit 7 of count + 0x80 - thr), remove_small_gaps a handful of ANDs / ORs of
@@ -406,21 +267,33 @@ __device__ __forceinline__ void mf_morph4(const uint32_t (*src)[MF_DP], uint32_t
     __syncthreads();
 }
 
-// FROM_FRAME: the field extraction (eedi2_fill_half, decomb_template.c:455-473) rides along: the source rows are
-// read from the frame itself (P.d = its planes, row start_line + 2y at pitch spitch[pl]) and the tile's own part of
-// SRCPF (P.a) is written for the passes that follow; bytes at x >= width read as 0, as fill_half writes them.
-struct MaskSrc { int spitch[3], start_line; };
+// The field extraction (eedi2_fill_half, decomb_template.c:455-473) rides along: the source rows are read from the
+// frame itself (S.frame[field] = its planes, row start_line + 2y at pitch S.spitch[pl], start_line = !tff) and the
+// tile's own part of SRCPF (P.a) is written for the passes that follow; bytes at x >= width read as 0, as fill_half
+// writes them (device pictures have no row padding to drag along).
+//
+// Fields.  The previous field's mask only enters through the rows of the lower half, so the tiles whose LDS frame
+// stays above height / 2 (`part` 1) are independent of it and go out in ONE launch for all fields of a batch; the
+// rest (`part` 2) is a chain: one launch per field, each reading the mask the launch before it completed.  Field 0
+// of a launch reads P.b (the last field of the previous batch), field f > 0 the new mask of field f - 1.
+struct MaskSrc { const uint8_t *frame[EEDI_MAX_FIELDS][3]; int spitch[3]; };
 
-template <bool FROM_FRAME>
-__global__ __launch_bounds__(256) void k_mask_fused4(P3 P, MaskSrc S, int mth, int vth, int lth, int erode_thr, int dilate_thr)
+__global__ __launch_bounds__(256) void k_mask_fused4(P3 P, MaskSrc S, int f0, int part, int mth, int vth, int lth, int erode_thr, int dilate_thr)
 {
     __shared__ uint32_t s_src[MF_LR][MF_DP];
     __shared__ uint32_t s_a[MF_LR][MF_DP];
     __shared__ uint32_t s_b[MF_LR][MF_DP];
-    const int pl = blockIdx.z;
+    const int zf = (int)blockIdx.z / 3, pl = (int)blockIdx.z - 3 * zf, fld = f0 + zf;   // f0: first field of this launch
     const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
     const int x0 = blockIdx.x * MF_W, y0 = blockIdx.y * MF_H;
     if (x0 >= width || y0 >= height) return;
+    const bool upper = y0 + MF_H + MF_OY <= height / 2;            // no row of the LDS frame reaches the kept half
+    if (part != 0 && upper != (part == 1)) return;
+    const size_t foff = (size_t)fld * P.fstride;
+    const uint8_t *oldm = fld == 0 ? P.b[pl] : P.c[pl] + foff - P.fstride;
+    const uint8_t *frame = S.frame[fld][pl];
+    const int start_line = (int)(((P.tffbits >> fld) & 1u) ^ 1u);
+    uint8_t *srcp = P.a[pl] + foff, *newm = P.c[pl] + foff;
     const int t = threadIdx.x, fx = x0 - MF_OX, fy = y0 - MF_OY;
 
     for (int i = t; i < MF_LR * MF_DW; i += 256)
@@ -430,20 +303,15 @@ __global__ __launch_bounds__(256) void k_mask_fused4(P3 P, MaskSrc S, int mth, i
         uint32_t sv = 0, mv = 0;
         if (y >= 0 && y < height && x >= 0 && x < pitch)
         {
-            if (FROM_FRAME)
+            if (x < width)
             {
-                if (x < width)
-                {
-                    sv = *reinterpret_cast<const uint32_t *>(P.d[pl] + (size_t)(S.start_line + 2 * y) * S.spitch[pl] + x);
-                    if (x + 3 >= width) sv &= 0xffffffffu >> (8 * (x + 4 - width));
-                }
-                // the tile's own cells go out as SRCPF (every cell of the plane belongs to exactly one tile)
-                if (r >= MF_OY && r < MF_OY + MF_H && c4 >= MF_OX / 4 && c4 < (MF_OX + MF_W) / 4)
-                    *reinterpret_cast<uint32_t *>(P.a[pl] + (size_t)y * pitch + x) = sv;
+                sv = *reinterpret_cast<const uint32_t *>(frame + (size_t)(start_line + 2 * y) * S.spitch[pl] + x);
+                if (x + 3 >= width) sv &= 0xffffffffu >> (8 * (x + 4 - width));
             }
-            else
-                sv = *reinterpret_cast<const uint32_t *>(P.a[pl] + (size_t)y * pitch + x);
-            mv = *reinterpret_cast<const uint32_t *>(P.b[pl] + (size_t)y * pitch + x);
+            // the tile's own cells go out as SRCPF (every cell of the plane belongs to exactly one tile)
+            if (r >= MF_OY && r < MF_OY + MF_H && c4 >= MF_OX / 4 && c4 < (MF_OX + MF_W) / 4)
+                *reinterpret_cast<uint32_t *>(srcp + (size_t)y * pitch + x) = sv;
+            if (!upper) mv = *reinterpret_cast<const uint32_t *>(oldm + (size_t)y * pitch + x);
         }
         s_src[r][c4 + 1] = sv;
         s_a[r][c4 + 1] = mv & 0x01010101u;
@@ -526,7 +394,7 @@ __global__ __launch_bounds__(256) void k_mask_fused4(P3 P, MaskSrc S, int mth, i
         const uint32_t fill = ((b1 & a123) | (b2 & a12) | (b3 & a1)) & (c ^ 0x01010101u);
         const uint32_t pm = (y >= 1 && y < height - 1) ? (mf_bytes_in(x, 3, width - 3) & 0x01010101u) : 0u;
         const uint32_t res = (((set | fill) & pm) | (c & ~pm)) * 255u;
-        uint8_t *d = P.c[pl] + (size_t)y * pitch + x;
+        uint8_t *d = newm + (size_t)y * pitch + x;
         if (x + 3 < width) *reinterpret_cast<uint32_t *>(d) = res;
         else for (int k = 0; k < 4 && x + k < width; k++) d[k] = (uint8_t)(res >> (8 * k));
     }
@@ -540,10 +408,10 @@ __global__ void k_calc_dir_mark(P3 P, uint32_t *__restrict__ list, int *__restri
 {
     XY_PLANE(P);
     if (x >= pitch || y >= height) return;
-    P.c[pl][(size_t)y * pitch + x] = 255;                      // memset(dstp, 255, pitch*height)
+    Q.c[(size_t)y * pitch + x] = 255;                      // memset(dstp, 255, pitch*height)
     if (x >= 1 && x < width - 1 && y >= 1 && y < height - 1)
     {
-        const uint8_t *mc = P.a[pl] + (size_t)y * pitch;
+        const uint8_t *mc = Q.a + (size_t)y * pitch;
         if (mc[x] == PEAK && (mc[x - 1] == PEAK || mc[x + 1] == PEAK))
             list[atomicAdd(count, 1)] = (uint32_t)x | ((uint32_t)y << 14) | ((uint32_t)pl << 28);
     }
@@ -556,10 +424,11 @@ __global__ __launch_bounds__(256) void k_calc_dir_work(P3 P, const uint32_t *__r
     if (gid >= *count) return;
     const uint32_t e = list[gid];
     const int x = e & 0x3fff, y = (e >> 14) & 0x3fff, pl = e >> 28;
+    const PL Q = plane_ptrs(P, pl, 0);                           // one field per launch (see Eedi2Engine::enqueue_passes)
     const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
-    const uint8_t *mc = P.a[pl] + (size_t)y * pitch;
+    const uint8_t *mc = Q.a + (size_t)y * pitch;
     const uint8_t *mp = mc - pitch, *mn = mc + pitch;
-    const uint8_t *sc = P.b[pl] + (size_t)y * pitch;
+    const uint8_t *sc = Q.b + (size_t)y * pitch;
     const uint8_t *sp = sc - pitch, *sn = sc + pitch, *s2p = sp - pitch, *s2n = sn + pitch;
     const int maxdt = pl == 0 ? maxd : (maxd >> 1);
     const int startu = max(-x + 1, -maxdt), stopu = min(width - 2 - x, maxdt);
@@ -615,7 +484,7 @@ __global__ __launch_bounds__(256) void k_calc_dir_work(P3 P, const uint32_t *__r
             if (iabs(order[i] - mid) <= tlim) { cnt++; sum += order[i]; }
         if (cnt > 1) out = (NEUTRAL + ((int)((float)sum / (float)cnt) * 4)) & 0xff;
     }
-    P.c[pl][(size_t)y * pitch + x] = (uint8_t)out;
+    Q.c[(size_t)y * pitch + x] = (uint8_t)out;
 }
 
 // calc_directions, fast path (search distance <= 30): one block = 256 consecutive pixels of one
@@ -625,131 +494,6 @@ __global__ __launch_bounds__(256) void k_calc_dir_work(P3 P, const uint32_t *__r
 // walks its +-maxd window out of LDS.
 constexpr int CD_W = 256, CD_HALO = 32, CD_LW = CD_W + 2 * CD_HALO;
 
-// does any of the three low bytes equal 255?
-__device__ __forceinline__ bool any_peak3(uint32_t v)
-{
-    const uint32_t t = v & 0x00ffffffu;
-    return ((((t & 0x007f7f7fu) + 0x00010101u) & t) & 0x00808080u) != 0u;
-}
-
-// sum of absolute differences of the three low bytes (+ acc)
-__device__ __forceinline__ uint32_t sad3p(uint32_t a24, uint32_t b, uint32_t acc)
-{
-    return __builtin_amdgcn_sad_u8(a24, b & 0x00ffffffu, acc);
-}
-
-__global__ __launch_bounds__(CD_W) void k_calc_dir_tile(P3 P, int maxd, int nt13, int nt19)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t s_band[8][CD_LW];   // rows 0..4 source y-2..y+2, 5..7 mask y-1..y+1
-    __shared__ uint16_t s_list[CD_W];
-    __shared__ int s_count;
-    const int pl = blockIdx.z;
-    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
-    const int x0 = blockIdx.x * CD_W, y = blockIdx.y;
-    if (y >= height || x0 >= pitch) return;
-    const int tid = threadIdx.x;
-    if (tid == 0) s_count = 0;
-    {
-        // staged as dwords (x0, CD_HALO and the pitch are multiples of 4)
-        const uint8_t *sb = P.b[pl] + (ptrdiff_t)(y - 2) * pitch + x0 - CD_HALO;
-        const uint8_t *mb = P.a[pl] + (ptrdiff_t)(y - 1) * pitch + x0 - CD_HALO;
-        for (int i = tid; i < 8 * (CD_LW / 4); i += CD_W)
-        {
-            const int r = i / (CD_LW / 4), c4 = i - r * (CD_LW / 4);
-            const uint8_t *src = r < 5 ? sb + (ptrdiff_t)r * pitch : mb + (ptrdiff_t)(r - 5) * pitch;
-            reinterpret_cast<uint32_t *>(s_band[r])[c4] = reinterpret_cast<const uint32_t *>(src)[c4];
-        }
-    }
-    __syncthreads();
-    const int x = x0 + tid, c = tid + CD_HALO;
-    bool active = false;
-    if (x < pitch)
-    {
-        if (x >= 1 && x < width - 1 && y >= 1 && y < height - 1)
-            active = s_band[6][c] == PEAK && (s_band[6][c - 1] == PEAK || s_band[6][c + 1] == PEAK);
-        if (!active) P.c[pl][(size_t)y * pitch + x] = 255;        // memset(dstp, 255, pitch*height)
-    }
-    if (active) s_list[atomicAdd(&s_count, 1)] = (uint16_t)tid;
-    __syncthreads();
-    if (tid >= s_count) return;
-
-    const int lx = s_list[tid];
-    const int px = x0 + lx, cc = lx + CD_HALO;
-    const int maxdt = pl == 0 ? maxd : (maxd >> 1);
-    const int startu = max(-px + 1, -maxdt), stopu = min(width - 2 - px, maxdt);
-    // the centre triples (columns cc-1..cc+1) of the five source rows, packed in 24 bits
-    auto triple = [&](int r) -> uint32_t {
-        return (uint32_t)s_band[r][cc - 1] | ((uint32_t)s_band[r][cc] << 8) | ((uint32_t)s_band[r][cc + 1] << 16);
-    };
-    const uint32_t F2p = triple(0), Fp = triple(1), Fc = triple(2), Fn = triple(3), F2n = triple(4);
-    const int vert = iabs((int)s_band[2][cc] - (int)s_band[3][cc]) + iabs((int)s_band[2][cc] - (int)s_band[1][cc]);
-    int minb = min(nt13, vert * 6), mina = min(nt19, vert * 9);
-    int minc = mina, mind = minb, mine = minb;
-    int dira = -5000, dirb = -5000, dirc = -5000, dird = -5000, dire = -5000;
-    const bool first = y == 1, last = y == height - 2;
-    // Per step u the triples at column (cc-1+u) of four rows and at (cc-1-u) of five rows are
-    // needed: each is two aligned LDS dwords realigned with v_alignbyte (an unaligned LDS dword
-    // read exists on gfx950 but is several times slower), then one v_sad_u8 against a centre triple.
-    const uint32_t *band = reinterpret_cast<const uint32_t *>(&s_band[0][0]);
-    constexpr int RW = CD_LW / 4;                                   // dwords per staged row
-    struct { uint32_t sn_m, sp_p, sc_m, sc_p, sp_m, s2p_p, sn_p, s2n_m, mp_p, mn_m; } g;
-    for (int u = startu; u <= stopu; u++)
-    {
-        const int ca = cc - 1 + u, cm = cc - 1 - u;
-        const uint32_t *qa = band + (ca >> 2), *qm = band + (cm >> 2);
-        const uint32_t sa = (uint32_t)(ca & 3), sm = (uint32_t)(cm & 3);
-#define TRI(q, row, sh) __builtin_amdgcn_alignbyte((q)[(row) * RW + 1], (q)[(row) * RW], (sh))
-        g.mp_p = TRI(qa, 5, sa);
-        g.mn_m = TRI(qm, 7, sm);
-        if (!(first || any_peak3(g.mp_p))) continue;              // (:395-399)
-        if (!(last || any_peak3(g.mn_m))) continue;
-        g.sn_m = TRI(qm, 3, sm); g.sc_m = TRI(qm, 2, sm); g.sp_m = TRI(qm, 1, sm); g.s2n_m = TRI(qm, 4, sm);
-        g.sp_p = TRI(qa, 1, sa); g.sc_p = TRI(qa, 2, sa); g.s2p_p = TRI(qa, 0, sa); g.sn_p = TRI(qa, 3, sa);
-#undef TRI
-        const int e1 = (int)sad3p(Fp, g.sc_m, sad3p(Fc, g.sn_m, 0));   // diffsn + diffps
-        const int d1 = (int)sad3p(Fn, g.sc_p, sad3p(Fc, g.sp_p, 0));   // diffsp + diffns
-        const int diff = e1 + d1;
-        int diffd = d1, diffe = e1;
-        if (diff < minb) { dirb = u; minb = diff; }
-        if (!first)
-        {
-            const int diff2pp = (int)sad3p(F2p, g.sp_m, 0);
-            const int diffp2p = (int)sad3p(Fp, g.s2p_p, 0);
-            const int diffa = diff + diff2pp + diffp2p;
-            diffd += diffp2p;
-            diffe += diff2pp;
-            if (diffa < mina) { dira = u; mina = diffa; }
-        }
-        if (!last)
-        {
-            const int diff2nn = (int)sad3p(F2n, g.sn_p, 0);
-            const int diffn2n = (int)sad3p(Fn, g.s2n_m, 0);
-            const int diffc = diff + diff2nn + diffn2n;
-            diffd += diff2nn;
-            diffe += diffn2n;
-            if (diffc < minc) { dirc = u; minc = diffc; }
-        }
-        if (diffd < mind) { dird = u; mind = diffd; }
-        if (diffe < mine) { dire = u; mine = diffe; }
-    }
-    int order[5], k = 0;
-    if (dira != -5000) order[k++] = dira;
-    if (dirb != -5000) order[k++] = dirb;
-    if (dirc != -5000) order[k++] = dirc;
-    if (dird != -5000) order[k++] = dird;
-    if (dire != -5000) order[k++] = dire;
-    int out = NEUTRAL;
-    if (k > 1)
-    {
-        const int mid = sorted_mid(order, k);
-        const int tlim = max((int)c_limlut[iabs(mid)] >> 2, 2);
-        int sum = 0, cnt = 0;
-        for (int i = 0; i < k; i++)
-            if (iabs(order[i] - mid) <= tlim) { cnt++; sum += order[i]; }
-        if (cnt > 1) out = (NEUTRAL + ((int)((float)sum / (float)cnt) * 4)) & 0xff;
-    }
-    P.c[pl][(size_t)y * pitch + px] = (uint8_t)out;
-}
 
 // calc_directions, second form of the fast path.  Same block shape as k_calc_dir_tile (256 consecutive pixels of one row,
 // active pixels compacted), but the search loop is stripped to what has to happen per step:
@@ -764,273 +508,9 @@ __global__ __launch_bounds__(CD_W) void k_calc_dir_tile(P3 P, int maxd, int nt13
 //  * the loop runs -maxd .. +maxd for every lane with the per-lane range test folded into the step's predicate, so the
 //    trip count is wave-uniform and the step body is one predicated region.
 // Values are the reference's (:358-525): same sums, same order of comparisons.
-__global__ __launch_bounds__(CD_W) void k_calc_dir_tile2(P3 P, int maxd, int nt13, int nt19)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t s_band[8][CD_LW];   // rows 0..4 source y-2..y+2, 5..7 mask y-1..y+1
-    __shared__ uint32_t s_tri[5][CD_LW];                                  // [r][i] = bytes i..i+2 of source row r (+ flags in row 2)
-    __shared__ uint16_t s_list[CD_W];
-    __shared__ int s_count;
-    const int pl = blockIdx.z;
-    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
-    const int x0 = blockIdx.x * CD_W, y = blockIdx.y;
-    if (y >= height || x0 >= pitch) return;
-    const int tid = threadIdx.x;
-    if (tid == 0) s_count = 0;
-    {
-        const uint8_t *sb = P.b[pl] + (ptrdiff_t)(y - 2) * pitch + x0 - CD_HALO;
-        const uint8_t *mb = P.a[pl] + (ptrdiff_t)(y - 1) * pitch + x0 - CD_HALO;
-        for (int i = tid; i < 8 * (CD_LW / 4); i += CD_W)
-        {
-            const int r = i / (CD_LW / 4), c4 = i - r * (CD_LW / 4);
-            const uint8_t *src = r < 5 ? sb + (ptrdiff_t)r * pitch : mb + (ptrdiff_t)(r - 5) * pitch;
-            reinterpret_cast<uint32_t *>(s_band[r])[c4] = reinterpret_cast<const uint32_t *>(src)[c4];
-        }
-    }
-    __syncthreads();
-    const int x = x0 + tid, c = tid + CD_HALO;
-    bool active = false;
-    if (x < pitch)
-    {
-        if (x >= 1 && x < width - 1 && y >= 1 && y < height - 1)
-            active = s_band[6][c] == PEAK && (s_band[6][c - 1] == PEAK || s_band[6][c + 1] == PEAK);
-        if (!active) P.c[pl][(size_t)y * pitch + x] = 255;        // memset(dstp, 255, pitch*height)
-    }
-    if (active) s_list[atomicAdd(&s_count, 1)] = (uint16_t)tid;
-    __syncthreads();
-    const int count = s_count;
-    if (count == 0) return;
-    {
-        // the tables: column i of row r <- dwords i/4 and i/4 + 1 of the staged row, realigned once
-        const uint32_t *band = reinterpret_cast<const uint32_t *>(&s_band[0][0]);
-        constexpr int RW = CD_LW / 4;
-        for (int i = tid; i < CD_LW - 3; i += CD_W)      // columns 1 .. CD_LW-4 are looked at (cc-1+-u, |u| <= CD_HALO-2)
-        {
-            const int q = i >> 2, sh = i & 3;
-#define TRI(row) (__builtin_amdgcn_alignbyte(band[(row) * RW + q + 1], band[(row) * RW + q], sh) & 0x00ffffffu)
-            const uint32_t mp = TRI(5), mn = TRI(7);
-            s_tri[0][i] = TRI(0);
-            s_tri[1][i] = TRI(1);
-            s_tri[2][i] = TRI(2) | (any_peak3(mp) ? 1u << 24 : 0u) | (any_peak3(mn) ? 1u << 25 : 0u);
-            s_tri[3][i] = TRI(3);
-            s_tri[4][i] = TRI(4);
-#undef TRI
-        }
-    }
-    __syncthreads();
-    if (tid >= count) return;
-
-    const int lx = s_list[tid];
-    const int px = x0 + lx, cc = lx + CD_HALO;
-    const int maxdt = pl == 0 ? maxd : (maxd >> 1);
-    const int startu = max(-px + 1, -maxdt), stopu = min(width - 2 - px, maxdt);
-    const uint32_t F2p = s_tri[0][cc - 1], Fp = s_tri[1][cc - 1], Fc = s_tri[2][cc - 1] & 0x00ffffffu,
-                   Fn = s_tri[3][cc - 1], F2n = s_tri[4][cc - 1];
-    const int ctr = (int)((Fc >> 8) & 0xff);
-    const int vert = iabs(ctr - (int)((Fn >> 8) & 0xff)) + iabs(ctr - (int)((Fp >> 8) & 0xff));
-    const bool first = y == 1, last = y == height - 2;
-    // keys: (running minimum << 6) | (u + 32), low six bits 0 = unset
-    uint32_t kb = (uint32_t)min(nt13, vert * 6) << 6, ka = (uint32_t)min(nt19, vert * 9) << 6;
-    uint32_t kc = ka, kd = kb, ke = kb;
-    const uint32_t need_p = first ? 0u : 1u << 24, need_m = last ? 0u : 1u << 25;
-    const uint32_t span = (uint32_t)(stopu - startu);
-    const uint32_t *tp = &s_tri[0][cc - 1 - maxdt], *tm = &s_tri[0][cc - 1 + maxdt];   // columns cc-1+u / cc-1-u at u = -maxdt
-    for (int u = -maxdt; u <= maxdt; u++, tp++, tm--)
-    {
-        const uint32_t c_p = tp[2 * CD_LW], c_m = tm[2 * CD_LW];
-        // in range, and - unless on the first / last row - a mask peak above at +u and below at -u (:395-399)
-        if ((uint32_t)(u - startu) > span || ((c_p & need_p) != need_p) || ((c_m & need_m) != need_m)) continue;
-        const uint32_t ub = (uint32_t)(u + 32);
-        const uint32_t sn_m = tm[3 * CD_LW], sp_p = tp[1 * CD_LW];
-        const int e1 = (int)__builtin_amdgcn_sad_u8(Fp, c_m & 0x00ffffffu, __builtin_amdgcn_sad_u8(Fc, sn_m, 0u));   // diffsn + diffps
-        const int d1 = (int)__builtin_amdgcn_sad_u8(Fn, c_p & 0x00ffffffu, __builtin_amdgcn_sad_u8(Fc, sp_p, 0u));   // diffsp + diffns
-        const int diff = e1 + d1;
-        int diffd = d1, diffe = e1;
-        kb = min(kb, ((uint32_t)diff << 6) | ub);
-        if (!first)
-        {
-            const int diff2pp = (int)__builtin_amdgcn_sad_u8(F2p, tm[1 * CD_LW], 0u);
-            const int diffp2p = (int)__builtin_amdgcn_sad_u8(Fp, tp[0 * CD_LW], 0u);
-            diffd += diffp2p;
-            diffe += diff2pp;
-            ka = min(ka, ((uint32_t)(diff + diff2pp + diffp2p) << 6) | ub);
-        }
-        if (!last)
-        {
-            const int diff2nn = (int)__builtin_amdgcn_sad_u8(F2n, tp[3 * CD_LW], 0u);
-            const int diffn2n = (int)__builtin_amdgcn_sad_u8(Fn, tm[4 * CD_LW], 0u);
-            diffd += diff2nn;
-            diffe += diffn2n;
-            kc = min(kc, ((uint32_t)(diff + diff2nn + diffn2n) << 6) | ub);
-        }
-        kd = min(kd, ((uint32_t)diffd << 6) | ub);
-        ke = min(ke, ((uint32_t)diffe << 6) | ub);
-    }
-    int order[5], k = 0;
-    if (ka & 63) order[k++] = (int)(ka & 63) - 32;
-    if (kb & 63) order[k++] = (int)(kb & 63) - 32;
-    if (kc & 63) order[k++] = (int)(kc & 63) - 32;
-    if (kd & 63) order[k++] = (int)(kd & 63) - 32;
-    if (ke & 63) order[k++] = (int)(ke & 63) - 32;
-    int out = NEUTRAL;
-    if (k > 1)
-    {
-        const int mid = sorted_mid(order, k);
-        const int tlim = max((int)c_limlut[iabs(mid)] >> 2, 2);
-        int sum = 0, cnt = 0;
-        for (int i = 0; i < k; i++)
-            if (iabs(order[i] - mid) <= tlim) { cnt++; sum += order[i]; }
-        if (cnt > 1) out = (NEUTRAL + ((int)((float)sum / (float)cnt) * 4)) & 0xff;
-    }
-    P.c[pl][(size_t)y * pitch + px] = (uint8_t)out;
-}
 
 // calc_directions, third form: k_calc_dir_tile2 with the search loop walking only the steps that pass the mask test
 // (see the bit sets below).  maxd <= 31 (the set is one 64-bit word).
-__global__ __launch_bounds__(CD_W) void k_calc_dir_tile3(P3 P, int maxd, int nt13, int nt19)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t s_band[8][CD_LW];   // rows 0..4 source y-2..y+2, 5..7 mask y-1..y+1
-    __shared__ uint32_t s_tri[5][CD_LW];                                  // [r][i] = bytes i..i+2 of source row r (+ flags in row 2)
-    __shared__ uint16_t s_list[CD_W];
-    __shared__ uint64_t s_bp[8], s_bm[8];                                 // bit i: a mask peak among columns i..i+2 of the row above / below
-    __shared__ int s_count;
-    const int pl = blockIdx.z;
-    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
-    const int x0 = blockIdx.x * CD_W, y = blockIdx.y;
-    if (y >= height || x0 >= pitch) return;
-    const int tid = threadIdx.x;
-    if (tid == 0) s_count = 0;
-    {
-        const uint8_t *sb = P.b[pl] + (ptrdiff_t)(y - 2) * pitch + x0 - CD_HALO;
-        const uint8_t *mb = P.a[pl] + (ptrdiff_t)(y - 1) * pitch + x0 - CD_HALO;
-        for (int i = tid; i < 8 * (CD_LW / 4); i += CD_W)
-        {
-            const int r = i / (CD_LW / 4), c4 = i - r * (CD_LW / 4);
-            const uint8_t *src = r < 5 ? sb + (ptrdiff_t)r * pitch : mb + (ptrdiff_t)(r - 5) * pitch;
-            reinterpret_cast<uint32_t *>(s_band[r])[c4] = reinterpret_cast<const uint32_t *>(src)[c4];
-        }
-    }
-    __syncthreads();
-    const int x = x0 + tid, c = tid + CD_HALO;
-    bool active = false;
-    if (x < pitch)
-    {
-        if (x >= 1 && x < width - 1 && y >= 1 && y < height - 1)
-            active = s_band[6][c] == PEAK && (s_band[6][c - 1] == PEAK || s_band[6][c + 1] == PEAK);
-        if (!active) P.c[pl][(size_t)y * pitch + x] = 255;        // memset(dstp, 255, pitch*height)
-    }
-    if (active) s_list[atomicAdd(&s_count, 1)] = (uint16_t)tid;
-    __syncthreads();
-    const int count = s_count;
-    if (count == 0) return;
-    {
-        // the tables: column i of row r <- dwords i/4 and i/4 + 1 of the staged row, realigned once
-        const uint32_t *band = reinterpret_cast<const uint32_t *>(&s_band[0][0]);
-        constexpr int RW = CD_LW / 4;
-        for (int k = 0; k < 2; k++)                      // columns 1 .. CD_LW-4 are looked at (cc-1+-u, |u| <= CD_HALO-2)
-        {
-            const int i = tid + k * CD_W;
-            bool fp = false, fm = false;
-            if (i < CD_LW - 3)
-            {
-                const int q = i >> 2, sh = i & 3;
-#define TRI(row) (__builtin_amdgcn_alignbyte(band[(row) * RW + q + 1], band[(row) * RW + q], sh) & 0x00ffffffu)
-                fp = any_peak3(TRI(5));
-                fm = any_peak3(TRI(7));
-                s_tri[0][i] = TRI(0);
-                s_tri[1][i] = TRI(1);
-                s_tri[2][i] = TRI(2);
-                s_tri[3][i] = TRI(3);
-                s_tri[4][i] = TRI(4);
-#undef TRI
-            }
-            const uint64_t wp = __ballot(fp), wm = __ballot(fm);      // the wave's 64 consecutive columns = one word
-            if ((tid & 63) == 0) { s_bp[i >> 6] = wp; s_bm[i >> 6] = wm; }
-        }
-    }
-    __syncthreads();
-    if (tid >= count) return;
-
-    const int lx = s_list[tid];
-    const int px = x0 + lx, cc = lx + CD_HALO;
-    const int maxdt = pl == 0 ? maxd : (maxd >> 1);
-    const int startu = max(-px + 1, -maxdt), stopu = min(width - 2 - px, maxdt);
-    const int b = cc - 1;
-    const uint32_t F2p = s_tri[0][b], Fp = s_tri[1][b], Fc = s_tri[2][b], Fn = s_tri[3][b], F2n = s_tri[4][b];
-    const int ctr = (int)((Fc >> 8) & 0xff);
-    const int vert = iabs(ctr - (int)((Fn >> 8) & 0xff)) + iabs(ctr - (int)((Fp >> 8) & 0xff));
-    const bool first = y == 1, last = y == height - 2;
-    // keys: (running minimum << 6) | (u + 32), low six bits 0 = unset
-    uint32_t kb = (uint32_t)min(nt13, vert * 6) << 6, ka = (uint32_t)min(nt19, vert * 9) << 6;
-    uint32_t kc = ka, kd = kb, ke = kb;
-    // The steps this pixel takes, as a bit set (bit j: u = j - maxdt): inside its range, and - unless on the first /
-    // last row - with a mask peak above at +u and below at -u (:395-399).  Above: bits b-maxdt .. b+maxdt of s_bp in
-    // that order; below: the same bits of s_bm in reverse.  Only about a quarter of the steps pass, so walking the set
-    // bits (ascending u, as the key minimum needs nothing else) more than halves the trips of a wave.
-    const int len = 2 * maxdt + 1;
-    auto window = [&](const uint64_t *bits) {
-        const int start = b - maxdt, wq = start >> 6, sh = start & 63;
-        const uint64_t lo = bits[wq], hi = bits[wq + 1];
-        return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
-    };
-    uint64_t pass = 0;
-    if (stopu >= startu)
-    {
-        const int nb = stopu - startu + 1;
-        pass = (nb >= 64 ? ~0ull : ((1ull << nb) - 1ull)) << (startu + maxdt);
-        if (!first) pass &= window(s_bp);
-        if (!last)  pass &= __brevll(window(s_bm)) >> (64 - len);
-    }
-    while (pass)
-    {
-        const int j = __ffsll((unsigned long long)pass) - 1;
-        pass &= pass - 1ull;
-        const int u = j - maxdt;
-        const uint32_t ub = (uint32_t)(u + 32);
-        const uint32_t *tp = &s_tri[0][b + u], *tm = &s_tri[0][b - u];
-        const uint32_t c_p = tp[2 * CD_LW], c_m = tm[2 * CD_LW];
-        const uint32_t sn_m = tm[3 * CD_LW], sp_p = tp[1 * CD_LW];
-        const int e1 = (int)__builtin_amdgcn_sad_u8(Fp, c_m, __builtin_amdgcn_sad_u8(Fc, sn_m, 0u));   // diffsn + diffps
-        const int d1 = (int)__builtin_amdgcn_sad_u8(Fn, c_p, __builtin_amdgcn_sad_u8(Fc, sp_p, 0u));   // diffsp + diffns
-        const int diff = e1 + d1;
-        int diffd = d1, diffe = e1;
-        kb = min(kb, ((uint32_t)diff << 6) | ub);
-        if (!first)
-        {
-            const int diff2pp = (int)__builtin_amdgcn_sad_u8(F2p, tm[1 * CD_LW], 0u);
-            const int diffp2p = (int)__builtin_amdgcn_sad_u8(Fp, tp[0 * CD_LW], 0u);
-            diffd += diffp2p;
-            diffe += diff2pp;
-            ka = min(ka, ((uint32_t)(diff + diff2pp + diffp2p) << 6) | ub);
-        }
-        if (!last)
-        {
-            const int diff2nn = (int)__builtin_amdgcn_sad_u8(F2n, tp[3 * CD_LW], 0u);
-            const int diffn2n = (int)__builtin_amdgcn_sad_u8(Fn, tm[4 * CD_LW], 0u);
-            diffd += diff2nn;
-            diffe += diffn2n;
-            kc = min(kc, ((uint32_t)(diff + diff2nn + diffn2n) << 6) | ub);
-        }
-        kd = min(kd, ((uint32_t)diffd << 6) | ub);
-        ke = min(ke, ((uint32_t)diffe << 6) | ub);
-    }
-    int order[5], k = 0;
-    if (ka & 63) order[k++] = (int)(ka & 63) - 32;
-    if (kb & 63) order[k++] = (int)(kb & 63) - 32;
-    if (kc & 63) order[k++] = (int)(kc & 63) - 32;
-    if (kd & 63) order[k++] = (int)(kd & 63) - 32;
-    if (ke & 63) order[k++] = (int)(ke & 63) - 32;
-    int out = NEUTRAL;
-    if (k > 1)
-    {
-        const int mid = sorted_mid(order, k);
-        const int tlim = max((int)c_limlut[iabs(mid)] >> 2, 2);
-        int sum = 0, cnt = 0;
-        for (int i = 0; i < k; i++)
-            if (iabs(order[i] - mid) <= tlim) { cnt++; sum += order[i]; }
-        if (cnt > 1) out = (NEUTRAL + ((int)((float)sum / (float)cnt) * 4)) & 0xff;
-    }
-    P.c[pl][(size_t)y * pitch + px] = (uint8_t)out;
-}
 
 // calc_directions, fourth form: a block takes 256 columns x R rows.
 //  * Rows share their staging: R + 4 source and R + 2 mask rows (and the triple tables / peak bitmaps made from them)
@@ -1140,7 +620,7 @@ __global__ __launch_bounds__(CD_W) void k_calc_dir_rows(P3 P, int maxd, int nt13
     __shared__ uint16_t s_list[R * CD_W];                                      // the listed pixels, (row << 8) | column
     __shared__ __attribute__((aligned(16))) uint8_t s_out[R][CD_W];
     __shared__ int s_count;
-    const int pl = blockIdx.z;
+    FIELD_PLANE(P);
     const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
     const int x0 = blockIdx.x * CD_W, y0 = blockIdx.y * R;
     if (y0 >= height || x0 >= pitch) return;
@@ -1152,7 +632,7 @@ __global__ __launch_bounds__(CD_W) void k_calc_dir_rows(P3 P, int maxd, int nt13
         // flat addressing as in the one-row forms (out-of-row columns pick up the neighbouring rows' bytes, as the
         // reference's pointer arithmetic does); rows past height + 1 serve no pixel and are not touched.  16 bytes per
         // load (the scratch planes, their pitches and x0 - CD_HALO are multiples of 16).
-        const uint8_t *sb = P.b[pl] + x0 - CD_HALO, *mb = P.a[pl] + x0 - CD_HALO;
+        const uint8_t *sb = Q.b + x0 - CD_HALO, *mb = Q.a + x0 - CD_HALO;
         for (int i = tid; i < (NS + NM) * RQ; i += CD_W)
         {
             const int r = i / RQ, c16 = i - r * RQ;
@@ -1258,7 +738,7 @@ __global__ __launch_bounds__(CD_W) void k_calc_dir_rows(P3 P, int maxd, int nt13
     {
         const int j = jr + (tid >> 6), y = y0 + j, xb = x0 + 4 * lane;
         if (j < R && y < height && xb < pitch)
-            *reinterpret_cast<uint32_t *>(P.c[pl] + (size_t)y * pitch + xb) = reinterpret_cast<const uint32_t *>(&s_out[j][0])[lane];
+            *reinterpret_cast<uint32_t *>(Q.c + (size_t)y * pitch + xb) = reinterpret_cast<const uint32_t *>(&s_out[j][0])[lane];
     }
 }
 
@@ -1266,64 +746,6 @@ __global__ __launch_bounds__(CD_W) void k_calc_dir_rows(P3 P, int maxd, int nt13
 // a = edge mask, b = direction map in, c = out.  step = 1 (half height) or 2.
 // step 1: rows 1..height-2, neighbours y+-1, mask row y.
 // step 2: rows y0, y0+2, ... < height-1, neighbours y+-2 (guarded by y>1 / y<height-2), mask rows y-1 and y+1.
-__global__ void k_dir_map(P3 P, int step, int y0, int expand)
-{
-    XY_PLANE(P);
-    if (x >= width || y >= height) return;
-    // Every byte this pixel may look at is loaded before the first decision (the rows exist: the
-    // scratch frames sit inside zeroed guard bands), so the kernel pays one memory round trip
-    // instead of three dependent ones.
-    const uint8_t *dc = P.b[pl] + (size_t)y * pitch + x;
-    const uint8_t *du = dc - (ptrdiff_t)step * pitch, *dd = dc + (ptrdiff_t)step * pitch;
-    const uint8_t *mk = P.a[pl] + (size_t)y * pitch + x;
-    const int c0 = dc[-1], c1 = dc[0], c2 = dc[1];
-    const int u0 = du[-1], u1 = du[0], u2 = du[1];
-    const int n0 = dd[-1], n1 = dd[0], n2 = dd[1];
-    const int m0 = step == 1 ? mk[0] : mk[-(ptrdiff_t)pitch], m1 = step == 1 ? 0 : mk[pitch];
-    int out = c1;                                              // bit_blit
-    if (P.d[pl]) P.d[pl][(size_t)y * pitch + x] = (uint8_t)c1;  // optional copy of the input (the eedi2_bit_blit before post-processing)
-    const bool row_ok = step == 1 ? (y >= 1 && y < height - 1) : (y >= y0 && y < height - 1 && ((y - y0) & 1) == 0);
-    if (row_ok && x >= 1 && x < width - 1)
-    {
-        const bool masked = m0 == PEAK || (step != 1 && m1 == PEAK);
-        if (masked && !(expand && c1 != PEAK))
-        {
-            // keep this a real branch: flattened, every wave would pay for the sort below
-            asm volatile("" ::: "memory");
-            const bool up_ok = step == 1 || y > 1, dn_ok = step == 1 || y < height - 2;
-            const bool h0 = up_ok && u0 != PEAK, h1 = up_ok && u1 != PEAK, h2 = up_ok && u2 != PEAK;
-            const bool h3 = c0 != PEAK, h4 = !expand && c1 != PEAK, h5 = c2 != PEAK;
-            const bool h6 = dn_ok && n0 != PEAK, h7 = dn_ok && n1 != PEAK, h8 = dn_ok && n2 != PEAK;
-            const int u = h0 + h1 + h2 + h3 + h4 + h5 + h6 + h7 + h8;
-            if (u < (expand ? 5 : 4))
-            {
-                if (!expand) out = PEAK;
-            }
-            else
-            {
-                int v0 = h0 ? u0 : ABSENT, v1 = h1 ? u1 : ABSENT, v2 = h2 ? u2 : ABSENT;
-                int v3 = h3 ? c0 : ABSENT, v4 = h4 ? c1 : ABSENT, v5 = h5 ? c2 : ABSENT;
-                int v6 = h6 ? n0 : ABSENT, v7 = h7 ? n1 : ABSENT, v8 = h8 ? n2 : ABSENT;
-                const int mid = mid9(v0, v1, v2, v3, v4, v5, v6, v7, v8, u);
-                const int lim = c_limlut[iabs(mid - NEUTRAL) >> 2];
-                int sum = 0, count = 0;
-                vote1(v0, mid, lim, sum, count); vote1(v1, mid, lim, sum, count); vote1(v2, mid, lim, sum, count);
-                vote1(v3, mid, lim, sum, count); vote1(v4, mid, lim, sum, count); vote1(v5, mid, lim, sum, count);
-                vote1(v6, mid, lim, sum, count); vote1(v7, mid, lim, sum, count); vote1(v8, mid, lim, sum, count);
-                const int val = (int)(((float)(sum + mid) / (float)(count + 1)) + 0.5f);
-                if (expand)
-                {
-                    if (count >= 5) out = val & 0xff;
-                }
-                else if (count < 4 || (count < 5 && c1 == PEAK))
-                    out = PEAK;
-                else
-                    out = val & 0xff;
-            }
-        }
-    }
-    P.c[pl][(size_t)y * pitch + x] = (uint8_t)out;
-}
 
 // k_dir_map with four pixels per thread (the form that runs; k_dir_map above is the one-pixel reference form kept for
 // HBHIP_EEDI2_1PX).  One byte per thread makes these passes latency bound: a wave lives for two dependent memory round
@@ -1354,12 +776,13 @@ __device__ __forceinline__ int dir_map_px(int u0, int u1, int u2, int c0, int c1
     return val & 0xff;
 }
 
-__global__ __launch_bounds__(256) void k_dir_map4(P3 P, int step, int y0, int expand)
+__global__ __launch_bounds__(256) void k_dir_map4(P3 P, int step, int expand)
 {
     XY4_PLANE(P);
+    const int y0 = step == 1 ? 1 : 2 - tff;
     if (x >= width || y >= height) return;
-    const uint8_t *dc = P.b[pl] + (size_t)y * pitch + x;
-    uint8_t *o = P.c[pl] + (size_t)y * pitch + x;
+    const uint8_t *dc = Q.b + (size_t)y * pitch + x;
+    uint8_t *o = Q.c + (size_t)y * pitch + x;
     const bool row_ok = step == 1 ? (y >= 1 && y < height - 1) : (y >= y0 && y < height - 1 && ((y - y0) & 1) == 0);
     if (!row_ok)
     {
@@ -1367,11 +790,11 @@ __global__ __launch_bounds__(256) void k_dir_map4(P3 P, int step, int y0, int ex
         const uint32_t v = *reinterpret_cast<const uint32_t *>(dc);
         int out[4] = { (int)(v & 0xff), (int)((v >> 8) & 0xff), (int)((v >> 16) & 0xff), (int)(v >> 24) };
         st4(o, out, x, width);
-        if (P.d[pl]) st4(P.d[pl] + (size_t)y * pitch + x, out, x, width);
+        if (Q.d) st4(Q.d + (size_t)y * pitch + x, out, x, width);
         return;
     }
     const Win12 wc = ldwin(dc), wu = ldwin(dc - (ptrdiff_t)step * pitch), wd = ldwin(dc + (ptrdiff_t)step * pitch);
-    const uint8_t *mk = P.a[pl] + (size_t)y * pitch + x;
+    const uint8_t *mk = Q.a + (size_t)y * pitch + x;
     const uint32_t m0 = *reinterpret_cast<const uint32_t *>(step == 1 ? mk : mk - (ptrdiff_t)pitch);
     const uint32_t m1 = step == 1 ? 0u : *reinterpret_cast<const uint32_t *>(mk + pitch);
     const bool up_ok = step == 1 || y > 1, dn_ok = step == 1 || y < height - 2;
@@ -1391,10 +814,10 @@ __global__ __launch_bounds__(256) void k_dir_map4(P3 P, int step, int y0, int ex
         }
     }
     st4(o, out, x, width);
-    if (P.d[pl])
+    if (Q.d)
     {
         int in[4] = { wb(wc, 0), wb(wc, 1), wb(wc, 2), wb(wc, 3) };
-        st4(P.d[pl] + (size_t)y * pitch + x, in, x, width);
+        st4(Q.d + (size_t)y * pitch + x, in, x, width);
     }
 }
 
@@ -1417,12 +840,13 @@ __device__ __forceinline__ uint32_t live3(const Win12 &w, uint32_t &centre)   //
 
 // post != 0 (the last expand_dir_map_2x of a field): eedi2_post_process (:1349-1378, k_post) rides along - it is
 // pointwise in the map this pass has just made (e = the map before the post filters, f = dst2p, rebuilt rows only).
-__global__ __launch_bounds__(256) void k_dir_map_c(P3 P, int step, int y0, int expand, int post)
+__global__ __launch_bounds__(256) void k_dir_map_c(P3 P, int step, int expand, int post)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_out[4][256];
     __shared__ uint16_t s_list[4 * 256];
     __shared__ int s_count;
-    const int pl = blockIdx.z;
+    FIELD_PLANE(P);
+    const int y0 = step == 1 ? 1 : 2 - tff;
     const int bx0 = 4 * (blockIdx.x * 64), x = bx0 + 4 * threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
     if (bx0 >= width || (int)blockIdx.y * 4 >= height) return;                       // whole workgroup outside
@@ -1431,7 +855,7 @@ __global__ __launch_bounds__(256) void k_dir_map_c(P3 P, int step, int y0, int e
     __syncthreads();
     const bool inside = x < width && y < height;
     const bool row_ok = step == 1 ? (y >= 1 && y < height - 1) : (y >= y0 && y < height - 1 && ((y - y0) & 1) == 0);
-    const uint8_t *dc = P.b[pl] + (size_t)y * pitch + x;
+    const uint8_t *dc = Q.b + (size_t)y * pitch + x;
     if (inside)
     {
         uint32_t out;
@@ -1439,7 +863,7 @@ __global__ __launch_bounds__(256) void k_dir_map_c(P3 P, int step, int y0, int e
         else
         {
             const Win12 wc = ldwin(dc), wu = ldwin(dc - (ptrdiff_t)step * pitch), wd = ldwin(dc + (ptrdiff_t)step * pitch);
-            const uint8_t *mk = P.a[pl] + (size_t)y * pitch + x;
+            const uint8_t *mk = Q.a + (size_t)y * pitch + x;
             const uint32_t m0 = *reinterpret_cast<const uint32_t *>(step == 1 ? mk : mk - (ptrdiff_t)pitch);
             const uint32_t m1 = step == 1 ? 0u : *reinterpret_cast<const uint32_t *>(mk + pitch);
             const bool up_ok = step == 1 || y > 1, dn_ok = step == 1 || y < height - 2;
@@ -1465,11 +889,11 @@ __global__ __launch_bounds__(256) void k_dir_map_c(P3 P, int step, int y0, int e
             (void)nu; (void)nd;
         }
         *reinterpret_cast<uint32_t *>(&s_out[threadIdx.y][4 * threadIdx.x]) = out;
-        if (P.d[pl])                                                                    // optional copy of the input (the eedi2_bit_blit before post-processing)
+        if (Q.d)                                                                    // optional copy of the input (the eedi2_bit_blit before post-processing)
         {
             const uint32_t v = *reinterpret_cast<const uint32_t *>(dc);
             int in[4] = { (int)(v & 0xff), (int)((v >> 8) & 0xff), (int)((v >> 16) & 0xff), (int)(v >> 24) };
-            st4(P.d[pl] + (size_t)y * pitch + x, in, x, width);
+            st4(Q.d + (size_t)y * pitch + x, in, x, width);
         }
     }
     __syncthreads();
@@ -1478,7 +902,7 @@ __global__ __launch_bounds__(256) void k_dir_map_c(P3 P, int step, int y0, int e
     {
         const int e = s_list[i], ly = e >> 8, lx = e & 255;
         const int yy = blockIdx.y * 4 + ly;
-        const uint8_t *c = P.b[pl] + (size_t)yy * pitch + bx0 + lx;
+        const uint8_t *c = Q.b + (size_t)yy * pitch + bx0 + lx;
         const uint8_t *up = c - (ptrdiff_t)step * pitch, *dn = c + (ptrdiff_t)step * pitch;
         const bool up_ok = step == 1 || yy > 1, dn_ok = step == 1 || yy < height - 2;
         s_out[ly][lx] = (uint8_t)dir_map_px(up[-1], up[0], up[1], c[-1], c[0], c[1], dn[-1], dn[0], dn[1], up_ok, dn_ok, expand);
@@ -1487,14 +911,14 @@ __global__ __launch_bounds__(256) void k_dir_map_c(P3 P, int step, int y0, int e
     if (inside)
     {
         const uint32_t v = *reinterpret_cast<const uint32_t *>(&s_out[threadIdx.y][4 * threadIdx.x]);
-        uint8_t *o = P.c[pl] + (size_t)y * pitch + x;
+        uint8_t *o = Q.c + (size_t)y * pitch + x;
         if (x + 3 < width) *reinterpret_cast<uint32_t *>(o) = v;
         else for (int k = 0; k < 4 && x + k < width; k++) o[k] = (uint8_t)(v >> (8 * k));
         if (post && row_ok)
         {
             const size_t at = (size_t)y * pitch + x;
-            const uint32_t om4 = *reinterpret_cast<const uint32_t *>(P.e[pl] + at);
-            uint8_t *d = P.f[pl] + at;
+            const uint32_t om4 = *reinterpret_cast<const uint32_t *>(Q.e + at);
+            uint8_t *d = Q.f + at;
             const uint32_t up4 = *reinterpret_cast<const uint32_t *>(d - pitch), dn4 = *reinterpret_cast<const uint32_t *>(d + pitch);
             const uint32_t cur4 = *reinterpret_cast<const uint32_t *>(d);
             int out[4];
@@ -1530,9 +954,9 @@ __global__ void k_filter_map(P3 P)
 {
     XY_PLANE(P);
     if (x >= width || y >= height) return;
-    const uint8_t *dc = P.b[pl] + (size_t)y * pitch;
+    const uint8_t *dc = Q.b + (size_t)y * pitch;
     int out = dc[x];
-    if (x >= 1 && x < width - 1 && y >= 1 && y < height - 1 && dc[x] != PEAK && P.a[pl][(size_t)y * pitch + x] == PEAK)
+    if (x >= 1 && x < width - 1 && y >= 1 && y < height - 1 && dc[x] != PEAK && Q.a[(size_t)y * pitch + x] == PEAK)
     {
         const uint8_t *dp = dc - pitch, *dn = dc + pitch;
         int dir = ((int)dc[x] - NEUTRAL) >> 2;
@@ -1549,7 +973,7 @@ __global__ void k_filter_map(P3 P)
             if (icb) out = PEAK;
         }
     }
-    P.c[pl][(size_t)y * pitch + x] = (uint8_t)out;
+    Q.c[(size_t)y * pitch + x] = (uint8_t)out;
 }
 
 // a = msk2p, b = dmsk (tmp2p2), c = out (tmp2p)
@@ -1558,73 +982,29 @@ __global__ void k_filter_map(P3 P)
 // The rows y-1 / y+1 of the doubled maps that mark_directions reads are rows (y-1)>>1 / (y+1)>>1 of
 // the half-height ones, so it reads those directly and no separate upscale launch is needed.
 // a = mskp, b = dstp, c = out (tmp2p), g = srcp; `height` = full height.
-__global__ void k_mark_2x(P3 P, int y0)
-{
-    XY_PLANE(P);
-    if (x >= pitch || y >= height) return;
-    int out = 255;                                            // memset(dstp, 255, pitch*height)
-    {
-        const size_t hs = (size_t)(y >> 1) * pitch + x, fs = (size_t)y * pitch + x;
-        P.d[pl][fs] = P.g[pl][hs];
-        P.e[pl][fs] = P.b[pl][hs];
-        P.f[pl][fs] = P.a[pl][hs];
-    }
-    // all loads up front (one memory round trip); row -1 exists inside the guard band
-    const uint8_t *d0 = P.b[pl] + (ptrdiff_t)((y - 1) >> 1) * pitch + x, *d1 = P.b[pl] + (ptrdiff_t)((y + 1) >> 1) * pitch + x;
-    const uint8_t *m0 = P.a[pl] + (ptrdiff_t)((y - 1) >> 1) * pitch + x, *m1 = P.a[pl] + (ptrdiff_t)((y + 1) >> 1) * pitch + x;
-    const int a0 = d0[-1], a1 = d0[0], a2 = d0[1], b0 = d1[-1], b1 = d1[0], b2 = d1[1];
-    const int k0 = m0[0], k1 = m1[0];
-    if (y >= y0 && y < height - 1 && ((y - y0) & 1) == 0 && x >= 1 && x < width - 1)
-    {
-        if (k0 == PEAK || k1 == PEAK)
-        {
-            asm volatile("" ::: "memory");                    // keep the branch (see k_dir_map)
-            const int v = (a0 != PEAK) + (a1 != PEAK) + (a2 != PEAK) + (b0 != PEAK) + (b1 != PEAK) + (b2 != PEAK);
-            if (v >= 3)
-            {
-                int s0 = a0 != PEAK ? a0 : ABSENT, s1 = a1 != PEAK ? a1 : ABSENT, s2 = a2 != PEAK ? a2 : ABSENT;
-                int s3 = b0 != PEAK ? b0 : ABSENT, s4 = b1 != PEAK ? b1 : ABSENT, s5 = b2 != PEAK ? b2 : ABSENT;
-                const int mid = mid6(s0, s1, s2, s3, s4, s5, v);
-                const int lim = c_limlut[iabs(mid - NEUTRAL) >> 2];
-                int u = 0;
-                if (iabs(a0 - b0) <= lim || a0 == PEAK || b0 == PEAK) u++;
-                if (iabs(a1 - b1) <= lim || a1 == PEAK || b1 == PEAK) u++;
-                if (iabs(a2 - b0) <= lim || a2 == PEAK || b2 == PEAK) u++;   // sic (:835): d0[x+1] against d1[x-1]
-                if (u >= 2)
-                {
-                    int sum = 0, count = 0;
-                    vote1(s0, mid, lim, sum, count); vote1(s1, mid, lim, sum, count); vote1(s2, mid, lim, sum, count);
-                    vote1(s3, mid, lim, sum, count); vote1(s4, mid, lim, sum, count); vote1(s5, mid, lim, sum, count);
-                    const int val = (int)(((float)(sum + mid) / (float)(count + 1)) + 0.5f);
-                    if (!(count < v - 2 || count < 2)) out = val & 0xff;
-                }
-            }
-        }
-    }
-    P.c[pl][(size_t)y * pitch + x] = (uint8_t)out;
-}
 
 // k_mark_2x with four pixels per thread (see k_dir_map4): the three line doublings are dword copies, and only the
 // rows mark_directions_2x rebuilds (every other one) load the two neighbouring half-height rows.
-__global__ __launch_bounds__(256) void k_mark_2x4(P3 P, int y0)
+__global__ __launch_bounds__(256) void k_mark_2x4(P3 P)
 {
     XY4_PLANE(P);
+    const int y0 = 2 - tff;
     if (x >= pitch || y >= height) return;
     {
         const size_t hs = (size_t)(y >> 1) * pitch + x, fs = (size_t)y * pitch + x;
-        *reinterpret_cast<uint32_t *>(P.d[pl] + fs) = *reinterpret_cast<const uint32_t *>(P.g[pl] + hs);
-        *reinterpret_cast<uint32_t *>(P.e[pl] + fs) = *reinterpret_cast<const uint32_t *>(P.b[pl] + hs);
-        *reinterpret_cast<uint32_t *>(P.f[pl] + fs) = *reinterpret_cast<const uint32_t *>(P.a[pl] + hs);
+        *reinterpret_cast<uint32_t *>(Q.d + fs) = *reinterpret_cast<const uint32_t *>(Q.g + hs);
+        *reinterpret_cast<uint32_t *>(Q.e + fs) = *reinterpret_cast<const uint32_t *>(Q.b + hs);
+        *reinterpret_cast<uint32_t *>(Q.f + fs) = *reinterpret_cast<const uint32_t *>(Q.a + hs);
     }
-    uint32_t *o = reinterpret_cast<uint32_t *>(P.c[pl] + (size_t)y * pitch + x);
+    uint32_t *o = reinterpret_cast<uint32_t *>(Q.c + (size_t)y * pitch + x);
     if (!(y >= y0 && y < height - 1 && ((y - y0) & 1) == 0))
     {
         *o = 0xffffffffu;                                         // memset(dstp, 255, pitch*height)
         return;
     }
-    const Win12 wa = ldwin(P.b[pl] + (ptrdiff_t)((y - 1) >> 1) * pitch + x), wbn = ldwin(P.b[pl] + (ptrdiff_t)((y + 1) >> 1) * pitch + x);
-    const uint32_t k0w = *reinterpret_cast<const uint32_t *>(P.a[pl] + (ptrdiff_t)((y - 1) >> 1) * pitch + x);
-    const uint32_t k1w = *reinterpret_cast<const uint32_t *>(P.a[pl] + (ptrdiff_t)((y + 1) >> 1) * pitch + x);
+    const Win12 wa = ldwin(Q.b + (ptrdiff_t)((y - 1) >> 1) * pitch + x), wbn = ldwin(Q.b + (ptrdiff_t)((y + 1) >> 1) * pitch + x);
+    const uint32_t k0w = *reinterpret_cast<const uint32_t *>(Q.a + (ptrdiff_t)((y - 1) >> 1) * pitch + x);
+    const uint32_t k1w = *reinterpret_cast<const uint32_t *>(Q.a + (ptrdiff_t)((y + 1) >> 1) * pitch + x);
     uint32_t packed = 0xffffffffu;
 #pragma unroll
     for (int k = 0; k < 4; k++)
@@ -1663,63 +1043,6 @@ __global__ __launch_bounds__(256) void k_mark_2x4(P3 P, int y0)
 // a = msk2p, b = dmsk in, c = out.  Every pixel of a fillable gap computes the same
 // (u, v, back, forward, verdict) as its neighbours in the gap (:1053-1120), so each
 // thread only writes its own pixel.
-__global__ void k_fill_gaps(P3 P, int y0)
-{
-    XY_PLANE(P);
-    if (x >= width || y >= height) return;
-    const uint8_t *dc = P.b[pl] + (size_t)y * pitch;
-    int out = dc[x];
-    if (y >= y0 && y < height - 1 && ((y - y0) & 1) == 0 && x >= 1 && x < width - 1)
-    {
-        const uint8_t *mc = P.a[pl] + (size_t)(y - 1) * pitch;
-        const uint8_t *mn = mc + 2 * (size_t)pitch;
-        if (dc[x] == PEAK && (mc[x] == PEAK || mn[x] == PEAK))
-        {
-            const uint8_t *dp = dc - 2 * (ptrdiff_t)pitch, *dn = dc + 2 * (ptrdiff_t)pitch;
-            const uint8_t *mp = mc - 2 * (ptrdiff_t)pitch, *mnn = mn + 2 * (ptrdiff_t)pitch;
-            int u = x - 1, back = 500, forward = -500;
-            while (u)
-            {
-                if (dc[u] != PEAK) { back = dc[u]; break; }
-                if (mc[u] != PEAK && mn[u] != PEAK) break;
-                u--;
-            }
-            int v = x + 1;
-            while (v < width)
-            {
-                if (dc[v] != PEAK) { forward = dc[v]; break; }
-                if (mc[v] != PEAK && mn[v] != PEAK) break;
-                v++;
-            }
-            int tc = 1, bc = 1, mint = 500, maxt = -20, minb = 500, maxb = -20;
-            for (int j = u; j <= v; j++)
-            {
-                if (tc)
-                {
-                    if (y <= 2 || dp[j] == PEAK || (mp[j] != PEAK && mc[j] != PEAK)) { tc = 0; mint = maxt = 20; }
-                    else { mint = min(mint, (int)dp[j]); maxt = max(maxt, (int)dp[j]); }
-                }
-                if (bc)
-                {
-                    if (y >= height - 3 || dn[j] == PEAK || (mn[j] != PEAK && mnn[j] != PEAK)) { bc = 0; minb = maxb = 20; }
-                    else { minb = min(minb, (int)dn[j]); maxb = max(maxb, (int)dn[j]); }
-                }
-            }
-            if (maxt == -20) maxt = mint = 20;
-            if (maxb == -20) maxb = minb = 20;
-            const int far = max(iabs(forward - NEUTRAL), iabs(back - NEUTRAL));
-            const int thresh = max(max(far >> 2, 8), max(iabs(mint - maxt), iabs(minb - maxb)));
-            const int flim = min(far >> 2, 6);
-            if (iabs(forward - back) <= thresh && (v - u - 1 <= flim || tc || bc))
-            {
-                const double stepd = (double)(forward - back) / (double)(v - u);
-                const int j = x - u - 1;
-                out = (back + (int)(j * stepd + 0.5)) & 0xff;
-            }
-        }
-    }
-    P.c[pl][(size_t)y * pitch + x] = (uint8_t)out;
-}
 
 // fill_gaps_2x, the form that runs (k_fill_gaps above is the one-pixel form kept for HBHIP_EEDI2_1PX).
 // Two things cost time in the one-pixel form: most waves exist only to copy 64 bytes, and the few pixels that really
@@ -1737,117 +1060,6 @@ __global__ void k_fill_gaps(P3 P, int y0)
 // against 29; the walk on LDS without compaction, 38 us.)
 constexpr int FG_W = 1024, FG_HALO = 64, FG_LW = FG_W + 2 * FG_HALO;
 
-__global__ __launch_bounds__(256) void k_fill_gaps_c(P3 P, int y0)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t s_r[7][FG_LW];
-    __shared__ __attribute__((aligned(16))) uint8_t s_out[FG_W];
-    __shared__ uint16_t s_list[FG_W];
-    __shared__ int s_count;
-    const int pl = blockIdx.z, y = blockIdx.y;
-    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
-    const int x0 = blockIdx.x * FG_W, tid = threadIdx.x;
-    if (y >= height || x0 >= width) return;
-    const uint8_t *dcg = P.b[pl] + (size_t)y * pitch;
-    uint8_t *og = P.c[pl] + (size_t)y * pitch;
-    const int x = x0 + 4 * tid;
-    if (!(y >= y0 && y < height - 1 && ((y - y0) & 1) == 0))
-    {
-        if (x < width)
-        {
-            const uint32_t v = *reinterpret_cast<const uint32_t *>(dcg + x);
-            if (x + 3 < width) *reinterpret_cast<uint32_t *>(og + x) = v;
-            else for (int k = 0; k < 4 && x + k < width; k++) og[x + k] = (uint8_t)(v >> (8 * k));
-        }
-        return;
-    }
-    if (tid == 0) s_count = 0;
-    const uint8_t *g[7] = { dcg, P.a[pl] + (ptrdiff_t)(y - 1) * pitch, P.a[pl] + (ptrdiff_t)(y + 1) * pitch,
-                            dcg - 2 * (ptrdiff_t)pitch, dcg + 2 * (ptrdiff_t)pitch,
-                            P.a[pl] + (ptrdiff_t)(y - 3) * pitch, P.a[pl] + (ptrdiff_t)(y + 3) * pitch };
-    const int lo = x0 - FG_HALO;                                   // column of staged byte 0 (a multiple of 4)
-    const int ndw = (min(FG_W, hbhip_align_up_dev(width - x0, 4)) + 2 * FG_HALO) / 4;
-    for (int r = 0; r < 7; r++)
-        for (int i = tid; i < ndw; i += 256)
-            reinterpret_cast<uint32_t *>(s_r[r])[i] = reinterpret_cast<const uint32_t *>(g[r] + lo)[i];
-    __syncthreads();
-    enum { DC = 0, MC = 1, MN = 2, DP = 3, DN = 4, MP = 5, MNN = 6 };
-    if (x < width)
-    {
-        const int c = 4 * tid + FG_HALO;
-        const uint32_t cw = *reinterpret_cast<const uint32_t *>(&s_r[DC][c]);
-        const uint32_t mcw = *reinterpret_cast<const uint32_t *>(&s_r[MC][c]), mnw = *reinterpret_cast<const uint32_t *>(&s_r[MN][c]);
-        *reinterpret_cast<uint32_t *>(&s_out[4 * tid]) = cw;
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-        {
-            const int xx = x + k;
-            if (xx >= 1 && xx < width - 1 && ((cw >> (8 * k)) & 0xff) == PEAK &&
-                (((mcw >> (8 * k)) & 0xff) == PEAK || ((mnw >> (8 * k)) & 0xff) == PEAK))
-                s_list[atomicAdd(&s_count, 1)] = (uint16_t)(4 * tid + k);
-        }
-    }
-    __syncthreads();
-    const int count = s_count;
-    const unsigned staged = 4u * (unsigned)ndw;
-    auto rd = [&](int r, int col) -> int {
-        const unsigned k = (unsigned)(col - lo);
-        return k < staged ? (int)s_r[r][k] : (int)g[r][col];
-    };
-    for (int i = tid; i < count; i += 256)
-    {
-        const int lx = s_list[i], px = x0 + lx;
-        int u = px - 1, back = 500, forward = -500;
-        while (u)
-        {
-            const int d = rd(DC, u);
-            if (d != PEAK) { back = d; break; }
-            if (rd(MC, u) != PEAK && rd(MN, u) != PEAK) break;
-            u--;
-        }
-        int v = px + 1;
-        while (v < width)
-        {
-            const int d = rd(DC, v);
-            if (d != PEAK) { forward = d; break; }
-            if (rd(MC, v) != PEAK && rd(MN, v) != PEAK) break;
-            v++;
-        }
-        int tc = 1, bc = 1, mint = 500, maxt = -20, minb = 500, maxb = -20;
-        for (int j = u; j <= v; j++)
-        {
-            if (tc)
-            {
-                int t;
-                if (y <= 2 || (t = rd(DP, j)) == PEAK || (rd(MP, j) != PEAK && rd(MC, j) != PEAK)) { tc = 0; mint = maxt = 20; }
-                else { mint = min(mint, t); maxt = max(maxt, t); }
-            }
-            if (bc)
-            {
-                int t;
-                if (y >= height - 3 || (t = rd(DN, j)) == PEAK || (rd(MN, j) != PEAK && rd(MNN, j) != PEAK)) { bc = 0; minb = maxb = 20; }
-                else { minb = min(minb, t); maxb = max(maxb, t); }
-            }
-        }
-        if (maxt == -20) maxt = mint = 20;
-        if (maxb == -20) maxb = minb = 20;
-        const int far = max(iabs(forward - NEUTRAL), iabs(back - NEUTRAL));
-        const int thresh = max(max(far >> 2, 8), max(iabs(mint - maxt), iabs(minb - maxb)));
-        const int flim = min(far >> 2, 6);
-        if (iabs(forward - back) <= thresh && (v - u - 1 <= flim || tc || bc))
-        {
-            const double stepd = (double)(forward - back) / (double)(v - u);
-            const int j = px - u - 1;
-            s_out[lx] = (uint8_t)((back + (int)(j * stepd + 0.5)) & 0xff);
-        }
-    }
-    __syncthreads();
-    if (x < width)
-    {
-        const uint32_t v = *reinterpret_cast<const uint32_t *>(&s_out[4 * tid]);
-        if (x + 3 < width) *reinterpret_cast<uint32_t *>(og + x) = v;
-        else for (int k = 0; k < 4 && x + k < width; k++) og[x + k] = (uint8_t)(v >> (8 * k));
-    }
-}
 
 // k_fill_gaps_c with the walks done on bitmaps (the form that runs).  Every pixel of a gap walks the gap's whole length
 // on dependent byte reads in k_fill_gaps_c - 1.9 M VALU instructions in a 24.7 us kernel: its time is the longest
@@ -1855,19 +1067,20 @@ __global__ __launch_bounds__(256) void k_fill_gaps_c(P3 P, int y0)
 // turned into four bit rows (ballots), and a pixel finds its gap's ends, and whether the rows above / below break
 // the gap's support, with a few 64-bit operations; only the min / max over a supported gap still walks bytes
 // (independent reads).  Walks that leave the staged span take the byte path (rare).
-__global__ __launch_bounds__(256) void k_fill_gaps_b(P3 P, int y0)
+__global__ __launch_bounds__(256) void k_fill_gaps_b(P3 P)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_r[7][FG_LW];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[FG_W];
     __shared__ uint16_t s_list[FG_W];
     __shared__ int s_count;
     __shared__ uint64_t s_stop[FG_LW / 64 + 1], s_np[FG_LW / 64 + 1], s_bt[FG_LW / 64 + 1], s_bb[FG_LW / 64 + 1];   // one bit per staged column
-    const int pl = blockIdx.z, y = blockIdx.y;
+    FIELD_PLANE(P);
+    const int y = blockIdx.y, y0 = 2 - tff;
     const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
     const int x0 = blockIdx.x * FG_W, tid = threadIdx.x;
     if (y >= height || x0 >= width) return;
-    const uint8_t *dcg = P.b[pl] + (size_t)y * pitch;
-    uint8_t *og = P.c[pl] + (size_t)y * pitch;
+    const uint8_t *dcg = Q.b + (size_t)y * pitch;
+    uint8_t *og = Q.c + (size_t)y * pitch;
     const int x = x0 + 4 * tid;
     if (!(y >= y0 && y < height - 1 && ((y - y0) & 1) == 0))
     {
@@ -1880,9 +1093,9 @@ __global__ __launch_bounds__(256) void k_fill_gaps_b(P3 P, int y0)
         return;
     }
     if (tid == 0) s_count = 0;
-    const uint8_t *g[7] = { dcg, P.a[pl] + (ptrdiff_t)(y - 1) * pitch, P.a[pl] + (ptrdiff_t)(y + 1) * pitch,
+    const uint8_t *g[7] = { dcg, Q.a + (ptrdiff_t)(y - 1) * pitch, Q.a + (ptrdiff_t)(y + 1) * pitch,
                             dcg - 2 * (ptrdiff_t)pitch, dcg + 2 * (ptrdiff_t)pitch,
-                            P.a[pl] + (ptrdiff_t)(y - 3) * pitch, P.a[pl] + (ptrdiff_t)(y + 3) * pitch };
+                            Q.a + (ptrdiff_t)(y - 3) * pitch, Q.a + (ptrdiff_t)(y + 3) * pitch };
     const int lo = x0 - FG_HALO;                                   // column of staged byte 0 (a multiple of 4)
     const int ndw = (min(FG_W, hbhip_align_up_dev(width - x0, 4)) + 2 * FG_HALO) / 4;
     {
@@ -2049,99 +1262,6 @@ __global__ __launch_bounds__(256) void k_fill_gaps_b(P3 P, int y0)
     }
 }
 
-// Everything k_lattice_cand packs for one pixel; the row pointers are indexed by the absolute column.
-__device__ __forceinline__ uint32_t lattice_px(const uint8_t *top, const uint8_t *bot, const uint8_t *ot, const uint8_t *ob,
-                                               const uint8_t *dm, int x, int width, int pl, int nt4, int nt7, int nt8, int nt)
-{
-    // the fixed-offset bytes every path below needs, loaded together
-    const int d = dm[x], dr = dm[x + 1];
-    const int T0 = top[x - 2], T1 = top[x - 1], T2 = top[x], T3 = top[x + 1], T4 = top[x + 2];
-    const int B0 = bot[x - 2], B1 = bot[x - 1], B2 = bot[x], B3 = bot[x + 1], B4 = bot[x + 2];
-    const int lim = c_limlut[iabs(d - NEUTRAL) >> 2];
-    const int avg = (T2 + B2 + 1) >> 1;
-    const bool always_a = d == PEAK;
-    const bool right = iabs(d - dr) > lim;
-    int valB = avg, newB = NEUTRAL;
-    if (!always_a)
-    {
-        bool done = false;
-        if (lim < 9)
-        {
-            const int t0 = T1, t1 = T2, t2 = T3, b0 = B1, b1 = B2, b2 = B3;
-            const int sum = t0 + t1 + t2 + b0 + b1 + b2;
-            const int sumsq = t0 * t0 + t1 * t1 + t2 * t2 + b0 * b0 + b1 * b1 + b2 * b2;
-            if (6 * sumsq - sum * sum < 576) { valB = avg; newB = PEAK; done = true; }
-        }
-        if (!done && x > 1 && x < width - 2)
-        {
-            const int t = T2, b = B2;
-            const int tl = max(T0, T1), tr = max(T4, T3);
-            const int bl = max(B0, B1), br = max(B4, B3);
-            const int tl2 = min(T0, T1), tr2 = min(T4, T3);
-            const int bl2 = min(B0, B1), br2 = min(B4, B3);
-            if ((t < tl - 3 && t < tr - 3 && b < bl - 3 && b < br - 3) ||
-                (t > tl2 + 3 && t > tr2 + 3 && b > bl2 + 3 && b > br2 + 3))
-            { valB = avg; newB = NEUTRAL; done = true; }
-        }
-        if (!done)
-        {
-            int dir = (d - NEUTRAL + 2) >> 2;
-            int val = avg;
-            const int startu = (dir - 2 < 0) ? max(-x + 1, max(dir - 2, -width + 2 + x)) : min(x - 1, min(dir - 2, width - 2 - x));
-            const int stopu = (dir + 2 < 0) ? max(-x + 1, max(dir + 2, -width + 2 + x)) : min(x - 1, min(dir + 2, width - 2 - x));
-            int mn = nt8;
-#define NEAR(row, i) ((row)[i] != PEAK && iabs((int)(row)[i] - d) <= lim)
-            for (int u = startu; u <= stopu; u++)
-            {
-                const int diff = sad3(top, x, bot, x - u) + sad3(bot, x, top, x + u);
-                if (!(diff < mn && (NEAR(ot, x - 1 + u) || NEAR(ot, x + u) || NEAR(ot, x + 1 + u)) &&
-                      (NEAR(ob, x - 1 - u) || NEAR(ob, x - u) || NEAR(ob, x + 1 - u))))
-                    continue;
-                const int h0 = u >> 1, h1 = (u + 1) >> 1;
-                const int diff2 = sad3(top, x + h0, bot, x - h0);
-                const int o0 = ot[x + h0], o1 = ot[x + h1], q0 = ob[x - h0], q1 = ob[x - h1];
-                if (!(diff2 < nt4 && (((iabs(o0 - q0) <= lim || iabs(o0 - q1) <= lim) && o0 != PEAK) ||
-                                      ((iabs(o1 - q0) <= lim || iabs(o1 - q1) <= lim) && o1 != PEAK))))
-                    continue;
-                if ((iabs(d - o0) <= lim || iabs(d - o1) <= lim) && (iabs(d - q0) <= lim || iabs(d - q1) <= lim))
-                {
-                    val = ((int)top[x + h0] + (int)top[x + h1] + (int)bot[x - h0] + (int)bot[x - h1] + 2) >> 2;
-                    mn = diff;
-                    dir = u;
-                }
-            }
-#undef NEAR
-            if (mn != nt8)
-            {
-                valB = val;
-                newB = (NEUTRAL + dir * 4) & 0xff;
-            }
-            else
-            {
-                const int lo = min((int)top[x], (int)bot[x]), hi = max((int)top[x], (int)bot[x]);
-                const int dd = pl == 0 ? 4 : 2;
-                const int su = max(-x + 1, -dd), eu = min(width - 2 - x, dd);
-                mn = nt7;
-                for (int u = su; u <= eu; u++)
-                {
-                    const int h0 = u >> 1, h1 = (u + 1) >> 1;
-                    const int p1 = (int)top[x + h0] + (int)top[x + h1];
-                    const int p2 = (int)bot[x - h0] + (int)bot[x - h1];
-                    const int diff = sad3(top, x, bot, x - u) + sad3(bot, x, top, x + u) + iabs(p1 - p2);
-                    if (diff < mn)
-                    {
-                        const int valt = (p1 + p2 + 2) >> 2;
-                        if (valt >= lo && valt <= hi) { val = valt; mn = diff; dir = u; }
-                    }
-                }
-                valB = val;
-                newB = (mn == 7 * nt) ? NEUTRAL : ((NEUTRAL + dir * 4) & 0xff);
-            }
-        }
-    }
-    return (uint32_t)avg | ((uint32_t)valB << 8) | ((uint32_t)newB << 16) | ((uint32_t)always_a << 24) | ((uint32_t)right << 25);
-}
-
 // lattice_px cut at its two decision points, for k_lattice_cand_q: each stage either finishes the word or hands
 // the pixel to the next one.  `base` carries the bits every outcome shares (valA and the right-hand test).
 constexpr uint32_t LAT_MORE = 0x80000000u;
@@ -2246,43 +1366,8 @@ __device__ __forceinline__ uint32_t lattice_stage_c(const uint8_t *top, const ui
 // that depends on the value just written at x-1 (:1194) — with a 64-lane prefix composition
 // of 2-state maps, carrying the last written value from chunk to chunk, then writes the row.
 // a = dmsk (tmp2p, in/out), b = dst (dst2p, in/out), c = omsk (tmp2p2).
-constexpr int LC_W = 256, LC_HALO = 40, LC_LW = LC_W + 2 * LC_HALO;   // |u| <= 34, +-1 for the triples, rounded to dwords
+constexpr int LC_HALO = 40;   // |u| <= 34, +-1 for the triples, rounded to dwords
 
-__global__ __launch_bounds__(LC_W) void k_lattice_cand(P3 P, uint32_t *__restrict__ cand, int cand_pitch,
-                                                        int cand_plane_stride, int field, int nt4, int nt7, int nt8, int nt)
-{
-    // One workgroup = 256 consecutive pixels of one rebuilt row.  The five rows the search reads
-    // (dst y-1 / y+1, old direction map y-1 / y+1, new direction map y) are staged in LDS with the
-    // same flat addressing, so every data-dependent byte read below is an LDS read.
-    __shared__ __attribute__((aligned(16))) uint8_t s_rows[5][LC_LW];
-    const int pl = blockIdx.z;
-    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
-    const int x0 = blockIdx.x * LC_W;
-    const int x = x0 + threadIdx.x;
-    const int ri = blockIdx.y;
-    const int nrows = (height - (2 - field)) / 2;
-    if (x0 >= width || ri >= nrows) return;
-    const int y = (2 - field) + 2 * ri;
-    {
-        const uint8_t *g[5] = { P.b[pl] + (size_t)(y - 1) * pitch, P.b[pl] + (size_t)(y + 1) * pitch,
-                                P.c[pl] + (size_t)(y - 1) * pitch, P.c[pl] + (size_t)(y + 1) * pitch,
-                                P.a[pl] + (size_t)y * pitch };
-        for (int i = threadIdx.x; i < 5 * (LC_LW / 4); i += LC_W)
-        {
-            const int r = i / (LC_LW / 4), c4 = i - r * (LC_LW / 4);
-            reinterpret_cast<uint32_t *>(s_rows[r])[c4] =
-                reinterpret_cast<const uint32_t *>(g[r] + x0 - LC_HALO)[c4];
-        }
-    }
-    __syncthreads();
-    if (x >= width) return;
-    // row pointers indexed by the absolute column, as in the reference
-    const uint8_t *top = s_rows[0] + LC_HALO - x0, *bot = s_rows[1] + LC_HALO - x0;
-    const uint8_t *ot = s_rows[2] + LC_HALO - x0, *ob = s_rows[3] + LC_HALO - x0;
-    const uint8_t *dm = s_rows[4] + LC_HALO - x0;
-
-    cand[(size_t)pl * cand_plane_stride + (size_t)ri * cand_pitch + x] = lattice_px(top, bot, ot, ob, dm, x, width, pl, nt4, nt7, nt8, nt);
-}
 
 // k_lattice_cand with the searching pixels queued.  Only pixels that carry a direction (d != peak) go
 // through the variance / edge tests and the two searches - on real pictures roughly one in ten, but
@@ -2292,13 +1377,15 @@ __global__ __launch_bounds__(LC_W) void k_lattice_cand(P3 P, uint32_t *__restric
 constexpr int LQ_W = 1024, LQ_LW = LQ_W + 2 * LC_HALO;
 
 __global__ __launch_bounds__(256) void k_lattice_cand_q(P3 P, uint32_t *__restrict__ cand, int cand_pitch,
-                                                        int cand_plane_stride, int field, int nt4, int nt7, int nt8, int nt)
+                                                        int cand_plane_stride, int nt4, int nt7, int nt8, int nt)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_rows[5][LQ_LW];
     __shared__ __attribute__((aligned(16))) uint32_t s_cand[LQ_W];
     __shared__ uint16_t s_list[3][LQ_W];                          // one queue per stage
     __shared__ int s_count[3];
-    const int pl = blockIdx.z;
+    FIELD_PLANE(P);
+    const int field = tff;
+    cand += (size_t)fld * (P.fstride / sizeof(uint32_t));          // the candidates live in the field's slab too
     const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
     const int x0 = blockIdx.x * LQ_W, t = threadIdx.x;
     const int ri = blockIdx.y;
@@ -2307,9 +1394,9 @@ __global__ __launch_bounds__(256) void k_lattice_cand_q(P3 P, uint32_t *__restri
     const int y = (2 - field) + 2 * ri;
     if (t < 3) s_count[t] = 0;
     {
-        const uint8_t *g[5] = { P.b[pl] + (size_t)(y - 1) * pitch, P.b[pl] + (size_t)(y + 1) * pitch,
-                                P.c[pl] + (size_t)(y - 1) * pitch, P.c[pl] + (size_t)(y + 1) * pitch,
-                                P.a[pl] + (size_t)y * pitch };
+        const uint8_t *g[5] = { Q.b + (size_t)(y - 1) * pitch, Q.b + (size_t)(y + 1) * pitch,
+                                Q.c + (size_t)(y - 1) * pitch, Q.c + (size_t)(y + 1) * pitch,
+                                Q.a + (size_t)y * pitch };
         // only as far right as the row's pixels (+ halo) reach
         const int need4 = (min(LQ_W, hbhip_align_up_dev(width - x0, 4)) + 2 * LC_HALO) / 4;
         for (int r = 0; r < 5; r++)
@@ -2390,16 +1477,18 @@ __global__ __launch_bounds__(256) void k_lattice_cand_q(P3 P, uint32_t *__restri
 constexpr int LR_T = 1024;
 
 __global__ __launch_bounds__(LR_T) void k_lattice_resolve(P3 P, const uint32_t *__restrict__ cand, int cand_pitch,
-                                                          int cand_plane_stride, int field)
+                                                          int cand_plane_stride)
 {
     __shared__ uint8_t s_wmap[LR_T / 64];        // composed map of each wave
     __shared__ uint8_t s_win[LR_T / 64];         // resolved state entering each wave
     __shared__ int s_carry;                      // outcome of the last pixel of the previous pass
-    const int pl = blockIdx.z;
+    FIELD_PLANE(P);
+    const int field = tff;
+    cand += (size_t)fld * (P.fstride / sizeof(uint32_t));
     const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int nrows = (height - (2 - field)) / 2;                // rows y0, y0+2, ... < height-1
-    uint8_t *dst = P.b[pl];
+    uint8_t *dst = Q.b;
     if ((int)blockIdx.y >= nrows)
     {
         if ((int)blockIdx.y == nrows)                              // the one-row blit (:1162-1179)
@@ -2412,7 +1501,7 @@ __global__ __launch_bounds__(LR_T) void k_lattice_resolve(P3 P, const uint32_t *
     }
     const int y = (2 - field) + 2 * blockIdx.y;
     uint8_t *mid = dst + (size_t)y * pitch;
-    uint8_t *dm = P.a[pl] + (size_t)y * pitch;
+    uint8_t *dm = Q.a + (size_t)y * pitch;
     const uint32_t *cr = cand + (size_t)pl * cand_plane_stride + (size_t)blockIdx.y * cand_pitch;
     // value standing at dm[x-1] for x == 0: memory just before the row, never written by this pass
     const int before_row = dm[-1];
@@ -2488,13 +1577,14 @@ __global__ __launch_bounds__(LR_T) void k_lattice_resolve(P3 P, const uint32_t *
 }
 
 // a = nmsk, b = omsk, c = dst (in place, row y from rows y+-1), 4 pixels per thread
-__global__ void k_post(P3 P, int y0)
+__global__ void k_post(P3 P)
 {
     XY4_PLANE(P);
+    const int y0 = 2 - tff;
     if (x >= width || y >= height - 1 || y < y0 || ((y - y0) & 1)) return;
     const size_t at = (size_t)y * pitch + x;
-    const uint32_t nm4 = *reinterpret_cast<const uint32_t *>(P.a[pl] + at), om4 = *reinterpret_cast<const uint32_t *>(P.b[pl] + at);
-    uint8_t *d = P.c[pl] + at;
+    const uint32_t nm4 = *reinterpret_cast<const uint32_t *>(Q.a + at), om4 = *reinterpret_cast<const uint32_t *>(Q.b + at);
+    uint8_t *d = Q.c + at;
     const uint32_t up4 = *reinterpret_cast<const uint32_t *>(d - pitch), dn4 = *reinterpret_cast<const uint32_t *>(d + pitch);
     const uint32_t cur4 = *reinterpret_cast<const uint32_t *>(d);
     int out[4];
@@ -2626,28 +1716,21 @@ __global__ void k_post_corner(CornerArgs A, const uint8_t *msk, uint8_t *dst, in
 } // namespace
 
 // ------------------------------------------------------------------- engine
-Eedi2Engine::Eedi2Engine(hbhip_ctx *ctx, const PicGeometry &geo, const Eedi2Params &p, hbhip_ctx *main, EediMaskShare *share,
-                         int ring_index)
+// Fields are queued (add_field) and run together (launch): the edge mask is the only thing one field's run takes from
+// the previous one (the lower half of MSKPF keeps the previous run's mask, eedi2_template.c:132), so the mask kernels
+// form a chain and every pass behind them takes all queued fields in one launch (blockIdx.z = 3 * field + plane).
+// Each field has a slot: its nine scratch frames and its lattice candidates in one slab, slot_bytes_ apart.
+Eedi2Engine::Eedi2Engine(hbhip_ctx *ctx, const PicGeometry &geo, const Eedi2Params &p, int capacity)
     : ctx_(ctx), geo_(geo), par_(p)
 {
-    use_graph_ = getenv("HBHIP_NO_GRAPH") == nullptr;
-    main_ = main ? main : ctx;
-    share_ = share ? share : &own_share_;
-    ring_index_ = share ? ring_index : -1;
+    cap_ = std::min(std::max(capacity, 1), EEDI_MAX_FIELDS);
 }
 
 Eedi2Engine::~Eedi2Engine()
 {
-    for (auto &gg : graph_) for (auto &g : gg) if (g) (void)hipGraphExecDestroy(g);
-    if (cap_ctx_) hbhip_ctx_destroy(cap_ctx_);
-    if (own_share_.mask[1].alloc) (void)hipFree(own_share_.mask[1].alloc);
-    if (own_share_.ev_mask) (void)hipEventDestroy(own_share_.ev_mask);
-    if (ev_done_) (void)hipEventDestroy(ev_done_);
-    for (auto &f : half_) if (f.alloc) (void)hipFree(f.alloc);
-    for (auto &f : full_) if (f.alloc) (void)hipFree(f.alloc);
+    if (slab_) (void)hipFree(slab_);
     if (work_list_) (void)hipFree(work_list_);
     if (work_count_) (void)hipFree(work_count_);
-    if (cand_) (void)hipFree(cand_);
     for (int i = 0; i < 3; i++)
     {
         if (deriv_[i]) (void)hipFree(deriv_[i]);
@@ -2655,23 +1738,20 @@ Eedi2Engine::~Eedi2Engine()
     }
 }
 
-int Eedi2Engine::alloc_frame(EediFrame &f, int width, int height)
+// lays a frame out at `at` bytes into a slot (planes as hb_frame_buffer_init places them); returns the end
+size_t Eedi2Engine::place_frame(EediFrame &f, int width, int height, size_t at)
 {
-    size_t off[3], total = 0;
+    size_t total = 0;
     for (int c = 0; c < 3; c++)
     {
         f.width[c] = c ? -((-width) >> geo_.log2_cw) : width;
         f.height[c] = c ? -((-height) >> geo_.log2_ch) : height;
         f.stride[c] = hbhip_align_up(f.width[c], 64);          // hb_image_stride
-        off[c] = total;
+        f.plane[c] = reinterpret_cast<uint8_t *>(at + total);  // offset for now, init() adds the slab's address
         total += (size_t)f.stride[c] * f.height[c];
     }
-    f.bytes = total + 2 * GUARD;
-    HBHIP_CHECK(ctx_, hipMalloc((void **)&f.alloc, f.bytes));
-    HBHIP_CHECK(ctx_, hipMemsetAsync(f.alloc, 0, f.bytes, ctx_->stream));
-    f.base = f.alloc + GUARD;
-    for (int c = 0; c < 3; c++) f.plane[c] = f.base + off[c];
-    return HBHIP_OK;
+    f.bytes = total;
+    return at + total;
 }
 
 int Eedi2Engine::init()
@@ -2681,35 +1761,33 @@ int Eedi2Engine::init()
     if (geo_.height % (2 << geo_.log2_ch) != 0 || geo_.height < 16 || geo_.width < 16)
         return HBHIP_ERR_UNSUPPORTED;
     if (par_.post_processing < 0 || par_.post_processing > 3) return HBHIP_ERR_UNSUPPORTED;
-    for (auto &f : half_)
-    {
-        int rc = alloc_frame(f, geo_.width, geo_.height / 2);      // decomb.c:291-296
-        if (rc != HBHIP_OK) return rc;
-    }
-    for (auto &f : full_)
-    {
-        int rc = alloc_frame(f, geo_.width, geo_.height);          // decomb.c:299-303
-        if (rc != HBHIP_OK) return rc;
-    }
-    if (share_ == &own_share_)
-    {
-        own_share_.mask[0] = half_[1];                             // same memory as MSKPF (not owned twice)
-        int rc = alloc_frame(own_share_.mask[1], geo_.width, geo_.height / 2);
-        if (rc != HBHIP_OK) return rc;
-        own_share_.sel = 0;
-        HBHIP_CHECK(ctx_, hipEventCreateWithFlags(&own_share_.ev_mask, hipEventDisableTiming));
-    }
-    if (ring_index_ >= 0) share_->mask[ring_index_] = half_[1];   // this engine's MSKPF is its buffer of the ring
-    if (main_ != ctx_) HBHIP_CHECK(ctx_, hipEventCreateWithFlags(&ev_done_, hipEventDisableTiming));
-    // work list of calc_directions (every half-height pixel could qualify) + lattice candidates
-    size_t half_px = 0;
-    for (int c = 0; c < 3; c++) half_px += (size_t)half_[0].stride[c] * half_[0].height[c];
-    HBHIP_CHECK(ctx_, hipMalloc((void **)&work_list_, sizeof(uint32_t) * half_px));
-    HBHIP_CHECK(ctx_, hipMalloc((void **)&work_count_, sizeof(int)));
+    if (geo_.width >= (1 << 14) || geo_.height >= (1 << 14)) return HBHIP_ERR_UNSUPPORTED;
+    // one slot: GUARD, then the frames with a GUARD behind each (zeroed once, never written: the passes' reads outside
+    // rows and planes land there), then the candidates
+    size_t at = GUARD;
+    for (auto &f : half_) at = place_frame(f, geo_.width, geo_.height / 2, at) + GUARD;     // decomb.c:291-296
+    for (auto &f : full_) at = place_frame(f, geo_.width, geo_.height, at) + GUARD;         // decomb.c:299-303
     cand_pitch_ = full_[0].stride[0];
     cand_plane_stride_ = cand_pitch_ * ((full_[0].height[0] + 1) / 2);
-    HBHIP_CHECK(ctx_, hipMalloc((void **)&cand_, sizeof(uint32_t) * (size_t)cand_plane_stride_ * 3));
-    if (geo_.width >= (1 << 14) || geo_.height >= (1 << 14)) return HBHIP_ERR_UNSUPPORTED;
+    auto up256 = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t cand_at = up256(at);
+    slot_bytes_ = up256(cand_at + sizeof(uint32_t) * (size_t)cand_plane_stride_ * 3);
+    // one slot more than a batch holds, so that a batch never writes the slot whose mask its first field reads
+    const size_t total = slot_bytes_ * (size_t)(cap_ + 1);
+    HBHIP_CHECK(ctx_, hipMalloc((void **)&slab_, total));
+    HBHIP_CHECK(ctx_, hipMemsetAsync(slab_, 0, total, ctx_->stream));
+    for (auto &f : half_) for (int c = 0; c < 3; c++) f.plane[c] = slab_ + (size_t)(uintptr_t)f.plane[c];
+    for (auto &f : full_) for (int c = 0; c < 3; c++) f.plane[c] = slab_ + (size_t)(uintptr_t)f.plane[c];
+    cand_ = reinterpret_cast<uint32_t *>(slab_ + cand_at);
+    last_slot_ = cap_;                                             // "the previous mask" of the first run: zeros, like the reference's
+    if (par_.maximum_search_distance > CD_HALO - 2)
+    {
+        // work list of the calc_directions fallback (every half-height pixel could qualify)
+        size_t half_px = 0;
+        for (int c = 0; c < 3; c++) half_px += (size_t)half_[0].stride[c] * half_[0].height[c];
+        HBHIP_CHECK(ctx_, hipMalloc((void **)&work_list_, sizeof(uint32_t) * half_px));
+        HBHIP_CHECK(ctx_, hipMalloc((void **)&work_count_, sizeof(int)));
+    }
     if (par_.post_processing > 1)
     {
         // cx2, cy2, cxy: height * stride(luma) ints each, shared by the planes (decomb.c:398-403);
@@ -2728,156 +1806,97 @@ int Eedi2Engine::init()
     return HBHIP_OK;
 }
 
-int Eedi2Engine::run(const DevPicture *cur, int tff, hipEvent_t wait_for)
+EediFrame Eedi2Engine::at_slot(const EediFrame &f, int slot) const
 {
-    EediFrame &srcp = half_[0], &dst2p = full_[0];
-    P3 P;
-    memset(&P, 0, sizeof(P));
-    if (wait_for) HBHIP_CHECK(ctx_, hipStreamWaitEvent(ctx_->stream, wait_for, 0));
+    EediFrame r = f;
+    for (int c = 0; c < 3; c++) r.plane[c] = f.plane[c] + (size_t)slot * slot_bytes_;
+    return r;
+}
 
-    // field extraction (decomb_template.c:455-473)
+// eedi2_planer (decomb_template.c:455-473) for one more field of `cur`; the run itself happens in launch()
+int Eedi2Engine::add_field(const DevPicture *cur, int tff)
+{
+    if (n_ >= cap_) return -1;
     for (int c = 0; c < 3; c++)
-    {
-        P.pitch[c] = srcp.stride[c]; P.width[c] = srcp.width[c]; P.height[c] = srcp.height[c];
-        P.a[c] = cur->plane[c];
-        P.b[c] = srcp.plane[c];
-    }
-    // (a launch of its own only for the byte-per-thread A/B form or a frame whose rows are not dword aligned; otherwise
-    // the mask kernel reads the field rows from the frame and writes SRCPF, see k_mask_fused4<true>)
-    static const bool one_px_fill = getenv("HBHIP_EEDI2_1PX") != nullptr;
-    bool from_frame = !one_px_fill;
-    for (int c = 0; c < 3; c++) from_frame &= (cur->pitch[c] & 3) == 0 && ((uintptr_t)cur->plane[c] & 3) == 0;
-    if (!from_frame)
-    {
-        int rows[3];
-        for (int c = 0; c < 3; c++) rows[c] = (dst2p.height[c] + 1) / 2;
-        HBHIP_LAUNCH(ctx_, "eedi2_fill_half", k_fill_half4,
-                     dim3((srcp.stride[0] + 255) / 256, (srcp.height[0] + 3) / 4, 3), dim3(64, 4), 0, P,
-                     cur->pitch[0], cur->pitch[1], cur->pitch[2], !tff, rows[0], rows[1], rows[2]);
-    }
-    HBHIP_CHECK(ctx_, hipGetLastError());
-
-    // The mask passes read the previous run's mask (possibly made on the other engine's stream) and
-    // write the other buffer; an event behind them lets the next run's mask passes start while the
-    // rest of this run is still going.
-    const int old = share_->sel;
-    const int sel = ring_index_ >= 0 ? ring_index_ : (old ^ 1);     // the new mask goes to another buffer
-    share_->sel = sel;
-    if (share_->ev_valid) HBHIP_CHECK(ctx_, hipStreamWaitEvent(ctx_->stream, share_->ev_mask, 0));
-    {
-        const int rc = enqueue_mask(sel, old, from_frame ? cur : nullptr, !tff);
-        if (rc != HBHIP_OK) return rc;
-    }
-    HBHIP_CHECK(ctx_, hipEventRecord(share_->ev_mask, ctx_->stream));
-    share_->ev_valid = true;
-
-    // Everything after the mask only touches this engine's own scratch frames, so the ~20 launches
-    // of a field are identical from frame to frame (per field parity and mask buffer): they are
-    // captured once into a hipGraph and replayed, which removes the per-launch submission gaps.
-    // The per-kernel profiler needs individual launches, so it bypasses the graph.
-    int rc = HBHIP_OK;
-    if (ctx_->profile || !use_graph_) rc = enqueue_passes(tff, sel, ctx_);
-    else
-    {
-        hipGraphExec_t &exec = graph_[tff ? 1 : 0][ring_index_ >= 0 ? 0 : sel];
-        if (!exec)
-        {
-            hipGraph_t g = nullptr;
-            if (!cap_ctx_ && hbhip_ctx_create(ctx_->device, &cap_ctx_) != HBHIP_OK) cap_ctx_ = nullptr;
-            if (!cap_ctx_) { use_graph_ = false; return enqueue_passes(tff, sel, ctx_); }
-            HBHIP_CHECK(ctx_, hipStreamBeginCapture(cap_ctx_->stream, hipStreamCaptureModeThreadLocal));
-            const int crc = enqueue_passes(tff, sel, cap_ctx_);
-            const hipError_t e = hipStreamEndCapture(cap_ctx_->stream, &g);
-            hipError_t ie = hipErrorUnknown;
-            if (crc == HBHIP_OK && e == hipSuccess && g) ie = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
-            if (g) (void)hipGraphDestroy(g);
-            if (ie != hipSuccess)
-            {
-                exec = nullptr;
-                use_graph_ = false;                  // fall back to plain launches for good
-                (void)hipGetLastError();
-            }
-        }
-        if (exec) HBHIP_CHECK(ctx_, hipGraphLaunch(exec, ctx_->stream));
-        else      rc = enqueue_passes(tff, sel, ctx_);
-    }
-    if (rc != HBHIP_OK) return rc;
-    if (ev_done_) HBHIP_CHECK(ctx_, hipEventRecord(ev_done_, ctx_->stream));
-    return HBHIP_OK;
+        if ((cur->pitch[c] & 3) != 0 || ((uintptr_t)cur->plane[c] & 3) != 0) return -1;   // device pictures are 256-byte aligned
+    if (n_ == 0) { start_ = last_slot_ == 0 ? 1 : 0; tffbits_ = 0; }
+    for (int c = 0; c < 3; c++) { src_frame_[n_][c] = cur->plane[c]; src_pitch_[c] = cur->pitch[c]; }
+    if (tff) tffbits_ |= 1u << n_;
+    return start_ + n_++;
 }
 
-int Eedi2Engine::mark_done()
+int Eedi2Engine::launch(hbhip_ctx *lc)
 {
-    if (ev_done_) HBHIP_CHECK(ctx_, hipEventRecord(ev_done_, ctx_->stream));
-    return HBHIP_OK;
+    if (n_ == 0) return HBHIP_OK;
+    const int n = n_;
+    n_ = 0;
+    int rc = enqueue_mask(n, lc);
+    if (rc == HBHIP_OK) rc = enqueue_passes(n, lc);
+    last_slot_ = start_ + n - 1;
+    return rc;
 }
 
-int Eedi2Engine::join()
+// the five mask passes (+ the field extraction) of the n queued fields: old mask -> new mask
+int Eedi2Engine::enqueue_mask(int n, hbhip_ctx *lc)
 {
-    if (ev_done_) HBHIP_CHECK(main_, hipStreamWaitEvent(main_->stream, ev_done_, 0));
-    return HBHIP_OK;
-}
-
-// The pass sequence of eedi2_interpolate_plane (decomb_template.c:366-441) for the 3 planes, from
-// the edge mask to the post-processing, on the engine's scratch frames.
-int Eedi2Engine::enqueue_mask(int sel, int old, const DevPicture *frame, int start_line)
-{
-    // frame != nullptr: the kernel extracts the field itself (rows start_line, start_line + 2, ... of `frame`)
-    EediFrame &srcp = half_[0], &mskp = share_->mask[sel], &mskp_old = share_->mask[old];
+    const EediFrame srcp = at_slot(half_[0], start_), mskp = at_slot(half_[1], start_), mskp_old = at_slot(half_[1], last_slot_);
     P3 P;
     memset(&P, 0, sizeof(P));
-    MaskSrc S = {{0, 0, 0}, start_line};
+    MaskSrc S;
+    memset(&S, 0, sizeof(S));
     for (int c = 0; c < 3; c++)
     {
         P.pitch[c] = srcp.stride[c]; P.width[c] = srcp.width[c]; P.height[c] = srcp.height[c];
         P.a[c] = srcp.plane[c]; P.b[c] = mskp_old.plane[c]; P.c[c] = mskp.plane[c];
-        if (frame) { P.d[c] = frame->plane[c]; S.spitch[c] = frame->pitch[c]; }
+        S.spitch[c] = src_pitch_[c];
     }
-    // edge mask, erode, dilate, erode, remove_small_gaps in one launch (old mask -> new mask)
-    static const bool one_px = getenv("HBHIP_EEDI2_1PX") != nullptr;                   // A/B switch: the byte-per-thread form
-    const dim3 grid((srcp.width[0] + MF_W - 1) / MF_W, (srcp.height[0] + MF_H - 1) / MF_H, 3);
-    if (one_px)
-        HBHIP_LAUNCH(ctx_, "eedi2_mask_passes", k_mask_fused, grid, dim3(256), 0, P,
-                     par_.magnitude_threshold * 10, par_.laplacian_threshold * 81, par_.variance_threshold,
-                     par_.erosion_threshold, par_.dilation_threshold);
-    else if (frame)
-        HBHIP_LAUNCH(ctx_, "eedi2_mask_passes", k_mask_fused4<true>, grid, dim3(256), 0, P, S,
-                     par_.magnitude_threshold * 10, par_.laplacian_threshold * 81, par_.variance_threshold,
+    for (int f = 0; f < n; f++) for (int c = 0; c < 3; c++) S.frame[f][c] = src_frame_[f][c];
+    P.fstride = slot_bytes_;
+    P.tffbits = tffbits_;
+    const int mth = par_.magnitude_threshold * 10, vth = par_.laplacian_threshold * 81, lth = par_.variance_threshold;   // sic: swapped (decomb_template.c:390)
+    const unsigned gx = (srcp.width[0] + MF_W - 1) / MF_W, gy = (srcp.height[0] + MF_H - 1) / MF_H;
+    if (n == 1)
+        HBHIP_LAUNCH(lc, "eedi2_mask_passes", k_mask_fused4, dim3(gx, gy, 3), dim3(256), 0, P, S, 0, 0, mth, vth, lth,
                      par_.erosion_threshold, par_.dilation_threshold);
     else
-        HBHIP_LAUNCH(ctx_, "eedi2_mask_passes", k_mask_fused4<false>, grid, dim3(256), 0, P, S,
-                     par_.magnitude_threshold * 10, par_.laplacian_threshold * 81, par_.variance_threshold,
+    {
+        // the tiles no earlier field can influence: all fields at once (tile rows below the middle return at once)
+        const unsigned gy_up = std::max(1, (srcp.height[0] / 2 - MF_OY) / MF_H);
+        HBHIP_LAUNCH(lc, "eedi2_mask_upper", k_mask_fused4, dim3(gx, gy_up, 3 * n), dim3(256), 0, P, S, 0, 1, mth, vth, lth,
                      par_.erosion_threshold, par_.dilation_threshold);
-    HBHIP_CHECK(ctx_, hipGetLastError());
+        for (int f = 0; f < n; f++)
+            HBHIP_LAUNCH(lc, "eedi2_mask_passes", k_mask_fused4, dim3(gx, gy, 3), dim3(256), 0, P, S, f, 2, mth, vth, lth,
+                         par_.erosion_threshold, par_.dilation_threshold);
+    }
+    HBHIP_CHECK(lc, hipGetLastError());
     return HBHIP_OK;
 }
 
-int Eedi2Engine::enqueue_passes(int tff, int sel, hbhip_ctx *lc)
+// The pass sequence of eedi2_interpolate_plane (decomb_template.c:366-441) behind the mask passes, for the 3 planes of
+// the n queued fields, on their scratch frames.
+int Eedi2Engine::enqueue_passes(int n, hbhip_ctx *lc)
 {
-    // lc = the context whose stream the launches go to: the engine's own, or - while the sequence is being captured
-    // into a graph - a private one (another filter's thread may be launching into the shared stream at that moment,
-    // and whatever enters a capturing stream becomes part of the capture)
-    EediFrame &srcp = half_[0], &mskp = share_->mask[sel], &tmpp = half_[2], &dstp = half_[3];
-    EediFrame &dst2p = full_[0], &tmp2p2 = full_[1], &msk2p = full_[2], &tmp2p = full_[3], &dst2mp = full_[4];
+    const EediFrame srcp = at_slot(half_[0], start_), mskp = at_slot(half_[1], start_), tmpp = at_slot(half_[2], start_),
+                    dstp = at_slot(half_[3], start_);
+    const EediFrame dst2p = at_slot(full_[0], start_), tmp2p2 = at_slot(full_[1], start_), msk2p = at_slot(full_[2], start_),
+                    tmp2p = at_slot(full_[3], start_), dst2mp = at_slot(full_[4], start_);
+    uint32_t *cand = cand_ + (size_t)start_ * (slot_bytes_ / sizeof(uint32_t));
     const dim3 blk(64, 4);
+    const unsigned gz = 3u * (unsigned)n;
     auto grid_for = [&](const EediFrame &f, bool whole_pitch) {
         const int w = whole_pitch ? f.stride[0] : f.width[0];
-        return dim3((w + 63) / 64, (f.height[0] + 3) / 4, 3);
+        return dim3((w + 63) / 64, (f.height[0] + 3) / 4, gz);
     };
     auto grid4_for = [&](const EediFrame &f, bool whole_pitch) {        // kernels with 4 pixels per thread
         const int w = whole_pitch ? f.stride[0] : f.width[0];
-        return dim3((w + 255) / 256, (f.height[0] + 3) / 4, 3);
+        return dim3((w + 255) / 256, (f.height[0] + 3) / 4, gz);
     };
-    static const bool one_px = getenv("HBHIP_EEDI2_1PX") != nullptr;                   // A/B switch: the one-pixel-per-thread forms
     bool post_folded = false;
-    auto dir_map = [&](const char *name, const EediFrame &f, const P3 &Pv, int step, int y0v, int expand, int post = 0) {
-        static const bool four_px = getenv("HBHIP_EEDI2_4PX") != nullptr;              // A/B switch: four pixels per thread, sort in place
-        static const bool filter_queue = getenv("HBHIP_EEDI2_FILTER_QUEUE") != nullptr;  // A/B switch: filter_dir_map through the queueing form too
-        if (one_px)       HBHIP_LAUNCH(lc, name, k_dir_map, grid_for(f, false), blk, 0, Pv, step, y0v, expand);
+    auto dir_map = [&](const char *name, const EediFrame &f, const P3 &Pv, int step, int expand, int post = 0) {
         // the queueing form pays where few pixels reach the sort (expand: only peak pixels with >= 5 usable neighbours);
         // filter_dir_map sorts at most masked pixels, there the in-place form is ahead
-        else if (four_px || (!expand && !filter_queue)) HBHIP_LAUNCH(lc, name, k_dir_map4, grid4_for(f, false), blk, 0, Pv, step, y0v, expand);
-        else            { HBHIP_LAUNCH(lc, name, k_dir_map_c, grid4_for(f, false), blk, 0, Pv, step, y0v, expand, post); post_folded = post != 0; }
+        if (!expand) HBHIP_LAUNCH(lc, name, k_dir_map4, grid4_for(f, false), blk, 0, Pv, step, expand);
+        else       { HBHIP_LAUNCH(lc, name, k_dir_map_c, grid4_for(f, false), blk, 0, Pv, step, expand, post); post_folded = post != 0; }
     };
     auto geom = [&](P3 &P, const EediFrame &f) {
         for (int c = 0; c < 3; c++) { P.pitch[c] = f.stride[c]; P.width[c] = f.width[c]; P.height[c] = f.height[c]; }
@@ -2886,96 +1905,69 @@ int Eedi2Engine::enqueue_passes(int tff, int sel, hbhip_ctx *lc)
 
     P3 P;
     memset(&P, 0, sizeof(P));
+    P.fstride = slot_bytes_;
+    P.tffbits = tffbits_;
 
     // half-height passes
     geom(P, srcp);
     bind(P.a, mskp); bind(P.b, srcp); bind(P.c, tmpp);
+    const int nt13 = (par_.noise_threshold * 13) & 0xff, nt19 = (par_.noise_threshold * 19) & 0xff;      // typed `pixel` in the reference
     if (par_.maximum_search_distance <= CD_HALO - 2)
-    {
-        static const bool old_form = getenv("HBHIP_EEDI2_OLD_CALCDIR") != nullptr;     // A/B switch for profiling
-        static const bool tile3_form = getenv("HBHIP_EEDI2_CALCDIR_TILE3") != nullptr;  // A/B switch: one row per block, unsorted
-        static const int rows_per_block = getenv("HBHIP_EEDI2_CALCDIR_ROWS") ? atoi(getenv("HBHIP_EEDI2_CALCDIR_ROWS")) : 2;   // A/B: 2, 4 or 8 rows per block
-        if (old_form)
-            HBHIP_LAUNCH(lc, "eedi2_calc_directions", k_calc_dir_tile,
-                         dim3((srcp.stride[0] + CD_W - 1) / CD_W, srcp.height[0], 3), dim3(CD_W), 0, P,
-                         par_.maximum_search_distance, (par_.noise_threshold * 13) & 0xff, (par_.noise_threshold * 19) & 0xff);
-        else if (one_px || par_.maximum_search_distance > 31)
-            HBHIP_LAUNCH(lc, "eedi2_calc_directions", k_calc_dir_tile2,
-                         dim3((srcp.stride[0] + CD_W - 1) / CD_W, srcp.height[0], 3), dim3(CD_W), 0, P,
-                         par_.maximum_search_distance, (par_.noise_threshold * 13) & 0xff, (par_.noise_threshold * 19) & 0xff);
-        else if (tile3_form)
-            HBHIP_LAUNCH(lc, "eedi2_calc_directions", k_calc_dir_tile3,
-                         dim3((srcp.stride[0] + CD_W - 1) / CD_W, srcp.height[0], 3), dim3(CD_W), 0, P,
-                         par_.maximum_search_distance, (par_.noise_threshold * 13) & 0xff, (par_.noise_threshold * 19) & 0xff);
         // rows per block, measured (kernel alone / decomb bob throughput): 2: 44 us / 5.72 k fps, 4: 53 / 5.62 k, 8: 69 / 5.82 k
-        // (the more rows, the fewer instructions - and the fewer, longer workgroups to balance over the CUs);
-        // k_calc_dir_tile3: 54 us / 5.37 k fps
-        else if (rows_per_block == 2)
-            HBHIP_LAUNCH(lc, "eedi2_calc_directions", k_calc_dir_rows<2>,
-                         dim3((srcp.stride[0] + CD_W - 1) / CD_W, (srcp.height[0] + 1) / 2, 3), dim3(CD_W), 0, P,
-                         par_.maximum_search_distance, (par_.noise_threshold * 13) & 0xff, (par_.noise_threshold * 19) & 0xff);
-        else if (rows_per_block == 8)
-            HBHIP_LAUNCH(lc, "eedi2_calc_directions", k_calc_dir_rows<8>,
-                         dim3((srcp.stride[0] + CD_W - 1) / CD_W, (srcp.height[0] + 7) / 8, 3), dim3(CD_W), 0, P,
-                         par_.maximum_search_distance, (par_.noise_threshold * 13) & 0xff, (par_.noise_threshold * 19) & 0xff);
-        else if (rows_per_block == 4)
-            HBHIP_LAUNCH(lc, "eedi2_calc_directions", k_calc_dir_rows<4>,
-                         dim3((srcp.stride[0] + CD_W - 1) / CD_W, (srcp.height[0] + 3) / 4, 3), dim3(CD_W), 0, P,
-                         par_.maximum_search_distance, (par_.noise_threshold * 13) & 0xff, (par_.noise_threshold * 19) & 0xff);
-        else return HBHIP_ERR_ARG;
-    }
+        // (the more rows, the fewer instructions - and the fewer, longer workgroups to balance over the CUs)
+        HBHIP_LAUNCH(lc, "eedi2_calc_directions", k_calc_dir_rows<2>,
+                     dim3((srcp.stride[0] + CD_W - 1) / CD_W, (srcp.height[0] + 1) / 2, gz), dim3(CD_W), 0, P,
+                     par_.maximum_search_distance, nt13, nt19);
     else
     {
-        HBHIP_CHECK(lc, hipMemsetAsync(work_count_, 0, sizeof(int), lc->stream));
-        HBHIP_LAUNCH(lc, "eedi2_calc_directions_mark", k_calc_dir_mark, grid_for(srcp, true), blk, 0, P, work_list_, work_count_);
+        // search distances beyond the LDS halo: a work list of the edge pixels, field after field
         size_t half_px = 0;
         for (int c = 0; c < 3; c++) half_px += (size_t)srcp.width[c] * srcp.height[c];
-        HBHIP_LAUNCH(lc, "eedi2_calc_directions_work", k_calc_dir_work, dim3((unsigned)((half_px + 255) / 256)), dim3(256), 0, P,
-                     (const uint32_t *)work_list_, (const int *)work_count_, par_.maximum_search_distance,
-                     (par_.noise_threshold * 13) & 0xff, (par_.noise_threshold * 19) & 0xff);
+        P3 Q = P;
+        Q.fstride = 0;
+        for (int f = 0; f < n; f++)
+        {
+            for (int c = 0; c < 3; c++)
+            {
+                Q.a[c] = P.a[c] + (size_t)f * slot_bytes_; Q.b[c] = P.b[c] + (size_t)f * slot_bytes_; Q.c[c] = P.c[c] + (size_t)f * slot_bytes_;
+            }
+            HBHIP_CHECK(lc, hipMemsetAsync(work_count_, 0, sizeof(int), lc->stream));
+            HBHIP_LAUNCH(lc, "eedi2_calc_directions_mark", k_calc_dir_mark, dim3((srcp.stride[0] + 63) / 64, (srcp.height[0] + 3) / 4, 3), blk, 0,
+                         Q, work_list_, work_count_);
+            HBHIP_LAUNCH(lc, "eedi2_calc_directions_work", k_calc_dir_work, dim3((unsigned)((half_px + 255) / 256)), dim3(256), 0, Q,
+                         (const uint32_t *)work_list_, (const int *)work_count_, par_.maximum_search_distance, nt13, nt19);
+        }
     }
     bind(P.a, mskp); bind(P.b, tmpp); bind(P.c, dstp);
-    dir_map("eedi2_filter_dir_map", srcp, P, 1, 1, 0);
+    dir_map("eedi2_filter_dir_map", srcp, P, 1, 0);
     bind(P.a, mskp); bind(P.b, dstp); bind(P.c, tmpp);
-    dir_map("eedi2_expand_dir_map", srcp, P, 1, 1, 1);
+    dir_map("eedi2_expand_dir_map", srcp, P, 1, 1);
     bind(P.a, mskp); bind(P.b, tmpp); bind(P.c, dstp);
     HBHIP_LAUNCH(lc, "eedi2_filter_map", k_filter_map, grid_for(srcp, false), blk, 0, P);
     // line doubling of srcp / dstp / mskp + mark_directions_2x in one launch (full-height geometry)
     geom(P, dst2p);
-    const int y0 = 2 - tff;
     bind(P.g, srcp); bind(P.b, dstp); bind(P.a, mskp);
     bind(P.d, dst2p); bind(P.e, tmp2p2); bind(P.f, msk2p); bind(P.c, tmp2p);
-    if (one_px) HBHIP_LAUNCH(lc, "eedi2_mark_directions_2x", k_mark_2x, grid_for(dst2p, true), blk, 0, P, y0);
-    else        HBHIP_LAUNCH(lc, "eedi2_mark_directions_2x", k_mark_2x4, grid4_for(dst2p, true), blk, 0, P, y0);
-    for (int c = 0; c < 3; c++) P.d[c] = P.e[c] = P.f[c] = P.g[c] = nullptr;    // slot d doubles as k_dir_map's optional copy target
+    HBHIP_LAUNCH(lc, "eedi2_mark_directions_2x", k_mark_2x4, grid4_for(dst2p, true), blk, 0, P);
+    for (int c = 0; c < 3; c++) P.d[c] = P.e[c] = P.f[c] = P.g[c] = nullptr;    // slot d doubles as the dir-map kernels' optional copy target
     bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
-    dir_map("eedi2_filter_dir_map_2x", dst2p, P, 2, y0, 0);
+    dir_map("eedi2_filter_dir_map_2x", dst2p, P, 2, 0);
     bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
-    dir_map("eedi2_expand_dir_map_2x", dst2p, P, 2, y0, 1);
-    auto fill_gaps = [&](const P3 &Pv) {
-        if (one_px) HBHIP_LAUNCH(lc, "eedi2_fill_gaps_2x", k_fill_gaps, grid_for(dst2p, false), blk, 0, Pv, y0);
-        else if (getenv("HBHIP_EEDI2_FILLGAPS_WALK"))                                   // A/B switch: the byte walks
-            HBHIP_LAUNCH(lc, "eedi2_fill_gaps_2x", k_fill_gaps_c, dim3((dst2p.width[0] + FG_W - 1) / FG_W, dst2p.height[0], 3), dim3(256), 0, Pv, y0);
-        else
-            HBHIP_LAUNCH(lc, "eedi2_fill_gaps_2x", k_fill_gaps_b, dim3((dst2p.width[0] + FG_W - 1) / FG_W, dst2p.height[0], 3), dim3(256), 0, Pv, y0);
-    };
+    dir_map("eedi2_expand_dir_map_2x", dst2p, P, 2, 1);
+    const dim3 fg_grid((dst2p.width[0] + FG_W - 1) / FG_W, dst2p.height[0], gz);
     bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
-    fill_gaps(P);
+    HBHIP_LAUNCH(lc, "eedi2_fill_gaps_2x", k_fill_gaps_b, fg_grid, dim3(256), 0, P);
     bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
-    fill_gaps(P);
+    HBHIP_LAUNCH(lc, "eedi2_fill_gaps_2x", k_fill_gaps_b, fg_grid, dim3(256), 0, P);
     // lattice
     bind(P.a, tmp2p); bind(P.b, dst2p); bind(P.c, tmp2p2);
     {
-        const int nrows = (dst2p.height[0] - y0) / 2;
+        const int nrows = (dst2p.height[0] - 1) / 2;      // rows y0, y0 + 2, ... < height - 1 for either parity (the heights are even)
         const int nt = par_.noise_threshold;
-        if (one_px)
-            HBHIP_LAUNCH(lc, "eedi2_lattice_candidates", k_lattice_cand, dim3((dst2p.width[0] + LC_W - 1) / LC_W, nrows, 3),
-                         dim3(LC_W), 0, P, cand_, cand_pitch_, cand_plane_stride_, tff, (nt * 4) & 0xff, (nt * 7) & 0xff, (nt * 8) & 0xff, nt);
-        else
-            HBHIP_LAUNCH(lc, "eedi2_lattice_candidates", k_lattice_cand_q, dim3((dst2p.width[0] + LQ_W - 1) / LQ_W, nrows, 3),
-                         dim3(256), 0, P, cand_, cand_pitch_, cand_plane_stride_, tff, (nt * 4) & 0xff, (nt * 7) & 0xff, (nt * 8) & 0xff, nt);
-        HBHIP_LAUNCH(lc, "eedi2_lattice_resolve", k_lattice_resolve, dim3(1, nrows + 1, 3), dim3(LR_T), 0, P,
-                     (const uint32_t *)cand_, cand_pitch_, cand_plane_stride_, tff);
+        HBHIP_LAUNCH(lc, "eedi2_lattice_candidates", k_lattice_cand_q, dim3((dst2p.width[0] + LQ_W - 1) / LQ_W, nrows, gz),
+                     dim3(256), 0, P, cand, cand_pitch_, cand_plane_stride_, (nt * 4) & 0xff, (nt * 7) & 0xff, (nt * 8) & 0xff, nt);
+        HBHIP_LAUNCH(lc, "eedi2_lattice_resolve", k_lattice_resolve, dim3(1, nrows + 1, gz), dim3(LR_T), 0, P,
+                     (const uint32_t *)cand, cand_pitch_, cand_plane_stride_);
     }
     if (par_.post_processing == 1 || par_.post_processing == 3)
     {
@@ -2983,33 +1975,39 @@ int Eedi2Engine::enqueue_passes(int tff, int sel, hbhip_ctx *lc)
         // (decomb_template.c:426); the filter that follows reads every byte of tmp2p the blit copies,
         // so it writes that copy itself (slot d) and the separate launch is saved
         bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp); bind(P.d, tmp2p2);
-        dir_map("eedi2_filter_dir_map_2x", dst2p, P, 2, y0, 0);
+        dir_map("eedi2_filter_dir_map_2x", dst2p, P, 2, 0);
         for (int c = 0; c < 3; c++) P.d[c] = nullptr;
         bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p); bind(P.e, tmp2p2); bind(P.f, dst2p);
-        dir_map("eedi2_expand_dir_map_2x", dst2p, P, 2, y0, 1, 1);                          // + post_process where the kernel can carry it
+        dir_map("eedi2_expand_dir_map_2x", dst2p, P, 2, 1, 1);                          // + post_process where the kernel can carry it
         for (int c = 0; c < 3; c++) P.e[c] = P.f[c] = nullptr;
         bind(P.a, tmp2p); bind(P.b, tmp2p2); bind(P.c, dst2p);
-        if (!post_folded) HBHIP_LAUNCH(lc, "eedi2_post_process", k_post, grid4_for(dst2p, false), blk, 0, P, y0);
+        if (!post_folded) HBHIP_LAUNCH(lc, "eedi2_post_process", k_post, grid4_for(dst2p, false), blk, 0, P);
     }
     if (par_.post_processing == 2 || par_.post_processing == 3)
     {
-        // junctions and corners, plane after plane (see CornerArgs)
-        for (int c = 0; c < 3; c++)
+        // junctions and corners, field after field and plane after plane (see CornerArgs: the derivative arrays carry
+        // values from plane to plane and from field to field)
+        for (int f = 0; f < n; f++)
         {
-            CornerArgs A;
-            A.src = srcp.plane[c]; A.tmp = tmpp.plane[c];
-            for (int i = 0; i < 3; i++) { A.c[i] = deriv_[i]; A.t[i] = deriv_tmp_[i]; }
-            A.pitch = srcp.stride[c]; A.width = srcp.width[c]; A.height = srcp.height[c];
-            const dim3 g1((A.width + 63) / 64, (A.height + 3) / 4, 1), g3(g1.x, g1.y, 3);
-            HBHIP_LAUNCH(lc, "eedi2_gaussian_blur1_h", k_blur1<false>, g1, blk, 0, A);
-            HBHIP_LAUNCH(lc, "eedi2_gaussian_blur1_v", k_blur1<true>, g1, blk, 0, A);
-            HBHIP_LAUNCH(lc, "eedi2_calc_derivatives", k_derivatives, g1, blk, 0, A);
-            HBHIP_LAUNCH(lc, "eedi2_gaussian_blur_sqrt2_h", k_blur_sqrt2<false>, g3, blk, 0, A);
-            HBHIP_LAUNCH(lc, "eedi2_gaussian_blur_sqrt2_v", k_blur_sqrt2<true>, g3, blk, 0, A);
-            const int rows = (dst2p.height[c] - 7 - (8 - tff) + 1) / 2;      // y = 8-field, 10-field, ... < height-7
-            if (rows > 0)
-                HBHIP_LAUNCH(lc, "eedi2_post_process_corner", k_post_corner, dim3((A.width + 63) / 64, (rows + 3) / 4, 1), blk, 0, A,
-                             (const uint8_t *)tmp2p2.plane[c], dst2p.plane[c], tff, dst2p.height[c]);
+            const int tff = (int)((tffbits_ >> f) & 1u);
+            const size_t foff = (size_t)f * slot_bytes_;
+            for (int c = 0; c < 3; c++)
+            {
+                CornerArgs A;
+                A.src = srcp.plane[c] + foff; A.tmp = tmpp.plane[c] + foff;
+                for (int i = 0; i < 3; i++) { A.c[i] = deriv_[i]; A.t[i] = deriv_tmp_[i]; }
+                A.pitch = srcp.stride[c]; A.width = srcp.width[c]; A.height = srcp.height[c];
+                const dim3 g1((A.width + 63) / 64, (A.height + 3) / 4, 1), g3(g1.x, g1.y, 3);
+                HBHIP_LAUNCH(lc, "eedi2_gaussian_blur1_h", k_blur1<false>, g1, blk, 0, A);
+                HBHIP_LAUNCH(lc, "eedi2_gaussian_blur1_v", k_blur1<true>, g1, blk, 0, A);
+                HBHIP_LAUNCH(lc, "eedi2_calc_derivatives", k_derivatives, g1, blk, 0, A);
+                HBHIP_LAUNCH(lc, "eedi2_gaussian_blur_sqrt2_h", k_blur_sqrt2<false>, g3, blk, 0, A);
+                HBHIP_LAUNCH(lc, "eedi2_gaussian_blur_sqrt2_v", k_blur_sqrt2<true>, g3, blk, 0, A);
+                const int rows = (dst2p.height[c] - 7 - (8 - tff) + 1) / 2;      // y = 8-field, 10-field, ... < height-7
+                if (rows > 0)
+                    HBHIP_LAUNCH(lc, "eedi2_post_process_corner", k_post_corner, dim3((A.width + 63) / 64, (rows + 3) / 4, 1), blk, 0, A,
+                                 (const uint8_t *)(tmp2p2.plane[c] + foff), dst2p.plane[c] + foff, tff, dst2p.height[c]);
+            }
         }
     }
     HBHIP_CHECK(lc, hipGetLastError());

@@ -18,7 +18,7 @@ struct Eedi2Params
 // the pixels — is part of its behaviour; `guard` zero bytes surround the frame.
 struct EediFrame
 {
-    uint8_t *alloc = nullptr;
+    uint8_t *alloc = nullptr;     // owner of the memory (16-bit engine; the 8-bit engine's frames live in its slab)
     uint8_t *base = nullptr;
     uint8_t *plane[3] = {nullptr, nullptr, nullptr};
     int      stride[3] = {0, 0, 0};
@@ -27,65 +27,48 @@ struct EediFrame
     size_t   bytes = 0;
 };
 
-// The edge mask is the one piece of EEDI2 state that runs depend on (the lower half of MSKPF keeps
-// the previous run's mask, eedi2_template.c:132).  When consecutive runs go to different engines
-// (different HIP streams), they all work on one set of mask buffers, in run order: a lone engine
-// alternates between two, an engine of a ring always writes its own (mask[i] = its MSKPF frame) and
-// reads the one the previous run wrote.
-constexpr int EEDI_MAX_RING = 8;
-struct EediMaskShare
-{
-    EediFrame  mask[EEDI_MAX_RING];
-    int        sel = 0;               // which one holds the current mask
-    hipEvent_t ev_mask = nullptr;     // recorded behind every mask kernel: the next run's mask kernel waits for it
-    bool       ev_valid = false;
-};
-
+// EEDI2 on 8-bit samples (eedi2.hip).  Fields are queued with add_field() and run by launch(): the mask passes field
+// after field (the edge mask is the one piece of state a run takes from the one before it: the lower half of MSKPF
+// keeps the previous run's mask, eedi2_template.c:132), every pass behind them once for all queued fields.  A field's
+// scratch frames live in its slot; result(slot) stays valid until the slot is reused, i.e. for `capacity` more fields.
+constexpr int EEDI_MAX_BATCH = 32;
 class Eedi2Engine
 {
 public:
-    // main: the filter's context when this engine executes on a context (stream) of its own;
-    // share + ring_index: the ring's mask state and this engine's place in it (see EediMaskShare)
-    Eedi2Engine(hbhip_ctx *ctx, const PicGeometry &geo, const Eedi2Params &p,
-                hbhip_ctx *main = nullptr, EediMaskShare *share = nullptr, int ring_index = -1);
+    Eedi2Engine(hbhip_ctx *ctx, const PicGeometry &geo, const Eedi2Params &p, int capacity);
     ~Eedi2Engine();
-    int  init();                                   // allocate the 9 scratch frames (zeroed once)
-    // eedi2_planer (decomb_template.c:455-473): field extraction + the pass
-    // sequence of eedi2_interpolate_plane for the 3 planes; `tff` is pv->tff.
-    // wait_for: an event of the main stream behind which `cur` is complete and this engine's previous
-    // result has been consumed (side engines only; the main-stream engine is ordered by its stream)
-    int  run(const DevPicture *cur, int tff, hipEvent_t wait_for = nullptr);
-    int  mark_done();                              // side engine: whatever was launched on its stream so far belongs to the run
-    int  join();                                   // side engine: make the main stream wait for the last run
-    hbhip_ctx *stream_ctx() { return ctx_; }       // the context (stream) the engine launches on
-    EediMaskShare *share() { return share_; }
-    const EediFrame &result() const { return full_[0]; }   // eedi_full[DST2PF]
-    // MSKPF alternates between two buffers (the fused mask kernel reads the previous field's mask
-    // while it writes the new one): index 1 always names the current one
-    const EediFrame &half(int i) const { return i == 1 ? share_->mask[share_->sel] : half_[i]; }
-    const EediFrame &full(int i) const { return full_[i]; }
+    int  init();                                   // allocate capacity + 1 slots (zeroed once)
+    int  capacity() const { return cap_; }
+    int  queued() const { return n_; }
+    // eedi2_planer (decomb_template.c:455-473): field extraction + the pass sequence of eedi2_interpolate_plane for
+    // the 3 planes; `tff` is pv->tff.  Returns the field's slot (< 0: queue full / picture not dword aligned); `cur`
+    // must stay alive until launch() has been called.
+    int  add_field(const DevPicture *cur, int tff);
+    int  launch(hbhip_ctx *lc);                    // run the queued fields on lc's stream
+    int  last_slot() const { return last_slot_; }
+    EediFrame result(int slot) const { return at_slot(full_[0], slot); }   // eedi_full[DST2PF]
+    EediFrame half(int i, int slot) const { return at_slot(half_[i], slot); }
+    EediFrame full(int i, int slot) const { return at_slot(full_[i], slot); }
 
 private:
-    int alloc_frame(EediFrame &f, int width, int height);
-    // the five mask passes (+ the field extraction when `frame` is given); sel = mask buffer to write, old = the previous run's
-    int enqueue_mask(int sel, int old, const DevPicture *frame, int start_line);
-    int enqueue_passes(int tff, int sel, hbhip_ctx *lc);   // everything after them, launched on lc's stream
-    hipGraphExec_t graph_[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // captured pass sequence per (field parity, mask buffer)
-    EediMaskShare  own_share_;                     // the two MSKPF buffers (mask[0] is half_[1]) when not shared
-    EediMaskShare *share_ = nullptr;
-    int         ring_index_ = -1;                  // >= 0: engine of a ring, writes share_->mask[ring_index_]
-    hbhip_ctx  *main_ = nullptr;                   // != ctx_ for a side engine
-    hbhip_ctx  *cap_ctx_ = nullptr;                // private stream the pass sequence is captured on
-    hipEvent_t  ev_done_ = nullptr;
-    bool        use_graph_ = true;
+    size_t place_frame(EediFrame &f, int width, int height, size_t at);
+    EediFrame at_slot(const EediFrame &f, int slot) const;
+    int enqueue_mask(int n, hbhip_ctx *lc);        // the five mask passes (+ the field extraction)
+    int enqueue_passes(int n, hbhip_ctx *lc);      // everything after them
     hbhip_ctx  *ctx_;
     PicGeometry geo_;
     Eedi2Params par_;
-    EediFrame   half_[4];    // SRCPF, MSKPF, TMPPF, DSTPF          (decomb.c:64-68)
-    EediFrame   full_[5];    // DST2PF, TMP2PF2, MSK2PF, TMP2PF, DST2MPF (decomb.c:69-74)
-    uint32_t   *work_list_ = nullptr;   // calc_directions: compacted edge pixels
+    int         cap_ = 1, n_ = 0, start_ = 0, last_slot_ = 0;
+    uint32_t    tffbits_ = 0;
+    const uint8_t *src_frame_[EEDI_MAX_BATCH][3];  // the queued fields' frames
+    int         src_pitch_[3] = {0, 0, 0};
+    uint8_t    *slab_ = nullptr;
+    size_t      slot_bytes_ = 0;
+    EediFrame   half_[4];    // slot 0's SRCPF, MSKPF, TMPPF, DSTPF          (decomb.c:64-68)
+    EediFrame   full_[5];    // slot 0's DST2PF, TMP2PF2, MSK2PF, TMP2PF, DST2MPF (decomb.c:69-74)
+    uint32_t   *work_list_ = nullptr;   // calc_directions fallback: compacted edge pixels
     int        *work_count_ = nullptr;
-    uint32_t   *cand_ = nullptr;        // interpolate_lattice: per-pixel candidate outcomes
+    uint32_t   *cand_ = nullptr;        // slot 0's interpolate_lattice candidates
     int         cand_pitch_ = 0, cand_plane_stride_ = 0;
     int        *deriv_[3] = {nullptr, nullptr, nullptr};       // post-processing 2/3: cx2, cy2, cxy (decomb.c:398-403)
     int        *deriv_tmp_[3] = {nullptr, nullptr, nullptr};   //                      tmpc, one per array
