@@ -5,16 +5,16 @@
 //   monochrome_kernel   FFmpeg monochrome as grayscale_init configures it
 //                       (libhb/grayscale.c:32-68; same math as the reference's Metal
 //                       shader platform/macosx/shaders/grayscale_vt.metal:68-136)
-//   cropscale_kernel    crop + zscale(filter=lanczos) as crop_scale_init configures them
-//                       (libhb/cropscale.c:52-185)
+//   scale8_*_kernel     crop + zscale(filter=lanczos) as crop_scale_init configures them
+//   cropscale_*_kernel  (libhb/cropscale.c:52-185): 8-bit planes in zimg's 16-bit fixed point, 10 / 12-bit ones in double
 //
 // PARITY UNPINNED: the arithmetic of these filters is in FFmpeg / zimg, which are not in
 // the reference tree.  These kernels are bit-exact against OUR restatement
 // (oracle/alias_oracle.c): pure permutations for rotate; host-built exp() table + plain
-// IEEE float ops for monochrome; host-built Lanczos tap tables (double, libm sin) and
-// double accumulation in the oracle's order for the scaler.
-// All three are HBM-bound (1 read + 1 write per pixel; the scaler reads each source
-// pixel ~taps^2/scale^2 times from L2).
+// IEEE float ops for monochrome; host-built Lanczos tap tables (double, libm sin), quantised
+// to 14 bits for 8-bit planes (integer passes, orc_cropscale_plane_fx) and used as they are
+// with double accumulation in the oracle's order for 10 / 12-bit planes.
+// All three are HBM-bound by their bytes (1 read + 1 write per pixel).
 #include "hbhip_internal.h"
 
 #include <algorithm>
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256) void cropscale_h_kernel(ScaleArgs a, double *_
     double h = 0.0;
     for (int i = 0; i < a.tx; i++)
         h += cx[i] * (double)row[ix[i]];
-    hbuf[(size_t)r * a.dw + x] = h;
+    hbuf[(size_t)r * a.dw + x] = h < 0.0 ? 0.0 : h > a.vmax ? a.vmax : h;      // the horizontal pass is stored clamped (see oracle)
 }
 
 template <typename PIX>
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256) void cropscale_fused_kernel(ScaleArgs3 all)
             const PIX *row = reinterpret_cast<const PIX *>(a.src + (size_t)(rmin + rr) * a.spitch);
             double h = 0.0;
             for (int i = 0; i < tx; i++) h += cx[i] * (double)row[ix[i]];
-            s_h[rr][xl] = h;
+            s_h[rr][xl] = h < 0.0 ? 0.0 : h > a.vmax ? a.vmax : h;
         }
     }
     __syncthreads();
@@ -578,89 +578,166 @@ __global__ __launch_bounds__(256) void cropscale_fused_kernel(ScaleArgs3 all)
     }
 }
 
-// The 6 x 6-tap case (every upscale, e.g. 1080p -> 2160p), the form that runs for it.  What bounded the generic kernel
-// above was not arithmetic but a chain of dependent latencies per workgroup at low occupancy: tap rows from memory, a
-// barrier, per-thread tap tables from memory, byte gathers from memory for every horizontal tap, a barrier, then scalar
-// loads of the vertical taps for every output row - with 20 KB of LDS allowing five workgroups per CU.  Here
-//   * the host precomputes, per tile row and tile column, which source rows / columns the tile taps (tile_y, tile_x);
-//   * ONE round of loads fetches everything a workgroup needs: the tapped source samples (dwords -> LDS), the vertical
-//     taps of its 32 output rows (-> LDS) and each thread's own six horizontal taps (-> registers);
-//   * the horizontal pass gathers from LDS, the vertical pass reads its taps from LDS (broadcast);
-//   * LDS is sized to what the tile really taps (dynamic): 22 rows for a 2x upscale instead of 40.
-// Each H value and each output is the same sequence of double operations as in the kernels above.
-struct Tile6 { const int *tile_y[3]; const int *tile_x[3]; int nr_max, span_max; };
-
-template <typename PIX>
-__global__ __launch_bounds__(256) void cropscale_fused6_kernel(ScaleArgs3 all, Tile6 T)
+// ---- 8-bit planes: zimg's own arithmetic ------------------------------------------------------------------------
+// zimg resizes an 8-bit plane as a 16-bit one (v << 8) in 16-bit fixed point: per pass
+//     dst = clamp((sum_k c[k] * src[k] + (1 << 13)) >> 14, 0, 65535),    c = the filter row with 14 fractional bits,
+// horizontal pass first, then back to 8 bits with round half up of v / 256 (oracle/alias_oracle.c:
+// orc_cropscale_plane_fx has the derivation and the caveats - parity unpinned).  Integer throughout, so the result
+// does not depend on evaluation order and the kernels below are free to use packed dot products: two taps per
+// v_dot2_i32_i16, the 16-bit value between the passes kept biased by -32768 as zimg keeps it (a filter row sums to
+// exactly 1 << 14, so the bias comes out as a constant).
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int acc)
 {
-    extern __shared__ __attribute__((aligned(16))) double smem6[];
-    const int pl = blockIdx.z;
-    if (!all.active[pl]) return;
-    const ScaleArgs &a = all.p[pl];
-    const int x0 = blockIdx.x * FS_TW, y0 = blockIdx.y * FS_TH;
-    if (x0 >= a.dw || y0 >= a.dh) return;
-    const int t = threadIdx.x;
-    const int rows = min(FS_TH, a.dh - y0);
-    const int rmin = T.tile_y[pl][2 * blockIdx.y], nr = T.tile_y[pl][2 * blockIdx.y + 1];
-    const int c0 = T.tile_x[pl][2 * blockIdx.x], span = T.tile_x[pl][2 * blockIdx.x + 1];
-    double *s_h = smem6;                                             // [nr_max][FS_TW]
-    double *s_cy = s_h + (size_t)T.nr_max * FS_TW;                   // [FS_TH][6]
-    int *s_iy = reinterpret_cast<int *>(s_cy + FS_TH * 6);           // [FS_TH][6]
-    const int sp = (T.span_max + 4 + 3) & ~3;                        // samples per staged row
-    PIX *s_src = reinterpret_cast<PIX *>(s_iy + FS_TH * 6);          // [nr_max][sp]
-    const int xl = t & (FS_TW - 1), x = x0 + xl;
-    const int wave_row = __builtin_amdgcn_readfirstlane(t / FS_TW);
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), acc, false);
+}
+__device__ __forceinline__ int reflect_idx(int j, int n)          // taps outside the plane fold back in (edge sample repeated)
+{
+    if (j < 0) j = -j - 1;
+    if (j >= n) j = 2 * n - 1 - j;
+    return min(max(j, 0), n - 1);
+}
+__device__ __forceinline__ int fx_round14(int acc) { return min(max(((acc + 8192) >> 14) + 32768, 0), 65535); }
+__device__ __forceinline__ int fx_to8(int v16) { return min((v16 + 128) >> 8, 255); }
 
-    // one round of loads
-    int ixr[6];
-    double cxr[6];
-    if (x < a.dw)
+// Any tap counts, two launches with the 16-bit plane between them in HBM (downscales; an upscale takes the fused
+// kernel below).  ix / iy: tap positions (already reflected), qx / qy: 14-bit coefficients.
+struct Scale8Args
+{
+    const uint8_t *src; uint8_t *dst;
+    int spitch, dpitch, dw, dh, tx, ty, src_rows;
+    const int *ix, *iy;
+    const short *qx, *qy;
+};
+
+__global__ __launch_bounds__(256) void scale8_h_kernel(Scale8Args a, uint16_t *__restrict__ hbuf)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= a.dw || r >= a.src_rows) return;
+    const int *ix = a.ix + (size_t)x * a.tx;
+    const short *q = a.qx + (size_t)x * a.tx;
+    const uint8_t *row = a.src + (size_t)r * a.spitch;
+    int s = 0;
+    for (int i = 0; i < a.tx; i++) s += (int)q[i] * (int)row[ix[i]];
+    hbuf[(size_t)r * a.dw + x] = (uint16_t)min(max((s + 32) >> 6, 0), 65535);      // = (256 s + 8192) >> 14
+}
+
+__global__ __launch_bounds__(256) void scale8_v_kernel(Scale8Args a, const uint16_t *__restrict__ hbuf)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= a.dw || y >= a.dh) return;
+    int acc = 0;
+    for (int j = 0; j < a.ty; j++)
+        acc += (int)a.qy[(size_t)y * a.ty + j] * ((int)hbuf[(size_t)a.iy[(size_t)y * a.ty + j] * a.dw + x] - 32768);
+    a.dst[(size_t)y * a.dpitch + x] = (uint8_t)fx_to8(fx_round14(acc));
+}
+
+// 6 x 6 taps (every upscale and same-size resampling, e.g. 1080p -> 2160p), both passes in one kernel, the three
+// planes of up to SU_FRAMES frames per launch.  A workgroup owns a 256 x 16 tile of the output:
+//   1. the source rows / columns the tile taps go into LDS as they lie (dwords), the reflection at the plane's
+//      edges applied while staging - so every tap window is six CONSECUTIVE bytes of a staged row;
+//   2. horizontal pass: a thread owns one output column; its six coefficients (three packed pairs) and the three
+//      v_perm selectors that cut its window out of three staged dwords are constants of the thread, a staged row
+//      costs it three LDS reads, three v_perm, three v_dot2.  The 16-bit results are stored as PAIRS of rows
+//      (row 2p in the low half, 2p + 1 in the high half of a dword) ...
+//   3. ... so that the vertical pass takes two taps per v_dot2 as well: a thread owns four adjacent columns of an
+//      output row, a 16-byte LDS read brings the row pairs of all four; a window that starts on an odd row uses
+//      the coefficient pairs (0, c0) (c1, c2) (c3, c4) (c5, 0) over four row pairs instead of realigning.
+// bx / by: first tapped source column / row of an output column / row before reflection (may be < 0).
+constexpr int SU_TW = 256, SU_TH = 16, SU_SRC_DW = 68, SU_MAXR = 24, SU_PAIRS = SU_MAXR / 2 + 2, SU_FRAMES = 16;
+struct ScalePlane8
+{
+    const int *bx, *by;
+    const uint32_t *qx, *qy;         // [dw][3], [dh][3]: coefficient pairs (c0, c1) (c2, c3) (c4, c5)
+    int dw, dh, sw, sh, active;
+};
+struct ScaleBatch8
+{
+    ScalePlane8 p[3];
+    int spitch[3], dpitch[3];
+    const uint8_t *src[SU_FRAMES][3];    // crop window origins
+    uint8_t       *dst[SU_FRAMES][3];
+};
+
+__global__ __launch_bounds__(256) void scale8_up_kernel(ScaleBatch8 B)
+{
+    __shared__ uint32_t s_src[SU_MAXR][SU_SRC_DW];
+    __shared__ __attribute__((aligned(16))) uint32_t s_h[SU_PAIRS][SU_TW];
+    const int f = (int)blockIdx.z / 3, pl = (int)blockIdx.z - 3 * f;
+    const ScalePlane8 &P = B.p[pl];
+    if (!P.active) return;
+    const int x0 = blockIdx.x * SU_TW, y0 = blockIdx.y * SU_TH;
+    if (x0 >= P.dw || y0 >= P.dh) return;
+    const int t = threadIdx.x;
+    const int xe = min(x0 + SU_TW, P.dw) - 1, ye = min(y0 + SU_TH, P.dh) - 1;
+    const int cmin = P.bx[x0] & ~3, cmax = P.bx[xe] + 5;           // bx, by are non-decreasing
+    const int rmin = P.by[y0], nr = P.by[ye] + 5 - rmin + 1;
+    const int ndw = (cmax - cmin) / 4 + 1;                          // <= SU_SRC_DW - 2, nr <= SU_MAXR (checked by the host)
     {
-#pragma unroll
-        for (int i = 0; i < 6; i++) { ixr[i] = a.ix[(size_t)x * 6 + i] - c0; cxr[i] = a.cx[(size_t)x * 6 + i]; }
-    }
-    if (t < rows * 6)
-    {
-        s_cy[t] = a.cy[(size_t)y0 * 6 + t];
-        s_iy[t] = a.iy[(size_t)y0 * 6 + t] - rmin;
-    }
-    {
-        const int ndw = (span * (int)sizeof(PIX) + 3) / 4;
-        const int avail = a.spitch - c0 * (int)sizeof(PIX);          // bytes from c0 to the end of the row's pitch
-        const bool aligned = ((a.spitch | (int)((uintptr_t)a.src & 3)) & 3) == 0;
+        const uint8_t *src = B.src[f][pl];
+        const int spitch = B.spitch[pl];
         for (int i = t; i < nr * ndw; i += 256)
         {
-            const int rr = i / ndw, d = i - rr * ndw;
-            const uint8_t *g = a.src + (size_t)(rmin + rr) * a.spitch + (size_t)c0 * sizeof(PIX) + 4 * d;
+            const int rr = i / ndw, d = i - rr * ndw, col = cmin + 4 * d;
+            const uint8_t *row = src + (size_t)reflect_idx(rmin + rr, P.sh) * spitch;
             uint32_t v;
-            if (aligned && 4 * d + 4 <= avail) v = *reinterpret_cast<const uint32_t *>(g);
+            if (col >= 0 && col + 3 < P.sw && (((uintptr_t)(row + col)) & 3) == 0) v = *reinterpret_cast<const uint32_t *>(row + col);
             else
             {
                 v = 0;
-                for (int k = 0; k < 4 && 4 * d + k < avail; k++) v |= (uint32_t)g[k] << (8 * k);
+#pragma unroll
+                for (int k = 0; k < 4; k++) v |= (uint32_t)row[reflect_idx(col + k, P.sw)] << (8 * k);
             }
-            reinterpret_cast<uint32_t *>(s_src + (size_t)rr * sp)[d] = v;
+            s_src[rr][d] = v;
         }
     }
     __syncthreads();
-    if (x < a.dw)
-        for (int rr = wave_row; rr < nr; rr += 256 / FS_TW)
-        {
-            const PIX *row = s_src + (size_t)rr * sp;
-            double h = 0.0;
-#pragma unroll
-            for (int i = 0; i < 6; i++) h += cxr[i] * (double)row[ixr[i]];
-            s_h[rr * FS_TW + xl] = h;
-        }
-    __syncthreads();
-    if (x >= a.dw) return;
-    for (int yy = wave_row; yy < rows; yy += 256 / FS_TW)
+    if (x0 + t < P.dw)
     {
-        double acc = 0.0;
+        const int x = x0 + t, o = P.bx[x] - cmin, dq = o >> 2, ob = o & 3;
+        // selectors of v_perm_b32(hi, lo, sel): bytes ob, ob + 1 (ob + 2, ob + 3) of {hi:lo} zero-extended to halves
+        const uint32_t sel01 = (uint32_t)ob | 0x0c000c00u | ((uint32_t)(ob + 1) << 16);
+        const uint32_t sel23 = (uint32_t)(ob + 2) | 0x0c000c00u | ((uint32_t)(ob + 3) << 16);
+        const uint32_t c01 = P.qx[3 * (size_t)x], c23 = P.qx[3 * (size_t)x + 1], c45 = P.qx[3 * (size_t)x + 2];
+        uint16_t *hp = reinterpret_cast<uint16_t *>(&s_h[0][0]) + 2 * t;
+        for (int rr = 0; rr < nr; rr++)
+        {
+            const uint32_t d0 = s_src[rr][dq], d1 = s_src[rr][dq + 1], d2 = s_src[rr][dq + 2];
+            int s = dot2(__builtin_amdgcn_perm(d1, d0, sel01), c01, 0);
+            s = dot2(__builtin_amdgcn_perm(d1, d0, sel23), c23, s);
+            s = dot2(__builtin_amdgcn_perm(d2, d1, sel01), c45, s);
+            const int h = min(max((s + 32) >> 6, 0), 65535);         // the 16-bit plane between the passes
+            hp[(size_t)(rr >> 1) * (2 * SU_TW) + (rr & 1)] = (uint16_t)(h ^ 0x8000);    // biased, as zimg holds it
+        }
+    }
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, xq = x0 + 4 * lane;
+    if (xq >= P.dw) return;
+    for (int y = y0 + wave; y <= ye; y += 4)
+    {
+        const int ob = __builtin_amdgcn_readfirstlane(P.by[y] - rmin);
+        const uint32_t c01 = P.qy[3 * (size_t)y], c23 = P.qy[3 * (size_t)y + 1], c45 = P.qy[3 * (size_t)y + 2];
+        int acc[4] = {0, 0, 0, 0};
+        const uint4 *hq = reinterpret_cast<const uint4 *>(&s_h[ob >> 1][4 * lane]);
+        auto tap = [&](int pair_row, uint32_t cpair) {
+            const uint4 q = hq[(size_t)pair_row * (SU_TW / 4)];
+            acc[0] = dot2(q.x, cpair, acc[0]); acc[1] = dot2(q.y, cpair, acc[1]);
+            acc[2] = dot2(q.z, cpair, acc[2]); acc[3] = dot2(q.w, cpair, acc[3]);
+        };
+        if (!(ob & 1)) { tap(0, c01); tap(1, c23); tap(2, c45); }
+        else
+        {
+            // rows ob .. ob + 5 against the pairs (ob - 1, ob) (ob + 1, ob + 2) (ob + 3, ob + 4) (ob + 5, ob + 6)
+            tap(0, c01 << 16); tap(1, (c01 >> 16) | (c23 << 16)); tap(2, (c23 >> 16) | (c45 << 16)); tap(3, c45 >> 16);
+        }
+        uint32_t out = 0;
 #pragma unroll
-        for (int j = 0; j < 6; j++) acc += s_cy[yy * 6 + j] * s_h[s_iy[yy * 6 + j] * FS_TW + xl];
-        acc = acc < 0.0 ? 0.0 : acc > a.vmax ? a.vmax : acc;
-        reinterpret_cast<PIX *>(a.dst + (size_t)(y0 + yy) * a.dpitch)[x] = (PIX)(int)(acc + 0.5);
+        for (int k = 0; k < 4; k++) out |= (uint32_t)fx_to8(fx_round14(acc[k])) << (8 * k);
+        uint8_t *d = B.dst[f][pl] + (size_t)y * B.dpitch[pl] + xq;
+        if (xq + 3 < P.dw && (((uintptr_t)d) & 3) == 0) *reinterpret_cast<uint32_t *>(d) = out;
+        else for (int k = 0; k < 4 && xq + k < P.dw; k++) d[k] = (uint8_t)(out >> (8 * k));
     }
 }
 
@@ -682,8 +759,10 @@ double lanczos3(double x)
 }
 
 // zimg-style tap table of one dimension (see oracle/alias_oracle.c for the conventions)
-int lanczos_table(int src_dim, int dst_dim, double shift, std::vector<int> &idx, std::vector<double> &coef)
+int lanczos_table(int src_dim, int dst_dim, double shift, std::vector<int> &idx, std::vector<double> &coef,
+                  std::vector<int> *first = nullptr)
 {
+    if (first) first->assign((size_t)dst_dim, 0);
     const double scale = (double)dst_dim / (double)src_dim;
     const double step = scale < 1.0 ? scale : 1.0;
     const double support = 3.0 / step;
@@ -696,6 +775,7 @@ int lanczos_table(int src_dim, int dst_dim, double shift, std::vector<int> &idx,
     {
         const double pos = (i + 0.5) / scale + shift;
         const double begin = std::floor(pos - taps / 2.0 + 0.5);
+        if (first) (*first)[i] = (int)begin;
         double w[64], total = 0.0;
         for (int k = 0; k < taps; k++)
         {
@@ -716,6 +796,21 @@ int lanczos_table(int src_dim, int dst_dim, double shift, std::vector<int> &idx,
     return taps;
 }
 
+// a filter row with 14 fractional bits that still sums to 1 << 14: the rounding residue goes to the largest tap
+// (oracle/alias_oracle.c: orc_quantize_taps)
+void quantize_taps(const double *coef, int taps, short *q)
+{
+    int sum = 0, big = 0;
+    for (int k = 0; k < taps; k++)
+    {
+        const long v = std::lrint(coef[k] * 16384.0);
+        q[k] = (short)v;
+        sum += (int)v;
+        if (std::fabs(coef[k]) > std::fabs(coef[big])) big = k;
+    }
+    q[big] = (short)(q[big] + (16384 - sum));
+}
+
 class CropScaleFilter : public SimpleFilter
 {
 public:
@@ -728,10 +823,13 @@ public:
             if (d_iy[c]) (void)hipFree(d_iy[c]);
             if (d_cx[c]) (void)hipFree(d_cx[c]);
             if (d_cy[c]) (void)hipFree(d_cy[c]);
-            if (d_tile_y[c]) (void)hipFree(d_tile_y[c]);
-            if (d_tile_x[c]) (void)hipFree(d_tile_x[c]);
+            if (d_bx[c]) (void)hipFree(d_bx[c]);
+            if (d_by[c]) (void)hipFree(d_by[c]);
+            if (d_qx[c]) (void)hipFree(d_qx[c]);
+            if (d_qy[c]) (void)hipFree(d_qy[c]);
         }
         if (hbuf) (void)hipFree(hbuf);
+        if (hbuf16) (void)hipFree(hbuf16);
     }
     int setup()
     {
@@ -750,11 +848,38 @@ public:
             const double sx = (c && lw) ? 0.25 * (1.0 - (double)cw / (double)out_geo.width) : 0.0;
             identity[c] = (dw == crop_w[c] && dh == crop_h[c] && sx == 0.0);
             if (identity[c]) continue;
-            std::vector<int> ix, iy;
+            std::vector<int> ix, iy, bx, by;
             std::vector<double> cx, cy;
-            tx[c] = lanczos_table(crop_w[c], dw, sx, ix, cx);
-            ty[c] = lanczos_table(crop_h[c], dh, 0.0, iy, cy);
-            // the fused kernel keeps the tapped source rows of a 32-row output tile in LDS
+            tx[c] = lanczos_table(crop_w[c], dw, sx, ix, cx, &bx);
+            ty[c] = lanczos_table(crop_h[c], dh, 0.0, iy, cy, &by);
+            auto upload = [&](auto *&dptr, const auto &v) -> int {
+                HBHIP_CHECK(ctx, hipMalloc((void **)&dptr, sizeof(v[0]) * v.size()));
+                HBHIP_CHECK(ctx, hipMemcpy(dptr, v.data(), sizeof(v[0]) * v.size(), hipMemcpyHostToDevice));
+                return HBHIP_OK;
+            };
+            int rc = upload(d_ix[c], ix);
+            if (rc == HBHIP_OK) rc = upload(d_iy[c], iy);
+            if (rc != HBHIP_OK) return rc;
+            if (in_geo.bps == 1)
+            {
+                // 8-bit planes: zimg's fixed-point arithmetic (scale8_*_kernel)
+                std::vector<short> qx(cx.size()), qy(cy.size());
+                for (int x = 0; x < dw; x++) quantize_taps(&cx[(size_t)x * tx[c]], tx[c], &qx[(size_t)x * tx[c]]);
+                for (int y = 0; y < dh; y++) quantize_taps(&cy[(size_t)y * ty[c]], ty[c], &qy[(size_t)y * ty[c]]);
+                rc = upload(d_qx[c], qx);
+                if (rc == HBHIP_OK) rc = upload(d_qy[c], qy);
+                if (rc == HBHIP_OK) rc = upload(d_bx[c], bx);
+                if (rc == HBHIP_OK) rc = upload(d_by[c], by);
+                if (rc != HBHIP_OK) return rc;
+                // the fused kernel: six taps either way, and what a 256 x 16 tile taps must fit its LDS frame
+                if (tx[c] != 6 || ty[c] != 6) up6 = false;
+                for (int x0 = 0; x0 < dw && up6; x0 += SU_TW)
+                    if (((bx[std::min(x0 + SU_TW, dw) - 1] + 5) - (bx[x0] & ~3)) / 4 + 1 > SU_SRC_DW - 2) up6 = false;
+                for (int y0 = 0; y0 < dh && up6; y0 += SU_TH)
+                    if (by[std::min(y0 + SU_TH, dh) - 1] + 5 - by[y0] + 1 > SU_MAXR) up6 = false;
+                continue;
+            }
+            // 10 / 12-bit planes: the double form (cropscale_fused_kernel, or two passes when a tile taps too many rows)
             for (int y0 = 0; y0 < dh && fused; y0 += FS_TH)
             {
                 int lo = 0x7fffffff, hi = -1;
@@ -765,63 +890,91 @@ public:
                 }
                 if (hi - lo + 1 > FS_MAXR) fused = false;
             }
-            if (tx[c] == 6 && ty[c] == 6)
-            {
-                // which source rows / columns each output tile taps (cropscale_fused6_kernel); the column origin is
-                // rounded down to a dword of samples
-                std::vector<int> tyv, txv;
-                const int al = 4 / in_geo.bps;
-                for (int y0 = 0; y0 < dh; y0 += FS_TH)
-                {
-                    int lo = 0x7fffffff, hi = -1;
-                    for (int i = 0; i < std::min(FS_TH, dh - y0) * 6; i++) { lo = std::min(lo, iy[(size_t)y0 * 6 + i]); hi = std::max(hi, iy[(size_t)y0 * 6 + i]); }
-                    tyv.push_back(lo); tyv.push_back(hi - lo + 1);
-                    nr_max = std::max(nr_max, hi - lo + 1);
-                }
-                for (int x0 = 0; x0 < dw; x0 += FS_TW)
-                {
-                    int lo = 0x7fffffff, hi = -1;
-                    for (int i = 0; i < std::min(FS_TW, dw - x0) * 6; i++) { lo = std::min(lo, ix[(size_t)x0 * 6 + i]); hi = std::max(hi, ix[(size_t)x0 * 6 + i]); }
-                    lo = lo / al * al;
-                    txv.push_back(lo); txv.push_back(hi - lo + 1);
-                    span_max = std::max(span_max, hi - lo + 1);
-                }
-                HBHIP_CHECK(ctx, hipMalloc((void **)&d_tile_y[c], sizeof(int) * tyv.size()));
-                HBHIP_CHECK(ctx, hipMalloc((void **)&d_tile_x[c], sizeof(int) * txv.size()));
-                HBHIP_CHECK(ctx, hipMemcpy(d_tile_y[c], tyv.data(), sizeof(int) * tyv.size(), hipMemcpyHostToDevice));
-                HBHIP_CHECK(ctx, hipMemcpy(d_tile_x[c], txv.data(), sizeof(int) * txv.size(), hipMemcpyHostToDevice));
-            }
-            HBHIP_CHECK(ctx, hipMalloc((void **)&d_ix[c], sizeof(int) * ix.size()));
-            HBHIP_CHECK(ctx, hipMalloc((void **)&d_iy[c], sizeof(int) * iy.size()));
-            HBHIP_CHECK(ctx, hipMalloc((void **)&d_cx[c], sizeof(double) * cx.size()));
-            HBHIP_CHECK(ctx, hipMalloc((void **)&d_cy[c], sizeof(double) * cy.size()));
-            HBHIP_CHECK(ctx, hipMemcpy(d_ix[c], ix.data(), sizeof(int) * ix.size(), hipMemcpyHostToDevice));
-            HBHIP_CHECK(ctx, hipMemcpy(d_iy[c], iy.data(), sizeof(int) * iy.size(), hipMemcpyHostToDevice));
-            HBHIP_CHECK(ctx, hipMemcpy(d_cx[c], cx.data(), sizeof(double) * cx.size(), hipMemcpyHostToDevice));
-            HBHIP_CHECK(ctx, hipMemcpy(d_cy[c], cy.data(), sizeof(double) * cy.size(), hipMemcpyHostToDevice));
+            rc = upload(d_cx[c], cx);
+            if (rc == HBHIP_OK) rc = upload(d_cy[c], cy);
+            if (rc != HBHIP_OK) return rc;
         }
-        if (getenv("HBHIP_SCALE_TWO_PASS")) fused = false;
         size_t need = 0;
         for (int c = 0; c < 3; c++)
             if (!identity[c]) need = std::max(need, (size_t)out_geo.pw[c] * crop_h[c]);
-        if (need && !fused) HBHIP_CHECK(ctx, hipMalloc((void **)&hbuf, sizeof(double) * need));
+        if (need && in_geo.bps == 1 && !up6) HBHIP_CHECK(ctx, hipMalloc((void **)&hbuf16, sizeof(uint16_t) * need));
+        if (need && in_geo.bps != 1 && !fused) HBHIP_CHECK(ctx, hipMalloc((void **)&hbuf, sizeof(double) * need));
         return HBHIP_OK;
     }
+
+    const uint8_t *window(const DevPicture *in, int c) const
+    {
+        return in->plane[c] + (size_t)crop_y[c] * in->pitch[c] + (size_t)crop_x[c] * in_geo.bps;
+    }
+    int copy_identity_planes(DevPicture *in, DevPicture *out)
+    {
+        for (int c = 0; c < 3; c++)
+            if (identity[c])
+                HBHIP_LAUNCH(ctx, "crop_copy", crop_copy_kernel, dim3((out->width[c] * in_geo.bps + 255) / 256, out->height[c]), dim3(256), 0,
+                             window(in, c), in->pitch[c], out->plane[c], out->pitch[c], out->width[c] * in_geo.bps, out->height[c]);
+        return HBHIP_OK;
+    }
+
+    // 8-bit planes
+    int process_many(DevPicture *const *ins, DevPicture *const *outs, int n) override
+    {
+        if (in_geo.bps != 1) return SimpleFilter::process_many(ins, outs, n);
+        for (int i = 0; i < n; i++) (void)copy_identity_planes(ins[i], outs[i]);
+        if (identity[0] && identity[1] && identity[2]) { HBHIP_CHECK(ctx, hipGetLastError()); return HBHIP_OK; }
+        if (up6)
+            for (int i0 = 0; i0 < n; i0 += SU_FRAMES)
+            {
+                const int m = std::min(SU_FRAMES, n - i0);
+                ScaleBatch8 B;
+                memset(&B, 0, sizeof(B));
+                for (int c = 0; c < 3; c++)
+                {
+                    ScalePlane8 &P = B.p[c];
+                    P.bx = d_bx[c]; P.by = d_by[c];
+                    P.qx = reinterpret_cast<const uint32_t *>(d_qx[c]); P.qy = reinterpret_cast<const uint32_t *>(d_qy[c]);
+                    P.dw = out_geo.pw[c]; P.dh = out_geo.ph[c]; P.sw = crop_w[c]; P.sh = crop_h[c];
+                    P.active = !identity[c];
+                    B.spitch[c] = ins[i0]->pitch[c]; B.dpitch[c] = outs[i0]->pitch[c];
+                    for (int k = 0; k < m; k++)
+                    {
+                        if (ins[i0 + k]->pitch[c] != B.spitch[c] || outs[i0 + k]->pitch[c] != B.dpitch[c]) return HBHIP_ERR_ARG;
+                        B.src[k][c] = window(ins[i0 + k], c); B.dst[k][c] = outs[i0 + k]->plane[c];
+                    }
+                }
+                const dim3 grid((out_geo.pw[0] + SU_TW - 1) / SU_TW, (out_geo.ph[0] + SU_TH - 1) / SU_TH, 3 * m);
+                HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", scale8_up_kernel, grid, dim3(256), 0, B);
+            }
+        else
+            for (int i = 0; i < n; i++)
+                for (int c = 0; c < 3; c++)
+                {
+                    if (identity[c]) continue;
+                    Scale8Args a;
+                    a.src = window(ins[i], c); a.dst = outs[i]->plane[c];
+                    a.spitch = ins[i]->pitch[c]; a.dpitch = outs[i]->pitch[c];
+                    a.dw = out_geo.pw[c]; a.dh = out_geo.ph[c]; a.tx = tx[c]; a.ty = ty[c]; a.src_rows = crop_h[c];
+                    a.ix = d_ix[c]; a.iy = d_iy[c]; a.qx = d_qx[c]; a.qy = d_qy[c];
+                    const dim3 gh((a.dw + 63) / 64, (crop_h[c] + 3) / 4), gv((a.dw + 63) / 64, (a.dh + 3) / 4);
+                    HBHIP_LAUNCH(ctx, "cropscale_lanczos_h", scale8_h_kernel, gh, dim3(64, 4), 0, a, hbuf16);
+                    HBHIP_LAUNCH(ctx, "cropscale_lanczos_v", scale8_v_kernel, gv, dim3(64, 4), 0, a, (const uint16_t *)hbuf16);
+                }
+        HBHIP_CHECK(ctx, hipGetLastError());
+        return HBHIP_OK;
+    }
+
+    // one frame: 8-bit planes through process_many, 10 / 12-bit planes here
     int process(DevPicture *in, DevPicture *out) override
     {
+        if (in_geo.bps == 1) return process_many(&in, &out, 1);
         ScaleArgs3 all;
         memset(&all, 0, sizeof(all));
+        (void)copy_identity_planes(in, out);
         for (int c = 0; c < 3; c++)
         {
-            const uint8_t *win = in->plane[c] + (size_t)crop_y[c] * in->pitch[c] + (size_t)crop_x[c] * in_geo.bps;
+            const uint8_t *win = window(in, c);
             const int dw = out->width[c], dh = out->height[c];
             const double vmax = (double)((1 << in_geo.depth) - 1);
-            if (identity[c])
-            {
-                HBHIP_LAUNCH(ctx, "crop_copy", crop_copy_kernel, dim3((dw * in_geo.bps + 255) / 256, dh), dim3(256), 0,
-                             win, in->pitch[c], out->plane[c], out->pitch[c], dw * in_geo.bps, dh);
-                continue;
-            }
+            if (identity[c]) continue;
             if (fused)
             {
                 ScaleArgs &f = all.p[c];
@@ -838,50 +991,28 @@ public:
             a.dw = dw; a.dh = dh; a.tx = tx[c]; a.ty = ty[c];
             a.ix = d_ix[c]; a.iy = d_iy[c]; a.cx = d_cx[c]; a.cy = d_cy[c]; a.vmax = vmax;
             const dim3 gh((dw + 63) / 64, (crop_h[c] + 3) / 4), gv((dw + 63) / 64, (dh + 3) / 4);
-            if (in_geo.bps == 1)
-            {
-                HBHIP_LAUNCH(ctx, "cropscale_lanczos_h", cropscale_h_kernel<uint8_t>, gh, dim3(64, 4), 0, a, hbuf, crop_h[c]);
-                HBHIP_LAUNCH(ctx, "cropscale_lanczos_v", cropscale_v_kernel<uint8_t>, gv, dim3(64, 4), 0, a, (const double *)hbuf);
-            }
-            else
-            {
-                HBHIP_LAUNCH(ctx, "cropscale_lanczos_h", cropscale_h_kernel<uint16_t>, gh, dim3(64, 4), 0, a, hbuf, crop_h[c]);
-                HBHIP_LAUNCH(ctx, "cropscale_lanczos_v", cropscale_v_kernel<uint16_t>, gv, dim3(64, 4), 0, a, (const double *)hbuf);
-            }
+            HBHIP_LAUNCH(ctx, "cropscale_lanczos_h", cropscale_h_kernel<uint16_t>, gh, dim3(64, 4), 0, a, hbuf, crop_h[c]);
+            HBHIP_LAUNCH(ctx, "cropscale_lanczos_v", cropscale_v_kernel<uint16_t>, gv, dim3(64, 4), 0, a, (const double *)hbuf);
         }
         if (all.active[0] || all.active[1] || all.active[2])
         {
             const dim3 grid((out->width[0] + FS_TW - 1) / FS_TW, (out->height[0] + FS_TH - 1) / FS_TH, 3);
-            bool six = true;
-            for (int c = 0; c < 3; c++) six &= !all.active[c] || (tx[c] == 6 && ty[c] == 6);
-            const int sp = (span_max + 4 + 3) & ~3;
-            const size_t lds6 = sizeof(double) * ((size_t)nr_max * FS_TW + FS_TH * 6) + sizeof(int) * FS_TH * 6 +
-                                (size_t)nr_max * sp * in_geo.bps + 16;
-            if (six && lds6 <= 64 * 1024 && getenv("HBHIP_SCALE_GENERIC") == nullptr)
-            {
-                Tile6 T;
-                for (int c = 0; c < 3; c++) { T.tile_y[c] = d_tile_y[c]; T.tile_x[c] = d_tile_x[c]; }
-                T.nr_max = nr_max; T.span_max = span_max;
-                if (in_geo.bps == 1) HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", cropscale_fused6_kernel<uint8_t>, grid, dim3(256), lds6, all, T);
-                else                 HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", cropscale_fused6_kernel<uint16_t>, grid, dim3(256), lds6, all, T);
-            }
-            else if (in_geo.bps == 1)
-                HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", (cropscale_fused_kernel<0, 0, uint8_t>), grid, dim3(256), 0, all);
-            else
-                HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", (cropscale_fused_kernel<0, 0, uint16_t>), grid, dim3(256), 0, all);
+            HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", (cropscale_fused_kernel<0, 0, uint16_t>), grid, dim3(256), 0, all);
         }
         HBHIP_CHECK(ctx, hipGetLastError());
         return HBHIP_OK;
     }
-    bool fused = true;          // all scaled planes fit the fused kernel's LDS budget
+    bool fused = true;          // 10 / 12 bits: all scaled planes fit the fused kernel's LDS budget
+    bool up6 = true;            // 8 bits: six taps either way and every tile fits scale8_up_kernel's LDS frame
     hbhip_cropscale_params par;
     int crop_x[3], crop_y[3], crop_w[3], crop_h[3], tx[3] = {0, 0, 0}, ty[3] = {0, 0, 0};
     bool identity[3] = {false, false, false};
     int *d_ix[3] = {nullptr, nullptr, nullptr}, *d_iy[3] = {nullptr, nullptr, nullptr};
     double *d_cx[3] = {nullptr, nullptr, nullptr}, *d_cy[3] = {nullptr, nullptr, nullptr};
-    double *hbuf = nullptr;     // horizontally filtered rows of one plane (dst_w x crop_h doubles)
-    int *d_tile_y[3] = {nullptr, nullptr, nullptr}, *d_tile_x[3] = {nullptr, nullptr, nullptr};
-    int nr_max = 0, span_max = 0;
+    double *hbuf = nullptr;     // horizontally filtered rows of one plane (dst_w x crop_h doubles; 10 / 12 bits, two-pass form)
+    uint16_t *hbuf16 = nullptr; // the same for 8-bit planes (zimg's 16-bit plane between the passes)
+    int *d_bx[3] = {nullptr, nullptr, nullptr}, *d_by[3] = {nullptr, nullptr, nullptr};
+    short *d_qx[3] = {nullptr, nullptr, nullptr}, *d_qy[3] = {nullptr, nullptr, nullptr};
 };
 
 // ------------------------------------------------------------------ pad

@@ -20,9 +20,11 @@
  *     1/scale when shrinking, windows centred with round-half-up, taps that fall
  *     outside the picture reflected back in (edge sample repeated), weights
  *     normalised per output sample; left-sited 4:2:0 chroma gets the horizontal
- *     shift 0.25*(1 - src/dst).  zimg itself filters in 16-bit fixed point; this
- *     restatement uses double and rounds half up once at the end, so it can differ
- *     from real zimg by 1 LSB.
+ *     shift 0.25*(1 - src/dst).  zimg itself filters in 16-bit fixed point, horizontal
+ *     pass first, each pass stored clamped to the sample range; this restatement keeps
+ *     the order and the clamp between the passes but uses double and rounds half up once
+ *     at the end, so it can differ from real zimg by 1 LSB (orc_cropscale_plane_fx is
+ *     the fixed-point form for 8-bit planes).
  * The HIP path is tested bit-for-bit against THIS file (tables are built by the
  * same formulas with host libm), never against FFmpeg/zimg.
  */
@@ -198,6 +200,8 @@ void orc_cropscale_plane_d(const void *src, int sstride, int crop_x, int crop_y,
 {
     const int bps = depth > 8 ? 2 : 1;
     const double vmax = (double)((1 << depth) - 1);
+    /* range of the value between the passes: an 8-bit plane is resized as a 16-bit one (65535 = 255.996 * 256) */
+    const double hmax = depth == 8 ? 65535.0 / 256.0 : vmax;
     const uint8_t *win = (const uint8_t *)src + (size_t)crop_y * sstride + (size_t)crop_x * bps;
     if (dw == crop_w && dh == crop_h && shift_x == 0.0 && shift_y == 0.0)
     {
@@ -219,12 +223,84 @@ void orc_cropscale_plane_d(const void *src, int sstride, int crop_x, int crop_y,
                 double h = 0.0;
                 for (int i = 0; i < tx; i++)
                     h += cx[(size_t)x * tx + i] * (double)getpx(win, sstride, ix[(size_t)x * tx + i], r, bps);
+                h = h < 0.0 ? 0.0 : h > hmax ? hmax : h;       /* zimg stores the horizontal pass clamped to the sample range */
                 acc += cy[(size_t)y * ty + j] * h;
             }
             acc = acc < 0.0 ? 0.0 : acc > vmax ? vmax : acc;
             setpx(dst, dstride, x, y, bps, (unsigned)(int)(acc + 0.5));
         }
     free(ix); free(iy); free(cx); free(cy);
+}
+
+/* ---- the same resize in zimg's own arithmetic for 8-bit planes ----------------------------------------
+ * zimg has no 8-bit resize kernel: a BYTE plane is first widened to a 16-bit WORD plane (limited-range integer
+ * to integer depth conversion = left shift by 8), resized in 16-bit fixed point, and brought back to 8 bits by
+ * the depth converter (dither=none: round half up of v / 256).  The WORD resize kernels (resize_impl.cpp,
+ * resize_line_h_u16_c / resize_line_v_u16_c, from memory) are
+ *     accum = sum_k coeff_i16[k] * (src[k] + INT16_MIN);
+ *     dst   = clamp(((accum + (1 << 13)) >> 14) - INT16_MIN, 0, pixel_max)
+ * with the filter row quantised to 14 fractional bits such that it still sums to exactly 1 << 14 (filter.cpp:
+ * the rounding residue is folded back into the row; here: into its largest tap).  Because a row sums to 1 << 14
+ * the bias cancels: dst = clamp((sum_k c[k] * src[k] + 8192) >> 14), floor division.  Horizontal pass first
+ * (the cheaper order for an upscale, which is what zimg's cost estimate picks), its result rounded to 16 bits,
+ * then the vertical pass.  For an 8-bit source sample v the widened value is 256 v, so the horizontal pass is
+ * (sum_k c[k] v[k] + 32) >> 6.
+ * PARITY UNPINNED like the double form above (zimg is not in the reference tree); it is the arithmetic the HIP
+ * kernel runs, tests/test_alias_cpu.py holds it within 1 LSB of the double form and of Pillow's Lanczos. */
+void orc_quantize_taps(const double *coef, int taps, int16_t *q)
+{
+    int sum = 0, big = 0;
+    for (int k = 0; k < taps; k++)
+    {
+        const long v = lrint(coef[k] * 16384.0);
+        q[k] = (int16_t)v;
+        sum += (int)v;
+        if (fabs(coef[k]) > fabs(coef[big])) big = k;
+    }
+    q[big] = (int16_t)(q[big] + (16384 - sum));
+}
+
+static inline int clamp_u16(int v) { return v < 0 ? 0 : v > 65535 ? 65535 : v; }
+
+void orc_cropscale_plane_fx(const uint8_t *src, int sstride, int crop_x, int crop_y, int crop_w, int crop_h,
+                            uint8_t *dst, int dstride, int dw, int dh, double shift_x, double shift_y)
+{
+    const uint8_t *win = src + (size_t)crop_y * sstride + crop_x;
+    if (dw == crop_w && dh == crop_h && shift_x == 0.0 && shift_y == 0.0)
+    {
+        for (int y = 0; y < dh; y++)
+            memcpy(dst + (size_t)y * dstride, win + (size_t)y * sstride, (size_t)dw);
+        return;
+    }
+    int *ix = malloc(sizeof(int) * (size_t)dw * 64), *iy = malloc(sizeof(int) * (size_t)dh * 64);
+    double *cx = malloc(sizeof(double) * (size_t)dw * 64), *cy = malloc(sizeof(double) * (size_t)dh * 64);
+    const int tx = orc_lanczos_table(crop_w, dw, shift_x, ix, cx);
+    const int ty = orc_lanczos_table(crop_h, dh, shift_y, iy, cy);
+    int16_t *qx = malloc(sizeof(int16_t) * (size_t)dw * tx), *qy = malloc(sizeof(int16_t) * (size_t)dh * ty);
+    for (int x = 0; x < dw; x++) orc_quantize_taps(cx + (size_t)x * tx, tx, qx + (size_t)x * tx);
+    for (int y = 0; y < dh; y++) orc_quantize_taps(cy + (size_t)y * ty, ty, qy + (size_t)y * ty);
+    uint16_t *hbuf = malloc(sizeof(uint16_t) * (size_t)dw * crop_h);
+    for (int r = 0; r < crop_h; r++)
+    {
+        const uint8_t *row = win + (size_t)r * sstride;
+        for (int x = 0; x < dw; x++)
+        {
+            int s = 0;
+            for (int i = 0; i < tx; i++) s += (int)qx[(size_t)x * tx + i] * (int)row[ix[(size_t)x * tx + i]];
+            hbuf[(size_t)r * dw + x] = (uint16_t)clamp_u16((s + 32) >> 6);         /* = (256 s + 8192) >> 14 */
+        }
+    }
+    for (int y = 0; y < dh; y++)
+        for (int x = 0; x < dw; x++)
+        {
+            int acc = 0;
+            for (int j = 0; j < ty; j++)
+                acc += (int)qy[(size_t)y * ty + j] * ((int)hbuf[(size_t)iy[(size_t)y * ty + j] * dw + x] - 32768);
+            const int v16 = clamp_u16(((acc + 8192) >> 14) + 32768);
+            const int v8 = (v16 + 128) >> 8;
+            dst[(size_t)y * dstride + x] = (uint8_t)(v8 > 255 ? 255 : v8);
+        }
+    free(ix); free(iy); free(cx); free(cy); free(qx); free(qy); free(hbuf);
 }
 
 /* ---- pad (libhb/pad.c:40-148 -> FFmpeg vf_pad.c + drawutils.c; parity unpinned) ----------------

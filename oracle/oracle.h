@@ -250,6 +250,10 @@ void orc_pad_plane(const void *src, int sw, int sh, int sstride, void *dst, int 
 /* The tap table of one dimension (exposed so tests can look at it): for each of the
  * `dst_dim` outputs `taps` (index, weight) pairs; returns taps. idx/coef sized dst_dim*64. */
 int orc_lanczos_table(int src_dim, int dst_dim, double shift, int *idx, double *coef);
+/* 8-bit planes in zimg's 16-bit fixed-point arithmetic (the form the HIP scaler runs) */
+void orc_quantize_taps(const double *coef, int taps, int16_t *q);
+void orc_cropscale_plane_fx(const uint8_t *src, int sstride, int crop_x, int crop_y, int crop_w, int crop_h,
+                            uint8_t *dst, int dstride, int dw, int dh, double shift_x, double shift_y);
 
 /* ---- colorspace (colorspace.c:20-207 -> zscale / tonemap; PARITY UNPINNED, colorspace_oracle.c) -- */
 typedef struct

@@ -464,10 +464,21 @@ def orc_grayscale_frame(frame, cb=0.0, cr=0.0, size=1.0, high=0.0, depth=8):
     return dst, np.full_like(u, 1 << (depth - 1)), np.full_like(v, 1 << (depth - 1))
 
 
-def orc_cropscale_frame(frame, width, height, top=0, bottom=0, left=0, right=0, depth=8):
-    fn = oracle().orc_cropscale_plane_d
-    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
-                   C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]
+def orc_cropscale_frame(frame, width, height, top=0, bottom=0, left=0, right=0, depth=8, arithmetic=None):
+    """crop + Lanczos scale of a frame.  arithmetic: "fixed" = zimg's 16-bit fixed point (orc_cropscale_plane_fx, 8-bit
+    planes only: the form the HIP scaler runs and is compared with bit for bit), "double" = the float64 form
+    (10 / 12-bit planes, and the independent check of the fixed-point form); default: fixed at 8 bits."""
+    if arithmetic is None:
+        arithmetic = "fixed" if depth == 8 else "double"
+    if arithmetic == "fixed":
+        assert depth == 8
+        fn = oracle().orc_cropscale_plane_fx
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                       C.c_int, C.c_int, C.c_double, C.c_double]
+    else:
+        fn = oracle().orc_cropscale_plane_d
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                       C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]
     h0, w0 = frame[0].shape
     cw, ch = w0 - left - right, h0 - top - bottom
     out = []
@@ -480,7 +491,10 @@ def orc_cropscale_frame(frame, width, height, top=0, bottom=0, left=0, right=0, 
             dw, dh = (width + 1) // 2, (height + 1) // 2
             sx = 0.25 * (1.0 - cw / width)
         dst = np.zeros((dh, dw), p.dtype)
-        fn(p.ctypes.data, p.strides[0], cx, cy, pw, ph, dst.ctypes.data, dst.strides[0], dw, dh, sx, 0.0, depth)
+        args = [p.ctypes.data, p.strides[0], cx, cy, pw, ph, dst.ctypes.data, dst.strides[0], dw, dh, sx, 0.0]
+        if arithmetic != "fixed":
+            args.append(depth)
+        fn(*args)
         out.append(dst)
     return tuple(out)
 

@@ -62,6 +62,53 @@ def test_scale_identity_constant_and_partition_of_unity(built):
     assert taps == 12                                                 # support stretches when shrinking
 
 
+@pytest.mark.parametrize("w,h,ow,oh", [(640, 360, 1280, 720), (640, 360, 320, 180), (638, 362, 850, 480), (320, 180, 300, 250)])
+def test_fixed_point_scaler_within_one_lsb_of_the_double_form(built, w, h, ow, oh):
+    """zimg's 16-bit fixed-point arithmetic (what the HIP scaler runs) against the float64 restatement of the same
+    filter: north_star's bar for the scaler is +-1 LSB."""
+    for model in ("progressive", "random"):
+        fr = synth.stream(model, w, h, 1)[0]
+        fx = ol.orc_cropscale_frame(fr, ow, oh, arithmetic="fixed")
+        fd = ol.orc_cropscale_frame(fr, ow, oh, arithmetic="double")
+        for c in range(3):
+            d = np.abs(fx[c].astype(int) - fd[c].astype(int))
+            assert d.max() <= 1, f"{model} plane {c}: max |delta| {d.max()}"
+            assert (d == 0).mean() > 0.97                            # they differ at rounding boundaries only
+
+
+def test_quantised_taps_sum_to_one(built):
+    import ctypes as C
+    L = ol.oracle()
+    L.orc_lanczos_table.argtypes = [C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    L.orc_quantize_taps.argtypes = [C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int16)]
+    for src, dst, shift in ((1920, 3840, 0.0), (960, 1920, 0.125), (640, 300, 0.0), (1080, 1081, 0.0)):
+        idx = (C.c_int * (dst * 64))()
+        coef = (C.c_double * (dst * 64))()
+        taps = L.orc_lanczos_table(src, dst, shift, idx, coef)
+        for x in (0, 1, dst // 3, dst - 1):
+            q = (C.c_int16 * taps)()
+            row = (C.c_double * taps)(*coef[x * taps:(x + 1) * taps])
+            L.orc_quantize_taps(row, taps, q)
+            assert sum(q) == 16384
+            assert max(abs(q[k] - row[k] * 16384) for k in range(taps)) <= 1.5
+
+
+@pytest.mark.parametrize("ow,oh", [(1280, 720), (320, 180)])
+def test_scaler_vs_pillow(built, ow, oh):
+    """Independent implementation (NOT parity: Pillow is neither zimg nor swscale): Pillow's Lanczos (a = 3, the
+    same kernel and edge-normalised windows, its own fixed-point passes) on the luma of a synthetic 640x360
+    frame.  It bounds how far the restatement can be from 'a Lanczos-3 resize'."""
+    Image = pytest.importorskip("PIL.Image")
+    fr = synth.stream("progressive", 640, 360, 1)[0]
+    got = ol.orc_cropscale_frame(fr, ow, oh)[0]
+    ref = np.asarray(Image.fromarray(fr[0]).resize((ow, oh), Image.LANCZOS))
+    d = np.abs(got.astype(int) - ref.astype(int))
+    # edges differ in kind (zimg reflects taps back into the picture, Pillow renormalises the clipped window)
+    inner = d[8:-8, 8:-8]
+    assert inner.max() <= 2
+    assert (inner <= 1).mean() >= 0.9999
+
+
 def test_crop_is_a_window(built):
     fr = synth.progressive_frame(320, 180, 3)
     out = ol.orc_cropscale_frame(fr, 300, 160, top=8, bottom=12, left=4, right=16)
