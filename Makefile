@@ -1,6 +1,7 @@
 # Top-level build: product libraries (handbrake_amd/) + checkers (oracle/).
 #   make            everything
 #   make product    libhbrt.so, libhbhip.so (HIP kernels + C-ABI), libhbhip_filters.so
+#   make dev        the product libraries with -DHBHIP_DEV (tuning knobs from the environment; never shipped / tested)
 #   make oracle     liboracle.so and, when /root/reference exists, oracle/_ref/libhbref.so
 HIPCC   ?= /opt/rocm/bin/hipcc
 CC      ?= gcc
@@ -32,8 +33,14 @@ $(PKG)/libhbhip_filters.so: $(FLT_SRC) $(PKG)/libhbrt.so $(PKG)/libhbhip.so incl
 oracle: $(PKG)/libhbrt.so
 	$(MAKE) -C oracle all
 
+# development build of the kernels library: environment tuning knobs and HBHIP_SKIP_KERNELS compiled in
+dev:
+	rm -f $(HIP_OBJ)
+	$(MAKE) product HIPFLAGS="$(HIPFLAGS) -DHBHIP_DEV"
+	rm -f $(HIP_OBJ)
+
 clean:
 	rm -f $(PKG)/*.so $(PKG)/csrc/*.o
 	$(MAKE) -C oracle clean
 
-.PHONY: all product oracle clean
+.PHONY: all product oracle clean dev

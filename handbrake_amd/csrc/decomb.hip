@@ -550,8 +550,7 @@ public:
             // bob) are queued and go through each pass together: one launch per pass for up to `fields` fields
             // (Eedi2Engine), followed by the blends that consume the guesses.  Driven a frame at a time (work() of the
             // plugin), a frame's fields still share their launches.
-            int fields = 16;
-            if (const char *e = getenv("HBHIP_EEDI2_FIELDS")) fields = atoi(e);       // tuning: fields per launch (1..32)
+            const int fields = hbhip_dev_int("HBHIP_EEDI2_FIELDS", 32);               // fields per batch (1..32)
             eedi = new (std::nothrow) Eedi2Engine(ctx, in_geo, ep, fields);
             if (!eedi) return HBHIP_ERR_NOMEM;
             int rc = eedi->init();
@@ -620,14 +619,14 @@ private:
         if (!p || --p->refs != 0) return;
         // a queued EEDI2 field or a blend gathered for the batch launch may still read it: hand it back when the
         // batch is out
-        if (batch.n > 0 || (eedi && eedi->queued() > 0)) late_unref.push_back(p);
+        if (!gathered.empty() || (eedi && eedi->queued() > 0)) late_unref.push_back(p);
         else hbhip_pic_release(p, ctx);                    // possibly another filter's picture (fused chain)
     }
     // launch what has been gathered: the queued EEDI2 fields, then the blends (which read their guesses)
     int flush_batch()
     {
         int rc = eedi ? eedi->launch(ctx) : HBHIP_OK;
-        const int rc2 = launch_batch(batch, ctx);
+        const int rc2 = launch_gathered(ctx);
         for (DevPicture *p : late_unref) hbhip_pic_release(p, ctx);
         late_unref.clear();
         return rc != HBHIP_OK ? rc : rc2;
@@ -694,35 +693,35 @@ private:
             HBHIP_CHECK(lc, hipGetLastError());
             return HBHIP_OK;
         }
-        // 8-bit: four pixels per thread.  The frames are gathered and go out together (launch_batch, at most DB_FRAMES
-        // per launch): at the end of the call, or - inside a chain batch - when the batch is complete.  A frame whose
-        // guess is still queued in the EEDI2 engine cannot be launched before the engine, so a full blend batch
-        // flushes both.
-        if (batch.n == DB_FRAMES)
-        {
-            const int rc = flush_batch();
-            if (rc != HBHIP_OK) return rc;
-        }
-        DecombBatch &B = batch;
-        DecombFrame &F = B.f[B.n++];
+        // 8-bit: four pixels per thread.  The frames are gathered and go out together (launch_gathered, DB_FRAMES per
+        // launch): at the end of the call, or - inside a chain batch - when the batch is complete or the EEDI2 engine
+        // is full (a frame whose guess is still queued there cannot be launched before the engine).
+        DecombFrame F;
         for (int c = 0; c < 3; c++)
         {
             const DecombPlane &P = a.pl[c];
             F.prev[c] = P.prev; F.cur[c] = P.cur; F.next[c] = P.next; F.guess[c] = P.guess; F.dst[c] = P.dst;
-            B.pitch[c] = P.pitch; B.dst_pitch[c] = P.dst_pitch; B.w[c] = P.w; B.h[c] = P.h;
-            if (P.guess) B.guess_pitch[c] = P.guess_pitch;          // the same for every frame that has a guess
+            geo.pitch[c] = P.pitch; geo.dst_pitch[c] = P.dst_pitch; geo.w[c] = P.w; geo.h[c] = P.h;
+            if (P.guess) geo.guess_pitch[c] = P.guess_pitch;        // the same for every frame that has a guess
         }
         F.mode = a.mode; F.parity = a.parity; F.field_parity = a.field_parity; F.pad = 0;
+        gathered.push_back(F);
         return HBHIP_OK;
     }
 
-    int launch_batch(DecombBatch &B, hbhip_ctx *lc)
+    int launch_gathered(hbhip_ctx *lc)
     {
-        if (B.n == 0) return HBHIP_OK;
-        const dim3 block(64, 4), grid((B.w[0] + 255) / 256, (B.h[0] + 3) / 4, 3 * B.n);
-        B.n = 0;
-        HBHIP_LAUNCH(lc, "decomb_plane", decomb_plane4_kernel, grid, block, 0, B);
-        HBHIP_CHECK(lc, hipGetLastError());
+        for (size_t i0 = 0; i0 < gathered.size(); i0 += DB_FRAMES)
+        {
+            DecombBatch B = geo;
+            B.n = (int)std::min<size_t>(DB_FRAMES, gathered.size() - i0);
+            for (int k = 0; k < B.n; k++) B.f[k] = gathered[i0 + k];
+            const dim3 block(64, 4), grid((B.w[0] + 255) / 256, (B.h[0] + 3) / 4, 3 * B.n);
+            HBHIP_LAUNCH(lc, "decomb_plane", decomb_plane4_kernel, grid, block, 0, B);
+        }
+        const bool any = !gathered.empty();
+        gathered.clear();
+        if (any) HBHIP_CHECK(lc, hipGetLastError());
         return HBHIP_OK;
     }
 
@@ -801,7 +800,8 @@ private:
     Eedi2Engine *eedi = nullptr;           // 8-bit EEDI2: fields queued here run together (flush_batch)
     std::vector<DevPicture *> late_unref;  // input pictures whose last reference went while something gathered could still read them
     bool deferred = false;
-    DecombBatch batch;                     // blends gathered for one launch
+    std::vector<DecombFrame> gathered;     // blends waiting for their launch (launch_gathered)
+    DecombBatch geo;                       // the pitches / sizes they share
 public:
     Eedi2Engine16 *eedi16 = nullptr;       // 10 / 12-bit samples
 private:

@@ -1728,6 +1728,10 @@ Eedi2Engine::Eedi2Engine(hbhip_ctx *ctx, const PicGeometry &geo, const Eedi2Para
 
 Eedi2Engine::~Eedi2Engine()
 {
+    if (side_) { (void)hipStreamSynchronize(side_->stream); hbhip_ctx_destroy(side_); }
+    if (side_stream_) (void)hipStreamDestroy(side_stream_);
+    if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+    for (hipEvent_t e : ev_group_) if (e) (void)hipEventDestroy(e);
     if (slab_) (void)hipFree(slab_);
     if (work_list_) (void)hipFree(work_list_);
     if (work_count_) (void)hipFree(work_count_);
@@ -1802,6 +1806,27 @@ int Eedi2Engine::init()
             HBHIP_CHECK(ctx_, hipMemsetAsync(deriv_tmp_[i], 0, n, ctx_->stream));
         }
     }
+    // the stream of the mask chain (see launch); without it everything runs on the caller's stream
+    group_ = std::min(std::max(hbhip_dev_int("HBHIP_EEDI2_GROUP", 8), 0), cap_);
+    if (group_ > 0 && group_ < cap_)
+    {
+        // high priority: the chain's small workgroups must not queue up behind the passes' big grids
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipStreamCreateWithPriority(&side_stream_, hipStreamNonBlocking, greatest) != hipSuccess) { side_stream_ = nullptr; (void)hipGetLastError(); }
+        if (side_stream_ && hbhip_ctx_create_on_stream(ctx_->device, side_stream_, &side_) != HBHIP_OK) side_ = nullptr;
+    }
+    if (side_)
+    {
+        bool ok = hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming) == hipSuccess;
+        for (int g = 0; ok && g * group_ < cap_; g++)
+        {
+            hipEvent_t e = nullptr;
+            ok = hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+            if (ok) ev_group_.push_back(e);
+        }
+        if (!ok) { hbhip_ctx_destroy(side_); side_ = nullptr; (void)hipGetLastError(); }
+    }
     HBHIP_CHECK(ctx_, hipStreamSynchronize(ctx_->stream));
     return HBHIP_OK;
 }
@@ -1825,19 +1850,41 @@ int Eedi2Engine::add_field(const DevPicture *cur, int tff)
     return start_ + n_++;
 }
 
+// The mask passes of the queued fields are a chain of short launches (each field's lower half needs the previous
+// field's finished mask) that occupy a fraction of the GPU, and every later pass of a field needs only that field's
+// mask.  So the chain goes to a stream of its own and the passes follow it in groups of `group_` fields on the
+// caller's stream: while the passes of one group run, the chain works on the next groups' masks.  Fork and join are
+// inside this call: the side stream starts behind the caller's stream (whatever used these slots before is done),
+// and the caller's stream has waited for the last mask by the time the last group's passes are queued.
 int Eedi2Engine::launch(hbhip_ctx *lc)
 {
     if (n_ == 0) return HBHIP_OK;
     const int n = n_;
     n_ = 0;
-    int rc = enqueue_mask(n, lc);
-    if (rc == HBHIP_OK) rc = enqueue_passes(n, lc);
+    int rc = HBHIP_OK;
+    const bool forked = side_ && !lc->profile && n > group_;         // the per-kernel profiler times launches on lc only
+    if (!forked)
+    {
+        rc = enqueue_mask(n, lc, lc, 0);
+        if (rc == HBHIP_OK) rc = enqueue_passes(0, n, lc);
+    }
+    else
+    {
+        rc = enqueue_mask(n, lc, side_, group_);
+        for (int f0 = 0, g = 0; rc == HBHIP_OK && f0 < n; f0 += group_, g++)
+        {
+            HBHIP_CHECK(lc, hipStreamWaitEvent(lc->stream, ev_group_[g], 0));
+            rc = enqueue_passes(f0, std::min(group_, n - f0), lc);
+        }
+    }
     last_slot_ = start_ + n - 1;
     return rc;
 }
 
-// the five mask passes (+ the field extraction) of the n queued fields: old mask -> new mask
-int Eedi2Engine::enqueue_mask(int n, hbhip_ctx *lc)
+// the five mask passes (+ the field extraction) of the n queued fields: old mask -> new mask.  The part no earlier
+// field can influence goes to `lc` in one launch; the chain goes to `mc` (== lc, or the side stream: then behind an
+// event on lc, and with an event recorded behind every `group` fields)
+int Eedi2Engine::enqueue_mask(int n, hbhip_ctx *lc, hbhip_ctx *mc, int group)
 {
     const EediFrame srcp = at_slot(half_[0], start_), mskp = at_slot(half_[1], start_), mskp_old = at_slot(half_[1], last_slot_);
     P3 P;
@@ -1864,23 +1911,35 @@ int Eedi2Engine::enqueue_mask(int n, hbhip_ctx *lc)
         const unsigned gy_up = std::max(1, (srcp.height[0] / 2 - MF_OY) / MF_H);
         HBHIP_LAUNCH(lc, "eedi2_mask_upper", k_mask_fused4, dim3(gx, gy_up, 3 * n), dim3(256), 0, P, S, 0, 1, mth, vth, lth,
                      par_.erosion_threshold, par_.dilation_threshold);
+        if (mc != lc)
+        {
+            HBHIP_CHECK(lc, hipEventRecord(ev_fork_, lc->stream));
+            HBHIP_CHECK(mc, hipStreamWaitEvent(mc->stream, ev_fork_, 0));
+        }
         for (int f = 0; f < n; f++)
-            HBHIP_LAUNCH(lc, "eedi2_mask_passes", k_mask_fused4, dim3(gx, gy, 3), dim3(256), 0, P, S, f, 2, mth, vth, lth,
+        {
+            HBHIP_LAUNCH(mc, "eedi2_mask_passes", k_mask_fused4, dim3(gx, gy, 3), dim3(256), 0, P, S, f, 2, mth, vth, lth,
                          par_.erosion_threshold, par_.dilation_threshold);
+            if (mc != lc && ((f + 1) % group == 0 || f + 1 == n))
+                HBHIP_CHECK(mc, hipEventRecord(ev_group_[f / group], mc->stream));
+        }
     }
     HBHIP_CHECK(lc, hipGetLastError());
     return HBHIP_OK;
 }
 
 // The pass sequence of eedi2_interpolate_plane (decomb_template.c:366-441) behind the mask passes, for the 3 planes of
-// the n queued fields, on their scratch frames.
-int Eedi2Engine::enqueue_passes(int n, hbhip_ctx *lc)
+// n of the queued fields, on their scratch frames.
+int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc)
 {
-    const EediFrame srcp = at_slot(half_[0], start_), mskp = at_slot(half_[1], start_), tmpp = at_slot(half_[2], start_),
-                    dstp = at_slot(half_[3], start_);
-    const EediFrame dst2p = at_slot(full_[0], start_), tmp2p2 = at_slot(full_[1], start_), msk2p = at_slot(full_[2], start_),
-                    tmp2p = at_slot(full_[3], start_), dst2mp = at_slot(full_[4], start_);
-    uint32_t *cand = cand_ + (size_t)start_ * (slot_bytes_ / sizeof(uint32_t));
+    // fields f0 .. f0 + n - 1 of the batch
+    const int s0 = start_ + f0;
+    const uint32_t tffbits = tffbits_ >> f0;
+    const EediFrame srcp = at_slot(half_[0], s0), mskp = at_slot(half_[1], s0), tmpp = at_slot(half_[2], s0),
+                    dstp = at_slot(half_[3], s0);
+    const EediFrame dst2p = at_slot(full_[0], s0), tmp2p2 = at_slot(full_[1], s0), msk2p = at_slot(full_[2], s0),
+                    tmp2p = at_slot(full_[3], s0), dst2mp = at_slot(full_[4], s0);
+    uint32_t *cand = cand_ + (size_t)s0 * (slot_bytes_ / sizeof(uint32_t));
     const dim3 blk(64, 4);
     const unsigned gz = 3u * (unsigned)n;
     auto grid_for = [&](const EediFrame &f, bool whole_pitch) {
@@ -1906,7 +1965,7 @@ int Eedi2Engine::enqueue_passes(int n, hbhip_ctx *lc)
     P3 P;
     memset(&P, 0, sizeof(P));
     P.fstride = slot_bytes_;
-    P.tffbits = tffbits_;
+    P.tffbits = tffbits;
 
     // half-height passes
     geom(P, srcp);
@@ -1915,9 +1974,23 @@ int Eedi2Engine::enqueue_passes(int n, hbhip_ctx *lc)
     if (par_.maximum_search_distance <= CD_HALO - 2)
         // rows per block, measured (kernel alone / decomb bob throughput): 2: 44 us / 5.72 k fps, 4: 53 / 5.62 k, 8: 69 / 5.82 k
         // (the more rows, the fewer instructions - and the fewer, longer workgroups to balance over the CUs)
+    {
+#ifdef HBHIP_DEV
+        const int rows = hbhip_dev_int("HBHIP_EEDI2_CALCDIR_ROWS", 2);
+        if (rows == 4)
+            HBHIP_LAUNCH(lc, "eedi2_calc_directions", k_calc_dir_rows<4>,
+                         dim3((srcp.stride[0] + CD_W - 1) / CD_W, (srcp.height[0] + 3) / 4, gz), dim3(CD_W), 0, P,
+                         par_.maximum_search_distance, nt13, nt19);
+        else if (rows == 8)
+            HBHIP_LAUNCH(lc, "eedi2_calc_directions", k_calc_dir_rows<8>,
+                         dim3((srcp.stride[0] + CD_W - 1) / CD_W, (srcp.height[0] + 7) / 8, gz), dim3(CD_W), 0, P,
+                         par_.maximum_search_distance, nt13, nt19);
+        else
+#endif
         HBHIP_LAUNCH(lc, "eedi2_calc_directions", k_calc_dir_rows<2>,
                      dim3((srcp.stride[0] + CD_W - 1) / CD_W, (srcp.height[0] + 1) / 2, gz), dim3(CD_W), 0, P,
                      par_.maximum_search_distance, nt13, nt19);
+    }
     else
     {
         // search distances beyond the LDS halo: a work list of the edge pixels, field after field
@@ -1989,7 +2062,7 @@ int Eedi2Engine::enqueue_passes(int n, hbhip_ctx *lc)
         // values from plane to plane and from field to field)
         for (int f = 0; f < n; f++)
         {
-            const int tff = (int)((tffbits_ >> f) & 1u);
+            const int tff = (int)((tffbits >> f) & 1u);
             const size_t foff = (size_t)f * slot_bytes_;
             for (int c = 0; c < 3; c++)
             {

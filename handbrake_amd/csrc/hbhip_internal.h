@@ -74,10 +74,16 @@ struct hbhip_ctx
         if (_e != hipSuccess) return (ctx)->fail(_e, #expr);                    \
     } while (0)
 
-// Launch a kernel on the context's stream; when profiling is on the launch is
-// bracketed by two events whose delta is accumulated under `name`.
-// What-if profiling: HBHIP_SKIP_KERNELS=<substring>[,<substring>...] drops the launches whose name matches (results are
-// wrong then, by design): how much of a workload's wall time hangs on a kernel is then a measurement, not an estimate.
+// Development builds only (make dev: -DHBHIP_DEV; `make product` never defines it):
+//  * hbhip_dev_int("NAME", default): a tuning knob read from the environment - in a product build the default, a constant;
+//  * what-if profiling: HBHIP_SKIP_KERNELS=<substring>[,<substring>...] drops the launches whose name matches (results
+//    are wrong then, by design): how much of a workload's wall time hangs on a kernel is then a measurement.
+#ifdef HBHIP_DEV
+static inline int hbhip_dev_int(const char *name, int def)
+{
+    const char *e = getenv(name);
+    return e && *e ? atoi(e) : def;
+}
 static inline bool hbhip_skip_launch(const char *name)
 {
     static const char *list = getenv("HBHIP_SKIP_KERNELS");
@@ -91,7 +97,13 @@ static inline bool hbhip_skip_launch(const char *name)
     }
     return false;
 }
+#else
+#define hbhip_dev_int(name, def) (def)
+#define hbhip_skip_launch(name) false
+#endif
 
+// Launch a kernel on the context's stream; when profiling is on the launch is
+// bracketed by two events whose delta is accumulated under `name`.
 #define HBHIP_LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                \
     do {                                                                        \
         if (hbhip_skip_launch(name)) break;                                     \
