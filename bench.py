@@ -158,8 +158,11 @@ def cpu_baseline_nlmeans(frames_np):
 
 
 def cpu_baseline_chain(workload, frames_np, scale):
-    """The reference's own filter objects (oracle/_ref) for the chain workloads on the host cores.
-    EEDI2 runs on 3 plane threads whatever the core count (decomb.c:386-394), ~0.5 s per 1080p field."""
+    """The reference's own filter objects (oracle/_ref) for the chain workloads on the host cores, stage by stage.
+    EEDI2 runs on 3 plane threads whatever the core count (decomb.c:386-394), ~0.5 s per 1080p field.  libhb runs
+    every filter on a thread of its own with fifos between them (work.c:2527-2600), so a job's frame rate is that of
+    its slowest stage: `value` is that rate - an upper bound for the CPU, the stages then compete for the same cores -
+    and `serial_value` what one gets running the stages one after the other."""
     from handbrake_amd import hbrt, hip
     import oracle_lib as ol
     import oracle_stream as os_
@@ -171,30 +174,60 @@ def cpu_baseline_chain(workload, frames_np, scale):
     nlm = hip.NLMEANS_MEDIUM + f":threads={threads}"
     n_in = 6 if frames_np[0][0].shape[1] <= 1920 else 2
     seq = [frames_np[i % len(frames_np)] for i in range(n_in)]
-    chain = [("hb_filter_decomb", "mode=31")]
-    note = "reference hb_filter_decomb mode=31 (EEDI2 bob, 3 plane threads)"
-    if workload != "decomb_eedi2":
-        chain.append(("hb_filter_nlmeans", nlm))
-        note += f" -> hb_filter_nlmeans medium (taskset threads={threads})"
-    t0 = time.perf_counter()
-    out = hbrt.run_stream(ref, chain, seq, flags=8)
-    dt = time.perf_counter() - t0
+    stages = []
+
+    def timed(name, fn, note):
+        t0 = time.perf_counter()
+        out = fn()
+        dt = time.perf_counter() - t0
+        stages.append({"stage": name, "seconds": round(dt, 3), "frames": len(out), "note": note})
+        return out
+
+    out = timed("decomb", lambda: hbrt.run_stream(ref, [("hb_filter_decomb", "mode=31")], seq, flags=8),
+                "reference hb_filter_decomb mode=31 (EEDI2 bob, 3 plane threads)")
+    n_out = len(out)
     frames = [o.planes for o in out]
     if workload != "decomb_eedi2":
+        out = timed("nlmeans", lambda: hbrt.run_stream(ref, [("hb_filter_nlmeans", nlm)], frames),
+                    f"reference hb_filter_nlmeans medium (taskset threads={threads})")
+        frames = [o.planes for o in out]
         if scale:
-            t1 = time.perf_counter()
-            frames = os_.cropscale_stream(frames, dict(width=scale[0], height=scale[1]))
-            dt += time.perf_counter() - t1
-            note += f" -> crop/scale Lanczos to {scale[0]}x{scale[1]} (OUR restatement oracle/alias_oracle.c: the " \
-                    f"reference's scaler is zimg, not buildable here)"
-        t1 = time.perf_counter()
-        out2 = hbrt.run_stream(ref, [("hb_filter_lapsharp", LAPSHARP)], frames)
-        dt += time.perf_counter() - t1
-        note += " -> reference hb_filter_lapsharp (mt_frame_filter threaded)"
-        assert len(out2) == len(out)
-    return {"value": round(len(out) / dt, 3), "unit": "output frames/s", "cores": threads, "kind": "reference",
-            "sample": f"{len(seq)} input / {len(out)} output frames, {note}; stages timed one after the other, "
-                      f"{dt:.1f}s wall"}
+            frames = timed("crop_scale", lambda: os_.cropscale_stream(frames, dict(width=scale[0], height=scale[1])),
+                           f"crop/scale Lanczos to {scale[0]}x{scale[1]}: OUR restatement of zimg's fixed-point resize "
+                           "(oracle/alias_oracle.c, one thread) - the reference's scaler is zimg, not buildable here")
+        out = timed("lapsharp", lambda: hbrt.run_stream(ref, [("hb_filter_lapsharp", LAPSHARP)], frames),
+                    "reference hb_filter_lapsharp (mt_frame_filter threaded)")
+        assert len(out) == n_out
+    for st in stages:
+        st["output_fps"] = round(n_out / st["seconds"], 3)
+    slowest = max(stages, key=lambda st: st["seconds"])
+    total = sum(st["seconds"] for st in stages)
+    return {"value": round(n_out / slowest["seconds"], 3), "unit": "output frames/s", "cores": threads, "kind": "reference",
+            "stages": stages, "slowest_stage": slowest["stage"], "serial_value": round(n_out / total, 3),
+            "sample": f"{len(seq)} input / {n_out} output frames; value = rate of the slowest stage ({slowest['stage']}), as "
+                      f"libhb's thread-per-filter pipeline delivers it; stages timed one after the other: {total:.1f}s wall"}
+
+
+def measured_hbm_peak(device_index):
+    """On-box ceiling: a 1 GiB device-to-device copy (2 GiB of traffic, well past the 256 MB Infinity Cache),
+    HIP-event timed, best of 5."""
+    import torch
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=f"cuda:{device_index}")
+    b = torch.empty_like(a)
+    a.fill_(1)
+    best = None
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1)
+        best = ms if best is None else min(best, ms)
+    del a, b
+    torch.cuda.empty_cache()
+    return round(2 * n / (best * 1e-3) / 1e9, 1)
 
 
 def pcie_inclusive(workload, frames_np, scale, n_warm=16, n_in=64):
@@ -466,6 +499,14 @@ def run_chain(args, world, rank, local_rank):
         dist.barrier()
     out_frames = sum(ln.produced for ln in lanes) - start
     frames_total, dt_max = shard.reduce_throughput(float(out_frames), dt, device="cuda")
+    # host time to enqueue a step when nothing holds the host back: three steps into an empty queue (in the timed
+    # region the host runs ahead of the GPU until a filter's ring of job tables / pictures makes it wait)
+    t1 = time.perf_counter()
+    for _ in range(3):
+        for ln in lanes:
+            ln.step()
+    t_enq_free = (time.perf_counter() - t1) / 3
+    sync_all()
 
     # per-kernel launch times: same launches, bracketed by HIP events on their stream, right after the timed region
     stats = {}
@@ -532,11 +573,21 @@ def run_chain(args, world, rank, local_rank):
                        "stage_streams": bool(args.stage_streams),
                        "parallelism": f"{world} GPU(s) x {len(lanes)} independent stream(s)", "device": ctx.name()},
             "input_fps": round(frames_total / dt_max / 2, 2),
-            "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4),
+            "host_enqueue_ms_per_step": round(t_enq_free * 1e3, 4),
+            "host_enqueue_ms_per_step_timed_region": round(t_enq / args.steps * 1e3, 4),
             "chain_hbm_GBps_algorithmic": round(per_out * frames_total / dt_max / 1e9, 2),
             "chain_frac_of_hbm_peak": round(per_out * frames_total / dt_max / 1e9 / HBM_PEAK_GBS, 5),
             "roofline": roof, "kernels": kernels,
         }
+        if roof is not None and not args.no_kernel_timer:
+            try:
+                mp = measured_hbm_peak(local_rank)
+                roof["measured_peak"] = mp
+                roof["frac_of_measured_peak"] = round(roof["achieved"] / mp, 5)
+                line["chain_frac_of_measured_peak"] = round(per_out * frames_total / dt_max / 1e9 / mp, 5)
+            except Exception as e:
+                roof["measured_peak"] = None
+                roof["measured_peak_error"] = repr(e)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_chain(args.workload, frames_np, scale)
         else:

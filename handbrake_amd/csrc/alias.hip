@@ -184,7 +184,7 @@ public:
     // the batch kernel moves dwords: 8-bit planes whose rows are dword aligned
     bool batch_ok(const DevPicture *in, const DevPicture *out) const
     {
-        if (in_geo.bps != 1 || getenv("HBHIP_ROTATE_OLD")) return false;
+        if (in_geo.bps != 1) return false;
         for (int c = 0; c < 3; c++)
             if ((in->pitch[c] & 3) || (out->pitch[c] & 3) || ((uintptr_t)in->plane[c] & 3) || ((uintptr_t)out->plane[c] & 3)) return false;
         return true;
@@ -406,7 +406,7 @@ public:
     // the batch kernel moves 16 luma / 8 chroma bytes at a time: 8-bit 4:2:0 planes aligned accordingly
     bool batch_ok(const DevPicture *in, const DevPicture *out) const
     {
-        return in_geo.bps == 1 && in_geo.log2_cw == 1 && in_geo.log2_ch == 1 && !getenv("HBHIP_MONOCHROME_OLD") &&
+        return in_geo.bps == 1 && in_geo.log2_cw == 1 && in_geo.log2_ch == 1 &&
                (in->pitch[0] & 15) == 0 && (out->pitch[0] & 15) == 0 && ((uintptr_t)in->plane[0] & 15) == 0 && ((uintptr_t)out->plane[0] & 15) == 0 &&
                (in->pitch[1] & 7) == 0 && ((uintptr_t)in->plane[1] & 7) == 0 && ((uintptr_t)in->plane[2] & 7) == 0;
     }

@@ -17,7 +17,9 @@
 // filter: the chain then orders stage k+1 behind stage k with an event per hand-over, nothing else,
 // so while the last stages work on one batch the first ones already run the next.  Pictures find
 // their way back across streams through their `idle` event (PicturePool).  The caller's input frames
-// must be complete in the chain context's stream order; the output frames are complete once
+// must be complete in the chain context's stream order, and may be rewritten in that order as soon as
+// the call has returned (the chain's stream waits for the copy-in); the output frames are written behind
+// whatever the chain context's stream held when the call was made, and are complete once
 // hbhip_chain_sync() returns (or the last stage's context has been synchronized).
 #include "hbhip_internal.h"
 
@@ -71,10 +73,11 @@ struct hbhip_chain
     hbhip_ctx *ctx = nullptr;
     std::vector<hbhip_filter *> st;
     std::deque<DevPicture *> held;          // finished pictures the caller had no room for yet
-    std::vector<hipEvent_t> ev;             // ev[s]: stage s has been given everything of the current batch; ev[n]: the caller's inputs
+    std::vector<hipEvent_t> ev;             // ev[s]: stage s has been given everything of the current batch; ev[n]: the caller's inputs;
+                                            // ev[n+1]: the copy-in is done; ev[n+2]: the caller's earlier use of the output frames
     bool split = false;                     // stages on more than one context
     std::vector<double> host_ms;            // HBHIP_CHAIN_TIMING: host time spent per stage (+ copy-in at the end)
-    bool timing = getenv("HBHIP_CHAIN_TIMING") != nullptr;
+    bool timing = hbhip_dev_int("HBHIP_CHAIN_TIMING", 0) != 0;   // development builds only
 
     // make `to`'s stream wait for what `from`'s stream holds right now
     int order(hbhip_ctx *from, hbhip_ctx *to, hipEvent_t e)
@@ -142,6 +145,9 @@ struct hbhip_chain
         if (timing && host_ms.empty()) host_ms.assign(st.size() + 1, 0.0);
         double t_mark = timing ? now() : 0.0;
         if (n_in > 0) { rc = order(ctx, first->ctx, ev[st.size()]); if (rc != HBHIP_OK) return rc; }
+        // whoever writes the caller's output frames (the last stage, direct or by copy-out) does so behind what the
+        // caller's stream has queued on them so far - also on a flush, or when only delayed frames come out
+        if (cap > 0) { rc = order(ctx, st.back()->ctx, ev[st.size() + 2]); if (rc != HBHIP_OK) return rc; }
         for (int i = 0; i < n_in; i++)
         {
             DevPicture *p = first->acquire_input();
@@ -161,6 +167,8 @@ struct hbhip_chain
             }
             cur.push_back(p);
         }
+        // the caller may refill its input frames in its stream's order from here on
+        if (n_in > 0) { rc = order(first->ctx, ctx, ev[st.size() + 1]); if (rc != HBHIP_OK) return rc; }
         if (timing) { const double t = now(); host_ms[st.size()] += t - t_mark; t_mark = t; }
         for (size_t s = 0; s < st.size(); s++)
         {
@@ -244,7 +252,7 @@ int hbhip_chain_create(hbhip_ctx *ctx, hbhip_filter *const *stages, int n_stages
     c->ctx = ctx;
     c->st.assign(stages, stages + n_stages);
     (void)hipSetDevice(ctx->device);
-    for (int i = 0; i <= n_stages; i++)
+    for (int i = 0; i <= n_stages + 2; i++)
     {
         hipEvent_t e = nullptr;
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess)

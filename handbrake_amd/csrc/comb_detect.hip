@@ -636,8 +636,7 @@ public:
         dim3 b(64, 4);
         dim3 g((mstride + 63) / 64, (height - 4 + 3) / 4);
         const size_t lds = (par.mode & 1) ? sizeof(float) * k.lut_len : 0;
-        static const bool one_px = getenv("HBHIP_COMB_1PX") != nullptr;                // A/B switch: the byte-per-thread kernels
-        const bool quad = bps == 1 && !overlay && !one_px;
+        const bool quad = bps == 1 && !overlay;
         if (quad)
         {
             CombBatch B;
@@ -662,7 +661,7 @@ public:
             // overlay modes: the box outline written into the filtered mask persists in the cells no pass rewrites
             // and the passes read it, so they run one by one on the real buffers (the fused kernel carries its
             // intermediate masks in LDS and assumes those cells are zero)
-            const bool fused = par.filter_mode == 2 && !overlay && getenv("HBHIP_COMB_UNFUSED") == nullptr;
+            const bool fused = par.filter_mode == 2 && !overlay;
             if (fused && quad)
                 HBHIP_LAUNCH(ctx, "comb_mask_passes", comb_mask_fused4_kernel, dim3((width + 63) / 64, (height + 15) / 16, 1), b, 0,
                              (const uint8_t *)mask, mask_filtered, (size_t)0, mstride, width, height);

@@ -55,23 +55,6 @@ __device__ __forceinline__ int sorted_mid16(int *v, int n)
     return (n & 1) ? v[n >> 1] : (v[(n - 1) >> 1] + v[n >> 1] + 1) >> 1;
 }
 
-__device__ __forceinline__ int vote16(const int *v, int n, int mid, int lim, int &count)
-{
-    int sum = 0, cnt = 0;
-    for (int i = 0; i < n; i++)
-        if (iabs16(v[i] - mid) <= lim) { cnt++; sum += v[i]; }
-    count = cnt;
-    return (int)(((float)(sum + mid) / (float)(cnt + 1)) + 0.5f);
-}
-
-__device__ __forceinline__ int collect16(int *v, int k, const uint16_t *row, int x, bool skip_centre, int peak)
-{
-    if (row[x - 1] != peak) v[k++] = row[x - 1];
-    if (!skip_centre && row[x] != peak) v[k++] = row[x];
-    if (row[x + 1] != peak) v[k++] = row[x + 1];
-    return k;
-}
-
 // a = source plane (pitch in samples in `sp*`), b = srcp.  Device frames have no row padding:
 // samples at x >= width are written as 0 (see the 8-bit k_fill_half).
 __global__ void q_fill_half(Q3 P, int sp0, int sp1, int sp2, int start_line, int rows0, int rows1, int rows2)
@@ -688,121 +671,6 @@ __global__ void q_blit(Q3 P)
     P.c[pl][(size_t)y * pitch + x] = P.a[pl][(size_t)y * pitch + x];
 }
 
-// eedi2_interpolate_lattice (:1148-1335), in place: a = tmp2p (direction map, rewritten), b = dst2p
-// (rewritten on the interpolated rows), c = tmp2p2.  The test at x looks at the direction just
-// written at x-1, so a row is walked left to right by one thread; rows are independent.
-__global__ void q_lattice(Q3 P, K16 k, int field, int nt)
-{
-    const int pl = blockIdx.z;
-    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    const int nrows = (height - 1 - (2 - field) + 1) / 2;                 // rows 2-field, 4-field, ... < height-1
-    uint16_t *dstp = P.b[pl];
-    if (r == nrows)                                                       // the one-row blit (:1162-1179)
-    {
-        for (int xx = 0; xx < width; xx++)
-        {
-            if (field == 1) dstp[(size_t)(height - 1) * pitch + xx] = dstp[(size_t)(height - 2) * pitch + xx];
-            else            dstp[xx] = dstp[pitch + xx];
-        }
-        return;
-    }
-    if (r > nrows) return;
-    const int y = (2 - field) + 2 * r;
-    if (y >= height - 1) return;
-    const int peak = k.peak, neutral = k.neutral, sh = k.shift, sh2 = 2 + k.shift;
-    const int nt4 = (uint16_t)((nt << sh) * 4), nt7 = (uint16_t)((nt << sh) * 7), nt8 = (uint16_t)((nt << sh) * 8);
-    const int three = 3 << sh, nine = 9 << sh;
-    uint16_t *top = dstp + (size_t)(y - 1) * pitch, *mid = top + pitch, *bot = mid + pitch;
-    const uint16_t *ot = P.c[pl] + (size_t)(y - 1) * pitch, *ob = ot + 2 * (size_t)pitch;
-    uint16_t *dm = P.a[pl] + (size_t)y * pitch;
-    for (int x = 0; x < width; x++)
-    {
-        int dir = dm[x];
-        const int lim = k.limlut[iabs16(dir - neutral) >> sh2];
-        const int avg = ((int)top[x] + (int)bot[x] + 1) >> 1;
-        if (dir == peak || (iabs16((int)dm[x] - (int)dm[x - 1]) > lim && iabs16((int)dm[x] - (int)dm[x + 1]) > lim))
-        {
-            mid[x] = (uint16_t)avg;
-            if (dir != peak) dm[x] = (uint16_t)neutral;
-            continue;
-        }
-        if (lim < nine)
-        {
-            const int sum = ((int)top[x - 1] + (int)top[x] + (int)top[x + 1] + (int)bot[x - 1] + (int)bot[x] + (int)bot[x + 1]) >> sh;
-            auto sq = [&](int v) { return (v >> sh) * (v >> sh); };
-            const int sumsq = sq(top[x - 1]) + sq(top[x]) + sq(top[x + 1]) + sq(bot[x - 1]) + sq(bot[x]) + sq(bot[x + 1]);
-            if (6 * sumsq - sum * sum < 576)
-            {
-                mid[x] = (uint16_t)avg;
-                dm[x] = (uint16_t)peak;
-                continue;
-            }
-        }
-        if (x > 1 && x < width - 2 &&
-            (((int)top[x] < max((int)top[x - 2], (int)top[x - 1]) - three && (int)top[x] < max((int)top[x + 2], (int)top[x + 1]) - three &&
-              (int)bot[x] < max((int)bot[x - 2], (int)bot[x - 1]) - three && (int)bot[x] < max((int)bot[x + 2], (int)bot[x + 1]) - three) ||
-             ((int)top[x] > min((int)top[x - 2], (int)top[x - 1]) + three && (int)top[x] > min((int)top[x + 2], (int)top[x + 1]) + three &&
-              (int)bot[x] > min((int)bot[x - 2], (int)bot[x - 1]) + three && (int)bot[x] > min((int)bot[x + 2], (int)bot[x + 1]) + three)))
-        {
-            mid[x] = (uint16_t)avg;
-            dm[x] = (uint16_t)neutral;
-            continue;
-        }
-        dir = (dir - neutral + (1 << (sh2 - 1))) >> sh2;
-        int val = avg;
-        const int startu = (dir - 2 < 0) ? max(-x + 1, max(dir - 2, -width + 2 + x)) : min(x - 1, min(dir - 2, width - 2 - x));
-        const int stopu = (dir + 2 < 0) ? max(-x + 1, max(dir + 2, -width + 2 + x)) : min(x - 1, min(dir + 2, width - 2 - x));
-        int mn = nt8;
-        const int here = dm[x];
-        auto near = [&](const uint16_t *row, int i) { return row[i] != peak && iabs16((int)row[i] - here) <= lim; };
-        for (int u = startu; u <= stopu; u++)
-        {
-            const int diff = sad3w(top, x, bot, x - u) + sad3w(bot, x, top, x + u);
-            if (!(diff < mn && (near(ot, x - 1 + u) || near(ot, x + u) || near(ot, x + 1 + u)) &&
-                  (near(ob, x - 1 - u) || near(ob, x - u) || near(ob, x + 1 - u))))
-                continue;
-            const int h0 = u >> 1, h1 = (u + 1) >> 1;
-            const int diff2 = sad3w(top, x + h0, bot, x - h0);
-            if (!(diff2 < nt4 &&
-                  (((iabs16((int)ot[x + h0] - (int)ob[x - h0]) <= lim || iabs16((int)ot[x + h0] - (int)ob[x - h1]) <= lim) && ot[x + h0] != peak) ||
-                   ((iabs16((int)ot[x + h1] - (int)ob[x - h0]) <= lim || iabs16((int)ot[x + h1] - (int)ob[x - h1]) <= lim) && ot[x + h1] != peak))))
-                continue;
-            if ((iabs16(here - (int)ot[x + h0]) <= lim || iabs16(here - (int)ot[x + h1]) <= lim) &&
-                (iabs16(here - (int)ob[x - h0]) <= lim || iabs16(here - (int)ob[x - h1]) <= lim))
-            {
-                val = ((int)top[x + h0] + (int)top[x + h1] + (int)bot[x - h0] + (int)bot[x - h1] + 2) >> 2;
-                mn = diff;
-                dir = u;
-            }
-        }
-        if (mn != nt8)
-        {
-            mid[x] = (uint16_t)val;
-            dm[x] = (uint16_t)(neutral + (dir << sh2));
-            continue;
-        }
-        const int lo = min((int)top[x], (int)bot[x]), hi = max((int)top[x], (int)bot[x]);
-        const int d = pl == 0 ? 4 : 2;
-        const int su = max(-x + 1, -d), eu = min(width - 2 - x, d);
-        mn = nt7;
-        for (int u = su; u <= eu; u++)
-        {
-            const int h0 = u >> 1, h1 = (u + 1) >> 1;
-            const int p1 = (int)top[x + h0] + (int)top[x + h1];
-            const int p2 = (int)bot[x - h0] + (int)bot[x - h1];
-            const int diff = sad3w(top, x, bot, x - u) + sad3w(bot, x, top, x + u) + iabs16(p1 - p2);
-            if (diff < mn)
-            {
-                const int valt = (p1 + p2 + 2) >> 2;
-                if (valt >= lo && valt <= hi) { val = valt; mn = diff; dir = u; }
-            }
-        }
-        mid[x] = (uint16_t)val;
-        dm[x] = (mn == 7 * nt) ? (uint16_t)neutral : (uint16_t)(neutral + (dir << sh2));      // unshifted 7*nt (:1324)
-    }
-}
-
 // interpolate_lattice in two launches, as for 8-bit samples (eedi2.hip: k_lattice_cand / k_lattice_resolve).  Of all a
 // pixel's tests only one looks at the direction value just written at x-1 (the left-hand half of :1194); everything else
 // - including the whole "outcome B" the pixel takes when that test fails - reads values no pixel of the pass changes.
@@ -1229,8 +1097,7 @@ int Eedi2Engine16::enqueue(const DevPicture *cur, int tff, hbhip_ctx *lc, bool d
     bind(P.a, tmpp); bind(P.c, mskp);
     HBHIP_LAUNCH(lc, "eedi2_16_small_gaps", q_small_gaps, grid(srcp, false), blk, 0, P, k);
     bind(P.a, mskp); bind(P.b, srcp); bind(P.c, tmpp);
-    static const bool one_sample_calc_dir = getenv("HBHIP_EEDI2_16_OLD_CALCDIR") != nullptr;     // A/B switch
-    if (par_.maximum_search_distance <= QHALO - 2 && !one_sample_calc_dir)
+    if (par_.maximum_search_distance <= QHALO - 2)
         HBHIP_LAUNCH(lc, "eedi2_16_calc_directions", q_calc_dir_rows<2>, dim3((srcp.stride[0] / 2 + QW - 1) / QW, (srcp.height[0] + 1) / 2, 3),
                      dim3(QW), 0, P, k, par_.maximum_search_distance, par_.noise_threshold);
     else
@@ -1268,17 +1135,10 @@ int Eedi2Engine16::enqueue(const DevPicture *cur, int tff, hbhip_ctx *lc, bool d
     bind(P.a, tmp2p); bind(P.b, dst2p); bind(P.c, tmp2p2);
     {
         const int nrows = (dst2p.height[0] - 1 - y0 + 1) / 2;
-        static const bool serial = getenv("HBHIP_EEDI2_16_SERIAL_LATTICE") != nullptr;     // A/B switch: one thread per row
-        if (serial || !cand_)
-            HBHIP_LAUNCH(lc, "eedi2_16_interpolate_lattice", q_lattice, dim3((nrows + 1 + 63) / 64, 1, 3), dim3(64), 0, P, k, tff,
-                         par_.noise_threshold);
-        else
-        {
-            HBHIP_LAUNCH(lc, "eedi2_16_lattice_candidates", q_lattice_cand, dim3((dst2p.width[0] + 255) / 256, nrows, 3), dim3(256), 0, P, k,
-                         tff, par_.noise_threshold, cand_, cand_pitch_, cand_plane_stride_);
-            HBHIP_LAUNCH(lc, "eedi2_16_lattice_resolve", q_lattice_resolve16, dim3(1, nrows + 1, 3), dim3(LR16_T), 0, P, k, tff,
-                         (const unsigned long long *)cand_, cand_pitch_, cand_plane_stride_);
-        }
+        HBHIP_LAUNCH(lc, "eedi2_16_lattice_candidates", q_lattice_cand, dim3((dst2p.width[0] + 255) / 256, nrows, 3), dim3(256), 0, P, k,
+                     tff, par_.noise_threshold, cand_, cand_pitch_, cand_plane_stride_);
+        HBHIP_LAUNCH(lc, "eedi2_16_lattice_resolve", q_lattice_resolve16, dim3(1, nrows + 1, 3), dim3(LR16_T), 0, P, k, tff,
+                     (const unsigned long long *)cand_, cand_pitch_, cand_plane_stride_);
     }
     if (par_.post_processing == 1 || par_.post_processing == 3)
     {
@@ -1321,8 +1181,7 @@ int Eedi2Engine16::enqueue(const DevPicture *cur, int tff, hbhip_ctx *lc, bool d
 // for a 12 ms step of 32 fields).  The per-kernel profiler needs individual launches and bypasses the graph.
 int Eedi2Engine16::run(const DevPicture *cur, int tff)
 {
-    static const bool no_graph = getenv("HBHIP_EEDI2_16_NO_GRAPH") != nullptr;          // A/B switch
-    if (ctx_->profile || !use_graph_ || no_graph) return enqueue(cur, tff, ctx_, true, true);
+    if (ctx_->profile || !use_graph_) return enqueue(cur, tff, ctx_, true, true);
     int rc = enqueue(cur, tff, ctx_, true, false);
     if (rc != HBHIP_OK) return rc;
     hipGraphExec_t &exec = graph_[tff ? 1 : 0];

@@ -717,7 +717,11 @@ int hbhip_filter_submit_async(hbhip_filter *f, const hbhip_host_frame *in, const
             out->stride[c] < o->width[c] * o->bps)
             rc = HBHIP_ERR_ARG;
     auto fail = [&](int code) {
-        f->abandon_input(pic);
+        // copies of the caller's `in` / `out` may be in flight: nothing of them may outlive this call
+        (void)hipStreamSynchronize(ctx->up_stream);
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamSynchronize(ctx->down_stream);
+        if (pic) f->abandon_input(pic);            // (already handed back once the kernels were queued)
         f->recycle_output(o);
         ctx->sync_ev_put(ev);
         ctx->sync_ev_put(done);
@@ -738,6 +742,7 @@ int hbhip_filter_submit_async(hbhip_filter *f, const hbhip_host_frame *in, const
     rc = f->process_pair(pic, o);
     if (rc != HBHIP_OK) return fail(rc);
     hbhip_pic_release(pic, f->ctx);                // idle event behind the kernels that read it
+    pic = nullptr;
     ASYNC_CHECK(hipEventRecord(ev, ctx->stream));
     ASYNC_CHECK(hipStreamWaitEvent(ctx->down_stream, ev, 0));
     for (int c = 0; c < 3; c++)

@@ -997,7 +997,6 @@ public:
                     if ((int)((float)d * wft) == 127) diff_cap[c] = d;
                     break;
                 }
-            if (getenv("HBHIP_NLM_NOFAST")) diff_cap[c] = -1;
         }
         if (any_pre)
         {

@@ -595,7 +595,7 @@ public:
     // up to LS_FRAMES frames per launch when every plane uses a 3x3 kernel on 8-bit samples
     int process_many(DevPicture *const *ins, DevPicture *const *outs, int n) override
     {
-        bool rows3 = in_geo.bps == 1 && getenv("HBHIP_LAPSHARP_OLD") == nullptr;
+        bool rows3 = in_geo.bps == 1;
         for (int c = 0; c < 3; c++) rows3 &= LAP_TABLE[par.kernel[c]].size == 3;
         if (!rows3) return SimpleFilter::process_many(ins, outs, n);
         for (int at = 0; at < n; at += LS_FRAMES)
@@ -633,7 +633,7 @@ public:
     int process(DevPicture *in, DevPicture *out) override
     {
         if (in_geo.bps == 1 && LAP_TABLE[par.kernel[0]].size == 3 && LAP_TABLE[par.kernel[1]].size == 3 &&
-            LAP_TABLE[par.kernel[2]].size == 3 && getenv("HBHIP_LAPSHARP_OLD") == nullptr)
+            LAP_TABLE[par.kernel[2]].size == 3)
         {
             DevPicture *i1[1] = { in }, *o1[1] = { out };
             return process_many(i1, o1, 1);
@@ -691,7 +691,7 @@ public:
     // the rows kernel takes 8-bit planes with sizes up to 9 whose rows are dword aligned
     bool rows_ok(const DevPicture *in, const DevPicture *out) const
     {
-        if (in_geo.bps != 1 || getenv("HBHIP_BLUR_OLD")) return false;
+        if (in_geo.bps != 1) return false;
         for (int c = 0; c < 3; c++)
         {
             if (par.amount[c] && par.size[c] / 2 > BR_MAX_STEPS) return false;

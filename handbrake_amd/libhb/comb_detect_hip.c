@@ -176,11 +176,11 @@ static hb_buffer_t *overlay_copy(hb_filter_private_t *pv, hb_buffer_t *src)
     {
         const AVPixFmtDescriptor *desc = av_pix_fmt_desc_get(pv->input.pix_fmt);
         hbhip_frame *dst = NULL;
-        if (desc == NULL ||
-            hbhip_frame_alloc(hbhip_host_ctx(), src->f.width, src->f.height, desc->comp[0].depth,
-                              desc->log2_chroma_w, desc->log2_chroma_h, &dst) != HBHIP_OK)
-            return NULL;
-        hbhip_host_ctx_release();
+        if (desc == NULL) return NULL;
+        const int arc = hbhip_frame_alloc(hbhip_host_ctx(), src->f.width, src->f.height, desc->comp[0].depth,
+                                          desc->log2_chroma_w, desc->log2_chroma_h, &dst);
+        hbhip_host_ctx_release();                       /* the frame holds its own reference to the context */
+        if (arc != HBHIP_OK) return NULL;
         hbhip_dev_frame d;
         hbhip_frame_describe(dst, &d, NULL, NULL);
         if (hbhip_frame_copy(dst, fr) != HBHIP_OK || hbhip_comb_detect_overlay_dev(pv->dev, &d, pw, ph) != HBHIP_OK)

@@ -128,6 +128,55 @@ def test_decomb_in_a_chain_batch(built, w, h, mode, combed):
         ctx.close()
 
 
+@pytest.mark.parametrize("profiled", [False, True], ids=["plain", "profiled"])
+@pytest.mark.parametrize("mode,postproc,selective", [(31, 1, False), (31, 2, False), (15, 3, False), (63, 1, True), (24, 0, False)])
+def test_decomb_eedi2_in_a_chain_batch(built, mode, postproc, selective, profiled):
+    """EEDI2 modes inside a fused chain: the fields of a batch are queued in the engine (a slot each) and run together,
+    the blends that read their guesses go out behind them.  20 frames in one call = 40 fields with bob: more than the
+    engine holds, so it is flushed in the middle of the batch; selective mode mixes EEDI2 frames with plain copies
+    and blend-only frames; with the per-kernel profiler on, everything runs on one stream."""
+    import torch
+    w, h, n = 322, 184, 20
+    frames = synth.stream("interlaced", w, h, n)
+    cmb = ([2, 1, 0, 2, 0, 1, 2, 2, 0, 2] * 2)[:n] if selective else None
+    want = os_.decomb_eedi2_stream(frames, dict(mode=mode, postproc=postproc), flags=TFF, combed=cmb)
+    ctx = hip.Ctx(0)
+    dec = hip.DecombDevice(ctx, w, h, mode=mode, postproc=postproc)
+    stage = hip.DeviceFilter(ctx, dec.h)
+    dec.h = None
+    chain = hip.Chain(ctx, [stage])
+    try:
+        if profiled:
+            ctx.profile(True)
+        dev_in = [[torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in f] for f in frames]
+        cap = 2 * n + 2
+        outs = [[torch.zeros((h, w), dtype=torch.uint8, device="cuda"),
+                 torch.zeros((h // 2, w // 2), dtype=torch.uint8, device="cuda"),
+                 torch.zeros((h // 2, w // 2), dtype=torch.uint8, device="cuda")] for _ in range(cap)]
+        torch.cuda.synchronize()
+        got, t = [], 0
+        for b in (n - 3, 3):
+            arr_in = (hip.DevFrame * b)(*[hip.dev_frame(dev_in[t + i]) for i in range(b)])
+            arr_out = (hip.DevFrame * cap)(*[hip.dev_frame(o) for o in outs])
+            k = chain.process_dev(arr_in, arr_out, tag0=t, flags=[TFF] * b, combed=(cmb[t:t + b] if cmb else [2] * b))
+            chain.sync()
+            got += [[p.cpu().numpy().copy() for p in outs[i]] for i in range(k)]
+            t += b
+        arr_out = (hip.DevFrame * cap)(*[hip.dev_frame(o) for o in outs])
+        k = chain.flush_dev(arr_out)
+        chain.sync()
+        got += [[p.cpu().numpy().copy() for p in outs[i]] for i in range(k)]
+        assert len(got) == len(want)
+        for i in range(len(want)):
+            for c in range(3):
+                np.testing.assert_array_equal(got[i][c], want[i]["planes"][c], err_msg=f"frame {i} plane {c}")
+    finally:
+        if profiled:
+            ctx.profile(False)
+        chain.close()
+        ctx.close()
+
+
 @pytest.mark.parametrize("model", ["interlaced", "progressive", "random"])
 @pytest.mark.parametrize("w,h", [(128, 72), (636, 362), (1920, 1080)])
 @pytest.mark.parametrize("par", [gc.COMB_DEFAULT_PAR, dict(mode=2, spatial_metric=0, motion_thresh=0, spatial_thresh=3, filter_mode=2, block_thresh=20),
