@@ -230,12 +230,12 @@ def measured_hbm_peak(device_index):
     return round(2 * n / (best * 1e-3) / 1e9, 1)
 
 
-def pcie_inclusive(workload, frames_np, scale, n_warm=16, n_in=64):
+def pcie_inclusive(workload, frames_np, scale, n_warm=32, n_in=256):
     """The chain through the hb_filter_object_t surface, host hb_buffer_t in and out (H2D + D2H on the path), driven
     the way libhb drives it: one thread per filter with a fifo in front (filter_loop, work.c:2527-2600), the frames
     the last stage makes consumed as fast as they come (counted and dropped, as an encoder that keeps up would).
-    Timed in the steady state: from the moment the first n_warm frames' outputs are out (allocations, pinned pool,
-    graphs captured) to the end of the stream n_in frames later."""
+    Timed from a warmed-up, quiet pipeline (n_warm frames in, their outputs out as far as the batching stages let
+    them) to the end of the stream n_in frames later, EOF drain included."""
     from handbrake_amd import hbrt, hip
     chain = [("hb_filter_hip_upload", ""), ("hb_filter_decomb_hip", "mode=31")]
     if workload != "decomb_eedi2":
@@ -252,18 +252,26 @@ def pcie_inclusive(workload, frames_np, scale, n_warm=16, n_in=64):
         with hbrt.Chain(hip.filters(), chain, w, h) as ch:
             for i in range(n_warm):
                 ch.push(seq[i], start=i * 3003, stop=(i + 1) * 3003, flags=8)
-            # decomb holds one frame back, NLMeans looks one ahead: two output frames per input frame, four late
-            want = 2 * n_warm - 4
-            t_wait = time.perf_counter()
-            while ch.produced() < want and time.perf_counter() - t_wait < 60:
-                time.sleep(0.0005)
+            # decomb and NLMeans gather batches and the download adapter keeps copies in flight, so part of the warm-up
+            # frames stays inside the pipe: wait until it has gone quiet (allocations, pinned pool, slabs all made)
+            t_wait, last, t_last = time.perf_counter(), -1, time.perf_counter()
+            while time.perf_counter() - t_wait < 60:
+                n = ch.produced()
+                if n != last:
+                    last, t_last = n, time.perf_counter()
+                elif n > 0 and time.perf_counter() - t_last > 0.1:
+                    break
+                time.sleep(0.002)
             n0 = ch.produced()
             t0 = time.perf_counter()
+            busy0 = [ch.stage_busy_ms(s) for s in range(len(chain))]
             for i in range(n_warm, n_warm + n_in):
                 ch.push(seq[i], start=i * 3003, stop=(i + 1) * 3003, flags=8)
             ch.push_eof()                         # returns when every stage has finished
             dt = time.perf_counter() - t0
             n_out = ch.produced() - n0
+            busy = {chain[s][0].replace("hb_filter_", ""): round((ch.stage_busy_ms(s) - busy0[s]) / (dt * 1e3), 3)
+                    for s in range(len(chain))}
     finally:
         hbrt.set_discard_output(False)
         hbrt.set_threaded(False)
@@ -272,6 +280,7 @@ def pcie_inclusive(workload, frames_np, scale, n_warm=16, n_in=64):
                     "per filter as filter_loop runs them, pinned host hb_buffer_t in and out; H2D / D2H on the "
                     "context's copy streams; output frames dropped as they arrive",
             "pcie_GBps": round((n_out / 2 * frame_bytes(w, h) + n_out * frame_bytes(*(scale or (w, h)))) / dt / 1e9, 2),
+            "stage_thread_busy_fraction": busy,
             "sample": f"{n_in} input frames after {n_warm} of warm-up / {n_out} output frames, {dt:.3f}s wall"}
 
 

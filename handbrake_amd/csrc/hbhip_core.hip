@@ -190,6 +190,23 @@ void PicturePool::release(DevPicture *p, hbhip_ctx *last_user)
 // ---------------------------------------------------------------- copies
 // Uploads carry the caller's row padding too (up to our pitch): a few reference
 // filters read into it (lapsharp.c:145-157 when stride > width).
+// The host frame and the device picture have the same strides and their planes lie one behind the other in both:
+// the whole frame is one contiguous block on either side (hbhip_frame_alloc lays its frames out like hb_frame_buffer_init).
+static bool same_layout(const DevPicture *p, uint8_t *const plane[3], const int stride[3])
+{
+    for (int c = 0; c < 3; c++)
+    {
+        if (stride[c] != p->pitch[c]) return false;
+        if (c && plane[c] - plane[c - 1] != p->plane[c] - p->plane[c - 1]) return false;
+        if (c && p->plane[c] - p->plane[c - 1] != (ptrdiff_t)p->pitch[c - 1] * p->height[c - 1]) return false;
+    }
+    return true;
+}
+static size_t layout_bytes(const DevPicture *p)
+{
+    return (size_t)(p->plane[2] - p->plane[0]) + (size_t)p->pitch[2] * p->height[2];
+}
+
 int hbhip_copy_h2d(hbhip_ctx *ctx, DevPicture *dst, const hbhip_host_frame *src)
 {
     for (int c = 0; c < 3; c++)
@@ -198,12 +215,15 @@ int hbhip_copy_h2d(hbhip_ctx *ctx, DevPicture *dst, const hbhip_host_frame *src)
     if (!done) return ctx->fail(hipErrorOutOfMemory, "hipEventCreate(upload)");
     // whatever still reads the picture's previous contents was queued on ctx->stream before it was recycled
     if (dst->idle_valid) HBHIP_CHECK(ctx, hipStreamWaitEvent(ctx->up_stream, dst->idle, 0));
-    for (int c = 0; c < 3; c++)
-    {
-        const size_t row = (size_t)std::min(src->stride[c], dst->pitch[c]);
-        HBHIP_CHECK(ctx, hipMemcpy2DAsync(dst->plane[c], dst->pitch[c], src->plane[c], src->stride[c],
-                                          row, dst->height[c], hipMemcpyHostToDevice, ctx->up_stream));
-    }
+    if (same_layout(dst, src->plane, src->stride))
+        HBHIP_CHECK(ctx, hipMemcpyAsync(dst->plane[0], src->plane[0], layout_bytes(dst), hipMemcpyHostToDevice, ctx->up_stream));
+    else
+        for (int c = 0; c < 3; c++)
+        {
+            const size_t row = (size_t)std::min(src->stride[c], dst->pitch[c]);
+            HBHIP_CHECK(ctx, hipMemcpy2DAsync(dst->plane[c], dst->pitch[c], src->plane[c], src->stride[c],
+                                              row, dst->height[c], hipMemcpyHostToDevice, ctx->up_stream));
+        }
     // The caller may free or reuse its planes as soon as we return (filter_loop closes buf_in, work.c:2566-2569):
     // wait for THIS copy - not for the kernels other filters have queued.  Once it has completed, work launched
     // on any stream afterwards sees the data.
@@ -526,13 +546,27 @@ int hbhip_frame_alloc(hbhip_ctx *ctx, int width, int height, int depth, int lcw,
     *out = nullptr;
     (void)hipSetDevice(ctx->device);
     std::unique_lock<std::mutex> lk(ctx->frame_lock);
-    for (size_t i = 0; i < ctx->frame_pool.size(); i++)
     {
-        hbhip_frame *fr = ctx->frame_pool[i];
-        if (fr->width == width && fr->height == height && fr->depth == depth && fr->lcw == lcw && fr->lch == lch)
+        // a frame whose last user has finished (its idle event has fired) can be filled at once; one that is still
+        // being read would hold an upload back until the GPU gets there - take such a frame only when the pool has
+        // grown to its bound (the oldest: the likeliest to be free soonest)
+        int same = 0, pick = -1, oldest = -1;
+        for (size_t i = 0; i < ctx->frame_pool.size(); i++)
         {
-            ctx->frame_pool.erase(ctx->frame_pool.begin() + i);
+            hbhip_frame *fr = ctx->frame_pool[i];
+            if (fr->width != width || fr->height != height || fr->depth != depth || fr->lcw != lcw || fr->lch != lch) continue;
+            same++;
+            if (oldest < 0) oldest = (int)i;
+            if (!fr->pic.idle_valid || hipEventQuery(fr->pic.idle) == hipSuccess) { pick = (int)i; break; }
+        }
+        (void)hipGetLastError();                                  // hipErrorNotReady of the queries
+        if (pick < 0 && same >= 48) pick = oldest;
+        if (pick >= 0)
+        {
+            hbhip_frame *fr = ctx->frame_pool[pick];
+            ctx->frame_pool.erase(ctx->frame_pool.begin() + pick);
             fr->refs = 1;
+            fr->ready_valid = false;
             *out = fr;
             return HBHIP_OK;
         }
@@ -543,16 +577,18 @@ int hbhip_frame_alloc(hbhip_ctx *ctx, int width, int height, int depth, int lcw,
     fr->ctx = ctx; fr->width = width; fr->height = height; fr->depth = depth; fr->lcw = lcw; fr->lch = lch;
     PicGeometry g;
     g.set(width, height, depth, lcw, lch);
+    // laid out exactly like hb_frame_buffer_init lays a host frame out (fifo.c:820-881: stride = the row rounded up to
+    // 64 bytes, the planes one behind the other), so that a frame moves between the two in ONE 1-D copy
     size_t off[3], total = 0;
     for (int c = 0; c < 3; c++)
     {
         fr->pic.width[c] = g.pw[c];
         fr->pic.height[c] = g.ph[c];
-        fr->pic.pitch[c] = hbhip_align_up(g.pw[c] * g.bps, 256);
+        fr->pic.pitch[c] = hbhip_align_up(g.pw[c] * g.bps, 64);
         off[c] = total;
         total += (size_t)fr->pic.pitch[c] * g.ph[c];
-        total = (total + 255) & ~(size_t)255;
     }
+    total = (total + 255) & ~(size_t)255;
     fr->pic.bps = g.bps;
     fr->pic.bytes = total;
     if (hipMalloc((void **)&fr->pic.base, total) != hipSuccess)
@@ -620,8 +656,76 @@ int hbhip_frame_upload(hbhip_frame *fr, const hbhip_host_frame *src)
 int hbhip_frame_download(hbhip_frame *fr, const hbhip_host_frame *dst)
 {
     if (!fr || !dst) return HBHIP_ERR_ARG;
-    (void)hipSetDevice(fr->ctx->device);
-    return hbhip_copy_d2h(fr->ctx, dst, &fr->pic);
+    void *token = nullptr;
+    const int rc = hbhip_frame_download_async(fr, dst, &token);
+    return rc != HBHIP_OK ? rc : hbhip_frame_download_wait(fr, token);
+}
+
+int hbhip_frame_mark_ready(hbhip_frame *fr)
+{
+    if (!fr) return HBHIP_ERR_ARG;
+    hbhip_ctx *ctx = fr->ctx;
+    (void)hipSetDevice(ctx->device);
+    if (!fr->ready) HBHIP_CHECK(ctx, hipEventCreateWithFlags(&fr->ready, hipEventDisableTiming));
+    HBHIP_CHECK(ctx, hipEventRecord(fr->ready, ctx->stream));
+    fr->ready_valid = true;
+    return HBHIP_OK;
+}
+
+// D2H on the download stream behind the frame's ready point (or, without one, behind everything queued on the
+// context's stream so far).  Several in flight keep the bus busy while the kernels of later frames run.
+int hbhip_frame_download_async(hbhip_frame *fr, const hbhip_host_frame *dst, void **token)
+{
+    if (!fr || !dst || !token) return HBHIP_ERR_ARG;
+    *token = nullptr;
+    hbhip_ctx *ctx = fr->ctx;
+    (void)hipSetDevice(ctx->device);
+    const DevPicture *src = &fr->pic;
+    for (int c = 0; c < 3; c++)
+        if (dst->plane[c] == nullptr || dst->stride[c] < src->width[c] * src->bps) return HBHIP_ERR_ARG;
+    hipEvent_t ev = ctx->sync_ev_get();
+    if (!ev) return ctx->fail(hipErrorOutOfMemory, "hipEventCreate(download)");
+    auto fail = [&](hipError_t e, const char *what) { ctx->sync_ev_put(ev); return ctx->fail(e, what); };
+    hipError_t e;
+    if (fr->ready_valid) e = hipStreamWaitEvent(ctx->down_stream, fr->ready, 0);
+    else
+    {
+        e = hipEventRecord(ev, ctx->stream);           // the picture's producers are on ctx->stream, all queued by now
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->down_stream, ev, 0);
+    }
+    if (e != hipSuccess) return fail(e, "download: order behind the frame's producers");
+    if (same_layout(src, dst->plane, dst->stride))
+    {
+        e = hipMemcpyAsync(dst->plane[0], src->plane[0], layout_bytes(src), hipMemcpyDeviceToHost, ctx->down_stream);
+        if (e != hipSuccess) return fail(e, "hipMemcpyAsync(download)");
+    }
+    else
+        for (int c = 0; c < 3; c++)
+        {
+            const size_t row = (size_t)src->width[c] * src->bps;
+            e = hipMemcpy2DAsync(dst->plane[c], dst->stride[c], src->plane[c], src->pitch[c], row, src->height[c],
+                                 hipMemcpyDeviceToHost, ctx->down_stream);
+            if (e != hipSuccess)
+            {
+                (void)hipStreamSynchronize(ctx->down_stream);      // planes already queued must not outlive the call
+                return fail(e, "hipMemcpy2DAsync(download)");
+            }
+        }
+    e = hipEventRecord(ev, ctx->down_stream);
+    if (e != hipSuccess) { (void)hipStreamSynchronize(ctx->down_stream); return fail(e, "hipEventRecord(download)"); }
+    *token = ev;
+    return HBHIP_OK;
+}
+
+int hbhip_frame_download_wait(hbhip_frame *fr, void *token)
+{
+    if (!fr || !token) return HBHIP_ERR_ARG;
+    hbhip_ctx *ctx = fr->ctx;
+    (void)hipSetDevice(ctx->device);
+    hipEvent_t ev = (hipEvent_t)token;
+    const hipError_t e = hipEventSynchronize(ev);
+    ctx->sync_ev_put(ev);
+    return e == hipSuccess ? HBHIP_OK : ctx->fail(e, "hipEventSynchronize(download)");
 }
 
 // ---- generic filter surface -------------------------------------------------
@@ -784,6 +888,21 @@ int hbhip_filter_flush(hbhip_filter *f)
 int hbhip_filter_pending(hbhip_filter *f)
 {
     return f ? f->pending() : 0;
+}
+
+int hbhip_filter_defer(hbhip_filter *f, int on)
+{
+    if (!f) return HBHIP_ERR_ARG;
+    (void)hipSetDevice(f->ctx->device);
+    f->defer_launches(on != 0);
+    return HBHIP_OK;
+}
+
+int hbhip_filter_kick(hbhip_filter *f)
+{
+    if (!f) return HBHIP_ERR_ARG;
+    (void)hipSetDevice(f->ctx->device);
+    return f->kick();
 }
 
 void hbhip_filter_destroy(hbhip_filter *f)

@@ -149,6 +149,10 @@ struct hbhip_frame
     DevPicture  pic;
     int         width = 0, height = 0, depth = 8, lcw = 1, lch = 1;
     int         refs = 1;
+    // hbhip_frame_mark_ready: the point of the context's stream behind which the frame's contents are complete -
+    // a download waits for this point, not for whatever other filter threads have queued since
+    hipEvent_t  ready = nullptr;
+    bool        ready_valid = false;
 };
 
 // Geometry of a planar YUV picture.

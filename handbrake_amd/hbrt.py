@@ -53,6 +53,8 @@ def runtime() -> C.CDLL:
         lib.hbh_chain_pending.argtypes = [C.c_void_p]
         lib.hbh_chain_produced.restype = C.c_int
         lib.hbh_chain_produced.argtypes = [C.c_void_p]
+        lib.hbh_chain_stage_busy_ms.restype = C.c_double
+        lib.hbh_chain_stage_busy_ms.argtypes = [C.c_void_p, C.c_int]
         lib.hbh_chain_peek.restype = C.c_int
         lib.hbh_chain_peek.argtypes = [C.c_void_p, C.POINTER(FrameInfo)]
         lib.hbh_chain_pop.restype = C.c_int
@@ -128,6 +130,10 @@ class Chain:
     def produced(self) -> int:
         """Threaded mode: frames the last stage has made so far (callable while the stages run)."""
         return self._rt.hbh_chain_produced(self._h)
+
+    def stage_busy_ms(self, stage: int) -> float:
+        """Threaded mode: milliseconds the stage's thread has spent inside work() so far."""
+        return self._rt.hbh_chain_stage_busy_ms(self._h, stage)
 
     def pop(self):
         """Next output frame, or None for the EOF marker / empty queue."""

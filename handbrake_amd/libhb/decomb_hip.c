@@ -10,6 +10,8 @@
  */
 #include "hbhip_host.h"
 
+#define DECOMB_BATCH 8
+
 struct hb_filter_private_s
 {
     hbhip_decomb_params par;
@@ -17,6 +19,8 @@ struct hb_filter_private_s
     hb_buffer_list_t    props;       /* per queued input frame: its `s` */
     int64_t             next_tag;
     int                 ready;
+    int                 batch;       /* input frames gathered per launch (see decomb_hip_work) */
+    int                 gathered;
     int                 dev_io;
     int                 selective;   /* yadif: deint=interlaced */
     int                 ff_yadif;    /* the Deinterlace (FFmpeg yadif) object below: outputs are progressive */
@@ -104,6 +108,13 @@ static int decomb_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init)
     if (p->mode & DECOMB_BOB)
         init->vrate.num *= 2;                  /* decomb.c:427-430 */
     pv->output = *init;
+    /* 8-bit frames are gathered DECOMB_BATCH at a time: EEDI2 takes the fields of a batch through every pass in one
+     * launch, the blends of a batch are one launch (csrc/decomb.hip) - a frame alone leaves most of the GPU idle.  The
+     * filter answers HB_FILTER_DELAY meanwhile and then emits the batch's frames as one list, the burst pattern of
+     * the reference's own threaded filters (nlmeans.c:548-571). */
+    pv->batch = 1;
+    if (desc->comp[0].depth == 8 && hbhip_filter_defer(pv->dev, 1) == HBHIP_OK)
+        pv->batch = DECOMB_BATCH;
     return 0;
 fail:
     free(pv);
@@ -121,11 +132,22 @@ static void decomb_hip_close(hb_filter_object_t *filter)
     filter->private_data = NULL;
 }
 
-/* Pull the frames made from ONE input frame: the head of pv->props describes it. */
+static void decomb_hip_split_pair(hb_buffer_t *first, hb_buffer_t *second)
+{
+    if (first != NULL && second != NULL)                       /* bob pair, decomb.c:562-569 */
+    {
+        first->s.stop -= (first->s.stop - first->s.start) / 2LL;
+        second->s.start = first->s.stop;
+        second->s.new_chap = 0;
+    }
+}
+
+/* Pull every finished frame.  The frames made from one input frame carry its tag (<< 1, | 1 for the second of a bob
+ * pair); the input frames' properties wait in pv->props in order. */
 static int decomb_hip_collect(hb_filter_private_t *pv, hb_buffer_list_t *list)
 {
-    hb_buffer_t *first = NULL, *second = NULL;
-    hb_buffer_t *props = hb_buffer_list_rem_head(&pv->props);
+    hb_buffer_t *first = NULL, *second = NULL, *props = NULL;
+    int64_t cur = -1;
     while (hbhip_filter_pending(pv->dev) > 0)
     {
         int64_t tag = 0;
@@ -136,6 +158,14 @@ static int decomb_hip_collect(hb_filter_private_t *pv, hb_buffer_list_t *list)
             hb_error("decomb(hip): pull failed");
             hb_buffer_close(&props);
             return -1;
+        }
+        if ((tag >> 1) != cur)                                 /* the next input frame's outputs begin */
+        {
+            decomb_hip_split_pair(first, second);
+            first = second = NULL;
+            hb_buffer_close(&props);
+            props = hb_buffer_list_rem_head(&pv->props);
+            cur = tag >> 1;
         }
         if (props != NULL)
             hb_buffer_copy_props(out, props);                  /* decomb.c:555 */
@@ -149,12 +179,7 @@ static int decomb_hip_collect(hb_filter_private_t *pv, hb_buffer_list_t *list)
         if (tag & 1) second = out; else first = out;
         hb_buffer_list_append(list, out);
     }
-    if (first != NULL && second != NULL)                       /* bob pair, decomb.c:562-569 */
-    {
-        first->s.stop -= (first->s.stop - first->s.start) / 2LL;
-        second->s.start = first->s.stop;
-        second->s.new_chap = 0;
-    }
+    decomb_hip_split_pair(first, second);
     hb_buffer_close(&props);
     return 0;
 }
@@ -214,6 +239,16 @@ static int decomb_hip_work(hb_filter_object_t *filter, hb_buffer_t **buf_in, hb_
     {
         pv->ready = 1;
         return HB_FILTER_DELAY;                                /* decomb.c:597-605 */
+    }
+    if (pv->batch > 1)
+    {
+        if (++pv->gathered < pv->batch) return HB_FILTER_DELAY;
+        pv->gathered = 0;
+        if (hbhip_filter_kick(pv->dev) != HBHIP_OK)            /* the gathered frames' launches */
+        {
+            hb_error("decomb(hip): launch failed");
+            return HB_FILTER_FAILED;
+        }
     }
     if (decomb_hip_collect(pv, &list) != 0)
     {

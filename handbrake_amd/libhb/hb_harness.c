@@ -14,15 +14,20 @@
 #include "hb_harness.h"
 
 #include <pthread.h>
+#include <time.h>
 
 #define HBH_MAX_STAGES 32
 
 /* threaded mode: a fifo in front of every stage, one thread per stage (filter_loop, work.c:2527-2600) */
+/* bounded like libhb's: filter fifos hold FIFO_MINI = 4 buffers (work.c:46, 2113, 2181); a producer waits until
+ * there is room and then pushes its whole output list (hb_fifo_full_wait + hb_fifo_push, work.c:2577-2586) */
+#define HBH_FIFO_CAP 4
 typedef struct
 {
     pthread_mutex_t lock;
-    pthread_cond_t  cond;
+    pthread_cond_t  cond, room;
     hb_buffer_t    *head, *tail;
+    int             count;
 } hbh_fifo_t;
 
 struct hbh_chain_s
@@ -33,6 +38,7 @@ struct hbh_chain_s
     int                 thread_live[HBH_MAX_STAGES];
     pthread_mutex_t     out_lock;
     int                 discard, produced;  /* threaded mode: drop finished frames / how many the last stage has made */
+    double              busy_ms[HBH_MAX_STAGES];   /* threaded mode: time each stage's thread spent inside work() */
     int                 nstages;
     hb_filter_object_t *stage[HBH_MAX_STAGES];
     int                 done[HBH_MAX_STAGES];
@@ -65,12 +71,12 @@ static int g_discard = 0;            /* threaded mode: count and drop the last s
 void hbh_set_threaded(int on) { g_threaded = on; }
 void hbh_set_discard_output(int on) { g_discard = on; }
 
-static void fifo_put(hbh_fifo_t *q, hb_buffer_t *b)
+static void fifo_put(hbh_fifo_t *q, hb_buffer_t *list)        /* a buffer or a ->next list of them */
 {
     pthread_mutex_lock(&q->lock);
-    b->next = NULL;
-    if (q->tail) q->tail->next = b; else q->head = b;
-    q->tail = b;
+    while (q->count >= HBH_FIFO_CAP) pthread_cond_wait(&q->room, &q->lock);
+    if (q->tail) q->tail->next = list; else q->head = list;
+    for (hb_buffer_t *b = list; b != NULL; b = b->next) { q->tail = b; q->count++; }
     pthread_cond_signal(&q->cond);
     pthread_mutex_unlock(&q->lock);
 }
@@ -83,6 +89,7 @@ static hb_buffer_t *fifo_get(hbh_fifo_t *q)
     q->head = b->next;
     if (q->head == NULL) q->tail = NULL;
     b->next = NULL;
+    if (--q->count < HBH_FIFO_CAP) pthread_cond_signal(&q->room);
     pthread_mutex_unlock(&q->lock);
     return b;
 }
@@ -100,19 +107,26 @@ static void *stage_loop(void *pv)                 /* filter_loop (work.c:2527-26
     {
         hb_buffer_t *in = fifo_get(&c->fifo[s]), *out = NULL;
         const int eof_in = (in->s.flags & HB_BUF_FLAG_EOF) != 0;
+        struct timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
         int status = f->work(f, &in, &out);
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        c->busy_ms[s] += (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
         if (in != NULL) hb_buffer_close(&in);
         if (status == HB_FILTER_FAILED)
         {
             c->failed = 1;
             if (out == NULL) out = hb_buffer_eof_init();      /* let the stages behind finish */
         }
+        if (out != NULL && s + 1 < c->nstages)
+        {
+            fifo_put(&c->fifo[s + 1], out);
+            out = NULL;
+        }
         while (out != NULL)
         {
             hb_buffer_t *next = out->next;
             out->next = NULL;
-            if (s + 1 < c->nstages) fifo_put(&c->fifo[s + 1], out);
-            else
             {
                 pthread_mutex_lock(&c->out_lock);
                 if (!(out->s.flags & HB_BUF_FLAG_EOF)) c->produced++;
@@ -137,6 +151,7 @@ static void start_threads(hbh_chain_t *c)
     {
         pthread_mutex_init(&c->fifo[s].lock, NULL);
         pthread_cond_init(&c->fifo[s].cond, NULL);
+        pthread_cond_init(&c->fifo[s].room, NULL);
     }
     for (int s = 0; s < c->nstages; s++)
     {
@@ -386,6 +401,11 @@ int hbh_chain_push_eof(hbh_chain_t *c)
     else
         run_from(c, 0, hb_buffer_eof_init());
     return c->failed ? -2 : 0;
+}
+
+double hbh_chain_stage_busy_ms(hbh_chain_t *c, int stage)
+{
+    return (c == NULL || stage < 0 || stage >= c->nstages) ? 0.0 : c->busy_ms[stage];
 }
 
 int hbh_chain_produced(hbh_chain_t *c)

@@ -45,6 +45,8 @@ void hbh_set_threaded(int on);
  * encoder) and only count them: hbh_chain_produced() = frames made so far, callable while the stages run. */
 void hbh_set_discard_output(int on);
 int  hbh_chain_produced(hbh_chain_t *c);
+/* threaded chains: milliseconds stage's thread has spent inside its filter's work() so far (which stage a pipeline waits for) */
+double hbh_chain_stage_busy_ms(hbh_chain_t *c, int stage);
 /* Colour description of the source for chains opened from now on (init->color_*; AVCOL_* numbers,
  * range 1 = tv, 2 = pc).  Default bt709 / tv. */
 void hbh_set_source_color(int prim, int transfer, int matrix, int range);

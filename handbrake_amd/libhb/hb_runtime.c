@@ -360,6 +360,12 @@ void hbhip_rt_set_alloc_hooks(void *(*alloc)(size_t), void (*release)(void *, si
     g_big_free = release;
 }
 
+/* libhb's hb_buffer_init does not clear its payload (fifo.c: av_malloc); this stand-in does, so that whatever the
+ * reference's filters read from row padding is the same from run to run.  A caller that is about to overwrite the whole
+ * payload (the download adapter: a DMA fills it) says so for its next buffer and saves a pass over the memory. */
+static __thread int t_skip_clear = 0;
+void hbhip_rt_next_buffer_uninitialised(void) { t_skip_clear = 1; }
+
 hb_buffer_t *hb_buffer_init(int size)
 {
     hb_buffer_t *b = calloc(1, sizeof(*b));
@@ -375,8 +381,9 @@ hb_buffer_t *hb_buffer_init(int size)
         }
         if (b->data == NULL) b->data = av_malloc(b->alloc);
         if (b->data == NULL) { free(b); return NULL; }
-        memset(b->data, 0, b->alloc);
+        if (!t_skip_clear) memset(b->data, 0, b->alloc);
     }
+    t_skip_clear = 0;
     b->s.start = AV_NOPTS_VALUE;
     b->s.stop = AV_NOPTS_VALUE;
     b->s.renderOffset = AV_NOPTS_VALUE;

@@ -96,7 +96,7 @@ static void storage_release(void *p) { hbhip_frame_release((hbhip_frame *)p); }
  * uploads / downloads of the filters are DMA transfers.  (hipHostMalloc itself is far too slow to
  * call per frame.)  Blocks are kept per exact size; at most PIN_KEEP idle blocks are retained.
  * HBHIP_PINNED=0 turns the pool off. */
-#define PIN_KEEP 64
+#define PIN_KEEP 256
 static pthread_mutex_t g_pin_lock = PTHREAD_MUTEX_INITIALIZER;
 static struct { void *p; size_t size; } g_pin_idle[PIN_KEEP];
 static int g_pin_count = 0;
@@ -213,6 +213,7 @@ hb_buffer_t *hbhip_host_pull(hbhip_filter *dev, const hb_filter_init_t *o, int w
             hbhip_frame_release(fr);
             return NULL;
         }
+        hbhip_frame_mark_ready(fr);                    /* what fills it is queued: a download waits for this point only */
         if (tag) *tag = t;
         return hbhip_host_wrap_frame(fr, o, width, height);
     }
@@ -301,7 +302,10 @@ int hbhip_host_simple_work(hbhip_filter *dev, const hb_filter_init_t *output, co
             hbhip_frame_describe(dst, &dd, NULL, NULL);
             rc = hbhip_filter_process_dev(dev, &di, 1, 0, &dd, 1, &n);
             if (rc == HBHIP_OK && n == 1)
+            {
+                hbhip_frame_mark_ready(dst);
                 out = hbhip_host_wrap_frame(dst, output, ow, oh);      /* takes the reference */
+            }
             else
                 hbhip_frame_release(dst);
         }
@@ -360,11 +364,20 @@ int hbhip_host_simple_work(hbhip_filter *dev, const hb_filter_init_t *output, co
 
 /* ---- adapters: host <-> device at the ends of a run of HIP filters ----------------------
  * (the reference's analogue is HB_FILTER_ADAPTER_VT, platform/macosx/adapter_vt.c) */
+/* The download adapter keeps DL_DEPTH copies in flight on the context's download stream: the D2H of frame n runs
+ * while the kernels of the frames behind it do, and the filter thread waits for the oldest copy only - the frames in
+ * flight of the reference's own threaded filters (nlmeans.c:464-597, mt_frame_filter.c:45-237); like them it answers
+ * HB_FILTER_DELAY until its pipe is full. */
+#define DL_DEPTH 6
+typedef struct { hb_buffer_t *in, *out; void *token; } dl_slot_t;
+
 struct hb_filter_private_s
 {
     hb_filter_init_t input;
     hb_filter_init_t output;
     int              depth, lcw, lch;
+    dl_slot_t        dl[DL_DEPTH + 1];
+    int              dl_head, dl_count;
 };
 
 static int adapter_init(hb_filter_object_t *filter, hb_filter_init_t *init, int to_device)
@@ -391,9 +404,29 @@ static int adapter_init(hb_filter_object_t *filter, hb_filter_init_t *init, int 
 static int upload_init(hb_filter_object_t *f, hb_filter_init_t *init)   { return adapter_init(f, init, 1); }
 static int download_init(hb_filter_object_t *f, hb_filter_init_t *init) { return adapter_init(f, init, 0); }
 
+/* oldest copy in flight -> its host buffer (NULL on error); the device frame goes back to its pool */
+static hb_buffer_t *dl_collect(hb_filter_private_t *pv)
+{
+    dl_slot_t s = pv->dl[pv->dl_head];
+    pv->dl_head = (pv->dl_head + 1) % (DL_DEPTH + 1);
+    pv->dl_count--;
+    const int rc = hbhip_frame_download_wait(hbhip_host_frame_of(s.in), s.token);
+    hb_buffer_copy_props(s.out, s.in);
+    hb_buffer_close(&s.in);
+    if (rc != HBHIP_OK) hb_buffer_close(&s.out);
+    return s.out;
+}
+
 static void adapter_close(hb_filter_object_t *filter)
 {
-    free(filter->private_data);
+    hb_filter_private_t *pv = filter->private_data;
+    if (pv == NULL) return;
+    while (pv->dl_count > 0)                           /* a cancelled job: drop what is still in the pipe */
+    {
+        hb_buffer_t *o = dl_collect(pv);
+        if (o != NULL) hb_buffer_close(&o);
+    }
+    free(pv);
     filter->private_data = NULL;
 }
 
@@ -432,20 +465,40 @@ static int download_work(hb_filter_object_t *filter, hb_buffer_t **buf_in, hb_bu
     hbhip_frame *fr = hbhip_host_frame_of(in);
     if ((in->s.flags & HB_BUF_FLAG_EOF) || fr == NULL)
     {
-        *buf_out = in;
+        /* drain the pipe in order, then the buffer itself (EOF, or a frame that never was on the device) */
+        hb_buffer_list_t list;
+        hb_buffer_list_clear(&list);
+        while (pv->dl_count > 0)
+        {
+            hb_buffer_t *o = dl_collect(pv);
+            if (o == NULL) { hb_buffer_list_close(&list); return HB_FILTER_FAILED; }
+            hb_buffer_list_append(&list, o);
+        }
+        hb_buffer_list_append(&list, in);
+        *buf_out = hb_buffer_list_clear(&list);
         *buf_in = NULL;
         return (in->s.flags & HB_BUF_FLAG_EOF) ? HB_FILTER_DONE : HB_FILTER_OK;
     }
+#ifndef HBHIP_IN_LIBHB
+    hbhip_rt_next_buffer_uninitialised();               /* the copy fills it (libhb's own hb_buffer_init never clears) */
+#endif
     hb_buffer_t *out = hbhip_host_alloc_out(&pv->output, in->f.width, in->f.height);
     if (out == NULL) return HB_FILTER_FAILED;
     hbhip_host_frame hf;
     hbhip_host_frame_from_buf(&hf, out);
-    if (hbhip_frame_download(fr, &hf) != HBHIP_OK)
+    void *token = NULL;
+    if (hbhip_frame_download_async(fr, &hf, &token) != HBHIP_OK)
     {
         hb_buffer_close(&out);
         return HB_FILTER_FAILED;
     }
-    hb_buffer_copy_props(out, in);
+    dl_slot_t *s = &pv->dl[(pv->dl_head + pv->dl_count) % (DL_DEPTH + 1)];
+    s->in = in; s->out = out; s->token = token;
+    pv->dl_count++;
+    *buf_in = NULL;                                     /* ours until its copy has finished */
+    if (pv->dl_count <= DL_DEPTH) return HB_FILTER_DELAY;
+    out = dl_collect(pv);
+    if (out == NULL) return HB_FILTER_FAILED;
     *buf_out = out;
     return HB_FILTER_OK;
 }

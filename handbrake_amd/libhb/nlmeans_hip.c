@@ -173,9 +173,10 @@ static int nlmeans_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init)
         hb_error("nlmeans(hip): %s", hbhip_strerror(rc));
         goto fail;
     }
+    /* frames per launch: the kernel needs several frames' tiles to fill the GPU.  Like the reference, which works on
+     * `threads` frames at a time (nlmeans.c:548-571), the filter then emits bursts. */
     const char *env = getenv("HBHIP_NLMEANS_BATCH");
-    if (env != NULL && atoi(env) > 0)
-        hbhip_nlmeans_set_batch(pv->dev, atoi(env));
+    hbhip_nlmeans_set_batch(pv->dev, env != NULL && atoi(env) > 0 ? atoi(env) : 8);
 
     hb_buffer_list_clear(&pv->props);
     pv->output = *init;

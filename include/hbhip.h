@@ -113,6 +113,13 @@ int  hbhip_frame_describe(hbhip_frame *fr, hbhip_dev_frame *out, int *width, int
 int  hbhip_frame_copy(hbhip_frame *dst, hbhip_frame *src);                  /* same geometry; stream-ordered D2D */
 int  hbhip_frame_upload(hbhip_frame *fr, const hbhip_host_frame *src);      /* H2D, returns when src is consumed */
 int  hbhip_frame_download(hbhip_frame *fr, const hbhip_host_frame *dst);    /* D2H, synchronous */
+/* The producer of a frame marks the point of the context's stream behind which its contents are complete; a
+ * download then waits for that point only (not for what other filter threads have queued since).  The pipelined
+ * D2H: queue the copy on the download stream and return; `dst` and the frame must stay valid until
+ * hbhip_frame_download_wait(fr, token) has returned.  A few in flight keep the bus busy (the download adapter). */
+int  hbhip_frame_mark_ready(hbhip_frame *fr);
+int  hbhip_frame_download_async(hbhip_frame *fr, const hbhip_host_frame *dst, void **token);
+int  hbhip_frame_download_wait(hbhip_frame *fr, void *token);
 
 /* ---- generic streaming surface of a filter instance ---------------------------
  * Mirrors hb_filter_object_t.work (common.h:1682-1685): push one input frame,
@@ -137,6 +144,12 @@ int  hbhip_filter_wait(hbhip_filter *f, int64_t *tag);      /* oldest submission
 int  hbhip_filter_inflight(hbhip_filter *f);
 int  hbhip_filter_flush(hbhip_filter *f);             /* input ended (HB_BUF_FLAG_EOF) */
 int  hbhip_filter_pending(hbhip_filter *f);           /* frames a pull would return now */
+/* Batching across work() calls: with defer on, a filter that gathers frames for a common launch (decomb / EEDI2:
+ * the fields of several frames per launch, NLMeans) launches nothing until hbhip_filter_kick() - the frames pushed
+ * meanwhile are pending but NOT complete until the kick has been given.  What libhb's filters do with `threads`
+ * frames in flight (nlmeans.c:464-597): answer HB_FILTER_DELAY for a few frames, then emit a burst. */
+int  hbhip_filter_defer(hbhip_filter *f, int on);
+int  hbhip_filter_kick(hbhip_filter *f);
 void hbhip_filter_destroy(hbhip_filter *f);
 /* Output geometry (cropscale / rotate change it; init->geometry, cropscale.c:170-178). */
 int  hbhip_filter_out_geometry(hbhip_filter *f, int *width, int *height);

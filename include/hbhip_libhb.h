@@ -277,6 +277,7 @@ void         hb_compute_chroma_smoothing_coefficient(uint32_t chroma_coeffs[2][4
 void         hbhip_rt_set_storage_hooks(void (*retain)(void *), void (*release)(void *));
 /* stand-in runtime only: allocator for frame-sized buffer payloads (page-locked pool) */
 void         hbhip_rt_set_alloc_hooks(void *(*alloc)(size_t), void (*release)(void *, size_t));
+void         hbhip_rt_next_buffer_uninitialised(void);   /* the next hb_buffer_init on this thread leaves its payload as it is */
 
 void         hb_buffer_list_append(hb_buffer_list_t *list, hb_buffer_t *buf);
 void         hb_buffer_list_prepend(hb_buffer_list_t *list, hb_buffer_t *buf);
