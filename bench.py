@@ -280,7 +280,7 @@ def pcie_inclusive(workload, frames_np, scale, n_warm=32, n_in=256):
                     "per filter as filter_loop runs them, pinned host hb_buffer_t in and out; H2D / D2H on the "
                     "context's copy streams; output frames dropped as they arrive",
             "pcie_GBps": round((n_out / 2 * frame_bytes(w, h) + n_out * frame_bytes(*(scale or (w, h)))) / dt / 1e9, 2),
-            "stage_thread_busy_fraction": busy,
+            "stage_thread_busy_fraction": busy, "_n_out": n_out, "_dt": dt,
             "sample": f"{n_in} input frames after {n_warm} of warm-up / {n_out} output frames, {dt:.3f}s wall"}
 
 
@@ -356,7 +356,7 @@ def run_nlmeans(args, world, rank, local_rank):
                                  "'valu' prices the same launch against the measured vector-ALU issue rate"},
         }
         if valu_insts:
-            out["roofline"]["valu"] = valu_roofline(valu_insts, avg_s)
+            out["roofline"]["valu"] = valu_roofline(valu_insts, avg_s, "nlmeans_plane_n7")
         if world == 1 and not args.no_cpu_baseline and args.depth == 8:
             out["cpu_baseline"] = cpu_baseline_nlmeans(frames_np)
         print(json.dumps(out), flush=True)
@@ -364,24 +364,52 @@ def run_nlmeans(args, world, rank, local_rank):
     ctx.close()
 
 
-def pmc_record(kname, frames_per_launch):
+def pmc_record(kname, units_per_launch):
+    """HBM bytes and VALU instructions per launch from the committed PMC passes (profiles/pmc_traffic.json), scaled from
+    the launch shape they were collected on (`units_per_launch` fields / frames) to this run's."""
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            rec = json.load(open(pmc)).get(kname, {}).get(str(frames_per_launch))
+            recs = json.load(open(pmc)).get(kname, {})
+            rec = recs.get(str(int(round(units_per_launch)))) or (next(iter(recs.values())) if recs else None)
             if rec:
-                return rec.get("hbm_bytes_per_launch"), rec.get("valu_insts_per_launch")
+                k = units_per_launch / float(rec.get("units_per_launch") or units_per_launch)
+                t, v = rec.get("hbm_bytes_per_launch"), rec.get("valu_insts_per_launch")
+                return (None if t is None else t * k), (None if v is None else v * k)
         except Exception:
             pass
     return None, None
 
 
-def valu_roofline(valu_insts, avg_s):
-    """wave64 VALU instructions (SQ_INSTS_VALU of the committed PMC pass) against the issue peak the
-    micro-benchmark tools/valu_rate.hip measured on this GPU type (profiles/r02_valu_rate.json): cycles a
-    SIMD needs per wave64 instruction for the NLMeans kernel's instruction mix."""
+# the device function behind a profiler name, for the kernel's own instruction mix (tools/isa_mix.py)
+ISA_NAMES = {"eedi2_calc_directions": ("r3_eedi2_isa_mix.json", "k_calc_dir_rows<2>"),
+             "eedi2_fill_gaps_2x": ("r3_eedi2_isa_mix.json", "k_fill_gaps_b"),
+             "eedi2_lattice_candidates": ("r3_eedi2_isa_mix.json", "k_lattice_cand_q"),
+             "eedi2_filter_dir_map_2x": ("r3_eedi2_isa_mix.json", "k_dir_map4"),
+             "nlmeans_plane_n7": ("r3_nlmeans_isa_mix.json", "nlmeans_lanes_kernel<7, true, 36, false>"),
+             "cropscale_lanczos_fused": ("r3_alias_isa_mix.json", "scale8_up_kernel")}
+
+
+def valu_roofline(valu_insts, avg_s, kname=None):
+    """wave64 VALU instructions (SQ_INSTS_VALU of the committed PMC pass) against the issue peak of the kernel's OWN
+    instruction mix: its text classified by tools/isa_mix.py into the issue classes tools/valu_rate.hip measured on
+    this GPU type (profiles/r02_valu_rate.json).  Without such a file: the NLMeans mix of r02_valu_rate.json."""
     cyc, src = 4.0, "assumed 4 cycles per wave64 instruction (no micro-benchmark result committed)"
     peak = 256 * 4 * 2.4e9 / cyc
+    own = ISA_NAMES.get(kname)
+    if own and os.path.exists(os.path.join(ROOT, "profiles", own[0])):
+        try:
+            ks = json.load(open(os.path.join(ROOT, "profiles", own[0])))["kernels"]
+            rec = next(v for k, v in ks.items() if own[1] in k)
+            peak, cyc = rec["peak_ginst_s"] * 1e9, rec["cyc_per_inst"]
+            src = (f"static instruction mix of {own[1]} (profiles/{own[0]}: {rec['full']} full-rate, {rec['half']} half-rate, "
+                   f"{rec['quarter']} quarter-rate VALU instructions) priced with the per-class issue rates measured by "
+                   f"tools/valu_rate.hip (profiles/r02_valu_rate.json)")
+            return {"insts_per_launch": int(valu_insts), "achieved_ginst_s": round(valu_insts / avg_s / 1e9, 1),
+                    "peak_ginst_s": round(peak / 1e9, 1), "frac": round(valu_insts / avg_s / peak, 4),
+                    "cycles_per_wave_inst": cyc, "peak_source": src}
+        except Exception:
+            pass
     p = os.path.join(ROOT, "profiles", "r02_valu_rate.json")
     if os.path.exists(p):
         try:
@@ -555,7 +583,7 @@ def run_chain(args, world, rank, local_rank):
             ab = d["algorithmic_bytes_per_launch"]
             if ab:
                 achieved = ab / (d["avg_us"] * 1e-6) / 1e9
-                traffic, valu = pmc_record(d["kernel"], int(round(d["frames_per_launch"])))
+                traffic, valu = pmc_record(d["kernel"], d["frames_per_launch"])
                 roof = {"bound": "hbm", "kernel": d["kernel"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                         "launch_us": d["avg_us"], "launches": d["launches"], "share_of_gpu_time": d["share"],
@@ -565,7 +593,7 @@ def run_chain(args, world, rank, local_rank):
                                 "arithmetic (a +-24 step search per edge pixel), see `valu`; a launch covers "
                                 "`frames_per_launch` fields"}
                 if valu:
-                    roof["valu"] = valu_roofline(valu, d["avg_us"] * 1e-6)
+                    roof["valu"] = valu_roofline(valu, d["avg_us"] * 1e-6, d["kernel"])
         per_out = {"chain": 62_208_000, "chain2160": 4 * frame_bytes(W, H) + 3 * frame_bytes(W, H) + 2 * frame_bytes(W, H),
                    "decomb_eedi2": 4 * frame_bytes(W, H)}[args.workload]      # SURVEY §8d, per output frame
         line = {
@@ -601,11 +629,28 @@ def run_chain(args, world, rank, local_rank):
             line["cpu_baseline"] = cpu_baseline_chain(args.workload, frames_np, scale)
         else:
             line["cpu_baseline"] = None
-        if world == 1 and not args.no_pcie:
-            try:
-                line["pcie_inclusive"] = pcie_inclusive(args.workload, frames_np, scale)
-            except Exception as e:                                           # never lose the bench line over it
-                line["pcie_inclusive"] = {"error": repr(e)}
+    # The same chain through the plugin surface, host frames in and out: on EVERY rank at the same time (each on its
+    # own GPU with its own pinned buffers), so that an N-GPU run shows what the host's PCIe root complex and memory
+    # give N streams at once - the resident rate above cannot.
+    pcie = None
+    if not args.no_pcie:
+        os.environ["HBHIP_DEVICE"] = str(local_rank)                        # the drop-ins' shared context (hbhip_registry.c)
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        try:
+            pcie = pcie_inclusive(args.workload, frames_np, scale)
+        except Exception as e:                                               # never lose the bench line over it
+            pcie = {"error": repr(e), "_n_out": 0, "_dt": 0.0}
+        n_all, dt_all = shard.reduce_throughput(float(pcie["_n_out"]), float(pcie["_dt"]), device="cuda")
+        if world > 1 and "error" not in pcie:
+            pcie["this_rank_value"] = pcie["value"]
+            pcie["value"] = round(n_all / dt_all, 2) if dt_all > 0 else None
+            pcie["ranks"] = world
+        pcie.pop("_n_out", None); pcie.pop("_dt", None)
+    if rank == 0:
+        if pcie is not None:
+            line["pcie_inclusive"] = pcie
         print(json.dumps(line), flush=True)
     for ln in lanes:
         ln.close()

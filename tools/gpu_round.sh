@@ -11,7 +11,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd $R
 if [ "$MODE" = "tests" ]; then
-  timeout 400 python -m pytest tests -m gpu -x -q -n 4 "$@" > $OUT/pytest.log 2>&1
+  timeout 600 python -m pytest tests -m gpu -x -q -n 4 "$@" > $OUT/pytest.log 2>&1
   echo "pytest rc=$?" >> $OUT/pytest.log
   tail -5 $OUT/pytest.log
 fi
@@ -31,9 +31,6 @@ timeout 240 python tools/kernel_rooflines.py > $OUT/kernel_rooflines.json 2> $OU
 cd /tmp
 PROF="python $R/bench.py --workload chain --steps 6 --warmup 2 --no-cpu-baseline --no-pcie --no-kernel-timer"
 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $PROF > $OUT/kt.log 2>&1
-# the same workload with the EEDI2 engine ring off (one field at a time, as the per-kernel event timer of bench.py runs
-# it): kernel durations without other kernels sharing the GPU
-HBHIP_EEDI2_SERIAL=1 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_serial -o kt -- $PROF > $OUT/kt_serial.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 240 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -o pmc -- $PROF > $OUT/pmc_$C.log 2>&1
 done

@@ -6,16 +6,18 @@ bench.py's profiler uses.  usage: pmc_to_traffic.py <pmc_summary.json> <source l
 import json
 import sys
 
-# C++ kernel name (as summarize_pmc.py shortens it) -> name of the launch in hbhip's profiler; frames per launch of
-# the chain workload's default batch (16 input frames = 32 fields / output frames)
+# C++ kernel name (as summarize_pmc.py shortens it) -> (name of the launch in hbhip's profiler, units a launch covers on
+# the production path of the default chain workload: 16 input frames = 32 fields per step, the EEDI2 passes in groups of
+# 8 fields (Eedi2Engine::launch), blends / scaler / lapsharp 16 frames, NLMeans 32).  bench.py scales the per-launch
+# figures to the launch shape of its own event-timed pass (units_per_launch is stored with them).
 NAMES = {
-    "k_calc_dir_tile3": ("eedi2_calc_directions", 1), "k_calc_dir_rows": ("eedi2_calc_directions", 1), "k_fill_gaps_c": ("eedi2_fill_gaps_2x", 1),
-    "k_lattice_cand_q": ("eedi2_lattice_candidates", 1), "k_lattice_resolve": ("eedi2_lattice_resolve", 1),
-    "k_mask_fused4": ("eedi2_mask_passes", 1), "k_mark_2x4": ("eedi2_mark_directions_2x", 1),
-    "k_filter_map": ("eedi2_filter_map", 1), "k_post": ("eedi2_post_process", 1), "k_fill_half4": ("eedi2_fill_half", 1),
-    "k_dir_map4": ("eedi2_filter_dir_map (half-height and _2x forms, mean)", 1),
-    "k_dir_map_c": ("eedi2_expand_dir_map (half-height and _2x forms, mean)", 1),
-    "decomb_plane4_kernel": ("decomb_plane", 1), "cropscale_fused6_kernel": ("cropscale_lanczos_fused", 1),
+    "k_calc_dir_rows": ("eedi2_calc_directions", 8), "k_fill_gaps_b": ("eedi2_fill_gaps_2x", 8),
+    "k_lattice_cand_q": ("eedi2_lattice_candidates", 8), "k_lattice_resolve": ("eedi2_lattice_resolve", 8),
+    "k_mark_2x4": ("eedi2_mark_directions_2x", 8),
+    "k_filter_map": ("eedi2_filter_map", 8), "k_post": ("eedi2_post_process", 8),
+    "k_dir_map4": ("eedi2_filter_dir_map_2x", 8),          # half-height and _2x forms, mean
+    "k_dir_map_c": ("eedi2_expand_dir_map_2x", 8),         # half-height and _2x forms, mean
+    "decomb_plane4_kernel": ("decomb_plane", 16), "scale8_up_kernel": ("cropscale_lanczos_fused", 16),
     "lapsharp3_rows_kernel": ("lapsharp_3x3", 16), "copy3_kernel": ("copy_planes", 1),
     "job_table_kernel": ("nlmeans_job_table", 32),
 }
@@ -42,7 +44,7 @@ def main():
         e = {"hbm_bytes_per_launch": rec["hbm_bytes_per_launch"], "raw_fetch_plus_write": rec["hbm_bytes_per_launch_raw"],
              "fetch_size_kib": rec["FETCH_SIZE"]["mean"], "write_size_kib": rec["WRITE_SIZE"]["mean"],
              "correction": "2*FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md HBM section; profiles/r01c_fetch_calibration.json)",
-             "source": label, "kernel_symbol": k}
+             "source": label, "kernel_symbol": k, "units_per_launch": frames}
         if "SQ_INSTS_VALU" in rec:
             e["valu_insts_per_launch"] = rec["SQ_INSTS_VALU"]["mean"]
         if "SQ_INSTS_LDS" in rec:
