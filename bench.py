@@ -230,58 +230,18 @@ def measured_hbm_peak(device_index):
     return round(2 * n / (best * 1e-3) / 1e9, 1)
 
 
-def pcie_inclusive(workload, frames_np, scale, n_warm=32, n_in=256):
-    """The chain through the hb_filter_object_t surface, host hb_buffer_t in and out (H2D + D2H on the path), driven
-    the way libhb drives it: one thread per filter with a fifo in front (filter_loop, work.c:2527-2600), the frames
-    the last stage makes consumed as fast as they come (counted and dropped, as an encoder that keeps up would).
-    Timed from a warmed-up, quiet pipeline (n_warm frames in, their outputs out as far as the batching stages let
-    them) to the end of the stream n_in frames later, EOF drain included."""
-    from handbrake_amd import hbrt, hip
-    chain = [("hb_filter_hip_upload", ""), ("hb_filter_decomb_hip", "mode=31")]
-    if workload != "decomb_eedi2":
-        chain.append(("hb_filter_nlmeans_hip", hip.NLMEANS_MEDIUM))
-        if scale:
-            chain.append(("hb_filter_crop_scale_hip", "width=%d:height=%d" % scale))
-        chain.append(("hb_filter_lapsharp_hip", LAPSHARP))
-    chain.append(("hb_filter_hip_download", ""))
-    seq = [frames_np[i % len(frames_np)] for i in range(n_warm + n_in)]
-    h, w = seq[0][0].shape
-    hbrt.set_threaded(True)
-    hbrt.set_discard_output(True)
-    try:
-        with hbrt.Chain(hip.filters(), chain, w, h) as ch:
-            for i in range(n_warm):
-                ch.push(seq[i], start=i * 3003, stop=(i + 1) * 3003, flags=8)
-            # decomb and NLMeans gather batches and the download adapter keeps copies in flight, so part of the warm-up
-            # frames stays inside the pipe: wait until it has gone quiet (allocations, pinned pool, slabs all made)
-            t_wait, last, t_last = time.perf_counter(), -1, time.perf_counter()
-            while time.perf_counter() - t_wait < 60:
-                n = ch.produced()
-                if n != last:
-                    last, t_last = n, time.perf_counter()
-                elif n > 0 and time.perf_counter() - t_last > 0.1:
-                    break
-                time.sleep(0.002)
-            n0 = ch.produced()
-            t0 = time.perf_counter()
-            busy0 = [ch.stage_busy_ms(s) for s in range(len(chain))]
-            for i in range(n_warm, n_warm + n_in):
-                ch.push(seq[i], start=i * 3003, stop=(i + 1) * 3003, flags=8)
-            ch.push_eof()                         # returns when every stage has finished
-            dt = time.perf_counter() - t0
-            n_out = ch.produced() - n0
-            busy = {chain[s][0].replace("hb_filter_", ""): round((ch.stage_busy_ms(s) - busy0[s]) / (dt * 1e3), 3)
-                    for s in range(len(chain))}
-    finally:
-        hbrt.set_discard_output(False)
-        hbrt.set_threaded(False)
-    return {"value": round(n_out / dt, 2), "unit": "output frames/s", "input_fps": round(n_out / 2 / dt, 2),
-            "path": "hb_filter_object_t chain (hip_upload -> ... -> hip_download) in the libhb stand-in harness, one thread "
-                    "per filter as filter_loop runs them, pinned host hb_buffer_t in and out; H2D / D2H on the "
-                    "context's copy streams; output frames dropped as they arrive",
-            "pcie_GBps": round((n_out / 2 * frame_bytes(w, h) + n_out * frame_bytes(*(scale or (w, h)))) / dt / 1e9, 2),
-            "stage_thread_busy_fraction": busy, "_n_out": n_out, "_dt": dt,
-            "sample": f"{n_in} input frames after {n_warm} of warm-up / {n_out} output frames, {dt:.3f}s wall"}
+def pcie_inclusive(workload, w, h, scale, cfg, device):
+    """The chain through the hb_filter_object_t surface, host hb_buffer_t in and out (H2D + D2H on the path), in a
+    process of its own (handbrake_amd/hostpath.py says why): one thread per filter with libhb's bounded fifos between
+    them (filter_loop, work.c:2527-2600)."""
+    import subprocess
+    cmd = [sys.executable, "-m", "handbrake_amd.hostpath", "--workload", workload, "--width", str(w), "--height", str(h),
+           "--scale", "none" if not scale else "%dx%d" % tuple(scale), "--cfg", str(cfg), "--device", str(device)]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if not lines:
+        return {"error": (r.stderr or "no output")[-400:], "n_out": 0, "seconds": 0.0}
+    return json.loads(lines[-1])
 
 
 def run_nlmeans(args, world, rank, local_rank):
@@ -634,20 +594,18 @@ def run_chain(args, world, rank, local_rank):
     # give N streams at once - the resident rate above cannot.
     pcie = None
     if not args.no_pcie:
-        os.environ["HBHIP_DEVICE"] = str(local_rank)                        # the drop-ins' shared context (hbhip_registry.c)
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
         try:
-            pcie = pcie_inclusive(args.workload, frames_np, scale)
+            pcie = pcie_inclusive(args.workload, W, H, scale, wl["cfg"] + 16 * rank, local_rank)
         except Exception as e:                                               # never lose the bench line over it
-            pcie = {"error": repr(e), "_n_out": 0, "_dt": 0.0}
-        n_all, dt_all = shard.reduce_throughput(float(pcie["_n_out"]), float(pcie["_dt"]), device="cuda")
+            pcie = {"error": repr(e), "n_out": 0, "seconds": 0.0}
+        n_all, dt_all = shard.reduce_throughput(float(pcie.get("n_out", 0)), float(pcie.get("seconds", 0.0)), device="cuda")
         if world > 1 and "error" not in pcie:
             pcie["this_rank_value"] = pcie["value"]
             pcie["value"] = round(n_all / dt_all, 2) if dt_all > 0 else None
             pcie["ranks"] = world
-        pcie.pop("_n_out", None); pcie.pop("_dt", None)
     if rank == 0:
         if pcie is not None:
             line["pcie_inclusive"] = pcie

@@ -705,10 +705,10 @@ __global__ __launch_bounds__(256) void scale8_up_kernel(ScaleBatch8 B)
         for (int rr = 0; rr < nr; rr++)
         {
             const uint32_t d0 = s_src[rr][dq], d1 = s_src[rr][dq + 1], d2 = s_src[rr][dq + 2];
-            int s = dot2(__builtin_amdgcn_perm(d1, d0, sel01), c01, 0);
+            int s = dot2(__builtin_amdgcn_perm(d1, d0, sel01), c01, 32);             // + 32: the rounding of (s + 32) >> 6
             s = dot2(__builtin_amdgcn_perm(d1, d0, sel23), c23, s);
             s = dot2(__builtin_amdgcn_perm(d2, d1, sel01), c45, s);
-            const int h = min(max((s + 32) >> 6, 0), 65535);         // the 16-bit plane between the passes
+            const int h = min(max(s >> 6, 0), 65535);                // the 16-bit plane between the passes
             hp[(size_t)(rr >> 1) * (2 * SU_TW) + (rr & 1)] = (uint16_t)(h ^ 0x8000);    // biased, as zimg holds it
         }
     }
@@ -719,7 +719,10 @@ __global__ __launch_bounds__(256) void scale8_up_kernel(ScaleBatch8 B)
     {
         const int ob = __builtin_amdgcn_readfirstlane(P.by[y] - rmin);
         const uint32_t c01 = P.qy[3 * (size_t)y], c23 = P.qy[3 * (size_t)y + 1], c45 = P.qy[3 * (size_t)y + 2];
-        int acc[4] = {0, 0, 0, 0};
+        // fx_to8(fx_round14(acc)) = clamp((((acc + 8192) >> 14) + 32768 + 128) >> 8, 0, 255) with the 16-bit clamp folded in
+        // (a value outside 0 .. 65535 lands outside 0 .. 255 either way) = clamp((acc + K) >> 22, 0, 255): the sums start at K
+        constexpr int K = 8192 + (32768 << 14) + (128 << 14);       // |acc| < 2^30, so acc + K stays inside int
+        int acc[4] = {K, K, K, K};
         const uint4 *hq = reinterpret_cast<const uint4 *>(&s_h[ob >> 1][4 * lane]);
         auto tap = [&](int pair_row, uint32_t cpair) {
             const uint4 q = hq[(size_t)pair_row * (SU_TW / 4)];
@@ -734,7 +737,7 @@ __global__ __launch_bounds__(256) void scale8_up_kernel(ScaleBatch8 B)
         }
         uint32_t out = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) out |= (uint32_t)fx_to8(fx_round14(acc[k])) << (8 * k);
+        for (int k = 0; k < 4; k++) out |= (uint32_t)min(max(acc[k] >> 22, 0), 255) << (8 * k);
         uint8_t *d = B.dst[f][pl] + (size_t)y * B.dpitch[pl] + xq;
         if (xq + 3 < P.dw && (((uintptr_t)d) & 3) == 0) *reinterpret_cast<uint32_t *>(d) = out;
         else for (int k = 0; k < 4 && xq + k < P.dw; k++) d[k] = (uint8_t)(out >> (8 * k));

@@ -18,27 +18,11 @@ VARIANTS = {
     "copy_2160": ([FULL[0], FULL[-1]], 3840, 2160),
 }
 
-def run(name, n_warm=32, n_in=192):
+def run(name):
+    from handbrake_amd import hostpath
     chain, w, h = VARIANTS[name]
-    frames = synth.stream("interlaced", w, h, 4, cfg=3)
-    seq = [frames[i % 4] for i in range(n_warm + n_in)]
-    hbrt.set_threaded(True); hbrt.set_discard_output(True)
-    try:
-        with hbrt.Chain(hip.filters(), chain, w, h) as ch:
-            for i in range(n_warm):
-                ch.push(seq[i], start=i * 3003, stop=(i + 1) * 3003, flags=8)
-            time.sleep(0.5)
-            n0 = ch.produced(); t0 = time.perf_counter()
-            busy0 = [ch.stage_busy_ms(s) for s in range(len(chain))]
-            for i in range(n_warm, n_warm + n_in):
-                ch.push(seq[i], start=i * 3003, stop=(i + 1) * 3003, flags=8)
-            ch.push_eof()
-            dt = time.perf_counter() - t0
-            n = ch.produced() - n0
-            busy = {chain[s][0].replace("hb_filter_", ""): round((ch.stage_busy_ms(s) - busy0[s]) / (dt * 1e3), 2) for s in range(len(chain))}
-    finally:
-        hbrt.set_discard_output(False); hbrt.set_threaded(False)
-    print(json.dumps({"variant": name, "out_fps": round(n / dt, 1), "in_fps": round(n_in / dt, 1), "busy": busy}), flush=True)
+    r = hostpath.run("chain", w, h, (3840, 2160), chain=chain, n_in=192)
+    print(json.dumps({"variant": name, "out_fps": r["value"], "in_fps": r["input_fps"], "busy": r["stage_thread_busy_fraction"]}), flush=True)
 
 if __name__ == "__main__":
     for v in (sys.argv[1:] or list(VARIANTS)):
