@@ -1728,10 +1728,6 @@ Eedi2Engine::Eedi2Engine(hbhip_ctx *ctx, const PicGeometry &geo, const Eedi2Para
 
 Eedi2Engine::~Eedi2Engine()
 {
-    if (side_) { (void)hipStreamSynchronize(side_->stream); hbhip_ctx_destroy(side_); }
-    if (side_stream_) (void)hipStreamDestroy(side_stream_);
-    if (ev_fork_) (void)hipEventDestroy(ev_fork_);
-    for (hipEvent_t e : ev_group_) if (e) (void)hipEventDestroy(e);
     if (slab_) (void)hipFree(slab_);
     if (work_list_) (void)hipFree(work_list_);
     if (work_count_) (void)hipFree(work_count_);
@@ -1806,27 +1802,6 @@ int Eedi2Engine::init()
             HBHIP_CHECK(ctx_, hipMemsetAsync(deriv_tmp_[i], 0, n, ctx_->stream));
         }
     }
-    // the stream of the mask chain (see launch); without it everything runs on the caller's stream
-    group_ = std::min(std::max(hbhip_dev_int("HBHIP_EEDI2_GROUP", 8), 0), cap_);
-    if (group_ > 0 && group_ < cap_)
-    {
-        // high priority: the chain's small workgroups must not queue up behind the passes' big grids
-        int least = 0, greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        if (hipStreamCreateWithPriority(&side_stream_, hipStreamNonBlocking, greatest) != hipSuccess) { side_stream_ = nullptr; (void)hipGetLastError(); }
-        if (side_stream_ && hbhip_ctx_create_on_stream(ctx_->device, side_stream_, &side_) != HBHIP_OK) side_ = nullptr;
-    }
-    if (side_)
-    {
-        bool ok = hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming) == hipSuccess;
-        for (int g = 0; ok && g * group_ < cap_; g++)
-        {
-            hipEvent_t e = nullptr;
-            ok = hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
-            if (ok) ev_group_.push_back(e);
-        }
-        if (!ok) { hbhip_ctx_destroy(side_); side_ = nullptr; (void)hipGetLastError(); }
-    }
     HBHIP_CHECK(ctx_, hipStreamSynchronize(ctx_->stream));
     return HBHIP_OK;
 }
@@ -1850,41 +1825,25 @@ int Eedi2Engine::add_field(const DevPicture *cur, int tff)
     return start_ + n_++;
 }
 
-// The mask passes of the queued fields are a chain of short launches (each field's lower half needs the previous
-// field's finished mask) that occupy a fraction of the GPU, and every later pass of a field needs only that field's
-// mask.  So the chain goes to a stream of its own and the passes follow it in groups of `group_` fields on the
-// caller's stream: while the passes of one group run, the chain works on the next groups' masks.  Fork and join are
-// inside this call: the side stream starts behind the caller's stream (whatever used these slots before is done),
-// and the caller's stream has waited for the last mask by the time the last group's passes are queued.
+// Tried and dropped: the mask chain on a (high-priority) stream of its own with the passes following it in groups of
+// 8 fields on the caller's stream.  One stream per GPU gained 2 % (the chain's short launches overlap the passes, but the
+// passes are VALU-bound and give little room); two independent streams per GPU lost half their rate (2 332 against
+// 5 282 output fps on the chain workload) - more streams than hardware queues, and a queue that holds a waiting stream
+// holds up whatever shares it.
 int Eedi2Engine::launch(hbhip_ctx *lc)
 {
     if (n_ == 0) return HBHIP_OK;
     const int n = n_;
     n_ = 0;
-    int rc = HBHIP_OK;
-    const bool forked = side_ && !lc->profile && n > group_;         // the per-kernel profiler times launches on lc only
-    if (!forked)
-    {
-        rc = enqueue_mask(n, lc, lc, 0);
-        if (rc == HBHIP_OK) rc = enqueue_passes(0, n, lc);
-    }
-    else
-    {
-        rc = enqueue_mask(n, lc, side_, group_);
-        for (int f0 = 0, g = 0; rc == HBHIP_OK && f0 < n; f0 += group_, g++)
-        {
-            HBHIP_CHECK(lc, hipStreamWaitEvent(lc->stream, ev_group_[g], 0));
-            rc = enqueue_passes(f0, std::min(group_, n - f0), lc);
-        }
-    }
+    int rc = enqueue_mask(n, lc);
+    if (rc == HBHIP_OK) rc = enqueue_passes(0, n, lc);
     last_slot_ = start_ + n - 1;
     return rc;
 }
 
 // the five mask passes (+ the field extraction) of the n queued fields: old mask -> new mask.  The part no earlier
-// field can influence goes to `lc` in one launch; the chain goes to `mc` (== lc, or the side stream: then behind an
-// event on lc, and with an event recorded behind every `group` fields)
-int Eedi2Engine::enqueue_mask(int n, hbhip_ctx *lc, hbhip_ctx *mc, int group)
+// field can influence is one launch, the rest a chain of launches, field after field
+int Eedi2Engine::enqueue_mask(int n, hbhip_ctx *lc)
 {
     const EediFrame srcp = at_slot(half_[0], start_), mskp = at_slot(half_[1], start_), mskp_old = at_slot(half_[1], last_slot_);
     P3 P;
@@ -1911,18 +1870,9 @@ int Eedi2Engine::enqueue_mask(int n, hbhip_ctx *lc, hbhip_ctx *mc, int group)
         const unsigned gy_up = std::max(1, (srcp.height[0] / 2 - MF_OY) / MF_H);
         HBHIP_LAUNCH(lc, "eedi2_mask_upper", k_mask_fused4, dim3(gx, gy_up, 3 * n), dim3(256), 0, P, S, 0, 1, mth, vth, lth,
                      par_.erosion_threshold, par_.dilation_threshold);
-        if (mc != lc)
-        {
-            HBHIP_CHECK(lc, hipEventRecord(ev_fork_, lc->stream));
-            HBHIP_CHECK(mc, hipStreamWaitEvent(mc->stream, ev_fork_, 0));
-        }
         for (int f = 0; f < n; f++)
-        {
-            HBHIP_LAUNCH(mc, "eedi2_mask_passes", k_mask_fused4, dim3(gx, gy, 3), dim3(256), 0, P, S, f, 2, mth, vth, lth,
+            HBHIP_LAUNCH(lc, "eedi2_mask_passes", k_mask_fused4, dim3(gx, gy, 3), dim3(256), 0, P, S, f, 2, mth, vth, lth,
                          par_.erosion_threshold, par_.dilation_threshold);
-            if (mc != lc && ((f + 1) % group == 0 || f + 1 == n))
-                HBHIP_CHECK(mc, hipEventRecord(ev_group_[f / group], mc->stream));
-        }
     }
     HBHIP_CHECK(lc, hipGetLastError());
     return HBHIP_OK;

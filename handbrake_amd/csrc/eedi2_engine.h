@@ -55,13 +55,8 @@ public:
 private:
     size_t place_frame(EediFrame &f, int width, int height, size_t at);
     EediFrame at_slot(const EediFrame &f, int slot) const;
-    int enqueue_mask(int n, hbhip_ctx *lc, hbhip_ctx *mc, int group);   // the five mask passes (+ the field extraction)
-    int enqueue_passes(int f0, int n, hbhip_ctx *lc);                   // everything after them, fields f0 .. f0 + n - 1
-    hbhip_ctx  *side_ = nullptr;                   // the mask chain's stream (high priority)
-    hipStream_t side_stream_ = nullptr;
-    hipEvent_t  ev_fork_ = nullptr;
-    std::vector<hipEvent_t> ev_group_;             // behind the mask of the last field of each group
-    int         group_ = 0;                        // fields per group of passes (0: no side stream)
+    int enqueue_mask(int n, hbhip_ctx *lc);                 // the five mask passes (+ the field extraction)
+    int enqueue_passes(int f0, int n, hbhip_ctx *lc);       // everything after them, fields f0 .. f0 + n - 1 of the batch
     hbhip_ctx  *ctx_;
     PicGeometry geo_;
     Eedi2Params par_;
