@@ -18,6 +18,9 @@ AV_PIX_FMT_YUV420P = 0
 AV_PIX_FMT_YUV420P10 = 62
 AV_PIX_FMT_YUV420P12 = 123
 PIX_FMT_FOR_DEPTH = {8: AV_PIX_FMT_YUV420P, 10: AV_PIX_FMT_YUV420P10, 12: AV_PIX_FMT_YUV420P12}
+# (chroma subsampling "WxH" of a chroma sample in luma samples, depth) -> AVPixelFormat, hbffmpeg.c:893-909
+PIX_FMT = {("2x2", 8): 0, ("2x1", 8): 4, ("1x1", 8): 5, ("2x2", 10): 62, ("2x1", 10): 64, ("1x1", 10): 68,
+           ("2x2", 12): 123, ("2x1", 12): 127, ("1x1", 12): 131}
 
 HB_COMB_NONE, HB_COMB_LIGHT, HB_COMB_HEAVY = 0, 1, 2
 
@@ -153,7 +156,7 @@ class Chain:
             ptrs[p] = a.ctypes.data
             strides[p] = a.strides[0]
         self._rt.hbh_chain_pop(self._h, ptrs, strides)
-        bps = 2 if info.fmt in (62, 123) else 1
+        bps = 2 if info.fmt in (62, 123, 64, 68, 127, 131) else 1
         planes = tuple(a[:, : info.plane_width[p] * bps] for p, a in enumerate(arrs))
         if bps == 2:                      # 10 / 12-bit samples in 16-bit containers
             planes = tuple(np.ascontiguousarray(p).view(np.uint16) for p in planes)

@@ -85,6 +85,13 @@ static const AVPixFmtDescriptor k_desc_yuv420p12 = {
     "yuv420p12le", 3, 1, 1, 0,
     { {0, 2, 0, 0, 12}, {1, 2, 0, 0, 12}, {2, 2, 0, 0, 12}, {0, 0, 0, 0, 0} } };
 
+#define DESC16(sym, nm, lcw, lch, depth) static const AVPixFmtDescriptor sym = { nm, 3, lcw, lch, 0, \
+    { {0, 2, 0, 0, depth}, {1, 2, 0, 0, depth}, {2, 2, 0, 0, depth}, {0, 0, 0, 0, 0} } }
+DESC16(k_desc_yuv422p10, "yuv422p10le", 1, 0, 10);
+DESC16(k_desc_yuv444p10, "yuv444p10le", 0, 0, 10);
+DESC16(k_desc_yuv422p12, "yuv422p12le", 1, 0, 12);
+DESC16(k_desc_yuv444p12, "yuv444p12le", 0, 0, 12);
+
 const AVPixFmtDescriptor *av_pix_fmt_desc_get(int pix_fmt)
 {
     switch (pix_fmt)
@@ -98,6 +105,10 @@ const AVPixFmtDescriptor *av_pix_fmt_desc_get(int pix_fmt)
         case AV_PIX_FMT_YUVA444P:    return &k_desc_yuva444p;
         case AV_PIX_FMT_YUV420P10LE: return &k_desc_yuv420p10;
         case AV_PIX_FMT_YUV420P12LE: return &k_desc_yuv420p12;
+        case AV_PIX_FMT_YUV422P10LE: return &k_desc_yuv422p10;
+        case AV_PIX_FMT_YUV444P10LE: return &k_desc_yuv444p10;
+        case AV_PIX_FMT_YUV422P12LE: return &k_desc_yuv422p12;
+        case AV_PIX_FMT_YUV444P12LE: return &k_desc_yuv444p12;
         default:                     return NULL;
     }
 }
@@ -106,7 +117,8 @@ int av_get_pix_fmt(const char *name)
 {
     static const int known[] = { AV_PIX_FMT_YUV420P, AV_PIX_FMT_YUV422P, AV_PIX_FMT_YUV444P, AV_PIX_FMT_GRAY8,
                                  AV_PIX_FMT_YUVA420P, AV_PIX_FMT_YUVA422P, AV_PIX_FMT_YUVA444P,
-                                 AV_PIX_FMT_YUV420P10LE, AV_PIX_FMT_YUV420P12LE };
+                                 AV_PIX_FMT_YUV420P10LE, AV_PIX_FMT_YUV420P12LE, AV_PIX_FMT_YUV422P10LE, AV_PIX_FMT_YUV444P10LE,
+                                 AV_PIX_FMT_YUV422P12LE, AV_PIX_FMT_YUV444P12LE };
     if (name == NULL) return AV_PIX_FMT_NONE;
     for (size_t i = 0; i < sizeof(known) / sizeof(known[0]); i++)
     {

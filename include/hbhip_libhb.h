@@ -85,7 +85,12 @@ enum hbhip_pix_fmt
     AV_PIX_FMT_YUV420P10LE = 62,
     AV_PIX_FMT_YUV420P10   = 62,
     AV_PIX_FMT_YUV420P12LE = 123,
-    AV_PIX_FMT_YUV420P12   = 123
+    AV_PIX_FMT_YUV420P12   = 123,
+    /* the other 10 / 12-bit layouts hb_av_can_use_zscale lists (hbffmpeg.c:893-909), FFmpeg's numbers */
+    AV_PIX_FMT_YUV422P10LE = 64,  AV_PIX_FMT_YUV422P10 = 64,
+    AV_PIX_FMT_YUV444P10LE = 68,  AV_PIX_FMT_YUV444P10 = 68,
+    AV_PIX_FMT_YUV422P12LE = 127, AV_PIX_FMT_YUV422P12 = 127,
+    AV_PIX_FMT_YUV444P12LE = 131, AV_PIX_FMT_YUV444P12 = 131
 };
 
 typedef struct AVComponentDescriptor

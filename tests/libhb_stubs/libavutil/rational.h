@@ -1,0 +1,1 @@
+#include "libav_stub.h"
