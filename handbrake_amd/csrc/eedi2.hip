@@ -219,7 +219,11 @@ constexpr int MF_LP = MF_W + 2 * MF_OX, MF_LR = MF_H + 2 * MF_OY; // 144 x 24
 // which the 8-byte column halo absorbs (the tile needs x0-3 .. x0+130 from the last erode).
 constexpr int MF_DW = MF_LP / 4;                 // 36 dwords per LDS row
 constexpr int MF_DP = MF_DW + 2;                 // + one pad dword either side
-constexpr int MF_SR = 4;                         // rows per thread and pass
+constexpr int MF_SR = 2;                         // rows per thread and pass
+constexpr int MF_T = 512;                        // threads: 12 strips of MF_SR rows x 36 dword columns = 432 of them work in a pass
+// (the per-field chain runs with one or two workgroups per CU and is bound by each thread's serial work: 4 rows per
+// thread and 256 threads 15.0 us per launch, 2 rows and 512 threads 12.6 us, 1 row and 1024 threads 12.6 us - with the
+// all-fields launch of the upper part at 55 / 57 / 77 us per 16 fields)
 
 // 0xff in byte k when lo <= X + k < hi
 __device__ __forceinline__ uint32_t mf_bytes_in(int X, int lo, int hi)
@@ -278,7 +282,7 @@ __device__ __forceinline__ void mf_morph4(const uint32_t (*src)[MF_DP], uint32_t
 // of a launch reads P.b (the last field of the previous batch), field f > 0 the new mask of field f - 1.
 struct MaskSrc { const uint8_t *frame[EEDI_MAX_FIELDS][3]; int spitch[3]; };
 
-__global__ __launch_bounds__(256) void k_mask_fused4(P3 P, MaskSrc S, int f0, int part, int mth, int vth, int lth, int erode_thr, int dilate_thr)
+__global__ __launch_bounds__(MF_T) void k_mask_fused4(P3 P, MaskSrc S, int f0, int part, int mth, int vth, int lth, int erode_thr, int dilate_thr)
 {
     __shared__ uint32_t s_src[MF_LR][MF_DP];
     __shared__ uint32_t s_a[MF_LR][MF_DP];
@@ -296,7 +300,7 @@ __global__ __launch_bounds__(256) void k_mask_fused4(P3 P, MaskSrc S, int f0, in
     uint8_t *srcp = P.a[pl] + foff, *newm = P.c[pl] + foff;
     const int t = threadIdx.x, fx = x0 - MF_OX, fy = y0 - MF_OY;
 
-    for (int i = t; i < MF_LR * MF_DW; i += 256)
+    for (int i = t; i < MF_LR * MF_DW; i += MF_T)
     {
         const int r = i / MF_DW, c4 = i - r * MF_DW;
         const int y = fy + r, x = fx + 4 * c4;
@@ -318,7 +322,7 @@ __global__ __launch_bounds__(256) void k_mask_fused4(P3 P, MaskSrc S, int f0, in
     }
     __syncthreads();
 
-    const int c4 = t % MF_DW, strip = t / MF_DW;               // strip 7 (t >= 252) has no rows in any pass
+    const int c4 = t % MF_DW, strip = t / MF_DW;               // strips past the frame have no rows in any pass
     const int X = fx + 4 * c4;
     const uint32_t px1 = mf_bytes_in(X, 1, width - 1) & 0x01010101u;
 
@@ -381,7 +385,7 @@ __global__ __launch_bounds__(256) void k_mask_fused4(P3 P, MaskSrc S, int f0, in
     mf_morph4<false>(s_a, s_b, c4, strip, 4, MF_LR - 5, erode_thr, px1, fy, height);
 
     // remove_small_gaps (:308-342) on the tile's 16 rows x 32 dwords, straight to the new mask
-    for (int i = t; i < MF_H * (MF_W / 4); i += 256)
+    for (int i = t; i < MF_H * (MF_W / 4); i += MF_T)
     {
         const int r = MF_OY + i / (MF_W / 4), g4 = MF_OX / 4 + (i & (MF_W / 4 - 1));
         const int y = fy + r, x = fx + 4 * g4;
@@ -1862,16 +1866,16 @@ int Eedi2Engine::enqueue_mask(int n, hbhip_ctx *lc)
     const int mth = par_.magnitude_threshold * 10, vth = par_.laplacian_threshold * 81, lth = par_.variance_threshold;   // sic: swapped (decomb_template.c:390)
     const unsigned gx = (srcp.width[0] + MF_W - 1) / MF_W, gy = (srcp.height[0] + MF_H - 1) / MF_H;
     if (n == 1)
-        HBHIP_LAUNCH(lc, "eedi2_mask_passes", k_mask_fused4, dim3(gx, gy, 3), dim3(256), 0, P, S, 0, 0, mth, vth, lth,
+        HBHIP_LAUNCH(lc, "eedi2_mask_passes", k_mask_fused4, dim3(gx, gy, 3), dim3(MF_T), 0, P, S, 0, 0, mth, vth, lth,
                      par_.erosion_threshold, par_.dilation_threshold);
     else
     {
         // the tiles no earlier field can influence: all fields at once (tile rows below the middle return at once)
         const unsigned gy_up = std::max(1, (srcp.height[0] / 2 - MF_OY) / MF_H);
-        HBHIP_LAUNCH(lc, "eedi2_mask_upper", k_mask_fused4, dim3(gx, gy_up, 3 * n), dim3(256), 0, P, S, 0, 1, mth, vth, lth,
+        HBHIP_LAUNCH(lc, "eedi2_mask_upper", k_mask_fused4, dim3(gx, gy_up, 3 * n), dim3(MF_T), 0, P, S, 0, 1, mth, vth, lth,
                      par_.erosion_threshold, par_.dilation_threshold);
         for (int f = 0; f < n; f++)
-            HBHIP_LAUNCH(lc, "eedi2_mask_passes", k_mask_fused4, dim3(gx, gy, 3), dim3(256), 0, P, S, f, 2, mth, vth, lth,
+            HBHIP_LAUNCH(lc, "eedi2_mask_passes", k_mask_fused4, dim3(gx, gy, 3), dim3(MF_T), 0, P, S, f, 2, mth, vth, lth,
                          par_.erosion_threshold, par_.dilation_threshold);
     }
     HBHIP_CHECK(lc, hipGetLastError());
