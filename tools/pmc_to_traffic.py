@@ -7,16 +7,16 @@ import json
 import sys
 
 # C++ kernel name (as summarize_pmc.py shortens it) -> (name of the launch in hbhip's profiler, units a launch covers on
-# the production path of the default chain workload: 16 input frames = 32 fields per step, the EEDI2 passes in groups of
-# 8 fields (Eedi2Engine::launch), blends / scaler / lapsharp 16 frames, NLMeans 32).  bench.py scales the per-launch
+# the production path of the default chain workload: 16 input frames = 32 fields per step, the EEDI2 passes 16 fields per
+# launch (Eedi2Engine::launch), blends / scaler / lapsharp 16 frames, NLMeans 32).  bench.py scales the per-launch
 # figures to the launch shape of its own event-timed pass (units_per_launch is stored with them).
 NAMES = {
-    "k_calc_dir_rows": ("eedi2_calc_directions", 8), "k_fill_gaps_b": ("eedi2_fill_gaps_2x", 8),
-    "k_lattice_cand_q": ("eedi2_lattice_candidates", 8), "k_lattice_resolve": ("eedi2_lattice_resolve", 8),
-    "k_mark_2x4": ("eedi2_mark_directions_2x", 8),
-    "k_filter_map": ("eedi2_filter_map", 8), "k_post": ("eedi2_post_process", 8),
-    "k_dir_map4": ("eedi2_filter_dir_map_2x", 8),          # half-height and _2x forms, mean
-    "k_dir_map_c": ("eedi2_expand_dir_map_2x", 8),         # half-height and _2x forms, mean
+    "k_calc_dir_rows": ("eedi2_calc_directions", 16), "k_fill_gaps_b": ("eedi2_fill_gaps_2x", 16),
+    "k_lattice_cand_q": ("eedi2_lattice_candidates", 16), "k_lattice_resolve": ("eedi2_lattice_resolve", 16),
+    "k_mark_2x4": ("eedi2_mark_directions_2x", 16),
+    "k_filter_map": ("eedi2_filter_map", 16), "k_post": ("eedi2_post_process", 16),
+    "k_dir_map4": ("eedi2_filter_dir_map_2x", 16),          # half-height and _2x forms, mean
+    "k_dir_map_c": ("eedi2_expand_dir_map_2x", 16),         # half-height and _2x forms, mean
     "decomb_plane4_kernel": ("decomb_plane", 16), "scale8_up_kernel": ("cropscale_lanczos_fused", 16),
     "lapsharp3_rows_kernel": ("lapsharp_3x3", 16), "copy3_kernel": ("copy_planes", 1),
     "job_table_kernel": ("nlmeans_job_table", 32),
