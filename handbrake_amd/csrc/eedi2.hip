@@ -1,35 +1,36 @@
-// eedi2.hip — EEDI2 (edge-directed interpolation of one field) for gfx950, 8-bit.
+// eedi2.hip — EEDI2 (edge-directed interpolation of a field) for gfx950, 8-bit.
 //
 // The reference's passes (libhb/templates/eedi2_template.c), sequenced as
 // eedi2_interpolate_plane does (libhb/templates/decomb_template.c:366-441), each
-// launch covering the three planes (blockIdx.z).  The scratch frames live in
-// HBM with the byte layout hb_frame_buffer_init gives them (fifo.c:820-881) inside
-// zeroed guards, because the reference's passes index a flat buffer and read a few
-// bytes outside rows and planes (e.g. eedi2_template.c:395-447, 1194-1195); with the
-// same layout the same bytes are read and the result is bit-identical.  The edge
-// mask keeps state between runs exactly as the reference's does (:132).
+// launch covering the three planes of EVERY field of a batch (blockIdx.z = 3 * field +
+// plane; Eedi2Engine at the end of the file).  A field's scratch frames live in HBM with
+// the byte layout hb_frame_buffer_init gives them (fifo.c:820-881) between zeroed
+// guards, because the reference's passes index a flat buffer and read a few bytes
+// outside rows and planes (e.g. eedi2_template.c:395-447, 1194-1195); with the same
+// layout the same bytes are read and the result is bit-identical.  The edge mask keeps
+// state from field to field exactly as the reference's does (:132).
 //
-//   k_fill_half        eedi2_fill_half_height_buffer_plane   :77-89
-//   k_mask_fused       eedi2_build_edge_mask :122-195, erode/dilate_edge_mask :207-293,
-//                      remove_small_gaps :308-342 — five passes, one LDS-tiled launch
-//   k_calc_dir_tile    eedi2_calc_directions                 :358-525   (the time sink; k_calc_dir_mark/work
+//   k_mask_fused4      eedi2_fill_half_height_buffer_plane :77-89, eedi2_build_edge_mask :122-195,
+//                      erode / dilate_edge_mask :207-293, remove_small_gaps :308-342 — the field extraction and
+//                      five passes, one LDS-tiled launch
+//   k_calc_dir_rows    eedi2_calc_directions                 :358-525   (the time sink; k_calc_dir_mark / work
 //                      is the fallback for search distances beyond the LDS halo)
-//   k_dir_map          eedi2_filter_dir_map / expand_dir_map :649-773 and the _2x forms :872-1011
+//   k_dir_map4 / k_dir_map_c   eedi2_filter_dir_map / expand_dir_map :649-773 and the _2x forms :872-1011
 //   k_filter_map       eedi2_filter_map                      :538-635
-//   k_mark_2x          eedi2_upscale_by_2 (x3) :98-108 + eedi2_mark_directions_2x :787-858
-//   k_fill_gaps        eedi2_fill_gaps_2x                    :1025-1132
-//   k_lattice_cand / k_lattice_resolve   eedi2_interpolate_lattice   :1148-1335
-//   k_post             eedi2_post_process :1349-1378 (the eedi2_bit_blit before it, :46-68, is folded into
-//                      the dir-map filter that follows it)
+//   k_mark_2x4         eedi2_upscale_by_2 (x3) :98-108 + eedi2_mark_directions_2x :787-858
+//   k_fill_gaps_b      eedi2_fill_gaps_2x                    :1025-1132
+//   k_lattice_cand_q / k_lattice_resolve   eedi2_interpolate_lattice   :1148-1335
+//   k_post             eedi2_post_process :1349-1378 (normally folded into the last expand_dir_map_2x; the
+//                      eedi2_bit_blit before it, :46-68, into the dir-map filter that follows it)
 //   k_blur1 / k_derivatives / k_blur_sqrt2 / k_post_corner   post-processing 2/3: eedi2_gaussian_blur1
 //                      :1391-1527, eedi2_calc_derivatives :1760-1848, eedi2_gaussian_blur_sqrt2 :1539-1748,
 //                      eedi2_post_process_corner :1864-1904
 //
 // interpolate_lattice rewrites its direction row in place and tests the value it
 // just wrote at x-1 (:1194), a left-to-right dependency.  Each row is given to one
-// wavefront: lanes evaluate both possible outcomes of their pixel in parallel and
-// the chain is resolved with a 64-lane prefix composition of 2-state maps, the
-// carry running from chunk to chunk.
+// workgroup: lanes evaluate both possible outcomes of their pixel in parallel and
+// the chain is resolved with a prefix composition of 2-state maps, the carry running
+// from chunk to chunk.
 #include "eedi2_engine.h"
 #include <algorithm>
 
@@ -491,32 +492,23 @@ __global__ __launch_bounds__(256) void k_calc_dir_work(P3 P, const uint32_t *__r
     Q.c[(size_t)y * pitch + x] = (uint8_t)out;
 }
 
-// calc_directions, fast path (search distance <= 30): one block = 256 consecutive pixels of one
-// row.  The 5 source rows and 3 mask rows the search touches are staged in LDS (with the same
-// flat addressing, so out-of-row offsets pick up the same bytes), the pixels that pass the edge
-// test are compacted inside the block so that busy lanes are contiguous, and each listed pixel
-// walks its +-maxd window out of LDS.
+// calc_directions, fast path (search distance <= 30).  The source and mask rows the search touches are staged in LDS
+// (with the same flat addressing, so out-of-row offsets pick up the same bytes), the pixels that pass the edge test are
+// compacted inside the block so that busy lanes are contiguous, and each listed pixel walks its +-maxd window out of LDS.
 constexpr int CD_W = 256, CD_HALO = 32, CD_LW = CD_W + 2 * CD_HALO;
 
-
-// calc_directions, second form of the fast path.  Same block shape as k_calc_dir_tile (256 consecutive pixels of one row,
-// active pixels compacted), but the search loop is stripped to what has to happen per step:
+// What the search loop does per step is stripped to what has to happen per step:
 //  * the 3-byte groups every step needs ("triples": bytes i..i+2 of a staged row, i = cc-1+-u) are formed ONCE per block
 //    into LDS tables, one dword per column and source row - a step reads eight dwords at per-lane columns instead of
 //    twenty and realigns nothing;
-//  * the two edge-mask look-ups of a step (:395-399: is there a mask peak among the three pixels above at +u / below at
-//    -u) are two flag bits carried in the spare top byte of the centre row's table;
-//  * each running minimum and its offset are ONE integer, (sum << 6) | (u + 32): `if (sum < min) { min = sum; dir = u; }`
-//    with u ascending is exactly min() on that key (ties keep the earlier = smaller u, the initial threshold is
-//    (thr << 6) | 0 so only strictly smaller sums get in, and low bits 0 mean "never set" = the reference's -5000);
-//  * the loop runs -maxd .. +maxd for every lane with the per-lane range test folded into the step's predicate, so the
-//    trip count is wave-uniform and the step body is one predicated region.
+//  * the steps that can count at all (a mask peak among the three pixels above at +u AND below at -u, :395-399) are a
+//    64-bit set per pixel cut from ballot bitmaps of the mask rows, and the loop walks its set bits only;
+//  * each running minimum and its offset are ONE integer key: `if (sum < min) { min = sum; dir = u; }` with u ascending
+//    is exactly min() on (sum << 16) | tag (ties keep the earlier = smaller u, the initial threshold is (thr << 16) | 0
+//    so only strictly smaller sums get in, and tag 0 means "never set" = the reference's -5000).
 // Values are the reference's (:358-525): same sums, same order of comparisons.
 
-// calc_directions, third form: k_calc_dir_tile2 with the search loop walking only the steps that pass the mask test
-// (see the bit sets below).  maxd <= 31 (the set is one 64-bit word).
-
-// calc_directions, fourth form: a block takes 256 columns x R rows.
+// A block takes 256 columns x R rows.
 //  * Rows share their staging: R + 4 source and R + 2 mask rows (and the triple tables / peak bitmaps made from them)
 //    serve R rows of pixels instead of 5 + 3 for one, and the masked pixels of R rows fill the waves of the search (one row
 //    of this content leaves the last wave of a block's list three quarters empty).
@@ -528,8 +520,8 @@ constexpr int CD_W = 256, CD_HALO = 32, CD_LW = CD_W + 2 * CD_HALO;
 //  * A running minimum and its offset are one integer built by v_sad_hi_u8 chains (see calc_dir_search), a step forms its
 //    two table addresses with one instruction each: 31 VALU instructions per step against 45.
 //  * The output rows are assembled in LDS and stored as dwords.
-// Values are those of k_calc_dir_tile3 (:358-525).  maxd <= 30.  Per launch (1080i field, the bench's content):
-// SQ_INSTS_VALU 26.5 M -> 16.8 M, SQ_INSTS_SALU 11.3 M -> 2.2 M, SQ_INSTS_LDS 3.2 M -> 2.1 M.
+// maxd <= 30.  Per 1080i field of the bench's content: SQ_INSTS_VALU 16.7 M, SQ_INSTS_SALU 2.9 M, SQ_INSTS_LDS 2.1 M
+// (one row per block without the key chains: 26.5 M / 11.3 M / 3.2 M).
 
 template <bool EDGE>
 __device__ __forceinline__ int calc_dir_search(const uint32_t *tr, uint64_t pass, int maxdt, bool first, bool last, int nt13, int nt19)
@@ -751,9 +743,8 @@ __global__ __launch_bounds__(CD_W) void k_calc_dir_rows(P3 P, int maxd, int nt13
 // step 1: rows 1..height-2, neighbours y+-1, mask row y.
 // step 2: rows y0, y0+2, ... < height-1, neighbours y+-2 (guarded by y>1 / y<height-2), mask rows y-1 and y+1.
 
-// k_dir_map with four pixels per thread (the form that runs; k_dir_map above is the one-pixel reference form kept for
-// HBHIP_EEDI2_1PX).  One byte per thread makes these passes latency bound: a wave lives for two dependent memory round
-// trips whatever it computes, so the time is (#waves / resident waves) x that.  Here a thread owns one aligned dword of
+// Four pixels per thread.  One byte per thread makes these passes latency bound: a wave lives for two dependent memory
+// round trips whatever it computes, so the time is (#waves / resident waves) x that.  Here a thread owns one aligned dword of
 // its row: three 12-byte windows (rows y-step, y, y+step of the direction map) + one or two mask dwords, a quarter of
 // the waves and of the load instructions, one dword store.  In the _2x forms (step 2) every other row is only copied:
 // that is decided per row (a wave = one row), before anything but the row's own dword is loaded.
@@ -987,7 +978,7 @@ __global__ void k_filter_map(P3 P)
 // the half-height ones, so it reads those directly and no separate upscale launch is needed.
 // a = mskp, b = dstp, c = out (tmp2p), g = srcp; `height` = full height.
 
-// k_mark_2x with four pixels per thread (see k_dir_map4): the three line doublings are dword copies, and only the
+// Four pixels per thread (see k_dir_map4): the three line doublings are dword copies, and only the
 // rows mark_directions_2x rebuilds (every other one) load the two neighbouring half-height rows.
 __global__ __launch_bounds__(256) void k_mark_2x4(P3 P)
 {
@@ -1017,7 +1008,7 @@ __global__ __launch_bounds__(256) void k_mark_2x4(P3 P)
         const int k0 = (k0w >> (8 * k)) & 0xff, k1 = (k1w >> (8 * k)) & 0xff;
         if (xx >= 1 && xx < width - 1 && (k0 == PEAK || k1 == PEAK))
         {
-            asm volatile("" ::: "memory");                        // keep the branch (see k_dir_map)
+            asm volatile("" ::: "memory");                        // keep the branch (see k_dir_map4)
             const int a0 = wb(wa, k - 1), a1 = wb(wa, k), a2 = wb(wa, k + 1), b0 = wb(wbn, k - 1), b1 = wb(wbn, k), b2 = wb(wbn, k + 1);
             const int v = (a0 != PEAK) + (a1 != PEAK) + (a2 != PEAK) + (b0 != PEAK) + (b1 != PEAK) + (b2 != PEAK);
             if (v >= 3)
@@ -1044,14 +1035,11 @@ __global__ __launch_bounds__(256) void k_mark_2x4(P3 P)
     *o = packed;
 }
 
-// a = msk2p, b = dmsk in, c = out.  Every pixel of a fillable gap computes the same
-// (u, v, back, forward, verdict) as its neighbours in the gap (:1053-1120), so each
-// thread only writes its own pixel.
-
-// fill_gaps_2x, the form that runs (k_fill_gaps above is the one-pixel form kept for HBHIP_EEDI2_1PX).
-// Two things cost time in the one-pixel form: most waves exist only to copy 64 bytes, and the few pixels that really
-// are gaps (direction unknown inside the mask) walk left and right on dependent byte loads (:1053-1073) while the
-// rest of their wave idles.  Here a workgroup owns FG_W consecutive pixels of one rebuilt row:
+// fill_gaps_2x.  a = msk2p, b = dmsk in, c = out.  Every pixel of a fillable gap computes the same
+// (u, v, back, forward, verdict) as its neighbours in the gap (:1053-1120), so each thread only writes its own pixel.
+// Two things cost time in a pixel-per-thread form: most waves exist only to copy 64 bytes, and the few pixels that
+// really are gaps (direction unknown inside the mask) walk left and right on dependent byte loads (:1053-1073) while
+// the rest of their wave idles.  Here a workgroup owns FG_W consecutive pixels of one rebuilt row:
 //   1. the seven rows involved (dc = y, mask y-1 / y+1 / y-3 / y+3, direction y-2 / y+2) are staged in LDS with
 //      FG_HALO pixels either side (dwords, same flat addressing);
 //   2. every thread takes four pixels of the span: copies them to the output row (in LDS) and appends the gap pixels
@@ -1065,9 +1053,8 @@ __global__ __launch_bounds__(256) void k_mark_2x4(P3 P)
 constexpr int FG_W = 1024, FG_HALO = 64, FG_LW = FG_W + 2 * FG_HALO;
 
 
-// k_fill_gaps_c with the walks done on bitmaps (the form that runs).  Every pixel of a gap walks the gap's whole length
-// on dependent byte reads in k_fill_gaps_c - 1.9 M VALU instructions in a 24.7 us kernel: its time is the longest
-// chain, and meanwhile its waves hold slots the other engines' kernels wait for.  Here the staged rows are first
+// The walks are done on bitmaps: walked byte by byte, every pixel of a gap goes the gap's whole length on dependent
+// reads (1.9 M VALU instructions in a 24.7 us kernel: its time was the longest chain).  The staged rows are first
 // turned into four bit rows (ballots), and a pixel finds its gap's ends, and whether the rows above / below break
 // the gap's support, with a few 64-bit operations; only the min / max over a supported gap still walks bytes
 // (independent reads).  Walks that leave the staged span take the byte path (rare).
@@ -1361,8 +1348,8 @@ __device__ __forceinline__ uint32_t lattice_stage_c(const uint8_t *top, const ui
 }
 
 // interpolate_lattice in two launches.
-// k_lattice_cand (one thread per pixel of the rows being rebuilt): everything about a pixel
-// that does not depend on its left neighbour's NEW direction value, packed into 32 bits:
+// k_lattice_cand_q: everything about a pixel of the rows being rebuilt that does not depend on its left
+// neighbour's NEW direction value, packed into 32 bits:
 //   [7:0] valA  = vertical average (outcome A)      [15:8]  valB = outcome-B pixel value
 //   [23:16] newB = outcome-B direction value        bit 24 = "always A" (dir == peak)
 //   bit 25 = right-hand test |d[x]-d[x+1]| > lim    (newA is NEUTRAL, or PEAK when always A)
@@ -1373,7 +1360,7 @@ __device__ __forceinline__ uint32_t lattice_stage_c(const uint8_t *top, const ui
 constexpr int LC_HALO = 40;   // |u| <= 34, +-1 for the triples, rounded to dwords
 
 
-// k_lattice_cand with the searching pixels queued.  Only pixels that carry a direction (d != peak) go
+// The searching pixels are queued.  Only pixels that carry a direction (d != peak) go
 // through the variance / edge tests and the two searches - on real pictures roughly one in ten, but
 // nearly every wave holds some, and pays for all of it.  A workgroup takes 1024 pixels of a row:
 // every thread packs the word of its four pixels as if they were "always A" (vertical average, the
