@@ -535,7 +535,7 @@ public:
             Eedi2Params ep = { par.magnitude_threshold, par.variance_threshold, par.laplacian_threshold,
                                par.dilation_threshold, par.erosion_threshold, par.noise_threshold,
                                par.maximum_search_distance, par.post_processing };
-            eedi16 = new (std::nothrow) Eedi2Engine16(ctx, in_geo, ep);
+            eedi16 = new (std::nothrow) Eedi2Engine16(ctx, in_geo, ep, hbhip_dev_int("HBHIP_EEDI2_FIELDS", 16));
             if (!eedi16) return HBHIP_ERR_NOMEM;
             return eedi16->init();
         }
@@ -619,13 +619,14 @@ private:
         if (!p || --p->refs != 0) return;
         // a queued EEDI2 field or a blend gathered for the batch launch may still read it: hand it back when the
         // batch is out
-        if (!gathered.empty() || (eedi && eedi->queued() > 0)) late_unref.push_back(p);
+        if (!gathered.empty() || !gathered16.empty() || (eedi && eedi->queued() > 0) || (eedi16 && eedi16->queued() > 0))
+            late_unref.push_back(p);
         else hbhip_pic_release(p, ctx);                    // possibly another filter's picture (fused chain)
     }
     // launch what has been gathered: the queued EEDI2 fields, then the blends (which read their guesses)
     int flush_batch()
     {
-        int rc = eedi ? eedi->launch(ctx) : HBHIP_OK;
+        int rc = eedi ? eedi->launch(ctx) : eedi16 ? eedi16->launch(ctx) : HBHIP_OK;
         const int rc2 = launch_gathered(ctx);
         for (DevPicture *p : late_unref) hbhip_pic_release(p, ctx);
         late_unref.clear();
@@ -650,10 +651,11 @@ private:
             DecombPlane &P = a.pl[c];
             P.prev = ref[0]->plane[c]; P.cur = ref[1]->plane[c]; P.next = ref[2]->plane[c];
             P.guess = nullptr; P.guess_pitch = 0;
-            if ((mode & M_EEDI2) && eedi16)
+            if ((mode & M_EEDI2) && eedi16 && slot >= 0)
             {
-                P.guess = eedi16->result().plane[c];
-                P.guess_pitch = eedi16->result().stride[c];
+                const EediFrame g = eedi16->result(slot);
+                P.guess = g.plane[c];
+                P.guess_pitch = g.stride[c];
             }
             else if ((mode & M_EEDI2) && eedi && slot >= 0)
             {
@@ -689,6 +691,8 @@ private:
         }
         if (in_geo.bps == 2)
         {
+            // 10 / 12 bits: one launch per frame, behind the EEDI2 engine's launch when the frame's guess is queued there
+            if (eedi16 && (eedi16->queued() > 0 || !gathered16.empty())) { gathered16.push_back(a); return HBHIP_OK; }
             HBHIP_LAUNCH(lc, "decomb_plane", decomb_plane_kernel<uint16_t>, grid, block, 0, a, maxv);
             HBHIP_CHECK(lc, hipGetLastError());
             return HBHIP_OK;
@@ -719,8 +723,16 @@ private:
             const dim3 block(64, 4), grid((B.w[0] + 255) / 256, (B.h[0] + 3) / 4, 3 * B.n);
             HBHIP_LAUNCH(lc, "decomb_plane", decomb_plane4_kernel, grid, block, 0, B);
         }
-        const bool any = !gathered.empty();
+        if (!gathered16.empty())
+        {
+            const dim3 block(64, 4), grid((in_geo.pw[0] + 63) / 64, (in_geo.ph[0] + 3) / 4, 3);
+            const int maxv = (1 << in_geo.depth) - 1;
+            for (const DecombArgs &a : gathered16)
+                HBHIP_LAUNCH(lc, "decomb_plane", decomb_plane_kernel<uint16_t>, grid, block, 0, a, maxv);
+        }
+        const bool any = !gathered.empty() || !gathered16.empty();
         gathered.clear();
+        gathered16.clear();
         if (any) HBHIP_CHECK(lc, hipGetLastError());
         return HBHIP_OK;
     }
@@ -761,8 +773,13 @@ private:
             int slot = -1;
             if ((mode & M_EEDI2) && eedi16)
             {
-                int rc = eedi16->run(cur, !parity);                              // pv->tff = !parity (decomb.c:542)
-                if (rc != HBHIP_OK) return rc;
+                if (eedi16->queued() == eedi16->capacity())
+                {
+                    int rc = flush_batch();
+                    if (rc != HBHIP_OK) return rc;
+                }
+                slot = eedi16->add_field(cur, !parity);                          // pv->tff = !parity (decomb.c:542)
+                if (slot < 0) return HBHIP_ERR_ARG;
             }
             else if ((mode & M_EEDI2) && eedi)
             {
@@ -801,6 +818,7 @@ private:
     std::vector<DevPicture *> late_unref;  // input pictures whose last reference went while something gathered could still read them
     bool deferred = false;
     std::vector<DecombFrame> gathered;     // blends waiting for their launch (launch_gathered)
+    std::vector<DecombArgs> gathered16;    // the same for 10 / 12-bit frames (one launch each)
     DecombBatch geo;                       // the pitches / sizes they share
 public:
     Eedi2Engine16 *eedi16 = nullptr;       // 10 / 12-bit samples
@@ -896,8 +914,8 @@ extern "C" int hbhip_decomb_debug_eedi_plane(hbhip_filter *f, int buffer, int pl
 {
     DecombFilter *d = dynamic_cast<DecombFilter *>(f);
     if (!d || (!d->engine() && !d->eedi16) || buffer < 0 || buffer > 8 || plane < 0 || plane > 2) return HBHIP_ERR_ARG;
-    const int slot = d->eedi16 ? 0 : d->engine()->last_slot();          // the latest run's scratch
-    const EediFrame fr = d->eedi16 ? (buffer < 4 ? d->eedi16->half(buffer) : d->eedi16->full(buffer - 4))
+    const int slot = d->eedi16 ? d->eedi16->last_slot() : d->engine()->last_slot();          // the latest run's scratch
+    const EediFrame fr = d->eedi16 ? (buffer < 4 ? d->eedi16->half(buffer, slot) : d->eedi16->full(buffer - 4, slot))
                                    : (buffer < 4 ? d->engine()->half(buffer, slot) : d->engine()->full(buffer - 4, slot));
     if (stride) *stride = fr.stride[plane];
     if (height) *height = fr.height[plane];

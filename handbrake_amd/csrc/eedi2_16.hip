@@ -11,6 +11,7 @@
 // zeroed guards, because the passes index flat buffers and read outside rows / planes.
 // All pitches inside the kernels are in SAMPLES.
 #include "eedi2_engine.h"
+#include <algorithm>
 
 namespace {
 
@@ -26,10 +27,28 @@ struct Q3
 {
     uint16_t *a[3], *b[3], *c[3];          // pass specific roles, see each kernel
     int pitch[3], width[3], height[3];
+    size_t   fstride;                      // field batching (see eedi2.hip): samples between the slots of consecutive fields
+    uint32_t tffbits;                      // bit f: pv->tff of field f of the launch
 };
 
+// blockIdx.z = 3 * field + plane: the block's pointers, picked once from the arguments (never written back, eedi2.hip)
+struct QL { uint16_t *a, *b, *c; };
+__device__ __forceinline__ QL plane_ptrs16(const Q3 &P, int pl, size_t off)
+{
+    QL q = { P.a[pl], P.b[pl], P.c[pl] };
+    if (q.a) q.a += off;
+    if (q.b) q.b += off;
+    if (q.c) q.c += off;
+    return q;
+}
+#define FIELD16(P)                                                           \
+    const int fld = (int)blockIdx.z / 3, pl = (int)blockIdx.z - 3 * fld;     \
+    const int tff = (int)(((P).tffbits >> fld) & 1u);                        \
+    const QL Q = plane_ptrs16((P), pl, (size_t)fld * (P).fstride);           \
+    (void)tff
+
 #define XY16(P)                                                              \
-    const int pl = blockIdx.z;                                               \
+    FIELD16(P);                                                              \
     const int x = blockIdx.x * blockDim.x + threadIdx.x;                     \
     const int y = blockIdx.y * blockDim.y + threadIdx.y;                     \
     const int pitch = (P).pitch[pl], width = (P).width[pl], height = (P).height[pl]; \
@@ -55,97 +74,206 @@ __device__ __forceinline__ int sorted_mid16(int *v, int n)
     return (n & 1) ? v[n >> 1] : (v[(n - 1) >> 1] + v[n >> 1] + 1) >> 1;
 }
 
-// a = source plane (pitch in samples in `sp*`), b = srcp.  Device frames have no row padding:
-// samples at x >= width are written as 0 (see the 8-bit k_fill_half).
-__global__ void q_fill_half(Q3 P, int sp0, int sp1, int sp2, int start_line, int rows0, int rows1, int rows2)
+// ---- the field extraction and the five mask passes in one launch, as for 8-bit samples (eedi2.hip: k_mask_fused4) ----
+// build_edge_mask -> erode -> dilate -> erode -> remove_small_gaps each look one sample (three along x for the last)
+// around themselves, so a workgroup carries a 128 x 16 tile of the final mask through all of them in LDS with a
+// shrinking halo.  Only build_edge_mask sees samples; the mask itself is 0 / peak at any depth, so inside the kernel a
+// mask cell is a byte holding 0 / 1 and the morphology runs on four cells per 32-bit operation exactly as in the 8-bit
+// kernel.  a = SRCPF (written: the tile's part of the extracted field), b = the finished mask of the field before
+// field 0 of the launch, c = MSKPF.  `part`: 0 = every tile, 1 = only the tiles whose LDS frame stays above height / 2
+// (independent of the previous field: all fields of a batch in one launch), 2 = only the others (the chain).
+constexpr int QM_W = 128, QM_H = 16, QM_OX = 8, QM_OY = 4;
+constexpr int QM_LP = QM_W + 2 * QM_OX, QM_LR = QM_H + 2 * QM_OY;      // 144 x 24
+constexpr int QM_DW = QM_LP / 4, QM_DP = QM_DW + 2, QM_SR = 2, QM_T = 512;
+
+__device__ __forceinline__ uint32_t qm_bytes_in(int X, int lo, int hi)        // 0xff in byte k when lo <= X + k < hi
 {
-    XY16(P);
-    const int sp = pl == 0 ? sp0 : pl == 1 ? sp1 : sp2;
-    const int rows = pl == 0 ? rows0 : pl == 1 ? rows1 : rows2;
-    if (x >= pitch || y >= rows) return;
-    P.b[pl][(size_t)y * pitch + x] = x < width ? P.a[pl][(size_t)(start_line + 2 * y) * sp + x] : (uint16_t)0;
+    uint32_t m = 0xffffffffu;
+    const int a = lo - X, b = hi - X;
+    if (a > 0) m = a >= 4 ? 0u : (m << (8 * a));
+    if (b < 4) m = b <= 0 ? 0u : (m & (0xffffffffu >> (8 * (4 - b))));
+    return m;
 }
 
-// eedi2_build_edge_mask (:122-195), in place: a = srcp, c = mskp.  Rows of the upper half are cleared
-// first (whole pitch), the lower half keeps the previous run's mask where nothing is set (:132).
-__global__ void q_edge_mask(Q3 P, K16 k, int mth, int vth, int lth)
+template <bool GROW>
+__device__ __forceinline__ void qm_morph4(const uint32_t (*src)[QM_DP], uint32_t (*dst)[QM_DP], int c4, int strip,
+                                          int ra, int rb, int thr, uint32_t px1, int fy, int height)
 {
-    XY16(P);
-    if (x >= pitch || y >= height) return;
-    bool set = false;
-    if (x >= 1 && x < width - 1 && y >= 1 && y < height - 1)
+    const int r0 = ra + strip * QM_SR;
+    if (r0 <= rb)
     {
-        const uint16_t *c = P.a[pl] + (size_t)y * pitch, *p = c - pitch, *n = c + pitch;
-        const int ten = (uint16_t)(10 << k.shift), sh = k.shift;
-        auto flat = [&](int i) {
-            return iabs16((int)p[i] - (int)c[i]) < ten && iabs16((int)c[i] - (int)n[i]) < ten && iabs16((int)p[i] - (int)n[i]) < ten;
-        };
-        if (!(flat(x) || (flat(x - 1) && flat(x + 1))))
+        const uint32_t K = (uint32_t)(0x80 - min(max(thr, 0), 9)) * 0x01010101u;
+        uint32_t S2[QM_SR + 2], S3[QM_SR + 2], C[QM_SR + 2];
+#pragma unroll
+        for (int i = 0; i < QM_SR + 2; i++)
         {
-            int sum = 0, sumsq = 0;
-            for (int i = -1; i <= 1; i++)
+            const int r = min(r0 - 1 + i, QM_LR - 1);
+            const uint32_t l = src[r][c4], c = src[r][c4 + 1], rr = src[r][c4 + 2];
+            C[i] = c;
+            S2[i] = __builtin_amdgcn_alignbyte(c, l, 3) + __builtin_amdgcn_alignbyte(rr, c, 1);
+            S3[i] = S2[i] + c;
+        }
+#pragma unroll
+        for (int i = 0; i < QM_SR; i++)
+        {
+            const int r = r0 + i;
+            if (r > rb) break;
+            const int y = fy + r;
+            const uint32_t count = S3[i] + S2[i + 1] + S3[i + 2];
+            const uint32_t ge = ((count + K) >> 7) & 0x01010101u;          // count >= thr, per cell
+            const uint32_t pm = (y >= 1 && y < height - 1) ? px1 : 0u;
+            const uint32_t c = C[i + 1];
+            dst[r][c4 + 1] = GROW ? (c | (ge & pm)) : (c & ~((ge ^ 0x01010101u) & pm));
+        }
+    }
+    __syncthreads();
+}
+
+struct MaskSrc16 { const uint16_t *frame[EEDI_MAX_BATCH][3]; int sp[3]; };     // sp: frame pitch in samples
+
+__global__ __launch_bounds__(QM_T) void q_mask_fused(Q3 P, MaskSrc16 S, K16 k, int f0, int part, int mth, int vth, int lth,
+                                                     int erode_thr, int dilate_thr)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t s_src[QM_LR][QM_LP + 8];   // sample column = frame column + 4
+    __shared__ uint32_t s_a[QM_LR][QM_DP];
+    __shared__ uint32_t s_b[QM_LR][QM_DP];
+    const int zf = (int)blockIdx.z / 3, pl = (int)blockIdx.z - 3 * zf, fld = f0 + zf;   // f0: first field of this launch
+    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
+    const int x0 = blockIdx.x * QM_W, y0 = blockIdx.y * QM_H;
+    if (x0 >= width || y0 >= height) return;
+    const bool upper = y0 + QM_H + QM_OY <= height / 2;            // no row of the LDS frame reaches the kept half
+    if (part != 0 && upper != (part == 1)) return;
+    const size_t foff = (size_t)fld * P.fstride;
+    const uint16_t *oldm = fld == 0 ? P.b[pl] : P.c[pl] + foff - P.fstride;
+    const uint16_t *frame = S.frame[fld][pl];
+    const int start_line = (int)(((P.tffbits >> fld) & 1u) ^ 1u);
+    uint16_t *srcp = P.a[pl] + foff, *newm = P.c[pl] + foff;
+    const int t = threadIdx.x, fx = x0 - QM_OX, fy = y0 - QM_OY;
+    const int peak = k.peak, sh = k.shift;
+
+    for (int i = t; i < QM_LR * QM_DW; i += QM_T)
+    {
+        const int r = i / QM_DW, c4 = i - r * QM_DW;
+        const int y = fy + r, x = fx + 4 * c4;
+        uint2 sv = make_uint2(0u, 0u);
+        uint32_t mv = 0;
+        if (y >= 0 && y < height && x >= 0 && x < pitch)
+        {
+            if (x < width)
             {
-                sum += (int)p[x + i] + (int)c[x + i] + (int)n[x + i];
-                sumsq += (p[x + i] >> sh) * (p[x + i] >> sh) + (c[x + i] >> sh) * (c[x + i] >> sh) + (n[x + i] >> sh) * (n[x + i] >> sh);
-            }
-            sum >>= sh;
-            if (!(9 * sumsq - sum * sum < vth))
-            {
-                const int ix = ((int)c[x + 1] - (int)c[x - 1]) >> sh;
-                const int iy = max(max(iabs16((int)p[x] - (int)n[x]), iabs16((int)p[x] - (int)c[x])), iabs16((int)c[x] - (int)n[x])) >> sh;
-                if (ix * ix + iy * iy >= mth) set = true;
-                else
+                sv = *reinterpret_cast<const uint2 *>(frame + (size_t)(start_line + 2 * y) * S.sp[pl] + x);
+                const int n = width - x;                           // samples at x >= width read as 0
+                if (n < 4)
                 {
-                    const int ixx = ((int)c[x - 1] - 2 * (int)c[x] + (int)c[x + 1]) >> sh;
-                    const int iyy = ((int)p[x] - 2 * (int)c[x] + (int)n[x]) >> sh;
-                    set = iabs16(ixx) + iabs16(iyy) >= lth;
+                    if (n <= 2) sv.y = 0;
+                    if (n == 3) sv.y &= 0xffffu;
+                    if (n == 1) sv.x &= 0xffffu;
                 }
             }
+            // the tile's own cells go out as SRCPF (every cell of the plane belongs to exactly one tile)
+            if (r >= QM_OY && r < QM_OY + QM_H && c4 >= QM_OX / 4 && c4 < (QM_OX + QM_W) / 4)
+                *reinterpret_cast<uint2 *>(srcp + (size_t)y * pitch + x) = sv;
+            if (!upper)
+            {
+                const uint2 ov = *reinterpret_cast<const uint2 *>(oldm + (size_t)y * pitch + x);
+                mv = ((ov.x & 0xffffu) == (uint32_t)peak ? 1u : 0u) | ((ov.x >> 16) == (uint32_t)peak ? 0x100u : 0u) |
+                     ((ov.y & 0xffffu) == (uint32_t)peak ? 0x10000u : 0u) | ((ov.y >> 16) == (uint32_t)peak ? 0x1000000u : 0u);
+            }
         }
+        *reinterpret_cast<uint2 *>(&s_src[r][4 * c4 + 4]) = sv;
+        s_a[r][c4 + 1] = mv;
     }
-    uint16_t *o = P.c[pl] + (size_t)y * pitch + x;
-    if (set) *o = (uint16_t)k.peak;
-    else if (y < height / 2) *o = 0;
-}
+    __syncthreads();
 
-__device__ __forceinline__ int peaks_around16(const uint16_t *p, const uint16_t *c, const uint16_t *n, int x, int peak)
-{
-    return (p[x - 1] == peak) + (p[x] == peak) + (p[x + 1] == peak) + (c[x - 1] == peak) +
-           (c[x + 1] == peak) + (n[x - 1] == peak) + (n[x] == peak) + (n[x + 1] == peak);
-}
+    const int c4 = t % QM_DW, strip = t / QM_DW;               // strips past the frame have no rows in any pass
+    const int X = fx + 4 * c4;
+    const uint32_t px1 = qm_bytes_in(X, 1, width - 1) & 0x01010101u;
 
-// dilate (:207-247) when grow, erode (:259-293) otherwise: a = mask in, c = out
-__global__ void q_morph(Q3 P, K16 k, int thr, int grow)
-{
-    XY16(P);
-    if (x >= width || y >= height) return;
-    const uint16_t *c = P.a[pl] + (size_t)y * pitch, *p = c - pitch, *n = c + pitch;
-    int v = c[x];
-    if (x >= 1 && x < width - 1 && y >= 1 && y < height - 1)
+    // build_edge_mask (:122-195), in place on the old mask; LDS rows 1 .. 22
     {
-        if (grow) { if (v == 0 && peaks_around16(p, c, n, x, k.peak) >= thr) v = k.peak; }
-        else      { if (v == k.peak && peaks_around16(p, c, n, x, k.peak) < thr) v = 0; }
-    }
-    P.c[pl][(size_t)y * pitch + x] = (uint16_t)v;
-}
-
-// eedi2_remove_small_gaps (:308-342): a = mask in, c = out
-__global__ void q_small_gaps(Q3 P, K16 k)
-{
-    XY16(P);
-    if (x >= width || y >= height) return;
-    const uint16_t *m = P.a[pl] + (size_t)y * pitch;
-    int v = m[x];
-    if (x >= 3 && x < width - 3 && y >= 1 && y < height - 1)
-    {
-        if (m[x])
+        const int r0 = 1 + strip * QM_SR;
+        if (r0 <= QM_LR - 2)
         {
-            if (!(m[x - 3] || m[x - 2] || m[x - 1] || m[x + 1] || m[x + 2] || m[x + 3])) v = 0;
+            const int ten = (uint16_t)(10 << sh);
+            int b[QM_SR + 2][6], q[QM_SR + 2][6];
+#pragma unroll
+            for (int i = 0; i < QM_SR + 2; i++)
+            {
+                const int r = min(r0 - 1 + i, QM_LR - 1);
+                const uint16_t *row = &s_src[r][4 * c4 + 4];      // samples X .. X + 3 at row[0 .. 3]
+                const uint2 c = *reinterpret_cast<const uint2 *>(row);
+                b[i][0] = (int)row[-1];                            // column X - 1 (c4 = 0: a pad column, its cells are masked out)
+                b[i][1] = (int)(c.x & 0xffffu); b[i][2] = (int)(c.x >> 16); b[i][3] = (int)(c.y & 0xffffu); b[i][4] = (int)(c.y >> 16);
+                b[i][5] = (int)row[4];
+#pragma unroll
+                for (int j = 0; j < 6; j++) q[i][j] = (b[i][j] >> sh) * (b[i][j] >> sh);
+            }
+#pragma unroll
+            for (int i = 0; i < QM_SR; i++)
+            {
+                const int r = r0 + i;
+                if (r > QM_LR - 2) break;
+                const int y = fy + r;
+                const int (&Pr)[6] = b[i], (&Cr)[6] = b[i + 1], (&Nr)[6] = b[i + 2];
+                int cs[6], cq[6];
+                bool fl[6];
+#pragma unroll
+                for (int j = 0; j < 6; j++)
+                {
+                    cs[j] = Pr[j] + Cr[j] + Nr[j];
+                    cq[j] = q[i][j] + q[i + 1][j] + q[i + 2][j];
+                    fl[j] = iabs16(Pr[j] - Cr[j]) < ten && iabs16(Cr[j] - Nr[j]) < ten && iabs16(Pr[j] - Nr[j]) < ten;
+                }
+                uint32_t edge = 0;
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++)
+                {
+                    const int sum = (cs[kk] + cs[kk + 1] + cs[kk + 2]) >> sh, sumsq = cq[kk] + cq[kk + 1] + cq[kk + 2];
+                    const int C0 = Cr[kk], C1 = Cr[kk + 1], C2 = Cr[kk + 2], P1 = Pr[kk + 1], N1 = Nr[kk + 1];
+                    const int ix = (C2 - C0) >> sh;
+                    const int iy = max(max(iabs16(P1 - N1), iabs16(P1 - C1)), iabs16(C1 - N1)) >> sh;
+                    const int ixx = (C0 - 2 * C1 + C2) >> sh, iyy = (P1 - 2 * C1 + N1) >> sh;
+                    const bool e = !(fl[kk + 1] || (fl[kk] && fl[kk + 2])) && !(9 * sumsq - sum * sum < vth) &&
+                                   (ix * ix + iy * iy >= mth || iabs16(ixx) + iabs16(iyy) >= lth);
+                    edge |= (e ? 1u : 0u) << (8 * kk);
+                }
+                const uint32_t keep = (y < height / 2) ? 0u : s_a[r][c4 + 1];
+                const uint32_t pm = (y >= 1 && y < height - 1) ? px1 : 0u;
+                s_a[r][c4 + 1] = keep | (edge & pm);
+            }
         }
-        else if ((m[x + 1] && (m[x - 1] || m[x - 2] || m[x - 3])) || (m[x + 2] && (m[x - 1] || m[x - 2])) || (m[x + 3] && m[x - 1]))
-            v = k.peak;
     }
-    P.c[pl][(size_t)y * pitch + x] = (uint16_t)v;
+    __syncthreads();
+
+    qm_morph4<false>(s_a, s_b, c4, strip, 2, QM_LR - 3, erode_thr, px1, fy, height);
+    qm_morph4<true>(s_b, s_a, c4, strip, 3, QM_LR - 4, dilate_thr, px1, fy, height);
+    qm_morph4<false>(s_a, s_b, c4, strip, 4, QM_LR - 5, erode_thr, px1, fy, height);
+
+    // remove_small_gaps (:308-342) on the tile's 16 rows x 32 cell dwords, straight to the new mask
+    for (int i = t; i < QM_H * (QM_W / 4); i += QM_T)
+    {
+        const int r = QM_OY + i / (QM_W / 4), g4 = QM_OX / 4 + (i & (QM_W / 4 - 1));
+        const int y = fy + r, x = fx + 4 * g4;
+        if (y >= height || x >= width) continue;
+        const uint32_t l = s_b[r][g4], c = s_b[r][g4 + 1], rr = s_b[r][g4 + 2];
+        const uint32_t a1 = __builtin_amdgcn_alignbyte(c, l, 3), a2 = __builtin_amdgcn_alignbyte(c, l, 2), a3 = __builtin_amdgcn_alignbyte(c, l, 1);
+        const uint32_t b1 = __builtin_amdgcn_alignbyte(rr, c, 1), b2 = __builtin_amdgcn_alignbyte(rr, c, 2), b3 = __builtin_amdgcn_alignbyte(rr, c, 3);
+        const uint32_t a12 = a1 | a2, a123 = a12 | a3;
+        const uint32_t set = c & (a123 | b1 | b2 | b3);                               // a set cell survives with any neighbour set
+        const uint32_t fill = ((b1 & a123) | (b2 & a12) | (b3 & a1)) & (c ^ 0x01010101u);
+        const uint32_t pm = (y >= 1 && y < height - 1) ? (qm_bytes_in(x, 3, width - 3) & 0x01010101u) : 0u;
+        const uint32_t res = ((set | fill) & pm) | (c & ~pm);                         // 0 / 1 per cell
+        const uint32_t pk = (uint32_t)peak;
+        const uint2 out = make_uint2(((res & 1u) ? pk : 0u) | ((res & 0x100u) ? pk << 16 : 0u),
+                                     ((res & 0x10000u) ? pk : 0u) | ((res & 0x1000000u) ? pk << 16 : 0u));
+        uint16_t *d = newm + (size_t)y * pitch + x;
+        if (x + 3 < width) *reinterpret_cast<uint2 *>(d) = out;
+        else
+        {
+            const uint16_t o4[4] = { (uint16_t)(out.x & 0xffffu), (uint16_t)(out.x >> 16), (uint16_t)(out.y & 0xffffu), (uint16_t)(out.y >> 16) };
+            for (int kk = 0; kk < 4 && x + kk < width; kk++) d[kk] = o4[kk];
+        }
+    }
 }
 
 // eedi2_calc_directions (:358-525): a = mskp, b = srcp, c = out (whole pitch pre-filled with PEAK)
@@ -155,10 +283,10 @@ __global__ void q_calc_dir(Q3 P, K16 k, int maxd, int nt)
     if (x >= pitch || y >= height) return;
     const int peak = k.peak;
     int out = peak;
-    const uint16_t *mc = P.a[pl] + (size_t)y * pitch, *mp = mc - pitch, *mn = mc + pitch;
+    const uint16_t *mc = Q.a + (size_t)y * pitch, *mp = mc - pitch, *mn = mc + pitch;
     if (x >= 1 && x < width - 1 && y >= 1 && y < height - 1 && mc[x] == peak && (mc[x - 1] == peak || mc[x + 1] == peak))
     {
-        const uint16_t *sc = P.b[pl] + (size_t)y * pitch, *sp = sc - pitch, *s2p = sp - pitch, *sn = sc + pitch, *s2n = sn + pitch;
+        const uint16_t *sc = Q.b + (size_t)y * pitch, *sp = sc - pitch, *s2p = sp - pitch, *sn = sc + pitch, *s2n = sn + pitch;
         const int nt13 = (uint16_t)((nt << k.shift) * 13), nt19 = (uint16_t)((nt << k.shift) * 19);
         const int maxdt = pl == 0 ? maxd : (maxd >> 1);
         const int startu = max(-x + 1, -maxdt), stopu = min(width - 2 - x, maxdt);
@@ -215,7 +343,7 @@ __global__ void q_calc_dir(Q3 P, K16 k, int maxd, int nt)
             if (count > 1) out = (uint16_t)(k.neutral + ((int)((float)sum / (float)count) << (2 + k.shift)));
         }
     }
-    P.c[pl][(size_t)y * pitch + x] = (uint16_t)out;
+    Q.c[(size_t)y * pitch + x] = (uint16_t)out;
 }
 
 // calc_directions for search distances <= 30, the form that runs: the structure of k_calc_dir_rows (eedi2.hip) on 16-bit
@@ -312,7 +440,7 @@ __global__ __launch_bounds__(QW) void q_calc_dir_rows(Q3 P, K16 k, int maxd, int
     __shared__ __attribute__((aligned(16))) uint16_t s_out[R][QW];
     __shared__ int s_lim[33];
     __shared__ int s_count;
-    const int pl = blockIdx.z;
+    FIELD16(P);
     const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
     const int x0 = blockIdx.x * QW, y0 = blockIdx.y * R;
     if (y0 >= height || x0 >= pitch) return;
@@ -325,7 +453,7 @@ __global__ __launch_bounds__(QW) void q_calc_dir_rows(Q3 P, K16 k, int maxd, int
     {
         // flat addressing (out-of-row columns pick up the neighbouring rows' samples, as the reference's pointer arithmetic
         // does); rows past height + 1 serve no pixel and are not touched
-        const uint16_t *sb = P.b[pl] + x0 - QHALO, *mb = P.a[pl] + x0 - QHALO;
+        const uint16_t *sb = Q.b + x0 - QHALO, *mb = Q.a + x0 - QHALO;
         for (int i = tid; i < (NS + NM) * RWD; i += QW)
         {
             const int r = i / RWD, c2 = i - r * RWD;
@@ -417,7 +545,7 @@ __global__ __launch_bounds__(QW) void q_calc_dir_rows(Q3 P, K16 k, int maxd, int
     {
         const int j = i / (QW / 2), c2 = i - j * (QW / 2), y = y0 + j, xb = x0 + 2 * c2;
         if (y < height && xb < pitch)
-            *reinterpret_cast<uint32_t *>(P.c[pl] + (size_t)y * pitch + xb) = reinterpret_cast<const uint32_t *>(&s_out[j][0])[c2];
+            *reinterpret_cast<uint32_t *>(Q.c + (size_t)y * pitch + xb) = reinterpret_cast<const uint32_t *>(&s_out[j][0])[c2];
     }
 }
 
@@ -472,19 +600,20 @@ __device__ __forceinline__ void vote1q(int v, int mid, int lim, int &sum, int &c
     sum += in ? v : 0;
 }
 
-__global__ void q_dir_map(Q3 P, K16 k, int step, int y0, int expand)
+__global__ void q_dir_map(Q3 P, K16 k, int step, int expand)
 {
     XY16(P);
+    const int y0 = step == 1 ? 1 : 2 - tff;
     if (x >= width || y >= height) return;
     const int peak = k.peak;
-    const uint16_t *dc = P.b[pl] + (size_t)y * pitch;
+    const uint16_t *dc = Q.b + (size_t)y * pitch;
     int v = dc[x];
     const bool row_on = step == 1 ? (y >= 1 && y < height - 1) : (y >= y0 && y < height - 1 && ((y - y0) & 1) == 0);
     if (row_on && x >= 1 && x < width - 1)
     {
         bool masked;
-        if (step == 1) masked = P.a[pl][(size_t)y * pitch + x] == peak;
-        else           masked = P.a[pl][(size_t)(y - 1) * pitch + x] == peak || P.a[pl][(size_t)(y + 1) * pitch + x] == peak;
+        if (step == 1) masked = Q.a[(size_t)y * pitch + x] == peak;
+        else           masked = Q.a[(size_t)(y - 1) * pitch + x] == peak || Q.a[(size_t)(y + 1) * pitch + x] == peak;
         if (masked && !(expand && v != peak))
         {
             const bool up_ok = step == 1 || y > 1, dn_ok = step == 1 || y < height - 2;
@@ -516,7 +645,7 @@ __global__ void q_dir_map(Q3 P, K16 k, int step, int y0, int expand)
             }
         }
     }
-    P.c[pl][(size_t)y * pitch + x] = (uint16_t)v;
+    Q.c[(size_t)y * pitch + x] = (uint16_t)v;
 }
 
 __device__ __forceinline__ bool trips16(const uint16_t *side, const uint16_t *dc, int x, int from, int to, int lim, int peak)
@@ -535,9 +664,9 @@ __global__ void q_filter_map(Q3 P, K16 k)
     XY16(P);
     if (x >= width || y >= height) return;
     const int peak = k.peak;
-    const uint16_t *dc = P.b[pl] + (size_t)y * pitch;
+    const uint16_t *dc = Q.b + (size_t)y * pitch;
     int v = dc[x];
-    if (x >= 1 && x < width - 1 && y >= 1 && y < height - 1 && dc[x] != peak && P.a[pl][(size_t)y * pitch + x] == peak)
+    if (x >= 1 && x < width - 1 && y >= 1 && y < height - 1 && dc[x] != peak && Q.a[(size_t)y * pitch + x] == peak)
     {
         const uint16_t *dp = dc - pitch, *dn = dc + pitch;
         int dir = ((int)dc[x] - k.neutral) >> 2;
@@ -554,30 +683,34 @@ __global__ void q_filter_map(Q3 P, K16 k)
             if (icb) v = peak;
         }
     }
-    P.c[pl][(size_t)y * pitch + x] = (uint16_t)v;
+    Q.c[(size_t)y * pitch + x] = (uint16_t)v;
 }
 
-// eedi2_upscale_by_2 (:98-108): whole pitch; a = half-height in, c = full-height out (height = half height)
+// eedi2_upscale_by_2 (:98-108): whole pitch; a = half-height in, c = full-height out (height = half height).
+// Eight samples (16 bytes) per thread: the pitches are multiples of 32 samples and the planes 64-byte aligned.
 __global__ void q_upscale(Q3 P)
 {
-    XY16(P);
+    FIELD16(P);
+    const int x = 8 * (blockIdx.x * blockDim.x + threadIdx.x), y = blockIdx.y * blockDim.y + threadIdx.y;
+    const int pitch = P.pitch[pl], height = P.height[pl];
     if (x >= pitch || y >= height) return;
-    const uint16_t v = P.a[pl][(size_t)y * pitch + x];
-    P.c[pl][(size_t)(2 * y) * pitch + x] = v;
-    P.c[pl][(size_t)(2 * y + 1) * pitch + x] = v;
+    const uint4 v = *reinterpret_cast<const uint4 *>(Q.a + (size_t)y * pitch + x);
+    *reinterpret_cast<uint4 *>(Q.c + (size_t)(2 * y) * pitch + x) = v;
+    *reinterpret_cast<uint4 *>(Q.c + (size_t)(2 * y + 1) * pitch + x) = v;
 }
 
 // eedi2_mark_directions_2x (:787-858): a = msk2p, b = tmp2p2 (direction map), c = out (pre-filled PEAK, whole pitch)
-__global__ void q_mark_2x(Q3 P, K16 k, int y0)
+__global__ void q_mark_2x(Q3 P, K16 k)
 {
     XY16(P);
+    const int y0 = 2 - tff;
     if (x >= pitch || y >= height) return;
     const int peak = k.peak;
     int v = peak;
     if (x >= 1 && x < width - 1 && y >= y0 && y < height - 1 && ((y - y0) & 1) == 0)
     {
-        const uint16_t *d0 = P.b[pl] + (size_t)(y - 1) * pitch, *d1 = d0 + 2 * (size_t)pitch;
-        const uint16_t *m0 = P.a[pl] + (size_t)(y - 1) * pitch, *m1 = m0 + 2 * (size_t)pitch;
+        const uint16_t *d0 = Q.b + (size_t)(y - 1) * pitch, *d1 = d0 + 2 * (size_t)pitch;
+        const uint16_t *m0 = Q.a + (size_t)(y - 1) * pitch, *m1 = m0 + 2 * (size_t)pitch;
         if (m0[x] == peak || m1[x] == peak)
         {
             const int a0 = d0[x - 1], a1 = d0[x], a2 = d0[x + 1], b0 = d1[x - 1], b1 = d1[x], b2 = d1[x + 1];
@@ -604,20 +737,21 @@ __global__ void q_mark_2x(Q3 P, K16 k, int y0)
             }
         }
     }
-    P.c[pl][(size_t)y * pitch + x] = (uint16_t)v;
+    Q.c[(size_t)y * pitch + x] = (uint16_t)v;
 }
 
 // eedi2_fill_gaps_2x (:1025-1132): a = msk2p, b = direction map in, c = out.  Launched after a copy
 // of b into c; a thread whose sample opens a fillable gap writes the whole span (every thread of the
 // same gap computes and writes the same values).
-__global__ void q_fill_gaps(Q3 P, K16 k, int y0)
+__global__ void q_fill_gaps(Q3 P, K16 k)
 {
     XY16(P);
+    const int y0 = 2 - tff;
     if (x < 1 || x >= width - 1 || y < y0 || y >= height - 1 || ((y - y0) & 1)) return;
     const int peak = k.peak;
-    const uint16_t *dc = P.b[pl] + (size_t)y * pitch;
+    const uint16_t *dc = Q.b + (size_t)y * pitch;
     const uint16_t *dp = dc - 2 * (ptrdiff_t)pitch, *dn = dc + 2 * (ptrdiff_t)pitch;
-    const uint16_t *mc = P.a[pl] + (size_t)(y - 1) * pitch;
+    const uint16_t *mc = Q.a + (size_t)(y - 1) * pitch;
     const uint16_t *mp = mc - 2 * (ptrdiff_t)pitch, *mn = mc + 2 * (ptrdiff_t)pitch, *mnn = mn + 2 * (ptrdiff_t)pitch;
     if (dc[x] != peak || (mc[x] != peak && mn[x] != peak)) return;
     const int eight = 8 << k.shift, twenty = 20 << k.shift, five_hundred = 500 << k.shift;
@@ -657,18 +791,23 @@ __global__ void q_fill_gaps(Q3 P, K16 k, int y0)
     if (iabs16(forward - back) <= thresh && (v - u - 1 <= flim || tc || bc))
     {
         const double step = (double)(forward - back) / (double)(v - u);
-        uint16_t *o = P.c[pl] + (size_t)y * pitch;
+        uint16_t *o = Q.c + (size_t)y * pitch;
         for (int j = 0; j < v - u - 1; j++)
             o[u + j + 1] = (uint16_t)(back + (int)(j * step + 0.5));
     }
 }
 
-// plain copy of the visible width (eedi2_bit_blit :46-68): a = in, c = out
+// plain copy of the visible width (eedi2_bit_blit :46-68): a = in, c = out; eight samples per thread
 __global__ void q_blit(Q3 P)
 {
-    XY16(P);
+    FIELD16(P);
+    const int x = 8 * (blockIdx.x * blockDim.x + threadIdx.x), y = blockIdx.y * blockDim.y + threadIdx.y;
+    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
     if (x >= width || y >= height) return;
-    P.c[pl][(size_t)y * pitch + x] = P.a[pl][(size_t)y * pitch + x];
+    const uint16_t *in = Q.a + (size_t)y * pitch + x;
+    uint16_t *out = Q.c + (size_t)y * pitch + x;
+    if (x + 7 < width) *reinterpret_cast<uint4 *>(out) = *reinterpret_cast<const uint4 *>(in);
+    else for (int i = 0; x + i < width; i++) out[i] = in[i];
 }
 
 // interpolate_lattice in two launches, as for 8-bit samples (eedi2.hip: k_lattice_cand / k_lattice_resolve).  Of all a
@@ -679,10 +818,12 @@ __global__ void q_blit(Q3 P)
 //   bit 48 = "always A" (direction == peak)      bit 49 = right-hand test |d[x] - d[x+1]| > lim
 // q_lattice_resolve16 (one workgroup per row) resolves which outcome each pixel takes: every pixel is a 2-state map of
 // its left neighbour's outcome, composed by a prefix scan, and writes the row.
-__global__ __launch_bounds__(256) void q_lattice_cand(Q3 P, K16 k, int field, int nt, unsigned long long *__restrict__ cand,
+__global__ __launch_bounds__(256) void q_lattice_cand(Q3 P, K16 k, int nt, unsigned long long *__restrict__ cand,
                                                       int cand_pitch, int cand_plane_stride)
 {
-    const int pl = blockIdx.z;
+    FIELD16(P);
+    const int field = tff;
+    cand += (size_t)fld * (P.fstride / 4);                         // the candidates live in the field's slot (64-bit words)
     const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
     const int x = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
     const int nrows = (height - 1 - (2 - field) + 1) / 2;
@@ -691,9 +832,9 @@ __global__ __launch_bounds__(256) void q_lattice_cand(Q3 P, K16 k, int field, in
     const int peak = k.peak, neutral = k.neutral, sh = k.shift, sh2 = 2 + k.shift;
     const int nt4 = (uint16_t)((nt << sh) * 4), nt7 = (uint16_t)((nt << sh) * 7), nt8 = (uint16_t)((nt << sh) * 8);
     const int three = 3 << sh, nine = 9 << sh;
-    const uint16_t *top = P.b[pl] + (size_t)(y - 1) * pitch, *bot = top + 2 * (size_t)pitch;
-    const uint16_t *ot = P.c[pl] + (size_t)(y - 1) * pitch, *ob = ot + 2 * (size_t)pitch;
-    const uint16_t *dm = P.a[pl] + (size_t)y * pitch;
+    const uint16_t *top = Q.b + (size_t)(y - 1) * pitch, *bot = top + 2 * (size_t)pitch;
+    const uint16_t *ot = Q.c + (size_t)(y - 1) * pitch, *ob = ot + 2 * (size_t)pitch;
+    const uint16_t *dm = Q.a + (size_t)y * pitch;
     int dir = dm[x];
     const int here = dir;
     const int lim = k.limlut[iabs16(dir - neutral) >> sh2];
@@ -780,17 +921,19 @@ __global__ __launch_bounds__(256) void q_lattice_cand(Q3 P, K16 k, int field, in
 
 constexpr int LR16_T = 1024;
 
-__global__ __launch_bounds__(LR16_T) void q_lattice_resolve16(Q3 P, K16 k, int field, const unsigned long long *__restrict__ cand,
+__global__ __launch_bounds__(LR16_T) void q_lattice_resolve16(Q3 P, K16 k, const unsigned long long *__restrict__ cand,
                                                               int cand_pitch, int cand_plane_stride)
 {
     __shared__ uint8_t s_wmap[LR16_T / 64];        // composed map of each wave
     __shared__ uint8_t s_win[LR16_T / 64];         // resolved state entering each wave
     __shared__ int s_carry;                        // outcome of the last pixel of the previous pass
-    const int pl = blockIdx.z;
+    FIELD16(P);
+    const int field = tff;
+    cand += (size_t)fld * (P.fstride / 4);
     const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int nrows = (height - 1 - (2 - field) + 1) / 2;
-    uint16_t *dst = P.b[pl];
+    uint16_t *dst = Q.b;
     if ((int)blockIdx.y >= nrows)
     {
         if ((int)blockIdx.y == nrows)                              // the one-row blit (:1162-1179)
@@ -803,7 +946,7 @@ __global__ __launch_bounds__(LR16_T) void q_lattice_resolve16(Q3 P, K16 k, int f
     }
     const int y = (2 - field) + 2 * blockIdx.y;
     uint16_t *mid = dst + (size_t)y * pitch;
-    uint16_t *dm = P.a[pl] + (size_t)y * pitch;
+    uint16_t *dm = Q.a + (size_t)y * pitch;
     const unsigned long long *cr = cand + (size_t)pl * cand_plane_stride + (size_t)blockIdx.y * cand_pitch;
     const int sh2 = 2 + k.shift;
     const int before_row = dm[-1];                                 // stands at dm[x-1] for x == 0; never written by this pass
@@ -875,16 +1018,17 @@ __global__ __launch_bounds__(LR16_T) void q_lattice_resolve16(Q3 P, K16 k, int f
 }
 
 // eedi2_post_process (:1349-1378): a = new direction map, b = old one, c = dst2p (in place, rows y from y+-1)
-__global__ void q_post(Q3 P, K16 k, int y0)
+__global__ void q_post(Q3 P, K16 k)
 {
     XY16(P);
+    const int y0 = 2 - tff;
     if (x >= width || y < y0 || y >= height - 1 || ((y - y0) & 1)) return;
     const size_t at = (size_t)y * pitch + x;
-    const int nm = P.a[pl][at], om = P.b[pl][at];
+    const int nm = Q.a[at], om = Q.b[at];
     const int lim = k.limlut[iabs16(nm - k.neutral) >> (2 + k.shift)];
     if (iabs16(nm - om) > lim && om != k.peak && om != k.neutral)
     {
-        uint16_t *d = P.c[pl] + at;
+        uint16_t *d = Q.c + at;
         *d = (uint16_t)(((int)d[-pitch] + (int)d[pitch] + 1) >> 1);
     }
 }
@@ -987,15 +1131,19 @@ __global__ void q_post_corner(Corner16 A, const uint16_t *msk, uint16_t *dst, in
 } // namespace
 
 // ------------------------------------------------------------------- engine
-Eedi2Engine16::Eedi2Engine16(hbhip_ctx *ctx, const PicGeometry &geo, const Eedi2Params &p) : ctx_(ctx), geo_(geo), par_(p) {}
+// The field batching of the 8-bit engine (eedi2.hip): a slot per field (its nine scratch frames + lattice candidates),
+// fields queued with add_field() and run by launch(): the field extraction for all of them in one launch, the five mask
+// passes field after field (each field's edge mask reads the finished mask of the field before, eedi2_template.c:132),
+// every later pass once with blockIdx.z = 3 * field + plane.
+Eedi2Engine16::Eedi2Engine16(hbhip_ctx *ctx, const PicGeometry &geo, const Eedi2Params &p, int capacity)
+    : ctx_(ctx), geo_(geo), par_(p)
+{
+    cap_ = std::min(std::max(capacity, 1), EEDI_MAX_BATCH);
+}
 
 Eedi2Engine16::~Eedi2Engine16()
 {
-    for (auto &g : graph_) if (g) (void)hipGraphExecDestroy(g);
-    if (cap_ctx_) hbhip_ctx_destroy(cap_ctx_);
-    if (cand_) (void)hipFree(cand_);
-    for (auto &f : half_) if (f.alloc) (void)hipFree(f.alloc);
-    for (auto &f : full_) if (f.alloc) (void)hipFree(f.alloc);
+    if (slab_) (void)hipFree(slab_);
     for (int i = 0; i < 3; i++)
     {
         if (deriv_[i]) (void)hipFree(deriv_[i]);
@@ -1003,23 +1151,20 @@ Eedi2Engine16::~Eedi2Engine16()
     }
 }
 
-int Eedi2Engine16::alloc_frame(EediFrame &f, int width, int height)
+// lays a frame out at byte offset `at` of a slot (planes as hb_frame_buffer_init places a 16-bit frame); returns the end
+size_t Eedi2Engine16::place_frame(EediFrame &f, int width, int height, size_t at)
 {
-    size_t off[3], total = 0;                                       // in samples
+    size_t total = 0;
     for (int c = 0; c < 3; c++)
     {
         f.width[c] = c ? -((-width) >> geo_.log2_cw) : width;
         f.height[c] = c ? -((-height) >> geo_.log2_ch) : height;
         f.stride[c] = hbhip_align_up(f.width[c] * 2, 64);           // hb_image_stride of a 16-bit plane, bytes
-        off[c] = total;
-        total += (size_t)(f.stride[c] / 2) * f.height[c];
+        f.plane[c] = reinterpret_cast<uint8_t *>(at + total);       // offset for now, init() adds the slab's address
+        total += (size_t)f.stride[c] * f.height[c];
     }
-    f.bytes = 2 * (total + 2 * GUARD16);
-    HBHIP_CHECK(ctx_, hipMalloc((void **)&f.alloc, f.bytes));
-    HBHIP_CHECK(ctx_, hipMemsetAsync(f.alloc, 0, f.bytes, ctx_->stream));
-    f.base = f.alloc + 2 * GUARD16;
-    for (int c = 0; c < 3; c++) f.plane[c] = f.base + 2 * off[c];
-    return HBHIP_OK;
+    f.bytes = total;
+    return at + total;
 }
 
 int Eedi2Engine16::init()
@@ -1027,8 +1172,23 @@ int Eedi2Engine16::init()
     if (geo_.bps != 2 || geo_.depth < 9 || geo_.depth > 16) return HBHIP_ERR_UNSUPPORTED;
     if (geo_.height % (2 << geo_.log2_ch) != 0 || geo_.height < 16 || geo_.width < 16) return HBHIP_ERR_UNSUPPORTED;
     if (par_.post_processing < 0 || par_.post_processing > 3) return HBHIP_ERR_UNSUPPORTED;
-    for (auto &f : half_) { int rc = alloc_frame(f, geo_.width, geo_.height / 2); if (rc != HBHIP_OK) return rc; }
-    for (auto &f : full_) { int rc = alloc_frame(f, geo_.width, geo_.height); if (rc != HBHIP_OK) return rc; }
+    const size_t guard = 2 * GUARD16;                               // bytes; zeroed once, never written
+    size_t at = guard;
+    for (auto &f : half_) at = place_frame(f, geo_.width, geo_.height / 2, at) + guard;
+    for (auto &f : full_) at = place_frame(f, geo_.width, geo_.height, at) + guard;
+    // interpolate_lattice: per-pixel candidate outcomes of the rebuilt rows (every other row of the full-height frame)
+    cand_pitch_ = full_[0].stride[0] / 2;
+    cand_plane_stride_ = cand_pitch_ * ((full_[0].height[0] + 1) / 2);
+    auto up256 = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t cand_at = up256(at);
+    slot_bytes_ = up256(cand_at + sizeof(unsigned long long) * 3 * (size_t)cand_plane_stride_);
+    const size_t total = slot_bytes_ * (size_t)(cap_ + 1);
+    HBHIP_CHECK(ctx_, hipMalloc((void **)&slab_, total));
+    HBHIP_CHECK(ctx_, hipMemsetAsync(slab_, 0, total, ctx_->stream));
+    for (auto &f : half_) for (int c = 0; c < 3; c++) f.plane[c] = slab_ + (size_t)(uintptr_t)f.plane[c];
+    for (auto &f : full_) for (int c = 0; c < 3; c++) f.plane[c] = slab_ + (size_t)(uintptr_t)f.plane[c];
+    cand_ = reinterpret_cast<unsigned long long *>(slab_ + cand_at);
+    last_slot_ = cap_;                                              // "the previous mask" of the first run: zeros
     if (par_.post_processing > 1)
     {
         const size_t n = sizeof(int) * (size_t)geo_.height * full_[0].stride[0];     // decomb.c:398-403 sizes them by the byte stride
@@ -1040,18 +1200,43 @@ int Eedi2Engine16::init()
             HBHIP_CHECK(ctx_, hipMemsetAsync(deriv_tmp_[i], 0, n, ctx_->stream));
         }
     }
-    // interpolate_lattice: per-pixel candidate outcomes of the rebuilt rows (every other row of the full-height frame)
-    cand_pitch_ = full_[0].stride[0] / 2;
-    cand_plane_stride_ = cand_pitch_ * ((full_[0].height[0] + 1) / 2);
-    HBHIP_CHECK(ctx_, hipMalloc((void **)&cand_, sizeof(unsigned long long) * 3 * (size_t)cand_plane_stride_));
     HBHIP_CHECK(ctx_, hipStreamSynchronize(ctx_->stream));
     return HBHIP_OK;
 }
 
-int Eedi2Engine16::enqueue(const DevPicture *cur, int tff, hbhip_ctx *lc, bool do_fill, bool do_rest)
+EediFrame Eedi2Engine16::at_slot(const EediFrame &f, int slot) const
 {
-    EediFrame &srcp = half_[0], &mskp = half_[1], &tmpp = half_[2], &dstp = half_[3];
-    EediFrame &dst2p = full_[0], &tmp2p2 = full_[1], &msk2p = full_[2], &tmp2p = full_[3], &dst2mp = full_[4];
+    EediFrame r = f;
+    for (int c = 0; c < 3; c++) r.plane[c] = f.plane[c] + (size_t)slot * slot_bytes_;
+    return r;
+}
+
+int Eedi2Engine16::add_field(const DevPicture *cur, int tff)
+{
+    if (n_ >= cap_) return -1;
+    if (n_ == 0) { start_ = last_slot_ == 0 ? 1 : 0; tffbits_ = 0; }
+    for (int c = 0; c < 3; c++) { src_frame_[n_][c] = cur->plane[c]; src_pitch_[c] = cur->pitch[c]; }
+    if (tff) tffbits_ |= 1u << n_;
+    return start_ + n_++;
+}
+
+int Eedi2Engine16::launch(hbhip_ctx *lc)
+{
+    if (n_ == 0) return HBHIP_OK;
+    const int n = n_;
+    n_ = 0;
+    const int rc = enqueue(n, lc);
+    last_slot_ = start_ + n - 1;
+    return rc;
+}
+
+int Eedi2Engine16::enqueue(int n, hbhip_ctx *lc)
+{
+    const EediFrame srcp = at_slot(half_[0], start_), mskp = at_slot(half_[1], start_), tmpp = at_slot(half_[2], start_),
+                    dstp = at_slot(half_[3], start_);
+    const EediFrame dst2p = at_slot(full_[0], start_), tmp2p2 = at_slot(full_[1], start_), msk2p = at_slot(full_[2], start_),
+                    tmp2p = at_slot(full_[3], start_), dst2mp = at_slot(full_[4], start_);
+    unsigned long long *cand = cand_ + (size_t)start_ * (slot_bytes_ / sizeof(unsigned long long));
     K16 k;
     k.shift = geo_.depth - 8;
     k.peak = (1 << geo_.depth) - 1;
@@ -1061,149 +1246,130 @@ int Eedi2Engine16::enqueue(const DevPicture *cur, int tff, hbhip_ctx *lc, bool d
     for (int i = 0; i < 33; i++) k.limlut[i] = (uint16_t)((uint16_t)base[i] << k.shift);
 
     const dim3 blk(64, 4);
+    const unsigned gz = 3u * (unsigned)n;
     auto geom = [&](Q3 &P, const EediFrame &f) {
         for (int c = 0; c < 3; c++) { P.pitch[c] = f.stride[c] / 2; P.width[c] = f.width[c]; P.height[c] = f.height[c]; }
     };
     auto bind = [&](uint16_t *(&slot)[3], const EediFrame &f) { for (int c = 0; c < 3; c++) slot[c] = (uint16_t *)f.plane[c]; };
-    auto grid = [&](const EediFrame &f, bool whole_pitch) {
+    auto grid = [&](const EediFrame &f, bool whole_pitch, unsigned z) {
         const int w = whole_pitch ? f.stride[0] / 2 : f.width[0];
-        return dim3((w + 63) / 64, (f.height[0] + 3) / 4, 3);
+        return dim3((w + 63) / 64, (f.height[0] + 3) / 4, z);
+    };
+    auto grid8 = [&](const EediFrame &f, bool whole_pitch, unsigned z) {      // kernels with eight samples per thread
+        const int w = whole_pitch ? f.stride[0] / 2 : f.width[0];
+        return dim3((w + 511) / 512, (f.height[0] + 3) / 4, z);
     };
     Q3 P;
     memset(&P, 0, sizeof(P));
+    P.fstride = slot_bytes_ / 2;
+    P.tffbits = tffbits_;
 
-    // field extraction (decomb_template.c:455-473)
+    // field extraction (decomb_template.c:455-473) + the five mask passes (:390-397): one kernel.  The tiles no earlier
+    // field can influence go out for all fields at once, the rest field after field (see q_mask_fused)
     geom(P, srcp);
-    if (do_fill) for (int c = 0; c < 3; c++) P.a[c] = (uint16_t *)cur->plane[c];
-    bind(P.b, srcp);
-    if (do_fill)
     {
-        int rows[3];
-        for (int c = 0; c < 3; c++) rows[c] = (dst2p.height[c] + 1) / 2;
-        HBHIP_LAUNCH(lc, "eedi2_16_fill_half", q_fill_half, grid(srcp, true), blk, 0, P,
-                     cur->pitch[0] / 2, cur->pitch[1] / 2, cur->pitch[2] / 2, !tff, rows[0], rows[1], rows[2]);
+        MaskSrc16 S;
+        memset(&S, 0, sizeof(S));
+        for (int f = 0; f < n; f++) for (int c = 0; c < 3; c++) S.frame[f][c] = (const uint16_t *)src_frame_[f][c];
+        for (int c = 0; c < 3; c++) S.sp[c] = src_pitch_[c] / 2;
+        const EediFrame old = at_slot(half_[1], last_slot_);
+        bind(P.a, srcp); bind(P.b, old); bind(P.c, mskp);
+        const int mth = par_.magnitude_threshold * 10, vth = par_.laplacian_threshold * 81, lth = par_.variance_threshold;   // sic: swapped (decomb_template.c:390)
+        const unsigned gx = (srcp.width[0] + QM_W - 1) / QM_W, gy = (srcp.height[0] + QM_H - 1) / QM_H;
+        if (n == 1)
+            HBHIP_LAUNCH(lc, "eedi2_16_mask_passes", q_mask_fused, dim3(gx, gy, 3), dim3(QM_T), 0, P, S, k, 0, 0, mth, vth, lth,
+                         par_.erosion_threshold, par_.dilation_threshold);
+        else
+        {
+            const unsigned gy_up = std::max(1, (srcp.height[0] / 2 - QM_OY) / QM_H);
+            HBHIP_LAUNCH(lc, "eedi2_16_mask_upper", q_mask_fused, dim3(gx, gy_up, gz), dim3(QM_T), 0, P, S, k, 0, 1, mth, vth, lth,
+                         par_.erosion_threshold, par_.dilation_threshold);
+            for (int f = 0; f < n; f++)
+                HBHIP_LAUNCH(lc, "eedi2_16_mask_passes", q_mask_fused, dim3(gx, gy, 3), dim3(QM_T), 0, P, S, k, f, 2, mth, vth, lth,
+                             par_.erosion_threshold, par_.dilation_threshold);
+        }
     }
-    if (!do_rest) { HBHIP_CHECK(lc, hipGetLastError()); return HBHIP_OK; }
-    // half-height passes (decomb_template.c:390-404)
-    bind(P.a, srcp); bind(P.c, mskp);
-    HBHIP_LAUNCH(lc, "eedi2_16_edge_mask", q_edge_mask, grid(srcp, true), blk, 0, P, k,
-                 par_.magnitude_threshold * 10, par_.laplacian_threshold * 81, par_.variance_threshold);
-    bind(P.a, mskp); bind(P.c, tmpp);
-    HBHIP_LAUNCH(lc, "eedi2_16_erode", q_morph, grid(srcp, false), blk, 0, P, k, par_.erosion_threshold, 0);
-    bind(P.a, tmpp); bind(P.c, mskp);
-    HBHIP_LAUNCH(lc, "eedi2_16_dilate", q_morph, grid(srcp, false), blk, 0, P, k, par_.dilation_threshold, 1);
-    bind(P.a, mskp); bind(P.c, tmpp);
-    HBHIP_LAUNCH(lc, "eedi2_16_erode", q_morph, grid(srcp, false), blk, 0, P, k, par_.erosion_threshold, 0);
-    bind(P.a, tmpp); bind(P.c, mskp);
-    HBHIP_LAUNCH(lc, "eedi2_16_small_gaps", q_small_gaps, grid(srcp, false), blk, 0, P, k);
+    // half-height passes (decomb_template.c:398-404), all fields per launch from here on
     bind(P.a, mskp); bind(P.b, srcp); bind(P.c, tmpp);
     if (par_.maximum_search_distance <= QHALO - 2)
-        HBHIP_LAUNCH(lc, "eedi2_16_calc_directions", q_calc_dir_rows<2>, dim3((srcp.stride[0] / 2 + QW - 1) / QW, (srcp.height[0] + 1) / 2, 3),
+        HBHIP_LAUNCH(lc, "eedi2_16_calc_directions", q_calc_dir_rows<2>, dim3((srcp.stride[0] / 2 + QW - 1) / QW, (srcp.height[0] + 1) / 2, gz),
                      dim3(QW), 0, P, k, par_.maximum_search_distance, par_.noise_threshold);
     else
-        HBHIP_LAUNCH(lc, "eedi2_16_calc_directions", q_calc_dir, grid(srcp, true), blk, 0, P, k, par_.maximum_search_distance, par_.noise_threshold);
+        HBHIP_LAUNCH(lc, "eedi2_16_calc_directions", q_calc_dir, grid(srcp, true, gz), blk, 0, P, k, par_.maximum_search_distance, par_.noise_threshold);
     bind(P.a, mskp); bind(P.b, tmpp); bind(P.c, dstp);
-    HBHIP_LAUNCH(lc, "eedi2_16_filter_dir_map", q_dir_map, grid(srcp, false), blk, 0, P, k, 1, 1, 0);
+    HBHIP_LAUNCH(lc, "eedi2_16_filter_dir_map", q_dir_map, grid(srcp, false, gz), blk, 0, P, k, 1, 0);
     bind(P.a, mskp); bind(P.b, dstp); bind(P.c, tmpp);
-    HBHIP_LAUNCH(lc, "eedi2_16_expand_dir_map", q_dir_map, grid(srcp, false), blk, 0, P, k, 1, 1, 1);
+    HBHIP_LAUNCH(lc, "eedi2_16_expand_dir_map", q_dir_map, grid(srcp, false, gz), blk, 0, P, k, 1, 1);
     bind(P.a, mskp); bind(P.b, tmpp); bind(P.c, dstp);
-    HBHIP_LAUNCH(lc, "eedi2_16_filter_map", q_filter_map, grid(srcp, false), blk, 0, P, k);
+    HBHIP_LAUNCH(lc, "eedi2_16_filter_map", q_filter_map, grid(srcp, false, gz), blk, 0, P, k);
     // line doubling
     bind(P.a, srcp); bind(P.c, dst2p);
-    HBHIP_LAUNCH(lc, "eedi2_16_upscale", q_upscale, grid(srcp, true), blk, 0, P);
+    HBHIP_LAUNCH(lc, "eedi2_16_upscale", q_upscale, grid8(srcp, true, gz), blk, 0, P);
     bind(P.a, dstp); bind(P.c, tmp2p2);
-    HBHIP_LAUNCH(lc, "eedi2_16_upscale", q_upscale, grid(srcp, true), blk, 0, P);
+    HBHIP_LAUNCH(lc, "eedi2_16_upscale", q_upscale, grid8(srcp, true, gz), blk, 0, P);
     bind(P.a, mskp); bind(P.c, msk2p);
-    HBHIP_LAUNCH(lc, "eedi2_16_upscale", q_upscale, grid(srcp, true), blk, 0, P);
+    HBHIP_LAUNCH(lc, "eedi2_16_upscale", q_upscale, grid8(srcp, true, gz), blk, 0, P);
     // full-height passes
     geom(P, dst2p);
-    const int y0 = 2 - tff;
     bind(P.a, msk2p); bind(P.b, tmp2p2); bind(P.c, tmp2p);
-    HBHIP_LAUNCH(lc, "eedi2_16_mark_directions_2x", q_mark_2x, grid(dst2p, true), blk, 0, P, k, y0);
+    HBHIP_LAUNCH(lc, "eedi2_16_mark_directions_2x", q_mark_2x, grid(dst2p, true, gz), blk, 0, P, k);
     bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
-    HBHIP_LAUNCH(lc, "eedi2_16_filter_dir_map_2x", q_dir_map, grid(dst2p, false), blk, 0, P, k, 2, y0, 0);
+    HBHIP_LAUNCH(lc, "eedi2_16_filter_dir_map_2x", q_dir_map, grid(dst2p, false, gz), blk, 0, P, k, 2, 0);
     bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
-    HBHIP_LAUNCH(lc, "eedi2_16_expand_dir_map_2x", q_dir_map, grid(dst2p, false), blk, 0, P, k, 2, y0, 1);
+    HBHIP_LAUNCH(lc, "eedi2_16_expand_dir_map_2x", q_dir_map, grid(dst2p, false, gz), blk, 0, P, k, 2, 1);
     for (int pass = 0; pass < 2; pass++)
     {
         const EediFrame &in = pass ? dst2mp : tmp2p, &out = pass ? tmp2p : dst2mp;
         bind(P.a, in); bind(P.c, out);
-        HBHIP_LAUNCH(lc, "eedi2_16_blit", q_blit, grid(dst2p, false), blk, 0, P);
+        HBHIP_LAUNCH(lc, "eedi2_16_blit", q_blit, grid8(dst2p, false, gz), blk, 0, P);
         bind(P.a, msk2p); bind(P.b, in); bind(P.c, out);
-        HBHIP_LAUNCH(lc, "eedi2_16_fill_gaps_2x", q_fill_gaps, grid(dst2p, false), blk, 0, P, k, y0);
+        HBHIP_LAUNCH(lc, "eedi2_16_fill_gaps_2x", q_fill_gaps, grid(dst2p, false, gz), blk, 0, P, k);
     }
     bind(P.a, tmp2p); bind(P.b, dst2p); bind(P.c, tmp2p2);
     {
-        const int nrows = (dst2p.height[0] - 1 - y0 + 1) / 2;
-        HBHIP_LAUNCH(lc, "eedi2_16_lattice_candidates", q_lattice_cand, dim3((dst2p.width[0] + 255) / 256, nrows, 3), dim3(256), 0, P, k,
-                     tff, par_.noise_threshold, cand_, cand_pitch_, cand_plane_stride_);
-        HBHIP_LAUNCH(lc, "eedi2_16_lattice_resolve", q_lattice_resolve16, dim3(1, nrows + 1, 3), dim3(LR16_T), 0, P, k, tff,
-                     (const unsigned long long *)cand_, cand_pitch_, cand_plane_stride_);
+        const int nrows = (dst2p.height[0] - 1) / 2;                // rows y0, y0 + 2, ... < height - 1 for either parity (even heights)
+        HBHIP_LAUNCH(lc, "eedi2_16_lattice_candidates", q_lattice_cand, dim3((dst2p.width[0] + 255) / 256, nrows, gz), dim3(256), 0, P, k,
+                     par_.noise_threshold, cand, cand_pitch_, cand_plane_stride_);
+        HBHIP_LAUNCH(lc, "eedi2_16_lattice_resolve", q_lattice_resolve16, dim3(1, nrows + 1, gz), dim3(LR16_T), 0, P, k,
+                     (const unsigned long long *)cand, cand_pitch_, cand_plane_stride_);
     }
     if (par_.post_processing == 1 || par_.post_processing == 3)
     {
         bind(P.a, tmp2p); bind(P.c, tmp2p2);
-        HBHIP_LAUNCH(lc, "eedi2_16_blit", q_blit, grid(dst2p, false), blk, 0, P);                 // eedi2_bit_blit(tmp2p -> tmp2p2)
+        HBHIP_LAUNCH(lc, "eedi2_16_blit", q_blit, grid8(dst2p, false, gz), blk, 0, P);             // eedi2_bit_blit(tmp2p -> tmp2p2)
         bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
-        HBHIP_LAUNCH(lc, "eedi2_16_filter_dir_map_2x", q_dir_map, grid(dst2p, false), blk, 0, P, k, 2, y0, 0);
+        HBHIP_LAUNCH(lc, "eedi2_16_filter_dir_map_2x", q_dir_map, grid(dst2p, false, gz), blk, 0, P, k, 2, 0);
         bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
-        HBHIP_LAUNCH(lc, "eedi2_16_expand_dir_map_2x", q_dir_map, grid(dst2p, false), blk, 0, P, k, 2, y0, 1);
+        HBHIP_LAUNCH(lc, "eedi2_16_expand_dir_map_2x", q_dir_map, grid(dst2p, false, gz), blk, 0, P, k, 2, 1);
         bind(P.a, tmp2p); bind(P.b, tmp2p2); bind(P.c, dst2p);
-        HBHIP_LAUNCH(lc, "eedi2_16_post_process", q_post, grid(dst2p, false), blk, 0, P, k, y0);
+        HBHIP_LAUNCH(lc, "eedi2_16_post_process", q_post, grid(dst2p, false, gz), blk, 0, P, k);
     }
     if (par_.post_processing == 2 || par_.post_processing == 3)
     {
-        for (int c = 0; c < 3; c++)                                  // plane after plane, see eedi2.hip (CornerArgs)
+        // field after field, plane after plane: the derivative arrays carry values along (eedi2.hip, CornerArgs)
+        for (int f = 0; f < n; f++)
         {
-            Corner16 A;
-            A.src = (uint16_t *)srcp.plane[c]; A.tmp = (uint16_t *)tmpp.plane[c];
-            for (int i = 0; i < 3; i++) { A.c[i] = deriv_[i]; A.t[i] = deriv_tmp_[i]; }
-            A.pitch = srcp.stride[c] / 2; A.width = srcp.width[c]; A.height = srcp.height[c];
-            const dim3 g1((A.width + 63) / 64, (A.height + 3) / 4, 1), g3(g1.x, g1.y, 3);
-            HBHIP_LAUNCH(lc, "eedi2_16_gaussian_blur1_h", q_blur1<false>, g1, blk, 0, A);
-            HBHIP_LAUNCH(lc, "eedi2_16_gaussian_blur1_v", q_blur1<true>, g1, blk, 0, A);
-            HBHIP_LAUNCH(lc, "eedi2_16_calc_derivatives", q_derivatives, g1, blk, 0, A, k.shift);
-            HBHIP_LAUNCH(lc, "eedi2_16_gaussian_blur_sqrt2_h", q_blur_sqrt2<false>, g3, blk, 0, A);
-            HBHIP_LAUNCH(lc, "eedi2_16_gaussian_blur_sqrt2_v", q_blur_sqrt2<true>, g3, blk, 0, A);
-            const int rows = (dst2p.height[c] - 7 - (8 - tff) + 1) / 2;
-            if (rows > 0)
-                HBHIP_LAUNCH(lc, "eedi2_16_post_process_corner", q_post_corner, dim3((A.width + 63) / 64, (rows + 3) / 4, 1), blk, 0, A,
-                             (const uint16_t *)tmp2p2.plane[c], (uint16_t *)dst2p.plane[c], tff, dst2p.height[c], k.peak, k.neutral);
+            const int tff = (int)((tffbits_ >> f) & 1u);
+            const size_t foff = (size_t)f * slot_bytes_;
+            for (int c = 0; c < 3; c++)
+            {
+                Corner16 A;
+                A.src = (uint16_t *)(srcp.plane[c] + foff); A.tmp = (uint16_t *)(tmpp.plane[c] + foff);
+                for (int i = 0; i < 3; i++) { A.c[i] = deriv_[i]; A.t[i] = deriv_tmp_[i]; }
+                A.pitch = srcp.stride[c] / 2; A.width = srcp.width[c]; A.height = srcp.height[c];
+                const dim3 g1((A.width + 63) / 64, (A.height + 3) / 4, 1), g3(g1.x, g1.y, 3);
+                HBHIP_LAUNCH(lc, "eedi2_16_gaussian_blur1_h", q_blur1<false>, g1, blk, 0, A);
+                HBHIP_LAUNCH(lc, "eedi2_16_gaussian_blur1_v", q_blur1<true>, g1, blk, 0, A);
+                HBHIP_LAUNCH(lc, "eedi2_16_calc_derivatives", q_derivatives, g1, blk, 0, A, k.shift);
+                HBHIP_LAUNCH(lc, "eedi2_16_gaussian_blur_sqrt2_h", q_blur_sqrt2<false>, g3, blk, 0, A);
+                HBHIP_LAUNCH(lc, "eedi2_16_gaussian_blur_sqrt2_v", q_blur_sqrt2<true>, g3, blk, 0, A);
+                const int rows = (dst2p.height[c] - 7 - (8 - tff) + 1) / 2;
+                if (rows > 0)
+                    HBHIP_LAUNCH(lc, "eedi2_16_post_process_corner", q_post_corner, dim3((A.width + 63) / 64, (rows + 3) / 4, 1), blk, 0, A,
+                                 (const uint16_t *)(tmp2p2.plane[c] + foff), (uint16_t *)(dst2p.plane[c] + foff), tff, dst2p.height[c], k.peak, k.neutral);
+            }
         }
     }
     HBHIP_CHECK(lc, hipGetLastError());
     return HBHIP_OK;
-}
-
-// One field: the field extraction reads the caller's picture (a different one every time) and is launched as it is; the
-// ~28 launches after it only touch this engine's scratch frames and are the same from field to field (per field parity):
-// captured once into a hipGraph and replayed - the 16-bit path was bound by the host's launch calls (9.5 ms of enqueueing
-// for a 12 ms step of 32 fields).  The per-kernel profiler needs individual launches and bypasses the graph.
-int Eedi2Engine16::run(const DevPicture *cur, int tff)
-{
-    if (ctx_->profile || !use_graph_) return enqueue(cur, tff, ctx_, true, true);
-    int rc = enqueue(cur, tff, ctx_, true, false);
-    if (rc != HBHIP_OK) return rc;
-    hipGraphExec_t &exec = graph_[tff ? 1 : 0];
-    if (!exec)
-    {
-        hipGraph_t g = nullptr;
-        if (!cap_ctx_ && hbhip_ctx_create(ctx_->device, &cap_ctx_) != HBHIP_OK) cap_ctx_ = nullptr;
-        if (!cap_ctx_) { use_graph_ = false; return enqueue(cur, tff, ctx_, false, true); }
-        HBHIP_CHECK(ctx_, hipStreamBeginCapture(cap_ctx_->stream, hipStreamCaptureModeThreadLocal));
-        const int crc = enqueue(cur, tff, cap_ctx_, false, true);
-        const hipError_t e = hipStreamEndCapture(cap_ctx_->stream, &g);
-        hipError_t ie = hipErrorUnknown;
-        if (crc == HBHIP_OK && e == hipSuccess && g) ie = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
-        if (g) (void)hipGraphDestroy(g);
-        if (ie != hipSuccess)
-        {
-            exec = nullptr;
-            use_graph_ = false;                      // fall back to plain launches for good
-            (void)hipGetLastError();
-        }
-    }
-    if (exec) HBHIP_CHECK(ctx_, hipGraphLaunch(exec, ctx_->stream));
-    else      rc = enqueue(cur, tff, ctx_, false, true);
-    return rc;
 }

@@ -76,33 +76,40 @@ private:
     int        *deriv_tmp_[3] = {nullptr, nullptr, nullptr};   //                      tmpc, one per array
 };
 
-// EEDI2 on 10 / 12-bit samples (eedi2_16.hip): same role as Eedi2Engine, first correct form (one thread
-// per sample and pass, serial lattice rows, no graphs / pairing).  EediFrame strides are in BYTES, the
-// planes hold uint16 samples in the layout hb_frame_buffer_init gives a 16-bit frame.
+// EEDI2 on 10 / 12-bit samples (eedi2_16.hip): the same engine (slots, add_field / launch) on uint16 samples, one
+// thread per sample and pass; the five mask passes are separate launches per field.  EediFrame strides are in BYTES,
+// the planes hold uint16 samples in the layout hb_frame_buffer_init gives a 16-bit frame.
 class Eedi2Engine16
 {
 public:
-    Eedi2Engine16(hbhip_ctx *ctx, const PicGeometry &geo, const Eedi2Params &p);
+    Eedi2Engine16(hbhip_ctx *ctx, const PicGeometry &geo, const Eedi2Params &p, int capacity);
     ~Eedi2Engine16();
     int  init();
-    int  run(const DevPicture *cur, int tff);
-    const EediFrame &result() const { return full_[0]; }
-    const EediFrame &half(int i) const { return half_[i]; }
-    const EediFrame &full(int i) const { return full_[i]; }
+    int  capacity() const { return cap_; }
+    int  queued() const { return n_; }
+    int  add_field(const DevPicture *cur, int tff);   // returns the field's slot
+    int  launch(hbhip_ctx *lc);
+    int  last_slot() const { return last_slot_; }
+    EediFrame result(int slot) const { return at_slot(full_[0], slot); }
+    EediFrame half(int i, int slot) const { return at_slot(half_[i], slot); }
+    EediFrame full(int i, int slot) const { return at_slot(full_[i], slot); }
 
 private:
-    int alloc_frame(EediFrame &f, int width, int height);
-    // the field extraction (do_fill) and / or the pass sequence behind it (do_rest), launched on lc's stream
-    int enqueue(const DevPicture *cur, int tff, hbhip_ctx *lc, bool do_fill, bool do_rest);
-    hipGraphExec_t graph_[2] = {nullptr, nullptr};   // captured pass sequence per field parity
-    hbhip_ctx  *cap_ctx_ = nullptr;                  // private stream the pass sequence is captured on
-    bool        use_graph_ = true;
+    size_t place_frame(EediFrame &f, int width, int height, size_t at);
+    EediFrame at_slot(const EediFrame &f, int slot) const;
+    int enqueue(int n, hbhip_ctx *lc);
     hbhip_ctx  *ctx_;
     PicGeometry geo_;
     Eedi2Params par_;
-    EediFrame   half_[4];    // SRCPF, MSKPF, TMPPF, DSTPF
-    EediFrame   full_[5];    // DST2PF, TMP2PF2, MSK2PF, TMP2PF, DST2MPF
-    unsigned long long *cand_ = nullptr;   // interpolate_lattice: per-pixel candidate outcomes
+    int         cap_ = 1, n_ = 0, start_ = 0, last_slot_ = 0;
+    uint32_t    tffbits_ = 0;
+    const uint8_t *src_frame_[EEDI_MAX_BATCH][3];
+    int         src_pitch_[3] = {0, 0, 0};
+    uint8_t    *slab_ = nullptr;
+    size_t      slot_bytes_ = 0;
+    EediFrame   half_[4];    // slot 0's SRCPF, MSKPF, TMPPF, DSTPF
+    EediFrame   full_[5];    // slot 0's DST2PF, TMP2PF2, MSK2PF, TMP2PF, DST2MPF
+    unsigned long long *cand_ = nullptr;   // slot 0's interpolate_lattice candidates
     int         cand_pitch_ = 0, cand_plane_stride_ = 0;
     int        *deriv_[3] = {nullptr, nullptr, nullptr};
     int        *deriv_tmp_[3] = {nullptr, nullptr, nullptr};

@@ -108,12 +108,12 @@ static int decomb_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init)
     if (p->mode & DECOMB_BOB)
         init->vrate.num *= 2;                  /* decomb.c:427-430 */
     pv->output = *init;
-    /* 8-bit frames are gathered DECOMB_BATCH at a time: EEDI2 takes the fields of a batch through every pass in one
+    /* Frames are gathered DECOMB_BATCH at a time: EEDI2 takes the fields of a batch through every pass in one
      * launch, the blends of a batch are one launch (csrc/decomb.hip) - a frame alone leaves most of the GPU idle.  The
      * filter answers HB_FILTER_DELAY meanwhile and then emits the batch's frames as one list, the burst pattern of
      * the reference's own threaded filters (nlmeans.c:548-571). */
     pv->batch = 1;
-    if (desc->comp[0].depth == 8 && hbhip_filter_defer(pv->dev, 1) == HBHIP_OK)
+    if (hbhip_filter_defer(pv->dev, 1) == HBHIP_OK)
         pv->batch = DECOMB_BATCH;
     return 0;
 fail:
