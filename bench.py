@@ -441,14 +441,11 @@ def run_chain(args, world, rank, local_rank):
             self.fed = 0
 
         def combed_for(self, i0, n):
-            """comb_detect_work (comb_detect.c:1537-1583): frame i is classified from the luma of i-1, i, i+1."""
-            res = []
-            for i in range(i0, i0 + n):
-                for j in ((i - 1, i, i + 1) if i == 0 else (i + 1,)):
-                    luma = dev_in[max(j, 0) % nsrc][0]
-                    self.comb.store_dev(luma.data_ptr(), luma.stride(0))
-                res.append(self.comb.classify(force=(i == 0)))
-            return res
+            """comb_detect_work (comb_detect.c:1537-1583): frame i is classified from the luma of i-1, i, i+1 (the first
+            frame of the stream from itself twice and its successor, verdict forced) - the frames of a batch in three
+            launches and one read-back (hbhip_comb_detect_classify_many_dev)."""
+            lumas = [dev_in[max(j, 0) % nsrc][0] for j in range(i0 - 1, i0 + n + 1)]
+            return self.comb.classify_many([t.data_ptr() for t in lumas], lumas[0].stride(0), force_bits=1 if i0 == 0 else 0)
 
         def step(self):
             combed = self.combed_for(self.fed, B) if self.comb else [2] * B

@@ -73,9 +73,9 @@ __device__ __forceinline__ bool yadif_check(const PIX *c, int sp, int sn, int st
 // PIX = uint8_t, or uint16_t for the _16 instantiation (decomb.c:324-331); pitches arrive in bytes,
 // maxv = (1 << depth) - 1
 template <typename PIX>
-__global__ __launch_bounds__(256) void decomb_plane_kernel(DecombArgs a, int maxv)
+__device__ __forceinline__ void decomb_plane_px(const DecombArgs &a, int plane, int maxv)
 {
-    const DecombPlane &P = a.pl[blockIdx.z];
+    const DecombPlane &P = a.pl[plane];
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= P.w || y >= P.h) return;
@@ -174,6 +174,22 @@ __global__ __launch_bounds__(256) void decomb_plane_kernel(DecombArgs a, int max
     if (pred > d + diff)      pred = d + diff;
     else if (pred < d - diff) pred = d - diff;
     *o = (PIX)pred;
+}
+
+template <typename PIX>
+__global__ __launch_bounds__(256) void decomb_plane_kernel(DecombArgs a, int maxv)
+{
+    decomb_plane_px<PIX>(a, blockIdx.z, maxv);
+}
+
+// the frames of a batch in one launch (10 / 12-bit frames; the 8-bit ones take decomb_plane4_kernel)
+constexpr int DB16_FRAMES = 8;
+struct DecombArgsBatch { DecombArgs f[DB16_FRAMES]; };
+template <typename PIX>
+__global__ __launch_bounds__(256) void decomb_plane_batch_kernel(DecombArgsBatch B, int maxv)
+{
+    const int fr = (int)blockIdx.z / 3;
+    decomb_plane_px<PIX>(B.f[fr], (int)blockIdx.z - 3 * fr, maxv);
 }
 
 // ---- decomb_plane_kernel for 8-bit samples, four pixels per thread and several frames per launch --------------
@@ -604,6 +620,9 @@ public:
     DevPicture *pop_output() override
     {
         if (outq.empty()) return nullptr;
+        // a frame that is handed out must have been launched: whoever pulls without a kick gets one here
+        if (!gathered.empty() || !gathered16.empty() || (eedi && eedi->queued() > 0) || (eedi16 && eedi16->queued() > 0))
+            (void)flush_batch();
         DevPicture *p = outq.front();
         outq.pop_front();
         return p;
@@ -727,8 +746,13 @@ private:
         {
             const dim3 block(64, 4), grid((in_geo.pw[0] + 63) / 64, (in_geo.ph[0] + 3) / 4, 3);
             const int maxv = (1 << in_geo.depth) - 1;
-            for (const DecombArgs &a : gathered16)
-                HBHIP_LAUNCH(lc, "decomb_plane", decomb_plane_kernel<uint16_t>, grid, block, 0, a, maxv);
+            for (size_t i0 = 0; i0 < gathered16.size(); i0 += DB16_FRAMES)
+            {
+                const int m = (int)std::min<size_t>(DB16_FRAMES, gathered16.size() - i0);
+                DecombArgsBatch B;
+                for (int k = 0; k < DB16_FRAMES; k++) B.f[k] = gathered16[i0 + std::min(k, m - 1)];
+                HBHIP_LAUNCH(lc, "decomb_plane", decomb_plane_batch_kernel<uint16_t>, dim3(grid.x, grid.y, 3 * m), block, 0, B, maxv);
+            }
         }
         const bool any = !gathered.empty() || !gathered16.empty();
         gathered.clear();
