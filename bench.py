@@ -598,11 +598,7 @@ def run_chain(args, world, rank, local_rank):
             pcie = pcie_inclusive(args.workload, W, H, scale, wl["cfg"] + 16 * rank, local_rank)
         except Exception as e:                                               # never lose the bench line over it
             pcie = {"error": repr(e), "n_out": 0, "seconds": 0.0}
-        n_all, dt_all = shard.reduce_throughput(float(pcie.get("n_out", 0)), float(pcie.get("seconds", 0.0)), device="cuda")
-        if world > 1 and "error" not in pcie:
-            pcie["this_rank_value"] = pcie["value"]
-            pcie["value"] = round(n_all / dt_all, 2) if dt_all > 0 else None
-            pcie["ranks"] = world
+        pcie = shard.reduce_host_path(pcie, device="cuda")
     if rank == 0:
         if pcie is not None:
             line["pcie_inclusive"] = pcie

@@ -25,3 +25,19 @@ def reduce_throughput(frames_local: float, seconds_local: float, device=None):
     dist.all_reduce(f, op=dist.ReduceOp.SUM)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(f.item()), float(t.item())
+
+
+def reduce_host_path(res: dict, device=None) -> dict:
+    """Every rank ran the PCIe-inclusive pass (handbrake_amd/hostpath.py) at the same time, each on its own GPU: the
+    job's rate is all ranks' credited output frames over the slowest rank's time - what the host's PCIe root complex
+    and memory give N streams at once.  `res` = this rank's result (n_out, seconds, value, ...); returns
+    it with `value` replaced by the aggregate, the rank's own rate kept as `this_rank_value`."""
+    import torch.distributed as dist
+    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    n_all, dt_all = reduce_throughput(float(res.get("n_out", 0)), float(res.get("seconds", 0.0)), device=device)
+    out = dict(res)
+    if world > 1 and "error" not in res:
+        out["this_rank_value"] = res.get("value")
+        out["value"] = round(n_all / dt_all, 2) if dt_all > 0 else None
+        out["ranks"] = world
+    return out

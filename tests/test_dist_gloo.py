@@ -26,7 +26,8 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     frames, secs = shard.reduce_throughput(100.0 * (rank + 1), 1.0 + rank)
     streams = shard.stream_for_rank(rank, world, 5)
-    q.put((rank, frames, secs, streams))
+    host = shard.reduce_host_path({"value": 1000.0 * (rank + 1), "n_out": 512, "seconds": 0.25 * (rank + 1)})
+    q.put((rank, frames, secs, streams, host))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -42,9 +43,11 @@ def test_reduce_throughput_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, frames, secs, streams in res:
+    for rank, frames, secs, streams, host in res:
         assert frames == 300.0          # SUM over ranks
         assert secs == 2.0              # MAX over ranks
+        # the PCIe-inclusive pass of every rank at once: all ranks' frames over the slowest rank's time
+        assert host["value"] == 2048.0 and host["ranks"] == 2 and host["this_rank_value"] == 1000.0 * (rank + 1)
     assert res[0][3] == [0, 2, 4] and res[1][3] == [1, 3]
 
 
@@ -52,3 +55,5 @@ def test_single_process_identity():
     sys.path.insert(0, ROOT)
     from handbrake_amd import shard
     assert shard.reduce_throughput(10, 2.5) == (10.0, 2.5)
+    one = shard.reduce_host_path({"value": 2900.0, "n_out": 512, "seconds": 0.18})
+    assert one["value"] == 2900.0 and "ranks" not in one
