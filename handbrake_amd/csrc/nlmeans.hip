@@ -55,6 +55,8 @@ struct alignas(16) NlmJob
     float          wft;
     int            diff_max;
     int            diff_cap;       // FAST gate: smallest diff whose table index is 127 (weight 0)
+    uint32_t       imul4;          // FAST 2: 4 * weight_fact * 2^32 when (diff * that) >> 32 == 4 * (int)(diff * wft) for every
+                                   // diff <= diff_cap (checked on the host), else 0
     int            w, h, dst_pitch;
     int            nframes, r_half;
     int            tiles_x, tile_start;
@@ -142,7 +144,13 @@ __device__ __forceinline__ uint32_t from_lane_above(uint32_t x)   // lane l <- l
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
 }
 
-template <int N, bool FAST, int CPD, bool PRE>
+// FAST: how a patch distance becomes a table index.  0: the reference's expression with its gate (diff < diff_max).
+// 1: the gate folded into a clamp (exactly equivalent when the table ends in 0 at the index the cap maps to).  2: the
+// clamp, and the float product (int)(diff * wft) replaced by an integer multiply-high: wft is a float, so wft * 2^32 is
+// an integer M, and (diff * M) >> 32 is the exact floor of the real product - the float product can only differ from
+// it where rounding carries it across an integer, which the host rules out for every diff up to the cap before it
+// picks this form (three instructions per pixel instead of five: min, mul_hi, and).
+template <int N, int FAST, int CPD, bool PRE>
 __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJob *__restrict__ jobs, int njobs,
                                                                      int cmp_rows, int rq)
 {
@@ -158,13 +166,15 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
     // that are averaged come from the raw frames: s_r0 (frame 0, also the origin term and the
     // zero fallback) and s_rc (frame f > 0).  CPD is a template constant so every LDS read in
     // the row walk uses an immediate offset.
+    // The weight table sits first, at a fixed LDS address, so a table read is one ds_read with the address in its
+    // immediate offset; the tiles follow it (128 dwords on: the same banks as without it).
     extern __shared__ uint32_t smem[];
     const int tile_dwords = CPD * cmp_rows + 4;
-    uint32_t *s_t0 = smem;
+    float *s_exp = reinterpret_cast<float *>(smem);
+    uint32_t *s_t0 = smem + 128;
     uint32_t *s_tc = s_t0 + tile_dwords;
     uint32_t *s_r0 = PRE ? s_tc + tile_dwords : s_t0;
     uint32_t *s_rc = PRE ? s_r0 + tile_dwords : s_tc;
-    float *s_exp = reinterpret_cast<float *>((PRE ? s_rc : s_tc) + tile_dwords);
 
     // which (frame, plane) job owns this tile: binary search over the jobs' first tile indices
     int j = 0;
@@ -184,6 +194,10 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
     const int tx = threadIdx.x & (TXN - 1);
     const int ty = threadIdx.x / TXN;
 
+    // FAST 2 reads the table by its LDS address, taken to be 0: this kernel has no static LDS, so the dynamic block -
+    // and the table at its head - starts there (the compiler leaves "+ &smem" as an add of 0 per read otherwise)
+    typedef __attribute__((address_space(3))) const float lds_cfloat;
+    if (FAST == 2 && reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint32_t *)smem) != 0) __builtin_trap();
     if (threadIdx.x < 128) s_exp[threadIdx.x] = job.exptable[threadIdx.x];
     // lane tx holds the source pixels tx0 + 4*(tx-1) .. +3: the tiles start one lane (and rq
     // dwords of search halo) left of tx0
@@ -215,6 +229,7 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
     const float wft = job.wft;
     const int diff_max = job.diff_max;
     const int diff_cap = job.diff_cap;
+    const uint32_t imul4 = job.imul4;
     const double origin_tune = job.origin_tune;
     // a wave (two tile rows of lanes) whose 16 output rows all lie below the plane has nothing to do
     const bool wave_live = ty0 + (ty & ~1) * RY < h;
@@ -356,27 +371,39 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
 #pragma unroll
                         for (int pp = 0; pp < PX / 2; pp++)
                         {
-                            int idx[2];
-                            if (FAST)
+                            if (FAST == 2)
                             {
-                                const f2 fd = {(float)(int)min(v[2 * pp], (uint32_t)diff_cap),
-                                               (float)(int)min(v[2 * pp + 1], (uint32_t)diff_cap)};
-                                const f2 fi = fd * wft2;
-                                idx[0] = (int)fi.x;
-                                idx[1] = (int)fi.y;
+                                // byte offsets into the table: (diff * 4M) >> 32 = floor(4 * diff * wft), and clearing its two low
+                                // bits gives 4 * floor(diff * wft); the mask also tells the compiler the offset is < 512, so the
+                                // table's LDS address goes into the read's immediate offset
+                                const uint32_t o0 = __umulhi(min(v[2 * pp], (uint32_t)diff_cap), imul4) & 0x1fcu;
+                                const uint32_t o1 = __umulhi(min(v[2 * pp + 1], (uint32_t)diff_cap), imul4) & 0x1fcu;
+                                wq[pp] = f2{*reinterpret_cast<lds_cfloat *>(o0), *reinterpret_cast<lds_cfloat *>(o1)};
                             }
                             else
                             {
-#pragma unroll
-                                for (int e = 0; e < 2; e++)
+                                int idx[2];
+                                if (FAST == 1)
                                 {
-                                    const int diff = (int)v[2 * pp + e];
-                                    int ix = (int)((float)diff * wft);
-                                    ix = diff < diff_max ? ix : 127;
-                                    idx[e] = min(ix, 127);
+                                    const f2 fd = {(float)(int)min(v[2 * pp], (uint32_t)diff_cap),
+                                                   (float)(int)min(v[2 * pp + 1], (uint32_t)diff_cap)};
+                                    const f2 fi = fd * wft2;
+                                    idx[0] = (int)fi.x;
+                                    idx[1] = (int)fi.y;
                                 }
+                                else
+                                {
+#pragma unroll
+                                    for (int e = 0; e < 2; e++)
+                                    {
+                                        const int diff = (int)v[2 * pp + e];
+                                        int ix = (int)((float)diff * wft);
+                                        ix = diff < diff_max ? ix : 127;
+                                        idx[e] = min(ix, 127);
+                                    }
+                                }
+                                wq[pp] = f2{s_exp[idx[0]], s_exp[idx[1]]};
                             }
-                            wq[pp] = f2{s_exp[idx[0]], s_exp[idx[1]]};
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -997,6 +1024,21 @@ public:
                     if ((int)((float)d * wft) == 127) diff_cap[c] = d;
                     break;
                 }
+            // the integer form of the index (nlmeans_lanes_kernel, FAST 2): M = wft * 2^32 is an integer (wft is a float);
+            // usable when 4M fits 32 bits and (d * M) >> 32 equals the float expression for every d up to the cap
+            imul4[c] = 0;
+            if (diff_cap[c] >= 0)
+            {
+                const double m = std::ldexp((double)wft, 32);
+                if (m == std::floor(m) && m > 0.0 && m < 1073741824.0)
+                {
+                    const uint64_t M = (uint64_t)m;
+                    bool same = true;
+                    for (int d = 0; d <= diff_cap[c] && same; d++)
+                        same = (int)(((uint64_t)d * M) >> 32) == (int)((float)d * wft);
+                    if (same) imul4[c] = (uint32_t)(4 * M);
+                }
+            }
         }
         if (any_pre)
         {
@@ -1045,6 +1087,7 @@ public:
     int batch = 1;
     bool deferred = false;
     int diff_cap[3] = {-1, -1, -1};
+    uint32_t imul4[3] = {0, 0, 0};
     int pf_type[3] = {0, 0, 0};          // effective prefilter bits per plane (0 = none)
     bool passthru[3] = {false, false, false};
     bool any_pre = false;
@@ -1182,7 +1225,7 @@ private:
             NlmJob *hj = h_jobs + (size_t)table * jobs_cap;
             NlmJob *dj = d_jobs + (size_t)table * jobs_cap;
             int nj = 0, tiles = 0, max_rh = 0;
-            bool fast = true;
+            bool fast = true, fast_int = true;
             for (int t = 0; t < ready; t++)
                 for (int c = 0; c < 3; c++)
                 {
@@ -1210,7 +1253,9 @@ private:
                     jb.wft = par.weight_fact_table[c];
                     jb.diff_max = par.diff_max[c];
                     jb.diff_cap = diff_cap[c];
+                    jb.imul4 = imul4[c];
                     fast &= diff_cap[c] >= 0;
+                    fast_int &= imul4[c] != 0;
                     jb.w = in_geo.pw[c];
                     jb.h = in_geo.ph[c];
                     jb.dst_pitch = outs[t].pitch[c];
@@ -1253,8 +1298,8 @@ private:
 #define NLM_16(NN, FF) do { if (pre) NLM_16P(NN, FF, true); else NLM_16P(NN, FF, false); } while (0)
 #define NLM_VAR(NN) do { const char *kname = "nlmeans_plane_n" #NN; \
                      if (wide) { if (fast) NLM_16(NN, true); else NLM_16(NN, false); } \
-                     else if (cpd == 36) { if (fast) NLM_PRE(NN, true, 36); else NLM_PRE(NN, false, 36); } \
-                     else { if (fast) NLM_PRE(NN, true, 44); else NLM_PRE(NN, false, 44); } } while (0)
+                     else if (cpd == 36) { if (fast && fast_int) NLM_PRE(NN, 2, 36); else if (fast) NLM_PRE(NN, 1, 36); else NLM_PRE(NN, 0, 36); } \
+                     else { if (fast && fast_int) NLM_PRE(NN, 2, 44); else if (fast) NLM_PRE(NN, 1, 44); else NLM_PRE(NN, 0, 44); } } while (0)
             switch (n)
             {
                 case 3: NLM_VAR(3); break;
