@@ -56,6 +56,43 @@ __global__ void __launch_bounds__(256) copy3_kernel(CopyArgs a)
         for (int i = 0; i < 16 && x + i < rb; i++) d[i] = s[i];
 }
 
+// The copy-in of a whole batch: up to COPY_FRAMES frames, three planes each, in one launch (blockIdx.z = 3 * frame +
+// plane).  All frames of a call share the plane geometry; source and destination pitches are per call too (the
+// caller's frames of one call share their strides by contract, the pool's pictures by construction).
+constexpr int COPY_FRAMES = 16;
+struct CopyBatch
+{
+    const uint8_t *src[COPY_FRAMES][3];
+    uint8_t       *dst[COPY_FRAMES][3];
+    int spitch[3], dpitch[3], row_bytes[3], rows[3];
+};
+
+__global__ void __launch_bounds__(256) copy3_batch_kernel(CopyBatch a)
+{
+    const int fr = blockIdx.z / 3, pl = blockIdx.z - 3 * fr;
+    const int y = blockIdx.y;
+    if (y >= a.rows[pl]) return;
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 16;
+    const int rb = a.row_bytes[pl];
+    if (x >= rb) return;
+    const uint8_t *s = a.src[fr][pl] + (size_t)y * a.spitch[pl] + x;
+    uint8_t *d = a.dst[fr][pl] + (size_t)y * a.dpitch[pl] + x;
+    if (x + 16 <= rb && (((uintptr_t)s | (uintptr_t)d) & 15) == 0)
+        *reinterpret_cast<uint4 *>(d) = *reinterpret_cast<const uint4 *>(s);
+    else
+        for (int i = 0; i < 16 && x + i < rb; i++) d[i] = s[i];
+}
+
+int copy3_batch(hbhip_ctx *ctx, const CopyBatch &a, int frames)
+{
+    int maxrow = 0, maxrows = 0;
+    for (int c = 0; c < 3; c++) { maxrow = std::max(maxrow, a.row_bytes[c]); maxrows = std::max(maxrows, a.rows[c]); }
+    dim3 grid((maxrow + 4095) / 4096, maxrows, 3 * frames);
+    HBHIP_LAUNCH(ctx, "copy_planes", copy3_batch_kernel, grid, dim3(256), 0, a);
+    HBHIP_CHECK(ctx, hipGetLastError());
+    return HBHIP_OK;
+}
+
 int copy3(hbhip_ctx *ctx, const CopyArgs &a)
 {
     int maxrow = 0, maxrows = 0;
@@ -88,18 +125,35 @@ struct hbhip_chain
         return HBHIP_OK;
     }
 
-    int copy_in(DevPicture *dst, const hbhip_dev_frame *src)
+    // the caller's frames in[0..n) into the first stage's pictures dst[0..n): one launch per COPY_FRAMES frames that share
+    // their pitches (a frame whose pitches differ from the one before it starts a new launch)
+    int copy_in(DevPicture *const *dst, const hbhip_dev_frame *src, int n)
     {
-        CopyArgs a;
-        for (int c = 0; c < 3; c++)
+        for (int i = 0; i < n; i++)
+            for (int c = 0; c < 3; c++)
+                if (src[i].plane[c] == nullptr || src[i].stride[c] < dst[i]->width[c] * dst[i]->bps) return HBHIP_ERR_ARG;
+        for (int i0 = 0; i0 < n;)
         {
-            const int vis = dst->width[c] * dst->bps;
-            if (src->plane[c] == nullptr || src->stride[c] < vis) return HBHIP_ERR_ARG;
-            a.src[c] = (const uint8_t *)src->plane[c]; a.spitch[c] = src->stride[c];
-            a.dst[c] = dst->plane[c];                  a.dpitch[c] = dst->pitch[c];
-            a.row_bytes[c] = vis; a.rows[c] = dst->height[c];
+            CopyBatch a;
+            for (int c = 0; c < 3; c++)
+            {
+                a.spitch[c] = src[i0].stride[c]; a.dpitch[c] = dst[i0]->pitch[c];
+                a.row_bytes[c] = dst[i0]->width[c] * dst[i0]->bps; a.rows[c] = dst[i0]->height[c];
+            }
+            int k = 0;
+            for (; i0 + k < n && k < COPY_FRAMES; k++)
+            {
+                bool same = true;
+                for (int c = 0; c < 3; c++)
+                    same &= src[i0 + k].stride[c] == a.spitch[c] && dst[i0 + k]->pitch[c] == a.dpitch[c];
+                if (!same) break;
+                for (int c = 0; c < 3; c++) { a.src[k][c] = (const uint8_t *)src[i0 + k].plane[c]; a.dst[k][c] = dst[i0 + k]->plane[c]; }
+            }
+            int rc = copy3_batch(st.front()->ctx, a, k);
+            if (rc != HBHIP_OK) return rc;
+            i0 += k;
         }
-        return copy3(st.front()->ctx, a);
+        return HBHIP_OK;
     }
     int copy_out(const hbhip_dev_frame *dst, const DevPicture *src)
     {
@@ -151,21 +205,27 @@ struct hbhip_chain
         for (int i = 0; i < n_in; i++)
         {
             DevPicture *p = first->acquire_input();
-            if (!p) return HBHIP_ERR_NOMEM;
+            if (!p)
+            {
+                for (DevPicture *q : cur) first->abandon_input(q);
+                return HBHIP_ERR_NOMEM;
+            }
             p->tag = tag0 + i;
             p->refs = 0;
             if (flags) p->flags = flags[i];
             if (combed) p->combed = combed[i];
             for (int c = 0; c < 3; c++) first->in_stride[c] = in[i].stride[c];
             first->in_is_dev = true;
-            rc = copy_in(p, &in[i]);
+            cur.push_back(p);
+        }
+        if (n_in > 0)
+        {
+            rc = copy_in(cur.data(), in, n_in);
             if (rc != HBHIP_OK)
             {
-                first->abandon_input(p);
                 for (DevPicture *q : cur) first->abandon_input(q);
                 return rc;
             }
-            cur.push_back(p);
         }
         // the caller may refill its input frames in its stream's order from here on
         if (n_in > 0) { rc = order(first->ctx, ctx, ev[st.size() + 1]); if (rc != HBHIP_OK) return rc; }

@@ -68,6 +68,8 @@ private:
     size_t      slot_bytes_ = 0;
     EediFrame   half_[4];    // slot 0's SRCPF, MSKPF, TMPPF, DSTPF          (decomb.c:64-68)
     EediFrame   full_[5];    // slot 0's DST2PF, TMP2PF2, MSK2PF, TMP2PF, DST2MPF (decomb.c:69-74)
+    uint32_t   *chain_flags_ = nullptr; // mask chain: one completion flag per lower tile and field of a batch
+    uint32_t    chain_epoch_ = 0;       //             the number of the last chain launch
     uint32_t   *work_list_ = nullptr;   // calc_directions fallback: compacted edge pixels
     int        *work_count_ = nullptr;
     uint32_t   *cand_ = nullptr;        // slot 0's interpolate_lattice candidates

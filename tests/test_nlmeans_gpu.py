@@ -78,6 +78,18 @@ def test_random_noise_input(built):
     # the largest search range the reference's 16-pixel border admits with patch 3 (> 64 KB of LDS)
     ("y-strength=4:y-origin-tune=1:y-patch-size=3:y-range=29:y-frame-count=2:cb-strength=0",
      [par(4, 1.0, 3, 29, 2), par(0), par(0)]),
+    # the three forms of the table index (nlmeans.hip, FAST 0/1/2).  weight_fact = 16.84 / (patch * strength)^2:
+    # patch 7 strength 1 -> 0.34, too large for the integer multiply-high (float clamp form); patch 3 strength 1 ->
+    # 1.87, the index skips 127 (the reference's gated form); chroma at the medium tune keeps the integer form, and a
+    # launch that mixes planes takes the most general form any of its planes needs
+    ("y-strength=1:y-origin-tune=1:y-patch-size=7:y-range=3:y-frame-count=2:"
+     "cb-strength=6:cb-origin-tune=1:cb-patch-size=7:cb-range=3:cb-frame-count=2",
+     [par(1, 1.0, 7, 3, 2), par(6, 1.0, 7, 3, 2), par(6, 1.0, 7, 3, 2)]),
+    ("y-strength=1:y-origin-tune=1:y-patch-size=3:y-range=3:y-frame-count=2:"
+     "cb-strength=1.5:cb-origin-tune=1:cb-patch-size=5:cb-range=3:cb-frame-count=2",
+     [par(1, 1.0, 3, 3, 2), par(1.5, 1.0, 5, 3, 2), par(1.5, 1.0, 5, 3, 2)]),
+    ("y-strength=1.2:y-origin-tune=0.9:y-patch-size=7:y-range=5:y-frame-count=1:cb-strength=0",
+     [par(1.2, 0.9, 7, 5, 1), par(0), par(0)]),
 ])
 def test_tunes_bit_exact(built, settings, pp):
     frames = synth.stream("progressive", 192, 108, 6)

@@ -31,6 +31,7 @@ timeout 240 python tools/kernel_rooflines.py > $OUT/kernel_rooflines.json 2> $OU
 cd /tmp
 PROF="python $R/bench.py --workload chain --steps 6 --warmup 2 --no-cpu-baseline --no-pcie --no-kernel-timer"
 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $PROF > $OUT/kt.log 2>&1
+python $R/tools/trace_gaps.py $(find $OUT/kt -name '*kernel_trace.csv' | head -1) $OUT/trace_gaps.json > /dev/null 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 240 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$C -o pmc -- $PROF > $OUT/pmc_$C.log 2>&1
 done
