@@ -52,12 +52,67 @@ void hbhip_ctx::sync_ev_put(hipEvent_t e)
     sync_ev_pool.push_back(e);
 }
 
+void IdleMark::record_now()
+{
+    std::lock_guard<std::mutex> lk(lock);
+    if (recorded) return;
+    closed.store(true, std::memory_order_release);     // whoever still sees it open attached before the record below
+    (void)hipEventRecord(ev, stream);
+    recorded = true;
+}
+
+std::shared_ptr<IdleMark> hbhip_ctx::mark()
+{
+    std::lock_guard<std::recursive_mutex> lk(state_lock);
+    if (open_mark && open_mark->closed.load(std::memory_order_acquire)) open_mark.reset();   // recorded through a picture
+    if (!open_mark)
+    {
+        std::shared_ptr<IdleMark> m = std::make_shared<IdleMark>();
+        if (hipEventCreateWithFlags(&m->ev, hipEventDisableTiming) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        m->stream = stream;
+        open_mark = m;
+        has_open_mark.store(true, std::memory_order_release);
+    }
+    return open_mark;
+}
+
+void hbhip_ctx::close_mark()
+{
+    std::shared_ptr<IdleMark> m;
+    {
+        std::lock_guard<std::recursive_mutex> lk(state_lock);
+        m.swap(open_mark);
+        has_open_mark.store(false, std::memory_order_release);
+    }
+    if (m) m->record_now();
+}
+
 void hbhip_pic_mark_idle(hbhip_ctx *ctx, DevPicture *p)
 {
     if (!ctx || !p) return;
-    if (!p->idle && hipEventCreateWithFlags(&p->idle, hipEventDisableTiming) != hipSuccess) { p->idle = nullptr; return; }
-    p->idle_valid = hipEventRecord(p->idle, ctx->stream) == hipSuccess;
-    p->idle_on = ctx->stream;
+    p->idle = ctx->mark();
+    // no event to be had: the next user could not wait for this one's work, so it is waited out here
+    if (!p->idle) (void)hipStreamSynchronize(ctx->stream);
+}
+
+bool hbhip_pic_idle_done(DevPicture *p)
+{
+    if (!p || !p->idle) return true;
+    p->idle->record_now();
+    if (hipEventQuery(p->idle->ev) == hipSuccess) return true;
+    (void)hipGetLastError();                           // hipErrorNotReady
+    return false;
+}
+
+hipError_t hbhip_pic_wait_idle(hipStream_t stream, DevPicture *p)
+{
+    if (!p || !p->idle || p->idle->stream == stream) return hipSuccess;
+    p->idle->record_now();
+    return hipStreamWaitEvent(stream, p->idle->ev, 0);
 }
 
 int hbhip_ctx::prof_name(const char *name)
@@ -114,7 +169,6 @@ PicturePool::~PicturePool()
 {
     for (DevPicture *p : all_)
     {
-        if (p->idle) (void)hipEventDestroy(p->idle);
         if (p->base) (void)hipFree(p->base);
         delete p;
     }
@@ -139,16 +193,15 @@ DevPicture *PicturePool::acquire()
         for (size_t i = free_.size(); i-- > 0;)
         {
             DevPicture *p = free_[i];
-            if (p->idle_valid && p->idle_on != ctx_->stream && hipEventQuery(p->idle) != hipSuccess) continue;
+            if (p->idle && p->idle->stream != ctx_->stream && !hbhip_pic_idle_done(p)) continue;
             free_.erase(free_.begin() + (ptrdiff_t)i);
             return p;
         }
-        (void)hipGetLastError();                       // hipEventQuery's hipErrorNotReady
         if (all_.size() >= max_pictures_)
         {
             DevPicture *p = free_.front();
             free_.erase(free_.begin());
-            (void)hipStreamWaitEvent(ctx_->stream, p->idle, 0);
+            (void)hbhip_pic_wait_idle(ctx_->stream, p);
             return p;
         }
     }
@@ -214,7 +267,7 @@ int hbhip_copy_h2d(hbhip_ctx *ctx, DevPicture *dst, const hbhip_host_frame *src)
     hipEvent_t done = ctx->sync_ev_get();
     if (!done) return ctx->fail(hipErrorOutOfMemory, "hipEventCreate(upload)");
     // whatever still reads the picture's previous contents was queued on ctx->stream before it was recycled
-    if (dst->idle_valid) HBHIP_CHECK(ctx, hipStreamWaitEvent(ctx->up_stream, dst->idle, 0));
+    HBHIP_CHECK(ctx, hbhip_pic_wait_idle(ctx->up_stream, dst));
     if (same_layout(dst, src->plane, src->stride))
         HBHIP_CHECK(ctx, hipMemcpyAsync(dst->plane[0], src->plane[0], layout_bytes(dst), hipMemcpyHostToDevice, ctx->up_stream));
     else
@@ -406,6 +459,7 @@ void hbhip_ctx_destroy(hbhip_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    ctx->close_mark();
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->up_stream) { (void)hipStreamSynchronize(ctx->up_stream); (void)hipStreamDestroy(ctx->up_stream); }
     if (ctx->down_stream) { (void)hipStreamSynchronize(ctx->down_stream); (void)hipStreamDestroy(ctx->down_stream); }
@@ -417,7 +471,6 @@ void hbhip_ctx_destroy(hbhip_ctx *ctx)
     }
     for (hbhip_frame *fr : ctx->frame_pool)
     {
-        if (fr->pic.idle) (void)hipEventDestroy(fr->pic.idle);
         if (fr->pic.base) (void)hipFree(fr->pic.base);
         delete fr;
     }
@@ -557,7 +610,7 @@ int hbhip_frame_alloc(hbhip_ctx *ctx, int width, int height, int depth, int lcw,
             if (fr->width != width || fr->height != height || fr->depth != depth || fr->lcw != lcw || fr->lch != lch) continue;
             same++;
             if (oldest < 0) oldest = (int)i;
-            if (!fr->pic.idle_valid || hipEventQuery(fr->pic.idle) == hipSuccess) { pick = (int)i; break; }
+            if (hbhip_pic_idle_done(&fr->pic)) { pick = (int)i; break; }
         }
         (void)hipGetLastError();                                  // hipErrorNotReady of the queries
         if (pick < 0 && same >= 48) pick = oldest;
@@ -566,7 +619,7 @@ int hbhip_frame_alloc(hbhip_ctx *ctx, int width, int height, int depth, int lcw,
             hbhip_frame *fr = ctx->frame_pool[pick];
             ctx->frame_pool.erase(ctx->frame_pool.begin() + pick);
             fr->refs = 1;
-            fr->ready_valid = false;
+            fr->ready.reset();
             *out = fr;
             return HBHIP_OK;
         }
@@ -666,9 +719,8 @@ int hbhip_frame_mark_ready(hbhip_frame *fr)
     if (!fr) return HBHIP_ERR_ARG;
     hbhip_ctx *ctx = fr->ctx;
     (void)hipSetDevice(ctx->device);
-    if (!fr->ready) HBHIP_CHECK(ctx, hipEventCreateWithFlags(&fr->ready, hipEventDisableTiming));
-    HBHIP_CHECK(ctx, hipEventRecord(fr->ready, ctx->stream));
-    fr->ready_valid = true;
+    fr->ready = ctx->mark();
+    if (!fr->ready) return ctx->fail(hipErrorOutOfMemory, "hipEventCreate(ready)");
     return HBHIP_OK;
 }
 
@@ -687,7 +739,11 @@ int hbhip_frame_download_async(hbhip_frame *fr, const hbhip_host_frame *dst, voi
     if (!ev) return ctx->fail(hipErrorOutOfMemory, "hipEventCreate(download)");
     auto fail = [&](hipError_t e, const char *what) { ctx->sync_ev_put(ev); return ctx->fail(e, what); };
     hipError_t e;
-    if (fr->ready_valid) e = hipStreamWaitEvent(ctx->down_stream, fr->ready, 0);
+    if (fr->ready)
+    {
+        fr->ready->record_now();
+        e = hipStreamWaitEvent(ctx->down_stream, fr->ready->ev, 0);
+    }
     else
     {
         e = hipEventRecord(ev, ctx->stream);           // the picture's producers are on ctx->stream, all queued by now
@@ -836,7 +892,7 @@ int hbhip_filter_submit_async(hbhip_filter *f, const hbhip_host_frame *in, const
     pic->tag = tag;
     for (int c = 0; c < 3; c++) f->in_stride[c] = in->stride[c];
     f->in_is_dev = false;
-    if (pic->idle_valid) ASYNC_CHECK(hipStreamWaitEvent(ctx->up_stream, pic->idle, 0));
+    ASYNC_CHECK(hbhip_pic_wait_idle(ctx->up_stream, pic));
     for (int c = 0; c < 3; c++)
         ASYNC_CHECK(hipMemcpy2DAsync(pic->plane[c], pic->pitch[c], in->plane[c], in->stride[c],
                                      (size_t)std::min(in->stride[c], pic->pitch[c]), pic->height[c],

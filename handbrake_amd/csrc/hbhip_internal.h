@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <deque>
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -30,6 +31,22 @@ struct hbhip_prof_stat
     double      total_ms = 0.0;
 };
 
+// A point on a stream behind which some pictures' last users have all run: the pictures released between two launches
+// on a stream share ONE event, recorded right before the stream's next launch (or when somebody needs it first).  An
+// event per released picture is what this replaces: every record is a barrier packet the command processor works off
+// in about 4.5 us, and a chain step released 80 pictures (32 + 32 + 16 at its stage boundaries: three 143 us bubbles
+// in the kernel trace, 6 % of a step).
+struct IdleMark
+{
+    hipEvent_t  ev = nullptr;
+    hipStream_t stream = nullptr;
+    std::atomic<bool> closed{false};                 // set ahead of the record: nothing attaches to the mark from then on
+    bool        recorded = false;                    // (lock)
+    std::mutex  lock;
+    ~IdleMark() { if (ev) (void)hipEventDestroy(ev); }
+    void record_now();                               // idempotent; any thread
+};
+
 struct hbhip_ctx
 {
     int         device = 0;
@@ -41,6 +58,10 @@ struct hbhip_ctx
     // events: a picture's `idle` event (recorded when it goes back to its pool) gates the next upload into it, an
     // event recorded on `stream` at download time gates the copy out.
     hipStream_t up_stream = nullptr, down_stream = nullptr;
+    std::shared_ptr<IdleMark> open_mark;            // the mark pictures released right now attach to (state_lock)
+    std::atomic<bool> has_open_mark{false};
+    std::shared_ptr<IdleMark> mark();               // the open mark (made if there is none); null: no event to be had
+    void close_mark();                              // record it: called ahead of every launch on `stream`
     std::vector<hipEvent_t> sync_ev_pool;           // hipEventDisableTiming events (state_lock)
     hipEvent_t sync_ev_get();
     void       sync_ev_put(hipEvent_t e);
@@ -107,6 +128,7 @@ static inline bool hbhip_skip_launch(const char *name)
 #define HBHIP_LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                \
     do {                                                                        \
         if (hbhip_skip_launch(name)) break;                                     \
+        if ((ctx)->has_open_mark.load(std::memory_order_acquire)) (ctx)->close_mark(); \
         if ((ctx)->profile)                                                     \
         {                                                                       \
             /* launch and its two events as one unit: other filter threads share the stream */ \
@@ -136,9 +158,8 @@ struct DevPicture
     int      flags = 0;      // PIC_FLAG_* of the source buffer (decomb / comb detect)
     int      combed = 0;     // HB_COMB_* of the source buffer
     int      aux = 0;        // filter specific (decomb: which field of a bob pair)
-    hipEvent_t idle = nullptr;   // recorded on the stream of its last user when the picture goes back to its pool:
-    bool     idle_valid = false; // everything that used it has been queued before that point
-    hipStream_t idle_on = nullptr;   // the stream `idle` was recorded on
+    std::shared_ptr<IdleMark> idle;  // set when the picture goes back to its pool: everything that used it has been queued
+                                     // on idle->stream ahead of that mark (null: never used)
     class PicturePool *owner = nullptr;   // the pool the picture goes back to (hbhip_pic_release)
 };
 
@@ -151,8 +172,7 @@ struct hbhip_frame
     int         refs = 1;
     // hbhip_frame_mark_ready: the point of the context's stream behind which the frame's contents are complete -
     // a download waits for this point, not for whatever other filter threads have queued since
-    hipEvent_t  ready = nullptr;
-    bool        ready_valid = false;
+    std::shared_ptr<IdleMark> ready;      // (shared by the frames marked between two launches, like `idle`)
 };
 
 // Geometry of a planar YUV picture.
@@ -205,8 +225,12 @@ inline void hbhip_pic_release(DevPicture *p, hbhip_ctx *last_user = nullptr)
 // upload returns when `src` has been consumed, download when `dst` is filled.
 int hbhip_copy_h2d(hbhip_ctx *ctx, DevPicture *dst, const hbhip_host_frame *src);
 int hbhip_copy_d2h(hbhip_ctx *ctx, const hbhip_host_frame *dst, const DevPicture *src);
-// record `p->idle` on the context's stream (the picture is being recycled)
+// attach `p` to the context's open mark (the picture is being recycled; its users are all queued on ctx->stream)
 void hbhip_pic_mark_idle(hbhip_ctx *ctx, DevPicture *p);
+// has everything that used `p` run? (records the mark if it still is open)
+bool hbhip_pic_idle_done(DevPicture *p);
+// make `stream` wait for everything that used `p` (nothing to do when that was queued on `stream` itself)
+hipError_t hbhip_pic_wait_idle(hipStream_t stream, DevPicture *p);
 // Device <-> device copies (2-D, any pitch on either side) on ctx->stream.
 int hbhip_copy_d2d_in(hbhip_ctx *ctx, DevPicture *dst, const hbhip_dev_frame *src);
 int hbhip_copy_d2d_out(hbhip_ctx *ctx, const hbhip_dev_frame *dst, const DevPicture *src);
