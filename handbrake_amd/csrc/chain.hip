@@ -32,31 +32,7 @@
 
 namespace {
 
-struct CopyArgs
-{
-    const uint8_t *src[3];
-    uint8_t       *dst[3];
-    int spitch[3], dpitch[3], row_bytes[3], rows[3];
-};
-
-// 16 bytes per thread where both rows allow it; the three planes in one launch
-__global__ void __launch_bounds__(256) copy3_kernel(CopyArgs a)
-{
-    const int pl = blockIdx.z;
-    const int y = blockIdx.y;
-    if (y >= a.rows[pl]) return;
-    const int x = (blockIdx.x * 256 + threadIdx.x) * 16;
-    const int rb = a.row_bytes[pl];
-    if (x >= rb) return;
-    const uint8_t *s = a.src[pl] + (size_t)y * a.spitch[pl] + x;
-    uint8_t *d = a.dst[pl] + (size_t)y * a.dpitch[pl] + x;
-    if (x + 16 <= rb && (((uintptr_t)s | (uintptr_t)d) & 15) == 0)
-        *reinterpret_cast<uint4 *>(d) = *reinterpret_cast<const uint4 *>(s);
-    else
-        for (int i = 0; i < 16 && x + i < rb; i++) d[i] = s[i];
-}
-
-// The copy-in of a whole batch: up to COPY_FRAMES frames, three planes each, in one launch (blockIdx.z = 3 * frame +
+// The copy-in (or copy-out) of a whole batch: up to COPY_FRAMES frames, three planes each, in one launch (blockIdx.z = 3 * frame +
 // plane).  All frames of a call share the plane geometry; source and destination pitches are per call too (the
 // caller's frames of one call share their strides by contract, the pool's pictures by construction).
 constexpr int COPY_FRAMES = 16;
@@ -89,16 +65,6 @@ int copy3_batch(hbhip_ctx *ctx, const CopyBatch &a, int frames)
     for (int c = 0; c < 3; c++) { maxrow = std::max(maxrow, a.row_bytes[c]); maxrows = std::max(maxrows, a.rows[c]); }
     dim3 grid((maxrow + 4095) / 4096, maxrows, 3 * frames);
     HBHIP_LAUNCH(ctx, "copy_planes", copy3_batch_kernel, grid, dim3(256), 0, a);
-    HBHIP_CHECK(ctx, hipGetLastError());
-    return HBHIP_OK;
-}
-
-int copy3(hbhip_ctx *ctx, const CopyArgs &a)
-{
-    int maxrow = 0, maxrows = 0;
-    for (int c = 0; c < 3; c++) { maxrow = std::max(maxrow, a.row_bytes[c]); maxrows = std::max(maxrows, a.rows[c]); }
-    dim3 grid((maxrow + 4095) / 4096, maxrows, 3);
-    HBHIP_LAUNCH(ctx, "copy_planes", copy3_kernel, grid, dim3(256), 0, a);
     HBHIP_CHECK(ctx, hipGetLastError());
     return HBHIP_OK;
 }
@@ -155,33 +121,54 @@ struct hbhip_chain
         }
         return HBHIP_OK;
     }
-    int copy_out(const hbhip_dev_frame *dst, const DevPicture *src)
-    {
-        CopyArgs a;
-        for (int c = 0; c < 3; c++)
-        {
-            const int vis = src->width[c] * src->bps;
-            if (dst->plane[c] == nullptr || dst->stride[c] < vis) return HBHIP_ERR_ARG;
-            a.src[c] = src->plane[c];            a.spitch[c] = src->pitch[c];
-            a.dst[c] = (uint8_t *)dst->plane[c]; a.dpitch[c] = dst->stride[c];
-            a.row_bytes[c] = vis; a.rows[c] = src->height[c];
-        }
-        return copy3(st.back()->ctx, a);
-    }
-
-    // Deliver held / freshly finished pictures into the caller's frames.
+    // Deliver held / freshly finished pictures into the caller's frames: one copy launch per COPY_FRAMES pictures that
+    // share their pitches.  A picture whose output frame cannot take it is given up (recycled) and the call fails, after
+    // the pictures ahead of it have been delivered.
     int deliver(const hbhip_dev_frame *out, int64_t *tags, int cap, int &produced)
     {
         hbhip_filter *last = st.back();
         while (!held.empty() && produced < cap)
         {
-            DevPicture *p = held.front();
-            held.pop_front();
-            int rc = copy_out(&out[produced], p);
-            if (tags) tags[produced] = p->tag;
-            last->recycle_output(p);
+            CopyBatch a;
+            const DevPicture *p0 = held.front();
+            for (int c = 0; c < 3; c++)
+            {
+                a.spitch[c] = p0->pitch[c]; a.dpitch[c] = out[produced].stride[c];
+                a.row_bytes[c] = p0->width[c] * p0->bps; a.rows[c] = p0->height[c];
+            }
+            int k = 0;
+            bool bad = false;
+            for (; k < COPY_FRAMES && k < (int)held.size() && produced + k < cap; k++)
+            {
+                const DevPicture *p = held[k];
+                const hbhip_dev_frame &d = out[produced + k];
+                bool same = true;
+                for (int c = 0; c < 3; c++)
+                {
+                    bad |= d.plane[c] == nullptr || d.stride[c] < a.row_bytes[c];
+                    same &= p->pitch[c] == a.spitch[c] && d.stride[c] == a.dpitch[c];
+                }
+                if (bad || !same) break;
+                for (int c = 0; c < 3; c++) { a.src[k][c] = p->plane[c]; a.dst[k][c] = (uint8_t *)d.plane[c]; }
+            }
+            if (k == 0)
+            {
+                // `bad` (a frame always shares its pitches with itself)
+                DevPicture *p = held.front();
+                held.pop_front();
+                last->recycle_output(p);
+                return HBHIP_ERR_ARG;
+            }
+            const int rc = copy3_batch(last->ctx, a, k);
+            for (int i = 0; i < k; i++)
+            {
+                DevPicture *p = held.front();
+                held.pop_front();
+                if (tags) tags[produced + i] = p->tag;
+                last->recycle_output(p);
+            }
             if (rc != HBHIP_OK) return rc;
-            produced++;
+            produced += k;
         }
         return HBHIP_OK;
     }

@@ -283,23 +283,7 @@ __device__ __forceinline__ void mf_morph4(const uint32_t (*src)[MF_DP], uint32_t
 // of a launch reads P.b (the last field of the previous batch), field f > 0 the new mask of field f - 1.
 struct MaskSrc { const uint8_t *frame[EEDI_MAX_FIELDS][3]; int spitch[3]; };
 
-// The lower tiles of all fields in ONE launch (k_mask_chain): a tile of field f waits for the (up to nine) lower tiles of
-// field f - 1 whose rows its LDS frame reads, through one flag per tile in device memory.  A flag holds the number of the
-// launch that completed the tile (`epoch`, so nothing is cleared between launches).  Workgroups are numbered field-major
-// and dispatched in that order, so a waiting workgroup only ever waits for one that is already resident or done; the
-// wait is bounded all the same and traps if it runs out.  Two workgroups on different XCDs do not share an L2: the
-// chain's mask bytes and flags therefore move as agent-scope relaxed atomics (sc1 loads and write-through stores, which
-// are coherent across the XCDs), ordered by "all my stores have completed" (s_waitcnt vmcnt(0)) before the flag is
-// written.  Agent-scope FENCES do the same job for plain accesses but write back / invalidate the whole L2 each time:
-// measured, 6 600 of them per launch made the chain 3.4 ms slower than the per-field launches it replaces.
-struct MaskChain
-{
-    uint32_t *flags;          // [field][tile]
-    uint32_t  epoch;
-    int tx[3], ty0[3], tyn[3], base[3];   // per plane: tiles per row, first lower tile row, lower tile rows, first tile number
-    int ntiles;               // lower tiles of one field, all planes
-};
-
+// CHAIN: the tile is one of k_mask_chain's (MaskChain, eedi2_engine.h)
 template <bool CHAIN>
 __device__ __forceinline__ void mask_tile(const P3 &P, const MaskSrc &S, const MaskChain &C, int fld, int pl, int bx, int by,
                                           int mth, int vth, int lth, int erode_thr, int dilate_thr,
@@ -331,25 +315,7 @@ __device__ __forceinline__ void mask_tile(const P3 &P, const MaskSrc &S, const M
             *reinterpret_cast<uint32_t *>(srcp + (size_t)y * pitch + x) = sv;
         s_src[r][c4 + 1] = sv;
     }
-    if (CHAIN && fld > 0)
-    {
-        // the source rows above are already on their way; now the previous field's tiles around this one
-        if (t < 9)
-        {
-            const int nx = bx + t % 3 - 1, ny = by + t / 3 - 1;
-            if (nx >= 0 && nx < C.tx[pl] && ny >= C.ty0[pl] && ny < C.ty0[pl] + C.tyn[pl])
-            {
-                const uint32_t *flag = C.flags + (size_t)(fld - 1) * C.ntiles + C.base[pl] + (ny - C.ty0[pl]) * C.tx[pl] + nx;
-                int spins = 0;
-                while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != C.epoch)
-                {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++spins > (1 << 20)) __builtin_trap();     // about a second: the dispatch order this rests on did not hold
-                }
-            }
-        }
-        __syncthreads();                                           // (a workgroup fence: the loads below stay below)
-    }
+    if (CHAIN && fld > 0) eedi_chain_wait(C, fld, pl, bx, by);    // (the source rows above are already on their way)
     for (int i = t; i < MF_LR * MF_DW; i += MF_T)
     {
         const int r = i / MF_DW, c4 = i - r * MF_DW;
@@ -450,14 +416,7 @@ __device__ __forceinline__ void mask_tile(const P3 &P, const MaskSrc &S, const M
         else if (x + 3 < width) *reinterpret_cast<uint32_t *>(d) = res;
         else for (int k = 0; k < 4 && x + k < width; k++) d[k] = (uint8_t)(res >> (8 * k));
     }
-    if (CHAIN)
-    {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // each wave: s_waitcnt vmcnt(0), its stores have completed
-        __syncthreads();
-        if (t == 0)
-            __hip_atomic_store(C.flags + (size_t)fld * C.ntiles + C.base[pl] + (by - C.ty0[pl]) * C.tx[pl] + bx, C.epoch,
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (CHAIN) eedi_chain_signal(C, fld, pl, bx, by);
 }
 
 __global__ __launch_bounds__(MF_T) void k_mask_fused4(P3 P, MaskSrc S, int f0, int part, int mth, int vth, int lth, int erode_thr, int dilate_thr)
@@ -480,12 +439,9 @@ __global__ __launch_bounds__(MF_T) void k_mask_chain(P3 P, MaskSrc S, MaskChain 
     __shared__ uint32_t s_src[MF_LR][MF_DP];
     __shared__ uint32_t s_a[MF_LR][MF_DP];
     __shared__ uint32_t s_b[MF_LR][MF_DP];
-    const int fld = (int)blockIdx.x / C.ntiles;
-    int tile = (int)blockIdx.x - fld * C.ntiles;
-    const int pl = tile >= C.base[2] ? 2 : tile >= C.base[1] ? 1 : 0;
-    tile -= C.base[pl];
-    const int ry = tile / C.tx[pl];
-    mask_tile<true>(P, S, C, fld, pl, tile - ry * C.tx[pl], C.ty0[pl] + ry, mth, vth, lth, erode_thr, dilate_thr, s_src, s_a, s_b);
+    int fld, pl, bx, by;
+    eedi_chain_tile(C, fld, pl, bx, by);
+    mask_tile<true>(P, S, C, fld, pl, bx, by, mth, vth, lth, erode_thr, dilate_thr, s_src, s_a, s_b);
 }
 
 // calc_directions in two launches so that no lane idles while its neighbour walks the
@@ -1787,23 +1743,6 @@ __global__ void k_post_corner(CornerArgs A, const uint8_t *msk, uint8_t *dst, in
     if (hit) dst[at] = (uint8_t)(((int)dst[at - A.pitch] + (int)dst[at + A.pitch] + 1) >> 1);
 }
 
-// the lower tiles of one field, numbered plane by plane (k_mask_chain)
-MaskChain mask_chain_tiles(const EediFrame &srcp)
-{
-    MaskChain C;
-    memset(&C, 0, sizeof(C));
-    for (int c = 0; c < 3; c++)
-    {
-        const int tys = (srcp.height[c] + MF_H - 1) / MF_H;
-        C.tx[c] = (srcp.width[c] + MF_W - 1) / MF_W;
-        while (C.ty0[c] < tys && C.ty0[c] * MF_H + MF_H + MF_OY <= srcp.height[c] / 2) C.ty0[c]++;   // k_mask_fused4's `upper`
-        C.tyn[c] = tys - C.ty0[c];
-        C.base[c] = C.ntiles;
-        C.ntiles += C.tx[c] * C.tyn[c];
-    }
-    return C;
-}
-
 } // namespace
 
 // ------------------------------------------------------------------- engine
@@ -1875,7 +1814,7 @@ int Eedi2Engine::init()
     if (cap_ > 1)
     {
         // one completion flag per lower mask tile and field of a batch (MaskChain); 0 is no launch's number
-        const size_t nflags = (size_t)mask_chain_tiles(half_[0]).ntiles * cap_;
+        const size_t nflags = (size_t)eedi_mask_chain_tiles(half_[0], MF_W, MF_H, MF_OY).ntiles * cap_;
         HBHIP_CHECK(ctx_, hipMalloc((void **)&chain_flags_, sizeof(uint32_t) * nflags));
         HBHIP_CHECK(ctx_, hipMemsetAsync(chain_flags_, 0, sizeof(uint32_t) * nflags, ctx_->stream));
     }
@@ -1970,7 +1909,7 @@ int Eedi2Engine::enqueue_mask(int n, hbhip_ctx *lc)
         HBHIP_LAUNCH(lc, "eedi2_mask_upper", k_mask_fused4, dim3(gx, gy_up, 3 * n), dim3(MF_T), 0, P, S, 0, 1, mth, vth, lth,
                      par_.erosion_threshold, par_.dilation_threshold);
         // the rest: a chain through the fields, in one launch (MaskChain)
-        MaskChain C = mask_chain_tiles(srcp);
+        MaskChain C = eedi_mask_chain_tiles(srcp, MF_W, MF_H, MF_OY);
         C.flags = chain_flags_;
         C.epoch = ++chain_epoch_;
         HBHIP_LAUNCH(lc, "eedi2_mask_passes", k_mask_chain, dim3((unsigned)(C.ntiles * n)), dim3(MF_T), 0, P, S, C, mth, vth, lth,

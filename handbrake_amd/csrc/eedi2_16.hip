@@ -131,18 +131,16 @@ __device__ __forceinline__ void qm_morph4(const uint32_t (*src)[QM_DP], uint32_t
 
 struct MaskSrc16 { const uint16_t *frame[EEDI_MAX_BATCH][3]; int sp[3]; };     // sp: frame pitch in samples
 
-__global__ __launch_bounds__(QM_T) void q_mask_fused(Q3 P, MaskSrc16 S, K16 k, int f0, int part, int mth, int vth, int lth,
-                                                     int erode_thr, int dilate_thr)
+// CHAIN: the tile is one of q_mask_chain's (MaskChain, eedi2_engine.h): it waits for the previous field's tiles around it
+// before it reads their mask, reads and writes mask words as agent-scope atomics, and publishes itself at the end
+template <bool CHAIN>
+__device__ __forceinline__ void qmask_tile(const Q3 &P, const MaskSrc16 &S, const K16 &k, const MaskChain &C, int fld, int pl, int bx, int by,
+                                           int mth, int vth, int lth, int erode_thr, int dilate_thr,
+                                           uint16_t (*s_src)[QM_LP + 8], uint32_t (*s_a)[QM_DP], uint32_t (*s_b)[QM_DP])
 {
-    __shared__ __attribute__((aligned(16))) uint16_t s_src[QM_LR][QM_LP + 8];   // sample column = frame column + 4
-    __shared__ uint32_t s_a[QM_LR][QM_DP];
-    __shared__ uint32_t s_b[QM_LR][QM_DP];
-    const int zf = (int)blockIdx.z / 3, pl = (int)blockIdx.z - 3 * zf, fld = f0 + zf;   // f0: first field of this launch
     const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
-    const int x0 = blockIdx.x * QM_W, y0 = blockIdx.y * QM_H;
-    if (x0 >= width || y0 >= height) return;
+    const int x0 = bx * QM_W, y0 = by * QM_H;
     const bool upper = y0 + QM_H + QM_OY <= height / 2;            // no row of the LDS frame reaches the kept half
-    if (part != 0 && upper != (part == 1)) return;
     const size_t foff = (size_t)fld * P.fstride;
     const uint16_t *oldm = fld == 0 ? P.b[pl] : P.c[pl] + foff - P.fstride;
     const uint16_t *frame = S.frame[fld][pl];
@@ -156,7 +154,6 @@ __global__ __launch_bounds__(QM_T) void q_mask_fused(Q3 P, MaskSrc16 S, K16 k, i
         const int r = i / QM_DW, c4 = i - r * QM_DW;
         const int y = fy + r, x = fx + 4 * c4;
         uint2 sv = make_uint2(0u, 0u);
-        uint32_t mv = 0;
         if (y >= 0 && y < height && x >= 0 && x < pitch)
         {
             if (x < width)
@@ -173,14 +170,29 @@ __global__ __launch_bounds__(QM_T) void q_mask_fused(Q3 P, MaskSrc16 S, K16 k, i
             // the tile's own cells go out as SRCPF (every cell of the plane belongs to exactly one tile)
             if (r >= QM_OY && r < QM_OY + QM_H && c4 >= QM_OX / 4 && c4 < (QM_OX + QM_W) / 4)
                 *reinterpret_cast<uint2 *>(srcp + (size_t)y * pitch + x) = sv;
-            if (!upper)
-            {
-                const uint2 ov = *reinterpret_cast<const uint2 *>(oldm + (size_t)y * pitch + x);
-                mv = ((ov.x & 0xffffu) == (uint32_t)peak ? 1u : 0u) | ((ov.x >> 16) == (uint32_t)peak ? 0x100u : 0u) |
-                     ((ov.y & 0xffffu) == (uint32_t)peak ? 0x10000u : 0u) | ((ov.y >> 16) == (uint32_t)peak ? 0x1000000u : 0u);
-            }
         }
         *reinterpret_cast<uint2 *>(&s_src[r][4 * c4 + 4]) = sv;
+    }
+    if (CHAIN && fld > 0) eedi_chain_wait(C, fld, pl, bx, by);    // (the source rows above are already on their way)
+    for (int i = t; i < QM_LR * QM_DW; i += QM_T)
+    {
+        const int r = i / QM_DW, c4 = i - r * QM_DW;
+        const int y = fy + r, x = fx + 4 * c4;
+        uint32_t mv = 0;
+        // (only the rows of the kept half are used, and those were written by lower tiles)
+        if (!upper && y >= 0 && y < height && x >= 0 && x < pitch)
+        {
+            const uint32_t *m = reinterpret_cast<const uint32_t *>(oldm + (size_t)y * pitch + x);
+            uint2 ov;
+            if (CHAIN)
+            {
+                ov.x = __hip_atomic_load(m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ov.y = __hip_atomic_load(m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            else ov = *reinterpret_cast<const uint2 *>(m);
+            mv = ((ov.x & 0xffffu) == (uint32_t)peak ? 1u : 0u) | ((ov.x >> 16) == (uint32_t)peak ? 0x100u : 0u) |
+                 ((ov.y & 0xffffu) == (uint32_t)peak ? 0x10000u : 0u) | ((ov.y >> 16) == (uint32_t)peak ? 0x1000000u : 0u);
+        }
         s_a[r][c4 + 1] = mv;
     }
     __syncthreads();
@@ -267,13 +279,53 @@ __global__ __launch_bounds__(QM_T) void q_mask_fused(Q3 P, MaskSrc16 S, K16 k, i
         const uint2 out = make_uint2(((res & 1u) ? pk : 0u) | ((res & 0x100u) ? pk << 16 : 0u),
                                      ((res & 0x10000u) ? pk : 0u) | ((res & 0x1000000u) ? pk << 16 : 0u));
         uint16_t *d = newm + (size_t)y * pitch + x;
-        if (x + 3 < width) *reinterpret_cast<uint2 *>(d) = out;
+        if (x + 3 < width)
+        {
+            if (CHAIN)
+            {
+                __hip_atomic_store(reinterpret_cast<uint32_t *>(d), out.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(reinterpret_cast<uint32_t *>(d) + 1, out.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            else *reinterpret_cast<uint2 *>(d) = out;
+        }
         else
         {
             const uint16_t o4[4] = { (uint16_t)(out.x & 0xffffu), (uint16_t)(out.x >> 16), (uint16_t)(out.y & 0xffffu), (uint16_t)(out.y >> 16) };
-            for (int kk = 0; kk < 4 && x + kk < width; kk++) d[kk] = o4[kk];
+            for (int kk = 0; kk < 4 && x + kk < width; kk++)
+            {
+                if (CHAIN) __hip_atomic_store(d + kk, o4[kk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else d[kk] = o4[kk];
+            }
         }
     }
+    if (CHAIN) eedi_chain_signal(C, fld, pl, bx, by);
+}
+
+__global__ __launch_bounds__(QM_T) void q_mask_fused(Q3 P, MaskSrc16 S, K16 k, int f0, int part, int mth, int vth, int lth,
+                                                     int erode_thr, int dilate_thr)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t s_src[QM_LR][QM_LP + 8];   // sample column = frame column + 4
+    __shared__ uint32_t s_a[QM_LR][QM_DP];
+    __shared__ uint32_t s_b[QM_LR][QM_DP];
+    const int zf = (int)blockIdx.z / 3, pl = (int)blockIdx.z - 3 * zf, fld = f0 + zf;   // f0: first field of this launch
+    const int x0 = blockIdx.x * QM_W, y0 = blockIdx.y * QM_H;
+    if (x0 >= P.width[pl] || y0 >= P.height[pl]) return;
+    const bool upper = y0 + QM_H + QM_OY <= P.height[pl] / 2;
+    if (part != 0 && upper != (part == 1)) return;
+    MaskChain none;
+    qmask_tile<false>(P, S, k, none, fld, pl, (int)blockIdx.x, (int)blockIdx.y, mth, vth, lth, erode_thr, dilate_thr, s_src, s_a, s_b);
+}
+
+// blockIdx.x = field * C.ntiles + tile: field-major, see MaskChain
+__global__ __launch_bounds__(QM_T) void q_mask_chain(Q3 P, MaskSrc16 S, K16 k, MaskChain C, int mth, int vth, int lth,
+                                                     int erode_thr, int dilate_thr)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t s_src[QM_LR][QM_LP + 8];
+    __shared__ uint32_t s_a[QM_LR][QM_DP];
+    __shared__ uint32_t s_b[QM_LR][QM_DP];
+    int fld, pl, bx, by;
+    eedi_chain_tile(C, fld, pl, bx, by);
+    qmask_tile<true>(P, S, k, C, fld, pl, bx, by, mth, vth, lth, erode_thr, dilate_thr, s_src, s_a, s_b);
 }
 
 // eedi2_calc_directions (:358-525): a = mskp, b = srcp, c = out (whole pitch pre-filled with PEAK)
@@ -740,61 +792,205 @@ __global__ void q_mark_2x(Q3 P, K16 k)
     Q.c[(size_t)y * pitch + x] = (uint16_t)v;
 }
 
-// eedi2_fill_gaps_2x (:1025-1132): a = msk2p, b = direction map in, c = out.  Launched after a copy
-// of b into c; a thread whose sample opens a fillable gap writes the whole span (every thread of the
-// same gap computes and writes the same values).
-__global__ void q_fill_gaps(Q3 P, K16 k)
+// eedi2_fill_gaps_2x (:1025-1132): a = msk2p, b = direction map in, c = out.
+// The same pass in the form of the 8-bit kernel (eedi2.hip: k_fill_gaps_b), copy included: a workgroup owns QF_W
+// consecutive samples of one row.  Rows the pass does not rebuild are copied.  For a rebuilt row the seven rows involved
+// (dc = y, mask y-1 / y+1 / y-3 / y+3, direction y-2 / y+2) are staged in LDS with QF_HALO samples either side (same flat
+// addressing), turned into four bit rows by ballots (a walk stops here / the direction is known / the row above, below
+// ends the "continues" state), the gap samples of the span are compacted into a list, and each listed sample finds its
+// gap's ends and its support with 64-bit scans; only min / max over a supported gap still reads samples.  A walk that
+// leaves the staged span takes the sample-by-sample path on memory (rare).  Every sample of a fillable gap computes the
+// same (u, v, back, forward, verdict) as its neighbours in the gap, so each thread writes its own sample only.
+constexpr int QF_W = 1024, QF_HALO = 64, QF_LW = QF_W + 2 * QF_HALO;
+
+__global__ __launch_bounds__(256) void q_fill_gaps_b(Q3 P, K16 k)
 {
-    XY16(P);
-    const int y0 = 2 - tff;
-    if (x < 1 || x >= width - 1 || y < y0 || y >= height - 1 || ((y - y0) & 1)) return;
+    __shared__ __attribute__((aligned(16))) uint16_t s_r[7][QF_LW];
+    __shared__ __attribute__((aligned(16))) uint16_t s_out[QF_W];
+    __shared__ uint16_t s_list[QF_W];
+    __shared__ int s_count;
+    __shared__ uint64_t s_stop[QF_LW / 64 + 1], s_np[QF_LW / 64 + 1], s_bt[QF_LW / 64 + 1], s_bb[QF_LW / 64 + 1];   // one bit per staged column
+    FIELD16(P);
+    const int y = blockIdx.y, y0 = 2 - tff;
+    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
+    const int x0 = blockIdx.x * QF_W, tid = threadIdx.x;
+    if (y >= height || x0 >= width) return;
     const int peak = k.peak;
-    const uint16_t *dc = Q.b + (size_t)y * pitch;
-    const uint16_t *dp = dc - 2 * (ptrdiff_t)pitch, *dn = dc + 2 * (ptrdiff_t)pitch;
-    const uint16_t *mc = Q.a + (size_t)(y - 1) * pitch;
-    const uint16_t *mp = mc - 2 * (ptrdiff_t)pitch, *mn = mc + 2 * (ptrdiff_t)pitch, *mnn = mn + 2 * (ptrdiff_t)pitch;
-    if (dc[x] != peak || (mc[x] != peak && mn[x] != peak)) return;
+    const uint16_t *dcg = Q.b + (size_t)y * pitch;
+    uint16_t *og = Q.c + (size_t)y * pitch;
+    const int x = x0 + 4 * tid;
+    auto store4 = [&](uint2 v) {
+        if (x + 3 < width) *reinterpret_cast<uint2 *>(og + x) = v;
+        else
+        {
+            const uint16_t o4[4] = { (uint16_t)(v.x & 0xffffu), (uint16_t)(v.x >> 16), (uint16_t)(v.y & 0xffffu), (uint16_t)(v.y >> 16) };
+            for (int j = 0; j < 4 && x + j < width; j++) og[x + j] = o4[j];
+        }
+    };
+    if (!(y >= y0 && y < height - 1 && ((y - y0) & 1) == 0))
+    {
+        if (x < width) store4(*reinterpret_cast<const uint2 *>(dcg + x));
+        return;
+    }
+    if (tid == 0) s_count = 0;
+    const uint16_t *g[7] = { dcg, Q.a + (ptrdiff_t)(y - 1) * pitch, Q.a + (ptrdiff_t)(y + 1) * pitch,
+                             dcg - 2 * (ptrdiff_t)pitch, dcg + 2 * (ptrdiff_t)pitch,
+                             Q.a + (ptrdiff_t)(y - 3) * pitch, Q.a + (ptrdiff_t)(y + 3) * pitch };
+    const int lo = x0 - QF_HALO;                                   // column of staged sample 0 (a multiple of 4)
+    const int nq = (min(QF_W, (width - x0 + 3) & ~3) + 2 * QF_HALO) / 4;       // groups of four samples, <= 288
+    {
+        // all loads of a thread in flight before the first LDS store
+        uint2 v[7][2];
+#pragma unroll
+        for (int r = 0; r < 7; r++)
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+            {
+                const int i = tid + 256 * q;
+                v[r][q] = i < nq ? reinterpret_cast<const uint2 *>(g[r] + lo)[i] : make_uint2(0u, 0u);
+            }
+#pragma unroll
+        for (int r = 0; r < 7; r++)
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+            {
+                const int i = tid + 256 * q;
+                if (i < nq) reinterpret_cast<uint2 *>(s_r[r])[i] = v[r][q];
+            }
+    }
+    __syncthreads();
+    enum { DC = 0, MC = 1, MN = 2, DP = 3, DN = 4, MP = 5, MNN = 6 };
+    const unsigned staged = 4u * (unsigned)nq;
+    for (int q = 0; q < (QF_LW + 255) / 256; q++)
+    {
+        const unsigned col = tid + 256 * q;
+        bool np = false, stop = false, bt = false, bb = false;
+        if (col < staged)
+        {
+            const bool mc = s_r[MC][col] == peak, mn = s_r[MN][col] == peak;
+            np = s_r[DC][col] != peak;
+            stop = np || (!mc && !mn);
+            bt = s_r[DP][col] == peak || (s_r[MP][col] != peak && !mc);
+            bb = s_r[DN][col] == peak || (!mn && s_r[MNN][col] != peak);
+        }
+        const uint64_t w0 = __ballot(stop), w1 = __ballot(np), w2 = __ballot(bt), w3 = __ballot(bb);
+        if ((tid & 63) == 0 && (col >> 6) < QF_LW / 64 + 1) { s_stop[col >> 6] = w0; s_np[col >> 6] = w1; s_bt[col >> 6] = w2; s_bb[col >> 6] = w3; }
+    }
+    if (x < width)
+    {
+        const int c = 4 * tid + QF_HALO;
+        const uint2 cw = *reinterpret_cast<const uint2 *>(&s_r[DC][c]);
+        *reinterpret_cast<uint2 *>(&s_out[4 * tid]) = cw;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+        {
+            const int xx = x + j;
+            if (xx >= 1 && xx < width - 1 && s_r[DC][c + j] == peak && (s_r[MC][c + j] == peak || s_r[MN][c + j] == peak))
+                s_list[atomicAdd(&s_count, 1)] = (uint16_t)(4 * tid + j);
+        }
+    }
+    __syncthreads();
+    const int count = s_count;
     const int eight = 8 << k.shift, twenty = 20 << k.shift, five_hundred = 500 << k.shift;
-    int u = x - 1, back = five_hundred, forward = -five_hundred;
-    while (u)
+    auto rd = [&](int r, int col) -> int {
+        const unsigned kk = (unsigned)(col - lo);
+        return kk < staged ? (int)s_r[r][kk] : (int)g[r][col];
+    };
+    for (int i = tid; i < count; i += 256)
     {
-        if (dc[u] != peak) { back = dc[u]; break; }
-        if (mc[u] != peak && mn[u] != peak) break;
-        u--;
-    }
-    int v = x + 1;
-    while (v < width)
-    {
-        if (dc[v] != peak) { forward = dc[v]; break; }
-        if (mc[v] != peak && mn[v] != peak) break;
-        v++;
-    }
-    int tc = 1, bc = 1, mint = five_hundred, maxt = -twenty, minb = five_hundred, maxb = -twenty;
-    for (int j = u; j <= v; j++)
-    {
-        if (tc)
+        const int lx = s_list[i], px = x0 + lx;
+        int u = px - 1, back = five_hundred, forward = -five_hundred;
+        int v = px + 1;
+        int tc = 1, bc = 1, mint = five_hundred, maxt = -twenty, minb = five_hundred, maxb = -twenty;
+        // the two walks as bit scans over the staged columns [first, last) = plane columns [max(lo, 1), min(lo + staged, width))
+        const int c = px - lo;
+        const int first = max(1 - lo, 0), last = min((int)staged, width - lo);
+        int ul = -1, vl = -1;
+        for (int wi = (c - 1) >> 6; wi >= (first >> 6) && c - 1 >= first; wi--)      // highest stop bit in [first, c - 1]
         {
-            if (y <= 2 || dp[j] == peak || (mp[j] != peak && mc[j] != peak)) { tc = 0; mint = maxt = twenty; }
-            else { if (dp[j] < mint) mint = dp[j]; if (dp[j] > maxt) maxt = dp[j]; }
+            uint64_t w = s_stop[wi];
+            if (wi == ((c - 1) >> 6) && ((c - 1) & 63) != 63) w &= (2ull << ((c - 1) & 63)) - 1ull;
+            if (wi == (first >> 6)) w &= ~0ull << (first & 63);
+            if (w) { ul = 64 * wi + 63 - __clzll((long long)w); break; }
         }
-        if (bc)
+        for (int wi = (c + 1) >> 6; wi <= ((last - 1) >> 6) && c + 1 < last; wi++)   // lowest stop bit in [c + 1, last - 1]
         {
-            if (y >= height - 3 || dn[j] == peak || (mn[j] != peak && mnn[j] != peak)) { bc = 0; minb = maxb = twenty; }
-            else { if (dn[j] < minb) minb = dn[j]; if (dn[j] > maxb) maxb = dn[j]; }
+            uint64_t w = s_stop[wi];
+            if (wi == ((c + 1) >> 6)) w &= ~0ull << ((c + 1) & 63);
+            if (wi == ((last - 1) >> 6) && ((last - 1) & 63) != 63) w &= (2ull << ((last - 1) & 63)) - 1ull;
+            if (w) { vl = 64 * wi + __ffsll((long long)w) - 1; break; }
+        }
+        // inside the staged span when each walk found its stop there or ran into the row end inside it
+        const bool fast = (ul >= 0 || lo <= 1) && (vl >= 0 || lo + (int)staged > width);     // column `width` itself must be staged too
+        if (fast)
+        {
+            if (ul >= 0) { u = lo + ul; if ((s_np[ul >> 6] >> (ul & 63)) & 1ull) back = s_r[DC][ul]; }
+            else u = 0;
+            if (vl >= 0) { v = lo + vl; if ((s_np[vl >> 6] >> (vl & 63)) & 1ull) forward = s_r[DC][vl]; }
+            else v = width;
+            // columns u .. v (v = width included, as the reference's loop includes it) are staged
+            const int a0 = u - lo, a1 = v - lo;
+            auto any_in = [&](const uint64_t *bits) {
+                for (int wi = a0 >> 6; wi <= (a1 >> 6); wi++)
+                {
+                    uint64_t w = bits[wi];
+                    if (wi == (a0 >> 6)) w &= ~0ull << (a0 & 63);
+                    if (wi == (a1 >> 6) && (a1 & 63) != 63) w &= (2ull << (a1 & 63)) - 1ull;
+                    if (w) return true;
+                }
+                return false;
+            };
+            if (y <= 2 || any_in(s_bt)) { tc = 0; mint = maxt = twenty; }
+            else for (int j = a0; j <= a1; j++) { const int t = s_r[DP][j]; mint = min(mint, t); maxt = max(maxt, t); }
+            if (y >= height - 3 || any_in(s_bb)) { bc = 0; minb = maxb = twenty; }
+            else for (int j = a0; j <= a1; j++) { const int t = s_r[DN][j]; minb = min(minb, t); maxb = max(maxb, t); }
+        }
+        else
+        {
+            while (u)
+            {
+                const int d = rd(DC, u);
+                if (d != peak) { back = d; break; }
+                if (rd(MC, u) != peak && rd(MN, u) != peak) break;
+                u--;
+            }
+            while (v < width)
+            {
+                const int d = rd(DC, v);
+                if (d != peak) { forward = d; break; }
+                if (rd(MC, v) != peak && rd(MN, v) != peak) break;
+                v++;
+            }
+            for (int j = u; j <= v; j++)
+            {
+                if (tc)
+                {
+                    int t;
+                    if (y <= 2 || (t = rd(DP, j)) == peak || (rd(MP, j) != peak && rd(MC, j) != peak)) { tc = 0; mint = maxt = twenty; }
+                    else { mint = min(mint, t); maxt = max(maxt, t); }
+                }
+                if (bc)
+                {
+                    int t;
+                    if (y >= height - 3 || (t = rd(DN, j)) == peak || (rd(MN, j) != peak && rd(MNN, j) != peak)) { bc = 0; minb = maxb = twenty; }
+                    else { minb = min(minb, t); maxb = max(maxb, t); }
+                }
+            }
+        }
+        if (maxt == -twenty) maxt = mint = twenty;
+        if (maxb == -twenty) maxb = minb = twenty;
+        const int far = max(iabs16(forward - k.neutral), iabs16(back - k.neutral));
+        const int thresh = max(max(far >> 2, eight), max(iabs16(mint - maxt), iabs16(minb - maxb)));
+        const int flim = min(far >> (2 + k.shift), 6);
+        if (iabs16(forward - back) <= thresh && (v - u - 1 <= flim || tc || bc))
+        {
+            const double step = (double)(forward - back) / (double)(v - u);
+            const int j = px - u - 1;
+            s_out[lx] = (uint16_t)(back + (int)(j * step + 0.5));
         }
     }
-    if (maxt == -twenty) maxt = mint = twenty;
-    if (maxb == -twenty) maxb = minb = twenty;
-    const int far = max(iabs16(forward - k.neutral), iabs16(back - k.neutral));
-    const int thresh = max(max(far >> 2, eight), max(iabs16(mint - maxt), iabs16(minb - maxb)));
-    const int flim = min(far >> (2 + k.shift), 6);
-    if (iabs16(forward - back) <= thresh && (v - u - 1 <= flim || tc || bc))
-    {
-        const double step = (double)(forward - back) / (double)(v - u);
-        uint16_t *o = Q.c + (size_t)y * pitch;
-        for (int j = 0; j < v - u - 1; j++)
-            o[u + j + 1] = (uint16_t)(back + (int)(j * step + 0.5));
-    }
+    __syncthreads();
+    if (x < width) store4(*reinterpret_cast<const uint2 *>(&s_out[4 * tid]));
 }
 
 // plain copy of the visible width (eedi2_bit_blit :46-68): a = in, c = out; eight samples per thread
@@ -1144,6 +1340,7 @@ Eedi2Engine16::Eedi2Engine16(hbhip_ctx *ctx, const PicGeometry &geo, const Eedi2
 Eedi2Engine16::~Eedi2Engine16()
 {
     if (slab_) (void)hipFree(slab_);
+    if (chain_flags_) (void)hipFree(chain_flags_);
     for (int i = 0; i < 3; i++)
     {
         if (deriv_[i]) (void)hipFree(deriv_[i]);
@@ -1189,6 +1386,13 @@ int Eedi2Engine16::init()
     for (auto &f : full_) for (int c = 0; c < 3; c++) f.plane[c] = slab_ + (size_t)(uintptr_t)f.plane[c];
     cand_ = reinterpret_cast<unsigned long long *>(slab_ + cand_at);
     last_slot_ = cap_;                                              // "the previous mask" of the first run: zeros
+    if (cap_ > 1)
+    {
+        // one completion flag per lower mask tile and field of a batch (MaskChain); 0 is no launch's number
+        const size_t nflags = (size_t)eedi_mask_chain_tiles(half_[0], QM_W, QM_H, QM_OY).ntiles * cap_;
+        HBHIP_CHECK(ctx_, hipMalloc((void **)&chain_flags_, sizeof(uint32_t) * nflags));
+        HBHIP_CHECK(ctx_, hipMemsetAsync(chain_flags_, 0, sizeof(uint32_t) * nflags, ctx_->stream));
+    }
     if (par_.post_processing > 1)
     {
         const size_t n = sizeof(int) * (size_t)geo_.height * full_[0].stride[0];     // decomb.c:398-403 sizes them by the byte stride
@@ -1284,9 +1488,11 @@ int Eedi2Engine16::enqueue(int n, hbhip_ctx *lc)
             const unsigned gy_up = std::max(1, (srcp.height[0] / 2 - QM_OY) / QM_H);
             HBHIP_LAUNCH(lc, "eedi2_16_mask_upper", q_mask_fused, dim3(gx, gy_up, gz), dim3(QM_T), 0, P, S, k, 0, 1, mth, vth, lth,
                          par_.erosion_threshold, par_.dilation_threshold);
-            for (int f = 0; f < n; f++)
-                HBHIP_LAUNCH(lc, "eedi2_16_mask_passes", q_mask_fused, dim3(gx, gy, 3), dim3(QM_T), 0, P, S, k, f, 2, mth, vth, lth,
-                             par_.erosion_threshold, par_.dilation_threshold);
+            MaskChain C = eedi_mask_chain_tiles(srcp, QM_W, QM_H, QM_OY);
+            C.flags = chain_flags_;
+            C.epoch = ++chain_epoch_;
+            HBHIP_LAUNCH(lc, "eedi2_16_mask_passes", q_mask_chain, dim3((unsigned)(C.ntiles * n)), dim3(QM_T), 0, P, S, k, C, mth, vth, lth,
+                         par_.erosion_threshold, par_.dilation_threshold);
         }
     }
     // half-height passes (decomb_template.c:398-404), all fields per launch from here on
@@ -1320,10 +1526,8 @@ int Eedi2Engine16::enqueue(int n, hbhip_ctx *lc)
     for (int pass = 0; pass < 2; pass++)
     {
         const EediFrame &in = pass ? dst2mp : tmp2p, &out = pass ? tmp2p : dst2mp;
-        bind(P.a, in); bind(P.c, out);
-        HBHIP_LAUNCH(lc, "eedi2_16_blit", q_blit, grid8(dst2p, false, gz), blk, 0, P);
         bind(P.a, msk2p); bind(P.b, in); bind(P.c, out);
-        HBHIP_LAUNCH(lc, "eedi2_16_fill_gaps_2x", q_fill_gaps, grid(dst2p, false, gz), blk, 0, P, k);
+        HBHIP_LAUNCH(lc, "eedi2_16_fill_gaps_2x", q_fill_gaps_b, dim3((dst2p.width[0] + QF_W - 1) / QF_W, dst2p.height[0], gz), dim3(256), 0, P, k);
     }
     bind(P.a, tmp2p); bind(P.b, dst2p); bind(P.c, tmp2p2);
     {

@@ -4,6 +4,7 @@
 
 #include "hbhip_internal.h"
 
+#include <cstring>
 #include <vector>
 
 struct Eedi2Params
@@ -28,6 +29,87 @@ struct EediFrame
     int      height[3] = {0, 0, 0};
     size_t   bytes = 0;
 };
+
+// The lower mask tiles of all fields of a batch in ONE launch: a tile of field f waits for the (up to nine) lower tiles
+// of field f - 1 whose rows its LDS frame reads, through one flag per tile in device memory.  A flag holds the number
+// of the launch that completed the tile (`epoch`, so nothing is cleared between launches).  Workgroups are numbered
+// field-major and dispatched in that order, so a waiting workgroup only ever waits for one that is already resident
+// or done; the wait is bounded all the same and traps if it runs out.  Two workgroups on different XCDs do not share
+// an L2: the chain's mask words and flags therefore move as agent-scope relaxed atomics (sc1 loads and write-through
+// stores, which are coherent across the XCDs), ordered by "all my stores have completed" (an explicit s_waitcnt
+// vmcnt(0) in every wave) before the flag is written.  Agent-scope FENCES do the same job for plain accesses but write back / invalidate the whole
+// L2 each time: measured, 6 600 of them per launch made the chain 3.4 ms slower than the per-field launches it replaces.
+struct MaskChain
+{
+    uint32_t *flags;          // [field][tile]
+    uint32_t  epoch;
+    int tx[3], ty0[3], tyn[3], base[3];   // per plane: tiles per row, first lower tile row, lower tile rows, first tile number
+    int ntiles;               // lower tiles of one field, all planes
+};
+
+// the lower tiles of one field, numbered plane by plane; a tile row is "upper" (no row of its LDS frame reaches the half
+// of the mask that is kept from the previous field) while by * tile_h + tile_h + oy <= height / 2
+static inline MaskChain eedi_mask_chain_tiles(const EediFrame &srcp, int tile_w, int tile_h, int oy)
+{
+    MaskChain C;
+    memset(&C, 0, sizeof(C));
+    for (int c = 0; c < 3; c++)
+    {
+        const int tys = (srcp.height[c] + tile_h - 1) / tile_h;
+        C.tx[c] = (srcp.width[c] + tile_w - 1) / tile_w;
+        while (C.ty0[c] < tys && C.ty0[c] * tile_h + tile_h + oy <= srcp.height[c] / 2) C.ty0[c]++;
+        C.tyn[c] = tys - C.ty0[c];
+        C.base[c] = C.ntiles;
+        C.ntiles += C.tx[c] * C.tyn[c];
+    }
+    return C;
+}
+
+// blockIdx.x = field * C.ntiles + tile -> field, plane, tile column and row
+__device__ __forceinline__ void eedi_chain_tile(const MaskChain &C, int &fld, int &pl, int &bx, int &by)
+{
+    fld = (int)blockIdx.x / C.ntiles;
+    int tile = (int)blockIdx.x - fld * C.ntiles;
+    pl = tile >= C.base[2] ? 2 : tile >= C.base[1] ? 1 : 0;
+    tile -= C.base[pl];
+    const int ry = tile / C.tx[pl];
+    bx = tile - ry * C.tx[pl];
+    by = C.ty0[pl] + ry;
+}
+
+// threads 0 .. 8 of the workgroup: wait for the previous field's tile at (bx + t % 3 - 1, by + t / 3 - 1), if there is one
+__device__ __forceinline__ void eedi_chain_wait(const MaskChain &C, int fld, int pl, int bx, int by)
+{
+    const int t = threadIdx.x;
+    if (t < 9)
+    {
+        const int nx = bx + t % 3 - 1, ny = by + t / 3 - 1;
+        if (nx >= 0 && nx < C.tx[pl] && ny >= C.ty0[pl] && ny < C.ty0[pl] + C.tyn[pl])
+        {
+            const uint32_t *flag = C.flags + (size_t)(fld - 1) * C.ntiles + C.base[pl] + (ny - C.ty0[pl]) * C.tx[pl] + nx;
+            int spins = 0;
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != C.epoch)
+            {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1 << 20)) __builtin_trap();     // about a second: the dispatch order this rests on did not hold
+            }
+        }
+    }
+    __syncthreads();                                           // (a workgroup fence: the mask loads that follow stay below)
+}
+
+// after the tile's mask stores (agent-scope atomics): publish the tile
+__device__ __forceinline__ void eedi_chain_signal(const MaskChain &C, int fld, int pl, int bx, int by)
+{
+    // each wave: its stores have completed (a workgroup-scope release fence does not wait for them - waves of a
+    // workgroup share their L1 - and without the wait the flag overtakes mask words still in flight: seen as a handful
+    // of wrong mask samples in one run out of a few)
+    __builtin_amdgcn_s_waitcnt(0x0f70);                        // vmcnt(0), gfx9 encoding
+    __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_store(C.flags + (size_t)fld * C.ntiles + C.base[pl] + (by - C.ty0[pl]) * C.tx[pl] + bx, C.epoch,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // EEDI2 on 8-bit samples (eedi2.hip).  Fields are queued with add_field() and run by launch(): the mask passes field
 // after field (the edge mask is the one piece of state a run takes from the one before it: the lower half of MSKPF
@@ -111,6 +193,8 @@ private:
     size_t      slot_bytes_ = 0;
     EediFrame   half_[4];    // slot 0's SRCPF, MSKPF, TMPPF, DSTPF
     EediFrame   full_[5];    // slot 0's DST2PF, TMP2PF2, MSK2PF, TMP2PF, DST2MPF
+    uint32_t   *chain_flags_ = nullptr; // mask chain (MaskChain)
+    uint32_t    chain_epoch_ = 0;
     unsigned long long *cand_ = nullptr;   // slot 0's interpolate_lattice candidates
     int         cand_pitch_ = 0, cand_plane_stride_ = 0;
     int        *deriv_[3] = {nullptr, nullptr, nullptr};

@@ -204,3 +204,58 @@ def test_comb_detect_many_frames_per_launch(built, model, w, h, par):
     finally:
         cd.close()
         ctx.close()
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_eedi2_mask_chain_is_repeatable_at_1080p(built, depth):
+    """The lower mask tiles of a batch run as one launch in which the tiles of field f wait for their neighbours of
+    field f - 1 through flags in device memory (MaskChain, eedi2_engine.h) - workgroups on different XCDs handing
+    bytes to each other inside a launch.  An ordering slip there shows as a few wrong mask samples once in a few
+    runs, so: the same 12 frames (24 fields, 400-odd tiles per field and plane set) six times over through fresh
+    filters, every output frame of every run identical to the first run's; the first run itself is pinned by a frame
+    of the oracle's.  The chroma planes matter most here: their rows start on 64-byte boundaries, so a 128-byte line
+    of the mask holds the halves of two tiles."""
+    import torch
+    w, h, n = 1920, 1080, 12
+    frames = synth.stream("interlaced", w, h, n, depth=depth)
+    dt = torch.uint8 if depth == 8 else torch.uint16
+    ctx = hip.Ctx(0)
+    first = None
+    try:
+        dev_in = [[torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in f] for f in frames]
+        cap = 2 * n + 2
+        outs = [[torch.zeros((h, w), dtype=dt, device="cuda"),
+                 torch.zeros((h // 2, w // 2), dtype=dt, device="cuda"),
+                 torch.zeros((h // 2, w // 2), dtype=dt, device="cuda")] for _ in range(cap)]
+        for run in range(6):
+            dec = hip.DecombDevice(ctx, w, h, mode=31, postproc=1, depth=depth)
+            stage = hip.DeviceFilter(ctx, dec.h)
+            dec.h = None
+            chain = hip.Chain(ctx, [stage])
+            try:
+                arr_in = (hip.DevFrame * n)(*[hip.dev_frame(f) for f in dev_in])
+                arr_out = (hip.DevFrame * cap)(*[hip.dev_frame(o) for o in outs])
+                k = chain.process_dev(arr_in, arr_out, tag0=0, flags=[TFF] * n, combed=[2] * n)
+                chain.sync()
+                got = [[p.cpu().numpy().copy() for p in outs[i]] for i in range(k)]
+                arr_out = (hip.DevFrame * cap)(*[hip.dev_frame(o) for o in outs])
+                k = chain.flush_dev(arr_out)
+                chain.sync()
+                got += [[p.cpu().numpy().copy() for p in outs[i]] for i in range(k)]
+            finally:
+                chain.close()
+            if first is None:
+                first = got
+                assert len(first) == 2 * n
+                continue
+            assert len(got) == len(first)
+            for i in range(len(first)):
+                for c in range(3):
+                    np.testing.assert_array_equal(got[i][c], first[i][c], err_msg=f"run {run} frame {i} plane {c}")
+        # pin the first run: output frames 0 .. 3 (two input frames, four fields) against the oracle
+        want = os_.decomb_eedi2_stream(frames[:3], dict(mode=31, postproc=1, depth=depth), flags=TFF)
+        for i in range(4):
+            for c in range(3):
+                np.testing.assert_array_equal(first[i][c], want[i]["planes"][c], err_msg=f"frame {i} plane {c} against the oracle")
+    finally:
+        ctx.close()
