@@ -652,52 +652,125 @@ __device__ __forceinline__ void vote1q(int v, int mid, int lim, int &sum, int &c
     sum += in ? v : 0;
 }
 
-__global__ void q_dir_map(Q3 P, K16 k, int step, int expand)
+// one sample of filter_dir_map / expand_dir_map (:649-773, _2x :872-1011) whose neighbourhood holds enough directions
+__device__ __forceinline__ int dir_map_px16(int u0, int u1, int u2, int c0, int c1, int c2, int n0, int n1, int n2,
+                                            bool up_ok, bool dn_ok, int expand, int peak, int neutral, int sh2, const int *limlut)
 {
-    XY16(P);
+    const bool h0 = up_ok && u0 != peak, h1 = up_ok && u1 != peak, h2 = up_ok && u2 != peak;
+    const bool h3 = c0 != peak, h4 = !expand && c1 != peak, h5 = c2 != peak;
+    const bool h6 = dn_ok && n0 != peak, h7 = dn_ok && n1 != peak, h8 = dn_ok && n2 != peak;
+    const int u = h0 + h1 + h2 + h3 + h4 + h5 + h6 + h7 + h8;
+    if (u < (expand ? 5 : 4)) return expand ? c1 : peak;
+    int v0 = h0 ? u0 : ABSENT16, v1 = h1 ? u1 : ABSENT16, v2 = h2 ? u2 : ABSENT16;
+    int v3 = h3 ? c0 : ABSENT16, v4 = h4 ? c1 : ABSENT16, v5 = h5 ? c2 : ABSENT16;
+    int v6 = h6 ? n0 : ABSENT16, v7 = h7 ? n1 : ABSENT16, v8 = h8 ? n2 : ABSENT16;
+    const int mid = mid9q(v0, v1, v2, v3, v4, v5, v6, v7, v8, u);
+    const int lim = limlut[iabs16(mid - neutral) >> sh2];
+    int sum = 0, count = 0;
+    vote1q(v0, mid, lim, sum, count); vote1q(v1, mid, lim, sum, count); vote1q(v2, mid, lim, sum, count);
+    vote1q(v3, mid, lim, sum, count); vote1q(v4, mid, lim, sum, count); vote1q(v5, mid, lim, sum, count);
+    vote1q(v6, mid, lim, sum, count); vote1q(v7, mid, lim, sum, count); vote1q(v8, mid, lim, sum, count);
+    const int val = (int)(((float)(sum + mid) / (float)(count + 1)) + 0.5f);
+    if (expand) return count >= 5 ? val : c1;
+    if (count < 4 || (count < 5 && c1 == peak)) return peak;
+    return val;
+}
+
+// Two phases, as for 8-bit samples (eedi2.hip: k_dir_map_c).  Phase 1, four samples per thread: which samples reach the
+// sort at all (inside the mask, enough usable directions around them) - on real pictures a small minority, spread so
+// that nearly every wave holds a few, and a wave pays for the sort if one lane needs it.  They are queued (an LDS list
+// per workgroup of 4 rows x 256 samples) and phase 2 gives each queued sample a lane of its own.  a = edge mask,
+// b = direction map in, c = out; step 1 (half height) or 2.
+__global__ __launch_bounds__(256) void q_dir_map(Q3 P, K16 k, int step, int expand)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t s_out[4][256];
+    __shared__ uint16_t s_list[4 * 256];
+    __shared__ int s_count;
+    __shared__ int s_lim[33];
+    FIELD16(P);
     const int y0 = step == 1 ? 1 : 2 - tff;
-    if (x >= width || y >= height) return;
+    const int bx0 = 4 * (blockIdx.x * 64), x = bx0 + 4 * threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
+    if (bx0 >= width || (int)blockIdx.y * 4 >= height) return;                       // whole workgroup outside
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    if (tid == 0) s_count = 0;
+    if (tid < 33) s_lim[tid] = k.limlut[tid];
+    __syncthreads();
     const int peak = k.peak;
-    const uint16_t *dc = Q.b + (size_t)y * pitch;
-    int v = dc[x];
-    const bool row_on = step == 1 ? (y >= 1 && y < height - 1) : (y >= y0 && y < height - 1 && ((y - y0) & 1) == 0);
-    if (row_on && x >= 1 && x < width - 1)
+    const bool inside = x < width && y < height;
+    const bool row_ok = step == 1 ? (y >= 1 && y < height - 1) : (y >= y0 && y < height - 1 && ((y - y0) & 1) == 0);
+    const uint16_t *dc = Q.b + (size_t)y * pitch + x;
+    if (inside)
     {
-        bool masked;
-        if (step == 1) masked = Q.a[(size_t)y * pitch + x] == peak;
-        else           masked = Q.a[(size_t)(y - 1) * pitch + x] == peak || Q.a[(size_t)(y + 1) * pitch + x] == peak;
-        if (masked && !(expand && v != peak))
+        uint2 out = *reinterpret_cast<const uint2 *>(dc);
+        if (row_ok)
         {
             const bool up_ok = step == 1 || y > 1, dn_ok = step == 1 || y < height - 2;
-            const uint16_t *dp = up_ok ? dc - (ptrdiff_t)step * pitch : dc, *dn = dn_ok ? dc + (ptrdiff_t)step * pitch : dc;
-            const int u0 = dp[x - 1], u1 = dp[x], u2 = dp[x + 1], c0 = dc[x - 1], c2 = dc[x + 1], n0 = dn[x - 1], n1 = dn[x], n2 = dn[x + 1];
-            const bool h0 = up_ok && u0 != peak, h1 = up_ok && u1 != peak, h2 = up_ok && u2 != peak;
-            const bool h3 = c0 != peak, h4 = !expand && v != peak, h5 = c2 != peak;
-            const bool h6 = dn_ok && n0 != peak, h7 = dn_ok && n1 != peak, h8 = dn_ok && n2 != peak;
-            const int u = h0 + h1 + h2 + h3 + h4 + h5 + h6 + h7 + h8;
-            if (u < (expand ? 5 : 4))
+            // six samples x-1 .. x+4 of the three rows: usable (non-peak) flags, bit j = sample x-1+j
+            auto usable6 = [&](const uint16_t *row) -> uint32_t {
+                const uint2 v = *reinterpret_cast<const uint2 *>(row);
+                const int l = row[-1], r = row[4];
+                return (l != peak ? 1u : 0u) | ((int)(v.x & 0xffffu) != peak ? 2u : 0u) | ((int)(v.x >> 16) != peak ? 4u : 0u) |
+                       ((int)(v.y & 0xffffu) != peak ? 8u : 0u) | ((int)(v.y >> 16) != peak ? 16u : 0u) | (r != peak ? 32u : 0u);
+            };
+            const uint32_t fc = usable6(dc);
+            const uint32_t fu = up_ok ? usable6(dc - (ptrdiff_t)step * pitch) : 0u;
+            const uint32_t fd = dn_ok ? usable6(dc + (ptrdiff_t)step * pitch) : 0u;
+            const uint16_t *mk = Q.a + (size_t)y * pitch + x;
+            const uint2 m0 = *reinterpret_cast<const uint2 *>(step == 1 ? mk : mk - (ptrdiff_t)pitch);
+            const uint2 m1 = step == 1 ? make_uint2(0u, 0u) : *reinterpret_cast<const uint2 *>(mk + pitch);
+            const int mm0[4] = { (int)(m0.x & 0xffffu), (int)(m0.x >> 16), (int)(m0.y & 0xffffu), (int)(m0.y >> 16) };
+            const int mm1[4] = { (int)(m1.x & 0xffffu), (int)(m1.x >> 16), (int)(m1.y & 0xffffu), (int)(m1.y >> 16) };
+            uint32_t o4[4] = { out.x & 0xffffu, out.x >> 16, out.y & 0xffffu, out.y >> 16 };
+            uint32_t sortpx = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
             {
-                if (!expand) v = peak;
+                const int xx = x + j;
+                const bool masked = mm0[j] == peak || (step != 1 && mm1[j] == peak);
+                const bool centre_usable = (fc >> (j + 1)) & 1u;
+                const bool cand = xx >= 1 && xx < width - 1 && masked && !(expand && centre_usable);
+                // usable values among the 3 x 3 (expand leaves the centre out, :671)
+                const int u = __popc((fu >> j) & 7u) + __popc((fd >> j) & 7u) + __popc((fc >> j) & (expand ? 5u : 7u));
+                const bool enough = u >= (expand ? 5 : 4);
+                if (cand && !enough && !expand) o4[j] = (uint32_t)peak;               // too few neighbours: peak
+                if (cand && enough) sortpx |= 1u << j;
             }
-            else
+            out = make_uint2(o4[0] | (o4[1] << 16), o4[2] | (o4[3] << 16));
+            if (sortpx)
             {
-                int v0 = h0 ? u0 : ABSENT16, v1 = h1 ? u1 : ABSENT16, v2 = h2 ? u2 : ABSENT16;
-                int v3 = h3 ? c0 : ABSENT16, v4 = h4 ? v : ABSENT16, v5 = h5 ? c2 : ABSENT16;
-                int v6 = h6 ? n0 : ABSENT16, v7 = h7 ? n1 : ABSENT16, v8 = h8 ? n2 : ABSENT16;
-                const int mid = mid9q(v0, v1, v2, v3, v4, v5, v6, v7, v8, u);
-                const int lim = k.limlut[iabs16(mid - k.neutral) >> (2 + k.shift)];
-                int sum = 0, count = 0;
-                vote1q(v0, mid, lim, sum, count); vote1q(v1, mid, lim, sum, count); vote1q(v2, mid, lim, sum, count);
-                vote1q(v3, mid, lim, sum, count); vote1q(v4, mid, lim, sum, count); vote1q(v5, mid, lim, sum, count);
-                vote1q(v6, mid, lim, sum, count); vote1q(v7, mid, lim, sum, count); vote1q(v8, mid, lim, sum, count);
-                const int val = (int)(((float)(sum + mid) / (float)(count + 1)) + 0.5f);
-                if (expand) { if (count >= 5) v = val; }
-                else if (count < 4 || (count < 5 && v == peak)) v = peak;
-                else v = val;
+                int at = atomicAdd(&s_count, __popc(sortpx));
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if ((sortpx >> j) & 1u) s_list[at++] = (uint16_t)((threadIdx.y << 8) | (4 * threadIdx.x + j));
             }
         }
+        *reinterpret_cast<uint2 *>(&s_out[threadIdx.y][4 * threadIdx.x]) = out;
     }
-    Q.c[(size_t)y * pitch + x] = (uint16_t)v;
+    __syncthreads();
+    const int count = s_count;
+    for (int i = tid; i < count; i += 256)
+    {
+        const int e = s_list[i], ly = e >> 8, lx = e & 255;
+        const int yy = blockIdx.y * 4 + ly;
+        const uint16_t *c = Q.b + (size_t)yy * pitch + bx0 + lx;
+        const bool up_ok = step == 1 || yy > 1, dn_ok = step == 1 || yy < height - 2;
+        const uint16_t *up = up_ok ? c - (ptrdiff_t)step * pitch : c, *dn = dn_ok ? c + (ptrdiff_t)step * pitch : c;
+        s_out[ly][lx] = (uint16_t)dir_map_px16(up[-1], up[0], up[1], c[-1], c[0], c[1], dn[-1], dn[0], dn[1], up_ok, dn_ok, expand,
+                                               peak, k.neutral, 2 + k.shift, s_lim);
+    }
+    __syncthreads();
+    if (inside)
+    {
+        const uint2 v = *reinterpret_cast<const uint2 *>(&s_out[threadIdx.y][4 * threadIdx.x]);
+        uint16_t *o = Q.c + (size_t)y * pitch + x;
+        if (x + 3 < width) *reinterpret_cast<uint2 *>(o) = v;
+        else
+        {
+            const uint16_t o4[4] = { (uint16_t)(v.x & 0xffffu), (uint16_t)(v.x >> 16), (uint16_t)(v.y & 0xffffu), (uint16_t)(v.y >> 16) };
+            for (int j = 0; j < 4 && x + j < width; j++) o[j] = o4[j];
+        }
+    }
 }
 
 __device__ __forceinline__ bool trips16(const uint16_t *side, const uint16_t *dc, int x, int from, int to, int lim, int peak)
@@ -1009,110 +1082,216 @@ __global__ void q_blit(Q3 P)
 // interpolate_lattice in two launches, as for 8-bit samples (eedi2.hip: k_lattice_cand / k_lattice_resolve).  Of all a
 // pixel's tests only one looks at the direction value just written at x-1 (the left-hand half of :1194); everything else
 // - including the whole "outcome B" the pixel takes when that test fails - reads values no pixel of the pass changes.
-// q_lattice_cand (one thread per pixel of the rebuilt rows) packs into 64 bits:
+// q_lattice_cand packs into 64 bits:
 //   [15:0] valA = vertical average (outcome A)   [31:16] valB   [47:32] newB = outcome-B direction value
 //   bit 48 = "always A" (direction == peak)      bit 49 = right-hand test |d[x] - d[x+1]| > lim
 // q_lattice_resolve16 (one workgroup per row) resolves which outcome each pixel takes: every pixel is a 2-state map of
 // its left neighbour's outcome, composed by a prefix scan, and writes the row.
+// The candidates are made the way the 8-bit kernel makes them (eedi2.hip: k_lattice_cand_q): a workgroup takes 1024
+// samples of a rebuilt row with the five rows involved staged in LDS; every thread packs the words of its four samples as
+// if they were "always A" and queues the ones that carry a direction (roughly one in ten on real pictures, but nearly
+// every wave holds some); the queue then gets one lane per sample, stage by stage - the variance / edge tests, the search
+// around the sample's direction, the short search - each stage either finishing the word or handing the sample on.
+constexpr int LQ16_W = 1024, LQ16_HALO = 40, LQ16_LW = LQ16_W + 2 * LQ16_HALO;   // |u| <= 34, +-1 for the triples
+constexpr unsigned long long LAT16_MORE = 1ull << 63;
+
+struct Lat16
+{
+    int peak, neutral, sh, sh2, three, nine, nt4, nt7, nt8, nt7_unshifted;
+    const int *lim;                    // limlut, in LDS
+};
+
+__device__ __forceinline__ unsigned long long lat16_word(int valB, int newB) { return ((unsigned long long)(uint16_t)valB << 16) | ((unsigned long long)(uint16_t)newB << 32); }
+
+// the variance and the edge test on the fixed 2 x 5 neighbourhood (:1213-1240)
+__device__ __forceinline__ unsigned long long lat16_stage_a(const uint16_t *top, const uint16_t *bot, const uint16_t *dm, int x, int width,
+                                                            unsigned long long base, const Lat16 &L)
+{
+    const int d = dm[x];
+    const int T0 = top[x - 2], T1 = top[x - 1], T2 = top[x], T3 = top[x + 1], T4 = top[x + 2];
+    const int B0 = bot[x - 2], B1 = bot[x - 1], B2 = bot[x], B3 = bot[x + 1], B4 = bot[x + 2];
+    const int lim = L.lim[iabs16(d - L.neutral) >> L.sh2];
+    const int avg = (int)(base & 0xffffu);
+    if (lim < L.nine)
+    {
+        const int sh = L.sh;
+        const int sum = (T1 + T2 + T3 + B1 + B2 + B3) >> sh;
+        const int t1 = T1 >> sh, t2 = T2 >> sh, t3 = T3 >> sh, b1 = B1 >> sh, b2 = B2 >> sh, b3 = B3 >> sh;
+        const int sumsq = t1 * t1 + t2 * t2 + t3 * t3 + b1 * b1 + b2 * b2 + b3 * b3;
+        if (6 * sumsq - sum * sum < 576) return base | lat16_word(avg, L.peak);
+    }
+    if (x > 1 && x < width - 2)
+    {
+        const int three = L.three;
+        if ((T2 < max(T0, T1) - three && T2 < max(T4, T3) - three && B2 < max(B0, B1) - three && B2 < max(B4, B3) - three) ||
+            (T2 > min(T0, T1) + three && T2 > min(T4, T3) + three && B2 > min(B0, B1) + three && B2 > min(B4, B3) + three))
+            return base | lat16_word(avg, L.neutral);
+    }
+    return base | LAT16_MORE;
+}
+
+// the search around the sample's direction (:1242-1290)
+__device__ __forceinline__ unsigned long long lat16_stage_b(const uint16_t *top, const uint16_t *bot, const uint16_t *ot, const uint16_t *ob,
+                                                            const uint16_t *dm, int x, int width, unsigned long long base, const Lat16 &L)
+{
+    const int here = dm[x], peak = L.peak;
+    const int lim = L.lim[iabs16(here - L.neutral) >> L.sh2];
+    int dir = (here - L.neutral + (1 << (L.sh2 - 1))) >> L.sh2;
+    int val = (int)(base & 0xffffu);
+    const int startu = (dir - 2 < 0) ? max(-x + 1, max(dir - 2, -width + 2 + x)) : min(x - 1, min(dir - 2, width - 2 - x));
+    const int stopu = (dir + 2 < 0) ? max(-x + 1, max(dir + 2, -width + 2 + x)) : min(x - 1, min(dir + 2, width - 2 - x));
+    int mn = L.nt8;
+    auto near = [&](const uint16_t *row, int i) { return row[i] != peak && iabs16((int)row[i] - here) <= lim; };
+    for (int u = startu; u <= stopu; u++)
+    {
+        const int diff = sad3w(top, x, bot, x - u) + sad3w(bot, x, top, x + u);
+        if (!(diff < mn && (near(ot, x - 1 + u) || near(ot, x + u) || near(ot, x + 1 + u)) &&
+              (near(ob, x - 1 - u) || near(ob, x - u) || near(ob, x + 1 - u))))
+            continue;
+        const int h0 = u >> 1, h1 = (u + 1) >> 1;
+        const int diff2 = sad3w(top, x + h0, bot, x - h0);
+        const int o0 = ot[x + h0], o1 = ot[x + h1], q0 = ob[x - h0], q1 = ob[x - h1];
+        if (!(diff2 < L.nt4 && (((iabs16(o0 - q0) <= lim || iabs16(o0 - q1) <= lim) && o0 != peak) ||
+                                ((iabs16(o1 - q0) <= lim || iabs16(o1 - q1) <= lim) && o1 != peak))))
+            continue;
+        if ((iabs16(here - o0) <= lim || iabs16(here - o1) <= lim) && (iabs16(here - q0) <= lim || iabs16(here - q1) <= lim))
+        {
+            val = ((int)top[x + h0] + (int)top[x + h1] + (int)bot[x - h0] + (int)bot[x - h1] + 2) >> 2;
+            mn = diff;
+            dir = u;
+        }
+    }
+    if (mn != L.nt8) return base | lat16_word(val, L.neutral + (dir << L.sh2));
+    return base | LAT16_MORE;
+}
+
+// the short search for samples the first one left without a match (:1292-1318)
+__device__ __forceinline__ unsigned long long lat16_stage_c(const uint16_t *top, const uint16_t *bot, const uint16_t *dm, int x, int width, int pl,
+                                                            unsigned long long base, const Lat16 &L)
+{
+    int dir = ((int)dm[x] - L.neutral + (1 << (L.sh2 - 1))) >> L.sh2;
+    int val = (int)(base & 0xffffu);
+    const int lo = min((int)top[x], (int)bot[x]), hi = max((int)top[x], (int)bot[x]);
+    const int dd = pl == 0 ? 4 : 2;
+    const int su = max(-x + 1, -dd), eu = min(width - 2 - x, dd);
+    int mn = L.nt7;
+    for (int u = su; u <= eu; u++)
+    {
+        const int h0 = u >> 1, h1 = (u + 1) >> 1;
+        const int p1 = (int)top[x + h0] + (int)top[x + h1];
+        const int p2 = (int)bot[x - h0] + (int)bot[x - h1];
+        const int diff = sad3w(top, x, bot, x - u) + sad3w(bot, x, top, x + u) + iabs16(p1 - p2);
+        if (diff < mn)
+        {
+            const int valt = (p1 + p2 + 2) >> 2;
+            if (valt >= lo && valt <= hi) { val = valt; mn = diff; dir = u; }
+        }
+    }
+    const int newB = (mn == L.nt7_unshifted) ? L.neutral : (int)(uint16_t)(L.neutral + (dir << L.sh2));      // unshifted 7*nt (:1324)
+    return base | lat16_word(val, newB);
+}
+
 __global__ __launch_bounds__(256) void q_lattice_cand(Q3 P, K16 k, int nt, unsigned long long *__restrict__ cand,
                                                       int cand_pitch, int cand_plane_stride)
 {
+    __shared__ __attribute__((aligned(16))) uint16_t s_rows[5][LQ16_LW];
+    __shared__ __attribute__((aligned(16))) unsigned long long s_cand[LQ16_W];
+    __shared__ uint16_t s_list[3][LQ16_W];                        // one queue per stage
+    __shared__ int s_count[3];
+    __shared__ int s_lim[33];
     FIELD16(P);
     const int field = tff;
     cand += (size_t)fld * (P.fstride / 4);                         // the candidates live in the field's slot (64-bit words)
     const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
-    const int nrows = (height - 1 - (2 - field) + 1) / 2;
-    if (x >= width || r >= nrows) return;
-    const int y = (2 - field) + 2 * r;
-    const int peak = k.peak, neutral = k.neutral, sh = k.shift, sh2 = 2 + k.shift;
-    const int nt4 = (uint16_t)((nt << sh) * 4), nt7 = (uint16_t)((nt << sh) * 7), nt8 = (uint16_t)((nt << sh) * 8);
-    const int three = 3 << sh, nine = 9 << sh;
-    const uint16_t *top = Q.b + (size_t)(y - 1) * pitch, *bot = top + 2 * (size_t)pitch;
-    const uint16_t *ot = Q.c + (size_t)(y - 1) * pitch, *ob = ot + 2 * (size_t)pitch;
-    const uint16_t *dm = Q.a + (size_t)y * pitch;
-    int dir = dm[x];
-    const int here = dir;
-    const int lim = k.limlut[iabs16(dir - neutral) >> sh2];
-    const int avg = ((int)top[x] + (int)bot[x] + 1) >> 1;
-    const bool always_a = dir == peak;
-    const bool right = iabs16(here - (int)dm[x + 1]) > lim;
-    int valB = avg, newB = neutral;
-    if (!always_a)
+    const int x0 = blockIdx.x * LQ16_W, t = threadIdx.x;
+    const int ri = blockIdx.y;
+    const int nrows = (height - (2 - field)) / 2;
+    if (x0 >= width || ri >= nrows) return;
+    const int y = (2 - field) + 2 * ri;
+    if (t < 3) s_count[t] = 0;
+    if (t < 33) s_lim[t] = k.limlut[t];
     {
-        bool done = false;
-        if (lim < nine)
+        const uint16_t *g[5] = { Q.b + (size_t)(y - 1) * pitch, Q.b + (size_t)(y + 1) * pitch,
+                                 Q.c + (size_t)(y - 1) * pitch, Q.c + (size_t)(y + 1) * pitch,
+                                 Q.a + (size_t)y * pitch };
+        // only as far right as the row's samples (+ halo) reach; groups of four samples
+        const int need4 = (min(LQ16_W, (width - x0 + 3) & ~3) + 2 * LQ16_HALO) / 4;
+        for (int r = 0; r < 5; r++)
+            for (int c4 = t; c4 < need4; c4 += 256)
+                reinterpret_cast<uint2 *>(s_rows[r])[c4] = reinterpret_cast<const uint2 *>(g[r] + x0 - LQ16_HALO)[c4];
+    }
+    __syncthreads();
+    Lat16 L;
+    L.peak = k.peak; L.neutral = k.neutral; L.sh = k.shift; L.sh2 = 2 + k.shift;
+    L.three = 3 << k.shift; L.nine = 9 << k.shift;
+    L.nt4 = (uint16_t)((nt << k.shift) * 4); L.nt7 = (uint16_t)((nt << k.shift) * 7); L.nt8 = (uint16_t)((nt << k.shift) * 8);
+    L.nt7_unshifted = 7 * nt;
+    L.lim = s_lim;
+    const uint16_t *top = s_rows[0] + LQ16_HALO - x0, *bot = s_rows[1] + LQ16_HALO - x0;
+    const uint16_t *ot = s_rows[2] + LQ16_HALO - x0, *ob = s_rows[3] + LQ16_HALO - x0;
+    const uint16_t *dm = s_rows[4] + LQ16_HALO - x0;
+    {
+        const int x = x0 + 4 * t;
+        if (x < width)
         {
-            const int sum = ((int)top[x - 1] + (int)top[x] + (int)top[x + 1] + (int)bot[x - 1] + (int)bot[x] + (int)bot[x + 1]) >> sh;
-            auto sq = [&](int v) { return (v >> sh) * (v >> sh); };
-            const int sumsq = sq(top[x - 1]) + sq(top[x]) + sq(top[x + 1]) + sq(bot[x - 1]) + sq(bot[x]) + sq(bot[x + 1]);
-            if (6 * sumsq - sum * sum < 576) { valB = avg; newB = peak; done = true; }
-        }
-        if (!done && x > 1 && x < width - 2 &&
-            (((int)top[x] < max((int)top[x - 2], (int)top[x - 1]) - three && (int)top[x] < max((int)top[x + 2], (int)top[x + 1]) - three &&
-              (int)bot[x] < max((int)bot[x - 2], (int)bot[x - 1]) - three && (int)bot[x] < max((int)bot[x + 2], (int)bot[x + 1]) - three) ||
-             ((int)top[x] > min((int)top[x - 2], (int)top[x - 1]) + three && (int)top[x] > min((int)top[x + 2], (int)top[x + 1]) + three &&
-              (int)bot[x] > min((int)bot[x - 2], (int)bot[x - 1]) + three && (int)bot[x] > min((int)bot[x + 2], (int)bot[x + 1]) + three)))
-        { valB = avg; newB = neutral; done = true; }
-        if (!done)
-        {
-            dir = (dir - neutral + (1 << (sh2 - 1))) >> sh2;
-            int val = avg;
-            const int startu = (dir - 2 < 0) ? max(-x + 1, max(dir - 2, -width + 2 + x)) : min(x - 1, min(dir - 2, width - 2 - x));
-            const int stopu = (dir + 2 < 0) ? max(-x + 1, max(dir + 2, -width + 2 + x)) : min(x - 1, min(dir + 2, width - 2 - x));
-            int mn = nt8;
-            auto near = [&](const uint16_t *row, int i) { return row[i] != peak && iabs16((int)row[i] - here) <= lim; };
-            for (int u = startu; u <= stopu; u++)
+            unsigned long long w[4];
+            uint32_t queue = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
             {
-                const int diff = sad3w(top, x, bot, x - u) + sad3w(bot, x, top, x + u);
-                if (!(diff < mn && (near(ot, x - 1 + u) || near(ot, x + u) || near(ot, x + 1 + u)) &&
-                      (near(ob, x - 1 - u) || near(ob, x - u) || near(ob, x + 1 - u))))
-                    continue;
-                const int h0 = u >> 1, h1 = (u + 1) >> 1;
-                const int diff2 = sad3w(top, x + h0, bot, x - h0);
-                if (!(diff2 < nt4 &&
-                      (((iabs16((int)ot[x + h0] - (int)ob[x - h0]) <= lim || iabs16((int)ot[x + h0] - (int)ob[x - h1]) <= lim) && ot[x + h0] != peak) ||
-                       ((iabs16((int)ot[x + h1] - (int)ob[x - h0]) <= lim || iabs16((int)ot[x + h1] - (int)ob[x - h1]) <= lim) && ot[x + h1] != peak))))
-                    continue;
-                if ((iabs16(here - (int)ot[x + h0]) <= lim || iabs16(here - (int)ot[x + h1]) <= lim) &&
-                    (iabs16(here - (int)ob[x - h0]) <= lim || iabs16(here - (int)ob[x - h1]) <= lim))
-                {
-                    val = ((int)top[x + h0] + (int)top[x + h1] + (int)bot[x - h0] + (int)bot[x - h1] + 2) >> 2;
-                    mn = diff;
-                    dir = u;
-                }
+                const int d = dm[x + j], dr = dm[x + j + 1];
+                const int avg = ((int)top[x + j] + (int)bot[x + j] + 1) >> 1;
+                const int lim = s_lim[iabs16(d - L.neutral) >> L.sh2];
+                const unsigned long long right = iabs16(d - dr) > lim ? 1ull << 49 : 0ull;
+                const bool searching = d != L.peak && x + j < width;
+                w[j] = searching ? ((unsigned long long)(uint16_t)avg | right)
+                                 : ((unsigned long long)(uint16_t)avg | lat16_word(avg, L.neutral) | (1ull << 48) | right);
+                if (searching) queue |= 1u << j;
             }
-            if (mn != nt8)
+#pragma unroll
+            for (int j = 0; j < 4; j++) s_cand[4 * t + j] = w[j];
+            if (queue)
             {
-                valB = val;
-                newB = (uint16_t)(neutral + (dir << sh2));
-            }
-            else
-            {
-                const int lo = min((int)top[x], (int)bot[x]), hi = max((int)top[x], (int)bot[x]);
-                const int d = pl == 0 ? 4 : 2;
-                const int su = max(-x + 1, -d), eu = min(width - 2 - x, d);
-                mn = nt7;
-                for (int u = su; u <= eu; u++)
-                {
-                    const int h0 = u >> 1, h1 = (u + 1) >> 1;
-                    const int p1 = (int)top[x + h0] + (int)top[x + h1];
-                    const int p2 = (int)bot[x - h0] + (int)bot[x - h1];
-                    const int diff = sad3w(top, x, bot, x - u) + sad3w(bot, x, top, x + u) + iabs16(p1 - p2);
-                    if (diff < mn)
-                    {
-                        const int valt = (p1 + p2 + 2) >> 2;
-                        if (valt >= lo && valt <= hi) { val = valt; mn = diff; dir = u; }
-                    }
-                }
-                valB = val;
-                newB = (mn == 7 * nt) ? neutral : (int)(uint16_t)(neutral + (dir << sh2));      // unshifted 7*nt (:1324)
+                int at = atomicAdd(&s_count[0], __popc(queue));
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if ((queue >> j) & 1u) s_list[0][at++] = (uint16_t)(4 * t + j);
             }
         }
     }
-    cand[(size_t)pl * cand_plane_stride + (size_t)r * cand_pitch + x] =
-        (unsigned long long)(uint16_t)avg | ((unsigned long long)(uint16_t)valB << 16) | ((unsigned long long)(uint16_t)newB << 32) |
-        ((unsigned long long)always_a << 48) | ((unsigned long long)right << 49);
+    __syncthreads();
+    for (int i = t, n = s_count[0]; i < n; i += 256)
+    {
+        const int lx = s_list[0][i];
+        const unsigned long long w = lat16_stage_a(top, bot, dm, x0 + lx, width, s_cand[lx], L);
+        if (w & LAT16_MORE) s_list[1][atomicAdd(&s_count[1], 1)] = (uint16_t)lx;
+        else s_cand[lx] = w;
+    }
+    __syncthreads();
+    for (int i = t, n = s_count[1]; i < n; i += 256)
+    {
+        const int lx = s_list[1][i];
+        const unsigned long long w = lat16_stage_b(top, bot, ot, ob, dm, x0 + lx, width, s_cand[lx], L);
+        if (w & LAT16_MORE) s_list[2][atomicAdd(&s_count[2], 1)] = (uint16_t)lx;
+        else s_cand[lx] = w;
+    }
+    __syncthreads();
+    for (int i = t, n = s_count[2]; i < n; i += 256)
+    {
+        const int lx = s_list[2][i];
+        s_cand[lx] = lat16_stage_c(top, bot, dm, x0 + lx, width, pl, s_cand[lx], L);
+    }
+    __syncthreads();
+    {
+        const int x = x0 + 4 * t;
+        unsigned long long *o = cand + (size_t)pl * cand_plane_stride + (size_t)ri * cand_pitch + x;
+        if (x + 3 < width && (((uintptr_t)o) & 15) == 0)
+        {
+            reinterpret_cast<uint4 *>(o)[0] = *reinterpret_cast<const uint4 *>(&s_cand[4 * t]);
+            reinterpret_cast<uint4 *>(o)[1] = *reinterpret_cast<const uint4 *>(&s_cand[4 * t + 2]);
+        }
+        else for (int j = 0; j < 4 && x + j < width; j++) o[j] = s_cand[4 * t + j];
+    }
 }
 
 constexpr int LR16_T = 1024;
@@ -1459,6 +1638,9 @@ int Eedi2Engine16::enqueue(int n, hbhip_ctx *lc)
         const int w = whole_pitch ? f.stride[0] / 2 : f.width[0];
         return dim3((w + 63) / 64, (f.height[0] + 3) / 4, z);
     };
+    auto grid4 = [&](const EediFrame &f, unsigned z) {                          // four samples per thread, blocks of 64 x 4 threads
+        return dim3((f.width[0] + 255) / 256, (f.height[0] + 3) / 4, z);
+    };
     auto grid8 = [&](const EediFrame &f, bool whole_pitch, unsigned z) {      // kernels with eight samples per thread
         const int w = whole_pitch ? f.stride[0] / 2 : f.width[0];
         return dim3((w + 511) / 512, (f.height[0] + 3) / 4, z);
@@ -1503,9 +1685,9 @@ int Eedi2Engine16::enqueue(int n, hbhip_ctx *lc)
     else
         HBHIP_LAUNCH(lc, "eedi2_16_calc_directions", q_calc_dir, grid(srcp, true, gz), blk, 0, P, k, par_.maximum_search_distance, par_.noise_threshold);
     bind(P.a, mskp); bind(P.b, tmpp); bind(P.c, dstp);
-    HBHIP_LAUNCH(lc, "eedi2_16_filter_dir_map", q_dir_map, grid(srcp, false, gz), blk, 0, P, k, 1, 0);
+    HBHIP_LAUNCH(lc, "eedi2_16_filter_dir_map", q_dir_map, grid4(srcp, gz), blk, 0, P, k, 1, 0);
     bind(P.a, mskp); bind(P.b, dstp); bind(P.c, tmpp);
-    HBHIP_LAUNCH(lc, "eedi2_16_expand_dir_map", q_dir_map, grid(srcp, false, gz), blk, 0, P, k, 1, 1);
+    HBHIP_LAUNCH(lc, "eedi2_16_expand_dir_map", q_dir_map, grid4(srcp, gz), blk, 0, P, k, 1, 1);
     bind(P.a, mskp); bind(P.b, tmpp); bind(P.c, dstp);
     HBHIP_LAUNCH(lc, "eedi2_16_filter_map", q_filter_map, grid(srcp, false, gz), blk, 0, P, k);
     // line doubling
@@ -1520,9 +1702,9 @@ int Eedi2Engine16::enqueue(int n, hbhip_ctx *lc)
     bind(P.a, msk2p); bind(P.b, tmp2p2); bind(P.c, tmp2p);
     HBHIP_LAUNCH(lc, "eedi2_16_mark_directions_2x", q_mark_2x, grid(dst2p, true, gz), blk, 0, P, k);
     bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
-    HBHIP_LAUNCH(lc, "eedi2_16_filter_dir_map_2x", q_dir_map, grid(dst2p, false, gz), blk, 0, P, k, 2, 0);
+    HBHIP_LAUNCH(lc, "eedi2_16_filter_dir_map_2x", q_dir_map, grid4(dst2p, gz), blk, 0, P, k, 2, 0);
     bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
-    HBHIP_LAUNCH(lc, "eedi2_16_expand_dir_map_2x", q_dir_map, grid(dst2p, false, gz), blk, 0, P, k, 2, 1);
+    HBHIP_LAUNCH(lc, "eedi2_16_expand_dir_map_2x", q_dir_map, grid4(dst2p, gz), blk, 0, P, k, 2, 1);
     for (int pass = 0; pass < 2; pass++)
     {
         const EediFrame &in = pass ? dst2mp : tmp2p, &out = pass ? tmp2p : dst2mp;
@@ -1532,7 +1714,7 @@ int Eedi2Engine16::enqueue(int n, hbhip_ctx *lc)
     bind(P.a, tmp2p); bind(P.b, dst2p); bind(P.c, tmp2p2);
     {
         const int nrows = (dst2p.height[0] - 1) / 2;                // rows y0, y0 + 2, ... < height - 1 for either parity (even heights)
-        HBHIP_LAUNCH(lc, "eedi2_16_lattice_candidates", q_lattice_cand, dim3((dst2p.width[0] + 255) / 256, nrows, gz), dim3(256), 0, P, k,
+        HBHIP_LAUNCH(lc, "eedi2_16_lattice_candidates", q_lattice_cand, dim3((dst2p.width[0] + LQ16_W - 1) / LQ16_W, nrows, gz), dim3(256), 0, P, k,
                      par_.noise_threshold, cand, cand_pitch_, cand_plane_stride_);
         HBHIP_LAUNCH(lc, "eedi2_16_lattice_resolve", q_lattice_resolve16, dim3(1, nrows + 1, gz), dim3(LR16_T), 0, P, k,
                      (const unsigned long long *)cand, cand_pitch_, cand_plane_stride_);
@@ -1542,9 +1724,9 @@ int Eedi2Engine16::enqueue(int n, hbhip_ctx *lc)
         bind(P.a, tmp2p); bind(P.c, tmp2p2);
         HBHIP_LAUNCH(lc, "eedi2_16_blit", q_blit, grid8(dst2p, false, gz), blk, 0, P);             // eedi2_bit_blit(tmp2p -> tmp2p2)
         bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
-        HBHIP_LAUNCH(lc, "eedi2_16_filter_dir_map_2x", q_dir_map, grid(dst2p, false, gz), blk, 0, P, k, 2, 0);
+        HBHIP_LAUNCH(lc, "eedi2_16_filter_dir_map_2x", q_dir_map, grid4(dst2p, gz), blk, 0, P, k, 2, 0);
         bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
-        HBHIP_LAUNCH(lc, "eedi2_16_expand_dir_map_2x", q_dir_map, grid(dst2p, false, gz), blk, 0, P, k, 2, 1);
+        HBHIP_LAUNCH(lc, "eedi2_16_expand_dir_map_2x", q_dir_map, grid4(dst2p, gz), blk, 0, P, k, 2, 1);
         bind(P.a, tmp2p); bind(P.b, tmp2p2); bind(P.c, dst2p);
         HBHIP_LAUNCH(lc, "eedi2_16_post_process", q_post, grid(dst2p, false, gz), blk, 0, P, k);
     }
