@@ -26,10 +26,29 @@ __device__ __forceinline__ uint32_t lowpass(int prev, int cur, const int16_t *co
     return (uint32_t)(cur + coef[CENTRE + ((prev - cur) >> 4)]);
 }
 
+// the 16 KB table into LDS: 16 bytes per load, and a thread's loads all in flight before its first LDS store (as a plain
+// copy loop a workgroup of 256 spent sixteen dependent round trips to L2 here - most of a launch's time)
 __device__ __forceinline__ void stage_lut(int16_t *dst, const int16_t *src, int nthreads)
 {
-    for (int i = threadIdx.x; i < LUT_N / 2; i += nthreads)
-        reinterpret_cast<uint32_t *>(dst)[i] = reinterpret_cast<const uint32_t *>(src)[i];
+    constexpr int NQ = LUT_N * 2 / 16;                 // 1024 uint4
+    const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+    uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+    for (int base = threadIdx.x; base < NQ; base += 4 * nthreads)      // one round for workgroups of 256 threads and more
+    {
+        uint4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            const int i = base + k * nthreads;
+            if (i < NQ) v[k] = s4[i];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            const int i = base + k * nthreads;
+            if (i < NQ) d4[i] = v[k];
+        }
+    }
 }
 
 // The three planes of a frame are independent, and each of these kernels is latency bound with
@@ -75,18 +94,22 @@ constexpr int H_SEG = 32, H_ROWS = 256 / H_SEG;   // horizontal chains: 8 rows x
 struct HqSeg { int seg, len, warm; };      // segments per chain, samples per segment, warm-up samples
 
 // horizontal recurrence: a workgroup of 256 threads = H_ROWS rows x up to H_SEG segments
+// `groups`: row groups (of H_ROWS rows) a workgroup works off one after the other on the table it staged once
 template <typename PIX, int SH>
-__global__ __launch_bounds__(256) void hqdn3d_h_kernel(HqArgs a, HqSeg g)
+__device__ __forceinline__ void hq_h_rows(const HqPlane &P, const HqSeg &g, int groups)
 {
-    const HqPlane &P = a.pl[blockIdx.y];
-    if (!P.spatial_on) return;
-    __shared__ int16_t lut[LUT_N];
+    if (!P.spatial_on || (int)blockIdx.x * groups * H_ROWS >= P.h) return;   // (the grid is sized for the luma plane)
+    __shared__ __attribute__((aligned(16))) int16_t lut[LUT_N];
     __shared__ uint32_t s_in[H_ROWS][H_SEG], s_out[H_ROWS][H_SEG];
     stage_lut(lut, P.spatial, 256);
     __syncthreads();
     const int seg = threadIdx.x % H_SEG, rl = threadIdx.x / H_SEG;
-    const int y = blockIdx.x * H_ROWS + rl;
     const int w = P.w;
+    for (int grp = 0; grp < groups; grp++)
+    {
+    const int y = ((int)blockIdx.x * groups + grp) * H_ROWS + rl;
+    if (y - rl >= P.h) break;                                              // (uniform)
+    if (grp) __syncthreads();                                              // the group before is done with s_in / s_out
     const bool live = y < P.h && seg < g.seg && seg * g.len < w;
     const uint8_t *s = P.src + (size_t)(live ? y : 0) * P.spitch;
     uint16_t *o = P.hbuf + (size_t)(live ? y : 0) * w;
@@ -158,7 +181,7 @@ __global__ __launch_bounds__(256) void hqdn3d_h_kernel(HqArgs a, HqSeg g)
     __threadfence_block();
     __syncthreads();
     // verification / repair: one thread per row, segments in order
-    if (seg != 0 || y >= P.h) return;
+    if (seg != 0 || y >= P.h) continue;
     uint32_t state = s_out[rl][0];
     for (int k = 1; k < g.seg && k * g.len < w; k++)
     {
@@ -174,32 +197,81 @@ __global__ __launch_bounds__(256) void hqdn3d_h_kernel(HqArgs a, HqSeg g)
         }
         state = met ? s_out[rl][k] : run;
     }
+    }
+}
+
+template <typename PIX, int SH>
+__global__ __launch_bounds__(256) void hqdn3d_h_kernel(HqArgs a, HqSeg g)
+{
+    hq_h_rows<PIX, SH>(a.pl[blockIdx.y], g, 1);
+}
+
+// Several frames per launch.  The two spatial recurrences of a frame do not look at any other frame, so the frames of
+// a batch go through them side by side (blockIdx.z = frame): sixteen times the workgroups of a launch whose time is
+// the length of its longest chain, not its sample count.  Only the temporal step ties frame t to frame t - 1, and it
+// is pointwise: hqdn3d_tn_kernel walks the frames of the batch per sample.  hbuf / vsp: the h-filtered samples and
+// the vertical spatial results of every frame of the batch (frame f of plane c at + f * stride[c]).
+constexpr int HQ_BATCH = 16;
+// a workgroup of the batched horizontal pass takes three row groups: a 1080p batch is then 1 450 workgroups, all
+// resident at once (eight to a CU), instead of 4 300 in two and a bit rounds of which the last runs nearly empty
+constexpr int H_GROUPS = 3;
+struct HqBatch
+{
+    const uint8_t *src[HQ_BATCH][3];
+    uint8_t       *dst[HQ_BATCH][3];
+    uint16_t      *hbuf[3], *vsp[3], *ant[3];
+    size_t         stride[3];
+    const int16_t *spatial[3], *temporal[3];
+    int spitch[3], dpitch[3], w[3], h[3], seeded[3], spatial_on[3];
+    int n;
+};
+
+__device__ __forceinline__ HqPlane hq_batch_plane(const HqBatch &B, int f, int c)
+{
+    HqPlane P;
+    P.src = B.src[f][c]; P.dst = B.dst[f][c];
+    P.hbuf = B.hbuf[c] + (size_t)f * B.stride[c];
+    P.vstate = B.vsp[c] + (size_t)f * B.stride[c];
+    P.ant = P.ant_out = nullptr;
+    P.spatial = B.spatial[c]; P.temporal = B.temporal[c];
+    P.spitch = B.spitch[c]; P.dpitch = B.dpitch[c]; P.w = B.w[c]; P.h = B.h[c];
+    P.seeded = 0; P.spatial_on = B.spatial_on[c];
+    return P;
+}
+
+template <typename PIX, int SH>
+__global__ __launch_bounds__(256) void hqdn3d_h_batch_kernel(HqBatch B, HqSeg g)
+{
+    hq_h_rows<PIX, SH>(hq_batch_plane(B, blockIdx.z, blockIdx.y), g, H_GROUPS);
 }
 
 // vertical recurrence + temporal step: a workgroup = 64 columns x up to 16 segments of rows.
 // `ant` (the previous frame's temporal state) is read-only here and the new state goes to `ant_out`:
 // a repaired sample needs the ORIGINAL previous state.
-template <typename PIX, int SH>
-__global__ __launch_bounds__(1024) void hqdn3d_vt_kernel(HqArgs a, HqSeg g)
+// TEMPORAL false (the batched form): the vertical results go to `vstate` and that is all - no previous state is read,
+// nothing else written; the temporal step follows in hqdn3d_tn_kernel.
+template <typename PIX, int SH, bool TEMPORAL>
+__device__ __forceinline__ void hq_v_cols(const HqPlane &P, const HqSeg &g)
 {
-    const HqPlane &P = a.pl[blockIdx.y];
-    if (!P.spatial_on) return;
-    __shared__ int16_t lut_s[LUT_N];
-    __shared__ int16_t lut_t[LUT_N];
+    if (!P.spatial_on || (int)blockIdx.x * 64 >= P.w) return;              // (the grid is sized for the luma plane)
+    __shared__ __attribute__((aligned(16))) int16_t lut_s[LUT_N];
+    __shared__ __attribute__((aligned(16))) int16_t lut_t[LUT_N];
     __shared__ uint32_t s_in[MAX_SEG][64], s_out[MAX_SEG][64];
     stage_lut(lut_s, P.spatial, blockDim.x);
-    stage_lut(lut_t, P.temporal, blockDim.x);
+    if (TEMPORAL) stage_lut(lut_t, P.temporal, blockDim.x);
     __syncthreads();
     const int xl = threadIdx.x & 63, seg = threadIdx.x >> 6;
     const int x = blockIdx.x * 64 + xl;
     const int w = P.w, h = P.h;
     const bool live = x < w && seg < g.seg && seg * g.len < h;
     auto prev_state = [&](int y) -> uint32_t {
+        if (!TEMPORAL) return 0u;
         return P.seeded ? (uint32_t)P.ant[(size_t)y * w + x] : (uint32_t)(uint16_t)hq_load<PIX, SH>(P.src + (size_t)y * P.spitch, x);
     };
     auto emit = [&](int y, uint32_t v, uint32_t pv) {
-        const uint32_t t = lowpass((int)pv, (int)v, lut_t);
         P.vstate[(size_t)y * w + x] = (uint16_t)v;
+        if (!TEMPORAL) return;
+        const uint32_t t = lowpass((int)pv, (int)v, lut_t);
         P.ant_out[(size_t)y * w + x] = (uint16_t)t;
         reinterpret_cast<PIX *>(P.dst + (size_t)y * P.dpitch)[x] = (PIX)(t >> SH);
     };
@@ -274,6 +346,84 @@ __global__ __launch_bounds__(1024) void hqdn3d_vt_kernel(HqArgs a, HqSeg g)
     }
 }
 
+template <typename PIX, int SH>
+__global__ __launch_bounds__(1024) void hqdn3d_vt_kernel(HqArgs a, HqSeg g)
+{
+    hq_v_cols<PIX, SH, true>(a.pl[blockIdx.y], g);
+}
+
+template <typename PIX, int SH>
+__global__ __launch_bounds__(1024) void hqdn3d_v_batch_kernel(HqBatch B, HqSeg g)
+{
+    hq_v_cols<PIX, SH, false>(hq_batch_plane(B, blockIdx.z, blockIdx.y), g);
+}
+
+// The temporal step of a batch (denoise.c:102-124 and the tail of :167-201): per sample, frame after frame.  The
+// current value is the frame's vertical spatial result (vsp) or, for a plane without a spatial filter, its input
+// sample; the previous one is the state left by the frame before - `ant` for the first frame of the batch, or that
+// frame's own input sample when the filter has seen no frame yet (the seeding of hqdn3d_denoise_depth).
+// grid: (samples of a row / 1024, rows, planes); a thread takes the samples x0 + tid + 256 k, k = 0 .. 3 (a wave's 64
+// lanes read 64 consecutive samples), and has the values of ALL frames of the batch in flight before its chains start:
+// a chain step is then an LDS look-up and nothing else.
+template <typename PIX, int SH>
+__global__ __launch_bounds__(256) void hqdn3d_tn_kernel(HqBatch B)
+{
+    __shared__ __attribute__((aligned(16))) int16_t lut_t[LUT_N];
+    const int c = blockIdx.z;
+    const int w = B.w[c], y = blockIdx.y;
+    const int x0 = 1024 * blockIdx.x + threadIdx.x;
+    if (y >= B.h[c] || 1024 * (int)blockIdx.x >= w) return;                // (the grid is sized for the luma plane)
+    const bool spatial = B.spatial_on[c] != 0;
+    const size_t at = (size_t)y * w + x0;
+    uint32_t cur[HQ_BATCH][4];
+#pragma unroll
+    for (int f = 0; f < HQ_BATCH; f++)
+    {
+        if (f >= B.n) continue;                                            // (uniform; no break: the loop must unroll, cur[][] live in registers)
+        if (spatial)
+        {
+            const uint16_t *v = B.vsp[c] + (size_t)f * B.stride[c] + at;
+#pragma unroll
+            for (int k = 0; k < 4; k++) cur[f][k] = x0 + 256 * k < w ? v[256 * k] : 0u;
+        }
+        else
+        {
+            const uint8_t *row = B.src[f][c] + (size_t)y * B.spitch[c];
+#pragma unroll
+            for (int k = 0; k < 4; k++) cur[f][k] = x0 + 256 * k < w ? hq_load<PIX, SH>(row, x0 + 256 * k) : 0u;
+        }
+    }
+    uint32_t prev[4];
+    if (B.seeded[c])
+    {
+#pragma unroll
+        for (int k = 0; k < 4; k++) prev[k] = x0 + 256 * k < w ? B.ant[c][at + 256 * k] : 0u;
+    }
+    else
+    {
+        const uint8_t *row = B.src[0][c] + (size_t)y * B.spitch[c];
+#pragma unroll
+        for (int k = 0; k < 4; k++) prev[k] = x0 + 256 * k < w ? (uint32_t)(uint16_t)hq_load<PIX, SH>(row, x0 + 256 * k) : 0u;
+    }
+    stage_lut(lut_t, B.temporal[c], 256);
+    __syncthreads();
+#pragma unroll
+    for (int f = 0; f < HQ_BATCH; f++)
+    {
+        if (f >= B.n) continue;
+        PIX *d = reinterpret_cast<PIX *>(B.dst[f][c] + (size_t)y * B.dpitch[c]) + x0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            prev[k] = (uint32_t)(uint16_t)lowpass((int)prev[k], (int)cur[f][k], lut_t);
+            if (x0 + 256 * k < w) d[256 * k] = (PIX)(prev[k] >> SH);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (x0 + 256 * k < w) B.ant[c][at + 256 * k] = (uint16_t)prev[k];
+}
+
 // temporal only (spatial strength 0): fully parallel
 template <typename PIX, int SH>
 __global__ __launch_bounds__(256) void hqdn3d_t_kernel(HqArgs a)
@@ -301,6 +451,8 @@ public:
         for (int c = 0; c < 3; c++) if (hbuf[c]) (void)hipFree(hbuf[c]);
         for (int c = 0; c < 3; c++) if (ant2[c]) (void)hipFree(ant2[c]);
         for (int c = 0; c < 3; c++) if (vstate[c]) (void)hipFree(vstate[c]);
+        for (int c = 0; c < 3; c++) if (hbuf_n[c]) (void)hipFree(hbuf_n[c]);
+        for (int c = 0; c < 3; c++) if (vsp_n[c]) (void)hipFree(vsp_n[c]);
     }
     int setup()
     {
@@ -364,7 +516,77 @@ public:
         HBHIP_CHECK(ctx, hipGetLastError());
         return HBHIP_OK;
     }
+    // Several frames: the spatial passes of all of them in one launch each, then the temporal step frame after frame
+    // per sample (see HqBatch).  The same numbers as frame-by-frame calls: the spatial passes never looked at another
+    // frame, and the temporal chain is walked in the same order.
+    int process_many(DevPicture *const *ins, DevPicture *const *outs, int n) override
+    {
+        if (n < 2) return SimpleFilter::process_many(ins, outs, n);
+        for (int c = 0; c < 3 && !hbuf_n[c]; c++)
+        {
+            const size_t bytes = sizeof(uint16_t) * (size_t)in_geo.pw[c] * in_geo.ph[c] * HQ_BATCH;
+            HBHIP_CHECK(ctx, hipMalloc((void **)&hbuf_n[c], bytes));
+            HBHIP_CHECK(ctx, hipMalloc((void **)&vsp_n[c], bytes));
+        }
+        for (int at = 0; at < n; at += HQ_BATCH)
+        {
+            const int k = std::min(HQ_BATCH, n - at);
+            HqBatch B;
+            memset(&B, 0, sizeof(B));
+            B.n = k;
+            bool any_spatial = false, same = true;
+            int max_w = 0, max_h = 0;
+            for (int c = 0; c < 3; c++)
+            {
+                B.hbuf[c] = hbuf_n[c]; B.vsp[c] = vsp_n[c]; B.ant[c] = ant[c];
+                B.stride[c] = (size_t)in_geo.pw[c] * in_geo.ph[c];
+                B.spatial[c] = d_coef + (size_t)(2 * c) * LUT_N; B.temporal[c] = B.spatial[c] + LUT_N;
+                B.spitch[c] = ins[at]->pitch[c]; B.dpitch[c] = outs[at]->pitch[c];
+                B.w[c] = ins[at]->width[c]; B.h[c] = ins[at]->height[c];
+                B.seeded[c] = seeded[c];
+                B.spatial_on[c] = par.coef[2 * c][0] != 0;                  // spatial strength != 0 (denoise.c:191)
+                any_spatial |= B.spatial_on[c] != 0;
+                max_w = std::max(max_w, B.w[c]); max_h = std::max(max_h, B.h[c]);
+                for (int f = 0; f < k; f++)
+                {
+                    B.src[f][c] = ins[at + f]->plane[c]; B.dst[f][c] = outs[at + f]->plane[c];
+                    same &= ins[at + f]->pitch[c] == B.spitch[c] && outs[at + f]->pitch[c] == B.dpitch[c];
+                }
+            }
+            if (!same)
+            {
+                int rc = SimpleFilter::process_many(ins + at, outs + at, k);
+                if (rc != HBHIP_OK) return rc;
+                continue;
+            }
+            auto cut = [&](int len, int target, int align, int most) {
+                HqSeg g;
+                g.seg = std::min(most, std::max(1, (len + target - 1) / target));
+                g.len = ((len + g.seg - 1) / g.seg + align - 1) / align * align;
+                g.warm = warm;
+                return g;
+            };
+            const HqSeg gh = cut(max_w, 64, 16, H_SEG), gv = cut(max_h, 64, 1, MAX_SEG);
+#define HQ_GO_N(PIX, SH) do { \
+                if (any_spatial) \
+                { \
+                    HBHIP_LAUNCH(ctx, "hqdn3d_h", (hqdn3d_h_batch_kernel<PIX, SH>), dim3((max_h + H_ROWS * H_GROUPS - 1) / (H_ROWS * H_GROUPS), 3, k), dim3(256), 0, B, gh); \
+                    HBHIP_LAUNCH(ctx, "hqdn3d_v", (hqdn3d_v_batch_kernel<PIX, SH>), dim3((max_w + 63) / 64, 3, k), dim3(64 * gv.seg), 0, B, gv); \
+                } \
+                HBHIP_LAUNCH(ctx, "hqdn3d_t", (hqdn3d_tn_kernel<PIX, SH>), dim3((max_w + 1023) / 1024, max_h, 3), dim3(256), 0, B); \
+            } while (0)
+            if (in_geo.depth == 8)       HQ_GO_N(uint8_t, 8);
+            else if (in_geo.depth == 10) HQ_GO_N(uint16_t, 6);
+            else                         HQ_GO_N(uint16_t, 4);
+#undef HQ_GO_N
+            HBHIP_CHECK(ctx, hipGetLastError());
+            for (int c = 0; c < 3; c++) seeded[c] = 1;
+        }
+        return HBHIP_OK;
+    }
     hbhip_hqdn3d_params par;
+    uint16_t *hbuf_n[3] = {nullptr, nullptr, nullptr};   // batches: the h-filtered rows of HQ_BATCH frames per plane
+    uint16_t *vsp_n[3] = {nullptr, nullptr, nullptr};    //          their vertical spatial results
     int16_t *d_coef = nullptr;
     uint16_t *ant[3] = {nullptr, nullptr, nullptr};
     uint16_t *hbuf[3] = {nullptr, nullptr, nullptr};   // h-filtered rows, one buffer per plane

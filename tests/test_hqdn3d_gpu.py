@@ -63,3 +63,55 @@ def test_speculative_segments_are_exact(built, monkeypatch, warmup, w, h):
         for t in range(len(want)):
             for c in range(3):
                 np.testing.assert_array_equal(got[t].planes[c], want[t][c], err_msg=f"{st} frame {t} plane {c}")
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("w,h", [(66, 50), (638, 362), (1920, 1080)])
+@pytest.mark.parametrize("case", [0, 1, 2, 3])
+def test_hqdn3d_batched_equals_frame_by_frame(built, case, w, h, depth):
+    """Several frames per call (hbhip_filter_process_dev -> Hqdn3dFilter::process_many): the spatial passes of the
+    whole batch in one launch each, the temporal step frame after frame per sample.  Nine frames as calls of 5, 1
+    and 3: the first batch seeds the temporal state from its own first frame, the single frame in between goes
+    through the frame-at-a-time kernels on the state the batch left, the last batch continues from there - all
+    against the oracle's frame-by-frame stream.  Case 2 mixes planes with and without a spatial filter."""
+    import ctypes as C
+    import torch
+    import oracle_lib as ol
+    if depth > 8 and (w, h) == (1920, 1080) and case != 1:
+        pytest.skip("one 10-bit 1080p case is enough")
+    n = 9
+    frames = synth.stream("progressive", w, h, n, depth=depth)
+    st, par = CASES[case]
+    want = os_.hqdn3d_stream(frames, dict(par, depth=depth)) if depth > 8 else os_.hqdn3d_stream(frames, par)
+    orc = ol.OrcHqdn3d(w, h, depth=depth, **par)
+
+    class HQ(C.Structure):
+        _fields_ = [("coef", (C.c_int16 * 8192) * 6)]
+    hq = HQ()
+    for k in range(6):
+        C.memmove(hq.coef[k], orc.coef[k], 8192 * 2)
+    ctx = hip.Ctx(0)
+    flt = hip._create("hbhip_hqdn3d_create", ctx, [C.c_void_p, C.POINTER(HQ)] + [C.c_int] * 5 + [C.POINTER(C.c_void_p)],
+                      ctx.h, C.byref(hq), w, h, depth, 1, 1)
+    try:
+        dt = torch.uint8 if depth == 8 else torch.int16
+        dev_in = [[torch.from_numpy(np.ascontiguousarray(p).view(np.int16) if depth > 8 else np.ascontiguousarray(p)).cuda()
+                   for p in f] for f in frames]
+        outs = [[torch.zeros(tuple(p.shape), dtype=dt, device="cuda") for p in f] for f in frames]
+        torch.cuda.synchronize()
+        t = 0
+        for b in (5, 1, 3):
+            arr_in = (hip.DevFrame * b)(*[hip.dev_frame(dev_in[t + i]) for i in range(b)])
+            arr_out = (hip.DevFrame * b)(*[hip.dev_frame(outs[t + i]) for i in range(b)])
+            assert flt.process_dev(arr_in, t, arr_out) == b
+            t += b
+        ctx.sync()
+        for i in range(n):
+            for c in range(3):
+                got = outs[i][c].cpu().numpy()
+                if depth > 8:
+                    got = got.view(np.uint16)
+                np.testing.assert_array_equal(got, want[i][c], err_msg=f"{st} frame {i} plane {c}")
+    finally:
+        flt.close()
+        ctx.close()

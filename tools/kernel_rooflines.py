@@ -242,6 +242,11 @@ def main():
     add_batched(batched(lambda: mk_blur("hbhip_unsharp_create"), W, H, W, H), {"unsharp_blur_mix": 2 * FRAME}, "unsharp 7x7 x16", NB)
     add_batched(batched(lambda: mk_blur("hbhip_chroma_smooth_create", 0), W, H, W, H), {"chroma_smooth_blur_mix": 2 * FRAME},
                 "chroma_smooth 7x7 x16 (luma copied)", NB)
+    # hqdn3d: the spatial passes of 16 frames in one launch each, the temporal step frame after frame per sample
+    st = batched(mk, W, H, W, H)
+    add_batched(st, {"hqdn3d_h": 3 * FRAME}, "hqdn3d_h x16 (px in, u16 out)", NB)
+    add_batched(st, {"hqdn3d_v": 4 * FRAME}, "hqdn3d_v x16 (u16 in, u16 out)", NB)
+    add_batched(st, {"hqdn3d_t": 3 * FRAME + 4 * FRAME // NB}, "hqdn3d_t x16 (u16 in, px out, the state once per launch)", NB)
     # decomb blend (default mode 7: yadif + cubic), the frames of a chain batch in one launch
     frames = synth.stream("interlaced", W, H, 4)
     dev_in = [[torch.from_numpy(p).cuda() for p in fr] for fr in frames]
