@@ -81,8 +81,8 @@ def algorithmic_bytes(kernel, w, h, out_w, out_h, frames_per_launch=1):
         "decomb_plane": 5 * full,                                     # prev, cur, next, EEDI2 guess -> out
         "cropscale_lanczos_fused": full + out,
         "lapsharp_3x3": 2 * out, "lapsharp_5x5": 2 * out,
-        "copy_planes": 2 * full,
-        "eedi2_mask_passes": 2 * half,                                # the lower half of a field: field rows + old mask -> srcp + new mask
+        "copy_planes": full,                                          # the chain's copy-in: one input frame read + written per TWO output frames
+        "eedi2_mask_passes": 2 * half,                                # the lower half of a field: field rows + old mask -> srcp + new mask (all fields of a batch per launch)
         "eedi2_mask_upper": 1.5 * half,                               # the upper half: field rows -> srcp + new mask
         "eedi2_calc_directions": 3 * half,                            # mskp + srcp -> tmpp
         "eedi2_filter_dir_map": 3 * half, "eedi2_expand_dir_map": 3 * half, "eedi2_filter_map": 3 * half,
@@ -346,7 +346,7 @@ ISA_NAMES = {"eedi2_calc_directions": ("r3_eedi2_isa_mix.json", "k_calc_dir_rows
              "eedi2_fill_gaps_2x": ("r3_eedi2_isa_mix.json", "k_fill_gaps_b"),
              "eedi2_lattice_candidates": ("r3_eedi2_isa_mix.json", "k_lattice_cand_q"),
              "eedi2_filter_dir_map_2x": ("r3_eedi2_isa_mix.json", "k_dir_map4"),
-             "nlmeans_plane_n7": ("r3_nlmeans_isa_mix.json", "nlmeans_lanes_kernel<7, true, 36, false>"),
+             "nlmeans_plane_n7": ("r3_nlmeans_isa_mix.json", "nlmeans_lanes_kernel<7, 2, 36, false>"),
              "cropscale_lanczos_fused": ("r3_alias_isa_mix.json", "scale8_up_kernel")}
 
 
