@@ -27,6 +27,7 @@
 #include "hbhip_internal.h"
 
 #include <algorithm>
+#include <type_traits>
 #include <unordered_map>
 
 namespace {
@@ -150,12 +151,24 @@ __device__ __forceinline__ uint32_t from_lane_above(uint32_t x)   // lane l <- l
 // an integer M, and (diff * M) >> 32 is the exact floor of the real product - the float product can only differ from
 // it where rounding carries it across an integer, which the host rules out for every diff up to the cap before it
 // picks this form (three instructions per pixel instead of five: min, mul_hi, and).
+// 3: form 2, and inside frame 0 the patch distance of a displacement and of its mirror computed once (range 3 only, no
+// prefilter).  The distance between the patches at p and p + d IS the distance between the patches at p + d and
+// (p + d) - d: W(-d)(p) = W(d)(p - d) - taken on the same mirrored picture, so it holds at the borders too.  The
+// displacements of frame 0 come in the order (-1,-1) (-1,0) (-1,1) (0,-1) (0,0) (0,1) (1,-1) (1,0) (1,1): the first
+// four are computed as ever and leave the table index of every pixel of the lane (4 x 7 bits per dword and row; one
+// row more than the lane puts out for the three with dy = -1) in LDS, in the space the tile of the NEXT frame takes
+// later plus 26.5 KB; the last four read the index of their mirror one row down and / or one pixel across (a
+// neighbouring lane's dword of the same wave) and only look the weight up, convert the pixel and accumulate - in the
+// reference's order of displacements, with the reference's weights.
 template <int N, int FAST, int CPD, bool PRE>
 __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJob *__restrict__ jobs, int njobs,
                                                                      int cmp_rows, int rq)
 {
     constexpr int NH = N / 2;
     constexpr int ROWS = RY + N - 1;
+    constexpr bool INTIDX = FAST >= 2;
+    constexpr bool SYM = FAST == 3 && !PRE;
+    constexpr int ST_ROWS = RY + 1, ST_SLOT = ST_ROWS * TXN * TYN;        // the stash: [slot 0..3][row 0..RY][thread] dwords
     static_assert(NH <= PX, "patch must not reach past the adjacent lane");
     static_assert(CPD % 8 == 4, "the two tile rows of a wave must sit 32 banks apart");
 
@@ -175,6 +188,7 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
     uint32_t *s_tc = s_t0 + tile_dwords;
     uint32_t *s_r0 = PRE ? s_tc + tile_dwords : s_t0;
     uint32_t *s_rc = PRE ? s_r0 + tile_dwords : s_tc;
+    uint32_t *s_stash = s_tc;                                     // SYM: over the next frame's tile (free while f == 0) and beyond
 
     // which (frame, plane) job owns this tile: binary search over the jobs' first tile indices
     int j = 0;
@@ -197,7 +211,7 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
     // FAST 2 reads the table by its LDS address, taken to be 0: this kernel has no static LDS, so the dynamic block -
     // and the table at its head - starts there (the compiler leaves "+ &smem" as an add of 0 per read otherwise)
     typedef __attribute__((address_space(3))) const float lds_cfloat;
-    if (FAST == 2 && reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint32_t *)smem) != 0) __builtin_trap();
+    if (INTIDX && reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint32_t *)smem) != 0) __builtin_trap();
     if (threadIdx.x < 128) s_exp[threadIdx.x] = job.exptable[threadIdx.x];
     // lane tx holds the source pixels tx0 + 4*(tx-1) .. +3: the tiles start one lane (and rq
     // dwords of search halo) left of tx0
@@ -258,9 +272,11 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
         const uint32_t *cmp_tile = (PRE || f > 0) ? s_tc : s_t0;     // what the patch distances are taken against
         const uint32_t *pix_tile = f > 0 ? s_rc : s_r0;              // what is averaged (== cmp_tile without a prefilter)
 
-        for (int dy = -RH; dy <= RH; dy++)
+        // one displacement; F0: frame 0 of a launch that shares the pairs' distances (a compile-time flag, so that the
+        // row walk of every other frame carries none of the stash code)
+        auto displacement = [&](auto f0c, int dy, int dx) __attribute__((always_inline))
         {
-            for (int dx = -RH; dx <= RH; dx++)
+            constexpr bool F0 = decltype(f0c)::value;
             {
                 if (f == 0 && dx == 0 && dy == 0)
                 {
@@ -276,11 +292,38 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
                             __builtin_amdgcn_sched_barrier(0);   // cold block: keep its f64 temporaries few
                         }
                     }
-                    continue;
+                    return;
                 }
 
                 const int s = dx + 4 * rq;                   // >= 0, wave-uniform
                 const int sh = s & 3;
+                if (SYM && F0 && (dy > 0 || (dy == 0 && dx > 0)))
+                {
+                    // the second of a pair: the index its mirror (-dy, -dx) left for the pixel at (row + dy, x + dx)
+                    const uint32_t *st = s_stash + ((-dy + 1) * 3 + (-dx + 1)) * ST_SLOT + dy * (TXN * TYN) + (int)threadIdx.x;
+                    const uint32_t *prow = pix_tile + (ty * RY + dy + RH + NH) * CPD + tx + (s >> 2);
+#pragma unroll
+                    for (int o = 0; o < RY; o++)
+                    {
+                        const uint32_t w0 = st[o * (TXN * TYN)];
+                        uint32_t id4 = w0;
+                        if (dx > 0) id4 = __builtin_amdgcn_alignbyte(st[o * (TXN * TYN) + 1], w0, 1);
+                        else if (dx < 0) id4 = __builtin_amdgcn_alignbyte(w0, st[o * (TXN * TYN) - 1], 3);
+                        const uint32_t pix = __builtin_amdgcn_alignbyte(prow[o * CPD + 1], prow[o * CPD], sh);
+                        const uint32_t o0 = (id4 << 2) & 0x1fcu, o1 = (id4 >> 6) & 0x1fcu, o2 = (id4 >> 14) & 0x1fcu, o3 = (id4 >> 22) & 0x1fcu;
+                        const f2 wa = {*reinterpret_cast<lds_cfloat *>(o0), *reinterpret_cast<lds_cfloat *>(o1)};
+                        const f2 wb = {*reinterpret_cast<lds_cfloat *>(o2), *reinterpret_cast<lds_cfloat *>(o3)};
+                        const f2 pa = {(float)(int)byte_of(pix, 0), (float)(int)byte_of(pix, 1)};
+                        const f2 pb = {(float)(int)byte_of(pix, 2), (float)(int)byte_of(pix, 3)};
+                        aw[o][0] += wa; ap[o][0] += wa * pa;
+                        aw[o][1] += wb; ap[o][1] += wb * pb;
+                    }
+                    return;
+                }
+                // the first of a pair leaves its indices behind; with dy < 0 its mirror reads them one row down
+                constexpr bool stash_on = SYM && F0;        // (here: dy < 0 or dy == 0 && dx < 0)
+                const bool extra_row = stash_on && dy < 0;
+                uint32_t *stw = s_stash + ((dy + 1) * 3 + (dx + 1)) * ST_SLOT + (int)threadIdx.x;
                 const uint32_t *srow = own;
                 const uint32_t *crow = cmp_tile + (ty * RY + dy + RH) * CPD + tx + (s >> 2);
 
@@ -288,7 +331,7 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
                 // squared differences, hist[] keeps the first RY-1 of them, so the n-row window sum of
                 // output row o is C(after row o+n-1) - C(after row o-1).  Only output rows then pay
                 // for the horizontal n-sum across lanes.
-                uint32_t C[PX], hist[RY - 1][PX], v[PX];
+                uint32_t C[PX], hist[RY - 1 + (SYM ? 1 : 0)][PX], v[PX];
                 uint32_t centre[NH + 1];                     // compare-frame dwords of the last NH+1 rows
                 uint32_t pixq = 0;                           // pixels and ...
                 f2 wq[PX / 2];                               // ... table weights in flight for the previous output row
@@ -298,11 +341,15 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
 
                 uint32_t a_n = srow[0], b_n0 = crow[0], b_n1 = crow[1];
 #pragma unroll
-                for (int i = 0; i < ROWS; i++)
+                for (int i = 0; i < ROWS + (SYM ? 1 : 0); i++)
                 {
+                    // (the trip past ROWS only exists for the pairs' sake; a uniform branch around it, not a break: the
+                    // loop has to unroll for hist[] / centre[] to stay in registers)
+                    if (!(SYM && i == ROWS) || extra_row)
+                    {
                     const uint32_t a = a_n;
                     const uint32_t bw = __builtin_amdgcn_alignbyte(b_n1, b_n0, sh);
-                    if (i + 1 < ROWS)
+                    if (i + 1 < ROWS || (SYM && i + 1 == ROWS && extra_row))
                     {
                         a_n = srow[(i + 1) * CPD];
                         b_n0 = crow[(i + 1) * CPD];
@@ -314,7 +361,7 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
                     {
                         const int d = (int)byte_of(a, q) - (int)byte_of(bw, q);
                         C[q] += (uint32_t)(d * d);
-                        if (i < RY - 1) hist[i][q] = C[q];
+                        if (i < RY - 1 + (SYM ? 1 : 0)) hist[i][q] = C[q];
                     }
                     if (i >= N - 1)
                     {
@@ -346,7 +393,7 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
                     }
                     // The table reads issued for the previous output row have had this row's integer
                     // work to complete: fold them in now, then issue this row's.
-                    if (i >= N)
+                    if (i >= N && i < ROWS)
                     {
                         const int o = i - N;
                         const uint32_t pix = pixq;
@@ -360,6 +407,19 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
                     }
                     if (i >= N - 1)
                     {
+                        // byte offsets into the table: (diff * 4M) >> 32 = floor(4 * diff * wft), and clearing its two low
+                        // bits gives 4 * floor(diff * wft); the mask also tells the compiler the offset is < 512, so the
+                        // table's LDS address goes into the read's immediate offset
+                        uint32_t offs[PX];
+                        if (INTIDX)
+                        {
+#pragma unroll
+                            for (int q = 0; q < PX; q++) offs[q] = __umulhi(min(v[q], (uint32_t)diff_cap), imul4) & 0x1fcu;
+                            if (SYM && stash_on)                 // (uniform) four 7-bit indices per dword: byte q = offs[q] >> 2
+                                stw[(i - (N - 1)) * (TXN * TYN)] = (offs[0] >> 2) | (offs[1] << 6) | (offs[2] << 14) | (offs[3] << 22);
+                        }
+                        if (!(SYM && i == ROWS))                  // (the row below the lane's last: only its indices were wanted)
+                        {
                         // the pixels that go with these weights: the compare frame's row i - NH
                         if (PRE)
                         {
@@ -371,15 +431,8 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
 #pragma unroll
                         for (int pp = 0; pp < PX / 2; pp++)
                         {
-                            if (FAST == 2)
-                            {
-                                // byte offsets into the table: (diff * 4M) >> 32 = floor(4 * diff * wft), and clearing its two low
-                                // bits gives 4 * floor(diff * wft); the mask also tells the compiler the offset is < 512, so the
-                                // table's LDS address goes into the read's immediate offset
-                                const uint32_t o0 = __umulhi(min(v[2 * pp], (uint32_t)diff_cap), imul4) & 0x1fcu;
-                                const uint32_t o1 = __umulhi(min(v[2 * pp + 1], (uint32_t)diff_cap), imul4) & 0x1fcu;
-                                wq[pp] = f2{*reinterpret_cast<lds_cfloat *>(o0), *reinterpret_cast<lds_cfloat *>(o1)};
-                            }
+                            if (INTIDX)
+                                wq[pp] = f2{*reinterpret_cast<lds_cfloat *>(offs[2 * pp]), *reinterpret_cast<lds_cfloat *>(offs[2 * pp + 1])};
                             else
                             {
                                 int idx[2];
@@ -405,6 +458,8 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
                                 wq[pp] = f2{s_exp[idx[0]], s_exp[idx[1]]};
                             }
                         }
+                        }
+                    }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -420,7 +475,13 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
                     }
                 }
             }
-        }
+        };
+        for (int dy = -RH; dy <= RH; dy++)
+            for (int dx = -RH; dx <= RH; dx++)
+            {
+                if (SYM && f == 0) displacement(std::true_type{}, dy, dx);
+                else displacement(std::false_type{}, dy, dx);
+            }
     }
 
     // normalise + store (the outer lanes own no pixels)
@@ -1225,6 +1286,7 @@ private:
             NlmJob *hj = h_jobs + (size_t)table * jobs_cap;
             NlmJob *dj = d_jobs + (size_t)table * jobs_cap;
             int nj = 0, tiles = 0, max_rh = 0;
+            bool all_rh1 = true;
             bool fast = true, fast_int = true;
             for (int t = 0; t < ready; t++)
                 for (int c = 0; c < 3; c++)
@@ -1264,6 +1326,7 @@ private:
                     jb.tile_start = tiles;
                     tiles += jb.tiles_x * ((jb.h + TH - 1) / TH);
                     max_rh = std::max(max_rh, jb.r_half);
+                    all_rh1 &= jb.r_half == 1;
                 }
             if (nj == 0) continue;
             // the table travels by a copy kernel reading the pinned host buffer: hipMemcpyAsync of this size holds the
@@ -1284,7 +1347,10 @@ private:
             const int rq = (max_rh + 3) / 4;
             const bool wide = in_geo.bps == 2;                 // 16-bit samples: 2 pixels per tile dword
             const int cpd = wide ? (rq <= 2 ? 76 : 84) : (rq <= 1 ? 36 : 44);
-            const size_t shmem = sizeof(uint32_t) * (pre ? 4 : 2) * (cpd * cmp_rows + 4) + 512;
+            // the pairs of frame 0 share their patch distances (FAST 3) when every plane of the launch searches 3 x 3
+            const bool sym = fast && fast_int && !pre && !wide && all_rh1;
+            size_t shmem = sizeof(uint32_t) * (pre ? 4 : 2) * (cpd * cmp_rows + 4) + 512;
+            if (sym) shmem = 512 + sizeof(uint32_t) * ((size_t)(cpd * cmp_rows + 4) + std::max<size_t>(cpd * cmp_rows + 4, 4 * (RY + 1) * TXN * TYN));
             // the widest search ranges need more than the default 64 KB of dynamic LDS
 #define NLM_LAUNCH(KERNEL) do { \
                 if (shmem > 65536) \
@@ -1298,8 +1364,8 @@ private:
 #define NLM_16(NN, FF) do { if (pre) NLM_16P(NN, FF, true); else NLM_16P(NN, FF, false); } while (0)
 #define NLM_VAR(NN) do { const char *kname = "nlmeans_plane_n" #NN; \
                      if (wide) { if (fast) NLM_16(NN, true); else NLM_16(NN, false); } \
-                     else if (cpd == 36) { if (fast && fast_int) NLM_PRE(NN, 2, 36); else if (fast) NLM_PRE(NN, 1, 36); else NLM_PRE(NN, 0, 36); } \
-                     else { if (fast && fast_int) NLM_PRE(NN, 2, 44); else if (fast) NLM_PRE(NN, 1, 44); else NLM_PRE(NN, 0, 44); } } while (0)
+                     else if (cpd == 36) { if (sym) NLM_GO(NN, 3, 36, false); else if (fast && fast_int) NLM_PRE(NN, 2, 36); else if (fast) NLM_PRE(NN, 1, 36); else NLM_PRE(NN, 0, 36); } \
+                     else { if (sym) NLM_GO(NN, 3, 44, false); else if (fast && fast_int) NLM_PRE(NN, 2, 44); else if (fast) NLM_PRE(NN, 1, 44); else NLM_PRE(NN, 0, 44); } } while (0)
             switch (n)
             {
                 case 3: NLM_VAR(3); break;
