@@ -168,6 +168,7 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
     constexpr int ROWS = RY + N - 1;
     constexpr bool INTIDX = FAST >= 2;
     constexpr bool SYM = FAST == 3 && !PRE;
+    static_assert(FAST != 3 || N <= 7, "the pairs' sharing reads a neighbouring lane's edge pixel: patch sizes up to 7");
     constexpr int ST_ROWS = RY + 1, ST_SLOT = ST_ROWS * TXN * TYN;        // the stash: [slot 0..3][row 0..RY][thread] dwords
     static_assert(NH <= PX, "patch must not reach past the adjacent lane");
     static_assert(CPD % 8 == 4, "the two tile rows of a wave must sit 32 banks apart");
@@ -549,7 +550,8 @@ __device__ __forceinline__ void load_tile16(uint32_t *lds, int pitch, int dwords
 
 __device__ __forceinline__ uint32_t half_of(uint32_t v, int k) { return (v >> (16 * k)) & 0xffffu; }
 
-template <int N, bool FAST, int CPD, bool PRE>
+// FAST 0 / 1 / 2 as in the 8-bit kernel (2: the table index by an integer multiply-high, the table at LDS address 0)
+template <int N, int FAST, int CPD, bool PRE>
 __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes16_kernel(const NlmJob *__restrict__ jobs, int njobs,
                                                                        int cmp_rows, int rq)
 {
@@ -560,14 +562,16 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes16_kernel(const Nlm
 
     extern __shared__ uint32_t smem[];
     const int tile_dwords = CPD * cmp_rows + 4;
-    uint32_t *s_t0 = smem;                                       // frame 0: source patches and compare tile of f = 0
+    float *s_exp = reinterpret_cast<float *>(smem);             // the weight table first (see the 8-bit kernel)
+    uint32_t *s_t0 = smem + 128;                                 // frame 0: source patches and compare tile of f = 0
     uint32_t *s_tc = s_t0 + tile_dwords;                         // frame f > 0
     // PRE (a prefilter is on, nlmeans.c:253-262 `_16` instantiation of nlmeans_template.c:428-543): distances between
     // src_pre (s_t0) and the prefiltered frame f (s_tc); the samples that are averaged come from the raw frames,
     // s_r0 (frame 0: also the origin term and the zero fallback) and s_rc (frame f > 0) - as in the 8-bit kernel
     uint32_t *s_r0 = PRE ? s_tc + tile_dwords : s_t0;
     uint32_t *s_rc = PRE ? s_r0 + tile_dwords : s_tc;
-    float *s_exp = reinterpret_cast<float *>((PRE ? s_rc : s_tc) + tile_dwords);
+    typedef __attribute__((address_space(3))) const float lds_cfloat;
+    if (FAST == 2 && reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint32_t *)smem) != 0) __builtin_trap();
 
     int j = 0;
     for (int hi = njobs - 1; j < hi;)
@@ -608,6 +612,7 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes16_kernel(const Nlm
     const float wft = job.wft;
     const int diff_max = job.diff_max;
     const int diff_cap = job.diff_cap;
+    const uint32_t imul4 = job.imul4;
     const double origin_tune = job.origin_tune;
     const bool wave_live = ty0 + (ty & ~1) * RY < h;
 
@@ -734,8 +739,15 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes16_kernel(const Nlm
 #pragma unroll
                         for (int pp = 0; pp < PX / 2; pp++)
                         {
+                            if (FAST == 2)
+                            {
+                                const uint32_t o0 = __umulhi(min(v[2 * pp], (uint32_t)diff_cap), imul4) & 0x1fcu;
+                                const uint32_t o1 = __umulhi(min(v[2 * pp + 1], (uint32_t)diff_cap), imul4) & 0x1fcu;
+                                wq[pp] = f2{*reinterpret_cast<lds_cfloat *>(o0), *reinterpret_cast<lds_cfloat *>(o1)};
+                                continue;
+                            }
                             int idx[2];
-                            if (FAST)
+                            if (FAST == 1)
                             {
                                 const f2 fd = {(float)(int)min(v[2 * pp], (uint32_t)diff_cap),
                                                (float)(int)min(v[2 * pp + 1], (uint32_t)diff_cap)};
@@ -1348,7 +1360,9 @@ private:
             const bool wide = in_geo.bps == 2;                 // 16-bit samples: 2 pixels per tile dword
             const int cpd = wide ? (rq <= 2 ? 76 : 84) : (rq <= 1 ? 36 : 44);
             // the pairs of frame 0 share their patch distances (FAST 3) when every plane of the launch searches 3 x 3
-            const bool sym = fast && fast_int && !pre && !wide && all_rh1;
+            // (patch sizes up to 7: the mirrored index of a lane's edge pixel comes from the neighbouring lane's edge pixel,
+            // whose own window must not reach past ITS neighbour - the outer lanes of a tile row have none)
+            const bool sym = fast && fast_int && !pre && !wide && all_rh1 && n <= 7;
             size_t shmem = sizeof(uint32_t) * (pre ? 4 : 2) * (cpd * cmp_rows + 4) + 512;
             if (sym) shmem = 512 + sizeof(uint32_t) * ((size_t)(cpd * cmp_rows + 4) + std::max<size_t>(cpd * cmp_rows + 4, 4 * (RY + 1) * TXN * TYN));
             // the widest search ranges need more than the default 64 KB of dynamic LDS
@@ -1363,9 +1377,9 @@ private:
                                 else NLM_LAUNCH((nlmeans_lanes16_kernel<NN, FF, 84, PP>)); } while (0)
 #define NLM_16(NN, FF) do { if (pre) NLM_16P(NN, FF, true); else NLM_16P(NN, FF, false); } while (0)
 #define NLM_VAR(NN) do { const char *kname = "nlmeans_plane_n" #NN; \
-                     if (wide) { if (fast) NLM_16(NN, true); else NLM_16(NN, false); } \
-                     else if (cpd == 36) { if (sym) NLM_GO(NN, 3, 36, false); else if (fast && fast_int) NLM_PRE(NN, 2, 36); else if (fast) NLM_PRE(NN, 1, 36); else NLM_PRE(NN, 0, 36); } \
-                     else { if (sym) NLM_GO(NN, 3, 44, false); else if (fast && fast_int) NLM_PRE(NN, 2, 44); else if (fast) NLM_PRE(NN, 1, 44); else NLM_PRE(NN, 0, 44); } } while (0)
+                     if (wide) { if (fast && fast_int) NLM_16(NN, 2); else if (fast) NLM_16(NN, 1); else NLM_16(NN, 0); } \
+                     else if (cpd == 36) { if (sym && NN <= 7) NLM_GO(NN, (NN <= 7 ? 3 : 2), 36, false); else if (fast && fast_int) NLM_PRE(NN, 2, 36); else if (fast) NLM_PRE(NN, 1, 36); else NLM_PRE(NN, 0, 36); } \
+                     else { if (sym && NN <= 7) NLM_GO(NN, (NN <= 7 ? 3 : 2), 44, false); else if (fast && fast_int) NLM_PRE(NN, 2, 44); else if (fast) NLM_PRE(NN, 1, 44); else NLM_PRE(NN, 0, 44); } } while (0)
             switch (n)
             {
                 case 3: NLM_VAR(3); break;

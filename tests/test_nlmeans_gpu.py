@@ -90,6 +90,15 @@ def test_random_noise_input(built):
      [par(1, 1.0, 3, 3, 2), par(1.5, 1.0, 5, 3, 2), par(1.5, 1.0, 5, 3, 2)]),
     ("y-strength=1.2:y-origin-tune=0.9:y-patch-size=7:y-range=5:y-frame-count=1:cb-strength=0",
      [par(1.2, 0.9, 7, 5, 1), par(0), par(0)]),
+    # range 3 on every plane: the kernel form that computes a displacement of frame 0 and its mirror once (FAST 3) - at
+    # every patch size it takes (up to 7; 9 falls back to the plain integer form), with one frame only (nothing but frame 0)
+    # and with three
+    ("y-strength=6:y-origin-tune=1:y-patch-size=3:y-range=3:y-frame-count=1:"
+     "cb-strength=5:cb-origin-tune=0.8:cb-patch-size=5:cb-range=3:cb-frame-count=3",
+     [par(6, 1.0, 3, 3, 1), par(5, 0.8, 5, 3, 3), par(5, 0.8, 5, 3, 3)]),
+    ("y-strength=7:y-origin-tune=0.6:y-patch-size=9:y-range=3:y-frame-count=2:"
+     "cb-strength=6:cb-origin-tune=1:cb-patch-size=7:cb-range=3:cb-frame-count=1",
+     [par(7, 0.6, 9, 3, 2), par(6, 1.0, 7, 3, 1), par(6, 1.0, 7, 3, 1)]),
 ])
 def test_tunes_bit_exact(built, settings, pp):
     frames = synth.stream("progressive", 192, 108, 6)
