@@ -56,8 +56,9 @@ struct alignas(16) NlmJob
     float          wft;
     int            diff_max;
     int            diff_cap;       // FAST gate: smallest diff whose table index is 127 (weight 0)
-    uint32_t       imul4;          // FAST 2: 4 * weight_fact * 2^32 when (diff * that) >> 32 == 4 * (int)(diff * wft) for every
-                                   // diff <= diff_cap (checked on the host), else 0
+    uint32_t       imul4;          // FAST 2: weight_fact * 2^(34 + ishift) when ((diff * that) >> 32 >> ishift) & ~3 == 4 * (int)(diff * wft)
+    int            ishift;         // for every diff <= diff_cap (checked on the host), else 0.  ishift is 0 at 8 bits (the 8-bit kernel
+                                   // takes nothing else); small weight factors (10 / 12 bits) need it for the product to be an integer
     int            w, h, dst_pitch;
     int            nframes, r_half;
     int            tiles_x, tile_start;
@@ -613,6 +614,7 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes16_kernel(const Nlm
     const int diff_max = job.diff_max;
     const int diff_cap = job.diff_cap;
     const uint32_t imul4 = job.imul4;
+    const int ishift = job.ishift;
     const double origin_tune = job.origin_tune;
     const bool wave_live = ty0 + (ty & ~1) * RY < h;
 
@@ -741,8 +743,8 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes16_kernel(const Nlm
                         {
                             if (FAST == 2)
                             {
-                                const uint32_t o0 = __umulhi(min(v[2 * pp], (uint32_t)diff_cap), imul4) & 0x1fcu;
-                                const uint32_t o1 = __umulhi(min(v[2 * pp + 1], (uint32_t)diff_cap), imul4) & 0x1fcu;
+                                const uint32_t o0 = (__umulhi(min(v[2 * pp], (uint32_t)diff_cap), imul4) >> ishift) & 0x1fcu;
+                                const uint32_t o1 = (__umulhi(min(v[2 * pp + 1], (uint32_t)diff_cap), imul4) >> ishift) & 0x1fcu;
                                 wq[pp] = f2{*reinterpret_cast<lds_cfloat *>(o0), *reinterpret_cast<lds_cfloat *>(o1)};
                                 continue;
                             }
@@ -1097,21 +1099,24 @@ public:
                     if ((int)((float)d * wft) == 127) diff_cap[c] = d;
                     break;
                 }
-            // the integer form of the index (nlmeans_lanes_kernel, FAST 2): M = wft * 2^32 is an integer (wft is a float);
-            // usable when 4M fits 32 bits and (d * M) >> 32 equals the float expression for every d up to the cap
+            // the integer form of the index (FAST 2): wft is a float, so wft * 2^(34 + s) is an integer M for some small s;
+            // usable when M fits 32 bits and (d * M) >> (34 + s) equals the float expression for every d up to the cap.
+            // The kernels take (mul_hi(d, M) >> s) & 0x1fc = 4 * index as the table's byte offset.
             imul4[c] = 0;
+            ishift[c] = 0;
             if (diff_cap[c] >= 0)
-            {
-                const double m = std::ldexp((double)wft, 32);
-                if (m == std::floor(m) && m > 0.0 && m < 1073741824.0)
+                for (int sft = 0; sft <= 12; sft++)
                 {
+                    const double m = std::ldexp((double)wft, 34 + sft);
+                    if (!(m > 0.0 && m < 4294967296.0)) break;
+                    if (m != std::floor(m)) continue;
                     const uint64_t M = (uint64_t)m;
                     bool same = true;
                     for (int d = 0; d <= diff_cap[c] && same; d++)
-                        same = (int)(((uint64_t)d * M) >> 32) == (int)((float)d * wft);
-                    if (same) imul4[c] = (uint32_t)(4 * M);
+                        same = (int)(((uint64_t)d * M) >> (34 + sft)) == (int)((float)d * wft);
+                    if (same) { imul4[c] = (uint32_t)M; ishift[c] = sft; }
+                    break;
                 }
-            }
         }
         if (any_pre)
         {
@@ -1161,6 +1166,7 @@ public:
     bool deferred = false;
     int diff_cap[3] = {-1, -1, -1};
     uint32_t imul4[3] = {0, 0, 0};
+    int ishift[3] = {0, 0, 0};
     int pf_type[3] = {0, 0, 0};          // effective prefilter bits per plane (0 = none)
     bool passthru[3] = {false, false, false};
     bool any_pre = false;
@@ -1328,8 +1334,9 @@ private:
                     jb.diff_max = par.diff_max[c];
                     jb.diff_cap = diff_cap[c];
                     jb.imul4 = imul4[c];
+                    jb.ishift = ishift[c];
                     fast &= diff_cap[c] >= 0;
-                    fast_int &= imul4[c] != 0;
+                    fast_int &= imul4[c] != 0 && (in_geo.bps == 2 || ishift[c] == 0);
                     jb.w = in_geo.pw[c];
                     jb.h = in_geo.ph[c];
                     jb.dst_pitch = outs[t].pitch[c];
