@@ -395,7 +395,7 @@ def run_chain(args, world, rank, local_rank):
     OW, OH = scale if scale else (W, H)
     B = args.batch or wl["batch"]
     nsrc = min(B, 8)
-    depth = args.depth if args.workload == "decomb_eedi2" else 8      # 10 / 12 bits: the decomb workload only (eedi2_16.hip)
+    depth = args.depth                                                 # 10 / 12 bits: uint16 planes through the same chain
     frames_np = synth.stream("interlaced", W, H, nsrc, cfg=wl["cfg"] + 16 * rank, depth=depth)
     dev_in = [[torch.from_numpy(p.view(np.int16) if depth > 8 else p).cuda() for p in fr] for fr in frames_np]
     in_arr = (hip.DevFrame * B)(*[hip.dev_frame(dev_in[i % nsrc]) for i in range(B)])
@@ -428,10 +428,10 @@ def run_chain(args, world, rank, local_rank):
             self.comb = hip.CombDetectDevice(self.ctx, W, H) if args.comb_detect else None
             stages = [hip.DeviceFilter(c, self.decomb.h)]
             if not only_decomb:
-                stages.append(hip.nlmeans_device_filter(stage_ctx(), hip.NLMEANS_MEDIUM, W, H, batch=1))
+                stages.append(hip.nlmeans_device_filter(stage_ctx(), hip.NLMEANS_MEDIUM, W, H, batch=1, depth=depth))
                 if scale:
-                    stages.append(hip.cropscale_device_filter(stage_ctx(), W, H, OW, OH))
-                stages.append(hip.lapsharp_device_filter(stage_ctx(), OW, OH))
+                    stages.append(hip.cropscale_device_filter(stage_ctx(), W, H, OW, OH, depth=depth))
+                stages.append(hip.lapsharp_device_filter(stage_ctx(), OW, OH, depth=depth))
             self.decomb.h = None                              # owned by the chain from here on
             self.chain = hip.Chain(self.ctx, stages)
             self.cap = 2 * B + 4

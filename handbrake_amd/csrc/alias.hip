@@ -474,110 +474,6 @@ public:
 };
 
 // ------------------------------------------------------------------ crop + lanczos scale
-struct ScaleArgs
-{
-    const uint8_t *src;      // already offset to the crop window
-    uint8_t       *dst;
-    int spitch, dpitch, dw, dh, tx, ty;
-    const int    *ix, *iy;
-    const double *cx, *cy;
-    double vmax;             // (1 << depth) - 1
-};
-
-// Pass 1: H[r][x] = sum_i cx[x][i] * src[r][ix[x][i]] for every source row r of the crop window.
-// Pass 2: out[y][x] = round(clamp(sum_j cy[y][j] * H[iy[y][j]][x])).
-// Same products, same order of additions as the one-loop form in oracle/alias_oracle.c, so the
-// split changes nothing numerically; it turns taps^2 gathers per pixel into 2*taps.
-template <typename PIX>
-__global__ __launch_bounds__(256) void cropscale_h_kernel(ScaleArgs a, double *__restrict__ hbuf, int src_rows)
-{
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= a.dw || r >= src_rows) return;
-    const int *ix = a.ix + (size_t)x * a.tx;
-    const double *cx = a.cx + (size_t)x * a.tx;
-    const PIX *row = reinterpret_cast<const PIX *>(a.src + (size_t)r * a.spitch);
-    double h = 0.0;
-    for (int i = 0; i < a.tx; i++)
-        h += cx[i] * (double)row[ix[i]];
-    hbuf[(size_t)r * a.dw + x] = h < 0.0 ? 0.0 : h > a.vmax ? a.vmax : h;      // the horizontal pass is stored clamped (see oracle)
-}
-
-template <typename PIX>
-__global__ __launch_bounds__(256) void cropscale_v_kernel(ScaleArgs a, const double *__restrict__ hbuf)
-{
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= a.dw || y >= a.dh) return;
-    double acc = 0.0;
-    for (int j = 0; j < a.ty; j++)
-        acc += a.cy[(size_t)y * a.ty + j] * hbuf[(size_t)a.iy[(size_t)y * a.ty + j] * a.dw + x];
-    acc = acc < 0.0 ? 0.0 : acc > a.vmax ? a.vmax : acc;
-    reinterpret_cast<PIX *>(a.dst + (size_t)y * a.dpitch)[x] = (PIX)(int)(acc + 0.5);
-}
-
-// Both passes in one kernel: a workgroup owns a FS_TW x FS_TH tile of the output.  It first forms
-// the horizontally filtered values H[r][x] of the few source rows its output rows tap (those sit in
-// LDS as doubles instead of making a round trip through HBM), then the vertical sums.  Each H value
-// and each output is the same sequence of double operations as in the two-pass kernels above.
-constexpr int FS_TW = 64, FS_TH = 32, FS_MAXR = 40;
-struct ScaleArgs3 { ScaleArgs p[3]; int active[3]; };
-
-// Any tap counts (read from the arguments); the 6 x 6 case has its own kernel below.
-template <int TX, int TY, typename PIX>
-__global__ __launch_bounds__(256) void cropscale_fused_kernel(ScaleArgs3 all)
-{
-    __shared__ double s_h[FS_MAXR][FS_TW];
-    __shared__ int s_rmin, s_rmax;
-    const int pl = blockIdx.z;
-    if (!all.active[pl]) return;
-    const ScaleArgs &a = all.p[pl];
-    const int x0 = blockIdx.x * FS_TW, y0 = blockIdx.y * FS_TH;
-    if (x0 >= a.dw || y0 >= a.dh) return;
-    const int t = threadIdx.x;
-    const int tx = TX > 0 ? TX : a.tx, ty = TY > 0 ? TY : a.ty;
-    const int rows = min(FS_TH, a.dh - y0);
-    if (t == 0) { s_rmin = 0x7fffffff; s_rmax = -1; }
-    __syncthreads();
-    {
-        int lo = 0x7fffffff, hi = -1;
-        for (int i = t; i < rows * ty; i += 256)
-        {
-            const int r = a.iy[(size_t)y0 * ty + i];
-            lo = min(lo, r); hi = max(hi, r);
-        }
-        if (hi >= 0) { atomicMin(&s_rmin, lo); atomicMax(&s_rmax, hi); }
-    }
-    __syncthreads();
-    const int rmin = s_rmin, nr = s_rmax - rmin + 1;            // nr <= FS_MAXR (checked by the host)
-    const int xl = t & (FS_TW - 1), x = x0 + xl;
-    const int wave_row = __builtin_amdgcn_readfirstlane(t / FS_TW);   // a wave = one tile row: uniform
-    if (x < a.dw)
-    {
-        const int *ix = a.ix + (size_t)x * tx;
-        const double *cx = a.cx + (size_t)x * tx;
-        for (int rr = wave_row; rr < nr; rr += 256 / FS_TW)
-        {
-            const PIX *row = reinterpret_cast<const PIX *>(a.src + (size_t)(rmin + rr) * a.spitch);
-            double h = 0.0;
-            for (int i = 0; i < tx; i++) h += cx[i] * (double)row[ix[i]];
-            s_h[rr][xl] = h < 0.0 ? 0.0 : h > a.vmax ? a.vmax : h;
-        }
-    }
-    __syncthreads();
-    if (x >= a.dw) return;
-    for (int yy = wave_row; yy < rows; yy += 256 / FS_TW)
-    {
-        const int y = y0 + yy;                                   // uniform: the taps come through scalar loads
-        const double *cy = a.cy + (size_t)y * ty;
-        const int *iy = a.iy + (size_t)y * ty;
-        double acc = 0.0;
-        for (int j = 0; j < ty; j++) acc += cy[j] * s_h[iy[j] - rmin][xl];
-        acc = acc < 0.0 ? 0.0 : acc > a.vmax ? a.vmax : acc;
-        reinterpret_cast<PIX *>(a.dst + (size_t)y * a.dpitch)[x] = (PIX)(int)(acc + 0.5);
-    }
-}
-
 // ---- 8-bit planes: zimg's own arithmetic ------------------------------------------------------------------------
 // zimg resizes an 8-bit plane as a 16-bit one (v << 8) in 16-bit fixed point: per pass
 //     dst = clamp((sum_k c[k] * src[k] + (1 << 13)) >> 14, 0, 65535),    c = the filter row with 14 fractional bits,
@@ -744,6 +640,108 @@ __global__ __launch_bounds__(256) void scale8_up_kernel(ScaleBatch8 B)
     }
 }
 
+// ---- 10 / 12-bit planes: the same arithmetic at the samples' own depth --------------------------------------------
+// zimg resizes a uint16 plane in place of its depth: per pass dst = clamp((sum c[k] * src[k] + (1 << 13)) >> 14, 0,
+// vmax) (oracle/alias_oracle.c: orc_cropscale_plane_fx16).  Samples and the plane between the passes are below 4096,
+// so they are signed 16-bit values as they stand and v_dot2_i32_i16 takes two taps at a time without any bias.
+__global__ __launch_bounds__(256) void scale16_h_kernel(Scale8Args a, uint16_t *__restrict__ hbuf, int vmax)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= a.dw || r >= a.src_rows) return;
+    const int *ix = a.ix + (size_t)x * a.tx;
+    const short *q = a.qx + (size_t)x * a.tx;
+    const uint16_t *row = reinterpret_cast<const uint16_t *>(a.src + (size_t)r * a.spitch);
+    int s = 8192;
+    for (int i = 0; i < a.tx; i++) s += (int)q[i] * (int)row[ix[i]];
+    hbuf[(size_t)r * a.dw + x] = (uint16_t)min(max(s >> 14, 0), vmax);
+}
+
+__global__ __launch_bounds__(256) void scale16_v_kernel(Scale8Args a, const uint16_t *__restrict__ hbuf, int vmax)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= a.dw || y >= a.dh) return;
+    int acc = 8192;
+    for (int j = 0; j < a.ty; j++)
+        acc += (int)a.qy[(size_t)y * a.ty + j] * (int)hbuf[(size_t)a.iy[(size_t)y * a.ty + j] * a.dw + x];
+    reinterpret_cast<uint16_t *>(a.dst + (size_t)y * a.dpitch)[x] = (uint16_t)min(max(acc >> 14, 0), vmax);
+}
+
+// 6 x 6 taps, both passes in one kernel, the planes of up to SU_FRAMES frames per launch: scale8_up_kernel's shape on
+// uint16 samples.  The staged source rows hold two samples per dword; a thread's six-sample window starts on an even
+// or an odd sample, so it reads four dwords of a row and realigns them by 0 or 2 bytes (v_alignbyte_b32 with the
+// thread's own shift) into the three sample pairs its three v_dot2 take.  The horizontal results go to LDS as pairs
+// of rows, the vertical pass is the 8-bit kernel's with another rounding and a 16-bit store.
+constexpr int SW_SRC_DW = 138;          // 2 * 136 samples of a row (+ the dwords the realignment reads past the window)
+__global__ __launch_bounds__(256) void scale16_up_kernel(ScaleBatch8 B, int vmax)
+{
+    __shared__ uint32_t s_src[SU_MAXR][SW_SRC_DW];
+    __shared__ __attribute__((aligned(16))) uint32_t s_h[SU_PAIRS][SU_TW];
+    const int f = (int)blockIdx.z / 3, pl = (int)blockIdx.z - 3 * f;
+    const ScalePlane8 &P = B.p[pl];
+    if (!P.active) return;
+    const int x0 = blockIdx.x * SU_TW, y0 = blockIdx.y * SU_TH;
+    if (x0 >= P.dw || y0 >= P.dh) return;
+    const int t = threadIdx.x;
+    const int xe = min(x0 + SU_TW, P.dw) - 1, ye = min(y0 + SU_TH, P.dh) - 1;
+    const int cmin = P.bx[x0] & ~1, cmax = P.bx[xe] + 5;           // in samples; bx, by are non-decreasing
+    const int rmin = P.by[y0], nr = P.by[ye] + 5 - rmin + 1;
+    const int ndw = (cmax - cmin) / 2 + 2;                          // + 1: the dword an odd window's last pair reaches into
+    {
+        const uint8_t *src = B.src[f][pl];
+        const int spitch = B.spitch[pl];
+        for (int i = t; i < nr * ndw; i += 256)
+        {
+            const int rr = i / ndw, d = i - rr * ndw, col = cmin + 2 * d;
+            const uint16_t *row = reinterpret_cast<const uint16_t *>(src + (size_t)reflect_idx(rmin + rr, P.sh) * spitch);
+            uint32_t v;
+            if (col >= 0 && col + 1 < P.sw && (((uintptr_t)(row + col)) & 3) == 0) v = *reinterpret_cast<const uint32_t *>(row + col);
+            else v = (uint32_t)row[reflect_idx(col, P.sw)] | ((uint32_t)row[reflect_idx(col + 1, P.sw)] << 16);
+            s_src[rr][d] = v;
+        }
+    }
+    __syncthreads();
+    if (x0 + t < P.dw)
+    {
+        const int x = x0 + t, o = P.bx[x] - cmin, dq = o >> 1;
+        const uint32_t shift = (uint32_t)(o & 1) * 2u;              // bytes
+        const uint32_t c01 = P.qx[3 * (size_t)x], c23 = P.qx[3 * (size_t)x + 1], c45 = P.qx[3 * (size_t)x + 2];
+        uint16_t *hp = reinterpret_cast<uint16_t *>(&s_h[0][0]) + 2 * t;
+        for (int rr = 0; rr < nr; rr++)
+        {
+            const uint32_t d0 = s_src[rr][dq], d1 = s_src[rr][dq + 1], d2 = s_src[rr][dq + 2], d3 = s_src[rr][dq + 3];
+            int s = dot2(__builtin_amdgcn_alignbyte(d1, d0, shift), c01, 8192);
+            s = dot2(__builtin_amdgcn_alignbyte(d2, d1, shift), c23, s);
+            s = dot2(__builtin_amdgcn_alignbyte(d3, d2, shift), c45, s);
+            hp[(size_t)(rr >> 1) * (2 * SU_TW) + (rr & 1)] = (uint16_t)min(max(s >> 14, 0), vmax);
+        }
+    }
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, xq = x0 + 4 * lane;
+    if (xq >= P.dw) return;
+    for (int y = y0 + wave; y <= ye; y += 4)
+    {
+        const int ob = __builtin_amdgcn_readfirstlane(P.by[y] - rmin);
+        const uint32_t c01 = P.qy[3 * (size_t)y], c23 = P.qy[3 * (size_t)y + 1], c45 = P.qy[3 * (size_t)y + 2];
+        int acc[4] = {8192, 8192, 8192, 8192};
+        const uint4 *hq = reinterpret_cast<const uint4 *>(&s_h[ob >> 1][4 * lane]);
+        auto tap = [&](int pair_row, uint32_t cpair) {
+            const uint4 q = hq[(size_t)pair_row * (SU_TW / 4)];
+            acc[0] = dot2(q.x, cpair, acc[0]); acc[1] = dot2(q.y, cpair, acc[1]);
+            acc[2] = dot2(q.z, cpair, acc[2]); acc[3] = dot2(q.w, cpair, acc[3]);
+        };
+        if (!(ob & 1)) { tap(0, c01); tap(1, c23); tap(2, c45); }
+        else { tap(0, c01 << 16); tap(1, (c01 >> 16) | (c23 << 16)); tap(2, (c23 >> 16) | (c45 << 16)); tap(3, c45 >> 16); }
+        uint32_t o4[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) o4[k] = (uint32_t)min(max(acc[k] >> 14, 0), vmax);
+        uint16_t *d = reinterpret_cast<uint16_t *>(B.dst[f][pl] + (size_t)y * B.dpitch[pl]) + xq;
+        if (xq + 3 < P.dw && (((uintptr_t)d) & 7) == 0) *reinterpret_cast<uint2 *>(d) = make_uint2(o4[0] | (o4[1] << 16), o4[2] | (o4[3] << 16));
+        else for (int k = 0; k < 4 && xq + k < P.dw; k++) d[k] = (uint16_t)o4[k];
+    }
+}
+
 __global__ void crop_copy_kernel(const uint8_t *src, int spitch, uint8_t *dst, int dpitch, int w, int h)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -824,14 +822,11 @@ public:
         {
             if (d_ix[c]) (void)hipFree(d_ix[c]);
             if (d_iy[c]) (void)hipFree(d_iy[c]);
-            if (d_cx[c]) (void)hipFree(d_cx[c]);
-            if (d_cy[c]) (void)hipFree(d_cy[c]);
             if (d_bx[c]) (void)hipFree(d_bx[c]);
             if (d_by[c]) (void)hipFree(d_by[c]);
             if (d_qx[c]) (void)hipFree(d_qx[c]);
             if (d_qy[c]) (void)hipFree(d_qy[c]);
         }
-        if (hbuf) (void)hipFree(hbuf);
         if (hbuf16) (void)hipFree(hbuf16);
     }
     int setup()
@@ -863,9 +858,8 @@ public:
             int rc = upload(d_ix[c], ix);
             if (rc == HBHIP_OK) rc = upload(d_iy[c], iy);
             if (rc != HBHIP_OK) return rc;
-            if (in_geo.bps == 1)
             {
-                // 8-bit planes: zimg's fixed-point arithmetic (scale8_*_kernel)
+                // zimg's fixed-point arithmetic at every depth (scale8_* / scale16_* kernels)
                 std::vector<short> qx(cx.size()), qy(cy.size());
                 for (int x = 0; x < dw; x++) quantize_taps(&cx[(size_t)x * tx[c]], tx[c], &qx[(size_t)x * tx[c]]);
                 for (int y = 0; y < dh; y++) quantize_taps(&cy[(size_t)y * ty[c]], ty[c], &qy[(size_t)y * ty[c]]);
@@ -874,34 +868,21 @@ public:
                 if (rc == HBHIP_OK) rc = upload(d_bx[c], bx);
                 if (rc == HBHIP_OK) rc = upload(d_by[c], by);
                 if (rc != HBHIP_OK) return rc;
-                // the fused kernel: six taps either way, and what a 256 x 16 tile taps must fit its LDS frame
+                // the fused kernels: six taps either way, and what a 256 x 16 tile taps must fit their LDS frame
                 if (tx[c] != 6 || ty[c] != 6) up6 = false;
                 for (int x0 = 0; x0 < dw && up6; x0 += SU_TW)
-                    if (((bx[std::min(x0 + SU_TW, dw) - 1] + 5) - (bx[x0] & ~3)) / 4 + 1 > SU_SRC_DW - 2) up6 = false;
+                {
+                    const int last = bx[std::min(x0 + SU_TW, dw) - 1] + 5;
+                    if (in_geo.bps == 1 ? (last - (bx[x0] & ~3)) / 4 + 1 > SU_SRC_DW - 2 : (last - (bx[x0] & ~1)) / 2 + 2 > SW_SRC_DW) up6 = false;
+                }
                 for (int y0 = 0; y0 < dh && up6; y0 += SU_TH)
                     if (by[std::min(y0 + SU_TH, dh) - 1] + 5 - by[y0] + 1 > SU_MAXR) up6 = false;
-                continue;
             }
-            // 10 / 12-bit planes: the double form (cropscale_fused_kernel, or two passes when a tile taps too many rows)
-            for (int y0 = 0; y0 < dh && fused; y0 += FS_TH)
-            {
-                int lo = 0x7fffffff, hi = -1;
-                for (int i = 0; i < std::min(FS_TH, dh - y0) * ty[c]; i++)
-                {
-                    lo = std::min(lo, iy[(size_t)y0 * ty[c] + i]);
-                    hi = std::max(hi, iy[(size_t)y0 * ty[c] + i]);
-                }
-                if (hi - lo + 1 > FS_MAXR) fused = false;
-            }
-            rc = upload(d_cx[c], cx);
-            if (rc == HBHIP_OK) rc = upload(d_cy[c], cy);
-            if (rc != HBHIP_OK) return rc;
         }
         size_t need = 0;
         for (int c = 0; c < 3; c++)
             if (!identity[c]) need = std::max(need, (size_t)out_geo.pw[c] * crop_h[c]);
-        if (need && in_geo.bps == 1 && !up6) HBHIP_CHECK(ctx, hipMalloc((void **)&hbuf16, sizeof(uint16_t) * need));
-        if (need && in_geo.bps != 1 && !fused) HBHIP_CHECK(ctx, hipMalloc((void **)&hbuf, sizeof(double) * need));
+        if (need && !up6) HBHIP_CHECK(ctx, hipMalloc((void **)&hbuf16, sizeof(uint16_t) * need));
         return HBHIP_OK;
     }
 
@@ -918,10 +899,9 @@ public:
         return HBHIP_OK;
     }
 
-    // 8-bit planes
     int process_many(DevPicture *const *ins, DevPicture *const *outs, int n) override
     {
-        if (in_geo.bps != 1) return SimpleFilter::process_many(ins, outs, n);
+        const int vmax = (1 << in_geo.depth) - 1;
         for (int i = 0; i < n; i++) (void)copy_identity_planes(ins[i], outs[i]);
         if (identity[0] && identity[1] && identity[2]) { HBHIP_CHECK(ctx, hipGetLastError()); return HBHIP_OK; }
         if (up6)
@@ -945,7 +925,8 @@ public:
                     }
                 }
                 const dim3 grid((out_geo.pw[0] + SU_TW - 1) / SU_TW, (out_geo.ph[0] + SU_TH - 1) / SU_TH, 3 * m);
-                HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", scale8_up_kernel, grid, dim3(256), 0, B);
+                if (in_geo.bps == 1) HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", scale8_up_kernel, grid, dim3(256), 0, B);
+                else                 HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", scale16_up_kernel, grid, dim3(256), 0, B, vmax);
             }
         else
             for (int i = 0; i < n; i++)
@@ -958,62 +939,28 @@ public:
                     a.dw = out_geo.pw[c]; a.dh = out_geo.ph[c]; a.tx = tx[c]; a.ty = ty[c]; a.src_rows = crop_h[c];
                     a.ix = d_ix[c]; a.iy = d_iy[c]; a.qx = d_qx[c]; a.qy = d_qy[c];
                     const dim3 gh((a.dw + 63) / 64, (crop_h[c] + 3) / 4), gv((a.dw + 63) / 64, (a.dh + 3) / 4);
-                    HBHIP_LAUNCH(ctx, "cropscale_lanczos_h", scale8_h_kernel, gh, dim3(64, 4), 0, a, hbuf16);
-                    HBHIP_LAUNCH(ctx, "cropscale_lanczos_v", scale8_v_kernel, gv, dim3(64, 4), 0, a, (const uint16_t *)hbuf16);
+                    if (in_geo.bps == 1)
+                    {
+                        HBHIP_LAUNCH(ctx, "cropscale_lanczos_h", scale8_h_kernel, gh, dim3(64, 4), 0, a, hbuf16);
+                        HBHIP_LAUNCH(ctx, "cropscale_lanczos_v", scale8_v_kernel, gv, dim3(64, 4), 0, a, (const uint16_t *)hbuf16);
+                    }
+                    else
+                    {
+                        HBHIP_LAUNCH(ctx, "cropscale_lanczos_h", scale16_h_kernel, gh, dim3(64, 4), 0, a, hbuf16, vmax);
+                        HBHIP_LAUNCH(ctx, "cropscale_lanczos_v", scale16_v_kernel, gv, dim3(64, 4), 0, a, (const uint16_t *)hbuf16, vmax);
+                    }
                 }
         HBHIP_CHECK(ctx, hipGetLastError());
         return HBHIP_OK;
     }
 
-    // one frame: 8-bit planes through process_many, 10 / 12-bit planes here
-    int process(DevPicture *in, DevPicture *out) override
-    {
-        if (in_geo.bps == 1) return process_many(&in, &out, 1);
-        ScaleArgs3 all;
-        memset(&all, 0, sizeof(all));
-        (void)copy_identity_planes(in, out);
-        for (int c = 0; c < 3; c++)
-        {
-            const uint8_t *win = window(in, c);
-            const int dw = out->width[c], dh = out->height[c];
-            const double vmax = (double)((1 << in_geo.depth) - 1);
-            if (identity[c]) continue;
-            if (fused)
-            {
-                ScaleArgs &f = all.p[c];
-                f.src = win; f.dst = out->plane[c];
-                f.spitch = in->pitch[c]; f.dpitch = out->pitch[c];
-                f.dw = dw; f.dh = dh; f.tx = tx[c]; f.ty = ty[c];
-                f.ix = d_ix[c]; f.iy = d_iy[c]; f.cx = d_cx[c]; f.cy = d_cy[c]; f.vmax = vmax;
-                all.active[c] = 1;
-                continue;
-            }
-            ScaleArgs a;
-            a.src = win; a.dst = out->plane[c];
-            a.spitch = in->pitch[c]; a.dpitch = out->pitch[c];
-            a.dw = dw; a.dh = dh; a.tx = tx[c]; a.ty = ty[c];
-            a.ix = d_ix[c]; a.iy = d_iy[c]; a.cx = d_cx[c]; a.cy = d_cy[c]; a.vmax = vmax;
-            const dim3 gh((dw + 63) / 64, (crop_h[c] + 3) / 4), gv((dw + 63) / 64, (dh + 3) / 4);
-            HBHIP_LAUNCH(ctx, "cropscale_lanczos_h", cropscale_h_kernel<uint16_t>, gh, dim3(64, 4), 0, a, hbuf, crop_h[c]);
-            HBHIP_LAUNCH(ctx, "cropscale_lanczos_v", cropscale_v_kernel<uint16_t>, gv, dim3(64, 4), 0, a, (const double *)hbuf);
-        }
-        if (all.active[0] || all.active[1] || all.active[2])
-        {
-            const dim3 grid((out->width[0] + FS_TW - 1) / FS_TW, (out->height[0] + FS_TH - 1) / FS_TH, 3);
-            HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", (cropscale_fused_kernel<0, 0, uint16_t>), grid, dim3(256), 0, all);
-        }
-        HBHIP_CHECK(ctx, hipGetLastError());
-        return HBHIP_OK;
-    }
-    bool fused = true;          // 10 / 12 bits: all scaled planes fit the fused kernel's LDS budget
-    bool up6 = true;            // 8 bits: six taps either way and every tile fits scale8_up_kernel's LDS frame
+    int process(DevPicture *in, DevPicture *out) override { return process_many(&in, &out, 1); }
+    bool up6 = true;            // six taps either way and every tile fits the fused kernel's LDS frame
     hbhip_cropscale_params par;
     int crop_x[3], crop_y[3], crop_w[3], crop_h[3], tx[3] = {0, 0, 0}, ty[3] = {0, 0, 0};
     bool identity[3] = {false, false, false};
     int *d_ix[3] = {nullptr, nullptr, nullptr}, *d_iy[3] = {nullptr, nullptr, nullptr};
-    double *d_cx[3] = {nullptr, nullptr, nullptr}, *d_cy[3] = {nullptr, nullptr, nullptr};
-    double *hbuf = nullptr;     // horizontally filtered rows of one plane (dst_w x crop_h doubles; 10 / 12 bits, two-pass form)
-    uint16_t *hbuf16 = nullptr; // the same for 8-bit planes (zimg's 16-bit plane between the passes)
+    uint16_t *hbuf16 = nullptr; // the 16-bit plane between the passes (two-launch form)
     int *d_bx[3] = {nullptr, nullptr, nullptr}, *d_by[3] = {nullptr, nullptr, nullptr};
     short *d_qx[3] = {nullptr, nullptr, nullptr}, *d_qy[3] = {nullptr, nullptr, nullptr};
 };

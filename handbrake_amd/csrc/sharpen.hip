@@ -587,15 +587,100 @@ __global__ __launch_bounds__(256) void lapsharp3_rows_kernel(LapBatch3 B)
     }
 }
 
+// The same walk for 10 / 12-bit samples (lapsharp_16, lapsharp.c:184): a thread owns four adjacent columns = two dwords of
+// every row and reads four (samples x0 - 2 .. x0 + 5), int32 sums, clamp to the depth.  Right of the plane the reference
+// reads its stride padding, which the 16-bit hb_frame_buffer_mirror_stride really fills (fifo.c:906-932): sample
+// w + i = sample w - 1 - i - applied while a row's samples are unpacked, as lapsharp16_kernel does.
+__global__ __launch_bounds__(256) void lapsharp3_rows16_kernel(LapBatch3 B, int max_value)
+{
+    const int job = blockIdx.z, f = job / 3, c = job - 3 * f;
+    const LapPlane3 &P = B.pl[c];
+    if (!P.active) return;
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int ys = (blockIdx.y * 4 + threadIdx.y) * LS_ROWS;
+    if (x0 >= P.width || ys >= P.height) return;
+    const uint8_t *src = B.src[f][c];
+    uint8_t *dst = B.dst[f][c];
+    const int pitch_dw = P.src_pitch >> 2, xd = x0 >> 1;
+    const bool tail = x0 + 5 > P.width;
+    const uint32_t o0 = 4u * (uint32_t)max(xd - 1, 0), o1 = 4u * (uint32_t)xd, o2 = 4u * (uint32_t)min(xd + 1, pitch_dw - 1),
+                   o3 = 4u * (uint32_t)min(xd + 2, pitch_dw - 1);
+    int u_prev[4], u_cur[4], v_cur[4], m_cur[4];
+    auto load_row = [&](int yy, int (&u)[4], int (&v)[4], int (&m)[4]) {
+        yy = min(max(yy, 0), P.height - 1);                  // only read for samples that end up copied
+        const uint32_t ro = (uint32_t)__mul24(yy, P.src_pitch);
+        const uint32_t w0 = *reinterpret_cast<const uint32_t *>(src + (ro + o0)), w1 = *reinterpret_cast<const uint32_t *>(src + (ro + o1)),
+                       w2 = *reinterpret_cast<const uint32_t *>(src + (ro + o2)), w3 = *reinterpret_cast<const uint32_t *>(src + (ro + o3));
+        int bb[6] = { (int)(w0 >> 16), (int)(w1 & 0xffffu), (int)(w1 >> 16), (int)(w2 & 0xffffu), (int)(w2 >> 16), (int)(w3 & 0xffffu) };
+        if (tail)
+        {
+            const uint16_t *r16 = reinterpret_cast<const uint16_t *>(src + ro);
+#pragma unroll
+            for (int k = 0; k < 6; k++)
+            {
+                const int xx = x0 - 1 + k;
+                if (xx >= P.width) bb[k] = (int)r16[max(2 * P.width - 1 - xx, 0)];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            const int h = bb[k] + bb[k + 2];
+            m[k] = bb[k + 1];
+            u[k] = __mul24(P.a, h) + __mul24(P.b, m[k]);       // |taps| <= 25, samples < 2^13: 24-bit multiplies
+            v[k] = __mul24(P.b, h) + __mul24(P.c, m[k]);
+        }
+    };
+    {
+        int v_tmp[4], m_tmp[4];
+        load_row(ys - 1, u_prev, v_tmp, m_tmp);
+        load_row(ys, u_cur, v_cur, m_cur);
+    }
+    const int y_end = min(ys + LS_ROWS, P.height);
+    uint32_t copy_cols = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (x0 + k < P.stride_border + 2 || x0 + k > P.width + P.stride_border - 2) copy_cols |= 1u << k;
+    const bool full = x0 + 3 < P.width;
+#pragma unroll
+    for (int r = 0; r < LS_ROWS; r++)
+    {
+        const int y = ys + r;
+        if (y >= y_end) break;
+        int u_next[4], v_next[4], m_next[4];
+        load_row(y + 1, u_next, v_next, m_next);
+        const bool row_copy = (y < 2) || (y > P.height - 2);
+        int out[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            const int centre = m_cur[k];
+            out[k] = centre;
+            if (!row_copy && !((copy_cols >> k) & 1u))
+            {
+                const int acc = u_prev[k] + v_cur[k] + u_next[k];
+                const double mixed = (((double)acc * P.coef) - (double)centre) * P.strength;   // lapsharp.c:174-175
+                out[k] = min(max((int)mixed + centre, 0), max_value);
+            }
+        }
+        uint16_t *d = reinterpret_cast<uint16_t *>(dst + (uint32_t)__mul24(y, P.dst_pitch)) + x0;
+        if (full && (((uintptr_t)d) & 7) == 0)
+            *reinterpret_cast<uint2 *>(d) = make_uint2((uint32_t)out[0] | ((uint32_t)out[1] << 16), (uint32_t)out[2] | ((uint32_t)out[3] << 16));
+        else for (int k = 0; k < 4 && x0 + k < P.width; k++) d[k] = (uint16_t)out[k];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { u_prev[k] = u_cur[k]; u_cur[k] = u_next[k]; v_cur[k] = v_next[k]; m_cur[k] = m_next[k]; }
+    }
+}
+
 // ------------------------------------------------------------------ filter classes
 class LapsharpFilter : public SimpleFilter
 {
 public:
     LapsharpFilter(hbhip_ctx *c, const hbhip_lapsharp_params &p) : SimpleFilter(c), par(p) {}
-    // up to LS_FRAMES frames per launch when every plane uses a 3x3 kernel on 8-bit samples
+    // up to LS_FRAMES frames per launch when every plane uses a 3x3 kernel
     int process_many(DevPicture *const *ins, DevPicture *const *outs, int n) override
     {
-        bool rows3 = in_geo.bps == 1;
+        bool rows3 = true;
         for (int c = 0; c < 3; c++) rows3 &= LAP_TABLE[par.kernel[c]].size == 3;
         if (!rows3) return SimpleFilter::process_many(ins, outs, n);
         for (int at = 0; at < n; at += LS_FRAMES)
@@ -625,15 +710,15 @@ public:
                 }
             }
             const dim3 grid(((max_w + 3) / 4 + 63) / 64, (max_h + 4 * LS_ROWS - 1) / (4 * LS_ROWS), 3 * nf);
-            HBHIP_LAUNCH(ctx, "lapsharp_3x3", lapsharp3_rows_kernel, grid, dim3(64, 4), 0, B);
+            if (in_geo.bps == 1) HBHIP_LAUNCH(ctx, "lapsharp_3x3", lapsharp3_rows_kernel, grid, dim3(64, 4), 0, B);
+            else                 HBHIP_LAUNCH(ctx, "lapsharp_3x3", lapsharp3_rows16_kernel, grid, dim3(64, 4), 0, B, (1 << in_geo.depth) - 1);
             HBHIP_CHECK(ctx, hipGetLastError());
         }
         return HBHIP_OK;
     }
     int process(DevPicture *in, DevPicture *out) override
     {
-        if (in_geo.bps == 1 && LAP_TABLE[par.kernel[0]].size == 3 && LAP_TABLE[par.kernel[1]].size == 3 &&
-            LAP_TABLE[par.kernel[2]].size == 3)
+        if (LAP_TABLE[par.kernel[0]].size == 3 && LAP_TABLE[par.kernel[1]].size == 3 && LAP_TABLE[par.kernel[2]].size == 3)
         {
             DevPicture *i1[1] = { in }, *o1[1] = { out };
             return process_many(i1, o1, 1);

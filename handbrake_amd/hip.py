@@ -436,19 +436,19 @@ def _create(fn_name, ctx, argtypes, *args):
     return DeviceFilter(ctx, h)
 
 
-def lapsharp_device_filter(ctx, width, height, strength=0.2, kernel=1):
+def lapsharp_device_filter(ctx, width, height, strength=0.2, kernel=1, depth=8):
     """lapsharp 'medium' = strength 0.2, isolap (param.c:932-935)."""
     p = LapsharpParams((C.c_double * 3)(strength, strength, strength), (C.c_int * 3)(kernel, kernel, kernel))
     return _create("hbhip_lapsharp_create", ctx,
                    [C.c_void_p, C.POINTER(LapsharpParams)] + [C.c_int] * 5 + [C.POINTER(C.c_void_p)],
-                   ctx.h, C.byref(p), width, height, 8, 1, 1)
+                   ctx.h, C.byref(p), width, height, depth, 1, 1)
 
 
-def cropscale_device_filter(ctx, width, height, out_w, out_h, crop=(0, 0, 0, 0)):
+def cropscale_device_filter(ctx, width, height, out_w, out_h, crop=(0, 0, 0, 0), depth=8):
     p = CropScaleParams(out_w, out_h, *crop)
     return _create("hbhip_cropscale_create", ctx,
                    [C.c_void_p, C.POINTER(CropScaleParams)] + [C.c_int] * 5 + [C.POINTER(C.c_void_p)],
-                   ctx.h, C.byref(p), width, height, 8, 1, 1)
+                   ctx.h, C.byref(p), width, height, depth, 1, 1)
 
 
 class ColorspaceParams(C.Structure):

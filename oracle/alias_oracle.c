@@ -303,6 +303,57 @@ void orc_cropscale_plane_fx(const uint8_t *src, int sstride, int crop_x, int cro
     free(ix); free(iy); free(cx); free(cy); free(qx); free(qy); free(hbuf);
 }
 
+/* The same for 10 / 12-bit planes (uint16 samples).  zimg resizes a WORD plane at its own depth: per pass
+ *     dst = clamp((sum_k c[k] * src[k] + (1 << 13)) >> 14, 0, (1 << depth) - 1)
+ * (it holds the samples biased by -32768 to use signed 16-bit multiplies; a filter row sums to exactly 1 << 14, so
+ * the bias is a multiple of 1 << 14 in the sum and comes out unchanged: the plain form above is the same number).
+ * Horizontal pass first, the plane between the passes clamped to the depth.  PARITY UNPINNED like the 8-bit form;
+ * tests/test_alias_cpu.py holds it within 1 LSB of the double form. */
+void orc_cropscale_plane_fx16(const uint16_t *src, int sstride, int crop_x, int crop_y, int crop_w, int crop_h,
+                              uint16_t *dst, int dstride, int dw, int dh, double shift_x, double shift_y, int depth)
+{
+    const int vmax = (1 << depth) - 1;
+    const uint8_t *win = (const uint8_t *)src + (size_t)crop_y * sstride + (size_t)crop_x * 2;
+    if (dw == crop_w && dh == crop_h && shift_x == 0.0 && shift_y == 0.0)
+    {
+        for (int y = 0; y < dh; y++)
+            memcpy((uint8_t *)dst + (size_t)y * dstride, win + (size_t)y * sstride, (size_t)dw * 2);
+        return;
+    }
+    int *ix = malloc(sizeof(int) * (size_t)dw * 64), *iy = malloc(sizeof(int) * (size_t)dh * 64);
+    double *cx = malloc(sizeof(double) * (size_t)dw * 64), *cy = malloc(sizeof(double) * (size_t)dh * 64);
+    const int tx = orc_lanczos_table(crop_w, dw, shift_x, ix, cx);
+    const int ty = orc_lanczos_table(crop_h, dh, shift_y, iy, cy);
+    int16_t *qx = malloc(sizeof(int16_t) * (size_t)dw * tx), *qy = malloc(sizeof(int16_t) * (size_t)dh * ty);
+    for (int x = 0; x < dw; x++) orc_quantize_taps(cx + (size_t)x * tx, tx, qx + (size_t)x * tx);
+    for (int y = 0; y < dh; y++) orc_quantize_taps(cy + (size_t)y * ty, ty, qy + (size_t)y * ty);
+    uint16_t *hbuf = malloc(sizeof(uint16_t) * (size_t)dw * crop_h);
+    for (int r = 0; r < crop_h; r++)
+    {
+        const uint16_t *row = (const uint16_t *)(win + (size_t)r * sstride);
+        for (int x = 0; x < dw; x++)
+        {
+            int s = 0;
+            for (int i = 0; i < tx; i++) s += (int)qx[(size_t)x * tx + i] * (int)row[ix[(size_t)x * tx + i]];
+            const int v = (s + 8192) >> 14;
+            hbuf[(size_t)r * dw + x] = (uint16_t)(v < 0 ? 0 : v > vmax ? vmax : v);
+        }
+    }
+    for (int y = 0; y < dh; y++)
+    {
+        uint16_t *drow = (uint16_t *)((uint8_t *)dst + (size_t)y * dstride);
+        for (int x = 0; x < dw; x++)
+        {
+            int acc = 0;
+            for (int j = 0; j < ty; j++)
+                acc += (int)qy[(size_t)y * ty + j] * (int)hbuf[(size_t)iy[(size_t)y * ty + j] * dw + x];
+            const int v = (acc + 8192) >> 14;
+            drow[x] = (uint16_t)(v < 0 ? 0 : v > vmax ? vmax : v);
+        }
+    }
+    free(ix); free(iy); free(cx); free(cy); free(qx); free(qy); free(hbuf);
+}
+
 /* ---- pad (libhb/pad.c:40-148 -> FFmpeg vf_pad.c + drawutils.c; parity unpinned) ----------------
  * vf_pad copies the input picture into a larger one at (x, y) - both rounded down to the chroma
  * subsampling - and fills the rest with one colour.  The colour is given as RGB and converted the

@@ -254,6 +254,9 @@ int orc_lanczos_table(int src_dim, int dst_dim, double shift, int *idx, double *
 void orc_quantize_taps(const double *coef, int taps, int16_t *q);
 void orc_cropscale_plane_fx(const uint8_t *src, int sstride, int crop_x, int crop_y, int crop_w, int crop_h,
                             uint8_t *dst, int dstride, int dw, int dh, double shift_x, double shift_y);
+/* the same at 10 / 12 bits: uint16 samples, both passes clamped to the depth (strides in bytes) */
+void orc_cropscale_plane_fx16(const uint16_t *src, int sstride, int crop_x, int crop_y, int crop_w, int crop_h,
+                              uint16_t *dst, int dstride, int dw, int dh, double shift_x, double shift_y, int depth);
 
 /* ---- colorspace (colorspace.c:20-207 -> zscale / tonemap; PARITY UNPINNED, colorspace_oracle.c) -- */
 typedef struct

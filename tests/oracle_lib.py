@@ -465,16 +465,19 @@ def orc_grayscale_frame(frame, cb=0.0, cr=0.0, size=1.0, high=0.0, depth=8):
 
 
 def orc_cropscale_frame(frame, width, height, top=0, bottom=0, left=0, right=0, depth=8, arithmetic=None):
-    """crop + Lanczos scale of a frame.  arithmetic: "fixed" = zimg's 16-bit fixed point (orc_cropscale_plane_fx, 8-bit
-    planes only: the form the HIP scaler runs and is compared with bit for bit), "double" = the float64 form
-    (10 / 12-bit planes, and the independent check of the fixed-point form); default: fixed at 8 bits."""
+    """crop + Lanczos scale of a frame.  arithmetic: "fixed" = zimg's 16-bit fixed point (orc_cropscale_plane_fx at 8
+    bits, orc_cropscale_plane_fx16 at 10 / 12: the form the HIP scaler runs and is compared with bit for bit; the
+    default), "double" = the float64 form (the independent check of the fixed-point forms)."""
     if arithmetic is None:
-        arithmetic = "fixed" if depth == 8 else "double"
-    if arithmetic == "fixed":
-        assert depth == 8
+        arithmetic = "fixed"
+    if arithmetic == "fixed" and depth == 8:
         fn = oracle().orc_cropscale_plane_fx
         fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                        C.c_int, C.c_int, C.c_double, C.c_double]
+    elif arithmetic == "fixed":
+        fn = oracle().orc_cropscale_plane_fx16
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                       C.c_int, C.c_int, C.c_double, C.c_double, C.c_int]
     else:
         fn = oracle().orc_cropscale_plane_d
         fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
@@ -492,7 +495,7 @@ def orc_cropscale_frame(frame, width, height, top=0, bottom=0, left=0, right=0, 
             sx = 0.25 * (1.0 - cw / width)
         dst = np.zeros((dh, dw), p.dtype)
         args = [p.ctypes.data, p.strides[0], cx, cy, pw, ph, dst.ctypes.data, dst.strides[0], dw, dh, sx, 0.0]
-        if arithmetic != "fixed":
+        if arithmetic != "fixed" or depth != 8:
             args.append(depth)
         fn(*args)
         out.append(dst)

@@ -62,18 +62,21 @@ def test_scale_identity_constant_and_partition_of_unity(built):
     assert taps == 12                                                 # support stretches when shrinking
 
 
+@pytest.mark.parametrize("depth", [8, 10, 12])
 @pytest.mark.parametrize("w,h,ow,oh", [(640, 360, 1280, 720), (640, 360, 320, 180), (638, 362, 850, 480), (320, 180, 300, 250)])
-def test_fixed_point_scaler_within_one_lsb_of_the_double_form(built, w, h, ow, oh):
-    """zimg's 16-bit fixed-point arithmetic (what the HIP scaler runs) against the float64 restatement of the same
-    filter: north_star's bar for the scaler is +-1 LSB."""
+def test_fixed_point_scaler_within_one_lsb_of_the_double_form(built, w, h, ow, oh, depth):
+    """zimg's 16-bit fixed-point arithmetic (what the HIP scaler runs, at every depth) against the float64 restatement
+    of the same filter: north_star's bar for the scaler is +-1 LSB."""
     for model in ("progressive", "random"):
-        fr = synth.stream(model, w, h, 1)[0]
-        fx = ol.orc_cropscale_frame(fr, ow, oh, arithmetic="fixed")
-        fd = ol.orc_cropscale_frame(fr, ow, oh, arithmetic="double")
+        fr = synth.stream(model, w, h, 1, depth=depth)[0]
+        fx = ol.orc_cropscale_frame(fr, ow, oh, depth=depth, arithmetic="fixed")
+        fd = ol.orc_cropscale_frame(fr, ow, oh, depth=depth, arithmetic="double")
         for c in range(3):
             d = np.abs(fx[c].astype(int) - fd[c].astype(int))
             assert d.max() <= 1, f"{model} plane {c}: max |delta| {d.max()}"
-            assert (d == 0).mean() > 0.97                            # they differ at rounding boundaries only
+            # they differ at rounding boundaries only; at 10 / 12 bits zimg keeps the plane between the passes at the
+            # samples' own depth (no spare fraction bits as at 8, where the plane is 16 bits wide), so more of them do
+            assert (d == 0).mean() > (0.97 if depth == 8 else 0.7)
 
 
 def test_quantised_taps_sum_to_one(built):

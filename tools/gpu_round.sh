@@ -24,6 +24,8 @@ for WL in chain2160 decomb_eedi2 nlmeans; do
   head -c 600 $OUT/bench_$WL.json; echo
 done
 timeout 200 python bench.py --workload decomb_eedi2 --depth 10 --no-cpu-baseline --no-pcie > $OUT/bench_decomb_eedi2_10bit.json 2> $OUT/bench_decomb_eedi2_10bit.err
+timeout 200 python bench.py --workload chain --depth 10 --no-cpu-baseline --no-pcie > $OUT/bench_chain_10bit.json 2> $OUT/bench_chain_10bit.err
+timeout 200 python bench.py --workload nlmeans --depth 10 --no-cpu-baseline --no-pcie > $OUT/bench_nlmeans_10bit.json 2> $OUT/bench_nlmeans_10bit.err
 timeout 200 python bench.py --workload chain --stage-streams 1 --no-cpu-baseline --no-pcie --no-kernel-timer > $OUT/bench_chain_stage_streams.json 2>> $OUT/bench_default.err
 timeout 200 python bench.py --workload chain --streams 2 --no-cpu-baseline --no-pcie --no-kernel-timer > $OUT/bench_chain_2streams.json 2>> $OUT/bench_default.err
 timeout 200 python bench.py --workload chain --comb-detect --no-cpu-baseline --no-pcie --no-kernel-timer > $OUT/bench_chain_combdetect.json 2>> $OUT/bench_default.err
