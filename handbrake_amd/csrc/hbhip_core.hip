@@ -309,29 +309,69 @@ int hbhip_copy_d2h(hbhip_ctx *ctx, const hbhip_host_frame *dst, const DevPicture
     return HBHIP_OK;
 }
 
+// Device-to-device copies of a picture's three planes as ONE kernel launch: hipMemcpy2DAsync makes a blit kernel per
+// plane and brackets it with system-scope barrier packets - 25 us of idle queue per picture in the kernel trace of the
+// NLMeans workload (tools/trace_gaps.py).
+namespace {
+struct PlaneCopy3
+{
+    const uint8_t *src[3];
+    uint8_t       *dst[3];
+    int spitch[3], dpitch[3], row_bytes[3], rows[3];
+};
+
+__global__ void __launch_bounds__(256) plane_copy3_kernel(PlaneCopy3 a)
+{
+    const int pl = blockIdx.z, y = blockIdx.y;
+    if (y >= a.rows[pl]) return;
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 16;
+    const int rb = a.row_bytes[pl];
+    if (x >= rb) return;
+    const uint8_t *s = a.src[pl] + (size_t)y * a.spitch[pl] + x;
+    uint8_t *d = a.dst[pl] + (size_t)y * a.dpitch[pl] + x;
+    if (x + 16 <= rb && (((uintptr_t)s | (uintptr_t)d) & 15) == 0)
+        *reinterpret_cast<uint4 *>(d) = *reinterpret_cast<const uint4 *>(s);
+    else
+        for (int i = 0; i < 16 && x + i < rb; i++) d[i] = s[i];
+}
+
+int plane_copy3(hbhip_ctx *ctx, const PlaneCopy3 &a)
+{
+    int maxrow = 0, maxrows = 0;
+    for (int c = 0; c < 3; c++) { maxrow = std::max(maxrow, a.row_bytes[c]); maxrows = std::max(maxrows, a.rows[c]); }
+    HBHIP_LAUNCH(ctx, "copy_planes", plane_copy3_kernel, dim3((maxrow + 4095) / 4096, maxrows, 3), dim3(256), 0, a);
+    HBHIP_CHECK(ctx, hipGetLastError());
+    return HBHIP_OK;
+}
+} // namespace
+
 int hbhip_copy_d2d_in(hbhip_ctx *ctx, DevPicture *dst, const hbhip_dev_frame *src)
 {
+    PlaneCopy3 a;
     for (int c = 0; c < 3; c++)
     {
         const size_t vis = (size_t)dst->width[c] * dst->bps;
         if (src->plane[c] == nullptr || src->stride[c] < (int)vis) return HBHIP_ERR_ARG;
-        const size_t row = (size_t)std::min(src->stride[c], dst->pitch[c]);
-        HBHIP_CHECK(ctx, hipMemcpy2DAsync(dst->plane[c], dst->pitch[c], src->plane[c], src->stride[c],
-                                          row, dst->height[c], hipMemcpyDeviceToDevice, ctx->stream));
+        a.src[c] = (const uint8_t *)src->plane[c]; a.dst[c] = dst->plane[c];
+        a.spitch[c] = src->stride[c]; a.dpitch[c] = dst->pitch[c];
+        a.row_bytes[c] = std::min(src->stride[c], dst->pitch[c]);      // the caller's row padding travels too (up to our pitch)
+        a.rows[c] = dst->height[c];
     }
-    return HBHIP_OK;
+    return plane_copy3(ctx, a);
 }
 
 int hbhip_copy_d2d_out(hbhip_ctx *ctx, const hbhip_dev_frame *dst, const DevPicture *src)
 {
+    PlaneCopy3 a;
     for (int c = 0; c < 3; c++)
     {
         const size_t row = (size_t)src->width[c] * src->bps;
         if (dst->plane[c] == nullptr || dst->stride[c] < (int)row) return HBHIP_ERR_ARG;
-        HBHIP_CHECK(ctx, hipMemcpy2DAsync(dst->plane[c], dst->stride[c], src->plane[c], src->pitch[c],
-                                          row, src->height[c], hipMemcpyDeviceToDevice, ctx->stream));
+        a.src[c] = src->plane[c]; a.dst[c] = (uint8_t *)dst->plane[c];
+        a.spitch[c] = src->pitch[c]; a.dpitch[c] = dst->stride[c];
+        a.row_bytes[c] = (int)row; a.rows[c] = src->height[c];
     }
-    return HBHIP_OK;
+    return plane_copy3(ctx, a);
 }
 
 int hbhip_filter::process_dev_batch(const hbhip_dev_frame *in, int n_in, int64_t tag0,
