@@ -351,7 +351,7 @@ ISA_NAMES = {"eedi2_calc_directions": ("r3_eedi2_isa_mix.json", "k_calc_dir_rows
              "eedi2_fill_gaps_2x": ("r3_eedi2_isa_mix.json", "k_fill_gaps_b"),
              "eedi2_lattice_candidates": ("r3_eedi2_isa_mix.json", "k_lattice_cand_q"),
              "eedi2_filter_dir_map_2x": ("r3_eedi2_isa_mix.json", "k_dir_map4"),
-             "nlmeans_plane_n7": ("r3_nlmeans_isa_mix.json", "nlmeans_lanes_kernel<7, 2, 36, false>"),
+             "nlmeans_plane_n7": ("r3_nlmeans_isa_mix.json", "nlmeans_lanes_kernel<7, 3, 36, false>"),
              "cropscale_lanczos_fused": ("r3_alias_isa_mix.json", "scale8_up_kernel")}
 
 
