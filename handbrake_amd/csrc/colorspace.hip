@@ -97,10 +97,14 @@ HBHIP_HD float det_expf(float x) { return det_exp2f(x * 1.44269502f); }
 HBHIP_HD float det_logf(float x) { return det_log2f(x) * 0.693147182f; }
 
 // transfer functions, display referred as zimg's set (gamma.cpp); classes as transfer_class() numbers them
+// (9 / 10: log100 / log316, 11: xvYCC - oracle/colorspace_oracle.c has the definitions)
 __device__ __forceinline__ float to_linear_dev(int cls, float v)
 {
     switch (cls)
     {
+        case 9:  return v <= 0.0f ? 0.01f : det_exp2f((2.0f * (v - 1.0f)) * 3.32192802f);
+        case 10: return v <= 0.0f ? 0.00316227766f : det_exp2f((2.5f * (v - 1.0f)) * 3.32192802f);
+        case 11: return v < 0.0f ? -det_powf(-v, 2.4f) : det_powf(v, 2.4f);
         case 1:  return det_powf(v, 2.4f);
         case 4:  return det_powf(v, 2.2f);
         case 5:  return det_powf(v, 2.8f);
@@ -130,6 +134,9 @@ __device__ __forceinline__ float to_gamma_dev(int cls, float x)
 {
     switch (cls)
     {
+        case 9:  return x <= 0.01f ? 0.0f : 1.0f + fdiv(det_log2f(x) * 0.301029996f, 2.0f);
+        case 10: return x <= 0.00316227766f ? 0.0f : 1.0f + fdiv(det_log2f(x) * 0.301029996f, 2.5f);
+        case 11: return x < 0.0f ? -det_powf(-x, 1.0f / 2.4f) : det_powf(x, 1.0f / 2.4f);
         case 1:  return det_powf(x, 1.0f / 2.4f);
         case 4:  return det_powf(x, 1.0f / 2.2f);
         case 5:  return det_powf(x, 1.0f / 2.8f);
@@ -431,7 +438,7 @@ void gamut_matrix(double g[3][3], const double in_xy[8], const double out_xy[8])
 // display-referred transfer functions (zimg's set); PQ / HLG only towards linear light
 bool transfer_known(int cls)
 {
-    return cls == 1 || cls == 4 || cls == 5 || cls == 7 || cls == 8 || cls == 13 || cls == 16 || cls == 18;
+    return cls == 1 || cls == 4 || cls == 5 || cls == 7 || (cls >= 8 && cls <= 11) || cls == 13 || cls == 16 || cls == 18;
 }
 
 float hable_host(float in)

@@ -220,13 +220,19 @@ float orc_det_logf(float x) { return det_logf(x); }
 static int transfer_known(int cls, int as_output)
 {
     (void)as_output;
-    return cls == 1 || cls == 4 || cls == 5 || cls == 7 || cls == 8 || cls == 13 || cls == 16 || cls == 18;
+    return cls == 1 || cls == 4 || cls == 5 || cls == 7 || (cls >= 8 && cls <= 11) || cls == 13 || cls == 16 || cls == 18;
 }
 
+/* 9 / 10: zimg's log100 / log316 pair (gamma.cpp: 1 + log10(x) / 2 above 0.01, resp. 1 + log10(x) / 2.5 above
+ * sqrt(10) / 1000, 0 below; inverse 10^(2 (v - 1)) resp. 10^(2.5 (v - 1)), the threshold itself at or below 0).
+ * 11: IEC 61966-2-4 (xvYCC), display referred like class 1: the 2.4 power law carried to negative values by its sign. */
 static inline float to_linear(int cls, float v)
 {
     switch (cls)
     {
+        case 9:  return v <= 0.0f ? 0.01f : det_exp2f((2.0f * (v - 1.0f)) * 3.32192802f);
+        case 10: return v <= 0.0f ? 0.00316227766f : det_exp2f((2.5f * (v - 1.0f)) * 3.32192802f);
+        case 11: return v < 0.0f ? -det_powf(-v, 2.4f) : det_powf(v, 2.4f);
         case 1:  return det_powf(v, 2.4f);
         case 4:  return det_powf(v, 2.2f);
         case 5:  return det_powf(v, 2.8f);
@@ -256,6 +262,9 @@ static inline float to_gamma(int cls, float x)
 {
     switch (cls)
     {
+        case 9:  return x <= 0.01f ? 0.0f : 1.0f + (det_log2f(x) * 0.301029996f) / 2.0f;
+        case 10: return x <= 0.00316227766f ? 0.0f : 1.0f + (det_log2f(x) * 0.301029996f) / 2.5f;
+        case 11: return x < 0.0f ? -det_powf(-x, 1.0f / 2.4f) : det_powf(x, 1.0f / 2.4f);
         case 1:  return det_powf(x, 1.0f / 2.4f);
         case 4:  return det_powf(x, 1.0f / 2.2f);
         case 5:  return det_powf(x, 1.0f / 2.8f);

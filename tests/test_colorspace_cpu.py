@@ -86,11 +86,14 @@ def test_uncovered_conversions_are_refused(built):
         ol.orc_colorspace_frame(flat(100, 128, 128), ol.colorspace_params(BT709, (1, 3, 1, 1)))      # unknown transfer
 
 
-@pytest.mark.parametrize("via", [(9, 16, 9, 1), (9, 18, 9, 1), (1, 1, 8, 1), (1, 13, 1, 2)], ids=["pq", "hlg", "ycgco", "srgb_full"])
+@pytest.mark.parametrize("via", [(9, 16, 9, 1), (9, 18, 9, 1), (1, 1, 8, 1), (1, 13, 1, 2), (1, 9, 1, 1), (1, 10, 1, 1), (1, 11, 1, 2)],
+                         ids=["pq", "hlg", "ycgco", "srgb_full", "log100", "log316", "xvycc_full"])
 def test_round_trips_through_the_new_outputs(built, via):
     """BT.709 -> X -> BT.709 at 10 bits comes back within a code or two (PQ / HLG as *output* transfers, the YCgCo
     matrix): forward and inverse functions are consistent."""
     for code, cb, cr in [(64, 512, 512), (300, 512, 512), (502, 400, 600), (940, 512, 512), (700, 620, 380)]:
+        if via[1] in (9, 10) and code < 300:
+            continue            # the log curves end at 0.01 / 0.00316 of linear light: black comes back as that floor
         src = flat(code, cb, cr, dt=np.uint16)
         there = ol.orc_colorspace_frame(src, ol.colorspace_params(BT709, via, tonemap="none"), depth=10)
         back = ol.orc_colorspace_frame(there, ol.colorspace_params(via, BT709, tonemap="none"), depth=10)

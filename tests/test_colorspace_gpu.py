@@ -27,6 +27,10 @@ SDR_CASES = [
     (BT709, "primaries=bt2020:transfer=smpte2084:matrix=bt2020nc", (9, 16, 9, 1), {}),          # PQ / HLG as output transfers
     (BT709, "primaries=bt2020:transfer=arib-std-b67:matrix=bt2020nc", (9, 18, 9, 1), {}),
     ((1, 13, 1, 2), "transfer=smpte240m:range=tv", (1, 7, 1, 1), {}),              # sRGB full range (super-whites stay) -> 240M
+    (BT709, "transfer=log100", (1, 9, 1, 1), {}),                                   # zimg's log pair and xvYCC, either way
+    ((1, 10, 1, 1), "transfer=bt709", BT709, {}),
+    (BT709, "transfer=iec61966-2-4:range=pc", (1, 11, 1, 2), {}),
+    ((1, 11, 1, 2), "primaries=bt2020:transfer=log316:matrix=bt2020nc:range=tv", (9, 10, 9, 1), {}),
 ]
 
 
