@@ -35,19 +35,17 @@ __device__ __forceinline__ void stage_lut(int16_t *dst, const int16_t *src, int 
     uint4 *d4 = reinterpret_cast<uint4 *>(dst);
     for (int base = threadIdx.x; base < NQ; base += 4 * nthreads)      // one round for workgroups of 256 threads and more
     {
-        uint4 v[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-        {
-            const int i = base + k * nthreads;
-            if (i < NQ) v[k] = s4[i];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-        {
-            const int i = base + k * nthreads;
-            if (i < NQ) d4[i] = v[k];
-        }
+        // (four named registers, not an array: conditionally written arrays go to scratch memory)
+        const int i0 = base, i1 = base + nthreads, i2 = base + 2 * nthreads, i3 = base + 3 * nthreads;
+        uint4 a = make_uint4(0, 0, 0, 0), b = a, c = a, d = a;
+        if (i0 < NQ) a = s4[i0];
+        if (i1 < NQ) b = s4[i1];
+        if (i2 < NQ) c = s4[i2];
+        if (i3 < NQ) d = s4[i3];
+        if (i0 < NQ) d4[i0] = a;
+        if (i1 < NQ) d4[i1] = b;
+        if (i2 < NQ) d4[i2] = c;
+        if (i3 < NQ) d4[i3] = d;
     }
 }
 
@@ -95,9 +93,11 @@ struct HqSeg { int seg, len, warm; };      // segments per chain, samples per se
 
 // horizontal recurrence: a workgroup of 256 threads = H_ROWS rows x up to H_SEG segments
 // `groups`: row groups (of H_ROWS rows) a workgroup works off one after the other on the table it staged once
-template <typename PIX, int SH>
+// HSEG: the segments a row is cut into at most (a power of two) = the lanes a row takes; 256 / HSEG rows per group
+template <typename PIX, int SH, int HSEG>
 __device__ __forceinline__ void hq_h_rows(const HqPlane &P, const HqSeg &g, int groups)
 {
+    constexpr int H_SEG = HSEG, H_ROWS = 256 / HSEG;
     if (!P.spatial_on || (int)blockIdx.x * groups * H_ROWS >= P.h) return;   // (the grid is sized for the luma plane)
     __shared__ __attribute__((aligned(16))) int16_t lut[LUT_N];
     __shared__ uint32_t s_in[H_ROWS][H_SEG], s_out[H_ROWS][H_SEG];
@@ -135,41 +135,61 @@ __device__ __forceinline__ void hq_h_rows(const HqPlane &P, const HqSeg &g, int 
             run = lowpass((int)run, (int)hq_load<PIX, SH>(s, x), lut);
             if (x >= x0) o[x] = (uint16_t)run;
         }
-        // one 16-byte load per NS samples, the next load in flight while the chain works through this one
+        // NS samples of one 16-byte load: the chain through them and, from the segment's own first sample on, their results
         const PIX *sp = reinterpret_cast<const PIX *>(s);
-        uint4 nxt = x + NS <= x1 ? *reinterpret_cast<const uint4 *>(sp + x) : make_uint4(0, 0, 0, 0);
-        for (; x + NS <= x1; x += NS)
-        {
-            const uint4 v = nxt;
-            if (x + 2 * NS <= x1) nxt = *reinterpret_cast<const uint4 *>(sp + x + NS);
+        // (results as packed pairs in dwords: arrays of halfwords end up in scratch memory)
+        auto chain16 = [&](const uint4 &v, int xx, uint32_t (&rp)[NS / 2]) {
             const uint32_t wds[4] = { v.x, v.y, v.z, v.w };
-            uint16_t r[NS];
-            if (x == x0) s_in[rl][seg] = run;                  // x0 is a multiple of 16: a group is kept or dropped whole
+            if (xx == x0) s_in[rl][seg] = run;                 // x0 is a multiple of 16: a block is kept or dropped whole
 #pragma unroll
-            for (int k = 0; k < NS; k++)
+            for (int k = 0; k < NS; k += 2)
             {
-                const uint32_t px = sizeof(PIX) == 1 ? (wds[k >> 2] >> (8 * (k & 3))) & 0xffu : (wds[k >> 1] >> (16 * (k & 1))) & 0xffffu;
-                run = lowpass((int)run, (int)load_sh<SH>(px), lut);
-                r[k] = (uint16_t)run;
+                const uint32_t p0 = sizeof(PIX) == 1 ? (wds[k >> 2] >> (8 * (k & 3))) & 0xffu : wds[k >> 1] & 0xffffu;
+                const uint32_t p1 = sizeof(PIX) == 1 ? (wds[k >> 2] >> (8 * ((k + 1) & 3))) & 0xffu : wds[k >> 1] >> 16;
+                run = lowpass((int)run, (int)load_sh<SH>(p0), lut);
+                const uint32_t lo = run & 0xffffu;
+                run = lowpass((int)run, (int)load_sh<SH>(p1), lut);
+                rp[k >> 1] = lo | (run << 16);
             }
-            if (x < x0) continue;
-            if (((uintptr_t)(o + x) & 15) == 0)
+        };
+        auto store16 = [&](int xx, const uint32_t (&rp)[NS / 2]) {
+            if (xx < x0) return;
+            if (((uintptr_t)(o + xx) & 15) == 0)
             {
 #pragma unroll
                 for (int q = 0; q < NS / 8; q++)
-                {
-                    uint4 pk;
-                    pk.x = r[8 * q + 0] | (r[8 * q + 1] << 16); pk.y = r[8 * q + 2] | (r[8 * q + 3] << 16);
-                    pk.z = r[8 * q + 4] | (r[8 * q + 5] << 16); pk.w = r[8 * q + 6] | (r[8 * q + 7] << 16);
-                    reinterpret_cast<uint4 *>(o + x)[q] = pk;
-                }
+                    reinterpret_cast<uint4 *>(o + xx)[q] = make_uint4(rp[4 * q], rp[4 * q + 1], rp[4 * q + 2], rp[4 * q + 3]);
             }
             else
             {
 #pragma unroll
-                for (int k = 0; k < NS; k++) o[x + k] = r[k];
+                for (int k = 0; k < NS / 2; k++) { o[xx + 2 * k] = (uint16_t)rp[k]; o[xx + 2 * k + 1] = (uint16_t)(rp[k] >> 16); }
             }
+        };
+        auto block = [&](const uint4 &v, int xx) {
+            uint32_t rp[NS / 2];
+            chain16(v, xx, rp);
+            store16(xx, rp);
+        };
+        // Four loads = 64 bytes of the row at a time, and the 128 bytes of results stored together.  A lane reads its own
+        // stretch of the row, 64 lanes 64 different cache lines per load instruction: taken 16 bytes at a time with sixteen
+        // chain steps in between, a line is gone from the 16 KB L1 of a CU with 32 such waves before its next 16 bytes are
+        // asked for; asked for together they are one line fetch (103 -> 95 us per 16 frames; the pass stays the slowest of
+        // the three at 77 us - every memory instruction of a wave still touches 64 lines).
+        constexpr int GL = 4;
+        for (; x + GL * NS <= x1; x += GL * NS)
+        {
+            uint4 v[GL];
+#pragma unroll
+            for (int g4 = 0; g4 < GL; g4++) v[g4] = *reinterpret_cast<const uint4 *>(sp + x + g4 * NS);
+            // ... and the results leave together too: 128 bytes of the lane's own line in one burst
+            uint32_t rp[GL][NS / 2];
+#pragma unroll
+            for (int g4 = 0; g4 < GL; g4++) chain16(v[g4], x + g4 * NS, rp[g4]);
+#pragma unroll
+            for (int g4 = 0; g4 < GL; g4++) store16(x + g4 * NS, rp[g4]);
         }
+        for (; x + NS <= x1; x += NS) block(*reinterpret_cast<const uint4 *>(sp + x), x);
         for (; x < x1; x++)
         {
             if (x == x0) s_in[rl][seg] = run;
@@ -203,7 +223,7 @@ __device__ __forceinline__ void hq_h_rows(const HqPlane &P, const HqSeg &g, int 
 template <typename PIX, int SH>
 __global__ __launch_bounds__(256) void hqdn3d_h_kernel(HqArgs a, HqSeg g)
 {
-    hq_h_rows<PIX, SH>(a.pl[blockIdx.y], g, 1);
+    hq_h_rows<PIX, SH, H_SEG>(a.pl[blockIdx.y], g, 1);
 }
 
 // Several frames per launch.  The two spatial recurrences of a frame do not look at any other frame, so the frames of
@@ -214,7 +234,12 @@ __global__ __launch_bounds__(256) void hqdn3d_h_kernel(HqArgs a, HqSeg g)
 constexpr int HQ_BATCH = 16;
 // a workgroup of the batched horizontal pass takes three row groups: a 1080p batch is then 1 450 workgroups, all
 // resident at once (eight to a CU), instead of 4 300 in two and a bit rounds of which the last runs nearly empty
-constexpr int H_GROUPS = 3;
+// A batch has rows in plenty, so its chains are cut into FEWER and LONGER segments: a segment of 240 samples with its
+// 64 samples of warm-up does 1.27 x the serial work where one of 64 does 2 x - and with eight waves to a SIMD the
+// recurrences are bound by instruction issue, i.e. by the work (SQ_WAIT_ANY 68 % of the wave cycles with the short
+// segments, but 22 M vector instructions where the serial walk has 11 M).
+constexpr int HB_SEG = 8, HB_ROWS = 256 / HB_SEG, VB_SEG = 4;
+constexpr int H_GROUPS = 1;
 struct HqBatch
 {
     const uint8_t *src[HQ_BATCH][3];
@@ -242,7 +267,7 @@ __device__ __forceinline__ HqPlane hq_batch_plane(const HqBatch &B, int f, int c
 template <typename PIX, int SH>
 __global__ __launch_bounds__(256) void hqdn3d_h_batch_kernel(HqBatch B, HqSeg g)
 {
-    hq_h_rows<PIX, SH>(hq_batch_plane(B, blockIdx.z, blockIdx.y), g, H_GROUPS);
+    hq_h_rows<PIX, SH, HB_SEG>(hq_batch_plane(B, blockIdx.z, blockIdx.y), g, H_GROUPS);
 }
 
 // vertical recurrence + temporal step: a workgroup = 64 columns x up to 16 segments of rows.
@@ -566,11 +591,11 @@ public:
                 g.warm = warm;
                 return g;
             };
-            const HqSeg gh = cut(max_w, 64, 16, H_SEG), gv = cut(max_h, 64, 1, MAX_SEG);
+            const HqSeg gh = cut(max_w, (max_w + HB_SEG - 1) / HB_SEG, 16, HB_SEG), gv = cut(max_h, (max_h + VB_SEG - 1) / VB_SEG, 1, VB_SEG);
 #define HQ_GO_N(PIX, SH) do { \
                 if (any_spatial) \
                 { \
-                    HBHIP_LAUNCH(ctx, "hqdn3d_h", (hqdn3d_h_batch_kernel<PIX, SH>), dim3((max_h + H_ROWS * H_GROUPS - 1) / (H_ROWS * H_GROUPS), 3, k), dim3(256), 0, B, gh); \
+                    HBHIP_LAUNCH(ctx, "hqdn3d_h", (hqdn3d_h_batch_kernel<PIX, SH>), dim3((max_h + HB_ROWS * H_GROUPS - 1) / (HB_ROWS * H_GROUPS), 3, k), dim3(256), 0, B, gh); \
                     HBHIP_LAUNCH(ctx, "hqdn3d_v", (hqdn3d_v_batch_kernel<PIX, SH>), dim3((max_w + 63) / 64, 3, k), dim3(64 * gv.seg), 0, B, gv); \
                 } \
                 HBHIP_LAUNCH(ctx, "hqdn3d_t", (hqdn3d_tn_kernel<PIX, SH>), dim3((max_w + 1023) / 1024, max_h, 3), dim3(256), 0, B); \
