@@ -564,7 +564,7 @@ def run_chain(args, world, rank, local_rank):
             "value": round(frames_total / dt_max, 2), "unit": "output frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt_max / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("u8" if depth == 8 else f"u16, {depth}-bit samples") + " (f32 NLMeans weights, f64 scaler / sharpen mix as the reference)",
+            "dtype": ("u8" if depth == 8 else f"u16, {depth}-bit samples") + " (f32 NLMeans weights, 16-bit fixed-point scaler as zimg, f64 sharpen mix as the reference)",
             "data": "synthetic",
             "config": {"workload": wl["text"] + (" + comb detect in front (selective decomb, mode 63)" if args.comb_detect else ""),
                        "input_frames_per_step": B * len(lanes), "output_frames_per_step": 2 * B * len(lanes),
@@ -612,6 +612,49 @@ def run_chain(args, world, rank, local_rank):
         ln.close()
 
 
+def dry_run(args, world, rank):
+    """What `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` goes through around the kernels, on
+    the CPU with gloo in place of RCCL (tests/test_dist_gloo.py runs it at world sizes 2 and 4): RANK / WORLD_SIZE /
+    MASTER_* from the environment, the process group, the barrier + max-over-ranks timing, the stream -> rank sharding,
+    the SUM / MAX reduction and ONE line from rank 0.  A "step" here credits the frames a real step would put out and
+    sleeps - nothing is filtered, the line says so (`data`), `value` is not a throughput of anything."""
+    import torch.distributed as dist
+    from handbrake_amd import shard
+    wl = WORKLOADS[args.workload]
+    B = args.batch or wl["batch"]
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        dist.barrier()
+    streams = shard.stream_for_rank(rank, world, world)               # one stream per GPU: rank r owns stream r
+    produced = 0
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.002 * (1 + rank))                                # ranks finish at different times: MAX is exercised
+        produced += (B if args.workload == "nlmeans" else 2 * B) * len(streams)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+    frames_total, dt_max = shard.reduce_throughput(float(produced), dt)
+    pcie = shard.reduce_host_path({"value": produced / dt, "n_out": produced, "seconds": dt})
+    if rank == 0:
+        print(json.dumps({
+            "metric": "filtered frames/sec, 1080p YUV420p NLMeans+decomb chain" if args.workload == "chain"
+                      else "filtered frames/sec (" + args.workload + ")",
+            "value": round(frames_total / dt_max, 2), "unit": "output frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt_max / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "dry-run (no GPU, nothing filtered)",
+            "config": {"workload": wl["text"], "parallelism": f"{world} rank(s) x 1 stream, gloo", "streams_of_rank0": streams},
+            "frames_total": frames_total, "seconds_max": dt_max, "pcie_inclusive": pcie, "roofline": None, "cpu_baseline": None,
+        }), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -637,6 +680,9 @@ def main():
     ap.add_argument("--workload", default="chain", choices=sorted(WORKLOADS),
                     help="chain = BASELINE's metric, configs[3] (default, the line the driver records); nlmeans = "
                          "configs[1]; decomb_eedi2 = configs[2]; chain2160 = one stream of configs[4]")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU, no kernels: the rank plumbing of the multi-GPU launch only (gloo on the CPU) - see "
+                         "dry_run(); the line it prints is labelled and is not a measurement")
     args = ap.parse_args()
 
     import torch
@@ -645,6 +691,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if args.dry_run:
+        return dry_run(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
     torch.cuda.set_device(local_rank)
