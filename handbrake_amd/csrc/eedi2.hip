@@ -971,43 +971,76 @@ __global__ __launch_bounds__(256) void k_dir_map_c(P3 P, int step, int expand, i
     }
 }
 
-__device__ __forceinline__ bool trips(const uint8_t *side, const uint8_t *dc, int x, int from, int to, int lim)
+// a = mskp, b = dmsk in, c = out.  eedi2_filter_map (:538-635): a pixel that carries a direction loses it (-> peak) when
+// the map breaks along that direction on the row above AND on the row below - two short walks (at most 9 pixels: the
+// direction / 16) with an early exit.  One pixel per thread made this pass 70 scalar and 38 vector instructions per wave
+// around four dependent byte loads from memory (mask, map, then a pair per step of each walk): it ran at the scalar unit's
+// rate and the memory latency, not at its bytes.  Here a workgroup stages its 4 + 2 rows of the map (256 columns + 8 either
+// side) in LDS with dword loads, a thread owns an aligned dword of its row (mask and output as dwords), and the walks of
+// its four pixels read bytes from LDS.
+constexpr int FM_W = 256, FM_R = 4, FM_HALO = 8, FM_LW = FM_W + 2 * FM_HALO;
+
+__device__ __forceinline__ bool trips(const uint8_t *side, const uint8_t *dc, int from, int to, int lim)
 {
-    const int ref = dc[x];
+    const int ref = dc[0];
     for (int j = from; j <= to; j++)
     {
-        const int s = side[x + j], c = dc[x + j];
+        const int s = side[j], c = dc[j];
         if ((iabs(s - ref) > lim && s != PEAK) || (c == PEAK && s == PEAK) || (iabs(c - ref) > lim && c != PEAK))
             return true;
     }
     return false;
 }
 
-// a = mskp, b = dmsk in, c = out
-__global__ void k_filter_map(P3 P)
+__global__ __launch_bounds__(256) void k_filter_map(P3 P)
 {
-    XY_PLANE(P);
-    if (x >= width || y >= height) return;
-    const uint8_t *dc = Q.b + (size_t)y * pitch;
-    int out = dc[x];
-    if (x >= 1 && x < width - 1 && y >= 1 && y < height - 1 && dc[x] != PEAK && Q.a[(size_t)y * pitch + x] == PEAK)
+    __shared__ __attribute__((aligned(16))) uint8_t s_d[FM_R + 2][FM_LW];
+    FIELD_PLANE(P);
+    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
+    const int bx0 = blockIdx.x * FM_W, by0 = blockIdx.y * FM_R;
+    if (bx0 >= width || by0 >= height) return;                   // whole workgroup outside
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    for (int i = tid; i < (FM_R + 2) * (FM_LW / 4); i += 256)
     {
-        const uint8_t *dp = dc - pitch, *dn = dc + pitch;
-        int dir = ((int)dc[x] - NEUTRAL) >> 2;
+        const int r = i / (FM_LW / 4), c4 = i - r * (FM_LW / 4);
+        const int yy = by0 - 1 + r, col = bx0 - FM_HALO + 4 * c4;
+        uint32_t v = 0;                                          // outside the plane: never looked at (the walks are clipped to the row)
+        if (yy >= 0 && yy < height && col >= 0 && col < pitch) v = *reinterpret_cast<const uint32_t *>(Q.b + (size_t)yy * pitch + col);
+        reinterpret_cast<uint32_t *>(&s_d[0][0])[i] = v;
+    }
+    const int x = bx0 + 4 * threadIdx.x, y = by0 + threadIdx.y;
+    const bool inside = x < width && y < height;
+    uint32_t m4 = 0;
+    if (inside && y >= 1 && y < height - 1) m4 = *reinterpret_cast<const uint32_t *>(Q.a + (size_t)y * pitch + x);
+    __syncthreads();
+    if (!inside) return;
+    const uint8_t *rc = &s_d[threadIdx.y + 1][FM_HALO + 4 * threadIdx.x];
+    uint32_t out4 = *reinterpret_cast<const uint32_t *>(rc);
+    // candidates: mask peak, map not peak, inside the frame of :557-560 (m4 is 0 on the first / last row)
+    uint32_t cand = (ff_bytes(m4) & ~ff_bytes(out4)) >> 7;
+    cand &= mf_bytes_in(x, 1, width - 1);
+    for (int k = 0; k < 4; k++)
+    {
+        if (!((cand >> (8 * k)) & 1u)) continue;
+        const int xx = x + k;
+        const uint8_t *dc = rc + k, *dp = dc - FM_LW, *dn = dc + FM_LW;
+        int dir = ((int)dc[0] - NEUTRAL) >> 2;
         const int lim = max(iabs(dir) * 2, 12 << 2);
         dir >>= 2;
         bool ict;
-        if (dir < 0) ict = trips(dp, dc, x, max(-x, dir), 0, lim);
-        else         ict = trips(dp, dc, x, 0, min(width - x - 1, dir), lim);
+        if (dir < 0) ict = trips(dp, dc, max(-xx, dir), 0, lim);
+        else         ict = trips(dp, dc, 0, min(width - xx - 1, dir), lim);
         if (ict)
         {
             bool icb;
-            if (dir < 0) icb = trips(dn, dc, x, 0, min(width - x - 1, iabs(dir)), lim);
-            else         icb = trips(dn, dc, x, max(-x, -dir), 0, lim);
-            if (icb) out = PEAK;
+            if (dir < 0) icb = trips(dn, dc, 0, min(width - xx - 1, iabs(dir)), lim);
+            else         icb = trips(dn, dc, max(-xx, -dir), 0, lim);
+            if (icb) out4 |= 0xffu << (8 * k);
         }
     }
-    Q.c[(size_t)y * pitch + x] = (uint8_t)out;
+    uint8_t *o = Q.c + (size_t)y * pitch + x;
+    if (x + 3 < width) *reinterpret_cast<uint32_t *>(o) = out4;
+    else for (int k = 0; k < 4 && x + k < width; k++) o[k] = (uint8_t)(out4 >> (8 * k));
 }
 
 // a = msk2p, b = dmsk (tmp2p2), c = out (tmp2p)
@@ -1933,10 +1966,6 @@ int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc)
     uint32_t *cand = cand_ + (size_t)s0 * (slot_bytes_ / sizeof(uint32_t));
     const dim3 blk(64, 4);
     const unsigned gz = 3u * (unsigned)n;
-    auto grid_for = [&](const EediFrame &f, bool whole_pitch) {
-        const int w = whole_pitch ? f.stride[0] : f.width[0];
-        return dim3((w + 63) / 64, (f.height[0] + 3) / 4, gz);
-    };
     auto grid4_for = [&](const EediFrame &f, bool whole_pitch) {        // kernels with 4 pixels per thread
         const int w = whole_pitch ? f.stride[0] : f.width[0];
         return dim3((w + 255) / 256, (f.height[0] + 3) / 4, gz);
@@ -2007,7 +2036,7 @@ int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc)
     bind(P.a, mskp); bind(P.b, dstp); bind(P.c, tmpp);
     dir_map("eedi2_expand_dir_map", srcp, P, 1, 1);
     bind(P.a, mskp); bind(P.b, tmpp); bind(P.c, dstp);
-    HBHIP_LAUNCH(lc, "eedi2_filter_map", k_filter_map, grid_for(srcp, false), blk, 0, P);
+    HBHIP_LAUNCH(lc, "eedi2_filter_map", k_filter_map, grid4_for(srcp, false), blk, 0, P);
     // line doubling of srcp / dstp / mskp + mark_directions_2x in one launch (full-height geometry)
     geom(P, dst2p);
     bind(P.g, srcp); bind(P.b, dstp); bind(P.a, mskp);
