@@ -633,7 +633,10 @@ __device__ __forceinline__ int calc_dir_search(const uint32_t *tr, uint64_t pass
         const int lo = k == 2 ? v0 : (k == 5 ? v2 : v1);        // v[(k-1)>>1]: 0 1 1 2 for k = 2 3 4 5
         const int hi = k >= 4 ? v2 : v1;                         // v[k>>1]:     1 1 2 2
         const int mid = (lo + hi + 1) >> 1;
-        const int tlim = max((int)c_limlut[iabs(mid)] >> 2, 2);
+        // max(limlut[|mid|] >> 2, 2) without the table (a dependent load per pixel): |mid| <= 30 here, and the table
+        // (eedi2.c:21-25) is 12 from entry 13 on and below 12 before it - 3 and 2 after the shift and the max
+        static_assert(CD_HALO - 2 <= 30, "the closed form of limlut covers entries 0..30");
+        const int tlim = iabs(mid) >= 13 ? 3 : 2;
         int sum = 0, cnt = 0;
         if (iabs(v0 - mid) <= tlim) { cnt++; sum += v0; }        // the sentinels fail the test by themselves
         if (iabs(v1 - mid) <= tlim) { cnt++; sum += v1; }
@@ -980,16 +983,14 @@ __global__ __launch_bounds__(256) void k_dir_map_c(P3 P, int step, int expand, i
 // its four pixels read bytes from LDS.
 constexpr int FM_W = 256, FM_R = 4, FM_HALO = 8, FM_LW = FM_W + 2 * FM_HALO;
 
-__device__ __forceinline__ bool trips(const uint8_t *side, const uint8_t *dc, int from, int to, int lim)
+// The test of a step (:569-571 and its three siblings) without a branch per clause: every clause is the SIGN of an
+// integer - lim - |s - ref| is negative when s is off by more than lim, s - 255 is negative unless s is the peak,
+// 509 - c - s is negative only when both are the peak - and the step trips when the sign of
+// (off(s) & notpeak(s)) | (off(c) & notpeak(c)) | bothpeak is set.  v_sad_u16 of two bytes is their absolute difference.
+__device__ __forceinline__ int fm_step(uint32_t s, uint32_t c, uint32_t ref, int lim)
 {
-    const int ref = dc[0];
-    for (int j = from; j <= to; j++)
-    {
-        const int s = side[j], c = dc[j];
-        if ((iabs(s - ref) > lim && s != PEAK) || (c == PEAK && s == PEAK) || (iabs(c - ref) > lim && c != PEAK))
-            return true;
-    }
-    return false;
+    const int off_s = lim - (int)__builtin_amdgcn_sad_u16(s, ref, 0u), off_c = lim - (int)__builtin_amdgcn_sad_u16(c, ref, 0u);
+    return (off_s & (int)(s - 255u)) | (off_c & (int)(c - 255u)) | (509 - (int)c - (int)s);
 }
 
 __global__ __launch_bounds__(256) void k_filter_map(P3 P)
@@ -1019,24 +1020,31 @@ __global__ __launch_bounds__(256) void k_filter_map(P3 P)
     // candidates: mask peak, map not peak, inside the frame of :557-560 (m4 is 0 on the first / last row)
     uint32_t cand = (ff_bytes(m4) & ~ff_bytes(out4)) >> 7;
     cand &= mf_bytes_in(x, 1, width - 1);
+    // Both walks of a pixel in one loop, neither with an early exit: the pixel turns peak when the walk above trips
+    // somewhere AND the walk below does (:565-627 take the second only after the first has tripped - the same verdict).
+    // With neg = min(dir, 0), pos = max(dir, 0) the four ranges of :565-620 are [max(-x, neg), min(w - x - 1, pos)] above
+    // and [max(-x, -pos), min(w - x - 1, -neg)] below; the shorter walk repeats its last step.
+#pragma unroll 1
     for (int k = 0; k < 4; k++)
     {
         if (!((cand >> (8 * k)) & 1u)) continue;
         const int xx = x + k;
         const uint8_t *dc = rc + k, *dp = dc - FM_LW, *dn = dc + FM_LW;
-        int dir = ((int)dc[0] - NEUTRAL) >> 2;
+        const uint32_t ref = dc[0];
+        int dir = ((int)ref - NEUTRAL) >> 2;
         const int lim = max(iabs(dir) * 2, 12 << 2);
         dir >>= 2;
-        bool ict;
-        if (dir < 0) ict = trips(dp, dc, max(-xx, dir), 0, lim);
-        else         ict = trips(dp, dc, 0, min(width - xx - 1, dir), lim);
-        if (ict)
+        const int neg = min(dir, 0), pos = max(dir, 0);
+        const int tf = max(-xx, neg), tt = min(width - xx - 1, pos), bf = max(-xx, -pos), bt = min(width - xx - 1, -neg);
+        const int n = max(tt - tf, bt - bf);
+        int any_t = 0, any_b = 0;
+        for (int i = 0; i <= n; i++)
         {
-            bool icb;
-            if (dir < 0) icb = trips(dn, dc, 0, min(width - xx - 1, iabs(dir)), lim);
-            else         icb = trips(dn, dc, max(-xx, -dir), 0, lim);
-            if (icb) out4 |= 0xffu << (8 * k);
+            const int jt = min(tf + i, tt), jb = min(bf + i, bt);
+            any_t |= fm_step(dp[jt], dc[jt], ref, lim);
+            any_b |= fm_step(dn[jb], dc[jb], ref, lim);
         }
+        if ((any_t & any_b) < 0) out4 |= 0xffu << (8 * k);
     }
     uint8_t *o = Q.c + (size_t)y * pitch + x;
     if (x + 3 < width) *reinterpret_cast<uint32_t *>(o) = out4;
