@@ -64,14 +64,11 @@ struct P3
 struct PL { uint8_t *a, *b, *c, *d, *e, *f, *g; };
 __device__ __forceinline__ PL plane_ptrs(const P3 &P, int pl, size_t off)
 {
-    PL q = { P.a[pl], P.b[pl], P.c[pl], P.d[pl], P.e[pl], P.f[pl], P.g[pl] };
-    if (q.a) q.a += off;
-    if (q.b) q.b += off;
-    if (q.c) q.c += off;
+    // only d is ever tested for "not bound" (the optional copy of the dir-map passes); the others are either bound or not
+    // looked at by the pass, so they move without the test (a compare and two selects on the scalar unit per pointer and
+    // wave - these passes run near the scalar issue rate, tools/salu_rate.hip)
+    PL q = { P.a[pl] + off, P.b[pl] + off, P.c[pl] + off, P.d[pl], P.e[pl] + off, P.f[pl] + off, P.g[pl] + off };
     if (q.d) q.d += off;
-    if (q.e) q.e += off;
-    if (q.f) q.f += off;
-    if (q.g) q.g += off;
     return q;
 }
 #define FIELD_PLANE(P)                                                      \
@@ -813,14 +810,34 @@ __device__ __forceinline__ int dir_map_px(int u0, int u1, int u2, int c0, int c1
     return val & 0xff;
 }
 
+// In the _2x forms a thread takes the rows 2r and 2r + 1 of its dword column: the one with the parity of the rebuilt rows
+// is worked on, the other only copied (a wave per copied row spent more on finding its plane and field - scalar
+// instructions - than on its dword).
 __global__ __launch_bounds__(256) void k_dir_map4(P3 P, int step, int expand)
 {
-    XY4_PLANE(P);
+    FIELD_PLANE(P);
+    const int x = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
+    const int r = blockIdx.y * blockDim.y + threadIdx.y;
+    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
     const int y0 = step == 1 ? 1 : 2 - tff;
-    if (x >= width || y >= height) return;
+    const int y = step == 1 ? r : 2 * r + (y0 & 1);
+    if (x >= width) return;
+    // the row of the pair that is never rebuilt (bit_blit only): fetched now, stored after the other row's work, so that
+    // its load is one of the thread's loads in flight and not a round trip of its own
+    const int yc = 2 * r + 1 - (y0 & 1);
+    const bool copy = step != 1 && yc < height;
+    uint32_t vcopy = 0;
+    if (copy) vcopy = *reinterpret_cast<const uint32_t *>(Q.b + (size_t)yc * pitch + x);
+    auto put_copy = [&]() {
+        if (!copy) return;
+        int out[4] = { (int)(vcopy & 0xff), (int)((vcopy >> 8) & 0xff), (int)((vcopy >> 16) & 0xff), (int)(vcopy >> 24) };
+        st4(Q.c + (size_t)yc * pitch + x, out, x, width);
+        if (Q.d) st4(Q.d + (size_t)yc * pitch + x, out, x, width);
+    };
+    if (y >= height) { put_copy(); return; }
     const uint8_t *dc = Q.b + (size_t)y * pitch + x;
     uint8_t *o = Q.c + (size_t)y * pitch + x;
-    const bool row_ok = step == 1 ? (y >= 1 && y < height - 1) : (y >= y0 && y < height - 1 && ((y - y0) & 1) == 0);
+    const bool row_ok = step == 1 ? (y >= 1 && y < height - 1) : (y >= y0 && y < height - 1);
     if (!row_ok)
     {
         // bit_blit only (and the optional copy of the input, the eedi2_bit_blit before post-processing)
@@ -828,6 +845,7 @@ __global__ __launch_bounds__(256) void k_dir_map4(P3 P, int step, int expand)
         int out[4] = { (int)(v & 0xff), (int)((v >> 8) & 0xff), (int)((v >> 16) & 0xff), (int)(v >> 24) };
         st4(o, out, x, width);
         if (Q.d) st4(Q.d + (size_t)y * pitch + x, out, x, width);
+        put_copy();
         return;
     }
     const Win12 wc = ldwin(dc), wu = ldwin(dc - (ptrdiff_t)step * pitch), wd = ldwin(dc + (ptrdiff_t)step * pitch);
@@ -856,6 +874,7 @@ __global__ __launch_bounds__(256) void k_dir_map4(P3 P, int step, int expand)
         int in[4] = { wb(wc, 0), wb(wc, 1), wb(wc, 2), wb(wc, 3) };
         st4(Q.d + (size_t)y * pitch + x, in, x, width);
     }
+    put_copy();
 }
 
 // k_dir_map4 in two phases.  Which pixels reach the sort is decided by byte arithmetic on whole dwords
@@ -884,14 +903,23 @@ __global__ __launch_bounds__(256) void k_dir_map_c(P3 P, int step, int expand, i
     __shared__ int s_count;
     FIELD_PLANE(P);
     const int y0 = step == 1 ? 1 : 2 - tff;
-    const int bx0 = 4 * (blockIdx.x * 64), x = bx0 + 4 * threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    // step 2: a thread row takes the PAIR of rows 2r, 2r + 1 - the one with the rebuilt rows' parity goes through the
+    // pass, the other is only copied (k_dir_map4)
+    const int rb = blockIdx.y * 4, r = rb + threadIdx.y;
+    const int bx0 = 4 * (blockIdx.x * 64), x = bx0 + 4 * threadIdx.x, y = step == 1 ? r : 2 * r + (y0 & 1);
+    const int yb = step == 1 ? rb : 2 * rb + (y0 & 1);                              // row of thread row 0
     const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
-    if (bx0 >= width || (int)blockIdx.y * 4 >= height) return;                       // whole workgroup outside
+    if (bx0 >= width || (step == 1 ? rb : 2 * rb) >= height) return;                 // whole workgroup outside
     const int tid = threadIdx.y * 64 + threadIdx.x;
     if (tid == 0) s_count = 0;
     __syncthreads();
+    // the copied row of the pair: fetched now, stored when the workgroup is done (see k_dir_map4)
+    const int yc = 2 * r + 1 - (y0 & 1);
+    const bool copy = step != 1 && x < width && yc < height;
+    uint32_t vcopy = 0;
+    if (copy) vcopy = *reinterpret_cast<const uint32_t *>(Q.b + (size_t)yc * pitch + x);
     const bool inside = x < width && y < height;
-    const bool row_ok = step == 1 ? (y >= 1 && y < height - 1) : (y >= y0 && y < height - 1 && ((y - y0) & 1) == 0);
+    const bool row_ok = step == 1 ? (y >= 1 && y < height - 1) : (y >= y0 && y < height - 1);
     const uint8_t *dc = Q.b + (size_t)y * pitch + x;
     if (inside)
     {
@@ -938,7 +966,7 @@ __global__ __launch_bounds__(256) void k_dir_map_c(P3 P, int step, int expand, i
     for (int i = tid; i < count; i += 256)
     {
         const int e = s_list[i], ly = e >> 8, lx = e & 255;
-        const int yy = blockIdx.y * 4 + ly;
+        const int yy = yb + step * ly;
         const uint8_t *c = Q.b + (size_t)yy * pitch + bx0 + lx;
         const uint8_t *up = c - (ptrdiff_t)step * pitch, *dn = c + (ptrdiff_t)step * pitch;
         const bool up_ok = step == 1 || yy > 1, dn_ok = step == 1 || yy < height - 2;
@@ -971,6 +999,12 @@ __global__ __launch_bounds__(256) void k_dir_map_c(P3 P, int step, int expand, i
             }
             if (any) st4(d, out, x, width);
         }
+    }
+    if (copy)
+    {
+        int in[4] = { (int)(vcopy & 0xff), (int)((vcopy >> 8) & 0xff), (int)((vcopy >> 16) & 0xff), (int)(vcopy >> 24) };
+        st4(Q.c + (size_t)yc * pitch + x, in, x, width);
+        if (Q.d) st4(Q.d + (size_t)yc * pitch + x, in, x, width);
     }
 }
 
@@ -1060,21 +1094,40 @@ __global__ __launch_bounds__(256) void k_filter_map(P3 P)
 
 // Four pixels per thread (see k_dir_map4): the three line doublings are dword copies, and only the
 // rows mark_directions_2x rebuilds (every other one) load the two neighbouring half-height rows.
+// A thread takes the rows 2r and 2r + 1 of its dword column: both are doubled from half-height row r (three loads for six
+// stores), one of them at most is a row mark_directions_2x rebuilds, the other is the memset's 255 - a wave of its own
+// per row spent more scalar instructions on finding its plane and field than vector ones on its dword.
 __global__ __launch_bounds__(256) void k_mark_2x4(P3 P)
 {
-    XY4_PLANE(P);
+    FIELD_PLANE(P);
+    const int x = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
+    const int r = blockIdx.y * blockDim.y + threadIdx.y;
+    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
     const int y0 = 2 - tff;
-    if (x >= pitch || y >= height) return;
+    if (x >= pitch || 2 * r >= height) return;
+    const bool two = 2 * r + 1 < height;
     {
-        const size_t hs = (size_t)(y >> 1) * pitch + x, fs = (size_t)y * pitch + x;
-        *reinterpret_cast<uint32_t *>(Q.d + fs) = *reinterpret_cast<const uint32_t *>(Q.g + hs);
-        *reinterpret_cast<uint32_t *>(Q.e + fs) = *reinterpret_cast<const uint32_t *>(Q.b + hs);
-        *reinterpret_cast<uint32_t *>(Q.f + fs) = *reinterpret_cast<const uint32_t *>(Q.a + hs);
+        const size_t hs = (size_t)r * pitch + x, fs = (size_t)(2 * r) * pitch + x;
+        const uint32_t vg = *reinterpret_cast<const uint32_t *>(Q.g + hs), vb = *reinterpret_cast<const uint32_t *>(Q.b + hs),
+                       va = *reinterpret_cast<const uint32_t *>(Q.a + hs);
+        *reinterpret_cast<uint32_t *>(Q.d + fs) = vg;
+        *reinterpret_cast<uint32_t *>(Q.e + fs) = vb;
+        *reinterpret_cast<uint32_t *>(Q.f + fs) = va;
+        if (two)
+        {
+            *reinterpret_cast<uint32_t *>(Q.d + fs + pitch) = vg;
+            *reinterpret_cast<uint32_t *>(Q.e + fs + pitch) = vb;
+            *reinterpret_cast<uint32_t *>(Q.f + fs + pitch) = va;
+        }
     }
+    // the row of the pair with the parity of the rebuilt rows, and the other one
+    const int y = 2 * r + (y0 & 1), yc = 2 * r + 1 - (y0 & 1);
+    if (yc < height) *reinterpret_cast<uint32_t *>(Q.c + (size_t)yc * pitch + x) = 0xffffffffu;      // memset(dstp, 255, pitch*height)
+    if (y >= height) return;
     uint32_t *o = reinterpret_cast<uint32_t *>(Q.c + (size_t)y * pitch + x);
-    if (!(y >= y0 && y < height - 1 && ((y - y0) & 1) == 0))
+    if (!(y >= y0 && y < height - 1))
     {
-        *o = 0xffffffffu;                                         // memset(dstp, 255, pitch*height)
+        *o = 0xffffffffu;
         return;
     }
     const Win12 wa = ldwin(Q.b + (ptrdiff_t)((y - 1) >> 1) * pitch + x), wbn = ldwin(Q.b + (ptrdiff_t)((y + 1) >> 1) * pitch + x);
@@ -1540,18 +1593,27 @@ __global__ __launch_bounds__(256) void k_lattice_cand_q(P3 P, uint32_t *__restri
     }
 }
 
-// grid.y = processed rows (+1 for the border-row copy); one workgroup of LR_T threads per row, one
-// pixel per thread and pass over the row.  Which outcome a pixel takes depends only on which outcome
-// its left neighbour took (that decides the value left standing at x-1, :1194), so every pixel is a
-// 2-state map; the maps are composed by a prefix scan inside each wave, the 16 wave maps are chained
-// by one thread, and the incoming state of the next LR_T pixels is the outcome of the last one.
-constexpr int LR_T = 1024;
+// grid.y = processed rows (+1 for the border-row copy); one workgroup of LR_T threads per row, FOUR pixels per thread
+// and pass over the row (LR_PX pixels).  Which outcome a pixel takes depends only on which outcome its left neighbour
+// took (that decides the value left standing at x-1, :1194), so every pixel is a 2-state map (bit s = its outcome when
+// the left pixel took outcome s).  A thread composes the maps of its four pixels, the threads' maps are composed by a
+// prefix scan inside each wave, the wave maps are chained by one thread, and the state entering the next LR_PX pixels
+// is the outcome of the last one.  Candidates come in as one 16-byte load, the direction row as a dword, both rows
+// leave as dwords (one pixel per thread, byte loads and stores: 144 us per 16 fields).
+constexpr int LR_T = 256, LR_PX = 4 * LR_T;
+
+// later o earlier: the map that applies `earlier` first
+__device__ __forceinline__ unsigned lr_compose(unsigned later, unsigned earlier)
+{
+    return ((later >> (earlier & 1u)) & 1u) | (((later >> ((earlier >> 1) & 1u)) & 1u) << 1);
+}
 
 __global__ __launch_bounds__(LR_T) void k_lattice_resolve(P3 P, const uint32_t *__restrict__ cand, int cand_pitch,
                                                           int cand_plane_stride)
 {
     __shared__ uint8_t s_wmap[LR_T / 64];        // composed map of each wave
     __shared__ uint8_t s_win[LR_T / 64];         // resolved state entering each wave
+    __shared__ uint8_t s_lim[36];                // eedi2_limlut in LDS: four look-ups per thread and pass
     __shared__ int s_carry;                      // outcome of the last pixel of the previous pass
     FIELD_PLANE(P);
     const int field = tff;
@@ -1574,60 +1636,74 @@ __global__ __launch_bounds__(LR_T) void k_lattice_resolve(P3 P, const uint32_t *
     uint8_t *mid = dst + (size_t)y * pitch;
     uint8_t *dm = Q.a + (size_t)y * pitch;
     const uint32_t *cr = cand + (size_t)pl * cand_plane_stride + (size_t)blockIdx.y * cand_pitch;
+    const bool cr16 = ((reinterpret_cast<uintptr_t>(cr)) & 15u) == 0;      // block-uniform: the row of candidates starts on 16 bytes
     // value standing at dm[x-1] for x == 0: memory just before the row, never written by this pass
     const int before_row = dm[-1];
     if (t == 0) s_carry = 0;
+    if (t < 33) s_lim[t] = c_limlut[t];
     __syncthreads();
 
-    for (int x0 = 0; x0 < width; x0 += LR_T)
+    for (int x0 = 0; x0 < width; x0 += LR_PX)
     {
-        const int x = x0 + t;
-        const bool live = x < width;
-        int d = 0, lim = 0, valA = 0, newA = 0, valB = 0, newB = 0;
-        bool always_a = false, right = false;
-        if (live)
+        const int x = x0 + 4 * t;
+        const int nlive = min(max(width - x, 0), 4);             // pixels of this thread inside the row
+        uint32_t c[4] = { 0u, 0u, 0u, 0u }, d4 = 0u;
+        if (nlive == 4 && cr16)
         {
-            const uint32_t c = cr[x];
-            d = dm[x];
-            lim = c_limlut[iabs(d - NEUTRAL) >> 2];
-            valA = c & 0xff; valB = (c >> 8) & 0xff; newB = (c >> 16) & 0xff;
-            always_a = (c >> 24) & 1; right = (c >> 25) & 1;
-            newA = always_a ? PEAK : NEUTRAL;
+            const uint4 v = *reinterpret_cast<const uint4 *>(cr + x);
+            c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
         }
-        // the two values pixel x-1 can leave behind: from the neighbouring lane, or (first lane of a
-        // wave) from that pixel's candidate word; nothing has been written to this row yet
-        int pa = __shfl_up(newA, 1, 64), pb = __shfl_up(newB, 1, 64);
-        if (lane == 0 && live)
+        else
+            for (int k = 0; k < nlive; k++) c[k] = cr[x + k];
+        if (nlive) d4 = *reinterpret_cast<const uint32_t *>(dm + x);     // the row's pitch is a multiple of 4: the dword is inside it
+        // what the last pixel of the thread to the left can leave behind (pa: outcome A, pb: outcome B); the first lane
+        // of a wave reads that pixel's candidate word; nothing has been written to this row yet
+        const uint32_t cl3 = c[3];
+        int pa = __shfl_up((cl3 >> 24) & 1u ? PEAK : NEUTRAL, 1, 64), pb = __shfl_up((int)((cl3 >> 16) & 0xffu), 1, 64);
+        if (lane == 0 && nlive)
         {
             if (x == 0) { pa = before_row; pb = before_row; }
             else
             {
                 const uint32_t cl = cr[x - 1];
-                pa = ((cl >> 24) & 1) ? PEAK : NEUTRAL;
-                pb = (cl >> 16) & 0xff;
+                pa = ((cl >> 24) & 1u) ? PEAK : NEUTRAL;
+                pb = (int)((cl >> 16) & 0xffu);
             }
         }
-        unsigned m;                                            // bit s = outcome when the left pixel took outcome s
-        if (!live || always_a) m = 0u;
-        else
+        unsigned m[4], pm[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
         {
-            const unsigned oa = (right && iabs(d - pa) > lim) ? 0u : 1u;
-            const unsigned ob2 = (right && iabs(d - pb) > lim) ? 0u : 1u;
-            m = oa | (ob2 << 1);
+            const uint32_t ck = c[k];
+            const int d = (int)((d4 >> (8 * k)) & 0xffu);
+            const int lim = s_lim[iabs(d - NEUTRAL) >> 2];
+            const bool always_a = (ck >> 24) & 1u, right = (ck >> 25) & 1u;
+            if (k >= nlive || always_a) m[k] = 0u;
+            else
+            {
+                const unsigned oa = (right && iabs(d - pa) > lim) ? 0u : 1u;
+                const unsigned ob2 = (right && iabs(d - pb) > lim) ? 0u : 1u;
+                m[k] = oa | (ob2 << 1);
+            }
+            pm[k] = k == 0 ? m[0] : lr_compose(m[k], pm[k - 1]);    // the thread's pixels 0..k, earlier first
+            pa = always_a ? PEAK : NEUTRAL;                          // what pixel k leaves for k + 1
+            pb = (int)((ck >> 16) & 0xffu);
         }
-        // inclusive prefix composition inside the wave: m[x] := m[x] o m[x-1] o ... (earlier map first)
+        // inclusive prefix composition of the threads' maps inside the wave (earlier map first)
+        unsigned tm = pm[3];
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1)
         {
-            const unsigned e = __shfl_up(m, off, 64);
-            if (lane >= off)
-                m = ((m >> (e & 1u)) & 1u) | (((m >> ((e >> 1) & 1u)) & 1u) << 1);
+            const unsigned e = __shfl_up(tm, off, 64);
+            if (lane >= off) tm = lr_compose(tm, e);
         }
-        if (lane == 63) s_wmap[wave] = (uint8_t)m;
+        if (lane == 63) s_wmap[wave] = (uint8_t)tm;
+        unsigned before = __shfl_up(tm, 1, 64);                      // everything left of this thread inside the wave
+        if (lane == 0) before = 2u;                                  // the identity map
         __syncthreads();
         if (t == 0)
         {
-            unsigned state = (unsigned)s_carry;                  // outcome of pixel x0 - 1 (irrelevant for x0 == 0)
+            unsigned state = (unsigned)s_carry;                      // outcome of pixel x0 - 1 (irrelevant for x0 == 0)
             for (int w = 0; w < LR_T / 64; w++)
             {
                 s_win[w] = (uint8_t)state;
@@ -1635,14 +1711,31 @@ __global__ __launch_bounds__(LR_T) void k_lattice_resolve(P3 P, const uint32_t *
             }
         }
         __syncthreads();
-        const unsigned outcome = (m >> s_win[wave]) & 1u;
-        if (live)
+        const unsigned sin = (before >> s_win[wave]) & 1u;           // outcome of the pixel left of this thread's first
+        if (nlive)
         {
-            mid[x] = (uint8_t)(outcome ? valB : valA);
-            const int nd = outcome ? newB : newA;
-            if (nd != d) dm[x] = (uint8_t)nd;
+            uint32_t mid4 = 0u, dm4 = 0u;
+            unsigned last = 0u;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                const unsigned outcome = (pm[k] >> sin) & 1u;
+                const uint32_t ck = c[k];
+                const uint32_t val = outcome ? (ck >> 8) & 0xffu : ck & 0xffu;
+                const uint32_t nd = outcome ? (ck >> 16) & 0xffu : (((ck >> 24) & 1u) ? (uint32_t)PEAK : (uint32_t)NEUTRAL);
+                mid4 |= val << (8 * k);
+                dm4 |= nd << (8 * k);
+                if (k == nlive - 1) last = outcome;
+            }
+            if (nlive == 4)
+            {
+                *reinterpret_cast<uint32_t *>(mid + x) = mid4;
+                *reinterpret_cast<uint32_t *>(dm + x) = dm4;
+            }
+            else
+                for (int k = 0; k < nlive; k++) { mid[x + k] = (uint8_t)(mid4 >> (8 * k)); dm[x + k] = (uint8_t)(dm4 >> (8 * k)); }
+            if (x + nlive == min(x0 + LR_PX, width)) s_carry = (int)last;
         }
-        if (x == min(x0 + LR_T, width) - 1) s_carry = (int)outcome;
         __syncthreads();
     }
 }
@@ -1982,8 +2075,10 @@ int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc)
     auto dir_map = [&](const char *name, const EediFrame &f, const P3 &Pv, int step, int expand, int post = 0) {
         // the queueing form pays where few pixels reach the sort (expand: only peak pixels with >= 5 usable neighbours);
         // filter_dir_map sorts at most masked pixels, there the in-place form is ahead
-        if (!expand) HBHIP_LAUNCH(lc, name, k_dir_map4, grid4_for(f, false), blk, 0, Pv, step, expand);
-        else       { HBHIP_LAUNCH(lc, name, k_dir_map_c, grid4_for(f, false), blk, 0, Pv, step, expand, post); post_folded = post != 0; }
+        // step 2: a thread row per PAIR of rows (the rebuilt one and the copied one)
+        const dim3 g = step == 1 ? grid4_for(f, false) : dim3((f.width[0] + 255) / 256, ((f.height[0] + 1) / 2 + 3) / 4, gz);
+        if (!expand) HBHIP_LAUNCH(lc, name, k_dir_map4, g, blk, 0, Pv, step, expand);
+        else       { HBHIP_LAUNCH(lc, name, k_dir_map_c, g, blk, 0, Pv, step, expand, post); post_folded = post != 0; }
     };
     auto geom = [&](P3 &P, const EediFrame &f) {
         for (int c = 0; c < 3; c++) { P.pitch[c] = f.stride[c]; P.width[c] = f.width[c]; P.height[c] = f.height[c]; }
@@ -2049,12 +2144,15 @@ int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc)
     geom(P, dst2p);
     bind(P.g, srcp); bind(P.b, dstp); bind(P.a, mskp);
     bind(P.d, dst2p); bind(P.e, tmp2p2); bind(P.f, msk2p); bind(P.c, tmp2p);
-    HBHIP_LAUNCH(lc, "eedi2_mark_directions_2x", k_mark_2x4, grid4_for(dst2p, true), blk, 0, P);
+    HBHIP_LAUNCH(lc, "eedi2_mark_directions_2x", k_mark_2x4,                                      // a thread row per PAIR of full-height rows
+                 dim3((dst2p.stride[0] + 255) / 256, ((dst2p.height[0] + 1) / 2 + 3) / 4, gz), blk, 0, P);
     for (int c = 0; c < 3; c++) P.d[c] = P.e[c] = P.f[c] = P.g[c] = nullptr;    // slot d doubles as the dir-map kernels' optional copy target
     bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
     dir_map("eedi2_filter_dir_map_2x", dst2p, P, 2, 0);
     bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
     dir_map("eedi2_expand_dir_map_2x", dst2p, P, 2, 1);
+    // (a workgroup per row here: with the copied row of a pair folded into the workgroup of the rebuilt one, as in the dir-map
+    // passes, this kernel went from 131 to 163-165 us per launch)
     const dim3 fg_grid((dst2p.width[0] + FG_W - 1) / FG_W, dst2p.height[0], gz);
     bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
     HBHIP_LAUNCH(lc, "eedi2_fill_gaps_2x", k_fill_gaps_b, fg_grid, dim3(256), 0, P);

@@ -35,11 +35,7 @@ struct Q3
 struct QL { uint16_t *a, *b, *c; };
 __device__ __forceinline__ QL plane_ptrs16(const Q3 &P, int pl, size_t off)
 {
-    QL q = { P.a[pl], P.b[pl], P.c[pl] };
-    if (q.a) q.a += off;
-    if (q.b) q.b += off;
-    if (q.c) q.c += off;
-    return q;
+    return QL{ P.a[pl] + off, P.b[pl] + off, P.c[pl] + off };     // none is ever tested for "not bound" (eedi2.hip: plane_ptrs)
 }
 #define FIELD16(P)                                                           \
     const int fld = (int)blockIdx.z / 3, pl = (int)blockIdx.z - 3 * fld;     \
