@@ -43,6 +43,17 @@ constexpr size_t GUARD = 32768;   // >= 2 rows + halo of the widest plane the LD
 __constant__ uint8_t c_limlut[33] = { 6, 6, 7, 7, 8, 8, 9, 9, 9, 10, 10, 11, 11, 12, 12, 12, 12, 12, 12, 12,
                                       12, 12, 12, 12, 12, 12, 12, 12, 12, 12, 12, 255, 255 };   // eedi2.c:21-25 stored as u8
 
+// The table in LDS.  From constant memory a look-up is a vector memory load with a per-lane address - a round trip
+// through the L1 in the middle of a pixel's dependency chain (behind its sort, ahead of its vote); from LDS it is one
+// ds_read_u8.  Kernels with a barrier ahead of their first look-up fill one copy per workgroup (lim_fill + their
+// barrier: lattice candidates 276 -> 272, expand_dir_map_2x 78 -> 75 us per launch); the 4-pixel dir-map kernels have no
+// barrier and keep the constant table (a copy per wave, written and read by the wave itself, cost more than it saved).
+constexpr int LIM_N = 33, LIM_PAD = 40;
+__device__ __forceinline__ void lim_fill(uint8_t *tab, int tid)
+{
+    if (tid < LIM_N) tab[tid] = c_limlut[tid];
+}
+
 struct P3
 {
     uint8_t *a[3];       // pass specific roles, see each kernel
@@ -559,8 +570,10 @@ constexpr int CD_W = 256, CD_HALO = 32, CD_LW = CD_W + 2 * CD_HALO;
 // maxd <= 30.  Per 1080i field of the bench's content: SQ_INSTS_VALU 16.7 M, SQ_INSTS_SALU 2.9 M, SQ_INSTS_LDS 2.1 M
 // (one row per block without the key chains: 26.5 M / 11.3 M / 3.2 M).
 
-template <bool EDGE>
-__device__ __forceinline__ int calc_dir_search(const uint32_t *tr, uint64_t pass, int maxdt, bool first, bool last, int nt13, int nt19)
+// PASS = uint64_t, or uint32_t when the window fits (chroma: 2 * 12 + 1 steps): walking the set bits of one word costs
+// four vector instructions a step instead of nine.
+template <bool EDGE, typename PASS>
+__device__ __forceinline__ int calc_dir_search(const uint32_t *tr, PASS pass, int maxdt, bool first, bool last, int nt13, int nt19)
 {
     // tr = &s_tri[j][b]: row k of the table is k * CD_LW further (k = 0..4: rows y-2 .. y+2)
     const uint32_t F2p = tr[0], Fp = tr[CD_LW], Fc = tr[2 * CD_LW], Fn = tr[3 * CD_LW], F2n = tr[4 * CD_LW];
@@ -582,8 +595,8 @@ __device__ __forceinline__ int calc_dir_search(const uint32_t *tr, uint64_t pass
 #define SADH(a, b, acc) __builtin_amdgcn_sad_hi_u8((a), (b), (acc))
     while (pass)
     {
-        const int jj = __ffsll((unsigned long long)pass) - 1;
-        pass &= pass - 1ull;
+        const int jj = sizeof(PASS) == 8 ? __ffsll((unsigned long long)pass) - 1 : __ffs((unsigned int)pass) - 1;
+        pass &= pass - (PASS)1;
         const uint32_t tag = (uint32_t)jj + tag0;
         const lds_u32 tp = (lds_u32)(uintptr_t)(ap0 + 4u * (uint32_t)jj), tm = (lds_u32)(uintptr_t)(am0 - 4u * (uint32_t)jj);
         const uint32_t e1 = SADH(Fp, tm[2 * CD_LW], SADH(Fc, tm[3 * CD_LW], 0u));     // diffsn + diffps
@@ -762,8 +775,13 @@ __global__ __launch_bounds__(CD_W) void k_calc_dir_rows(P3 P, int maxd, int nt13
                 if (y != height - 2) pass &= __brevll(window(s_bits[j + 2])) >> (64 - len);
             }
             const uint32_t *tr = &s_tri[j][b];
-            const int out = edge ? calc_dir_search<true>(tr, pass, maxdt, y == 1, y == height - 2, nt13, nt19)
-                                 : calc_dir_search<false>(tr, pass, maxdt, false, false, nt13, nt19);
+            int out;
+            if (len <= 32)                                                    // block-uniform (the plane's search distance)
+                out = edge ? calc_dir_search<true, uint32_t>(tr, (uint32_t)pass, maxdt, y == 1, y == height - 2, nt13, nt19)
+                           : calc_dir_search<false, uint32_t>(tr, (uint32_t)pass, maxdt, false, false, nt13, nt19);
+            else
+                out = edge ? calc_dir_search<true, uint64_t>(tr, pass, maxdt, y == 1, y == height - 2, nt13, nt19)
+                           : calc_dir_search<false, uint64_t>(tr, pass, maxdt, false, false, nt13, nt19);
             s_out[j][lx] = (uint8_t)out;
         }
         __syncthreads();
@@ -788,7 +806,7 @@ __global__ __launch_bounds__(CD_W) void k_calc_dir_rows(P3 P, int maxd, int nt13
 // the waves and of the load instructions, one dword store.  In the _2x forms (step 2) every other row is only copied:
 // that is decided per row (a wave = one row), before anything but the row's own dword is loaded.
 __device__ __forceinline__ int dir_map_px(int u0, int u1, int u2, int c0, int c1, int c2, int n0, int n1, int n2,
-                                          bool up_ok, bool dn_ok, int expand)
+                                          bool up_ok, bool dn_ok, int expand, const uint8_t *limlut)
 {
     const bool h0 = up_ok && u0 != PEAK, h1 = up_ok && u1 != PEAK, h2 = up_ok && u2 != PEAK;
     const bool h3 = c0 != PEAK, h4 = !expand && c1 != PEAK, h5 = c2 != PEAK;
@@ -798,8 +816,11 @@ __device__ __forceinline__ int dir_map_px(int u0, int u1, int u2, int c0, int c1
     int v0 = h0 ? u0 : ABSENT, v1 = h1 ? u1 : ABSENT, v2 = h2 ? u2 : ABSENT;
     int v3 = h3 ? c0 : ABSENT, v4 = h4 ? c1 : ABSENT, v5 = h5 ? c2 : ABSENT;
     int v6 = h6 ? n0 : ABSENT, v7 = h7 ? n1 : ABSENT, v8 = h8 ? n2 : ABSENT;
-    const int mid = mid9(v0, v1, v2, v3, v4, v5, v6, v7, v8, u);
-    const int lim = c_limlut[iabs(mid - NEUTRAL) >> 2];
+    // the midpoint from a sorted COPY: the vote below is a sum and a count, whatever the order - it takes the slots as they
+    // are, and of the network only the exchanges that reach the middle entries are left (39 of its 50 min / max)
+    int s0 = v0, s1 = v1, s2 = v2, s3 = v3, s4 = v4, s5 = v5, s6 = v6, s7 = v7, s8 = v8;
+    const int mid = mid9(s0, s1, s2, s3, s4, s5, s6, s7, s8, u);
+    const int lim = limlut[iabs(mid - NEUTRAL) >> 2];
     int sum = 0, count = 0;
     vote1(v0, mid, lim, sum, count); vote1(v1, mid, lim, sum, count); vote1(v2, mid, lim, sum, count);
     vote1(v3, mid, lim, sum, count); vote1(v4, mid, lim, sum, count); vote1(v5, mid, lim, sum, count);
@@ -815,6 +836,7 @@ __device__ __forceinline__ int dir_map_px(int u0, int u1, int u2, int c0, int c1
 // instructions - than on its dword).
 __global__ __launch_bounds__(256) void k_dir_map4(P3 P, int step, int expand)
 {
+    const uint8_t *limlut = c_limlut;             // (a copy per wave in LDS, filled without a barrier: 117 -> 121 us per launch)
     FIELD_PLANE(P);
     const int x = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
     const int r = blockIdx.y * blockDim.y + threadIdx.y;
@@ -865,7 +887,7 @@ __global__ __launch_bounds__(256) void k_dir_map4(P3 P, int step, int expand)
         {
             asm volatile("" ::: "memory");                     // a real branch: waves without a masked pixel skip the sort
             out[k] = dir_map_px(wb(wu, k - 1), wb(wu, k), wb(wu, k + 1), wb(wc, k - 1), c1, wb(wc, k + 1),
-                                wb(wd, k - 1), wb(wd, k), wb(wd, k + 1), up_ok, dn_ok, expand);
+                                wb(wd, k - 1), wb(wd, k), wb(wd, k + 1), up_ok, dn_ok, expand, limlut);
         }
     }
     st4(o, out, x, width);
@@ -901,6 +923,7 @@ __global__ __launch_bounds__(256) void k_dir_map_c(P3 P, int step, int expand, i
     __shared__ __attribute__((aligned(16))) uint8_t s_out[4][256];
     __shared__ uint16_t s_list[4 * 256];
     __shared__ int s_count;
+    __shared__ uint8_t s_lim[LIM_PAD];
     FIELD_PLANE(P);
     const int y0 = step == 1 ? 1 : 2 - tff;
     // step 2: a thread row takes the PAIR of rows 2r, 2r + 1 - the one with the rebuilt rows' parity goes through the
@@ -912,6 +935,7 @@ __global__ __launch_bounds__(256) void k_dir_map_c(P3 P, int step, int expand, i
     if (bx0 >= width || (step == 1 ? rb : 2 * rb) >= height) return;                 // whole workgroup outside
     const int tid = threadIdx.y * 64 + threadIdx.x;
     if (tid == 0) s_count = 0;
+    lim_fill(s_lim, tid);
     __syncthreads();
     // the copied row of the pair: fetched now, stored when the workgroup is done (see k_dir_map4)
     const int yc = 2 * r + 1 - (y0 & 1);
@@ -970,7 +994,7 @@ __global__ __launch_bounds__(256) void k_dir_map_c(P3 P, int step, int expand, i
         const uint8_t *c = Q.b + (size_t)yy * pitch + bx0 + lx;
         const uint8_t *up = c - (ptrdiff_t)step * pitch, *dn = c + (ptrdiff_t)step * pitch;
         const bool up_ok = step == 1 || yy > 1, dn_ok = step == 1 || yy < height - 2;
-        s_out[ly][lx] = (uint8_t)dir_map_px(up[-1], up[0], up[1], c[-1], c[0], c[1], dn[-1], dn[0], dn[1], up_ok, dn_ok, expand);
+        s_out[ly][lx] = (uint8_t)dir_map_px(up[-1], up[0], up[1], c[-1], c[0], c[1], dn[-1], dn[0], dn[1], up_ok, dn_ok, expand, s_lim);
     }
     __syncthreads();
     if (inside)
@@ -992,7 +1016,7 @@ __global__ __launch_bounds__(256) void k_dir_map_c(P3 P, int step, int expand, i
             for (int k = 0; k < 4; k++)
             {
                 const int nm = (v >> (8 * k)) & 0xffu, om = (om4 >> (8 * k)) & 0xffu;
-                const int lim = c_limlut[iabs(nm - NEUTRAL) >> 2];
+                const int lim = s_lim[iabs(nm - NEUTRAL) >> 2];
                 const bool fix = iabs(nm - om) > lim && om != PEAK && om != NEUTRAL;
                 out[k] = fix ? (int)((((up4 >> (8 * k)) & 0xffu) + ((dn4 >> (8 * k)) & 0xffu) + 1) >> 1) : (int)((cur4 >> (8 * k)) & 0xffu);
                 any |= fix;
@@ -1099,6 +1123,7 @@ __global__ __launch_bounds__(256) void k_filter_map(P3 P)
 // per row spent more scalar instructions on finding its plane and field than vector ones on its dword.
 __global__ __launch_bounds__(256) void k_mark_2x4(P3 P)
 {
+    const uint8_t *limlut = c_limlut;
     FIELD_PLANE(P);
     const int x = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
     const int r = blockIdx.y * blockDim.y + threadIdx.y;
@@ -1149,7 +1174,7 @@ __global__ __launch_bounds__(256) void k_mark_2x4(P3 P)
                 int s0 = a0 != PEAK ? a0 : ABSENT, s1 = a1 != PEAK ? a1 : ABSENT, s2 = a2 != PEAK ? a2 : ABSENT;
                 int s3 = b0 != PEAK ? b0 : ABSENT, s4 = b1 != PEAK ? b1 : ABSENT, s5 = b2 != PEAK ? b2 : ABSENT;
                 const int mid = mid6(s0, s1, s2, s3, s4, s5, v);
-                const int lim = c_limlut[iabs(mid - NEUTRAL) >> 2];
+                const int lim = limlut[iabs(mid - NEUTRAL) >> 2];
                 int u = 0;
                 if (iabs(a0 - b0) <= lim || a0 == PEAK || b0 == PEAK) u++;
                 if (iabs(a1 - b1) <= lim || a1 == PEAK || b1 == PEAK) u++;
@@ -1391,12 +1416,13 @@ __global__ __launch_bounds__(256) void k_fill_gaps_b(P3 P)
 constexpr uint32_t LAT_MORE = 0x80000000u;
 
 // the variance and the edge test on the fixed 2 x 5 neighbourhood (:1213-1240)
-__device__ __forceinline__ uint32_t lattice_stage_a(const uint8_t *top, const uint8_t *bot, const uint8_t *dm, int x, int width, uint32_t base)
+__device__ __forceinline__ uint32_t lattice_stage_a(const uint8_t *top, const uint8_t *bot, const uint8_t *dm, int x, int width, uint32_t base,
+                                                    const uint8_t *limlut)
 {
     const int d = dm[x];
     const int T0 = top[x - 2], T1 = top[x - 1], T2 = top[x], T3 = top[x + 1], T4 = top[x + 2];
     const int B0 = bot[x - 2], B1 = bot[x - 1], B2 = bot[x], B3 = bot[x + 1], B4 = bot[x + 2];
-    const int lim = c_limlut[iabs(d - NEUTRAL) >> 2];
+    const int lim = limlut[iabs(d - NEUTRAL) >> 2];
     const uint32_t avg = base & 0xffu;
     if (lim < 9)
     {
@@ -1418,12 +1444,16 @@ __device__ __forceinline__ uint32_t lattice_stage_a(const uint8_t *top, const ui
     return base | LAT_MORE;
 }
 
+// (Tried and dropped: the three bytes around a column as ONE unaligned ds_read_b32 - gfx950 returns the right dword at every
+// byte offset, tools/lds_unaligned.hip - with v_sad_u8 on the masked dwords: a third of the LDS instructions and of the
+// arithmetic of the two searches below, and the candidates kernel went from 272 to 314 us per launch.  An LDS dword that
+// straddles two banks is not one access.)
 // the search around the pixel's direction (:1242-1290)
 __device__ __forceinline__ uint32_t lattice_stage_b(const uint8_t *top, const uint8_t *bot, const uint8_t *ot, const uint8_t *ob,
-                                                    const uint8_t *dm, int x, int width, int nt4, int nt8, uint32_t base)
+                                                    const uint8_t *dm, int x, int width, int nt4, int nt8, uint32_t base, const uint8_t *limlut)
 {
     const int d = dm[x];
-    const int lim = c_limlut[iabs(d - NEUTRAL) >> 2];
+    const int lim = limlut[iabs(d - NEUTRAL) >> 2];
     int dir = (d - NEUTRAL + 2) >> 2;
     int val = (int)(base & 0xffu);
     const int startu = (dir - 2 < 0) ? max(-x + 1, max(dir - 2, -width + 2 + x)) : min(x - 1, min(dir - 2, width - 2 - x));
@@ -1507,6 +1537,7 @@ __global__ __launch_bounds__(256) void k_lattice_cand_q(P3 P, uint32_t *__restri
     __shared__ __attribute__((aligned(16))) uint32_t s_cand[LQ_W];
     __shared__ uint16_t s_list[3][LQ_W];                          // one queue per stage
     __shared__ int s_count[3];
+    __shared__ uint8_t s_lim[LIM_PAD];
     FIELD_PLANE(P);
     const int field = tff;
     cand += (size_t)fld * (P.fstride / sizeof(uint32_t));          // the candidates live in the field's slab too
@@ -1517,6 +1548,7 @@ __global__ __launch_bounds__(256) void k_lattice_cand_q(P3 P, uint32_t *__restri
     if (x0 >= width || ri >= nrows) return;
     const int y = (2 - field) + 2 * ri;
     if (t < 3) s_count[t] = 0;
+    lim_fill(s_lim, t);
     {
         const uint8_t *g[5] = { Q.b + (size_t)(y - 1) * pitch, Q.b + (size_t)(y + 1) * pitch,
                                 Q.c + (size_t)(y - 1) * pitch, Q.c + (size_t)(y + 1) * pitch,
@@ -1544,7 +1576,7 @@ __global__ __launch_bounds__(256) void k_lattice_cand_q(P3 P, uint32_t *__restri
             {
                 const int d = (d4 >> (8 * k)) & 0xff, dr = k < 3 ? (int)((d4 >> (8 * k + 8)) & 0xff) : (int)dn;
                 const int avg = (int)(((t4 >> (8 * k)) & 0xff) + ((b4 >> (8 * k)) & 0xff) + 1) >> 1;
-                const int lim = c_limlut[iabs(d - NEUTRAL) >> 2];
+                const int lim = s_lim[iabs(d - NEUTRAL) >> 2];
                 const bool right = iabs(d - dr) > lim;
                 const bool searching = d != PEAK && x + k < width;
                 w[k] = searching ? ((uint32_t)avg | ((uint32_t)right << 25))
@@ -1566,7 +1598,7 @@ __global__ __launch_bounds__(256) void k_lattice_cand_q(P3 P, uint32_t *__restri
     for (int i = t, n = s_count[0]; i < n; i += 256)
     {
         const int lx = s_list[0][i];
-        const uint32_t w = lattice_stage_a(top, bot, dm, x0 + lx, width, s_cand[lx]);
+        const uint32_t w = lattice_stage_a(top, bot, dm, x0 + lx, width, s_cand[lx], s_lim);
         if (w & LAT_MORE) s_list[1][atomicAdd(&s_count[1], 1)] = (uint16_t)lx;
         else s_cand[lx] = w;
     }
@@ -1574,7 +1606,7 @@ __global__ __launch_bounds__(256) void k_lattice_cand_q(P3 P, uint32_t *__restri
     for (int i = t, n = s_count[1]; i < n; i += 256)
     {
         const int lx = s_list[1][i];
-        const uint32_t w = lattice_stage_b(top, bot, ot, ob, dm, x0 + lx, width, nt4, nt8, s_cand[lx]);
+        const uint32_t w = lattice_stage_b(top, bot, ot, ob, dm, x0 + lx, width, nt4, nt8, s_cand[lx], s_lim);
         if (w & LAT_MORE) s_list[2][atomicAdd(&s_count[2], 1)] = (uint16_t)lx;
         else s_cand[lx] = w;
     }
