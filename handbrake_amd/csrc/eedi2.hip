@@ -307,36 +307,52 @@ __device__ __forceinline__ void mask_tile(const P3 &P, const MaskSrc &S, const M
     uint8_t *srcp = P.a[pl] + foff, *newm = P.c[pl] + foff;
     const int t = threadIdx.x, fx = x0 - MF_OX, fy = y0 - MF_OY;
 
-    for (int i = t; i < MF_LR * MF_DW; i += MF_T)
+    // The LDS frame is MF_LR x MF_DW = 864 dwords for 512 threads: two per thread.  Both loads of a thread go out before
+    // anything is done with the first (as a loop, the store of SRCPF between them made the second wait for the first:
+    // two round trips in a row, and again for the old mask - on the chain's critical path from tile to tile).
+    static_assert(MF_LR * MF_DW <= 2 * MF_T, "two frame dwords per thread");
+    int fr[2], fc[2], fyy[2], fxx[2];
+    bool fin[2];
+    uint32_t sv[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++)
     {
-        const int r = i / MF_DW, c4 = i - r * MF_DW;
-        const int y = fy + r, x = fx + 4 * c4;
-        uint32_t sv = 0;
-        if (y >= 0 && y < height && x >= 0 && x < width)
-        {
-            sv = *reinterpret_cast<const uint32_t *>(frame + (size_t)(start_line + 2 * y) * S.spitch[pl] + x);
-            if (x + 3 >= width) sv &= 0xffffffffu >> (8 * (x + 4 - width));
-        }
+        const int i = t + MF_T * k;
+        fin[k] = i < MF_LR * MF_DW;
+        fr[k] = i / MF_DW; fc[k] = i - fr[k] * MF_DW;
+        fyy[k] = fy + fr[k]; fxx[k] = fx + 4 * fc[k];
+        sv[k] = 0;
+        if (fin[k] && fyy[k] >= 0 && fyy[k] < height && fxx[k] >= 0 && fxx[k] < width)
+            sv[k] = *reinterpret_cast<const uint32_t *>(frame + (size_t)(start_line + 2 * fyy[k]) * S.spitch[pl] + fxx[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+    {
+        if (!fin[k]) continue;
+        const int r = fr[k], c4 = fc[k], y = fyy[k], x = fxx[k];
+        if (x + 3 >= width && x < width) sv[k] &= 0xffffffffu >> (8 * (x + 4 - width));
         // the tile's own cells go out as SRCPF (every cell of the plane belongs to exactly one tile)
         if (y >= 0 && y < height && x >= 0 && x < pitch &&
             r >= MF_OY && r < MF_OY + MF_H && c4 >= MF_OX / 4 && c4 < (MF_OX + MF_W) / 4)
-            *reinterpret_cast<uint32_t *>(srcp + (size_t)y * pitch + x) = sv;
-        s_src[r][c4 + 1] = sv;
+            *reinterpret_cast<uint32_t *>(srcp + (size_t)y * pitch + x) = sv[k];
+        s_src[r][c4 + 1] = sv[k];
     }
     if (CHAIN && fld > 0) eedi_chain_wait(C, fld, pl, bx, by);    // (the source rows above are already on their way)
-    for (int i = t; i < MF_LR * MF_DW; i += MF_T)
+    uint32_t mv[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++)
     {
-        const int r = i / MF_DW, c4 = i - r * MF_DW;
-        const int y = fy + r, x = fx + 4 * c4;
-        uint32_t mv = 0;
+        mv[k] = 0;
         // (only the rows of the kept half are used, and those were written by lower tiles)
-        if (!upper && y >= 0 && y < height && x >= 0 && x < pitch)
+        if (fin[k] && !upper && fyy[k] >= 0 && fyy[k] < height && fxx[k] >= 0 && fxx[k] < pitch)
         {
-            const uint32_t *m = reinterpret_cast<const uint32_t *>(oldm + (size_t)y * pitch + x);
-            mv = CHAIN ? __hip_atomic_load(m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *m;
+            const uint32_t *m = reinterpret_cast<const uint32_t *>(oldm + (size_t)fyy[k] * pitch + fxx[k]);
+            mv[k] = CHAIN ? __hip_atomic_load(m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *m;
         }
-        s_a[r][c4 + 1] = mv & 0x01010101u;
     }
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+        if (fin[k]) s_a[fr[k]][fc[k] + 1] = mv[k] & 0x01010101u;
     __syncthreads();
 
     const int c4 = t % MF_DW, strip = t / MF_DW;               // strips past the frame have no rows in any pass
@@ -1555,9 +1571,26 @@ __global__ __launch_bounds__(256) void k_lattice_cand_q(P3 P, uint32_t *__restri
                                 Q.a + (size_t)y * pitch };
         // only as far right as the row's pixels (+ halo) reach
         const int need4 = (min(LQ_W, hbhip_align_up_dev(width - x0, 4)) + 2 * LC_HALO) / 4;
+        // all loads of a thread in flight before its first LDS store (need4 <= 276: two dwords per row and thread) - as a
+        // loop of load -> store pairs the ten round trips of a thread followed one another
+        static_assert(LQ_LW / 4 <= 2 * 256, "two staged dwords per row and thread");
+        uint32_t v[5][2];
+#pragma unroll
         for (int r = 0; r < 5; r++)
-            for (int c4 = t; c4 < need4; c4 += 256)
-                reinterpret_cast<uint32_t *>(s_rows[r])[c4] = reinterpret_cast<const uint32_t *>(g[r] + x0 - LC_HALO)[c4];
+#pragma unroll
+            for (int k = 0; k < 2; k++)
+            {
+                const int c4 = t + 256 * k;
+                v[r][k] = c4 < need4 ? reinterpret_cast<const uint32_t *>(g[r] + x0 - LC_HALO)[c4] : 0u;
+            }
+#pragma unroll
+        for (int r = 0; r < 5; r++)
+#pragma unroll
+            for (int k = 0; k < 2; k++)
+            {
+                const int c4 = t + 256 * k;
+                if (c4 < need4) reinterpret_cast<uint32_t *>(s_rows[r])[c4] = v[r][k];
+            }
     }
     __syncthreads();
     const uint8_t *top = s_rows[0] + LC_HALO - x0, *bot = s_rows[1] + LC_HALO - x0;
