@@ -574,19 +574,35 @@ __global__ __launch_bounds__(256) void scale8_up_kernel(ScaleBatch8 B)
     {
         const uint8_t *src = B.src[f][pl];
         const int spitch = B.spitch[pl];
-        for (int i = t; i < nr * ndw; i += 256)
+        // four dwords of a thread in flight before its first LDS store (a 2x tile stages 14 x 35 dwords: two per thread; as
+        // a loop of load -> store pairs they were two round trips in a row)
+        const int n = nr * ndw;
+        for (int base = 0; base < n; base += 4 * 256)
         {
-            const int rr = i / ndw, d = i - rr * ndw, col = cmin + 4 * d;
-            const uint8_t *row = src + (size_t)reflect_idx(rmin + rr, P.sh) * spitch;
-            uint32_t v;
-            if (col >= 0 && col + 3 < P.sw && (((uintptr_t)(row + col)) & 3) == 0) v = *reinterpret_cast<const uint32_t *>(row + col);
-            else
-            {
-                v = 0;
+            uint32_t v[4];
 #pragma unroll
-                for (int k = 0; k < 4; k++) v |= (uint32_t)row[reflect_idx(col + k, P.sw)] << (8 * k);
+            for (int j = 0; j < 4; j++)
+            {
+                const int i = base + t + 256 * j;
+                v[j] = 0;
+                if (i < n)
+                {
+                    const int rr = i / ndw, d = i - rr * ndw, col = cmin + 4 * d;
+                    const uint8_t *row = src + (size_t)reflect_idx(rmin + rr, P.sh) * spitch;
+                    if (col >= 0 && col + 3 < P.sw && (((uintptr_t)(row + col)) & 3) == 0) v[j] = *reinterpret_cast<const uint32_t *>(row + col);
+                    else
+                    {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) v[j] |= (uint32_t)row[reflect_idx(col + k, P.sw)] << (8 * k);
+                    }
+                }
             }
-            s_src[rr][d] = v;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+            {
+                const int i = base + t + 256 * j;
+                if (i < n) { const int rr = i / ndw; s_src[rr][i - rr * ndw] = v[j]; }
+            }
         }
     }
     __syncthreads();

@@ -1075,13 +1075,21 @@ __global__ __launch_bounds__(256) void k_filter_map(P3 P)
     const int bx0 = blockIdx.x * FM_W, by0 = blockIdx.y * FM_R;
     if (bx0 >= width || by0 >= height) return;                   // whole workgroup outside
     const int tid = threadIdx.y * 64 + threadIdx.x;
-    for (int i = tid; i < (FM_R + 2) * (FM_LW / 4); i += 256)
     {
-        const int r = i / (FM_LW / 4), c4 = i - r * (FM_LW / 4);
-        const int yy = by0 - 1 + r, col = bx0 - FM_HALO + 4 * c4;
-        uint32_t v = 0;                                          // outside the plane: never looked at (the walks are clipped to the row)
-        if (yy >= 0 && yy < height && col >= 0 && col < pitch) v = *reinterpret_cast<const uint32_t *>(Q.b + (size_t)yy * pitch + col);
-        reinterpret_cast<uint32_t *>(&s_d[0][0])[i] = v;
+        // 6 x 68 dwords for 256 threads: both loads of a thread in flight before the first LDS store
+        static_assert((FM_R + 2) * (FM_LW / 4) <= 2 * 256, "two staged dwords per thread");
+        uint32_t v[2] = { 0u, 0u };                              // outside the plane: never looked at (the walks are clipped to the row)
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+        {
+            const int i = tid + 256 * k, r = i / (FM_LW / 4), c4 = i - r * (FM_LW / 4);
+            const int yy = by0 - 1 + r, col = bx0 - FM_HALO + 4 * c4;
+            if (i < (FM_R + 2) * (FM_LW / 4) && yy >= 0 && yy < height && col >= 0 && col < pitch)
+                v[k] = *reinterpret_cast<const uint32_t *>(Q.b + (size_t)yy * pitch + col);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+            if (tid + 256 * k < (FM_R + 2) * (FM_LW / 4)) reinterpret_cast<uint32_t *>(&s_d[0][0])[tid + 256 * k] = v[k];
     }
     const int x = bx0 + 4 * threadIdx.x, y = by0 + threadIdx.y;
     const bool inside = x < width && y < height;
