@@ -1273,23 +1273,30 @@ __global__ __launch_bounds__(256) void k_fill_gaps_b(P3 P)
     const int ndw = (min(FG_W, hbhip_align_up_dev(width - x0, 4)) + 2 * FG_HALO) / 4;
     {
         // all loads of a thread in flight before the first LDS store (ndw <= 288: two dwords per row and thread)
-        uint32_t v[7][2];
+        // (one branch per column of the thread, not one per load: every divergent `if` is four or five instructions on the
+        // scalar unit, and this kernel runs at two thirds of its issue rate)
+        uint32_t v[7][2] = {};
+        const bool h0 = tid < ndw, h1 = tid + 256 < ndw;
+        if (h0)
+        {
 #pragma unroll
-        for (int r = 0; r < 7; r++)
+            for (int r = 0; r < 7; r++) v[r][0] = reinterpret_cast<const uint32_t *>(g[r] + lo)[tid];
+        }
+        if (h1)
+        {
 #pragma unroll
-            for (int k = 0; k < 2; k++)
-            {
-                const int i = tid + 256 * k;
-                v[r][k] = i < ndw ? reinterpret_cast<const uint32_t *>(g[r] + lo)[i] : 0u;
-            }
+            for (int r = 0; r < 7; r++) v[r][1] = reinterpret_cast<const uint32_t *>(g[r] + lo)[tid + 256];
+        }
+        if (h0)
+        {
 #pragma unroll
-        for (int r = 0; r < 7; r++)
+            for (int r = 0; r < 7; r++) reinterpret_cast<uint32_t *>(s_r[r])[tid] = v[r][0];
+        }
+        if (h1)
+        {
 #pragma unroll
-            for (int k = 0; k < 2; k++)
-            {
-                const int i = tid + 256 * k;
-                if (i < ndw) reinterpret_cast<uint32_t *>(s_r[r])[i] = v[r][k];
-            }
+            for (int r = 0; r < 7; r++) reinterpret_cast<uint32_t *>(s_r[r])[tid + 256] = v[r][1];
+        }
     }
     __syncthreads();
     enum { DC = 0, MC = 1, MN = 2, DP = 3, DN = 4, MP = 5, MNN = 6 };
@@ -1582,23 +1589,28 @@ __global__ __launch_bounds__(256) void k_lattice_cand_q(P3 P, uint32_t *__restri
         // all loads of a thread in flight before its first LDS store (need4 <= 276: two dwords per row and thread) - as a
         // loop of load -> store pairs the ten round trips of a thread followed one another
         static_assert(LQ_LW / 4 <= 2 * 256, "two staged dwords per row and thread");
-        uint32_t v[5][2];
+        uint32_t v[5][2] = {};
+        const bool h0 = t < need4, h1 = t + 256 < need4;           // one branch per column of the thread, not one per load
+        if (h0)
+        {
 #pragma unroll
-        for (int r = 0; r < 5; r++)
+            for (int r = 0; r < 5; r++) v[r][0] = reinterpret_cast<const uint32_t *>(g[r] + x0 - LC_HALO)[t];
+        }
+        if (h1)
+        {
 #pragma unroll
-            for (int k = 0; k < 2; k++)
-            {
-                const int c4 = t + 256 * k;
-                v[r][k] = c4 < need4 ? reinterpret_cast<const uint32_t *>(g[r] + x0 - LC_HALO)[c4] : 0u;
-            }
+            for (int r = 0; r < 5; r++) v[r][1] = reinterpret_cast<const uint32_t *>(g[r] + x0 - LC_HALO)[t + 256];
+        }
+        if (h0)
+        {
 #pragma unroll
-        for (int r = 0; r < 5; r++)
+            for (int r = 0; r < 5; r++) reinterpret_cast<uint32_t *>(s_rows[r])[t] = v[r][0];
+        }
+        if (h1)
+        {
 #pragma unroll
-            for (int k = 0; k < 2; k++)
-            {
-                const int c4 = t + 256 * k;
-                if (c4 < need4) reinterpret_cast<uint32_t *>(s_rows[r])[c4] = v[r][k];
-            }
+            for (int r = 0; r < 5; r++) reinterpret_cast<uint32_t *>(s_rows[r])[t + 256] = v[r][1];
+        }
     }
     __syncthreads();
     const uint8_t *top = s_rows[0] + LC_HALO - x0, *bot = s_rows[1] + LC_HALO - x0;
