@@ -1306,16 +1306,15 @@ __global__ __launch_bounds__(256) void k_fill_gaps_b(P3 P)
     // bit scans instead of chains of dependent byte reads.
     for (int k = 0; k < (FG_LW + 255) / 256; k++)
     {
-        const unsigned col = tid + 256 * k;
-        bool np = false, stop = false, bt = false, bb = false;
-        if (col < staged)
-        {
-            const bool mc = s_r[MC][col] == PEAK, mn = s_r[MN][col] == PEAK;
-            np = s_r[DC][col] != PEAK;
-            stop = np || (!mc && !mn);
-            bt = s_r[DP][col] == PEAK || (s_r[MP][col] != PEAK && !mc);
-            bb = s_r[DN][col] == PEAK || (!mn && s_r[MNN][col] != PEAK);
-        }
+        // (no branch and no short-circuit: the seven bytes are read whatever they hold - from the last staged column for the
+        // lanes past it, whose bits are then cleared - and the four conditions are mask arithmetic)
+        const unsigned col = tid + 256 * k, cc = min(col, staged - 1u);
+        const bool in = col < staged;
+        const bool mc = s_r[MC][cc] == PEAK, mn = s_r[MN][cc] == PEAK;
+        const bool np = in & (s_r[DC][cc] != PEAK);
+        const bool stop = in & (np | (!mc & !mn));
+        const bool bt = in & ((s_r[DP][cc] == PEAK) | ((s_r[MP][cc] != PEAK) & !mc));
+        const bool bb = in & ((s_r[DN][cc] == PEAK) | (!mn & (s_r[MNN][cc] != PEAK)));
         const uint64_t w0 = __ballot(stop), w1 = __ballot(np), w2 = __ballot(bt), w3 = __ballot(bb);
         if ((tid & 63) == 0 && (col >> 6) < FG_LW / 64 + 1) { s_stop[col >> 6] = w0; s_np[col >> 6] = w1; s_bt[col >> 6] = w2; s_bb[col >> 6] = w3; }
     }
@@ -1325,13 +1324,15 @@ __global__ __launch_bounds__(256) void k_fill_gaps_b(P3 P)
         const uint32_t cw = *reinterpret_cast<const uint32_t *>(&s_r[DC][c]);
         const uint32_t mcw = *reinterpret_cast<const uint32_t *>(&s_r[MC][c]), mnw = *reinterpret_cast<const uint32_t *>(&s_r[MN][c]);
         *reinterpret_cast<uint32_t *>(&s_out[4 * tid]) = cw;
-#pragma unroll
-        for (int k = 0; k < 4; k++)
+        // the gap pixels among the four (direction unknown, inside the mask: :1046-1050) as byte arithmetic, one atomic
+        // for all of them
+        const uint32_t gap = ((ff_bytes(cw) & (ff_bytes(mcw) | ff_bytes(mnw))) >> 7) & mf_bytes_in(x, 1, width - 1);
+        if (gap)
         {
-            const int xx = x + k;
-            if (xx >= 1 && xx < width - 1 && ((cw >> (8 * k)) & 0xff) == PEAK &&
-                (((mcw >> (8 * k)) & 0xff) == PEAK || ((mnw >> (8 * k)) & 0xff) == PEAK))
-                s_list[atomicAdd(&s_count, 1)] = (uint16_t)(4 * tid + k);
+            int at = atomicAdd(&s_count, __popc(gap));
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if ((gap >> (8 * k)) & 1u) s_list[at++] = (uint16_t)(4 * tid + k);
         }
     }
     __syncthreads();
