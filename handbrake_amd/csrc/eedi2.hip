@@ -154,7 +154,8 @@ __device__ __forceinline__ int mid6(int &v0, int &v1, int &v2, int &v3, int &v4,
 
 __device__ __forceinline__ void vote1(int v, int mid, int lim, int &sum, int &cnt)
 {
-    const bool in = iabs(v - mid) <= lim;        // never true for ABSENT (lim <= 255)
+    // |v - mid| as one v_sad_u16 (both are below 2^16 with empty upper halves); never within lim for ABSENT (lim <= 255)
+    const bool in = (int)__builtin_amdgcn_sad_u16((uint32_t)v, (uint32_t)mid, 0u) <= lim;
     cnt += in;
     sum += in ? v : 0;
 }
