@@ -16,7 +16,11 @@ HIP_HDR := $(wildcard $(PKG)/csrc/*.h) $(wildcard include/*.h)
 FLT_SRC := $(wildcard $(PKG)/libhb/*_hip.c) $(PKG)/libhb/hbhip_registry.c $(PKG)/libhb/hip_common.c
 
 all: product oracle
-product: $(PKG)/libhbrt.so $(PKG)/libhbhip.so $(PKG)/libhbhip_filters.so
+product: $(PKG)/libhbrt.so $(PKG)/libhbhip.so $(PKG)/libhbhip_filters.so tools/vote_avg_check
+
+# GPU-side exhaustive check of a device function shared with the kernels (tests/test_eedi2_gpu.py runs it)
+tools/vote_avg_check: tools/vote_avg_check.hip $(PKG)/csrc/eedi2_vote.h
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -ffp-contract=off -fno-fast-math -I$(PKG)/csrc -Wno-unused-result $< -o $@
 
 $(PKG)/libhbrt.so: $(PKG)/libhb/hb_runtime.c $(PKG)/libhb/hb_harness.c $(PKG)/libhb/hb_harness.h include/hbhip_libhb.h
 	$(CC) $(CFLAGS) -shared -o $@ $(PKG)/libhb/hb_runtime.c $(PKG)/libhb/hb_harness.c -lm -lpthread

@@ -31,6 +31,7 @@
 // workgroup: lanes evaluate both possible outcomes of their pixel in parallel and
 // the chain is resolved with a prefix composition of 2-state maps, the carry running
 // from chunk to chunk.
+#include "eedi2_vote.h"
 #include "eedi2_engine.h"
 #include <algorithm>
 
@@ -132,9 +133,11 @@ __device__ __forceinline__ int mid9(int &v0, int &v1, int &v2, int &v3, int &v4,
     cswap(v0, v1); cswap(v2, v4); cswap(v3, v5); cswap(v6, v8);
     cswap(v2, v3); cswap(v4, v5); cswap(v6, v7);
     cswap(v1, v2); cswap(v3, v4); cswap(v5, v6);
-    // n = 4..9: lower middle index (n-1)>>1 = 1,2,2,3,3,4 ; upper n>>1 = 2,2,3,3,4,4
-    const int lo = n <= 4 ? v1 : (n <= 6 ? v2 : (n <= 8 ? v3 : v4));
-    const int hi = n <= 5 ? v2 : (n <= 7 ? v3 : v4);
+    // n = 4..9: lower middle index (n-1)>>1 = 1,2,2,3,3,4 ; upper n>>1 = 2,2,3,3,4,4.  The lower one only counts for even n,
+    // where it is the upper one's left neighbour: both come off the same two comparisons
+    const bool n5 = n <= 5, n7 = n <= 7;
+    const int hi = n5 ? v2 : (n7 ? v3 : v4);
+    const int lo = n5 ? v1 : (n7 ? v2 : v3);
     return (n & 1) ? hi : (lo + hi + 1) >> 1;
 }
 
@@ -842,7 +845,7 @@ __device__ __forceinline__ int dir_map_px(int u0, int u1, int u2, int c0, int c1
     vote1(v0, mid, lim, sum, count); vote1(v1, mid, lim, sum, count); vote1(v2, mid, lim, sum, count);
     vote1(v3, mid, lim, sum, count); vote1(v4, mid, lim, sum, count); vote1(v5, mid, lim, sum, count);
     vote1(v6, mid, lim, sum, count); vote1(v7, mid, lim, sum, count); vote1(v8, mid, lim, sum, count);
-    const int val = (int)(((float)(sum + mid) / (float)(count + 1)) + 0.5f);
+    const int val = vote_avg(sum + mid, count + 1);              // (int)((float)(sum + mid) / (float)(count + 1) + 0.5f)
     if (expand) return count >= 5 ? (val & 0xff) : c1;
     if (count < 4 || (count < 5 && c1 == PEAK)) return PEAK;
     return val & 0xff;
@@ -1209,7 +1212,7 @@ __global__ __launch_bounds__(256) void k_mark_2x4(P3 P)
                     int sum = 0, count = 0;
                     vote1(s0, mid, lim, sum, count); vote1(s1, mid, lim, sum, count); vote1(s2, mid, lim, sum, count);
                     vote1(s3, mid, lim, sum, count); vote1(s4, mid, lim, sum, count); vote1(s5, mid, lim, sum, count);
-                    const int val = (int)(((float)(sum + mid) / (float)(count + 1)) + 0.5f);
+                    const int val = vote_avg(sum + mid, count + 1);
                     if (!(count < v - 2 || count < 2)) packed = (packed & ~(0xffu << (8 * k))) | ((uint32_t)(val & 0xff) << (8 * k));
                 }
             }

@@ -147,3 +147,16 @@ def test_16bit_decomb_eedi2_golden(built, name):
         for c in range(3):
             np.testing.assert_array_equal(got[t].planes[c], want[t][c], err_msg=f"{name} frame {t} plane {c}")
         assert (got[t].start, got[t].stop) == (int(meta[t][0]), int(meta[t][1]))
+
+
+@pytest.mark.gpu
+def test_vote_avg_every_case():
+    """The rounded average of the dir-map votes (csrc/eedi2_vote.h: a reciprocal and one correction instead of the IEEE
+    division of eedi2_template.c:703 / :767 / :850) on the GPU, for every (sum + mid, count + 1) the kernels can form."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "vote_avg_check")
+    assert os.path.exists(exe), "tools/vote_avg_check is not built (make product)"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 differ from the float expression, 0 from floor" in r.stdout, r.stdout
