@@ -685,16 +685,24 @@ __global__ __launch_bounds__(256) void q_dir_map(Q3 P, K16 k, int step, int expa
     __shared__ int s_lim[33];
     FIELD16(P);
     const int y0 = step == 1 ? 1 : 2 - tff;
-    const int bx0 = 4 * (blockIdx.x * 64), x = bx0 + 4 * threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    // step 2: a thread row takes the PAIR of rows 2r, 2r + 1 - the one with the rebuilt rows' parity goes through the pass,
+    // the other is only copied: fetched now, stored when the workgroup is done (eedi2.hip: k_dir_map_c)
+    const int rb = blockIdx.y * 4, r = rb + threadIdx.y;
+    const int bx0 = 4 * (blockIdx.x * 64), x = bx0 + 4 * threadIdx.x, y = step == 1 ? r : 2 * r + (y0 & 1);
+    const int yb = step == 1 ? rb : 2 * rb + (y0 & 1);                              // row of thread row 0
     const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
-    if (bx0 >= width || (int)blockIdx.y * 4 >= height) return;                       // whole workgroup outside
+    if (bx0 >= width || (step == 1 ? rb : 2 * rb) >= height) return;                 // whole workgroup outside
     const int tid = threadIdx.y * 64 + threadIdx.x;
     if (tid == 0) s_count = 0;
     if (tid < 33) s_lim[tid] = k.limlut[tid];
     __syncthreads();
     const int peak = k.peak;
+    const int yc = 2 * r + 1 - (y0 & 1);
+    const bool copy = step != 1 && x < width && yc < height;
+    uint2 vcopy = make_uint2(0u, 0u);
+    if (copy) vcopy = *reinterpret_cast<const uint2 *>(Q.b + (size_t)yc * pitch + x);
     const bool inside = x < width && y < height;
-    const bool row_ok = step == 1 ? (y >= 1 && y < height - 1) : (y >= y0 && y < height - 1 && ((y - y0) & 1) == 0);
+    const bool row_ok = step == 1 ? (y >= 1 && y < height - 1) : (y >= y0 && y < height - 1);
     const uint16_t *dc = Q.b + (size_t)y * pitch + x;
     if (inside)
     {
@@ -748,7 +756,7 @@ __global__ __launch_bounds__(256) void q_dir_map(Q3 P, K16 k, int step, int expa
     for (int i = tid; i < count; i += 256)
     {
         const int e = s_list[i], ly = e >> 8, lx = e & 255;
-        const int yy = blockIdx.y * 4 + ly;
+        const int yy = yb + step * ly;
         const uint16_t *c = Q.b + (size_t)yy * pitch + bx0 + lx;
         const bool up_ok = step == 1 || yy > 1, dn_ok = step == 1 || yy < height - 2;
         const uint16_t *up = up_ok ? c - (ptrdiff_t)step * pitch : c, *dn = dn_ok ? c + (ptrdiff_t)step * pitch : c;
@@ -767,44 +775,96 @@ __global__ __launch_bounds__(256) void q_dir_map(Q3 P, K16 k, int step, int expa
             for (int j = 0; j < 4 && x + j < width; j++) o[j] = o4[j];
         }
     }
-}
-
-__device__ __forceinline__ bool trips16(const uint16_t *side, const uint16_t *dc, int x, int from, int to, int lim, int peak)
-{
-    for (int j = from; j <= to; j++)
+    if (copy)
     {
-        const int s = side[x + j], c = dc[x + j], ref = dc[x];
-        if ((iabs16(s - ref) > lim && s != peak) || (s == peak && c == peak) || (iabs16(c - ref) > lim && c != peak)) return true;
-    }
-    return false;
-}
-
-// eedi2_filter_map (:538-635): a = mask, b = direction map in, c = out
-__global__ void q_filter_map(Q3 P, K16 k)
-{
-    XY16(P);
-    if (x >= width || y >= height) return;
-    const int peak = k.peak;
-    const uint16_t *dc = Q.b + (size_t)y * pitch;
-    int v = dc[x];
-    if (x >= 1 && x < width - 1 && y >= 1 && y < height - 1 && dc[x] != peak && Q.a[(size_t)y * pitch + x] == peak)
-    {
-        const uint16_t *dp = dc - pitch, *dn = dc + pitch;
-        int dir = ((int)dc[x] - k.neutral) >> 2;
-        const int lim = max(iabs16(dir) * 2, 12 << (2 + k.shift));
-        dir >>= 2 + k.shift;
-        bool ict;
-        if (dir < 0) ict = trips16(dp, dc, x, max(-x, dir), 0, lim, peak);
-        else         ict = trips16(dp, dc, x, 0, min(width - x - 1, dir), lim, peak);
-        if (ict)
+        uint16_t *o = Q.c + (size_t)yc * pitch + x;
+        if (x + 3 < width) *reinterpret_cast<uint2 *>(o) = vcopy;
+        else
         {
-            bool icb;
-            if (dir < 0) icb = trips16(dn, dc, x, 0, min(width - x - 1, iabs16(dir)), lim, peak);
-            else         icb = trips16(dn, dc, x, max(-x, -dir), 0, lim, peak);
-            if (icb) v = peak;
+            const uint16_t o4[4] = { (uint16_t)(vcopy.x & 0xffffu), (uint16_t)(vcopy.x >> 16), (uint16_t)(vcopy.y & 0xffffu), (uint16_t)(vcopy.y >> 16) };
+            for (int j = 0; j < 4 && x + j < width; j++) o[j] = o4[j];
         }
     }
-    Q.c[(size_t)y * pitch + x] = (uint16_t)v;
+}
+
+// eedi2_filter_map (:538-635): a = mask, b = direction map in, c = out.  The form of the 8-bit kernel (eedi2.hip:
+// k_filter_map): a workgroup stages its 4 + 2 rows of the map (256 samples + 8 either side) in LDS with 8-byte loads, a
+// thread owns four samples of its row, and both walks of a sample run in ONE loop whose step test is sign arithmetic:
+// lim - |s - ref| is negative when s is off by more than lim, s - peak unless s is the peak, 2 peak - 1 - c - s only
+// when both are the peak; the step trips on the sign of (off(s) & notpeak(s)) | (off(c) & notpeak(c)) | bothpeak.
+constexpr int QFM_W = 256, QFM_R = 4, QFM_HALO = 8, QFM_LW = QFM_W + 2 * QFM_HALO;
+
+__device__ __forceinline__ int qfm_step(uint32_t s, uint32_t c, uint32_t ref, int lim, int peak)
+{
+    const int off_s = lim - (int)__builtin_amdgcn_sad_u16(s, ref, 0u), off_c = lim - (int)__builtin_amdgcn_sad_u16(c, ref, 0u);
+    return (off_s & ((int)s - peak)) | (off_c & ((int)c - peak)) | (2 * peak - 1 - (int)c - (int)s);
+}
+
+__global__ __launch_bounds__(256) void q_filter_map(Q3 P, K16 k)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t s_d[QFM_R + 2][QFM_LW];
+    FIELD16(P);
+    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
+    const int bx0 = blockIdx.x * QFM_W, by0 = blockIdx.y * QFM_R;
+    if (bx0 >= width || by0 >= height) return;                   // whole workgroup outside
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    const int peak = k.peak;
+    {
+        // 6 rows x 68 groups of four samples for 256 threads: both loads of a thread in flight before the first LDS store
+        constexpr int G = QFM_LW / 4, N = (QFM_R + 2) * G;
+        static_assert(N <= 2 * 256, "two staged groups per thread");
+        uint2 v[2] = { make_uint2(0u, 0u), make_uint2(0u, 0u) }; // outside the plane: never looked at (the walks are clipped to the row)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+        {
+            const int i = tid + 256 * j, r = i / G, c4 = i - r * G;
+            const int yy = by0 - 1 + r, col = bx0 - QFM_HALO + 4 * c4;
+            if (i < N && yy >= 0 && yy < height && col >= 0 && col < pitch)
+                v[j] = *reinterpret_cast<const uint2 *>(Q.b + (size_t)yy * pitch + col);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+            if (tid + 256 * j < N) reinterpret_cast<uint2 *>(&s_d[0][0])[tid + 256 * j] = v[j];
+    }
+    const int x = bx0 + 4 * threadIdx.x, y = by0 + threadIdx.y;
+    const bool inside = x < width && y < height;
+    uint2 m4 = make_uint2(0u, 0u);
+    const bool mrow = inside && y >= 1 && y < height - 1;
+    if (mrow) m4 = *reinterpret_cast<const uint2 *>(Q.a + (size_t)y * pitch + x);
+    __syncthreads();
+    if (!inside) return;
+    const uint16_t *rc = &s_d[threadIdx.y + 1][QFM_HALO + 4 * threadIdx.x];
+    // the four samples and their mask as 64-bit words (sample j in bits 16 j ..): the loop below is not unrolled
+    unsigned long long out = *reinterpret_cast<const unsigned long long *>(rc);
+    const unsigned long long mw = (unsigned long long)m4.x | ((unsigned long long)m4.y << 32);
+#pragma unroll 1
+    for (int j = 0; j < 4; j++)
+    {
+        const int xx = x + j;
+        // candidates: mask peak, map not peak, inside the frame of :557-560
+        if (!(mrow && xx >= 1 && xx < width - 1 && (int)((mw >> (16 * j)) & 0xffffull) == peak && (int)rc[j] != peak)) continue;
+        const uint16_t *dc = rc + j, *dp = dc - QFM_LW, *dn = dc + QFM_LW;
+        const uint32_t ref = dc[0];
+        int dir = ((int)ref - k.neutral) >> 2;
+        const int lim = max(iabs16(dir) * 2, 12 << (2 + k.shift));
+        dir >>= 2 + k.shift;
+        // the four ranges of :565-620 with neg = min(dir, 0), pos = max(dir, 0): [max(-x, neg), min(w - x - 1, pos)] above,
+        // [max(-x, -pos), min(w - x - 1, -neg)] below; the shorter walk repeats its last step
+        const int neg = min(dir, 0), pos = max(dir, 0);
+        const int tf = max(-xx, neg), tt = min(width - xx - 1, pos), bf = max(-xx, -pos), bt = min(width - xx - 1, -neg);
+        const int n = max(tt - tf, bt - bf);
+        int any_t = 0, any_b = 0;
+        for (int i = 0; i <= n; i++)
+        {
+            const int jt = min(tf + i, tt), jb = min(bf + i, bt);
+            any_t |= qfm_step(dp[jt], dc[jt], ref, lim, peak);
+            any_b |= qfm_step(dn[jb], dc[jb], ref, lim, peak);
+        }
+        if ((any_t & any_b) < 0) out = (out & ~(0xffffull << (16 * j))) | ((unsigned long long)peak << (16 * j));
+    }
+    uint16_t *o = Q.c + (size_t)y * pitch + x;
+    if (x + 3 < width) *reinterpret_cast<uint2 *>(o) = make_uint2((uint32_t)out, (uint32_t)(out >> 32));
+    else for (int j = 0; j < 4 && x + j < width; j++) o[j] = (uint16_t)(out >> (16 * j));
 }
 
 // eedi2_upscale_by_2 (:98-108): whole pitch; a = half-height in, c = full-height out (height = half height).
@@ -820,21 +880,42 @@ __global__ void q_upscale(Q3 P)
     *reinterpret_cast<uint4 *>(Q.c + (size_t)(2 * y + 1) * pitch + x) = v;
 }
 
-// eedi2_mark_directions_2x (:787-858): a = msk2p, b = tmp2p2 (direction map), c = out (pre-filled PEAK, whole pitch)
-__global__ void q_mark_2x(Q3 P, K16 k)
+// eedi2_mark_directions_2x (:787-858): a = msk2p, b = tmp2p2 (direction map), c = out (pre-filled PEAK, whole pitch).
+// Four samples per thread and a PAIR of rows per thread row (2r, 2r + 1): the row with the rebuilt rows' parity is worked
+// on, the other is the memset's peak (eedi2.hip: k_mark_2x4).
+__global__ __launch_bounds__(256) void q_mark_2x(Q3 P, K16 k)
 {
-    XY16(P);
+    FIELD16(P);
+    const int x = 4 * (blockIdx.x * blockDim.x + threadIdx.x), r = blockIdx.y * blockDim.y + threadIdx.y;
+    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
     const int y0 = 2 - tff;
-    if (x >= pitch || y >= height) return;
+    if (x >= pitch || 2 * r >= height) return;
     const int peak = k.peak;
-    int v = peak;
-    if (x >= 1 && x < width - 1 && y >= y0 && y < height - 1 && ((y - y0) & 1) == 0)
+    const uint2 peak4 = make_uint2((uint32_t)peak | ((uint32_t)peak << 16), (uint32_t)peak | ((uint32_t)peak << 16));
+    const int y = 2 * r + (y0 & 1), yc = 2 * r + 1 - (y0 & 1);
+    if (yc < height) *reinterpret_cast<uint2 *>(Q.c + (size_t)yc * pitch + x) = peak4;
+    if (y >= height) return;
+    uint2 *o = reinterpret_cast<uint2 *>(Q.c + (size_t)y * pitch + x);
+    if (!(y >= y0 && y < height - 1)) { *o = peak4; return; }
+    const uint16_t *d0 = Q.b + (size_t)(y - 1) * pitch + x, *d1 = d0 + 2 * (size_t)pitch;
+    const uint16_t *m0 = Q.a + (size_t)(y - 1) * pitch + x, *m1 = m0 + 2 * (size_t)pitch;
+    // samples x-1 .. x+4 of the two direction rows, x .. x+3 of the two mask rows
+    const uint2 a4 = *reinterpret_cast<const uint2 *>(d0), b4 = *reinterpret_cast<const uint2 *>(d1);
+    const uint2 k0 = *reinterpret_cast<const uint2 *>(m0), k1 = *reinterpret_cast<const uint2 *>(m1);
+    const int al = x > 0 ? (int)d0[-1] : 0, ar = x + 4 < pitch ? (int)d0[4] : 0;
+    const int bl = x > 0 ? (int)d1[-1] : 0, br = x + 4 < pitch ? (int)d1[4] : 0;
+    const int A[6] = { al, (int)(a4.x & 0xffffu), (int)(a4.x >> 16), (int)(a4.y & 0xffffu), (int)(a4.y >> 16), ar };
+    const int B[6] = { bl, (int)(b4.x & 0xffffu), (int)(b4.x >> 16), (int)(b4.y & 0xffffu), (int)(b4.y >> 16), br };
+    const int M0[4] = { (int)(k0.x & 0xffffu), (int)(k0.x >> 16), (int)(k0.y & 0xffffu), (int)(k0.y >> 16) };
+    const int M1[4] = { (int)(k1.x & 0xffffu), (int)(k1.x >> 16), (int)(k1.y & 0xffffu), (int)(k1.y >> 16) };
+    uint32_t out[4] = { (uint32_t)peak, (uint32_t)peak, (uint32_t)peak, (uint32_t)peak };
+#pragma unroll
+    for (int j = 0; j < 4; j++)
     {
-        const uint16_t *d0 = Q.b + (size_t)(y - 1) * pitch, *d1 = d0 + 2 * (size_t)pitch;
-        const uint16_t *m0 = Q.a + (size_t)(y - 1) * pitch, *m1 = m0 + 2 * (size_t)pitch;
-        if (m0[x] == peak || m1[x] == peak)
+        const int xx = x + j;
+        if (xx >= 1 && xx < width - 1 && (M0[j] == peak || M1[j] == peak))
         {
-            const int a0 = d0[x - 1], a1 = d0[x], a2 = d0[x + 1], b0 = d1[x - 1], b1 = d1[x], b2 = d1[x + 1];
+            const int a0 = A[j], a1 = A[j + 1], a2 = A[j + 2], b0 = B[j], b1 = B[j + 1], b2 = B[j + 2];
             const bool h0 = a0 != peak, h1 = a1 != peak, h2 = a2 != peak, h3 = b0 != peak, h4 = b1 != peak, h5 = b2 != peak;
             const int n = h0 + h1 + h2 + h3 + h4 + h5;
             if (n >= 3)
@@ -853,12 +934,12 @@ __global__ void q_mark_2x(Q3 P, K16 k)
                     vote1q(v0, mid, lim, sum, count); vote1q(v1, mid, lim, sum, count); vote1q(v2, mid, lim, sum, count);
                     vote1q(v3, mid, lim, sum, count); vote1q(v4, mid, lim, sum, count); vote1q(v5, mid, lim, sum, count);
                     const int val = (int)(((float)(sum + mid) / (float)(count + 1)) + 0.5f);
-                    if (!(count < n - 2 || count < 2)) v = val;
+                    if (!(count < n - 2 || count < 2)) out[j] = (uint32_t)val;
                 }
             }
         }
     }
-    Q.c[(size_t)y * pitch + x] = (uint16_t)v;
+    *o = make_uint2(out[0] | (out[1] << 16), out[2] | (out[3] << 16));
 }
 
 // eedi2_fill_gaps_2x (:1025-1132): a = msk2p, b = direction map in, c = out.
@@ -1212,9 +1293,30 @@ __global__ __launch_bounds__(256) void q_lattice_cand(Q3 P, K16 k, int nt, unsig
                                  Q.a + (size_t)y * pitch };
         // only as far right as the row's samples (+ halo) reach; groups of four samples
         const int need4 = (min(LQ16_W, (width - x0 + 3) & ~3) + 2 * LQ16_HALO) / 4;
-        for (int r = 0; r < 5; r++)
-            for (int c4 = t; c4 < need4; c4 += 256)
-                reinterpret_cast<uint2 *>(s_rows[r])[c4] = reinterpret_cast<const uint2 *>(g[r] + x0 - LQ16_HALO)[c4];
+        // every load of a thread in flight before its first LDS store, one branch per column (eedi2.hip: k_lattice_cand_q)
+        static_assert(LQ16_LW / 4 <= 2 * 256, "two staged groups per row and thread");
+        uint2 v[5][2] = {};
+        const bool h0 = t < need4, h1 = t + 256 < need4;
+        if (h0)
+        {
+#pragma unroll
+            for (int r = 0; r < 5; r++) v[r][0] = reinterpret_cast<const uint2 *>(g[r] + x0 - LQ16_HALO)[t];
+        }
+        if (h1)
+        {
+#pragma unroll
+            for (int r = 0; r < 5; r++) v[r][1] = reinterpret_cast<const uint2 *>(g[r] + x0 - LQ16_HALO)[t + 256];
+        }
+        if (h0)
+        {
+#pragma unroll
+            for (int r = 0; r < 5; r++) reinterpret_cast<uint2 *>(s_rows[r])[t] = v[r][0];
+        }
+        if (h1)
+        {
+#pragma unroll
+            for (int r = 0; r < 5; r++) reinterpret_cast<uint2 *>(s_rows[r])[t + 256] = v[r][1];
+        }
     }
     __syncthreads();
     Lat16 L;
@@ -1290,13 +1392,22 @@ __global__ __launch_bounds__(256) void q_lattice_cand(Q3 P, K16 k, int nt, unsig
     }
 }
 
-constexpr int LR16_T = 1024;
+// Four samples per thread and pass over the row, as k_lattice_resolve of the 8-bit engine (eedi2.hip): the candidates of a
+// thread come in as two 16-byte loads, the direction row as 8 bytes, a thread composes the 2-state maps of its four samples
+// before the wave scan, both rows leave as 8 bytes, limlut sits in LDS.
+constexpr int LR16_T = 256, LR16_PX = 4 * LR16_T;
+
+__device__ __forceinline__ unsigned lr16_compose(unsigned later, unsigned earlier)     // later o earlier (earlier applies first)
+{
+    return ((later >> (earlier & 1u)) & 1u) | (((later >> ((earlier >> 1) & 1u)) & 1u) << 1);
+}
 
 __global__ __launch_bounds__(LR16_T) void q_lattice_resolve16(Q3 P, K16 k, const unsigned long long *__restrict__ cand,
                                                               int cand_pitch, int cand_plane_stride)
 {
     __shared__ uint8_t s_wmap[LR16_T / 64];        // composed map of each wave
     __shared__ uint8_t s_win[LR16_T / 64];         // resolved state entering each wave
+    __shared__ int s_lim[33];
     __shared__ int s_carry;                        // outcome of the last pixel of the previous pass
     FIELD16(P);
     const int field = tff;
@@ -1319,56 +1430,79 @@ __global__ __launch_bounds__(LR16_T) void q_lattice_resolve16(Q3 P, K16 k, const
     uint16_t *mid = dst + (size_t)y * pitch;
     uint16_t *dm = Q.a + (size_t)y * pitch;
     const unsigned long long *cr = cand + (size_t)pl * cand_plane_stride + (size_t)blockIdx.y * cand_pitch;
+    const bool cr16 = ((reinterpret_cast<uintptr_t>(cr)) & 15u) == 0;                   // block-uniform
+    const bool row8 = ((reinterpret_cast<uintptr_t>(mid) | reinterpret_cast<uintptr_t>(dm)) & 7u) == 0;
     const int sh2 = 2 + k.shift;
     const int before_row = dm[-1];                                 // stands at dm[x-1] for x == 0; never written by this pass
     if (t == 0) s_carry = 0;
+    if (t < 33) s_lim[t] = k.limlut[t];
     __syncthreads();
-    for (int x0 = 0; x0 < width; x0 += LR16_T)
+    for (int x0 = 0; x0 < width; x0 += LR16_PX)
     {
-        const int x = x0 + t;
-        const bool live = x < width;
-        int d = 0, lim = 0, valA = 0, newA = 0, valB = 0, newB = 0;
-        bool always_a = false, right = false;
-        if (live)
+        const int x = x0 + 4 * t;
+        const int nlive = min(max(width - x, 0), 4);             // samples of this thread inside the row
+        unsigned long long c[4] = { 0ull, 0ull, 0ull, 0ull };
+        int d[4] = { 0, 0, 0, 0 };
+        if (nlive == 4 && cr16)
         {
-            const unsigned long long c = cr[x];
-            d = dm[x];
-            lim = k.limlut[iabs16(d - k.neutral) >> sh2];
-            valA = (int)(c & 0xffff); valB = (int)((c >> 16) & 0xffff); newB = (int)((c >> 32) & 0xffff);
-            always_a = (c >> 48) & 1; right = (c >> 49) & 1;
-            newA = always_a ? k.peak : k.neutral;
+            const uint4 v0 = reinterpret_cast<const uint4 *>(cr + x)[0], v1 = reinterpret_cast<const uint4 *>(cr + x)[1];
+            c[0] = (unsigned long long)v0.x | ((unsigned long long)v0.y << 32); c[1] = (unsigned long long)v0.z | ((unsigned long long)v0.w << 32);
+            c[2] = (unsigned long long)v1.x | ((unsigned long long)v1.y << 32); c[3] = (unsigned long long)v1.z | ((unsigned long long)v1.w << 32);
         }
-        int pa = __shfl_up(newA, 1, 64), pb = __shfl_up(newB, 1, 64);
-        if (lane == 0 && live)
+        else
+            for (int j = 0; j < nlive; j++) c[j] = cr[x + j];
+        if (nlive == 4 && row8)
+        {
+            const uint2 v = *reinterpret_cast<const uint2 *>(dm + x);
+            d[0] = (int)(v.x & 0xffffu); d[1] = (int)(v.x >> 16); d[2] = (int)(v.y & 0xffffu); d[3] = (int)(v.y >> 16);
+        }
+        else
+            for (int j = 0; j < nlive; j++) d[j] = dm[x + j];
+        // what the last sample of the thread to the left can leave behind (pa: outcome A, pb: outcome B); the first lane of a
+        // wave reads that sample's candidate word
+        int pa = __shfl_up(((c[3] >> 48) & 1ull) ? k.peak : k.neutral, 1, 64), pb = __shfl_up((int)((c[3] >> 32) & 0xffffull), 1, 64);
+        if (lane == 0 && nlive)
         {
             if (x == 0) { pa = before_row; pb = before_row; }
             else
             {
                 const unsigned long long cl = cr[x - 1];
-                pa = ((cl >> 48) & 1) ? k.peak : k.neutral;
-                pb = (int)((cl >> 32) & 0xffff);
+                pa = ((cl >> 48) & 1ull) ? k.peak : k.neutral;
+                pb = (int)((cl >> 32) & 0xffffull);
             }
         }
-        unsigned m;                                            // bit s = outcome when the left pixel took outcome s
-        if (!live || always_a) m = 0u;
-        else
+        unsigned m[4], pm[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
         {
-            const unsigned oa = (right && iabs16(d - pa) > lim) ? 0u : 1u;
-            const unsigned ob2 = (right && iabs16(d - pb) > lim) ? 0u : 1u;
-            m = oa | (ob2 << 1);
+            const unsigned long long cj = c[j];
+            const int lim = s_lim[min(iabs16(d[j] - k.neutral) >> sh2, 32)];
+            const bool always_a = (cj >> 48) & 1ull, right = (cj >> 49) & 1ull;
+            if (j >= nlive || always_a) m[j] = 0u;
+            else
+            {
+                const unsigned oa = (right && iabs16(d[j] - pa) > lim) ? 0u : 1u;
+                const unsigned ob2 = (right && iabs16(d[j] - pb) > lim) ? 0u : 1u;
+                m[j] = oa | (ob2 << 1);
+            }
+            pm[j] = j == 0 ? m[0] : lr16_compose(m[j], pm[j - 1]);
+            pa = always_a ? k.peak : k.neutral;
+            pb = (int)((cj >> 32) & 0xffffull);
         }
+        unsigned tm = pm[3];
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1)
         {
-            const unsigned e = __shfl_up(m, off, 64);
-            if (lane >= off)
-                m = ((m >> (e & 1u)) & 1u) | (((m >> ((e >> 1) & 1u)) & 1u) << 1);
+            const unsigned e = __shfl_up(tm, off, 64);
+            if (lane >= off) tm = lr16_compose(tm, e);
         }
-        if (lane == 63) s_wmap[wave] = (uint8_t)m;
+        if (lane == 63) s_wmap[wave] = (uint8_t)tm;
+        unsigned before = __shfl_up(tm, 1, 64);
+        if (lane == 0) before = 2u;                                  // the identity map
         __syncthreads();
         if (t == 0)
         {
-            unsigned state = (unsigned)s_carry;                  // outcome of pixel x0 - 1 (irrelevant for x0 == 0)
+            unsigned state = (unsigned)s_carry;                      // outcome of sample x0 - 1 (irrelevant for x0 == 0)
             for (int w = 0; w < LR16_T / 64; w++)
             {
                 s_win[w] = (uint8_t)state;
@@ -1376,32 +1510,62 @@ __global__ __launch_bounds__(LR16_T) void q_lattice_resolve16(Q3 P, K16 k, const
             }
         }
         __syncthreads();
-        const unsigned outcome = (m >> s_win[wave]) & 1u;
-        if (live)
+        const unsigned sin = (before >> s_win[wave]) & 1u;
+        if (nlive)
         {
-            mid[x] = (uint16_t)(outcome ? valB : valA);
-            const int nd = outcome ? newB : newA;
-            if (nd != d) dm[x] = (uint16_t)nd;
+            uint32_t vm[4], vd[4];
+            unsigned last = 0u;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+            {
+                const unsigned outcome = (pm[j] >> sin) & 1u;
+                const unsigned long long cj = c[j];
+                vm[j] = (uint32_t)(outcome ? (cj >> 16) & 0xffffull : cj & 0xffffull);
+                vd[j] = outcome ? (uint32_t)((cj >> 32) & 0xffffull) : (uint32_t)(((cj >> 48) & 1ull) ? k.peak : k.neutral);
+                if (j == nlive - 1) last = outcome;
+            }
+            if (nlive == 4 && row8)
+            {
+                *reinterpret_cast<uint2 *>(mid + x) = make_uint2(vm[0] | (vm[1] << 16), vm[2] | (vm[3] << 16));
+                *reinterpret_cast<uint2 *>(dm + x) = make_uint2(vd[0] | (vd[1] << 16), vd[2] | (vd[3] << 16));
+            }
+            else
+                for (int j = 0; j < nlive; j++) { mid[x + j] = (uint16_t)vm[j]; dm[x + j] = (uint16_t)vd[j]; }
+            if (x + nlive == min(x0 + LR16_PX, width)) s_carry = (int)last;
         }
-        if (x == min(x0 + LR16_T, width) - 1) s_carry = (int)outcome;
         __syncthreads();
     }
 }
 
 // eedi2_post_process (:1349-1378): a = new direction map, b = old one, c = dst2p (in place, rows y from y+-1)
-__global__ void q_post(Q3 P, K16 k)
+// (four samples per thread, a thread row per REBUILT row: the rows in between have nothing to do here)
+__global__ __launch_bounds__(256) void q_post(Q3 P, K16 k)
 {
-    XY16(P);
-    const int y0 = 2 - tff;
-    if (x >= width || y < y0 || y >= height - 1 || ((y - y0) & 1)) return;
+    FIELD16(P);
+    const int x = 4 * (blockIdx.x * blockDim.x + threadIdx.x), r = blockIdx.y * blockDim.y + threadIdx.y;
+    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
+    const int y = (2 - tff) + 2 * r;
+    if (x >= width || y >= height - 1) return;
     const size_t at = (size_t)y * pitch + x;
-    const int nm = Q.a[at], om = Q.b[at];
-    const int lim = k.limlut[iabs16(nm - k.neutral) >> (2 + k.shift)];
-    if (iabs16(nm - om) > lim && om != k.peak && om != k.neutral)
+    const uint2 nm4 = *reinterpret_cast<const uint2 *>(Q.a + at), om4 = *reinterpret_cast<const uint2 *>(Q.b + at);
+    uint16_t *d = Q.c + at;
+    const uint2 up4 = *reinterpret_cast<const uint2 *>(d - pitch), dn4 = *reinterpret_cast<const uint2 *>(d + pitch);
+    const uint2 cur4 = *reinterpret_cast<const uint2 *>(d);
+    auto s4 = [](const uint2 &v, int j) -> int { return (int)(((j < 2 ? v.x : v.y) >> (16 * (j & 1))) & 0xffffu); };
+    uint32_t out[4];
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
     {
-        uint16_t *d = Q.c + at;
-        *d = (uint16_t)(((int)d[-pitch] + (int)d[pitch] + 1) >> 1);
+        const int nm = s4(nm4, j), om = s4(om4, j);
+        const int lim = k.limlut[iabs16(nm - k.neutral) >> (2 + k.shift)];
+        const bool fix = iabs16(nm - om) > lim && om != k.peak && om != k.neutral;
+        out[j] = fix ? (uint32_t)((s4(up4, j) + s4(dn4, j) + 1) >> 1) : (uint32_t)s4(cur4, j);
+        any |= fix;
     }
+    if (!any) return;
+    if (x + 3 < width) *reinterpret_cast<uint2 *>(d) = make_uint2(out[0] | (out[1] << 16), out[2] | (out[3] << 16));
+    else for (int j = 0; j < 4 && x + j < width; j++) d[j] = (uint16_t)out[j];
 }
 
 // ---- post-processing 2/3 (:1391-1904), as in eedi2.hip but on uint16 samples -----------------------
@@ -1637,6 +1801,9 @@ int Eedi2Engine16::enqueue(int n, hbhip_ctx *lc)
     auto grid4 = [&](const EediFrame &f, unsigned z) {                          // four samples per thread, blocks of 64 x 4 threads
         return dim3((f.width[0] + 255) / 256, (f.height[0] + 3) / 4, z);
     };
+    auto grid4p = [&](const EediFrame &f, unsigned z) {                         // the same with a thread row per PAIR of rows (step 2)
+        return dim3((f.width[0] + 255) / 256, ((f.height[0] + 1) / 2 + 3) / 4, z);
+    };
     auto grid8 = [&](const EediFrame &f, bool whole_pitch, unsigned z) {      // kernels with eight samples per thread
         const int w = whole_pitch ? f.stride[0] / 2 : f.width[0];
         return dim3((w + 511) / 512, (f.height[0] + 3) / 4, z);
@@ -1685,7 +1852,7 @@ int Eedi2Engine16::enqueue(int n, hbhip_ctx *lc)
     bind(P.a, mskp); bind(P.b, dstp); bind(P.c, tmpp);
     HBHIP_LAUNCH(lc, "eedi2_16_expand_dir_map", q_dir_map, grid4(srcp, gz), blk, 0, P, k, 1, 1);
     bind(P.a, mskp); bind(P.b, tmpp); bind(P.c, dstp);
-    HBHIP_LAUNCH(lc, "eedi2_16_filter_map", q_filter_map, grid(srcp, false, gz), blk, 0, P, k);
+    HBHIP_LAUNCH(lc, "eedi2_16_filter_map", q_filter_map, grid4(srcp, gz), blk, 0, P, k);
     // line doubling
     bind(P.a, srcp); bind(P.c, dst2p);
     HBHIP_LAUNCH(lc, "eedi2_16_upscale", q_upscale, grid8(srcp, true, gz), blk, 0, P);
@@ -1696,11 +1863,12 @@ int Eedi2Engine16::enqueue(int n, hbhip_ctx *lc)
     // full-height passes
     geom(P, dst2p);
     bind(P.a, msk2p); bind(P.b, tmp2p2); bind(P.c, tmp2p);
-    HBHIP_LAUNCH(lc, "eedi2_16_mark_directions_2x", q_mark_2x, grid(dst2p, true, gz), blk, 0, P, k);
+    HBHIP_LAUNCH(lc, "eedi2_16_mark_directions_2x", q_mark_2x,                                    // a thread row per pair of rows, four samples per thread
+                 dim3((dst2p.stride[0] / 2 + 255) / 256, ((dst2p.height[0] + 1) / 2 + 3) / 4, gz), blk, 0, P, k);
     bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
-    HBHIP_LAUNCH(lc, "eedi2_16_filter_dir_map_2x", q_dir_map, grid4(dst2p, gz), blk, 0, P, k, 2, 0);
+    HBHIP_LAUNCH(lc, "eedi2_16_filter_dir_map_2x", q_dir_map, grid4p(dst2p, gz), blk, 0, P, k, 2, 0);
     bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
-    HBHIP_LAUNCH(lc, "eedi2_16_expand_dir_map_2x", q_dir_map, grid4(dst2p, gz), blk, 0, P, k, 2, 1);
+    HBHIP_LAUNCH(lc, "eedi2_16_expand_dir_map_2x", q_dir_map, grid4p(dst2p, gz), blk, 0, P, k, 2, 1);
     for (int pass = 0; pass < 2; pass++)
     {
         const EediFrame &in = pass ? dst2mp : tmp2p, &out = pass ? tmp2p : dst2mp;
@@ -1720,11 +1888,11 @@ int Eedi2Engine16::enqueue(int n, hbhip_ctx *lc)
         bind(P.a, tmp2p); bind(P.c, tmp2p2);
         HBHIP_LAUNCH(lc, "eedi2_16_blit", q_blit, grid8(dst2p, false, gz), blk, 0, P);             // eedi2_bit_blit(tmp2p -> tmp2p2)
         bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
-        HBHIP_LAUNCH(lc, "eedi2_16_filter_dir_map_2x", q_dir_map, grid4(dst2p, gz), blk, 0, P, k, 2, 0);
+        HBHIP_LAUNCH(lc, "eedi2_16_filter_dir_map_2x", q_dir_map, grid4p(dst2p, gz), blk, 0, P, k, 2, 0);
         bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
-        HBHIP_LAUNCH(lc, "eedi2_16_expand_dir_map_2x", q_dir_map, grid4(dst2p, gz), blk, 0, P, k, 2, 1);
+        HBHIP_LAUNCH(lc, "eedi2_16_expand_dir_map_2x", q_dir_map, grid4p(dst2p, gz), blk, 0, P, k, 2, 1);
         bind(P.a, tmp2p); bind(P.b, tmp2p2); bind(P.c, dst2p);
-        HBHIP_LAUNCH(lc, "eedi2_16_post_process", q_post, grid(dst2p, false, gz), blk, 0, P, k);
+        HBHIP_LAUNCH(lc, "eedi2_16_post_process", q_post, grid4p(dst2p, gz), blk, 0, P, k);
     }
     if (par_.post_processing == 2 || par_.post_processing == 3)
     {
