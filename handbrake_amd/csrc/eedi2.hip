@@ -135,6 +135,7 @@ __device__ __forceinline__ int mid9(int &v0, int &v1, int &v2, int &v3, int &v4,
     cswap(v1, v2); cswap(v3, v4); cswap(v5, v6);
     // n = 4..9: lower middle index (n-1)>>1 = 1,2,2,3,3,4 ; upper n>>1 = 2,2,3,3,4,4.  The lower one only counts for even n,
     // where it is the upper one's left neighbour: both come off the same two comparisons
+    // (tests/test_eedi2_identities_cpu.py::test_midpoint_selection_and_unsorted_vote)
     const bool n5 = n <= 5, n7 = n <= 7;
     const int hi = n5 ? v2 : (n7 ? v3 : v4);
     const int lo = n5 ? v1 : (n7 ? v2 : v3);
@@ -665,6 +666,7 @@ __device__ __forceinline__ int calc_dir_search(const uint32_t *tr, PASS pass, in
         const int mid = (lo + hi + 1) >> 1;
         // max(limlut[|mid|] >> 2, 2) without the table (a dependent load per pixel): |mid| <= 30 here, and the table
         // (eedi2.c:21-25) is 12 from entry 13 on and below 12 before it - 3 and 2 after the shift and the max
+        // (tests/test_eedi2_identities_cpu.py::test_calc_directions_vote_limit_closed_form)
         static_assert(CD_HALO - 2 <= 30, "the closed form of limlut covers entries 0..30");
         const int tlim = iabs(mid) >= 13 ? 3 : 2;
         int sum = 0, cnt = 0;
@@ -1065,6 +1067,7 @@ constexpr int FM_W = 256, FM_R = 4, FM_HALO = 8, FM_LW = FM_W + 2 * FM_HALO;
 // integer - lim - |s - ref| is negative when s is off by more than lim, s - 255 is negative unless s is the peak,
 // 509 - c - s is negative only when both are the peak - and the step trips when the sign of
 // (off(s) & notpeak(s)) | (off(c) & notpeak(c)) | bothpeak is set.  v_sad_u16 of two bytes is their absolute difference.
+// (Every s, c, ref and limit: tests/test_eedi2_identities_cpu.py, which also holds the unified ranges of the loop below.)
 __device__ __forceinline__ int fm_step(uint32_t s, uint32_t c, uint32_t ref, int lim)
 {
     const int off_s = lim - (int)__builtin_amdgcn_sad_u16(s, ref, 0u), off_c = lim - (int)__builtin_amdgcn_sad_u16(c, ref, 0u);
@@ -1692,7 +1695,8 @@ __global__ __launch_bounds__(256) void k_lattice_cand_q(P3 P, uint32_t *__restri
 // leave as dwords (one pixel per thread, byte loads and stores: 144 us per 16 fields).
 constexpr int LR_T = 256, LR_PX = 4 * LR_T;
 
-// later o earlier: the map that applies `earlier` first
+// later o earlier: the map that applies `earlier` first (the thread / wave / pass composition against the pixel-by-pixel
+// walk: tests/test_eedi2_identities_cpu.py::test_lattice_resolve_scan_equals_the_serial_walk)
 __device__ __forceinline__ unsigned lr_compose(unsigned later, unsigned earlier)
 {
     return ((later >> (earlier & 1u)) & 1u) | (((later >> ((earlier >> 1) & 1u)) & 1u) << 1);

@@ -1,5 +1,5 @@
 // eedi2_vote.h - the rounded average of the EEDI2 direction votes, shared by eedi2.hip and tools/vote_avg_check.hip (which runs
-// every (a, b) the kernels can produce through it on the GPU; tests/test_eedi2_gpu.py::test_vote_avg_every_case).
+// every (a, b) the kernels can produce through it on the GPU; tests/test_eedi2_gpu.py::test_vote_avg_every_case; the float identity on the host: tests/test_eedi2_identities_cpu.py).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>

@@ -1,0 +1,190 @@
+"""The arithmetic identities the EEDI2 kernels of round 3 rest on, checked on the CPU over their whole domains.
+
+The GPU parity tests compare every scratch plane of a pass with the oracle on synthetic frames - content decides
+which corners of an expression they reach.  The rewrites below replace an expression of the reference by a cheaper
+one that is claimed to be the SAME function; each claim is restated here (numpy, the kernel's integer / float32
+operations transcribed one for one) and tried on every input the kernels can form, or on all of a reduced domain.
+Nothing here runs a kernel: csrc/eedi2.hip, csrc/eedi2_16.hip and csrc/eedi2_vote.h name the test that covers them.
+"""
+import itertools
+
+import numpy as np
+
+LIMLUT = [6, 6, 7, 7, 8, 8, 9, 9, 9, 10, 10, 11, 11, 12, 12, 12, 12, 12, 12, 12,
+          12, 12, 12, 12, 12, 12, 12, 12, 12, 12, 12, -1, -1]            # eedi2.c:21-25
+
+
+def test_filter_map_step_as_sign_arithmetic_8bit():
+    """k_filter_map's fm_step (eedi2.hip): (|s-ref| > lim && s != 255) || (c == 255 && s == 255) || (|c-ref| > lim &&
+    c != 255) is the sign of (lim-|s-ref| & s-255) | (lim-|c-ref| & c-255) | (509-c-s) - every s, c, ref and the limits
+    a direction value can give (lim = max(2 |dir|, 48), |dir| <= 32)."""
+    s = np.arange(256, dtype=np.int32)[:, None, None]
+    c = np.arange(256, dtype=np.int32)[None, :, None]
+    ref = np.arange(256, dtype=np.int32)[None, None, :]
+    for lim in sorted({max(2 * abs(d), 48) for d in range(-32, 32)}):
+        want = ((np.abs(s - ref) > lim) & (s != 255)) | ((c == 255) & (s == 255)) | ((np.abs(c - ref) > lim) & (c != 255))
+        got = (((lim - np.abs(s - ref)) & (s - 255)) | ((lim - np.abs(c - ref)) & (c - 255)) | (509 - c - s)) < 0
+        assert np.array_equal(want, got), lim
+
+
+def test_filter_map_step_as_sign_arithmetic_16bit():
+    """q_filter_map's qfm_step (eedi2_16.hip) at 10 and 12 bits: the same with peak = 2^depth - 1 and 2 peak - 1 - c - s;
+    random samples plus the values around the peak and the limits."""
+    rng = np.random.default_rng(7)
+    for depth in (10, 12):
+        peak, shift = (1 << depth) - 1, depth - 8
+        n = 400_000
+        edge = np.array([0, 1, peak - 1, peak, peak // 2, peak // 2 + 1], dtype=np.int64)
+        s = np.concatenate([rng.integers(0, peak + 1, n), rng.choice(edge, n)])
+        c = np.concatenate([rng.choice(edge, n), rng.integers(0, peak + 1, n)])
+        ref = rng.integers(0, peak + 1, 2 * n)
+        d = rng.integers(-(1 << (depth - 3)), 1 << (depth - 3), 2 * n)
+        lim = np.maximum(np.abs(d) * 2, 12 << (2 + shift))
+        want = ((np.abs(s - ref) > lim) & (s != peak)) | ((c == peak) & (s == peak)) | ((np.abs(c - ref) > lim) & (c != peak))
+        got = (((lim - np.abs(s - ref)) & (s - peak)) | ((lim - np.abs(c - ref)) & (c - peak)) | (2 * peak - 1 - c - s)) < 0
+        assert np.array_equal(want, got), depth
+
+
+def test_filter_map_ranges_unified():
+    """The four walk ranges of eedi2_template.c:565-620 as [max(-x, neg), min(w-x-1, pos)] above and
+    [max(-x, -pos), min(w-x-1, -neg)] below, neg = min(dir, 0), pos = max(dir, 0), for every interior x."""
+    for width in (3, 4, 9, 17, 40):
+        for x in range(1, width - 1):
+            for d in range(-8, 9):
+                if d < 0:
+                    top = (max(-x, d), 0)
+                    bot = (0, min(width - x - 1, abs(d)))
+                else:
+                    top = (0, min(width - x - 1, d))
+                    bot = (max(-x, -d), 0)
+                neg, pos = min(d, 0), max(d, 0)
+                assert top == (max(-x, neg), min(width - x - 1, pos))
+                assert bot == (max(-x, -pos), min(width - x - 1, -neg))
+
+
+def test_calc_directions_vote_limit_closed_form():
+    """max(limlut[|mid|] >> 2, 2) == (|mid| >= 13 ? 3 : 2) for every |mid| the LDS search can produce (<= 30)."""
+    for m in range(31):
+        assert max(LIMLUT[m] >> 2, 2) == (3 if m >= 13 else 2)
+
+
+def test_vote_average_is_an_integer_floor():
+    """(int)((float)a / (float)b + 0.5f) == (2a + b) // (2b) for a = sum + mid <= 2559, b = count + 1 <= 10
+    (csrc/eedi2_vote.h; the device side of it, v_rcp_f32 included, runs in tests/test_eedi2_gpu.py)."""
+    a = np.arange(2560, dtype=np.int64)
+    for b in range(1, 11):
+        ref = (a.astype(np.float32) / np.float32(b) + np.float32(0.5)).astype(np.int32)
+        assert np.array_equal(ref, (2 * a + b) // (2 * b)), b
+        # the reciprocal form with a reciprocal off by up to two units in the last place, and its one correction
+        n, m = (2 * a + b).astype(np.float32), np.float32(2 * b)
+        r0 = np.float32(1.0) / m
+        for ulp in (-2, -1, 0, 1, 2):
+            r = r0
+            for _ in range(abs(ulp)):
+                r = np.nextafter(r, np.float32(np.inf if ulp > 0 else -np.inf))
+            q = (n * r).astype(np.int64)
+            q += ((2 * a + b) - q * (2 * b)) >= 2 * b
+            assert np.array_equal(q, (2 * a + b) // (2 * b)), (b, ulp)
+
+
+def _sorted_mid(v):
+    """eedi2.c:65-80 on the present values."""
+    v = sorted(v)
+    n = len(v)
+    return v[n >> 1] if n & 1 else (v[(n - 1) >> 1] + v[n >> 1] + 1) >> 1
+
+
+def test_midpoint_selection_and_unsorted_vote():
+    """mid9's two middle entries off the same two comparisons (n <= 5, n <= 7), absent slots as a value above every
+    present one; and the vote (a sum and a count of the slots within lim of the midpoint) taken on the slots as they
+    are instead of the sorted ones."""
+    rng = np.random.default_rng(3)
+    ABSENT = 1000
+    for _ in range(20000):
+        n = int(rng.integers(4, 10))
+        present = [int(x) for x in rng.integers(0, 255, n)]
+        slots = present + [ABSENT] * (9 - n)
+        rng.shuffle(slots)
+        v = sorted(slots)
+        n5, n7 = n <= 5, n <= 7
+        hi = v[2] if n5 else (v[3] if n7 else v[4])
+        lo = v[1] if n5 else (v[2] if n7 else v[3])
+        mid = hi if n & 1 else (lo + hi + 1) >> 1
+        assert mid == _sorted_mid(present)
+        lim = int(rng.integers(0, 13))
+        in_sorted = [x for x in v if abs(x - mid) <= lim]
+        in_slots = [x for x in slots if abs(x - mid) <= lim]
+        assert (sum(in_sorted), len(in_sorted)) == (sum(in_slots), len(in_slots))
+        assert ABSENT not in in_slots
+
+
+def _compose(later, earlier):
+    """lr_compose (eedi2.hip): the 2-state map that applies `earlier` first; bit s = outcome for incoming state s."""
+    return ((later >> (earlier & 1)) & 1) | (((later >> ((earlier >> 1) & 1)) & 1) << 1)
+
+
+def test_lattice_resolve_scan_equals_the_serial_walk():
+    """k_lattice_resolve: the outcome of a pixel depends on its left neighbour's outcome only, so a row is a chain of
+    2-state maps.  The kernel composes the maps of a thread's four pixels, scans the threads' maps inside a wave,
+    chains the waves and carries the last outcome into the next pass; resolved that way a row must come out as it does
+    walked pixel by pixel."""
+    rng = np.random.default_rng(11)
+    T, PX, W = 256, 4, 64                                     # threads per workgroup, pixels per thread, wave size
+    for width in (1, 3, 4, 5, 63, 64, 255, 960, 1023, 1024, 1025, 1920, 2500):
+        maps = rng.integers(0, 4, width)
+        # the serial walk: pixel 0's incoming state is irrelevant for the kernel (both bits equal there); force that
+        maps[0] = 3 * int(rng.integers(0, 2))
+        state, serial = 0, []
+        for m in maps:
+            state = (int(m) >> state) & 1
+            serial.append(state)
+        out, carry = [], 0
+        for x0 in range(0, width, T * PX):
+            pm = np.zeros((T, PX), dtype=np.int64)
+            for t in range(T):
+                for k in range(PX):
+                    x = x0 + PX * t + k
+                    m = int(maps[x]) if x < width else 0
+                    pm[t, k] = m if k == 0 else _compose(m, int(pm[t, k - 1]))
+            tm = pm[:, PX - 1].copy()
+            for w in range(T // W):                            # inclusive scan inside each wave
+                seg = tm[w * W:(w + 1) * W]
+                off = 1
+                while off < W:
+                    prev = seg.copy()
+                    for lane in range(off, W):
+                        seg[lane] = _compose(int(prev[lane]), int(prev[lane - off]))
+                    off <<= 1
+            win, state = [], carry
+            for w in range(T // W):
+                win.append(state)
+                state = (int(tm[w * W + W - 1]) >> state) & 1
+            for t in range(T):
+                lane, w = t % W, t // W
+                before = 2 if lane == 0 else int(tm[t - 1])
+                sin = (before >> win[w]) & 1
+                for k in range(PX):
+                    x = x0 + PX * t + k
+                    if x < width:
+                        o = (int(pm[t, k]) >> sin) & 1
+                        out.append(o)
+                        if x == min(x0 + T * PX, width) - 1:
+                            carry = o
+        assert out == serial, width
+
+
+def test_row_pairs_cover_every_row_once():
+    """The _2x passes with a thread row per PAIR of rows (2r, 2r + 1): the row with the rebuilt rows' parity goes through
+    the pass (or is copied when it is outside y0 .. height - 2), the other is copied - every row of the plane exactly
+    once, the rebuilt ones exactly the reference's (y0, y0 + 2, ... < height - 1), for both field parities."""
+    for height, tff in itertools.product((2, 3, 4, 5, 8, 9, 270, 271, 540, 1080, 1081), (0, 1)):
+        y0 = 2 - tff
+        work, copied = [], []
+        for r in range((height + 1) // 2):
+            y, yc = 2 * r + (y0 & 1), 2 * r + 1 - (y0 & 1)
+            if yc < height:
+                copied.append(yc)
+            if y < height:
+                (work if y0 <= y < height - 1 else copied).append(y)
+        assert sorted(work + copied) == list(range(height))
+        assert work == list(range(y0, height - 1, 2))
