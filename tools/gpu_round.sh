@@ -41,6 +41,7 @@ timeout 240 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES
 timeout 240 rocprofv3 --kernel-trace --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_SMEM --output-format csv -d $OUT/pmc_SQ2 -o pmc -- $PROF > $OUT/pmc_SQ2.log 2>&1
 cd $R
 python tools/summarize_pmc.py $OUT $OUT/pmc_summary.json > /dev/null 2>&1
+python tools/kernel_bounds.py $OUT/pmc_summary.json $(find $OUT/kt -name '*kernel_stats.csv' | head -1) $OUT/kernel_bounds.json > $OUT/kernel_bounds.txt 2>&1
 # keep only small files
 find $OUT -name '*kernel_trace.csv' -size +3M -delete
 find $OUT -name '*counter_collection.csv' -delete
