@@ -27,7 +27,9 @@ Also on the JSON line:
   roofline       dominant kernel of the workload (largest share of GPU time): algorithmic bytes per
                  launch / its mean launch time.  Launch times come from a pass right after the timed
                  region in which the same launches are bracketed by HIP events on the stream they run
-                 on; `kernels` lists the rest.
+                 on; `kernels` lists the rest.  `roofline.valu` prices the kernel's vector instructions with its own mix,
+                 `roofline.issue_floors` carries the committed vector / scalar / LDS / HBM floors of that kernel
+                 (tools/kernel_bounds.py on the newest counter passes under profiles/ - evidence, not a measurement of this run).
   cpu_baseline   the reference's own C filters (oracle/_ref, threaded by its own taskset.c as libhb
                  does) on this box's host cores, bounded sample; the scaler leg is our restatement
                  (zimg is not buildable here) and is labelled as such.
@@ -355,6 +357,23 @@ ISA_NAMES = {"eedi2_calc_directions": ("r3_eedi2_isa_mix.json", "k_calc_dir_rows
              "cropscale_lanczos_fused": ("r3_alias_isa_mix.json", "scale8_up_kernel")}
 
 
+def issue_floors(kname):
+    """The committed per-kernel floors (tools/kernel_bounds.py on the newest counter passes: the time a launch of the
+    profiled shape would take if the vector pipe, the scalar unit, the LDS or the memory were its only limit) for the
+    kernel behind a profiler name - static evidence carried on the line, not measured by this run; None without it."""
+    own = ISA_NAMES.get(kname)
+    try:
+        files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_kernel_bounds.json"))
+        rec = json.load(open(os.path.join(ROOT, "profiles", files[-1])))
+        key = own[1].split("(")[0]
+        k, v = next((k, v) for k, v in rec["kernels"].items() if k.startswith(key))
+        return {"kernel": k, "profiled_launch_us": v["launch_us"], "valu_us": v["valu_us"], "salu_us": v["salu_us"],
+                "lds_us": v["lds_us"], "hbm_us": v["hbm_us"], "bound": v["bound"], "floor_frac": v["floor_frac"],
+                "source": "profiles/" + files[-1]}
+    except Exception:
+        return None
+
+
 def valu_roofline(valu_insts, avg_s, kname=None):
     """wave64 VALU instructions (SQ_INSTS_VALU of the committed PMC pass) against the issue peak of the kernel's OWN
     instruction mix: its text classified by tools/isa_mix.py into the issue classes tools/valu_rate.hip measured on
@@ -556,6 +575,9 @@ def run_chain(args, world, rank, local_rank):
                                 "`frames_per_launch` fields"}
                 if valu:
                     roof["valu"] = valu_roofline(valu, d["avg_us"] * 1e-6, d["kernel"])
+                fl = issue_floors(d["kernel"])
+                if fl:
+                    roof["issue_floors"] = fl
         per_out = {"chain": 62_208_000, "chain2160": 4 * frame_bytes(W, H) + 3 * frame_bytes(W, H) + 2 * frame_bytes(W, H),
                    "decomb_eedi2": 4 * frame_bytes(W, H)}[args.workload]      # SURVEY §8d, per output frame
         line = {

@@ -46,3 +46,12 @@ def test_counter_table_and_instruction_mixes_cover_the_dominant_kernels():
     t16, _ = bench.pmc_record("eedi2_calc_directions", 16.0)
     t8, _ = bench.pmc_record("eedi2_calc_directions", 8.0)
     assert abs(t8 * 2 - t16) < 1e-6 * t16
+
+
+def test_issue_floors_of_the_dominant_kernels():
+    for name, bound in (("eedi2_calc_directions", "valu"), ("nlmeans_plane_n7", "valu"), ("eedi2_lattice_candidates", "lds"),
+                        ("eedi2_fill_gaps_2x", "salu")):
+        f = bench.issue_floors(name)
+        assert f and f["bound"] == bound and 0.3 < f["floor_frac"] <= 1.0, (name, f)
+        assert max(f["valu_us"], f["salu_us"], f["lds_us"], f["hbm_us"]) <= f["profiled_launch_us"]
+    assert bench.issue_floors("no_such_kernel") is None
