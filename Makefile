@@ -2,6 +2,7 @@
 #   make            everything
 #   make product    libhbrt.so, libhbhip.so (HIP kernels + C-ABI), libhbhip_filters.so
 #   make dev        the product libraries with -DHBHIP_DEV (tuning knobs from the environment; never shipped / tested)
+#   make devlib     the same kernels library as build/dev/libhbhip.so, beside the product one (tools/exp_knobs.sh)
 #   make oracle     liboracle.so and, when /root/reference exists, oracle/_ref/libhbref.so
 HIPCC   ?= /opt/rocm/bin/hipcc
 CC      ?= gcc
@@ -43,8 +44,19 @@ dev:
 	$(MAKE) product HIPFLAGS="$(HIPFLAGS) -DHBHIP_DEV"
 	rm -f $(HIP_OBJ)
 
+# the development kernels library BESIDE the product one (build/dev/libhbhip.so, own objects): what tools/exp_knobs.sh swaps
+# in on the GPU box for knob experiments and swaps out again; nothing of the product build is touched
+DEV_OBJ := $(HIP_SRC:$(PKG)/csrc/%.hip=build/dev/%.o)
+build/dev/%.o: $(PKG)/csrc/%.hip $(HIP_HDR)
+	@mkdir -p build/dev
+	$(HIPCC) $(HIPFLAGS) -DHBHIP_DEV -c $< -o $@
+build/dev/libhbhip.so: $(DEV_OBJ)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(DEV_OBJ)
+devlib: build/dev/libhbhip.so
+
 clean:
+	rm -rf build/dev
 	rm -f $(PKG)/*.so $(PKG)/csrc/*.o
 	$(MAKE) -C oracle clean
 
-.PHONY: all product oracle clean dev
+.PHONY: all product oracle clean dev devlib

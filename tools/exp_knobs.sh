@@ -1,6 +1,6 @@
 #!/bin/bash
 # Development-build experiments on the GPU box (via gpurun): the chain / decomb workloads under the tuning knobs of a
-# `make dev` build of the kernels library kept beside the product one (build/dev/libhbhip.so).
+# development build of the kernels library kept beside the product one (`make devlib` -> build/dev/libhbhip.so).
 # The product library is put back before anything else runs.  Usage: tools/exp_knobs.sh <tag> "<ENV=V ...>" ...
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
