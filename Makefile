@@ -2,7 +2,8 @@
 #   make            everything
 #   make product    libhbrt.so, libhbhip.so (HIP kernels + C-ABI), libhbhip_filters.so
 #   make dev        the product libraries with -DHBHIP_DEV (tuning knobs from the environment; never shipped / tested)
-#   make devlib     the same kernels library as build/dev/libhbhip.so, beside the product one (tools/exp_knobs.sh)
+#   make devlib     the same kernels library as build/dev/libhbhip.so, beside the product one (tools/exp_knobs.sh,
+#                   tools/dev_run.sh); DEVDIR=build/devX DEVFLAGS=-D... for variants (-DHBHIP_DEV_STATS: search counters)
 #   make oracle     liboracle.so and, when /root/reference exists, oracle/_ref/libhbref.so
 HIPCC   ?= /opt/rocm/bin/hipcc
 CC      ?= gcc
@@ -46,13 +47,15 @@ dev:
 
 # the development kernels library BESIDE the product one (build/dev/libhbhip.so, own objects): what tools/exp_knobs.sh swaps
 # in on the GPU box for knob experiments and swaps out again; nothing of the product build is touched
-DEV_OBJ := $(HIP_SRC:$(PKG)/csrc/%.hip=build/dev/%.o)
-build/dev/%.o: $(PKG)/csrc/%.hip $(HIP_HDR)
-	@mkdir -p build/dev
-	$(HIPCC) $(HIPFLAGS) -DHBHIP_DEV -c $< -o $@
-build/dev/libhbhip.so: $(DEV_OBJ)
+DEVDIR   ?= build/dev
+DEVFLAGS ?=
+DEV_OBJ := $(HIP_SRC:$(PKG)/csrc/%.hip=$(DEVDIR)/%.o)
+$(DEVDIR)/%.o: $(PKG)/csrc/%.hip $(HIP_HDR)
+	@mkdir -p $(DEVDIR)
+	$(HIPCC) $(HIPFLAGS) -DHBHIP_DEV $(DEVFLAGS) -c $< -o $@
+$(DEVDIR)/libhbhip.so: $(DEV_OBJ)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(DEV_OBJ)
-devlib: build/dev/libhbhip.so
+devlib: $(DEVDIR)/libhbhip.so
 
 clean:
 	rm -rf build/dev

@@ -563,6 +563,16 @@ __global__ __launch_bounds__(256) void k_calc_dir_work(P3 P, const uint32_t *__r
 // calc_directions, fast path (search distance <= 30).  The source and mask rows the search touches are staged in LDS
 // (with the same flat addressing, so out-of-row offsets pick up the same bytes), the pixels that pass the edge test are
 // compacted inside the block so that busy lanes are contiguous, and each listed pixel walks its +-maxd window out of LDS.
+#ifdef HBHIP_DEV_STATS
+// development builds with -DHBHIP_DEV_STATS: what the search schedule really runs (tools/exp_knobs.sh prints it with HBHIP_DEV_STATS=1).
+// 0 workgroups past the early exit, 1 workgroups with listed pixels, 2 listed pixels, 3 wave trips of the list loop,
+// 4 steps of all lanes (useful), 5 wave-steps (the longest lane of each wave trip), 6 lanes in wave trips,
+// 7 workgroups in the dense form, 8 their waves with listed pixels, 9 those of them without a step to leave out
+__device__ unsigned long long g_cd_stats[12];
+#define CD_STAT(i, v) atomicAdd(&g_cd_stats[i], (unsigned long long)(v))
+#else
+#define CD_STAT(i, v) ((void)0)
+#endif
 constexpr int CD_W = 256, CD_HALO = 32, CD_LW = CD_W + 2 * CD_HALO;
 
 // What the search loop does per step is stripped to what has to happen per step:
@@ -590,6 +600,40 @@ constexpr int CD_W = 256, CD_HALO = 32, CD_LW = CD_W + 2 * CD_HALO;
 //  * The output rows are assembled in LDS and stored as dwords.
 // maxd <= 30.  Per 1080i field of the bench's content: SQ_INSTS_VALU 16.7 M, SQ_INSTS_SALU 2.9 M, SQ_INSTS_LDS 2.1 M
 // (one row per block without the key chains: 26.5 M / 11.3 M / 3.2 M).
+
+// The vote over the five offsets (:486-517).  ta..te: 0 = never set (the reference's -5000), else u + 32.
+__device__ __forceinline__ int calc_dir_vote(int ta, int tb, int tc, int td, int te)
+{
+    // the offsets that were set, sorted (unset ones as a large sentinel at the end): 9-exchange network on 5 values
+    constexpr int BIG = 1 << 20;
+    int v0 = ta ? ta - 32 : BIG, v1 = tb ? tb - 32 : BIG, v2 = tc ? tc - 32 : BIG, v3 = td ? td - 32 : BIG, v4 = te ? te - 32 : BIG;
+    const int k = (ta != 0) + (tb != 0) + (tc != 0) + (td != 0) + (te != 0);
+#define CD_CX(a, b) { const int lo_ = min(a, b), hi_ = max(a, b); a = lo_; b = hi_; }
+    CD_CX(v0, v1) CD_CX(v3, v4) CD_CX(v2, v4) CD_CX(v2, v3) CD_CX(v0, v3) CD_CX(v0, v2) CD_CX(v1, v4) CD_CX(v1, v3) CD_CX(v1, v2)
+#undef CD_CX
+    int out = NEUTRAL;
+    if (k > 1)
+    {
+        // sorted_mid's midpoint rule (eedi2.c:65-80): odd k -> v[k/2], even k -> (v[(k-1)/2] + v[k/2] + 1) >> 1; one formula
+        // serves both ((2v + 1) >> 1 == v)
+        const int lo = k == 2 ? v0 : (k == 5 ? v2 : v1);        // v[(k-1)>>1]: 0 1 1 2 for k = 2 3 4 5
+        const int hi = k >= 4 ? v2 : v1;                         // v[k>>1]:     1 1 2 2
+        const int mid = (lo + hi + 1) >> 1;
+        // max(limlut[|mid|] >> 2, 2) without the table (a dependent load per pixel): |mid| <= 30 here, and the table
+        // (eedi2.c:21-25) is 12 from entry 13 on and below 12 before it - 3 and 2 after the shift and the max
+        // (tests/test_eedi2_identities_cpu.py::test_calc_directions_vote_limit_closed_form)
+        static_assert(CD_HALO - 2 <= 30, "the closed form of limlut covers entries 0..30");
+        const int tlim = iabs(mid) >= 13 ? 3 : 2;
+        int sum = 0, cnt = 0;
+        if (iabs(v0 - mid) <= tlim) { cnt++; sum += v0; }        // the sentinels fail the test by themselves
+        if (iabs(v1 - mid) <= tlim) { cnt++; sum += v1; }
+        if (iabs(v2 - mid) <= tlim) { cnt++; sum += v2; }
+        if (iabs(v3 - mid) <= tlim) { cnt++; sum += v3; }
+        if (iabs(v4 - mid) <= tlim) { cnt++; sum += v4; }
+        if (cnt > 1) out = (NEUTRAL + ((int)((float)sum / (float)cnt) * 4)) & 0xff;
+    }
+    return out;
+}
 
 // PASS = uint64_t, or uint32_t when the window fits (chroma: 2 * 12 + 1 steps): walking the set bits of one word costs
 // four vector instructions a step instead of nine.
@@ -647,41 +691,151 @@ __device__ __forceinline__ int calc_dir_search(const uint32_t *tr, PASS pass, in
         ke = min(ke, diffe);
     }
 #undef SADH
-    // the offsets that were set, sorted (unset ones as a large sentinel at the end): 9-exchange network on 5 values
-    constexpr int BIG = 1 << 20;
-    const int ta = (int)((ka & 0xffffu) >> 1), tb = (int)(kb & 0xffffu), tc = (int)(kc & 0xffffu), td = (int)(kd & 0xffffu),
-              te = (int)(ke & 0xffffu);
-    int v0 = ta ? ta - 32 : BIG, v1 = tb ? tb - 32 : BIG, v2 = tc ? tc - 32 : BIG, v3 = td ? td - 32 : BIG, v4 = te ? te - 32 : BIG;
-    const int k = (ta != 0) + (tb != 0) + (tc != 0) + (td != 0) + (te != 0);
-#define CD_CX(a, b) { const int lo_ = min(a, b), hi_ = max(a, b); a = lo_; b = hi_; }
-    CD_CX(v0, v1) CD_CX(v3, v4) CD_CX(v2, v4) CD_CX(v2, v3) CD_CX(v0, v3) CD_CX(v0, v2) CD_CX(v1, v4) CD_CX(v1, v3) CD_CX(v1, v2)
-#undef CD_CX
-    int out = NEUTRAL;
-    if (k > 1)
-    {
-        // sorted_mid's midpoint rule (eedi2.c:65-80): odd k -> v[k/2], even k -> (v[(k-1)/2] + v[k/2] + 1) >> 1; one formula
-        // serves both ((2v + 1) >> 1 == v)
-        const int lo = k == 2 ? v0 : (k == 5 ? v2 : v1);        // v[(k-1)>>1]: 0 1 1 2 for k = 2 3 4 5
-        const int hi = k >= 4 ? v2 : v1;                         // v[k>>1]:     1 1 2 2
-        const int mid = (lo + hi + 1) >> 1;
-        // max(limlut[|mid|] >> 2, 2) without the table (a dependent load per pixel): |mid| <= 30 here, and the table
-        // (eedi2.c:21-25) is 12 from entry 13 on and below 12 before it - 3 and 2 after the shift and the max
-        // (tests/test_eedi2_identities_cpu.py::test_calc_directions_vote_limit_closed_form)
-        static_assert(CD_HALO - 2 <= 30, "the closed form of limlut covers entries 0..30");
-        const int tlim = iabs(mid) >= 13 ? 3 : 2;
-        int sum = 0, cnt = 0;
-        if (iabs(v0 - mid) <= tlim) { cnt++; sum += v0; }        // the sentinels fail the test by themselves
-        if (iabs(v1 - mid) <= tlim) { cnt++; sum += v1; }
-        if (iabs(v2 - mid) <= tlim) { cnt++; sum += v2; }
-        if (iabs(v3 - mid) <= tlim) { cnt++; sum += v3; }
-        if (iabs(v4 - mid) <= tlim) { cnt++; sum += v4; }
-        if (cnt > 1) out = (NEUTRAL + ((int)((float)sum / (float)cnt) * 4)) & 0xff;
-    }
-    return out;
+    return calc_dir_vote((int)((ka & 0xffffu) >> 1), (int)(kb & 0xffffu), (int)(kc & 0xffffu), (int)(kd & 0xffffu), (int)(ke & 0xffffu));
 }
 
+// The dense form of the search.  The reference clears only the upper half of the edge mask before it marks a field's
+// edges (eedi2_template.c:132, `height / 2`), so the lower half accumulates: after a few fields of moving content
+// nearly every pixel there is listed and takes every one of its 2 * maxd + 1 steps (measured on the bench's stream:
+// 65 % of a luma field listed, 39 of 49 steps per listed pixel, 97 % of all steps in the lower half).  Walking bit
+// sets buys nothing there, and the eight 3-byte SADs of a step are shared: with
+//     E_r(x, u) = sum_k |row_r[x + k] - row_{r+1}[x + k - u]|,   k = -1..1
+// the reference's sums (:402-470) are
+//     diffsn = E_y(x, u)      diffns = E_y(x + u, u)      diffps = E_{y-1}(x, u)    diffsp = E_{y-1}(x + u, u)
+//     diff2pp = E_{y-2}(x, u) diffp2p = E_{y-2}(x + u, u) diffn2n = E_{y+1}(x, u)   diff2nn = E_{y+1}(x + u, u)
+// so a thread that owns column x of R rows needs P_r = E_r(x, u) and Q_r = E_r(x + u, u) for the R + 3 row pairs around
+// its rows: 2 (R + 3) SADs serve R pixels (2.75 a pixel at R = 8 instead of 8), its own triples stay in registers, the
+// other side comes from the table at column x -+ u - which u and -u read alike, so a trip of the loop takes the pair and
+// the ten keys of a pixel take two candidates with one v_min3_u32 each.  With S = P + Q:
+//     diff (b) = S_{y-1} + S_y     diffa = diff + S_{y-2}     diffc = diff + S_{y+1}
+//     diffe = P_{y-2} + .. + P_{y+1}     diffd = Q_{y-2} + .. + Q_{y+1}
+// Keys as in calc_dir_search, the tag riding in every P and Q (v_sad_hi_u8's addend): b, d and e collect four tags,
+// a and c six.  A step a pixel does not take (PRED: its bit in `up` / `dn` - the complement of the step set, bit d for
+// u = +d / -d) gets 2^30 added to its five sums and cannot win; a wave whose pixels all take every step skips that.
+// At R = 8 that is 199 vector instructions a trip (two steps of 8 x 64 pixels) = 41 vector-ALU cycles per 64 pixel-steps
+// by the instruction classes of tools/valu_rate.hip, against 103 in the list form; at R = 4 (what runs: registers, see
+// the launch) 128 a trip = 53.
+template <int R, bool PRED>
+__device__ __forceinline__ void calc_dir_dense(const uint32_t *tr, int maxdt, const uint32_t (&up)[R], const uint32_t (&dn)[R],
+                                               int nt13, int nt19, uint32_t (&ka)[R], uint32_t (&kb)[R], uint32_t (&kc)[R],
+                                               uint32_t (&kd)[R], uint32_t (&ke)[R])
+{
+    constexpr int NS = R + 4, NE = R + 3;
+#define SADH(a, b, acc) __builtin_amdgcn_sad_hi_u8((a), (b), (acc))
+    uint32_t T[NS];
+#pragma unroll
+    for (int r = 0; r < NS; r++) T[r] = tr[r * CD_LW];
+#pragma unroll
+    for (int j = 0; j < R; j++)
+    {
+        const int ctr = (int)((T[j + 2] >> 8) & 0xff);
+        const int vert = iabs(ctr - (int)((T[j + 3] >> 8) & 0xff)) + iabs(ctr - (int)((T[j + 1] >> 8) & 0xff));
+        kb[j] = (uint32_t)min(nt13, vert * 6) << 16; ka[j] = (uint32_t)min(nt19, vert * 9) << 16;
+        kc[j] = ka[j]; kd[j] = kb[j]; ke[j] = kb[j];
+    }
+    // the five sums of every row from the P / Q of one step; X: the poison of the rows that do not take it
+    auto sums = [&](const uint32_t (&Pv)[NE], const uint32_t (&Qv)[NE], const uint32_t (&X)[R], uint32_t (&ca)[R], uint32_t (&cb)[R],
+                    uint32_t (&cc)[R], uint32_t (&cd)[R], uint32_t (&ce)[R]) {
+        uint32_t S[NE], P2[NE - 1], Q2[NE - 1];
+#pragma unroll
+        for (int r = 0; r < NE; r++) S[r] = Pv[r] + Qv[r];
+#pragma unroll
+        for (int r = 0; r < NE - 1; r++) { P2[r] = Pv[r] + Pv[r + 1]; Q2[r] = Qv[r] + Qv[r + 1]; }
+        if (PRED)
+        {
+#pragma unroll
+            for (int j = 0; j < R; j++)
+            {
+                cb[j] = S[j + 1] + S[j + 2] + X[j]; ca[j] = cb[j] + S[j]; cc[j] = cb[j] + S[j + 3];
+                ce[j] = P2[j] + P2[j + 2] + X[j];   cd[j] = Q2[j] + Q2[j + 2] + X[j];
+            }
+        }
+        else
+        {
+            // diffc of a row is diffa of the next one
+            uint32_t S2[NE - 1], S3[NE - 2];
+#pragma unroll
+            for (int r = 0; r < NE - 1; r++) S2[r] = S[r] + S[r + 1];
+#pragma unroll
+            for (int r = 0; r < NE - 2; r++) S3[r] = S2[r] + S[r + 2];
+#pragma unroll
+            for (int j = 0; j < R; j++)
+            {
+                cb[j] = S2[j + 1]; ca[j] = S3[j]; cc[j] = S3[j + 1];
+                ce[j] = P2[j] + P2[j + 2]; cd[j] = Q2[j] + Q2[j + 2];
+            }
+        }
+    };
+    uint32_t X1[R], X2[R];
+#pragma unroll
+    for (int j = 0; j < R; j++) { X1[j] = 0; X2[j] = 0; }
+    {
+        // u = 0: both sides are the thread's own column
+        uint32_t Pv[NE], ca[R], cb[R], cc[R], cd[R], ce[R];
+#pragma unroll
+        for (int r = 0; r < NE; r++) Pv[r] = SADH(T[r], T[r + 1], 32u);
+        if (PRED)
+        {
+#pragma unroll
+            for (int j = 0; j < R; j++) X1[j] = (up[j] << 30) & 0x40000000u;
+        }
+        sums(Pv, Pv, X1, ca, cb, cc, cd, ce);
+#pragma unroll
+        for (int j = 0; j < R; j++)
+        {
+            ka[j] = min(ka[j], ca[j]); kb[j] = min(kb[j], cb[j]); kc[j] = min(kc[j], cc[j]);
+            kd[j] = min(kd[j], cd[j]); ke[j] = min(ke[j], ce[j]);
+        }
+    }
+    for (int d = 1; d <= maxdt; d++)
+    {
+        const uint32_t *tp = tr + d, *tm = tr - d;
+        uint32_t Pl[NS], Mi[NS];
+#pragma unroll
+        for (int r = 0; r < NS; r++) { Pl[r] = tp[r * CD_LW]; Mi[r] = tm[r * CD_LW]; }
+        const uint32_t t1 = 32u + (uint32_t)d, t2 = 32u - (uint32_t)d;
+        uint32_t P1[NE], Q1[NE], Pn[NE], Qn[NE];
+#pragma unroll
+        for (int r = 0; r < NE; r++)
+        {
+            P1[r] = SADH(T[r], Mi[r + 1], t1); Q1[r] = SADH(Pl[r], T[r + 1], t1);      // u = +d: x - u left, x + u right
+            Pn[r] = SADH(T[r], Pl[r + 1], t2); Qn[r] = SADH(Mi[r], T[r + 1], t2);      // u = -d: the sides change places
+        }
+        if (PRED)
+        {
+            const uint32_t sh = 30u - (uint32_t)d;
+#pragma unroll
+            for (int j = 0; j < R; j++) { X1[j] = (up[j] << sh) & 0x40000000u; X2[j] = (dn[j] << sh) & 0x40000000u; }
+        }
+        uint32_t ca[R], cb[R], cc[R], cd[R], ce[R], na[R], nb[R], nc[R], nd[R], ne[R];
+        sums(P1, Q1, X1, ca, cb, cc, cd, ce);
+        sums(Pn, Qn, X2, na, nb, nc, nd, ne);
+#pragma unroll
+        for (int j = 0; j < R; j++)
+        {
+            ka[j] = min(ka[j], min(ca[j], na[j])); kb[j] = min(kb[j], min(cb[j], nb[j])); kc[j] = min(kc[j], min(cc[j], nc[j]));
+            kd[j] = min(kd[j], min(cd[j], nd[j])); ke[j] = min(ke[j], min(ce[j], ne[j]));
+        }
+    }
+#undef SADH
+}
+
+// bit t of a mask row's window: a peak among columns start + t .. + 2 (len + 2 <= 63 bits of the row's bitmap)
+__device__ __forceinline__ uint64_t calc_dir_window(const uint64_t *bits, int start, uint64_t lenmask)
+{
+    const int wq = start >> 6, sh = start & 63;
+    const uint64_t lo = bits[wq], hi = bits[wq + 1];
+    const uint64_t w = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+    return (w | (w >> 1) | (w >> 2)) & lenmask;
+}
+
+// dense_min: a block whose list holds at least this many pixels (and that touches neither the first nor the last row)
+// takes the dense form of the search (R >= 4)
+#ifndef CD_WAVES_ATTR
+#define CD_WAVES_ATTR
+#endif
 template <int R>
-__global__ __launch_bounds__(CD_W) void k_calc_dir_rows(P3 P, int maxd, int nt13, int nt19)
+__global__ __launch_bounds__(CD_W) CD_WAVES_ATTR void k_calc_dir_rows(P3 P, int maxd, int nt13, int nt19, int dense_min)
 {
     constexpr int NS = R + 4, NM = R + 2, RW = CD_LW / 4, RQ = CD_LW / 16;
     __shared__ __attribute__((aligned(16))) uint8_t s_band[NS + NM][CD_LW];   // staged rows: 0..NS-1 source y0-2.., NS.. mask y0-1..
@@ -767,12 +921,64 @@ __global__ __launch_bounds__(CD_W) void k_calc_dir_rows(P3 P, int maxd, int nt13
     }
     __syncthreads();
     const int count = s_count;
-    if (count)                                        // block-uniform
+    const int maxdt = pl == 0 ? maxd : (maxd >> 1);
+    const int len = 2 * maxdt + 1;
+    const uint64_t lenmask = (1ull << len) - 1ull;
+    const bool edge = y0 <= 1 || y0 + R - 1 >= height - 2;
+    const bool dense = R >= 4 && !edge && count >= dense_min;          // block-uniform
+#ifdef HBHIP_DEV_STATS
+    if (tid == 0) { CD_STAT(0, 1); CD_STAT(1, count != 0); CD_STAT(2, count); CD_STAT(7, dense); }
+#endif
+    if (R >= 4 && dense)
     {
-        const int maxdt = pl == 0 ? maxd : (maxd >> 1);
-        const int len = 2 * maxdt + 1;
-        const uint64_t lenmask = (1ull << len) - 1ull;
-        const bool edge = y0 <= 1 || y0 + R - 1 >= height - 2;
+        // a thread owns column tid of the block's R rows (all of them interior rows here)
+        constexpr int RD = R >= 4 ? R : 1;                             // (the two-row instantiation never gets here)
+        const int lx = tid, px = x0 + lx, b = lx + CD_HALO - 1;
+        const int startu = max(-px + 1, -maxdt), stopu = min(width - 2 - px, maxdt);
+        uint64_t range = 0;
+        if (stopu >= startu)
+        {
+            const int nb = stopu - startu + 1;
+            range = (nb >= 64 ? ~0ull : ((1ull << nb) - 1ull)) << (startu + maxdt);
+        }
+        // the windows of the block's R + 2 mask rows at this column, each serving the row below it (as it stands) and the
+        // row above it (reversed)
+        uint64_t win[RD + 2];
+#pragma unroll
+        for (int m = 0; m < RD + 2; m++) win[m] = calc_dir_window(s_bits[m], b - maxdt, lenmask);
+        uint32_t up[RD], dn[RD], act = 0, inactive = 0;
+#pragma unroll
+        for (int j = 0; j < RD; j++)
+        {
+            const uint8_t *mr = &s_band[NS + j + 1][CD_HALO + lx];
+            const bool a = px >= 1 && px < width - 1 && mr[0] == PEAK && (mr[-1] == PEAK || mr[1] == PEAK);    // :392-393
+            const uint64_t pass = a ? range & win[j] & (__brevll(win[j + 2]) >> (64 - len)) : 0ull;
+            const uint64_t npass = ~pass;
+            up[j] = (uint32_t)(npass >> maxdt);
+            dn[j] = __brev((uint32_t)npass << (31 - maxdt));
+            act |= (uint32_t)a << j;
+            inactive |= (up[j] | dn[j]) & ((2u << maxdt) - 1u);
+        }
+        if (__any(act != 0))                                           // wave-uniform
+        {
+            uint32_t ka[RD], kb[RD], kc[RD], kd[RD], ke[RD];
+            const uint32_t *tr = &s_tri[0][b];
+            if (__all(inactive == 0)) calc_dir_dense<RD, false>(tr, maxdt, up, dn, nt13, nt19, ka, kb, kc, kd, ke);
+            else                      calc_dir_dense<RD, true>(tr, maxdt, up, dn, nt13, nt19, ka, kb, kc, kd, ke);
+#pragma unroll
+            for (int j = 0; j < RD; j++)
+                if ((act >> j) & 1u)
+                    // b, d and e hold four tags, a and c six (calc_dir_dense)
+                    s_out[j][lx] = (uint8_t)calc_dir_vote((int)((ka[j] & 0xffffu) / 6u), (int)((kb[j] & 0xffffu) >> 2), (int)((kc[j] & 0xffffu) / 6u),
+                                                          (int)((kd[j] & 0xffffu) >> 2), (int)((ke[j] & 0xffffu) >> 2));
+#ifdef HBHIP_DEV_STATS
+            if (lane == 0) { CD_STAT(8, 1); CD_STAT(9, __all(inactive == 0)); }
+#endif
+        }
+        __syncthreads();
+    }
+    else if (count)                                   // block-uniform
+    {
         for (int p = tid; p < count; p += CD_W)
         {
             const uint32_t id = s_list[p];
@@ -781,21 +987,22 @@ __global__ __launch_bounds__(CD_W) void k_calc_dir_rows(P3 P, int maxd, int nt13
             // last row - with a mask peak above at +u and below at -u (:395-399).  Above: bits b-maxdt .. b+maxdt of the row's
             // bitmap in that order; below: the same bits of the other row's in reverse.
             const int startu = max(-px + 1, -maxdt), stopu = min(width - 2 - px, maxdt);
-            // bit t of a row's window: a mask peak among columns b-maxdt+t .. +2 (len + 2 <= 63 bits of the bitmap)
-            auto window = [&](const uint64_t *bits) {
-                const int start = b - maxdt, wq = start >> 6, sh = start & 63;
-                const uint64_t lo = bits[wq], hi = bits[wq + 1];
-                const uint64_t w = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
-                return (w | (w >> 1) | (w >> 2)) & lenmask;
-            };
             uint64_t pass = 0;
             if (stopu >= startu)
             {
                 const int nb = stopu - startu + 1;
                 pass = (nb >= 64 ? ~0ull : ((1ull << nb) - 1ull)) << (startu + maxdt);
-                if (y != 1)          pass &= window(s_bits[j]);
-                if (y != height - 2) pass &= __brevll(window(s_bits[j + 2])) >> (64 - len);
+                if (y != 1)          pass &= calc_dir_window(s_bits[j], b - maxdt, lenmask);
+                if (y != height - 2) pass &= __brevll(calc_dir_window(s_bits[j + 2], b - maxdt, lenmask)) >> (64 - len);
             }
+#ifdef HBHIP_DEV_STATS
+            {
+                int n = __popcll(pass), mx = n, sm = n, ln = 1;
+                for (int o = 32; o; o >>= 1) { mx = max(mx, __shfl_xor(mx, o)); sm += __shfl_xor(sm, o); ln += __shfl_xor(ln, o); }
+                const uint64_t act = __ballot(1);
+                if (lane == __ffsll((unsigned long long)act) - 1) { CD_STAT(3, 1); CD_STAT(4, sm); CD_STAT(5, mx); CD_STAT(6, ln); }
+            }
+#endif
             const uint32_t *tr = &s_tri[j][b];
             int out;
             if (len <= 32)                                                    // block-uniform (the plane's search distance)
@@ -2189,24 +2396,34 @@ int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc)
     bind(P.a, mskp); bind(P.b, srcp); bind(P.c, tmpp);
     const int nt13 = (par_.noise_threshold * 13) & 0xff, nt19 = (par_.noise_threshold * 19) & 0xff;      // typed `pixel` in the reference
     if (par_.maximum_search_distance <= CD_HALO - 2)
-        // rows per block, measured (kernel alone / decomb bob throughput): 2: 44 us / 5.72 k fps, 4: 53 / 5.62 k, 8: 69 / 5.82 k
-        // (the more rows, the fewer instructions - and the fewer, longer workgroups to balance over the CUs)
     {
+        // 256 columns x 4 rows per block: blocks with at least half of their pixels listed search in the dense form
+        // (calc_dir_dense), the others walk their list.  Measured on the decomb bob workload, us per 16 fields: the list form
+        // alone 505 (2 rows) / 673 (8 rows); with the dense form 349 at 4 rows (120 registers, four waves per SIMD), 384 at 6
+        // (161), 417 at 8 (202 registers, two waves: fewer instructions - 2.75 SADs a pixel-step against 3.5 - but the
+        // LDS latency of a trip shows; forced to 128 registers with spills: 334).  Thresholds of 3/8 .. 3/4 of a block's
+        // pixels measure alike (the blocks are either nearly full or far from it); below 1/4 the dense form loses.
+        int dense_min = CD_W * 4 / 2;
 #ifdef HBHIP_DEV
-        const int rows = hbhip_dev_int("HBHIP_EEDI2_CALCDIR_ROWS", 2);
-        if (rows == 4)
-            HBHIP_LAUNCH(lc, "eedi2_calc_directions", k_calc_dir_rows<4>,
-                         dim3((srcp.stride[0] + CD_W - 1) / CD_W, (srcp.height[0] + 3) / 4, gz), dim3(CD_W), 0, P,
-                         par_.maximum_search_distance, nt13, nt19);
-        else if (rows == 8)
+        const int rows = hbhip_dev_int("HBHIP_EEDI2_CALCDIR_ROWS", 4);
+        dense_min = hbhip_dev_int("HBHIP_EEDI2_CALCDIR_DENSE_MIN", CD_W * rows / 2);
+        if (rows == 8)
             HBHIP_LAUNCH(lc, "eedi2_calc_directions", k_calc_dir_rows<8>,
                          dim3((srcp.stride[0] + CD_W - 1) / CD_W, (srcp.height[0] + 7) / 8, gz), dim3(CD_W), 0, P,
-                         par_.maximum_search_distance, nt13, nt19);
+                         par_.maximum_search_distance, nt13, nt19, dense_min);
+        else if (rows == 6)
+            HBHIP_LAUNCH(lc, "eedi2_calc_directions", k_calc_dir_rows<6>,
+                         dim3((srcp.stride[0] + CD_W - 1) / CD_W, (srcp.height[0] + 5) / 6, gz), dim3(CD_W), 0, P,
+                         par_.maximum_search_distance, nt13, nt19, dense_min);
+        else if (rows == 2)
+            HBHIP_LAUNCH(lc, "eedi2_calc_directions", k_calc_dir_rows<2>,
+                         dim3((srcp.stride[0] + CD_W - 1) / CD_W, (srcp.height[0] + 1) / 2, gz), dim3(CD_W), 0, P,
+                         par_.maximum_search_distance, nt13, nt19, dense_min);
         else
 #endif
-        HBHIP_LAUNCH(lc, "eedi2_calc_directions", k_calc_dir_rows<2>,
-                     dim3((srcp.stride[0] + CD_W - 1) / CD_W, (srcp.height[0] + 1) / 2, gz), dim3(CD_W), 0, P,
-                     par_.maximum_search_distance, nt13, nt19);
+        HBHIP_LAUNCH(lc, "eedi2_calc_directions", k_calc_dir_rows<4>,
+                     dim3((srcp.stride[0] + CD_W - 1) / CD_W, (srcp.height[0] + 3) / 4, gz), dim3(CD_W), 0, P,
+                     par_.maximum_search_distance, nt13, nt19, dense_min);
     }
     else
     {
@@ -2306,3 +2523,16 @@ int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc)
     HBHIP_CHECK(lc, hipGetLastError());
     return HBHIP_OK;
 }
+
+#ifdef HBHIP_DEV_STATS
+// development builds with -DHBHIP_DEV_STATS: the search-schedule counters of k_calc_dir_rows (read and cleared)
+extern "C" int hbhip_dev_eedi2_stats(unsigned long long *out, int n)
+{
+    unsigned long long h[12] = { 0 };
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_cd_stats), sizeof(h)) != hipSuccess) return -1;
+    for (int i = 0; i < n && i < 12; i++) out[i] = h[i];
+    unsigned long long z[12] = { 0 };
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_cd_stats), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -38,6 +38,37 @@ def test_every_scratch_buffer(built, w, h):
         ctx.close()
 
 
+@pytest.mark.parametrize("model,w,h,n", [("random", 640, 360, 3), ("interlaced", 640, 360, 6), ("corners", 1024, 576, 4),
+                                         ("random", 322, 184, 3), ("interlaced", 1920, 1080, 5)])
+def test_dense_masks_every_scratch_buffer(built, model, w, h, n):
+    """The edge mask keeps its lower half from field to field (eedi2_template.c:132 clears `height / 2` rows), so after
+    a few fields of moving content - or at once on noise - nearly every pixel is listed and takes every step of the
+    calc_directions search: the blocks that are mostly listed run the dense form of the search (calc_dir_dense, with
+    and without steps to leave out), the others walk their lists.  Every scratch frame against the oracle."""
+    frames = synth.stream(model, w, h, n)
+    ctx = hip.Ctx(0)
+    dev = hip.DecombDevice(ctx, w, h, mode=24)
+    oe = ol.OrcEedi2(w, h)
+    try:
+        dev.push(frames[0])
+        for t in range(1, n):
+            dev.push(frames[t])
+            for tff in (1, 0):
+                oe.run(frames[t - 1], tff)
+            while dev.pull() is not None:
+                pass
+            for b in range(9):
+                for c in range(3):
+                    np.testing.assert_array_equal(dev.eedi_plane(b, c), oe.plane(b, c),
+                                                  err_msg=f"{ol.EEDI2_BUFFERS[b]} plane {c} after frame {t - 1}")
+        msk = oe.plane(ol.EEDI2_BUFFERS.index("mskp"), 0)
+        assert (msk[msk.shape[0] // 2:] == 255).mean() > 0.8           # the case this test is about
+    finally:
+        oe.close()
+        dev.close()
+        ctx.close()
+
+
 @pytest.mark.parametrize("postproc", [2, 3])
 @pytest.mark.parametrize("w,h", [(128, 72), (322, 184), (638, 360), (1920, 1080)])
 def test_corner_postprocessing_every_scratch_buffer(built, w, h, postproc):
