@@ -442,8 +442,9 @@ def run_chain(args, world, rank, local_rank):
             self.ctxs = [self.ctx]
 
             def stage_ctx():
-                if not split:
-                    return self.ctx
+                # split 1: a context (HIP stream) per stage; split 2: decomb on one context, the stages behind it on a second
+                if not split or (split == 2 and len(self.ctxs) >= 3):
+                    return self.ctxs[-1]
                 self.ctxs.append(hip.Ctx(local_rank))
                 return self.ctxs[-1]
 
@@ -591,7 +592,7 @@ def run_chain(args, world, rank, local_rank):
             "config": {"workload": wl["text"] + (" + comb detect in front (selective decomb, mode 63)" if args.comb_detect else ""),
                        "input_frames_per_step": B * len(lanes), "output_frames_per_step": 2 * B * len(lanes),
                        "input": f"{W}x{H}", "output": f"{OW}x{OH}", "streams_per_gpu": len(lanes),
-                       "stage_streams": bool(args.stage_streams),
+                       "stage_streams": int(args.stage_streams),
                        "parallelism": f"{world} GPU(s) x {len(lanes)} independent stream(s)", "device": ctx.name()},
             "input_fps": round(frames_total / dt_max / 2, 2),
             "host_enqueue_ms_per_step": round(t_enq_free * 1e3, 4),

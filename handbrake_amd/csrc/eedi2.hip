@@ -1060,12 +1060,139 @@ __device__ __forceinline__ int dir_map_px(int u0, int u1, int u2, int c0, int c1
     return val & 0xff;
 }
 
+__device__ __forceinline__ uint32_t ff_bytes(uint32_t v)          // 0x80 in every byte that is 0xff
+{
+    return (((v & 0x7f7f7f7fu) + 0x01010101u) & v) & 0x80808080u;
+}
+
+// ------------------------------------------------------------------------------------------
+// The dir-map vote on PAIRS of pixels.  With a dense edge mask (the lower half of a field's mask saturates,
+// eedi2_template.c:132) nearly every pixel of the dir-map passes reaches its sort and its vote, and both are 16-bit work:
+// two horizontally adjacent pixels ride in the halves of a dword through v_pk_min_u16 / v_pk_max_u16 (the 9-input
+// network once for both), v_pk_sub / add / mad_u16 and v_bfi_b32 selects.  A slot that holds no value (the reference
+// leaves peaks out of order[], :659-668) carries PK_ABSENT, above every value and farther from every midpoint than any
+// limit (also the 255 of limlut's last entries, eedi2.c:24).
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+typedef int16_t i16x2 __attribute__((ext_vector_type(2)));
+constexpr uint32_t PK_ABSENT_HI = 0x7f00u;                            // 0x00ff + 0x7f00 = 0x7fff
+__device__ __forceinline__ u16x2 pk(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ uint32_t un(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ u16x2 pk1(uint32_t both) { return pk(both * 0x00010001u); }
+// [a < b] per half as 0 / 1 for halves below 2^15: the borrow of a - b (two packed instructions; written as a comparison
+// or as min(saturated difference, 1) the compiler unpacks it into a compare and a select per half)
+__device__ __forceinline__ u16x2 pk_lt(u16x2 a, u16x2 b) { return (u16x2)((u16x2)(a - b) >> 15); }
+__device__ __forceinline__ void cswap2(u16x2 &a, u16x2 &b)
+{
+    const u16x2 lo = __builtin_elementwise_min(a, b), hi = __builtin_elementwise_max(a, b);
+    a = lo; b = hi;
+}
+// limlut[i] (eedi2.c:21-25 as 8-bit pixels: 6 6 7 7 8 8 9 9 9 10 10 11 11 12 ... 12, then 255 255 for i = 31, 32) in
+// closed form, both halves: min(12, 6 + ((i - [i >= 8]) >> 1)), 255 from 31 on
+// (tests/test_eedi2_identities_cpu.py::test_limlut_closed_form)
+__device__ __forceinline__ u16x2 limlut2(u16x2 i)
+{
+    const u16x2 g = pk_lt(pk1(7), i);
+    const u16x2 l = __builtin_elementwise_min((u16x2)(((i - g) >> 1) + pk1(6)), pk1(12));
+    const u16x2 big = pk_lt(pk1(30), i) * pk1(255);
+    return __builtin_elementwise_max(l, big);
+}
+// two bytes of the 8-byte window {hi, lo} as the halves of a dword (v_perm_b32; selector bytes: 0-3 = lo, 4-7 = hi, 12 = 0)
+#define PK_BYTES(hi, lo, a, b) __builtin_amdgcn_perm((hi), (lo), 0x0c000c00u | ((uint32_t)(b) << 16) | (uint32_t)(a))
+
+// The two pixels at columns k and k + 1 of a thread's dword (k = 0 or 2; windows wu / wc / wd = rows above, own, below as
+// the bytes x-4 .. x+7, rows that do not count - first / last rows of the _2x forms - already all 0xff).
+// Returns the pass's values for both (low byte of each half): filter_dir_map :649-707 (expand == 0) or expand_dir_map
+// :722-773 (expand != 0; the caller only takes them for pixels the pass works on).
+template <int K>
+__device__ __forceinline__ uint32_t dir_map_pair(const Win12 &wu, const Win12 &wc, const Win12 &wd, int expand)
+{
+    // slot s of pixel k is byte k - 1 + s % 3 of its row: the pairs (k-1, k), (k, k+1), (k+1, k+2); window byte index = column + 4
+    u16x2 v[9];
+    {
+        const Win12 *rows[3] = { &wu, &wc, &wd };
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+        {
+            const uint32_t w0 = rows[r]->w0, w1 = rows[r]->w1, w2 = rows[r]->w2;
+            if (K == 0)
+            {
+                v[3 * r + 0] = pk(PK_BYTES(w1, w0, 3, 4));            // columns -1, 0
+                v[3 * r + 1] = pk(PK_BYTES(w1, w0, 4, 5));            // 0, 1
+                v[3 * r + 2] = pk(PK_BYTES(w1, w0, 5, 6));            // 1, 2
+            }
+            else
+            {
+                v[3 * r + 0] = pk(PK_BYTES(w1, w0, 5, 6));            // 1, 2
+                v[3 * r + 1] = pk(PK_BYTES(w1, w0, 6, 7));            // 2, 3
+                v[3 * r + 2] = pk(PK_BYTES(w2, w1, 3, 4));            // 3, 4
+            }
+        }
+    }
+    const u16x2 c1 = v[4];
+    // absent slots: 1 per half that holds a peak (a pixel expand works on has a peak in its centre: left out as :739-746
+    // leave it out), the value pushed up to PK_ABSENT
+    u16x2 a[9];
+    uint32_t absent = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+    {
+        a[i] = (u16x2)((v[i] + pk1(1)) >> 8);
+        absent += un(a[i]);
+        v[i] = v[i] + a[i] * pk1(PK_ABSENT_HI);
+    }
+    // midpoint of the n = 9 - absent present values (mid9's selection with masks): n <= 5 <=> absent >= 4, n <= 7 <=> absent >= 2
+    u16x2 s0 = v[0], s1 = v[1], s2 = v[2], s3 = v[3], s4 = v[4], s5 = v[5], s6 = v[6], s7 = v[7], s8 = v[8];
+    cswap2(s0, s3); cswap2(s1, s7); cswap2(s2, s5); cswap2(s4, s8);
+    cswap2(s0, s7); cswap2(s2, s4); cswap2(s3, s8); cswap2(s5, s6);
+    cswap2(s0, s2); cswap2(s1, s3); cswap2(s4, s5); cswap2(s7, s8);
+    cswap2(s1, s4); cswap2(s3, s6); cswap2(s5, s7);
+    cswap2(s0, s1); cswap2(s2, s4); cswap2(s3, s5); cswap2(s6, s8);
+    cswap2(s2, s3); cswap2(s4, s5); cswap2(s6, s7);
+    cswap2(s1, s2); cswap2(s3, s4); cswap2(s5, s6);
+    const u16x2 ab = pk(absent), one = pk1(1), zero = pk1(0);
+    const uint32_t m5 = un(zero - pk_lt(pk1(3), ab));
+    const uint32_t m7 = un(zero - pk_lt(one, ab));
+    const uint32_t modd = un((ab & one) - one);                        // n odd <=> absent even
+#define PK_SEL(m, x, y) (((m) & (x)) | (~(m) & (y)))                    /* v_bfi_b32 */
+    const uint32_t hi = PK_SEL(m5, un(s2), PK_SEL(m7, un(s3), un(s4)));
+    const uint32_t lo = PK_SEL(m5, un(s1), PK_SEL(m7, un(s2), un(s3)));
+    const u16x2 mid = pk(PK_SEL(modd, hi, un((u16x2)((pk(lo) + pk(hi) + one) >> 1))));
+    // the vote (:685-697): values within limlut[|mid - neutral| >> 2] of the midpoint
+    const i16x2 t = __builtin_bit_cast(i16x2, (u16x2)(mid - pk1(NEUTRAL)));
+    const u16x2 lim1 = limlut2(__builtin_bit_cast(u16x2, __builtin_elementwise_max(t, (i16x2)(-t))) >> 2) + one;
+    u16x2 sum = zero, cnt = zero;
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+    {
+        const u16x2 d = __builtin_elementwise_max(v[i], mid) - __builtin_elementwise_min(v[i], mid);
+        const u16x2 in = pk_lt(d, lim1);
+        cnt += in;
+        sum += in * v[i];
+    }
+    const uint32_t sm = un((u16x2)(sum + mid)), ct = un(cnt);
+    uint32_t out = 0;
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+    {
+        // too few values (:669-673 / :747): the midpoint above may be a PK_ABSENT then, so the count says nothing
+        const int n = 9 - (int)((absent >> (16 * h)) & 0xffffu);
+        const int count = n >= 4 ? (int)((ct >> (16 * h)) & 0xffffu) : 0;
+        const int val = vote_avg((int)((sm >> (16 * h)) & 0xffffu), count + 1) & 0xff;
+        const int c = (int)((un(c1) >> (16 * h)) & 0xffu);
+        int res;
+        if (expand) res = count >= 5 ? val : c;
+        else        res = (count < 4 || (count < 5 && c == PEAK)) ? PEAK : val;
+        out |= (uint32_t)res << (16 * h);
+    }
+#undef PK_SEL
+    return out;
+}
+
 // In the _2x forms a thread takes the rows 2r and 2r + 1 of its dword column: the one with the parity of the rebuilt rows
 // is worked on, the other only copied (a wave per copied row spent more on finding its plane and field - scalar
 // instructions - than on its dword).
 __global__ __launch_bounds__(256) void k_dir_map4(P3 P, int step, int expand)
 {
-    const uint8_t *limlut = c_limlut;             // (a copy per wave in LDS, filled without a barrier: 117 -> 121 us per launch)
     FIELD_PLANE(P);
     const int x = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
     const int r = blockIdx.y * blockDim.y + threadIdx.y;
@@ -1104,21 +1231,21 @@ __global__ __launch_bounds__(256) void k_dir_map4(P3 P, int step, int expand)
     const uint32_t m0 = *reinterpret_cast<const uint32_t *>(step == 1 ? mk : mk - (ptrdiff_t)pitch);
     const uint32_t m1 = step == 1 ? 0u : *reinterpret_cast<const uint32_t *>(mk + pitch);
     const bool up_ok = step == 1 || y > 1, dn_ok = step == 1 || y < height - 2;
-    int out[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++)
+    // the pixels the pass works on, one flag byte each (:658 / :738): inside the row, on the mask, and for expand a peak
+    uint32_t work = ((ff_bytes(m0) | ff_bytes(m1)) >> 7) & mf_bytes_in(x, 1, width - 1);
+    if (expand) work &= ff_bytes(wc.w1) >> 7;
+    uint32_t res = wc.w1;
+    if (work)
     {
-        const int c1 = wb(wc, k);
-        out[k] = c1;
-        const int xx = x + k;
-        const bool masked = ((m0 >> (8 * k)) & 0xff) == PEAK || (step != 1 && ((m1 >> (8 * k)) & 0xff) == PEAK);
-        if (xx >= 1 && xx < width - 1 && masked && !(expand && c1 != PEAK))
-        {
-            asm volatile("" ::: "memory");                     // a real branch: waves without a masked pixel skip the sort
-            out[k] = dir_map_px(wb(wu, k - 1), wb(wu, k), wb(wu, k + 1), wb(wc, k - 1), c1, wb(wc, k + 1),
-                                wb(wd, k - 1), wb(wd, k), wb(wd, k + 1), up_ok, dn_ok, expand, limlut);
-        }
+        asm volatile("" ::: "memory");                         // a real branch: waves without such a pixel skip the votes
+        const Win12 none = { 0xffffffffu, 0xffffffffu, 0xffffffffu };
+        const Win12 eu = up_ok ? wu : none, ed = dn_ok ? wd : none;
+        const uint32_t p01 = dir_map_pair<0>(eu, wc, ed, expand), p23 = dir_map_pair<2>(eu, wc, ed, expand);
+        const uint32_t votes = __builtin_amdgcn_perm(p23, p01, 0x06040200u);     // the low bytes of the four halves
+        const uint32_t sel = work * 255u;
+        res = (res & ~sel) | (votes & sel);
     }
+    int out[4] = { (int)(res & 0xff), (int)((res >> 8) & 0xff), (int)((res >> 16) & 0xff), (int)(res >> 24) };
     st4(o, out, x, width);
     if (Q.d)
     {
@@ -1134,10 +1261,6 @@ __global__ __launch_bounds__(256) void k_dir_map4(P3 P, int step, int expand)
 // holds a few - and a wave pays for the sort if one lane needs it.  So phase 1 only queues them (LDS
 // list, per workgroup of 4 rows x 256 pixels) and phase 2 gives each queued pixel a lane of its own:
 // the sort runs on full waves, on as few of them as the queue fills.
-__device__ __forceinline__ uint32_t ff_bytes(uint32_t v)          // 0x80 in every byte that is 0xff
-{
-    return (((v & 0x7f7f7f7fu) + 0x01010101u) & v) & 0x80808080u;
-}
 __device__ __forceinline__ uint32_t live3(const Win12 &w, uint32_t &centre)   // per byte: usable (non-peak) values among x-1, x, x+1
 {
     const uint32_t n0 = (~ff_bytes(w.w0) >> 7) & 0x01010101u, n1 = (~ff_bytes(w.w1) >> 7) & 0x01010101u, n2 = (~ff_bytes(w.w2) >> 7) & 0x01010101u;

@@ -188,3 +188,36 @@ def test_row_pairs_cover_every_row_once():
                 (work if y0 <= y < height - 1 else copied).append(y)
         assert sorted(work + copied) == list(range(height))
         assert work == list(range(y0, height - 1, 2))
+
+
+def test_limlut_closed_form():
+    """csrc/eedi2.hip:limlut2 - the 8-bit limlut (eedi2.c:21-25 cast to `pixel`: its two -1 entries read 255) as
+    min(12, 6 + ((i - [i >= 8]) >> 1)) below 31 and 255 from there on, with [a < b] taken as the borrow bit of a
+    16-bit difference (both operands below 2^15)."""
+    table = [6, 6, 7, 7, 8, 8, 9, 9, 9, 10, 10, 11, 11, 12, 12, 12, 12, 12, 12, 12, 12, 12, 12, 12, 12, 12, 12, 12, 12, 12,
+             12, -1, -1]
+    lt = lambda a, b: ((a - b) & 0xffff) >> 15
+    for i in range(0, 8192):                                   # |mid - 128| >> 2 of any 15-bit midpoint
+        g = lt(7, i)
+        lim = max(min(((i - g) >> 1) + 6, 12), lt(30, i) * 255)
+        want = (table[i] & 0xff) if i < 33 else 255
+        assert lim == want, i
+    # the indicator itself: exact for operands below 2^15
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 1 << 15, 20000); b = rng.integers(0, 1 << 15, 20000)
+    assert np.array_equal(((a - b) & 0xffff) >> 15, (a < b).astype(np.int64))
+
+
+def test_pair_vote_slots():
+    """csrc/eedi2.hip:dir_map_pair - an absent slot (peak 255 pushed to 0x7fff) sorts behind every value, never comes
+    within any limit (also 255) of a midpoint of present values, and the midpoint selection by the number of absent
+    slots picks the entries mid9 picks."""
+    for mid in range(0, 255):
+        for lim in (6, 12, 255):
+            assert abs(0x7fff - mid) > lim
+    for n in range(4, 10):
+        absent = 9 - n
+        m5, m7, odd = absent >= 4, absent >= 2, (absent & 1) == 0
+        hi = 2 if m5 else (3 if m7 else 4)
+        lo = 1 if m5 else (2 if m7 else 3)
+        assert hi == n >> 1 and (odd == bool(n & 1)) and (odd or lo == (n - 1) >> 1)
