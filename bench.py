@@ -84,8 +84,7 @@ def algorithmic_bytes(kernel, w, h, out_w, out_h, frames_per_launch=1):
         "cropscale_lanczos_fused": full + out,
         "lapsharp_3x3": 2 * out, "lapsharp_5x5": 2 * out,
         "copy_planes": full,                                          # the chain's copy-in: one input frame read + written per TWO output frames
-        "eedi2_mask_passes": 2 * half,                                # the lower half of a field: field rows + old mask -> srcp + new mask (all fields of a batch per launch)
-        "eedi2_mask_upper": 1.5 * half,                               # the upper half: field rows -> srcp + new mask
+        "eedi2_mask_passes": 3.5 * half,                              # field rows + the old mask's lower half -> srcp + new mask (all fields of a batch per launch)
         "eedi2_calc_directions": 3 * half,                            # mskp + srcp -> tmpp
         "eedi2_filter_dir_map": 3 * half, "eedi2_expand_dir_map": 3 * half, "eedi2_filter_map": 3 * half,
         "eedi2_mark_directions_2x": 3 * half + 4 * full,              # 3 line doublings + tmp2p
@@ -694,10 +693,11 @@ def main():
                          "as BASELINE configs[2] words it")
     ap.add_argument("--no-kernel-timer", action="store_true",
                     help="chain workloads: skip the event-bracketed pass after the timed region (roofline = null)")
-    ap.add_argument("--stage-streams", type=int, default=0,
-                    help="chain workloads: 1 = every filter of the chain on a HIP stream of its own (libhb: one thread per "
-                         "filter), 0 = the whole chain on one stream (default; measured equal - the EEDI2 engine ring "
-                         "already keeps the GPU full)")
+    ap.add_argument("--stage-streams", type=int, default=2,
+                    help="chain workloads: 2 = decomb on one HIP stream, the stages behind it on a second (default: a batch's "
+                         "NLMeans / scaler / sharpen overlap the next batch's EEDI2, +4 %% measured); 1 = every filter of the "
+                         "chain on a stream of its own (libhb: one thread per filter; more streams than hardware queues: "
+                         "-6 %%); 0 = the whole chain on one stream")
     ap.add_argument("--streams", type=int, default=1,
                     help="chain workloads: independent streams (own HIP stream and filter instances) per GPU")
     ap.add_argument("--workload", default="chain", choices=sorted(WORKLOADS),

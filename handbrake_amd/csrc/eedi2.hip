@@ -469,8 +469,10 @@ __global__ __launch_bounds__(MF_T) void k_mask_chain(P3 P, MaskSrc S, MaskChain 
     __shared__ uint32_t s_a[MF_LR][MF_DP];
     __shared__ uint32_t s_b[MF_LR][MF_DP];
     int fld, pl, bx, by;
-    eedi_chain_tile(C, fld, pl, bx, by);
-    mask_tile<true>(P, S, C, fld, pl, bx, by, mth, vth, lth, erode_thr, dilate_thr, s_src, s_a, s_b);
+    if (eedi_chain_tile(C, fld, pl, bx, by))                      // block-uniform
+        mask_tile<true>(P, S, C, fld, pl, bx, by, mth, vth, lth, erode_thr, dilate_thr, s_src, s_a, s_b);
+    else
+        mask_tile<false>(P, S, C, fld, pl, bx, by, mth, vth, lth, erode_thr, dilate_thr, s_src, s_a, s_b);
 }
 
 // calc_directions in two launches so that no lane idles while its neighbour walks the
@@ -568,7 +570,7 @@ __global__ __launch_bounds__(256) void k_calc_dir_work(P3 P, const uint32_t *__r
 // 0 workgroups past the early exit, 1 workgroups with listed pixels, 2 listed pixels, 3 wave trips of the list loop,
 // 4 steps of all lanes (useful), 5 wave-steps (the longest lane of each wave trip), 6 lanes in wave trips,
 // 7 workgroups in the dense form, 8 their waves with listed pixels, 9 those of them without a step to leave out
-__device__ unsigned long long g_cd_stats[12];
+__device__ unsigned long long g_cd_stats[24];
 #define CD_STAT(i, v) atomicAdd(&g_cd_stats[i], (unsigned long long)(v))
 #else
 #define CD_STAT(i, v) ((void)0)
@@ -1674,6 +1676,9 @@ __global__ __launch_bounds__(256) void k_fill_gaps_b(P3 P)
     }
     __syncthreads();
     const int count = s_count;
+#ifdef HBHIP_DEV_STATS
+    if (tid == 0) CD_STAT(12, 1);
+#endif
     auto rd = [&](int r, int col) -> int {
         const unsigned k = (unsigned)(col - lo);
         return k < staged ? (int)s_r[r][k] : (int)g[r][col];
@@ -1759,6 +1764,9 @@ __global__ __launch_bounds__(256) void k_fill_gaps_b(P3 P)
                 else { minb = min(minb, t); maxb = max(maxb, t); }
             }
         }
+#ifdef HBHIP_DEV_STATS
+        CD_STAT(13, 1); CD_STAT(14, v - u); CD_STAT(15, fast); CD_STAT(16, tc + bc); CD_STAT(17, (tc + bc) * (v - u + 1));
+#endif
         if (maxt == -20) maxt = mint = 20;
         if (maxb == -20) maxb = minb = 20;
         const int far = max(iabs(forward - NEUTRAL), iabs(back - NEUTRAL));
@@ -2462,15 +2470,14 @@ int Eedi2Engine::enqueue_mask(int n, hbhip_ctx *lc)
                      par_.erosion_threshold, par_.dilation_threshold);
     else
     {
-        // the tiles no earlier field can influence: all fields at once (tile rows below the middle return at once)
-        const unsigned gy_up = std::max(1, (srcp.height[0] / 2 - MF_OY) / MF_H);
-        HBHIP_LAUNCH(lc, "eedi2_mask_upper", k_mask_fused4, dim3(gx, gy_up, 3 * n), dim3(MF_T), 0, P, S, 0, 1, mth, vth, lth,
-                     par_.erosion_threshold, par_.dilation_threshold);
-        // the rest: a chain through the fields, in one launch (MaskChain)
+        // One launch: the tiles no earlier field can influence (upper) and the chain through the fields (lower, MaskChain),
+        // field-major - a field's lower tiles, then its upper ones.  As two launches (all upper tiles, then the chain) the
+        // chain ran alone at a third of the GPU: it is 16 links of latency, not work (58 + 139 us per 16 fields).
         MaskChain C = eedi_mask_chain_tiles(srcp, MF_W, MF_H, MF_OY);
         C.flags = chain_flags_;
         C.epoch = ++chain_epoch_;
-        HBHIP_LAUNCH(lc, "eedi2_mask_passes", k_mask_chain, dim3((unsigned)(C.ntiles * n)), dim3(MF_T), 0, P, S, C, mth, vth, lth,
+        C.group = C.ntiles + C.nupper;
+        HBHIP_LAUNCH(lc, "eedi2_mask_passes", k_mask_chain, dim3((unsigned)(C.group * n)), dim3(MF_T), 0, P, S, C, mth, vth, lth,
                      par_.erosion_threshold, par_.dilation_threshold);
     }
     HBHIP_CHECK(lc, hipGetLastError());
@@ -2651,11 +2658,11 @@ int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc)
 // development builds with -DHBHIP_DEV_STATS: the search-schedule counters of k_calc_dir_rows (read and cleared)
 extern "C" int hbhip_dev_eedi2_stats(unsigned long long *out, int n)
 {
-    unsigned long long h[12] = { 0 };
+    unsigned long long h[24] = { 0 };
     if (hipDeviceSynchronize() != hipSuccess) return -1;
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_cd_stats), sizeof(h)) != hipSuccess) return -1;
-    for (int i = 0; i < n && i < 12; i++) out[i] = h[i];
-    unsigned long long z[12] = { 0 };
+    for (int i = 0; i < n && i < 24; i++) out[i] = h[i];
+    unsigned long long z[24] = { 0 };
     return hipMemcpyToSymbol(HIP_SYMBOL(g_cd_stats), z, sizeof(z)) == hipSuccess ? 0 : -1;
 }
 #endif

@@ -45,6 +45,8 @@ struct MaskChain
     uint32_t  epoch;
     int tx[3], ty0[3], tyn[3], base[3];   // per plane: tiles per row, first lower tile row, lower tile rows, first tile number
     int ntiles;               // lower tiles of one field, all planes
+    int ubase[3], nupper;     // the upper tiles of a field (rows 0 .. ty0 - 1), numbered plane by plane behind the lower ones
+    int group;                // workgroups per field of a launch: ntiles, or ntiles + nupper when the upper tiles ride along
 };
 
 // the lower tiles of one field, numbered plane by plane; a tile row is "upper" (no row of its LDS frame reaches the half
@@ -61,20 +63,36 @@ static inline MaskChain eedi_mask_chain_tiles(const EediFrame &srcp, int tile_w,
         C.tyn[c] = tys - C.ty0[c];
         C.base[c] = C.ntiles;
         C.ntiles += C.tx[c] * C.tyn[c];
+        C.ubase[c] = C.nupper;
+        C.nupper += C.tx[c] * C.ty0[c];
     }
+    C.group = C.ntiles;
     return C;
 }
 
-// blockIdx.x = field * C.ntiles + tile -> field, plane, tile column and row
-__device__ __forceinline__ void eedi_chain_tile(const MaskChain &C, int &fld, int &pl, int &bx, int &by)
+// blockIdx.x = field * C.group + tile -> field, plane, tile column and row; returns whether the tile is a lower one (a
+// link of the chain).  With C.group = ntiles + nupper the upper tiles of a field - which no other tile waits for and which
+// wait for none - sit behind its lower ones in the dispatch order: they keep the CUs busy while the next field's lower
+// tiles wait for this field's.
+__device__ __forceinline__ bool eedi_chain_tile(const MaskChain &C, int &fld, int &pl, int &bx, int &by)
 {
-    fld = (int)blockIdx.x / C.ntiles;
-    int tile = (int)blockIdx.x - fld * C.ntiles;
-    pl = tile >= C.base[2] ? 2 : tile >= C.base[1] ? 1 : 0;
-    tile -= C.base[pl];
-    const int ry = tile / C.tx[pl];
-    bx = tile - ry * C.tx[pl];
-    by = C.ty0[pl] + ry;
+    fld = (int)blockIdx.x / C.group;
+    int tile = (int)blockIdx.x - fld * C.group;
+    if (tile < C.ntiles)
+    {
+        pl = tile >= C.base[2] ? 2 : tile >= C.base[1] ? 1 : 0;
+        tile -= C.base[pl];
+        const int ry = tile / C.tx[pl];
+        bx = tile - ry * C.tx[pl];
+        by = C.ty0[pl] + ry;
+        return true;
+    }
+    tile -= C.ntiles;
+    pl = tile >= C.ubase[2] ? 2 : tile >= C.ubase[1] ? 1 : 0;
+    tile -= C.ubase[pl];
+    by = tile / C.tx[pl];
+    bx = tile - by * C.tx[pl];
+    return false;
 }
 
 // threads 0 .. 8 of the workgroup: wait for the previous field's tile at (bx + t % 3 - 1, by + t / 3 - 1), if there is one

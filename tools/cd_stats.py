@@ -33,15 +33,16 @@ def main():
               torch.empty((H // 2, W // 2), dtype=torch.uint8, device="cuda")] for _ in range(cap)]
     out_arr = (hip.DevFrame * cap)(*[hip.dev_frame(t) for t in out_t])
     flags = [synth.PIC_FLAG_TOP_FIELD_FIRST] * B
-    out = (ctypes.c_ulonglong * 12)()
+    out = (ctypes.c_ulonglong * 24)()
     produced = 0
     for b in range(nb):
         produced_b = chain.process_dev(in_arr, out_arr, tag0=b * B, flags=flags, combed=[2] * B)
         chain.sync()
-        fn(out, 12)
+        fn(out, 24)
         v = [int(x) for x in out]
         fields = max(produced_b, 1)
-        names = ["workgroups", "workgroups_listing", "listed_pixels", "wave_trips", "lane_steps", "wave_steps", "lanes_in_trips", "dense_workgroups", "dense_waves", "dense_waves_all", "-", "-"]
+        names = ["workgroups", "workgroups_listing", "listed_pixels", "wave_trips", "lane_steps", "wave_steps", "lanes_in_trips", "dense_workgroups", "dense_waves", "dense_waves_all", "-", "-",
+                 "fg_workgroups", "fg_gap_pixels", "fg_sum_gap_len", "fg_fast", "fg_minmax_walks", "fg_minmax_bytes"] + ["-"] * 6
         print(json.dumps({"batch": b, "fields": produced_b, "per_field": {n: round(x / fields, 1) for n, x in zip(names, v)},
                           "lane_efficiency": round(v[4] / (64.0 * v[5]), 3) if v[5] else None}))
         produced += produced_b

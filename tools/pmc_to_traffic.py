@@ -19,7 +19,7 @@ NAMES = {
     "k_dir_map_c": ("eedi2_expand_dir_map_2x", 16),         # half-height and _2x forms, mean
     "decomb_plane4_kernel": ("decomb_plane", 16), "scale8_up_kernel": ("cropscale_lanczos_fused", 16),
     "lapsharp3_rows_kernel": ("lapsharp_3x3", 16), "copy3_batch_kernel": ("copy_planes", 32),
-    "k_mask_chain": ("eedi2_mask_passes", 16), "k_mask_fused4": ("eedi2_mask_upper", 16),
+    "k_mask_chain": ("eedi2_mask_passes", 16), "k_mask_fused4": ("eedi2_mask_passes", 1),
     "job_table_kernel": ("nlmeans_job_table", 32),
 }
 
