@@ -1579,99 +1579,135 @@ constexpr int FG_W = 1024, FG_HALO = 64, FG_LW = FG_W + 2 * FG_HALO;
 // turned into four bit rows (ballots), and a pixel finds its gap's ends, and whether the rows above / below break
 // the gap's support, with a few 64-bit operations; only the min / max over a supported gap still walks bytes
 // (independent reads).  Walks that leave the staged span take the byte path (rare).
+// FG_R rebuilt rows (and the FG_R copied rows between them) per workgroup: the rows a rebuilt row looks at (direction
+// rows y - 2 / y / y + 2, mask rows y - 3 / y - 1 / y + 1 / y + 3) are its neighbours' too - 2 FG_R + 5 staged rows serve
+// FG_R of them instead of 7 serving one - and a quarter of the waves find their plane and field (the one-row form ran
+// at the scalar unit's rate: 104 scalar instructions per wave, half of the waves only there to copy a row or to return).
+#ifndef FG_ROWS
+#define FG_ROWS 4
+#endif
+constexpr int FG_R = FG_ROWS, FG_ND = FG_R + 2, FG_NM = FG_R + 3, FG_WORDS = FG_LW / 64 + 1;
 __global__ __launch_bounds__(256) void k_fill_gaps_b(P3 P)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_r[7][FG_LW];
-    __shared__ __attribute__((aligned(16))) uint8_t s_out[FG_W];
-    __shared__ uint16_t s_list[FG_W];
+    __shared__ __attribute__((aligned(16))) uint8_t s_d[FG_ND][FG_LW];      // direction rows yb - 2, yb, .. , yb + 2 FG_R
+    __shared__ __attribute__((aligned(16))) uint8_t s_m[FG_NM][FG_LW];      // mask rows yb - 3, yb - 1, .. , yb + 2 FG_R + 1
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[FG_R][FG_W];
+    __shared__ uint16_t s_list[FG_R * FG_W];
     __shared__ int s_count;
-    __shared__ uint64_t s_stop[FG_LW / 64 + 1], s_np[FG_LW / 64 + 1], s_bt[FG_LW / 64 + 1], s_bb[FG_LW / 64 + 1];   // one bit per staged column
+    __shared__ uint64_t s_stop[FG_R][FG_WORDS], s_np[FG_R][FG_WORDS], s_bt[FG_R][FG_WORDS], s_bb[FG_R][FG_WORDS];   // one bit per staged column
     FIELD_PLANE(P);
-    const int y = blockIdx.y, y0 = 2 - tff;
+    const int y0 = 2 - tff;
     const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
     const int x0 = blockIdx.x * FG_W, tid = threadIdx.x;
-    if (y >= height || x0 >= width) return;
-    const uint8_t *dcg = Q.b + (size_t)y * pitch;
-    uint8_t *og = Q.c + (size_t)y * pitch;
+    const int ya = (int)blockIdx.y * 2 * FG_R;                     // the workgroup's 2 FG_R plane rows: ya .. ya + 2 FG_R - 1
+    if (ya >= height || x0 >= width) return;
+    const int yb = ya + (y0 & 1);                                  // its rows of the rebuilt parity: yb, yb + 2, ..
     const int x = x0 + 4 * tid;
-    if (!(y >= y0 && y < height - 1 && ((y - y0) & 1) == 0))
+    auto rebuilt = [&](int y) { return y >= y0 && y < height - 1; };
+    // the rows that are only copied (the reference's bit_blit): the other parity, and what lies outside y0 .. height - 2
+    uint32_t vcopy[2 * FG_R];
+#pragma unroll
+    for (int i = 0; i < 2 * FG_R; i++)
     {
-        if (x < width)
-        {
-            const uint32_t v = *reinterpret_cast<const uint32_t *>(dcg + x);
-            if (x + 3 < width) *reinterpret_cast<uint32_t *>(og + x) = v;
-            else for (int k = 0; k < 4 && x + k < width; k++) og[x + k] = (uint8_t)(v >> (8 * k));
-        }
-        return;
+        const int y = ya + i;
+        vcopy[i] = 0;
+        if (x < width && y < height && !((((y - y0) & 1) == 0) && rebuilt(y)))
+            vcopy[i] = *reinterpret_cast<const uint32_t *>(Q.b + (size_t)y * pitch + x);
     }
     if (tid == 0) s_count = 0;
-    const uint8_t *g[7] = { dcg, Q.a + (ptrdiff_t)(y - 1) * pitch, Q.a + (ptrdiff_t)(y + 1) * pitch,
-                            dcg - 2 * (ptrdiff_t)pitch, dcg + 2 * (ptrdiff_t)pitch,
-                            Q.a + (ptrdiff_t)(y - 3) * pitch, Q.a + (ptrdiff_t)(y + 3) * pitch };
     const int lo = x0 - FG_HALO;                                   // column of staged byte 0 (a multiple of 4)
     const int ndw = (min(FG_W, hbhip_align_up_dev(width - x0, 4)) + 2 * FG_HALO) / 4;
     {
-        // all loads of a thread in flight before the first LDS store (ndw <= 288: two dwords per row and thread)
-        // (one branch per column of the thread, not one per load: every divergent `if` is four or five instructions on the
-        // scalar unit, and this kernel runs at two thirds of its issue rate)
-        uint32_t v[7][2] = {};
+        // all loads of a thread in flight before its first LDS store (ndw <= 288: two dwords per row and thread); rows
+        // outside the plane are rows no pixel's tests reach (:1076, :1090): they are read from the nearest row inside
         const bool h0 = tid < ndw, h1 = tid + 256 < ndw;
+        uint32_t vd[FG_ND][2] = {}, vm[FG_NM][2] = {};
         if (h0)
         {
 #pragma unroll
-            for (int r = 0; r < 7; r++) v[r][0] = reinterpret_cast<const uint32_t *>(g[r] + lo)[tid];
+            for (int r = 0; r < FG_ND; r++)
+                vd[r][0] = reinterpret_cast<const uint32_t *>(Q.b + (size_t)min(max(yb - 2 + 2 * r, 0), height - 1) * pitch + lo)[tid];
+#pragma unroll
+            for (int r = 0; r < FG_NM; r++)
+                vm[r][0] = reinterpret_cast<const uint32_t *>(Q.a + (size_t)min(max(yb - 3 + 2 * r, 0), height - 1) * pitch + lo)[tid];
         }
         if (h1)
         {
 #pragma unroll
-            for (int r = 0; r < 7; r++) v[r][1] = reinterpret_cast<const uint32_t *>(g[r] + lo)[tid + 256];
+            for (int r = 0; r < FG_ND; r++)
+                vd[r][1] = reinterpret_cast<const uint32_t *>(Q.b + (size_t)min(max(yb - 2 + 2 * r, 0), height - 1) * pitch + lo)[tid + 256];
+#pragma unroll
+            for (int r = 0; r < FG_NM; r++)
+                vm[r][1] = reinterpret_cast<const uint32_t *>(Q.a + (size_t)min(max(yb - 3 + 2 * r, 0), height - 1) * pitch + lo)[tid + 256];
         }
         if (h0)
         {
 #pragma unroll
-            for (int r = 0; r < 7; r++) reinterpret_cast<uint32_t *>(s_r[r])[tid] = v[r][0];
+            for (int r = 0; r < FG_ND; r++) reinterpret_cast<uint32_t *>(s_d[r])[tid] = vd[r][0];
+#pragma unroll
+            for (int r = 0; r < FG_NM; r++) reinterpret_cast<uint32_t *>(s_m[r])[tid] = vm[r][0];
         }
         if (h1)
         {
 #pragma unroll
-            for (int r = 0; r < 7; r++) reinterpret_cast<uint32_t *>(s_r[r])[tid + 256] = v[r][1];
+            for (int r = 0; r < FG_ND; r++) reinterpret_cast<uint32_t *>(s_d[r])[tid + 256] = vd[r][1];
+#pragma unroll
+            for (int r = 0; r < FG_NM; r++) reinterpret_cast<uint32_t *>(s_m[r])[tid + 256] = vm[r][1];
         }
     }
     __syncthreads();
-    enum { DC = 0, MC = 1, MN = 2, DP = 3, DN = 4, MP = 5, MNN = 6 };
+    // rebuilt row k = yb + 2k: direction rows s_d[k] (y - 2), s_d[k + 1] (y), s_d[k + 2] (y + 2); mask rows s_m[k] (y - 3),
+    // s_m[k + 1] (y - 1), s_m[k + 2] (y + 1), s_m[k + 3] (y + 3)
     const unsigned staged = 4u * (unsigned)ndw;
-    // Per staged column: does a walk stop here (a known direction, or outside the mask: :1055-1058), is the direction
-    // known, does the row above / below end the "top / bottom continues" state (:1078-1093).  The walks then are
-    // bit scans instead of chains of dependent byte reads.
+    // Per staged column and rebuilt row: does a walk stop here (a known direction, or outside the mask: :1055-1058), is the
+    // direction known, does the row above / below end the "top / bottom continues" state (:1078-1093).  The walks then
+    // are bit scans instead of chains of dependent byte reads.  First the rows' own bits - direction known, mask set -
+    // once per staged row, then the four combinations per rebuilt row as word arithmetic.
     for (int k = 0; k < (FG_LW + 255) / 256; k++)
     {
-        // (no branch and no short-circuit: the seven bytes are read whatever they hold - from the last staged column for the
-        // lanes past it, whose bits are then cleared - and the four conditions are mask arithmetic)
+        // (no branch: the bytes are read whatever they hold - from the last staged column for the lanes past it, whose
+        // bits are then cleared)
         const unsigned col = tid + 256 * k, cc = min(col, staged - 1u);
         const bool in = col < staged;
-        const bool mc = s_r[MC][cc] == PEAK, mn = s_r[MN][cc] == PEAK;
-        const bool np = in & (s_r[DC][cc] != PEAK);
-        const bool stop = in & (np | (!mc & !mn));
-        const bool bt = in & ((s_r[DP][cc] == PEAK) | ((s_r[MP][cc] != PEAK) & !mc));
-        const bool bb = in & ((s_r[DN][cc] == PEAK) | (!mn & (s_r[MNN][cc] != PEAK)));
-        const uint64_t w0 = __ballot(stop), w1 = __ballot(np), w2 = __ballot(bt), w3 = __ballot(bb);
-        if ((tid & 63) == 0 && (col >> 6) < FG_LW / 64 + 1) { s_stop[col >> 6] = w0; s_np[col >> 6] = w1; s_bt[col >> 6] = w2; s_bb[col >> 6] = w3; }
-    }
-    if (x < width)
-    {
-        const int c = 4 * tid + FG_HALO;
-        const uint32_t cw = *reinterpret_cast<const uint32_t *>(&s_r[DC][c]);
-        const uint32_t mcw = *reinterpret_cast<const uint32_t *>(&s_r[MC][c]), mnw = *reinterpret_cast<const uint32_t *>(&s_r[MN][c]);
-        *reinterpret_cast<uint32_t *>(&s_out[4 * tid]) = cw;
-        // the gap pixels among the four (direction unknown, inside the mask: :1046-1050) as byte arithmetic, one atomic
-        // for all of them
-        const uint32_t gap = ((ff_bytes(cw) & (ff_bytes(mcw) | ff_bytes(mnw))) >> 7) & mf_bytes_in(x, 1, width - 1);
-        if (gap)
-        {
-            int at = atomicAdd(&s_count, __popc(gap));
+        uint64_t nd[FG_ND], pm[FG_NM];
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-                if ((gap >> (8 * k)) & 1u) s_list[at++] = (uint16_t)(4 * tid + k);
+        for (int r = 0; r < FG_ND; r++) nd[r] = __ballot(in & (s_d[r][cc] != PEAK));       // direction known
+#pragma unroll
+        for (int r = 0; r < FG_NM; r++) pm[r] = __ballot(in & (s_m[r][cc] == PEAK));       // on the mask
+        const uint64_t inw = __ballot(in);
+        if ((tid & 63) == 0 && (col >> 6) < (unsigned)FG_WORDS)
+        {
+#pragma unroll
+            for (int r = 0; r < FG_R; r++)
+            {
+                const uint64_t mc = pm[r + 1], mn = pm[r + 2];
+                s_np[r][col >> 6] = nd[r + 1];
+                s_stop[r][col >> 6] = nd[r + 1] | (inw & ~mc & ~mn);
+                s_bt[r][col >> 6] = inw & (~nd[r] | (~pm[r] & ~mc));
+                s_bb[r][col >> 6] = inw & (~nd[r + 2] | (~mn & ~pm[r + 3]));
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < FG_R; r++)
+    {
+        const int y = yb + 2 * r;
+        if (x < width && y < height && rebuilt(y))                              // (rows that are copied have their dword in vcopy)
+        {
+            const int c = 4 * tid + FG_HALO;
+            const uint32_t cw = *reinterpret_cast<const uint32_t *>(&s_d[r + 1][c]);
+            const uint32_t mcw = *reinterpret_cast<const uint32_t *>(&s_m[r + 1][c]), mnw = *reinterpret_cast<const uint32_t *>(&s_m[r + 2][c]);
+            *reinterpret_cast<uint32_t *>(&s_out[r][4 * tid]) = cw;
+            // the gap pixels among the four (direction unknown, inside the mask: :1046-1050) as byte arithmetic, one atomic
+            // for all of them
+            const uint32_t gap = ((ff_bytes(cw) & (ff_bytes(mcw) | ff_bytes(mnw))) >> 7) & mf_bytes_in(x, 1, width - 1);
+            if (gap)
+            {
+                int at = atomicAdd(&s_count, __popc(gap));
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if ((gap >> (8 * k)) & 1u) s_list[at++] = (uint16_t)((r << 12) | (4 * tid + k));
+            }
         }
     }
     __syncthreads();
@@ -1679,13 +1715,17 @@ __global__ __launch_bounds__(256) void k_fill_gaps_b(P3 P)
 #ifdef HBHIP_DEV_STATS
     if (tid == 0) CD_STAT(12, 1);
 #endif
-    auto rd = [&](int r, int col) -> int {
-        const unsigned k = (unsigned)(col - lo);
-        return k < staged ? (int)s_r[r][k] : (int)g[r][col];
-    };
     for (int i = tid; i < count; i += 256)
     {
-        const int lx = s_list[i], px = x0 + lx;
+        const int e = s_list[i], r = e >> 12, lx = e & 0xfff, px = x0 + lx, y = yb + 2 * r;
+        const uint8_t *DC = s_d[r + 1], *DP = s_d[r], *DN = s_d[r + 2];
+        const uint8_t *MC = s_m[r + 1], *MN = s_m[r + 2], *MP = s_m[r], *MNN = s_m[r + 3];
+        // (columns outside the staged span: from memory; the rows these are read from exist for every pixel that gets here)
+        const uint8_t *gd = Q.b + (size_t)y * pitch, *gma = Q.a + (ptrdiff_t)(y - 1) * pitch;
+        auto rd = [&](const uint8_t *srow, const uint8_t *grow, int col) -> int {
+            const unsigned k = (unsigned)(col - lo);
+            return k < staged ? (int)srow[k] : (int)grow[col];
+        };
         int u = px - 1, back = 500, forward = -500;
         int v = px + 1;
         int tc = 1, bc = 1, mint = 500, maxt = -20, minb = 500, maxb = -20;
@@ -1695,14 +1735,14 @@ __global__ __launch_bounds__(256) void k_fill_gaps_b(P3 P)
         int ul = -1, vl = -1;
         for (int wi = (c - 1) >> 6; wi >= (first >> 6) && c - 1 >= first; wi--)      // highest stop bit in [first, c - 1]
         {
-            uint64_t w = s_stop[wi];
+            uint64_t w = s_stop[r][wi];
             if (wi == ((c - 1) >> 6) && ((c - 1) & 63) != 63) w &= (2ull << ((c - 1) & 63)) - 1ull;
             if (wi == (first >> 6)) w &= ~0ull << (first & 63);
             if (w) { ul = 64 * wi + 63 - __clzll((long long)w); break; }
         }
         for (int wi = (c + 1) >> 6; wi <= ((last - 1) >> 6) && c + 1 < last; wi++)   // lowest stop bit in [c + 1, last - 1]
         {
-            uint64_t w = s_stop[wi];
+            uint64_t w = s_stop[r][wi];
             if (wi == ((c + 1) >> 6)) w &= ~0ull << ((c + 1) & 63);
             if (wi == ((last - 1) >> 6) && ((last - 1) & 63) != 63) w &= (2ull << ((last - 1) & 63)) - 1ull;
             if (w) { vl = 64 * wi + __ffsll((long long)w) - 1; break; }
@@ -1711,9 +1751,9 @@ __global__ __launch_bounds__(256) void k_fill_gaps_b(P3 P)
         const bool fast = (ul >= 0 || lo <= 1) && (vl >= 0 || lo + (int)staged > width);     // column `width` itself must be staged too
         if (fast)
         {
-            if (ul >= 0) { u = lo + ul; if ((s_np[ul >> 6] >> (ul & 63)) & 1ull) back = s_r[DC][ul]; }
+            if (ul >= 0) { u = lo + ul; if ((s_np[r][ul >> 6] >> (ul & 63)) & 1ull) back = DC[ul]; }
             else u = 0;
-            if (vl >= 0) { v = lo + vl; if ((s_np[vl >> 6] >> (vl & 63)) & 1ull) forward = s_r[DC][vl]; }
+            if (vl >= 0) { v = lo + vl; if ((s_np[r][vl >> 6] >> (vl & 63)) & 1ull) forward = DC[vl]; }
             else v = width;
             // columns u .. v (v = width included, as the reference's loop includes it) are staged
             const int a0 = u - lo, a1 = v - lo;
@@ -1727,41 +1767,45 @@ __global__ __launch_bounds__(256) void k_fill_gaps_b(P3 P)
                 }
                 return false;
             };
-            if (y <= 2 || any_in(s_bt)) { tc = 0; mint = maxt = 20; }
-            else for (int j = a0; j <= a1; j++) { const int t = s_r[DP][j]; mint = min(mint, t); maxt = max(maxt, t); }
-            if (y >= height - 3 || any_in(s_bb)) { bc = 0; minb = maxb = 20; }
-            else for (int j = a0; j <= a1; j++) { const int t = s_r[DN][j]; minb = min(minb, t); maxb = max(maxb, t); }
+            if (y <= 2 || any_in(s_bt[r])) { tc = 0; mint = maxt = 20; }
+            else for (int j = a0; j <= a1; j++) { const int t = DP[j]; mint = min(mint, t); maxt = max(maxt, t); }
+            if (y >= height - 3 || any_in(s_bb[r])) { bc = 0; minb = maxb = 20; }
+            else for (int j = a0; j <= a1; j++) { const int t = DN[j]; minb = min(minb, t); maxb = max(maxb, t); }
         }
         else
         {
-        while (u)
-        {
-            const int d = rd(DC, u);
-            if (d != PEAK) { back = d; break; }
-            if (rd(MC, u) != PEAK && rd(MN, u) != PEAK) break;
-            u--;
-        }
-        while (v < width)
-        {
-            const int d = rd(DC, v);
-            if (d != PEAK) { forward = d; break; }
-            if (rd(MC, v) != PEAK && rd(MN, v) != PEAK) break;
-            v++;
-        }
-        }
-        for (int j = u; !fast && j <= v; j++)
-        {
-            if (tc)
+            const uint8_t *gmn = gma + 2 * (ptrdiff_t)pitch;
+            while (u)
             {
-                int t;
-                if (y <= 2 || (t = rd(DP, j)) == PEAK || (rd(MP, j) != PEAK && rd(MC, j) != PEAK)) { tc = 0; mint = maxt = 20; }
-                else { mint = min(mint, t); maxt = max(maxt, t); }
+                const int d = rd(DC, gd, u);
+                if (d != PEAK) { back = d; break; }
+                if (rd(MC, gma, u) != PEAK && rd(MN, gmn, u) != PEAK) break;
+                u--;
             }
-            if (bc)
+            while (v < width)
             {
-                int t;
-                if (y >= height - 3 || (t = rd(DN, j)) == PEAK || (rd(MN, j) != PEAK && rd(MNN, j) != PEAK)) { bc = 0; minb = maxb = 20; }
-                else { minb = min(minb, t); maxb = max(maxb, t); }
+                const int d = rd(DC, gd, v);
+                if (d != PEAK) { forward = d; break; }
+                if (rd(MC, gma, v) != PEAK && rd(MN, gmn, v) != PEAK) break;
+                v++;
+            }
+            // (rows y - 2 / y - 3 and y + 2 / y + 3 are only looked at where the reference looks at them: :1076, :1090)
+            const uint8_t *gdp = gd - 2 * (ptrdiff_t)pitch, *gdn = gd + 2 * (ptrdiff_t)pitch;
+            const uint8_t *gmp = gma - 2 * (ptrdiff_t)pitch, *gmnn = gmn + 2 * (ptrdiff_t)pitch;
+            for (int j = u; j <= v; j++)
+            {
+                if (tc)
+                {
+                    int t;
+                    if (y <= 2 || (t = rd(DP, gdp, j)) == PEAK || (rd(MP, gmp, j) != PEAK && rd(MC, gma, j) != PEAK)) { tc = 0; mint = maxt = 20; }
+                    else { mint = min(mint, t); maxt = max(maxt, t); }
+                }
+                if (bc)
+                {
+                    int t;
+                    if (y >= height - 3 || (t = rd(DN, gdn, j)) == PEAK || (rd(MN, gmn, j) != PEAK && rd(MNN, gmnn, j) != PEAK)) { bc = 0; minb = maxb = 20; }
+                    else { minb = min(minb, t); maxb = max(maxb, t); }
+                }
             }
         }
 #ifdef HBHIP_DEV_STATS
@@ -1776,15 +1820,23 @@ __global__ __launch_bounds__(256) void k_fill_gaps_b(P3 P)
         {
             const double stepd = (double)(forward - back) / (double)(v - u);
             const int j = px - u - 1;
-            s_out[lx] = (uint8_t)((back + (int)(j * stepd + 0.5)) & 0xff);
+            s_out[r][lx] = (uint8_t)((back + (int)(j * stepd + 0.5)) & 0xff);
         }
     }
     __syncthreads();
     if (x < width)
     {
-        const uint32_t v = *reinterpret_cast<const uint32_t *>(&s_out[4 * tid]);
-        if (x + 3 < width) *reinterpret_cast<uint32_t *>(og + x) = v;
-        else for (int k = 0; k < 4 && x + k < width; k++) og[x + k] = (uint8_t)(v >> (8 * k));
+#pragma unroll
+        for (int i = 0; i < 2 * FG_R; i++)
+        {
+            const int y = ya + i;
+            if (y >= height) break;
+            const bool work = (((y - y0) & 1) == 0) && rebuilt(y);
+            const uint32_t v = work ? *reinterpret_cast<const uint32_t *>(&s_out[(i - (y0 & 1)) >> 1][4 * tid]) : vcopy[i];
+            uint8_t *o = Q.c + (size_t)y * pitch + x;
+            if (x + 3 < width) *reinterpret_cast<uint32_t *>(o) = v;
+            else for (int k = 0; k < 4 && x + k < width; k++) o[k] = (uint8_t)(v >> (8 * k));
+        }
     }
 }
 
@@ -2594,7 +2646,7 @@ int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc)
     dir_map("eedi2_expand_dir_map_2x", dst2p, P, 2, 1);
     // (a workgroup per row here: with the copied row of a pair folded into the workgroup of the rebuilt one, as in the dir-map
     // passes, this kernel went from 131 to 163-165 us per launch)
-    const dim3 fg_grid((dst2p.width[0] + FG_W - 1) / FG_W, dst2p.height[0], gz);
+    const dim3 fg_grid((dst2p.width[0] + FG_W - 1) / FG_W, (dst2p.height[0] + 2 * FG_R - 1) / (2 * FG_R), gz);
     bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
     HBHIP_LAUNCH(lc, "eedi2_fill_gaps_2x", k_fill_gaps_b, fg_grid, dim3(256), 0, P);
     bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
