@@ -348,12 +348,21 @@ def pmc_record(kname, units_per_launch):
 
 
 # the device function behind a profiler name, for the kernel's own instruction mix (tools/isa_mix.py)
-ISA_NAMES = {"eedi2_calc_directions": ("r3_eedi2_isa_mix.json", "k_calc_dir_rows<2>"),
-             "eedi2_fill_gaps_2x": ("r3_eedi2_isa_mix.json", "k_fill_gaps_b"),
-             "eedi2_lattice_candidates": ("r3_eedi2_isa_mix.json", "k_lattice_cand_q"),
-             "eedi2_filter_dir_map_2x": ("r3_eedi2_isa_mix.json", "k_dir_map4"),
-             "nlmeans_plane_n7": ("r3_nlmeans_isa_mix.json", "nlmeans_lanes_kernel<7, 3, 36, false>"),
-             "cropscale_lanczos_fused": ("r3_alias_isa_mix.json", "scale8_up_kernel")}
+ISA_NAMES = {"eedi2_calc_directions": ("eedi2_isa_mix.json", "k_calc_dir_rows<4>"),
+             "eedi2_fill_gaps_2x": ("eedi2_isa_mix.json", "k_fill_gaps_b"),
+             "eedi2_lattice_candidates": ("eedi2_isa_mix.json", "k_lattice_cand_q"),
+             "eedi2_filter_dir_map_2x": ("eedi2_isa_mix.json", "k_dir_map4"),
+             "nlmeans_plane_n7": ("nlmeans_isa_mix.json", "nlmeans_lanes_kernel<7, 3, 36, false>"),
+             "cropscale_lanczos_fused": ("alias_isa_mix.json", "scale8_up_kernel")}
+
+
+def _newest_profile(suffix):
+    """the newest committed profiles/<round>_<suffix> (rounds sort by name: r3_ < r4_)"""
+    try:
+        files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_" + suffix))
+        return files[-1] if files else None
+    except OSError:
+        return None
 
 
 def issue_floors(kname):
@@ -380,7 +389,8 @@ def valu_roofline(valu_insts, avg_s, kname=None):
     cyc, src = 4.0, "assumed 4 cycles per wave64 instruction (no micro-benchmark result committed)"
     peak = 256 * 4 * 2.4e9 / cyc
     own = ISA_NAMES.get(kname)
-    if own and os.path.exists(os.path.join(ROOT, "profiles", own[0])):
+    if own and _newest_profile(own[0]):
+        own = (_newest_profile(own[0]), own[1])
         try:
             ks = json.load(open(os.path.join(ROOT, "profiles", own[0])))["kernels"]
             rec = next(v for k, v in ks.items() if own[1] in k)

@@ -320,8 +320,10 @@ __global__ __launch_bounds__(QM_T) void q_mask_chain(Q3 P, MaskSrc16 S, K16 k, M
     __shared__ uint32_t s_a[QM_LR][QM_DP];
     __shared__ uint32_t s_b[QM_LR][QM_DP];
     int fld, pl, bx, by;
-    eedi_chain_tile(C, fld, pl, bx, by);
-    qmask_tile<true>(P, S, k, C, fld, pl, bx, by, mth, vth, lth, erode_thr, dilate_thr, s_src, s_a, s_b);
+    if (eedi_chain_tile(C, fld, pl, bx, by))                      // block-uniform: a link of the chain, or an upper tile riding along
+        qmask_tile<true>(P, S, k, C, fld, pl, bx, by, mth, vth, lth, erode_thr, dilate_thr, s_src, s_a, s_b);
+    else
+        qmask_tile<false>(P, S, k, C, fld, pl, bx, by, mth, vth, lth, erode_thr, dilate_thr, s_src, s_a, s_b);
 }
 
 // eedi2_calc_directions (:358-525): a = mskp, b = srcp, c = out (whole pitch pre-filled with PEAK)
@@ -408,6 +410,150 @@ __device__ __forceinline__ uint32_t sad3q(uint2 a, uint2 b, uint32_t acc)
     return __builtin_amdgcn_sad_u16(a.x, b.x, __builtin_amdgcn_sad_u16(a.y, b.y, acc));
 }
 
+// the vote over the five offsets (:486-517): ta .. te = u + 32, 0 = never set (the reference's -5000)
+__device__ __forceinline__ int calc_dir_vote16(int ta, int tb, int tc, int td, int te, const int *limlut, int neutral, int shift)
+{
+    // the offsets that were set, sorted (unset ones as a large sentinel at the end): 9-exchange network on 5 values
+    constexpr int BIG = 1 << 20;
+    int v0 = ta ? ta - 32 : BIG, v1 = tb ? tb - 32 : BIG, v2 = tc ? tc - 32 : BIG, v3 = td ? td - 32 : BIG, v4 = te ? te - 32 : BIG;
+    const int n = (ta != 0) + (tb != 0) + (tc != 0) + (td != 0) + (te != 0);
+#define Q_CX(a, b) { const int lo_ = min(a, b), hi_ = max(a, b); a = lo_; b = hi_; }
+    Q_CX(v0, v1) Q_CX(v3, v4) Q_CX(v2, v4) Q_CX(v2, v3) Q_CX(v0, v3) Q_CX(v0, v2) Q_CX(v1, v4) Q_CX(v1, v3) Q_CX(v1, v2)
+#undef Q_CX
+    int out = neutral;
+    if (n > 1)
+    {
+        // sorted_mid16's midpoint rule: odd n -> v[n/2], even n -> (v[(n-1)/2] + v[n/2] + 1) >> 1; one formula serves both
+        const int lo = n == 2 ? v0 : (n == 5 ? v2 : v1);
+        const int hi = n >= 4 ? v2 : v1;
+        const int mid = (lo + hi + 1) >> 1;
+        const int tlim = max(limlut[iabs16(mid)] >> 2, 2);
+        int sum = 0, cnt = 0;
+        if (iabs16(v0 - mid) <= tlim) { cnt++; sum += v0; }          // the sentinels fail the test by themselves
+        if (iabs16(v1 - mid) <= tlim) { cnt++; sum += v1; }
+        if (iabs16(v2 - mid) <= tlim) { cnt++; sum += v2; }
+        if (iabs16(v3 - mid) <= tlim) { cnt++; sum += v3; }
+        if (iabs16(v4 - mid) <= tlim) { cnt++; sum += v4; }
+        if (cnt > 1) out = (uint16_t)(neutral + ((int)((float)sum / (float)cnt) << (2 + shift)));
+    }
+    return out;
+}
+
+// The dense form of the search (calc_dir_dense in eedi2.hip has the derivation: the mask's lower half saturates, and the
+// 3-sample SADs of a step are shared between a column's rows and between u and -u).  On 16-bit samples a SAD is two
+// v_sad_u16 and does not come shifted, so P_r / Q_r are moved into place with their tag by one v_lshl_add each:
+// keys (sum << 9) | tags, tags = 4 (u + 32) for b / d / e and 6 (u + 32) for a / c (sums of 18 samples of at most 12 bits
+// stay below 2^17), a step a pixel does not take gets 2^30 added.
+template <int R, bool PRED>
+__device__ __forceinline__ void calc_dir_dense16(const uint2 *tr, int maxdt, const uint32_t (&up)[R], const uint32_t (&dn)[R],
+                                                 int nt13, int nt19, uint32_t (&ka)[R], uint32_t (&kb)[R], uint32_t (&kc)[R],
+                                                 uint32_t (&kd)[R], uint32_t (&ke)[R])
+{
+    constexpr int NS = R + 4, NE = R + 3;
+    uint2 T[NS];
+#pragma unroll
+    for (int r = 0; r < NS; r++) T[r] = tr[r * QLW];
+#pragma unroll
+    for (int j = 0; j < R; j++)
+    {
+        const int ctr = (int)(T[j + 2].x >> 16);
+        const int vert = iabs16(ctr - (int)(T[j + 3].x >> 16)) + iabs16(ctr - (int)(T[j + 1].x >> 16));
+        kb[j] = (uint32_t)min(nt13, vert * 6) << 9; ka[j] = (uint32_t)min(nt19, vert * 9) << 9;
+        kc[j] = ka[j]; kd[j] = kb[j]; ke[j] = kb[j];
+    }
+    auto term = [](uint2 a, uint2 b, uint32_t tag) { return (sad3q(a, b, 0u) << 9) + tag; };
+    auto sums = [&](const uint32_t (&Pv)[NE], const uint32_t (&Qv)[NE], const uint32_t (&X)[R], uint32_t (&ca)[R], uint32_t (&cb)[R],
+                    uint32_t (&cc)[R], uint32_t (&cd)[R], uint32_t (&ce)[R]) {
+        uint32_t S[NE], P2[NE - 1], Q2[NE - 1];
+#pragma unroll
+        for (int r = 0; r < NE; r++) S[r] = Pv[r] + Qv[r];
+#pragma unroll
+        for (int r = 0; r < NE - 1; r++) { P2[r] = Pv[r] + Pv[r + 1]; Q2[r] = Qv[r] + Qv[r + 1]; }
+        if (PRED)
+        {
+#pragma unroll
+            for (int j = 0; j < R; j++)
+            {
+                cb[j] = S[j + 1] + S[j + 2] + X[j]; ca[j] = cb[j] + S[j]; cc[j] = cb[j] + S[j + 3];
+                ce[j] = P2[j] + P2[j + 2] + X[j];   cd[j] = Q2[j] + Q2[j + 2] + X[j];
+            }
+        }
+        else
+        {
+            uint32_t S2[NE - 1], S3[NE - 2];
+#pragma unroll
+            for (int r = 0; r < NE - 1; r++) S2[r] = S[r] + S[r + 1];
+#pragma unroll
+            for (int r = 0; r < NE - 2; r++) S3[r] = S2[r] + S[r + 2];
+#pragma unroll
+            for (int j = 0; j < R; j++)
+            {
+                cb[j] = S2[j + 1]; ca[j] = S3[j]; cc[j] = S3[j + 1];
+                ce[j] = P2[j] + P2[j + 2]; cd[j] = Q2[j] + Q2[j + 2];
+            }
+        }
+    };
+    uint32_t X1[R], X2[R];
+#pragma unroll
+    for (int j = 0; j < R; j++) { X1[j] = 0; X2[j] = 0; }
+    {
+        uint32_t Pv[NE], ca[R], cb[R], cc[R], cd[R], ce[R];
+#pragma unroll
+        for (int r = 0; r < NE; r++) Pv[r] = term(T[r], T[r + 1], 32u);
+        if (PRED)
+        {
+#pragma unroll
+            for (int j = 0; j < R; j++) X1[j] = (up[j] << 30) & 0x40000000u;
+        }
+        sums(Pv, Pv, X1, ca, cb, cc, cd, ce);
+#pragma unroll
+        for (int j = 0; j < R; j++)
+        {
+            ka[j] = min(ka[j], ca[j]); kb[j] = min(kb[j], cb[j]); kc[j] = min(kc[j], cc[j]);
+            kd[j] = min(kd[j], cd[j]); ke[j] = min(ke[j], ce[j]);
+        }
+    }
+    for (int d = 1; d <= maxdt; d++)
+    {
+        const uint2 *tp = tr + d, *tm = tr - d;
+        uint2 Pl[NS], Mi[NS];
+#pragma unroll
+        for (int r = 0; r < NS; r++) { Pl[r] = tp[r * QLW]; Mi[r] = tm[r * QLW]; }
+        const uint32_t t1 = 32u + (uint32_t)d, t2 = 32u - (uint32_t)d;
+        uint32_t P1[NE], Q1[NE], Pn[NE], Qn[NE];
+#pragma unroll
+        for (int r = 0; r < NE; r++)
+        {
+            P1[r] = term(T[r], Mi[r + 1], t1); Q1[r] = term(Pl[r], T[r + 1], t1);      // u = +d
+            Pn[r] = term(T[r], Pl[r + 1], t2); Qn[r] = term(Mi[r], T[r + 1], t2);      // u = -d
+        }
+        if (PRED)
+        {
+            const uint32_t sh = 30u - (uint32_t)d;
+#pragma unroll
+            for (int j = 0; j < R; j++) { X1[j] = (up[j] << sh) & 0x40000000u; X2[j] = (dn[j] << sh) & 0x40000000u; }
+        }
+        uint32_t ca[R], cb[R], cc[R], cd[R], ce[R], na[R], nb[R], nc[R], nd[R], ne[R];
+        sums(P1, Q1, X1, ca, cb, cc, cd, ce);
+        sums(Pn, Qn, X2, na, nb, nc, nd, ne);
+#pragma unroll
+        for (int j = 0; j < R; j++)
+        {
+            ka[j] = min(ka[j], min(ca[j], na[j])); kb[j] = min(kb[j], min(cb[j], nb[j])); kc[j] = min(kc[j], min(cc[j], nc[j]));
+            kd[j] = min(kd[j], min(cd[j], nd[j])); ke[j] = min(ke[j], min(ce[j], ne[j]));
+        }
+    }
+}
+
+// bit t of a mask row's window: a peak among columns start + t .. + 2
+__device__ __forceinline__ uint64_t calc_dir_window16(const uint64_t *bits, int start, uint64_t lenmask)
+{
+    const int wq = start >> 6, sh = start & 63;
+    const uint64_t lo = bits[wq], hi = bits[wq + 1];
+    const uint64_t w = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+    return (w | (w >> 1) | (w >> 2)) & lenmask;
+}
+
 template <bool EDGE>
 __device__ __forceinline__ int calc_dir_search16(const uint2 *tr, uint64_t pass, int maxdt, bool first, bool last, int nt13, int nt19,
                                                  const int *limlut, int neutral, int shift)
@@ -450,35 +596,13 @@ __device__ __forceinline__ int calc_dir_search16(const uint2 *tr, uint64_t pass,
         kd = min(kd, (diffd << 6) | ub);
         ke = min(ke, (diffe << 6) | ub);
     }
-    // the offsets that were set, sorted (unset ones as a large sentinel at the end): 9-exchange network on 5 values
-    constexpr int BIG = 1 << 20;
-    const int ta = (int)(ka & 63u), tb = (int)(kb & 63u), tc = (int)(kc & 63u), td = (int)(kd & 63u), te = (int)(ke & 63u);
-    int v0 = ta ? ta - 32 : BIG, v1 = tb ? tb - 32 : BIG, v2 = tc ? tc - 32 : BIG, v3 = td ? td - 32 : BIG, v4 = te ? te - 32 : BIG;
-    const int n = (ta != 0) + (tb != 0) + (tc != 0) + (td != 0) + (te != 0);
-#define Q_CX(a, b) { const int lo_ = min(a, b), hi_ = max(a, b); a = lo_; b = hi_; }
-    Q_CX(v0, v1) Q_CX(v3, v4) Q_CX(v2, v4) Q_CX(v2, v3) Q_CX(v0, v3) Q_CX(v0, v2) Q_CX(v1, v4) Q_CX(v1, v3) Q_CX(v1, v2)
-#undef Q_CX
-    int out = neutral;
-    if (n > 1)
-    {
-        // sorted_mid16's midpoint rule: odd n -> v[n/2], even n -> (v[(n-1)/2] + v[n/2] + 1) >> 1; one formula serves both
-        const int lo = n == 2 ? v0 : (n == 5 ? v2 : v1);
-        const int hi = n >= 4 ? v2 : v1;
-        const int mid = (lo + hi + 1) >> 1;
-        const int tlim = max(limlut[iabs16(mid)] >> 2, 2);
-        int sum = 0, cnt = 0;
-        if (iabs16(v0 - mid) <= tlim) { cnt++; sum += v0; }          // the sentinels fail the test by themselves
-        if (iabs16(v1 - mid) <= tlim) { cnt++; sum += v1; }
-        if (iabs16(v2 - mid) <= tlim) { cnt++; sum += v2; }
-        if (iabs16(v3 - mid) <= tlim) { cnt++; sum += v3; }
-        if (iabs16(v4 - mid) <= tlim) { cnt++; sum += v4; }
-        if (cnt > 1) out = (uint16_t)(neutral + ((int)((float)sum / (float)cnt) << (2 + shift)));
-    }
-    return out;
+    return calc_dir_vote16((int)(ka & 63u), (int)(kb & 63u), (int)(kc & 63u), (int)(kd & 63u), (int)(ke & 63u), limlut, neutral, shift);
 }
 
+// dense_min: a block with at least this many listed pixels (none of them on the plane's first / last row) searches in the
+// dense form (R >= 4, depths up to 12 bits)
 template <int R>
-__global__ __launch_bounds__(QW) void q_calc_dir_rows(Q3 P, K16 k, int maxd, int nt)
+__global__ __launch_bounds__(QW) void q_calc_dir_rows(Q3 P, K16 k, int maxd, int nt, int dense_min)
 {
     constexpr int NS = R + 4, NM = R + 2, RWD = QLW / 2;                      // RWD: dwords per staged row
     __shared__ __attribute__((aligned(16))) uint16_t s_band[NS + NM][QLW];    // staged rows: 0..NS-1 source y0-2.., NS.. mask y0-1..
@@ -551,13 +675,54 @@ __global__ __launch_bounds__(QW) void q_calc_dir_rows(Q3 P, K16 k, int maxd, int
     }
     __syncthreads();
     const int count = s_count;
-    if (count)                                        // block-uniform
+    const int nt13 = (uint16_t)((nt << k.shift) * 13), nt19 = (uint16_t)((nt << k.shift) * 19);
+    const int maxdt = pl == 0 ? maxd : (maxd >> 1);
+    const int len = 2 * maxdt + 1;
+    const uint64_t lenmask = (1ull << len) - 1ull;
+    const bool edge = y0 <= 1 || y0 + R - 1 >= height - 2;
+    if (R >= 4 && !edge && count >= dense_min)         // block-uniform
     {
-        const int nt13 = (uint16_t)((nt << k.shift) * 13), nt19 = (uint16_t)((nt << k.shift) * 19);
-        const int maxdt = pl == 0 ? maxd : (maxd >> 1);
-        const int len = 2 * maxdt + 1;
-        const uint64_t lenmask = (1ull << len) - 1ull;
-        const bool edge = y0 <= 1 || y0 + R - 1 >= height - 2;
+        constexpr int RD = R >= 4 ? R : 1;
+        const int lx = tid, px = x0 + lx, b = lx + QHALO - 1;
+        const int startu = max(-px + 1, -maxdt), stopu = min(width - 2 - px, maxdt);
+        uint64_t range = 0;
+        if (stopu >= startu)
+        {
+            const int nb = stopu - startu + 1;
+            range = (nb >= 64 ? ~0ull : ((1ull << nb) - 1ull)) << (startu + maxdt);
+        }
+        uint64_t win[RD + 2];
+#pragma unroll
+        for (int m = 0; m < RD + 2; m++) win[m] = calc_dir_window16(s_pk[m], b - maxdt, lenmask);
+        uint32_t up[RD], dn[RD], act = 0, inactive = 0;
+#pragma unroll
+        for (int j = 0; j < RD; j++)
+        {
+            const uint16_t *m = &s_band[NS + j + 1][tid + QHALO];
+            const bool a = px >= 1 && px < width - 1 && m[0] == peak && (m[-1] == peak || m[1] == peak);      // :392-393
+            const uint64_t pass = a ? range & win[j] & (__brevll(win[j + 2]) >> (64 - len)) : 0ull;
+            const uint64_t npass = ~pass;
+            up[j] = (uint32_t)(npass >> maxdt);
+            dn[j] = __brev((uint32_t)npass << (31 - maxdt));
+            act |= (uint32_t)a << j;
+            inactive |= (up[j] | dn[j]) & ((2u << maxdt) - 1u);
+        }
+        if (__any(act != 0))                                           // wave-uniform
+        {
+            uint32_t ka[RD], kb[RD], kc[RD], kd[RD], ke[RD];
+            const uint2 *tr = &s_tri[0][b];
+            if (__all(inactive == 0)) calc_dir_dense16<RD, false>(tr, maxdt, up, dn, nt13, nt19, ka, kb, kc, kd, ke);
+            else                      calc_dir_dense16<RD, true>(tr, maxdt, up, dn, nt13, nt19, ka, kb, kc, kd, ke);
+#pragma unroll
+            for (int j = 0; j < RD; j++)
+                if ((act >> j) & 1u)
+                    s_out[j][lx] = (uint16_t)calc_dir_vote16((int)((ka[j] & 511u) / 6u), (int)((kb[j] & 511u) >> 2), (int)((kc[j] & 511u) / 6u),
+                                                             (int)((kd[j] & 511u) >> 2), (int)((ke[j] & 511u) >> 2), s_lim, k.neutral, k.shift);
+        }
+        __syncthreads();
+    }
+    else if (count)                                   // block-uniform
+    {
         for (int p = tid; p < count; p += QW)
         {
             const uint32_t id = s_list[p];
@@ -953,102 +1118,131 @@ __global__ __launch_bounds__(256) void q_mark_2x(Q3 P, K16 k)
 // same (u, v, back, forward, verdict) as its neighbours in the gap, so each thread writes its own sample only.
 constexpr int QF_W = 1024, QF_HALO = 64, QF_LW = QF_W + 2 * QF_HALO;
 
+// QF_R rebuilt rows (and the copied rows between them) per workgroup, as k_fill_gaps_b in eedi2.hip: 2 QF_R + 5 staged rows
+// serve QF_R rebuilt rows, the rows' own bitmaps are made once, a quarter of the waves.
+constexpr int QF_R = 4, QF_ND = QF_R + 2, QF_NM = QF_R + 3, QF_WORDS = QF_LW / 64 + 1;
 __global__ __launch_bounds__(256) void q_fill_gaps_b(Q3 P, K16 k)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t s_r[7][QF_LW];
-    __shared__ __attribute__((aligned(16))) uint16_t s_out[QF_W];
-    __shared__ uint16_t s_list[QF_W];
+    __shared__ __attribute__((aligned(16))) uint16_t s_d[QF_ND][QF_LW];     // direction rows yb - 2, yb, .. , yb + 2 QF_R
+    __shared__ __attribute__((aligned(16))) uint16_t s_m[QF_NM][QF_LW];     // mask rows yb - 3, yb - 1, .. , yb + 2 QF_R + 1
+    __shared__ __attribute__((aligned(16))) uint16_t s_out[QF_R][QF_W];
+    __shared__ uint16_t s_list[QF_R * QF_W];
     __shared__ int s_count;
-    __shared__ uint64_t s_stop[QF_LW / 64 + 1], s_np[QF_LW / 64 + 1], s_bt[QF_LW / 64 + 1], s_bb[QF_LW / 64 + 1];   // one bit per staged column
+    __shared__ uint64_t s_stop[QF_R][QF_WORDS], s_np[QF_R][QF_WORDS], s_bt[QF_R][QF_WORDS], s_bb[QF_R][QF_WORDS];   // one bit per staged column
     FIELD16(P);
-    const int y = blockIdx.y, y0 = 2 - tff;
+    const int y0 = 2 - tff;
     const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
     const int x0 = blockIdx.x * QF_W, tid = threadIdx.x;
-    if (y >= height || x0 >= width) return;
+    const int ya = (int)blockIdx.y * 2 * QF_R;                     // the workgroup's plane rows: ya .. ya + 2 QF_R - 1
+    if (ya >= height || x0 >= width) return;
+    const int yb = ya + (y0 & 1);                                  // its rows of the rebuilt parity: yb, yb + 2, ..
     const int peak = k.peak;
-    const uint16_t *dcg = Q.b + (size_t)y * pitch;
-    uint16_t *og = Q.c + (size_t)y * pitch;
     const int x = x0 + 4 * tid;
-    auto store4 = [&](uint2 v) {
-        if (x + 3 < width) *reinterpret_cast<uint2 *>(og + x) = v;
-        else
-        {
-            const uint16_t o4[4] = { (uint16_t)(v.x & 0xffffu), (uint16_t)(v.x >> 16), (uint16_t)(v.y & 0xffffu), (uint16_t)(v.y >> 16) };
-            for (int j = 0; j < 4 && x + j < width; j++) og[x + j] = o4[j];
-        }
-    };
-    if (!(y >= y0 && y < height - 1 && ((y - y0) & 1) == 0))
+    auto rebuilt = [&](int y) { return y >= y0 && y < height - 1; };
+    // the rows that are only copied (the reference's bit_blit)
+    uint2 vcopy[2 * QF_R];
+#pragma unroll
+    for (int i = 0; i < 2 * QF_R; i++)
     {
-        if (x < width) store4(*reinterpret_cast<const uint2 *>(dcg + x));
-        return;
+        const int y = ya + i;
+        vcopy[i] = make_uint2(0u, 0u);
+        if (x < width && y < height && !((((y - y0) & 1) == 0) && rebuilt(y)))
+            vcopy[i] = *reinterpret_cast<const uint2 *>(Q.b + (size_t)y * pitch + x);
     }
     if (tid == 0) s_count = 0;
-    const uint16_t *g[7] = { dcg, Q.a + (ptrdiff_t)(y - 1) * pitch, Q.a + (ptrdiff_t)(y + 1) * pitch,
-                             dcg - 2 * (ptrdiff_t)pitch, dcg + 2 * (ptrdiff_t)pitch,
-                             Q.a + (ptrdiff_t)(y - 3) * pitch, Q.a + (ptrdiff_t)(y + 3) * pitch };
     const int lo = x0 - QF_HALO;                                   // column of staged sample 0 (a multiple of 4)
     const int nq = (min(QF_W, (width - x0 + 3) & ~3) + 2 * QF_HALO) / 4;       // groups of four samples, <= 288
     {
-        // all loads of a thread in flight before the first LDS store
-        uint2 v[7][2];
+        // all loads of a thread in flight before its first LDS store; rows outside the plane are rows no pixel's tests
+        // reach (:1076, :1090): they are read from the nearest row inside
+        const bool h0 = tid < nq, h1 = tid + 256 < nq;
+        uint2 vd[QF_ND][2], vm[QF_NM][2];
 #pragma unroll
-        for (int r = 0; r < 7; r++)
+        for (int r = 0; r < QF_ND; r++)
+        {
+            const uint2 *row = reinterpret_cast<const uint2 *>(Q.b + (size_t)min(max(yb - 2 + 2 * r, 0), height - 1) * pitch + lo);
+            vd[r][0] = h0 ? row[tid] : make_uint2(0u, 0u);
+            vd[r][1] = h1 ? row[tid + 256] : make_uint2(0u, 0u);
+        }
 #pragma unroll
-            for (int q = 0; q < 2; q++)
-            {
-                const int i = tid + 256 * q;
-                v[r][q] = i < nq ? reinterpret_cast<const uint2 *>(g[r] + lo)[i] : make_uint2(0u, 0u);
-            }
+        for (int r = 0; r < QF_NM; r++)
+        {
+            const uint2 *row = reinterpret_cast<const uint2 *>(Q.a + (size_t)min(max(yb - 3 + 2 * r, 0), height - 1) * pitch + lo);
+            vm[r][0] = h0 ? row[tid] : make_uint2(0u, 0u);
+            vm[r][1] = h1 ? row[tid + 256] : make_uint2(0u, 0u);
+        }
+        if (h0)
+        {
 #pragma unroll
-        for (int r = 0; r < 7; r++)
+            for (int r = 0; r < QF_ND; r++) reinterpret_cast<uint2 *>(s_d[r])[tid] = vd[r][0];
 #pragma unroll
-            for (int q = 0; q < 2; q++)
-            {
-                const int i = tid + 256 * q;
-                if (i < nq) reinterpret_cast<uint2 *>(s_r[r])[i] = v[r][q];
-            }
+            for (int r = 0; r < QF_NM; r++) reinterpret_cast<uint2 *>(s_m[r])[tid] = vm[r][0];
+        }
+        if (h1)
+        {
+#pragma unroll
+            for (int r = 0; r < QF_ND; r++) reinterpret_cast<uint2 *>(s_d[r])[tid + 256] = vd[r][1];
+#pragma unroll
+            for (int r = 0; r < QF_NM; r++) reinterpret_cast<uint2 *>(s_m[r])[tid + 256] = vm[r][1];
+        }
     }
     __syncthreads();
-    enum { DC = 0, MC = 1, MN = 2, DP = 3, DN = 4, MP = 5, MNN = 6 };
+    // rebuilt row r = yb + 2r: direction rows s_d[r] (y - 2), s_d[r + 1] (y), s_d[r + 2] (y + 2); mask rows s_m[r] (y - 3),
+    // s_m[r + 1] (y - 1), s_m[r + 2] (y + 1), s_m[r + 3] (y + 3)
     const unsigned staged = 4u * (unsigned)nq;
     for (int q = 0; q < (QF_LW + 255) / 256; q++)
     {
-        const unsigned col = tid + 256 * q;
-        bool np = false, stop = false, bt = false, bb = false;
-        if (col < staged)
-        {
-            const bool mc = s_r[MC][col] == peak, mn = s_r[MN][col] == peak;
-            np = s_r[DC][col] != peak;
-            stop = np || (!mc && !mn);
-            bt = s_r[DP][col] == peak || (s_r[MP][col] != peak && !mc);
-            bb = s_r[DN][col] == peak || (!mn && s_r[MNN][col] != peak);
-        }
-        const uint64_t w0 = __ballot(stop), w1 = __ballot(np), w2 = __ballot(bt), w3 = __ballot(bb);
-        if ((tid & 63) == 0 && (col >> 6) < QF_LW / 64 + 1) { s_stop[col >> 6] = w0; s_np[col >> 6] = w1; s_bt[col >> 6] = w2; s_bb[col >> 6] = w3; }
-    }
-    if (x < width)
-    {
-        const int c = 4 * tid + QF_HALO;
-        const uint2 cw = *reinterpret_cast<const uint2 *>(&s_r[DC][c]);
-        *reinterpret_cast<uint2 *>(&s_out[4 * tid]) = cw;
+        const unsigned col = tid + 256 * q, cc = min(col, staged - 1u);
+        const bool in = col < staged;
+        uint64_t nd[QF_ND], pm[QF_NM];
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int r = 0; r < QF_ND; r++) nd[r] = __ballot(in & (s_d[r][cc] != peak));       // direction known
+#pragma unroll
+        for (int r = 0; r < QF_NM; r++) pm[r] = __ballot(in & (s_m[r][cc] == peak));       // on the mask
+        const uint64_t inw = __ballot(in);
+        if ((tid & 63) == 0 && (col >> 6) < (unsigned)QF_WORDS)
         {
-            const int xx = x + j;
-            if (xx >= 1 && xx < width - 1 && s_r[DC][c + j] == peak && (s_r[MC][c + j] == peak || s_r[MN][c + j] == peak))
-                s_list[atomicAdd(&s_count, 1)] = (uint16_t)(4 * tid + j);
+#pragma unroll
+            for (int r = 0; r < QF_R; r++)
+            {
+                const uint64_t mc = pm[r + 1], mn = pm[r + 2];
+                s_np[r][col >> 6] = nd[r + 1];
+                s_stop[r][col >> 6] = nd[r + 1] | (inw & ~mc & ~mn);
+                s_bt[r][col >> 6] = inw & (~nd[r] | (~pm[r] & ~mc));
+                s_bb[r][col >> 6] = inw & (~nd[r + 2] | (~mn & ~pm[r + 3]));
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < QF_R; r++)
+    {
+        const int y = yb + 2 * r;
+        if (x < width && y < height && rebuilt(y))
+        {
+            const int c = 4 * tid + QF_HALO;
+            *reinterpret_cast<uint2 *>(&s_out[r][4 * tid]) = *reinterpret_cast<const uint2 *>(&s_d[r + 1][c]);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+            {
+                const int xx = x + j;
+                if (xx >= 1 && xx < width - 1 && s_d[r + 1][c + j] == peak && (s_m[r + 1][c + j] == peak || s_m[r + 2][c + j] == peak))
+                    s_list[atomicAdd(&s_count, 1)] = (uint16_t)((r << 12) | (4 * tid + j));
+            }
         }
     }
     __syncthreads();
     const int count = s_count;
     const int eight = 8 << k.shift, twenty = 20 << k.shift, five_hundred = 500 << k.shift;
-    auto rd = [&](int r, int col) -> int {
-        const unsigned kk = (unsigned)(col - lo);
-        return kk < staged ? (int)s_r[r][kk] : (int)g[r][col];
-    };
     for (int i = tid; i < count; i += 256)
     {
-        const int lx = s_list[i], px = x0 + lx;
+        const int e = s_list[i], r = e >> 12, lx = e & 0xfff, px = x0 + lx, y = yb + 2 * r;
+        const uint16_t *DC = s_d[r + 1], *DP = s_d[r], *DN = s_d[r + 2];
+        const uint16_t *MC = s_m[r + 1], *MN = s_m[r + 2], *MP = s_m[r], *MNN = s_m[r + 3];
+        const uint16_t *gd = Q.b + (size_t)y * pitch, *gma = Q.a + (ptrdiff_t)(y - 1) * pitch;
+        auto rd = [&](const uint16_t *srow, const uint16_t *grow, int col) -> int {
+            const unsigned kk = (unsigned)(col - lo);
+            return kk < staged ? (int)srow[kk] : (int)grow[col];
+        };
         int u = px - 1, back = five_hundred, forward = -five_hundred;
         int v = px + 1;
         int tc = 1, bc = 1, mint = five_hundred, maxt = -twenty, minb = five_hundred, maxb = -twenty;
@@ -1058,14 +1252,14 @@ __global__ __launch_bounds__(256) void q_fill_gaps_b(Q3 P, K16 k)
         int ul = -1, vl = -1;
         for (int wi = (c - 1) >> 6; wi >= (first >> 6) && c - 1 >= first; wi--)      // highest stop bit in [first, c - 1]
         {
-            uint64_t w = s_stop[wi];
+            uint64_t w = s_stop[r][wi];
             if (wi == ((c - 1) >> 6) && ((c - 1) & 63) != 63) w &= (2ull << ((c - 1) & 63)) - 1ull;
             if (wi == (first >> 6)) w &= ~0ull << (first & 63);
             if (w) { ul = 64 * wi + 63 - __clzll((long long)w); break; }
         }
         for (int wi = (c + 1) >> 6; wi <= ((last - 1) >> 6) && c + 1 < last; wi++)   // lowest stop bit in [c + 1, last - 1]
         {
-            uint64_t w = s_stop[wi];
+            uint64_t w = s_stop[r][wi];
             if (wi == ((c + 1) >> 6)) w &= ~0ull << ((c + 1) & 63);
             if (wi == ((last - 1) >> 6) && ((last - 1) & 63) != 63) w &= (2ull << ((last - 1) & 63)) - 1ull;
             if (w) { vl = 64 * wi + __ffsll((long long)w) - 1; break; }
@@ -1074,11 +1268,10 @@ __global__ __launch_bounds__(256) void q_fill_gaps_b(Q3 P, K16 k)
         const bool fast = (ul >= 0 || lo <= 1) && (vl >= 0 || lo + (int)staged > width);     // column `width` itself must be staged too
         if (fast)
         {
-            if (ul >= 0) { u = lo + ul; if ((s_np[ul >> 6] >> (ul & 63)) & 1ull) back = s_r[DC][ul]; }
+            if (ul >= 0) { u = lo + ul; if ((s_np[r][ul >> 6] >> (ul & 63)) & 1ull) back = DC[ul]; }
             else u = 0;
-            if (vl >= 0) { v = lo + vl; if ((s_np[vl >> 6] >> (vl & 63)) & 1ull) forward = s_r[DC][vl]; }
+            if (vl >= 0) { v = lo + vl; if ((s_np[r][vl >> 6] >> (vl & 63)) & 1ull) forward = DC[vl]; }
             else v = width;
-            // columns u .. v (v = width included, as the reference's loop includes it) are staged
             const int a0 = u - lo, a1 = v - lo;
             auto any_in = [&](const uint64_t *bits) {
                 for (int wi = a0 >> 6; wi <= (a1 >> 6); wi++)
@@ -1090,39 +1283,42 @@ __global__ __launch_bounds__(256) void q_fill_gaps_b(Q3 P, K16 k)
                 }
                 return false;
             };
-            if (y <= 2 || any_in(s_bt)) { tc = 0; mint = maxt = twenty; }
-            else for (int j = a0; j <= a1; j++) { const int t = s_r[DP][j]; mint = min(mint, t); maxt = max(maxt, t); }
-            if (y >= height - 3 || any_in(s_bb)) { bc = 0; minb = maxb = twenty; }
-            else for (int j = a0; j <= a1; j++) { const int t = s_r[DN][j]; minb = min(minb, t); maxb = max(maxb, t); }
+            if (y <= 2 || any_in(s_bt[r])) { tc = 0; mint = maxt = twenty; }
+            else for (int j = a0; j <= a1; j++) { const int t = DP[j]; mint = min(mint, t); maxt = max(maxt, t); }
+            if (y >= height - 3 || any_in(s_bb[r])) { bc = 0; minb = maxb = twenty; }
+            else for (int j = a0; j <= a1; j++) { const int t = DN[j]; minb = min(minb, t); maxb = max(maxb, t); }
         }
         else
         {
+            const uint16_t *gmn = gma + 2 * (ptrdiff_t)pitch;
             while (u)
             {
-                const int d = rd(DC, u);
+                const int d = rd(DC, gd, u);
                 if (d != peak) { back = d; break; }
-                if (rd(MC, u) != peak && rd(MN, u) != peak) break;
+                if (rd(MC, gma, u) != peak && rd(MN, gmn, u) != peak) break;
                 u--;
             }
             while (v < width)
             {
-                const int d = rd(DC, v);
+                const int d = rd(DC, gd, v);
                 if (d != peak) { forward = d; break; }
-                if (rd(MC, v) != peak && rd(MN, v) != peak) break;
+                if (rd(MC, gma, v) != peak && rd(MN, gmn, v) != peak) break;
                 v++;
             }
+            const uint16_t *gdp = gd - 2 * (ptrdiff_t)pitch, *gdn = gd + 2 * (ptrdiff_t)pitch;
+            const uint16_t *gmp = gma - 2 * (ptrdiff_t)pitch, *gmnn = gmn + 2 * (ptrdiff_t)pitch;
             for (int j = u; j <= v; j++)
             {
                 if (tc)
                 {
                     int t;
-                    if (y <= 2 || (t = rd(DP, j)) == peak || (rd(MP, j) != peak && rd(MC, j) != peak)) { tc = 0; mint = maxt = twenty; }
+                    if (y <= 2 || (t = rd(DP, gdp, j)) == peak || (rd(MP, gmp, j) != peak && rd(MC, gma, j) != peak)) { tc = 0; mint = maxt = twenty; }
                     else { mint = min(mint, t); maxt = max(maxt, t); }
                 }
                 if (bc)
                 {
                     int t;
-                    if (y >= height - 3 || (t = rd(DN, j)) == peak || (rd(MN, j) != peak && rd(MNN, j) != peak)) { bc = 0; minb = maxb = twenty; }
+                    if (y >= height - 3 || (t = rd(DN, gdn, j)) == peak || (rd(MN, gmn, j) != peak && rd(MNN, gmnn, j) != peak)) { bc = 0; minb = maxb = twenty; }
                     else { minb = min(minb, t); maxb = max(maxb, t); }
                 }
             }
@@ -1136,11 +1332,28 @@ __global__ __launch_bounds__(256) void q_fill_gaps_b(Q3 P, K16 k)
         {
             const double step = (double)(forward - back) / (double)(v - u);
             const int j = px - u - 1;
-            s_out[lx] = (uint16_t)(back + (int)(j * step + 0.5));
+            s_out[r][lx] = (uint16_t)(back + (int)(j * step + 0.5));
         }
     }
     __syncthreads();
-    if (x < width) store4(*reinterpret_cast<const uint2 *>(&s_out[4 * tid]));
+    if (x < width)
+    {
+#pragma unroll
+        for (int i = 0; i < 2 * QF_R; i++)
+        {
+            const int y = ya + i;
+            if (y >= height) break;
+            const bool work = (((y - y0) & 1) == 0) && rebuilt(y);
+            const uint2 v = work ? *reinterpret_cast<const uint2 *>(&s_out[(i - (y0 & 1)) >> 1][4 * tid]) : vcopy[i];
+            uint16_t *o = Q.c + (size_t)y * pitch + x;
+            if (x + 3 < width) *reinterpret_cast<uint2 *>(o) = v;
+            else
+            {
+                const uint16_t o4[4] = { (uint16_t)(v.x & 0xffffu), (uint16_t)(v.x >> 16), (uint16_t)(v.y & 0xffffu), (uint16_t)(v.y >> 16) };
+                for (int j = 0; j < 4 && x + j < width; j++) o[j] = o4[j];
+            }
+        }
+    }
 }
 
 // plain copy of the visible width (eedi2_bit_blit :46-68): a = in, c = out; eight samples per thread
@@ -1813,8 +2026,7 @@ int Eedi2Engine16::enqueue(int n, hbhip_ctx *lc)
     P.fstride = slot_bytes_ / 2;
     P.tffbits = tffbits_;
 
-    // field extraction (decomb_template.c:455-473) + the five mask passes (:390-397): one kernel.  The tiles no earlier
-    // field can influence go out for all fields at once, the rest field after field (see q_mask_fused)
+    // field extraction (decomb_template.c:455-473) + the five mask passes (:390-397): one kernel, one launch
     geom(P, srcp);
     {
         MaskSrc16 S;
@@ -1830,21 +2042,22 @@ int Eedi2Engine16::enqueue(int n, hbhip_ctx *lc)
                          par_.erosion_threshold, par_.dilation_threshold);
         else
         {
-            const unsigned gy_up = std::max(1, (srcp.height[0] / 2 - QM_OY) / QM_H);
-            HBHIP_LAUNCH(lc, "eedi2_16_mask_upper", q_mask_fused, dim3(gx, gy_up, gz), dim3(QM_T), 0, P, S, k, 0, 1, mth, vth, lth,
-                         par_.erosion_threshold, par_.dilation_threshold);
+            // one launch, field-major: a field's chain tiles, then its upper tiles (see Eedi2Engine::enqueue_mask)
             MaskChain C = eedi_mask_chain_tiles(srcp, QM_W, QM_H, QM_OY);
             C.flags = chain_flags_;
             C.epoch = ++chain_epoch_;
-            HBHIP_LAUNCH(lc, "eedi2_16_mask_passes", q_mask_chain, dim3((unsigned)(C.ntiles * n)), dim3(QM_T), 0, P, S, k, C, mth, vth, lth,
+            C.group = C.ntiles + C.nupper;
+            HBHIP_LAUNCH(lc, "eedi2_16_mask_passes", q_mask_chain, dim3((unsigned)(C.group * n)), dim3(QM_T), 0, P, S, k, C, mth, vth, lth,
                          par_.erosion_threshold, par_.dilation_threshold);
         }
     }
     // half-height passes (decomb_template.c:398-404), all fields per launch from here on
     bind(P.a, mskp); bind(P.b, srcp); bind(P.c, tmpp);
     if (par_.maximum_search_distance <= QHALO - 2)
-        HBHIP_LAUNCH(lc, "eedi2_16_calc_directions", q_calc_dir_rows<2>, dim3((srcp.stride[0] / 2 + QW - 1) / QW, (srcp.height[0] + 1) / 2, gz),
-                     dim3(QW), 0, P, k, par_.maximum_search_distance, par_.noise_threshold);
+        // 256 columns x 4 rows per block, the mostly listed blocks in the dense form (eedi2.hip: Eedi2Engine::enqueue_passes);
+        // its keys hold sums of 12-bit samples at most
+        HBHIP_LAUNCH(lc, "eedi2_16_calc_directions", q_calc_dir_rows<4>, dim3((srcp.stride[0] / 2 + QW - 1) / QW, (srcp.height[0] + 3) / 4, gz),
+                     dim3(QW), 0, P, k, par_.maximum_search_distance, par_.noise_threshold, k.peak < (1 << 12) ? QW * 4 / 2 : 1 << 30);
     else
         HBHIP_LAUNCH(lc, "eedi2_16_calc_directions", q_calc_dir, grid(srcp, true, gz), blk, 0, P, k, par_.maximum_search_distance, par_.noise_threshold);
     bind(P.a, mskp); bind(P.b, tmpp); bind(P.c, dstp);
@@ -1873,7 +2086,7 @@ int Eedi2Engine16::enqueue(int n, hbhip_ctx *lc)
     {
         const EediFrame &in = pass ? dst2mp : tmp2p, &out = pass ? tmp2p : dst2mp;
         bind(P.a, msk2p); bind(P.b, in); bind(P.c, out);
-        HBHIP_LAUNCH(lc, "eedi2_16_fill_gaps_2x", q_fill_gaps_b, dim3((dst2p.width[0] + QF_W - 1) / QF_W, dst2p.height[0], gz), dim3(256), 0, P, k);
+        HBHIP_LAUNCH(lc, "eedi2_16_fill_gaps_2x", q_fill_gaps_b, dim3((dst2p.width[0] + QF_W - 1) / QF_W, (dst2p.height[0] + 2 * QF_R - 1) / (2 * QF_R), gz), dim3(256), 0, P, k);
     }
     bind(P.a, tmp2p); bind(P.b, dst2p); bind(P.c, tmp2p2);
     {

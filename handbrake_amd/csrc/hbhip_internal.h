@@ -210,7 +210,8 @@ private:
     int pad_rows_ = 0;
     std::vector<DevPicture *> all_;
     std::vector<DevPicture *> free_;
-    size_t max_pictures_ = 192;           // growth bound of the cross-stream case (acquire)
+    size_t max_pictures_ = 96;            // growth bound of the cross-stream case (acquire): three batches of 32 - a chain split over
+                                          // two streams is there after its warm-up; every new picture is a hipMalloc and a memset
 };
 
 // Give a picture back to the pool it came from.  Filters release their INPUT pictures through this,

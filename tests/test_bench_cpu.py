@@ -41,7 +41,7 @@ def test_counter_table_and_instruction_mixes_cover_the_dominant_kernels():
         t, v = bench.pmc_record(name, 16.0 if name != "nlmeans_plane_n7" else 32.0)
         assert t and t > 1e6 and v and v > 1e6, name
         r = bench.valu_roofline(v, 500e-6, name)
-        assert 300.0 < r["peak_ginst_s"] < 1100.0 and "profiles/r3_" in r["peak_source"], name
+        assert 300.0 < r["peak_ginst_s"] < 1100.0 and "profiles/r" in r["peak_source"], name
     # a launch of half the fields moves half the bytes (the record scales with the launch shape)
     t16, _ = bench.pmc_record("eedi2_calc_directions", 16.0)
     t8, _ = bench.pmc_record("eedi2_calc_directions", 8.0)

@@ -163,6 +163,35 @@ def test_16bit_every_scratch_buffer(built, depth, w, h, postproc):
         ctx.close()
 
 
+@pytest.mark.parametrize("depth,model,w,h,n", [(10, "random", 640, 360, 3), (12, "random", 322, 184, 3), (10, "interlaced", 640, 360, 6),
+                                               (12, "corners", 1024, 576, 4)])
+def test_16bit_dense_masks_every_scratch_buffer(built, depth, model, w, h, n):
+    """test_dense_masks_every_scratch_buffer at 10 / 12 bits: the dense form of the 16-bit calc_directions search
+    (calc_dir_dense16) and the fill_gaps row groups on masks whose lower half has filled up."""
+    frames = synth.stream(model, w, h, n, depth=depth)
+    ctx = hip.Ctx(0)
+    dev = hip.DecombDevice(ctx, w, h, mode=24, depth=depth)
+    oe = ol.OrcEedi2_16(w, h, depth)
+    try:
+        dev.push(frames[0])
+        for t in range(1, n):
+            dev.push(frames[t])
+            for tff in (1, 0):
+                oe.run(frames[t - 1], tff)
+            while dev.pull() is not None:
+                pass
+            for b in range(9):
+                for c in range(3):
+                    np.testing.assert_array_equal(dev.eedi_plane(b, c), oe.plane(b, c),
+                                                  err_msg=f"{ol.EEDI2_BUFFERS[b]} plane {c} after frame {t - 1}")
+        msk = oe.plane(ol.EEDI2_BUFFERS.index("mskp"), 0)
+        assert (msk[msk.shape[0] // 2:] == (1 << depth) - 1).mean() > 0.8
+    finally:
+        oe.close()
+        dev.close()
+        ctx.close()
+
+
 @pytest.mark.parametrize("name", ["decomb_eedi2_bob_10bit_128x64", "decomb_eedi2_cubic_12bit_190x96"])
 def test_16bit_decomb_eedi2_golden(built, name):
     """The reference-generated 10 / 12-bit vectors through the hb_filter_object_t surface."""

@@ -2,7 +2,15 @@
 """A host-side model of k_calc_dir_rows' search schedule (no GPU): how many of the +-maxd steps each listed pixel of a
 field takes, and what a wave pays for them under different ways of dealing the pixels of a workgroup to lanes.
 
-usage: calc_dir_model.py [width height]      (the synthetic interlaced stream of SURVEY 8d, luma plane of one field)
+usage: calc_dir_model.py [width height [frames]]   (the synthetic interlaced stream of SURVEY 8d, luma plane of one field,
+                                                    after `frames` frames = 2 x frames fields; default 7)
+
+The number of fields matters: build_edge_mask clears only the upper half of the mask (eedi2_template.c:132), the lower
+half accumulates from field to field.  Round 3 ran this model after THREE fields (43 % of the plane listed, 12.5 steps
+per listed pixel) and could not explain the counters of the bench, which runs in the steady state: 65 % listed, 39 of
+49 steps each - the lower half saturated (tools/cd_stats.py has the kernel's own counters).  In that state the
+schedules below hardly differ (lane efficiency 0.94 in column order): what pays is not a better order but sharing the
+SADs of a step between rows and between u and -u (calc_dir_dense).
 
 The kernel lists the pixels of a 256-column x R-row workgroup that pass the edge test (eedi2_template.c:392-393) in
 column order and gives each a lane; a lane walks the set bits of its step set (the steps with a mask peak above at +u
@@ -78,11 +86,16 @@ def main():
     import oracle_lib as ol
     from handbrake_amd import synth
     w, h = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1920, 1080)
-    frames = synth.stream("interlaced", w, h, 2, cfg=3)
+    nfr = int(sys.argv[3]) if len(sys.argv) > 3 else 7
+    frames = synth.stream("interlaced", w, h, nfr, cfg=3)
     oe = ol.OrcEedi2(w, h)
-    oe.run(frames[0], 1); oe.run(frames[0], 0); oe.run(frames[1], 1)
+    for t in range(nfr):
+        for tff in (1, 0):
+            oe.run(frames[t], tff)
     msk = oe.plane(ol.EEDI2_BUFFERS.index("mskp"), 0).copy()
     oe.close()
+    half = msk.shape[0] // 2
+    print(f"after {2 * nfr} fields: mask density upper half {np.mean(msk[:half] == 255):.3f}, lower half {np.mean(msk[half:] == 255):.3f}")
     px = step_counts(msk)
     n = px[:, 2]
     print(f"luma field {msk.shape[1]}x{msk.shape[0]}: mask density {np.mean(msk == 255):.3f}, listed pixels {n.size} "

@@ -27,11 +27,12 @@ timeout 200 python bench.py --workload decomb_eedi2 --depth 10 --no-cpu-baseline
 timeout 200 python bench.py --workload chain --depth 10 --no-cpu-baseline --no-pcie > $OUT/bench_chain_10bit.json 2> $OUT/bench_chain_10bit.err
 timeout 200 python bench.py --workload nlmeans --depth 10 --no-cpu-baseline --no-pcie > $OUT/bench_nlmeans_10bit.json 2> $OUT/bench_nlmeans_10bit.err
 timeout 200 python bench.py --workload chain --stage-streams 1 --no-cpu-baseline --no-pcie --no-kernel-timer > $OUT/bench_chain_stage_streams.json 2>> $OUT/bench_default.err
+timeout 200 python bench.py --workload chain --stage-streams 0 --no-cpu-baseline --no-pcie --no-kernel-timer > $OUT/bench_chain_one_stream.json 2>> $OUT/bench_default.err
 timeout 200 python bench.py --workload chain --streams 2 --no-cpu-baseline --no-pcie --no-kernel-timer > $OUT/bench_chain_2streams.json 2>> $OUT/bench_default.err
 timeout 200 python bench.py --workload chain --comb-detect --no-cpu-baseline --no-pcie --no-kernel-timer > $OUT/bench_chain_combdetect.json 2>> $OUT/bench_default.err
 timeout 240 python tools/kernel_rooflines.py > $OUT/kernel_rooflines.json 2> $OUT/kernel_rooflines.err
 cd /tmp
-PROF="python $R/bench.py --workload chain --steps 6 --warmup 2 --no-cpu-baseline --no-pcie --no-kernel-timer"
+PROF="python $R/bench.py --workload chain --stage-streams 0 --steps 6 --warmup 2 --no-cpu-baseline --no-pcie --no-kernel-timer"
 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $PROF > $OUT/kt.log 2>&1
 python $R/tools/trace_gaps.py $(find $OUT/kt -name '*kernel_trace.csv' | head -1) $OUT/trace_gaps.json > /dev/null 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
