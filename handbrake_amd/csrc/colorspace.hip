@@ -110,6 +110,7 @@ __device__ __forceinline__ float to_linear_dev(int cls, float v)
         case 5:  return det_powf(v, 2.8f);
         case 7:  return v < 0.0913f ? fdiv(v, 4.0f) : det_powf(fdiv(v + 0.1115f, 1.1115f), 1.0f / 0.45f);
         case 13: return v <= 0.04045f ? fdiv(v, 12.92f) : det_powf(fdiv(v + 0.055f, 1.055f), 2.4f);
+        case 17: return v <= 0.0f ? 0.0f : fdiv(det_powf(v, 2.6f) * 52.37f, 48.0f);          // SMPTE ST 428-1
         case 16:
         {
             if (v <= 0.0f) return 0.0f;
@@ -142,6 +143,7 @@ __device__ __forceinline__ float to_gamma_dev(int cls, float x)
         case 5:  return det_powf(x, 1.0f / 2.8f);
         case 7:  return x < 0.0228f ? 4.0f * x : 1.1115f * det_powf(x, 0.45f) - 0.1115f;
         case 13: return x <= 0.0031308f ? 12.92f * x : 1.055f * det_powf(x, 1.0f / 2.4f) - 0.055f;
+        case 17: return x <= 0.0f ? 0.0f : det_powf(fdiv(48.0f * x, 52.37f), 1.0f / 2.6f);
         case 16:
         {
             if (x <= 0.0f) return 0.0f;
@@ -438,7 +440,7 @@ void gamut_matrix(double g[3][3], const double in_xy[8], const double out_xy[8])
 // display-referred transfer functions (zimg's set); PQ / HLG only towards linear light
 bool transfer_known(int cls)
 {
-    return cls == 1 || cls == 4 || cls == 5 || cls == 7 || (cls >= 8 && cls <= 11) || cls == 13 || cls == 16 || cls == 18;
+    return cls == 1 || cls == 4 || cls == 5 || cls == 7 || (cls >= 8 && cls <= 11) || cls == 13 || cls == 16 || cls == 17 || cls == 18;
 }
 
 float hable_host(float in)

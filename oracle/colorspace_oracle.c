@@ -220,12 +220,13 @@ float orc_det_logf(float x) { return det_logf(x); }
 static int transfer_known(int cls, int as_output)
 {
     (void)as_output;
-    return cls == 1 || cls == 4 || cls == 5 || cls == 7 || (cls >= 8 && cls <= 11) || cls == 13 || cls == 16 || cls == 18;
+    return cls == 1 || cls == 4 || cls == 5 || cls == 7 || (cls >= 8 && cls <= 11) || cls == 13 || cls == 16 || cls == 17 || cls == 18;
 }
 
 /* 9 / 10: zimg's log100 / log316 pair (gamma.cpp: 1 + log10(x) / 2 above 0.01, resp. 1 + log10(x) / 2.5 above
  * sqrt(10) / 1000, 0 below; inverse 10^(2 (v - 1)) resp. 10^(2.5 (v - 1)), the threshold itself at or below 0).
- * 11: IEC 61966-2-4 (xvYCC), display referred like class 1: the 2.4 power law carried to negative values by its sign. */
+ * 11: IEC 61966-2-4 (xvYCC), display referred like class 1: the 2.4 power law carried to negative values by its sign.
+ * 17: SMPTE ST 428-1 (gamma.cpp: st_428_eotf / inverse): L = v^2.6 * 52.37 / 48, v = (48 L / 52.37)^(1 / 2.6), 0 at or below 0. */
 static inline float to_linear(int cls, float v)
 {
     switch (cls)
@@ -238,6 +239,7 @@ static inline float to_linear(int cls, float v)
         case 5:  return det_powf(v, 2.8f);
         case 7:  return v < 0.0913f ? v / 4.0f : det_powf((v + 0.1115f) / 1.1115f, 1.0f / 0.45f);
         case 13: return v <= 0.04045f ? v / 12.92f : det_powf((v + 0.055f) / 1.055f, 2.4f);
+        case 17: return v <= 0.0f ? 0.0f : (det_powf(v, 2.6f) * 52.37f) / 48.0f;
         case 16:                                                     /* ST 2084 EOTF, 1.0 = 10000 cd/m2 */
         {
             if (v <= 0.0f) return 0.0f;
@@ -270,6 +272,7 @@ static inline float to_gamma(int cls, float x)
         case 5:  return det_powf(x, 1.0f / 2.8f);
         case 7:  return x < 0.0228f ? 4.0f * x : 1.1115f * det_powf(x, 0.45f) - 0.1115f;
         case 13: return x <= 0.0031308f ? 12.92f * x : 1.055f * det_powf(x, 1.0f / 2.4f) - 0.055f;
+        case 17: return x <= 0.0f ? 0.0f : det_powf((48.0f * x) / 52.37f, 1.0f / 2.6f);
         case 16:                                                     /* ST 2084 inverse EOTF */
         {
             if (x <= 0.0f) return 0.0f;

@@ -86,8 +86,8 @@ def test_uncovered_conversions_are_refused(built):
         ol.orc_colorspace_frame(flat(100, 128, 128), ol.colorspace_params(BT709, (1, 3, 1, 1)))      # unknown transfer
 
 
-@pytest.mark.parametrize("via", [(9, 16, 9, 1), (9, 18, 9, 1), (1, 1, 8, 1), (1, 13, 1, 2), (1, 9, 1, 1), (1, 10, 1, 1), (1, 11, 1, 2)],
-                         ids=["pq", "hlg", "ycgco", "srgb_full", "log100", "log316", "xvycc_full"])
+@pytest.mark.parametrize("via", [(9, 16, 9, 1), (9, 18, 9, 1), (1, 1, 8, 1), (1, 13, 1, 2), (1, 9, 1, 1), (1, 10, 1, 1), (1, 11, 1, 2), (1, 17, 1, 1)],
+                         ids=["pq", "hlg", "ycgco", "srgb_full", "log100", "log316", "xvycc_full", "st428"])
 def test_round_trips_through_the_new_outputs(built, via):
     """BT.709 -> X -> BT.709 at 10 bits comes back within a code or two (PQ / HLG as *output* transfers, the YCgCo
     matrix): forward and inverse functions are consistent."""

@@ -31,6 +31,8 @@ SDR_CASES = [
     ((1, 10, 1, 1), "transfer=bt709", BT709, {}),
     (BT709, "transfer=iec61966-2-4:range=pc", (1, 11, 1, 2), {}),
     ((1, 11, 1, 2), "primaries=bt2020:transfer=log316:matrix=bt2020nc:range=tv", (9, 10, 9, 1), {}),
+    (BT709, "transfer=smpte428", (1, 17, 1, 1), {}),                                # SMPTE ST 428-1, either way
+    ((1, 17, 1, 1), "primaries=bt2020:transfer=bt2020-10:matrix=bt2020nc", (9, 14, 9, 1), {}),
 ]
 
 
