@@ -1272,18 +1272,25 @@ __device__ __forceinline__ uint32_t live3(const Win12 &w, uint32_t &centre)   //
 
 // post != 0 (the last expand_dir_map_2x of a field): eedi2_post_process (:1349-1378, k_post) rides along - it is
 // pointwise in the map this pass has just made (e = the map before the post filters, f = dst2p, rebuilt rows only).
+// DC_R thread rows per thread: the pass is two phases around a queue with little arithmetic in the first, and a wave that
+// takes one dword row of it spends more scalar instructions on finding its plane, field and rows than vector ones on the
+// row (91 scalar instructions per wave with one row each; expand_dir_map_2x 73 -> 66 us per launch at two rows, 63 at four).
+#ifndef DC_THREAD_ROWS
+#define DC_THREAD_ROWS 4
+#endif
+constexpr int DC_R = DC_THREAD_ROWS, DC_ROWS = 4 * DC_R;
 __global__ __launch_bounds__(256) void k_dir_map_c(P3 P, int step, int expand, int post)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_out[4][256];
-    __shared__ uint16_t s_list[4 * 256];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[DC_ROWS][256];
+    __shared__ uint16_t s_list[DC_ROWS * 256];
     __shared__ int s_count;
     __shared__ uint8_t s_lim[LIM_PAD];
     FIELD_PLANE(P);
     const int y0 = step == 1 ? 1 : 2 - tff;
     // step 2: a thread row takes the PAIR of rows 2r, 2r + 1 - the one with the rebuilt rows' parity goes through the
     // pass, the other is only copied (k_dir_map4)
-    const int rb = blockIdx.y * 4, r = rb + threadIdx.y;
-    const int bx0 = 4 * (blockIdx.x * 64), x = bx0 + 4 * threadIdx.x, y = step == 1 ? r : 2 * r + (y0 & 1);
+    const int rb = blockIdx.y * DC_ROWS;
+    const int bx0 = 4 * (blockIdx.x * 64), x = bx0 + 4 * threadIdx.x;
     const int yb = step == 1 ? rb : 2 * rb + (y0 & 1);                              // row of thread row 0
     const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
     if (bx0 >= width || (step == 1 ? rb : 2 * rb) >= height) return;                 // whole workgroup outside
@@ -1291,52 +1298,57 @@ __global__ __launch_bounds__(256) void k_dir_map_c(P3 P, int step, int expand, i
     if (tid == 0) s_count = 0;
     lim_fill(s_lim, tid);
     __syncthreads();
-    // the copied row of the pair: fetched now, stored when the workgroup is done (see k_dir_map4)
-    const int yc = 2 * r + 1 - (y0 & 1);
-    const bool copy = step != 1 && x < width && yc < height;
-    uint32_t vcopy = 0;
-    if (copy) vcopy = *reinterpret_cast<const uint32_t *>(Q.b + (size_t)yc * pitch + x);
-    const bool inside = x < width && y < height;
-    const bool row_ok = step == 1 ? (y >= 1 && y < height - 1) : (y >= y0 && y < height - 1);
-    const uint8_t *dc = Q.b + (size_t)y * pitch + x;
-    if (inside)
-    {
-        uint32_t out;
-        if (!row_ok) out = *reinterpret_cast<const uint32_t *>(dc);                   // bit_blit only
-        else
-        {
-            const Win12 wc = ldwin(dc), wu = ldwin(dc - (ptrdiff_t)step * pitch), wd = ldwin(dc + (ptrdiff_t)step * pitch);
-            const uint8_t *mk = Q.a + (size_t)y * pitch + x;
-            const uint32_t m0 = *reinterpret_cast<const uint32_t *>(step == 1 ? mk : mk - (ptrdiff_t)pitch);
-            const uint32_t m1 = step == 1 ? 0u : *reinterpret_cast<const uint32_t *>(mk + pitch);
-            const bool up_ok = step == 1 || y > 1, dn_ok = step == 1 || y < height - 2;
-            uint32_t nc, nu, nd;
-            const uint32_t s3c = live3(wc, nc), s3u = live3(wu, nu), s3d = live3(wd, nd);
-            uint32_t u = expand ? s3c - nc : s3c;                                      // expand leaves the centre out (:671)
-            if (up_ok) u += s3u;
-            if (dn_ok) u += s3d;
-            const uint32_t enough = ((u + (uint32_t)(0x80 - (expand ? 5 : 4)) * 0x01010101u) >> 7) & 0x01010101u;
-            uint32_t cand = ((ff_bytes(m0) | ff_bytes(m1)) >> 7) & mf_bytes_in(x, 1, width - 1);
-            if (expand) cand &= ~nc;                                                   // expand only fills peak pixels
-            out = wc.w1;
-            if (!expand) out |= (cand & ~enough) * 255u;                               // too few neighbours: peak
-            uint32_t sortpx = cand & enough;
-            if (sortpx)
-            {
-                const int n = __popc(sortpx);
-                int at = atomicAdd(&s_count, n);
+    uint32_t vcopy[DC_R];
 #pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if ((sortpx >> (8 * k)) & 1u) s_list[at++] = (uint16_t)((threadIdx.y << 8) | (4 * threadIdx.x + k));
-            }
-            (void)nu; (void)nd;
-        }
-        *reinterpret_cast<uint32_t *>(&s_out[threadIdx.y][4 * threadIdx.x]) = out;
-        if (Q.d)                                                                    // optional copy of the input (the eedi2_bit_blit before post-processing)
+    for (int h = 0; h < DC_R; h++)
+    {
+        const int lr = (int)threadIdx.y + 4 * h, r = rb + lr, y = step == 1 ? r : 2 * r + (y0 & 1);
+        // the copied row of the pair: fetched now, stored when the workgroup is done (see k_dir_map4)
+        const int yc = 2 * r + 1 - (y0 & 1);
+        vcopy[h] = 0;
+        if (step != 1 && x < width && yc < height) vcopy[h] = *reinterpret_cast<const uint32_t *>(Q.b + (size_t)yc * pitch + x);
+        const bool inside = x < width && y < height;
+        const bool row_ok = step == 1 ? (y >= 1 && y < height - 1) : (y >= y0 && y < height - 1);
+        const uint8_t *dc = Q.b + (size_t)y * pitch + x;
+        if (inside)
         {
-            const uint32_t v = *reinterpret_cast<const uint32_t *>(dc);
-            int in[4] = { (int)(v & 0xff), (int)((v >> 8) & 0xff), (int)((v >> 16) & 0xff), (int)(v >> 24) };
-            st4(Q.d + (size_t)y * pitch + x, in, x, width);
+            uint32_t out;
+            if (!row_ok) out = *reinterpret_cast<const uint32_t *>(dc);                   // bit_blit only
+            else
+            {
+                const Win12 wc = ldwin(dc), wu = ldwin(dc - (ptrdiff_t)step * pitch), wd = ldwin(dc + (ptrdiff_t)step * pitch);
+                const uint8_t *mk = Q.a + (size_t)y * pitch + x;
+                const uint32_t m0 = *reinterpret_cast<const uint32_t *>(step == 1 ? mk : mk - (ptrdiff_t)pitch);
+                const uint32_t m1 = step == 1 ? 0u : *reinterpret_cast<const uint32_t *>(mk + pitch);
+                const bool up_ok = step == 1 || y > 1, dn_ok = step == 1 || y < height - 2;
+                uint32_t nc, nu, nd;
+                const uint32_t s3c = live3(wc, nc), s3u = live3(wu, nu), s3d = live3(wd, nd);
+                uint32_t u = expand ? s3c - nc : s3c;                                      // expand leaves the centre out (:671)
+                if (up_ok) u += s3u;
+                if (dn_ok) u += s3d;
+                const uint32_t enough = ((u + (uint32_t)(0x80 - (expand ? 5 : 4)) * 0x01010101u) >> 7) & 0x01010101u;
+                uint32_t cand = ((ff_bytes(m0) | ff_bytes(m1)) >> 7) & mf_bytes_in(x, 1, width - 1);
+                if (expand) cand &= ~nc;                                                   // expand only fills peak pixels
+                out = wc.w1;
+                if (!expand) out |= (cand & ~enough) * 255u;                               // too few neighbours: peak
+                uint32_t sortpx = cand & enough;
+                if (sortpx)
+                {
+                    const int n = __popc(sortpx);
+                    int at = atomicAdd(&s_count, n);
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if ((sortpx >> (8 * k)) & 1u) s_list[at++] = (uint16_t)((lr << 8) | (4 * threadIdx.x + k));
+                }
+                (void)nu; (void)nd;
+            }
+            *reinterpret_cast<uint32_t *>(&s_out[lr][4 * threadIdx.x]) = out;
+            if (Q.d)                                                                    // optional copy of the input (the eedi2_bit_blit before post-processing)
+            {
+                const uint32_t v = *reinterpret_cast<const uint32_t *>(dc);
+                int in[4] = { (int)(v & 0xff), (int)((v >> 8) & 0xff), (int)((v >> 16) & 0xff), (int)(v >> 24) };
+                st4(Q.d + (size_t)y * pitch + x, in, x, width);
+            }
         }
     }
     __syncthreads();
@@ -1351,38 +1363,45 @@ __global__ __launch_bounds__(256) void k_dir_map_c(P3 P, int step, int expand, i
         s_out[ly][lx] = (uint8_t)dir_map_px(up[-1], up[0], up[1], c[-1], c[0], c[1], dn[-1], dn[0], dn[1], up_ok, dn_ok, expand, s_lim);
     }
     __syncthreads();
-    if (inside)
-    {
-        const uint32_t v = *reinterpret_cast<const uint32_t *>(&s_out[threadIdx.y][4 * threadIdx.x]);
-        uint8_t *o = Q.c + (size_t)y * pitch + x;
-        if (x + 3 < width) *reinterpret_cast<uint32_t *>(o) = v;
-        else for (int k = 0; k < 4 && x + k < width; k++) o[k] = (uint8_t)(v >> (8 * k));
-        if (post && row_ok)
-        {
-            const size_t at = (size_t)y * pitch + x;
-            const uint32_t om4 = *reinterpret_cast<const uint32_t *>(Q.e + at);
-            uint8_t *d = Q.f + at;
-            const uint32_t up4 = *reinterpret_cast<const uint32_t *>(d - pitch), dn4 = *reinterpret_cast<const uint32_t *>(d + pitch);
-            const uint32_t cur4 = *reinterpret_cast<const uint32_t *>(d);
-            int out[4];
-            bool any = false;
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-            {
-                const int nm = (v >> (8 * k)) & 0xffu, om = (om4 >> (8 * k)) & 0xffu;
-                const int lim = s_lim[iabs(nm - NEUTRAL) >> 2];
-                const bool fix = iabs(nm - om) > lim && om != PEAK && om != NEUTRAL;
-                out[k] = fix ? (int)((((up4 >> (8 * k)) & 0xffu) + ((dn4 >> (8 * k)) & 0xffu) + 1) >> 1) : (int)((cur4 >> (8 * k)) & 0xffu);
-                any |= fix;
-            }
-            if (any) st4(d, out, x, width);
-        }
-    }
-    if (copy)
+    for (int h = 0; h < DC_R; h++)
     {
-        int in[4] = { (int)(vcopy & 0xff), (int)((vcopy >> 8) & 0xff), (int)((vcopy >> 16) & 0xff), (int)(vcopy >> 24) };
-        st4(Q.c + (size_t)yc * pitch + x, in, x, width);
-        if (Q.d) st4(Q.d + (size_t)yc * pitch + x, in, x, width);
+        const int lr = (int)threadIdx.y + 4 * h, r = rb + lr, y = step == 1 ? r : 2 * r + (y0 & 1);
+        const int yc = 2 * r + 1 - (y0 & 1);
+        const bool row_ok = step == 1 ? (y >= 1 && y < height - 1) : (y >= y0 && y < height - 1);
+        if (x < width && y < height)
+        {
+            const uint32_t v = *reinterpret_cast<const uint32_t *>(&s_out[lr][4 * threadIdx.x]);
+            uint8_t *o = Q.c + (size_t)y * pitch + x;
+            if (x + 3 < width) *reinterpret_cast<uint32_t *>(o) = v;
+            else for (int k = 0; k < 4 && x + k < width; k++) o[k] = (uint8_t)(v >> (8 * k));
+            if (post && row_ok)
+            {
+                const size_t at = (size_t)y * pitch + x;
+                const uint32_t om4 = *reinterpret_cast<const uint32_t *>(Q.e + at);
+                uint8_t *d = Q.f + at;
+                const uint32_t up4 = *reinterpret_cast<const uint32_t *>(d - pitch), dn4 = *reinterpret_cast<const uint32_t *>(d + pitch);
+                const uint32_t cur4 = *reinterpret_cast<const uint32_t *>(d);
+                int out[4];
+                bool any = false;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                {
+                    const int nm = (v >> (8 * k)) & 0xffu, om = (om4 >> (8 * k)) & 0xffu;
+                    const int lim = s_lim[iabs(nm - NEUTRAL) >> 2];
+                    const bool fix = iabs(nm - om) > lim && om != PEAK && om != NEUTRAL;
+                    out[k] = fix ? (int)((((up4 >> (8 * k)) & 0xffu) + ((dn4 >> (8 * k)) & 0xffu) + 1) >> 1) : (int)((cur4 >> (8 * k)) & 0xffu);
+                    any |= fix;
+                }
+                if (any) st4(d, out, x, width);
+            }
+        }
+        if (step != 1 && x < width && yc < height)
+        {
+            int in[4] = { (int)(vcopy[h] & 0xff), (int)((vcopy[h] >> 8) & 0xff), (int)((vcopy[h] >> 16) & 0xff), (int)(vcopy[h] >> 24) };
+            st4(Q.c + (size_t)yc * pitch + x, in, x, width);
+            if (Q.d) st4(Q.d + (size_t)yc * pitch + x, in, x, width);
+        }
     }
 }
 
@@ -2559,9 +2578,13 @@ int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc)
         // the queueing form pays where few pixels reach the sort (expand: only peak pixels with >= 5 usable neighbours);
         // filter_dir_map sorts at most masked pixels, there the in-place form is ahead
         // step 2: a thread row per PAIR of rows (the rebuilt one and the copied one)
-        const dim3 g = step == 1 ? grid4_for(f, false) : dim3((f.width[0] + 255) / 256, ((f.height[0] + 1) / 2 + 3) / 4, gz);
-        if (!expand) HBHIP_LAUNCH(lc, name, k_dir_map4, g, blk, 0, Pv, step, expand);
-        else       { HBHIP_LAUNCH(lc, name, k_dir_map_c, g, blk, 0, Pv, step, expand, post); post_folded = post != 0; }
+        const int trows = step == 1 ? f.height[0] : (f.height[0] + 1) / 2;             // thread rows
+        if (!expand) HBHIP_LAUNCH(lc, name, k_dir_map4, dim3((f.width[0] + 255) / 256, (trows + 3) / 4, gz), blk, 0, Pv, step, expand);
+        else
+        {
+            HBHIP_LAUNCH(lc, name, k_dir_map_c, dim3((f.width[0] + 255) / 256, (trows + DC_ROWS - 1) / DC_ROWS, gz), blk, 0, Pv, step, expand, post);
+            post_folded = post != 0;
+        }
     };
     auto geom = [&](P3 &P, const EediFrame &f) {
         for (int c = 0; c < 3; c++) { P.pitch[c] = f.stride[c]; P.width[c] = f.width[c]; P.height[c] = f.height[c]; }
