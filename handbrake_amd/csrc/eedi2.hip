@@ -67,12 +67,18 @@ struct P3
     int pitch[3], width[3], height[3];   // height = rows of the buffers this pass walks
     size_t   fstride;    // field batching: the scratch buffers of consecutive fields of a launch lie this many bytes apart
     uint32_t tffbits;    // bit f: pv->tff of field f of the launch (the rebuilt rows start at y0 = 2 - tff)
+    const uint32_t *pflags;   // [field][plane] of the launch: == pepoch when the plane's edge mask has a pixel set (MaskChain::pflags)
+    uint32_t pepoch;
 };
 
 // A launch covers the three planes of every field of a batch: blockIdx.z = 3 * field + plane.  All scratch frames of
 // a field sit in one slab (Eedi2Engine::init), so one offset moves every pointer of the pass to the block's field.
 // The block's pointers are picked once into Q (scalar loads from the kernel arguments; P itself is never written -
 // a dynamically indexed store would push the whole struct into scratch memory).
+// `maskless`: the plane's edge mask is empty (no mask tile left a pixel set: MaskChain::pflags) - chroma without edges, a
+// flat or letterboxed picture.  Every pass behind the mask only works on or next to mask pixels and copies (or fills) the
+// rest, so for such a plane a pass is a copy, and its kernel takes the shortest way to it: the planes of the synthetic
+// stream's chroma, a third of a field's pixels, cost 18 % of the decomb workload before (measured by leaving them out).
 struct PL { uint8_t *a, *b, *c, *d, *e, *f, *g; };
 __device__ __forceinline__ PL plane_ptrs(const P3 &P, int pl, size_t off)
 {
@@ -87,7 +93,8 @@ __device__ __forceinline__ PL plane_ptrs(const P3 &P, int pl, size_t off)
     const int fld = (int)blockIdx.z / 3, pl = (int)blockIdx.z - 3 * fld;    \
     const int tff = (int)(((P).tffbits >> fld) & 1u);                       \
     const PL Q = plane_ptrs((P), pl, (size_t)fld * (P).fstride);            \
-    (void)tff
+    const bool maskless = (P).pflags[blockIdx.z] != (P).pepoch;             \
+    (void)tff; (void)maskless
 
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int hbhip_align_up_dev(int v, int a) { return (v + a - 1) / a * a; }
@@ -423,6 +430,7 @@ __device__ __forceinline__ void mask_tile(const P3 &P, const MaskSrc &S, const M
     mf_morph4<false>(s_a, s_b, c4, strip, 4, MF_LR - 5, erode_thr, px1, fy, height);
 
     // remove_small_gaps (:308-342) on the tile's 16 rows x 32 dwords, straight to the new mask
+    uint32_t anyset = 0;
     for (int i = t; i < MF_H * (MF_W / 4); i += MF_T)
     {
         const int r = MF_OY + i / (MF_W / 4), g4 = MF_OX / 4 + (i & (MF_W / 4 - 1));
@@ -436,6 +444,7 @@ __device__ __forceinline__ void mask_tile(const P3 &P, const MaskSrc &S, const M
         const uint32_t fill = ((b1 & a123) | (b2 & a12) | (b3 & a1)) & (c ^ 0x01010101u);
         const uint32_t pm = (y >= 1 && y < height - 1) ? (mf_bytes_in(x, 3, width - 3) & 0x01010101u) : 0u;
         const uint32_t res = (((set | fill) & pm) | (c & ~pm)) * 255u;
+        anyset |= x + 3 < width ? res : res & (0xffffffffu >> (8 * (x + 4 - width)));
         uint8_t *d = newm + (size_t)y * pitch + x;
         if (CHAIN)
         {
@@ -445,10 +454,17 @@ __device__ __forceinline__ void mask_tile(const P3 &P, const MaskSrc &S, const M
         else if (x + 3 < width) *reinterpret_cast<uint32_t *>(d) = res;
         else for (int k = 0; k < 4 && x + k < width; k++) d[k] = (uint8_t)(res >> (8 * k));
     }
-    if (CHAIN) eedi_chain_signal(C, fld, pl, bx, by);
+    // a plane with a mask pixel somewhere: say so (P3::pflags - the passes behind the mask take a shortcut for the others).
+    // One thread of the tile, and only while the flag is not up yet: thousands of tiles storing to the same few words
+    // serialise in the L2 (the mask launch went from 120 us to 2 ms with a store per wave).
+    // (behind the tile's own flag: the next field's tiles wait for that one)
+    const bool has = CHAIN ? eedi_chain_signal(C, fld, pl, bx, by, anyset != 0u) : (bool)__syncthreads_or(anyset != 0u);
+    if (has && t == 0 && __hip_atomic_load(C.pflags + 3 * fld + pl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != C.epoch)
+        __hip_atomic_store(C.pflags + 3 * fld + pl, C.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(MF_T) void k_mask_fused4(P3 P, MaskSrc S, int f0, int part, int mth, int vth, int lth, int erode_thr, int dilate_thr)
+__global__ __launch_bounds__(MF_T) void k_mask_fused4(P3 P, MaskSrc S, int f0, int part, int mth, int vth, int lth, int erode_thr, int dilate_thr,
+                                                      uint32_t *pflags, uint32_t epoch)
 {
     __shared__ uint32_t s_src[MF_LR][MF_DP];
     __shared__ uint32_t s_a[MF_LR][MF_DP];
@@ -459,6 +475,7 @@ __global__ __launch_bounds__(MF_T) void k_mask_fused4(P3 P, MaskSrc S, int f0, i
     const bool upper = y0 + MF_H + MF_OY <= P.height[pl] / 2;
     if (part != 0 && upper != (part == 1)) return;
     MaskChain none;
+    none.pflags = pflags; none.epoch = epoch;
     mask_tile<false>(P, S, none, fld, pl, (int)blockIdx.x, (int)blockIdx.y, mth, vth, lth, erode_thr, dilate_thr, s_src, s_a, s_b);
 }
 
@@ -851,6 +868,17 @@ __global__ __launch_bounds__(CD_W) CD_WAVES_ATTR void k_calc_dir_rows(P3 P, int 
     const int x0 = blockIdx.x * CD_W, y0 = blockIdx.y * R;
     if (y0 >= height || x0 >= pitch) return;
     const int tid = threadIdx.x, lane = tid & 63;
+    if (maskless)
+    {
+        // no mask pixel in the plane: the reference's memset(dstp, 255, ...) is all there is (:371)
+#pragma unroll
+        for (int jr = 0; jr < R; jr += CD_W / 64)
+        {
+            const int j = jr + (tid >> 6), y = y0 + j, xb = x0 + 4 * lane;
+            if (j < R && y < height && xb < pitch) *reinterpret_cast<uint32_t *>(Q.c + (size_t)y * pitch + xb) = 0xffffffffu;
+        }
+        return;
+    }
     if (tid == 0) s_count = 0;
     if (tid < NM * 3) s_bits[tid / 3][5 + tid % 3] = 0;           // words past the staged columns (the window reads one of them)
     uint32_t *band = reinterpret_cast<uint32_t *>(&s_band[0][0]);
@@ -868,27 +896,6 @@ __global__ __launch_bounds__(CD_W) CD_WAVES_ATTR void k_calc_dir_rows(P3 P, int 
         }
     }
     __syncthreads();
-    // tables: the four columns of a staged dword at a time (two dwords realigned three ways, one 16-byte write); columns
-    // 0 .. CD_LW-4 are looked at (b+-u, |u| <= CD_HALO-2), the last dword's are made but never read
-    for (int i = tid; i < NS * RW; i += CD_W)
-    {
-        const uint32_t d0 = band[i], d1 = band[i + 1];
-        reinterpret_cast<uint4 *>(&s_tri[0][0])[i] =
-            make_uint4(d0 & 0x00ffffffu, __builtin_amdgcn_alignbyte(d1, d0, 1) & 0x00ffffffu,
-                       __builtin_amdgcn_alignbyte(d1, d0, 2) & 0x00ffffffu, __builtin_amdgcn_alignbyte(d1, d0, 3) & 0x00ffffffu);
-    }
-    // peak bitmaps of the mask rows: a first round for all, the 64 columns left over for the first wave
-    for (int k = 0; k < 2; k++)
-    {
-        if (k == 1 && tid >= 64) break;                          // wave-uniform
-        const int i = tid + k * CD_W;
-#pragma unroll
-        for (int m = 0; m < NM; m++)
-        {
-            const uint64_t w = __ballot(s_band[NS + m][i] == PEAK);   // the wave's 64 consecutive columns = one word
-            if (lane == 0) s_bits[m][i >> 6] = w;
-        }
-    }
     // the pixels that pass the edge test (:392-393), four per thread from dwords of the mask row; the rest of the
     // output is 255 (memset(dstp, 255, pitch*height))
 #pragma unroll
@@ -928,6 +935,33 @@ __global__ __launch_bounds__(CD_W) CD_WAVES_ATTR void k_calc_dir_rows(P3 P, int 
     const uint64_t lenmask = (1ull << len) - 1ull;
     const bool edge = y0 <= 1 || y0 + R - 1 >= height - 2;
     const bool dense = R >= 4 && !edge && count >= dense_min;          // block-uniform
+    if (count)                                                         // block-uniform
+    {
+        // (behind the list: a block without a listed pixel - off the mask, like whole chroma planes without edges - makes
+        // neither tables nor bitmaps)
+        // tables: the four columns of a staged dword at a time (two dwords realigned three ways, one 16-byte write); columns
+        // 0 .. CD_LW-4 are looked at (b+-u, |u| <= CD_HALO-2), the last dword's are made but never read
+        for (int i = tid; i < NS * RW; i += CD_W)
+        {
+            const uint32_t d0 = band[i], d1 = band[i + 1];
+            reinterpret_cast<uint4 *>(&s_tri[0][0])[i] =
+                make_uint4(d0 & 0x00ffffffu, __builtin_amdgcn_alignbyte(d1, d0, 1) & 0x00ffffffu,
+                           __builtin_amdgcn_alignbyte(d1, d0, 2) & 0x00ffffffu, __builtin_amdgcn_alignbyte(d1, d0, 3) & 0x00ffffffu);
+        }
+        // peak bitmaps of the mask rows: a first round for all, the 64 columns left over for the first wave
+        for (int k = 0; k < 2; k++)
+        {
+            if (k == 1 && tid >= 64) break;                          // wave-uniform
+            const int i = tid + k * CD_W;
+    #pragma unroll
+            for (int m = 0; m < NM; m++)
+            {
+                const uint64_t w = __ballot(s_band[NS + m][i] == PEAK);   // the wave's 64 consecutive columns = one word
+                if (lane == 0) s_bits[m][i >> 6] = w;
+            }
+        }
+        __syncthreads();
+    }
 #ifdef HBHIP_DEV_STATS
     if (tid == 0) { CD_STAT(0, 1); CD_STAT(1, count != 0); CD_STAT(2, count); CD_STAT(7, dense); }
 #endif
@@ -1202,6 +1236,22 @@ __global__ __launch_bounds__(256) void k_dir_map4(P3 P, int step, int expand)
     const int y0 = step == 1 ? 1 : 2 - tff;
     const int y = step == 1 ? r : 2 * r + (y0 & 1);
     if (x >= width) return;
+    if (maskless)
+    {
+        // No mask pixel in the plane: the pass is its bit_blit (:656 / :729) - of a map that calc_directions filled with
+        // peaks for want of a mask pixel (:371) and that every pass since has only copied: the output is peaks too, and a
+        // thread stores its dwords without loading anything (as copies the chroma planes of 16 fields were 66 MB and 14 us
+        // per full-height launch).
+        const int ya = step == 1 ? r : 2 * r, nrows = step == 1 ? 1 : 2;
+        const int out[4] = { PEAK, PEAK, PEAK, PEAK };
+        for (int i = 0; i < nrows && ya + i < height; i++)
+        {
+            const size_t at = (size_t)(ya + i) * pitch + x;
+            st4(Q.c + at, out, x, width);
+            if (Q.d) st4(Q.d + at, out, x, width);
+        }
+        return;
+    }
     // the row of the pair that is never rebuilt (bit_blit only): fetched now, stored after the other row's work, so that
     // its load is one of the thread's loads in flight and not a round trip of its own
     const int yc = 2 * r + 1 - (y0 & 1);
@@ -1228,18 +1278,21 @@ __global__ __launch_bounds__(256) void k_dir_map4(P3 P, int step, int expand)
         put_copy();
         return;
     }
-    const Win12 wc = ldwin(dc), wu = ldwin(dc - (ptrdiff_t)step * pitch), wd = ldwin(dc + (ptrdiff_t)step * pitch);
+    // The row's own dword and the mask first: a thread without a pixel to work on (off the mask - whole planes of them
+    // where the chroma has no edges: a third of a field's pixels) copies its dword and never fetches the 32 bytes around it.
+    const uint32_t own = *reinterpret_cast<const uint32_t *>(dc);
     const uint8_t *mk = Q.a + (size_t)y * pitch + x;
     const uint32_t m0 = *reinterpret_cast<const uint32_t *>(step == 1 ? mk : mk - (ptrdiff_t)pitch);
     const uint32_t m1 = step == 1 ? 0u : *reinterpret_cast<const uint32_t *>(mk + pitch);
     const bool up_ok = step == 1 || y > 1, dn_ok = step == 1 || y < height - 2;
     // the pixels the pass works on, one flag byte each (:658 / :738): inside the row, on the mask, and for expand a peak
     uint32_t work = ((ff_bytes(m0) | ff_bytes(m1)) >> 7) & mf_bytes_in(x, 1, width - 1);
-    if (expand) work &= ff_bytes(wc.w1) >> 7;
-    uint32_t res = wc.w1;
+    if (expand) work &= ff_bytes(own) >> 7;
+    uint32_t res = own;
     if (work)
     {
-        asm volatile("" ::: "memory");                         // a real branch: waves without such a pixel skip the votes
+        asm volatile("" ::: "memory");                         // a real branch: waves without such a pixel skip the loads and the votes
+        const Win12 wc = ldwin(dc), wu = ldwin(dc - (ptrdiff_t)step * pitch), wd = ldwin(dc + (ptrdiff_t)step * pitch);
         const Win12 none = { 0xffffffffu, 0xffffffffu, 0xffffffffu };
         const Win12 eu = up_ok ? wu : none, ed = dn_ok ? wd : none;
         const uint32_t p01 = dir_map_pair<0>(eu, wc, ed, expand), p23 = dir_map_pair<2>(eu, wc, ed, expand);
@@ -1251,7 +1304,7 @@ __global__ __launch_bounds__(256) void k_dir_map4(P3 P, int step, int expand)
     st4(o, out, x, width);
     if (Q.d)
     {
-        int in[4] = { wb(wc, 0), wb(wc, 1), wb(wc, 2), wb(wc, 3) };
+        int in[4] = { (int)(own & 0xff), (int)((own >> 8) & 0xff), (int)((own >> 16) & 0xff), (int)(own >> 24) };
         st4(Q.d + (size_t)y * pitch + x, in, x, width);
     }
     put_copy();
@@ -1294,6 +1347,27 @@ __global__ __launch_bounds__(256) void k_dir_map_c(P3 P, int step, int expand, i
     const int yb = step == 1 ? rb : 2 * rb + (y0 & 1);                              // row of thread row 0
     const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
     if (bx0 >= width || (step == 1 ? rb : 2 * rb) >= height) return;                 // whole workgroup outside
+    if (maskless)
+    {
+        // no mask pixel in the plane: the pass is its bit_blit of a map of peaks (k_dir_map4), and the post-processing that
+        // may ride along finds every direction a peak and leaves the picture alone (:1364)
+        if (x < width)
+        {
+            const int out[4] = { PEAK, PEAK, PEAK, PEAK };
+#pragma unroll
+            for (int h = 0; h < DC_R; h++)
+            {
+                const int r = rb + (int)threadIdx.y + 4 * h, ya = step == 1 ? r : 2 * r, nrows = step == 1 ? 1 : 2;
+                for (int i = 0; i < nrows && ya + i < height; i++)
+                {
+                    const size_t at = (size_t)(ya + i) * pitch + x;
+                    st4(Q.c + at, out, x, width);
+                    if (Q.d) st4(Q.d + at, out, x, width);
+                }
+            }
+        }
+        return;
+    }
     const int tid = threadIdx.y * 64 + threadIdx.x;
     if (tid == 0) s_count = 0;
     lim_fill(s_lim, tid);
@@ -1316,31 +1390,36 @@ __global__ __launch_bounds__(256) void k_dir_map_c(P3 P, int step, int expand, i
             if (!row_ok) out = *reinterpret_cast<const uint32_t *>(dc);                   // bit_blit only
             else
             {
-                const Win12 wc = ldwin(dc), wu = ldwin(dc - (ptrdiff_t)step * pitch), wd = ldwin(dc + (ptrdiff_t)step * pitch);
+                // the row's own dword and the mask first: without a candidate among its four pixels a thread copies its dword
+                // and fetches nothing else (k_dir_map4)
+                out = *reinterpret_cast<const uint32_t *>(dc);
                 const uint8_t *mk = Q.a + (size_t)y * pitch + x;
                 const uint32_t m0 = *reinterpret_cast<const uint32_t *>(step == 1 ? mk : mk - (ptrdiff_t)pitch);
                 const uint32_t m1 = step == 1 ? 0u : *reinterpret_cast<const uint32_t *>(mk + pitch);
-                const bool up_ok = step == 1 || y > 1, dn_ok = step == 1 || y < height - 2;
-                uint32_t nc, nu, nd;
-                const uint32_t s3c = live3(wc, nc), s3u = live3(wu, nu), s3d = live3(wd, nd);
-                uint32_t u = expand ? s3c - nc : s3c;                                      // expand leaves the centre out (:671)
-                if (up_ok) u += s3u;
-                if (dn_ok) u += s3d;
-                const uint32_t enough = ((u + (uint32_t)(0x80 - (expand ? 5 : 4)) * 0x01010101u) >> 7) & 0x01010101u;
                 uint32_t cand = ((ff_bytes(m0) | ff_bytes(m1)) >> 7) & mf_bytes_in(x, 1, width - 1);
-                if (expand) cand &= ~nc;                                                   // expand only fills peak pixels
-                out = wc.w1;
-                if (!expand) out |= (cand & ~enough) * 255u;                               // too few neighbours: peak
-                uint32_t sortpx = cand & enough;
-                if (sortpx)
+                if (expand) cand &= ff_bytes(out) >> 7;                                    // expand only fills peak pixels
+                if (cand)
                 {
-                    const int n = __popc(sortpx);
-                    int at = atomicAdd(&s_count, n);
+                    const Win12 wc = ldwin(dc), wu = ldwin(dc - (ptrdiff_t)step * pitch), wd = ldwin(dc + (ptrdiff_t)step * pitch);
+                    const bool up_ok = step == 1 || y > 1, dn_ok = step == 1 || y < height - 2;
+                    uint32_t nc, nu, nd;
+                    const uint32_t s3c = live3(wc, nc), s3u = live3(wu, nu), s3d = live3(wd, nd);
+                    uint32_t u = expand ? s3c - nc : s3c;                                  // expand leaves the centre out (:671)
+                    if (up_ok) u += s3u;
+                    if (dn_ok) u += s3d;
+                    const uint32_t enough = ((u + (uint32_t)(0x80 - (expand ? 5 : 4)) * 0x01010101u) >> 7) & 0x01010101u;
+                    if (!expand) out |= (cand & ~enough) * 255u;                           // too few neighbours: peak
+                    const uint32_t sortpx = cand & enough;
+                    if (sortpx)
+                    {
+                        const int n = __popc(sortpx);
+                        int at = atomicAdd(&s_count, n);
 #pragma unroll
-                    for (int k = 0; k < 4; k++)
-                        if ((sortpx >> (8 * k)) & 1u) s_list[at++] = (uint16_t)((lr << 8) | (4 * threadIdx.x + k));
+                        for (int k = 0; k < 4; k++)
+                            if ((sortpx >> (8 * k)) & 1u) s_list[at++] = (uint16_t)((lr << 8) | (4 * threadIdx.x + k));
+                    }
+                    (void)nu; (void)nd;
                 }
-                (void)nu; (void)nd;
             }
             *reinterpret_cast<uint32_t *>(&s_out[lr][4 * threadIdx.x]) = out;
             if (Q.d)                                                                    // optional copy of the input (the eedi2_bit_blit before post-processing)
@@ -1433,6 +1512,38 @@ __global__ __launch_bounds__(256) void k_filter_map(P3 P)
     const int bx0 = blockIdx.x * FM_W, by0 = blockIdx.y * FM_R;
     if (bx0 >= width || by0 >= height) return;                   // whole workgroup outside
     const int tid = threadIdx.y * 64 + threadIdx.x;
+    const int x = bx0 + 4 * threadIdx.x, y = by0 + threadIdx.y;
+    if (maskless)
+    {
+        // no mask pixel in the plane: the pass is its bit_blit (:547) of a map of peaks (k_dir_map4)
+        if (x < width && y < height)
+        {
+            uint8_t *o = Q.c + (size_t)y * pitch + x;
+            if (x + 3 < width) *reinterpret_cast<uint32_t *>(o) = 0xffffffffu;
+            else for (int k = 0; k < 4 && x + k < width; k++) o[k] = (uint8_t)PEAK;
+        }
+        return;
+    }
+    const bool inside = x < width && y < height;
+    // The thread's own dword and its mask first: a workgroup without a candidate (mask peak, map not peak, inside the frame
+    // of :557-560) - off the mask, like whole chroma planes without edges - copies its rows and stages nothing.
+    uint32_t m4 = 0, own = 0;
+    if (inside)
+    {
+        own = *reinterpret_cast<const uint32_t *>(Q.b + (size_t)y * pitch + x);
+        if (y >= 1 && y < height - 1) m4 = *reinterpret_cast<const uint32_t *>(Q.a + (size_t)y * pitch + x);   // (m4 stays 0 on the first / last row)
+    }
+    uint32_t cand = ((ff_bytes(m4) & ~ff_bytes(own)) >> 7) & mf_bytes_in(x, 1, width - 1);
+    if (!__syncthreads_or(cand != 0u))                           // block-uniform
+    {
+        if (inside)
+        {
+            uint8_t *o = Q.c + (size_t)y * pitch + x;
+            if (x + 3 < width) *reinterpret_cast<uint32_t *>(o) = own;
+            else for (int k = 0; k < 4 && x + k < width; k++) o[k] = (uint8_t)(own >> (8 * k));
+        }
+        return;
+    }
     {
         // 6 x 68 dwords for 256 threads: both loads of a thread in flight before the first LDS store
         static_assert((FM_R + 2) * (FM_LW / 4) <= 2 * 256, "two staged dwords per thread");
@@ -1449,17 +1560,10 @@ __global__ __launch_bounds__(256) void k_filter_map(P3 P)
         for (int k = 0; k < 2; k++)
             if (tid + 256 * k < (FM_R + 2) * (FM_LW / 4)) reinterpret_cast<uint32_t *>(&s_d[0][0])[tid + 256 * k] = v[k];
     }
-    const int x = bx0 + 4 * threadIdx.x, y = by0 + threadIdx.y;
-    const bool inside = x < width && y < height;
-    uint32_t m4 = 0;
-    if (inside && y >= 1 && y < height - 1) m4 = *reinterpret_cast<const uint32_t *>(Q.a + (size_t)y * pitch + x);
     __syncthreads();
     if (!inside) return;
     const uint8_t *rc = &s_d[threadIdx.y + 1][FM_HALO + 4 * threadIdx.x];
-    uint32_t out4 = *reinterpret_cast<const uint32_t *>(rc);
-    // candidates: mask peak, map not peak, inside the frame of :557-560 (m4 is 0 on the first / last row)
-    uint32_t cand = (ff_bytes(m4) & ~ff_bytes(out4)) >> 7;
-    cand &= mf_bytes_in(x, 1, width - 1);
+    uint32_t out4 = own;
     // Both walks of a pixel in one loop, neither with an early exit: the pixel turns peak when the walk above trips
     // somewhere AND the walk below does (:565-627 take the second only after the first has tripped - the same verdict).
     // With neg = min(dir, 0), pos = max(dir, 0) the four ranges of :565-620 are [max(-x, neg), min(w - x - 1, pos)] above
@@ -1532,15 +1636,22 @@ __global__ __launch_bounds__(256) void k_mark_2x4(P3 P)
     if (yc < height) *reinterpret_cast<uint32_t *>(Q.c + (size_t)yc * pitch + x) = 0xffffffffu;      // memset(dstp, 255, pitch*height)
     if (y >= height) return;
     uint32_t *o = reinterpret_cast<uint32_t *>(Q.c + (size_t)y * pitch + x);
-    if (!(y >= y0 && y < height - 1))
+    if (maskless || !(y >= y0 && y < height - 1))             // (no mask pixel in the plane: nothing but the memset, :800)
     {
         *o = 0xffffffffu;
         return;
     }
-    const Win12 wa = ldwin(Q.b + (ptrdiff_t)((y - 1) >> 1) * pitch + x), wbn = ldwin(Q.b + (ptrdiff_t)((y + 1) >> 1) * pitch + x);
+    // the mask first: a thread none of whose four pixels sits under or above a mask pixel writes peaks and never fetches the
+    // direction rows (k_dir_map4)
     const uint32_t k0w = *reinterpret_cast<const uint32_t *>(Q.a + (ptrdiff_t)((y - 1) >> 1) * pitch + x);
     const uint32_t k1w = *reinterpret_cast<const uint32_t *>(Q.a + (ptrdiff_t)((y + 1) >> 1) * pitch + x);
     uint32_t packed = 0xffffffffu;
+    if (((ff_bytes(k0w) | ff_bytes(k1w)) & mf_bytes_in(x, 1, width - 1)) == 0u)
+    {
+        *o = packed;
+        return;
+    }
+    const Win12 wa = ldwin(Q.b + (ptrdiff_t)((y - 1) >> 1) * pitch + x), wbn = ldwin(Q.b + (ptrdiff_t)((y + 1) >> 1) * pitch + x);
 #pragma unroll
     for (int k = 0; k < 4; k++)
     {
@@ -1622,6 +1733,23 @@ __global__ __launch_bounds__(256) void k_fill_gaps_b(P3 P)
     if (ya >= height || x0 >= width) return;
     const int yb = ya + (y0 & 1);                                  // its rows of the rebuilt parity: yb, yb + 2, ..
     const int x = x0 + 4 * tid;
+    if (maskless)
+    {
+        // no mask pixel in the plane, no gap to fill (:1048-1050): the pass is its bit_blit of a map of peaks (k_dir_map4)
+        if (x < width)
+        {
+#pragma unroll
+            for (int i = 0; i < 2 * FG_R; i++)
+            {
+                const int y = ya + i;
+                if (y >= height) break;
+                uint8_t *o = Q.c + (size_t)y * pitch + x;
+                if (x + 3 < width) *reinterpret_cast<uint32_t *>(o) = 0xffffffffu;
+                else for (int k = 0; k < 4 && x + k < width; k++) o[k] = (uint8_t)PEAK;
+            }
+        }
+        return;
+    }
     auto rebuilt = [&](int y) { return y >= y0 && y < height - 1; };
     // the rows that are only copied (the reference's bit_blit): the other parity, and what lies outside y0 .. height - 2
     uint32_t vcopy[2 * FG_R];
@@ -1678,35 +1806,6 @@ __global__ __launch_bounds__(256) void k_fill_gaps_b(P3 P)
     // rebuilt row k = yb + 2k: direction rows s_d[k] (y - 2), s_d[k + 1] (y), s_d[k + 2] (y + 2); mask rows s_m[k] (y - 3),
     // s_m[k + 1] (y - 1), s_m[k + 2] (y + 1), s_m[k + 3] (y + 3)
     const unsigned staged = 4u * (unsigned)ndw;
-    // Per staged column and rebuilt row: does a walk stop here (a known direction, or outside the mask: :1055-1058), is the
-    // direction known, does the row above / below end the "top / bottom continues" state (:1078-1093).  The walks then
-    // are bit scans instead of chains of dependent byte reads.  First the rows' own bits - direction known, mask set -
-    // once per staged row, then the four combinations per rebuilt row as word arithmetic.
-    for (int k = 0; k < (FG_LW + 255) / 256; k++)
-    {
-        // (no branch: the bytes are read whatever they hold - from the last staged column for the lanes past it, whose
-        // bits are then cleared)
-        const unsigned col = tid + 256 * k, cc = min(col, staged - 1u);
-        const bool in = col < staged;
-        uint64_t nd[FG_ND], pm[FG_NM];
-#pragma unroll
-        for (int r = 0; r < FG_ND; r++) nd[r] = __ballot(in & (s_d[r][cc] != PEAK));       // direction known
-#pragma unroll
-        for (int r = 0; r < FG_NM; r++) pm[r] = __ballot(in & (s_m[r][cc] == PEAK));       // on the mask
-        const uint64_t inw = __ballot(in);
-        if ((tid & 63) == 0 && (col >> 6) < (unsigned)FG_WORDS)
-        {
-#pragma unroll
-            for (int r = 0; r < FG_R; r++)
-            {
-                const uint64_t mc = pm[r + 1], mn = pm[r + 2];
-                s_np[r][col >> 6] = nd[r + 1];
-                s_stop[r][col >> 6] = nd[r + 1] | (inw & ~mc & ~mn);
-                s_bt[r][col >> 6] = inw & (~nd[r] | (~pm[r] & ~mc));
-                s_bb[r][col >> 6] = inw & (~nd[r + 2] | (~mn & ~pm[r + 3]));
-            }
-        }
-    }
 #pragma unroll
     for (int r = 0; r < FG_R; r++)
     {
@@ -1734,6 +1833,39 @@ __global__ __launch_bounds__(256) void k_fill_gaps_b(P3 P)
 #ifdef HBHIP_DEV_STATS
     if (tid == 0) CD_STAT(12, 1);
 #endif
+    if (count)                                                                     // block-uniform: no gap pixel (off the mask,
+    {                                                                              // whole chroma planes without edges), no bitmaps
+        // Per staged column and rebuilt row: does a walk stop here (a known direction, or outside the mask: :1055-1058), is the
+        // direction known, does the row above / below end the "top / bottom continues" state (:1078-1093).  The walks then
+        // are bit scans instead of chains of dependent byte reads.  First the rows' own bits - direction known, mask set -
+        // once per staged row, then the four combinations per rebuilt row as word arithmetic.
+        for (int k = 0; k < (FG_LW + 255) / 256; k++)
+        {
+            // (no branch: the bytes are read whatever they hold - from the last staged column for the lanes past it, whose
+            // bits are then cleared)
+            const unsigned col = tid + 256 * k, cc = min(col, staged - 1u);
+            const bool in = col < staged;
+            uint64_t nd[FG_ND], pm[FG_NM];
+    #pragma unroll
+            for (int r = 0; r < FG_ND; r++) nd[r] = __ballot(in & (s_d[r][cc] != PEAK));       // direction known
+    #pragma unroll
+            for (int r = 0; r < FG_NM; r++) pm[r] = __ballot(in & (s_m[r][cc] == PEAK));       // on the mask
+            const uint64_t inw = __ballot(in);
+            if ((tid & 63) == 0 && (col >> 6) < (unsigned)FG_WORDS)
+            {
+    #pragma unroll
+                for (int r = 0; r < FG_R; r++)
+                {
+                    const uint64_t mc = pm[r + 1], mn = pm[r + 2];
+                    s_np[r][col >> 6] = nd[r + 1];
+                    s_stop[r][col >> 6] = nd[r + 1] | (inw & ~mc & ~mn);
+                    s_bt[r][col >> 6] = inw & (~nd[r] | (~pm[r] & ~mc));
+                    s_bb[r][col >> 6] = inw & (~nd[r + 2] | (~mn & ~pm[r + 3]));
+                }
+            }
+        }
+        __syncthreads();
+    }
     for (int i = tid; i < count; i += 256)
     {
         const int e = s_list[i], r = e >> 12, lx = e & 0xfff, px = x0 + lx, y = yb + 2 * r;
@@ -1994,6 +2126,7 @@ __global__ __launch_bounds__(256) void k_lattice_cand_q(P3 P, uint32_t *__restri
     const int ri = blockIdx.y;
     const int nrows = (height - (2 - field)) / 2;
     if (x0 >= width || ri >= nrows) return;
+    if (maskless) return;                                          // no direction anywhere: k_lattice_resolve averages by itself
     const int y = (2 - field) + 2 * ri;
     if (t < 3) s_count[t] = 0;
     lim_fill(s_lim, t);
@@ -2138,6 +2271,21 @@ __global__ __launch_bounds__(LR_T) void k_lattice_resolve(P3 P, const uint32_t *
     const int y = (2 - field) + 2 * blockIdx.y;
     uint8_t *mid = dst + (size_t)y * pitch;
     uint8_t *dm = Q.a + (size_t)y * pitch;
+    if (maskless)
+    {
+        // no mask pixel in the plane: every direction is a peak, every pixel of the row the rounded mean of the pixels
+        // above and below it (:1192-1197), the direction row stays as it is.  Four pixels per operation:
+        // (a + b + 1) >> 1 = (a | b) - (((a ^ b) >> 1) & 0x7f) per byte
+        const uint8_t *top = mid - pitch, *bot = mid + pitch;
+        for (int x = 4 * t; x < width; x += 4 * LR_T)
+        {
+            const uint32_t a = *reinterpret_cast<const uint32_t *>(top + x), b = *reinterpret_cast<const uint32_t *>(bot + x);
+            const uint32_t v = (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7fu);
+            if (x + 3 < width) *reinterpret_cast<uint32_t *>(mid + x) = v;
+            else for (int k = 0; k < 4 && x + k < width; k++) mid[x + k] = (uint8_t)(v >> (8 * k));
+        }
+        return;
+    }
     const uint32_t *cr = cand + (size_t)pl * cand_plane_stride + (size_t)blockIdx.y * cand_pitch;
     const bool cr16 = ((reinterpret_cast<uintptr_t>(cr)) & 15u) == 0;      // block-uniform: the row of candidates starts on 16 bytes
     // value standing at dm[x-1] for x == 0: memory just before the row, never written by this pass
@@ -2397,6 +2545,7 @@ Eedi2Engine::~Eedi2Engine()
 {
     if (slab_) (void)hipFree(slab_);
     if (chain_flags_) (void)hipFree(chain_flags_);
+    if (plane_flags_) (void)hipFree(plane_flags_);
     if (work_list_) (void)hipFree(work_list_);
     if (work_count_) (void)hipFree(work_count_);
     for (int i = 0; i < 3; i++)
@@ -2447,6 +2596,8 @@ int Eedi2Engine::init()
     for (auto &f : half_) for (int c = 0; c < 3; c++) f.plane[c] = slab_ + (size_t)(uintptr_t)f.plane[c];
     for (auto &f : full_) for (int c = 0; c < 3; c++) f.plane[c] = slab_ + (size_t)(uintptr_t)f.plane[c];
     cand_ = reinterpret_cast<uint32_t *>(slab_ + cand_at);
+    HBHIP_CHECK(ctx_, hipMalloc((void **)&plane_flags_, sizeof(uint32_t) * 3 * EEDI_MAX_BATCH));
+    HBHIP_CHECK(ctx_, hipMemsetAsync(plane_flags_, 0, sizeof(uint32_t) * 3 * EEDI_MAX_BATCH, ctx_->stream));
     last_slot_ = cap_;                                             // "the previous mask" of the first run: zeros, like the reference's
     if (cap_ > 1)
     {
@@ -2536,9 +2687,10 @@ int Eedi2Engine::enqueue_mask(int n, hbhip_ctx *lc)
     P.tffbits = tffbits_;
     const int mth = par_.magnitude_threshold * 10, vth = par_.laplacian_threshold * 81, lth = par_.variance_threshold;   // sic: swapped (decomb_template.c:390)
     const unsigned gx = (srcp.width[0] + MF_W - 1) / MF_W, gy = (srcp.height[0] + MF_H - 1) / MF_H;
+    const uint32_t epoch = ++chain_epoch_;                        // the number of this mask launch (chain flags, plane flags)
     if (n == 1)
         HBHIP_LAUNCH(lc, "eedi2_mask_passes", k_mask_fused4, dim3(gx, gy, 3), dim3(MF_T), 0, P, S, 0, 0, mth, vth, lth,
-                     par_.erosion_threshold, par_.dilation_threshold);
+                     par_.erosion_threshold, par_.dilation_threshold, plane_flags_, epoch);
     else
     {
         // One launch: the tiles no earlier field can influence (upper) and the chain through the fields (lower, MaskChain),
@@ -2546,7 +2698,8 @@ int Eedi2Engine::enqueue_mask(int n, hbhip_ctx *lc)
         // chain ran alone at a third of the GPU: it is 16 links of latency, not work (58 + 139 us per 16 fields).
         MaskChain C = eedi_mask_chain_tiles(srcp, MF_W, MF_H, MF_OY);
         C.flags = chain_flags_;
-        C.epoch = ++chain_epoch_;
+        C.pflags = plane_flags_;
+        C.epoch = epoch;
         C.group = C.ntiles + C.nupper;
         HBHIP_LAUNCH(lc, "eedi2_mask_passes", k_mask_chain, dim3((unsigned)(C.group * n)), dim3(MF_T), 0, P, S, C, mth, vth, lth,
                      par_.erosion_threshold, par_.dilation_threshold);
@@ -2595,6 +2748,8 @@ int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc)
     memset(&P, 0, sizeof(P));
     P.fstride = slot_bytes_;
     P.tffbits = tffbits;
+    P.pflags = plane_flags_ + 3 * f0;
+    P.pepoch = chain_epoch_;
 
     // half-height passes
     geom(P, srcp);

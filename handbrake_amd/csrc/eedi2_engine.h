@@ -47,6 +47,8 @@ struct MaskChain
     int ntiles;               // lower tiles of one field, all planes
     int ubase[3], nupper;     // the upper tiles of a field (rows 0 .. ty0 - 1), numbered plane by plane behind the lower ones
     int group;                // workgroups per field of a launch: ntiles, or ntiles + nupper when the upper tiles ride along
+    uint32_t *pflags;         // [field][plane]: set to `epoch` by any tile that leaves a mask pixel set - a plane whose flag is
+                              // not the epoch afterwards has an empty mask, and every later pass only copies it (8-bit engine)
 };
 
 // the lower tiles of one field, numbered plane by plane; a tile row is "upper" (no row of its LDS frame reaches the half
@@ -116,17 +118,19 @@ __device__ __forceinline__ void eedi_chain_wait(const MaskChain &C, int fld, int
     __syncthreads();                                           // (a workgroup fence: the mask loads that follow stay below)
 }
 
-// after the tile's mask stores (agent-scope atomics): publish the tile
-__device__ __forceinline__ void eedi_chain_signal(const MaskChain &C, int fld, int pl, int bx, int by)
+// after the tile's mask stores (agent-scope atomics): publish the tile.  Returns the workgroup's OR of `pred` (the barrier
+// the publication needs anyway carries it)
+__device__ __forceinline__ bool eedi_chain_signal(const MaskChain &C, int fld, int pl, int bx, int by, bool pred = false)
 {
     // each wave: its stores have completed (a workgroup-scope release fence does not wait for them - waves of a
     // workgroup share their L1 - and without the wait the flag overtakes mask words still in flight: seen as a handful
     // of wrong mask samples in one run out of a few)
     __builtin_amdgcn_s_waitcnt(0x0f70);                        // vmcnt(0), gfx9 encoding
-    __syncthreads();
+    const bool any = __syncthreads_or(pred);
     if (threadIdx.x == 0)
         __hip_atomic_store(C.flags + (size_t)fld * C.ntiles + C.base[pl] + (by - C.ty0[pl]) * C.tx[pl] + bx, C.epoch,
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return any;
 }
 
 // EEDI2 on 8-bit samples (eedi2.hip).  Fields are queued with add_field() and run by launch(): the mask passes field
@@ -169,7 +173,8 @@ private:
     EediFrame   half_[4];    // slot 0's SRCPF, MSKPF, TMPPF, DSTPF          (decomb.c:64-68)
     EediFrame   full_[5];    // slot 0's DST2PF, TMP2PF2, MSK2PF, TMP2PF, DST2MPF (decomb.c:69-74)
     uint32_t   *chain_flags_ = nullptr; // mask chain: one completion flag per lower tile and field of a batch
-    uint32_t    chain_epoch_ = 0;       //             the number of the last chain launch
+    uint32_t    chain_epoch_ = 0;       //             the number of the last mask launch
+    uint32_t   *plane_flags_ = nullptr; // [field of the batch][plane]: == chain_epoch_ when the plane's new mask has a pixel set
     uint32_t   *work_list_ = nullptr;   // calc_directions fallback: compacted edge pixels
     int        *work_count_ = nullptr;
     uint32_t   *cand_ = nullptr;        // slot 0's interpolate_lattice candidates
