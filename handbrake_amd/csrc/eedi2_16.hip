@@ -29,6 +29,8 @@ struct Q3
     int pitch[3], width[3], height[3];
     size_t   fstride;                      // field batching (see eedi2.hip): samples between the slots of consecutive fields
     uint32_t tffbits;                      // bit f: pv->tff of field f of the launch
+    const uint32_t *pflags;                // [field][plane] of the launch: == pepoch when the plane's edge mask has a sample set
+    uint32_t pepoch;                       // (eedi2.hip: P3::pflags - a plane without one is filled / copied by the shortest way)
 };
 
 // blockIdx.z = 3 * field + plane: the block's pointers, picked once from the arguments (never written back, eedi2.hip)
@@ -41,7 +43,8 @@ __device__ __forceinline__ QL plane_ptrs16(const Q3 &P, int pl, size_t off)
     const int fld = (int)blockIdx.z / 3, pl = (int)blockIdx.z - 3 * fld;     \
     const int tff = (int)(((P).tffbits >> fld) & 1u);                        \
     const QL Q = plane_ptrs16((P), pl, (size_t)fld * (P).fstride);           \
-    (void)tff
+    const bool maskless = (P).pflags[blockIdx.z] != (P).pepoch;              \
+    (void)tff; (void)maskless
 
 #define XY16(P)                                                              \
     FIELD16(P);                                                              \
@@ -258,6 +261,7 @@ __device__ __forceinline__ void qmask_tile(const Q3 &P, const MaskSrc16 &S, cons
     qm_morph4<false>(s_a, s_b, c4, strip, 4, QM_LR - 5, erode_thr, px1, fy, height);
 
     // remove_small_gaps (:308-342) on the tile's 16 rows x 32 cell dwords, straight to the new mask
+    uint32_t anyset = 0;
     for (int i = t; i < QM_H * (QM_W / 4); i += QM_T)
     {
         const int r = QM_OY + i / (QM_W / 4), g4 = QM_OX / 4 + (i & (QM_W / 4 - 1));
@@ -271,6 +275,7 @@ __device__ __forceinline__ void qmask_tile(const Q3 &P, const MaskSrc16 &S, cons
         const uint32_t fill = ((b1 & a123) | (b2 & a12) | (b3 & a1)) & (c ^ 0x01010101u);
         const uint32_t pm = (y >= 1 && y < height - 1) ? (qm_bytes_in(x, 3, width - 3) & 0x01010101u) : 0u;
         const uint32_t res = ((set | fill) & pm) | (c & ~pm);                         // 0 / 1 per cell
+        anyset |= x + 3 < width ? res : res & (0xffffffffu >> (8 * (x + 4 - width)));
         const uint32_t pk = (uint32_t)peak;
         const uint2 out = make_uint2(((res & 1u) ? pk : 0u) | ((res & 0x100u) ? pk << 16 : 0u),
                                      ((res & 0x10000u) ? pk : 0u) | ((res & 0x1000000u) ? pk << 16 : 0u));
@@ -294,11 +299,14 @@ __device__ __forceinline__ void qmask_tile(const Q3 &P, const MaskSrc16 &S, cons
             }
         }
     }
-    if (CHAIN) eedi_chain_signal(C, fld, pl, bx, by);
+    // a plane with a mask sample somewhere: say so (eedi2.hip: mask_tile)
+    const bool has = CHAIN ? eedi_chain_signal(C, fld, pl, bx, by, anyset != 0u) : (bool)__syncthreads_or(anyset != 0u);
+    if (has && t == 0 && __hip_atomic_load(C.pflags + 3 * fld + pl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != C.epoch)
+        __hip_atomic_store(C.pflags + 3 * fld + pl, C.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __global__ __launch_bounds__(QM_T) void q_mask_fused(Q3 P, MaskSrc16 S, K16 k, int f0, int part, int mth, int vth, int lth,
-                                                     int erode_thr, int dilate_thr)
+                                                     int erode_thr, int dilate_thr, uint32_t *pflags, uint32_t epoch)
 {
     __shared__ __attribute__((aligned(16))) uint16_t s_src[QM_LR][QM_LP + 8];   // sample column = frame column + 4
     __shared__ uint32_t s_a[QM_LR][QM_DP];
@@ -309,6 +317,7 @@ __global__ __launch_bounds__(QM_T) void q_mask_fused(Q3 P, MaskSrc16 S, K16 k, i
     const bool upper = y0 + QM_H + QM_OY <= P.height[pl] / 2;
     if (part != 0 && upper != (part == 1)) return;
     MaskChain none;
+    none.pflags = pflags; none.epoch = epoch;
     qmask_tile<false>(P, S, k, none, fld, pl, (int)blockIdx.x, (int)blockIdx.y, mth, vth, lth, erode_thr, dilate_thr, s_src, s_a, s_b);
 }
 
@@ -618,6 +627,17 @@ __global__ __launch_bounds__(QW) void q_calc_dir_rows(Q3 P, K16 k, int maxd, int
     if (y0 >= height || x0 >= pitch) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int peak = k.peak;
+    if (maskless)
+    {
+        // no mask sample in the plane: the reference's fill with the peak value is all there is (:371)
+        const uint32_t pk2 = (uint32_t)peak | ((uint32_t)peak << 16);
+        for (int i = tid; i < R * (QW / 2); i += QW)
+        {
+            const int j = i / (QW / 2), c2 = i - j * (QW / 2), y = y0 + j, xb = x0 + 2 * c2;
+            if (y < height && xb < pitch) *reinterpret_cast<uint32_t *>(Q.c + (size_t)y * pitch + xb) = pk2;
+        }
+        return;
+    }
     if (tid == 0) s_count = 0;
     if (tid < 33) s_lim[tid] = k.limlut[tid];
     if (tid >= 64 && tid < 64 + NM * 3) s_pk[(tid - 64) / 3][5 + (tid - 64) % 3] = 0;   // words past the staged columns
@@ -857,6 +877,17 @@ __global__ __launch_bounds__(256) void q_dir_map(Q3 P, K16 k, int step, int expa
     const int yb = step == 1 ? rb : 2 * rb + (y0 & 1);                              // row of thread row 0
     const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
     if (bx0 >= width || (step == 1 ? rb : 2 * rb) >= height) return;                 // whole workgroup outside
+    if (maskless)
+    {
+        // no mask sample in the plane: the pass is its bit_blit of a map of peaks (eedi2.hip: k_dir_map4)
+        if (x < width)
+        {
+            const int ya = step == 1 ? r : 2 * r, nrows = step == 1 ? 1 : 2;
+            for (int i = 0; i < nrows && ya + i < height; i++)
+                for (int j = 0; j < 4 && x + j < width; j++) Q.c[(size_t)(ya + i) * pitch + x + j] = (uint16_t)k.peak;
+        }
+        return;
+    }
     const int tid = threadIdx.y * 64 + threadIdx.x;
     if (tid == 0) s_count = 0;
     if (tid < 33) s_lim[tid] = k.limlut[tid];
@@ -974,6 +1005,14 @@ __global__ __launch_bounds__(256) void q_filter_map(Q3 P, K16 k)
     if (bx0 >= width || by0 >= height) return;                   // whole workgroup outside
     const int tid = threadIdx.y * 64 + threadIdx.x;
     const int peak = k.peak;
+    if (maskless)
+    {
+        // no mask sample in the plane: the pass is its bit_blit of a map of peaks (eedi2.hip: k_dir_map4)
+        const int x = bx0 + 4 * threadIdx.x, y = by0 + threadIdx.y;
+        if (y < height)
+            for (int j = 0; j < 4 && x + j < width; j++) Q.c[(size_t)y * pitch + x + j] = (uint16_t)peak;
+        return;
+    }
     {
         // 6 rows x 68 groups of four samples for 256 threads: both loads of a thread in flight before the first LDS store
         constexpr int G = QFM_LW / 4, N = (QFM_R + 2) * G;
@@ -1061,7 +1100,7 @@ __global__ __launch_bounds__(256) void q_mark_2x(Q3 P, K16 k)
     if (yc < height) *reinterpret_cast<uint2 *>(Q.c + (size_t)yc * pitch + x) = peak4;
     if (y >= height) return;
     uint2 *o = reinterpret_cast<uint2 *>(Q.c + (size_t)y * pitch + x);
-    if (!(y >= y0 && y < height - 1)) { *o = peak4; return; }
+    if (maskless || !(y >= y0 && y < height - 1)) { *o = peak4; return; }      // (no mask sample in the plane: nothing but the fill, :800)
     const uint16_t *d0 = Q.b + (size_t)(y - 1) * pitch + x, *d1 = d0 + 2 * (size_t)pitch;
     const uint16_t *m0 = Q.a + (size_t)(y - 1) * pitch + x, *m1 = m0 + 2 * (size_t)pitch;
     // samples x-1 .. x+4 of the two direction rows, x .. x+3 of the two mask rows
@@ -1138,6 +1177,14 @@ __global__ __launch_bounds__(256) void q_fill_gaps_b(Q3 P, K16 k)
     const int yb = ya + (y0 & 1);                                  // its rows of the rebuilt parity: yb, yb + 2, ..
     const int peak = k.peak;
     const int x = x0 + 4 * tid;
+    if (maskless)
+    {
+        // no mask sample in the plane, no gap to fill (:1048-1050): the pass is its bit_blit of a map of peaks
+        if (x < width)
+            for (int i = 0; i < 2 * QF_R && ya + i < height; i++)
+                for (int j = 0; j < 4 && x + j < width; j++) Q.c[(size_t)(ya + i) * pitch + x + j] = (uint16_t)peak;
+        return;
+    }
     auto rebuilt = [&](int y) { return y >= y0 && y < height - 1; };
     // the rows that are only copied (the reference's bit_blit)
     uint2 vcopy[2 * QF_R];
@@ -1497,6 +1544,7 @@ __global__ __launch_bounds__(256) void q_lattice_cand(Q3 P, K16 k, int nt, unsig
     const int ri = blockIdx.y;
     const int nrows = (height - (2 - field)) / 2;
     if (x0 >= width || ri >= nrows) return;
+    if (maskless) return;                                          // no direction anywhere: q_lattice_resolve16 averages by itself
     const int y = (2 - field) + 2 * ri;
     if (t < 3) s_count[t] = 0;
     if (t < 33) s_lim[t] = k.limlut[t];
@@ -1642,6 +1690,14 @@ __global__ __launch_bounds__(LR16_T) void q_lattice_resolve16(Q3 P, K16 k, const
     const int y = (2 - field) + 2 * blockIdx.y;
     uint16_t *mid = dst + (size_t)y * pitch;
     uint16_t *dm = Q.a + (size_t)y * pitch;
+    if (maskless)
+    {
+        // no mask sample in the plane: every direction is a peak, every sample of the row the rounded mean of the samples
+        // above and below it (:1192-1197), the direction row stays as it is
+        const uint16_t *top = mid - pitch, *bot = mid + pitch;
+        for (int xx = t; xx < width; xx += LR16_T) mid[xx] = (uint16_t)(((int)top[xx] + (int)bot[xx] + 1) >> 1);
+        return;
+    }
     const unsigned long long *cr = cand + (size_t)pl * cand_plane_stride + (size_t)blockIdx.y * cand_pitch;
     const bool cr16 = ((reinterpret_cast<uintptr_t>(cr)) & 15u) == 0;                   // block-uniform
     const bool row8 = ((reinterpret_cast<uintptr_t>(mid) | reinterpret_cast<uintptr_t>(dm)) & 7u) == 0;
@@ -1759,6 +1815,7 @@ __global__ __launch_bounds__(256) void q_post(Q3 P, K16 k)
     const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
     const int y = (2 - tff) + 2 * r;
     if (x >= width || y >= height - 1) return;
+    if (maskless) return;                                          // every direction a peak: the picture stays (:1364)
     const size_t at = (size_t)y * pitch + x;
     const uint2 nm4 = *reinterpret_cast<const uint2 *>(Q.a + at), om4 = *reinterpret_cast<const uint2 *>(Q.b + at);
     uint16_t *d = Q.c + at;
@@ -1893,6 +1950,7 @@ Eedi2Engine16::~Eedi2Engine16()
 {
     if (slab_) (void)hipFree(slab_);
     if (chain_flags_) (void)hipFree(chain_flags_);
+    if (plane_flags_) (void)hipFree(plane_flags_);
     for (int i = 0; i < 3; i++)
     {
         if (deriv_[i]) (void)hipFree(deriv_[i]);
@@ -1938,6 +1996,8 @@ int Eedi2Engine16::init()
     for (auto &f : full_) for (int c = 0; c < 3; c++) f.plane[c] = slab_ + (size_t)(uintptr_t)f.plane[c];
     cand_ = reinterpret_cast<unsigned long long *>(slab_ + cand_at);
     last_slot_ = cap_;                                              // "the previous mask" of the first run: zeros
+    HBHIP_CHECK(ctx_, hipMalloc((void **)&plane_flags_, sizeof(uint32_t) * 3 * EEDI_MAX_BATCH));
+    HBHIP_CHECK(ctx_, hipMemsetAsync(plane_flags_, 0, sizeof(uint32_t) * 3 * EEDI_MAX_BATCH, ctx_->stream));
     if (cap_ > 1)
     {
         // one completion flag per lower mask tile and field of a batch (MaskChain); 0 is no launch's number
@@ -2037,21 +2097,25 @@ int Eedi2Engine16::enqueue(int n, hbhip_ctx *lc)
         bind(P.a, srcp); bind(P.b, old); bind(P.c, mskp);
         const int mth = par_.magnitude_threshold * 10, vth = par_.laplacian_threshold * 81, lth = par_.variance_threshold;   // sic: swapped (decomb_template.c:390)
         const unsigned gx = (srcp.width[0] + QM_W - 1) / QM_W, gy = (srcp.height[0] + QM_H - 1) / QM_H;
+        const uint32_t epoch = ++chain_epoch_;                    // the number of this mask launch (chain flags, plane flags)
         if (n == 1)
             HBHIP_LAUNCH(lc, "eedi2_16_mask_passes", q_mask_fused, dim3(gx, gy, 3), dim3(QM_T), 0, P, S, k, 0, 0, mth, vth, lth,
-                         par_.erosion_threshold, par_.dilation_threshold);
+                         par_.erosion_threshold, par_.dilation_threshold, plane_flags_, epoch);
         else
         {
             // one launch, field-major: a field's chain tiles, then its upper tiles (see Eedi2Engine::enqueue_mask)
             MaskChain C = eedi_mask_chain_tiles(srcp, QM_W, QM_H, QM_OY);
             C.flags = chain_flags_;
-            C.epoch = ++chain_epoch_;
+            C.pflags = plane_flags_;
+            C.epoch = epoch;
             C.group = C.ntiles + C.nupper;
             HBHIP_LAUNCH(lc, "eedi2_16_mask_passes", q_mask_chain, dim3((unsigned)(C.group * n)), dim3(QM_T), 0, P, S, k, C, mth, vth, lth,
                          par_.erosion_threshold, par_.dilation_threshold);
         }
     }
     // half-height passes (decomb_template.c:398-404), all fields per launch from here on
+    P.pflags = plane_flags_;
+    P.pepoch = chain_epoch_;
     bind(P.a, mskp); bind(P.b, srcp); bind(P.c, tmpp);
     if (par_.maximum_search_distance <= QHALO - 2)
         // 256 columns x 4 rows per block, the mostly listed blocks in the dense form (eedi2.hip: Eedi2Engine::enqueue_passes);

@@ -218,6 +218,7 @@ private:
     EediFrame   full_[5];    // slot 0's DST2PF, TMP2PF2, MSK2PF, TMP2PF, DST2MPF
     uint32_t   *chain_flags_ = nullptr; // mask chain (MaskChain)
     uint32_t    chain_epoch_ = 0;
+    uint32_t   *plane_flags_ = nullptr; // [field of the batch][plane]: == chain_epoch_ when the plane's new mask has a sample set
     unsigned long long *cand_ = nullptr;   // slot 0's interpolate_lattice candidates
     int         cand_pitch_ = 0, cand_plane_stride_ = 0;
     int        *deriv_[3] = {nullptr, nullptr, nullptr};
