@@ -318,6 +318,10 @@ __device__ __forceinline__ void mask_tile(const P3 &P, const MaskSrc &S, const M
     const int start_line = (int)(((P.tffbits >> fld) & 1u) ^ 1u);
     uint8_t *srcp = P.a[pl] + foff, *newm = P.c[pl] + foff;
     const int t = threadIdx.x, fx = x0 - MF_OX, fy = y0 - MF_OY;
+    // the plane's "has a mask pixel" flag as it stands now (looked at when the tile is done: fetched here, the round trip
+    // is under the tile's work instead of behind it - 18 us of the launch otherwise)
+    uint32_t pflag_now = 0;
+    if (t == 0) pflag_now = __hip_atomic_load(C.pflags + 3 * fld + pl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // The LDS frame is MF_LR x MF_DW = 864 dwords for 512 threads: two per thread.  Both loads of a thread go out before
     // anything is done with the first (as a loop, the store of SRCPF between them made the second wait for the first:
@@ -459,7 +463,7 @@ __device__ __forceinline__ void mask_tile(const P3 &P, const MaskSrc &S, const M
     // serialise in the L2 (the mask launch went from 120 us to 2 ms with a store per wave).
     // (behind the tile's own flag: the next field's tiles wait for that one)
     const bool has = CHAIN ? eedi_chain_signal(C, fld, pl, bx, by, anyset != 0u) : (bool)__syncthreads_or(anyset != 0u);
-    if (has && t == 0 && __hip_atomic_load(C.pflags + 3 * fld + pl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != C.epoch)
+    if (has && t == 0 && pflag_now != C.epoch)                   // (a stale view costs a store the flag did not need)
         __hip_atomic_store(C.pflags + 3 * fld + pl, C.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -2214,6 +2218,9 @@ __global__ __launch_bounds__(256) void k_lattice_cand_q(P3 P, uint32_t *__restri
         else s_cand[lx] = w;
     }
     __syncthreads();
+#ifdef HBHIP_DEV_STATS
+    if (t == 0) { CD_STAT(18, s_count[0]); CD_STAT(19, s_count[1]); CD_STAT(20, s_count[2]); CD_STAT(21, 1); }
+#endif
     for (int i = t, n = s_count[2]; i < n; i += 256)
     {
         const int lx = s_list[2][i];
