@@ -318,10 +318,6 @@ __device__ __forceinline__ void mask_tile(const P3 &P, const MaskSrc &S, const M
     const int start_line = (int)(((P.tffbits >> fld) & 1u) ^ 1u);
     uint8_t *srcp = P.a[pl] + foff, *newm = P.c[pl] + foff;
     const int t = threadIdx.x, fx = x0 - MF_OX, fy = y0 - MF_OY;
-    // the plane's "has a mask pixel" flag as it stands now (looked at when the tile is done: fetched here, the round trip
-    // is under the tile's work instead of behind it - 18 us of the launch otherwise)
-    uint32_t pflag_now = 0;
-    if (t == 0) pflag_now = __hip_atomic_load(C.pflags + 3 * fld + pl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // The LDS frame is MF_LR x MF_DW = 864 dwords for 512 threads: two per thread.  Both loads of a thread go out before
     // anything is done with the first (as a loop, the store of SRCPF between them made the second wait for the first:
@@ -463,7 +459,10 @@ __device__ __forceinline__ void mask_tile(const P3 &P, const MaskSrc &S, const M
     // serialise in the L2 (the mask launch went from 120 us to 2 ms with a store per wave).
     // (behind the tile's own flag: the next field's tiles wait for that one)
     const bool has = CHAIN ? eedi_chain_signal(C, fld, pl, bx, by, anyset != 0u) : (bool)__syncthreads_or(anyset != 0u);
-    if (has && t == 0 && pflag_now != C.epoch)                   // (a stale view costs a store the flag did not need)
+    // (the look at the flag costs the workgroup a round trip at its end: 122 -> 140 us per launch.  Measured and worse:
+    // the same load at the tile's start, where it sits in front of the tile's own loads - 350 us; no look at all but
+    // a store into one of four words per plane - 257 us)
+    if (has && t == 0 && __hip_atomic_load(C.pflags + 3 * fld + pl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != C.epoch)
         __hip_atomic_store(C.pflags + 3 * fld + pl, C.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 

@@ -146,8 +146,6 @@ __device__ __forceinline__ void qmask_tile(const Q3 &P, const MaskSrc16 &S, cons
     const int start_line = (int)(((P.tffbits >> fld) & 1u) ^ 1u);
     uint16_t *srcp = P.a[pl] + foff, *newm = P.c[pl] + foff;
     const int t = threadIdx.x, fx = x0 - QM_OX, fy = y0 - QM_OY;
-    uint32_t pflag_now = 0;                                        // the plane's flag as it stands now (eedi2.hip: mask_tile)
-    if (threadIdx.x == 0) pflag_now = __hip_atomic_load(C.pflags + 3 * fld + pl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int peak = k.peak, sh = k.shift;
 
     for (int i = t; i < QM_LR * QM_DW; i += QM_T)
@@ -303,7 +301,7 @@ __device__ __forceinline__ void qmask_tile(const Q3 &P, const MaskSrc16 &S, cons
     }
     // a plane with a mask sample somewhere: say so (eedi2.hip: mask_tile)
     const bool has = CHAIN ? eedi_chain_signal(C, fld, pl, bx, by, anyset != 0u) : (bool)__syncthreads_or(anyset != 0u);
-    if (has && t == 0 && pflag_now != C.epoch)
+    if (has && t == 0 && __hip_atomic_load(C.pflags + 3 * fld + pl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != C.epoch)
         __hip_atomic_store(C.pflags + 3 * fld + pl, C.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 

@@ -28,7 +28,7 @@ timeout 200 python bench.py --workload chain --depth 10 --no-cpu-baseline --no-p
 timeout 200 python bench.py --workload nlmeans --depth 10 --no-cpu-baseline --no-pcie > $OUT/bench_nlmeans_10bit.json 2> $OUT/bench_nlmeans_10bit.err
 timeout 200 python bench.py --workload chain --stage-streams 1 --no-cpu-baseline --no-pcie --no-kernel-timer > $OUT/bench_chain_stage_streams.json 2>> $OUT/bench_default.err
 timeout 200 python bench.py --workload chain --stage-streams 0 --no-cpu-baseline --no-pcie --no-kernel-timer > $OUT/bench_chain_one_stream.json 2>> $OUT/bench_default.err
-timeout 200 python bench.py --workload chain --streams 2 --no-cpu-baseline --no-pcie --no-kernel-timer > $OUT/bench_chain_2streams.json 2>> $OUT/bench_default.err
+timeout 200 python bench.py --workload chain --streams 2 --stage-streams 0 --no-cpu-baseline --no-pcie --no-kernel-timer > $OUT/bench_chain_2streams.json 2>> $OUT/bench_default.err
 timeout 200 python bench.py --workload chain --comb-detect --no-cpu-baseline --no-pcie --no-kernel-timer > $OUT/bench_chain_combdetect.json 2>> $OUT/bench_default.err
 timeout 240 python tools/kernel_rooflines.py > $OUT/kernel_rooflines.json 2> $OUT/kernel_rooflines.err
 cd /tmp
