@@ -2804,6 +2804,7 @@ int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc)
             {
                 Q.a[c] = P.a[c] + (size_t)f * slot_bytes_; Q.b[c] = P.b[c] + (size_t)f * slot_bytes_; Q.c[c] = P.c[c] + (size_t)f * slot_bytes_;
             }
+            Q.pflags = P.pflags + 3 * f;                              // (the launch's field 0 is the batch's field f)
             HBHIP_CHECK(lc, hipMemsetAsync(work_count_, 0, sizeof(int), lc->stream));
             HBHIP_LAUNCH(lc, "eedi2_calc_directions_mark", k_calc_dir_mark, dim3((srcp.stride[0] + 63) / 64, (srcp.height[0] + 3) / 4, 3), blk, 0,
                          Q, work_list_, work_count_);

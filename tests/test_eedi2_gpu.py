@@ -69,6 +69,35 @@ def test_dense_masks_every_scratch_buffer(built, model, w, h, n):
         ctx.close()
 
 
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("model,search", [("random", 30), ("interlaced", 30), ("random", 8), ("random", 32), ("interlaced", 32)])
+def test_search_distances_every_scratch_buffer(built, depth, model, search):
+    """maximum_search_distance (decomb.c:241 sets 24; the reference takes any, and its limlut ends at 32): 30 is the widest
+    window the tiled calc_directions kernels take (a 61-step set per pixel, dense and list forms), 32 goes to the
+    work-list fallback, 8 is a window of less than a word.  Every scratch frame against the oracle."""
+    w, h, n = 640, 360, 4
+    frames = synth.stream(model, w, h, n, depth=depth)
+    ctx = hip.Ctx(0)
+    dev = hip.DecombDevice(ctx, w, h, mode=24, search=search, depth=depth)
+    oe = ol.OrcEedi2(w, h, search=search) if depth == 8 else ol.OrcEedi2_16(w, h, depth, search=search)
+    try:
+        dev.push(frames[0])
+        for t in range(1, n):
+            dev.push(frames[t])
+            for tff in (1, 0):
+                oe.run(frames[t - 1], tff)
+            while dev.pull() is not None:
+                pass
+            for b in range(9):
+                for c in range(3):
+                    np.testing.assert_array_equal(dev.eedi_plane(b, c), oe.plane(b, c),
+                                                  err_msg=f"{ol.EEDI2_BUFFERS[b]} plane {c} after frame {t - 1}")
+    finally:
+        oe.close()
+        dev.close()
+        ctx.close()
+
+
 @pytest.mark.parametrize("postproc", [2, 3])
 @pytest.mark.parametrize("w,h", [(128, 72), (322, 184), (638, 360), (1920, 1080)])
 def test_corner_postprocessing_every_scratch_buffer(built, w, h, postproc):
