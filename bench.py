@@ -703,11 +703,11 @@ def main():
                          "as BASELINE configs[2] words it")
     ap.add_argument("--no-kernel-timer", action="store_true",
                     help="chain workloads: skip the event-bracketed pass after the timed region (roofline = null)")
-    ap.add_argument("--stage-streams", type=int, default=2,
-                    help="chain workloads: 2 = decomb on one HIP stream, the stages behind it on a second (default: a batch's "
-                         "NLMeans / scaler / sharpen overlap the next batch's EEDI2, +4 %% measured); 1 = every filter of the "
-                         "chain on a stream of its own (libhb: one thread per filter; more streams than hardware queues: "
-                         "-6 %%); 0 = the whole chain on one stream")
+    ap.add_argument("--stage-streams", type=int, default=0,
+                    help="chain workloads: 0 = the whole chain on one HIP stream (default; EEDI2 itself forks the passes of a "
+                         "batch's second half onto a side stream); 2 = decomb on one stream, the stages behind it on a second "
+                         "(+2 %% before EEDI2 forked, -3.5 %% with it); 1 = every filter of the chain on a stream of its own "
+                         "(libhb: one thread per filter; more streams than hardware queues: slower still)")
     ap.add_argument("--streams", type=int, default=1,
                     help="chain workloads: independent streams (own HIP stream and filter instances) per GPU")
     ap.add_argument("--workload", default="chain", choices=sorted(WORKLOADS),

@@ -2552,6 +2552,9 @@ Eedi2Engine::~Eedi2Engine()
     if (slab_) (void)hipFree(slab_);
     if (chain_flags_) (void)hipFree(chain_flags_);
     if (plane_flags_) (void)hipFree(plane_flags_);
+    if (side_) (void)hipStreamDestroy(side_);
+    if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+    if (ev_join_) (void)hipEventDestroy(ev_join_);
     if (work_list_) (void)hipFree(work_list_);
     if (work_count_) (void)hipFree(work_count_);
     for (int i = 0; i < 3; i++)
@@ -2602,6 +2605,12 @@ int Eedi2Engine::init()
     for (auto &f : half_) for (int c = 0; c < 3; c++) f.plane[c] = slab_ + (size_t)(uintptr_t)f.plane[c];
     for (auto &f : full_) for (int c = 0; c < 3; c++) f.plane[c] = slab_ + (size_t)(uintptr_t)f.plane[c];
     cand_ = reinterpret_cast<uint32_t *>(slab_ + cand_at);
+    if (cap_ >= 8)
+    {
+        HBHIP_CHECK(ctx_, hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
+        HBHIP_CHECK(ctx_, hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+        HBHIP_CHECK(ctx_, hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+    }
     HBHIP_CHECK(ctx_, hipMalloc((void **)&plane_flags_, sizeof(uint32_t) * 3 * EEDI_MAX_BATCH));
     HBHIP_CHECK(ctx_, hipMemsetAsync(plane_flags_, 0, sizeof(uint32_t) * 3 * EEDI_MAX_BATCH, ctx_->stream));
     last_slot_ = cap_;                                             // "the previous mask" of the first run: zeros, like the reference's
@@ -2657,18 +2666,33 @@ int Eedi2Engine::add_field(const DevPicture *cur, int tff)
     return start_ + n_++;
 }
 
-// Tried and dropped: the mask chain on a (high-priority) stream of its own with the passes following it in groups of
-// 8 fields on the caller's stream.  One stream per GPU gained 2 % (the chain's short launches overlap the passes, but the
-// passes are VALU-bound and give little room); two independent streams per GPU lost half their rate (2 332 against
-// 5 282 output fps on the chain workload) - more streams than hardware queues, and a queue that holds a waiting stream
-// holds up whatever shares it.
+// (Round 3 tried the mask chain on a high-priority stream of its own with the passes following it in groups of 8 fields:
+// + 2 % on one stream per GPU, and two independent streams per GPU lost half their rate - more streams than hardware
+// queues.  What runs since round 4 is the other way round: the mask launch on the caller's stream, the passes of the
+// batch's second half beside those of its first, see below.)
 int Eedi2Engine::launch(hbhip_ctx *lc)
 {
     if (n_ == 0) return HBHIP_OK;
     const int n = n_;
     n_ = 0;
     int rc = enqueue_mask(n, lc);
-    if (rc == HBHIP_OK) rc = enqueue_passes(0, n, lc);
+    // The passes behind the mask: every field has its own slot, so two halves of a batch run them beside each other on two
+    // streams - the same kernels half a launch apart fill each other's tails and latency-bound stretches (decomb bob
+    // 10 750 -> 11 560, the chain 7 390 -> 7 640 output fps; three quarters / one quarter: 11 100 / 7 540).  Not with
+    // post-processing 2 / 3 (its derivative arrays carry values from field to field), not while the profiler brackets
+    // launches (its events live on the context's stream), not for the long-search fallback (one work list).
+    const bool fork = side_ && n >= 8 && par_.post_processing < 2 && !lc->profile && par_.maximum_search_distance <= CD_HALO - 2;
+    if (rc == HBHIP_OK && fork)
+    {
+        const int h = n / 2;
+        HBHIP_CHECK(lc, hipEventRecord(ev_fork_, lc->stream));
+        HBHIP_CHECK(lc, hipStreamWaitEvent(side_, ev_fork_, 0));
+        rc = enqueue_passes(0, h, lc, lc->stream);
+        if (rc == HBHIP_OK) rc = enqueue_passes(h, n - h, lc, side_);
+        HBHIP_CHECK(lc, hipEventRecord(ev_join_, side_));
+        HBHIP_CHECK(lc, hipStreamWaitEvent(lc->stream, ev_join_, 0));
+    }
+    else if (rc == HBHIP_OK) rc = enqueue_passes(0, n, lc, lc->stream);
     last_slot_ = start_ + n - 1;
     return rc;
 }
@@ -2716,7 +2740,7 @@ int Eedi2Engine::enqueue_mask(int n, hbhip_ctx *lc)
 
 // The pass sequence of eedi2_interpolate_plane (decomb_template.c:366-441) behind the mask passes, for the 3 planes of
 // n of the queued fields, on their scratch frames.
-int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc)
+int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st)
 {
     // fields f0 .. f0 + n - 1 of the batch
     const int s0 = start_ + f0;
@@ -2738,10 +2762,10 @@ int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc)
         // filter_dir_map sorts at most masked pixels, there the in-place form is ahead
         // step 2: a thread row per PAIR of rows (the rebuilt one and the copied one)
         const int trows = step == 1 ? f.height[0] : (f.height[0] + 1) / 2;             // thread rows
-        if (!expand) HBHIP_LAUNCH(lc, name, k_dir_map4, dim3((f.width[0] + 255) / 256, (trows + 3) / 4, gz), blk, 0, Pv, step, expand);
+        if (!expand) HBHIP_LAUNCH_ON(lc, st, name, k_dir_map4, dim3((f.width[0] + 255) / 256, (trows + 3) / 4, gz), blk, 0, Pv, step, expand);
         else
         {
-            HBHIP_LAUNCH(lc, name, k_dir_map_c, dim3((f.width[0] + 255) / 256, (trows + DC_ROWS - 1) / DC_ROWS, gz), blk, 0, Pv, step, expand, post);
+            HBHIP_LAUNCH_ON(lc, st, name, k_dir_map_c, dim3((f.width[0] + 255) / 256, (trows + DC_ROWS - 1) / DC_ROWS, gz), blk, 0, Pv, step, expand, post);
             post_folded = post != 0;
         }
     };
@@ -2774,20 +2798,20 @@ int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc)
         const int rows = hbhip_dev_int("HBHIP_EEDI2_CALCDIR_ROWS", 4);
         dense_min = hbhip_dev_int("HBHIP_EEDI2_CALCDIR_DENSE_MIN", CD_W * rows / 2);
         if (rows == 8)
-            HBHIP_LAUNCH(lc, "eedi2_calc_directions", k_calc_dir_rows<8>,
+            HBHIP_LAUNCH_ON(lc, st, "eedi2_calc_directions", k_calc_dir_rows<8>,
                          dim3((srcp.stride[0] + CD_W - 1) / CD_W, (srcp.height[0] + 7) / 8, gz), dim3(CD_W), 0, P,
                          par_.maximum_search_distance, nt13, nt19, dense_min);
         else if (rows == 6)
-            HBHIP_LAUNCH(lc, "eedi2_calc_directions", k_calc_dir_rows<6>,
+            HBHIP_LAUNCH_ON(lc, st, "eedi2_calc_directions", k_calc_dir_rows<6>,
                          dim3((srcp.stride[0] + CD_W - 1) / CD_W, (srcp.height[0] + 5) / 6, gz), dim3(CD_W), 0, P,
                          par_.maximum_search_distance, nt13, nt19, dense_min);
         else if (rows == 2)
-            HBHIP_LAUNCH(lc, "eedi2_calc_directions", k_calc_dir_rows<2>,
+            HBHIP_LAUNCH_ON(lc, st, "eedi2_calc_directions", k_calc_dir_rows<2>,
                          dim3((srcp.stride[0] + CD_W - 1) / CD_W, (srcp.height[0] + 1) / 2, gz), dim3(CD_W), 0, P,
                          par_.maximum_search_distance, nt13, nt19, dense_min);
         else
 #endif
-        HBHIP_LAUNCH(lc, "eedi2_calc_directions", k_calc_dir_rows<4>,
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_calc_directions", k_calc_dir_rows<4>,
                      dim3((srcp.stride[0] + CD_W - 1) / CD_W, (srcp.height[0] + 3) / 4, gz), dim3(CD_W), 0, P,
                      par_.maximum_search_distance, nt13, nt19, dense_min);
     }
@@ -2805,10 +2829,10 @@ int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc)
                 Q.a[c] = P.a[c] + (size_t)f * slot_bytes_; Q.b[c] = P.b[c] + (size_t)f * slot_bytes_; Q.c[c] = P.c[c] + (size_t)f * slot_bytes_;
             }
             Q.pflags = P.pflags + 3 * f;                              // (the launch's field 0 is the batch's field f)
-            HBHIP_CHECK(lc, hipMemsetAsync(work_count_, 0, sizeof(int), lc->stream));
-            HBHIP_LAUNCH(lc, "eedi2_calc_directions_mark", k_calc_dir_mark, dim3((srcp.stride[0] + 63) / 64, (srcp.height[0] + 3) / 4, 3), blk, 0,
+            HBHIP_CHECK(lc, hipMemsetAsync(work_count_, 0, sizeof(int), st));
+            HBHIP_LAUNCH_ON(lc, st, "eedi2_calc_directions_mark", k_calc_dir_mark, dim3((srcp.stride[0] + 63) / 64, (srcp.height[0] + 3) / 4, 3), blk, 0,
                          Q, work_list_, work_count_);
-            HBHIP_LAUNCH(lc, "eedi2_calc_directions_work", k_calc_dir_work, dim3((unsigned)((half_px + 255) / 256)), dim3(256), 0, Q,
+            HBHIP_LAUNCH_ON(lc, st, "eedi2_calc_directions_work", k_calc_dir_work, dim3((unsigned)((half_px + 255) / 256)), dim3(256), 0, Q,
                          (const uint32_t *)work_list_, (const int *)work_count_, par_.maximum_search_distance, nt13, nt19);
         }
     }
@@ -2817,12 +2841,12 @@ int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc)
     bind(P.a, mskp); bind(P.b, dstp); bind(P.c, tmpp);
     dir_map("eedi2_expand_dir_map", srcp, P, 1, 1);
     bind(P.a, mskp); bind(P.b, tmpp); bind(P.c, dstp);
-    HBHIP_LAUNCH(lc, "eedi2_filter_map", k_filter_map, grid4_for(srcp, false), blk, 0, P);
+    HBHIP_LAUNCH_ON(lc, st, "eedi2_filter_map", k_filter_map, grid4_for(srcp, false), blk, 0, P);
     // line doubling of srcp / dstp / mskp + mark_directions_2x in one launch (full-height geometry)
     geom(P, dst2p);
     bind(P.g, srcp); bind(P.b, dstp); bind(P.a, mskp);
     bind(P.d, dst2p); bind(P.e, tmp2p2); bind(P.f, msk2p); bind(P.c, tmp2p);
-    HBHIP_LAUNCH(lc, "eedi2_mark_directions_2x", k_mark_2x4,                                      // a thread row per PAIR of full-height rows
+    HBHIP_LAUNCH_ON(lc, st, "eedi2_mark_directions_2x", k_mark_2x4,                                      // a thread row per PAIR of full-height rows
                  dim3((dst2p.stride[0] + 255) / 256, ((dst2p.height[0] + 1) / 2 + 3) / 4, gz), blk, 0, P);
     for (int c = 0; c < 3; c++) P.d[c] = P.e[c] = P.f[c] = P.g[c] = nullptr;    // slot d doubles as the dir-map kernels' optional copy target
     bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
@@ -2833,17 +2857,17 @@ int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc)
     // passes, this kernel went from 131 to 163-165 us per launch)
     const dim3 fg_grid((dst2p.width[0] + FG_W - 1) / FG_W, (dst2p.height[0] + 2 * FG_R - 1) / (2 * FG_R), gz);
     bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
-    HBHIP_LAUNCH(lc, "eedi2_fill_gaps_2x", k_fill_gaps_b, fg_grid, dim3(256), 0, P);
+    HBHIP_LAUNCH_ON(lc, st, "eedi2_fill_gaps_2x", k_fill_gaps_b, fg_grid, dim3(256), 0, P);
     bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
-    HBHIP_LAUNCH(lc, "eedi2_fill_gaps_2x", k_fill_gaps_b, fg_grid, dim3(256), 0, P);
+    HBHIP_LAUNCH_ON(lc, st, "eedi2_fill_gaps_2x", k_fill_gaps_b, fg_grid, dim3(256), 0, P);
     // lattice
     bind(P.a, tmp2p); bind(P.b, dst2p); bind(P.c, tmp2p2);
     {
         const int nrows = (dst2p.height[0] - 1) / 2;      // rows y0, y0 + 2, ... < height - 1 for either parity (the heights are even)
         const int nt = par_.noise_threshold;
-        HBHIP_LAUNCH(lc, "eedi2_lattice_candidates", k_lattice_cand_q, dim3((dst2p.width[0] + LQ_W - 1) / LQ_W, nrows, gz),
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_lattice_candidates", k_lattice_cand_q, dim3((dst2p.width[0] + LQ_W - 1) / LQ_W, nrows, gz),
                      dim3(256), 0, P, cand, cand_pitch_, cand_plane_stride_, (nt * 4) & 0xff, (nt * 7) & 0xff, (nt * 8) & 0xff, nt);
-        HBHIP_LAUNCH(lc, "eedi2_lattice_resolve", k_lattice_resolve, dim3(1, nrows + 1, gz), dim3(LR_T), 0, P,
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_lattice_resolve", k_lattice_resolve, dim3(1, nrows + 1, gz), dim3(LR_T), 0, P,
                      (const uint32_t *)cand, cand_pitch_, cand_plane_stride_);
     }
     if (par_.post_processing == 1 || par_.post_processing == 3)
@@ -2858,7 +2882,7 @@ int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc)
         dir_map("eedi2_expand_dir_map_2x", dst2p, P, 2, 1, 1);                          // + post_process where the kernel can carry it
         for (int c = 0; c < 3; c++) P.e[c] = P.f[c] = nullptr;
         bind(P.a, tmp2p); bind(P.b, tmp2p2); bind(P.c, dst2p);
-        if (!post_folded) HBHIP_LAUNCH(lc, "eedi2_post_process", k_post, grid4_for(dst2p, false), blk, 0, P);
+        if (!post_folded) HBHIP_LAUNCH_ON(lc, st, "eedi2_post_process", k_post, grid4_for(dst2p, false), blk, 0, P);
     }
     if (par_.post_processing == 2 || par_.post_processing == 3)
     {
@@ -2875,14 +2899,14 @@ int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc)
                 for (int i = 0; i < 3; i++) { A.c[i] = deriv_[i]; A.t[i] = deriv_tmp_[i]; }
                 A.pitch = srcp.stride[c]; A.width = srcp.width[c]; A.height = srcp.height[c];
                 const dim3 g1((A.width + 63) / 64, (A.height + 3) / 4, 1), g3(g1.x, g1.y, 3);
-                HBHIP_LAUNCH(lc, "eedi2_gaussian_blur1_h", k_blur1<false>, g1, blk, 0, A);
-                HBHIP_LAUNCH(lc, "eedi2_gaussian_blur1_v", k_blur1<true>, g1, blk, 0, A);
-                HBHIP_LAUNCH(lc, "eedi2_calc_derivatives", k_derivatives, g1, blk, 0, A);
-                HBHIP_LAUNCH(lc, "eedi2_gaussian_blur_sqrt2_h", k_blur_sqrt2<false>, g3, blk, 0, A);
-                HBHIP_LAUNCH(lc, "eedi2_gaussian_blur_sqrt2_v", k_blur_sqrt2<true>, g3, blk, 0, A);
+                HBHIP_LAUNCH_ON(lc, st, "eedi2_gaussian_blur1_h", k_blur1<false>, g1, blk, 0, A);
+                HBHIP_LAUNCH_ON(lc, st, "eedi2_gaussian_blur1_v", k_blur1<true>, g1, blk, 0, A);
+                HBHIP_LAUNCH_ON(lc, st, "eedi2_calc_derivatives", k_derivatives, g1, blk, 0, A);
+                HBHIP_LAUNCH_ON(lc, st, "eedi2_gaussian_blur_sqrt2_h", k_blur_sqrt2<false>, g3, blk, 0, A);
+                HBHIP_LAUNCH_ON(lc, st, "eedi2_gaussian_blur_sqrt2_v", k_blur_sqrt2<true>, g3, blk, 0, A);
                 const int rows = (dst2p.height[c] - 7 - (8 - tff) + 1) / 2;      // y = 8-field, 10-field, ... < height-7
                 if (rows > 0)
-                    HBHIP_LAUNCH(lc, "eedi2_post_process_corner", k_post_corner, dim3((A.width + 63) / 64, (rows + 3) / 4, 1), blk, 0, A,
+                    HBHIP_LAUNCH_ON(lc, st, "eedi2_post_process_corner", k_post_corner, dim3((A.width + 63) / 64, (rows + 3) / 4, 1), blk, 0, A,
                                  (const uint8_t *)(tmp2p2.plane[c] + foff), dst2p.plane[c] + foff, tff, dst2p.height[c]);
             }
         }

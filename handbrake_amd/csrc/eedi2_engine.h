@@ -160,7 +160,7 @@ private:
     size_t place_frame(EediFrame &f, int width, int height, size_t at);
     EediFrame at_slot(const EediFrame &f, int slot) const;
     int enqueue_mask(int n, hbhip_ctx *lc);                 // the five mask passes (+ the field extraction)
-    int enqueue_passes(int f0, int n, hbhip_ctx *lc);       // everything after them, fields f0 .. f0 + n - 1 of the batch
+    int enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st);   // everything after them, fields f0 .. f0 + n - 1 of the batch, on st
     hbhip_ctx  *ctx_;
     PicGeometry geo_;
     Eedi2Params par_;
@@ -175,6 +175,8 @@ private:
     uint32_t   *chain_flags_ = nullptr; // mask chain: one completion flag per lower tile and field of a batch
     uint32_t    chain_epoch_ = 0;       //             the number of the last mask launch
     uint32_t   *plane_flags_ = nullptr; // [field of the batch][plane]: == chain_epoch_ when the plane's new mask has a pixel set
+    hipStream_t side_ = nullptr;        // the second half of a batch's fields runs its passes here, beside the first half's
+    hipEvent_t  ev_fork_ = nullptr, ev_join_ = nullptr;
     uint32_t   *work_list_ = nullptr;   // calc_directions fallback: compacted edge pixels
     int        *work_count_ = nullptr;
     uint32_t   *cand_ = nullptr;        // slot 0's interpolate_lattice candidates

@@ -141,6 +141,14 @@ static inline bool hbhip_skip_launch(const char *name)
             hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__); \
     } while (0)
 
+// The same on a stream of the caller's choosing: the context's own (then it IS HBHIP_LAUNCH) or a side stream that the
+// caller has ordered against it with events (no profiling brackets, no idle marks: neither lives on a side stream).
+#define HBHIP_LAUNCH_ON(ctx, strm, name, kernel, grid, block, shmem, ...)       \
+    do {                                                                        \
+        if ((strm) == (ctx)->stream) HBHIP_LAUNCH(ctx, name, kernel, grid, block, shmem, __VA_ARGS__); \
+        else if (!hbhip_skip_launch(name)) hipLaunchKernelGGL(kernel, grid, block, shmem, (strm), __VA_ARGS__); \
+    } while (0)
+
 static inline int hbhip_align_up(int v, int a) { return (v + a - 1) / a * a; }
 
 // One planar picture in HBM (a single allocation, planes 256-byte aligned).
