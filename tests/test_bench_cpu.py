@@ -13,7 +13,9 @@ import bench  # noqa: E402
 
 
 def _launch_names(path):
-    return set(re.findall(r'HBHIP_LAUNCH\(\s*\w+,\s*"([a-z0-9_]+)"', open(path).read()))
+    text = open(path).read()
+    return set(re.findall(r'HBHIP_LAUNCH\(\s*\w+,\s*"([a-z0-9_]+)"', text)) | \
+        set(re.findall(r'HBHIP_LAUNCH_ON\(\s*\w+,\s*\w+,\s*"([a-z0-9_]+)"', text))
 
 
 def test_every_8bit_eedi2_pass_has_algorithmic_bytes():
