@@ -1951,6 +1951,9 @@ Eedi2Engine16::~Eedi2Engine16()
     if (slab_) (void)hipFree(slab_);
     if (chain_flags_) (void)hipFree(chain_flags_);
     if (plane_flags_) (void)hipFree(plane_flags_);
+    if (side_) (void)hipStreamDestroy(side_);
+    if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+    if (ev_join_) (void)hipEventDestroy(ev_join_);
     for (int i = 0; i < 3; i++)
     {
         if (deriv_[i]) (void)hipFree(deriv_[i]);
@@ -1996,6 +1999,12 @@ int Eedi2Engine16::init()
     for (auto &f : full_) for (int c = 0; c < 3; c++) f.plane[c] = slab_ + (size_t)(uintptr_t)f.plane[c];
     cand_ = reinterpret_cast<unsigned long long *>(slab_ + cand_at);
     last_slot_ = cap_;                                              // "the previous mask" of the first run: zeros
+    if (cap_ >= 8)
+    {
+        HBHIP_CHECK(ctx_, hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
+        HBHIP_CHECK(ctx_, hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+        HBHIP_CHECK(ctx_, hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+    }
     HBHIP_CHECK(ctx_, hipMalloc((void **)&plane_flags_, sizeof(uint32_t) * 3 * EEDI_MAX_BATCH));
     HBHIP_CHECK(ctx_, hipMemsetAsync(plane_flags_, 0, sizeof(uint32_t) * 3 * EEDI_MAX_BATCH, ctx_->stream));
     if (cap_ > 1)
@@ -2046,41 +2055,30 @@ int Eedi2Engine16::launch(hbhip_ctx *lc)
     return rc;
 }
 
-int Eedi2Engine16::enqueue(int n, hbhip_ctx *lc)
+// the per-depth constants the kernels take (eedi2_init_limlut :23-33)
+static K16 make_k16(int depth)
 {
-    const EediFrame srcp = at_slot(half_[0], start_), mskp = at_slot(half_[1], start_), tmpp = at_slot(half_[2], start_),
-                    dstp = at_slot(half_[3], start_);
-    const EediFrame dst2p = at_slot(full_[0], start_), tmp2p2 = at_slot(full_[1], start_), msk2p = at_slot(full_[2], start_),
-                    tmp2p = at_slot(full_[3], start_), dst2mp = at_slot(full_[4], start_);
-    unsigned long long *cand = cand_ + (size_t)start_ * (slot_bytes_ / sizeof(unsigned long long));
     K16 k;
-    k.shift = geo_.depth - 8;
-    k.peak = (1 << geo_.depth) - 1;
-    k.neutral = 1 << (geo_.depth - 1);
+    k.shift = depth - 8;
+    k.peak = (1 << depth) - 1;
+    k.neutral = 1 << (depth - 1);
     static const int base[33] = { 6, 6, 7, 7, 8, 8, 9, 9, 9, 10, 10, 11, 11, 12, 12, 12, 12, 12, 12, 12,
                                   12, 12, 12, 12, 12, 12, 12, 12, 12, 12, 12, -1, -1 };        // eedi2.c:21-25
     for (int i = 0; i < 33; i++) k.limlut[i] = (uint16_t)((uint16_t)base[i] << k.shift);
+    return k;
+}
 
-    const dim3 blk(64, 4);
-    const unsigned gz = 3u * (unsigned)n;
+// The field extraction and the mask passes of the n queued fields on lc's stream, then the passes behind them: for the
+// whole batch on the same stream, or for its two halves beside each other on two (Eedi2Engine::launch in eedi2.hip has
+// the why and the when).
+int Eedi2Engine16::enqueue(int n, hbhip_ctx *lc)
+{
+    const EediFrame srcp = at_slot(half_[0], start_), mskp = at_slot(half_[1], start_);
+    const K16 k = make_k16(geo_.depth);
     auto geom = [&](Q3 &P, const EediFrame &f) {
         for (int c = 0; c < 3; c++) { P.pitch[c] = f.stride[c] / 2; P.width[c] = f.width[c]; P.height[c] = f.height[c]; }
     };
     auto bind = [&](uint16_t *(&slot)[3], const EediFrame &f) { for (int c = 0; c < 3; c++) slot[c] = (uint16_t *)f.plane[c]; };
-    auto grid = [&](const EediFrame &f, bool whole_pitch, unsigned z) {
-        const int w = whole_pitch ? f.stride[0] / 2 : f.width[0];
-        return dim3((w + 63) / 64, (f.height[0] + 3) / 4, z);
-    };
-    auto grid4 = [&](const EediFrame &f, unsigned z) {                          // four samples per thread, blocks of 64 x 4 threads
-        return dim3((f.width[0] + 255) / 256, (f.height[0] + 3) / 4, z);
-    };
-    auto grid4p = [&](const EediFrame &f, unsigned z) {                         // the same with a thread row per PAIR of rows (step 2)
-        return dim3((f.width[0] + 255) / 256, ((f.height[0] + 1) / 2 + 3) / 4, z);
-    };
-    auto grid8 = [&](const EediFrame &f, bool whole_pitch, unsigned z) {      // kernels with eight samples per thread
-        const int w = whole_pitch ? f.stride[0] / 2 : f.width[0];
-        return dim3((w + 511) / 512, (f.height[0] + 3) / 4, z);
-    };
     Q3 P;
     memset(&P, 0, sizeof(P));
     P.fstride = slot_bytes_ / 2;
@@ -2113,63 +2111,111 @@ int Eedi2Engine16::enqueue(int n, hbhip_ctx *lc)
                          par_.erosion_threshold, par_.dilation_threshold);
         }
     }
+    const bool fork = side_ && n >= 8 && par_.post_processing < 2 && !lc->profile;
+    if (!fork) return enqueue_passes(0, n, lc, lc->stream);
+    const int h = n / 2;
+    HBHIP_CHECK(lc, hipEventRecord(ev_fork_, lc->stream));
+    HBHIP_CHECK(lc, hipStreamWaitEvent(side_, ev_fork_, 0));
+    int rc = enqueue_passes(0, h, lc, lc->stream);
+    if (rc == HBHIP_OK) rc = enqueue_passes(h, n - h, lc, side_);
+    HBHIP_CHECK(lc, hipEventRecord(ev_join_, side_));
+    HBHIP_CHECK(lc, hipStreamWaitEvent(lc->stream, ev_join_, 0));
+    return rc;
+}
+
+// the passes behind the mask for fields f0 .. f0 + n - 1 of the batch, on st
+int Eedi2Engine16::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st)
+{
+    const EediFrame srcp = at_slot(half_[0], start_ + f0), mskp = at_slot(half_[1], start_ + f0), tmpp = at_slot(half_[2], start_ + f0),
+                    dstp = at_slot(half_[3], start_ + f0);
+    const EediFrame dst2p = at_slot(full_[0], start_ + f0), tmp2p2 = at_slot(full_[1], start_ + f0), msk2p = at_slot(full_[2], start_ + f0),
+                    tmp2p = at_slot(full_[3], start_ + f0), dst2mp = at_slot(full_[4], start_ + f0);
+    unsigned long long *cand = cand_ + (size_t)(start_ + f0) * (slot_bytes_ / sizeof(unsigned long long));
+    const K16 k = make_k16(geo_.depth);
+
+    const dim3 blk(64, 4);
+    const unsigned gz = 3u * (unsigned)n;
+    auto geom = [&](Q3 &P, const EediFrame &f) {
+        for (int c = 0; c < 3; c++) { P.pitch[c] = f.stride[c] / 2; P.width[c] = f.width[c]; P.height[c] = f.height[c]; }
+    };
+    auto bind = [&](uint16_t *(&slot)[3], const EediFrame &f) { for (int c = 0; c < 3; c++) slot[c] = (uint16_t *)f.plane[c]; };
+    auto grid = [&](const EediFrame &f, bool whole_pitch, unsigned z) {
+        const int w = whole_pitch ? f.stride[0] / 2 : f.width[0];
+        return dim3((w + 63) / 64, (f.height[0] + 3) / 4, z);
+    };
+    auto grid4 = [&](const EediFrame &f, unsigned z) {                          // four samples per thread, blocks of 64 x 4 threads
+        return dim3((f.width[0] + 255) / 256, (f.height[0] + 3) / 4, z);
+    };
+    auto grid4p = [&](const EediFrame &f, unsigned z) {                         // the same with a thread row per PAIR of rows (step 2)
+        return dim3((f.width[0] + 255) / 256, ((f.height[0] + 1) / 2 + 3) / 4, z);
+    };
+    auto grid8 = [&](const EediFrame &f, bool whole_pitch, unsigned z) {      // kernels with eight samples per thread
+        const int w = whole_pitch ? f.stride[0] / 2 : f.width[0];
+        return dim3((w + 511) / 512, (f.height[0] + 3) / 4, z);
+    };
+    Q3 P;
+    memset(&P, 0, sizeof(P));
+    P.fstride = slot_bytes_ / 2;
+    P.tffbits = tffbits_ >> f0;
+
     // half-height passes (decomb_template.c:398-404), all fields per launch from here on
-    P.pflags = plane_flags_;
+    geom(P, srcp);
+    P.pflags = plane_flags_ + 3 * f0;
     P.pepoch = chain_epoch_;
     bind(P.a, mskp); bind(P.b, srcp); bind(P.c, tmpp);
     if (par_.maximum_search_distance <= QHALO - 2)
         // 256 columns x 4 rows per block, the mostly listed blocks in the dense form (eedi2.hip: Eedi2Engine::enqueue_passes);
         // its keys hold sums of 12-bit samples at most
-        HBHIP_LAUNCH(lc, "eedi2_16_calc_directions", q_calc_dir_rows<4>, dim3((srcp.stride[0] / 2 + QW - 1) / QW, (srcp.height[0] + 3) / 4, gz),
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_calc_directions", q_calc_dir_rows<4>, dim3((srcp.stride[0] / 2 + QW - 1) / QW, (srcp.height[0] + 3) / 4, gz),
                      dim3(QW), 0, P, k, par_.maximum_search_distance, par_.noise_threshold, k.peak < (1 << 12) ? QW * 4 / 2 : 1 << 30);
     else
-        HBHIP_LAUNCH(lc, "eedi2_16_calc_directions", q_calc_dir, grid(srcp, true, gz), blk, 0, P, k, par_.maximum_search_distance, par_.noise_threshold);
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_calc_directions", q_calc_dir, grid(srcp, true, gz), blk, 0, P, k, par_.maximum_search_distance, par_.noise_threshold);
     bind(P.a, mskp); bind(P.b, tmpp); bind(P.c, dstp);
-    HBHIP_LAUNCH(lc, "eedi2_16_filter_dir_map", q_dir_map, grid4(srcp, gz), blk, 0, P, k, 1, 0);
+    HBHIP_LAUNCH_ON(lc, st, "eedi2_16_filter_dir_map", q_dir_map, grid4(srcp, gz), blk, 0, P, k, 1, 0);
     bind(P.a, mskp); bind(P.b, dstp); bind(P.c, tmpp);
-    HBHIP_LAUNCH(lc, "eedi2_16_expand_dir_map", q_dir_map, grid4(srcp, gz), blk, 0, P, k, 1, 1);
+    HBHIP_LAUNCH_ON(lc, st, "eedi2_16_expand_dir_map", q_dir_map, grid4(srcp, gz), blk, 0, P, k, 1, 1);
     bind(P.a, mskp); bind(P.b, tmpp); bind(P.c, dstp);
-    HBHIP_LAUNCH(lc, "eedi2_16_filter_map", q_filter_map, grid4(srcp, gz), blk, 0, P, k);
+    HBHIP_LAUNCH_ON(lc, st, "eedi2_16_filter_map", q_filter_map, grid4(srcp, gz), blk, 0, P, k);
     // line doubling
     bind(P.a, srcp); bind(P.c, dst2p);
-    HBHIP_LAUNCH(lc, "eedi2_16_upscale", q_upscale, grid8(srcp, true, gz), blk, 0, P);
+    HBHIP_LAUNCH_ON(lc, st, "eedi2_16_upscale", q_upscale, grid8(srcp, true, gz), blk, 0, P);
     bind(P.a, dstp); bind(P.c, tmp2p2);
-    HBHIP_LAUNCH(lc, "eedi2_16_upscale", q_upscale, grid8(srcp, true, gz), blk, 0, P);
+    HBHIP_LAUNCH_ON(lc, st, "eedi2_16_upscale", q_upscale, grid8(srcp, true, gz), blk, 0, P);
     bind(P.a, mskp); bind(P.c, msk2p);
-    HBHIP_LAUNCH(lc, "eedi2_16_upscale", q_upscale, grid8(srcp, true, gz), blk, 0, P);
+    HBHIP_LAUNCH_ON(lc, st, "eedi2_16_upscale", q_upscale, grid8(srcp, true, gz), blk, 0, P);
     // full-height passes
     geom(P, dst2p);
     bind(P.a, msk2p); bind(P.b, tmp2p2); bind(P.c, tmp2p);
-    HBHIP_LAUNCH(lc, "eedi2_16_mark_directions_2x", q_mark_2x,                                    // a thread row per pair of rows, four samples per thread
+    HBHIP_LAUNCH_ON(lc, st, "eedi2_16_mark_directions_2x", q_mark_2x,                                    // a thread row per pair of rows, four samples per thread
                  dim3((dst2p.stride[0] / 2 + 255) / 256, ((dst2p.height[0] + 1) / 2 + 3) / 4, gz), blk, 0, P, k);
     bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
-    HBHIP_LAUNCH(lc, "eedi2_16_filter_dir_map_2x", q_dir_map, grid4p(dst2p, gz), blk, 0, P, k, 2, 0);
+    HBHIP_LAUNCH_ON(lc, st, "eedi2_16_filter_dir_map_2x", q_dir_map, grid4p(dst2p, gz), blk, 0, P, k, 2, 0);
     bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
-    HBHIP_LAUNCH(lc, "eedi2_16_expand_dir_map_2x", q_dir_map, grid4p(dst2p, gz), blk, 0, P, k, 2, 1);
+    HBHIP_LAUNCH_ON(lc, st, "eedi2_16_expand_dir_map_2x", q_dir_map, grid4p(dst2p, gz), blk, 0, P, k, 2, 1);
     for (int pass = 0; pass < 2; pass++)
     {
         const EediFrame &in = pass ? dst2mp : tmp2p, &out = pass ? tmp2p : dst2mp;
         bind(P.a, msk2p); bind(P.b, in); bind(P.c, out);
-        HBHIP_LAUNCH(lc, "eedi2_16_fill_gaps_2x", q_fill_gaps_b, dim3((dst2p.width[0] + QF_W - 1) / QF_W, (dst2p.height[0] + 2 * QF_R - 1) / (2 * QF_R), gz), dim3(256), 0, P, k);
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_fill_gaps_2x", q_fill_gaps_b, dim3((dst2p.width[0] + QF_W - 1) / QF_W, (dst2p.height[0] + 2 * QF_R - 1) / (2 * QF_R), gz), dim3(256), 0, P, k);
     }
     bind(P.a, tmp2p); bind(P.b, dst2p); bind(P.c, tmp2p2);
     {
         const int nrows = (dst2p.height[0] - 1) / 2;                // rows y0, y0 + 2, ... < height - 1 for either parity (even heights)
-        HBHIP_LAUNCH(lc, "eedi2_16_lattice_candidates", q_lattice_cand, dim3((dst2p.width[0] + LQ16_W - 1) / LQ16_W, nrows, gz), dim3(256), 0, P, k,
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_lattice_candidates", q_lattice_cand, dim3((dst2p.width[0] + LQ16_W - 1) / LQ16_W, nrows, gz), dim3(256), 0, P, k,
                      par_.noise_threshold, cand, cand_pitch_, cand_plane_stride_);
-        HBHIP_LAUNCH(lc, "eedi2_16_lattice_resolve", q_lattice_resolve16, dim3(1, nrows + 1, gz), dim3(LR16_T), 0, P, k,
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_lattice_resolve", q_lattice_resolve16, dim3(1, nrows + 1, gz), dim3(LR16_T), 0, P, k,
                      (const unsigned long long *)cand, cand_pitch_, cand_plane_stride_);
     }
     if (par_.post_processing == 1 || par_.post_processing == 3)
     {
         bind(P.a, tmp2p); bind(P.c, tmp2p2);
-        HBHIP_LAUNCH(lc, "eedi2_16_blit", q_blit, grid8(dst2p, false, gz), blk, 0, P);             // eedi2_bit_blit(tmp2p -> tmp2p2)
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_blit", q_blit, grid8(dst2p, false, gz), blk, 0, P);             // eedi2_bit_blit(tmp2p -> tmp2p2)
         bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
-        HBHIP_LAUNCH(lc, "eedi2_16_filter_dir_map_2x", q_dir_map, grid4p(dst2p, gz), blk, 0, P, k, 2, 0);
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_filter_dir_map_2x", q_dir_map, grid4p(dst2p, gz), blk, 0, P, k, 2, 0);
         bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
-        HBHIP_LAUNCH(lc, "eedi2_16_expand_dir_map_2x", q_dir_map, grid4p(dst2p, gz), blk, 0, P, k, 2, 1);
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_expand_dir_map_2x", q_dir_map, grid4p(dst2p, gz), blk, 0, P, k, 2, 1);
         bind(P.a, tmp2p); bind(P.b, tmp2p2); bind(P.c, dst2p);
-        HBHIP_LAUNCH(lc, "eedi2_16_post_process", q_post, grid4p(dst2p, gz), blk, 0, P, k);
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_post_process", q_post, grid4p(dst2p, gz), blk, 0, P, k);
     }
     if (par_.post_processing == 2 || par_.post_processing == 3)
     {
@@ -2185,14 +2231,14 @@ int Eedi2Engine16::enqueue(int n, hbhip_ctx *lc)
                 for (int i = 0; i < 3; i++) { A.c[i] = deriv_[i]; A.t[i] = deriv_tmp_[i]; }
                 A.pitch = srcp.stride[c] / 2; A.width = srcp.width[c]; A.height = srcp.height[c];
                 const dim3 g1((A.width + 63) / 64, (A.height + 3) / 4, 1), g3(g1.x, g1.y, 3);
-                HBHIP_LAUNCH(lc, "eedi2_16_gaussian_blur1_h", q_blur1<false>, g1, blk, 0, A);
-                HBHIP_LAUNCH(lc, "eedi2_16_gaussian_blur1_v", q_blur1<true>, g1, blk, 0, A);
-                HBHIP_LAUNCH(lc, "eedi2_16_calc_derivatives", q_derivatives, g1, blk, 0, A, k.shift);
-                HBHIP_LAUNCH(lc, "eedi2_16_gaussian_blur_sqrt2_h", q_blur_sqrt2<false>, g3, blk, 0, A);
-                HBHIP_LAUNCH(lc, "eedi2_16_gaussian_blur_sqrt2_v", q_blur_sqrt2<true>, g3, blk, 0, A);
+                HBHIP_LAUNCH_ON(lc, st, "eedi2_16_gaussian_blur1_h", q_blur1<false>, g1, blk, 0, A);
+                HBHIP_LAUNCH_ON(lc, st, "eedi2_16_gaussian_blur1_v", q_blur1<true>, g1, blk, 0, A);
+                HBHIP_LAUNCH_ON(lc, st, "eedi2_16_calc_derivatives", q_derivatives, g1, blk, 0, A, k.shift);
+                HBHIP_LAUNCH_ON(lc, st, "eedi2_16_gaussian_blur_sqrt2_h", q_blur_sqrt2<false>, g3, blk, 0, A);
+                HBHIP_LAUNCH_ON(lc, st, "eedi2_16_gaussian_blur_sqrt2_v", q_blur_sqrt2<true>, g3, blk, 0, A);
                 const int rows = (dst2p.height[c] - 7 - (8 - tff) + 1) / 2;
                 if (rows > 0)
-                    HBHIP_LAUNCH(lc, "eedi2_16_post_process_corner", q_post_corner, dim3((A.width + 63) / 64, (rows + 3) / 4, 1), blk, 0, A,
+                    HBHIP_LAUNCH_ON(lc, st, "eedi2_16_post_process_corner", q_post_corner, dim3((A.width + 63) / 64, (rows + 3) / 4, 1), blk, 0, A,
                                  (const uint16_t *)(tmp2p2.plane[c] + foff), (uint16_t *)(dst2p.plane[c] + foff), tff, dst2p.height[c], k.peak, k.neutral);
             }
         }

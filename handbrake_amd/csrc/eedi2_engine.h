@@ -207,6 +207,7 @@ private:
     size_t place_frame(EediFrame &f, int width, int height, size_t at);
     EediFrame at_slot(const EediFrame &f, int slot) const;
     int enqueue(int n, hbhip_ctx *lc);
+    int enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st);
     hbhip_ctx  *ctx_;
     PicGeometry geo_;
     Eedi2Params par_;
@@ -221,6 +222,8 @@ private:
     uint32_t   *chain_flags_ = nullptr; // mask chain (MaskChain)
     uint32_t    chain_epoch_ = 0;
     uint32_t   *plane_flags_ = nullptr; // [field of the batch][plane]: == chain_epoch_ when the plane's new mask has a sample set
+    hipStream_t side_ = nullptr;        // the second half of a batch's fields runs its passes here (Eedi2Engine::side_)
+    hipEvent_t  ev_fork_ = nullptr, ev_join_ = nullptr;
     unsigned long long *cand_ = nullptr;   // slot 0's interpolate_lattice candidates
     int         cand_pitch_ = 0, cand_plane_stride_ = 0;
     int        *deriv_[3] = {nullptr, nullptr, nullptr};
