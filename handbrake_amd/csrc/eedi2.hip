@@ -2552,9 +2552,12 @@ Eedi2Engine::~Eedi2Engine()
     if (slab_) (void)hipFree(slab_);
     if (chain_flags_) (void)hipFree(chain_flags_);
     if (plane_flags_) (void)hipFree(plane_flags_);
-    if (side_) (void)hipStreamDestroy(side_);
+    for (int g = 0; g < MAX_SIDE; g++)
+    {
+        if (side_[g]) (void)hipStreamDestroy(side_[g]);
+        if (ev_join_[g]) (void)hipEventDestroy(ev_join_[g]);
+    }
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
-    if (ev_join_) (void)hipEventDestroy(ev_join_);
     if (work_list_) (void)hipFree(work_list_);
     if (work_count_) (void)hipFree(work_count_);
     for (int i = 0; i < 3; i++)
@@ -2607,9 +2610,13 @@ int Eedi2Engine::init()
     cand_ = reinterpret_cast<uint32_t *>(slab_ + cand_at);
     if (cap_ >= 8)
     {
-        HBHIP_CHECK(ctx_, hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
+        const int sides = std::min(hbhip_dev_int("HBHIP_EEDI2_GROUPS", 2), MAX_SIDE + 1) - 1;
         HBHIP_CHECK(ctx_, hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
-        HBHIP_CHECK(ctx_, hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+        for (int g = 0; g < sides; g++)
+        {
+            HBHIP_CHECK(ctx_, hipStreamCreateWithFlags(&side_[g], hipStreamNonBlocking));
+            HBHIP_CHECK(ctx_, hipEventCreateWithFlags(&ev_join_[g], hipEventDisableTiming));
+        }
     }
     HBHIP_CHECK(ctx_, hipMalloc((void **)&plane_flags_, sizeof(uint32_t) * 3 * EEDI_MAX_BATCH));
     HBHIP_CHECK(ctx_, hipMemsetAsync(plane_flags_, 0, sizeof(uint32_t) * 3 * EEDI_MAX_BATCH, ctx_->stream));
@@ -2678,19 +2685,27 @@ int Eedi2Engine::launch(hbhip_ctx *lc)
     int rc = enqueue_mask(n, lc);
     // The passes behind the mask: every field has its own slot, so two halves of a batch run them beside each other on two
     // streams - the same kernels half a launch apart fill each other's tails and latency-bound stretches (decomb bob
-    // 10 750 -> 11 560, the chain 7 390 -> 7 640 output fps; three quarters / one quarter: 11 100 / 7 540).  Not with
+    // 10 750 -> 11 560, the chain 7 390 -> 7 640 output fps; three quarters / one quarter: 11 100 / 7 540; three
+    // groups on three streams + 1.5 %, four - 9 %: development knob HBHIP_EEDI2_GROUPS).  Not with
     // post-processing 2 / 3 (its derivative arrays carry values from field to field), not while the profiler brackets
     // launches (its events live on the context's stream), not for the long-search fallback (one work list).
-    const bool fork = side_ && n >= 8 && par_.post_processing < 2 && !lc->profile && par_.maximum_search_distance <= CD_HALO - 2;
+    const int groups = std::min(hbhip_dev_int("HBHIP_EEDI2_GROUPS", 2), MAX_SIDE + 1);
+    const bool fork = side_[0] && groups > 1 && n >= 4 * groups && par_.post_processing < 2 && !lc->profile &&
+                      par_.maximum_search_distance <= CD_HALO - 2;
     if (rc == HBHIP_OK && fork)
     {
-        const int h = n / 2;
         HBHIP_CHECK(lc, hipEventRecord(ev_fork_, lc->stream));
-        HBHIP_CHECK(lc, hipStreamWaitEvent(side_, ev_fork_, 0));
-        rc = enqueue_passes(0, h, lc, lc->stream);
-        if (rc == HBHIP_OK) rc = enqueue_passes(h, n - h, lc, side_);
-        HBHIP_CHECK(lc, hipEventRecord(ev_join_, side_));
-        HBHIP_CHECK(lc, hipStreamWaitEvent(lc->stream, ev_join_, 0));
+        for (int g = 0; g < groups && rc == HBHIP_OK; g++)
+        {
+            const int f0 = n * g / groups, f1 = n * (g + 1) / groups;
+            if (g) HBHIP_CHECK(lc, hipStreamWaitEvent(side_[g - 1], ev_fork_, 0));
+            rc = enqueue_passes(f0, f1 - f0, lc, g ? side_[g - 1] : lc->stream);
+        }
+        for (int g = 1; g < groups; g++)
+        {
+            HBHIP_CHECK(lc, hipEventRecord(ev_join_[g - 1], side_[g - 1]));
+            HBHIP_CHECK(lc, hipStreamWaitEvent(lc->stream, ev_join_[g - 1], 0));
+        }
     }
     else if (rc == HBHIP_OK) rc = enqueue_passes(0, n, lc, lc->stream);
     last_slot_ = start_ + n - 1;

@@ -175,8 +175,9 @@ private:
     uint32_t   *chain_flags_ = nullptr; // mask chain: one completion flag per lower tile and field of a batch
     uint32_t    chain_epoch_ = 0;       //             the number of the last mask launch
     uint32_t   *plane_flags_ = nullptr; // [field of the batch][plane]: == chain_epoch_ when the plane's new mask has a pixel set
-    hipStream_t side_ = nullptr;        // the second half of a batch's fields runs its passes here, beside the first half's
-    hipEvent_t  ev_fork_ = nullptr, ev_join_ = nullptr;
+    static constexpr int MAX_SIDE = 3;
+    hipStream_t side_[MAX_SIDE] = {};   // the later groups of a batch's fields run their passes here, beside the first group's
+    hipEvent_t  ev_fork_ = nullptr, ev_join_[MAX_SIDE] = {};
     uint32_t   *work_list_ = nullptr;   // calc_directions fallback: compacted edge pixels
     int        *work_count_ = nullptr;
     uint32_t   *cand_ = nullptr;        // slot 0's interpolate_lattice candidates
