@@ -2690,7 +2690,7 @@ int Eedi2Engine::launch(hbhip_ctx *lc)
     // post-processing 2 / 3 (its derivative arrays carry values from field to field), not while the profiler brackets
     // launches (its events live on the context's stream), not for the long-search fallback (one work list).
     const int groups = std::min(hbhip_dev_int("HBHIP_EEDI2_GROUPS", 2), MAX_SIDE + 1);
-    const bool fork = side_[0] && groups > 1 && n >= 4 * groups && par_.post_processing < 2 && !lc->profile &&
+    const bool fork = side_[0] && eedi_fork_enabled() && groups > 1 && n >= 4 * groups && par_.post_processing < 2 && !lc->profile &&
                       par_.maximum_search_distance <= CD_HALO - 2;
     if (rc == HBHIP_OK && fork)
     {

@@ -2111,7 +2111,7 @@ int Eedi2Engine16::enqueue(int n, hbhip_ctx *lc)
                          par_.erosion_threshold, par_.dilation_threshold);
         }
     }
-    const bool fork = side_ && n >= 8 && par_.post_processing < 2 && !lc->profile;
+    const bool fork = side_ && eedi_fork_enabled() && n >= 8 && par_.post_processing < 2 && !lc->profile;
     if (!fork) return enqueue_passes(0, n, lc, lc->stream);
     const int h = n / 2;
     HBHIP_CHECK(lc, hipEventRecord(ev_fork_, lc->stream));

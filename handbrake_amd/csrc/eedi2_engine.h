@@ -4,6 +4,7 @@
 
 #include "hbhip_internal.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -131,6 +132,14 @@ __device__ __forceinline__ bool eedi_chain_signal(const MaskChain &C, int fld, i
         __hip_atomic_store(C.flags + (size_t)fld * C.ntiles + C.base[pl] + (by - C.ty0[pl]) * C.tx[pl] + bx, C.epoch,
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return any;
+}
+
+// HBHIP_EEDI2_FORK=0: the passes of a whole batch on the caller's stream, one launch per pass (profiling runs: a launch then
+// covers all fields of the batch, as the counters' bookkeeping and the kernel-timer pass of bench.py assume)
+static inline bool eedi_fork_enabled()
+{
+    static const bool on = [] { const char *e = getenv("HBHIP_EEDI2_FORK"); return !(e && *e == '0'); }();
+    return on;
 }
 
 // EEDI2 on 8-bit samples (eedi2.hip).  Fields are queued with add_field() and run by launch(): the mask passes field

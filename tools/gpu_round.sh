@@ -32,7 +32,7 @@ timeout 200 python bench.py --workload chain --streams 2 --stage-streams 0 --no-
 timeout 200 python bench.py --workload chain --comb-detect --no-cpu-baseline --no-pcie --no-kernel-timer > $OUT/bench_chain_combdetect.json 2>> $OUT/bench_default.err
 timeout 240 python tools/kernel_rooflines.py > $OUT/kernel_rooflines.json 2> $OUT/kernel_rooflines.err
 cd /tmp
-PROF="python $R/bench.py --workload chain --stage-streams 0 --steps 6 --warmup 2 --no-cpu-baseline --no-pcie --no-kernel-timer"
+PROF="env HBHIP_EEDI2_FORK=0 python $R/bench.py --workload chain --stage-streams 0 --steps 6 --warmup 2 --no-cpu-baseline --no-pcie --no-kernel-timer"
 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $PROF > $OUT/kt.log 2>&1
 python $R/tools/trace_gaps.py $(find $OUT/kt -name '*kernel_trace.csv' | head -1) $OUT/trace_gaps.json > /dev/null 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
