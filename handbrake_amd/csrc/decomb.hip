@@ -566,7 +566,7 @@ public:
             // bob) are queued and go through each pass together: one launch per pass for up to `fields` fields
             // (Eedi2Engine), followed by the blends that consume the guesses.  Driven a frame at a time (work() of the
             // plugin), a frame's fields still share their launches.
-            const int fields = hbhip_dev_int("HBHIP_EEDI2_FIELDS", 16);               // fields per batch (1..32); measured 8: 4 596, 16: 4 633, 32: 4 583 fps on the chain
+            const int fields = hbhip_dev_int("HBHIP_EEDI2_FIELDS", 32);               // fields per batch (1..32): two parts of 16 (Eedi2Engine::launch)
             eedi = new (std::nothrow) Eedi2Engine(ctx, in_geo, ep, fields);
             if (!eedi) return HBHIP_ERR_NOMEM;
             int rc = eedi->init();

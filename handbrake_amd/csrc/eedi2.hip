@@ -1998,32 +1998,33 @@ __global__ __launch_bounds__(256) void k_fill_gaps_b(P3 P)
 // the pixel to the next one.  `base` carries the bits every outcome shares (valA and the right-hand test).
 constexpr uint32_t LAT_MORE = 0x80000000u;
 
-// the variance and the edge test on the fixed 2 x 5 neighbourhood (:1213-1240)
-__device__ __forceinline__ uint32_t lattice_stage_a(const uint8_t *top, const uint8_t *bot, const uint8_t *dm, int x, int width, uint32_t base,
-                                                    const uint8_t *limlut)
+// the variance and the edge test on the fixed 2 x 5 neighbourhood (:1213-1240) for one of the four pixels of a thread, out
+// of registers: {thi, tlo} / {bhi, blo} are eight staged bytes of the rows above / below with the pixel's column - 2 at
+// byte O.  The six-pixel sums are a v_sad_u8 against zero and a v_dot4_u32_u8 per row; the edge test rides in 16-bit
+// halves - (T0, T4) against (T1, T3): one packed max gives (left, right) maxima, one packed min the minima, and a borrow
+// bit per half says on which side of them T2 -+ 3 lies.  Returns the pixel's word, LAT_MORE set when it has to search.
+template <int O>
+__device__ __forceinline__ uint32_t lattice_stage_a4(uint32_t thi, uint32_t tlo, uint32_t bhi, uint32_t blo, int lim, bool inner, uint32_t base)
 {
-    const int d = dm[x];
-    const int T0 = top[x - 2], T1 = top[x - 1], T2 = top[x], T3 = top[x + 1], T4 = top[x + 2];
-    const int B0 = bot[x - 2], B1 = bot[x - 1], B2 = bot[x], B3 = bot[x + 1], B4 = bot[x + 2];
-    const int lim = limlut[iabs(d - NEUTRAL) >> 2];
     const uint32_t avg = base & 0xffu;
-    if (lim < 9)
-    {
-        const int sum = T1 + T2 + T3 + B1 + B2 + B3;
-        const int sumsq = T1 * T1 + T2 * T2 + T3 * T3 + B1 * B1 + B2 * B2 + B3 * B3;
-        if (6 * sumsq - sum * sum < 576) return base | (avg << 8) | ((uint32_t)PEAK << 16);
-    }
-    if (x > 1 && x < width - 2)
-    {
-        const int t = T2, b = B2;
-        const int tl = max(T0, T1), tr = max(T4, T3);
-        const int bl = max(B0, B1), br = max(B4, B3);
-        const int tl2 = min(T0, T1), tr2 = min(T4, T3);
-        const int bl2 = min(B0, B1), br2 = min(B4, B3);
-        if ((t < tl - 3 && t < tr - 3 && b < bl - 3 && b < br - 3) ||
-            (t > tl2 + 3 && t > tr2 + 3 && b > bl2 + 3 && b > br2 + 3))
-            return base | (avg << 8) | ((uint32_t)NEUTRAL << 16);
-    }
+    constexpr uint32_t SEL3 = (uint32_t)(O + 1) | ((uint32_t)(O + 2) << 8) | ((uint32_t)(O + 3) << 16) | 0x0c000000u;
+    const uint32_t mt = __builtin_amdgcn_perm(thi, tlo, SEL3), mb = __builtin_amdgcn_perm(bhi, blo, SEL3);   // columns x-1 .. x+1
+    const int sum = (int)__builtin_amdgcn_sad_u8(mt, 0u, __builtin_amdgcn_sad_u8(mb, 0u, 0u));
+    const int sumsq = (int)__builtin_amdgcn_udot4(mt, mt, __builtin_amdgcn_udot4(mb, mb, 0u, false), false);
+    if (lim < 9 && 6 * sumsq - sum * sum < 576) return base | (avg << 8) | ((uint32_t)PEAK << 16);
+    const u16x2 three = pk1(3);
+    auto sides = [&](uint32_t hi, uint32_t lo, uint32_t &below, uint32_t &above) {
+        const u16x2 outer = pk(PK_BYTES(hi, lo, O, O + 4)), near = pk(PK_BYTES(hi, lo, O + 1, O + 3));
+        const u16x2 mid = pk(PK_BYTES(hi, lo, O + 2, O + 2));
+        const u16x2 mx = __builtin_elementwise_max(outer, near), mn = __builtin_elementwise_min(outer, near);
+        below = un((u16x2)(mid + three - mx));        // bit 15 of a half: mid < max - 3 on that side
+        above = un((u16x2)(mn + three - mid));        //                   mid > min + 3
+    };
+    uint32_t tbelow, tabove, bbelow, babove;
+    sides(thi, tlo, tbelow, tabove);
+    sides(bhi, blo, bbelow, babove);
+    const bool edge = ((tbelow & bbelow & 0x80008000u) == 0x80008000u) || ((tabove & babove & 0x80008000u) == 0x80008000u);
+    if (inner && edge) return base | (avg << 8) | ((uint32_t)NEUTRAL << 16);
     return base | LAT_MORE;
 }
 
@@ -2063,6 +2064,98 @@ __device__ __forceinline__ uint32_t lattice_stage_b(const uint8_t *top, const ui
         }
     }
 #undef NEAR
+    if (mn != nt8) return base | ((uint32_t)val << 8) | ((uint32_t)((NEUTRAL + dir * 4) & 0xff) << 16);
+    return base | LAT_MORE;
+}
+
+// The same search out of four 8-byte windows.  Its five steps u = dir - 2 .. dir + 2 look at the rows below / above at
+// x - u -+ 1 and x + u -+ 1: seven consecutive bytes around x - dir and x + dir of each of the four rows, which three
+// aligned ds_read_b32 and two v_alignbyte bring into a register pair (as byte reads the five steps took 60 to 90 of
+// them per pixel, and the kernel was bound by the LDS pipe: 154 of its 209 us per 16 fields).  A step's two SADs are a
+// v_perm (three window bytes and a zero) and a v_sad_u8 each, the six "near the pixel's direction" tests two bit tests
+// on masks made once per window, two bytes per packed operation.  A pixel whose steps the row ends clamp
+// (:1244-1247 - the range then lies outside dir -+ 2) takes the plain walk above.
+struct LatRows { const uint32_t *top, *bot, *ot, *ob; int org; };      // the staged rows as dwords; org: local index of column 0
+
+// row[c] .. row[c + 7] (any alignment) as two dwords
+__device__ __forceinline__ void lat_window8(const uint32_t *row, int li, uint32_t &lo, uint32_t &hi)
+{
+    const uint32_t *w = row + (li >> 2);
+    const uint32_t r0 = w[0], r1 = w[1], r2 = w[2];
+    const uint32_t sh = (uint32_t)li & 3u;
+    lo = __builtin_amdgcn_alignbyte(r1, r0, sh);
+    hi = __builtin_amdgcn_alignbyte(r2, r1, sh);
+}
+// row[c - 1], row[c], row[c + 1] and a zero
+__device__ __forceinline__ uint32_t lat_three(const uint32_t *row, int li)
+{
+    const uint32_t *w = row + ((li - 1) >> 2);
+    return __builtin_amdgcn_alignbyte(w[1], w[0], (uint32_t)(li - 1) & 3u) & 0x00ffffffu;
+}
+// which of a window's eight bytes are a direction (not the peak) within lim of d: byte 2i at bit 2i, byte 2i + 1 at bit 16 + 2i
+__device__ __forceinline__ uint32_t lat_near8(uint32_t lo, uint32_t hi, u16x2 d2, u16x2 lim1)
+{
+    uint32_t m = 0;
+    const u16x2 peak = pk1(PEAK);
+#define LAT_NEAR2(i)                                                                                   \
+    {                                                                                                  \
+        const u16x2 h = pk(PK_BYTES(hi, lo, 2 * i, 2 * i + 1));                                        \
+        const i16x2 t = __builtin_bit_cast(i16x2, (u16x2)(h - d2));                                    \
+        const u16x2 a = __builtin_bit_cast(u16x2, __builtin_elementwise_max(t, (i16x2)(-t)));          \
+        m |= un(pk_lt(a, lim1) & pk_lt(h, peak)) << (2 * i);                                           \
+    }
+    LAT_NEAR2(0) LAT_NEAR2(1) LAT_NEAR2(2) LAT_NEAR2(3)
+#undef LAT_NEAR2
+    return m;
+}
+constexpr uint32_t lat_bit(int b) { return (b & 1) ? 1u << (16 + b - 1) : 1u << b; }
+constexpr uint32_t lat_bits3(int g) { return lat_bit(g) | lat_bit(g + 1) | lat_bit(g + 2); }
+constexpr uint32_t lat_sel3(int g) { return (uint32_t)g | ((uint32_t)(g + 1) << 8) | ((uint32_t)(g + 2) << 16) | 0x0c000000u; }
+
+__device__ __forceinline__ uint32_t lattice_stage_b_win(const LatRows R, const uint8_t *top, const uint8_t *bot, const uint8_t *ot,
+                                                        const uint8_t *ob, const uint8_t *dm, int x, int width, int nt4, int nt8,
+                                                        uint32_t base, const uint8_t *limlut)
+{
+    const int d = dm[x];
+    const int lim = limlut[iabs(d - NEUTRAL) >> 2];
+    int dir = (d - NEUTRAL + 2) >> 2;
+    const int startu = (dir - 2 < 0) ? max(-x + 1, max(dir - 2, -width + 2 + x)) : min(x - 1, min(dir - 2, width - 2 - x));
+    const int stopu = (dir + 2 < 0) ? max(-x + 1, max(dir + 2, -width + 2 + x)) : min(x - 1, min(dir + 2, width - 2 - x));
+    if (startu != dir - 2 || stopu != dir + 2) return lattice_stage_b(top, bot, ot, ob, dm, x, width, nt4, nt8, base, limlut);
+    int val = (int)(base & 0xffu);
+    const int first = dir;
+    const int lx = R.org + x;
+    uint32_t blo, bhi, tlo, thi, olo, ohi, qlo, qhi;
+    lat_window8(R.bot, lx - first - 3, blo, bhi);            // the row below and its directions around x - dir
+    lat_window8(R.ob, lx - first - 3, qlo, qhi);
+    lat_window8(R.top, lx + first - 3, tlo, thi);            // the row above and its directions around x + dir
+    lat_window8(R.ot, lx + first - 3, olo, ohi);
+    const uint32_t tc = lat_three(R.top, lx), bc = lat_three(R.bot, lx);
+    const u16x2 d2 = pk1((uint32_t)d), lim1 = pk1((uint32_t)lim + 1u);
+    const uint32_t near_t = lat_near8(olo, ohi, d2, lim1), near_b = lat_near8(qlo, qhi, d2, lim1);
+    int mn = nt8;
+#define LAT_STEP(j)                                                                                                   \
+    {                                                                                                                 \
+        const uint32_t bg = __builtin_amdgcn_perm(bhi, blo, lat_sel3(2 - (j))), tg = __builtin_amdgcn_perm(thi, tlo, lat_sel3(2 + (j))); \
+        const int diff = (int)__builtin_amdgcn_sad_u8(tc, bg, __builtin_amdgcn_sad_u8(bc, tg, 0u));                   \
+        if (diff < mn && (near_t & lat_bits3(2 + (j))) && (near_b & lat_bits3(2 - (j))))                               \
+        {                                                                                                             \
+            const int u = first + (j);                                                                                \
+            const int h0 = u >> 1, h1 = (u + 1) >> 1;                                                                 \
+            const int diff2 = sad3(top, x + h0, bot, x - h0);                                                         \
+            const int o0 = ot[x + h0], o1 = ot[x + h1], q0 = ob[x - h0], q1 = ob[x - h1];                             \
+            if (diff2 < nt4 && (((iabs(o0 - q0) <= lim || iabs(o0 - q1) <= lim) && o0 != PEAK) ||                     \
+                                ((iabs(o1 - q0) <= lim || iabs(o1 - q1) <= lim) && o1 != PEAK)) &&                    \
+                (iabs(d - o0) <= lim || iabs(d - o1) <= lim) && (iabs(d - q0) <= lim || iabs(d - q1) <= lim))         \
+            {                                                                                                         \
+                val = ((int)top[x + h0] + (int)top[x + h1] + (int)bot[x - h0] + (int)bot[x - h1] + 2) >> 2;           \
+                mn = diff;                                                                                            \
+                dir = u;                                                                                              \
+            }                                                                                                         \
+        }                                                                                                             \
+    }
+    LAT_STEP(-2) LAT_STEP(-1) LAT_STEP(0) LAT_STEP(1) LAT_STEP(2)
+#undef LAT_STEP
     if (mn != nt8) return base | ((uint32_t)val << 8) | ((uint32_t)((NEUTRAL + dir * 4) & 0xff) << 16);
     return base | LAT_MORE;
 }
@@ -2118,7 +2211,7 @@ __global__ __launch_bounds__(256) void k_lattice_cand_q(P3 P, uint32_t *__restri
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_rows[5][LQ_LW];
     __shared__ __attribute__((aligned(16))) uint32_t s_cand[LQ_W];
-    __shared__ uint16_t s_list[3][LQ_W];                          // one queue per stage
+    __shared__ uint16_t s_list[3][LQ_W];                          // [1], [2]: the queues of the two searches
     __shared__ int s_count[3];
     __shared__ uint8_t s_lim[LIM_PAD];
     FIELD_PLANE(P);
@@ -2170,11 +2263,15 @@ __global__ __launch_bounds__(256) void k_lattice_cand_q(P3 P, uint32_t *__restri
     const uint8_t *ot = s_rows[2] + LC_HALO - x0, *ob = s_rows[3] + LC_HALO - x0;
     const uint8_t *dm = s_rows[4] + LC_HALO - x0;
     {
+        // every pixel's word, the variance and the edge test included, four pixels per thread out of the rows' dwords
         const int x = x0 + 4 * t;
         if (x < width)
         {
-            const uint32_t d4 = *reinterpret_cast<const uint32_t *>(dm + x), dn = dm[x + 4];
-            const uint32_t t4 = *reinterpret_cast<const uint32_t *>(top + x), b4 = *reinterpret_cast<const uint32_t *>(bot + x);
+            const uint32_t *T = reinterpret_cast<const uint32_t *>(s_rows[0]) + LC_HALO / 4 + t;   // T[0]: columns x .. x + 3
+            const uint32_t *B = reinterpret_cast<const uint32_t *>(s_rows[1]) + LC_HALO / 4 + t;
+            const uint32_t *D = reinterpret_cast<const uint32_t *>(s_rows[4]) + LC_HALO / 4 + t;
+            const uint32_t tm = T[-1], t4 = T[0], tp = T[1], bm = B[-1], b4 = B[0], bp = B[1];
+            const uint32_t d4 = D[0], dn = D[1] & 0xffu;
             uint32_t w[4];
             uint32_t queue = 0;
 #pragma unroll
@@ -2185,40 +2282,41 @@ __global__ __launch_bounds__(256) void k_lattice_cand_q(P3 P, uint32_t *__restri
                 const int lim = s_lim[iabs(d - NEUTRAL) >> 2];
                 const bool right = iabs(d - dr) > lim;
                 const bool searching = d != PEAK && x + k < width;
-                w[k] = searching ? ((uint32_t)avg | ((uint32_t)right << 25))
-                                 : ((uint32_t)avg | ((uint32_t)avg << 8) | ((uint32_t)NEUTRAL << 16) | (1u << 24) | ((uint32_t)right << 25));
-                if (searching) queue |= 1u << k;
+                const uint32_t base = (uint32_t)avg | ((uint32_t)right << 25);
+                const bool inner = x + k > 1 && x + k < width - 2;
+                const uint32_t ws = k == 0 ? lattice_stage_a4<2>(t4, tm, b4, bm, lim, inner, base)
+                                  : k == 1 ? lattice_stage_a4<3>(t4, tm, b4, bm, lim, inner, base)
+                                  : k == 2 ? lattice_stage_a4<0>(tp, t4, bp, b4, lim, inner, base)
+                                           : lattice_stage_a4<1>(tp, t4, bp, b4, lim, inner, base);
+                w[k] = searching ? (ws & ~LAT_MORE) : (base | ((uint32_t)avg << 8) | ((uint32_t)NEUTRAL << 16) | (1u << 24));
+                if (searching && (ws & LAT_MORE)) queue |= 1u << k;
             }
             *reinterpret_cast<uint4 *>(&s_cand[4 * t]) = make_uint4(w[0], w[1], w[2], w[3]);
             if (queue)
             {
-                int at = atomicAdd(&s_count[0], __popc(queue));
+                int at = atomicAdd(&s_count[1], __popc(queue));
 #pragma unroll
                 for (int k = 0; k < 4; k++)
-                    if ((queue >> k) & 1u) s_list[0][at++] = (uint16_t)(4 * t + k);
+                    if ((queue >> k) & 1u) s_list[1][at++] = (uint16_t)(4 * t + k);
             }
         }
     }
     __syncthreads();
-    // a stage's lanes all run the same code: the tests, then the 5-step search, then the short search
-    for (int i = t, n = s_count[0]; i < n; i += 256)
+    // a stage's lanes all run the same code: the 5-step search, then the short search
     {
-        const int lx = s_list[0][i];
-        const uint32_t w = lattice_stage_a(top, bot, dm, x0 + lx, width, s_cand[lx], s_lim);
-        if (w & LAT_MORE) s_list[1][atomicAdd(&s_count[1], 1)] = (uint16_t)lx;
-        else s_cand[lx] = w;
-    }
-    __syncthreads();
-    for (int i = t, n = s_count[1]; i < n; i += 256)
-    {
-        const int lx = s_list[1][i];
-        const uint32_t w = lattice_stage_b(top, bot, ot, ob, dm, x0 + lx, width, nt4, nt8, s_cand[lx], s_lim);
-        if (w & LAT_MORE) s_list[2][atomicAdd(&s_count[2], 1)] = (uint16_t)lx;
-        else s_cand[lx] = w;
+        const LatRows R = { reinterpret_cast<const uint32_t *>(s_rows[0]), reinterpret_cast<const uint32_t *>(s_rows[1]),
+                            reinterpret_cast<const uint32_t *>(s_rows[2]), reinterpret_cast<const uint32_t *>(s_rows[3]), LC_HALO - x0 };
+        for (int i = t, n = s_count[1]; i < n; i += 256)
+        {
+            const int lx = s_list[1][i];
+            const uint32_t w = lattice_stage_b_win(R, top, bot, ot, ob, dm, x0 + lx, width, nt4, nt8, s_cand[lx], s_lim);
+            if (w & LAT_MORE) s_list[2][atomicAdd(&s_count[2], 1)] = (uint16_t)lx;
+            else s_cand[lx] = w;
+        }
     }
     __syncthreads();
 #ifdef HBHIP_DEV_STATS
-    if (t == 0) { CD_STAT(18, s_count[0]); CD_STAT(19, s_count[1]); CD_STAT(20, s_count[2]); CD_STAT(21, 1); }
+    if (t == 0) { CD_STAT(19, s_count[1]); CD_STAT(20, s_count[2]); CD_STAT(21, 1); }
 #endif
     for (int i = t, n = s_count[2]; i < n; i += 256)
     {
@@ -2558,6 +2656,7 @@ Eedi2Engine::~Eedi2Engine()
         if (ev_join_[g]) (void)hipEventDestroy(ev_join_[g]);
     }
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+    if (ev_mask_) (void)hipEventDestroy(ev_mask_);
     if (work_list_) (void)hipFree(work_list_);
     if (work_count_) (void)hipFree(work_count_);
     for (int i = 0; i < 3; i++)
@@ -2610,9 +2709,9 @@ int Eedi2Engine::init()
     cand_ = reinterpret_cast<uint32_t *>(slab_ + cand_at);
     if (cap_ >= 8)
     {
-        const int sides = std::min(hbhip_dev_int("HBHIP_EEDI2_GROUPS", 2), MAX_SIDE + 1) - 1;
         HBHIP_CHECK(ctx_, hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
-        for (int g = 0; g < sides; g++)
+        HBHIP_CHECK(ctx_, hipEventCreateWithFlags(&ev_mask_, hipEventDisableTiming));
+        for (int g = 0; g < 2; g++)                                        // [0] the passes' twin, [1] the next part's mask
         {
             HBHIP_CHECK(ctx_, hipStreamCreateWithFlags(&side_[g], hipStreamNonBlocking));
             HBHIP_CHECK(ctx_, hipEventCreateWithFlags(&ev_join_[g], hipEventDisableTiming));
@@ -2682,41 +2781,81 @@ int Eedi2Engine::launch(hbhip_ctx *lc)
     if (n_ == 0) return HBHIP_OK;
     const int n = n_;
     n_ = 0;
-    int rc = enqueue_mask(n, lc);
-    // The passes behind the mask: every field has its own slot, so two halves of a batch run them beside each other on two
-    // streams - the same kernels half a launch apart fill each other's tails and latency-bound stretches (decomb bob
-    // 10 750 -> 11 560, the chain 7 390 -> 7 640 output fps; three quarters / one quarter: 11 100 / 7 540; three
-    // groups on three streams + 1.5 %, four - 9 %: development knob HBHIP_EEDI2_GROUPS).  Not with
-    // post-processing 2 / 3 (its derivative arrays carry values from field to field), not while the profiler brackets
-    // launches (its events live on the context's stream), not for the long-search fallback (one work list).
-    const int groups = std::min(hbhip_dev_int("HBHIP_EEDI2_GROUPS", 2), MAX_SIDE + 1);
-    const bool fork = side_[0] && eedi_fork_enabled() && groups > 1 && n >= 4 * groups && par_.post_processing < 2 && !lc->profile &&
+    // A batch goes out in parts of at most EEDI_PART fields: one mask launch per part (a chain of that many links), and the
+    // passes behind it.
+    //  * The passes: every field has its own slot, so the two halves of a part run them beside each other on two streams -
+    //    the same kernels half a launch apart fill each other's tails and latency-bound stretches (decomb bob 10 750 ->
+    //    11 560, the chain 7 390 -> 7 640 output fps; three quarters / one quarter: 11 100 / 7 540; three groups on three
+    //    streams + 1.5 %, four - 9 %).
+    //  * The mask launch of the second part (it waits for the first part's mask only) runs on a stream of its own beside
+    //    the first part's passes instead of alone in front of its own.
+    // Not with post-processing 2 / 3 (its derivative arrays carry values from field to field), not while the profiler
+    // brackets launches (its events live on the context's stream) or HBHIP_EEDI2_FORK=0 says so (counter runs), not for
+    // the long-search fallback (one work list): then everything goes out on the caller's stream, part after part.
+    constexpr int EEDI_PART = 16;
+    const bool fork = side_[0] && eedi_fork_enabled() && par_.post_processing < 2 && !lc->profile &&
                       par_.maximum_search_distance <= CD_HALO - 2;
-    if (rc == HBHIP_OK && fork)
+    const int parts = (n + EEDI_PART - 1) / EEDI_PART;
+    uint32_t epoch[(EEDI_MAX_BATCH + EEDI_PART - 1) / EEDI_PART] = {};
+    int rc = enqueue_mask(0, std::min(n, EEDI_PART), lc, lc->stream, &epoch[0]);
+    if (!fork)
     {
-        HBHIP_CHECK(lc, hipEventRecord(ev_fork_, lc->stream));
-        for (int g = 0; g < groups && rc == HBHIP_OK; g++)
+        for (int p = 0; p < parts && rc == HBHIP_OK; p++)
         {
-            const int f0 = n * g / groups, f1 = n * (g + 1) / groups;
-            if (g) HBHIP_CHECK(lc, hipStreamWaitEvent(side_[g - 1], ev_fork_, 0));
-            rc = enqueue_passes(f0, f1 - f0, lc, g ? side_[g - 1] : lc->stream);
-        }
-        for (int g = 1; g < groups; g++)
-        {
-            HBHIP_CHECK(lc, hipEventRecord(ev_join_[g - 1], side_[g - 1]));
-            HBHIP_CHECK(lc, hipStreamWaitEvent(lc->stream, ev_join_[g - 1], 0));
+            const int f0 = p * EEDI_PART, m = std::min(EEDI_PART, n - f0);
+            if (p) rc = enqueue_mask(f0, m, lc, lc->stream, &epoch[p]);
+            if (rc == HBHIP_OK) rc = enqueue_passes(f0, m, lc, lc->stream, epoch[p]);
         }
     }
-    else if (rc == HBHIP_OK) rc = enqueue_passes(0, n, lc, lc->stream);
+    else if (rc == HBHIP_OK)
+    {
+        hipStream_t twin = side_[0], ahead = side_[1];
+        bool twin_used = false;
+        HBHIP_CHECK(lc, hipEventRecord(ev_fork_, lc->stream));                 // the first part's mask is out
+        for (int p = 0; p < parts && rc == HBHIP_OK; p++)
+        {
+            const int f0 = p * EEDI_PART, m = std::min(EEDI_PART, n - f0);
+            hipEvent_t ready = p ? ev_mask_ : ev_fork_;                       // this part's mask
+            if (p)
+            {
+                // (parts > 2 would need an event per part: EEDI_MAX_BATCH is two parts)
+                HBHIP_CHECK(lc, hipStreamWaitEvent(lc->stream, ev_mask_, 0));
+            }
+            if (p + 1 < parts)
+            {
+                // the next part's mask beside this part's passes: behind this part's mask, on its own stream
+                const int g0 = f0 + EEDI_PART, gm = std::min(EEDI_PART, n - g0);
+                HBHIP_CHECK(lc, hipStreamWaitEvent(ahead, ready, 0));
+                rc = enqueue_mask(g0, gm, lc, ahead, &epoch[p + 1]);
+                if (rc != HBHIP_OK) break;
+                HBHIP_CHECK(lc, hipEventRecord(ev_mask_, ahead));
+            }
+            if (m >= 8)
+            {
+                const int h = m / 2;
+                HBHIP_CHECK(lc, hipStreamWaitEvent(twin, ready, 0));
+                twin_used = true;
+                rc = enqueue_passes(f0, h, lc, lc->stream, epoch[p]);
+                if (rc == HBHIP_OK) rc = enqueue_passes(f0 + h, m - h, lc, twin, epoch[p]);
+            }
+            else rc = enqueue_passes(f0, m, lc, lc->stream, epoch[p]);
+        }
+        if (twin_used)
+        {
+            HBHIP_CHECK(lc, hipEventRecord(ev_join_[0], twin));
+            HBHIP_CHECK(lc, hipStreamWaitEvent(lc->stream, ev_join_[0], 0));
+        }
+    }
     last_slot_ = start_ + n - 1;
     return rc;
 }
 
 // the five mask passes (+ the field extraction) of the n queued fields: old mask -> new mask.  The part no earlier
 // field can influence is one launch, the rest a chain of launches, field after field
-int Eedi2Engine::enqueue_mask(int n, hbhip_ctx *lc)
+int Eedi2Engine::enqueue_mask(int f0, int n, hbhip_ctx *lc, hipStream_t st, uint32_t *epoch_out)
 {
-    const EediFrame srcp = at_slot(half_[0], start_), mskp = at_slot(half_[1], start_), mskp_old = at_slot(half_[1], last_slot_);
+    const EediFrame srcp = at_slot(half_[0], start_ + f0), mskp = at_slot(half_[1], start_ + f0),
+                    mskp_old = at_slot(half_[1], f0 ? start_ + f0 - 1 : last_slot_);
     P3 P;
     memset(&P, 0, sizeof(P));
     MaskSrc S;
@@ -2727,15 +2866,17 @@ int Eedi2Engine::enqueue_mask(int n, hbhip_ctx *lc)
         P.a[c] = srcp.plane[c]; P.b[c] = mskp_old.plane[c]; P.c[c] = mskp.plane[c];
         S.spitch[c] = src_pitch_[c];
     }
-    for (int f = 0; f < n; f++) for (int c = 0; c < 3; c++) S.frame[f][c] = src_frame_[f][c];
+    for (int f = 0; f < n; f++) for (int c = 0; c < 3; c++) S.frame[f][c] = src_frame_[f0 + f][c];
     P.fstride = slot_bytes_;
-    P.tffbits = tffbits_;
+    P.tffbits = tffbits_ >> f0;
     const int mth = par_.magnitude_threshold * 10, vth = par_.laplacian_threshold * 81, lth = par_.variance_threshold;   // sic: swapped (decomb_template.c:390)
     const unsigned gx = (srcp.width[0] + MF_W - 1) / MF_W, gy = (srcp.height[0] + MF_H - 1) / MF_H;
     const uint32_t epoch = ++chain_epoch_;                        // the number of this mask launch (chain flags, plane flags)
+    *epoch_out = epoch;
+    uint32_t *pflags = plane_flags_ + 3 * f0;
     if (n == 1)
-        HBHIP_LAUNCH(lc, "eedi2_mask_passes", k_mask_fused4, dim3(gx, gy, 3), dim3(MF_T), 0, P, S, 0, 0, mth, vth, lth,
-                     par_.erosion_threshold, par_.dilation_threshold, plane_flags_, epoch);
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_mask_passes", k_mask_fused4, dim3(gx, gy, 3), dim3(MF_T), 0, P, S, 0, 0, mth, vth, lth,
+                        par_.erosion_threshold, par_.dilation_threshold, pflags, epoch);
     else
     {
         // One launch: the tiles no earlier field can influence (upper) and the chain through the fields (lower, MaskChain),
@@ -2743,10 +2884,10 @@ int Eedi2Engine::enqueue_mask(int n, hbhip_ctx *lc)
         // chain ran alone at a third of the GPU: it is 16 links of latency, not work (58 + 139 us per 16 fields).
         MaskChain C = eedi_mask_chain_tiles(srcp, MF_W, MF_H, MF_OY);
         C.flags = chain_flags_;
-        C.pflags = plane_flags_;
+        C.pflags = pflags;
         C.epoch = epoch;
         C.group = C.ntiles + C.nupper;
-        HBHIP_LAUNCH(lc, "eedi2_mask_passes", k_mask_chain, dim3((unsigned)(C.group * n)), dim3(MF_T), 0, P, S, C, mth, vth, lth,
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_mask_passes", k_mask_chain, dim3((unsigned)(C.group * n)), dim3(MF_T), 0, P, S, C, mth, vth, lth,
                      par_.erosion_threshold, par_.dilation_threshold);
     }
     HBHIP_CHECK(lc, hipGetLastError());
@@ -2755,7 +2896,7 @@ int Eedi2Engine::enqueue_mask(int n, hbhip_ctx *lc)
 
 // The pass sequence of eedi2_interpolate_plane (decomb_template.c:366-441) behind the mask passes, for the 3 planes of
 // n of the queued fields, on their scratch frames.
-int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st)
+int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st, uint32_t epoch)
 {
     // fields f0 .. f0 + n - 1 of the batch
     const int s0 = start_ + f0;
@@ -2794,7 +2935,7 @@ int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st)
     P.fstride = slot_bytes_;
     P.tffbits = tffbits;
     P.pflags = plane_flags_ + 3 * f0;
-    P.pepoch = chain_epoch_;
+    P.pepoch = epoch;
 
     // half-height passes
     geom(P, srcp);

@@ -168,8 +168,10 @@ public:
 private:
     size_t place_frame(EediFrame &f, int width, int height, size_t at);
     EediFrame at_slot(const EediFrame &f, int slot) const;
-    int enqueue_mask(int n, hbhip_ctx *lc);                 // the five mask passes (+ the field extraction)
-    int enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st);   // everything after them, fields f0 .. f0 + n - 1 of the batch, on st
+    // the five mask passes (+ the field extraction) of fields f0 .. f0 + n - 1 of the batch on st; *epoch: the launch's number
+    int enqueue_mask(int f0, int n, hbhip_ctx *lc, hipStream_t st, uint32_t *epoch);
+    // everything after them for fields f0 .. f0 + n - 1 (of one mask launch: `epoch`), on st
+    int enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st, uint32_t epoch);
     hbhip_ctx  *ctx_;
     PicGeometry geo_;
     Eedi2Params par_;
@@ -186,7 +188,7 @@ private:
     uint32_t   *plane_flags_ = nullptr; // [field of the batch][plane]: == chain_epoch_ when the plane's new mask has a pixel set
     static constexpr int MAX_SIDE = 3;
     hipStream_t side_[MAX_SIDE] = {};   // the later groups of a batch's fields run their passes here, beside the first group's
-    hipEvent_t  ev_fork_ = nullptr, ev_join_[MAX_SIDE] = {};
+    hipEvent_t  ev_fork_ = nullptr, ev_mask_ = nullptr, ev_join_[MAX_SIDE] = {};
     uint32_t   *work_list_ = nullptr;   // calc_directions fallback: compacted edge pixels
     int        *work_count_ = nullptr;
     uint32_t   *cand_ = nullptr;        // slot 0's interpolate_lattice candidates
