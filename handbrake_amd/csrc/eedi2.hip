@@ -2112,52 +2112,84 @@ constexpr uint32_t lat_bit(int b) { return (b & 1) ? 1u << (16 + b - 1) : 1u << 
 constexpr uint32_t lat_bits3(int g) { return lat_bit(g) | lat_bit(g + 1) | lat_bit(g + 2); }
 constexpr uint32_t lat_sel3(int g) { return (uint32_t)g | ((uint32_t)(g + 1) << 8) | ((uint32_t)(g + 2) << 16) | 0x0c000000u; }
 
+template <int K> __device__ __forceinline__ uint32_t lat_byte(uint32_t lo, uint32_t hi)
+{
+    return K < 4 ? (lo >> (8 * (K & 3))) & 0xffu : (hi >> (8 * (K & 3))) & 0xffu;
+}
+// row[c] .. row[c + 3]
+__device__ __forceinline__ uint32_t lat_window4(const uint32_t *row, int li)
+{
+    const uint32_t *w = row + (li >> 2);
+    return __builtin_amdgcn_alignbyte(w[1], w[0], (uint32_t)li & 3u);
+}
+
+// The loop over u (:1249-1290) keeps the step with the smallest diff among those that pass its tests (the first of
+// them on a tie: `diff < min`), and no test looks at what an earlier step left behind - so the steps are evaluated
+// side by side and the winner is the minimum of the keys (diff << 3) | step.  Counted from the even number at or below
+// dir - 2 (six steps, the first or the last of them outside dir -+ 2) the half steps u >> 1 and (u + 1) >> 1 are
+// constants too, and the second test's pixels (:1262-1279) come out of four more windows; only the winner's four
+// pixels are read per byte.  (As a loop with the second test under a branch: 2.0 of a pixel's 5 steps took it, which
+// for a wave meant all five, each with 14 byte reads on a third of its lanes.)
 __device__ __forceinline__ uint32_t lattice_stage_b_win(const LatRows R, const uint8_t *top, const uint8_t *bot, const uint8_t *ot,
                                                         const uint8_t *ob, const uint8_t *dm, int x, int width, int nt4, int nt8,
                                                         uint32_t base, const uint8_t *limlut)
 {
     const int d = dm[x];
     const int lim = limlut[iabs(d - NEUTRAL) >> 2];
-    int dir = (d - NEUTRAL + 2) >> 2;
+    const int dir = (d - NEUTRAL + 2) >> 2;
     const int startu = (dir - 2 < 0) ? max(-x + 1, max(dir - 2, -width + 2 + x)) : min(x - 1, min(dir - 2, width - 2 - x));
     const int stopu = (dir + 2 < 0) ? max(-x + 1, max(dir + 2, -width + 2 + x)) : min(x - 1, min(dir + 2, width - 2 - x));
-    if (startu != dir - 2 || stopu != dir + 2) return lattice_stage_b(top, bot, ot, ob, dm, x, width, nt4, nt8, base, limlut);
-    int val = (int)(base & 0xffu);
-    const int first = dir;
+    if (startu != dir - 2 || stopu != dir + 2)
+    {
+        CD_STAT(22, 1);
+        return lattice_stage_b(top, bot, ot, ob, dm, x, width, nt4, nt8, base, limlut);
+    }
+    const int de = dir & ~1, par = dir & 1, hb = (de >> 1) - 1;     // step i: u = de - 2 + i, u >> 1 = hb + (i >> 1), (u + 1) >> 1 = hb + ((i + 1) >> 1)
     const int lx = R.org + x;
-    uint32_t blo, bhi, tlo, thi, olo, ohi, qlo, qhi;
-    lat_window8(R.bot, lx - first - 3, blo, bhi);            // the row below and its directions around x - dir
-    lat_window8(R.ob, lx - first - 3, qlo, qhi);
-    lat_window8(R.top, lx + first - 3, tlo, thi);            // the row above and its directions around x + dir
-    lat_window8(R.ot, lx + first - 3, olo, ohi);
+    uint32_t blo, bhi, tlo, thi, olo, ohi, qlo, qhi, t2lo, t2hi, b2lo, b2hi;
+    lat_window8(R.bot, lx - de - 4, blo, bhi);               // x - u - 1 at byte 5 - i
+    lat_window8(R.ob, lx - de - 4, qlo, qhi);
+    lat_window8(R.top, lx + de - 3, tlo, thi);               // x + u - 1 at byte i
+    lat_window8(R.ot, lx + de - 3, olo, ohi);
+    lat_window8(R.top, lx + hb - 1, t2lo, t2hi);             // x + (u >> 1) - 1 at byte i >> 1
+    lat_window8(R.bot, lx - hb - 4, b2lo, b2hi);             // x - (u >> 1) - 1 at byte 3 - (i >> 1)
+    const uint32_t o2 = lat_window4(R.ot, lx + hb);          // x + (u >> 1) at byte i >> 1
+    const uint32_t q2 = lat_window4(R.ob, lx - hb - 3);      // x - (u >> 1) at byte 3 - (i >> 1)
     const uint32_t tc = lat_three(R.top, lx), bc = lat_three(R.bot, lx);
     const u16x2 d2 = pk1((uint32_t)d), lim1 = pk1((uint32_t)lim + 1u);
     const uint32_t near_t = lat_near8(olo, ohi, d2, lim1), near_b = lat_near8(qlo, qhi, d2, lim1);
-    int mn = nt8;
-#define LAT_STEP(j)                                                                                                   \
+    const uint32_t ulim = (uint32_t)lim, ulim2 = 2u * ulim;
+    auto within = [&](uint32_t a, uint32_t b) { return a - b + ulim <= ulim2; };              // |a - b| <= lim
+    const uint32_t o[4] = { o2 & 0xffu, (o2 >> 8) & 0xffu, (o2 >> 16) & 0xffu, o2 >> 24 };
+    const uint32_t q[4] = { q2 & 0xffu, (q2 >> 8) & 0xffu, (q2 >> 16) & 0xffu, q2 >> 24 };
+    const bool od[4] = { within(o[0], (uint32_t)d), within(o[1], (uint32_t)d), within(o[2], (uint32_t)d), within(o[3], (uint32_t)d) };
+    const bool qd[4] = { within(q[0], (uint32_t)d), within(q[1], (uint32_t)d), within(q[2], (uint32_t)d), within(q[3], (uint32_t)d) };
+    // the three distinct second SADs (they only know u >> 1)
+    const int diff2[3] = {
+        (int)__builtin_amdgcn_sad_u8(__builtin_amdgcn_perm(t2hi, t2lo, lat_sel3(0)), __builtin_amdgcn_perm(b2hi, b2lo, lat_sel3(3)), 0u),
+        (int)__builtin_amdgcn_sad_u8(__builtin_amdgcn_perm(t2hi, t2lo, lat_sel3(1)), __builtin_amdgcn_perm(b2hi, b2lo, lat_sel3(2)), 0u),
+        (int)__builtin_amdgcn_sad_u8(__builtin_amdgcn_perm(t2hi, t2lo, lat_sel3(2)), __builtin_amdgcn_perm(b2hi, b2lo, lat_sel3(1)), 0u) };
+    uint32_t best = 0x7fffffffu;
+#define LAT_STEP(i)                                                                                                   \
     {                                                                                                                 \
-        const uint32_t bg = __builtin_amdgcn_perm(bhi, blo, lat_sel3(2 - (j))), tg = __builtin_amdgcn_perm(thi, tlo, lat_sel3(2 + (j))); \
+        constexpr int A = (i) >> 1, B = ((i) + 1) >> 1;                                                               \
+        const uint32_t bg = __builtin_amdgcn_perm(bhi, blo, lat_sel3(5 - (i))), tg = __builtin_amdgcn_perm(thi, tlo, lat_sel3(i)); \
         const int diff = (int)__builtin_amdgcn_sad_u8(tc, bg, __builtin_amdgcn_sad_u8(bc, tg, 0u));                   \
-        if (diff < mn && (near_t & lat_bits3(2 + (j))) && (near_b & lat_bits3(2 - (j))))                               \
-        {                                                                                                             \
-            const int u = first + (j);                                                                                \
-            const int h0 = u >> 1, h1 = (u + 1) >> 1;                                                                 \
-            const int diff2 = sad3(top, x + h0, bot, x - h0);                                                         \
-            const int o0 = ot[x + h0], o1 = ot[x + h1], q0 = ob[x - h0], q1 = ob[x - h1];                             \
-            if (diff2 < nt4 && (((iabs(o0 - q0) <= lim || iabs(o0 - q1) <= lim) && o0 != PEAK) ||                     \
-                                ((iabs(o1 - q0) <= lim || iabs(o1 - q1) <= lim) && o1 != PEAK)) &&                    \
-                (iabs(d - o0) <= lim || iabs(d - o1) <= lim) && (iabs(d - q0) <= lim || iabs(d - q1) <= lim))         \
-            {                                                                                                         \
-                val = ((int)top[x + h0] + (int)top[x + h1] + (int)bot[x - h0] + (int)bot[x - h1] + 2) >> 2;           \
-                mn = diff;                                                                                            \
-                dir = u;                                                                                              \
-            }                                                                                                         \
-        }                                                                                                             \
+        const bool oq = A == B ? (within(o[A], q[3 - A]) && o[A] != PEAK)                                             \
+                               : (((within(o[A], q[3 - A]) || within(o[A], q[3 - B])) && o[A] != PEAK) ||             \
+                                  ((within(o[B], q[3 - A]) || within(o[B], q[3 - B])) && o[B] != PEAK));              \
+        const bool ok = ((i) == 0 ? par == 0 : (i) == 5 ? par != 0 : true) && diff < nt8 &&                           \
+                        (near_t & lat_bits3(i)) && (near_b & lat_bits3(5 - (i))) && diff2[A] < nt4 && oq &&           \
+                        (od[A] || od[B]) && (qd[3 - A] || qd[3 - B]);                                                 \
+        best = min(best, ok ? ((uint32_t)diff << 3) | (uint32_t)(i) : 0x7fffffffu);                                   \
     }
-    LAT_STEP(-2) LAT_STEP(-1) LAT_STEP(0) LAT_STEP(1) LAT_STEP(2)
+    LAT_STEP(0) LAT_STEP(1) LAT_STEP(2) LAT_STEP(3) LAT_STEP(4) LAT_STEP(5)
 #undef LAT_STEP
-    if (mn != nt8) return base | ((uint32_t)val << 8) | ((uint32_t)((NEUTRAL + dir * 4) & 0xff) << 16);
-    return base | LAT_MORE;
+    if (best == 0x7fffffffu) return base | LAT_MORE;
+    const int u = de - 2 + (int)(best & 7u);
+    const int h0 = u >> 1, h1 = (u + 1) >> 1;
+    const int val = ((int)top[x + h0] + (int)top[x + h1] + (int)bot[x - h0] + (int)bot[x - h1] + 2) >> 2;
+    return base | ((uint32_t)val << 8) | ((uint32_t)((NEUTRAL + u * 4) & 0xff) << 16);
 }
 
 // the short search for pixels the first one left without a match (:1292-1318)

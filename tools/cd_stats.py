@@ -43,7 +43,7 @@ def main():
         fields = max(produced_b, 1)
         names = ["workgroups", "workgroups_listing", "listed_pixels", "wave_trips", "lane_steps", "wave_steps", "lanes_in_trips", "dense_workgroups", "dense_waves", "dense_waves_all", "-", "-",
                  "fg_workgroups", "fg_gap_pixels", "fg_sum_gap_len", "fg_fast", "fg_minmax_walks", "fg_minmax_bytes",
-                 "lat_stage_a", "lat_stage_b", "lat_stage_c", "lat_workgroups", "-", "-"]
+                 "-", "lat_stage_b", "lat_stage_c", "lat_workgroups", "lat_b_clamped", "lat_b_second_tests"]
         print(json.dumps({"batch": b, "fields": produced_b, "per_field": {n: round(x / fields, 1) for n, x in zip(names, v)},
                           "lane_efficiency": round(v[4] / (64.0 * v[5]), 3) if v[5] else None}))
         produced += produced_b
