@@ -557,6 +557,9 @@ struct ScaleBatch8
     uint8_t       *dst[SU_FRAMES][3];
 };
 
+// TH: rows of a tile - 32 where the source rows that many output rows tap fit the LDS frame (every upscale by 4/3 or more:
+// 22 source rows under 32 output rows at 2x, against 14 under 16 - a fifth less staging and horizontal work), else 16
+template <int TH>
 __global__ __launch_bounds__(256) void scale8_up_kernel(ScaleBatch8 B)
 {
     __shared__ uint32_t s_src[SU_MAXR][SU_SRC_DW];
@@ -564,10 +567,10 @@ __global__ __launch_bounds__(256) void scale8_up_kernel(ScaleBatch8 B)
     const int f = (int)blockIdx.z / 3, pl = (int)blockIdx.z - 3 * f;
     const ScalePlane8 &P = B.p[pl];
     if (!P.active) return;
-    const int x0 = blockIdx.x * SU_TW, y0 = blockIdx.y * SU_TH;
+    const int x0 = blockIdx.x * SU_TW, y0 = blockIdx.y * TH;
     if (x0 >= P.dw || y0 >= P.dh) return;
     const int t = threadIdx.x;
-    const int xe = min(x0 + SU_TW, P.dw) - 1, ye = min(y0 + SU_TH, P.dh) - 1;
+    const int xe = min(x0 + SU_TW, P.dw) - 1, ye = min(y0 + TH, P.dh) - 1;
     const int cmin = P.bx[x0] & ~3, cmax = P.bx[xe] + 5;           // bx, by are non-decreasing
     const int rmin = P.by[y0], nr = P.by[ye] + 5 - rmin + 1;
     const int ndw = (cmax - cmin) / 4 + 1;                          // <= SU_SRC_DW - 2, nr <= SU_MAXR (checked by the host)
@@ -893,6 +896,8 @@ public:
                 }
                 for (int y0 = 0; y0 < dh && up6; y0 += SU_TH)
                     if (by[std::min(y0 + SU_TH, dh) - 1] + 5 - by[y0] + 1 > SU_MAXR) up6 = false;
+                for (int y0 = 0; y0 < dh && tall; y0 += 2 * SU_TH)
+                    if (by[std::min(y0 + 2 * SU_TH, dh) - 1] + 5 - by[y0] + 1 > SU_MAXR) tall = false;
             }
         }
         size_t need = 0;
@@ -941,7 +946,9 @@ public:
                     }
                 }
                 const dim3 grid((out_geo.pw[0] + SU_TW - 1) / SU_TW, (out_geo.ph[0] + SU_TH - 1) / SU_TH, 3 * m);
-                if (in_geo.bps == 1) HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", scale8_up_kernel, grid, dim3(256), 0, B);
+                const dim3 grid_tall(grid.x, (out_geo.ph[0] + 2 * SU_TH - 1) / (2 * SU_TH), grid.z);
+                if (in_geo.bps == 1 && tall) HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", scale8_up_kernel<2 * SU_TH>, grid_tall, dim3(256), 0, B);
+                else if (in_geo.bps == 1) HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", scale8_up_kernel<SU_TH>, grid, dim3(256), 0, B);
                 else                 HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", scale16_up_kernel, grid, dim3(256), 0, B, vmax);
             }
         else
@@ -972,6 +979,7 @@ public:
 
     int process(DevPicture *in, DevPicture *out) override { return process_many(&in, &out, 1); }
     bool up6 = true;            // six taps either way and every tile fits the fused kernel's LDS frame
+    bool tall = true;           // ... also at 32 rows per tile (8-bit kernel)
     hbhip_cropscale_params par;
     int crop_x[3], crop_y[3], crop_w[3], crop_h[3], tx[3] = {0, 0, 0}, ty[3] = {0, 0, 0};
     bool identity[3] = {false, false, false};
