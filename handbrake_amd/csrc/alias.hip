@@ -564,6 +564,7 @@ __global__ __launch_bounds__(256) void scale8_up_kernel(ScaleBatch8 B)
 {
     __shared__ uint32_t s_src[SU_MAXR][SU_SRC_DW];
     __shared__ __attribute__((aligned(16))) uint32_t s_h[SU_PAIRS][SU_TW];
+    __shared__ uint4 s_v[TH];
     const int f = (int)blockIdx.z / 3, pl = (int)blockIdx.z - 3 * f;
     const ScalePlane8 &P = B.p[pl];
     if (!P.active) return;
@@ -574,48 +575,67 @@ __global__ __launch_bounds__(256) void scale8_up_kernel(ScaleBatch8 B)
     const int cmin = P.bx[x0] & ~3, cmax = P.bx[xe] + 5;           // bx, by are non-decreasing
     const int rmin = P.by[y0], nr = P.by[ye] + 5 - rmin + 1;
     const int ndw = (cmax - cmin) / 4 + 1;                          // <= SU_SRC_DW - 2, nr <= SU_MAXR (checked by the host)
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+    // the thread's column of the horizontal pass: its window and coefficients are on their way while the tile is staged
+    const int xh = min(x0 + t, P.dw - 1);
+    const int bxh = P.bx[xh];
+    const uint32_t hc01 = P.qx[3 * (size_t)xh], hc23 = P.qx[3 * (size_t)xh + 1], hc45 = P.qx[3 * (size_t)xh + 2];
+    // the vertical pass's rows: first tapped row and the three coefficient pairs of the tile's output rows
+    if (t < TH && y0 + t <= ye)
+    {
+        const int y = y0 + t;
+        s_v[t] = make_uint4((uint32_t)(P.by[y] - rmin), P.qy[3 * (size_t)y], P.qy[3 * (size_t)y + 1], P.qy[3 * (size_t)y + 2]);
+    }
     {
         const uint8_t *src = B.src[f][pl];
         const int spitch = B.spitch[pl];
-        // four dwords of a thread in flight before its first LDS store (a 2x tile stages 14 x 35 dwords: two per thread; as
-        // a loop of load -> store pairs they were two round trips in a row)
-        const int n = nr * ndw;
-        for (int base = 0; base < n; base += 4 * 256)
+        // a wave stages the rows wave, wave + 4, ..: a lane per dword of the row (a 2x tile: 35 of them, two more lanes'
+        // worth at most), the row loop without a division, all loads of a thread in flight before its first LDS store
+        constexpr int RPW = SU_MAXR / 4;
+        uint32_t v[RPW][2];
+#pragma unroll
+        for (int j = 0; j < RPW; j++)
         {
-            uint32_t v[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++)
+            const int rr = wave + 4 * j;
+            v[j][0] = v[j][1] = 0;
+            if (rr < nr)
             {
-                const int i = base + t + 256 * j;
-                v[j] = 0;
-                if (i < n)
-                {
-                    const int rr = i / ndw, d = i - rr * ndw, col = cmin + 4 * d;
-                    const uint8_t *row = src + (size_t)reflect_idx(rmin + rr, P.sh) * spitch;
-                    if (col >= 0 && col + 3 < P.sw && (((uintptr_t)(row + col)) & 3) == 0) v[j] = *reinterpret_cast<const uint32_t *>(row + col);
-                    else
-                    {
+                const uint8_t *row = src + (size_t)reflect_idx(rmin + rr, P.sh) * spitch;
 #pragma unroll
-                        for (int k = 0; k < 4; k++) v[j] |= (uint32_t)row[reflect_idx(col + k, P.sw)] << (8 * k);
+                for (int h = 0; h < 2; h++)
+                {
+                    const int d = lane + 64 * h, col = cmin + 4 * d;
+                    if (d < ndw)
+                    {
+                        if (col >= 0 && col + 3 < P.sw && (((uintptr_t)(row + col)) & 3) == 0) v[j][h] = *reinterpret_cast<const uint32_t *>(row + col);
+                        else
+                        {
+#pragma unroll
+                            for (int k = 0; k < 4; k++) v[j][h] |= (uint32_t)row[reflect_idx(col + k, P.sw)] << (8 * k);
+                        }
                     }
                 }
             }
+        }
 #pragma unroll
-            for (int j = 0; j < 4; j++)
+        for (int j = 0; j < RPW; j++)
+        {
+            const int rr = wave + 4 * j;
+            if (rr < nr)
             {
-                const int i = base + t + 256 * j;
-                if (i < n) { const int rr = i / ndw; s_src[rr][i - rr * ndw] = v[j]; }
+                if (lane < ndw) s_src[rr][lane] = v[j][0];
+                if (lane + 64 < ndw) s_src[rr][lane + 64] = v[j][1];
             }
         }
     }
     __syncthreads();
     if (x0 + t < P.dw)
     {
-        const int x = x0 + t, o = P.bx[x] - cmin, dq = o >> 2, ob = o & 3;
+        const int o = bxh - cmin, dq = o >> 2, ob = o & 3;
         // selectors of v_perm_b32(hi, lo, sel): bytes ob, ob + 1 (ob + 2, ob + 3) of {hi:lo} zero-extended to halves
         const uint32_t sel01 = (uint32_t)ob | 0x0c000c00u | ((uint32_t)(ob + 1) << 16);
         const uint32_t sel23 = (uint32_t)(ob + 2) | 0x0c000c00u | ((uint32_t)(ob + 3) << 16);
-        const uint32_t c01 = P.qx[3 * (size_t)x], c23 = P.qx[3 * (size_t)x + 1], c45 = P.qx[3 * (size_t)x + 2];
+        const uint32_t c01 = hc01, c23 = hc23, c45 = hc45;
         uint16_t *hp = reinterpret_cast<uint16_t *>(&s_h[0][0]) + 2 * t;
         for (int rr = 0; rr < nr; rr++)
         {
@@ -628,12 +648,13 @@ __global__ __launch_bounds__(256) void scale8_up_kernel(ScaleBatch8 B)
         }
     }
     __syncthreads();
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, xq = x0 + 4 * lane;
+    const int xq = x0 + 4 * lane;
     if (xq >= P.dw) return;
     for (int y = y0 + wave; y <= ye; y += 4)
     {
-        const int ob = __builtin_amdgcn_readfirstlane(P.by[y] - rmin);
-        const uint32_t c01 = P.qy[3 * (size_t)y], c23 = P.qy[3 * (size_t)y + 1], c45 = P.qy[3 * (size_t)y + 2];
+        const uint4 vt = s_v[y - y0];
+        const int ob = __builtin_amdgcn_readfirstlane((int)vt.x);
+        const uint32_t c01 = vt.y, c23 = vt.z, c45 = vt.w;
         // fx_to8(fx_round14(acc)) = clamp((((acc + 8192) >> 14) + 32768 + 128) >> 8, 0, 255) with the 16-bit clamp folded in
         // (a value outside 0 .. 65535 lands outside 0 .. 255 either way) = clamp((acc + K) >> 22, 0, 255): the sums start at K
         constexpr int K = 8192 + (32768 << 14) + (128 << 14);       // |acc| < 2^30, so acc + K stays inside int
