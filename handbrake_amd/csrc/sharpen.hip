@@ -479,7 +479,7 @@ int launch_copy(hbhip_ctx *ctx, const char *name, DevPicture *in, DevPicture *ou
 // double arithmetic, operation for operation (lapsharp.c:174-175).  One launch covers the three planes of up to
 // LS_FRAMES frames (blockIdx.z): single 1080p planes are too small to fill the GPU or hide a launch.
 constexpr int LS_ROWS = 8, LS_FRAMES = 16;
-struct LapPlane3 { int width, height, src_pitch, dst_pitch, stride_border, valid_w, a, b, c, active; double coef, strength; };
+struct LapPlane3 { int width, height, src_pitch, dst_pitch, stride_border, valid_w, a, b, c, active; double coef, strength; int fast, kinv; float mixf; };
 struct LapBatch3
 {
     LapPlane3      pl[3];
@@ -504,11 +504,21 @@ __global__ __launch_bounds__(256) void lapsharp3_rows_kernel(LapBatch3 B)
     // byte offsets of the three dwords of a row this thread reads (clamped into the row: only read for pixels that end up
     // copied), as 32-bit unsigned offsets from the plane's base: a row costs one multiply and three adds of address work
     const uint32_t o0 = 4u * (uint32_t)max(xd - 1, 0), o1 = 4u * (uint32_t)xd, o2 = 4u * (uint32_t)min(xd + 1, pitch_dw - 1);
-    auto load_row = [&](int yy, int (&u)[4], int (&v)[4], int (&m)[4]) {
-        yy = min(max(yy, 0), P.height - 1);                  // only read for pixels that end up copied
+    // All of the thread's rows are fetched before the first of them is used: the stores of a row may alias the loads of the
+    // next as far as the compiler knows, so a load inside the row loop waited for the previous row's store to be issued -
+    // one row of loads in flight per thread, ten round trips to memory in a row.
+    uint32_t raw[LS_ROWS + 2][3];
+#pragma unroll
+    for (int i = 0; i < LS_ROWS + 2; i++)
+    {
+        const int yy = min(max(ys - 1 + i, 0), P.height - 1);                  // (outside the plane: only read for pixels that end up copied)
         const uint32_t ro = (uint32_t)__mul24(yy, P.src_pitch);      // rows and pitches stay below 2^23
-        uint32_t w[3] = { *reinterpret_cast<const uint32_t *>(src + (ro + o0)), *reinterpret_cast<const uint32_t *>(src + (ro + o1)),
-                          *reinterpret_cast<const uint32_t *>(src + (ro + o2)) };
+        raw[i][0] = *reinterpret_cast<const uint32_t *>(src + (ro + o0));
+        raw[i][1] = *reinterpret_cast<const uint32_t *>(src + (ro + o1));
+        raw[i][2] = *reinterpret_cast<const uint32_t *>(src + (ro + o2));
+    }
+    auto load_row = [&](int i, int (&u)[4], int (&v)[4], int (&m)[4]) {
+        uint32_t w[3] = { raw[i][0], raw[i][1], raw[i][2] };
         if (tail)
         {
 #pragma unroll
@@ -534,8 +544,8 @@ __global__ __launch_bounds__(256) void lapsharp3_rows_kernel(LapBatch3 B)
     };
     {
         int v_tmp[4], m_tmp[4];
-        load_row(ys - 1, u_prev, v_tmp, m_tmp);
-        load_row(ys, u_cur, v_cur, m_cur);
+        load_row(0, u_prev, v_tmp, m_tmp);
+        load_row(1, u_cur, v_cur, m_cur);
     }
     const int y_end = min(ys + LS_ROWS, P.height);
     // which of the thread's four columns are copied whatever the row (x < stride_border + HI || x > width + stride_border
@@ -552,7 +562,7 @@ __global__ __launch_bounds__(256) void lapsharp3_rows_kernel(LapBatch3 B)
         const int y = ys + r;
         if (y >= y_end) break;
         int u_next[4], v_next[4], m_next[4];
-        load_row(y + 1, u_next, v_next, m_next);
+        load_row(r + 2, u_next, v_next, m_next);
         const bool row_copy = (y < 2) || (y > P.height - 2);                 // y < HI || y > height - HI, HI = 2
         uint32_t packed = 0;
         if (row_copy)                                                        // wave-uniform (a wave works on one row)
@@ -562,15 +572,30 @@ __global__ __launch_bounds__(256) void lapsharp3_rows_kernel(LapBatch3 B)
         }
         else
         {
-#pragma unroll
-            for (int k = 0; k < 4; k++)
+            if (P.fast)                                                      // one float multiply stands for the mix (lap_float_mix)
             {
-                const int centre = m_cur[k];
-                const int acc = u_prev[k] + v_cur[k] + u_next[k];
-                const double mixed = (((double)acc * P.coef) - (double)centre) * P.strength;   // lapsharp.c:174-175
-                int out = (int)(short)(int)mixed + centre;
-                out = min(max(out, 0), 255);
-                packed |= (uint32_t)out << (8 * k);
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                {
+                    const int centre = m_cur[k];
+                    const int acc = u_prev[k] + v_cur[k] + u_next[k];
+                    int out = (int)((float)(acc - __mul24(P.kinv, centre)) * P.mixf) + centre;
+                    out = min(max(out, 0), 255);
+                    packed |= (uint32_t)out << (8 * k);
+                }
+            }
+            else
+            {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                {
+                    const int centre = m_cur[k];
+                    const int acc = u_prev[k] + v_cur[k] + u_next[k];
+                    const double mixed = (((double)acc * P.coef) - (double)centre) * P.strength;   // lapsharp.c:174-175
+                    int out = (int)(short)(int)mixed + centre;
+                    out = min(max(out, 0), 255);
+                    packed |= (uint32_t)out << (8 * k);
+                }
             }
             if (copy_cols)                                                   // border columns keep the source sample
             {
@@ -672,6 +697,36 @@ __global__ __launch_bounds__(256) void lapsharp3_rows16_kernel(LapBatch3 B, int 
     }
 }
 
+// The mix of lapsharp.c:174-175 - (((double)sum * coef) - centre) * strength, truncated - as ONE float multiply for 8-bit
+// planes: 1 / coef is an integer k for every table, so the difference is (sum - k centre) coef up to the doubles' rounding,
+// and the product with coef * strength is either an integer (where a float constant a hair above or below the real one
+// lands on the side the double form lands on) or far from one.  Whether some float constant reproduces the double form
+// is not argued but tried: every (sum, centre) the taps can produce, 2.9 M cases for isolap, once per filter; strengths for
+// which none does (most that are not short decimals) keep the double form.
+static bool lap_float_mix(const LapKernel &k, double strength, int &kinv, float &mixf)
+{
+    if (!(strength >= 0.0) || !(k.coef > 0.0) || k.size != 3) return false;
+    const int ki = (int)std::lround(1.0 / k.coef);
+    if (ki < 1 || ki > 255 || std::fabs(k.coef * ki - 1.0) > 1e-12) return false;
+    int lo = 0, hi = 0;
+    for (int i = 0; i < 9; i++) (k.tap[i] < 0 ? lo : hi) += 255 * k.tap[i];
+    const float s = (float)(k.coef * strength);
+    const float cands[3] = { s, std::nextafterf(s, INFINITY), std::nextafterf(s, -INFINITY) };
+    for (float c : cands)
+    {
+        bool ok = true;
+        for (int sum = lo; sum <= hi && ok; sum++)
+            for (int centre = 0; centre < 256; centre++)
+            {
+                const double mixed = (((double)sum * k.coef) - (double)centre) * strength;
+                const volatile float prod = (float)(sum - ki * centre) * c;      // one rounding, as v_mul_f32
+                if ((int)(short)(int)mixed != (int)prod) { ok = false; break; }
+            }
+        if (ok) { kinv = ki; mixf = c; return true; }
+    }
+    return false;
+}
+
 // ------------------------------------------------------------------ filter classes
 class LapsharpFilter : public SimpleFilter
 {
@@ -701,6 +756,14 @@ public:
                 P.a = k.tap[0]; P.b = k.tap[1]; P.c = k.tap[4];
                 P.coef = k.coef; P.strength = par.strength[c];
                 P.active = 1;
+                if (!mix_tried[c])
+                {
+                    mix_tried[c] = true;
+                    if (c && mix_tried[c - 1] && par.kernel[c] == par.kernel[c - 1] && par.strength[c] == par.strength[c - 1])
+                    { mix_fast[c] = mix_fast[c - 1]; mix_k[c] = mix_k[c - 1]; mix_f[c] = mix_f[c - 1]; }
+                    else mix_fast[c] = in_geo.bps == 1 && lap_float_mix(k, par.strength[c], mix_k[c], mix_f[c]);
+                }
+                P.fast = mix_fast[c]; P.kinv = mix_k[c]; P.mixf = mix_f[c];
                 max_w = std::max(max_w, P.width); max_h = std::max(max_h, P.height);
                 for (int f = 0; f < nf; f++)
                 {
@@ -766,6 +829,9 @@ public:
         return HBHIP_OK;
     }
     hbhip_lapsharp_params par;
+    bool  mix_tried[3] = {}, mix_fast[3] = {};     // lap_float_mix per plane, tried on first use
+    int   mix_k[3] = {};
+    float mix_f[3] = {};
 };
 
 class BlurMixFilter : public SimpleFilter
