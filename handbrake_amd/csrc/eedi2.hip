@@ -1620,10 +1620,32 @@ __global__ __launch_bounds__(256) void k_mark_2x4(P3 P)
     const int y0 = 2 - tff;
     if (x >= pitch || 2 * r >= height) return;
     const bool two = 2 * r + 1 < height;
+    // the row of the pair with the parity of the rebuilt rows, and the other one
+    const int y = 2 * r + (y0 & 1), yc = 2 * r + 1 - (y0 & 1);
+    const bool rebuilt = y < height && !maskless && y >= y0 && y < height - 1;
+    const size_t hs = (size_t)r * pitch + x, fs = (size_t)(2 * r) * pitch + x;
+    // every load the thread may need goes out ahead of its first store: the memory counter is in order, and a load behind
+    // a store is only known to be there once the store is (the mask rows (y - 1) >> 1 and (y + 1) >> 1 are row r and the one
+    // above or below it)
+    const uint32_t vg = *reinterpret_cast<const uint32_t *>(Q.g + hs), vb = *reinterpret_cast<const uint32_t *>(Q.b + hs),
+                   va = *reinterpret_cast<const uint32_t *>(Q.a + hs);
+    uint32_t k0w = 0, k1w = 0;
+    if (rebuilt)
     {
-        const size_t hs = (size_t)r * pitch + x, fs = (size_t)(2 * r) * pitch + x;
-        const uint32_t vg = *reinterpret_cast<const uint32_t *>(Q.g + hs), vb = *reinterpret_cast<const uint32_t *>(Q.b + hs),
-                       va = *reinterpret_cast<const uint32_t *>(Q.a + hs);
+        const int ra = (y - 1) >> 1, rb = (y + 1) >> 1;
+        k0w = ra == r ? va : *reinterpret_cast<const uint32_t *>(Q.a + (ptrdiff_t)ra * pitch + x);
+        k1w = rb == r ? va : *reinterpret_cast<const uint32_t *>(Q.a + (ptrdiff_t)rb * pitch + x);
+    }
+    // the mask first: a thread none of whose four pixels sits under or above a mask pixel writes peaks and never fetches the
+    // direction rows (k_dir_map4)
+    const bool vote = rebuilt && ((ff_bytes(k0w) | ff_bytes(k1w)) & mf_bytes_in(x, 1, width - 1)) != 0u;
+    Win12 wa = { 0u, 0u, 0u }, wbn = { 0u, 0u, 0u };
+    if (vote)
+    {
+        wa = ldwin(Q.b + (ptrdiff_t)((y - 1) >> 1) * pitch + x);
+        wbn = ldwin(Q.b + (ptrdiff_t)((y + 1) >> 1) * pitch + x);
+    }
+    {
         *reinterpret_cast<uint32_t *>(Q.d + fs) = vg;
         *reinterpret_cast<uint32_t *>(Q.e + fs) = vb;
         *reinterpret_cast<uint32_t *>(Q.f + fs) = va;
@@ -1634,27 +1656,15 @@ __global__ __launch_bounds__(256) void k_mark_2x4(P3 P)
             *reinterpret_cast<uint32_t *>(Q.f + fs + pitch) = va;
         }
     }
-    // the row of the pair with the parity of the rebuilt rows, and the other one
-    const int y = 2 * r + (y0 & 1), yc = 2 * r + 1 - (y0 & 1);
     if (yc < height) *reinterpret_cast<uint32_t *>(Q.c + (size_t)yc * pitch + x) = 0xffffffffu;      // memset(dstp, 255, pitch*height)
     if (y >= height) return;
     uint32_t *o = reinterpret_cast<uint32_t *>(Q.c + (size_t)y * pitch + x);
-    if (maskless || !(y >= y0 && y < height - 1))             // (no mask pixel in the plane: nothing but the memset, :800)
-    {
-        *o = 0xffffffffu;
-        return;
-    }
-    // the mask first: a thread none of whose four pixels sits under or above a mask pixel writes peaks and never fetches the
-    // direction rows (k_dir_map4)
-    const uint32_t k0w = *reinterpret_cast<const uint32_t *>(Q.a + (ptrdiff_t)((y - 1) >> 1) * pitch + x);
-    const uint32_t k1w = *reinterpret_cast<const uint32_t *>(Q.a + (ptrdiff_t)((y + 1) >> 1) * pitch + x);
     uint32_t packed = 0xffffffffu;
-    if (((ff_bytes(k0w) | ff_bytes(k1w)) & mf_bytes_in(x, 1, width - 1)) == 0u)
+    if (!vote)                                                 // (no mask pixel in the plane or near the thread: nothing but the memset, :800)
     {
         *o = packed;
         return;
     }
-    const Win12 wa = ldwin(Q.b + (ptrdiff_t)((y - 1) >> 1) * pitch + x), wbn = ldwin(Q.b + (ptrdiff_t)((y + 1) >> 1) * pitch + x);
 #pragma unroll
     for (int k = 0; k < 4; k++)
     {

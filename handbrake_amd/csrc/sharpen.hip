@@ -631,11 +631,18 @@ __global__ __launch_bounds__(256) void lapsharp3_rows16_kernel(LapBatch3 B, int 
     const uint32_t o0 = 4u * (uint32_t)max(xd - 1, 0), o1 = 4u * (uint32_t)xd, o2 = 4u * (uint32_t)min(xd + 1, pitch_dw - 1),
                    o3 = 4u * (uint32_t)min(xd + 2, pitch_dw - 1);
     int u_prev[4], u_cur[4], v_cur[4], m_cur[4];
-    auto load_row = [&](int yy, int (&u)[4], int (&v)[4], int (&m)[4]) {
-        yy = min(max(yy, 0), P.height - 1);                  // only read for samples that end up copied
-        const uint32_t ro = (uint32_t)__mul24(yy, P.src_pitch);
-        const uint32_t w0 = *reinterpret_cast<const uint32_t *>(src + (ro + o0)), w1 = *reinterpret_cast<const uint32_t *>(src + (ro + o1)),
-                       w2 = *reinterpret_cast<const uint32_t *>(src + (ro + o2)), w3 = *reinterpret_cast<const uint32_t *>(src + (ro + o3));
+    // all rows of the thread fetched ahead of its first store (lapsharp3_rows_kernel)
+    uint32_t raw[LS_ROWS + 2][4];
+#pragma unroll
+    for (int i = 0; i < LS_ROWS + 2; i++)
+    {
+        const uint32_t ro = (uint32_t)__mul24(min(max(ys - 1 + i, 0), P.height - 1), P.src_pitch);
+        raw[i][0] = *reinterpret_cast<const uint32_t *>(src + (ro + o0)); raw[i][1] = *reinterpret_cast<const uint32_t *>(src + (ro + o1));
+        raw[i][2] = *reinterpret_cast<const uint32_t *>(src + (ro + o2)); raw[i][3] = *reinterpret_cast<const uint32_t *>(src + (ro + o3));
+    }
+    auto load_row = [&](int i, int (&u)[4], int (&v)[4], int (&m)[4]) {
+        const uint32_t ro = (uint32_t)__mul24(min(max(ys - 1 + i, 0), P.height - 1), P.src_pitch);   // only read for samples that end up copied
+        const uint32_t w0 = raw[i][0], w1 = raw[i][1], w2 = raw[i][2], w3 = raw[i][3];
         int bb[6] = { (int)(w0 >> 16), (int)(w1 & 0xffffu), (int)(w1 >> 16), (int)(w2 & 0xffffu), (int)(w2 >> 16), (int)(w3 & 0xffffu) };
         if (tail)
         {
@@ -658,8 +665,8 @@ __global__ __launch_bounds__(256) void lapsharp3_rows16_kernel(LapBatch3 B, int 
     };
     {
         int v_tmp[4], m_tmp[4];
-        load_row(ys - 1, u_prev, v_tmp, m_tmp);
-        load_row(ys, u_cur, v_cur, m_cur);
+        load_row(0, u_prev, v_tmp, m_tmp);
+        load_row(1, u_cur, v_cur, m_cur);
     }
     const int y_end = min(ys + LS_ROWS, P.height);
     uint32_t copy_cols = 0;
@@ -673,7 +680,7 @@ __global__ __launch_bounds__(256) void lapsharp3_rows16_kernel(LapBatch3 B, int 
         const int y = ys + r;
         if (y >= y_end) break;
         int u_next[4], v_next[4], m_next[4];
-        load_row(y + 1, u_next, v_next, m_next);
+        load_row(r + 2, u_next, v_next, m_next);
         const bool row_copy = (y < 2) || (y > P.height - 2);
         int out[4];
 #pragma unroll
