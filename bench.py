@@ -450,9 +450,12 @@ def run_chain(args, world, rank, local_rank):
             self.ctx = hip.Ctx(local_rank)
             self.ctxs = [self.ctx]
 
-            def stage_ctx():
-                # split 1: a context (HIP stream) per stage; split 2: decomb on one context, the stages behind it on a second
-                if not split or (split == 2 and len(self.ctxs) >= 3):
+            def stage_ctx(stage=0):
+                # split 1: a context (HIP stream) per stage; split 2: decomb on one context, the stages behind it on a second;
+                # split 3: decomb + NLMeans (arithmetic-bound) on one, the scaler + lapsharp (memory-bound) on a second;
+                # split 4: decomb / NLMeans / scaler + lapsharp
+                if (not split or (split == 2 and len(self.ctxs) >= 3) or (split == 3 and stage != 2 and len(self.ctxs) >= 2) or
+                        (split == 4 and stage == 3)):
                     return self.ctxs[-1]
                 self.ctxs.append(hip.Ctx(local_rank))
                 return self.ctxs[-1]
@@ -462,10 +465,10 @@ def run_chain(args, world, rank, local_rank):
             self.comb = hip.CombDetectDevice(self.ctx, W, H) if args.comb_detect else None
             stages = [hip.DeviceFilter(c, self.decomb.h)]
             if not only_decomb:
-                stages.append(hip.nlmeans_device_filter(stage_ctx(), hip.NLMEANS_MEDIUM, W, H, batch=1, depth=depth))
+                stages.append(hip.nlmeans_device_filter(stage_ctx(1), hip.NLMEANS_MEDIUM, W, H, batch=1, depth=depth))
                 if scale:
-                    stages.append(hip.cropscale_device_filter(stage_ctx(), W, H, OW, OH, depth=depth))
-                stages.append(hip.lapsharp_device_filter(stage_ctx(), OW, OH, depth=depth))
+                    stages.append(hip.cropscale_device_filter(stage_ctx(2), W, H, OW, OH, depth=depth))
+                stages.append(hip.lapsharp_device_filter(stage_ctx(3), OW, OH, depth=depth))
             self.decomb.h = None                              # owned by the chain from here on
             self.chain = hip.Chain(self.ctx, stages)
             self.cap = 2 * B + 4
@@ -703,11 +706,13 @@ def main():
                          "as BASELINE configs[2] words it")
     ap.add_argument("--no-kernel-timer", action="store_true",
                     help="chain workloads: skip the event-bracketed pass after the timed region (roofline = null)")
-    ap.add_argument("--stage-streams", type=int, default=0,
-                    help="chain workloads: 0 = the whole chain on one HIP stream (default; EEDI2 itself forks the passes of a "
-                         "batch's second half onto a side stream); 2 = decomb on one stream, the stages behind it on a second "
-                         "(+2 %% before EEDI2 forked, -3.5 %% with it); 1 = every filter of the chain on a stream of its own "
-                         "(libhb: one thread per filter; more streams than hardware queues: slower still)")
+    ap.add_argument("--stage-streams", type=int, default=2,
+                    help="chain workloads: 2 = decomb on one HIP stream, the stages behind it on a second (default: the next "
+                         "batch's EEDI2 passes beside this batch's NLMeans / scaler / lapsharp; 8 100 -> 8 300 output fps - it was "
+                         "-3.5 %% while EEDI2 took 16 fields per launch group); 0 = the whole chain on one stream (EEDI2 itself "
+                         "still forks its passes onto side streams); 1 = every filter on a stream of its own (libhb: one thread "
+                         "per filter; 7 400), 3 = decomb + NLMeans | scaler + lapsharp (7 900), 4 = decomb | NLMeans | scaler + "
+                         "lapsharp (7 300)")
     ap.add_argument("--streams", type=int, default=1,
                     help="chain workloads: independent streams (own HIP stream and filter instances) per GPU")
     ap.add_argument("--workload", default="chain", choices=sorted(WORKLOADS),
