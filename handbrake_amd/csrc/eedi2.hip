@@ -2314,24 +2314,36 @@ __global__ __launch_bounds__(256) void k_lattice_cand_q(P3 P, uint32_t *__restri
             const uint32_t *D = reinterpret_cast<const uint32_t *>(s_rows[4]) + LC_HALO / 4 + t;
             const uint32_t tm = T[-1], t4 = T[0], tp = T[1], bm = B[-1], b4 = B[0], bp = B[1];
             const uint32_t d4 = D[0], dn = D[1] & 0xffu;
-            uint32_t w[4];
-            uint32_t queue = 0;
+            uint32_t w[4], base[4];
+            int lim[4];
+            uint32_t queue = 0, searching = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++)
             {
                 const int d = (d4 >> (8 * k)) & 0xff, dr = k < 3 ? (int)((d4 >> (8 * k + 8)) & 0xff) : (int)dn;
                 const int avg = (int)(((t4 >> (8 * k)) & 0xff) + ((b4 >> (8 * k)) & 0xff) + 1) >> 1;
-                const int lim = s_lim[iabs(d - NEUTRAL) >> 2];
-                const bool right = iabs(d - dr) > lim;
-                const bool searching = d != PEAK && x + k < width;
-                const uint32_t base = (uint32_t)avg | ((uint32_t)right << 25);
-                const bool inner = x + k > 1 && x + k < width - 2;
-                const uint32_t ws = k == 0 ? lattice_stage_a4<2>(t4, tm, b4, bm, lim, inner, base)
-                                  : k == 1 ? lattice_stage_a4<3>(t4, tm, b4, bm, lim, inner, base)
-                                  : k == 2 ? lattice_stage_a4<0>(tp, t4, bp, b4, lim, inner, base)
-                                           : lattice_stage_a4<1>(tp, t4, bp, b4, lim, inner, base);
-                w[k] = searching ? (ws & ~LAT_MORE) : (base | ((uint32_t)avg << 8) | ((uint32_t)NEUTRAL << 16) | (1u << 24));
-                if (searching && (ws & LAT_MORE)) queue |= 1u << k;
+                lim[k] = s_lim[iabs(d - NEUTRAL) >> 2];
+                const bool right = iabs(d - dr) > lim[k];
+                if (d != PEAK && x + k < width) searching |= 1u << k;
+                base[k] = (uint32_t)avg | ((uint32_t)right << 25);
+                w[k] = base[k] | ((uint32_t)avg << 8) | ((uint32_t)NEUTRAL << 16) | (1u << 24);       // the word of a pixel without a direction
+            }
+            if (searching)                                         // (whole waves have none: the rows above the saturated part of the mask)
+            {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                {
+                    const bool inner = x + k > 1 && x + k < width - 2;
+                    const uint32_t ws = k == 0 ? lattice_stage_a4<2>(t4, tm, b4, bm, lim[k], inner, base[k])
+                                      : k == 1 ? lattice_stage_a4<3>(t4, tm, b4, bm, lim[k], inner, base[k])
+                                      : k == 2 ? lattice_stage_a4<0>(tp, t4, bp, b4, lim[k], inner, base[k])
+                                               : lattice_stage_a4<1>(tp, t4, bp, b4, lim[k], inner, base[k]);
+                    if ((searching >> k) & 1u)
+                    {
+                        w[k] = ws & ~LAT_MORE;
+                        if (ws & LAT_MORE) queue |= 1u << k;
+                    }
+                }
             }
             *reinterpret_cast<uint4 *>(&s_cand[4 * t]) = make_uint4(w[0], w[1], w[2], w[3]);
             if (queue)

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Copies what a tools/gpu_round.sh session left under gpurun_out/<tag>/ into profiles/ as <tag>_*, drops the files of the
+# tag it replaces, and regenerates what bench.py reads (pmc_traffic.json, the static instruction mixes).
+# usage: tools/install_profiles.sh <tag> [<old tag>]
+set -eu
+TAG=$1; OLD=${2:-}
+R=$(cd $(dirname $0)/.. && pwd); cd $R
+S=gpurun_out/$TAG
+[ -n "$OLD" ] && git rm -q --ignore-unmatch profiles/${OLD}_* || true
+for f in $S/bench_*.json; do cp $f profiles/${TAG}_$(basename $f); done
+cp $(find $S/kt -name '*kernel_stats.csv' | head -1) profiles/${TAG}_chain_kernel_stats.csv
+[ -d $S/kt_fork ] && cp $(find $S/kt_fork -name '*kernel_stats.csv' | head -1) profiles/${TAG}_chain_kernel_stats_forked.csv
+[ -f $S/fork_overlap.json ] && cp $S/fork_overlap.json profiles/${TAG}_chain_fork_overlap.json
+cp $S/pmc_summary.json profiles/${TAG}_chain_pmc_summary.json
+cp $S/trace_gaps.json profiles/${TAG}_chain_trace_gaps.json
+cp $S/kernel_bounds.json profiles/${TAG}_kernel_bounds.json
+cp $S/kernel_rooflines.json profiles/${TAG}_kernel_rooflines.json
+python tools/pmc_to_traffic.py $S/pmc_summary.json "profiles/${TAG}_chain_pmc_summary.json (tools/gpu_round.sh $TAG)" profiles/pmc_traffic.json
+python tools/isa_mix.py handbrake_amd/csrc/eedi2.hip profiles/r4_eedi2_isa_mix.json k_calc_dir_rows k_fill_gaps_b k_lattice_cand_q k_dir_map4 k_dir_map_c k_mark_2x4 k_filter_map k_mask_chain k_lattice_resolve > /dev/null
+python tools/isa_mix.py handbrake_amd/csrc/alias.hip profiles/r4_alias_isa_mix.json scale8_up_kernel > /dev/null
+python tools/isa_mix.py handbrake_amd/csrc/nlmeans.hip profiles/r4_nlmeans_isa_mix.json nlmeans_lanes_kernel > /dev/null
+git add profiles
+ls profiles | grep "^${TAG}_" | wc -l
