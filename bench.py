@@ -353,7 +353,7 @@ ISA_NAMES = {"eedi2_calc_directions": ("eedi2_isa_mix.json", "k_calc_dir_rows<4>
              "eedi2_lattice_candidates": ("eedi2_isa_mix.json", "k_lattice_cand_q"),
              "eedi2_filter_dir_map_2x": ("eedi2_isa_mix.json", "k_dir_map4"),
              "nlmeans_plane_n7": ("nlmeans_isa_mix.json", "nlmeans_lanes_kernel<7, 3, 36, false>"),
-             "cropscale_lanczos_fused": ("alias_isa_mix.json", "scale8_up_kernel")}
+             "cropscale_lanczos_fused": ("alias_isa_mix.json", "scale8_up_kernel<32>")}
 
 
 def _newest_profile(suffix):
@@ -584,8 +584,8 @@ def run_chain(args, world, rank, local_rank):
                         "algorithmic_bytes_per_launch": ab,
                         "note": "dominant kernel of the chain = largest share of summed kernel time in the event-"
                                 "bracketed pass that follows the timed region; its bytes are small against its "
-                                "arithmetic (a +-24 step search per edge pixel), see `valu`; a launch covers "
-                                "`frames_per_launch` fields"}
+                                "arithmetic (NLMeans: 17 patch comparisons per pixel; calc_directions: a +-24 step search "
+                                "per edge pixel), see `valu`; a launch covers `frames_per_launch` frames / fields"}
                 if valu:
                     roof["valu"] = valu_roofline(valu, d["avg_us"] * 1e-6, d["kernel"])
                 fl = issue_floors(d["kernel"])
@@ -599,7 +599,7 @@ def run_chain(args, world, rank, local_rank):
             "value": round(frames_total / dt_max, 2), "unit": "output frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt_max / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("u8" if depth == 8 else f"u16, {depth}-bit samples") + " (f32 NLMeans weights, 16-bit fixed-point scaler as zimg, f64 sharpen mix as the reference)",
+            "dtype": ("u8" if depth == 8 else f"u16, {depth}-bit samples") + " (f32 NLMeans weights, 16-bit fixed-point scaler as zimg, sharpen mix = the reference's f64 expression, as one f32 multiply where init proves that equal)",
             "data": "synthetic",
             "config": {"workload": wl["text"] + (" + comb detect in front (selective decomb, mode 63)" if args.comb_detect else ""),
                        "input_frames_per_step": B * len(lanes), "output_frames_per_step": 2 * B * len(lanes),
@@ -706,8 +706,9 @@ def main():
                          "as BASELINE configs[2] words it")
     ap.add_argument("--no-kernel-timer", action="store_true",
                     help="chain workloads: skip the event-bracketed pass after the timed region (roofline = null)")
-    ap.add_argument("--stage-streams", type=int, default=2,
-                    help="chain workloads: 2 = decomb on one HIP stream, the stages behind it on a second (default: the next "
+    ap.add_argument("--stage-streams", type=int, default=None,
+                    help="chain workloads: 2 = decomb on one HIP stream, the stages behind it on a second (default at 8 bits; at 10 / 12 "
+                         "bits, where it costs 3 %%, the default is 0: the next "
                          "batch's EEDI2 passes beside this batch's NLMeans / scaler / lapsharp; 8 100 -> 8 300 output fps - it was "
                          "-3.5 %% while EEDI2 took 16 fields per launch group); 0 = the whole chain on one stream (EEDI2 itself "
                          "still forks its passes onto side streams); 1 = every filter on a stream of its own (libhb: one thread "
@@ -722,6 +723,8 @@ def main():
                     help="no GPU, no kernels: the rank plumbing of the multi-GPU launch only (gloo on the CPU) - see "
                          "dry_run(); the line it prints is labelled and is not a measurement")
     args = ap.parse_args()
+    if args.stage_streams is None:
+        args.stage_streams = 2 if args.depth == 8 else 0
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -51,7 +51,7 @@ def test_counter_table_and_instruction_mixes_cover_the_dominant_kernels():
 
 
 def test_issue_floors_of_the_dominant_kernels():
-    for name, bound in (("eedi2_calc_directions", "valu"), ("nlmeans_plane_n7", "valu"), ("eedi2_lattice_candidates", "lds"),
+    for name, bound in (("eedi2_calc_directions", "valu"), ("nlmeans_plane_n7", "valu"), ("eedi2_lattice_candidates", "valu"),
                         ("eedi2_fill_gaps_2x", "salu")):
         f = bench.issue_floors(name)
         assert f and f["bound"] == bound and 0.3 < f["floor_frac"] <= 1.0, (name, f)

@@ -25,6 +25,19 @@ def test_lapsharp(built, w, h, kern, ys, cs):
     _eq(got, want)
 
 
+@pytest.mark.parametrize("kern", ["isolap", "lap"])
+@pytest.mark.parametrize("ys,cs", [(0.2, 0.3), (0.35, 0.7), (0.7, 0.123456789), (1.5, 0.04)])
+def test_lapsharp_mix_forms(built, kern, ys, cs):
+    """The 8-bit 3x3 kernel takes the mix as one float multiply where its init proves that equal to the reference's double
+    expression over every (sum, centre) (0.2, 0.3, 1.5, 0.04) and keeps the double form where no float constant does
+    (0.35 and 0.7 for both tables, 0.123456789 for lap): random content reaches every corner of both."""
+    frames = synth.stream("random", 638, 362, 2)
+    st = f"y-strength={ys}:y-kernel={kern}:cb-strength={cs}:cb-kernel={kern}"
+    got = hbrt.run_stream(hip.filters(), [("hb_filter_lapsharp_hip", st)], frames)
+    want = os_.lapsharp_stream(frames, [dict(strength=ys, kernel=kern)] + [dict(strength=cs, kernel=kern)] * 2)
+    _eq(got, want)
+
+
 def test_lapsharp_2160p(built):
     frames = synth.stream("progressive", 3840, 2160, 1)
     st = "y-strength=0.2:y-kernel=isolap:cb-strength=0.2:cb-kernel=isolap"

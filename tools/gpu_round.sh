@@ -43,6 +43,11 @@ timeout 240 rocprofv3 --kernel-trace --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INS
 cd $R
 python tools/summarize_pmc.py $OUT $OUT/pmc_summary.json > /dev/null 2>&1
 python tools/kernel_bounds.py $OUT/pmc_summary.json $(find $OUT/kt -name '*kernel_stats.csv' | head -1) $OUT/kernel_bounds.json > $OUT/kernel_bounds.txt 2>&1
+# the forked production path's trace too (what the chain really runs: EEDI2's side streams, decomb beside the other stages)
+cd /tmp
+timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_fork -o kt -- python $R/bench.py --workload chain --steps 6 --warmup 2 --no-cpu-baseline --no-pcie --no-kernel-timer > $OUT/kt_fork.log 2>&1
+cd $R
+python tools/trace_overlap.py $(find $OUT/kt_fork -name '*kernel_trace.csv' | head -1) $OUT/fork_overlap.json 250 > /dev/null 2>&1
 # keep only small files
 find $OUT -name '*kernel_trace.csv' -size +3M -delete
 find $OUT -name '*counter_collection.csv' -delete

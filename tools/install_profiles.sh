@@ -16,8 +16,8 @@ cp $S/trace_gaps.json profiles/${TAG}_chain_trace_gaps.json
 cp $S/kernel_bounds.json profiles/${TAG}_kernel_bounds.json
 cp $S/kernel_rooflines.json profiles/${TAG}_kernel_rooflines.json
 python tools/pmc_to_traffic.py $S/pmc_summary.json "profiles/${TAG}_chain_pmc_summary.json (tools/gpu_round.sh $TAG)" profiles/pmc_traffic.json
-python tools/isa_mix.py handbrake_amd/csrc/eedi2.hip profiles/r4_eedi2_isa_mix.json k_calc_dir_rows k_fill_gaps_b k_lattice_cand_q k_dir_map4 k_dir_map_c k_mark_2x4 k_filter_map k_mask_chain k_lattice_resolve > /dev/null
-python tools/isa_mix.py handbrake_amd/csrc/alias.hip profiles/r4_alias_isa_mix.json scale8_up_kernel > /dev/null
-python tools/isa_mix.py handbrake_amd/csrc/nlmeans.hip profiles/r4_nlmeans_isa_mix.json nlmeans_lanes_kernel > /dev/null
+python tools/isa_mix.py handbrake_amd/csrc/eedi2.hip profiles/r4_eedi2_isa_mix.json > /dev/null
+python tools/isa_mix.py handbrake_amd/csrc/alias.hip profiles/r4_alias_isa_mix.json > /dev/null
+python tools/isa_mix.py handbrake_amd/csrc/nlmeans.hip profiles/r4_nlmeans_isa_mix.json > /dev/null
 git add profiles
 ls profiles | grep "^${TAG}_" | wc -l
