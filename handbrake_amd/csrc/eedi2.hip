@@ -1714,7 +1714,10 @@ __global__ __launch_bounds__(256) void k_mark_2x4(P3 P)
 // Rows the pass does not rebuild are only copied (the reference's bit_blit), decided per workgroup.
 // (Tried and dropped: four pixels per thread without compaction - nearly every wave then pays four serial walks, 45 us
 // against 29; the walk on LDS without compaction, 38 us.)
-constexpr int FG_W = 1024, FG_HALO = 64, FG_LW = FG_W + 2 * FG_HALO;
+#ifndef FG_WIDTH
+#define FG_WIDTH 1024
+#endif
+constexpr int FG_W = FG_WIDTH, FG_T = FG_W / 4, FG_HALO = 64, FG_LW = FG_W + 2 * FG_HALO;
 
 
 // The walks are done on bitmaps: walked byte by byte, every pixel of a gap goes the gap's whole length on dependent
@@ -1730,7 +1733,7 @@ constexpr int FG_W = 1024, FG_HALO = 64, FG_LW = FG_W + 2 * FG_HALO;
 #define FG_ROWS 4
 #endif
 constexpr int FG_R = FG_ROWS, FG_ND = FG_R + 2, FG_NM = FG_R + 3, FG_WORDS = FG_LW / 64 + 1;
-__global__ __launch_bounds__(256) void k_fill_gaps_b(P3 P)
+__global__ __launch_bounds__(FG_T) void k_fill_gaps_b(P3 P)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_d[FG_ND][FG_LW];      // direction rows yb - 2, yb, .. , yb + 2 FG_R
     __shared__ __attribute__((aligned(16))) uint8_t s_m[FG_NM][FG_LW];      // mask rows yb - 3, yb - 1, .. , yb + 2 FG_R + 1
@@ -1780,7 +1783,7 @@ __global__ __launch_bounds__(256) void k_fill_gaps_b(P3 P)
     {
         // all loads of a thread in flight before its first LDS store (ndw <= 288: two dwords per row and thread); rows
         // outside the plane are rows no pixel's tests reach (:1076, :1090): they are read from the nearest row inside
-        const bool h0 = tid < ndw, h1 = tid + 256 < ndw;
+        const bool h0 = tid < ndw, h1 = tid + FG_T < ndw;
         uint32_t vd[FG_ND][2] = {}, vm[FG_NM][2] = {};
         if (h0)
         {
@@ -1795,10 +1798,10 @@ __global__ __launch_bounds__(256) void k_fill_gaps_b(P3 P)
         {
 #pragma unroll
             for (int r = 0; r < FG_ND; r++)
-                vd[r][1] = reinterpret_cast<const uint32_t *>(Q.b + (size_t)min(max(yb - 2 + 2 * r, 0), height - 1) * pitch + lo)[tid + 256];
+                vd[r][1] = reinterpret_cast<const uint32_t *>(Q.b + (size_t)min(max(yb - 2 + 2 * r, 0), height - 1) * pitch + lo)[tid + FG_T];
 #pragma unroll
             for (int r = 0; r < FG_NM; r++)
-                vm[r][1] = reinterpret_cast<const uint32_t *>(Q.a + (size_t)min(max(yb - 3 + 2 * r, 0), height - 1) * pitch + lo)[tid + 256];
+                vm[r][1] = reinterpret_cast<const uint32_t *>(Q.a + (size_t)min(max(yb - 3 + 2 * r, 0), height - 1) * pitch + lo)[tid + FG_T];
         }
         if (h0)
         {
@@ -1810,9 +1813,9 @@ __global__ __launch_bounds__(256) void k_fill_gaps_b(P3 P)
         if (h1)
         {
 #pragma unroll
-            for (int r = 0; r < FG_ND; r++) reinterpret_cast<uint32_t *>(s_d[r])[tid + 256] = vd[r][1];
+            for (int r = 0; r < FG_ND; r++) reinterpret_cast<uint32_t *>(s_d[r])[tid + FG_T] = vd[r][1];
 #pragma unroll
-            for (int r = 0; r < FG_NM; r++) reinterpret_cast<uint32_t *>(s_m[r])[tid + 256] = vm[r][1];
+            for (int r = 0; r < FG_NM; r++) reinterpret_cast<uint32_t *>(s_m[r])[tid + FG_T] = vm[r][1];
         }
     }
     __syncthreads();
@@ -1852,11 +1855,11 @@ __global__ __launch_bounds__(256) void k_fill_gaps_b(P3 P)
         // direction known, does the row above / below end the "top / bottom continues" state (:1078-1093).  The walks then
         // are bit scans instead of chains of dependent byte reads.  First the rows' own bits - direction known, mask set -
         // once per staged row, then the four combinations per rebuilt row as word arithmetic.
-        for (int k = 0; k < (FG_LW + 255) / 256; k++)
+        for (int k = 0; k < (FG_LW + FG_T - 1) / FG_T; k++)
         {
             // (no branch: the bytes are read whatever they hold - from the last staged column for the lanes past it, whose
             // bits are then cleared)
-            const unsigned col = tid + 256 * k, cc = min(col, staged - 1u);
+            const unsigned col = tid + FG_T * k, cc = min(col, staged - 1u);
             const bool in = col < staged;
             uint64_t nd[FG_ND], pm[FG_NM];
     #pragma unroll
@@ -1879,7 +1882,7 @@ __global__ __launch_bounds__(256) void k_fill_gaps_b(P3 P)
         }
         __syncthreads();
     }
-    for (int i = tid; i < count; i += 256)
+    for (int i = tid; i < count; i += FG_T)
     {
         const int e = s_list[i], r = e >> 12, lx = e & 0xfff, px = x0 + lx, y = yb + 2 * r;
         const uint8_t *DC = s_d[r + 1], *DP = s_d[r], *DN = s_d[r + 2];
@@ -3067,9 +3070,9 @@ int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st, ui
     // passes, this kernel went from 131 to 163-165 us per launch)
     const dim3 fg_grid((dst2p.width[0] + FG_W - 1) / FG_W, (dst2p.height[0] + 2 * FG_R - 1) / (2 * FG_R), gz);
     bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
-    HBHIP_LAUNCH_ON(lc, st, "eedi2_fill_gaps_2x", k_fill_gaps_b, fg_grid, dim3(256), 0, P);
+    HBHIP_LAUNCH_ON(lc, st, "eedi2_fill_gaps_2x", k_fill_gaps_b, fg_grid, dim3(FG_T), 0, P);
     bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
-    HBHIP_LAUNCH_ON(lc, st, "eedi2_fill_gaps_2x", k_fill_gaps_b, fg_grid, dim3(256), 0, P);
+    HBHIP_LAUNCH_ON(lc, st, "eedi2_fill_gaps_2x", k_fill_gaps_b, fg_grid, dim3(FG_T), 0, P);
     // lattice
     bind(P.a, tmp2p); bind(P.b, dst2p); bind(P.c, tmp2p2);
     {

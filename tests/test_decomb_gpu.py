@@ -128,6 +128,50 @@ def test_decomb_in_a_chain_batch(built, w, h, mode, combed):
         ctx.close()
 
 
+@pytest.mark.parametrize("batches", [(9, 10, 12, 1), (16, 5, 11), (4, 13, 15)])
+def test_decomb_eedi2_batch_parts(built, batches):
+    """A batch of the engine goes out in parts of 16 fields - a mask launch per part (the second one on a stream of its own
+    beside the first part's passes), the passes of a part in two halves on two streams when it has 8 fields or more.
+    Calls of 9, 10, 12 .. frames make second parts of 2, 4, 8 .. fields; the mask's lower half runs from field to field
+    through all of them (eedi2_template.c:132), so a wrong order anywhere shows in every frame behind it."""
+    import torch
+    w, h = 322, 184
+    n = sum(batches)
+    frames = synth.stream("interlaced", w, h, n)
+    want = os_.decomb_eedi2_stream(frames, dict(mode=31, postproc=1), flags=TFF)
+    ctx = hip.Ctx(0)
+    dec = hip.DecombDevice(ctx, w, h, mode=31, postproc=1)
+    stage = hip.DeviceFilter(ctx, dec.h)
+    dec.h = None
+    chain = hip.Chain(ctx, [stage])
+    try:
+        dev_in = [[torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in f] for f in frames]
+        cap = 2 * max(batches) + 4
+        outs = [[torch.zeros((h, w), dtype=torch.uint8, device="cuda"),
+                 torch.zeros((h // 2, w // 2), dtype=torch.uint8, device="cuda"),
+                 torch.zeros((h // 2, w // 2), dtype=torch.uint8, device="cuda")] for _ in range(cap)]
+        torch.cuda.synchronize()
+        got, t = [], 0
+        for b in batches:
+            arr_in = (hip.DevFrame * b)(*[hip.dev_frame(dev_in[t + i]) for i in range(b)])
+            arr_out = (hip.DevFrame * cap)(*[hip.dev_frame(o) for o in outs])
+            k = chain.process_dev(arr_in, arr_out, tag0=t, flags=[TFF] * b, combed=[2] * b)
+            chain.sync()
+            got += [[p.cpu().numpy().copy() for p in outs[i]] for i in range(k)]
+            t += b
+        arr_out = (hip.DevFrame * cap)(*[hip.dev_frame(o) for o in outs])
+        k = chain.flush_dev(arr_out)
+        chain.sync()
+        got += [[p.cpu().numpy().copy() for p in outs[i]] for i in range(k)]
+        assert len(got) == len(want)
+        for i in range(len(want)):
+            for c in range(3):
+                np.testing.assert_array_equal(got[i][c], want[i]["planes"][c], err_msg=f"frame {i} plane {c}")
+    finally:
+        chain.close()
+        ctx.close()
+
+
 @pytest.mark.parametrize("profiled", [False, True], ids=["plain", "profiled"])
 @pytest.mark.parametrize("mode,postproc,selective", [(31, 1, False), (31, 2, False), (15, 3, False), (63, 1, True), (24, 0, False)])
 def test_decomb_eedi2_in_a_chain_batch(built, mode, postproc, selective, profiled):
