@@ -714,39 +714,79 @@ __global__ __launch_bounds__(256) void scale16_v_kernel(Scale8Args a, const uint
 // thread's own shift) into the three sample pairs its three v_dot2 take.  The horizontal results go to LDS as pairs
 // of rows, the vertical pass is the 8-bit kernel's with another rounding and a 16-bit store.
 constexpr int SW_SRC_DW = 138;          // 2 * 136 samples of a row (+ the dwords the realignment reads past the window)
+template <int TH>
 __global__ __launch_bounds__(256) void scale16_up_kernel(ScaleBatch8 B, int vmax)
 {
     __shared__ uint32_t s_src[SU_MAXR][SW_SRC_DW];
     __shared__ __attribute__((aligned(16))) uint32_t s_h[SU_PAIRS][SU_TW];
+    __shared__ uint4 s_v[TH];
     const int f = (int)blockIdx.z / 3, pl = (int)blockIdx.z - 3 * f;
     const ScalePlane8 &P = B.p[pl];
     if (!P.active) return;
-    const int x0 = blockIdx.x * SU_TW, y0 = blockIdx.y * SU_TH;
+    const int x0 = blockIdx.x * SU_TW, y0 = blockIdx.y * TH;
     if (x0 >= P.dw || y0 >= P.dh) return;
     const int t = threadIdx.x;
-    const int xe = min(x0 + SU_TW, P.dw) - 1, ye = min(y0 + SU_TH, P.dh) - 1;
+    const int xe = min(x0 + SU_TW, P.dw) - 1, ye = min(y0 + TH, P.dh) - 1;
     const int cmin = P.bx[x0] & ~1, cmax = P.bx[xe] + 5;           // in samples; bx, by are non-decreasing
     const int rmin = P.by[y0], nr = P.by[ye] + 5 - rmin + 1;
     const int ndw = (cmax - cmin) / 2 + 2;                          // + 1: the dword an odd window's last pair reaches into
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+    // the thread's column of the horizontal pass and the tile's rows of the vertical one, fetched ahead of the staging
+    // (scale8_up_kernel)
+    const int xh = min(x0 + t, P.dw - 1);
+    const int bxh = P.bx[xh];
+    const uint32_t hc01 = P.qx[3 * (size_t)xh], hc23 = P.qx[3 * (size_t)xh + 1], hc45 = P.qx[3 * (size_t)xh + 2];
+    if (t < TH && y0 + t <= ye)
+    {
+        const int y = y0 + t;
+        s_v[t] = make_uint4((uint32_t)(P.by[y] - rmin), P.qy[3 * (size_t)y], P.qy[3 * (size_t)y + 1], P.qy[3 * (size_t)y + 2]);
+    }
     {
         const uint8_t *src = B.src[f][pl];
         const int spitch = B.spitch[pl];
-        for (int i = t; i < nr * ndw; i += 256)
+        // a wave stages the rows wave, wave + 4, ..: a lane per dword (two samples) of the row, all loads of a thread in flight
+        // before its first LDS store
+        constexpr int RPW = SU_MAXR / 4, CH = (SW_SRC_DW + 63) / 64;
+        uint32_t v[RPW][CH];
+#pragma unroll
+        for (int j = 0; j < RPW; j++)
         {
-            const int rr = i / ndw, d = i - rr * ndw, col = cmin + 2 * d;
-            const uint16_t *row = reinterpret_cast<const uint16_t *>(src + (size_t)reflect_idx(rmin + rr, P.sh) * spitch);
-            uint32_t v;
-            if (col >= 0 && col + 1 < P.sw && (((uintptr_t)(row + col)) & 3) == 0) v = *reinterpret_cast<const uint32_t *>(row + col);
-            else v = (uint32_t)row[reflect_idx(col, P.sw)] | ((uint32_t)row[reflect_idx(col + 1, P.sw)] << 16);
-            s_src[rr][d] = v;
+            const int rr = wave + 4 * j;
+#pragma unroll
+            for (int h = 0; h < CH; h++) v[j][h] = 0;
+            if (rr < nr)
+            {
+                const uint16_t *row = reinterpret_cast<const uint16_t *>(src + (size_t)reflect_idx(rmin + rr, P.sh) * spitch);
+#pragma unroll
+                for (int h = 0; h < CH; h++)
+                {
+                    const int d = lane + 64 * h, col = cmin + 2 * d;
+                    if (d < ndw)
+                    {
+                        if (col >= 0 && col + 1 < P.sw && (((uintptr_t)(row + col)) & 3) == 0) v[j][h] = *reinterpret_cast<const uint32_t *>(row + col);
+                        else v[j][h] = (uint32_t)row[reflect_idx(col, P.sw)] | ((uint32_t)row[reflect_idx(col + 1, P.sw)] << 16);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < RPW; j++)
+        {
+            const int rr = wave + 4 * j;
+            if (rr < nr)
+            {
+#pragma unroll
+                for (int h = 0; h < CH; h++)
+                    if (lane + 64 * h < ndw) s_src[rr][lane + 64 * h] = v[j][h];
+            }
         }
     }
     __syncthreads();
     if (x0 + t < P.dw)
     {
-        const int x = x0 + t, o = P.bx[x] - cmin, dq = o >> 1;
+        const int o = bxh - cmin, dq = o >> 1;
         const uint32_t shift = (uint32_t)(o & 1) * 2u;              // bytes
-        const uint32_t c01 = P.qx[3 * (size_t)x], c23 = P.qx[3 * (size_t)x + 1], c45 = P.qx[3 * (size_t)x + 2];
+        const uint32_t c01 = hc01, c23 = hc23, c45 = hc45;
         uint16_t *hp = reinterpret_cast<uint16_t *>(&s_h[0][0]) + 2 * t;
         for (int rr = 0; rr < nr; rr++)
         {
@@ -758,12 +798,13 @@ __global__ __launch_bounds__(256) void scale16_up_kernel(ScaleBatch8 B, int vmax
         }
     }
     __syncthreads();
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, xq = x0 + 4 * lane;
+    const int xq = x0 + 4 * lane;
     if (xq >= P.dw) return;
     for (int y = y0 + wave; y <= ye; y += 4)
     {
-        const int ob = __builtin_amdgcn_readfirstlane(P.by[y] - rmin);
-        const uint32_t c01 = P.qy[3 * (size_t)y], c23 = P.qy[3 * (size_t)y + 1], c45 = P.qy[3 * (size_t)y + 2];
+        const uint4 vt = s_v[y - y0];
+        const int ob = __builtin_amdgcn_readfirstlane((int)vt.x);
+        const uint32_t c01 = vt.y, c23 = vt.z, c45 = vt.w;
         int acc[4] = {8192, 8192, 8192, 8192};
         const uint4 *hq = reinterpret_cast<const uint4 *>(&s_h[ob >> 1][4 * lane]);
         auto tap = [&](int pair_row, uint32_t cpair) {
@@ -970,7 +1011,8 @@ public:
                 const dim3 grid_tall(grid.x, (out_geo.ph[0] + 2 * SU_TH - 1) / (2 * SU_TH), grid.z);
                 if (in_geo.bps == 1 && tall) HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", scale8_up_kernel<2 * SU_TH>, grid_tall, dim3(256), 0, B);
                 else if (in_geo.bps == 1) HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", scale8_up_kernel<SU_TH>, grid, dim3(256), 0, B);
-                else                 HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", scale16_up_kernel, grid, dim3(256), 0, B, vmax);
+                else if (tall)       HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", scale16_up_kernel<2 * SU_TH>, grid_tall, dim3(256), 0, B, vmax);
+                else                 HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", scale16_up_kernel<SU_TH>, grid, dim3(256), 0, B, vmax);
             }
         else
             for (int i = 0; i < n; i++)
@@ -1000,7 +1042,7 @@ public:
 
     int process(DevPicture *in, DevPicture *out) override { return process_many(&in, &out, 1); }
     bool up6 = true;            // six taps either way and every tile fits the fused kernel's LDS frame
-    bool tall = true;           // ... also at 32 rows per tile (8-bit kernel)
+    bool tall = true;           // ... also at 32 rows per tile
     hbhip_cropscale_params par;
     int crop_x[3], crop_y[3], crop_w[3], crop_h[3], tx[3] = {0, 0, 0}, ty[3] = {0, 0, 0};
     bool identity[3] = {false, false, false};
