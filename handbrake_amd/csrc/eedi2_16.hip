@@ -1440,33 +1440,6 @@ struct Lat16
 
 __device__ __forceinline__ unsigned long long lat16_word(int valB, int newB) { return ((unsigned long long)(uint16_t)valB << 16) | ((unsigned long long)(uint16_t)newB << 32); }
 
-// the variance and the edge test on the fixed 2 x 5 neighbourhood (:1213-1240)
-__device__ __forceinline__ unsigned long long lat16_stage_a(const uint16_t *top, const uint16_t *bot, const uint16_t *dm, int x, int width,
-                                                            unsigned long long base, const Lat16 &L)
-{
-    const int d = dm[x];
-    const int T0 = top[x - 2], T1 = top[x - 1], T2 = top[x], T3 = top[x + 1], T4 = top[x + 2];
-    const int B0 = bot[x - 2], B1 = bot[x - 1], B2 = bot[x], B3 = bot[x + 1], B4 = bot[x + 2];
-    const int lim = L.lim[iabs16(d - L.neutral) >> L.sh2];
-    const int avg = (int)(base & 0xffffu);
-    if (lim < L.nine)
-    {
-        const int sh = L.sh;
-        const int sum = (T1 + T2 + T3 + B1 + B2 + B3) >> sh;
-        const int t1 = T1 >> sh, t2 = T2 >> sh, t3 = T3 >> sh, b1 = B1 >> sh, b2 = B2 >> sh, b3 = B3 >> sh;
-        const int sumsq = t1 * t1 + t2 * t2 + t3 * t3 + b1 * b1 + b2 * b2 + b3 * b3;
-        if (6 * sumsq - sum * sum < 576) return base | lat16_word(avg, L.peak);
-    }
-    if (x > 1 && x < width - 2)
-    {
-        const int three = L.three;
-        if ((T2 < max(T0, T1) - three && T2 < max(T4, T3) - three && B2 < max(B0, B1) - three && B2 < max(B4, B3) - three) ||
-            (T2 > min(T0, T1) + three && T2 > min(T4, T3) + three && B2 > min(B0, B1) + three && B2 > min(B4, B3) + three))
-            return base | lat16_word(avg, L.neutral);
-    }
-    return base | LAT16_MORE;
-}
-
 // the search around the sample's direction (:1242-1290)
 __device__ __forceinline__ unsigned long long lat16_stage_b(const uint16_t *top, const uint16_t *bot, const uint16_t *ot, const uint16_t *ob,
                                                             const uint16_t *dm, int x, int width, unsigned long long base, const Lat16 &L)
@@ -1500,6 +1473,144 @@ __device__ __forceinline__ unsigned long long lat16_stage_b(const uint16_t *top,
     }
     if (mn != L.nt8) return base | lat16_word(val, L.neutral + (dir << L.sh2));
     return base | LAT16_MORE;
+}
+
+// ---- the forms of eedi2.hip's k_lattice_cand_q for 16-bit samples: the tests out of registers, the search out of
+// windows of eight samples with its steps side by side (see there for the why; here a window is four dwords, a step's
+// three samples a pair and a single through v_sad_u16, and two samples ride in a packed operation as they lie)
+typedef uint16_t u16x2q __attribute__((ext_vector_type(2)));
+typedef int16_t i16x2q __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2q pkq(uint32_t v) { return __builtin_bit_cast(u16x2q, v); }
+__device__ __forceinline__ uint32_t unq(u16x2q v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ u16x2q pkq1(uint32_t both) { return pkq(both * 0x00010001u); }
+__device__ __forceinline__ u16x2q pkq_lt(u16x2q a, u16x2q b) { return (u16x2q)((u16x2q)(a - b) >> 15); }   // halves below 2^15
+
+// the variance and the edge test on the fixed 2 x 5 neighbourhood (:1213-1240), on values (T0 .. T4 / B0 .. B4: the samples
+// x - 2 .. x + 2 of the rows above / below)
+__device__ __forceinline__ unsigned long long lat16_stage_a_vals(int T0, int T1, int T2, int T3, int T4, int B0, int B1, int B2, int B3, int B4,
+                                                                 int lim, bool inner, unsigned long long base, const Lat16 &L)
+{
+    const int avg = (int)(base & 0xffffu);
+    if (lim < L.nine)
+    {
+        const int sh = L.sh;
+        const int sum = (T1 + T2 + T3 + B1 + B2 + B3) >> sh;
+        const int t1 = T1 >> sh, t2 = T2 >> sh, t3 = T3 >> sh, b1 = B1 >> sh, b2 = B2 >> sh, b3 = B3 >> sh;
+        const int sumsq = t1 * t1 + t2 * t2 + t3 * t3 + b1 * b1 + b2 * b2 + b3 * b3;
+        if (6 * sumsq - sum * sum < 576) return base | lat16_word(avg, L.peak);
+    }
+    if (inner)
+    {
+        const int three = L.three;
+        if ((T2 < max(T0, T1) - three && T2 < max(T4, T3) - three && B2 < max(B0, B1) - three && B2 < max(B4, B3) - three) ||
+            (T2 > min(T0, T1) + three && T2 > min(T4, T3) + three && B2 > min(B0, B1) + three && B2 > min(B4, B3) + three))
+            return base | lat16_word(avg, L.neutral);
+    }
+    return base | LAT16_MORE;
+}
+
+struct Lat16Rows { const uint32_t *top, *bot, *ot, *ob; int org; };      // the staged rows as dwords; org: local index of sample 0
+
+// samples row[li] .. row[li + 7] (any alignment) as four dwords
+__device__ __forceinline__ void lat16_window8(const uint32_t *row, int li, uint32_t (&w)[4])
+{
+    const uint32_t *p = row + (li >> 1);
+    const uint32_t r0 = p[0], r1 = p[1], r2 = p[2], r3 = p[3], r4 = p[4];
+    const uint32_t sh = ((uint32_t)li & 1u) * 2u;
+    w[0] = __builtin_amdgcn_alignbyte(r1, r0, sh); w[1] = __builtin_amdgcn_alignbyte(r2, r1, sh);
+    w[2] = __builtin_amdgcn_alignbyte(r3, r2, sh); w[3] = __builtin_amdgcn_alignbyte(r4, r3, sh);
+}
+// samples row[li] .. row[li + 3] as two dwords
+__device__ __forceinline__ void lat16_window4(const uint32_t *row, int li, uint32_t (&w)[2])
+{
+    const uint32_t *p = row + (li >> 1);
+    const uint32_t r0 = p[0], r1 = p[1], r2 = p[2];
+    const uint32_t sh = ((uint32_t)li & 1u) * 2u;
+    w[0] = __builtin_amdgcn_alignbyte(r1, r0, sh); w[1] = __builtin_amdgcn_alignbyte(r2, r1, sh);
+}
+// the three samples G, G + 1, G + 2 of a window: the pair as it lies (or realigned), the single zero-extended
+template <int G, int N> __device__ __forceinline__ uint32_t lat16_pair(const uint32_t (&w)[N])
+{
+    if constexpr (G & 1) return __builtin_amdgcn_alignbyte(w[(G + 1) / 2], w[G / 2], 2u);
+    else return w[G / 2];
+}
+template <int G, int N> __device__ __forceinline__ uint32_t lat16_one(const uint32_t (&w)[N])      // sample G
+{
+    if constexpr (G & 1) return w[G / 2] >> 16;
+    else return w[G / 2] & 0xffffu;
+}
+#define LAT16_SAD3(wa, GA, wb, GB) \
+    __builtin_amdgcn_sad_u16(lat16_pair<GA>(wa), lat16_pair<GB>(wb), __builtin_amdgcn_sad_u16(lat16_one<(GA) + 2>(wa), lat16_one<(GB) + 2>(wb), 0u))
+// which of a window's eight samples are a direction (below the peak) within lim of d: sample 2i at bit i, 2i + 1 at bit 16 + i
+__device__ __forceinline__ uint32_t lat16_near8(const uint32_t (&w)[4], u16x2q d2, u16x2q lim1, u16x2q peak2)
+{
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+    {
+        const u16x2q h = pkq(w[i]);
+        const i16x2q t = __builtin_bit_cast(i16x2q, (u16x2q)(h - d2));
+        const u16x2q a = __builtin_bit_cast(u16x2q, __builtin_elementwise_max(t, (i16x2q)(-t)));
+        m |= unq(pkq_lt(a, lim1) & pkq_lt(h, peak2)) << i;
+    }
+    return m;
+}
+constexpr uint32_t lat16_bit(int b) { return (b & 1) ? 1u << (16 + (b >> 1)) : 1u << (b >> 1); }
+constexpr uint32_t lat16_bits3(int g) { return lat16_bit(g) | lat16_bit(g + 1) | lat16_bit(g + 2); }
+
+__device__ __forceinline__ unsigned long long lat16_stage_b_win(const Lat16Rows R, const uint16_t *top, const uint16_t *bot, const uint16_t *ot,
+                                                                const uint16_t *ob, const uint16_t *dm, int x, int width,
+                                                                unsigned long long base, const Lat16 &L)
+{
+    const int here = dm[x];
+    const int lim = L.lim[iabs16(here - L.neutral) >> L.sh2];
+    const int dir = (here - L.neutral + (1 << (L.sh2 - 1))) >> L.sh2;
+    const int startu = (dir - 2 < 0) ? max(-x + 1, max(dir - 2, -width + 2 + x)) : min(x - 1, min(dir - 2, width - 2 - x));
+    const int stopu = (dir + 2 < 0) ? max(-x + 1, max(dir + 2, -width + 2 + x)) : min(x - 1, min(dir + 2, width - 2 - x));
+    if (startu != dir - 2 || stopu != dir + 2) return lat16_stage_b(top, bot, ot, ob, dm, x, width, base, L);   // clamped at a row end
+    const int de = dir & ~1, par = dir & 1, hb = (de >> 1) - 1;     // step i: u = de - 2 + i, u >> 1 = hb + (i >> 1), (u + 1) >> 1 = hb + ((i + 1) >> 1)
+    const int lx = R.org + x;
+    uint32_t bw[4], qw[4], tw[4], ow[4], t2[4], b2[4], o2[2], q2[2], tcw[2], bcw[2];
+    lat16_window8(R.bot, lx - de - 4, bw);                   // x - u - 1 at sample 5 - i
+    lat16_window8(R.ob, lx - de - 4, qw);
+    lat16_window8(R.top, lx + de - 3, tw);                   // x + u - 1 at sample i
+    lat16_window8(R.ot, lx + de - 3, ow);
+    lat16_window8(R.top, lx + hb - 1, t2);                   // x + (u >> 1) - 1 at sample i >> 1
+    lat16_window8(R.bot, lx - hb - 4, b2);                   // x - (u >> 1) - 1 at sample 3 - (i >> 1)
+    lat16_window4(R.ot, lx + hb, o2);                        // x + (u >> 1) at sample i >> 1
+    lat16_window4(R.ob, lx - hb - 3, q2);                    // x - (u >> 1) at sample 3 - (i >> 1)
+    lat16_window4(R.top, lx - 1, tcw);
+    lat16_window4(R.bot, lx - 1, bcw);
+    const u16x2q d2 = pkq1((uint32_t)here), lim1 = pkq1((uint32_t)min(lim + 1, 0x7fff)), peak2 = pkq1((uint32_t)L.peak);
+    const uint32_t near_t = lat16_near8(ow, d2, lim1, peak2), near_b = lat16_near8(qw, d2, lim1, peak2);
+    const uint32_t ulim = (uint32_t)lim, ulim2 = 2u * ulim;
+    auto within = [&](uint32_t a, uint32_t b) { return a - b + ulim <= ulim2; };              // |a - b| <= lim
+    const uint32_t o[4] = { o2[0] & 0xffffu, o2[0] >> 16, o2[1] & 0xffffu, o2[1] >> 16 };
+    const uint32_t q[4] = { q2[0] & 0xffffu, q2[0] >> 16, q2[1] & 0xffffu, q2[1] >> 16 };
+    const uint32_t uh = (uint32_t)here, peak = (uint32_t)L.peak;
+    const bool od[4] = { within(o[0], uh), within(o[1], uh), within(o[2], uh), within(o[3], uh) };
+    const bool qd[4] = { within(q[0], uh), within(q[1], uh), within(q[2], uh), within(q[3], uh) };
+    const int diff2[3] = { (int)LAT16_SAD3(t2, 0, b2, 3), (int)LAT16_SAD3(t2, 1, b2, 2), (int)LAT16_SAD3(t2, 2, b2, 1) };
+    uint32_t best = 0x7fffffffu;
+#define LAT16_STEP(i)                                                                                                 \
+    {                                                                                                                 \
+        constexpr int A = (i) >> 1, B = ((i) + 1) >> 1;                                                               \
+        const int diff = (int)(LAT16_SAD3(tcw, 0, bw, 5 - (i)) + LAT16_SAD3(bcw, 0, tw, (i)));                        \
+        const bool oq = A == B ? (within(o[A], q[3 - A]) && o[A] != peak)                                             \
+                               : (((within(o[A], q[3 - A]) || within(o[A], q[3 - B])) && o[A] != peak) ||             \
+                                  ((within(o[B], q[3 - A]) || within(o[B], q[3 - B])) && o[B] != peak));              \
+        const bool ok = ((i) == 0 ? par == 0 : (i) == 5 ? par != 0 : true) && diff < L.nt8 &&                         \
+                        (near_t & lat16_bits3(i)) && (near_b & lat16_bits3(5 - (i))) && diff2[A] < L.nt4 && oq &&     \
+                        (od[A] || od[B]) && (qd[3 - A] || qd[3 - B]);                                                 \
+        best = min(best, ok ? ((uint32_t)diff << 3) | (uint32_t)(i) : 0x7fffffffu);                                   \
+    }
+    LAT16_STEP(0) LAT16_STEP(1) LAT16_STEP(2) LAT16_STEP(3) LAT16_STEP(4) LAT16_STEP(5)
+#undef LAT16_STEP
+    if (best == 0x7fffffffu) return base | LAT16_MORE;
+    const int u = de - 2 + (int)(best & 7u);
+    const int h0 = u >> 1, h1 = (u + 1) >> 1;
+    const int val = ((int)top[x + h0] + (int)top[x + h1] + (int)bot[x - h0] + (int)bot[x - h1] + 2) >> 2;
+    return base | lat16_word(val, L.neutral + (u << L.sh2));
 }
 
 // the short search for samples the first one left without a match (:1292-1318)
@@ -1590,49 +1701,75 @@ __global__ __launch_bounds__(256) void q_lattice_cand(Q3 P, K16 k, int nt, unsig
     const uint16_t *ot = s_rows[2] + LQ16_HALO - x0, *ob = s_rows[3] + LQ16_HALO - x0;
     const uint16_t *dm = s_rows[4] + LQ16_HALO - x0;
     {
+        // every sample's word, the variance and the edge test included, four samples per thread out of the rows' dwords
         const int x = x0 + 4 * t;
         if (x < width)
         {
-            unsigned long long w[4];
-            uint32_t queue = 0;
+            const uint32_t *T = reinterpret_cast<const uint32_t *>(s_rows[0]) + LQ16_HALO / 2 + 2 * t;   // T[0]: samples x, x + 1
+            const uint32_t *B = reinterpret_cast<const uint32_t *>(s_rows[1]) + LQ16_HALO / 2 + 2 * t;
+            const uint32_t *D = reinterpret_cast<const uint32_t *>(s_rows[4]) + LQ16_HALO / 2 + 2 * t;
+            const uint32_t tw4[4] = { T[-1], T[0], T[1], T[2] }, bw4[4] = { B[-1], B[0], B[1], B[2] };
+            const uint32_t dw3[3] = { D[0], D[1], D[2] };
+            int tv[8], bv[8], dv[5];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+            {
+                tv[2 * i] = (int)(tw4[i] & 0xffffu); tv[2 * i + 1] = (int)(tw4[i] >> 16);
+                bv[2 * i] = (int)(bw4[i] & 0xffffu); bv[2 * i + 1] = (int)(bw4[i] >> 16);
+            }
+            dv[0] = (int)(dw3[0] & 0xffffu); dv[1] = (int)(dw3[0] >> 16); dv[2] = (int)(dw3[1] & 0xffffu); dv[3] = (int)(dw3[1] >> 16);
+            dv[4] = (int)(dw3[2] & 0xffffu);
+            unsigned long long w[4], base[4];
+            int lim[4];
+            uint32_t queue = 0, searching = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++)
             {
-                const int d = dm[x + j], dr = dm[x + j + 1];
-                const int avg = ((int)top[x + j] + (int)bot[x + j] + 1) >> 1;
-                const int lim = s_lim[iabs16(d - L.neutral) >> L.sh2];
-                const unsigned long long right = iabs16(d - dr) > lim ? 1ull << 49 : 0ull;
-                const bool searching = d != L.peak && x + j < width;
-                w[j] = searching ? ((unsigned long long)(uint16_t)avg | right)
-                                 : ((unsigned long long)(uint16_t)avg | lat16_word(avg, L.neutral) | (1ull << 48) | right);
-                if (searching) queue |= 1u << j;
+                const int d = dv[j], dr = dv[j + 1];
+                const int avg = (tv[j + 2] + bv[j + 2] + 1) >> 1;
+                lim[j] = s_lim[iabs16(d - L.neutral) >> L.sh2];
+                const unsigned long long right = iabs16(d - dr) > lim[j] ? 1ull << 49 : 0ull;
+                if (d != L.peak && x + j < width) searching |= 1u << j;
+                base[j] = (unsigned long long)(uint16_t)avg | right;
+                w[j] = base[j] | lat16_word(avg, L.neutral) | (1ull << 48);                  // the word of a sample without a direction
+            }
+            if (searching)
+            {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                {
+                    const bool inner = x + j > 1 && x + j < width - 2;
+                    const unsigned long long ws = lat16_stage_a_vals(tv[j], tv[j + 1], tv[j + 2], tv[j + 3], tv[j + 4],
+                                                                     bv[j], bv[j + 1], bv[j + 2], bv[j + 3], bv[j + 4], lim[j], inner, base[j], L);
+                    if ((searching >> j) & 1u)
+                    {
+                        w[j] = ws & ~LAT16_MORE;
+                        if (ws & LAT16_MORE) queue |= 1u << j;
+                    }
+                }
             }
 #pragma unroll
             for (int j = 0; j < 4; j++) s_cand[4 * t + j] = w[j];
             if (queue)
             {
-                int at = atomicAdd(&s_count[0], __popc(queue));
+                int at = atomicAdd(&s_count[1], __popc(queue));
 #pragma unroll
                 for (int j = 0; j < 4; j++)
-                    if ((queue >> j) & 1u) s_list[0][at++] = (uint16_t)(4 * t + j);
+                    if ((queue >> j) & 1u) s_list[1][at++] = (uint16_t)(4 * t + j);
             }
         }
     }
     __syncthreads();
-    for (int i = t, n = s_count[0]; i < n; i += 256)
     {
-        const int lx = s_list[0][i];
-        const unsigned long long w = lat16_stage_a(top, bot, dm, x0 + lx, width, s_cand[lx], L);
-        if (w & LAT16_MORE) s_list[1][atomicAdd(&s_count[1], 1)] = (uint16_t)lx;
-        else s_cand[lx] = w;
-    }
-    __syncthreads();
-    for (int i = t, n = s_count[1]; i < n; i += 256)
-    {
-        const int lx = s_list[1][i];
-        const unsigned long long w = lat16_stage_b(top, bot, ot, ob, dm, x0 + lx, width, s_cand[lx], L);
-        if (w & LAT16_MORE) s_list[2][atomicAdd(&s_count[2], 1)] = (uint16_t)lx;
-        else s_cand[lx] = w;
+        const Lat16Rows R = { reinterpret_cast<const uint32_t *>(s_rows[0]), reinterpret_cast<const uint32_t *>(s_rows[1]),
+                              reinterpret_cast<const uint32_t *>(s_rows[2]), reinterpret_cast<const uint32_t *>(s_rows[3]), LQ16_HALO - x0 };
+        for (int i = t, n = s_count[1]; i < n; i += 256)
+        {
+            const int lx = s_list[1][i];
+            const unsigned long long w = lat16_stage_b_win(R, top, bot, ot, ob, dm, x0 + lx, width, s_cand[lx], L);
+            if (w & LAT16_MORE) s_list[2][atomicAdd(&s_count[2], 1)] = (uint16_t)lx;
+            else s_cand[lx] = w;
+        }
     }
     __syncthreads();
     for (int i = t, n = s_count[2]; i < n; i += 256)
