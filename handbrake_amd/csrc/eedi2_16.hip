@@ -26,6 +26,7 @@ struct K16
 struct Q3
 {
     uint16_t *a[3], *b[3], *c[3];          // pass specific roles, see each kernel
+    uint16_t *d[3], *e[3], *f[3], *g[3];   // q_mark_2x's line doublings (picked by that kernel itself)
     int pitch[3], width[3], height[3];
     size_t   fstride;                      // field batching (see eedi2.hip): samples between the slots of consecutive fields
     uint32_t tffbits;                      // bit f: pv->tff of field f of the launch
@@ -1071,22 +1072,13 @@ __global__ __launch_bounds__(256) void q_filter_map(Q3 P, K16 k)
     else for (int j = 0; j < 4 && x + j < width; j++) o[j] = (uint16_t)(out >> (16 * j));
 }
 
-// eedi2_upscale_by_2 (:98-108): whole pitch; a = half-height in, c = full-height out (height = half height).
-// Eight samples (16 bytes) per thread: the pitches are multiples of 32 samples and the planes 64-byte aligned.
-__global__ void q_upscale(Q3 P)
-{
-    FIELD16(P);
-    const int x = 8 * (blockIdx.x * blockDim.x + threadIdx.x), y = blockIdx.y * blockDim.y + threadIdx.y;
-    const int pitch = P.pitch[pl], height = P.height[pl];
-    if (x >= pitch || y >= height) return;
-    const uint4 v = *reinterpret_cast<const uint4 *>(Q.a + (size_t)y * pitch + x);
-    *reinterpret_cast<uint4 *>(Q.c + (size_t)(2 * y) * pitch + x) = v;
-    *reinterpret_cast<uint4 *>(Q.c + (size_t)(2 * y + 1) * pitch + x) = v;
-}
-
-// eedi2_mark_directions_2x (:787-858): a = msk2p, b = tmp2p2 (direction map), c = out (pre-filled PEAK, whole pitch).
-// Four samples per thread and a PAIR of rows per thread row (2r, 2r + 1): the row with the rebuilt rows' parity is worked
-// on, the other is the memset's peak (eedi2.hip: k_mark_2x4).
+// eedi2_mark_directions_2x (:787-858) and the three eedi2_upscale_by_2 line doublings in front of it (:98-108,
+// decomb_template.c:408-410), as eedi2.hip's k_mark_2x4: a = mskp, b = dstp (the half-height direction map), g = srcp come in
+// at half height, d (dst2p), e (tmp2p2), f (msk2p) leave doubled, c = out (tmp2p).  The rows y - 1 / y + 1 of the doubled
+// maps that mark_directions reads are rows (y - 1) >> 1 / (y + 1) >> 1 of the half-height ones, so it reads those.
+// Four samples per thread and a PAIR of full-height rows per thread row (2r, 2r + 1 - both doubled from half-height row r):
+// the row with the rebuilt rows' parity is worked on, the other is the memset's peak.  `height` = full height.  Every load
+// goes out ahead of the first store.
 __global__ __launch_bounds__(256) void q_mark_2x(Q3 P, K16 k)
 {
     FIELD16(P);
@@ -1097,17 +1089,40 @@ __global__ __launch_bounds__(256) void q_mark_2x(Q3 P, K16 k)
     const int peak = k.peak;
     const uint2 peak4 = make_uint2((uint32_t)peak | ((uint32_t)peak << 16), (uint32_t)peak | ((uint32_t)peak << 16));
     const int y = 2 * r + (y0 & 1), yc = 2 * r + 1 - (y0 & 1);
+    const bool two = 2 * r + 1 < height;
+    const bool rebuilt = y < height && !maskless && y >= y0 && y < height - 1;
+    const size_t hs = (size_t)r * pitch + x, fs = (size_t)(2 * r) * pitch + x, off = (size_t)fld * P.fstride;
+    const uint16_t *Qg = P.g[pl] + off;
+    uint16_t *Qd = P.d[pl] + off, *Qe = P.e[pl] + off, *Qf = P.f[pl] + off;
+    const uint2 vg = *reinterpret_cast<const uint2 *>(Qg + hs), vb = *reinterpret_cast<const uint2 *>(Q.b + hs),
+                va = *reinterpret_cast<const uint2 *>(Q.a + hs);
+    uint2 a4 = peak4, b4 = peak4, k0 = make_uint2(0u, 0u), k1 = make_uint2(0u, 0u);
+    int al = 0, ar = 0, bl = 0, br = 0;
+    if (rebuilt)
+    {
+        const int ra = (y - 1) >> 1, rb = (y + 1) >> 1;
+        const uint16_t *d0 = Q.b + (size_t)ra * pitch + x, *d1 = Q.b + (size_t)rb * pitch + x;
+        k0 = ra == r ? va : *reinterpret_cast<const uint2 *>(Q.a + (size_t)ra * pitch + x);
+        k1 = rb == r ? va : *reinterpret_cast<const uint2 *>(Q.a + (size_t)rb * pitch + x);
+        // samples x-1 .. x+4 of the two direction rows
+        a4 = ra == r ? vb : *reinterpret_cast<const uint2 *>(d0);
+        b4 = rb == r ? vb : *reinterpret_cast<const uint2 *>(d1);
+        al = x > 0 ? (int)d0[-1] : 0; ar = x + 4 < pitch ? (int)d0[4] : 0;
+        bl = x > 0 ? (int)d1[-1] : 0; br = x + 4 < pitch ? (int)d1[4] : 0;
+    }
+    *reinterpret_cast<uint2 *>(Qd + fs) = vg;
+    *reinterpret_cast<uint2 *>(Qe + fs) = vb;
+    *reinterpret_cast<uint2 *>(Qf + fs) = va;
+    if (two)
+    {
+        *reinterpret_cast<uint2 *>(Qd + fs + pitch) = vg;
+        *reinterpret_cast<uint2 *>(Qe + fs + pitch) = vb;
+        *reinterpret_cast<uint2 *>(Qf + fs + pitch) = va;
+    }
     if (yc < height) *reinterpret_cast<uint2 *>(Q.c + (size_t)yc * pitch + x) = peak4;
     if (y >= height) return;
     uint2 *o = reinterpret_cast<uint2 *>(Q.c + (size_t)y * pitch + x);
-    if (maskless || !(y >= y0 && y < height - 1)) { *o = peak4; return; }      // (no mask sample in the plane: nothing but the fill, :800)
-    const uint16_t *d0 = Q.b + (size_t)(y - 1) * pitch + x, *d1 = d0 + 2 * (size_t)pitch;
-    const uint16_t *m0 = Q.a + (size_t)(y - 1) * pitch + x, *m1 = m0 + 2 * (size_t)pitch;
-    // samples x-1 .. x+4 of the two direction rows, x .. x+3 of the two mask rows
-    const uint2 a4 = *reinterpret_cast<const uint2 *>(d0), b4 = *reinterpret_cast<const uint2 *>(d1);
-    const uint2 k0 = *reinterpret_cast<const uint2 *>(m0), k1 = *reinterpret_cast<const uint2 *>(m1);
-    const int al = x > 0 ? (int)d0[-1] : 0, ar = x + 4 < pitch ? (int)d0[4] : 0;
-    const int bl = x > 0 ? (int)d1[-1] : 0, br = x + 4 < pitch ? (int)d1[4] : 0;
+    if (!rebuilt) { *o = peak4; return; }                                      // (no mask sample in the plane: nothing but the fill, :800)
     const int A[6] = { al, (int)(a4.x & 0xffffu), (int)(a4.x >> 16), (int)(a4.y & 0xffffu), (int)(a4.y >> 16), ar };
     const int B[6] = { bl, (int)(b4.x & 0xffffu), (int)(b4.x >> 16), (int)(b4.y & 0xffffu), (int)(b4.y >> 16), br };
     const int M0[4] = { (int)(k0.x & 0xffffu), (int)(k0.x >> 16), (int)(k0.y & 0xffffu), (int)(k0.y >> 16) };
@@ -2286,10 +2301,6 @@ int Eedi2Engine16::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st)
     auto grid4p = [&](const EediFrame &f, unsigned z) {                         // the same with a thread row per PAIR of rows (step 2)
         return dim3((f.width[0] + 255) / 256, ((f.height[0] + 1) / 2 + 3) / 4, z);
     };
-    auto grid8 = [&](const EediFrame &f, bool whole_pitch, unsigned z) {      // kernels with eight samples per thread
-        const int w = whole_pitch ? f.stride[0] / 2 : f.width[0];
-        return dim3((w + 511) / 512, (f.height[0] + 3) / 4, z);
-    };
     Q3 P;
     memset(&P, 0, sizeof(P));
     P.fstride = slot_bytes_ / 2;
@@ -2313,16 +2324,9 @@ int Eedi2Engine16::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st)
     HBHIP_LAUNCH_ON(lc, st, "eedi2_16_expand_dir_map", q_dir_map, grid4(srcp, gz), blk, 0, P, k, 1, 1);
     bind(P.a, mskp); bind(P.b, tmpp); bind(P.c, dstp);
     HBHIP_LAUNCH_ON(lc, st, "eedi2_16_filter_map", q_filter_map, grid4(srcp, gz), blk, 0, P, k);
-    // line doubling
-    bind(P.a, srcp); bind(P.c, dst2p);
-    HBHIP_LAUNCH_ON(lc, st, "eedi2_16_upscale", q_upscale, grid8(srcp, true, gz), blk, 0, P);
-    bind(P.a, dstp); bind(P.c, tmp2p2);
-    HBHIP_LAUNCH_ON(lc, st, "eedi2_16_upscale", q_upscale, grid8(srcp, true, gz), blk, 0, P);
-    bind(P.a, mskp); bind(P.c, msk2p);
-    HBHIP_LAUNCH_ON(lc, st, "eedi2_16_upscale", q_upscale, grid8(srcp, true, gz), blk, 0, P);
-    // full-height passes
+    // the three line doublings + mark_directions_2x in one launch (full-height geometry)
     geom(P, dst2p);
-    bind(P.a, msk2p); bind(P.b, tmp2p2); bind(P.c, tmp2p);
+    bind(P.a, mskp); bind(P.b, dstp); bind(P.g, srcp); bind(P.c, tmp2p); bind(P.d, dst2p); bind(P.e, tmp2p2); bind(P.f, msk2p);
     HBHIP_LAUNCH_ON(lc, st, "eedi2_16_mark_directions_2x", q_mark_2x,                                    // a thread row per pair of rows, four samples per thread
                  dim3((dst2p.stride[0] / 2 + 255) / 256, ((dst2p.height[0] + 1) / 2 + 3) / 4, gz), blk, 0, P, k);
     bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
@@ -2345,8 +2349,9 @@ int Eedi2Engine16::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st)
     }
     if (par_.post_processing == 1 || par_.post_processing == 3)
     {
+        // (the copy as a store of the filter behind it, as the 8-bit engine has it, cost that launch what the blit costs: 44 us)
         bind(P.a, tmp2p); bind(P.c, tmp2p2);
-        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_blit", q_blit, grid8(dst2p, false, gz), blk, 0, P);             // eedi2_bit_blit(tmp2p -> tmp2p2)
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_blit", q_blit, dim3((dst2p.width[0] + 511) / 512, (dst2p.height[0] + 3) / 4, gz), blk, 0, P);   // eedi2_bit_blit(tmp2p -> tmp2p2)
         bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
         HBHIP_LAUNCH_ON(lc, st, "eedi2_16_filter_dir_map_2x", q_dir_map, grid4p(dst2p, gz), blk, 0, P, k, 2, 0);
         bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
