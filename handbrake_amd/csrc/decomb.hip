@@ -1,13 +1,13 @@
-// decomb.hip — decomb (yadif / blend / cubic / EEDI2-guided) for gfx950, 8-bit.
+// decomb.hip — decomb (yadif / blend / cubic / EEDI2-guided) for gfx950, 8 / 10 / 12-bit samples.
 //
-//   decomb_plane_kernel   replaces yadif_decomb_filter_work_8 + yadif_filter_line_8,
-//                         cubic_interpolate_line_8, blend_filter_line_8 and the row
-//                         copies of filter_8   (libhb/templates/decomb_template.c:43-107,
-//                         279-361, 579-898)
+//   decomb_plane4_kernel  replaces yadif_decomb_filter_work + yadif_filter_line,
+//                         cubic_interpolate_line, blend_filter_line and the row
+//                         copies of filter (both instantiations of the template)
+//                         (libhb/templates/decomb_template.c:43-107, 279-361, 579-898)
 //   DecombFilter          replaces store_ref / process_frame / hb_decomb_work frame
 //                         logic               (libhb/decomb.c:195-200, 495-612)
 //
-// One thread per output pixel, three planes per launch.  Rows of the parity being
+// Four samples per thread, the planes of up to 16 frames per launch.  Rows of the parity being
 // rebuilt are interpolated, the others are copied from the current frame; every
 // decision (vertical-edge rows, the x margin of the spatial search, first/last
 // row stride mirroring, C-style truncating /40) follows the reference so the
@@ -47,152 +47,7 @@ __device__ __forceinline__ int cubic4(int y0, int y1, int y2, int y3, int maxv)
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
 
-template <typename PIX>
-__device__ __forceinline__ bool yadif_check(const PIX *c, int sp, int sn, int st, int j, bool cubic_ok, int maxv,
-                                            int &best, int &pred)
-{
-    const int score = abs((int)c[sp - 1 + j] - (int)c[sn - 1 - j]) + abs((int)c[sp + j] - (int)c[sn - j]) +
-                      abs((int)c[sp + 1 + j] - (int)c[sn + 1 - j]);
-    if (score >= best) return false;
-    best = score;
-    if (cubic_ok)
-    {
-        // :541-570
-        if (j == -1)      pred = cubic4(c[-3 * st - 3], c[-st - 1], c[st + 1], c[3 * st + 3], maxv);
-        else if (j == -2) pred = cubic4((c[-3 * st - 4] + c[-st - 4]) / 2, c[-st - 2], c[st + 2], (c[3 * st + 4] + c[st + 4]) / 2, maxv);
-        else if (j == 1)  pred = cubic4(c[-3 * st + 3], c[-st + 1], c[st - 1], c[3 * st - 3], maxv);
-        else              pred = cubic4((c[-3 * st + 4] + c[-st + 4]) / 2, c[-st + 2], c[st - 2], (c[3 * st - 4] + c[st - 4]) / 2, maxv);
-    }
-    else
-    {
-        pred = ((int)c[sp + j] + (int)c[sn - j]) >> 1;
-    }
-    return true;
-}
-
-// PIX = uint8_t, or uint16_t for the _16 instantiation (decomb.c:324-331); pitches arrive in bytes,
-// maxv = (1 << depth) - 1
-template <typename PIX>
-__device__ __forceinline__ void decomb_plane_px(const DecombArgs &a, int plane, int maxv)
-{
-    const DecombPlane &P = a.pl[plane];
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= P.w || y >= P.h) return;
-    const int st = P.pitch / (int)sizeof(PIX);
-    const PIX *c = reinterpret_cast<const PIX *>(P.cur) + (size_t)y * st + x;
-    PIX *o = reinterpret_cast<PIX *>(P.dst + (size_t)y * P.dst_pitch) + x;
-    const PIX *guess = reinterpret_cast<const PIX *>(P.guess + (size_t)y * P.guess_pitch) + x;
-    const int mode = a.mode;
-
-    if (mode == 0)                                         // pass-through (:892-897)
-    {
-        *o = *c;
-        return;
-    }
-    if ((mode & M_EEDI2) && !(mode & M_YADIF))             // EEDI2 only (:855-875)
-    {
-        *o = *guess;
-        return;
-    }
-    if ((y & 1) != (a.parity ? 0 : 1))                     // kept field (:795-807)
-    {
-        *o = *c;
-        return;
-    }
-    const int h = P.h;
-    if (mode == M_BLEND)                                   // :300-361
-    {
-        int u1, u2, d1, d2;
-        if (y > 1 && y < h - 2) { u1 = -st; u2 = -2 * st; d1 = st; d2 = 2 * st; }
-        else if (y == 0)        { u1 = u2 = 0; d1 = st; d2 = 2 * st; }
-        else if (y == 1)        { u1 = u2 = -st; d1 = st; d2 = 2 * st; }
-        else if (y == h - 2)    { u1 = -st; u2 = -2 * st; d1 = d2 = st; }
-        else                    { u1 = -st; u2 = -2 * st; d1 = d2 = 0; }
-        const int v = (-(int)c[u2] + 2 * (int)c[u1] + 6 * (int)c[0] + 2 * (int)c[d1] - (int)c[d2]) >> 3;
-        *o = (PIX)cropv(v, maxv);
-        return;
-    }
-    if (mode == M_CUBIC)                                   // :50-107
-    {
-        int p0 = 0, p1 = 0, p2 = 0, p3 = 0;
-        if (y >= 3)                { p0 = c[-3 * st]; p1 = c[-st]; }
-        else if (y == 2 || y == 1) { p0 = p1 = c[-st]; }
-        else if (y == 0)           { p0 = p1 = c[st]; }
-        if (y <= h - 4)                      { p2 = c[st]; p3 = c[3 * st]; }
-        else if (y == h - 3 || y == h - 2)   { p2 = p3 = c[st]; }
-        else if (y == h - 1)                 { p2 = p3 = c[-st]; }
-        *o = (PIX)cubic4(p0, p1, p2, p3, maxv);
-        return;
-    }
-    if (!(mode & M_YADIF))
-        return;                                            // untouched, as the reference leaves it
-
-    // ---- yadif_filter_line (:579-712)
-    const PIX *pp = reinterpret_cast<const PIX *>(P.prev) + (size_t)y * st + x;
-    const PIX *pn = reinterpret_cast<const PIX *>(P.next) + (size_t)y * st + x;
-    const PIX *p2 = a.field_parity ? pp : c;
-    const PIX *n2 = a.field_parity ? c : pn;
-    const int sp = y ? -st : st;
-    const int sn = y + 1 < h ? st : -st;
-    const bool vertical_edge = (y < 3) || (y > h - 4);
-    const bool use_cubic = (mode & M_CUBIC) && !vertical_edge;
-    const int margin = (mode & M_CUBIC) ? 3 : 2;
-
-    const int cc = c[sp];
-    const int d = ((int)p2[0] + (int)n2[0]) >> 1;
-    const int e = c[sn];
-    const int td0 = abs((int)p2[0] - (int)n2[0]);
-    const int td1 = (abs((int)pp[sp] - cc) + abs((int)pp[sn] - e)) >> 1;
-    const int td2 = (abs((int)pn[sp] - cc) + abs((int)pn[sn] - e)) >> 1;
-    int diff = max3i(td0 >> 1, td1, td2);
-    int pred;
-    if (mode & M_EEDI2)
-    {
-        pred = *guess;
-    }
-    else
-    {
-        pred = use_cubic ? cubic4(c[-3 * st], c[-st], c[st], c[3 * st], maxv) : (cc + e) >> 1;
-        if (x > margin && x < P.w - (margin + 1))
-        {
-            int best = abs((int)c[sp - 1] - (int)c[sn - 1]) + abs(cc - e) + abs((int)c[sp + 1] - (int)c[sn + 1]) - 1;
-            if (yadif_check(c, sp, sn, st, -1, use_cubic, maxv, best, pred))
-                yadif_check(c, sp, sn, st, -2, use_cubic, maxv, best, pred);
-            if (yadif_check(c, sp, sn, st, 1, use_cubic, maxv, best, pred))
-                yadif_check(c, sp, sn, st, 2, use_cubic, maxv, best, pred);
-        }
-    }
-    if (!vertical_edge)
-    {
-        const int b = ((int)p2[-2 * st] + (int)n2[-2 * st]) >> 1;
-        const int f = ((int)p2[2 * st] + (int)n2[2 * st]) >> 1;
-        const int mx = max3i(d - e, d - cc, min(b - cc, f - e));
-        const int mn = min3i(d - e, d - cc, max(b - cc, f - e));
-        diff = max3i(diff, mn, -mx);
-    }
-    if (pred > d + diff)      pred = d + diff;
-    else if (pred < d - diff) pred = d - diff;
-    *o = (PIX)pred;
-}
-
-template <typename PIX>
-__global__ __launch_bounds__(256) void decomb_plane_kernel(DecombArgs a, int maxv)
-{
-    decomb_plane_px<PIX>(a, blockIdx.z, maxv);
-}
-
-// the frames of a batch in one launch (10 / 12-bit frames; the 8-bit ones take decomb_plane4_kernel)
-constexpr int DB16_FRAMES = 8;
-struct DecombArgsBatch { DecombArgs f[DB16_FRAMES]; };
-template <typename PIX>
-__global__ __launch_bounds__(256) void decomb_plane_batch_kernel(DecombArgsBatch B, int maxv)
-{
-    const int fr = (int)blockIdx.z / 3;
-    decomb_plane_px<PIX>(B.f[fr], (int)blockIdx.z - 3 * fr, maxv);
-}
-
-// ---- decomb_plane_kernel for 8-bit samples, four pixels per thread and several frames per launch --------------
+// ---- decomb_plane_kernel with four samples per thread and several frames per launch (every depth) --------------
 // One plane of one 1080p frame is ~2 MB: a launch per frame is mostly dispatch latency, and a thread per byte spends
 // its time on load instructions.  Here a thread owns one aligned dword of its row (the rows it needs come in as
 // dwords or 12-byte windows x-4 .. x+7, the arithmetic is the scalar kernel's, per byte), and grid.z runs over the
@@ -213,28 +68,50 @@ struct DecombBatch
     int n = 0;
 };
 
-struct W12 { uint32_t w0, w1, w2; };       // bytes x-4 .. x+7 of a row
+// four adjacent samples of a row as they lie in memory: a dword of bytes, or two dwords of 16-bit samples
+template <typename PIX> struct Px4;
+template <> struct Px4<uint8_t>
+{
+    typedef uint32_t T;
+    static __device__ __forceinline__ T zero() { return 0u; }
+    static __device__ __forceinline__ int get(T v, int k) { return (int)((v >> (8 * k)) & 0xffu); }
+    static __device__ __forceinline__ T pack(const int (&o)[4]) { return ((uint32_t)o[0] & 0xffu) | (((uint32_t)o[1] & 0xffu) << 8) | (((uint32_t)o[2] & 0xffu) << 16) | ((uint32_t)o[3] << 24); }
+};
+template <> struct Px4<uint16_t>
+{
+    typedef uint2 T;
+    static __device__ __forceinline__ T zero() { return make_uint2(0u, 0u); }
+    static __device__ __forceinline__ int get(T v, int k) { return (int)(((k < 2 ? v.x : v.y) >> (16 * (k & 1))) & 0xffffu); }
+    static __device__ __forceinline__ T pack(const int (&o)[4]) { return make_uint2(((uint32_t)o[0] & 0xffffu) | ((uint32_t)o[1] << 16), ((uint32_t)o[2] & 0xffffu) | ((uint32_t)o[3] << 16)); }
+};
+template <typename PIX> struct W12 { typename Px4<PIX>::T w0, w1, w2; };       // samples x-4 .. x+7 of a row
 
-__device__ __forceinline__ int w12b(const W12 &w, int i)          // byte at column x+i, i in [-4, 7] (constant after unrolling)
+template <typename PIX>
+__device__ __forceinline__ int w12b(const W12<PIX> &w, int i)     // sample at column x+i, i in [-4, 7] (constant after unrolling)
 {
     const int k = i + 4;
-    const uint32_t d = k < 4 ? w.w0 : (k < 8 ? w.w1 : w.w2);
-    return (int)((d >> (8 * (k & 3))) & 0xffu);
-}
-__device__ __forceinline__ int dwb(uint32_t d, int k) { return (int)((d >> (8 * k)) & 0xffu); }
-
-// the dwords either side are only read where they exist inside the row
-__device__ __forceinline__ W12 ldw12(const uint8_t *row, int x, int pitch)
-{
-    const uint32_t *p = reinterpret_cast<const uint32_t *>(row + x);
-    return W12{ x >= 4 ? p[-1] : 0u, p[0], x + 4 < pitch ? p[1] : 0u };
+    return Px4<PIX>::get(k < 4 ? w.w0 : (k < 8 ? w.w1 : w.w2), k & 3);
 }
 
-__global__ __launch_bounds__(256) void decomb_plane4_kernel(DecombBatch B)
+// the units either side are only read where they exist inside the row (pitch in samples)
+template <typename PIX>
+__device__ __forceinline__ W12<PIX> ldw12(const uint8_t *row, int x, int pitch)
 {
+    typedef typename Px4<PIX>::T T;
+    const T *p = reinterpret_cast<const T *>(row + (size_t)x * sizeof(PIX));
+    return W12<PIX>{ x >= 4 ? p[-1] : Px4<PIX>::zero(), p[0], x + 4 < pitch ? p[1] : Px4<PIX>::zero() };
+}
+
+template <typename PIX>
+__global__ __launch_bounds__(256) void decomb_plane4_kernel(DecombBatch B, int maxv)
+{
+    typedef Px4<PIX> X4;
+    typedef typename X4::T T;
+    typedef W12<PIX> WIN;
     const int pl = blockIdx.z % 3;
     const DecombFrame &F = B.f[blockIdx.z / 3];
-    const int w = B.w[pl], h = B.h[pl], st = B.pitch[pl];
+    const int w = B.w[pl], h = B.h[pl], st = B.pitch[pl];             // st: bytes between rows
+    const int pitch_s = st / (int)sizeof(PIX);
     const int x = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= w || y >= h) return;
@@ -242,11 +119,13 @@ __global__ __launch_bounds__(256) void decomb_plane4_kernel(DecombBatch B)
     const uint8_t *crow = cb + (size_t)y * st;
     uint8_t *orow = F.dst[pl] + (size_t)y * B.dst_pitch[pl];
     const int mode = F.mode;
-    auto store = [&](uint32_t v) {
-        if (x + 3 < w) *reinterpret_cast<uint32_t *>(orow + x) = v;
-        else for (int k = 0; k < 4 && x + k < w; k++) orow[x + k] = (uint8_t)(v >> (8 * k));
+    auto store = [&](T v) {
+        PIX *o = reinterpret_cast<PIX *>(orow) + x;
+        if (x + 3 < w) *reinterpret_cast<T *>(o) = v;
+        else for (int k = 0; k < 4 && x + k < w; k++) o[k] = (PIX)X4::get(v, k);
     };
-    auto dw = [&](const uint8_t *row) { return *reinterpret_cast<const uint32_t *>(row + x); };
+    auto dw = [&](const uint8_t *row) { return *reinterpret_cast<const T *>(row + (size_t)x * sizeof(PIX)); };
+    auto dwb = [](T v, int k) { return X4::get(v, k); };
 
     if (mode == 0) { store(dw(crow)); return; }                                    // pass-through (:892-897)
     if ((mode & M_EEDI2) && !(mode & M_YADIF))                                    // EEDI2 only (:855-875)
@@ -256,7 +135,7 @@ __global__ __launch_bounds__(256) void decomb_plane4_kernel(DecombBatch B)
     }
     if ((y & 1) != (F.parity ? 0 : 1)) { store(dw(crow)); return; }               // kept field (:795-807)
 
-    uint32_t out = 0;
+    int o4[4] = { 0, 0, 0, 0 };
     if (mode == M_BLEND)                                                           // :300-361
     {
         int u1, u2, d1, d2;
@@ -265,11 +144,11 @@ __global__ __launch_bounds__(256) void decomb_plane4_kernel(DecombBatch B)
         else if (y == 1)        { u1 = u2 = -st; d1 = st; d2 = 2 * st; }
         else if (y == h - 2)    { u1 = -st; u2 = -2 * st; d1 = d2 = st; }
         else                    { u1 = -st; u2 = -2 * st; d1 = d2 = 0; }
-        const uint32_t a2 = dw(crow + u2), a1 = dw(crow + u1), c0 = dw(crow), b1 = dw(crow + d1), b2 = dw(crow + d2);
+        const T a2 = dw(crow + u2), a1 = dw(crow + u1), c0 = dw(crow), b1 = dw(crow + d1), b2 = dw(crow + d2);
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            out |= (uint32_t)cropv((-dwb(a2, k) + 2 * dwb(a1, k) + 6 * dwb(c0, k) + 2 * dwb(b1, k) - dwb(b2, k)) >> 3, 255) << (8 * k);
-        store(out);
+            o4[k] = cropv((-dwb(a2, k) + 2 * dwb(a1, k) + 6 * dwb(c0, k) + 2 * dwb(b1, k) - dwb(b2, k)) >> 3, maxv);
+        store(X4::pack(o4));
         return;
     }
     if (mode == M_CUBIC)                                                           // :50-107
@@ -282,10 +161,10 @@ __global__ __launch_bounds__(256) void decomb_plane4_kernel(DecombBatch B)
         if (y <= h - 4)                    { o2 = st; o3 = 3 * st; }
         else if (y == h - 3 || y == h - 2) { o2 = o3 = st; }
         else                               { o2 = o3 = -st; }
-        const uint32_t p0 = dw(crow + o0), p1 = dw(crow + o1), p2 = dw(crow + o2), p3 = dw(crow + o3);
+        const T p0 = dw(crow + o0), p1 = dw(crow + o1), p2 = dw(crow + o2), p3 = dw(crow + o3);
 #pragma unroll
-        for (int k = 0; k < 4; k++) out |= (uint32_t)cubic4(dwb(p0, k), dwb(p1, k), dwb(p2, k), dwb(p3, k), 255) << (8 * k);
-        store(out);
+        for (int k = 0; k < 4; k++) o4[k] = cubic4(dwb(p0, k), dwb(p1, k), dwb(p2, k), dwb(p3, k), maxv);
+        store(X4::pack(o4));
         return;
     }
     if (!(mode & M_YADIF)) return;                                                 // untouched, as the reference leaves it
@@ -300,21 +179,21 @@ __global__ __launch_bounds__(256) void decomb_plane4_kernel(DecombBatch B)
     const int margin = (mode & M_CUBIC) ? 3 : 2;
     const bool spatial = !(mode & M_EEDI2);
 
-    const uint32_t p20 = dw(p2row), n20 = dw(n2row);
-    const uint32_t ppu = dw(prow + sp), ppd = dw(prow + sn), pnu = dw(nrow + sp), pnd = dw(nrow + sn);
-    uint32_t p2a = 0, p2b = 0, n2a = 0, n2b = 0;                                   // rows y-2 / y+2
+    const T p20 = dw(p2row), n20 = dw(n2row);
+    const T ppu = dw(prow + sp), ppd = dw(prow + sn), pnu = dw(nrow + sp), pnd = dw(nrow + sn);
+    T p2a = X4::zero(), p2b = X4::zero(), n2a = X4::zero(), n2b = X4::zero();         // rows y-2 / y+2
     if (!vertical_edge) { p2a = dw(p2row - 2 * st); p2b = dw(p2row + 2 * st); n2a = dw(n2row - 2 * st); n2b = dw(n2row + 2 * st); }
-    uint32_t g = 0;
+    T g = X4::zero();
     if (!spatial) g = dw(F.guess[pl] + (size_t)y * B.guess_pitch[pl]);
-    W12 cu, cd, cu3 = {0, 0, 0}, cd3 = {0, 0, 0};                                  // rows y+sp, y+sn, y-3, y+3 of cur
+    WIN cu, cd, cu3 = { X4::zero(), X4::zero(), X4::zero() }, cd3 = cu3;             // rows y+sp, y+sn, y-3, y+3 of cur
     if (spatial)
     {
-        cu = ldw12(crow + sp, x, st); cd = ldw12(crow + sn, x, st);
-        if (use_cubic) { cu3 = ldw12(crow - 3 * st, x, st); cd3 = ldw12(crow + 3 * st, x, st); }
+        cu = ldw12<PIX>(crow + sp, x, pitch_s); cd = ldw12<PIX>(crow + sn, x, pitch_s);
+        if (use_cubic) { cu3 = ldw12<PIX>(crow - 3 * st, x, pitch_s); cd3 = ldw12<PIX>(crow + 3 * st, x, pitch_s); }
     }
     else
     {
-        cu = W12{0u, dw(crow + sp), 0u}; cd = W12{0u, dw(crow + sn), 0u};
+        cu = WIN{ X4::zero(), dw(crow + sp), X4::zero() }; cd = WIN{ X4::zero(), dw(crow + sn), X4::zero() };
     }
 #pragma unroll
     for (int k = 0; k < 4; k++)
@@ -331,7 +210,7 @@ __global__ __launch_bounds__(256) void decomb_plane4_kernel(DecombBatch B)
         else
         {
             // c[sp + i] = cu(k + i), c[sn + i] = cd(k + i); with the cubic predictor sp = -st, sn = st (no vertical edge)
-            pred = use_cubic ? cubic4(w12b(cu3, k), cc, e, w12b(cd3, k), 255) : (cc + e) >> 1;
+            pred = use_cubic ? cubic4(w12b(cu3, k), cc, e, w12b(cd3, k), maxv) : (cc + e) >> 1;
             const int xx = x + k;
             if (xx > margin && xx < w - (margin + 1))
             {
@@ -344,12 +223,12 @@ __global__ __launch_bounds__(256) void decomb_plane4_kernel(DecombBatch B)
                     if (use_cubic)
                     {
                         // :541-570
-                        if (j == -1)      pred = cubic4(w12b(cu3, k - 3), w12b(cu, k - 1), w12b(cd, k + 1), w12b(cd3, k + 3), 255);
+                        if (j == -1)      pred = cubic4(w12b(cu3, k - 3), w12b(cu, k - 1), w12b(cd, k + 1), w12b(cd3, k + 3), maxv);
                         else if (j == -2) pred = cubic4((w12b(cu3, k - 4) + w12b(cu, k - 4)) / 2, w12b(cu, k - 2), w12b(cd, k + 2),
-                                                        (w12b(cd3, k + 4) + w12b(cd, k + 4)) / 2, 255);
-                        else if (j == 1)  pred = cubic4(w12b(cu3, k + 3), w12b(cu, k + 1), w12b(cd, k - 1), w12b(cd3, k - 3), 255);
+                                                        (w12b(cd3, k + 4) + w12b(cd, k + 4)) / 2, maxv);
+                        else if (j == 1)  pred = cubic4(w12b(cu3, k + 3), w12b(cu, k + 1), w12b(cd, k - 1), w12b(cd3, k - 3), maxv);
                         else              pred = cubic4((w12b(cu3, k + 4) + w12b(cu, k + 4)) / 2, w12b(cu, k + 2), w12b(cd, k - 2),
-                                                        (w12b(cd3, k - 4) + w12b(cd, k - 4)) / 2, 255);
+                                                        (w12b(cd3, k - 4) + w12b(cd, k - 4)) / 2, maxv);
                     }
                     else pred = (w12b(cu, k + j) + w12b(cd, k - j)) >> 1;
                     return true;
@@ -368,9 +247,9 @@ __global__ __launch_bounds__(256) void decomb_plane4_kernel(DecombBatch B)
         }
         if (pred > d + diff)      pred = d + diff;
         else if (pred < d - diff) pred = d - diff;
-        out |= (uint32_t)(pred & 0xff) << (8 * k);
+        o4[k] = pred;
     }
-    store(out);
+    store(X4::pack(o4));
 }
 
 // ------------------------------------------------------------------- host side
@@ -621,7 +500,7 @@ public:
     {
         if (outq.empty()) return nullptr;
         // a frame that is handed out must have been launched: whoever pulls without a kick gets one here
-        if (!gathered.empty() || !gathered16.empty() || (eedi && eedi->queued() > 0) || (eedi16 && eedi16->queued() > 0))
+        if (!gathered.empty() || (eedi && eedi->queued() > 0) || (eedi16 && eedi16->queued() > 0))
             (void)flush_batch();
         DevPicture *p = outq.front();
         outq.pop_front();
@@ -638,7 +517,7 @@ private:
         if (!p || --p->refs != 0) return;
         // a queued EEDI2 field or a blend gathered for the batch launch may still read it: hand it back when the
         // batch is out
-        if (!gathered.empty() || !gathered16.empty() || (eedi && eedi->queued() > 0) || (eedi16 && eedi16->queued() > 0))
+        if (!gathered.empty() || (eedi && eedi->queued() > 0) || (eedi16 && eedi16->queued() > 0))
             late_unref.push_back(p);
         else hbhip_pic_release(p, ctx);                    // possibly another filter's picture (fused chain)
     }
@@ -663,7 +542,6 @@ private:
     // slot: the EEDI2 slot holding this frame's guess (8-bit EEDI2 modes)
     int launch(DevPicture *dst, int mode, int parity, int tff, int slot = -1)
     {
-        hbhip_ctx *lc = ctx;
         DecombArgs a;
         for (int c = 0; c < 3; c++)
         {
@@ -708,15 +586,7 @@ private:
             HBHIP_CHECK(ctx, hipGetLastError());
             return HBHIP_OK;
         }
-        if (in_geo.bps == 2)
-        {
-            // 10 / 12 bits: one launch per frame, behind the EEDI2 engine's launch when the frame's guess is queued there
-            if (eedi16 && (eedi16->queued() > 0 || !gathered16.empty())) { gathered16.push_back(a); return HBHIP_OK; }
-            HBHIP_LAUNCH(lc, "decomb_plane", decomb_plane_kernel<uint16_t>, grid, block, 0, a, maxv);
-            HBHIP_CHECK(lc, hipGetLastError());
-            return HBHIP_OK;
-        }
-        // 8-bit: four pixels per thread.  The frames are gathered and go out together (launch_gathered, DB_FRAMES per
+        // Four samples per thread (every depth).  The frames are gathered and go out together (launch_gathered, DB_FRAMES per
         // launch): at the end of the call, or - inside a chain batch - when the batch is complete or the EEDI2 engine
         // is full (a frame whose guess is still queued there cannot be launched before the engine).
         DecombFrame F;
@@ -740,23 +610,11 @@ private:
             B.n = (int)std::min<size_t>(DB_FRAMES, gathered.size() - i0);
             for (int k = 0; k < B.n; k++) B.f[k] = gathered[i0 + k];
             const dim3 block(64, 4), grid((B.w[0] + 255) / 256, (B.h[0] + 3) / 4, 3 * B.n);
-            HBHIP_LAUNCH(lc, "decomb_plane", decomb_plane4_kernel, grid, block, 0, B);
+            if (in_geo.bps == 2) HBHIP_LAUNCH(lc, "decomb_plane", decomb_plane4_kernel<uint16_t>, grid, block, 0, B, (1 << in_geo.depth) - 1);
+            else                 HBHIP_LAUNCH(lc, "decomb_plane", decomb_plane4_kernel<uint8_t>, grid, block, 0, B, 255);
         }
-        if (!gathered16.empty())
-        {
-            const dim3 block(64, 4), grid((in_geo.pw[0] + 63) / 64, (in_geo.ph[0] + 3) / 4, 3);
-            const int maxv = (1 << in_geo.depth) - 1;
-            for (size_t i0 = 0; i0 < gathered16.size(); i0 += DB16_FRAMES)
-            {
-                const int m = (int)std::min<size_t>(DB16_FRAMES, gathered16.size() - i0);
-                DecombArgsBatch B;
-                for (int k = 0; k < DB16_FRAMES; k++) B.f[k] = gathered16[i0 + std::min(k, m - 1)];
-                HBHIP_LAUNCH(lc, "decomb_plane", decomb_plane_batch_kernel<uint16_t>, dim3(grid.x, grid.y, 3 * m), block, 0, B, maxv);
-            }
-        }
-        const bool any = !gathered.empty() || !gathered16.empty();
+        const bool any = !gathered.empty();
         gathered.clear();
-        gathered16.clear();
         if (any) HBHIP_CHECK(lc, hipGetLastError());
         return HBHIP_OK;
     }
@@ -842,7 +700,6 @@ private:
     std::vector<DevPicture *> late_unref;  // input pictures whose last reference went while something gathered could still read them
     bool deferred = false;
     std::vector<DecombFrame> gathered;     // blends waiting for their launch (launch_gathered)
-    std::vector<DecombArgs> gathered16;    // the same for 10 / 12-bit frames (one launch each)
     DecombBatch geo;                       // the pitches / sizes they share
 public:
     Eedi2Engine16 *eedi16 = nullptr;       // 10 / 12-bit samples
