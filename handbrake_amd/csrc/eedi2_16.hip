@@ -858,6 +858,193 @@ __device__ __forceinline__ int dir_map_px16(int u0, int u1, int u2, int c0, int 
     return val;
 }
 
+// ---- filter_dir_map / _2x in registers, the vote on PAIRS of samples (eedi2.hip: dir_map_pair, k_dir_map4) ----------------
+// With a dense mask nearly every sample of the pass reaches its sort and its vote; two horizontally adjacent samples ride
+// in the halves of a dword - which is how 16-bit samples lie in memory, so the nine slots of a pair are three dwords of
+// each row as they are or realigned by two bytes, no unpacking.  An absent slot (a peak; a row that does not count)
+// holds 0x7fff: above every sample and 0x7000 or more from every midpoint, the cap of the vote's limit.
+typedef uint16_t u16x2d __attribute__((ext_vector_type(2)));
+typedef int16_t i16x2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2d pkd(uint32_t v) { return __builtin_bit_cast(u16x2d, v); }
+__device__ __forceinline__ uint32_t und(u16x2d v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ u16x2d pkd1(uint32_t both) { return pkd(both * 0x00010001u); }
+__device__ __forceinline__ u16x2d pkd_lt(u16x2d a, u16x2d b) { return (u16x2d)((u16x2d)(a - b) >> 15); }   // halves below 2^15
+__device__ __forceinline__ void cswap2d(u16x2d &a, u16x2d &b)
+{
+    const u16x2d lo = __builtin_elementwise_min(a, b), hi = __builtin_elementwise_max(a, b);
+    a = lo; b = hi;
+}
+struct Win16 { uint32_t w0, w1, w2, w3; };       // samples x-2 .. x+5 of a row
+
+// the pair of samples at columns K, K + 1 of the thread's four (K = 0 or 2); returns the pass's values for both halves
+template <int K>
+__device__ __forceinline__ uint32_t dir_map_pair16(const Win16 &wu, const Win16 &wc, const Win16 &wd, int expand, int peak, int neutral, int shift)
+{
+    u16x2d v[9];
+    {
+        const Win16 *rows[3] = { &wu, &wc, &wd };
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+        {
+            const Win16 &w = *rows[r];
+            if (K == 0)
+            {
+                v[3 * r + 0] = pkd(__builtin_amdgcn_alignbyte(w.w1, w.w0, 2u));       // columns -1, 0
+                v[3 * r + 1] = pkd(w.w1);                                             // 0, 1
+                v[3 * r + 2] = pkd(__builtin_amdgcn_alignbyte(w.w2, w.w1, 2u));       // 1, 2
+            }
+            else
+            {
+                v[3 * r + 0] = pkd(__builtin_amdgcn_alignbyte(w.w2, w.w1, 2u));       // 1, 2
+                v[3 * r + 1] = pkd(w.w2);                                             // 2, 3
+                v[3 * r + 2] = pkd(__builtin_amdgcn_alignbyte(w.w3, w.w2, 2u));       // 3, 4
+            }
+        }
+    }
+    const u16x2d c1 = v[4];
+    // (a direction value can lie ABOVE the peak: neutral + (32 << (2 + shift)) is one more than it - a search distance of 32 gets
+    // there - so the peak is found by equality)
+    const u16x2d peakv = pkd1((uint32_t)peak), lift = pkd1(0x7fffu - (uint32_t)peak);
+    uint32_t absent = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+    {
+        const u16x2d a = pkd_lt(v[i] ^ peakv, pkd1(1));                 // 1 per half that holds the peak
+        absent += und(a);
+        v[i] = v[i] + a * lift;
+    }
+    u16x2d s0 = v[0], s1 = v[1], s2 = v[2], s3 = v[3], s4 = v[4], s5 = v[5], s6 = v[6], s7 = v[7], s8 = v[8];
+    cswap2d(s0, s3); cswap2d(s1, s7); cswap2d(s2, s5); cswap2d(s4, s8);
+    cswap2d(s0, s7); cswap2d(s2, s4); cswap2d(s3, s8); cswap2d(s5, s6);
+    cswap2d(s0, s2); cswap2d(s1, s3); cswap2d(s4, s5); cswap2d(s7, s8);
+    cswap2d(s1, s4); cswap2d(s3, s6); cswap2d(s5, s7);
+    cswap2d(s0, s1); cswap2d(s2, s4); cswap2d(s3, s5); cswap2d(s6, s8);
+    cswap2d(s2, s3); cswap2d(s4, s5); cswap2d(s6, s7);
+    cswap2d(s1, s2); cswap2d(s3, s4); cswap2d(s5, s6);
+    const u16x2d ab = pkd(absent), one = pkd1(1), zero = pkd1(0);
+    const uint32_t m5 = und(zero - pkd_lt(pkd1(3), ab));                // n <= 5 <=> absent >= 4
+    const uint32_t m7 = und(zero - pkd_lt(one, ab));                    // n <= 7 <=> absent >= 2
+    const uint32_t modd = und((ab & one) - one);                        // n odd <=> absent even
+#define PKD_SEL(m, x, y) (((m) & (x)) | (~(m) & (y)))
+    const uint32_t hi = PKD_SEL(m5, und(s2), PKD_SEL(m7, und(s3), und(s4)));
+    const uint32_t lo = PKD_SEL(m5, und(s1), PKD_SEL(m7, und(s2), und(s3)));
+    const u16x2d mid = pkd(PKD_SEL(modd, hi, und((u16x2d)((pkd(lo) + pkd(hi) + one) >> 1))));
+#undef PKD_SEL
+    // the limit: (limlut[i] << shift) with limlut in closed form (eedi2.hip: limlut2), i = |mid - neutral| >> (2 + shift); the two
+    // last entries (a -1 stored as a sample: every present value is in) capped at 0x7000
+    const i16x2d t = __builtin_bit_cast(i16x2d, (u16x2d)(mid - pkd1((uint32_t)neutral)));
+    const u16x2d ii = __builtin_bit_cast(u16x2d, __builtin_elementwise_max(t, (i16x2d)(-t))) >> (uint16_t)(2 + shift);
+    const u16x2d g = pkd_lt(pkd1(7), ii);
+    const u16x2d l8 = __builtin_elementwise_min((u16x2d)(((ii - g) >> 1) + pkd1(6)), pkd1(12));
+    const u16x2d lim1 = __builtin_elementwise_max((u16x2d)((l8 << (uint16_t)shift) + one), (u16x2d)(pkd_lt(pkd1(30), ii) * pkd1(0x7000)));
+    u16x2d sum = zero, cnt = zero;
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+    {
+        const u16x2d d = __builtin_elementwise_max(v[i], mid) - __builtin_elementwise_min(v[i], mid);
+        const u16x2d in = pkd_lt(d, lim1);
+        cnt += in;
+        sum += in * v[i];
+    }
+    const uint32_t sm = und((u16x2d)(sum + mid)), ct = und(cnt);
+    uint32_t out = 0;
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+    {
+        const int n = 9 - (int)((absent >> (16 * h)) & 0xffffu);
+        const int count = n >= 4 ? (int)((ct >> (16 * h)) & 0xffffu) : 0;              // (fewer: the midpoint may be an absent slot)
+        const int val = (int)(((float)((sm >> (16 * h)) & 0xffffu) / (float)(count + 1)) + 0.5f);
+        const int c = (int)((und(c1) >> (16 * h)) & 0xffffu);
+        int res;
+        if (expand) res = count >= 5 ? val : c;
+        else        res = (count < 4 || (count < 5 && c == peak)) ? peak : val;
+        out |= ((uint32_t)res & 0xffffu) << (16 * h);
+    }
+    return out;
+}
+
+// a = mask, b = direction map in, c = out.  Four samples per thread; in the _2x form a thread takes the rows 2r and 2r + 1 -
+// the one with the rebuilt rows' parity is worked on, the other copied (eedi2.hip: k_dir_map4)
+__global__ __launch_bounds__(256) void q_dir_map4(Q3 P, K16 k, int step, int expand)
+{
+    FIELD16(P);
+    const int x = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
+    const int r = blockIdx.y * blockDim.y + threadIdx.y;
+    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
+    const int y0 = step == 1 ? 1 : 2 - tff;
+    const int y = step == 1 ? r : 2 * r + (y0 & 1);
+    if (x >= width) return;
+    const int peak = k.peak;
+    const uint32_t peak2 = (uint32_t)peak * 0x00010001u;
+    auto put = [&](int yy, uint2 v) {
+        uint16_t *o = Q.c + (size_t)yy * pitch + x;
+        if (x + 3 < width) *reinterpret_cast<uint2 *>(o) = v;
+        else
+        {
+            const uint16_t o4[4] = { (uint16_t)(v.x & 0xffffu), (uint16_t)(v.x >> 16), (uint16_t)(v.y & 0xffffu), (uint16_t)(v.y >> 16) };
+            for (int j = 0; j < 4 && x + j < width; j++) o[j] = o4[j];
+        }
+    };
+    if (maskless)
+    {
+        const int ya = step == 1 ? r : 2 * r, nrows = step == 1 ? 1 : 2;
+        for (int i = 0; i < nrows && ya + i < height; i++) put(ya + i, make_uint2(peak2, peak2));
+        return;
+    }
+    const int yc = 2 * r + 1 - (y0 & 1);
+    const bool copy = step != 1 && yc < height;
+    uint2 vcopy = make_uint2(0u, 0u);
+    if (copy) vcopy = *reinterpret_cast<const uint2 *>(Q.b + (size_t)yc * pitch + x);
+    if (y >= height) { if (copy) put(yc, vcopy); return; }
+    const uint16_t *dc = Q.b + (size_t)y * pitch + x;
+    const bool row_ok = step == 1 ? (y >= 1 && y < height - 1) : (y >= y0 && y < height - 1);
+    const uint2 own = *reinterpret_cast<const uint2 *>(dc);
+    if (!row_ok)
+    {
+        put(y, own);
+        if (copy) put(yc, vcopy);
+        return;
+    }
+    const uint16_t *mk = Q.a + (size_t)y * pitch + x;
+    const uint2 m0 = *reinterpret_cast<const uint2 *>(step == 1 ? mk : mk - (ptrdiff_t)pitch);
+    const uint2 m1 = step == 1 ? make_uint2(0u, 0u) : *reinterpret_cast<const uint2 *>(mk + pitch);
+    const bool up_ok = step == 1 || y > 1, dn_ok = step == 1 || y < height - 2;
+    // the samples the pass works on (:658 / :738): inside the row, on the mask, and for expand a peak
+    const int mm0[4] = { (int)(m0.x & 0xffffu), (int)(m0.x >> 16), (int)(m0.y & 0xffffu), (int)(m0.y >> 16) };
+    const int mm1[4] = { (int)(m1.x & 0xffffu), (int)(m1.x >> 16), (int)(m1.y & 0xffffu), (int)(m1.y >> 16) };
+    const int oo[4] = { (int)(own.x & 0xffffu), (int)(own.x >> 16), (int)(own.y & 0xffffu), (int)(own.y >> 16) };
+    uint32_t work = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+    {
+        const int xx = x + j;
+        const bool masked = mm0[j] == peak || (step != 1 && mm1[j] == peak);
+        if (xx >= 1 && xx < width - 1 && masked && !(expand && oo[j] != peak)) work |= 1u << j;
+    }
+    uint2 res = own;
+    if (work)
+    {
+        asm volatile("" ::: "memory");                         // a real branch: waves without such a sample skip the loads and the votes
+        auto ldwin = [&](const uint16_t *row) -> Win16 {
+            const uint2 c4 = *reinterpret_cast<const uint2 *>(row);
+            const uint32_t l = x >= 2 ? *reinterpret_cast<const uint32_t *>(row - 2) : 0u;
+            const uint32_t rr = x + 4 < pitch ? *reinterpret_cast<const uint32_t *>(row + 4) : 0u;
+            return Win16{ l, c4.x, c4.y, rr };
+        };
+        const Win16 none = { peak2, peak2, peak2, peak2 };
+        const Win16 wc = ldwin(dc);
+        const Win16 wu = up_ok ? ldwin(dc - (ptrdiff_t)step * pitch) : none, wd = dn_ok ? ldwin(dc + (ptrdiff_t)step * pitch) : none;
+        const uint32_t p01 = dir_map_pair16<0>(wu, wc, wd, expand, peak, k.neutral, k.shift);
+        const uint32_t p23 = dir_map_pair16<2>(wu, wc, wd, expand, peak, k.neutral, k.shift);
+        const uint32_t s01 = ((work & 1u) ? 0x0000ffffu : 0u) | ((work & 2u) ? 0xffff0000u : 0u);
+        const uint32_t s23 = ((work & 4u) ? 0x0000ffffu : 0u) | ((work & 8u) ? 0xffff0000u : 0u);
+        res.x = (res.x & ~s01) | (p01 & s01);
+        res.y = (res.y & ~s23) | (p23 & s23);
+    }
+    put(y, res);
+    if (copy) put(yc, vcopy);
+}
+
 // Two phases, as for 8-bit samples (eedi2.hip: k_dir_map_c).  Phase 1, four samples per thread: which samples reach the
 // sort at all (inside the mask, enough usable directions around them) - on real pictures a small minority, spread so
 // that nearly every wave holds a few, and a wave pays for the sort if one lane needs it.  They are queued (an LDS list
@@ -1556,7 +1743,7 @@ template <int G, int N> __device__ __forceinline__ uint32_t lat16_one(const uint
 }
 #define LAT16_SAD3(wa, GA, wb, GB) \
     __builtin_amdgcn_sad_u16(lat16_pair<GA>(wa), lat16_pair<GB>(wb), __builtin_amdgcn_sad_u16(lat16_one<(GA) + 2>(wa), lat16_one<(GB) + 2>(wb), 0u))
-// which of a window's eight samples are a direction (below the peak) within lim of d: sample 2i at bit i, 2i + 1 at bit 16 + i
+// which of a window's eight samples are a direction (not the peak) within lim of d: sample 2i at bit i, 2i + 1 at bit 16 + i
 __device__ __forceinline__ uint32_t lat16_near8(const uint32_t (&w)[4], u16x2q d2, u16x2q lim1, u16x2q peak2)
 {
     uint32_t m = 0;
@@ -1566,7 +1753,7 @@ __device__ __forceinline__ uint32_t lat16_near8(const uint32_t (&w)[4], u16x2q d
         const u16x2q h = pkq(w[i]);
         const i16x2q t = __builtin_bit_cast(i16x2q, (u16x2q)(h - d2));
         const u16x2q a = __builtin_bit_cast(u16x2q, __builtin_elementwise_max(t, (i16x2q)(-t)));
-        m |= unq(pkq_lt(a, lim1) & pkq_lt(h, peak2)) << i;
+        m |= unq(pkq_lt(a, lim1) & (pkq_lt(h ^ peak2, pkq1(1)) ^ pkq1(1))) << i;      // (not the peak: by equality - a value can lie above it)
     }
     return m;
 }
@@ -2319,7 +2506,7 @@ int Eedi2Engine16::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st)
     else
         HBHIP_LAUNCH_ON(lc, st, "eedi2_16_calc_directions", q_calc_dir, grid(srcp, true, gz), blk, 0, P, k, par_.maximum_search_distance, par_.noise_threshold);
     bind(P.a, mskp); bind(P.b, tmpp); bind(P.c, dstp);
-    HBHIP_LAUNCH_ON(lc, st, "eedi2_16_filter_dir_map", q_dir_map, grid4(srcp, gz), blk, 0, P, k, 1, 0);
+    HBHIP_LAUNCH_ON(lc, st, "eedi2_16_filter_dir_map", q_dir_map4, grid4(srcp, gz), blk, 0, P, k, 1, 0);
     bind(P.a, mskp); bind(P.b, dstp); bind(P.c, tmpp);
     HBHIP_LAUNCH_ON(lc, st, "eedi2_16_expand_dir_map", q_dir_map, grid4(srcp, gz), blk, 0, P, k, 1, 1);
     bind(P.a, mskp); bind(P.b, tmpp); bind(P.c, dstp);
@@ -2330,7 +2517,7 @@ int Eedi2Engine16::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st)
     HBHIP_LAUNCH_ON(lc, st, "eedi2_16_mark_directions_2x", q_mark_2x,                                    // a thread row per pair of rows, four samples per thread
                  dim3((dst2p.stride[0] / 2 + 255) / 256, ((dst2p.height[0] + 1) / 2 + 3) / 4, gz), blk, 0, P, k);
     bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
-    HBHIP_LAUNCH_ON(lc, st, "eedi2_16_filter_dir_map_2x", q_dir_map, grid4p(dst2p, gz), blk, 0, P, k, 2, 0);
+    HBHIP_LAUNCH_ON(lc, st, "eedi2_16_filter_dir_map_2x", q_dir_map4, grid4p(dst2p, gz), blk, 0, P, k, 2, 0);
     bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
     HBHIP_LAUNCH_ON(lc, st, "eedi2_16_expand_dir_map_2x", q_dir_map, grid4p(dst2p, gz), blk, 0, P, k, 2, 1);
     for (int pass = 0; pass < 2; pass++)
@@ -2353,7 +2540,7 @@ int Eedi2Engine16::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st)
         bind(P.a, tmp2p); bind(P.c, tmp2p2);
         HBHIP_LAUNCH_ON(lc, st, "eedi2_16_blit", q_blit, dim3((dst2p.width[0] + 511) / 512, (dst2p.height[0] + 3) / 4, gz), blk, 0, P);   // eedi2_bit_blit(tmp2p -> tmp2p2)
         bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
-        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_filter_dir_map_2x", q_dir_map, grid4p(dst2p, gz), blk, 0, P, k, 2, 0);
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_filter_dir_map_2x", q_dir_map4, grid4p(dst2p, gz), blk, 0, P, k, 2, 0);
         bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
         HBHIP_LAUNCH_ON(lc, st, "eedi2_16_expand_dir_map_2x", q_dir_map, grid4p(dst2p, gz), blk, 0, P, k, 2, 1);
         bind(P.a, tmp2p); bind(P.b, tmp2p2); bind(P.c, dst2p);
