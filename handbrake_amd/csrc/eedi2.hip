@@ -1375,60 +1375,86 @@ __global__ __launch_bounds__(256) void k_dir_map_c(P3 P, int step, int expand, i
     if (tid == 0) s_count = 0;
     lim_fill(s_lim, tid);
     __syncthreads();
-    uint32_t vcopy[DC_R];
+    // Three sweeps over the thread's DC_R rows, so that the loads of all of them are in flight together: as one loop (load the
+    // row's dword and masks, wait, load its windows, wait, count) a thread went through 2 DC_R memory round trips one after
+    // the other, and the pass - mostly a copy - ran at half of what its bytes allow.
+    uint32_t vcopy[DC_R], own[DC_R], m0[DC_R], m1[DC_R], cand[DC_R];
 #pragma unroll
     for (int h = 0; h < DC_R; h++)
     {
         const int lr = (int)threadIdx.y + 4 * h, r = rb + lr, y = step == 1 ? r : 2 * r + (y0 & 1);
         // the copied row of the pair: fetched now, stored when the workgroup is done (see k_dir_map4)
         const int yc = 2 * r + 1 - (y0 & 1);
-        vcopy[h] = 0;
+        vcopy[h] = 0; own[h] = 0; m0[h] = 0; m1[h] = 0;
         if (step != 1 && x < width && yc < height) vcopy[h] = *reinterpret_cast<const uint32_t *>(Q.b + (size_t)yc * pitch + x);
         const bool inside = x < width && y < height;
         const bool row_ok = step == 1 ? (y >= 1 && y < height - 1) : (y >= y0 && y < height - 1);
-        const uint8_t *dc = Q.b + (size_t)y * pitch + x;
         if (inside)
         {
-            uint32_t out;
-            if (!row_ok) out = *reinterpret_cast<const uint32_t *>(dc);                   // bit_blit only
-            else
+            own[h] = *reinterpret_cast<const uint32_t *>(Q.b + (size_t)y * pitch + x);
+            if (row_ok)
             {
-                // the row's own dword and the mask first: without a candidate among its four pixels a thread copies its dword
-                // and fetches nothing else (k_dir_map4)
-                out = *reinterpret_cast<const uint32_t *>(dc);
                 const uint8_t *mk = Q.a + (size_t)y * pitch + x;
-                const uint32_t m0 = *reinterpret_cast<const uint32_t *>(step == 1 ? mk : mk - (ptrdiff_t)pitch);
-                const uint32_t m1 = step == 1 ? 0u : *reinterpret_cast<const uint32_t *>(mk + pitch);
-                uint32_t cand = ((ff_bytes(m0) | ff_bytes(m1)) >> 7) & mf_bytes_in(x, 1, width - 1);
-                if (expand) cand &= ff_bytes(out) >> 7;                                    // expand only fills peak pixels
-                if (cand)
-                {
-                    const Win12 wc = ldwin(dc), wu = ldwin(dc - (ptrdiff_t)step * pitch), wd = ldwin(dc + (ptrdiff_t)step * pitch);
-                    const bool up_ok = step == 1 || y > 1, dn_ok = step == 1 || y < height - 2;
-                    uint32_t nc, nu, nd;
-                    const uint32_t s3c = live3(wc, nc), s3u = live3(wu, nu), s3d = live3(wd, nd);
-                    uint32_t u = expand ? s3c - nc : s3c;                                  // expand leaves the centre out (:671)
-                    if (up_ok) u += s3u;
-                    if (dn_ok) u += s3d;
-                    const uint32_t enough = ((u + (uint32_t)(0x80 - (expand ? 5 : 4)) * 0x01010101u) >> 7) & 0x01010101u;
-                    if (!expand) out |= (cand & ~enough) * 255u;                           // too few neighbours: peak
-                    const uint32_t sortpx = cand & enough;
-                    if (sortpx)
-                    {
-                        const int n = __popc(sortpx);
-                        int at = atomicAdd(&s_count, n);
+                m0[h] = *reinterpret_cast<const uint32_t *>(step == 1 ? mk : mk - (ptrdiff_t)pitch);
+                if (step != 1) m1[h] = *reinterpret_cast<const uint32_t *>(mk + pitch);
+            }
+        }
+    }
+    Win12 wc[DC_R], wu[DC_R], wd[DC_R];
 #pragma unroll
-                        for (int k = 0; k < 4; k++)
-                            if ((sortpx >> (8 * k)) & 1u) s_list[at++] = (uint16_t)((lr << 8) | (4 * threadIdx.x + k));
-                    }
-                    (void)nu; (void)nd;
+    for (int h = 0; h < DC_R; h++)
+    {
+        const int lr = (int)threadIdx.y + 4 * h, r = rb + lr, y = step == 1 ? r : 2 * r + (y0 & 1);
+        const bool inside = x < width && y < height;
+        const bool row_ok = step == 1 ? (y >= 1 && y < height - 1) : (y >= y0 && y < height - 1);
+        // the row's own dword and the mask first: without a candidate among its four pixels a thread copies its dword and
+        // fetches nothing else (k_dir_map4)
+        cand[h] = 0;
+        wc[h] = wu[h] = wd[h] = Win12{ 0u, 0u, 0u };
+        if (inside && row_ok)
+        {
+            cand[h] = ((ff_bytes(m0[h]) | ff_bytes(m1[h])) >> 7) & mf_bytes_in(x, 1, width - 1);
+            if (expand) cand[h] &= ff_bytes(own[h]) >> 7;                                  // expand only fills peak pixels
+            if (cand[h])
+            {
+                const uint8_t *dc = Q.b + (size_t)y * pitch + x;
+                wc[h] = ldwin(dc); wu[h] = ldwin(dc - (ptrdiff_t)step * pitch); wd[h] = ldwin(dc + (ptrdiff_t)step * pitch);
+            }
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < DC_R; h++)
+    {
+        const int lr = (int)threadIdx.y + 4 * h, r = rb + lr, y = step == 1 ? r : 2 * r + (y0 & 1);
+        const bool inside = x < width && y < height;
+        if (inside)
+        {
+            uint32_t out = own[h];
+            if (cand[h])
+            {
+                const bool up_ok = step == 1 || y > 1, dn_ok = step == 1 || y < height - 2;
+                uint32_t nc, nu, nd;
+                const uint32_t s3c = live3(wc[h], nc), s3u = live3(wu[h], nu), s3d = live3(wd[h], nd);
+                uint32_t u = expand ? s3c - nc : s3c;                                  // expand leaves the centre out (:671)
+                if (up_ok) u += s3u;
+                if (dn_ok) u += s3d;
+                const uint32_t enough = ((u + (uint32_t)(0x80 - (expand ? 5 : 4)) * 0x01010101u) >> 7) & 0x01010101u;
+                if (!expand) out |= (cand[h] & ~enough) * 255u;                        // too few neighbours: peak
+                const uint32_t sortpx = cand[h] & enough;
+                if (sortpx)
+                {
+                    const int n = __popc(sortpx);
+                    int at = atomicAdd(&s_count, n);
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if ((sortpx >> (8 * k)) & 1u) s_list[at++] = (uint16_t)((lr << 8) | (4 * threadIdx.x + k));
                 }
+                (void)nu; (void)nd;
             }
             *reinterpret_cast<uint32_t *>(&s_out[lr][4 * threadIdx.x]) = out;
             if (Q.d)                                                                    // optional copy of the input (the eedi2_bit_blit before post-processing)
             {
-                const uint32_t v = *reinterpret_cast<const uint32_t *>(dc);
-                int in[4] = { (int)(v & 0xff), (int)((v >> 8) & 0xff), (int)((v >> 16) & 0xff), (int)(v >> 24) };
+                int in[4] = { (int)(own[h] & 0xff), (int)((own[h] >> 8) & 0xff), (int)((own[h] >> 16) & 0xff), (int)(own[h] >> 24) };
                 st4(Q.d + (size_t)y * pitch + x, in, x, width);
             }
         }
