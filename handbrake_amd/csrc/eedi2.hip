@@ -2168,7 +2168,9 @@ __device__ __forceinline__ uint32_t lat_window4(const uint32_t *row, int li)
 // dir - 2 (six steps, the first or the last of them outside dir -+ 2) the half steps u >> 1 and (u + 1) >> 1 are
 // constants too, and the second test's pixels (:1262-1279) come out of four more windows; only the winner's four
 // pixels are read per byte.  (As a loop with the second test under a branch: 2.0 of a pixel's 5 steps took it, which
-// for a wave meant all five, each with 14 byte reads on a third of its lanes.)
+// for a wave meant all five, each with 14 byte reads on a third of its lanes.)  The claims on the CPU:
+// tests/test_eedi2_identities_cpu.py::test_lattice_search_steps_side_by_side, ::test_lattice_half_steps_are_constants_of_the_step,
+// ::test_within_limit_as_one_unsigned_compare.
 __device__ __forceinline__ uint32_t lattice_stage_b_win(const LatRows R, const uint8_t *top, const uint8_t *bot, const uint8_t *ot,
                                                         const uint8_t *ob, const uint8_t *dm, int x, int width, int nt4, int nt8,
                                                         uint32_t base, const uint8_t *limlut)

@@ -709,7 +709,8 @@ __global__ __launch_bounds__(256) void lapsharp3_rows16_kernel(LapBatch3 B, int 
 // and the product with coef * strength is either an integer (where a float constant a hair above or below the real one
 // lands on the side the double form lands on) or far from one.  Whether some float constant reproduces the double form
 // is not argued but tried: every (sum, centre) the taps can produce, 2.9 M cases for isolap, once per filter; strengths for
-// which none does (most that are not short decimals) keep the double form.
+// which none does (0.35, 0.7) keep the double form (tests/test_eedi2_identities_cpu.py::test_lapsharp_mix_as_one_float_multiply
+// runs the same search in numpy; tests/test_sharpen_gpu.py::test_lapsharp_mix_forms both forms against the oracle).
 static bool lap_float_mix(const LapKernel &k, double strength, int &kinv, float &mixf)
 {
     if (!(strength >= 0.0) || !(k.coef > 0.0) || k.size != 3) return false;

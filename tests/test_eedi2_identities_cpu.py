@@ -221,3 +221,98 @@ def test_pair_vote_slots():
         hi = 2 if m5 else (3 if m7 else 4)
         lo = 1 if m5 else (2 if m7 else 3)
         assert hi == n >> 1 and (odd == bool(n & 1)) and (odd or lo == (n - 1) >> 1)
+
+
+def test_lattice_search_steps_side_by_side():
+    """lattice_stage_b_win (eedi2.hip, eedi2_16.hip): the reference's loop over u (eedi2.c:1249-1290) accepts a step when its diff
+    is below the last accepted one and its other tests pass - tests that never look at what an earlier step left behind - so
+    the step it ends on is the first one with the smallest diff among those that pass: the minimum of (diff << 3) | step."""
+    rng = np.random.default_rng(11)
+    nt8 = 160
+    for _ in range(20000):
+        diff = rng.integers(0, 200, 5)
+        ok = rng.integers(0, 2, 5).astype(bool)
+        mn, last = nt8, -1
+        for i in range(5):                                   # the loop as the reference writes it
+            if diff[i] < mn and ok[i]:
+                mn, last = diff[i], i
+        keys = [(int(diff[i]) << 3) | i if (ok[i] and diff[i] < nt8) else 0x7fffffff for i in range(5)]
+        best = min(keys)
+        assert (last == -1) == (best == 0x7fffffff)
+        if last >= 0:
+            assert best & 7 == last and best >> 3 == mn
+
+
+def test_lattice_half_steps_are_constants_of_the_step():
+    """Counted from the even number at or below dir - 2 (de - 2 with de = dir & ~1: six steps, the first or the last outside
+    dir -+ 2), step i has u = de - 2 + i, u >> 1 = hb + (i >> 1) and (u + 1) >> 1 = hb + ((i + 1) >> 1) with hb = (de >> 1) - 1;
+    the windows' sample positions follow: x - u - 1 sits 5 - i behind x - de - 4, x + u - 1 sits i behind x + de - 3."""
+    for d in range(-32, 33):
+        de, par = d & ~1, d & 1
+        hb = (de >> 1) - 1
+        active = []
+        for i in range(6):
+            u = de - 2 + i
+            assert u >> 1 == hb + (i >> 1) and (u + 1) >> 1 == hb + ((i + 1) >> 1)
+            if (i == 0 and par) or (i == 5 and not par):
+                continue
+            active.append(u)
+            x = 1000
+            assert (x - u - 1) - (x - de - 4) == 5 - i and (x + u - 1) - (x + de - 3) == i
+            assert (x + (u >> 1) - 1) - (x + hb - 1) == i >> 1 and (x - (u >> 1) - 1) - (x - hb - 4) == 3 - (i >> 1)
+            assert (x + ((u + 1) >> 1)) - (x + hb) == (i + 1) >> 1 and (x - ((u + 1) >> 1)) - (x - hb - 3) == 3 - ((i + 1) >> 1)
+        assert active == list(range(d - 2, d + 3))
+
+
+def test_within_limit_as_one_unsigned_compare():
+    """|a - b| <= lim as (a - b + lim) <= 2 lim in unsigned 32-bit arithmetic (the lattice search's pair tests): every pair of
+    8-bit values and limit of the table, and 12-bit samples with the 16-bit table's limits (its -1 entries are 65532 / 65520)."""
+    a = np.arange(256, dtype=np.int64)[:, None]
+    b = np.arange(256, dtype=np.int64)[None, :]
+    for lim in sorted(set(l & 0xff for l in LIMLUT)):
+        got = ((a - b + lim) & 0xffffffff) <= 2 * lim
+        assert np.array_equal(got, np.abs(a - b) <= lim), lim
+    rng = np.random.default_rng(3)
+    for shift in (2, 4):
+        peak = (256 << shift) - 1
+        a = rng.integers(0, peak + 2, 300_000)
+        b = rng.integers(0, peak + 2, 300_000)
+        for l in sorted(set(LIMLUT)):
+            lim = ((l & 0xffff) << shift) & 0xffff
+            got = ((a - b + lim) & 0xffffffff) <= 2 * lim
+            assert np.array_equal(got, np.abs(a - b) <= lim), (shift, lim)
+
+
+def test_a_direction_value_can_exceed_the_peak_at_16_bits():
+    """Directions are stored as neutral + (dir << (2 + shift)) in the sample type (eedi2.c:1289 and its siblings).  With
+    |dir| <= 32 the 8-bit value wraps (128 + 128 = 0); the 10 / 12-bit one does not: it is peak + 1 - so "is the peak" is
+    an equality in every 16-bit kernel (dir_map_pair16, lat16_near8), never `< peak`."""
+    assert (128 + (32 << 2)) & 0xff == 0
+    for depth in (10, 12):
+        shift, peak, neutral = depth - 8, (1 << depth) - 1, 1 << (depth - 1)
+        assert (neutral + (32 << (2 + shift))) & 0xffff == peak + 1
+
+
+def test_lapsharp_mix_as_one_float_multiply():
+    """lap_float_mix (sharpen.hip): (((double)sum * coef) - centre) * strength, truncated (lapsharp.c:174-175), equals
+    trunc((float)(sum - k centre) * c) for a float c next to coef * strength - for every (sum, centre) the 3x3 taps can
+    produce - at the strengths of the presets; for others (0.35, 0.7) no such float exists and the kernel keeps the doubles.
+    Same search as the host code runs at init, in numpy."""
+    def float_form(taps, coef, strength):
+        ki = round(1 / coef)
+        lo = sum(255 * t for t in taps if t < 0)
+        hi = sum(255 * t for t in taps if t > 0)
+        acc = np.arange(lo, hi + 1, dtype=np.int64)[:, None]
+        cen = np.arange(256, dtype=np.int64)[None, :]
+        ref = np.trunc(((acc.astype(np.float64) * coef) - cen.astype(np.float64)) * strength).astype(np.int64)
+        q = (acc - ki * cen).astype(np.float32)
+        s = np.float32(coef * strength)
+        for c in (s, np.nextafter(s, np.float32(np.inf)), np.nextafter(s, np.float32(-np.inf))):
+            if np.array_equal(np.trunc(q * c).astype(np.int64), ref):
+                return True
+        return False
+    lap = [0, -1, 0, -1, 5, -1, 0, -1, 0]
+    iso = [-1, -4, -1, -4, 25, -4, -1, -4, -1]
+    for st in (0.2, 0.3, 0.04, 0.15, 0.5, 1.0, 1.5):
+        assert float_form(lap, 1.0, st) and float_form(iso, 0.2, st), st
+    assert not float_form(iso, 0.2, 0.35) and not float_form(lap, 1.0, 0.7)
