@@ -137,3 +137,21 @@ def test_pad_fill_colours(built):
     # above 8 bits ff_draw_color scales the 8-bit-anchored values by (2^depth - 1) / 255, so 10-bit
     # black is (64, 514, 514) rather than (64, 512, 512)
     assert col(0x000000, depth=10) == (64, 514, 514) and col(0xFFFFFF, depth=10) == (943, 514, 514)
+
+
+def test_pad_colour_vs_pillow(built):
+    """Independent implementation (NOT parity: Pillow is not libavfilter's drawutils): the RGB -> YCbCr conversion behind a pad
+    colour, full-range BT.601, against Pillow's JPEG YCbCr for 2 000 random colours and the primaries - within 1 code
+    value.  It bounds how far the restatement of ff_draw_color's matrix can be from 'BT.601 full range'."""
+    import ctypes as C
+    Image = pytest.importorskip("PIL.Image")
+    L = ol.oracle()
+    L.orc_pad_color.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    rng = np.random.default_rng(5)
+    colours = [0xFF0000, 0x00FF00, 0x0000FF, 0x808080, 0x000000, 0xFFFFFF] + [int(x) for x in rng.integers(0, 1 << 24, 2000)]
+    for rgb in colours:
+        ref = Image.new("RGB", (1, 1), ((rgb >> 16) & 255, (rgb >> 8) & 255, rgb & 255)).convert("YCbCr").getpixel((0, 0))
+        for matrix in (5, 6):                                      # AVCOL_SPC_BT470BG, AVCOL_SPC_SMPTE170M: the same coefficients
+            out = (C.c_int * 3)()
+            L.orc_pad_color(rgb, matrix, 1, 8, out)
+            assert max(abs(a - b) for a, b in zip(tuple(out), ref)) <= 1, (hex(rgb), tuple(out), ref)
