@@ -15,7 +15,7 @@ HIPFLAGS:= --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fa
 HIP_SRC := $(wildcard $(PKG)/csrc/*.hip)
 HIP_OBJ := $(HIP_SRC:%.hip=%.o)
 HIP_HDR := $(wildcard $(PKG)/csrc/*.h) $(wildcard include/*.h)
-FLT_SRC := $(wildcard $(PKG)/libhb/*_hip.c) $(PKG)/libhb/hbhip_registry.c $(PKG)/libhb/hip_common.c
+FLT_SRC := $(wildcard $(PKG)/libhb/*_hip.c) $(PKG)/libhb/hbhip_registry.c $(PKG)/libhb/hip_common.c $(PKG)/libhb/vfr_standin.c
 
 all: product oracle
 product: $(PKG)/libhbrt.so $(PKG)/libhbhip.so $(PKG)/libhbhip_filters.so tools/vote_avg_check

@@ -23,9 +23,15 @@ def frame_bytes(w, h):
     return w * h * 3 // 2
 
 
-def chain_for(workload, scale):
+def chain_for(workload, scale, vfr=True):
+    """The filter list a front-end builds for this job, as hb_hip_setup_hw_filters leaves it: every preset-built job has
+    a frame-rate shaper between decomb and NLMeans (preset.c:2026-2048) - "same as source" here, after a bob that
+    doubles 29.97 - and it is a member of the device-resident run (libhb/hip_common.c).  Outside libhb the shaper is
+    libhb/vfr_standin.c (held to the reference's vfr.c by tests/test_vfr_cpu.py)."""
     from handbrake_amd import hip
     chain = [("hb_filter_hip_upload", ""), ("hb_filter_decomb_hip", "mode=31")]
+    if vfr:
+        chain.append(("hb_filter_vfr_standin", "mode=0:rate=60000/1001"))
     if workload != "decomb_eedi2":
         chain.append(("hb_filter_nlmeans_hip", hip.NLMEANS_MEDIUM))
         if scale:
@@ -35,7 +41,7 @@ def chain_for(workload, scale):
     return chain
 
 
-def run(workload, w, h, scale, cfg=3, n_warm=32, n_in=256, chain=None):
+def run(workload, w, h, scale, cfg=3, n_warm=32, n_in=2048, chain=None):
     """Timed from a warmed-up, quiet pipeline (n_warm frames in, their outputs out as far as the batching stages let
     them: allocations, pinned pool, slabs all made) to the end of the stream n_in frames later, EOF drain included.
     The frames the last stage makes are counted and dropped as they come, as an encoder that keeps up would."""
@@ -92,14 +98,17 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scale", default="3840x2160", help="WxH of the crop/scale stage, or 'none'")
     ap.add_argument("--cfg", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=256)
+    ap.add_argument("--frames", type=int, default=2048,
+                    help="input frames of the timed interval (2048 = 4096 output frames, a sample of about a second)")
+    ap.add_argument("--no-vfr", action="store_true", help="leave the frame-rate shaper out of the list (round 4's list)")
     ap.add_argument("--device", type=int, default=0)
     a = ap.parse_args()
     os.environ["HBHIP_DEVICE"] = str(a.device)          # the drop-ins' shared context (libhb/hbhip_registry.c)
     sys.path.insert(0, ROOT)
     scale = None if a.scale == "none" else tuple(int(v) for v in a.scale.split("x"))
     try:
-        res = run(a.workload, a.width, a.height, scale, cfg=a.cfg, n_in=a.frames)
+        res = run(a.workload, a.width, a.height, scale, cfg=a.cfg, n_in=a.frames,
+                  chain=chain_for(a.workload, scale, vfr=not a.no_vfr))
     except Exception as e:                               # the caller never loses its own line over this pass
         res = {"error": repr(e), "n_out": 0, "seconds": 0.0}
     print(json.dumps(res), flush=True)

@@ -357,6 +357,23 @@ int hb_dict_extract_string(char **dst, const hb_dict_t *dict, const char *key)
     return 1;
 }
 
+/* hb_dict.c:607-662, the string form ("30000/1001"): both parts entirely numbers, else 0 */
+int hb_dict_extract_rational(hb_rational_t *dst, const hb_dict_t *dict, const char *key)
+{
+    kv_t *e = dict_find(dict, key);
+    if (e == NULL || dst == NULL) return 0;
+    const char *slash = strchr(e->v, '/');
+    if (slash == NULL || slash == e->v || slash[1] == 0) return 0;
+    if (e->v[0] < '0' || e->v[0] > '9' || slash[1] < '0' || slash[1] > '9') return 0;
+    char *num_end = NULL, *den_end = NULL;
+    const long num = strtol(e->v, &num_end, 0);
+    const long den = strtol(slash + 1, &den_end, 0);
+    if (num_end != slash || den_end[0] != 0) return 0;
+    dst->num = (int)num;
+    dst->den = (int)den;
+    return 1;
+}
+
 /* ----------------------------------------------------------------- buffers */
 #define HBHIP_BUF_PADDING 64
 
@@ -721,6 +738,121 @@ void hb_buffer_list_close(hb_buffer_list_t *l)
 int hb_buffer_list_count(hb_buffer_list_t *l) { return l ? l->count : 0; }
 int hb_buffer_list_size(hb_buffer_list_t *l)  { return l ? l->size : 0; }
 
+
+/* ------------------------------------------------------------ fifos (fifo.c:1194-1557)
+ * What a filter's own queues need: a locked singly linked list that never blocks. */
+struct hb_fifo_s
+{
+    pthread_mutex_t lock;
+    hb_buffer_t    *first, *last;
+    int             size;
+};
+
+hb_fifo_t *hb_fifo_init(int capacity, int thresh)
+{
+    (void)capacity; (void)thresh;
+    hb_fifo_t *f = calloc(1, sizeof(*f));
+    if (f != NULL) pthread_mutex_init(&f->lock, NULL);
+    return f;
+}
+
+int hb_fifo_size(hb_fifo_t *f)
+{
+    pthread_mutex_lock(&f->lock);
+    const int n = f->size;
+    pthread_mutex_unlock(&f->lock);
+    return n;
+}
+
+hb_buffer_t *hb_fifo_get(hb_fifo_t *f)
+{
+    pthread_mutex_lock(&f->lock);
+    hb_buffer_t *b = f->size < 1 ? NULL : f->first;
+    if (b != NULL)
+    {
+        f->first = b->next;
+        b->next = NULL;
+        f->size--;
+    }
+    pthread_mutex_unlock(&f->lock);
+    return b;
+}
+
+hb_buffer_t *hb_fifo_see(hb_fifo_t *f)
+{
+    pthread_mutex_lock(&f->lock);
+    hb_buffer_t *b = f->size < 1 ? NULL : f->first;
+    pthread_mutex_unlock(&f->lock);
+    return b;
+}
+
+void hb_fifo_push(hb_fifo_t *f, hb_buffer_t *b)
+{
+    if (b == NULL) return;
+    pthread_mutex_lock(&f->lock);
+    if (f->size > 0) f->last->next = b; else f->first = b;
+    f->last = b;
+    f->size++;
+    while (f->last->next != NULL)                  /* a ->next list goes in whole (fifo.c:1455-1460) */
+    {
+        f->size++;
+        f->last = f->last->next;
+    }
+    pthread_mutex_unlock(&f->lock);
+}
+
+void hb_fifo_flush(hb_fifo_t *f)
+{
+    hb_buffer_t *b;
+    while ((b = hb_fifo_get(f)) != NULL)
+        hb_buffer_close(&b);
+}
+
+void hb_fifo_close(hb_fifo_t **pf)
+{
+    if (pf == NULL || *pf == NULL) return;
+    hb_fifo_flush(*pf);
+    pthread_mutex_destroy(&(*pf)->lock);
+    free(*pf);
+    *pf = NULL;
+}
+
+/* handbrake.h:136 / hb.c: one hb_interjob_t per hb_handle_t; the stand-in has one handle */
+hb_interjob_t *hb_interjob_get(hb_handle_t *h)
+{
+    static hb_interjob_t interjob;
+    (void)h;
+    return &interjob;
+}
+
+/* the helper objects a hw pipeline registers for its hw_pix_fmt (see include/hbhip_libhb.h) */
+#define HW_HELPER_MAX 8
+static struct { int kind, fmt; void *obj; } g_hw_helper[HW_HELPER_MAX];
+static int g_hw_helpers = 0;
+
+void hbhip_rt_register_hw_helper(int kind, int hw_pix_fmt, void *object)
+{
+    for (int i = 0; i < g_hw_helpers; i++)
+        if (g_hw_helper[i].kind == kind && g_hw_helper[i].fmt == hw_pix_fmt)
+        {
+            g_hw_helper[i].obj = object;
+            return;
+        }
+    if (g_hw_helpers < HW_HELPER_MAX)
+    {
+        g_hw_helper[g_hw_helpers].kind = kind;
+        g_hw_helper[g_hw_helpers].fmt = hw_pix_fmt;
+        g_hw_helper[g_hw_helpers++].obj = object;
+    }
+}
+
+void *hbhip_rt_hw_helper(int kind, int hw_pix_fmt)
+{
+    for (int i = 0; i < g_hw_helpers; i++)
+        if (g_hw_helper[i].kind == kind && g_hw_helper[i].fmt == hw_pix_fmt)
+            return g_hw_helper[i].obj;
+    return NULL;
+}
 
 /* ---------------------------------------------------------------- lists, filter registry, filter lists
  * (common.c:2489-2700, :5247-5540; hb.c:1676-1723) */

@@ -138,6 +138,9 @@ __attribute__((constructor)) static void hbhip_host_register_hooks(void)
 #ifndef HBHIP_IN_LIBHB
     hbhip_rt_set_storage_hooks(storage_retain, storage_release);
     hbhip_rt_set_job_hooks(hb_hip_setup_hw_filters, hb_hip_filter_init_failed);   /* inside libhb work.c calls them itself */
+    /* inside libhb: `case AV_PIX_FMT_HBHIP:` in vfr.c:76-108 and rendersub.c:1129-1161 */
+    hbhip_rt_register_hw_helper(0, AV_PIX_FMT_HBHIP, &hb_motion_metric_hip);
+    hbhip_rt_register_hw_helper(1, AV_PIX_FMT_HBHIP, &hb_blend_hip);
     const char *e = getenv("HBHIP_PINNED");
     if (e == NULL || atoi(e) != 0)
         hbhip_rt_set_alloc_hooks(pinned_alloc, pinned_release);

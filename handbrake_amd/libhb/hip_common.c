@@ -6,8 +6,9 @@
  * hb_hip_setup_hw_filters() is the same for HIP:
  *   1. every filter of job->list_filter that has a HIP drop-in (hbhip_filter_get, same id) is replaced by a copy of
  *      the drop-in carrying the same settings dict, at the same list position;
- *   2. every run of two or more adjacent drop-ins is bracketed by hb_filter_hip_upload / hb_filter_hip_download, so
- *      frames stay in HBM inside the run (a lone drop-in moves its own frames; adapters would only add two threads).
+ *   2. every run of two or more drop-ins - adjacent, or with only "hw-transparent" filters between them (vfr,
+ *      rendersub, rpu: hb_hip_filter_is_hw_transparent) - is bracketed by hb_filter_hip_upload / hb_filter_hip_download,
+ *      so frames stay in HBM inside the run (a lone drop-in moves its own frames; adapters would only add two threads).
  * And one thing the VideoToolbox path does not need: a drop-in's init() may refuse settings it has no kernels for.
  * work.c drops a filter whose init fails (:1861-1868) - for a drop-in that would silently lose the filter, so the init
  * loop calls hb_hip_filter_init_failed() first, which puts the CPU filter back (and re-brackets the run around it).
@@ -62,6 +63,46 @@ static void replace_at(hb_list_t *list, int pos, hb_filter_object_t *proto)
     hb_filter_close(&old);
 }
 
+/* Filters that never look at a picture's samples themselves, only at the hb_buffer_t around it: they sit INSIDE a
+ * device-resident run without breaking it.  The reference has the same notion for its Metal pipeline -
+ * are_filters_supported() (platform/macosx/vt_common.c:424-448) lists HB_FILTER_VFR, RENDER_SUB, FORMAT and RPU
+ * beside the filters it has kernels for - and the first two choose their pixel helper by init->hw_pix_fmt:
+ * vfr.c:76-108 the motion metric (hb_motion_metric_hip here), rendersub.c:1129-1161 the compositor (hb_blend_hip).
+ * FORMAT has a drop-in of its own (format_hip.c); RPU only edits Dolby Vision side data (rpu.c).
+ * Every preset-built job has a VFR between decomb (6) and NLMeans (16) (preset.c:2026-2048, ids common.h:1739-1751):
+ * without this the run - and the frames - would leave the device there. */
+int hb_hip_filter_is_hw_transparent(const hb_filter_object_t *f)
+{
+    if (f == NULL || hb_hip_filter_is_hip(f)) return 0;
+    return f->id == HB_FILTER_VFR || f->id == HB_FILTER_RENDER_SUB || f->id == HB_FILTER_RPU;
+}
+
+/* Bracket, from position `from` on, every run [drop-in (drop-in | transparent)* drop-in] that holds at least two
+ * drop-ins with hb_filter_hip_upload / hb_filter_hip_download (a lone drop-in moves its own frames; adapters would only
+ * add two threads).  Transparent filters at either end of a run stay outside: nothing is gained by uploading for them. */
+static void bracket_runs(hb_list_t *list, int from)
+{
+    for (int i = from; i < hb_list_count(list);)
+    {
+        if (!hb_hip_filter_is_hip(hb_list_item(list, i)) || is_adapter(hb_list_item(list, i))) { i++; continue; }
+        int last = i, n = 1;
+        for (int j = i + 1; j < hb_list_count(list); j++)
+        {
+            hb_filter_object_t *f = hb_list_item(list, j);
+            if (is_adapter(f)) break;
+            if (hb_hip_filter_is_hip(f)) { last = j; n++; }
+            else if (!hb_hip_filter_is_hw_transparent(f)) break;
+        }
+        if (n >= 2)
+        {
+            hb_list_insert(list, last + 1, new_adapter(HB_FILTER_HIP_DOWNLOAD));
+            hb_list_insert(list, i, new_adapter(HB_FILTER_HIP_UPLOAD));
+            last += 2;
+        }
+        i = last + 1;
+    }
+}
+
 void hb_hip_setup_hw_filters(hb_job_t *job)
 {
     if (job == NULL || job->list_filter == NULL || !hip_enabled()) return;
@@ -74,19 +115,7 @@ void hb_hip_setup_hw_filters(hb_job_t *job)
         hb_filter_object_t *proto = hbhip_filter_get(f->id);
         if (proto != NULL) replace_at(list, i, proto);
     }
-    for (int i = 0; i < hb_list_count(list);)
-    {
-        if (!hb_hip_filter_is_hip(hb_list_item(list, i))) { i++; continue; }
-        int j = i;
-        while (j < hb_list_count(list) && hb_hip_filter_is_hip(hb_list_item(list, j))) j++;
-        if (j - i >= 2)
-        {
-            hb_list_insert(list, j, new_adapter(HB_FILTER_HIP_DOWNLOAD));
-            hb_list_insert(list, i, new_adapter(HB_FILTER_HIP_UPLOAD));
-            j += 2;
-        }
-        i = j;
-    }
+    bracket_runs(list, 0);
 }
 
 int hb_hip_filter_init_failed(hb_job_t *job, int index, hb_filter_init_t *init)
@@ -108,13 +137,21 @@ int hb_hip_filter_init_failed(hb_job_t *job, int index, hb_filter_init_t *init)
     hb_list_rem(list, f);
     hb_filter_close(&f);
 
-    int pos = index;
+    /* everything from `index` on has not been initialised yet: take its adapters out, put the CPU filter in, and
+     * bracket what is left of the runs afresh.  What lies before `index` has seen its init and stays as it is. */
+    for (int i = index; i < hb_list_count(list);)
+    {
+        hb_filter_object_t *a = hb_list_item(list, i);
+        if (!is_adapter(a)) { i++; continue; }
+        hb_list_rem(list, a);
+        hb_filter_close(&a);
+    }
+    int pos = index, ret = 1;
     if (hbhip_host_dev_io(init))
     {
         /* inside a device-resident run: the CPU filter needs host frames */
         hb_filter_object_t *prev = pos > 0 ? hb_list_item(list, pos - 1) : NULL;
-        const int undo_upload = prev != NULL && prev->id == HB_FILTER_HIP_UPLOAD;
-        if (undo_upload)
+        if (prev != NULL && prev->id == HB_FILTER_HIP_UPLOAD)
         {
             /* the run's own upload sits right in front: undo it instead of downloading straight again */
             if (prev->close != NULL) prev->close(prev);
@@ -122,30 +159,12 @@ int hb_hip_filter_init_failed(hb_job_t *job, int index, hb_filter_init_t *init)
             hb_filter_close(&prev);
             init->hw_pix_fmt = AV_PIX_FMT_NONE;
             pos--;
+            ret = 2;                                          /* the CPU filter now sits one slot earlier */
         }
         else
             hb_list_insert(list, pos++, new_adapter(HB_FILTER_HIP_DOWNLOAD));
-        hb_list_insert(list, pos++, cpu);
-        hb_filter_object_t *next = hb_list_item(list, pos);
-        if (next != NULL && next->id == HB_FILTER_HIP_DOWNLOAD)
-        {
-            hb_list_rem(list, next);                          /* the run ended here anyway */
-            hb_filter_close(&next);
-        }
-        else if (next != NULL && hb_hip_filter_is_hip(next))
-        {
-            /* what is left of the run: keep it on the device only if it is still a run */
-            hb_filter_object_t *after = hb_list_item(list, pos + 1);
-            if (after != NULL && after->id == HB_FILTER_HIP_DOWNLOAD)
-            {
-                hb_list_rem(list, after);                     /* a single drop-in moves its own frames */
-                hb_filter_close(&after);
-            }
-            else
-                hb_list_insert(list, pos, new_adapter(HB_FILTER_HIP_UPLOAD));
-        }
-        return undo_upload ? 2 : 1;                            /* 2: the CPU filter now sits one slot earlier */
     }
     hb_list_insert(list, pos, cpu);
-    return 1;
+    bracket_runs(list, pos + 1);
+    return ret;
 }

@@ -12,5 +12,8 @@ void hb_hip_setup_hw_filters(hb_job_t *job);
 int  hb_hip_filter_init_failed(hb_job_t *job, int index, hb_filter_init_t *init);
 /* hb_avfilter_combine (hbavfilter.c:520-541): an aliased id whose object is a drop-in is a real filter */
 int  hb_hip_filter_is_hip(const hb_filter_object_t *filter);
+/* a filter that only handles the hb_buffer_t around a picture (vfr, rendersub, rpu): a member of a device-resident
+ * run like the ones are_filters_supported() lists (platform/macosx/vt_common.c:424-448) */
+int  hb_hip_filter_is_hw_transparent(const hb_filter_object_t *filter);
 
 #endif

@@ -182,6 +182,7 @@ int hb_dict_extract_int(int *dst, const hb_dict_t *dict, const char *key);
 int hb_dict_extract_double(double *dst, const hb_dict_t *dict, const char *key);
 int hb_dict_extract_bool(int *dst, const hb_dict_t *dict, const char *key);
 int hb_dict_extract_string(char **dst, const hb_dict_t *dict, const char *key);
+int hb_dict_extract_rational(hb_rational_t *dst, const hb_dict_t *dict, const char *key);   /* "num/den", hb_dict.c:607-662 */
 
 /* ---- buffers (internal.h:65-165) ------------------------------------------ */
 #define PIC_FLAG_TOP_FIELD_FIRST    0x0008
@@ -283,6 +284,16 @@ void         hbhip_rt_set_storage_hooks(void (*retain)(void *), void (*release)(
 /* stand-in runtime only: allocator for frame-sized buffer payloads (page-locked pool) */
 void         hbhip_rt_set_alloc_hooks(void *(*alloc)(size_t), void (*release)(void *, size_t));
 void         hbhip_rt_next_buffer_uninitialised(void);   /* the next hb_buffer_init on this thread leaves its payload as it is */
+
+/* fifo.c:1194-1557 - the part a filter uses for its own queues (vfr.c's delay queue, rendersub.c's subtitle fifo):
+ * unbounded, never blocking; hb_fifo_push takes a ->next list, hb_fifo_get returns NULL when empty */
+hb_fifo_t   *hb_fifo_init(int capacity, int thresh);
+void         hb_fifo_close(hb_fifo_t **);
+int          hb_fifo_size(hb_fifo_t *);
+hb_buffer_t *hb_fifo_get(hb_fifo_t *);
+hb_buffer_t *hb_fifo_see(hb_fifo_t *);
+void         hb_fifo_push(hb_fifo_t *, hb_buffer_t *);
+void         hb_fifo_flush(hb_fifo_t *);
 
 void         hb_buffer_list_append(hb_buffer_list_t *list, hb_buffer_t *buf);
 void         hb_buffer_list_prepend(hb_buffer_list_t *list, hb_buffer_t *buf);
@@ -463,11 +474,27 @@ void       hb_list_insert(hb_list_t *, int pos, void *);
 void       hb_list_rem(hb_list_t *, void *);
 void       hb_list_close(hb_list_t **);
 hb_dict_t *hb_value_dup(const hb_dict_t *);                         /* hb_dict.h: deep copy of a settings dict */
-struct hb_job_s                                                     /* the fields of hb_job_t the swap reads */
+typedef struct hb_handle_s hb_handle_t;
+/* handbrake.h:121-136: what vfr.c leaves behind for a second pass */
+typedef struct hb_interjob_s
+{
+    int     sequence_id;
+    int     frame_count;
+    int     out_frame_count;
+    int64_t total_time;
+    hb_rational_t vrate;
+    hb_subtitle_t *select_subtitle;
+    void *context;
+    int   context_size;
+} hb_interjob_t;
+hb_interjob_t *hb_interjob_get(hb_handle_t *);
+struct hb_job_s                                                     /* the fields of hb_job_t the swap and the filters read */
 {
     hb_list_t   *list_filter;
     int          hw_pix_fmt;                                        /* AV_PIX_FMT_NONE unless a hw decoder set it */
     int          input_pix_fmt;
+    int          hw_device_index;                                   /* common.h:991: which adapter the job runs on; -1 = default */
+    hb_handle_t *h;
     volatile int done;
 };
 hb_filter_object_t *hb_filter_get(int filter_id);                   /* the registered CPU prototype, or NULL */
@@ -490,6 +517,12 @@ struct hb_motion_metric_object_s
     void  (*close)(hb_motion_metric_object_t *);
     hb_motion_metric_private_t *private_data;
 };
+
+extern hb_motion_metric_object_t hb_motion_metric;                 /* motion_metric.c:306-312 (tests: from oracle/_ref) */
+/* stand-in only: the helper object a hw pipeline supplies for hw_pix_fmt (inside libhb: one more `case` in
+ * vfr.c:76-108 / rendersub.c:1129-1161).  kind 0 = motion metric, 1 = blend.  NULL when none. */
+void        hbhip_rt_register_hw_helper(int kind, int hw_pix_fmt, void *object);
+void       *hbhip_rt_hw_helper(int kind, int hw_pix_fmt);
 
 /* ---- the subtitle compositor plugin type (handbrake/common.h:1813-1828) ---------------- */
 struct hb_blend_object_s

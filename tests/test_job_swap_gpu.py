@@ -62,3 +62,78 @@ def test_comb_detect_then_selective_decomb_device_resident(registered):
     frames = synth.stream("interlaced", 320, 180, 6)
     names = run_both([(F["comb_detect"], ""), (F["decomb"], "mode=39"), (F["denoise"], "y-spatial=3")], frames, flags=TFF)
     assert names[0] == UP and names[-1] == DOWN and len(names) == 5
+
+
+# ---- hw-transparent members of a run: VFR (every preset-built job has one between decomb and NLMeans) ------------
+VFR = 11
+SHAPER = "Framerate Shaper"
+
+
+@pytest.fixture()
+def with_vfr(registered):
+    """the reference's own vfr.c as HB_FILTER_VFR (oracle/ref_wrap/wrap_vfr.c: unmodified; its metric switch resolves
+    to hb_motion_metric_hip for AV_PIX_FMT_HBHIP frames the way INTEGRATION.md §2 patches vfr.c:76-108)"""
+    import oracle_lib as ol
+    hbrt.register_filters(ol.ref(), {VFR: "hb_filter_vfr"})
+    yield
+    hbrt.register_filters(ol.ref(), {VFR: None})
+
+
+def reference_job_with_scale(frames, vfr, scale_to, flags=TFF):
+    """the all-reference job: decomb -> vfr -> nlmeans (the reference's C, oracle/_ref) -> crop/scale (the restatement:
+    FFmpeg / zimg are not in the image) -> lapsharp (the reference's C)"""
+    import oracle_lib as ol
+    _, mid = hbrt.run_job([(F["decomb"], "mode=31"), (VFR, vfr), (F["nlmeans"], NLM)], frames, flags=flags, use_hip=False)
+    scaled = [ol.orc_cropscale_frame(m.planes, width=scale_to[0], height=scale_to[1]) for m in mid]
+    want = hbrt.run_stream(ol.ref(), [("hb_filter_lapsharp", LAP)], scaled)
+    return [(w.planes, m.start, m.stop) for w, m in zip(want, mid)]
+
+
+@pytest.mark.parametrize("vfr", ["mode=0:rate=30000/1001", "mode=1:rate=30000/1001", "mode=1:rate=90000/1001", "mode=2:rate=25/1"],
+                         ids=["same_as_source", "constant_half", "constant_dup", "peak25"])
+def test_vfr_stays_inside_the_device_run(with_vfr, vfr):
+    """[decomb 31, vfr, nlmeans, crop_scale, lapsharp]: ONE upload / download pair around the whole list - the frames
+    vfr queues, drops (device motion metric) and duplicates (shared device picture) never leave HBM - and pictures and
+    timestamps equal the all-reference job's."""
+    frames = synth.stream("interlaced", 320, 180, 9, cfg=3)
+    filters = [(F["decomb"], "mode=31"), (VFR, vfr), (F["nlmeans"], NLM), (F["crop_scale"], "width=640:height=360"),
+               (F["lapsharp"], LAP)]
+    names, out = hbrt.run_job(filters, frames, flags=TFF, use_hip=True)
+    assert names[0] == UP and names[-1] == DOWN and names[2] == SHAPER and len(names) == 7
+    assert names.count(UP) == 1 and names.count(DOWN) == 1 and all("HIP" in n for i, n in enumerate(names) if i != 2)
+    want = reference_job_with_scale(frames, vfr, (640, 360))
+    assert len(out) == len(want) > 0
+    for o, (planes, start, stop) in zip(out, want):
+        assert (o.start, o.stop) == (start, stop)
+        for c in range(3):
+            np.testing.assert_array_equal(o.planes[c], planes[c])
+
+
+def test_vfr_at_the_edge_of_a_run_stays_on_host_frames(with_vfr):
+    frames = synth.stream("progressive", 320, 180, 6)
+    names = run_both([(VFR, "mode=0:rate=30000/1001"), (F["nlmeans"], NLM), (F["lapsharp"], LAP)], frames)
+    assert names[0] == SHAPER and names[1] == UP and names[-1] == DOWN and len(names) == 5
+
+
+def test_declined_dropin_behind_vfr_closes_the_run_after_it(with_vfr):
+    frames = synth.stream("interlaced", 320, 180, 6)
+    names = run_both([(F["decomb"], "mode=7"), (F["comb_detect"], ""), (VFR, "mode=0:rate=30000/1001"), (F["nlmeans"], NLM_P11),
+                      (F["lapsharp"], LAP), (F["unsharp"], "y-strength=0.25:y-size=7")], frames, flags=TFF)
+    # [UP comb decomb vfr nlm lap unsharp DOWN] -> nlm declines: the frames come down in front of it, after vfr
+    assert names[0] == UP and names[3] == SHAPER and names[4] == DOWN and names[5] == "Denoise (nlmeans)"
+    assert names[6] == UP and names[-1] == DOWN and len(names) == 10
+
+
+def test_configs3_job_with_vfr_1080i_to_2160p(with_vfr):
+    """the bench chain's filter list as a front-end builds it, at BASELINE configs[3]'s size"""
+    frames = synth.stream("interlaced", 1920, 1080, 4, cfg=3)
+    filters = [(F["decomb"], "mode=31"), (VFR, "mode=0:rate=60000/1001"), (F["nlmeans"], NLM),
+               (F["crop_scale"], "width=3840:height=2160"), (F["lapsharp"], LAP)]
+    names, out = hbrt.run_job(filters, frames, flags=TFF, use_hip=True)
+    assert names.count(UP) == 1 and names.count(DOWN) == 1 and names[2] == SHAPER and len(names) == 7
+    want = reference_job_with_scale(frames, "mode=0:rate=60000/1001", (3840, 2160))
+    assert len(out) == len(want) == 8
+    for o, (planes, start, stop) in zip(out, want):
+        assert (o.start, o.stop) == (start, stop)
+        for c in range(3):
+            np.testing.assert_array_equal(o.planes[c], planes[c])
