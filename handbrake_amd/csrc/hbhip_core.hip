@@ -545,6 +545,11 @@ int hbhip_ctx_device_name(hbhip_ctx *ctx, char *buf, int len)
     return HBHIP_OK;
 }
 
+int hbhip_ctx_device_index(hbhip_ctx *ctx)
+{
+    return ctx ? ctx->device : -1;
+}
+
 int hbhip_ctx_profile_enable(hbhip_ctx *ctx, int on)
 {
     if (!ctx) return HBHIP_ERR_ARG;
@@ -633,6 +638,11 @@ int hbhip_dev_download(hbhip_ctx *ctx, void *dst, const void *src, size_t bytes)
 }
 
 // ---- device-resident frames -----------------------------------------------------
+hbhip_ctx *hbhip_frame_context(hbhip_frame *fr)
+{
+    return fr ? fr->ctx : nullptr;
+}
+
 int hbhip_frame_alloc(hbhip_ctx *ctx, int width, int height, int depth, int lcw, int lch, hbhip_frame **out)
 {
     if (!ctx || !out || width < 1 || height < 1) return HBHIP_ERR_ARG;
@@ -1008,6 +1018,11 @@ void hbhip_filter_destroy(hbhip_filter *f)
     while (!f->async_q.empty()) (void)hbhip_filter_wait(f, nullptr);
     (void)hipStreamSynchronize(f->ctx->stream);
     delete f;
+}
+
+hbhip_ctx *hbhip_filter_context(hbhip_filter *f)
+{
+    return f ? f->ctx : nullptr;
 }
 
 int hbhip_filter_out_geometry(hbhip_filter *f, int *width, int *height)

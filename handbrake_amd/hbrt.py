@@ -195,7 +195,7 @@ class Chain:
 
 
 # hb_filter_object_t ids (handbrake/common.h:1729-1778; include/hbhip_libhb.h)
-FILTER_ID = {"comb_detect": 4, "decomb": 6, "yadif": 7, "bwdif": 9, "denoise": 14, "nlmeans": 16, "chroma_smooth": 17,
+FILTER_ID = {"comb_detect": 4, "decomb": 6, "yadif": 7, "bwdif": 9, "vfr": 11, "denoise": 14, "nlmeans": 16, "chroma_smooth": 17,
              "rotate": 19, "crop_scale": 22, "lapsharp": 24, "unsharp": 26, "grayscale": 28, "pad": 30,
              "colorspace": 32, "format": 33}
 
@@ -245,6 +245,14 @@ def run_job(filters, frames, flags: int = 0x10, pix_fmt: int = AV_PIX_FMT_YUV420
         ch.push_eof()
         out += ch.drain()
     return names, out
+
+
+def set_job_device(index: int = -1):
+    """job->hw_device_index (common.h:991) of jobs opened from now on: the GPU their drop-ins run on; -1 = not set."""
+    rt = runtime()
+    rt.hbh_set_job_device.argtypes = [C.c_int]
+    rt.hbh_set_job_device.restype = None
+    rt.hbh_set_job_device(index)
 
 
 def set_threaded(on: bool):

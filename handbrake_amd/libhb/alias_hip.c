@@ -147,7 +147,7 @@ static int crop_scale_hip_init(hb_filter_object_t *filter, hb_filter_init_t *ini
         return alias_fail(filter, HBHIP_ERR_UNSUPPORTED);
     }
 
-    hbhip_ctx *ctx = hbhip_host_ctx();
+    hbhip_ctx *ctx = hbhip_host_ctx_for(init);
     if (ctx == NULL) return alias_fail(filter, HBHIP_ERR_NODEVICE);
     int rc = hbhip_cropscale_create(ctx, &p, init->geometry.width, init->geometry.height, desc->comp[0].depth,
                                     desc->log2_chroma_w, desc->log2_chroma_h, &pv->dev);
@@ -195,7 +195,7 @@ static int grayscale_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init
     hb_dict_extract_double(&cr, filter->settings, "cr");
     hb_dict_extract_double(&size, filter->settings, "size");
     hb_dict_extract_double(&high, filter->settings, "high");
-    hbhip_ctx *ctx = hbhip_host_ctx();
+    hbhip_ctx *ctx = hbhip_host_ctx_for(init);
     if (ctx == NULL) return alias_fail(filter, HBHIP_ERR_NODEVICE);
     int rc = hbhip_grayscale_create(ctx, cb, cr, size, high, init->geometry.width, init->geometry.height,
                                     desc->comp[0].depth, desc->log2_chroma_w, desc->log2_chroma_h, &pv->dev);
@@ -231,7 +231,7 @@ static int rotate_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init)
     int angle = 0, flip = 0;
     hb_dict_extract_int(&angle, filter->settings, "angle");                  /* rotate.c:166-167 */
     hb_dict_extract_bool(&flip, filter->settings, "hflip");
-    hbhip_ctx *ctx = hbhip_host_ctx();
+    hbhip_ctx *ctx = hbhip_host_ctx_for(init);
     if (ctx == NULL) return alias_fail(filter, HBHIP_ERR_NODEVICE);
     int rc = hbhip_rotate_create(ctx, angle, flip, init->geometry.width, init->geometry.height,
                                  desc->comp[0].depth, desc->log2_chroma_w, desc->log2_chroma_h, &pv->dev);
@@ -292,7 +292,7 @@ static int format_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init)
     if (dd == NULL || dd->nb_components != desc->nb_components || desc->nb_components < 3 ||
         dd->log2_chroma_w != desc->log2_chroma_w || dd->log2_chroma_h != desc->log2_chroma_h)
         return alias_fail(filter, HBHIP_ERR_UNSUPPORTED);
-    hbhip_ctx *ctx = hbhip_host_ctx();
+    hbhip_ctx *ctx = hbhip_host_ctx_for(init);
     if (ctx == NULL) return alias_fail(filter, HBHIP_ERR_NODEVICE);
     int rc = hbhip_format_create(ctx, init->geometry.width, init->geometry.height, desc->comp[0].depth,
                                  dd->comp[0].depth, desc->log2_chroma_w, desc->log2_chroma_h,

@@ -14,9 +14,23 @@
 
 struct hb_blend_private_s
 {
-    hbhip_blend *dev;
+    hbhip_blend *dev;                /* made on the first frame: on the GPU that frame lives on */
     int          have_overlays;      /* the device holds the current list */
+    int          width, height, depth, lcw, lch, chroma_location, ov_lcw, ov_lch;
 };
+
+/* hb_blend_object_t.init gets no hb_filter_init_t (common.h:1813-1828), so it cannot ask which GPU the job runs on
+ * (job->hw_device_index); the first frame can: a device-resident frame is composited on the context it belongs to,
+ * host frames on the process default. */
+static int blend_hip_device(hb_blend_private_t *pv, const hb_buffer_t *in)
+{
+    if (pv->dev != NULL) return HBHIP_OK;
+    hbhip_frame *fr = hbhip_host_frame_of(in);
+    hbhip_ctx *ctx = fr != NULL ? hbhip_frame_context(fr) : hbhip_host_ctx();
+    if (ctx == NULL) return HBHIP_ERR_NODEVICE;
+    return hbhip_blend_create(ctx, pv->width, pv->height, pv->depth, pv->lcw, pv->lch, pv->chroma_location,
+                              pv->ov_lcw, pv->ov_lch, &pv->dev);
+}
 
 static int blend_hip_init(hb_blend_object_t *object, int in_width, int in_height, int in_pix_fmt,
                           int in_chroma_location, int in_color_range, int overlay_pix_fmt)
@@ -31,14 +45,24 @@ static int blend_hip_init(hb_blend_object_t *object, int in_width, int in_height
     }
     const AVPixFmtDescriptor *in_desc = av_pix_fmt_desc_get(in_pix_fmt);
     const AVPixFmtDescriptor *ov_desc = av_pix_fmt_desc_get(overlay_pix_fmt);
-    hbhip_ctx *ctx = in_desc != NULL && ov_desc != NULL ? hbhip_host_ctx() : NULL;
-    int rc = ctx == NULL ? HBHIP_ERR_NODEVICE : HBHIP_OK;
+    int rc = in_desc == NULL || ov_desc == NULL || hbhip_device_count() <= 0 ? HBHIP_ERR_NODEVICE : HBHIP_OK;
     if (rc == HBHIP_OK && av_pix_fmt_count_planes(in_pix_fmt) != 3)
         rc = HBHIP_ERR_UNSUPPORTED;                     /* NV12 / P010: blend8onbi*, not built */
     if (rc == HBHIP_OK)
-        rc = hbhip_blend_create(ctx, in_width, in_height, in_desc->comp[0].depth, in_desc->log2_chroma_w,
-                                in_desc->log2_chroma_h, in_chroma_location, ov_desc->log2_chroma_w,
-                                ov_desc->log2_chroma_h, &pv->dev);
+    {
+        /* what hbhip_blend_create would refuse on the first frame is refused here, where rendersub can still react */
+        const int d = in_desc->comp[0].depth;
+        const int sub = in_desc->log2_chroma_w != ov_desc->log2_chroma_w || in_desc->log2_chroma_h != ov_desc->log2_chroma_h;
+        if ((d != 8 && d != 10 && d != 12) || in_desc->log2_chroma_w > 1 || in_desc->log2_chroma_h > 1 ||
+            (sub && (ov_desc->log2_chroma_w || ov_desc->log2_chroma_h)))
+            rc = HBHIP_ERR_UNSUPPORTED;
+    }
+    if (rc == HBHIP_OK)
+    {
+        pv->width = in_width; pv->height = in_height; pv->depth = in_desc->comp[0].depth;
+        pv->lcw = in_desc->log2_chroma_w; pv->lch = in_desc->log2_chroma_h; pv->chroma_location = in_chroma_location;
+        pv->ov_lcw = ov_desc->log2_chroma_w; pv->ov_lch = ov_desc->log2_chroma_h;
+    }
     if (rc != HBHIP_OK)
     {
         hb_error("blend(hip): %s", hbhip_strerror(rc));
@@ -57,8 +81,8 @@ static hb_buffer_t *blend_hip_work(hb_blend_object_t *object, hb_buffer_t *in, h
     if (n == 0)
         return out;                                                                /* blend.c:856-859 */
 
-    int rc = HBHIP_OK;
-    if (changed || !pv->have_overlays)
+    int rc = blend_hip_device(pv, in);
+    if (rc == HBHIP_OK && (changed || !pv->have_overlays))
     {
         hbhip_overlay *ov = calloc((size_t)n, sizeof(*ov));
         if (ov == NULL) return NULL;

@@ -147,7 +147,7 @@ static int colorspace_hip_init(hb_filter_object_t *filter, hb_filter_init_t *ini
             p.npl = npl;
             p.peak = signal_peak(init);
             const AVPixFmtDescriptor *desc = av_pix_fmt_desc_get(init->pix_fmt);
-            hbhip_ctx *ctx = desc != NULL && p.tonemap >= 0 ? hbhip_host_ctx() : NULL;
+            hbhip_ctx *ctx = desc != NULL && p.tonemap >= 0 ? hbhip_host_ctx_for(init) : NULL;
             int err = ctx == NULL ? HBHIP_ERR_NODEVICE
                                   : hbhip_colorspace_create(ctx, &p, init->geometry.width, init->geometry.height,
                                                             desc->comp[0].depth, desc->log2_chroma_w,

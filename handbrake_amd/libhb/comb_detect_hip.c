@@ -103,7 +103,7 @@ static int comb_detect_hip_init(hb_filter_object_t *filter, hb_filter_init_t *in
     }
 
     pv->force_exhaustive = 1;              /* :1111 */
-    hbhip_ctx *ctx = hbhip_host_ctx();
+    hbhip_ctx *ctx = hbhip_host_ctx_for(init);
     if (ctx == NULL) { free(wide_lut); goto fail; }
     int rc = hbhip_comb_detect_create(ctx, p, init->geometry.width, init->geometry.height, depth, &pv->dev);
     if (rc == HBHIP_OK && wide_lut != NULL)
@@ -177,9 +177,8 @@ static hb_buffer_t *overlay_copy(hb_filter_private_t *pv, hb_buffer_t *src)
         const AVPixFmtDescriptor *desc = av_pix_fmt_desc_get(pv->input.pix_fmt);
         hbhip_frame *dst = NULL;
         if (desc == NULL) return NULL;
-        const int arc = hbhip_frame_alloc(hbhip_host_ctx(), src->f.width, src->f.height, desc->comp[0].depth,
+        const int arc = hbhip_frame_alloc(hbhip_frame_context(fr), src->f.width, src->f.height, desc->comp[0].depth,
                                           desc->log2_chroma_w, desc->log2_chroma_h, &dst);
-        hbhip_host_ctx_release();                       /* the frame holds its own reference to the context */
         if (arc != HBHIP_OK) return NULL;
         hbhip_dev_frame d;
         hbhip_frame_describe(dst, &d, NULL, NULL);

@@ -96,7 +96,7 @@ static int decomb_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init)
         }
     }
 
-    hbhip_ctx *ctx = hbhip_host_ctx();
+    hbhip_ctx *ctx = hbhip_host_ctx_for(init);
     if (ctx == NULL) goto fail;
     int rc = hbhip_decomb_create(ctx, p, init->geometry.width, init->geometry.height,
                                  desc->comp[0].depth, desc->log2_chroma_w, desc->log2_chroma_h, &pv->dev);
@@ -335,7 +335,7 @@ static int deint_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init, in
     }
     pv->selective = !!(mode & YADIF_SELECTIVE);
     const AVPixFmtDescriptor *desc = av_pix_fmt_desc_get(init->pix_fmt);
-    hbhip_ctx *ctx = desc != NULL ? hbhip_host_ctx() : NULL;
+    hbhip_ctx *ctx = desc != NULL ? hbhip_host_ctx_for(init) : NULL;
     int rc = ctx == NULL ? HBHIP_ERR_NODEVICE
            : is_yadif    ? hbhip_yadif_create(ctx, !!(mode & YADIF_SPATIAL), !!(mode & YADIF_BOB), pv->selective, parity,
                                               init->geometry.width, init->geometry.height, desc->comp[0].depth,

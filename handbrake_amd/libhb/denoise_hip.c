@@ -78,7 +78,7 @@ static int denoise_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init)
     precalc_coef(pv->par.coef[4], scr);
     precalc_coef(pv->par.coef[5], tcr);
 
-    hbhip_ctx *ctx = hbhip_host_ctx();
+    hbhip_ctx *ctx = hbhip_host_ctx_for(init);
     if (ctx == NULL) goto fail;
     int rc = hbhip_hqdn3d_create(ctx, &pv->par, init->geometry.width, init->geometry.height,
                                  desc->comp[0].depth, desc->log2_chroma_w, desc->log2_chroma_h, &pv->dev);

@@ -47,6 +47,7 @@ struct hbh_chain_s
     hb_buffer_list_t    out;         /* frames that left the last stage       */
     int                 eof_seen;
     int                 failed;
+    hb_job_t           *job;         /* hbh_job_open: what init->job points to */
 };
 
 static hb_filter_object_t *clone_filter(const hb_filter_object_t *proto, const char *settings)
@@ -68,6 +69,8 @@ static int g_discard = 0;            /* threaded mode: count and drop the last s
 /* Chains opened from now on run every stage on a thread of its own, as libhb does (work.c:2527-2600): distinct
  * filters then call into the shared device context concurrently.  Frames pushed are queued; hbh_chain_push_eof()
  * returns when every stage has finished, so output is complete once it returns. */
+static int g_job_device = -1;        /* job->hw_device_index of jobs opened from now on (common.h:991; -1 = not set) */
+void hbh_set_job_device(int index) { g_job_device = index; }
 void hbh_set_threaded(int on) { g_threaded = on; }
 void hbh_set_discard_output(int on) { g_discard = on; }
 
@@ -198,11 +201,14 @@ hbh_chain_t *hbh_job_open(int nfilters, const int *ids, const char *const *setti
 {
     hbh_chain_t *c = calloc(1, sizeof(*c));
     if (c == NULL) return NULL;
-    hb_job_t job;
-    memset(&job, 0, sizeof(job));
-    job.hw_pix_fmt = AV_PIX_FMT_NONE;
-    job.input_pix_fmt = pix_fmt;
-    job.list_filter = hb_list_init();
+    /* the filters keep init->job (vfr.c:413, :546), so the job lives as long as the chain */
+    hb_job_t *pjob = calloc(1, sizeof(*pjob));
+    if (pjob == NULL) { free(c); return NULL; }
+    c->job = pjob;
+    pjob->hw_pix_fmt = AV_PIX_FMT_NONE;
+    pjob->input_pix_fmt = pix_fmt;
+    pjob->hw_device_index = g_job_device;
+    pjob->list_filter = hb_list_init();
     for (int i = 0; i < nfilters; i++)
     {
         hb_filter_object_t *f = hb_filter_init(ids[i]);
@@ -212,36 +218,37 @@ hbh_chain_t *hbh_job_open(int nfilters, const int *ids, const char *const *setti
             continue;
         }
         hb_dict_t *d = hbhip_dict_from_string(settings && settings[i] ? settings[i] : "");
-        hb_add_filter_dict(job.list_filter, f, d);
+        hb_add_filter_dict(pjob->list_filter, f, d);
         hb_dict_free(&d);
     }
-    if (use_hip && g_hip_setup != NULL) g_hip_setup(&job);
+    if (use_hip && g_hip_setup != NULL) g_hip_setup(pjob);
 
     hb_filter_init_t init;
     source_init(&init, pix_fmt, width, height, vrate_num, vrate_den);
+    init.job = pjob;
     c->init_in = init;
-    for (int i = 0; i < hb_list_count(job.list_filter);)
+    for (int i = 0; i < hb_list_count(pjob->list_filter);)
     {
-        hb_filter_object_t *f = hb_list_item(job.list_filter, i);
+        hb_filter_object_t *f = hb_list_item(pjob->list_filter, i);
         f->private_data = NULL;
         if (f->init != NULL && f->init(f, &init))
         {
-            const int back = (use_hip && g_hip_init_failed != NULL) ? g_hip_init_failed(&job, i, &init) : 0;
+            const int back = (use_hip && g_hip_init_failed != NULL) ? g_hip_init_failed(pjob, i, &init) : 0;
             if (back > 0)
             {
                 i -= back - 1;
                 continue;
             }
             hb_log("Failure to initialise filter '%s', disabling", f->name);
-            hb_list_rem(job.list_filter, f);
+            hb_list_rem(pjob->list_filter, f);
             hb_filter_close(&f);
             continue;
         }
         i++;
     }
-    for (int i = 0; i < hb_list_count(job.list_filter) && c->nstages < HBH_MAX_STAGES; i++)
-        c->stage[c->nstages++] = hb_list_item(job.list_filter, i);
-    hb_list_close(&job.list_filter);
+    for (int i = 0; i < hb_list_count(pjob->list_filter) && c->nstages < HBH_MAX_STAGES; i++)
+        c->stage[c->nstages++] = hb_list_item(pjob->list_filter, i);
+    hb_list_close(&pjob->list_filter);
     c->init = init;
     start_threads(c);
     return c;
@@ -490,6 +497,7 @@ void hbh_chain_close(hbh_chain_t *c)
         free(f);
     }
     hb_buffer_list_close(&c->out);
+    free(c->job);
     free(c);
 }
 

@@ -36,6 +36,8 @@ hbh_chain_t *hbh_chain_open(int nstages, void *const *protos, const char *const 
  * (hb_hip_setup_hw_filters) when use_hip, init with drop / CPU-fallback on failure (work.c:1820-1870). */
 hbh_chain_t *hbh_job_open(int nfilters, const int *ids, const char *const *settings, int pix_fmt, int width, int height,
                           int vrate_num, int vrate_den, int use_hip);
+/* job->hw_device_index (common.h:991) of jobs opened from now on: which GPU the job's drop-ins run on; -1 = not set */
+void hbh_set_job_device(int index);
 /* "|"-separated names of the stages as initialised; returns their count */
 int hbh_chain_describe(hbh_chain_t *c, char *buf, int len);
 /* Chains opened from now on run every stage on its own thread with a fifo in front (filter_loop, work.c:2527-2600);

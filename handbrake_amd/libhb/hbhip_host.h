@@ -9,11 +9,15 @@
 #include "hbhip_libhb.h"
 #include "hbhip.h"
 
-/* One process-wide device context per GPU index, created on first use
- * (HBHIP_DEVICE env selects the index; default 0).  Filters of one job share
- * it, i.e. they share one stream, which is what lets adjacent HIP filters
- * hand frames over in HBM without extra synchronisation. */
-hbhip_ctx *hbhip_host_ctx(void);
+/* One process-wide device context per GPU index, created on first use.  Filters of one job share it, i.e. they share
+ * one stream, which is what lets adjacent HIP filters hand frames over in HBM without extra synchronisation.  The GPU
+ * is the job's: init->job->hw_device_index (common.h:991) when it is >= 0, else the process default (HBHIP_DEVICE in
+ * the environment, else 0) - libhb/hbhip_registry.c. */
+int        hbhip_host_default_device(void);
+int        hbhip_host_device_for(const hb_filter_init_t *init);
+hbhip_ctx *hbhip_host_ctx_on(int device);
+hbhip_ctx *hbhip_host_ctx_for(const hb_filter_init_t *init);     /* what a drop-in's init() uses */
+hbhip_ctx *hbhip_host_ctx(void);                                 /* the process default's context */
 void       hbhip_host_ctx_release(void);
 
 static inline void hbhip_host_frame_from_buf(hbhip_host_frame *f, const hb_buffer_t *b)

@@ -13,48 +13,60 @@
 
 #include <pthread.h>
 
+/* One context per GPU index, created on first use and kept for the life of the process (filters of later jobs reuse
+ * it; HIP tears it down at exit).  Filters of one job share it, i.e. they share one stream, which is what lets adjacent
+ * HIP filters hand frames over in HBM without extra synchronisation.
+ * WHICH GPU is the job's business: hb_job_t carries hw_device_index (common.h:991; the QSV / NVENC paths read it the same
+ * way, hwaccel.c:230-257, qsv_common.c:2238-2244), so a process that runs several jobs (one hb_handle_t each, as the
+ * queue of a GUI does) puts stream k on GPU k.  A job that does not say (index < 0) - or a caller without an init, such
+ * as rendersub's compositor object - gets the process default: HBHIP_DEVICE from the environment, else 0. */
+#define HBHIP_MAX_DEVICES 64
 static pthread_mutex_t g_ctx_lock = PTHREAD_MUTEX_INITIALIZER;
-static hbhip_ctx      *g_ctx = NULL;
-static int             g_ctx_refs = 0;
+static hbhip_ctx      *g_ctx[HBHIP_MAX_DEVICES];
+static int             g_ctx_failed[HBHIP_MAX_DEVICES];
 
-hbhip_ctx *hbhip_host_ctx(void)
+int hbhip_host_default_device(void)
 {
+    const char *env = getenv("HBHIP_DEVICE");
+    const int device = env != NULL ? atoi(env) : 0;
+    return device < 0 ? 0 : device;
+}
+
+int hbhip_host_device_for(const hb_filter_init_t *init)
+{
+    if (init != NULL && init->job != NULL && init->job->hw_device_index >= 0)
+        return init->job->hw_device_index;
+    return hbhip_host_default_device();
+}
+
+hbhip_ctx *hbhip_host_ctx_on(int device)
+{
+    if (device < 0 || device >= HBHIP_MAX_DEVICES) return NULL;
     pthread_mutex_lock(&g_ctx_lock);
-    if (g_ctx == NULL)
+    if (g_ctx[device] == NULL && !g_ctx_failed[device])
     {
-        int device = 0;
-        const char *env = getenv("HBHIP_DEVICE");
-        if (env != NULL) device = atoi(env);
-        int rc = hbhip_ctx_create(device, &g_ctx);
+        int rc = hbhip_ctx_create(device, &g_ctx[device]);
         if (rc != HBHIP_OK)
         {
             hb_error("hbhip: cannot create device context on GPU %d: %s", device, hbhip_strerror(rc));
-            g_ctx = NULL;
+            g_ctx[device] = NULL;
+            g_ctx_failed[device] = hbhip_device_count() > 0;      /* a GPU that is not there stays not there; no GPU at all may change (tests) */
         }
         else
         {
             char name[256];
-            hbhip_ctx_device_name(g_ctx, name, sizeof(name));
+            hbhip_ctx_device_name(g_ctx[device], name, sizeof(name));
             hb_log("hbhip: using GPU %d: %s", device, name);
         }
     }
-    if (g_ctx != NULL) g_ctx_refs++;
-    hbhip_ctx *c = g_ctx;
+    hbhip_ctx *c = g_ctx[device];
     pthread_mutex_unlock(&g_ctx_lock);
     return c;
 }
 
-void hbhip_host_ctx_release(void)
-{
-    pthread_mutex_lock(&g_ctx_lock);
-    if (g_ctx != NULL && --g_ctx_refs <= 0)
-    {
-        /* keep the context alive for the life of the process: filters of later
-         * jobs reuse it and HIP tears it down at exit */
-        g_ctx_refs = 0;
-    }
-    pthread_mutex_unlock(&g_ctx_lock);
-}
+hbhip_ctx *hbhip_host_ctx_for(const hb_filter_init_t *init) { return hbhip_host_ctx_on(hbhip_host_device_for(init)); }
+hbhip_ctx *hbhip_host_ctx(void)                             { return hbhip_host_ctx_on(hbhip_host_default_device()); }
+void       hbhip_host_ctx_release(void)                     { /* contexts live as long as the process */ }
 
 hb_filter_object_t *hbhip_filter_get(int filter_id)
 {
@@ -205,10 +217,9 @@ hb_buffer_t *hbhip_host_pull(hbhip_filter *dev, const hb_filter_init_t *o, int w
         const AVPixFmtDescriptor *desc = av_pix_fmt_desc_get(o->pix_fmt);
         hbhip_frame *fr = NULL;
         if (desc == NULL ||
-            hbhip_frame_alloc(hbhip_host_ctx(), width, height, desc->comp[0].depth,
+            hbhip_frame_alloc(hbhip_filter_context(dev), width, height, desc->comp[0].depth,
                               desc->log2_chroma_w, desc->log2_chroma_h, &fr) != HBHIP_OK)
             return NULL;
-        hbhip_host_ctx_release();
         hbhip_dev_frame d;
         hbhip_frame_describe(fr, &d, NULL, NULL);
         if (hbhip_filter_pull_dev(dev, &d, &t) != HBHIP_OK)
@@ -294,9 +305,8 @@ int hbhip_host_simple_work(hbhip_filter *dev, const hb_filter_init_t *output, co
         const AVPixFmtDescriptor *desc = av_pix_fmt_desc_get(output->pix_fmt);
         hbhip_frame *dst = NULL;
         rc = desc == NULL ? HBHIP_ERR_ARG
-                          : hbhip_frame_alloc(hbhip_host_ctx(), ow, oh, desc->comp[0].depth,
+                          : hbhip_frame_alloc(hbhip_filter_context(dev), ow, oh, desc->comp[0].depth,
                                               desc->log2_chroma_w, desc->log2_chroma_h, &dst);
-        if (desc != NULL) hbhip_host_ctx_release();
         if (rc == HBHIP_OK)
         {
             hbhip_dev_frame di, dd;
@@ -379,6 +389,7 @@ struct hb_filter_private_s
     hb_filter_init_t input;
     hb_filter_init_t output;
     int              depth, lcw, lch;
+    hbhip_ctx       *ctx;                 /* the job's GPU (hbhip_host_ctx_for) */
     dl_slot_t        dl[DL_DEPTH + 1];
     int              dl_head, dl_count;
 };
@@ -388,8 +399,9 @@ static int adapter_init(hb_filter_object_t *filter, hb_filter_init_t *init, int 
     hb_filter_private_t *pv = calloc(1, sizeof(*pv));
     if (pv == NULL) return 1;
     const AVPixFmtDescriptor *desc = av_pix_fmt_desc_get(init->pix_fmt);
+    pv->ctx = hbhip_host_ctx_for(init);
     if (desc == NULL || (desc->comp[0].depth != 8 && desc->comp[0].depth != 10 && desc->comp[0].depth != 12) ||
-        hbhip_host_ctx() == NULL)
+        pv->ctx == NULL)
     {
         free(pv);
         return 1;
@@ -446,9 +458,8 @@ static int upload_work(hb_filter_object_t *filter, hb_buffer_t **buf_in, hb_buff
     hbhip_frame *fr = NULL;
     hbhip_host_frame hf;
     hbhip_host_frame_from_buf(&hf, in);
-    if (hbhip_frame_alloc(hbhip_host_ctx(), in->f.width, in->f.height, pv->depth, pv->lcw, pv->lch, &fr) != HBHIP_OK)
+    if (hbhip_frame_alloc(pv->ctx, in->f.width, in->f.height, pv->depth, pv->lcw, pv->lch, &fr) != HBHIP_OK)
         return HB_FILTER_FAILED;
-    hbhip_host_ctx_release();
     if (hbhip_frame_upload(fr, &hf) != HBHIP_OK)
     {
         hbhip_frame_release(fr);

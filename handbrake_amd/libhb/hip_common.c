@@ -107,6 +107,12 @@ void hb_hip_setup_hw_filters(hb_job_t *job)
 {
     if (job == NULL || job->list_filter == NULL || !hip_enabled()) return;
     if (job->hw_pix_fmt != AV_PIX_FMT_NONE) return;           /* another hw pipeline owns the frames */
+    if (getenv("HBHIP_FORCE_SWAP") == NULL && job->hw_device_index >= hbhip_device_count())
+    {
+        /* the job names an adapter (common.h:991, hb_json.c "AdapterIndex") this process has no GPU for */
+        hb_log("hbhip: job asks for GPU %d, %d present: keeping the CPU filters", job->hw_device_index, hbhip_device_count());
+        return;
+    }
     hb_list_t *list = job->list_filter;
     for (int i = 0; i < hb_list_count(list); i++)
     {

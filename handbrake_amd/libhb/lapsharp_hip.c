@@ -86,7 +86,7 @@ static int lapsharp_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init)
         if (pv->par.kernel[c] < 0 || pv->par.kernel[c] >= 4) pv->par.kernel[c] = 2;
     }
 
-    hbhip_ctx *ctx = hbhip_host_ctx();
+    hbhip_ctx *ctx = hbhip_host_ctx_for(init);
     if (ctx == NULL) goto fail;
     int rc = hbhip_lapsharp_create(ctx, &pv->par, init->geometry.width, init->geometry.height,
                                    desc->comp[0].depth, desc->log2_chroma_w, desc->log2_chroma_h, &pv->dev);

@@ -30,7 +30,7 @@ static int motion_metric_hip_init(hb_motion_metric_object_t *metric, hb_filter_i
     const int depth = desc != NULL ? desc->comp[0].depth : 0;
     const int max_value = (1 << depth) - 1;
     unsigned *lut = desc != NULL ? malloc(sizeof(unsigned) * (size_t)(max_value + 1)) : NULL;
-    hbhip_ctx *ctx = lut != NULL ? hbhip_host_ctx() : NULL;
+    hbhip_ctx *ctx = lut != NULL ? hbhip_host_ctx_for(init) : NULL;
     int rc = ctx == NULL ? HBHIP_ERR_NODEVICE : HBHIP_OK;
     if (rc == HBHIP_OK)
     {

@@ -160,7 +160,7 @@ static int nlmeans_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init)
 
     nlmeans_hip_params(filter->settings, depth, &pv->par);
 
-    hbhip_ctx *ctx = hbhip_host_ctx();
+    hbhip_ctx *ctx = hbhip_host_ctx_for(init);
     if (ctx == NULL)
     {
         hb_error("nlmeans(hip): no HIP device context");

@@ -126,7 +126,7 @@ static int pad_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init)
     if (height < init->geometry.height) height = init->geometry.height;
 
     const AVPixFmtDescriptor *desc = av_pix_fmt_desc_get(init->pix_fmt);
-    hbhip_ctx *ctx = desc != NULL ? hbhip_host_ctx() : NULL;
+    hbhip_ctx *ctx = desc != NULL ? hbhip_host_ctx_for(init) : NULL;
     int rc = ctx == NULL ? HBHIP_ERR_NODEVICE : HBHIP_OK;
     if (rc == HBHIP_OK)
     {

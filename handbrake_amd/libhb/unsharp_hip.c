@@ -100,7 +100,7 @@ static int blur_hip_init_common(hb_filter_object_t *filter, hb_filter_init_t *in
     if (chroma_only)
         pv->par.amount[0] = 0;                             /* luma is copied, chroma_smooth.c:262-269 */
 
-    hbhip_ctx *ctx = hbhip_host_ctx();
+    hbhip_ctx *ctx = hbhip_host_ctx_for(init);
     if (ctx == NULL) goto fail;
     int rc = chroma_only
         ? hbhip_chroma_smooth_create(ctx, &pv->par, init->geometry.width, init->geometry.height,

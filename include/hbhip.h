@@ -73,6 +73,7 @@ void        hbhip_ctx_destroy(hbhip_ctx *ctx);
 int         hbhip_ctx_sync(hbhip_ctx *ctx);           /* hipStreamSynchronize */
 const char *hbhip_ctx_last_error(hbhip_ctx *ctx);     /* text of the last HIP failure */
 int         hbhip_ctx_device_name(hbhip_ctx *ctx, char *buf, int len);
+int         hbhip_ctx_device_index(hbhip_ctx *ctx);   /* the `device` it was created on; < 0 on a NULL context */
 
 /* Per-kernel timing with HIP events on the context's stream (off by default).
  * When enabled every kernel launch is bracketed by two events; stats are read
@@ -110,6 +111,7 @@ int  hbhip_frame_alloc(hbhip_ctx *ctx, int width, int height, int depth,
 void hbhip_frame_retain(hbhip_frame *fr);
 void hbhip_frame_release(hbhip_frame *fr);            /* back to the pool at refcount 0 */
 int  hbhip_frame_describe(hbhip_frame *fr, hbhip_dev_frame *out, int *width, int *height);
+hbhip_ctx *hbhip_frame_context(hbhip_frame *fr);      /* the context (device, stream) whose pool the frame belongs to */
 int  hbhip_frame_copy(hbhip_frame *dst, hbhip_frame *src);                  /* same geometry; stream-ordered D2D */
 int  hbhip_frame_upload(hbhip_frame *fr, const hbhip_host_frame *src);      /* H2D, returns when src is consumed */
 int  hbhip_frame_download(hbhip_frame *fr, const hbhip_host_frame *dst);    /* D2H, synchronous */
@@ -153,6 +155,7 @@ int  hbhip_filter_kick(hbhip_filter *f);
 void hbhip_filter_destroy(hbhip_filter *f);
 /* Output geometry (cropscale / rotate change it; init->geometry, cropscale.c:170-178). */
 int  hbhip_filter_out_geometry(hbhip_filter *f, int *width, int *height);
+hbhip_ctx *hbhip_filter_context(hbhip_filter *f);     /* the context the instance was created on */
 
 /* ---- a run of adjacent HIP filters fused into one object ------------------------------------
  * The reference merges runs of libavfilter-backed filters into one filter object whose work()

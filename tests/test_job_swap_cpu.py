@@ -75,3 +75,59 @@ def test_unregistered_id_is_dropped_like_work_c_does(registered):
     frames = synth.stream("progressive", 128, 72, 3)
     names, out = hbrt.run_job([(hbrt.FILTER_ID["lapsharp"], LAP), (hbrt.FILTER_ID["rotate"], "angle=90")], frames, use_hip=False)
     assert names == ["Sharpen (lapsharp)"] and len(out) == 3
+
+
+# ---- which GPU a job runs on: job->hw_device_index (common.h:991), libhb/hbhip_registry.c -----------------------
+def _device_for(job_index, monkeypatch, env=None):
+    """hbhip_host_device_for(init) for an init whose job carries hw_device_index = job_index (None: init->job NULL)"""
+    import ctypes as C
+    flt = hip.filters()
+    if env is None:
+        monkeypatch.delenv("HBHIP_DEVICE", raising=False)
+    else:
+        monkeypatch.setenv("HBHIP_DEVICE", str(env))
+    flt.hbhip_host_device_for.restype = C.c_int
+    flt.hbhip_host_device_for.argtypes = [C.c_void_p]
+    if job_index is None:
+        return flt.hbhip_host_device_for(None)
+    # hb_job_t (include/hbhip_libhb.h): list_filter*, hw_pix_fmt, input_pix_fmt, hw_device_index, h*, done
+    class Job(C.Structure):
+        _fields_ = [("list_filter", C.c_void_p), ("hw_pix_fmt", C.c_int), ("input_pix_fmt", C.c_int),
+                    ("hw_device_index", C.c_int), ("h", C.c_void_p), ("done", C.c_int)]
+    job = Job(None, -1, 0, job_index, None, 0)
+    init = (C.c_void_p * 32)()                     # hb_filter_init_t starts with hb_job_t *job
+    init[0] = C.addressof(job)
+    return flt.hbhip_host_device_for(init)
+
+
+def test_device_of_a_job_is_its_adapter_index_else_the_process_default(built, monkeypatch):
+    assert _device_for(None, monkeypatch) == 0                     # no init / no job, no environment: GPU 0
+    assert _device_for(None, monkeypatch, env=3) == 3              # HBHIP_DEVICE is the process default
+    assert _device_for(-1, monkeypatch, env=3) == 3                # hb_job_init leaves -1 (common.c:4981): default
+    assert _device_for(5, monkeypatch, env=3) == 5                 # the job's own adapter wins
+    assert _device_for(0, monkeypatch, env=3) == 0
+    assert _device_for(2, monkeypatch) == 2
+
+
+def test_contexts_are_kept_per_device_and_absent_gpus_give_none(built, monkeypatch):
+    import ctypes as C
+    flt = hip.filters()
+    flt.hbhip_host_ctx_on.restype = C.c_void_p
+    flt.hbhip_host_ctx_on.argtypes = [C.c_int]
+    n = hip.lib().hbhip_device_count()
+    assert flt.hbhip_host_ctx_on(-1) is None and flt.hbhip_host_ctx_on(64) is None
+    assert flt.hbhip_host_ctx_on(max(n, 0) + 3) is None            # a GPU that is not there
+    if n > 0:
+        a, b = flt.hbhip_host_ctx_on(0), flt.hbhip_host_ctx_on(0)
+        assert a is not None and a == b                            # one context per GPU, reused
+
+
+@pytest.mark.skipif(__import__("torch").cuda.is_available(), reason="box without a GPU")
+def test_job_naming_an_absent_adapter_keeps_its_cpu_filters(registered):
+    frames = synth.stream("progressive", 128, 72, 3)
+    hbrt.set_job_device(7)
+    try:
+        names, _ = hbrt.run_job([(hbrt.FILTER_ID["lapsharp"], LAP)], frames, use_hip=True)
+    finally:
+        hbrt.set_job_device(-1)
+    assert names == ["Sharpen (lapsharp)"]

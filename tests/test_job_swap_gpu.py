@@ -137,3 +137,31 @@ def test_configs3_job_with_vfr_1080i_to_2160p(with_vfr):
         assert (o.start, o.stop) == (start, stop)
         for c in range(3):
             np.testing.assert_array_equal(o.planes[c], planes[c])
+
+
+# ---- which GPU a job runs on: job->hw_device_index (common.h:991) -------------------------------------------------
+def test_jobs_pick_their_gpu_by_hw_device_index(registered):
+    """Two jobs in one process, as a queue runs them: one names adapter 0, the other leaves hb_job_init's -1 (the process
+    default).  On a one-GPU box both land on GPU 0 - one shared context, the same pictures -; a job that names an adapter
+    the box does not have keeps the reference's CPU filters (nothing dropped)."""
+    import ctypes as C
+    flt = hip.filters()
+    flt.hbhip_host_ctx_on.restype = C.c_void_p
+    flt.hbhip_host_ctx_on.argtypes = [C.c_int]
+    frames = synth.stream("progressive", 320, 180, 4)
+    filters = [(F["nlmeans"], NLM), (F["lapsharp"], LAP)]
+    outs = []
+    for index in (0, -1, hip.lib().hbhip_device_count() + 2):
+        hbrt.set_job_device(index)
+        try:
+            names, out = hbrt.run_job(filters, frames, use_hip=True)
+        finally:
+            hbrt.set_job_device(-1)
+        outs.append(out)
+        if index <= 0:
+            assert names[0] == UP and names[-1] == DOWN
+        else:
+            assert names == ["Denoise (nlmeans)", "Sharpen (lapsharp)"]
+    same(outs[0], outs[1])
+    same(outs[0], outs[2])
+    assert flt.hbhip_host_ctx_on(0) == flt.hbhip_host_ctx_on(0) is not None
