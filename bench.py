@@ -41,6 +41,7 @@ from __future__ import annotations
 import argparse
 import ctypes as C
 import json
+import math
 import os
 import sys
 import time
@@ -85,6 +86,7 @@ def algorithmic_bytes(kernel, w, h, out_w, out_h, frames_per_launch=1):
         "lapsharp_3x3": 2 * out, "lapsharp_5x5": 2 * out,
         "copy_planes": full,                                          # the chain's copy-in: one input frame read + written per TWO output frames
         "eedi2_mask_passes": 3.5 * half,                              # field rows + the old mask's lower half -> srcp + new mask (all fields of a batch per launch)
+        "eedi2_mask_repair": 4,                                       # one workgroup that reads the chain's error word and returns (MaskChain)
         "eedi2_calc_directions": 3 * half,                            # mskp + srcp -> tmpp
         "eedi2_filter_dir_map": 3 * half, "eedi2_expand_dir_map": 3 * half, "eedi2_filter_map": 3 * half,
         "eedi2_mark_directions_2x": 3 * half + 4 * full,              # 3 line doublings + tmp2p
@@ -231,13 +233,14 @@ def measured_hbm_peak(device_index):
     return round(2 * n / (best * 1e-3) / 1e9, 1)
 
 
-def pcie_inclusive(workload, w, h, scale, cfg, device):
+def pcie_inclusive(workload, w, h, scale, cfg, device, content="interlaced"):
     """The chain through the hb_filter_object_t surface, host hb_buffer_t in and out (H2D + D2H on the path), in a
     process of its own (handbrake_amd/hostpath.py says why): one thread per filter with libhb's bounded fifos between
     them (filter_loop, work.c:2527-2600)."""
     import subprocess
     cmd = [sys.executable, "-m", "handbrake_amd.hostpath", "--workload", workload, "--width", str(w), "--height", str(h),
-           "--scale", "none" if not scale else "%dx%d" % tuple(scale), "--cfg", str(cfg), "--device", str(device)]
+           "--scale", "none" if not scale else "%dx%d" % tuple(scale), "--cfg", str(cfg), "--device", str(device),
+           "--content", content]
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     if not lines:
@@ -417,6 +420,70 @@ def valu_roofline(valu_insts, avg_s, kname=None):
             "cycles_per_wave_inst": cyc, "peak_source": src}
 
 
+def build_chain(hip, device, W, H, scale, depth=8, split=2, only_decomb=False, comb_detect=False):
+    """The chain object of one stream of frames exactly as the bench drives it (tests/test_configs_gpu.py::test_bench_shape
+    builds its chain through this function too): decomb (EEDI2 bob) -> NLMeans medium -> Lanczos scale -> lapsharp behind
+    one hbhip_chain.  split: 0 every stage on one context (HIP stream); 1 a context per stage - one stream per filter, as
+    libhb runs one thread per filter; 2 decomb on one context, the stages behind it on a second (the default: DESIGN 4.10);
+    3 decomb + NLMeans (arithmetic-bound) on one, scaler + lapsharp (memory-bound) on a second; 4 decomb / NLMeans /
+    scaler + lapsharp.  Returns (contexts, chain); the chain owns its stages, the caller closes chain then contexts."""
+    OW, OH = scale if scale else (W, H)
+    ctxs = [hip.Ctx(device)]
+
+    def stage_ctx(stage=0):
+        if (not split or (split == 2 and len(ctxs) >= 3) or (split == 3 and stage != 2 and len(ctxs) >= 2) or
+                (split == 4 and stage == 3)):
+            return ctxs[-1]
+        ctxs.append(hip.Ctx(device))
+        return ctxs[-1]
+
+    c = stage_ctx()
+    decomb = hip.DecombDevice(c, W, H, mode=63 if comb_detect else 31, depth=depth)
+    stages = [hip.DeviceFilter(c, decomb.h)]
+    decomb.h = None                                       # owned by the chain from here on
+    if not only_decomb:
+        stages.append(hip.nlmeans_device_filter(stage_ctx(1), hip.NLMEANS_MEDIUM, W, H, batch=1, depth=depth))
+        if scale:
+            stages.append(hip.cropscale_device_filter(stage_ctx(2), W, H, OW, OH, depth=depth))
+        stages.append(hip.lapsharp_device_filter(stage_ctx(3), OW, OH, depth=depth))
+    return ctxs, hip.Chain(ctxs[0], stages)
+
+
+CONTENTS = {
+    # the survey's interlaced model (SURVEY 8d): bars moving 6 px / field + a diagonal texture; its chroma steps are too
+    # small for EEDI2's edge test (eedi2_template.c:122-195), so the chroma planes' masks are empty and every pass behind
+    # the mask only copies them - as the reference's passes skip unmasked pixels (:371, :392-393)
+    "interlaced": "interlaced",
+    # diamonds in luma, saturated discs in chroma, field-shifted: edges and corners in all three planes
+    "corners": "corners",
+    # uniform random bytes: nearly every pixel is an edge pixel - the worst case for every masked pass
+    "random": "random",
+}
+
+
+def mask_density(hip, device, frames_np, W, H, depth):
+    """Fraction of set pixels in EEDI2's edge mask (MSKPF, decomb.c:64-68) per plane, measured on the GPU from the
+    engine's own scratch plane after the fields of two frames: what decides how much work the passes behind the mask
+    have (they skip unmasked pixels, eedi2_template.c:371, :392-393)."""
+    import numpy as np
+    ctx = hip.Ctx(device)
+    dec = hip.DecombDevice(ctx, W, H, mode=31, depth=depth)
+    try:
+        for fr in frames_np[:3]:
+            dec.push(fr)
+        while dec.pull() is not None:
+            pass
+        out = {}
+        for c, name in enumerate(("y", "cb", "cr")):
+            m = dec.eedi_plane(1, c)
+            w = W if c == 0 else (W + 1) // 2
+            out[name] = round(float(np.count_nonzero(m[:, :w])) / float(m.shape[0] * w), 4)
+        return out
+    finally:
+        dec.close()
+        ctx.close()
+
+
 def run_chain(args, world, rank, local_rank):
     """The chain workloads through hbhip_chain (device-resident, one or more independent streams per GPU)."""
     import numpy as np
@@ -427,11 +494,14 @@ def run_chain(args, world, rank, local_rank):
     W, H, scale = wl["w"], wl["h"], wl["scale"]
     OW, OH = scale if scale else (W, H)
     B = args.batch or wl["batch"]
-    nsrc = min(B, 8)
+    # a stream of NSRC consecutive frames of the model, walked batch after batch (it starts over after NSRC: a scene cut
+    # every NSRC frames) - no two consecutive steps see the same frames
+    nsrc = args.stream_frames if args.stream_frames > 0 else (3 * B if W <= 1920 else B)
     depth = args.depth                                                 # 10 / 12 bits: uint16 planes through the same chain
-    frames_np = synth.stream("interlaced", W, H, nsrc, cfg=wl["cfg"] + 16 * rank, depth=depth)
+    frames_np = synth.stream(CONTENTS[args.content], W, H, nsrc, cfg=wl["cfg"] + 16 * rank, depth=depth)
     dev_in = [[torch.from_numpy(p.view(np.int16) if depth > 8 else p).cuda() for p in fr] for fr in frames_np]
-    in_arr = (hip.DevFrame * B)(*[hip.dev_frame(dev_in[i % nsrc]) for i in range(B)])
+    nphase = nsrc // math.gcd(nsrc, B)                                 # distinct batches before the walk repeats
+    in_arrs = [(hip.DevFrame * B)(*[hip.dev_frame(dev_in[(k * B + i) % nsrc]) for i in range(B)]) for k in range(nphase)]
     flags = [synth.PIC_FLAG_TOP_FIELD_FIRST] * B
     torch.cuda.synchronize()
     only_decomb = args.workload == "decomb_eedi2"
@@ -447,30 +517,10 @@ def run_chain(args, world, rank, local_rank):
         split: every stage on a context (HIP stream) of its own - one stream per filter, as libhb runs one
         thread per filter - so the chain overlaps the stages of consecutive batches."""
         def __init__(self, split):
-            self.ctx = hip.Ctx(local_rank)
-            self.ctxs = [self.ctx]
-
-            def stage_ctx(stage=0):
-                # split 1: a context (HIP stream) per stage; split 2: decomb on one context, the stages behind it on a second;
-                # split 3: decomb + NLMeans (arithmetic-bound) on one, the scaler + lapsharp (memory-bound) on a second;
-                # split 4: decomb / NLMeans / scaler + lapsharp
-                if (not split or (split == 2 and len(self.ctxs) >= 3) or (split == 3 and stage != 2 and len(self.ctxs) >= 2) or
-                        (split == 4 and stage == 3)):
-                    return self.ctxs[-1]
-                self.ctxs.append(hip.Ctx(local_rank))
-                return self.ctxs[-1]
-
-            c = stage_ctx()
-            self.decomb = hip.DecombDevice(c, W, H, mode=63 if args.comb_detect else 31, depth=depth)
+            self.ctxs, self.chain = build_chain(hip, local_rank, W, H, scale, depth=depth, split=split, only_decomb=only_decomb,
+                                                comb_detect=args.comb_detect)
+            self.ctx = self.ctxs[0]
             self.comb = hip.CombDetectDevice(self.ctx, W, H) if args.comb_detect else None
-            stages = [hip.DeviceFilter(c, self.decomb.h)]
-            if not only_decomb:
-                stages.append(hip.nlmeans_device_filter(stage_ctx(1), hip.NLMEANS_MEDIUM, W, H, batch=1, depth=depth))
-                if scale:
-                    stages.append(hip.cropscale_device_filter(stage_ctx(2), W, H, OW, OH, depth=depth))
-                stages.append(hip.lapsharp_device_filter(stage_ctx(3), OW, OH, depth=depth))
-            self.decomb.h = None                              # owned by the chain from here on
-            self.chain = hip.Chain(self.ctx, stages)
             self.cap = 2 * B + 4
             self.out_t = [planes(OW, OH) for _ in range(self.cap)]
             self.out_arr = (hip.DevFrame * self.cap)(*[hip.dev_frame(t) for t in self.out_t])
@@ -486,7 +536,8 @@ def run_chain(args, world, rank, local_rank):
 
         def step(self):
             combed = self.combed_for(self.fed, B) if self.comb else [2] * B
-            self.produced += self.chain.process_dev(in_arr, self.out_arr, tag0=self.fed, flags=flags, combed=combed)
+            self.produced += self.chain.process_dev(in_arrs[(self.fed // B) % nphase], self.out_arr, tag0=self.fed, flags=flags,
+                                                    combed=combed)
             self.fed += B
 
         def sync(self):
@@ -604,6 +655,7 @@ def run_chain(args, world, rank, local_rank):
             "config": {"workload": wl["text"] + (" + comb detect in front (selective decomb, mode 63)" if args.comb_detect else ""),
                        "input_frames_per_step": B * len(lanes), "output_frames_per_step": 2 * B * len(lanes),
                        "input": f"{W}x{H}", "output": f"{OW}x{OH}", "streams_per_gpu": len(lanes),
+                       "content": args.content, "stream_frames": nsrc,
                        "stage_streams": int(args.stage_streams),
                        "parallelism": f"{world} GPU(s) x {len(lanes)} independent stream(s)", "device": ctx.name()},
             "input_fps": round(frames_total / dt_max / 2, 2),
@@ -622,6 +674,11 @@ def run_chain(args, world, rank, local_rank):
             except Exception as e:
                 roof["measured_peak"] = None
                 roof["measured_peak_error"] = repr(e)
+        if not args.no_kernel_timer:
+            try:
+                line["config"]["eedi2_mask_density"] = mask_density(hip, local_rank, frames_np, W, H, depth)
+            except Exception as e:
+                line["config"]["eedi2_mask_density"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_chain(args.workload, frames_np, scale)
         else:
@@ -635,7 +692,7 @@ def run_chain(args, world, rank, local_rank):
             import torch.distributed as dist
             dist.barrier()
         try:
-            pcie = pcie_inclusive(args.workload, W, H, scale, wl["cfg"] + 16 * rank, local_rank)
+            pcie = pcie_inclusive(args.workload, W, H, scale, wl["cfg"] + 16 * rank, local_rank, CONTENTS[args.content])
         except Exception as e:                                               # never lose the bench line over it
             pcie = {"error": repr(e), "n_out": 0, "seconds": 0.0}
         pcie = shard.reduce_host_path(pcie, device="cuda")
@@ -719,6 +776,13 @@ def main():
     ap.add_argument("--workload", default="chain", choices=sorted(WORKLOADS),
                     help="chain = BASELINE's metric, configs[3] (default, the line the driver records); nlmeans = "
                          "configs[1]; decomb_eedi2 = configs[2]; chain2160 = one stream of configs[4]")
+    ap.add_argument("--content", default="interlaced", choices=sorted(CONTENTS),
+                    help="chain workloads: the synthetic picture model (handbrake_amd/synth.py).  interlaced (default) = the survey's "
+                         "model, whose chroma has no EEDI2 edge; corners = edges and corners in all three planes; random = uniform "
+                         "noise, every pixel an edge pixel.  The EEDI2 passes skip unmasked pixels as the reference does "
+                         "(eedi2_template.c:371, :392-393), so the rate depends on it: config.eedi2_mask_density says how much")
+    ap.add_argument("--stream-frames", type=int, default=0,
+                    help="chain workloads: length of the synthetic stream the steps walk through (default 3 batches; 2160p: 1)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU, no kernels: the rank plumbing of the multi-GPU launch only (gloo on the CPU) - see "
                          "dry_run(); the line it prints is labelled and is not a measurement")

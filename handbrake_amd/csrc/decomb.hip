@@ -445,11 +445,25 @@ public:
             // bob) are queued and go through each pass together: one launch per pass for up to `fields` fields
             // (Eedi2Engine), followed by the blends that consume the guesses.  Driven a frame at a time (work() of the
             // plugin), a frame's fields still share their launches.
-            const int fields = hbhip_dev_int("HBHIP_EEDI2_FIELDS", 32);               // fields per batch (1..32): two parts of 16 (Eedi2Engine::launch)
-            eedi = new (std::nothrow) Eedi2Engine(ctx, in_geo, ep, fields);
-            if (!eedi) return HBHIP_ERR_NOMEM;
-            int rc = eedi->init();
-            if (rc != HBHIP_OK) return rc;
+            // fields per batch (1..32): two parts of 16 (Eedi2Engine::launch).  A field's slot holds 4 half-height and 5
+            // full-height scratch frames plus the lattice candidates - about 11 bytes per frame pixel, 34 MB at 1080p -
+            // and the engine keeps fields + 1 slots: 1.1 GB at 1080p for 32 fields, four times that at 2160p.  Up to
+            // 1080p a batch is 32 fields; above, 16 (2.3 GB at 2160p: a 2160p field already fills the GPU four times
+            // over, the second part adds nothing there).  Should the slab not fit beside what else lives on the GPU
+            // the batch is halved until it does; the 16-bit engine (22 bytes per pixel) starts from 16 for every size.
+            int fields = hbhip_dev_int("HBHIP_EEDI2_FIELDS", (long long)in_geo.width * in_geo.height <= 1920LL * 1088 ? 32 : 16);
+            for (;;)
+            {
+                eedi = new (std::nothrow) Eedi2Engine(ctx, in_geo, ep, fields);
+                if (!eedi) return HBHIP_ERR_NOMEM;
+                const int rc = eedi->init();
+                if (rc == HBHIP_OK) break;
+                delete eedi;
+                eedi = nullptr;
+                if (rc != HBHIP_ERR_HIP || fields <= 2) return rc;
+                (void)hipGetLastError();                                  // hipErrorOutOfMemory of the slab: try half
+                fields /= 2;
+            }
         }
         return HBHIP_OK;
     }

@@ -33,6 +33,8 @@
 // from chunk to chunk.
 #include "eedi2_vote.h"
 #include "eedi2_engine.h"
+
+#include <atomic>
 #include <algorithm>
 
 namespace {
@@ -93,6 +95,8 @@ __device__ __forceinline__ PL plane_ptrs(const P3 &P, int pl, size_t off)
     const int fld = (int)blockIdx.z / 3, pl = (int)blockIdx.z - 3 * fld;    \
     const int tff = (int)(((P).tffbits >> fld) & 1u);                       \
     const PL Q = plane_ptrs((P), pl, (size_t)fld * (P).fstride);            \
+    /* pflags: bound by every enqueue_passes path (never null); a mask launch's number is never 0 (enqueue_mask),  */ \
+    /* so a flag that was only ever zeroed reads as "empty mask" - which is what no mask launch having set it means */ \
     const bool maskless = (P).pflags[blockIdx.z] != (P).pepoch;             \
     (void)tff; (void)maskless
 
@@ -493,6 +497,33 @@ __global__ __launch_bounds__(MF_T) void k_mask_chain(P3 P, MaskSrc S, MaskChain 
         mask_tile<true>(P, S, C, fld, pl, bx, by, mth, vth, lth, erode_thr, dilate_thr, s_src, s_a, s_b);
     else
         mask_tile<false>(P, S, C, fld, pl, bx, by, mth, vth, lth, erode_thr, dilate_thr, s_src, s_a, s_b);
+}
+
+// Queued behind every k_mask_chain launch, ONE workgroup: nothing to do unless a wait of the chain ran out (C.err).  Then
+// the launch's lower tiles are recomputed field after field, tile after tile, by this one workgroup - program order is
+// the dependency order, every flag already carries the epoch (each tile publishes itself, timed out or not), so the
+// waits inside mask_tile<true> pass at once - from the same sources with the same arithmetic: the new masks end up as
+// the per-field launches would have left them.  (The upper tiles and SRCPF never depended on another field.)
+__global__ __launch_bounds__(MF_T) void k_mask_chain_repair(P3 P, MaskSrc S, MaskChain C, int nfields, int mth, int vth, int lth,
+                                                            int erode_thr, int dilate_thr)
+{
+    __shared__ uint32_t s_src[MF_LR][MF_DP];
+    __shared__ uint32_t s_a[MF_LR][MF_DP];
+    __shared__ uint32_t s_b[MF_LR][MF_DP];
+    if (__hip_atomic_load(C.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;      // block-uniform
+    for (int fld = 0; fld < nfields; fld++)
+        for (int tile = 0; tile < C.ntiles; tile++)
+        {
+            int pl, bx, by;
+            eedi_chain_lower_tile(C, tile, pl, bx, by);
+            mask_tile<true>(P, S, C, fld, pl, bx, by, mth, vth, lth, erode_thr, dilate_thr, s_src, s_a, s_b);
+            __syncthreads();
+        }
+    if (threadIdx.x == 0)
+    {
+        __hip_atomic_store(C.err, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(C.fallbacks, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // calc_directions in two launches so that no lane idles while its neighbour walks the
@@ -2719,6 +2750,59 @@ __global__ void k_post_corner(CornerArgs A, const uint8_t *msk, uint8_t *dst, in
 
 } // namespace
 
+// ---- MaskChainGuard (eedi2_engine.h): what happens when a wait of the mask chain runs out ------------------------
+static std::atomic<int>      g_chain_spin_limit{1 << 20};     // about a second of polling
+static std::atomic<uint32_t> g_chain_fallbacks{0};
+int  eedi_chain_spin_limit() { return g_chain_spin_limit.load(); }
+void eedi_chain_note_fallbacks(uint32_t n) { g_chain_fallbacks += n; }
+
+// Test hook (ABI): spin_limit > 0 sets the polls a chain wait makes before it gives up for every mask launch from now
+// on (1 = give up at once: every launch then takes the repair path), 0 restores the default; returns the number of mask
+// launches the repair pass has redone in this process so far (as far as the engines' launch() calls have seen).
+extern "C" unsigned hbhip_debug_mask_chain(int spin_limit)
+{
+    if (spin_limit > 0) g_chain_spin_limit = spin_limit;
+    else if (spin_limit == 0) g_chain_spin_limit = 1 << 20;
+    return g_chain_fallbacks.load();
+}
+
+int MaskChainGuard::init(hbhip_ctx *ctx)
+{
+    HBHIP_CHECK(ctx, hipMalloc((void **)&err, sizeof(uint32_t)));
+    HBHIP_CHECK(ctx, hipMemsetAsync(err, 0, sizeof(uint32_t), ctx->stream));
+    HBHIP_CHECK(ctx, hipHostMalloc((void **)&count_host, sizeof(uint32_t), hipHostMallocMapped));
+    *count_host = 0;
+    HBHIP_CHECK(ctx, hipHostGetDevicePointer((void **)&count_dev, count_host, 0));
+    return HBHIP_OK;
+}
+
+void MaskChainGuard::destroy()
+{
+    poll("eedi2");
+    if (err) (void)hipFree(err);
+    if (count_host) (void)hipHostFree(count_host);
+    err = nullptr; count_host = nullptr; count_dev = nullptr;
+}
+
+void MaskChainGuard::poll(const char *who)
+{
+    if (!count_host) return;
+    const uint32_t now = __atomic_load_n(count_host, __ATOMIC_RELAXED);
+    if (now == seen) return;
+    if (seen == 0)
+        fprintf(stderr, "hbhip: %s: a wait of the mask chain ran out (workgroups were not dispatched in order); the batch's "
+                        "masks were recomputed field by field - results are unaffected, that batch was slower\n", who);
+    eedi_chain_note_fallbacks(now - seen);
+    seen = now;
+}
+
+void MaskChainGuard::bind(MaskChain &C) const
+{
+    C.err = err;
+    C.fallbacks = count_dev;
+    C.spin_limit = eedi_chain_spin_limit();
+}
+
 // ------------------------------------------------------------------- engine
 // Fields are queued (add_field) and run together (launch): the edge mask is the only thing one field's run takes from
 // the previous one (the lower half of MSKPF keeps the previous run's mask, eedi2_template.c:132), so the mask kernels
@@ -2735,6 +2819,7 @@ Eedi2Engine::~Eedi2Engine()
     if (slab_) (void)hipFree(slab_);
     if (chain_flags_) (void)hipFree(chain_flags_);
     if (plane_flags_) (void)hipFree(plane_flags_);
+    guard_.destroy();
     for (int g = 0; g < MAX_SIDE; g++)
     {
         if (side_[g]) (void)hipStreamDestroy(side_[g]);
@@ -2811,6 +2896,8 @@ int Eedi2Engine::init()
         const size_t nflags = (size_t)eedi_mask_chain_tiles(half_[0], MF_W, MF_H, MF_OY).ntiles * cap_;
         HBHIP_CHECK(ctx_, hipMalloc((void **)&chain_flags_, sizeof(uint32_t) * nflags));
         HBHIP_CHECK(ctx_, hipMemsetAsync(chain_flags_, 0, sizeof(uint32_t) * nflags, ctx_->stream));
+        const int grc = guard_.init(ctx_);
+        if (grc != HBHIP_OK) return grc;
     }
     if (par_.maximum_search_distance > CD_HALO - 2)
     {
@@ -2866,6 +2953,7 @@ int Eedi2Engine::launch(hbhip_ctx *lc)
     if (n_ == 0) return HBHIP_OK;
     const int n = n_;
     n_ = 0;
+    guard_.poll("decomb EEDI2");
     // A batch goes out in parts of at most EEDI_PART fields: one mask launch per part (a chain of that many links), and the
     // passes behind it.
     //  * The passes: every field has its own slot, so the two halves of a part run them beside each other on two streams -
@@ -2894,38 +2982,53 @@ int Eedi2Engine::launch(hbhip_ctx *lc)
     }
     else if (rc == HBHIP_OK)
     {
+        // one event (ev_mask_) orders the parts: good for two of them
+        static_assert(EEDI_MAX_BATCH <= 2 * EEDI_PART, "the fork below orders at most two parts with its one mask event");
         hipStream_t twin = side_[0], ahead = side_[1];
-        bool twin_used = false;
-        HBHIP_CHECK(lc, hipEventRecord(ev_fork_, lc->stream));                 // the first part's mask is out
-        for (int p = 0; p < parts && rc == HBHIP_OK; p++)
+        bool twin_used = false, ahead_used = false;
+        // a HIP call that fails in here must not leave the side streams running into slots the caller goes on to reuse:
+        // remember it, stop queueing, and fall through to the joins
+        hipError_t herr = hipSuccess;
+        const char *hwhat = "";
+#define FORK_TRY(call) do { if (herr == hipSuccess && (herr = (call)) != hipSuccess) hwhat = #call; } while (0)
+        FORK_TRY(hipEventRecord(ev_fork_, lc->stream));                        // the first part's mask is out
+        for (int p = 0; p < parts && rc == HBHIP_OK && herr == hipSuccess; p++)
         {
             const int f0 = p * EEDI_PART, m = std::min(EEDI_PART, n - f0);
             hipEvent_t ready = p ? ev_mask_ : ev_fork_;                       // this part's mask
-            if (p)
-            {
-                // (parts > 2 would need an event per part: EEDI_MAX_BATCH is two parts)
-                HBHIP_CHECK(lc, hipStreamWaitEvent(lc->stream, ev_mask_, 0));
-            }
-            if (p + 1 < parts)
+            if (p) FORK_TRY(hipStreamWaitEvent(lc->stream, ev_mask_, 0));
+            if (p + 1 < parts && herr == hipSuccess)
             {
                 // the next part's mask beside this part's passes: behind this part's mask, on its own stream
                 const int g0 = f0 + EEDI_PART, gm = std::min(EEDI_PART, n - g0);
-                HBHIP_CHECK(lc, hipStreamWaitEvent(ahead, ready, 0));
+                FORK_TRY(hipStreamWaitEvent(ahead, ready, 0));
+                if (herr != hipSuccess) break;
+                ahead_used = true;
                 rc = enqueue_mask(g0, gm, lc, ahead, &epoch[p + 1]);
                 if (rc != HBHIP_OK) break;
-                HBHIP_CHECK(lc, hipEventRecord(ev_mask_, ahead));
+                FORK_TRY(hipEventRecord(ev_mask_, ahead));
             }
+            if (herr != hipSuccess) break;
             if (m >= 8)
             {
                 const int h = m / 2;
-                HBHIP_CHECK(lc, hipStreamWaitEvent(twin, ready, 0));
+                FORK_TRY(hipStreamWaitEvent(twin, ready, 0));
+                if (herr != hipSuccess) break;
                 twin_used = true;
                 rc = enqueue_passes(f0, h, lc, lc->stream, epoch[p]);
                 if (rc == HBHIP_OK) rc = enqueue_passes(f0 + h, m - h, lc, twin, epoch[p]);
             }
             else rc = enqueue_passes(f0, m, lc, lc->stream, epoch[p]);
         }
-        if (twin_used)
+#undef FORK_TRY
+        if (herr != hipSuccess || rc != HBHIP_OK)
+        {
+            // whatever was queued on the side streams finishes before the caller sees the error
+            if (twin_used) (void)hipStreamSynchronize(twin);
+            if (ahead_used) (void)hipStreamSynchronize(ahead);
+            if (herr != hipSuccess) rc = lc->fail(herr, hwhat);
+        }
+        else if (twin_used)
         {
             HBHIP_CHECK(lc, hipEventRecord(ev_join_[0], twin));
             HBHIP_CHECK(lc, hipStreamWaitEvent(lc->stream, ev_join_[0], 0));
@@ -2956,6 +3059,16 @@ int Eedi2Engine::enqueue_mask(int f0, int n, hbhip_ctx *lc, hipStream_t st, uint
     P.tffbits = tffbits_ >> f0;
     const int mth = par_.magnitude_threshold * 10, vth = par_.laplacian_threshold * 81, lth = par_.variance_threshold;   // sic: swapped (decomb_template.c:390)
     const unsigned gx = (srcp.width[0] + MF_W - 1) / MF_W, gy = (srcp.height[0] + MF_H - 1) / MF_H;
+    if (chain_epoch_ == 0xffffffffu)
+    {
+        // 2^32 mask launches later: 0 means "no launch" in the flag arrays and old numbers must not come round again -
+        // drain the device, clear the flags and start over at 1 (months of continuous running apart)
+        HBHIP_CHECK(lc, hipDeviceSynchronize());
+        if (chain_flags_)
+            HBHIP_CHECK(lc, hipMemset(chain_flags_, 0, sizeof(uint32_t) * (size_t)eedi_mask_chain_tiles(half_[0], MF_W, MF_H, MF_OY).ntiles * cap_));
+        HBHIP_CHECK(lc, hipMemset(plane_flags_, 0, sizeof(uint32_t) * 3 * EEDI_MAX_BATCH));
+        chain_epoch_ = 0;
+    }
     const uint32_t epoch = ++chain_epoch_;                        // the number of this mask launch (chain flags, plane flags)
     *epoch_out = epoch;
     uint32_t *pflags = plane_flags_ + 3 * f0;
@@ -2972,8 +3085,12 @@ int Eedi2Engine::enqueue_mask(int f0, int n, hbhip_ctx *lc, hipStream_t st, uint
         C.pflags = pflags;
         C.epoch = epoch;
         C.group = C.ntiles + C.nupper;
+        guard_.bind(C);
         HBHIP_LAUNCH_ON(lc, st, "eedi2_mask_passes", k_mask_chain, dim3((unsigned)(C.group * n)), dim3(MF_T), 0, P, S, C, mth, vth, lth,
                      par_.erosion_threshold, par_.dilation_threshold);
+        // one workgroup that returns at once unless a wait above ran out (MaskChain): no abort, no host round trip
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_mask_repair", k_mask_chain_repair, dim3(1), dim3(MF_T), 0, P, S, C, n, mth, vth, lth,
+                        par_.erosion_threshold, par_.dilation_threshold);
     }
     HBHIP_CHECK(lc, hipGetLastError());
     return HBHIP_OK;
@@ -3019,7 +3136,7 @@ int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st, ui
     memset(&P, 0, sizeof(P));
     P.fstride = slot_bytes_;
     P.tffbits = tffbits;
-    P.pflags = plane_flags_ + 3 * f0;
+    P.pflags = plane_flags_ + 3 * f0;                             // every kernel behind FIELD_PLANE reads it: never null here
     P.pepoch = epoch;
 
     // half-height passes

@@ -336,6 +336,30 @@ __global__ __launch_bounds__(QM_T) void q_mask_chain(Q3 P, MaskSrc16 S, K16 k, M
         qmask_tile<false>(P, S, k, C, fld, pl, bx, by, mth, vth, lth, erode_thr, dilate_thr, s_src, s_a, s_b);
 }
 
+// the repair pass behind q_mask_chain (k_mask_chain_repair, eedi2.hip, says what it is for): one workgroup, a no-op unless
+// a wait of the chain ran out
+__global__ __launch_bounds__(QM_T) void q_mask_chain_repair(Q3 P, MaskSrc16 S, K16 k, MaskChain C, int nfields, int mth, int vth, int lth,
+                                                            int erode_thr, int dilate_thr)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t s_src[QM_LR][QM_LP + 8];
+    __shared__ uint32_t s_a[QM_LR][QM_DP];
+    __shared__ uint32_t s_b[QM_LR][QM_DP];
+    if (__hip_atomic_load(C.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;      // block-uniform
+    for (int fld = 0; fld < nfields; fld++)
+        for (int tile = 0; tile < C.ntiles; tile++)
+        {
+            int pl, bx, by;
+            eedi_chain_lower_tile(C, tile, pl, bx, by);
+            qmask_tile<true>(P, S, k, C, fld, pl, bx, by, mth, vth, lth, erode_thr, dilate_thr, s_src, s_a, s_b);
+            __syncthreads();
+        }
+    if (threadIdx.x == 0)
+    {
+        __hip_atomic_store(C.err, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(C.fallbacks, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // eedi2_calc_directions (:358-525): a = mskp, b = srcp, c = out (whole pitch pre-filled with PEAK)
 __global__ void q_calc_dir(Q3 P, K16 k, int maxd, int nt)
 {
@@ -2289,6 +2313,7 @@ Eedi2Engine16::~Eedi2Engine16()
 {
     if (slab_) (void)hipFree(slab_);
     if (chain_flags_) (void)hipFree(chain_flags_);
+    guard_.destroy();
     if (plane_flags_) (void)hipFree(plane_flags_);
     if (side_) (void)hipStreamDestroy(side_);
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
@@ -2352,6 +2377,8 @@ int Eedi2Engine16::init()
         const size_t nflags = (size_t)eedi_mask_chain_tiles(half_[0], QM_W, QM_H, QM_OY).ntiles * cap_;
         HBHIP_CHECK(ctx_, hipMalloc((void **)&chain_flags_, sizeof(uint32_t) * nflags));
         HBHIP_CHECK(ctx_, hipMemsetAsync(chain_flags_, 0, sizeof(uint32_t) * nflags, ctx_->stream));
+        const int grc = guard_.init(ctx_);
+        if (grc != HBHIP_OK) return grc;
     }
     if (par_.post_processing > 1)
     {
@@ -2389,6 +2416,7 @@ int Eedi2Engine16::launch(hbhip_ctx *lc)
     if (n_ == 0) return HBHIP_OK;
     const int n = n_;
     n_ = 0;
+    guard_.poll("decomb EEDI2 (16-bit)");
     const int rc = enqueue(n, lc);
     last_slot_ = start_ + n - 1;
     return rc;
@@ -2434,6 +2462,16 @@ int Eedi2Engine16::enqueue(int n, hbhip_ctx *lc)
         bind(P.a, srcp); bind(P.b, old); bind(P.c, mskp);
         const int mth = par_.magnitude_threshold * 10, vth = par_.laplacian_threshold * 81, lth = par_.variance_threshold;   // sic: swapped (decomb_template.c:390)
         const unsigned gx = (srcp.width[0] + QM_W - 1) / QM_W, gy = (srcp.height[0] + QM_H - 1) / QM_H;
+        if (chain_epoch_ == 0xffffffffu)
+        {
+            // 2^32 mask launches later: 0 means "no launch" in the flag arrays and old numbers must not come round
+            // again - drain the device, clear the flags and start over at 1 (months of continuous running apart)
+            HBHIP_CHECK(lc, hipDeviceSynchronize());
+            if (chain_flags_)
+                HBHIP_CHECK(lc, hipMemset(chain_flags_, 0, sizeof(uint32_t) * (size_t)eedi_mask_chain_tiles(half_[0], QM_W, QM_H, QM_OY).ntiles * cap_));
+            HBHIP_CHECK(lc, hipMemset(plane_flags_, 0, sizeof(uint32_t) * 3 * EEDI_MAX_BATCH));
+            chain_epoch_ = 0;
+        }
         const uint32_t epoch = ++chain_epoch_;                    // the number of this mask launch (chain flags, plane flags)
         if (n == 1)
             HBHIP_LAUNCH(lc, "eedi2_16_mask_passes", q_mask_fused, dim3(gx, gy, 3), dim3(QM_T), 0, P, S, k, 0, 0, mth, vth, lth,
@@ -2446,7 +2484,10 @@ int Eedi2Engine16::enqueue(int n, hbhip_ctx *lc)
             C.pflags = plane_flags_;
             C.epoch = epoch;
             C.group = C.ntiles + C.nupper;
+            guard_.bind(C);
             HBHIP_LAUNCH(lc, "eedi2_16_mask_passes", q_mask_chain, dim3((unsigned)(C.group * n)), dim3(QM_T), 0, P, S, k, C, mth, vth, lth,
+                         par_.erosion_threshold, par_.dilation_threshold);
+            HBHIP_LAUNCH(lc, "eedi2_16_mask_repair", q_mask_chain_repair, dim3(1), dim3(QM_T), 0, P, S, k, C, n, mth, vth, lth,
                          par_.erosion_threshold, par_.dilation_threshold);
         }
     }

@@ -146,6 +146,15 @@ __device__ __forceinline__ uint32_t from_lane_above(uint32_t x)   // lane l <- l
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
 }
 
+// a kernel whose code object declares no static LDS: its dynamic LDS block starts at LDS address 0
+static bool nlm_no_static_lds(const void *kernel)
+{
+    hipFuncAttributes a;
+    memset(&a, 0, sizeof(a));
+    if (hipFuncGetAttributes(&a, kernel) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.sharedSizeBytes == 0;
+}
+
 // FAST: how a patch distance becomes a table index.  0: the reference's expression with its gate (diff < diff_max).
 // 1: the gate folded into a clamp (exactly equivalent when the table ends in 0 at the index the cap maps to).  2: the
 // clamp, and the float product (int)(diff * wft) replaced by an integer multiply-high: wft is a float, so wft * 2^32 is
@@ -213,7 +222,8 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
     // FAST 2 reads the table by its LDS address, taken to be 0: this kernel has no static LDS, so the dynamic block -
     // and the table at its head - starts there (the compiler leaves "+ &smem" as an add of 0 per read otherwise)
     typedef __attribute__((address_space(3))) const float lds_cfloat;
-    if (INTIDX && reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint32_t *)smem) != 0) __builtin_trap();
+    // (checked on the host before the first launch of every such instantiation: nlm_no_static_lds)
+    __builtin_assume(!INTIDX || reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint32_t *)smem) == 0);
     if (threadIdx.x < 128) s_exp[threadIdx.x] = job.exptable[threadIdx.x];
     // lane tx holds the source pixels tx0 + 4*(tx-1) .. +3: the tiles start one lane (and rq
     // dwords of search halo) left of tx0
@@ -572,7 +582,7 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes16_kernel(const Nlm
     uint32_t *s_r0 = PRE ? s_tc + tile_dwords : s_t0;
     uint32_t *s_rc = PRE ? s_r0 + tile_dwords : s_tc;
     typedef __attribute__((address_space(3))) const float lds_cfloat;
-    if (FAST == 2 && reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint32_t *)smem) != 0) __builtin_trap();
+    __builtin_assume(FAST != 2 || reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint32_t *)smem) == 0);   // nlm_no_static_lds
 
     int j = 0;
     for (int hi = njobs - 1; j < hi;)
@@ -1373,7 +1383,12 @@ private:
             size_t shmem = sizeof(uint32_t) * (pre ? 4 : 2) * (cpd * cmp_rows + 4) + 512;
             if (sym) shmem = 512 + sizeof(uint32_t) * ((size_t)(cpd * cmp_rows + 4) + std::max<size_t>(cpd * cmp_rows + 4, 4 * (RY + 1) * TXN * TYN));
             // the widest search ranges need more than the default 64 KB of dynamic LDS
+            // The integer-index kernels (FAST >= 2) read the weight table at LDS address 0: true when the kernel has no static
+            // LDS in front of its dynamic block.  Asked of the code object once per instantiation; a kernel that fails it is
+            // refused here (the filter reports an error) rather than launched.
 #define NLM_LAUNCH(KERNEL) do { \
+                static const bool lds_free = nlm_no_static_lds((const void *)KERNEL); \
+                if ((fast && fast_int) && !lds_free) return ctx->fail(hipErrorInvalidValue, "nlmeans: kernel has static LDS in front of its table"); \
                 if (shmem > 65536) \
                     HBHIP_CHECK(ctx, hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
                 HBHIP_LAUNCH(ctx, kname, (KERNEL), grid, block, shmem, dj, nj, cmp_rows, rq); \

@@ -10,6 +10,9 @@
 // lapsharp replays the reference's int16 accumulate and double mix; the
 // binomial blur is exact in uint32 modular arithmetic (the reference's running
 // pair sums are the same sums, unsharp.c:128-156).
+#include <map>
+#include <mutex>
+#include <utility>
 #include "hbhip_internal.h"
 
 namespace {
@@ -736,10 +739,37 @@ static bool lap_float_mix(const LapKernel &k, double strength, int &kinv, float 
 }
 
 // ------------------------------------------------------------------ filter classes
+// the result per (kernel of LAP_TABLE, strength), kept for the process: every filter instance of a job - and of the jobs
+// after it - with the same settings asks once
+static bool lap_float_mix_cached(int kernel, double strength, int &kinv, float &mixf)
+{
+    struct Entry { bool ok; int kinv; float mixf; };
+    static std::mutex lock;
+    static std::map<std::pair<int, double>, Entry> cache;
+    std::lock_guard<std::mutex> lk(lock);
+    const auto key = std::make_pair(kernel, strength);
+    auto it = cache.find(key);
+    if (it == cache.end())
+    {
+        Entry e = { false, 0, 0.f };
+        e.ok = lap_float_mix(LAP_TABLE[kernel], strength, e.kinv, e.mixf);
+        it = cache.emplace(key, e).first;
+    }
+    kinv = it->second.kinv;
+    mixf = it->second.mixf;
+    return it->second.ok;
+}
+
 class LapsharpFilter : public SimpleFilter
 {
 public:
-    LapsharpFilter(hbhip_ctx *c, const hbhip_lapsharp_params &p) : SimpleFilter(c), par(p) {}
+    LapsharpFilter(hbhip_ctx *c, const hbhip_lapsharp_params &p) : SimpleFilter(c), par(p)
+    {
+        // the search behind lap_float_mix (tens of milliseconds) runs here, at create time - init() of the plugin -, once
+        // per (kernel, strength) of the process, not inside the first frame's work()
+        for (int pl = 0; pl < 3; pl++)
+            mix_fast[pl] = LAP_TABLE[par.kernel[pl]].size == 3 && lap_float_mix_cached(par.kernel[pl], par.strength[pl], mix_k[pl], mix_f[pl]);
+    }
     // up to LS_FRAMES frames per launch when every plane uses a 3x3 kernel
     int process_many(DevPicture *const *ins, DevPicture *const *outs, int n) override
     {
@@ -764,14 +794,7 @@ public:
                 P.a = k.tap[0]; P.b = k.tap[1]; P.c = k.tap[4];
                 P.coef = k.coef; P.strength = par.strength[c];
                 P.active = 1;
-                if (!mix_tried[c])
-                {
-                    mix_tried[c] = true;
-                    if (c && mix_tried[c - 1] && par.kernel[c] == par.kernel[c - 1] && par.strength[c] == par.strength[c - 1])
-                    { mix_fast[c] = mix_fast[c - 1]; mix_k[c] = mix_k[c - 1]; mix_f[c] = mix_f[c - 1]; }
-                    else mix_fast[c] = in_geo.bps == 1 && lap_float_mix(k, par.strength[c], mix_k[c], mix_f[c]);
-                }
-                P.fast = mix_fast[c]; P.kinv = mix_k[c]; P.mixf = mix_f[c];
+                P.fast = in_geo.bps == 1 && mix_fast[c]; P.kinv = mix_k[c]; P.mixf = mix_f[c];
                 max_w = std::max(max_w, P.width); max_h = std::max(max_h, P.height);
                 for (int f = 0; f < nf; f++)
                 {
@@ -837,7 +860,7 @@ public:
         return HBHIP_OK;
     }
     hbhip_lapsharp_params par;
-    bool  mix_tried[3] = {}, mix_fast[3] = {};     // lap_float_mix per plane, tried on first use
+    bool  mix_fast[3] = {};                        // lap_float_mix per plane (the constructor)
     int   mix_k[3] = {};
     float mix_f[3] = {};
 };

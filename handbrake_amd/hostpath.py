@@ -41,13 +41,13 @@ def chain_for(workload, scale, vfr=True):
     return chain
 
 
-def run(workload, w, h, scale, cfg=3, n_warm=32, n_in=2048, chain=None):
+def run(workload, w, h, scale, cfg=3, n_warm=32, n_in=2048, chain=None, content="interlaced"):
     """Timed from a warmed-up, quiet pipeline (n_warm frames in, their outputs out as far as the batching stages let
     them: allocations, pinned pool, slabs all made) to the end of the stream n_in frames later, EOF drain included.
     The frames the last stage makes are counted and dropped as they come, as an encoder that keeps up would."""
     from handbrake_amd import hbrt, hip, synth
     chain = chain or chain_for(workload, scale)
-    frames = synth.stream("interlaced", w, h, 8, cfg=cfg)
+    frames = synth.stream(content, w, h, 48, cfg=cfg)          # a 48-frame stream walked round and round
     seq = [frames[i % len(frames)] for i in range(n_warm + n_in)]
     hbrt.set_threaded(True)
     hbrt.set_discard_output(True)
@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--frames", type=int, default=2048,
                     help="input frames of the timed interval (2048 = 4096 output frames, a sample of about a second)")
     ap.add_argument("--no-vfr", action="store_true", help="leave the frame-rate shaper out of the list (round 4's list)")
+    ap.add_argument("--content", default="interlaced", help="picture model of handbrake_amd/synth.py")
     ap.add_argument("--device", type=int, default=0)
     a = ap.parse_args()
     os.environ["HBHIP_DEVICE"] = str(a.device)          # the drop-ins' shared context (libhb/hbhip_registry.c)
@@ -108,7 +109,7 @@ def main():
     scale = None if a.scale == "none" else tuple(int(v) for v in a.scale.split("x"))
     try:
         res = run(a.workload, a.width, a.height, scale, cfg=a.cfg, n_in=a.frames,
-                  chain=chain_for(a.workload, scale, vfr=not a.no_vfr))
+                  chain=chain_for(a.workload, scale, vfr=not a.no_vfr), content=a.content)
     except Exception as e:                               # the caller never loses its own line over this pass
         res = {"error": repr(e), "n_out": 0, "seconds": 0.0}
     print(json.dumps(res), flush=True)

@@ -401,6 +401,14 @@ int  hbhip_blend_apply(hbhip_blend *b, const hbhip_host_frame *frame);       /* 
 int  hbhip_blend_apply_dev(hbhip_blend *b, const hbhip_dev_frame *frame);    /* frame already in HBM */
 void hbhip_blend_destroy(hbhip_blend *b);                                    /* hb_blend_close (:875-885) */
 
+/* ---- test hook ------------------------------------------------------------------------------
+ * The EEDI2 mask passes of a batch run as ONE launch whose tiles wait for the previous field's tiles (csrc/eedi2_engine.h:
+ * MaskChain).  A wait that runs out never aborts: the launch ends, and a repair pass behind it recomputes the batch's
+ * masks field by field.  spin_limit > 0: polls a wait makes before it gives up, for every mask launch from now on
+ * (1 = at once, i.e. every launch takes the repair path); 0: back to the default (about a second).  Returns how many
+ * mask launches have been repaired in this process so far. */
+unsigned hbhip_debug_mask_chain(int spin_limit);
+
 #ifdef __cplusplus
 }
 #endif

@@ -156,3 +156,57 @@ def test_fused_chain_object_vs_chained_oracle(built, w, h, scale_to, batches, sp
         chain.close()
         for c in reversed(ctxs):
             c.close()
+
+
+# ---- the bench's own launch shape (bench.py builds its chain through the same function) ---------------------------
+def _sha(t):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(t.cpu().numpy()).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("content,steps", [("interlaced", 3), ("corners", 1)])
+def test_bench_shape(built, content, steps):
+    """The configuration the driver's bench line comes from, pinned frame for frame: 1920x1080 -> 3840x2160, B = 16 input
+    frames per step, decomb on a context (HIP stream) of its own and NLMeans / scaler / lapsharp on a second
+    (--stage-streams 2), 32-field EEDI2 batches in two parts with forked passes, the steps enqueued back to back with
+    no synchronisation in between, each into output frames of its own - then the flush.  Every plane of every output
+    frame against the SHA-256 the all-reference chain produced here for the same stream (tests/golden/
+    make_bench_shape.py: reference decomb / NLMeans / lapsharp, restated scaler)."""
+    import json
+    import os
+    import torch
+    import bench
+    want = json.load(open(os.path.join(os.path.dirname(__file__), "golden", f"bench_shape_{content}.json")))
+    W, H, OW, OH, B = 1920, 1080, 3840, 2160, 16
+    n = B * steps
+    assert want["input_frames"] == n and len(want["frames"]) == 2 * n
+    frames = synth.stream(bench.CONTENTS[content], W, H, n, cfg=3)
+    ctxs, chain = bench.build_chain(hip, 0, W, H, (OW, OH), depth=8, split=2)
+    assert len(ctxs) == 3                                    # the chain's own, decomb's, and one for the stages behind it
+    try:
+        dev_in = [_dev(f, torch) for f in frames]
+        cap = 2 * B + 4
+
+        def out_frames():
+            return [[torch.zeros((OH, OW), dtype=torch.uint8, device="cuda"),
+                     torch.zeros((OH // 2, OW // 2), dtype=torch.uint8, device="cuda"),
+                     torch.zeros((OH // 2, OW // 2), dtype=torch.uint8, device="cuda")] for _ in range(cap)]
+
+        sets = [out_frames() for _ in range(steps + 1)]
+        torch.cuda.synchronize()                             # the zero fills ran on torch's stream
+        calls = []
+        for s in range(steps):                               # back to back: nothing is waited for between the steps
+            arr_in = (hip.DevFrame * B)(*[hip.dev_frame(dev_in[s * B + i]) for i in range(B)])
+            arr_out = (hip.DevFrame * cap)(*[hip.dev_frame(o) for o in sets[s]])
+            calls.append((sets[s], chain.process_dev(arr_in, arr_out, tag0=s * B, flags=[TFF] * B, combed=[2] * B)))
+        arr_out = (hip.DevFrame * cap)(*[hip.dev_frame(o) for o in sets[steps]])
+        calls.append((sets[steps], chain.flush_dev(arr_out)))
+        chain.sync()
+        got = [o[i] for o, k in calls for i in range(k)]
+        assert len(got) == 2 * n
+        bad = [(i, c) for i in range(2 * n) for c in range(3) if _sha(got[i][c]) != want["frames"][i]["sha256"][c]]
+        assert not bad, f"{len(bad)} planes differ from the reference chain; first: output frame {bad[0][0]} plane {bad[0][1]}"
+    finally:
+        chain.close()
+        for c in reversed(ctxs):
+            c.close()

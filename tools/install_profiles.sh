@@ -16,8 +16,9 @@ cp $S/trace_gaps.json profiles/${TAG}_chain_trace_gaps.json
 cp $S/kernel_bounds.json profiles/${TAG}_kernel_bounds.json
 cp $S/kernel_rooflines.json profiles/${TAG}_kernel_rooflines.json
 python tools/pmc_to_traffic.py $S/pmc_summary.json "profiles/${TAG}_chain_pmc_summary.json (tools/gpu_round.sh $TAG)" profiles/pmc_traffic.json
-python tools/isa_mix.py handbrake_amd/csrc/eedi2.hip profiles/r4_eedi2_isa_mix.json > /dev/null
-python tools/isa_mix.py handbrake_amd/csrc/alias.hip profiles/r4_alias_isa_mix.json > /dev/null
-python tools/isa_mix.py handbrake_amd/csrc/nlmeans.hip profiles/r4_nlmeans_isa_mix.json > /dev/null
+RND=$(echo $TAG | sed -E 's/^(r[0-9]+).*/\1/')              # r5b -> r5: the static mixes are per round, not per session
+for K in eedi2 alias nlmeans; do
+  python tools/isa_mix.py handbrake_amd/csrc/$K.hip profiles/${RND}_${K}_isa_mix.json > /dev/null
+done
 git add profiles
 ls profiles | grep "^${TAG}_" | wc -l
