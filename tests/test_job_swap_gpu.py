@@ -75,8 +75,12 @@ def with_vfr(registered):
     to hb_motion_metric_hip for AV_PIX_FMT_HBHIP frames the way INTEGRATION.md §2 patches vfr.c:76-108)"""
     import oracle_lib as ol
     hbrt.register_filters(ol.ref(), {VFR: "hb_filter_vfr"})
+    # crop/scale is an alias filter in the reference (a settings holder for the combined avfilter graph, cropscale.c;
+    # FFmpeg is not in the image): the id resolves to the drop-in itself, which the swap then leaves in place
+    hbrt.register_filters(hip.filters(), {F["crop_scale"]: "hb_filter_crop_scale_hip"})
     yield
     hbrt.register_filters(ol.ref(), {VFR: None})
+    hbrt.register_filters(hip.filters(), {F["crop_scale"]: None})
 
 
 def reference_job_with_scale(frames, vfr, scale_to, flags=TFF):
