@@ -545,6 +545,46 @@ int hbhip_ctx_device_name(hbhip_ctx *ctx, char *buf, int len)
     return HBHIP_OK;
 }
 
+// ---- the on-box copy ceiling ("measure an on-box ... ceiling and report against both") -----------------
+// A float4 grid-stride copy, the way /opt/skills/guides/MI355X_MICROARCH.md measures its 6.29 TB/s: 16 bytes per lane and
+// trip, enough workgroups to fill every CU several times over, buffers far past the 256 MB Infinity Cache.
+__global__ __launch_bounds__(256) void copy_f4_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
+int hbhip_ctx_copy_bandwidth(hbhip_ctx *ctx, size_t bytes, int iters, double *gbps)
+{
+    if (!ctx || !gbps || bytes < (1u << 20) || iters < 1) return HBHIP_ERR_ARG;
+    (void)hipSetDevice(ctx->device);
+    float4 *a = nullptr, *b = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const size_t n = bytes / sizeof(float4);
+    int rc = HBHIP_OK;
+    double best_ms = 0.0;
+    if (hipMalloc((void **)&a, n * sizeof(float4)) != hipSuccess || hipMalloc((void **)&b, n * sizeof(float4)) != hipSuccess ||
+        hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+        rc = ctx->fail(hipErrorOutOfMemory, "hbhip_ctx_copy_bandwidth: buffers");
+    if (rc == HBHIP_OK && hipMemsetAsync(a, 1, n * sizeof(float4), ctx->stream) != hipSuccess) rc = HBHIP_ERR_HIP;
+    for (int i = 0; rc == HBHIP_OK && i < iters + 1; i++)                        // the first pass warms up
+    {
+        (void)hipEventRecord(e0, ctx->stream);
+        copy_f4_kernel<<<dim3(256 * 16), dim3(256), 0, ctx->stream>>>(a, b, n);
+        (void)hipEventRecord(e1, ctx->stream);
+        if (hipEventSynchronize(e1) != hipSuccess) { rc = ctx->fail(hipGetLastError(), "copy_f4_kernel"); break; }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (i > 0 && (best_ms == 0.0 || ms < best_ms)) best_ms = ms;
+    }
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (rc == HBHIP_OK) *gbps = best_ms > 0.0 ? 2.0 * (double)(n * sizeof(float4)) / (best_ms * 1e-3) / 1e9 : 0.0;   // read + write
+    return rc;
+}
+
 int hbhip_ctx_device_index(hbhip_ctx *ctx)
 {
     return ctx ? ctx->device : -1;

@@ -17,7 +17,7 @@ ABI_SYMBOLS = [
     "hbhip_host_alloc", "hbhip_host_free",
     "hbhip_abi_version", "hbhip_device_count", "hbhip_strerror", "hbhip_ctx_create",
     "hbhip_ctx_create_on_stream", "hbhip_ctx_destroy", "hbhip_ctx_sync", "hbhip_ctx_last_error",
-    "hbhip_debug_mask_chain", "hbhip_ctx_device_name", "hbhip_ctx_device_index", "hbhip_frame_context", "hbhip_filter_context",
+    "hbhip_debug_mask_chain", "hbhip_ctx_copy_bandwidth", "hbhip_ctx_device_name", "hbhip_ctx_device_index", "hbhip_frame_context", "hbhip_filter_context",
     "hbhip_ctx_profile_enable", "hbhip_ctx_profile_reset",
     "hbhip_ctx_profile_count", "hbhip_ctx_profile_get", "hbhip_ctx_mark", "hbhip_ctx_elapsed_ms",
     "hbhip_dev_alloc", "hbhip_dev_free", "hbhip_dev_upload", "hbhip_dev_download",

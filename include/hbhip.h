@@ -73,7 +73,11 @@ void        hbhip_ctx_destroy(hbhip_ctx *ctx);
 int         hbhip_ctx_sync(hbhip_ctx *ctx);           /* hipStreamSynchronize */
 const char *hbhip_ctx_last_error(hbhip_ctx *ctx);     /* text of the last HIP failure */
 int         hbhip_ctx_device_name(hbhip_ctx *ctx, char *buf, int len);
-int         hbhip_ctx_device_index(hbhip_ctx *ctx);   /* the `device` it was created on; < 0 on a NULL context */
+int         hbhip_ctx_device_index(hbhip_ctx *ctx);
+/* The on-box HBM ceiling: a float4 copy kernel over two buffers of `bytes` each (take them well past the 256 MB Infinity
+ * Cache), best of `iters` timed passes with HIP events; *gbps = (read + write) bytes / time.  bench.py reports roofline
+ * fractions against this as well as against the nominal 8 TB/s. */
+int         hbhip_ctx_copy_bandwidth(hbhip_ctx *ctx, size_t bytes, int iters, double *gbps);   /* the `device` it was created on; < 0 on a NULL context */
 
 /* Per-kernel timing with HIP events on the context's stream (off by default).
  * When enabled every kernel launch is bracketed by two events; stats are read
