@@ -83,7 +83,6 @@ def algorithmic_bytes(kernel, w, h, out_w, out_h, frames_per_launch=1):
         "nlmeans_plane_n9": 3 * full * frames_per_launch,
         "decomb_plane": 5 * full,                                     # prev, cur, next, EEDI2 guess -> out
         "cropscale_lanczos_fused": full + out,
-        "cropscale_lapsharp_fused": full + out,                       # scaler + sharpen in one kernel: the 2160p picture is written once, never read back
         "lapsharp_3x3": 2 * out, "lapsharp_5x5": 2 * out,
         "copy_planes": full,                                          # the chain's copy-in: one input frame read + written per TWO output frames
         "eedi2_mask_passes": 3.5 * half,                              # field rows + the old mask's lower half -> srcp + new mask (all fields of a batch per launch)

@@ -680,227 +680,6 @@ __global__ __launch_bounds__(256) void scale8_up_kernel(ScaleBatch8 B)
     }
 }
 
-// ---- crop/scale + lapsharp 3 x 3 in one kernel (inside an hbhip_chain, when the sharpen stage sits directly behind the
-// scaler: what hb_avfilter_combine, hbavfilter.c:510-622, does for the reference's alias run) ---------------------------
-// scale8_up_kernel<32> with its output tile kept in LDS and sharpened there before the store (lapsharp3_rows_kernel's
-// walk, csrc/sharpen.hip): the scaled picture - 12.4 MB per 2160p frame, a fifth of the chain's bytes - is neither
-// written nor read back.  A workgroup owns SL_TW x SL_TH output pixels and computes the 256 x 34 scaled samples around
-// them (8 columns either side, of which the sharpen uses one - the tile's first column stays 16-byte aligned - and one row
-// above and below): 240 divides 3840 and 1920, so a 2160p luma row is 16 tiles where the plain scaler has 15, and the 34
-// rows tap at most 23 source rows at 2x, inside the same LDS frame (setup() checks both for the job's geometry).
-// Border rule as lapsharp.c:165-171 has it for a device picture (stride = hb_image_stride(width), nothing right of the
-// width but zeros: lapsharp3_rows_kernel's valid_w): rows y < 2, y > height - 2 and columns x < stride_border + 2,
-// x > width + stride_border - 2 keep the scaled sample.
-constexpr int SL_TW = 240, SL_TH = 32, SL_HX = 8, SL_ROWS = SL_TH + 2;
-struct LapFusePlane { int a, b, c, fast, kinv, stride_border; float mixf; double coef, strength; };
-struct ScaleLapBatch8 { ScaleBatch8 s; LapFusePlane lap[3]; };
-
-__global__ __launch_bounds__(256) void scale8_up_lap_kernel(ScaleLapBatch8 A)
-{
-    __shared__ uint32_t s_src[SU_MAXR][SU_SRC_DW];
-    __shared__ __attribute__((aligned(16))) uint32_t s_h[SU_PAIRS][SU_TW];
-    __shared__ uint4 s_v[SL_ROWS];
-    __shared__ uint32_t s_o[SL_ROWS][SU_TW / 4];                      // the scaled tile: row y0 - 1 + i, columns xb .. xb + 255
-    const ScaleBatch8 &B = A.s;
-    const int f = (int)blockIdx.z / 3, pl = (int)blockIdx.z - 3 * f;
-    const ScalePlane8 &P = B.p[pl];
-    const int x0 = blockIdx.x * SL_TW, y0 = blockIdx.y * SL_TH;
-    if (x0 >= P.dw || y0 >= P.dh) return;
-    const int t = threadIdx.x;
-    const int xb = x0 - SL_HX;                                       // column of thread / LDS column 0 (may be < 0)
-    const int xs = max(xb, 0), xe = min(xb + SU_TW, P.dw) - 1;       // computed columns inside the plane
-    const int ya = max(y0 - 1, 0), ye = min(y0 + SL_TH, P.dh - 1);   // computed rows inside the plane
-    const int cmin = P.bx[xs] & ~3, cmax = P.bx[xe] + 5;             // bx, by are non-decreasing
-    const int rmin = P.by[ya], nr = P.by[ye] + 5 - rmin + 1;
-    const int ndw = (cmax - cmin) / 4 + 1;                            // <= SU_SRC_DW - 2, nr <= SU_MAXR (CropScaleFilter::setup)
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
-    const int xc = xb + t, xh = min(max(xc, 0), P.dw - 1);
-    const int bxh = P.bx[xh];
-    const uint32_t hc01 = P.qx[3 * (size_t)xh], hc23 = P.qx[3 * (size_t)xh + 1], hc45 = P.qx[3 * (size_t)xh + 2];
-    if (t < SL_ROWS)
-    {
-        const int y = y0 - 1 + t;
-        if (y >= ya && y <= ye)
-            s_v[t] = make_uint4((uint32_t)(P.by[y] - rmin), P.qy[3 * (size_t)y], P.qy[3 * (size_t)y + 1], P.qy[3 * (size_t)y + 2]);
-    }
-    {
-        // staging exactly as scale8_up_kernel does it
-        const uint8_t *src = B.src[f][pl];
-        const int spitch = B.spitch[pl];
-        constexpr int RPW = SU_MAXR / 4;
-        uint32_t v[RPW][2];
-#pragma unroll
-        for (int j = 0; j < RPW; j++)
-        {
-            const int rr = wave + 4 * j;
-            v[j][0] = v[j][1] = 0;
-            if (rr < nr)
-            {
-                const uint8_t *row = src + (size_t)reflect_idx(rmin + rr, P.sh) * spitch;
-#pragma unroll
-                for (int h = 0; h < 2; h++)
-                {
-                    const int d = lane + 64 * h, col = cmin + 4 * d;
-                    if (d < ndw)
-                    {
-                        if (col >= 0 && col + 3 < P.sw && (((uintptr_t)(row + col)) & 3) == 0) v[j][h] = *reinterpret_cast<const uint32_t *>(row + col);
-                        else
-                        {
-#pragma unroll
-                            for (int k = 0; k < 4; k++) v[j][h] |= (uint32_t)row[reflect_idx(col + k, P.sw)] << (8 * k);
-                        }
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < RPW; j++)
-        {
-            const int rr = wave + 4 * j;
-            if (rr < nr)
-            {
-                if (lane < ndw) s_src[rr][lane] = v[j][0];
-                if (lane + 64 < ndw) s_src[rr][lane + 64] = v[j][1];
-            }
-        }
-    }
-    __syncthreads();
-    if (xc >= 0 && xc < P.dw)
-    {
-        const int o = bxh - cmin, dq = o >> 2, ob = o & 3;
-        const uint32_t sel01 = (uint32_t)ob | 0x0c000c00u | ((uint32_t)(ob + 1) << 16);
-        const uint32_t sel23 = (uint32_t)(ob + 2) | 0x0c000c00u | ((uint32_t)(ob + 3) << 16);
-        uint16_t *hp = reinterpret_cast<uint16_t *>(&s_h[0][0]) + 2 * t;
-        for (int rr = 0; rr < nr; rr++)
-        {
-            const uint32_t d0 = s_src[rr][dq], d1 = s_src[rr][dq + 1], d2 = s_src[rr][dq + 2];
-            int sm = dot2(__builtin_amdgcn_perm(d1, d0, sel01), hc01, 32);
-            sm = dot2(__builtin_amdgcn_perm(d1, d0, sel23), hc23, sm);
-            sm = dot2(__builtin_amdgcn_perm(d2, d1, sel01), hc45, sm);
-            const int h = min(max(sm >> 6, 0), 65535);
-            hp[(size_t)(rr >> 1) * (2 * SU_TW) + (rr & 1)] = (uint16_t)(h ^ 0x8000);
-        }
-    }
-    __syncthreads();
-    // vertical pass: a wave per row of the 34, the scaled samples to LDS; columns outside the plane hold 0 (what the
-    // sharpen reads right of the width)
-    {
-        const int xq = xb + 4 * lane;
-        uint32_t inside = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) if (xq + k >= 0 && xq + k < P.dw) inside |= 0xffu << (8 * k);
-        for (int i = wave; i < SL_ROWS; i += 4)
-        {
-            const int y = y0 - 1 + i;
-            if (y < ya || y > ye) continue;                            // wave-uniform
-            const uint4 vt = s_v[i];
-            const int ob = __builtin_amdgcn_readfirstlane((int)vt.x);
-            const uint32_t c01 = vt.y, c23 = vt.z, c45 = vt.w;
-            constexpr int K = 8192 + (32768 << 14) + (128 << 14);
-            int acc[4] = {K, K, K, K};
-            const uint4 *hq = reinterpret_cast<const uint4 *>(&s_h[ob >> 1][4 * lane]);
-            auto tap = [&](int pair_row, uint32_t cpair) {
-                const uint4 q = hq[(size_t)pair_row * (SU_TW / 4)];
-                acc[0] = dot2(q.x, cpair, acc[0]); acc[1] = dot2(q.y, cpair, acc[1]);
-                acc[2] = dot2(q.z, cpair, acc[2]); acc[3] = dot2(q.w, cpair, acc[3]);
-            };
-            if (!(ob & 1)) { tap(0, c01); tap(1, c23); tap(2, c45); }
-            else { tap(0, c01 << 16); tap(1, (c01 >> 16) | (c23 << 16)); tap(2, (c23 >> 16) | (c45 << 16)); tap(3, c45 >> 16); }
-            uint32_t out = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) out |= (uint32_t)min(max(acc[k] >> 22, 0), 255) << (8 * k);
-            s_o[i][lane] = out & inside;
-        }
-    }
-    __syncthreads();
-    // the sharpen: lanes 2 .. 61 own the tile's 60 dword columns, a wave eight of its rows (lapsharp3_rows_kernel's walk,
-    // rows from LDS instead of memory)
-    const LapFusePlane &L = A.lap[pl];
-    const int x = xb + 4 * lane;
-    if (lane < SL_HX / 4 || lane >= (SL_HX + SL_TW) / 4 || x >= P.dw) return;
-    const int ys = y0 + 8 * wave;
-    if (ys >= P.dh) return;
-    int u_prev[4], u_cur[4], v_cur[4], m_cur[4];
-    auto load_row = [&](int i, int (&u)[4], int (&v)[4], int (&m)[4]) {
-        const uint32_t w0 = s_o[i][lane - 1], w1 = s_o[i][lane], w2 = s_o[i][lane + 1];
-        const int bb[6] = { (int)(w0 >> 24), (int)(w1 & 0xff), (int)((w1 >> 8) & 0xff), (int)((w1 >> 16) & 0xff), (int)(w1 >> 24), (int)(w2 & 0xff) };
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-        {
-            const int h = bb[k] + bb[k + 2];
-            m[k] = bb[k + 1];
-            u[k] = __mul24(L.a, h) + __mul24(L.b, m[k]);
-            v[k] = __mul24(L.b, h) + __mul24(L.c, m[k]);
-        }
-    };
-    {
-        int v_tmp[4], m_tmp[4];
-        load_row(8 * wave, u_prev, v_tmp, m_tmp);                     // LDS row i = y - (y0 - 1)
-        load_row(8 * wave + 1, u_cur, v_cur, m_cur);
-    }
-    uint32_t copy_cols = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-        if (x + k < L.stride_border + 2 || x + k > P.dw + L.stride_border - 2) copy_cols |= 1u << k;
-    const bool full_dword = x + 3 < P.dw;
-    uint8_t *dst = B.dst[f][pl];
-    const int y_end = min(ys + 8, P.dh);
-#pragma unroll
-    for (int r = 0; r < 8; r++)
-    {
-        const int y = ys + r;
-        if (y >= y_end) break;
-        int u_next[4], v_next[4], m_next[4];
-        load_row(8 * wave + r + 2, u_next, v_next, m_next);
-        const bool row_copy = (y < 2) || (y > P.dh - 2);
-        uint32_t packed = 0;
-        if (row_copy)
-        {
-#pragma unroll
-            for (int k = 0; k < 4; k++) packed |= (uint32_t)m_cur[k] << (8 * k);
-        }
-        else
-        {
-            if (L.fast)
-            {
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                {
-                    const int centre = m_cur[k];
-                    const int acc = u_prev[k] + v_cur[k] + u_next[k];
-                    int out = (int)((float)(acc - __mul24(L.kinv, centre)) * L.mixf) + centre;
-                    out = min(max(out, 0), 255);
-                    packed |= (uint32_t)out << (8 * k);
-                }
-            }
-            else
-            {
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                {
-                    const int centre = m_cur[k];
-                    const int acc = u_prev[k] + v_cur[k] + u_next[k];
-                    const double mixed = (((double)acc * L.coef) - (double)centre) * L.strength;   // lapsharp.c:174-175
-                    int out = (int)(short)(int)mixed + centre;
-                    out = min(max(out, 0), 255);
-                    packed |= (uint32_t)out << (8 * k);
-                }
-            }
-            if (copy_cols)
-            {
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if ((copy_cols >> k) & 1u) packed = (packed & ~(0xffu << (8 * k))) | ((uint32_t)m_cur[k] << (8 * k));
-            }
-        }
-        uint8_t *d = dst + (size_t)y * B.dpitch[pl] + x;
-        if (full_dword && (((uintptr_t)d) & 3) == 0) *reinterpret_cast<uint32_t *>(d) = packed;
-        else for (int k = 0; k < 4 && x + k < P.dw; k++) d[k] = (uint8_t)(packed >> (8 * k));
-#pragma unroll
-        for (int k = 0; k < 4; k++) { u_prev[k] = u_cur[k]; u_cur[k] = u_next[k]; v_cur[k] = v_next[k]; m_cur[k] = m_next[k]; }
-    }
-}
-
 // ---- 10 / 12-bit planes: the same arithmetic at the samples' own depth --------------------------------------------
 // zimg resizes a uint16 plane in place of its depth: per pass dst = clamp((sum c[k] * src[k] + (1 << 13)) >> 14, 0,
 // vmax) (oracle/alias_oracle.c: orc_cropscale_plane_fx16).  Samples and the plane between the passes are below 4096,
@@ -1181,14 +960,6 @@ public:
                     if (by[std::min(y0 + SU_TH, dh) - 1] + 5 - by[y0] + 1 > SU_MAXR) up6 = false;
                 for (int y0 = 0; y0 < dh && tall; y0 += 2 * SU_TH)
                     if (by[std::min(y0 + 2 * SU_TH, dh) - 1] + 5 - by[y0] + 1 > SU_MAXR) tall = false;
-                // the scaler + sharpen kernel's tiles (scale8_up_lap_kernel: 256 columns around 240, 34 rows around 32)
-                for (int x0 = 0; x0 < dw && lap_fits; x0 += SL_TW)
-                {
-                    const int xs = std::max(x0 - SL_HX, 0), xe = std::min(x0 - SL_HX + SU_TW, dw) - 1;
-                    if ((bx[xe] + 5 - (bx[xs] & ~3)) / 4 + 1 > SU_SRC_DW - 2) lap_fits = false;
-                }
-                for (int y0 = 0; y0 < dh && lap_fits; y0 += SL_TH)
-                    if (by[std::min(y0 + SL_TH, dh - 1)] + 5 - by[std::max(y0 - 1, 0)] + 1 > SU_MAXR) lap_fits = false;
             }
         }
         size_t need = 0;
@@ -1236,20 +1007,6 @@ public:
                         B.src[k][c] = window(ins[i0 + k], c); B.dst[k][c] = outs[i0 + k]->plane[c];
                     }
                 }
-                if (lap_on)
-                {
-                    ScaleLapBatch8 A;
-                    A.s = B;
-                    for (int c = 0; c < 3; c++)
-                    {
-                        LapFusePlane &L = A.lap[c];
-                        L.a = lap.a[c]; L.b = lap.b[c]; L.c = lap.c[c]; L.fast = lap.fast[c]; L.kinv = lap.kinv[c];
-                        L.stride_border = lap.stride_border[c]; L.mixf = lap.mixf[c]; L.coef = lap.coef[c]; L.strength = lap.strength[c];
-                    }
-                    const dim3 gl((out_geo.pw[0] + SL_TW - 1) / SL_TW, (out_geo.ph[0] + SL_TH - 1) / SL_TH, 3 * m);
-                    HBHIP_LAUNCH(ctx, "cropscale_lapsharp_fused", scale8_up_lap_kernel, gl, dim3(256), 0, A);
-                    continue;
-                }
                 const dim3 grid((out_geo.pw[0] + SU_TW - 1) / SU_TW, (out_geo.ph[0] + SU_TH - 1) / SU_TH, 3 * m);
                 const dim3 grid_tall(grid.x, (out_geo.ph[0] + 2 * SU_TH - 1) / (2 * SU_TH), grid.z);
                 if (in_geo.bps == 1 && tall) HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", scale8_up_kernel<2 * SU_TH>, grid_tall, dim3(256), 0, B);
@@ -1284,22 +1041,6 @@ public:
     }
 
     int process(DevPicture *in, DevPicture *out) override { return process_many(&in, &out, 1); }
-    // a 3 x 3 sharpen stage directly behind an 8-bit six-tap scale of all three planes: from now on this stage writes
-    // the sharpened picture (scale8_up_lap_kernel)
-    bool fuse_next(hbhip_filter *next) override
-    {
-        if (lap_on || !next || in_geo.bps != 1 || !up6 || !lap_fits || identity[0] || identity[1] || identity[2]) return false;
-        const PicGeometry &g = next->in_geo, &h = next->out_geo;
-        if (g.width != out_geo.width || g.height != out_geo.height || g.depth != out_geo.depth || g.log2_cw != out_geo.log2_cw ||
-            g.log2_ch != out_geo.log2_ch || h.width != g.width || h.height != g.height || h.depth != g.depth)
-            return false;
-        if (!next->lap_fuse_params(&lap)) return false;
-        lap_on = true;
-        return true;
-    }
-    bool lap_on = false;        // the sharpen stage behind this one rides along (fuse_next)
-    bool lap_fits = true;       // ... and its tiles fit the LDS frame
-    LapFuse lap;
     bool up6 = true;            // six taps either way and every tile fits the fused kernel's LDS frame
     bool tall = true;           // ... also at 32 rows per tile
     hbhip_cropscale_params par;

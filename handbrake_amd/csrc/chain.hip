@@ -298,14 +298,6 @@ int hbhip_chain_create(hbhip_ctx *ctx, hbhip_filter *const *stages, int n_stages
     if (!c) return HBHIP_ERR_NOMEM;
     c->ctx = ctx;
     c->st.assign(stages, stages + n_stages);
-    // kernel-level fusion of neighbours on one context (hbhip_filter::fuse_next): the absorbed stage stays the caller's
-    // object, the chain just never runs it
-    if (hbhip_dev_int("HBHIP_CHAIN_FUSE", 1))
-        for (size_t i = 0; i + 1 < c->st.size();)
-        {
-            if (c->st[i]->ctx == c->st[i + 1]->ctx && c->st[i]->fuse_next(c->st[i + 1])) c->st.erase(c->st.begin() + i + 1);
-            else i++;
-        }
     (void)hipSetDevice(ctx->device);
     for (int i = 0; i <= n_stages + 2; i++)
     {

@@ -394,6 +394,31 @@ int hbhip_filter::process_dev_batch(const hbhip_dev_frame *in, int n_in, int64_t
 }
 
 // ---------------------------------------------------------------- C ABI
+// ---- the on-box copy ceiling (SURVEY 8d: "measure an on-box ... ceiling and report against both") -----------------
+// A float4 grid-stride copy, the way /opt/skills/guides/MI355X_MICROARCH.md measures its 6.29 TB/s: 16 bytes per lane and
+// trip, enough workgroups to fill every CU several times over, buffers far past the 256 MB Infinity Cache.
+// U float4 per lane in flight and trip; NT: non-temporal stores (the written buffer is not read again)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void copy_f4_kernel(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + (size_t)(U - 1) * stride < n; i += (size_t)U * stride)
+    {
+        f32x4 v[U];
+#pragma unroll
+        for (int k = 0; k < U; k++) v[k] = src[i + (size_t)k * stride];
+#pragma unroll
+        for (int k = 0; k < U; k++)
+        {
+            if (NT) __builtin_nontemporal_store(v[k], &dst[i + (size_t)k * stride]);
+            else dst[i + (size_t)k * stride] = v[k];
+        }
+    }
+    for (; i < n; i += stride) dst[i] = src[i];
+}
+
 extern "C" {
 
 int hbhip_abi_version(void) { return HBHIP_ABI_VERSION; }
@@ -545,15 +570,6 @@ int hbhip_ctx_device_name(hbhip_ctx *ctx, char *buf, int len)
     return HBHIP_OK;
 }
 
-// ---- the on-box copy ceiling (SURVEY 8d: "measure an on-box ... ceiling and report against both") -----------------
-// A float4 grid-stride copy, the way /opt/skills/guides/MI355X_MICROARCH.md measures its 6.29 TB/s: 16 bytes per lane and
-// trip, enough workgroups to fill every CU several times over, buffers far past the 256 MB Infinity Cache.
-__global__ __launch_bounds__(256) void copy_f4_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n)
-{
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
-}
-
 int hbhip_ctx_copy_bandwidth(hbhip_ctx *ctx, size_t bytes, int iters, double *gbps)
 {
     if (!ctx || !gbps || bytes < (1u << 20) || iters < 1) return HBHIP_ERR_ARG;
@@ -567,16 +583,25 @@ int hbhip_ctx_copy_bandwidth(hbhip_ctx *ctx, size_t bytes, int iters, double *gb
         hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
         rc = ctx->fail(hipErrorOutOfMemory, "hbhip_ctx_copy_bandwidth: buffers");
     if (rc == HBHIP_OK && hipMemsetAsync(a, 1, n * sizeof(float4), ctx->stream) != hipSuccess) rc = HBHIP_ERR_HIP;
-    for (int i = 0; rc == HBHIP_OK && i < iters + 1; i++)                        // the first pass warms up
-    {
-        (void)hipEventRecord(e0, ctx->stream);
-        copy_f4_kernel<<<dim3(256 * 16), dim3(256), 0, ctx->stream>>>(a, b, n);
-        (void)hipEventRecord(e1, ctx->stream);
-        if (hipEventSynchronize(e1) != hipSuccess) { rc = ctx->fail(hipGetLastError(), "copy_f4_kernel"); break; }
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, e0, e1);
-        if (i > 0 && (best_ms == 0.0 || ms < best_ms)) best_ms = ms;
-    }
+    // the ceiling is whatever the best of a few shapes reaches: one or four float4 in flight per lane, plain or non-temporal
+    // stores, 8 or 32 workgroups per CU
+    for (int shape = 0; rc == HBHIP_OK && shape < 6; shape++)
+        for (int i = 0; rc == HBHIP_OK && i < iters + 1; i++)                    // the first pass of a shape warms up
+        {
+            const dim3 grid(256 * (shape < 3 ? 8 : 32));
+            (void)hipEventRecord(e0, ctx->stream);
+            switch (shape % 3)
+            {
+                case 0: copy_f4_kernel<1, false><<<grid, dim3(256), 0, ctx->stream>>>((const f32x4 *)a, (f32x4 *)b, n); break;
+                case 1: copy_f4_kernel<4, false><<<grid, dim3(256), 0, ctx->stream>>>((const f32x4 *)a, (f32x4 *)b, n); break;
+                default: copy_f4_kernel<4, true><<<grid, dim3(256), 0, ctx->stream>>>((const f32x4 *)a, (f32x4 *)b, n); break;
+            }
+            (void)hipEventRecord(e1, ctx->stream);
+            if (hipEventSynchronize(e1) != hipSuccess) { rc = ctx->fail(hipGetLastError(), "copy_f4_kernel"); break; }
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if (i > 0 && (best_ms == 0.0 || ms < best_ms)) best_ms = ms;
+        }
     if (a) (void)hipFree(a);
     if (b) (void)hipFree(b);
     if (e0) (void)hipEventDestroy(e0);

@@ -290,15 +290,6 @@ struct hbhip_filter
         }
         return HBHIP_OK;
     }
-    // ---- kernel-level fusion of adjacent stages of a chain: what hb_avfilter_combine (hbavfilter.c:510-622) does for the
-    // reference's alias run, one graph - here one kernel - for crop/scale + the stage behind it.
-    // A 3 x 3 sharpen stage describes its arithmetic (lapsharp.c:125-182: taps corner a / edge b / centre c, the mix, the
-    // border rule's stride_border) so that the stage in front can apply it to its own output tile while that is in LDS.
-    struct LapFuse { int a[3], b[3], c[3], fast[3], kinv[3], stride_border[3]; float mixf[3]; double coef[3], strength[3]; };
-    virtual bool lap_fuse_params(LapFuse *) { return false; }
-    // try to take over the work of `next`, the stage directly behind this one on the same context: true = from now on this
-    // stage's output is what `next` would have made of it, and the chain leaves `next` out
-    virtual bool fuse_next(hbhip_filter *) { return false; }
     // ---- pipelined host path (hbhip_filter_submit_async): one-in / one-out filters ----
     virtual DevPicture *acquire_output() { return nullptr; }
     virtual int process_pair(DevPicture *, DevPicture *) { return HBHIP_ERR_UNSUPPORTED; }   // in -> out on ctx->stream

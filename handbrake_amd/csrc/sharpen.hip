@@ -770,23 +770,6 @@ public:
         for (int pl = 0; pl < 3; pl++)
             mix_fast[pl] = LAP_TABLE[par.kernel[pl]].size == 3 && lap_float_mix_cached(par.kernel[pl], par.strength[pl], mix_k[pl], mix_f[pl]);
     }
-    // inside a chain the stage in front may do this filter's work on its own output tile (csrc/alias.hip:
-    // scale8_up_lap_kernel): every plane a 3 x 3 kernel on 8-bit samples; frames there are device pictures, so the border
-    // rule's stride is hb_image_stride of the width (process_many below: in_is_dev)
-    bool lap_fuse_params(LapFuse *o) override
-    {
-        if (in_geo.bps != 1) return false;
-        for (int c = 0; c < 3; c++)
-        {
-            const LapKernel &k = LAP_TABLE[par.kernel[c]];
-            if (k.size != 3) return false;
-            o->a[c] = k.tap[0]; o->b[c] = k.tap[1]; o->c[c] = k.tap[4];
-            o->coef[c] = k.coef; o->strength[c] = par.strength[c];
-            o->fast[c] = mix_fast[c]; o->kinv[c] = mix_k[c]; o->mixf[c] = mix_f[c];
-            o->stride_border[c] = (hbhip_align_up(in_geo.pw[c], 64) - in_geo.pw[c]) / 2;
-        }
-        return true;
-    }
     // up to LS_FRAMES frames per launch when every plane uses a 3x3 kernel
     int process_many(DevPicture *const *ins, DevPicture *const *outs, int n) override
     {

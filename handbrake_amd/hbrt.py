@@ -195,7 +195,7 @@ class Chain:
 
 
 # hb_filter_object_t ids (handbrake/common.h:1729-1778; include/hbhip_libhb.h)
-FILTER_ID = {"comb_detect": 4, "decomb": 6, "yadif": 7, "bwdif": 9, "vfr": 11, "denoise": 14, "nlmeans": 16, "chroma_smooth": 17,
+FILTER_ID = {"comb_detect": 4, "decomb": 6, "yadif": 7, "bwdif": 9, "vfr": 11, "render_sub": 21, "denoise": 14, "nlmeans": 16, "chroma_smooth": 17,
              "rotate": 19, "crop_scale": 22, "lapsharp": 24, "unsharp": 26, "grayscale": 28, "pad": 30,
              "colorspace": 32, "format": 33}
 
@@ -225,6 +225,16 @@ class Job(Chain):
             raise RuntimeError(f"job init failed: {filters}")
         self.eof = False
 
+    def push_subtitle(self, overlay, start: int, stop: int = -1, window=None):
+        """A decoded bitmap subtitle for the job's burn-in track: overlay = (x, y, (Y, Cb, Cr, A) uint8 4:4:4 planes), shown
+        from start to stop (90 kHz; -1: until the next one) on a canvas of `window` = (w, h) (default: the frame)."""
+        arr, keep = overlay_array([overlay])
+        self._rt.hbh_chain_push_subtitle.restype = C.c_int
+        self._rt.hbh_chain_push_subtitle.argtypes = [C.c_void_p, C.POINTER(Overlay), C.c_int64, C.c_int64, C.c_int, C.c_int]
+        ww, wh = window if window else (self.width, self.height)
+        if self._rt.hbh_chain_push_subtitle(self._h, arr, start, stop, ww, wh) != 0:
+            raise RuntimeError("hbh_chain_push_subtitle failed (no burn-in track on this job?)")
+
     def stages(self):
         buf = C.create_string_buffer(2048)
         self._rt.hbh_chain_describe(self._h, buf, 2048)
@@ -253,6 +263,18 @@ def set_job_device(index: int = -1):
     rt.hbh_set_job_device.argtypes = [C.c_int]
     rt.hbh_set_job_device.restype = None
     rt.hbh_set_job_device(index)
+
+
+SUBSOURCE = {"vobsub": 0, "pgs": 6, "dvb": 9}          # enum subsource, handbrake/common.h:1286-1298
+
+
+def set_job_subtitle(source=None):
+    """Jobs opened from now on carry one subtitle track of this source ("pgs", "vobsub", "dvb") marked for burn-in - what
+    rendersub.c's init looks for in job->list_subtitle (:1199-1209); None = no track."""
+    rt = runtime()
+    rt.hbh_set_job_subtitle.argtypes = [C.c_int]
+    rt.hbh_set_job_subtitle.restype = None
+    rt.hbh_set_job_subtitle(-1 if source is None else SUBSOURCE[source])
 
 
 def set_threaded(on: bool):

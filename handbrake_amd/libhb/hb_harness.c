@@ -48,6 +48,8 @@ struct hbh_chain_s
     int                 eof_seen;
     int                 failed;
     hb_job_t           *job;         /* hbh_job_open: what init->job points to */
+    hb_subtitle_t      *subtitle;    /*               the job's burn-in track, if any */
+    hb_title_t          title;
 };
 
 static hb_filter_object_t *clone_filter(const hb_filter_object_t *proto, const char *settings)
@@ -71,6 +73,8 @@ static int g_discard = 0;            /* threaded mode: count and drop the last s
  * returns when every stage has finished, so output is complete once it returns. */
 static int g_job_device = -1;        /* job->hw_device_index of jobs opened from now on (common.h:991; -1 = not set) */
 void hbh_set_job_device(int index) { g_job_device = index; }
+static int g_job_subtitle = -1;      /* jobs opened from now on carry one subtitle track of this source marked for burn-in */
+void hbh_set_job_subtitle(int source) { g_job_subtitle = source; }
 void hbh_set_threaded(int on) { g_threaded = on; }
 void hbh_set_discard_output(int on) { g_discard = on; }
 
@@ -209,6 +213,27 @@ hbh_chain_t *hbh_job_open(int nfilters, const int *ids, const char *const *setti
     pjob->input_pix_fmt = pix_fmt;
     pjob->hw_device_index = g_job_device;
     pjob->list_filter = hb_list_init();
+    if (g_job_subtitle >= 0)
+    {
+        /* a track marked for burn-in (rendersub.c:1199-1209 looks for config.dest == RENDERSUB); its decoder's output is
+         * what hbh_chain_push_subtitle() puts into fifo_out */
+        hb_subtitle_t *sub = calloc(1, sizeof(*sub));
+        c->title.geometry.width = width; c->title.geometry.height = height;
+        c->title.geometry.par.num = c->title.geometry.par.den = 1;
+        pjob->title = &c->title;
+        pjob->list_subtitle = hb_list_init();
+        pjob->list_attachment = hb_list_init();
+        if (sub != NULL)
+        {
+            sub->source = g_job_subtitle;
+            sub->format = PICTURESUB;
+            sub->config.dest = RENDERSUB;
+            sub->width = width; sub->height = height;
+            sub->fifo_out = hb_fifo_init(8, 1);
+            hb_list_add(pjob->list_subtitle, sub);
+            c->subtitle = sub;
+        }
+    }
     for (int i = 0; i < nfilters; i++)
     {
         hb_filter_object_t *f = hb_filter_init(ids[i]);
@@ -241,6 +266,20 @@ hbh_chain_t *hbh_job_open(int nfilters, const int *ids, const char *const *setti
             }
             hb_log("Failure to initialise filter '%s', disabling", f->name);
             hb_list_rem(pjob->list_filter, f);
+            hb_filter_close(&f);
+            continue;
+        }
+        i++;
+    }
+    /* post_init: the filters learn the final job (work.c:1891-1898); one that fails it is dropped like a failed init */
+    for (int i = 0; i < hb_list_count(pjob->list_filter);)
+    {
+        hb_filter_object_t *f = hb_list_item(pjob->list_filter, i);
+        if (f->post_init != NULL && f->post_init(f, pjob))
+        {
+            hb_log("Failure to initialise filter '%s', disabling", f->name);
+            hb_list_rem(pjob->list_filter, f);
+            if (f->close != NULL) f->close(f);
             hb_filter_close(&f);
             continue;
         }
@@ -497,8 +536,39 @@ void hbh_chain_close(hbh_chain_t *c)
         free(f);
     }
     hb_buffer_list_close(&c->out);
+    if (c->subtitle != NULL)
+    {
+        hb_fifo_close(&c->subtitle->fifo_out);
+        free(c->subtitle);
+    }
+    if (c->job != NULL)
+    {
+        hb_list_close(&c->job->list_subtitle);
+        hb_list_close(&c->job->list_attachment);
+    }
     free(c->job);
     free(c);
+}
+
+/* A decoded bitmap subtitle (what decpgssub / decvobsub hand on): a YUVA 4:4:4 picture at (x, y) of a window_w x window_h
+ * canvas, shown from start to stop (90 kHz; stop < 0: until the next one).  Goes into the burn-in track's fifo_out, where
+ * rendersub picks it up with the next frame. */
+int hbh_chain_push_subtitle(hbh_chain_t *c, const hbh_overlay_t *ov, int64_t start, int64_t stop, int window_w, int window_h)
+{
+    if (c == NULL || c->subtitle == NULL || ov == NULL) return -1;
+    hb_buffer_t *o = hb_frame_buffer_init(AV_PIX_FMT_YUVA444P, ov->width, ov->height);
+    if (o == NULL) return -1;
+    for (int p = 0; p <= o->f.max_plane; p++)
+        for (int y = 0; y < o->plane[p].height; y++)
+            memcpy(o->plane[p].data + (size_t)y * o->plane[p].stride, ov->plane[p] + (size_t)y * ov->stride[p], o->plane[p].width);
+    o->f.x = ov->x;
+    o->f.y = ov->y;
+    o->f.window_width = window_w;
+    o->f.window_height = window_h;
+    o->s.start = start;
+    o->s.stop = stop < 0 ? AV_NOPTS_VALUE : stop;
+    hb_fifo_push(c->subtitle->fifo_out, o);
+    return 0;
 }
 
 /* ---- compositor objects (hb_blend_object_t, handbrake/common.h:1813-1828) ------------------

@@ -38,6 +38,9 @@ hbh_chain_t *hbh_job_open(int nfilters, const int *ids, const char *const *setti
                           int vrate_num, int vrate_den, int use_hip);
 /* job->hw_device_index (common.h:991) of jobs opened from now on: which GPU the job's drop-ins run on; -1 = not set */
 void hbh_set_job_device(int index);
+/* jobs opened from now on carry one subtitle track of this source (enum subsource: 0 VOBSUB, 6 PGSSUB, ...) marked for
+ * burn-in, which is what makes rendersub.c's init find its track (:1199-1209); -1 = none */
+void hbh_set_job_subtitle(int source);
 /* "|"-separated names of the stages as initialised; returns their count */
 int hbh_chain_describe(hbh_chain_t *c, char *buf, int len);
 /* Chains opened from now on run every stage on its own thread with a fifo in front (filter_loop, work.c:2527-2600);
@@ -75,6 +78,10 @@ typedef struct
 /* Run a compositor object (address of an hb_blend_object_t) on one frame, in place. */
 int hbh_blend_run(const void *proto, int pix_fmt, int width, int height, int chroma_location, int overlay_fmt,
                   uint8_t *const plane[3], const int stride[3], int n_overlays, const hbh_overlay_t *ov, int passes);
+
+/* a decoded bitmap subtitle for the job's burn-in track (see hbh_set_job_subtitle): shown from start to stop (90 kHz, stop < 0:
+ * until the next one) on a window_w x window_h canvas */
+int hbh_chain_push_subtitle(hbh_chain_t *c, const hbh_overlay_t *ov, int64_t start, int64_t stop, int window_w, int window_h);
 
 void hbhip_set_log_level(int level);
 

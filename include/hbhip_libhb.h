@@ -488,6 +488,34 @@ typedef struct hb_interjob_s
     int   context_size;
 } hb_interjob_t;
 hb_interjob_t *hb_interjob_get(hb_handle_t *);
+/* what rendersub.c reads of a subtitle track (common.h:1254-1332) and of an attachment (:1339-1345) */
+typedef struct hb_data_s { uint8_t *bytes; size_t size; } hb_data_t;
+typedef struct hb_subtitle_config_s
+{
+    enum subdest { RENDERSUB, PASSTHRUSUB } dest;
+    int      force, default_track, external_filename_set;
+    int64_t  offset;
+} hb_subtitle_config_t;
+struct hb_subtitle_s
+{
+    int  id, track, out_track;
+    hb_subtitle_config_t config;
+    enum subtype { PICTURESUB, TEXTSUB } format;
+    enum subsource { VOBSUB, CC608SUB, CC708SUB, UTF8SUB, TX3GSUB, SSASUB, PGSSUB, IMPORTSRT, IMPORTSSA, DVBSUB,
+                     SRTSUB = IMPORTSRT } source;
+    uint32_t     palette[16];
+    uint8_t      palette_set;
+    int          width, height;
+    hb_data_t   *extradata;
+    hb_fifo_t   *fifo_in, *fifo_raw, *fifo_sync, *fifo_out;          /* rendersub takes its bitmaps from fifo_out */
+};
+typedef struct hb_attachment_s
+{
+    enum attachtype { FONT_TTF_ATTACH, FONT_OTF_ATTACH, HB_ART_ATTACH } type;
+    char *name, *data;
+    int   size;
+} hb_attachment_t;
+typedef struct hb_title_s { hb_geometry_t geometry; } hb_title_t;
 struct hb_job_s                                                     /* the fields of hb_job_t the swap and the filters read */
 {
     hb_list_t   *list_filter;
@@ -496,6 +524,9 @@ struct hb_job_s                                                     /* the field
     int          hw_device_index;                                   /* common.h:991: which adapter the job runs on; -1 = default */
     hb_handle_t *h;
     volatile int done;
+    int          crop[4];                                           /* rendersub keeps subtitles inside the picture that is left */
+    hb_title_t  *title;
+    hb_list_t   *list_subtitle, *list_attachment;
 };
 hb_filter_object_t *hb_filter_get(int filter_id);                   /* the registered CPU prototype, or NULL */
 hb_filter_object_t *hb_filter_init(int filter_id);                  /* a copy of it, ready for settings */
@@ -519,6 +550,7 @@ struct hb_motion_metric_object_s
 };
 
 extern hb_motion_metric_object_t hb_motion_metric;                 /* motion_metric.c:306-312 (tests: from oracle/_ref) */
+extern hb_blend_object_t         hb_blend;                         /* blend.c:40-46 (tests: from oracle/_ref) */
 /* stand-in only: the helper object a hw pipeline supplies for hw_pix_fmt (inside libhb: one more `case` in
  * vfr.c:76-108 / rendersub.c:1129-1161).  kind 0 = motion metric, 1 = blend.  NULL when none. */
 void        hbhip_rt_register_hw_helper(int kind, int hw_pix_fmt, void *object);
