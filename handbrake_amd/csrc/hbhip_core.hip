@@ -397,10 +397,10 @@ int hbhip_filter::process_dev_batch(const hbhip_dev_frame *in, int n_in, int64_t
 // ---- the on-box copy ceiling ("measure an on-box ... ceiling and report against both") -----------------
 // A float4 grid-stride copy, the way /opt/skills/guides/MI355X_MICROARCH.md measures its 6.29 TB/s: 16 bytes per lane and
 // trip, enough workgroups to fill every CU several times over, buffers far past the 256 MB Infinity Cache.
-// U float4 per lane in flight and trip; NT: non-temporal stores (the written buffer is not read again)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// U float4 per lane in flight and trip; NT: non-temporal loads and stores (neither buffer is touched again)
 template <int U, bool NT>
-__global__ __launch_bounds__(256) void copy_f4_kernel(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst, size_t n)
+__global__ __launch_bounds__(1024) void copy_f4_kernel(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst, size_t n)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256) void copy_f4_kernel(const f32x4 *__restrict__ 
     {
         f32x4 v[U];
 #pragma unroll
-        for (int k = 0; k < U; k++) v[k] = src[i + (size_t)k * stride];
+        for (int k = 0; k < U; k++) v[k] = NT ? __builtin_nontemporal_load(&src[i + (size_t)k * stride]) : src[i + (size_t)k * stride];
 #pragma unroll
         for (int k = 0; k < U; k++)
         {
@@ -583,18 +583,27 @@ int hbhip_ctx_copy_bandwidth(hbhip_ctx *ctx, size_t bytes, int iters, double *gb
         hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
         rc = ctx->fail(hipErrorOutOfMemory, "hbhip_ctx_copy_bandwidth: buffers");
     if (rc == HBHIP_OK && hipMemsetAsync(a, 1, n * sizeof(float4), ctx->stream) != hipSuccess) rc = HBHIP_ERR_HIP;
-    // the ceiling is whatever the best of a few shapes reaches: one or four float4 in flight per lane, plain or non-temporal
-    // stores, 8 or 32 workgroups per CU
-    for (int shape = 0; rc == HBHIP_OK && shape < 6; shape++)
+    // the ceiling is whatever the best of a few shapes reaches: 1 / 4 / 8 float4 in flight per lane, plain or non-temporal
+    // accesses, 256 or 1024 lanes per workgroup, 8 or 32 workgroups per CU - and the runtime's own device-to-device copy
+    struct Shape { int u, nt, block, per_cu; };
+    static const Shape shapes[] = { {1, 0, 256, 8}, {4, 0, 256, 8}, {4, 1, 256, 8}, {8, 1, 256, 8}, {4, 0, 256, 32}, {4, 1, 256, 32},
+                                    {4, 1, 1024, 2}, {8, 1, 1024, 2}, {8, 0, 512, 4}, {0, 0, 0, 0} /* hipMemcpyAsync */ };
+    for (const Shape &sh : shapes)
         for (int i = 0; rc == HBHIP_OK && i < iters + 1; i++)                    // the first pass of a shape warms up
         {
-            const dim3 grid(256 * (shape < 3 ? 8 : 32));
             (void)hipEventRecord(e0, ctx->stream);
-            switch (shape % 3)
+            if (sh.u == 0)
+                (void)hipMemcpyAsync(b, a, n * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream);
+            else
             {
-                case 0: copy_f4_kernel<1, false><<<grid, dim3(256), 0, ctx->stream>>>((const f32x4 *)a, (f32x4 *)b, n); break;
-                case 1: copy_f4_kernel<4, false><<<grid, dim3(256), 0, ctx->stream>>>((const f32x4 *)a, (f32x4 *)b, n); break;
-                default: copy_f4_kernel<4, true><<<grid, dim3(256), 0, ctx->stream>>>((const f32x4 *)a, (f32x4 *)b, n); break;
+                const dim3 grid(256 * sh.per_cu), block(sh.block);
+                const f32x4 *pa = (const f32x4 *)a;
+                f32x4 *pb = (f32x4 *)b;
+                if (sh.u == 1)                copy_f4_kernel<1, false><<<grid, block, 0, ctx->stream>>>(pa, pb, n);
+                else if (sh.u == 4 && !sh.nt) copy_f4_kernel<4, false><<<grid, block, 0, ctx->stream>>>(pa, pb, n);
+                else if (sh.u == 4)           copy_f4_kernel<4, true><<<grid, block, 0, ctx->stream>>>(pa, pb, n);
+                else if (!sh.nt)              copy_f4_kernel<8, false><<<grid, block, 0, ctx->stream>>>(pa, pb, n);
+                else                          copy_f4_kernel<8, true><<<grid, block, 0, ctx->stream>>>(pa, pb, n);
             }
             (void)hipEventRecord(e1, ctx->stream);
             if (hipEventSynchronize(e1) != hipSuccess) { rc = ctx->fail(hipGetLastError(), "copy_f4_kernel"); break; }

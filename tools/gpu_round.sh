@@ -11,7 +11,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd $R
 if [ "$MODE" = "tests" ]; then
-  timeout 600 python -m pytest tests -m gpu -x -q -n 4 "$@" > $OUT/pytest.log 2>&1
+  timeout 900 python -m pytest tests -m gpu -x -q -n 4 "$@" > $OUT/pytest.log 2>&1
   echo "pytest rc=$?" >> $OUT/pytest.log
   tail -5 $OUT/pytest.log
 fi
@@ -19,6 +19,10 @@ fi
 # the driver's command line first (defaults), then the other workloads
 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err
 head -c 1200 $OUT/bench_default.json; echo
+for C in corners random; do
+  timeout 300 python bench.py --content $C --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_chain_$C.json 2> $OUT/bench_chain_$C.err
+  head -c 400 $OUT/bench_chain_$C.json; echo
+done
 for WL in chain2160 decomb_eedi2 nlmeans; do
   timeout 240 python bench.py --workload $WL --steps 20 --warmup 3 --no-pcie > $OUT/bench_$WL.json 2> $OUT/bench_$WL.err
   head -c 600 $OUT/bench_$WL.json; echo
