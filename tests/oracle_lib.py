@@ -47,6 +47,21 @@ def ref():
     return _ref
 
 
+_metal = None
+
+
+def metal():
+    """oracle/_ref/libhbmetal.so: the reference's Metal compute shaders compiled as host C++ (oracle/ref_wrap/metal/metal_wrap.h);
+    None where it has not been built."""
+    global _metal
+    if _metal is None:
+        path = os.path.join(ROOT, "oracle", "_ref", "libhbmetal.so")
+        if not os.path.exists(path):
+            return None
+        _metal = C.CDLL(path)
+    return _metal
+
+
 def u8p(a: np.ndarray):
     return a.ctypes.data_as(C.POINTER(C.c_uint8))
 
