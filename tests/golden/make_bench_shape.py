@@ -27,7 +27,7 @@ import oracle_lib as ol  # noqa: E402
 
 W, H, OW, OH, CFG = 1920, 1080, 3840, 2160, 3
 LAP = "y-strength=0.2:y-kernel=isolap:cb-strength=0.2:cb-kernel=isolap"
-FRAMES = {"interlaced": 48, "corners": 16}          # three bench steps of 16 / one
+FRAMES = {"interlaced": 48, "corners": 16, "interlaced10": 16}          # three bench steps of 16 / one / one at 10 bits
 
 
 def digest(a):
@@ -40,19 +40,21 @@ def main():
         raise SystemExit("oracle/_ref/libhbref.so missing: run `make oracle` where /root/reference exists")
     for content in (sys.argv[1:] or list(FRAMES)):
         n = FRAMES[content]
-        frames = synth.stream(content, W, H, n, cfg=CFG)
+        depth = 10 if content.endswith("10") else 8
+        fmt = hbrt.PIX_FMT_FOR_DEPTH[depth]
+        frames = synth.stream(content[:-2] if depth == 10 else content, W, H, n, cfg=CFG, depth=depth)
         mid = hbrt.run_stream(ref, [("hb_filter_decomb", "mode=31"), ("hb_filter_nlmeans", hip.NLMEANS_MEDIUM + ":threads=4")],
-                              frames, flags=synth.PIC_FLAG_TOP_FIELD_FIRST)
+                              frames, flags=synth.PIC_FLAG_TOP_FIELD_FIRST, pix_fmt=fmt)
         out = []
         for m in mid:                                                     # frame by frame: 2n frames of 12.4 MB are not kept
-            scaled = ol.orc_cropscale_frame(m.planes, width=OW, height=OH)
-            sharp = hbrt.run_stream(ref, [("hb_filter_lapsharp", LAP)], [scaled])[0]
+            scaled = ol.orc_cropscale_frame(m.planes, width=OW, height=OH, depth=depth)
+            sharp = hbrt.run_stream(ref, [("hb_filter_lapsharp", LAP)], [scaled], pix_fmt=fmt)[0]
             out.append({"start": m.start, "stop": m.stop, "sha256": [digest(p) for p in sharp.planes]})
         path = os.path.join(HERE, f"bench_shape_{content}.json")
         json.dump({"what": "SHA-256 of the output planes (Y, Cb, Cr) of BASELINE configs[3] on synth.stream(%r, %d, %d, %d, cfg=%d): "
                            "reference decomb 31 -> reference nlmeans medium -> restated Lanczos %dx%d -> reference lapsharp"
                            % (content, W, H, n, CFG, OW, OH),
-                   "content": content, "input_frames": n, "frames": out}, open(path, "w"), indent=0)
+                   "content": content, "depth": depth, "input_frames": n, "frames": out}, open(path, "w"), indent=0)
         print(f"{content}: {len(out)} output frames -> {path}")
 
 

@@ -164,8 +164,8 @@ def _sha(t):
     return hashlib.sha256(np.ascontiguousarray(t.cpu().numpy()).tobytes()).hexdigest()
 
 
-@pytest.mark.parametrize("content,steps", [("interlaced", 3), ("corners", 1)])
-def test_bench_shape(built, content, steps):
+@pytest.mark.parametrize("content,steps,depth,split", [("interlaced", 3, 8, 2), ("corners", 1, 8, 2), ("interlaced10", 1, 10, 0)])
+def test_bench_shape(built, content, steps, depth, split):
     """The configuration the driver's bench line comes from, pinned frame for frame: 1920x1080 -> 3840x2160, B = 16 input
     frames per step, decomb on a context (HIP stream) of its own and NLMeans / scaler / lapsharp on a second
     (--stage-streams 2), 32-field EEDI2 batches in two parts with forked passes, the steps enqueued back to back with
@@ -180,17 +180,19 @@ def test_bench_shape(built, content, steps):
     W, H, OW, OH, B = 1920, 1080, 3840, 2160, 16
     n = B * steps
     assert want["input_frames"] == n and len(want["frames"]) == 2 * n
-    frames = synth.stream(bench.CONTENTS[content], W, H, n, cfg=3)
-    ctxs, chain = bench.build_chain(hip, 0, W, H, (OW, OH), depth=8, split=2)
-    assert len(ctxs) == 3                                    # the chain's own, decomb's, and one for the stages behind it
+    assert want.get("depth", 8) == depth
+    frames = synth.stream(bench.CONTENTS[content[:-2] if depth == 10 else content], W, H, n, cfg=3, depth=depth)
+    ctxs, chain = bench.build_chain(hip, 0, W, H, (OW, OH), depth=depth, split=split)
+    assert len(ctxs) == (3 if split == 2 else 1)             # split 2: the chain's own, decomb's, and one for the stages behind it
+    dt = torch.uint8 if depth == 8 else torch.int16          # (the bit patterns of uint16 samples: what bench.py hands over too)
     try:
-        dev_in = [_dev(f, torch) for f in frames]
+        dev_in = [_dev([p.view(np.int16) if depth > 8 else p for p in f], torch) for f in frames]
         cap = 2 * B + 4
 
         def out_frames():
-            return [[torch.zeros((OH, OW), dtype=torch.uint8, device="cuda"),
-                     torch.zeros((OH // 2, OW // 2), dtype=torch.uint8, device="cuda"),
-                     torch.zeros((OH // 2, OW // 2), dtype=torch.uint8, device="cuda")] for _ in range(cap)]
+            return [[torch.zeros((OH, OW), dtype=dt, device="cuda"),
+                     torch.zeros((OH // 2, OW // 2), dtype=dt, device="cuda"),
+                     torch.zeros((OH // 2, OW // 2), dtype=dt, device="cuda")] for _ in range(cap)]
 
         sets = [out_frames() for _ in range(steps + 1)]
         torch.cuda.synchronize()                             # the zero fills ran on torch's stream
