@@ -530,6 +530,43 @@ __global__ __launch_bounds__(256) void scale8_v_kernel(Scale8Args a, const uint1
     a.dst[(size_t)y * a.dpitch + x] = (uint8_t)fx_to8(fx_round14(acc));
 }
 
+// ---- the swscale branch (cropscale.c:159-165: `scale=flags=lanczos+accurate_rnd` for sizes zscale is not used for -
+// an odd width or height): libswscale's arithmetic for 8-bit planar YUV, restated in oracle/alias_oracle.c
+// (orc_cropscale_plane_sws; PARITY UNPINNED like the zimg form).  px / py: first tapped source column / row of an output
+// column / row (taps outside the plane already folded onto the edge sample by the table), qx: 14-bit, qy: 12-bit
+// coefficients.  Two plain launches per plane: the sizes that come here are the odd ones, a fallback, not a hot path.
+struct ScaleSwsArgs
+{
+    const uint8_t *src; uint8_t *dst;
+    int spitch, dpitch, dw, dh, tx, ty, src_rows;
+    const int *px, *py;
+    const short *qx, *qy;
+};
+
+__global__ __launch_bounds__(256) void scale8_sws_h_kernel(ScaleSwsArgs a, int16_t *__restrict__ hbuf)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= a.dw || r >= a.src_rows) return;
+    const uint8_t *row = a.src + (size_t)r * a.spitch + a.px[x];
+    const short *q = a.qx + (size_t)x * a.tx;
+    int val = 0;
+    for (int j = 0; j < a.tx; j++) val += (int)row[j] * (int)q[j];
+    hbuf[(size_t)r * a.dw + x] = (int16_t)min(val >> 7, (1 << 15) - 1);             // hScale8To15_c
+}
+
+__global__ __launch_bounds__(256) void scale8_sws_v_kernel(ScaleSwsArgs a, const int16_t *__restrict__ hbuf)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= a.dw || y >= a.dh) return;
+    const int16_t *col = hbuf + (size_t)a.py[y] * a.dw + x;
+    const short *q = a.qy + (size_t)y * a.ty;
+    int val = 64 << 12;                                                              // yuv2planeX_8_c with the flat dither of 64
+    for (int j = 0; j < a.ty; j++) val += (int)col[(size_t)j * a.dw] * (int)q[j];
+    a.dst[(size_t)y * a.dpitch + x] = (uint8_t)min(max(val >> 19, 0), 255);
+}
+
 // 6 x 6 taps (every upscale and same-size resampling, e.g. 1080p -> 2160p), both passes in one kernel, the three
 // planes of up to SU_FRAMES frames per launch.  A workgroup owns a 256 x 16 tile of the output:
 //   1. the source rows / columns the tile taps go into LDS as they lie (dwords), the reflection at the plane's
@@ -878,6 +915,118 @@ int lanczos_table(int src_dim, int dst_dim, double shift, std::vector<int> &idx,
     return taps;
 }
 
+// libswscale's filter of one dimension for SWS_LANCZOS (utils.c:initFilter), formula for formula as oracle/alias_oracle.c:
+// orc_sws_filter states it (same libm, same expression order: the tables come out equal).  Returns the tap count.
+int sws_filter(int src, int dst, int one, int src_pos, int dst_pos, std::vector<int> &pos, std::vector<short> &coef)
+{
+    auto ilog2 = [](unsigned v) { int n = 0; while (v >>= 1) n++; return n; };
+    const int64_t fone = 1LL << (54 - std::min(ilog2((unsigned)(src / dst)), 8));
+    const int x_inc = (int)((((int64_t)src << 16) + (dst >> 1)) / dst);
+    pos.assign((size_t)dst, 0);
+    int size;
+    std::vector<int64_t> f;
+    if (std::llabs((long long)x_inc - 0x10000) < 10 && src_pos == dst_pos)
+    {
+        size = 1;
+        f.assign((size_t)dst, fone);
+        for (int i = 0; i < dst; i++) pos[i] = i;
+    }
+    else
+    {
+        const int size_factor = 6;
+        size = x_inc <= (1 << 16) ? 1 + size_factor : 1 + (size_factor * src + dst - 1) / dst;
+        size = std::max(std::min(size, src - 2), 1);
+        f.assign((size_t)dst * size, 0);
+        int64_t x_dst_in_src = (((int64_t)dst_pos * x_inc) >> 7) - (((int64_t)src_pos * 0x10000LL) >> 7);
+        for (int i = 0; i < dst; i++)
+        {
+            int xx = (int)((x_dst_in_src - (int64_t)(size - 2) * (1LL << 16)) / (1 << 17));
+            pos[i] = xx;
+            for (int j = 0; j < size; j++)
+            {
+                int64_t d = std::llabs(((int64_t)xx * (1 << 17)) - x_dst_in_src) << 13;
+                if (x_inc > (1 << 16)) d = d * dst / src;
+                const double fd = (double)d * (1.0 / (1 << 30));
+                int64_t c = (int64_t)((d ? std::sin(fd * M_PI) * std::sin(fd * M_PI / 3.0) / (fd * fd * M_PI * M_PI / 3.0) : 1.0) * (double)fone);
+                if (fd > 3.0) c = 0;
+                f[(size_t)i * size + j] = c;
+                xx++;
+            }
+            x_dst_in_src += 2 * (int64_t)x_inc;
+        }
+    }
+    int min_size = 0;
+    const double cut = 0.002 * (double)fone;
+    for (int i = dst - 1; i >= 0; i--)
+    {
+        int64_t *row = &f[(size_t)i * size];
+        int mn = size;
+        int64_t cut_off = 0;
+        for (int j = 0; j < size; j++)
+        {
+            cut_off += std::llabs(row[0]);
+            if ((double)cut_off > cut) break;
+            if (i < dst - 1 && pos[i] >= pos[i + 1]) break;
+            for (int k = 1; k < size; k++) row[k - 1] = row[k];
+            row[size - 1] = 0;
+            pos[i]++;
+        }
+        cut_off = 0;
+        for (int j = size - 1; j > 0; j--)
+        {
+            cut_off += std::llabs(row[j]);
+            if ((double)cut_off > cut) break;
+            mn--;
+        }
+        min_size = std::max(min_size, mn);
+    }
+    const int fsize = min_size;
+    std::vector<int64_t> g((size_t)dst * fsize, 0);
+    for (int i = 0; i < dst; i++)
+        for (int j = 0; j < fsize && j < size; j++) g[(size_t)i * fsize + j] = f[(size_t)i * size + j];
+    for (int i = 0; i < dst; i++)
+    {
+        int64_t *row = &g[(size_t)i * fsize];
+        if (pos[i] < 0)
+        {
+            for (int j = 1; j < fsize; j++)
+            {
+                const int left = std::max(j + pos[i], 0);
+                row[left] += row[j];
+                row[j] = 0;
+            }
+            pos[i] = 0;
+        }
+        if (pos[i] + fsize > src)
+        {
+            const int shift = pos[i] + std::min(fsize - src, 0);
+            int64_t acc = 0;
+            for (int j = fsize - 1; j >= 0; j--)
+                if (pos[i] + j >= src) { acc += row[j]; row[j] = 0; }
+            for (int j = fsize - 1; j >= 0; j--) row[j] = j < shift ? 0 : row[j - shift];
+            pos[i] -= shift;
+            row[src - 1 - pos[i]] += acc;
+        }
+    }
+    coef.assign((size_t)dst * fsize, 0);
+    for (int i = 0; i < dst; i++)
+    {
+        const int64_t *row = &g[(size_t)i * fsize];
+        int64_t error = 0, sum = 0;
+        for (int j = 0; j < fsize; j++) sum += row[j];
+        sum = (sum + one / 2) / one;
+        if (!sum) sum = 1;
+        for (int j = 0; j < fsize; j++)
+        {
+            const int64_t v = row[j] + error;
+            const int64_t iv = v >= 0 ? (v + (sum >> 1)) / sum : -((-v + (sum >> 1)) / sum);
+            coef[(size_t)i * fsize + j] = (short)iv;
+            error = v - iv * sum;
+        }
+    }
+    return fsize;
+}
+
 // a filter row with 14 fractional bits that still sums to 1 << 14: the rounding residue goes to the largest tap
 // (oracle/alias_oracle.c: orc_quantize_taps)
 void quantize_taps(const double *coef, int taps, short *q)
@@ -925,8 +1074,30 @@ public:
             const int dw = out_geo.pw[c], dh = out_geo.ph[c];
             // left-sited chroma: 0.25 * (1 - src/dst) of a chroma sample, horizontally only
             const double sx = (c && lw) ? 0.25 * (1.0 - (double)cw / (double)out_geo.width) : 0.0;
-            identity[c] = (dw == crop_w[c] && dh == crop_h[c] && sx == 0.0);
+            identity[c] = (dw == crop_w[c] && dh == crop_h[c] && (sws || sx == 0.0));
             if (identity[c]) continue;
+            if (sws)
+            {
+                // libswscale's tables: positions + 14-bit (horizontal) / 12-bit (vertical) coefficients; left-sited chroma
+                // at horizontal position 0 (srcPos = dstPos = 64), everything else centred (128)
+                std::vector<int> px, py;
+                std::vector<short> qx, qy;
+                const int hpos = (c && lw) ? 64 : 128;
+                tx[c] = sws_filter(crop_w[c], dw, 1 << 14, hpos, hpos, px, qx);
+                ty[c] = sws_filter(crop_h[c], dh, 1 << 12, 128, 128, py, qy);
+                auto up = [&](auto *&dptr, const auto &v) -> int {
+                    HBHIP_CHECK(ctx, hipMalloc((void **)&dptr, sizeof(v[0]) * v.size()));
+                    HBHIP_CHECK(ctx, hipMemcpy(dptr, v.data(), sizeof(v[0]) * v.size(), hipMemcpyHostToDevice));
+                    return HBHIP_OK;
+                };
+                int rc = up(d_bx[c], px);
+                if (rc == HBHIP_OK) rc = up(d_by[c], py);
+                if (rc == HBHIP_OK) rc = up(d_qx[c], qx);
+                if (rc == HBHIP_OK) rc = up(d_qy[c], qy);
+                if (rc != HBHIP_OK) return rc;
+                up6 = false;
+                continue;
+            }
             std::vector<int> ix, iy, bx, by;
             std::vector<double> cx, cy;
             tx[c] = lanczos_table(crop_w[c], dw, sx, ix, cx, &bx);
@@ -1019,6 +1190,18 @@ public:
                 for (int c = 0; c < 3; c++)
                 {
                     if (identity[c]) continue;
+                    if (sws)
+                    {
+                        ScaleSwsArgs w;
+                        w.src = window(ins[i], c); w.dst = outs[i]->plane[c];
+                        w.spitch = ins[i]->pitch[c]; w.dpitch = outs[i]->pitch[c];
+                        w.dw = out_geo.pw[c]; w.dh = out_geo.ph[c]; w.tx = tx[c]; w.ty = ty[c]; w.src_rows = crop_h[c];
+                        w.px = d_bx[c]; w.py = d_by[c]; w.qx = d_qx[c]; w.qy = d_qy[c];
+                        const dim3 gh((w.dw + 63) / 64, (crop_h[c] + 3) / 4), gv((w.dw + 63) / 64, (w.dh + 3) / 4);
+                        HBHIP_LAUNCH(ctx, "cropscale_sws_h", scale8_sws_h_kernel, gh, dim3(64, 4), 0, w, (int16_t *)hbuf16);
+                        HBHIP_LAUNCH(ctx, "cropscale_sws_v", scale8_sws_v_kernel, gv, dim3(64, 4), 0, w, (const int16_t *)hbuf16);
+                        continue;
+                    }
                     Scale8Args a;
                     a.src = window(ins[i], c); a.dst = outs[i]->plane[c];
                     a.spitch = ins[i]->pitch[c]; a.dpitch = outs[i]->pitch[c];
@@ -1041,6 +1224,7 @@ public:
     }
 
     int process(DevPicture *in, DevPicture *out) override { return process_many(&in, &out, 1); }
+    bool sws = false;           // libswscale's arithmetic (the reference's path for odd sizes) instead of zimg's
     bool up6 = true;            // six taps either way and every tile fits the fused kernel's LDS frame
     bool tall = true;           // ... also at 32 rows per tile
     hbhip_cropscale_params par;
@@ -1254,8 +1438,24 @@ extern "C" int hbhip_grayscale_create(hbhip_ctx *ctx, double cb, double cr, doub
     return HBHIP_OK;
 }
 
+static int cropscale_create(hbhip_ctx *ctx, const hbhip_cropscale_params *p, int width, int height,
+                            int depth, int log2_chroma_w, int log2_chroma_h, bool sws, hbhip_filter **out);
+
 extern "C" int hbhip_cropscale_create(hbhip_ctx *ctx, const hbhip_cropscale_params *p, int width, int height,
                                       int depth, int log2_chroma_w, int log2_chroma_h, hbhip_filter **out)
+{
+    return cropscale_create(ctx, p, width, height, depth, log2_chroma_w, log2_chroma_h, false, out);
+}
+
+extern "C" int hbhip_cropscale_sws_create(hbhip_ctx *ctx, const hbhip_cropscale_params *p, int width, int height,
+                                          int depth, int log2_chroma_w, int log2_chroma_h, hbhip_filter **out)
+{
+    if (depth != 8) return HBHIP_ERR_UNSUPPORTED;               // hScale16To19 / yuv2planeX_16: not restated
+    return cropscale_create(ctx, p, width, height, depth, log2_chroma_w, log2_chroma_h, true, out);
+}
+
+static int cropscale_create(hbhip_ctx *ctx, const hbhip_cropscale_params *p, int width, int height,
+                            int depth, int log2_chroma_w, int log2_chroma_h, bool sws, hbhip_filter **out)
 {
     if (!ctx || !p || !out) return HBHIP_ERR_ARG;
     *out = nullptr;
@@ -1264,6 +1464,7 @@ extern "C" int hbhip_cropscale_create(hbhip_ctx *ctx, const hbhip_cropscale_para
     (void)hipSetDevice(ctx->device);
     CropScaleFilter *f = new (std::nothrow) CropScaleFilter(ctx, *p);
     if (!f) return HBHIP_ERR_NOMEM;
+    f->sws = sws;
     PicGeometry gi, go;
     gi.set(width, height, depth, log2_chroma_w, log2_chroma_h);
     go.set(p->width, p->height, depth, log2_chroma_w, log2_chroma_h);

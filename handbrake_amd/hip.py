@@ -17,7 +17,7 @@ ABI_SYMBOLS = [
     "hbhip_host_alloc", "hbhip_host_free",
     "hbhip_abi_version", "hbhip_device_count", "hbhip_strerror", "hbhip_ctx_create",
     "hbhip_ctx_create_on_stream", "hbhip_ctx_destroy", "hbhip_ctx_sync", "hbhip_ctx_last_error",
-    "hbhip_debug_mask_chain", "hbhip_ctx_copy_bandwidth", "hbhip_ctx_device_name", "hbhip_ctx_device_index", "hbhip_frame_context", "hbhip_filter_context",
+    "hbhip_debug_mask_chain", "hbhip_cropscale_sws_create", "hbhip_ctx_copy_bandwidth", "hbhip_ctx_device_name", "hbhip_ctx_device_index", "hbhip_frame_context", "hbhip_filter_context",
     "hbhip_ctx_profile_enable", "hbhip_ctx_profile_reset",
     "hbhip_ctx_profile_count", "hbhip_ctx_profile_get", "hbhip_ctx_mark", "hbhip_ctx_elapsed_ms",
     "hbhip_dev_alloc", "hbhip_dev_free", "hbhip_dev_upload", "hbhip_dev_download",
@@ -445,9 +445,10 @@ def lapsharp_device_filter(ctx, width, height, strength=0.2, kernel=1, depth=8):
                    ctx.h, C.byref(p), width, height, depth, 1, 1)
 
 
-def cropscale_device_filter(ctx, width, height, out_w, out_h, crop=(0, 0, 0, 0), depth=8):
+def cropscale_device_filter(ctx, width, height, out_w, out_h, crop=(0, 0, 0, 0), depth=8, sws=False):
+    """sws: libswscale's arithmetic (the reference's branch for odd sizes) instead of zimg's"""
     p = CropScaleParams(out_w, out_h, *crop)
-    return _create("hbhip_cropscale_create", ctx,
+    return _create("hbhip_cropscale_sws_create" if sws else "hbhip_cropscale_create", ctx,
                    [C.c_void_p, C.POINTER(CropScaleParams)] + [C.c_int] * 5 + [C.POINTER(C.c_void_p)],
                    ctx.h, C.byref(p), width, height, depth, 1, 1)
 

@@ -136,21 +136,25 @@ static int crop_scale_hip_init(hb_filter_object_t *filter, hb_filter_init_t *ini
     p.height = cropped_height;
     hb_dict_extract_int(&p.width, filter->settings, "width");                /* :93-94 */
     hb_dict_extract_int(&p.height, filter->settings, "height");
-    /* The restated scaler is zimg's (zscale=filter=lanczos).  The reference only takes that path when
-     * hb_av_can_use_zscale() agrees (cropscale.c:97-118; hbffmpeg.c:870-915: every dimension even, a planar YUV
-     * format) and otherwise scales with swscale "lanczos+accurate_rnd", which computes something else: decline,
-     * so that the CPU filter stays (work.c:1861-1868), rather than replace it with different arithmetic. */
-    if ((cropped_width & 1) || (cropped_height & 1) || (p.width & 1) || (p.height & 1))
+    /* crop_scale_init has two scalers (cropscale.c:97-165): zscale=filter=lanczos where hb_av_can_use_zscale() agrees
+     * (hbffmpeg.c:870-915: every dimension even, a planar YUV format), else swscale `lanczos+accurate_rnd`, which computes
+     * something else.  The drop-in follows the same rule with the restatement of the same library (both parity unpinned:
+     * neither library is in the reference tree).  The swscale form exists for 8-bit planes; an odd size at 10 / 12 bits is
+     * declined, so that the CPU filter stays (work.c:1861-1868) rather than being replaced by different arithmetic. */
+    const int odd = (cropped_width & 1) || (cropped_height & 1) || (p.width & 1) || (p.height & 1);
+    if (odd && desc->comp[0].depth != 8)
     {
-        hb_log("cropscale(hip): odd dimension %dx%d -> %dx%d is the reference's swscale case, not built",
-               cropped_width, cropped_height, p.width, p.height);
+        hb_log("cropscale(hip): odd dimension %dx%d -> %dx%d at %d bits is the reference's swscale case, not built",
+               cropped_width, cropped_height, p.width, p.height, desc->comp[0].depth);
         return alias_fail(filter, HBHIP_ERR_UNSUPPORTED);
     }
 
     hbhip_ctx *ctx = hbhip_host_ctx_for(init);
     if (ctx == NULL) return alias_fail(filter, HBHIP_ERR_NODEVICE);
-    int rc = hbhip_cropscale_create(ctx, &p, init->geometry.width, init->geometry.height, desc->comp[0].depth,
-                                    desc->log2_chroma_w, desc->log2_chroma_h, &pv->dev);
+    int rc = odd ? hbhip_cropscale_sws_create(ctx, &p, init->geometry.width, init->geometry.height, desc->comp[0].depth,
+                                              desc->log2_chroma_w, desc->log2_chroma_h, &pv->dev)
+                 : hbhip_cropscale_create(ctx, &p, init->geometry.width, init->geometry.height, desc->comp[0].depth,
+                                          desc->log2_chroma_w, desc->log2_chroma_h, &pv->dev);
     if (rc != HBHIP_OK) return alias_fail(filter, rc);
 
     init->crop[0] = p.crop_top;                                              /* :168-178 */

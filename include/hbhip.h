@@ -331,6 +331,11 @@ typedef struct hbhip_cropscale_params
 } hbhip_cropscale_params;
 int hbhip_cropscale_create(hbhip_ctx *ctx, const hbhip_cropscale_params *p, int width, int height,
                            int depth, int log2_chroma_w, int log2_chroma_h, hbhip_filter **out);
+/* The other branch of crop_scale_init (cropscale.c:159-165): `crop` + `scale=flags=lanczos+accurate_rnd`, which the
+ * reference builds when hb_av_can_use_zscale() says no (an odd width or height, hbffmpeg.c:870-915) - libswscale's
+ * arithmetic instead of zimg's.  8-bit planes only. */
+int hbhip_cropscale_sws_create(hbhip_ctx *ctx, const hbhip_cropscale_params *p, int width, int height,
+                               int depth, int log2_chroma_w, int log2_chroma_h, hbhip_filter **out);
 /* FFmpeg `pad=width:height:x:y:color` as pad_init sets it up (pad.c:40-148): the picture at (x, y)
  * of a width x height one, the rest filled with fill[] (Y, Cb, Cr sample values, already converted
  * from the RGB colour the way drawutils.c:ff_draw_color does).  x, y multiples of the chroma subsampling. */

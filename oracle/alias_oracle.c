@@ -303,6 +303,179 @@ void orc_cropscale_plane_fx(const uint8_t *src, int sstride, int crop_x, int cro
     free(ix); free(iy); free(cx); free(cy); free(qx); free(qy); free(hbuf);
 }
 
+/* ---- the swscale branch of crop/scale (cropscale.c:159-165) ---------------------------------------------------------
+ * When hb_av_can_use_zscale() says no - an odd width or height on either side, or a build without AVX2
+ * (hbffmpeg.c:870-915) - crop_scale_init builds `scale=w:h:flags=lanczos+accurate_rnd` instead of zscale: libswscale.
+ * PARITY UNPINNED, like the zimg form above and for the same reason (libswscale is not in the reference tree; FFmpeg
+ * 9.0.1 per contrib/ffmpeg/module.defs).  What follows restates libswscale's published algorithm for planar 8-bit YUV:
+ *   * the filter of one dimension as libswscale/utils.c:initFilter builds it: positions in 16.16 fixed point
+ *     (xInc = (src << 16 + dst / 2) / dst; the first tap of output i at (xDstInSrc - (size - 2) << 16) >> 17 with
+ *     xDstInSrc = dstPos * xInc >> 7 - srcPos << 16 >> 7, advancing by 2 xInc), Lanczos-3 weights evaluated at the
+ *     tap distances as 64-bit integers scaled by 2^54, near-zero taps at either end dropped (SWS_MAX_REDUCE_CUTOFF =
+ *     0.002), taps outside the plane folded onto the edge sample, then normalised to `one` with the rounding error carried
+ *     from tap to tap;
+ *   * horizontal pass (hScale8To15_c): 14-bit coefficients, the sum >> 7 into a 15-bit plane, clamped at 32767;
+ *   * vertical pass (yuv2planeX_8_c): 12-bit coefficients, (64 << 12) + sum >> 19, clamped to 8 bits - the C paths'
+ *     arithmetic, which `accurate_rnd` makes the SIMD paths reproduce;
+ *   * chroma positions as vf_scale hands them over for left-sited 4:2:0 (horizontal position 0, vertical 128): srcPos =
+ *     dstPos = 64 horizontally, 128 everywhere else.
+ * Held within 2 code values of the zimg form and of Pillow's Lanczos (tests/test_alias_cpu.py); the HIP scaler runs it bit
+ * for bit (tests/test_alias_gpu.py). */
+#define SWS_FONE_SHIFT 54
+static int sws_log2(unsigned v) { int n = 0; while (v >>= 1) n++; return n; }
+
+/* initFilter for SWS_LANCZOS (default parameter 3): pos[dst], coef[dst * size] (caller frees); returns size */
+int orc_sws_filter(int src, int dst, int one, int src_pos, int dst_pos, int **out_pos, int16_t **out_coef)
+{
+    const int64_t fone = 1LL << (SWS_FONE_SHIFT - (sws_log2((unsigned)(src / dst)) < 8 ? sws_log2((unsigned)(src / dst)) : 8));
+    const int x_inc = (int)((((int64_t)src << 16) + (dst >> 1)) / dst);
+    int *pos = malloc(sizeof(int) * (size_t)dst);
+    int size;
+    int64_t *f;
+    if (llabs((long long)x_inc - 0x10000) < 10 && src_pos == dst_pos)
+    {
+        size = 1;                                                   /* unscaled: the sample itself */
+        f = malloc(sizeof(int64_t) * (size_t)dst);
+        for (int i = 0; i < dst; i++) { f[i] = fone; pos[i] = i; }
+    }
+    else
+    {
+        const int size_factor = 6;                                  /* lanczos, default parameter */
+        size = x_inc <= (1 << 16) ? 1 + size_factor : 1 + (size_factor * src + dst - 1) / dst;
+        if (size > src - 2) size = src - 2;
+        if (size < 1) size = 1;
+        f = malloc(sizeof(int64_t) * (size_t)dst * (size_t)size);
+        int64_t x_dst_in_src = (((int64_t)dst_pos * x_inc) >> 7) - (((int64_t)src_pos * 0x10000LL) >> 7);
+        for (int i = 0; i < dst; i++)
+        {
+            int xx = (int)((x_dst_in_src - (int64_t)(size - 2) * (1LL << 16)) / (1 << 17));
+            pos[i] = xx;
+            for (int j = 0; j < size; j++)
+            {
+                int64_t d = llabs(((int64_t)xx * (1 << 17)) - x_dst_in_src) << 13;
+                if (x_inc > (1 << 16)) d = d * dst / src;
+                const double fd = (double)d * (1.0 / (1 << 30));
+                int64_t coeff = (int64_t)((d ? sin(fd * M_PI) * sin(fd * M_PI / 3.0) / (fd * fd * M_PI * M_PI / 3.0) : 1.0) * (double)fone);
+                if (fd > 3.0) coeff = 0;
+                f[(size_t)i * size + j] = coeff;
+                xx++;
+            }
+            x_dst_in_src += 2 * (int64_t)x_inc;
+        }
+    }
+    /* drop near-zero taps: shift each row left past them, find how many taps any row still needs */
+    int min_size = 0;
+    const double cut = 0.002 * (double)fone;
+    for (int i = dst - 1; i >= 0; i--)
+    {
+        int64_t *row = f + (size_t)i * size;
+        int min = size;
+        int64_t cut_off = 0;
+        for (int j = 0; j < size; j++)
+        {
+            cut_off += llabs(row[0]);
+            if ((double)cut_off > cut) break;
+            if (i < dst - 1 && pos[i] >= pos[i + 1]) break;         /* positions stay monotonic */
+            for (int k = 1; k < size; k++) row[k - 1] = row[k];
+            row[size - 1] = 0;
+            pos[i]++;
+        }
+        cut_off = 0;
+        for (int j = size - 1; j > 0; j--)
+        {
+            cut_off += llabs(row[j]);
+            if ((double)cut_off > cut) break;
+            min--;
+        }
+        if (min > min_size) min_size = min;
+    }
+    const int fsize = min_size;                                     /* (filterAlign only appends zero taps) */
+    int64_t *g = malloc(sizeof(int64_t) * (size_t)dst * (size_t)fsize);
+    for (int i = 0; i < dst; i++)
+        for (int j = 0; j < fsize; j++) g[(size_t)i * fsize + j] = j < size ? f[(size_t)i * size + j] : 0;
+    free(f);
+    /* taps outside the plane fold onto the edge sample */
+    for (int i = 0; i < dst; i++)
+    {
+        int64_t *row = g + (size_t)i * fsize;
+        if (pos[i] < 0)
+        {
+            for (int j = 1; j < fsize; j++)
+            {
+                const int left = j + pos[i] > 0 ? j + pos[i] : 0;
+                row[left] += row[j];
+                row[j] = 0;
+            }
+            pos[i] = 0;
+        }
+        if (pos[i] + fsize > src)
+        {
+            const int shift = pos[i] + (fsize - src < 0 ? fsize - src : 0);
+            int64_t acc = 0;
+            for (int j = fsize - 1; j >= 0; j--)
+                if (pos[i] + j >= src) { acc += row[j]; row[j] = 0; }
+            for (int j = fsize - 1; j >= 0; j--)
+                row[j] = j < shift ? 0 : row[j - shift];
+            pos[i] -= shift;
+            row[src - 1 - pos[i]] += acc;
+        }
+    }
+    /* normalise to `one`, the rounding error carried along the row */
+    int16_t *coef = malloc(sizeof(int16_t) * (size_t)dst * (size_t)fsize);
+    for (int i = 0; i < dst; i++)
+    {
+        const int64_t *row = g + (size_t)i * fsize;
+        int64_t error = 0, sum = 0;
+        for (int j = 0; j < fsize; j++) sum += row[j];
+        sum = (sum + one / 2) / one;
+        if (!sum) sum = 1;
+        for (int j = 0; j < fsize; j++)
+        {
+            const int64_t v = row[j] + error;
+            const int64_t iv = v >= 0 ? (v + (sum >> 1)) / sum : -((-v + (sum >> 1)) / sum);   /* ROUNDED_DIV */
+            coef[(size_t)i * fsize + j] = (int16_t)iv;
+            error = v - iv * sum;
+        }
+    }
+    free(g);
+    *out_pos = pos;
+    *out_coef = coef;
+    return fsize;
+}
+
+/* one plane; chroma_h: the plane is a horizontally subsampled, left-sited chroma plane */
+void orc_cropscale_plane_sws(const uint8_t *src, int sstride, int crop_x, int crop_y, int crop_w, int crop_h,
+                             uint8_t *dst, int dstride, int dw, int dh, int chroma_h)
+{
+    const uint8_t *win = src + (size_t)crop_y * sstride + crop_x;
+    int *px, *py;
+    int16_t *qx, *qy;
+    const int hpos = chroma_h ? 64 : 128;
+    const int tx = orc_sws_filter(crop_w, dw, 1 << 14, hpos, hpos, &px, &qx);
+    const int ty = orc_sws_filter(crop_h, dh, 1 << 12, 128, 128, &py, &qy);
+    int16_t *hbuf = malloc(sizeof(int16_t) * (size_t)dw * crop_h);
+    for (int r = 0; r < crop_h; r++)
+    {
+        const uint8_t *row = win + (size_t)r * sstride;
+        for (int x = 0; x < dw; x++)
+        {
+            int val = 0;
+            for (int j = 0; j < tx; j++) val += (int)row[px[x] + j] * qx[(size_t)x * tx + j];
+            val >>= 7;
+            hbuf[(size_t)r * dw + x] = (int16_t)(val < (1 << 15) - 1 ? val : (1 << 15) - 1);
+        }
+    }
+    for (int y = 0; y < dh; y++)
+        for (int x = 0; x < dw; x++)
+        {
+            int val = 64 << 12;
+            for (int j = 0; j < ty; j++) val += (int)hbuf[(size_t)(py[y] + j) * dw + x] * qy[(size_t)y * ty + j];
+            val >>= 19;
+            dst[(size_t)y * dstride + x] = (uint8_t)(val < 0 ? 0 : val > 255 ? 255 : val);
+        }
+    free(px); free(py); free(qx); free(qy); free(hbuf);
+}
+
 /* The same for 10 / 12-bit planes (uint16 samples).  zimg resizes a WORD plane at its own depth: per pass
  *     dst = clamp((sum_k c[k] * src[k] + (1 << 13)) >> 14, 0, (1 << depth) - 1)
  * (it holds the samples biased by -32768 to use signed 16-bit multiplies; a filter row sums to exactly 1 << 14, so

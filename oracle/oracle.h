@@ -254,6 +254,12 @@ int orc_lanczos_table(int src_dim, int dst_dim, double shift, int *idx, double *
 void orc_quantize_taps(const double *coef, int taps, int16_t *q);
 void orc_cropscale_plane_fx(const uint8_t *src, int sstride, int crop_x, int crop_y, int crop_w, int crop_h,
                             uint8_t *dst, int dstride, int dw, int dh, double shift_x, double shift_y);
+/* the swscale branch (cropscale.c:159-165: `scale=flags=lanczos+accurate_rnd` when zscale cannot be used - odd sizes):
+ * libswscale's filter of one dimension (initFilter: positions, `one`-normalised coefficients; returns the tap count, the
+ * caller frees both arrays) and one 8-bit plane through its 15-bit horizontal / 8-bit vertical passes.  PARITY UNPINNED. */
+int  orc_sws_filter(int src, int dst, int one, int src_pos, int dst_pos, int **out_pos, int16_t **out_coef);
+void orc_cropscale_plane_sws(const uint8_t *src, int sstride, int crop_x, int crop_y, int crop_w, int crop_h,
+                             uint8_t *dst, int dstride, int dw, int dh, int chroma_h);
 /* the same at 10 / 12 bits: uint16 samples, both passes clamped to the depth (strides in bytes) */
 void orc_cropscale_plane_fx16(const uint16_t *src, int sstride, int crop_x, int crop_y, int crop_w, int crop_h,
                               uint16_t *dst, int dstride, int dw, int dh, double shift_x, double shift_y, int depth);

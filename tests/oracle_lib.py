@@ -482,9 +482,28 @@ def orc_grayscale_frame(frame, cb=0.0, cr=0.0, size=1.0, high=0.0, depth=8):
 def orc_cropscale_frame(frame, width, height, top=0, bottom=0, left=0, right=0, depth=8, arithmetic=None):
     """crop + Lanczos scale of a frame.  arithmetic: "fixed" = zimg's 16-bit fixed point (orc_cropscale_plane_fx at 8
     bits, orc_cropscale_plane_fx16 at 10 / 12: the form the HIP scaler runs and is compared with bit for bit; the
-    default), "double" = the float64 form (the independent check of the fixed-point forms)."""
+    default for even sizes), "double" = the float64 form (the independent check of the fixed-point forms), "sws" =
+    libswscale's arithmetic (orc_cropscale_plane_sws: what crop_scale_init builds when a width or height is odd,
+    cropscale.c:159-165, and the default then, as in the reference; 8-bit planes)."""
+    h0, w0 = frame[0].shape
     if arithmetic is None:
-        arithmetic = "fixed"
+        odd = ((w0 - left - right) | (h0 - top - bottom) | width | height) & 1
+        arithmetic = "sws" if odd and depth == 8 else "fixed"
+    if arithmetic == "sws":
+        fn = oracle().orc_cropscale_plane_sws
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        cw, ch = w0 - left - right, h0 - top - bottom
+        out = []
+        for c, p in enumerate(frame):
+            p = np.ascontiguousarray(p)
+            if c == 0:
+                cx, cy, pw, ph, dw, dh = left, top, cw, ch, width, height
+            else:
+                cx, cy, pw, ph, dw, dh = left >> 1, top >> 1, (cw + 1) // 2, (ch + 1) // 2, (width + 1) // 2, (height + 1) // 2
+            dst = np.zeros((dh, dw), p.dtype)
+            fn(p.ctypes.data, p.strides[0], cx, cy, pw, ph, dst.ctypes.data, dst.strides[0], dw, dh, int(c > 0))
+            out.append(dst)
+        return tuple(out)
     if arithmetic == "fixed" and depth == 8:
         fn = oracle().orc_cropscale_plane_fx
         fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,

@@ -52,6 +52,29 @@ def test_cropscale(built, w, h, ow, oh, crop):
     assert (got[0].width, got[0].height) == (ow, oh)
 
 
+@pytest.mark.parametrize("w,h,ow,oh,crop", [(321, 181, 641, 361, (0, 0, 0, 0)), (638, 362, 851, 481, (2, 4, 6, 8)),
+                                            (641, 361, 321, 181, (0, 0, 0, 0)), (640, 360, 641, 360, (0, 0, 0, 0)),
+                                            (1919, 1079, 1279, 719, (0, 0, 0, 0)), (322, 182, 321, 181, (0, 1, 1, 0))])
+def test_cropscale_odd_sizes_take_the_swscale_form(built, w, h, ow, oh, crop):
+    """An odd width or height on either side: the reference builds `scale=flags=lanczos+accurate_rnd` instead of zscale
+    (cropscale.c:159-165, hbffmpeg.c:888-892) - libswscale's arithmetic.  The drop-in follows: bit-exact against the
+    restatement of libswscale's 8-bit path (oracle/alias_oracle.c: orc_cropscale_plane_sws; parity unpinned like zimg's)."""
+    frames = synth.stream("progressive", w, h, 2 if w < 1000 else 1) + synth.stream("random", w, h, 1)
+    t, b, l, r = crop
+    st = f"width={ow}:height={oh}:crop-top={t}:crop-bottom={b}:crop-left={l}:crop-right={r}"
+    got = run(("hb_filter_crop_scale_hip", st), frames)
+    want = [ol.orc_cropscale_frame(fr, ow, oh, top=t, bottom=b, left=l, right=r, arithmetic="sws") for fr in frames]
+    check(got, want)
+    assert (got[0].width, got[0].height) == (ow, oh)
+
+
+def test_cropscale_odd_size_at_10_bits_is_declined(built):
+    """libswscale's 16-bit path is not restated: the drop-in's init fails and libhb keeps its CPU filter"""
+    frames = synth.stream("progressive", 321, 181, 1, depth=10)
+    with pytest.raises(RuntimeError):
+        run16(("hb_filter_crop_scale_hip", "width=641:height=361"), frames, 10)
+
+
 def test_config1_grayscale_then_rotate(built):
     """BASELINE configs[0] on the GPU: grayscale + rotate, 640x360."""
     frames = synth.stream("progressive", 640, 360, 4)
