@@ -1322,8 +1322,13 @@ __global__ __launch_bounds__(256) void format_kernel(FormatArgs a)
             constexpr uint64_t D4 = 0xB784ull | (0x3F0Cull << 16) | (0x95A6ull << 32) | (0x1D2Eull << 48);
             const unsigned dm = shift == 2 ? ((0x0321u >> (4 * ((y & 1) * 2 + (x & 1)))) & 15u)
                                            : (unsigned)((D4 >> (16 * (y & 3) + 4 * (x & 3))) & 15u);
-            const unsigned tmp = (v + dm) >> shift;
-            o = tmp - (tmp >> a.ddepth);
+            if (shiftonly)
+            {
+                const unsigned tmp = (v + dm) >> shift;
+                o = tmp - (tmp >> a.ddepth);
+            }
+            else
+                o = (v - (v >> a.ddepth) + dm) >> shift;                // full-range luma: DITHER_COPY's other arm
         }
         d[x] = (DST)o;
     }
@@ -1363,8 +1368,6 @@ extern "C" int hbhip_format_create(hbhip_ctx *ctx, int width, int height, int sr
     *out = nullptr;
     for (int d : {src_depth, dst_depth})
         if (d != 8 && d != 10 && d != 12) return HBHIP_ERR_UNSUPPORTED;
-    // the range-stretching dither of full-range luma on the way down is not restated
-    if (dst_depth < src_depth && full_range) return HBHIP_ERR_UNSUPPORTED;
     if (width < 1 || height < 1) return HBHIP_ERR_ARG;
     (void)hipSetDevice(ctx->device);
     FormatFilter *f = new (std::nothrow) FormatFilter(ctx, full_range);

@@ -348,8 +348,9 @@ int hbhip_pad_create(hbhip_ctx *ctx, const hbhip_pad_params *p, int width, int h
                      int log2_chroma_w, int log2_chroma_h, hbhip_filter **out);
 /* `format=pix_fmts=<fmt>` as format_init sets it up (format.c:13-111): libavfilter then converts with a same-size
  * `scale`, i.e. libswscale's unscaled planar copy.  Built: planar YUV depth changes 8 / 10 / 12 -> 8 / 10 / 12 with the
- * chroma subsampling unchanged (up: shift, full-range luma replicates the top bits; down: ordered dither, limited
- * range only - full-range down conversion returns HBHIP_ERR_UNSUPPORTED).  Arithmetic pinned to
+ * chroma subsampling unchanged (up: shift, full-range luma replicates the top bits; down: ordered dither - the
+ * shift-only form for chroma and limited-range luma, (v - (v >> dst_depth) + d) >> shift for full-range luma, both arms of
+ * swscale_unscaled.c's DITHER_COPY).  Arithmetic pinned to
  * oracle/alias_oracle.c:orc_format_plane only (parity unpinned). */
 int hbhip_format_create(hbhip_ctx *ctx, int width, int height, int src_depth, int dst_depth,
                         int log2_chroma_w, int log2_chroma_h, int full_range, hbhip_filter **out);

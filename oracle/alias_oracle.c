@@ -589,9 +589,10 @@ void orc_pad_plane(const void *src, int sw, int sh, int sstride, void *dst, int 
  *        full-range luma replicates the top bits: (v << (dd - sd)) | (v >> (2 sd - dd))
  *        (shiftonly = plane == 1 || plane == 2 || (!srcRange && plane == 0))
  *   down (10/12 -> 8, 12 -> 10): ordered dither, tmp = (v + dithers[shift - 1][y & 7][x & 7]) >> shift,
- *        out = tmp - (tmp >> dd)  (the clamp of the one value that can overflow) - the shiftonly form; the
- *        full-range luma form multiplies by a range-stretch factor first and is NOT restated (the HIP filter
- *        refuses it).  dithers[1] / dithers[3] (shift 2 / 4) are the 2x2 and 4x4 ordered matrices below.
+ *        out = tmp - (tmp >> dd)  (the clamp of the one value that can overflow) - the shiftonly form; full-range
+ *        luma takes the macro's other arm (DITHER_COPY, !shiftonly), which folds the top code values down BEFORE the
+ *        shift so that full scale maps onto full scale: out = (v - (v >> dd) + dither) >> shift.
+ *        dithers[1] / dithers[3] (shift 2 / 4) are the 2x2 and 4x4 ordered matrices below.
  * Same chroma subsampling on both sides; anything else (chroma resampling, semi-planar) is out of scope. */
 static const uint8_t k_dither2[2][2] = { { 1, 2 }, { 3, 0 } };
 static const uint8_t k_dither4[4][4] = { { 4, 8, 7, 11 }, { 12, 0, 15, 3 }, { 6, 10, 5, 9 }, { 14, 2, 13, 1 } };
@@ -601,7 +602,6 @@ int orc_format_plane(const void *src, int sstride, int sdepth, void *dst, int ds
 {
     const int sb = sdepth > 8 ? 2 : 1, db = ddepth > 8 ? 2 : 1;
     const int shiftonly = plane == 1 || plane == 2 || (!full_range && plane == 0);
-    if (sdepth > ddepth && !shiftonly) return -1;
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++)
         {
@@ -617,8 +617,13 @@ int orc_format_plane(const void *src, int sstride, int sdepth, void *dst, int ds
                 const int shift = sdepth - ddepth;
                 const unsigned d = shift == 2 ? k_dither2[y & 1][x & 1] : k_dither4[y & 3][x & 3];
                 if (shift != 2 && shift != 4) return -1;
-                const unsigned tmp = (v + d) >> shift;
-                o = tmp - (tmp >> ddepth);
+                if (shiftonly)
+                {
+                    const unsigned tmp = (v + d) >> shift;
+                    o = tmp - (tmp >> ddepth);
+                }
+                else
+                    o = (v - (v >> ddepth) + d) >> shift;
             }
             if (db == 1) ((uint8_t *)dst)[(size_t)y * dstride + x] = (uint8_t)o;
             else         ((uint16_t *)((uint8_t *)dst + (size_t)y * dstride))[x] = (uint16_t)o;

@@ -38,3 +38,21 @@ def test_down_conversion_dither_is_ordered_and_clamped(built):
     mono = tuple(np.arange(4096, dtype=np.uint16).reshape(64, 64) for _ in range(3))
     out = ol.orc_format_frame(mono, 12, 10)[0].astype(int).ravel()
     assert (np.diff(out) >= -1).all() and out[-1] == 1023
+
+
+def test_full_range_luma_down_conversion_maps_full_scale_to_full_scale(built):
+    """DITHER_COPY's !shiftonly arm, out = (v - (v >> dd) + dither) >> shift: 0 -> 0, full scale -> full scale for every
+    dither cell, monotone, and within one output code of the ideal v * (2^dd - 1) / (2^sd - 1)"""
+    for sd, dd in ((10, 8), (12, 8), (12, 10)):
+        n = 1 << sd
+        ramp = np.repeat(np.arange(n, dtype=np.uint16), 8)                  # every value under every cell of the 8x8 dither
+        plane = np.tile(ramp, (8, 1))
+        fr = (plane, plane[::2, ::2].copy(), plane[::2, ::2].copy())
+        out = ol.orc_format_frame(fr, sd, dd, full_range=True)[0].astype(int)
+        assert (out[:, :8] == 0).all() and (out[:, -8:] == (1 << dd) - 1).all()
+        cells = out.reshape(8, n, 8)                                         # [dither row, value, dither column]
+        assert (np.diff(cells, axis=1) >= 0).all() and out.max() == (1 << dd) - 1
+        ideal = ramp.astype(float) * ((1 << dd) - 1) / (n - 1)
+        assert np.abs(out - ideal[None, :]).max() <= 1.0
+        lim = ol.orc_format_frame(fr, sd, dd, full_range=False)[0].astype(int)
+        assert (lim != out).any()                                            # the limited-range form is another function

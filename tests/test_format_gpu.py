@@ -34,8 +34,25 @@ def test_full_range_luma_replicates_top_bits(built):
             for c in range(3):
                 np.testing.assert_array_equal(got[t].planes[c], want[c])
         assert int(got[0].planes[0].max()) > 1020 or int(frames[0][0].max()) < 255      # 255 -> 1023, not 1020
-        with pytest.raises(RuntimeError):                   # full-range down conversion is not restated: init fails
-            hbrt.Chain(hip.filters(), [("hb_filter_format_hip", "format=yuv420p")], 322, 182, hbrt.AV_PIX_FMT_YUV420P10)
+    finally:
+        hbrt.set_source_color(1, 1, 1, 1)
+
+
+@pytest.mark.parametrize("sd,dd", [(10, 8), (12, 8), (12, 10)])
+def test_full_range_luma_on_the_way_down(built, sd, dd):
+    """full-range luma takes DITHER_COPY's other arm (swscale_unscaled.c): the top code values are folded down before the
+    shift, so full scale lands on full scale; chroma stays shift-only"""
+    frames = synth.stream("random", 322, 182, 2, depth=sd)
+    frames[0][0][0, :4] = (1 << sd) - 1                         # a few full-scale samples
+    hbrt.set_source_color(1, 1, 1, 2)                          # pc range
+    try:
+        got = hbrt.run_stream(hip.filters(), [("hb_filter_format_hip", f"format={NAME[dd]}")], frames,
+                              pix_fmt=hbrt.PIX_FMT_FOR_DEPTH[sd])
+        for t in range(2):
+            want = ol.orc_format_frame(frames[t], sd, dd, full_range=True)
+            for c in range(3):
+                np.testing.assert_array_equal(got[t].planes[c], want[c], err_msg=f"{sd}->{dd} frame {t} plane {c}")
+        assert int(got[0].planes[0][0, 0]) == (1 << dd) - 1
     finally:
         hbrt.set_source_color(1, 1, 1, 1)
 
