@@ -531,8 +531,8 @@ __global__ __launch_bounds__(256) void scale8_v_kernel(Scale8Args a, const uint1
 }
 
 // ---- the swscale branch (cropscale.c:159-165: `scale=flags=lanczos+accurate_rnd` for sizes zscale is not used for -
-// an odd width or height): libswscale's arithmetic for 8-bit planar YUV, restated in oracle/alias_oracle.c
-// (orc_cropscale_plane_sws; PARITY UNPINNED like the zimg form).  px / py: first tapped source column / row of an output
+// an odd width or height): libswscale's arithmetic for planar YUV at 8 / 10 / 12 bits, restated in oracle/alias_oracle.c
+// (orc_cropscale_plane_sws / _sws16; PARITY UNPINNED like the zimg form).  px / py: first tapped source column / row of an output
 // column / row (taps outside the plane already folded onto the edge sample by the table), qx: 14-bit, qy: 12-bit
 // coefficients.  Two plain launches per plane: the sizes that come here are the odd ones, a fallback, not a hot path.
 struct ScaleSwsArgs
@@ -543,28 +543,31 @@ struct ScaleSwsArgs
     const short *qx, *qy;
 };
 
-__global__ __launch_bounds__(256) void scale8_sws_h_kernel(ScaleSwsArgs a, int16_t *__restrict__ hbuf)
+template <typename PIX>
+__global__ __launch_bounds__(256) void scale_sws_h_kernel(ScaleSwsArgs a, int16_t *__restrict__ hbuf, int sh)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int r = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= a.dw || r >= a.src_rows) return;
-    const uint8_t *row = a.src + (size_t)r * a.spitch + a.px[x];
+    const PIX *row = reinterpret_cast<const PIX *>(a.src + (size_t)r * a.spitch) + a.px[x];
     const short *q = a.qx + (size_t)x * a.tx;
     int val = 0;
     for (int j = 0; j < a.tx; j++) val += (int)row[j] * (int)q[j];
-    hbuf[(size_t)r * a.dw + x] = (int16_t)min(val >> 7, (1 << 15) - 1);             // hScale8To15_c
+    hbuf[(size_t)r * a.dw + x] = (int16_t)min(val >> sh, (1 << 15) - 1);            // hScale8To15_c (sh 7) / hScale16To15_c (depth - 1)
 }
 
-__global__ __launch_bounds__(256) void scale8_sws_v_kernel(ScaleSwsArgs a, const int16_t *__restrict__ hbuf)
+// yuv2planeX_8_c: the flat dither of 64 (round = 64 << 12, shift 19); yuv2planeX_10 / _12: half of the shift 27 - depth
+template <typename PIX>
+__global__ __launch_bounds__(256) void scale_sws_v_kernel(ScaleSwsArgs a, const int16_t *__restrict__ hbuf, int round, int shift, int vmax)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= a.dw || y >= a.dh) return;
     const int16_t *col = hbuf + (size_t)a.py[y] * a.dw + x;
     const short *q = a.qy + (size_t)y * a.ty;
-    int val = 64 << 12;                                                              // yuv2planeX_8_c with the flat dither of 64
+    int val = round;
     for (int j = 0; j < a.ty; j++) val += (int)col[(size_t)j * a.dw] * (int)q[j];
-    a.dst[(size_t)y * a.dpitch + x] = (uint8_t)min(max(val >> 19, 0), 255);
+    reinterpret_cast<PIX *>(a.dst + (size_t)y * a.dpitch)[x] = (PIX)min(max(val >> shift, 0), vmax);
 }
 
 // 6 x 6 taps (every upscale and same-size resampling, e.g. 1080p -> 2160p), both passes in one kernel, the three
@@ -1198,8 +1201,17 @@ public:
                         w.dw = out_geo.pw[c]; w.dh = out_geo.ph[c]; w.tx = tx[c]; w.ty = ty[c]; w.src_rows = crop_h[c];
                         w.px = d_bx[c]; w.py = d_by[c]; w.qx = d_qx[c]; w.qy = d_qy[c];
                         const dim3 gh((w.dw + 63) / 64, (crop_h[c] + 3) / 4), gv((w.dw + 63) / 64, (w.dh + 3) / 4);
-                        HBHIP_LAUNCH(ctx, "cropscale_sws_h", scale8_sws_h_kernel, gh, dim3(64, 4), 0, w, (int16_t *)hbuf16);
-                        HBHIP_LAUNCH(ctx, "cropscale_sws_v", scale8_sws_v_kernel, gv, dim3(64, 4), 0, w, (const int16_t *)hbuf16);
+                        if (in_geo.bps == 1)
+                        {
+                            HBHIP_LAUNCH(ctx, "cropscale_sws_h", scale_sws_h_kernel<uint8_t>, gh, dim3(64, 4), 0, w, (int16_t *)hbuf16, 7);
+                            HBHIP_LAUNCH(ctx, "cropscale_sws_v", scale_sws_v_kernel<uint8_t>, gv, dim3(64, 4), 0, w, (const int16_t *)hbuf16, 64 << 12, 19, 255);
+                        }
+                        else
+                        {
+                            const int d = in_geo.depth, shift = 11 + 16 - d;
+                            HBHIP_LAUNCH(ctx, "cropscale_sws_h", scale_sws_h_kernel<uint16_t>, gh, dim3(64, 4), 0, w, (int16_t *)hbuf16, d - 1);
+                            HBHIP_LAUNCH(ctx, "cropscale_sws_v", scale_sws_v_kernel<uint16_t>, gv, dim3(64, 4), 0, w, (const int16_t *)hbuf16, 1 << (shift - 1), shift, (1 << d) - 1);
+                        }
                         continue;
                     }
                     Scale8Args a;
@@ -1453,7 +1465,6 @@ extern "C" int hbhip_cropscale_create(hbhip_ctx *ctx, const hbhip_cropscale_para
 extern "C" int hbhip_cropscale_sws_create(hbhip_ctx *ctx, const hbhip_cropscale_params *p, int width, int height,
                                           int depth, int log2_chroma_w, int log2_chroma_h, hbhip_filter **out)
 {
-    if (depth != 8) return HBHIP_ERR_UNSUPPORTED;               // hScale16To19 / yuv2planeX_16: not restated
     return cropscale_create(ctx, p, width, height, depth, log2_chroma_w, log2_chroma_h, true, out);
 }
 

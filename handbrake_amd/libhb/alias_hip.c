@@ -139,15 +139,9 @@ static int crop_scale_hip_init(hb_filter_object_t *filter, hb_filter_init_t *ini
     /* crop_scale_init has two scalers (cropscale.c:97-165): zscale=filter=lanczos where hb_av_can_use_zscale() agrees
      * (hbffmpeg.c:870-915: every dimension even, a planar YUV format), else swscale `lanczos+accurate_rnd`, which computes
      * something else.  The drop-in follows the same rule with the restatement of the same library (both parity unpinned:
-     * neither library is in the reference tree).  The swscale form exists for 8-bit planes; an odd size at 10 / 12 bits is
-     * declined, so that the CPU filter stays (work.c:1861-1868) rather than being replaced by different arithmetic. */
+     * neither library is in the reference tree).  The swscale form covers 8-bit planes (hScale8To15 / yuv2planeX_8) and
+     * 10 / 12-bit planes (hScale16To15 / yuv2planeX_10, _12). */
     const int odd = (cropped_width & 1) || (cropped_height & 1) || (p.width & 1) || (p.height & 1);
-    if (odd && desc->comp[0].depth != 8)
-    {
-        hb_log("cropscale(hip): odd dimension %dx%d -> %dx%d at %d bits is the reference's swscale case, not built",
-               cropped_width, cropped_height, p.width, p.height, desc->comp[0].depth);
-        return alias_fail(filter, HBHIP_ERR_UNSUPPORTED);
-    }
 
     hbhip_ctx *ctx = hbhip_host_ctx_for(init);
     if (ctx == NULL) return alias_fail(filter, HBHIP_ERR_NODEVICE);

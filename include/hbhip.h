@@ -333,7 +333,7 @@ int hbhip_cropscale_create(hbhip_ctx *ctx, const hbhip_cropscale_params *p, int 
                            int depth, int log2_chroma_w, int log2_chroma_h, hbhip_filter **out);
 /* The other branch of crop_scale_init (cropscale.c:159-165): `crop` + `scale=flags=lanczos+accurate_rnd`, which the
  * reference builds when hb_av_can_use_zscale() says no (an odd width or height, hbffmpeg.c:870-915) - libswscale's
- * arithmetic instead of zimg's.  8-bit planes only. */
+ * arithmetic instead of zimg's (8-bit planes: hScale8To15 + yuv2planeX_8; 10 / 12-bit: hScale16To15 + yuv2planeX_10 / _12). */
 int hbhip_cropscale_sws_create(hbhip_ctx *ctx, const hbhip_cropscale_params *p, int width, int height,
                                int depth, int log2_chroma_w, int log2_chroma_h, hbhip_filter **out);
 /* FFmpeg `pad=width:height:x:y:color` as pad_init sets it up (pad.c:40-148): the picture at (x, y)

@@ -476,6 +476,48 @@ void orc_cropscale_plane_sws(const uint8_t *src, int sstride, int crop_x, int cr
     free(px); free(py); free(qx); free(qy); free(hbuf);
 }
 
+/* The swscale branch for 10 / 12-bit planes (libswscale: srcBpc > 8, dstBpc <= 14 -> hScale16To15_c, then the
+ * yuv2planeX_10 / _12 template).  Same filter tables; the 16-bit samples come down to the same 15-bit plane between the
+ * passes (>> depth - 1 instead of >> 7), the vertical pass rounds with half of its shift (no dither above 8 bits):
+ *     h   = min(sum_k q14[k] * src[k] >> (depth - 1), 32767)
+ *     out = clip_uintp2(((1 << (26 - depth)) + sum_k q12[k] * h[k]) >> (27 - depth), depth)
+ * PARITY UNPINNED like the 8-bit form.  sstride / dstride in bytes. */
+void orc_cropscale_plane_sws16(const uint16_t *src, int sstride, int crop_x, int crop_y, int crop_w, int crop_h,
+                               uint16_t *dst, int dstride, int dw, int dh, int chroma_h, int depth)
+{
+    const uint8_t *win = (const uint8_t *)src + (size_t)crop_y * sstride + (size_t)crop_x * 2;
+    int *px, *py;
+    int16_t *qx, *qy;
+    const int hpos = chroma_h ? 64 : 128;
+    const int tx = orc_sws_filter(crop_w, dw, 1 << 14, hpos, hpos, &px, &qx);
+    const int ty = orc_sws_filter(crop_h, dh, 1 << 12, 128, 128, &py, &qy);
+    const int sh = depth - 1, shift = 11 + 16 - depth, vmax = (1 << depth) - 1;
+    int16_t *hbuf = malloc(sizeof(int16_t) * (size_t)dw * crop_h);
+    for (int r = 0; r < crop_h; r++)
+    {
+        const uint16_t *row = (const uint16_t *)(win + (size_t)r * sstride);
+        for (int x = 0; x < dw; x++)
+        {
+            int val = 0;
+            for (int j = 0; j < tx; j++) val += (int)row[px[x] + j] * qx[(size_t)x * tx + j];
+            val >>= sh;
+            hbuf[(size_t)r * dw + x] = (int16_t)(val < (1 << 15) - 1 ? val : (1 << 15) - 1);
+        }
+    }
+    for (int y = 0; y < dh; y++)
+    {
+        uint16_t *out = (uint16_t *)((uint8_t *)dst + (size_t)y * dstride);
+        for (int x = 0; x < dw; x++)
+        {
+            int val = 1 << (shift - 1);
+            for (int j = 0; j < ty; j++) val += (int)hbuf[(size_t)(py[y] + j) * dw + x] * qy[(size_t)y * ty + j];
+            val >>= shift;
+            out[x] = (uint16_t)(val < 0 ? 0 : val > vmax ? vmax : val);
+        }
+    }
+    free(px); free(py); free(qx); free(qy); free(hbuf);
+}
+
 /* The same for 10 / 12-bit planes (uint16 samples).  zimg resizes a WORD plane at its own depth: per pass
  *     dst = clamp((sum_k c[k] * src[k] + (1 << 13)) >> 14, 0, (1 << depth) - 1)
  * (it holds the samples biased by -32768 to use signed 16-bit multiplies; a filter row sums to exactly 1 << 14, so

@@ -260,6 +260,8 @@ void orc_cropscale_plane_fx(const uint8_t *src, int sstride, int crop_x, int cro
 int  orc_sws_filter(int src, int dst, int one, int src_pos, int dst_pos, int **out_pos, int16_t **out_coef);
 void orc_cropscale_plane_sws(const uint8_t *src, int sstride, int crop_x, int crop_y, int crop_w, int crop_h,
                              uint8_t *dst, int dstride, int dw, int dh, int chroma_h);
+void orc_cropscale_plane_sws16(const uint16_t *src, int sstride, int crop_x, int crop_y, int crop_w, int crop_h,
+                               uint16_t *dst, int dstride, int dw, int dh, int chroma_h, int depth);
 /* the same at 10 / 12 bits: uint16 samples, both passes clamped to the depth (strides in bytes) */
 void orc_cropscale_plane_fx16(const uint16_t *src, int sstride, int crop_x, int crop_y, int crop_w, int crop_h,
                               uint16_t *dst, int dstride, int dw, int dh, double shift_x, double shift_y, int depth);

@@ -484,14 +484,18 @@ def orc_cropscale_frame(frame, width, height, top=0, bottom=0, left=0, right=0, 
     bits, orc_cropscale_plane_fx16 at 10 / 12: the form the HIP scaler runs and is compared with bit for bit; the
     default for even sizes), "double" = the float64 form (the independent check of the fixed-point forms), "sws" =
     libswscale's arithmetic (orc_cropscale_plane_sws: what crop_scale_init builds when a width or height is odd,
-    cropscale.c:159-165, and the default then, as in the reference; 8-bit planes)."""
+    cropscale.c:159-165, and the default then, as in the reference; orc_cropscale_plane_sws16 at 10 / 12 bits)."""
     h0, w0 = frame[0].shape
     if arithmetic is None:
         odd = ((w0 - left - right) | (h0 - top - bottom) | width | height) & 1
-        arithmetic = "sws" if odd and depth == 8 else "fixed"
+        arithmetic = "sws" if odd else "fixed"
     if arithmetic == "sws":
-        fn = oracle().orc_cropscale_plane_sws
+        fn = oracle().orc_cropscale_plane_sws if depth == 8 else oracle().orc_cropscale_plane_sws16
         fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        extra = []
+        if depth != 8:
+            fn.argtypes = fn.argtypes + [C.c_int]
+            extra = [depth]
         cw, ch = w0 - left - right, h0 - top - bottom
         out = []
         for c, p in enumerate(frame):
@@ -501,7 +505,7 @@ def orc_cropscale_frame(frame, width, height, top=0, bottom=0, left=0, right=0, 
             else:
                 cx, cy, pw, ph, dw, dh = left >> 1, top >> 1, (cw + 1) // 2, (ch + 1) // 2, (width + 1) // 2, (height + 1) // 2
             dst = np.zeros((dh, dw), p.dtype)
-            fn(p.ctypes.data, p.strides[0], cx, cy, pw, ph, dst.ctypes.data, dst.strides[0], dw, dh, int(c > 0))
+            fn(p.ctypes.data, p.strides[0], cx, cy, pw, ph, dst.ctypes.data, dst.strides[0], dw, dh, int(c > 0), *extra)
             out.append(dst)
         return tuple(out)
     if arithmetic == "fixed" and depth == 8:

@@ -218,3 +218,29 @@ def test_odd_sizes_default_to_the_swscale_form_as_in_the_reference(built):
     odd = ol.orc_cropscale_frame(fr, 641, 360)                                    # hb_av_can_use_zscale: no (hbffmpeg.c:888-892)
     assert all(np.array_equal(a, b) for a, b in zip(odd, ol.orc_cropscale_frame(fr, 641, 360, arithmetic="sws")))
     assert odd[1].shape == (180, 321)
+
+
+@pytest.mark.parametrize("depth", [10, 12])
+@pytest.mark.parametrize("w,h,ow,oh", [(321, 181, 641, 361), (641, 361, 321, 181), (720, 480, 853, 480)])
+def test_swscale_form_at_10_and_12_bits(built, depth, w, h, ow, oh):
+    """The 16-bit planes of the swscale branch (hScale16To15_c, yuv2planeX_10 / _12; PARITY UNPINNED).  Checked: the
+    plane between the passes is the same 15-bit plane as at 8 bits, so a picture whose samples are the 8-bit ones shifted
+    up comes out as the 8-bit result at the higher precision (within one 8-bit code value, 2^(depth-8) codes); the result
+    stays within 2 8-bit code values of the zimg form at that depth away from the edges; a flat plane stays flat and
+    full scale stays full scale."""
+    fr8 = synth.stream("progressive", w, h, 1)[0]
+    sh = depth - 8
+    fr = tuple((p.astype(np.uint16) << sh) for p in fr8)
+    sws = ol.orc_cropscale_frame(fr, ow, oh, depth=depth, arithmetic="sws")
+    sws8 = ol.orc_cropscale_frame(fr8, ow, oh, arithmetic="sws")
+    zim = ol.orc_cropscale_frame(fr, ow, oh, depth=depth, arithmetic="fixed")
+    for c in range(3):
+        assert sws[c].dtype == np.uint16 and int(sws[c].max()) < (1 << depth)
+        d = np.abs(sws[c].astype(int) - (sws8[c].astype(int) << sh))
+        assert d.max() <= (1 << sh), (c, d.max())
+        d = np.abs(sws[c].astype(int) - zim[c].astype(int))[8:-8, 8:-8]
+        assert d.max() <= (2 << sh) and (d <= (1 << sh)).mean() >= 0.999, (c, d.max())
+    top = (1 << depth) - 1
+    flat = tuple(np.full(p.shape, v, np.uint16) for p, v in zip(fr, (top, 1 << (depth - 1), 0)))
+    out = ol.orc_cropscale_frame(flat, ow, oh, depth=depth, arithmetic="sws")
+    assert (out[0] == top).all() and (out[1] == 1 << (depth - 1)).all() and (out[2] == 0).all()

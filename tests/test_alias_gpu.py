@@ -68,11 +68,19 @@ def test_cropscale_odd_sizes_take_the_swscale_form(built, w, h, ow, oh, crop):
     assert (got[0].width, got[0].height) == (ow, oh)
 
 
-def test_cropscale_odd_size_at_10_bits_is_declined(built):
-    """libswscale's 16-bit path is not restated: the drop-in's init fails and libhb keeps its CPU filter"""
-    frames = synth.stream("progressive", 321, 181, 1, depth=10)
-    with pytest.raises(RuntimeError):
-        run16(("hb_filter_crop_scale_hip", "width=641:height=361"), frames, 10)
+@pytest.mark.parametrize("depth", [10, 12])
+@pytest.mark.parametrize("w,h,ow,oh,crop", [(321, 181, 641, 361, (0, 0, 0, 0)), (638, 362, 851, 481, (2, 4, 6, 8)),
+                                            (641, 361, 321, 181, (0, 0, 0, 0)), (640, 360, 641, 360, (0, 0, 0, 0))])
+def test_cropscale_odd_sizes_at_10_and_12_bits(built, depth, w, h, ow, oh, crop):
+    """The same branch on 16-bit planes: libswscale's hScale16To15_c + yuv2planeX_10 / _12 as restated in
+    oracle/alias_oracle.c: orc_cropscale_plane_sws16 (parity unpinned), bit for bit."""
+    frames = synth.stream("progressive", w, h, 2, depth=depth) + synth.stream("random", w, h, 1, depth=depth)
+    t, b, l, r = crop
+    st = f"width={ow}:height={oh}:crop-top={t}:crop-bottom={b}:crop-left={l}:crop-right={r}"
+    got = run16(("hb_filter_crop_scale_hip", st), frames, depth)
+    want = [ol.orc_cropscale_frame(fr, ow, oh, top=t, bottom=b, left=l, right=r, depth=depth, arithmetic="sws") for fr in frames]
+    check(got, want)
+    assert max(int(p.max()) for g in got for p in g.planes) < (1 << depth)
 
 
 def test_config1_grayscale_then_rotate(built):
