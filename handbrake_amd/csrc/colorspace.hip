@@ -8,11 +8,12 @@
 // whose header lists what is restated and what is simplified).
 //
 // MI355X shape: the CPU graph makes five passes over float planes (to float, chroma to 4:4:4,
-// colour conversion, chroma back to 4:2:0, to integer).  Here one launch does all of it: a
-// workgroup owns a 64 x 16 luma tile, converts the tile plus the one-column / three-row apron the
-// chroma decimation needs, keeps the converted Cb'/Cr' of that region in LDS (10 KB), writes luma
-// straight out and then decimates chroma from LDS.  HBM traffic is the input frame once and the
-// output frame once; the transfer-function tables (2 x 64 KB) stay in L2.
+// colour conversion, chroma back to 4:2:0, to integer).  Here one launch does all of it for up to 16 frames: a
+// workgroup owns a 60 x 30 luma tile (4:2:0; 64 / 32 where a direction is not subsampled), converts the tile plus the
+// apron the chroma decimation needs (four columns to the left, one row above and below: a 64 x 32 region, two passes of
+// 256 threads with four adjacent pixels each - dword loads and stores, the chroma samples of the four shared), keeps
+// the converted Cb'/Cr' of the region in LDS (16 KB), writes luma straight out and then decimates chroma from LDS.
+// HBM traffic is the input frame once and the output frame once.
 #include "hbhip_internal.h"
 
 #include <cmath>
@@ -21,7 +22,7 @@
 
 namespace {
 
-constexpr int CS_TW = 64, CS_TH = 16, CS_RW = CS_TW + 2, CS_RH = CS_TH + 3;
+constexpr int CS_RW = 64, CS_RH = 32, CS_FRAMES = 16;
 
 struct CsPlan
 {
@@ -34,17 +35,18 @@ struct CsPlan
     float lin_scale, gam_scale;          // PQ / HLG: display-light scale after the EOTF / before its inverse
 };
 
-struct CsArgs
+struct CsBatch
 {
-    const uint8_t *src[3];
-    uint8_t       *dst[3];
+    const uint8_t *src[CS_FRAMES][3];
+    uint8_t       *dst[CS_FRAMES][3];
     int spitch[3], dpitch[3];
-    int w, h, cw, ch, subw, subh;
+    int w, h, cw, ch;
 };
 
 // ---- per-sample pipeline: every operation in float, correctly rounded, in the oracle's order ----
-// Deterministic float math: range reduction + fixed polynomials in IEEE single +, -, *, / (no contraction, correctly
-// rounded division) - the operation sequence of oracle/colorspace_oracle.c's det_* routines, so that transfer
+// Deterministic float math: range reduction + fixed polynomials in IEEE single +, -, *, / and explicit fused
+// multiply-adds (nothing contracted by the compiler, correctly rounded division) - the operation sequence of
+// oracle/colorspace_oracle.c's det_* routines, so that transfer
 // functions can be evaluated per sample (no tables, nothing clipped before the integer conversion) and still
 // come out bit for bit as the checker's.  HOST_DEV: the same code builds the per-filter tone-map constants on the host.
 #define HBHIP_HD __host__ __device__ __forceinline__
@@ -59,20 +61,35 @@ HBHIP_HD float fdiv(float a, float b)
 #endif
 }
 
+HBHIP_HD float ffma(float a, float b, float c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __fmaf_rn(a, b, c);
+#else
+    return fmaf(a, b, c);
+#endif
+}
+
 HBHIP_HD float det_log2f(float x)
 {
     const uint32_t bits = f2u(x);
     int e = (int)(bits >> 23) - 127;
     float m = u2f((bits & 0x007fffffu) | 0x3f800000u);
     if (m > 1.41421354f) { m = m * 0.5f; e += 1; }
-    const float t = fdiv(m - 1.0f, m + 1.0f);
-    const float t2 = t * t;
-    float p = 0.111111112f;
-    p = p * t2 + 0.142857149f;
-    p = p * t2 + 0.200000003f;
-    p = p * t2 + 0.333333343f;
-    p = p * t2 + 1.0f;
-    return (float)e + (t * p) * 2.88539004f;
+    const float f = m - 1.0f;
+    const float z = f * f;
+    float p = 7.0376836292e-2f;
+    p = ffma(p, f, -1.1514610310e-1f);
+    p = ffma(p, f, 1.1676998740e-1f);
+    p = ffma(p, f, -1.2420140846e-1f);
+    p = ffma(p, f, 1.4249322787e-1f);
+    p = ffma(p, f, -1.6668057665e-1f);
+    p = ffma(p, f, 2.0000714765e-1f);
+    p = ffma(p, f, -2.4999993993e-1f);
+    p = ffma(p, f, 3.3333331174e-1f);
+    float y = (f * z) * p;
+    y = ffma(-0.5f, z, y);
+    return ffma(f + y, 1.44269502f, (float)e);
 }
 
 HBHIP_HD float det_exp2f(float y)
@@ -82,13 +99,13 @@ HBHIP_HD float det_exp2f(float y)
     const int i = (int)(y + (y < 0.0f ? -0.5f : 0.5f));
     const float z = (y - (float)i) * 0.693147182f;
     float p = 0.000198412701f;
-    p = p * z + 0.00138888892f;
-    p = p * z + 0.00833333377f;
-    p = p * z + 0.0416666679f;
-    p = p * z + 0.166666672f;
-    p = p * z + 0.5f;
-    p = p * z + 1.0f;
-    p = p * z + 1.0f;
+    p = ffma(p, z, 0.00138888892f);
+    p = ffma(p, z, 0.00833333377f);
+    p = ffma(p, z, 0.0416666679f);
+    p = ffma(p, z, 0.166666672f);
+    p = ffma(p, z, 0.5f);
+    p = ffma(p, z, 1.0f);
+    p = ffma(p, z, 1.0f);
     return p * u2f((uint32_t)(i + 127) << 23);
 }
 
@@ -156,7 +173,7 @@ __device__ __forceinline__ float to_gamma_dev(int cls, float x)
         {
             if (x <= 0.0f) return 0.0f;
             const float s = det_powf(x, 1.0f / 1.2f);
-            return s <= 1.0f / 12.0f ? __fsqrt_rn(3.0f * s) : 0.17883277f * det_logf(12.0f * s - 0.28466892f) + 0.55991073f;
+            return s <= 1.0f / 12.0f ? __builtin_sqrtf(3.0f * s) : 0.17883277f * det_logf(12.0f * s - 0.28466892f) + 0.55991073f;
         }
     }
     return x;
@@ -185,20 +202,27 @@ __device__ __forceinline__ float tonemap_sig(const CsPlan &p, float sig)
     return sig;
 }
 
+__device__ __forceinline__ float row3(const float (&m)[3], float a, float b, float c)
+{
+    return __fmaf_rn(m[2], c, __fmaf_rn(m[1], b, m[0] * a));
+}
+
+// LINEAR = false: the instantiation for conversions without a trip through linear light (one matrix)
+template <bool LINEAR>
 __device__ __forceinline__ void convert_px(const CsPlan &p, float y, float u, float v, float out[3])
 {
-    if (!p.need_linear)
+    if (!LINEAR || !p.need_linear)
     {
 #pragma unroll
         for (int i = 0; i < 3; i++)
-            out[i] = p.m_direct[i][0] * y + p.m_direct[i][1] * u + p.m_direct[i][2] * v;
+            out[i] = row3(p.m_direct[i], y, u, v);
         return;
     }
     float c[3], g[3];
 #pragma unroll
     for (int i = 0; i < 3; i++)
     {
-        const float e = p.m_in[i][0] * y + p.m_in[i][1] * u + p.m_in[i][2] * v;
+        const float e = row3(p.m_in[i], y, u, v);
         c[i] = to_linear_dev(p.tc_in, e) * p.lin_scale;
     }
     if (p.tonemap >= 0)
@@ -214,7 +238,7 @@ __device__ __forceinline__ void convert_px(const CsPlan &p, float y, float u, fl
     {
 #pragma unroll
         for (int i = 0; i < 3; i++)
-            g[i] = p.m_gamut[i][0] * c[0] + p.m_gamut[i][1] * c[1] + p.m_gamut[i][2] * c[2];
+            g[i] = row3(p.m_gamut[i], c[0], c[1], c[2]);
     }
     else
     {
@@ -226,86 +250,228 @@ __device__ __forceinline__ void convert_px(const CsPlan &p, float y, float u, fl
         g[i] = to_gamma_dev(p.tc_out, g[i] * p.gam_scale);
 #pragma unroll
     for (int i = 0; i < 3; i++)
-        out[i] = p.m_out[i][0] * g[0] + p.m_out[i][1] * g[1] + p.m_out[i][2] * g[2];
+        out[i] = row3(p.m_out[i], g[0], g[1], g[2]);
 }
 
 __device__ __forceinline__ int quant(float v, float mul, float off, int vmax)
 {
-    float t = v * mul + off;                 // +-inf / NaN (out-of-gamut input beyond a transfer function's pole): to the clip limits
+    float t = __fmaf_rn(v, mul, off);        // +-inf / NaN (out-of-gamut input beyond a transfer function's pole): to the clip limits
     if (!(t > -1e9f)) t = -1e9f;
     if (t > 1e9f) t = 1e9f;
     const int q = __float2int_rn(t);
     return q < 0 ? 0 : q > vmax ? vmax : q;
 }
 
-template <typename PIX>
-__device__ __forceinline__ float sample(const uint8_t *plane, int pitch, int x, int y)
-{
-    return (float)reinterpret_cast<const PIX *>(plane + (size_t)y * pitch)[x];
-}
-
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
 
 template <typename PIX>
-__global__ __launch_bounds__(256) void colorspace_kernel(CsArgs a, CsPlan p)
-{
-    __shared__ float s_u[CS_RH][CS_RW], s_v[CS_RH][CS_RW];
-    const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * CS_TW, y0 = blockIdx.y * CS_TH;
-    const int hx = a.subw ? 1 : 0, hy = a.subh ? 1 : 0;
-    const int rw = CS_TW + hx, rh = CS_TH + (a.subh ? 3 : 0);
+__device__ __forceinline__ float samp(const uint8_t *row, int x) { return (float)reinterpret_cast<const PIX *>(row)[x]; }
 
-    // phase 1: convert the tile and its apron at luma resolution
-    for (int i = tid; i < rw * rh; i += 256)
+// SUBW / SUBH: log2 of the chroma subsampling.  Region = CS_RW x CS_RH luma positions starting HX columns left of and HY
+// rows above the tile; thread (gx, gr) converts the four positions 4 gx .. 4 gx + 3 of region rows gr and gr + 16.  The
+// samples of both rows are fetched before the first is converted (one memory latency per workgroup, not two).
+template <typename PIX, int SUBW, int SUBH, bool LINEAR>
+__global__ __launch_bounds__(256) void colorspace_kernel(CsBatch a, CsPlan p)
+{
+    constexpr int HX = SUBW ? 4 : 0, HY = SUBH ? 1 : 0, TW = CS_RW - HX, TH = CS_RH - 2 * HY;
+    constexpr bool LDS = SUBW || SUBH;
+    constexpr int NC = SUBW ? 3 : 4;                               // chroma columns under four positions
+    __shared__ __attribute__((aligned(16))) float s_u[LDS ? CS_RH : 1][CS_RW], s_v[LDS ? CS_RH : 1][CS_RW];
+    const int f = blockIdx.z;
+    const uint8_t *sy = a.src[f][0], *su = a.src[f][1], *sv = a.src[f][2];
+    uint8_t *dy = a.dst[f][0];
+    const int tid = threadIdx.x, gx = tid & 15, gr = tid >> 4;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int ux = x0 - HX + 4 * gx;                              // unclamped column of the thread's first position
+    const bool wide = sizeof(PIX) == 1 ? ((a.dpitch[0] | a.spitch[0]) & 3) == 0 && (((uintptr_t)dy | (uintptr_t)sy) & 3) == 0
+                                       : ((a.dpitch[0] | a.spitch[0]) & 7) == 0 && (((uintptr_t)dy | (uintptr_t)sy) & 7) == 0;
+    // four positions none of which is clamped, rows that can be moved as dwords: luma as one load, the chroma columns
+    // they share once
+    const bool inner = wide && ux >= 0 && ux + 3 <= a.w - 1;
+    int cc[NC];
+    if (SUBW) { cc[0] = ux >> 1; cc[1] = cc[0] + 1; cc[NC - 1] = min(cc[0] + 2, a.cw - 1); }
+    else
     {
-        const int ry = i / rw, rx = i - ry * rw;
-        const int ux = x0 - hx + rx, uy = y0 - hy + ry;              // unclamped luma position
-        const int x = clampi(ux, 0, a.w - 1), y = clampi(uy, 0, a.h - 1);
-        int r0 = y, r1 = y, c0 = x, c1 = x;
-        float wy0 = 1.f, wy1 = 0.f, wx0 = 1.f, wx1 = 0.f;
-        if (a.subh)
-        {
-            const int k = y >> 1;
-            if (y & 1) { r0 = k; r1 = clampi(k + 1, 0, a.ch - 1); wy0 = 0.75f; wy1 = 0.25f; }
-            else       { r0 = clampi(k - 1, 0, a.ch - 1); r1 = k; wy0 = 0.25f; wy1 = 0.75f; }
-        }
-        if (a.subw)
-        {
-            c0 = x >> 1; c1 = c0;
-            if (x & 1) { c1 = clampi(c0 + 1, 0, a.cw - 1); wx0 = 0.5f; wx1 = 0.5f; }
-        }
-        float uv[2];
 #pragma unroll
-        for (int k = 0; k < 2; k++)
-        {
-            const uint8_t *pl = a.src[1 + k];
-            const int pt = a.spitch[1 + k];
-            const float s00 = (sample<PIX>(pl, pt, c0, r0) - p.coff_in) * p.cmul_in;
-            const float s10 = (sample<PIX>(pl, pt, c0, r1) - p.coff_in) * p.cmul_in;
-            const float s01 = (sample<PIX>(pl, pt, c1, r0) - p.coff_in) * p.cmul_in;
-            const float s11 = (sample<PIX>(pl, pt, c1, r1) - p.coff_in) * p.cmul_in;
-            const float va = wy0 * s00 + wy1 * s10;
-            const float vb = wy0 * s01 + wy1 * s11;
-            uv[k] = wx0 * va + wx1 * vb;
-        }
-        const float yf = (sample<PIX>(a.src[0], a.spitch[0], x, y) - p.yoff_in) * p.ymul_in;
-        float o[3];
-        convert_px(p, yf, uv[0], uv[1], o);
-        s_u[ry][rx] = o[1];
-        s_v[ry][rx] = o[2];
-        if (ux >= x0 && ux < x0 + CS_TW && ux < a.w && uy >= y0 && uy < y0 + CS_TH && uy < a.h)
-            reinterpret_cast<PIX *>(a.dst[0] + (size_t)uy * a.dpitch[0])[ux] = (PIX)quant(o[0], p.ymul_out, p.yoff_out, p.vmax);
+        for (int j = 0; j < NC; j++) cc[j] = ux + j;
     }
+    struct Rows { int y, r0, r1; float wy0, wy1; };
+    auto rows_of = [&](int uy) __attribute__((always_inline)) {
+        Rows r;
+        r.y = clampi(uy, 0, a.h - 1);
+        r.r0 = r.r1 = r.y; r.wy0 = 1.f; r.wy1 = 0.f;
+        if (SUBH)
+        {
+            const int k = r.y >> 1;
+            if (r.y & 1) { r.r0 = k; r.r1 = min(k + 1, a.ch - 1); r.wy0 = 0.75f; r.wy1 = 0.25f; }
+            else         { r.r0 = max(k - 1, 0); r.r1 = k; r.wy0 = 0.25f; r.wy1 = 0.75f; }
+        }
+        return r;
+    };
+    struct Raw { uint32_t ly0, ly1; uint32_t u0[NC], u1[NC], v0[NC], v1[NC]; };
+    auto fetch = [&](int uy) __attribute__((always_inline)) {
+        Raw w = {};
+        if (!inner || uy > a.h + 1) return w;
+        const Rows r = rows_of(uy);
+        const uint8_t *yrow = sy + (size_t)r.y * a.spitch[0];
+        if (sizeof(PIX) == 1) w.ly0 = *reinterpret_cast<const uint32_t *>(yrow + ux);
+        else { const uint2 v = *reinterpret_cast<const uint2 *>(yrow + 2 * ux); w.ly0 = v.x; w.ly1 = v.y; }
+        const PIX *u0 = reinterpret_cast<const PIX *>(su + (size_t)r.r0 * a.spitch[1]), *u1 = reinterpret_cast<const PIX *>(su + (size_t)r.r1 * a.spitch[1]);
+        const PIX *v0 = reinterpret_cast<const PIX *>(sv + (size_t)r.r0 * a.spitch[2]), *v1 = reinterpret_cast<const PIX *>(sv + (size_t)r.r1 * a.spitch[2]);
+#pragma unroll
+        for (int j = 0; j < NC; j++)
+        {
+            w.u0[j] = u0[cc[j]]; w.v0[j] = v0[cc[j]];
+            if (SUBH) { w.u1[j] = u1[cc[j]]; w.v1[j] = v1[cc[j]]; }
+        }
+        return w;
+    };
+    // (the instantiation with the transfer functions has its registers full of them: it fetches a row when it gets there)
+    Raw rawA = {}, rawB = {};
+    if constexpr (!LINEAR) { rawA = fetch(y0 - HY + gr); rawB = fetch(y0 - HY + gr + 16); }
+
+    // phase 1: convert the region at luma resolution (positions outside the picture are the nearest one inside: what
+    // the decimation reads there).  (With the transfer functions inlined a conversion is a few hundred instructions: the
+    // two passes are a loop there.)
+    auto pass = [&](int it) __attribute__((always_inline)) {
+        const int ry = gr + 16 * it;
+        const int uy = y0 - HY + ry;
+        if (ux > a.w || uy > a.h + 1) return;                      // nothing reads a position beyond column w, row h + 1
+        const Rows r = rows_of(uy);
+        const float wy0 = r.wy0, wy1 = r.wy1;
+        float yf[4], uf[4], vf[4];
+        if (inner)
+        {
+            Raw w;
+            if constexpr (LINEAR) w = fetch(uy);
+            else w = it ? rawB : rawA;
+            float ys[4];
+            if (sizeof(PIX) == 1)
+            {
+#pragma unroll
+                for (int j = 0; j < 4; j++) ys[j] = (float)((w.ly0 >> (8 * j)) & 0xffu);
+            }
+            else
+            {
+                ys[0] = (float)(w.ly0 & 0xffffu); ys[1] = (float)(w.ly0 >> 16); ys[2] = (float)(w.ly1 & 0xffffu); ys[3] = (float)(w.ly1 >> 16);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) yf[j] = (ys[j] - p.yoff_in) * p.ymul_in;
+            float cu[NC], cv[NC];
+#pragma unroll
+            for (int j = 0; j < NC; j++)
+            {
+                const float u0 = ((float)w.u0[j] - p.coff_in) * p.cmul_in, v0 = ((float)w.v0[j] - p.coff_in) * p.cmul_in;
+                if (SUBH)
+                {
+                    const float u1 = ((float)w.u1[j] - p.coff_in) * p.cmul_in, v1 = ((float)w.v1[j] - p.coff_in) * p.cmul_in;
+                    cu[j] = __fmaf_rn(wy1, u1, wy0 * u0);
+                    cv[j] = __fmaf_rn(wy1, v1, wy0 * v0);
+                }
+                else { cu[j] = u0; cv[j] = v0; }
+            }
+            if (SUBW)
+            {
+                uf[0] = cu[0]; uf[1] = __fmaf_rn(0.5f, cu[1], 0.5f * cu[0]); uf[2] = cu[1]; uf[3] = __fmaf_rn(0.5f, cu[NC - 1], 0.5f * cu[1]);
+                vf[0] = cv[0]; vf[1] = __fmaf_rn(0.5f, cv[1], 0.5f * cv[0]); vf[2] = cv[1]; vf[3] = __fmaf_rn(0.5f, cv[NC - 1], 0.5f * cv[1]);
+            }
+            else
+            {
+#pragma unroll
+                for (int j = 0; j < 4; j++) { uf[j] = cu[j]; vf[j] = cv[j]; }
+            }
+        }
+        else
+        {
+            const uint8_t *yrow = sy + (size_t)r.y * a.spitch[0];
+            const uint8_t *urow0 = su + (size_t)r.r0 * a.spitch[1], *urow1 = su + (size_t)r.r1 * a.spitch[1];
+            const uint8_t *vrow0 = sv + (size_t)r.r0 * a.spitch[2], *vrow1 = sv + (size_t)r.r1 * a.spitch[2];
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+            {
+                const int x = clampi(ux + j, 0, a.w - 1);
+                yf[j] = (samp<PIX>(yrow, x) - p.yoff_in) * p.ymul_in;
+                int c0 = x, c1 = x;
+                bool mix = false;
+                if (SUBW) { c0 = x >> 1; c1 = c0; if (x & 1) { c1 = min(c0 + 1, a.cw - 1); mix = true; } }
+                float au, bu, av, bv;
+                {
+                    const float u00 = (samp<PIX>(urow0, c0) - p.coff_in) * p.cmul_in, u01 = (samp<PIX>(urow0, c1) - p.coff_in) * p.cmul_in;
+                    const float v00 = (samp<PIX>(vrow0, c0) - p.coff_in) * p.cmul_in, v01 = (samp<PIX>(vrow0, c1) - p.coff_in) * p.cmul_in;
+                    if (SUBH)
+                    {
+                        const float u10 = (samp<PIX>(urow1, c0) - p.coff_in) * p.cmul_in, u11 = (samp<PIX>(urow1, c1) - p.coff_in) * p.cmul_in;
+                        const float v10 = (samp<PIX>(vrow1, c0) - p.coff_in) * p.cmul_in, v11 = (samp<PIX>(vrow1, c1) - p.coff_in) * p.cmul_in;
+                        au = __fmaf_rn(wy1, u10, wy0 * u00); bu = __fmaf_rn(wy1, u11, wy0 * u01);
+                        av = __fmaf_rn(wy1, v10, wy0 * v00); bv = __fmaf_rn(wy1, v11, wy0 * v01);
+                    }
+                    else { au = u00; bu = u01; av = v00; bv = v01; }
+                }
+                uf[j] = mix ? __fmaf_rn(0.5f, bu, 0.5f * au) : au;
+                vf[j] = mix ? __fmaf_rn(0.5f, bv, 0.5f * av) : av;
+            }
+        }
+        float oy[4], ou[4], ov[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+        {
+            float o[3];
+            convert_px<LINEAR>(p, yf[j], uf[j], vf[j], o);
+            oy[j] = o[0]; ou[j] = o[1]; ov[j] = o[2];
+        }
+        if (LDS)
+        {
+            *reinterpret_cast<float4 *>(&s_u[ry][4 * gx]) = make_float4(ou[0], ou[1], ou[2], ou[3]);
+            *reinterpret_cast<float4 *>(&s_v[ry][4 * gx]) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+        }
+        // the tile's own positions: luma out (and chroma, where it is not subsampled)
+        if (ux >= x0 && ux < a.w && uy >= y0 && uy < y0 + TH && uy < a.h)
+        {
+            uint32_t q[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) q[j] = (uint32_t)quant(oy[j], p.ymul_out, p.yoff_out, p.vmax);
+            PIX *d = reinterpret_cast<PIX *>(dy + (size_t)uy * a.dpitch[0]) + ux;
+            if (inner)
+            {
+                if (sizeof(PIX) == 1) *reinterpret_cast<uint32_t *>(d) = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
+                else                  *reinterpret_cast<uint2 *>(d) = make_uint2(q[0] | (q[1] << 16), q[2] | (q[3] << 16));
+            }
+            else
+            {
+#pragma unroll
+                for (int j = 0; j < 4; j++) if (ux + j < a.w) d[j] = (PIX)q[j];
+            }
+            if (!LDS)
+            {
+                PIX *du = reinterpret_cast<PIX *>(a.dst[f][1] + (size_t)uy * a.dpitch[1]) + ux;
+                PIX *dv = reinterpret_cast<PIX *>(a.dst[f][2] + (size_t)uy * a.dpitch[2]) + ux;
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (ux + j < a.w)
+                    {
+                        du[j] = (PIX)quant(ou[j], p.cmul_out, p.coff_out, p.vmax);
+                        dv[j] = (PIX)quant(ov[j], p.cmul_out, p.coff_out, p.vmax);
+                    }
+            }
+        }
+    };
+    if (LINEAR)
+    {
+#pragma unroll 1
+        for (int it = 0; it < 2; it++) pass(it);
+    }
+    else { pass(0); pass(1); }
+    if (!LDS) return;
     __syncthreads();
 
     // phase 2: chroma of the tile, decimated from LDS (rows first, then columns)
-    const int ncx = CS_TW >> a.subw, ncy = CS_TH >> a.subh;
-    for (int i = tid; i < ncx * ncy; i += 256)
+    constexpr int NCX = TW >> SUBW, NCY = TH >> SUBH;
+    for (int i = tid; i < NCX * NCY; i += 256)
     {
-        const int oy = i / ncx, ox = i - oy * ncx;
-        const int cx = (x0 >> a.subw) + ox, cy = (y0 >> a.subh) + oy;
+        const int oy = i / NCX, ox = i - oy * NCX;
+        const int cx = (x0 >> SUBW) + ox, cy = (y0 >> SUBH) + oy;
         if (cx >= a.cw || cy >= a.ch) continue;
-        const int rx = (ox << a.subw) + hx, ry = (oy << a.subh) + hy;
+        const int rx = (ox << SUBW) + HX, ry = (oy << SUBH) + HY;
 #pragma unroll
         for (int k = 0; k < 2; k++)
         {
@@ -314,12 +480,13 @@ __global__ __launch_bounds__(256) void colorspace_kernel(CsArgs a, CsPlan p)
 #pragma unroll
             for (int j = 0; j < 3; j++)
             {
-                const int xx = a.subw ? rx - 1 + j : rx;
-                col[j] = a.subh ? 0.125f * s[ry - 1][xx] + 0.375f * s[ry][xx] + 0.375f * s[ry + 1][xx] + 0.125f * s[ry + 2][xx]
-                                : s[ry][xx];
+                if (!SUBW && j != 1) continue;
+                const int xx = SUBW ? rx - 1 + j : rx;
+                col[j] = SUBH ? __fmaf_rn(0.125f, s[ry + 2][xx], __fmaf_rn(0.375f, s[ry + 1][xx], __fmaf_rn(0.375f, s[ry][xx], 0.125f * s[ry - 1][xx])))
+                              : s[ry][xx];
             }
-            const float v = a.subw ? 0.25f * col[0] + 0.5f * col[1] + 0.25f * col[2] : col[1];
-            reinterpret_cast<PIX *>(a.dst[1 + k] + (size_t)cy * a.dpitch[1 + k])[cx] = (PIX)quant(v, p.cmul_out, p.coff_out, p.vmax);
+            const float v = SUBW ? __fmaf_rn(0.25f, col[2], __fmaf_rn(0.5f, col[1], 0.25f * col[0])) : col[1];
+            reinterpret_cast<PIX *>(a.dst[f][1 + k] + (size_t)cy * a.dpitch[1 + k])[cx] = (PIX)quant(v, p.cmul_out, p.coff_out, p.vmax);
         }
     }
 }
@@ -549,21 +716,57 @@ public:
         }
         return HBHIP_OK;
     }
+    template <typename PIX>
+    void launch(const CsBatch &B, int nf)
+    {
+        const int sw = in_geo.log2_cw, sh = in_geo.log2_ch;
+        const int tw = CS_RW - (sw ? 4 : 0), th = CS_RH - (sh ? 2 : 0);
+        const dim3 grid((B.w + tw - 1) / tw, (B.h + th - 1) / th, nf);
+        if (plan.need_linear)
+        {
+            if (sw && sh)       HBHIP_LAUNCH(ctx, "colorspace", (colorspace_kernel<PIX, 1, 1, true>), grid, dim3(256), 0, B, plan);
+            else if (sw)        HBHIP_LAUNCH(ctx, "colorspace", (colorspace_kernel<PIX, 1, 0, true>), grid, dim3(256), 0, B, plan);
+            else if (sh)        HBHIP_LAUNCH(ctx, "colorspace", (colorspace_kernel<PIX, 0, 1, true>), grid, dim3(256), 0, B, plan);
+            else                HBHIP_LAUNCH(ctx, "colorspace", (colorspace_kernel<PIX, 0, 0, true>), grid, dim3(256), 0, B, plan);
+        }
+        else
+        {
+            if (sw && sh)       HBHIP_LAUNCH(ctx, "colorspace", (colorspace_kernel<PIX, 1, 1, false>), grid, dim3(256), 0, B, plan);
+            else if (sw)        HBHIP_LAUNCH(ctx, "colorspace", (colorspace_kernel<PIX, 1, 0, false>), grid, dim3(256), 0, B, plan);
+            else if (sh)        HBHIP_LAUNCH(ctx, "colorspace", (colorspace_kernel<PIX, 0, 1, false>), grid, dim3(256), 0, B, plan);
+            else                HBHIP_LAUNCH(ctx, "colorspace", (colorspace_kernel<PIX, 0, 0, false>), grid, dim3(256), 0, B, plan);
+        }
+    }
+    // the frames of a batch (a chain batch, a device-resident batch) in one launch where their pitches agree
+    int process_many(DevPicture *const *ins, DevPicture *const *outs, int n) override
+    {
+        int at = 0;
+        while (at < n)
+        {
+            int nf = 1;
+            auto same = [&](int i) {
+                for (int c = 0; c < 3; c++)
+                    if (ins[i]->pitch[c] != ins[at]->pitch[c] || outs[i]->pitch[c] != outs[at]->pitch[c]) return false;
+                return true;
+            };
+            while (at + nf < n && nf < CS_FRAMES && same(at + nf)) nf++;
+            CsBatch B;
+            memset(&B, 0, sizeof(B));
+            for (int f = 0; f < nf; f++)
+                for (int c = 0; c < 3; c++) { B.src[f][c] = ins[at + f]->plane[c]; B.dst[f][c] = outs[at + f]->plane[c]; }
+            for (int c = 0; c < 3; c++) { B.spitch[c] = ins[at]->pitch[c]; B.dpitch[c] = outs[at]->pitch[c]; }
+            B.w = ins[at]->width[0]; B.h = ins[at]->height[0]; B.cw = ins[at]->width[1]; B.ch = ins[at]->height[1];
+            if (in_geo.bps == 1) launch<uint8_t>(B, nf);
+            else                 launch<uint16_t>(B, nf);
+            HBHIP_CHECK(ctx, hipGetLastError());
+            at += nf;
+        }
+        return HBHIP_OK;
+    }
     int process(DevPicture *in, DevPicture *out) override
     {
-        CsArgs a;
-        for (int c = 0; c < 3; c++)
-        {
-            a.src[c] = in->plane[c]; a.dst[c] = out->plane[c];
-            a.spitch[c] = in->pitch[c]; a.dpitch[c] = out->pitch[c];
-        }
-        a.w = in->width[0]; a.h = in->height[0]; a.cw = in->width[1]; a.ch = in->height[1];
-        a.subw = in_geo.log2_cw; a.subh = in_geo.log2_ch;
-        const dim3 grid((a.w + CS_TW - 1) / CS_TW, (a.h + CS_TH - 1) / CS_TH);
-        if (in_geo.bps == 1) HBHIP_LAUNCH(ctx, "colorspace", colorspace_kernel<uint8_t>, grid, dim3(256), 0, a, plan);
-        else                 HBHIP_LAUNCH(ctx, "colorspace", colorspace_kernel<uint16_t>, grid, dim3(256), 0, a, plan);
-        HBHIP_CHECK(ctx, hipGetLastError());
-        return HBHIP_OK;
+        DevPicture *i1[1] = { in }, *o1[1] = { out };
+        return process_many(i1, o1, 1);
     }
     hbhip_colorspace_params par;
     CsPlan plan;

@@ -30,7 +30,9 @@
  * values below black and above white go through (the pure power laws return 0 below 0 like zimg's rec_1886
  * pair, the piecewise ones continue their linear segment), and only the final integer conversion clips.
  * The powers / exp / log are the deterministic float routines below (range reduction + fixed polynomials in
- * IEEE single arithmetic, no libm, about 2e-6 relative) so that the HIP kernel can reproduce them bit for bit;
+ * IEEE single arithmetic with fused multiply-adds, no libm's pow / exp / log, about 1e-7 relative for log, 6e-6 for
+ * the steepest power) so that the HIP kernel can reproduce them bit for bit - every sum of products in this file is
+ * written as an explicit chain of fmaf() for the same reason (round 5; before, every product was rounded on its own);
  * tests/test_colorspace_cpu.py holds them against libm.  What still separates this file from real zimg is that
  * rounding - not modelling: no tables, no clipping of super-whites.
  * The HIP path is tested bit-for-bit against THIS file, never against FFmpeg/zimg.
@@ -168,28 +170,38 @@ static void gamut_matrix(double g[3][3], const double in_xy[8], const double out
     mul3(g, bi, a);
 }
 
-/* ---- deterministic float math (IEEE single +, -, *, / only; the HIP kernel carries the same sequence) ---- */
+/* ---- deterministic float math (IEEE single +, -, *, / and fused multiply-add only - each correctly rounded, so the
+ * HIP kernel carries the same sequence and gets the same bits) ---- */
 static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
-/* log2 of a positive normal float: x = m 2^e with m in [sqrt(1/2), sqrt(2)), log2 m by the atanh series in (m-1)/(m+1) */
+/* log2 of a positive normal float: x = m 2^e with m in [sqrt(1/2), sqrt(2)); ln m = f - f^2 / 2 + f^3 P(f), f = m - 1,
+ * with the degree-8 polynomial of the Cephes single-precision logarithm (Moshier), evaluated by Horner's rule in fused
+ * multiply-adds; no division */
 static inline float det_log2f(float x)
 {
     const uint32_t bits = f2u(x);
     int e = (int)(bits >> 23) - 127;
     float m = u2f((bits & 0x007fffffu) | 0x3f800000u);
     if (m > 1.41421354f) { m = m * 0.5f; e += 1; }
-    const float t = (m - 1.0f) / (m + 1.0f);
-    const float t2 = t * t;
-    float p = 0.111111112f;
-    p = p * t2 + 0.142857149f;
-    p = p * t2 + 0.200000003f;
-    p = p * t2 + 0.333333343f;
-    p = p * t2 + 1.0f;
-    return (float)e + (t * p) * 2.88539004f;
+    const float f = m - 1.0f;
+    const float z = f * f;
+    float p = 7.0376836292e-2f;
+    p = fmaf(p, f, -1.1514610310e-1f);
+    p = fmaf(p, f, 1.1676998740e-1f);
+    p = fmaf(p, f, -1.2420140846e-1f);
+    p = fmaf(p, f, 1.4249322787e-1f);
+    p = fmaf(p, f, -1.6668057665e-1f);
+    p = fmaf(p, f, 2.0000714765e-1f);
+    p = fmaf(p, f, -2.4999993993e-1f);
+    p = fmaf(p, f, 3.3333331174e-1f);
+    float y = (f * z) * p;
+    y = fmaf(-0.5f, z, y);
+    return fmaf(f + y, 1.44269502f, (float)e);
 }
 
-/* 2^y: y = i + f with |f| <= 1/2, e^(f ln 2) by its Taylor polynomial of degree 7, scaled by the exponent bits */
+/* 2^y: y = i + f with |f| <= 1/2, e^(f ln 2) by its Taylor polynomial of degree 7 (Horner, fused), scaled by the
+ * exponent bits */
 static inline float det_exp2f(float y)
 {
     if (!(y >= -126.0f)) return 0.0f;                  /* also what a NaN becomes */
@@ -197,13 +209,13 @@ static inline float det_exp2f(float y)
     const int i = (int)(y + (y < 0.0f ? -0.5f : 0.5f));
     const float z = (y - (float)i) * 0.693147182f;
     float p = 0.000198412701f;
-    p = p * z + 0.00138888892f;
-    p = p * z + 0.00833333377f;
-    p = p * z + 0.0416666679f;
-    p = p * z + 0.166666672f;
-    p = p * z + 0.5f;
-    p = p * z + 1.0f;
-    p = p * z + 1.0f;
+    p = fmaf(p, z, 0.00138888892f);
+    p = fmaf(p, z, 0.00833333377f);
+    p = fmaf(p, z, 0.0416666679f);
+    p = fmaf(p, z, 0.166666672f);
+    p = fmaf(p, z, 0.5f);
+    p = fmaf(p, z, 1.0f);
+    p = fmaf(p, z, 1.0f);
     return p * u2f((uint32_t)(i + 127) << 23);
 }
 
@@ -316,18 +328,21 @@ static inline float tonemap_sig(const plan_t *p, float sig)
     return sig;                                                                              /* none     */
 }
 
+/* a row of a 3x3 matrix times a vector: one product, two fused multiply-adds, left to right */
+static inline float row3(const float m[3], float a, float b, float c) { return fmaf(m[2], c, fmaf(m[1], b, m[0] * a)); }
+
 static inline void convert_px(const plan_t *p, float y, float u, float v, float out[3])
 {
     if (!p->need_linear)
     {
         for (int i = 0; i < 3; i++)
-            out[i] = p->m_direct[i][0] * y + p->m_direct[i][1] * u + p->m_direct[i][2] * v;
+            out[i] = row3(p->m_direct[i], y, u, v);
         return;
     }
     float c[3], g[3];
     for (int i = 0; i < 3; i++)
     {
-        const float e = p->m_in[i][0] * y + p->m_in[i][1] * u + p->m_in[i][2] * v;
+        const float e = row3(p->m_in[i], y, u, v);
         c[i] = to_linear(p->tc_in, e) * p->lin_scale;
     }
     if (p->tonemap >= 0)
@@ -340,20 +355,20 @@ static inline void convert_px(const plan_t *p, float y, float u, float v, float 
     }
     if (p->gamut)
         for (int i = 0; i < 3; i++)
-            g[i] = p->m_gamut[i][0] * c[0] + p->m_gamut[i][1] * c[1] + p->m_gamut[i][2] * c[2];
+            g[i] = row3(p->m_gamut[i], c[0], c[1], c[2]);
     else
         for (int i = 0; i < 3; i++) g[i] = c[i];
     for (int i = 0; i < 3; i++)
         g[i] = to_gamma(p->tc_out, g[i] * p->gam_scale);
     for (int i = 0; i < 3; i++)
-        out[i] = p->m_out[i][0] * g[0] + p->m_out[i][1] * g[1] + p->m_out[i][2] * g[2];
+        out[i] = row3(p->m_out[i], g[0], g[1], g[2]);
 }
 
 static inline int quant(float v, float mul, float off, int vmax)
 {
     /* out-of-gamut input can reach +-inf / NaN on the way (e.g. the PQ EOTF beyond its pole): pinned to the clip
      * limits here rather than left to what the float -> integer conversion of the platform makes of them */
-    float t = v * mul + off;
+    float t = fmaf(v, mul, off);
     if (!(t > -1e9f)) t = -1e9f;
     if (t > 1e9f) t = 1e9f;
     const long q = lrintf(t);
@@ -504,9 +519,10 @@ int orc_colorspace_frame(const orc_colorspace_params_t *cs, const void *const sr
                 const float s10 = (sample(pl, sstride[1 + k], c0, r1, bps) - p.coff_in) * p.cmul_in;
                 const float s01 = (sample(pl, sstride[1 + k], c1, r0, bps) - p.coff_in) * p.cmul_in;
                 const float s11 = (sample(pl, sstride[1 + k], c1, r1, bps) - p.coff_in) * p.cmul_in;
-                const float a = wy0 * s00 + wy1 * s10;
-                const float b = wy0 * s01 + wy1 * s11;
-                uv[k] = wx0 * a + wx1 * b;
+                /* rows first (a sample that is not interpolated is taken as it is), then columns */
+                const float a = subh ? fmaf(wy1, s10, wy0 * s00) : s00;
+                const float b = subh ? fmaf(wy1, s11, wy0 * s01) : s01;
+                uv[k] = (x & 1) && subw ? fmaf(wx1, b, wx0 * a) : a;
             }
             const float yf = (sample(src[0], sstride[0], x, y, bps) - p.yoff_in) * p.ymul_in;
             float o[3];
@@ -533,13 +549,13 @@ int orc_colorspace_frame(const orc_colorspace_params_t *cs, const void *const sr
                     {
                         const int y0 = clampi(2 * cy - 1, 0, h - 1), y1 = clampi(2 * cy, 0, h - 1),
                                   y2 = clampi(2 * cy + 1, 0, h - 1), y3 = clampi(2 * cy + 2, 0, h - 1);
-                        col[i] = 0.125f * o[(size_t)y0 * w + xx] + 0.375f * o[(size_t)y1 * w + xx] +
-                                 0.375f * o[(size_t)y2 * w + xx] + 0.125f * o[(size_t)y3 * w + xx];
+                        col[i] = fmaf(0.125f, o[(size_t)y3 * w + xx], fmaf(0.375f, o[(size_t)y2 * w + xx],
+                                 fmaf(0.375f, o[(size_t)y1 * w + xx], 0.125f * o[(size_t)y0 * w + xx])));
                     }
                     else
                         col[i] = o[(size_t)cy * w + xx];
                 }
-                const float v = subw ? 0.25f * col[0] + 0.5f * col[1] + 0.25f * col[2] : col[1];
+                const float v = subw ? fmaf(0.25f, col[2], fmaf(0.5f, col[1], 0.25f * col[0])) : col[1];
                 store(dst[1 + k], dstride[1 + k], cx, cy, bps, quant(v, p.cmul_out, p.coff_out, p.vmax));
             }
     }

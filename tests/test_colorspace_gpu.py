@@ -112,3 +112,34 @@ def test_unsupported_conversion_fails_init(built):
             hbrt.Chain(hip.filters(), [("hb_filter_colorspace_hip", "matrix=bt2020c")], 320, 180)      # constant luminance
     finally:
         hbrt.set_source_color()
+
+
+@pytest.mark.parametrize("w,h,depth,src,dst,kw", [(640, 360, 8, BT601, BT709, {}), (1920, 1080, 8, BT709, (1, 1, 6, 2), {}),
+                                                  (644, 364, 10, HDR10, BT709, dict(peak=100.0))])
+def test_many_frames_per_launch(built, w, h, depth, src, dst, kw):
+    """hbhip_filter_process_dev -> ColorspaceFilter::process_many: the frames of a batch (19: one full launch of 16 and
+    a rest) in one launch per 16, each against the oracle"""
+    import torch
+    n = 19 if w < 1000 else 3
+    frames = synth.stream("progressive", w, h, n - 1, depth=depth) + synth.stream("random", w, h, 1, depth=depth)
+    ctx = hip.Ctx(0)
+    flt = hip.colorspace_device_filter(ctx, w, h, src, dst, depth=depth, **kw)
+    try:
+        tdt = torch.uint8 if depth == 8 else torch.int16
+        dev_in = [[torch.from_numpy(np.ascontiguousarray(p).view(np.uint8 if depth == 8 else np.int16)).cuda() for p in f] for f in frames]
+        outs = [[torch.zeros((h, w), dtype=tdt, device="cuda"), torch.zeros((h // 2, w // 2), dtype=tdt, device="cuda"),
+                 torch.zeros((h // 2, w // 2), dtype=tdt, device="cuda")] for _ in frames]
+        torch.cuda.synchronize()
+        arr_in = (hip.DevFrame * n)(*[hip.dev_frame(f) for f in dev_in])
+        arr_out = (hip.DevFrame * n)(*[hip.dev_frame(o) for o in outs])
+        assert flt.process_dev(arr_in, 0, arr_out) == n
+        ctx.sync()
+        got = [[p.cpu().numpy().view(np.uint8 if depth == 8 else np.uint16) for p in o] for o in outs]
+    finally:
+        flt.close()
+        ctx.close()
+    params = ol.colorspace_params(src, dst, **kw)
+    for t, fr in enumerate(frames):
+        want = ol.orc_colorspace_frame(fr, params, depth=depth)
+        for c in range(3):
+            np.testing.assert_array_equal(got[t][c], want[c], err_msg=f"frame {t} plane {c}")

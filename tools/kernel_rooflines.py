@@ -217,10 +217,10 @@ def main():
                           "us_per_frame": round(us / frames_per_launch, 3), "algorithmic_bytes_per_launch": b,
                           "achieved_GBps": round(b / (us * 1e-6) / 1e9, 1), "frac_of_8TBps": round(b / (us * 1e-6) / 1e9 / PEAK, 4)}
 
-    def batched(make, w, h, ow, oh, model="progressive", reps=8):
-        frames = synth.stream(model, w, h, 4)
-        dev_in = [[torch.from_numpy(p).cuda() for p in fr] for fr in frames]
-        outs = [planes(ow, oh) for _ in range(NB)]
+    def batched(make, w, h, ow, oh, model="progressive", reps=8, depth=8):
+        frames = synth.stream(model, w, h, 4, depth=depth) if depth != 8 else synth.stream(model, w, h, 4)
+        dev_in = [[torch.from_numpy(p.view(np.int16) if depth != 8 else p).cuda() for p in fr] for fr in frames]
+        outs = [planes(ow, oh, torch.int16 if depth != 8 else torch.uint8) for _ in range(NB)]
         torch.cuda.synchronize()
         flt = make()
         arr_in = (hip.DevFrame * NB)(*[hip.dev_frame(dev_in[i % 4]) for i in range(NB)])
@@ -247,6 +247,12 @@ def main():
     add_batched(st, {"hqdn3d_h": 3 * FRAME}, "hqdn3d_h x16 (px in, u16 out)", NB)
     add_batched(st, {"hqdn3d_v": 4 * FRAME}, "hqdn3d_v x16 (u16 in, u16 out)", NB)
     add_batched(st, {"hqdn3d_t": 3 * FRAME + 4 * FRAME // NB}, "hqdn3d_t x16 (u16 in, px out, the state once per launch)", NB)
+    add_batched(batched(lambda: hip.colorspace_device_filter(ctx, W, H, (6, 6, 6, 1), (1, 1, 1, 1)), W, H, W, H),
+                {"colorspace": 2 * FRAME}, "colorspace x16 (8-bit SDR 601->709)", NB)
+    add_batched(batched(lambda: hip.colorspace_device_filter(ctx, W, H, (9, 16, 9, 1), (1, 1, 1, 1), peak=100.0, depth=10), W, H, W, H, depth=10),
+                {"colorspace": 2 * 2 * FRAME}, "colorspace x16 (10-bit HDR10->709 hable)", NB)
+    add_batched(batched(lambda: hip.colorspace_device_filter(ctx, W, H, (1, 1, 1, 1), (1, 1, 6, 2)), W, H, W, H),
+                {"colorspace": 2 * FRAME}, "colorspace x16 (8-bit matrix+range only)", NB)
     # decomb blend (default mode 7: yadif + cubic), the frames of a chain batch in one launch
     frames = synth.stream("interlaced", W, H, 4)
     dev_in = [[torch.from_numpy(p).cuda() for p in fr] for fr in frames]
