@@ -7,9 +7,11 @@
 // The 8-bit functions are the 16-bit ones with shift 0, so each kernel is one template over the
 // sample type.  Integer arithmetic throughout: bit-exact with the reference.  A thread owns one
 // chroma sample of the frame and the (1 << wshift) x (1 << hshift) luma samples that go with it, so a
-// frame sample is read and written by exactly one thread; overlays are composited in list order,
-// one launch each (they may overlap, hb_blend_work :866-869).  Overlay bitmaps are uploaded once
-// per change (rendersub's `changed`), not per frame.
+// frame sample is read and written by exactly one thread; overlays are composited in list order
+// (they may overlap, hb_blend_work :866-869): consecutive overlays that touch disjoint parts of the frame - the
+// usual case, a few lines of text - go into one launch (grid.z = overlay; the groups are found when the list is
+// set), one that overlaps an earlier one of its group starts the next launch.  Overlay bitmaps are uploaded once per
+// change (rendersub's `changed`), not per frame.
 //
 // Not reproduced: the reference's stray chroma writes one sample before the row when a
 // same-subsampling overlay hangs over the left / top edge by an odd amount (:485-505), and its
@@ -17,6 +19,7 @@
 // at the frame edge.  Biplanar (NV12 / P010) frames are refused (planar frames only).
 #include "hbhip_internal.h"
 
+#include <algorithm>
 #include <vector>
 
 namespace {
@@ -26,6 +29,13 @@ struct OverlayDev
     const uint8_t *plane[4];
     int stride[4];
     int x, y, width, height;
+};
+
+constexpr int BL_GROUP = 8;          // overlays per launch
+struct OverlayGroup
+{
+    OverlayDev o[BL_GROUP];
+    int bx0[BL_GROUP], by0[BL_GROUP];    // blend_subsample_kernel: the first frame chroma sample the overlay touches
 };
 
 struct BlendArgs
@@ -44,8 +54,9 @@ template <typename PIX> __device__ __forceinline__ PIX *row_of(uint8_t *plane, i
 
 // grid: overlay chroma samples (xx, yy) in the overlay's own coordinates
 template <typename PIX>
-__global__ __launch_bounds__(256) void blend_same_kernel(BlendArgs a, OverlayDev o)
+__global__ __launch_bounds__(256) void blend_same_kernel(BlendArgs a, OverlayGroup G)
 {
+    const OverlayDev &o = G.o[blockIdx.z];
     const int xx = blockIdx.x * blockDim.x + threadIdx.x, yy = blockIdx.y * blockDim.y + threadIdx.y;
     const int left = o.x, top = o.y;
     const int x0 = left < 0 ? -left : 0, y0 = top < 0 ? -top : 0;
@@ -83,8 +94,10 @@ __global__ __launch_bounds__(256) void blend_same_kernel(BlendArgs a, OverlayDev
 
 // grid: frame chroma samples starting at (bx0, by0) = the first one the overlay touches
 template <typename PIX>
-__global__ __launch_bounds__(256) void blend_subsample_kernel(BlendArgs a, OverlayDev o, int bx0, int by0)
+__global__ __launch_bounds__(256) void blend_subsample_kernel(BlendArgs a, OverlayGroup G)
 {
+    const OverlayDev &o = G.o[blockIdx.z];
+    const int bx0 = G.bx0[blockIdx.z], by0 = G.by0[blockIdx.z];
     const int cx = bx0 + blockIdx.x * blockDim.x + threadIdx.x, cy = by0 + blockIdx.y * blockDim.y + threadIdx.y;
     const int x0 = o.x, y0 = o.y;
     const int ow = o.width <= a.width ? o.width : a.width;          // :74-75 with left == x0
@@ -142,6 +155,8 @@ struct hbhip_blend
     uint8_t *d_store = nullptr;          // the uploaded overlay bitmaps, back to back
     size_t   store_bytes = 0;
     std::vector<OverlayDev> overlays;
+    struct Launch { OverlayGroup g; int n; dim3 grid; };
+    std::vector<Launch> launches;        // the overlays in list order, grouped (build_launches)
     hbhip_frame *staging = nullptr;      // device frame of the host-frame entry point
 
     ~hbhip_blend()
@@ -150,6 +165,56 @@ struct hbhip_blend
         if (staging) hbhip_frame_release(staging);
     }
 };
+
+// The launches of an overlay list: what a launch of one overlay used to cover (its grid and, for the subsampling
+// kernel, its origin), and consecutive overlays joined while the frame rectangles they touch - luma, widened to whole
+// chroma samples and by one more sample for the odd-origin cases - stay disjoint.
+static void build_launches(hbhip_blend *b)
+{
+    b->launches.clear();
+    const int ws = b->geo.log2_cw, hs = b->geo.log2_ch, W = b->geo.width, H = b->geo.height;
+    struct Rect { int x0, y0, x1, y1; };
+    std::vector<Rect> rects;                                    // of the overlays in the group being filled
+    hbhip_blend::Launch cur;
+    cur.n = 0;
+    cur.grid = dim3(0, 0, 0);
+    auto flush = [&]() {
+        if (cur.n) { cur.grid.z = cur.n; b->launches.push_back(cur); }
+        cur.n = 0; cur.grid = dim3(0, 0, 0); rects.clear();
+    };
+    for (const OverlayDev &o : b->overlays)
+    {
+        int bx0 = 0, by0 = 0, nx, ny;
+        if (b->subsample)
+        {
+            int x0c = o.x & ~((1 << ws) - 1), y0c = o.y & ~((1 << hs) - 1);
+            if (x0c < 0) x0c = 0;
+            if (y0c < 0) y0c = 0;
+            const int ow = o.width <= W ? o.width : W, oh = o.height <= H ? o.height : H;
+            int x1 = o.x + ow, y1 = o.y + oh;                     // one past the last frame sample touched
+            if (x1 > W) x1 = W;
+            if (y1 > H) y1 = H;
+            if (x1 <= x0c || y1 <= y0c) continue;
+            bx0 = x0c >> ws; by0 = y0c >> hs;
+            nx = ((x1 - 1) >> ws) - bx0 + 1; ny = ((y1 - 1) >> hs) - by0 + 1;
+        }
+        else
+        {
+            nx = -((-o.width) >> ws); ny = -((-o.height) >> hs);
+        }
+        const int m = 2 << (ws > hs ? ws : hs);
+        const Rect r = { o.x - m, o.y - m, o.x + o.width + m, o.y + o.height + m };
+        bool clash = cur.n == BL_GROUP;
+        for (const Rect &q : rects) clash = clash || (r.x0 < q.x1 && q.x0 < r.x1 && r.y0 < q.y1 && q.y0 < r.y1);
+        if (clash) flush();
+        cur.g.o[cur.n] = o; cur.g.bx0[cur.n] = bx0; cur.g.by0[cur.n] = by0;
+        cur.grid.x = std::max<unsigned>(cur.grid.x, (nx + 63) / 64);
+        cur.grid.y = std::max<unsigned>(cur.grid.y, (ny + 3) / 4);
+        cur.n++;
+        rects.push_back(r);
+    }
+    flush();
+}
 
 extern "C" int hbhip_blend_create(hbhip_ctx *ctx, int width, int height, int depth, int log2_chroma_w, int log2_chroma_h,
                                   int chroma_location, int overlay_log2_chroma_w, int overlay_log2_chroma_h,
@@ -203,6 +268,7 @@ extern "C" int hbhip_blend_set_overlays(hbhip_blend *b, const hbhip_overlay *ov,
     // launches of the previous set may still be reading the store
     HBHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     b->overlays.clear();
+    b->launches.clear();
     size_t total = 0;
     for (int i = 0; i < n; i++)
     {
@@ -236,6 +302,7 @@ extern "C" int hbhip_blend_set_overlays(hbhip_blend *b, const hbhip_overlay *ov,
         }
         b->overlays.push_back(d);
     }
+    build_launches(b);
     // the caller may free its bitmaps as soon as this returns
     HBHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return HBHIP_OK;
@@ -252,30 +319,17 @@ extern "C" int hbhip_blend_apply_dev(hbhip_blend *b, const hbhip_dev_frame *fram
     a.wshift = b->geo.log2_cw; a.hshift = b->geo.log2_ch; a.shift = b->geo.depth - 8;
     for (int i = 0; i < 2; i++) { a.coeff[0][i] = b->coeff[0][i]; a.coeff[1][i] = b->coeff[1][i]; }
     const dim3 blk(64, 4);
-    for (const OverlayDev &o : b->overlays)
+    for (const hbhip_blend::Launch &l : b->launches)
     {
         if (b->subsample)
         {
-            int x0c = o.x & ~((1 << a.wshift) - 1), y0c = o.y & ~((1 << a.hshift) - 1);
-            if (x0c < 0) x0c = 0;
-            if (y0c < 0) y0c = 0;
-            const int ow = o.width <= a.width ? o.width : a.width, oh = o.height <= a.height ? o.height : a.height;
-            int x1 = o.x + ow, y1 = o.y + oh;                     // one past the last frame sample touched
-            if (x1 > a.width) x1 = a.width;
-            if (y1 > a.height) y1 = a.height;
-            if (x1 <= x0c || y1 <= y0c) continue;
-            const int bx0 = x0c >> a.wshift, by0 = y0c >> a.hshift;
-            const int nx = ((x1 - 1) >> a.wshift) - bx0 + 1, ny = ((y1 - 1) >> a.hshift) - by0 + 1;
-            const dim3 grid((nx + 63) / 64, (ny + 3) / 4);
-            if (b->geo.bps == 1) HBHIP_LAUNCH(ctx, "blend_subsample", blend_subsample_kernel<uint8_t>, grid, blk, 0, a, o, bx0, by0);
-            else                 HBHIP_LAUNCH(ctx, "blend_subsample", blend_subsample_kernel<uint16_t>, grid, blk, 0, a, o, bx0, by0);
+            if (b->geo.bps == 1) HBHIP_LAUNCH(ctx, "blend_subsample", blend_subsample_kernel<uint8_t>, l.grid, blk, 0, a, l.g);
+            else                 HBHIP_LAUNCH(ctx, "blend_subsample", blend_subsample_kernel<uint16_t>, l.grid, blk, 0, a, l.g);
         }
         else
         {
-            const int nx = -((-o.width) >> a.wshift), ny = -((-o.height) >> a.hshift);
-            const dim3 grid((nx + 63) / 64, (ny + 3) / 4);
-            if (b->geo.bps == 1) HBHIP_LAUNCH(ctx, "blend", blend_same_kernel<uint8_t>, grid, blk, 0, a, o);
-            else                 HBHIP_LAUNCH(ctx, "blend", blend_same_kernel<uint16_t>, grid, blk, 0, a, o);
+            if (b->geo.bps == 1) HBHIP_LAUNCH(ctx, "blend", blend_same_kernel<uint8_t>, l.grid, blk, 0, a, l.g);
+            else                 HBHIP_LAUNCH(ctx, "blend", blend_same_kernel<uint16_t>, l.grid, blk, 0, a, l.g);
         }
     }
     HBHIP_CHECK(ctx, hipGetLastError());

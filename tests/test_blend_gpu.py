@@ -93,3 +93,33 @@ def test_uncovered_combination_is_refused(built):
         assert L.hbhip_blend_create(ctx.h, 64, 48, 8, 0, 0, 1, 1, 1, hip.C.byref(h)) != 0
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("subsampled", [False, True])
+@pytest.mark.parametrize("gap", [0, 3, 20])
+def test_neighbouring_overlays_share_launches(built, subsampled, gap):
+    """Overlays that touch disjoint parts of the frame are composited in one launch (csrc/blend.hip: build_launches), ones
+    that overlap one after the other: rows of tiles `gap` samples apart at odd and even origins (a chroma sample of a
+    4:2:0 frame can lie under two of them), then two that overlap the first row - the result is the reference's, which
+    takes them strictly in list order."""
+    w, h = 644, 364
+    frame = synth.stream("progressive", w, h, 1)[0]
+    base = synth.overlays(w, h, 14, seed=41, subsampled=subsampled, inside=True)
+    ovs, at = [], 0
+    for row, y in enumerate((3, 80, 161)):
+        x = 5 + row
+        for k in range(4):
+            _, _, (py, pu, pv, pa) = base[at]; at += 1
+            bw, bh = min(py.shape[1], 120) & ~1, min(py.shape[0], 60) & ~1
+            xx, yy = (x & ~1, y & ~1) if subsampled else (x, y)
+            cut = (lambda p, c: p[:bh >> (c and subsampled), :bw >> (c and subsampled)])
+            ovs.append((xx, yy, (np.ascontiguousarray(cut(py, 0)), np.ascontiguousarray(cut(pu, 1)),
+                                 np.ascontiguousarray(cut(pv, 1)), np.ascontiguousarray(cut(pa, 0)))))
+            x += bw + gap
+    for k in range(2):                                                     # and two on top of the first row
+        _, _, planes = base[at]; at += 1
+        ovs.append((40 + 200 * k, 20, planes))
+    fmt = hbrt.AV_PIX_FMT_YUVA420P if subsampled else hbrt.AV_PIX_FMT_YUVA444P
+    got = hbrt.blend_run(hip.filters(), "hb_blend_hip", frame, ovs, overlay_fmt=fmt)
+    kw = dict(overlay_wshift=1, overlay_hshift=1) if subsampled else {}
+    check(got, ol.orc_blend_frame(frame, ovs, **kw))
