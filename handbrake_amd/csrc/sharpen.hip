@@ -313,8 +313,12 @@ __global__ __launch_bounds__(256) void blur_mix_kernel(BlurArgs3 all)
 // times from L1 / L2 instead of gathered bytewise, one dword stored per row.  Columns and rows outside the plane are
 // clamped (unsharp.c:117-126, 166-170): threads whose window crosses a border gather their twelve bytes one by one.
 // The sums are the reference's uint32 sums, taken exactly in float (see the kernel).  One launch covers the three planes
-// of up to BR_FRAMES frames (blockIdx.z); a plane with amount 0 is copied (unsharp.c:111-115).
-constexpr int BR_ROWS = 16, BR_FRAMES = 16, BR_MAX_STEPS = 4;
+// of up to BR_FRAMES frames (blockIdx.z); a plane with amount 0 is copied (unsharp.c:111-115).  Strips away from the top
+// and bottom of the plane take a branch-free form of the same arithmetic (byte dot products), see there.
+#ifndef BR_ROWS_N
+#define BR_ROWS_N 16
+#endif
+constexpr int BR_ROWS = BR_ROWS_N, BR_FRAMES = 16, BR_MAX_STEPS = 4;
 struct BlurPlane8 { int width, height, src_pitch, dst_pitch, steps, scalebits, halfscale, amount, active; uint32_t coef[2 * BR_MAX_STEPS + 1]; };
 struct BlurBatch8
 {
@@ -352,6 +356,98 @@ __global__ __launch_bounds__(256) void blur_rows8_kernel(BlurBatch8 B)
             if (full_dword) v = *reinterpret_cast<const uint32_t *>(g);
             else for (int k = 0; x0 + k < P.width; k++) v |= (uint32_t)g[k] << (8 * k);
             store_row(ys + r, v);
+        }
+        return;
+    }
+    // ---- the strips that need no row clamp (all but the plane's first and last ones), planes whose rows are whole dwords:
+    // no per-row branch, no exit test; the horizontal sums as byte dot products (v_dot4_u32_u8: four taps an instruction,
+    // the windows cut out of the row's three dwords with v_alignbyte), exact like everything else here.  Only the lanes at
+    // the plane's left / right edge differ: the dword they have no neighbour for is their own edge sample four times.
+    if ((P.width & 3) == 0 && ((P.src_pitch | P.dst_pitch) & 3) == 0 && ys >= S && ys + BR_ROWS + S <= P.height)      // wave-uniform
+    {
+        const bool lane_l = x0 == 0, lane_r = x0 + 4 >= P.width;
+        const bool edges = __any(lane_l || lane_r);
+        uint32_t cq[(NT + 3) / 4];                                            // the coefficients, four to a dword
+#pragma unroll
+        for (int q = 0; q < (NT + 3) / 4; q++)
+        {
+            cq[q] = 0;
+#pragma unroll
+            for (int t = 0; t < 4; t++) if (4 * q + t < NT) cq[q] |= (P.coef[4 * q + t] & 0xffu) << (8 * t);
+        }
+        float cf[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) cf[t] = (float)P.coef[t];
+        const uint8_t *g = src + ((uint32_t)__mul24(ys - S, P.src_pitch) + (uint32_t)x0);
+        const int off_l = lane_l ? 0 : -4, off_r = lane_r ? 0 : 4;
+        // (kept in vector registers and opaque to the optimiser: p + sgn * dd is then one v_mad_i32_i24, and the clamp can
+        // be one v_med3_i32, which takes a single scalar operand)
+        int sgn = B.sign > 0 ? 1 : -1, vlo = B.vmin, vhi = B.vmax;
+        asm volatile("" : "+v"(sgn), "+v"(vlo), "+v"(vhi));
+        uint8_t *d = dst + ((uint32_t)__mul24(ys, P.dst_pitch) + (uint32_t)x0);
+        typedef float f2 __attribute__((ext_vector_type(2)));               // the vertical sums two columns at a time (v_pk_fma_f32)
+        auto row_sums = [&](const uint8_t *row, f2 (&h)[2], uint32_t &centre) __attribute__((always_inline)) {
+            uint32_t w[4];
+            w[0] = *reinterpret_cast<const uint32_t *>(row + off_l);
+            w[1] = *reinterpret_cast<const uint32_t *>(row);
+            w[2] = *reinterpret_cast<const uint32_t *>(row + off_r);
+            w[3] = 0;
+            if (edges)
+            {
+                if (lane_l) w[0] = (w[1] & 0xffu) * 0x01010101u;
+                if (lane_r) w[2] = (w[1] >> 24) * 0x01010101u;
+            }
+            centre = w[1];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                uint32_t sum = 0;
+#pragma unroll
+                for (int q = 0; q < (NT + 3) / 4; q++)
+                {
+                    const int o = 4 - S + k + 4 * q;                          // window byte of this chunk's first tap
+                    const uint32_t lo = w[o >> 2], hi = (o >> 2) + 1 < 4 ? w[(o >> 2) + 1] : 0u;
+                    const uint32_t bytes = (o & 3) ? __builtin_amdgcn_alignbyte(hi, lo, o & 3) : lo;
+                    sum = __builtin_amdgcn_udot4(bytes, cq[q], sum, false);
+                }
+                h[k >> 1][k & 1] = (float)sum;
+            }
+        };
+        f2 H[NT][2];
+        uint32_t C[NT];
+#pragma unroll
+        for (int r = 0; r < NT - 1; r++) row_sums(g + (uint32_t)__mul24(r, P.src_pitch), H[r], C[r]);
+#pragma unroll
+        for (int r = 0; r < BR_ROWS; r++)
+        {
+            row_sums(g + (uint32_t)__mul24(r + NT - 1, P.src_pitch), H[NT - 1], C[NT - 1]);
+            uint32_t packed = 0;
+            f2 tv[2] = { { 0.f, 0.f }, { 0.f, 0.f } };
+#pragma unroll
+            for (int j = 0; j < NT; j++)
+            {
+                const f2 cj = { cf[j], cf[j] };
+                tv[0] = __builtin_elementwise_fma(cj, H[j][0], tv[0]);
+                tv[1] = __builtin_elementwise_fma(cj, H[j][1], tv[1]);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                const uint32_t t = (uint32_t)tv[k >> 1][k & 1];
+                const int p = (int)((C[S] >> (8 * k)) & 0xffu);
+                const int blur = (int)((t + (uint32_t)P.halfscale) >> P.scalebits);
+                const int dd = ((p - blur) * P.amount) >> 16;                  // arithmetic shift, as gcc does
+                int res = __mul24(sgn, dd) + p;                                // p + dd or p - dd (|dd| < 2^23): one v_mad_i32_i24
+                asm("v_med3_i32 %0, %1, %2, %3" : "=v"(res) : "v"(res), "v"(vlo), "v"(vhi));   // the clamp (vlo <= vhi)
+                packed |= (uint32_t)res << (8 * k);
+            }
+            *reinterpret_cast<uint32_t *>(d + (uint32_t)__mul24(r, P.dst_pitch)) = packed;
+#pragma unroll
+            for (int j = 0; j < NT - 1; j++)
+            {
+                C[j] = C[j + 1];
+                H[j][0] = H[j + 1][0]; H[j][1] = H[j + 1][1];
+            }
         }
         return;
     }
