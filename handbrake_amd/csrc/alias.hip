@@ -1251,47 +1251,91 @@ public:
 // ------------------------------------------------------------------ pad
 // FFmpeg vf_pad as pad_init configures it (libhb/pad.c:40-148): the picture at (x, y) of a larger
 // one, the rest one colour.  One launch for the three planes; HBM-bound (read in, write out).
+constexpr int PAD_FRAMES = 16;
 struct PadArgs
 {
-    const uint8_t *src[3];
-    uint8_t       *dst[3];
-    int spitch[3], dpitch[3], sw[3], sh[3], dw[3], dh[3], x[3], y[3], fill[3];
+    const uint8_t *src[PAD_FRAMES][3];
+    uint8_t       *dst[PAD_FRAMES][3];
+    int spitch[3], dpitch[3], sw[3], sh[3], dw[3], dh[3], x[3], y[3], fill[3];       // widths and x in BYTES
 };
 
-template <typename PIX>
-__global__ __launch_bounds__(256) void pad_kernel(PadArgs a)
+// A thread makes one dword of an output row: the fill colour, four bytes of the picture (two aligned loads and a
+// v_alignbyte when the picture sits at an odd byte offset, as a 4:2:0 chroma plane at x = 2 (mod 4) does), or - the
+// dword the picture's edge runs through - byte by byte.  grid.z = 3 * frame + plane: the frames of a batch in one launch.
+__global__ __launch_bounds__(256) void pad_kernel(PadArgs a, int bps)
 {
-    const int c = blockIdx.z;
-    const int xx = blockIdx.x * blockDim.x + threadIdx.x, yy = blockIdx.y * blockDim.y + threadIdx.y;
-    if (xx >= a.dw[c] || yy >= a.dh[c]) return;
-    const int sx = xx - a.x[c], sy = yy - a.y[c];
-    const bool inside = sx >= 0 && sx < a.sw[c] && sy >= 0 && sy < a.sh[c];
-    const PIX v = inside ? reinterpret_cast<const PIX *>(a.src[c] + (size_t)sy * a.spitch[c])[sx] : (PIX)a.fill[c];
-    reinterpret_cast<PIX *>(a.dst[c] + (size_t)yy * a.dpitch[c])[xx] = v;
+    const int c = blockIdx.z % 3, f = blockIdx.z / 3;
+    const int ob = 4 * (blockIdx.x * blockDim.x + threadIdx.x), yy = blockIdx.y * blockDim.y + threadIdx.y;
+    if (ob >= a.dw[c] || yy >= a.dh[c]) return;
+    const uint32_t fillw = bps == 1 ? (uint32_t)a.fill[c] * 0x01010101u : (uint32_t)a.fill[c] * 0x00010001u;
+    uint8_t *drow = a.dst[f][c] + (size_t)yy * a.dpitch[c];
+    const int sy = yy - a.y[c], lo = ob - a.x[c];                    // source row, source byte of the dword's first byte
+    uint32_t v = fillw;
+    if (sy >= 0 && sy < a.sh[c] && lo + 3 >= 0 && lo < a.sw[c])
+    {
+        const uint8_t *srow = a.src[f][c] + (size_t)sy * a.spitch[c];
+        if (lo >= 0 && lo + 3 < a.sw[c])
+        {
+            const int al = lo & ~3, sh = lo & 3;
+            const uint32_t w0 = *reinterpret_cast<const uint32_t *>(srow + al);
+            const uint32_t w1 = sh ? *reinterpret_cast<const uint32_t *>(srow + al + 4) : 0u;     // (al + 4 <= lo + 3 < sw: inside the row)
+            v = __builtin_amdgcn_alignbyte(w1, w0, (uint32_t)sh);
+        }
+        else
+        {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (lo + k >= 0 && lo + k < a.sw[c]) v = (v & ~(0xffu << (8 * k))) | ((uint32_t)srow[lo + k] << (8 * k));
+        }
+    }
+    if (ob + 3 < a.dw[c]) *reinterpret_cast<uint32_t *>(drow + ob) = v;
+    else for (int k = 0; ob + k < a.dw[c]; k++) drow[ob + k] = (uint8_t)(v >> (8 * k));
 }
 
 class PadFilter : public SimpleFilter
 {
 public:
     PadFilter(hbhip_ctx *c, const hbhip_pad_params &p) : SimpleFilter(c), par(p) {}
-    int process(DevPicture *in, DevPicture *out) override
+    int process_many(DevPicture *const *ins, DevPicture *const *outs, int n) override
     {
-        PadArgs a;
-        for (int c = 0; c < 3; c++)
+        const int bps = in_geo.bps;
+        int at = 0;
+        while (at < n)
         {
-            a.src[c] = in->plane[c]; a.dst[c] = out->plane[c];
-            a.spitch[c] = in->pitch[c]; a.dpitch[c] = out->pitch[c];
-            a.sw[c] = in->width[c]; a.sh[c] = in->height[c]; a.dw[c] = out->width[c]; a.dh[c] = out->height[c];
-            a.x[c] = c ? par.x >> in_geo.log2_cw : par.x;
-            a.y[c] = c ? par.y >> in_geo.log2_ch : par.y;
-            a.fill[c] = par.fill[c];
+            int nf = 1;
+            auto same = [&](int i) {
+                for (int c = 0; c < 3; c++)
+                    if (ins[i]->pitch[c] != ins[at]->pitch[c] || outs[i]->pitch[c] != outs[at]->pitch[c]) return false;
+                return true;
+            };
+            while (at + nf < n && nf < PAD_FRAMES && same(at + nf)) nf++;
+            PadArgs a;
+            memset(&a, 0, sizeof(a));
+            bool aligned = true;
+            for (int c = 0; c < 3; c++)
+            {
+                DevPicture *in = ins[at], *out = outs[at];
+                a.spitch[c] = in->pitch[c]; a.dpitch[c] = out->pitch[c];
+                a.sw[c] = in->width[c] * bps; a.sh[c] = in->height[c]; a.dw[c] = out->width[c] * bps; a.dh[c] = out->height[c];
+                a.x[c] = (c ? par.x >> in_geo.log2_cw : par.x) * bps;
+                a.y[c] = c ? par.y >> in_geo.log2_ch : par.y;
+                a.fill[c] = par.fill[c];
+                aligned = aligned && ((a.spitch[c] | a.dpitch[c]) & 3) == 0;
+                for (int f = 0; f < nf; f++)
+                {
+                    a.src[f][c] = ins[at + f]->plane[c]; a.dst[f][c] = outs[at + f]->plane[c];
+                    aligned = aligned && (((uintptr_t)a.src[f][c] | (uintptr_t)a.dst[f][c]) & 3) == 0;
+                }
+            }
+            if (!aligned) return HBHIP_ERR_ARG;                              // planes and pitches of this library are 64-byte aligned
+            const dim3 grid(((a.dw[0] + 3) / 4 + 63) / 64, (a.dh[0] + 3) / 4, 3 * nf);
+            HBHIP_LAUNCH(ctx, "pad", pad_kernel, grid, dim3(64, 4), 0, a, bps);
+            HBHIP_CHECK(ctx, hipGetLastError());
+            at += nf;
         }
-        const dim3 grid((a.dw[0] + 63) / 64, (a.dh[0] + 3) / 4, 3);
-        if (in_geo.bps == 1) HBHIP_LAUNCH(ctx, "pad", pad_kernel<uint8_t>, grid, dim3(64, 4), 0, a);
-        else                 HBHIP_LAUNCH(ctx, "pad", pad_kernel<uint16_t>, grid, dim3(64, 4), 0, a);
-        HBHIP_CHECK(ctx, hipGetLastError());
         return HBHIP_OK;
     }
+    int process(DevPicture *in, DevPicture *out) override { return process_many(&in, &out, 1); }
     hbhip_pad_params par;
 };
 
@@ -1301,28 +1345,51 @@ public:
 // oracle/alias_oracle.c:orc_format_plane).  Up: shift (limited range, chroma) or top-bit replication
 // (full-range luma); down: ordered dither then the overflow clamp tmp - (tmp >> depth).  One launch for the
 // three planes, four samples per thread, HBM-bound (read in + write out).
+constexpr int FMT_FRAMES = 16;
 struct FormatArgs
 {
-    const uint8_t *src[3];
-    uint8_t       *dst[3];
+    const uint8_t *src[FMT_FRAMES][3];
+    uint8_t       *dst[FMT_FRAMES][3];
     int spitch[3], dpitch[3], w[3], h[3];
     int sdepth, ddepth, full_range;
 };
 
+// four samples per thread, moved as one dword (bytes) or two (16-bit samples) where the row has them; grid.z =
+// 3 * frame + plane: the frames of a batch in one launch
 template <typename SRC, typename DST>
 __global__ __launch_bounds__(256) void format_kernel(FormatArgs a)
 {
-    const int c = blockIdx.z;
+    const int c = blockIdx.z % 3, f = blockIdx.z / 3;
     const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4, y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x0 >= a.w[c] || y >= a.h[c]) return;
-    const SRC *s = reinterpret_cast<const SRC *>(a.src[c] + (size_t)y * a.spitch[c]);
-    DST *d = reinterpret_cast<DST *>(a.dst[c] + (size_t)y * a.dpitch[c]);
+    const SRC *s = reinterpret_cast<const SRC *>(a.src[f][c] + (size_t)y * a.spitch[c]);
+    DST *d = reinterpret_cast<DST *>(a.dst[f][c] + (size_t)y * a.dpitch[c]);
     const bool shiftonly = c != 0 || !a.full_range;
     const int up = a.ddepth - a.sdepth;
-    for (int i = 0; i < 4 && x0 + i < a.w[c]; i++)
+    const bool whole = x0 + 3 < a.w[c];
+    unsigned v4[4] = { 0, 0, 0, 0 };
+    if (whole)
+    {
+        if (sizeof(SRC) == 1)
+        {
+            const uint32_t w = *reinterpret_cast<const uint32_t *>(s + x0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) v4[i] = (w >> (8 * i)) & 0xffu;
+        }
+        else
+        {
+            const uint2 w = *reinterpret_cast<const uint2 *>(s + x0);
+            v4[0] = w.x & 0xffffu; v4[1] = w.x >> 16; v4[2] = w.y & 0xffffu; v4[3] = w.y >> 16;
+        }
+    }
+    else
+        for (int i = 0; x0 + i < a.w[c]; i++) v4[i] = s[x0 + i];
+    unsigned o4[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
     {
         const int x = x0 + i;
-        const unsigned v = s[x];
+        const unsigned v = v4[i];
         unsigned o;
         if (up == 0) o = v;
         else if (up > 0) o = shiftonly ? v << up : (v << up) | (v >> (2 * a.sdepth - a.ddepth));
@@ -1342,32 +1409,60 @@ __global__ __launch_bounds__(256) void format_kernel(FormatArgs a)
             else
                 o = (v - (v >> a.ddepth) + dm) >> shift;                // full-range luma: DITHER_COPY's other arm
         }
-        d[x] = (DST)o;
+        o4[i] = o;
     }
+    if (whole)
+    {
+        if (sizeof(DST) == 1) *reinterpret_cast<uint32_t *>(d + x0) = o4[0] | (o4[1] << 8) | (o4[2] << 16) | (o4[3] << 24);
+        else                  *reinterpret_cast<uint2 *>(d + x0) = make_uint2(o4[0] | (o4[1] << 16), o4[2] | (o4[3] << 16));
+    }
+    else
+        for (int i = 0; x0 + i < a.w[c]; i++) d[x0 + i] = (DST)o4[i];
 }
 
 class FormatFilter : public SimpleFilter
 {
 public:
     FormatFilter(hbhip_ctx *c, int full) : SimpleFilter(c), full_range(full) {}
-    int process(DevPicture *in, DevPicture *out) override
+    int process_many(DevPicture *const *ins, DevPicture *const *outs, int n) override
     {
-        FormatArgs a;
-        for (int c = 0; c < 3; c++)
+        int at = 0;
+        while (at < n)
         {
-            a.src[c] = in->plane[c]; a.dst[c] = out->plane[c];
-            a.spitch[c] = in->pitch[c]; a.dpitch[c] = out->pitch[c];
-            a.w[c] = in_geo.pw[c]; a.h[c] = in_geo.ph[c];
+            int nf = 1;
+            auto same = [&](int i) {
+                for (int c = 0; c < 3; c++)
+                    if (ins[i]->pitch[c] != ins[at]->pitch[c] || outs[i]->pitch[c] != outs[at]->pitch[c]) return false;
+                return true;
+            };
+            while (at + nf < n && nf < FMT_FRAMES && same(at + nf)) nf++;
+            FormatArgs a;
+            memset(&a, 0, sizeof(a));
+            bool aligned = true;
+            for (int c = 0; c < 3; c++)
+            {
+                a.spitch[c] = ins[at]->pitch[c]; a.dpitch[c] = outs[at]->pitch[c];
+                a.w[c] = in_geo.pw[c]; a.h[c] = in_geo.ph[c];
+                aligned = aligned && ((a.spitch[c] | a.dpitch[c]) & 7) == 0;
+                for (int f = 0; f < nf; f++)
+                {
+                    a.src[f][c] = ins[at + f]->plane[c]; a.dst[f][c] = outs[at + f]->plane[c];
+                    aligned = aligned && (((uintptr_t)a.src[f][c] | (uintptr_t)a.dst[f][c]) & 7) == 0;
+                }
+            }
+            if (!aligned) return HBHIP_ERR_ARG;                              // planes and pitches of this library are 64-byte aligned
+            a.sdepth = in_geo.depth; a.ddepth = out_geo.depth; a.full_range = full_range;
+            const dim3 grid((a.w[0] + 255) / 256, (a.h[0] + 3) / 4, 3 * nf);
+            if (in_geo.bps == 1 && out_geo.bps == 1)      HBHIP_LAUNCH(ctx, "format", (format_kernel<uint8_t, uint8_t>), grid, dim3(64, 4), 0, a);
+            else if (in_geo.bps == 1)                     HBHIP_LAUNCH(ctx, "format", (format_kernel<uint8_t, uint16_t>), grid, dim3(64, 4), 0, a);
+            else if (out_geo.bps == 1)                    HBHIP_LAUNCH(ctx, "format", (format_kernel<uint16_t, uint8_t>), grid, dim3(64, 4), 0, a);
+            else                                          HBHIP_LAUNCH(ctx, "format", (format_kernel<uint16_t, uint16_t>), grid, dim3(64, 4), 0, a);
+            HBHIP_CHECK(ctx, hipGetLastError());
+            at += nf;
         }
-        a.sdepth = in_geo.depth; a.ddepth = out_geo.depth; a.full_range = full_range;
-        const dim3 grid((a.w[0] + 255) / 256, (a.h[0] + 3) / 4, 3);
-        if (in_geo.bps == 1 && out_geo.bps == 1)      HBHIP_LAUNCH(ctx, "format", (format_kernel<uint8_t, uint8_t>), grid, dim3(64, 4), 0, a);
-        else if (in_geo.bps == 1)                     HBHIP_LAUNCH(ctx, "format", (format_kernel<uint8_t, uint16_t>), grid, dim3(64, 4), 0, a);
-        else if (out_geo.bps == 1)                    HBHIP_LAUNCH(ctx, "format", (format_kernel<uint16_t, uint8_t>), grid, dim3(64, 4), 0, a);
-        else                                          HBHIP_LAUNCH(ctx, "format", (format_kernel<uint16_t, uint16_t>), grid, dim3(64, 4), 0, a);
-        HBHIP_CHECK(ctx, hipGetLastError());
         return HBHIP_OK;
     }
+    int process(DevPicture *in, DevPicture *out) override { return process_many(&in, &out, 1); }
     int full_range;
 };
 

@@ -158,6 +158,18 @@ def test_pad(built, depth, st, geo, rgb):
     assert (got[0].width, got[0].height) == (w, h)
 
 
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("w,h,left,right,top,bottom", [(638, 362, 6, 20, 2, 4), (322, 182, 2, 2, 0, 6), (130, 66, 10, 0, 8, 0),
+                                                       (66, 34, 0, 62, 0, 30)])
+def test_pad_ragged_sizes(built, depth, w, h, left, right, top, bottom):
+    """rows that are no whole number of dwords, the picture at byte offsets 2 and 3 (mod 4) of the padded rows (the
+    kernel moves dwords: csrc/alias.hip: pad_kernel)"""
+    frames = synth.stream("random", w, h, 2, depth=depth)
+    st = f"top={top}:bottom={bottom}:left={left}:right={right}:color=0x8040c0"
+    got = hbrt.run_stream(hip.filters(), [("hb_filter_pad_hip", st)], frames, pix_fmt=hbrt.PIX_FMT_FOR_DEPTH[depth])
+    check(got, [ol.orc_pad_frame(fr, w + left + right, h + top + bottom, left, top, rgb=0x8040c0, depth=depth) for fr in frames])
+
+
 # ---- several device-resident frames per launch (hbhip_filter_process_dev -> process_many) ------------------------------
 def _batch_through(make, frames, ow, oh):
     import ctypes as C
@@ -207,3 +219,29 @@ def test_grayscale_many_frames_per_launch(built, w, h):
     for t in range(len(want)):
         for c in range(3):
             np.testing.assert_array_equal(got[t][c], want[t][c], err_msg=f"frame {t} plane {c}")
+
+
+def test_pad_and_format_many_frames_per_launch(built):
+    import ctypes as C
+    w, h = 640, 360
+    frames = synth.stream("progressive", w, h, 18) + synth.stream("random", w, h, 1)
+
+    class PP(C.Structure):
+        _fields_ = [("width", C.c_int), ("height", C.c_int), ("x", C.c_int), ("y", C.c_int), ("fill", C.c_int * 3)]
+    L = ol.oracle()
+    L.orc_pad_color.argtypes = [C.c_int] * 4 + [C.POINTER(C.c_int)]
+    out3 = (C.c_int * 3)()
+    L.orc_pad_color(0x336699, 1, 0, 8, out3)
+    pp = PP(704, 384, 38, 10, (C.c_int * 3)(*out3))
+    make = lambda ctx: hip._create("hbhip_pad_create", ctx, [C.c_void_p, C.POINTER(PP)] + [C.c_int] * 5 + [C.POINTER(C.c_void_p)],
+                                   ctx.h, C.byref(pp), w, h, 8, 1, 1)
+    got = _batch_through(make, frames, 704, 384)
+    for t, fr in enumerate(frames):
+        want = ol.orc_pad_frame(fr, 704, 384, 38, 10, rgb=0x336699)
+        for c in range(3):
+            np.testing.assert_array_equal(got[t][c], want[c], err_msg=f"pad frame {t} plane {c}")
+    make = lambda ctx: hip._create("hbhip_format_create", ctx, [C.c_void_p] + [C.c_int] * 7 + [C.POINTER(C.c_void_p)], ctx.h, w, h, 8, 8, 1, 1, 0)
+    got = _batch_through(make, frames, w, h)
+    for t, fr in enumerate(frames):
+        for c in range(3):
+            np.testing.assert_array_equal(got[t][c], fr[c], err_msg=f"format frame {t} plane {c}")

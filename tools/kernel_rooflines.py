@@ -264,6 +264,36 @@ def main():
                 {"colorspace": 2 * 2 * FRAME}, "colorspace x16 (10-bit HDR10->709 hable)", NB)
     add_batched(batched(lambda: hip.colorspace_device_filter(ctx, W, H, (1, 1, 1, 1), (1, 1, 6, 2)), W, H, W, H),
                 {"colorspace": 2 * FRAME}, "colorspace x16 (8-bit matrix+range only)", NB)
+    # format (depth conversion, the filter work.c adds in front of a 10-bit encoder) and pad
+    fmt = lambda sd, dd: (lambda: hip._create("hbhip_format_create", ctx, [C.c_void_p] + [C.c_int] * 7 + [C.POINTER(C.c_void_p)],
+                                              ctx.h, W, H, sd, dd, 1, 1, 0))
+
+    def batched_fmt(sd, dd):
+        frames = synth.stream("progressive", W, H, 4, depth=sd) if sd != 8 else synth.stream("progressive", W, H, 4)
+        dev_in = [[torch.from_numpy(p.view(np.int16) if sd != 8 else p).cuda() for p in fr] for fr in frames]
+        outs = [planes(W, H, torch.int16 if dd != 8 else torch.uint8) for _ in range(NB)]
+        torch.cuda.synchronize()
+        flt = fmt(sd, dd)()
+        arr_in = (hip.DevFrame * NB)(*[hip.dev_frame(dev_in[i % 4]) for i in range(NB)])
+        arr_out = (hip.DevFrame * NB)(*[hip.dev_frame(o) for o in outs])
+        for _ in range(2):
+            flt.process_dev(arr_in, 0, arr_out)
+        ctx.sync(); ctx.profile(True); ctx.profile_reset()
+        for _ in range(8):
+            flt.process_dev(arr_in, 0, arr_out)
+        ctx.sync()
+        st = ctx.profile_stats(); ctx.profile(False)
+        flt.close()
+        return st
+    add_batched(batched_fmt(8, 10), {"format": 3 * FRAME}, "format 8 -> 10 bits x16", NB)
+    add_batched(batched_fmt(10, 8), {"format": 3 * FRAME}, "format 10 -> 8 bits x16 (dithered)", NB)
+
+    class PadP(C.Structure):
+        _fields_ = [("width", C.c_int), ("height", C.c_int), ("x", C.c_int), ("y", C.c_int), ("fill", C.c_int * 3)]
+    padp = PadP(W + 128, H + 72, 64, 36, (C.c_int * 3)(16, 128, 128))
+    mkpad = lambda: hip._create("hbhip_pad_create", ctx, [C.c_void_p, C.POINTER(PadP)] + [C.c_int] * 5 + [C.POINTER(C.c_void_p)],
+                                ctx.h, C.byref(padp), W, H, 8, 1, 1)
+    add_batched(batched(mkpad, W, H, W + 128, H + 72), {"pad": FRAME + (W + 128) * (H + 72) * 3 // 2}, "pad 1920x1080 -> 2048x1152 x16", NB)
     # decomb blend (default mode 7: yadif + cubic), the frames of a chain batch in one launch
     frames = synth.stream("interlaced", W, H, 4)
     dev_in = [[torch.from_numpy(p).cuda() for p in fr] for fr in frames]
