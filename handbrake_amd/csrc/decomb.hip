@@ -66,6 +66,7 @@ struct DecombBatch
     DecombFrame f[DB_FRAMES];
     int pitch[3], guess_pitch[3], dst_pitch[3], w[3], h[3];
     int n = 0;
+    int ff = 0;          // 0: decomb's yadif; 1 / 2: FFmpeg's (the Deinterlace filter), 2 = its nospatial modes - see the kernel
 };
 
 // four adjacent samples of a row as they lie in memory: a dword of bytes, or two dwords of 16-bit samples
@@ -174,7 +175,10 @@ __global__ __launch_bounds__(256) void decomb_plane4_kernel(DecombBatch B, int m
     const uint8_t *p2row = F.field_parity ? prow : crow, *n2row = F.field_parity ? crow : nrow;
     const int sp = y ? -st : st;
     const int sn = y + 1 < h ? st : -st;
-    const bool vertical_edge = (y < 3) || (y > h - 4);
+    // the rows next to the top / bottom edge skip the test against rows y +- 2: decomb's three rows either side
+    // (decomb_template.c:600-603), vf_yadif.c's one (filter_slice: `mode = 2` for y == 1 and y + 2 == h, or every row in
+    // the nospatial modes) - it then mirrors where decomb does not get to (2 * sp / 2 * sn below)
+    const bool vertical_edge = B.ff ? (B.ff == 2 || y == 1 || y + 2 == h) : (y < 3) || (y > h - 4);
     const bool use_cubic = (mode & M_CUBIC) && !vertical_edge;
     const int margin = (mode & M_CUBIC) ? 3 : 2;
     const bool spatial = !(mode & M_EEDI2);
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(256) void decomb_plane4_kernel(DecombBatch B, int m
     const T p20 = dw(p2row), n20 = dw(n2row);
     const T ppu = dw(prow + sp), ppd = dw(prow + sn), pnu = dw(nrow + sp), pnd = dw(nrow + sn);
     T p2a = X4::zero(), p2b = X4::zero(), n2a = X4::zero(), n2b = X4::zero();         // rows y-2 / y+2
-    if (!vertical_edge) { p2a = dw(p2row - 2 * st); p2b = dw(p2row + 2 * st); n2a = dw(n2row - 2 * st); n2b = dw(n2row + 2 * st); }
+    if (!vertical_edge) { p2a = dw(p2row + 2 * sp); p2b = dw(p2row + 2 * sn); n2a = dw(n2row + 2 * sp); n2b = dw(n2row + 2 * sn); }
     T g = X4::zero();
     if (!spatial) g = dw(F.guess[pl] + (size_t)y * B.guess_pitch[pl]);
     WIN cu, cd, cu3 = { X4::zero(), X4::zero(), X4::zero() }, cd3 = cu3;             // rows y+sp, y+sn, y-3, y+3 of cur
@@ -264,63 +268,9 @@ __global__ __launch_bounds__(256) void decomb_plane4_kernel(DecombBatch B, int m
 // bottom edge - is widened by the vertical-neighbour check over rows y +- 2; the spatial
 // prediction is the average of the rows above / below, replaced by a diagonal average when one of
 // the +-1 (then +-2) diagonals matches better - only for 3 <= x < w - 3 (vf_yadif.c: filter_edges).
-template <typename PIX>
-__global__ __launch_bounds__(256) void yadif_ff_kernel(DecombArgs a, int nospatial)
-{
-    const DecombPlane &P = a.pl[blockIdx.z];
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= P.w || y >= P.h) return;
-    const int st = P.pitch / (int)sizeof(PIX);
-    const size_t at = (size_t)y * st + x;
-    const PIX *cur = reinterpret_cast<const PIX *>(P.cur) + at;
-    PIX *o = reinterpret_cast<PIX *>(P.dst + (size_t)y * P.dst_pitch) + x;
-    if (a.mode == 0 || !((y ^ a.parity) & 1))              // pass-through frame, or a row of the kept field
-    {
-        *o = *cur;
-        return;
-    }
-    const PIX *prev = reinterpret_cast<const PIX *>(P.prev) + at;
-    const PIX *next = reinterpret_cast<const PIX *>(P.next) + at;
-    const int h = P.h, w = P.w;
-    const int prefs = y + 1 < h ? st : -st, mrefs = y ? -st : st;
-    const bool skip_vertical = nospatial || y == 1 || y + 2 == h;       // `mode = 2` of filter_slice
-    const PIX *prev2 = a.field_parity ? prev : cur;
-    const PIX *next2 = a.field_parity ? cur : next;
-
-    const int c = cur[mrefs], e = cur[prefs];
-    const int d = ((int)prev2[0] + (int)next2[0]) >> 1;
-    const int td0 = abs((int)prev2[0] - (int)next2[0]);
-    const int td1 = (abs((int)prev[mrefs] - c) + abs((int)prev[prefs] - e)) >> 1;
-    const int td2 = (abs((int)next[mrefs] - c) + abs((int)next[prefs] - e)) >> 1;
-    int diff = max(max(td0 >> 1, td1), td2);
-    int pred = (c + e) >> 1;
-    if (x >= 3 && x < w - 3)
-    {
-        int score = abs((int)cur[mrefs - 1] - (int)cur[prefs - 1]) + abs(c - e) + abs((int)cur[mrefs + 1] - (int)cur[prefs + 1]) - 1;
-        auto check = [&](int j) -> bool {
-            const int s = abs((int)cur[mrefs - 1 + j] - (int)cur[prefs - 1 - j]) + abs((int)cur[mrefs + j] - (int)cur[prefs - j]) +
-                          abs((int)cur[mrefs + 1 + j] - (int)cur[prefs + 1 - j]);
-            if (s >= score) return false;
-            score = s;
-            pred = ((int)cur[mrefs + j] + (int)cur[prefs - j]) >> 1;
-            return true;
-        };
-        if (check(-1)) check(-2);
-        if (check(1)) check(2);
-    }
-    if (!skip_vertical)
-    {
-        const int b = ((int)prev2[2 * mrefs] + (int)next2[2 * mrefs]) >> 1;
-        const int f = ((int)prev2[2 * prefs] + (int)next2[2 * prefs]) >> 1;
-        const int mx = max(max(d - e, d - c), min(b - c, f - e));
-        const int mn = min(min(d - e, d - c), max(b - c, f - e));
-        diff = max(max(diff, mn), -mx);
-    }
-    if (pred > d + diff) pred = d + diff;
-    else if (pred < d - diff) pred = d - diff;
-    *o = (PIX)pred;
-}
+// That is decomb's yadif without the cubic predictor and with another rule for the rows next to the edge:
+// it runs as decomb_plane4_kernel with DecombBatch::ff set (four samples per thread, the frames of a batch
+// in one launch) since round 5; the one-sample-per-thread kernel this comment used to head is gone.
 
 // FFmpeg's bwdif as the reference's "Bwdif" filter configures it (deinterlace.c:46 -> vf_bwdif.c; parity
 // unpinned, restated in oracle/decomb_oracle.c:orc_bwdif_plane, which lists where it follows the in-tree
@@ -593,13 +543,7 @@ private:
             HBHIP_CHECK(ctx, hipGetLastError());
             return HBHIP_OK;
         }
-        if (ff_yadif)
-        {
-            if (in_geo.bps == 2) HBHIP_LAUNCH(ctx, "yadif", yadif_ff_kernel<uint16_t>, grid, block, 0, a, ff_nospatial);
-            else                 HBHIP_LAUNCH(ctx, "yadif", yadif_ff_kernel<uint8_t>, grid, block, 0, a, ff_nospatial);
-            HBHIP_CHECK(ctx, hipGetLastError());
-            return HBHIP_OK;
-        }
+        geo.ff = ff_yadif ? (ff_nospatial ? 2 : 1) : 0;        // FFmpeg's yadif: the same kernel, its rule for the edge rows
         // Four samples per thread (every depth).  The frames are gathered and go out together (launch_gathered, DB_FRAMES per
         // launch): at the end of the call, or - inside a chain batch - when the batch is complete or the EEDI2 engine
         // is full (a frame whose guess is still queued there cannot be launched before the engine).
@@ -624,8 +568,9 @@ private:
             B.n = (int)std::min<size_t>(DB_FRAMES, gathered.size() - i0);
             for (int k = 0; k < B.n; k++) B.f[k] = gathered[i0 + k];
             const dim3 block(64, 4), grid((B.w[0] + 255) / 256, (B.h[0] + 3) / 4, 3 * B.n);
-            if (in_geo.bps == 2) HBHIP_LAUNCH(lc, "decomb_plane", decomb_plane4_kernel<uint16_t>, grid, block, 0, B, (1 << in_geo.depth) - 1);
-            else                 HBHIP_LAUNCH(lc, "decomb_plane", decomb_plane4_kernel<uint8_t>, grid, block, 0, B, 255);
+            const char *name = ff_yadif ? "yadif" : "decomb_plane";
+            if (in_geo.bps == 2) HBHIP_LAUNCH(lc, name, decomb_plane4_kernel<uint16_t>, grid, block, 0, B, (1 << in_geo.depth) - 1);
+            else                 HBHIP_LAUNCH(lc, name, decomb_plane4_kernel<uint8_t>, grid, block, 0, B, 255);
         }
         const bool any = !gathered.empty();
         gathered.clear();
