@@ -278,76 +278,103 @@ __global__ __launch_bounds__(256) void decomb_plane4_kernel(DecombBatch B, int m
 // One thread per sample.  field_end = yadif->current_field == YADIF_FIELD_END: the intra (spatial only)
 // filter of the first field of a stream and of the last field of a bob stream.  df = bytes per sample:
 // vf_bwdif.c's mirror tests at the top / bottom rows compare against it, (y + df) < h, y > df - 1, ...
+// Four adjacent samples per thread: every tap is a whole row above / below the sample in one of the three frames, so a
+// thread's eighteen tap rows come in as one dword (two for 16-bit samples) each and the arithmetic is the scalar
+// filter's per sample.
 template <typename PIX>
 __global__ __launch_bounds__(256) void bwdif_kernel(DecombArgs a, int field_end, int clip_max)
 {
+    typedef Px4<PIX> X4;
+    typedef typename X4::T T;
     const DecombPlane &P = a.pl[blockIdx.z];
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int x = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= P.w || y >= P.h) return;
-    const int st = P.pitch / (int)sizeof(PIX), df = (int)sizeof(PIX), h = P.h;
-    const size_t at = (size_t)y * st + x;
-    const PIX *cur = reinterpret_cast<const PIX *>(P.cur) + at;
-    PIX *o = reinterpret_cast<PIX *>(P.dst + (size_t)y * P.dst_pitch) + x;
+    const int st = P.pitch, df = (int)sizeof(PIX), h = P.h;              // st: bytes between rows
+    const uint8_t *cur = P.cur + (size_t)y * st;
+    uint8_t *orow = P.dst + (size_t)y * P.dst_pitch;
+    auto dw = [&](const uint8_t *row) { return *reinterpret_cast<const T *>(row + (size_t)x * sizeof(PIX)); };
+    auto store = [&](T v) {
+        PIX *o = reinterpret_cast<PIX *>(orow) + x;
+        if (x + 3 < P.w) *reinterpret_cast<T *>(o) = v;
+        else for (int k = 0; k < 4 && x + k < P.w; k++) o[k] = (PIX)X4::get(v, k);
+    };
     if (a.mode == 0 || !((y ^ a.parity) & 1))              // pass-through frame, or a row of the kept field
     {
-        *o = *cur;
+        store(dw(cur));
         return;
     }
     constexpr int lf0 = 4309, lf1 = 213, hf0 = 5570, hf1 = 3801, hf2 = 1016, sp0 = 5077, sp1 = 981;
+    int o4[4];
     if (field_end)
     {
         const int prefs = (y + df) < h ? st : -st, mrefs = y > (df - 1) ? -st : st;
         const int prefs3 = (y + 3 * df) < h ? 3 * st : -st, mrefs3 = y > (3 * df - 1) ? -3 * st : st;
-        const int v = (sp0 * ((int)cur[mrefs] + (int)cur[prefs]) - sp1 * ((int)cur[mrefs3] + (int)cur[prefs3])) >> 13;
-        *o = (PIX)min(max(v, 0), clip_max);
+        const T c1 = dw(cur + mrefs), e1 = dw(cur + prefs), c3 = dw(cur + mrefs3), e3 = dw(cur + prefs3);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            const int v = (sp0 * (X4::get(c1, k) + X4::get(e1, k)) - sp1 * (X4::get(c3, k) + X4::get(e3, k))) >> 13;
+            o4[k] = min(max(v, 0), clip_max);
+        }
+        store(X4::pack(o4));
         return;
     }
-    const PIX *prev = reinterpret_cast<const PIX *>(P.prev) + at;
-    const PIX *next = reinterpret_cast<const PIX *>(P.next) + at;
-    const PIX *prev2 = a.field_parity ? prev : cur;
-    const PIX *next2 = a.field_parity ? cur : next;
+    const uint8_t *prev = P.prev + (size_t)y * st, *next = P.next + (size_t)y * st;
+    const uint8_t *prev2 = a.field_parity ? prev : cur;
+    const uint8_t *next2 = a.field_parity ? cur : next;
     const bool edge = (y < 4) || ((y + 5) > h);
     const int prefs = edge ? ((y + df) < h ? st : -st) : st, mrefs = edge ? (y > (df - 1) ? -st : st) : -st;
-    const int c = cur[mrefs], e = cur[prefs];
-    const int p0 = prev2[0], n0 = next2[0];
-    const int d = (p0 + n0) >> 1;
-    const int td0 = abs(p0 - n0);
-    const int td1 = (abs((int)prev[mrefs] - c) + abs((int)prev[prefs] - e)) >> 1;
-    const int td2 = (abs((int)next[mrefs] - c) + abs((int)next[prefs] - e)) >> 1;
-    int diff = max(max(td0 >> 1, td1), td2);
-    if (!diff)
-    {
-        *o = (PIX)d;
-        return;
-    }
     const bool spat = edge ? !((y < 2) || ((y + 3) > h)) : true;
-    if (spat)
+    const T wc = dw(cur + mrefs), we = dw(cur + prefs), wp0 = dw(prev2), wn0 = dw(next2);
+    const T wpm = dw(prev + mrefs), wpp = dw(prev + prefs), wnm = dw(next + mrefs), wnp = dw(next + prefs);
+    T wp2a = X4::zero(), wn2a = X4::zero(), wp2b = X4::zero(), wn2b = X4::zero();
+    if (spat) { wp2a = dw(prev2 - 2 * st); wn2a = dw(next2 - 2 * st); wp2b = dw(prev2 + 2 * st); wn2b = dw(next2 + 2 * st); }
+    T wc3a = X4::zero(), wc3b = X4::zero(), wp4a = X4::zero(), wn4a = X4::zero(), wp4b = X4::zero(), wn4b = X4::zero();
+    if (!edge)
     {
-        const int b = (((int)prev2[-2 * st] + (int)next2[-2 * st]) >> 1) - c;
-        const int f = (((int)prev2[2 * st] + (int)next2[2 * st]) >> 1) - e;
-        const int dc = d - c, de = d - e;
-        const int mx = max(max(de, dc), min(b, f));
-        const int mn = min(min(de, dc), max(b, f));
-        diff = max(max(diff, mn), -mx);
+        wc3a = dw(cur - 3 * st); wc3b = dw(cur + 3 * st);
+        wp4a = dw(prev2 - 4 * st); wn4a = dw(next2 - 4 * st); wp4b = dw(prev2 + 4 * st); wn4b = dw(next2 + 4 * st);
     }
-    int interpol;
-    if (edge)
-        interpol = (c + e) >> 1;
-    else
+#pragma unroll
+    for (int k = 0; k < 4; k++)
     {
-        const int c3 = (int)cur[-3 * st] + (int)cur[3 * st];
-        if (abs(c - e) > td0)
-            interpol = (((hf0 * (p0 + n0)
-                          - hf1 * ((int)prev2[-2 * st] + (int)next2[-2 * st] + (int)prev2[2 * st] + (int)next2[2 * st])
-                          + hf2 * ((int)prev2[-4 * st] + (int)next2[-4 * st] + (int)prev2[4 * st] + (int)next2[4 * st])) >> 2)
-                        + lf0 * (c + e) - lf1 * c3) >> 13;
+        const int c = X4::get(wc, k), e = X4::get(we, k);
+        const int p0 = X4::get(wp0, k), n0 = X4::get(wn0, k);
+        const int d = (p0 + n0) >> 1;
+        const int td0 = abs(p0 - n0);
+        const int td1 = (abs(X4::get(wpm, k) - c) + abs(X4::get(wpp, k) - e)) >> 1;
+        const int td2 = (abs(X4::get(wnm, k) - c) + abs(X4::get(wnp, k) - e)) >> 1;
+        int diff = max(max(td0 >> 1, td1), td2);
+        if (!diff) { o4[k] = d; continue; }
+        const int s2a = X4::get(wp2a, k) + X4::get(wn2a, k), s2b = X4::get(wp2b, k) + X4::get(wn2b, k);
+        if (spat)
+        {
+            const int b = (s2a >> 1) - c;
+            const int f = (s2b >> 1) - e;
+            const int dc = d - c, de = d - e;
+            const int mx = max(max(de, dc), min(b, f));
+            const int mn = min(min(de, dc), max(b, f));
+            diff = max(max(diff, mn), -mx);
+        }
+        int interpol;
+        if (edge)
+            interpol = (c + e) >> 1;
         else
-            interpol = (sp0 * (c + e) - sp1 * c3) >> 13;
+        {
+            const int c3 = X4::get(wc3a, k) + X4::get(wc3b, k);
+            if (abs(c - e) > td0)
+                interpol = (((hf0 * (p0 + n0) - hf1 * (s2a + s2b)
+                              + hf2 * (X4::get(wp4a, k) + X4::get(wn4a, k) + X4::get(wp4b, k) + X4::get(wn4b, k))) >> 2)
+                            + lf0 * (c + e) - lf1 * c3) >> 13;
+            else
+                interpol = (sp0 * (c + e) - sp1 * c3) >> 13;
+        }
+        if (interpol > d + diff) interpol = d + diff;
+        else if (interpol < d - diff) interpol = d - diff;
+        o4[k] = min(max(interpol, 0), clip_max);
     }
-    if (interpol > d + diff) interpol = d + diff;
-    else if (interpol < d - diff) interpol = d - diff;
-    *o = (PIX)min(max(interpol, 0), clip_max);
+    store(X4::pack(o4));
 }
 
 class DecombFilter : public hbhip_filter
@@ -537,8 +564,9 @@ private:
             // field; END selects the intra filter and is consumed by the first field that is filtered
             if (bw_second && bw_field == BW_BACK_END) bw_field = BW_END;
             const int field_end = mode != 0 && bw_field == BW_END;
-            if (in_geo.bps == 2) HBHIP_LAUNCH(ctx, "bwdif", bwdif_kernel<uint16_t>, grid, block, 0, a, field_end, maxv);
-            else                 HBHIP_LAUNCH(ctx, "bwdif", bwdif_kernel<uint8_t>, grid, block, 0, a, field_end, maxv);
+            const dim3 grid4((in_geo.pw[0] + 255) / 256, (in_geo.ph[0] + 3) / 4, 3);      // four samples per thread
+            if (in_geo.bps == 2) HBHIP_LAUNCH(ctx, "bwdif", bwdif_kernel<uint16_t>, grid4, block, 0, a, field_end, maxv);
+            else                 HBHIP_LAUNCH(ctx, "bwdif", bwdif_kernel<uint8_t>, grid4, block, 0, a, field_end, maxv);
             if (mode != 0 && bw_field == BW_END) bw_field = BW_NORMAL;
             HBHIP_CHECK(ctx, hipGetLastError());
             return HBHIP_OK;
