@@ -620,9 +620,17 @@ private:
             B.n = (int)std::min<size_t>(DB_FRAMES, gathered.size() - i0);
             for (int k = 0; k < B.n; k++) B.f[k] = gathered[i0 + k];
             const dim3 block(64, 4), grid((B.w[0] + 255) / 256, (B.h[0] + 3) / 4, 3 * B.n);
-            const char *name = ff_yadif ? "yadif" : "decomb_plane";
-            if (in_geo.bps == 2) HBHIP_LAUNCH(lc, name, decomb_plane4_kernel<uint16_t>, grid, block, 0, B, (1 << in_geo.depth) - 1);
-            else                 HBHIP_LAUNCH(lc, name, decomb_plane4_kernel<uint8_t>, grid, block, 0, B, 255);
+            const int maxv = (1 << in_geo.depth) - 1;
+            if (ff_yadif)
+            {
+                if (in_geo.bps == 2) HBHIP_LAUNCH(lc, "yadif", decomb_plane4_kernel<uint16_t>, grid, block, 0, B, maxv);
+                else                 HBHIP_LAUNCH(lc, "yadif", decomb_plane4_kernel<uint8_t>, grid, block, 0, B, maxv);
+            }
+            else
+            {
+                if (in_geo.bps == 2) HBHIP_LAUNCH(lc, "decomb_plane", decomb_plane4_kernel<uint16_t>, grid, block, 0, B, maxv);
+                else                 HBHIP_LAUNCH(lc, "decomb_plane", decomb_plane4_kernel<uint8_t>, grid, block, 0, B, maxv);
+            }
         }
         const bool any = !gathered.empty();
         gathered.clear();
