@@ -122,15 +122,27 @@ struct CombBatch
 
 __device__ __forceinline__ int cb_b(uint32_t d, int k) { return (int)((d >> (8 * k)) & 0xffu); }
 
-template <bool GAMMA>
+// TAB (gamma metric only): the threshold tests on differences of table values as integer compares.  The gamma table is
+// monotone, so for a sample value v the values a with L[v] - L[a] > t are a prefix 0 .. hi[v] - 1 of the value range and
+// those with L[v] - L[a] < -t a suffix lo[v] .. 255: the host finds hi / lo by evaluating the float expression itself for
+// all 256 x 256 pairs (and keeps the float form should a table ever not be monotone).  A test then costs one look-up on
+// one of its two operands and two integer compares instead of two look-ups, a subtraction and the float compares; the six
+// motion tests share three look-ups.  tab: 256 dwords hi | lo << 16 for the spatial threshold, 256 for the motion one.
+template <bool GAMMA, bool TAB>
 __global__ __launch_bounds__(256) void comb_detect4_kernel(CombBatch B, int pitch, uint8_t *__restrict__ mask_base, size_t mask_fs,
                                                            int mask_stride, int width, int height, CombConst k,
-                                                           const float *__restrict__ lut_g)
+                                                           const float *__restrict__ lut_g, const uint32_t *__restrict__ tab)
 {
     __shared__ float L[256];
+    __shared__ uint32_t TA[TAB ? 256 : 1], TM[TAB ? 256 : 1];
     if (GAMMA)
     {
         L[threadIdx.y * 64 + threadIdx.x] = lut_g[threadIdx.y * 64 + threadIdx.x];
+        if (TAB)
+        {
+            TA[threadIdx.y * 64 + threadIdx.x] = tab[threadIdx.y * 64 + threadIdx.x];
+            TM[threadIdx.y * 64 + threadIdx.x] = tab[256 + threadIdx.y * 64 + threadIdx.x];
+        }
         __syncthreads();
     }
     const int f = blockIdx.z;
@@ -151,7 +163,12 @@ __global__ __launch_bounds__(256) void comb_detect4_kernel(CombBatch B, int pitc
         {
             const int v = cb_b(cv, j), u1 = cb_b(cu1, j), d1 = cb_b(cd1, j);
             bool pass;
-            if (GAMMA)
+            if (GAMMA && TAB)
+            {
+                const uint32_t t = TA[v];
+                pass = max(u1, d1) < (int)(t & 0xffffu) || min(u1, d1) >= (int)(t >> 16);
+            }
+            else if (GAMMA)
             {
                 const float up = L[v] - L[u1], dn = L[v] - L[d1];
                 pass = (up > k.g_athresh && dn > k.g_athresh) || (up < -k.g_athresh && dn < -k.g_athresh);
@@ -178,7 +195,14 @@ __global__ __launch_bounds__(256) void comb_detect4_kernel(CombBatch B, int pitc
                 bool comb = false;
                 if (GAMMA)
                 {
-                    if (k.g_mthresh > 0)
+                    if (k.g_mthresh > 0 && TAB)
+                    {
+                        const uint32_t tv = TM[v], tu = TM[u1], td = TM[d1];
+                        auto far = [](uint32_t t, int b) { return b < (int)(t & 0xffffu) || b >= (int)(t >> 16); };   // |L[a] - L[b]| > mthresh
+                        if (far(tv, cb_b(pv, j)) && far(tu, cb_b(nu1, j)) && far(td, cb_b(nd1, j))) motion++;
+                        if (far(tv, cb_b(nv, j)) && far(tu, cb_b(pu1, j)) && far(td, cb_b(pd1, j))) motion++;
+                    }
+                    else if (k.g_mthresh > 0)
                     {
                         if (fabsf(L[cb_b(pv, j)] - L[v]) > k.g_mthresh && fabsf(L[u1] - L[cb_b(nu1, j)]) > k.g_mthresh &&
                             fabsf(L[d1] - L[cb_b(nd1, j)]) > k.g_mthresh)
@@ -524,6 +548,7 @@ public:
         for (int i = 0; i < 3; i++) if (luma_alloc[i]) (void)hipFree(luma_alloc[i]);
         if (masks) (void)hipFree(masks);
         if (d_lut) (void)hipFree(d_lut);
+        if (d_tab) (void)hipFree(d_tab);
         if (d_result) (void)hipFree(d_result);
         if (h_result) (void)hipHostFree(h_result);
         if (stage) (void)hipFree(stage);
@@ -579,6 +604,33 @@ public:
         k.athresh6 = 6 * par.spatial_threshold;
         k.c32_min = 10 << up; k.c32_max = 15 << up;
         k.lut_len = max_value + 1;
+        if (depth == 8 && (par.mode & 1)) return build_threshold_tables();
+        return HBHIP_OK;
+    }
+
+    // comb_detect4_kernel's integer form of the gamma metric's threshold tests (see there)
+    int build_threshold_tables()
+    {
+        const float *L = par.gamma_lut;
+        std::vector<uint32_t> tab(512);
+        bool ok = true;
+        for (int which = 0; which < 2 && ok; which++)
+        {
+            const float t = which ? k.g_mthresh : k.g_athresh;
+            for (int v = 0; v < 256 && ok; v++)
+            {
+                int hi = 0, lo = 256;
+                while (hi < 256 && L[v] - L[hi] > t) hi++;
+                for (int a = 255; a >= 0 && L[v] - L[a] < -t; a--) lo = a;
+                for (int a = 0; a < 256 && ok; a++)                        // a prefix and a suffix, nothing else
+                    ok = ((L[v] - L[a] > t) == (a < hi)) && ((L[v] - L[a] < -t) == (a >= lo)) &&
+                         ((fabsf(L[a] - L[v]) > t) == (a < hi || a >= lo));
+                tab[256 * which + v] = (uint32_t)hi | ((uint32_t)lo << 16);
+            }
+        }
+        if (!ok) return HBHIP_OK;                                          // not monotone: the float form stays
+        HBHIP_CHECK(ctx, hipMalloc((void **)&d_tab, sizeof(uint32_t) * 512));
+        HBHIP_CHECK(ctx, hipMemcpy(d_tab, tab.data(), sizeof(uint32_t) * 512, hipMemcpyHostToDevice));
         return HBHIP_OK;
     }
 
@@ -643,8 +695,9 @@ public:
             for (int i = 0; i < 3; i++) B.luma[i] = luma_alloc[ref[i]];
             B.force = force ? 1u : 0u; B.n = 1;
             const dim3 g4((mstride / 4 + 63) / 64, (height - 4 + 3) / 4, 1);
-            if (par.mode & 1) HBHIP_LAUNCH(ctx, "comb_detect", comb_detect4_kernel<true>, g4, b, 0, B, pitch, mask, (size_t)0, mstride, width, height, k, (const float *)d_lut);
-            else              HBHIP_LAUNCH(ctx, "comb_detect", comb_detect4_kernel<false>, g4, b, 0, B, pitch, mask, (size_t)0, mstride, width, height, k, (const float *)d_lut);
+            if ((par.mode & 1) && d_tab) HBHIP_LAUNCH(ctx, "comb_detect", (comb_detect4_kernel<true, true>), g4, b, 0, B, pitch, mask, (size_t)0, mstride, width, height, k, (const float *)d_lut, (const uint32_t *)d_tab);
+            else if (par.mode & 1)       HBHIP_LAUNCH(ctx, "comb_detect", (comb_detect4_kernel<true, false>), g4, b, 0, B, pitch, mask, (size_t)0, mstride, width, height, k, (const float *)d_lut, (const uint32_t *)nullptr);
+            else                         HBHIP_LAUNCH(ctx, "comb_detect", (comb_detect4_kernel<false, false>), g4, b, 0, B, pitch, mask, (size_t)0, mstride, width, height, k, (const float *)d_lut, (const uint32_t *)nullptr);
         }
         else if (bps == 2)
             HBHIP_LAUNCH(ctx, "comb_detect", comb_detect_kernel<uint16_t>, g, b, lds, (const uint16_t *)luma_alloc[ref[0]],
@@ -737,8 +790,9 @@ public:
             HBHIP_CHECK(ctx, hipHostMalloc((void **)&h_bresult, sizeof(int) * 4 * CB_FRAMES, hipHostMallocDefault));
         }
         const dim3 b(64, 4), g4((mstride / 4 + 63) / 64, (height - 4 + 3) / 4, n);
-        if (par.mode & 1) HBHIP_LAUNCH(ctx, "comb_detect", comb_detect4_kernel<true>, g4, b, 0, B, stride, bmasks, fs, mstride, width, height, k, (const float *)d_lut);
-        else              HBHIP_LAUNCH(ctx, "comb_detect", comb_detect4_kernel<false>, g4, b, 0, B, stride, bmasks, fs, mstride, width, height, k, (const float *)d_lut);
+        if ((par.mode & 1) && d_tab) HBHIP_LAUNCH(ctx, "comb_detect", (comb_detect4_kernel<true, true>), g4, b, 0, B, stride, bmasks, fs, mstride, width, height, k, (const float *)d_lut, (const uint32_t *)d_tab);
+        else if (par.mode & 1)       HBHIP_LAUNCH(ctx, "comb_detect", (comb_detect4_kernel<true, false>), g4, b, 0, B, stride, bmasks, fs, mstride, width, height, k, (const float *)d_lut, (const uint32_t *)nullptr);
+        else                         HBHIP_LAUNCH(ctx, "comb_detect", (comb_detect4_kernel<false, false>), g4, b, 0, B, stride, bmasks, fs, mstride, width, height, k, (const float *)d_lut, (const uint32_t *)nullptr);
         if (filt)
             HBHIP_LAUNCH(ctx, "comb_mask_passes", comb_mask_fused4_kernel, dim3((width + 63) / 64, (height + 15) / 16, n), b, 0,
                          (const uint8_t *)bmasks, bmasks + msz, fs, mstride, width, height);
@@ -838,6 +892,7 @@ private:
     int ref[3] = {-1, -1, -1};
     uint8_t *masks = nullptr, *mask = nullptr, *mask_filtered = nullptr, *mask_temp = nullptr;
     float *d_lut = nullptr;
+    uint32_t *d_tab = nullptr;          // comb_detect4_kernel<true, true>'s threshold tables (8-bit gamma metric)
     int *d_result = nullptr, *h_result = nullptr;
     bool overlay = false;
     int box_x = 0, box_y = 0;                        // pv->mask_box_x / _y
