@@ -245,3 +245,22 @@ def test_pad_and_format_many_frames_per_launch(built):
     for t, fr in enumerate(frames):
         for c in range(3):
             np.testing.assert_array_equal(got[t][c], fr[c], err_msg=f"format frame {t} plane {c}")
+
+
+def test_pad_frames_whose_rows_are_not_16_byte_aligned(built):
+    """device frames with 642-byte rows: the zero-copy batch path wants 16-byte rows, so these go through the filter's
+    own pictures (hbhip_filter::process_dev_batch) - same result"""
+    import ctypes as C
+    w, h = 642, 362
+    frames = synth.stream("random", w, h, 3)
+
+    class PP(C.Structure):
+        _fields_ = [("width", C.c_int), ("height", C.c_int), ("x", C.c_int), ("y", C.c_int), ("fill", C.c_int * 3)]
+    pp = PP(w + 10, h + 6, 6, 2, (C.c_int * 3)(16, 128, 128))
+    make = lambda ctx: hip._create("hbhip_pad_create", ctx, [C.c_void_p, C.POINTER(PP)] + [C.c_int] * 5 + [C.POINTER(C.c_void_p)],
+                                   ctx.h, C.byref(pp), w, h, 8, 1, 1)
+    got = _batch_through(make, frames, w + 10, h + 6)
+    for t, fr in enumerate(frames):
+        want = ol.orc_pad_frame(fr, w + 10, h + 6, 6, 2, rgb=0)
+        for c in range(3):
+            np.testing.assert_array_equal(got[t][c], want[c], err_msg=f"frame {t} plane {c}")

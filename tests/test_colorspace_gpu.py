@@ -143,3 +143,32 @@ def test_many_frames_per_launch(built, w, h, depth, src, dst, kw):
         want = ol.orc_colorspace_frame(fr, params, depth=depth)
         for c in range(3):
             np.testing.assert_array_equal(got[t][c], want[c], err_msg=f"frame {t} plane {c}")
+
+
+def test_vertically_subsampled_only(built):
+    """4:4:0 (chroma halved vertically only): no pixel format of the stand-in runtime has it, the C ABI takes it - the
+    (SUBW, SUBH) = (0, 1) instantiation of the kernel against the oracle"""
+    import torch
+    w, h = 200, 120
+    base = synth.stream("random", 2 * w, 2 * h, 2)
+    frames = [(np.ascontiguousarray(b[0][:h, :w]), np.ascontiguousarray(b[1][:h // 2, :w]), np.ascontiguousarray(b[2][:h // 2, :w])) for b in base]
+    ctx = hip.Ctx(0)
+    flt = hip.colorspace_device_filter(ctx, w, h, BT601, BT709, log2_cw=0, log2_ch=1)
+    try:
+        got = []
+        for fr in frames:
+            dev = [torch.from_numpy(p).cuda() for p in fr]
+            out = [torch.zeros_like(d) for d in dev]
+            torch.cuda.synchronize()
+            flt.push_dev(hip.dev_frame(dev), 0)
+            assert flt.pull_dev(hip.dev_frame(out)) is not None
+            ctx.sync()
+            got.append([o.cpu().numpy() for o in out])
+    finally:
+        flt.close()
+        ctx.close()
+    params = ol.colorspace_params(BT601, BT709)
+    for t, fr in enumerate(frames):
+        want = ol.orc_colorspace_frame(fr, params, subw=0, subh=1)
+        for c in range(3):
+            np.testing.assert_array_equal(got[t][c], want[c], err_msg=f"frame {t} plane {c}")
