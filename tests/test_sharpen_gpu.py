@@ -58,6 +58,18 @@ def test_unsharp_and_chroma_smooth(built, w, h, size):
     _eq(got, want)
 
 
+@pytest.mark.parametrize("w,h", [(40, 22), (72, 38), (136, 70), (264, 100), (520, 54), (1032, 44)])
+@pytest.mark.parametrize("size", [3, 7, 9])
+def test_unsharp_strips_and_edges(built, w, h, size):
+    """planes whose rows are whole dwords take the branch-free strips of blur_rows8_kernel where no row clamp is needed:
+    heights with one, a few and a ragged last strip of 16 rows, widths with part of a wave, the plane's left and right edge
+    lanes in the same wave and in different ones, luma on that path while chroma (w / 2 odd multiples of 2) is not"""
+    frames = synth.stream("random", w, h, 1) + synth.stream("progressive", w, h, 1)
+    got = hbrt.run_stream(hip.filters(), [("hb_filter_unsharp_hip", f"y-strength=0.9:y-size={size}:cb-strength=0.5:cb-size={size}")], frames)
+    want = os_.unsharp_stream(frames, [dict(strength=0.9, size=size)] + [dict(strength=0.5, size=size)] * 2)
+    _eq(got, want)
+
+
 def test_unsharp_zero_strength_is_copy(built):
     frames = synth.stream("progressive", 320, 180, 1)
     got = hbrt.run_stream(hip.filters(), [("hb_filter_unsharp_hip", "y-strength=0:cb-strength=0")], frames)
