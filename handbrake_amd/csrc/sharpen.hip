@@ -577,7 +577,10 @@ int launch_copy(hbhip_ctx *ctx, const char *name, DevPicture *in, DevPicture *ou
 // unpacked once, and the 9-tap sum costs ~7 integer operations per pixel instead of 18.  The mix is the reference's
 // double arithmetic, operation for operation (lapsharp.c:174-175).  One launch covers the three planes of up to
 // LS_FRAMES frames (blockIdx.z): single 1080p planes are too small to fill the GPU or hide a launch.
-constexpr int LS_ROWS = 8, LS_FRAMES = 16;
+#ifndef LS_ROWS_N
+#define LS_ROWS_N 8
+#endif
+constexpr int LS_ROWS = LS_ROWS_N, LS_FRAMES = 16;
 struct LapPlane3 { int width, height, src_pitch, dst_pitch, stride_border, valid_w, a, b, c, active; double coef, strength; int fast, kinv; float mixf; };
 struct LapBatch3
 {
