@@ -1074,7 +1074,10 @@ __global__ __launch_bounds__(256) void q_dir_map4(Q3 P, K16 k, int step, int exp
 // that nearly every wave holds a few, and a wave pays for the sort if one lane needs it.  They are queued (an LDS list
 // per workgroup of 4 rows x 256 samples) and phase 2 gives each queued sample a lane of its own.  a = edge mask,
 // b = direction map in, c = out; step 1 (half height) or 2.
-__global__ __launch_bounds__(256) void q_dir_map(Q3 P, K16 k, int step, int expand)
+// post != 0 (the last expand_dir_map_2x of a field): eedi2_post_process (:1349-1378, q_post) rides along, as in the
+// 8-bit engine - it is pointwise in the map this pass has just made (e = the map before the post filters, f = dst2p,
+// rebuilt rows only; the rows it averages are of the other parity, which no thread of the pass writes).
+__global__ __launch_bounds__(256) void q_dir_map(Q3 P, K16 k, int step, int expand, int post)
 {
     __shared__ __attribute__((aligned(16))) uint16_t s_out[4][256];
     __shared__ uint16_t s_list[4 * 256];
@@ -1181,6 +1184,31 @@ __global__ __launch_bounds__(256) void q_dir_map(Q3 P, K16 k, int step, int expa
         {
             const uint16_t o4[4] = { (uint16_t)(v.x & 0xffffu), (uint16_t)(v.x >> 16), (uint16_t)(v.y & 0xffffu), (uint16_t)(v.y >> 16) };
             for (int j = 0; j < 4 && x + j < width; j++) o[j] = o4[j];
+        }
+        if (post && row_ok)
+        {
+            const size_t at = (size_t)fld * P.fstride + (size_t)y * pitch + x;
+            const uint2 om4 = *reinterpret_cast<const uint2 *>(P.e[pl] + at);
+            uint16_t *d = P.f[pl] + at;
+            const uint2 up4 = *reinterpret_cast<const uint2 *>(d - pitch), dn4 = *reinterpret_cast<const uint2 *>(d + pitch);
+            const uint2 cur4 = *reinterpret_cast<const uint2 *>(d);
+            auto s4 = [](const uint2 &w, int j) -> int { return (int)(((j < 2 ? w.x : w.y) >> (16 * (j & 1))) & 0xffffu); };
+            uint32_t out[4];
+            bool any = false;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+            {
+                const int nm = s4(v, j), om = s4(om4, j);
+                const int lim = s_lim[iabs16(nm - k.neutral) >> (2 + k.shift)];
+                const bool fix = iabs16(nm - om) > lim && om != k.peak && om != k.neutral;
+                out[j] = fix ? (uint32_t)((s4(up4, j) + s4(dn4, j) + 1) >> 1) : (uint32_t)s4(cur4, j);
+                any |= fix;
+            }
+            if (any)
+            {
+                if (x + 3 < width) *reinterpret_cast<uint2 *>(d) = make_uint2(out[0] | (out[1] << 16), out[2] | (out[3] << 16));
+                else for (int j = 0; j < 4 && x + j < width; j++) d[j] = (uint16_t)out[j];
+            }
         }
     }
     if (copy)
@@ -2169,38 +2197,6 @@ __global__ __launch_bounds__(LR16_T) void q_lattice_resolve16(Q3 P, K16 k, const
     }
 }
 
-// eedi2_post_process (:1349-1378): a = new direction map, b = old one, c = dst2p (in place, rows y from y+-1)
-// (four samples per thread, a thread row per REBUILT row: the rows in between have nothing to do here)
-__global__ __launch_bounds__(256) void q_post(Q3 P, K16 k)
-{
-    FIELD16(P);
-    const int x = 4 * (blockIdx.x * blockDim.x + threadIdx.x), r = blockIdx.y * blockDim.y + threadIdx.y;
-    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
-    const int y = (2 - tff) + 2 * r;
-    if (x >= width || y >= height - 1) return;
-    if (maskless) return;                                          // every direction a peak: the picture stays (:1364)
-    const size_t at = (size_t)y * pitch + x;
-    const uint2 nm4 = *reinterpret_cast<const uint2 *>(Q.a + at), om4 = *reinterpret_cast<const uint2 *>(Q.b + at);
-    uint16_t *d = Q.c + at;
-    const uint2 up4 = *reinterpret_cast<const uint2 *>(d - pitch), dn4 = *reinterpret_cast<const uint2 *>(d + pitch);
-    const uint2 cur4 = *reinterpret_cast<const uint2 *>(d);
-    auto s4 = [](const uint2 &v, int j) -> int { return (int)(((j < 2 ? v.x : v.y) >> (16 * (j & 1))) & 0xffffu); };
-    uint32_t out[4];
-    bool any = false;
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-    {
-        const int nm = s4(nm4, j), om = s4(om4, j);
-        const int lim = k.limlut[iabs16(nm - k.neutral) >> (2 + k.shift)];
-        const bool fix = iabs16(nm - om) > lim && om != k.peak && om != k.neutral;
-        out[j] = fix ? (uint32_t)((s4(up4, j) + s4(dn4, j) + 1) >> 1) : (uint32_t)s4(cur4, j);
-        any |= fix;
-    }
-    if (!any) return;
-    if (x + 3 < width) *reinterpret_cast<uint2 *>(d) = make_uint2(out[0] | (out[1] << 16), out[2] | (out[3] << 16));
-    else for (int j = 0; j < 4 && x + j < width; j++) d[j] = (uint16_t)out[j];
-}
-
 // ---- post-processing 2/3 (:1391-1904), as in eedi2.hip but on uint16 samples -----------------------
 struct Corner16
 {
@@ -2549,7 +2545,7 @@ int Eedi2Engine16::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st)
     bind(P.a, mskp); bind(P.b, tmpp); bind(P.c, dstp);
     HBHIP_LAUNCH_ON(lc, st, "eedi2_16_filter_dir_map", q_dir_map4, grid4(srcp, gz), blk, 0, P, k, 1, 0);
     bind(P.a, mskp); bind(P.b, dstp); bind(P.c, tmpp);
-    HBHIP_LAUNCH_ON(lc, st, "eedi2_16_expand_dir_map", q_dir_map, grid4(srcp, gz), blk, 0, P, k, 1, 1);
+    HBHIP_LAUNCH_ON(lc, st, "eedi2_16_expand_dir_map", q_dir_map, grid4(srcp, gz), blk, 0, P, k, 1, 1, 0);
     bind(P.a, mskp); bind(P.b, tmpp); bind(P.c, dstp);
     HBHIP_LAUNCH_ON(lc, st, "eedi2_16_filter_map", q_filter_map, grid4(srcp, gz), blk, 0, P, k);
     // the three line doublings + mark_directions_2x in one launch (full-height geometry)
@@ -2560,7 +2556,7 @@ int Eedi2Engine16::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st)
     bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
     HBHIP_LAUNCH_ON(lc, st, "eedi2_16_filter_dir_map_2x", q_dir_map4, grid4p(dst2p, gz), blk, 0, P, k, 2, 0);
     bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
-    HBHIP_LAUNCH_ON(lc, st, "eedi2_16_expand_dir_map_2x", q_dir_map, grid4p(dst2p, gz), blk, 0, P, k, 2, 1);
+    HBHIP_LAUNCH_ON(lc, st, "eedi2_16_expand_dir_map_2x", q_dir_map, grid4p(dst2p, gz), blk, 0, P, k, 2, 1, 0);
     for (int pass = 0; pass < 2; pass++)
     {
         const EediFrame &in = pass ? dst2mp : tmp2p, &out = pass ? tmp2p : dst2mp;
@@ -2582,10 +2578,9 @@ int Eedi2Engine16::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st)
         HBHIP_LAUNCH_ON(lc, st, "eedi2_16_blit", q_blit, dim3((dst2p.width[0] + 511) / 512, (dst2p.height[0] + 3) / 4, gz), blk, 0, P);   // eedi2_bit_blit(tmp2p -> tmp2p2)
         bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
         HBHIP_LAUNCH_ON(lc, st, "eedi2_16_filter_dir_map_2x", q_dir_map4, grid4p(dst2p, gz), blk, 0, P, k, 2, 0);
-        bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
-        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_expand_dir_map_2x", q_dir_map, grid4p(dst2p, gz), blk, 0, P, k, 2, 1);
-        bind(P.a, tmp2p); bind(P.b, tmp2p2); bind(P.c, dst2p);
-        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_post_process", q_post, grid4p(dst2p, gz), blk, 0, P, k);
+        // + eedi2_post_process (new map = what the pass writes, old map tmp2p2, picture dst2p): folded into the pass
+        bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p); bind(P.e, tmp2p2); bind(P.f, dst2p);
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_expand_dir_map_2x", q_dir_map, grid4p(dst2p, gz), blk, 0, P, k, 2, 1, 1);
     }
     if (par_.post_processing == 2 || par_.post_processing == 3)
     {
