@@ -82,3 +82,24 @@ def test_without_a_gpu_every_drop_in_refuses_to_start(built):
     for stage in [("hb_filter_colorspace_hip", ""), ("hb_filter_colorspace_hip", "matrix=bt709:range=tv"),
                   ("hb_filter_yadif_hip", "mode=0")]:
         hbrt.Chain(F, [stage], 640, 360).close()                 # nothing to do => no device needed
+
+
+def test_product_libraries_do_not_link_or_name_the_oracle(built):
+    """The oracle is test infrastructure: nothing the product ships may need it.  DT_NEEDED of the three product libraries
+    names no oracle library, no string in them names one, and the package's Python neither imports nor loads one."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "handbrake_amd")
+    for lib in ("libhbhip.so", "libhbhip_filters.so", "libhbrt.so"):
+        path = os.path.join(pkg, lib)
+        out = subprocess.run(["readelf", "-d", path], capture_output=True, text=True, check=True).stdout
+        needed = re.findall(r"\(NEEDED\)\s+Shared library: \[(.*?)\]", out)
+        assert needed, lib
+        assert not [n for n in needed if "oracle" in n or "hbref" in n or "hbmetal" in n], (lib, needed)
+        blob = open(path, "rb").read()
+        assert b"liboracle" not in blob and b"libhbref" not in blob and b"oracle/_ref" not in blob, lib
+    for name in os.listdir(pkg):
+        if name.endswith(".py"):
+            text = open(os.path.join(pkg, name)).read()
+            assert not re.search(r"import\s+oracle|from\s+oracle|liboracle|CDLL\([^)]*(oracle|hbref)|dlopen\([^)]*(oracle|hbref)", text), name
