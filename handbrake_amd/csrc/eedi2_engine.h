@@ -103,12 +103,41 @@ static inline MaskChain eedi_mask_chain_tiles(const EediFrame &srcp, int tile_w,
 // link of the chain).  With C.group = ntiles + nupper the upper tiles of a field - which no other tile waits for and which
 // wait for none - sit behind its lower ones in the dispatch order: they keep the CUs busy while the next field's lower
 // tiles wait for this field's.
+// Workgroups go to the eight XCDs round robin in dispatch order (workgroup i to XCD i mod 8), each XCD with an L2 of its
+// own: numbered row by row, the tiles that share a halo - left / right neighbours, and the rows above / below, 15 tiles
+// away in a 1080p luma plane - would sit on different XCDs and fetch each other's halo from HBM (the counters had the pass
+// at 1.96 x its algorithmic bytes).  So the position p of a workgroup among the n lower tiles of its field is turned into
+// the tile number by XCD: the positions that land on XCD k take a contiguous run of tiles.  A permutation inside a field,
+// so a tile still only waits for tiles of the field before it, all dispatched earlier.  MEASURED AND NOT ADOPTED
+// (profiles/r5w_mask_chain_xcd_order.json): 43 % fewer bytes read, and 138 -> 155 us per launch - the launch is a chain
+// of tile latencies, and a run of neighbouring tiles on one XCD serialises what row-by-row numbering spreads over eight.
+#ifndef EEDI_XCD_ORDER
+#define EEDI_XCD_ORDER 0
+#endif
+__device__ __forceinline__ int eedi_xcd_order(int p, int n, int first)       // first = blockIdx.x of the field's position 0
+{
+#if EEDI_XCD_ORDER
+    const int s = first & 7, k = (p + s) & 7;
+    int run = 0;                                                               // tiles on the XCDs before k
+    for (int q = 0; q < k; q++)
+    {
+        const int f0 = (q - s) & 7;                                            // first position of the field that lands on XCD q
+        run += f0 < n ? (n - f0 + 7) >> 3 : 0;
+    }
+    return run + ((p - ((k - s) & 7)) >> 3);
+#else
+    (void)n; (void)first;
+    return p;
+#endif
+}
+
 __device__ __forceinline__ bool eedi_chain_tile(const MaskChain &C, int &fld, int &pl, int &bx, int &by)
 {
     fld = (int)blockIdx.x / C.group;
     int tile = (int)blockIdx.x - fld * C.group;
     if (tile < C.ntiles)
     {
+        tile = eedi_xcd_order(tile, C.ntiles, fld * C.group);
         pl = tile >= C.base[2] ? 2 : tile >= C.base[1] ? 1 : 0;
         tile -= C.base[pl];
         const int ry = tile / C.tx[pl];
