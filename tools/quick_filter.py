@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from handbrake_amd import hip, synth
 
-W, H, NB = 1920, 1080, 16
+W, H, NB = int(os.environ.get("QF_W", 1920)), int(os.environ.get("QF_H", 1080)), 16
 
 
 def planes(w, h, dtype=torch.uint8):
