@@ -1328,7 +1328,7 @@ public:
                 }
             }
             if (!aligned) return HBHIP_ERR_ARG;                              // planes and pitches of this library are 64-byte aligned
-            const dim3 grid(((a.dw[0] + 3) / 4 + 63) / 64, (a.dh[0] + 3) / 4, 3 * nf);
+            const dim3 grid(hbhip_grid_x(((a.dw[0] + 3) / 4 + 63) / 64), (a.dh[0] + 3) / 4, 3 * nf);
             HBHIP_LAUNCH(ctx, "pad", pad_kernel, grid, dim3(64, 4), 0, a, bps);
             HBHIP_CHECK(ctx, hipGetLastError());
             at += nf;
@@ -1452,7 +1452,7 @@ public:
             }
             if (!aligned) return HBHIP_ERR_ARG;                              // planes and pitches of this library are 64-byte aligned
             a.sdepth = in_geo.depth; a.ddepth = out_geo.depth; a.full_range = full_range;
-            const dim3 grid((a.w[0] + 255) / 256, (a.h[0] + 3) / 4, 3 * nf);
+            const dim3 grid(hbhip_grid_x((a.w[0] + 255) / 256), (a.h[0] + 3) / 4, 3 * nf);
             if (in_geo.bps == 1 && out_geo.bps == 1)      HBHIP_LAUNCH(ctx, "format", (format_kernel<uint8_t, uint8_t>), grid, dim3(64, 4), 0, a);
             else if (in_geo.bps == 1)                     HBHIP_LAUNCH(ctx, "format", (format_kernel<uint8_t, uint16_t>), grid, dim3(64, 4), 0, a);
             else if (out_geo.bps == 1)                    HBHIP_LAUNCH(ctx, "format", (format_kernel<uint16_t, uint8_t>), grid, dim3(64, 4), 0, a);

@@ -721,7 +721,7 @@ public:
     {
         const int sw = in_geo.log2_cw, sh = in_geo.log2_ch;
         const int tw = CS_RW - (sw ? 4 : 0), th = CS_RH - (sh ? 2 : 0);
-        const dim3 grid((B.w + tw - 1) / tw, (B.h + th - 1) / th, nf);
+        const dim3 grid(hbhip_grid_x((B.w + tw - 1) / tw), (B.h + th - 1) / th, nf);
         if (plan.need_linear)
         {
             if (sw && sh)       HBHIP_LAUNCH(ctx, "colorspace", (colorspace_kernel<PIX, 1, 1, true>), grid, dim3(256), 0, B, plan);

@@ -694,7 +694,7 @@ public:
             CombBatch B;
             for (int i = 0; i < 3; i++) B.luma[i] = luma_alloc[ref[i]];
             B.force = force ? 1u : 0u; B.n = 1;
-            const dim3 g4((mstride / 4 + 63) / 64, (height - 4 + 3) / 4, 1);
+            const dim3 g4(hbhip_grid_x((mstride / 4 + 63) / 64), (height - 4 + 3) / 4, 1);
             if ((par.mode & 1) && d_tab) HBHIP_LAUNCH(ctx, "comb_detect", (comb_detect4_kernel<true, true>), g4, b, 0, B, pitch, mask, (size_t)0, mstride, width, height, k, (const float *)d_lut, (const uint32_t *)d_tab);
             else if (par.mode & 1)       HBHIP_LAUNCH(ctx, "comb_detect", (comb_detect4_kernel<true, false>), g4, b, 0, B, pitch, mask, (size_t)0, mstride, width, height, k, (const float *)d_lut, (const uint32_t *)nullptr);
             else                         HBHIP_LAUNCH(ctx, "comb_detect", (comb_detect4_kernel<false, false>), g4, b, 0, B, pitch, mask, (size_t)0, mstride, width, height, k, (const float *)d_lut, (const uint32_t *)nullptr);
@@ -789,7 +789,7 @@ public:
             HBHIP_CHECK(ctx, hipMalloc((void **)&d_bresult, sizeof(int) * 4 * CB_FRAMES));
             HBHIP_CHECK(ctx, hipHostMalloc((void **)&h_bresult, sizeof(int) * 4 * CB_FRAMES, hipHostMallocDefault));
         }
-        const dim3 b(64, 4), g4((mstride / 4 + 63) / 64, (height - 4 + 3) / 4, n);
+        const dim3 b(64, 4), g4(hbhip_grid_x((mstride / 4 + 63) / 64), (height - 4 + 3) / 4, n);
         if ((par.mode & 1) && d_tab) HBHIP_LAUNCH(ctx, "comb_detect", (comb_detect4_kernel<true, true>), g4, b, 0, B, stride, bmasks, fs, mstride, width, height, k, (const float *)d_lut, (const uint32_t *)d_tab);
         else if (par.mode & 1)       HBHIP_LAUNCH(ctx, "comb_detect", (comb_detect4_kernel<true, false>), g4, b, 0, B, stride, bmasks, fs, mstride, width, height, k, (const float *)d_lut, (const uint32_t *)nullptr);
         else                         HBHIP_LAUNCH(ctx, "comb_detect", (comb_detect4_kernel<false, false>), g4, b, 0, B, stride, bmasks, fs, mstride, width, height, k, (const float *)d_lut, (const uint32_t *)nullptr);

@@ -588,7 +588,7 @@ private:
             // field; END selects the intra filter and is consumed by the first field that is filtered
             if (bw_second && bw_field == BW_BACK_END) bw_field = BW_END;
             const int field_end = mode != 0 && bw_field == BW_END;
-            const dim3 grid4((in_geo.pw[0] + 255) / 256, (in_geo.ph[0] + 3) / 4, 3);      // four samples per thread
+            const dim3 grid4(hbhip_grid_x((in_geo.pw[0] + 255) / 256), (in_geo.ph[0] + 3) / 4, 3);      // four samples per thread
             if (in_geo.bps == 2) HBHIP_LAUNCH(ctx, "bwdif", bwdif_kernel<uint16_t>, grid4, block, 0, a, field_end, maxv);
             else                 HBHIP_LAUNCH(ctx, "bwdif", bwdif_kernel<uint8_t>, grid4, block, 0, a, field_end, maxv);
             if (mode != 0 && bw_field == BW_END) bw_field = BW_NORMAL;
@@ -619,7 +619,7 @@ private:
             DecombBatch B = geo;
             B.n = (int)std::min<size_t>(DB_FRAMES, gathered.size() - i0);
             for (int k = 0; k < B.n; k++) B.f[k] = gathered[i0 + k];
-            const dim3 block(64, 4), grid((B.w[0] + 255) / 256, (B.h[0] + 3) / 4, 3 * B.n);
+            const dim3 block(64, 4), grid(hbhip_grid_x((B.w[0] + 255) / 256), (B.h[0] + 3) / 4, 3 * B.n);
             const int maxv = (1 << in_geo.depth) - 1;
             if (ff_yadif)
             {

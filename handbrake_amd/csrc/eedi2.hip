@@ -3112,7 +3112,7 @@ int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st, ui
     const unsigned gz = 3u * (unsigned)n;
     auto grid4_for = [&](const EediFrame &f, bool whole_pitch) {        // kernels with 4 pixels per thread
         const int w = whole_pitch ? f.stride[0] : f.width[0];
-        return dim3((w + 255) / 256, (f.height[0] + 3) / 4, gz);
+        return dim3(hbhip_grid_x((w + 255) / 256), (f.height[0] + 3) / 4, gz);
     };
     bool post_folded = false;
     auto dir_map = [&](const char *name, const EediFrame &f, const P3 &Pv, int step, int expand, int post = 0) {
@@ -3120,10 +3120,10 @@ int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st, ui
         // filter_dir_map sorts at most masked pixels, there the in-place form is ahead
         // step 2: a thread row per PAIR of rows (the rebuilt one and the copied one)
         const int trows = step == 1 ? f.height[0] : (f.height[0] + 1) / 2;             // thread rows
-        if (!expand) HBHIP_LAUNCH_ON(lc, st, name, k_dir_map4, dim3((f.width[0] + 255) / 256, (trows + 3) / 4, gz), blk, 0, Pv, step, expand);
+        if (!expand) HBHIP_LAUNCH_ON(lc, st, name, k_dir_map4, dim3(hbhip_grid_x((f.width[0] + 255) / 256), (trows + 3) / 4, gz), blk, 0, Pv, step, expand);
         else
         {
-            HBHIP_LAUNCH_ON(lc, st, name, k_dir_map_c, dim3((f.width[0] + 255) / 256, (trows + DC_ROWS - 1) / DC_ROWS, gz), blk, 0, Pv, step, expand, post);
+            HBHIP_LAUNCH_ON(lc, st, name, k_dir_map_c, dim3(hbhip_grid_x((f.width[0] + 255) / 256), (trows + DC_ROWS - 1) / DC_ROWS, gz), blk, 0, Pv, step, expand, post);
             post_folded = post != 0;
         }
     };
@@ -3157,20 +3157,20 @@ int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st, ui
         dense_min = hbhip_dev_int("HBHIP_EEDI2_CALCDIR_DENSE_MIN", CD_W * rows / 2);
         if (rows == 8)
             HBHIP_LAUNCH_ON(lc, st, "eedi2_calc_directions", k_calc_dir_rows<8>,
-                         dim3((srcp.stride[0] + CD_W - 1) / CD_W, (srcp.height[0] + 7) / 8, gz), dim3(CD_W), 0, P,
+                         dim3(hbhip_grid_x((srcp.stride[0] + CD_W - 1) / CD_W), (srcp.height[0] + 7) / 8, gz), dim3(CD_W), 0, P,
                          par_.maximum_search_distance, nt13, nt19, dense_min);
         else if (rows == 6)
             HBHIP_LAUNCH_ON(lc, st, "eedi2_calc_directions", k_calc_dir_rows<6>,
-                         dim3((srcp.stride[0] + CD_W - 1) / CD_W, (srcp.height[0] + 5) / 6, gz), dim3(CD_W), 0, P,
+                         dim3(hbhip_grid_x((srcp.stride[0] + CD_W - 1) / CD_W), (srcp.height[0] + 5) / 6, gz), dim3(CD_W), 0, P,
                          par_.maximum_search_distance, nt13, nt19, dense_min);
         else if (rows == 2)
             HBHIP_LAUNCH_ON(lc, st, "eedi2_calc_directions", k_calc_dir_rows<2>,
-                         dim3((srcp.stride[0] + CD_W - 1) / CD_W, (srcp.height[0] + 1) / 2, gz), dim3(CD_W), 0, P,
+                         dim3(hbhip_grid_x((srcp.stride[0] + CD_W - 1) / CD_W), (srcp.height[0] + 1) / 2, gz), dim3(CD_W), 0, P,
                          par_.maximum_search_distance, nt13, nt19, dense_min);
         else
 #endif
         HBHIP_LAUNCH_ON(lc, st, "eedi2_calc_directions", k_calc_dir_rows<4>,
-                     dim3((srcp.stride[0] + CD_W - 1) / CD_W, (srcp.height[0] + 3) / 4, gz), dim3(CD_W), 0, P,
+                     dim3(hbhip_grid_x((srcp.stride[0] + CD_W - 1) / CD_W), (srcp.height[0] + 3) / 4, gz), dim3(CD_W), 0, P,
                      par_.maximum_search_distance, nt13, nt19, dense_min);
     }
     else
@@ -3205,7 +3205,7 @@ int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st, ui
     bind(P.g, srcp); bind(P.b, dstp); bind(P.a, mskp);
     bind(P.d, dst2p); bind(P.e, tmp2p2); bind(P.f, msk2p); bind(P.c, tmp2p);
     HBHIP_LAUNCH_ON(lc, st, "eedi2_mark_directions_2x", k_mark_2x4,                                      // a thread row per PAIR of full-height rows
-                 dim3((dst2p.stride[0] + 255) / 256, ((dst2p.height[0] + 1) / 2 + 3) / 4, gz), blk, 0, P);
+                 dim3(hbhip_grid_x((dst2p.stride[0] + 255) / 256), ((dst2p.height[0] + 1) / 2 + 3) / 4, gz), blk, 0, P);
     for (int c = 0; c < 3; c++) P.d[c] = P.e[c] = P.f[c] = P.g[c] = nullptr;    // slot d doubles as the dir-map kernels' optional copy target
     bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
     dir_map("eedi2_filter_dir_map_2x", dst2p, P, 2, 0);

@@ -2520,10 +2520,10 @@ int Eedi2Engine16::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st)
         return dim3((w + 63) / 64, (f.height[0] + 3) / 4, z);
     };
     auto grid4 = [&](const EediFrame &f, unsigned z) {                          // four samples per thread, blocks of 64 x 4 threads
-        return dim3((f.width[0] + 255) / 256, (f.height[0] + 3) / 4, z);
+        return dim3(hbhip_grid_x((f.width[0] + 255) / 256), (f.height[0] + 3) / 4, z);
     };
     auto grid4p = [&](const EediFrame &f, unsigned z) {                         // the same with a thread row per PAIR of rows (step 2)
-        return dim3((f.width[0] + 255) / 256, ((f.height[0] + 1) / 2 + 3) / 4, z);
+        return dim3(hbhip_grid_x((f.width[0] + 255) / 256), ((f.height[0] + 1) / 2 + 3) / 4, z);
     };
     Q3 P;
     memset(&P, 0, sizeof(P));
@@ -2552,7 +2552,7 @@ int Eedi2Engine16::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st)
     geom(P, dst2p);
     bind(P.a, mskp); bind(P.b, dstp); bind(P.g, srcp); bind(P.c, tmp2p); bind(P.d, dst2p); bind(P.e, tmp2p2); bind(P.f, msk2p);
     HBHIP_LAUNCH_ON(lc, st, "eedi2_16_mark_directions_2x", q_mark_2x,                                    // a thread row per pair of rows, four samples per thread
-                 dim3((dst2p.stride[0] / 2 + 255) / 256, ((dst2p.height[0] + 1) / 2 + 3) / 4, gz), blk, 0, P, k);
+                 dim3(hbhip_grid_x((dst2p.stride[0] / 2 + 255) / 256), ((dst2p.height[0] + 1) / 2 + 3) / 4, gz), blk, 0, P, k);
     bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
     HBHIP_LAUNCH_ON(lc, st, "eedi2_16_filter_dir_map_2x", q_dir_map4, grid4p(dst2p, gz), blk, 0, P, k, 2, 0);
     bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);

@@ -131,6 +131,8 @@ __device__ __forceinline__ int eedi_xcd_order(int p, int n, int first)       // 
 #endif
 }
 
+// (rotating the tile columns of the chroma planes - 8 tiles per row at 1080p, so each column sits on one XCD - the way
+// hbhip_grid_x() does for the other passes made this launch 3 % slower, 138 -> 143 us: it is a chain of tile latencies)
 __device__ __forceinline__ bool eedi_chain_tile(const MaskChain &C, int &fld, int &pl, int &bx, int &by)
 {
     fld = (int)blockIdx.x / C.group;

@@ -902,9 +902,8 @@ public:
                     B.dst[f][c] = outs[at + f]->plane[c];
                 }
             }
-            // (the same grid with a multiple of 8 workgroups per row of strips - the strips above / below a workgroup then sit
-            // on its own XCD and share its L2 - measured 165 us per 16 frames of 2160p against 121: row-by-row numbering stays)
-            const dim3 grid(((max_w + 3) / 4 + 63) / 64, (max_h + 4 * LS_ROWS - 1) / (4 * LS_ROWS), 3 * nf);
+            // (hbhip_grid_x: never a multiple of 8 workgroups per row of strips - see hbhip_internal.h)
+            const dim3 grid(hbhip_grid_x(((max_w + 3) / 4 + 63) / 64), (max_h + 4 * LS_ROWS - 1) / (4 * LS_ROWS), 3 * nf);
             if (in_geo.bps == 1) HBHIP_LAUNCH(ctx, "lapsharp_3x3", lapsharp3_rows_kernel, grid, dim3(64, 4), 0, B);
             else                 HBHIP_LAUNCH(ctx, "lapsharp_3x3", lapsharp3_rows16_kernel, grid, dim3(64, 4), 0, B, (1 << in_geo.depth) - 1);
             HBHIP_CHECK(ctx, hipGetLastError());
@@ -1010,7 +1009,7 @@ public:
             max_w = std::max(max_w, P.width); max_h = std::max(max_h, P.height);
             for (int f = 0; f < nf; f++) { B.src[f][c] = ins[f]->plane[c]; B.dst[f][c] = outs[f]->plane[c]; }
         }
-        const dim3 grid(((max_w + 3) / 4 + 63) / 64, (max_h + 4 * BR_ROWS - 1) / (4 * BR_ROWS), 3 * nf), block(64, 4);
+        const dim3 grid(hbhip_grid_x(((max_w + 3) / 4 + 63) / 64), (max_h + 4 * BR_ROWS - 1) / (4 * BR_ROWS), 3 * nf), block(64, 4);
         bool copies_done = false;
         for (int st = 1; st <= BR_MAX_STEPS; st++)
         {
