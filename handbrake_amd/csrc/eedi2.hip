@@ -3213,7 +3213,7 @@ int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st, ui
     dir_map("eedi2_expand_dir_map_2x", dst2p, P, 2, 1);
     // (a workgroup per row here: with the copied row of a pair folded into the workgroup of the rebuilt one, as in the dir-map
     // passes, this kernel went from 131 to 163-165 us per launch)
-    const dim3 fg_grid((dst2p.width[0] + FG_W - 1) / FG_W, (dst2p.height[0] + 2 * FG_R - 1) / (2 * FG_R), gz);
+    const dim3 fg_grid(hbhip_grid_x((dst2p.width[0] + FG_W - 1) / FG_W), (dst2p.height[0] + 2 * FG_R - 1) / (2 * FG_R), gz);
     bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
     HBHIP_LAUNCH_ON(lc, st, "eedi2_fill_gaps_2x", k_fill_gaps_b, fg_grid, dim3(FG_T), 0, P);
     bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
@@ -3223,7 +3223,7 @@ int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st, ui
     {
         const int nrows = (dst2p.height[0] - 1) / 2;      // rows y0, y0 + 2, ... < height - 1 for either parity (the heights are even)
         const int nt = par_.noise_threshold;
-        HBHIP_LAUNCH_ON(lc, st, "eedi2_lattice_candidates", k_lattice_cand_q, dim3((dst2p.width[0] + LQ_W - 1) / LQ_W, nrows, gz),
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_lattice_candidates", k_lattice_cand_q, dim3(hbhip_grid_x((dst2p.width[0] + LQ_W - 1) / LQ_W), nrows, gz),
                      dim3(256), 0, P, cand, cand_pitch_, cand_plane_stride_, (nt * 4) & 0xff, (nt * 7) & 0xff, (nt * 8) & 0xff, nt);
         HBHIP_LAUNCH_ON(lc, st, "eedi2_lattice_resolve", k_lattice_resolve, dim3(1, nrows + 1, gz), dim3(LR_T), 0, P,
                      (const uint32_t *)cand, cand_pitch_, cand_plane_stride_);

@@ -127,13 +127,15 @@ static inline bool hbhip_skip_launch(const char *name)
 // workgroups per row pins every column of tiles to one XCD for the whole launch - which is what a 1920-sample row cut into
 // 256-sample tiles gives - and that measured 20 - 25 % slower than letting the columns rotate over the XCDs (lapsharp 1080p:
 // 50.9 us per 16 frames with 8 workgroups per row, 39.9 us with 9; the other way round, 2160p padded from 15 to 16: 121 ->
-// 165 us; profiles/r5x_*, r5y_*).  hbhip_grid_x() adds one workgroup per row when the count is a multiple of 8: every kernel
+// 165 us; profiles/r5x_*, r5y_*).  With an ODD count a column visits all eight XCDs (gcd(count, 8) = 1), with an even one
+// 8 / gcd of them: hbhip_grid_x() makes the count odd by adding a workgroup per row where it is even (2 -> 3 for the
+// 1024-sample tiles of fill_gaps / the lattice candidates: 18 - 22 % faster on dense masks, profiles/r5E_*).  Every kernel
 // launched through it returns at once for a tile that starts beyond its plane (their grids are sized for the widest plane
-// of the launch anyway).
+// of the launch anyway).  HBHIP_GRID_ROTATE: 0 = grids as computed, 1 = only multiples of 8 bumped, 2 = always odd.
 #ifndef HBHIP_GRID_ROTATE
-#define HBHIP_GRID_ROTATE 1
+#define HBHIP_GRID_ROTATE 2
 #endif
-static inline unsigned hbhip_grid_x(unsigned gx) { return (HBHIP_GRID_ROTATE && gx && (gx & 7u) == 0u) ? gx + 1u : gx; }
+static inline unsigned hbhip_grid_x(unsigned gx) { return HBHIP_GRID_ROTATE == 2 ? (gx | 1u) : (HBHIP_GRID_ROTATE && gx && (gx & 7u) == 0u) ? gx + 1u : gx; }
 
 // Launch a kernel on the context's stream; when profiling is on the launch is
 // bracketed by two events whose delta is accumulated under `name`.
