@@ -215,7 +215,7 @@ public:
                 }
             }
             B.trans = trans; B.hflip = hflip; B.vflip = vflip; B.n = nf;
-            HBHIP_LAUNCH(ctx, "rotate", rotate8_batch_kernel, dim3((max_w + 63) / 64, (max_h + 63) / 64, 3 * nf), dim3(64, 4), 0, B);
+            HBHIP_LAUNCH(ctx, "rotate", rotate8_batch_kernel, dim3(hbhip_grid_x((max_w + 63) / 64), (max_h + 63) / 64, 3 * nf), dim3(64, 4), 0, B);
             HBHIP_CHECK(ctx, hipGetLastError());
         }
         return HBHIP_OK;

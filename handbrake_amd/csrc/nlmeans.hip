@@ -212,9 +212,10 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes_kernel(const NlmJo
     const int tile = blockIdx.x - job.tile_start;
     const int tile_y = tile / job.tiles_x;
     int tile_x = tile - tile_y * job.tiles_x;
-    // a multiple of 8 tiles per row (1920 / 120 = 16) would keep every column of tiles on one XCD (workgroups go to the XCDs
-    // round robin): each row of tiles starts one column further on instead (hbhip_internal.h: hbhip_grid_x has the numbers)
-    if (HBHIP_GRID_ROTATE && (job.tiles_x & 7) == 0) { tile_x += tile_y % job.tiles_x; if (tile_x >= job.tiles_x) tile_x -= job.tiles_x; }
+    // an even number of tiles per row (1920 / 120 = 16) would keep every column of tiles on one XCD, or on a few (workgroups
+    // go to the XCDs round robin): each row of tiles starts one column further on instead, so that the tile below a tile is an
+    // odd number of workgroups away (hbhip_internal.h: hbhip_grid_x has the numbers)
+    if (HBHIP_GRID_ROTATE && (job.tiles_x & 1) == 0) { tile_x += tile_y % job.tiles_x; if (tile_x >= job.tiles_x) tile_x -= job.tiles_x; }
     const int tx0 = tile_x * LTW, ty0 = tile_y * TH;
     const int w = job.w, h = job.h;
     const int RH = job.r_half;
@@ -597,9 +598,10 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes16_kernel(const Nlm
     const int tile = blockIdx.x - job.tile_start;
     const int tile_y = tile / job.tiles_x;
     int tile_x = tile - tile_y * job.tiles_x;
-    // a multiple of 8 tiles per row (1920 / 120 = 16) would keep every column of tiles on one XCD (workgroups go to the XCDs
-    // round robin): each row of tiles starts one column further on instead (hbhip_internal.h: hbhip_grid_x has the numbers)
-    if (HBHIP_GRID_ROTATE && (job.tiles_x & 7) == 0) { tile_x += tile_y % job.tiles_x; if (tile_x >= job.tiles_x) tile_x -= job.tiles_x; }
+    // an even number of tiles per row (1920 / 120 = 16) would keep every column of tiles on one XCD, or on a few (workgroups
+    // go to the XCDs round robin): each row of tiles starts one column further on instead, so that the tile below a tile is an
+    // odd number of workgroups away (hbhip_internal.h: hbhip_grid_x has the numbers)
+    if (HBHIP_GRID_ROTATE && (job.tiles_x & 1) == 0) { tile_x += tile_y % job.tiles_x; if (tile_x >= job.tiles_x) tile_x -= job.tiles_x; }
     const int tx0 = tile_x * LTW, ty0 = tile_y * TH;
     const int w = job.w, h = job.h;
     const int RH = job.r_half;
