@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void blur_mix_kernel(BlurArgs3 all)
 // of up to BR_FRAMES frames (blockIdx.z); a plane with amount 0 is copied (unsharp.c:111-115).  Strips away from the top
 // and bottom of the plane take a branch-free form of the same arithmetic (byte dot products), see there.
 #ifndef BR_ROWS_N
-#define BR_ROWS_N 16
+#define BR_ROWS_N 8
 #endif
 constexpr int BR_ROWS = BR_ROWS_N, BR_FRAMES = 16, BR_MAX_STEPS = 4;
 struct BlurPlane8 { int width, height, src_pitch, dst_pitch, steps, scalebits, halfscale, amount, active; uint32_t coef[2 * BR_MAX_STEPS + 1]; };
