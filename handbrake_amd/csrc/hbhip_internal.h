@@ -127,7 +127,9 @@ static inline bool hbhip_skip_launch(const char *name)
 // workgroups per row pins every column of tiles to one XCD for the whole launch - which is what a 1920-sample row cut into
 // 256-sample tiles gives - and that measured 20 - 25 % slower than letting the columns rotate over the XCDs (lapsharp 1080p:
 // 50.9 us per 16 frames with 8 workgroups per row, 39.9 us with 9; the other way round, 2160p padded from 15 to 16: 121 ->
-// 165 us; profiles/r5x_*, r5y_*).  With an ODD count a column visits all eight XCDs (gcd(count, 8) = 1), with an even one
+// 165 us; profiles/r5x_*, r5y_*).  The counters say it is balance, not caching (profiles/r5N_*): the grids are sized for the
+// widest plane and the chroma planes' right-hand tiles return at once, so with column k on XCD k half of the XCDs get no
+// chroma work.  With an ODD count a column visits all eight XCDs (gcd(count, 8) = 1), with an even one
 // 8 / gcd of them: hbhip_grid_x() makes the count odd by adding a workgroup per row where it is even (2 -> 3 for the
 // 1024-sample tiles of fill_gaps / the lattice candidates: 18 - 22 % faster on dense masks, profiles/r5E_*).  Every kernel
 // launched through it returns at once for a tile that starts beyond its plane (their grids are sized for the widest plane
