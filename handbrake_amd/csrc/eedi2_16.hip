@@ -2538,7 +2538,7 @@ int Eedi2Engine16::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st)
     if (par_.maximum_search_distance <= QHALO - 2)
         // 256 columns x 4 rows per block, the mostly listed blocks in the dense form (eedi2.hip: Eedi2Engine::enqueue_passes);
         // its keys hold sums of 12-bit samples at most
-        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_calc_directions", q_calc_dir_rows<4>, dim3((srcp.stride[0] / 2 + QW - 1) / QW, (srcp.height[0] + 3) / 4, gz),
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_calc_directions", q_calc_dir_rows<4>, dim3(hbhip_grid_x((srcp.stride[0] / 2 + QW - 1) / QW), (srcp.height[0] + 3) / 4, gz),
                      dim3(QW), 0, P, k, par_.maximum_search_distance, par_.noise_threshold, k.peak < (1 << 12) ? QW * 4 / 2 : 1 << 30);
     else
         HBHIP_LAUNCH_ON(lc, st, "eedi2_16_calc_directions", q_calc_dir, grid(srcp, true, gz), blk, 0, P, k, par_.maximum_search_distance, par_.noise_threshold);
@@ -2561,12 +2561,12 @@ int Eedi2Engine16::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st)
     {
         const EediFrame &in = pass ? dst2mp : tmp2p, &out = pass ? tmp2p : dst2mp;
         bind(P.a, msk2p); bind(P.b, in); bind(P.c, out);
-        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_fill_gaps_2x", q_fill_gaps_b, dim3((dst2p.width[0] + QF_W - 1) / QF_W, (dst2p.height[0] + 2 * QF_R - 1) / (2 * QF_R), gz), dim3(256), 0, P, k);
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_fill_gaps_2x", q_fill_gaps_b, dim3(hbhip_grid_x((dst2p.width[0] + QF_W - 1) / QF_W), (dst2p.height[0] + 2 * QF_R - 1) / (2 * QF_R), gz), dim3(256), 0, P, k);
     }
     bind(P.a, tmp2p); bind(P.b, dst2p); bind(P.c, tmp2p2);
     {
         const int nrows = (dst2p.height[0] - 1) / 2;                // rows y0, y0 + 2, ... < height - 1 for either parity (even heights)
-        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_lattice_candidates", q_lattice_cand, dim3((dst2p.width[0] + LQ16_W - 1) / LQ16_W, nrows, gz), dim3(256), 0, P, k,
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_lattice_candidates", q_lattice_cand, dim3(hbhip_grid_x((dst2p.width[0] + LQ16_W - 1) / LQ16_W), nrows, gz), dim3(256), 0, P, k,
                      par_.noise_threshold, cand, cand_pitch_, cand_plane_stride_);
         HBHIP_LAUNCH_ON(lc, st, "eedi2_16_lattice_resolve", q_lattice_resolve16, dim3(1, nrows + 1, gz), dim3(LR16_T), 0, P, k,
                      (const unsigned long long *)cand, cand_pitch_, cand_plane_stride_);
