@@ -2575,7 +2575,7 @@ int Eedi2Engine16::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st)
     {
         // (the copy as a store of the filter behind it, as the 8-bit engine has it, cost that launch what the blit costs: 44 us)
         bind(P.a, tmp2p); bind(P.c, tmp2p2);
-        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_blit", q_blit, dim3((dst2p.width[0] + 511) / 512, (dst2p.height[0] + 3) / 4, gz), blk, 0, P);   // eedi2_bit_blit(tmp2p -> tmp2p2)
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_blit", q_blit, dim3(hbhip_grid_x((dst2p.width[0] + 511) / 512), (dst2p.height[0] + 3) / 4, gz), blk, 0, P);   // eedi2_bit_blit(tmp2p -> tmp2p2)
         bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
         HBHIP_LAUNCH_ON(lc, st, "eedi2_16_filter_dir_map_2x", q_dir_map4, grid4p(dst2p, gz), blk, 0, P, k, 2, 0);
         // + eedi2_post_process (new map = what the pass writes, old map tmp2p2, picture dst2p): folded into the pass
