@@ -598,7 +598,7 @@ public:
                     HBHIP_LAUNCH(ctx, "hqdn3d_h", (hqdn3d_h_batch_kernel<PIX, SH>), dim3((max_h + HB_ROWS * H_GROUPS - 1) / (HB_ROWS * H_GROUPS), 3, k), dim3(256), 0, B, gh); \
                     HBHIP_LAUNCH(ctx, "hqdn3d_v", (hqdn3d_v_batch_kernel<PIX, SH>), dim3((max_w + 63) / 64, 3, k), dim3(64 * gv.seg), 0, B, gv); \
                 } \
-                HBHIP_LAUNCH(ctx, "hqdn3d_t", (hqdn3d_tn_kernel<PIX, SH>), dim3((max_w + 1023) / 1024, max_h, 3), dim3(256), 0, B); \
+                HBHIP_LAUNCH(ctx, "hqdn3d_t", (hqdn3d_tn_kernel<PIX, SH>), dim3(hbhip_grid_x((max_w + 1023) / 1024), max_h, 3), dim3(256), 0, B); \
             } while (0)
             if (in_geo.depth == 8)       HQ_GO_N(uint8_t, 8);
             else if (in_geo.depth == 10) HQ_GO_N(uint16_t, 6);
