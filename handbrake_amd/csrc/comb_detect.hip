@@ -641,6 +641,14 @@ public:
         HBHIP_CHECK(ctx, hipMemcpyAsync(d_lut, lut, sizeof(float) * entries, hipMemcpyHostToDevice, ctx->stream));
         HBHIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         lut_ready = true;
+        if (k.lut_len == 256 && (par.mode & 1))
+        {
+            // the 8-bit kernel classifies through integer thresholds derived from the table (build_threshold_tables):
+            // a new table means new thresholds, or the float form when the new one is not monotone
+            memcpy(par.gamma_lut, lut, sizeof(float) * 256);
+            if (d_tab) { (void)hipFree(d_tab); d_tab = nullptr; }
+            return build_threshold_tables();
+        }
         return HBHIP_OK;
     }
 

@@ -798,6 +798,15 @@ void hbhip_frame_release(hbhip_frame *fr)
     fr->ctx->frame_pool.push_back(fr);        // reuse is ordered by that event (uploads) or by the stream itself
 }
 
+// The writability test of a device picture (fifo.c:624-639 asks av_buffer_is_writable the same thing): a holder that
+// sees 1 is the only one, and nobody else can take a reference except through it.
+int hbhip_frame_refs(hbhip_frame *fr)
+{
+    if (!fr) return 0;
+    std::lock_guard<std::mutex> lk(fr->ctx->frame_lock);
+    return fr->refs;
+}
+
 int hbhip_frame_describe(hbhip_frame *fr, hbhip_dev_frame *out, int *width, int *height)
 {
     if (!fr || !out) return HBHIP_ERR_ARG;

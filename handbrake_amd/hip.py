@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "hbhip_ctx_profile_enable", "hbhip_ctx_profile_reset",
     "hbhip_ctx_profile_count", "hbhip_ctx_profile_get", "hbhip_ctx_mark", "hbhip_ctx_elapsed_ms",
     "hbhip_dev_alloc", "hbhip_dev_free", "hbhip_dev_upload", "hbhip_dev_download",
-    "hbhip_frame_alloc", "hbhip_frame_retain", "hbhip_frame_release", "hbhip_frame_describe", "hbhip_frame_copy",
+    "hbhip_frame_alloc", "hbhip_frame_retain", "hbhip_frame_release", "hbhip_frame_refs", "hbhip_frame_describe", "hbhip_frame_copy",
     "hbhip_frame_upload", "hbhip_frame_download", "hbhip_frame_mark_ready", "hbhip_frame_download_async", "hbhip_frame_download_wait",
     "hbhip_filter_push", "hbhip_filter_push_dev", "hbhip_filter_pull", "hbhip_filter_pull_dev",
     "hbhip_filter_process_dev", "hbhip_filter_submit_async", "hbhip_filter_wait", "hbhip_filter_inflight", "hbhip_filter_flush", "hbhip_filter_pending", "hbhip_filter_defer", "hbhip_filter_kick", "hbhip_filter_destroy",
@@ -371,7 +371,7 @@ class DecombDevice:
     EEDI2 scratch buffers; the hb_filter_object_t path is hb_filter_decomb_hip)."""
 
     def __init__(self, ctx: Ctx, width, height, mode=8, parity=-1, magnitude=10, variance=20, laplacian=20,
-                 dilation=4, erosion=2, noise=50, search=24, postproc=1, depth=8):
+                 dilation=4, erosion=2, noise=50, search=24, postproc=1, depth=8, lcw=1, lch=1):
         L = lib()
         L.hbhip_decomb_create.argtypes = [C.c_void_p, C.POINTER(DecombParams)] + [C.c_int] * 5 + [C.POINTER(C.c_void_p)]
         L.hbhip_decomb_push.argtypes = [C.c_void_p, C.POINTER(HostFrame), C.c_int64, C.c_int, C.c_int]
@@ -379,8 +379,9 @@ class DecombDevice:
                                                     C.POINTER(C.c_int), C.POINTER(C.c_int)]
         par = DecombParams(mode, parity, magnitude, variance, laplacian, dilation, erosion, noise, search, postproc)
         h = C.c_void_p()
-        check(L.hbhip_decomb_create(ctx.h, C.byref(par), width, height, depth, 1, 1, C.byref(h)), ctx.h, "decomb_create")
+        check(L.hbhip_decomb_create(ctx.h, C.byref(par), width, height, depth, lcw, lch, C.byref(h)), ctx.h, "decomb_create")
         self.ctx, self.h, self.w, self.hgt, self.depth = ctx, h, width, height, depth
+        self.lcw, self.lch = lcw, lch
         self.tag = 0
 
     def push(self, planes, flags=0x0008, combed=2):
@@ -394,7 +395,7 @@ class DecombDevice:
         import numpy as np
         if lib().hbhip_filter_pending(self.h) <= 0:
             return None
-        cw, ch = (self.w + 1) // 2, (self.hgt + 1) // 2
+        cw, ch = -(-self.w >> self.lcw), -(-self.hgt >> self.lch)
         dt = np.uint8 if self.depth == 8 else np.uint16
         out = [np.zeros((self.hgt, self.w), dt), np.zeros((ch, cw), dt), np.zeros((ch, cw), dt)]
         fr = host_frame(out)

@@ -142,6 +142,15 @@ static int crop_scale_hip_init(hb_filter_object_t *filter, hb_filter_init_t *ini
      * neither library is in the reference tree).  The swscale form covers 8-bit planes (hScale8To15 / yuv2planeX_8) and
      * 10 / 12-bit planes (hScale16To15 / yuv2planeX_10, _12). */
     const int odd = (cropped_width & 1) || (cropped_height & 1) || (p.width & 1) || (p.height & 1);
+    /* The swscale restatement has never met a real libswscale (vf_scale's chroma positions from chroma_location, its
+     * field handling and its cascaded contexts for large ratios are what could differ silently), and unlike the zimg form
+     * it has no second implementation to be held against: it is OPT-IN (HBHIP_SWSCALE=1).  Without it an odd size
+     * declines here and the job keeps the reference's CPU filter (hb_hip_filter_init_failed). */
+    if (odd)
+    {
+        const char *sws = getenv("HBHIP_SWSCALE");
+        if (sws == NULL || atoi(sws) == 0) return alias_fail(filter, HBHIP_ERR_UNSUPPORTED);
+    }
 
     hbhip_ctx *ctx = hbhip_host_ctx_for(init);
     if (ctx == NULL) return alias_fail(filter, HBHIP_ERR_NODEVICE);

@@ -45,7 +45,10 @@ static int blend_hip_init(hb_blend_object_t *object, int in_width, int in_height
     }
     const AVPixFmtDescriptor *in_desc = av_pix_fmt_desc_get(in_pix_fmt);
     const AVPixFmtDescriptor *ov_desc = av_pix_fmt_desc_get(overlay_pix_fmt);
-    int rc = in_desc == NULL || ov_desc == NULL || hbhip_device_count() <= 0 ? HBHIP_ERR_NODEVICE : HBHIP_OK;
+    /* a GPU that cannot give a context (busy, out of memory) is found here, where rendersub can still take hb_blend
+     * (rendersub.c:1129-1161), not at the first frame in the middle of an encode */
+    int rc = in_desc == NULL || ov_desc == NULL || hbhip_device_count() <= 0 || hbhip_host_ctx() == NULL
+             ? HBHIP_ERR_NODEVICE : HBHIP_OK;
     if (rc == HBHIP_OK && av_pix_fmt_count_planes(in_pix_fmt) != 3)
         rc = HBHIP_ERR_UNSUPPORTED;                     /* NV12 / P010: blend8onbi*, not built */
     if (rc == HBHIP_OK)
@@ -108,9 +111,38 @@ static hb_buffer_t *blend_hip_work(hb_blend_object_t *object, hb_buffer_t *in, h
         hbhip_frame *dev_frame = hbhip_host_frame_of(in);
         if (dev_frame != NULL)
         {
-            hbhip_dev_frame d;
-            hbhip_frame_describe(dev_frame, &d, NULL, NULL);
-            rc = hbhip_blend_apply_dev(pv->dev, &d);
+            /* blend.c:861-865 for a picture in HBM: a frame somebody else holds too (vfr's CFR duplicates are
+             * hb_buffer_shallow_dup's of one hbhip_frame, vfr.c:393-411) is not writable - composite on a copy of it,
+             * or the overlay lands twice on the shared picture */
+            if (hbhip_frame_refs(dev_frame) > 1)
+            {
+                hbhip_frame *copy = NULL;
+                int fw = 0, fh = 0;
+                hbhip_dev_frame d0;
+                hbhip_frame_describe(dev_frame, &d0, &fw, &fh);
+                rc = hbhip_frame_alloc(hbhip_frame_context(dev_frame), fw, fh, pv->depth, pv->lcw, pv->lch, &copy);
+                if (rc == HBHIP_OK) rc = hbhip_frame_copy(copy, dev_frame);
+                if (rc == HBHIP_OK && (out = hb_buffer_dup(in)) == NULL) rc = HBHIP_ERR_NOMEM;
+                if (rc != HBHIP_OK)
+                {
+                    hbhip_frame_release(copy);
+                    out = in;
+                }
+                else
+                {
+                    hbhip_frame_release(dev_frame);            /* the reference hb_buffer_dup took for `out` */
+                    out->storage = copy;                       /* `out` owns the copy's one reference */
+                    hb_buffer_close(&in);
+                    dev_frame = copy;
+                }
+            }
+            if (rc == HBHIP_OK)
+            {
+                hbhip_dev_frame d;
+                hbhip_frame_describe(dev_frame, &d, NULL, NULL);
+                rc = hbhip_blend_apply_dev(pv->dev, &d);
+                if (rc == HBHIP_OK) rc = hbhip_frame_mark_ready(dev_frame);    /* complete behind the compositor now */
+            }
         }
         else
         {

@@ -15,6 +15,7 @@
  * the environment, else 0) - libhb/hbhip_registry.c. */
 int        hbhip_host_default_device(void);
 int        hbhip_host_device_for(const hb_filter_init_t *init);
+int        hbhip_host_job_index_is_hip(const hb_job_t *job);     /* hw_device_index names a HIP device (no other vendor's hw path in the job) */
 hbhip_ctx *hbhip_host_ctx_on(int device);
 hbhip_ctx *hbhip_host_ctx_for(const hb_filter_init_t *init);     /* what a drop-in's init() uses */
 hbhip_ctx *hbhip_host_ctx(void);                                 /* the process default's context */

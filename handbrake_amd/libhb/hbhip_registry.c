@@ -32,9 +32,26 @@ int hbhip_host_default_device(void)
     return device < 0 ? 0 : device;
 }
 
+/* hw_device_index is an ADAPTER index owned by whichever hardware path the job uses: QSV sets it to a DX11 / VA adapter
+ * (qsv_common.c:2238-2244, also when only the encoder is QSV and hw_pix_fmt stays NONE), NVDEC / NVENC to a CUDA ordinal
+ * (hwaccel.c:230-257).  Only when no other vendor's decoder or encoder is in the job - software codecs, or AMD's own
+ * AMF decoder / VCE encoders, whose adapter is this GPU - does the number name a HIP device. */
+int hbhip_host_job_index_is_hip(const hb_job_t *job)
+{
+    if (job == NULL || job->hw_device_index < 0) return 0;
+    if (job->hw_decode & (HB_DECODE_QSV | HB_DECODE_NVDEC | HB_DECODE_VIDEOTOOLBOX | HB_DECODE_MF)) return 0;
+    if (job->vcodec & (HB_VCODEC_QSV_MASK | HB_VCODEC_VT_MASK)) return 0;
+    if (job->vcodec & HB_VCODEC_FFMPEG_MASK)
+    {
+        const int n = job->vcodec & 0xff;                     /* common.h:747-756: 0x20-0x22 Media Foundation, 0x30-0x35 NVENC */
+        if ((n >= 0x20 && n <= 0x22) || (n >= 0x30 && n <= 0x35)) return 0;
+    }
+    return 1;
+}
+
 int hbhip_host_device_for(const hb_filter_init_t *init)
 {
-    if (init != NULL && init->job != NULL && init->job->hw_device_index >= 0)
+    if (init != NULL && hbhip_host_job_index_is_hip(init->job))
         return init->job->hw_device_index;
     return hbhip_host_default_device();
 }

@@ -33,12 +33,17 @@ int hb_hip_filter_is_hip(const hb_filter_object_t *f)
     return p != NULL && p->init == f->init;
 }
 
+static int force_swap(void)
+{
+    const char *force = getenv("HBHIP_FORCE_SWAP");           /* tests: swap even without a device, so that */
+    return force != NULL && atoi(force) != 0;                 /* every init fails and the fallback is exercised */
+}
+
 static int hip_enabled(void)
 {
     const char *off = getenv("HBHIP_DISABLE");
     if (off != NULL && atoi(off) != 0) return 0;
-    const char *force = getenv("HBHIP_FORCE_SWAP");           /* tests: swap even without a device, so that */
-    if (force != NULL && atoi(force) != 0) return 1;          /* every init fails and the fallback is exercised */
+    if (force_swap()) return 1;
     return hbhip_device_count() > 0;
 }
 
@@ -107,7 +112,7 @@ void hb_hip_setup_hw_filters(hb_job_t *job)
 {
     if (job == NULL || job->list_filter == NULL || !hip_enabled()) return;
     if (job->hw_pix_fmt != AV_PIX_FMT_NONE) return;           /* another hw pipeline owns the frames */
-    if (getenv("HBHIP_FORCE_SWAP") == NULL && job->hw_device_index >= hbhip_device_count())
+    if (!force_swap() && hbhip_host_job_index_is_hip(job) && job->hw_device_index >= hbhip_device_count())
     {
         /* the job names an adapter (common.h:991, hb_json.c "AdapterIndex") this process has no GPU for */
         hb_log("hbhip: job asks for GPU %d, %d present: keeping the CPU filters", job->hw_device_index, hbhip_device_count());

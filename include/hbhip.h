@@ -73,11 +73,11 @@ void        hbhip_ctx_destroy(hbhip_ctx *ctx);
 int         hbhip_ctx_sync(hbhip_ctx *ctx);           /* hipStreamSynchronize */
 const char *hbhip_ctx_last_error(hbhip_ctx *ctx);     /* text of the last HIP failure */
 int         hbhip_ctx_device_name(hbhip_ctx *ctx, char *buf, int len);
-int         hbhip_ctx_device_index(hbhip_ctx *ctx);
+int         hbhip_ctx_device_index(hbhip_ctx *ctx);   /* the `device` it was created on; < 0 on a NULL context */
 /* The on-box HBM ceiling: a float4 copy kernel over two buffers of `bytes` each (take them well past the 256 MB Infinity
  * Cache), best of `iters` timed passes with HIP events; *gbps = (read + write) bytes / time.  bench.py reports roofline
  * fractions against this as well as against the nominal 8 TB/s. */
-int         hbhip_ctx_copy_bandwidth(hbhip_ctx *ctx, size_t bytes, int iters, double *gbps);   /* the `device` it was created on; < 0 on a NULL context */
+int         hbhip_ctx_copy_bandwidth(hbhip_ctx *ctx, size_t bytes, int iters, double *gbps);
 
 /* Per-kernel timing with HIP events on the context's stream (off by default).
  * When enabled every kernel launch is bracketed by two events; stats are read
@@ -114,6 +114,7 @@ int  hbhip_frame_alloc(hbhip_ctx *ctx, int width, int height, int depth,
                        int log2_chroma_w, int log2_chroma_h, hbhip_frame **out);
 void hbhip_frame_retain(hbhip_frame *fr);
 void hbhip_frame_release(hbhip_frame *fr);            /* back to the pool at refcount 0 */
+int  hbhip_frame_refs(hbhip_frame *fr);               /* holders right now; 1 = the caller is the only one (it may write in place) */
 int  hbhip_frame_describe(hbhip_frame *fr, hbhip_dev_frame *out, int *width, int *height);
 hbhip_ctx *hbhip_frame_context(hbhip_frame *fr);      /* the context (device, stream) whose pool the frame belongs to */
 int  hbhip_frame_copy(hbhip_frame *dst, hbhip_frame *src);                  /* same geometry; stream-ordered D2D */

@@ -527,7 +527,18 @@ struct hb_job_s                                                     /* the field
     int          crop[4];                                           /* rendersub keeps subtitles inside the picture that is left */
     hb_title_t  *title;
     hb_list_t   *list_subtitle, *list_attachment;
+    int          vcodec;                                            /* common.h:707-770: whose encoder */
+    int          hw_decode;                                         /* common.h:990, 1433-1440: whose decoder */
 };
+/* whose hardware a job's decoder / encoder is (common.h:715-756, 1433-1440): hw_device_index is THEIR adapter index then */
+#define HB_VCODEC_VT_MASK            0x00080000
+#define HB_VCODEC_QSV_MASK           0x00040000
+#define HB_VCODEC_FFMPEG_MASK        0x00010000
+#define HB_DECODE_QSV                0x02
+#define HB_DECODE_NVDEC              0x04
+#define HB_DECODE_VIDEOTOOLBOX       0x08
+#define HB_DECODE_MF                 0x10
+#define HB_DECODE_AMFDEC             0x20
 hb_filter_object_t *hb_filter_get(int filter_id);                   /* the registered CPU prototype, or NULL */
 hb_filter_object_t *hb_filter_init(int filter_id);                  /* a copy of it, ready for settings */
 hb_filter_object_t *hb_filter_copy(hb_filter_object_t *);

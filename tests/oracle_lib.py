@@ -377,6 +377,11 @@ class RefEedi2:
 
     def __init__(self, width, height, settings="mode=8"):
         lib = ref()
+        self._bind(lib)
+        self.h = lib.hbref_eedi2_new(width, height, settings.encode())
+        assert self.h
+
+    def _bind(self, lib):
         lib.hbref_eedi2_new.restype = C.c_void_p
         lib.hbref_eedi2_new.argtypes = [C.c_int, C.c_int, C.c_char_p]
         lib.hbref_eedi2_run.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_int), C.c_int]
@@ -385,8 +390,6 @@ class RefEedi2:
         lib.hbref_eedi2_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         lib.hbref_eedi2_free.argtypes = [C.c_void_p]
         self.lib = lib
-        self.h = lib.hbref_eedi2_new(width, height, settings.encode())
-        assert self.h
 
     def run(self, frame, tff, serial=False):
         """serial: the three planes in order on this thread (needed for postproc 2/3, where the
@@ -479,7 +482,10 @@ def orc_grayscale_frame(frame, cb=0.0, cr=0.0, size=1.0, high=0.0, depth=8):
     return dst, np.full_like(u, 1 << (depth - 1)), np.full_like(v, 1 << (depth - 1))
 
 
-def orc_cropscale_frame(frame, width, height, top=0, bottom=0, left=0, right=0, depth=8, arithmetic=None):
+SUBSAMPLING = {"2x2": (1, 1), "2x1": (1, 0), "1x1": (0, 0)}      # log2 (chroma_w, chroma_h), as hbrt.PIX_FMT names them
+
+
+def orc_cropscale_frame(frame, width, height, top=0, bottom=0, left=0, right=0, depth=8, arithmetic=None, sub="2x2"):
     """crop + Lanczos scale of a frame.  arithmetic: "fixed" = zimg's 16-bit fixed point (orc_cropscale_plane_fx at 8
     bits, orc_cropscale_plane_fx16 at 10 / 12: the form the HIP scaler runs and is compared with bit for bit; the
     default for even sizes), "double" = the float64 form (the independent check of the fixed-point forms), "sws" =
@@ -503,7 +509,9 @@ def orc_cropscale_frame(frame, width, height, top=0, bottom=0, left=0, right=0, 
             if c == 0:
                 cx, cy, pw, ph, dw, dh = left, top, cw, ch, width, height
             else:
-                cx, cy, pw, ph, dw, dh = left >> 1, top >> 1, (cw + 1) // 2, (ch + 1) // 2, (width + 1) // 2, (height + 1) // 2
+                lw, lh = SUBSAMPLING[sub]
+                cx, cy, pw, ph = left >> lw, top >> lh, -(-cw >> lw), -(-ch >> lh)
+                dw, dh = -(-width >> lw), -(-height >> lh)
             dst = np.zeros((dh, dw), p.dtype)
             fn(p.ctypes.data, p.strides[0], cx, cy, pw, ph, dst.ctypes.data, dst.strides[0], dw, dh, int(c > 0), *extra)
             out.append(dst)
@@ -528,9 +536,10 @@ def orc_cropscale_frame(frame, width, height, top=0, bottom=0, left=0, right=0, 
         if c == 0:
             cx, cy, pw, ph, dw, dh, sx = left, top, cw, ch, width, height, 0.0
         else:
-            cx, cy, pw, ph = left >> 1, top >> 1, (cw + 1) // 2, (ch + 1) // 2
-            dw, dh = (width + 1) // 2, (height + 1) // 2
-            sx = 0.25 * (1.0 - cw / width)
+            lw, lh = SUBSAMPLING[sub]
+            cx, cy, pw, ph = left >> lw, top >> lh, -(-cw >> lw), -(-ch >> lh)
+            dw, dh = -(-width >> lw), -(-height >> lh)
+            sx = 0.25 * (1.0 - cw / width) if lw else 0.0       # left-sited chroma: only where it is subsampled horizontally
         dst = np.zeros((dh, dw), p.dtype)
         args = [p.ctypes.data, p.strides[0], cx, cy, pw, ph, dst.ctypes.data, dst.strides[0], dw, dh, sx, 0.0]
         if arithmetic != "fixed" or depth != 8:
@@ -616,24 +625,25 @@ def orc_motion_metric(luma_a, luma_b, depth=8) -> float:
     return fn(a.ctypes.data, a.strides[0], b.ctypes.data, b.strides[0], w, h, depth)
 
 
-def orc_pad_frame(frame, width, height, x, y, rgb=0, matrix=1, full_range=False, depth=8):
-    """vf_pad as pad.c configures it: x, y already resolved (>= 0); rounds them to the 4:2:0 grid."""
+def orc_pad_frame(frame, width, height, x, y, rgb=0, matrix=1, full_range=False, depth=8, sub="2x2"):
+    """vf_pad as pad.c configures it: x, y already resolved (>= 0); rounds them to the chroma grid."""
     L = oracle()
     L.orc_pad_color.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.orc_pad_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                 C.c_int, C.c_int, C.c_int, C.c_int]
     fill = (C.c_int * 3)()
     L.orc_pad_color(rgb, matrix, int(full_range), depth, fill)
-    x &= ~1
-    y &= ~1
+    lw, lh = SUBSAMPLING[sub]
+    x &= ~((1 << lw) - 1)
+    y &= ~((1 << lh) - 1)
     out = []
     for c, p in enumerate(frame):
         p = np.ascontiguousarray(p)
         sh, sw = p.shape
-        dw, dh = (width, height) if c == 0 else ((width + 1) // 2, (height + 1) // 2)
+        dw, dh = (width, height) if c == 0 else (-(-width >> lw), -(-height >> lh))
         dst = np.zeros((dh, dw), p.dtype)
         L.orc_pad_plane(p.ctypes.data, sw, sh, p.strides[0], dst.ctypes.data, dw, dh, dst.strides[0],
-                        x if c == 0 else x >> 1, y if c == 0 else y >> 1, fill[c], p.itemsize)
+                        x if c == 0 else x >> lw, y if c == 0 else y >> lh, fill[c], p.itemsize)
         out.append(dst)
     return tuple(out)
 
@@ -707,6 +717,35 @@ class OrcEedi2_16:
         if self.e:
             self.lib.orc_eedi2_16_free(self.e)
             self.e = None
+
+
+class RefEedi2Fmt:
+    """The reference's EEDI2 on a frame of ANY planar format the reference accepts (hbffmpeg.c:893-909: 4:2:0 / 4:2:2 /
+    4:4:4 at 8 / 10 / 12 bits): its decomb object initialised with that pix_fmt, eedi2_planer_8 / _16 run on the frame.
+    plane(buffer, c) is (height, stride in samples) of the scratch frame, as for the other Eedi2 classes."""
+
+    def __init__(self, width, height, pix_fmt, depth, settings="mode=8"):
+        self.depth = depth
+        self.r8 = self.r16 = None
+        if depth == 8:
+            lib = ref()
+            lib.hbref_eedi2_new_fmt.restype = C.c_void_p
+            lib.hbref_eedi2_new_fmt.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int]
+            self.r8 = RefEedi2.__new__(RefEedi2)
+            RefEedi2._bind(self.r8, lib)
+            self.r8.h = lib.hbref_eedi2_new_fmt(width, height, settings.encode(), pix_fmt)
+            assert self.r8.h
+        else:
+            self.r16 = RefEedi2_16(width, height, pix_fmt, settings)
+
+    def run(self, frame, tff, serial=False):
+        (self.r8 or self.r16).run(frame, tff, serial=serial)
+
+    def plane(self, buffer, plane):
+        return (self.r8 or self.r16).plane(buffer, plane)
+
+    def close(self):
+        (self.r8 or self.r16).close()
 
 
 class RefEedi2_16:

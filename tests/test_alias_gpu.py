@@ -55,10 +55,11 @@ def test_cropscale(built, w, h, ow, oh, crop):
 @pytest.mark.parametrize("w,h,ow,oh,crop", [(321, 181, 641, 361, (0, 0, 0, 0)), (638, 362, 851, 481, (2, 4, 6, 8)),
                                             (641, 361, 321, 181, (0, 0, 0, 0)), (640, 360, 641, 360, (0, 0, 0, 0)),
                                             (1919, 1079, 1279, 719, (0, 0, 0, 0)), (322, 182, 321, 181, (0, 1, 1, 0))])
-def test_cropscale_odd_sizes_take_the_swscale_form(built, w, h, ow, oh, crop):
-    """An odd width or height on either side: the reference builds `scale=flags=lanczos+accurate_rnd` instead of zscale
+def test_cropscale_odd_sizes_take_the_swscale_form(built, monkeypatch, w, h, ow, oh, crop):
+    """(Opt-in: HBHIP_SWSCALE=1; test_cropscale_odd_sizes_decline_by_default is the default.)  An odd width or height on either side: the reference builds `scale=flags=lanczos+accurate_rnd` instead of zscale
     (cropscale.c:159-165, hbffmpeg.c:888-892) - libswscale's arithmetic.  The drop-in follows: bit-exact against the
     restatement of libswscale's 8-bit path (oracle/alias_oracle.c: orc_cropscale_plane_sws; parity unpinned like zimg's)."""
+    monkeypatch.setenv("HBHIP_SWSCALE", "1")
     frames = synth.stream("progressive", w, h, 2 if w < 1000 else 1) + synth.stream("random", w, h, 1)
     t, b, l, r = crop
     st = f"width={ow}:height={oh}:crop-top={t}:crop-bottom={b}:crop-left={l}:crop-right={r}"
@@ -68,12 +69,24 @@ def test_cropscale_odd_sizes_take_the_swscale_form(built, w, h, ow, oh, crop):
     assert (got[0].width, got[0].height) == (ow, oh)
 
 
+def test_cropscale_odd_sizes_decline_by_default(built, monkeypatch):
+    """Without HBHIP_SWSCALE=1 an odd size is not taken: init() fails, and hb_hip_filter_init_failed puts the reference's
+    CPU filter back (the swscale restatement has never been held against a real libswscale)."""
+    monkeypatch.delenv("HBHIP_SWSCALE", raising=False)
+    with pytest.raises(RuntimeError):
+        hbrt.Chain(hip.filters(), [("hb_filter_crop_scale_hip", "width=641:height=361")], 321, 181)
+    with pytest.raises(RuntimeError):
+        hbrt.Chain(hip.filters(), [("hb_filter_crop_scale_hip", "width=640:height=360")], 641, 360)
+    hbrt.Chain(hip.filters(), [("hb_filter_crop_scale_hip", "width=640:height=360")], 320, 180).close()
+
+
 @pytest.mark.parametrize("depth", [10, 12])
 @pytest.mark.parametrize("w,h,ow,oh,crop", [(321, 181, 641, 361, (0, 0, 0, 0)), (638, 362, 851, 481, (2, 4, 6, 8)),
                                             (641, 361, 321, 181, (0, 0, 0, 0)), (640, 360, 641, 360, (0, 0, 0, 0))])
-def test_cropscale_odd_sizes_at_10_and_12_bits(built, depth, w, h, ow, oh, crop):
+def test_cropscale_odd_sizes_at_10_and_12_bits(built, monkeypatch, depth, w, h, ow, oh, crop):
     """The same branch on 16-bit planes: libswscale's hScale16To15_c + yuv2planeX_10 / _12 as restated in
     oracle/alias_oracle.c: orc_cropscale_plane_sws16 (parity unpinned), bit for bit."""
+    monkeypatch.setenv("HBHIP_SWSCALE", "1")
     frames = synth.stream("progressive", w, h, 2, depth=depth) + synth.stream("random", w, h, 1, depth=depth)
     t, b, l, r = crop
     st = f"width={ow}:height={oh}:crop-top={t}:crop-bottom={b}:crop-left={l}:crop-right={r}"

@@ -78,7 +78,7 @@ def test_unregistered_id_is_dropped_like_work_c_does(registered):
 
 
 # ---- which GPU a job runs on: job->hw_device_index (common.h:991), libhb/hbhip_registry.c -----------------------
-def _device_for(job_index, monkeypatch, env=None):
+def _device_for(job_index, monkeypatch, env=None, vcodec=0, hw_decode=0):
     """hbhip_host_device_for(init) for an init whose job carries hw_device_index = job_index (None: init->job NULL)"""
     import ctypes as C
     flt = hip.filters()
@@ -91,10 +91,14 @@ def _device_for(job_index, monkeypatch, env=None):
     if job_index is None:
         return flt.hbhip_host_device_for(None)
     # hb_job_t (include/hbhip_libhb.h): list_filter*, hw_pix_fmt, input_pix_fmt, hw_device_index, h*, done
+    #                                  ..., crop[4], title*, list_subtitle*, list_attachment*, vcodec, hw_decode
     class Job(C.Structure):
         _fields_ = [("list_filter", C.c_void_p), ("hw_pix_fmt", C.c_int), ("input_pix_fmt", C.c_int),
-                    ("hw_device_index", C.c_int), ("h", C.c_void_p), ("done", C.c_int)]
+                    ("hw_device_index", C.c_int), ("h", C.c_void_p), ("done", C.c_int), ("crop", C.c_int * 4),
+                    ("title", C.c_void_p), ("list_subtitle", C.c_void_p), ("list_attachment", C.c_void_p),
+                    ("vcodec", C.c_int), ("hw_decode", C.c_int)]
     job = Job(None, -1, 0, job_index, None, 0)
+    job.vcodec, job.hw_decode = vcodec, hw_decode
     init = (C.c_void_p * 32)()                     # hb_filter_init_t starts with hb_job_t *job
     init[0] = C.addressof(job)
     return flt.hbhip_host_device_for(init)
@@ -107,6 +111,25 @@ def test_device_of_a_job_is_its_adapter_index_else_the_process_default(built, mo
     assert _device_for(5, monkeypatch, env=3) == 5                 # the job's own adapter wins
     assert _device_for(0, monkeypatch, env=3) == 0
     assert _device_for(2, monkeypatch) == 2
+
+
+def test_another_vendors_adapter_index_is_not_a_hip_device(built, monkeypatch):
+    """hw_device_index belongs to whichever hardware path the job uses (QSV: a DX11 / VA adapter,
+    qsv_common.c:2238-2244; NVDEC / NVENC: a CUDA ordinal) - it names a HIP device only when no other vendor's decoder or
+    encoder is in the job (software codecs, AMF / VCE)."""
+    QSV_H264 = 0x00040000 | 0x20000000 | 0x60
+    NVENC_H265 = 0x31 | 0x00010000 | 0x10000000
+    MF_H264 = 0x20 | 0x00010000 | 0x20000000
+    VCE_H265 = 0x0E | 0x00010000 | 0x10000000
+    X264 = 0x02 | 0x00400000 | 0x20000000
+    assert _device_for(2, monkeypatch, env=1, vcodec=QSV_H264) == 1            # QSV's adapter: the process default instead
+    assert _device_for(2, monkeypatch, env=1, vcodec=NVENC_H265) == 1
+    assert _device_for(2, monkeypatch, env=1, vcodec=MF_H264) == 1
+    assert _device_for(2, monkeypatch, env=1, vcodec=X264, hw_decode=0x04) == 1     # NVDEC
+    assert _device_for(2, monkeypatch, env=1, vcodec=X264, hw_decode=0x02) == 1     # QSV decode
+    assert _device_for(2, monkeypatch, env=1, vcodec=VCE_H265) == 2            # AMD's encoder: the same adapter
+    assert _device_for(2, monkeypatch, env=1, vcodec=X264, hw_decode=0x20) == 2     # AMF decode
+    assert _device_for(2, monkeypatch, env=1, vcodec=X264, hw_decode=0x01) == 2     # software
 
 
 def test_contexts_are_kept_per_device_and_absent_gpus_give_none(built, monkeypatch):
