@@ -513,7 +513,8 @@ def orc_cropscale_frame(frame, width, height, top=0, bottom=0, left=0, right=0, 
                 cx, cy, pw, ph = left >> lw, top >> lh, -(-cw >> lw), -(-ch >> lh)
                 dw, dh = -(-width >> lw), -(-height >> lh)
             dst = np.zeros((dh, dw), p.dtype)
-            fn(p.ctypes.data, p.strides[0], cx, cy, pw, ph, dst.ctypes.data, dst.strides[0], dw, dh, int(c > 0), *extra)
+            fn(p.ctypes.data, p.strides[0], cx, cy, pw, ph, dst.ctypes.data, dst.strides[0], dw, dh,
+               int(c > 0 and SUBSAMPLING[sub][0] > 0), *extra)      # chroma_h: a horizontally subsampled, left-sited plane
             out.append(dst)
         return tuple(out)
     if arithmetic == "fixed" and depth == 8:

@@ -267,7 +267,11 @@ def test_device_resident_job_on_yuv422p10(built):
     LAP = "y-strength=0.2:y-kernel=isolap:cb-strength=0.2:cb-kernel=isolap"
     fmt = hbrt.PIX_FMT[("2x1", 10)]
     hip.filters()
+    REF = {**REF, VFR: "hb_filter_vfr"}                        # + the reference's own vfr.c, unmodified
     hbrt.register_filters(ol.ref(), REF)
+    # crop/scale is a settings holder for the combined avfilter graph in the reference (FFmpeg is not in the image): the
+    # id resolves to the drop-in itself, which the swap then leaves in place (as tests/test_job_swap_gpu.py::with_vfr)
+    hbrt.register_filters(hip.filters(), {F["crop_scale"]: "hb_filter_crop_scale_hip"})
     try:
         frames = frames_for("2x1", 10, 320, 180, 7, "interlaced")
         vfr = "mode=0:rate=60000/1001"
@@ -285,3 +289,4 @@ def test_device_resident_job_on_yuv422p10(built):
                 np.testing.assert_array_equal(o.planes[c], wnt.planes[c])
     finally:
         hbrt.register_filters(ol.ref(), {k: None for k in REF})
+        hbrt.register_filters(hip.filters(), {F["crop_scale"]: None})
