@@ -38,6 +38,9 @@ constexpr int TXN = 32;          // threads along x
 constexpr int TYN = 8;           // threads along y
 constexpr int TH = TYN * RY;     // 64
 constexpr int NLM_BORDER = 16;   // nlmeans.c:529 for every patch size <= 29
+#ifndef NLM16_SYM_PAIRS
+#define NLM16_SYM_PAIRS 3        // 16-bit samples: how many of frame 0's four displacement pairs share their distances (3 | 4)
+#endif
 
 struct alignas(16) NlmJob
 {
@@ -549,7 +552,8 @@ __device__ __forceinline__ void load_tile16(uint32_t *lds, int pitch, int dwords
     const int x = x0 + 2 * c;                                  // first of the dword's two pixels
     const bool whole = x >= 0 && x + 1 < w;
     const int o0 = reflect(x, w), o1 = reflect(x + 1, w);
-    uint32_t *out = lds + r0 * pitch + c;
+    // dword c of a row goes to the row's even half (c / 2) or odd half (pitch / 2 + c / 2): see nlmeans_lanes16_kernel
+    uint32_t *out = lds + r0 * pitch + (c >> 1) + (c & 1) * (pitch >> 1);
 #pragma nounroll
     for (int r = r0; r < rows; r += rpp, out += rpp * pitch)
     {
@@ -565,15 +569,46 @@ __device__ __forceinline__ void load_tile16(uint32_t *lds, int pitch, int dwords
 
 __device__ __forceinline__ uint32_t half_of(uint32_t v, int k) { return (v >> (16 * k)) & 0xffffu; }
 
-// FAST 0 / 1 / 2 as in the 8-bit kernel (2: the table index by an integer multiply-high, the table at LDS address 0)
-template <int N, int FAST, int CPD, bool PRE>
+// (a.lo - b.lo, a.hi - b.hi) as two int16, and c + d.lo^2 / c + d.hi^2 (the compiler extracts the halves with a v_bfe and
+// a shift before a 24-bit multiply-add; the 16-bit multiply-add takes either half of its operands itself)
+typedef short nlm_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_sub_i16(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, (nlm_s2)(__builtin_bit_cast(nlm_s2, a) - __builtin_bit_cast(nlm_s2, b)));
+}
+__device__ __forceinline__ uint32_t sq_acc_lo(uint32_t d, uint32_t c)
+{
+    uint32_t r;
+    asm("v_mad_i32_i16 %0, %1, %1, %2" : "=v"(r) : "v"(d), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t sq_acc_hi(uint32_t d, uint32_t c)
+{
+    uint32_t r;
+    asm("v_mad_i32_i16 %0, %1, %1, %2 op_sel:[1,1,0,0]" : "=v"(r) : "v"(d), "v"(c));
+    return r;
+}
+
+// FAST 0 / 1 / 2 / 3 as in the 8-bit kernel (2: the table index by an integer multiply-high, the table at LDS address 0;
+// 3: 2, and inside frame 0 the patch distance of a displacement and of its mirror computed once - SYM_PAIRS of the four
+// pairs: all four need 59 KB of LDS per workgroup (two workgroups per CU), the three with dy != 0 fit three)
+template <int N, int FAST, int CPD, bool PRE, int SYM_PAIRS = 4>
 __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes16_kernel(const NlmJob *__restrict__ jobs, int njobs,
                                                                        int cmp_rows, int rq)
 {
     constexpr int NH = N / 2;
     constexpr int ROWS = RY + N - 1;
+    constexpr bool SYM = FAST == 3 && !PRE;
+    static_assert(FAST != 3 || N <= 7, "the pairs' sharing reads a neighbouring lane's edge pixel: patch sizes up to 7");
+    constexpr int ST_ROWS = RY + 1, ST_SLOT = ST_ROWS * TXN * TYN;        // the stash: [slot][row 0..RY][thread] dwords
     static_assert(NH <= PX, "patch must not reach past the adjacent lane");
     static_assert(CPD % 8 == 4, "the two tile rows of a wave must sit 32 banks apart");
+    // A lane's four samples are two dwords, so a plain row layout has the lanes of a group read with a stride of two dwords:
+    // under the 32-bank rule of ds_read_b32 / ds_read2_b32 lanes l and l + 16 then meet on a bank, and every row read of the
+    // walk took twice its cycles (46 % of the kernel's LDS cycles were conflict cycles, and the LDS was what bound it).  A tile
+    // row is therefore stored as its even dwords followed by its odd dwords (H = CPD / 2 each): the lanes of a group read
+    // consecutive dwords of one half, whichever parity the compare window's offset has.
+    constexpr int H = CPD / 2;
 
     extern __shared__ uint32_t smem[];
     const int tile_dwords = CPD * cmp_rows + 4;
@@ -585,8 +620,11 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes16_kernel(const Nlm
     // s_r0 (frame 0: also the origin term and the zero fallback) and s_rc (frame f > 0) - as in the 8-bit kernel
     uint32_t *s_r0 = PRE ? s_tc + tile_dwords : s_t0;
     uint32_t *s_rc = PRE ? s_r0 + tile_dwords : s_tc;
+    // SYM: over the next frame's tile (free while f == 0) and beyond; slot = (dy + 1) * 3 + (dx + 1) of the pair's first:
+    // 0..3, or with three pairs 0..2 (the (0, -1) slot, 3, is never touched)
+    uint32_t *s_stash = s_tc;
     typedef __attribute__((address_space(3))) const float lds_cfloat;
-    __builtin_assume(FAST != 2 || reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint32_t *)smem) == 0);   // nlm_no_static_lds
+    __builtin_assume(FAST < 2 || reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint32_t *)smem) == 0);   // nlm_no_static_lds
 
     int j = 0;
     for (int hi = njobs - 1; j < hi;)
@@ -617,8 +655,8 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes16_kernel(const Nlm
     }
     else
         load_tile16(s_t0, CPD, CPD, cmp_rows, job.frame[0], job.fpitch[0], w, h, tx0 - PX - 4 * rq, ty0 - NH - RH);
-    // lane tx's own 4 pixels = dwords 2*tx + 2*rq, +1 of a tile row
-    const int own_off = (ty * RY + RH) * CPD + 2 * tx + 2 * rq;
+    // lane tx's own 4 pixels = dwords 2*tx + 2*rq, +1 of a tile row = entry tx + rq of the row's even and of its odd half
+    const int own_off = (ty * RY + RH) * CPD + tx + rq;
     const uint32_t *own = s_t0 + own_off;
     const uint32_t *own_raw = s_r0 + own_off;                    // the same samples of the raw frame being filtered
 
@@ -658,149 +696,219 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes16_kernel(const Nlm
         const uint32_t *cmp_tile = (PRE || f > 0) ? s_tc : s_t0;
         const uint32_t *pix_tile = f > 0 ? s_rc : s_r0;          // what is averaged (== cmp_tile without a prefilter)
 
-        for (int dy = -RH; dy <= RH; dy++)
+        // one displacement; F0: frame 0 of a launch that shares the pairs' distances (FAST 3, as in the 8-bit kernel: the first
+        // of a pair (-dy, -dx) / (dy, dx) leaves the table index of every pixel of the lane in LDS - four 7-bit indices per
+        // dword and row -, the second reads the index of its mirror one row down and / or one pixel across)
+        auto displacement = [&](auto f0c, int dy, int dx) __attribute__((always_inline))
         {
-            for (int dx = -RH; dx <= RH; dx++)
+            constexpr bool F0 = decltype(f0c)::value;
+            if (f == 0 && dx == 0 && dy == 0)
             {
-                if (f == 0 && dx == 0 && dy == 0)
+#pragma unroll
+                for (int o = 0; o < RY; o++)
                 {
+                    const uint32_t c0 = own_raw[(o + NH) * CPD], c1 = own_raw[(o + NH) * CPD + H];
 #pragma unroll
-                    for (int o = 0; o < RY; o++)
+                    for (int p = 0; p < PX; p++)
                     {
-                        const uint32_t c0 = own_raw[(o + NH) * CPD], c1 = own_raw[(o + NH) * CPD + 1];
-#pragma unroll
-                        for (int p = 0; p < PX; p++)
-                        {
-                            const int sv = (int)half_of(p < 2 ? c0 : c1, p & 1);
-                            aw[o][p / 2][p & 1] = (float)((double)aw[o][p / 2][p & 1] + origin_tune);
-                            ap[o][p / 2][p & 1] = (float)((double)ap[o][p / 2][p & 1] + origin_tune * (double)sv);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
+                        const int sv = (int)half_of(p < 2 ? c0 : c1, p & 1);
+                        aw[o][p / 2][p & 1] = (float)((double)aw[o][p / 2][p & 1] + origin_tune);
+                        ap[o][p / 2][p & 1] = (float)((double)ap[o][p / 2][p & 1] + origin_tune * (double)sv);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    continue;
                 }
+                return;
+            }
 
-                const int s = dx + 4 * rq;                   // pixel offset of the compare window, >= 0, uniform
-                const int sh = 2 * (s & 1);                  // byte shift inside the dword pair
-                const uint32_t *srow = own;
-                const uint32_t *crow = cmp_tile + (ty * RY + dy + RH) * CPD + 2 * tx + (s >> 1);
-                const uint32_t *prow = pix_tile + (ty * RY + dy + RH + NH) * CPD + 2 * tx + (s >> 1);   // the row whose pixels are averaged
-
-                uint32_t C[PX], hist[RY - 1][PX], v[PX];
-                uint32_t pixq0 = 0, pixq1 = 0;
-                f2 wq[PX / 2];
+            const int s = dx + 4 * rq;                   // pixel offset of the compare window, >= 0, uniform
+            const int sh = 2 * (s & 1);                  // byte shift inside the dword pair
+            // the three dwords 2 tx + m .. + 2 (m = s / 2) of a row, each in its half: entry e of half (m + k) & 1
+            const int m = s >> 1;
+            const int e0 = (m >> 1) + (m & 1) * H, e1 = ((m + 1) >> 1) + ((m + 1) & 1) * H, e2 = ((m + 2) >> 1) + (m & 1) * H;
+            const uint32_t *prow = pix_tile + (ty * RY + dy + RH + NH) * CPD + tx;   // the row whose pixels are averaged
+            const uint32_t *prow0 = prow + e0, *prow1 = prow + e1, *prow2 = prow + e2;
+            // which pairs share: all four, or (SYM_PAIRS == 3) the three with dy != 0 - their stash then fits beside the
+            // tiles of three workgroups per CU
+            const bool shared_pair = SYM_PAIRS == 4 || dy != 0;
+            if (SYM && F0 && shared_pair && (dy > 0 || (dy == 0 && dx > 0)))
+            {
+                const uint32_t *st = s_stash + ((-dy + 1) * 3 + (-dx + 1)) * ST_SLOT + dy * (TXN * TYN) + (int)threadIdx.x;
 #pragma unroll
-                for (int q = 0; q < PX; q++) C[q] = 0;
-
-                uint32_t a_n0 = srow[0], a_n1 = srow[1], b_n0 = crow[0], b_n1 = crow[1], b_n2 = crow[2];
-#pragma unroll
-                for (int i = 0; i < ROWS; i++)
+                for (int o = 0; o < RY; o++)
                 {
-                    const uint32_t a0 = a_n0, a1 = a_n1;
-                    const uint32_t bw0 = __builtin_amdgcn_alignbyte(b_n1, b_n0, sh);
-                    const uint32_t bw1 = __builtin_amdgcn_alignbyte(b_n2, b_n1, sh);
-                    if (i + 1 < ROWS)
-                    {
-                        a_n0 = srow[(i + 1) * CPD]; a_n1 = srow[(i + 1) * CPD + 1];
-                        b_n0 = crow[(i + 1) * CPD]; b_n1 = crow[(i + 1) * CPD + 1]; b_n2 = crow[(i + 1) * CPD + 2];
-                    }
+                    const uint32_t w0 = st[o * (TXN * TYN)];
+                    uint32_t id4 = w0;
+                    if (dx > 0) id4 = __builtin_amdgcn_alignbyte(st[o * (TXN * TYN) + 1], w0, 1);
+                    else if (dx < 0) id4 = __builtin_amdgcn_alignbyte(w0, st[o * (TXN * TYN) - 1], 3);
+                    const uint32_t p0 = prow0[o * CPD], p1 = prow1[o * CPD], p2 = prow2[o * CPD];
+                    const uint32_t pix0 = __builtin_amdgcn_alignbyte(p1, p0, sh), pix1 = __builtin_amdgcn_alignbyte(p2, p1, sh);
+                    const uint32_t o0 = (id4 << 2) & 0x1fcu, o1 = (id4 >> 6) & 0x1fcu, o2 = (id4 >> 14) & 0x1fcu, o3 = (id4 >> 22) & 0x1fcu;
+                    const f2 wa = {*reinterpret_cast<lds_cfloat *>(o0), *reinterpret_cast<lds_cfloat *>(o1)};
+                    const f2 wb = {*reinterpret_cast<lds_cfloat *>(o2), *reinterpret_cast<lds_cfloat *>(o3)};
+                    const f2 pa = {(float)(int)half_of(pix0, 0), (float)(int)half_of(pix0, 1)};
+                    const f2 pb = {(float)(int)half_of(pix1, 0), (float)(int)half_of(pix1, 1)};
+                    aw[o][0] += wa; ap[o][0] += wa * pa;
+                    aw[o][1] += wb; ap[o][1] += wb * pb;
+                }
+                return;
+            }
+            constexpr bool stash_can = SYM && F0;            // (here: dy < 0, or dy == 0 && dx < 0)
+            const bool stash_on = stash_can && shared_pair;
+            const bool extra_row = stash_on && dy < 0;
+            uint32_t *stw = s_stash + ((dy + 1) * 3 + (dx + 1)) * ST_SLOT + (int)threadIdx.x;
+            const uint32_t *srow = own;
+            const uint32_t *crow = cmp_tile + (ty * RY + dy + RH) * CPD + tx;
+            const uint32_t *crow0 = crow + e0, *crow1 = crow + e1, *crow2 = crow + e2;
+
+            uint32_t C[PX], hist[RY - 1 + (SYM ? 1 : 0)][PX], v[PX];
+            uint32_t centre0[NH + 1], centre1[NH + 1];           // !PRE: the compare window's dwords of the last NH + 1 rows
+            uint32_t pixq0 = 0, pixq1 = 0;
+            f2 wq[PX / 2];
+#pragma unroll
+            for (int q = 0; q < PX; q++) C[q] = 0;
+
+            uint32_t a_n0 = srow[0], a_n1 = srow[H], b_n0 = crow0[0], b_n1 = crow1[0], b_n2 = crow2[0];
+#pragma unroll
+            for (int i = 0; i < ROWS + (SYM ? 1 : 0); i++)
+            {
+                // (the trip past ROWS only exists for the pairs' sake: a uniform branch around it, not a break - the loop has
+                // to unroll for hist[] to stay in registers)
+                if (!(SYM && i == ROWS) || extra_row)
+                {
+                const uint32_t a0 = a_n0, a1 = a_n1;
+                const uint32_t bw0 = __builtin_amdgcn_alignbyte(b_n1, b_n0, sh);
+                const uint32_t bw1 = __builtin_amdgcn_alignbyte(b_n2, b_n1, sh);
+                if (i + 1 < ROWS || (SYM && i + 1 == ROWS && extra_row))
+                {
+                    a_n0 = srow[(i + 1) * CPD]; a_n1 = srow[(i + 1) * CPD + H];
+                    b_n0 = crow0[(i + 1) * CPD]; b_n1 = crow1[(i + 1) * CPD]; b_n2 = crow2[(i + 1) * CPD];
+                }
+                if (!PRE) { centre0[i % (NH + 1)] = bw0; centre1[i % (NH + 1)] = bw1; }
+                // two differences per v_pk_sub_i16 (samples < 2^15), then C += d * d on either half of the pair by
+                // v_mad_i32_i16 with op_sel: six instructions per row of four pixels instead of eight
+                const uint32_t d01 = pk_sub_i16(a0, bw0), d23 = pk_sub_i16(a1, bw1);
+                C[0] = sq_acc_lo(d01, C[0]); C[1] = sq_acc_hi(d01, C[1]);
+                C[2] = sq_acc_lo(d23, C[2]); C[3] = sq_acc_hi(d23, C[3]);
+                if (i < RY - 1 + (SYM ? 1 : 0))
+                {
+#pragma unroll
+                    for (int q = 0; q < PX; q++) hist[i][q] = C[q];
+                }
+                if (i >= N - 1)
+                {
+                    const int o = i - (N - 1);
+                    uint32_t V[PX], pre[PX + 1], suf[PX + 1];
+#pragma unroll
+                    for (int q = 0; q < PX; q++) V[q] = o > 0 ? C[q] - hist[o > 0 ? o - 1 : 0][q] : C[q];
+                    pre[0] = 0; suf[0] = 0;
 #pragma unroll
                     for (int q = 0; q < PX; q++)
                     {
-                        const int d = (int)half_of(q < 2 ? a0 : a1, q & 1) - (int)half_of(q < 2 ? bw0 : bw1, q & 1);
-                        C[q] += (uint32_t)(d * d);
-                        if (i < RY - 1) hist[i][q] = C[q];
+                        pre[q + 1] = pre[q] + V[q];
+                        suf[q + 1] = suf[q] + V[PX - 1 - q];
                     }
-                    if (i >= N - 1)
+#pragma unroll
+                    for (int p = 0; p < PX; p++)
                     {
-                        const int o = i - (N - 1);
-                        uint32_t V[PX], pre[PX + 1], suf[PX + 1];
-#pragma unroll
-                        for (int q = 0; q < PX; q++) V[q] = o > 0 ? C[q] - hist[o > 0 ? o - 1 : 0][q] : C[q];
-                        pre[0] = 0; suf[0] = 0;
-#pragma unroll
-                        for (int q = 0; q < PX; q++)
-                        {
-                            pre[q + 1] = pre[q] + V[q];
-                            suf[q + 1] = suf[q] + V[PX - 1 - q];
-                        }
-#pragma unroll
-                        for (int p = 0; p < PX; p++)
-                        {
-                            const int lo = p - NH, hi = p + NH;
-                            uint32_t t;
-                            if (lo <= 0 && hi >= PX - 1) t = pre[PX];
-                            else if (lo <= 0) t = pre[hi + 1];
-                            else if (hi >= PX - 1) t = suf[PX - lo];
-                            else t = pre[hi + 1] - pre[lo];
-                            if (lo < 0) { t += from_lane_below(suf[-lo]); asm volatile("" : "+v"(t)); }
-                            if (hi > PX - 1) { t += from_lane_above(pre[hi - (PX - 1)]); asm volatile("" : "+v"(t)); }
-                            v[p] = t;
-                        }
+                        const int lo = p - NH, hi = p + NH;
+                        uint32_t t;
+                        if (lo <= 0 && hi >= PX - 1) t = pre[PX];
+                        else if (lo <= 0) t = pre[hi + 1];
+                        else if (hi >= PX - 1) t = suf[PX - lo];
+                        else t = pre[hi + 1] - pre[lo];
+                        if (lo < 0) { t += from_lane_below(suf[-lo]); asm volatile("" : "+v"(t)); }
+                        if (hi > PX - 1) { t += from_lane_above(pre[hi - (PX - 1)]); asm volatile("" : "+v"(t)); }
+                        v[p] = t;
                     }
-                    if (i >= N)
-                    {
-                        const int o = i - N;
+                }
+                if (i >= N && i < ROWS)
+                {
+                    const int o = i - N;
 #pragma unroll
-                        for (int pp = 0; pp < PX / 2; pp++)
-                        {
-                            const uint32_t pix = pp ? pixq1 : pixq0;
-                            const f2 pv = {(float)(int)half_of(pix, 0), (float)(int)half_of(pix, 1)};
-                            aw[o][pp] += wq[pp];
-                            ap[o][pp] += wq[pp] * pv;
-                        }
-                    }
-                    if (i >= N - 1)
+                    for (int pp = 0; pp < PX / 2; pp++)
                     {
-                        const int o = i - (N - 1);
-                        const uint32_t p0 = prow[o * CPD], p1 = prow[o * CPD + 1], p2 = prow[o * CPD + 2];
+                        const uint32_t pix = pp ? pixq1 : pixq0;
+                        const f2 pv = {(float)(int)half_of(pix, 0), (float)(int)half_of(pix, 1)};
+                        aw[o][pp] += wq[pp];
+                        ap[o][pp] += wq[pp] * pv;
+                    }
+                }
+                if (i >= N - 1)
+                {
+                    const int o = i - (N - 1);
+                    uint32_t offs[PX];
+                    if (FAST >= 2)
+                    {
+#pragma unroll
+                        for (int q = 0; q < PX; q++) offs[q] = (__umulhi(min(v[q], (uint32_t)diff_cap), imul4) >> ishift) & 0x1fcu;
+                        if (stash_can && stash_on)           // (uniform) four 7-bit indices per dword: byte q = offs[q] >> 2
+                            stw[o * (TXN * TYN)] = (offs[0] >> 2) | (offs[1] << 6) | (offs[2] << 14) | (offs[3] << 22);
+                    }
+                    if (!(SYM && i == ROWS))                  // (the row below the lane's last: only its indices were wanted)
+                    {
+                    // the samples that go with these weights: the compare frame's row i - NH - without a prefilter the
+                    // dwords the walk had in its hands NH rows ago
+                    if (PRE)
+                    {
+                        const uint32_t p0 = prow0[o * CPD], p1 = prow1[o * CPD], p2 = prow2[o * CPD];
                         pixq0 = __builtin_amdgcn_alignbyte(p1, p0, sh);
                         pixq1 = __builtin_amdgcn_alignbyte(p2, p1, sh);
-#pragma unroll
-                        for (int pp = 0; pp < PX / 2; pp++)
-                        {
-                            if (FAST == 2)
-                            {
-                                const uint32_t o0 = (__umulhi(min(v[2 * pp], (uint32_t)diff_cap), imul4) >> ishift) & 0x1fcu;
-                                const uint32_t o1 = (__umulhi(min(v[2 * pp + 1], (uint32_t)diff_cap), imul4) >> ishift) & 0x1fcu;
-                                wq[pp] = f2{*reinterpret_cast<lds_cfloat *>(o0), *reinterpret_cast<lds_cfloat *>(o1)};
-                                continue;
-                            }
-                            int idx[2];
-                            if (FAST == 1)
-                            {
-                                const f2 fd = {(float)(int)min(v[2 * pp], (uint32_t)diff_cap),
-                                               (float)(int)min(v[2 * pp + 1], (uint32_t)diff_cap)};
-                                const f2 fi = fd * wft2;
-                                idx[0] = (int)fi.x;
-                                idx[1] = (int)fi.y;
-                            }
-                            else
-                            {
-#pragma unroll
-                                for (int e = 0; e < 2; e++)
-                                {
-                                    const int diff = (int)v[2 * pp + e];
-                                    int ix = (int)((float)diff * wft);
-                                    ix = diff < diff_max ? ix : 127;
-                                    idx[e] = min(ix, 127);
-                                }
-                            }
-                            wq[pp] = f2{s_exp[idx[0]], s_exp[idx[1]]};
-                        }
                     }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                    else
+                    {
+                        pixq0 = centre0[(i - NH) % (NH + 1)];
+                        pixq1 = centre1[(i - NH) % (NH + 1)];
+                    }
 #pragma unroll
-                for (int pp = 0; pp < PX / 2; pp++)
-                {
-                    const uint32_t pix = pp ? pixq1 : pixq0;
-                    const f2 pv = {(float)(int)half_of(pix, 0), (float)(int)half_of(pix, 1)};
-                    aw[RY - 1][pp] += wq[pp];
-                    ap[RY - 1][pp] += wq[pp] * pv;
+                    for (int pp = 0; pp < PX / 2; pp++)
+                    {
+                        if (FAST >= 2)
+                        {
+                            wq[pp] = f2{*reinterpret_cast<lds_cfloat *>(offs[2 * pp]), *reinterpret_cast<lds_cfloat *>(offs[2 * pp + 1])};
+                            continue;
+                        }
+                        int idx[2];
+                        if (FAST == 1)
+                        {
+                            const f2 fd = {(float)(int)min(v[2 * pp], (uint32_t)diff_cap),
+                                           (float)(int)min(v[2 * pp + 1], (uint32_t)diff_cap)};
+                            const f2 fi = fd * wft2;
+                            idx[0] = (int)fi.x;
+                            idx[1] = (int)fi.y;
+                        }
+                        else
+                        {
+#pragma unroll
+                            for (int e = 0; e < 2; e++)
+                            {
+                                const int diff = (int)v[2 * pp + e];
+                                int ix = (int)((float)diff * wft);
+                                ix = diff < diff_max ? ix : 127;
+                                idx[e] = min(ix, 127);
+                            }
+                        }
+                        wq[pp] = f2{s_exp[idx[0]], s_exp[idx[1]]};
+                    }
+                    }
                 }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-        }
+#pragma unroll
+            for (int pp = 0; pp < PX / 2; pp++)
+            {
+                const uint32_t pix = pp ? pixq1 : pixq0;
+                const f2 pv = {(float)(int)half_of(pix, 0), (float)(int)half_of(pix, 1)};
+                aw[RY - 1][pp] += wq[pp];
+                ap[RY - 1][pp] += wq[pp] * pv;
+            }
+        };
+        for (int dy = -RH; dy <= RH; dy++)
+            for (int dx = -RH; dx <= RH; dx++)
+            {
+                if (SYM && f == 0) displacement(std::true_type{}, dy, dx);
+                else displacement(std::false_type{}, dy, dx);
+            }
     }
 
     const int x = tx0 + (tx - 1) * PX;
@@ -810,7 +918,7 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes16_kernel(const Nlm
     {
         const int y = ty0 + ty * RY + o;
         if (y >= h) break;
-        const uint32_t c0 = own_raw[(o + NH) * CPD], c1 = own_raw[(o + NH) * CPD + 1];
+        const uint32_t c0 = own_raw[(o + NH) * CPD], c1 = own_raw[(o + NH) * CPD + H];
         uint32_t r[PX];
 #pragma unroll
         for (int p = 0; p < PX; p++)
@@ -1387,9 +1495,11 @@ private:
             // the pairs of frame 0 share their patch distances (FAST 3) when every plane of the launch searches 3 x 3
             // (patch sizes up to 7: the mirrored index of a lane's edge pixel comes from the neighbouring lane's edge pixel,
             // whose own window must not reach past ITS neighbour - the outer lanes of a tile row have none)
-            const bool sym = fast && fast_int && !pre && !wide && all_rh1 && n <= 7;
+            const bool sym = fast && fast_int && !pre && all_rh1 && n <= 7;
             size_t shmem = sizeof(uint32_t) * (pre ? 4 : 2) * (cpd * cmp_rows + 4) + 512;
-            if (sym) shmem = 512 + sizeof(uint32_t) * ((size_t)(cpd * cmp_rows + 4) + std::max<size_t>(cpd * cmp_rows + 4, 4 * (RY + 1) * TXN * TYN));
+            // (16-bit samples: NLM16_SYM_PAIRS of the four pairs share - the stash of three fits three workgroups on a CU)
+            const int sym_slots = wide ? NLM16_SYM_PAIRS : 4;
+            if (sym) shmem = 512 + sizeof(uint32_t) * ((size_t)(cpd * cmp_rows + 4) + std::max<size_t>(cpd * cmp_rows + 4, (size_t)sym_slots * (RY + 1) * TXN * TYN));
             // the widest search ranges need more than the default 64 KB of dynamic LDS
             // The integer-index kernels (FAST >= 2) read the weight table at LDS address 0: true when the kernel has no static
             // LDS in front of its dynamic block.  Asked of the code object once per instantiation; a kernel that fails it is
@@ -1406,8 +1516,9 @@ private:
 #define NLM_16P(NN, FF, PP) do { if (cpd == 76) NLM_LAUNCH((nlmeans_lanes16_kernel<NN, FF, 76, PP>)); \
                                 else NLM_LAUNCH((nlmeans_lanes16_kernel<NN, FF, 84, PP>)); } while (0)
 #define NLM_16(NN, FF) do { if (pre) NLM_16P(NN, FF, true); else NLM_16P(NN, FF, false); } while (0)
+#define NLM_16S(NN) NLM_LAUNCH((nlmeans_lanes16_kernel<NN, (NN <= 7 ? 3 : 2), 76, false, NLM16_SYM_PAIRS>))
 #define NLM_VAR(NN) do { const char *kname = "nlmeans_plane_n" #NN; \
-                     if (wide) { if (fast && fast_int) NLM_16(NN, 2); else if (fast) NLM_16(NN, 1); else NLM_16(NN, 0); } \
+                     if (wide) { if (sym && NN <= 7 && cpd == 76) NLM_16S(NN); else if (fast && fast_int) NLM_16(NN, 2); else if (fast) NLM_16(NN, 1); else NLM_16(NN, 0); } \
                      else if (cpd == 36) { if (sym && NN <= 7) NLM_GO(NN, (NN <= 7 ? 3 : 2), 36, false); else if (fast && fast_int) NLM_PRE(NN, 2, 36); else if (fast) NLM_PRE(NN, 1, 36); else NLM_PRE(NN, 0, 36); } \
                      else { if (sym && NN <= 7) NLM_GO(NN, (NN <= 7 ? 3 : 2), 44, false); else if (fast && fast_int) NLM_PRE(NN, 2, 44); else if (fast) NLM_PRE(NN, 1, 44); else NLM_PRE(NN, 0, 44); } } while (0)
             switch (n)
@@ -1420,6 +1531,7 @@ private:
 #undef NLM_VAR
 #undef NLM_16
 #undef NLM_16P
+#undef NLM_16S
 #undef NLM_PRE
 #undef NLM_GO
 #undef NLM_LAUNCH

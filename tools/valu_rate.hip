@@ -92,6 +92,32 @@
 #define OP_MSAD(r)    "v_msad_u8 " r ", " r ", %8, " r "\n"
 #define OP_SDWAADD(r) "v_add_u32_sdwa " r ", " r ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1\n"
 #define OP_SDWAMUL(r) "v_mul_u32_u24_sdwa " r ", " r ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0\n"
+// f16 / mixed-precision classes (round 6: can the NLMeans SSD leave the half-rate integer classes?)
+#define OP_PKADDH(r)  "v_pk_add_f16 " r ", " r ", %8\n"
+#define OP_PKMULH(r)  "v_pk_mul_f16 " r ", " r ", %8\n"
+#define OP_PKFMAH(r)  "v_pk_fma_f16 " r ", " r ", %8, " r "\n"
+#define OP_DOT2F(r)   "v_dot2_f32_f16 " r ", " r ", %8, " r "\n"
+#define OP_DOT2CF(r)  "v_dot2c_f32_f16 " r ", " r ", %8\n"
+#define OP_FMAMIX(r)  "v_fma_mix_f32 " r ", " r ", %8, " r " op_sel_hi:[1,1,0]\n"
+#define OP_FMAMIXLO(r) "v_fma_mixlo_f16 " r ", " r ", %8, " r "\n"
+#define OP_CVTFH(r)   "v_cvt_f32_f16 " r ", " r "\n"
+#define OP_CVTHF(r)   "v_cvt_f16_f32 " r ", " r "\n"
+#define OP_CVTPKRTZ(r) "v_cvt_pkrtz_f16_f32 " r ", " r ", %8\n"
+#define OP_ADDH(r)    "v_add_f16 " r ", " r ", %8\n"
+#define OP_FMACH(r)   "v_mac_f16 " r ", " r ", %8\n"
+#define OP_DOT2I16(r) "v_dot2_i32_i16 " r ", " r ", %8, " r "\n"
+#define OP_DOT2CI16(r) "v_dot2c_i32_i16 " r ", " r ", %8\n"
+#define OP_MULHI(r)   "v_mul_hi_u32 " r ", " r ", %8\n"
+#define OP_ADDF_DPP(r) "v_add_f32_dpp " r ", " r ", %8 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+#define OP_FMA_NEG(r) "v_fma_f32 " r ", " r ", -%8, " r "\n"
+#define OP_MULF_SDWA(r) "v_mul_f32_sdwa " r ", " r ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:DWORD\n"
+#define OP_CVTUB_SDWA(r) "v_cvt_f32_u32_sdwa " r ", " r " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1\n"
+#define OP_FLOORF(r)  "v_floor_f32 " r ", " r "\n"
+#define OP_MAD_U64(r) "v_mad_u32_u24 " r ", " r ", %8, %8\n"
+#define OP_PKADDI16(r) "v_pk_add_i16 " r ", " r ", %8\n"
+#define OP_PKMAXH(r)  "v_pk_max_f16 " r ", " r ", %8\n"
+#define OP_SUBF_E64(r) "v_sub_f32_e64 " r ", " r ", |%8|\n"
+#define OP_LDEXP(r)   "v_ldexp_f32 " r ", " r ", 2\n"
 // 64-bit register classes
 #define OP_PKMUL(r)   "v_pk_mul_f32 " r ", " r ", %8\n"
 #define OP_PKADD(r)   "v_pk_add_f32 " r ", " r ", %8\n"
@@ -207,6 +233,30 @@ DEFINE_KERNEL(k_sad_u16, uint32_t, OP_SADU16)
 DEFINE_KERNEL(k_msad, uint32_t, OP_MSAD)
 DEFINE_KERNEL(k_sdwa_add_word, uint32_t, OP_SDWAADD)
 DEFINE_KERNEL(k_sdwa_mul_byte, uint32_t, OP_SDWAMUL)
+DEFINE_KERNEL(k_pk_add_f16, uint32_t, OP_PKADDH)
+DEFINE_KERNEL(k_pk_mul_f16, uint32_t, OP_PKMULH)
+DEFINE_KERNEL(k_pk_fma_f16, uint32_t, OP_PKFMAH)
+DEFINE_KERNEL(k_dot2_f32_f16, uint32_t, OP_DOT2F)
+DEFINE_KERNEL(k_dot2c_f32_f16, uint32_t, OP_DOT2CF)
+DEFINE_KERNEL(k_fma_mix, uint32_t, OP_FMAMIX)
+DEFINE_KERNEL(k_fma_mixlo, uint32_t, OP_FMAMIXLO)
+DEFINE_KERNEL(k_cvt_f32_f16, uint32_t, OP_CVTFH)
+DEFINE_KERNEL(k_cvt_f16_f32, uint32_t, OP_CVTHF)
+DEFINE_KERNEL(k_cvt_pkrtz, uint32_t, OP_CVTPKRTZ)
+DEFINE_KERNEL(k_add_f16, uint32_t, OP_ADDH)
+DEFINE_KERNEL(k_fmac_f16, uint32_t, OP_FMACH)
+DEFINE_KERNEL(k_dot2_i16, uint32_t, OP_DOT2I16)
+DEFINE_KERNEL(k_dot2c_i16, uint32_t, OP_DOT2CI16)
+DEFINE_KERNEL(k_mul_hi, uint32_t, OP_MULHI)
+DEFINE_KERNEL(k_add_f32_dpp, uint32_t, OP_ADDF_DPP)
+DEFINE_KERNEL(k_fma_neg, uint32_t, OP_FMA_NEG)
+DEFINE_KERNEL(k_mul_f32_sdwa, uint32_t, OP_MULF_SDWA)
+DEFINE_KERNEL(k_cvt_ub_sdwa, uint32_t, OP_CVTUB_SDWA)
+DEFINE_KERNEL(k_floor_f32, uint32_t, OP_FLOORF)
+DEFINE_KERNEL(k_pk_add_i16, uint32_t, OP_PKADDI16)
+DEFINE_KERNEL(k_pk_max_f16, uint32_t, OP_PKMAXH)
+DEFINE_KERNEL(k_sub_f32_abs, uint32_t, OP_SUBF_E64)
+DEFINE_KERNEL(k_ldexp, uint32_t, OP_LDEXP)
 DEFINE_KERNEL(k_pk_mul_f32, float2v, OP_PKMUL)
 DEFINE_KERNEL(k_pk_add_f32, float2v, OP_PKADD)
 DEFINE_KERNEL(k_pk_fma_f32, float2v, OP_PKFMA)
@@ -243,7 +293,16 @@ int main(int argc, char **argv)
         {"v_add_u32_sdwa word", k_sdwa_add_word}, {"v_mul_u32_u24_sdwa byte", k_sdwa_mul_byte},
         {"v_pk_mul_f32", k_pk_mul_f32}, {"v_pk_add_f32", k_pk_add_f32}, {"v_pk_fma_f32", k_pk_fma_f32},
         {"v_add_f64", k_add_f64}, {"v_lshl_add_u64", k_lshl_add_u64},
+        {"v_pk_add_f16", k_pk_add_f16}, {"v_pk_mul_f16", k_pk_mul_f16}, {"v_pk_fma_f16", k_pk_fma_f16},
+        {"v_dot2_f32_f16", k_dot2_f32_f16}, {"v_dot2c_f32_f16", k_dot2c_f32_f16}, {"v_fma_mix_f32", k_fma_mix},
+        {"v_fma_mixlo_f16", k_fma_mixlo}, {"v_cvt_f32_f16", k_cvt_f32_f16}, {"v_cvt_f16_f32", k_cvt_f16_f32},
+        {"v_cvt_pkrtz_f16_f32", k_cvt_pkrtz}, {"v_add_f16", k_add_f16}, {"v_fmac_f16", k_fmac_f16},
+        {"v_dot2_i32_i16", k_dot2_i16}, {"v_dot2c_i32_i16", k_dot2c_i16}, {"v_mul_hi_u32", k_mul_hi},
+        {"v_add_f32_dpp wave_shr", k_add_f32_dpp}, {"v_fma_f32 neg src", k_fma_neg}, {"v_mul_f32_sdwa", k_mul_f32_sdwa},
+        {"v_cvt_f32_u32_sdwa byte", k_cvt_ub_sdwa}, {"v_floor_f32", k_floor_f32}, {"v_pk_add_i16", k_pk_add_i16},
+        {"v_pk_max_f16", k_pk_max_f16}, {"v_sub_f32_e64 abs", k_sub_f32_abs}, {"v_ldexp_f32", k_ldexp},
     };
+    const char *only = argc > 2 ? argv[2] : NULL;          // run only the classes whose name contains this
     const int nclasses = sizeof(classes) / sizeof(classes[0]);
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
@@ -260,9 +319,12 @@ int main(int argc, char **argv)
     std::string json = "{\n  \"device\": \"" + std::string(prop.name) + "\", \"gcn_arch\": \"" + prop.gcnArchName +
                        "\", \"cus\": " + std::to_string(cus) + ", \"clock_mhz_max\": " + std::to_string(prop.clockRate / 1000) +
                        ", \"instructions_per_wave\": " + std::to_string(iters * 64) + ",\n  \"classes\": {\n";
+    bool first = true;
     for (int c = 0; c < nclasses; c++)
     {
-        json += std::string("    \"") + classes[c].name + "\": {";
+        if (only != NULL && strstr(classes[c].name, only) == NULL && c < nclasses - 24) continue;   // (the round-6 classes always)
+        json += std::string(first ? "" : ",\n") + "    \"" + classes[c].name + "\": {";
+        first = false;
         for (int k = 1; k <= 8; k *= 2)
         {
             const int blocks = cus * k;                  // k 256-thread blocks per CU = k waves per SIMD
@@ -288,9 +350,9 @@ int main(int argc, char **argv)
             json += buf;
             printf("%-26s k=%d  %.3f cyc/inst/SIMD  %.1f Ginst/s chip  (%.3f ms)\n", classes[c].name, k, cyc_per_inst, ginst, ms);
         }
-        json += c + 1 < nclasses ? "},\n" : "}\n";
+        json += "}";
     }
-    json += "  }\n}\n";
+    json += "\n  }\n}\n";
     FILE *f = fopen(out_path, "w");
     if (f) { fputs(json.c_str(), f); fclose(f); }
     return 0;
