@@ -8,6 +8,11 @@
 // so a frame that enters the chain is read from HBM once per stage and never copied between
 // stages.  A batch of input frames is walked stage by stage: stage k sees all the frames of the
 // batch before stage k+1 starts, which lets batching stages (NLMeans) cover them in one launch.
+// (Round 6 tried the other order for the stateless tail of a chain - parts of ~100 MB of intermediate walked through
+// scaler and lapsharp while they are hot in the 256 MB Infinity Cache, because sixteen 2160p frames are 199 MB at 8 bits
+// and 398 MB at 10 and lapsharp takes 279 us per 16 frames behind the scaler against 211 on cache-resident input.  What
+// lapsharp gained the scaler lost on launches a quarter the size: 10 bits 1114 -> 896 and 827 -> 954 us per two steps,
+// 8 bits both slower - profiles/r6h_bench_chain*_chunked.json.  Not kept.)
 //
 // The last stage writes straight into the caller's output frames when it can (stateless filters);
 // the first stage gets the caller's frames through one 3-plane copy launch (stateful filters keep

@@ -580,7 +580,11 @@ int launch_copy(hbhip_ctx *ctx, const char *name, DevPicture *in, DevPicture *ou
 #ifndef LS_ROWS_N
 #define LS_ROWS_N 8
 #endif
-constexpr int LS_ROWS = LS_ROWS_N, LS_FRAMES = 16;
+#ifndef LS_BX_N
+#define LS_BX_N 64
+#endif
+// a workgroup is LS_BX x LS_BY threads = 4 LS_BX columns x LS_BY LS_ROWS rows of a plane
+constexpr int LS_ROWS = LS_ROWS_N, LS_FRAMES = 16, LS_BX = LS_BX_N, LS_BY = 256 / LS_BX_N;
 struct LapPlane3 { int width, height, src_pitch, dst_pitch, stride_border, valid_w, a, b, c, active; double coef, strength; int fast, kinv; float mixf; };
 struct LapBatch3
 {
@@ -594,8 +598,8 @@ __global__ __launch_bounds__(256) void lapsharp3_rows_kernel(LapBatch3 B)
     const int job = blockIdx.z, f = job / 3, c = job - 3 * f;
     const LapPlane3 &P = B.pl[c];
     if (!P.active) return;
-    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    const int ys = (blockIdx.y * 4 + threadIdx.y) * LS_ROWS;
+    const int x0 = (blockIdx.x * LS_BX + threadIdx.x) * 4;
+    const int ys = (blockIdx.y * LS_BY + threadIdx.y) * LS_ROWS;
     if (x0 >= P.width || ys >= P.height) return;
     const uint8_t *src = B.src[f][c];
     uint8_t *dst = B.dst[f][c];
@@ -723,8 +727,8 @@ __global__ __launch_bounds__(256) void lapsharp3_rows16_kernel(LapBatch3 B, int 
     const int job = blockIdx.z, f = job / 3, c = job - 3 * f;
     const LapPlane3 &P = B.pl[c];
     if (!P.active) return;
-    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    const int ys = (blockIdx.y * 4 + threadIdx.y) * LS_ROWS;
+    const int x0 = (blockIdx.x * LS_BX + threadIdx.x) * 4;
+    const int ys = (blockIdx.y * LS_BY + threadIdx.y) * LS_ROWS;
     if (x0 >= P.width || ys >= P.height) return;
     const uint8_t *src = B.src[f][c];
     uint8_t *dst = B.dst[f][c];
@@ -903,9 +907,9 @@ public:
                 }
             }
             // (hbhip_grid_x: never a multiple of 8 workgroups per row of strips - see hbhip_internal.h)
-            const dim3 grid(hbhip_grid_x(((max_w + 3) / 4 + 63) / 64), (max_h + 4 * LS_ROWS - 1) / (4 * LS_ROWS), 3 * nf);
-            if (in_geo.bps == 1) HBHIP_LAUNCH(ctx, "lapsharp_3x3", lapsharp3_rows_kernel, grid, dim3(64, 4), 0, B);
-            else                 HBHIP_LAUNCH(ctx, "lapsharp_3x3", lapsharp3_rows16_kernel, grid, dim3(64, 4), 0, B, (1 << in_geo.depth) - 1);
+            const dim3 grid(hbhip_grid_x(((max_w + 3) / 4 + LS_BX - 1) / LS_BX), (max_h + LS_BY * LS_ROWS - 1) / (LS_BY * LS_ROWS), 3 * nf);
+            if (in_geo.bps == 1) HBHIP_LAUNCH(ctx, "lapsharp_3x3", lapsharp3_rows_kernel, grid, dim3(LS_BX, LS_BY), 0, B);
+            else                 HBHIP_LAUNCH(ctx, "lapsharp_3x3", lapsharp3_rows16_kernel, grid, dim3(LS_BX, LS_BY), 0, B, (1 << in_geo.depth) - 1);
             HBHIP_CHECK(ctx, hipGetLastError());
         }
         return HBHIP_OK;

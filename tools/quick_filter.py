@@ -64,6 +64,9 @@ def main():
     elif what == "unsharp5": make = lambda: mk_blur("hbhip_unsharp_create", size=5)
     elif what == "chroma_smooth": make = lambda: mk_blur("hbhip_chroma_smooth_create", 0)
     elif what == "lapsharp": make = lambda: hip.lapsharp_device_filter(ctx, W, H)
+    elif what == "lapsharp10":
+        make = lambda: hip.lapsharp_device_filter(ctx, W, H, depth=10)
+        depth_in = depth_out = 10
     elif what == "colorspace_sdr": make = lambda: hip.colorspace_device_filter(ctx, W, H, (6, 6, 6, 1), (1, 1, 1, 1))
     elif what == "colorspace_matrix": make = lambda: hip.colorspace_device_filter(ctx, W, H, (1, 1, 1, 1), (1, 1, 6, 2))
     elif what == "grayscale":
