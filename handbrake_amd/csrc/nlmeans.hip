@@ -942,6 +942,109 @@ __global__ __launch_bounds__(TXN * TYN, 3) void nlmeans_lanes16_kernel(const Nlm
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The generic form: every patch size and search range the reference takes (nlmeans.c:284-334 keeps any odd patch size
+// >= 1 and any odd range; what bounds them is the 16-pixel mirrored border, nlmeans.c:529) that the lane-sharing kernels
+// above have no instantiation for - patch 1, 11, 13, 15, ... - at 8 and 10 / 12 bits, with or without a prefilter.  Not
+// tuned: it exists so that no valid setting drops a job to the CPU filter (VERDICT r05 "missing" 3), and as a second
+// implementation the tuned kernels can be held against (tests/test_nlmeans_gpu.py runs patch 7 through both).
+// A workgroup of 32 x 8 threads owns 32 x 8 pixels, one each.  Per displacement the squared differences are summed along
+// x first (one n-tap row sum per pixel of the 8 + n - 1 rows the workgroup's patches cover, through LDS), then n row
+// sums down each pixel's column: 2 n operations per pixel and displacement instead of n * n.  The same integers as the
+// reference's integral image gives (nlmeans_template.c:545-591, :672-675), the same float sequence per pixel (:677-686).
+constexpr int GW = 32, GH = 8;
+
+template <typename PIX>
+__device__ __forceinline__ void generic_stage(PIX *lds, int tw, int th, const uint8_t *__restrict__ plane, int pitch,
+                                              int w, int h, int x0, int y0)
+{
+    for (int i = threadIdx.x; i < tw * th; i += GW * GH)
+    {
+        const int r = i / tw, c = i - r * tw;
+        lds[i] = reinterpret_cast<const PIX *>(plane + (size_t)reflect(y0 + r, h) * pitch)[reflect(x0 + c, w)];
+    }
+}
+
+template <typename PIX>
+__global__ __launch_bounds__(GW * GH) void nlmeans_generic_kernel(const NlmJob *__restrict__ jobs, int njobs, int n, int max_rh, int pre)
+{
+    extern __shared__ uint32_t gsm[];
+    const int nh = n / 2;
+    const int aw_ = GW + 2 * nh, ah_ = GH + 2 * nh;                    // source-patch tile
+    const int bw_ = aw_ + 2 * max_rh, bh_ = ah_ + 2 * max_rh;          // compare tile: the search halo around it
+    uint32_t *rs = gsm;                                                // row sums: ah_ rows of GW
+    PIX *ta = reinterpret_cast<PIX *>(rs + ah_ * GW);
+    PIX *tb = ta + ((aw_ * ah_ + 1) & ~1);
+
+    int j = 0;
+    for (int hi = njobs - 1; j < hi;)
+    {
+        const int mid = (j + hi + 1) >> 1;
+        if ((int)blockIdx.x >= jobs[mid].tile_start) j = mid; else hi = mid - 1;
+    }
+    const NlmJob &job = jobs[j];
+    const int tile = blockIdx.x - job.tile_start;
+    const int tile_y = tile / job.tiles_x, tile_x = tile - tile_y * job.tiles_x;
+    const int tx0 = tile_x * GW, ty0 = tile_y * GH;
+    const int w = job.w, h = job.h, RH = job.r_half;
+    const int lx = threadIdx.x % GW, ly = threadIdx.x / GW;
+    const int x = tx0 + lx, y = ty0 + ly;
+    const bool live = x < w && y < h;
+
+    generic_stage<PIX>(ta, aw_, ah_, pre ? job.src_pre : job.frame[0], pre ? job.src_pre_pitch : job.fpitch[0], w, h, tx0 - nh, ty0 - nh);
+    const uint8_t *raw0 = job.frame[0];
+    const int own = live ? (int)reinterpret_cast<const PIX *>(raw0 + (size_t)y * job.fpitch[0])[x] : 0;
+    float wsum = 0.f, psum = 0.f;
+    for (int f = 0; f < job.nframes; f++)
+    {
+        __syncthreads();                                               // the previous frame's compare tile is done with
+        generic_stage<PIX>(tb, bw_, bh_, pre ? job.frame_pre[f] : job.frame[f], pre ? job.ppitch[f] : job.fpitch[f], w, h,
+                           tx0 - nh - max_rh, ty0 - nh - max_rh);
+        __syncthreads();
+        for (int dy = -RH; dy <= RH; dy++)
+            for (int dx = -RH; dx <= RH; dx++)
+            {
+                if (f == 0 && dx == 0 && dy == 0)
+                {
+                    wsum = (float)((double)wsum + job.origin_tune);                       // nlmeans_template.c:644-655
+                    psum = (float)((double)psum + job.origin_tune * (double)own);
+                    continue;
+                }
+                for (int i = threadIdx.x; i < ah_ * GW; i += GW * GH)
+                {
+                    const int r = i / GW, c = i - r * GW;
+                    const PIX *pa = ta + r * aw_ + c;
+                    const PIX *pb = tb + (r + dy + max_rh) * bw_ + c + dx + max_rh;
+                    uint32_t acc = 0;
+                    for (int k = 0; k < n; k++)
+                    {
+                        const int d = (int)pa[k] - (int)pb[k];
+                        acc += (uint32_t)(d * d);
+                    }
+                    rs[i] = acc;
+                }
+                __syncthreads();
+                uint32_t du = 0;
+                for (int k = 0; k < n; k++) du += rs[(ly + k) * GW + lx];
+                __syncthreads();                                       // (the next displacement rewrites rs)
+                const int diff = (int)du;                              // :672-675
+                if (live && diff < job.diff_max)
+                {
+                    const int idx = (int)((float)diff * job.wft);
+                    const float wgt = job.exptable[min(max(idx, 0), 127)];
+                    const int cmp = (int)reinterpret_cast<const PIX *>(job.frame[f] + (size_t)reflect(y + dy, h) * job.fpitch[f])[reflect(x + dx, w)];
+                    wsum += wgt;
+                    psum += wgt * (float)cmp;
+                }
+            }
+    }
+    if (!live) return;
+    const float q = psum / wsum;
+    PIX r = (PIX)(int)q;                                               // :710-711
+    if (r == 0) r = (PIX)own;
+    reinterpret_cast<PIX *>(job.dst + (size_t)y * job.dst_pitch)[x] = r;
+}
+
 // ------------------------------------------------------------------------------- prefilters
 // nlmeans_prefilter (nlmeans_template.c:428-543) on one plane.  The reference filters the bordered
 // image and re-mirrors the result, so a prefiltered plane is fully described by its w x h interior;
@@ -1207,8 +1310,8 @@ public:
             max_frames = std::max(max_frames, par.nframes[c]);
             if (par.strength[c] == 0) continue;
             const int n = par.patch_size[c];
-            if (n != 3 && n != 5 && n != 7 && n != 9) return HBHIP_ERR_UNSUPPORTED;
-            if (n / 2 + par.range[c] / 2 > NLM_BORDER) return HBHIP_ERR_UNSUPPORTED;
+            if (n < 1 || (n & 1) == 0) return HBHIP_ERR_ARG;                        // (the drop-in sanitises as nlmeans.c:329-330)
+            if (n / 2 + par.range[c] / 2 > NLM_BORDER) return HBHIP_ERR_UNSUPPORTED;  // past the reference's own mirrored border
             if (par.nframes[c] < 1 || par.nframes[c] > HBHIP_NLMEANS_FRAMES_MAX) return HBHIP_ERR_ARG;
             if (in_geo.pw[c] < NLM_BORDER || in_geo.ph[c] < NLM_BORDER) return HBHIP_ERR_UNSUPPORTED;
         }
@@ -1296,6 +1399,9 @@ public:
     int pf_type[3] = {0, 0, 0};          // effective prefilter bits per plane (0 = none)
     bool passthru[3] = {false, false, false};
     bool any_pre = false;
+    // HBHIP_NLMEANS_GENERIC=1: every patch size through nlmeans_generic_kernel (a verification switch: the tuned kernels and
+    // the generic one are two implementations of the same integers and the same float sequence)
+    bool force_generic = [] { const char *e = getenv("HBHIP_NLMEANS_GENERIC"); return e != nullptr && atoi(e) != 0; }();
 
 private:
     int ensure_jobs(int n)
@@ -1415,8 +1521,16 @@ private:
         const int total = (int)ins.size();
 
         // group jobs by patch size (one launch per distinct n)
-        for (int n : {3, 5, 7, 9})
+        std::vector<int> sizes;
+        for (int c = 0; c < 3; c++)
+            if (!passthru[c] && par.strength[c] != 0 && std::find(sizes.begin(), sizes.end(), par.patch_size[c]) == sizes.end())
+                sizes.push_back(par.patch_size[c]);
+        std::sort(sizes.begin(), sizes.end());
+        for (int n : sizes)
         {
+            // patch sizes without a lane-sharing instantiation (1, 11, 13, 15, ...) - or all of them, when asked for the
+            // second implementation - go to nlmeans_generic_kernel
+            const bool generic = force_generic || !(n == 3 || n == 5 || n == 7 || n == 9);
             bool any = false, pre = false;
             for (int c = 0; c < 3; c++)
                 if (!passthru[c] && par.strength[c] != 0 && par.patch_size[c] == n)
@@ -1467,9 +1581,9 @@ private:
                     jb.h = in_geo.ph[c];
                     jb.dst_pitch = outs[t].pitch[c];
                     jb.r_half = (par.range[c] - 1) / 2;
-                    jb.tiles_x = (jb.w + LTW - 1) / LTW;
+                    jb.tiles_x = generic ? (jb.w + GW - 1) / GW : (jb.w + LTW - 1) / LTW;
                     jb.tile_start = tiles;
-                    tiles += jb.tiles_x * ((jb.h + TH - 1) / TH);
+                    tiles += jb.tiles_x * (generic ? (jb.h + GH - 1) / GH : (jb.h + TH - 1) / TH);
                     max_rh = std::max(max_rh, jb.r_half);
                     all_rh1 &= jb.r_half == 1;
                 }
@@ -1485,6 +1599,17 @@ private:
             HBHIP_CHECK(ctx, hipEventRecord(table_ev[table], ctx->stream));
             table_used[table] = true;
             const int nh = n / 2;
+            if (generic)
+            {
+                const int aw_ = GW + 2 * nh, ah_ = GH + 2 * nh, bw_ = aw_ + 2 * max_rh, bh_ = ah_ + 2 * max_rh;
+                const size_t shmem = sizeof(uint32_t) * ah_ * GW + (size_t)in_geo.bps * (((aw_ * ah_ + 1) & ~1) + bw_ * bh_ + 2);
+                if (in_geo.bps == 1)
+                    HBHIP_LAUNCH(ctx, "nlmeans_plane_generic", nlmeans_generic_kernel<uint8_t>, dim3(tiles), dim3(GW * GH), shmem, dj, nj, n, max_rh, (int)pre);
+                else
+                    HBHIP_LAUNCH(ctx, "nlmeans_plane_generic", nlmeans_generic_kernel<uint16_t>, dim3(tiles), dim3(GW * GH), shmem, dj, nj, n, max_rh, (int)pre);
+                HBHIP_CHECK(ctx, hipGetLastError());
+                continue;
+            }
             const int cmp_rows = TH + 2 * (nh + max_rh);
             dim3 grid(tiles), block(TXN * TYN);
             // tiles: 32 lanes + rq dwords of search halo either side (+1 for the alignbyte high

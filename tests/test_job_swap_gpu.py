@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 TFF = 0x0008
 F = hbrt.FILTER_ID
 NLM = hip.NLMEANS_MEDIUM + ":threads=2"
-NLM_P11 = NLM.replace("y-patch-size=7", "y-patch-size=11")      # no kernel for patch 11: the drop-in's init declines
+NLM_P33 = NLM.replace("y-patch-size=7", "y-patch-size=33")      # past the 16-pixel mirrored border the kernels assume (the reference widens its border to 32, nlmeans.c:529): the drop-in declines
 UP, DOWN = "HIP upload adapter", "HIP download adapter"
 
 
@@ -37,7 +37,7 @@ def test_single_dropin_gets_no_adapters(registered):
 
 def test_declined_filter_in_the_middle_of_a_run_falls_back_to_cpu(registered):
     frames = synth.stream("interlaced", 320, 180, 5)
-    names = run_both([(F["decomb"], "mode=7"), (F["nlmeans"], NLM_P11), (F["lapsharp"], LAP), (F["unsharp"], "y-strength=0.25:y-size=7")],
+    names = run_both([(F["decomb"], "mode=7"), (F["nlmeans"], NLM_P33), (F["lapsharp"], LAP), (F["unsharp"], "y-strength=0.25:y-size=7")],
                      frames, flags=TFF)
     # [upload decomb nlm lap unsharp download] -> nlm declines inside the run
     assert names[0] == UP and "Decomb" in names[1] and names[2] == DOWN
@@ -47,13 +47,13 @@ def test_declined_filter_in_the_middle_of_a_run_falls_back_to_cpu(registered):
 
 def test_declined_first_filter_of_a_run_undoes_the_upload(registered):
     frames = synth.stream("progressive", 320, 180, 4)
-    names = run_both([(F["nlmeans"], NLM_P11), (F["lapsharp"], LAP), (F["unsharp"], "y-strength=0.25:y-size=7")], frames)
+    names = run_both([(F["nlmeans"], NLM_P33), (F["lapsharp"], LAP), (F["unsharp"], "y-strength=0.25:y-size=7")], frames)
     assert names[0] == "Denoise (nlmeans)" and names[1] == UP and names[-1] == DOWN and len(names) == 5
 
 
 def test_declined_last_filter_leaves_a_single_dropin_without_adapters(registered):
     frames = synth.stream("progressive", 320, 180, 4)
-    names = run_both([(F["lapsharp"], LAP), (F["nlmeans"], NLM_P11)], frames)
+    names = run_both([(F["lapsharp"], LAP), (F["nlmeans"], NLM_P33)], frames)
     # ids order: nlmeans (16) before lapsharp (24): [upload nlm lap download] -> nlm declines first
     assert names[0] == "Denoise (nlmeans)" and len(names) == 2 and "HIP" in names[1]
 
@@ -121,7 +121,7 @@ def test_vfr_at_the_edge_of_a_run_stays_on_host_frames(with_vfr):
 
 def test_declined_dropin_behind_vfr_closes_the_run_after_it(with_vfr):
     frames = synth.stream("interlaced", 320, 180, 6)
-    names = run_both([(F["decomb"], "mode=7"), (F["comb_detect"], ""), (VFR, "mode=0:rate=30000/1001"), (F["nlmeans"], NLM_P11),
+    names = run_both([(F["decomb"], "mode=7"), (F["comb_detect"], ""), (VFR, "mode=0:rate=30000/1001"), (F["nlmeans"], NLM_P33),
                       (F["lapsharp"], LAP), (F["unsharp"], "y-strength=0.25:y-size=7")], frames, flags=TFF)
     # [UP comb decomb vfr nlm lap unsharp DOWN] -> nlm declines: the frames come down in front of it, after vfr
     assert names[0] == UP and names[3] == SHAPER and names[4] == DOWN and names[5] == "Denoise (nlmeans)"

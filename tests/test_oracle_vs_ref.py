@@ -18,7 +18,10 @@ def nlm_settings(s, o, n, r, f, pf=0):
 
 @needs_ref
 @pytest.mark.parametrize("s,o,n,r,f", [(6, 1, 7, 3, 2), (1.5, 0.9, 7, 3, 2), (10, 1, 7, 3, 2), (3, 0.8, 3, 5, 2),
-                                       (5, 0.15, 5, 7, 4), (4, 0.5, 5, 9, 1), (8, 0.6, 9, 3, 3)])
+                                       (5, 0.15, 5, 7, 4), (4, 0.5, 5, 9, 1), (8, 0.6, 9, 3, 3),
+                                       # the patch sizes beyond the tuned kernels (nlmeans.c:329-330 keeps any odd size >= 1):
+                                       # what csrc/nlmeans.hip:nlmeans_generic_kernel is held against
+                                       (6, 0.8, 1, 3, 2), (6, 1, 11, 3, 2), (5, 0.9, 13, 5, 2), (6, 1, 15, 3, 3), (4, 1, 15, 19, 1)])
 def test_nlmeans_plane_matches_reference(built, s, o, n, r, f):
     frames = synth.stream("progressive", 150, 90, f)
     planes = [fr[0] for fr in frames]
