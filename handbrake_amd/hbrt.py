@@ -235,6 +235,12 @@ class Job(Chain):
         if self._rt.hbh_chain_push_subtitle(self._h, arr, start, stop, ww, wh) != 0:
             raise RuntimeError("hbh_chain_push_subtitle failed (no burn-in track on this job?)")
 
+    def job_ptr(self):
+        """address of the job's hb_job_t (what the drop-ins see as init->job)"""
+        self._rt.hbh_chain_job.restype = C.c_void_p
+        self._rt.hbh_chain_job.argtypes = [C.c_void_p]
+        return self._rt.hbh_chain_job(self._h)
+
     def stages(self):
         buf = C.create_string_buffer(2048)
         self._rt.hbh_chain_describe(self._h, buf, 2048)

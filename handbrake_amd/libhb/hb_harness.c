@@ -181,12 +181,18 @@ static void join_threads(hbh_chain_t *c)
 /* what work.c calls directly inside libhb (hip_common.h); here the filter library registers them when it loads */
 static void (*g_hip_setup)(hb_job_t *) = NULL;
 static int  (*g_hip_init_failed)(hb_job_t *, int, hb_filter_init_t *) = NULL;
+static void (*g_hip_job_close)(hb_job_t *) = NULL;
 
-void hbhip_rt_set_job_hooks(void (*setup)(hb_job_t *), int (*init_failed)(hb_job_t *, int, hb_filter_init_t *))
+void hbhip_rt_set_job_hooks(void (*setup)(hb_job_t *), int (*init_failed)(hb_job_t *, int, hb_filter_init_t *),
+                            void (*job_close)(hb_job_t *))
 {
     g_hip_setup = setup;
     g_hip_init_failed = init_failed;
+    g_hip_job_close = job_close;
 }
+
+/* the hb_job_t of a chain opened with hbh_job_open (NULL for hbh_chain_open) */
+void *hbh_chain_job(hbh_chain_t *c) { return c != NULL ? c->job : NULL; }
 
 void hbh_set_source_color(int prim, int transfer, int matrix, int range)
 {
@@ -543,6 +549,7 @@ void hbh_chain_close(hbh_chain_t *c)
     }
     if (c->job != NULL)
     {
+        if (g_hip_job_close != NULL) g_hip_job_close(c->job);      /* do_job's clean-up (hip_common.h) */
         hb_list_close(&c->job->list_subtitle);
         hb_list_close(&c->job->list_attachment);
     }

@@ -17,7 +17,8 @@ int        hbhip_host_default_device(void);
 int        hbhip_host_device_for(const hb_filter_init_t *init);
 int        hbhip_host_job_index_is_hip(const hb_job_t *job);     /* hw_device_index names a HIP device (no other vendor's hw path in the job) */
 hbhip_ctx *hbhip_host_ctx_on(int device);
-hbhip_ctx *hbhip_host_ctx_for(const hb_filter_init_t *init);     /* what a drop-in's init() uses */
+hbhip_ctx *hbhip_host_ctx_for(const hb_filter_init_t *init);     /* what a drop-in's init() uses: the job's own stream on the job's GPU */
+hbhip_ctx *hbhip_host_job_ctx(const hb_job_t *job);              /* the context a live job has leased, or NULL */
 hbhip_ctx *hbhip_host_ctx(void);                                 /* the process default's context */
 void       hbhip_host_ctx_release(void);
 

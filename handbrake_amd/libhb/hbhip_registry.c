@@ -13,17 +13,23 @@
 
 #include <pthread.h>
 
-/* One context per GPU index, created on first use and kept for the life of the process (filters of later jobs reuse
- * it; HIP tears it down at exit).  Filters of one job share it, i.e. they share one stream, which is what lets adjacent
- * HIP filters hand frames over in HBM without extra synchronisation.
+/* Contexts (a GPU, a HIP stream, the pools behind them) are created on first use and kept for the life of the process
+ * (HIP tears them down at exit).  The filters of ONE job share one: they share a stream, which is what lets adjacent HIP
+ * filters hand frames over in HBM without extra synchronisation.  Two jobs that are live at the same time on one GPU (a
+ * GUI's queue beside a preview encode: one hb_handle_t each) get a context EACH - up to HBHIP_CTX_SLOTS per GPU -, so their
+ * kernels sit on different streams instead of queueing behind each other: a job leases a slot at its first
+ * hbhip_host_ctx_for() and hb_hip_job_close() gives it back, so that jobs run one after the other keep reusing slot 0
+ * and its pools.  A job that is never closed costs nothing but its slot: once all are leased, later jobs share them
+ * (by job address, so that all filters of a job still agree).
  * WHICH GPU is the job's business: hb_job_t carries hw_device_index (common.h:991; the QSV / NVENC paths read it the same
- * way, hwaccel.c:230-257, qsv_common.c:2238-2244), so a process that runs several jobs (one hb_handle_t each, as the
- * queue of a GUI does) puts stream k on GPU k.  A job that does not say (index < 0) - or a caller without an init, such
- * as rendersub's compositor object - gets the process default: HBHIP_DEVICE from the environment, else 0. */
+ * way, hwaccel.c:230-257, qsv_common.c:2238-2244), so a process that runs several jobs puts stream k on GPU k.  A job
+ * that does not say (index < 0) - or a caller without an init, such as rendersub's compositor object - gets the process
+ * default: HBHIP_DEVICE from the environment, else 0, and a caller without a job slot 0 of it. */
 #define HBHIP_MAX_DEVICES 64
+#define HBHIP_CTX_SLOTS   4
+typedef struct { hbhip_ctx *ctx; const hb_job_t *job; int failed; } ctx_slot_t;
 static pthread_mutex_t g_ctx_lock = PTHREAD_MUTEX_INITIALIZER;
-static hbhip_ctx      *g_ctx[HBHIP_MAX_DEVICES];
-static int             g_ctx_failed[HBHIP_MAX_DEVICES];
+static ctx_slot_t      g_slot[HBHIP_MAX_DEVICES][HBHIP_CTX_SLOTS];
 
 int hbhip_host_default_device(void)
 {
@@ -56,32 +62,80 @@ int hbhip_host_device_for(const hb_filter_init_t *init)
     return hbhip_host_default_device();
 }
 
-hbhip_ctx *hbhip_host_ctx_on(int device)
+/* g_ctx_lock held */
+static hbhip_ctx *slot_ctx(int device, int k)
 {
-    if (device < 0 || device >= HBHIP_MAX_DEVICES) return NULL;
-    pthread_mutex_lock(&g_ctx_lock);
-    if (g_ctx[device] == NULL && !g_ctx_failed[device])
+    ctx_slot_t *s = &g_slot[device][k];
+    if (s->ctx == NULL && !s->failed)
     {
-        int rc = hbhip_ctx_create(device, &g_ctx[device]);
+        int rc = hbhip_ctx_create(device, &s->ctx);
         if (rc != HBHIP_OK)
         {
             hb_error("hbhip: cannot create device context on GPU %d: %s", device, hbhip_strerror(rc));
-            g_ctx[device] = NULL;
-            g_ctx_failed[device] = hbhip_device_count() > 0;      /* a GPU that is not there stays not there; no GPU at all may change (tests) */
+            s->ctx = NULL;
+            s->failed = hbhip_device_count() > 0;      /* a GPU that is not there stays not there; no GPU at all may change (tests) */
         }
         else
         {
             char name[256];
-            hbhip_ctx_device_name(g_ctx[device], name, sizeof(name));
-            hb_log("hbhip: using GPU %d: %s", device, name);
+            hbhip_ctx_device_name(s->ctx, name, sizeof(name));
+            hb_log("hbhip: using GPU %d: %s%s", device, name, k ? " (a further job's stream)" : "");
         }
     }
-    hbhip_ctx *c = g_ctx[device];
+    return s->ctx;
+}
+
+hbhip_ctx *hbhip_host_ctx_on(int device)
+{
+    if (device < 0 || device >= HBHIP_MAX_DEVICES) return NULL;
+    pthread_mutex_lock(&g_ctx_lock);
+    hbhip_ctx *c = slot_ctx(device, 0);
     pthread_mutex_unlock(&g_ctx_lock);
     return c;
 }
 
-hbhip_ctx *hbhip_host_ctx_for(const hb_filter_init_t *init) { return hbhip_host_ctx_on(hbhip_host_device_for(init)); }
+hbhip_ctx *hbhip_host_ctx_for(const hb_filter_init_t *init)
+{
+    const int device = hbhip_host_device_for(init);
+    const hb_job_t *job = init != NULL ? init->job : NULL;
+    if (job == NULL) return hbhip_host_ctx_on(device);
+    if (device < 0 || device >= HBHIP_MAX_DEVICES) return NULL;
+    pthread_mutex_lock(&g_ctx_lock);
+    int k = -1;
+    for (int i = 0; i < HBHIP_CTX_SLOTS && k < 0; i++)
+        if (g_slot[device][i].job == job) k = i;                              /* the job's lease */
+    for (int i = 0; i < HBHIP_CTX_SLOTS && k < 0; i++)
+        if (g_slot[device][i].job == NULL) { g_slot[device][i].job = job; k = i; }   /* the lowest free slot */
+    if (k < 0) k = (int)(((uintptr_t)job >> 6) % HBHIP_CTX_SLOTS);                /* all leased: share, the same one for every filter of the job */
+    hbhip_ctx *c = slot_ctx(device, k);
+    if (c == NULL && k > 0) c = slot_ctx(device, 0);                          /* (no further stream to be had: the shared one) */
+    pthread_mutex_unlock(&g_ctx_lock);
+    return c;
+}
+
+/* the job's lease, if it has one (tests) */
+hbhip_ctx *hbhip_host_job_ctx(const hb_job_t *job)
+{
+    hbhip_ctx *c = NULL;
+    pthread_mutex_lock(&g_ctx_lock);
+    for (int d = 0; d < HBHIP_MAX_DEVICES && c == NULL && job != NULL; d++)
+        for (int i = 0; i < HBHIP_CTX_SLOTS; i++)
+            if (g_slot[d][i].job == job) { c = g_slot[d][i].ctx; break; }
+    pthread_mutex_unlock(&g_ctx_lock);
+    return c;
+}
+
+/* work.c, when a job's filters have been closed: the job's stream goes back to the pool (hip_common.h) */
+void hb_hip_job_close(hb_job_t *job)
+{
+    if (job == NULL) return;
+    pthread_mutex_lock(&g_ctx_lock);
+    for (int d = 0; d < HBHIP_MAX_DEVICES; d++)
+        for (int i = 0; i < HBHIP_CTX_SLOTS; i++)
+            if (g_slot[d][i].job == job) g_slot[d][i].job = NULL;
+    pthread_mutex_unlock(&g_ctx_lock);
+}
+
 hbhip_ctx *hbhip_host_ctx(void)                             { return hbhip_host_ctx_on(hbhip_host_default_device()); }
 void       hbhip_host_ctx_release(void)                     { /* contexts live as long as the process */ }
 
@@ -166,7 +220,7 @@ __attribute__((constructor)) static void hbhip_host_register_hooks(void)
 {
 #ifndef HBHIP_IN_LIBHB
     hbhip_rt_set_storage_hooks(storage_retain, storage_release);
-    hbhip_rt_set_job_hooks(hb_hip_setup_hw_filters, hb_hip_filter_init_failed);   /* inside libhb work.c calls them itself */
+    hbhip_rt_set_job_hooks(hb_hip_setup_hw_filters, hb_hip_filter_init_failed, hb_hip_job_close);   /* inside libhb work.c calls them itself */
     /* inside libhb: `case AV_PIX_FMT_HBHIP:` in vfr.c:76-108 and rendersub.c:1129-1161 */
     hbhip_rt_register_hw_helper(0, AV_PIX_FMT_HBHIP, &hb_motion_metric_hip);
     hbhip_rt_register_hw_helper(1, AV_PIX_FMT_HBHIP, &hb_blend_hip);

@@ -10,6 +10,9 @@ void hb_hip_setup_hw_filters(hb_job_t *job);
  * drop-in, put the CPU filter of the same id and settings back in its place (fixing the adapters around it) and
  * return > 0 - the loop then CONTINUES AT index - (return value - 1) instead of dropping the filter; 0 = not ours. */
 int  hb_hip_filter_init_failed(hb_job_t *job, int index, hb_filter_init_t *init);
+/* do_job's clean-up, once the job's filters have been closed (work.c:2311-2321): the HIP stream the job had leased goes
+ * back to the pool (libhb/hbhip_registry.c: concurrent jobs on one GPU run on streams of their own) */
+void hb_hip_job_close(hb_job_t *job);
 /* hb_avfilter_combine (hbavfilter.c:520-541): an aliased id whose object is a drop-in is a real filter */
 int  hb_hip_filter_is_hip(const hb_filter_object_t *filter);
 /* a filter that only handles the hb_buffer_t around a picture (vfr, rendersub, rpu): a member of a device-resident

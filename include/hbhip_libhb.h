@@ -548,7 +548,8 @@ void                hb_add_filter_dict(hb_list_t *, hb_filter_object_t *, const 
 /* stand-in only: what hb_filter_get's switch holds inside libhb (tests register the reference's own objects) */
 void                hbhip_rt_register_filter(int filter_id, hb_filter_object_t *proto);
 /* stand-in only: the harness's do_job() calls hip_common.c through these (inside libhb work.c calls it directly) */
-void                hbhip_rt_set_job_hooks(void (*setup)(hb_job_t *), int (*init_failed)(hb_job_t *, int, hb_filter_init_t *));
+void                hbhip_rt_set_job_hooks(void (*setup)(hb_job_t *), int (*init_failed)(hb_job_t *, int, hb_filter_init_t *),
+                                           void (*job_close)(hb_job_t *));
 
 /* ---- the frame-difference metric plugin type vfr.c uses (handbrake/common.h:1799-1811) -- */
 struct hb_motion_metric_object_s
