@@ -204,3 +204,33 @@ def test_concurrent_jobs_on_one_gpu_run_on_streams_of_their_own(registered):
     same(out_b, alone_b)
     with hbrt.Job(la, 320, 180, use_hip=True) as jc:
         assert flt.hbhip_host_job_ctx(jc.job_ptr()) == ca          # the leases were given back: slot 0 again
+
+
+def test_more_live_jobs_than_streams_share_them(registered):
+    """HBHIP_CTX_SLOTS (4) contexts per GPU: a fifth live job shares one of them - the same one for all of its filters (by
+    job address), so its frames still pass from filter to filter on one stream - and every job's pictures are right."""
+    import ctypes as C
+    flt = hip.filters()
+    flt.hbhip_host_job_ctx.restype = C.c_void_p
+    flt.hbhip_host_job_ctx.argtypes = [C.c_void_p]
+    frames = synth.stream("progressive", 192, 108, 4)
+    lst = [(F["nlmeans"], NLM), (F["lapsharp"], LAP)]
+    _, alone = hbrt.run_job(lst, frames, use_hip=True)
+    jobs = [hbrt.Job(lst, 192, 108, use_hip=True) for _ in range(5)]
+    try:
+        ctxs = [flt.hbhip_host_job_ctx(j.job_ptr()) for j in jobs]
+        assert len(set(ctxs[:4])) == 4 and all(c is not None for c in ctxs[:4])
+        assert ctxs[4] is None                                    # no lease of its own: it shares
+        outs = [[] for _ in jobs]
+        for i, fr in enumerate(frames):
+            for k, j in enumerate(jobs):
+                j.push(fr, start=i * 3003, stop=(i + 1) * 3003)
+                outs[k] += j.drain()
+        for k, j in enumerate(jobs):
+            j.push_eof()
+            outs[k] += j.drain()
+        for o in outs:
+            same(o, alone)
+    finally:
+        for j in jobs:
+            j.close()
