@@ -35,6 +35,8 @@ timeout 200 python bench.py --workload chain --stage-streams 0 --no-cpu-baseline
 timeout 200 python bench.py --workload chain --streams 2 --stage-streams 0 --no-cpu-baseline --no-pcie --no-kernel-timer > $OUT/bench_chain_2streams.json 2>> $OUT/bench_default.err
 timeout 200 python bench.py --workload chain --comb-detect --no-cpu-baseline --no-pcie --no-kernel-timer > $OUT/bench_chain_combdetect.json 2>> $OUT/bench_default.err
 timeout 240 python tools/kernel_rooflines.py > $OUT/kernel_rooflines.json 2> $OUT/kernel_rooflines.err
+# the same table on 2160p frames: the 16 frames of a batched launch (199 MB in, 199 MB out) are past the 256 MB Infinity Cache
+KR_W=3840 KR_H=2160 timeout 400 python tools/kernel_rooflines.py > $OUT/kernel_rooflines_2160p.json 2> $OUT/kernel_rooflines_2160p.err
 cd /tmp
 PROF="env HBHIP_EEDI2_FORK=0 python $R/bench.py --workload chain --stage-streams 0 --steps 6 --warmup 2 --no-cpu-baseline --no-pcie --no-kernel-timer"
 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $PROF > $OUT/kt.log 2>&1
@@ -52,6 +54,8 @@ cd /tmp
 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_fork -o kt -- python $R/bench.py --workload chain --steps 6 --warmup 2 --no-cpu-baseline --no-pcie --no-kernel-timer > $OUT/kt_fork.log 2>&1
 cd $R
 python tools/trace_overlap.py $(find $OUT/kt_fork -name '*kernel_trace.csv' | head -1) $OUT/fork_overlap.json 250 > /dev/null 2>&1
+# the 10-bit chain under the same counters (tools/pmc_chain.sh)
+tools/pmc_chain.sh $TAG/chain10 --depth 10 > $OUT/chain10_bounds.txt 2>&1
 # keep only small files
 find $OUT -name '*kernel_trace.csv' -size +3M -delete
 find $OUT -name '*counter_collection.csv' -delete

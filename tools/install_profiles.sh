@@ -15,6 +15,13 @@ cp $S/pmc_summary.json profiles/${TAG}_chain_pmc_summary.json
 cp $S/trace_gaps.json profiles/${TAG}_chain_trace_gaps.json
 cp $S/kernel_bounds.json profiles/${TAG}_kernel_bounds.json
 cp $S/kernel_rooflines.json profiles/${TAG}_kernel_rooflines.json
+[ -s $S/kernel_rooflines_2160p.json ] && cp $S/kernel_rooflines_2160p.json profiles/${TAG}_kernel_rooflines_2160p.json
+if [ -d $S/chain10 ]; then
+  cp $S/chain10/kernel_stats.csv profiles/${TAG}_chain_10bit_kernel_stats.csv
+  cp $S/chain10/pmc_summary.json profiles/${TAG}_chain_10bit_pmc_summary.json
+  cp $S/chain10/kernel_bounds.json profiles/${TAG}_chain_10bit_kernel_bounds.json
+fi
+[ -f $S/pytest.log ] && cp $S/pytest.log profiles/${TAG}_pytest.log
 python tools/pmc_to_traffic.py $S/pmc_summary.json "profiles/${TAG}_chain_pmc_summary.json (tools/gpu_round.sh $TAG)" profiles/pmc_traffic.json
 RND=$(echo $TAG | sed -E 's/^(r[0-9]+).*/\1/')              # r5b -> r5: the static mixes are per round, not per session
 for K in eedi2 alias nlmeans; do
