@@ -394,6 +394,12 @@ def issue_floors(kname):
         return None
 
 
+# the guide's nominal vector issue rate: 256 CUs x 4 SIMDs x 2.4 GHz, a wave64 instruction every 2 cycles (MI355X_MICROARCH.md).
+# No kernel of this path can reach it: 70 % of NLMeans' instructions are in classes that issue every 4 cycles
+# (profiles/r02_valu_rate.json, r6_valu_rate_f16.json) - `frac` prices the kernel's own mix, `frac_of_nominal` this figure.
+NOMINAL_VALU = 256 * 4 * 2.4e9 / 2.0
+
+
 def valu_roofline(valu_insts, avg_s, kname=None):
     """wave64 VALU instructions (SQ_INSTS_VALU of the committed PMC pass) against the issue peak of the kernel's OWN
     instruction mix: its text classified by tools/isa_mix.py into the issue classes tools/valu_rate.hip measured on
@@ -412,6 +418,7 @@ def valu_roofline(valu_insts, avg_s, kname=None):
                    f"tools/valu_rate.hip (profiles/r02_valu_rate.json)")
             return {"insts_per_launch": int(valu_insts), "achieved_ginst_s": round(valu_insts / avg_s / 1e9, 1),
                     "peak_ginst_s": round(peak / 1e9, 1), "frac": round(valu_insts / avg_s / peak, 4),
+                    "nominal_ginst_s": round(NOMINAL_VALU / 1e9, 1), "frac_of_nominal": round(valu_insts / avg_s / NOMINAL_VALU, 4),
                     "cycles_per_wave_inst": cyc, "peak_source": src}
         except Exception:
             pass
@@ -426,6 +433,7 @@ def valu_roofline(valu_insts, avg_s, kname=None):
             pass
     return {"insts_per_launch": int(valu_insts), "achieved_ginst_s": round(valu_insts / avg_s / 1e9, 1),
             "peak_ginst_s": round(peak / 1e9, 1), "frac": round(valu_insts / avg_s / peak, 4),
+            "nominal_ginst_s": round(NOMINAL_VALU / 1e9, 1), "frac_of_nominal": round(valu_insts / avg_s / NOMINAL_VALU, 4),
             "cycles_per_wave_inst": cyc, "peak_source": src}
 
 
