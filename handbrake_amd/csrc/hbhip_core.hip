@@ -744,6 +744,11 @@ int hbhip_frame_alloc(hbhip_ctx *ctx, int width, int height, int depth, int lcw,
             ctx->frame_pool.erase(ctx->frame_pool.begin() + pick);
             fr->refs = 1;
             fr->ready.reset();
+            fr->last_user = nullptr;
+            fr->complete = false;
+            // taken although its last reader may still be running (the pool is at its bound): whoever fills it on this
+            // context's stream does so behind that reader, which may sit on another context's stream (hbhip_frame_use_on)
+            if (fr->pic.idle && fr->pic.idle->stream != ctx->stream) (void)hbhip_pic_wait_idle(ctx->stream, &fr->pic);
             *out = fr;
             return HBHIP_OK;
         }
@@ -794,8 +799,49 @@ void hbhip_frame_release(hbhip_frame *fr)
     std::lock_guard<std::mutex> lk(fr->ctx->frame_lock);
     if (--fr->refs > 0) return;
     (void)hipSetDevice(fr->ctx->device);
-    hbhip_pic_mark_idle(fr->ctx, &fr->pic);   // its users are all queued on the context's stream by now
+    // its users are all queued by now: on the context's stream, or on the stream of the context that read it last
+    hbhip_pic_mark_idle(fr->last_user ? fr->last_user : fr->ctx, &fr->pic);
     fr->ctx->frame_pool.push_back(fr);        // reuse is ordered by that event (uploads) or by the stream itself
+}
+
+// A filter on another context of the same GPU is about to queue work that reads the frame (a job whose filters run on
+// more than one HIP stream: libhb/hbhip_registry.c, hbhip_host_ctx_for_role).  Orders `ctx`'s stream behind the frame's
+// producer - its ready mark, nothing else of the owner's stream: the point of a second stream is not to wait for what
+// the first has queued since - and notes `ctx` as the stream the frame goes idle behind.  A frame that a second foreign
+// context (or its owner again) reads after the first is ordered behind that first reader's stream as it stands, so
+// that one idle mark still covers every reader.  No-op on the owner's context while nobody else has read the frame.
+int hbhip_frame_use_on(hbhip_frame *fr, hbhip_ctx *ctx)
+{
+    if (!fr || !ctx || ctx->device != fr->ctx->device) return HBHIP_ERR_ARG;
+    std::lock_guard<std::mutex> lk(fr->ctx->frame_lock);
+    hbhip_ctx *prev = fr->last_user ? fr->last_user : fr->ctx;
+    if (prev == ctx) return HBHIP_OK;
+    (void)hipSetDevice(ctx->device);
+    auto behind = [&](hbhip_ctx *of) -> int {          // ctx->stream behind everything queued on of->stream so far
+        hipEvent_t ev = of->sync_ev_get();
+        if (!ev) return ctx->fail(hipErrorOutOfMemory, "hipEventCreate(use_on)");
+        hipError_t e = hipEventRecord(ev, of->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ev, 0);
+        of->sync_ev_put(ev);                              // (the wait holds the event's state as recorded here)
+        return e == hipSuccess ? HBHIP_OK : ctx->fail(e, "use_on: order behind the frame's earlier users");
+    };
+    int rc = HBHIP_OK;
+    if (fr->last_user == nullptr || fr->last_user == fr->ctx)
+    {
+        // (the owner as the last user: it has written the frame again - the compositor - and marked it ready behind that)
+        if (fr->ready)
+        {
+            fr->ready->record_now();
+            const hipError_t e = hipStreamWaitEvent(ctx->stream, fr->ready->ev, 0);
+            if (e != hipSuccess) rc = ctx->fail(e, "use_on: order behind the frame's producer");
+        }
+        else if (!fr->complete)
+            rc = behind(fr->ctx);
+    }
+    else
+        rc = behind(prev);
+    if (rc == HBHIP_OK) fr->last_user = ctx;
+    return rc;
 }
 
 // The writability test of a device picture (fifo.c:624-639 asks av_buffer_is_writable the same thing): a holder that
@@ -836,7 +882,9 @@ int hbhip_frame_upload(hbhip_frame *fr, const hbhip_host_frame *src)
 {
     if (!fr || !src) return HBHIP_ERR_ARG;
     (void)hipSetDevice(fr->ctx->device);
-    return hbhip_copy_h2d(fr->ctx, &fr->pic, src);
+    const int rc = hbhip_copy_h2d(fr->ctx, &fr->pic, src);      // returns when the copy has finished
+    if (rc == HBHIP_OK && !fr->ready) fr->complete = true;
+    return rc;
 }
 
 int hbhip_frame_download(hbhip_frame *fr, const hbhip_host_frame *dst)

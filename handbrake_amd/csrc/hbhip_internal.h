@@ -197,6 +197,11 @@ struct hbhip_frame
     // hbhip_frame_mark_ready: the point of the context's stream behind which the frame's contents are complete -
     // a download waits for this point, not for whatever other filter threads have queued since
     std::shared_ptr<IdleMark> ready;      // (shared by the frames marked between two launches, like `idle`)
+    // A job may run its filters on more than one context of a GPU (hbhip_frame_use_on): the context whose stream the
+    // frame's newest reader sits on, if that is not the owner's - the frame goes idle behind THAT stream's work
+    // (frame_lock of the owner)
+    hbhip_ctx  *last_user = nullptr;
+    bool        complete = false;         // filled by a copy that has finished (hbhip_frame_upload): no producer to wait for
 };
 
 // Geometry of a planar YUV picture.

@@ -140,7 +140,9 @@ static hb_buffer_t *blend_hip_work(hb_blend_object_t *object, hb_buffer_t *in, h
             {
                 hbhip_dev_frame d;
                 hbhip_frame_describe(dev_frame, &d, NULL, NULL);
-                rc = hbhip_blend_apply_dev(pv->dev, &d);
+                /* the compositor writes on the frame's own context: behind whoever read it on another stream of the job */
+                rc = hbhip_frame_use_on(dev_frame, hbhip_frame_context(dev_frame));
+                if (rc == HBHIP_OK) rc = hbhip_blend_apply_dev(pv->dev, &d);
                 if (rc == HBHIP_OK) rc = hbhip_frame_mark_ready(dev_frame);    /* complete behind the compositor now */
             }
         }

@@ -103,7 +103,7 @@ static int comb_detect_hip_init(hb_filter_object_t *filter, hb_filter_init_t *in
     }
 
     pv->force_exhaustive = 1;              /* :1111 */
-    hbhip_ctx *ctx = hbhip_host_ctx_for(init);
+    hbhip_ctx *ctx = hbhip_host_ctx_for_role(init, 1);
     if (ctx == NULL) { free(wide_lut); goto fail; }
     int rc = hbhip_comb_detect_create(ctx, p, init->geometry.width, init->geometry.height, depth, &pv->dev);
     if (rc == HBHIP_OK && wide_lut != NULL)
@@ -153,7 +153,8 @@ static int store_ref(hb_filter_private_t *pv, hb_buffer_t *b, int repeat)
     {
         hbhip_dev_frame d;
         hbhip_frame_describe(fr, &d, NULL, NULL);
-        rc = hbhip_comb_detect_store_dev(pv->dev, d.plane[0], d.stride[0]);
+        rc = hbhip_frame_use_on(fr, hbhip_filter_context(pv->dev));
+        if (rc == HBHIP_OK) rc = hbhip_comb_detect_store_dev(pv->dev, d.plane[0], d.stride[0]);
     }
     else
         rc = hbhip_comb_detect_store(pv->dev, b->plane[0].data, b->plane[0].stride);
@@ -182,7 +183,9 @@ static hb_buffer_t *overlay_copy(hb_filter_private_t *pv, hb_buffer_t *src)
         if (arc != HBHIP_OK) return NULL;
         hbhip_dev_frame d;
         hbhip_frame_describe(dst, &d, NULL, NULL);
-        if (hbhip_frame_copy(dst, fr) != HBHIP_OK || hbhip_comb_detect_overlay_dev(pv->dev, &d, pw, ph) != HBHIP_OK)
+        /* (the copy is made on the frame's context, the mask drawn on the filter's: ordered behind the copy) */
+        if (hbhip_frame_copy(dst, fr) != HBHIP_OK || hbhip_frame_use_on(dst, hbhip_filter_context(pv->dev)) != HBHIP_OK ||
+            hbhip_comb_detect_overlay_dev(pv->dev, &d, pw, ph) != HBHIP_OK)
         {
             hbhip_frame_release(dst);
             return NULL;

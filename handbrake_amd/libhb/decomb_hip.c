@@ -96,7 +96,7 @@ static int decomb_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init)
         }
     }
 
-    hbhip_ctx *ctx = hbhip_host_ctx_for(init);
+    hbhip_ctx *ctx = hbhip_host_ctx_for_role(init, 1);
     if (ctx == NULL) goto fail;
     int rc = hbhip_decomb_create(ctx, p, init->geometry.width, init->geometry.height,
                                  desc->comp[0].depth, desc->log2_chroma_w, desc->log2_chroma_h, &pv->dev);
@@ -218,7 +218,8 @@ static int decomb_hip_work(hb_filter_object_t *filter, hb_buffer_t **buf_in, hb_
     {
         hbhip_dev_frame d;
         hbhip_frame_describe(fr, &d, NULL, NULL);
-        rc = hbhip_decomb_push_dev(pv->dev, &d, pv->next_tag++, in->s.flags, in->s.combed);
+        rc = hbhip_frame_use_on(fr, hbhip_filter_context(pv->dev));
+        if (rc == HBHIP_OK) rc = hbhip_decomb_push_dev(pv->dev, &d, pv->next_tag++, in->s.flags, in->s.combed);
     }
     else
     {
@@ -335,7 +336,7 @@ static int deint_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init, in
     }
     pv->selective = !!(mode & YADIF_SELECTIVE);
     const AVPixFmtDescriptor *desc = av_pix_fmt_desc_get(init->pix_fmt);
-    hbhip_ctx *ctx = desc != NULL ? hbhip_host_ctx_for(init) : NULL;
+    hbhip_ctx *ctx = desc != NULL ? hbhip_host_ctx_for_role(init, 1) : NULL;
     int rc = ctx == NULL ? HBHIP_ERR_NODEVICE
            : is_yadif    ? hbhip_yadif_create(ctx, !!(mode & YADIF_SPATIAL), !!(mode & YADIF_BOB), pv->selective, parity,
                                               init->geometry.width, init->geometry.height, desc->comp[0].depth,

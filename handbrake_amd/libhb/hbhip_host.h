@@ -19,6 +19,11 @@ int        hbhip_host_job_index_is_hip(const hb_job_t *job);     /* hw_device_in
 hbhip_ctx *hbhip_host_ctx_on(int device);
 hbhip_ctx *hbhip_host_ctx_for(const hb_filter_init_t *init);     /* what a drop-in's init() uses: the job's own stream on the job's GPU */
 hbhip_ctx *hbhip_host_job_ctx(const hb_job_t *job);              /* the context a live job has leased, or NULL */
+/* role 1 = the deinterlacing side of a job (comb detect, decomb, yadif, bwdif): a second context of the job's GPU unless
+ * HBHIP_JOB_STREAMS=1, then the job's own; hbhip_host_use_frame: called by every consumer of a device frame in front of the
+ * work that reads it (libhb/hbhip_registry.c) */
+hbhip_ctx *hbhip_host_ctx_for_role(const hb_filter_init_t *init, int role);
+int        hbhip_host_use_frame(hbhip_ctx *ctx, const hb_buffer_t *in);
 hbhip_ctx *hbhip_host_ctx(void);                                 /* the process default's context */
 void       hbhip_host_ctx_release(void);
 

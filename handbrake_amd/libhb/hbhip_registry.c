@@ -27,7 +27,7 @@
  * default: HBHIP_DEVICE from the environment, else 0, and a caller without a job slot 0 of it. */
 #define HBHIP_MAX_DEVICES 64
 #define HBHIP_CTX_SLOTS   4
-typedef struct { hbhip_ctx *ctx; const hb_job_t *job; int failed; } ctx_slot_t;
+typedef struct { hbhip_ctx *ctx; const hb_job_t *job; int failed; hbhip_ctx *aux; int aux_failed; } ctx_slot_t;
 static pthread_mutex_t g_ctx_lock = PTHREAD_MUTEX_INITIALIZER;
 static ctx_slot_t      g_slot[HBHIP_MAX_DEVICES][HBHIP_CTX_SLOTS];
 
@@ -111,6 +111,53 @@ hbhip_ctx *hbhip_host_ctx_for(const hb_filter_init_t *init)
     if (c == NULL && k > 0) c = slot_ctx(device, 0);                          /* (no further stream to be had: the shared one) */
     pthread_mutex_unlock(&g_ctx_lock);
     return c;
+}
+
+/* A SECOND stream inside a job (the default; HBHIP_JOB_STREAMS=1 turns it off): the deinterlacing side of a job's filter
+ * list - comb detect, decomb, yadif, bwdif: ids 4 - 9, always at the head of a device-resident run - gets a context of its
+ * own beside the job's, so that EEDI2 of the next frames runs beside NLMeans / scaler / sharpen of the current ones the way
+ * bench.py's device-resident line runs them (--stage-streams 2).  Frames then cross contexts: every consumer of a device
+ * frame orders its stream behind the frame's producer (hbhip_frame_use_on) - behind the producer only, not behind what
+ * the other stream has queued since - and the frame goes idle behind its last reader's stream.  Measured through the
+ * plugin surface (python -m handbrake_amd.hostpath): a list that ends in a 2160p download is bound by the bus
+ * either way (4 068 / 4 101 fps); the same list scaled to 960 x 540 runs at 4 800 fps on one stream and 5 900 - 6 250 on two. */
+#define HBHIP_ROLE_MAIN        0
+#define HBHIP_ROLE_DEINTERLACE 1
+static int job_streams(void)
+{
+    const char *e = getenv("HBHIP_JOB_STREAMS");
+    return e != NULL && atoi(e) == 1 ? 1 : 2;
+}
+
+hbhip_ctx *hbhip_host_ctx_for_role(const hb_filter_init_t *init, int role)
+{
+    hbhip_ctx *main_ctx = hbhip_host_ctx_for(init);
+    if (main_ctx == NULL || role != HBHIP_ROLE_DEINTERLACE || job_streams() < 2) return main_ctx;
+    hbhip_ctx *aux = NULL;
+    pthread_mutex_lock(&g_ctx_lock);
+    for (int d = 0; d < HBHIP_MAX_DEVICES && aux == NULL; d++)
+        for (int i = 0; i < HBHIP_CTX_SLOTS; i++)
+        {
+            ctx_slot_t *sl = &g_slot[d][i];
+            if (sl->ctx != main_ctx) continue;
+            if (sl->aux == NULL && !sl->aux_failed && hbhip_ctx_create(d, &sl->aux) != HBHIP_OK)
+            {
+                sl->aux = NULL;
+                sl->aux_failed = 1;
+            }
+            aux = sl->aux;
+            break;
+        }
+    pthread_mutex_unlock(&g_ctx_lock);
+    return aux != NULL ? aux : main_ctx;
+}
+
+/* a filter on `ctx` is about to queue work that reads `in`: see above (nothing to do for host frames / one stream) */
+int hbhip_host_use_frame(hbhip_ctx *ctx, const hb_buffer_t *in)
+{
+    hbhip_frame *fr = in != NULL ? hbhip_host_frame_of(in) : NULL;
+    if (fr == NULL || ctx == NULL) return HBHIP_OK;
+    return hbhip_frame_use_on(fr, ctx);
 }
 
 /* the job's lease, if it has one (tests) */
@@ -272,6 +319,8 @@ int hbhip_host_push(hbhip_filter *dev, const hb_buffer_t *in, int64_t tag)
     {
         hbhip_dev_frame d;
         hbhip_frame_describe(fr, &d, NULL, NULL);
+        const int urc = hbhip_frame_use_on(fr, hbhip_filter_context(dev));
+        if (urc != HBHIP_OK) return urc;
         return hbhip_filter_push_dev(dev, &d, tag);
     }
     hbhip_host_frame hf;
@@ -384,7 +433,8 @@ int hbhip_host_simple_work(hbhip_filter *dev, const hb_filter_init_t *output, co
             int n = 0;
             hbhip_frame_describe(src, &di, NULL, NULL);
             hbhip_frame_describe(dst, &dd, NULL, NULL);
-            rc = hbhip_filter_process_dev(dev, &di, 1, 0, &dd, 1, &n);
+            rc = hbhip_frame_use_on(src, hbhip_filter_context(dev));
+            if (rc == HBHIP_OK) rc = hbhip_filter_process_dev(dev, &di, 1, 0, &dd, 1, &n);
             if (rc == HBHIP_OK && n == 1)
             {
                 hbhip_frame_mark_ready(dst);

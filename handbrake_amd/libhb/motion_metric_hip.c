@@ -15,6 +15,7 @@
 struct hb_motion_metric_private_s
 {
     hbhip_motion_metric *dev;
+    hbhip_ctx *ctx;                  /* the context the metric's kernels run on (the job's) */
 };
 
 static int motion_metric_hip_init(hb_motion_metric_object_t *metric, hb_filter_init_t *init)
@@ -37,6 +38,7 @@ static int motion_metric_hip_init(hb_motion_metric_object_t *metric, hb_filter_i
         for (int i = 0; i <= max_value; i++)
             lut[i] = 4095 * pow(((float)i / (float)(max_value - 1)), 2.2f);
         rc = hbhip_motion_metric_create(ctx, init->geometry.width, init->geometry.height, depth, lut, max_value + 1, &pv->dev);
+        pv->ctx = ctx;
     }
     free(lut);
     if (rc != HBHIP_OK)
@@ -60,7 +62,9 @@ static float motion_metric_hip_work(hb_motion_metric_object_t *metric, hb_buffer
         hbhip_dev_frame da, db;
         hbhip_frame_describe(fa, &da, NULL, NULL);
         hbhip_frame_describe(fb, &db, NULL, NULL);
-        rc = hbhip_motion_metric_run_dev(pv->dev, da.plane[0], da.stride[0], db.plane[0], db.stride[0], &value);
+        rc = hbhip_frame_use_on(fa, pv->ctx);                    /* frames of another stream of the job (decomb's): behind their producer */
+        if (rc == HBHIP_OK) rc = hbhip_frame_use_on(fb, pv->ctx);
+        if (rc == HBHIP_OK) rc = hbhip_motion_metric_run_dev(pv->dev, da.plane[0], da.stride[0], db.plane[0], db.stride[0], &value);
     }
     else
         rc = hbhip_motion_metric_run(pv->dev, buf_a->plane[0].data, buf_a->plane[0].stride,

@@ -114,6 +114,10 @@ int  hbhip_frame_alloc(hbhip_ctx *ctx, int width, int height, int depth,
                        int log2_chroma_w, int log2_chroma_h, hbhip_frame **out);
 void hbhip_frame_retain(hbhip_frame *fr);
 void hbhip_frame_release(hbhip_frame *fr);            /* back to the pool at refcount 0 */
+/* A filter on ANOTHER context of the same GPU is about to queue work that reads the frame: its stream is ordered behind
+ * the frame's producer (the ready mark only) and the frame goes idle behind that stream (a job with more than one HIP
+ * stream, libhb/hbhip_registry.c).  No-op for the owner's context while nobody else has read the frame. */
+int  hbhip_frame_use_on(hbhip_frame *fr, hbhip_ctx *ctx);
 int  hbhip_frame_refs(hbhip_frame *fr);               /* holders right now; 1 = the caller is the only one (it may write in place) */
 int  hbhip_frame_describe(hbhip_frame *fr, hbhip_dev_frame *out, int *width, int *height);
 hbhip_ctx *hbhip_frame_context(hbhip_frame *fr);      /* the context (device, stream) whose pool the frame belongs to */
