@@ -260,27 +260,45 @@ static size_t layout_bytes(const DevPicture *p)
     return (size_t)(p->plane[2] - p->plane[0]) + (size_t)p->pitch[2] * p->height[2];
 }
 
-int hbhip_copy_h2d(hbhip_ctx *ctx, DevPicture *dst, const hbhip_host_frame *src)
+// the H2D copy of a frame queued on the context's upload stream, and an event behind it (from the context's pool: the
+// caller gives it back with sync_ev_put once it has fired)
+static int hbhip_copy_h2d_queue(hbhip_ctx *ctx, DevPicture *dst, const hbhip_host_frame *src, hipEvent_t *done_out)
 {
     for (int c = 0; c < 3; c++)
         if (src->plane[c] == nullptr || src->stride[c] < dst->width[c] * dst->bps) return HBHIP_ERR_ARG;
     hipEvent_t done = ctx->sync_ev_get();
     if (!done) return ctx->fail(hipErrorOutOfMemory, "hipEventCreate(upload)");
-    // whatever still reads the picture's previous contents was queued on ctx->stream before it was recycled
-    HBHIP_CHECK(ctx, hbhip_pic_wait_idle(ctx->up_stream, dst));
+    auto fail = [&](hipError_t e, const char *what) { ctx->sync_ev_put(done); return ctx->fail(e, what); };
+    // whatever still reads the picture's previous contents was queued ahead of its idle mark when it was recycled
+    hipError_t e = hbhip_pic_wait_idle(ctx->up_stream, dst);
+    if (e != hipSuccess) return fail(e, "upload: wait for the picture's last reader");
     if (same_layout(dst, src->plane, src->stride))
-        HBHIP_CHECK(ctx, hipMemcpyAsync(dst->plane[0], src->plane[0], layout_bytes(dst), hipMemcpyHostToDevice, ctx->up_stream));
+        e = hipMemcpyAsync(dst->plane[0], src->plane[0], layout_bytes(dst), hipMemcpyHostToDevice, ctx->up_stream);
     else
-        for (int c = 0; c < 3; c++)
+        for (int c = 0; c < 3 && e == hipSuccess; c++)
         {
             const size_t row = (size_t)std::min(src->stride[c], dst->pitch[c]);
-            HBHIP_CHECK(ctx, hipMemcpy2DAsync(dst->plane[c], dst->pitch[c], src->plane[c], src->stride[c],
-                                              row, dst->height[c], hipMemcpyHostToDevice, ctx->up_stream));
+            e = hipMemcpy2DAsync(dst->plane[c], dst->pitch[c], src->plane[c], src->stride[c],
+                                 row, dst->height[c], hipMemcpyHostToDevice, ctx->up_stream);
         }
+    if (e == hipSuccess) e = hipEventRecord(done, ctx->up_stream);
+    if (e != hipSuccess)
+    {
+        (void)hipStreamSynchronize(ctx->up_stream);                // planes already queued must not outlive the call
+        return fail(e, "hipMemcpyAsync(upload)");
+    }
+    *done_out = done;
+    return HBHIP_OK;
+}
+
+int hbhip_copy_h2d(hbhip_ctx *ctx, DevPicture *dst, const hbhip_host_frame *src)
+{
+    hipEvent_t done = nullptr;
+    const int rc = hbhip_copy_h2d_queue(ctx, dst, src, &done);
+    if (rc != HBHIP_OK) return rc;
     // The caller may free or reuse its planes as soon as we return (filter_loop closes buf_in, work.c:2566-2569):
     // wait for THIS copy - not for the kernels other filters have queued.  Once it has completed, work launched
     // on any stream afterwards sees the data.
-    HBHIP_CHECK(ctx, hipEventRecord(done, ctx->up_stream));
     const hipError_t e = hipEventSynchronize(done);
     ctx->sync_ev_put(done);
     if (e != hipSuccess) return ctx->fail(e, "hipEventSynchronize(upload)");
@@ -814,9 +832,19 @@ int hbhip_frame_use_on(hbhip_frame *fr, hbhip_ctx *ctx)
 {
     if (!fr || !ctx || ctx->device != fr->ctx->device) return HBHIP_ERR_ARG;
     std::lock_guard<std::mutex> lk(fr->ctx->frame_lock);
+    (void)hipSetDevice(ctx->device);
+    bool waited_ready = false;
+    if (fr->ready && fr->ready->stream != ctx->stream)
+    {
+        // the producer sits on another stream: the owner's (a foreign reader), or the upload stream (every reader, the
+        // owner's context included: hbhip_frame_upload_async)
+        fr->ready->record_now();
+        const hipError_t e = hipStreamWaitEvent(ctx->stream, fr->ready->ev, 0);
+        if (e != hipSuccess) return ctx->fail(e, "use_on: order behind the frame's producer");
+        waited_ready = true;
+    }
     hbhip_ctx *prev = fr->last_user ? fr->last_user : fr->ctx;
     if (prev == ctx) return HBHIP_OK;
-    (void)hipSetDevice(ctx->device);
     auto behind = [&](hbhip_ctx *of) -> int {          // ctx->stream behind everything queued on of->stream so far
         hipEvent_t ev = of->sync_ev_get();
         if (!ev) return ctx->fail(hipErrorOutOfMemory, "hipEventCreate(use_on)");
@@ -829,14 +857,7 @@ int hbhip_frame_use_on(hbhip_frame *fr, hbhip_ctx *ctx)
     if (fr->last_user == nullptr || fr->last_user == fr->ctx)
     {
         // (the owner as the last user: it has written the frame again - the compositor - and marked it ready behind that)
-        if (fr->ready)
-        {
-            fr->ready->record_now();
-            const hipError_t e = hipStreamWaitEvent(ctx->stream, fr->ready->ev, 0);
-            if (e != hipSuccess) rc = ctx->fail(e, "use_on: order behind the frame's producer");
-        }
-        else if (!fr->complete)
-            rc = behind(fr->ctx);
+        if (!waited_ready && !fr->ready && !fr->complete) rc = behind(fr->ctx);     // no mark to go by: the owner's stream as it stands
     }
     else
         rc = behind(prev);
@@ -873,6 +894,12 @@ int hbhip_frame_copy(hbhip_frame *dst, hbhip_frame *src)
         dst->lcw != src->lcw || dst->lch != src->lch)
         return HBHIP_ERR_ARG;
     (void)hipSetDevice(dst->ctx->device);
+    if (src->ready && src->ready->stream != dst->ctx->stream)              // (a frame whose upload is still in flight)
+    {
+        src->ready->record_now();
+        const hipError_t e = hipStreamWaitEvent(dst->ctx->stream, src->ready->ev, 0);
+        if (e != hipSuccess) return dst->ctx->fail(e, "frame_copy: order behind the source's producer");
+    }
     hbhip_dev_frame d;
     for (int c = 0; c < 3; c++) { d.plane[c] = src->pic.plane[c]; d.stride[c] = src->pic.pitch[c]; }
     return hbhip_copy_d2d_in(dst->ctx, &dst->pic, &d);
@@ -885,6 +912,54 @@ int hbhip_frame_upload(hbhip_frame *fr, const hbhip_host_frame *src)
     const int rc = hbhip_copy_h2d(fr->ctx, &fr->pic, src);      // returns when the copy has finished
     if (rc == HBHIP_OK && !fr->ready) fr->complete = true;
     return rc;
+}
+
+// The pipelined H2D (the upload adapter keeps a few in flight, as the download adapter does with its copies): the copy is
+// queued on the upload stream and the call returns; `src` must stay valid until hbhip_ctx_upload_done(token) says so.  The
+// frame's ready mark is the copy's event, so whoever reads the frame - on any context: hbhip_frame_use_on,
+// hbhip_frame_copy, a download - waits for the copy and for nothing else.
+int hbhip_frame_upload_async(hbhip_frame *fr, const hbhip_host_frame *src, void **token)
+{
+    if (!fr || !src || !token) return HBHIP_ERR_ARG;
+    *token = nullptr;
+    hbhip_ctx *ctx = fr->ctx;
+    (void)hipSetDevice(ctx->device);
+    std::shared_ptr<IdleMark> m = std::make_shared<IdleMark>();
+    if (hipEventCreateWithFlags(&m->ev, hipEventDisableTiming) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        return ctx->fail(hipErrorOutOfMemory, "hipEventCreate(upload ready)");
+    }
+    hipEvent_t done = nullptr;
+    const int rc = hbhip_copy_h2d_queue(ctx, &fr->pic, src, &done);
+    if (rc != HBHIP_OK) return rc;
+    m->stream = ctx->up_stream;
+    const hipError_t e = hipEventRecord(m->ev, ctx->up_stream);
+    if (e != hipSuccess)
+    {
+        (void)hipEventSynchronize(done);
+        ctx->sync_ev_put(done);
+        return ctx->fail(e, "hipEventRecord(upload ready)");
+    }
+    m->recorded = true;
+    m->closed.store(true, std::memory_order_release);
+    fr->ready = m;
+    fr->complete = false;
+    *token = done;
+    return HBHIP_OK;
+}
+
+// has the copy behind `token` finished (block != 0: wait for it)?  HBHIP_OK: yes, the source planes are free again and the
+// token is spent; HBHIP_AGAIN: not yet (block == 0 only)
+int hbhip_ctx_upload_done(hbhip_ctx *ctx, void *token, int block)
+{
+    if (!ctx || !token) return HBHIP_ERR_ARG;
+    (void)hipSetDevice(ctx->device);
+    hipEvent_t ev = (hipEvent_t)token;
+    hipError_t e = block ? hipEventSynchronize(ev) : hipEventQuery(ev);
+    if (e == hipErrorNotReady) { (void)hipGetLastError(); return HBHIP_AGAIN; }
+    ctx->sync_ev_put(ev);
+    return e == hipSuccess ? HBHIP_OK : ctx->fail(e, "upload: wait for the copy");
 }
 
 int hbhip_frame_download(hbhip_frame *fr, const hbhip_host_frame *dst)

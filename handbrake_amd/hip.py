@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "hbhip_ctx_profile_count", "hbhip_ctx_profile_get", "hbhip_ctx_mark", "hbhip_ctx_elapsed_ms",
     "hbhip_dev_alloc", "hbhip_dev_free", "hbhip_dev_upload", "hbhip_dev_download",
     "hbhip_frame_alloc", "hbhip_frame_retain", "hbhip_frame_release", "hbhip_frame_refs", "hbhip_frame_use_on", "hbhip_frame_describe", "hbhip_frame_copy",
-    "hbhip_frame_upload", "hbhip_frame_download", "hbhip_frame_mark_ready", "hbhip_frame_download_async", "hbhip_frame_download_wait",
+    "hbhip_frame_upload", "hbhip_frame_upload_async", "hbhip_ctx_upload_done", "hbhip_frame_download", "hbhip_frame_mark_ready", "hbhip_frame_download_async", "hbhip_frame_download_wait",
     "hbhip_filter_push", "hbhip_filter_push_dev", "hbhip_filter_pull", "hbhip_filter_pull_dev",
     "hbhip_filter_process_dev", "hbhip_filter_submit_async", "hbhip_filter_wait", "hbhip_filter_inflight", "hbhip_filter_flush", "hbhip_filter_pending", "hbhip_filter_defer", "hbhip_filter_kick", "hbhip_filter_destroy",
     "hbhip_filter_out_geometry",

@@ -504,6 +504,12 @@ int hbhip_host_simple_work(hbhip_filter *dev, const hb_filter_init_t *output, co
  * HB_FILTER_DELAY until its pipe is full. */
 #define DL_DEPTH 6
 typedef struct { hb_buffer_t *in, *out; void *token; } dl_slot_t;
+/* The upload adapter keeps UL_DEPTH copies in flight on the context's upload stream: the device frame goes downstream at
+ * once - its readers wait for the copy, hbhip_frame_use_on - while the host buffer stays with the adapter until the copy
+ * has finished (a synchronous copy per frame held the thread for a bus round trip each: 0.27 ms of a 0.32 ms frame
+ * period on a list that the GPU, not the download, bounds). */
+#define UL_DEPTH 4
+typedef struct { hb_buffer_t *in; void *token; } ul_slot_t;
 
 struct hb_filter_private_s
 {
@@ -513,6 +519,8 @@ struct hb_filter_private_s
     hbhip_ctx       *ctx;                 /* the job's GPU (hbhip_host_ctx_for) */
     dl_slot_t        dl[DL_DEPTH + 1];
     int              dl_head, dl_count;
+    ul_slot_t        ul[UL_DEPTH];
+    int              ul_head, ul_count;
 };
 
 static int adapter_init(hb_filter_object_t *filter, hb_filter_init_t *init, int to_device)
@@ -537,6 +545,7 @@ static int adapter_init(hb_filter_object_t *filter, hb_filter_init_t *init, int 
     return 0;
 }
 
+static int ul_retire(hb_filter_private_t *pv, int all);
 static int upload_init(hb_filter_object_t *f, hb_filter_init_t *init)   { return adapter_init(f, init, 1); }
 static int download_init(hb_filter_object_t *f, hb_filter_init_t *init) { return adapter_init(f, init, 0); }
 
@@ -557,6 +566,7 @@ static void adapter_close(hb_filter_object_t *filter)
 {
     hb_filter_private_t *pv = filter->private_data;
     if (pv == NULL) return;
+    (void)ul_retire(pv, 1);                            /* copies still in flight read the host buffers: wait them out */
     while (pv->dl_count > 0)                           /* a cancelled job: drop what is still in the pipe */
     {
         hb_buffer_t *o = dl_collect(pv);
@@ -566,29 +576,57 @@ static void adapter_close(hb_filter_object_t *filter)
     filter->private_data = NULL;
 }
 
+/* give back the host buffers whose copies have finished (all of them when `all` - then the oldest ones are waited for) */
+static int ul_retire(hb_filter_private_t *pv, int all)
+{
+    int rc = HBHIP_OK;
+    while (pv->ul_count > 0)
+    {
+        ul_slot_t *s = &pv->ul[pv->ul_head];
+        const int d = hbhip_ctx_upload_done(pv->ctx, s->token, all || pv->ul_count >= UL_DEPTH);
+        if (d == HBHIP_AGAIN) break;
+        if (d != HBHIP_OK) rc = d;                      /* (the buffer is released all the same: nothing reads it any more) */
+        hb_buffer_close(&s->in);
+        pv->ul_head = (pv->ul_head + 1) % UL_DEPTH;
+        pv->ul_count--;
+    }
+    return rc;
+}
+
 static int upload_work(hb_filter_object_t *filter, hb_buffer_t **buf_in, hb_buffer_t **buf_out)
 {
     hb_filter_private_t *pv = filter->private_data;
     hb_buffer_t *in = *buf_in;
     if ((in->s.flags & HB_BUF_FLAG_EOF) || hbhip_host_frame_of(in) != NULL)
     {
+        if (ul_retire(pv, (in->s.flags & HB_BUF_FLAG_EOF) != 0) != HBHIP_OK) return HB_FILTER_FAILED;
         *buf_out = in;
         *buf_in = NULL;
         return (in->s.flags & HB_BUF_FLAG_EOF) ? HB_FILTER_DONE : HB_FILTER_OK;
     }
+    if (ul_retire(pv, 0) != HBHIP_OK) return HB_FILTER_FAILED;       /* makes room: waits for the oldest copy when the ring is full */
     hbhip_frame *fr = NULL;
     hbhip_host_frame hf;
     hbhip_host_frame_from_buf(&hf, in);
     if (hbhip_frame_alloc(pv->ctx, in->f.width, in->f.height, pv->depth, pv->lcw, pv->lch, &fr) != HBHIP_OK)
         return HB_FILTER_FAILED;
-    if (hbhip_frame_upload(fr, &hf) != HBHIP_OK)
+    void *token = NULL;
+    if (hbhip_frame_upload_async(fr, &hf, &token) != HBHIP_OK)
     {
         hbhip_frame_release(fr);
         return HB_FILTER_FAILED;
     }
     hb_buffer_t *out = hbhip_host_wrap_frame(fr, &pv->output, in->f.width, in->f.height);
-    if (out == NULL) return HB_FILTER_FAILED;
+    if (out == NULL)
+    {
+        (void)hbhip_ctx_upload_done(pv->ctx, token, 1);
+        return HB_FILTER_FAILED;
+    }
     hb_buffer_copy_props(out, in);
+    ul_slot_t *s = &pv->ul[(pv->ul_head + pv->ul_count) % UL_DEPTH];
+    s->in = in; s->token = token;
+    pv->ul_count++;
+    *buf_in = NULL;                                     /* ours until its copy has finished */
     *buf_out = out;
     return HB_FILTER_OK;
 }

@@ -124,6 +124,11 @@ hbhip_ctx *hbhip_frame_context(hbhip_frame *fr);      /* the context (device, st
 int  hbhip_frame_copy(hbhip_frame *dst, hbhip_frame *src);                  /* same geometry; stream-ordered D2D */
 int  hbhip_frame_upload(hbhip_frame *fr, const hbhip_host_frame *src);      /* H2D, returns when src is consumed */
 int  hbhip_frame_download(hbhip_frame *fr, const hbhip_host_frame *dst);    /* D2H, synchronous */
+/* The pipelined H2D: the copy is queued on the context's upload stream and the call returns; `src` must stay valid until
+ * hbhip_ctx_upload_done(ctx, token, block) has answered HBHIP_OK (HBHIP_AGAIN: not yet; block != 0 waits).  The frame's
+ * ready mark is the copy itself: readers (hbhip_frame_use_on, hbhip_frame_copy, a download) wait for it and nothing else. */
+int  hbhip_frame_upload_async(hbhip_frame *fr, const hbhip_host_frame *src, void **token);
+int  hbhip_ctx_upload_done(hbhip_ctx *ctx, void *token, int block);
 /* The producer of a frame marks the point of the context's stream behind which its contents are complete; a
  * download then waits for that point only (not for what other filter threads have queued since).  The pipelined
  * D2H: queue the copy on the download stream and return; `dst` and the frame must stay valid until
