@@ -38,3 +38,21 @@ def test_decomb_really_sits_on_a_context_of_its_own(registered, monkeypatch):
         monkeypatch.delenv("HBHIP_JOB_STREAMS")
         b = flt.hbhip_host_ctx_for_role(init, 1)
         assert b is not None and b != a                                               # the default: two
+
+
+@pytest.mark.parametrize("w,h,n", [(1920, 1080, 96), (320, 180, 400)])
+def test_two_streams_equal_one_stream_over_a_long_run(with_vfr, monkeypatch, w, h, n):
+    """A long run at full speed through [comb detect, decomb 63, vfr (duplicates), nlmeans, lapsharp], one thread per filter:
+    frames cross from the job's context to decomb's and back while both streams are busy, pool frames are recycled many
+    times over (hbhip_frame_use_on's idle marks) and the upload adapter has copies in flight - the pictures of the default
+    (two streams) must equal those of one stream, frame for frame."""
+    base = synth.stream("interlaced", w, h, 8, cfg=3)
+    frames = [base[i % 8] for i in range(n)]
+    F = hbrt.FILTER_ID
+    lst = [(F["comb_detect"], ""), (F["decomb"], "mode=63"), (11, "mode=1:rate=60000/1001"),
+           (F["nlmeans"], hip.NLMEANS_MEDIUM + ":threads=2"), (F["lapsharp"], "y-strength=0.2:y-kernel=isolap")]
+    _, one = hbrt.run_job(lst, frames, flags=0x0008, use_hip=True)              # this module's setting: one stream
+    monkeypatch.delenv("HBHIP_JOB_STREAMS")
+    _, two = hbrt.run_job(lst, frames, flags=0x0008, use_hip=True)
+    assert len(one) == len(two) >= n
+    same(two, one)
