@@ -619,7 +619,8 @@ static int upload_work(hb_filter_object_t *filter, hb_buffer_t **buf_in, hb_buff
     hb_buffer_t *out = hbhip_host_wrap_frame(fr, &pv->output, in->f.width, in->f.height);
     if (out == NULL)
     {
-        (void)hbhip_ctx_upload_done(pv->ctx, token, 1);
+        (void)hbhip_ctx_upload_done(pv->ctx, token, 1);            /* the copy reads `in`, which the caller closes */
+        hbhip_frame_release(fr);
         return HB_FILTER_FAILED;
     }
     hb_buffer_copy_props(out, in);
