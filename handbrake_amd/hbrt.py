@@ -122,6 +122,22 @@ class Chain:
         if rc != 0:
             raise RuntimeError(f"hbh_chain_push failed ({rc})")
 
+    def feed(self, frames, first: int, count: int, duration: int = 3003, flags: int = 0x10, threads: int = 4):
+        """`count` frames cycling through the pictures of `frames` (same shapes), numbered from `first`: copied into
+        hb_buffer_t's by `threads` C threads and pushed in order (hbh_chain_feed) - a source that keeps up"""
+        n = len(frames)
+        keep = [[np.ascontiguousarray(p) for p in fr] for fr in frames]
+        ptrs = (C.c_void_p * (3 * n))(*[p.ctypes.data for fr in keep for p in fr])
+        strides = (C.c_int * 3)(*[p.strides[0] for p in keep[0]])
+        for fr in keep:
+            assert [p.strides[0] for p in fr] == list(strides)
+        self._rt.hbh_chain_feed.restype = C.c_int
+        self._rt.hbh_chain_feed.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int,
+                                            C.c_int64, C.c_int, C.c_int]
+        rc = self._rt.hbh_chain_feed(self._h, ptrs, strides, n, first, count, duration, flags, threads)
+        if rc != 0:
+            raise RuntimeError(f"hbh_chain_feed failed ({rc})")
+
     def push_eof(self):
         rc = self._rt.hbh_chain_push_eof(self._h)
         if rc != 0:

@@ -41,20 +41,19 @@ def chain_for(workload, scale, vfr=True):
     return chain
 
 
-def run(workload, w, h, scale, cfg=3, n_warm=32, n_in=2048, chain=None, content="interlaced"):
+def run(workload, w, h, scale, cfg=3, n_warm=32, n_in=2048, chain=None, content="interlaced", feeders=4):
     """Timed from a warmed-up, quiet pipeline (n_warm frames in, their outputs out as far as the batching stages let
     them: allocations, pinned pool, slabs all made) to the end of the stream n_in frames later, EOF drain included.
     The frames the last stage makes are counted and dropped as they come, as an encoder that keeps up would."""
     from handbrake_amd import hbrt, hip, synth
     chain = chain or chain_for(workload, scale)
     frames = synth.stream(content, w, h, 48, cfg=cfg)          # a 48-frame stream walked round and round
-    seq = [frames[i % len(frames)] for i in range(n_warm + n_in)]
     hbrt.set_threaded(True)
     hbrt.set_discard_output(True)
     try:
         with hbrt.Chain(hip.filters(), chain, w, h) as ch:
-            for i in range(n_warm):
-                ch.push(seq[i], start=i * 3003, stop=(i + 1) * 3003, flags=8)
+            # the source: `feeders` C threads fill hb_buffer_t's (the decoder's part in libhb) and the frames go in in order
+            ch.feed(frames, 0, n_warm, flags=8, threads=feeders)
             t_wait, last, t_last = time.perf_counter(), -1, time.perf_counter()
             while time.perf_counter() - t_wait < 60:
                 n = ch.produced()
@@ -66,8 +65,7 @@ def run(workload, w, h, scale, cfg=3, n_warm=32, n_in=2048, chain=None, content=
             n0 = ch.produced()
             t0 = time.perf_counter()
             busy0 = [ch.stage_busy_ms(s) for s in range(len(chain))]
-            for i in range(n_warm, n_warm + n_in):
-                ch.push(seq[i], start=i * 3003, stop=(i + 1) * 3003, flags=8)
+            ch.feed(frames, n_warm, n_in, flags=8, threads=feeders)
             ch.push_eof()                         # returns when every stage has finished
             dt = time.perf_counter() - t0
             total_out = ch.produced()
@@ -84,7 +82,7 @@ def run(workload, w, h, scale, cfg=3, n_warm=32, n_in=2048, chain=None, content=
     return {"value": round(n_out / dt, 2), "unit": "output frames/s", "input_fps": round(n_in / dt, 2),
             "path": "hb_filter_object_t chain (" + " -> ".join(c[0].replace("hb_filter_", "") for c in chain) + ") in the libhb "
                     "stand-in harness, one thread per filter with libhb's bounded fifos between them, pinned host "
-                    "hb_buffer_t in and out, in a process of its own; output frames dropped as they arrive",
+                    "hb_buffer_t in and out (the source: %d threads filling them), in a process of its own; output frames dropped as they arrive" % feeders,
             "pcie_GBps": round((n_in * frame_bytes(w, h) + n_out * frame_bytes(ow, oh)) / dt / 1e9, 2),
             "stage_thread_busy_fraction": busy, "n_out": n_out, "seconds": round(dt, 4),
             "sample": f"{n_in} input frames after {n_warm} of warm-up -> {n_out} output frames credited ({n_late} more were "
@@ -103,13 +101,14 @@ def main():
     ap.add_argument("--no-vfr", action="store_true", help="leave the frame-rate shaper out of the list (round 4's list)")
     ap.add_argument("--content", default="interlaced", help="picture model of handbrake_amd/synth.py")
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--feeders", type=int, default=4, help="threads of the source (copy pictures into pinned hb_buffer_t's)")
     a = ap.parse_args()
     os.environ["HBHIP_DEVICE"] = str(a.device)          # the drop-ins' shared context (libhb/hbhip_registry.c)
     sys.path.insert(0, ROOT)
     scale = None if a.scale == "none" else tuple(int(v) for v in a.scale.split("x"))
     try:
         res = run(a.workload, a.width, a.height, scale, cfg=a.cfg, n_in=a.frames,
-                  chain=chain_for(a.workload, scale, vfr=not a.no_vfr), content=a.content)
+                  chain=chain_for(a.workload, scale, vfr=not a.no_vfr), content=a.content, feeders=a.feeders)
     except Exception as e:                               # the caller never loses its own line over this pass
         res = {"error": repr(e), "n_out": 0, "seconds": 0.0}
     print(json.dumps(res), flush=True)

@@ -57,6 +57,10 @@ double hbh_chain_stage_busy_ms(hbh_chain_t *c, int stage);
 void hbh_set_source_color(int prim, int transfer, int matrix, int range);
 int  hbh_chain_push(hbh_chain_t *c, const uint8_t *const plane[3], const int stride[3],
                     int64_t start, int64_t stop, int flags, int combed);
+/* `count` frames from `n_unique` prepared pictures (plane[3 * k + p], one stride per plane), numbered first, first + 1, ...:
+ * filled by `nthreads` threads (the decoder's part in libhb), pushed in order; returns when the last one is in */
+int  hbh_chain_feed(hbh_chain_t *c, const uint8_t *const *plane, const int stride[3], int n_unique, int first, int count,
+                    int64_t duration, int flags, int nthreads);
 int  hbh_chain_push_eof(hbh_chain_t *c);
 int  hbh_chain_pending(hbh_chain_t *c);
 int  hbh_chain_peek(hbh_chain_t *c, hbh_frame_info_t *info);
