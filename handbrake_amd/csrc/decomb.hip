@@ -475,6 +475,8 @@ public:
         if (p) { p->refs = 0; p->flags = next_flags; p->combed = next_combed; }
         return p;
     }
+    int use_frames() override { pool.use_frames(true); frames_mode = true; return HBHIP_OK; }
+    void adopt_input(DevPicture *p) override { p->refs = 0; p->flags = next_flags; p->combed = next_combed; }
 
     int submit(DevPicture *pic) override
     {
@@ -805,6 +807,15 @@ extern "C" int hbhip_decomb_push_dev(hbhip_filter *f, const hbhip_dev_frame *in,
     d->next_flags = pic_flags;
     d->next_combed = combed;
     return hbhip_filter_push_dev(f, in, tag);
+}
+
+extern "C" int hbhip_decomb_push_frame(hbhip_filter *f, hbhip_frame *fr, int64_t tag, int pic_flags, int combed)
+{
+    DecombFilter *d = dynamic_cast<DecombFilter *>(f);
+    if (!d) return HBHIP_ERR_ARG;
+    d->next_flags = pic_flags;
+    d->next_combed = combed;
+    return hbhip_filter_push_frame(f, fr, tag);
 }
 
 // Test hook: download one plane of one EEDI2 scratch frame (0..3 = eedi_half[],

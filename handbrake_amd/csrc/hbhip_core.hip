@@ -184,6 +184,12 @@ void PicturePool::configure(hbhip_ctx *ctx, const PicGeometry &g, int pitch_alig
 
 DevPicture *PicturePool::acquire()
 {
+    if (frames_)
+    {
+        hbhip_frame *fr = nullptr;
+        if (hbhip_frame_alloc(ctx_, geo_.width, geo_.height, geo_.depth, geo_.log2_cw, geo_.log2_ch, &fr) != HBHIP_OK) return nullptr;
+        return &fr->pic;
+    }
     if (!free_.empty())
     {
         // Most recently released first (warm in L2) when its last user ran on this pool's stream.  One last used on
@@ -236,6 +242,7 @@ DevPicture *PicturePool::acquire()
 void PicturePool::release(DevPicture *p, hbhip_ctx *last_user)
 {
     if (!p) return;
+    if (p->frame) { hbhip_frame_release(p->frame); return; }      // a frame's picture, whoever made it
     hbhip_pic_mark_idle(last_user ? last_user : ctx_, p);   // an upload into the recycled picture waits for this (hbhip_copy_h2d)
     free_.push_back(p);
 }
@@ -764,6 +771,8 @@ int hbhip_frame_alloc(hbhip_ctx *ctx, int width, int height, int depth, int lcw,
             fr->ready.reset();
             fr->last_user = nullptr;
             fr->complete = false;
+            fr->pic.frame = fr;
+            fr->pic.refs = 0; fr->pic.flags = 0; fr->pic.combed = 0; fr->pic.aux = 0; fr->pic.tag = 0;
             // taken although its last reader may still be running (the pool is at its bound): whoever fills it on this
             // context's stream does so behind that reader, which may sit on another context's stream (hbhip_frame_use_on)
             if (fr->pic.idle && fr->pic.idle->stream != ctx->stream) (void)hbhip_pic_wait_idle(ctx->stream, &fr->pic);
@@ -800,6 +809,7 @@ int hbhip_frame_alloc(hbhip_ctx *ctx, int width, int height, int depth, int lcw,
     (void)hipMemsetAsync(fr->pic.base, 0, total, ctx->stream);
     hbhip_pic_mark_idle(ctx, &fr->pic);    // an upload (on the copy stream) must not overtake the clearing
     for (int c = 0; c < 3; c++) fr->pic.plane[c] = fr->pic.base + off[c];
+    fr->pic.frame = fr;
     *out = fr;
     return HBHIP_OK;
 }
@@ -1075,6 +1085,69 @@ int hbhip_filter_push_dev(hbhip_filter *f, const hbhip_dev_frame *in, int64_t ta
         return rc;
     }
     return f->submit(pic);
+}
+
+// ---- frames in, frames out: the drop-ins of a device-resident run ---------------------------------------------
+int hbhip_filter_use_frames(hbhip_filter *f)
+{
+    if (!f) return HBHIP_ERR_ARG;
+    return f->use_frames();
+}
+
+// The frame becomes the filter's input picture - no copy - when the filter works on frames, the caller is the frame's
+// only holder (a frame vfr has duplicated stays shared: it is copied, as before) and the geometry is the filter's; the
+// filter keeps a reference of its own until it is done with the picture.
+int hbhip_filter_push_frame(hbhip_filter *f, hbhip_frame *fr, int64_t tag)
+{
+    if (!f || !fr) return HBHIP_ERR_ARG;
+    (void)hipSetDevice(f->ctx->device);
+    int rc = hbhip_frame_use_on(fr, f->ctx);
+    if (rc != HBHIP_OK) return rc;
+    const PicGeometry &g = f->in_geo;
+    const bool fits = fr->width == g.width && fr->height == g.height && fr->depth == g.depth && fr->lcw == g.log2_cw && fr->lch == g.log2_ch;
+    if (!f->frames_mode || !fits || hbhip_frame_refs(fr) != 1)
+    {
+        hbhip_dev_frame d;
+        hbhip_frame_describe(fr, &d, nullptr, nullptr);
+        return hbhip_filter_push_dev(f, &d, tag);
+    }
+    hbhip_frame_retain(fr);
+    DevPicture *pic = &fr->pic;
+    pic->tag = tag;
+    f->adopt_input(pic);
+    for (int c = 0; c < 3; c++) f->in_stride[c] = pic->pitch[c];
+    f->in_is_dev = true;
+    return f->submit(pic);
+}
+
+// The next output as a frame: the picture itself when the filter works on frames (its reference passes to the caller), else
+// a fresh frame the picture is copied into.  HBHIP_AGAIN: none pending.
+int hbhip_filter_pull_frame(hbhip_filter *f, hbhip_frame **out, int64_t *tag)
+{
+    if (!f || !out) return HBHIP_ERR_ARG;
+    *out = nullptr;
+    (void)hipSetDevice(f->ctx->device);
+    DevPicture *pic = f->pop_output();
+    if (!pic) return HBHIP_AGAIN;
+    if (tag) *tag = pic->tag;
+    if (pic->frame)
+    {
+        *out = pic->frame;
+        return HBHIP_OK;
+    }
+    const PicGeometry &g = f->out_geo;
+    hbhip_frame *fr = nullptr;
+    int rc = hbhip_frame_alloc(f->ctx, g.width, g.height, g.depth, g.log2_cw, g.log2_ch, &fr);
+    if (rc == HBHIP_OK)
+    {
+        hbhip_dev_frame d;
+        hbhip_frame_describe(fr, &d, nullptr, nullptr);
+        rc = hbhip_copy_d2d_out(f->ctx, &d, pic);
+        if (rc != HBHIP_OK) { hbhip_frame_release(fr); fr = nullptr; }
+    }
+    f->recycle_output(pic);
+    *out = fr;
+    return rc;
 }
 
 int hbhip_filter_pull(hbhip_filter *f, const hbhip_host_frame *out, int64_t *tag)

@@ -185,6 +185,7 @@ struct DevPicture
     std::shared_ptr<IdleMark> idle;  // set when the picture goes back to its pool: everything that used it has been queued
                                      // on idle->stream ahead of that mark (null: never used)
     class PicturePool *owner = nullptr;   // the pool the picture goes back to (hbhip_pic_release)
+    struct hbhip_frame *frame = nullptr;  // the picture IS a frame's (hbhip_frame::pic): it goes back through hbhip_frame_release
 };
 
 // A reference-counted device picture that travels between filters inside an hb_buffer_t.
@@ -229,6 +230,12 @@ public:
     PicturePool() = default;
     ~PicturePool();
     void configure(hbhip_ctx *ctx, const PicGeometry &g, int pitch_align = 256, int pad_rows = 0);
+    // Frame-backed: acquire() hands out the picture of a fresh hbhip_frame of the context's frame pool (laid out like
+    // hb_frame_buffer_init lays a host frame out) and release() gives the frame back.  What a drop-in inside a
+    // device-resident run wants: the pictures a filter produces leave it AS frames (hbhip_filter_pull_frame) and the frames
+    // it is pushed become its input pictures (hbhip_filter_push_frame) - nothing is copied at either end.
+    void use_frames(bool on) { frames_ = on; }
+    bool frames() const { return frames_; }
     DevPicture *acquire();            // nullptr on allocation failure
     void        release(DevPicture *p, hbhip_ctx *last_user = nullptr);   // last_user: the context that read it (default: the pool's)
     const PicGeometry &geometry() const { return geo_; }
@@ -237,6 +244,7 @@ private:
     PicGeometry geo_;
     int pitch_align_ = 256;
     int pad_rows_ = 0;
+    bool frames_ = false;
     std::vector<DevPicture *> all_;
     std::vector<DevPicture *> free_;
     size_t max_pictures_ = 96;            // growth bound of the cross-stream case (acquire): three batches of 32 - a chain split over
@@ -246,9 +254,11 @@ private:
 // Give a picture back to the pool it came from.  Filters release their INPUT pictures through this,
 // so that a picture one filter produced can be handed to the next filter of a fused chain
 // (hbhip_chain, chain.hip) without a copy: whoever finishes with it returns it to its producer's pool.
+void hbhip_frame_release(struct hbhip_frame *fr);
 inline void hbhip_pic_release(DevPicture *p, hbhip_ctx *last_user = nullptr)
 {
-    if (p && p->owner) p->owner->release(p, last_user);
+    if (p && p->frame) hbhip_frame_release(p->frame);        // (its reader's stream is on record: hbhip_frame_use_on)
+    else if (p && p->owner) p->owner->release(p, last_user);
 }
 
 // Host <-> device: on the context's copy streams, synchronous for the CALLER only (see hbhip_ctx::up_stream):
@@ -300,6 +310,10 @@ struct hbhip_filter
     // takes ownership of `in`.  HBHIP_ERR_UNSUPPORTED when the filter has no such path.
     virtual int submit_to(DevPicture *, const DevPicture *) { return HBHIP_ERR_UNSUPPORTED; }
     virtual bool can_submit_to() const { return false; }
+    // ---- frames in, frames out (hbhip_filter_use_frames: the drop-ins of a device-resident run) ----
+    bool frames_mode = false;
+    virtual int use_frames() { return HBHIP_ERR_UNSUPPORTED; }      // switch the filter's pools to frame-backed pictures
+    virtual void adopt_input(DevPicture *pic) { pic->refs = 0; }      // a pushed frame's picture becomes an input picture
     // Several pictures at once (a chain batch).  out_views != nullptr: write into those pictures (only when
     // can_submit_to()); default = one by one.
     virtual int submit_many(DevPicture *const *pics, int n, const DevPicture *out_views)
@@ -394,6 +408,7 @@ struct SimpleFilter : hbhip_filter
         return HBHIP_OK;
     }
     int flush() override { return HBHIP_OK; }
+    int use_frames() override { in_pool.use_frames(true); out_pool.use_frames(true); frames_mode = true; return HBHIP_OK; }
     int pending() override { return (int)outq.size(); }
     DevPicture *pop_output() override
     {

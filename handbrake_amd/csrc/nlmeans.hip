@@ -1364,6 +1364,7 @@ public:
     }
 
     DevPicture *acquire_input() override { return pool.acquire(); }
+    int use_frames() override { pool.use_frames(true); frames_mode = true; return HBHIP_OK; }
 
     int submit(DevPicture *pic) override
     {

@@ -23,13 +23,13 @@ ABI_SYMBOLS = [
     "hbhip_dev_alloc", "hbhip_dev_free", "hbhip_dev_upload", "hbhip_dev_download",
     "hbhip_frame_alloc", "hbhip_frame_retain", "hbhip_frame_release", "hbhip_frame_refs", "hbhip_frame_use_on", "hbhip_frame_describe", "hbhip_frame_copy",
     "hbhip_frame_upload", "hbhip_frame_upload_async", "hbhip_ctx_upload_done", "hbhip_frame_download", "hbhip_frame_mark_ready", "hbhip_frame_download_async", "hbhip_frame_download_wait",
-    "hbhip_filter_push", "hbhip_filter_push_dev", "hbhip_filter_pull", "hbhip_filter_pull_dev",
+    "hbhip_filter_use_frames", "hbhip_filter_push_frame", "hbhip_filter_pull_frame", "hbhip_filter_push", "hbhip_filter_push_dev", "hbhip_filter_pull", "hbhip_filter_pull_dev",
     "hbhip_filter_process_dev", "hbhip_filter_submit_async", "hbhip_filter_wait", "hbhip_filter_inflight", "hbhip_filter_flush", "hbhip_filter_pending", "hbhip_filter_defer", "hbhip_filter_kick", "hbhip_filter_destroy",
     "hbhip_filter_out_geometry",
     "hbhip_chain_create", "hbhip_chain_process_dev", "hbhip_chain_flush_dev", "hbhip_chain_pending", "hbhip_chain_sync", "hbhip_chain_destroy",
     "hbhip_nlmeans_create", "hbhip_nlmeans_set_batch",
     "hbhip_lapsharp_create", "hbhip_unsharp_create", "hbhip_chroma_smooth_create",
-    "hbhip_hqdn3d_create", "hbhip_decomb_create", "hbhip_decomb_push", "hbhip_decomb_push_dev", "hbhip_decomb_debug_eedi_plane",
+    "hbhip_hqdn3d_create", "hbhip_decomb_create", "hbhip_decomb_push", "hbhip_decomb_push_dev", "hbhip_decomb_push_frame", "hbhip_decomb_debug_eedi_plane",
     "hbhip_comb_detect_create", "hbhip_comb_detect_set_gamma_lut", "hbhip_comb_detect_store",
     "hbhip_comb_detect_store_dev",
     "hbhip_comb_detect_classify", "hbhip_comb_detect_classify_many_dev", "hbhip_comb_detect_overlay", "hbhip_comb_detect_overlay_dev",

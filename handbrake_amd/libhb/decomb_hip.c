@@ -105,6 +105,8 @@ static int decomb_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init)
         hb_error("decomb(hip): %s", hbhip_strerror(rc));
         goto fail;
     }
+    /* inside a device-resident run frames come in and go out AS frames: nothing is copied at either end (include/hbhip.h) */
+    if (pv->dev_io && hbhip_host_zero_copy()) hbhip_filter_use_frames(pv->dev);
     if (p->mode & DECOMB_BOB)
         init->vrate.num *= 2;                  /* decomb.c:427-430 */
     pv->output = *init;
@@ -114,7 +116,10 @@ static int decomb_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init)
      * the reference's own threaded filters (nlmeans.c:548-571). */
     pv->batch = 1;
     if (hbhip_filter_defer(pv->dev, 1) == HBHIP_OK)
-        pv->batch = DECOMB_BATCH;
+    {
+        const char *env = getenv("HBHIP_DECOMB_BATCH");
+        pv->batch = env != NULL && atoi(env) > 0 ? atoi(env) : DECOMB_BATCH;
+    }
     return 0;
 fail:
     free(pv);
@@ -216,10 +221,7 @@ static int decomb_hip_work(hb_filter_object_t *filter, hb_buffer_t **buf_in, hb_
     hbhip_frame *fr = hbhip_host_frame_of(in);
     if (fr != NULL)
     {
-        hbhip_dev_frame d;
-        hbhip_frame_describe(fr, &d, NULL, NULL);
-        rc = hbhip_frame_use_on(fr, hbhip_filter_context(pv->dev));
-        if (rc == HBHIP_OK) rc = hbhip_decomb_push_dev(pv->dev, &d, pv->next_tag++, in->s.flags, in->s.combed);
+        rc = hbhip_decomb_push_frame(pv->dev, fr, pv->next_tag++, in->s.flags, in->s.combed);   /* no copy: the frame is the input picture */
     }
     else
     {
@@ -351,6 +353,7 @@ static int deint_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init, in
         filter->private_data = NULL;
         return -1;
     }
+    if (pv->dev_io && hbhip_host_zero_copy()) hbhip_filter_use_frames(pv->dev);
     if (mode & YADIF_BOB)
         init->vrate.num *= 2;                                    /* :107 */
     pv->output = *init;

@@ -62,6 +62,9 @@ static inline hbhip_frame *hbhip_host_frame_of(const hb_buffer_t *b)
 {
     return b->storage_type == HBHIP_DEVICE ? (hbhip_frame *)b->storage : NULL;
 }
+/* HBHIP_ZERO_COPY=0: the drop-ins of a device-resident run copy frames into and out of pictures of their own again
+ * (hbhip_filter_push_dev / pull_dev) instead of adopting them (hbhip_filter_use_frames) - for A/B measurements */
+static inline int hbhip_host_zero_copy(void) { const char *e = getenv("HBHIP_ZERO_COPY"); return e == NULL || atoi(e) != 0; }
 /* hb_buffer_t shell around a device frame (takes over the caller's reference). */
 hb_buffer_t *hbhip_host_wrap_frame(hbhip_frame *fr, const hb_filter_init_t *o, int width, int height);
 /* Feed `in` (host planes or device frame) to a device filter. */

@@ -316,13 +316,7 @@ int hbhip_host_push(hbhip_filter *dev, const hb_buffer_t *in, int64_t tag)
 {
     hbhip_frame *fr = hbhip_host_frame_of(in);
     if (fr != NULL)
-    {
-        hbhip_dev_frame d;
-        hbhip_frame_describe(fr, &d, NULL, NULL);
-        const int urc = hbhip_frame_use_on(fr, hbhip_filter_context(dev));
-        if (urc != HBHIP_OK) return urc;
-        return hbhip_filter_push_dev(dev, &d, tag);
-    }
+        return hbhip_filter_push_frame(dev, fr, tag);      /* the frame itself where the filter works on frames, else a copy of it */
     hbhip_host_frame hf;
     hbhip_host_frame_from_buf(&hf, in);
     return hbhip_filter_push(dev, &hf, tag);
@@ -334,19 +328,9 @@ hb_buffer_t *hbhip_host_pull(hbhip_filter *dev, const hb_filter_init_t *o, int w
     int64_t t = 0;
     if (dev_io)
     {
-        const AVPixFmtDescriptor *desc = av_pix_fmt_desc_get(o->pix_fmt);
         hbhip_frame *fr = NULL;
-        if (desc == NULL ||
-            hbhip_frame_alloc(hbhip_filter_context(dev), width, height, desc->comp[0].depth,
-                              desc->log2_chroma_w, desc->log2_chroma_h, &fr) != HBHIP_OK)
+        if (hbhip_filter_pull_frame(dev, &fr, &t) != HBHIP_OK || fr == NULL)     /* the filter's own picture, or a copy of it */
             return NULL;
-        hbhip_dev_frame d;
-        hbhip_frame_describe(fr, &d, NULL, NULL);
-        if (hbhip_filter_pull_dev(dev, &d, &t) != HBHIP_OK)
-        {
-            hbhip_frame_release(fr);
-            return NULL;
-        }
         hbhip_frame_mark_ready(fr);                    /* what fills it is queued: a download waits for this point only */
         if (tag) *tag = t;
         return hbhip_host_wrap_frame(fr, o, width, height);
@@ -508,7 +492,9 @@ typedef struct { hb_buffer_t *in, *out; void *token; } dl_slot_t;
  * once - its readers wait for the copy, hbhip_frame_use_on - while the host buffer stays with the adapter until the copy
  * has finished (a synchronous copy per frame held the thread for a bus round trip each: 0.27 ms of a 0.32 ms frame
  * period on a list that the GPU, not the download, bounds). */
+#ifndef UL_DEPTH
 #define UL_DEPTH 4
+#endif
 typedef struct { hb_buffer_t *in; void *token; } ul_slot_t;
 
 struct hb_filter_private_s

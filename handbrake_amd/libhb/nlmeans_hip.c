@@ -173,6 +173,8 @@ static int nlmeans_hip_init(hb_filter_object_t *filter, hb_filter_init_t *init)
         hb_error("nlmeans(hip): %s", hbhip_strerror(rc));
         goto fail;
     }
+    /* inside a device-resident run frames come in and go out AS frames: nothing is copied at either end (include/hbhip.h) */
+    if (pv->dev_io && hbhip_host_zero_copy()) hbhip_filter_use_frames(pv->dev);
     /* frames per launch: the kernel needs several frames' tiles to fill the GPU.  Like the reference, which works on
      * `threads` frames at a time (nlmeans.c:548-571), the filter then emits bursts. */
     const char *env = getenv("HBHIP_NLMEANS_BATCH");

@@ -137,6 +137,15 @@ int  hbhip_frame_mark_ready(hbhip_frame *fr);
 int  hbhip_frame_download_async(hbhip_frame *fr, const hbhip_host_frame *dst, void **token);
 int  hbhip_frame_download_wait(hbhip_frame *fr, void *token);
 
+/* ---- frames in, frames out: what a drop-in inside a device-resident run uses instead of push_dev / pull_dev -----------
+ * hbhip_filter_use_frames(f) (once, before the first push): the filter's pictures are frames of its context's pool.
+ * hbhip_filter_push_frame: the frame becomes the filter's input picture without a copy (the filter holds a reference of its
+ * own; a frame with other holders, or of another geometry, is copied as hbhip_filter_push_dev would).
+ * hbhip_filter_pull_frame: the next output AS a frame (its one reference passes to the caller); HBHIP_AGAIN when none. */
+int hbhip_filter_use_frames(hbhip_filter *f);
+int hbhip_filter_push_frame(hbhip_filter *f, hbhip_frame *fr, int64_t tag);
+int hbhip_filter_pull_frame(hbhip_filter *f, hbhip_frame **out, int64_t *tag);
+
 /* ---- generic streaming surface of a filter instance ---------------------------
  * Mirrors hb_filter_object_t.work (common.h:1682-1685): push one input frame,
  * pull zero or more output frames, flush at EOF, destroy in close().
@@ -269,6 +278,7 @@ int hbhip_decomb_create(hbhip_ctx *ctx, const hbhip_decomb_params *p, int width,
  * (input tag << 1) | field_index, field_index = 1 for the second frame of a bob pair. */
 int hbhip_decomb_push(hbhip_filter *f, const hbhip_host_frame *in, int64_t tag, int pic_flags, int combed);
 int hbhip_decomb_push_dev(hbhip_filter *f, const hbhip_dev_frame *in, int64_t tag, int pic_flags, int combed);
+int hbhip_decomb_push_frame(hbhip_filter *f, hbhip_frame *fr, int64_t tag, int pic_flags, int combed);   /* as hbhip_filter_push_frame */
 /* The reference's "Deinterlace" filter = FFmpeg yadif as deinterlace_init configures it
  * (deinterlace.c:72-143): spatial_check 0 = send_*_nospatial, bob = send_field (two frames per
  * input), selective = deint=interlaced (only frames whose s.combed is set), parity -1 / 0 (tff) /
