@@ -56,3 +56,22 @@ def test_two_streams_equal_one_stream_over_a_long_run(with_vfr, monkeypatch, w, 
     _, two = hbrt.run_job(lst, frames, flags=0x0008, use_hip=True)
     assert len(one) == len(two) >= n
     same(two, one)
+
+
+def test_adopted_frames_equal_copied_frames(with_vfr, monkeypatch):
+    """Inside a device-resident run decomb and NLMeans take the frames they are pushed as their input pictures and hand their
+    result pictures on as frames (hbhip_filter_use_frames / push_frame / pull_frame); HBHIP_ZERO_COPY=0 makes them copy into
+    and out of pictures of their own, as they did until round 6.  Same pictures either way - with vfr's duplicates in the
+    list (shared frames are copied, not adopted) and with two streams per job (adopted frames cross contexts)."""
+    monkeypatch.delenv("HBHIP_JOB_STREAMS")
+    w, h, n = 640, 360, 40
+    base = synth.stream("interlaced", w, h, 8, cfg=3)
+    frames = [base[i % 8] for i in range(n)]
+    F = hbrt.FILTER_ID
+    lst = [(F["comb_detect"], ""), (F["decomb"], "mode=31"), (11, "mode=1:rate=90000/1001"),
+           (F["nlmeans"], hip.NLMEANS_MEDIUM + ":threads=2"), (F["lapsharp"], "y-strength=0.2:y-kernel=isolap")]
+    _, adopted = hbrt.run_job(lst, frames, flags=0x0008, use_hip=True)
+    monkeypatch.setenv("HBHIP_ZERO_COPY", "0")
+    _, copied = hbrt.run_job(lst, frames, flags=0x0008, use_hip=True)
+    assert len(adopted) == len(copied) > 2 * n          # 90000/1001 = three out of every bobbed pair: duplicates
+    same(adopted, copied)
