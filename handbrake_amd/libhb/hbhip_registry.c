@@ -491,9 +491,10 @@ typedef struct { hb_buffer_t *in, *out; void *token; } dl_slot_t;
 /* The upload adapter keeps UL_DEPTH copies in flight on the context's upload stream: the device frame goes downstream at
  * once - its readers wait for the copy, hbhip_frame_use_on - while the host buffer stays with the adapter until the copy
  * has finished (a synchronous copy per frame held the thread for a bus round trip each: 0.27 ms of a 0.32 ms frame
- * period on a list that the GPU, not the download, bounds). */
+ * period on a list that the GPU, not the download, bounds; with four in flight the thread was 90 % busy waiting for the
+ * oldest at 7.7 k output fps, with eight 11 % at 8.2 k). */
 #ifndef UL_DEPTH
-#define UL_DEPTH 4
+#define UL_DEPTH 8
 #endif
 typedef struct { hb_buffer_t *in; void *token; } ul_slot_t;
 
