@@ -89,6 +89,8 @@ def algorithmic_bytes(kernel, w, h, out_w, out_h, frames_per_launch=1):
         "eedi2_mask_repair": 4,                                       # one workgroup that reads the chain's error word and returns (MaskChain)
         "eedi2_calc_directions": 3 * half,                            # mskp + srcp -> tmpp
         "eedi2_filter_dir_map": 3 * half, "eedi2_expand_dir_map": 3 * half, "eedi2_filter_map": 3 * half,
+        "eedi2_filter_expand_dir_map": 3 * half,                      # the two passes in one launch: mskp + map -> map
+
         "eedi2_mark_directions_2x": 3 * half + 4 * full,              # 3 line doublings + tmp2p
         "eedi2_filter_dir_map_2x": 3 * full, "eedi2_expand_dir_map_2x": 3 * full,
         "eedi2_fill_gaps_2x": 3 * full,

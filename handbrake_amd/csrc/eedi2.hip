@@ -260,6 +260,14 @@ __device__ __forceinline__ uint32_t mf_bytes_in(int X, int lo, int hi)
     return m;
 }
 
+// the four bytes at columns X .. X + 3 with those at or beyond `width` (the row's padding) replaced by padv's: the reference's
+// memset(dstp, 255, pitch * height) writes the padding, its bit_blit of `width` columns does not
+__device__ __forceinline__ uint32_t pad_bytes(uint32_t v, int X, int width, uint32_t padv)
+{
+    const uint32_t in = mf_bytes_in(X, 0, width);
+    return (v & in) | (padv & ~in);
+}
+
 // erode (GROW = false) / dilate (GROW = true) of LDS rows ra .. rb
 template <bool GROW>
 __device__ __forceinline__ void mf_morph4(const uint32_t (*src)[MF_DP], uint32_t (*dst)[MF_DP], int c4, int strip,
@@ -888,7 +896,7 @@ __device__ __forceinline__ uint64_t calc_dir_window(const uint64_t *bits, int st
 #define CD_WAVES_ATTR
 #endif
 template <int R>
-__global__ __launch_bounds__(CD_W) CD_WAVES_ATTR void k_calc_dir_rows(P3 P, int maxd, int nt13, int nt19, int dense_min)
+__global__ __launch_bounds__(CD_W) CD_WAVES_ATTR void k_calc_dir_rows(P3 P, int maxd, int nt13, int nt19, int dense_min, uint32_t padv)
 {
     constexpr int NS = R + 4, NM = R + 2, RW = CD_LW / 4, RQ = CD_LW / 16;
     __shared__ __attribute__((aligned(16))) uint8_t s_band[NS + NM][CD_LW];   // staged rows: 0..NS-1 source y0-2.., NS.. mask y0-1..
@@ -909,7 +917,7 @@ __global__ __launch_bounds__(CD_W) CD_WAVES_ATTR void k_calc_dir_rows(P3 P, int 
         for (int jr = 0; jr < R; jr += CD_W / 64)
         {
             const int j = jr + (tid >> 6), y = y0 + j, xb = x0 + 4 * lane;
-            if (j < R && y < height && xb < pitch) *reinterpret_cast<uint32_t *>(Q.c + (size_t)y * pitch + xb) = 0xffffffffu;
+            if (j < R && y < height && xb < pitch) *reinterpret_cast<uint32_t *>(Q.c + (size_t)y * pitch + xb) = pad_bytes(0xffffffffu, xb, width, padv);
         }
         return;
     }
@@ -1090,7 +1098,7 @@ __global__ __launch_bounds__(CD_W) CD_WAVES_ATTR void k_calc_dir_rows(P3 P, int 
     {
         const int j = jr + (tid >> 6), y = y0 + j, xb = x0 + 4 * lane;
         if (j < R && y < height && xb < pitch)
-            *reinterpret_cast<uint32_t *>(Q.c + (size_t)y * pitch + xb) = reinterpret_cast<const uint32_t *>(&s_out[j][0])[lane];
+            *reinterpret_cast<uint32_t *>(Q.c + (size_t)y * pitch + xb) = pad_bytes(reinterpret_cast<const uint32_t *>(&s_out[j][0])[lane], xb, width, padv);
     }
 }
 
@@ -1543,6 +1551,136 @@ __global__ __launch_bounds__(256) void k_dir_map_c(P3 P, int step, int expand, i
         }
     }
 }
+
+// eedi2_filter_dir_map and the eedi2_expand_dir_map behind it (half height, step 1) in one launch.  A workgroup makes the
+// filtered map of its FE_R rows x 256 columns AND of the one-pixel ring around them (a dword column either side, a row
+// above and below) in LDS, expands out of that, and stores the expanded map only: the filtered map never reaches memory.
+// a = mskp, b = map in, c = out (which must not be b: the ring of a tile is its neighbours' input).
+#ifndef FE_ROWS
+#define FE_ROWS 14
+#endif
+constexpr int FE_R = FE_ROWS, FE_LW = 68;
+
+// eedi2_expand_dir_map (:719-773) out of the filtered tile s_f (k_dir_map_c at step 1): fe_expand_row decides a dword of
+// output row lr - copied, or its pixels with enough usable neighbours queued for the vote -, fe_expand_finish votes and stores.
+// cand: the row's pixels on the mask and inside the row (one flag byte each).
+__device__ __forceinline__ void fe_expand_row(const uint32_t (*s_f)[FE_LW], int lr, int tx, uint32_t cand, uint8_t (*s_out)[256],
+                                              uint16_t *s_list, int *s_count)
+{
+    const uint32_t own = s_f[lr + 1][tx + 1];
+    cand &= ff_bytes(own) >> 7;                                                      // expand only fills peak pixels
+    if (cand)
+    {
+        const Win12 wc = { s_f[lr + 1][tx], own, s_f[lr + 1][tx + 2] };
+        const Win12 wu = { s_f[lr][tx], s_f[lr][tx + 1], s_f[lr][tx + 2] };
+        const Win12 wd = { s_f[lr + 2][tx], s_f[lr + 2][tx + 1], s_f[lr + 2][tx + 2] };
+        uint32_t nc, nu, nd;
+        const uint32_t s3c = live3(wc, nc), s3u = live3(wu, nu), s3d = live3(wd, nd);
+        const uint32_t u = s3c - nc + s3u + s3d;                                     // the centre is left out (:671)
+        const uint32_t enough = ((u + (uint32_t)(0x80 - 5) * 0x01010101u) >> 7) & 0x01010101u;
+        const uint32_t sortpx = cand & enough;
+        if (sortpx)
+        {
+            int at = atomicAdd(s_count, __popc(sortpx));
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if ((sortpx >> (8 * k)) & 1u) s_list[at++] = (uint16_t)((lr << 8) | (4 * tx + k));
+        }
+        (void)nu; (void)nd;
+    }
+    *reinterpret_cast<uint32_t *>(&s_out[lr][4 * tx]) = own;
+}
+
+// (between two barriers of its own; the caller has one behind the last fe_expand_row)
+__device__ __forceinline__ void fe_expand_finish(const uint32_t (*s_f)[FE_LW], uint8_t (*s_out)[256], const uint16_t *s_list, int count,
+                                                 const uint8_t *s_lim, uint8_t *dst, int rb, int x, int pitch, int width, int height)
+{
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    for (int i = tid; i < count; i += 256)
+    {
+        const int e = s_list[i], ly = e >> 8, lx = e & 255;
+        const uint8_t *c = reinterpret_cast<const uint8_t *>(&s_f[ly + 1][1]) + lx;
+        const uint8_t *up = c - 4 * FE_LW, *dn = c + 4 * FE_LW;
+        s_out[ly][lx] = (uint8_t)dir_map_px(up[-1], up[0], up[1], c[-1], c[0], c[1], dn[-1], dn[0], dn[1], true, true, 1, s_lim);
+    }
+    __syncthreads();
+    for (int lr = threadIdx.y; lr < FE_R; lr += 4)
+    {
+        const int y = rb + lr;
+        if (x >= pitch || y >= height) continue;
+        // the row's padding: 255, as calc_directions' memset leaves it in the plane the reference expands into
+        const uint32_t v = x < width ? *reinterpret_cast<const uint32_t *>(&s_out[lr][4 * threadIdx.x]) : 0u;
+        *reinterpret_cast<uint32_t *>(dst + (size_t)y * pitch + x) = pad_bytes(v, x, width, 0xffffffffu);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dir_map_fe(P3 P)
+{
+    __shared__ uint32_t s_f[FE_R + 2][FE_LW];                       // rows rb - 1 .. rb + FE_R, dword columns -1 .. 64
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[FE_R][256];
+    __shared__ uint16_t s_list[FE_R * 256];
+    __shared__ int s_count;
+    __shared__ uint8_t s_lim[LIM_PAD];
+    FIELD_PLANE(P);
+    const int rb = blockIdx.y * FE_R;
+    const int bx0 = 256 * blockIdx.x, x = bx0 + 4 * threadIdx.x;
+    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
+    if (bx0 >= pitch || rb >= height) return;
+    if (maskless)
+    {
+        if (x < pitch)
+            for (int lr = threadIdx.y; lr < FE_R && rb + lr < height; lr += 4) *reinterpret_cast<uint32_t *>(Q.c + (size_t)(rb + lr) * pitch + x) = 0xffffffffu;
+        return;
+    }
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    if (tid == 0) s_count = 0;
+    lim_fill(s_lim, tid);
+    // SIDE 0: the whole dword; -1 / +1: the ring's dword left / right of the tile, of which only the pixel next to the tile
+    // is ever read (half the vote)
+    auto filtered = [&](int y, int xx, auto side) -> uint32_t {
+        constexpr int SIDE = decltype(side)::value;
+        if (y < 0 || y >= height || xx < 0 || xx >= width) return 0u;
+        const uint8_t *dc = Q.b + (size_t)y * pitch + xx;
+        const uint32_t own = *reinterpret_cast<const uint32_t *>(dc);
+        if (y < 1 || y >= height - 1) return own;
+        const uint32_t m0 = *reinterpret_cast<const uint32_t *>(Q.a + (size_t)y * pitch + xx);
+        uint32_t work = (ff_bytes(m0) >> 7) & mf_bytes_in(xx, 1, width - 1);
+        if (SIDE < 0) work &= 0xff000000u;
+        if (SIDE > 0) work &= 0x000000ffu;
+        uint32_t res = own;
+        if (work)
+        {
+            asm volatile("" ::: "memory");
+            const Win12 wc = ldwin(dc), wu = ldwin(dc - (ptrdiff_t)pitch), wd = ldwin(dc + (ptrdiff_t)pitch);
+            const uint32_t p01 = SIDE < 0 ? 0u : dir_map_pair<0>(wu, wc, wd, 0), p23 = SIDE > 0 ? 0u : dir_map_pair<2>(wu, wc, wd, 0);
+            const uint32_t votes = __builtin_amdgcn_perm(p23, p01, 0x06040200u);
+            const uint32_t sel = work * 255u;
+            res = (res & ~sel) | (votes & sel);
+        }
+        return res;
+    };
+    for (int lr = threadIdx.y; lr < FE_R + 2; lr += 4) s_f[lr][threadIdx.x + 1] = filtered(rb - 1 + lr, x, std::integral_constant<int, 0>());
+    static_assert(FE_R + 2 <= 64, "a lane per ring row");
+    if (threadIdx.y == 0 && (int)threadIdx.x < FE_R + 2) s_f[threadIdx.x][0] = filtered(rb - 1 + (int)threadIdx.x, bx0 - 4, std::integral_constant<int, -1>());
+    if (threadIdx.y == 1 && (int)threadIdx.x < FE_R + 2) s_f[threadIdx.x][65] = filtered(rb - 1 + (int)threadIdx.x, bx0 + 256, std::integral_constant<int, 1>());
+    __syncthreads();
+    for (int lr = threadIdx.y; lr < FE_R; lr += 4)
+    {
+        const int y = rb + lr;
+        if (x >= width || y >= height) continue;
+        uint32_t cand = 0;
+        if (y >= 1 && y < height - 1)
+            cand = (ff_bytes(*reinterpret_cast<const uint32_t *>(Q.a + (size_t)y * pitch + x)) >> 7) & mf_bytes_in(x, 1, width - 1);
+        fe_expand_row(s_f, lr, threadIdx.x, cand, s_out, s_list, &s_count);
+    }
+    __syncthreads();
+    fe_expand_finish(s_f, s_out, s_list, s_count, s_lim, Q.c, rb, x, pitch, width, height);
+}
+
+// (Measured and dropped, DESIGN.md 4.2.3: the filter pass's votes on a queue - the tile staged in LDS, the aligned pixel
+// pairs with a mask pixel listed, a lane per listed pair - 131 us per launch against the 103 of this form: a wave here
+// votes for all 64 of its dwords when one holds a mask pixel, and half of those votes are for nothing on the bench's
+// pictures, but the list costs what it saves - 48 M vector instructions per launch against 42 + 6 M - and adds four barriers.)
 
 // a = mskp, b = dmsk in, c = out.  eedi2_filter_map (:538-635): a pixel that carries a direction loses it (-> peak) when
 // the map breaks along that direction on the row above AND on the row below - two short walks (at most 9 pixels: the
@@ -3141,7 +3279,13 @@ int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st, ui
 
     // half-height passes
     geom(P, srcp);
-    bind(P.a, mskp); bind(P.b, srcp); bind(P.c, tmpp);
+    // filter_dir_map and expand_dir_map as one launch (k_dir_map_fe): calc_directions then writes dstp, so that the fused
+    // pass leaves the expanded map in tmpp, where the reference has it
+    // (the padding of the rows with it: calc_directions' memset leaves 255 there, which the fused pass writes into tmpp,
+    // while dstp keeps the zeros the passes of the reference never touch)
+    const bool fused = par_.maximum_search_distance <= CD_HALO - 2 && hbhip_dev_int("HBHIP_EEDI2_FUSE_DIRMAP", 1) != 0;
+    const uint32_t padv = fused ? 0u : 0xffffffffu;
+    bind(P.a, mskp); bind(P.b, srcp); bind(P.c, fused ? dstp : tmpp);
     const int nt13 = (par_.noise_threshold * 13) & 0xff, nt19 = (par_.noise_threshold * 19) & 0xff;      // typed `pixel` in the reference
     if (par_.maximum_search_distance <= CD_HALO - 2)
     {
@@ -3158,20 +3302,20 @@ int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st, ui
         if (rows == 8)
             HBHIP_LAUNCH_ON(lc, st, "eedi2_calc_directions", k_calc_dir_rows<8>,
                          dim3(hbhip_grid_x((srcp.stride[0] + CD_W - 1) / CD_W), (srcp.height[0] + 7) / 8, gz), dim3(CD_W), 0, P,
-                         par_.maximum_search_distance, nt13, nt19, dense_min);
+                         par_.maximum_search_distance, nt13, nt19, dense_min, padv);
         else if (rows == 6)
             HBHIP_LAUNCH_ON(lc, st, "eedi2_calc_directions", k_calc_dir_rows<6>,
                          dim3(hbhip_grid_x((srcp.stride[0] + CD_W - 1) / CD_W), (srcp.height[0] + 5) / 6, gz), dim3(CD_W), 0, P,
-                         par_.maximum_search_distance, nt13, nt19, dense_min);
+                         par_.maximum_search_distance, nt13, nt19, dense_min, padv);
         else if (rows == 2)
             HBHIP_LAUNCH_ON(lc, st, "eedi2_calc_directions", k_calc_dir_rows<2>,
                          dim3(hbhip_grid_x((srcp.stride[0] + CD_W - 1) / CD_W), (srcp.height[0] + 1) / 2, gz), dim3(CD_W), 0, P,
-                         par_.maximum_search_distance, nt13, nt19, dense_min);
+                         par_.maximum_search_distance, nt13, nt19, dense_min, padv);
         else
 #endif
         HBHIP_LAUNCH_ON(lc, st, "eedi2_calc_directions", k_calc_dir_rows<4>,
                      dim3(hbhip_grid_x((srcp.stride[0] + CD_W - 1) / CD_W), (srcp.height[0] + 3) / 4, gz), dim3(CD_W), 0, P,
-                     par_.maximum_search_distance, nt13, nt19, dense_min);
+                     par_.maximum_search_distance, nt13, nt19, dense_min, padv);
     }
     else
     {
@@ -3194,10 +3338,19 @@ int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st, ui
                          (const uint32_t *)work_list_, (const int *)work_count_, par_.maximum_search_distance, nt13, nt19);
         }
     }
-    bind(P.a, mskp); bind(P.b, tmpp); bind(P.c, dstp);
-    dir_map("eedi2_filter_dir_map", srcp, P, 1, 0);
-    bind(P.a, mskp); bind(P.b, dstp); bind(P.c, tmpp);
-    dir_map("eedi2_expand_dir_map", srcp, P, 1, 1);
+    if (fused)
+    {
+        bind(P.a, mskp); bind(P.b, dstp); bind(P.c, tmpp);
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_filter_expand_dir_map", k_dir_map_fe,
+                        dim3(hbhip_grid_x((srcp.stride[0] + 255) / 256), (srcp.height[0] + FE_R - 1) / FE_R, gz), blk, 0, P);
+    }
+    else
+    {
+        bind(P.a, mskp); bind(P.b, tmpp); bind(P.c, dstp);
+        dir_map("eedi2_filter_dir_map", srcp, P, 1, 0);
+        bind(P.a, mskp); bind(P.b, dstp); bind(P.c, tmpp);
+        dir_map("eedi2_expand_dir_map", srcp, P, 1, 1);
+    }
     bind(P.a, mskp); bind(P.b, tmpp); bind(P.c, dstp);
     HBHIP_LAUNCH_ON(lc, st, "eedi2_filter_map", k_filter_map, grid4_for(srcp, false), blk, 0, P);
     // line doubling of srcp / dstp / mskp + mark_directions_2x in one launch (full-height geometry)

@@ -124,7 +124,7 @@ def main():
                      "eedi2_lattice_resolve": FRAME // 2 * 4 + FRAME, "eedi2_filter_dir_map_2x": 3 * FRAME,
                      "eedi2_expand_dir_map_2x": 3 * FRAME, "eedi2_fill_gaps_2x": 3 * FRAME,
                      "eedi2_mark_directions_2x": 3 * FRAME, "eedi2_filter_dir_map": 3 * half,
-                     "eedi2_expand_dir_map": 3 * half, "eedi2_filter_map": 3 * half, "eedi2_erode": 2 * half,
+                     "eedi2_filter_expand_dir_map": 3 * half, "eedi2_expand_dir_map": 3 * half, "eedi2_filter_map": 3 * half, "eedi2_erode": 2 * half,
                      "eedi2_dilate": 2 * half, "eedi2_edge_mask": 2 * half, "eedi2_small_gaps": 2 * half,
                      "eedi2_mask_passes": 3.5 * half,
                      "eedi2_upscale_by_2": 3 * half + 3 * FRAME, "eedi2_bit_blit": 2 * FRAME, "eedi2_post_process": 3 * FRAME,
