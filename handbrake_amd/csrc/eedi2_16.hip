@@ -635,8 +635,17 @@ __device__ __forceinline__ int calc_dir_search16(const uint2 *tr, uint64_t pass,
 
 // dense_min: a block with at least this many listed pixels (none of them on the plane's first / last row) searches in the
 // dense form (R >= 4, depths up to 12 bits)
+// the two samples at columns X, X + 1 with those at or beyond `width` (the row's padding) replaced by padv: the reference's
+// fill of calc_directions' output covers the padding, the bit_blit of the passes behind it does not (eedi2.hip: pad_bytes)
+__device__ __forceinline__ uint32_t pad_pair16(uint32_t v, int X, int width, int padv)
+{
+    if (X >= width) return (uint32_t)padv * 0x00010001u;
+    if (X + 1 >= width) return (v & 0xffffu) | ((uint32_t)padv << 16);
+    return v;
+}
+
 template <int R>
-__global__ __launch_bounds__(QW) void q_calc_dir_rows(Q3 P, K16 k, int maxd, int nt, int dense_min)
+__global__ __launch_bounds__(QW) void q_calc_dir_rows(Q3 P, K16 k, int maxd, int nt, int dense_min, int padv)
 {
     constexpr int NS = R + 4, NM = R + 2, RWD = QLW / 2;                      // RWD: dwords per staged row
     __shared__ __attribute__((aligned(16))) uint16_t s_band[NS + NM][QLW];    // staged rows: 0..NS-1 source y0-2.., NS.. mask y0-1..
@@ -659,7 +668,7 @@ __global__ __launch_bounds__(QW) void q_calc_dir_rows(Q3 P, K16 k, int maxd, int
         for (int i = tid; i < R * (QW / 2); i += QW)
         {
             const int j = i / (QW / 2), c2 = i - j * (QW / 2), y = y0 + j, xb = x0 + 2 * c2;
-            if (y < height && xb < pitch) *reinterpret_cast<uint32_t *>(Q.c + (size_t)y * pitch + xb) = pk2;
+            if (y < height && xb < pitch) *reinterpret_cast<uint32_t *>(Q.c + (size_t)y * pitch + xb) = pad_pair16(pk2, xb, width, padv);
         }
         return;
     }
@@ -803,7 +812,7 @@ __global__ __launch_bounds__(QW) void q_calc_dir_rows(Q3 P, K16 k, int maxd, int
     {
         const int j = i / (QW / 2), c2 = i - j * (QW / 2), y = y0 + j, xb = x0 + 2 * c2;
         if (y < height && xb < pitch)
-            *reinterpret_cast<uint32_t *>(Q.c + (size_t)y * pitch + xb) = reinterpret_cast<const uint32_t *>(&s_out[j][0])[c2];
+            *reinterpret_cast<uint32_t *>(Q.c + (size_t)y * pitch + xb) = pad_pair16(reinterpret_cast<const uint32_t *>(&s_out[j][0])[c2], xb, width, padv);
     }
 }
 
@@ -1220,6 +1229,141 @@ __global__ __launch_bounds__(256) void q_dir_map(Q3 P, K16 k, int step, int expa
             const uint16_t o4[4] = { (uint16_t)(vcopy.x & 0xffffu), (uint16_t)(vcopy.x >> 16), (uint16_t)(vcopy.y & 0xffffu), (uint16_t)(vcopy.y >> 16) };
             for (int j = 0; j < 4 && x + j < width; j++) o[j] = o4[j];
         }
+    }
+}
+
+// filter_dir_map and the expand_dir_map behind it (half height, step 1) in one launch (eedi2.hip: k_dir_map_fe): a workgroup
+// makes the filtered map of its QFE_R rows x 256 samples and of the one-sample ring around them in LDS (q_dir_map4's vote),
+// expands out of that (q_dir_map's two phases) and stores the expanded map only.  a = mask, b = map in, c = out (not b).
+#ifndef FE16_ROWS
+#define FE16_ROWS 14
+#endif
+constexpr int QFE_R = FE16_ROWS, QFE_LW = 272;                      // LDS row: the group of 4 left of the tile, 256 samples, the group right of it
+__global__ __launch_bounds__(256) void q_dir_map_fe(Q3 P, K16 k)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t s_f[QFE_R + 2][QFE_LW];      // rows rb - 1 .. rb + QFE_R
+    __shared__ __attribute__((aligned(16))) uint16_t s_out[QFE_R][256];
+    __shared__ uint16_t s_list[QFE_R * 256];
+    __shared__ int s_count;
+    __shared__ int s_lim[33];
+    static_assert(QFE_R + 2 <= 64, "a lane per ring row");
+    FIELD16(P);
+    const int rb = blockIdx.y * QFE_R;
+    const int bx0 = 256 * blockIdx.x, x = bx0 + 4 * threadIdx.x;
+    const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
+    if (bx0 >= pitch || rb >= height) return;
+    const int peak = k.peak;
+    const uint32_t peak2 = (uint32_t)peak * 0x00010001u;
+    if (maskless)
+    {
+        if (x < pitch)
+            for (int lr = threadIdx.y; lr < QFE_R && rb + lr < height; lr += 4)
+                *reinterpret_cast<uint2 *>(Q.c + (size_t)(rb + lr) * pitch + x) = make_uint2(peak2, peak2);
+        return;
+    }
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    if (tid == 0) s_count = 0;
+    if (tid < 33) s_lim[tid] = k.limlut[tid];
+    // SIDE 0: the thread's four samples; -1 / +1: the ring's group left / right of the tile, of which only the sample next to
+    // the tile is ever read (half the vote)
+    auto filtered = [&](int y, int xx, auto side) -> uint2 {
+        constexpr int SIDE = decltype(side)::value;
+        if (y < 0 || y >= height || xx < 0 || xx >= width) return make_uint2(0u, 0u);
+        const uint16_t *dc = Q.b + (size_t)y * pitch + xx;
+        const uint2 own = *reinterpret_cast<const uint2 *>(dc);
+        if (y < 1 || y >= height - 1) return own;
+        const uint2 m0 = *reinterpret_cast<const uint2 *>(Q.a + (size_t)y * pitch + xx);
+        const int mm0[4] = { (int)(m0.x & 0xffffu), (int)(m0.x >> 16), (int)(m0.y & 0xffffu), (int)(m0.y >> 16) };
+        uint32_t work = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (xx + j >= 1 && xx + j < width - 1 && mm0[j] == peak) work |= 1u << j;
+        if (SIDE < 0) work &= 8u;
+        if (SIDE > 0) work &= 1u;
+        uint2 res = own;
+        if (work)
+        {
+            asm volatile("" ::: "memory");
+            auto ldwin = [&](const uint16_t *row) -> Win16 {
+                const uint2 c4 = *reinterpret_cast<const uint2 *>(row);
+                const uint32_t l = xx >= 2 ? *reinterpret_cast<const uint32_t *>(row - 2) : 0u;
+                const uint32_t rr = xx + 4 < pitch ? *reinterpret_cast<const uint32_t *>(row + 4) : 0u;
+                return Win16{ l, c4.x, c4.y, rr };
+            };
+            const Win16 wc = ldwin(dc), wu = ldwin(dc - (ptrdiff_t)pitch), wd = ldwin(dc + (ptrdiff_t)pitch);
+            const uint32_t p01 = SIDE < 0 ? 0u : dir_map_pair16<0>(wu, wc, wd, 0, peak, k.neutral, k.shift);
+            const uint32_t p23 = SIDE > 0 ? 0u : dir_map_pair16<2>(wu, wc, wd, 0, peak, k.neutral, k.shift);
+            const uint32_t s01 = ((work & 1u) ? 0x0000ffffu : 0u) | ((work & 2u) ? 0xffff0000u : 0u);
+            const uint32_t s23 = ((work & 4u) ? 0x0000ffffu : 0u) | ((work & 8u) ? 0xffff0000u : 0u);
+            res.x = (res.x & ~s01) | (p01 & s01);
+            res.y = (res.y & ~s23) | (p23 & s23);
+        }
+        return res;
+    };
+    for (int lr = threadIdx.y; lr < QFE_R + 2; lr += 4)
+        *reinterpret_cast<uint2 *>(&s_f[lr][4 + 4 * threadIdx.x]) = filtered(rb - 1 + lr, x, std::integral_constant<int, 0>());
+    if (threadIdx.y == 0 && (int)threadIdx.x < QFE_R + 2)
+        *reinterpret_cast<uint2 *>(&s_f[threadIdx.x][0]) = filtered(rb - 1 + (int)threadIdx.x, bx0 - 4, std::integral_constant<int, -1>());
+    if (threadIdx.y == 1 && (int)threadIdx.x < QFE_R + 2)
+        *reinterpret_cast<uint2 *>(&s_f[threadIdx.x][260]) = filtered(rb - 1 + (int)threadIdx.x, bx0 + 256, std::integral_constant<int, 1>());
+    __syncthreads();
+    // expand_dir_map (:722-773) out of s_f: which samples reach the sort (q_dir_map, phase 1)
+    for (int lr = threadIdx.y; lr < QFE_R; lr += 4)
+    {
+        const int y = rb + lr;
+        if (x >= width || y >= height) continue;
+        const uint16_t *row = &s_f[lr + 1][4 + 4 * threadIdx.x];
+        const uint2 out = *reinterpret_cast<const uint2 *>(row);
+        if (y >= 1 && y < height - 1)
+        {
+            // six samples x-1 .. x+4 of the three rows: usable (non-peak) flags, bit j = sample x-1+j
+            auto usable6 = [&](const uint16_t *rw) -> uint32_t {
+                const uint2 v = *reinterpret_cast<const uint2 *>(rw);
+                const int l = rw[-1], r = rw[4];
+                return (l != peak ? 1u : 0u) | ((int)(v.x & 0xffffu) != peak ? 2u : 0u) | ((int)(v.x >> 16) != peak ? 4u : 0u) |
+                       ((int)(v.y & 0xffffu) != peak ? 8u : 0u) | ((int)(v.y >> 16) != peak ? 16u : 0u) | (r != peak ? 32u : 0u);
+            };
+            const uint32_t fc = usable6(row), fu = usable6(row - QFE_LW), fd = usable6(row + QFE_LW);
+            const uint2 m0 = *reinterpret_cast<const uint2 *>(Q.a + (size_t)y * pitch + x);
+            const int mm0[4] = { (int)(m0.x & 0xffffu), (int)(m0.x >> 16), (int)(m0.y & 0xffffu), (int)(m0.y >> 16) };
+            uint32_t sortpx = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+            {
+                const int xx = x + j;
+                const bool cand = xx >= 1 && xx < width - 1 && mm0[j] == peak && !((fc >> (j + 1)) & 1u);   // expand only fills peak samples
+                const int u = __popc((fu >> j) & 7u) + __popc((fd >> j) & 7u) + __popc((fc >> j) & 5u);     // the centre is left out (:671)
+                if (cand && u >= 5) sortpx |= 1u << j;
+            }
+            if (sortpx)
+            {
+                int at = atomicAdd(&s_count, __popc(sortpx));
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if ((sortpx >> j) & 1u) s_list[at++] = (uint16_t)((lr << 8) | (4 * threadIdx.x + j));
+            }
+        }
+        *reinterpret_cast<uint2 *>(&s_out[lr][4 * threadIdx.x]) = out;
+    }
+    __syncthreads();
+    const int count = s_count;
+    for (int i = tid; i < count; i += 256)
+    {
+        const int e = s_list[i], ly = e >> 8, lx = e & 255;
+        const uint16_t *c = &s_f[ly + 1][4 + lx], *up = c - QFE_LW, *dn = c + QFE_LW;
+        s_out[ly][lx] = (uint16_t)dir_map_px16(up[-1], up[0], up[1], c[-1], c[0], c[1], dn[-1], dn[0], dn[1], true, true, 1,
+                                               peak, k.neutral, 2 + k.shift, s_lim);
+    }
+    __syncthreads();
+    for (int lr = threadIdx.y; lr < QFE_R; lr += 4)
+    {
+        const int y = rb + lr;
+        if (x >= pitch || y >= height) continue;
+        // the row's padding: the peak value, as calc_directions' fill leaves it in the plane the reference expands into
+        uint2 v = x < width ? *reinterpret_cast<const uint2 *>(&s_out[lr][4 * threadIdx.x]) : make_uint2(0u, 0u);
+        v.x = pad_pair16(v.x, x, width, peak);
+        v.y = pad_pair16(v.y, x + 2, width, peak);
+        *reinterpret_cast<uint2 *>(Q.c + (size_t)y * pitch + x) = v;
     }
 }
 
@@ -2534,18 +2678,32 @@ int Eedi2Engine16::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st)
     geom(P, srcp);
     P.pflags = plane_flags_ + 3 * f0;
     P.pepoch = chain_epoch_;
-    bind(P.a, mskp); bind(P.b, srcp); bind(P.c, tmpp);
+    // filter_dir_map and expand_dir_map as one launch (q_dir_map_fe; eedi2.hip: Eedi2Engine::enqueue_passes): calc_directions
+    // then writes dstp, and leaves the padding of its rows alone, so that the fused pass leaves the expanded map - and the
+    // padding calc_directions' fill gives it - in tmpp, where the reference has them
+    const bool fused = par_.maximum_search_distance <= QHALO - 2 && hbhip_dev_int("HBHIP_EEDI2_FUSE_DIRMAP", 1) != 0;
+    bind(P.a, mskp); bind(P.b, srcp); bind(P.c, fused ? dstp : tmpp);
     if (par_.maximum_search_distance <= QHALO - 2)
         // 256 columns x 4 rows per block, the mostly listed blocks in the dense form (eedi2.hip: Eedi2Engine::enqueue_passes);
         // its keys hold sums of 12-bit samples at most
         HBHIP_LAUNCH_ON(lc, st, "eedi2_16_calc_directions", q_calc_dir_rows<4>, dim3(hbhip_grid_x((srcp.stride[0] / 2 + QW - 1) / QW), (srcp.height[0] + 3) / 4, gz),
-                     dim3(QW), 0, P, k, par_.maximum_search_distance, par_.noise_threshold, k.peak < (1 << 12) ? QW * 4 / 2 : 1 << 30);
+                     dim3(QW), 0, P, k, par_.maximum_search_distance, par_.noise_threshold, k.peak < (1 << 12) ? QW * 4 / 2 : 1 << 30,
+                     fused ? 0 : k.peak);
     else
         HBHIP_LAUNCH_ON(lc, st, "eedi2_16_calc_directions", q_calc_dir, grid(srcp, true, gz), blk, 0, P, k, par_.maximum_search_distance, par_.noise_threshold);
-    bind(P.a, mskp); bind(P.b, tmpp); bind(P.c, dstp);
-    HBHIP_LAUNCH_ON(lc, st, "eedi2_16_filter_dir_map", q_dir_map4, grid4(srcp, gz), blk, 0, P, k, 1, 0);
-    bind(P.a, mskp); bind(P.b, dstp); bind(P.c, tmpp);
-    HBHIP_LAUNCH_ON(lc, st, "eedi2_16_expand_dir_map", q_dir_map, grid4(srcp, gz), blk, 0, P, k, 1, 1, 0);
+    if (fused)
+    {
+        bind(P.a, mskp); bind(P.b, dstp); bind(P.c, tmpp);
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_filter_expand_dir_map", q_dir_map_fe,
+                        dim3(hbhip_grid_x((srcp.stride[0] / 2 + 255) / 256), (srcp.height[0] + QFE_R - 1) / QFE_R, gz), blk, 0, P, k);
+    }
+    else
+    {
+        bind(P.a, mskp); bind(P.b, tmpp); bind(P.c, dstp);
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_filter_dir_map", q_dir_map4, grid4(srcp, gz), blk, 0, P, k, 1, 0);
+        bind(P.a, mskp); bind(P.b, dstp); bind(P.c, tmpp);
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_expand_dir_map", q_dir_map, grid4(srcp, gz), blk, 0, P, k, 1, 1, 0);
+    }
     bind(P.a, mskp); bind(P.b, tmpp); bind(P.c, dstp);
     HBHIP_LAUNCH_ON(lc, st, "eedi2_16_filter_map", q_filter_map, grid4(srcp, gz), blk, 0, P, k);
     // the three line doublings + mark_directions_2x in one launch (full-height geometry)
