@@ -584,7 +584,12 @@ int launch_copy(hbhip_ctx *ctx, const char *name, DevPicture *in, DevPicture *ou
 #define LS_BX_N 64
 #endif
 // a workgroup is LS_BX x LS_BY threads = 4 LS_BX columns x LS_BY LS_ROWS rows of a plane
-constexpr int LS_ROWS = LS_ROWS_N, LS_FRAMES = 16, LS_BX = LS_BX_N, LS_BY = 256 / LS_BX_N;
+#ifndef LS_ROWS16_N
+#define LS_ROWS16_N 4
+#endif
+// (16-bit samples: four rows per thread - 2160p x 16 frames 197 us per launch against 211 at eight; at 8 bits eight rows are
+// 7 % ahead of four, profiles/r6g_lapsharp_block_shapes.log)
+constexpr int LS_ROWS = LS_ROWS_N, LS_ROWS16 = LS_ROWS16_N, LS_FRAMES = 16, LS_BX = LS_BX_N, LS_BY = 256 / LS_BX_N;
 struct LapPlane3 { int width, height, src_pitch, dst_pitch, stride_border, valid_w, a, b, c, active; double coef, strength; int fast, kinv; float mixf; };
 struct LapBatch3
 {
@@ -728,7 +733,7 @@ __global__ __launch_bounds__(256) void lapsharp3_rows16_kernel(LapBatch3 B, int 
     const LapPlane3 &P = B.pl[c];
     if (!P.active) return;
     const int x0 = (blockIdx.x * LS_BX + threadIdx.x) * 4;
-    const int ys = (blockIdx.y * LS_BY + threadIdx.y) * LS_ROWS;
+    const int ys = (blockIdx.y * LS_BY + threadIdx.y) * LS_ROWS16;
     if (x0 >= P.width || ys >= P.height) return;
     const uint8_t *src = B.src[f][c];
     uint8_t *dst = B.dst[f][c];
@@ -738,9 +743,9 @@ __global__ __launch_bounds__(256) void lapsharp3_rows16_kernel(LapBatch3 B, int 
                    o3 = 4u * (uint32_t)min(xd + 2, pitch_dw - 1);
     int u_prev[4], u_cur[4], v_cur[4], m_cur[4];
     // all rows of the thread fetched ahead of its first store (lapsharp3_rows_kernel)
-    uint32_t raw[LS_ROWS + 2][4];
+    uint32_t raw[LS_ROWS16 + 2][4];
 #pragma unroll
-    for (int i = 0; i < LS_ROWS + 2; i++)
+    for (int i = 0; i < LS_ROWS16 + 2; i++)
     {
         const uint32_t ro = (uint32_t)__mul24(min(max(ys - 1 + i, 0), P.height - 1), P.src_pitch);
         raw[i][0] = *reinterpret_cast<const uint32_t *>(src + (ro + o0)); raw[i][1] = *reinterpret_cast<const uint32_t *>(src + (ro + o1));
@@ -774,14 +779,14 @@ __global__ __launch_bounds__(256) void lapsharp3_rows16_kernel(LapBatch3 B, int 
         load_row(0, u_prev, v_tmp, m_tmp);
         load_row(1, u_cur, v_cur, m_cur);
     }
-    const int y_end = min(ys + LS_ROWS, P.height);
+    const int y_end = min(ys + LS_ROWS16, P.height);
     uint32_t copy_cols = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++)
         if (x0 + k < P.stride_border + 2 || x0 + k > P.width + P.stride_border - 2) copy_cols |= 1u << k;
     const bool full = x0 + 3 < P.width;
 #pragma unroll
-    for (int r = 0; r < LS_ROWS; r++)
+    for (int r = 0; r < LS_ROWS16; r++)
     {
         const int y = ys + r;
         if (y >= y_end) break;
@@ -907,7 +912,8 @@ public:
                 }
             }
             // (hbhip_grid_x: never a multiple of 8 workgroups per row of strips - see hbhip_internal.h)
-            const dim3 grid(hbhip_grid_x(((max_w + 3) / 4 + LS_BX - 1) / LS_BX), (max_h + LS_BY * LS_ROWS - 1) / (LS_BY * LS_ROWS), 3 * nf);
+            const int rows = LS_BY * (in_geo.bps == 1 ? LS_ROWS : LS_ROWS16);
+            const dim3 grid(hbhip_grid_x(((max_w + 3) / 4 + LS_BX - 1) / LS_BX), (max_h + rows - 1) / rows, 3 * nf);
             if (in_geo.bps == 1) HBHIP_LAUNCH(ctx, "lapsharp_3x3", lapsharp3_rows_kernel, grid, dim3(LS_BX, LS_BY), 0, B);
             else                 HBHIP_LAUNCH(ctx, "lapsharp_3x3", lapsharp3_rows16_kernel, grid, dim3(LS_BX, LS_BY), 0, B, (1 << in_geo.depth) - 1);
             HBHIP_CHECK(ctx, hipGetLastError());
