@@ -1561,19 +1561,24 @@ __global__ __launch_bounds__(256) void k_dir_map_c(P3 P, int step, int expand, i
 #endif
 constexpr int FE_R = FE_ROWS, FE_LW = 68;
 
-// eedi2_expand_dir_map (:719-773) out of the filtered tile s_f (k_dir_map_c at step 1): fe_expand_row decides a dword of
-// output row lr - copied, or its pixels with enough usable neighbours queued for the vote -, fe_expand_finish votes and stores.
+// STEP 2 is the pair of _2x passes (:872-1011) on the lattice of the rows they rebuild: lattice row r is plane row
+// y = 2 r + (y0 & 1), its neighbours the plane rows y -+ 2 (where they exist: up_ok / dn_ok), its mask rows y - 1 and y + 1;
+// the plane rows between them are the passes' bit_blit and leave as they came.
+//
+// eedi2_expand_dir_map (:719-773) out of the filtered tile s_f (k_dir_map_c): fe_expand_row decides a dword of output
+// row lr - copied, or its pixels with enough usable neighbours queued for the vote -, fe_expand_finish votes and stores.
 // cand: the row's pixels on the mask and inside the row (one flag byte each).
-__device__ __forceinline__ void fe_expand_row(const uint32_t (*s_f)[FE_LW], int lr, int tx, uint32_t cand, uint8_t (*s_out)[256],
-                                              uint16_t *s_list, int *s_count)
+__device__ __forceinline__ void fe_expand_row(const uint32_t (*s_f)[FE_LW], int lr, int tx, uint32_t cand, bool up_ok, bool dn_ok,
+                                              uint8_t (*s_out)[256], uint16_t *s_list, int *s_count)
 {
     const uint32_t own = s_f[lr + 1][tx + 1];
     cand &= ff_bytes(own) >> 7;                                                      // expand only fills peak pixels
     if (cand)
     {
+        const Win12 none = { 0xffffffffu, 0xffffffffu, 0xffffffffu };
         const Win12 wc = { s_f[lr + 1][tx], own, s_f[lr + 1][tx + 2] };
-        const Win12 wu = { s_f[lr][tx], s_f[lr][tx + 1], s_f[lr][tx + 2] };
-        const Win12 wd = { s_f[lr + 2][tx], s_f[lr + 2][tx + 1], s_f[lr + 2][tx + 2] };
+        const Win12 wu = up_ok ? Win12{ s_f[lr][tx], s_f[lr][tx + 1], s_f[lr][tx + 2] } : none;
+        const Win12 wd = dn_ok ? Win12{ s_f[lr + 2][tx], s_f[lr + 2][tx + 1], s_f[lr + 2][tx + 2] } : none;
         uint32_t nc, nu, nd;
         const uint32_t s3c = live3(wc, nc), s3u = live3(wu, nu), s3d = live3(wd, nd);
         const uint32_t u = s3c - nc + s3u + s3d;                                     // the centre is left out (:671)
@@ -1591,67 +1596,66 @@ __device__ __forceinline__ void fe_expand_row(const uint32_t (*s_f)[FE_LW], int 
     *reinterpret_cast<uint32_t *>(&s_out[lr][4 * tx]) = own;
 }
 
-// (between two barriers of its own; the caller has one behind the last fe_expand_row)
-__device__ __forceinline__ void fe_expand_finish(const uint32_t (*s_f)[FE_LW], uint8_t (*s_out)[256], const uint16_t *s_list, int count,
-                                                 const uint8_t *s_lim, uint8_t *dst, int rb, int x, int pitch, int width, int height)
-{
-    const int tid = threadIdx.y * 64 + threadIdx.x;
-    for (int i = tid; i < count; i += 256)
-    {
-        const int e = s_list[i], ly = e >> 8, lx = e & 255;
-        const uint8_t *c = reinterpret_cast<const uint8_t *>(&s_f[ly + 1][1]) + lx;
-        const uint8_t *up = c - 4 * FE_LW, *dn = c + 4 * FE_LW;
-        s_out[ly][lx] = (uint8_t)dir_map_px(up[-1], up[0], up[1], c[-1], c[0], c[1], dn[-1], dn[0], dn[1], true, true, 1, s_lim);
-    }
-    __syncthreads();
-    for (int lr = threadIdx.y; lr < FE_R; lr += 4)
-    {
-        const int y = rb + lr;
-        if (x >= pitch || y >= height) continue;
-        // the row's padding: 255, as calc_directions' memset leaves it in the plane the reference expands into
-        const uint32_t v = x < width ? *reinterpret_cast<const uint32_t *>(&s_out[lr][4 * threadIdx.x]) : 0u;
-        *reinterpret_cast<uint32_t *>(dst + (size_t)y * pitch + x) = pad_bytes(v, x, width, 0xffffffffu);
-    }
-}
-
+template <int STEP>
 __global__ __launch_bounds__(256) void k_dir_map_fe(P3 P)
 {
-    __shared__ uint32_t s_f[FE_R + 2][FE_LW];                       // rows rb - 1 .. rb + FE_R, dword columns -1 .. 64
+    __shared__ uint32_t s_f[FE_R + 2][FE_LW];                       // lattice rows rb - 1 .. rb + FE_R, dword columns -1 .. 64
     __shared__ __attribute__((aligned(16))) uint8_t s_out[FE_R][256];
     __shared__ uint16_t s_list[FE_R * 256];
     __shared__ int s_count;
     __shared__ uint8_t s_lim[LIM_PAD];
     FIELD_PLANE(P);
+    const int y0 = STEP == 1 ? 1 : 2 - tff, par = STEP == 1 ? 0 : (y0 & 1);
     const int rb = blockIdx.y * FE_R;
     const int bx0 = 256 * blockIdx.x, x = bx0 + 4 * threadIdx.x;
     const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
-    if (bx0 >= pitch || rb >= height) return;
+    if (bx0 >= pitch || STEP * rb >= height) return;
+    auto row_ok = [&](int y) { return STEP == 1 ? (y >= 1 && y < height - 1) : (y >= y0 && y < height - 1); };
     if (maskless)
     {
+        // no mask pixel in the plane: both passes are their bit_blit of a map of peaks (k_dir_map4)
         if (x < pitch)
-            for (int lr = threadIdx.y; lr < FE_R && rb + lr < height; lr += 4) *reinterpret_cast<uint32_t *>(Q.c + (size_t)(rb + lr) * pitch + x) = 0xffffffffu;
+            for (int lr = threadIdx.y; lr < FE_R; lr += 4)
+#pragma unroll
+                for (int i = 0; i < STEP; i++)
+                    if (STEP * (rb + lr) + i < height) *reinterpret_cast<uint32_t *>(Q.c + (size_t)(STEP * (rb + lr) + i) * pitch + x) = 0xffffffffu;
         return;
     }
     const int tid = threadIdx.y * 64 + threadIdx.x;
     if (tid == 0) s_count = 0;
     lim_fill(s_lim, tid);
+    // the rows between the lattice's: fetched now, stored at the end
+    constexpr int NCOPY = STEP == 1 ? 1 : (FE_R + 3) / 4;
+    uint32_t vcopy[NCOPY];
+    if (STEP != 1)
+#pragma unroll
+        for (int h = 0; h < NCOPY; h++)
+        {
+            const int lr = threadIdx.y + 4 * h, yc = 2 * (rb + lr) + 1 - par;
+            vcopy[h] = (lr < FE_R && yc < height && x < width) ? *reinterpret_cast<const uint32_t *>(Q.b + (size_t)yc * pitch + x) : 0u;
+        }
     // SIDE 0: the whole dword; -1 / +1: the ring's dword left / right of the tile, of which only the pixel next to the tile
     // is ever read (half the vote)
-    auto filtered = [&](int y, int xx, auto side) -> uint32_t {
+    auto filtered = [&](int r, int xx, auto side) -> uint32_t {
         constexpr int SIDE = decltype(side)::value;
-        if (y < 0 || y >= height || xx < 0 || xx >= width) return 0u;
+        const int y = STEP * r + par;
+        if (r < 0 || y >= height || xx < 0 || xx >= width) return 0u;
         const uint8_t *dc = Q.b + (size_t)y * pitch + xx;
         const uint32_t own = *reinterpret_cast<const uint32_t *>(dc);
-        if (y < 1 || y >= height - 1) return own;
-        const uint32_t m0 = *reinterpret_cast<const uint32_t *>(Q.a + (size_t)y * pitch + xx);
-        uint32_t work = (ff_bytes(m0) >> 7) & mf_bytes_in(xx, 1, width - 1);
+        if (!row_ok(y)) return own;
+        const uint8_t *mk = Q.a + (size_t)y * pitch + xx;
+        const uint32_t m0 = *reinterpret_cast<const uint32_t *>(STEP == 1 ? mk : mk - (ptrdiff_t)pitch);
+        const uint32_t m1 = STEP == 1 ? 0u : *reinterpret_cast<const uint32_t *>(mk + pitch);
+        uint32_t work = ((ff_bytes(m0) | ff_bytes(m1)) >> 7) & mf_bytes_in(xx, 1, width - 1);
         if (SIDE < 0) work &= 0xff000000u;
         if (SIDE > 0) work &= 0x000000ffu;
         uint32_t res = own;
         if (work)
         {
             asm volatile("" ::: "memory");
-            const Win12 wc = ldwin(dc), wu = ldwin(dc - (ptrdiff_t)pitch), wd = ldwin(dc + (ptrdiff_t)pitch);
+            const bool up_ok = STEP == 1 || y > 1, dn_ok = STEP == 1 || y < height - 2;
+            const Win12 none = { 0xffffffffu, 0xffffffffu, 0xffffffffu };
+            const Win12 wc = ldwin(dc), wu = up_ok ? ldwin(dc - (ptrdiff_t)STEP * pitch) : none, wd = dn_ok ? ldwin(dc + (ptrdiff_t)STEP * pitch) : none;
             const uint32_t p01 = SIDE < 0 ? 0u : dir_map_pair<0>(wu, wc, wd, 0), p23 = SIDE > 0 ? 0u : dir_map_pair<2>(wu, wc, wd, 0);
             const uint32_t votes = __builtin_amdgcn_perm(p23, p01, 0x06040200u);
             const uint32_t sel = work * 255u;
@@ -1666,15 +1670,48 @@ __global__ __launch_bounds__(256) void k_dir_map_fe(P3 P)
     __syncthreads();
     for (int lr = threadIdx.y; lr < FE_R; lr += 4)
     {
-        const int y = rb + lr;
+        const int y = STEP * (rb + lr) + par;
         if (x >= width || y >= height) continue;
         uint32_t cand = 0;
-        if (y >= 1 && y < height - 1)
-            cand = (ff_bytes(*reinterpret_cast<const uint32_t *>(Q.a + (size_t)y * pitch + x)) >> 7) & mf_bytes_in(x, 1, width - 1);
-        fe_expand_row(s_f, lr, threadIdx.x, cand, s_out, s_list, &s_count);
+        if (row_ok(y))
+        {
+            const uint8_t *mk = Q.a + (size_t)y * pitch + x;
+            const uint32_t m0 = *reinterpret_cast<const uint32_t *>(STEP == 1 ? mk : mk - (ptrdiff_t)pitch);
+            const uint32_t m1 = STEP == 1 ? 0u : *reinterpret_cast<const uint32_t *>(mk + pitch);
+            cand = ((ff_bytes(m0) | ff_bytes(m1)) >> 7) & mf_bytes_in(x, 1, width - 1);
+        }
+        fe_expand_row(s_f, lr, threadIdx.x, cand, STEP == 1 || y > 1, STEP == 1 || y < height - 2, s_out, s_list, &s_count);
     }
     __syncthreads();
-    fe_expand_finish(s_f, s_out, s_list, s_count, s_lim, Q.c, rb, x, pitch, width, height);
+    const int count = s_count;
+    for (int i = tid; i < count; i += 256)
+    {
+        const int e = s_list[i], ly = e >> 8, lx = e & 255;
+        const int y = STEP * (rb + ly) + par;
+        const uint8_t *c = reinterpret_cast<const uint8_t *>(&s_f[ly + 1][1]) + lx;
+        const uint8_t *up = c - 4 * FE_LW, *dn = c + 4 * FE_LW;
+        s_out[ly][lx] = (uint8_t)dir_map_px(up[-1], up[0], up[1], c[-1], c[0], c[1], dn[-1], dn[0], dn[1],
+                                            STEP == 1 || y > 1, STEP == 1 || y < height - 2, 1, s_lim);
+    }
+    __syncthreads();
+    // the padding of the rows: 255, as the fill in front of the passes (calc_directions', mark_directions_2x's memset) leaves
+    // it in the plane the reference expands into
+#pragma unroll
+    for (int h = 0; h < (FE_R + 3) / 4; h++)
+    {
+        const int lr = threadIdx.y + 4 * h, y = STEP * (rb + lr) + par;
+        if (lr >= FE_R || x >= pitch) continue;
+        if (y < height)
+        {
+            const uint32_t v = x < width ? *reinterpret_cast<const uint32_t *>(&s_out[lr][4 * threadIdx.x]) : 0u;
+            *reinterpret_cast<uint32_t *>(Q.c + (size_t)y * pitch + x) = pad_bytes(v, x, width, 0xffffffffu);
+        }
+        if (STEP != 1)
+        {
+            const int yc = 2 * (rb + lr) + 1 - par;
+            if (yc < height) *reinterpret_cast<uint32_t *>(Q.c + (size_t)yc * pitch + x) = pad_bytes(vcopy[h < NCOPY ? h : 0], x, width, 0xffffffffu);
+        }
+    }
 }
 
 // (Measured and dropped, DESIGN.md 4.2.3: the filter pass's votes on a queue - the tile staged in LDS, the aligned pixel
@@ -1805,7 +1842,7 @@ __global__ __launch_bounds__(256) void k_filter_map(P3 P)
 // A thread takes the rows 2r and 2r + 1 of its dword column: both are doubled from half-height row r (three loads for six
 // stores), one of them at most is a row mark_directions_2x rebuilds, the other is the memset's 255 - a wave of its own
 // per row spent more scalar instructions on finding its plane and field than vector ones on its dword.
-__global__ __launch_bounds__(256) void k_mark_2x4(P3 P)
+__global__ __launch_bounds__(256) void k_mark_2x4(P3 P, uint32_t padv)
 {
     const uint8_t *limlut = c_limlut;
     FIELD_PLANE(P);
@@ -1851,13 +1888,15 @@ __global__ __launch_bounds__(256) void k_mark_2x4(P3 P)
             *reinterpret_cast<uint32_t *>(Q.f + fs + pitch) = va;
         }
     }
-    if (yc < height) *reinterpret_cast<uint32_t *>(Q.c + (size_t)yc * pitch + x) = 0xffffffffu;      // memset(dstp, 255, pitch*height)
+    // memset(dstp, 255, pitch*height); padv: what the rows' padding gets (0 when the map goes to the plane the fused dir-map
+    // pass reads, whose padding the reference never writes)
+    if (yc < height) *reinterpret_cast<uint32_t *>(Q.c + (size_t)yc * pitch + x) = pad_bytes(0xffffffffu, x, width, padv);
     if (y >= height) return;
     uint32_t *o = reinterpret_cast<uint32_t *>(Q.c + (size_t)y * pitch + x);
     uint32_t packed = 0xffffffffu;
     if (!vote)                                                 // (no mask pixel in the plane or near the thread: nothing but the memset, :800)
     {
-        *o = packed;
+        *o = pad_bytes(packed, x, width, padv);
         return;
     }
 #pragma unroll
@@ -1891,7 +1930,7 @@ __global__ __launch_bounds__(256) void k_mark_2x4(P3 P)
             }
         }
     }
-    *o = packed;
+    *o = pad_bytes(packed, x, width, padv);
 }
 
 // fill_gaps_2x.  a = msk2p, b = dmsk in, c = out.  Every pixel of a fillable gap computes the same
@@ -3341,7 +3380,7 @@ int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st, ui
     if (fused)
     {
         bind(P.a, mskp); bind(P.b, dstp); bind(P.c, tmpp);
-        HBHIP_LAUNCH_ON(lc, st, "eedi2_filter_expand_dir_map", k_dir_map_fe,
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_filter_expand_dir_map", k_dir_map_fe<1>,
                         dim3(hbhip_grid_x((srcp.stride[0] + 255) / 256), (srcp.height[0] + FE_R - 1) / FE_R, gz), blk, 0, P);
     }
     else
@@ -3356,14 +3395,25 @@ int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st, ui
     // line doubling of srcp / dstp / mskp + mark_directions_2x in one launch (full-height geometry)
     geom(P, dst2p);
     bind(P.g, srcp); bind(P.b, dstp); bind(P.a, mskp);
-    bind(P.d, dst2p); bind(P.e, tmp2p2); bind(P.f, msk2p); bind(P.c, tmp2p);
+    // the pair of _2x dir-map passes behind it as one launch too (k_dir_map_fe<2>): the marked map then goes to dst2mp
+    const bool fused2 = hbhip_dev_int("HBHIP_EEDI2_FUSE_DIRMAP_2X", 1) != 0;
+    bind(P.d, dst2p); bind(P.e, tmp2p2); bind(P.f, msk2p); bind(P.c, fused2 ? dst2mp : tmp2p);
     HBHIP_LAUNCH_ON(lc, st, "eedi2_mark_directions_2x", k_mark_2x4,                                      // a thread row per PAIR of full-height rows
-                 dim3(hbhip_grid_x((dst2p.stride[0] + 255) / 256), ((dst2p.height[0] + 1) / 2 + 3) / 4, gz), blk, 0, P);
+                 dim3(hbhip_grid_x((dst2p.stride[0] + 255) / 256), ((dst2p.height[0] + 1) / 2 + 3) / 4, gz), blk, 0, P, fused2 ? 0u : 0xffffffffu);
     for (int c = 0; c < 3; c++) P.d[c] = P.e[c] = P.f[c] = P.g[c] = nullptr;    // slot d doubles as the dir-map kernels' optional copy target
-    bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
-    dir_map("eedi2_filter_dir_map_2x", dst2p, P, 2, 0);
-    bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
-    dir_map("eedi2_expand_dir_map_2x", dst2p, P, 2, 1);
+    if (fused2)
+    {
+        bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_filter_expand_dir_map_2x", k_dir_map_fe<2>,
+                        dim3(hbhip_grid_x((dst2p.stride[0] + 255) / 256), ((dst2p.height[0] + 1) / 2 + FE_R - 1) / FE_R, gz), blk, 0, P);
+    }
+    else
+    {
+        bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
+        dir_map("eedi2_filter_dir_map_2x", dst2p, P, 2, 0);
+        bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
+        dir_map("eedi2_expand_dir_map_2x", dst2p, P, 2, 1);
+    }
     // (a workgroup per row here: with the copied row of a pair folded into the workgroup of the rebuilt one, as in the dir-map
     // passes, this kernel went from 131 to 163-165 us per launch)
     const dim3 fg_grid(hbhip_grid_x((dst2p.width[0] + FG_W - 1) / FG_W), (dst2p.height[0] + 2 * FG_R - 1) / (2 * FG_R), gz);

@@ -121,7 +121,7 @@ def main():
         else:
             half = FRAME // 2
             add(st, {"eedi2_calc_directions": 3 * half, "eedi2_lattice_candidates": 3 * FRAME // 2 + FRAME // 2 * 4,
-                     "eedi2_lattice_resolve": FRAME // 2 * 4 + FRAME, "eedi2_filter_dir_map_2x": 3 * FRAME,
+                     "eedi2_lattice_resolve": FRAME // 2 * 4 + FRAME, "eedi2_filter_dir_map_2x": 3 * FRAME, "eedi2_filter_expand_dir_map_2x": 3 * FRAME,
                      "eedi2_expand_dir_map_2x": 3 * FRAME, "eedi2_fill_gaps_2x": 3 * FRAME,
                      "eedi2_mark_directions_2x": 3 * FRAME, "eedi2_filter_dir_map": 3 * half,
                      "eedi2_filter_expand_dir_map": 3 * half, "eedi2_expand_dir_map": 3 * half, "eedi2_filter_map": 3 * half, "eedi2_erode": 2 * half,
