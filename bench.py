@@ -93,6 +93,7 @@ def algorithmic_bytes(kernel, w, h, out_w, out_h, frames_per_launch=1):
 
         "eedi2_mark_directions_2x": 3 * half + 4 * full,              # 3 line doublings + tmp2p
         "eedi2_filter_dir_map_2x": 3 * full, "eedi2_expand_dir_map_2x": 3 * full, "eedi2_filter_expand_dir_map_2x": 3 * full,
+        "eedi2_filter_expand_dir_map_2x_post": 6 * full,              # msk2p + map -> map + filtered map; dst2p read and (rarely) written
         "eedi2_fill_gaps_2x": 3 * full,
         "eedi2_lattice_candidates": 3 * full + 4 * full,              # tmp2p, dst2p, tmp2p2 -> u32 candidates
         "eedi2_lattice_resolve": 4 * full + 2 * full,

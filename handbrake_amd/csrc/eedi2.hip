@@ -1596,8 +1596,11 @@ __device__ __forceinline__ void fe_expand_row(const uint32_t (*s_f)[FE_LW], int 
     *reinterpret_cast<uint32_t *>(&s_out[lr][4 * tx]) = own;
 }
 
-template <int STEP>
-__global__ __launch_bounds__(256) void k_dir_map_fe(P3 P)
+// POST (the pair in front of eedi2_post_process, :1349-1378, which rides along as in k_dir_map_c): d = where the filtered
+// map goes as well (the reference leaves it in dst2mp), f = the picture; the old map is the pass's own input, so the
+// eedi2_bit_blit that keeps a copy of it is not needed - the caller has the input in the plane the copy would go to.
+template <int STEP, bool POST>
+__global__ __launch_bounds__(256) void k_dir_map_fe(P3 P, uint32_t padv)
 {
     __shared__ uint32_t s_f[FE_R + 2][FE_LW];                       // lattice rows rb - 1 .. rb + FE_R, dword columns -1 .. 64
     __shared__ __attribute__((aligned(16))) uint8_t s_out[FE_R][256];
@@ -1618,7 +1621,12 @@ __global__ __launch_bounds__(256) void k_dir_map_fe(P3 P)
             for (int lr = threadIdx.y; lr < FE_R; lr += 4)
 #pragma unroll
                 for (int i = 0; i < STEP; i++)
-                    if (STEP * (rb + lr) + i < height) *reinterpret_cast<uint32_t *>(Q.c + (size_t)(STEP * (rb + lr) + i) * pitch + x) = 0xffffffffu;
+                    if (STEP * (rb + lr) + i < height)
+                    {
+                        const size_t at = (size_t)(STEP * (rb + lr) + i) * pitch + x;
+                        *reinterpret_cast<uint32_t *>(Q.c + at) = pad_bytes(0xffffffffu, x, width, padv);
+                        if (POST && x < width) { const int out[4] = { PEAK, PEAK, PEAK, PEAK }; st4(Q.d + at, out, x, width); }
+                    }
         return;
     }
     const int tid = threadIdx.y * 64 + threadIdx.x;
@@ -1694,22 +1702,53 @@ __global__ __launch_bounds__(256) void k_dir_map_fe(P3 P)
                                             STEP == 1 || y > 1, STEP == 1 || y < height - 2, 1, s_lim);
     }
     __syncthreads();
-    // the padding of the rows: 255, as the fill in front of the passes (calc_directions', mark_directions_2x's memset) leaves
-    // it in the plane the reference expands into
+    // the padding of the rows (padv): 255 where the reference expands into a plane that the fill in front of the passes
+    // (calc_directions', mark_directions_2x's memset) has covered, 0 where into one nothing has
 #pragma unroll
     for (int h = 0; h < (FE_R + 3) / 4; h++)
     {
         const int lr = threadIdx.y + 4 * h, y = STEP * (rb + lr) + par;
         if (lr >= FE_R || x >= pitch) continue;
+        auto put_d = [&](int yy, uint32_t v) {                     // the filtered map: the row's pixels only, as the pass's bit_blit
+            if (x >= width) return;
+            uint8_t *o = Q.d + (size_t)yy * pitch + x;
+            if (x + 3 < width) *reinterpret_cast<uint32_t *>(o) = v;
+            else for (int k = 0; k < 4 && x + k < width; k++) o[k] = (uint8_t)(v >> (8 * k));
+        };
         if (y < height)
         {
             const uint32_t v = x < width ? *reinterpret_cast<const uint32_t *>(&s_out[lr][4 * threadIdx.x]) : 0u;
-            *reinterpret_cast<uint32_t *>(Q.c + (size_t)y * pitch + x) = pad_bytes(v, x, width, 0xffffffffu);
+            *reinterpret_cast<uint32_t *>(Q.c + (size_t)y * pitch + x) = pad_bytes(v, x, width, padv);
+            if (POST) put_d(y, s_f[lr + 1][threadIdx.x + 1]);
+            if (POST && x < width && row_ok(y))
+            {
+                const size_t at = (size_t)y * pitch + x;
+                const uint32_t om4 = *reinterpret_cast<const uint32_t *>(Q.b + at);
+                uint8_t *d = Q.f + at;
+                const uint32_t up4 = *reinterpret_cast<const uint32_t *>(d - pitch), dn4 = *reinterpret_cast<const uint32_t *>(d + pitch);
+                const uint32_t cur4 = *reinterpret_cast<const uint32_t *>(d);
+                int out[4];
+                bool any = false;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                {
+                    const int nm = (v >> (8 * k)) & 0xffu, om = (om4 >> (8 * k)) & 0xffu;
+                    const int lim = s_lim[iabs(nm - NEUTRAL) >> 2];
+                    const bool fix = iabs(nm - om) > lim && om != PEAK && om != NEUTRAL;
+                    out[k] = fix ? (int)((((up4 >> (8 * k)) & 0xffu) + ((dn4 >> (8 * k)) & 0xffu) + 1) >> 1) : (int)((cur4 >> (8 * k)) & 0xffu);
+                    any |= fix;
+                }
+                if (any) st4(d, out, x, width);
+            }
         }
         if (STEP != 1)
         {
             const int yc = 2 * (rb + lr) + 1 - par;
-            if (yc < height) *reinterpret_cast<uint32_t *>(Q.c + (size_t)yc * pitch + x) = pad_bytes(vcopy[h < NCOPY ? h : 0], x, width, 0xffffffffu);
+            if (yc < height)
+            {
+                *reinterpret_cast<uint32_t *>(Q.c + (size_t)yc * pitch + x) = pad_bytes(vcopy[h < NCOPY ? h : 0], x, width, padv);
+                if (POST) put_d(yc, vcopy[h < NCOPY ? h : 0]);
+            }
         }
     }
 }
@@ -3380,8 +3419,8 @@ int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st, ui
     if (fused)
     {
         bind(P.a, mskp); bind(P.b, dstp); bind(P.c, tmpp);
-        HBHIP_LAUNCH_ON(lc, st, "eedi2_filter_expand_dir_map", k_dir_map_fe<1>,
-                        dim3(hbhip_grid_x((srcp.stride[0] + 255) / 256), (srcp.height[0] + FE_R - 1) / FE_R, gz), blk, 0, P);
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_filter_expand_dir_map", (k_dir_map_fe<1, false>),
+                        dim3(hbhip_grid_x((srcp.stride[0] + 255) / 256), (srcp.height[0] + FE_R - 1) / FE_R, gz), blk, 0, P, 0xffffffffu);
     }
     else
     {
@@ -3397,15 +3436,24 @@ int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st, ui
     bind(P.g, srcp); bind(P.b, dstp); bind(P.a, mskp);
     // the pair of _2x dir-map passes behind it as one launch too (k_dir_map_fe<2>): the marked map then goes to dst2mp
     const bool fused2 = hbhip_dev_int("HBHIP_EEDI2_FUSE_DIRMAP_2X", 1) != 0;
-    bind(P.d, dst2p); bind(P.e, tmp2p2); bind(P.f, msk2p); bind(P.c, fused2 ? dst2mp : tmp2p);
+    // ... and the pair in front of post_process (k_dir_map_fe<2, true>).  That pass reads the map the lattice leaves and the
+    // reference has it write the new map over it, with the eedi2_bit_blit in front keeping a copy in tmp2p2
+    // (decomb_template.c:426-429); one launch cannot read a plane's neighbourhoods and write that plane.  So the two planes
+    // change places from mark_directions_2x on: the direction map lives in tmp2p2 - where the copy would go: no blit - and the
+    // doubled half-height map (the lattice's omsk, dead behind it) in tmp2p, which the fused pass then overwrites with the new
+    // map.  Every plane ends as the reference leaves it, the padding of its rows included.
+    const bool post1 = par_.post_processing == 1 || par_.post_processing == 3;
+    const bool swapped = fused2 && post1 && hbhip_dev_int("HBHIP_EEDI2_FUSE_DIRMAP_POST", 1) != 0;
+    const EediFrame &map2 = swapped ? tmp2p2 : tmp2p, &omsk2 = swapped ? tmp2p : tmp2p2;
+    bind(P.d, dst2p); bind(P.e, omsk2); bind(P.f, msk2p); bind(P.c, fused2 ? dst2mp : map2);
     HBHIP_LAUNCH_ON(lc, st, "eedi2_mark_directions_2x", k_mark_2x4,                                      // a thread row per PAIR of full-height rows
                  dim3(hbhip_grid_x((dst2p.stride[0] + 255) / 256), ((dst2p.height[0] + 1) / 2 + 3) / 4, gz), blk, 0, P, fused2 ? 0u : 0xffffffffu);
     for (int c = 0; c < 3; c++) P.d[c] = P.e[c] = P.f[c] = P.g[c] = nullptr;    // slot d doubles as the dir-map kernels' optional copy target
+    const dim3 fe2_grid(hbhip_grid_x((dst2p.stride[0] + 255) / 256), ((dst2p.height[0] + 1) / 2 + FE_R - 1) / FE_R, gz);
     if (fused2)
     {
-        bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
-        HBHIP_LAUNCH_ON(lc, st, "eedi2_filter_expand_dir_map_2x", k_dir_map_fe<2>,
-                        dim3(hbhip_grid_x((dst2p.stride[0] + 255) / 256), ((dst2p.height[0] + 1) / 2 + FE_R - 1) / FE_R, gz), blk, 0, P);
+        bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, map2);
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_filter_expand_dir_map_2x", (k_dir_map_fe<2, false>), fe2_grid, blk, 0, P, swapped ? 0u : 0xffffffffu);
     }
     else
     {
@@ -3417,12 +3465,12 @@ int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st, ui
     // (a workgroup per row here: with the copied row of a pair folded into the workgroup of the rebuilt one, as in the dir-map
     // passes, this kernel went from 131 to 163-165 us per launch)
     const dim3 fg_grid(hbhip_grid_x((dst2p.width[0] + FG_W - 1) / FG_W), (dst2p.height[0] + 2 * FG_R - 1) / (2 * FG_R), gz);
-    bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
+    bind(P.a, msk2p); bind(P.b, map2); bind(P.c, dst2mp);
     HBHIP_LAUNCH_ON(lc, st, "eedi2_fill_gaps_2x", k_fill_gaps_b, fg_grid, dim3(FG_T), 0, P);
-    bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
+    bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, map2);
     HBHIP_LAUNCH_ON(lc, st, "eedi2_fill_gaps_2x", k_fill_gaps_b, fg_grid, dim3(FG_T), 0, P);
     // lattice
-    bind(P.a, tmp2p); bind(P.b, dst2p); bind(P.c, tmp2p2);
+    bind(P.a, map2); bind(P.b, dst2p); bind(P.c, omsk2);
     {
         const int nrows = (dst2p.height[0] - 1) / 2;      // rows y0, y0 + 2, ... < height - 1 for either parity (the heights are even)
         const int nt = par_.noise_threshold;
@@ -3431,7 +3479,15 @@ int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st, ui
         HBHIP_LAUNCH_ON(lc, st, "eedi2_lattice_resolve", k_lattice_resolve, dim3(1, nrows + 1, gz), dim3(LR_T), 0, P,
                      (const uint32_t *)cand, cand_pitch_, cand_plane_stride_);
     }
-    if (par_.post_processing == 1 || par_.post_processing == 3)
+    if (swapped)
+    {
+        // filter_dir_map_2x, expand_dir_map_2x and post_process in one launch: tmp2p2 (the map, and what the reference's copy of
+        // it would hold) -> tmp2p, the filtered map to dst2mp, the corrections to dst2p
+        bind(P.a, msk2p); bind(P.b, tmp2p2); bind(P.c, tmp2p); bind(P.d, dst2mp); bind(P.f, dst2p);
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_filter_expand_dir_map_2x_post", (k_dir_map_fe<2, true>), fe2_grid, blk, 0, P, 0xffffffffu);
+        for (int c = 0; c < 3; c++) P.d[c] = P.f[c] = nullptr;
+    }
+    else if (post1)
     {
         // eedi2_bit_blit(tmp2p -> tmp2p2) keeps the pre-filter direction map for post_process
         // (decomb_template.c:426); the filter that follows reads every byte of tmp2p the blit copies,

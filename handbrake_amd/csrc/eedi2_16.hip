@@ -1232,52 +1232,78 @@ __global__ __launch_bounds__(256) void q_dir_map(Q3 P, K16 k, int step, int expa
     }
 }
 
-// filter_dir_map and the expand_dir_map behind it (half height, step 1) in one launch (eedi2.hip: k_dir_map_fe): a workgroup
-// makes the filtered map of its QFE_R rows x 256 samples and of the one-sample ring around them in LDS (q_dir_map4's vote),
-// expands out of that (q_dir_map's two phases) and stores the expanded map only.  a = mask, b = map in, c = out (not b).
+// filter_dir_map and the expand_dir_map behind it in one launch (eedi2.hip: k_dir_map_fe): a workgroup makes the filtered
+// map of its QFE_R rows x 256 samples and of the one-sample ring around them in LDS (q_dir_map4's vote), expands out of
+// that (q_dir_map's two phases) and stores the expanded map only.  a = mask, b = map in, c = out (not b).  STEP 1: the half-
+// height pair; STEP 2: the _2x pair on the lattice of the rows it rebuilds (row r = plane row 2 r + (y0 & 1), neighbours
+// y -+ 2 where they exist, mask rows y - 1 / y + 1), the plane rows between them copied.
 #ifndef FE16_ROWS
 #define FE16_ROWS 14
 #endif
 constexpr int QFE_R = FE16_ROWS, QFE_LW = 272;                      // LDS row: the group of 4 left of the tile, 256 samples, the group right of it
+template <int STEP>
 __global__ __launch_bounds__(256) void q_dir_map_fe(Q3 P, K16 k)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t s_f[QFE_R + 2][QFE_LW];      // rows rb - 1 .. rb + QFE_R
+    __shared__ __attribute__((aligned(16))) uint16_t s_f[QFE_R + 2][QFE_LW];      // lattice rows rb - 1 .. rb + QFE_R
     __shared__ __attribute__((aligned(16))) uint16_t s_out[QFE_R][256];
     __shared__ uint16_t s_list[QFE_R * 256];
     __shared__ int s_count;
     __shared__ int s_lim[33];
     static_assert(QFE_R + 2 <= 64, "a lane per ring row");
     FIELD16(P);
+    const int y0 = STEP == 1 ? 1 : 2 - tff, par = STEP == 1 ? 0 : (y0 & 1);
     const int rb = blockIdx.y * QFE_R;
     const int bx0 = 256 * blockIdx.x, x = bx0 + 4 * threadIdx.x;
     const int pitch = P.pitch[pl], width = P.width[pl], height = P.height[pl];
-    if (bx0 >= pitch || rb >= height) return;
+    if (bx0 >= pitch || STEP * rb >= height) return;
     const int peak = k.peak;
     const uint32_t peak2 = (uint32_t)peak * 0x00010001u;
+    auto row_ok = [&](int y) { return STEP == 1 ? (y >= 1 && y < height - 1) : (y >= y0 && y < height - 1); };
     if (maskless)
     {
         if (x < pitch)
-            for (int lr = threadIdx.y; lr < QFE_R && rb + lr < height; lr += 4)
-                *reinterpret_cast<uint2 *>(Q.c + (size_t)(rb + lr) * pitch + x) = make_uint2(peak2, peak2);
+            for (int lr = threadIdx.y; lr < QFE_R; lr += 4)
+#pragma unroll
+                for (int i = 0; i < STEP; i++)
+                    if (STEP * (rb + lr) + i < height)
+                        *reinterpret_cast<uint2 *>(Q.c + (size_t)(STEP * (rb + lr) + i) * pitch + x) = make_uint2(peak2, peak2);
         return;
     }
     const int tid = threadIdx.y * 64 + threadIdx.x;
     if (tid == 0) s_count = 0;
     if (tid < 33) s_lim[tid] = k.limlut[tid];
-    // SIDE 0: the thread's four samples; -1 / +1: the ring's group left / right of the tile, of which only the sample next to
-    // the tile is ever read (half the vote)
-    auto filtered = [&](int y, int xx, auto side) -> uint2 {
-        constexpr int SIDE = decltype(side)::value;
-        if (y < 0 || y >= height || xx < 0 || xx >= width) return make_uint2(0u, 0u);
-        const uint16_t *dc = Q.b + (size_t)y * pitch + xx;
-        const uint2 own = *reinterpret_cast<const uint2 *>(dc);
-        if (y < 1 || y >= height - 1) return own;
-        const uint2 m0 = *reinterpret_cast<const uint2 *>(Q.a + (size_t)y * pitch + xx);
+    // the rows between the lattice's: fetched now, stored at the end
+    constexpr int NCOPY = STEP == 1 ? 1 : (QFE_R + 3) / 4;
+    uint2 vcopy[NCOPY];
+    if (STEP != 1)
+#pragma unroll
+        for (int h = 0; h < NCOPY; h++)
+        {
+            const int lr = threadIdx.y + 4 * h, yc = 2 * (rb + lr) + 1 - par;
+            vcopy[h] = (lr < QFE_R && yc < height && x < width) ? *reinterpret_cast<const uint2 *>(Q.b + (size_t)yc * pitch + x) : make_uint2(0u, 0u);
+        }
+    auto masked4 = [&](int y, int xx) -> uint32_t {                // bit j: sample xx + j is inside the row and under / above a mask sample
+        const uint16_t *mk = Q.a + (size_t)y * pitch + xx;
+        const uint2 m0 = *reinterpret_cast<const uint2 *>(STEP == 1 ? mk : mk - (ptrdiff_t)pitch);
+        const uint2 m1 = STEP == 1 ? make_uint2(0u, 0u) : *reinterpret_cast<const uint2 *>(mk + pitch);
         const int mm0[4] = { (int)(m0.x & 0xffffu), (int)(m0.x >> 16), (int)(m0.y & 0xffffu), (int)(m0.y >> 16) };
-        uint32_t work = 0;
+        const int mm1[4] = { (int)(m1.x & 0xffffu), (int)(m1.x >> 16), (int)(m1.y & 0xffffu), (int)(m1.y >> 16) };
+        uint32_t w = 0;
 #pragma unroll
         for (int j = 0; j < 4; j++)
-            if (xx + j >= 1 && xx + j < width - 1 && mm0[j] == peak) work |= 1u << j;
+            if (xx + j >= 1 && xx + j < width - 1 && (mm0[j] == peak || (STEP != 1 && mm1[j] == peak))) w |= 1u << j;
+        return w;
+    };
+    // SIDE 0: the thread's four samples; -1 / +1: the ring's group left / right of the tile, of which only the sample next to
+    // the tile is ever read (half the vote)
+    auto filtered = [&](int r, int xx, auto side) -> uint2 {
+        constexpr int SIDE = decltype(side)::value;
+        const int y = STEP * r + par;
+        if (r < 0 || y >= height || xx < 0 || xx >= width) return make_uint2(0u, 0u);
+        const uint16_t *dc = Q.b + (size_t)y * pitch + xx;
+        const uint2 own = *reinterpret_cast<const uint2 *>(dc);
+        if (!row_ok(y)) return own;
+        uint32_t work = masked4(y, xx);
         if (SIDE < 0) work &= 8u;
         if (SIDE > 0) work &= 1u;
         uint2 res = own;
@@ -1290,7 +1316,10 @@ __global__ __launch_bounds__(256) void q_dir_map_fe(Q3 P, K16 k)
                 const uint32_t rr = xx + 4 < pitch ? *reinterpret_cast<const uint32_t *>(row + 4) : 0u;
                 return Win16{ l, c4.x, c4.y, rr };
             };
-            const Win16 wc = ldwin(dc), wu = ldwin(dc - (ptrdiff_t)pitch), wd = ldwin(dc + (ptrdiff_t)pitch);
+            const bool up_ok = STEP == 1 || y > 1, dn_ok = STEP == 1 || y < height - 2;
+            const Win16 none = { peak2, peak2, peak2, peak2 };
+            const Win16 wc = ldwin(dc);
+            const Win16 wu = up_ok ? ldwin(dc - (ptrdiff_t)STEP * pitch) : none, wd = dn_ok ? ldwin(dc + (ptrdiff_t)STEP * pitch) : none;
             const uint32_t p01 = SIDE < 0 ? 0u : dir_map_pair16<0>(wu, wc, wd, 0, peak, k.neutral, k.shift);
             const uint32_t p23 = SIDE > 0 ? 0u : dir_map_pair16<2>(wu, wc, wd, 0, peak, k.neutral, k.shift);
             const uint32_t s01 = ((work & 1u) ? 0x0000ffffu : 0u) | ((work & 2u) ? 0xffff0000u : 0u);
@@ -1310,12 +1339,13 @@ __global__ __launch_bounds__(256) void q_dir_map_fe(Q3 P, K16 k)
     // expand_dir_map (:722-773) out of s_f: which samples reach the sort (q_dir_map, phase 1)
     for (int lr = threadIdx.y; lr < QFE_R; lr += 4)
     {
-        const int y = rb + lr;
+        const int y = STEP * (rb + lr) + par;
         if (x >= width || y >= height) continue;
         const uint16_t *row = &s_f[lr + 1][4 + 4 * threadIdx.x];
         const uint2 out = *reinterpret_cast<const uint2 *>(row);
-        if (y >= 1 && y < height - 1)
+        if (row_ok(y))
         {
+            const bool up_ok = STEP == 1 || y > 1, dn_ok = STEP == 1 || y < height - 2;
             // six samples x-1 .. x+4 of the three rows: usable (non-peak) flags, bit j = sample x-1+j
             auto usable6 = [&](const uint16_t *rw) -> uint32_t {
                 const uint2 v = *reinterpret_cast<const uint2 *>(rw);
@@ -1323,15 +1353,13 @@ __global__ __launch_bounds__(256) void q_dir_map_fe(Q3 P, K16 k)
                 return (l != peak ? 1u : 0u) | ((int)(v.x & 0xffffu) != peak ? 2u : 0u) | ((int)(v.x >> 16) != peak ? 4u : 0u) |
                        ((int)(v.y & 0xffffu) != peak ? 8u : 0u) | ((int)(v.y >> 16) != peak ? 16u : 0u) | (r != peak ? 32u : 0u);
             };
-            const uint32_t fc = usable6(row), fu = usable6(row - QFE_LW), fd = usable6(row + QFE_LW);
-            const uint2 m0 = *reinterpret_cast<const uint2 *>(Q.a + (size_t)y * pitch + x);
-            const int mm0[4] = { (int)(m0.x & 0xffffu), (int)(m0.x >> 16), (int)(m0.y & 0xffffu), (int)(m0.y >> 16) };
+            const uint32_t fc = usable6(row), fu = up_ok ? usable6(row - QFE_LW) : 0u, fd = dn_ok ? usable6(row + QFE_LW) : 0u;
+            const uint32_t on_mask = masked4(y, x);
             uint32_t sortpx = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++)
             {
-                const int xx = x + j;
-                const bool cand = xx >= 1 && xx < width - 1 && mm0[j] == peak && !((fc >> (j + 1)) & 1u);   // expand only fills peak samples
+                const bool cand = ((on_mask >> j) & 1u) && !((fc >> (j + 1)) & 1u);                         // expand only fills peak samples
                 const int u = __popc((fu >> j) & 7u) + __popc((fd >> j) & 7u) + __popc((fc >> j) & 5u);     // the centre is left out (:671)
                 if (cand && u >= 5) sortpx |= 1u << j;
             }
@@ -1350,20 +1378,28 @@ __global__ __launch_bounds__(256) void q_dir_map_fe(Q3 P, K16 k)
     for (int i = tid; i < count; i += 256)
     {
         const int e = s_list[i], ly = e >> 8, lx = e & 255;
-        const uint16_t *c = &s_f[ly + 1][4 + lx], *up = c - QFE_LW, *dn = c + QFE_LW;
-        s_out[ly][lx] = (uint16_t)dir_map_px16(up[-1], up[0], up[1], c[-1], c[0], c[1], dn[-1], dn[0], dn[1], true, true, 1,
+        const int y = STEP * (rb + ly) + par;
+        const bool up_ok = STEP == 1 || y > 1, dn_ok = STEP == 1 || y < height - 2;
+        const uint16_t *c = &s_f[ly + 1][4 + lx], *up = up_ok ? c - QFE_LW : c, *dn = dn_ok ? c + QFE_LW : c;
+        s_out[ly][lx] = (uint16_t)dir_map_px16(up[-1], up[0], up[1], c[-1], c[0], c[1], dn[-1], dn[0], dn[1], up_ok, dn_ok, 1,
                                                peak, k.neutral, 2 + k.shift, s_lim);
     }
     __syncthreads();
-    for (int lr = threadIdx.y; lr < QFE_R; lr += 4)
+    // the padding of the rows: the peak value, as the fill in front of the passes (calc_directions', mark_directions_2x's)
+    // leaves it in the plane the reference expands into
+    auto padded = [&](uint2 v) { return make_uint2(pad_pair16(v.x, x, width, peak), pad_pair16(v.y, x + 2, width, peak)); };
+#pragma unroll
+    for (int h = 0; h < (QFE_R + 3) / 4; h++)
     {
-        const int y = rb + lr;
-        if (x >= pitch || y >= height) continue;
-        // the row's padding: the peak value, as calc_directions' fill leaves it in the plane the reference expands into
-        uint2 v = x < width ? *reinterpret_cast<const uint2 *>(&s_out[lr][4 * threadIdx.x]) : make_uint2(0u, 0u);
-        v.x = pad_pair16(v.x, x, width, peak);
-        v.y = pad_pair16(v.y, x + 2, width, peak);
-        *reinterpret_cast<uint2 *>(Q.c + (size_t)y * pitch + x) = v;
+        const int lr = threadIdx.y + 4 * h, y = STEP * (rb + lr) + par;
+        if (lr >= QFE_R || x >= pitch) continue;
+        if (y < height)
+            *reinterpret_cast<uint2 *>(Q.c + (size_t)y * pitch + x) = padded(x < width ? *reinterpret_cast<const uint2 *>(&s_out[lr][4 * threadIdx.x]) : make_uint2(0u, 0u));
+        if (STEP != 1)
+        {
+            const int yc = 2 * (rb + lr) + 1 - par;
+            if (yc < height) *reinterpret_cast<uint2 *>(Q.c + (size_t)yc * pitch + x) = padded(vcopy[h < NCOPY ? h : 0]);
+        }
     }
 }
 
@@ -1462,7 +1498,7 @@ __global__ __launch_bounds__(256) void q_filter_map(Q3 P, K16 k)
 // Four samples per thread and a PAIR of full-height rows per thread row (2r, 2r + 1 - both doubled from half-height row r):
 // the row with the rebuilt rows' parity is worked on, the other is the memset's peak.  `height` = full height.  Every load
 // goes out ahead of the first store.
-__global__ __launch_bounds__(256) void q_mark_2x(Q3 P, K16 k)
+__global__ __launch_bounds__(256) void q_mark_2x(Q3 P, K16 k, int padv)
 {
     FIELD16(P);
     const int x = 4 * (blockIdx.x * blockDim.x + threadIdx.x), r = blockIdx.y * blockDim.y + threadIdx.y;
@@ -1502,10 +1538,13 @@ __global__ __launch_bounds__(256) void q_mark_2x(Q3 P, K16 k)
         *reinterpret_cast<uint2 *>(Qe + fs + pitch) = vb;
         *reinterpret_cast<uint2 *>(Qf + fs + pitch) = va;
     }
-    if (yc < height) *reinterpret_cast<uint2 *>(Q.c + (size_t)yc * pitch + x) = peak4;
+    // padv: what the rows' padding gets (0 when the map goes to the plane the fused dir-map pass reads, whose padding the
+    // reference never writes; eedi2.hip: k_mark_2x4)
+    auto padded = [&](uint2 v) { return make_uint2(pad_pair16(v.x, x, width, padv), pad_pair16(v.y, x + 2, width, padv)); };
+    if (yc < height) *reinterpret_cast<uint2 *>(Q.c + (size_t)yc * pitch + x) = padded(peak4);
     if (y >= height) return;
     uint2 *o = reinterpret_cast<uint2 *>(Q.c + (size_t)y * pitch + x);
-    if (!rebuilt) { *o = peak4; return; }                                      // (no mask sample in the plane: nothing but the fill, :800)
+    if (!rebuilt) { *o = padded(peak4); return; }                              // (no mask sample in the plane: nothing but the fill, :800)
     const int A[6] = { al, (int)(a4.x & 0xffffu), (int)(a4.x >> 16), (int)(a4.y & 0xffffu), (int)(a4.y >> 16), ar };
     const int B[6] = { bl, (int)(b4.x & 0xffffu), (int)(b4.x >> 16), (int)(b4.y & 0xffffu), (int)(b4.y >> 16), br };
     const int M0[4] = { (int)(k0.x & 0xffffu), (int)(k0.x >> 16), (int)(k0.y & 0xffffu), (int)(k0.y >> 16) };
@@ -1541,7 +1580,7 @@ __global__ __launch_bounds__(256) void q_mark_2x(Q3 P, K16 k)
             }
         }
     }
-    *o = make_uint2(out[0] | (out[1] << 16), out[2] | (out[3] << 16));
+    *o = padded(make_uint2(out[0] | (out[1] << 16), out[2] | (out[3] << 16)));
 }
 
 // eedi2_fill_gaps_2x (:1025-1132): a = msk2p, b = direction map in, c = out.
@@ -2694,7 +2733,7 @@ int Eedi2Engine16::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st)
     if (fused)
     {
         bind(P.a, mskp); bind(P.b, dstp); bind(P.c, tmpp);
-        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_filter_expand_dir_map", q_dir_map_fe,
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_filter_expand_dir_map", q_dir_map_fe<1>,
                         dim3(hbhip_grid_x((srcp.stride[0] / 2 + 255) / 256), (srcp.height[0] + QFE_R - 1) / QFE_R, gz), blk, 0, P, k);
     }
     else
@@ -2708,13 +2747,24 @@ int Eedi2Engine16::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st)
     HBHIP_LAUNCH_ON(lc, st, "eedi2_16_filter_map", q_filter_map, grid4(srcp, gz), blk, 0, P, k);
     // the three line doublings + mark_directions_2x in one launch (full-height geometry)
     geom(P, dst2p);
-    bind(P.a, mskp); bind(P.b, dstp); bind(P.g, srcp); bind(P.c, tmp2p); bind(P.d, dst2p); bind(P.e, tmp2p2); bind(P.f, msk2p);
+    // the pair of _2x dir-map passes behind it as one launch too (q_dir_map_fe<2>): the marked map then goes to dst2mp
+    const bool fused2 = hbhip_dev_int("HBHIP_EEDI2_FUSE_DIRMAP_2X", 1) != 0;
+    bind(P.a, mskp); bind(P.b, dstp); bind(P.g, srcp); bind(P.c, fused2 ? dst2mp : tmp2p); bind(P.d, dst2p); bind(P.e, tmp2p2); bind(P.f, msk2p);
     HBHIP_LAUNCH_ON(lc, st, "eedi2_16_mark_directions_2x", q_mark_2x,                                    // a thread row per pair of rows, four samples per thread
-                 dim3(hbhip_grid_x((dst2p.stride[0] / 2 + 255) / 256), ((dst2p.height[0] + 1) / 2 + 3) / 4, gz), blk, 0, P, k);
-    bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
-    HBHIP_LAUNCH_ON(lc, st, "eedi2_16_filter_dir_map_2x", q_dir_map4, grid4p(dst2p, gz), blk, 0, P, k, 2, 0);
-    bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
-    HBHIP_LAUNCH_ON(lc, st, "eedi2_16_expand_dir_map_2x", q_dir_map, grid4p(dst2p, gz), blk, 0, P, k, 2, 1, 0);
+                 dim3(hbhip_grid_x((dst2p.stride[0] / 2 + 255) / 256), ((dst2p.height[0] + 1) / 2 + 3) / 4, gz), blk, 0, P, k, fused2 ? 0 : k.peak);
+    if (fused2)
+    {
+        bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_filter_expand_dir_map_2x", q_dir_map_fe<2>,
+                        dim3(hbhip_grid_x((dst2p.stride[0] / 2 + 255) / 256), ((dst2p.height[0] + 1) / 2 + QFE_R - 1) / QFE_R, gz), blk, 0, P, k);
+    }
+    else
+    {
+        bind(P.a, msk2p); bind(P.b, tmp2p); bind(P.c, dst2mp);
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_filter_dir_map_2x", q_dir_map4, grid4p(dst2p, gz), blk, 0, P, k, 2, 0);
+        bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_expand_dir_map_2x", q_dir_map, grid4p(dst2p, gz), blk, 0, P, k, 2, 1, 0);
+    }
     for (int pass = 0; pass < 2; pass++)
     {
         const EediFrame &in = pass ? dst2mp : tmp2p, &out = pass ? tmp2p : dst2mp;
