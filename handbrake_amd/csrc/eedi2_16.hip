@@ -1241,8 +1241,11 @@ __global__ __launch_bounds__(256) void q_dir_map(Q3 P, K16 k, int step, int expa
 #define FE16_ROWS 14
 #endif
 constexpr int QFE_R = FE16_ROWS, QFE_LW = 272;                      // LDS row: the group of 4 left of the tile, 256 samples, the group right of it
-template <int STEP>
-__global__ __launch_bounds__(256) void q_dir_map_fe(Q3 P, K16 k)
+// POST (the pair in front of eedi2_post_process, which rides along as in q_dir_map): d = where the filtered map goes as
+// well, f = the picture, the old map = the pass's own input (eedi2.hip: k_dir_map_fe<2, true>); padv = what the padding of
+// the output's rows gets.
+template <int STEP, bool POST>
+__global__ __launch_bounds__(256) void q_dir_map_fe(Q3 P, K16 k, int padv)
 {
     __shared__ __attribute__((aligned(16))) uint16_t s_f[QFE_R + 2][QFE_LW];      // lattice rows rb - 1 .. rb + QFE_R
     __shared__ __attribute__((aligned(16))) uint16_t s_out[QFE_R][256];
@@ -1266,7 +1269,12 @@ __global__ __launch_bounds__(256) void q_dir_map_fe(Q3 P, K16 k)
 #pragma unroll
                 for (int i = 0; i < STEP; i++)
                     if (STEP * (rb + lr) + i < height)
-                        *reinterpret_cast<uint2 *>(Q.c + (size_t)(STEP * (rb + lr) + i) * pitch + x) = make_uint2(peak2, peak2);
+                    {
+                        const size_t at = (size_t)(STEP * (rb + lr) + i) * pitch + x;
+                        *reinterpret_cast<uint2 *>(Q.c + at) = make_uint2(pad_pair16(peak2, x, width, padv), pad_pair16(peak2, x + 2, width, padv));
+                        if (POST)
+                            for (int j = 0; j < 4 && x + j < width; j++) (P.d[pl] + (size_t)fld * P.fstride + at)[j] = (uint16_t)peak;
+                    }
         return;
     }
     const int tid = threadIdx.y * 64 + threadIdx.x;
@@ -1385,20 +1393,63 @@ __global__ __launch_bounds__(256) void q_dir_map_fe(Q3 P, K16 k)
                                                peak, k.neutral, 2 + k.shift, s_lim);
     }
     __syncthreads();
-    // the padding of the rows: the peak value, as the fill in front of the passes (calc_directions', mark_directions_2x's)
-    // leaves it in the plane the reference expands into
-    auto padded = [&](uint2 v) { return make_uint2(pad_pair16(v.x, x, width, peak), pad_pair16(v.y, x + 2, width, peak)); };
+    // the padding of the rows (padv): the peak value where the reference expands into a plane that the fill in front of the
+    // passes (calc_directions', mark_directions_2x's) has covered, 0 where into one nothing has
+    auto padded = [&](uint2 v) { return make_uint2(pad_pair16(v.x, x, width, padv), pad_pair16(v.y, x + 2, width, padv)); };
+    auto put_d = [&](int yy, uint2 v) {                            // the filtered map: the row's samples only, as the pass's bit_blit
+        if (x >= width) return;
+        uint16_t *o = P.d[pl] + (size_t)fld * P.fstride + (size_t)yy * pitch + x;
+        if (x + 3 < width) *reinterpret_cast<uint2 *>(o) = v;
+        else
+        {
+            const uint16_t o4[4] = { (uint16_t)(v.x & 0xffffu), (uint16_t)(v.x >> 16), (uint16_t)(v.y & 0xffffu), (uint16_t)(v.y >> 16) };
+            for (int j = 0; j < 4 && x + j < width; j++) o[j] = o4[j];
+        }
+    };
 #pragma unroll
     for (int h = 0; h < (QFE_R + 3) / 4; h++)
     {
         const int lr = threadIdx.y + 4 * h, y = STEP * (rb + lr) + par;
         if (lr >= QFE_R || x >= pitch) continue;
         if (y < height)
-            *reinterpret_cast<uint2 *>(Q.c + (size_t)y * pitch + x) = padded(x < width ? *reinterpret_cast<const uint2 *>(&s_out[lr][4 * threadIdx.x]) : make_uint2(0u, 0u));
+        {
+            const uint2 v = x < width ? *reinterpret_cast<const uint2 *>(&s_out[lr][4 * threadIdx.x]) : make_uint2(0u, 0u);
+            *reinterpret_cast<uint2 *>(Q.c + (size_t)y * pitch + x) = padded(v);
+            if (POST) put_d(y, *reinterpret_cast<const uint2 *>(&s_f[lr + 1][4 + 4 * threadIdx.x]));
+            if (POST && x < width && row_ok(y))
+            {
+                const size_t at = (size_t)y * pitch + x;
+                const uint2 om4 = *reinterpret_cast<const uint2 *>(Q.b + at);
+                uint16_t *d = P.f[pl] + (size_t)fld * P.fstride + at;
+                const uint2 up4 = *reinterpret_cast<const uint2 *>(d - pitch), dn4 = *reinterpret_cast<const uint2 *>(d + pitch);
+                const uint2 cur4 = *reinterpret_cast<const uint2 *>(d);
+                auto s4 = [](const uint2 &w, int j) -> int { return (int)(((j < 2 ? w.x : w.y) >> (16 * (j & 1))) & 0xffffu); };
+                uint32_t out[4];
+                bool any = false;
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                {
+                    const int nm = s4(v, j), om = s4(om4, j);
+                    const int lim = s_lim[iabs16(nm - k.neutral) >> (2 + k.shift)];
+                    const bool fix = iabs16(nm - om) > lim && om != k.peak && om != k.neutral;
+                    out[j] = fix ? (uint32_t)((s4(up4, j) + s4(dn4, j) + 1) >> 1) : (uint32_t)s4(cur4, j);
+                    any |= fix;
+                }
+                if (any)
+                {
+                    if (x + 3 < width) *reinterpret_cast<uint2 *>(d) = make_uint2(out[0] | (out[1] << 16), out[2] | (out[3] << 16));
+                    else for (int j = 0; j < 4 && x + j < width; j++) d[j] = (uint16_t)out[j];
+                }
+            }
+        }
         if (STEP != 1)
         {
             const int yc = 2 * (rb + lr) + 1 - par;
-            if (yc < height) *reinterpret_cast<uint2 *>(Q.c + (size_t)yc * pitch + x) = padded(vcopy[h < NCOPY ? h : 0]);
+            if (yc < height)
+            {
+                *reinterpret_cast<uint2 *>(Q.c + (size_t)yc * pitch + x) = padded(vcopy[h < NCOPY ? h : 0]);
+                if (POST) put_d(yc, vcopy[h < NCOPY ? h : 0]);
+            }
         }
     }
 }
@@ -2733,8 +2784,8 @@ int Eedi2Engine16::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st)
     if (fused)
     {
         bind(P.a, mskp); bind(P.b, dstp); bind(P.c, tmpp);
-        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_filter_expand_dir_map", q_dir_map_fe<1>,
-                        dim3(hbhip_grid_x((srcp.stride[0] / 2 + 255) / 256), (srcp.height[0] + QFE_R - 1) / QFE_R, gz), blk, 0, P, k);
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_filter_expand_dir_map", (q_dir_map_fe<1, false>),
+                        dim3(hbhip_grid_x((srcp.stride[0] / 2 + 255) / 256), (srcp.height[0] + QFE_R - 1) / QFE_R, gz), blk, 0, P, k, k.peak);
     }
     else
     {
@@ -2747,16 +2798,22 @@ int Eedi2Engine16::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st)
     HBHIP_LAUNCH_ON(lc, st, "eedi2_16_filter_map", q_filter_map, grid4(srcp, gz), blk, 0, P, k);
     // the three line doublings + mark_directions_2x in one launch (full-height geometry)
     geom(P, dst2p);
-    // the pair of _2x dir-map passes behind it as one launch too (q_dir_map_fe<2>): the marked map then goes to dst2mp
+    // the pair of _2x dir-map passes behind it as one launch too (q_dir_map_fe<2>): the marked map then goes to dst2mp; and the
+    // pair in front of post_process with tmp2p and tmp2p2 in each other's places from here on, so that it reads the map where
+    // the reference's copy of it would go (no blit) and writes the new one where the reference has it (eedi2.hip:
+    // Eedi2Engine::enqueue_passes has the whole argument)
     const bool fused2 = hbhip_dev_int("HBHIP_EEDI2_FUSE_DIRMAP_2X", 1) != 0;
-    bind(P.a, mskp); bind(P.b, dstp); bind(P.g, srcp); bind(P.c, fused2 ? dst2mp : tmp2p); bind(P.d, dst2p); bind(P.e, tmp2p2); bind(P.f, msk2p);
+    const bool post1 = par_.post_processing == 1 || par_.post_processing == 3;
+    const bool swapped = fused2 && post1 && hbhip_dev_int("HBHIP_EEDI2_FUSE_DIRMAP_POST", 1) != 0;
+    const EediFrame &map2 = swapped ? tmp2p2 : tmp2p, &omsk2 = swapped ? tmp2p : tmp2p2;
+    bind(P.a, mskp); bind(P.b, dstp); bind(P.g, srcp); bind(P.c, fused2 ? dst2mp : map2); bind(P.d, dst2p); bind(P.e, omsk2); bind(P.f, msk2p);
     HBHIP_LAUNCH_ON(lc, st, "eedi2_16_mark_directions_2x", q_mark_2x,                                    // a thread row per pair of rows, four samples per thread
                  dim3(hbhip_grid_x((dst2p.stride[0] / 2 + 255) / 256), ((dst2p.height[0] + 1) / 2 + 3) / 4, gz), blk, 0, P, k, fused2 ? 0 : k.peak);
+    const dim3 fe2_grid(hbhip_grid_x((dst2p.stride[0] / 2 + 255) / 256), ((dst2p.height[0] + 1) / 2 + QFE_R - 1) / QFE_R, gz);
     if (fused2)
     {
-        bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, tmp2p);
-        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_filter_expand_dir_map_2x", q_dir_map_fe<2>,
-                        dim3(hbhip_grid_x((dst2p.stride[0] / 2 + 255) / 256), ((dst2p.height[0] + 1) / 2 + QFE_R - 1) / QFE_R, gz), blk, 0, P, k);
+        bind(P.a, msk2p); bind(P.b, dst2mp); bind(P.c, map2);
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_filter_expand_dir_map_2x", (q_dir_map_fe<2, false>), fe2_grid, blk, 0, P, k, swapped ? 0 : k.peak);
     }
     else
     {
@@ -2767,11 +2824,11 @@ int Eedi2Engine16::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st)
     }
     for (int pass = 0; pass < 2; pass++)
     {
-        const EediFrame &in = pass ? dst2mp : tmp2p, &out = pass ? tmp2p : dst2mp;
+        const EediFrame &in = pass ? dst2mp : map2, &out = pass ? map2 : dst2mp;
         bind(P.a, msk2p); bind(P.b, in); bind(P.c, out);
         HBHIP_LAUNCH_ON(lc, st, "eedi2_16_fill_gaps_2x", q_fill_gaps_b, dim3(hbhip_grid_x((dst2p.width[0] + QF_W - 1) / QF_W), (dst2p.height[0] + 2 * QF_R - 1) / (2 * QF_R), gz), dim3(256), 0, P, k);
     }
-    bind(P.a, tmp2p); bind(P.b, dst2p); bind(P.c, tmp2p2);
+    bind(P.a, map2); bind(P.b, dst2p); bind(P.c, omsk2);
     {
         const int nrows = (dst2p.height[0] - 1) / 2;                // rows y0, y0 + 2, ... < height - 1 for either parity (even heights)
         HBHIP_LAUNCH_ON(lc, st, "eedi2_16_lattice_candidates", q_lattice_cand, dim3(hbhip_grid_x((dst2p.width[0] + LQ16_W - 1) / LQ16_W), nrows, gz), dim3(256), 0, P, k,
@@ -2779,7 +2836,14 @@ int Eedi2Engine16::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st)
         HBHIP_LAUNCH_ON(lc, st, "eedi2_16_lattice_resolve", q_lattice_resolve16, dim3(1, nrows + 1, gz), dim3(LR16_T), 0, P, k,
                      (const unsigned long long *)cand, cand_pitch_, cand_plane_stride_);
     }
-    if (par_.post_processing == 1 || par_.post_processing == 3)
+    if (swapped)
+    {
+        // filter_dir_map_2x, expand_dir_map_2x and post_process in one launch: tmp2p2 -> tmp2p, the filtered map to dst2mp,
+        // the corrections to dst2p
+        bind(P.a, msk2p); bind(P.b, tmp2p2); bind(P.c, tmp2p); bind(P.d, dst2mp); bind(P.f, dst2p);
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_filter_expand_dir_map_2x_post", (q_dir_map_fe<2, true>), fe2_grid, blk, 0, P, k, k.peak);
+    }
+    else if (post1)
     {
         // (the copy as a store of the filter behind it, as the 8-bit engine has it, cost that launch what the blit costs: 44 us)
         bind(P.a, tmp2p); bind(P.c, tmp2p2);
