@@ -1869,6 +1869,95 @@ __global__ __launch_bounds__(256) void k_filter_map(P3 P)
     else for (int k = 0; k < 4 && x + k < width; k++) o[k] = (uint8_t)(out4 >> (8 * k));
 }
 
+// eedi2_mark_directions_2x's vote (:800-868) for the two pixels at columns K and K + 1 of a thread's dword (K = 0 or 2), the
+// way dir_map_pair votes: wa / wb = the half-height direction rows above and below the rebuilt row (bytes x - 4 .. x + 7), six
+// slots, an absent one (a peak) lifted to PK_ABSENT; returns the pass's value (or PEAK) in the low byte of each half.
+template <int K>
+__device__ __forceinline__ uint32_t mark_pair(const Win12 &wa, const Win12 &wb)
+{
+    u16x2 v[6];
+    {
+        const Win12 *rows[2] = { &wa, &wb };
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+        {
+            const uint32_t w0 = rows[r]->w0, w1 = rows[r]->w1, w2 = rows[r]->w2;
+            if (K == 0)
+            {
+                v[3 * r + 0] = pk(PK_BYTES(w1, w0, 3, 4));            // columns -1, 0
+                v[3 * r + 1] = pk(PK_BYTES(w1, w0, 4, 5));            // 0, 1
+                v[3 * r + 2] = pk(PK_BYTES(w1, w0, 5, 6));            // 1, 2
+            }
+            else
+            {
+                v[3 * r + 0] = pk(PK_BYTES(w1, w0, 5, 6));            // 1, 2
+                v[3 * r + 1] = pk(PK_BYTES(w1, w0, 6, 7));            // 2, 3
+                v[3 * r + 2] = pk(PK_BYTES(w2, w1, 3, 4));            // 3, 4
+            }
+        }
+    }
+    const u16x2 one = pk1(1), zero = pk1(0);
+    u16x2 a[6], raw[6];
+    uint32_t absent = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+    {
+        raw[i] = v[i];
+        a[i] = (u16x2)((v[i] + one) >> 8);                              // 1 per half that holds a peak
+        absent += un(a[i]);
+        v[i] = v[i] + a[i] * pk1(PK_ABSENT_HI);
+    }
+    // mid6's network and selection with masks: n = 6 - absent present values; n <= 4 <=> absent >= 2, n <= 3 <=> absent >= 3,
+    // n <= 5 <=> absent >= 1, n odd <=> absent odd
+    u16x2 s0 = v[0], s1 = v[1], s2 = v[2], s3 = v[3], s4 = v[4], s5 = v[5];
+    cswap2(s0, s5); cswap2(s1, s3); cswap2(s2, s4);
+    cswap2(s1, s2); cswap2(s3, s4);
+    cswap2(s0, s3); cswap2(s2, s5);
+    cswap2(s0, s1); cswap2(s2, s3); cswap2(s4, s5);
+    cswap2(s1, s2); cswap2(s3, s4);
+    const u16x2 ab = pk(absent);
+    const uint32_t m4 = un(zero - pk_lt(one, ab));                     // absent >= 2
+    const uint32_t m3 = un(zero - pk_lt(pk1(2), ab));                  // absent >= 3
+    const uint32_t m5 = un(zero - pk_lt(zero, ab));                    // absent >= 1
+    const uint32_t modd = un(zero - (ab & one));                       // n odd
+#define PK_SEL(m, x, y) (((m) & (x)) | (~(m) & (y)))                    /* v_bfi_b32 */
+    const uint32_t lo = PK_SEL(m4, un(s1), un(s2));
+    const uint32_t hi = PK_SEL(m3, un(s1), PK_SEL(m5, un(s2), un(s3)));
+    const u16x2 mid = pk(PK_SEL(modd, hi, un((u16x2)((pk(lo) + pk(hi) + one) >> 1))));
+#undef PK_SEL
+    const i16x2 t = __builtin_bit_cast(i16x2, (u16x2)(mid - pk1(NEUTRAL)));
+    const u16x2 lim1 = limlut2(__builtin_bit_cast(u16x2, __builtin_elementwise_max(t, (i16x2)(-t))) >> 2) + one;
+    // the three pairs across the rebuilt row (:833-835; the third one compares a2 with b0 and excuses b2 - sic)
+    auto close = [&](int i, int j, int k) -> u16x2 {
+        const u16x2 d = __builtin_elementwise_max(raw[i], raw[j]) - __builtin_elementwise_min(raw[i], raw[j]);
+        return pk_lt(d, lim1) | a[i] | a[k];
+    };
+    const u16x2 u = close(0, 3, 3) + close(1, 4, 4) + close(2, 3, 5);
+    u16x2 sum = zero, cnt = zero;
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+    {
+        const u16x2 d = __builtin_elementwise_max(v[i], mid) - __builtin_elementwise_min(v[i], mid);
+        const u16x2 in = pk_lt(d, lim1);
+        cnt += in;
+        sum += in * v[i];
+    }
+    const uint32_t sm = un((u16x2)(sum + mid)), ct = un(cnt), uu = un(u);
+    uint32_t out = 0;
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+    {
+        const int n = 6 - (int)((absent >> (16 * h)) & 0xffffu);
+        const int count = (int)((ct >> (16 * h)) & 0xffffu);
+        int res = PEAK;
+        // (with fewer than three values the midpoint above may be a PK_ABSENT: nothing of it is used)
+        if (n >= 3 && (int)((uu >> (16 * h)) & 0xffffu) >= 2 && !(count < n - 2 || count < 2))
+            res = vote_avg((int)((sm >> (16 * h)) & 0xffffu), count + 1) & 0xff;
+        out |= (uint32_t)res << (16 * h);
+    }
+    return out;
+}
+
 // a = msk2p, b = dmsk (tmp2p2), c = out (tmp2p)
 // Also performs the three eedi2_upscale_by_2 line doublings (:98-108, decomb_template.c:408-410):
 // g (srcp) -> d (dst2p), b (dstp, the half-height direction map) -> e (tmp2p2), a (mskp) -> f (msk2p).
@@ -1883,7 +1972,6 @@ __global__ __launch_bounds__(256) void k_filter_map(P3 P)
 // per row spent more scalar instructions on finding its plane and field than vector ones on its dword.
 __global__ __launch_bounds__(256) void k_mark_2x4(P3 P, uint32_t padv)
 {
-    const uint8_t *limlut = c_limlut;
     FIELD_PLANE(P);
     const int x = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
     const int r = blockIdx.y * blockDim.y + threadIdx.y;
@@ -1938,36 +2026,14 @@ __global__ __launch_bounds__(256) void k_mark_2x4(P3 P, uint32_t padv)
         *o = pad_bytes(packed, x, width, padv);
         return;
     }
-#pragma unroll
-    for (int k = 0; k < 4; k++)
     {
-        const int xx = x + k;
-        const int k0 = (k0w >> (8 * k)) & 0xff, k1 = (k1w >> (8 * k)) & 0xff;
-        if (xx >= 1 && xx < width - 1 && (k0 == PEAK || k1 == PEAK))
-        {
-            asm volatile("" ::: "memory");                        // keep the branch (see k_dir_map4)
-            const int a0 = wb(wa, k - 1), a1 = wb(wa, k), a2 = wb(wa, k + 1), b0 = wb(wbn, k - 1), b1 = wb(wbn, k), b2 = wb(wbn, k + 1);
-            const int v = (a0 != PEAK) + (a1 != PEAK) + (a2 != PEAK) + (b0 != PEAK) + (b1 != PEAK) + (b2 != PEAK);
-            if (v >= 3)
-            {
-                int s0 = a0 != PEAK ? a0 : ABSENT, s1 = a1 != PEAK ? a1 : ABSENT, s2 = a2 != PEAK ? a2 : ABSENT;
-                int s3 = b0 != PEAK ? b0 : ABSENT, s4 = b1 != PEAK ? b1 : ABSENT, s5 = b2 != PEAK ? b2 : ABSENT;
-                const int mid = mid6(s0, s1, s2, s3, s4, s5, v);
-                const int lim = limlut[iabs(mid - NEUTRAL) >> 2];
-                int u = 0;
-                if (iabs(a0 - b0) <= lim || a0 == PEAK || b0 == PEAK) u++;
-                if (iabs(a1 - b1) <= lim || a1 == PEAK || b1 == PEAK) u++;
-                if (iabs(a2 - b0) <= lim || a2 == PEAK || b2 == PEAK) u++;   // sic (:835): d0[x+1] against d1[x-1]
-                if (u >= 2)
-                {
-                    int sum = 0, count = 0;
-                    vote1(s0, mid, lim, sum, count); vote1(s1, mid, lim, sum, count); vote1(s2, mid, lim, sum, count);
-                    vote1(s3, mid, lim, sum, count); vote1(s4, mid, lim, sum, count); vote1(s5, mid, lim, sum, count);
-                    const int val = vote_avg(sum + mid, count + 1);
-                    if (!(count < v - 2 || count < 2)) packed = (packed & ~(0xffu << (8 * k))) | ((uint32_t)(val & 0xff) << (8 * k));
-                }
-            }
-        }
+        // the pixels under or above a mask pixel, one flag byte each; the vote on pixel pairs (mark_pair)
+        const uint32_t work = ((ff_bytes(k0w) | ff_bytes(k1w)) >> 7) & mf_bytes_in(x, 1, width - 1);
+        asm volatile("" ::: "memory");                            // keep the branch above (see k_dir_map4)
+        const uint32_t p01 = mark_pair<0>(wa, wbn), p23 = mark_pair<2>(wa, wbn);
+        const uint32_t votes = __builtin_amdgcn_perm(p23, p01, 0x06040200u);
+        const uint32_t sel = work * 255u;
+        packed = (packed & ~sel) | (votes & sel);
     }
     *o = pad_bytes(packed, x, width, padv);
 }
