@@ -633,8 +633,6 @@ __device__ __forceinline__ int calc_dir_search16(const uint2 *tr, uint64_t pass,
     return calc_dir_vote16((int)(ka & 63u), (int)(kb & 63u), (int)(kc & 63u), (int)(kd & 63u), (int)(ke & 63u), limlut, neutral, shift);
 }
 
-// dense_min: a block with at least this many listed pixels (none of them on the plane's first / last row) searches in the
-// dense form (R >= 4, depths up to 12 bits)
 // the two samples at columns X, X + 1 with those at or beyond `width` (the row's padding) replaced by padv: the reference's
 // fill of calc_directions' output covers the padding, the bit_blit of the passes behind it does not (eedi2.hip: pad_bytes)
 __device__ __forceinline__ uint32_t pad_pair16(uint32_t v, int X, int width, int padv)
@@ -643,6 +641,9 @@ __device__ __forceinline__ uint32_t pad_pair16(uint32_t v, int X, int width, int
     if (X + 1 >= width) return (v & 0xffffu) | ((uint32_t)padv << 16);
     return v;
 }
+
+// dense_min: a block with at least this many listed pixels (none of them on the plane's first / last row) searches in the
+// dense form (R >= 4, depths up to 12 bits)
 
 template <int R>
 __global__ __launch_bounds__(QW) void q_calc_dir_rows(Q3 P, K16 k, int maxd, int nt, int dense_min, int padv)
