@@ -55,6 +55,9 @@ def main():
             continue
         base = re.split(r"[<(]", k)[0]
         hit = [(n, t) for n, t in stats.items() if base + "(" in n or base + "<" in n]
+        if "<" in k:                                              # an instantiation of its own where the trace names it
+            exact = [(n, t) for n, t in hit if k.split("(")[0] in n]
+            hit = exact or hit
         if not hit:
             continue
         us = sum(c * t for _, (c, t) in hit) / sum(c for _, (c, _) in hit)

@@ -38,6 +38,11 @@ def main():
         base = k.split("<")[0]
         if base.startswith("nlmeans_lanes_kernel"):
             name, frames = "nlmeans_plane_n7", 32
+        elif base.endswith("k_dir_map_fe"):                  # the fused filter_dir_map + expand_dir_map launches, by instantiation
+            args = k.split("<", 1)[1].replace(" ", "") if "<" in k else ""
+            name = ("eedi2_filter_expand_dir_map" if args.startswith("1,") else
+                    "eedi2_filter_expand_dir_map_2x_post" if args.startswith("2,true") else "eedi2_filter_expand_dir_map_2x")
+            frames = 16
         elif base in NAMES:
             name, frames = NAMES[base]
         else:
