@@ -496,40 +496,6 @@ __device__ __forceinline__ int reflect_idx(int j, int n)          // taps outsid
 __device__ __forceinline__ int fx_round14(int acc) { return min(max(((acc + 8192) >> 14) + 32768, 0), 65535); }
 __device__ __forceinline__ int fx_to8(int v16) { return min((v16 + 128) >> 8, 255); }
 
-// Any tap counts, two launches with the 16-bit plane between them in HBM (downscales; an upscale takes the fused
-// kernel below).  ix / iy: tap positions (already reflected), qx / qy: 14-bit coefficients.
-struct Scale8Args
-{
-    const uint8_t *src; uint8_t *dst;
-    int spitch, dpitch, dw, dh, tx, ty, src_rows;
-    const int *ix, *iy;
-    const short *qx, *qy;
-};
-
-__global__ __launch_bounds__(256) void scale8_h_kernel(Scale8Args a, uint16_t *__restrict__ hbuf)
-{
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= a.dw || r >= a.src_rows) return;
-    const int *ix = a.ix + (size_t)x * a.tx;
-    const short *q = a.qx + (size_t)x * a.tx;
-    const uint8_t *row = a.src + (size_t)r * a.spitch;
-    int s = 0;
-    for (int i = 0; i < a.tx; i++) s += (int)q[i] * (int)row[ix[i]];
-    hbuf[(size_t)r * a.dw + x] = (uint16_t)min(max((s + 32) >> 6, 0), 65535);      // = (256 s + 8192) >> 14
-}
-
-__global__ __launch_bounds__(256) void scale8_v_kernel(Scale8Args a, const uint16_t *__restrict__ hbuf)
-{
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= a.dw || y >= a.dh) return;
-    int acc = 0;
-    for (int j = 0; j < a.ty; j++)
-        acc += (int)a.qy[(size_t)y * a.ty + j] * ((int)hbuf[(size_t)a.iy[(size_t)y * a.ty + j] * a.dw + x] - 32768);
-    a.dst[(size_t)y * a.dpitch + x] = (uint8_t)fx_to8(fx_round14(acc));
-}
-
 // ---- the swscale branch (cropscale.c:159-165: `scale=flags=lanczos+accurate_rnd` for sizes zscale is not used for -
 // an odd width or height): libswscale's arithmetic for planar YUV at 8 / 10 / 12 bits, restated in oracle/alias_oracle.c
 // (orc_cropscale_plane_sws / _sws16; PARITY UNPINNED like the zimg form).  px / py: first tapped source column / row of an output
@@ -721,31 +687,152 @@ __global__ __launch_bounds__(256) void scale8_up_kernel(ScaleBatch8 B)
 }
 
 // ---- 10 / 12-bit planes: the same arithmetic at the samples' own depth --------------------------------------------
-// zimg resizes a uint16 plane in place of its depth: per pass dst = clamp((sum c[k] * src[k] + (1 << 13)) >> 14, 0,
-// vmax) (oracle/alias_oracle.c: orc_cropscale_plane_fx16).  Samples and the plane between the passes are below 4096,
-// so they are signed 16-bit values as they stand and v_dot2_i32_i16 takes two taps at a time without any bias.
-__global__ __launch_bounds__(256) void scale16_h_kernel(Scale8Args a, uint16_t *__restrict__ hbuf, int vmax)
+// The two-pass form: any tap counts, the 16-bit plane between the passes in HBM - what a downscale, or any resize the fused
+// kernels' LDS frame does not hold, runs through; an upscale takes the fused kernels.  ix / iy: tap positions (already
+// reflected), qx / qy: 14-bit coefficients.  The planes of up to SD_FRAMES frames per launch (grid.z = 3 * frame + plane): a
+// launch per plane and pass of every frame was 6 launches of 8 - 14 us per 1080p frame (28 % of the kernel time of a
+// 1080i -> 540p list through the plugin surface).  8-bit planes: zimg's 16-bit fixed point between the passes (biased by
+// -32768, fx_round14 / fx_to8).  10 / 12 bits: zimg resizes a uint16 plane in place of its depth, per pass
+// dst = clamp((sum c[k] * src[k] + (1 << 13)) >> 14, 0, vmax) (oracle/alias_oracle.c: orc_cropscale_plane_fx16).
+constexpr int SD_FRAMES = 8;
+struct ScaleBatchHV
 {
+    const uint8_t *src[SD_FRAMES][3];
+    uint8_t       *dst[SD_FRAMES][3];
+    int spitch[3], dpitch[3], dw[3], dh[3], tx[3], ty[3], src_rows[3], src_bytes[3];   // src_bytes: a source row's samples, in bytes
+    const uint32_t *tqx[3];             // horizontal taps, tap-major: [i * dw + x] = position << 16 | coefficient & 0xffff (a lane per column: coalesced)
+    const int *iy[3];
+    const short *qy[3];
+    size_t hoff[3], hframe;             // the plane between the passes: plane c of frame f at hbuf + f * hframe + hoff[c] (samples)
+    unsigned active;                    // bit c: plane c is resized (the others were copied)
+};
+
+// A thread makes SD_HR consecutive rows of its column: the taps (position and coefficient in one word, a lane per column) are
+// fetched once for them, and all CH taps of a chunk - the whole filter where it has at most CH taps: the host picks the
+// instantiation - are in flight before the first multiply.  As a plain loop over the taps every trip waited for its own two
+// loads and the pass ran at the latency of 2 tx round trips (141 us per 8 frames 1080p -> 540p).
+#ifndef SD_HR_N
+#define SD_HR_N 4
+#endif
+constexpr int SD_HR = SD_HR_N;
+template <typename PIX, int CH>
+__global__ __launch_bounds__(256) void scale_h_batch_kernel(ScaleBatchHV a, uint16_t *__restrict__ hbuf, int vmax)
+{
+    const int c = blockIdx.z % 3, f = blockIdx.z / 3;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= a.dw || r >= a.src_rows) return;
-    const int *ix = a.ix + (size_t)x * a.tx;
-    const short *q = a.qx + (size_t)x * a.tx;
-    const uint16_t *row = reinterpret_cast<const uint16_t *>(a.src + (size_t)r * a.spitch);
-    int s = 8192;
-    for (int i = 0; i < a.tx; i++) s += (int)q[i] * (int)row[ix[i]];
-    hbuf[(size_t)r * a.dw + x] = (uint16_t)min(max(s >> 14, 0), vmax);
+    const int r0 = (blockIdx.y * blockDim.y + threadIdx.y) * SD_HR;
+    if (!((a.active >> c) & 1u) || x >= a.dw[c] || r0 >= a.src_rows[c]) return;
+    const int tx = a.tx[c], dw = a.dw[c], nr = min(SD_HR, a.src_rows[c] - r0);
+    const uint32_t *tq = a.tqx[c] + x;
+    const uint8_t *rows = a.src[f][c] + (size_t)r0 * a.spitch[c];
+    uint16_t *h = hbuf + (size_t)f * a.hframe + a.hoff[c] + (size_t)r0 * dw + x;
+    int s[SD_HR];
+#pragma unroll
+    for (int k = 0; k < SD_HR; k++) s[k] = sizeof(PIX) == 1 ? 0 : 8192;
+    for (int i0 = 0; i0 < tx; i0 += CH)
+    {
+        uint32_t t[CH];
+#pragma unroll
+        for (int i = 0; i < CH; i++) t[i] = i0 + i < tx ? tq[(size_t)(i0 + i) * dw] : 0u;          // (a tap beyond tx: coefficient 0 on sample 0)
+        // Away from the plane's edges (where the table folds the taps back) a column's taps are consecutive samples: they
+        // come as the aligned dwords that hold them, realigned by the column's byte offset - a third of the load
+        // instructions of the sample-by-sample form (a quarter at 8 bits), which is what the pass is bound by (a wave's
+        // byte load costs the texture path what its dword load does).
+        const uint32_t base = t[0] >> 16;
+        bool consecutive = true;
+#pragma unroll
+        for (int i = 1; i < CH; i++) consecutive &= i0 + i >= tx || (t[i] >> 16) == base + (uint32_t)i;
+        if (consecutive)
+        {
+            constexpr int SZ = (int)sizeof(PIX), NW = CH * SZ / 4 + 1;
+            const int mis = (int)(reinterpret_cast<uintptr_t>(rows) & 3u);           // (the pitch is a multiple of 4: the same for every row)
+            const int bo = (int)base * SZ + mis, ao = (bo & ~3) - mis, last = ((a.src_bytes[c] - 1 + mis) & ~3) - mis;
+            const uint32_t sh = (uint32_t)bo & 3u;
+            uint32_t w[SD_HR][NW];
+#pragma unroll
+            for (int k = 0; k < SD_HR; k++)
+            {
+                const uint8_t *row = rows + (size_t)min(k, nr - 1) * a.spitch[c];
+#pragma unroll
+                for (int q = 0; q < NW; q++) w[k][q] = *reinterpret_cast<const uint32_t *>(row + min(ao + 4 * q, last));
+            }
+#pragma unroll
+            for (int k = 0; k < SD_HR; k++)
+#pragma unroll
+                for (int i = 0; i < CH; i++)
+                {
+                    const int q = i * SZ / 4;
+                    const uint32_t u = __builtin_amdgcn_alignbyte(w[k][q + 1], w[k][q], sh);
+                    const int px = SZ == 1 ? (int)((u >> (8 * (i & 3))) & 0xffu) : (int)((u >> (16 * (i & 1))) & 0xffffu);
+                    s[k] += (int)(int16_t)(t[i] & 0xffffu) * px;
+                }
+        }
+        else
+        {
+#pragma unroll
+            for (int k = 0; k < SD_HR; k++)
+            {
+                const PIX *row = reinterpret_cast<const PIX *>(rows + (size_t)min(k, nr - 1) * a.spitch[c]);
+#pragma unroll
+                for (int i = 0; i < CH; i++) s[k] += (int)(int16_t)(t[i] & 0xffffu) * (int)row[t[i] >> 16];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < SD_HR; k++)
+        if (k < nr)
+            h[(size_t)k * dw] = sizeof(PIX) == 1 ? (uint16_t)min(max((s[k] + 32) >> 6, 0), 65535)       // = (256 s + 8192) >> 14
+                                                 : (uint16_t)min(max(s[k] >> 14, 0), vmax);
 }
 
-__global__ __launch_bounds__(256) void scale16_v_kernel(Scale8Args a, const uint16_t *__restrict__ hbuf, int vmax)
+// The vertical pass: two adjacent columns per thread (a dword of the plane between the passes), the taps of a row - the same
+// for the whole wave - through the scalar unit, a chunk's loads in flight together.
+template <typename PIX, int CH>
+__global__ __launch_bounds__(256) void scale_v_batch_kernel(ScaleBatchHV a, const uint16_t *__restrict__ hbuf, int vmax)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y * blockDim.y + threadIdx.y;
-    if (x >= a.dw || y >= a.dh) return;
-    int acc = 8192;
-    for (int j = 0; j < a.ty; j++)
-        acc += (int)a.qy[(size_t)y * a.ty + j] * (int)hbuf[(size_t)a.iy[(size_t)y * a.ty + j] * a.dw + x];
-    reinterpret_cast<uint16_t *>(a.dst + (size_t)y * a.dpitch)[x] = (uint16_t)min(max(acc >> 14, 0), vmax);
+    const int c = blockIdx.z % 3, f = blockIdx.z / 3;
+    const int x = 2 * (blockIdx.x * blockDim.x + threadIdx.x);
+    const int y = __builtin_amdgcn_readfirstlane(blockIdx.y * blockDim.y + threadIdx.y);      // (a wave is one row of the block)
+    if (!((a.active >> c) & 1u) || y >= a.dh[c]) return;
+    const int ty = a.ty[c], dw = a.dw[c];
+    const short *qy = a.qy[c] + (size_t)y * ty;
+    const int *iy = a.iy[c] + (size_t)y * ty;
+    if (x >= dw) return;
+    const uint16_t *h = hbuf + (size_t)f * a.hframe + a.hoff[c] + x;
+    const bool pair = x + 1 < dw, dword = pair && (dw & 1) == 0;     // (an even row length: every pair starts on a dword)
+    int acc0 = sizeof(PIX) == 1 ? 0 : 8192, acc1 = acc0;
+    for (int j0 = 0; j0 < ty; j0 += CH)
+    {
+        uint32_t v[CH];
+        int q[CH];
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+        {
+            const bool on = j0 + j < ty;
+            q[j] = on ? (int)qy[j0 + j] : 0;
+            const uint16_t *p = h + (size_t)(on ? iy[j0 + j] : iy[0]) * dw;
+            v[j] = dword ? *reinterpret_cast<const uint32_t *>(p) : (uint32_t)p[0] | (pair ? (uint32_t)p[1] << 16 : 0u);
+        }
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+        {
+            const int bias = sizeof(PIX) == 1 ? 32768 : 0;
+            acc0 += q[j] * ((int)(v[j] & 0xffffu) - bias);
+            acc1 += q[j] * ((int)(v[j] >> 16) - bias);
+        }
+    }
+    if (sizeof(PIX) == 1)
+    {
+        uint8_t *d = a.dst[f][c] + (size_t)y * a.dpitch[c] + x;
+        d[0] = (uint8_t)fx_to8(fx_round14(acc0));
+        if (pair) d[1] = (uint8_t)fx_to8(fx_round14(acc1));
+    }
+    else
+    {
+        uint16_t *d = reinterpret_cast<uint16_t *>(a.dst[f][c] + (size_t)y * a.dpitch[c]) + x;
+        d[0] = (uint16_t)min(max(acc0 >> 14, 0), vmax);
+        if (pair) d[1] = (uint16_t)min(max(acc1 >> 14, 0), vmax);
+    }
 }
 
 // 6 x 6 taps, both passes in one kernel, the planes of up to SU_FRAMES frames per launch: scale8_up_kernel's shape on
@@ -1053,7 +1140,7 @@ public:
     {
         for (int c = 0; c < 3; c++)
         {
-            if (d_ix[c]) (void)hipFree(d_ix[c]);
+            if (d_tqx[c]) (void)hipFree(d_tqx[c]);
             if (d_iy[c]) (void)hipFree(d_iy[c]);
             if (d_bx[c]) (void)hipFree(d_bx[c]);
             if (d_by[c]) (void)hipFree(d_by[c]);
@@ -1110,8 +1197,7 @@ public:
                 HBHIP_CHECK(ctx, hipMemcpy(dptr, v.data(), sizeof(v[0]) * v.size(), hipMemcpyHostToDevice));
                 return HBHIP_OK;
             };
-            int rc = upload(d_ix[c], ix);
-            if (rc == HBHIP_OK) rc = upload(d_iy[c], iy);
+            int rc = upload(d_iy[c], iy);
             if (rc != HBHIP_OK) return rc;
             {
                 // zimg's fixed-point arithmetic at every depth (scale8_* / scale16_* kernels)
@@ -1120,6 +1206,14 @@ public:
                 for (int y = 0; y < dh; y++) quantize_taps(&cy[(size_t)y * ty[c]], ty[c], &qy[(size_t)y * ty[c]]);
                 rc = upload(d_qx[c], qx);
                 if (rc == HBHIP_OK) rc = upload(d_qy[c], qy);
+                if (rc == HBHIP_OK)
+                {
+                    std::vector<uint32_t> tq((size_t)dw * tx[c]);
+                    for (int x = 0; x < dw; x++)
+                        for (int i = 0; i < tx[c]; i++)
+                            tq[(size_t)i * dw + x] = ((uint32_t)ix[(size_t)x * tx[c] + i] << 16) | ((uint32_t)(uint16_t)qx[(size_t)x * tx[c] + i]);
+                    rc = upload(d_tqx[c], tq);
+                }
                 if (rc == HBHIP_OK) rc = upload(d_bx[c], bx);
                 if (rc == HBHIP_OK) rc = upload(d_by[c], by);
                 if (rc != HBHIP_OK) return rc;
@@ -1137,8 +1231,15 @@ public:
             }
         }
         size_t need = 0;
+        hframe = 0;
         for (int c = 0; c < 3; c++)
-            if (!identity[c]) need = std::max(need, (size_t)out_geo.pw[c] * crop_h[c]);
+            if (!identity[c])
+            {
+                need = std::max(need, (size_t)out_geo.pw[c] * crop_h[c]);
+                hoff[c] = hframe;
+                hframe += ((size_t)out_geo.pw[c] * crop_h[c] + 127) & ~(size_t)127;
+            }
+        if (!sws) need = hframe * SD_FRAMES;        // the batched two-pass form: every plane of SD_FRAMES frames between the passes
         if (need && !up6) HBHIP_CHECK(ctx, hipMalloc((void **)&hbuf16, sizeof(uint16_t) * need));
         return HBHIP_OK;
     }
@@ -1188,14 +1289,58 @@ public:
                 else if (tall)       HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", scale16_up_kernel<2 * SU_TH>, grid_tall, dim3(256), 0, B, vmax);
                 else                 HBHIP_LAUNCH(ctx, "cropscale_lanczos_fused", scale16_up_kernel<SU_TH>, grid, dim3(256), 0, B, vmax);
             }
+        else if (!sws)
+            for (int i0 = 0; i0 < n; i0 += SD_FRAMES)
+            {
+                const int m = std::min(SD_FRAMES, n - i0);
+                ScaleBatchHV B;
+                memset(&B, 0, sizeof(B));
+                int gw = 0, ghr = 0, gvr = 0;
+                for (int c = 0; c < 3; c++)
+                {
+                    if (identity[c]) continue;
+                    B.active |= 1u << c;
+                    B.spitch[c] = ins[i0]->pitch[c]; B.dpitch[c] = outs[i0]->pitch[c];
+                    B.dw[c] = out_geo.pw[c]; B.dh[c] = out_geo.ph[c]; B.tx[c] = tx[c]; B.ty[c] = ty[c]; B.src_rows[c] = crop_h[c];
+                    B.src_bytes[c] = crop_w[c] * in_geo.bps;
+                    B.tqx[c] = d_tqx[c]; B.iy[c] = d_iy[c]; B.qy[c] = d_qy[c];
+                    B.hoff[c] = hoff[c];
+                    for (int k = 0; k < m; k++)
+                    {
+                        if (ins[i0 + k]->pitch[c] != B.spitch[c] || outs[i0 + k]->pitch[c] != B.dpitch[c]) return HBHIP_ERR_ARG;
+                        B.src[k][c] = window(ins[i0 + k], c); B.dst[k][c] = outs[i0 + k]->plane[c];
+                    }
+                    gw = std::max(gw, B.dw[c]); ghr = std::max(ghr, B.src_rows[c]); gvr = std::max(gvr, B.dh[c]);
+                }
+                B.hframe = hframe;
+                const dim3 gh((gw + 63) / 64, (ghr + 4 * SD_HR - 1) / (4 * SD_HR), 3 * m), gv(((gw + 1) / 2 + 63) / 64, (gvr + 3) / 4, 3 * m);
+                // the instantiation that holds the planes' longest filter in one chunk (or the widest one, in several)
+                int mtx = 0, mty = 0;
+                for (int c = 0; c < 3; c++)
+                    if (!identity[c]) { mtx = std::max(mtx, tx[c]); mty = std::max(mty, ty[c]); }
+#define SD_GO(K, PIX, CH, G, HB) HBHIP_LAUNCH(ctx, "cropscale_lanczos_" #K, (scale_##K##_batch_kernel<PIX, CH>), G, dim3(64, 4), 0, B, HB, vmax)
+#define SD_PICK(K, PIX, T, G, HB) do { if ((T) <= 8) SD_GO(K, PIX, 8, G, HB); else if ((T) <= 12) SD_GO(K, PIX, 12, G, HB); \
+                                       else if ((T) <= 16) SD_GO(K, PIX, 16, G, HB); else SD_GO(K, PIX, 24, G, HB); } while (0)
+                if (in_geo.bps == 1)
+                {
+                    SD_PICK(h, uint8_t, mtx, gh, hbuf16);
+                    SD_PICK(v, uint8_t, mty, gv, (const uint16_t *)hbuf16);
+                }
+                else
+                {
+                    SD_PICK(h, uint16_t, mtx, gh, hbuf16);
+                    SD_PICK(v, uint16_t, mty, gv, (const uint16_t *)hbuf16);
+                }
+#undef SD_PICK
+#undef SD_GO
+            }
         else
             for (int i = 0; i < n; i++)
                 for (int c = 0; c < 3; c++)
                 {
                     if (identity[c]) continue;
-                    if (sws)
                     {
-                        ScaleSwsArgs w;
+                        ScaleSwsArgs w;                                     // (swscale's arithmetic: odd sizes, a plane and a pass per launch)
                         w.src = window(ins[i], c); w.dst = outs[i]->plane[c];
                         w.spitch = ins[i]->pitch[c]; w.dpitch = outs[i]->pitch[c];
                         w.dw = out_geo.pw[c]; w.dh = out_geo.ph[c]; w.tx = tx[c]; w.ty = ty[c]; w.src_rows = crop_h[c];
@@ -1212,23 +1357,6 @@ public:
                             HBHIP_LAUNCH(ctx, "cropscale_sws_h", scale_sws_h_kernel<uint16_t>, gh, dim3(64, 4), 0, w, (int16_t *)hbuf16, d - 1);
                             HBHIP_LAUNCH(ctx, "cropscale_sws_v", scale_sws_v_kernel<uint16_t>, gv, dim3(64, 4), 0, w, (const int16_t *)hbuf16, 1 << (shift - 1), shift, (1 << d) - 1);
                         }
-                        continue;
-                    }
-                    Scale8Args a;
-                    a.src = window(ins[i], c); a.dst = outs[i]->plane[c];
-                    a.spitch = ins[i]->pitch[c]; a.dpitch = outs[i]->pitch[c];
-                    a.dw = out_geo.pw[c]; a.dh = out_geo.ph[c]; a.tx = tx[c]; a.ty = ty[c]; a.src_rows = crop_h[c];
-                    a.ix = d_ix[c]; a.iy = d_iy[c]; a.qx = d_qx[c]; a.qy = d_qy[c];
-                    const dim3 gh((a.dw + 63) / 64, (crop_h[c] + 3) / 4), gv((a.dw + 63) / 64, (a.dh + 3) / 4);
-                    if (in_geo.bps == 1)
-                    {
-                        HBHIP_LAUNCH(ctx, "cropscale_lanczos_h", scale8_h_kernel, gh, dim3(64, 4), 0, a, hbuf16);
-                        HBHIP_LAUNCH(ctx, "cropscale_lanczos_v", scale8_v_kernel, gv, dim3(64, 4), 0, a, (const uint16_t *)hbuf16);
-                    }
-                    else
-                    {
-                        HBHIP_LAUNCH(ctx, "cropscale_lanczos_h", scale16_h_kernel, gh, dim3(64, 4), 0, a, hbuf16, vmax);
-                        HBHIP_LAUNCH(ctx, "cropscale_lanczos_v", scale16_v_kernel, gv, dim3(64, 4), 0, a, (const uint16_t *)hbuf16, vmax);
                     }
                 }
         HBHIP_CHECK(ctx, hipGetLastError());
@@ -1242,8 +1370,10 @@ public:
     hbhip_cropscale_params par;
     int crop_x[3], crop_y[3], crop_w[3], crop_h[3], tx[3] = {0, 0, 0}, ty[3] = {0, 0, 0};
     bool identity[3] = {false, false, false};
-    int *d_ix[3] = {nullptr, nullptr, nullptr}, *d_iy[3] = {nullptr, nullptr, nullptr};
-    uint16_t *hbuf16 = nullptr; // the 16-bit plane between the passes (two-launch form)
+    int *d_iy[3] = {nullptr, nullptr, nullptr};
+    uint32_t *d_tqx[3] = {nullptr, nullptr, nullptr};   // the two-pass form's horizontal taps (ScaleBatchHV::tqx)
+    uint16_t *hbuf16 = nullptr; // the 16-bit plane between the passes (two-launch form); zimg form: the planes of SD_FRAMES frames
+    size_t hoff[3] = {0, 0, 0}, hframe = 0;
     int *d_bx[3] = {nullptr, nullptr, nullptr}, *d_by[3] = {nullptr, nullptr, nullptr};
     short *d_qx[3] = {nullptr, nullptr, nullptr}, *d_qy[3] = {nullptr, nullptr, nullptr};
 };

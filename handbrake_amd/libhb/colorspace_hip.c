@@ -187,13 +187,15 @@ static int colorspace_hip_work(hb_filter_object_t *filter, hb_buffer_t **buf_in,
         return ((*buf_out)->s.flags & HB_BUF_FLAG_EOF) ? HB_FILTER_DONE : HB_FILTER_OK;
     }
     const int status = hbhip_host_simple_work(pv->dev, &pv->output, filter->short_name, pv->dev_io, buf_in, buf_out);
-    if (status == HB_FILTER_OK && *buf_out != NULL)
-    {
-        (*buf_out)->f.color_prim = pv->output.color_prim;
-        (*buf_out)->f.color_transfer = pv->output.color_transfer;
-        (*buf_out)->f.color_matrix = pv->output.color_matrix;
-        (*buf_out)->f.color_range = pv->output.color_range;
-    }
+    if (status == HB_FILTER_OK || status == HB_FILTER_DONE)
+        for (hb_buffer_t *b = *buf_out; b != NULL; b = b->next)    /* a burst, or the frames an EOF drains, come as a list */
+        {
+            if (b->s.flags & HB_BUF_FLAG_EOF) continue;
+            b->f.color_prim = pv->output.color_prim;
+            b->f.color_transfer = pv->output.color_transfer;
+            b->f.color_matrix = pv->output.color_matrix;
+            b->f.color_range = pv->output.color_range;
+        }
     return status;
 }
 

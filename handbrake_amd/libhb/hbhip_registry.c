@@ -366,10 +366,107 @@ static hb_buffer_t *pipe_collect(hbhip_filter *dev)
     return out;
 }
 
+/* device frames: a stateless filter inside a device-resident run gathers a burst of frames and makes them in one launch
+ * per burst (hbhip_filter_process_dev with n frames), the way decomb_hip and nlmeans_hip gather theirs: a launch per frame
+ * costs such a filter 8-20 us of a 1080p frame where the batched launch takes 2-4 (profiles/r6X_kernel_rooflines.json).  It
+ * answers HB_FILTER_DELAY while it gathers and emits the burst as a buffer list - what the filters in front of it do with
+ * their bursts of eight anyway.  HBHIP_STATELESS_BATCH: frames per burst (default 8, 1 = a launch per frame). */
+#define SB_MAX 16
+typedef struct hold_s { struct hold_s *next; hbhip_filter *dev; int n; hb_buffer_t *in[SB_MAX]; } hold_t;
+static hold_t *g_holds;
+static pthread_mutex_t g_hold_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static int burst_frames(void)
+{
+    const char *e = getenv("HBHIP_STATELESS_BATCH");       /* (read per call: the tests switch it inside a process) */
+    const int v = e != NULL ? atoi(e) : 8;
+    return v < 1 ? 1 : (v > SB_MAX ? SB_MAX : v);
+}
+
+static hold_t *hold_of(hbhip_filter *dev, int create)
+{
+    pthread_mutex_lock(&g_hold_lock);
+    hold_t *h = g_holds;
+    while (h != NULL && h->dev != dev) h = h->next;
+    if (h == NULL && create && (h = calloc(1, sizeof(*h))) != NULL)
+    {
+        h->dev = dev;
+        h->next = g_holds;
+        g_holds = h;
+    }
+    pthread_mutex_unlock(&g_hold_lock);
+    return h;
+}
+
+static void hold_drop(hbhip_filter *dev)
+{
+    pthread_mutex_lock(&g_hold_lock);
+    for (hold_t **pp = &g_holds; *pp != NULL; pp = &(*pp)->next)
+        if ((*pp)->dev == dev)
+        {
+            hold_t *h = *pp;
+            *pp = h->next;
+            for (int i = 0; i < h->n; i++) hb_buffer_close(&h->in[i]);
+            free(h);
+            break;
+        }
+    pthread_mutex_unlock(&g_hold_lock);
+}
+
+/* the gathered frames through the filter in one call; the results as a buffer list appended to `list` */
+static int burst_run(hbhip_filter *dev, const hb_filter_init_t *output, const char *who, hold_t *h, hb_buffer_list_t *list)
+{
+    const int n = h->n;
+    if (n == 0) return HBHIP_OK;
+    int ow = h->in[0]->f.width, oh = h->in[0]->f.height;
+    hbhip_filter_out_geometry(dev, &ow, &oh);
+    const AVPixFmtDescriptor *desc = av_pix_fmt_desc_get(output->pix_fmt);
+    hbhip_frame *dst[SB_MAX] = { NULL };
+    hbhip_dev_frame di[SB_MAX], dd[SB_MAX];
+    int rc = desc == NULL ? HBHIP_ERR_ARG : HBHIP_OK, made = 0;
+    for (int i = 0; rc == HBHIP_OK && i < n; i++)
+    {
+        hbhip_frame *src = hbhip_host_frame_of(h->in[i]);
+        rc = src == NULL ? HBHIP_ERR_ARG
+                         : hbhip_frame_alloc(hbhip_filter_context(dev), ow, oh, desc->comp[0].depth,
+                                             desc->log2_chroma_w, desc->log2_chroma_h, &dst[i]);
+        if (rc != HBHIP_OK) break;
+        hbhip_frame_describe(src, &di[i], NULL, NULL);
+        hbhip_frame_describe(dst[i], &dd[i], NULL, NULL);
+        rc = hbhip_frame_use_on(src, hbhip_filter_context(dev));
+    }
+    if (rc == HBHIP_OK) rc = hbhip_filter_process_dev(dev, di, n, 0, dd, n, &made);
+    if (rc == HBHIP_OK && made != n) rc = HBHIP_ERR_ARG;
+    if (rc != HBHIP_OK)
+    {
+        for (int i = 0; i < n; i++) if (dst[i] != NULL) hbhip_frame_release(dst[i]);
+        hb_error("%s(hip): burst of %d frames failed (%s)", who, n, hbhip_strerror(rc));
+        return rc;
+    }
+    for (int i = 0; i < n; i++)
+    {
+        hbhip_frame_mark_ready(dst[i]);
+        hb_buffer_t *out = hbhip_host_wrap_frame(dst[i], output, ow, oh);      /* takes the reference */
+        if (out == NULL)
+        {
+            for (int k = i; k < n; k++) hbhip_frame_release(dst[k]);
+            for (int k = i; k < n; k++) hb_buffer_close(&h->in[k]);
+            h->n = 0;
+            return HBHIP_ERR_NOMEM;
+        }
+        hb_buffer_copy_props(out, h->in[i]);
+        hb_buffer_close(&h->in[i]);
+        hb_buffer_list_append(list, out);
+    }
+    h->n = 0;
+    return HBHIP_OK;
+}
+
 /* close(): frames still in the pipe (a cancelled job) are dropped with their buffers */
 void hbhip_host_simple_destroy(hbhip_filter *dev)
 {
     if (dev == NULL) return;
+    hold_drop(dev);
     while (hbhip_filter_inflight(dev) > 0)
     {
         hb_buffer_t *o = pipe_collect(dev);
@@ -387,6 +484,12 @@ int hbhip_host_simple_work(hbhip_filter *dev, const hb_filter_init_t *output, co
     {
         hb_buffer_list_t list;
         hb_buffer_list_clear(&list);
+        hold_t *held = hold_of(dev, 0);
+        if (held != NULL && burst_run(dev, output, who, held, &list) != HBHIP_OK)       /* the frames gathered so far */
+        {
+            hb_buffer_list_close(&list);
+            return HB_FILTER_FAILED;
+        }
         while (hbhip_filter_inflight(dev) > 0)                 /* drain the pipe in order */
         {
             hb_buffer_t *o = pipe_collect(dev);
@@ -403,6 +506,24 @@ int hbhip_host_simple_work(hbhip_filter *dev, const hb_filter_init_t *output, co
     int rc;
     hb_buffer_t *out = NULL;
     hbhip_frame *src = hbhip_host_frame_of(in);
+    if (src != NULL && dev_io && burst_frames() > 1)
+    {
+        /* device frames in, device frames out, a burst per launch */
+        hold_t *h = hold_of(dev, 1);
+        if (h == NULL) { hb_error("%s(hip): out of memory", who); return HB_FILTER_FAILED; }
+        h->in[h->n++] = in;
+        *buf_in = NULL;
+        if (h->n < burst_frames()) return HB_FILTER_DELAY;
+        hb_buffer_list_t list;
+        hb_buffer_list_clear(&list);
+        if (burst_run(dev, output, who, h, &list) != HBHIP_OK)
+        {
+            hb_buffer_list_close(&list);
+            return HB_FILTER_FAILED;
+        }
+        *buf_out = hb_buffer_list_clear(&list);
+        return HB_FILTER_OK;
+    }
     if (src != NULL && dev_io)
     {
         /* device frame in, device frame out: the filter reads and writes the two frames in place */

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times one stateless filter's batch path (16 device-resident 1080p frames per call) with the context's kernel timer.
-usage: quick_filter.py unsharp|chroma_smooth|lapsharp|colorspace_sdr|colorspace_matrix|grayscale|rotate [reps]
+usage: quick_filter.py unsharp|chroma_smooth|lapsharp|colorspace_sdr|colorspace_matrix|grayscale|rotate|scale<W>x<H> [reps]
 Prints one line per kernel: name, launches, average us.  For knob experiments with tools/dev_run.sh."""
 import ctypes as C, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -79,6 +79,9 @@ def main():
         sd, dd = (8, 10) if what == "format8to10" else (10, 8)
         make = lambda: hip._create("hbhip_format_create", ctx, [C.c_void_p] + [C.c_int] * 7 + [C.POINTER(C.c_void_p)], ctx.h, W, H, sd, dd, 1, 1, 0)
         depth_in, depth_out = sd, dd
+    elif what.startswith("scale"):                     # scale960x540, scale1280x720, scale3840x2160 ...
+        ow, oh = (int(v) for v in what[5:].split("x"))
+        make = lambda: hip.cropscale_device_filter(ctx, W, H, ow, oh)
     elif what == "pad":
         class PP(C.Structure):
             _fields_ = [("width", C.c_int), ("height", C.c_int), ("x", C.c_int), ("y", C.c_int), ("fill", C.c_int * 3)]
