@@ -868,6 +868,52 @@ __device__ __forceinline__ void calc_dir_dense(const uint32_t *tr, int maxdt, co
 #pragma unroll
             for (int j = 0; j < R; j++) { X1[j] = (up[j] << sh) & 0x40000000u; X2[j] = (dn[j] << sh) & 0x40000000u; }
         }
+#ifdef CD_SEQ
+        // development form: u = +d and u = -d one after the other, so that only one direction's SADs
+        // and candidates are live at a time (5 R more v_min, ~5 R + 2 (R + 3) fewer live registers); measured in
+        // profiles/r6Z_calcdir_seq.log
+        (void)P1; (void)Q1; (void)Pn; (void)Qn;
+        {
+            uint32_t Pa[NE], Qa[NE], ca[R], cb[R], cc[R], cd[R], ce[R];
+#pragma unroll
+            for (int r = 0; r < NE; r++) { Pa[r] = SADH(T[r], Mi[r + 1], t1); Qa[r] = SADH(Pl[r], T[r + 1], t1); }
+            if (PRED)
+            {
+                const uint32_t sh = 30u - (uint32_t)d;
+#pragma unroll
+                for (int j = 0; j < R; j++) X1[j] = (up[j] << sh) & 0x40000000u;
+            }
+            sums(Pa, Qa, X1, ca, cb, cc, cd, ce);
+#pragma unroll
+            for (int j = 0; j < R; j++)
+            {
+                ka[j] = min(ka[j], ca[j]); kb[j] = min(kb[j], cb[j]); kc[j] = min(kc[j], cc[j]);
+                kd[j] = min(kd[j], cd[j]); ke[j] = min(ke[j], ce[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < R; j++) asm volatile("" : "+v"(ka[j]), "+v"(kb[j]), "+v"(kc[j]), "+v"(kd[j]), "+v"(ke[j]));
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            uint32_t Pa[NE], Qa[NE], ca[R], cb[R], cc[R], cd[R], ce[R];
+#pragma unroll
+            for (int r = 0; r < NE; r++) { Pa[r] = SADH(T[r], Pl[r + 1], t2); Qa[r] = SADH(Mi[r], T[r + 1], t2); }
+            if (PRED)
+            {
+                const uint32_t sh = 30u - (uint32_t)d;
+#pragma unroll
+                for (int j = 0; j < R; j++) X2[j] = (dn[j] << sh) & 0x40000000u;
+            }
+            sums(Pa, Qa, X2, ca, cb, cc, cd, ce);
+#pragma unroll
+            for (int j = 0; j < R; j++)
+            {
+                ka[j] = min(ka[j], ca[j]); kb[j] = min(kb[j], cb[j]); kc[j] = min(kc[j], cc[j]);
+                kd[j] = min(kd[j], cd[j]); ke[j] = min(ke[j], ce[j]);
+            }
+        }
+        continue;
+#endif
         uint32_t ca[R], cb[R], cc[R], cd[R], ce[R], na[R], nb[R], nc[R], nd[R], ne[R];
         sums(P1, Q1, X1, ca, cb, cc, cd, ce);
         sums(Pn, Qn, X2, na, nb, nc, nd, ne);
