@@ -409,7 +409,6 @@ public:
     {
         for (DevPicture *p : late_unref) hbhip_pic_release(p, ctx);
         late_unref.clear();
-        delete eedi16;
         delete eedi;
     }
 
@@ -424,17 +423,6 @@ public:
         const int hm = par.mode & ~M_SELECTIVE;
         if (!(hm == 0 || hm == M_BLEND || hm == M_CUBIC || (hm & M_YADIF) || (hm & M_EEDI2)))
             return HBHIP_ERR_UNSUPPORTED;
-        if ((par.mode & M_EEDI2) && in_geo.bps != 1)
-        {
-            // 10 / 12-bit EEDI2: eedi2_16.hip, first correct form (tests/test_eedi2_gpu.py::test_16bit_*)
-            if (par.post_processing < 0 || par.post_processing > 3) return HBHIP_ERR_UNSUPPORTED;
-            Eedi2Params ep = { par.magnitude_threshold, par.variance_threshold, par.laplacian_threshold,
-                               par.dilation_threshold, par.erosion_threshold, par.noise_threshold,
-                               par.maximum_search_distance, par.post_processing };
-            eedi16 = new (std::nothrow) Eedi2Engine16(ctx, in_geo, ep, hbhip_dev_int("HBHIP_EEDI2_FIELDS", 16));
-            if (!eedi16) return HBHIP_ERR_NOMEM;
-            return eedi16->init();
-        }
         if (par.mode & M_EEDI2)
         {
             if (par.post_processing < 0 || par.post_processing > 3) return HBHIP_ERR_UNSUPPORTED;
@@ -444,18 +432,19 @@ public:
             // EEDI2 runs depend on each other only through the edge mask (the first of ~15 kernels), and every kernel
             // of a run is too short to fill the GPU.  So the fields of a chain batch (both fields of every frame with
             // bob) are queued and go through each pass together: one launch per pass for up to `fields` fields
-            // (Eedi2Engine), followed by the blends that consume the guesses.  Driven a frame at a time (work() of the
+            // (EediEngineBase), followed by the blends that consume the guesses.  Driven a frame at a time (work() of the
             // plugin), a frame's fields still share their launches.
-            // fields per batch (1..32): two parts of 16 (Eedi2Engine::launch).  A field's slot holds 4 half-height and 5
-            // full-height scratch frames plus the lattice candidates - about 11 bytes per frame pixel, 34 MB at 1080p -
-            // and the engine keeps fields + 1 slots: 1.1 GB at 1080p for 32 fields, four times that at 2160p.  Up to
-            // 1080p a batch is 32 fields; above, 16 (2.3 GB at 2160p: a 2160p field already fills the GPU four times
-            // over, the second part adds nothing there).  Should the slab not fit beside what else lives on the GPU
-            // the batch is halved until it does; the 16-bit engine (22 bytes per pixel) starts from 16 for every size.
+            // fields per batch (1..32): two parts of 16 (EediEngineBase::launch).  A field's slot holds 4 half-height and 5
+            // full-height scratch frames plus the lattice candidates - about 11 bytes per frame pixel at 8 bits (34 MB at
+            // 1080p), 22 at 10 / 12 bits - and the engine keeps fields + 1 slots: 1.1 / 2.3 GB at 1080p for 32 fields, four
+            // times that at 2160p.  Up to 1080p a batch is 32 fields; above, 16 (a 2160p field already fills the GPU four
+            // times over, the second part adds nothing there).  Should the slab not fit beside what else lives on the GPU
+            // the batch is halved until it does.
             int fields = hbhip_dev_int("HBHIP_EEDI2_FIELDS", (long long)in_geo.width * in_geo.height <= 1920LL * 1088 ? 32 : 16);
             for (;;)
             {
-                eedi = new (std::nothrow) Eedi2Engine(ctx, in_geo, ep, fields);
+                if (in_geo.bps != 1) eedi = new (std::nothrow) Eedi2Engine16(ctx, in_geo, ep, fields);   // 10 / 12-bit samples: eedi2_16.hip
+                else                 eedi = new (std::nothrow) Eedi2Engine(ctx, in_geo, ep, fields);
                 if (!eedi) return HBHIP_ERR_NOMEM;
                 const int rc = eedi->init();
                 if (rc == HBHIP_OK) break;
@@ -517,7 +506,7 @@ public:
     {
         if (outq.empty()) return nullptr;
         // a frame that is handed out must have been launched: whoever pulls without a kick gets one here
-        if (!gathered.empty() || (eedi && eedi->queued() > 0) || (eedi16 && eedi16->queued() > 0))
+        if (!gathered.empty() || (eedi && eedi->queued() > 0))
             (void)flush_batch();
         DevPicture *p = outq.front();
         outq.pop_front();
@@ -526,7 +515,7 @@ public:
     void recycle_output(DevPicture *p) override { pool.release(p); }
 
     int next_flags = 0, next_combed = 0;
-    Eedi2Engine *engine() { return eedi; }
+    EediEngineBase *engine() { return eedi; }
 
 private:
     void unref(DevPicture *p)
@@ -534,14 +523,14 @@ private:
         if (!p || --p->refs != 0) return;
         // a queued EEDI2 field or a blend gathered for the batch launch may still read it: hand it back when the
         // batch is out
-        if (!gathered.empty() || (eedi && eedi->queued() > 0) || (eedi16 && eedi16->queued() > 0))
+        if (!gathered.empty() || (eedi && eedi->queued() > 0))
             late_unref.push_back(p);
         else hbhip_pic_release(p, ctx);                    // possibly another filter's picture (fused chain)
     }
     // launch what has been gathered: the queued EEDI2 fields, then the blends (which read their guesses)
     int flush_batch()
     {
-        int rc = eedi ? eedi->launch(ctx) : eedi16 ? eedi16->launch(ctx) : HBHIP_OK;
+        int rc = eedi ? eedi->launch(ctx) : HBHIP_OK;
         const int rc2 = launch_gathered(ctx);
         for (DevPicture *p : late_unref) hbhip_pic_release(p, ctx);
         late_unref.clear();
@@ -565,13 +554,7 @@ private:
             DecombPlane &P = a.pl[c];
             P.prev = ref[0]->plane[c]; P.cur = ref[1]->plane[c]; P.next = ref[2]->plane[c];
             P.guess = nullptr; P.guess_pitch = 0;
-            if ((mode & M_EEDI2) && eedi16 && slot >= 0)
-            {
-                const EediFrame g = eedi16->result(slot);
-                P.guess = g.plane[c];
-                P.guess_pitch = g.stride[c];
-            }
-            else if ((mode & M_EEDI2) && eedi && slot >= 0)
+            if ((mode & M_EEDI2) && eedi && slot >= 0)
             {
                 const EediFrame g = eedi->result(slot);
                 P.guess = g.plane[c];
@@ -674,17 +657,7 @@ private:
         {
             const int parity = frame ^ tff ^ 1;
             int slot = -1;
-            if ((mode & M_EEDI2) && eedi16)
-            {
-                if (eedi16->queued() == eedi16->capacity())
-                {
-                    int rc = flush_batch();
-                    if (rc != HBHIP_OK) return rc;
-                }
-                slot = eedi16->add_field(cur, !parity);                          // pv->tff = !parity (decomb.c:542)
-                if (slot < 0) return HBHIP_ERR_ARG;
-            }
-            else if ((mode & M_EEDI2) && eedi)
+            if ((mode & M_EEDI2) && eedi)
             {
                 if (eedi->queued() == eedi->capacity())
                 {
@@ -717,14 +690,11 @@ private:
     PicturePool pool;
     DevPicture *ref[3] = {nullptr, nullptr, nullptr};
     std::deque<DevPicture *> outq;
-    Eedi2Engine *eedi = nullptr;           // 8-bit EEDI2: fields queued here run together (flush_batch)
+    EediEngineBase *eedi = nullptr;        // EEDI2 (Eedi2Engine at 8 bits, Eedi2Engine16 at 10 / 12): fields queued here run together (flush_batch)
     std::vector<DevPicture *> late_unref;  // input pictures whose last reference went while something gathered could still read them
     bool deferred = false;
     std::vector<DecombFrame> gathered;     // blends waiting for their launch (launch_gathered)
     DecombBatch geo;                       // the pitches / sizes they share
-public:
-    Eedi2Engine16 *eedi16 = nullptr;       // 10 / 12-bit samples
-private:
     bool ready = false, flushed = false;
 };
 
@@ -824,10 +794,9 @@ extern "C" int hbhip_decomb_debug_eedi_plane(hbhip_filter *f, int buffer, int pl
                                              int *stride, int *height)
 {
     DecombFilter *d = dynamic_cast<DecombFilter *>(f);
-    if (!d || (!d->engine() && !d->eedi16) || buffer < 0 || buffer > 8 || plane < 0 || plane > 2) return HBHIP_ERR_ARG;
-    const int slot = d->eedi16 ? d->eedi16->last_slot() : d->engine()->last_slot();          // the latest run's scratch
-    const EediFrame fr = d->eedi16 ? (buffer < 4 ? d->eedi16->half(buffer, slot) : d->eedi16->full(buffer - 4, slot))
-                                   : (buffer < 4 ? d->engine()->half(buffer, slot) : d->engine()->full(buffer - 4, slot));
+    if (!d || !d->engine() || buffer < 0 || buffer > 8 || plane < 0 || plane > 2) return HBHIP_ERR_ARG;
+    const int slot = d->engine()->last_slot();                                                // the latest run's scratch
+    const EediFrame fr = buffer < 4 ? d->engine()->half(buffer, slot) : d->engine()->full(buffer - 4, slot);
     if (stride) *stride = fr.stride[plane];
     if (height) *height = fr.height[plane];
     if (dst == nullptr) return HBHIP_OK;

@@ -3136,13 +3136,14 @@ void MaskChainGuard::bind(MaskChain &C) const
 // the previous one (the lower half of MSKPF keeps the previous run's mask, eedi2_template.c:132), so the mask kernels
 // form a chain and every pass behind them takes all queued fields in one launch (blockIdx.z = 3 * field + plane).
 // Each field has a slot: its nine scratch frames and its lattice candidates in one slab, slot_bytes_ apart.
-Eedi2Engine::Eedi2Engine(hbhip_ctx *ctx, const PicGeometry &geo, const Eedi2Params &p, int capacity)
-    : ctx_(ctx), geo_(geo), par_(p)
+// ---- what both engines share (EediEngineBase, eedi2_engine.h)
+EediEngineBase::EediEngineBase(hbhip_ctx *ctx, const PicGeometry &geo, const Eedi2Params &p, int capacity, const char *who)
+    : ctx_(ctx), geo_(geo), par_(p), who_(who)
 {
-    cap_ = std::min(std::max(capacity, 1), EEDI_MAX_FIELDS);
+    cap_ = std::min(std::max(capacity, 1), EEDI_MAX_BATCH);
 }
 
-Eedi2Engine::~Eedi2Engine()
+EediEngineBase::~EediEngineBase()
 {
     if (slab_) (void)hipFree(slab_);
     if (chain_flags_) (void)hipFree(chain_flags_);
@@ -3155,8 +3156,6 @@ Eedi2Engine::~Eedi2Engine()
     }
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
     if (ev_mask_) (void)hipEventDestroy(ev_mask_);
-    if (work_list_) (void)hipFree(work_list_);
-    if (work_count_) (void)hipFree(work_count_);
     for (int i = 0; i < 3; i++)
     {
         if (deriv_[i]) (void)hipFree(deriv_[i]);
@@ -3164,47 +3163,45 @@ Eedi2Engine::~Eedi2Engine()
     }
 }
 
-// lays a frame out at `at` bytes into a slot (planes as hb_frame_buffer_init places them); returns the end
-size_t Eedi2Engine::place_frame(EediFrame &f, int width, int height, size_t at)
+// lays a frame out at `at` bytes into a slot (planes as hb_frame_buffer_init places them, strides in bytes); returns the end
+size_t EediEngineBase::place_frame(EediFrame &f, int width, int height, size_t at) const
 {
     size_t total = 0;
     for (int c = 0; c < 3; c++)
     {
         f.width[c] = c ? -((-width) >> geo_.log2_cw) : width;
         f.height[c] = c ? -((-height) >> geo_.log2_ch) : height;
-        f.stride[c] = hbhip_align_up(f.width[c], 64);          // hb_image_stride
-        f.plane[c] = reinterpret_cast<uint8_t *>(at + total);  // offset for now, init() adds the slab's address
+        f.stride[c] = hbhip_align_up(f.width[c] * geo_.bps, 64);  // hb_image_stride
+        f.plane[c] = reinterpret_cast<uint8_t *>(at + total);  // offset for now, init_slots() adds the slab's address
         total += (size_t)f.stride[c] * f.height[c];
     }
     f.bytes = total;
     return at + total;
 }
 
-int Eedi2Engine::init()
+int EediEngineBase::init_slots(const EediLayout &L)
 {
     // the reference overruns its scratch planes when a chroma plane has an odd number
     // of rows (upscale_by_2 writes 2*ceil(h/2) rows); refuse instead of guessing
     if (geo_.height % (2 << geo_.log2_ch) != 0 || geo_.height < 16 || geo_.width < 16)
         return HBHIP_ERR_UNSUPPORTED;
     if (par_.post_processing < 0 || par_.post_processing > 3) return HBHIP_ERR_UNSUPPORTED;
-    if (geo_.width >= (1 << 14) || geo_.height >= (1 << 14)) return HBHIP_ERR_UNSUPPORTED;
-    // one slot: GUARD, then the frames with a GUARD behind each (zeroed once, never written: the passes' reads outside
-    // rows and planes land there), then the candidates
-    size_t at = GUARD;
-    for (auto &f : half_) at = place_frame(f, geo_.width, geo_.height / 2, at) + GUARD;     // decomb.c:291-296
-    for (auto &f : full_) at = place_frame(f, geo_.width, geo_.height, at) + GUARD;         // decomb.c:299-303
-    cand_pitch_ = full_[0].stride[0];
+    size_t at = L.guard;
+    for (auto &f : half_) at = place_frame(f, geo_.width, geo_.height / 2, at) + L.guard;     // decomb.c:291-296
+    for (auto &f : full_) at = place_frame(f, geo_.width, geo_.height, at) + L.guard;         // decomb.c:299-303
+    // interpolate_lattice: per-pixel candidate outcomes of the rebuilt rows (every other row of the full-height frame)
+    cand_pitch_ = full_[0].stride[0] / geo_.bps;
     cand_plane_stride_ = cand_pitch_ * ((full_[0].height[0] + 1) / 2);
     auto up256 = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t cand_at = up256(at);
-    slot_bytes_ = up256(cand_at + sizeof(uint32_t) * (size_t)cand_plane_stride_ * 3);
+    slot_bytes_ = up256(cand_at + L.cand_elem * (size_t)cand_plane_stride_ * 3);
     // one slot more than a batch holds, so that a batch never writes the slot whose mask its first field reads
     const size_t total = slot_bytes_ * (size_t)(cap_ + 1);
     HBHIP_CHECK(ctx_, hipMalloc((void **)&slab_, total));
     HBHIP_CHECK(ctx_, hipMemsetAsync(slab_, 0, total, ctx_->stream));
     for (auto &f : half_) for (int c = 0; c < 3; c++) f.plane[c] = slab_ + (size_t)(uintptr_t)f.plane[c];
     for (auto &f : full_) for (int c = 0; c < 3; c++) f.plane[c] = slab_ + (size_t)(uintptr_t)f.plane[c];
-    cand_ = reinterpret_cast<uint32_t *>(slab_ + cand_at);
+    cand_raw_ = slab_ + cand_at;
     if (cap_ >= 8)
     {
         HBHIP_CHECK(ctx_, hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
@@ -3218,26 +3215,19 @@ int Eedi2Engine::init()
     HBHIP_CHECK(ctx_, hipMalloc((void **)&plane_flags_, sizeof(uint32_t) * 3 * EEDI_MAX_BATCH));
     HBHIP_CHECK(ctx_, hipMemsetAsync(plane_flags_, 0, sizeof(uint32_t) * 3 * EEDI_MAX_BATCH, ctx_->stream));
     last_slot_ = cap_;                                             // "the previous mask" of the first run: zeros, like the reference's
+    chain_ntiles_ = eedi_mask_chain_tiles(half_[0], L.tile_w, L.tile_h, L.tile_oy).ntiles;
     if (cap_ > 1)
     {
         // one completion flag per lower mask tile and field of a batch (MaskChain); 0 is no launch's number
-        const size_t nflags = (size_t)eedi_mask_chain_tiles(half_[0], MF_W, MF_H, MF_OY).ntiles * cap_;
+        const size_t nflags = (size_t)chain_ntiles_ * cap_;
         HBHIP_CHECK(ctx_, hipMalloc((void **)&chain_flags_, sizeof(uint32_t) * nflags));
         HBHIP_CHECK(ctx_, hipMemsetAsync(chain_flags_, 0, sizeof(uint32_t) * nflags, ctx_->stream));
         const int grc = guard_.init(ctx_);
         if (grc != HBHIP_OK) return grc;
     }
-    if (par_.maximum_search_distance > CD_HALO - 2)
-    {
-        // work list of the calc_directions fallback (every half-height pixel could qualify)
-        size_t half_px = 0;
-        for (int c = 0; c < 3; c++) half_px += (size_t)half_[0].stride[c] * half_[0].height[c];
-        HBHIP_CHECK(ctx_, hipMalloc((void **)&work_list_, sizeof(uint32_t) * half_px));
-        HBHIP_CHECK(ctx_, hipMalloc((void **)&work_count_, sizeof(int)));
-    }
     if (par_.post_processing > 1)
     {
-        // cx2, cy2, cxy: height * stride(luma) ints each, shared by the planes (decomb.c:398-403);
+        // cx2, cy2, cxy: height * stride(luma, bytes) ints each, shared by the planes (decomb.c:398-403);
         // zeroed once — the reference mallocs them, and one element per row is read before anything
         // wrote it (eedi2_template.c:1589)
         const size_t n = sizeof(int) * (size_t)geo_.height * full_[0].stride[0];
@@ -3249,11 +3239,10 @@ int Eedi2Engine::init()
             HBHIP_CHECK(ctx_, hipMemsetAsync(deriv_tmp_[i], 0, n, ctx_->stream));
         }
     }
-    HBHIP_CHECK(ctx_, hipStreamSynchronize(ctx_->stream));
     return HBHIP_OK;
 }
 
-EediFrame Eedi2Engine::at_slot(const EediFrame &f, int slot) const
+EediFrame EediEngineBase::at_slot(const EediFrame &f, int slot) const
 {
     EediFrame r = f;
     for (int c = 0; c < 3; c++) r.plane[c] = f.plane[c] + (size_t)slot * slot_bytes_;
@@ -3261,7 +3250,7 @@ EediFrame Eedi2Engine::at_slot(const EediFrame &f, int slot) const
 }
 
 // eedi2_planer (decomb_template.c:455-473) for one more field of `cur`; the run itself happens in launch()
-int Eedi2Engine::add_field(const DevPicture *cur, int tff)
+int EediEngineBase::add_field(const DevPicture *cur, int tff)
 {
     if (n_ >= cap_) return -1;
     for (int c = 0; c < 3; c++)
@@ -3272,16 +3261,66 @@ int Eedi2Engine::add_field(const DevPicture *cur, int tff)
     return start_ + n_++;
 }
 
+// the number of the next mask launch (chain flags, plane flags)
+int EediEngineBase::next_epoch(hbhip_ctx *lc, uint32_t *epoch)
+{
+    if (chain_epoch_ == 0xffffffffu)
+    {
+        // 2^32 mask launches later: 0 means "no launch" in the flag arrays and old numbers must not come round again -
+        // drain the device, clear the flags and start over at 1 (months of continuous running apart)
+        HBHIP_CHECK(lc, hipDeviceSynchronize());
+        if (chain_flags_) HBHIP_CHECK(lc, hipMemset(chain_flags_, 0, sizeof(uint32_t) * (size_t)chain_ntiles_ * cap_));
+        HBHIP_CHECK(lc, hipMemset(plane_flags_, 0, sizeof(uint32_t) * 3 * EEDI_MAX_BATCH));
+        chain_epoch_ = 0;
+    }
+    *epoch = ++chain_epoch_;
+    return HBHIP_OK;
+}
+
+// ---- the 8-bit engine
+Eedi2Engine::Eedi2Engine(hbhip_ctx *ctx, const PicGeometry &geo, const Eedi2Params &p, int capacity)
+    : EediEngineBase(ctx, geo, p, capacity, "decomb EEDI2")
+{
+    static_assert(EEDI_MAX_FIELDS == EEDI_MAX_BATCH, "a batch is one launch's fields");
+}
+
+Eedi2Engine::~Eedi2Engine()
+{
+    if (work_list_) (void)hipFree(work_list_);
+    if (work_count_) (void)hipFree(work_count_);
+}
+
+int Eedi2Engine::init()
+{
+    if (geo_.bps != 1) return HBHIP_ERR_UNSUPPORTED;
+    if (geo_.width >= (1 << 14) || geo_.height >= (1 << 14)) return HBHIP_ERR_UNSUPPORTED;
+    const int rc = init_slots({ GUARD, sizeof(uint32_t), MF_W, MF_H, MF_OY });
+    if (rc != HBHIP_OK) return rc;
+    if (par_.maximum_search_distance > CD_HALO - 2)
+    {
+        // work list of the calc_directions fallback (every half-height pixel could qualify)
+        size_t half_px = 0;
+        for (int c = 0; c < 3; c++) half_px += (size_t)half_[0].stride[c] * half_[0].height[c];
+        HBHIP_CHECK(ctx_, hipMalloc((void **)&work_list_, sizeof(uint32_t) * half_px));
+        HBHIP_CHECK(ctx_, hipMalloc((void **)&work_count_, sizeof(int)));
+    }
+    HBHIP_CHECK(ctx_, hipStreamSynchronize(ctx_->stream));
+    return HBHIP_OK;
+}
+
+// the long-search fallback keeps one work list: everything on the caller's stream then
+bool Eedi2Engine::may_fork() const { return par_.maximum_search_distance <= CD_HALO - 2; }
+
 // (Round 3 tried the mask chain on a high-priority stream of its own with the passes following it in groups of 8 fields:
 // + 2 % on one stream per GPU, and two independent streams per GPU lost half their rate - more streams than hardware
 // queues.  What runs since round 4 is the other way round: the mask launch on the caller's stream, the passes of the
 // batch's second half beside those of its first, see below.)
-int Eedi2Engine::launch(hbhip_ctx *lc)
+int EediEngineBase::launch(hbhip_ctx *lc)
 {
     if (n_ == 0) return HBHIP_OK;
     const int n = n_;
     n_ = 0;
-    guard_.poll("decomb EEDI2");
+    guard_.poll(who_);
     // A batch goes out in parts of at most EEDI_PART fields: one mask launch per part (a chain of that many links), and the
     // passes behind it.
     //  * The passes: every field has its own slot, so the two halves of a part run them beside each other on two streams -
@@ -3293,9 +3332,7 @@ int Eedi2Engine::launch(hbhip_ctx *lc)
     // Not with post-processing 2 / 3 (its derivative arrays carry values from field to field), not while the profiler
     // brackets launches (its events live on the context's stream) or HBHIP_EEDI2_FORK=0 says so (counter runs), not for
     // the long-search fallback (one work list): then everything goes out on the caller's stream, part after part.
-    constexpr int EEDI_PART = 16;
-    const bool fork = side_[0] && eedi_fork_enabled() && par_.post_processing < 2 && !lc->profile &&
-                      par_.maximum_search_distance <= CD_HALO - 2;
+    const bool fork = side_[0] && eedi_fork_enabled() && par_.post_processing < 2 && !lc->profile && may_fork();
     const int parts = (n + EEDI_PART - 1) / EEDI_PART;
     uint32_t epoch[(EEDI_MAX_BATCH + EEDI_PART - 1) / EEDI_PART] = {};
     int rc = enqueue_mask(0, std::min(n, EEDI_PART), lc, lc->stream, &epoch[0]);
@@ -3387,17 +3424,8 @@ int Eedi2Engine::enqueue_mask(int f0, int n, hbhip_ctx *lc, hipStream_t st, uint
     P.tffbits = tffbits_ >> f0;
     const int mth = par_.magnitude_threshold * 10, vth = par_.laplacian_threshold * 81, lth = par_.variance_threshold;   // sic: swapped (decomb_template.c:390)
     const unsigned gx = (srcp.width[0] + MF_W - 1) / MF_W, gy = (srcp.height[0] + MF_H - 1) / MF_H;
-    if (chain_epoch_ == 0xffffffffu)
-    {
-        // 2^32 mask launches later: 0 means "no launch" in the flag arrays and old numbers must not come round again -
-        // drain the device, clear the flags and start over at 1 (months of continuous running apart)
-        HBHIP_CHECK(lc, hipDeviceSynchronize());
-        if (chain_flags_)
-            HBHIP_CHECK(lc, hipMemset(chain_flags_, 0, sizeof(uint32_t) * (size_t)eedi_mask_chain_tiles(half_[0], MF_W, MF_H, MF_OY).ntiles * cap_));
-        HBHIP_CHECK(lc, hipMemset(plane_flags_, 0, sizeof(uint32_t) * 3 * EEDI_MAX_BATCH));
-        chain_epoch_ = 0;
-    }
-    const uint32_t epoch = ++chain_epoch_;                        // the number of this mask launch (chain flags, plane flags)
+    uint32_t epoch = 0;
+    { const int erc = next_epoch(lc, &epoch); if (erc != HBHIP_OK) return erc; }
     *epoch_out = epoch;
     uint32_t *pflags = plane_flags_ + 3 * f0;
     if (n == 1)
@@ -3435,7 +3463,7 @@ int Eedi2Engine::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st, ui
                     dstp = at_slot(half_[3], s0);
     const EediFrame dst2p = at_slot(full_[0], s0), tmp2p2 = at_slot(full_[1], s0), msk2p = at_slot(full_[2], s0),
                     tmp2p = at_slot(full_[3], s0), dst2mp = at_slot(full_[4], s0);
-    uint32_t *cand = cand_ + (size_t)s0 * (slot_bytes_ / sizeof(uint32_t));
+    uint32_t *cand = reinterpret_cast<uint32_t *>(cand_raw_) + (size_t)s0 * (slot_bytes_ / sizeof(uint32_t));
     const dim3 blk(64, 4);
     const unsigned gz = 3u * (unsigned)n;
     auto grid4_for = [&](const EediFrame &f, bool whole_pitch) {        // kernels with 4 pixels per thread

@@ -2535,122 +2535,17 @@ __global__ void q_post_corner(Corner16 A, const uint16_t *msk, uint16_t *dst, in
 // passes field after field (each field's edge mask reads the finished mask of the field before, eedi2_template.c:132),
 // every later pass once with blockIdx.z = 3 * field + plane.
 Eedi2Engine16::Eedi2Engine16(hbhip_ctx *ctx, const PicGeometry &geo, const Eedi2Params &p, int capacity)
-    : ctx_(ctx), geo_(geo), par_(p)
+    : EediEngineBase(ctx, geo, p, capacity, "decomb EEDI2 (16-bit)")
 {
-    cap_ = std::min(std::max(capacity, 1), EEDI_MAX_BATCH);
-}
-
-Eedi2Engine16::~Eedi2Engine16()
-{
-    if (slab_) (void)hipFree(slab_);
-    if (chain_flags_) (void)hipFree(chain_flags_);
-    guard_.destroy();
-    if (plane_flags_) (void)hipFree(plane_flags_);
-    if (side_) (void)hipStreamDestroy(side_);
-    if (ev_fork_) (void)hipEventDestroy(ev_fork_);
-    if (ev_join_) (void)hipEventDestroy(ev_join_);
-    for (int i = 0; i < 3; i++)
-    {
-        if (deriv_[i]) (void)hipFree(deriv_[i]);
-        if (deriv_tmp_[i]) (void)hipFree(deriv_tmp_[i]);
-    }
-}
-
-// lays a frame out at byte offset `at` of a slot (planes as hb_frame_buffer_init places a 16-bit frame); returns the end
-size_t Eedi2Engine16::place_frame(EediFrame &f, int width, int height, size_t at)
-{
-    size_t total = 0;
-    for (int c = 0; c < 3; c++)
-    {
-        f.width[c] = c ? -((-width) >> geo_.log2_cw) : width;
-        f.height[c] = c ? -((-height) >> geo_.log2_ch) : height;
-        f.stride[c] = hbhip_align_up(f.width[c] * 2, 64);           // hb_image_stride of a 16-bit plane, bytes
-        f.plane[c] = reinterpret_cast<uint8_t *>(at + total);       // offset for now, init() adds the slab's address
-        total += (size_t)f.stride[c] * f.height[c];
-    }
-    f.bytes = total;
-    return at + total;
 }
 
 int Eedi2Engine16::init()
 {
     if (geo_.bps != 2 || geo_.depth < 9 || geo_.depth > 16) return HBHIP_ERR_UNSUPPORTED;
-    if (geo_.height % (2 << geo_.log2_ch) != 0 || geo_.height < 16 || geo_.width < 16) return HBHIP_ERR_UNSUPPORTED;
-    if (par_.post_processing < 0 || par_.post_processing > 3) return HBHIP_ERR_UNSUPPORTED;
-    const size_t guard = 2 * GUARD16;                               // bytes; zeroed once, never written
-    size_t at = guard;
-    for (auto &f : half_) at = place_frame(f, geo_.width, geo_.height / 2, at) + guard;
-    for (auto &f : full_) at = place_frame(f, geo_.width, geo_.height, at) + guard;
-    // interpolate_lattice: per-pixel candidate outcomes of the rebuilt rows (every other row of the full-height frame)
-    cand_pitch_ = full_[0].stride[0] / 2;
-    cand_plane_stride_ = cand_pitch_ * ((full_[0].height[0] + 1) / 2);
-    auto up256 = [](size_t v) { return (v + 255) / 256 * 256; };
-    const size_t cand_at = up256(at);
-    slot_bytes_ = up256(cand_at + sizeof(unsigned long long) * 3 * (size_t)cand_plane_stride_);
-    const size_t total = slot_bytes_ * (size_t)(cap_ + 1);
-    HBHIP_CHECK(ctx_, hipMalloc((void **)&slab_, total));
-    HBHIP_CHECK(ctx_, hipMemsetAsync(slab_, 0, total, ctx_->stream));
-    for (auto &f : half_) for (int c = 0; c < 3; c++) f.plane[c] = slab_ + (size_t)(uintptr_t)f.plane[c];
-    for (auto &f : full_) for (int c = 0; c < 3; c++) f.plane[c] = slab_ + (size_t)(uintptr_t)f.plane[c];
-    cand_ = reinterpret_cast<unsigned long long *>(slab_ + cand_at);
-    last_slot_ = cap_;                                              // "the previous mask" of the first run: zeros
-    if (cap_ >= 8)
-    {
-        HBHIP_CHECK(ctx_, hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
-        HBHIP_CHECK(ctx_, hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
-        HBHIP_CHECK(ctx_, hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
-    }
-    HBHIP_CHECK(ctx_, hipMalloc((void **)&plane_flags_, sizeof(uint32_t) * 3 * EEDI_MAX_BATCH));
-    HBHIP_CHECK(ctx_, hipMemsetAsync(plane_flags_, 0, sizeof(uint32_t) * 3 * EEDI_MAX_BATCH, ctx_->stream));
-    if (cap_ > 1)
-    {
-        // one completion flag per lower mask tile and field of a batch (MaskChain); 0 is no launch's number
-        const size_t nflags = (size_t)eedi_mask_chain_tiles(half_[0], QM_W, QM_H, QM_OY).ntiles * cap_;
-        HBHIP_CHECK(ctx_, hipMalloc((void **)&chain_flags_, sizeof(uint32_t) * nflags));
-        HBHIP_CHECK(ctx_, hipMemsetAsync(chain_flags_, 0, sizeof(uint32_t) * nflags, ctx_->stream));
-        const int grc = guard_.init(ctx_);
-        if (grc != HBHIP_OK) return grc;
-    }
-    if (par_.post_processing > 1)
-    {
-        const size_t n = sizeof(int) * (size_t)geo_.height * full_[0].stride[0];     // decomb.c:398-403 sizes them by the byte stride
-        for (int i = 0; i < 3; i++)
-        {
-            HBHIP_CHECK(ctx_, hipMalloc((void **)&deriv_[i], n));
-            HBHIP_CHECK(ctx_, hipMemsetAsync(deriv_[i], 0, n, ctx_->stream));
-            HBHIP_CHECK(ctx_, hipMalloc((void **)&deriv_tmp_[i], n));
-            HBHIP_CHECK(ctx_, hipMemsetAsync(deriv_tmp_[i], 0, n, ctx_->stream));
-        }
-    }
+    const int rc = init_slots({ 2 * GUARD16, sizeof(unsigned long long), QM_W, QM_H, QM_OY });     // (guard in bytes)
+    if (rc != HBHIP_OK) return rc;
     HBHIP_CHECK(ctx_, hipStreamSynchronize(ctx_->stream));
     return HBHIP_OK;
-}
-
-EediFrame Eedi2Engine16::at_slot(const EediFrame &f, int slot) const
-{
-    EediFrame r = f;
-    for (int c = 0; c < 3; c++) r.plane[c] = f.plane[c] + (size_t)slot * slot_bytes_;
-    return r;
-}
-
-int Eedi2Engine16::add_field(const DevPicture *cur, int tff)
-{
-    if (n_ >= cap_) return -1;
-    if (n_ == 0) { start_ = last_slot_ == 0 ? 1 : 0; tffbits_ = 0; }
-    for (int c = 0; c < 3; c++) { src_frame_[n_][c] = cur->plane[c]; src_pitch_[c] = cur->pitch[c]; }
-    if (tff) tffbits_ |= 1u << n_;
-    return start_ + n_++;
-}
-
-int Eedi2Engine16::launch(hbhip_ctx *lc)
-{
-    if (n_ == 0) return HBHIP_OK;
-    const int n = n_;
-    n_ = 0;
-    guard_.poll("decomb EEDI2 (16-bit)");
-    const int rc = enqueue(n, lc);
-    last_slot_ = start_ + n - 1;
-    return rc;
 }
 
 // the per-depth constants the kernels take (eedi2_init_limlut :23-33)
@@ -2666,82 +2561,61 @@ static K16 make_k16(int depth)
     return k;
 }
 
-// The field extraction and the mask passes of the n queued fields on lc's stream, then the passes behind them: for the
-// whole batch on the same stream, or for its two halves beside each other on two (Eedi2Engine::launch in eedi2.hip has
-// the why and the when).
-int Eedi2Engine16::enqueue(int n, hbhip_ctx *lc)
+// The field extraction (decomb_template.c:455-473) and the five mask passes (:390-397) of fields f0 .. f0 + n - 1 of the
+// batch on st: one kernel, one launch (EediEngineBase::launch in eedi2.hip has the parts and the streams).
+int Eedi2Engine16::enqueue_mask(int f0, int n, hbhip_ctx *lc, hipStream_t st, uint32_t *epoch_out)
 {
-    const EediFrame srcp = at_slot(half_[0], start_), mskp = at_slot(half_[1], start_);
+    const EediFrame srcp = at_slot(half_[0], start_ + f0), mskp = at_slot(half_[1], start_ + f0),
+                    old = at_slot(half_[1], f0 ? start_ + f0 - 1 : last_slot_);
     const K16 k = make_k16(geo_.depth);
-    auto geom = [&](Q3 &P, const EediFrame &f) {
-        for (int c = 0; c < 3; c++) { P.pitch[c] = f.stride[c] / 2; P.width[c] = f.width[c]; P.height[c] = f.height[c]; }
-    };
-    auto bind = [&](uint16_t *(&slot)[3], const EediFrame &f) { for (int c = 0; c < 3; c++) slot[c] = (uint16_t *)f.plane[c]; };
     Q3 P;
     memset(&P, 0, sizeof(P));
     P.fstride = slot_bytes_ / 2;
-    P.tffbits = tffbits_;
-
-    // field extraction (decomb_template.c:455-473) + the five mask passes (:390-397): one kernel, one launch
-    geom(P, srcp);
+    P.tffbits = tffbits_ >> f0;
+    MaskSrc16 S;
+    memset(&S, 0, sizeof(S));
+    for (int f = 0; f < n; f++) for (int c = 0; c < 3; c++) S.frame[f][c] = (const uint16_t *)src_frame_[f0 + f][c];
+    for (int c = 0; c < 3; c++)
     {
-        MaskSrc16 S;
-        memset(&S, 0, sizeof(S));
-        for (int f = 0; f < n; f++) for (int c = 0; c < 3; c++) S.frame[f][c] = (const uint16_t *)src_frame_[f][c];
-        for (int c = 0; c < 3; c++) S.sp[c] = src_pitch_[c] / 2;
-        const EediFrame old = at_slot(half_[1], last_slot_);
-        bind(P.a, srcp); bind(P.b, old); bind(P.c, mskp);
-        const int mth = par_.magnitude_threshold * 10, vth = par_.laplacian_threshold * 81, lth = par_.variance_threshold;   // sic: swapped (decomb_template.c:390)
-        const unsigned gx = (srcp.width[0] + QM_W - 1) / QM_W, gy = (srcp.height[0] + QM_H - 1) / QM_H;
-        if (chain_epoch_ == 0xffffffffu)
-        {
-            // 2^32 mask launches later: 0 means "no launch" in the flag arrays and old numbers must not come round
-            // again - drain the device, clear the flags and start over at 1 (months of continuous running apart)
-            HBHIP_CHECK(lc, hipDeviceSynchronize());
-            if (chain_flags_)
-                HBHIP_CHECK(lc, hipMemset(chain_flags_, 0, sizeof(uint32_t) * (size_t)eedi_mask_chain_tiles(half_[0], QM_W, QM_H, QM_OY).ntiles * cap_));
-            HBHIP_CHECK(lc, hipMemset(plane_flags_, 0, sizeof(uint32_t) * 3 * EEDI_MAX_BATCH));
-            chain_epoch_ = 0;
-        }
-        const uint32_t epoch = ++chain_epoch_;                    // the number of this mask launch (chain flags, plane flags)
-        if (n == 1)
-            HBHIP_LAUNCH(lc, "eedi2_16_mask_passes", q_mask_fused, dim3(gx, gy, 3), dim3(QM_T), 0, P, S, k, 0, 0, mth, vth, lth,
-                         par_.erosion_threshold, par_.dilation_threshold, plane_flags_, epoch);
-        else
-        {
-            // one launch, field-major: a field's chain tiles, then its upper tiles (see Eedi2Engine::enqueue_mask)
-            MaskChain C = eedi_mask_chain_tiles(srcp, QM_W, QM_H, QM_OY);
-            C.flags = chain_flags_;
-            C.pflags = plane_flags_;
-            C.epoch = epoch;
-            C.group = C.ntiles + C.nupper;
-            guard_.bind(C);
-            HBHIP_LAUNCH(lc, "eedi2_16_mask_passes", q_mask_chain, dim3((unsigned)(C.group * n)), dim3(QM_T), 0, P, S, k, C, mth, vth, lth,
-                         par_.erosion_threshold, par_.dilation_threshold);
-            HBHIP_LAUNCH(lc, "eedi2_16_mask_repair", q_mask_chain_repair, dim3(1), dim3(QM_T), 0, P, S, k, C, n, mth, vth, lth,
-                         par_.erosion_threshold, par_.dilation_threshold);
-        }
+        P.pitch[c] = srcp.stride[c] / 2; P.width[c] = srcp.width[c]; P.height[c] = srcp.height[c];
+        P.a[c] = (uint16_t *)srcp.plane[c]; P.b[c] = (uint16_t *)old.plane[c]; P.c[c] = (uint16_t *)mskp.plane[c];
+        S.sp[c] = src_pitch_[c] / 2;
     }
-    const bool fork = side_ && eedi_fork_enabled() && n >= 8 && par_.post_processing < 2 && !lc->profile;
-    if (!fork) return enqueue_passes(0, n, lc, lc->stream);
-    const int h = n / 2;
-    HBHIP_CHECK(lc, hipEventRecord(ev_fork_, lc->stream));
-    HBHIP_CHECK(lc, hipStreamWaitEvent(side_, ev_fork_, 0));
-    int rc = enqueue_passes(0, h, lc, lc->stream);
-    if (rc == HBHIP_OK) rc = enqueue_passes(h, n - h, lc, side_);
-    HBHIP_CHECK(lc, hipEventRecord(ev_join_, side_));
-    HBHIP_CHECK(lc, hipStreamWaitEvent(lc->stream, ev_join_, 0));
-    return rc;
+    const int mth = par_.magnitude_threshold * 10, vth = par_.laplacian_threshold * 81, lth = par_.variance_threshold;   // sic: swapped (decomb_template.c:390)
+    const unsigned gx = (srcp.width[0] + QM_W - 1) / QM_W, gy = (srcp.height[0] + QM_H - 1) / QM_H;
+    uint32_t epoch = 0;
+    { const int erc = next_epoch(lc, &epoch); if (erc != HBHIP_OK) return erc; }
+    *epoch_out = epoch;
+    uint32_t *pflags = plane_flags_ + 3 * f0;
+    if (n == 1)
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_mask_passes", q_mask_fused, dim3(gx, gy, 3), dim3(QM_T), 0, P, S, k, 0, 0, mth, vth, lth,
+                        par_.erosion_threshold, par_.dilation_threshold, pflags, epoch);
+    else
+    {
+        // one launch, field-major: a field's chain tiles, then its upper tiles (see Eedi2Engine::enqueue_mask)
+        MaskChain C = eedi_mask_chain_tiles(srcp, QM_W, QM_H, QM_OY);
+        C.flags = chain_flags_;
+        C.pflags = pflags;
+        C.epoch = epoch;
+        C.group = C.ntiles + C.nupper;
+        guard_.bind(C);
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_mask_passes", q_mask_chain, dim3((unsigned)(C.group * n)), dim3(QM_T), 0, P, S, k, C, mth, vth, lth,
+                        par_.erosion_threshold, par_.dilation_threshold);
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_mask_repair", q_mask_chain_repair, dim3(1), dim3(QM_T), 0, P, S, k, C, n, mth, vth, lth,
+                        par_.erosion_threshold, par_.dilation_threshold);
+    }
+    HBHIP_CHECK(lc, hipGetLastError());
+    return HBHIP_OK;
 }
 
 // the passes behind the mask for fields f0 .. f0 + n - 1 of the batch, on st
-int Eedi2Engine16::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st)
+int Eedi2Engine16::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st, uint32_t epoch)
 {
     const EediFrame srcp = at_slot(half_[0], start_ + f0), mskp = at_slot(half_[1], start_ + f0), tmpp = at_slot(half_[2], start_ + f0),
                     dstp = at_slot(half_[3], start_ + f0);
     const EediFrame dst2p = at_slot(full_[0], start_ + f0), tmp2p2 = at_slot(full_[1], start_ + f0), msk2p = at_slot(full_[2], start_ + f0),
                     tmp2p = at_slot(full_[3], start_ + f0), dst2mp = at_slot(full_[4], start_ + f0);
-    unsigned long long *cand = cand_ + (size_t)(start_ + f0) * (slot_bytes_ / sizeof(unsigned long long));
+    unsigned long long *cand = reinterpret_cast<unsigned long long *>(cand_raw_) + (size_t)(start_ + f0) * (slot_bytes_ / sizeof(unsigned long long));
     const K16 k = make_k16(geo_.depth);
 
     const dim3 blk(64, 4);
@@ -2768,7 +2642,7 @@ int Eedi2Engine16::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st)
     // half-height passes (decomb_template.c:398-404), all fields per launch from here on
     geom(P, srcp);
     P.pflags = plane_flags_ + 3 * f0;
-    P.pepoch = chain_epoch_;
+    P.pepoch = epoch;
     // filter_dir_map and expand_dir_map as one launch (q_dir_map_fe; eedi2.hip: Eedi2Engine::enqueue_passes): calc_directions
     // then writes dstp, and leaves the padding of its rows alone, so that the fused pass leaves the expanded map - and the
     // padding calc_directions' fill gives it - in tmpp, where the reference has them
@@ -2860,7 +2734,7 @@ int Eedi2Engine16::enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st)
         // field after field, plane after plane: the derivative arrays carry values along (eedi2.hip, CornerArgs)
         for (int f = 0; f < n; f++)
         {
-            const int tff = (int)((tffbits_ >> f) & 1u);
+            const int tff = (int)((tffbits_ >> (f0 + f)) & 1u);
             const size_t foff = (size_t)f * slot_bytes_;
             for (int c = 0; c < 3; c++)
             {

@@ -227,17 +227,32 @@ static inline bool eedi_fork_enabled()
     return on;
 }
 
-// EEDI2 on 8-bit samples (eedi2.hip).  Fields are queued with add_field() and run by launch(): the mask passes field
-// after field (the edge mask is the one piece of state a run takes from the one before it: the lower half of MSKPF
-// keeps the previous run's mask, eedi2_template.c:132), every pass behind them once for all queued fields.  A field's
-// scratch frames live in its slot; result(slot) stays valid until the slot is reused, i.e. for `capacity` more fields.
+// What the two engines (8-bit samples: eedi2.hip, 10 / 12-bit samples: eedi2_16.hip) share - everything on the host side
+// that does not name a kernel.  Fields are queued with add_field() and run by launch(): the mask passes field after field
+// (the edge mask is the one piece of state a run takes from the one before it: the lower half of MSKPF keeps the previous
+// run's mask, eedi2_template.c:132), every pass behind them once for all queued fields.  A field's scratch frames live in
+// its slot; result(slot) stays valid until the slot is reused, i.e. for `capacity` more fields.
+//  * slots: GUARD, then the nine scratch frames (4 half-height: SRCPF, MSKPF, TMPPF, DSTPF, decomb.c:64-68; 5 full-height:
+//    DST2PF, TMP2PF2, MSK2PF, TMP2PF, DST2MPF, :69-74) with a GUARD behind each (zeroed once, never written: the passes'
+//    reads outside rows and planes land there), then the lattice candidates; capacity + 1 slots, so that a batch never
+//    writes the slot whose mask its first field reads;
+//  * launch(): a batch goes out in parts of at most EEDI_PART fields - one mask launch per part (a chain of that many links),
+//    the passes behind it, forked over side streams where that is allowed (the comment in EediEngineBase::launch);
+//  * the numbering of mask launches (`epoch`: chain flags and plane flags are never cleared between launches).
+// A derived engine says how its slots are laid out (EediLayout) and queues its kernels (enqueue_mask / enqueue_passes).
 constexpr int EEDI_MAX_BATCH = 32;
-class Eedi2Engine
+constexpr int EEDI_PART = 16;
+struct EediLayout
+{
+    size_t guard;                     // bytes in front of / behind every scratch frame
+    size_t cand_elem;                 // bytes per lattice candidate word
+    int    tile_w, tile_h, tile_oy;   // the mask kernel's tile (eedi_mask_chain_tiles)
+};
+class EediEngineBase
 {
 public:
-    Eedi2Engine(hbhip_ctx *ctx, const PicGeometry &geo, const Eedi2Params &p, int capacity);
-    ~Eedi2Engine();
-    int  init();                                   // allocate capacity + 1 slots (zeroed once)
+    virtual ~EediEngineBase();
+    virtual int init() = 0;                        // allocate capacity + 1 slots (zeroed once)
     int  capacity() const { return cap_; }
     int  queued() const { return n_; }
     // eedi2_planer (decomb_template.c:455-473): field extraction + the pass sequence of eedi2_interpolate_plane for
@@ -250,16 +265,22 @@ public:
     EediFrame half(int i, int slot) const { return at_slot(half_[i], slot); }
     EediFrame full(int i, int slot) const { return at_slot(full_[i], slot); }
 
-private:
-    size_t place_frame(EediFrame &f, int width, int height, size_t at);
+protected:
+    EediEngineBase(hbhip_ctx *ctx, const PicGeometry &geo, const Eedi2Params &p, int capacity, const char *who);
+    int  init_slots(const EediLayout &L);          // the checks both engines make, slots, flags, side streams, derivative arrays
+    size_t place_frame(EediFrame &f, int width, int height, size_t at) const;
     EediFrame at_slot(const EediFrame &f, int slot) const;
+    int  next_epoch(hbhip_ctx *lc, uint32_t *epoch);
+    virtual bool may_fork() const { return true; } // beyond what launch() itself rules out
     // the five mask passes (+ the field extraction) of fields f0 .. f0 + n - 1 of the batch on st; *epoch: the launch's number
-    int enqueue_mask(int f0, int n, hbhip_ctx *lc, hipStream_t st, uint32_t *epoch);
+    virtual int enqueue_mask(int f0, int n, hbhip_ctx *lc, hipStream_t st, uint32_t *epoch) = 0;
     // everything after them for fields f0 .. f0 + n - 1 (of one mask launch: `epoch`), on st
-    int enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st, uint32_t epoch);
+    virtual int enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st, uint32_t epoch) = 0;
+
     hbhip_ctx  *ctx_;
     PicGeometry geo_;
     Eedi2Params par_;
+    const char *who_;
     int         cap_ = 1, n_ = 0, start_ = 0, last_slot_ = 0;
     uint32_t    tffbits_ = 0;
     const uint8_t *src_frame_[EEDI_MAX_BATCH][3];  // the queued fields' frames
@@ -268,63 +289,45 @@ private:
     size_t      slot_bytes_ = 0;
     EediFrame   half_[4];    // slot 0's SRCPF, MSKPF, TMPPF, DSTPF          (decomb.c:64-68)
     EediFrame   full_[5];    // slot 0's DST2PF, TMP2PF2, MSK2PF, TMP2PF, DST2MPF (decomb.c:69-74)
-    uint32_t   *chain_flags_ = nullptr; // mask chain: one completion flag per lower tile and field of a batch
+    uint8_t    *cand_raw_ = nullptr;    // slot 0's interpolate_lattice candidates (cand_pitch_ words a row, per plane cand_plane_stride_)
+    int         cand_pitch_ = 0, cand_plane_stride_ = 0;
+    int         chain_ntiles_ = 0;      // mask chain: lower tiles of one field
+    uint32_t   *chain_flags_ = nullptr; //             one completion flag per lower tile and field of a batch
     uint32_t    chain_epoch_ = 0;       //             the number of the last mask launch (never 0: 0 is "no launch" in the flag arrays)
     MaskChainGuard guard_;              //             what happens when a wait of the chain runs out
-    uint32_t   *plane_flags_ = nullptr; // [field of the batch][plane]: == chain_epoch_ when the plane's new mask has a pixel set
+    uint32_t   *plane_flags_ = nullptr; // [field of the batch][plane]: == the mask launch's number when the plane's new mask has a sample set
     static constexpr int MAX_SIDE = 3;
     hipStream_t side_[MAX_SIDE] = {};   // the later groups of a batch's fields run their passes here, beside the first group's
     hipEvent_t  ev_fork_ = nullptr, ev_mask_ = nullptr, ev_join_[MAX_SIDE] = {};
-    uint32_t   *work_list_ = nullptr;   // calc_directions fallback: compacted edge pixels
-    int        *work_count_ = nullptr;
-    uint32_t   *cand_ = nullptr;        // slot 0's interpolate_lattice candidates
-    int         cand_pitch_ = 0, cand_plane_stride_ = 0;
     int        *deriv_[3] = {nullptr, nullptr, nullptr};       // post-processing 2/3: cx2, cy2, cxy (decomb.c:398-403)
     int        *deriv_tmp_[3] = {nullptr, nullptr, nullptr};   //                      tmpc, one per array
 };
 
-// EEDI2 on 10 / 12-bit samples (eedi2_16.hip): the same engine (slots, add_field / launch) on uint16 samples, one
-// thread per sample and pass; the five mask passes are separate launches per field.  EediFrame strides are in BYTES,
-// the planes hold uint16 samples in the layout hb_frame_buffer_init gives a 16-bit frame.
-class Eedi2Engine16
+// EEDI2 on 8-bit samples (eedi2.hip).
+class Eedi2Engine : public EediEngineBase
+{
+public:
+    Eedi2Engine(hbhip_ctx *ctx, const PicGeometry &geo, const Eedi2Params &p, int capacity);
+    ~Eedi2Engine() override;
+    int  init() override;
+
+private:
+    bool may_fork() const override;
+    int enqueue_mask(int f0, int n, hbhip_ctx *lc, hipStream_t st, uint32_t *epoch) override;
+    int enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st, uint32_t epoch) override;
+    uint32_t   *work_list_ = nullptr;   // calc_directions fallback: compacted edge pixels
+    int        *work_count_ = nullptr;
+};
+
+// EEDI2 on 10 / 12-bit samples (eedi2_16.hip): the same engine on uint16 samples.  EediFrame strides are in BYTES, the
+// planes hold uint16 samples in the layout hb_frame_buffer_init gives a 16-bit frame.
+class Eedi2Engine16 : public EediEngineBase
 {
 public:
     Eedi2Engine16(hbhip_ctx *ctx, const PicGeometry &geo, const Eedi2Params &p, int capacity);
-    ~Eedi2Engine16();
-    int  init();
-    int  capacity() const { return cap_; }
-    int  queued() const { return n_; }
-    int  add_field(const DevPicture *cur, int tff);   // returns the field's slot
-    int  launch(hbhip_ctx *lc);
-    int  last_slot() const { return last_slot_; }
-    EediFrame result(int slot) const { return at_slot(full_[0], slot); }
-    EediFrame half(int i, int slot) const { return at_slot(half_[i], slot); }
-    EediFrame full(int i, int slot) const { return at_slot(full_[i], slot); }
+    int  init() override;
 
 private:
-    size_t place_frame(EediFrame &f, int width, int height, size_t at);
-    EediFrame at_slot(const EediFrame &f, int slot) const;
-    int enqueue(int n, hbhip_ctx *lc);
-    int enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st);
-    hbhip_ctx  *ctx_;
-    PicGeometry geo_;
-    Eedi2Params par_;
-    int         cap_ = 1, n_ = 0, start_ = 0, last_slot_ = 0;
-    uint32_t    tffbits_ = 0;
-    const uint8_t *src_frame_[EEDI_MAX_BATCH][3];
-    int         src_pitch_[3] = {0, 0, 0};
-    uint8_t    *slab_ = nullptr;
-    size_t      slot_bytes_ = 0;
-    EediFrame   half_[4];    // slot 0's SRCPF, MSKPF, TMPPF, DSTPF
-    EediFrame   full_[5];    // slot 0's DST2PF, TMP2PF2, MSK2PF, TMP2PF, DST2MPF
-    uint32_t   *chain_flags_ = nullptr; // mask chain (MaskChain)
-    uint32_t    chain_epoch_ = 0;
-    MaskChainGuard guard_;
-    uint32_t   *plane_flags_ = nullptr; // [field of the batch][plane]: == chain_epoch_ when the plane's new mask has a sample set
-    hipStream_t side_ = nullptr;        // the second half of a batch's fields runs its passes here (Eedi2Engine::side_)
-    hipEvent_t  ev_fork_ = nullptr, ev_join_ = nullptr;
-    unsigned long long *cand_ = nullptr;   // slot 0's interpolate_lattice candidates
-    int         cand_pitch_ = 0, cand_plane_stride_ = 0;
-    int        *deriv_[3] = {nullptr, nullptr, nullptr};
-    int        *deriv_tmp_[3] = {nullptr, nullptr, nullptr};
+    int enqueue_mask(int f0, int n, hbhip_ctx *lc, hipStream_t st, uint32_t *epoch) override;
+    int enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st, uint32_t epoch) override;
 };

@@ -128,28 +128,31 @@ def test_decomb_in_a_chain_batch(built, w, h, mode, combed):
         ctx.close()
 
 
+@pytest.mark.parametrize("depth", [8, 10])
 @pytest.mark.parametrize("batches", [(9, 10, 12, 1), (16, 5, 11), (4, 13, 15)])
-def test_decomb_eedi2_batch_parts(built, batches):
+def test_decomb_eedi2_batch_parts(built, batches, depth):
     """A batch of the engine goes out in parts of 16 fields - a mask launch per part (the second one on a stream of its own
-    beside the first part's passes), the passes of a part in two halves on two streams when it has 8 fields or more.
+    beside the first part's passes), the passes of a part in two halves on two streams when it has 8 fields or more
+    (EediEngineBase::launch: one piece of host code for the 8-bit and the 10 / 12-bit engine).
     Calls of 9, 10, 12 .. frames make second parts of 2, 4, 8 .. fields; the mask's lower half runs from field to field
     through all of them (eedi2_template.c:132), so a wrong order anywhere shows in every frame behind it."""
     import torch
     w, h = 322, 184
     n = sum(batches)
-    frames = synth.stream("interlaced", w, h, n)
-    want = os_.decomb_eedi2_stream(frames, dict(mode=31, postproc=1), flags=TFF)
+    frames = synth.stream("interlaced", w, h, n, depth=depth)
+    dt = torch.uint8 if depth == 8 else torch.uint16
+    want = os_.decomb_eedi2_stream(frames, dict(mode=31, postproc=1, depth=depth), flags=TFF)
     ctx = hip.Ctx(0)
-    dec = hip.DecombDevice(ctx, w, h, mode=31, postproc=1)
+    dec = hip.DecombDevice(ctx, w, h, mode=31, postproc=1, depth=depth)
     stage = hip.DeviceFilter(ctx, dec.h)
     dec.h = None
     chain = hip.Chain(ctx, [stage])
     try:
         dev_in = [[torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in f] for f in frames]
         cap = 2 * max(batches) + 4
-        outs = [[torch.zeros((h, w), dtype=torch.uint8, device="cuda"),
-                 torch.zeros((h // 2, w // 2), dtype=torch.uint8, device="cuda"),
-                 torch.zeros((h // 2, w // 2), dtype=torch.uint8, device="cuda")] for _ in range(cap)]
+        outs = [[torch.zeros((h, w), dtype=dt, device="cuda"),
+                 torch.zeros((h // 2, w // 2), dtype=dt, device="cuda"),
+                 torch.zeros((h // 2, w // 2), dtype=dt, device="cuda")] for _ in range(cap)]
         torch.cuda.synchronize()
         got, t = [], 0
         for b in batches:
