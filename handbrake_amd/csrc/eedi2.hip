@@ -245,6 +245,14 @@ constexpr int MF_LP = MF_W + 2 * MF_OX, MF_LR = MF_H + 2 * MF_OY; // 144 x 24
 constexpr int MF_DW = MF_LP / 4;                 // 36 dwords per LDS row
 constexpr int MF_DP = MF_DW + 2;                 // + one pad dword either side
 constexpr int MF_SR = 2;                         // rows per thread and pass
+// The chain link's round trips (build knob, bits: 1 = the look at the flags of the field before goes out in front of the
+// tile's own loads, 2 = the edge tests are computed while the old mask is on its way, 4 = no look at the plane flag at the
+// tile's end - a word per tile, folded into the plane flags by the pass behind the launch).  Measured, us per 16 fields
+// (profiles/r6Z_mask_link.log): none 133-135, 1: 135-136, 2: 142-147, 1 + 2: 144, 4: 127 - the launch is not the pure chain
+// of latencies the first two assume (its vector instructions alone are 93 us of issue); only the last one is on.
+#ifndef MF_OPT
+#define MF_OPT 4
+#endif
 constexpr int MF_T = 512;                        // threads: 12 strips of MF_SR rows x 36 dword columns = 432 of them work in a pass
 // (the per-field chain runs with one or two workgroups per CU and is bound by each thread's serial work: 4 rows per
 // thread and 256 threads 15.0 us per launch, 2 rows and 512 threads 12.6 us, 1 row and 1024 threads 12.6 us - with the
@@ -338,6 +346,16 @@ __device__ __forceinline__ void mask_tile(const P3 &P, const MaskSrc &S, const M
     int fr[2], fc[2], fyy[2], fxx[2];
     bool fin[2];
     uint32_t sv[2];
+    // a link of the chain: the look at the flags of the field before in front of the tile's own loads (a flag that is up
+    // - the rule: that tile ran a field's worth of workgroups ago - then costs no round trip of its own)
+    const uint32_t *cflag = nullptr;
+    uint32_t cseen = 0;
+    if (CHAIN && fld > 0)
+    {
+        cflag = eedi_chain_flag(C, fld, pl, bx, by);
+        cseen = C.epoch + 1u;
+        if ((MF_OPT & 1) && cflag) cseen = __hip_atomic_load(cflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #pragma unroll
     for (int k = 0; k < 2; k++)
     {
@@ -361,7 +379,8 @@ __device__ __forceinline__ void mask_tile(const P3 &P, const MaskSrc &S, const M
             *reinterpret_cast<uint32_t *>(srcp + (size_t)y * pitch + x) = sv[k];
         s_src[r][c4 + 1] = sv[k];
     }
-    if (CHAIN && fld > 0) eedi_chain_wait(C, fld, pl, bx, by);    // (the source rows above are already on their way)
+    if (CHAIN && fld > 0) eedi_chain_wait(C, cflag, cseen);        // (the source rows above are already on their way)
+    else if ((MF_OPT & 2) || upper) __syncthreads();              // (s_src)
     uint32_t mv[2];
 #pragma unroll
     for (int k = 0; k < 2; k++)
@@ -374,16 +393,25 @@ __device__ __forceinline__ void mask_tile(const P3 &P, const MaskSrc &S, const M
             mv[k] = CHAIN ? __hip_atomic_load(m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *m;
         }
     }
+    // an upper tile keeps nothing of the old mask, and with MF_OPT & 2 the edge tests (which never needed it) are computed
+    // while it is on its way: s_src is complete here (the barrier above), the old mask goes to LDS behind them
+    const bool edge_first = (MF_OPT & 2) || upper;
+    if (!edge_first)
+    {
 #pragma unroll
-    for (int k = 0; k < 2; k++)
-        if (fin[k]) s_a[fr[k]][fc[k] + 1] = mv[k] & 0x01010101u;
-    __syncthreads();
+        for (int k = 0; k < 2; k++)
+            if (fin[k]) s_a[fr[k]][fc[k] + 1] = mv[k] & 0x01010101u;
+        __syncthreads();
+    }
 
     const int c4 = t % MF_DW, strip = t / MF_DW;               // strips past the frame have no rows in any pass
     const int X = fx + 4 * c4;
     const uint32_t px1 = mf_bytes_in(X, 1, width - 1) & 0x01010101u;
 
     // build_edge_mask (:122-195), in place on the old mask; LDS rows 1 .. 22
+    uint32_t edges[MF_SR];
+#pragma unroll
+    for (int i = 0; i < MF_SR; i++) edges[i] = 0;
     {
         const int r0 = 1 + strip * MF_SR;
         if (r0 <= MF_LR - 2)
@@ -407,32 +435,66 @@ __device__ __forceinline__ void mask_tile(const P3 &P, const MaskSrc &S, const M
                 if (r > MF_LR - 2) break;
                 const int y = fy + r;
                 const int (&Pr)[6] = b[i], (&Cr)[6] = b[i + 1], (&Nr)[6] = b[i + 2];
-                int cs[6], cq[6];
+                // the three samples of a column: all pairwise differences below 10 (:157-160) is max - min < 10, and the largest
+                // pairwise difference (Iy, :172-173) is that same max - min: one v_max3 / v_min3 pair per column serves both
+                int cs[6], cq[6], rng[6];
                 bool fl[6];
 #pragma unroll
                 for (int j = 0; j < 6; j++)
                 {
                     cs[j] = Pr[j] + Cr[j] + Nr[j];
                     cq[j] = q[i][j] + q[i + 1][j] + q[i + 2][j];
-                    fl[j] = iabs(Pr[j] - Cr[j]) < 10 && iabs(Cr[j] - Nr[j]) < 10 && iabs(Pr[j] - Nr[j]) < 10;
+                    rng[j] = max(max(Pr[j], Cr[j]), Nr[j]) - min(min(Pr[j], Cr[j]), Nr[j]);
+                    fl[j] = rng[j] < 10;
                 }
                 uint32_t edge = 0;
 #pragma unroll
                 for (int k = 0; k < 4; k++)
                 {
+                    // (no short-circuit: as `&&` / `||` the tests became 118 exec-mask branches per tile pair of the kernel)
                     const int sum = cs[k] + cs[k + 1] + cs[k + 2], sumsq = cq[k] + cq[k + 1] + cq[k + 2];
-                    const int C0 = Cr[k], C1 = Cr[k + 1], C2 = Cr[k + 2], P1 = Pr[k + 1], N1 = Nr[k + 1];
+                    const int C0 = Cr[k], C1 = Cr[k + 1], C2 = Cr[k + 2];
                     const int ix = C2 - C0;
-                    const int iy = max(max(iabs(P1 - N1), iabs(P1 - C1)), iabs(C1 - N1));
-                    const int ixx = C0 - 2 * C1 + C2, iyy = P1 - 2 * C1 + N1;
-                    const bool e = !(fl[k + 1] || (fl[k] && fl[k + 2])) && 9 * sumsq - sum * sum >= vth &&
-                                   (ix * ix + iy * iy >= mth || iabs(ixx) + iabs(iyy) >= lth);
+                    const int iy = rng[k + 1];
+                    // |Ixx| + |Iyy| = |(C0 + C2) - 2 C1| + |(P1 + N1) - 2 C1|, both sides non-negative: two v_sad_u32
+                    const uint32_t c2 = 2u * (uint32_t)C1;
+                    uint32_t lap;
+                    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(lap) : "v"((uint32_t)(cs[k + 1] - C1)), "v"(c2));
+                    asm("v_sad_u32 %0, %1, %2, %0" : "+v"(lap) : "v"((uint32_t)(C0 + C2)), "v"(c2));
+                    const bool notflat = !(fl[k + 1] | (fl[k] & fl[k + 2]));
+                    const bool var = 9 * sumsq - sum * sum >= vth;
+                    const bool mag = ix * ix + iy * iy >= mth;
+                    const bool e = notflat & var & (mag | ((int)lap >= lth));
                     edge |= (e ? 1u : 0u) << (8 * k);
                 }
-                const uint32_t keep = (y < height / 2) ? 0u : s_a[r][c4 + 1];
                 const uint32_t pm = (y >= 1 && y < height - 1) ? px1 : 0u;
-                s_a[r][c4 + 1] = keep | (edge & pm);
+                edges[i] = edge & pm;
+                if (!edge_first)
+                {
+                    const uint32_t keep = (y < height / 2) ? 0u : s_a[r][c4 + 1];
+                    s_a[r][c4 + 1] = keep | edges[i];
+                }
             }
+        }
+    }
+    if (edge_first)
+    {
+        // the old mask to LDS - every cell of the frame, also rows 0 and 23, which no edge test writes and the first erode
+        // reads - then the edges on top of what is kept of it
+        // (an upper tile: zeros in those two rows, the edges everywhere else - no cell is written twice, no barrier)
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+            if (fin[k] && (!upper || fr[k] == 0 || fr[k] == MF_LR - 1)) s_a[fr[k]][fc[k] + 1] = upper ? 0u : mv[k] & 0x01010101u;
+        if (!upper) __syncthreads();
+        const int r0 = 1 + strip * MF_SR;
+#pragma unroll
+        for (int i = 0; i < MF_SR; i++)
+        {
+            const int r = r0 + i;
+            if (r > MF_LR - 2) break;
+            if (upper) { s_a[r][c4 + 1] = edges[i]; continue; }
+            const uint32_t keep = (fy + r < height / 2) ? 0u : s_a[r][c4 + 1];
+            s_a[r][c4 + 1] = keep | edges[i];
         }
     }
     __syncthreads();
@@ -471,11 +533,7 @@ __device__ __forceinline__ void mask_tile(const P3 &P, const MaskSrc &S, const M
     // serialise in the L2 (the mask launch went from 120 us to 2 ms with a store per wave).
     // (behind the tile's own flag: the next field's tiles wait for that one)
     const bool has = CHAIN ? eedi_chain_signal(C, fld, pl, bx, by, anyset != 0u) : (bool)__syncthreads_or(anyset != 0u);
-    // (the look at the flag costs the workgroup a round trip at its end: 122 -> 140 us per launch.  Measured and worse:
-    // the same load at the tile's start, where it sits in front of the tile's own loads - 350 us; no look at all but
-    // a store into one of four words per plane - 257 us)
-    if (has && t == 0 && __hip_atomic_load(C.pflags + 3 * fld + pl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != C.epoch)
-        __hip_atomic_store(C.pflags + 3 * fld + pl, C.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    eedi_chain_note_has(C, fld, pl, has);
 }
 
 __global__ __launch_bounds__(MF_T) void k_mask_fused4(P3 P, MaskSrc S, int f0, int part, int mth, int vth, int lth, int erode_thr, int dilate_thr,
@@ -490,7 +548,7 @@ __global__ __launch_bounds__(MF_T) void k_mask_fused4(P3 P, MaskSrc S, int f0, i
     const bool upper = y0 + MF_H + MF_OY <= P.height[pl] / 2;
     if (part != 0 && upper != (part == 1)) return;
     MaskChain none;
-    none.pflags = pflags; none.epoch = epoch;
+    none.pflags = pflags; none.epoch = epoch; none.has = nullptr;
     mask_tile<false>(P, S, none, fld, pl, (int)blockIdx.x, (int)blockIdx.y, mth, vth, lth, erode_thr, dilate_thr, s_src, s_a, s_b);
 }
 
@@ -507,24 +565,32 @@ __global__ __launch_bounds__(MF_T) void k_mask_chain(P3 P, MaskSrc S, MaskChain 
         mask_tile<false>(P, S, C, fld, pl, bx, by, mth, vth, lth, erode_thr, dilate_thr, s_src, s_a, s_b);
 }
 
-// Queued behind every k_mask_chain launch, ONE workgroup: nothing to do unless a wait of the chain ran out (C.err).  Then
-// the launch's lower tiles are recomputed field after field, tile after tile, by this one workgroup - program order is
-// the dependency order, every flag already carries the epoch (each tile publishes itself, timed out or not), so the
-// waits inside mask_tile<true> pass at once - from the same sources with the same arithmetic: the new masks end up as
-// the per-field launches would have left them.  (The upper tiles and SRCPF never depended on another field.)
+// Queued behind every k_mask_chain launch, a workgroup per field and plane.
+//  * Each folds the words its plane's tiles left in C.has into the plane flag (P3::pflags: the passes behind the mask take
+//    a shortcut for a plane without a mask pixel) - the tiles themselves no longer look at the flag, which cost every
+//    workgroup of the chain a round trip at its end.
+//  * Workgroup 0 then has nothing to do unless a wait of the chain ran out (C.err).  Then the launch's lower tiles are
+//    recomputed field after field, tile after tile, by this one workgroup - program order is the dependency order, every
+//    flag already carries the epoch (each tile publishes itself, timed out or not), so the waits inside mask_tile<true>
+//    pass at once - from the same sources with the same arithmetic: the new masks end up as the per-field launches would
+//    have left them.  (The upper tiles and SRCPF never depended on another field.)  A plane flag that went up for a mask the
+//    repair empties only costs the shortcut.
 __global__ __launch_bounds__(MF_T) void k_mask_chain_repair(P3 P, MaskSrc S, MaskChain C, int nfields, int mth, int vth, int lth,
                                                             int erode_thr, int dilate_thr)
 {
     __shared__ uint32_t s_src[MF_LR][MF_DP];
     __shared__ uint32_t s_a[MF_LR][MF_DP];
     __shared__ uint32_t s_b[MF_LR][MF_DP];
-    if (__hip_atomic_load(C.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;      // block-uniform
+    eedi_chain_fold_has(C, MF_T);
+    if (blockIdx.x != 0 || __hip_atomic_load(C.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;      // block-uniform
+    MaskChain R = C;
+    R.has = nullptr;                                               // the repaired tiles raise the plane flags themselves
     for (int fld = 0; fld < nfields; fld++)
         for (int tile = 0; tile < C.ntiles; tile++)
         {
             int pl, bx, by;
             eedi_chain_lower_tile(C, tile, pl, bx, by);
-            mask_tile<true>(P, S, C, fld, pl, bx, by, mth, vth, lth, erode_thr, dilate_thr, s_src, s_a, s_b);
+            mask_tile<true>(P, S, R, fld, pl, bx, by, mth, vth, lth, erode_thr, dilate_thr, s_src, s_a, s_b);
             __syncthreads();
         }
     if (threadIdx.x == 0)
@@ -3147,6 +3213,7 @@ EediEngineBase::~EediEngineBase()
 {
     if (slab_) (void)hipFree(slab_);
     if (chain_flags_) (void)hipFree(chain_flags_);
+    if (chain_has_) (void)hipFree(chain_has_);
     if (plane_flags_) (void)hipFree(plane_flags_);
     guard_.destroy();
     for (int g = 0; g < MAX_SIDE; g++)
@@ -3215,13 +3282,20 @@ int EediEngineBase::init_slots(const EediLayout &L)
     HBHIP_CHECK(ctx_, hipMalloc((void **)&plane_flags_, sizeof(uint32_t) * 3 * EEDI_MAX_BATCH));
     HBHIP_CHECK(ctx_, hipMemsetAsync(plane_flags_, 0, sizeof(uint32_t) * 3 * EEDI_MAX_BATCH, ctx_->stream));
     last_slot_ = cap_;                                             // "the previous mask" of the first run: zeros, like the reference's
-    chain_ntiles_ = eedi_mask_chain_tiles(half_[0], L.tile_w, L.tile_h, L.tile_oy).ntiles;
+    {
+        const MaskChain C = eedi_mask_chain_tiles(half_[0], L.tile_w, L.tile_h, L.tile_oy);
+        chain_ntiles_ = C.ntiles;
+        chain_group_ = C.ntiles + C.nupper;
+    }
     if (cap_ > 1)
     {
         // one completion flag per lower mask tile and field of a batch (MaskChain); 0 is no launch's number
         const size_t nflags = (size_t)chain_ntiles_ * cap_;
         HBHIP_CHECK(ctx_, hipMalloc((void **)&chain_flags_, sizeof(uint32_t) * nflags));
         HBHIP_CHECK(ctx_, hipMemsetAsync(chain_flags_, 0, sizeof(uint32_t) * nflags, ctx_->stream));
+        // and a word per tile (upper ones too) and field: "left a mask sample set" (MaskChain::has)
+        HBHIP_CHECK(ctx_, hipMalloc((void **)&chain_has_, sizeof(uint32_t) * (size_t)chain_group_ * cap_));
+        HBHIP_CHECK(ctx_, hipMemsetAsync(chain_has_, 0, sizeof(uint32_t) * (size_t)chain_group_ * cap_, ctx_->stream));
         const int grc = guard_.init(ctx_);
         if (grc != HBHIP_OK) return grc;
     }
@@ -3270,6 +3344,7 @@ int EediEngineBase::next_epoch(hbhip_ctx *lc, uint32_t *epoch)
         // drain the device, clear the flags and start over at 1 (months of continuous running apart)
         HBHIP_CHECK(lc, hipDeviceSynchronize());
         if (chain_flags_) HBHIP_CHECK(lc, hipMemset(chain_flags_, 0, sizeof(uint32_t) * (size_t)chain_ntiles_ * cap_));
+        if (chain_has_) HBHIP_CHECK(lc, hipMemset(chain_has_, 0, sizeof(uint32_t) * (size_t)chain_group_ * cap_));
         HBHIP_CHECK(lc, hipMemset(plane_flags_, 0, sizeof(uint32_t) * 3 * EEDI_MAX_BATCH));
         chain_epoch_ = 0;
     }
@@ -3441,11 +3516,13 @@ int Eedi2Engine::enqueue_mask(int f0, int n, hbhip_ctx *lc, hipStream_t st, uint
         C.pflags = pflags;
         C.epoch = epoch;
         C.group = C.ntiles + C.nupper;
+        C.has = (MF_OPT & 4) ? chain_has_ + (size_t)f0 * C.group : nullptr;
         guard_.bind(C);
         HBHIP_LAUNCH_ON(lc, st, "eedi2_mask_passes", k_mask_chain, dim3((unsigned)(C.group * n)), dim3(MF_T), 0, P, S, C, mth, vth, lth,
                      par_.erosion_threshold, par_.dilation_threshold);
-        // one workgroup that returns at once unless a wait above ran out (MaskChain): no abort, no host round trip
-        HBHIP_LAUNCH_ON(lc, st, "eedi2_mask_repair", k_mask_chain_repair, dim3(1), dim3(MF_T), 0, P, S, C, n, mth, vth, lth,
+        // the plane flags out of the tiles' words; and one workgroup that returns at once unless a wait above ran out
+        // (MaskChain): no abort, no host round trip
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_mask_repair", k_mask_chain_repair, dim3(C.has ? 3u * (unsigned)n : 1u), dim3(MF_T), 0, P, S, C, n, mth, vth, lth,
                         par_.erosion_threshold, par_.dilation_threshold);
     }
     HBHIP_CHECK(lc, hipGetLastError());

@@ -227,14 +227,16 @@ __device__ __forceinline__ void qmask_tile(const Q3 &P, const MaskSrc16 &S, cons
                 if (r > QM_LR - 2) break;
                 const int y = fy + r;
                 const int (&Pr)[6] = b[i], (&Cr)[6] = b[i + 1], (&Nr)[6] = b[i + 2];
-                int cs[6], cq[6];
+                // (max - min of a column's three samples serves the flatness test and Iy: eedi2.hip, mask_tile)
+                int cs[6], cq[6], rng[6];
                 bool fl[6];
 #pragma unroll
                 for (int j = 0; j < 6; j++)
                 {
                     cs[j] = Pr[j] + Cr[j] + Nr[j];
                     cq[j] = q[i][j] + q[i + 1][j] + q[i + 2][j];
-                    fl[j] = iabs16(Pr[j] - Cr[j]) < ten && iabs16(Cr[j] - Nr[j]) < ten && iabs16(Pr[j] - Nr[j]) < ten;
+                    rng[j] = max(max(Pr[j], Cr[j]), Nr[j]) - min(min(Pr[j], Cr[j]), Nr[j]);
+                    fl[j] = rng[j] < ten;
                 }
                 uint32_t edge = 0;
 #pragma unroll
@@ -243,10 +245,13 @@ __device__ __forceinline__ void qmask_tile(const Q3 &P, const MaskSrc16 &S, cons
                     const int sum = (cs[kk] + cs[kk + 1] + cs[kk + 2]) >> sh, sumsq = cq[kk] + cq[kk + 1] + cq[kk + 2];
                     const int C0 = Cr[kk], C1 = Cr[kk + 1], C2 = Cr[kk + 2], P1 = Pr[kk + 1], N1 = Nr[kk + 1];
                     const int ix = (C2 - C0) >> sh;
-                    const int iy = max(max(iabs16(P1 - N1), iabs16(P1 - C1)), iabs16(C1 - N1)) >> sh;
+                    const int iy = rng[kk + 1] >> sh;
                     const int ixx = (C0 - 2 * C1 + C2) >> sh, iyy = (P1 - 2 * C1 + N1) >> sh;
-                    const bool e = !(fl[kk + 1] || (fl[kk] && fl[kk + 2])) && !(9 * sumsq - sum * sum < vth) &&
-                                   (ix * ix + iy * iy >= mth || iabs16(ixx) + iabs16(iyy) >= lth);
+                    // (no short-circuit: as `&&` / `||` the tests become exec-mask branches)
+                    const bool notflat = !(fl[kk + 1] | (fl[kk] & fl[kk + 2]));
+                    const bool var = !(9 * sumsq - sum * sum < vth);
+                    const bool mag = ix * ix + iy * iy >= mth;
+                    const bool e = notflat & var & (mag | (iabs16(ixx) + iabs16(iyy) >= lth));
                     edge |= (e ? 1u : 0u) << (8 * kk);
                 }
                 const uint32_t keep = (y < height / 2) ? 0u : s_a[r][c4 + 1];
@@ -302,8 +307,7 @@ __device__ __forceinline__ void qmask_tile(const Q3 &P, const MaskSrc16 &S, cons
     }
     // a plane with a mask sample somewhere: say so (eedi2.hip: mask_tile)
     const bool has = CHAIN ? eedi_chain_signal(C, fld, pl, bx, by, anyset != 0u) : (bool)__syncthreads_or(anyset != 0u);
-    if (has && t == 0 && __hip_atomic_load(C.pflags + 3 * fld + pl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != C.epoch)
-        __hip_atomic_store(C.pflags + 3 * fld + pl, C.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    eedi_chain_note_has(C, fld, pl, has);
 }
 
 __global__ __launch_bounds__(QM_T) void q_mask_fused(Q3 P, MaskSrc16 S, K16 k, int f0, int part, int mth, int vth, int lth,
@@ -318,7 +322,7 @@ __global__ __launch_bounds__(QM_T) void q_mask_fused(Q3 P, MaskSrc16 S, K16 k, i
     const bool upper = y0 + QM_H + QM_OY <= P.height[pl] / 2;
     if (part != 0 && upper != (part == 1)) return;
     MaskChain none;
-    none.pflags = pflags; none.epoch = epoch;
+    none.pflags = pflags; none.epoch = epoch; none.has = nullptr;
     qmask_tile<false>(P, S, k, none, fld, pl, (int)blockIdx.x, (int)blockIdx.y, mth, vth, lth, erode_thr, dilate_thr, s_src, s_a, s_b);
 }
 
@@ -336,21 +340,24 @@ __global__ __launch_bounds__(QM_T) void q_mask_chain(Q3 P, MaskSrc16 S, K16 k, M
         qmask_tile<false>(P, S, k, C, fld, pl, bx, by, mth, vth, lth, erode_thr, dilate_thr, s_src, s_a, s_b);
 }
 
-// the repair pass behind q_mask_chain (k_mask_chain_repair, eedi2.hip, says what it is for): one workgroup, a no-op unless
-// a wait of the chain ran out
+// the pass behind q_mask_chain (k_mask_chain_repair, eedi2.hip, says what it is for): the plane flags out of the tiles'
+// words, a workgroup per field and plane; the first one then repairs - a no-op unless a wait of the chain ran out
 __global__ __launch_bounds__(QM_T) void q_mask_chain_repair(Q3 P, MaskSrc16 S, K16 k, MaskChain C, int nfields, int mth, int vth, int lth,
                                                             int erode_thr, int dilate_thr)
 {
     __shared__ __attribute__((aligned(16))) uint16_t s_src[QM_LR][QM_LP + 8];
     __shared__ uint32_t s_a[QM_LR][QM_DP];
     __shared__ uint32_t s_b[QM_LR][QM_DP];
-    if (__hip_atomic_load(C.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;      // block-uniform
+    eedi_chain_fold_has(C, QM_T);
+    if (blockIdx.x != 0 || __hip_atomic_load(C.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;      // block-uniform
+    MaskChain R = C;
+    R.has = nullptr;                                               // the repaired tiles raise the plane flags themselves
     for (int fld = 0; fld < nfields; fld++)
         for (int tile = 0; tile < C.ntiles; tile++)
         {
             int pl, bx, by;
             eedi_chain_lower_tile(C, tile, pl, bx, by);
-            qmask_tile<true>(P, S, k, C, fld, pl, bx, by, mth, vth, lth, erode_thr, dilate_thr, s_src, s_a, s_b);
+            qmask_tile<true>(P, S, k, R, fld, pl, bx, by, mth, vth, lth, erode_thr, dilate_thr, s_src, s_a, s_b);
             __syncthreads();
         }
     if (threadIdx.x == 0)
@@ -2598,10 +2605,11 @@ int Eedi2Engine16::enqueue_mask(int f0, int n, hbhip_ctx *lc, hipStream_t st, ui
         C.pflags = pflags;
         C.epoch = epoch;
         C.group = C.ntiles + C.nupper;
+        C.has = chain_has_ + (size_t)f0 * C.group;
         guard_.bind(C);
         HBHIP_LAUNCH_ON(lc, st, "eedi2_16_mask_passes", q_mask_chain, dim3((unsigned)(C.group * n)), dim3(QM_T), 0, P, S, k, C, mth, vth, lth,
                         par_.erosion_threshold, par_.dilation_threshold);
-        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_mask_repair", q_mask_chain_repair, dim3(1), dim3(QM_T), 0, P, S, k, C, n, mth, vth, lth,
+        HBHIP_LAUNCH_ON(lc, st, "eedi2_16_mask_repair", q_mask_chain_repair, dim3(3u * (unsigned)n), dim3(QM_T), 0, P, S, k, C, n, mth, vth, lth,
                         par_.erosion_threshold, par_.dilation_threshold);
     }
     HBHIP_CHECK(lc, hipGetLastError());

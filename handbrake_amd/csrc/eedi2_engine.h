@@ -55,6 +55,8 @@ struct MaskChain
     int group;                // workgroups per field of a launch: ntiles, or ntiles + nupper when the upper tiles ride along
     uint32_t *pflags;         // [field][plane]: set to `epoch` by any tile that leaves a mask pixel set - a plane whose flag is
                               // not the epoch afterwards has an empty mask, and every later pass only copies it (8-bit engine)
+    uint32_t *has;            // [field][tile of the group]: set to `epoch` by a tile that leaves a mask pixel set; the pass behind the
+                              // launch (k_mask_chain_repair) folds them into pflags.  Null: every tile looks at pflags itself
     uint32_t *err;            // raised by a tile whose wait ran out (MaskChainGuard::err)
     uint32_t *fallbacks;      // host-visible count of repaired launches (MaskChainGuard::count_dev)
     int       spin_limit;     // polls before a wait gives up
@@ -155,31 +157,40 @@ __device__ __forceinline__ bool eedi_chain_tile(const MaskChain &C, int &fld, in
     return false;
 }
 
-// threads 0 .. 8 of the workgroup: wait for the previous field's tile at (bx + t % 3 - 1, by + t / 3 - 1), if there is one
-__device__ __forceinline__ void eedi_chain_wait(const MaskChain &C, int fld, int pl, int bx, int by)
+// threads 0 .. 8 of the workgroup: the flag of the previous field's tile at (bx + t % 3 - 1, by + t / 3 - 1), if there is one
+__device__ __forceinline__ const uint32_t *eedi_chain_flag(const MaskChain &C, int fld, int pl, int bx, int by)
 {
     const int t = threadIdx.x;
-    if (t < 9)
+    if (t >= 9) return nullptr;
+    const int nx = bx + t % 3 - 1, ny = by + t / 3 - 1;
+    if (nx < 0 || nx >= C.tx[pl] || ny < C.ty0[pl] || ny >= C.ty0[pl] + C.tyn[pl]) return nullptr;
+    return C.flags + (size_t)(fld - 1) * C.ntiles + C.base[pl] + (ny - C.ty0[pl]) * C.tx[pl] + nx;
+}
+
+// wait for those tiles.  `seen`: what a look at the flag returned that the caller issued in front of its own loads (the
+// flag's round trip then rides with theirs: most of the time the tile of the field before is long done)
+__device__ __forceinline__ void eedi_chain_wait(const MaskChain &C, const uint32_t *flag, uint32_t seen)
+{
+    if (flag && seen != C.epoch)
     {
-        const int nx = bx + t % 3 - 1, ny = by + t / 3 - 1;
-        if (nx >= 0 && nx < C.tx[pl] && ny >= C.ty0[pl] && ny < C.ty0[pl] + C.tyn[pl])
+        int spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != C.epoch)
         {
-            const uint32_t *flag = C.flags + (size_t)(fld - 1) * C.ntiles + C.base[pl] + (ny - C.ty0[pl]) * C.tx[pl] + nx;
-            int spins = 0;
-            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != C.epoch)
+            if (++spins > C.spin_limit)
             {
-                if (++spins > C.spin_limit)
-                {
-                    // the dispatch order this rests on did not hold (or a test says so): no abort - the repair pass
-                    // behind the launch redoes the lower tiles in order
-                    __hip_atomic_store(C.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(2);
+                // the dispatch order this rests on did not hold (or a test says so): no abort - the repair pass
+                // behind the launch redoes the lower tiles in order
+                __hip_atomic_store(C.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
             }
+            __builtin_amdgcn_s_sleep(2);
         }
     }
     __syncthreads();                                           // (a workgroup fence: the mask loads that follow stay below)
+}
+__device__ __forceinline__ void eedi_chain_wait(const MaskChain &C, int fld, int pl, int bx, int by)
+{
+    eedi_chain_wait(C, eedi_chain_flag(C, fld, pl, bx, by), C.epoch + 1u);
 }
 
 // after the tile's mask stores (agent-scope atomics): publish the tile.  Returns the workgroup's OR of `pred` (the barrier
@@ -207,6 +218,33 @@ __device__ __forceinline__ bool eedi_chain_signal(const MaskChain &C, int fld, i
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return any;
 #endif
+}
+
+// the tile's end: it left a mask sample set (`has`, workgroup-uniform).  With C.has the tile stores a word of its own and
+// is gone (blockIdx.x = its place in the launch, field-major) - the pass behind the launch folds the words into the plane
+// flags (eedi_chain_fold_has); without, one thread looks at the plane flag and raises it if it is not up yet.
+// (The look costs the workgroup a round trip at its end: 122 -> 140 us per launch when it came in.  Measured and worse:
+// the same load at the tile's start, where it sits in front of the tile's own loads - 350 us; no look at all but a store
+// into one of four words per plane - 257 us: thousands of tiles storing to the same few words serialise in the L2.)
+__device__ __forceinline__ void eedi_chain_note_has(const MaskChain &C, int fld, int pl, bool has)
+{
+    if (!has || threadIdx.x != 0) return;
+    if (C.has) __hip_atomic_store(C.has + blockIdx.x, C.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (__hip_atomic_load(C.pflags + 3 * fld + pl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != C.epoch)
+        __hip_atomic_store(C.pflags + 3 * fld + pl, C.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// workgroup b of the pass behind a chain launch: field b / 3, plane b % 3 - the plane flag out of its tiles' words
+__device__ __forceinline__ void eedi_chain_fold_has(const MaskChain &C, int nthreads)
+{
+    if (!C.has) return;
+    const int fld = (int)blockIdx.x / 3, pl = (int)blockIdx.x - 3 * fld;
+    const uint32_t *h = C.has + (size_t)fld * C.group;
+    const int nl = C.tx[pl] * C.tyn[pl], nu = C.tx[pl] * C.ty0[pl];
+    bool any = false;
+    for (int i = threadIdx.x; i < nl + nu; i += nthreads)
+        any |= h[i < nl ? C.base[pl] + i : C.ntiles + C.ubase[pl] + (i - nl)] == C.epoch;
+    if (__syncthreads_or(any) && threadIdx.x == 0) C.pflags[3 * fld + pl] = C.epoch;
 }
 
 // the repair pass's loop head: lower tile number `tile` of a field -> plane, column, row (eedi_chain_tile without blockIdx)
@@ -291,8 +329,9 @@ protected:
     EediFrame   full_[5];    // slot 0's DST2PF, TMP2PF2, MSK2PF, TMP2PF, DST2MPF (decomb.c:69-74)
     uint8_t    *cand_raw_ = nullptr;    // slot 0's interpolate_lattice candidates (cand_pitch_ words a row, per plane cand_plane_stride_)
     int         cand_pitch_ = 0, cand_plane_stride_ = 0;
-    int         chain_ntiles_ = 0;      // mask chain: lower tiles of one field
+    int         chain_ntiles_ = 0, chain_group_ = 0;   // mask chain: lower tiles / all tiles of one field
     uint32_t   *chain_flags_ = nullptr; //             one completion flag per lower tile and field of a batch
+    uint32_t   *chain_has_ = nullptr;   //             one word per tile and field: the tile left a mask sample set (MaskChain::has)
     uint32_t    chain_epoch_ = 0;       //             the number of the last mask launch (never 0: 0 is "no launch" in the flag arrays)
     MaskChainGuard guard_;              //             what happens when a wait of the chain runs out
     uint32_t   *plane_flags_ = nullptr; // [field of the batch][plane]: == the mask launch's number when the plane's new mask has a sample set
