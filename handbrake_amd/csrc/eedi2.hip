@@ -437,6 +437,7 @@ __device__ __forceinline__ void mask_tile(const P3 &P, const MaskSrc &S, const M
                 const int (&Pr)[6] = b[i], (&Cr)[6] = b[i + 1], (&Nr)[6] = b[i + 2];
                 // the three samples of a column: all pairwise differences below 10 (:157-160) is max - min < 10, and the largest
                 // pairwise difference (Iy, :172-173) is that same max - min: one v_max3 / v_min3 pair per column serves both
+                // (tests/test_eedi2_identities_cpu.py::test_edge_mask_flatness_and_iy_are_one_range, ::test_edge_mask_laplacian_as_two_unsigned_sads)
                 int cs[6], cq[6], rng[6];
                 bool fl[6];
 #pragma unroll

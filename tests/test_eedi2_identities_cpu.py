@@ -316,3 +316,38 @@ def test_lapsharp_mix_as_one_float_multiply():
     for st in (0.2, 0.3, 0.04, 0.15, 0.5, 1.0, 1.5):
         assert float_form(lap, 1.0, st) and float_form(iso, 0.2, st), st
     assert not float_form(iso, 0.2, 0.35) and not float_form(lap, 1.0, 0.7)
+
+
+def test_edge_mask_flatness_and_iy_are_one_range():
+    """mask_tile / qmask_tile (eedi2.hip, eedi2_16.hip): build_edge_mask's flatness test of a column - all three pairwise
+    differences of the samples above / at / below below ten (eedi2_template.c:141-150) - is max - min < ten, and Iy, the
+    largest pairwise difference (:172-173), is that same max - min.  Every triple of 8-bit samples; 10-bit triples on a
+    grid that holds every residue and both ends."""
+    p = np.arange(256, dtype=np.int32)[:, None, None]
+    c = np.arange(256, dtype=np.int32)[None, :, None]
+    n = np.arange(256, dtype=np.int32)[None, None, :]
+    rng = np.maximum(np.maximum(p, c), n) - np.minimum(np.minimum(p, c), n)
+    assert np.array_equal((np.abs(p - c) < 10) & (np.abs(c - n) < 10) & (np.abs(p - n) < 10), rng < 10)
+    assert np.array_equal(np.maximum(np.maximum(np.abs(p - n), np.abs(p - c)), np.abs(c - n)), rng)
+    g = np.unique(np.concatenate([np.arange(0, 1024, 7), np.arange(0, 48), np.arange(976, 1024)])).astype(np.int32)
+    p, c, n = g[:, None, None], g[None, :, None], g[None, None, :]
+    rng = np.maximum(np.maximum(p, c), n) - np.minimum(np.minimum(p, c), n)
+    for shift in (2, 4):                                                  # `ten` = 10 << (depth - 8), Iy >> shift
+        ten = 10 << shift
+        assert np.array_equal((np.abs(p - c) < ten) & (np.abs(c - n) < ten) & (np.abs(p - n) < ten), rng < ten)
+        assert np.array_equal(np.maximum(np.maximum(np.abs(p - n), np.abs(p - c)), np.abs(c - n)) >> shift, rng >> shift)
+
+
+def test_edge_mask_laplacian_as_two_unsigned_sads():
+    """mask_tile (eedi2.hip, 8-bit): |Ixx| + |Iyy| (:183-186) with Ixx = C0 - 2 C1 + C2 and Iyy = P1 - 2 C1 + N1 is
+    |(C0 + C2) - 2 C1| + |(P1 + N1) - 2 C1| on non-negative operands - two v_sad_u32 -, and P1 + N1 is the column sum
+    the variance test already has, less C1."""
+    r = np.random.default_rng(5)
+    c0, c1, c2, p1, n1 = (r.integers(0, 256, 1 << 20, dtype=np.int64) for _ in range(5))
+    for arr in (c0, c1, c2, p1, n1):
+        arr[:4096] = r.choice([0, 255], 4096)                              # the corners
+    want = np.abs(c0 - 2 * c1 + c2) + np.abs(p1 - 2 * c1 + n1)
+    cs = p1 + c1 + n1
+    sad = lambda a, b, acc: np.abs(a.astype(np.uint32).astype(np.int64) - b.astype(np.uint32).astype(np.int64)) + acc
+    got = sad(c0 + c2, 2 * c1, sad(cs - c1, 2 * c1, 0))
+    assert np.array_equal(want, got)
