@@ -74,7 +74,7 @@ struct P3
 };
 
 // A launch covers the three planes of every field of a batch: blockIdx.z = 3 * field + plane.  All scratch frames of
-// a field sit in one slab (Eedi2Engine::init), so one offset moves every pointer of the pass to the block's field.
+// a field sit in one slab (EediEngineBase::init_slots), so one offset moves every pointer of the pass to the block's field.
 // The block's pointers are picked once into Q (scalar loads from the kernel arguments; P itself is never written -
 // a dynamically indexed store would push the whole struct into scratch memory).
 // `maskless`: the plane's edge mask is empty (no mask tile left a pixel set: MaskChain::pflags) - chroma without edges, a

@@ -37,7 +37,7 @@ struct EediFrame
 // field-major and dispatched in that order, so a waiting workgroup only ever waits for one that is already resident
 // or done; the wait is bounded all the same.  When it runs out the tile does NOT abort anything: it raises the launch's
 // error word, goes on with the mask as it finds it (atomic loads: a defined value) and publishes itself like every
-// other tile, so the launch always ends; a one-workgroup repair pass queued behind the launch (eedi_chain_repair_tile
+// other tile, so the launch always ends; a repair pass queued behind the launch - its workgroup 0 - (eedi_chain_repair_tile
 // loop: k_mask_chain_repair / q_mask_chain_repair) looks at the word and, only if it is up, recomputes the lower tiles
 // of the launch's fields serially in field order - the per-field form of the same arithmetic, no waits - and counts the
 // event for the host, which logs it once (MaskChainGuard).  Two workgroups on different XCDs do not share
