@@ -229,8 +229,26 @@ __device__ __forceinline__ void st4(uint8_t *dst_at_x, const int (&out)[4], int 
 // the lower half that build_edge_mask does not touch keep it, :146-150), c = the new mask.  The old
 // and the new mask are different buffers (the engine alternates them) because neighbouring tiles
 // read each other's halos.  Pixels a pass does not process keep their input, as in the reference.
-constexpr int MF_W = 128, MF_H = 16, MF_OX = 8, MF_OY = 4;      // tile and the LDS frame's origin offset
-constexpr int MF_LP = MF_W + 2 * MF_OX, MF_LR = MF_H + 2 * MF_OY; // 144 x 24
+// The tile's shape is a build parameter (tools/variant.sh; -DMF_TILE_W / MF_TILE_H / MF_STRIP_ROWS / MF_THREADS).  What runs
+// since round 6 is 64 x 16 pixels on 256 threads; until then 128 x 16 on 512.  Measured on one box, the chain / decomb bob
+// / the kernel alone (output fps / fps / us per 16 fields, profiles/r6Z_mask_tile_shapes.log): 128 x 16 x 512 8 617 / 12 725 /
+// 117; 64 x 16 x 256 8 888 / 13 201 / 112-115; 128 x 8 x 256 8 824 / 13 373 / 112; 128 x 16 x 256 with four rows per
+// thread 8 754 / 12 715 / 164 - a slower kernel and a faster chain: what the chain gains is not the kernel's own time but
+// the 256-thread workgroup, which shares the CUs with the kernels of the other streams (the next part's mask beside this
+// part's passes, decomb beside the other stages) where four 512-thread workgroups of a CU kept them out; 128 x 32, 128 x
+// 24, 128 x 12, 128 x 8 on 512 threads, 256 x 8 and 64 x 8 lose (138-160 us: a taller tile is a longer link of the chain,
+// a flatter one stages 2 x its pixels).
+#ifndef MF_TILE_H
+#define MF_TILE_H 16
+#endif
+#ifndef MF_STRIP_ROWS
+#define MF_STRIP_ROWS 2
+#endif
+#ifndef MF_TILE_W
+#define MF_TILE_W 64
+#endif
+constexpr int MF_W = MF_TILE_W, MF_H = MF_TILE_H, MF_OX = 8, MF_OY = 4;      // tile and the LDS frame's origin offset
+constexpr int MF_LP = MF_W + 2 * MF_OX, MF_LR = MF_H + 2 * MF_OY; // the LDS frame: 80 x 24
 
 
 // The passes work on dwords.  Every value of the mask is 0 or 255, so inside the kernel a mask
@@ -241,10 +259,10 @@ constexpr int MF_LP = MF_W + 2 * MF_OX, MF_LR = MF_H + 2 * MF_OY; // 144 x 24
 // 6 rows x 3 dwords around the strip once and keeps the per-row partial sums in registers.  Each pass
 // computes the whole frame minus one more row top and bottom; the cells next to the frame's left / right
 // edge come out wrong by design (they read the unwritten pad column), one byte further in per pass,
-// which the 8-byte column halo absorbs (the tile needs x0-3 .. x0+130 from the last erode).
-constexpr int MF_DW = MF_LP / 4;                 // 36 dwords per LDS row
+// which the 8-byte column halo absorbs (the tile needs x0 - 3 .. x0 + MF_W + 2 from the last erode).
+constexpr int MF_DW = MF_LP / 4;                 // 20 dwords per LDS row
 constexpr int MF_DP = MF_DW + 2;                 // + one pad dword either side
-constexpr int MF_SR = 2;                         // rows per thread and pass
+constexpr int MF_SR = MF_STRIP_ROWS;             // rows per thread and pass
 // The chain link's round trips (build knob, bits: 1 = the look at the flags of the field before goes out in front of the
 // tile's own loads, 2 = the edge tests are computed while the old mask is on its way, 4 = no look at the plane flag at the
 // tile's end - a word per tile, folded into the plane flags by the pass behind the launch).  Measured, us per 16 fields
@@ -253,10 +271,13 @@ constexpr int MF_SR = 2;                         // rows per thread and pass
 #ifndef MF_OPT
 #define MF_OPT 4
 #endif
-constexpr int MF_T = 512;                        // threads: 12 strips of MF_SR rows x 36 dword columns = 432 of them work in a pass
-// (the per-field chain runs with one or two workgroups per CU and is bound by each thread's serial work: 4 rows per
-// thread and 256 threads 15.0 us per launch, 2 rows and 512 threads 12.6 us, 1 row and 1024 threads 12.6 us - with the
-// all-fields launch of the upper part at 55 / 57 / 77 us per 16 fields)
+#ifndef MF_THREADS
+#define MF_THREADS 256
+#endif
+constexpr int MF_T = MF_THREADS;                // threads: 11 strips of MF_SR rows x 20 dword columns = 220 of them work in a pass
+// (round 2, on the 128-pixel tile as a launch per field: 4 rows per thread and 256 threads 15.0 us per launch, 2 rows and
+// 512 threads 12.6 us, 1 row and 1024 threads 12.6 us - with the all-fields launch of the upper part at 55 / 57 / 77 us
+// per 16 fields)
 
 // 0xff in byte k when lo <= X + k < hi
 __device__ __forceinline__ uint32_t mf_bytes_in(int X, int lo, int hi)
@@ -339,13 +360,14 @@ __device__ __forceinline__ void mask_tile(const P3 &P, const MaskSrc &S, const M
     uint8_t *srcp = P.a[pl] + foff, *newm = P.c[pl] + foff;
     const int t = threadIdx.x, fx = x0 - MF_OX, fy = y0 - MF_OY;
 
-    // The LDS frame is MF_LR x MF_DW = 864 dwords for 512 threads: two per thread.  Both loads of a thread go out before
+    // The LDS frame is MF_LR x MF_DW = 480 dwords for 256 threads: two per thread (MF_LD).  All loads of a thread go out before
     // anything is done with the first (as a loop, the store of SRCPF between them made the second wait for the first:
     // two round trips in a row, and again for the old mask - on the chain's critical path from tile to tile).
-    static_assert(MF_LR * MF_DW <= 2 * MF_T, "two frame dwords per thread");
-    int fr[2], fc[2], fyy[2], fxx[2];
-    bool fin[2];
-    uint32_t sv[2];
+    constexpr int MF_LD = (MF_LR * MF_DW + MF_T - 1) / MF_T;     // frame dwords per thread (two for the 16-row tile)
+    static_assert(((MF_LR - 2 + MF_SR - 1) / MF_SR) * MF_DW <= MF_T, "a thread per strip and dword column");
+    int fr[MF_LD], fc[MF_LD], fyy[MF_LD], fxx[MF_LD];
+    bool fin[MF_LD];
+    uint32_t sv[MF_LD];
     // a link of the chain: the look at the flags of the field before in front of the tile's own loads (a flag that is up
     // - the rule: that tile ran a field's worth of workgroups ago - then costs no round trip of its own)
     const uint32_t *cflag = nullptr;
@@ -357,7 +379,7 @@ __device__ __forceinline__ void mask_tile(const P3 &P, const MaskSrc &S, const M
         if ((MF_OPT & 1) && cflag) cseen = __hip_atomic_load(cflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #pragma unroll
-    for (int k = 0; k < 2; k++)
+    for (int k = 0; k < MF_LD; k++)
     {
         const int i = t + MF_T * k;
         fin[k] = i < MF_LR * MF_DW;
@@ -368,7 +390,7 @@ __device__ __forceinline__ void mask_tile(const P3 &P, const MaskSrc &S, const M
             sv[k] = *reinterpret_cast<const uint32_t *>(frame + (size_t)(start_line + 2 * fyy[k]) * S.spitch[pl] + fxx[k]);
     }
 #pragma unroll
-    for (int k = 0; k < 2; k++)
+    for (int k = 0; k < MF_LD; k++)
     {
         if (!fin[k]) continue;
         const int r = fr[k], c4 = fc[k], y = fyy[k], x = fxx[k];
@@ -381,9 +403,9 @@ __device__ __forceinline__ void mask_tile(const P3 &P, const MaskSrc &S, const M
     }
     if (CHAIN && fld > 0) eedi_chain_wait(C, cflag, cseen);        // (the source rows above are already on their way)
     else if ((MF_OPT & 2) || upper) __syncthreads();              // (s_src)
-    uint32_t mv[2];
+    uint32_t mv[MF_LD];
 #pragma unroll
-    for (int k = 0; k < 2; k++)
+    for (int k = 0; k < MF_LD; k++)
     {
         mv[k] = 0;
         // (only the rows of the kept half are used, and those were written by lower tiles)
@@ -399,7 +421,7 @@ __device__ __forceinline__ void mask_tile(const P3 &P, const MaskSrc &S, const M
     if (!edge_first)
     {
 #pragma unroll
-        for (int k = 0; k < 2; k++)
+        for (int k = 0; k < MF_LD; k++)
             if (fin[k]) s_a[fr[k]][fc[k] + 1] = mv[k] & 0x01010101u;
         __syncthreads();
     }
@@ -484,7 +506,7 @@ __device__ __forceinline__ void mask_tile(const P3 &P, const MaskSrc &S, const M
         // reads - then the edges on top of what is kept of it
         // (an upper tile: zeros in those two rows, the edges everywhere else - no cell is written twice, no barrier)
 #pragma unroll
-        for (int k = 0; k < 2; k++)
+        for (int k = 0; k < MF_LD; k++)
             if (fin[k] && (!upper || fr[k] == 0 || fr[k] == MF_LR - 1)) s_a[fr[k]][fc[k] + 1] = upper ? 0u : mv[k] & 0x01010101u;
         if (!upper) __syncthreads();
         const int r0 = 1 + strip * MF_SR;

@@ -82,9 +82,16 @@ __device__ __forceinline__ int sorted_mid16(int *v, int n)
 // kernel.  a = SRCPF (written: the tile's part of the extracted field), b = the finished mask of the field before
 // field 0 of the launch, c = MSKPF.  `part`: 0 = every tile, 1 = only the tiles whose LDS frame stays above height / 2
 // (independent of the previous field: all fields of a batch in one launch), 2 = only the others (the chain).
-constexpr int QM_W = 128, QM_H = 16, QM_OX = 8, QM_OY = 4;
+#ifndef QM_TILE_W
+#define QM_TILE_W 128
+#endif
+#ifndef QM_THREADS
+#define QM_THREADS 512
+#endif
+constexpr int QM_W = QM_TILE_W, QM_H = 16, QM_OX = 8, QM_OY = 4;
 constexpr int QM_LP = QM_W + 2 * QM_OX, QM_LR = QM_H + 2 * QM_OY;      // 144 x 24
-constexpr int QM_DW = QM_LP / 4, QM_DP = QM_DW + 2, QM_SR = 2, QM_T = 512;
+constexpr int QM_DW = QM_LP / 4, QM_DP = QM_DW + 2, QM_SR = 2, QM_T = QM_THREADS;
+static_assert(((QM_LR - 2 + QM_SR - 1) / QM_SR) * QM_DW <= QM_T, "a thread per strip and dword column");
 
 __device__ __forceinline__ uint32_t qm_bytes_in(int X, int lo, int hi)        // 0xff in byte k when lo <= X + k < hi
 {
