@@ -556,7 +556,7 @@ __device__ __forceinline__ void mask_tile(const P3 &P, const MaskSrc &S, const M
     // serialise in the L2 (the mask launch went from 120 us to 2 ms with a store per wave).
     // (behind the tile's own flag: the next field's tiles wait for that one)
     const bool has = CHAIN ? eedi_chain_signal(C, fld, pl, bx, by, anyset != 0u) : (bool)__syncthreads_or(anyset != 0u);
-    eedi_chain_note_has(C, fld, pl, has);
+    eedi_chain_note_has(C, fld, pl, bx, by, has);
 }
 
 __global__ __launch_bounds__(MF_T) void k_mask_fused4(P3 P, MaskSrc S, int f0, int part, int mth, int vth, int lth, int erode_thr, int dilate_thr,

@@ -314,7 +314,7 @@ __device__ __forceinline__ void qmask_tile(const Q3 &P, const MaskSrc16 &S, cons
     }
     // a plane with a mask sample somewhere: say so (eedi2.hip: mask_tile)
     const bool has = CHAIN ? eedi_chain_signal(C, fld, pl, bx, by, anyset != 0u) : (bool)__syncthreads_or(anyset != 0u);
-    eedi_chain_note_has(C, fld, pl, has);
+    eedi_chain_note_has(C, fld, pl, bx, by, has);
 }
 
 __global__ __launch_bounds__(QM_T) void q_mask_fused(Q3 P, MaskSrc16 S, K16 k, int f0, int part, int mth, int vth, int lth,

@@ -221,15 +221,20 @@ __device__ __forceinline__ bool eedi_chain_signal(const MaskChain &C, int fld, i
 }
 
 // the tile's end: it left a mask sample set (`has`, workgroup-uniform).  With C.has the tile stores a word of its own and
-// is gone (blockIdx.x = its place in the launch, field-major) - the pass behind the launch folds the words into the plane
-// flags (eedi_chain_fold_has); without, one thread looks at the plane flag and raises it if it is not up yet.
+// is gone (its place among the launch's words: field-major, a field's lower tiles by number, then its upper ones - whatever
+// order the workgroups were given the tiles in) - the pass behind the launch folds the words into the plane flags
+// (eedi_chain_fold_has); without, one thread looks at the plane flag and raises it if it is not up yet.
 // (The look costs the workgroup a round trip at its end: 122 -> 140 us per launch when it came in.  Measured and worse:
 // the same load at the tile's start, where it sits in front of the tile's own loads - 350 us; no look at all but a store
 // into one of four words per plane - 257 us: thousands of tiles storing to the same few words serialise in the L2.)
-__device__ __forceinline__ void eedi_chain_note_has(const MaskChain &C, int fld, int pl, bool has)
+__device__ __forceinline__ void eedi_chain_note_has(const MaskChain &C, int fld, int pl, int bx, int by, bool has)
 {
     if (!has || threadIdx.x != 0) return;
-    if (C.has) __hip_atomic_store(C.has + blockIdx.x, C.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (C.has)
+    {
+        const int tile = by >= C.ty0[pl] ? C.base[pl] + (by - C.ty0[pl]) * C.tx[pl] + bx : C.ntiles + C.ubase[pl] + by * C.tx[pl] + bx;
+        __hip_atomic_store(C.has + (size_t)fld * C.group + tile, C.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     else if (__hip_atomic_load(C.pflags + 3 * fld + pl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != C.epoch)
         __hip_atomic_store(C.pflags + 3 * fld + pl, C.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
