@@ -451,7 +451,10 @@ def build_chain(hip, device, W, H, scale, depth=8, split=2, only_decomb=False, c
     ctxs = [hip.Ctx(device)]
 
     def stage_ctx(stage=0):
-        if (not split or (split == 2 and len(ctxs) >= 3) or (split == 3 and stage != 2 and len(ctxs) >= 2) or
+        # split 2: decomb stays on the chain's own context - the caller's stream -, the other stages get one more: with
+        # EEDI2's two side streams that makes four busy HIP streams, one per hardware queue of the runtime's default four
+        # (a fifth shares a queue with one of them, and whatever waits in it holds the other up: DESIGN 4.10)
+        if (not split or (split == 2 and (stage == 0 or len(ctxs) >= 2)) or (split == 3 and stage != 2 and len(ctxs) >= 2) or
                 (split == 4 and stage == 3)):
             return ctxs[-1]
         ctxs.append(hip.Ctx(device))

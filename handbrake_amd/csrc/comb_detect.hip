@@ -679,8 +679,8 @@ public:
             hipEvent_t done = ctx->sync_ev_get();
             if (!done) return ctx->fail(hipErrorOutOfMemory, "hipEventCreate(store)");
             HBHIP_CHECK(ctx, hipMemcpy2DAsync(luma_alloc[use], pitch, luma, stride, (size_t)width * bps, height,
-                                              hipMemcpyHostToDevice, ctx->up_stream));
-            HBHIP_CHECK(ctx, hipEventRecord(done, ctx->up_stream));
+                                              hipMemcpyHostToDevice, ctx->up()));
+            HBHIP_CHECK(ctx, hipEventRecord(done, ctx->up()));
             const hipError_t e = hipEventSynchronize(done);
             ctx->sync_ev_put(done);
             if (e != hipSuccess) return ctx->fail(e, "hipEventSynchronize(store)");

@@ -3244,6 +3244,7 @@ EediEngineBase::~EediEngineBase()
         if (side_[g]) (void)hipStreamDestroy(side_[g]);
         if (ev_join_[g]) (void)hipEventDestroy(ev_join_[g]);
     }
+    if (ahead_) (void)hipStreamDestroy(ahead_);
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
     if (ev_mask_) (void)hipEventDestroy(ev_mask_);
     for (int i = 0; i < 3; i++)
@@ -3296,7 +3297,11 @@ int EediEngineBase::init_slots(const EediLayout &L)
     {
         HBHIP_CHECK(ctx_, hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
         HBHIP_CHECK(ctx_, hipEventCreateWithFlags(&ev_mask_, hipEventDisableTiming));
-        for (int g = 0; g < 2; g++)                                        // [0] the passes' twin, [1] the next part's mask
+        // the side streams of a part's later groups of fields: one (two groups; three with two measured + 1.5 % in round 4
+        // and nothing now - a stream more than the hardware has queues for once the stages behind decomb have theirs)
+        nside_ = std::min(std::max(hbhip_dev_int("HBHIP_EEDI2_GROUPS", 2) - 1, 1), MAX_SIDE);
+        if (mask_ahead()) HBHIP_CHECK(ctx_, hipStreamCreateWithFlags(&ahead_, hipStreamNonBlocking));
+        for (int g = 0; g < nside_; g++)
         {
             HBHIP_CHECK(ctx_, hipStreamCreateWithFlags(&side_[g], hipStreamNonBlocking));
             HBHIP_CHECK(ctx_, hipEventCreateWithFlags(&ev_join_[g], hipEventDisableTiming));
@@ -3425,8 +3430,15 @@ int EediEngineBase::launch(hbhip_ctx *lc)
     //    the same kernels half a launch apart fill each other's tails and latency-bound stretches (decomb bob 10 750 ->
     //    11 560, the chain 7 390 -> 7 640 output fps; three quarters / one quarter: 11 100 / 7 540; three groups on three
     //    streams + 1.5 %, four - 9 %).
-    //  * The mask launch of the second part (it waits for the first part's mask only) runs on a stream of its own beside
-    //    the first part's passes instead of alone in front of its own.
+    //  * The mask launch of the second part goes out on the caller's stream right behind the first part's, in front of the
+    //    first part's passes there: it runs beside the other half's passes on the side stream.  (Until round 6 it had a
+    //    stream of its own.  HIP spreads its streams over four hardware queues, and a stream that shares its queue with
+    //    another waits behind whatever that one waits for: with the mask on the caller's stream a chain keeps three streams
+    //    busy - the caller's, the side stream, the stages behind decomb - and measures the same however the process's
+    //    other streams were made; with a fourth and fifth it read 8 230 - 8 880 fps by the order of their creation.
+    //    8 810 -> 8 916 fps on the chain, 13 390 -> 13 435 on decomb bob: profiles/r6Z_streams_and_queues.log.  The 16-bit
+    //    engine keeps the stream of its own: its mask launch is the longer one, and in front of the passes it costs the
+    //    10-bit chain 1.5 %, 10-bit decomb bob 3 % - mask_ahead().)
     // Not with post-processing 2 / 3 (its derivative arrays carry values from field to field), not while the profiler
     // brackets launches (its events live on the context's stream) or HBHIP_EEDI2_FORK=0 says so (counter runs), not for
     // the long-search fallback (one work list): then everything goes out on the caller's stream, part after part.
@@ -3445,10 +3457,9 @@ int EediEngineBase::launch(hbhip_ctx *lc)
     }
     else if (rc == HBHIP_OK)
     {
-        // one event (ev_mask_) orders the parts: good for two of them
-        static_assert(EEDI_MAX_BATCH <= 2 * EEDI_PART, "the fork below orders at most two parts with its one mask event");
-        hipStream_t twin = side_[0], ahead = side_[1];
-        bool twin_used = false, ahead_used = false;
+        // two events order the side streams behind the masks: ev_fork_ = the first part's is out, ev_mask_ = the next part's
+        static_assert(EEDI_MAX_BATCH <= 2 * EEDI_PART, "the fork below orders at most two parts with its two mask events");
+        bool used[MAX_SIDE] = {}, ahead_used = false;
         // a HIP call that fails in here must not leave the side streams running into slots the caller goes on to reuse:
         // remember it, stop queueing, and fall through to the joins
         hipError_t herr = hipSuccess;
@@ -3459,43 +3470,49 @@ int EediEngineBase::launch(hbhip_ctx *lc)
         {
             const int f0 = p * EEDI_PART, m = std::min(EEDI_PART, n - f0);
             hipEvent_t ready = p ? ev_mask_ : ev_fork_;                       // this part's mask
-            if (p) FORK_TRY(hipStreamWaitEvent(lc->stream, ev_mask_, 0));
-            if (p + 1 < parts && herr == hipSuccess)
+            if (p && ahead_) FORK_TRY(hipStreamWaitEvent(lc->stream, ev_mask_, 0));   // (it ran on the stream of its own)
+            if (p + 1 < parts)
             {
-                // the next part's mask beside this part's passes: behind this part's mask, on its own stream
+                // the next part's mask: behind this part's mask, in front of this part's passes on this stream
+                // (the 16-bit engine: on its stream of its own, behind this part's mask - see mask_ahead())
                 const int g0 = f0 + EEDI_PART, gm = std::min(EEDI_PART, n - g0);
-                FORK_TRY(hipStreamWaitEvent(ahead, ready, 0));
-                if (herr != hipSuccess) break;
-                ahead_used = true;
-                rc = enqueue_mask(g0, gm, lc, ahead, &epoch[p + 1]);
+                hipStream_t ms = ahead_ ? ahead_ : lc->stream;
+                if (ahead_) { FORK_TRY(hipStreamWaitEvent(ahead_, ready, 0)); if (herr != hipSuccess) break; ahead_used = true; }
+                rc = enqueue_mask(g0, gm, lc, ms, &epoch[p + 1]);
                 if (rc != HBHIP_OK) break;
-                FORK_TRY(hipEventRecord(ev_mask_, ahead));
+                FORK_TRY(hipEventRecord(ev_mask_, ms));
             }
             if (herr != hipSuccess) break;
-            if (m >= 8)
+            const int groups = m >= 8 ? nside_ + 1 : 1;                       // the caller's stream and the side streams
+            for (int g = 0, at = f0; g < groups && rc == HBHIP_OK && herr == hipSuccess; g++)
             {
-                const int h = m / 2;
-                FORK_TRY(hipStreamWaitEvent(twin, ready, 0));
-                if (herr != hipSuccess) break;
-                twin_used = true;
-                rc = enqueue_passes(f0, h, lc, lc->stream, epoch[p]);
-                if (rc == HBHIP_OK) rc = enqueue_passes(f0 + h, m - h, lc, twin, epoch[p]);
+                const int k = (f0 + m - at) / (groups - g);                   // what is left, evenly
+                if (g == 0) rc = enqueue_passes(at, k, lc, lc->stream, epoch[p]);
+                else
+                {
+                    FORK_TRY(hipStreamWaitEvent(side_[g - 1], ready, 0));
+                    if (herr != hipSuccess) break;
+                    used[g - 1] = true;
+                    rc = enqueue_passes(at, k, lc, side_[g - 1], epoch[p]);
+                }
+                at += k;
             }
-            else rc = enqueue_passes(f0, m, lc, lc->stream, epoch[p]);
         }
 #undef FORK_TRY
         if (herr != hipSuccess || rc != HBHIP_OK)
         {
             // whatever was queued on the side streams finishes before the caller sees the error
-            if (twin_used) (void)hipStreamSynchronize(twin);
-            if (ahead_used) (void)hipStreamSynchronize(ahead);
+            for (int g = 0; g < MAX_SIDE; g++) if (used[g]) (void)hipStreamSynchronize(side_[g]);
+            if (ahead_used) (void)hipStreamSynchronize(ahead_);
             if (herr != hipSuccess) rc = lc->fail(herr, hwhat);
         }
-        else if (twin_used)
-        {
-            HBHIP_CHECK(lc, hipEventRecord(ev_join_[0], twin));
-            HBHIP_CHECK(lc, hipStreamWaitEvent(lc->stream, ev_join_[0], 0));
-        }
+        else
+            for (int g = 0; g < MAX_SIDE; g++)
+                if (used[g])
+                {
+                    HBHIP_CHECK(lc, hipEventRecord(ev_join_[g], side_[g]));
+                    HBHIP_CHECK(lc, hipStreamWaitEvent(lc->stream, ev_join_[g], 0));
+                }
     }
     last_slot_ = start_ + n - 1;
     return rc;

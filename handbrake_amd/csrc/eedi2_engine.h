@@ -315,6 +315,7 @@ protected:
     EediFrame at_slot(const EediFrame &f, int slot) const;
     int  next_epoch(hbhip_ctx *lc, uint32_t *epoch);
     virtual bool may_fork() const { return true; } // beyond what launch() itself rules out
+    virtual bool mask_ahead() const { return false; }   // the next part's mask on a stream of its own (launch())
     // the five mask passes (+ the field extraction) of fields f0 .. f0 + n - 1 of the batch on st; *epoch: the launch's number
     virtual int enqueue_mask(int f0, int n, hbhip_ctx *lc, hipStream_t st, uint32_t *epoch) = 0;
     // everything after them for fields f0 .. f0 + n - 1 (of one mask launch: `epoch`), on st
@@ -341,7 +342,9 @@ protected:
     MaskChainGuard guard_;              //             what happens when a wait of the chain runs out
     uint32_t   *plane_flags_ = nullptr; // [field of the batch][plane]: == the mask launch's number when the plane's new mask has a sample set
     static constexpr int MAX_SIDE = 3;
-    hipStream_t side_[MAX_SIDE] = {};   // the later groups of a batch's fields run their passes here, beside the first group's
+    int         nside_ = 0;
+    hipStream_t ahead_ = nullptr;       // mask_ahead(): the next part's mask launch runs here
+    hipStream_t side_[MAX_SIDE] = {};   // the later groups of a part's fields run their passes here, beside the first group's
     hipEvent_t  ev_fork_ = nullptr, ev_mask_ = nullptr, ev_join_[MAX_SIDE] = {};
     int        *deriv_[3] = {nullptr, nullptr, nullptr};       // post-processing 2/3: cx2, cy2, cxy (decomb.c:398-403)
     int        *deriv_tmp_[3] = {nullptr, nullptr, nullptr};   //                      tmpc, one per array
@@ -372,6 +375,7 @@ public:
     int  init() override;
 
 private:
+    bool mask_ahead() const override { return true; }
     int enqueue_mask(int f0, int n, hbhip_ctx *lc, hipStream_t st, uint32_t *epoch) override;
     int enqueue_passes(int f0, int n, hbhip_ctx *lc, hipStream_t st, uint32_t epoch) override;
 };

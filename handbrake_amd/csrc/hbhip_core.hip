@@ -277,21 +277,21 @@ static int hbhip_copy_h2d_queue(hbhip_ctx *ctx, DevPicture *dst, const hbhip_hos
     if (!done) return ctx->fail(hipErrorOutOfMemory, "hipEventCreate(upload)");
     auto fail = [&](hipError_t e, const char *what) { ctx->sync_ev_put(done); return ctx->fail(e, what); };
     // whatever still reads the picture's previous contents was queued ahead of its idle mark when it was recycled
-    hipError_t e = hbhip_pic_wait_idle(ctx->up_stream, dst);
+    hipError_t e = hbhip_pic_wait_idle(ctx->up(), dst);
     if (e != hipSuccess) return fail(e, "upload: wait for the picture's last reader");
     if (same_layout(dst, src->plane, src->stride))
-        e = hipMemcpyAsync(dst->plane[0], src->plane[0], layout_bytes(dst), hipMemcpyHostToDevice, ctx->up_stream);
+        e = hipMemcpyAsync(dst->plane[0], src->plane[0], layout_bytes(dst), hipMemcpyHostToDevice, ctx->up());
     else
         for (int c = 0; c < 3 && e == hipSuccess; c++)
         {
             const size_t row = (size_t)std::min(src->stride[c], dst->pitch[c]);
             e = hipMemcpy2DAsync(dst->plane[c], dst->pitch[c], src->plane[c], src->stride[c],
-                                 row, dst->height[c], hipMemcpyHostToDevice, ctx->up_stream);
+                                 row, dst->height[c], hipMemcpyHostToDevice, ctx->up());
         }
-    if (e == hipSuccess) e = hipEventRecord(done, ctx->up_stream);
+    if (e == hipSuccess) e = hipEventRecord(done, ctx->up());
     if (e != hipSuccess)
     {
-        (void)hipStreamSynchronize(ctx->up_stream);                // planes already queued must not outlive the call
+        (void)hipStreamSynchronize(ctx->up());                // planes already queued must not outlive the call
         return fail(e, "hipMemcpyAsync(upload)");
     }
     *done_out = done;
@@ -320,14 +320,14 @@ int hbhip_copy_d2h(hbhip_ctx *ctx, const hbhip_host_frame *dst, const DevPicture
     if (!ev) return ctx->fail(hipErrorOutOfMemory, "hipEventCreate(download)");
     // the picture's producers are on ctx->stream, all queued by now
     HBHIP_CHECK(ctx, hipEventRecord(ev, ctx->stream));
-    HBHIP_CHECK(ctx, hipStreamWaitEvent(ctx->down_stream, ev, 0));
+    HBHIP_CHECK(ctx, hipStreamWaitEvent(ctx->down(), ev, 0));
     for (int c = 0; c < 3; c++)
     {
         const size_t row = (size_t)src->width[c] * src->bps;
         HBHIP_CHECK(ctx, hipMemcpy2DAsync(dst->plane[c], dst->stride[c], src->plane[c], src->pitch[c],
-                                          row, src->height[c], hipMemcpyDeviceToHost, ctx->down_stream));
+                                          row, src->height[c], hipMemcpyDeviceToHost, ctx->down()));
     }
-    HBHIP_CHECK(ctx, hipEventRecord(ev, ctx->down_stream));
+    HBHIP_CHECK(ctx, hipEventRecord(ev, ctx->down()));
     const hipError_t e = hipEventSynchronize(ev);
     ctx->sync_ev_put(ev);
     if (e != hipSuccess) return ctx->fail(e, "hipEventSynchronize(download)");
@@ -493,6 +493,18 @@ const char *hbhip_strerror(int code)
     }
 }
 
+// the copy streams, made when first asked for (hbhip_internal.h); without one the copies go to the context's own stream
+static hipStream_t lazy_stream(hbhip_ctx *ctx, std::once_flag &once, hipStream_t &slot)
+{
+    std::call_once(once, [&] {
+        (void)hipSetDevice(ctx->device);
+        if (hipStreamCreateWithFlags(&slot, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); slot = nullptr; }
+    });
+    return slot ? slot : ctx->stream;
+}
+hipStream_t hbhip_ctx::up() { return lazy_stream(this, up_once, up_stream); }
+hipStream_t hbhip_ctx::down() { return lazy_stream(this, down_once, down_stream); }
+
 static int ctx_create_common(int device, void *stream, bool adopt, hbhip_ctx **out)
 {
     if (out == nullptr) return HBHIP_ERR_ARG;
@@ -515,15 +527,6 @@ static int ctx_create_common(int device, void *stream, bool adopt, hbhip_ctx **o
     else if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess)
     {
         (void)hipGetLastError();
-        delete ctx;
-        return HBHIP_ERR_HIP;
-    }
-    if (hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&ctx->down_stream, hipStreamNonBlocking) != hipSuccess)
-    {
-        (void)hipGetLastError();
-        if (ctx->up_stream) (void)hipStreamDestroy(ctx->up_stream);
-        if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
         delete ctx;
         return HBHIP_ERR_HIP;
     }
@@ -943,8 +946,8 @@ int hbhip_frame_upload_async(hbhip_frame *fr, const hbhip_host_frame *src, void 
     hipEvent_t done = nullptr;
     const int rc = hbhip_copy_h2d_queue(ctx, &fr->pic, src, &done);
     if (rc != HBHIP_OK) return rc;
-    m->stream = ctx->up_stream;
-    const hipError_t e = hipEventRecord(m->ev, ctx->up_stream);
+    m->stream = ctx->up();
+    const hipError_t e = hipEventRecord(m->ev, ctx->up());
     if (e != hipSuccess)
     {
         (void)hipEventSynchronize(done);
@@ -1008,17 +1011,17 @@ int hbhip_frame_download_async(hbhip_frame *fr, const hbhip_host_frame *dst, voi
     if (fr->ready)
     {
         fr->ready->record_now();
-        e = hipStreamWaitEvent(ctx->down_stream, fr->ready->ev, 0);
+        e = hipStreamWaitEvent(ctx->down(), fr->ready->ev, 0);
     }
     else
     {
         e = hipEventRecord(ev, ctx->stream);           // the picture's producers are on ctx->stream, all queued by now
-        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->down_stream, ev, 0);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->down(), ev, 0);
     }
     if (e != hipSuccess) return fail(e, "download: order behind the frame's producers");
     if (same_layout(src, dst->plane, dst->stride))
     {
-        e = hipMemcpyAsync(dst->plane[0], src->plane[0], layout_bytes(src), hipMemcpyDeviceToHost, ctx->down_stream);
+        e = hipMemcpyAsync(dst->plane[0], src->plane[0], layout_bytes(src), hipMemcpyDeviceToHost, ctx->down());
         if (e != hipSuccess) return fail(e, "hipMemcpyAsync(download)");
     }
     else
@@ -1026,15 +1029,15 @@ int hbhip_frame_download_async(hbhip_frame *fr, const hbhip_host_frame *dst, voi
         {
             const size_t row = (size_t)src->width[c] * src->bps;
             e = hipMemcpy2DAsync(dst->plane[c], dst->stride[c], src->plane[c], src->pitch[c], row, src->height[c],
-                                 hipMemcpyDeviceToHost, ctx->down_stream);
+                                 hipMemcpyDeviceToHost, ctx->down());
             if (e != hipSuccess)
             {
-                (void)hipStreamSynchronize(ctx->down_stream);      // planes already queued must not outlive the call
+                (void)hipStreamSynchronize(ctx->down());      // planes already queued must not outlive the call
                 return fail(e, "hipMemcpy2DAsync(download)");
             }
         }
-    e = hipEventRecord(ev, ctx->down_stream);
-    if (e != hipSuccess) { (void)hipStreamSynchronize(ctx->down_stream); return fail(e, "hipEventRecord(download)"); }
+    e = hipEventRecord(ev, ctx->down());
+    if (e != hipSuccess) { (void)hipStreamSynchronize(ctx->down()); return fail(e, "hipEventRecord(download)"); }
     *token = ev;
     return HBHIP_OK;
 }
@@ -1207,9 +1210,9 @@ int hbhip_filter_submit_async(hbhip_filter *f, const hbhip_host_frame *in, const
             rc = HBHIP_ERR_ARG;
     auto fail = [&](int code) {
         // copies of the caller's `in` / `out` may be in flight: nothing of them may outlive this call
-        (void)hipStreamSynchronize(ctx->up_stream);
+        if (ctx->up_stream) (void)hipStreamSynchronize(ctx->up_stream);
         (void)hipStreamSynchronize(ctx->stream);
-        (void)hipStreamSynchronize(ctx->down_stream);
+        if (ctx->down_stream) (void)hipStreamSynchronize(ctx->down_stream);
         if (pic) f->abandon_input(pic);            // (already handed back once the kernels were queued)
         f->recycle_output(o);
         ctx->sync_ev_put(ev);
@@ -1221,23 +1224,23 @@ int hbhip_filter_submit_async(hbhip_filter *f, const hbhip_host_frame *in, const
     pic->tag = tag;
     for (int c = 0; c < 3; c++) f->in_stride[c] = in->stride[c];
     f->in_is_dev = false;
-    ASYNC_CHECK(hbhip_pic_wait_idle(ctx->up_stream, pic));
+    ASYNC_CHECK(hbhip_pic_wait_idle(ctx->up(), pic));
     for (int c = 0; c < 3; c++)
         ASYNC_CHECK(hipMemcpy2DAsync(pic->plane[c], pic->pitch[c], in->plane[c], in->stride[c],
                                      (size_t)std::min(in->stride[c], pic->pitch[c]), pic->height[c],
-                                     hipMemcpyHostToDevice, ctx->up_stream));
-    ASYNC_CHECK(hipEventRecord(ev, ctx->up_stream));
+                                     hipMemcpyHostToDevice, ctx->up()));
+    ASYNC_CHECK(hipEventRecord(ev, ctx->up()));
     ASYNC_CHECK(hipStreamWaitEvent(ctx->stream, ev, 0));
     rc = f->process_pair(pic, o);
     if (rc != HBHIP_OK) return fail(rc);
     hbhip_pic_release(pic, f->ctx);                // idle event behind the kernels that read it
     pic = nullptr;
     ASYNC_CHECK(hipEventRecord(ev, ctx->stream));
-    ASYNC_CHECK(hipStreamWaitEvent(ctx->down_stream, ev, 0));
+    ASYNC_CHECK(hipStreamWaitEvent(ctx->down(), ev, 0));
     for (int c = 0; c < 3; c++)
         ASYNC_CHECK(hipMemcpy2DAsync(out->plane[c], out->stride[c], o->plane[c], o->pitch[c], (size_t)o->width[c] * o->bps,
-                                     o->height[c], hipMemcpyDeviceToHost, ctx->down_stream));
-    ASYNC_CHECK(hipEventRecord(done, ctx->down_stream));
+                                     o->height[c], hipMemcpyDeviceToHost, ctx->down()));
+    ASYNC_CHECK(hipEventRecord(done, ctx->down()));
 #undef ASYNC_CHECK
     ctx->sync_ev_put(ev);
     f->async_q.push_back({o, done, tag});

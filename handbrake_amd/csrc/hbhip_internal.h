@@ -57,7 +57,13 @@ struct hbhip_ctx
     // its own thread, work.c:2527-2600), and so that copies overlap the kernels.  Ordering against `stream` is by
     // events: a picture's `idle` event (recorded when it goes back to its pool) gates the next upload into it, an
     // event recorded on `stream` at download time gates the copy out.
+    // Both are made at their first use (up() / down()): HIP spreads its streams over a handful of hardware queues in the
+    // order they are made, so a stream that is never used still decides which of the others share a queue - a chain whose
+    // frames never leave the device (the bench's, a device-resident run between its two adapters) creates none of them.
     hipStream_t up_stream = nullptr, down_stream = nullptr;
+    std::once_flag up_once, down_once;
+    hipStream_t up();                               // the upload stream; `stream` itself should it not be had
+    hipStream_t down();
     std::shared_ptr<IdleMark> open_mark;            // the mark pictures released right now attach to (state_lock)
     std::atomic<bool> has_open_mark{false};
     std::shared_ptr<IdleMark> mark();               // the open mark (made if there is none); null: no event to be had

@@ -167,7 +167,7 @@ def _sha(t):
 @pytest.mark.parametrize("content,steps,depth,split", [("interlaced", 3, 8, 2), ("corners", 1, 8, 2), ("interlaced10", 1, 10, 0)])
 def test_bench_shape(built, content, steps, depth, split):
     """The configuration the driver's bench line comes from, pinned frame for frame: 1920x1080 -> 3840x2160, B = 16 input
-    frames per step, decomb on a context (HIP stream) of its own and NLMeans / scaler / lapsharp on a second
+    frames per step, decomb on the chain's context (the caller's HIP stream) and NLMeans / scaler / lapsharp on a second
     (--stage-streams 2), 32-field EEDI2 batches in two parts with forked passes, the steps enqueued back to back with
     no synchronisation in between, each into output frames of its own - then the flush.  Every plane of every output
     frame against the SHA-256 the all-reference chain produced here for the same stream (tests/golden/
@@ -183,7 +183,7 @@ def test_bench_shape(built, content, steps, depth, split):
     assert want.get("depth", 8) == depth
     frames = synth.stream(bench.CONTENTS[content[:-2] if depth == 10 else content], W, H, n, cfg=3, depth=depth)
     ctxs, chain = bench.build_chain(hip, 0, W, H, (OW, OH), depth=depth, split=split)
-    assert len(ctxs) == (3 if split == 2 else 1)             # split 2: the chain's own, decomb's, and one for the stages behind it
+    assert len(ctxs) == (2 if split == 2 else 1)             # split 2: the chain's own (decomb's too), and one for the stages behind it
     dt = torch.uint8 if depth == 8 else torch.int16          # (the bit patterns of uint16 samples: what bench.py hands over too)
     try:
         dev_in = [_dev([p.view(np.int16) if depth > 8 else p for p in f], torch) for f in frames]
