@@ -530,6 +530,13 @@ static int ctx_create_common(int device, void *stream, bool adopt, hbhip_ctx **o
         delete ctx;
         return HBHIP_ERR_HIP;
     }
+#ifndef HBHIP_LAZY_COPY_STREAMS
+    // The copy streams with the context.  (Made at their first use instead - -DHBHIP_LAZY_COPY_STREAMS - a chain whose
+    // frames never leave the device has two streams fewer per context, which NLMeans alone likes (37.8 -> 38.7 k fps) and
+    // the chain does not notice; but the host path's download stream, made last then, lands on a hardware queue it shares
+    // with a busy compute stream: 4 070 -> 3 710 fps PCIe-inclusive, 56.9 -> 51.9 GB/s.  profiles/r6Z_streams_and_queues.log)
+    (void)ctx->up(); (void)ctx->down();
+#endif
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess)
         snprintf(ctx->dev_name, sizeof(ctx->dev_name), "%s (%s, %d CUs)", prop.name,

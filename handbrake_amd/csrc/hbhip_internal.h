@@ -57,9 +57,9 @@ struct hbhip_ctx
     // its own thread, work.c:2527-2600), and so that copies overlap the kernels.  Ordering against `stream` is by
     // events: a picture's `idle` event (recorded when it goes back to its pool) gates the next upload into it, an
     // event recorded on `stream` at download time gates the copy out.
-    // Both are made at their first use (up() / down()): HIP spreads its streams over a handful of hardware queues in the
-    // order they are made, so a stream that is never used still decides which of the others share a queue - a chain whose
-    // frames never leave the device (the bench's, a device-resident run between its two adapters) creates none of them.
+    // Reached through up() / down().  HIP spreads its streams over a handful of hardware queues in the order they are made,
+    // so when these two are made decides which streams share a queue: with the context (the product: ctx_create_common
+    // has the measurement) or at their first use (-DHBHIP_LAZY_COPY_STREAMS).
     hipStream_t up_stream = nullptr, down_stream = nullptr;
     std::once_flag up_once, down_once;
     hipStream_t up();                               // the upload stream; `stream` itself should it not be had
