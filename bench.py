@@ -444,9 +444,10 @@ def build_chain(hip, device, W, H, scale, depth=8, split=2, only_decomb=False, c
     """The chain object of one stream of frames exactly as the bench drives it (tests/test_configs_gpu.py::test_bench_shape
     builds its chain through this function too): decomb (EEDI2 bob) -> NLMeans medium -> Lanczos scale -> lapsharp behind
     one hbhip_chain.  split: 0 every stage on one context (HIP stream); 1 a context per stage - one stream per filter, as
-    libhb runs one thread per filter; 2 decomb on one context, the stages behind it on a second (the default: DESIGN 4.10);
-    3 decomb + NLMeans (arithmetic-bound) on one, scaler + lapsharp (memory-bound) on a second; 4 decomb / NLMeans /
-    scaler + lapsharp.  Returns (contexts, chain); the chain owns its stages, the caller closes chain then contexts."""
+    libhb runs one thread per filter; 2 decomb on the chain's context, the stages behind it on a second (the default:
+    DESIGN 4.10.5); 3 decomb + NLMeans (arithmetic-bound) on one, scaler + lapsharp (memory-bound) on a second; 4 decomb /
+    NLMeans / scaler + lapsharp.  The first stage always runs on the chain's own context - the caller's stream.  Returns
+    (contexts, chain); the chain owns its stages, the caller closes chain then contexts."""
     OW, OH = scale if scale else (W, H)
     ctxs = [hip.Ctx(device)]
 
@@ -454,7 +455,7 @@ def build_chain(hip, device, W, H, scale, depth=8, split=2, only_decomb=False, c
         # split 2: decomb stays on the chain's own context - the caller's stream -, the other stages get one more: with
         # EEDI2's two side streams that makes four busy HIP streams, one per hardware queue of the runtime's default four
         # (a fifth shares a queue with one of them, and whatever waits in it holds the other up: DESIGN 4.10)
-        if (not split or (split == 2 and (stage == 0 or len(ctxs) >= 2)) or (split == 3 and stage != 2 and len(ctxs) >= 2) or
+        if (not split or stage == 0 or (split == 2 and len(ctxs) >= 2) or (split == 3 and stage != 2) or
                 (split == 4 and stage == 3)):
             return ctxs[-1]
         ctxs.append(hip.Ctx(device))
